@@ -1,0 +1,242 @@
+"""Generate the golden vectors in tests/golden/ from the REAL reference (container-only).
+
+Run:  python oracle/make_golden.py
+Needs /root/reference (imported through oracle/ref_shim.py).  Only data (seeded synthetic inputs
+and the reference's outputs) is written; no reference source travels.
+
+Files
+  ref_weights.npz    G1  log_weights / ESS / log_evidence_ratio / variance   (samples.py:1221-1249, utils.py:248-255,510-512)
+  ref_beta.npz       G2  SMCSampler.determine_beta                            (smc/base.py:123-213)
+  ref_resample.npz   G3  SMCSamples.resample indices for default_rng(seed)    (samples.py:1251-1287)
+  ref_loop.npz       G4  SMCSampler.sample history with deterministic stub mutate (smc/base.py:215-488)
+  ref_initial.npz    G5  MCMCSampler.draw_initial_samples with invalid rows   (mcmc.py:49-110)
+  ref_anchors.npz        the tiny known-answer cases of reference tests/test_samples.py:637-731
+"""
+from __future__ import annotations
+
+import logging
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def synth(n, d, seed, sigma_q=1.5):
+    """The synthetic Gaussian batch of BASELINE.md §3 (config 2 shape): x = sigma_q*N(0,I),
+    ll = lp = -0.5|x|^2, lq = log N(x; 0, sigma_q^2 I)."""
+    g = np.random.default_rng(seed)
+    x = sigma_q * g.normal(size=(n, d))
+    ll = -0.5 * np.sum(x**2, axis=1)
+    lp = ll.copy()
+    lq = -0.5 * np.sum((x / sigma_q) ** 2, axis=1) - d * np.log(sigma_q) - 0.5 * d * np.log(2 * np.pi)
+    return x, ll, lp, lq
+
+
+def main():
+    logging.disable(logging.CRITICAL)
+    rs, smc, mcmc, ut = ref_shim.import_reference()
+    os.makedirs(OUT, exist_ok=True)
+
+    # ---------------- G1 weights -------------------------------------------------------------
+    g1 = {}
+    cases = []
+    for n, d, seed in [(10, 2, 11), (2000, 4, 12), (65536, 8, 13)]:
+        x, ll, lp, lq = synth(n, d, seed)
+        for beta0 in (0.0, 0.3):
+            for beta in (beta0 + 0.01, 0.5, 1.0):
+                s = rs.SMCSamples(x=x, log_likelihood=ll, log_prior=lp, log_q=lq, beta=beta0)
+                lw = s.log_weights(beta)
+                key = f"n{n}_b{beta0}_t{beta}"
+                cases.append((n, d, seed, beta0, beta))
+                g1[key + "_lse_unnorm"] = float(ut.logsumexp(s.unnormalized_log_weights(beta)))
+                g1[key + "_ess"] = float(ut.effective_sample_size(lw))
+                g1[key + "_ratio"] = float(s.log_evidence_ratio(beta))
+                g1[key + "_var"] = float(s.log_evidence_ratio_variance(beta))
+                if n <= 2000:
+                    g1[key + "_lw"] = np.asarray(lw)
+                else:
+                    g1[key + "_lw_stride"] = np.asarray(lw)[::257]
+                    g1[key + "_lw_sum"] = float(np.sum(lw))
+    g1["cases"] = np.array(cases, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "ref_weights.npz"), **g1)
+
+    # ---------------- G2 determine_beta ------------------------------------------------------
+    class _Flow:
+        xp = np
+
+    def mk_sampler(cls=smc.SMCSampler, **kw):
+        return cls(log_likelihood=lambda s: None, log_prior=lambda s: None, dims=4, prior_flow=_Flow(), xp=np, **kw)
+
+    g2 = {}
+    cases = []
+    for n, d, seed in [(2000, 4, 0), (65536, 8, 21)]:
+        if seed == 0:  # the SURVEY anchor: X = 2*normal, lq = N(0,4I)
+            x, ll, lp, lq = synth(n, d, 0, sigma_q=2.0)
+        else:
+            x, ll, lp, lq = synth(n, d, seed)
+        for beta0 in (0.0, 0.2):
+            for tol in (1e-6, 1e-8):
+                for ti, target in enumerate([0.5, (0.3, 0.9)]):
+                    sp = mk_sampler()
+                    sp.adaptive = True
+                    sp.adaptive_min_beta_step = False
+                    sp.target_efficiency = target
+                    sp.target_efficiency_rate = 1.0
+                    s = rs.SMCSamples(x=x, log_likelihood=ll, log_prior=lp, log_q=lq, beta=beta0)
+                    b, ms = sp.determine_beta(s, beta0, np.nan, 0.0, max_beta_step=1.0, beta_tolerance=tol)
+                    cases.append((n, d, seed, beta0, tol, ti, float(b)))
+        # adaptive min step + max step clamp
+        sp = mk_sampler()
+        sp.adaptive = True
+        sp.adaptive_min_beta_step = True
+        sp.target_efficiency = 0.5
+        sp.target_efficiency_rate = 1.0
+        s = rs.SMCSamples(x=x, log_likelihood=ll, log_prior=lp, log_q=lq, beta=0.0)
+        b, ms = sp.determine_beta(s, 0.0, np.nan, 1 / 5, max_beta_step=0.25, beta_tolerance=1e-6)
+        g2[f"n{n}_minstep"] = np.array([float(b), float(ms)])
+    g2["cases"] = np.array(cases, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "ref_beta.npz"), **g2)
+
+    # ---------------- G3 resample indices ----------------------------------------------------
+    g3 = {}
+    cases = []
+    for n, d, seed in [(10, 2, 31), (2000, 4, 32), (65536, 8, 33)]:
+        x, ll, lp, lq = synth(n, d, seed)
+        for beta0, beta in [(0.0, 0.05), (0.3, 0.6)]:
+            for n_out in (n, 7, 2 * n):
+                s = rs.SMCSamples(x=x, log_likelihood=ll, log_prior=lp, log_q=lq, beta=beta0)
+                rng = np.random.default_rng(1000 + seed)
+                out = s.resample(beta, n_samples=n_out, rng=rng)
+                # recover indices: rows are unique with probability 1 -> match on log_q + x[:,0]
+                order = np.argsort(lq, kind="stable")
+                pos = np.searchsorted(lq[order], out.log_q)
+                idx = order[pos]
+                assert np.array_equal(x[idx], out.x) and np.array_equal(ll[idx], out.log_likelihood)
+                key = f"n{n}_b{beta0}_t{beta}_o{n_out}"
+                g3[key + "_idx"] = idx.astype(np.int64)
+                g3[key + "_next_u"] = rng.random(3)  # generator state after the call
+                cases.append((n, d, seed, beta0, beta, n_out))
+    # same-beta branch with n_samples != N (uniform weights, samples.py:1273-1274)
+    x, ll, lp, lq = synth(2000, 4, 32)
+    s = rs.SMCSamples(x=x, log_likelihood=ll, log_prior=lp, log_q=lq, beta=0.4)
+    rng = np.random.default_rng(77)
+    out = s.resample(0.4, n_samples=50, rng=rng)
+    order = np.argsort(lq, kind="stable")
+    g3["samebeta_idx"] = order[np.searchsorted(lq[order], out.log_q)].astype(np.int64)
+    g3["cases"] = np.array(cases, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "ref_resample.npz"), **g3)
+
+    # ---------------- G4 whole loop with stub mutate -----------------------------------------
+    class GaussFlow:
+        xp = np
+
+        def __init__(self, d, sigma, seed):
+            self.d, self.sigma, self.g = d, sigma, np.random.default_rng(seed)
+
+        def log_prob(self, x):
+            x = np.asarray(x)
+            return (
+                -0.5 * np.sum((x / self.sigma) ** 2, axis=1)
+                - self.d * np.log(self.sigma)
+                - 0.5 * self.d * np.log(2 * np.pi)
+            )
+
+        def sample_and_log_prob(self, n):
+            x = self.sigma * self.g.normal(size=(n, self.d))
+            return x, self.log_prob(x)
+
+    def log_like(s):
+        return -0.5 * np.sum(np.asarray(s.x) ** 2, axis=1)
+
+    class StubSMC(smc.SMCSampler):
+        kind = "identity"
+
+        def mutate(self, particles, beta, n_steps=None):
+            if self.kind == "identity":
+                return particles
+            # seeded random-walk Metropolis on the tempered target, 3 steps, host numpy
+            x = np.array(particles.x, copy=True)
+            for _ in range(3):
+                lp_old = self.log_prob(x, beta)
+                prop = x + 0.5 * self.rng.normal(size=x.shape)
+                lp_new = self.log_prob(prop, beta)
+                acc = np.log(self.rng.random(len(x))) < (lp_new - lp_old)
+                x[acc] = prop[acc]
+            out = rs.SMCSamples(x, xp=self.xp, beta=beta, dtype=self.dtype, parameters=self.parameters)
+            out.log_q = self.prior_flow.log_prob(out.x)
+            out.log_prior = self.log_prior(out)
+            out.log_likelihood = self.log_likelihood(out)
+            return out
+
+    g4 = {}
+    for name, kind, kwargs in [
+        ("identity_adaptive", "identity", dict(adaptive=True, target_efficiency=0.5, beta_tolerance=1e-6)),
+        ("rw_adaptive", "rw", dict(adaptive=True, target_efficiency=0.5, beta_tolerance=1e-6)),
+        ("rw_adaptive_ramp", "rw", dict(adaptive=True, target_efficiency=(0.3, 0.9), beta_tolerance=1e-8)),
+        ("rw_fixed20", "rw", dict(adaptive=False, n_steps=20)),
+        ("rw_maxsteps", "rw", dict(adaptive=True, max_n_steps=4, target_efficiency=0.5)),
+    ]:
+        sp = StubSMC(
+            log_likelihood=log_like, log_prior=log_like, dims=4, prior_flow=GaussFlow(4, 2.0, 5), xp=np,
+            rng=np.random.default_rng(9),
+        )
+        sp.kind = kind
+        sp.sampler_kwargs = {}
+        out = sp.sample(2000, store_sample_history=False, **kwargs)
+        h = sp.history
+        g4[name + "_beta"] = np.array(h.beta)
+        g4[name + "_ess"] = np.array(h.ess)
+        g4[name + "_ess_target"] = np.array(h.ess_target)
+        g4[name + "_eff_target"] = np.array(h.eff_target)
+        g4[name + "_log_norm_ratio"] = np.array(h.log_norm_ratio)
+        g4[name + "_log_norm_ratio_var"] = np.array(h.log_norm_ratio_var)
+        g4[name + "_log_evidence"] = float(out.log_evidence)
+        g4[name + "_log_evidence_error"] = float(out.log_evidence_error)
+        g4[name + "_x_final"] = np.asarray(out.x)
+        g4[name + "_nlike"] = sp.n_likelihood_evaluations
+    np.savez_compressed(os.path.join(OUT, "ref_loop.npz"), **g4)
+
+    # ---------------- G5 draw_initial_samples -------------------------------------------------
+    class HoleFlow(GaussFlow):
+        pass
+
+    def lp_holes(s):
+        x = np.asarray(s.x)
+        v = -0.5 * np.sum(x**2, axis=1)
+        return np.where(x[:, 0] > 1.0, -np.inf, v)
+
+    def ll_holes(s):
+        x = np.asarray(s.x)
+        v = -0.5 * np.sum(x**2, axis=1)
+        return np.where(x[:, 1] < -1.5, -np.inf, v)
+
+    sp = mcmc.MCMCSampler(
+        log_likelihood=ll_holes, log_prior=lp_holes, dims=3, prior_flow=HoleFlow(3, 1.0, 41), xp=np
+    )
+    init = sp.draw_initial_samples(500)
+    g5 = dict(x=np.asarray(init.x), ll=np.asarray(init.log_likelihood), lp=np.asarray(init.log_prior),
+              lq=np.asarray(init.log_q), nlike=sp.n_likelihood_evaluations)
+    np.savez_compressed(os.path.join(OUT, "ref_initial.npz"), **g5)
+
+    # ---------------- anchors from the reference's own tests ---------------------------------
+    a = {}
+    x = np.arange(20.0).reshape(10, 2)
+    ll = np.linspace(0, 1, 10)
+    s = rs.SMCSamples(x=x, log_likelihood=ll, log_prior=np.zeros(10), log_q=np.zeros(10), beta=0.2)
+    a["t10_ratio"] = float(s.log_evidence_ratio(0.8))
+    a["t10_ess"] = float(ut.effective_sample_size(s.log_weights(0.8)))
+    a["t10_var"] = float(s.log_evidence_ratio_variance(0.8))
+    a["t10_rows"] = s.resample(0.8, n_samples=7, rng=np.random.default_rng(42)).x[:, 0] / 2
+    np.savez_compressed(os.path.join(OUT, "ref_anchors.npz"), **a)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
