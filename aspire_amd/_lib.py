@@ -1,0 +1,125 @@
+"""ctypes binding of libasmc_hip.so (the C ABI declared in include/asmc.h).
+
+The product path has NO CPU fallback: if the shared library is missing `load()` raises, and every
+compute entry point needs a HIP device.  (`oracle/` is test infrastructure and is never imported
+from this package.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libasmc_hip.so")
+
+ASMC_OK = 0
+ASMC_F64, ASMC_F32 = 0, 1
+ASMC_CDF_EXACT, ASMC_CDF_FAST = 0, 1
+ASMC_MAX_BETAS = 32
+ASMC_MAX_COMPONENTS = 8
+ASMC_MAX_DIMS = 256
+ASMC_ABI_VERSION = 1
+
+
+class AsmcMixture(ctypes.Structure):
+    _fields_ = [
+        ("n_components", c_int32),
+        ("reserved", c_int32),
+        ("logw_dev", c_void_p),
+        ("mu_dev", c_void_p),
+        ("prec_dev", c_void_p),
+    ]
+
+
+class AsmcPcnParams(ctypes.Structure):
+    _fields_ = [
+        ("d", c_int32),
+        ("x_dtype", c_int32),
+        ("beta", c_double),
+        ("mu_dev", c_void_p),
+        ("L_dev", c_void_p),
+        ("Linv_dev", c_void_p),
+        ("log_likelihood", AsmcMixture),
+        ("log_prior", AsmcMixture),
+        ("log_q", AsmcMixture),
+        ("seed", c_uint64),
+        ("gid0", c_uint64),
+        ("target_accept", c_double),
+        ("adapt", c_int32),
+        ("reserved", c_int32),
+    ]
+
+
+_vp, _d, _i, _i64, _u64, _u32 = c_void_p, c_double, c_int, c_int64, c_uint64, c_uint32
+_pd, _pi64 = POINTER(c_double), POINTER(c_int64)
+
+# name -> (restype, argtypes); must list exactly the functions include/asmc.h declares
+SIGNATURES = {
+    "asmc_abi_version": (_i, []),
+    "asmc_last_error": (c_char_p, []),
+    "asmc_device_count": (_i, [POINTER(c_int)]),
+    "asmc_ctx_create": (_i, [POINTER(c_void_p), _i, _i64, _i]),
+    "asmc_ctx_destroy": (_i, [_vp]),
+    "asmc_weights_max": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _pd, _i, _pd, _pi64, _vp]),
+    "asmc_weights_sums": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _pd, _pd, _pd, _i, _pd, _vp]),
+    "asmc_weights_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _pd, _i, _pd, _vp]),
+    "asmc_weights_m2": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _pd, _vp]),
+    "asmc_log_weights": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _vp, _vp]),
+    "asmc_normalized_weights": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _vp, _vp]),
+    "asmc_count_nonfinite": (_i, [_vp, _i64, _vp, _pi64, _pi64, _vp]),
+    "asmc_cdf": (_i, [_vp, _i64, _vp, _vp, _i, _d, _pd, _vp]),
+    "asmc_cdf_normalize": (_i, [_vp, _i64, _vp, _d, _vp]),
+    "asmc_pcg64_uniforms": (_i, [_vp, POINTER(c_uint64), _u64, _i64, _vp, _vp]),
+    "asmc_systematic_uniforms": (_i, [_vp, _i64, _i64, _i64, _d, _vp, _vp, _vp]),
+    "asmc_search": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "asmc_gather": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "asmc_gaussian_draw": (_i, [_vp, _i64, _i, _i, _vp, _vp, _u64, _u64, _u32, _vp, _vp, _vp]),
+    "asmc_mixture_logpdf": (_i, [_vp, _i64, _i, _i, _vp, POINTER(AsmcMixture), _vp, _vp]),
+    "asmc_compact_valid": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pi64, _vp]),
+    "asmc_colsum": (_i, [_vp, _i64, _i, _i, _vp, _pd, _vp]),
+    "asmc_centered_gram": (_i, [_vp, _i64, _i, _i, _vp, _pd, _pd, _vp]),
+    "asmc_pcn_mutate": (
+        _i,
+        [_vp, _i64, _vp, _vp, _vp, _vp, POINTER(AsmcPcnParams), _i, _u32, _pd, _pi64, _pd, _vp],
+    ),
+    "asmc_pcn_propose": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _u64, _u64, _u32, _vp]),
+    "asmc_pcn_accept": (
+        _i,
+        [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _u64, _u64, _u32, _pi64, _vp],
+    ),
+}
+
+_lib = None
+
+
+class AsmcError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libasmc_hip.so; raises (no fallback) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AsmcError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C aspire_amd/csrc). "
+            "aspire_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.asmc_abi_version() != ASMC_ABI_VERSION:
+        raise AsmcError("libasmc_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != ASMC_OK:
+        msg = load().asmc_last_error()
+        raise AsmcError(f"{what or 'asmc call'} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,186 @@
+"""`Aspire` façade with the reference's API surface for the SMC path (src/aspire/aspire.py:25-570).
+
+Kept: constructor keywords (aspire.py:79-98), `fit`, `sample_posterior` (signature, kwargs routing by
+`inspect.signature`, `return_history`, `n_likelihood_evaluations`), `get_sampler_class`,
+`init_sampler`.  Only `sampler in {"smc", "minipcn_smc"}` is implemented natively (the hot path this
+repository replaces); other names resolve through the `aspire.samplers` entry-point group exactly
+like the reference (aspire.py:293-304) and otherwise raise.  HDF5 checkpoint files, plotting and
+the JAX backend are out of scope.
+"""
+from __future__ import annotations
+
+import copy
+import logging
+from inspect import signature
+from typing import Any, Callable
+
+import numpy as np
+import torch
+
+from ._xp import is_torch_namespace
+from .flows import CouplingFlow, Flow, GaussianFlow
+from .history import FlowHistory, History
+from .samples import Samples
+from .samplers.base import IdentityTransform, Sampler
+
+logger = logging.getLogger(__name__)
+
+
+class Aspire:
+    """Accelerated Sequential Posterior Inference via REuse — SMC path on MI355X."""
+
+    def __init__(self, *, log_likelihood: Callable, log_prior: Callable, dims: int,
+                 parameters: list[str] | None = None, periodic_parameters: list[str] | None = None,
+                 prior_bounds: dict[str, tuple[float, float]] | None = None, bounded_to_unbounded: bool = True,
+                 bounded_transform: str = "logit", device: str | None = None, xp: Callable | None = None,
+                 flow: Flow | None = None, flow_backend: str = "coupling", flow_matching: bool = False,
+                 eps: float = 1e-6, dtype: Any | str | None = None, **kwargs) -> None:
+        self.log_likelihood = log_likelihood
+        self.log_prior = log_prior
+        self.dims = dims
+        self.parameters = parameters
+        self.device = device
+        self.eps = eps
+        self.periodic_parameters = periodic_parameters
+        self.prior_bounds = prior_bounds
+        self.bounded_to_unbounded = bounded_to_unbounded
+        self.bounded_transform = bounded_transform
+        self.flow_matching = flow_matching
+        self.flow_backend = flow_backend
+        self.flow_kwargs = kwargs
+        self.xp = xp
+        self.dtype = dtype
+        self._flow = flow
+        self._sampler = None
+        if flow_matching:
+            raise NotImplementedError("flow matching is outside the SMC hot path (SURVEY.md §2)")
+
+    @property
+    def flow(self):
+        return self._flow
+
+    @flow.setter
+    def flow(self, flow: Flow):
+        self._flow = flow
+
+    @property
+    def sampler(self) -> Sampler | None:
+        return self._sampler
+
+    @property
+    def n_likelihood_evaluations(self):
+        return None if self._sampler is None else self._sampler.n_likelihood_evaluations
+
+    def convert_to_samples(self, x, log_likelihood=None, log_prior=None, log_q=None, evaluate: bool = True, xp=None):
+        """aspire.py:142-175."""
+        samples = Samples(x=x, parameters=self.parameters, log_likelihood=log_likelihood, log_prior=log_prior,
+                          log_q=log_q, xp=xp or self.xp, dtype=self.dtype)
+        if evaluate:
+            if log_prior is None:
+                samples.log_prior = samples.array_to_namespace(self.log_prior(samples))
+            if log_likelihood is None:
+                samples.log_likelihood = samples.array_to_namespace(self.log_likelihood(samples))
+            if samples.log_q is not None:
+                samples.compute_weights()
+        return samples
+
+    def init_flow(self):
+        """aspire.py:177-206.  Backends: "coupling" (PyTorch RealNVP) and "gaussian" (analytic, HIP).
+        "zuko" is accepted when zuko is importable and otherwise maps to "coupling" with a warning
+        (zuko is not part of this image)."""
+        backend = self.flow_backend.lower()
+        if self.prior_bounds is not None and self.bounded_to_unbounded:
+            raise NotImplementedError("bounded-to-unbounded flow transforms are a 'next' row (SURVEY.md §8f)")
+        if backend == "zuko":
+            logger.warning("flow_backend='zuko' is not available here; using the built-in coupling flow")
+            backend = "coupling"
+        if backend == "coupling":
+            kw = dict(self.flow_kwargs)
+            self._flow = CouplingFlow(dims=self.dims, device=self.device or "cpu",
+                                      dtype=kw.pop("flow_dtype", torch.float32), **kw)
+        elif backend == "gaussian":
+            self._flow = GaussianFlow(dims=self.dims, **self.flow_kwargs)
+        else:
+            raise ValueError(f"Unknown flow backend: {self.flow_backend}")
+
+    def fit(self, samples: Samples, checkpoint_path: str | None = None, checkpoint_save_config: bool = True,
+            overwrite: bool = False, **kwargs) -> History:
+        """aspire.py:208-270 (flow training runs in PyTorch, upstream of the hot path)."""
+        if checkpoint_path is not None:
+            raise NotImplementedError("HDF5 checkpoint files are out of scope (h5py unavailable)")
+        if self.xp is None:
+            self.xp = samples.xp
+        if self.parameters is None and samples.parameters is not None:
+            self.parameters = samples.parameters.copy()
+        if self.flow is None:
+            self.init_flow()
+        self.training_samples = samples
+        logger.info(f"Training with {len(samples.x)} samples")
+        return self.flow.fit(samples.x, **kwargs) or FlowHistory()
+
+    def get_sampler_class(self, sampler_type: str) -> Callable:
+        """aspire.py:272-305."""
+        if sampler_type in ["smc", "minipcn_smc"]:
+            from .samplers.smc import HipSMC as SamplerClass
+        else:
+            from importlib.metadata import entry_points
+
+            eps = {ep.name: ep for ep in entry_points(group="aspire.samplers")}
+            if sampler_type in eps:
+                SamplerClass = eps[sampler_type].load()
+            else:
+                raise ValueError(f"Unknown sampler type: {sampler_type}")
+        return SamplerClass
+
+    def init_sampler(self, sampler_type: str, preconditioning: str | None = None,
+                     preconditioning_kwargs: dict | None = None, **kwargs) -> Callable:
+        """aspire.py:307-381.  "default" preconditioning for smc is affine_transform=False,
+        bounded_to_unbounded=False (aspire.py:337-341): the identity for unbounded problems."""
+        SamplerClass = self.get_sampler_class(sampler_type)
+        if sampler_type != "importance" and preconditioning is None:
+            preconditioning = "default"
+        preconditioning = preconditioning.lower() if preconditioning else None
+        if preconditioning is None or preconditioning == "none":
+            transform = None
+        elif preconditioning in ["standard", "default"]:
+            pk = dict(preconditioning_kwargs or {})
+            if pk.get("affine_transform") or pk.get("bounded_to_unbounded") or self.periodic_parameters:
+                raise NotImplementedError("device preconditioning transforms are a 'next' row (SURVEY.md §8f)")
+            transform = IdentityTransform(xp=self.xp)
+        elif preconditioning == "flow":
+            raise NotImplementedError("flow preconditioning is out of scope (SURVEY.md §2)")
+        else:
+            raise ValueError(f"Unknown preconditioning: {preconditioning}")
+        return SamplerClass(log_likelihood=self.log_likelihood, log_prior=self.log_prior, dims=self.dims,
+                            prior_flow=self.flow, xp=self.xp, dtype=self.dtype,
+                            preconditioning_transform=transform, parameters=self.parameters, **kwargs)
+
+    def sample_posterior(self, n_samples: int | None = None, sampler: str = "importance", xp: Any = None,
+                         return_history: bool = False, preconditioning: str | None = None,
+                         preconditioning_kwargs: dict | None = None, checkpoint_path: str | None = None,
+                         checkpoint_every: int = 1, checkpoint_save_config: bool = True, **kwargs) -> Samples:
+        """aspire.py:383-570."""
+        if checkpoint_path is not None:
+            raise NotImplementedError("HDF5 checkpoint files are out of scope; pass checkpoint_callback instead")
+        SamplerClass = self.get_sampler_class(sampler)
+        init_params = signature(SamplerClass.__init__).parameters
+        sampler_kwargs = {k: v for k, v in kwargs.items() if k in init_params and k != "self"}
+        kwargs = {k: v for k, v in kwargs.items() if k not in init_params or k == "self"}
+        self._sampler = self.init_sampler(sampler, preconditioning=preconditioning,
+                                          preconditioning_kwargs=preconditioning_kwargs, **sampler_kwargs)
+        self._last_sampler_type = sampler
+        samples = self._sampler.sample(n_samples, **kwargs)
+        self._last_sample_posterior_kwargs = {
+            "n_samples": n_samples, "sampler": sampler, "xp": xp, "return_history": return_history,
+            "preconditioning": preconditioning, "preconditioning_kwargs": preconditioning_kwargs,
+            "sampler_init_kwargs": sampler_kwargs,
+            "sample_kwargs": {k: v for k, v in kwargs.items() if k not in ("rng", "checkpoint_callback")},
+        }
+        out_xp = xp if xp is not None else (self.xp if self.xp is not None else np)
+        samples = samples.to_namespace(out_xp) if is_torch_namespace(out_xp) else samples.to_numpy()
+        samples.parameters = self.parameters if self.parameters is not None else samples.parameters
+        logger.info(f"Sampled {len(samples)} samples from the posterior")
+        logger.info(f"Number of likelihood evaluations: {self.n_likelihood_evaluations}")
+        if return_history:
+            return samples, self._sampler.history
+        return samples

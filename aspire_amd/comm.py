@@ -1,0 +1,129 @@
+"""Particle sharding across ranks (one process per GPU, torch.distributed; "nccl" is RCCL on ROCm).
+
+The reference has no distributed code; this is new design.  Rank r owns the
+contiguous block [r*N/G, (r+1)*N/G) of the GLOBAL particle order, so a 1-rank and a G-rank run with
+the same generator produce the same global resample indices.
+
+Collectives used by the hot path:
+  C1  all-reduce(max) + all-gather of the per-rank (S1, S2) sums per candidate beta; merged on every
+      rank in rank order (bitwise identical on all ranks)
+  C2  exact-cdf carry chained rank to rank (sequential fp64 rounding preserved) / exclusive sum of
+      per-rank masses in fast mode
+  C3  all-gather of the normalised cdf, all-to-all of requested rows
+  C4  all-gather of column sums / centred Gram partials, accept counts
+Scalars travel as small fp64 tensors; with xGMI's point-to-point links an all-gather of 24*K bytes
+is latency bound, so every scalar exchange is ONE all-gather followed by a local rank-ordered merge.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+class Comm:
+    """Single-process communicator (world size 1)."""
+
+    rank = 0
+    world = 1
+
+    def all_gather_f64(self, arr) -> np.ndarray:
+        return np.asarray(arr, dtype=np.float64)[None, ...]
+
+    def all_reduce_max_f64(self, arr) -> np.ndarray:
+        return np.asarray(arr, dtype=np.float64)
+
+    def all_gather_tensor(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+    def all_to_all_rows(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int]) -> torch.Tensor:
+        return send
+
+    def barrier(self):
+        pass
+
+    def chain_recv(self) -> float | None:
+        return None
+
+    def chain_send(self, value: float) -> None:
+        pass
+
+    def broadcast_f64(self, value: float, src: int) -> float:
+        return value
+
+
+class TorchDistComm(Comm):
+    """torch.distributed communicator; tensors live on `device` (cuda for nccl/RCCL, cpu for gloo)."""
+
+    def __init__(self, device: torch.device | str, group=None):
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = torch.device(device)
+
+    def all_gather_f64(self, arr) -> np.ndarray:
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        t = torch.as_tensor(a.reshape(-1), device=self.device)
+        out = torch.empty(self.world * t.numel(), dtype=torch.float64, device=self.device)
+        self.dist.all_gather_into_tensor(out, t, group=self.group)
+        return out.cpu().numpy().reshape((self.world,) + a.shape)
+
+    def all_reduce_max_f64(self, arr) -> np.ndarray:
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        t = torch.as_tensor(a.reshape(-1), device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return t.cpu().numpy().reshape(a.shape)
+
+    def all_gather_tensor(self, t: torch.Tensor) -> torch.Tensor:
+        """Concatenate equal-sized shards along dim 0 in rank order."""
+        t = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t, group=self.group)
+        return out
+
+    def all_to_all_rows(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int]) -> torch.Tensor:
+        """Variable all-to-all along dim 0 (rows grouped by destination rank in `send`)."""
+        send = send.contiguous()
+        out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        self.dist.all_to_all_single(out, send, output_split_sizes=list(map(int, recv_counts)),
+                                    input_split_sizes=list(map(int, send_counts)), group=self.group)
+        return out
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+    # exact-cdf carry: rank r waits for the exact running sum of ranks < r, then forwards its own
+    def chain_recv(self) -> float | None:
+        if self.rank == 0:
+            return None
+        t = torch.empty(1, dtype=torch.float64, device=self.device)
+        self.dist.recv(t, src=self.rank - 1, group=self.group)
+        return float(t.item())
+
+    def chain_send(self, value: float) -> None:
+        if self.rank + 1 < self.world:
+            t = torch.tensor([value], dtype=torch.float64, device=self.device)
+            self.dist.send(t, dst=self.rank + 1, group=self.group)
+
+    def broadcast_f64(self, value: float, src: int) -> float:
+        t = torch.tensor([value], dtype=torch.float64, device=self.device)
+        self.dist.broadcast(t, src=src, group=self.group)
+        return float(t.item())
+
+
+def default_comm(device) -> Comm:
+    """TorchDistComm when a process group with world size > 1 exists, else the trivial communicator."""
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dev = torch.device(device)
+            backend = dist.get_backend()
+            return TorchDistComm(dev if backend == "nccl" else torch.device("cpu"))
+    except Exception:
+        raise
+    return Comm()

@@ -1,0 +1,109 @@
+// asmc_common.h — internals shared by the HIP translation units of libasmc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/asmc.h"
+
+#define ASMC_WAVE 64
+#define ASMC_BLOCK 256          // 4 waves: one per SIMD of a CU
+#define ASMC_MAX_BLOCKS 2048    // cap for grid-stride reduction kernels (256 CUs x 8)
+#define ASMC_SCAN_TILE 2048     // elements per scan tile (256 threads x 8)
+#define ASMC_MAX_PCN_STEPS 2048 // per asmc_pcn_mutate call (bounded by the pinned staging buffer)
+
+void asmc_set_error(const char* fmt, ...);
+
+#define ASMC_HIP(call)                                                                      \
+    do {                                                                                    \
+        hipError_t _e = (call);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            asmc_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, \
+                           __LINE__);                                                       \
+            return ASMC_ERR_HIP;                                                            \
+        }                                                                                   \
+    } while (0)
+
+#define ASMC_REQUIRE(cond, msg)                                   \
+    do {                                                          \
+        if (!(cond)) {                                            \
+            asmc_set_error("%s: %s", __func__, msg);              \
+            return ASMC_ERR_ARG;                                  \
+        }                                                         \
+    } while (0)
+
+#define ASMC_LAUNCH_CHECK()                                                                 \
+    do {                                                                                    \
+        hipError_t _e = hipGetLastError();                                                  \
+        if (_e != hipSuccess) {                                                             \
+            asmc_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),       \
+                           __FILE__, __LINE__);                                             \
+            return ASMC_ERR_HIP;                                                            \
+        }                                                                                   \
+    } while (0)
+
+struct asmc_ctx {
+    int device;
+    int64_t n_max;
+    int d_max;
+    int num_cu;
+    // device scratch (all allocated in asmc_ctx_create)
+    double* d_partials;            // [ASMC_MAX_BLOCKS * ASMC_MAX_BETAS * 2] block partial sums
+    double* d_small;               // [4096] small result vectors
+    unsigned long long* d_keys;    // [ASMC_MAX_BETAS + 8] atomicMax keys + integer counters
+    double* d_tiles;               // [n_tiles_max * 4 + 64] scan tile aggregates
+    long long* d_tiles_i;          // [n_tiles_max * 4 + 64] integer tile aggregates (exact cdf, compaction)
+    double* d_gram;                // [gram_blocks * d_max * d_max] gram partials
+    long long* d_counts;           // [ASMC_MAX_PCN_STEPS + ASMC_MAX_BLOCKS] accept counts / partials
+    double* d_rho;                 // [ASMC_MAX_PCN_STEPS + 8] step-size history on device
+    unsigned long long* d_pcgtab;  // [64*4 + 8] PCG64 jump table
+    int64_t n_tiles_max;
+    int gram_blocks;
+    unsigned long long pcg_inc[2];  // increment the device jump table was built for
+    int pcg_tab_valid;
+    // pinned host staging for scalar read-back / small uploads
+    double* h_pinned;  // [8192] doubles
+};
+
+static inline hipStream_t as_stream(asmc_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- device helpers -------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// order-preserving map double -> u64 (for atomicMax on doubles; NaNs are filtered by callers)
+__device__ __forceinline__ unsigned long long f64_to_key(double v) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ULL) ? ~b : (b | 0x8000000000000000ULL);
+}
+__host__ __device__ __forceinline__ double key_to_f64(unsigned long long k) {
+    unsigned long long b = (k & 0x8000000000000000ULL) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
+    double d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    d = __longlong_as_double((long long)b);
+#else
+    memcpy(&d, &b, sizeof(d));
+#endif
+    return d;
+}
+
+static inline int grid_for(int64_t n, int per_block, int cap) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}

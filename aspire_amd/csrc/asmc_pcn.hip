@@ -1,0 +1,817 @@
+// asmc_pcn.hip — proposal draw, built-in densities, population moments, pCN mutation.
+//
+// Replaces (reference mj-will/aspire):
+//   src/aspire/samplers/smc/minipcn.py:69-135  MiniPCNSMC.mutate  (wraps third-party minipcn —
+//       absent from the reference tree; the kernel below implements THIS repository's pCN
+//       specification; parity with minipcn is unpinned)
+//   src/aspire/samplers/smc/base.py:507-519 + src/aspire/samples.py:1217-1219  tempered target
+//       log p_t = (1-beta) log_q + beta (log_likelihood + log_prior) [+ log|J|], NaN -> -inf
+//   src/aspire/samplers/mcmc.py:66-67  flow.sample_and_log_prob for the analytic Gaussian proposal
+//
+// Data movement: particle rows (d*s bytes, particle-major) are fetched with fully coalesced
+// 16-B-per-lane loads into a padded LDS tile (64 rows per wave, row stride = rowbytes + 16 so that
+// per-lane row reads are bank-conflict free), processed one particle per lane, and written back
+// coalesced from the same tile.  Noise is generated in-kernel (Philox4x32-10 + Box-Muller), so one
+// pCN step moves 2*d*s + 48 bytes per particle and nothing else.
+#include "asmc_common.h"
+
+// =============================================================================================
+// Philox4x32-10 (Salmon et al. SC'11; Random123 constants) and Box-Muller
+// =============================================================================================
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+__device__ __forceinline__ double u01_from_words(uint32_t hi, uint32_t lo) {
+    unsigned long long v = ((unsigned long long)hi << 21) ^ ((unsigned long long)lo >> 11);
+    v &= ((1ULL << 53) - 1ULL);
+    return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// counter = {gid_lo, gid_hi, step, slot}; key = {seed_lo, seed_hi}
+__device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned long long gid,
+                                            uint32_t step, uint32_t slot, double& z0, double& z1) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, slot, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), w);
+    const double u1 = u01_from_words(w[0], w[1]);
+    const double u2 = u01_from_words(w[2], w[3]);
+    const double r = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+__device__ __forceinline__ double accept_uniform(unsigned long long seed, unsigned long long gid,
+                                                 uint32_t step) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, 0xFFFFFFFFu, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), w);
+    return u01_from_words(w[0], w[1]);
+}
+
+// =============================================================================================
+// LDS row tiles
+// =============================================================================================
+struct MixDev {
+    int C;
+    const double* logw;
+    const double* mu;
+    const double* prec;
+};
+
+static inline MixDev to_dev(const asmc_mixture& m) {
+    MixDev r;
+    r.C = m.n_components;
+    r.logw = m.logw_dev;
+    r.mu = m.mu_dev;
+    r.prec = m.prec_dev;
+    return r;
+}
+
+__host__ __device__ __forceinline__ int lds_row_stride(int rowbytes) {
+    // +16 B breaks the power-of-two stride (bank-conflict free per-lane row reads); rows whose
+    // byte length is not a multiple of 16 are padded up to the next multiple of 8 first
+    return ((rowbytes + 7) & ~7) + 16;
+}
+
+// coalesced copy of a 64-row tile global -> LDS (VEC = bytes per lane per access: 16, 8 or 4)
+template <int VEC>
+__device__ __forceinline__ void tile_load(const char* __restrict__ g, int64_t valid_bytes, int rowbytes,
+                                          int ldsrow, char* lds, int lane) {
+    const int tile_bytes = 64 * rowbytes;
+    for (int off = lane * VEC; off < tile_bytes; off += 64 * VEC) {
+        const int r = off / rowbytes, c = off - r * rowbytes;
+        if (VEC == 16) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (off < valid_bytes) v = *reinterpret_cast<const uint4*>(g + off);
+            *reinterpret_cast<uint4*>(lds + r * ldsrow + c) = v;
+        } else if (VEC == 8) {
+            unsigned long long v = 0;
+            if (off < valid_bytes) v = *reinterpret_cast<const unsigned long long*>(g + off);
+            *reinterpret_cast<unsigned long long*>(lds + r * ldsrow + c) = v;
+        } else {
+            uint32_t v = 0;
+            if (off < valid_bytes) v = *reinterpret_cast<const uint32_t*>(g + off);
+            *reinterpret_cast<uint32_t*>(lds + r * ldsrow + c) = v;
+        }
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void tile_store(char* __restrict__ g, int64_t valid_bytes, int rowbytes,
+                                           int ldsrow, const char* lds, int lane) {
+    const int tile_bytes = 64 * rowbytes;
+    for (int off = lane * VEC; off < tile_bytes; off += 64 * VEC) {
+        if (off >= valid_bytes) break;
+        const int r = off / rowbytes, c = off - r * rowbytes;
+        if (VEC == 16)
+            *reinterpret_cast<uint4*>(g + off) = *reinterpret_cast<const uint4*>(lds + r * ldsrow + c);
+        else if (VEC == 8)
+            *reinterpret_cast<unsigned long long*>(g + off) =
+                *reinterpret_cast<const unsigned long long*>(lds + r * ldsrow + c);
+        else
+            *reinterpret_cast<uint32_t*>(g + off) = *reinterpret_cast<const uint32_t*>(lds + r * ldsrow + c);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ double row_get(const char* row, int j) {
+    return (double)reinterpret_cast<const T*>(row)[j];
+}
+template <typename T>
+__device__ __forceinline__ void row_set(char* row, int j, double v) {
+    reinterpret_cast<T*>(row)[j] = (T)v;
+}
+
+// diagonal-mixture log-density of the row stored (as T) at `row`
+template <typename T>
+__device__ __forceinline__ double mixture_eval(const MixDev& m, int d, const char* row) {
+    double best = -INFINITY;
+    double terms[ASMC_MAX_COMPONENTS];
+    const int C = m.C;
+    for (int c = 0; c < C; c++) {
+        double q = 0.0;
+        const double* mu = m.mu + (size_t)c * d;
+        const double* pr = m.prec + (size_t)c * d;
+        for (int j = 0; j < d; j++) {
+            const double t = row_get<T>(row, j) - mu[j];
+            q = fma(t * t, pr[j], q);
+        }
+        const double v = m.logw[c] - 0.5 * q;
+        terms[c] = v;
+        best = fmax(best, v);
+    }
+    if (C == 1) return terms[0];
+    if (best == -INFINITY) return -INFINITY;
+    double s = 0.0;
+    for (int c = 0; c < C; c++) s += exp(terms[c] - best);
+    return best + log(s);
+}
+
+__device__ __forceinline__ double log_p_t(double ll, double lp, double lq, double beta) {
+    double r = (1.0 - beta) * lq + beta * (ll + lp);
+    return (r != r) ? -INFINITY : r;
+}
+
+// =============================================================================================
+// fused pCN step, generic in d: per-lane work vector v[k] lives in LDS (SoA: v[k*64 + lane])
+// =============================================================================================
+struct PcnDev {
+    int d;
+    double beta;
+    const double* mu;
+    const double* L;
+    const double* Linv;
+    MixDev ll, lp, lq;
+    unsigned long long seed, gid0;
+};
+
+// PHASE 0: fused (propose + built-in targets + accept, in place)
+// PHASE 1: propose only (writes x_prop tile, qform_old, qform_new)
+template <typename T, int VEC, int PHASE>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_step(
+    int64_t n, T* __restrict__ x, double* __restrict__ ll, double* __restrict__ lp, double* __restrict__ lq,
+    PcnDev p, const double* __restrict__ rho_ptr, uint32_t step, long long* __restrict__ block_counts,
+    T* __restrict__ x_prop, double* __restrict__ qf_old, double* __restrict__ qf_new, int waves_per_block) {
+    extern __shared__ __align__(16) char smem[];
+    const int d = p.d;
+    const int rowbytes = d * (int)sizeof(T);
+    const int ldsrow = lds_row_stride(rowbytes);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_bytes = 64 * ldsrow + 64 * 8 * d;
+    char* tile = smem + (size_t)wave * wave_bytes;
+    double* v = reinterpret_cast<double*>(tile + 64 * ldsrow) + lane;  // v[k*64]
+    char* myrow = tile + lane * ldsrow;
+    const double rho = *rho_ptr;
+    const double a = sqrt(1.0 - rho * rho);
+    long long n_acc = 0;
+    const int64_t n_tiles = (n + 63) / 64;
+    for (int64_t tile0 = (int64_t)blockIdx.x * waves_per_block; tile0 < n_tiles;
+         tile0 += (int64_t)gridDim.x * waves_per_block) {
+        const int64_t t = tile0 + wave;
+        const bool active = t < n_tiles;
+        const int64_t i = t * 64 + lane;
+        const bool valid = active && i < n;
+        const int64_t row0 = t * 64;
+        const int64_t valid_bytes = active ? (((n - row0) < 64 ? (n - row0) : 64) * (int64_t)rowbytes) : 0;
+        if (active) tile_load<VEC>(reinterpret_cast<const char*>(x) + row0 * rowbytes, valid_bytes, rowbytes, ldsrow, tile, lane);
+        __syncthreads();
+        bool acc = false;
+        if (valid) {
+            const unsigned long long gid = p.gid0 + (unsigned long long)i;
+            // dx -> v
+            for (int j = 0; j < d; j++) v[j * 64] = row_get<T>(myrow, j) - p.mu[j];
+            // y = Linv dx (in place, descending rows), q0 = |y|^2
+            double q0 = 0.0;
+            for (int j = d - 1; j >= 0; j--) {
+                const double* Lr = p.Linv + (size_t)j * d;
+                double s = 0.0;
+                for (int k = 0; k <= j; k++) s = fma(Lr[k], v[k * 64], s);
+                v[j * 64] = s;
+                q0 = fma(s, s, q0);
+            }
+            // y' = a y + rho xi, q1 = |y'|^2
+            double q1 = 0.0;
+            for (int pr = 0; 2 * pr < d; pr++) {
+                double z0, z1;
+                normal_pair(p.seed, gid, step, (uint32_t)pr, z0, z1);
+                double y0 = fma(rho, z0, a * v[(2 * pr) * 64]);
+                v[(2 * pr) * 64] = y0;
+                q1 = fma(y0, y0, q1);
+                if (2 * pr + 1 < d) {
+                    double y1 = fma(rho, z1, a * v[(2 * pr + 1) * 64]);
+                    v[(2 * pr + 1) * 64] = y1;
+                    q1 = fma(y1, y1, q1);
+                }
+            }
+            // x' = mu + L y' (in place, descending rows); rounded to the storage type
+            for (int j = d - 1; j >= 0; j--) {
+                const double* Lr = p.L + (size_t)j * d;
+                double s = 0.0;
+                for (int k = 0; k <= j; k++) s = fma(Lr[k], v[k * 64], s);
+                v[j * 64] = (double)(T)(p.mu[j] + s);
+            }
+            if (PHASE == 1) {
+                qf_old[i] = q0;
+                qf_new[i] = q1;
+                for (int j = 0; j < d; j++) row_set<T>(myrow, j, v[j * 64]);
+            } else {
+                // the old row is still in `myrow`; stage x' into it only on acceptance, so evaluate
+                // the targets from a scratch copy: write x' to the row AFTER saving nothing — the old
+                // row is not needed again (old ll/lp/lq come from HBM), so overwrite and restore on reject
+                const double oll = ll[i], olp = lp[i], olq = lq[i];
+                // evaluate the built-in targets at x' directly from the work vector via a temp row view
+                double nll, nlp, nlq;
+                {
+                    // temporarily keep the old row in registers-free form: swap through LDS element-wise
+                    // (row <- x', v <- old x) so mixture_eval can read a contiguous typed row
+                    for (int j = 0; j < d; j++) {
+                        const double oldx = row_get<T>(myrow, j);
+                        row_set<T>(myrow, j, v[j * 64]);
+                        v[j * 64] = oldx;
+                    }
+                    nll = mixture_eval<T>(p.ll, d, myrow);
+                    nlp = mixture_eval<T>(p.lp, d, myrow);
+                    nlq = mixture_eval<T>(p.lq, d, myrow);
+                }
+                const double lpn = log_p_t(nll, nlp, nlq, p.beta);
+                const double lpo = log_p_t(oll, olp, olq, p.beta);
+                const double log_a = (lpn + 0.5 * q1) - (lpo + 0.5 * q0);
+                const double u = accept_uniform(p.seed, gid, step);
+                acc = log(u) < log_a;
+                if (acc) {
+                    ll[i] = nll;
+                    lp[i] = nlp;
+                    lq[i] = nlq;
+                    n_acc++;
+                } else {
+                    for (int j = 0; j < d; j++) row_set<T>(myrow, j, v[j * 64]);  // restore old row
+                }
+            }
+        }
+        __syncthreads();
+        if (active) {
+            if (PHASE == 1) {
+                tile_store<VEC>(reinterpret_cast<char*>(x_prop) + row0 * rowbytes, valid_bytes, rowbytes, ldsrow, tile, lane);
+            } else if (__ballot(acc) != 0ULL) {
+                tile_store<VEC>(reinterpret_cast<char*>(x) + row0 * rowbytes, valid_bytes, rowbytes, ldsrow, tile, lane);
+            }
+        }
+        __syncthreads();
+    }
+    if (PHASE == 0) {
+        __shared__ long long s_cnt[ASMC_BLOCK / 64];
+        n_acc = wave_sum_ll(n_acc);
+        if (lane == 0) s_cnt[wave] = n_acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long tsum = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); w++) tsum += s_cnt[w];
+            block_counts[blockIdx.x] = tsum;
+        }
+    }
+}
+
+// sums the per-block accept counts of step `t`, records them, adapts the step size
+// (log rho += (acc - target)/(t+1)^0.75, rho clipped to [1e-4, 0.99])
+__global__ __launch_bounds__(64) void k_pcn_adapt(int nblocks, const long long* __restrict__ block_counts,
+                                                 int64_t n, int t, long long* __restrict__ counts_out,
+                                                 double* __restrict__ rho_ptr, double* __restrict__ rho_hist,
+                                                 double target, int adapt) {
+    long long c = 0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) c += block_counts[b];
+    c = wave_sum_ll(c);
+    if (threadIdx.x == 0) {
+        counts_out[t] = c;
+        const double rho = *rho_ptr;
+        rho_hist[t] = rho;
+        if (adapt) {
+            const double acc = (double)c / (double)n;
+            double r = exp(log(rho) + (acc - target) / pow((double)(t + 1), 0.75));
+            r = r < 1e-4 ? 1e-4 : r;
+            r = r > 0.99 ? 0.99 : r;
+            *rho_ptr = r;
+        }
+    }
+}
+
+// split-path accept: per particle decision + scalar update, then a flat conditional row copy
+__global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_accept_flags(
+    int64_t n, double* __restrict__ ll, double* __restrict__ lp, double* __restrict__ lq,
+    const double* __restrict__ ll_new, const double* __restrict__ lp_new, const double* __restrict__ lq_new,
+    const double* __restrict__ lj_old, const double* __restrict__ lj_new, const double* __restrict__ qf_old,
+    const double* __restrict__ qf_new, double beta, unsigned long long seed, unsigned long long gid0,
+    uint32_t step, unsigned char* __restrict__ flags, unsigned long long* __restrict__ count) {
+    long long c = 0;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) {
+        double lpn = log_p_t(ll_new[i], lp_new[i], lq_new[i], beta);
+        double lpo = log_p_t(ll[i], lp[i], lq[i], beta);
+        if (lj_new) {
+            lpn += lj_new[i];
+            lpn = (lpn != lpn) ? -INFINITY : lpn;
+        }
+        if (lj_old) {
+            lpo += lj_old[i];
+            lpo = (lpo != lpo) ? -INFINITY : lpo;
+        }
+        const double log_a = (lpn + 0.5 * qf_new[i]) - (lpo + 0.5 * qf_old[i]);
+        const double u = accept_uniform(seed, gid0 + (unsigned long long)i, step);
+        const bool acc = log(u) < log_a;
+        flags[i] = acc ? 1 : 0;
+        if (acc) {
+            ll[i] = ll_new[i];
+            lp[i] = lp_new[i];
+            lq[i] = lq_new[i];
+            c++;
+        }
+    }
+    c = wave_sum_ll(c);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_copy_flagged_rows(int64_t n, int d, T* __restrict__ x,
+                                                                 const T* __restrict__ x_prop,
+                                                                 const unsigned char* __restrict__ flags) {
+    const int64_t total = n * d;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t e = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / d;
+        if (flags[r]) x[e] = x_prop[e];
+    }
+}
+
+// =============================================================================================
+// analytic Gaussian proposal draw, built-in density evaluation
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_gaussian_draw(int64_t n, int d, const double* __restrict__ mu,
+                                                             const double* __restrict__ sigma,
+                                                             unsigned long long seed, unsigned long long gid0,
+                                                             uint32_t draw_id, T* __restrict__ x) {
+    const int pairs = (d + 1) / 2;
+    const int64_t total = n * pairs;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t e = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; e < total; e += stride) {
+        const int64_t i = e / pairs;
+        const int pr = (int)(e - i * pairs);
+        double z0, z1;
+        normal_pair(seed, gid0 + (unsigned long long)i, draw_id, (uint32_t)pr, z0, z1);
+        const int j = 2 * pr;
+        x[i * d + j] = (T)fma(sigma[j], z0, mu[j]);
+        if (j + 1 < d) x[i * d + j + 1] = (T)fma(sigma[j + 1], z1, mu[j + 1]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_gaussian_logq(int64_t n, int d, const double* __restrict__ mu,
+                                                             const double* __restrict__ sigma,
+                                                             const T* __restrict__ x, double* __restrict__ lq) {
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) {
+        double q = 0.0, ls = 0.0;
+        for (int j = 0; j < d; j++) {
+            const double z = ((double)x[i * d + j] - mu[j]) / sigma[j];
+            q = fma(z, z, q);
+            ls += log(sigma[j]);
+        }
+        lq[i] = -0.5 * q - ls - 0.5 * (double)d * 1.8378770664093454835606594728112;  // log(2 pi)
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_mixture_logpdf(int64_t n, int d, const T* __restrict__ x,
+                                                              MixDev m, double* __restrict__ out,
+                                                              int waves_per_block) {
+    extern __shared__ __align__(16) char smem[];
+    const int rowbytes = d * (int)sizeof(T);
+    const int ldsrow = lds_row_stride(rowbytes);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* tile = smem + (size_t)wave * 64 * ldsrow;
+    const int64_t n_tiles = (n + 63) / 64;
+    for (int64_t tile0 = (int64_t)blockIdx.x * waves_per_block; tile0 < n_tiles;
+         tile0 += (int64_t)gridDim.x * waves_per_block) {
+        const int64_t t = tile0 + wave;
+        const bool active = t < n_tiles;
+        const int64_t i = t * 64 + lane;
+        const int64_t row0 = t * 64;
+        const int64_t valid_bytes = active ? (((n - row0) < 64 ? (n - row0) : 64) * (int64_t)rowbytes) : 0;
+        if (active) tile_load<VEC>(reinterpret_cast<const char*>(x) + row0 * rowbytes, valid_bytes, rowbytes, ldsrow, tile, lane);
+        __syncthreads();
+        if (active && i < n) out[i] = mixture_eval<T>(m, d, tile + lane * ldsrow);
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
+// population moments
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_colsum(int64_t n, int d, const T* __restrict__ x,
+                                                      double* __restrict__ partials) {
+    // thread t owns column (t % d) when ASMC_BLOCK % d == 0, otherwise a strided element walk with
+    // per-element column lookup; partial sums are combined through LDS atomics-free reduction.
+    extern __shared__ __align__(16) char smem[];
+    double* s_acc = reinterpret_cast<double*>(smem);  // [ASMC_BLOCK]
+    const int rows_per_pass = ASMC_BLOCK / d;         // >= 1 (d <= 256)
+    const int my_col = threadIdx.x % d;
+    const int my_sub = threadIdx.x / d;
+    double acc = 0.0;
+    if (my_sub < rows_per_pass) {
+        for (int64_t r = (int64_t)blockIdx.x * rows_per_pass + my_sub; r < n; r += (int64_t)gridDim.x * rows_per_pass)
+            acc += (double)x[r * d + my_col];
+    }
+    s_acc[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < d) {
+        double v = 0.0;
+        for (int s = 0; s < rows_per_pass; s++) v += s_acc[s * d + threadIdx.x];
+        partials[(size_t)blockIdx.x * d + threadIdx.x] = v;
+    }
+}
+
+// gram partial: G[j,k] += (x_ij - c_j)(x_ik - c_k) over the block's rows; tile of 64 centred rows in LDS
+template <typename T>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_gram(int64_t n, int d, const T* __restrict__ x,
+                                                    const double* __restrict__ center,
+                                                    double* __restrict__ partials) {
+    extern __shared__ __align__(16) char smem[];
+    double* s_rows = reinterpret_cast<double*>(smem);  // [64][d+1]
+    const int ld = d + 1;
+    const int dd = d * d;
+    // entries e = tid, tid+256, ... (< d*d <= 4096): at most 16 accumulators per thread
+    double acc[16];
+    int jj[16], kk[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++) {
+        acc[a] = 0.0;
+        const int e = threadIdx.x + a * ASMC_BLOCK;
+        const int ec = e < dd ? e : 0;
+        jj[a] = ec / d;
+        kk[a] = ec - jj[a] * d;
+    }
+    for (int64_t row0 = (int64_t)blockIdx.x * 64; row0 < n; row0 += (int64_t)gridDim.x * 64) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * d; e += ASMC_BLOCK) {
+            const int r = e / d, c = e - r * d;
+            const int64_t gr = row0 + r;
+            s_rows[r * ld + c] = gr < n ? (double)x[gr * d + c] - center[c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int r = 0; r < 64; r++) {
+            const double* row = s_rows + r * ld;
+#pragma unroll
+            for (int a = 0; a < 16; a++)
+                if (a * ASMC_BLOCK < dd) acc[a] = fma(row[jj[a]], row[kk[a]], acc[a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 16; a++) {
+        const int e = threadIdx.x + a * ASMC_BLOCK;
+        if (e < dd) partials[(size_t)blockIdx.x * dd + e] = acc[a];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_reduce_columns(int nblocks, int ncols, const double* __restrict__ partials,
+                                                      double* __restrict__ out) {
+    for (int col = blockIdx.x; col < ncols; col += gridDim.x) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += 64) v += partials[(size_t)b * ncols + col];
+        v = wave_sum(v);
+        if (threadIdx.x == 0) out[col] = v;
+    }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static int pick_vec(int rowbytes, const void* p0, const void* p1) {
+    const uintptr_t a = (uintptr_t)p0 | (uintptr_t)p1;
+    if (rowbytes % 16 == 0 && a % 16 == 0) return 16;
+    if (rowbytes % 8 == 0 && a % 8 == 0) return 8;
+    return 4;
+}
+
+static int waves_for_lds(size_t per_wave_bytes, size_t* lds_bytes_out) {
+    const size_t budget = 160 * 1024 - 1024;
+    int w = ASMC_BLOCK / 64;
+    while (w > 1 && per_wave_bytes * (size_t)w > budget) w >>= 1;
+    *lds_bytes_out = per_wave_bytes * (size_t)w;
+    return w;
+}
+
+template <typename T, int PHASE>
+static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const PcnDev& pd,
+                           const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
+                           T* x_prop, double* qf_old, double* qf_new, hipStream_t st) {
+    const int rowbytes = pd.d * (int)sizeof(T);
+    const size_t per_wave = (size_t)64 * lds_row_stride(rowbytes) + (size_t)64 * 8 * pd.d;
+    size_t lds_bytes = 0;
+    const int wpb = waves_for_lds(per_wave, &lds_bytes);
+    if (per_wave > 160 * 1024 - 1024) {
+        asmc_set_error("pcn: d=%d needs %zu B of LDS per wave (unsupported)", pd.d, per_wave);
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    const int64_t n_tiles = (n + 63) / 64;
+    int blocks_per_cu = (int)((160 * 1024) / lds_bytes);
+    blocks_per_cu = blocks_per_cu < 1 ? 1 : (blocks_per_cu > 8 ? 8 : blocks_per_cu);
+    int cap = ctx->num_cu * blocks_per_cu * 2;  // two rounds of resident blocks, grid-stride over tiles
+    if (cap > ASMC_MAX_BLOCKS) cap = ASMC_MAX_BLOCKS;
+    const int grid = grid_for(n_tiles, wpb, cap);
+    *grid_out = grid;
+    const int vec = pick_vec(rowbytes, x, x_prop ? (const void*)x_prop : (const void*)x);
+    auto launch = [&](auto kern) {
+        if (lds_bytes > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, pd, rho_ptr, step,
+                           block_counts, x_prop, qf_old, qf_new, wpb);
+    };
+    if (vec == 16)
+        launch(k_pcn_step<T, 16, PHASE>);
+    else if (vec == 8)
+        launch(k_pcn_step<T, 8, PHASE>);
+    else
+        launch(k_pcn_step<T, 4, PHASE>);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+static int check_mixture(const asmc_mixture& m) {
+    ASMC_REQUIRE(m.n_components >= 1 && m.n_components <= ASMC_MAX_COMPONENTS, "mixture: bad component count");
+    ASMC_REQUIRE(m.logw_dev && m.mu_dev && m.prec_dev, "mixture: null device pointer");
+    return ASMC_OK;
+}
+
+extern "C" {
+
+int asmc_gaussian_draw(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const double* mu, const double* sigma,
+                       uint64_t seed, uint64_t gid0, uint32_t draw_id, void* x_out, double* lq_out,
+                       asmc_stream stream) {
+    ASMC_REQUIRE(ctx && mu && sigma && x_out, "null pointer");
+    ASMC_REQUIRE(n > 0 && d > 0 && d <= ASMC_MAX_DIMS, "bad sizes");
+    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(n * ((d + 1) / 2), ASMC_BLOCK * 2, ASMC_MAX_BLOCKS * 2);
+    const int grid2 = grid_for(n, ASMC_BLOCK, ASMC_MAX_BLOCKS * 2);
+    if (x_dtype == ASMC_F64) {
+        hipLaunchKernelGGL(k_gaussian_draw<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma,
+                           (unsigned long long)seed, (unsigned long long)gid0, draw_id, (double*)x_out);
+        ASMC_LAUNCH_CHECK();
+        if (lq_out) hipLaunchKernelGGL(k_gaussian_logq<double>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma, (const double*)x_out, lq_out);
+    } else {
+        hipLaunchKernelGGL(k_gaussian_draw<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma,
+                           (unsigned long long)seed, (unsigned long long)gid0, draw_id, (float*)x_out);
+        ASMC_LAUNCH_CHECK();
+        if (lq_out) hipLaunchKernelGGL(k_gaussian_logq<float>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma, (const float*)x_out, lq_out);
+    }
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_mixture_logpdf(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const asmc_mixture* density,
+                        double* out, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && density && out, "null pointer");
+    ASMC_REQUIRE(n > 0 && d > 0 && d <= ASMC_MAX_DIMS, "bad sizes");
+    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    int rc = check_mixture(*density);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    const int elem = x_dtype == ASMC_F64 ? 8 : 4;
+    const int rowbytes = d * elem;
+    size_t lds_bytes = 0;
+    const int wpb = waves_for_lds((size_t)64 * lds_row_stride(rowbytes), &lds_bytes);
+    const int64_t n_tiles = (n + 63) / 64;
+    int cap = ctx->num_cu * 4;
+    if (cap > ASMC_MAX_BLOCKS) cap = ASMC_MAX_BLOCKS;
+    const int grid = grid_for(n_tiles, wpb, cap);
+    const int vec = pick_vec(rowbytes, x, x);
+    const MixDev m = to_dev(*density);
+    auto launch = [&](auto kern, auto xp) {
+        if (lds_bytes > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, d, xp, m, out, wpb);
+    };
+    if (x_dtype == ASMC_F64) {
+        const double* xp = (const double*)x;
+        if (vec == 16) launch(k_mixture_logpdf<double, 16>, xp);
+        else launch(k_mixture_logpdf<double, 8>, xp);
+    } else {
+        const float* xp = (const float*)x;
+        if (vec == 16) launch(k_mixture_logpdf<float, 16>, xp);
+        else if (vec == 8) launch(k_mixture_logpdf<float, 8>, xp);
+        else launch(k_mixture_logpdf<float, 4>, xp);
+    }
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, double* sum_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && sum_host, "null pointer");
+    ASMC_REQUIRE(n > 0 && d > 0 && d <= ctx->d_max && d <= ASMC_BLOCK, "bad sizes");
+    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    hipStream_t st = as_stream(stream);
+    int grid = grid_for(n, (ASMC_BLOCK / d) * 16, ctx->gram_blocks);
+    if (x_dtype == ASMC_F64)
+        hipLaunchKernelGGL(k_colsum<double>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const double*)x, ctx->d_gram);
+    else
+        hipLaunchKernelGGL(k_colsum<float>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const float*)x, ctx->d_gram);
+    ASMC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_reduce_columns, dim3(d), dim3(64), 0, st, grid, d, (const double*)ctx->d_gram, ctx->d_small);
+    ASMC_LAUNCH_CHECK();
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, sizeof(double) * d, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    memcpy(sum_host, ctx->h_pinned, sizeof(double) * d);
+    return ASMC_OK;
+}
+
+int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* center_host,
+                       double* gram_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && center_host && gram_host, "null pointer");
+    ASMC_REQUIRE(n > 0 && d > 0 && d <= ctx->d_max && d <= 64, "bad sizes (gram supports d <= 64)");
+    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    hipStream_t st = as_stream(stream);
+    ASMC_HIP(hipStreamSynchronize(st));
+    memcpy(ctx->h_pinned + 2048, center_host, sizeof(double) * d);
+    double* d_center = ctx->d_small + 2048;
+    ASMC_HIP(hipMemcpyAsync(d_center, ctx->h_pinned + 2048, sizeof(double) * d, hipMemcpyHostToDevice, st));
+    const int grid = grid_for(n, 64 * 8, ctx->gram_blocks);
+    const size_t lds = sizeof(double) * 64 * (d + 1);
+    if (x_dtype == ASMC_F64)
+        hipLaunchKernelGGL(k_gram<double>, dim3(grid), dim3(ASMC_BLOCK), lds, st, n, d, (const double*)x, (const double*)d_center, ctx->d_gram);
+    else
+        hipLaunchKernelGGL(k_gram<float>, dim3(grid), dim3(ASMC_BLOCK), lds, st, n, d, (const float*)x, (const double*)d_center, ctx->d_gram);
+    ASMC_LAUNCH_CHECK();
+    // d*d <= 4096 doubles: reduce into the tail of d_partials, then read back in <=4096-double pieces
+    double* d_out = ctx->d_partials;
+    hipLaunchKernelGGL(k_reduce_columns, dim3(d * d < 1024 ? d * d : 1024), dim3(64), 0, st, grid, d * d, (const double*)ctx->d_gram, d_out);
+    ASMC_LAUNCH_CHECK();
+    ASMC_HIP(hipMemcpyAsync(gram_host, d_out, sizeof(double) * d * d, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    return ASMC_OK;
+}
+
+int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq,
+                    const asmc_pcn_params* prm, int n_steps, uint32_t step0, double* rho_inout_host,
+                    int64_t* n_accept_host, double* rho_hist_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && ll && lp && lq && prm && rho_inout_host && n_accept_host, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+    ASMC_REQUIRE(n_steps >= 1 && n_steps <= ASMC_MAX_PCN_STEPS, "n_steps out of range (<= 2048 per call)");
+    ASMC_REQUIRE(prm->d > 0 && prm->d <= ASMC_MAX_DIMS, "bad d");
+    ASMC_REQUIRE(prm->x_dtype == ASMC_F64 || prm->x_dtype == ASMC_F32, "bad x_dtype");
+    ASMC_REQUIRE(prm->mu_dev && prm->L_dev && prm->Linv_dev, "null reference-Gaussian pointer");
+    ASMC_REQUIRE(*rho_inout_host > 0.0 && *rho_inout_host <= 1.0, "rho must be in (0, 1]");
+    int rc = check_mixture(prm->log_likelihood);
+    if (!rc) rc = check_mixture(prm->log_prior);
+    if (!rc) rc = check_mixture(prm->log_q);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    PcnDev pd;
+    pd.d = prm->d;
+    pd.beta = prm->beta;
+    pd.mu = prm->mu_dev;
+    pd.L = prm->L_dev;
+    pd.Linv = prm->Linv_dev;
+    pd.ll = to_dev(prm->log_likelihood);
+    pd.lp = to_dev(prm->log_prior);
+    pd.lq = to_dev(prm->log_q);
+    pd.seed = prm->seed;
+    pd.gid0 = prm->gid0;
+    // device step-size cell + history
+    double* d_rho = ctx->d_rho;            // [0]: current rho
+    double* d_rho_hist = ctx->d_rho + 8;   // [n_steps]
+    long long* d_counts = ctx->d_counts;   // [n_steps]
+    long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
+    ASMC_HIP(hipStreamSynchronize(st));
+    ctx->h_pinned[0] = *rho_inout_host;
+    ASMC_HIP(hipMemcpyAsync(d_rho, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, st));
+    for (int t = 0; t < n_steps; t++) {
+        int grid = 0;
+        if (prm->x_dtype == ASMC_F64)
+            rc = launch_pcn_step<double, 0>(ctx, n, (double*)x, ll, lp, lq, pd, d_rho, step0 + (uint32_t)t, d_block,
+                                            &grid, nullptr, nullptr, nullptr, st);
+        else
+            rc = launch_pcn_step<float, 0>(ctx, n, (float*)x, ll, lp, lq, pd, d_rho, step0 + (uint32_t)t, d_block,
+                                           &grid, nullptr, nullptr, nullptr, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_pcn_adapt, dim3(1), dim3(64), 0, st, grid, (const long long*)d_block, n, t, d_counts,
+                           d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+        ASMC_LAUNCH_CHECK();
+    }
+    // read back: counts [n_steps] | rho_hist [n_steps] | rho
+    long long* h_counts = reinterpret_cast<long long*>(ctx->h_pinned);
+    double* h_rho_hist = ctx->h_pinned + ASMC_MAX_PCN_STEPS + 8;  // disjoint from the counts
+    ASMC_HIP(hipMemcpyAsync(h_counts, d_counts, sizeof(long long) * n_steps, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipMemcpyAsync(h_rho_hist, d_rho_hist, sizeof(double) * n_steps, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8000, d_rho, sizeof(double), hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    for (int t = 0; t < n_steps; t++) n_accept_host[t] = (int64_t)h_counts[t];
+    if (rho_hist_host)
+        for (int t = 0; t < n_steps; t++) rho_hist_host[t] = h_rho_hist[t];
+    *rho_inout_host = ctx->h_pinned[8000];
+    return ASMC_OK;
+}
+
+int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, void* x_prop, double* qf_old,
+                     double* qf_new, const double* mu, const double* L, const double* Linv, double rho,
+                     uint64_t seed, uint64_t gid0, uint32_t step, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && x_prop && qf_old && qf_new && mu && L && Linv, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max && d > 0 && d <= ASMC_MAX_DIMS, "bad sizes");
+    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    ASMC_REQUIRE(rho > 0.0 && rho <= 1.0, "rho must be in (0, 1]");
+    hipStream_t st = as_stream(stream);
+    PcnDev pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.d = d;
+    pd.mu = mu;
+    pd.L = L;
+    pd.Linv = Linv;
+    pd.seed = seed;
+    pd.gid0 = gid0;
+    ASMC_HIP(hipStreamSynchronize(st));
+    ctx->h_pinned[0] = rho;
+    ASMC_HIP(hipMemcpyAsync(ctx->d_rho, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, st));
+    int grid = 0;
+    if (x_dtype == ASMC_F64)
+        return launch_pcn_step<double, 1>(ctx, n, (double*)const_cast<void*>(x), nullptr, nullptr, nullptr, pd, ctx->d_rho,
+                                          step, nullptr, &grid, (double*)x_prop, qf_old, qf_new, st);
+    return launch_pcn_step<float, 1>(ctx, n, (float*)const_cast<void*>(x), nullptr, nullptr, nullptr, pd, ctx->d_rho, step,
+                                     nullptr, &grid, (float*)x_prop, qf_old, qf_new, st);
+}
+
+int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x, const void* x_prop, double* ll, double* lp,
+                    double* lq, const double* ll_new, const double* lp_new, const double* lq_new,
+                    const double* lj_old, const double* lj_new, const double* qf_old, const double* qf_new,
+                    double beta, uint64_t seed, uint64_t gid0, uint32_t step, int64_t* n_accept_host,
+                    asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && x_prop && ll && lp && lq && ll_new && lp_new && lq_new && qf_old && qf_new, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max && d > 0, "bad sizes");
+    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    hipStream_t st = as_stream(stream);
+    // flags live in the (otherwise unused here) integer tile scratch: n bytes <= n_tiles_max*32 bytes
+    ASMC_REQUIRE((size_t)n <= (size_t)(ctx->n_tiles_max * 4 + 64) * sizeof(long long), "n exceeds flag scratch");
+    unsigned char* flags = reinterpret_cast<unsigned char*>(ctx->d_tiles_i);
+    ASMC_HIP(hipMemsetAsync(ctx->d_keys, 0, sizeof(unsigned long long), st));
+    const int grid = grid_for(n, ASMC_BLOCK * 2, ASMC_MAX_BLOCKS);
+    hipLaunchKernelGGL(k_pcn_accept_flags, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, ll_new, lp_new, lq_new,
+                       lj_old, lj_new, qf_old, qf_new, beta, (unsigned long long)seed, (unsigned long long)gid0, step,
+                       flags, ctx->d_keys);
+    ASMC_LAUNCH_CHECK();
+    const int grid2 = grid_for(n * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
+    if (x_dtype == ASMC_F64)
+        hipLaunchKernelGGL(k_copy_flagged_rows<double>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, (double*)x,
+                           (const double*)x_prop, (const unsigned char*)flags);
+    else
+        hipLaunchKernelGGL(k_copy_flagged_rows<float>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, (float*)x,
+                           (const float*)x_prop, (const unsigned char*)flags);
+    ASMC_LAUNCH_CHECK();
+    if (n_accept_host) {
+        unsigned long long* h = reinterpret_cast<unsigned long long*>(ctx->h_pinned);
+        ASMC_HIP(hipMemcpyAsync(h, ctx->d_keys, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        ASMC_HIP(hipStreamSynchronize(st));
+        *n_accept_host = (int64_t)h[0];
+    }
+    return ASMC_OK;
+}
+
+}  // extern "C"

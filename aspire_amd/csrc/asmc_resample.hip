@@ -1,0 +1,646 @@
+// asmc_resample.hip — cdf scans (exact sequential-order and fast), PCG64 uniforms, upper-bound
+// search, row gather, validity compaction.
+//
+// Replaces (reference mj-will/aspire):
+//   src/aspire/samples.py:1277-1278  w = exp(lw - LSE); idx = rng.choice(N, n, True, p=w)
+//     == numpy Generator.choice: cdf = cumsum(w); cdf /= cdf[-1]; u = random(n);
+//        idx = cdf.searchsorted(u, side="right")                      
+//   src/aspire/samples.py:1279-1287  x[idx], log_likelihood[idx], log_prior[idx], log_q[idx]
+//   src/aspire/samplers/mcmc.py:88-108  finite-mask filter of draw_initial_samples
+//
+// Exact cdf.  numpy's cumsum is a strictly sequential fp64 accumulation s_k = fl(s_{k-1} + w_k).
+// While s stays inside one binade [2^e, 2^(e+1)) every such add is an INTEGER add on the grid
+// q = 2^(e-52):  s_k/q = s_{k-1}/q + RNE(w_k/q), ties-to-even depending only on the parity of
+// s_{k-1}/q.  Each element is therefore a 2-state transducer (a0, a1) = increment when the
+// running integer is even / odd; transducers compose associatively, so a block-wide scan
+// reproduces the sequential rounding bit-for-bit.  When the running sum would leave the binade
+// (S + floor(w/q) >= 2^53) the first such element is added with a genuine fp64 add and the scan
+// restarts behind it in the new binade.
+#include "asmc_common.h"
+
+// =============================================================================================
+// exact cdf
+// =============================================================================================
+struct TD {
+    long long a0, a1;
+};
+#define TD_SAT (1LL << 60)
+#define TD_BIG (1LL << 54)
+#define TWO53 9007199254740992.0
+#define TWO53_LL (1LL << 53)
+
+__device__ __forceinline__ TD td_compose(TD f, TD g) {  // apply f, then g
+    TD h;
+    h.a0 = f.a0 + ((f.a0 & 1) ? g.a1 : g.a0);
+    h.a1 = f.a1 + ((f.a1 & 1) ? g.a0 : g.a1);
+    h.a0 = h.a0 > TD_SAT ? TD_SAT : h.a0;
+    h.a1 = h.a1 > TD_SAT ? TD_SAT : h.a1;
+    return h;
+}
+
+// element transducer for weight w >= 0 on the grid 2^(e-52); nf = floor(w/q) (BIG if >= 2^53)
+__device__ __forceinline__ void td_of(double w, int e, long long& a0, long long& a1, long long& nf) {
+    const double x = ldexp(w, 52 - e);
+    const bool big = !(x < TWO53);
+    const long long n = big ? TD_BIG : (long long)x;  // x >= 0: truncation == floor
+    const double f = big ? 0.0 : x - (double)n;
+    nf = n;
+    const long long up = (f > 0.5) ? 1 : 0;
+    const bool tie = (f == 0.5);
+    a0 = n + (tie ? (n & 1) : up);        // running integer even: tie rounds to even
+    a1 = n + (tie ? ((n + 1) & 1) : up);  // running integer odd
+}
+
+#define EX_THREADS 1024
+#define EX_E 4
+#define EX_CHUNK (EX_THREADS * EX_E)
+
+__global__ __launch_bounds__(EX_THREADS) void k_cdf_exact(int64_t n, const double* __restrict__ w,
+                                                         double* __restrict__ cdf, double carry_in,
+                                                         double* __restrict__ total_out) {
+    __shared__ double sh_s;
+    __shared__ long long sh_pos;
+    __shared__ long long sh_cross;
+    __shared__ TD sh_wave[EX_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        sh_s = carry_in;
+        sh_pos = 0;
+    }
+    __syncthreads();
+    while (true) {
+        const long long pos = sh_pos;
+        const double s = sh_s;
+        if (pos >= n) break;
+        __syncthreads();  // everyone has read sh_pos / sh_s
+        if (tid == 0) sh_cross = INT64_MAX;
+        int e = (s > 0.0) ? ilogb(s) : -1022;
+        if (e < -1022) e = -1022;
+        const long long S0 = (long long)ldexp(s, 52 - e);
+        const int64_t base = pos + (int64_t)tid * EX_E;
+        double wv[EX_E];
+        long long ta0[EX_E], ta1[EX_E], nf[EX_E];
+        TD mine = {0, 0};
+#pragma unroll
+        for (int j = 0; j < EX_E; j++) {
+            const int64_t i = base + j;
+            wv[j] = (i < n) ? w[i] : 0.0;
+            td_of(wv[j], e, ta0[j], ta1[j], nf[j]);  // w = 0 -> identity transducer
+            mine = td_compose(mine, TD{ta0[j], ta1[j]});
+        }
+        // inclusive scan of `mine` over the block (lower tid first)
+        TD inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            TD t;
+            t.a0 = __shfl_up(inc.a0, o, 64);
+            t.a1 = __shfl_up(inc.a1, o, 64);
+            if (lane >= o) inc = td_compose(t, inc);
+        }
+        if (lane == 63) sh_wave[wave] = inc;
+        __syncthreads();
+        TD wave_prefix = {0, 0};
+        for (int v = 0; v < wave; v++) wave_prefix = td_compose(wave_prefix, sh_wave[v]);
+        // exclusive prefix of this thread
+        TD excl;
+        excl.a0 = __shfl_up(inc.a0, 1, 64);
+        excl.a1 = __shfl_up(inc.a1, 1, 64);
+        if (lane == 0) excl = TD{0, 0};
+        excl = td_compose(wave_prefix, excl);
+        long long S = S0 + ((S0 & 1) ? excl.a1 : excl.a0);
+        const long long S_in = S;
+        long long Sout[EX_E];
+        int cross_j = EX_E;
+#pragma unroll
+        for (int j = 0; j < EX_E; j++) {
+            if (cross_j == EX_E) {
+                if (base + j < n && S + nf[j] >= TWO53_LL) {
+                    cross_j = j;
+                } else {
+                    S += (S & 1) ? ta1[j] : ta0[j];
+                }
+            }
+            Sout[j] = S;
+        }
+        if (cross_j < EX_E) atomicMin((long long*)&sh_cross, (long long)(base + cross_j));
+        __syncthreads();
+        const long long c = sh_cross;  // first crossing index (global) or INT64_MAX
+        long long chunk_end = pos + EX_CHUNK;
+        if (chunk_end > n) chunk_end = n;
+#pragma unroll
+        for (int j = 0; j < EX_E; j++) {
+            const int64_t i = base + j;
+            if (i < chunk_end && i < c) cdf[i] = ldexp((double)Sout[j], e - 52);
+        }
+        if (c < chunk_end) {
+            // owner of the crossing element: genuine fp64 add, restart behind it
+#pragma unroll
+            for (int j = 0; j < EX_E; j++) {
+                if (c == base + j) {
+                    const long long Sprev = (j == 0) ? S_in : Sout[j > 0 ? j - 1 : 0];
+                    const double prev = (c == pos) ? s : ldexp((double)Sprev, e - 52);
+                    const double s_new = prev + wv[j];
+                    cdf[c] = s_new;
+                    sh_s = s_new;
+                    sh_pos = c + 1;
+                }
+            }
+        } else {
+            // the state after the last valid element: held by the thread owning chunk_end - 1
+#pragma unroll
+            for (int j = 0; j < EX_E; j++) {
+                if (chunk_end - 1 == base + j) {
+                    sh_s = ldexp((double)Sout[j], e - 52);
+                    sh_pos = chunk_end;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *total_out = sh_s;
+}
+
+// =============================================================================================
+// fast cdf: reduce-then-scan (fixed order => deterministic)
+// =============================================================================================
+#define SC_E (ASMC_SCAN_TILE / ASMC_BLOCK)
+
+__global__ __launch_bounds__(ASMC_BLOCK) void k_tile_sum(int64_t n, const double* __restrict__ w,
+                                                        double* __restrict__ tiles) {
+    const int64_t base = (int64_t)blockIdx.x * ASMC_SCAN_TILE + (int64_t)threadIdx.x * SC_E;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < SC_E; j++)
+        if (base + j < n) acc += w[base + j];
+    __shared__ double s_p[ASMC_BLOCK / 64];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) tiles[blockIdx.x] = ((s_p[0] + s_p[1]) + s_p[2]) + s_p[3];
+}
+
+// exclusive scan of tile sums by one block, sequential over chunks of 1024; tiles[] overwritten
+// with the exclusive prefix (+carry); total written to total_out.
+__global__ __launch_bounds__(1024) void k_scan_tiles(int64_t n_tiles, double* __restrict__ tiles,
+                                                    double carry_in, double* __restrict__ total_out) {
+    __shared__ double s_wave[16];
+    __shared__ double s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = carry_in;
+    __syncthreads();
+    for (int64_t start = 0; start < n_tiles; start += 1024) {
+        const int64_t i = start + tid;
+        double v = i < n_tiles ? tiles[i] : 0.0;
+        double inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            double t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        double wp = s_carry;
+        for (int k = 0; k < wave; k++) wp += s_wave[k];
+        if (i < n_tiles) tiles[i] = wp + (inc - v);
+        __syncthreads();
+        if (tid == 1023) s_carry = wp + inc;
+        __syncthreads();
+    }
+    if (tid == 0) *total_out = s_carry;
+}
+
+__global__ __launch_bounds__(ASMC_BLOCK) void k_tile_scan(int64_t n, const double* __restrict__ w,
+                                                         const double* __restrict__ tiles,
+                                                         double* __restrict__ cdf) {
+    const int64_t base = (int64_t)blockIdx.x * ASMC_SCAN_TILE + (int64_t)threadIdx.x * SC_E;
+    double v[SC_E];
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < SC_E; j++) {
+        v[j] = (base + j < n) ? w[base + j] : 0.0;
+        acc += v[j];
+        v[j] = acc;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double inc = acc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        double t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __shared__ double s_wave[ASMC_BLOCK / 64];
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    double off = tiles[blockIdx.x];
+    for (int k = 0; k < wave; k++) off += s_wave[k];
+    off += inc - acc;
+#pragma unroll
+    for (int j = 0; j < SC_E; j++)
+        if (base + j < n) cdf[base + j] = off + v[j];
+}
+
+__global__ __launch_bounds__(ASMC_BLOCK) void k_divide(int64_t n, double* __restrict__ cdf, double last) {
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride)
+        cdf[i] = cdf[i] / last;
+}
+
+// =============================================================================================
+// PCG64 (XSL-RR 128/64) uniforms — numpy.random.PCG64 stream, parallel through LCG jump-ahead
+// =============================================================================================
+struct U128 {
+    unsigned long long lo, hi;
+};
+__host__ __device__ __forceinline__ U128 u128_mul(U128 a, U128 b) {
+    U128 r;
+    r.lo = a.lo * b.lo;
+#if defined(__HIP_DEVICE_COMPILE__)
+    r.hi = __umul64hi(a.lo, b.lo) + a.lo * b.hi + a.hi * b.lo;
+#else
+    r.hi = (unsigned long long)(((unsigned __int128)a.lo * b.lo) >> 64) + a.lo * b.hi + a.hi * b.lo;
+#endif
+    return r;
+}
+__host__ __device__ __forceinline__ U128 u128_add(U128 a, U128 b) {
+    U128 r;
+    r.lo = a.lo + b.lo;
+    r.hi = a.hi + b.hi + (r.lo < a.lo ? 1ULL : 0ULL);
+    return r;
+}
+
+#define PCG_THREADS_LOG2 16
+#define PCG_THREADS (1 << PCG_THREADS_LOG2)
+
+// tab[i] = {A_lo, A_hi, C_lo, C_hi} for a jump of 2^i steps
+__global__ __launch_bounds__(ASMC_BLOCK) void k_pcg64_uniforms(const unsigned long long* __restrict__ tab,
+                                                              U128 state0, unsigned long long offset,
+                                                              int64_t n, double* __restrict__ u) {
+    const unsigned long long j = (unsigned long long)blockIdx.x * ASMC_BLOCK + threadIdx.x;
+    if ((int64_t)j >= n) return;
+    // post-step state of draw j: advance(state0, offset + j + 1)
+    unsigned long long delta = offset + j + 1ULL;
+    U128 st = state0;
+    for (int b = 0; b < 64 && delta; b++, delta >>= 1) {
+        if (delta & 1ULL) {
+            U128 A = {tab[4 * b], tab[4 * b + 1]}, C = {tab[4 * b + 2], tab[4 * b + 3]};
+            st = u128_add(u128_mul(st, A), C);
+        }
+    }
+    const U128 AT = {tab[4 * PCG_THREADS_LOG2], tab[4 * PCG_THREADS_LOG2 + 1]};
+    const U128 CT = {tab[4 * PCG_THREADS_LOG2 + 2], tab[4 * PCG_THREADS_LOG2 + 3]};
+    for (int64_t i = (int64_t)j; i < n; i += PCG_THREADS) {
+        const unsigned long long x = st.hi ^ st.lo;
+        const unsigned rot = (unsigned)(st.hi >> 58);
+        const unsigned long long out = (x >> rot) | (x << ((64u - rot) & 63u));
+        u[i] = (double)(out >> 11) * (1.0 / 9007199254740992.0);
+        st = u128_add(u128_mul(st, AT), CT);
+    }
+}
+
+__global__ __launch_bounds__(ASMC_BLOCK) void k_systematic(int64_t n_out, int64_t j0, int64_t n_total,
+                                                          double u0, const double* __restrict__ v,
+                                                          double* __restrict__ u) {
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; j < n_out; j += stride) {
+        const double off = v ? v[j] : u0;
+        u[j] = ((double)(j0 + j) + off) / (double)n_total;
+    }
+}
+
+// =============================================================================================
+// search: idx[j] = #{k : cdf[k] <= u[j]}   (searchsorted side="right")
+// =============================================================================================
+__global__ __launch_bounds__(ASMC_BLOCK) void k_search(int64_t n, const double* __restrict__ cdf,
+                                                      int64_t n_out, const double* __restrict__ u,
+                                                      int64_t* __restrict__ idx) {
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; j < n_out; j += stride) {
+        const double key = u[j];
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (cdf[mid] <= key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        idx[j] = lo;
+    }
+}
+
+// =============================================================================================
+// gather rows
+// =============================================================================================
+// 16-byte chunks: chunk c -> (row = c / cpr, col = c % cpr); lanes of a wave cover whole rows, so
+// every random row is fetched as full 64-B+ bursts and the output is written fully coalesced.
+__global__ __launch_bounds__(ASMC_BLOCK) void k_gather16(int64_t n_out, const int64_t* __restrict__ idx,
+                                                        int cpr, const uint4* __restrict__ x_in,
+                                                        uint4* __restrict__ x_out,
+                                                        const double* __restrict__ ll_in,
+                                                        const double* __restrict__ lp_in,
+                                                        const double* __restrict__ lq_in,
+                                                        double* __restrict__ ll_out,
+                                                        double* __restrict__ lp_out,
+                                                        double* __restrict__ lq_out) {
+    const int64_t total = n_out * cpr;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    int64_t c = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x;
+    // two chunks in flight per lane
+    for (; c + stride < total; c += 2 * stride) {
+        const int64_t c1 = c + stride;
+        const int64_t r0 = c / cpr, r1 = c1 / cpr;
+        const int k0 = (int)(c - r0 * cpr), k1 = (int)(c1 - r1 * cpr);
+        const int64_t s0 = idx[r0], s1 = idx[r1];
+        const uint4 v0 = x_in[s0 * cpr + k0];
+        const uint4 v1 = x_in[s1 * cpr + k1];
+        x_out[c] = v0;
+        x_out[c1] = v1;
+        if (k0 == 0) {
+            ll_out[r0] = ll_in[s0];
+            lp_out[r0] = lp_in[s0];
+            lq_out[r0] = lq_in[s0];
+        }
+        if (k1 == 0) {
+            ll_out[r1] = ll_in[s1];
+            lp_out[r1] = lp_in[s1];
+            lq_out[r1] = lq_in[s1];
+        }
+    }
+    for (; c < total; c += stride) {
+        const int64_t r0 = c / cpr;
+        const int k0 = (int)(c - r0 * cpr);
+        const int64_t s0 = idx[r0];
+        x_out[c] = x_in[s0 * cpr + k0];
+        if (k0 == 0) {
+            ll_out[r0] = ll_in[s0];
+            lp_out[r0] = lp_in[s0];
+            lq_out[r0] = lq_in[s0];
+        }
+    }
+}
+
+// generic element-wise fallback (row bytes not a multiple of 16)
+template <typename T>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_gather_elem(int64_t n_out, const int64_t* __restrict__ idx,
+                                                           int d, const T* __restrict__ x_in,
+                                                           T* __restrict__ x_out,
+                                                           const double* __restrict__ ll_in,
+                                                           const double* __restrict__ lp_in,
+                                                           const double* __restrict__ lq_in,
+                                                           double* __restrict__ ll_out,
+                                                           double* __restrict__ lp_out,
+                                                           double* __restrict__ lq_out) {
+    const int64_t total = n_out * d;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t c = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; c < total; c += stride) {
+        const int64_t r = c / d;
+        const int k = (int)(c - r * d);
+        const int64_t s = idx[r];
+        x_out[c] = x_in[s * d + k];
+        if (k == 0) {
+            ll_out[r] = ll_in[s];
+            lp_out[r] = lp_in[s];
+            lq_out[r] = lq_in[s];
+        }
+    }
+}
+
+// =============================================================================================
+// validity compaction (finite log_prior & log_likelihood), order preserving
+// =============================================================================================
+__device__ __forceinline__ bool row_valid(double ll, double lp) { return isfinite(ll) && isfinite(lp); }
+
+__global__ __launch_bounds__(ASMC_BLOCK) void k_valid_count(int64_t n, const double* __restrict__ ll,
+                                                           const double* __restrict__ lp,
+                                                           long long* __restrict__ tiles) {
+    const int64_t base = (int64_t)blockIdx.x * ASMC_SCAN_TILE + (int64_t)threadIdx.x * SC_E;
+    long long c = 0;
+#pragma unroll
+    for (int j = 0; j < SC_E; j++)
+        if (base + j < n && row_valid(ll[base + j], lp[base + j])) c++;
+    __shared__ long long s_p[ASMC_BLOCK / 64];
+    c = wave_sum_ll(c);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tiles[blockIdx.x] = s_p[0] + s_p[1] + s_p[2] + s_p[3];
+}
+
+__global__ __launch_bounds__(64) void k_scan_tiles_ll(int64_t n_tiles, long long* __restrict__ tiles,
+                                                     long long* __restrict__ total_out) {
+    // single wave, sequential chunks of 64 (n_tiles is small)
+    long long carry = 0;
+    const int lane = threadIdx.x;
+    for (int64_t start = 0; start < n_tiles; start += 64) {
+        const int64_t i = start + lane;
+        long long v = i < n_tiles ? tiles[i] : 0;
+        long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            long long t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (i < n_tiles) tiles[i] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) *total_out = carry;
+}
+
+template <typename T>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_compact_scatter(
+    int64_t n, int d, const T* __restrict__ x, const double* __restrict__ ll, const double* __restrict__ lp,
+    const double* __restrict__ lq, const long long* __restrict__ tiles, T* __restrict__ x_out,
+    double* __restrict__ ll_out, double* __restrict__ lp_out, double* __restrict__ lq_out) {
+    const int64_t base = (int64_t)blockIdx.x * ASMC_SCAN_TILE + (int64_t)threadIdx.x * SC_E;
+    bool ok[SC_E];
+    long long c = 0;
+#pragma unroll
+    for (int j = 0; j < SC_E; j++) {
+        ok[j] = (base + j < n) && row_valid(ll[base + j], lp[base + j]);
+        c += ok[j] ? 1 : 0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        long long t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __shared__ long long s_wave[ASMC_BLOCK / 64];
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    long long dst = tiles[blockIdx.x] + (inc - c);
+    for (int k = 0; k < wave; k++) dst += s_wave[k];
+#pragma unroll
+    for (int j = 0; j < SC_E; j++) {
+        if (ok[j]) {
+            const int64_t src = base + j;
+            for (int k = 0; k < d; k++) x_out[dst * d + k] = x[src * d + k];
+            ll_out[dst] = ll[src];
+            lp_out[dst] = lp[src];
+            lq_out[dst] = lq[src];
+            dst++;
+        }
+    }
+}
+
+// =============================================================================================
+// host entry points
+// =============================================================================================
+extern "C" {
+
+int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, double carry_in,
+             double* total_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && w && cdf, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+    hipStream_t st = as_stream(stream);
+    double* d_total = ctx->d_small + 1024;
+    if (mode == ASMC_CDF_EXACT) {
+        hipLaunchKernelGGL(k_cdf_exact, dim3(1), dim3(EX_THREADS), 0, st, n, w, cdf, carry_in, d_total);
+        ASMC_LAUNCH_CHECK();
+    } else if (mode == ASMC_CDF_FAST) {
+        const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+        hipLaunchKernelGGL(k_tile_sum, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w, ctx->d_tiles);
+        ASMC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, carry_in, d_total);
+        ASMC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w,
+                           (const double*)ctx->d_tiles, cdf);
+        ASMC_LAUNCH_CHECK();
+    } else {
+        asmc_set_error("asmc_cdf: unknown mode %d", mode);
+        return ASMC_ERR_ARG;
+    }
+    if (total_host) {
+        ASMC_HIP(hipMemcpyAsync(ctx->h_pinned, d_total, sizeof(double), hipMemcpyDeviceToHost, st));
+        ASMC_HIP(hipStreamSynchronize(st));
+        *total_host = ctx->h_pinned[0];
+    }
+    return ASMC_OK;
+}
+
+int asmc_cdf_normalize(asmc_ctx* ctx, int64_t n, double* cdf, double last, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && cdf, "null pointer");
+    ASMC_REQUIRE(n > 0, "n must be positive");
+    const int grid = grid_for(n, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS);
+    hipLaunchKernelGGL(k_divide, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, cdf, last);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_pcg64_uniforms(asmc_ctx* ctx, const uint64_t state_host[4], uint64_t offset, int64_t n,
+                        double* u, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && state_host && u, "null pointer");
+    ASMC_REQUIRE(n > 0, "n must be positive");
+    hipStream_t st = as_stream(stream);
+    // jump table for this stream's increment: A_0 = MULT, C_0 = inc; A_{i+1} = A_i^2, C_{i+1} = (A_i+1) C_i
+    // (rebuilt only when the increment changes, i.e. when a different Generator is passed)
+    if (!ctx->pcg_tab_valid || ctx->pcg_inc[0] != state_host[2] || ctx->pcg_inc[1] != state_host[3]) {
+        unsigned long long* tab = reinterpret_cast<unsigned long long*>(ctx->h_pinned) + 4096;
+        ASMC_HIP(hipStreamSynchronize(st));  // pinned staging may still be in use by a previous call
+        U128 A = {0x4385DF649FCCF645ULL, 0x2360ED051FC65DA4ULL};
+        U128 C = {state_host[3], state_host[2]};
+        for (int i = 0; i < 64; i++) {
+            tab[4 * i] = A.lo;
+            tab[4 * i + 1] = A.hi;
+            tab[4 * i + 2] = C.lo;
+            tab[4 * i + 3] = C.hi;
+            U128 A1 = u128_add(A, U128{1ULL, 0ULL});
+            C = u128_mul(A1, C);
+            A = u128_mul(A, A);
+        }
+        ASMC_HIP(hipMemcpyAsync(ctx->d_pcgtab, tab, sizeof(unsigned long long) * 256, hipMemcpyHostToDevice, st));
+        ASMC_HIP(hipStreamSynchronize(st));
+        ctx->pcg_inc[0] = state_host[2];
+        ctx->pcg_inc[1] = state_host[3];
+        ctx->pcg_tab_valid = 1;
+    }
+    U128 s0 = {state_host[1], state_host[0]};
+    const int64_t threads = n < PCG_THREADS ? n : PCG_THREADS;
+    const int grid = (int)((threads + ASMC_BLOCK - 1) / ASMC_BLOCK);
+    hipLaunchKernelGGL(k_pcg64_uniforms, dim3(grid), dim3(ASMC_BLOCK), 0, st,
+                       (const unsigned long long*)ctx->d_pcgtab, s0, (unsigned long long)offset, n, u);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_systematic_uniforms(asmc_ctx* ctx, int64_t n_out, int64_t j0, int64_t n_total, double u0,
+                             const double* v, double* u, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && u, "null pointer");
+    ASMC_REQUIRE(n_out > 0 && n_total > 0, "bad sizes");
+    const int grid = grid_for(n_out, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS);
+    hipLaunchKernelGGL(k_systematic, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n_out, j0, n_total,
+                       u0, v, u);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_search(asmc_ctx* ctx, int64_t n, const double* cdf, int64_t n_out, const double* u,
+                int64_t* idx, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && cdf && u && idx, "null pointer");
+    ASMC_REQUIRE(n > 0 && n_out > 0, "bad sizes");
+    const int grid = grid_for(n_out, ASMC_BLOCK, ASMC_MAX_BLOCKS * 4);
+    hipLaunchKernelGGL(k_search, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, cdf, n_out, u, idx);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_gather(asmc_ctx* ctx, int64_t n_out, const int64_t* idx, int d, int x_dtype, const void* x_in,
+                void* x_out, const double* ll_in, const double* lp_in, const double* lq_in,
+                double* ll_out, double* lp_out, double* lq_out, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && idx && x_in && x_out && ll_in && lp_in && lq_in && ll_out && lp_out && lq_out,
+                 "null pointer");
+    ASMC_REQUIRE(n_out > 0 && d > 0, "bad sizes");
+    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    hipStream_t st = as_stream(stream);
+    const size_t elem = x_dtype == ASMC_F64 ? 8 : 4;
+    const size_t rowbytes = elem * (size_t)d;
+    const bool vec_ok = (rowbytes % 16 == 0) && (((uintptr_t)x_in | (uintptr_t)x_out) % 16 == 0);
+    if (vec_ok) {
+        const int cpr = (int)(rowbytes / 16);
+        const int grid = grid_for(n_out * cpr, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
+        hipLaunchKernelGGL(k_gather16, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, cpr,
+                           (const uint4*)x_in, (uint4*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
+    } else if (x_dtype == ASMC_F64) {
+        const int grid = grid_for(n_out * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
+        hipLaunchKernelGGL(k_gather_elem<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, d,
+                           (const double*)x_in, (double*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
+    } else {
+        const int grid = grid_for(n_out * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
+        hipLaunchKernelGGL(k_gather_elem<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, d,
+                           (const float*)x_in, (float*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
+    }
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_compact_valid(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* ll,
+                       const double* lp, const double* lq, void* x_out, double* ll_out, double* lp_out,
+                       double* lq_out, int64_t* n_valid_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && ll && lp && lq && x_out && ll_out && lp_out && lq_out && n_valid_host,
+                 "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max && d > 0, "bad sizes");
+    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    hipStream_t st = as_stream(stream);
+    const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+    long long* d_total = ctx->d_tiles_i + ctx->n_tiles_max * 4;
+    hipLaunchKernelGGL(k_valid_count, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, ll, lp, ctx->d_tiles_i);
+    ASMC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_tiles_ll, dim3(1), dim3(64), 0, st, n_tiles, ctx->d_tiles_i, d_total);
+    ASMC_LAUNCH_CHECK();
+    if (x_dtype == ASMC_F64)
+        hipLaunchKernelGGL(k_compact_scatter<double>, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, d,
+                           (const double*)x, ll, lp, lq, (const long long*)ctx->d_tiles_i, (double*)x_out,
+                           ll_out, lp_out, lq_out);
+    else
+        hipLaunchKernelGGL(k_compact_scatter<float>, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, d,
+                           (const float*)x, ll, lp, lq, (const long long*)ctx->d_tiles_i, (float*)x_out,
+                           ll_out, lp_out, lq_out);
+    ASMC_LAUNCH_CHECK();
+    long long* h = reinterpret_cast<long long*>(ctx->h_pinned);
+    ASMC_HIP(hipMemcpyAsync(h, d_total, sizeof(long long), hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    *n_valid_host = (int64_t)h[0];
+    return ASMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,410 @@
+// asmc_weights.hip — tempered log-weights, stable log-sum-exp / ESS reductions, evidence moments.
+//
+// Replaces (reference mj-will/aspire, paths relative to its root):
+//   src/aspire/samples.py:1221-1224  SMCSamples.unnormalized_log_weights
+//   src/aspire/utils.py:248-255      logsumexp   (max pass, then sum of exp(x - max))
+//   src/aspire/utils.py:510-512      effective_sample_size
+//   src/aspire/samples.py:1226-1249  log_evidence_ratio(_variance), log_weights
+//
+// Layout: ll, lp, lq are fp64 vectors [N] in HBM; one coalesced pass serves K candidate betas
+// (the k-ary bisection of determine_beta, smc/base.py:177-185).  24 B per particle per pass.
+// Reductions: per-lane accumulators -> wave64 __shfl_xor tree -> LDS combine of the 4 waves ->
+// per-block partial in HBM -> fixed-order finalize kernel (bitwise reproducible, no fp atomics).
+// Max pass uses integer atomicMax on an order-preserving key (order independent => deterministic).
+// Compiled with -ffp-contract=off so lw is the reference's plain IEEE mul/mul/add sequence.
+#include "asmc_common.h"
+
+template <int KT>
+struct BetaPack {
+    double c1[KT];     // beta0 - beta_k
+    double c2[KT];     // beta_k - beta0
+    double m[KT];      // max (when supplied by the host)
+    double shift[KT];  // additive shift applied before subtracting m
+};
+
+__device__ __forceinline__ double lw_of(double ll, double lp, double lq, double c1, double c2) {
+    // (self.beta - beta) * log_q + (beta - self.beta) * (log_likelihood + log_prior)
+    double t1 = c1 * lq;
+    double t2 = c2 * (ll + lp);
+    return t1 + t2;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_weights_max(int64_t n, const double* __restrict__ ll,
+                                                           const double* __restrict__ lp,
+                                                           const double* __restrict__ lq,
+                                                           BetaPack<KT> bp,
+                                                           unsigned long long* __restrict__ keys,
+                                                           unsigned long long* __restrict__ nan_count) {
+    double mx[KT];
+#pragma unroll
+    for (int k = 0; k < KT; k++) mx[k] = -INFINITY;
+    long long nn = 0;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) {
+        const double a = ll[i], b = lp[i], q = lq[i];
+#pragma unroll
+        for (int k = 0; k < KT; k++) {
+            double lw = lw_of(a, b, q, bp.c1[k], bp.c2[k]);
+            if (lw != lw)
+                nn++;
+            else
+                mx[k] = fmax(mx[k], lw);
+        }
+    }
+    __shared__ double s_mx[ASMC_BLOCK / 64][KT];
+    __shared__ long long s_nn[ASMC_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < KT; k++) {
+        double v = wave_max(mx[k]);
+        if (lane == 0) s_mx[wave][k] = v;
+    }
+    nn = wave_sum_ll(nn);
+    if (lane == 0) s_nn[wave] = nn;
+    __syncthreads();
+    if (threadIdx.x < KT) {
+        double v = s_mx[0][threadIdx.x];
+        for (int w = 1; w < ASMC_BLOCK / 64; w++) v = fmax(v, s_mx[w][threadIdx.x]);
+        atomicMax(&keys[threadIdx.x], f64_to_key(v));
+    }
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < ASMC_BLOCK / 64; w++) t += s_nn[w];
+        if (t) atomicAdd(nan_count, (unsigned long long)t);
+    }
+}
+
+// S1_k = sum exp(t), S2_k = sum exp(t)^2, t = (lw + shift_k) - m_k
+template <int KT>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_weights_sums(int64_t n, const double* __restrict__ ll,
+                                                            const double* __restrict__ lp,
+                                                            const double* __restrict__ lq,
+                                                            BetaPack<KT> bp,
+                                                            const unsigned long long* __restrict__ keys,
+                                                            double* __restrict__ partials) {
+    double s1[KT], s2[KT], m[KT];
+#pragma unroll
+    for (int k = 0; k < KT; k++) {
+        s1[k] = 0.0;
+        s2[k] = 0.0;
+        m[k] = keys ? key_to_f64(keys[k]) : bp.m[k];
+    }
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) {
+        const double a = ll[i], b = lp[i], q = lq[i];
+#pragma unroll
+        for (int k = 0; k < KT; k++) {
+            double lw = lw_of(a, b, q, bp.c1[k], bp.c2[k]);
+            double t = (lw + bp.shift[k]) - m[k];
+            double e = exp(t);
+            s1[k] += e;
+            s2[k] += e * e;
+        }
+    }
+    __shared__ double s_p[ASMC_BLOCK / 64][KT * 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < KT; k++) {
+        double v1 = wave_sum(s1[k]);
+        double v2 = wave_sum(s2[k]);
+        if (lane == 0) {
+            s_p[wave][2 * k] = v1;
+            s_p[wave][2 * k + 1] = v2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < KT * 2) {
+        double v = s_p[0][threadIdx.x];
+        for (int w = 1; w < ASMC_BLOCK / 64; w++) v += s_p[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * (KT * 2) + threadIdx.x] = v;
+    }
+}
+
+// one 64-lane block per output column: fixed-order reduction of the block partials
+__global__ __launch_bounds__(64) void k_finalize_columns(int nblocks, int ncols,
+                                                        const double* __restrict__ partials,
+                                                        double* __restrict__ out, int out_stride,
+                                                        int out_offset_mode,
+                                                        const unsigned long long* __restrict__ keys,
+                                                        const unsigned long long* __restrict__ nan_count) {
+    const int col = blockIdx.x;
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) v += partials[(size_t)b * ncols + col];
+    v = wave_sum(v);
+    if (threadIdx.x == 0) {
+        if (out_offset_mode == 1) {
+            // stats layout {m, S1, S2, n_nan} per beta; col = 2k + which
+            const int k = col >> 1, which = col & 1;
+            out[k * 4 + 1 + which] = v;
+            if (which == 0) {
+                out[k * 4 + 0] = key_to_f64(keys[k]);
+                out[k * 4 + 3] = (double)(*nan_count);
+            }
+        } else {
+            out[(size_t)col * out_stride] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(ASMC_BLOCK) void k_weights_m2(int64_t n, const double* __restrict__ ll,
+                                                          const double* __restrict__ lp,
+                                                          const double* __restrict__ lq, double c1,
+                                                          double c2, double m, double mean_u,
+                                                          double* __restrict__ partials) {
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) {
+        double lw = lw_of(ll[i], lp[i], lq[i], c1, c2);
+        double dlt = exp(lw - m) - mean_u;
+        acc += dlt * dlt;
+    }
+    __shared__ double s_p[ASMC_BLOCK / 64];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v = s_p[0];
+        for (int w = 1; w < ASMC_BLOCK / 64; w++) v += s_p[w];
+        partials[blockIdx.x] = v;
+    }
+}
+
+// mode 0: out = lw + shift           (SMCSamples.log_weights)
+// mode 1: out = exp((lw + shift) - lse)   (normalised weights for resampling)
+template <int MODE>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_weights_map(int64_t n, const double* __restrict__ ll,
+                                                           const double* __restrict__ lp,
+                                                           const double* __restrict__ lq, double c1,
+                                                           double c2, double shift, double lse,
+                                                           double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) {
+        double lw = lw_of(ll[i], lp[i], lq[i], c1, c2) + shift;
+        out[i] = MODE == 0 ? lw : exp(lw - lse);
+    }
+}
+
+__global__ __launch_bounds__(ASMC_BLOCK) void k_count_nonfinite(int64_t n, const double* __restrict__ v,
+                                                               unsigned long long* __restrict__ counters) {
+    long long n_nan = 0, n_inf = 0;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) {
+        double x = v[i];
+        if (x != x)
+            n_nan++;
+        else if (isinf(x))
+            n_inf++;
+    }
+    n_nan = wave_sum_ll(n_nan);
+    n_inf = wave_sum_ll(n_inf);
+    if ((threadIdx.x & 63) == 0) {
+        if (n_nan) atomicAdd(&counters[0], (unsigned long long)n_nan);
+        if (n_inf) atomicAdd(&counters[1], (unsigned long long)n_inf);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int KT>
+static void fill_pack(BetaPack<KT>& bp, double beta0, const double* betas, const double* m,
+                      const double* shift, int K) {
+    for (int k = 0; k < KT; k++) {
+        int kk = k < K ? k : K - 1;  // pad with the last candidate
+        bp.c1[k] = beta0 - betas[kk];
+        bp.c2[k] = betas[kk] - beta0;
+        bp.m[k] = m ? m[kk] : 0.0;
+        bp.shift[k] = shift ? shift[kk] : 0.0;
+    }
+}
+
+static int bucket_of(int K) {
+    int kt = 1;
+    while (kt < K) kt <<= 1;
+    return kt;
+}
+
+#define ASMC_DISPATCH_KT(KTV, BODY) \
+    switch (KTV) {                  \
+        case 1: { constexpr int KT = 1; BODY; } break;   \
+        case 2: { constexpr int KT = 2; BODY; } break;   \
+        case 4: { constexpr int KT = 4; BODY; } break;   \
+        case 8: { constexpr int KT = 8; BODY; } break;   \
+        case 16: { constexpr int KT = 16; BODY; } break; \
+        default: { constexpr int KT = 32; BODY; } break; \
+    }
+
+static int reduce_grid(const asmc_ctx* ctx, int64_t n, int kt) {
+    // enough work per thread to amortise the K-way block reduction; cap by scratch size
+    int per_block = ASMC_BLOCK * (kt >= 16 ? 4 : 8);
+    int cap = ctx->num_cu * 4;
+    if (cap > ASMC_MAX_BLOCKS) cap = ASMC_MAX_BLOCKS;
+    return grid_for(n, per_block, cap);
+}
+
+static int launch_max(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq,
+                      double beta0, const double* betas, int K, hipStream_t st) {
+    ASMC_HIP(hipMemsetAsync(ctx->d_keys, 0, sizeof(unsigned long long) * (ASMC_MAX_BETAS + 8), st));
+    const int kt = bucket_of(K);
+    const int grid = reduce_grid(ctx, n, kt);
+    ASMC_DISPATCH_KT(kt, {
+        BetaPack<KT> bp;
+        fill_pack<KT>(bp, beta0, betas, nullptr, nullptr, K);
+        hipLaunchKernelGGL(k_weights_max<KT>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, bp,
+                           ctx->d_keys, ctx->d_keys + ASMC_MAX_BETAS);
+    });
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+static int launch_sums(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq,
+                       double beta0, const double* betas, const double* m, const double* shift, int K,
+                       bool m_from_keys, int* grid_out, hipStream_t st) {
+    const int kt = bucket_of(K);
+    const int grid = reduce_grid(ctx, n, kt);
+    *grid_out = grid;
+    ASMC_DISPATCH_KT(kt, {
+        BetaPack<KT> bp;
+        fill_pack<KT>(bp, beta0, betas, m, shift, K);
+        hipLaunchKernelGGL(k_weights_sums<KT>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, bp,
+                           m_from_keys ? ctx->d_keys : nullptr, ctx->d_partials);
+    });
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+static int check_common(asmc_ctx* ctx, int64_t n, const void* a, const void* b, const void* c) {
+    ASMC_REQUIRE(ctx != nullptr, "null ctx");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+    ASMC_REQUIRE(a && b && c, "null device pointer");
+    return ASMC_OK;
+}
+
+extern "C" {
+
+int asmc_weights_max(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq,
+                     double beta0, const double* betas_host, int K, double* m_host,
+                     int64_t* n_nan_host, asmc_stream stream) {
+    int rc = check_common(ctx, n, ll, lp, lq);
+    if (rc) return rc;
+    ASMC_REQUIRE(K >= 1 && K <= ASMC_MAX_BETAS && betas_host && m_host, "bad K / null host pointer");
+    hipStream_t st = as_stream(stream);
+    rc = launch_max(ctx, n, ll, lp, lq, beta0, betas_host, K, st);
+    if (rc) return rc;
+    unsigned long long* h = reinterpret_cast<unsigned long long*>(ctx->h_pinned);
+    ASMC_HIP(hipMemcpyAsync(h, ctx->d_keys, sizeof(unsigned long long) * (ASMC_MAX_BETAS + 1),
+                            hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < K; k++) m_host[k] = key_to_f64(h[k]);
+    if (n_nan_host) *n_nan_host = (int64_t)h[ASMC_MAX_BETAS];
+    return ASMC_OK;
+}
+
+int asmc_weights_sums(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq,
+                      double beta0, const double* betas_host, const double* m_host,
+                      const double* shift_host, int K, double* out_host, asmc_stream stream) {
+    int rc = check_common(ctx, n, ll, lp, lq);
+    if (rc) return rc;
+    ASMC_REQUIRE(K >= 1 && K <= ASMC_MAX_BETAS && betas_host && m_host && out_host, "bad K / null host pointer");
+    hipStream_t st = as_stream(stream);
+    int grid = 0;
+    rc = launch_sums(ctx, n, ll, lp, lq, beta0, betas_host, m_host, shift_host, K, false, &grid, st);
+    if (rc) return rc;
+    const int ncols = bucket_of(K) * 2;
+    hipLaunchKernelGGL(k_finalize_columns, dim3(ncols), dim3(64), 0, st, grid, ncols, ctx->d_partials,
+                       ctx->d_small, 1, 0, (const unsigned long long*)nullptr,
+                       (const unsigned long long*)nullptr);
+    ASMC_LAUNCH_CHECK();
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, sizeof(double) * ncols, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < 2 * K; k++) out_host[k] = ctx->h_pinned[k];
+    return ASMC_OK;
+}
+
+int asmc_weights_stats(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq,
+                       double beta0, const double* betas_host, int K, double* out_host,
+                       asmc_stream stream) {
+    int rc = check_common(ctx, n, ll, lp, lq);
+    if (rc) return rc;
+    ASMC_REQUIRE(K >= 1 && K <= ASMC_MAX_BETAS && betas_host && out_host, "bad K / null host pointer");
+    hipStream_t st = as_stream(stream);
+    rc = launch_max(ctx, n, ll, lp, lq, beta0, betas_host, K, st);
+    if (rc) return rc;
+    int grid = 0;
+    rc = launch_sums(ctx, n, ll, lp, lq, beta0, betas_host, nullptr, nullptr, K, true, &grid, st);
+    if (rc) return rc;
+    const int kt = bucket_of(K);
+    hipLaunchKernelGGL(k_finalize_columns, dim3(kt * 2), dim3(64), 0, st, grid, kt * 2, ctx->d_partials,
+                       ctx->d_small, 1, 1, (const unsigned long long*)ctx->d_keys,
+                       (const unsigned long long*)(ctx->d_keys + ASMC_MAX_BETAS));
+    ASMC_LAUNCH_CHECK();
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, sizeof(double) * kt * 4, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < 4 * K; k++) out_host[k] = ctx->h_pinned[k];
+    return ASMC_OK;
+}
+
+int asmc_weights_m2(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq,
+                    double beta0, double beta, double m, double mean_u, double* m2_host,
+                    asmc_stream stream) {
+    int rc = check_common(ctx, n, ll, lp, lq);
+    if (rc) return rc;
+    ASMC_REQUIRE(m2_host != nullptr, "null host pointer");
+    hipStream_t st = as_stream(stream);
+    const int grid = reduce_grid(ctx, n, 1);
+    hipLaunchKernelGGL(k_weights_m2, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, beta0 - beta,
+                       beta - beta0, m, mean_u, ctx->d_partials);
+    ASMC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_finalize_columns, dim3(1), dim3(64), 0, st, grid, 1, ctx->d_partials,
+                       ctx->d_small, 1, 0, (const unsigned long long*)nullptr,
+                       (const unsigned long long*)nullptr);
+    ASMC_LAUNCH_CHECK();
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, sizeof(double), hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    *m2_host = ctx->h_pinned[0];
+    return ASMC_OK;
+}
+
+int asmc_log_weights(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq,
+                     double beta0, double beta, double shift, double* lw_out, asmc_stream stream) {
+    int rc = check_common(ctx, n, ll, lp, lq);
+    if (rc) return rc;
+    ASMC_REQUIRE(lw_out != nullptr, "null output");
+    const int grid = grid_for(n, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS);
+    hipLaunchKernelGGL(k_weights_map<0>, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, ll, lp, lq,
+                       beta0 - beta, beta - beta0, shift, 0.0, lw_out);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_normalized_weights(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
+                            const double* lq, double beta0, double beta, double shift, double lse,
+                            double* w_out, asmc_stream stream) {
+    int rc = check_common(ctx, n, ll, lp, lq);
+    if (rc) return rc;
+    ASMC_REQUIRE(w_out != nullptr, "null output");
+    const int grid = grid_for(n, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS);
+    hipLaunchKernelGGL(k_weights_map<1>, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, ll, lp, lq,
+                       beta0 - beta, beta - beta0, shift, lse, w_out);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_count_nonfinite(asmc_ctx* ctx, int64_t n, const double* v, int64_t* n_nan_host,
+                         int64_t* n_inf_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && v, "null pointer");
+    ASMC_REQUIRE(n > 0, "n must be positive");
+    hipStream_t st = as_stream(stream);
+    ASMC_HIP(hipMemsetAsync(ctx->d_keys, 0, sizeof(unsigned long long) * 2, st));
+    const int grid = grid_for(n, ASMC_BLOCK * 8, ASMC_MAX_BLOCKS);
+    hipLaunchKernelGGL(k_count_nonfinite, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, v, ctx->d_keys);
+    ASMC_LAUNCH_CHECK();
+    unsigned long long* h = reinterpret_cast<unsigned long long*>(ctx->h_pinned);
+    ASMC_HIP(hipMemcpyAsync(h, ctx->d_keys, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    if (n_nan_host) *n_nan_host = (int64_t)h[0];
+    if (n_inf_host) *n_inf_host = (int64_t)h[1];
+    return ASMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+"""HipEngine — thin, 1:1 Python face of the C ABI (include/asmc.h) over torch device tensors.
+
+torch is used only for device memory, streams and (in `comm.py`) torch.distributed; every
+arithmetic step of the hot path runs in the hand-written HIP kernels of libasmc_hip.so.
+There is no CPU fallback: constructing a HipEngine without a HIP device raises.
+
+The same method set is implemented by the oracle-backed test double in `tests/oracle_engine.py`
+so that the host logic (`smc_math.py`, the sampler loop) can be exercised without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ASMC_CDF_EXACT, ASMC_CDF_FAST, ASMC_F32, ASMC_F64, AsmcMixture, AsmcPcnParams, check
+
+CDF_MODES = {"exact": ASMC_CDF_EXACT, "fast": ASMC_CDF_FAST}
+
+
+def _dptr(t: torch.Tensor | None):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _f64p(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+@dataclass
+class DeviceMixture:
+    """Diagonal Gaussian mixture log-density with parameters resident in HBM.
+
+    log sum_c exp(logw[c] - 0.5 * sum_j (x_j - mu[c,j])^2 * prec[c,j]); logw includes constants.
+    """
+
+    logw: torch.Tensor  # [C]
+    mu: torch.Tensor  # [C, d]
+    prec: torch.Tensor  # [C, d]
+
+    @property
+    def n_components(self) -> int:
+        return int(self.mu.shape[0])
+
+    @property
+    def dims(self) -> int:
+        return int(self.mu.shape[1])
+
+    def c_struct(self) -> AsmcMixture:
+        return AsmcMixture(self.n_components, 0, self.logw.data_ptr(), self.mu.data_ptr(), self.prec.data_ptr())
+
+
+class HipEngine:
+    """One engine per (process, device).  Not thread-safe (the ctx is bound to one host thread)."""
+
+    name = "hip"
+
+    def __init__(self, device: int | str | torch.device = 0, n_max: int = 1 << 20, d_max: int = 32):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.AsmcError("HipEngine needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
+        dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if dev.type != "cuda":
+            raise _lib.AsmcError(f"HipEngine needs a cuda (HIP) device, got {dev}")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        self.n_max, self.d_max = int(n_max), int(d_max)
+        self._ctx = ctypes.c_void_p()
+        check(self.lib.asmc_ctx_create(ctypes.byref(self._ctx), self.device.index, self.n_max, self.d_max), "asmc_ctx_create")
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.lib.asmc_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ensure_capacity(self, n: int, d: int):
+        if n > self.n_max or d > self.d_max:
+            torch.cuda.synchronize(self.device)
+            self.close()
+            self.n_max, self.d_max = max(n, self.n_max), max(d, self.d_max)
+            self._ctx = ctypes.c_void_p()
+            check(self.lib.asmc_ctx_create(ctypes.byref(self._ctx), self.device.index, self.n_max, self.d_max), "asmc_ctx_create")
+
+    # ---- plumbing --------------------------------------------------------------------------
+    @property
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def asarray(self, a, dtype=torch.float64) -> torch.Tensor:
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=self.device)
+
+    def empty(self, shape, dtype=torch.float64) -> torch.Tensor:
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def full(self, n: int, value: float) -> torch.Tensor:
+        return torch.full((n,), value, dtype=torch.float64, device=self.device)
+
+    def to_numpy(self, t: torch.Tensor) -> np.ndarray:
+        return t.detach().cpu().numpy()
+
+    def synchronize(self):
+        torch.cuda.current_stream(self.device).synchronize()
+
+    @staticmethod
+    def _xdt(x: torch.Tensor) -> int:
+        if x.dtype == torch.float64:
+            return ASMC_F64
+        if x.dtype == torch.float32:
+            return ASMC_F32
+        raise TypeError(f"x must be float64 or float32, got {x.dtype}")
+
+    @staticmethod
+    def _chk3(ll, lp, lq):
+        for t in (ll, lp, lq):
+            assert t.dtype == torch.float64 and t.is_contiguous() and t.dim() == 1
+
+    # ---- weighting -------------------------------------------------------------------------
+    def weights_max(self, ll, lp, lq, beta0: float, betas) -> tuple[np.ndarray, int]:
+        self._chk3(ll, lp, lq)
+        betas = np.ascontiguousarray(betas, dtype=np.float64)
+        m = np.empty(betas.size)
+        nnan = ctypes.c_int64(0)
+        check(self.lib.asmc_weights_max(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0, _f64p(betas),
+                                        betas.size, _f64p(m), ctypes.byref(nnan), self._stream), "asmc_weights_max")
+        return m, int(nnan.value)
+
+    def weights_sums(self, ll, lp, lq, beta0: float, betas, m, shift=None) -> np.ndarray:
+        self._chk3(ll, lp, lq)
+        betas = np.ascontiguousarray(betas, dtype=np.float64)
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        sh = None if shift is None else np.ascontiguousarray(shift, dtype=np.float64)
+        out = np.empty(2 * betas.size)
+        check(self.lib.asmc_weights_sums(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0, _f64p(betas),
+                                         _f64p(m), None if sh is None else _f64p(sh), betas.size, _f64p(out),
+                                         self._stream), "asmc_weights_sums")
+        return out.reshape(-1, 2)
+
+    def weights_stats(self, ll, lp, lq, beta0: float, betas) -> np.ndarray:
+        """[K,4] = (m, S1, S2, n_nan) per candidate beta, one pass over the batch."""
+        self._chk3(ll, lp, lq)
+        betas = np.ascontiguousarray(betas, dtype=np.float64)
+        out = np.empty(4 * betas.size)
+        check(self.lib.asmc_weights_stats(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0,
+                                          _f64p(betas), betas.size, _f64p(out), self._stream), "asmc_weights_stats")
+        return out.reshape(-1, 4)
+
+    def weights_m2(self, ll, lp, lq, beta0: float, beta: float, m: float, mean_u: float) -> float:
+        self._chk3(ll, lp, lq)
+        out = ctypes.c_double(0.0)
+        check(self.lib.asmc_weights_m2(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0, beta, m, mean_u,
+                                       ctypes.byref(out), self._stream), "asmc_weights_m2")
+        return out.value
+
+    def log_weights(self, ll, lp, lq, beta0: float, beta: float, shift: float) -> torch.Tensor:
+        self._chk3(ll, lp, lq)
+        out = torch.empty_like(ll)
+        check(self.lib.asmc_log_weights(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0, beta, shift,
+                                        _dptr(out), self._stream), "asmc_log_weights")
+        return out
+
+    def normalized_weights(self, ll, lp, lq, beta0: float, beta: float, shift: float, lse: float) -> torch.Tensor:
+        self._chk3(ll, lp, lq)
+        out = torch.empty_like(ll)
+        check(self.lib.asmc_normalized_weights(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0, beta,
+                                               shift, lse, _dptr(out), self._stream), "asmc_normalized_weights")
+        return out
+
+    def count_nonfinite(self, v: torch.Tensor) -> tuple[int, int]:
+        assert v.dtype == torch.float64 and v.is_contiguous()
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self.lib.asmc_count_nonfinite(self._ctx, v.numel(), _dptr(v), ctypes.byref(a), ctypes.byref(b),
+                                            self._stream), "asmc_count_nonfinite")
+        return int(a.value), int(b.value)
+
+    # ---- resampling ------------------------------------------------------------------------
+    def cdf(self, w: torch.Tensor, mode: str = "exact", carry_in: float = 0.0) -> tuple[torch.Tensor, float]:
+        assert w.dtype == torch.float64 and w.is_contiguous()
+        out = torch.empty_like(w)
+        total = ctypes.c_double(0.0)
+        check(self.lib.asmc_cdf(self._ctx, w.numel(), _dptr(w), _dptr(out), CDF_MODES[mode], carry_in,
+                                ctypes.byref(total), self._stream), "asmc_cdf")
+        return out, total.value
+
+    def cdf_normalize(self, cdf: torch.Tensor, last: float) -> torch.Tensor:
+        check(self.lib.asmc_cdf_normalize(self._ctx, cdf.numel(), _dptr(cdf), last, self._stream), "asmc_cdf_normalize")
+        return cdf
+
+    def uniforms_pcg64(self, state4: np.ndarray, offset: int, n: int) -> torch.Tensor:
+        st = np.ascontiguousarray(state4, dtype=np.uint64)
+        out = self.empty(n)
+        check(self.lib.asmc_pcg64_uniforms(self._ctx, st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), offset, n,
+                                           _dptr(out), self._stream), "asmc_pcg64_uniforms")
+        return out
+
+    def systematic_uniforms(self, n_out: int, j0: int, n_total: int, u0: float, v: torch.Tensor | None = None):
+        out = self.empty(n_out)
+        check(self.lib.asmc_systematic_uniforms(self._ctx, n_out, j0, n_total, u0, _dptr(v), _dptr(out), self._stream),
+              "asmc_systematic_uniforms")
+        return out
+
+    def search(self, cdf: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+        assert cdf.dtype == torch.float64 and u.dtype == torch.float64 and cdf.is_contiguous() and u.is_contiguous()
+        idx = torch.empty(u.numel(), dtype=torch.int64, device=self.device)
+        check(self.lib.asmc_search(self._ctx, cdf.numel(), _dptr(cdf), u.numel(), _dptr(u), _dptr(idx), self._stream),
+              "asmc_search")
+        return idx
+
+    def gather(self, idx, x, ll, lp, lq):
+        assert idx.dtype == torch.int64 and idx.is_contiguous() and x.is_contiguous()
+        self._chk3(ll, lp, lq)
+        n_out, d = idx.numel(), x.shape[1]
+        xo = torch.empty((n_out, d), dtype=x.dtype, device=self.device)
+        llo, lpo, lqo = (torch.empty(n_out, dtype=torch.float64, device=self.device) for _ in range(3))
+        check(self.lib.asmc_gather(self._ctx, n_out, _dptr(idx), d, self._xdt(x), _dptr(x), _dptr(xo), _dptr(ll),
+                                   _dptr(lp), _dptr(lq), _dptr(llo), _dptr(lpo), _dptr(lqo), self._stream), "asmc_gather")
+        return xo, llo, lpo, lqo
+
+    # ---- proposal / densities / filter -----------------------------------------------------
+    def make_mixture(self, logw, mu, prec) -> DeviceMixture:
+        mu = np.atleast_2d(np.asarray(mu, dtype=np.float64))
+        prec = np.atleast_2d(np.asarray(prec, dtype=np.float64))
+        logw = np.atleast_1d(np.asarray(logw, dtype=np.float64))
+        assert mu.shape == prec.shape and logw.shape == (mu.shape[0],)
+        return DeviceMixture(self.asarray(logw), self.asarray(mu), self.asarray(prec))
+
+    def gaussian_draw(self, n, d, x_dtype, mu, sigma, seed, gid0, draw_id, want_lq=True):
+        x = torch.empty((n, d), dtype=x_dtype, device=self.device)
+        lq = self.empty(n) if want_lq else None
+        check(self.lib.asmc_gaussian_draw(self._ctx, n, d, self._xdt(x), _dptr(mu), _dptr(sigma), seed, gid0, draw_id,
+                                          _dptr(x), _dptr(lq), self._stream), "asmc_gaussian_draw")
+        return x, lq
+
+    def mixture_logpdf(self, x: torch.Tensor, mix: DeviceMixture) -> torch.Tensor:
+        assert x.is_contiguous() and x.dim() == 2
+        out = self.empty(x.shape[0])
+        cs = mix.c_struct()
+        check(self.lib.asmc_mixture_logpdf(self._ctx, x.shape[0], x.shape[1], self._xdt(x), _dptr(x), ctypes.byref(cs),
+                                           _dptr(out), self._stream), "asmc_mixture_logpdf")
+        return out
+
+    def compact_valid(self, x, ll, lp, lq):
+        self._chk3(ll, lp, lq)
+        n, d = x.shape
+        xo = torch.empty_like(x)
+        llo, lpo, lqo = torch.empty_like(ll), torch.empty_like(lp), torch.empty_like(lq)
+        nv = ctypes.c_int64(0)
+        check(self.lib.asmc_compact_valid(self._ctx, n, d, self._xdt(x), _dptr(x), _dptr(ll), _dptr(lp), _dptr(lq),
+                                          _dptr(xo), _dptr(llo), _dptr(lpo), _dptr(lqo), ctypes.byref(nv), self._stream),
+              "asmc_compact_valid")
+        k = int(nv.value)
+        return xo[:k], llo[:k], lpo[:k], lqo[:k]
+
+    # ---- moments / pCN ---------------------------------------------------------------------
+    def colsum(self, x: torch.Tensor) -> np.ndarray:
+        n, d = x.shape
+        out = np.empty(d)
+        check(self.lib.asmc_colsum(self._ctx, n, d, self._xdt(x), _dptr(x), _f64p(out), self._stream), "asmc_colsum")
+        return out
+
+    def centered_gram(self, x: torch.Tensor, center: np.ndarray) -> np.ndarray:
+        n, d = x.shape
+        c = np.ascontiguousarray(center, dtype=np.float64)
+        out = np.empty((d, d))
+        check(self.lib.asmc_centered_gram(self._ctx, n, d, self._xdt(x), _dptr(x), _f64p(c), _f64p(out), self._stream),
+              "asmc_centered_gram")
+        return out
+
+    def pcn_mutate(self, x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed, gid0, rho, n_steps, step0=0,
+                   target_accept=0.234, adapt=True):
+        """n_steps fused pCN steps in place.  Returns (n_accept[n_steps], rho_hist[n_steps], rho_out)."""
+        self._chk3(ll, lp, lq)
+        n, d = x.shape
+        prm = AsmcPcnParams(d, self._xdt(x), beta, mu.data_ptr(), L.data_ptr(), Linv.data_ptr(), t_ll.c_struct(),
+                            t_lp.c_struct(), t_lq.c_struct(), seed, gid0, target_accept, int(adapt), 0)
+        n_acc = np.zeros(n_steps, dtype=np.int64)
+        rho_hist = np.zeros(n_steps)
+        rho_io = ctypes.c_double(rho)
+        check(self.lib.asmc_pcn_mutate(self._ctx, n, _dptr(x), _dptr(ll), _dptr(lp), _dptr(lq), ctypes.byref(prm),
+                                       n_steps, step0, ctypes.byref(rho_io),
+                                       n_acc.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _f64p(rho_hist),
+                                       self._stream), "asmc_pcn_mutate")
+        return n_acc, rho_hist, rho_io.value
+
+    def pcn_propose(self, x, mu, L, Linv, rho, seed, gid0, step):
+        n, d = x.shape
+        xp = torch.empty_like(x)
+        q0, q1 = self.empty(n), self.empty(n)
+        check(self.lib.asmc_pcn_propose(self._ctx, n, d, self._xdt(x), _dptr(x), _dptr(xp), _dptr(q0), _dptr(q1),
+                                        _dptr(mu), _dptr(L), _dptr(Linv), rho, seed, gid0, step, self._stream),
+              "asmc_pcn_propose")
+        return xp, q0, q1
+
+    def pcn_accept(self, x, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0, step,
+                   logj_old=None, logj_new=None) -> int:
+        n, d = x.shape
+        nacc = ctypes.c_int64(0)
+        check(self.lib.asmc_pcn_accept(self._ctx, n, d, self._xdt(x), _dptr(x), _dptr(x_prop), _dptr(ll), _dptr(lp),
+                                       _dptr(lq), _dptr(ll_new), _dptr(lp_new), _dptr(lq_new), _dptr(logj_old),
+                                       _dptr(logj_new), _dptr(q0), _dptr(q1), beta, seed, gid0, step,
+                                       ctypes.byref(nacc), self._stream), "asmc_pcn_accept")
+        return int(nacc.value)

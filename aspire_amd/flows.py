@@ -1,0 +1,259 @@
+"""Proposal flows behind the reference's `Flow` interface (src/aspire/flows/base.py:11-98).
+
+`GaussianFlow`  — analytic diagonal-Gaussian proposal; sampling and log-density run in HIP kernels
+                  (asmc_gaussian_draw / asmc_mixture_logpdf) and it exposes `device_mixture()` so the
+                  pCN kernel can evaluate log_q in-register (fused path).
+`CouplingFlow`  — RealNVP-style affine coupling flow in PyTorch-ROCm (the north-star's "PyTorch only
+                  for the flow forward/inverse pass"): stands in for the reference's zuko MAF
+                  (src/aspire/flows/torch/flows.py:113-444; zuko is absent from this image, so the
+                  flow arithmetic is this repository's own — parity unpinned).
+"""
+from __future__ import annotations
+
+import logging
+import math
+
+import numpy as np
+import torch
+
+from .history import FlowHistory
+
+logger = logging.getLogger(__name__)
+
+
+class Flow:
+    """flows/base.py:11-98: the interface the samplers rely on."""
+
+    xp = None
+
+    def __init__(self, dims: int, device=None, data_transform=None):
+        self.dims = dims
+        self.device = device
+        self.data_transform = data_transform
+
+    def log_prob(self, x):
+        raise NotImplementedError
+
+    def sample(self, n_samples):
+        return self.sample_and_log_prob(n_samples)[0]
+
+    def sample_and_log_prob(self, n_samples):
+        raise NotImplementedError
+
+    def fit(self, samples, **kwargs) -> FlowHistory:
+        raise NotImplementedError
+
+    def config_dict(self):
+        return getattr(self, "_init_args", {})
+
+
+class GaussianFlow(Flow):
+    """q(x) = N(mu, diag sigma^2), device resident."""
+
+    xp = torch
+
+    def __init__(self, dims: int, mu=0.0, sigma=1.0, seed: int = 1234, device=None, dtype=torch.float64,
+                 engine=None, data_transform=None):
+        super().__init__(dims, device=device, data_transform=data_transform)
+        self.mu = np.broadcast_to(np.asarray(mu, dtype=np.float64), (dims,)).copy()
+        self.sigma = np.broadcast_to(np.asarray(sigma, dtype=np.float64), (dims,)).copy()
+        self.seed = int(seed)
+        self.dtype = dtype if isinstance(dtype, torch.dtype) else {"float32": torch.float32, "float64": torch.float64}[np.dtype(dtype).name]
+        self.engine = engine
+        self.gid0 = 0  # global index of this rank's first particle (sharded runs)
+        self._draws = 0
+        self._dev = None
+
+    def _eng(self):
+        if self.engine is None:
+            from .samples import get_default_engine
+
+            self.engine = get_default_engine()
+        return self.engine
+
+    def _device_params(self):
+        e = self._eng()
+        if self._dev is None or self._dev[0] is not e:
+            logw = -np.sum(np.log(self.sigma)) - 0.5 * self.dims * math.log(2 * math.pi)
+            self._dev = (e, e.asarray(self.mu), e.asarray(self.sigma),
+                         e.make_mixture([logw], self.mu[None], (1.0 / self.sigma**2)[None]))
+        return self._dev
+
+    def device_mixture(self, engine=None):
+        if engine is not None:
+            self.engine = engine
+        return self._device_params()[3]
+
+    def fit(self, samples, **kwargs) -> FlowHistory:
+        """Moment-match the diagonal Gaussian to the training samples (closed form)."""
+        x = np.asarray(samples.detach().cpu() if isinstance(samples, torch.Tensor) else samples, dtype=np.float64)
+        self.mu = x.mean(axis=0)
+        self.sigma = x.std(axis=0, ddof=1)
+        self._dev = None
+        return FlowHistory()
+
+    def sample_and_log_prob(self, n_samples: int):
+        e, mu, sigma, mix = self._device_params()
+        x, _ = e.gaussian_draw(n_samples, self.dims, self.dtype, mu, sigma, self.seed, self.gid0, self._draws,
+                               want_lq=False)
+        self._draws += 1
+        return x, e.mixture_logpdf(x, mix)
+
+    def log_prob(self, x):
+        e, _, _, mix = self._device_params()
+        xt = e.asarray(x, dtype=x.dtype if isinstance(x, torch.Tensor) and x.dtype in (torch.float32, torch.float64) else torch.float64)
+        return e.mixture_logpdf(xt, mix)
+
+
+class _Coupling(torch.nn.Module):
+    def __init__(self, dims, mask, hidden):
+        super().__init__()
+        self.register_buffer("mask", mask)
+        n_in = int(mask.sum().item())
+        n_out = dims - n_in
+        layers, last = [], n_in
+        for h in hidden:
+            layers += [torch.nn.Linear(last, h), torch.nn.ReLU()]
+            last = h
+        layers.append(torch.nn.Linear(last, 2 * n_out))
+        self.net = torch.nn.Sequential(*layers)
+        torch.nn.init.zeros_(self.net[-1].weight)
+        torch.nn.init.zeros_(self.net[-1].bias)
+        self.n_out = n_out
+
+    def _st(self, x):
+        h = self.net(x[:, self.mask])
+        s, t = h[:, : self.n_out], h[:, self.n_out:]
+        return 2.0 * torch.tanh(s / 2.0), t  # bounded log-scale
+
+    def forward(self, x):  # data -> latent
+        s, t = self._st(x)
+        z = x.clone()
+        z[:, ~self.mask] = (x[:, ~self.mask] - t) * torch.exp(-s)
+        return z, -s.sum(-1)
+
+    def inverse(self, z):  # latent -> data
+        s, t = self._st(z)
+        x = z.clone()
+        x[:, ~self.mask] = z[:, ~self.mask] * torch.exp(s) + t
+        return x, s.sum(-1)
+
+
+class CouplingFlow(Flow):
+    """RealNVP affine-coupling flow (alternating half masks, MLP conditioners) in PyTorch.
+
+    Interface mirrors ZukoFlow (flows/torch/flows.py:113-444): fit / sample_and_log_prob / log_prob /
+    forward / inverse.  Dense layers run on hipBLASLt (MFMA) through torch; everything else in the
+    SMC step stays in the HIP kernels.
+    """
+
+    xp = torch
+
+    def __init__(self, dims: int, n_layers: int = 4, hidden_features=(64, 64), seed: int = 1234, device=None,
+                 dtype=torch.float32, data_transform=None):
+        super().__init__(dims, device=torch.device(device or "cpu"), data_transform=data_transform)
+        self.dtype = dtype
+        torch.manual_seed(seed)
+        half = torch.arange(dims) < (dims + 1) // 2
+        masks = [half if i % 2 == 0 else ~half for i in range(n_layers)]
+        if dims == 1:
+            raise ValueError("CouplingFlow needs dims >= 2")
+        self.layers = torch.nn.ModuleList([_Coupling(dims, m, tuple(map(int, hidden_features))) for m in masks])
+        self.layers.to(device=self.device, dtype=dtype)
+        self.loc = torch.zeros(dims, device=self.device, dtype=dtype)
+        self.scale = torch.ones(dims, device=self.device, dtype=dtype)
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(seed)
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self.layers.to(self.device)
+        self.loc, self.scale = self.loc.to(self.device), self.scale.to(self.device)
+        g = torch.Generator(device=self.device)
+        g.manual_seed(self._gen.initial_seed())
+        self._gen = g
+        return self
+
+    def _to_latent(self, x):
+        z = (x - self.loc) / self.scale
+        ladj = -torch.log(self.scale).sum().expand(x.shape[0]).clone()
+        for layer in self.layers:
+            z, l = layer(z)
+            ladj = ladj + l
+        return z, ladj
+
+    def _from_latent(self, z):
+        x = z
+        ladj = torch.zeros(z.shape[0], device=z.device, dtype=z.dtype)
+        for layer in reversed(self.layers):
+            x, l = layer.inverse(x)
+            ladj = ladj + l
+        return x * self.scale + self.loc, ladj + torch.log(self.scale).sum()
+
+    def _base_logp(self, z):
+        return -0.5 * (z * z).sum(-1) - 0.5 * self.dims * math.log(2 * math.pi)
+
+    def fit(self, samples, n_epochs: int = 100, lr_annealing: bool = False, patience: int = 20, batch_size: int = 500,
+            validation_fraction: float = 0.2, lr: float = 1e-3, clip_grad: float | None = None, **kwargs) -> FlowHistory:
+        """Maximum-likelihood training, same knobs as ZukoFlow.fit (flows/torch/flows.py:170-325)."""
+        x = torch.as_tensor(np.asarray(samples.detach().cpu() if isinstance(samples, torch.Tensor) else samples),
+                            dtype=self.dtype, device=self.device)
+        self.loc, self.scale = x.mean(0), x.std(0).clamp_min(1e-6)
+        n = x.shape[0]
+        perm = torch.randperm(n, generator=torch.Generator().manual_seed(0)).to(self.device)
+        n_val = int(n * validation_fraction)
+        xv, xt = x[perm[:n_val]], x[perm[n_val:]]
+        opt = torch.optim.Adam(self.layers.parameters(), lr=lr)
+        hist = FlowHistory()
+        best, best_state, bad = float("inf"), None, 0
+        for _ in range(n_epochs):
+            self.layers.train()
+            order = torch.randperm(xt.shape[0], device=self.device)
+            tot = 0.0
+            for i in range(0, xt.shape[0], batch_size):
+                xb = xt[order[i:i + batch_size]]
+                z, ladj = self._to_latent(xb)
+                loss = -(self._base_logp(z) + ladj).mean()
+                opt.zero_grad()
+                loss.backward()
+                if clip_grad is not None:
+                    torch.nn.utils.clip_grad_norm_(self.layers.parameters(), clip_grad)
+                opt.step()
+                tot += float(loss) * xb.shape[0]
+            hist.training_loss.append(tot / max(1, xt.shape[0]))
+            if n_val:
+                with torch.no_grad():
+                    z, ladj = self._to_latent(xv)
+                    vl = float(-(self._base_logp(z) + ladj).mean())
+                hist.validation_loss.append(vl)
+                if vl < best:
+                    best, bad = vl, 0
+                    best_state = {k: v.detach().clone() for k, v in self.layers.state_dict().items()}
+                else:
+                    bad += 1
+                    if bad >= patience:
+                        break
+        if best_state is not None:
+            self.layers.load_state_dict(best_state)
+        self.layers.eval()
+        return hist
+
+    @torch.no_grad()
+    def sample_and_log_prob(self, n_samples: int, xp=None):
+        z = torch.randn((n_samples, self.dims), device=self.device, dtype=self.dtype, generator=self._gen)
+        x, ladj = self._from_latent(z)
+        return x, self._base_logp(z) - ladj
+
+    @torch.no_grad()
+    def log_prob(self, x, xp=None):
+        x = torch.as_tensor(x, dtype=self.dtype, device=self.device)
+        z, ladj = self._to_latent(x)
+        return self._base_logp(z) + ladj
+
+    @torch.no_grad()
+    def forward(self, x, xp=None):
+        return self._to_latent(torch.as_tensor(x, dtype=self.dtype, device=self.device))
+
+    @torch.no_grad()
+    def inverse(self, z, xp=None):
+        return self._from_latent(torch.as_tensor(z, dtype=self.dtype, device=self.device))

@@ -1,0 +1,423 @@
+"""Particle containers with the reference's API surface (src/aspire/samples.py).
+
+`BaseSamples` / `Samples` / `SMCSamples` keep the reference's field names, constructor arguments
+and method names (samples.py:36-595, :1208-1332).  The difference is WHERE the per-particle
+arithmetic runs: every SMC method (`log_weights`, `log_evidence_ratio`, `..._variance`, `resample`)
+is executed by the engine — the HIP kernels of libasmc_hip.so — on device-resident tensors, and only
+scalars come back to the host.  Without a HIP device these methods raise (no CPU fallback); tests
+inject the oracle-backed test double through the `engine` field.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from dataclasses import dataclass, field, fields
+from typing import Any, Callable
+
+import numpy as np
+import torch
+
+from . import smc_math
+from ._xp import asarray, default_dtype, is_torch, is_torch_namespace, namespace_of, resolve_dtype, to_numpy
+from .comm import Comm
+
+logger = logging.getLogger(__name__)
+
+_default_engine = None
+
+
+def get_default_engine():
+    """Process-wide HipEngine on the current device (created on first use; raises without a GPU)."""
+    global _default_engine
+    if _default_engine is None:
+        from .engine import HipEngine
+
+        _default_engine = HipEngine(torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return _default_engine
+
+
+def set_default_engine(engine) -> None:
+    global _default_engine
+    _default_engine = engine
+
+
+@dataclass
+class BaseSamples:
+    """samples.py:36-413 (the parts the SMC path touches)."""
+
+    x: Any
+    log_likelihood: Any | None = None
+    log_prior: Any | None = None
+    log_q: Any | None = None
+    parameters: list[str] | None = None
+    dtype: Any | str | None = None
+    xp: Callable | None = None
+    device: Any = None
+
+    def __post_init__(self):
+        if self.xp is None:
+            self.xp = namespace_of(self.x)
+        if self.dtype is not None:
+            self.dtype = resolve_dtype(self.dtype, self.xp)
+        elif hasattr(self.x, "dtype") and self._is_float(self.x):
+            self.dtype = resolve_dtype(self.x.dtype, self.xp)  # keep the precision the caller handed over
+        else:
+            self.dtype = default_dtype(self.xp)
+        if self.device is None and is_torch(self.x):
+            self.device = self.x.device
+        self.x = self.array_to_namespace(self.x, dtype=self.dtype)
+        if self.log_likelihood is not None:
+            self.log_likelihood = self.array_to_namespace(self.log_likelihood, dtype=self._scalar_dtype())
+        if self.log_prior is not None:
+            self.log_prior = self.array_to_namespace(self.log_prior, dtype=self._scalar_dtype())
+        if self.log_q is not None:
+            self.log_q = self.array_to_namespace(self.log_q, dtype=self._scalar_dtype())
+        if self.parameters is None:
+            self.parameters = [f"x_{i}" for i in range(self.dims)]
+
+    @staticmethod
+    def _is_float(a) -> bool:
+        dt = a.dtype
+        return dt in (torch.float32, torch.float64) if isinstance(dt, torch.dtype) else np.issubdtype(dt, np.floating)
+
+    def _scalar_dtype(self):
+        """dtype of the per-particle scalars.  Device-resident (torch) state keeps log-probabilities
+        in fp64 whatever the x dtype; host (numpy) containers follow the reference and
+        use the sample dtype (samples.py:83-92)."""
+        if is_torch_namespace(self.xp):
+            return torch.float64
+        return self.dtype
+
+    @property
+    def dims(self):
+        if self.x is None:
+            return 0
+        return self.x.shape[1] if self.x.ndim > 1 else 1
+
+    def array_to_namespace(self, x, dtype=None):
+        return asarray(x, self.xp, dtype=dtype, device=self.device)
+
+    def to_numpy(self, dtype: Any | str | None = None):
+        return self.__class__(
+            x=to_numpy(self.x),
+            parameters=self.parameters,
+            log_likelihood=None if self.log_likelihood is None else to_numpy(self.log_likelihood),
+            log_prior=None if self.log_prior is None else to_numpy(self.log_prior),
+            log_q=None if self.log_q is None else to_numpy(self.log_q),
+            xp=np,
+        )
+
+    def to_namespace(self, xp, dtype: Any | str | None = None):
+        return self.__class__(
+            x=self.x,
+            parameters=self.parameters,
+            log_likelihood=self.log_likelihood,
+            log_prior=self.log_prior,
+            log_q=self.log_q,
+            xp=xp,
+            device=self.device if is_torch_namespace(xp) else None,
+            dtype=dtype,
+        )
+
+    def to_dict(self, flat: bool = True, copy: bool = True):
+        out = {}
+        for f in fields(self):
+            if f.name in ("x", "xp", "engine", "comm"):
+                continue
+            out[f.name] = getattr(self, f.name)
+        out["xp"] = self.xp
+        samples = dict(zip(self.parameters, to_numpy(self.x).T))
+        if flat:
+            out.update(samples)
+        else:
+            out["samples"] = samples
+        return out
+
+    def __str__(self):
+        return f"No. samples: {len(self.x)}\nNo. parameters: {self.x.shape[-1]}\n"
+
+    def __len__(self):
+        return len(self.x)
+
+    def __getitem__(self, idx):
+        return self.__class__(
+            x=self.x[idx],
+            log_likelihood=self.log_likelihood[idx] if self.log_likelihood is not None else None,
+            log_prior=self.log_prior[idx] if self.log_prior is not None else None,
+            log_q=self.log_q[idx] if self.log_q is not None else None,
+            parameters=self.parameters,
+            dtype=self.dtype,
+        )
+
+    def __setitem__(self, idx, value):
+        raise NotImplementedError("Setting items is not supported")
+
+    @classmethod
+    def concatenate(cls, samples: list["BaseSamples"]):
+        if not samples:
+            raise ValueError("No samples to concatenate")
+        if not all(s.parameters == samples[0].parameters for s in samples):
+            raise ValueError("Parameters do not match")
+        if not all(s.xp == samples[0].xp for s in samples):
+            raise ValueError("Array namespaces do not match")
+        if not all(s.dtype == samples[0].dtype for s in samples):
+            raise ValueError("Dtypes do not match")
+        xp = samples[0].xp
+        cat = (lambda arrs: torch.cat(arrs, dim=0)) if is_torch_namespace(xp) else (lambda arrs: np.concatenate(arrs, axis=0))
+
+        def opt(name):
+            vals = [getattr(s, name) for s in samples]
+            return cat(vals) if all(v is not None for v in vals) else None
+
+        return cls(x=cat([s.x for s in samples]), log_likelihood=opt("log_likelihood"), log_prior=opt("log_prior"),
+                   log_q=opt("log_q"), parameters=samples[0].parameters, dtype=samples[0].dtype)
+
+    @classmethod
+    def from_samples(cls, samples: "BaseSamples", **kwargs):
+        xp = kwargs.pop("xp", samples.xp)
+        device = kwargs.pop("device", samples.device)
+        kwargs.pop("dtype", None)  # reference computes but never forwards it (samples.py:378-392)
+        return cls(x=samples.x, log_likelihood=samples.log_likelihood, log_prior=samples.log_prior,
+                   log_q=samples.log_q, parameters=samples.parameters, xp=xp, device=device,
+                   dtype=samples.dtype if is_torch_namespace(xp) == is_torch_namespace(samples.xp) else None, **kwargs)
+
+
+@dataclass
+class Samples(BaseSamples):
+    """samples.py:416-595.  Importance weights are computed when all three log-terms are given."""
+
+    log_w: Any = field(init=False)
+    weights: Any = field(init=False)
+    evidence: float = field(init=False)
+    evidence_error: float = field(init=False)
+    log_evidence: float | None = None
+    log_evidence_error: float | None = None
+    effective_sample_size: float = field(init=False)
+
+    def __post_init__(self):
+        super().__post_init__()
+        if all(v is not None for v in (self.log_likelihood, self.log_prior, self.log_q)):
+            self.compute_weights()
+        else:
+            self.log_w = None
+            self.weights = None
+            self.evidence = None
+            self.evidence_error = None
+            self.effective_sample_size = None
+
+    @property
+    def efficiency(self):
+        if self.log_w is None:
+            raise RuntimeError("Samples do not contain weights!")
+        return self.effective_sample_size / len(self.x)
+
+    def compute_weights(self):
+        """samples.py:457-475 — one-shot importance weights (not the SMC hot path; plain array ops)."""
+        xp = torch if is_torch_namespace(self.xp) else np
+
+        def lse(v):
+            c = v.max()
+            return c + xp.log(xp.exp(v - c).sum())
+
+        self.log_w = self.log_likelihood + self.log_prior - self.log_q
+        self.log_evidence = lse(self.log_w) - math.log(len(self.x))
+        self.weights = xp.exp(self.log_w)
+        self.evidence = xp.exp(self.log_evidence)
+        n = len(self.x)
+        self.evidence_error = xp.sqrt(((self.weights - self.evidence) ** 2).sum() / (n * (n - 1)))
+        self.log_evidence_error = abs(self.evidence_error / self.evidence)
+        log_w = self.log_w - self.log_w.max()
+        self.effective_sample_size = xp.exp(lse(log_w) * 2 - lse(log_w * 2))
+
+    @property
+    def scaled_weights(self):
+        xp = torch if is_torch_namespace(self.xp) else np
+        return xp.exp(self.log_w - self.log_w.max())
+
+    def __str__(self):
+        out = super().__str__()
+        if self.log_evidence is not None:
+            out += f"Log evidence: {float(self.log_evidence):.2f} +/- {float(self.log_evidence_error):.2f}\n"
+        if self.log_w is not None:
+            out += f"Effective sample size: {float(self.effective_sample_size):.1f}\nEfficiency: {float(self.efficiency):.2f}\n"
+        return out
+
+    def to_namespace(self, xp):
+        dev = self.device if is_torch_namespace(xp) else None
+        conv = lambda v: None if v is None else asarray(v, xp, device=dev)  # noqa: E731
+        return self.__class__(x=conv(self.x), parameters=self.parameters, log_likelihood=conv(self.log_likelihood),
+                              log_prior=conv(self.log_prior), log_q=conv(self.log_q), xp=xp,
+                              log_evidence=self.log_evidence, log_evidence_error=self.log_evidence_error)
+
+    def to_numpy(self):
+        conv = lambda v: None if v is None else to_numpy(v)  # noqa: E731
+        return self.__class__(x=to_numpy(self.x), parameters=self.parameters, log_likelihood=conv(self.log_likelihood),
+                              log_prior=conv(self.log_prior), log_q=conv(self.log_q),
+                              log_evidence=self.log_evidence, log_evidence_error=self.log_evidence_error)
+
+    def __getitem__(self, idx):
+        sliced = super().__getitem__(idx)
+        sliced.log_evidence = self.log_evidence
+        sliced.log_evidence_error = self.log_evidence_error
+        return sliced
+
+
+@dataclass
+class SMCSamples(BaseSamples):
+    """samples.py:1208-1332 — tempered particle population; the arithmetic runs in the engine."""
+
+    beta: float | None = None
+    log_evidence: float | None = None
+    log_evidence_error: float | None = None
+    engine: Any = field(default=None, repr=False, compare=False)
+    comm: Any = field(default=None, repr=False, compare=False)
+
+    # ---- engine plumbing ------------------------------------------------------------------
+    def _eng(self):
+        if self.engine is None:
+            self.engine = get_default_engine()
+        return self.engine
+
+    def _comm(self):
+        if self.comm is None:
+            self.comm = Comm()
+        return self.comm
+
+    def _dev3(self):
+        """(ll, lp, lq) as contiguous fp64 tensors on the engine's device."""
+        e = self._eng()
+        return tuple(e.asarray(v) for v in (self.log_likelihood, self.log_prior, self.log_q))
+
+    def _n_global(self) -> int:
+        return len(self.x) * self._comm().world
+
+    def _from_device(self, t):
+        if is_torch_namespace(self.xp):
+            return t
+        return to_numpy(t)
+
+    # ---- reference API --------------------------------------------------------------------
+    def log_p_t(self, beta):
+        """samples.py:1217-1219 (host-side convenience; the mutation kernel fuses this)."""
+        log_p_T = self.log_likelihood + self.log_prior
+        return (1 - beta) * self.log_q + beta * log_p_T
+
+    def _stats(self, beta: float) -> smc_math.Stats:
+        ll, lp, lq = self._dev3()
+        return smc_math.global_stats(self._eng(), self._comm(), ll, lp, lq, float(self.beta), [float(beta)],
+                                     self._n_global())[0]
+
+    def unnormalized_log_weights(self, beta: float):
+        """samples.py:1221-1224."""
+        ll, lp, lq = self._dev3()
+        return self._from_device(self._eng().log_weights(ll, lp, lq, float(self.beta), float(beta), 0.0))
+
+    def log_evidence_ratio(self, beta: float) -> float:
+        """samples.py:1226-1228."""
+        return smc_math.log_evidence_ratio(self._stats(beta))
+
+    def log_evidence_ratio_variance(self, beta: float) -> float:
+        """samples.py:1230-1242."""
+        ll, lp, lq = self._dev3()
+        st = self._stats(beta)
+        return smc_math.evidence_variance(self._eng(), self._comm(), ll, lp, lq, float(self.beta), float(beta), st)
+
+    def log_weights(self, beta: float):
+        """samples.py:1244-1249 (raises ValueError on NaN log-weights)."""
+        ll, lp, lq = self._dev3()
+        st = self._stats(beta)
+        shift = smc_math.log_evidence_ratio(st)
+        return self._from_device(self._eng().log_weights(ll, lp, lq, float(self.beta), float(beta), shift))
+
+    def effective_sample_size(self, beta: float) -> float:
+        """utils.py:510-512 of log_weights(beta) without materialising the weights."""
+        return smc_math.ess(self._stats(beta))
+
+    def resample(self, beta, n_samples: int | None = None, rng: np.random.Generator = None, *,
+                 resample_mode: str = "exact", resample_method: str = "multinomial") -> "SMCSamples":
+        """samples.py:1251-1287.  `resample_mode`: "exact" (sequential-order cdf == numpy cumsum,
+        bit-exact indices) or "fast"; `resample_method`: "multinomial" (reference) or the opt-in
+        "systematic" / "stratified"."""
+        if rng is None:
+            rng = np.random.default_rng()
+        comm = self._comm()
+        n_global = self._n_global()
+        if n_samples is None:
+            n_samples = n_global
+        uniform = False
+        if beta == self.beta:
+            if n_samples is None or n_samples == n_global:
+                logger.warning("Resampling with the same beta value, returning identical samples")
+                return self
+            uniform = True
+        e = self._eng()
+        ll, lp, lq = self._dev3()
+        x = e.asarray(self.x, dtype=self.x.dtype if is_torch(self.x) else torch.float64)
+        idx, _ = smc_math.resample_indices(e, comm, ll, lp, lq, float(self.beta), float(beta), int(n_samples), rng,
+                                           mode=resample_mode, method=resample_method, uniform_weights=uniform)
+        xo, llo, lpo, lqo = gather_global(e, comm, idx, x, ll, lp, lq)
+        return self.__class__(x=self._from_device(xo), log_likelihood=self._from_device(llo),
+                              log_prior=self._from_device(lpo), log_q=self._from_device(lqo), beta=beta,
+                              dtype=self.dtype, parameters=self.parameters, xp=self.xp, engine=self.engine,
+                              comm=self.comm)
+
+    def __str__(self):
+        out = super().__str__()
+        if self.log_evidence is not None:
+            out += f"Log evidence: {float(self.log_evidence):.2f}\n"
+        return out
+
+    def to_standard_samples(self):
+        """samples.py:1295-1305 — drops log_q on purpose, keeps the evidence."""
+        return Samples(x=self.x, log_likelihood=self.log_likelihood, log_prior=self.log_prior, xp=self.xp,
+                       parameters=self.parameters, log_evidence=self.log_evidence,
+                       log_evidence_error=self.log_evidence_error)
+
+    def to_numpy(self):
+        conv = lambda v: None if v is None else to_numpy(v)  # noqa: E731
+        return self.__class__(x=to_numpy(self.x), parameters=self.parameters, log_likelihood=conv(self.log_likelihood),
+                              log_prior=conv(self.log_prior), log_q=conv(self.log_q), beta=self.beta,
+                              log_evidence=self.log_evidence, log_evidence_error=self.log_evidence_error,
+                              engine=self.engine, comm=self.comm)
+
+    def __getitem__(self, idx):
+        sliced = super().__getitem__(idx)
+        sliced.beta = self.beta
+        sliced.log_evidence = self.log_evidence
+        sliced.log_evidence_error = self.log_evidence_error
+        sliced.engine, sliced.comm = self.engine, self.comm
+        return sliced
+
+
+def gather_global(engine, comm, idx, x, ll, lp, lq):
+    """Rows `idx` (GLOBAL indices) of the sharded population -> this rank's new shard.
+
+    World 1: one row-gather kernel (samples.py:1279-1287).  Sharded: requests are bucketed by owner
+    rank, exchanged with one all-to-all of the index lists, served by the owner's gather kernel and
+    returned with one all-to-all of rows; a final local gather restores the output order."""
+    if comm.world == 1:
+        return engine.gather(idx, x, ll, lp, lq)
+    n_local = x.shape[0]
+    d = x.shape[1]
+    owner = torch.div(idx, n_local, rounding_mode="floor")
+    order = torch.argsort(owner, stable=True)
+    send_idx = (idx - owner * n_local)[order].contiguous()
+    counts = torch.bincount(owner, minlength=comm.world).cpu().tolist()
+    all_counts = comm.all_gather_f64(np.array(counts, dtype=np.float64)).astype(np.int64)  # [world(src), world(dst owner)]
+    recv_counts = all_counts[:, comm.rank].tolist()  # how many rows each rank asks of me
+    req = comm.all_to_all_rows(send_idx, counts, recv_counts)
+    if req.numel() > 0:
+        rx, rll, rlp, rlq = engine.gather(req.contiguous(), x, ll, lp, lq)
+    else:
+        rx = x[:0]
+        rll = rlp = rlq = ll[:0]
+    packed = torch.empty((rx.shape[0], 3), dtype=torch.float64, device=rx.device)
+    if rx.shape[0] > 0:
+        packed[:, 0], packed[:, 1], packed[:, 2] = rll, rlp, rlq
+    got_x = comm.all_to_all_rows(rx.contiguous(), recv_counts, counts)
+    got_s = comm.all_to_all_rows(packed, recv_counts, counts)
+    # rows arrive grouped by owner in `order`; undo the permutation with a local gather
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel(), device=order.device)
+    return engine.gather(inv.contiguous(), got_x.contiguous(), got_s[:, 0].contiguous(), got_s[:, 1].contiguous(),
+                         got_s[:, 2].contiguous())

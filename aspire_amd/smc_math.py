@@ -1,0 +1,277 @@
+"""Host-side scalar logic of the SMC step, written against the engine + communicator interfaces.
+
+Everything per-particle happens in the engine (HIP kernels); this module only combines the
+reduction results with the reference's scalar arithmetic, in the reference's order, so that the
+beta schedule and evidence match it.  File:line citations are relative to the reference
+(mj-will/aspire).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+BISECT_LEVELS = 4  # candidate betas per pass = 2**4 - 1 = 15 (one k-ary bisection round)
+
+
+class BetaScheduleError(RuntimeError):
+    """Same name/meaning as reference smc/base.py:26."""
+
+
+@dataclass
+class Stats:
+    """Global reduction triple for one beta: m = max lw, S1 = sum e^(lw-m), S2 = sum e^(2(lw-m))."""
+
+    m: float
+    S1: float
+    S2: float
+    n: int  # global particle count
+
+
+def global_stats(engine, comm, ll, lp, lq, beta0: float, betas, n_global: int) -> list[Stats]:
+    """(m, S1, S2) for each candidate beta over the GLOBAL population.
+
+    Raises the reference's ValueError when a log-weight is NaN (samples.py:1246-1247).
+    Sharded: all-reduce(max) first, so every rank exponentiates against the same global maximum
+    (the reference's exp(x - x.max()), utils.py:253-255), then a rank-ordered sum of the partials.
+    """
+    betas = np.asarray(betas, dtype=np.float64)
+    if comm.world == 1:
+        st = engine.weights_stats(ll, lp, lq, beta0, betas)
+        n_nan = int(st[:, 3].max())
+        m, S1, S2 = st[:, 0], st[:, 1], st[:, 2]
+    else:
+        m_loc, n_nan_loc = engine.weights_max(ll, lp, lq, beta0, betas)
+        packed = comm.all_reduce_max_f64(np.concatenate([m_loc, [float(n_nan_loc)]]))
+        m, n_nan = packed[:-1], int(packed[-1])
+        sums = engine.weights_sums(ll, lp, lq, beta0, betas, m)
+        allsums = comm.all_gather_f64(sums)  # [world, K, 2]
+        tot = allsums[0].copy()
+        for r in range(1, comm.world):  # rank order => identical on every rank
+            tot = tot + allsums[r]
+        S1, S2 = tot[:, 0], tot[:, 1]
+    if n_nan > 0:
+        raise ValueError(f"Log weights contain NaN values for beta={betas[0] if betas.size == 1 else betas}")
+    return [Stats(float(m[k]), float(S1[k]), float(S2[k]), n_global) for k in range(betas.size)]
+
+
+def log_evidence_ratio(st: Stats) -> float:
+    """samples.py:1226-1228: logsumexp(log_w) - log(N); logsumexp = c + log(sum(exp(x - c)))."""
+    return float((st.m + np.log(st.S1)) - math.log(st.n))
+
+
+def ess(st: Stats) -> float:
+    """utils.py:510-512 applied to samples.py:1244-1249's shifted log-weights.
+
+    log_weights = lw + (LSE(lw) - log N) =: lw + c, so max = m + c and the two log-sum-exps are
+    (m + c) + log S1 and 2 (m + c) + log S2; ESS = exp(2 LSE(lw') - LSE(2 lw')).
+    """
+    with np.errstate(all="ignore"):
+        c = (st.m + np.log(st.S1)) - math.log(st.n)
+        mp = st.m + c
+        l1 = mp + np.log(st.S1)
+        l2 = mp * 2.0 + np.log(st.S2)
+        return float(np.exp(l1 * 2.0 - l2))
+
+
+def evidence_variance(engine, comm, ll, lp, lq, beta0: float, beta: float, st: Stats) -> float:
+    """samples.py:1230-1242: u = exp(lw - max); var(u) / (N mean(u)^2), population variance."""
+    mean_u = st.S1 / st.n
+    m2 = engine.weights_m2(ll, lp, lq, beta0, beta, st.m, mean_u)
+    if comm.world > 1:
+        parts = comm.all_gather_f64(np.array([m2]))
+        m2 = float(parts[0, 0])
+        for r in range(1, comm.world):
+            m2 = m2 + float(parts[r, 0])
+    var_u = m2 / st.n
+    if mean_u != 0:
+        return float(var_u / (st.n * (mean_u**2)))
+    return float("nan")
+
+
+def current_target_efficiency(target, rate: float, beta: float) -> float:
+    """smc/base.py:114-121."""
+    if isinstance(target, tuple):
+        return target[0] + (target[1] - target[0]) * (beta**rate)
+    return target
+
+
+def validate_target_efficiency(value):
+    """smc/base.py:84-112 (same messages)."""
+    if isinstance(value, float):
+        if not (0 < value < 1):
+            raise ValueError("target_efficiency must be in (0, 1)")
+        return value
+    if len(value) != 2:
+        raise ValueError("target_efficiency must be a float or tuple of two floats")
+    value = tuple(map(float, value))
+    if not (0 < value[0] < value[1] < 1):
+        raise ValueError("target_efficiency tuple must be in (0, 1) and increasing")
+    return value
+
+
+def _bisection_tree(lo: float, hi: float, levels: int):
+    """Heap-ordered midpoints of the next `levels` bisection steps from (lo, hi).
+
+    node i: interval (lo_i, hi_i), mid_i = 0.5*(hi_i + lo_i) (the reference's expression,
+    smc/base.py:178); child 2i+1 is taken when eff < target (hi <- mid), child 2i+2 when
+    eff >= target (lo <- mid).  The values are exactly those the sequential loop would visit.
+    """
+    n_nodes = (1 << levels) - 1
+    los, his, mids = [0.0] * n_nodes, [0.0] * n_nodes, [0.0] * n_nodes
+    los[0], his[0] = lo, hi
+    for i in range(n_nodes):
+        mids[i] = 0.5 * (his[i] + los[i])
+        l, r = 2 * i + 1, 2 * i + 2
+        if r < n_nodes:
+            los[l], his[l] = los[i], mids[i]
+            los[r], his[r] = mids[i], his[i]
+    return mids
+
+
+def determine_beta(eff_fn, beta: float, *, adaptive: bool, beta_step: float, min_beta_step: float,
+                   max_beta_step: float, beta_tolerance: float, adaptive_min_beta_step: bool, target,
+                   rate: float, levels: int = BISECT_LEVELS, logger=None):
+    """smc/base.py:123-213.  `eff_fn(betas) -> list[float]` returns ESS/N for candidate betas
+    (one device pass per call).  Returns (beta, min_beta_step, n_passes)."""
+    n_pass = 0
+    if not adaptive:
+        beta += beta_step
+        if beta >= 1.0:
+            beta = 1.0
+        return beta, min_beta_step, n_pass
+    beta_prev = beta
+    beta_min = beta_prev
+    beta_max = 1.0
+    eff_beta_max = eff_fn([beta_max])[0]
+    n_pass += 1
+    current_eff = current_target_efficiency(target, rate, beta_prev)
+    if eff_beta_max >= current_eff:
+        beta_min = 1.0
+    target_eff = current_eff
+    while beta_max - beta_min > beta_tolerance:
+        mids = _bisection_tree(beta_min, beta_max, levels)
+        effs = eff_fn(mids)
+        n_pass += 1
+        i = 0
+        for _ in range(levels):
+            if not (beta_max - beta_min > beta_tolerance):
+                break
+            beta_try = mids[i]  # == 0.5 * (beta_max + beta_min)
+            if effs[i] >= target_eff:
+                beta_min = beta_try
+                i = 2 * i + 2
+            else:
+                beta_max = beta_try
+                i = 2 * i + 1
+    beta_star = beta_min
+    if beta_star <= beta_prev + beta_tolerance and beta_prev < 1.0 and logger is not None:
+        logger.warning(
+            "Adaptive beta search could not find a beta above %.6g that satisfies the target "
+            "efficiency %.3f within tolerance %.1e; beta may remain unchanged. Consider decreasing "
+            "beta_tolerance or target_efficiency.", beta_prev, target_eff, beta_tolerance)
+    if adaptive_min_beta_step:
+        min_beta_step = min_beta_step * (1 - beta_prev) / (1 - beta_star)
+    beta = max(beta_star, beta_prev + min_beta_step)
+    beta = min(beta, beta_prev + max_beta_step, 1.0)
+    if beta == beta_prev:
+        raise BetaScheduleError(
+            f"Beta did not increase from previous value {beta:.6g}. "
+            "Adaptive beta search may have failed to find a suitable beta. "
+            f"Consider adjusting beta_tolerance ({beta_tolerance}), "
+            f"min_beta_step ({min_beta_step}) or "
+            f"target_efficiency ({target_eff}) "
+            "(values may be adaptive).")
+    return beta, min_beta_step, n_pass
+
+
+def pcg64_state(rng):
+    """{state_hi, state_lo, inc_hi, inc_lo} of a numpy Generator if it is PCG64-backed, else None."""
+    bg = getattr(rng, "bit_generator", None)
+    st = getattr(bg, "state", None)
+    if not isinstance(st, dict) or st.get("bit_generator") != "PCG64":
+        return None
+    s, inc = st["state"]["state"], st["state"]["inc"]
+    m = (1 << 64) - 1
+    return np.array([s >> 64, s & m, inc >> 64, inc & m], dtype=np.uint64)
+
+
+def draw_uniforms(engine, rng, n_total: int, j0: int, n_local: int, method: str = "multinomial"):
+    """The uniforms Generator.choice would draw (samples.py:1278 -> `random(n)`), slots [j0, j0+n_local).
+
+    PCG64 generators are continued ON DEVICE through LCG jump-ahead and the host generator is then
+    advanced by the same number of draws, so its state afterwards equals the reference's.  Any other
+    generator draws on the host and uploads.  systematic / stratified are opt-in extras with no
+    reference counterpart."""
+    if method == "multinomial":
+        st = pcg64_state(rng)
+        if st is not None and hasattr(engine, "uniforms_pcg64"):
+            u = engine.uniforms_pcg64(st, j0, n_local) if n_local > 0 else engine.empty(0)
+            rng.bit_generator.advance(n_total)
+            return u
+        u_all = rng.random(n_total)
+        return engine.asarray(u_all[j0:j0 + n_local])
+    if method == "systematic":
+        u0 = float(rng.random())
+        return engine.systematic_uniforms(n_local, j0, n_total, u0, None)
+    if method == "stratified":
+        v = rng.random(n_total)
+        return engine.systematic_uniforms(n_local, j0, n_total, 0.0, engine.asarray(v[j0:j0 + n_local]))
+    raise ValueError(f"Unknown resample_method: {method}")
+
+
+def resample_indices(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out: int, rng, *, mode: str = "exact",
+                     method: str = "multinomial", uniform_weights: bool = False):
+    """Global ancestor indices for this rank's output slots (samples.py:1276-1278).
+
+    w = exp(log_w - logsumexp(log_w)) with log_w = log_weights(beta);
+    idx = rng.choice(N, size=n_out, replace=True, p=w)
+        = searchsorted(cumsum(w)/cumsum(w)[-1], random(n_out), side="right").
+    Returns (idx tensor [n_out_local] of GLOBAL indices, j0)."""
+    n_local = ll.numel()
+    n_global = n_local * comm.world
+    if uniform_weights:
+        # samples.py:1273-1274: log_w = zeros -> w = exp(0 - logsumexp(zeros)) = exp(0 - log N)
+        lse = float(0.0 + np.log(np.float64(n_global)))
+        w = engine.full(n_local, float(np.exp(0.0 - lse)))
+    else:
+        st = global_stats(engine, comm, ll, lp, lq, beta0, [beta], n_global)[0]
+        shift = float((st.m + np.log(st.S1)) - math.log(n_global))  # log_weights adds the log-ratio
+        mp = st.m + shift
+        # second log-sum-exp, over the shifted log-weights (samples.py:1277)
+        if comm.world == 1:
+            s1p = engine.weights_sums(ll, lp, lq, beta0, [beta], [mp], [shift])[0, 0]
+        else:
+            parts = comm.all_gather_f64(engine.weights_sums(ll, lp, lq, beta0, [beta], [mp], [shift]))
+            s1p = parts[0][0, 0]
+            for r in range(1, comm.world):
+                s1p = s1p + parts[r][0, 0]
+        lse = float(mp + np.log(s1p))
+        w = engine.normalized_weights(ll, lp, lq, beta0, beta, shift, lse)
+    # cumulative sum in global order: exact mode chains the running sum rank to rank
+    if comm.world == 1:
+        cdf, last = engine.cdf(w, mode, 0.0)
+    elif mode == "exact":
+        carry = comm.chain_recv()
+        cdf, total = engine.cdf(w, mode, 0.0 if carry is None else carry)
+        comm.chain_send(total)
+        last = comm.broadcast_f64(total, comm.world - 1)
+    else:
+        _, mass = engine.cdf(w, mode, 0.0)
+        masses = comm.all_gather_f64(np.array([mass]))[:, 0]
+        carry = 0.0
+        for r in range(comm.rank):
+            carry = carry + masses[r]
+        cdf, total = engine.cdf(w, mode, carry)
+        last = comm.broadcast_f64(total, comm.world - 1)
+    engine.cdf_normalize(cdf, last)
+    if comm.world > 1:
+        cdf = comm.all_gather_tensor(cdf)
+    # this rank's output slots
+    per = -(-n_out // comm.world)
+    j0 = min(comm.rank * per, n_out)
+    j1 = min(j0 + per, n_out)
+    u = draw_uniforms(engine, rng, n_out, j0, j1 - j0, method)
+    idx = engine.search(cdf, u)
+    return idx, j0

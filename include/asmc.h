@@ -1,0 +1,215 @@
+/*
+ * asmc.h — C ABI of libasmc_hip.so: aspire's SMC particle-batch hot path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  The reference (mj-will/aspire) is pure Python;
+ * the interfaces replaced are numpy/array-API expressions inside
+ *   src/aspire/samples.py          SMCSamples (weights, evidence, resample)
+ *   src/aspire/utils.py            logsumexp, effective_sample_size
+ *   src/aspire/samplers/smc/base.py  determine_beta / sample loop / log_prob
+ *   src/aspire/samplers/smc/minipcn.py  mutate (third-party minipcn kernel)
+ *   src/aspire/samplers/mcmc.py    draw_initial_samples
+ * Each entry point below cites the reference file:line (relative to the reference root) it
+ * replaces.  A maintainer binds these with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns int: 0 = ASMC_OK, <0 = error (asmc_last_error() has the text);
+ *     no C++ exception crosses the ABI; NaN detection is returned as a count so the host can
+ *     raise the reference's exception types.
+ *   - pointers named *_dev are device (HBM) pointers owned by the caller; *_host are host
+ *     pointers.  The library never frees caller memory and allocates nothing after
+ *     asmc_ctx_create (scratch lives in the ctx).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls that return
+ *     host scalars synchronise that stream; all others only enqueue.
+ *   - particle state layout: x row-major [N, d] (particle-major; fp64 or fp32, `x_dtype`),
+ *     log_likelihood / log_prior / log_q as three fp64 vectors [N].
+ *   - a ctx is bound to one device and one host thread.
+ */
+#ifndef ASMC_H
+#define ASMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASMC_ABI_VERSION 1
+
+#define ASMC_OK 0
+#define ASMC_ERR_ARG (-1)
+#define ASMC_ERR_HIP (-2)
+#define ASMC_ERR_NOMEM (-3)
+#define ASMC_ERR_UNSUPPORTED (-4)
+
+#define ASMC_F64 0
+#define ASMC_F32 1
+
+#define ASMC_MAX_BETAS 32      /* candidate betas evaluated per pass */
+#define ASMC_MAX_COMPONENTS 8  /* mixture components of a built-in density */
+#define ASMC_MAX_DIMS 256
+
+#define ASMC_CDF_EXACT 0 /* sequential-order fp64 rounding == numpy cumsum (bit-exact) */
+#define ASMC_CDF_FAST 1  /* parallel-order rounding */
+
+typedef struct asmc_ctx asmc_ctx;
+typedef void* asmc_stream;
+
+/* Built-in log-density: diagonal Gaussian mixture
+ *   log sum_c exp(logw[c] - 0.5 * sum_j (x_j - mu[c,j])^2 * prec[c,j]),  logw includes constants.
+ * All pointers are DEVICE pointers (fp64). */
+typedef struct {
+    int32_t n_components;
+    int32_t reserved;
+    const double* logw_dev; /* [C] */
+    const double* mu_dev;   /* [C, d] */
+    const double* prec_dev; /* [C, d] */
+} asmc_mixture;
+
+/* Parameters of the fused pCN mutation (this repository's pCN specification, DESIGN.md §pCN;
+ * replaces minipcn.Sampler(...).sample(z, n_steps) at reference samplers/smc/minipcn.py:97-114
+ * and the tempered target of samplers/smc/base.py:507-519 + samples.py:1217-1219). */
+typedef struct {
+    int32_t d;
+    int32_t x_dtype;          /* ASMC_F64 | ASMC_F32 */
+    double beta;              /* inverse temperature of the tempered target */
+    const double* mu_dev;     /* [d] reference-Gaussian mean */
+    const double* L_dev;      /* [d,d] row-major lower Cholesky factor of the covariance */
+    const double* Linv_dev;   /* [d,d] row-major inverse of L */
+    asmc_mixture log_likelihood;
+    asmc_mixture log_prior;
+    asmc_mixture log_q;
+    uint64_t seed;            /* Philox key */
+    uint64_t gid0;            /* global index of local particle 0 (sharded runs) */
+    double target_accept;     /* e.g. 0.234 (reference minipcn.py:47) */
+    int32_t adapt;            /* 1: Robbins-Monro step-size adaptation on device */
+    int32_t reserved;
+} asmc_pcn_params;
+
+/* ---- library / context ---------------------------------------------------------------- */
+int asmc_abi_version(void);
+const char* asmc_last_error(void); /* thread-local */
+int asmc_device_count(int* n_out);
+int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max);
+int asmc_ctx_destroy(asmc_ctx* ctx);
+
+/* ---- weighting / ESS / evidence (reference samples.py:1221-1249, utils.py:248-255,510-512) ---
+ * Unnormalised tempered log-weight, exactly the reference association (samples.py:1222-1224):
+ *     lw_i(beta) = (beta0 - beta) * lq_i + (beta - beta0) * (ll_i + lp_i)
+ * evaluated for K candidate betas in one pass over (ll, lp, lq).
+ *
+ * asmc_weights_max : m_k = max_i lw_i(beta_k); n_nan = #NaN log-weights over all k (reference
+ *                    raises ValueError when > 0, samples.py:1246-1247).
+ * asmc_weights_sums: S1_k = sum_i exp(t), S2_k = sum_i exp(t)^2, t = (lw_i(beta_k) + shift_k) - m_k.
+ *                    out_host = {S1_0, S2_0, S1_1, S2_1, ...}.  shift_host may be NULL (zeros).
+ * asmc_weights_stats: both passes back-to-back, out_host[k*4..] = {m, S1, S2, n_nan}.
+ * From these the host forms logsumexp = m + log S1 (utils.py:248-255), the ESS
+ * exp(2*LSE(lw) - LSE(2 lw)) (utils.py:510-512) and the evidence ratio (samples.py:1226-1228).
+ * asmc_weights_m2  : sum_i (exp(lw_i - m) - mean_u)^2, the numerator of the population variance in
+ *                    log_evidence_ratio_variance (samples.py:1230-1242). */
+int asmc_weights_max(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
+                     const double* lq_dev, double beta0, const double* betas_host, int K,
+                     double* m_host, int64_t* n_nan_host, asmc_stream stream);
+int asmc_weights_sums(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
+                      const double* lq_dev, double beta0, const double* betas_host,
+                      const double* m_host, const double* shift_host, int K, double* out_host,
+                      asmc_stream stream);
+int asmc_weights_stats(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
+                       const double* lq_dev, double beta0, const double* betas_host, int K,
+                       double* out_host, asmc_stream stream);
+int asmc_weights_m2(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
+                    const double* lq_dev, double beta0, double beta, double m, double mean_u,
+                    double* m2_host, asmc_stream stream);
+
+/* SMCSamples.log_weights(beta) as an array (samples.py:1244-1249): lw_out = lw(beta) + shift,
+ * shift = logsumexp(lw) - log N formed on the host from asmc_weights_stats. */
+int asmc_log_weights(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
+                     const double* lq_dev, double beta0, double beta, double shift,
+                     double* lw_out_dev, asmc_stream stream);
+
+/* w_i = exp((lw_i(beta) + shift) - lse)  — the normalised weights of samples.py:1277. */
+int asmc_normalized_weights(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
+                            const double* lq_dev, double beta0, double beta, double shift,
+                            double lse, double* w_out_dev, asmc_stream stream);
+
+/* NaN / non-finite guards (smc/base.py:330-335, mcmc.py:68-74, minipcn.py:133-134). */
+int asmc_count_nonfinite(asmc_ctx* ctx, int64_t n, const double* v_dev, int64_t* n_nan_host,
+                         int64_t* n_inf_host, asmc_stream stream);
+
+/* ---- resampling (reference samples.py:1277-1287; numpy Generator.choice semantics) ---------
+ * asmc_cdf: inclusive cumulative sum of w, carry_in added in front (rank chaining).
+ *   mode ASMC_CDF_EXACT reproduces the *sequential* fp64 accumulation of numpy's cumsum
+ *   bit-for-bit (parallelised through round-to-nearest-even integer transducers);
+ *   ASMC_CDF_FAST uses a parallel scan order.  total_host receives the last element.
+ * asmc_cdf_normalize: cdf /= last    (numpy: cdf /= cdf[-1]).
+ * asmc_pcg64_uniforms: u[j] = j-th next double of numpy's PCG64 stream given its raw state
+ *   {state_hi, state_lo, inc_hi, inc_lo} after skipping `offset` draws (the host then calls
+ *   bit_generator.advance(n)).
+ * asmc_search: idx[j] = #{k : cdf[k] <= u[j]}  == cdf.searchsorted(u, side="right").
+ * asmc_gather: x_out[j,:] = x_in[idx[j],:] and the three scalar vectors (samples.py:1279-1287). */
+int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w_dev, double* cdf_dev, int mode,
+             double carry_in, double* total_host, asmc_stream stream);
+int asmc_cdf_normalize(asmc_ctx* ctx, int64_t n, double* cdf_dev, double last, asmc_stream stream);
+int asmc_pcg64_uniforms(asmc_ctx* ctx, const uint64_t state_host[4], uint64_t offset, int64_t n,
+                        double* u_dev, asmc_stream stream);
+int asmc_systematic_uniforms(asmc_ctx* ctx, int64_t n_out, int64_t j0, int64_t n_total, double u0,
+                             const double* v_dev /* NULL: systematic; else stratified */,
+                             double* u_dev, asmc_stream stream);
+int asmc_search(asmc_ctx* ctx, int64_t n, const double* cdf_dev, int64_t n_out, const double* u_dev,
+                int64_t* idx_dev, asmc_stream stream);
+int asmc_gather(asmc_ctx* ctx, int64_t n_out, const int64_t* idx_dev, int d, int x_dtype,
+                const void* x_in_dev, void* x_out_dev, const double* ll_in_dev,
+                const double* lp_in_dev, const double* lq_in_dev, double* ll_out_dev,
+                double* lp_out_dev, double* lq_out_dev, asmc_stream stream);
+
+/* ---- proposal draw / built-in densities / validity filter (reference mcmc.py:49-110) --------
+ * asmc_gaussian_draw: analytic diagonal-Gaussian proposal (a `Flow`-interface object with
+ *   sample_and_log_prob, flows/base.py:11-98): x = mu + sigma * xi (Philox4x32-10 normals, keyed
+ *   by seed; counter = global particle index gid0+i, draw id), lq = log N(x; mu, diag sigma^2).
+ * asmc_mixture_logpdf: evaluate a built-in density over the batch.
+ * asmc_compact_valid: keep rows with finite lp and ll, preserving order (mcmc.py:88-90);
+ *   n_valid_host receives the count; outputs must hold n rows. */
+int asmc_gaussian_draw(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const double* mu_dev,
+                       const double* sigma_dev, uint64_t seed, uint64_t gid0, uint32_t draw_id,
+                       void* x_out_dev, double* lq_out_dev, asmc_stream stream);
+int asmc_mixture_logpdf(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
+                        const asmc_mixture* density, double* out_dev, asmc_stream stream);
+int asmc_compact_valid(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
+                       const double* ll_dev, const double* lp_dev, const double* lq_dev,
+                       void* x_out_dev, double* ll_out_dev, double* lp_out_dev, double* lq_out_dev,
+                       int64_t* n_valid_host, asmc_stream stream);
+
+/* ---- pCN mutation (replaces minipcn via smc/minipcn.py:69-135; spec in DESIGN.md) -----------
+ * asmc_colsum / asmc_centered_gram: population moments for the reference Gaussian
+ *   (sum_i x_i ; sum_i (x_i - c)(x_i - c)^T, full d x d, row-major) — per-rank partial sums.
+ * asmc_pcn_mutate: n_steps fused pCN steps (propose + built-in target + accept) in place.
+ *   rho_inout_host: step size in/out; n_accept_host[n_steps] accepted counts per step
+ *   (LOCAL particles); rho_hist_host[n_steps] step size used at each step (may be NULL).
+ *   With params->adapt the step size is adapted on device from the LOCAL acceptance rate
+ *   (single-GPU); sharded runs call with n_steps=1 and adapt on the host after an all-reduce.
+ * asmc_pcn_propose / asmc_pcn_accept: the split form for arbitrary Python callables / torch flows
+ *   (the host evaluates log_q, log_prior, log_likelihood on x_prop between the two calls,
+ *   reference smc/base.py:507-519). */
+int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, double* sum_host,
+                asmc_stream stream);
+int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
+                       const double* center_host, double* gram_host, asmc_stream stream);
+int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, double* lp_dev,
+                    double* lq_dev, const asmc_pcn_params* params, int n_steps, uint32_t step0,
+                    double* rho_inout_host, int64_t* n_accept_host, double* rho_hist_host,
+                    asmc_stream stream);
+int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
+                     void* x_prop_dev, double* qform_old_dev, double* qform_new_dev,
+                     const double* mu_dev, const double* L_dev, const double* Linv_dev, double rho,
+                     uint64_t seed, uint64_t gid0, uint32_t step, asmc_stream stream);
+int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x_dev,
+                    const void* x_prop_dev, double* ll_dev, double* lp_dev, double* lq_dev,
+                    const double* ll_new_dev, const double* lp_new_dev, const double* lq_new_dev,
+                    const double* logj_old_dev, const double* logj_new_dev,
+                    const double* qform_old_dev, const double* qform_new_dev, double beta,
+                    uint64_t seed, uint64_t gid0, uint32_t step, int64_t* n_accept_host,
+                    asmc_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASMC_H */

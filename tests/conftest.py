@@ -1,0 +1,51 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def synth(n, d, seed, sigma_q=1.5):
+    """Synthetic Gaussian batch: x = sigma_q N(0,I); ll = lp = -|x|^2/2; lq = log N(0, sigma_q^2 I).
+    Same recipe as oracle/make_golden.py (kept separate so the GPU box needs no reference tooling)."""
+    g = np.random.default_rng(seed)
+    x = sigma_q * g.normal(size=(n, d))
+    ll = -0.5 * np.sum(x**2, axis=1)
+    lp = ll.copy()
+    lq = -0.5 * np.sum((x / sigma_q) ** 2, axis=1) - d * np.log(sigma_q) - 0.5 * d * np.log(2 * np.pi)
+    return x, ll, lp, lq
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return {name[:-4]: np.load(os.path.join(GOLDEN, name)) for name in os.listdir(GOLDEN) if name.endswith(".npz")}
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as O
+
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def hip_engine():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from aspire_amd.engine import HipEngine
+
+    return HipEngine(0, n_max=1 << 21, d_max=64)

@@ -1,0 +1,200 @@
+"""OracleEngine — a TEST DOUBLE with HipEngine's method set, backed by the CPU oracle.
+
+Lives under tests/ on purpose: the product (`aspire_amd/`) has no CPU path.  It lets the host
+logic (smc_math, the sampler loop, sharding over gloo) run in the `-m "not gpu"` suite, following
+the reference's own fake-backend test pattern (tests/test_samplers/test_mcmc/test_checkpointing.py:88-109).
+Tensors are CPU torch tensors; every computation goes through oracle/oracle.py.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import oracle as O  # noqa: E402
+
+
+class OracleMixture:
+    def __init__(self, logw, mu, prec):
+        self.mix = O.Mixture(logw, mu, prec)
+        self.logw, self.mu, self.prec = self.mix.logw, self.mix.mu, self.mix.prec
+
+
+def _np(t):
+    return t.detach().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+class OracleEngine:
+    name = "oracle"
+    device = torch.device("cpu")
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def ensure_capacity(self, n, d):
+        pass
+
+    def asarray(self, a, dtype=torch.float64):
+        if isinstance(a, torch.Tensor):
+            return a.to(dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype)
+
+    def empty(self, shape, dtype=torch.float64):
+        return torch.empty(shape, dtype=dtype)
+
+    def full(self, n, value):
+        return torch.full((n,), value, dtype=torch.float64)
+
+    def to_numpy(self, t):
+        return _np(t)
+
+    def synchronize(self):
+        pass
+
+    # ---- weighting --------------------------------------------------------------------------
+    def weights_max(self, ll, lp, lq, beta0, betas):
+        m, nn = [], 0
+        for b in np.atleast_1d(betas):
+            lw = O.unnormalized_log_weights(_np(ll), _np(lp), _np(lq), beta0, float(b))
+            nn += int(np.isnan(lw).sum())
+            m.append(np.nanmax(lw) if not np.all(np.isnan(lw)) else -np.inf)
+        return np.array(m), nn
+
+    def weights_sums(self, ll, lp, lq, beta0, betas, m, shift=None):
+        out = []
+        for k, b in enumerate(np.atleast_1d(betas)):
+            lw = O.unnormalized_log_weights(_np(ll), _np(lp), _np(lq), beta0, float(b))
+            sh = 0.0 if shift is None else float(np.atleast_1d(shift)[k])
+            with np.errstate(all="ignore"):
+                e = np.exp((lw + sh) - float(np.atleast_1d(m)[k]))
+            out.append([np.sum(e), np.sum(e * e)])
+        return np.array(out)
+
+    def weights_stats(self, ll, lp, lq, beta0, betas):
+        m, nn = self.weights_max(ll, lp, lq, beta0, betas)
+        s = self.weights_sums(ll, lp, lq, beta0, betas, m)
+        return np.column_stack([m, s[:, 0], s[:, 1], np.full(len(m), float(nn))])
+
+    def weights_m2(self, ll, lp, lq, beta0, beta, m, mean_u):
+        lw = O.unnormalized_log_weights(_np(ll), _np(lp), _np(lq), beta0, beta)
+        return float(np.sum((np.exp(lw - m) - mean_u) ** 2))
+
+    def log_weights(self, ll, lp, lq, beta0, beta, shift):
+        return torch.from_numpy(O.unnormalized_log_weights(_np(ll), _np(lp), _np(lq), beta0, beta) + shift)
+
+    def normalized_weights(self, ll, lp, lq, beta0, beta, shift, lse):
+        lw = O.unnormalized_log_weights(_np(ll), _np(lp), _np(lq), beta0, beta) + shift
+        return torch.from_numpy(np.exp(lw - lse))
+
+    def count_nonfinite(self, v):
+        a = _np(v)
+        return int(np.isnan(a).sum()), int(np.isinf(a).sum())
+
+    # ---- resampling -------------------------------------------------------------------------
+    def cdf(self, w, mode="exact", carry_in=0.0):
+        a = _np(w).copy()
+        if mode == "exact":  # strictly sequential accumulation (numpy cumsum), with carry in front
+            if carry_in != 0.0:
+                out = np.cumsum(np.concatenate([[carry_in], a]))[1:]
+            else:
+                out = np.cumsum(a)
+        else:
+            out = carry_in + np.cumsum(a)
+        return torch.from_numpy(out), float(out[-1])
+
+    def cdf_normalize(self, cdf, last):
+        cdf /= last
+        return cdf
+
+    def uniforms_pcg64(self, state4, offset, n):
+        st = np.array(state4, dtype=np.uint64)
+        O.pcg64_advance(st, int(offset))
+        return torch.from_numpy(O.pcg64_random(st, n))
+
+    def systematic_uniforms(self, n_out, j0, n_total, u0, v=None):
+        j = np.arange(j0, j0 + n_out, dtype=np.float64)
+        off = u0 if v is None else _np(v)
+        return torch.from_numpy((j + off) / float(n_total))
+
+    def search(self, cdf, u):
+        return torch.from_numpy(O.searchsorted_right(_np(cdf), _np(u)))
+
+    def gather(self, idx, x, ll, lp, lq):
+        xo, a, b, c = O.gather_rows(_np(idx), _np(x), _np(ll), _np(lp), _np(lq))
+        return torch.from_numpy(xo), torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(c)
+
+    # ---- proposal / densities ---------------------------------------------------------------
+    def make_mixture(self, logw, mu, prec):
+        return OracleMixture(logw, mu, prec)
+
+    def gaussian_draw(self, n, d, x_dtype, mu, sigma, seed, gid0, draw_id, want_lq=True):
+        x = np.empty((n, d))
+        for i in range(n):
+            xi, _ = O.pcn_noise(seed, gid0 + i, draw_id, d)
+            x[i] = _np(mu) + _np(sigma) * xi
+        xt = torch.from_numpy(x).to(x_dtype)
+        lq = None
+        if want_lq:
+            z = (xt.double().numpy() - _np(mu)) / _np(sigma)
+            lq = torch.from_numpy(-0.5 * (z * z).sum(1) - np.log(_np(sigma)).sum() - 0.5 * d * np.log(2 * np.pi))
+        return xt, lq
+
+    def mixture_logpdf(self, x, mix):
+        return torch.from_numpy(mix.mix.logpdf(_np(x).astype(np.float64)))
+
+    def compact_valid(self, x, ll, lp, lq):
+        assert x.dtype == torch.float64
+        return tuple(torch.from_numpy(a) for a in O.compact_valid(_np(x), _np(ll), _np(lp), _np(lq)))
+
+    # ---- moments / pCN ----------------------------------------------------------------------
+    def colsum(self, x):
+        return _np(x).astype(np.float64).sum(axis=0)
+
+    def centered_gram(self, x, center):
+        c = _np(x).astype(np.float64) - np.asarray(center)
+        return c.T @ c
+
+    def pcn_mutate(self, x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed, gid0, rho, n_steps, step0=0,
+                   target_accept=0.234, adapt=True):
+        assert x.dtype == torch.float64
+        n = x.shape[0]
+        n_acc, hist = np.zeros(n_steps, dtype=np.int64), np.zeros(n_steps)
+        for t in range(n_steps):
+            hist[t] = rho
+            n_acc[t] = O.pcn_step(_np(x), _np(ll), _np(lp), _np(lq), beta, _np(mu), _np(L), _np(Linv), rho,
+                                  t_ll.mix, t_lp.mix, t_lq.mix, seed, gid0, step0 + t)
+            if adapt:
+                rho = O.pcn_adapt(rho, n_acc[t] / n, target_accept, t)
+        return n_acc, hist, rho
+
+    def pcn_propose(self, x, mu, L, Linv, rho, seed, gid0, step):
+        xn, mun, Ln, Li = _np(x).astype(np.float64), _np(mu), _np(L), _np(Linv)
+        n, d = xn.shape
+        y = (xn - mun) @ Li.T
+        xi = np.stack([O.pcn_noise(seed, gid0 + i, step, d)[0] for i in range(n)])
+        yp = np.sqrt(1 - rho * rho) * y + rho * xi
+        xp = (mun + yp @ Ln.T).astype(xn.dtype if x.dtype == torch.float64 else np.float32)
+        return (torch.from_numpy(xp).to(x.dtype), torch.from_numpy((y * y).sum(1)), torch.from_numpy((yp * yp).sum(1)))
+
+    def pcn_accept(self, x, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0, step,
+                   logj_old=None, logj_new=None):
+        n, d = x.shape
+        u = np.array([O.pcn_noise(seed, gid0 + i, step, d)[1] for i in range(n)])
+
+        def lpt(a, b, c):
+            with np.errstate(all="ignore"):
+                r = (1 - beta) * _np(c) + beta * (_np(a) + _np(b))
+            return np.where(np.isnan(r), -np.inf, r)
+
+        new, old = lpt(ll_new, lp_new, lq_new), lpt(ll, lp, lq)
+        if logj_new is not None:
+            new = new + _np(logj_new)
+        if logj_old is not None:
+            old = old + _np(logj_old)
+        with np.errstate(all="ignore"):
+            acc = np.log(u) < (new + 0.5 * _np(q1)) - (old + 0.5 * _np(q0))
+        acc_t = torch.from_numpy(acc)
+        x[acc_t] = x_prop[acc_t]
+        ll[acc_t], lp[acc_t], lq[acc_t] = ll_new[acc_t], lp_new[acc_t], lq_new[acc_t]
+        return int(acc.sum())

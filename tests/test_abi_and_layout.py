@@ -1,0 +1,108 @@
+"""C-ABI library loads and exports exactly what include/asmc.h declares (no compute: no GPU here);
+the product never touches oracle/ and refuses to run without a HIP device."""
+import ast
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "asmc.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(asmc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from aspire_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+
+        g.build()
+    lib = _lib.load()
+    declared = header_functions()
+    assert len(declared) >= 25
+    assert sorted(_lib.SIGNATURES) == declared  # the ctypes table binds exactly the header's functions
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.asmc_abi_version() == _lib.ASMC_ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    import ctypes
+
+    from aspire_amd._lib import AsmcMixture, AsmcPcnParams
+
+    assert ctypes.sizeof(AsmcMixture) == 32
+    assert AsmcPcnParams.log_likelihood.offset == 40 and AsmcPcnParams.seed.offset == 40 + 3 * 32
+    assert ctypes.sizeof(AsmcPcnParams) == 40 + 96 + 8 + 8 + 8 + 8
+
+
+def test_error_reporting_without_gpu():
+    import ctypes
+
+    from aspire_amd import _lib
+
+    lib = _lib.load()
+    ctx = ctypes.c_void_p()
+    rc = lib.asmc_ctx_create(ctypes.byref(ctx), 0, 0, 4)  # n_max = 0 is an argument error before any HIP call
+    assert rc == -1 and b"n_max" in lib.asmc_last_error()
+
+
+def test_product_has_no_cpu_fallback():
+    import torch
+
+    from aspire_amd import _lib
+    from aspire_amd.engine import HipEngine
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.AsmcError, match="no CPU fallback"):
+        HipEngine(0)
+
+
+def test_product_never_imports_oracle_or_reference():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    pkg = os.path.join(ROOT, "aspire_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            src = open(os.path.join(dirpath, f)).read()
+            tree = ast.parse(src)
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                for n in names:
+                    assert not n.split(".")[0] in ("oracle", "ref_shim", "oracle_engine", "make_golden"), (f, n)
+            assert "/root/reference" not in src, f
+    for dirpath, _, files in os.walk(os.path.join(pkg, "csrc")):
+        for f in files:
+            if f.endswith((".hip", ".h")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().lower().replace("oracle-backed", ""), f
+
+
+def test_oracle_vs_reference_live_if_present(oracle):
+    """In the build container the oracle is additionally checked against the imported reference."""
+    import numpy as np
+
+    import ref_shim
+
+    if not ref_shim.reference_available():
+        pytest.skip("reference tree not present (GPU box)")
+    rs, smc, mcmc, ut = ref_shim.import_reference()
+    g = np.random.default_rng(123)
+    x = g.normal(size=(777, 3))
+    ll, lp, lq = g.normal(size=777) * 3, g.normal(size=777), g.normal(size=777)
+    s = rs.SMCSamples(x=x, log_likelihood=ll, log_prior=lp, log_q=lq, beta=0.1)
+    assert np.array_equal(np.asarray(s.log_weights(0.45)), oracle.log_weights(ll, lp, lq, 0.1, 0.45))
+    assert float(s.log_evidence_ratio(0.45)) == oracle.log_evidence_ratio(ll, lp, lq, 0.1, 0.45)
+    out = s.resample(0.45, rng=np.random.default_rng(5))
+    idx = oracle.resample_indices(ll, lp, lq, 0.1, 0.45, np.random.default_rng(5).random(777))
+    assert np.array_equal(np.asarray(out.x), x[idx])

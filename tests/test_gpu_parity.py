@@ -1,0 +1,481 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference goldens.
+
+Bars: bit-exact for integer/index work (resample indices, PCG64 doubles, gather, compaction, beta*),
+relative 1e-12 (far inside the north-star's 1e-6) for log-weights and reductions.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(hip_engine):
+    return hip_engine
+
+
+def dev(eng, *arrs):
+    return tuple(eng.asarray(a) for a in arrs)
+
+
+# ---- K1/K2/K4: weights, LSE, ESS, evidence ----------------------------------------------------
+@pytest.mark.parametrize("n,d,seed", [(10, 2, 11), (2000, 4, 12), (65536, 8, 13), (1000003, 4, 14)])
+def test_weights_stats_vs_oracle(eng, oracle, n, d, seed):
+    from aspire_amd import smc_math
+    from aspire_amd.comm import Comm
+
+    x, ll, lp, lq = synth(n, d, seed)
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    for beta0 in (0.0, 0.3):
+        betas = [beta0 + 0.01, 0.5, 1.0]
+        stats = smc_math.global_stats(eng, Comm(), lld, lpd, lqd, beta0, betas, n)
+        for b, st in zip(betas, stats):
+            lw = oracle.unnormalized_log_weights(ll, lp, lq, beta0, b)
+            assert st.m == lw.max()  # max is order independent: exact
+            assert smc_math.log_evidence_ratio(st) == pytest.approx(oracle.log_evidence_ratio(ll, lp, lq, beta0, b), rel=1e-12, abs=1e-12)
+            assert smc_math.ess(st) == pytest.approx(oracle.ess_at_beta(ll, lp, lq, beta0, b), rel=1e-11)
+            var = smc_math.evidence_variance(eng, Comm(), lld, lpd, lqd, beta0, b, st)
+            assert var == pytest.approx(oracle.log_evidence_ratio_variance(ll, lp, lq, beta0, b), rel=1e-9)
+
+
+def test_weights_golden_reference(eng, golden):
+    from aspire_amd.samples import SMCSamples
+
+    g = golden["ref_weights"]
+    for n, d, seed, b0, b in g["cases"]:
+        n, d, seed = int(n), int(d), int(seed)
+        x, ll, lp, lq = synth(n, d, seed)
+        s = SMCSamples(x=x, log_likelihood=ll, log_prior=lp, log_q=lq, beta=b0, engine=eng)
+        key = f"n{n}_b{b0}_t{b}"
+        lw = s.log_weights(b)
+        if n <= 2000:
+            np.testing.assert_allclose(lw, g[key + "_lw"], rtol=1e-12, atol=1e-12)
+        else:
+            np.testing.assert_allclose(lw[::257], g[key + "_lw_stride"], rtol=1e-12, atol=1e-12)
+        assert s.effective_sample_size(b) == pytest.approx(float(g[key + "_ess"]), rel=1e-11)
+        assert s.log_evidence_ratio(b) == pytest.approx(float(g[key + "_ratio"]), rel=1e-12, abs=1e-12)
+        assert s.log_evidence_ratio_variance(b) == pytest.approx(float(g[key + "_var"]), rel=1e-9)
+
+
+def test_all_beta_buckets_agree(eng, oracle):
+    """K = 1..32 candidates in one pass give the same numbers as K separate passes."""
+    x, ll, lp, lq = synth(30011, 4, 5)
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    betas = np.linspace(0.01, 1.0, 32)
+    full = eng.weights_stats(lld, lpd, lqd, 0.0, betas)
+    for K in (1, 2, 3, 5, 8, 15, 16, 31):
+        part = eng.weights_stats(lld, lpd, lqd, 0.0, betas[:K])
+        np.testing.assert_allclose(part[:, :3], full[:K, :3], rtol=1e-13)
+    for k in (0, 7, 31):
+        lw = oracle.unnormalized_log_weights(ll, lp, lq, 0.0, betas[k])
+        assert full[k, 0] == lw.max()
+        assert full[k, 1] == pytest.approx(np.exp(lw - lw.max()).sum(), rel=1e-12)
+
+
+def test_split_max_sums_equal_fused(eng):
+    x, ll, lp, lq = synth(50000, 4, 6)
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    betas = [0.1, 0.7]
+    fused = eng.weights_stats(lld, lpd, lqd, 0.0, betas)
+    m, nn = eng.weights_max(lld, lpd, lqd, 0.0, betas)
+    s = eng.weights_sums(lld, lpd, lqd, 0.0, betas, m)
+    assert nn == 0 and np.array_equal(m, fused[:, 0]) and np.array_equal(s, fused[:, 1:3])
+
+
+def test_nan_guard_and_inf_semantics(eng):
+    from aspire_amd.samples import SMCSamples
+
+    ll = np.array([0.0, np.nan, 1.0])
+    s = SMCSamples(x=np.zeros((3, 1)), log_likelihood=ll, log_prior=np.zeros(3), log_q=np.zeros(3), beta=0.0, engine=eng)
+    with pytest.raises(ValueError, match="Log weights contain NaN"):
+        s.log_weights(0.5)
+    # -inf likelihood rows get zero weight, not NaN (H6)
+    ll = np.array([0.0, -np.inf, 1.0, 2.0])
+    s = SMCSamples(x=np.zeros((4, 1)), log_likelihood=ll, log_prior=np.zeros(4), log_q=np.zeros(4), beta=0.0, engine=eng)
+    assert math.isfinite(s.log_evidence_ratio(0.5))
+    assert eng.count_nonfinite(eng.asarray(ll)) == (0, 1)
+
+
+# ---- K3: beta bisection -----------------------------------------------------------------------
+def test_determine_beta_matches_reference_golden(eng, golden):
+    from aspire_amd.flows import GaussianFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.samples import SMCSamples
+    from aspire_amd.targets import DiagGaussianMixture
+
+    g = golden["ref_beta"]
+    for n, d, seed, b0, tol, ti, b_ref in g["cases"]:
+        n, d, seed, ti = int(n), int(d), int(seed), int(ti)
+        x, ll, lp, lq = synth(n, d, 0, 2.0) if seed == 0 else synth(n, d, seed)
+        lik = DiagGaussianMixture.isotropic(d, normalized=False)
+        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, engine=eng), xp=np, engine=eng)
+        sp.adaptive, sp.adaptive_min_beta_step = True, False
+        sp.target_efficiency = [0.5, (0.3, 0.9)][ti]
+        sp.target_efficiency_rate = 1.0
+        s = SMCSamples(x=eng.asarray(x), log_likelihood=eng.asarray(ll), log_prior=eng.asarray(lp), log_q=eng.asarray(lq),
+                       beta=b0, engine=eng)
+        b, _ = sp.determine_beta(s, b0, np.nan, 0.0, max_beta_step=1.0, beta_tolerance=tol)
+        assert b == b_ref, (n, b0, tol, ti, b, b_ref)
+
+
+# ---- K6: PCG64, cdf, search ---------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 7, 1000, 65536, 65537, 300001])
+def test_pcg64_uniforms_bit_exact_vs_numpy(eng, n):
+    from aspire_amd.smc_math import pcg64_state
+
+    for seed, offset in ((0, 0), (123, 5), (9, 70000)):
+        rng = np.random.default_rng(seed)
+        st = pcg64_state(rng)
+        u = eng.uniforms_pcg64(st, offset, n).cpu().numpy()
+        ref = np.random.default_rng(seed).random(offset + n)[offset:]
+        assert np.array_equal(u, ref)
+
+
+def _weights(n, seed, kind):
+    g = np.random.default_rng(seed)
+    if kind == "smooth":
+        w = np.exp(g.normal(size=n))
+    elif kind == "heavy":  # spans hundreds of binades, exact zeros, a dominant weight
+        w = np.exp(60 * g.normal(size=n))
+        w[g.integers(0, n, n // 10)] = 0.0
+    elif kind == "tiny_first":
+        w = np.exp(g.normal(size=n))
+        k = min(5, n)
+        w[:k] = [0.0, 5e-324, 1e-310, 3e-300, 1e-200][:k]
+    elif kind == "equal":
+        w = np.full(n, 1.0 / n)
+    elif kind == "ties":  # dyadic weights: every add is a round-to-even tie candidate
+        w = np.ldexp(1.0, -g.integers(1, 60, n).astype(np.int64)).astype(np.float64)
+    if kind == "tiny_first" or w.sum() == 0:
+        return w
+    return w / w.sum()
+
+
+@pytest.mark.parametrize("kind", ["smooth", "heavy", "tiny_first", "equal", "ties"])
+@pytest.mark.parametrize("n", [1, 5, 4096, 4097, 100003, 1 << 20])
+def test_exact_cdf_is_numpy_cumsum_bitwise(eng, n, kind):
+    w = _weights(n, 17 + n, kind)
+    cdf, total = eng.cdf(eng.asarray(w), "exact", 0.0)
+    ref = np.cumsum(w)
+    got = cdf.cpu().numpy()
+    assert np.array_equal(got, ref), np.flatnonzero(got != ref)[:5]
+    assert total == ref[-1]
+
+
+def test_exact_cdf_with_carry_chains_like_one_array(eng):
+    w = _weights(50000, 3, "smooth")
+    a, ta = eng.cdf(eng.asarray(w[:20000]), "exact", 0.0)
+    b, tb = eng.cdf(eng.asarray(w[20000:]), "exact", ta)
+    ref = np.cumsum(w)
+    assert np.array_equal(np.concatenate([a.cpu().numpy(), b.cpu().numpy()]), ref) and tb == ref[-1]
+
+
+def test_fast_cdf_close_and_monotone(eng):
+    w = _weights(300001, 4, "smooth")
+    cdf, total = eng.cdf(eng.asarray(w), "fast", 0.0)
+    got = cdf.cpu().numpy()
+    np.testing.assert_allclose(got, np.cumsum(w), rtol=1e-12)
+    assert np.all(np.diff(got) >= 0) and total == got[-1]
+
+
+def test_search_is_searchsorted_right(eng):
+    g = np.random.default_rng(5)
+    cdf = np.cumsum(g.random(100000))
+    cdf /= cdf[-1]
+    u = np.concatenate([g.random(50000), cdf[::997][:50], [0.0]])  # includes exact hits on cdf values
+    u = u[u < 1.0]
+    idx = eng.search(eng.asarray(cdf), eng.asarray(u)).cpu().numpy()
+    assert np.array_equal(idx, np.searchsorted(cdf, u, side="right"))
+
+
+def test_resample_indices_match_reference_golden(eng, golden):
+    from aspire_amd.samples import SMCSamples
+
+    g = golden["ref_resample"]
+    for n, d, seed, b0, b, n_out in g["cases"]:
+        n, d, seed, n_out = int(n), int(d), int(seed), int(n_out)
+        x, ll, lp, lq = synth(n, d, seed)
+        rng = np.random.default_rng(1000 + seed)
+        s = SMCSamples(x=x, log_likelihood=ll, log_prior=lp, log_q=lq, beta=b0, engine=eng)
+        out = s.resample(b, n_samples=n_out, rng=rng)
+        idx = g[f"n{n}_b{b0}_t{b}_o{n_out}_idx"]
+        assert np.array_equal(out.x, x[idx]), (n, b0, b, n_out)
+        assert np.array_equal(out.log_likelihood, ll[idx]) and np.array_equal(out.log_q, lq[idx])
+        assert np.array_equal(rng.random(3), g[f"n{n}_b{b0}_t{b}_o{n_out}_next_u"])
+    x, ll, lp, lq = synth(2000, 4, 32)
+    s = SMCSamples(x=x, log_likelihood=ll, log_prior=lp, log_q=lq, beta=0.4, engine=eng)
+    out = s.resample(0.4, n_samples=50, rng=np.random.default_rng(77))
+    assert np.array_equal(out.x, x[g["samebeta_idx"]])
+
+
+def test_resample_indices_vs_oracle_1m(eng, oracle):
+    """Full size: 1M particles, exact mode == oracle (sequential cumsum) indices."""
+    from aspire_amd import smc_math
+    from aspire_amd.comm import Comm
+
+    n = 1 << 20
+    x, ll, lp, lq = synth(n, 2, 99)
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    idx, _ = smc_math.resample_indices(eng, Comm(), lld, lpd, lqd, 0.0, 0.02, n, np.random.default_rng(5), mode="exact")
+    ref = oracle.resample_indices(ll, lp, lq, 0.0, 0.02, np.random.default_rng(5).random(n))
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    idx_f, _ = smc_math.resample_indices(eng, Comm(), lld, lpd, lqd, 0.0, 0.02, n, np.random.default_rng(5), mode="fast")
+    diff = idx_f.cpu().numpy() != ref
+    assert diff.sum() <= 4 and np.all(np.abs(idx_f.cpu().numpy()[diff] - ref[diff]) == 1)
+
+
+# ---- K7 gather, K11 compaction ----------------------------------------------------------------------
+@pytest.mark.parametrize("d,dtype", [(32, torch.float64), (32, torch.float32), (4, torch.float64), (3, torch.float64),
+                                     (5, torch.float32), (128, torch.float64)])
+def test_gather_rows_exact(eng, d, dtype):
+    g = np.random.default_rng(7)
+    n, n_out = 20011, 30007
+    x = torch.as_tensor(g.normal(size=(n, d))).to(dtype)
+    ll, lp, lq = (g.normal(size=n) for _ in range(3))
+    idx = g.integers(0, n, n_out)
+    xo, a, b, c = eng.gather(eng.asarray(idx, dtype=torch.int64), x.to(eng.device), *dev(eng, ll, lp, lq))
+    assert torch.equal(xo.cpu(), x[idx]) and np.array_equal(a.cpu().numpy(), ll[idx])
+    assert np.array_equal(b.cpu().numpy(), lp[idx]) and np.array_equal(c.cpu().numpy(), lq[idx])
+
+
+def test_compact_valid_matches_oracle(eng, oracle):
+    g = np.random.default_rng(8)
+    n, d = 10007, 5
+    x = g.normal(size=(n, d))
+    ll, lp, lq = g.normal(size=n), g.normal(size=n), g.normal(size=n)
+    ll[g.integers(0, n, 500)] = -np.inf
+    lp[g.integers(0, n, 500)] = np.inf
+    ll[g.integers(0, n, 100)] = np.nan
+    got = eng.compact_valid(*dev(eng, x, ll, lp, lq))
+    ref = oracle.compact_valid(x, ll, lp, lq)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a.cpu().numpy(), b)
+
+
+# ---- proposal draw, densities, moments -----------------------------------------------------------------
+def test_philox_normals_match_oracle_and_are_normal(eng, oracle):
+    d, n = 6, 4096
+    mu, sigma = np.linspace(-1, 1, d), np.linspace(0.5, 2, d)
+    x, lq = eng.gaussian_draw(n, d, torch.float64, eng.asarray(mu), eng.asarray(sigma), 1234, 10, 3)
+    xn = x.cpu().numpy()
+    for i in (0, 1, 4095):
+        xi, _ = oracle.pcn_noise(1234, 10 + i, 3, d)
+        np.testing.assert_allclose(xn[i], mu + sigma * xi, rtol=1e-12, atol=1e-13)
+    z = (xn - mu) / sigma
+    ref_lq = -0.5 * (z * z).sum(1) - np.log(sigma).sum() - 0.5 * d * np.log(2 * np.pi)
+    np.testing.assert_allclose(lq.cpu().numpy(), ref_lq, rtol=1e-12)
+    from scipy import stats
+
+    big, _ = eng.gaussian_draw(200000, 4, torch.float64, eng.asarray(np.zeros(4)), eng.asarray(np.ones(4)), 7, 0, 0, want_lq=False)
+    assert stats.kstest(big.cpu().numpy().ravel(), "norm").pvalue > 1e-3
+
+
+@pytest.mark.parametrize("d,C,dtype", [(32, 1, torch.float64), (4, 2, torch.float64), (7, 3, torch.float32), (128, 2, torch.float64)])
+def test_mixture_logpdf_vs_oracle(eng, oracle, d, C, dtype):
+    g = np.random.default_rng(9)
+    n = 5003
+    mu, var = g.normal(size=(C, d)), g.uniform(0.5, 2.0, size=(C, d))
+    logw = np.log(np.full(C, 1.0 / C)) - 0.5 * d * np.log(2 * np.pi) - 0.5 * np.log(var).sum(1)
+    x = torch.as_tensor(g.normal(size=(n, d)) * 2).to(dtype)
+    got = eng.mixture_logpdf(x.to(eng.device), eng.make_mixture(logw, mu, 1 / var)).cpu().numpy()
+    ref = oracle.Mixture(logw, mu, 1 / var).logpdf(x.double().numpy())
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("d", [2, 4, 32, 64])
+def test_moments_vs_oracle(eng, oracle, d):
+    g = np.random.default_rng(10)
+    n = 30011
+    x = g.normal(size=(n, d)) @ g.normal(size=(d, d)) + 3.0
+    xd = eng.asarray(x)
+    mean = eng.colsum(xd) / n
+    cov = eng.centered_gram(xd, mean) / (n - 1)
+    rm, rc = oracle.moments(x)
+    np.testing.assert_allclose(mean, rm, rtol=1e-12)
+    np.testing.assert_allclose(cov, rc, rtol=1e-10, atol=1e-12)
+
+
+# ---- K8/K9: pCN ------------------------------------------------------------------------------------------
+def _pcn_setup(eng, n, d, seed, dtype=torch.float64, C=1):
+    g = np.random.default_rng(seed)
+    x = 1.5 * g.normal(size=(n, d))
+    A = g.normal(size=(d, d)) / np.sqrt(d)
+    cov = A @ A.T + 0.5 * np.eye(d)
+    L = np.linalg.cholesky(cov)
+    Linv = np.linalg.inv(L)
+    mu = 0.1 * g.normal(size=d)
+    mixes = []
+    for k in range(3):
+        m = g.normal(size=(C, d)) * (0.5 if k < 2 else 0.0)
+        v = g.uniform(0.7, 1.5, size=(C, d)) * (2.25 if k == 2 else 1.0)
+        lw = np.log(np.full(C, 1.0 / C)) - 0.5 * d * np.log(2 * np.pi) - 0.5 * np.log(v).sum(1)
+        mixes.append((lw, m, 1 / v))
+    return x, mu, np.tril(L), np.tril(Linv), mixes
+
+
+@pytest.mark.parametrize("d,C", [(32, 1), (4, 2), (7, 1), (2, 1)])
+def test_pcn_step_vs_oracle(eng, oracle, d, C):
+    """One fused pCN step == the oracle's restatement of the same specification: proposals to 1e-12,
+    accept decisions identical except where log u is within 1e-9 of log alpha."""
+    n = 3000
+    x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 21 + d, C=C)
+    om = [oracle.Mixture(*m) for m in mixes]
+    ll, lp, lq = (m.logpdf(x) for m in om)
+    dm = [eng.make_mixture(*m) for m in mixes]
+    xd, lld, lpd, lqd = dev(eng, x, ll, lp, lq)
+    rho, beta, seed, gid0, step = 0.4, 0.37, 4242, 1000, 5
+    n_acc, rho_hist, rho_out = eng.pcn_mutate(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv),
+                                              dm[0], dm[1], dm[2], seed, gid0, rho, 1, step, 0.234, False)
+    xr, llr, lpr, lqr = x.copy(), ll.copy(), lp.copy(), lq.copy()
+    acc_ref = oracle.pcn_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, om[0], om[1], om[2], seed, gid0, step)
+    got = xd.cpu().numpy()
+    moved_g = np.any(got != x, axis=1)
+    moved_r = np.any(xr != x, axis=1)
+    disagree = moved_g != moved_r
+    assert disagree.sum() <= 2, disagree.sum()  # only razor-edge accept decisions may differ
+    same = ~disagree
+    np.testing.assert_allclose(got[same], xr[same], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(lld.cpu().numpy()[same], llr[same], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(lqd.cpu().numpy()[same], lqr[same], rtol=1e-11, atol=1e-11)
+    assert abs(int(n_acc[0]) - acc_ref) <= 2 and rho_out == rho and rho_hist[0] == rho
+    assert 0.02 < n_acc[0] / n < 0.98
+
+
+def test_pcn_split_path_equals_fused(eng, oracle):
+    n, d = 2000, 8
+    x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 77)
+    om = [oracle.Mixture(*m) for m in mixes]
+    dm = [eng.make_mixture(*m) for m in mixes]
+    ll, lp, lq = (m.logpdf(x) for m in om)
+    a = dev(eng, x, ll, lp, lq)
+    b = dev(eng, x, ll, lp, lq)
+    mud, Ld, Lid = dev(eng, mu, L, Linv)
+    n_acc, _, _ = eng.pcn_mutate(*a, 0.6, mud, Ld, Lid, dm[0], dm[1], dm[2], 5, 0, 0.3, 1, 9, 0.234, False)
+    xp, q0, q1 = eng.pcn_propose(b[0], mud, Ld, Lid, 0.3, 5, 0, 9)
+    lln, lpn, lqn = (eng.mixture_logpdf(xp, m) for m in dm)
+    nacc = eng.pcn_accept(b[0], xp, b[1], b[2], b[3], lln, lpn, lqn, q0, q1, 0.6, 5, 0, 9)
+    assert nacc == int(n_acc[0])
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+def test_pcn_leaves_gaussian_target_invariant(eng):
+    """Stationarity: particles ~ N(0, 1/2 I) stay N(0, 1/2 I) under many pCN steps at beta=1
+    (ll = lp = -|x|^2/2), with the reference Gaussian deliberately mis-specified."""
+    n, d = 200000, 4
+    g = np.random.default_rng(1)
+    x = g.normal(size=(n, d)) * np.sqrt(0.5)
+    tgt = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    q = eng.make_mixture([-d * np.log(1.5) - 0.5 * d * np.log(2 * np.pi)], np.zeros((1, d)), np.full((1, d), 1 / 2.25))
+    xd = eng.asarray(x)
+    ll = eng.mixture_logpdf(xd, tgt)
+    lp = ll.clone()
+    lq = eng.mixture_logpdf(xd, q)
+    L = np.diag(np.full(d, 0.9))
+    n_acc, rho_hist, rho = eng.pcn_mutate(xd, ll, lp, lq, 1.0, eng.asarray(np.full(d, 0.2)), eng.asarray(L),
+                                          eng.asarray(np.linalg.inv(L)), tgt, tgt, q, 11, 0, 0.5, 40, 0, 0.234, True)
+    xs = xd.cpu().numpy()
+    assert np.all(np.abs(xs.mean(0)) < 0.01) and np.all(np.abs(xs.var(0) - 0.5) < 0.01)
+    # adaptation drives the acceptance towards 0.234 until the step size hits its 0.99 ceiling
+    assert rho == 0.99 or abs(n_acc[-10:].mean() / n - 0.234) < 0.05
+    assert np.all(np.diff(rho_hist[:5]) > 0)  # acceptance above target -> step size grows
+    np.testing.assert_allclose(ll.cpu().numpy(), -0.5 * (xs**2).sum(1), rtol=1e-12)  # carried log-probs stay consistent
+
+
+def test_pcn_adapt_device_equals_host_formula(eng):
+    from aspire_amd.samplers.smc import pcn_adapt
+
+    n, d = 5000, 4
+    g = np.random.default_rng(2)
+    x = g.normal(size=(n, d))
+    tgt = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    xd = eng.asarray(x)
+    ll = eng.mixture_logpdf(xd, tgt)
+    lp, lq = ll.clone(), ll.clone()
+    eye = eng.asarray(np.eye(d))
+    n_acc, rho_hist, rho = eng.pcn_mutate(xd, ll, lp, lq, 0.5, eng.asarray(np.zeros(d)), eye, eye, tgt, tgt, tgt, 3, 0,
+                                          0.6, 6, 0, 0.234, True)
+    r = 0.6
+    for t in range(6):
+        assert rho_hist[t] == pytest.approx(r, rel=1e-13)
+        r = pcn_adapt(r, n_acc[t] / n, 0.234, t)
+    assert rho == pytest.approx(r, rel=1e-13)
+
+
+# ---- end to end -----------------------------------------------------------------------------------------------------
+def test_sampler_loop_history_matches_reference_golden(eng, golden):
+    """Same whole-loop golden as the CPU suite, now with the HIP engine underneath (stub mutate on host)."""
+    from test_host_logic import NumpyGaussFlow, StubSMC, _log_like
+
+    g = golden["ref_loop"]
+    for name, kind, kwargs in [("identity_adaptive", "identity", dict(adaptive=True, target_efficiency=0.5, beta_tolerance=1e-6)),
+                               ("rw_adaptive", "rw", dict(adaptive=True, target_efficiency=0.5, beta_tolerance=1e-6))]:
+        sp = StubSMC(log_likelihood=_log_like, log_prior=_log_like, dims=4, prior_flow=NumpyGaussFlow(4, 2.0, 5), xp=np,
+                     rng=np.random.default_rng(9), engine=eng)
+        sp.kind = kind
+        sp.sampler_kwargs = {}
+        if kind == "rw":  # the host stub works on numpy views of device tensors
+            orig = sp.mutate
+
+            def mutate(particles, beta, n_steps=None, _orig=orig):
+                cpu = particles.to_numpy()
+                cpu.x = torch.from_numpy(cpu.x)
+                out = _orig(cpu, beta)
+                return sp._wrap(eng.asarray(out.x), eng.asarray(out.log_likelihood), eng.asarray(out.log_prior),
+                                eng.asarray(out.log_q), beta)
+
+            sp.mutate = mutate
+        out = sp.sample(2000, store_sample_history=False, **kwargs)
+        assert np.array_equal(np.array(sp.history.beta), g[name + "_beta"])
+        np.testing.assert_allclose(sp.history.ess, g[name + "_ess"], rtol=1e-10)
+        np.testing.assert_allclose(sp.history.log_norm_ratio, g[name + "_log_norm_ratio"], rtol=1e-11, atol=1e-13)
+        assert np.array_equal(np.asarray(out.x.cpu() if torch.is_tensor(out.x) else out.x), g[name + "_x_final"])
+
+
+def test_quickstart_api_config1(eng):
+    """BASELINE config 1 (README quickstart shape): Aspire(...).fit(...).sample_posterior(sampler="smc")."""
+    from aspire_amd import Aspire, Samples
+    from aspire_amd.samples import set_default_engine
+
+    set_default_engine(eng)
+
+    def log_likelihood(samples):
+        return -0.5 * np.sum(samples.x**2, axis=-1)
+
+    def log_prior(samples):
+        return -0.5 * np.sum(samples.x**2, axis=-1)
+
+    rng = np.random.default_rng(0)
+    init = Samples(rng.normal(size=(2000, 4)))
+    aspire = Aspire(log_likelihood=log_likelihood, log_prior=log_prior, dims=4, parameters=[f"x{i}" for i in range(4)],
+                    flow_backend="gaussian")
+    aspire.fit(init)
+    post, hist = aspire.sample_posterior(sampler="smc", n_samples=500, sampler_kwargs=dict(n_steps=20),
+                                         return_history=True, rng=np.random.default_rng(1))
+    assert isinstance(post, Samples) and post.x.shape == (500, 4) and isinstance(post.x, np.ndarray)
+    assert post.parameters == [f"x{i}" for i in range(4)] and post.log_w is None
+    assert hist.beta[-1] == 1.0 and len(hist.ess) == len(hist.beta) == len(hist.mcmc_acceptance)
+    assert abs(float(post.log_evidence) - 2 * math.log(math.pi)) < 5 * float(post.log_evidence_error) + 0.15
+    assert aspire.n_likelihood_evaluations > 0
+
+
+def test_fused_sampler_1m_d32_evidence(eng):
+    """BASELINE config 2/3 size: 1M particles, d=32, fused pCN; log Z within 1 sigma-ish of (d/2) log pi."""
+    from aspire_amd.flows import GaussianFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    d, n = 32, 1 << 20
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=1.5, engine=eng, seed=1),
+                xp=np, engine=eng, rng=np.random.default_rng(0))
+    out = sp.sample(n, sampler_kwargs=dict(n_steps=8), store_sample_history=False)
+    true = 0.5 * d * math.log(math.pi)
+    err = float(out.log_evidence_error)
+    assert abs(float(out.log_evidence) - true) < max(4 * err, 0.02), (float(out.log_evidence), true, err)
+    assert sp.history.beta[-1] == 1.0

@@ -1,0 +1,117 @@
+"""The CPU oracle pinned against the real reference's golden vectors (tests/golden/ref_*.npz, made by
+oracle/make_golden.py from /root/reference) and against numpy / Random123 known answers."""
+import numpy as np
+import pytest
+
+from conftest import synth
+
+
+def test_weights_golden(oracle, golden):
+    g = golden["ref_weights"]
+    for n, d, seed, b0, b in g["cases"]:
+        n, d, seed = int(n), int(d), int(seed)
+        x, ll, lp, lq = synth(n, d, seed)
+        key = f"n{n}_b{b0}_t{b}"
+        lw = oracle.log_weights(ll, lp, lq, b0, b)
+        if n <= 2000:
+            assert np.array_equal(lw, g[key + "_lw"])
+        else:
+            assert np.array_equal(lw[::257], g[key + "_lw_stride"])
+        assert oracle.logsumexp(oracle.unnormalized_log_weights(ll, lp, lq, b0, b)) == float(g[key + "_lse_unnorm"])
+        assert oracle.effective_sample_size(lw) == pytest.approx(float(g[key + "_ess"]), rel=1e-13)
+        assert oracle.log_evidence_ratio(ll, lp, lq, b0, b) == float(g[key + "_ratio"])
+        assert oracle.log_evidence_ratio_variance(ll, lp, lq, b0, b) == pytest.approx(float(g[key + "_var"]), rel=1e-12)
+
+
+def test_beta_golden(oracle, golden):
+    g = golden["ref_beta"]
+    for n, d, seed, b0, tol, ti, b_ref in g["cases"]:
+        n, d, seed, ti = int(n), int(d), int(seed), int(ti)
+        x, ll, lp, lq = synth(n, d, 0, 2.0) if seed == 0 else synth(n, d, seed)
+        r = oracle.determine_beta(ll, lp, lq, b0, beta_tolerance=tol, target_efficiency=[0.5, (0.3, 0.9)][ti])
+        assert r.beta == b_ref and not r.stalled
+    x, ll, lp, lq = synth(2000, 4, 0, 2.0)
+    r = oracle.determine_beta(ll, lp, lq, 0.0, min_beta_step=0.2, max_beta_step=0.25, beta_tolerance=1e-6,
+                              adaptive_min_beta_step=True)
+    assert [r.beta, r.min_beta_step] == list(g["n2000_minstep"])
+
+
+def test_survey_anchor_values(oracle):
+    # SURVEY.md §8c anchors observed on the reference
+    x, ll, lp, lq = synth(2000, 4, 0, 2.0)
+    assert oracle.determine_beta(ll, lp, lq, 0.0, beta_tolerance=1e-8).beta == 0.16844338178634644
+    assert oracle.determine_beta(ll, lp, lq, 0.0, beta_tolerance=1e-6).beta == 0.1684427261352539
+
+
+def test_resample_golden(oracle, golden):
+    g = golden["ref_resample"]
+    for n, d, seed, b0, b, n_out in g["cases"]:
+        n, d, seed, n_out = int(n), int(d), int(seed), int(n_out)
+        x, ll, lp, lq = synth(n, d, seed)
+        st = oracle.pcg64_state_from_numpy(np.random.default_rng(1000 + seed))
+        u = oracle.pcg64_random(st, n_out)
+        key = f"n{n}_b{b0}_t{b}_o{n_out}"
+        assert np.array_equal(oracle.resample_indices(ll, lp, lq, b0, b, u), g[key + "_idx"])
+        assert np.array_equal(oracle.pcg64_random(st, 3), g[key + "_next_u"])
+    x, ll, lp, lq = synth(2000, 4, 32)
+    u = np.random.default_rng(77).random(50)
+    assert np.array_equal(oracle.resample_indices(ll, lp, lq, 0.4, 0.4, u, uniform_weights=True), g["samebeta_idx"])
+
+
+def test_choice_equivalence_live(oracle):
+    """numpy Generator.choice(p=w) == cumsum/searchsorted restatement, live."""
+    x, ll, lp, lq = synth(5000, 3, 8)
+    w = oracle.normalized_weights(ll, lp, lq, 0.0, 0.3)
+    for n_out in (5000, 37):
+        ref = np.random.default_rng(3).choice(5000, size=n_out, replace=True, p=w)
+        u = np.random.default_rng(3).random(n_out)
+        assert np.array_equal(oracle.searchsorted_right(oracle.cdf_from_weights(w), u), ref)
+
+
+def test_pcg64_vs_numpy(oracle):
+    for seed in (0, 1, 2**40 + 7):
+        rng = np.random.default_rng(seed)
+        st = oracle.pcg64_state_from_numpy(rng)
+        assert np.array_equal(oracle.pcg64_random(st, 1000), rng.random(1000))
+        oracle.pcg64_advance(st, 123456789)
+        rng.bit_generator.advance(123456789)
+        assert np.array_equal(st, oracle.pcg64_state_from_numpy(rng))
+
+
+def test_philox_known_answers(oracle):
+    """Random123 kat_vectors, philox4x32 10 rounds."""
+    kat = [
+        ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+        ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+        ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0],
+         [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+    ]
+    for ctr, key, out in kat:
+        assert list(oracle.philox4x32_10(ctr, key)) == out
+
+
+def test_nan_guard_and_compaction(oracle):
+    with pytest.raises(ValueError, match="Log weights contain NaN"):
+        oracle.log_weights([0.0, np.nan], [0.0, 0.0], [0.0, 0.0], 0.0, 0.5)
+    x = np.arange(12.0).reshape(6, 2)
+    ll = np.array([0, -np.inf, 1, np.nan, 2, 3.0])
+    lp = np.array([0, 0, np.inf, 0, 0, 0.0])
+    xo, llo, lpo, lqo = oracle.compact_valid(x, ll, lp, np.arange(6.0))
+    assert np.array_equal(lqo, [0.0, 4.0, 5.0]) and np.array_equal(xo, x[[0, 4, 5]])
+
+
+def test_pcn_oracle_is_a_valid_kernel(oracle):
+    """The restated pCN spec leaves its target invariant (statistical pin; parity with minipcn is unpinned)."""
+    d, n = 3, 20000
+    g = np.random.default_rng(0)
+    x = g.normal(size=(n, d)) * np.sqrt(0.5)
+    tgt = oracle.Mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    q = oracle.Mixture([0.0], np.zeros((1, d)), np.full((1, d), 0.25))
+    ll, lp, lq = tgt.logpdf(x), tgt.logpdf(x), q.logpdf(x)
+    L = np.diag([0.8, 1.0, 1.3])
+    rho = 0.5
+    for t in range(15):
+        acc = oracle.pcn_step(x, ll, lp, lq, 1.0, np.full(d, 0.1), L, np.linalg.inv(L), rho, tgt, tgt, q, 5, 0, t)
+        rho = oracle.pcn_adapt(rho, acc / n, 0.234, t)
+    assert np.all(np.abs(x.mean(0)) < 0.03) and np.all(np.abs(x.var(0) - 0.5) < 0.03)
+    np.testing.assert_allclose(ll, -0.5 * (x**2).sum(1), rtol=1e-12)
