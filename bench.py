@@ -1,0 +1,271 @@
+#!/usr/bin/env python
+"""bench.py — throughput of the SMC particle-batch hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
+torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (default, BASELINE.json configs[1]): 1M particles per GPU, d=32, Gaussian target
+(ll = lp = -|x|^2/2), analytic proposal q = N(0, 1.5^2 I) ("flow off"), IS-only: one *step* is one
+temperature iteration of the reference loop (smc/base.py:401-445) without mutation:
+  adaptive beta bisection (target efficiency 0.5, tol 1e-6) -> ESS(beta), ESS(1) -> evidence ratio +
+  variance -> resample (normalised weights, cdf, PCG64 uniforms, search, row gather).
+Inputs are resident in HBM before the timed region; every step processes the same pristine batch.
+`value` = particles x steps / time ("particle-steps/s"; here a step is a temperature iteration —
+SURVEY.md §8d calls this unit particle-iterations/s).
+
+Extra (same JSON line, `extra`): the mutation path (configs[2] shape, analytic proposal):
+fused pCN kernel throughput and one full `HipSMC.sample()` run with its log-evidence error.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+class OpTimer:
+    """HIP-event timing of individual engine calls on the stream they are launched on."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.events = {}
+        self.enabled = False
+
+    def wrap(self, names):
+        for name in names:
+            fn = getattr(self.engine, name)
+
+            def timed(*a, _fn=fn, _name=name, **k):
+                if not self.enabled:
+                    return _fn(*a, **k)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = _fn(*a, **k)
+                e.record()
+                self.events.setdefault(_name, []).append((s, e))
+                return out
+
+            setattr(self.engine, name, timed)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(s.elapsed_time(e) for s, e in v) / len(v)) for k, v in self.events.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--particles-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--dims", type=int, default=32)
+    ap.add_argument("--x-dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--resample-mode", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--mcmc-steps", type=int, default=32, help="pCN steps per temperature in the extra leg")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from aspire_amd import smc_math
+    from aspire_amd.comm import default_comm
+    from aspire_amd.engine import HipEngine
+    from aspire_amd.flows import GaussianFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.samples import gather_global
+    from aspire_amd.targets import DiagGaussianMixture
+
+    n_local, d = args.particles_per_gpu, args.dims
+    n_global = n_local * world
+    xdt = torch.float64 if args.x_dtype == "f64" else torch.float32
+    s_bytes = 8 if args.x_dtype == "f64" else 4
+    eng = HipEngine(local_rank, n_max=n_local, d_max=max(d, 32))
+    comm = default_comm(eng.device)
+
+    # ---- synthetic batch, resident in HBM ---------------------------------------------------
+    sigma_q = 1.5
+    flow = GaussianFlow(d, sigma=sigma_q, seed=0, engine=eng, dtype=xdt)
+    flow.gid0 = rank * n_local
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    x, lq = flow.sample_and_log_prob(n_local)
+    ll = eng.mixture_logpdf(x, lik.device_mixture(eng))
+    lp = ll.clone()
+    torch.cuda.synchronize()
+
+    timer = OpTimer(eng)
+    timer.wrap(["weights_stats", "weights_max", "weights_sums", "weights_m2", "normalized_weights", "cdf",
+                "cdf_normalize", "uniforms_pcg64", "search", "gather", "pcn_mutate"])
+    rng = np.random.default_rng(12345)
+    scal = {}
+
+    def is_step():
+        def eff_fn(betas):
+            return [smc_math.ess(s) / n_global for s in smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, betas, n_global)]
+
+        beta, _, n_pass = smc_math.determine_beta(eff_fn, 0.0, adaptive=True, beta_step=float("nan"), min_beta_step=0.0,
+                                                  max_beta_step=1.0, beta_tolerance=1e-6, adaptive_min_beta_step=False,
+                                                  target=0.5, rate=1.0)
+        st_b, st_1 = smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, [beta, 1.0], n_global)
+        scal.update(beta=beta, ess=smc_math.ess(st_b), ess1=smc_math.ess(st_1), ratio=smc_math.log_evidence_ratio(st_b),
+                    var=smc_math.evidence_variance(eng, comm, ll, lp, lq, 0.0, beta, st_b), passes=n_pass)
+        idx, _ = smc_math.resample_indices(eng, comm, ll, lp, lq, 0.0, beta, n_global, rng, mode=args.resample_mode)
+        return gather_global(eng, comm, idx, x, ll, lp, lq)
+
+    def sync_all():
+        if world > 1:
+            comm.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        is_step()
+    sync_all()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = is_step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        import torch.distributed as dist
+
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ops = timer.summary()
+    value = n_global * args.steps / dt
+
+    # ---- roofline of the dominant kernel (algorithmic bytes per launch / HIP-event duration) ----
+    alg_bytes = {
+        "weights_stats": 24 * n_local,
+        "weights_max": 24 * n_local,
+        "weights_sums": 24 * n_local,
+        "weights_m2": 24 * n_local,
+        "normalized_weights": 32 * n_local,
+        "cdf": 16 * n_local,
+        "cdf_normalize": 16 * n_local,
+        "uniforms_pcg64": 8 * n_local,
+        "search": 24 * n_local,
+        "gather": (2 * (d * s_bytes + 24) + 8) * n_local,
+    }
+    tot = {k: c * ms for k, (c, ms) in ops.items() if k in alg_bytes}
+    dom = max(tot, key=tot.get)
+    dom_ms = ops[dom][1]
+    achieved = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(dom_ms, 4),
+                "alg_bytes_per_launch": alg_bytes[dom],
+                "per_op_ms": {k: [c // max(1, args.steps), round(ms, 4)] for k, (c, ms) in sorted(ops.items())}}
+
+    result = {
+        "metric": "particle-steps/sec (N x n_steps), 1M particles d=32; log-evidence err vs ref",
+        "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[1]: IS-only temperature iteration (bisection+ESS+evidence+resample), "
+                               f"{n_local} particles/GPU, d={d}, Gaussian target, analytic proposal N(0,1.5^2 I)",
+                   "n_steps_meaning": "temperature iterations (no mutation)", "particles_per_gpu": n_local,
+                   "global_particles": n_global, "dims": d, "x_dtype": args.x_dtype, "resample_mode": args.resample_mode,
+                   "resample_method": "multinomial", "beta_tolerance": 1e-6, "target_efficiency": 0.5,
+                   "parallelism": f"particle-shard x{world}"},
+        "roofline": roofline,
+        "scalars": {k: (float(v) if not isinstance(v, int) else v) for k, v in scal.items()},
+    }
+
+    # ---- extra: mutation path -------------------------------------------------------------------
+    if not args.no_extra:
+        extra = {}
+        mu0 = eng.asarray(np.zeros(d))
+        eye = eng.asarray(np.eye(d))
+        xm, llm, lpm, lqm = out[0].clone(), out[1].clone(), out[2].clone(), out[3].clone()
+        tgt, qm = lik.device_mixture(eng), flow.device_mixture(eng)
+        n_mc = args.mcmc_steps
+        eng.pcn_mutate(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, tgt, tgt, qm, 7, rank * n_local, 0.3, 4, 0, 0.234, True)
+        sync_all()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        n_acc, rho_hist, rho = eng.pcn_mutate(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, tgt, tgt, qm, 7,
+                                              rank * n_local, 0.3, n_mc, 4, 0.234, True)
+        ev1.record()
+        sync_all()
+        ms = ev0.elapsed_time(ev1) / n_mc
+        b_step = (2 * d * s_bytes + 16) * n_local
+        extra["pcn_kernel"] = {"ms_per_step": round(ms, 4), "particle_steps_per_s_per_gpu": n_local / (ms * 1e-3),
+                               "alg_bytes_per_step": b_step, "achieved_GBs": round(b_step / (ms * 1e-3) / 1e9, 1),
+                               "frac_of_hbm_peak": round(b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "mean_accept": float(n_acc.mean() / n_local), "rho_final": rho}
+        # one full sampler run (configs[2] shape with the analytic proposal): log-evidence check
+        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=sigma_q, seed=1, engine=eng, dtype=xdt),
+                    xp=np, engine=eng, comm=comm, rng=np.random.default_rng(2), dtype=args.x_dtype.replace("f", "float"))
+        sync_all()
+        t0 = time.perf_counter()
+        post = sp.sample(n_global, sampler_kwargs=dict(n_steps=n_mc), store_sample_history=False,
+                         resample_mode=args.resample_mode)
+        sync_all()
+        t_s = time.perf_counter() - t0
+        n_temps = len(sp.history.beta)
+        true_logz = 0.5 * d * math.log(math.pi)
+        extra["smc_pcn_run"] = {"wall_s": round(t_s, 4), "temperatures": n_temps, "mcmc_steps_per_temperature": n_mc,
+                                "particle_steps_per_s": n_global * n_temps * n_mc / t_s,
+                                "log_evidence": float(post.log_evidence), "log_evidence_error": float(post.log_evidence_error),
+                                "analytic_log_evidence": true_logz,
+                                "abs_err_in_sigma": abs(float(post.log_evidence) - true_logz) / max(float(post.log_evidence_error), 1e-300),
+                                "mean_accept": float(np.mean(sp.history.mcmc_acceptance))}
+        result["extra"] = extra
+
+    # ---- CPU baseline: the oracle (kind "port") on a bounded sample, rank 0, N=1 only ---------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O
+
+        n_cpu = min(n_local, 1_000_000)
+        xc = x[:n_cpu].double().cpu().numpy()
+        llc, lpc, lqc = (t[:n_cpu].cpu().numpy() for t in (ll, lp, lq))
+        st = O.pcg64_state_from_numpy(np.random.default_rng(12345))
+        O.is_iteration(xc[:1000], llc[:1000], lpc[:1000], lqc[:1000], 0.0, 0.5, 1e-6, st.copy())  # warm the library
+        t0 = time.perf_counter()
+        n_it = 0
+        while True:
+            (_, _, _, _), sc = O.is_iteration(xc, llc, lpc, lqc, 0.0, 0.5, 1e-6, st)
+            n_it += 1
+            el = time.perf_counter() - t0
+            if el > 12.0 or n_it >= 20:
+                break
+        result["cpu_baseline"] = {"value": n_cpu * n_it / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+                                  "sample": f"{n_it} IS-only temperature iterations of the same {n_cpu} x {d} fp64 batch "
+                                            f"(oracle/asmc_oracle.c orc_is_iteration, single thread)",
+                                  "host_cpus": os.cpu_count(), "beta": float(sc[0])}
+        result["cpu_baseline"]["beta_matches_gpu"] = bool(sc[0] == scal["beta"])
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -383,7 +383,7 @@ def test_pcn_leaves_gaussian_target_invariant(eng):
     assert np.all(np.abs(xs.mean(0)) < 0.01) and np.all(np.abs(xs.var(0) - 0.5) < 0.01)
     # adaptation drives the acceptance towards 0.234 until the step size hits its 0.99 ceiling
     assert rho == 0.99 or abs(n_acc[-10:].mean() / n - 0.234) < 0.05
-    assert np.all(np.diff(rho_hist[:5]) > 0)  # acceptance above target -> step size grows
+    assert rho_hist[1] > rho_hist[0] and np.all(np.diff(rho_hist) >= 0)  # acceptance above target -> step size grows
     np.testing.assert_allclose(ll.cpu().numpy(), -0.5 * (xs**2).sum(1), rtol=1e-12)  # carried log-probs stay consistent
 
 
