@@ -11,11 +11,12 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libasmc_hip.so")
+LIB_PATH = os.environ.get("ASMC_LIB_PATH") or os.path.join(_HERE, "libasmc_hip.so")
 
 ASMC_OK = 0
 ASMC_F64, ASMC_F32 = 0, 1
 ASMC_CDF_EXACT, ASMC_CDF_FAST = 0, 1
+ASMC_NOISE_F64, ASMC_NOISE_F32 = 0, 1
 ASMC_MAX_BETAS = 32
 ASMC_MAX_COMPONENTS = 8
 ASMC_MAX_DIMS = 256
@@ -47,7 +48,7 @@ class AsmcPcnParams(ctypes.Structure):
         ("gid0", c_uint64),
         ("target_accept", c_double),
         ("adapt", c_int32),
-        ("reserved", c_int32),
+        ("noise", c_int32),
     ]
 
 

@@ -13,6 +13,8 @@
 // per-lane row reads are bank-conflict free), processed one particle per lane, and written back
 // coalesced from the same tile.  Noise is generated in-kernel (Philox4x32-10 + Box-Muller), so one
 // pCN step moves 2*d*s + 48 bytes per particle and nothing else.
+#include <stdlib.h>
+
 #include "asmc_common.h"
 
 // =============================================================================================
@@ -58,6 +60,28 @@ __device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned lo
     sincospi(2.0 * u2, &s, &c);
     z0 = r * c;
     z1 = r * s;
+}
+
+// Fast noise (NOISE_F32): one Philox block -> FOUR standard normals through fp32 Box-Muller on the
+// hardware transcendental units (v_log_f32 / v_sin_f32 / v_cos_f32 / v_sqrt_f32):
+//   u = w*2^-32 + 2^-33 (float), t = w'*2^-32 revolutions, r = sqrt(-2 ln u), z = r (cos 2 pi t, sin 2 pi t).
+// ~1e-7 relative accuracy, tails to 6.7 sigma; 8x fewer VALU cycles than the fp64 path.
+__device__ __forceinline__ void normal_quad_f32(unsigned long long seed, unsigned long long gid, uint32_t step,
+                                                uint32_t slot, double& z0, double& z1, double& z2, double& z3) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, slot | 0x40000000u, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), w);
+    const float k = 2.3283064365386963e-10f;  // 2^-32
+    const float u0 = fmaf((float)w[0], k, 1.1641532182693481e-10f);
+    const float u1 = fmaf((float)w[2], k, 1.1641532182693481e-10f);
+    const float t0 = (float)w[1] * k, t1 = (float)w[3] * k;
+    // ln u = log2(u) * ln 2
+    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
+    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    z0 = (double)(r0 * __builtin_amdgcn_cosf(t0));
+    z1 = (double)(r0 * __builtin_amdgcn_sinf(t0));
+    z2 = (double)(r1 * __builtin_amdgcn_cosf(t1));
+    z3 = (double)(r1 * __builtin_amdgcn_sinf(t1));
 }
 
 __device__ __forceinline__ double accept_uniform(unsigned long long seed, unsigned long long gid,
@@ -183,6 +207,7 @@ struct PcnDev {
     const double* Linv;
     MixDev ll, lp, lq;
     unsigned long long seed, gid0;
+    int noise;
 };
 
 // PHASE 0: fused (propose + built-in targets + accept, in place)
@@ -308,6 +333,259 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_step(
             for (int w = 0; w < (int)(blockDim.x >> 6); w++) tsum += s_cnt[w];
             block_counts[blockIdx.x] = tsum;
         }
+    }
+}
+
+// =============================================================================================
+// fused pCN step, register resident (d == D, compile time): one particle per lane, the working
+// vector v[D] lives in VGPRs, L / Linv / mu / target parameters are wave-uniform scalar loads, both
+// triangular mat-vecs are fully unrolled FMA chains.  Rows travel HBM <-> LDS tile <-> registers
+// with 16-B accesses on every hop.
+// =============================================================================================
+template <typename T, int D>
+__device__ __forceinline__ void row_to_regs(const char* row, double (&v)[D]) {
+    constexpr int ROWB = D * (int)sizeof(T);
+#pragma unroll
+    for (int c = 0; c < ROWB / 16; c++) {
+        const uint4 q = *reinterpret_cast<const uint4*>(row + 16 * c);
+        if (sizeof(T) == 8) {
+            v[2 * c] = __longlong_as_double(((long long)q.y << 32) | (long long)q.x);
+            v[2 * c + 1] = __longlong_as_double(((long long)q.w << 32) | (long long)q.z);
+        } else {
+            v[4 * c] = (double)__uint_as_float(q.x);
+            v[4 * c + 1] = (double)__uint_as_float(q.y);
+            v[4 * c + 2] = (double)__uint_as_float(q.z);
+            v[4 * c + 3] = (double)__uint_as_float(q.w);
+        }
+    }
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void regs_to_row(char* row, const double (&v)[D]) {
+    constexpr int ROWB = D * (int)sizeof(T);
+#pragma unroll
+    for (int c = 0; c < ROWB / 16; c++) {
+        uint4 q;
+        if (sizeof(T) == 8) {
+            const long long a = __double_as_longlong(v[2 * c]), b = __double_as_longlong(v[2 * c + 1]);
+            q.x = (uint32_t)a;
+            q.y = (uint32_t)(a >> 32);
+            q.z = (uint32_t)b;
+            q.w = (uint32_t)(b >> 32);
+        } else {
+            q.x = __float_as_uint((float)v[4 * c]);
+            q.y = __float_as_uint((float)v[4 * c + 1]);
+            q.z = __float_as_uint((float)v[4 * c + 2]);
+            q.w = __float_as_uint((float)v[4 * c + 3]);
+        }
+        *reinterpret_cast<uint4*>(row + 16 * c) = q;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ double mixture_eval_regs(const MixDev& m, const double (&v)[D]) {
+    // component 0 (the only one for plain Gaussians): no exp/log
+    double q = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        const double t = v[j] - m.mu[j];
+        q = fma(t * t, m.prec[j], q);
+    }
+    double best = m.logw[0] - 0.5 * q;
+    if (m.C == 1) return best;
+    // further components: running (max, sum) log-sum-exp; runtime loop keeps the code small
+    double s = 1.0;
+#pragma unroll 1
+    for (int c = 1; c < m.C; c++) {
+        const double* __restrict__ mu = m.mu + c * D;
+        const double* __restrict__ pr = m.prec + c * D;
+        double qc = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            const double t = v[j] - mu[j];
+            qc = fma(t * t, pr[j], qc);
+        }
+        const double tc = m.logw[c] - 0.5 * qc;
+        if (tc > best) {
+            s = fma(s, exp(best - tc), 1.0);
+            best = tc;
+        } else if (tc > -INFINITY) {
+            s += exp(tc - best);
+        }
+    }
+    return best == -INFINITY ? -INFINITY : best + log(s);
+}
+
+// All read-only tables are packed into ONE `const __restrict__` buffer (ctx scratch, filled per mutate call):
+// only a noalias kernel argument lets LLVM prove the tables are not clobbered by the particle stores and
+// select scalar (s_load) instead of vector loads, and one base pointer keeps the SGPR budget for data.
+// layout (doubles): L[D*D] | Linv[D*D] | mu[D] | 3 x { logw[8] | mu[8*D] | prec[8*D] }  (ll, lp, lq)
+#define PTAB_MIX(D) (ASMC_MAX_COMPONENTS * (1 + 2 * (D)))
+#define PTAB_SIZE(D) (2 * (D) * (D) + (D) + 3 * PTAB_MIX(D))
+struct PcnScalars {
+    double beta;
+    unsigned long long seed, gid0;
+    int c_ll, c_lp, c_lq;
+};
+
+// v <- A v for a lower-triangular row-major A [D,D] (wave-uniform, read through scalar loads), in place.
+// Descending row groups of RG: rows j0-RG+1..j0 only read v[0..j0], which later (lower) groups never need
+// overwritten entries of, so the update is legal in place.
+template <int D>
+__device__ __forceinline__ void tri_matvec_inplace(const double* __restrict__ A, double (&v)[D]) {
+    constexpr int RG = D >= 4 ? 4 : D;
+#pragma unroll
+    for (int g = D / RG - 1; g >= 0; g--) {
+        const int j0 = g * RG;  // rows j0 .. j0+RG-1
+        double s[RG];
+#pragma unroll
+        for (int r = 0; r < RG; r++) s[r] = 0.0;
+#pragma unroll
+        for (int k = 0; k < j0 + RG; k++) {
+#pragma unroll
+            for (int r = 0; r < RG; r++)
+                if (k <= j0 + r) s[r] = fma(A[(j0 + r) * D + k], v[k], s[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RG; r++) v[j0 + r] = s[r];
+    }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // each wave owns its LDS tile: ordering within the wave is enough (no s_barrier, waves run decoupled)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T, int D, int NOISE>
+__global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restrict__ x, double* __restrict__ ll,
+                                                          double* __restrict__ lp, double* __restrict__ lq,
+                                                          const double* __restrict__ ptab, PcnScalars p,
+                                                          const double* __restrict__ rho_ptr, uint32_t step,
+                                                          long long* __restrict__ block_counts) {
+    extern __shared__ __align__(16) char smem[];
+    constexpr int ROWB = D * (int)sizeof(T);
+    constexpr int LDSROW = ROWB + 16;
+    constexpr int WPB = ASMC_BLOCK / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* tile = smem + (size_t)wave * 64 * LDSROW;
+    char* myrow = tile + lane * LDSROW;
+    const double rho = *rho_ptr;
+    const double a = sqrt(1.0 - rho * rho);
+    long long n_acc = 0;
+    const int64_t n_tiles = (n + 63) / 64;
+    // one 64-particle tile per wave and NO tile loop: with a loop LLVM hoists the ~1300 loop-invariant
+    // table loads and the fp64 polynomial constants out of it and then spills them
+    const int64_t t = (int64_t)blockIdx.x * WPB + wave;
+    if (t < n_tiles) {
+        const bool active = true;
+        const int64_t row0 = t * 64;
+        const int64_t i = row0 + lane;
+        const bool valid = active && i < n;
+        const int64_t valid_bytes = active ? (((n - row0) < 64 ? (n - row0) : 64) * (int64_t)ROWB) : 0;
+        char* gbase = reinterpret_cast<char*>(x) + row0 * ROWB;
+        if (active) tile_load<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane);
+        double oll = 0.0, olp = 0.0, olq = 0.0;
+        if (valid) {
+            oll = ll[i];
+            olp = lp[i];
+            olq = lq[i];
+        }
+        wave_lds_sync();
+        bool acc = false;
+        const long zoff = 0;
+        const double* __restrict__ tab = ptab + zoff;
+        const double* __restrict__ Lp = tab;
+        const double* __restrict__ Lip = tab + D * D;
+        const double* __restrict__ mup = tab + 2 * D * D;
+        const double* __restrict__ m0 = tab + 2 * D * D + D;
+        const MixDev mll = {p.c_ll, m0, m0 + ASMC_MAX_COMPONENTS, m0 + ASMC_MAX_COMPONENTS * (1 + D)};
+        const MixDev mlp = {p.c_lp, m0 + PTAB_MIX(D), m0 + PTAB_MIX(D) + ASMC_MAX_COMPONENTS,
+                            m0 + PTAB_MIX(D) + ASMC_MAX_COMPONENTS * (1 + D)};
+        const MixDev mlq = {p.c_lq, m0 + 2 * PTAB_MIX(D), m0 + 2 * PTAB_MIX(D) + ASMC_MAX_COMPONENTS,
+                            m0 + 2 * PTAB_MIX(D) + ASMC_MAX_COMPONENTS * (1 + D)};
+        if (valid) {
+            const unsigned long long gid = p.gid0 + (unsigned long long)i;
+            double v[D];
+            row_to_regs<T, D>(myrow, v);
+#pragma unroll
+            for (int j = 0; j < D; j++) v[j] -= mup[j];
+            // y = Linv (x - mu), in place; q0 = |y|^2.  Rows are processed in descending groups of RG so
+            // that RG independent FMA chains are in flight (fp64 FMA latency >> issue) and each v[k] feeds RG rows.
+            double q0 = 0.0;
+#ifndef ASMC_ABLATE_MATVEC
+            tri_matvec_inplace<D>(Lip, v);
+#endif
+#pragma unroll
+            for (int j = 0; j < D; j++) q0 = fma(v[j], v[j], q0);
+            // y' = a y + rho xi; q1 = |y'|^2
+            double q1 = 0.0;
+            if (NOISE == ASMC_NOISE_F64) {
+#pragma unroll
+                for (int pr = 0; pr < D / 2; pr++) {
+                    double z0, z1;
+                    normal_pair(p.seed, gid, step, (uint32_t)pr, z0, z1);
+                    v[2 * pr] = fma(rho, z0, a * v[2 * pr]);
+                    v[2 * pr + 1] = fma(rho, z1, a * v[2 * pr + 1]);
+                    q1 = fma(v[2 * pr], v[2 * pr], q1);
+                    q1 = fma(v[2 * pr + 1], v[2 * pr + 1], q1);
+                    __builtin_amdgcn_sched_barrier(0);  // one pair at a time (register pressure)
+                }
+            } else {
+#pragma unroll
+                for (int qd = 0; qd < D / 4; qd++) {
+                    double z[4];
+#ifndef ASMC_ABLATE_NOISE
+                    normal_quad_f32(p.seed, gid, step, (uint32_t)qd, z[0], z[1], z[2], z[3]);
+#else
+                    z[0] = z[1] = z[2] = z[3] = 0.25 * (double)(lane + qd);
+#endif
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        v[4 * qd + e] = fma(rho, z[e], a * v[4 * qd + e]);
+                        q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
+                    }
+                    if (qd & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // x' = mu + L y', rounded to the storage type
+#ifndef ASMC_ABLATE_MATVEC
+            tri_matvec_inplace<D>(Lp, v);
+#endif
+#pragma unroll
+            for (int j = 0; j < D; j++) v[j] = (double)(T)(mup[j] + v[j]);
+#ifndef ASMC_ABLATE_TARGET
+            const double nll = mixture_eval_regs<D>(mll, v);
+            const double nlp = mixture_eval_regs<D>(mlp, v);
+            const double nlq = mixture_eval_regs<D>(mlq, v);
+#else
+            const double nll = v[0], nlp = v[1], nlq = v[2];
+#endif
+            const double lpn = log_p_t(nll, nlp, nlq, p.beta);
+            const double lpo = log_p_t(oll, olp, olq, p.beta);
+            const double log_a = (lpn + 0.5 * q1) - (lpo + 0.5 * q0);
+            const double u = accept_uniform(p.seed, gid, step);
+            acc = log(u) < log_a;
+            if (acc) {
+                regs_to_row<T, D>(myrow, v);
+                ll[i] = nll;
+                lp[i] = nlp;
+                lq[i] = nlq;
+                n_acc++;
+            }
+        }
+        wave_lds_sync();
+        if (__ballot(acc) != 0ULL) tile_store<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane);
+        wave_lds_sync();
+    }
+    __shared__ long long s_cnt[WPB];
+    n_acc = wave_sum_ll(n_acc);
+    if (lane == 0) s_cnt[wave] = n_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long tsum = 0;
+        for (int w = 0; w < WPB; w++) tsum += s_cnt[w];
+        block_counts[blockIdx.x] = tsum;
     }
 }
 
@@ -541,11 +819,78 @@ static int waves_for_lds(size_t per_wave_bytes, size_t* lds_bytes_out) {
     return w;
 }
 
+// gather the caller's tables into the ctx parameter block (device-to-device, stream ordered)
+static int pack_pcn_tables(asmc_ctx* ctx, const PcnDev& pd, hipStream_t st) {
+    const int D = pd.d;
+    double* t = ctx->d_ptab;
+    const size_t dd = (size_t)D * D * sizeof(double);
+    ASMC_HIP(hipMemcpyAsync(t, pd.L, dd, hipMemcpyDeviceToDevice, st));
+    ASMC_HIP(hipMemcpyAsync(t + D * D, pd.Linv, dd, hipMemcpyDeviceToDevice, st));
+    ASMC_HIP(hipMemcpyAsync(t + 2 * D * D, pd.mu, D * sizeof(double), hipMemcpyDeviceToDevice, st));
+    double* m0 = t + 2 * D * D + D;
+    const MixDev* mixes[3] = {&pd.ll, &pd.lp, &pd.lq};
+    for (int i = 0; i < 3; i++) {
+        double* b = m0 + (size_t)i * PTAB_MIX(D);
+        const int C = mixes[i]->C;
+        ASMC_HIP(hipMemcpyAsync(b, mixes[i]->logw, C * sizeof(double), hipMemcpyDeviceToDevice, st));
+        ASMC_HIP(hipMemcpyAsync(b + ASMC_MAX_COMPONENTS, mixes[i]->mu, (size_t)C * D * sizeof(double), hipMemcpyDeviceToDevice, st));
+        ASMC_HIP(hipMemcpyAsync(b + ASMC_MAX_COMPONENTS * (1 + D), mixes[i]->prec, (size_t)C * D * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    return ASMC_OK;
+}
+
+static bool pcn_reg_supported(int d, size_t elem, const void* x) {
+    return (d == 4 || d == 8 || d == 16 || d == 32) && (d * elem) % 16 == 0 && ((uintptr_t)x % 16) == 0 &&
+           !getenv("ASMC_PCN_GENERIC");
+}
+
+template <typename T, int D, int NOISE>
+static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const PcnDev& pd,
+                          const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out, hipStream_t st) {
+    constexpr int LDSROW = D * (int)sizeof(T) + 16;
+    constexpr size_t lds_bytes = (size_t)(ASMC_BLOCK / 64) * 64 * LDSROW;
+    const int64_t n_tiles = (n + 63) / 64;
+    const int64_t grid64 = (n_tiles + ASMC_BLOCK / 64 - 1) / (ASMC_BLOCK / 64);
+    if (grid64 > ASMC_PCN_MAX_GRID) {
+        asmc_set_error("pcn: n=%lld exceeds the per-call block budget", (long long)n);
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    const int grid = (int)grid64;
+    *grid_out = grid;
+    auto kern = k_pcn_reg<T, D, NOISE>;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    PcnScalars ps;
+    ps.beta = pd.beta;
+    ps.seed = pd.seed;
+    ps.gid0 = pd.gid0;
+    ps.c_ll = pd.ll.C;
+    ps.c_lp = pd.lp.C;
+    ps.c_lq = pd.lq.C;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(ASMC_BLOCK), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
+                       rho_ptr, step, block_counts);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
 template <typename T, int PHASE>
 static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const PcnDev& pd,
                            const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
                            T* x_prop, double* qf_old, double* qf_new, hipStream_t st) {
     const int rowbytes = pd.d * (int)sizeof(T);
+    if (PHASE == 0 && pcn_reg_supported(pd.d, sizeof(T), x)) {
+        switch (pd.d * 2 + (pd.noise == ASMC_NOISE_F32 ? 1 : 0)) {  // register-resident specialisations
+#define PCN_CASE(DD)                                                                                                   \
+    case DD * 2: return launch_pcn_reg<T, DD, ASMC_NOISE_F64>(ctx, n, x, ll, lp, lq, pd, rho_ptr, step, block_counts, grid_out, st); \
+    case DD * 2 + 1: return launch_pcn_reg<T, DD, ASMC_NOISE_F32>(ctx, n, x, ll, lp, lq, pd, rho_ptr, step, block_counts, grid_out, st);
+            PCN_CASE(4)
+            PCN_CASE(8)
+            PCN_CASE(16)
+            PCN_CASE(32)
+#undef PCN_CASE
+            default: break;
+        }
+    }
     const size_t per_wave = (size_t)64 * lds_row_stride(rowbytes) + (size_t)64 * 8 * pd.d;
     size_t lds_bytes = 0;
     const int wpb = waves_for_lds(per_wave, &lds_bytes);
@@ -717,6 +1062,8 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     pd.lq = to_dev(prm->log_q);
     pd.seed = prm->seed;
     pd.gid0 = prm->gid0;
+    pd.noise = prm->noise;
+    ASMC_REQUIRE(pd.noise == ASMC_NOISE_F64 || pd.noise == ASMC_NOISE_F32, "bad noise mode");
     // device step-size cell + history
     double* d_rho = ctx->d_rho;            // [0]: current rho
     double* d_rho_hist = ctx->d_rho + 8;   // [n_steps]
@@ -725,6 +1072,10 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     ASMC_HIP(hipStreamSynchronize(st));
     ctx->h_pinned[0] = *rho_inout_host;
     ASMC_HIP(hipMemcpyAsync(d_rho, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, st));
+    if (pcn_reg_supported(pd.d, prm->x_dtype == ASMC_F64 ? 8 : 4, x)) {
+        rc = pack_pcn_tables(ctx, pd, st);
+        if (rc) return rc;
+    }
     for (int t = 0; t < n_steps; t++) {
         int grid = 0;
         if (prm->x_dtype == ASMC_F64)

@@ -276,12 +276,13 @@ class HipEngine:
         return out
 
     def pcn_mutate(self, x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed, gid0, rho, n_steps, step0=0,
-                   target_accept=0.234, adapt=True):
+                   target_accept=0.234, adapt=True, noise="f64"):
         """n_steps fused pCN steps in place.  Returns (n_accept[n_steps], rho_hist[n_steps], rho_out)."""
         self._chk3(ll, lp, lq)
         n, d = x.shape
         prm = AsmcPcnParams(d, self._xdt(x), beta, mu.data_ptr(), L.data_ptr(), Linv.data_ptr(), t_ll.c_struct(),
-                            t_lp.c_struct(), t_lq.c_struct(), seed, gid0, target_accept, int(adapt), 0)
+                            t_lp.c_struct(), t_lq.c_struct(), seed, gid0, target_accept, int(adapt),
+                            {"f64": 0, "f32": 1}[noise])
         n_acc = np.zeros(n_steps, dtype=np.int64)
         rho_hist = np.zeros(n_steps)
         rho_io = ctypes.c_double(rho)

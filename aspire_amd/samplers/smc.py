@@ -303,6 +303,9 @@ class HipSMC(SMCSampler):
         # pCN kernel and says so rather than silently substituting it
         self.sampler_kwargs.setdefault("step_fn", "pcn")
         self.sampler_kwargs.setdefault("verbose", False)
+        # proposal-noise generator of the fused kernel: "f64" (fp64 Box-Muller, matches the oracle to 1e-12)
+        # or "f32" (hardware fp32 Box-Muller, 4 normals per Philox block; the fast production mode)
+        self.sampler_kwargs.setdefault("noise", "f64")
         if self.sampler_kwargs["step_fn"] != "pcn":
             raise NotImplementedError(
                 f"step_fn={self.sampler_kwargs['step_fn']!r} is not implemented by the HIP mutation kernel; "
@@ -363,6 +366,7 @@ class HipSMC(SMCSampler):
         kwargs = self.sampler_kwargs.copy()
         n_steps = n_steps or kwargs.pop("n_steps")
         target = float(kwargs.get("target_acceptance_rate", 0.234))
+        noise = kwargs.get("noise", "f64")
         if not isinstance(self.preconditioning_transform, IdentityTransform):
             raise NotImplementedError("only the identity preconditioning transform is supported on device")
         self.fit_preconditioning_transform(particles.x)
@@ -387,14 +391,14 @@ class HipSMC(SMCSampler):
                 while done < n_steps:
                     chunk = min(n_steps - done, 2048)
                     n_acc, rho_hist, rho = e.pcn_mutate(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed,
-                                                        gid0, st["rho"], chunk, step0 + done, target, True)
+                                                        gid0, st["rho"], chunk, step0 + done, target, True, noise)
                     st["rho"] = rho
                     acc_rates.extend((n_acc / n_global).tolist())
                     done += chunk
             else:
                 for t in range(n_steps):
                     n_acc, _, _ = e.pcn_mutate(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed, gid0,
-                                               st["rho"], 1, step0 + t, target, False)
+                                               st["rho"], 1, step0 + t, target, False, noise)
                     tot = float(comm.all_gather_f64(np.array([float(n_acc[0])])).sum())
                     acc_rates.append(tot / n_global)
                     st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)

@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--x-dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--resample-mode", choices=["exact", "fast"], default="exact")
     ap.add_argument("--mcmc-steps", type=int, default=32, help="pCN steps per temperature in the extra leg")
+    ap.add_argument("--noise", choices=["f64", "f32"], default="f32", help="proposal-noise generator of the pCN kernel")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -203,12 +204,12 @@ def main():
         xm, llm, lpm, lqm = out[0].clone(), out[1].clone(), out[2].clone(), out[3].clone()
         tgt, qm = lik.device_mixture(eng), flow.device_mixture(eng)
         n_mc = args.mcmc_steps
-        eng.pcn_mutate(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, tgt, tgt, qm, 7, rank * n_local, 0.3, 4, 0, 0.234, True)
+        eng.pcn_mutate(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, tgt, tgt, qm, 7, rank * n_local, 0.3, 4, 0, 0.234, True, args.noise)
         sync_all()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         n_acc, rho_hist, rho = eng.pcn_mutate(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, tgt, tgt, qm, 7,
-                                              rank * n_local, 0.3, n_mc, 4, 0.234, True)
+                                              rank * n_local, 0.3, n_mc, 4, 0.234, True, args.noise)
         ev1.record()
         sync_all()
         ms = ev0.elapsed_time(ev1) / n_mc
@@ -216,13 +217,13 @@ def main():
         extra["pcn_kernel"] = {"ms_per_step": round(ms, 4), "particle_steps_per_s_per_gpu": n_local / (ms * 1e-3),
                                "alg_bytes_per_step": b_step, "achieved_GBs": round(b_step / (ms * 1e-3) / 1e9, 1),
                                "frac_of_hbm_peak": round(b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                               "mean_accept": float(n_acc.mean() / n_local), "rho_final": rho}
+                               "mean_accept": float(n_acc.mean() / n_local), "rho_final": rho, "noise": args.noise}
         # one full sampler run (configs[2] shape with the analytic proposal): log-evidence check
         sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=sigma_q, seed=1, engine=eng, dtype=xdt),
                     xp=np, engine=eng, comm=comm, rng=np.random.default_rng(2), dtype=args.x_dtype.replace("f", "float"))
         sync_all()
         t0 = time.perf_counter()
-        post = sp.sample(n_global, sampler_kwargs=dict(n_steps=n_mc), store_sample_history=False,
+        post = sp.sample(n_global, sampler_kwargs=dict(n_steps=n_mc, noise=args.noise), store_sample_history=False,
                          resample_mode=args.resample_mode)
         sync_all()
         t_s = time.perf_counter() - t0

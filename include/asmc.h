@@ -48,6 +48,9 @@ extern "C" {
 #define ASMC_MAX_COMPONENTS 8  /* mixture components of a built-in density */
 #define ASMC_MAX_DIMS 256
 
+#define ASMC_NOISE_F64 0
+#define ASMC_NOISE_F32 1
+
 #define ASMC_CDF_EXACT 0 /* sequential-order fp64 rounding == numpy cumsum (bit-exact) */
 #define ASMC_CDF_FAST 1  /* parallel-order rounding */
 
@@ -82,7 +85,9 @@ typedef struct {
     uint64_t gid0;            /* global index of local particle 0 (sharded runs) */
     double target_accept;     /* e.g. 0.234 (reference minipcn.py:47) */
     int32_t adapt;            /* 1: Robbins-Monro step-size adaptation on device */
-    int32_t reserved;
+    int32_t noise;            /* ASMC_NOISE_F64: fp64 Box-Muller, 2 normals / Philox block (1e-15 parity with
+                                 the oracle); ASMC_NOISE_F32: fp32 hardware Box-Muller, 4 normals / block
+                                 (fast; honoured by the register-resident kernels, d in {4,8,16,32}) */
 } asmc_pcn_params;
 
 /* ---- library / context ---------------------------------------------------------------- */

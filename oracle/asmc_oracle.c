@@ -466,6 +466,29 @@ void orc_pcn_noise(uint64_t seed, uint64_t gid, uint32_t step, int d, double* xi
     *u_acc = u01_from_words(w[0], w[1]);
 }
 
+/* Fast noise mode (ASMC_NOISE_F32): one Philox block -> four normals by fp32 Box-Muller.
+ * Counter slot = quad index | 0x40000000.  The GPU uses the hardware transcendental units, so parity with
+ * this libm restatement is ~1e-6 relative, not bitwise. */
+void orc_pcn_noise_f32(uint64_t seed, uint64_t gid, uint32_t step, int d, double* xi, double* u_acc) {
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t ctr[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), step, 0};
+    uint32_t w[4];
+    const float k = 2.3283064365386963e-10f, h = 1.1641532182693481e-10f;
+    for (int q = 0; 4 * q < d; q++) {
+        ctr[3] = (uint32_t)q | 0x40000000u;
+        orc_philox4x32_10(ctr, key, w);
+        float u0 = fmaf((float)w[0], k, h), u1 = fmaf((float)w[2], k, h);
+        float t0 = (float)w[1] * k, t1 = (float)w[3] * k;
+        float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u1));
+        float z[4] = {r0 * cosf(6.28318530717958647692f * t0), r0 * sinf(6.28318530717958647692f * t0),
+                      r1 * cosf(6.28318530717958647692f * t1), r1 * sinf(6.28318530717958647692f * t1)};
+        for (int e = 0; e < 4 && 4 * q + e < d; e++) xi[4 * q + e] = (double)z[e];
+    }
+    ctr[3] = 0xFFFFFFFFu;
+    orc_philox4x32_10(ctr, key, w);
+    *u_acc = u01_from_words(w[0], w[1]);
+}
+
 /* Built-in device targets: each of log_likelihood / log_prior / log_q is a
  * diagonal-Gaussian-mixture log-density
  *     log sum_c exp( logw_c - 0.5 * sum_j (x_j - mu_cj)^2 * prec_cj )          (C components)
@@ -510,7 +533,7 @@ typedef struct {
 int64_t orc_pcn_step(int64_t n, int d, double* x, double* ll, double* lp, double* lq, double beta,
                      const double* mu, const double* L, const double* Linv, double rho,
                      const orc_mixture* t_ll, const orc_mixture* t_lp, const orc_mixture* t_lq,
-                     uint64_t seed, uint64_t gid0, uint32_t step) {
+                     uint64_t seed, uint64_t gid0, uint32_t step, int noise_f32) {
     int64_t n_acc = 0;
     double* buf = (double*)malloc(sizeof(double) * (size_t)d * 4);
     double *y = buf, *yp = buf + d, *xp = buf + 2 * d, *xi = buf + 3 * d;
@@ -518,7 +541,8 @@ int64_t orc_pcn_step(int64_t n, int d, double* x, double* ll, double* lp, double
     for (int64_t i = 0; i < n; i++) {
         double* xr = x + (size_t)i * d;
         double u;
-        orc_pcn_noise(seed, gid0 + (uint64_t)i, step, d, xi, &u);
+        if (noise_f32) orc_pcn_noise_f32(seed, gid0 + (uint64_t)i, step, d, xi, &u);
+        else orc_pcn_noise(seed, gid0 + (uint64_t)i, step, d, xi, &u);
         double q0 = 0.0, q1 = 0.0;
         for (int j = 0; j < d; j++) {
             double s = 0.0;

@@ -74,8 +74,9 @@ def lib():
             "orc_diag_mixture_logpdf": (d, [ci, ci, vp, vp, vp, vp]),
             "orc_pcn_step": (
                 i64,
-                [i64, ci, vp, vp, vp, vp, d, vp, vp, vp, d, vp, vp, vp, u64, u64, u32],
+                [i64, ci, vp, vp, vp, vp, d, vp, vp, vp, d, vp, vp, vp, u64, u64, u32, ci],
             ),
+            "orc_pcn_noise_f32": (None, [u64, u64, u32, ci, vp, vp]),
             "orc_pcn_adapt": (d, [d, d, d, ci]),
             "orc_moments": (None, [i64, ci, vp, vp, vp]),
             "orc_is_iteration": (ci, [i64, ci, vp, vp, vp, vp, d, d, d, vp, vp, vp, vp, vp, vp]),
@@ -292,10 +293,11 @@ def philox4x32_10(ctr, key):
     return out
 
 
-def pcn_noise(seed, gid, step, d):
+def pcn_noise(seed, gid, step, d, noise="f64"):
     xi = np.empty(d)
     u = ctypes.c_double(0)
-    lib().orc_pcn_noise(seed, gid, step, d, _p(xi), ctypes.addressof(u))
+    fn = lib().orc_pcn_noise if noise == "f64" else lib().orc_pcn_noise_f32
+    fn(seed, gid, step, d, _p(xi), ctypes.addressof(u))
     return xi, u.value
 
 
@@ -322,7 +324,7 @@ class Mixture:
         )
 
 
-def pcn_step(x, ll, lp, lq, beta, mu, L, Linv, rho, t_ll, t_lp, t_lq, seed, gid0, step):
+def pcn_step(x, ll, lp, lq, beta, mu, L, Linv, rho, t_ll, t_lp, t_lq, seed, gid0, step, noise="f64"):
     """In-place pCN step on numpy arrays; returns #accepted."""
     assert x.dtype == np.float64 and x.flags.c_contiguous
     n, d = x.shape
@@ -330,7 +332,7 @@ def pcn_step(x, ll, lp, lq, beta, mu, L, Linv, rho, t_ll, t_lp, t_lq, seed, gid0
     a, b, c = t_ll.c_struct(), t_lp.c_struct(), t_lq.c_struct()
     return lib().orc_pcn_step(
         n, d, _p(x), _p(ll), _p(lp), _p(lq), beta, _p(mu), _p(L), _p(Linv), rho,
-        ctypes.addressof(a), ctypes.addressof(b), ctypes.addressof(c), seed, gid0, step,
+        ctypes.addressof(a), ctypes.addressof(b), ctypes.addressof(c), seed, gid0, step, int(noise == "f32"),
     )
 
 

@@ -156,14 +156,14 @@ class OracleEngine:
         return c.T @ c
 
     def pcn_mutate(self, x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed, gid0, rho, n_steps, step0=0,
-                   target_accept=0.234, adapt=True):
+                   target_accept=0.234, adapt=True, noise="f64"):
         assert x.dtype == torch.float64
         n = x.shape[0]
         n_acc, hist = np.zeros(n_steps, dtype=np.int64), np.zeros(n_steps)
         for t in range(n_steps):
             hist[t] = rho
             n_acc[t] = O.pcn_step(_np(x), _np(ll), _np(lp), _np(lq), beta, _np(mu), _np(L), _np(Linv), rho,
-                                  t_ll.mix, t_lp.mix, t_lq.mix, seed, gid0, step0 + t)
+                                  t_ll.mix, t_lp.mix, t_lq.mix, seed, gid0, step0 + t, noise)
             if adapt:
                 rho = O.pcn_adapt(rho, n_acc[t] / n, target_accept, t)
         return n_acc, hist, rho

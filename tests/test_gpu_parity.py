@@ -346,6 +346,41 @@ def test_pcn_step_vs_oracle(eng, oracle, d, C):
     assert 0.02 < n_acc[0] / n < 0.98
 
 
+def test_pcn_fast_noise_vs_oracle(eng, oracle):
+    """ASMC_NOISE_F32 (hardware fp32 Box-Muller): proposals within 2e-6 of the libm restatement, accept
+    decisions equal except for a handful of razor-edge cases; noise is standard normal."""
+    d, n = 32, 4000
+    x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 5)
+    om = [oracle.Mixture(*m) for m in mixes]
+    ll, lp, lq = (m.logpdf(x) for m in om)
+    dm = [eng.make_mixture(*m) for m in mixes]
+    xd, lld, lpd, lqd = dev(eng, x, ll, lp, lq)
+    n_acc, _, _ = eng.pcn_mutate(xd, lld, lpd, lqd, 0.37, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), dm[0], dm[1],
+                                 dm[2], 99, 7, 0.4, 1, 3, 0.234, False, "f32")
+    xr, llr, lpr, lqr = x.copy(), ll.copy(), lp.copy(), lq.copy()
+    acc_ref = oracle.pcn_step(xr, llr, lpr, lqr, 0.37, mu, L, Linv, 0.4, om[0], om[1], om[2], 99, 7, 3, noise="f32")
+    got = xd.cpu().numpy()
+    moved_g, moved_r = np.any(got != x, axis=1), np.any(xr != x, axis=1)
+    assert (moved_g != moved_r).sum() <= 4
+    same = moved_g == moved_r
+    np.testing.assert_allclose(got[same], xr[same], rtol=1e-5, atol=2e-5)
+    assert abs(int(n_acc[0]) - acc_ref) <= 4
+    # distribution of the fast normals: recover xi from a pure-noise step (rho = 1, identity reference)
+    from scipy import stats
+
+    n2, d2 = 200000, 4
+    tgt = eng.make_mixture([0.0], np.zeros((1, d2)), np.full((1, d2), 1e-30))  # flat target: always accept
+    x0 = eng.asarray(np.zeros((n2, d2)))
+    z = torch.zeros(n2, dtype=torch.float64, device=eng.device)
+    eye = eng.asarray(np.eye(d2))
+    na, _, _ = eng.pcn_mutate(x0, z.clone(), z.clone(), z.clone(), 1.0, eng.asarray(np.zeros(d2)), eye, eye, tgt, tgt, tgt,
+                              5, 0, 1.0, 1, 0, 0.234, False, "f32")
+    xi = x0.cpu().numpy()  # flat target, rho = 1, y = 0: every proposal is accepted and equals the noise draw
+    assert int(na[0]) == n2
+    assert stats.kstest(xi.ravel(), "norm").pvalue > 1e-3
+    assert abs(np.mean(xi[:, 0] * xi[:, 1])) < 0.01 and abs(np.mean(xi[:, 2] * xi[:, 3])) < 0.01
+
+
 def test_pcn_split_path_equals_fused(eng, oracle):
     n, d = 2000, 8
     x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 77)
