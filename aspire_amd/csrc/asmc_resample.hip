@@ -51,70 +51,102 @@ __device__ __forceinline__ void td_of(double w, int e, long long& a0, long long&
     a1 = n + (tie ? ((n + 1) & 1) : up);  // running integer odd
 }
 
-#define EX_THREADS 1024
-#define EX_E 4
-#define EX_CHUNK (EX_THREADS * EX_E)
+// ---- block-level ordered scan of transducers --------------------------------------------------
+#define XT_THREADS ASMC_BLOCK
+#define XT_E (ASMC_SCAN_TILE / ASMC_BLOCK)  // 8 elements per thread, one 2048-element tile per block pass
 
-__global__ __launch_bounds__(EX_THREADS) void k_cdf_exact(int64_t n, const double* __restrict__ w,
-                                                         double* __restrict__ cdf, double carry_in,
-                                                         double* __restrict__ total_out) {
-    __shared__ double sh_s;
-    __shared__ long long sh_pos;
-    __shared__ long long sh_cross;
-    __shared__ TD sh_wave[EX_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// in: `mine` = composition of this thread's elements.  out: excl = composition of all lower threads,
+// total = composition of the whole block (valid in every thread).  sh: [XT_THREADS/64 + 1] TDs.
+__device__ __forceinline__ void td_block_scan(TD mine, TD& excl, TD& total, TD* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    TD inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        TD t;
+        t.a0 = __shfl_up(inc.a0, o, 64);
+        t.a1 = __shfl_up(inc.a1, o, 64);
+        if (lane >= o) inc = td_compose(t, inc);
+    }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    TD wave_prefix = {0, 0};
+    TD tot = {0, 0};
+#pragma unroll
+    for (int v = 0; v < XT_THREADS / 64; v++) {
+        if (v < wave) wave_prefix = td_compose(wave_prefix, sh[v]);
+        tot = td_compose(tot, sh[v]);
+    }
+    excl.a0 = __shfl_up(inc.a0, 1, 64);
+    excl.a1 = __shfl_up(inc.a1, 1, 64);
+    if (lane == 0) excl = TD{0, 0};
+    excl = td_compose(wave_prefix, excl);
+    total = tot;
+    __syncthreads();  // sh may be reused by the caller
+}
+
+__device__ __forceinline__ long long readlane_ll(long long v, int lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xFFFFFFFFLL), lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), lane);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ int binade_of(double s) {
+    int e = (s > 0.0) ? ilogb(s) : -1022;
+    return e < -1022 ? -1022 : e;
+}
+
+// Exact sequential-order cumulative sum of ONE tile w[lo, hi) (hi - lo <= 2048) starting from the exact
+// running sum s0, by the whole block.  Each thread owns 8 fixed elements (loaded once); every pass scans the
+// still-open elements on the grid of the current binade and restarts behind the first element whose add
+// leaves the binade (that add is a genuine fp64 add).  Returns the exact running sum at `hi`.
+__device__ double exact_tile(const double* __restrict__ w, double* __restrict__ cdf, int64_t lo, int64_t hi,
+                             double s0, TD* sh_td, double* sh_s, long long* sh_pos, long long* sh_cross) {
+    const int tid = threadIdx.x;
+    const int64_t base = lo + (int64_t)tid * XT_E;
+    double wv[XT_E];
+#pragma unroll
+    for (int j = 0; j < XT_E; j++) wv[j] = (base + j < hi) ? w[base + j] : 0.0;
     if (tid == 0) {
-        sh_s = carry_in;
-        sh_pos = 0;
+        double s = s0;
+        long long pos = lo;
+        if (lo == 0) {  // the very first elements change binade at almost every add: plain sequential adds
+            const int64_t lim = hi < 64 ? hi : 64;
+            for (; pos < lim; pos++) {
+                s = s + w[pos];
+                cdf[pos] = s;
+            }
+        }
+        *sh_s = s;
+        *sh_pos = pos;
     }
     __syncthreads();
     while (true) {
-        const long long pos = sh_pos;
-        const double s = sh_s;
-        if (pos >= n) break;
-        __syncthreads();  // everyone has read sh_pos / sh_s
-        if (tid == 0) sh_cross = INT64_MAX;
-        int e = (s > 0.0) ? ilogb(s) : -1022;
-        if (e < -1022) e = -1022;
+        const long long pos = *sh_pos;
+        const double s = *sh_s;
+        if (pos >= hi) break;
+        __syncthreads();  // everyone has read the state
+        if (tid == 0) *sh_cross = INT64_MAX;
+        const int e = binade_of(s);
         const long long S0 = (long long)ldexp(s, 52 - e);
-        const int64_t base = pos + (int64_t)tid * EX_E;
-        double wv[EX_E];
-        long long ta0[EX_E], ta1[EX_E], nf[EX_E];
+        long long ta0[XT_E], ta1[XT_E], nf[XT_E];
         TD mine = {0, 0};
 #pragma unroll
-        for (int j = 0; j < EX_E; j++) {
+        for (int j = 0; j < XT_E; j++) {
             const int64_t i = base + j;
-            wv[j] = (i < n) ? w[i] : 0.0;
-            td_of(wv[j], e, ta0[j], ta1[j], nf[j]);  // w = 0 -> identity transducer
+            td_of((i >= pos && i < hi) ? wv[j] : 0.0, e, ta0[j], ta1[j], nf[j]);  // closed elements: identity
             mine = td_compose(mine, TD{ta0[j], ta1[j]});
         }
-        // inclusive scan of `mine` over the block (lower tid first)
-        TD inc = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            TD t;
-            t.a0 = __shfl_up(inc.a0, o, 64);
-            t.a1 = __shfl_up(inc.a1, o, 64);
-            if (lane >= o) inc = td_compose(t, inc);
-        }
-        if (lane == 63) sh_wave[wave] = inc;
-        __syncthreads();
-        TD wave_prefix = {0, 0};
-        for (int v = 0; v < wave; v++) wave_prefix = td_compose(wave_prefix, sh_wave[v]);
-        // exclusive prefix of this thread
-        TD excl;
-        excl.a0 = __shfl_up(inc.a0, 1, 64);
-        excl.a1 = __shfl_up(inc.a1, 1, 64);
-        if (lane == 0) excl = TD{0, 0};
-        excl = td_compose(wave_prefix, excl);
+        TD excl, total;
+        td_block_scan(mine, excl, total, sh_td);  // contains __syncthreads: the sh_cross reset is visible after it
         long long S = S0 + ((S0 & 1) ? excl.a1 : excl.a0);
         const long long S_in = S;
-        long long Sout[EX_E];
-        int cross_j = EX_E;
+        long long Sout[XT_E];
+        int cross_j = XT_E;
 #pragma unroll
-        for (int j = 0; j < EX_E; j++) {
-            if (cross_j == EX_E) {
-                if (base + j < n && S + nf[j] >= TWO53_LL) {
+        for (int j = 0; j < XT_E; j++) {
+            const int64_t i = base + j;
+            if (cross_j == XT_E) {
+                if (i >= pos && i < hi && S + nf[j] >= TWO53_LL) {
                     cross_j = j;
                 } else {
                     S += (S & 1) ? ta1[j] : ta0[j];
@@ -122,42 +154,185 @@ __global__ __launch_bounds__(EX_THREADS) void k_cdf_exact(int64_t n, const doubl
             }
             Sout[j] = S;
         }
-        if (cross_j < EX_E) atomicMin((long long*)&sh_cross, (long long)(base + cross_j));
+        if (cross_j < XT_E) atomicMin(sh_cross, (long long)(base + cross_j));
         __syncthreads();
-        const long long c = sh_cross;  // first crossing index (global) or INT64_MAX
-        long long chunk_end = pos + EX_CHUNK;
-        if (chunk_end > n) chunk_end = n;
+        const long long c = *sh_cross;  // first crossing index (global) or INT64_MAX
 #pragma unroll
-        for (int j = 0; j < EX_E; j++) {
+        for (int j = 0; j < XT_E; j++) {
             const int64_t i = base + j;
-            if (i < chunk_end && i < c) cdf[i] = ldexp((double)Sout[j], e - 52);
+            if (i >= pos && i < hi && i < c) cdf[i] = ldexp((double)Sout[j], e - 52);
         }
-        if (c < chunk_end) {
-            // owner of the crossing element: genuine fp64 add, restart behind it
+        if (c < hi) {
 #pragma unroll
-            for (int j = 0; j < EX_E; j++) {
-                if (c == base + j) {
+            for (int j = 0; j < XT_E; j++) {
+                if (c == base + j) {  // owner of the crossing element: genuine fp64 add, restart behind it
                     const long long Sprev = (j == 0) ? S_in : Sout[j > 0 ? j - 1 : 0];
-                    const double prev = (c == pos) ? s : ldexp((double)Sprev, e - 52);
-                    const double s_new = prev + wv[j];
+                    const double s_new = ldexp((double)Sprev, e - 52) + wv[j];
                     cdf[c] = s_new;
-                    sh_s = s_new;
-                    sh_pos = c + 1;
+                    *sh_s = s_new;
+                    *sh_pos = c + 1;
                 }
             }
         } else {
-            // the state after the last valid element: held by the thread owning chunk_end - 1
-#pragma unroll
-            for (int j = 0; j < EX_E; j++) {
-                if (chunk_end - 1 == base + j) {
-                    sh_s = ldexp((double)Sout[j], e - 52);
-                    sh_pos = chunk_end;
-                }
+            if (tid == XT_THREADS - 1) {  // no crossing left: the block total is the state after the tile
+                const long long Send = S0 + ((S0 & 1) ? total.a1 : total.a0);
+                *sh_s = ldexp((double)Send, e - 52);
+                *sh_pos = hi;
             }
         }
         __syncthreads();
     }
-    if (tid == 0) *total_out = sh_s;
+    return *sh_s;
+}
+
+// ---- multi-tile exact cdf ---------------------------------------------------------------------------
+// Pass C: per tile, from the APPROXIMATE incoming prefix (fast scan) guess the binade; if the whole tile
+// sits comfortably inside it ("safe"), compose the tile's elements into one transducer on that grid.
+// tile_info layout (long long, 4 per tile): {a0, a1, e, safe}
+__device__ __forceinline__ void k_exact_tile_td_body(int64_t n, const double* __restrict__ w,
+                                                             const double* __restrict__ approx_prefix,
+                                                             double approx_total, int64_t n_tiles,
+                                                             long long* __restrict__ tile_info) {
+    __shared__ TD sh_td[XT_THREADS / 64 + 1];
+    const int64_t t = blockIdx.x;
+    const double lo = approx_prefix[t];
+    const double hi = (t + 1 < n_tiles) ? approx_prefix[t + 1] : approx_total;
+    const int e = binade_of(lo);
+    const double b0 = ldexp(1.0, e), b1 = ldexp(1.0, e + 1);
+    const bool safe = (lo > 0.0) && (lo >= b0 * (1.0 + 1e-9)) && (hi <= b1 * (1.0 - 1e-9)) && (hi >= lo);
+    TD mine = {0, 0};
+    if (safe) {
+        const int64_t base = t * ASMC_SCAN_TILE + (int64_t)threadIdx.x * XT_E;
+#pragma unroll
+        for (int j = 0; j < XT_E; j++) {
+            const int64_t i = base + j;
+            long long a0, a1, nf;
+            td_of((i < n) ? w[i] : 0.0, e, a0, a1, nf);
+            mine = td_compose(mine, TD{a0, a1});
+        }
+    }
+    TD excl, total;
+    td_block_scan(mine, excl, total, sh_td);
+    if (threadIdx.x == 0) {
+        tile_info[4 * t + 0] = total.a0;
+        tile_info[4 * t + 1] = total.a1;
+        tile_info[4 * t + 2] = e;
+        tile_info[4 * t + 3] = safe ? 1 : 0;
+    }
+}
+
+// launch shim: the approximate total is still on the device (no host round trip)
+__global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_launch(int64_t n, const double* __restrict__ w,
+                                                                    const double* __restrict__ approx_prefix,
+                                                                    const double* __restrict__ approx_total,
+                                                                    int64_t n_tiles, long long* __restrict__ tile_info) {
+    k_exact_tile_td_body(n, w, approx_prefix, *approx_total, n_tiles, tile_info);
+}
+
+// Pass D: one block chains the EXACT running sum through the tiles.  Safe tiles cost O(1) (verify the binade
+// guess against the exact incoming sum, apply the tile transducer); any tile that fails the check or was
+// flagged unsafe is processed element-wise by exact_range.  tile_s[t] = exact sum entering tile t;
+// tile_info[4t+3] becomes 1 if pass E must still write the tile, 0 if it has been written here.
+__global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const double* __restrict__ w,
+                                                           double* __restrict__ cdf, double carry_in,
+                                                           int64_t n_tiles, long long* __restrict__ tile_info,
+                                                           double* __restrict__ tile_s,
+                                                           double* __restrict__ total_out) {
+    __shared__ TD sh_td[XT_THREADS / 64 + 1];
+    __shared__ double sh_s, sh_walk_s;
+    __shared__ long long sh_pos, sh_cross, sh_walk_t;
+    int64_t t = 0;
+    double s = carry_in;
+    while (t < n_tiles) {
+        // wave 0 walks up to 64 tiles per round: lane l holds tile t+l's record, the chain itself is a scalar
+        // recurrence evaluated redundantly by all lanes on values broadcast with readlane (no memory latency
+        // inside the dependent chain)
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            const int64_t my_t = t + lane;
+            long long a0 = 0, a1 = 0, ee = 0, sf = 0;
+            if (my_t < n_tiles) {
+                a0 = tile_info[4 * my_t + 0];
+                a1 = tile_info[4 * my_t + 1];
+                ee = tile_info[4 * my_t + 2];
+                sf = tile_info[4 * my_t + 3];
+            }
+            // chain state as (integer S on the grid of binade e_cur): consecutive safe tiles of one binade
+            // are pure integer adds; anything else (binade change, overflow of the grid, unsafe flag) stops
+            // the walk and goes through exact_tile
+            const int e_cur = binade_of(s);
+            long long S = (s > 0.0) ? (long long)ldexp(s, 52 - e_cur) : -1;
+            long long my_S = 0;
+            int stop = 64;
+            for (int i = 0; i < 64; i++) {
+                const long long a0i = readlane_ll(a0, i), a1i = readlane_ll(a1, i);
+                const int ei = __builtin_amdgcn_readlane((int)ee, i);
+                const int sfi = __builtin_amdgcn_readlane((int)sf, i);
+                const long long Sout = S + ((S & 1) ? a1i : a0i);
+                if (!(sfi == 1 && S >= 0 && ei == e_cur && Sout < TWO53_LL)) {
+                    stop = i;
+                    break;
+                }
+                if (lane == i) my_S = S;
+                S = Sout;
+            }
+            const double my_s = ldexp((double)my_S, e_cur - 52);
+            const double ss = (stop > 0) ? ldexp((double)S, e_cur - 52) : s;
+            if (lane < stop) tile_s[my_t] = my_s;
+            if (lane == 0) {
+                sh_walk_t = t + stop;
+                sh_walk_s = ss;
+            }
+        }
+        __syncthreads();
+        const bool advanced_full = (sh_walk_t == t + 64);
+        t = sh_walk_t;
+        s = sh_walk_s;
+        __syncthreads();
+        if (advanced_full) continue;
+        if (t >= n_tiles) break;
+        // tile t needs the element-wise treatment
+        const int64_t lo = t * ASMC_SCAN_TILE;
+        const int64_t hi = (lo + ASMC_SCAN_TILE < n) ? lo + ASMC_SCAN_TILE : n;
+        if (threadIdx.x == 0) {
+            tile_info[4 * t + 3] = 0;
+            tile_s[t] = s;
+        }
+        s = exact_tile(w, cdf, lo, hi, s, sh_td, &sh_s, &sh_pos, &sh_cross);
+        __syncthreads();
+        t++;
+    }
+    if (threadIdx.x == 0) *total_out = s;
+}
+
+// Pass E: write the safe tiles from their exact incoming sums (integer scan on the tile's grid).
+__global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, const double* __restrict__ w,
+                                                                double* __restrict__ cdf,
+                                                                const long long* __restrict__ tile_info,
+                                                                const double* __restrict__ tile_s) {
+    __shared__ TD sh_td[XT_THREADS / 64 + 1];
+    const int64_t t = blockIdx.x;
+    if (tile_info[4 * t + 3] != 1) return;  // uniform per block
+    const int e = (int)tile_info[4 * t + 2];
+    const long long S0 = (long long)ldexp(tile_s[t], 52 - e);
+    const int64_t base = t * ASMC_SCAN_TILE + (int64_t)threadIdx.x * XT_E;
+    long long ta0[XT_E], ta1[XT_E];
+    TD mine = {0, 0};
+#pragma unroll
+    for (int j = 0; j < XT_E; j++) {
+        const int64_t i = base + j;
+        long long nf;
+        td_of((i < n) ? w[i] : 0.0, e, ta0[j], ta1[j], nf);
+        mine = td_compose(mine, TD{ta0[j], ta1[j]});
+    }
+    TD excl, total;
+    td_block_scan(mine, excl, total, sh_td);
+    long long S = S0 + ((S0 & 1) ? excl.a1 : excl.a0);
+#pragma unroll
+    for (int j = 0; j < XT_E; j++) {
+        S += (S & 1) ? ta1[j] : ta0[j];
+        if (base + j < n) cdf[base + j] = ldexp((double)S, e - 52);
+    }
 }
 
 // =============================================================================================
@@ -495,7 +670,22 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
     hipStream_t st = as_stream(stream);
     double* d_total = ctx->d_small + 1024;
     if (mode == ASMC_CDF_EXACT) {
-        hipLaunchKernelGGL(k_cdf_exact, dim3(1), dim3(EX_THREADS), 0, st, n, w, cdf, carry_in, d_total);
+        // A+B: approximate (parallel-order) tile prefixes; C: per-tile transducers; D: exact chain; E: write
+        const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+        double* d_tile_s = ctx->d_tiles + ctx->n_tiles_max * 2;
+        double* d_approx_total = ctx->d_small + 1025;
+        hipLaunchKernelGGL(k_tile_sum, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w, ctx->d_tiles);
+        ASMC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, carry_in, d_approx_total);
+        ASMC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_exact_tile_td_launch, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w,
+                           (const double*)ctx->d_tiles, (const double*)d_approx_total, n_tiles, ctx->d_tiles_i);
+        ASMC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_exact_chain, dim3(1), dim3(XT_THREADS), 0, st, n, w, cdf, carry_in, n_tiles,
+                           ctx->d_tiles_i, d_tile_s, d_total);
+        ASMC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_exact_tile_write, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w, cdf,
+                           (const long long*)ctx->d_tiles_i, (const double*)d_tile_s);
         ASMC_LAUNCH_CHECK();
     } else if (mode == ASMC_CDF_FAST) {
         const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
