@@ -62,6 +62,8 @@ SIGNATURES = {
     "asmc_device_count": (_i, [POINTER(c_int)]),
     "asmc_ctx_create": (_i, [POINTER(c_void_p), _i, _i64, _i]),
     "asmc_ctx_destroy": (_i, [_vp]),
+    "asmc_profile_enable": (_i, [_vp, _i]),
+    "asmc_profile_report": (_i, [_vp, c_char_p, _i64]),
     "asmc_weights_max": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _pd, _i, _pd, _pi64, _vp]),
     "asmc_weights_sums": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _pd, _pd, _pd, _i, _pd, _vp]),
     "asmc_weights_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _pd, _i, _pd, _vp]),

@@ -15,6 +15,18 @@
 #define ASMC_MAX_PCN_STEPS 2048 // per asmc_pcn_mutate call (bounded by the pinned staging buffer)
 
 void asmc_set_error(const char* fmt, ...);
+struct asmc_ctx;
+void asmc_prof_begin(asmc_ctx* ctx, const char* label, hipStream_t st);
+void asmc_prof_end(asmc_ctx* ctx, hipStream_t st);
+#define ASMC_PROF_MAX 8192
+// every kernel goes through this macro so that bench.py can time individual kernels with HIP events recorded on
+// the stream the kernel is launched on
+#define ASMC_LAUNCH(ctx, st, label, ...)   \
+    do {                                   \
+        asmc_prof_begin((ctx), (label), (st)); \
+        hipLaunchKernelGGL(__VA_ARGS__);   \
+        asmc_prof_end((ctx), (st));        \
+    } while (0)
 
 #define ASMC_HIP(call)                                                                      \
     do {                                                                                    \
@@ -64,6 +76,11 @@ struct asmc_ctx {
     int gram_blocks;
     unsigned long long pcg_inc[2];  // increment the device jump table was built for
     int pcg_tab_valid;
+    // optional per-kernel HIP-event timing (asmc_profile_enable / asmc_profile_report)
+    int prof_on;
+    int prof_n;
+    hipEvent_t* prof_ev;        // [2 * ASMC_PROF_MAX]
+    const char** prof_label;    // [ASMC_PROF_MAX]
     // pinned host staging for scalar read-back / small uploads
     double* h_pinned;  // [8192] doubles
 };

@@ -12,7 +12,67 @@ void asmc_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+void asmc_prof_begin(asmc_ctx* ctx, const char* label, hipStream_t st) {
+    if (!ctx || !ctx->prof_on || ctx->prof_n >= ASMC_PROF_MAX) return;
+    ctx->prof_label[ctx->prof_n] = label;
+    (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n], st);
+}
+
+void asmc_prof_end(asmc_ctx* ctx, hipStream_t st) {
+    if (!ctx || !ctx->prof_on || ctx->prof_n >= ASMC_PROF_MAX) return;
+    (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], st);
+    ctx->prof_n++;
+}
+
 extern "C" {
+
+int asmc_profile_enable(asmc_ctx* ctx, int on) {
+    ASMC_REQUIRE(ctx != nullptr, "null ctx");
+    if (on && !ctx->prof_ev) {
+        ctx->prof_ev = new (std::nothrow) hipEvent_t[2 * ASMC_PROF_MAX];
+        ctx->prof_label = new (std::nothrow) const char*[ASMC_PROF_MAX];
+        if (!ctx->prof_ev || !ctx->prof_label) {
+            asmc_set_error("out of host memory");
+            return ASMC_ERR_NOMEM;
+        }
+        for (int i = 0; i < 2 * ASMC_PROF_MAX; i++) ASMC_HIP(hipEventCreate(&ctx->prof_ev[i]));
+    }
+    ctx->prof_on = on ? 1 : 0;
+    if (on) ctx->prof_n = 0;
+    return ASMC_OK;
+}
+
+int asmc_profile_report(asmc_ctx* ctx, char* buf, int64_t buf_len) {
+    ASMC_REQUIRE(ctx && buf && buf_len > 0, "bad arguments");
+    buf[0] = 0;
+    if (!ctx->prof_ev || ctx->prof_n == 0) return ASMC_OK;
+    ASMC_HIP(hipEventSynchronize(ctx->prof_ev[2 * (ctx->prof_n - 1) + 1]));
+    // aggregate by label (labels are string literals: pointer or content equality)
+    const int n = ctx->prof_n;
+    int64_t off = 0;
+    char* done = new (std::nothrow) char[n]();
+    if (!done) return ASMC_ERR_NOMEM;
+    for (int i = 0; i < n; i++) {
+        if (done[i]) continue;
+        double tot = 0.0;
+        int cnt = 0;
+        for (int j = i; j < n; j++) {
+            if (done[j] || strcmp(ctx->prof_label[j], ctx->prof_label[i]) != 0) continue;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->prof_ev[2 * j], ctx->prof_ev[2 * j + 1]) == hipSuccess) {
+                tot += ms;
+                cnt++;
+            }
+            done[j] = 1;
+        }
+        const int w = snprintf(buf + off, (size_t)(buf_len - off), "%s %d %.6f\n", ctx->prof_label[i], cnt, cnt ? tot / cnt : 0.0);
+        if (w < 0 || off + w >= buf_len) break;
+        off += w;
+    }
+    delete[] done;
+    ctx->prof_n = 0;
+    return ASMC_OK;
+}
 
 int asmc_abi_version(void) { return ASMC_ABI_VERSION; }
 
@@ -89,6 +149,11 @@ int asmc_ctx_destroy(asmc_ctx* c) {
     (void)hipFree(c->d_rho);
     (void)hipFree(c->d_pcgtab);
     (void)hipFree(c->d_ptab);
+    if (c->prof_ev) {
+        for (int i = 0; i < 2 * ASMC_PROF_MAX; i++) (void)hipEventDestroy(c->prof_ev[i]);
+        delete[] c->prof_ev;
+        delete[] c->prof_label;
+    }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     delete c;
     return ASMC_OK;

@@ -15,6 +15,8 @@
 // pCN step moves 2*d*s + 48 bytes per particle and nothing else.
 #include <stdlib.h>
 
+#include <chrono>
+
 #include "asmc_common.h"
 
 // =============================================================================================
@@ -591,14 +593,19 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
 
 // sums the per-block accept counts of step `t`, records them, adapts the step size
 // (log rho += (acc - target)/(t+1)^0.75, rho clipped to [1e-4, 0.99])
-__global__ __launch_bounds__(64) void k_pcn_adapt(int nblocks, const long long* __restrict__ block_counts,
-                                                 int64_t n, int t, long long* __restrict__ counts_out,
-                                                 double* __restrict__ rho_ptr, double* __restrict__ rho_hist,
-                                                 double target, int adapt) {
+__global__ __launch_bounds__(1024) void k_pcn_adapt(int nblocks, const long long* __restrict__ block_counts,
+                                                   int64_t n, int t, long long* __restrict__ counts_out,
+                                                   double* __restrict__ rho_ptr, double* __restrict__ rho_hist,
+                                                   double target, int adapt) {
+    __shared__ long long s_c[16];
     long long c = 0;
-    for (int b = threadIdx.x; b < nblocks; b += 64) c += block_counts[b];
+    for (int b = threadIdx.x; b < nblocks; b += 1024) c += block_counts[b];
     c = wave_sum_ll(c);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
     if (threadIdx.x == 0) {
+        c = 0;
+        for (int w = 0; w < 16; w++) c += s_c[w];
         counts_out[t] = c;
         const double rho = *rho_ptr;
         rho_hist[t] = rho;
@@ -858,8 +865,11 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     const int grid = (int)grid64;
     *grid_out = grid;
     auto kern = k_pcn_reg<T, D, NOISE>;
-    if (lds_bytes > 64 * 1024)
+    static bool attr_set = false;  // per instantiation; the attribute call costs tens of microseconds
+    if (lds_bytes > 64 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
     PcnScalars ps;
     ps.beta = pd.beta;
     ps.seed = pd.seed;
@@ -867,7 +877,7 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(ASMC_BLOCK), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
+    ASMC_LAUNCH(ctx, st, "k_pcn_reg", kern, dim3(grid), dim3(ASMC_BLOCK), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
                        rho_ptr, step, block_counts);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -909,7 +919,7 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
     auto launch = [&](auto kern) {
         if (lds_bytes > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, pd, rho_ptr, step,
+        ASMC_LAUNCH(ctx, st, PHASE == 0 ? "k_pcn_step_generic" : "k_pcn_propose", kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, pd, rho_ptr, step,
                            block_counts, x_prop, qf_old, qf_new, wpb);
     };
     if (vec == 16)
@@ -940,15 +950,15 @@ int asmc_gaussian_draw(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const doubl
     const int grid = grid_for(n * ((d + 1) / 2), ASMC_BLOCK * 2, ASMC_MAX_BLOCKS * 2);
     const int grid2 = grid_for(n, ASMC_BLOCK, ASMC_MAX_BLOCKS * 2);
     if (x_dtype == ASMC_F64) {
-        hipLaunchKernelGGL(k_gaussian_draw<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma,
+        ASMC_LAUNCH(ctx, st, "k_gaussian_draw<double>", k_gaussian_draw<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma,
                            (unsigned long long)seed, (unsigned long long)gid0, draw_id, (double*)x_out);
         ASMC_LAUNCH_CHECK();
-        if (lq_out) hipLaunchKernelGGL(k_gaussian_logq<double>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma, (const double*)x_out, lq_out);
+        if (lq_out) ASMC_LAUNCH(ctx, st, "k_gaussian_logq<double>", k_gaussian_logq<double>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma, (const double*)x_out, lq_out);
     } else {
-        hipLaunchKernelGGL(k_gaussian_draw<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma,
+        ASMC_LAUNCH(ctx, st, "k_gaussian_draw<float>", k_gaussian_draw<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma,
                            (unsigned long long)seed, (unsigned long long)gid0, draw_id, (float*)x_out);
         ASMC_LAUNCH_CHECK();
-        if (lq_out) hipLaunchKernelGGL(k_gaussian_logq<float>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma, (const float*)x_out, lq_out);
+        if (lq_out) ASMC_LAUNCH(ctx, st, "k_gaussian_logq<float>", k_gaussian_logq<float>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma, (const float*)x_out, lq_out);
     }
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -975,7 +985,7 @@ int asmc_mixture_logpdf(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void
     auto launch = [&](auto kern, auto xp) {
         if (lds_bytes > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, d, xp, m, out, wpb);
+        ASMC_LAUNCH(ctx, st, "k_mixture_logpdf", kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, d, xp, m, out, wpb);
     };
     if (x_dtype == ASMC_F64) {
         const double* xp = (const double*)x;
@@ -998,11 +1008,11 @@ int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, dou
     hipStream_t st = as_stream(stream);
     int grid = grid_for(n, (ASMC_BLOCK / d) * 16, ctx->gram_blocks);
     if (x_dtype == ASMC_F64)
-        hipLaunchKernelGGL(k_colsum<double>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const double*)x, ctx->d_gram);
+        ASMC_LAUNCH(ctx, st, "k_colsum<double>", k_colsum<double>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const double*)x, ctx->d_gram);
     else
-        hipLaunchKernelGGL(k_colsum<float>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const float*)x, ctx->d_gram);
+        ASMC_LAUNCH(ctx, st, "k_colsum<float>", k_colsum<float>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const float*)x, ctx->d_gram);
     ASMC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_reduce_columns, dim3(d), dim3(64), 0, st, grid, d, (const double*)ctx->d_gram, ctx->d_small);
+    ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(d), dim3(64), 0, st, grid, d, (const double*)ctx->d_gram, ctx->d_small);
     ASMC_LAUNCH_CHECK();
     ASMC_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, sizeof(double) * d, hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipStreamSynchronize(st));
@@ -1023,13 +1033,13 @@ int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
     const int grid = grid_for(n, 64 * 8, ctx->gram_blocks);
     const size_t lds = sizeof(double) * 64 * (d + 1);
     if (x_dtype == ASMC_F64)
-        hipLaunchKernelGGL(k_gram<double>, dim3(grid), dim3(ASMC_BLOCK), lds, st, n, d, (const double*)x, (const double*)d_center, ctx->d_gram);
+        ASMC_LAUNCH(ctx, st, "k_gram<double>", k_gram<double>, dim3(grid), dim3(ASMC_BLOCK), lds, st, n, d, (const double*)x, (const double*)d_center, ctx->d_gram);
     else
-        hipLaunchKernelGGL(k_gram<float>, dim3(grid), dim3(ASMC_BLOCK), lds, st, n, d, (const float*)x, (const double*)d_center, ctx->d_gram);
+        ASMC_LAUNCH(ctx, st, "k_gram<float>", k_gram<float>, dim3(grid), dim3(ASMC_BLOCK), lds, st, n, d, (const float*)x, (const double*)d_center, ctx->d_gram);
     ASMC_LAUNCH_CHECK();
     // d*d <= 4096 doubles: reduce into the tail of d_partials, then read back in <=4096-double pieces
     double* d_out = ctx->d_partials;
-    hipLaunchKernelGGL(k_reduce_columns, dim3(d * d < 1024 ? d * d : 1024), dim3(64), 0, st, grid, d * d, (const double*)ctx->d_gram, d_out);
+    ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(d * d < 1024 ? d * d : 1024), dim3(64), 0, st, grid, d * d, (const double*)ctx->d_gram, d_out);
     ASMC_LAUNCH_CHECK();
     ASMC_HIP(hipMemcpyAsync(gram_host, d_out, sizeof(double) * d * d, hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipStreamSynchronize(st));
@@ -1069,7 +1079,11 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     double* d_rho_hist = ctx->d_rho + 8;   // [n_steps]
     long long* d_counts = ctx->d_counts;   // [n_steps]
     long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
+    const bool dbg = getenv("ASMC_DEBUG_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now();
     ASMC_HIP(hipStreamSynchronize(st));
+    const double t_b = now();
     ctx->h_pinned[0] = *rho_inout_host;
     ASMC_HIP(hipMemcpyAsync(d_rho, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, st));
     if (pcn_reg_supported(pd.d, prm->x_dtype == ASMC_F64 ? 8 : 4, x)) {
@@ -1085,10 +1099,11 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
             rc = launch_pcn_step<float, 0>(ctx, n, (float*)x, ll, lp, lq, pd, d_rho, step0 + (uint32_t)t, d_block,
                                            &grid, nullptr, nullptr, nullptr, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_pcn_adapt, dim3(1), dim3(64), 0, st, grid, (const long long*)d_block, n, t, d_counts,
+        ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, grid, (const long long*)d_block, n, t, d_counts,
                            d_rho, d_rho_hist, prm->target_accept, prm->adapt);
         ASMC_LAUNCH_CHECK();
     }
+    const double t_c = now();
     // read back: counts [n_steps] | rho_hist [n_steps] | rho
     long long* h_counts = reinterpret_cast<long long*>(ctx->h_pinned);
     double* h_rho_hist = ctx->h_pinned + ASMC_MAX_PCN_STEPS + 8;  // disjoint from the counts
@@ -1096,6 +1111,7 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     ASMC_HIP(hipMemcpyAsync(h_rho_hist, d_rho_hist, sizeof(double) * n_steps, hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8000, d_rho, sizeof(double), hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipStreamSynchronize(st));
+    if (dbg) fprintf(stderr, "[asmc_pcn_mutate] sync0 %.3f ms, enqueue %.3f ms, drain %.3f ms (n_steps=%d)\n", t_b - t_a, t_c - t_b, now() - t_c, n_steps);
     for (int t = 0; t < n_steps; t++) n_accept_host[t] = (int64_t)h_counts[t];
     if (rho_hist_host)
         for (int t = 0; t < n_steps; t++) rho_hist_host[t] = h_rho_hist[t];
@@ -1144,16 +1160,16 @@ int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x, const
     unsigned char* flags = reinterpret_cast<unsigned char*>(ctx->d_tiles_i);
     ASMC_HIP(hipMemsetAsync(ctx->d_keys, 0, sizeof(unsigned long long), st));
     const int grid = grid_for(n, ASMC_BLOCK * 2, ASMC_MAX_BLOCKS);
-    hipLaunchKernelGGL(k_pcn_accept_flags, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, ll_new, lp_new, lq_new,
+    ASMC_LAUNCH(ctx, st, "k_pcn_accept_flags", k_pcn_accept_flags, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, ll_new, lp_new, lq_new,
                        lj_old, lj_new, qf_old, qf_new, beta, (unsigned long long)seed, (unsigned long long)gid0, step,
                        flags, ctx->d_keys);
     ASMC_LAUNCH_CHECK();
     const int grid2 = grid_for(n * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
     if (x_dtype == ASMC_F64)
-        hipLaunchKernelGGL(k_copy_flagged_rows<double>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, (double*)x,
+        ASMC_LAUNCH(ctx, st, "k_copy_flagged_rows<double>", k_copy_flagged_rows<double>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, (double*)x,
                            (const double*)x_prop, (const unsigned char*)flags);
     else
-        hipLaunchKernelGGL(k_copy_flagged_rows<float>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, (float*)x,
+        ASMC_LAUNCH(ctx, st, "k_copy_flagged_rows<float>", k_copy_flagged_rows<float>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, (float*)x,
                            (const float*)x_prop, (const unsigned char*)flags);
     ASMC_LAUNCH_CHECK();
     if (n_accept_host) {

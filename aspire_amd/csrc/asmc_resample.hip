@@ -674,26 +674,26 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
         const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
         double* d_tile_s = ctx->d_tiles + ctx->n_tiles_max * 2;
         double* d_approx_total = ctx->d_small + 1025;
-        hipLaunchKernelGGL(k_tile_sum, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w, ctx->d_tiles);
+        ASMC_LAUNCH(ctx, st, "k_tile_sum", k_tile_sum, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w, ctx->d_tiles);
         ASMC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, carry_in, d_approx_total);
+        ASMC_LAUNCH(ctx, st, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, carry_in, d_approx_total);
         ASMC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_exact_tile_td_launch, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w,
+        ASMC_LAUNCH(ctx, st, "k_exact_tile_td_launch", k_exact_tile_td_launch, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w,
                            (const double*)ctx->d_tiles, (const double*)d_approx_total, n_tiles, ctx->d_tiles_i);
         ASMC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_exact_chain, dim3(1), dim3(XT_THREADS), 0, st, n, w, cdf, carry_in, n_tiles,
+        ASMC_LAUNCH(ctx, st, "k_exact_chain", k_exact_chain, dim3(1), dim3(XT_THREADS), 0, st, n, w, cdf, carry_in, n_tiles,
                            ctx->d_tiles_i, d_tile_s, d_total);
         ASMC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_exact_tile_write, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w, cdf,
+        ASMC_LAUNCH(ctx, st, "k_exact_tile_write", k_exact_tile_write, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w, cdf,
                            (const long long*)ctx->d_tiles_i, (const double*)d_tile_s);
         ASMC_LAUNCH_CHECK();
     } else if (mode == ASMC_CDF_FAST) {
         const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
-        hipLaunchKernelGGL(k_tile_sum, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w, ctx->d_tiles);
+        ASMC_LAUNCH(ctx, st, "k_tile_sum", k_tile_sum, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w, ctx->d_tiles);
         ASMC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, carry_in, d_total);
+        ASMC_LAUNCH(ctx, st, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, carry_in, d_total);
         ASMC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w,
+        ASMC_LAUNCH(ctx, st, "k_tile_scan", k_tile_scan, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w,
                            (const double*)ctx->d_tiles, cdf);
         ASMC_LAUNCH_CHECK();
     } else {
@@ -712,7 +712,7 @@ int asmc_cdf_normalize(asmc_ctx* ctx, int64_t n, double* cdf, double last, asmc_
     ASMC_REQUIRE(ctx && cdf, "null pointer");
     ASMC_REQUIRE(n > 0, "n must be positive");
     const int grid = grid_for(n, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS);
-    hipLaunchKernelGGL(k_divide, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, cdf, last);
+    ASMC_LAUNCH(ctx, as_stream(stream), "k_divide", k_divide, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, cdf, last);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
@@ -747,7 +747,7 @@ int asmc_pcg64_uniforms(asmc_ctx* ctx, const uint64_t state_host[4], uint64_t of
     U128 s0 = {state_host[1], state_host[0]};
     const int64_t threads = n < PCG_THREADS ? n : PCG_THREADS;
     const int grid = (int)((threads + ASMC_BLOCK - 1) / ASMC_BLOCK);
-    hipLaunchKernelGGL(k_pcg64_uniforms, dim3(grid), dim3(ASMC_BLOCK), 0, st,
+    ASMC_LAUNCH(ctx, st, "k_pcg64_uniforms", k_pcg64_uniforms, dim3(grid), dim3(ASMC_BLOCK), 0, st,
                        (const unsigned long long*)ctx->d_pcgtab, s0, (unsigned long long)offset, n, u);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -758,7 +758,7 @@ int asmc_systematic_uniforms(asmc_ctx* ctx, int64_t n_out, int64_t j0, int64_t n
     ASMC_REQUIRE(ctx && u, "null pointer");
     ASMC_REQUIRE(n_out > 0 && n_total > 0, "bad sizes");
     const int grid = grid_for(n_out, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS);
-    hipLaunchKernelGGL(k_systematic, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n_out, j0, n_total,
+    ASMC_LAUNCH(ctx, as_stream(stream), "k_systematic", k_systematic, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n_out, j0, n_total,
                        u0, v, u);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -769,7 +769,7 @@ int asmc_search(asmc_ctx* ctx, int64_t n, const double* cdf, int64_t n_out, cons
     ASMC_REQUIRE(ctx && cdf && u && idx, "null pointer");
     ASMC_REQUIRE(n > 0 && n_out > 0, "bad sizes");
     const int grid = grid_for(n_out, ASMC_BLOCK, ASMC_MAX_BLOCKS * 4);
-    hipLaunchKernelGGL(k_search, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, cdf, n_out, u, idx);
+    ASMC_LAUNCH(ctx, as_stream(stream), "k_search", k_search, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, cdf, n_out, u, idx);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
@@ -788,15 +788,15 @@ int asmc_gather(asmc_ctx* ctx, int64_t n_out, const int64_t* idx, int d, int x_d
     if (vec_ok) {
         const int cpr = (int)(rowbytes / 16);
         const int grid = grid_for(n_out * cpr, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
-        hipLaunchKernelGGL(k_gather16, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, cpr,
+        ASMC_LAUNCH(ctx, st, "k_gather16", k_gather16, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, cpr,
                            (const uint4*)x_in, (uint4*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
     } else if (x_dtype == ASMC_F64) {
         const int grid = grid_for(n_out * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
-        hipLaunchKernelGGL(k_gather_elem<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, d,
+        ASMC_LAUNCH(ctx, st, "k_gather_elem<double>", k_gather_elem<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, d,
                            (const double*)x_in, (double*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
     } else {
         const int grid = grid_for(n_out * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
-        hipLaunchKernelGGL(k_gather_elem<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, d,
+        ASMC_LAUNCH(ctx, st, "k_gather_elem<float>", k_gather_elem<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, d,
                            (const float*)x_in, (float*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
     }
     ASMC_LAUNCH_CHECK();
@@ -813,16 +813,16 @@ int asmc_compact_valid(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
     hipStream_t st = as_stream(stream);
     const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
     long long* d_total = ctx->d_tiles_i + ctx->n_tiles_max * 4;
-    hipLaunchKernelGGL(k_valid_count, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, ll, lp, ctx->d_tiles_i);
+    ASMC_LAUNCH(ctx, st, "k_valid_count", k_valid_count, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, ll, lp, ctx->d_tiles_i);
     ASMC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_scan_tiles_ll, dim3(1), dim3(64), 0, st, n_tiles, ctx->d_tiles_i, d_total);
+    ASMC_LAUNCH(ctx, st, "k_scan_tiles_ll", k_scan_tiles_ll, dim3(1), dim3(64), 0, st, n_tiles, ctx->d_tiles_i, d_total);
     ASMC_LAUNCH_CHECK();
     if (x_dtype == ASMC_F64)
-        hipLaunchKernelGGL(k_compact_scatter<double>, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, d,
+        ASMC_LAUNCH(ctx, st, "k_compact_scatter<double>", k_compact_scatter<double>, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, d,
                            (const double*)x, ll, lp, lq, (const long long*)ctx->d_tiles_i, (double*)x_out,
                            ll_out, lp_out, lq_out);
     else
-        hipLaunchKernelGGL(k_compact_scatter<float>, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, d,
+        ASMC_LAUNCH(ctx, st, "k_compact_scatter<float>", k_compact_scatter<float>, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, d,
                            (const float*)x, ll, lp, lq, (const long long*)ctx->d_tiles_i, (float*)x_out,
                            ll_out, lp_out, lq_out);
     ASMC_LAUNCH_CHECK();

@@ -250,7 +250,7 @@ static int launch_max(asmc_ctx* ctx, int64_t n, const double* ll, const double* 
     ASMC_DISPATCH_KT(kt, {
         BetaPack<KT> bp;
         fill_pack<KT>(bp, beta0, betas, nullptr, nullptr, K);
-        hipLaunchKernelGGL(k_weights_max<KT>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, bp,
+        ASMC_LAUNCH(ctx, st, "k_weights_max<KT>", k_weights_max<KT>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, bp,
                            ctx->d_keys, ctx->d_keys + ASMC_MAX_BETAS);
     });
     ASMC_LAUNCH_CHECK();
@@ -266,7 +266,7 @@ static int launch_sums(asmc_ctx* ctx, int64_t n, const double* ll, const double*
     ASMC_DISPATCH_KT(kt, {
         BetaPack<KT> bp;
         fill_pack<KT>(bp, beta0, betas, m, shift, K);
-        hipLaunchKernelGGL(k_weights_sums<KT>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, bp,
+        ASMC_LAUNCH(ctx, st, "k_weights_sums<KT>", k_weights_sums<KT>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, bp,
                            m_from_keys ? ctx->d_keys : nullptr, ctx->d_partials);
     });
     ASMC_LAUNCH_CHECK();
@@ -311,7 +311,7 @@ int asmc_weights_sums(asmc_ctx* ctx, int64_t n, const double* ll, const double* 
     rc = launch_sums(ctx, n, ll, lp, lq, beta0, betas_host, m_host, shift_host, K, false, &grid, st);
     if (rc) return rc;
     const int ncols = bucket_of(K) * 2;
-    hipLaunchKernelGGL(k_finalize_columns, dim3(ncols), dim3(64), 0, st, grid, ncols, ctx->d_partials,
+    ASMC_LAUNCH(ctx, st, "k_finalize_columns", k_finalize_columns, dim3(ncols), dim3(64), 0, st, grid, ncols, ctx->d_partials,
                        ctx->d_small, 1, 0, (const unsigned long long*)nullptr,
                        (const unsigned long long*)nullptr);
     ASMC_LAUNCH_CHECK();
@@ -334,7 +334,7 @@ int asmc_weights_stats(asmc_ctx* ctx, int64_t n, const double* ll, const double*
     rc = launch_sums(ctx, n, ll, lp, lq, beta0, betas_host, nullptr, nullptr, K, true, &grid, st);
     if (rc) return rc;
     const int kt = bucket_of(K);
-    hipLaunchKernelGGL(k_finalize_columns, dim3(kt * 2), dim3(64), 0, st, grid, kt * 2, ctx->d_partials,
+    ASMC_LAUNCH(ctx, st, "k_finalize_columns", k_finalize_columns, dim3(kt * 2), dim3(64), 0, st, grid, kt * 2, ctx->d_partials,
                        ctx->d_small, 1, 1, (const unsigned long long*)ctx->d_keys,
                        (const unsigned long long*)(ctx->d_keys + ASMC_MAX_BETAS));
     ASMC_LAUNCH_CHECK();
@@ -352,10 +352,10 @@ int asmc_weights_m2(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp
     ASMC_REQUIRE(m2_host != nullptr, "null host pointer");
     hipStream_t st = as_stream(stream);
     const int grid = reduce_grid(ctx, n, 1);
-    hipLaunchKernelGGL(k_weights_m2, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, beta0 - beta,
+    ASMC_LAUNCH(ctx, st, "k_weights_m2", k_weights_m2, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, beta0 - beta,
                        beta - beta0, m, mean_u, ctx->d_partials);
     ASMC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_finalize_columns, dim3(1), dim3(64), 0, st, grid, 1, ctx->d_partials,
+    ASMC_LAUNCH(ctx, st, "k_finalize_columns", k_finalize_columns, dim3(1), dim3(64), 0, st, grid, 1, ctx->d_partials,
                        ctx->d_small, 1, 0, (const unsigned long long*)nullptr,
                        (const unsigned long long*)nullptr);
     ASMC_LAUNCH_CHECK();
@@ -371,7 +371,7 @@ int asmc_log_weights(asmc_ctx* ctx, int64_t n, const double* ll, const double* l
     if (rc) return rc;
     ASMC_REQUIRE(lw_out != nullptr, "null output");
     const int grid = grid_for(n, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS);
-    hipLaunchKernelGGL(k_weights_map<0>, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, ll, lp, lq,
+    ASMC_LAUNCH(ctx, as_stream(stream), "k_weights_map<0>", k_weights_map<0>, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, ll, lp, lq,
                        beta0 - beta, beta - beta0, shift, 0.0, lw_out);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -384,7 +384,7 @@ int asmc_normalized_weights(asmc_ctx* ctx, int64_t n, const double* ll, const do
     if (rc) return rc;
     ASMC_REQUIRE(w_out != nullptr, "null output");
     const int grid = grid_for(n, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS);
-    hipLaunchKernelGGL(k_weights_map<1>, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, ll, lp, lq,
+    ASMC_LAUNCH(ctx, as_stream(stream), "k_weights_map<1>", k_weights_map<1>, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, ll, lp, lq,
                        beta0 - beta, beta - beta0, shift, lse, w_out);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -397,7 +397,7 @@ int asmc_count_nonfinite(asmc_ctx* ctx, int64_t n, const double* v, int64_t* n_n
     hipStream_t st = as_stream(stream);
     ASMC_HIP(hipMemsetAsync(ctx->d_keys, 0, sizeof(unsigned long long) * 2, st));
     const int grid = grid_for(n, ASMC_BLOCK * 8, ASMC_MAX_BLOCKS);
-    hipLaunchKernelGGL(k_count_nonfinite, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, v, ctx->d_keys);
+    ASMC_LAUNCH(ctx, st, "k_count_nonfinite", k_count_nonfinite, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, v, ctx->d_keys);
     ASMC_LAUNCH_CHECK();
     unsigned long long* h = reinterpret_cast<unsigned long long*>(ctx->h_pinned);
     ASMC_HIP(hipMemcpyAsync(h, ctx->d_keys, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, st));

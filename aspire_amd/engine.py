@@ -89,6 +89,20 @@ class HipEngine:
             self._ctx = ctypes.c_void_p()
             check(self.lib.asmc_ctx_create(ctypes.byref(self._ctx), self.device.index, self.n_max, self.d_max), "asmc_ctx_create")
 
+    # ---- per-kernel HIP-event timing --------------------------------------------------------
+    def profile(self, on: bool):
+        check(self.lib.asmc_profile_enable(self._ctx, int(on)), "asmc_profile_enable")
+
+    def profile_report(self) -> dict:
+        """{kernel: (launches, avg_ms)} since profiling was enabled (synchronises)."""
+        buf = ctypes.create_string_buffer(1 << 16)
+        check(self.lib.asmc_profile_report(self._ctx, buf, len(buf)), "asmc_profile_report")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.rsplit(" ", 2)
+            out[name] = (int(cnt), float(ms))
+        return out
+
     # ---- plumbing --------------------------------------------------------------------------
     @property
     def _stream(self):

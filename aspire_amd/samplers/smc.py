@@ -340,18 +340,20 @@ class HipSMC(SMCSampler):
         scale = float(np.mean(np.diag(cov)))
         if not np.isfinite(scale) or scale <= 0:
             scale = 1.0
-        jitter = 0.0
-        for _ in range(12):
-            try:
-                L = np.linalg.cholesky(cov + jitter * scale * np.eye(self.dims))
-                break
-            except np.linalg.LinAlgError:
-                jitter = 1e-12 if jitter == 0.0 else jitter * 100
-        else:
-            raise RuntimeError("could not factor the particle covariance")
-        from scipy.linalg import solve_triangular
-
-        Linv = solve_triangular(L, np.eye(self.dims), lower=True)
+        # The d x d factorisation is control-plane scalar work on the host.  It must NOT wake a multi-threaded
+        # BLAS pool: on the GPU box (256 host cores) OpenBLAS' spinning worker threads stalled the HIP runtime
+        # for ~60 ms after every few calls (measured; tools/smcprof.py), tripling the sampler's wall time.
+        with _single_threaded_blas():
+            jitter = 0.0
+            for _ in range(12):
+                try:
+                    L = np.linalg.cholesky(cov + jitter * scale * np.eye(self.dims))
+                    break
+                except np.linalg.LinAlgError:
+                    jitter = 1e-12 if jitter == 0.0 else jitter * 100
+            else:
+                raise RuntimeError("could not factor the particle covariance")
+            Linv = np.linalg.inv(L)
         return e.asarray(mean), e.asarray(np.tril(L)), e.asarray(np.tril(Linv))
 
     def _fused_ok(self) -> bool:
@@ -419,6 +421,17 @@ class HipSMC(SMCSampler):
         if e.count_nonfinite(lq)[0]:
             raise ValueError("Log proposal contains NaN values")
         return self._wrap(x, ll, lp, lq, beta)
+
+
+def _single_threaded_blas():
+    try:
+        from threadpoolctl import threadpool_limits
+
+        return threadpool_limits(limits=1)
+    except Exception:  # threadpoolctl missing: fall through (only a performance matter)
+        import contextlib
+
+        return contextlib.nullcontext()
 
 
 def pcn_adapt(rho: float, acc: float, target: float, t: int) -> float:

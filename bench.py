@@ -34,35 +34,6 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
-class OpTimer:
-    """HIP-event timing of individual engine calls on the stream they are launched on."""
-
-    def __init__(self, engine):
-        self.engine = engine
-        self.events = {}
-        self.enabled = False
-
-    def wrap(self, names):
-        for name in names:
-            fn = getattr(self.engine, name)
-
-            def timed(*a, _fn=fn, _name=name, **k):
-                if not self.enabled:
-                    return _fn(*a, **k)
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                out = _fn(*a, **k)
-                e.record()
-                self.events.setdefault(_name, []).append((s, e))
-                return out
-
-            setattr(self.engine, name, timed)
-
-    def summary(self):
-        torch.cuda.synchronize()
-        return {k: (len(v), sum(s.elapsed_time(e) for s, e in v) / len(v)) for k, v in self.events.items()}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,9 +87,6 @@ def main():
     lp = ll.clone()
     torch.cuda.synchronize()
 
-    timer = OpTimer(eng)
-    timer.wrap(["weights_stats", "weights_max", "weights_sums", "weights_m2", "normalized_weights", "cdf",
-                "cdf_normalize", "uniforms_pcg64", "search", "gather", "pcn_mutate"])
     rng = np.random.default_rng(12345)
     scal = {}
 
@@ -145,43 +113,63 @@ def main():
     for _ in range(30 + args.warmup):
         is_step()
     sync_all()
-    timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = is_step()
     sync_all()
     dt = time.perf_counter() - t0
-    timer.enabled = False
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
         import torch.distributed as dist
 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ops = timer.summary()
     value = n_global * args.steps / dt
 
-    # ---- roofline of the dominant kernel (algorithmic bytes per launch / HIP-event duration) ----
-    alg_bytes = {
-        "weights_stats": 24 * n_local,
-        "weights_max": 24 * n_local,
-        "weights_sums": 24 * n_local,
-        "weights_m2": 24 * n_local,
-        "normalized_weights": 32 * n_local,
-        "cdf": 16 * n_local,
-        "cdf_normalize": 16 * n_local,
-        "uniforms_pcg64": 8 * n_local,
-        "search": 24 * n_local,
-        "gather": (2 * (d * s_bytes + 24) + 8) * n_local,
+    # ---- roofline of the dominant kernel -----------------------------------------------------------
+    # The same steps once more with the library's per-kernel HIP events switched on (events recorded on the
+    # launch stream around every kernel; kept out of the timed region because two event records per launch
+    # perturb a launch-bound loop).  achieved = algorithmic bytes per launch / average kernel duration.
+    eng.profile(True)
+    n_prof = min(args.steps, 10)
+    for _ in range(n_prof):
+        is_step()
+    kern = eng.profile_report()
+    eng.profile(False)
+    row_b = d * s_bytes
+    alg_bytes = {  # per launch, from SURVEY.md §8d's per-particle figures
+        "k_weights_max": 24 * n_local, "k_weights_sums": 24 * n_local, "k_weights_m2": 24 * n_local,
+        "k_weights_map": 32 * n_local, "k_tile_sum": 8 * n_local, "k_exact_tile_td_launch": 8 * n_local,
+        "k_exact_tile_write": 16 * n_local, "k_tile_scan": 16 * n_local, "k_divide": 16 * n_local,
+        "k_pcg64_uniforms": 8 * n_local, "k_search": 24 * n_local, "k_gather16": (2 * (row_b + 24) + 8) * n_local,
+        # serial dependency chain over tile records (+ the ~log2 N tiles that straddle a binade): latency bound
+        "k_exact_chain": 40 * ((n_local + 2047) // 2048) + 16 * 2048 * 12,
     }
-    tot = {k: c * ms for k, (c, ms) in ops.items() if k in alg_bytes}
+
+    def alg_of(name):
+        base = name.split("<")[0]
+        return alg_bytes.get(base)
+
+    tot = {k: c * ms for k, (c, ms) in kern.items() if alg_of(k)}
     dom = max(tot, key=tot.get)
-    dom_ms = ops[dom][1]
-    achieved = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9
+    dom_ms = kern[dom][1]
+    achieved = alg_of(dom) / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC run of this configuration (profiles/, separate passes)
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_per_launch.json")))
+        key = f"{dom.split('(')[0]}|n={n_local}|d={d}|{args.x_dtype}"
+        traffic = tr.get(key)
+    except Exception:
+        traffic = None
+    per_kernel = {}
+    for k, (c, ms) in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+        ab = alg_of(k)
+        per_kernel[k] = {"launches_per_step": round(c / n_prof, 2), "avg_us": round(ms * 1e3, 2),
+                         "alg_GBs": None if not ab else round(ab / (ms * 1e-3) / 1e9, 1)}
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(dom_ms, 4),
-                "alg_bytes_per_launch": alg_bytes[dom],
-                "per_op_ms": {k: [c // max(1, args.steps), round(ms, 4)] for k, (c, ms) in sorted(ops.items())}}
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_ms": round(dom_ms, 5),
+                "alg_bytes_per_launch": alg_of(dom), "gpu_busy_ms_per_step": round(sum(tot.values()) / n_prof, 4),
+                "per_kernel": per_kernel}
 
     result = {
         "metric": "particle-steps/sec (N x n_steps), 1M particles d=32; log-evidence err vs ref",

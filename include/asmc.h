@@ -97,6 +97,12 @@ int asmc_device_count(int* n_out);
 int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max);
 int asmc_ctx_destroy(asmc_ctx* ctx);
 
+/* Per-kernel timing with HIP events recorded on the launch stream around every kernel of the library
+ * (measurement aid for bench.py's roofline leg; off by default, ~2 event records per launch when on).
+ * asmc_profile_report writes lines "<kernel> <launches> <avg_ms>\n" into buf and clears the log. */
+int asmc_profile_enable(asmc_ctx* ctx, int on);
+int asmc_profile_report(asmc_ctx* ctx, char* buf_host, int64_t buf_len);
+
 /* ---- weighting / ESS / evidence (reference samples.py:1221-1249, utils.py:248-255,510-512) ---
  * Unnormalised tempered log-weight, exactly the reference association (samples.py:1222-1224):
  *     lw_i(beta) = (beta0 - beta) * lq_i + (beta - beta0) * (ll_i + lp_i)
