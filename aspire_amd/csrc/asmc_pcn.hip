@@ -798,6 +798,72 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_gram(int64_t n, int d, const T* 
     }
 }
 
+// Register-blocked centred Gram matrix: one wave owns a (8*BLK) x (8*BLK) quadrant of G, lane (bi, bj) a
+// BLK x BLK block of it (16 or 64 accumulators in VGPRs).  Rows are staged 64 at a time through the wave's
+// LDS tile with coalesced 16-B loads; per row every lane reads two BLK-wide slices (same row for all lanes:
+// LDS broadcast, conflict free) and issues BLK^2 FMAs — 0.5 (BLK=4) / 0.25 (BLK=8) LDS reads per FMA.
+// blockIdx.y selects the quadrant (d > 8*BLK needs several).  Block partial [d_pad x d_pad] per block.
+template <typename T, int BLK>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_gram_rb(int64_t n, int d, const T* __restrict__ x,
+                                                       const double* __restrict__ center,
+                                                       double* __restrict__ partials, int n_quad_side) {
+    extern __shared__ __align__(16) char smem[];
+    constexpr int Q = 8 * BLK;  // quadrant side
+    const int rowbytes = d * (int)sizeof(T);
+    const int ldsrow = lds_row_stride(rowbytes);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* tile = smem + (size_t)wave * 64 * ldsrow;
+    const int qi = blockIdx.y / n_quad_side, qj = blockIdx.y % n_quad_side;
+    const int bi = lane >> 3, bj = lane & 7;
+    const int i0 = qi * Q + bi * BLK, j0 = qj * Q + bj * BLK;  // first row / column of this lane's block
+    double ci[BLK], cj[BLK], acc[BLK][BLK];
+#pragma unroll
+    for (int a = 0; a < BLK; a++) {
+        ci[a] = (i0 + a < d) ? center[i0 + a] : 0.0;
+        cj[a] = (j0 + a < d) ? center[j0 + a] : 0.0;
+#pragma unroll
+        for (int b = 0; b < BLK; b++) acc[a][b] = 0.0;
+    }
+    const int64_t n_tiles = (n + 63) / 64;
+    const int wpb = (int)(blockDim.x >> 6);
+    for (int64_t t = (int64_t)blockIdx.x * wpb + wave; t < n_tiles; t += (int64_t)gridDim.x * wpb) {
+        const int64_t row0 = t * 64;
+        const int rows = (int)((n - row0) < 64 ? (n - row0) : 64);
+        wave_lds_sync();
+        tile_load<16>(reinterpret_cast<const char*>(x) + row0 * rowbytes, (int64_t)rows * rowbytes, rowbytes, ldsrow, tile, lane);
+        wave_lds_sync();
+        for (int r = 0; r < rows; r++) {
+            const T* row = reinterpret_cast<const T*>(tile + r * ldsrow);
+            double ai[BLK], aj[BLK];
+#pragma unroll
+            for (int a = 0; a < BLK; a++) {
+                ai[a] = (i0 + a < d) ? (double)row[i0 + a] - ci[a] : 0.0;
+                aj[a] = (j0 + a < d) ? (double)row[j0 + a] - cj[a] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < BLK; a++)
+#pragma unroll
+                for (int b = 0; b < BLK; b++) acc[a][b] = fma(ai[a], aj[b], acc[a][b]);
+        }
+    }
+    // combine the block's waves through LDS (fixed order), write the block partial of this quadrant
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(smem);  // [wpb][Q*Q] fits: Q*Q*8 <= 64*ldsrow for d >= Q/2
+    double* mine = red + (size_t)wave * Q * Q;
+#pragma unroll
+    for (int a = 0; a < BLK; a++)
+#pragma unroll
+        for (int b = 0; b < BLK; b++) mine[(bi * BLK + a) * Q + bj * BLK + b] = acc[a][b];
+    __syncthreads();
+    const int dpad = n_quad_side * Q;
+    for (int e = threadIdx.x; e < Q * Q; e += (int)blockDim.x) {
+        double v = red[e];
+        for (int w = 1; w < wpb; w++) v += red[(size_t)w * Q * Q + e];
+        const int gi = qi * Q + e / Q, gj = qj * Q + e % Q;
+        partials[(size_t)blockIdx.x * dpad * dpad + (size_t)gi * dpad + gj] = v;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_reduce_columns(int nblocks, int ncols, const double* __restrict__ partials,
                                                       double* __restrict__ out) {
     for (int col = blockIdx.x; col < ncols; col += gridDim.x) {
@@ -1023,13 +1089,57 @@ int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, dou
 int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* center_host,
                        double* gram_host, asmc_stream stream) {
     ASMC_REQUIRE(ctx && x && center_host && gram_host, "null pointer");
-    ASMC_REQUIRE(n > 0 && d > 0 && d <= ctx->d_max && d <= 64, "bad sizes (gram supports d <= 64)");
+    ASMC_REQUIRE(n > 0 && d > 0 && d <= ctx->d_max && d <= 128, "bad sizes (gram supports d <= 128)");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
     hipStream_t st = as_stream(stream);
     ASMC_HIP(hipStreamSynchronize(st));
     memcpy(ctx->h_pinned + 2048, center_host, sizeof(double) * d);
     double* d_center = ctx->d_small + 2048;
     ASMC_HIP(hipMemcpyAsync(d_center, ctx->h_pinned + 2048, sizeof(double) * d, hipMemcpyHostToDevice, st));
+    const size_t elem = x_dtype == ASMC_F64 ? 8 : 4;
+    const int rowbytes = (int)(d * elem);
+    double* d_out = ctx->d_partials;
+    if (rowbytes % 16 == 0 && ((uintptr_t)x % 16) == 0 && d <= 128) {
+        // register-blocked kernel: BLK = 4 (quadrant 32) for d <= 32, else BLK = 8 (quadrant 64)
+        const int blk = d <= 32 ? 4 : 8;
+        const int Q = 8 * blk;
+        const int nq = (d + Q - 1) / Q;
+        const int dpad = nq * Q;
+        const int wpb = d > 64 ? 2 : ASMC_BLOCK / 64;  // d = 128: two waves per block keep the tiles inside 160 KB of LDS
+        const size_t lds = (size_t)wpb * 64 * lds_row_stride(rowbytes);
+        const size_t lds_red = (size_t)wpb * Q * Q * sizeof(double);
+        const size_t lds_bytes = lds > lds_red ? lds : lds_red;
+        int cap = (int)(((size_t)ctx->gram_blocks * ctx->d_max * ctx->d_max) / ((size_t)dpad * dpad));
+        if (cap > ctx->num_cu * 2) cap = ctx->num_cu * 2;
+        if (cap < 1) {
+            asmc_set_error("centered_gram: ctx d_max=%d too small for d=%d", ctx->d_max, d);
+            return ASMC_ERR_ARG;
+        }
+        const int grid = grid_for((n + 63) / 64, wpb, cap);
+        auto launch = [&](auto kern, auto xp) {
+            if (lds_bytes > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            ASMC_LAUNCH(ctx, st, "k_gram_rb", kern, dim3(grid, nq * nq), dim3(wpb * 64), lds_bytes, st, n, d, xp,
+                        (const double*)d_center, ctx->d_gram, nq);
+        };
+        if (x_dtype == ASMC_F64) {
+            if (blk == 4) launch(k_gram_rb<double, 4>, (const double*)x);
+            else launch(k_gram_rb<double, 8>, (const double*)x);
+        } else {
+            if (blk == 4) launch(k_gram_rb<float, 4>, (const float*)x);
+            else launch(k_gram_rb<float, 8>, (const float*)x);
+        }
+        ASMC_LAUNCH_CHECK();
+        ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(dpad * dpad < 1024 ? dpad * dpad : 1024), dim3(64), 0, st, grid,
+                    dpad * dpad, (const double*)ctx->d_gram, d_out);
+        ASMC_LAUNCH_CHECK();
+        // strip the padding while copying back
+        ASMC_HIP(hipMemcpy2DAsync(gram_host, sizeof(double) * d, d_out, sizeof(double) * dpad, sizeof(double) * d, d,
+                                  hipMemcpyDeviceToHost, st));
+        ASMC_HIP(hipStreamSynchronize(st));
+        return ASMC_OK;
+    }
+    ASMC_REQUIRE(d <= 64, "centered_gram: unaligned rows are supported for d <= 64 only");
     const int grid = grid_for(n, 64 * 8, ctx->gram_blocks);
     const size_t lds = sizeof(double) * 64 * (d + 1);
     if (x_dtype == ASMC_F64)
@@ -1037,8 +1147,7 @@ int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
     else
         ASMC_LAUNCH(ctx, st, "k_gram<float>", k_gram<float>, dim3(grid), dim3(ASMC_BLOCK), lds, st, n, d, (const float*)x, (const double*)d_center, ctx->d_gram);
     ASMC_LAUNCH_CHECK();
-    // d*d <= 4096 doubles: reduce into the tail of d_partials, then read back in <=4096-double pieces
-    double* d_out = ctx->d_partials;
+    // d*d <= 4096 doubles: reduce into d_partials, then read back
     ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(d * d < 1024 ? d * d : 1024), dim3(64), 0, st, grid, d * d, (const double*)ctx->d_gram, d_out);
     ASMC_LAUNCH_CHECK();
     ASMC_HIP(hipMemcpyAsync(gram_host, d_out, sizeof(double) * d * d, hipMemcpyDeviceToHost, st));

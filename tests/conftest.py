@@ -48,4 +48,4 @@ def hip_engine():
         pytest.skip("no HIP device")
     from aspire_amd.engine import HipEngine
 
-    return HipEngine(0, n_max=1 << 21, d_max=64)
+    return HipEngine(0, n_max=1 << 21, d_max=128)

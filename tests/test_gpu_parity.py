@@ -287,7 +287,7 @@ def test_mixture_logpdf_vs_oracle(eng, oracle, d, C, dtype):
     np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("d", [2, 4, 32, 64])
+@pytest.mark.parametrize("d", [2, 3, 4, 32, 64, 128])
 def test_moments_vs_oracle(eng, oracle, d):
     g = np.random.default_rng(10)
     n = 30011
