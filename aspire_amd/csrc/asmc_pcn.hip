@@ -421,16 +421,19 @@ __device__ __forceinline__ double mixture_eval_regs(const MixDev& m, const doubl
 // All read-only tables are packed into ONE `const __restrict__` buffer (ctx scratch, filled per mutate call):
 // only a noalias kernel argument lets LLVM prove the tables are not clobbered by the particle stores and
 // select scalar (s_load) instead of vector loads, and one base pointer keeps the SGPR budget for data.
-// layout (doubles): L[D*D] | Linv[D*D] | mu[D] | 3 x { logw[8] | mu[8*D] | prec[8*D] }  (ll, lp, lq)
+// L and Linv are stored as PACKED lower triangles (row j at j(j+1)/2): 2 x 4.2 KB at d = 32, so that everything a
+// step touches (~10 KB) stays inside the 16 KB scalar data cache (dense 2 x 8 KB tables thrashed it).
+// layout (doubles): Ltri[D(D+1)/2] | Linvtri[D(D+1)/2] | mu[D] | 3 x { logw[8] | mu[8*D] | prec[8*D] }  (ll, lp, lq)
+#define PTAB_TRI(D) ((D) * ((D) + 1) / 2)
 #define PTAB_MIX(D) (ASMC_MAX_COMPONENTS * (1 + 2 * (D)))
-#define PTAB_SIZE(D) (2 * (D) * (D) + (D) + 3 * PTAB_MIX(D))
+#define PTAB_SIZE(D) (2 * PTAB_TRI(D) + (D) + 3 * PTAB_MIX(D))
 struct PcnScalars {
     double beta;
     unsigned long long seed, gid0;
     int c_ll, c_lp, c_lq;
 };
 
-// v <- A v for a lower-triangular row-major A [D,D] (wave-uniform, read through scalar loads), in place.
+// v <- A v for a lower-triangular A stored packed by rows (wave-uniform, read through scalar loads), in place.
 // Descending row groups of RG: rows j0-RG+1..j0 only read v[0..j0], which later (lower) groups never need
 // overwritten entries of, so the update is legal in place.
 template <int D>
@@ -446,7 +449,7 @@ __device__ __forceinline__ void tri_matvec_inplace(const double* __restrict__ A,
         for (int k = 0; k < j0 + RG; k++) {
 #pragma unroll
             for (int r = 0; r < RG; r++)
-                if (k <= j0 + r) s[r] = fma(A[(j0 + r) * D + k], v[k], s[r]);
+                if (k <= j0 + r) s[r] = fma(A[(j0 + r) * (j0 + r + 1) / 2 + k], v[k], s[r]);
         }
 #pragma unroll
         for (int r = 0; r < RG; r++) v[j0 + r] = s[r];
@@ -498,9 +501,9 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
         const long zoff = 0;
         const double* __restrict__ tab = ptab + zoff;
         const double* __restrict__ Lp = tab;
-        const double* __restrict__ Lip = tab + D * D;
-        const double* __restrict__ mup = tab + 2 * D * D;
-        const double* __restrict__ m0 = tab + 2 * D * D + D;
+        const double* __restrict__ Lip = tab + PTAB_TRI(D);
+        const double* __restrict__ mup = tab + 2 * PTAB_TRI(D);
+        const double* __restrict__ m0 = tab + 2 * PTAB_TRI(D) + D;
         const MixDev mll = {p.c_ll, m0, m0 + ASMC_MAX_COMPONENTS, m0 + ASMC_MAX_COMPONENTS * (1 + D)};
         const MixDev mlp = {p.c_lp, m0 + PTAB_MIX(D), m0 + PTAB_MIX(D) + ASMC_MAX_COMPONENTS,
                             m0 + PTAB_MIX(D) + ASMC_MAX_COMPONENTS * (1 + D)};
@@ -892,23 +895,34 @@ static int waves_for_lds(size_t per_wave_bytes, size_t* lds_bytes_out) {
     return w;
 }
 
-// gather the caller's tables into the ctx parameter block (device-to-device, stream ordered)
-static int pack_pcn_tables(asmc_ctx* ctx, const PcnDev& pd, hipStream_t st) {
+// gather the caller's tables into the ctx parameter block (one tiny kernel, stream ordered)
+__global__ __launch_bounds__(256) void k_pcn_pack(PcnDev pd, double* __restrict__ t) {
     const int D = pd.d;
-    double* t = ctx->d_ptab;
-    const size_t dd = (size_t)D * D * sizeof(double);
-    ASMC_HIP(hipMemcpyAsync(t, pd.L, dd, hipMemcpyDeviceToDevice, st));
-    ASMC_HIP(hipMemcpyAsync(t + D * D, pd.Linv, dd, hipMemcpyDeviceToDevice, st));
-    ASMC_HIP(hipMemcpyAsync(t + 2 * D * D, pd.mu, D * sizeof(double), hipMemcpyDeviceToDevice, st));
-    double* m0 = t + 2 * D * D + D;
+    const int tri = D * (D + 1) / 2;
+    for (int e = threadIdx.x; e < D * D; e += 256) {
+        const int j = e / D, k = e - j * D;
+        if (k <= j) {
+            t[j * (j + 1) / 2 + k] = pd.L[e];
+            t[tri + j * (j + 1) / 2 + k] = pd.Linv[e];
+        }
+    }
+    for (int e = threadIdx.x; e < D; e += 256) t[2 * tri + e] = pd.mu[e];
+    double* m0 = t + 2 * tri + D;
     const MixDev* mixes[3] = {&pd.ll, &pd.lp, &pd.lq};
     for (int i = 0; i < 3; i++) {
         double* b = m0 + (size_t)i * PTAB_MIX(D);
         const int C = mixes[i]->C;
-        ASMC_HIP(hipMemcpyAsync(b, mixes[i]->logw, C * sizeof(double), hipMemcpyDeviceToDevice, st));
-        ASMC_HIP(hipMemcpyAsync(b + ASMC_MAX_COMPONENTS, mixes[i]->mu, (size_t)C * D * sizeof(double), hipMemcpyDeviceToDevice, st));
-        ASMC_HIP(hipMemcpyAsync(b + ASMC_MAX_COMPONENTS * (1 + D), mixes[i]->prec, (size_t)C * D * sizeof(double), hipMemcpyDeviceToDevice, st));
+        for (int e = threadIdx.x; e < C; e += 256) b[e] = mixes[i]->logw[e];
+        for (int e = threadIdx.x; e < C * D; e += 256) {
+            b[ASMC_MAX_COMPONENTS + e] = mixes[i]->mu[e];
+            b[ASMC_MAX_COMPONENTS * (1 + D) + e] = mixes[i]->prec[e];
+        }
     }
+}
+
+static int pack_pcn_tables(asmc_ctx* ctx, const PcnDev& pd, hipStream_t st) {
+    ASMC_LAUNCH(ctx, st, "k_pcn_pack", k_pcn_pack, dim3(1), dim3(256), 0, st, pd, ctx->d_ptab);
+    ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
 
