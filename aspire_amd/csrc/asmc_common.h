@@ -11,7 +11,7 @@
 #define ASMC_BLOCK 256          // 4 waves: one per SIMD of a CU
 #define ASMC_MAX_BLOCKS 2048    // cap for grid-stride reduction kernels (256 CUs x 8)
 #define ASMC_SCAN_TILE 2048     // elements per scan tile (256 threads x 8)
-#define ASMC_PCN_MAX_GRID (1 << 18)  // one 256-particle block each: up to 67M particles per rank
+#define ASMC_PCN_MAX_GRID (1 << 20)  // blocks per pCN launch (>= 64 particles each): up to 67M particles per rank
 #define ASMC_MAX_PCN_STEPS 2048 // per asmc_pcn_mutate call (bounded by the pinned staging buffer)
 
 void asmc_set_error(const char* fmt, ...);
@@ -68,7 +68,7 @@ struct asmc_ctx {
     double* d_tiles;               // [n_tiles_max * 4 + 64] scan tile aggregates
     long long* d_tiles_i;          // [n_tiles_max * 4 + 64] integer tile aggregates (exact cdf, compaction)
     double* d_gram;                // [gram_blocks * d_max * d_max] gram partials
-    long long* d_counts;           // [ASMC_MAX_PCN_STEPS + max(ASMC_MAX_BLOCKS, n_max/256+1)] accept counts / partials
+    long long* d_counts;           // [ASMC_MAX_PCN_STEPS + max(ASMC_MAX_BLOCKS, n_max/64+1)] accept counts / partials
     double* d_rho;                 // [ASMC_MAX_PCN_STEPS + 8] step-size history on device
     unsigned long long* d_pcgtab;  // [64*4 + 8] PCG64 jump table
     double* d_ptab;                // [2*32*32 + 32 + 3*8*(1+2*32)] packed pCN parameter block (d <= 32)

@@ -210,6 +210,7 @@ struct PcnDev {
     MixDev ll, lp, lq;
     unsigned long long seed, gid0;
     int noise;
+    int mode;  // PCN_X_STEP / PCN_Y_STEP / PCN_WHITEN / PCN_UNWHITEN (register-resident kernels)
 };
 
 // PHASE 0: fused (propose + built-in targets + accept, in place)
@@ -462,7 +463,17 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename T, int D, int NOISE>
+// MODE 0: one pCN step on x (whiten, propose, un-whiten, evaluate, accept)            — any built-in target
+// MODE 1: one pCN step on the WHITENED state y = Linv (x - mu) carried in the x buffer: y' = a y + rho xi needs
+//         no mat-vec, x' = mu + L y' is formed four rows at a time and consumed on the fly by the three
+//         (single-component) quadratic forms, so it is never materialised: one mat-vec per step instead of two
+// MODE 2: x -> y in place (start of a mutation);  MODE 3: y -> x in place + re-evaluate ll/lp/lq at the stored x
+#define PCN_X_STEP 0
+#define PCN_Y_STEP 1
+#define PCN_WHITEN 2
+#define PCN_UNWHITEN 3
+
+template <typename T, int D, int NOISE, int MODE>
 __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restrict__ x, double* __restrict__ ll,
                                                           double* __restrict__ lp, double* __restrict__ lq,
                                                           const double* __restrict__ ptab, PcnScalars p,
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
     extern __shared__ __align__(16) char smem[];
     constexpr int ROWB = D * (int)sizeof(T);
     constexpr int LDSROW = ROWB + 16;
-    constexpr int WPB = ASMC_BLOCK / 64;
+    const int WPB = (int)(blockDim.x >> 6);  // waves per block: chosen by the launcher from the LDS budget
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     char* tile = smem + (size_t)wave * 64 * LDSROW;
     char* myrow = tile + lane * LDSROW;
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
         char* gbase = reinterpret_cast<char*>(x) + row0 * ROWB;
         if (active) tile_load<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane);
         double oll = 0.0, olp = 0.0, olq = 0.0;
-        if (valid) {
+        if (valid && (MODE == PCN_X_STEP || MODE == PCN_Y_STEP)) {
             oll = ll[i];
             olp = lp[i];
             olq = lq[i];
@@ -513,84 +524,141 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
             const unsigned long long gid = p.gid0 + (unsigned long long)i;
             double v[D];
             row_to_regs<T, D>(myrow, v);
+            if (MODE == PCN_WHITEN) {
 #pragma unroll
-            for (int j = 0; j < D; j++) v[j] -= mup[j];
-            // y = Linv (x - mu), in place; q0 = |y|^2.  Rows are processed in descending groups of RG so
-            // that RG independent FMA chains are in flight (fp64 FMA latency >> issue) and each v[k] feeds RG rows.
-            double q0 = 0.0;
-#ifndef ASMC_ABLATE_MATVEC
-            tri_matvec_inplace<D>(Lip, v);
-#endif
+                for (int j = 0; j < D; j++) v[j] -= mup[j];
+                tri_matvec_inplace<D>(Lip, v);
 #pragma unroll
-            for (int j = 0; j < D; j++) q0 = fma(v[j], v[j], q0);
-            // y' = a y + rho xi; q1 = |y'|^2
-            double q1 = 0.0;
-            if (NOISE == ASMC_NOISE_F64) {
-#pragma unroll
-                for (int pr = 0; pr < D / 2; pr++) {
-                    double z0, z1;
-                    normal_pair(p.seed, gid, step, (uint32_t)pr, z0, z1);
-                    v[2 * pr] = fma(rho, z0, a * v[2 * pr]);
-                    v[2 * pr + 1] = fma(rho, z1, a * v[2 * pr + 1]);
-                    q1 = fma(v[2 * pr], v[2 * pr], q1);
-                    q1 = fma(v[2 * pr + 1], v[2 * pr + 1], q1);
-                    __builtin_amdgcn_sched_barrier(0);  // one pair at a time (register pressure)
-                }
-            } else {
-#pragma unroll
-                for (int qd = 0; qd < D / 4; qd++) {
-                    double z[4];
-#ifndef ASMC_ABLATE_NOISE
-                    normal_quad_f32(p.seed, gid, step, (uint32_t)qd, z[0], z[1], z[2], z[3]);
-#else
-                    z[0] = z[1] = z[2] = z[3] = 0.25 * (double)(lane + qd);
-#endif
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        v[4 * qd + e] = fma(rho, z[e], a * v[4 * qd + e]);
-                        q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
-                    }
-                    if (qd & 1) __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            // x' = mu + L y', rounded to the storage type
-#ifndef ASMC_ABLATE_MATVEC
-            tri_matvec_inplace<D>(Lp, v);
-#endif
-#pragma unroll
-            for (int j = 0; j < D; j++) v[j] = (double)(T)(mup[j] + v[j]);
-#ifndef ASMC_ABLATE_TARGET
-            const double nll = mixture_eval_regs<D>(mll, v);
-            const double nlp = mixture_eval_regs<D>(mlp, v);
-            const double nlq = mixture_eval_regs<D>(mlq, v);
-#else
-            const double nll = v[0], nlp = v[1], nlq = v[2];
-#endif
-            const double lpn = log_p_t(nll, nlp, nlq, p.beta);
-            const double lpo = log_p_t(oll, olp, olq, p.beta);
-            const double log_a = (lpn + 0.5 * q1) - (lpo + 0.5 * q0);
-            const double u = accept_uniform(p.seed, gid, step);
-            acc = log(u) < log_a;
-            if (acc) {
+                for (int j = 0; j < D; j++) v[j] = (double)(T)v[j];
                 regs_to_row<T, D>(myrow, v);
-                ll[i] = nll;
-                lp[i] = nlp;
-                lq[i] = nlq;
-                n_acc++;
+                acc = true;
+            } else if (MODE == PCN_UNWHITEN) {
+                tri_matvec_inplace<D>(Lp, v);
+#pragma unroll
+                for (int j = 0; j < D; j++) v[j] = (double)(T)(mup[j] + v[j]);
+                ll[i] = mixture_eval_regs<D>(mll, v);
+                lp[i] = mixture_eval_regs<D>(mlp, v);
+                lq[i] = mixture_eval_regs<D>(mlq, v);
+                regs_to_row<T, D>(myrow, v);
+                acc = true;
+            } else {
+                double q0 = 0.0;
+                if (MODE == PCN_X_STEP) {
+#pragma unroll
+                    for (int j = 0; j < D; j++) v[j] -= mup[j];
+                    // y = Linv (x - mu), in place, 4 interleaved FMA chains per row group
+#ifndef ASMC_ABLATE_MATVEC
+                    tri_matvec_inplace<D>(Lip, v);
+#endif
+                }
+#pragma unroll
+                for (int j = 0; j < D; j++) q0 = fma(v[j], v[j], q0);
+                // y' = a y + rho xi (rounded to the storage type when y is what gets stored); q1 = |y'|^2
+                double q1 = 0.0;
+                if (NOISE == ASMC_NOISE_F64) {
+#pragma unroll
+                    for (int pr = 0; pr < D / 2; pr++) {
+                        double z0, z1;
+                        normal_pair(p.seed, gid, step, (uint32_t)pr, z0, z1);
+                        v[2 * pr] = fma(rho, z0, a * v[2 * pr]);
+                        v[2 * pr + 1] = fma(rho, z1, a * v[2 * pr + 1]);
+                        if (MODE == PCN_Y_STEP) {
+                            v[2 * pr] = (double)(T)v[2 * pr];
+                            v[2 * pr + 1] = (double)(T)v[2 * pr + 1];
+                        }
+                        q1 = fma(v[2 * pr], v[2 * pr], q1);
+                        q1 = fma(v[2 * pr + 1], v[2 * pr + 1], q1);
+                        __builtin_amdgcn_sched_barrier(0);  // one pair at a time (register pressure)
+                    }
+                } else {
+#pragma unroll
+                    for (int qd = 0; qd < D / 4; qd++) {
+                        double z[4];
+#ifndef ASMC_ABLATE_NOISE
+                        normal_quad_f32(p.seed, gid, step, (uint32_t)qd, z[0], z[1], z[2], z[3]);
+#else
+                        z[0] = z[1] = z[2] = z[3] = 0.25 * (double)(lane + qd);
+#endif
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            v[4 * qd + e] = fma(rho, z[e], a * v[4 * qd + e]);
+                            if (MODE == PCN_Y_STEP) v[4 * qd + e] = (double)(T)v[4 * qd + e];
+                            q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
+                        }
+                        if (qd & 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                double nll, nlp, nlq;
+                if (MODE == PCN_X_STEP) {
+                    // x' = mu + L y', rounded to the storage type
+#ifndef ASMC_ABLATE_MATVEC
+                    tri_matvec_inplace<D>(Lp, v);
+#endif
+#pragma unroll
+                    for (int j = 0; j < D; j++) v[j] = (double)(T)(mup[j] + v[j]);
+#ifndef ASMC_ABLATE_TARGET
+                    nll = mixture_eval_regs<D>(mll, v);
+                    nlp = mixture_eval_regs<D>(mlp, v);
+                    nlq = mixture_eval_regs<D>(mlq, v);
+#else
+                    nll = v[0], nlp = v[1], nlq = v[2];
+#endif
+                } else {
+                    // v keeps y' (it is what gets stored); x'_j = mu_j + sum_k L[j,k] y'_k is produced four rows
+                    // at a time and folded straight into the three quadratic forms (component 0 of each target)
+                    double qa = 0.0, qb = 0.0, qc = 0.0;
+#pragma unroll
+                    for (int g = 0; g < D / 4; g++) {
+                        const int j0 = 4 * g;
+                        double sr[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int k = 0; k < j0 + 4; k++) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++)
+                                if (k <= j0 + r) sr[r] = fma(Lp[(j0 + r) * (j0 + r + 1) / 2 + k], v[k], sr[r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int j = j0 + r;
+                            const double xj = (double)(T)(mup[j] + sr[r]);
+                            const double ta = xj - mll.mu[j], tb = xj - mlp.mu[j], tc = xj - mlq.mu[j];
+                            qa = fma(ta * ta, mll.prec[j], qa);
+                            qb = fma(tb * tb, mlp.prec[j], qb);
+                            qc = fma(tc * tc, mlq.prec[j], qc);
+                        }
+                    }
+                    nll = mll.logw[0] - 0.5 * qa;
+                    nlp = mlp.logw[0] - 0.5 * qb;
+                    nlq = mlq.logw[0] - 0.5 * qc;
+                }
+                const double lpn = log_p_t(nll, nlp, nlq, p.beta);
+                const double lpo = log_p_t(oll, olp, olq, p.beta);
+                const double log_a = (lpn + 0.5 * q1) - (lpo + 0.5 * q0);
+                const double u = accept_uniform(p.seed, gid, step);
+                acc = log(u) < log_a;
+                if (acc) {
+                    regs_to_row<T, D>(myrow, v);
+                    ll[i] = nll;
+                    lp[i] = nlp;
+                    lq[i] = nlq;
+                    n_acc++;
+                }
             }
         }
         wave_lds_sync();
         if (__ballot(acc) != 0ULL) tile_store<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane);
         wave_lds_sync();
     }
-    __shared__ long long s_cnt[WPB];
-    n_acc = wave_sum_ll(n_acc);
-    if (lane == 0) s_cnt[wave] = n_acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long tsum = 0;
-        for (int w = 0; w < WPB; w++) tsum += s_cnt[w];
-        block_counts[blockIdx.x] = tsum;
+    if (MODE == PCN_X_STEP || MODE == PCN_Y_STEP) {
+        __shared__ long long s_cnt[ASMC_BLOCK / 64];
+        n_acc = wave_sum_ll(n_acc);
+        if (lane == 0) s_cnt[wave] = n_acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long tsum = 0;
+            for (int w = 0; w < WPB; w++) tsum += s_cnt[w];
+            block_counts[blockIdx.x] = tsum;
+        }
     }
 }
 
@@ -931,20 +999,25 @@ static bool pcn_reg_supported(int d, size_t elem, const void* x) {
            !getenv("ASMC_PCN_GENERIC");
 }
 
-template <typename T, int D, int NOISE>
+template <typename T, int D, int NOISE, int MODE>
 static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const PcnDev& pd,
                           const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out, hipStream_t st) {
     constexpr int LDSROW = D * (int)sizeof(T) + 16;
-    constexpr size_t lds_bytes = (size_t)(ASMC_BLOCK / 64) * 64 * LDSROW;
+    // waves per block: 160 KB of LDS hold floor(160K / tile) wave tiles; blocks of 4 waves waste the remainder
+    // when the tile is large (d = 32 fp64: 17 KB tiles -> 2 blocks of 4 = 8 waves, but 9 single-wave blocks)
+    constexpr size_t tile_bytes = (size_t)64 * LDSROW;
+    static int wpb_env = getenv("ASMC_PCN_WPB") ? atoi(getenv("ASMC_PCN_WPB")) : 0;
+    const int wpb = wpb_env > 0 ? wpb_env : ((160 * 1024) / tile_bytes % 4 == 0 || tile_bytes * 12 <= 160 * 1024 ? 4 : 1);
+    const size_t lds_bytes = (size_t)wpb * tile_bytes;
     const int64_t n_tiles = (n + 63) / 64;
-    const int64_t grid64 = (n_tiles + ASMC_BLOCK / 64 - 1) / (ASMC_BLOCK / 64);
+    const int64_t grid64 = (n_tiles + wpb - 1) / wpb;
     if (grid64 > ASMC_PCN_MAX_GRID) {
         asmc_set_error("pcn: n=%lld exceeds the per-call block budget", (long long)n);
         return ASMC_ERR_UNSUPPORTED;
     }
     const int grid = (int)grid64;
     *grid_out = grid;
-    auto kern = k_pcn_reg<T, D, NOISE>;
+    auto kern = k_pcn_reg<T, D, NOISE, MODE>;
     static bool attr_set = false;  // per instantiation; the attribute call costs tens of microseconds
     if (lds_bytes > 64 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -957,7 +1030,7 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
-    ASMC_LAUNCH(ctx, st, "k_pcn_reg", kern, dim3(grid), dim3(ASMC_BLOCK), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
+    ASMC_LAUNCH(ctx, st, MODE == PCN_X_STEP ? "k_pcn_reg" : MODE == PCN_Y_STEP ? "k_pcn_reg_y" : MODE == PCN_WHITEN ? "k_pcn_whiten" : "k_pcn_unwhiten", kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
                        rho_ptr, step, block_counts);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -969,15 +1042,23 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
                            T* x_prop, double* qf_old, double* qf_new, hipStream_t st) {
     const int rowbytes = pd.d * (int)sizeof(T);
     if (PHASE == 0 && pcn_reg_supported(pd.d, sizeof(T), x)) {
-        switch (pd.d * 2 + (pd.noise == ASMC_NOISE_F32 ? 1 : 0)) {  // register-resident specialisations
-#define PCN_CASE(DD)                                                                                                   \
-    case DD * 2: return launch_pcn_reg<T, DD, ASMC_NOISE_F64>(ctx, n, x, ll, lp, lq, pd, rho_ptr, step, block_counts, grid_out, st); \
-    case DD * 2 + 1: return launch_pcn_reg<T, DD, ASMC_NOISE_F32>(ctx, n, x, ll, lp, lq, pd, rho_ptr, step, block_counts, grid_out, st);
+        switch (pd.d * 8 + (pd.noise == ASMC_NOISE_F32 ? 4 : 0) + pd.mode) {  // register-resident specialisations
+#define PCN_CASE2(DD, NZ, MD) \
+    case DD * 8 + (NZ == ASMC_NOISE_F32 ? 4 : 0) + MD: \
+        return launch_pcn_reg<T, DD, NZ, MD>(ctx, n, x, ll, lp, lq, pd, rho_ptr, step, block_counts, grid_out, st);
+#define PCN_CASE(DD)                            \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_X_STEP)   \
+    PCN_CASE2(DD, ASMC_NOISE_F32, PCN_X_STEP)   \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_Y_STEP)   \
+    PCN_CASE2(DD, ASMC_NOISE_F32, PCN_Y_STEP)   \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_WHITEN)   \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN)
             PCN_CASE(4)
             PCN_CASE(8)
             PCN_CASE(16)
             PCN_CASE(32)
 #undef PCN_CASE
+#undef PCN_CASE2
             default: break;
         }
     }
@@ -1196,6 +1277,7 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     pd.seed = prm->seed;
     pd.gid0 = prm->gid0;
     pd.noise = prm->noise;
+    pd.mode = PCN_X_STEP;
     ASMC_REQUIRE(pd.noise == ASMC_NOISE_F64 || pd.noise == ASMC_NOISE_F32, "bad noise mode");
     // device step-size cell + history
     double* d_rho = ctx->d_rho;            // [0]: current rho
@@ -1209,22 +1291,40 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     const double t_b = now();
     ctx->h_pinned[0] = *rho_inout_host;
     ASMC_HIP(hipMemcpyAsync(d_rho, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, st));
-    if (pcn_reg_supported(pd.d, prm->x_dtype == ASMC_F64 ? 8 : 4, x)) {
+    const bool reg_ok = pcn_reg_supported(pd.d, prm->x_dtype == ASMC_F64 ? 8 : 4, x);
+    // whitened-state stepping: plain (single-component) targets, enough steps to amortise the two conversions
+    const bool y_state = reg_ok && pd.ll.C == 1 && pd.lp.C == 1 && pd.lq.C == 1 && n_steps >= 4 && !getenv("ASMC_PCN_XSTATE");
+    auto launch_mode = [&](int mode, uint32_t stp, int* grid) -> int {
+        pd.mode = mode;
+        const int nz = pd.noise;
+        if (mode == PCN_WHITEN || mode == PCN_UNWHITEN) pd.noise = ASMC_NOISE_F64;
+        int r;
+        if (prm->x_dtype == ASMC_F64)
+            r = launch_pcn_step<double, 0>(ctx, n, (double*)x, ll, lp, lq, pd, d_rho, stp, d_block, grid, nullptr, nullptr, nullptr, st);
+        else
+            r = launch_pcn_step<float, 0>(ctx, n, (float*)x, ll, lp, lq, pd, d_rho, stp, d_block, grid, nullptr, nullptr, nullptr, st);
+        pd.noise = nz;
+        return r;
+    };
+    if (reg_ok) {
         rc = pack_pcn_tables(ctx, pd, st);
         if (rc) return rc;
     }
+    int grid = 0;
+    if (y_state) {
+        rc = launch_mode(PCN_WHITEN, 0, &grid);
+        if (rc) return rc;
+    }
     for (int t = 0; t < n_steps; t++) {
-        int grid = 0;
-        if (prm->x_dtype == ASMC_F64)
-            rc = launch_pcn_step<double, 0>(ctx, n, (double*)x, ll, lp, lq, pd, d_rho, step0 + (uint32_t)t, d_block,
-                                            &grid, nullptr, nullptr, nullptr, st);
-        else
-            rc = launch_pcn_step<float, 0>(ctx, n, (float*)x, ll, lp, lq, pd, d_rho, step0 + (uint32_t)t, d_block,
-                                           &grid, nullptr, nullptr, nullptr, st);
+        rc = launch_mode(y_state ? PCN_Y_STEP : PCN_X_STEP, step0 + (uint32_t)t, &grid);
         if (rc) return rc;
         ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, grid, (const long long*)d_block, n, t, d_counts,
-                           d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+                    d_rho, d_rho_hist, prm->target_accept, prm->adapt);
         ASMC_LAUNCH_CHECK();
+    }
+    if (y_state) {
+        rc = launch_mode(PCN_UNWHITEN, 0, &grid);
+        if (rc) return rc;
     }
     const double t_c = now();
     // read back: counts [n_steps] | rho_hist [n_steps] | rho

@@ -346,6 +346,38 @@ def test_pcn_step_vs_oracle(eng, oracle, d, C):
     assert 0.02 < n_acc[0] / n < 0.98
 
 
+@pytest.mark.parametrize("d,dtype", [(32, torch.float64), (8, torch.float64), (32, torch.float32)])
+def test_pcn_whitened_state_multi_step_vs_oracle(eng, oracle, d, dtype):
+    """n_steps >= 4 with plain Gaussian targets runs on the whitened state (x -> y once, one mat-vec per step,
+    y -> x at the end).  Against the oracle's x-space restatement over 4 steps: same accept decisions up to
+    razor-edge cases, positions to 1e-9 (fp64 storage) / 1e-5 (fp32 storage), carried log-probs consistent."""
+    n = 3000
+    x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 31 + d)
+    om = [oracle.Mixture(*m) for m in mixes]
+    dm = [eng.make_mixture(*m) for m in mixes]
+    xd = torch.as_tensor(x).to(dtype).to(eng.device)
+    xr = xd.double().cpu().numpy().copy()
+    x0 = xr.copy()
+    ll, lp, lq = (m.logpdf(xr) for m in om)
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    rho, beta, seed = 0.35, 0.6, 777
+    n_acc, rho_hist, _ = eng.pcn_mutate(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), dm[0],
+                                        dm[1], dm[2], seed, 50, rho, 4, 10, 0.234, False)
+    llr, lpr, lqr = ll.copy(), lp.copy(), lq.copy()
+    acc_ref = [oracle.pcn_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, om[0], om[1], om[2], seed, 50, 10 + t) for t in range(4)]
+    got = xd.double().cpu().numpy()
+    tol = 1e-9 if dtype == torch.float64 else 2e-5
+    close = np.all(np.abs(got - xr) <= tol * (1 + np.abs(xr)), axis=1)
+    assert (~close).sum() <= (3 if dtype == torch.float64 else 40), (~close).sum()  # razor-edge decisions (fp32 rounding of y widens the edge)
+    assert np.all(np.abs(np.array(n_acc) - np.array(acc_ref)) <= (3 if dtype == torch.float64 else 40))
+    # carried log-probabilities equal the densities at the stored positions
+    np.testing.assert_allclose(lld.cpu().numpy(), om[0].logpdf(got), rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(lqd.cpu().numpy(), om[2].logpdf(got), rtol=1e-11, atol=1e-11)
+    # particles that never moved come back within rounding of where they started
+    still = np.all(np.abs(xr - x0) == 0, axis=1) & close
+    assert np.all(np.abs(got[still] - x0[still]) <= (1e-13 if dtype == torch.float64 else 1e-5) * (1 + np.abs(x0[still])))
+
+
 def test_pcn_fast_noise_vs_oracle(eng, oracle):
     """ASMC_NOISE_F32 (hardware fp32 Box-Muller): proposals within 2e-6 of the libm restatement, accept
     decisions equal except for a handful of razor-edge cases; noise is standard normal."""
