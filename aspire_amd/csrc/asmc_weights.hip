@@ -34,9 +34,13 @@ template <int KT>
 __global__ __launch_bounds__(ASMC_BLOCK) void k_weights_max(int64_t n, const double* __restrict__ ll,
                                                            const double* __restrict__ lp,
                                                            const double* __restrict__ lq,
-                                                           BetaPack<KT> bp,
+                                                           BetaPack<KT> bp_arg,
                                                            unsigned long long* __restrict__ keys,
-                                                           unsigned long long* __restrict__ nan_count) {
+                                                           unsigned long long* __restrict__ nan_count,
+                                                           const BetaPack<KT>* __restrict__ bp_dev,
+                                                           const double* __restrict__ skip_flag) {
+    if (skip_flag && *skip_flag != 0.0) return;  // device-side bisection already converged
+    const BetaPack<KT>& bp = bp_dev ? *bp_dev : bp_arg;
     double mx[KT];
 #pragma unroll
     for (int k = 0; k < KT; k++) mx[k] = -INFINITY;
@@ -81,9 +85,13 @@ template <int KT>
 __global__ __launch_bounds__(ASMC_BLOCK) void k_weights_sums(int64_t n, const double* __restrict__ ll,
                                                             const double* __restrict__ lp,
                                                             const double* __restrict__ lq,
-                                                            BetaPack<KT> bp,
+                                                            BetaPack<KT> bp_arg,
                                                             const unsigned long long* __restrict__ keys,
-                                                            double* __restrict__ partials) {
+                                                            double* __restrict__ partials,
+                                                            const BetaPack<KT>* __restrict__ bp_dev,
+                                                            const double* __restrict__ skip_flag) {
+    if (skip_flag && *skip_flag != 0.0) return;
+    const BetaPack<KT>& bp = bp_dev ? *bp_dev : bp_arg;
     double s1[KT], s2[KT], m[KT];
 #pragma unroll
     for (int k = 0; k < KT; k++) {
@@ -251,7 +259,7 @@ static int launch_max(asmc_ctx* ctx, int64_t n, const double* ll, const double* 
         BetaPack<KT> bp;
         fill_pack<KT>(bp, beta0, betas, nullptr, nullptr, K);
         ASMC_LAUNCH(ctx, st, "k_weights_max<KT>", k_weights_max<KT>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, bp,
-                           ctx->d_keys, ctx->d_keys + ASMC_MAX_BETAS);
+                    ctx->d_keys, ctx->d_keys + ASMC_MAX_BETAS, (const BetaPack<KT>*)nullptr, (const double*)nullptr);
     });
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -267,7 +275,7 @@ static int launch_sums(asmc_ctx* ctx, int64_t n, const double* ll, const double*
         BetaPack<KT> bp;
         fill_pack<KT>(bp, beta0, betas, m, shift, K);
         ASMC_LAUNCH(ctx, st, "k_weights_sums<KT>", k_weights_sums<KT>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, bp,
-                           m_from_keys ? ctx->d_keys : nullptr, ctx->d_partials);
+                    m_from_keys ? ctx->d_keys : nullptr, ctx->d_partials, (const BetaPack<KT>*)nullptr, (const double*)nullptr);
     });
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -278,6 +286,96 @@ static int check_common(asmc_ctx* ctx, int64_t n, const void* a, const void* b, 
     ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
     ASMC_REQUIRE(a && b && c, "null device pointer");
     return ASMC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-side k-ary bisection (smc/base.py:167-186): the whole adaptive-beta search runs as a chain of
+// launches without host round trips.  State (doubles) in ctx->d_small + 2048:
+//   [0] beta_min  [1] beta_max  [2] done  [3] target_eff  [4] tol  [5] log N  [6] n_pass  [7] beta0
+//   [8] N  [9] first_pass_done  [16..31] heap-ordered midpoints of the current round
+#define BIS_LEVELS 4
+#define BIS_NODES 15
+
+__device__ __forceinline__ double ess_over_n(double m, double S1, double S2, double logN, double N) {
+    // the host's smc_math.ess (utils.py:510-512 on samples.py:1244-1249), same operation order
+    const double c = (m + log(S1)) - logN;
+    const double mp = m + c;
+    const double l1 = mp + log(S1);
+    const double l2 = mp * 2.0 + log(S2);
+    return exp(l1 * 2.0 - l2) / N;
+}
+
+// phase 0: candidate {1.0}; phase 1: the 15 midpoints of the next four bisection levels
+__global__ __launch_bounds__(64) void k_bis_prepare(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
+                                                   unsigned long long* __restrict__ keys, int phase) {
+    if (threadIdx.x < ASMC_MAX_BETAS + 1 && !(phase == 1 && st[2] != 0.0)) keys[threadIdx.x] = 0ULL;
+    if (threadIdx.x != 0) return;
+    const double beta0 = st[7];
+    if (phase == 0) {
+        for (int k = 0; k < 16; k++) {
+            bp->c1[k] = beta0 - 1.0;
+            bp->c2[k] = 1.0 - beta0;
+            bp->m[k] = 0.0;
+            bp->shift[k] = 0.0;
+        }
+        return;
+    }
+    if (st[2] != 0.0) return;
+    if (!(st[1] - st[0] > st[4])) {  // converged (or eff(1.0) >= target made beta_min = 1)
+        st[2] = 1.0;
+        return;
+    }
+    double los[BIS_NODES], his[BIS_NODES];
+    los[0] = st[0];
+    his[0] = st[1];
+    for (int i = 0; i < BIS_NODES; i++) {
+        const double mid = 0.5 * (his[i] + los[i]);  // the reference's expression (smc/base.py:178)
+        st[16 + i] = mid;
+        const int l = 2 * i + 1, r = 2 * i + 2;
+        if (r < BIS_NODES) {
+            los[l] = los[i];
+            his[l] = mid;
+            los[r] = mid;
+            his[r] = his[i];
+        }
+        bp->c1[i] = beta0 - mid;
+        bp->c2[i] = mid - beta0;
+        bp->m[i] = 0.0;
+        bp->shift[i] = 0.0;
+    }
+    bp->c1[15] = bp->c1[14];
+    bp->c2[15] = bp->c2[14];
+    bp->m[15] = 0.0;
+    bp->shift[15] = 0.0;
+}
+
+__global__ __launch_bounds__(64) void k_bis_decide(double* __restrict__ st, const double* __restrict__ stats, int phase) {
+    if (threadIdx.x != 0 || st[2] != 0.0) return;
+    const double logN = st[5], N = st[8], target = st[3], tol = st[4];
+    st[6] += 1.0;
+    if (phase == 0) {
+        const double eff = ess_over_n(stats[0], stats[1], stats[2], logN, N);
+        if (eff >= target) st[0] = 1.0;  // smc/base.py:174-175
+        st[9] = eff;
+        return;
+    }
+    double bmin = st[0], bmax = st[1];
+    int i = 0;
+    for (int lev = 0; lev < BIS_LEVELS; lev++) {
+        if (!(bmax - bmin > tol)) break;
+        const double eff = ess_over_n(stats[4 * i], stats[4 * i + 1], stats[4 * i + 2], logN, N);
+        const double mid = st[16 + i];
+        if (eff >= target) {
+            bmin = mid;
+            i = 2 * i + 2;
+        } else {
+            bmax = mid;
+            i = 2 * i + 1;
+        }
+    }
+    st[0] = bmin;
+    st[1] = bmax;
+    if (!(bmax - bmin > tol)) st[2] = 1.0;
 }
 
 extern "C" {
@@ -341,6 +439,63 @@ int asmc_weights_stats(asmc_ctx* ctx, int64_t n, const double* ll, const double*
     ASMC_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, sizeof(double) * kt * 4, hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipStreamSynchronize(st));
     for (int k = 0; k < 4 * K; k++) out_host[k] = ctx->h_pinned[k];
+    return ASMC_OK;
+}
+
+int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double beta0,
+                   double target_eff, double tol, double* out_host, asmc_stream stream) {
+    int rc = check_common(ctx, n, ll, lp, lq);
+    if (rc) return rc;
+    ASMC_REQUIRE(out_host != nullptr, "null host pointer");
+    ASMC_REQUIRE(tol > 0.0 && beta0 >= 0.0 && beta0 < 1.0, "bad beta0 / tolerance");
+    hipStream_t st = as_stream(stream);
+    double* d_st = ctx->d_small + 2560;
+    BetaPack<16>* d_bp = reinterpret_cast<BetaPack<16>*>(ctx->d_small + 2560 + 64);
+    ASMC_HIP(hipStreamSynchronize(st));
+    double* h = ctx->h_pinned + 4096 + 512;
+    for (int i = 0; i < 32; i++) h[i] = 0.0;
+    h[0] = beta0;
+    h[1] = 1.0;
+    h[3] = target_eff;
+    h[4] = tol;
+    h[5] = log((double)n);
+    h[7] = beta0;
+    h[8] = (double)n;
+    ASMC_HIP(hipMemcpyAsync(d_st, h, sizeof(double) * 32, hipMemcpyHostToDevice, st));
+    const int grid = reduce_grid(ctx, n, 16);
+    BetaPack<16> dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    const int max_rounds = (int)ceil(log2(1.0 / tol) / BIS_LEVELS) + 2;
+    for (int round = 0; round <= max_rounds; round++) {
+        const int phase = round == 0 ? 0 : 1;
+        ASMC_LAUNCH(ctx, st, "k_bis_prepare", k_bis_prepare, dim3(1), dim3(64), 0, st, d_st, d_bp, ctx->d_keys, phase);
+        ASMC_LAUNCH_CHECK();
+        const double* skip = phase ? d_st + 2 : nullptr;
+        ASMC_LAUNCH(ctx, st, "k_weights_max<KT>", k_weights_max<16>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, dummy,
+                    ctx->d_keys, ctx->d_keys + ASMC_MAX_BETAS, (const BetaPack<16>*)d_bp, skip);
+        ASMC_LAUNCH_CHECK();
+        ASMC_LAUNCH(ctx, st, "k_weights_sums<KT>", k_weights_sums<16>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, dummy,
+                    (const unsigned long long*)ctx->d_keys, ctx->d_partials, (const BetaPack<16>*)d_bp, skip);
+        ASMC_LAUNCH_CHECK();
+        ASMC_LAUNCH(ctx, st, "k_finalize_columns", k_finalize_columns, dim3(32), dim3(64), 0, st, grid, 32, ctx->d_partials, ctx->d_small, 1, 1,
+                    (const unsigned long long*)ctx->d_keys, (const unsigned long long*)(ctx->d_keys + ASMC_MAX_BETAS));
+        ASMC_LAUNCH_CHECK();
+        ASMC_LAUNCH(ctx, st, "k_bis_decide", k_bis_decide, dim3(1), dim3(64), 0, st, d_st, (const double*)ctx->d_small, phase);
+        ASMC_LAUNCH_CHECK();
+    }
+    // one more prepare so that `done` reflects the final interval, then read back
+    ASMC_LAUNCH(ctx, st, "k_bis_prepare", k_bis_prepare, dim3(1), dim3(64), 0, st, d_st, d_bp, ctx->d_keys, 1);
+    ASMC_LAUNCH_CHECK();
+    ASMC_HIP(hipMemcpyAsync(h, d_st, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+    unsigned long long* hk = reinterpret_cast<unsigned long long*>(h + 16);
+    ASMC_HIP(hipMemcpyAsync(hk, ctx->d_keys + ASMC_MAX_BETAS, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    out_host[0] = h[0];               // beta_min = beta*
+    out_host[1] = h[1];               // beta_max
+    out_host[2] = h[2];               // converged flag
+    out_host[3] = h[6];               // device passes
+    out_host[4] = h[9];               // ESS(1.0)/N
+    out_host[5] = (double)hk[0];      // NaN log-weights seen in the last evaluated pass
     return ASMC_OK;
 }
 

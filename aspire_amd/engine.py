@@ -168,6 +168,14 @@ class HipEngine:
                                           _f64p(betas), betas.size, _f64p(out), self._stream), "asmc_weights_stats")
         return out.reshape(-1, 4)
 
+    def find_beta(self, ll, lp, lq, beta0: float, target_eff: float, tol: float):
+        """Device-side adaptive-beta search (single rank): (beta_star, eff_at_one, converged, passes, n_nan)."""
+        self._chk3(ll, lp, lq)
+        out = np.zeros(6)
+        check(self.lib.asmc_find_beta(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0, target_eff, tol,
+                                      _f64p(out), self._stream), "asmc_find_beta")
+        return float(out[0]), float(out[4]), bool(out[2]), int(out[3]), int(out[5])
+
     def weights_m2(self, ll, lp, lq, beta0: float, beta: float, m: float, mean_u: float) -> float:
         self._chk3(ll, lp, lq)
         out = ctypes.c_double(0.0)

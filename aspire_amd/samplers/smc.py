@@ -39,6 +39,7 @@ class SMCSampler(MCMCSampler):
                          xp=xp, dtype=dtype, parameters=parameters,
                          preconditioning_transform=preconditioning_transform, rng=rng, engine=engine, comm=comm)
         self._adaptive_target_efficiency = False
+        self.device_bisection = True  # single-rank: whole adaptive-beta search on device (asmc_find_beta)
         self.resample_mode = "exact"
         self.resample_method = "multinomial"
 
@@ -72,11 +73,22 @@ class SMCSampler(MCMCSampler):
         def eff_fn(betas):
             return [smc_math.ess(s) / n for s in self._stats(samples, betas)]
 
+        search_fn = None
+        if self.comm.world == 1 and hasattr(self.engine, "find_beta") and self.device_bisection and beta < 1.0:
+            def search_fn(beta_prev, target_eff, tol):
+                b, _, converged, passes, n_nan = self.engine.find_beta(
+                    samples.log_likelihood, samples.log_prior, samples.log_q, float(beta_prev), float(target_eff), float(tol))
+                if n_nan > 0:
+                    raise ValueError(f"Log weights contain NaN values for beta={b}")
+                if not converged:
+                    raise RuntimeError("device-side beta search did not converge")
+                return b, passes
+
         beta, min_beta_step, _ = smc_math.determine_beta(
             eff_fn, beta, adaptive=self.adaptive, beta_step=beta_step, min_beta_step=min_beta_step,
             max_beta_step=max_beta_step, beta_tolerance=beta_tolerance,
             adaptive_min_beta_step=self.adaptive_min_beta_step, target=self._target_efficiency,
-            rate=self.target_efficiency_rate, logger=logger)
+            rate=self.target_efficiency_rate, logger=logger, search_fn=search_fn)
         return beta, min_beta_step
 
     def _wrap(self, x, ll, lp, lq, beta) -> SMCSamples:

@@ -132,9 +132,11 @@ def _bisection_tree(lo: float, hi: float, levels: int):
 
 def determine_beta(eff_fn, beta: float, *, adaptive: bool, beta_step: float, min_beta_step: float,
                    max_beta_step: float, beta_tolerance: float, adaptive_min_beta_step: bool, target,
-                   rate: float, levels: int = BISECT_LEVELS, logger=None):
+                   rate: float, levels: int = BISECT_LEVELS, logger=None, search_fn=None):
     """smc/base.py:123-213.  `eff_fn(betas) -> list[float]` returns ESS/N for candidate betas
-    (one device pass per call).  Returns (beta, min_beta_step, n_passes)."""
+    (one device pass per call).  `search_fn(beta_prev, target_eff, tol) -> (beta_star, n_passes)`, when
+    given, runs the whole ESS(1.0)-check + bisection on the device (asmc_find_beta) instead.
+    Returns (beta, min_beta_step, n_passes)."""
     n_pass = 0
     if not adaptive:
         beta += beta_step
@@ -144,12 +146,16 @@ def determine_beta(eff_fn, beta: float, *, adaptive: bool, beta_step: float, min
     beta_prev = beta
     beta_min = beta_prev
     beta_max = 1.0
-    eff_beta_max = eff_fn([beta_max])[0]
-    n_pass += 1
     current_eff = current_target_efficiency(target, rate, beta_prev)
-    if eff_beta_max >= current_eff:
-        beta_min = 1.0
     target_eff = current_eff
+    if search_fn is not None:
+        beta_min, n_pass = search_fn(beta_prev, target_eff, beta_tolerance)
+        beta_max = beta_min  # converged on device
+    else:
+        eff_beta_max = eff_fn([beta_max])[0]
+        n_pass += 1
+        if eff_beta_max >= current_eff:
+            beta_min = 1.0
     while beta_max - beta_min > beta_tolerance:
         mids = _bisection_tree(beta_min, beta_max, levels)
         effs = eff_fn(mids)

@@ -127,6 +127,14 @@ int asmc_weights_sums(asmc_ctx* ctx, int64_t n, const double* ll_dev, const doub
 int asmc_weights_stats(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
                        const double* lq_dev, double beta0, const double* betas_host, int K,
                        double* out_host, asmc_stream stream);
+/* SMCSampler.determine_beta's adaptive search (smc/base.py:167-186) without host round trips: ESS(1.0) check,
+ * then k-ary bisection rounds (15 midpoints = 4 levels per pass, the reference's 0.5*(max+min) values) chained
+ * on the stream; decisions use the same scalar formulas on device.  Single-rank only (sharded runs drive the
+ * rounds from the host because every pass needs a collective).
+ * out_host[6] = {beta_star (= beta_min), beta_max, converged, device passes, ESS(1.0)/N, n_nan}. */
+int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
+                   const double* lq_dev, double beta0, double target_eff, double tol,
+                   double* out_host, asmc_stream stream);
 int asmc_weights_m2(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
                     const double* lq_dev, double beta0, double beta, double m, double mean_u,
                     double* m2_host, asmc_stream stream);

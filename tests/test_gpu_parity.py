@@ -123,6 +123,26 @@ def test_determine_beta_matches_reference_golden(eng, golden):
         assert b == b_ref, (n, b0, tol, ti, b, b_ref)
 
 
+def test_device_side_bisection_matches_reference_golden(eng, golden):
+    """asmc_find_beta (whole search on device, no host round trips) returns the reference's beta* bit-for-bit."""
+    g = golden["ref_beta"]
+    from aspire_amd import smc_math
+
+    for n, d, seed, b0, tol, ti, b_ref in g["cases"]:
+        n, d, seed, ti = int(n), int(d), int(seed), int(ti)
+        x, ll, lp, lq = synth(n, d, 0, 2.0) if seed == 0 else synth(n, d, seed)
+        target = smc_math.current_target_efficiency([0.5, (0.3, 0.9)][ti], 1.0, b0)
+        b, eff1, conv, passes, n_nan = eng.find_beta(*dev(eng, ll, lp, lq), b0, target, tol)
+        assert conv and n_nan == 0 and b == b_ref, (n, b0, tol, ti, b, b_ref)
+        assert passes <= 9
+    # ESS(1.0) >= target short-circuits to beta* = 1 (smc/base.py:170-175)
+    z = eng.asarray(np.zeros(64))
+    assert eng.find_beta(z, z, z, 0.0, 0.5, 1e-6)[0] == 1.0
+    # NaN inputs are reported
+    bad = eng.asarray(np.array([0.0, np.nan, 1.0, 2.0]))
+    assert eng.find_beta(bad, z[:4].contiguous(), z[:4].contiguous(), 0.0, 0.5, 1e-6)[4] > 0
+
+
 # ---- K6: PCG64, cdf, search ---------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 7, 1000, 65536, 65537, 300001])
 def test_pcg64_uniforms_bit_exact_vs_numpy(eng, n):

@@ -21,8 +21,12 @@ rng = np.random.default_rng(1)
 def is_step():
     def eff_fn(betas):
         return [smc_math.ess(s) / n for s in smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, betas, n)]
+    def search_fn(b0, target, tol):
+        b, _, conv, passes, n_nan = eng.find_beta(ll, lp, lq, b0, target, tol)
+        return b, passes
     beta, _, _ = smc_math.determine_beta(eff_fn, 0.0, adaptive=True, beta_step=float("nan"), min_beta_step=0.0, max_beta_step=1.0,
-                                         beta_tolerance=1e-6, adaptive_min_beta_step=False, target=0.5, rate=1.0)
+                                         beta_tolerance=1e-6, adaptive_min_beta_step=False, target=0.5, rate=1.0,
+                                         search_fn=None if os.environ.get("HOSTBIS") else search_fn)
     st_b, st_1 = smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, [beta, 1.0], n)
     smc_math.evidence_variance(eng, comm, ll, lp, lq, 0.0, beta, st_b)
     idx, _ = smc_math.resample_indices(eng, comm, ll, lp, lq, 0.0, beta, n, rng, mode=os.environ.get("MODE", "exact"))
