@@ -257,27 +257,33 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const dou
                 ee = tile_info[4 * my_t + 2];
                 sf = tile_info[4 * my_t + 3];
             }
-            // chain state as (integer S on the grid of binade e_cur): consecutive safe tiles of one binade
-            // are pure integer adds; anything else (binade change, overflow of the grid, unsafe flag) stops
-            // the walk and goes through exact_tile
+            // chain state as (integer S on the grid of binade e_cur): consecutive safe tiles of one binade are
+            // pure integer transducer applications, so a batch of 64 tiles is ONE wave-level ordered scan; the
+            // first tile that is flagged unsafe, sits in another binade or would push S past 2^53 stops the walk
+            // and goes through exact_tile
             const int e_cur = binade_of(s);
-            long long S = (s > 0.0) ? (long long)ldexp(s, 52 - e_cur) : -1;
-            long long my_S = 0;
-            int stop = 64;
-            for (int i = 0; i < 64; i++) {
-                const long long a0i = readlane_ll(a0, i), a1i = readlane_ll(a1, i);
-                const int ei = __builtin_amdgcn_readlane((int)ee, i);
-                const int sfi = __builtin_amdgcn_readlane((int)sf, i);
-                const long long Sout = S + ((S & 1) ? a1i : a0i);
-                if (!(sfi == 1 && S >= 0 && ei == e_cur && Sout < TWO53_LL)) {
-                    stop = i;
-                    break;
-                }
-                if (lane == i) my_S = S;
-                S = Sout;
+            const long long S = (s > 0.0) ? (long long)ldexp(s, 52 - e_cur) : -1;
+            const bool ok = (sf == 1) && (S >= 0) && ((int)ee == e_cur);
+            const unsigned long long bad_mask = ~__ballot(ok);
+            int stop = bad_mask ? (int)__builtin_ctzll(bad_mask) : 64;
+            TD inc = {ok ? a0 : 0, ok ? a1 : 0};
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                TD t2;
+                t2.a0 = __shfl_up(inc.a0, o, 64);
+                t2.a1 = __shfl_up(inc.a1, o, 64);
+                if (lane >= o) inc = td_compose(t2, inc);
             }
+            const long long S_out = S + ((S & 1) ? inc.a1 : inc.a0);
+            long long ex0 = __shfl_up(inc.a0, 1, 64), ex1 = __shfl_up(inc.a1, 1, 64);
+            if (lane == 0) ex0 = ex1 = 0;
+            const long long my_S = S + ((S & 1) ? ex1 : ex0);
+            const unsigned long long ovf_mask = __ballot(S_out >= TWO53_LL);
+            const int first_ovf = ovf_mask ? (int)__builtin_ctzll(ovf_mask) : 64;
+            stop = stop < first_ovf ? stop : first_ovf;
             const double my_s = ldexp((double)my_S, e_cur - 52);
-            const double ss = (stop > 0) ? ldexp((double)S, e_cur - 52) : s;
+            const long long S_end = stop > 0 ? __shfl(S_out, stop - 1, 64) : S;
+            const double ss = (stop > 0) ? ldexp((double)S_end, e_cur - 52) : s;
             if (lane < stop) tile_s[my_t] = my_s;
             if (lane == 0) {
                 sh_walk_t = t + stop;

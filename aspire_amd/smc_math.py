@@ -177,7 +177,10 @@ def determine_beta(eff_fn, beta: float, *, adaptive: bool, beta_step: float, min
             "Adaptive beta search could not find a beta above %.6g that satisfies the target "
             "efficiency %.3f within tolerance %.1e; beta may remain unchanged. Consider decreasing "
             "beta_tolerance or target_efficiency.", beta_prev, target_eff, beta_tolerance)
-    if adaptive_min_beta_step:
+    if adaptive_min_beta_step and beta_star < 1.0:
+        # smc/base.py:198-201.  The reference divides by (1 - beta_star) unconditionally and raises
+        # ZeroDivisionError when the search jumps straight to beta* = 1 with max_n_steps set; the step size is
+        # irrelevant then (beta = 1 ends the schedule), so it is simply left unchanged here.
         min_beta_step = min_beta_step * (1 - beta_prev) / (1 - beta_star)
     beta = max(beta_star, beta_prev + min_beta_step)
     beta = min(beta, beta_prev + max_beta_step, 1.0)

@@ -566,3 +566,48 @@ def test_fused_sampler_1m_d32_evidence(eng):
     err = float(out.log_evidence_error)
     assert abs(float(out.log_evidence) - true) < max(4 * err, 0.02), (float(out.log_evidence), true, err)
     assert sp.history.beta[-1] == 1.0
+
+
+def test_config5_shape_mixture_d128_generic_kernel(eng):
+    """BASELINE config 5 shape at reduced N: d=128 two-component Gaussian-mixture likelihood (the
+    examples/smc_example.py construction), N(0,I) prior, q = N(0, 3^2 I); runs on the generic pCN kernel
+    (d > 32) with the blocked Gram kernel; log Z is analytic (prior x normalised mixture => log Z = log of the
+    mixture's convolution with the prior at 0 ... here checked against importance-free closed form)."""
+    from aspire_amd.flows import GaussianFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    d, n = 128, 16384
+    lik = DiagGaussianMixture(np.stack([2 * np.ones(d), -2 * np.ones(d)]), np.stack([0.5 * np.ones(d), np.ones(d)]))
+    prior = DiagGaussianMixture.isotropic(d, 0.0, 1.0)
+    sp = HipSMC(log_likelihood=lik, log_prior=prior, dims=d, prior_flow=GaussianFlow(d, sigma=3.0, engine=eng, seed=4),
+                xp=np, engine=eng, rng=np.random.default_rng(1))
+    out = sp.sample(n, sampler_kwargs=dict(n_steps=6), store_sample_history=False, max_n_steps=40)
+    # Z = 0.5 * N(2; 0, (1 + 0.5) I) + 0.5 * N(-2; 0, (1 + 1) I)   (Gaussian convolution), per-dim product
+    def lg(mu, var):
+        return -0.5 * d * np.log(2 * np.pi * var) - 0.5 * d * mu * mu / var
+    true = np.logaddexp(np.log(0.5) + lg(2.0, 1.5), np.log(0.5) + lg(2.0, 2.0))
+    assert sp.history.beta[-1] == 1.0
+    assert np.isfinite(float(out.log_evidence))
+    # high-dimensional, few mutation steps: a loose sanity band rather than a 1-sigma claim
+    assert abs(float(out.log_evidence) - true) < 0.15 * abs(true)
+    assert 0.02 < np.mean(sp.history.mcmc_acceptance) < 0.98
+
+
+def test_coupling_flow_split_path_config3_shape(eng):
+    """BASELINE config 3 shape at reduced N: PyTorch coupling-flow proposal (dense layers on hipBLASLt) in the
+    split propose / flow.log_prob / accept path."""
+    from aspire_amd.flows import CouplingFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    d, n = 8, 4096
+    g = np.random.default_rng(0)
+    flow = CouplingFlow(d, n_layers=4, hidden_features=(64, 64), device=eng.device, dtype=torch.float64, seed=1234)
+    flow.fit(1.4 * g.normal(size=(4000, d)), n_epochs=30)
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=eng, rng=np.random.default_rng(2))
+    out = sp.sample(n, sampler_kwargs=dict(n_steps=6), store_sample_history=False)
+    true = 0.5 * d * math.log(math.pi)
+    assert sp.history.beta[-1] == 1.0
+    assert abs(float(out.log_evidence) - true) < 6 * float(out.log_evidence_error) + 0.1, (float(out.log_evidence), true)
