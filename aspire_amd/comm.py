@@ -7,9 +7,9 @@ the same generator produce the same global resample indices.
 Collectives used by the hot path:
   C1  all-reduce(max) + all-gather of the per-rank (S1, S2) sums per candidate beta; merged on every
       rank in rank order (bitwise identical on all ranks)
-  C2  exact-cdf carry chained rank to rank (sequential fp64 rounding preserved) / exclusive sum of
-      per-rank masses in fast mode
-  C3  all-gather of the normalised cdf, all-to-all of requested rows
+  C2  all-gather of the normalised weights (8 B/particle); every rank then runs the same exact
+      (sequential-order) scan over all N, so no rank-to-rank dependency chain exists
+  C3  all-to-all of requested rows (index lists, then rows)
   C4  all-gather of column sums / centred Gram partials, accept counts
 Scalars travel as small fp64 tensors; with xGMI's point-to-point links an all-gather of 24*K bytes
 is latency bound, so every scalar exchange is ONE all-gather followed by a local rank-ordered merge.

@@ -115,7 +115,7 @@ class SMCSampler(MCMCSampler):
         n_local = n_samples // comm.world
         if hasattr(self.engine, "ensure_capacity"):
             nf = n_final_samples or 0
-            self.engine.ensure_capacity(max(n_local, -(-nf // comm.world)), self.dims)
+            self.engine.ensure_capacity(max(n_samples if comm.world > 1 else n_local, nf), self.dims)
         if hasattr(self.prior_flow, "gid0"):
             self.prior_flow.gid0 = comm.rank * n_local
         resumed = resume_from is not None

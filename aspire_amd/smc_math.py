@@ -258,25 +258,15 @@ def resample_indices(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out:
                 s1p = s1p + parts[r][0, 0]
         lse = float(mp + np.log(s1p))
         w = engine.normalized_weights(ll, lp, lq, beta0, beta, shift, lse)
-    # cumulative sum in global order: exact mode chains the running sum rank to rank
-    if comm.world == 1:
-        cdf, last = engine.cdf(w, mode, 0.0)
-    elif mode == "exact":
-        carry = comm.chain_recv()
-        cdf, total = engine.cdf(w, mode, 0.0 if carry is None else carry)
-        comm.chain_send(total)
-        last = comm.broadcast_f64(total, comm.world - 1)
-    else:
-        _, mass = engine.cdf(w, mode, 0.0)
-        masses = comm.all_gather_f64(np.array([mass]))[:, 0]
-        carry = 0.0
-        for r in range(comm.rank):
-            carry = carry + masses[r]
-        cdf, total = engine.cdf(w, mode, carry)
-        last = comm.broadcast_f64(total, comm.world - 1)
-    engine.cdf_normalize(cdf, last)
+    # cumulative sum in GLOBAL particle order.  Sharded: every rank needs the whole normalised cdf for its
+    # searches anyway, so the weights (8 B/particle) are all-gathered and each rank runs the same exact
+    # (sequential-order) scan over all N — no rank-to-rank dependency chain, and bitwise identical everywhere.
     if comm.world > 1:
-        cdf = comm.all_gather_tensor(cdf)
+        w = comm.all_gather_tensor(w)
+        if hasattr(engine, "ensure_capacity"):
+            engine.ensure_capacity(w.numel(), 1)
+    cdf, last = engine.cdf(w, mode, 0.0)
+    engine.cdf_normalize(cdf, last)
     # this rank's output slots
     per = -(-n_out // comm.world)
     j0 = min(comm.rank * per, n_out)

@@ -74,7 +74,7 @@ def main():
     n_global = n_local * world
     xdt = torch.float64 if args.x_dtype == "f64" else torch.float32
     s_bytes = 8 if args.x_dtype == "f64" else 4
-    eng = HipEngine(local_rank, n_max=n_local, d_max=max(d, 32))
+    eng = HipEngine(local_rank, n_max=n_global, d_max=max(d, 32))  # the replicated exact cdf scan covers all N
     comm = default_comm(eng.device)
 
     # ---- synthetic batch, resident in HBM ---------------------------------------------------
