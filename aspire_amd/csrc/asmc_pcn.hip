@@ -159,6 +159,26 @@ __device__ __forceinline__ void tile_store(char* __restrict__ g, int64_t valid_b
     }
 }
 
+// coalesced LDS -> global copy of the rows selected by `rowmask` (bit r = row r of the tile): rows whose
+// proposal was rejected are simply not written, so a step writes acc_rate * d * s bytes per particle
+template <int VEC>
+__device__ __forceinline__ void tile_store_rows(char* __restrict__ g, int64_t valid_bytes, int rowbytes, int ldsrow,
+                                                const char* lds, int lane, unsigned long long rowmask) {
+    const int tile_bytes = 64 * rowbytes;
+    for (int off = lane * VEC; off < tile_bytes; off += 64 * VEC) {
+        if (off >= valid_bytes) break;
+        const int r = off / rowbytes, c = off - r * rowbytes;
+        if (!((rowmask >> r) & 1ULL)) continue;
+        if (VEC == 16)
+            *reinterpret_cast<uint4*>(g + off) = *reinterpret_cast<const uint4*>(lds + r * ldsrow + c);
+        else if (VEC == 8)
+            *reinterpret_cast<unsigned long long*>(g + off) =
+                *reinterpret_cast<const unsigned long long*>(lds + r * ldsrow + c);
+        else
+            *reinterpret_cast<uint32_t*>(g + off) = *reinterpret_cast<const uint32_t*>(lds + r * ldsrow + c);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ double row_get(const char* row, int j) {
     return (double)reinterpret_cast<const T*>(row)[j];
@@ -320,8 +340,10 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_step(
         if (active) {
             if (PHASE == 1) {
                 tile_store<VEC>(reinterpret_cast<char*>(x_prop) + row0 * rowbytes, valid_bytes, rowbytes, ldsrow, tile, lane);
-            } else if (__ballot(acc) != 0ULL) {
-                tile_store<VEC>(reinterpret_cast<char*>(x) + row0 * rowbytes, valid_bytes, rowbytes, ldsrow, tile, lane);
+            } else {
+                const unsigned long long accmask = __ballot(acc);
+                if (accmask != 0ULL)
+                    tile_store_rows<VEC>(reinterpret_cast<char*>(x) + row0 * rowbytes, valid_bytes, rowbytes, ldsrow, tile, lane, accmask);
             }
         }
         __syncthreads();
@@ -646,7 +668,10 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
             }
         }
         wave_lds_sync();
-        if (__ballot(acc) != 0ULL) tile_store<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane);
+        {
+            const unsigned long long accmask = __ballot(acc);
+            if (accmask != 0ULL) tile_store_rows<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane, accmask);
+        }
         wave_lds_sync();
     }
     if (MODE == PCN_X_STEP || MODE == PCN_Y_STEP) {
