@@ -20,7 +20,7 @@ ASMC_NOISE_F64, ASMC_NOISE_F32 = 0, 1
 ASMC_MAX_BETAS = 32
 ASMC_MAX_COMPONENTS = 8
 ASMC_MAX_DIMS = 256
-ASMC_ABI_VERSION = 1
+ASMC_ABI_VERSION = 2
 
 
 class AsmcMixture(ctypes.Structure):
@@ -49,6 +49,19 @@ class AsmcPcnParams(ctypes.Structure):
         ("target_accept", c_double),
         ("adapt", c_int32),
         ("noise", c_int32),
+    ]
+
+
+class AsmcCoupling(ctypes.Structure):
+    _fields_ = [
+        ("dims", c_int32),
+        ("n_layers", c_int32),
+        ("hidden", c_int32),
+        ("reserved", c_int32),
+        ("packed_dev", c_void_p),
+        ("loc_dev", c_void_p),
+        ("scale_dev", c_void_p),
+        ("log_scale_sum", c_double),
     ]
 
 
@@ -92,6 +105,9 @@ SIGNATURES = {
         _i,
         [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _u64, _u64, _u32, _pi64, _vp],
     ),
+    "asmc_coupling_pack_floats": (_i64, [_i, _i, _i]),
+    "asmc_coupling_pack": (_i, [_i, _i, _i, POINTER(c_void_p), POINTER(c_void_p), _vp]),
+    "asmc_coupling_logprob": (_i, [_vp, _i64, _i, _vp, POINTER(AsmcCoupling), _vp, _vp]),
 }
 
 _lib = None

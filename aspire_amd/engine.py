@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ASMC_CDF_EXACT, ASMC_CDF_FAST, ASMC_F32, ASMC_F64, AsmcMixture, AsmcPcnParams, check
+from ._lib import ASMC_CDF_EXACT, ASMC_CDF_FAST, ASMC_F32, ASMC_F64, AsmcCoupling, AsmcMixture, AsmcPcnParams, check
 
 CDF_MODES = {"exact": ASMC_CDF_EXACT, "fast": ASMC_CDF_FAST}
 
@@ -50,6 +50,44 @@ class DeviceMixture:
 
     def c_struct(self) -> AsmcMixture:
         return AsmcMixture(self.n_components, 0, self.logw.data_ptr(), self.mu.data_ptr(), self.prec.data_ptr())
+
+
+@dataclass
+class DeviceCoupling:
+    """Affine coupling flow with its parameters packed in MFMA operand order, resident in HBM."""
+
+    dims: int
+    n_layers: int
+    hidden: int
+    packed: torch.Tensor  # fp32 [asmc_coupling_pack_floats]
+    loc: torch.Tensor  # fp32 [dims]
+    scale: torch.Tensor  # fp32 [dims]
+    log_scale_sum: float
+
+    def c_struct(self) -> AsmcCoupling:
+        return AsmcCoupling(self.dims, self.n_layers, self.hidden, 0, self.packed.data_ptr(), self.loc.data_ptr(),
+                            self.scale.data_ptr(), self.log_scale_sum)
+
+
+def pack_coupling(lib, dims: int, hidden: int, weights, biases) -> np.ndarray:
+    """Host-side packing (asmc_coupling_pack): torch.nn.Linear-layout fp32 arrays, three per coupling layer."""
+    n_layers = len(weights) // 3
+    assert len(weights) == len(biases) == 3 * n_layers and n_layers >= 1
+    ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+    bs = [np.ascontiguousarray(b, dtype=np.float32) for b in biases]
+    dh = dims // 2
+    for c in range(n_layers):
+        assert ws[3 * c].shape == (hidden, dh) and ws[3 * c + 1].shape == (hidden, hidden)
+        assert ws[3 * c + 2].shape == (dims, hidden)
+        assert bs[3 * c].shape == (hidden,) and bs[3 * c + 1].shape == (hidden,) and bs[3 * c + 2].shape == (dims,)
+    nfl = lib.asmc_coupling_pack_floats(dims, n_layers, hidden)
+    if nfl < 0:
+        raise _lib.AsmcError(f"coupling flow shape not supported by the HIP kernel: {lib.asmc_last_error().decode()}")
+    out = np.empty(nfl, dtype=np.float32)
+    wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+    bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
+    check(lib.asmc_coupling_pack(dims, n_layers, hidden, wp, bp, out.ctypes.data_as(ctypes.c_void_p)), "asmc_coupling_pack")
+    return out
 
 
 class HipEngine:
@@ -268,6 +306,21 @@ class HipEngine:
         cs = mix.c_struct()
         check(self.lib.asmc_mixture_logpdf(self._ctx, x.shape[0], x.shape[1], self._xdt(x), _dptr(x), ctypes.byref(cs),
                                            _dptr(out), self._stream), "asmc_mixture_logpdf")
+        return out
+
+    def make_coupling(self, dims: int, hidden: int, weights, biases, loc, scale) -> DeviceCoupling:
+        packed = pack_coupling(self.lib, dims, hidden, weights, biases)
+        scale = np.asarray(scale, dtype=np.float32)
+        return DeviceCoupling(dims, len(weights) // 3, hidden, self.asarray(packed, dtype=torch.float32),
+                              self.asarray(np.asarray(loc, dtype=np.float32), dtype=torch.float32),
+                              self.asarray(scale, dtype=torch.float32), float(np.log(scale.astype(np.float64)).sum()))
+
+    def coupling_logprob(self, x: torch.Tensor, flow: DeviceCoupling) -> torch.Tensor:
+        assert x.is_contiguous() and x.dim() == 2 and x.shape[1] == flow.dims
+        out = self.empty(x.shape[0])
+        cs = flow.c_struct()
+        check(self.lib.asmc_coupling_logprob(self._ctx, x.shape[0], self._xdt(x), _dptr(x), ctypes.byref(cs), _dptr(out),
+                                             self._stream), "asmc_coupling_logprob")
         return out
 
     def compact_valid(self, x, ll, lp, lq):

@@ -164,6 +164,35 @@ class CouplingFlow(Flow):
         self.scale = torch.ones(dims, device=self.device, dtype=dtype)
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(seed)
+        self._packed, self._version = None, 0  # device pack cache; bumped whenever the parameters change
+
+    def export_layers(self):
+        """(weights, biases): fp32 numpy arrays, three dense layers per coupling layer, torch Linear layout."""
+        ws, bs = [], []
+        for layer in self.layers:
+            lin = [m for m in layer.net if isinstance(m, torch.nn.Linear)]
+            if len(lin) != 3:
+                raise ValueError("the HIP coupling kernel needs exactly two hidden layers")
+            for m in lin:
+                ws.append(m.weight.detach().to("cpu", torch.float32).numpy())
+                bs.append(m.bias.detach().to("cpu", torch.float32).numpy())
+        return ws, bs
+
+    def device_coupling(self, engine):
+        """Pack the flow for asmc_coupling_logprob (fp32 MFMA kernel).  Only for float32 flows (the kernel computes
+        in the flow's dtype) of a supported shape; raises otherwise so callers fall back to the torch modules
+        knowingly."""
+        if self.dtype != torch.float32:
+            raise ValueError("device_coupling needs a float32 flow")
+        key = (id(engine), self._version)
+        if self._packed is None or self._packed[0] != key:
+            ws, bs = self.export_layers()
+            hidden = ws[0].shape[0]
+            if ws[1].shape != (hidden, hidden) or self.dims % 2:
+                raise ValueError("the HIP coupling kernel needs equal hidden widths and even dims")
+            self._packed = (key, engine.make_coupling(self.dims, hidden, ws, bs, self.loc.detach().cpu().numpy(),
+                                                     self.scale.detach().cpu().numpy()))
+        return self._packed[1]
 
     def to(self, device):
         self.device = torch.device(device)
@@ -236,6 +265,7 @@ class CouplingFlow(Flow):
         if best_state is not None:
             self.layers.load_state_dict(best_state)
         self.layers.eval()
+        self._version += 1
         return hist
 
     @torch.no_grad()

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 1
+#define ASMC_ABI_VERSION 2
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -227,6 +227,38 @@ int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x_dev,
                     const double* qform_old_dev, const double* qform_new_dev, double beta,
                     uint64_t seed, uint64_t gid0, uint32_t step, int64_t* n_accept_host,
                     asmc_stream stream);
+
+/* ---- coupling-flow log-density ------------------------------------------
+ * Replaces the torch round trip of Flow.log_prob (flows/torch/flows.py:368-387) inside the tempered
+ * log-target of each MCMC step (smc/base.py:507-519) and in draw_initial_samples (mcmc.py:49-110).
+ * The flow is an affine coupling flow (RealNVP): x' = (x - loc) / scale, then n_layers coupling layers
+ * whose masks alternate first half / second half; each conditioner is the MLP
+ * d/2 -> hidden -> hidden -> d (ReLU), its output split into (s_raw, t) for the d/2 transformed
+ * coordinates; s = 2 tanh(s_raw / 2), z_b = (x_b - t) exp(-s);
+ * log q(x) = -|z|^2 / 2 - d/2 log(2 pi) - sum s - sum log(scale).  fp32 arithmetic on the fp32-input
+ * MFMA, result widened to fp64.  zuko (the reference's flow library) is absent: parity unpinned.
+ *   asmc_coupling_pack_floats: length of the packed parameter block, or <0 when the shape is
+ *     unsupported (dims even, <= 64; hidden in {32, 64, 128}).
+ *   asmc_coupling_pack (host only, no GPU): weights_host[3c+0..2] / biases_host[3c+0..2] are the
+ *     three dense layers of coupling layer c in torch.nn.Linear layout ([out, in] row-major;
+ *     [hidden, d/2], [hidden, hidden], [d, hidden] with output rows s_raw_0.. then t_0..);
+ *     writes them in MFMA operand order into packed_host.
+ *   asmc_coupling_logprob: out_dev[i] = log q(x_i). */
+typedef struct asmc_coupling {
+    int32_t dims;
+    int32_t n_layers;
+    int32_t hidden;
+    int32_t reserved;
+    const float* packed_dev; /* asmc_coupling_pack output copied to the device */
+    const float* loc_dev;    /* [dims] */
+    const float* scale_dev;  /* [dims] */
+    double log_scale_sum;    /* sum_j log(scale_j) */
+} asmc_coupling;
+int64_t asmc_coupling_pack_floats(int dims, int n_layers, int hidden);
+int asmc_coupling_pack(int dims, int n_layers, int hidden, const float* const* weights_host,
+                       const float* const* biases_host, float* packed_host);
+int asmc_coupling_logprob(asmc_ctx* ctx, int64_t n, int x_dtype, const void* x_dev,
+                          const asmc_coupling* flow, double* out_dev, asmc_stream stream);
 
 #ifdef __cplusplus
 }

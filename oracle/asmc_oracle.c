@@ -14,6 +14,10 @@
  *     package `minipcn[array-api]>=0.2.0a3` (reference pyproject.toml:44; call site
  *     src/aspire/samplers/smc/minipcn.py:89-114), which is absent from /root/reference and from
  *     this image.  These functions restate THIS REPOSITORY's pCN specification.
+ *   - orc_coupling_logprob: PARITY UNPINNED.  The reference's flows are zuko modules (reference
+ *     pyproject.toml:40, call sites src/aspire/flows/torch/flows.py:156-168,327-387); zuko is absent.
+ *     The function restates this repository's CouplingFlow (aspire_amd/flows.py) in fp32 and is
+ *     pinned only against that torch module (tests/test_oracle.py).
  *
  * Every function cites the reference file:line (relative to /root/reference) it follows.
  * Plain C11, no dependencies beyond libm.  Build: see oracle/Makefile.
@@ -628,4 +632,57 @@ int orc_is_iteration(int64_t n, int d, const double* x, const double* ll, const 
     free(u);
     free(idx);
     return st;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Coupling-flow log-density, fp32 (the flow's dtype; reference flows default to float32,
+ * src/aspire/flows/torch/flows.py:31-35).  Same role as ZukoFlow.log_prob
+ * (src/aspire/flows/torch/flows.py:368-387): standardise, run the flow data -> latent, return
+ * base log-density + log|det J|.  The flow is this repository's RealNVP (aspire_amd/flows.py):
+ * masks alternate first half / second half; conditioner MLP d/2 -> hidden -> hidden -> d with ReLU
+ * (torch.nn.Linear layout [out, in]); s = 2 tanh(s_raw/2); z_b = (x_b - t) exp(-s).
+ * weights[3c+k] / biases[3c+k]: layer k of coupling layer c.  x is [n, d] fp64 and is cast to fp32
+ * first (torch.as_tensor(x, dtype=float32)).  Dot products are accumulated in index order.
+ * ---------------------------------------------------------------------------------------- */
+static void dense_f32(int n_out, int n_in, const float* W, const float* b, const float* in, float* out,
+                      int relu) {
+    for (int o = 0; o < n_out; o++) {
+        float acc = b[o];
+        for (int k = 0; k < n_in; k++) acc = fmaf(W[(int64_t)o * n_in + k], in[k], acc);
+        out[o] = (relu && acc < 0.0f) ? 0.0f : acc;
+    }
+}
+
+int orc_coupling_logprob(int64_t n, int d, const double* x, int n_layers, int hidden,
+                         const float* const* weights, const float* const* biases, const float* loc,
+                         const float* scale, double* out) {
+    if (d < 2 || d % 2 || n_layers < 1 || hidden < 1) return ORC_ERR_ARG;
+    const int dh = d / 2;
+    float* z = (float*)malloc(sizeof(float) * (size_t)(d + 2 * hidden + d));
+    float *h1 = z + d, *h2 = h1 + hidden, *o = h2 + hidden;
+    float log_scale_sum = 0.0f;
+    for (int j = 0; j < d; j++) log_scale_sum += logf(scale[j]);
+    for (int64_t i = 0; i < n; i++) {
+        for (int j = 0; j < d; j++) z[j] = ((float)x[i * d + j] - loc[j]) / scale[j];
+        float ladj = -log_scale_sum;
+        for (int c = 0; c < n_layers; c++) {
+            float* cond = (c % 2 == 0) ? z : z + dh;
+            float* trans = (c % 2 == 0) ? z + dh : z;
+            dense_f32(hidden, dh, weights[3 * c], biases[3 * c], cond, h1, 1);
+            dense_f32(hidden, hidden, weights[3 * c + 1], biases[3 * c + 1], h1, h2, 1);
+            dense_f32(d, hidden, weights[3 * c + 2], biases[3 * c + 2], h2, o, 0);
+            float ssum = 0.0f;
+            for (int j = 0; j < dh; j++) {
+                const float sj = 2.0f * tanhf(o[j] * 0.5f);
+                trans[j] = (trans[j] - o[dh + j]) * expf(-sj);
+                ssum += sj;
+            }
+            ladj -= ssum;
+        }
+        float q = 0.0f;
+        for (int j = 0; j < d; j++) q += z[j] * z[j];
+        out[i] = (double)((-0.5f * q - 0.5f * (float)d * 1.8378770664093453f) + ladj);
+    }
+    free(z);
+    return ORC_OK;
 }

@@ -80,6 +80,7 @@ def lib():
             "orc_pcn_adapt": (d, [d, d, d, ci]),
             "orc_moments": (None, [i64, ci, vp, vp, vp]),
             "orc_is_iteration": (ci, [i64, ci, vp, vp, vp, vp, d, d, d, vp, vp, vp, vp, vp, vp]),
+            "orc_coupling_logprob": (ci, [i64, ci, vp, ci, ci, vp, vp, vp, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(_lib, name)
@@ -360,3 +361,21 @@ def is_iteration(x, ll, lp, lq, beta0, target_eff, tol, rng_state):
     )
     _check(st)
     return (xo, llo, lpo, lqo), sc
+
+
+def coupling_logprob(x, weights, biases, loc, scale):
+    """fp32 log-density of the RealNVP coupling flow; weights/biases: 3 per coupling layer, torch Linear layout."""
+    x = _f64(np.atleast_2d(x))
+    n, d = x.shape
+    ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+    bs = [np.ascontiguousarray(b, dtype=np.float32) for b in biases]
+    hidden = ws[0].shape[0]
+    loc = np.ascontiguousarray(loc, dtype=np.float32)
+    scale = np.ascontiguousarray(scale, dtype=np.float32)
+    wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+    bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
+    out = np.empty(n)
+    st = lib().orc_coupling_logprob(n, d, _p(x), len(ws) // 3, hidden, wp, bp, loc.ctypes.data, scale.ctypes.data, _p(out))
+    if st != 0:
+        raise ValueError(f"orc_coupling_logprob failed ({st})")
+    return out

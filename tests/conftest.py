@@ -49,3 +49,25 @@ def hip_engine():
     from aspire_amd.engine import HipEngine
 
     return HipEngine(0, n_max=1 << 21, d_max=128)
+
+
+def random_coupling_flow(d, n_layers=4, hidden=64, seed=3, dtype=None, device="cpu"):
+    """CouplingFlow with every dense layer randomised (the constructor zeroes the output layers) and a
+    non-trivial standardisation, for flow parity tests."""
+    import torch
+
+    from aspire_amd.flows import CouplingFlow
+
+    flow = CouplingFlow(d, n_layers=n_layers, hidden_features=(hidden, hidden), seed=seed, device=device,
+                        dtype=dtype or torch.float32)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for layer in flow.layers:
+            for m in layer.net:
+                if isinstance(m, torch.nn.Linear):
+                    m.weight.copy_((0.5 * torch.randn(m.weight.shape, generator=g) / m.weight.shape[1] ** 0.5).to(m.weight))
+                    m.bias.copy_((0.1 * torch.randn(m.bias.shape, generator=g)).to(m.bias))
+        flow.loc = (0.3 * torch.randn(d, generator=g)).to(flow.loc)
+        flow.scale = (0.5 + torch.rand(d, generator=g)).to(flow.scale)
+    flow._version += 1
+    return flow

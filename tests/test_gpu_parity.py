@@ -611,3 +611,47 @@ def test_coupling_flow_split_path_config3_shape(eng):
     true = 0.5 * d * math.log(math.pi)
     assert sp.history.beta[-1] == 1.0
     assert abs(float(out.log_evidence) - true) < 6 * float(out.log_evidence_error) + 0.1, (float(out.log_evidence), true)
+
+
+# ---- coupling-flow log-density on the fp32 MFMA -----------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,n_layers,hidden,n,xdt", [
+    (32, 4, 64, 4099, "f64"),   # BASELINE config 3's flow, ragged last tile
+    (32, 4, 64, 4099, "f32"),
+    (32, 6, 64, 1000, "f64"),   # does not fit LDS: streamed layer by layer
+    (32, 1, 32, 33, "f64"),
+    (4, 2, 32, 257, "f64"),     # padded half (2 -> 16)
+    (20, 3, 64, 64, "f32"),
+    (64, 2, 128, 777, "f64"),   # H = 32
+    (48, 3, 64, 1, "f64"),
+])
+def test_coupling_logprob_vs_oracle(eng, oracle, d, n_layers, hidden, n, xdt):
+    """HIP fp32-MFMA flow kernel vs the fp32 C oracle on the same inputs.  Both evaluate in fp32 with different
+    summation orders (MFMA k-order is permuted), so the tolerance is fp32 rounding of the result:
+    |delta| <= 1e-5 |log q| + 3e-4."""
+    from conftest import random_coupling_flow
+
+    flow = random_coupling_flow(d, n_layers, hidden)
+    x = np.random.default_rng(11).normal(size=(n, d)) * 1.3
+    if xdt == "f32":
+        x = x.astype(np.float32).astype(np.float64)
+    ws, bs = flow.export_layers()
+    want = oracle.coupling_logprob(x, ws, bs, flow.loc.numpy(), flow.scale.numpy())
+    dev = flow.device_coupling(eng)
+    xt = eng.asarray(x, dtype=torch.float32 if xdt == "f32" else torch.float64)
+    got = eng.to_numpy(eng.coupling_logprob(xt, dev))
+    assert np.all(np.isfinite(got))
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=3e-4)
+
+
+@pytest.mark.gpu
+def test_coupling_logprob_vs_torch_modules(eng):
+    """The same flow evaluated by its torch modules on the GPU (fp64 copy of the parameters = ground truth)."""
+    from conftest import random_coupling_flow
+
+    flow = random_coupling_flow(32, 4, 64)
+    flow64 = random_coupling_flow(32, 4, 64, dtype=torch.float64).to(eng.device)
+    x = torch.randn((20000, 32), device=eng.device, dtype=torch.float64, generator=torch.Generator(eng.device).manual_seed(1))
+    got = eng.coupling_logprob(x, flow.device_coupling(eng))
+    want = flow64.log_prob(x)
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=5e-4)

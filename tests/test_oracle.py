@@ -115,3 +115,22 @@ def test_pcn_oracle_is_a_valid_kernel(oracle):
         rho = oracle.pcn_adapt(rho, acc / n, 0.234, t)
     assert np.all(np.abs(x.mean(0)) < 0.03) and np.all(np.abs(x.var(0) - 0.5) < 0.03)
     np.testing.assert_allclose(ll, -0.5 * (x**2).sum(1), rtol=1e-12)
+
+
+@pytest.mark.parametrize("d,n_layers,hidden", [(32, 4, 64), (4, 2, 32), (20, 3, 64), (64, 2, 128)])
+def test_coupling_flow_oracle_vs_torch(oracle, d, n_layers, hidden):
+    """orc_coupling_logprob (fp32, C) against the torch CouplingFlow it restates: fp32 module within fp32
+    rounding, fp64 module (same parameters) within the fp32 evaluation error."""
+    import torch
+
+    from conftest import random_coupling_flow
+
+    flow = random_coupling_flow(d, n_layers, hidden)
+    x = np.random.default_rng(5).normal(size=(257, d)) * 1.3
+    ws, bs = flow.export_layers()
+    got = oracle.coupling_logprob(x, ws, bs, flow.loc.numpy(), flow.scale.numpy())
+    ref32 = flow.log_prob(torch.as_tensor(x)).double().numpy()
+    np.testing.assert_allclose(got, ref32, rtol=5e-6, atol=2e-4)
+    flow64 = random_coupling_flow(d, n_layers, hidden, dtype=torch.float64)
+    ref64 = flow64.log_prob(torch.as_tensor(x)).numpy()
+    np.testing.assert_allclose(got, ref64, rtol=2e-5, atol=5e-4)

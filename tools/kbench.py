@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Kernel micro-benchmarks (HIP-event timed) for the hot-path ops.  Usage: python tools/kbench.py [op ...]
-ops: pcn gram colsum cdf search gather weights"""
+ops: pcn gram colsum cdf search gather weights flow"""
 import os
 import sys
 
@@ -29,6 +29,19 @@ def main():
     n, d = int(os.environ.get("N", 1_000_000)), int(os.environ.get("D", 32))
     eng = HipEngine(0, n_max=n, d_max=max(d, 32))
     g = torch.Generator(device="cuda").manual_seed(0)
+    if "flow" in ops:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        from conftest import random_coupling_flow
+
+        flow = random_coupling_flow(d, 4, 64)
+        dev = flow.device_coupling(eng)
+        flops = n * 4 * 2 * ((d // 2) * 64 + 64 * 64 + 64 * d)
+        for xdt in (torch.float64, torch.float32):
+            xx = torch.randn((n, d), device="cuda", dtype=xdt, generator=g)
+            ms = timeit(lambda: eng.coupling_logprob(xx, dev))
+            flow.to("cuda")
+            mt = timeit(lambda: flow.log_prob(xx), reps=3, warm=1)
+            print(f"flow x={xdt}: hip {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s fp32   torch modules {mt*1e3:.1f} us")
     for xdt, sb in ((torch.float64, 8), (torch.float32, 4)):
         x = (1.5 * torch.randn((n, d), device="cuda", dtype=torch.float64, generator=g)).to(xdt)
         tgt = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
