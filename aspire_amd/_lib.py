@@ -108,6 +108,11 @@ SIGNATURES = {
     "asmc_coupling_pack_floats": (_i64, [_i, _i, _i]),
     "asmc_coupling_pack": (_i, [_i, _i, _i, POINTER(c_void_p), POINTER(c_void_p), _vp]),
     "asmc_coupling_logprob": (_i, [_vp, _i64, _i, _vp, POINTER(AsmcCoupling), _vp, _vp]),
+    "asmc_pcn_flow_work_bytes": (_i64, [_i64, _i, _i]),
+    "asmc_pcn_mutate_flow": (
+        _i,
+        [_vp, _i64, _vp, _vp, _vp, _vp, POINTER(AsmcPcnParams), POINTER(AsmcCoupling), _vp, _i64, _i, _u32, _pd, _pi64, _pd, _vp],
+    ),
 }
 
 _lib = None

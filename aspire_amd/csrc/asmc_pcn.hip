@@ -494,6 +494,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 #define PCN_Y_STEP 1
 #define PCN_WHITEN 2
 #define PCN_UNWHITEN 3
+#define PCN_UNWHITEN_X 4  // y -> x in place, carried ll/lp/lq untouched (flow-proposal path)
 
 template <typename T, int D, int NOISE, int MODE>
 __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restrict__ x, double* __restrict__ ll,
@@ -554,13 +555,15 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
                 for (int j = 0; j < D; j++) v[j] = (double)(T)v[j];
                 regs_to_row<T, D>(myrow, v);
                 acc = true;
-            } else if (MODE == PCN_UNWHITEN) {
+            } else if (MODE == PCN_UNWHITEN || MODE == PCN_UNWHITEN_X) {
                 tri_matvec_inplace<D>(Lp, v);
 #pragma unroll
                 for (int j = 0; j < D; j++) v[j] = (double)(T)(mup[j] + v[j]);
-                ll[i] = mixture_eval_regs<D>(mll, v);
-                lp[i] = mixture_eval_regs<D>(mlp, v);
-                lq[i] = mixture_eval_regs<D>(mlq, v);
+                if (MODE == PCN_UNWHITEN) {
+                    ll[i] = mixture_eval_regs<D>(mll, v);
+                    lp[i] = mixture_eval_regs<D>(mlp, v);
+                    lq[i] = mixture_eval_regs<D>(mlq, v);
+                }
                 regs_to_row<T, D>(myrow, v);
                 acc = true;
             } else {
@@ -675,6 +678,125 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
         wave_lds_sync();
     }
     if (MODE == PCN_X_STEP || MODE == PCN_Y_STEP) {
+        __shared__ long long s_cnt[ASMC_BLOCK / 64];
+        n_acc = wave_sum_ll(n_acc);
+        if (lane == 0) s_cnt[wave] = n_acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long tsum = 0;
+            for (int w = 0; w < WPB; w++) tsum += s_cnt[w];
+            block_counts[blockIdx.x] = tsum;
+        }
+    }
+}
+
+// Flow-proposal pCN on the whitened state, split around the flow's log-density kernel (asmc_flow.hip):
+//   PCN_FLOW_PROPOSE  y' = a y + rho xi;  x' = mu + L y'  -> x_prop tile, ll'(x'), lp'(x') (built-in targets)
+//   PCN_FLOW_ACCEPT   regenerates y' from the same Philox counters (no y' round trip through HBM), reads
+//                     ll', lp', lq' and accepts: y <- y' (accepted rows only), carried log-probs updated
+#define PCN_FLOW_PROPOSE 0
+#define PCN_FLOW_ACCEPT 1
+
+template <typename T, int D, int NOISE, int MODE>
+__global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
+    int64_t n, T* __restrict__ y, T* __restrict__ x_prop, double* __restrict__ ll, double* __restrict__ lp,
+    double* __restrict__ lq, double* __restrict__ ll_new, double* __restrict__ lp_new, const double* __restrict__ lq_new,
+    const double* __restrict__ ptab, PcnScalars p, const double* __restrict__ rho_ptr, uint32_t step,
+    long long* __restrict__ block_counts) {
+    extern __shared__ __align__(16) char smem[];
+    constexpr int ROWB = D * (int)sizeof(T);
+    constexpr int LDSROW = ROWB + 16;
+    const int WPB = (int)(blockDim.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* tile = smem + (size_t)wave * 64 * LDSROW;
+    char* myrow = tile + lane * LDSROW;
+    const double rho = *rho_ptr;
+    const double a = sqrt(1.0 - rho * rho);
+    long long n_acc = 0;
+    const int64_t n_tiles = (n + 63) / 64;
+    const int64_t t = (int64_t)blockIdx.x * WPB + wave;  // one tile per wave, no loop (see k_pcn_reg)
+    if (t < n_tiles) {
+        const int64_t row0 = t * 64;
+        const int64_t i = row0 + lane;
+        const bool valid = i < n;
+        const int64_t valid_bytes = ((n - row0) < 64 ? (n - row0) : 64) * (int64_t)ROWB;
+        tile_load<16>(reinterpret_cast<const char*>(y) + row0 * ROWB, valid_bytes, ROWB, LDSROW, tile, lane);
+        double oll = 0.0, olp = 0.0, olq = 0.0, nll = 0.0, nlp = 0.0, nlq = 0.0;
+        if (valid && MODE == PCN_FLOW_ACCEPT) {
+            oll = ll[i], olp = lp[i], olq = lq[i];
+            nll = ll_new[i], nlp = lp_new[i], nlq = lq_new[i];
+        }
+        wave_lds_sync();
+        bool acc = false;
+        const double* __restrict__ Lp = ptab;
+        const double* __restrict__ mup = ptab + 2 * PTAB_TRI(D);
+        const double* __restrict__ m0 = ptab + 2 * PTAB_TRI(D) + D;
+        const MixDev mll = {p.c_ll, m0, m0 + ASMC_MAX_COMPONENTS, m0 + ASMC_MAX_COMPONENTS * (1 + D)};
+        const MixDev mlp = {p.c_lp, m0 + PTAB_MIX(D), m0 + PTAB_MIX(D) + ASMC_MAX_COMPONENTS,
+                            m0 + PTAB_MIX(D) + ASMC_MAX_COMPONENTS * (1 + D)};
+        if (valid) {
+            const unsigned long long gid = p.gid0 + (unsigned long long)i;
+            double v[D];
+            row_to_regs<T, D>(myrow, v);
+            double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < D; j++) q0 = fma(v[j], v[j], q0);
+            if (NOISE == ASMC_NOISE_F64) {
+#pragma unroll
+                for (int pr = 0; pr < D / 2; pr++) {
+                    double z0, z1;
+                    normal_pair(p.seed, gid, step, (uint32_t)pr, z0, z1);
+                    v[2 * pr] = (double)(T)fma(rho, z0, a * v[2 * pr]);
+                    v[2 * pr + 1] = (double)(T)fma(rho, z1, a * v[2 * pr + 1]);
+                    q1 = fma(v[2 * pr], v[2 * pr], q1);
+                    q1 = fma(v[2 * pr + 1], v[2 * pr + 1], q1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int qd = 0; qd < D / 4; qd++) {
+                    double z[4];
+                    normal_quad_f32(p.seed, gid, step, (uint32_t)qd, z[0], z[1], z[2], z[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        v[4 * qd + e] = (double)(T)fma(rho, z[e], a * v[4 * qd + e]);
+                        q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
+                    }
+                    if (qd & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (MODE == PCN_FLOW_PROPOSE) {
+                tri_matvec_inplace<D>(Lp, v);
+#pragma unroll
+                for (int j = 0; j < D; j++) v[j] = (double)(T)(mup[j] + v[j]);
+                ll_new[i] = mixture_eval_regs<D>(mll, v);
+                lp_new[i] = mixture_eval_regs<D>(mlp, v);
+                regs_to_row<T, D>(myrow, v);
+                acc = true;
+            } else {
+                const double lpn = log_p_t(nll, nlp, nlq, p.beta);
+                const double lpo = log_p_t(oll, olp, olq, p.beta);
+                const double log_a = (lpn + 0.5 * q1) - (lpo + 0.5 * q0);
+                const double u = accept_uniform(p.seed, gid, step);
+                acc = log(u) < log_a;
+                if (acc) {
+                    regs_to_row<T, D>(myrow, v);
+                    ll[i] = nll;
+                    lp[i] = nlp;
+                    lq[i] = nlq;
+                    n_acc++;
+                }
+            }
+        }
+        wave_lds_sync();
+        {
+            const unsigned long long accmask = __ballot(acc);
+            char* obase = reinterpret_cast<char*>(MODE == PCN_FLOW_PROPOSE ? x_prop : y) + row0 * ROWB;
+            if (accmask != 0ULL) tile_store_rows<16>(obase, valid_bytes, ROWB, LDSROW, tile, lane, accmask);
+        }
+        wave_lds_sync();
+    }
+    if (MODE == PCN_FLOW_ACCEPT) {
         __shared__ long long s_cnt[ASMC_BLOCK / 64];
         n_acc = wave_sum_ll(n_acc);
         if (lane == 0) s_cnt[wave] = n_acc;
@@ -1061,15 +1183,72 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     return ASMC_OK;
 }
 
+template <typename T, int D, int NOISE, int MODE>
+static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double* ll, double* lp, double* lq,
+                               double* ll_new, double* lp_new, const double* lq_new, const PcnDev& pd,
+                               const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
+                               hipStream_t st) {
+    constexpr int LDSROW = D * (int)sizeof(T) + 16;
+    constexpr size_t tile_bytes = (size_t)64 * LDSROW;
+    const int wpb = ((160 * 1024) / tile_bytes % 4 == 0 || tile_bytes * 12 <= 160 * 1024) ? 4 : 1;
+    const size_t lds_bytes = (size_t)wpb * tile_bytes;
+    const int64_t grid64 = ((n + 63) / 64 + wpb - 1) / wpb;
+    if (grid64 > ASMC_PCN_MAX_GRID) {
+        asmc_set_error("pcn: n=%lld exceeds the per-call block budget", (long long)n);
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    *grid_out = (int)grid64;
+    auto kern = k_pcn_reg_flow<T, D, NOISE, MODE>;
+    static bool attr_set = false;
+    if (lds_bytes > 64 * 1024 && !attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    PcnScalars ps;
+    ps.beta = pd.beta;
+    ps.seed = pd.seed;
+    ps.gid0 = pd.gid0;
+    ps.c_ll = pd.ll.C;
+    ps.c_lp = pd.lp.C;
+    ps.c_lq = pd.lq.C;
+    ASMC_LAUNCH(ctx, st, MODE == PCN_FLOW_PROPOSE ? "k_pcn_flow_propose" : "k_pcn_flow_accept", kern, dim3((int)grid64),
+                dim3(wpb * 64), lds_bytes, st, n, y, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, (const double*)ctx->d_ptab, ps,
+                rho_ptr, step, block_counts);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+template <typename T, int MODE>
+static int dispatch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double* ll, double* lp, double* lq,
+                                 double* ll_new, double* lp_new, const double* lq_new, const PcnDev& pd,
+                                 const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
+                                 hipStream_t st) {
+#define PCN_FLOW_CASE(DD)                                                                                              \
+    if (pd.d == DD) {                                                                                                  \
+        if (pd.noise == ASMC_NOISE_F32)                                                                                \
+            return launch_pcn_reg_flow<T, DD, ASMC_NOISE_F32, MODE>(ctx, n, y, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, \
+                                                                    pd, rho_ptr, step, block_counts, grid_out, st);   \
+        return launch_pcn_reg_flow<T, DD, ASMC_NOISE_F64, MODE>(ctx, n, y, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, pd, \
+                                                                rho_ptr, step, block_counts, grid_out, st);           \
+    }
+    PCN_FLOW_CASE(4)
+    PCN_FLOW_CASE(8)
+    PCN_FLOW_CASE(16)
+    PCN_FLOW_CASE(32)
+#undef PCN_FLOW_CASE
+    asmc_set_error("pcn flow: d=%d has no register-resident kernel", pd.d);
+    return ASMC_ERR_UNSUPPORTED;
+}
+
 template <typename T, int PHASE>
 static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const PcnDev& pd,
                            const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
                            T* x_prop, double* qf_old, double* qf_new, hipStream_t st) {
     const int rowbytes = pd.d * (int)sizeof(T);
     if (PHASE == 0 && pcn_reg_supported(pd.d, sizeof(T), x)) {
-        switch (pd.d * 8 + (pd.noise == ASMC_NOISE_F32 ? 4 : 0) + pd.mode) {  // register-resident specialisations
+        switch (pd.d * 16 + (pd.noise == ASMC_NOISE_F32 ? 8 : 0) + pd.mode) {  // register-resident specialisations
 #define PCN_CASE2(DD, NZ, MD) \
-    case DD * 8 + (NZ == ASMC_NOISE_F32 ? 4 : 0) + MD: \
+    case DD * 16 + (NZ == ASMC_NOISE_F32 ? 8 : 0) + MD: \
         return launch_pcn_reg<T, DD, NZ, MD>(ctx, n, x, ll, lp, lq, pd, rho_ptr, step, block_counts, grid_out, st);
 #define PCN_CASE(DD)                            \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_X_STEP)   \
@@ -1077,7 +1256,8 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_Y_STEP)   \
     PCN_CASE2(DD, ASMC_NOISE_F32, PCN_Y_STEP)   \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_WHITEN)   \
-    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN)
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN) \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN_X)
             PCN_CASE(4)
             PCN_CASE(8)
             PCN_CASE(16)
@@ -1322,7 +1502,7 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     auto launch_mode = [&](int mode, uint32_t stp, int* grid) -> int {
         pd.mode = mode;
         const int nz = pd.noise;
-        if (mode == PCN_WHITEN || mode == PCN_UNWHITEN) pd.noise = ASMC_NOISE_F64;
+        if (mode == PCN_WHITEN || mode == PCN_UNWHITEN || mode == PCN_UNWHITEN_X) pd.noise = ASMC_NOISE_F64;
         int r;
         if (prm->x_dtype == ASMC_F64)
             r = launch_pcn_step<double, 0>(ctx, n, (double*)x, ll, lp, lq, pd, d_rho, stp, d_block, grid, nullptr, nullptr, nullptr, st);
@@ -1403,9 +1583,7 @@ int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x, const
     ASMC_REQUIRE(n > 0 && n <= ctx->n_max && d > 0, "bad sizes");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
     hipStream_t st = as_stream(stream);
-    // flags live in the (otherwise unused here) integer tile scratch: n bytes <= n_tiles_max*32 bytes
-    ASMC_REQUIRE((size_t)n <= (size_t)(ctx->n_tiles_max * 4 + 64) * sizeof(long long), "n exceeds flag scratch");
-    unsigned char* flags = reinterpret_cast<unsigned char*>(ctx->d_tiles_i);
+    unsigned char* flags = ctx->d_flags;
     ASMC_HIP(hipMemsetAsync(ctx->d_keys, 0, sizeof(unsigned long long), st));
     const int grid = grid_for(n, ASMC_BLOCK * 2, ASMC_MAX_BLOCKS);
     ASMC_LAUNCH(ctx, st, "k_pcn_accept_flags", k_pcn_accept_flags, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, ll_new, lp_new, lq_new,
@@ -1426,6 +1604,153 @@ int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x, const
         ASMC_HIP(hipStreamSynchronize(st));
         *n_accept_host = (int64_t)h[0];
     }
+    return ASMC_OK;
+}
+
+// pCN with a coupling-flow proposal density: per step  propose -> flow log q(x') (fp32 MFMA, asmc_flow.hip) ->
+// built-in log prior / log likelihood of x' -> accept -> device-side step-size adaptation; no host round trip
+// inside the loop.  Work buffer: x' [n, d] (storage type) | q0 | q1 | ll' | lp' | lq'  (fp64 [n] each).
+int64_t asmc_pcn_flow_work_bytes(int64_t n, int d, int x_dtype) {
+    const int64_t xb = ((n * d * (x_dtype == ASMC_F64 ? 8 : 4) + 255) / 256) * 256;
+    return xb + 5 * (((n * 8 + 255) / 256) * 256);
+}
+
+int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq,
+                         const asmc_pcn_params* prm, const asmc_coupling* flow, void* work_dev, int64_t work_bytes,
+                         int n_steps, uint32_t step0, double* rho_inout_host, int64_t* n_accept_host,
+                         double* rho_hist_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && ll && lp && lq && prm && flow && work_dev && rho_inout_host && n_accept_host, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+    ASMC_REQUIRE(n_steps >= 1 && n_steps <= ASMC_MAX_PCN_STEPS, "n_steps out of range (<= 2048 per call)");
+    ASMC_REQUIRE(prm->d > 0 && prm->d <= ASMC_MAX_DIMS && prm->d == flow->dims, "bad d");
+    ASMC_REQUIRE(prm->x_dtype == ASMC_F64 || prm->x_dtype == ASMC_F32, "bad x_dtype");
+    ASMC_REQUIRE(prm->mu_dev && prm->L_dev && prm->Linv_dev, "null reference-Gaussian pointer");
+    ASMC_REQUIRE(*rho_inout_host > 0.0 && *rho_inout_host <= 1.0, "rho must be in (0, 1]");
+    ASMC_REQUIRE(work_bytes >= asmc_pcn_flow_work_bytes(n, prm->d, prm->x_dtype), "work buffer too small");
+    int rc = check_mixture(prm->log_likelihood);
+    if (!rc) rc = check_mixture(prm->log_prior);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    const int d = prm->d;
+    const int64_t xb = ((n * d * (prm->x_dtype == ASMC_F64 ? 8 : 4) + 255) / 256) * 256;
+    const int64_t vb = ((n * 8 + 255) / 256) * 256;
+    char* w = reinterpret_cast<char*>(work_dev);
+    void* x_prop = w;
+    double* q0 = reinterpret_cast<double*>(w + xb);
+    double* q1 = reinterpret_cast<double*>(w + xb + vb);
+    double* ll_new = reinterpret_cast<double*>(w + xb + 2 * vb);
+    double* lp_new = reinterpret_cast<double*>(w + xb + 3 * vb);
+    double* lq_new = reinterpret_cast<double*>(w + xb + 4 * vb);
+    PcnDev pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.d = d;
+    pd.mu = prm->mu_dev;
+    pd.L = prm->L_dev;
+    pd.Linv = prm->Linv_dev;
+    pd.seed = prm->seed;
+    pd.gid0 = prm->gid0;
+    double* d_rho = ctx->d_rho;
+    double* d_rho_hist = ctx->d_rho + 8;
+    long long* d_counts = ctx->d_counts;
+    unsigned long long* d_cnt = ctx->d_keys;  // accept counter of the current step
+    unsigned char* flags = ctx->d_flags;
+    ASMC_HIP(hipStreamSynchronize(st));
+    ctx->h_pinned[0] = *rho_inout_host;
+    ASMC_HIP(hipMemcpyAsync(d_rho, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, st));
+    // register-resident whitened-state path (d in {4, 8, 16, 32}): x -> y once, then per step
+    // propose / flow / accept / adapt, y -> x at the end; four launches per step, no host round trip
+    const bool reg_ok = pcn_reg_supported(d, prm->x_dtype == ASMC_F64 ? 8 : 4, x) && !getenv("ASMC_PCN_XSTATE");
+    if (reg_ok) {
+        pd.beta = prm->beta;
+        pd.ll = to_dev(prm->log_likelihood);
+        pd.lp = to_dev(prm->log_prior);
+        pd.lq = pd.lp;  // placeholder: the proposal density is the flow
+        pd.noise = prm->noise;
+        ASMC_REQUIRE(pd.noise == ASMC_NOISE_F64 || pd.noise == ASMC_NOISE_F32, "bad noise mode");
+        rc = pack_pcn_tables(ctx, pd, st);
+        if (rc) return rc;
+        long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
+        int grid = 0;
+        auto convert = [&](int mode) -> int {
+            PcnDev pc = pd;
+            pc.mode = mode;
+            pc.noise = ASMC_NOISE_F64;
+            if (prm->x_dtype == ASMC_F64)
+                return launch_pcn_step<double, 0>(ctx, n, (double*)x, ll, lp, lq, pc, d_rho, 0, d_block, &grid, nullptr, nullptr, nullptr, st);
+            return launch_pcn_step<float, 0>(ctx, n, (float*)x, ll, lp, lq, pc, d_rho, 0, d_block, &grid, nullptr, nullptr, nullptr, st);
+        };
+        rc = convert(PCN_WHITEN);
+        if (rc) return rc;
+        for (int t = 0; t < n_steps; t++) {
+            const uint32_t step = step0 + (uint32_t)t;
+            if (prm->x_dtype == ASMC_F64)
+                rc = dispatch_pcn_reg_flow<double, PCN_FLOW_PROPOSE>(ctx, n, (double*)x, (double*)x_prop, ll, lp, lq, ll_new, lp_new,
+                                                                     lq_new, pd, d_rho, step, d_block, &grid, st);
+            else
+                rc = dispatch_pcn_reg_flow<float, PCN_FLOW_PROPOSE>(ctx, n, (float*)x, (float*)x_prop, ll, lp, lq, ll_new, lp_new,
+                                                                    lq_new, pd, d_rho, step, d_block, &grid, st);
+            if (rc) return rc;
+            rc = asmc_coupling_logprob(ctx, n, prm->x_dtype, x_prop, flow, lq_new, stream);
+            if (rc) return rc;
+            if (prm->x_dtype == ASMC_F64)
+                rc = dispatch_pcn_reg_flow<double, PCN_FLOW_ACCEPT>(ctx, n, (double*)x, (double*)x_prop, ll, lp, lq, ll_new, lp_new,
+                                                                    lq_new, pd, d_rho, step, d_block, &grid, st);
+            else
+                rc = dispatch_pcn_reg_flow<float, PCN_FLOW_ACCEPT>(ctx, n, (float*)x, (float*)x_prop, ll, lp, lq, ll_new, lp_new,
+                                                                   lq_new, pd, d_rho, step, d_block, &grid, st);
+            if (rc) return rc;
+            ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, grid, (const long long*)d_block, n, t, d_counts,
+                        d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+            ASMC_LAUNCH_CHECK();
+        }
+        rc = convert(PCN_UNWHITEN_X);
+        if (rc) return rc;
+    }
+    for (int t = 0; t < (reg_ok ? 0 : n_steps); t++) {
+        const uint32_t step = step0 + (uint32_t)t;
+        int grid = 0;
+        if (prm->x_dtype == ASMC_F64)
+            rc = launch_pcn_step<double, 1>(ctx, n, (double*)x, nullptr, nullptr, nullptr, pd, d_rho, step, nullptr, &grid,
+                                            (double*)x_prop, q0, q1, st);
+        else
+            rc = launch_pcn_step<float, 1>(ctx, n, (float*)x, nullptr, nullptr, nullptr, pd, d_rho, step, nullptr, &grid,
+                                           (float*)x_prop, q0, q1, st);
+        if (rc) return rc;
+        rc = asmc_coupling_logprob(ctx, n, prm->x_dtype, x_prop, flow, lq_new, stream);
+        if (rc) return rc;
+        rc = asmc_mixture_logpdf(ctx, n, d, prm->x_dtype, x_prop, &prm->log_prior, lp_new, stream);
+        if (rc) return rc;
+        rc = asmc_mixture_logpdf(ctx, n, d, prm->x_dtype, x_prop, &prm->log_likelihood, ll_new, stream);
+        if (rc) return rc;
+        ASMC_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+        const int g1 = grid_for(n, ASMC_BLOCK * 2, ASMC_MAX_BLOCKS);
+        ASMC_LAUNCH(ctx, st, "k_pcn_accept_flags", k_pcn_accept_flags, dim3(g1), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq,
+                    (const double*)ll_new, (const double*)lp_new, (const double*)lq_new, (const double*)nullptr,
+                    (const double*)nullptr, (const double*)q0, (const double*)q1, prm->beta, (unsigned long long)prm->seed,
+                    (unsigned long long)prm->gid0, step, flags, d_cnt);
+        ASMC_LAUNCH_CHECK();
+        const int g2 = grid_for(n * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
+        if (prm->x_dtype == ASMC_F64)
+            ASMC_LAUNCH(ctx, st, "k_copy_flagged_rows<double>", k_copy_flagged_rows<double>, dim3(g2), dim3(ASMC_BLOCK), 0, st,
+                        n, d, (double*)x, (const double*)x_prop, (const unsigned char*)flags);
+        else
+            ASMC_LAUNCH(ctx, st, "k_copy_flagged_rows<float>", k_copy_flagged_rows<float>, dim3(g2), dim3(ASMC_BLOCK), 0, st,
+                        n, d, (float*)x, (const float*)x_prop, (const unsigned char*)flags);
+        ASMC_LAUNCH_CHECK();
+        ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, 1, (const long long*)d_cnt, n, t, d_counts,
+                    d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+        ASMC_LAUNCH_CHECK();
+    }
+    long long* h_counts = reinterpret_cast<long long*>(ctx->h_pinned);
+    double* h_rho_hist = ctx->h_pinned + ASMC_MAX_PCN_STEPS + 8;
+    ASMC_HIP(hipMemcpyAsync(h_counts, d_counts, sizeof(long long) * n_steps, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipMemcpyAsync(h_rho_hist, d_rho_hist, sizeof(double) * n_steps, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8000, d_rho, sizeof(double), hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    for (int t = 0; t < n_steps; t++) n_accept_host[t] = (int64_t)h_counts[t];
+    if (rho_hist_host)
+        for (int t = 0; t < n_steps; t++) rho_hist_host[t] = h_rho_hist[t];
+    *rho_inout_host = ctx->h_pinned[8000];
     return ASMC_OK;
 }
 

@@ -105,6 +105,7 @@ class HipEngine:
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
         torch.cuda.set_device(self.device)
         self.n_max, self.d_max = int(n_max), int(d_max)
+        self._flow_work = None  # scratch of pcn_mutate_flow, grown on demand
         self._ctx = ctypes.c_void_p()
         check(self.lib.asmc_ctx_create(ctypes.byref(self._ctx), self.device.index, self.n_max, self.d_max), "asmc_ctx_create")
 
@@ -365,6 +366,27 @@ class HipEngine:
                                        n_steps, step0, ctypes.byref(rho_io),
                                        n_acc.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _f64p(rho_hist),
                                        self._stream), "asmc_pcn_mutate")
+        return n_acc, rho_hist, rho_io.value
+
+    def pcn_mutate_flow(self, x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, flow: DeviceCoupling, seed, gid0, rho,
+                        n_steps, step0=0, target_accept=0.234, adapt=True, noise="f64"):
+        """pcn_mutate with a coupling-flow proposal density (log_q evaluated on the MFMA each step)."""
+        self._chk3(ll, lp, lq)
+        n, d = x.shape
+        prm = AsmcPcnParams(d, self._xdt(x), beta, mu.data_ptr(), L.data_ptr(), Linv.data_ptr(), t_ll.c_struct(),
+                            t_lp.c_struct(), t_lp.c_struct(), seed, gid0, target_accept, int(adapt),
+                            {"f64": 0, "f32": 1}[noise])
+        nbytes = self.lib.asmc_pcn_flow_work_bytes(n, d, self._xdt(x))
+        if self._flow_work is None or self._flow_work.numel() < nbytes:
+            self._flow_work = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        cs = flow.c_struct()
+        n_acc = np.zeros(n_steps, dtype=np.int64)
+        rho_hist = np.zeros(n_steps)
+        rho_io = ctypes.c_double(rho)
+        check(self.lib.asmc_pcn_mutate_flow(self._ctx, n, _dptr(x), _dptr(ll), _dptr(lp), _dptr(lq), ctypes.byref(prm),
+                                            ctypes.byref(cs), _dptr(self._flow_work), nbytes, n_steps, step0,
+                                            ctypes.byref(rho_io), n_acc.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                            _f64p(rho_hist), self._stream), "asmc_pcn_mutate_flow")
         return n_acc, rho_hist, rho_io.value
 
     def pcn_propose(self, x, mu, L, Linv, rho, seed, gid0, step):

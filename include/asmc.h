@@ -260,6 +260,18 @@ int asmc_coupling_pack(int dims, int n_layers, int hidden, const float* const* w
 int asmc_coupling_logprob(asmc_ctx* ctx, int64_t n, int x_dtype, const void* x_dev,
                           const asmc_coupling* flow, double* out_dev, asmc_stream stream);
 
+/* asmc_pcn_mutate_flow: asmc_pcn_mutate with the proposal density q given by a coupling flow instead
+ * of a built-in mixture (params->log_q is ignored): per step propose -> log q(x') on the MFMA ->
+ * built-in log prior / log likelihood -> accept -> device-side adaptation, all enqueued without host
+ * round trips (smc/minipcn.py:97-114 + smc/base.py:507-519 with a flow proposal, BASELINE config 3).
+ * work_dev: caller-owned scratch of asmc_pcn_flow_work_bytes(n, d, x_dtype) bytes. */
+int64_t asmc_pcn_flow_work_bytes(int64_t n, int d, int x_dtype);
+int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, double* lp_dev,
+                         double* lq_dev, const asmc_pcn_params* params, const asmc_coupling* flow,
+                         void* work_dev, int64_t work_bytes, int n_steps, uint32_t step0,
+                         double* rho_inout_host, int64_t* n_accept_host, double* rho_hist_host,
+                         asmc_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

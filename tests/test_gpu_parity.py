@@ -655,3 +655,70 @@ def test_coupling_logprob_vs_torch_modules(eng):
     got = eng.coupling_logprob(x, flow.device_coupling(eng))
     want = flow64.log_prob(x)
     torch.testing.assert_close(got, want, rtol=2e-5, atol=5e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("xdt,d", [("f64", 32), ("f32", 32), ("f64", 8), ("f64", 20)])
+def test_pcn_mutate_flow_vs_split_calls(eng, xdt, d):
+    """asmc_pcn_mutate_flow (whitened-state register kernels around the MFMA flow kernel, all steps enqueued on
+    the device; d = 20 takes the generic composition) against the same steps issued one ABI call at a time in x
+    space (propose / coupling_logprob / mixture_logpdf / accept), each of which is checked against the oracle
+    above.  The whitened state rounds differently (1e-13 relative in fp64, 1e-6 in fp32 storage), so accept
+    decisions may differ for razor-edge cases; everything else must agree, and the carried log-probabilities
+    must equal the densities at the returned positions.  With adaptation on, the device-side step-size history
+    follows the host formula."""
+    from conftest import random_coupling_flow
+    from aspire_amd.samplers.smc import pcn_adapt
+
+    n, n_steps, beta, rho = 5000, 6, 0.35, 0.4
+    dt = torch.float64 if xdt == "f64" else torch.float32
+    flow = random_coupling_flow(d, 4, 64)
+    dev = flow.device_coupling(eng)
+    g = torch.Generator(eng.device).manual_seed(3)
+    x0 = torch.randn((n, d), device=eng.device, dtype=torch.float64, generator=g).to(dt)
+    t_ll = eng.make_mixture([0.0, -0.3], np.stack([np.full(d, 0.5), np.full(d, -0.5)]), np.ones((2, d)) * 1.5)
+    t_lp = eng.make_mixture([-0.5 * d * np.log(2 * np.pi)], np.zeros((1, d)), np.ones((1, d)))
+    mu = eng.asarray(0.1 * np.arange(d) / d)
+    A = np.eye(d) + 0.05 * np.tril(np.random.default_rng(2).normal(size=(d, d)), -1)
+    L, Linv = eng.asarray(A), eng.asarray(np.linalg.inv(A))
+
+    def init():
+        x = x0.clone()
+        return x, eng.mixture_logpdf(x, t_ll), eng.mixture_logpdf(x, t_lp), eng.coupling_logprob(x, dev)
+
+    xa, lla, lpa, lqa = init()
+    n_acc, rho_hist, rho_out = eng.pcn_mutate_flow(xa, lla, lpa, lqa, beta, mu, L, Linv, t_ll, t_lp, dev, 77, 1000, rho,
+                                                   n_steps, 5, 0.234, False)
+    xb, llb, lpb, lqb = init()
+    acc_b = []
+    for t in range(n_steps):
+        xp, q0, q1 = eng.pcn_propose(xb, mu, L, Linv, rho, 77, 1000, 5 + t)
+        lqn = eng.coupling_logprob(xp, dev)
+        acc_b.append(eng.pcn_accept(xb, xp, llb, lpb, lqb, eng.mixture_logpdf(xp, t_ll), eng.mixture_logpdf(xp, t_lp), lqn,
+                                    q0, q1, beta, 77, 1000, 5 + t))
+    assert 0 < sum(acc_b) < n * n_steps
+    assert rho_out == rho and np.all(rho_hist == rho)
+    tol = 1e-9 if xdt == "f64" else 2e-5
+    close = ((xa.double() - xb.double()).abs() <= tol * (1 + xb.double().abs())).all(dim=1)
+    edge = 5 if xdt == "f64" else 60
+    assert int((~close).sum()) <= edge, int((~close).sum())
+    assert np.all(np.abs(n_acc - np.array(acc_b)) <= edge)
+    if d == 20:  # generic composition: the very same kernels, bit-identical
+        assert bool(close.all()) and n_acc.tolist() == acc_b
+        for a, b in ((xa, xb), (lla, llb), (lpa, lpb), (lqa, lqb)):
+            assert torch.equal(a, b)
+    # carried log-probabilities are the densities at the returned positions
+    torch.testing.assert_close(lla, eng.mixture_logpdf(xa, t_ll), rtol=1e-9 if xdt == "f64" else 1e-4, atol=1e-9 if xdt == "f64" else 2e-3)
+    torch.testing.assert_close(lqa, eng.coupling_logprob(xa, dev), rtol=1e-5, atol=2e-3)
+    # untouched particles come back to where they started
+    still = (xb == x0).all(dim=1) & close
+    assert bool(((xa[still].double() - x0[still].double()).abs() <= (1e-13 if xdt == "f64" else 1e-5) * (1 + x0[still].double().abs())).all())
+    # adaptation on: rho_hist[t+1] = pcn_adapt(rho_hist[t], acc_t)
+    xa, lla, lpa, lqa = init()
+    n_acc, rho_hist, rho_out = eng.pcn_mutate_flow(xa, lla, lpa, lqa, beta, mu, L, Linv, t_ll, t_lp, dev, 77, 1000, rho,
+                                                   n_steps, 5, 0.234, True)
+    r = rho
+    for t in range(n_steps):
+        assert rho_hist[t] == pytest.approx(r, rel=1e-12)
+        r = pcn_adapt(rho_hist[t], n_acc[t] / n, 0.234, t)
+    assert rho_out == pytest.approx(r, rel=1e-12)

@@ -41,6 +41,15 @@ def main():
             ms = timeit(lambda: eng.coupling_logprob(xx, dev))
             flow.to("cuda")
             mt = timeit(lambda: flow.log_prob(xx), reps=3, warm=1)
+            tgt = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+            a = eng.mixture_logpdf(xx, tgt)
+            b, c = a.clone(), eng.coupling_logprob(xx, dev)
+            mu, eye = eng.asarray(np.zeros(d)), eng.asarray(np.eye(d))
+            eng.profile(True)
+            mp = timeit(lambda: eng.pcn_mutate_flow(xx, a, b, c, 0.3, mu, eye, eye, tgt, tgt, dev, 7, 0, 0.3, 8, 0, 0.234, True), reps=3, warm=1) / 8
+            rep = eng.profile_report()
+            eng.profile(False)
+            print(f"pcn+flow x={xdt}: {mp*1e3:.1f} us/step  " + "  ".join(f"{k}={v[1]*1e3:.0f}us" for k, v in rep.items()))
             print(f"flow x={xdt}: hip {ms*1e3:.1f} us  {flops/ms/1e9:.1f} TFLOP/s fp32   torch modules {mt*1e3:.1f} us")
     for xdt, sb in ((torch.float64, 8), (torch.float32, 4)):
         x = (1.5 * torch.randn((n, d), device="cuda", dtype=torch.float64, generator=g)).to(xdt)
