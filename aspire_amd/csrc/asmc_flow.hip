@@ -25,12 +25,12 @@
 //
 // Weights stay resident in LDS when the whole flow fits (4 layers of d = 32, W = 64: 115 KB of the CU's
 // 160 KB); otherwise each coupling layer's block is streamed in turn while the tile state waits in registers.
+#include <stdlib.h>
+
 #include "asmc_common.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-#define FLOW_THREADS 512  // 8 waves = 2 per SIMD: one wave's MFMAs cover the other's LDS reads and tanh/exp
-#define FLOW_WAVES (FLOW_THREADS / 64)
 
 template <int H, int W>
 struct FlowDims {
@@ -42,45 +42,55 @@ struct FlowDims {
 
 __host__ __device__ static inline int acc_row(int r, int hh) { return 8 * (r / 4) + 4 * hh + (r % 4); }
 
-template <int NB>
-__device__ __forceinline__ void acc_bias(floatx16 (&acc)[NB], const float* __restrict__ b, int hh) {
+// TPW = tiles (of 32 particles) per wave.  With two tiles a wave runs two independent accumulator chains that
+// share every A operand: half the LDS reads per MFMA, and the vector work of one tile (ReLU, tanh/exp, hazards
+// after a chain) issues in the shadow of the other tile's MFMAs instead of leaving the matrix pipe idle.
+template <int TPW, int NB>
+__device__ __forceinline__ void acc_bias(floatx16 (&acc)[TPW][NB], const float* __restrict__ b, int hh) {
 #pragma unroll
     for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[nb][r] = b[(nb * 16 + r) * 2 + hh];
+        for (int r = 0; r < 16; r++) {
+            const float v = b[(nb * 16 + r) * 2 + hh];
+#pragma unroll
+            for (int tt = 0; tt < TPW; tt++) acc[tt][nb][r] = v;
+        }
 }
 
-template <int NB>
-__device__ __forceinline__ void acc_relu(floatx16 (&acc)[NB]) {
+template <int TPW, int NB>
+__device__ __forceinline__ void acc_relu(floatx16 (&acc)[TPW][NB]) {
 #pragma unroll
-    for (int nb = 0; nb < NB; nb++)
+    for (int tt = 0; tt < TPW; tt++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[nb][r] = fmaxf(acc[nb][r], 0.0f);
+        for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[tt][nb][r] = fmaxf(acc[tt][nb][r], 0.0f);
 }
 
 // out[NBO] += Wt * in, `in` given as NBI accumulator blocks of the previous layer
-template <int NBO, int NBI>
-__device__ __forceinline__ void dense_from_acc(floatx16 (&out)[NBO], const floatx16 (&in)[NBI],
+template <int TPW, int NBO, int NBI>
+__device__ __forceinline__ void dense_from_acc(floatx16 (&out)[TPW][NBO], const floatx16 (&in)[TPW][NBI],
                                                const float* __restrict__ A, int lane) {
-    constexpr int G = NBI * 4;  // groups of four k-steps
+    constexpr int G = NBI * 4;  // groups of four k-steps per output block
+    const float4* Ap = reinterpret_cast<const float4*>(A) + lane;
 #pragma unroll
-    for (int nbo = 0; nbo < NBO; nbo++) {
+    for (int t = 0; t < NBO * G; t++) {
+        const int nbo = t / G, g = t % G;
+        const float4 a = Ap[(size_t)t * 64];
+        const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            const float4 a = *reinterpret_cast<const float4*>(A + ((size_t)(nbo * G + g) * 64 + lane) * 4);
-            const float av[4] = {a.x, a.y, a.z, a.w};
+        for (int e = 0; e < 4; e++) {
+            const int s = 4 * g + e;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int s = 4 * g + e;
-                out[nbo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], in[s / 16][s % 16], out[nbo], 0, 0, 0);
-            }
+            for (int tt = 0; tt < TPW; tt++)
+                out[tt][nbo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], in[tt][s / 16][s % 16], out[tt][nbo], 0, 0, 0);
         }
     }
 }
 
-template <int H, int W>
-__device__ __forceinline__ void coupling_layer(const float (&cond)[H / 2], float (&trans)[H / 2],
-                                               const float* __restrict__ lp, int lane, int hh, float& ladj) {
+template <int H, int W, int TPW>
+__device__ __forceinline__ void coupling_layer(const float (&cond)[TPW][H / 2], float (&trans)[TPW][H / 2],
+                                               const float* __restrict__ lp, int lane, int hh, float (&ladj)[TPW]) {
     using FD = FlowDims<H, W>;
     const float* b1 = lp;
     const float* b2 = b1 + FD::NB1 * 32;
@@ -88,38 +98,47 @@ __device__ __forceinline__ void coupling_layer(const float (&cond)[H / 2], float
     const float* A1 = b3 + FD::NB3 * 32;
     const float* A2 = A1 + W * H;
     const float* A3 = A2 + W * W;
-    floatx16 h1[FD::NB1];
-    acc_bias<FD::NB1>(h1, b1, hh);
+    floatx16 h1[TPW][FD::NB1];
+    acc_bias<TPW, FD::NB1>(h1, b1, hh);
+    {
+        constexpr int G1 = H / 8;
+        const float4* Ap = reinterpret_cast<const float4*>(A1) + lane;
 #pragma unroll
-    for (int nb = 0; nb < FD::NB1; nb++) {
-#pragma unroll
-        for (int g = 0; g < H / 8; g++) {
-            const float4 a = *reinterpret_cast<const float4*>(A1 + ((size_t)(nb * (H / 8) + g) * 64 + lane) * 4);
+        for (int t = 0; t < FD::NB1 * G1; t++) {
+            const int nb = t / G1, g = t % G1;
+            const float4 a = Ap[(size_t)t * 64];
             const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                h1[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], cond[4 * g + e], h1[nb], 0, 0, 0);
+#pragma unroll
+                for (int tt = 0; tt < TPW; tt++)
+                    h1[tt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], cond[tt][4 * g + e], h1[tt][nb], 0, 0, 0);
         }
     }
-    acc_relu<FD::NB1>(h1);
-    floatx16 h2[FD::NB1];
-    acc_bias<FD::NB1>(h2, b2, hh);
-    dense_from_acc<FD::NB1, FD::NB1>(h2, h1, A2, lane);
-    acc_relu<FD::NB1>(h2);
-    floatx16 o[FD::NB3];
-    acc_bias<FD::NB3>(o, b3, hh);
-    dense_from_acc<FD::NB3, FD::NB1>(o, h2, A3, lane);
+    acc_relu<TPW, FD::NB1>(h1);
+    floatx16 h2[TPW][FD::NB1];
+    acc_bias<TPW, FD::NB1>(h2, b2, hh);
+    dense_from_acc<TPW, FD::NB1, FD::NB1>(h2, h1, A2, lane);
+    acc_relu<TPW, FD::NB1>(h2);
+    floatx16 o[TPW][FD::NB3];
+    acc_bias<TPW, FD::NB3>(o, b3, hh);
+    dense_from_acc<TPW, FD::NB3, FD::NB1>(o, h2, A3, lane);
 #pragma unroll
-    for (int q = 0; q < H / 2; q++) {
-        const float sraw = o[q / 16][q % 16];
-        const float t = o[(H / 2 + q) / 16][(H / 2 + q) % 16];
-        const float s = 2.0f * tanhf(sraw * 0.5f);
-        trans[q] = (trans[q] - t) * expf(-s);
-        ladj -= s;
-    }
+    for (int tt = 0; tt < TPW; tt++)
+#pragma unroll
+        for (int q = 0; q < H / 2; q++) {
+            const float sraw = o[tt][q / 16][q % 16];
+            const float t = o[tt][(H / 2 + q) / 16][(H / 2 + q) % 16];
+            // s = 2 tanh(sraw / 2) = 2 - 4 / (exp(sraw) + 1) on the hardware exp2 / rcp units: absolute error
+            // ~1e-7, which is all that matters (s is added to the log-determinant and exponentiated); libm's
+            // tanhf + expf would cost as many issue cycles per layer as a third of its MFMAs
+            const float s = 2.0f - 4.0f * __frcp_rn(__expf(sraw) + 1.0f);
+            trans[tt][q] = (trans[tt][q] - t) * __expf(-s);
+            ladj[tt] -= s;
+        }
 }
 
-template <int H, int W, typename XT>
+template <int H, int W, typename XT, int FLOW_THREADS, int TPW>
 __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, int d, const XT* __restrict__ x,
                                                                   const float* __restrict__ packed, int n_layers,
                                                                   int resident, const float* __restrict__ loc,
@@ -127,6 +146,8 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, in
                                                                   float base_const, double* __restrict__ out) {
     extern __shared__ __align__(16) float sp[];
     using FD = FlowDims<H, W>;
+    constexpr int FLOW_WAVES = FLOW_THREADS / 64;
+    constexpr int ROWS = 32 * TPW;  // particles per wave and round
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, hh = lane >> 5;
     const int dh = d / 2;
@@ -135,25 +156,30 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, in
             *reinterpret_cast<float4*>(sp + i) = *reinterpret_cast<const float4*>(packed + i);
         __syncthreads();
     }
-    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t n_tiles = (n + ROWS - 1) / ROWS;
     const int64_t tiles_per_round = (int64_t)gridDim.x * FLOW_WAVES;
     const int64_t rounds = (n_tiles + tiles_per_round - 1) / tiles_per_round;  // same trip count for every wave
     for (int64_t it = 0; it < rounds; it++) {
         const int64_t tile = (it * gridDim.x + blockIdx.x) * FLOW_WAVES + wave;
-        const int64_t row = tile * 32 + p;
-        const bool valid = tile < n_tiles && row < n;
-        float xa[H / 2], xb[H / 2];
+        float xa[TPW][H / 2], xb[TPW][H / 2];
 #pragma unroll
-        for (int i = 0; i < H / 2; i++) {
-            const int jp = hh * (H / 2) + i;
-            xa[i] = 0.0f;
-            xb[i] = 0.0f;
-            if (valid && jp < dh) {
-                xa[i] = ((float)x[row * d + jp] - loc[jp]) / scale[jp];
-                xb[i] = ((float)x[row * d + dh + jp] - loc[dh + jp]) / scale[dh + jp];
+        for (int tt = 0; tt < TPW; tt++) {
+            const int64_t row = tile * ROWS + tt * 32 + p;
+            const bool valid = tile < n_tiles && row < n;
+#pragma unroll
+            for (int i = 0; i < H / 2; i++) {
+                const int jp = hh * (H / 2) + i;
+                xa[tt][i] = 0.0f;
+                xb[tt][i] = 0.0f;
+                if (valid && jp < dh) {
+                    xa[tt][i] = ((float)x[row * d + jp] - loc[jp]) / scale[jp];
+                    xb[tt][i] = ((float)x[row * d + dh + jp] - loc[dh + jp]) / scale[dh + jp];
+                }
             }
         }
-        float ladj = 0.0f;
+        float ladj[TPW];
+#pragma unroll
+        for (int tt = 0; tt < TPW; tt++) ladj[tt] = 0.0f;
         for (int c = 0; c < n_layers; c++) {
             const float* lp = sp + (resident ? (size_t)c * FD::LAYER : 0);
             if (!resident) {
@@ -164,16 +190,20 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, in
                 __syncthreads();
             }
             if ((c & 1) == 0)
-                coupling_layer<H, W>(xa, xb, lp, lane, hh, ladj);
+                coupling_layer<H, W, TPW>(xa, xb, lp, lane, hh, ladj);
             else
-                coupling_layer<H, W>(xb, xa, lp, lane, hh, ladj);
+                coupling_layer<H, W, TPW>(xb, xa, lp, lane, hh, ladj);
         }
-        float q = 0.0f;
 #pragma unroll
-        for (int i = 0; i < H / 2; i++) q += xa[i] * xa[i] + xb[i] * xb[i];
-        q += __shfl_xor(q, 32);
-        ladj += __shfl_xor(ladj, 32);
-        if (valid && hh == 0) out[row] = (double)((-0.5f * q + base_const) + (ladj0 + ladj));
+        for (int tt = 0; tt < TPW; tt++) {
+            const int64_t row = tile * ROWS + tt * 32 + p;
+            float q = 0.0f;
+#pragma unroll
+            for (int i = 0; i < H / 2; i++) q += xa[tt][i] * xa[tt][i] + xb[tt][i] * xb[tt][i];
+            q += __shfl_xor(q, 32);
+            const float lj = ladj[tt] + __shfl_xor(ladj[tt], 32);
+            if (tile < n_tiles && row < n && hh == 0) out[row] = (double)((-0.5f * q + base_const) + (ladj0 + lj));
+        }
     }
 }
 
@@ -261,20 +291,21 @@ extern "C" int asmc_coupling_pack(int dims, int n_layers, int hidden, const floa
     return ASMC_OK;
 }
 
-template <int H, int W, typename XT>
+template <int H, int W, typename XT, int FLOW_THREADS, int TPW>
 static int launch_flow(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_coupling* f, double* out, hipStream_t st) {
     using FD = FlowDims<H, W>;
     const size_t all = (size_t)f->n_layers * FD::LAYER * sizeof(float);
     const int resident = all <= 150 * 1024;
     const size_t lds = resident ? all : (size_t)FD::LAYER * sizeof(float);
     ASMC_REQUIRE(lds <= 160 * 1024, "one coupling layer does not fit in LDS");
-    auto kern = k_coupling_logprob<H, W, XT>;
+    constexpr int FLOW_WAVES = FLOW_THREADS / 64;
+    auto kern = k_coupling_logprob<H, W, XT, FLOW_THREADS, TPW>;
     static size_t attr_lds = 0;  // per instantiation
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t n_tiles = (n + 32 * TPW - 1) / (32 * TPW);
     const int64_t want = (n_tiles + FLOW_WAVES - 1) / FLOW_WAVES;
     const int per_cu = lds > 80 * 1024 ? 1 : 2;  // blocks that fit a CU's LDS
     const int grid = (int)(want < (int64_t)ctx->num_cu * per_cu ? want : (int64_t)ctx->num_cu * per_cu);
@@ -289,8 +320,13 @@ static int launch_flow(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_couplin
 template <typename XT>
 static int dispatch_flow(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_coupling* f, double* out, hipStream_t st) {
     const int H = flow_half_pad(f->dims);
-#define ASMC_FLOW_CASE(HH, WW) \
-    if (H == HH && f->hidden == WW) return launch_flow<HH, WW, XT>(ctx, n, x, f, out, st);
+    // two tiles per wave where the accumulators fit the 256-VGPR budget of 2 waves/SIMD
+    static const int tpw_env = getenv("ASMC_FLOW_TPW") ? atoi(getenv("ASMC_FLOW_TPW")) : 0;
+#define ASMC_FLOW_CASE(HH, WW)                                                                          \
+    if (H == HH && f->hidden == WW) {                                                                   \
+        if (HH == 16 && WW <= 64 && tpw_env != 1) return launch_flow<HH, WW, XT, 512, (HH == 16 && WW <= 64) ? 2 : 1>(ctx, n, x, f, out, st); \
+        return launch_flow<HH, WW, XT, 512, 1>(ctx, n, x, f, out, st);                                  \
+    }
     ASMC_FLOW_CASE(16, 32)
     ASMC_FLOW_CASE(16, 64)
     ASMC_FLOW_CASE(16, 128)

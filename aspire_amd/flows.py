@@ -248,7 +248,7 @@ class CouplingFlow(Flow):
                 if clip_grad is not None:
                     torch.nn.utils.clip_grad_norm_(self.layers.parameters(), clip_grad)
                 opt.step()
-                tot += float(loss) * xb.shape[0]
+                tot += float(loss.detach()) * xb.shape[0]
             hist.training_loss.append(tot / max(1, xt.shape[0]))
             if n_val:
                 with torch.no_grad():

@@ -134,6 +134,14 @@ class Sampler:
 
     def _flow_log_prob(self, x_dev: torch.Tensor) -> torch.Tensor:
         """prior_flow.log_prob(x) (smc/base.py:510); host (numpy-namespace) flows get a host copy."""
+        dev_flow = None
+        if hasattr(self.prior_flow, "device_coupling") and hasattr(self.engine, "coupling_logprob"):
+            try:  # float32 coupling flow of a supported shape: fp32 MFMA kernel instead of the torch modules
+                dev_flow = self.prior_flow.device_coupling(self.engine)
+            except (ValueError, RuntimeError):  # unsupported dtype / shape: the flow's own torch modules evaluate it
+                dev_flow = None
+        if dev_flow is not None:
+            return self.engine.coupling_logprob(x_dev if x_dev.is_contiguous() else x_dev.contiguous(), dev_flow)
         flow_xp = getattr(self.prior_flow, "xp", None)
         arg = x_dev if (flow_xp is None or is_torch_namespace(flow_xp)) else to_numpy(x_dev)
         return self._to_dev(self.prior_flow.log_prob(arg))

@@ -368,6 +368,21 @@ class HipSMC(SMCSampler):
             Linv = np.linalg.inv(L)
         return e.asarray(mean), e.asarray(np.tril(L)), e.asarray(np.tril(Linv))
 
+    def _device_flow(self):
+        """The proposal flow packed for the MFMA kernel, or None (not a float32 coupling flow of a supported shape)."""
+        if not hasattr(self.prior_flow, "device_coupling"):
+            return None
+        try:
+            return self.prior_flow.device_coupling(self.engine)
+        except (ValueError, RuntimeError) as exc:
+            logger.info("flow stays on its torch modules: %s", exc)
+            return None
+
+    def _flow_fused_ok(self, dev_flow) -> bool:
+        return (dev_flow is not None and isinstance(self._log_likelihood, DiagGaussianMixture)
+                and isinstance(self._log_prior, DiagGaussianMixture)
+                and isinstance(self.preconditioning_transform, IdentityTransform))
+
     def _fused_ok(self) -> bool:
         return (isinstance(self._log_likelihood, DiagGaussianMixture)
                 and isinstance(self._log_prior, DiagGaussianMixture)
@@ -396,7 +411,29 @@ class HipSMC(SMCSampler):
         seed = int(self.rng.integers(0, 2**63 - 1, dtype=np.int64))
         step0 = st["step"]
         acc_rates = []
-        if self._fused_ok():
+        dev_flow = self._device_flow()
+        if self._flow_fused_ok(dev_flow):
+            # flow proposal density evaluated on the MFMA inside the device-side step loop (BASELINE config 3)
+            t_ll = self._log_likelihood.device_mixture(e)
+            t_lp = self._log_prior.device_mixture(e)
+            if comm.world == 1:
+                done = 0
+                while done < n_steps:
+                    chunk = min(n_steps - done, 2048)
+                    n_acc, rho_hist, rho = e.pcn_mutate_flow(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed,
+                                                             gid0, st["rho"], chunk, step0 + done, target, True, noise)
+                    st["rho"] = rho
+                    acc_rates.extend((n_acc / n_global).tolist())
+                    done += chunk
+            else:
+                for t in range(n_steps):
+                    n_acc, _, _ = e.pcn_mutate_flow(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed, gid0,
+                                                    st["rho"], 1, step0 + t, target, False, noise)
+                    tot = float(comm.all_gather_f64(np.array([float(n_acc[0])])).sum())
+                    acc_rates.append(tot / n_global)
+                    st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)
+            self.n_likelihood_evaluations += n_steps * n_local
+        elif self._fused_ok():
             t_ll = self._log_likelihood.device_mixture(e)
             t_lp = self._log_prior.device_mixture(e)
             t_lq = self.prior_flow.device_mixture(e)

@@ -722,3 +722,33 @@ def test_pcn_mutate_flow_vs_split_calls(eng, xdt, d):
         assert rho_hist[t] == pytest.approx(r, rel=1e-12)
         r = pcn_adapt(rho_hist[t], n_acc[t] / n, 0.234, t)
     assert rho_out == pytest.approx(r, rel=1e-12)
+
+
+@pytest.mark.gpu
+def test_config3_flow_proposal_runs_on_the_mfma_path(eng):
+    """BASELINE config 3 at reduced N: a trained float32 coupling-flow proposal, built-in targets, pCN mutation.
+    The whole mutation loop must run in asmc_pcn_mutate_flow (flow log-density on the MFMA), and the evidence of
+    the unnormalised Gaussian product must come out right."""
+    from aspire_amd.flows import CouplingFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    d, n = 32, 20000
+    g = np.random.default_rng(0)
+    flow = CouplingFlow(d, n_layers=4, hidden_features=(64, 64), device=eng.device, dtype=torch.float32, seed=1234)
+    flow.fit(1.3 * g.normal(size=(6000, d)), n_epochs=15)
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=eng, rng=np.random.default_rng(2))
+    eng.profile(True)
+    out = sp.sample(n, sampler_kwargs=dict(n_steps=8), store_sample_history=False)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert rep["k_coupling_logprob"][0] >= 8 * (len(sp.history.beta) - 1)
+    assert rep["k_pcn_flow_propose"][0] == rep["k_pcn_flow_accept"][0] >= 8
+    assert "k_pcn_propose" not in rep  # not the generic split path
+    true = 0.5 * d * math.log(math.pi)
+    assert sp.history.beta[-1] == 1.0
+    assert abs(float(out.log_evidence) - true) < 5 * float(out.log_evidence_error) + 0.05, (float(out.log_evidence), true)
+    assert 0.05 < np.mean(sp.history.mcmc_acceptance) < 0.95
+    xs = out.x.double()
+    assert float(xs.var(dim=0).mean()) == pytest.approx(0.5, rel=0.1)  # posterior N(0, I/2)
