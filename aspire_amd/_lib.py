@@ -80,6 +80,7 @@ SIGNATURES = {
     "asmc_weights_max": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _pd, _i, _pd, _pi64, _vp]),
     "asmc_weights_sums": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _pd, _pd, _pd, _i, _pd, _vp]),
     "asmc_weights_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _pd, _i, _pd, _vp]),
+    "asmc_weights_m2_lse": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _d, _d, _pd, _vp]),
     "asmc_find_beta": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _pd, _vp]),
     "asmc_weights_m2": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _pd, _vp]),
     "asmc_log_weights": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _vp, _vp]),

@@ -179,6 +179,37 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_weights_m2(int64_t n, const doub
     }
 }
 
+// k_weights_m2 plus the sum of the second log-sum-exp of the resampling step in the same pass:
+// column 0: sum (exp(lw - m) - mean_u)^2 (samples.py:1230-1242); column 1: sum exp((lw + shift) - mp), the
+// logsumexp of the SHIFTED log-weights (samples.py:1277 on samples.py:1244-1249)
+__global__ __launch_bounds__(ASMC_BLOCK) void k_weights_m2_lse(int64_t n, const double* __restrict__ ll,
+                                                              const double* __restrict__ lp,
+                                                              const double* __restrict__ lq, double c1, double c2,
+                                                              double m, double mean_u, double shift, double mp,
+                                                              double* __restrict__ partials) {
+    double acc = 0.0, s1p = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) {
+        const double lw = lw_of(ll[i], lp[i], lq[i], c1, c2);
+        const double dlt = exp(lw - m) - mean_u;
+        acc += dlt * dlt;
+        s1p += exp((lw + shift) - mp);
+    }
+    __shared__ double s_p[ASMC_BLOCK / 64][2];
+    acc = wave_sum(acc);
+    s1p = wave_sum(s1p);
+    if ((threadIdx.x & 63) == 0) {
+        s_p[threadIdx.x >> 6][0] = acc;
+        s_p[threadIdx.x >> 6][1] = s1p;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double v = s_p[0][threadIdx.x];
+        for (int w = 1; w < ASMC_BLOCK / 64; w++) v += s_p[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * 2 + threadIdx.x] = v;
+    }
+}
+
 // mode 0: out = lw + shift           (SMCSamples.log_weights)
 // mode 1: out = exp((lw + shift) - lse)   (normalised weights for resampling)
 template <int MODE>
@@ -305,29 +336,80 @@ __device__ __forceinline__ double ess_over_n(double m, double S1, double S2, dou
     return exp(l1 * 2.0 - l2) / N;
 }
 
-// phase 0: candidate {1.0}; phase 1: the 15 midpoints of the next four bisection levels
-__global__ __launch_bounds__(64) void k_bis_prepare(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
-                                                   unsigned long long* __restrict__ keys, int phase) {
-    if (threadIdx.x < ASMC_MAX_BETAS + 1 && !(phase == 1 && st[2] != 0.0)) keys[threadIdx.x] = 0ULL;
-    if (threadIdx.x != 0) return;
-    const double beta0 = st[7];
-    if (phase == 0) {
-        for (int k = 0; k < 16; k++) {
-            bp->c1[k] = beta0 - 1.0;
-            bp->c2[k] = 1.0 - beta0;
-            bp->m[k] = 0.0;
-            bp->shift[k] = 0.0;
-        }
-        return;
+// One launch closes a bisection round: fixed-order reduction of the block partials, ESS of every candidate
+// (one lane each), the walk down the 4-level decision tree, and the candidates of the next round.
+//   phase 0: the single candidate beta = 1 (smc/base.py:170-175), exact maximum from the max kernel (keys[0])
+//   phase 1: the 15 heap-ordered midpoints.  Their stabilising maxima are not searched for: at beta >= beta0
+//   every log-weight is (beta - beta0) * Delta_i up to rounding, so max_i lw_i(beta) = m(1) (beta - beta0)/(1 - beta0)
+//   to rounding as well, and the log-sum-exp only needs a shift near the maximum, not the maximum itself.
+// State st[]: [0] beta_min [1] beta_max [2] done [3] target_eff [4] tol [5] log N [6] rounds [7] beta0 [8] N
+//   [9] ESS(1)/N [10] m(1) [11..13] (m, S1, S2) at beta_min [14] 1 when [11..13] are valid [16..30] midpoints
+//   [32] S1(1) [33] S2(1)
+__global__ __launch_bounds__(1024) void k_bis_tail(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
+                                                  const double* __restrict__ partials, int nblocks, int phase,
+                                                  const unsigned long long* __restrict__ keys) {
+    __shared__ double s_red[32][33];
+    __shared__ double s_S[32];
+    __shared__ double s_eff[16];
+    if (st[2] != 0.0) return;  // converged in an earlier round (uniform)
+    const int ncols = phase == 0 ? 2 : 32;
+    const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
+    double v = 0.0;
+    if (col < ncols)
+        for (int b = part; b < nblocks; b += 32) v += partials[(size_t)b * ncols + col];
+    s_red[part][col] = v;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+        for (int q = 0; q < 32; q++) t += s_red[q][threadIdx.x];
+        s_S[threadIdx.x] = t;
     }
-    if (st[2] != 0.0) return;
-    if (!(st[1] - st[0] > st[4])) {  // converged (or eff(1.0) >= target made beta_min = 1)
+    __syncthreads();
+    const double logN = st[5], N = st[8], target = st[3], tol = st[4], beta0 = st[7];
+    if (threadIdx.x < 16) {
+        const int k = threadIdx.x;
+        const double m = phase == 0 ? key_to_f64(keys[0]) : bp->m[k];
+        s_eff[k] = (phase == 0 && k > 0) ? 0.0 : ess_over_n(m, s_S[2 * k], s_S[2 * k + 1], logN, N);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    st[6] += 1.0;
+    double bmin = st[0], bmax = st[1];
+    if (phase == 0) {
+        const double m1 = key_to_f64(keys[0]);
+        st[9] = s_eff[0];
+        st[10] = m1;
+        st[32] = s_S[0], st[33] = s_S[1];
+        if (s_eff[0] >= target) {  // smc/base.py:174-175
+            bmin = 1.0;
+            st[11] = m1, st[12] = s_S[0], st[13] = s_S[1], st[14] = 1.0;
+        }
+    } else {
+        int i = 0;
+        for (int lev = 0; lev < BIS_LEVELS; lev++) {
+            if (!(bmax - bmin > tol)) break;
+            const double mid = st[16 + i];
+            if (s_eff[i] >= target) {
+                bmin = mid;
+                st[11] = bp->m[i], st[12] = s_S[2 * i], st[13] = s_S[2 * i + 1], st[14] = 1.0;
+                i = 2 * i + 2;
+            } else {
+                bmax = mid;
+                i = 2 * i + 1;
+            }
+        }
+    }
+    st[0] = bmin;
+    st[1] = bmax;
+    if (!(bmax - bmin > tol)) {  // converged (or eff(1.0) >= target made beta_min = 1)
         st[2] = 1.0;
         return;
     }
+    // next round: heap-ordered midpoints of the next four levels, exactly the values the sequential loop visits
+    const double m1 = st[10];
     double los[BIS_NODES], his[BIS_NODES];
-    los[0] = st[0];
-    his[0] = st[1];
+    los[0] = bmin;
+    his[0] = bmax;
     for (int i = 0; i < BIS_NODES; i++) {
         const double mid = 0.5 * (his[i] + los[i]);  // the reference's expression (smc/base.py:178)
         st[16 + i] = mid;
@@ -340,42 +422,13 @@ __global__ __launch_bounds__(64) void k_bis_prepare(double* __restrict__ st, Bet
         }
         bp->c1[i] = beta0 - mid;
         bp->c2[i] = mid - beta0;
-        bp->m[i] = 0.0;
+        bp->m[i] = m1 * ((mid - beta0) / (1.0 - beta0));
         bp->shift[i] = 0.0;
     }
     bp->c1[15] = bp->c1[14];
     bp->c2[15] = bp->c2[14];
-    bp->m[15] = 0.0;
+    bp->m[15] = bp->m[14];
     bp->shift[15] = 0.0;
-}
-
-__global__ __launch_bounds__(64) void k_bis_decide(double* __restrict__ st, const double* __restrict__ stats, int phase) {
-    if (threadIdx.x != 0 || st[2] != 0.0) return;
-    const double logN = st[5], N = st[8], target = st[3], tol = st[4];
-    st[6] += 1.0;
-    if (phase == 0) {
-        const double eff = ess_over_n(stats[0], stats[1], stats[2], logN, N);
-        if (eff >= target) st[0] = 1.0;  // smc/base.py:174-175
-        st[9] = eff;
-        return;
-    }
-    double bmin = st[0], bmax = st[1];
-    int i = 0;
-    for (int lev = 0; lev < BIS_LEVELS; lev++) {
-        if (!(bmax - bmin > tol)) break;
-        const double eff = ess_over_n(stats[4 * i], stats[4 * i + 1], stats[4 * i + 2], logN, N);
-        const double mid = st[16 + i];
-        if (eff >= target) {
-            bmin = mid;
-            i = 2 * i + 2;
-        } else {
-            bmax = mid;
-            i = 2 * i + 1;
-        }
-    }
-    st[0] = bmin;
-    st[1] = bmax;
-    if (!(bmax - bmin > tol)) st[2] = 1.0;
 }
 
 extern "C" {
@@ -453,7 +506,7 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
     BetaPack<16>* d_bp = reinterpret_cast<BetaPack<16>*>(ctx->d_small + 2560 + 64);
     ASMC_HIP(hipStreamSynchronize(st));
     double* h = ctx->h_pinned + 4096 + 512;
-    for (int i = 0; i < 32; i++) h[i] = 0.0;
+    for (int i = 0; i < 40; i++) h[i] = 0.0;
     h[0] = beta0;
     h[1] = 1.0;
     h[3] = target_eff;
@@ -461,41 +514,47 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
     h[5] = log((double)n);
     h[7] = beta0;
     h[8] = (double)n;
-    ASMC_HIP(hipMemcpyAsync(d_st, h, sizeof(double) * 32, hipMemcpyHostToDevice, st));
+    ASMC_HIP(hipMemcpyAsync(d_st, h, sizeof(double) * 40, hipMemcpyHostToDevice, st));
+    // round 0: beta = 1 with its exact maximum (also the NaN census: for beta > beta0 the NaN pattern of the
+    // log-weights does not depend on beta)
+    const double one = 1.0;
+    rc = launch_max(ctx, n, ll, lp, lq, beta0, &one, 1, st);
+    if (rc) return rc;
+    int grid1 = 0;
+    rc = launch_sums(ctx, n, ll, lp, lq, beta0, &one, nullptr, nullptr, 1, true, &grid1, st);
+    if (rc) return rc;
+    ASMC_LAUNCH(ctx, st, "k_bis_tail", k_bis_tail, dim3(1), dim3(1024), 0, st, d_st, d_bp, (const double*)ctx->d_partials, grid1, 0,
+                (const unsigned long long*)ctx->d_keys);
+    ASMC_LAUNCH_CHECK();
     const int grid = reduce_grid(ctx, n, 16);
     BetaPack<16> dummy;
     memset(&dummy, 0, sizeof(dummy));
-    const int max_rounds = (int)ceil(log2(1.0 / tol) / BIS_LEVELS) + 2;
-    for (int round = 0; round <= max_rounds; round++) {
-        const int phase = round == 0 ? 0 : 1;
-        ASMC_LAUNCH(ctx, st, "k_bis_prepare", k_bis_prepare, dim3(1), dim3(64), 0, st, d_st, d_bp, ctx->d_keys, phase);
-        ASMC_LAUNCH_CHECK();
-        const double* skip = phase ? d_st + 2 : nullptr;
-        ASMC_LAUNCH(ctx, st, "k_weights_max<KT>", k_weights_max<16>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, dummy,
-                    ctx->d_keys, ctx->d_keys + ASMC_MAX_BETAS, (const BetaPack<16>*)d_bp, skip);
-        ASMC_LAUNCH_CHECK();
+    const int max_rounds = (int)ceil(log2(1.0 / tol) / BIS_LEVELS) + 1;
+    for (int round = 0; round < max_rounds; round++) {
         ASMC_LAUNCH(ctx, st, "k_weights_sums<KT>", k_weights_sums<16>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, dummy,
-                    (const unsigned long long*)ctx->d_keys, ctx->d_partials, (const BetaPack<16>*)d_bp, skip);
+                    (const unsigned long long*)nullptr, ctx->d_partials, (const BetaPack<16>*)d_bp, (const double*)(d_st + 2));
         ASMC_LAUNCH_CHECK();
-        ASMC_LAUNCH(ctx, st, "k_finalize_columns", k_finalize_columns, dim3(32), dim3(64), 0, st, grid, 32, ctx->d_partials, ctx->d_small, 1, 1,
-                    (const unsigned long long*)ctx->d_keys, (const unsigned long long*)(ctx->d_keys + ASMC_MAX_BETAS));
-        ASMC_LAUNCH_CHECK();
-        ASMC_LAUNCH(ctx, st, "k_bis_decide", k_bis_decide, dim3(1), dim3(64), 0, st, d_st, (const double*)ctx->d_small, phase);
+        ASMC_LAUNCH(ctx, st, "k_bis_tail", k_bis_tail, dim3(1), dim3(1024), 0, st, d_st, d_bp, (const double*)ctx->d_partials, grid, 1,
+                    (const unsigned long long*)ctx->d_keys);
         ASMC_LAUNCH_CHECK();
     }
-    // one more prepare so that `done` reflects the final interval, then read back
-    ASMC_LAUNCH(ctx, st, "k_bis_prepare", k_bis_prepare, dim3(1), dim3(64), 0, st, d_st, d_bp, ctx->d_keys, 1);
-    ASMC_LAUNCH_CHECK();
-    ASMC_HIP(hipMemcpyAsync(h, d_st, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
-    unsigned long long* hk = reinterpret_cast<unsigned long long*>(h + 16);
+    ASMC_HIP(hipMemcpyAsync(h, d_st, sizeof(double) * 40, hipMemcpyDeviceToHost, st));
+    unsigned long long* hk = reinterpret_cast<unsigned long long*>(h + 40);
     ASMC_HIP(hipMemcpyAsync(hk, ctx->d_keys + ASMC_MAX_BETAS, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipStreamSynchronize(st));
     out_host[0] = h[0];               // beta_min = beta*
     out_host[1] = h[1];               // beta_max
     out_host[2] = h[2];               // converged flag
-    out_host[3] = h[6];               // device passes
+    out_host[3] = h[6];               // device rounds
     out_host[4] = h[9];               // ESS(1.0)/N
-    out_host[5] = (double)hk[0];      // NaN log-weights seen in the last evaluated pass
+    out_host[5] = (double)hk[0];      // NaN log-weights
+    out_host[6] = h[11];              // (m, S1, S2) of the log-sum-exp at beta*, valid when out[9] != 0
+    out_host[7] = h[12];
+    out_host[8] = h[13];
+    out_host[9] = h[14];
+    out_host[10] = h[10];             // (m, S1, S2) at beta = 1
+    out_host[11] = h[32];
+    out_host[12] = h[33];
     return ASMC_OK;
 }
 
@@ -517,6 +576,27 @@ int asmc_weights_m2(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp
     ASMC_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, sizeof(double), hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipStreamSynchronize(st));
     *m2_host = ctx->h_pinned[0];
+    return ASMC_OK;
+}
+
+int asmc_weights_m2_lse(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq,
+                        double beta0, double beta, double m, double mean_u, double shift, double mp,
+                        double* out_host, asmc_stream stream) {
+    int rc = check_common(ctx, n, ll, lp, lq);
+    if (rc) return rc;
+    ASMC_REQUIRE(out_host != nullptr, "null host pointer");
+    hipStream_t st = as_stream(stream);
+    const int grid = reduce_grid(ctx, n, 1);
+    ASMC_LAUNCH(ctx, st, "k_weights_m2_lse", k_weights_m2_lse, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, beta0 - beta,
+                beta - beta0, m, mean_u, shift, mp, ctx->d_partials);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_finalize_columns", k_finalize_columns, dim3(2), dim3(64), 0, st, grid, 2, ctx->d_partials,
+                ctx->d_small, 1, 0, (const unsigned long long*)nullptr, (const unsigned long long*)nullptr);
+    ASMC_LAUNCH_CHECK();
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    out_host[0] = ctx->h_pinned[0];
+    out_host[1] = ctx->h_pinned[1];
     return ASMC_OK;
 }
 

@@ -208,12 +208,14 @@ class HipEngine:
         return out.reshape(-1, 4)
 
     def find_beta(self, ll, lp, lq, beta0: float, target_eff: float, tol: float):
-        """Device-side adaptive-beta search (single rank): (beta_star, eff_at_one, converged, passes, n_nan)."""
+        """Device-side adaptive-beta search (single rank):
+        (beta_star, eff_at_one, converged, rounds, n_nan, (m, S1, S2) at beta_star or None, (m, S1, S2) at 1)."""
         self._chk3(ll, lp, lq)
-        out = np.zeros(6)
+        out = np.zeros(13)
         check(self.lib.asmc_find_beta(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0, target_eff, tol,
                                       _f64p(out), self._stream), "asmc_find_beta")
-        return float(out[0]), float(out[4]), bool(out[2]), int(out[3]), int(out[5])
+        trip = (float(out[6]), float(out[7]), float(out[8])) if out[9] != 0.0 else None
+        return float(out[0]), float(out[4]), bool(out[2]), int(out[3]), int(out[5]), trip, tuple(map(float, out[10:13]))
 
     def weights_m2(self, ll, lp, lq, beta0: float, beta: float, m: float, mean_u: float) -> float:
         self._chk3(ll, lp, lq)
@@ -221,6 +223,15 @@ class HipEngine:
         check(self.lib.asmc_weights_m2(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0, beta, m, mean_u,
                                        ctypes.byref(out), self._stream), "asmc_weights_m2")
         return out.value
+
+    def weights_m2_lse(self, ll, lp, lq, beta0: float, beta: float, m: float, mean_u: float, shift: float,
+                       mp: float) -> tuple[float, float]:
+        """(sum (exp(lw - m) - mean_u)^2, sum exp((lw + shift) - mp)) in one pass."""
+        self._chk3(ll, lp, lq)
+        out = np.zeros(2)
+        check(self.lib.asmc_weights_m2_lse(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0, beta, m, mean_u,
+                                           shift, mp, _f64p(out), self._stream), "asmc_weights_m2_lse")
+        return float(out[0]), float(out[1])
 
     def log_weights(self, ll, lp, lq, beta0: float, beta: float, shift: float) -> torch.Tensor:
         self._chk3(ll, lp, lq)

@@ -62,8 +62,7 @@ class SMCSampler(MCMCSampler):
         return len(samples.x) * self.comm.world
 
     def _stats(self, samples: SMCSamples, betas) -> list[smc_math.Stats]:
-        return smc_math.global_stats(self.engine, self.comm, samples.log_likelihood, samples.log_prior,
-                                     samples.log_q, float(samples.beta), betas, self._n_global(samples))
+        return samples.weight_stats(betas)
 
     def determine_beta(self, samples: SMCSamples, beta: float, beta_step: float, min_beta_step: float,
                        max_beta_step: float = 1.0, beta_tolerance: float = DEFAULT_BETA_TOLERANCE):
@@ -76,12 +75,17 @@ class SMCSampler(MCMCSampler):
         search_fn = None
         if self.comm.world == 1 and hasattr(self.engine, "find_beta") and self.device_bisection and beta < 1.0:
             def search_fn(beta_prev, target_eff, tol):
-                b, _, converged, passes, n_nan = self.engine.find_beta(
+                b, _, converged, passes, n_nan, trip, trip_one = self.engine.find_beta(
                     samples.log_likelihood, samples.log_prior, samples.log_q, float(beta_prev), float(target_eff), float(tol))
                 if n_nan > 0:
                     raise ValueError(f"Log weights contain NaN values for beta={b}")
                 if not converged:
                     raise RuntimeError("device-side beta search did not converge")
+                # the search already reduced the batch at beta* and at 1.0: keep those triples for the ESS /
+                # evidence / resampling steps of this iteration
+                if trip is not None:
+                    samples.remember_stats(b, smc_math.Stats(*trip, n))
+                samples.remember_stats(1.0, smc_math.Stats(*trip_one, n))
                 return b, passes
 
         beta, min_beta_step, _ = smc_math.determine_beta(
@@ -211,9 +215,10 @@ class SMCSampler(MCMCSampler):
                 self.history.ess_target.append(float(smc_math.ess(st_one)))
 
                 log_evidence_ratio = smc_math.log_evidence_ratio(st_beta)
-                log_evidence_ratio_var = smc_math.evidence_variance(
+                log_evidence_ratio_var, s1p = smc_math.evidence_variance_and_lse(
                     e, comm, samples.log_likelihood, samples.log_prior, samples.log_q, float(samples.beta),
                     float(beta), st_beta)
+                samples.remember_stats(beta, None, s1p)
                 self.history.log_norm_ratio.append(float(log_evidence_ratio))
                 self.history.log_norm_ratio_var.append(float(log_evidence_ratio_var))
                 logger.info(f"it {iterations} - Log evidence ratio: {log_evidence_ratio:.2f} +/- "

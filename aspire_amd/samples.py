@@ -303,9 +303,28 @@ class SMCSamples(BaseSamples):
         return (1 - beta) * self.log_q + beta * log_p_T
 
     def _stats(self, beta: float) -> smc_math.Stats:
-        ll, lp, lq = self._dev3()
-        return smc_math.global_stats(self._eng(), self._comm(), ll, lp, lq, float(self.beta), [float(beta)],
-                                     self._n_global())[0]
+        return self.weight_stats([float(beta)])[0]
+
+    def weight_stats(self, betas) -> list:
+        """(m, S1, S2) of the log-sum-exp of unnormalized_log_weights(beta) per candidate, memoised on this object
+        (its log-probabilities never change): ESS, evidence ratio, variance and the resampling weights at one
+        beta all come from the same device pass."""
+        cache = self.__dict__.setdefault("_wstats", {})
+        betas = [float(b) for b in betas]
+        missing = [b for b in dict.fromkeys(betas) if b not in cache]
+        if missing:
+            ll, lp, lq = self._dev3()
+            for b, st in zip(missing, smc_math.global_stats(self._eng(), self._comm(), ll, lp, lq, float(self.beta), missing,
+                                                            self._n_global())):
+                cache[b] = st
+        return [cache[b] for b in betas]
+
+    def remember_stats(self, beta: float, st, s1p: float | None = None):
+        """Record results computed elsewhere (device-side beta search, evidence-variance pass)."""
+        if st is not None:
+            self.__dict__.setdefault("_wstats", {})[float(beta)] = st
+        if s1p is not None:
+            self.__dict__.setdefault("_ws1p", {})[float(beta)] = float(s1p)
 
     def unnormalized_log_weights(self, beta: float):
         """samples.py:1221-1224."""
@@ -353,8 +372,10 @@ class SMCSamples(BaseSamples):
         e = self._eng()
         ll, lp, lq = self._dev3()
         x = e.asarray(self.x, dtype=self.x.dtype if is_torch(self.x) else torch.float64)
+        st = None if uniform else self._stats(beta)
         idx, _ = smc_math.resample_indices(e, comm, ll, lp, lq, float(self.beta), float(beta), int(n_samples), rng,
-                                           mode=resample_mode, method=resample_method, uniform_weights=uniform)
+                                           mode=resample_mode, method=resample_method, uniform_weights=uniform,
+                                           st=st, s1p=self.__dict__.get("_ws1p", {}).get(float(beta)))
         xo, llo, lpo, lqo = gather_global(e, comm, idx, x, ll, lp, lq)
         return self.__class__(x=self._from_device(xo), log_likelihood=self._from_device(llo),
                               log_prior=self._from_device(lpo), log_q=self._from_device(lqo), beta=beta,

@@ -90,6 +90,24 @@ def evidence_variance(engine, comm, ll, lp, lq, beta0: float, beta: float, st: S
     return float("nan")
 
 
+def evidence_variance_and_lse(engine, comm, ll, lp, lq, beta0: float, beta: float, st: Stats):
+    """`evidence_variance` and, from the same pass over the batch, the sum S1' of the second log-sum-exp that
+    the resampling step takes over the SHIFTED log-weights (samples.py:1277 on :1244-1249).
+    Returns (variance, S1')."""
+    mean_u = st.S1 / st.n
+    shift = float((st.m + np.log(st.S1)) - math.log(st.n))
+    mp = st.m + shift
+    m2, s1p = engine.weights_m2_lse(ll, lp, lq, beta0, beta, st.m, mean_u, shift, mp)
+    if comm.world > 1:
+        parts = comm.all_gather_f64(np.array([m2, s1p]))
+        m2, s1p = float(parts[0, 0]), float(parts[0, 1])
+        for r in range(1, comm.world):
+            m2, s1p = m2 + float(parts[r, 0]), s1p + float(parts[r, 1])
+    var_u = m2 / st.n
+    var = float(var_u / (st.n * (mean_u**2))) if mean_u != 0 else float("nan")
+    return var, s1p
+
+
 def current_target_efficiency(target, rate: float, beta: float) -> float:
     """smc/base.py:114-121."""
     if isinstance(target, tuple):
@@ -149,7 +167,7 @@ def determine_beta(eff_fn, beta: float, *, adaptive: bool, beta_step: float, min
     current_eff = current_target_efficiency(target, rate, beta_prev)
     target_eff = current_eff
     if search_fn is not None:
-        beta_min, n_pass = search_fn(beta_prev, target_eff, beta_tolerance)
+        beta_min, n_pass = search_fn(beta_prev, target_eff, beta_tolerance)[:2]
         beta_max = beta_min  # converged on device
     else:
         eff_beta_max = eff_fn([beta_max])[0]
@@ -231,12 +249,15 @@ def draw_uniforms(engine, rng, n_total: int, j0: int, n_local: int, method: str 
 
 
 def resample_indices(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out: int, rng, *, mode: str = "exact",
-                     method: str = "multinomial", uniform_weights: bool = False):
+                     method: str = "multinomial", uniform_weights: bool = False, st: Stats | None = None,
+                     s1p: float | None = None):
     """Global ancestor indices for this rank's output slots (samples.py:1276-1278).
 
     w = exp(log_w - logsumexp(log_w)) with log_w = log_weights(beta);
     idx = rng.choice(N, size=n_out, replace=True, p=w)
         = searchsorted(cumsum(w)/cumsum(w)[-1], random(n_out), side="right").
+    `st` / `s1p`: the (m, S1, S2) triple at `beta` and the second log-sum-exp's sum when the caller already has
+    them (the sampler loop does, from the beta search and the evidence-variance pass).
     Returns (idx tensor [n_out_local] of GLOBAL indices, j0)."""
     n_local = ll.numel()
     n_global = n_local * comm.world
@@ -245,11 +266,14 @@ def resample_indices(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out:
         lse = float(0.0 + np.log(np.float64(n_global)))
         w = engine.full(n_local, float(np.exp(0.0 - lse)))
     else:
-        st = global_stats(engine, comm, ll, lp, lq, beta0, [beta], n_global)[0]
+        if st is None:
+            st = global_stats(engine, comm, ll, lp, lq, beta0, [beta], n_global)[0]
         shift = float((st.m + np.log(st.S1)) - math.log(n_global))  # log_weights adds the log-ratio
         mp = st.m + shift
         # second log-sum-exp, over the shifted log-weights (samples.py:1277)
-        if comm.world == 1:
+        if s1p is not None:
+            pass
+        elif comm.world == 1:
             s1p = engine.weights_sums(ll, lp, lq, beta0, [beta], [mp], [shift])[0, 0]
         else:
             parts = comm.all_gather_f64(engine.weights_sums(ll, lp, lq, beta0, [beta], [mp], [shift]))

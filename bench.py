@@ -13,8 +13,9 @@ Inputs are resident in HBM before the timed region; every step processes the sam
 `value` = particles x steps / time ("particle-steps/s"; here a step is a temperature iteration —
 SURVEY.md §8d calls this unit particle-iterations/s).
 
-Extra (same JSON line, `extra`): the mutation path (configs[2] shape, analytic proposal):
-fused pCN kernel throughput and one full `HipSMC.sample()` run with its log-evidence error.
+Extra (same JSON line, `extra`): the mutation path — fused pCN kernel throughput and one full
+`HipSMC.sample()` run with its log-evidence error for the analytic proposal, and configs[2] proper
+(coupling-flow proposal evaluated on the fp32 MFMA inside the device-side pCN loop).
 """
 from __future__ import annotations
 
@@ -46,6 +47,7 @@ def main():
     ap.add_argument("--mcmc-steps", type=int, default=32, help="pCN steps per temperature in the extra leg")
     ap.add_argument("--noise", choices=["f64", "f32"], default="f32", help="proposal-noise generator of the pCN kernel")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-flow-leg", action="store_true", help="skip the coupling-flow (configs[2]) extra leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -95,19 +97,28 @@ def main():
             return [smc_math.ess(s) / n_global for s in smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, betas, n_global)]
 
         search_fn = None
+        found = {}
         if world == 1:  # single rank: whole bisection on device (asmc_find_beta); sharded: host-driven k-ary rounds
             def search_fn(b0, target, tol):
-                b, _, conv, passes, n_nan = eng.find_beta(ll, lp, lq, b0, target, tol)
+                b, _, conv, passes, n_nan, trip, trip_one = eng.find_beta(ll, lp, lq, b0, target, tol)
                 assert conv and n_nan == 0
+                found.update(beta=b, trip=trip, one=trip_one)
                 return b, passes
 
         beta, _, n_pass = smc_math.determine_beta(eff_fn, 0.0, adaptive=True, beta_step=float("nan"), min_beta_step=0.0,
                                                   max_beta_step=1.0, beta_tolerance=1e-6, adaptive_min_beta_step=False,
                                                   target=0.5, rate=1.0, search_fn=search_fn)
-        st_b, st_1 = smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, [beta, 1.0], n_global)
+        # same order as the sampler loop (smc/base.py:401-445): ESS(beta), ESS(1), evidence ratio + variance, resample;
+        # the device-side search has already reduced the batch at beta* and at 1.0
+        if found.get("beta") == beta and found.get("trip") is not None:
+            st_b, st_1 = smc_math.Stats(*found["trip"], n_global), smc_math.Stats(*found["one"], n_global)
+        else:
+            st_b, st_1 = smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, [beta, 1.0], n_global)
+        var, s1p = smc_math.evidence_variance_and_lse(eng, comm, ll, lp, lq, 0.0, beta, st_b)
         scal.update(beta=beta, ess=smc_math.ess(st_b), ess1=smc_math.ess(st_1), ratio=smc_math.log_evidence_ratio(st_b),
-                    var=smc_math.evidence_variance(eng, comm, ll, lp, lq, 0.0, beta, st_b), passes=n_pass)
-        idx, _ = smc_math.resample_indices(eng, comm, ll, lp, lq, 0.0, beta, n_global, rng, mode=args.resample_mode)
+                    var=var, passes=n_pass)
+        idx, _ = smc_math.resample_indices(eng, comm, ll, lp, lq, 0.0, beta, n_global, rng, mode=args.resample_mode,
+                                           st=st_b, s1p=s1p)
         return gather_global(eng, comm, idx, x, ll, lp, lq)
 
     def sync_all():
@@ -232,6 +243,45 @@ def main():
                                 "analytic_log_evidence": true_logz,
                                 "abs_err_in_sigma": abs(float(post.log_evidence) - true_logz) / max(float(post.log_evidence_error), 1e-300),
                                 "mean_accept": float(np.mean(sp.history.mcmc_acceptance))}
+        # configs[2] proper: coupling-flow proposal (4 coupling layers, MLP 16->64->64->32, float32) — flow
+        # log-density on the fp32 MFMA inside the device-side pCN loop; roofline of that kernel against the
+        # dense fp32 MFMA peak
+        if not args.no_flow_leg:
+            from aspire_amd.flows import CouplingFlow
+
+            cflow = CouplingFlow(d, n_layers=4, hidden_features=(64, 64), device=eng.device, dtype=torch.float32, seed=1234)
+            gtrain = np.random.default_rng(3)
+            cflow.fit(sigma_q * 0.9 * gtrain.normal(size=(8000, d)), n_epochs=8)
+            sp3 = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=cflow, xp=np, engine=eng, comm=comm,
+                         rng=np.random.default_rng(2), dtype=args.x_dtype.replace("f", "float"))
+            sp3.sample(min(n_global, 65536 * world), sampler_kwargs=dict(n_steps=2, noise=args.noise), store_sample_history=False,
+                       resample_mode=args.resample_mode)  # warm (first-launch costs)
+            sync_all()
+            eng.profile(True)
+            t0 = time.perf_counter()
+            post3 = sp3.sample(n_global, sampler_kwargs=dict(n_steps=n_mc, noise=args.noise), store_sample_history=False,
+                               resample_mode=args.resample_mode)
+            sync_all()
+            t3 = time.perf_counter() - t0
+            rep3 = eng.profile_report()
+            eng.profile(False)
+            nt3 = len(sp3.history.beta)
+            flow_ms = rep3.get("k_coupling_logprob", (0, 0.0))[1]
+            flow_flops = n_local * 4 * 2 * ((d // 2) * 64 + 64 * 64 + 64 * d)
+            step_ms = sum(rep3.get(k, (0, 0.0))[1] for k in ("k_pcn_flow_propose", "k_coupling_logprob", "k_pcn_flow_accept", "k_pcn_adapt"))
+            extra["smc_pcn_flow_run"] = {
+                "wall_s": round(t3, 4), "temperatures": nt3, "mcmc_steps_per_temperature": n_mc,
+                "particle_steps_per_s": n_global * nt3 * n_mc / t3,
+                "log_evidence": float(post3.log_evidence), "log_evidence_error": float(post3.log_evidence_error),
+                "analytic_log_evidence": true_logz,
+                "abs_err_in_sigma": abs(float(post3.log_evidence) - true_logz) / max(float(post3.log_evidence_error), 1e-300),
+                "mean_accept": float(np.mean(sp3.history.mcmc_acceptance)),
+                "device_ms_per_mcmc_step": round(step_ms, 4),
+                "flow_kernel": {"bound": "mfma", "dtype": "f32", "avg_ms": round(flow_ms, 4), "flops_per_launch": flow_flops,
+                                "achieved_TFLOPs": round(flow_flops / (flow_ms * 1e-3) / 1e12, 1) if flow_ms else None,
+                                "peak_TFLOPs": 157.3,
+                                "frac": round(flow_flops / (flow_ms * 1e-3) / 1e12 / 157.3, 4) if flow_ms else None},
+            }
         result["extra"] = extra
 
     # ---- CPU baseline: the oracle (kind "port") on a bounded sample, rank 0, N=1 only ---------------

@@ -128,16 +128,25 @@ int asmc_weights_stats(asmc_ctx* ctx, int64_t n, const double* ll_dev, const dou
                        const double* lq_dev, double beta0, const double* betas_host, int K,
                        double* out_host, asmc_stream stream);
 /* SMCSampler.determine_beta's adaptive search (smc/base.py:167-186) without host round trips: ESS(1.0) check,
- * then k-ary bisection rounds (15 midpoints = 4 levels per pass, the reference's 0.5*(max+min) values) chained
- * on the stream; decisions use the same scalar formulas on device.  Single-rank only (sharded runs drive the
- * rounds from the host because every pass needs a collective).
- * out_host[6] = {beta_star (= beta_min), beta_max, converged, device passes, ESS(1.0)/N, n_nan}. */
+ * then k-ary bisection rounds (15 midpoints = 4 levels per round, the reference's 0.5*(max+min) values) chained
+ * on the stream, two launches per round; decisions use the same scalar formulas on device.  The round-0
+ * pass (beta = 1) finds the exact maximum; later rounds shift their log-sum-exps by
+ * m(1) (beta - beta0) / (1 - beta0), which equals the maximum up to rounding (lw is linear in beta).
+ * Single-rank only (sharded runs drive the rounds from the host because every pass needs a collective).
+ * out_host[13] = {beta_star (= beta_min), beta_max, converged, device rounds, ESS(1.0)/N, n_nan,
+ *                m, S1, S2 of the log-sum-exp at beta_star, 1 if that triple is valid, m, S1, S2 at beta = 1}. */
 int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
                    const double* lq_dev, double beta0, double target_eff, double tol,
                    double* out_host, asmc_stream stream);
 int asmc_weights_m2(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
                     const double* lq_dev, double beta0, double beta, double m, double mean_u,
                     double* m2_host, asmc_stream stream);
+/* asmc_weights_m2 and, in the same pass, the sum of the second log-sum-exp of the resampling step
+ * (w = exp(log_w - logsumexp(log_w)) over the SHIFTED log-weights, samples.py:1277 on :1244-1249):
+ * out_host[2] = { sum (exp(lw - m) - mean_u)^2 ,  sum exp((lw + shift) - mp) }. */
+int asmc_weights_m2_lse(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
+                        const double* lq_dev, double beta0, double beta, double m, double mean_u,
+                        double shift, double mp, double* out_host, asmc_stream stream);
 
 /* SMCSamples.log_weights(beta) as an array (samples.py:1244-1249): lw_out = lw(beta) + shift,
  * shift = logsumexp(lw) - log N formed on the host from asmc_weights_stats. */

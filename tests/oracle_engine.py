@@ -80,6 +80,11 @@ class OracleEngine:
         lw = O.unnormalized_log_weights(_np(ll), _np(lp), _np(lq), beta0, beta)
         return float(np.sum((np.exp(lw - m) - mean_u) ** 2))
 
+    def weights_m2_lse(self, ll, lp, lq, beta0, beta, m, mean_u, shift, mp):
+        lw = O.unnormalized_log_weights(_np(ll), _np(lp), _np(lq), beta0, beta)
+        with np.errstate(all="ignore"):
+            return float(np.sum((np.exp(lw - m) - mean_u) ** 2)), float(np.sum(np.exp((lw + shift) - mp)))
+
     def log_weights(self, ll, lp, lq, beta0, beta, shift):
         return torch.from_numpy(O.unnormalized_log_weights(_np(ll), _np(lp), _np(lq), beta0, beta) + shift)
 

@@ -11,6 +11,8 @@ import torch
 
 from conftest import synth
 
+from aspire_amd.comm import Comm
+
 pytestmark = pytest.mark.gpu
 
 
@@ -132,9 +134,23 @@ def test_device_side_bisection_matches_reference_golden(eng, golden):
         n, d, seed, ti = int(n), int(d), int(seed), int(ti)
         x, ll, lp, lq = synth(n, d, 0, 2.0) if seed == 0 else synth(n, d, seed)
         target = smc_math.current_target_efficiency([0.5, (0.3, 0.9)][ti], 1.0, b0)
-        b, eff1, conv, passes, n_nan = eng.find_beta(*dev(eng, ll, lp, lq), b0, target, tol)
+        b, eff1, conv, passes, n_nan, trip, trip_one = eng.find_beta(*dev(eng, ll, lp, lq), b0, target, tol)
         assert conv and n_nan == 0 and b == b_ref, (n, b0, tol, ti, b, b_ref)
         assert passes <= 9
+        # the triples it hands back are the log-sum-exp reductions at beta* and at 1 (shifted by the closed-form
+        # maximum rather than the searched one: same ESS and evidence ratio to rounding)
+        n_g = ll.size
+        want_b, want_1 = smc_math.global_stats(eng, Comm(), *dev(eng, ll, lp, lq), b0, [b, 1.0], n_g)
+        got_1 = smc_math.Stats(*trip_one, n_g)
+        assert got_1.m == want_1.m and smc_math.ess(got_1) == pytest.approx(smc_math.ess(want_1), rel=1e-12)
+        assert eff1 == pytest.approx(smc_math.ess(want_1) / n_g, rel=1e-12)
+        if trip is not None:
+            got_b = smc_math.Stats(*trip, n_g)
+            assert got_b.m == pytest.approx(want_b.m, rel=1e-12, abs=1e-12)
+            assert smc_math.ess(got_b) == pytest.approx(smc_math.ess(want_b), rel=1e-12)
+            assert smc_math.log_evidence_ratio(got_b) == pytest.approx(smc_math.log_evidence_ratio(want_b), rel=1e-12, abs=1e-13)
+        else:
+            assert b == b0
     # ESS(1.0) >= target short-circuits to beta* = 1 (smc/base.py:170-175)
     z = eng.asarray(np.zeros(64))
     assert eng.find_beta(z, z, z, 0.0, 0.5, 1e-6)[0] == 1.0

@@ -22,7 +22,7 @@ def is_step():
     def eff_fn(betas):
         return [smc_math.ess(s) / n for s in smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, betas, n)]
     def search_fn(b0, target, tol):
-        b, _, conv, passes, n_nan = eng.find_beta(ll, lp, lq, b0, target, tol)
+        b, _, conv, passes, n_nan = eng.find_beta(ll, lp, lq, b0, target, tol)[:5]
         return b, passes
     beta, _, _ = smc_math.determine_beta(eff_fn, 0.0, adaptive=True, beta_step=float("nan"), min_beta_step=0.0, max_beta_step=1.0,
                                          beta_tolerance=1e-6, adaptive_min_beta_step=False, target=0.5, rate=1.0,
