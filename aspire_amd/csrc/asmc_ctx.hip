@@ -120,7 +120,7 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     dmalloc((void**)&c->d_small, sizeof(double) * 4096);
     dmalloc((void**)&c->d_keys, sizeof(unsigned long long) * (ASMC_MAX_BETAS + 8));
     dmalloc((void**)&c->d_tiles, sizeof(double) * (size_t)(c->n_tiles_max * 4 + 64));
-    dmalloc((void**)&c->d_tiles_i, sizeof(long long) * (size_t)(c->n_tiles_max * 4 + 64));
+    dmalloc((void**)&c->d_tiles_i, sizeof(long long) * (size_t)(c->n_tiles_max * 8 + 64));
     dmalloc((void**)&c->d_gram, sizeof(double) * (size_t)c->gram_blocks * d_max * d_max);
     dmalloc((void**)&c->d_flags, (size_t)n_max + 64);
     dmalloc((void**)&c->d_counts, sizeof(long long) * (size_t)(ASMC_MAX_PCN_STEPS + ASMC_MAX_BLOCKS + n_max / 64 + 8));

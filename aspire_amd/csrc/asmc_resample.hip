@@ -106,18 +106,27 @@ __device__ double exact_tile(const double* __restrict__ w, double* __restrict__ 
     double wv[XT_E];
 #pragma unroll
     for (int j = 0; j < XT_E; j++) wv[j] = (base + j < hi) ? w[base + j] : 0.0;
-    if (tid == 0) {
-        double s = s0;
-        long long pos = lo;
-        if (lo == 0) {  // the very first elements change binade at almost every add: plain sequential adds
-            const int64_t lim = hi < 64 ? hi : 64;
-            for (; pos < lim; pos++) {
-                s = s + w[pos];
-                cdf[pos] = s;
-            }
+    // the very first elements change binade at almost every add: plain sequential adds by one thread, on values
+    // staged through LDS (a dependent chain of global loads would cost ~0.5 us per element)
+    __shared__ double sh_head[64];
+    if (lo == 0 && tid < 64) sh_head[tid] = (tid < hi) ? w[tid] : 0.0;
+    __syncthreads();
+    if (lo == 0 && tid < 64) {
+        // every lane runs the same chain (LDS broadcast reads); lane j keeps the j-th partial sum and writes it
+        const int64_t lim = hi < 64 ? hi : 64;
+        double s = s0, mine_s = 0.0;
+        for (int64_t pos = 0; pos < lim; pos++) {
+            s = s + sh_head[pos];
+            if (pos == tid) mine_s = s;
         }
-        *sh_s = s;
-        *sh_pos = pos;
+        if (tid < lim) cdf[tid] = mine_s;
+        if (tid == 0) {
+            *sh_s = s;
+            *sh_pos = lim;
+        }
+    } else if (lo != 0 && tid == 0) {
+        *sh_s = s0;
+        *sh_pos = lo;
     }
     __syncthreads();
     while (true) {
@@ -186,38 +195,102 @@ __device__ double exact_tile(const double* __restrict__ w, double* __restrict__ 
 }
 
 // ---- multi-tile exact cdf ---------------------------------------------------------------------------
-// Pass C: per tile, from the APPROXIMATE incoming prefix (fast scan) guess the binade; if the whole tile
-// sits comfortably inside it ("safe"), compose the tile's elements into one transducer on that grid.
-// tile_info layout (long long, 4 per tile): {a0, a1, e, safe}
+// Pass C: per tile, from the APPROXIMATE incoming prefix (fast scan) guess the binade e of the running sum and
+// where (if anywhere) it leaves that binade inside the tile:
+//   flag 1  no crossing predicted: ONE transducer (a0, a1) on the grid of e for the whole tile
+//   flag 2  one crossing predicted at element c: transducer A = elements before c on the grid of e, transducer
+//           B = elements after c on the grid of e+1; element c itself is added with a genuine fp64 add
+//   flag 0  anything else (empty prefix, two crossings): the chain processes the tile element-wise
+// Predictions are only hints: pass D verifies every one of them against the exact running sum.
+// tile_info (long long, 4 per tile): {a0, a1, e, flag};  tile_split (4 per tile): {b0, b1, c - tile start, nf_c}
 __device__ __forceinline__ void k_exact_tile_td_body(int64_t n, const double* __restrict__ w,
                                                              const double* __restrict__ approx_prefix,
                                                              double approx_total, int64_t n_tiles,
-                                                             long long* __restrict__ tile_info) {
+                                                             long long* __restrict__ tile_info,
+                                                             long long* __restrict__ tile_split,
+                                                             double* __restrict__ tile_s2) {
     __shared__ TD sh_td[XT_THREADS / 64 + 1];
+    __shared__ double sh_ws[XT_THREADS / 64];
+    __shared__ int sh_c;
     const int64_t t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double lo = approx_prefix[t];
-    const double hi = (t + 1 < n_tiles) ? approx_prefix[t + 1] : approx_total;
     const int e = binade_of(lo);
-    const double b0 = ldexp(1.0, e), b1 = ldexp(1.0, e + 1);
-    const bool safe = (lo > 0.0) && (lo >= b0 * (1.0 + 1e-9)) && (hi <= b1 * (1.0 - 1e-9)) && (hi >= lo);
-    TD mine = {0, 0};
-    if (safe) {
-        const int64_t base = t * ASMC_SCAN_TILE + (int64_t)threadIdx.x * XT_E;
+    const double b1 = ldexp(1.0, e + 1);
+    const int64_t base = t * ASMC_SCAN_TILE + (int64_t)tid * XT_E;
+    double wv[XT_E];
+#pragma unroll
+    for (int j = 0; j < XT_E; j++) wv[j] = (base + j < n) ? w[base + j] : 0.0;
+    // approximate inclusive prefix of every element (parallel-order rounding is fine for a prediction)
+    double tsum = 0.0;
+#pragma unroll
+    for (int j = 0; j < XT_E; j++) tsum += wv[j];
+    double inc = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) sh_ws[wave] = inc;
+    if (tid == 0) sh_c = ASMC_SCAN_TILE;
+    __syncthreads();
+    double pre = lo + (inc - tsum);
+    for (int v = 0; v < wave; v++) pre += sh_ws[v];
+    double tile_end = lo;
+    for (int v = 0; v < XT_THREADS / 64; v++) tile_end += sh_ws[v];
+    {
+        double p = pre;
+        int cj = -1;
 #pragma unroll
         for (int j = 0; j < XT_E; j++) {
-            const int64_t i = base + j;
+            p += wv[j];
+            if (cj < 0 && p >= b1 && base + j < n) cj = j;
+        }
+        if (cj >= 0) atomicMin(&sh_c, tid * XT_E + cj);
+    }
+    __syncthreads();
+    const int c = sh_c;  // predicted crossing element (tile-local) or ASMC_SCAN_TILE
+    int flag = 1;
+    if (!(lo > 0.0)) flag = 0;
+    if (c < ASMC_SCAN_TILE) flag = (lo > 0.0 && tile_end < 2.0 * b1) ? 2 : 0;
+    TD mineA = {0, 0}, mineB = {0, 0};
+    long long nf_c = 0;
+    if (flag != 0) {
+#pragma unroll
+        for (int j = 0; j < XT_E; j++) {
+            const int k = tid * XT_E + j;
             long long a0, a1, nf;
-            td_of((i < n) ? w[i] : 0.0, e, a0, a1, nf);
-            mine = td_compose(mine, TD{a0, a1});
+            if (k < c) {
+                td_of(wv[j], e, a0, a1, nf);
+                mineA = td_compose(mineA, TD{a0, a1});
+            } else if (k == c) {
+                td_of(wv[j], e, a0, a1, nf);
+                nf_c = nf;
+            } else {
+                td_of(wv[j], e + 1, a0, a1, nf);
+                mineB = td_compose(mineB, TD{a0, a1});
+            }
         }
     }
-    TD excl, total;
-    td_block_scan(mine, excl, total, sh_td);
-    if (threadIdx.x == 0) {
-        tile_info[4 * t + 0] = total.a0;
-        tile_info[4 * t + 1] = total.a1;
+    TD excl, totalA, totalB = {0, 0};
+    td_block_scan(mineA, excl, totalA, sh_td);
+    if (flag == 2) td_block_scan(mineB, excl, totalB, sh_td);  // uniform per block
+    if (tid == 0) {
+        tile_info[4 * t + 0] = totalA.a0;
+        tile_info[4 * t + 1] = totalA.a1;
         tile_info[4 * t + 2] = e;
-        tile_info[4 * t + 3] = safe ? 1 : 0;
+        tile_info[4 * t + 3] = flag;
+        tile_split[4 * t + 0] = totalB.a0;
+        tile_split[4 * t + 1] = totalB.a1;
+        tile_split[4 * t + 2] = c;
+    }
+    if (flag == 2 && tid == c / XT_E) {
+        tile_split[4 * t + 3] = nf_c;
+        double wc = 0.0;
+#pragma unroll
+        for (int j = 0; j < XT_E; j++)
+            if (j == c % XT_E) wc = wv[j];
+        tile_s2[t] = wc;  // the chain reads it from here and replaces it by the sum behind element c
     }
 }
 
@@ -225,25 +298,49 @@ __device__ __forceinline__ void k_exact_tile_td_body(int64_t n, const double* __
 __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_launch(int64_t n, const double* __restrict__ w,
                                                                     const double* __restrict__ approx_prefix,
                                                                     const double* __restrict__ approx_total,
-                                                                    int64_t n_tiles, long long* __restrict__ tile_info) {
-    k_exact_tile_td_body(n, w, approx_prefix, *approx_total, n_tiles, tile_info);
+                                                                    int64_t n_tiles, long long* __restrict__ tile_info,
+                                                                    long long* __restrict__ tile_split,
+                                                                    double* __restrict__ tile_s2) {
+    k_exact_tile_td_body(n, w, approx_prefix, *approx_total, n_tiles, tile_info, tile_split, tile_s2);
 }
 
-// Pass D: one block chains the EXACT running sum through the tiles.  Safe tiles cost O(1) (verify the binade
-// guess against the exact incoming sum, apply the tile transducer); any tile that fails the check or was
-// flagged unsafe is processed element-wise by exact_range.  tile_s[t] = exact sum entering tile t;
-// tile_info[4t+3] becomes 1 if pass E must still write the tile, 0 if it has been written here.
+// Pass D: one block chains the EXACT running sum through the tiles.  Flag-1 tiles cost O(1) (verify the binade
+// guess against the exact incoming sum, apply the tile transducer; 64 of them per wave-level scan); flag-2
+// tiles cost O(1) as well (apply A, verify that the add of element c is the one that leaves the binade, do that
+// add in fp64, apply B on the next grid); any tile that fails a check or is flagged 0 is processed element-wise
+// by exact_tile.  tile_s[t] = exact sum entering tile t, tile_s2[t] = exact sum right after element c;
+// tile_info[4t+3] stays 1 / 2 if pass E must still write the tile and becomes 0 if it has been written here.
 __global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const double* __restrict__ w,
                                                            double* __restrict__ cdf, double carry_in,
                                                            int64_t n_tiles, long long* __restrict__ tile_info,
-                                                           double* __restrict__ tile_s,
+                                                           const long long* __restrict__ tile_split,
+                                                           double* __restrict__ tile_s, double* __restrict__ tile_s2,
                                                            double* __restrict__ total_out) {
     __shared__ TD sh_td[XT_THREADS / 64 + 1];
     __shared__ double sh_s, sh_walk_s;
+    __shared__ int sh_split_ok;
     __shared__ long long sh_pos, sh_cross, sh_walk_t;
+    // tile records of the current chunk of CHAIN_CHUNK tiles, staged once by the whole block: the walk below then
+    // reads LDS instead of paying a global-load latency in every round of the sequential chain
+    constexpr int CHAIN_CHUNK = 512;
+    __shared__ long long sh_info[CHAIN_CHUNK * 4];
+    __shared__ long long sh_split[CHAIN_CHUNK * 4];
+    __shared__ double sh_wc[CHAIN_CHUNK];  // weight of the predicted crossing element (pass C leaves it in tile_s2)
+    int64_t chunk0 = -CHAIN_CHUNK;
     int64_t t = 0;
     double s = carry_in;
     while (t < n_tiles) {
+        if (t + 64 > chunk0 + CHAIN_CHUNK || t < chunk0) {  // uniform: (re)stage so that tiles [t, t+64) are resident
+            __syncthreads();
+            chunk0 = t;
+            const int64_t cnt = (n_tiles - chunk0 < CHAIN_CHUNK ? n_tiles - chunk0 : CHAIN_CHUNK) * 4;
+            for (int64_t i = threadIdx.x; i < cnt; i += XT_THREADS) {
+                sh_info[i] = tile_info[4 * chunk0 + i];
+                sh_split[i] = tile_split[4 * chunk0 + i];
+            }
+            for (int64_t i = threadIdx.x; i < cnt / 4; i += XT_THREADS) sh_wc[i] = tile_s2[chunk0 + i];
+            __syncthreads();
+        }
         // wave 0 walks up to 64 tiles per round: lane l holds tile t+l's record, the chain itself is a scalar
         // recurrence evaluated redundantly by all lanes on values broadcast with readlane (no memory latency
         // inside the dependent chain)
@@ -252,10 +349,11 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const dou
             const int64_t my_t = t + lane;
             long long a0 = 0, a1 = 0, ee = 0, sf = 0;
             if (my_t < n_tiles) {
-                a0 = tile_info[4 * my_t + 0];
-                a1 = tile_info[4 * my_t + 1];
-                ee = tile_info[4 * my_t + 2];
-                sf = tile_info[4 * my_t + 3];
+                const long long* rec = sh_info + 4 * (my_t - chunk0);
+                a0 = rec[0];
+                a1 = rec[1];
+                ee = rec[2];
+                sf = rec[3];
             }
             // chain state as (integer S on the grid of binade e_cur): consecutive safe tiles of one binade are
             // pure integer transducer applications, so a batch of 64 tiles is ONE wave-level ordered scan; the
@@ -297,6 +395,41 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const dou
         __syncthreads();
         if (advanced_full) continue;
         if (t >= n_tiles) break;
+        if (sh_info[4 * (t - chunk0) + 3] == 2) {  // predicted single crossing: O(1) with verification
+            if (threadIdx.x == 0) {
+                const long long* rec = sh_info + 4 * (t - chunk0);
+                const int e = (int)rec[2];
+                const long long* sp = sh_split + 4 * (t - chunk0);
+                const long long b0 = sp[0], b1 = sp[1], nf_c = sp[3];
+                int ok = 0;
+                if (s > 0.0 && binade_of(s) == e) {
+                    const long long S = (long long)ldexp(s, 52 - e);
+                    const long long S_A = S + ((S & 1) ? rec[1] : rec[0]);
+                    if (S_A < TWO53_LL && S_A + nf_c >= TWO53_LL) {  // no add before c leaves the binade, c's does
+                        const double s_new = ldexp((double)S_A, e - 52) + sh_wc[t - chunk0];
+                        if (binade_of(s_new) == e + 1) {
+                            const long long S2 = (long long)ldexp(s_new, 52 - (e + 1));
+                            const long long S_B = S2 + ((S2 & 1) ? b1 : b0);
+                            if (S_B < TWO53_LL) {  // and none after it does
+                                tile_s[t] = s;
+                                tile_s2[t] = s_new;
+                                sh_walk_s = ldexp((double)S_B, e + 1 - 52);
+                                ok = 1;
+                            }
+                        }
+                    }
+                }
+                sh_split_ok = ok;
+            }
+            __syncthreads();
+            const bool done = sh_split_ok != 0;
+            if (done) s = sh_walk_s;
+            __syncthreads();
+            if (done) {
+                t++;
+                continue;
+            }
+        }
         // tile t needs the element-wise treatment
         const int64_t lo = t * ASMC_SCAN_TILE;
         const int64_t hi = (lo + ASMC_SCAN_TILE < n) ? lo + ASMC_SCAN_TILE : n;
@@ -311,33 +444,63 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const dou
     if (threadIdx.x == 0) *total_out = s;
 }
 
-// Pass E: write the safe tiles from their exact incoming sums (integer scan on the tile's grid).
+// Pass E: write the flag-1 / flag-2 tiles from their exact incoming sums (integer scans on the tile's grids).
 __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, const double* __restrict__ w,
                                                                 double* __restrict__ cdf,
                                                                 const long long* __restrict__ tile_info,
-                                                                const double* __restrict__ tile_s) {
+                                                                const long long* __restrict__ tile_split,
+                                                                const double* __restrict__ tile_s,
+                                                                const double* __restrict__ tile_s2) {
     __shared__ TD sh_td[XT_THREADS / 64 + 1];
     const int64_t t = blockIdx.x;
-    if (tile_info[4 * t + 3] != 1) return;  // uniform per block
+    const long long flag = tile_info[4 * t + 3];
+    if (flag != 1 && flag != 2) return;  // uniform per block
     const int e = (int)tile_info[4 * t + 2];
-    const long long S0 = (long long)ldexp(tile_s[t], 52 - e);
+    const int c = flag == 2 ? (int)tile_split[4 * t + 2] : ASMC_SCAN_TILE;
     const int64_t base = t * ASMC_SCAN_TILE + (int64_t)threadIdx.x * XT_E;
-    long long ta0[XT_E], ta1[XT_E];
-    TD mine = {0, 0};
+    double wv[XT_E];
 #pragma unroll
-    for (int j = 0; j < XT_E; j++) {
-        const int64_t i = base + j;
-        long long nf;
-        td_of((i < n) ? w[i] : 0.0, e, ta0[j], ta1[j], nf);
-        mine = td_compose(mine, TD{ta0[j], ta1[j]});
+    for (int j = 0; j < XT_E; j++) wv[j] = (base + j < n) ? w[base + j] : 0.0;
+    {   // elements before c (all of them for flag 1) on the grid of e
+        const long long S0 = (long long)ldexp(tile_s[t], 52 - e);
+        long long ta0[XT_E], ta1[XT_E];
+        TD mine = {0, 0};
+#pragma unroll
+        for (int j = 0; j < XT_E; j++) {
+            long long nf;
+            td_of(threadIdx.x * XT_E + j < c ? wv[j] : 0.0, e, ta0[j], ta1[j], nf);
+            mine = td_compose(mine, TD{ta0[j], ta1[j]});
+        }
+        TD excl, total;
+        td_block_scan(mine, excl, total, sh_td);
+        long long S = S0 + ((S0 & 1) ? excl.a1 : excl.a0);
+#pragma unroll
+        for (int j = 0; j < XT_E; j++) {
+            S += (S & 1) ? ta1[j] : ta0[j];
+            if (base + j < n && threadIdx.x * XT_E + j < c) cdf[base + j] = ldexp((double)S, e - 52);
+        }
     }
-    TD excl, total;
-    td_block_scan(mine, excl, total, sh_td);
-    long long S = S0 + ((S0 & 1) ? excl.a1 : excl.a0);
+    if (flag == 2) {  // element c, then the elements behind it on the grid of e + 1
+        const double s_new = tile_s2[t];
+        const long long S0 = (long long)ldexp(s_new, 52 - (e + 1));
+        long long ta0[XT_E], ta1[XT_E];
+        TD mine = {0, 0};
 #pragma unroll
-    for (int j = 0; j < XT_E; j++) {
-        S += (S & 1) ? ta1[j] : ta0[j];
-        if (base + j < n) cdf[base + j] = ldexp((double)S, e - 52);
+        for (int j = 0; j < XT_E; j++) {
+            long long nf;
+            td_of(threadIdx.x * XT_E + j > c ? wv[j] : 0.0, e + 1, ta0[j], ta1[j], nf);
+            mine = td_compose(mine, TD{ta0[j], ta1[j]});
+        }
+        TD excl, total;
+        td_block_scan(mine, excl, total, sh_td);
+        long long S = S0 + ((S0 & 1) ? excl.a1 : excl.a0);
+#pragma unroll
+        for (int j = 0; j < XT_E; j++) {
+            const int k = threadIdx.x * XT_E + j;
+            S += (S & 1) ? ta1[j] : ta0[j];
+            if (base + j < n && k > c) cdf[base + j] = ldexp((double)S, e + 1 - 52);
+            if (k == c) cdf[base + j] = s_new;
+        }
     }
 }
 
@@ -679,19 +842,23 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
         // A+B: approximate (parallel-order) tile prefixes; C: per-tile transducers; D: exact chain; E: write
         const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
         double* d_tile_s = ctx->d_tiles + ctx->n_tiles_max * 2;
+        double* d_tile_s2 = ctx->d_tiles + ctx->n_tiles_max * 3;
+        long long* d_split = ctx->d_tiles_i + ctx->n_tiles_max * 4;
         double* d_approx_total = ctx->d_small + 1025;
         ASMC_LAUNCH(ctx, st, "k_tile_sum", k_tile_sum, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w, ctx->d_tiles);
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, carry_in, d_approx_total);
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_exact_tile_td_launch", k_exact_tile_td_launch, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w,
-                           (const double*)ctx->d_tiles, (const double*)d_approx_total, n_tiles, ctx->d_tiles_i);
+                           (const double*)ctx->d_tiles, (const double*)d_approx_total, n_tiles, ctx->d_tiles_i, d_split,
+                           d_tile_s2);
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_exact_chain", k_exact_chain, dim3(1), dim3(XT_THREADS), 0, st, n, w, cdf, carry_in, n_tiles,
-                           ctx->d_tiles_i, d_tile_s, d_total);
+                           ctx->d_tiles_i, (const long long*)d_split, d_tile_s, d_tile_s2, d_total);
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_exact_tile_write", k_exact_tile_write, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w, cdf,
-                           (const long long*)ctx->d_tiles_i, (const double*)d_tile_s);
+                           (const long long*)ctx->d_tiles_i, (const long long*)d_split, (const double*)d_tile_s,
+                           (const double*)d_tile_s2);
         ASMC_LAUNCH_CHECK();
     } else if (mode == ASMC_CDF_FAST) {
         const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
@@ -818,7 +985,7 @@ int asmc_compact_valid(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
     hipStream_t st = as_stream(stream);
     const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
-    long long* d_total = ctx->d_tiles_i + ctx->n_tiles_max * 4;
+    long long* d_total = ctx->d_tiles_i + ctx->n_tiles_max * 8;
     ASMC_LAUNCH(ctx, st, "k_valid_count", k_valid_count, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, ll, lp, ctx->d_tiles_i);
     ASMC_LAUNCH_CHECK();
     ASMC_LAUNCH(ctx, st, "k_scan_tiles_ll", k_scan_tiles_ll, dim3(1), dim3(64), 0, st, n_tiles, ctx->d_tiles_i, d_total);
