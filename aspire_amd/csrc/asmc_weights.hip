@@ -12,6 +12,8 @@
 // per-block partial in HBM -> fixed-order finalize kernel (bitwise reproducible, no fp atomics).
 // Max pass uses integer atomicMax on an order-preserving key (order independent => deterministic).
 // Compiled with -ffp-contract=off so lw is the reference's plain IEEE mul/mul/add sequence.
+#include <stdlib.h>
+
 #include "asmc_common.h"
 
 template <int KT>
@@ -336,99 +338,204 @@ __device__ __forceinline__ double ess_over_n(double m, double S1, double S2, dou
     return exp(l1 * 2.0 - l2) / N;
 }
 
-// One launch closes a bisection round: fixed-order reduction of the block partials, ESS of every candidate
-// (one lane each), the walk down the 4-level decision tree, and the candidates of the next round.
+// Closes a bisection round: fixed-order reduction of the block partials, ESS of every candidate (one lane
+// each), the walk down the 4-level decision tree, and the candidates of the next round.  Runs in the LAST block
+// of the round's reduction kernel (k_bis_sums) or, for round 0, as its own launch.
 //   phase 0: the single candidate beta = 1 (smc/base.py:170-175), exact maximum from the max kernel (keys[0])
 //   phase 1: the 15 heap-ordered midpoints.  Their stabilising maxima are not searched for: at beta >= beta0
 //   every log-weight is (beta - beta0) * Delta_i up to rounding, so max_i lw_i(beta) = m(1) (beta - beta0)/(1 - beta0)
 //   to rounding as well, and the log-sum-exp only needs a shift near the maximum, not the maximum itself.
 // State st[]: [0] beta_min [1] beta_max [2] done [3] target_eff [4] tol [5] log N [6] rounds [7] beta0 [8] N
 //   [9] ESS(1)/N [10] m(1) [11..13] (m, S1, S2) at beta_min [14] 1 when [11..13] are valid [16..30] midpoints
-//   [32] S1(1) [33] S2(1)
-__global__ __launch_bounds__(1024) void k_bis_tail(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
-                                                  const double* __restrict__ partials, int nblocks, int phase,
-                                                  const unsigned long long* __restrict__ keys) {
-    __shared__ double s_red[32][33];
-    __shared__ double s_S[32];
-    __shared__ double s_eff[16];
-    if (st[2] != 0.0) return;  // converged in an earlier round (uniform)
+//   [32] S1(1) [33] S2(1)  [34..38] next round's grid: c1, c2, m of the LOWEST candidate, spacing h, Delta_max
+__device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
+                                              const double* __restrict__ partials, int nblocks, int phase,
+                                              const unsigned long long* __restrict__ keys, double (*s_red)[33],
+                                              double* s_S, double* s_eff) {
+    // the state record and the candidates' shifts are staged in LDS: thread 0's decision chain below must not pay a
+    // global-memory latency per dependent access
+    __shared__ double s_st[40];
+    __shared__ double s_bp[4][16];  // c1, c2, m, shift of the candidates (in: m of this round; out: next round)
     const int ncols = phase == 0 ? 2 : 32;
-    const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int col = threadIdx.x & 31, part = threadIdx.x >> 5, nparts = blockDim.x >> 5;
+    if (threadIdx.x < 40) s_st[threadIdx.x] = st[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 80) s_bp[2][threadIdx.x - 64] = phase == 0 ? 0.0 : bp->m[threadIdx.x - 64];
     double v = 0.0;
     if (col < ncols)
-        for (int b = part; b < nblocks; b += 32) v += partials[(size_t)b * ncols + col];
+        for (int b = part; b < nblocks; b += nparts) v += partials[(size_t)b * ncols + col];
     s_red[part][col] = v;
     __syncthreads();
     if (threadIdx.x < 32) {
         double t = 0.0;
-        for (int q = 0; q < 32; q++) t += s_red[q][threadIdx.x];
+        for (int q = 0; q < nparts; q++) t += s_red[q][threadIdx.x];
         s_S[threadIdx.x] = t;
     }
     __syncthreads();
-    const double logN = st[5], N = st[8], target = st[3], tol = st[4], beta0 = st[7];
+    const double logN = s_st[5], N = s_st[8], target = s_st[3], tol = s_st[4], beta0 = s_st[7];
+    const double m_one = phase == 0 ? key_to_f64(keys[0]) : s_st[10];
     if (threadIdx.x < 16) {
         const int k = threadIdx.x;
-        const double m = phase == 0 ? key_to_f64(keys[0]) : bp->m[k];
+        const double m = phase == 0 ? m_one : s_bp[2][k];
         s_eff[k] = (phase == 0 && k > 0) ? 0.0 : ess_over_n(m, s_S[2 * k], s_S[2 * k + 1], logN, N);
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    st[6] += 1.0;
-    double bmin = st[0], bmax = st[1];
-    if (phase == 0) {
-        const double m1 = key_to_f64(keys[0]);
-        st[9] = s_eff[0];
-        st[10] = m1;
-        st[32] = s_S[0], st[33] = s_S[1];
-        if (s_eff[0] >= target) {  // smc/base.py:174-175
-            bmin = 1.0;
-            st[11] = m1, st[12] = s_S[0], st[13] = s_S[1], st[14] = 1.0;
-        }
-    } else {
-        int i = 0;
-        for (int lev = 0; lev < BIS_LEVELS; lev++) {
-            if (!(bmax - bmin > tol)) break;
-            const double mid = st[16 + i];
-            if (s_eff[i] >= target) {
-                bmin = mid;
-                st[11] = bp->m[i], st[12] = s_S[2 * i], st[13] = s_S[2 * i + 1], st[14] = 1.0;
-                i = 2 * i + 2;
-            } else {
-                bmax = mid;
-                i = 2 * i + 1;
+    bool write_bp = false;
+    if (threadIdx.x == 0) {
+        s_st[6] += 1.0;
+        double bmin = s_st[0], bmax = s_st[1];
+        if (phase == 0) {
+            s_st[9] = s_eff[0];
+            s_st[10] = m_one;
+            s_st[32] = s_S[0], s_st[33] = s_S[1];
+            if (s_eff[0] >= target) {  // smc/base.py:174-175
+                bmin = 1.0;
+                s_st[11] = m_one, s_st[12] = s_S[0], s_st[13] = s_S[1], s_st[14] = 1.0;
+            }
+        } else {
+            int i = 0;
+            for (int lev = 0; lev < BIS_LEVELS; lev++) {
+                if (!(bmax - bmin > tol)) break;
+                const double mid = s_st[16 + i];
+                if (s_eff[i] >= target) {
+                    bmin = mid;
+                    s_st[11] = s_bp[2][i], s_st[12] = s_S[2 * i], s_st[13] = s_S[2 * i + 1], s_st[14] = 1.0;
+                    i = 2 * i + 2;
+                } else {
+                    bmax = mid;
+                    i = 2 * i + 1;
+                }
             }
         }
-    }
-    st[0] = bmin;
-    st[1] = bmax;
-    if (!(bmax - bmin > tol)) {  // converged (or eff(1.0) >= target made beta_min = 1)
-        st[2] = 1.0;
-        return;
-    }
-    // next round: heap-ordered midpoints of the next four levels, exactly the values the sequential loop visits
-    const double m1 = st[10];
-    double los[BIS_NODES], his[BIS_NODES];
-    los[0] = bmin;
-    his[0] = bmax;
-    for (int i = 0; i < BIS_NODES; i++) {
-        const double mid = 0.5 * (his[i] + los[i]);  // the reference's expression (smc/base.py:178)
-        st[16 + i] = mid;
-        const int l = 2 * i + 1, r = 2 * i + 2;
-        if (r < BIS_NODES) {
-            los[l] = los[i];
-            his[l] = mid;
-            los[r] = mid;
-            his[r] = his[i];
+        s_st[0] = bmin;
+        s_st[1] = bmax;
+        if (!(bmax - bmin > tol)) {  // converged (or eff(1.0) >= target made beta_min = 1)
+            s_st[2] = 1.0;
+        } else {
+            // next round: heap-ordered midpoints of the next four levels, exactly the values the sequential loop visits
+            double los[BIS_NODES], his[BIS_NODES];
+            los[0] = bmin;
+            his[0] = bmax;
+            const double inv = 1.0 / (1.0 - beta0);
+            for (int i = 0; i < BIS_NODES; i++) {
+                const double mid = 0.5 * (his[i] + los[i]);  // the reference's expression (smc/base.py:178)
+                s_st[16 + i] = mid;
+                const int l = 2 * i + 1, r = 2 * i + 2;
+                if (r < BIS_NODES) {
+                    los[l] = los[i];
+                    his[l] = mid;
+                    los[r] = mid;
+                    his[r] = his[i];
+                }
+                s_bp[0][i] = beta0 - mid;
+                s_bp[1][i] = mid - beta0;
+                s_bp[2][i] = m_one * ((mid - beta0) * inv);
+                s_bp[3][i] = 0.0;
+            }
+            for (int f = 0; f < 4; f++) s_bp[f][15] = s_bp[f][14];
+            s_st[34] = s_bp[0][7];  // heap node 7 = leftmost leaf = lowest candidate
+            s_st[35] = s_bp[1][7];
+            s_st[36] = s_bp[2][7];
+            s_st[37] = (bmax - bmin) / 16.0;
+            s_st[38] = m_one * inv;
+            s_st[39] = 1.0;  // marks that the candidate pack below is to be written
         }
-        bp->c1[i] = beta0 - mid;
-        bp->c2[i] = mid - beta0;
-        bp->m[i] = m1 * ((mid - beta0) / (1.0 - beta0));
-        bp->shift[i] = 0.0;
     }
-    bp->c1[15] = bp->c1[14];
-    bp->c2[15] = bp->c2[14];
-    bp->m[15] = bp->m[14];
-    bp->shift[15] = 0.0;
+    __syncthreads();
+    write_bp = s_st[39] != 0.0;
+    if (threadIdx.x < 39) st[threadIdx.x] = s_st[threadIdx.x];
+    if (write_bp && threadIdx.x >= 64 && threadIdx.x < 128) {
+        const int f = (threadIdx.x - 64) >> 4, k = (threadIdx.x - 64) & 15;
+        double* dst = f == 0 ? bp->c1 : f == 1 ? bp->c2 : f == 2 ? bp->m : bp->shift;
+        dst[k] = s_bp[f][k];
+    }
+}
+
+__global__ __launch_bounds__(ASMC_BLOCK) void k_bis_tail(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
+                                                        const double* __restrict__ partials, int nblocks, int phase,
+                                                        const unsigned long long* __restrict__ keys) {
+    __shared__ double s_red[ASMC_BLOCK / 32][33];
+    __shared__ double s_S[32];
+    __shared__ double s_eff[16];
+    if (st[2] != 0.0) return;  // converged in an earlier round (uniform)
+    bis_tail_body(st, bp, partials, nblocks, phase, keys, s_red, s_S, s_eff);
+}
+
+// One bisection round in ONE launch.  The 15 candidates are equally spaced, beta_j = beta_1 + (j-1) h, and every
+// log-sum-exp is shifted by m_j = (beta_j - beta0) Delta_max, so for particle i
+//     exp(lw_i(beta_j) - m_j) = exp(lw_i(beta_1) - m_1) * r_i^(j-1),   r_i = exp(h (Delta_i - Delta_max)) <= 1:
+// two exponentials per particle instead of fifteen.  The first factor uses the reference's own expression for the
+// log-weight (samples.py:1222-1224); the progression is non-increasing in j, so it can neither overflow nor lose
+// a term that matters.  Relative deviation from fifteen direct exponentials: ~1e-14 (it decides `eff >= target`
+// comparisons only; the values reported at the chosen beta carry the same 1e-14).
+// The block that arrives last (ticket counter behind an agent-scope release) reduces the partials and runs the
+// tail, so a round costs one launch.
+__constant__ int c_heap_of_sorted[15] = {7, 3, 8, 1, 9, 4, 10, 0, 11, 5, 12, 2, 13, 6, 14};  // in-order -> heap index
+
+#define BIS_THREADS 512  // one block per CU: few, large partial records keep the last block's reduction short
+
+__global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const double* __restrict__ ll,
+                                                        const double* __restrict__ lp, const double* __restrict__ lq,
+                                                        double* __restrict__ st, BetaPack<16>* __restrict__ bp,
+                                                        double* partials, unsigned int* ticket, int round) {
+    __shared__ double s_red[BIS_THREADS / 32][33];
+    __shared__ double s_S[32];
+    __shared__ double s_eff[16];
+    __shared__ int s_last;
+    if (st[2] != 0.0) return;  // converged in an earlier round (uniform across the grid)
+    const double c1 = st[34], c2 = st[35], m1 = st[36], h = st[37], dmax = st[38];
+    double s1[15], s2[15];
+#pragma unroll
+    for (int j = 0; j < 15; j++) s1[j] = 0.0, s2[j] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * BIS_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * BIS_THREADS + threadIdx.x; i < n; i += stride) {
+        const double a = ll[i], b = lp[i], q = lq[i];
+        double e = exp(lw_of(a, b, q, c1, c2) - m1);
+        const double r = exp(h * (((a + b) - q) - dmax));
+#pragma unroll
+        for (int j = 0; j < 15; j++) {
+            s1[j] += e;
+            s2[j] += e * e;
+            e *= r;
+        }
+    }
+    __shared__ double s_p[BIS_THREADS / 64][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 15; j++) {
+        const double v1 = wave_sum(s1[j]);
+        const double v2 = wave_sum(s2[j]);
+        if (lane == 0) {
+            const int k = c_heap_of_sorted[j];
+            s_p[wave][2 * k] = v1;
+            s_p[wave][2 * k + 1] = v2;
+        }
+    }
+    if (lane == 0) s_p[wave][30] = s_p[wave][31] = 0.0;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double v = s_p[0][threadIdx.x];
+        for (int w = 1; w < BIS_THREADS / 64; w++) v += s_p[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * 32 + threadIdx.x] = v;
+    }
+    if (!ticket) return;  // the tail runs as its own launch
+    // In-launch hand-off to the last-arriving block (cdna_hip_programming.md Guideline 16, counter form): the storing
+    // wave drains its stores, the block meets, ONE lane releases at agent scope and draws a ticket.  The counter is
+    // zeroed once per search by a memset on the stream and only ever grows: round r ends at ticket (r+1) * grid - 1.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (unsigned int)(round + 1) * gridDim.x - 1u);
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    bis_tail_body(st, bp, partials, (int)gridDim.x, 1, nullptr, s_red, s_S, s_eff);
 }
 
 extern "C" {
@@ -523,20 +630,24 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
     int grid1 = 0;
     rc = launch_sums(ctx, n, ll, lp, lq, beta0, &one, nullptr, nullptr, 1, true, &grid1, st);
     if (rc) return rc;
-    ASMC_LAUNCH(ctx, st, "k_bis_tail", k_bis_tail, dim3(1), dim3(1024), 0, st, d_st, d_bp, (const double*)ctx->d_partials, grid1, 0,
+    ASMC_LAUNCH(ctx, st, "k_bis_tail", k_bis_tail, dim3(1), dim3(ASMC_BLOCK), 0, st, d_st, d_bp, (const double*)ctx->d_partials, grid1, 0,
                 (const unsigned long long*)ctx->d_keys);
     ASMC_LAUNCH_CHECK();
-    const int grid = reduce_grid(ctx, n, 16);
-    BetaPack<16> dummy;
-    memset(&dummy, 0, sizeof(dummy));
-    const int max_rounds = (int)ceil(log2(1.0 / tol) / BIS_LEVELS) + 1;
-    for (int round = 0; round < max_rounds; round++) {
-        ASMC_LAUNCH(ctx, st, "k_weights_sums<KT>", k_weights_sums<16>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, dummy,
-                    (const unsigned long long*)nullptr, ctx->d_partials, (const BetaPack<16>*)d_bp, (const double*)(d_st + 2));
+    const int grid = grid_for(n, BIS_THREADS, ctx->num_cu);
+    unsigned int* d_ticket = reinterpret_cast<unsigned int*>(ctx->d_keys + ASMC_MAX_BETAS + 4);  // zeroed by launch_max
+    // every round narrows the bracket 16x: ceil(log16((1 - beta0) / tol)) rounds reach the tolerance; one spare
+    // round (it exits at once when the flag is already set) covers rounding in that estimate
+    const int rounds = (int)ceil(log2((1.0 - beta0) / tol) / BIS_LEVELS - 1e-9) + 1;
+    for (int round = 0; round < rounds; round++) {
+        static const bool split = getenv("ASMC_BIS_SPLIT") != nullptr;
+        ASMC_LAUNCH(ctx, st, "k_bis_sums", k_bis_sums, dim3(grid), dim3(BIS_THREADS), 0, st, n, ll, lp, lq, d_st, d_bp, ctx->d_partials,
+                    split ? (unsigned int*)nullptr : d_ticket, round);
         ASMC_LAUNCH_CHECK();
-        ASMC_LAUNCH(ctx, st, "k_bis_tail", k_bis_tail, dim3(1), dim3(1024), 0, st, d_st, d_bp, (const double*)ctx->d_partials, grid, 1,
-                    (const unsigned long long*)ctx->d_keys);
-        ASMC_LAUNCH_CHECK();
+        if (split) {
+            ASMC_LAUNCH(ctx, st, "k_bis_tail", k_bis_tail, dim3(1), dim3(ASMC_BLOCK), 0, st, d_st, d_bp, (const double*)ctx->d_partials, grid, 1,
+                        (const unsigned long long*)ctx->d_keys);
+            ASMC_LAUNCH_CHECK();
+        }
     }
     ASMC_HIP(hipMemcpyAsync(h, d_st, sizeof(double) * 40, hipMemcpyDeviceToHost, st));
     unsigned long long* hk = reinterpret_cast<unsigned long long*>(h + 40);
