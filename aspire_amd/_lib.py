@@ -88,6 +88,7 @@ SIGNATURES = {
     "asmc_count_nonfinite": (_i, [_vp, _i64, _vp, _pi64, _pi64, _vp]),
     "asmc_cdf": (_i, [_vp, _i64, _vp, _vp, _i, _d, _pd, _vp]),
     "asmc_cdf_normalize": (_i, [_vp, _i64, _vp, _d, _vp]),
+    "asmc_cdf_normalize_last": (_i, [_vp, _i64, _vp, _vp]),
     "asmc_pcg64_uniforms": (_i, [_vp, POINTER(c_uint64), _u64, _i64, _vp, _vp]),
     "asmc_systematic_uniforms": (_i, [_vp, _i64, _i64, _i64, _d, _vp, _vp, _vp]),
     "asmc_search": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),

@@ -583,6 +583,14 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_tile_scan(int64_t n, const doubl
         if (base + j < n) cdf[base + j] = off + v[j];
 }
 
+// divisor read from the device (the total the preceding cdf pass left there): no host round trip
+__global__ __launch_bounds__(ASMC_BLOCK) void k_divide_dev(int64_t n, double* __restrict__ cdf,
+                                                          const double* __restrict__ last_ptr) {
+    const double last = *last_ptr;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) cdf[i] = cdf[i] / last;
+}
+
 __global__ __launch_bounds__(ASMC_BLOCK) void k_divide(int64_t n, double* __restrict__ cdf, double last) {
     const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride)
@@ -886,6 +894,16 @@ int asmc_cdf_normalize(asmc_ctx* ctx, int64_t n, double* cdf, double last, asmc_
     ASMC_REQUIRE(n > 0, "n must be positive");
     const int grid = grid_for(n, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS);
     ASMC_LAUNCH(ctx, as_stream(stream), "k_divide", k_divide, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, cdf, last);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_cdf_normalize_last(asmc_ctx* ctx, int64_t n, double* cdf, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && cdf, "null pointer");
+    ASMC_REQUIRE(n > 0, "n must be positive");
+    const int grid = grid_for(n, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS);
+    ASMC_LAUNCH(ctx, as_stream(stream), "k_divide", k_divide_dev, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, cdf,
+                (const double*)(ctx->d_small + 1024));
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }

@@ -450,12 +450,24 @@ __device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<
     }
 }
 
+struct BisInit {
+    double beta0, target, tol, logN, N;
+};
+
 __global__ __launch_bounds__(ASMC_BLOCK) void k_bis_tail(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
                                                         const double* __restrict__ partials, int nblocks, int phase,
-                                                        const unsigned long long* __restrict__ keys) {
+                                                        const unsigned long long* __restrict__ keys, BisInit init) {
     __shared__ double s_red[ASMC_BLOCK / 32][33];
     __shared__ double s_S[32];
     __shared__ double s_eff[16];
+    if (phase == 0) {  // round 0 also creates the state record (no host-to-device copy, no host sync before the search)
+        if (threadIdx.x < 40) {
+            const int i = threadIdx.x;
+            st[i] = i == 0 ? init.beta0 : i == 1 ? 1.0 : i == 3 ? init.target : i == 4 ? init.tol : i == 5 ? init.logN
+                    : i == 7 ? init.beta0 : i == 8 ? init.N : 0.0;
+        }
+        __syncthreads();
+    }
     if (st[2] != 0.0) return;  // converged in an earlier round (uniform)
     bis_tail_body(st, bp, partials, nblocks, phase, keys, s_red, s_S, s_eff);
 }
@@ -469,8 +481,6 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_bis_tail(double* __restrict__ st
 // comparisons only; the values reported at the chosen beta carry the same 1e-14).
 // The block that arrives last (ticket counter behind an agent-scope release) reduces the partials and runs the
 // tail, so a round costs one launch.
-__constant__ int c_heap_of_sorted[15] = {7, 3, 8, 1, 9, 4, 10, 0, 11, 5, 12, 2, 13, 6, 14};  // in-order -> heap index
-
 #define BIS_THREADS 512  // one block per CU: few, large partial records keep the last block's reduction short
 
 __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const double* __restrict__ ll,
@@ -487,30 +497,54 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const doubl
 #pragma unroll
     for (int j = 0; j < 15; j++) s1[j] = 0.0, s2[j] = 0.0;
     const int64_t stride = (int64_t)gridDim.x * BIS_THREADS;
-    for (int64_t i = (int64_t)blockIdx.x * BIS_THREADS + threadIdx.x; i < n; i += stride) {
+    // two particles per trip: six loads in flight before the first exponential (the loop is latency bound otherwise)
+    for (int64_t i = (int64_t)blockIdx.x * BIS_THREADS + threadIdx.x; i < n; i += 2 * stride) {
+        const int64_t i2 = i + stride;
+        const bool has2 = i2 < n;
         const double a = ll[i], b = lp[i], q = lq[i];
+        const double a2 = has2 ? ll[i2] : 0.0, b2 = has2 ? lp[i2] : 0.0, q2 = has2 ? lq[i2] : 0.0;
         double e = exp(lw_of(a, b, q, c1, c2) - m1);
         const double r = exp(h * (((a + b) - q) - dmax));
+        double e2 = has2 ? exp(lw_of(a2, b2, q2, c1, c2) - m1) : 0.0;
+        const double r2 = has2 ? exp(h * (((a2 + b2) - q2) - dmax)) : 0.0;
 #pragma unroll
         for (int j = 0; j < 15; j++) {
             s1[j] += e;
             s2[j] += e * e;
             e *= r;
+            s1[j] += e2;
+            s2[j] += e2 * e2;
+            e2 *= r2;
         }
     }
     __shared__ double s_p[BIS_THREADS / 64][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave-level reduction of the 30 accumulators as a butterfly reduce-scatter: at distance o a lane keeps one
+    // half of its values and trades the other half with its partner, so 16+8+4+2+1+1 = 32 values cross lanes
+    // instead of 30 x 6 (the cross-lane permutes run on the LDS pipe, which 8 waves per CU share; the plain
+    // per-value butterflies cost more than the two exponentials per particle).  vals[c] = column c of the
+    // partial record (2 * heap index + {0: S1, 1: S2}); lane l ends up with the wave total of column l >> 1.
+    constexpr int HEAP_OF_SORTED[15] = {7, 3, 8, 1, 9, 4, 10, 0, 11, 5, 12, 2, 13, 6, 14};  // in-order -> heap index
+    double vals[32];
+#pragma unroll
+    for (int c = 0; c < 32; c++) vals[c] = 0.0;
 #pragma unroll
     for (int j = 0; j < 15; j++) {
-        const double v1 = wave_sum(s1[j]);
-        const double v2 = wave_sum(s2[j]);
-        if (lane == 0) {
-            const int k = c_heap_of_sorted[j];
-            s_p[wave][2 * k] = v1;
-            s_p[wave][2 * k + 1] = v2;
+        vals[2 * HEAP_OF_SORTED[j]] = s1[j];
+        vals[2 * HEAP_OF_SORTED[j] + 1] = s2[j];
+    }
+#pragma unroll
+    for (int o = 32, cnt = 32; o >= 2; o >>= 1, cnt >>= 1) {
+        const bool up = (lane & o) != 0;
+#pragma unroll
+        for (int k = 0; k < cnt / 2; k++) {
+            const double keep = up ? vals[k + cnt / 2] : vals[k];
+            const double send = up ? vals[k] : vals[k + cnt / 2];
+            vals[k] = keep + __shfl_xor(send, o, 64);
         }
     }
-    if (lane == 0) s_p[wave][30] = s_p[wave][31] = 0.0;
+    vals[0] += __shfl_xor(vals[0], 1, 64);
+    if ((lane & 1) == 0) s_p[wave][lane >> 1] = vals[0];
     __syncthreads();
     if (threadIdx.x < 32) {
         double v = s_p[0][threadIdx.x];
@@ -611,17 +645,8 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
     hipStream_t st = as_stream(stream);
     double* d_st = ctx->d_small + 2560;
     BetaPack<16>* d_bp = reinterpret_cast<BetaPack<16>*>(ctx->d_small + 2560 + 64);
-    ASMC_HIP(hipStreamSynchronize(st));
     double* h = ctx->h_pinned + 4096 + 512;
-    for (int i = 0; i < 40; i++) h[i] = 0.0;
-    h[0] = beta0;
-    h[1] = 1.0;
-    h[3] = target_eff;
-    h[4] = tol;
-    h[5] = log((double)n);
-    h[7] = beta0;
-    h[8] = (double)n;
-    ASMC_HIP(hipMemcpyAsync(d_st, h, sizeof(double) * 40, hipMemcpyHostToDevice, st));
+    const BisInit init = {beta0, target_eff, tol, log((double)n), (double)n};
     // round 0: beta = 1 with its exact maximum (also the NaN census: for beta > beta0 the NaN pattern of the
     // log-weights does not depend on beta)
     const double one = 1.0;
@@ -631,9 +656,10 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
     rc = launch_sums(ctx, n, ll, lp, lq, beta0, &one, nullptr, nullptr, 1, true, &grid1, st);
     if (rc) return rc;
     ASMC_LAUNCH(ctx, st, "k_bis_tail", k_bis_tail, dim3(1), dim3(ASMC_BLOCK), 0, st, d_st, d_bp, (const double*)ctx->d_partials, grid1, 0,
-                (const unsigned long long*)ctx->d_keys);
+                (const unsigned long long*)ctx->d_keys, init);
     ASMC_LAUNCH_CHECK();
-    const int grid = grid_for(n, BIS_THREADS, ctx->num_cu);
+    static const int bis_mult = getenv("ASMC_BIS_MULT") ? atoi(getenv("ASMC_BIS_MULT")) : 1;
+    const int grid = grid_for(n, BIS_THREADS, ctx->num_cu * bis_mult);
     unsigned int* d_ticket = reinterpret_cast<unsigned int*>(ctx->d_keys + ASMC_MAX_BETAS + 4);  // zeroed by launch_max
     // every round narrows the bracket 16x: ceil(log16((1 - beta0) / tol)) rounds reach the tolerance; one spare
     // round (it exits at once when the flag is already set) covers rounding in that estimate
@@ -645,7 +671,7 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
         ASMC_LAUNCH_CHECK();
         if (split) {
             ASMC_LAUNCH(ctx, st, "k_bis_tail", k_bis_tail, dim3(1), dim3(ASMC_BLOCK), 0, st, d_st, d_bp, (const double*)ctx->d_partials, grid, 1,
-                        (const unsigned long long*)ctx->d_keys);
+                        (const unsigned long long*)ctx->d_keys, init);
             ASMC_LAUNCH_CHECK();
         }
     }

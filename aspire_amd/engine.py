@@ -255,13 +255,19 @@ class HipEngine:
         return int(a.value), int(b.value)
 
     # ---- resampling ------------------------------------------------------------------------
-    def cdf(self, w: torch.Tensor, mode: str = "exact", carry_in: float = 0.0) -> tuple[torch.Tensor, float]:
+    def cdf(self, w: torch.Tensor, mode: str = "exact", carry_in: float = 0.0, want_total: bool = True):
+        """(cdf, last element).  want_total=False leaves the total on the device (None is returned) so that
+        `cdf_normalize_last` can follow without a host round trip."""
         assert w.dtype == torch.float64 and w.is_contiguous()
         out = torch.empty_like(w)
         total = ctypes.c_double(0.0)
         check(self.lib.asmc_cdf(self._ctx, w.numel(), _dptr(w), _dptr(out), CDF_MODES[mode], carry_in,
-                                ctypes.byref(total), self._stream), "asmc_cdf")
-        return out, total.value
+                                ctypes.byref(total) if want_total else None, self._stream), "asmc_cdf")
+        return out, (total.value if want_total else None)
+
+    def cdf_normalize_last(self, cdf: torch.Tensor) -> torch.Tensor:
+        check(self.lib.asmc_cdf_normalize_last(self._ctx, cdf.numel(), _dptr(cdf), self._stream), "asmc_cdf_normalize_last")
+        return cdf
 
     def cdf_normalize(self, cdf: torch.Tensor, last: float) -> torch.Tensor:
         check(self.lib.asmc_cdf_normalize(self._ctx, cdf.numel(), _dptr(cdf), last, self._stream), "asmc_cdf_normalize")

@@ -289,8 +289,12 @@ def resample_indices(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out:
         w = comm.all_gather_tensor(w)
         if hasattr(engine, "ensure_capacity"):
             engine.ensure_capacity(w.numel(), 1)
-    cdf, last = engine.cdf(w, mode, 0.0)
-    engine.cdf_normalize(cdf, last)
+    if hasattr(engine, "cdf_normalize_last"):  # divisor stays on the device
+        cdf, _ = engine.cdf(w, mode, 0.0, want_total=False)
+        engine.cdf_normalize_last(cdf)
+    else:
+        cdf, last = engine.cdf(w, mode, 0.0)
+        engine.cdf_normalize(cdf, last)
     # this rank's output slots
     per = -(-n_out // comm.world)
     j0 = min(comm.rank * per, n_out)

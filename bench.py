@@ -157,6 +157,7 @@ def main():
     row_b = d * s_bytes
     alg_bytes = {  # per launch, from SURVEY.md §8d's per-particle figures
         "k_weights_max": 24 * n_local, "k_weights_sums": 24 * n_local, "k_weights_m2": 24 * n_local,
+        "k_bis_sums": 24 * n_local, "k_weights_m2_lse": 24 * n_local,
         "k_weights_map": 32 * n_local, "k_tile_sum": 8 * n_local, "k_exact_tile_td_launch": 8 * n_local,
         "k_exact_tile_write": 16 * n_local, "k_tile_scan": 16 * n_local, "k_divide": 16 * n_local,
         "k_pcg64_uniforms": 8 * n_local, "k_search": 24 * n_local, "k_gather16": (2 * (row_b + 24) + 8) * n_local,

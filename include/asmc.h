@@ -169,6 +169,8 @@ int asmc_count_nonfinite(asmc_ctx* ctx, int64_t n, const double* v_dev, int64_t*
  *   bit-for-bit (parallelised through round-to-nearest-even integer transducers);
  *   ASMC_CDF_FAST uses a parallel scan order.  total_host receives the last element.
  * asmc_cdf_normalize: cdf /= last    (numpy: cdf /= cdf[-1]).
+ * asmc_cdf_normalize_last: the same with the total the preceding asmc_cdf on this ctx left on the device
+ *   (call asmc_cdf with total_host = NULL: no host round trip between the scan and the division).
  * asmc_pcg64_uniforms: u[j] = j-th next double of numpy's PCG64 stream given its raw state
  *   {state_hi, state_lo, inc_hi, inc_lo} after skipping `offset` draws (the host then calls
  *   bit_generator.advance(n)).
@@ -177,6 +179,7 @@ int asmc_count_nonfinite(asmc_ctx* ctx, int64_t n, const double* v_dev, int64_t*
 int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w_dev, double* cdf_dev, int mode,
              double carry_in, double* total_host, asmc_stream stream);
 int asmc_cdf_normalize(asmc_ctx* ctx, int64_t n, double* cdf_dev, double last, asmc_stream stream);
+int asmc_cdf_normalize_last(asmc_ctx* ctx, int64_t n, double* cdf_dev, asmc_stream stream);
 int asmc_pcg64_uniforms(asmc_ctx* ctx, const uint64_t state_host[4], uint64_t offset, int64_t n,
                         double* u_dev, asmc_stream stream);
 int asmc_systematic_uniforms(asmc_ctx* ctx, int64_t n_out, int64_t j0, int64_t n_total, double u0,
