@@ -65,6 +65,22 @@ class AsmcCoupling(ctypes.Structure):
     ]
 
 
+class AsmcTransform(ctypes.Structure):
+    _fields_ = [
+        ("d", c_int32),
+        ("reserved", c_int32),
+        ("kind_dev", c_void_p),
+        ("periodic_dev", c_void_p),
+        ("lower_dev", c_void_p),
+        ("upper_dev", c_void_p),
+        ("mean_dev", c_void_p),
+        ("std_dev", c_void_p),
+        ("eps", c_double),
+        ("unit_logj", c_double),
+        ("affine_logj", c_double),
+    ]
+
+
 _vp, _d, _i, _i64, _u64, _u32 = c_void_p, c_double, c_int, c_int64, c_uint64, c_uint32
 _pd, _pi64 = POINTER(c_double), POINTER(c_int64)
 
@@ -110,6 +126,8 @@ SIGNATURES = {
     "asmc_coupling_pack_floats": (_i64, [_i, _i, _i]),
     "asmc_coupling_pack": (_i, [_i, _i, _i, POINTER(c_void_p), POINTER(c_void_p), _vp]),
     "asmc_coupling_logprob": (_i, [_vp, _i64, _i, _vp, POINTER(AsmcCoupling), _vp, _vp]),
+    "asmc_transform_forward": (_i, [_vp, _i64, _i, _vp, _vp, _vp, POINTER(AsmcTransform), _vp]),
+    "asmc_transform_inverse": (_i, [_vp, _i64, _i, _vp, _vp, _vp, POINTER(AsmcTransform), _vp]),
     "asmc_pcn_flow_work_bytes": (_i64, [_i64, _i, _i]),
     "asmc_pcn_mutate_flow": (
         _i,

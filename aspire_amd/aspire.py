@@ -144,9 +144,19 @@ class Aspire:
             transform = None
         elif preconditioning in ["standard", "default"]:
             pk = dict(preconditioning_kwargs or {})
-            if pk.get("affine_transform") or pk.get("bounded_to_unbounded") or self.periodic_parameters:
-                raise NotImplementedError("device preconditioning transforms are a 'next' row (SURVEY.md §8f)")
-            transform = IdentityTransform(xp=self.xp)
+            pk.setdefault("affine_transform", False)  # aspire.py:337-341
+            pk.setdefault("bounded_to_unbounded", False)
+            pk.setdefault("bounded_transform", "logit")
+            needs_bounds = pk["bounded_to_unbounded"] and self.prior_bounds is not None
+            if pk["affine_transform"] or needs_bounds or self.periodic_parameters:
+                from .transforms import CompositeTransform
+
+                params = self.parameters if self.parameters is not None else [f"x_{i}" for i in range(self.dims)]
+                transform = CompositeTransform(parameters=params, prior_bounds=self.prior_bounds,
+                                               periodic_parameters=self.periodic_parameters, xp=self.xp,
+                                               device=self.device, dtype=self.dtype, **pk)
+            else:  # the reference builds a CompositeTransform with every stage off: the identity
+                transform = IdentityTransform(xp=self.xp)
         elif preconditioning == "flow":
             raise NotImplementedError("flow preconditioning is out of scope (SURVEY.md §2)")
         else:

@@ -18,6 +18,7 @@
 #include <chrono>
 
 #include "asmc_common.h"
+#include "asmc_tile.h"
 
 // =============================================================================================
 // Philox4x32-10 (Salmon et al. SC'11; Random123 constants) and Box-Muller
@@ -111,81 +112,6 @@ static inline MixDev to_dev(const asmc_mixture& m) {
     r.mu = m.mu_dev;
     r.prec = m.prec_dev;
     return r;
-}
-
-__host__ __device__ __forceinline__ int lds_row_stride(int rowbytes) {
-    // +16 B breaks the power-of-two stride (bank-conflict free per-lane row reads); rows whose
-    // byte length is not a multiple of 16 are padded up to the next multiple of 8 first
-    return ((rowbytes + 7) & ~7) + 16;
-}
-
-// coalesced copy of a 64-row tile global -> LDS (VEC = bytes per lane per access: 16, 8 or 4)
-template <int VEC>
-__device__ __forceinline__ void tile_load(const char* __restrict__ g, int64_t valid_bytes, int rowbytes,
-                                          int ldsrow, char* lds, int lane) {
-    const int tile_bytes = 64 * rowbytes;
-    for (int off = lane * VEC; off < tile_bytes; off += 64 * VEC) {
-        const int r = off / rowbytes, c = off - r * rowbytes;
-        if (VEC == 16) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (off < valid_bytes) v = *reinterpret_cast<const uint4*>(g + off);
-            *reinterpret_cast<uint4*>(lds + r * ldsrow + c) = v;
-        } else if (VEC == 8) {
-            unsigned long long v = 0;
-            if (off < valid_bytes) v = *reinterpret_cast<const unsigned long long*>(g + off);
-            *reinterpret_cast<unsigned long long*>(lds + r * ldsrow + c) = v;
-        } else {
-            uint32_t v = 0;
-            if (off < valid_bytes) v = *reinterpret_cast<const uint32_t*>(g + off);
-            *reinterpret_cast<uint32_t*>(lds + r * ldsrow + c) = v;
-        }
-    }
-}
-
-template <int VEC>
-__device__ __forceinline__ void tile_store(char* __restrict__ g, int64_t valid_bytes, int rowbytes,
-                                           int ldsrow, const char* lds, int lane) {
-    const int tile_bytes = 64 * rowbytes;
-    for (int off = lane * VEC; off < tile_bytes; off += 64 * VEC) {
-        if (off >= valid_bytes) break;
-        const int r = off / rowbytes, c = off - r * rowbytes;
-        if (VEC == 16)
-            *reinterpret_cast<uint4*>(g + off) = *reinterpret_cast<const uint4*>(lds + r * ldsrow + c);
-        else if (VEC == 8)
-            *reinterpret_cast<unsigned long long*>(g + off) =
-                *reinterpret_cast<const unsigned long long*>(lds + r * ldsrow + c);
-        else
-            *reinterpret_cast<uint32_t*>(g + off) = *reinterpret_cast<const uint32_t*>(lds + r * ldsrow + c);
-    }
-}
-
-// coalesced LDS -> global copy of the rows selected by `rowmask` (bit r = row r of the tile): rows whose
-// proposal was rejected are simply not written, so a step writes acc_rate * d * s bytes per particle
-template <int VEC>
-__device__ __forceinline__ void tile_store_rows(char* __restrict__ g, int64_t valid_bytes, int rowbytes, int ldsrow,
-                                                const char* lds, int lane, unsigned long long rowmask) {
-    const int tile_bytes = 64 * rowbytes;
-    for (int off = lane * VEC; off < tile_bytes; off += 64 * VEC) {
-        if (off >= valid_bytes) break;
-        const int r = off / rowbytes, c = off - r * rowbytes;
-        if (!((rowmask >> r) & 1ULL)) continue;
-        if (VEC == 16)
-            *reinterpret_cast<uint4*>(g + off) = *reinterpret_cast<const uint4*>(lds + r * ldsrow + c);
-        else if (VEC == 8)
-            *reinterpret_cast<unsigned long long*>(g + off) =
-                *reinterpret_cast<const unsigned long long*>(lds + r * ldsrow + c);
-        else
-            *reinterpret_cast<uint32_t*>(g + off) = *reinterpret_cast<const uint32_t*>(lds + r * ldsrow + c);
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ double row_get(const char* row, int j) {
-    return (double)reinterpret_cast<const T*>(row)[j];
-}
-template <typename T>
-__device__ __forceinline__ void row_set(char* row, int j, double v) {
-    reinterpret_cast<T*>(row)[j] = (T)v;
 }
 
 // diagonal-mixture log-density of the row stored (as T) at `row`
@@ -841,7 +767,7 @@ __global__ __launch_bounds__(1024) void k_pcn_adapt(int nblocks, const long long
 __global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_accept_flags(
     int64_t n, double* __restrict__ ll, double* __restrict__ lp, double* __restrict__ lq,
     const double* __restrict__ ll_new, const double* __restrict__ lp_new, const double* __restrict__ lq_new,
-    const double* __restrict__ lj_old, const double* __restrict__ lj_new, const double* __restrict__ qf_old,
+    double* __restrict__ lj_old, const double* __restrict__ lj_new, const double* __restrict__ qf_old,
     const double* __restrict__ qf_new, double beta, unsigned long long seed, unsigned long long gid0,
     uint32_t step, unsigned char* __restrict__ flags, unsigned long long* __restrict__ count) {
     long long c = 0;
@@ -865,6 +791,7 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_accept_flags(
             ll[i] = ll_new[i];
             lp[i] = lp_new[i];
             lq[i] = lq_new[i];
+            if (lj_old && lj_new) lj_old[i] = lj_new[i];  // the carried log-Jacobian follows the accepted state
             c++;
         }
     }
@@ -1576,7 +1503,7 @@ int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x
 
 int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x, const void* x_prop, double* ll, double* lp,
                     double* lq, const double* ll_new, const double* lp_new, const double* lq_new,
-                    const double* lj_old, const double* lj_new, const double* qf_old, const double* qf_new,
+                    double* lj_old, const double* lj_new, const double* qf_old, const double* qf_new,
                     double beta, uint64_t seed, uint64_t gid0, uint32_t step, int64_t* n_accept_host,
                     asmc_stream stream) {
     ASMC_REQUIRE(ctx && x && x_prop && ll && lp && lq && ll_new && lp_new && lq_new && qf_old && qf_new, "null pointer");
@@ -1725,7 +1652,7 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
         ASMC_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
         const int g1 = grid_for(n, ASMC_BLOCK * 2, ASMC_MAX_BLOCKS);
         ASMC_LAUNCH(ctx, st, "k_pcn_accept_flags", k_pcn_accept_flags, dim3(g1), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq,
-                    (const double*)ll_new, (const double*)lp_new, (const double*)lq_new, (const double*)nullptr,
+                    (const double*)ll_new, (const double*)lp_new, (const double*)lq_new, (double*)nullptr,
                     (const double*)nullptr, (const double*)q0, (const double*)q1, prm->beta, (unsigned long long)prm->seed,
                     (unsigned long long)prm->gid0, step, flags, d_cnt);
         ASMC_LAUNCH_CHECK();

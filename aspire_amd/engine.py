@@ -16,7 +16,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ASMC_CDF_EXACT, ASMC_CDF_FAST, ASMC_F32, ASMC_F64, AsmcCoupling, AsmcMixture, AsmcPcnParams, check
+from ._lib import (ASMC_CDF_EXACT, ASMC_CDF_FAST, ASMC_F32, ASMC_F64, AsmcCoupling, AsmcMixture, AsmcPcnParams,
+                   AsmcTransform, check)
 
 CDF_MODES = {"exact": ASMC_CDF_EXACT, "fast": ASMC_CDF_FAST}
 
@@ -67,6 +68,27 @@ class DeviceCoupling:
     def c_struct(self) -> AsmcCoupling:
         return AsmcCoupling(self.dims, self.n_layers, self.hidden, 0, self.packed.data_ptr(), self.loc.data_ptr(),
                             self.scale.data_ptr(), self.log_scale_sum)
+
+
+@dataclass
+class DeviceTransform:
+    """Per-dimension tables of a CompositeTransform in HBM (include/asmc.h `asmc_transform`)."""
+
+    d: int
+    kind: torch.Tensor  # int32 [d]: 0 none, 1 logit, 2 probit
+    periodic: torch.Tensor  # int32 [d]
+    lower: torch.Tensor  # fp64 [d]
+    upper: torch.Tensor
+    mean: torch.Tensor | None
+    std: torch.Tensor | None
+    eps: float
+    unit_logj: float
+    affine_logj: float
+
+    def c_struct(self) -> AsmcTransform:
+        return AsmcTransform(self.d, 0, self.kind.data_ptr(), self.periodic.data_ptr(), self.lower.data_ptr(),
+                             self.upper.data_ptr(), None if self.mean is None else self.mean.data_ptr(),
+                             None if self.std is None else self.std.data_ptr(), self.eps, self.unit_logj, self.affine_logj)
 
 
 def pack_coupling(lib, dims: int, hidden: int, weights, biases) -> np.ndarray:
@@ -340,6 +362,31 @@ class HipEngine:
         check(self.lib.asmc_coupling_logprob(self._ctx, x.shape[0], self._xdt(x), _dptr(x), ctypes.byref(cs), _dptr(out),
                                              self._stream), "asmc_coupling_logprob")
         return out
+
+    def make_transform(self, kind, periodic, lower, upper, mean=None, std=None, eps=1e-6, unit_logj=0.0,
+                       affine_logj=0.0) -> DeviceTransform:
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=self.device)  # noqa: E731
+        return DeviceTransform(len(kind), i32(kind), i32(periodic), self.asarray(np.asarray(lower, dtype=np.float64)),
+                               self.asarray(np.asarray(upper, dtype=np.float64)),
+                               None if mean is None else self.asarray(np.asarray(mean, dtype=np.float64)),
+                               None if std is None else self.asarray(np.asarray(std, dtype=np.float64)), float(eps),
+                               float(unit_logj), float(affine_logj))
+
+    def _transform(self, fn, name, x: torch.Tensor, t: DeviceTransform, want_logj: bool):
+        assert x.is_contiguous() and x.dim() == 2 and x.shape[1] == t.d
+        out = torch.empty_like(x)
+        lj = self.empty(x.shape[0]) if want_logj else None
+        cs = t.c_struct()
+        check(fn(self._ctx, x.shape[0], self._xdt(x), _dptr(x), _dptr(out), _dptr(lj), ctypes.byref(cs), self._stream), name)
+        return out, lj
+
+    def transform_forward(self, x: torch.Tensor, t: DeviceTransform, want_logj: bool = True):
+        """(z, log|det J|) of x -> z."""
+        return self._transform(self.lib.asmc_transform_forward, "asmc_transform_forward", x, t, want_logj)
+
+    def transform_inverse(self, z: torch.Tensor, t: DeviceTransform, want_logj: bool = True):
+        """(x, log|det J|) of z -> x."""
+        return self._transform(self.lib.asmc_transform_inverse, "asmc_transform_inverse", z, t, want_logj)
 
     def compact_valid(self, x, ll, lp, lq):
         self._chk3(ll, lp, lq)

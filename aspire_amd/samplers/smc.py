@@ -373,6 +373,50 @@ class HipSMC(SMCSampler):
             Linv = np.linalg.inv(L)
         return e.asarray(mean), e.asarray(np.tril(L)), e.asarray(np.tril(Linv))
 
+    def _mutate_preconditioned(self, particles: SMCSamples, x: torch.Tensor, beta: float, n_steps: int, target: float):
+        """smc/minipcn.py:105-132 with a non-trivial preconditioning transform: the chain runs in z = T(x) (refit at
+        every temperature), the tempered log-target there is log p_t(T^-1(z)) + log|det dT^-1/dz| (smc/base.py:507-519).
+        Per step: propose in z -> x', log|J| (asmc_transform_inverse) -> densities at x' -> accept; the carried
+        log-Jacobian follows the accepted state inside the accept kernel."""
+        e, comm, T = self.engine, self.comm, self.preconditioning_transform
+        if getattr(T, "engine", None) is None and hasattr(T, "engine"):
+            T.engine = e
+        ll, lp, lq = particles.log_likelihood, particles.log_prior, particles.log_q
+        n_local = x.shape[0]
+        n_global = n_local * comm.world
+        gid0 = comm.rank * n_local
+        try:
+            z = T.fit(x, comm=comm)
+        except TypeError:  # a user-supplied transform with the reference's fit(x) signature
+            z = T.fit(x)
+        z = e.asarray(z, dtype=x.dtype)
+        logj = e.asarray(T.inverse(z)[1])
+        mu, L, Linv = self._fit_reference_gaussian(z)
+        st = self._pcn_state
+        if st["rho"] is None:
+            st["rho"] = min(2.38 / math.sqrt(self.dims), 0.99)
+        seed = int(self.rng.integers(0, 2**63 - 1, dtype=np.int64))
+        step0 = st["step"]
+        acc_rates = []
+        for t in range(n_steps):
+            z_prop, q0, q1 = e.pcn_propose(z, mu, L, Linv, st["rho"], seed, gid0, step0 + t)
+            x_prop, logj_new = T.inverse(z_prop)
+            x_prop, logj_new = e.asarray(x_prop, dtype=x.dtype), e.asarray(logj_new)
+            lq_new = self._flow_log_prob(x_prop)
+            lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
+            n_acc = e.pcn_accept(z, z_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0, step0 + t,
+                                 logj_old=logj, logj_new=logj_new)
+            tot = float(comm.all_gather_f64(np.array([float(n_acc)])).sum())
+            acc_rates.append(tot / n_global)
+            st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)
+        st["step"] = step0 + n_steps
+        self.history.mcmc_acceptance.append(float(np.mean(acc_rates)))
+        self.history.mcmc_step_size.append(float(st["rho"]))
+        x_new = e.asarray(T.inverse(z)[0], dtype=x.dtype)
+        if e.count_nonfinite(lq)[0]:
+            raise ValueError("Log proposal contains NaN values")
+        return self._wrap(x_new, ll, lp, lq, beta)
+
     def _device_flow(self):
         """The proposal flow packed for the MFMA kernel, or None (not a float32 coupling flow of a supported shape)."""
         if not hasattr(self.prior_flow, "device_coupling"):
@@ -401,10 +445,12 @@ class HipSMC(SMCSampler):
         n_steps = n_steps or kwargs.pop("n_steps")
         target = float(kwargs.get("target_acceptance_rate", 0.234))
         noise = kwargs.get("noise", "f64")
-        if not isinstance(self.preconditioning_transform, IdentityTransform):
-            raise NotImplementedError("only the identity preconditioning transform is supported on device")
-        self.fit_preconditioning_transform(particles.x)
         x = particles.x if particles.x.is_contiguous() else particles.x.contiguous()
+        T = self.preconditioning_transform
+        transformed = not (isinstance(T, IdentityTransform) or getattr(T, "is_identity", False))
+        if transformed:
+            return self._mutate_preconditioned(particles, x, beta, n_steps, target)
+        self.fit_preconditioning_transform(particles.x)
         ll, lp, lq = particles.log_likelihood, particles.log_prior, particles.log_q
         n_local = x.shape[0]
         n_global = n_local * comm.world

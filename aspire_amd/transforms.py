@@ -1,0 +1,182 @@
+"""Preconditioning transforms on the device.
+
+`CompositeTransform` mirrors the reference class of the same name (src/aspire/transforms.py:142-316):
+periodic wrap -> bounded-to-unbounded (logit / probit of the unit interval) -> affine standardisation, with
+`fit`, `forward`, `inverse`, `new_instance` and `config_dict`.  All per-particle arithmetic runs in the HIP
+kernels `asmc_transform_forward` / `asmc_transform_inverse` (csrc/asmc_transform.hip); this class only keeps
+the per-dimension tables and the two scalar Jacobian constants, which it computes with numpy exactly as the
+reference does (`-log(upper - lower).sum()`, `-log|std|.sum()`).
+
+Inputs may be device tensors (the sampler's case: results stay on the device) or host arrays (results come
+back as numpy arrays); there is no host implementation — host arrays are uploaded, transformed on the GPU
+and downloaded.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any
+
+import numpy as np
+import torch
+
+from .comm import Comm
+
+logger = logging.getLogger(__name__)
+
+_KINDS = {"logit": 1, "probit": 2}
+
+
+class CompositeTransform:
+    def __init__(self, parameters: list, periodic_parameters: list | None = None,
+                 prior_bounds: dict | None = None, bounded_to_unbounded: bool = True,
+                 bounded_transform: str = "probit", affine_transform: bool = True, device=None, xp=None,
+                 eps: float = 1e-6, dtype: Any = None, engine=None):
+        # transforms.py:156-163 — same warnings / errors
+        if prior_bounds is None:
+            logger.warning("Missing prior bounds, some transforms may not be applied.")
+        if periodic_parameters and not prior_bounds:
+            raise ValueError("Must specify prior bounds to use periodic parameters.")
+        if bounded_transform not in _KINDS:
+            raise ValueError(f"Unknown bounded transform: {bounded_transform}")
+        self.parameters = list(parameters)
+        self.periodic_parameters = list(periodic_parameters or [])
+        self.bounded_to_unbounded = bounded_to_unbounded
+        self.bounded_transform = bounded_transform
+        self.affine_transform = affine_transform
+        self.eps = eps
+        self.device = device
+        self.xp = xp
+        self.dtype = dtype
+        self.engine = engine
+        d = len(self.parameters)
+        lower, upper = np.full(d, -np.inf), np.full(d, np.inf)
+        if prior_bounds is None:
+            self.prior_bounds = None
+            self.bounded_parameters = None
+        else:
+            self.prior_bounds = {k: np.asarray(prior_bounds[k], dtype=np.float64) for k in self.parameters}
+            for j, p in enumerate(self.parameters):
+                lower[j], upper[j] = self.prior_bounds[p]
+            if bounded_to_unbounded:  # transforms.py:183-189: finite bounds and not periodic
+                self.bounded_parameters = [p for p in self.parameters
+                                           if np.isfinite(self.prior_bounds[p]).all() and p not in self.periodic_parameters]
+            else:
+                self.bounded_parameters = None
+        self._lower, self._upper = lower, upper
+        self._periodic = np.array([p in self.periodic_parameters for p in self.parameters], dtype=np.int32)
+        bounded = np.array([bool(self.bounded_parameters) and p in self.bounded_parameters for p in self.parameters])
+        self._kind = np.where(bounded, _KINDS[bounded_transform], 0).astype(np.int32)
+        if bounded.any():
+            denom = upper[bounded] - lower[bounded]
+            if np.any(denom == 0.0):  # transforms.py:513-518
+                raise ValueError("Current floating precision (float64) is too small for specified parameter ranges")
+            self._unit_logj = float(-np.log(denom).sum())
+        else:
+            self._unit_logj = 0.0
+        wrap = self._periodic.astype(bool)
+        if wrap.any() and not np.all(np.isfinite(lower[wrap]) & np.isfinite(upper[wrap])):
+            raise ValueError("Periodic parameters need finite prior bounds.")
+        self._mean = self._std = None
+        self._affine_logj = 0.0
+        self._dev = None  # (engine, DeviceTransform) cache
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    @property
+    def is_identity(self) -> bool:
+        return not (self._periodic.any() or self._kind.any() or self.affine_transform)
+
+    def _eng(self):
+        if self.engine is None:
+            from .samples import get_default_engine
+
+            self.engine = get_default_engine()
+        return self.engine
+
+    def _tables(self, with_affine: bool = True):
+        e = self._eng()
+        fitted = with_affine and self.affine_transform
+        if fitted and self._mean is None:
+            raise RuntimeError("the affine stage has not been fitted: call fit(x) first")
+        key = (id(e), fitted, None if self._mean is None else self._mean.tobytes() + self._std.tobytes())
+        if self._dev is None or self._dev[0] != key:
+            # the kernel clamps the unit interval only where kind != 0 and wraps only where periodic: the infinite
+            # bounds of untouched dimensions are never used, but keep the tables finite anyway
+            lo = np.where(np.isfinite(self._lower), self._lower, 0.0)
+            up = np.where(np.isfinite(self._upper), self._upper, 1.0)
+            self._dev = (key, e.make_transform(self._kind, self._periodic, lo, up, self._mean if fitted else None,
+                                               self._std if fitted else None, self.eps, self._unit_logj,
+                                               self._affine_logj if fitted else 0.0))
+        return e, self._dev[1]
+
+    def _in(self, x):
+        e = self._eng()
+        host = not isinstance(x, torch.Tensor)
+        xt = e.asarray(np.atleast_2d(np.asarray(x)) if host else (x if x.dim() == 2 else x.reshape(1, -1)),
+                       dtype=x.dtype if (not host and x.dtype in (torch.float32, torch.float64)) else torch.float64)
+        return xt, host
+
+    def _out(self, y, lj, host):
+        if not host:
+            return y, lj
+        e = self._eng()
+        return e.to_numpy(y), (None if lj is None else e.to_numpy(lj))
+
+    # ---- reference API (transforms.py:252-316) -----------------------------------------------
+    def fit(self, x, comm: Comm | None = None):
+        """Fit the affine stage to the (periodic + bounded transformed) data and return the transformed data.
+        `comm`: sharded populations fit the GLOBAL mean / standard deviation."""
+        xt, host = self._in(x)
+        e, t0 = self._tables(with_affine=False)
+        z0 = xt.clone() if self.is_identity else e.transform_forward(xt, t0, want_logj=False)[0]
+        if self.affine_transform:
+            comm = comm or Comm()
+            n = z0.shape[0]
+            sums = np.asarray(e.colsum(z0), dtype=np.float64)
+            if comm.world > 1:
+                parts = comm.all_gather_f64(sums)
+                sums = parts[0].copy()
+                for r in range(1, comm.world):
+                    sums = sums + parts[r]
+            n_glob = n * comm.world
+            mean = sums / n_glob
+            m2 = np.diag(np.asarray(e.centered_gram(z0, mean), dtype=np.float64)).copy()
+            if comm.world > 1:
+                parts = comm.all_gather_f64(m2)
+                m2 = parts[0].copy()
+                for r in range(1, comm.world):
+                    m2 = m2 + parts[r]
+            self._mean, self._std = mean, np.sqrt(m2 / n_glob)  # x.mean(0), x.std(0) (population), transforms.py:622-626
+            self._affine_logj = float(-np.log(np.abs(self._std)).sum())
+            e, t = self._tables()
+            z = e.transform_forward(xt, t, want_logj=False)[0]
+        else:
+            z = z0
+        return self._out(z, None, host)[0]
+
+    def forward(self, x):
+        xt, host = self._in(x)
+        e, t = self._tables()
+        if self.is_identity:
+            return self._out(xt.clone(), e.full(xt.shape[0], 0.0), host)
+        return self._out(*e.transform_forward(xt, t), host)
+
+    def inverse(self, z):
+        zt, host = self._in(z)
+        e, t = self._tables()
+        if self.is_identity:
+            return self._out(zt.clone(), e.full(zt.shape[0], 0.0), host)
+        return self._out(*e.transform_inverse(zt, t), host)
+
+    def new_instance(self, xp=None, dtype: Any = None):
+        return self.__class__(parameters=self.parameters, periodic_parameters=self.periodic_parameters,
+                              prior_bounds=self.prior_bounds, bounded_to_unbounded=self.bounded_to_unbounded,
+                              bounded_transform=self.bounded_transform, affine_transform=self.affine_transform,
+                              device=self.device, xp=xp or self.xp, eps=self.eps, dtype=dtype or self.dtype,
+                              engine=self.engine)
+
+    def config_dict(self):
+        return {"xp": getattr(self.xp, "__name__", None), "dtype": str(self.dtype) if self.dtype else None,
+                "parameters": self.parameters, "periodic_parameters": self.periodic_parameters,
+                "prior_bounds": self.prior_bounds, "bounded_to_unbounded": self.bounded_to_unbounded,
+                "bounded_transform": self.bounded_transform, "affine_transform": self.affine_transform,
+                "eps": self.eps, "device": self.device}

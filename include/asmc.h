@@ -219,7 +219,9 @@ int asmc_compact_valid(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
  *   (single-GPU); sharded runs call with n_steps=1 and adapt on the host after an all-reduce.
  * asmc_pcn_propose / asmc_pcn_accept: the split form for arbitrary Python callables / torch flows
  *   (the host evaluates log_q, log_prior, log_likelihood on x_prop between the two calls,
- *   reference smc/base.py:507-519). */
+ *   reference smc/base.py:507-519).  logj_old_dev / logj_new_dev (both or neither): log|det J| of the
+ *   preconditioning transform at the current / proposed state, added to the tempered log-target
+ *   (smc/base.py:515-517); logj_old_dev is updated in place for accepted particles. */
 int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, double* sum_host,
                 asmc_stream stream);
 int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
@@ -235,7 +237,7 @@ int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x
 int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x_dev,
                     const void* x_prop_dev, double* ll_dev, double* lp_dev, double* lq_dev,
                     const double* ll_new_dev, const double* lp_new_dev, const double* lq_new_dev,
-                    const double* logj_old_dev, const double* logj_new_dev,
+                    double* logj_old_dev, const double* logj_new_dev,
                     const double* qform_old_dev, const double* qform_new_dev, double beta,
                     uint64_t seed, uint64_t gid0, uint32_t step, int64_t* n_accept_host,
                     asmc_stream stream);
@@ -283,6 +285,34 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, 
                          void* work_dev, int64_t work_bytes, int n_steps, uint32_t step0,
                          double* rho_inout_host, int64_t* n_accept_host, double* rho_hist_host,
                          asmc_stream stream);
+
+/* ---- preconditioning transforms ------------------------------------------
+ * Element-wise CompositeTransform of the reference (transforms.py:142-316): periodic wrap (:411-436),
+ * bounded -> unbounded through logit (utils.py:196-245) or probit (transforms.py:540-571) of the unit
+ * interval (:440-537), affine standardisation (:614-646); forward applies them in that order, inverse in
+ * the opposite order; logj_dev[i] (may be NULL) receives log|det J| of the direction applied.
+ * Per-dimension tables live in HBM: kind (0 none, 1 logit, 2 probit), periodic flag, lower, upper (finite
+ * wherever kind != 0 or periodic), mean / std (both NULL: no affine stage).  The two constants are the
+ * reference's scalars in FORWARD sign: unit_logj = -sum_{kind != 0} log(upper - lower),
+ * affine_logj = -sum log|std| (computed by the host so that they round as the reference's do).
+ * In-place operation (z_dev == x_dev) is allowed. */
+typedef struct asmc_transform {
+    int32_t d;
+    int32_t reserved;
+    const int32_t* kind_dev;
+    const int32_t* periodic_dev;
+    const double* lower_dev;
+    const double* upper_dev;
+    const double* mean_dev;
+    const double* std_dev;
+    double eps;
+    double unit_logj;
+    double affine_logj;
+} asmc_transform;
+int asmc_transform_forward(asmc_ctx* ctx, int64_t n, int x_dtype, const void* x_dev, void* z_dev,
+                           double* logj_dev, const asmc_transform* t, asmc_stream stream);
+int asmc_transform_inverse(asmc_ctx* ctx, int64_t n, int x_dtype, const void* z_dev, void* x_dev,
+                           double* logj_dev, const asmc_transform* t, asmc_stream stream);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,7 @@ Files
   ref_loop.npz       G4  SMCSampler.sample history with deterministic stub mutate (smc/base.py:215-488)
   ref_initial.npz    G5  MCMCSampler.draw_initial_samples with invalid rows   (mcmc.py:49-110)
   ref_anchors.npz        the tiny known-answer cases of reference tests/test_samples.py:637-731
+  ref_transforms.npz G6  CompositeTransform fit / forward / inverse + log|det J|     (transforms.py:142-316,411-646)
 """
 from __future__ import annotations
 
@@ -234,6 +235,57 @@ def main():
     a["t10_var"] = float(s.log_evidence_ratio_variance(0.8))
     a["t10_rows"] = s.resample(0.8, n_samples=7, rng=np.random.default_rng(42)).x[:, 0] / 2
     np.savez_compressed(os.path.join(OUT, "ref_anchors.npz"), **a)
+
+    # ---------------- G6 preconditioning transforms -------------------------------------------
+    import importlib
+
+    tr = importlib.import_module("aspire.transforms")
+    g6 = {}
+    tcases = {
+        # name: (bounds per dim (lo, hi) or None, periodic dims, bounded_to_unbounded, kind, affine)
+        "mixed_logit_affine": ([(-1.0, 2.0), None, (0.0, 2 * np.pi)], [2], True, "logit", True),
+        "probit": ([(-3.0, 5.0), (0.0, 1.0), (-10.0, 10.0), (2.0, 2.5)], [], True, "probit", False),
+        "default_periodic": ([(-10.0, 10.0), (0.0, 1.0), (-1.0, 1.0), None, (0.0, 6.0)], [1, 4], False, "logit", False),
+        "logit_affine_d32": ([(-10.0, 10.0)] * 32, [], True, "logit", True),
+        "probit_affine_periodic": ([(-2.0, 2.0), (0.0, 3.0), None, (-1.0, 1.0)], [3], True, "probit", True),
+    }
+    for name, (bounds, per, b2u, kind, affine) in tcases.items():
+        d = len(bounds)
+        params = [f"p{j}" for j in range(d)]
+        pb = {params[j]: (bounds[j] if bounds[j] is not None else (-np.inf, np.inf)) for j in range(d)}
+        T = tr.CompositeTransform(parameters=params, periodic_parameters=[params[j] for j in per], prior_bounds=pb,
+                                  bounded_to_unbounded=b2u, bounded_transform=kind, affine_transform=affine, xp=np,
+                                  dtype=np.float64, eps=1e-6)
+        g = np.random.default_rng(100 + d)
+        cols = []
+        for j in range(d):
+            if bounds[j] is None:
+                cols.append(2.0 * g.normal(size=120))
+            elif j in per:  # periodic: also values outside the interval (they wrap)
+                lo, hi = bounds[j]
+                cols.append(g.uniform(lo - 1.5 * (hi - lo), hi + 1.5 * (hi - lo), size=120))
+            else:
+                lo, hi = bounds[j]
+                u = g.uniform(size=120)
+                u[:3] = [0.0, 1.0, 1e-9]  # on / next to the bounds: the eps clamp
+                cols.append(lo + (hi - lo) * u)
+        x = np.column_stack(cols)
+        z_fit = T.fit(x)
+        z, lj = T.forward(x)
+        z2 = 1.5 * g.normal(size=(120, d))
+        x2, lj2 = T.inverse(z2)
+        g6[name + "_x"], g6[name + "_z_fit"], g6[name + "_z"], g6[name + "_lj"] = x, z_fit, z, lj
+        g6[name + "_z2"], g6[name + "_x2"], g6[name + "_lj2"] = z2, x2, lj2
+        g6[name + "_lower"] = np.array([pb[p][0] for p in params], dtype=np.float64)
+        g6[name + "_upper"] = np.array([pb[p][1] for p in params], dtype=np.float64)
+        g6[name + "_periodic"] = np.array([j in per for j in range(d)], dtype=np.int32)
+        bounded = [b2u and bounds[j] is not None and j not in per for j in range(d)]
+        g6[name + "_kind"] = np.array([({"logit": 1, "probit": 2}[kind] if b else 0) for b in bounded], dtype=np.int32)
+        g6[name + "_affine"] = np.array(int(affine))
+        if affine:
+            g6[name + "_mean"], g6[name + "_std"] = np.asarray(T._affine_transform._mean), np.asarray(T._affine_transform._std)
+    g6["names"] = np.array(list(tcases))
+    np.savez_compressed(os.path.join(OUT, "ref_transforms.npz"), **g6)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

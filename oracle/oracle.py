@@ -81,6 +81,7 @@ def lib():
             "orc_moments": (None, [i64, ci, vp, vp, vp]),
             "orc_is_iteration": (ci, [i64, ci, vp, vp, vp, vp, d, d, d, vp, vp, vp, vp, vp, vp]),
             "orc_coupling_logprob": (ci, [i64, ci, vp, ci, ci, vp, vp, vp, vp, vp]),
+            "orc_transform": (ci, [i64, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, d, ci]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(_lib, name)
@@ -379,3 +380,20 @@ def coupling_logprob(x, weights, biases, loc, scale):
     if st != 0:
         raise ValueError(f"orc_coupling_logprob failed ({st})")
     return out
+
+
+def transform(x, kind, periodic, lower, upper, mean=None, std=None, eps=1e-6, inverse=False):
+    """CompositeTransform forward / inverse on rows of x: returns (y, log|det J|)."""
+    x = _f64(np.atleast_2d(x))
+    n, d = x.shape
+    kind = np.ascontiguousarray(kind, dtype=np.int32)
+    periodic = np.ascontiguousarray(periodic, dtype=np.int32)
+    lower, upper = _f64(lower), _f64(upper)
+    out, logj = np.empty_like(x), np.empty(n)
+    m = None if mean is None else _f64(mean)
+    s = None if std is None else _f64(std)
+    st = lib().orc_transform(n, d, _p(x), _p(out), _p(logj), kind.ctypes.data, periodic.ctypes.data, _p(lower), _p(upper),
+                             None if m is None else _p(m), None if s is None else _p(s), float(eps), int(bool(inverse)))
+    if st != 0:
+        raise ValueError(f"orc_transform failed ({st})")
+    return out, logj

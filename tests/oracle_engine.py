@@ -148,6 +148,23 @@ class OracleEngine:
     def mixture_logpdf(self, x, mix):
         return torch.from_numpy(mix.mix.logpdf(_np(x).astype(np.float64)))
 
+    def make_transform(self, kind, periodic, lower, upper, mean=None, std=None, eps=1e-6, unit_logj=0.0, affine_logj=0.0):
+        return dict(kind=np.asarray(kind, dtype=np.int32), periodic=np.asarray(periodic, dtype=np.int32),
+                    lower=np.asarray(lower, dtype=np.float64), upper=np.asarray(upper, dtype=np.float64),
+                    mean=None if mean is None else np.asarray(mean, dtype=np.float64),
+                    std=None if std is None else np.asarray(std, dtype=np.float64), eps=eps)
+
+    def _transform(self, x, t, inverse, want_logj):
+        y, lj = O.transform(_np(x).astype(np.float64), t["kind"], t["periodic"], t["lower"], t["upper"], t["mean"], t["std"],
+                            t["eps"], inverse=inverse)
+        return torch.from_numpy(y).to(x.dtype), (torch.from_numpy(lj) if want_logj else None)
+
+    def transform_forward(self, x, t, want_logj=True):
+        return self._transform(x, t, False, want_logj)
+
+    def transform_inverse(self, z, t, want_logj=True):
+        return self._transform(z, t, True, want_logj)
+
     def compact_valid(self, x, ll, lp, lq):
         assert x.dtype == torch.float64
         return tuple(torch.from_numpy(a) for a in O.compact_valid(_np(x), _np(ll), _np(lp), _np(lq)))
@@ -202,4 +219,6 @@ class OracleEngine:
         acc_t = torch.from_numpy(acc)
         x[acc_t] = x_prop[acc_t]
         ll[acc_t], lp[acc_t], lq[acc_t] = ll_new[acc_t], lp_new[acc_t], lq_new[acc_t]
+        if logj_old is not None and logj_new is not None:
+            logj_old[acc_t] = logj_new[acc_t]
         return int(acc.sum())

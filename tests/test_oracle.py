@@ -134,3 +134,26 @@ def test_coupling_flow_oracle_vs_torch(oracle, d, n_layers, hidden):
     flow64 = random_coupling_flow(d, n_layers, hidden, dtype=torch.float64)
     ref64 = flow64.log_prob(torch.as_tensor(x)).numpy()
     np.testing.assert_allclose(got, ref64, rtol=2e-5, atol=5e-4)
+
+
+def test_transforms_golden(oracle, golden):
+    """orc_transform against the real reference's CompositeTransform (forward after fit, inverse, log|det J|):
+    elementary functions come from libm here and from numpy/scipy there, hence 1e-13 relative."""
+    g = golden["ref_transforms"]
+    for name in g["names"]:
+        kind, per, lo, up = g[f"{name}_kind"], g[f"{name}_periodic"], g[f"{name}_lower"], g[f"{name}_upper"]
+        mean = g[f"{name}_mean"] if int(g[f"{name}_affine"]) else None
+        std = g[f"{name}_std"] if int(g[f"{name}_affine"]) else None
+        z, lj = oracle.transform(g[f"{name}_x"], kind, per, lo, up, mean, std, 1e-6)
+        np.testing.assert_allclose(z, g[f"{name}_z"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(z, g[f"{name}_z_fit"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(lj, g[f"{name}_lj"], rtol=1e-13, atol=1e-12)
+        x2, lj2 = oracle.transform(g[f"{name}_z2"], kind, per, lo, up, mean, std, 1e-6, inverse=True)
+        np.testing.assert_allclose(x2, g[f"{name}_x2"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(lj2, g[f"{name}_lj2"], rtol=1e-13, atol=1e-12)
+        # round trip through the oracle itself (periodic dims come back wrapped)
+        xb, ljb = oracle.transform(z, kind, per, lo, up, mean, std, 1e-6, inverse=True)
+        inside = ~per.astype(bool)
+        clamp = (kind != 0)
+        ok = inside & ~clamp
+        np.testing.assert_allclose(xb[:, ok], g[f"{name}_x"][:, ok], rtol=1e-10, atol=1e-10)
