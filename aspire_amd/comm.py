@@ -64,6 +64,9 @@ class TorchDistComm(Comm):
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = torch.device(device)
+        # gloo moves host memory only: device tensors are staged through the host (debugging / CPU-only test
+        # rigs; the production backend is "nccl" = RCCL, which exchanges device memory over xGMI directly)
+        self._stage = dist.get_backend(group) == "gloo"
 
     def all_gather_f64(self, arr) -> np.ndarray:
         a = np.ascontiguousarray(arr, dtype=np.float64)
@@ -81,6 +84,8 @@ class TorchDistComm(Comm):
     def all_gather_tensor(self, t: torch.Tensor) -> torch.Tensor:
         """Concatenate equal-sized shards along dim 0 in rank order."""
         t = t.contiguous()
+        if self._stage and t.is_cuda:
+            return self.all_gather_tensor(t.cpu()).to(t.device)
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         self.dist.all_gather_into_tensor(out, t, group=self.group)
         return out
@@ -88,6 +93,8 @@ class TorchDistComm(Comm):
     def all_to_all_rows(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int]) -> torch.Tensor:
         """Variable all-to-all along dim 0 (rows grouped by destination rank in `send`)."""
         send = send.contiguous()
+        if self._stage and send.is_cuda:
+            return self.all_to_all_rows(send.cpu(), send_counts, recv_counts).to(send.device)
         out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         self.dist.all_to_all_single(out, send, output_split_sizes=list(map(int, recv_counts)),
                                     input_split_sizes=list(map(int, send_counts)), group=self.group)

@@ -69,7 +69,13 @@ class SMCSampler(MCMCSampler):
         """smc/base.py:123-213; the ESS evaluations of one k-ary bisection round share a device pass."""
         n = self._n_global(samples)
 
-        def eff_fn(betas):
+        def eff_fn(betas, closed_form=False):
+            if closed_form and 1.0 in samples.__dict__.get("_wstats", {}):
+                m_one, b0 = samples.weight_stats([1.0])[0].m, float(samples.beta)
+                shifts = [m_one * ((b - b0) / (1.0 - b0)) for b in betas]
+                sts = smc_math.global_stats(self.engine, self.comm, samples.log_likelihood, samples.log_prior, samples.log_q,
+                                            b0, betas, n, shifts=shifts)
+                return [smc_math.ess(s) / n for s in sts]
             return [smc_math.ess(s) / n for s in self._stats(samples, betas)]
 
         search_fn = None

@@ -29,14 +29,26 @@ class Stats:
     n: int  # global particle count
 
 
-def global_stats(engine, comm, ll, lp, lq, beta0: float, betas, n_global: int) -> list[Stats]:
+def global_stats(engine, comm, ll, lp, lq, beta0: float, betas, n_global: int, shifts=None) -> list[Stats]:
     """(m, S1, S2) for each candidate beta over the GLOBAL population.
 
     Raises the reference's ValueError when a log-weight is NaN (samples.py:1246-1247).
     Sharded: all-reduce(max) first, so every rank exponentiates against the same global maximum
     (the reference's exp(x - x.max()), utils.py:253-255), then a rank-ordered sum of the partials.
+    `shifts`: stabilising shifts to use instead of searching for the maxima (one per beta; the bisection rounds
+    pass the closed form m(1) (beta - beta0) / (1 - beta0), which equals the maximum up to rounding because every
+    log-weight is linear in beta): saves the max pass and, sharded, its all-reduce.  No NaN census then.
     """
     betas = np.asarray(betas, dtype=np.float64)
+    if shifts is not None:
+        m = np.asarray(shifts, dtype=np.float64)
+        sums = engine.weights_sums(ll, lp, lq, beta0, betas, m)
+        if comm.world > 1:
+            allsums = comm.all_gather_f64(sums)
+            sums = allsums[0].copy()
+            for r in range(1, comm.world):
+                sums = sums + allsums[r]
+        return [Stats(float(m[k]), float(sums[k, 0]), float(sums[k, 1]), n_global) for k in range(betas.size)]
     if comm.world == 1:
         st = engine.weights_stats(ll, lp, lq, beta0, betas)
         n_nan = int(st[:, 3].max())
@@ -176,7 +188,12 @@ def determine_beta(eff_fn, beta: float, *, adaptive: bool, beta_step: float, min
             beta_min = 1.0
     while beta_max - beta_min > beta_tolerance:
         mids = _bisection_tree(beta_min, beta_max, levels)
-        effs = eff_fn(mids)
+        # closed_form=True lets eff_fn shift the log-sum-exps by m(1) (beta - beta0) / (1 - beta0) instead of
+        # searching for each candidate's maximum (the pass at beta = 1 above has found m(1))
+        try:
+            effs = eff_fn(mids, closed_form=True)
+        except TypeError:
+            effs = eff_fn(mids)
         n_pass += 1
         i = 0
         for _ in range(levels):

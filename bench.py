@@ -58,11 +58,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
+    # test rig only: ASMC_BENCH_BACKEND=gloo ASMC_BENCH_DEVICE=0 runs several ranks on ONE GPU (collectives staged
+    # through the host) to exercise the sharded code path where no multi-GPU node is at hand
+    backend = os.environ.get("ASMC_BENCH_BACKEND", "nccl")
+    if "ASMC_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["ASMC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from aspire_amd import smc_math
     from aspire_amd.comm import default_comm
@@ -93,8 +101,17 @@ def main():
     scal = {}
 
     def is_step():
-        def eff_fn(betas):
-            return [smc_math.ess(s) / n_global for s in smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, betas, n_global)]
+        m_one = {}
+
+        def eff_fn(betas, closed_form=False):  # same as SMCSampler.determine_beta's (samplers/smc.py)
+            if closed_form and "m" in m_one:
+                shifts = [m_one["m"] * b for b in betas]
+                sts = smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, betas, n_global, shifts=shifts)
+            else:
+                sts = smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, betas, n_global)
+                if len(betas) == 1 and betas[0] == 1.0:
+                    m_one["m"] = sts[0].m
+            return [smc_math.ess(s) / n_global for s in sts]
 
         search_fn = None
         found = {}
