@@ -203,6 +203,30 @@ def test_exact_cdf_is_numpy_cumsum_bitwise(eng, n, kind):
     assert total == ref[-1]
 
 
+@pytest.mark.parametrize("kind", ["smooth", "heavy", "equal"])
+@pytest.mark.parametrize("n", [1_100_003, 8_000_000])
+def test_exact_cdf_bitwise_beyond_one_chain_chunk(kind, n):
+    """Config 4's replicated scan covers all 8M particles of the node: > 512 tiles, so the chain kernel restages its
+    LDS tile records several times.  Still bit-identical to numpy's sequential cumsum."""
+    from aspire_amd.engine import HipEngine
+
+    big = HipEngine(0, n_max=n, d_max=1)
+    w = _weights(n, 29, kind)
+    cdf, total = big.cdf(big.asarray(w), "exact", 0.0)
+    ref = np.cumsum(w)
+    got = cdf.cpu().numpy()
+    assert np.array_equal(got, ref), np.flatnonzero(got != ref)[:5]
+    assert total == ref[-1]
+    # resampling at that size: indices equal numpy's Generator.choice for the same generator
+    if kind == "smooth":
+        p = w / w.sum()
+        want = np.random.default_rng(5).choice(n, size=100000, replace=True, p=p)
+        cdfn = big.cdf_normalize_last(big.cdf(big.asarray(p), "exact", 0.0, want_total=False)[0])
+        u = big.asarray(np.random.default_rng(5).random(100000))
+        assert np.array_equal(big.search(cdfn, u).cpu().numpy(), want)
+    big.close()
+
+
 def test_exact_cdf_with_carry_chains_like_one_array(eng):
     w = _weights(50000, 3, "smooth")
     a, ta = eng.cdf(eng.asarray(w[:20000]), "exact", 0.0)
