@@ -68,6 +68,7 @@ struct asmc_ctx {
     double* d_tiles;               // [n_tiles_max * 4 + 64] scan tile aggregates
     long long* d_tiles_i;          // [n_tiles_max * 8 + 64] integer tile records (exact cdf: info + split; compaction)
     double* d_gram;                // [gram_blocks * d_max * d_max] gram partials
+    unsigned int* d_guide;         // [n_max / 4 + 8] guide table of the resampling search
     unsigned char* d_flags;        // [n_max + 64] accept flags of the split-path pCN step
     long long* d_counts;           // [ASMC_MAX_PCN_STEPS + max(ASMC_MAX_BLOCKS, n_max/64+1)] accept counts / partials
     double* d_rho;                 // [ASMC_MAX_PCN_STEPS + 8] step-size history on device

@@ -16,6 +16,8 @@
 // reproduces the sequential rounding bit-for-bit.  When the running sum would leave the binade
 // (S + floor(w/q) >= 2^53) the first such element is added with a genuine fp64 add and the scan
 // restarts behind it in the new binade.
+#include <stdlib.h>
+
 #include "asmc_common.h"
 
 // =============================================================================================
@@ -680,6 +682,55 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_search(int64_t n, const double* 
     }
 }
 
+// Guided search.  A guide table G[b] = #{k : cdf[k] <= b / NB}, b = 0..NB, is built from NB + 1 binary searches with
+// SORTED queries (neighbouring threads walk the same cache lines, so the build is cheap), and every lookup then
+// only searches the window [G[b], G[b+1]] of its bucket b = floor(u NB): about two random cache lines per output
+// instead of the ~6 cold levels of a full binary search over the 8 MB cdf.  The result is the same upper bound.
+__global__ __launch_bounds__(ASMC_BLOCK) void k_guide_build(int64_t n, const double* __restrict__ cdf, int64_t nb,
+                                                           unsigned int* __restrict__ guide) {
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t b = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; b <= nb; b += stride) {
+        const double key = (double)b / (double)nb;
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (cdf[mid] <= key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        guide[b] = (unsigned int)lo;
+    }
+}
+
+__global__ __launch_bounds__(ASMC_BLOCK) void k_search_guided(int64_t n, const double* __restrict__ cdf, int64_t nb,
+                                                             const unsigned int* __restrict__ guide, int64_t n_out,
+                                                             const double* __restrict__ u, int64_t* __restrict__ idx) {
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    const double fnb = (double)nb;
+    for (int64_t j = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; j < n_out; j += stride) {
+        const double key = u[j];
+        int64_t lo = 0, hi = n;
+        if (key >= 0.0 && key < 1.0) {
+            int64_t b = (int64_t)(key * fnb);
+            b = b > nb - 1 ? nb - 1 : b;
+            // make b / NB <= key < (b + 1) / NB hold for the very expressions the table was built with
+            while (b > 0 && (double)b / fnb > key) b--;
+            while (b < nb - 1 && (double)(b + 1) / fnb <= key) b++;
+            lo = guide[b];
+            hi = guide[b + 1];
+        }
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            if (cdf[mid] <= key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        idx[j] = lo;
+    }
+}
+
 // =============================================================================================
 // gather rows
 // =============================================================================================
@@ -959,8 +1010,21 @@ int asmc_search(asmc_ctx* ctx, int64_t n, const double* cdf, int64_t n_out, cons
                 int64_t* idx, asmc_stream stream) {
     ASMC_REQUIRE(ctx && cdf && u && idx, "null pointer");
     ASMC_REQUIRE(n > 0 && n_out > 0, "bad sizes");
+    hipStream_t st = as_stream(stream);
     const int grid = grid_for(n_out, ASMC_BLOCK, ASMC_MAX_BLOCKS * 4);
-    ASMC_LAUNCH(ctx, as_stream(stream), "k_search", k_search, dim3(grid), dim3(ASMC_BLOCK), 0, as_stream(stream), n, cdf, n_out, u, idx);
+    // guide table: one bucket per four cdf entries; worth building when the cdf no longer sits in L2 and there are
+    // enough lookups to pay for the nb + 1 (cache-friendly) searches of the build
+    static const bool no_guide = getenv("ASMC_SEARCH_PLAIN") != nullptr;
+    const int64_t nb = n / 4;
+    if (!no_guide && n >= (1 << 17) && n <= ctx->n_max && n < (1LL << 32) && n_out >= n / 8) {
+        ASMC_LAUNCH(ctx, st, "k_guide_build", k_guide_build, dim3(grid_for(nb + 1, ASMC_BLOCK, ASMC_MAX_BLOCKS * 4)), dim3(ASMC_BLOCK), 0, st,
+                    n, cdf, nb, ctx->d_guide);
+        ASMC_LAUNCH_CHECK();
+        ASMC_LAUNCH(ctx, st, "k_search", k_search_guided, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, cdf, nb,
+                    (const unsigned int*)ctx->d_guide, n_out, u, idx);
+    } else {
+        ASMC_LAUNCH(ctx, st, "k_search", k_search, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, cdf, n_out, u, idx);
+    }
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
