@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("ASMC_LIB_PATH") or os.path.join(_HERE, "libasmc_hip.s
 ASMC_OK = 0
 ASMC_F64, ASMC_F32 = 0, 1
 ASMC_CDF_EXACT, ASMC_CDF_FAST = 0, 1
+ASMC_CDF_NORMALIZE = 0x100
 ASMC_NOISE_F64, ASMC_NOISE_F32 = 0, 1
 ASMC_MAX_BETAS = 32
 ASMC_MAX_COMPONENTS = 8

@@ -452,11 +452,23 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, cons
                                                                 const long long* __restrict__ tile_info,
                                                                 const long long* __restrict__ tile_split,
                                                                 const double* __restrict__ tile_s,
-                                                                const double* __restrict__ tile_s2) {
+                                                                const double* __restrict__ tile_s2,
+                                                                const double* __restrict__ norm_ptr) {
     __shared__ TD sh_td[XT_THREADS / 64 + 1];
     const int64_t t = blockIdx.x;
     const long long flag = tile_info[4 * t + 3];
-    if (flag != 1 && flag != 2) return;  // uniform per block
+    // norm_ptr != NULL: the caller wants cdf / cdf[-1] (numpy's `cdf /= cdf[-1]`); the total is known by now, so
+    // the division rides on this pass (tiles the chain wrote element-wise are divided in place)
+    const double norm = norm_ptr ? *norm_ptr : 1.0;
+    if (flag != 1 && flag != 2) {  // uniform per block
+        if (norm_ptr) {
+            const int64_t b0 = t * ASMC_SCAN_TILE + (int64_t)threadIdx.x * XT_E;
+#pragma unroll
+            for (int j = 0; j < XT_E; j++)
+                if (b0 + j < n) cdf[b0 + j] = cdf[b0 + j] / norm;
+        }
+        return;
+    }
     const int e = (int)tile_info[4 * t + 2];
     const int c = flag == 2 ? (int)tile_split[4 * t + 2] : ASMC_SCAN_TILE;
     const int64_t base = t * ASMC_SCAN_TILE + (int64_t)threadIdx.x * XT_E;
@@ -479,7 +491,7 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, cons
 #pragma unroll
         for (int j = 0; j < XT_E; j++) {
             S += (S & 1) ? ta1[j] : ta0[j];
-            if (base + j < n && threadIdx.x * XT_E + j < c) cdf[base + j] = ldexp((double)S, e - 52);
+            if (base + j < n && threadIdx.x * XT_E + j < c) cdf[base + j] = ldexp((double)S, e - 52) / norm;
         }
     }
     if (flag == 2) {  // element c, then the elements behind it on the grid of e + 1
@@ -500,8 +512,8 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, cons
         for (int j = 0; j < XT_E; j++) {
             const int k = threadIdx.x * XT_E + j;
             S += (S & 1) ? ta1[j] : ta0[j];
-            if (base + j < n && k > c) cdf[base + j] = ldexp((double)S, e + 1 - 52);
-            if (k == c) cdf[base + j] = s_new;
+            if (base + j < n && k > c) cdf[base + j] = ldexp((double)S, e + 1 - 52) / norm;
+            if (k == c) cdf[base + j] = s_new / norm;
         }
     }
 }
@@ -557,7 +569,9 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int64_t n_tiles, double* __
 
 __global__ __launch_bounds__(ASMC_BLOCK) void k_tile_scan(int64_t n, const double* __restrict__ w,
                                                          const double* __restrict__ tiles,
-                                                         double* __restrict__ cdf) {
+                                                         double* __restrict__ cdf,
+                                                         const double* __restrict__ norm_ptr) {
+    const double norm = norm_ptr ? *norm_ptr : 1.0;
     const int64_t base = (int64_t)blockIdx.x * ASMC_SCAN_TILE + (int64_t)threadIdx.x * SC_E;
     double v[SC_E];
     double acc = 0.0;
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_tile_scan(int64_t n, const doubl
     off += inc - acc;
 #pragma unroll
     for (int j = 0; j < SC_E; j++)
-        if (base + j < n) cdf[base + j] = off + v[j];
+        if (base + j < n) cdf[base + j] = (off + v[j]) / norm;
 }
 
 // divisor read from the device (the total the preceding cdf pass left there): no host round trip
@@ -897,6 +911,8 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
     ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
     hipStream_t st = as_stream(stream);
     double* d_total = ctx->d_small + 1024;
+    const double* d_norm = (mode & ASMC_CDF_NORMALIZE) ? d_total : nullptr;
+    mode &= ~ASMC_CDF_NORMALIZE;
     if (mode == ASMC_CDF_EXACT) {
         // A+B: approximate (parallel-order) tile prefixes; C: per-tile transducers; D: exact chain; E: write
         const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
@@ -917,7 +933,7 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_exact_tile_write", k_exact_tile_write, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w, cdf,
                            (const long long*)ctx->d_tiles_i, (const long long*)d_split, (const double*)d_tile_s,
-                           (const double*)d_tile_s2);
+                           (const double*)d_tile_s2, d_norm);
         ASMC_LAUNCH_CHECK();
     } else if (mode == ASMC_CDF_FAST) {
         const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
@@ -926,7 +942,7 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
         ASMC_LAUNCH(ctx, st, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, carry_in, d_total);
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_tile_scan", k_tile_scan, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w,
-                           (const double*)ctx->d_tiles, cdf);
+                           (const double*)ctx->d_tiles, cdf, d_norm);
         ASMC_LAUNCH_CHECK();
     } else {
         asmc_set_error("asmc_cdf: unknown mode %d", mode);

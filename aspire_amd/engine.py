@@ -277,14 +277,16 @@ class HipEngine:
         return int(a.value), int(b.value)
 
     # ---- resampling ------------------------------------------------------------------------
-    def cdf(self, w: torch.Tensor, mode: str = "exact", carry_in: float = 0.0, want_total: bool = True):
+    def cdf(self, w: torch.Tensor, mode: str = "exact", carry_in: float = 0.0, want_total: bool = True,
+            normalize: bool = False):
         """(cdf, last element).  want_total=False leaves the total on the device (None is returned) so that
-        `cdf_normalize_last` can follow without a host round trip."""
+        `cdf_normalize_last` can follow without a host round trip; normalize=True writes cdf / cdf[-1] directly
+        (the returned total is still the unnormalised last element)."""
         assert w.dtype == torch.float64 and w.is_contiguous()
         out = torch.empty_like(w)
         total = ctypes.c_double(0.0)
-        check(self.lib.asmc_cdf(self._ctx, w.numel(), _dptr(w), _dptr(out), CDF_MODES[mode], carry_in,
-                                ctypes.byref(total) if want_total else None, self._stream), "asmc_cdf")
+        check(self.lib.asmc_cdf(self._ctx, w.numel(), _dptr(w), _dptr(out), CDF_MODES[mode] | (_lib.ASMC_CDF_NORMALIZE if normalize else 0),
+                                carry_in, ctypes.byref(total) if want_total else None, self._stream), "asmc_cdf")
         return out, (total.value if want_total else None)
 
     def cdf_normalize_last(self, cdf: torch.Tensor) -> torch.Tensor:

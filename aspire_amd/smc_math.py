@@ -306,9 +306,8 @@ def resample_indices(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out:
         w = comm.all_gather_tensor(w)
         if hasattr(engine, "ensure_capacity"):
             engine.ensure_capacity(w.numel(), 1)
-    if hasattr(engine, "cdf_normalize_last"):  # divisor stays on the device
-        cdf, _ = engine.cdf(w, mode, 0.0, want_total=False)
-        engine.cdf_normalize_last(cdf)
+    if hasattr(engine, "cdf_normalize_last"):  # divisor stays on the device and the division rides on the scan
+        cdf, _ = engine.cdf(w, mode, 0.0, want_total=False, normalize=True)
     else:
         cdf, last = engine.cdf(w, mode, 0.0)
         engine.cdf_normalize(cdf, last)

@@ -53,6 +53,7 @@ extern "C" {
 
 #define ASMC_CDF_EXACT 0 /* sequential-order fp64 rounding == numpy cumsum (bit-exact) */
 #define ASMC_CDF_FAST 1  /* parallel-order rounding */
+#define ASMC_CDF_NORMALIZE 0x100 /* OR into the mode: write cdf / cdf[-1] (numpy's `cdf /= cdf[-1]`) in the same pass */
 
 typedef struct asmc_ctx asmc_ctx;
 typedef void* asmc_stream;

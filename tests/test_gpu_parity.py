@@ -227,6 +227,18 @@ def test_exact_cdf_bitwise_beyond_one_chain_chunk(kind, n):
     big.close()
 
 
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("n", [7, 4097, 300001])
+def test_cdf_fused_normalisation_is_divide_by_last(eng, n, mode):
+    """normalize=True == numpy's `cdf /= cdf[-1]` applied to the same scan (bitwise), last element exactly 1."""
+    w = eng.asarray(_weights(n, 3 + n, "smooth") * 0.37)
+    plain, total = eng.cdf(w, mode, 0.0)
+    fused, total2 = eng.cdf(w, mode, 0.0, normalize=True)
+    assert total2 == total
+    # (numpy division: torch divides a tensor by a Python scalar through a reciprocal multiply)
+    assert np.array_equal(fused.cpu().numpy(), plain.cpu().numpy() / total) and float(fused[-1]) == 1.0
+
+
 def test_exact_cdf_with_carry_chains_like_one_array(eng):
     w = _weights(50000, 3, "smooth")
     a, ta = eng.cdf(eng.asarray(w[:20000]), "exact", 0.0)
