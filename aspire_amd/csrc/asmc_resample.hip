@@ -750,6 +750,51 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_search_guided(int64_t n, const d
 // =============================================================================================
 // 16-byte chunks: chunk c -> (row = c / cpr, col = c % cpr); lanes of a wave cover whole rows, so
 // every random row is fetched as full 64-B+ bursts and the output is written fully coalesced.
+// power-of-two rows (cpr = 2^SH 16-byte chunks): shifts instead of 64-bit divisions, four chunks in flight per lane,
+// non-temporal stores (the output is not re-read by this kernel and should not displace the cdf / input rows in L2)
+template <int SH>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_gather16_pow2(int64_t n_out, const int64_t* __restrict__ idx,
+                                                             const uint4* __restrict__ x_in, uint4* __restrict__ x_out,
+                                                             const double* __restrict__ ll_in,
+                                                             const double* __restrict__ lp_in,
+                                                             const double* __restrict__ lq_in,
+                                                             double* __restrict__ ll_out, double* __restrict__ lp_out,
+                                                             double* __restrict__ lq_out) {
+    constexpr int U = 4;
+    const int64_t total = n_out << SH;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t c0 = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; c0 < total; c0 += U * stride) {
+        int64_t src[U];
+        uint4 v[U];
+#pragma unroll
+        for (int q = 0; q < U; q++) {
+            const int64_t c = c0 + q * stride;
+            src[q] = c < total ? idx[c >> SH] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < U; q++) {
+            const int64_t c = c0 + q * stride;
+            if (c < total) v[q] = x_in[(src[q] << SH) + (c & ((1 << SH) - 1))];
+        }
+#pragma unroll
+        for (int q = 0; q < U; q++) {
+            const int64_t c = c0 + q * stride;
+            if (c < total) {
+                __builtin_nontemporal_store(v[q].x, &x_out[c].x);
+                __builtin_nontemporal_store(v[q].y, &x_out[c].y);
+                __builtin_nontemporal_store(v[q].z, &x_out[c].z);
+                __builtin_nontemporal_store(v[q].w, &x_out[c].w);
+                const int k = (int)(c & ((1 << SH) - 1));
+                if (k < 3) {  // lanes 0..2 of a row move its three log-probabilities: one load + one store instruction
+                    const double* sp = k == 0 ? ll_in : (k == 1 ? lp_in : lq_in);
+                    double* dp = k == 0 ? ll_out : (k == 1 ? lp_out : lq_out);
+                    dp[c >> SH] = sp[src[q]];
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(ASMC_BLOCK) void k_gather16(int64_t n_out, const int64_t* __restrict__ idx,
                                                         int cpr, const uint4* __restrict__ x_in,
                                                         uint4* __restrict__ x_out,
@@ -1059,8 +1104,20 @@ int asmc_gather(asmc_ctx* ctx, int64_t n_out, const int64_t* idx, int d, int x_d
     if (vec_ok) {
         const int cpr = (int)(rowbytes / 16);
         const int grid = grid_for(n_out * cpr, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
-        ASMC_LAUNCH(ctx, st, "k_gather16", k_gather16, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, cpr,
+        static const bool plain_gather = getenv("ASMC_GATHER_PLAIN") != nullptr;
+#define ASMC_GATHER_POW2(SHV)                                                                                       \
+    if (!plain_gather && cpr == (1 << SHV)) {                                                                      \
+        ASMC_LAUNCH(ctx, st, "k_gather16", k_gather16_pow2<SHV>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx,   \
+                    (const uint4*)x_in, (uint4*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);               \
+    } else
+        ASMC_GATHER_POW2(4)
+        ASMC_GATHER_POW2(3)
+        ASMC_GATHER_POW2(5)
+        {
+    ASMC_LAUNCH(ctx, st, "k_gather16", k_gather16, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, cpr,
                            (const uint4*)x_in, (uint4*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
+        }
+#undef ASMC_GATHER_POW2
     } else if (x_dtype == ASMC_F64) {
         const int grid = grid_for(n_out * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
         ASMC_LAUNCH(ctx, st, "k_gather_elem<double>", k_gather_elem<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, d,
