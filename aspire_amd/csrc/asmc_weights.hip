@@ -360,15 +360,41 @@ __device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<
     const int col = threadIdx.x & 31, part = threadIdx.x >> 5, nparts = blockDim.x >> 5;
     if (threadIdx.x < 40) s_st[threadIdx.x] = st[threadIdx.x];
     if (threadIdx.x >= 64 && threadIdx.x < 80) s_bp[2][threadIdx.x - 64] = phase == 0 ? 0.0 : bp->m[threadIdx.x - 64];
-    double v = 0.0;
-    if (col < ncols)
-        for (int b = part; b < nblocks; b += nparts) v += partials[(size_t)b * ncols + col];
-    s_red[part][col] = v;
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        double t = 0.0;
-        for (int q = 0; q < nparts; q++) t += s_red[q][threadIdx.x];
-        s_S[threadIdx.x] = t;
+    if (phase == 0) {
+        // two columns only: spread the records over every thread (lane parity = column), reduce inside the wave with
+        // parity-preserving butterflies, then across the waves — a 16-thread sequential sum here cost 20 us
+        const int c2 = threadIdx.x & 1;
+        double v = 0.0;
+        for (int b = threadIdx.x >> 1; b < nblocks; b += blockDim.x >> 1) v += partials[(size_t)b * 2 + c2];
+#pragma unroll
+        for (int o = 32; o >= 2; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) < 2) s_red[threadIdx.x >> 6][c2] = v;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            double t = 0.0;
+            if (threadIdx.x < 2)
+                for (int q = 0; q < (int)(blockDim.x >> 6); q++) t += s_red[q][threadIdx.x];
+            s_S[threadIdx.x] = t;
+        }
+    } else {
+        double v = 0.0;
+        for (int b0 = part; b0 < nblocks; b0 += 8 * nparts) {  // eight records in flight per thread, fixed order
+            double t8[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int b = b0 + q * nparts;
+                t8[q] = b < nblocks ? partials[(size_t)b * ncols + col] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) v += t8[q];
+        }
+        s_red[part][col] = v;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            double t = 0.0;
+            for (int q = 0; q < nparts; q++) t += s_red[q][threadIdx.x];
+            s_S[threadIdx.x] = t;
+        }
     }
     __syncthreads();
     const double logN = s_st[5], N = s_st[8], target = s_st[3], tol = s_st[4], beta0 = s_st[7];
