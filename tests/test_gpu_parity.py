@@ -891,3 +891,49 @@ def test_sampler_with_bounded_preconditioning_gpu(eng):
     assert np.all(np.abs(np.asarray(out.x)) <= 4.0)
     assert abs(float(out.log_evidence) - true_logz) < 5 * float(out.log_evidence_error) + 0.05, (float(out.log_evidence), true_logz)
     assert np.all(np.abs(np.asarray(out.x).var(axis=0) - 1.0) < 0.1)
+
+
+@pytest.mark.gpu
+def test_device_bisection_stress_equals_host_driven_exact_search(eng):
+    """asmc_find_beta (closed-form shifts + geometric progression + in-launch tail) against the host-driven search that
+    evaluates every candidate with its exact maximum and direct exponentials: same beta* on heavy-tailed, nearly
+    degenerate, tiny and large populations, late-stage beta0 and both tolerances."""
+    from aspire_amd import smc_math
+
+    g = np.random.default_rng(2024)
+    mismatches, cases = [], 0
+    for trial in range(40):
+        n = int(g.choice([3, 17, 64, 300, 2048, 5000, 70001, 400000]))
+        kind = trial % 5
+        if kind == 0:    # Gaussian-like
+            ll, lp, lq = -0.5 * g.chisquare(8, n), -0.5 * g.chisquare(8, n), -0.5 * g.chisquare(8, n) - 3.0
+        elif kind == 1:  # heavy tails: a few huge log-likelihoods
+            ll, lp, lq = g.standard_t(2, n) * 20.0, g.normal(size=n), g.normal(size=n)
+        elif kind == 2:  # peaked likelihood: Delta of order 1e3-1e4
+            ll, lp, lq = -np.abs(g.normal(size=n)) * 3e3, g.normal(size=n), g.normal(size=n) * 2
+        elif kind == 3:  # nearly uniform weights (search jumps to 1)
+            ll, lp, lq = 1e-3 * g.normal(size=n), np.zeros(n), np.zeros(n)
+        else:            # some particles with zero likelihood
+            ll, lp, lq = g.normal(size=n), g.normal(size=n), g.normal(size=n)
+            ll[g.uniform(size=n) < 0.2] = -np.inf
+        b0 = float(g.choice([0.0, 0.0, 0.013, 0.4, 0.93, 0.999]))
+        tol = float(g.choice([1e-6, 1e-8]))
+        target = float(g.choice([0.5, 0.3, 0.9]))
+        tl, tp, tq = dev(eng, ll, lp, lq)
+        b_dev, eff1, conv, rounds, n_nan, trip, trip_one = eng.find_beta(tl, tp, tq, b0, target, tol)
+        assert conv and n_nan == 0
+
+        def eff_fn(betas):
+            return [smc_math.ess(s) / n for s in smc_math.global_stats(eng, Comm(), tl, tp, tq, b0, betas, n)]
+
+        try:
+            b_host, _, _ = smc_math.determine_beta(eff_fn, b0, adaptive=True, beta_step=float("nan"), min_beta_step=0.0,
+                                                   max_beta_step=1.0, beta_tolerance=tol, adaptive_min_beta_step=False,
+                                                   target=target, rate=1.0)
+        except smc_math.BetaScheduleError:
+            b_host = b0
+        cases += 1
+        if b_dev != b_host and not (b_host == b0 and b_dev <= b0 + tol):
+            mismatches.append((trial, n, kind, b0, tol, target, b_dev, b_host))
+    assert not mismatches, mismatches
+    assert cases == 40
