@@ -67,24 +67,57 @@ __device__ __forceinline__ void acc_relu(floatx16 (&acc)[TPW][NB]) {
             for (int r = 0; r < 16; r++) acc[tt][nb][r] = fmaxf(acc[tt][nb][r], 0.0f);
 }
 
-// out[NBO] += Wt * in, `in` given as NBI accumulator blocks of the previous layer
+// out[NBO] += Wt * in, `in` given as NBI accumulator blocks of the previous layer.  Consecutive MFMAs never hit the
+// same accumulator: the output blocks (or, for a single output block, two partial accumulators over the even and
+// odd k-groups) alternate, so the matrix pipe does not wait on the previous instruction's write-back.
 template <int TPW, int NBO, int NBI>
 __device__ __forceinline__ void dense_from_acc(floatx16 (&out)[TPW][NBO], const floatx16 (&in)[TPW][NBI],
                                                const float* __restrict__ A, int lane) {
     constexpr int G = NBI * 4;  // groups of four k-steps per output block
     const float4* Ap = reinterpret_cast<const float4*>(A) + lane;
+    if constexpr (NBO >= 2) {
 #pragma unroll
-    for (int t = 0; t < NBO * G; t++) {
-        const int nbo = t / G, g = t % G;
-        const float4 a = Ap[(size_t)t * 64];
-        const float av[4] = {a.x, a.y, a.z, a.w};
+        for (int g = 0; g < G; g++) {
+            float av[NBO][4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int s = 4 * g + e;
+            for (int nbo = 0; nbo < NBO; nbo++) {
+                const float4 a = Ap[(size_t)(nbo * G + g) * 64];
+                av[nbo][0] = a.x, av[nbo][1] = a.y, av[nbo][2] = a.z, av[nbo][3] = a.w;
+            }
 #pragma unroll
-            for (int tt = 0; tt < TPW; tt++)
-                out[tt][nbo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], in[tt][s / 16][s % 16], out[tt][nbo], 0, 0, 0);
+            for (int e = 0; e < 4; e++) {
+                const int s = 4 * g + e;
+#pragma unroll
+                for (int nbo = 0; nbo < NBO; nbo++)
+#pragma unroll
+                    for (int tt = 0; tt < TPW; tt++)
+                        out[tt][nbo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nbo][e], in[tt][s / 16][s % 16], out[tt][nbo], 0, 0, 0);
+            }
         }
+    } else {
+        floatx16 part[TPW];
+#pragma unroll
+        for (int tt = 0; tt < TPW; tt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) part[tt][r] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; g += 2) {
+            const float4 a0 = Ap[(size_t)g * 64], a1 = Ap[(size_t)(g + 1) * 64];
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int s0 = 4 * g + e, s1 = 4 * (g + 1) + e;
+#pragma unroll
+                for (int tt = 0; tt < TPW; tt++) {
+                    out[tt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], in[tt][s0 / 16][s0 % 16], out[tt][0], 0, 0, 0);
+                    part[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], in[tt][s1 / 16][s1 % 16], part[tt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < TPW; tt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) out[tt][0][r] += part[tt][r];
     }
 }
 
@@ -104,15 +137,20 @@ __device__ __forceinline__ void coupling_layer(const float (&cond)[TPW][H / 2], 
         constexpr int G1 = H / 8;
         const float4* Ap = reinterpret_cast<const float4*>(A1) + lane;
 #pragma unroll
-        for (int t = 0; t < FD::NB1 * G1; t++) {
-            const int nb = t / G1, g = t % G1;
-            const float4 a = Ap[(size_t)t * 64];
-            const float av[4] = {a.x, a.y, a.z, a.w};
+        for (int g = 0; g < G1; g++) {
+            float av[FD::NB1][4];
+#pragma unroll
+            for (int nb = 0; nb < FD::NB1; nb++) {
+                const float4 a = Ap[(size_t)(nb * G1 + g) * 64];
+                av[nb][0] = a.x, av[nb][1] = a.y, av[nb][2] = a.z, av[nb][3] = a.w;
+            }
 #pragma unroll
             for (int e = 0; e < 4; e++)
 #pragma unroll
-                for (int tt = 0; tt < TPW; tt++)
-                    h1[tt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], cond[tt][4 * g + e], h1[tt][nb], 0, 0, 0);
+                for (int nb = 0; nb < FD::NB1; nb++)
+#pragma unroll
+                    for (int tt = 0; tt < TPW; tt++)
+                        h1[tt][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[nb][e], cond[tt][4 * g + e], h1[tt][nb], 0, 0, 0);
         }
     }
     acc_relu<TPW, FD::NB1>(h1);
@@ -152,31 +190,83 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, in
     const int p = lane & 31, hh = lane >> 5;
     const int dh = d / 2;
     if (resident) {
-        for (int i = threadIdx.x * 4; i < n_layers * FD::LAYER; i += FLOW_THREADS * 4)
-            *reinterpret_cast<float4*>(sp + i) = *reinterpret_cast<const float4*>(packed + i);
+        // all of a thread's loads are issued before the first LDS store: 14 dependent round trips to L2 would
+        // otherwise cost ~5 % of the kernel at 1M particles
+        const int total4 = n_layers * FD::LAYER / 4;
+        for (int base = 0; base < total4; base += FLOW_THREADS * 8) {
+            float4 tmp[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i4 = base + q * FLOW_THREADS + threadIdx.x;
+                tmp[q] = i4 < total4 ? reinterpret_cast<const float4*>(packed)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i4 = base + q * FLOW_THREADS + threadIdx.x;
+                if (i4 < total4) reinterpret_cast<float4*>(sp)[i4] = tmp[q];
+            }
+        }
         __syncthreads();
     }
     const int64_t n_tiles = (n + ROWS - 1) / ROWS;
     const int64_t tiles_per_round = (int64_t)gridDim.x * FLOW_WAVES;
     const int64_t rounds = (n_tiles + tiles_per_round - 1) / tiles_per_round;  // same trip count for every wave
-    for (int64_t it = 0; it < rounds; it++) {
-        const int64_t tile = (it * gridDim.x + blockIdx.x) * FLOW_WAVES + wave;
-        float xa[TPW][H / 2], xb[TPW][H / 2];
+    // raw rows of the NEXT tile are fetched while the current one is in the matrix pipe (TPW = 1: the registers
+    // are there; with two tiles per wave the accumulators leave no room and the loads stay at the loop head)
+    constexpr bool PREFETCH = (TPW == 1);
+    XT ra[TPW][H / 2], rb[TPW][H / 2];
+    auto load_raw = [&](int64_t tile) {
 #pragma unroll
         for (int tt = 0; tt < TPW; tt++) {
             const int64_t row = tile * ROWS + tt * 32 + p;
             const bool valid = tile < n_tiles && row < n;
 #pragma unroll
-            for (int i = 0; i < H / 2; i++) {
-                const int jp = hh * (H / 2) + i;
-                xa[tt][i] = 0.0f;
-                xb[tt][i] = 0.0f;
-                if (valid && jp < dh) {
-                    xa[tt][i] = ((float)x[row * d + jp] - loc[jp]) / scale[jp];
-                    xb[tt][i] = ((float)x[row * d + dh + jp] - loc[dh + jp]) / scale[dh + jp];
+            for (int i = 0; i < H / 2; i++) ra[tt][i] = rb[tt][i] = (XT)0;
+            if (!valid) continue;
+            if (d == 2 * H) {  // unpadded rows: each lane's two segments as 16-byte vector loads
+                constexpr int V = 16 / (int)sizeof(XT);
+                struct alignas(16) Vec {
+                    XT e[V];
+                };
+                const Vec* pa = reinterpret_cast<const Vec*>(x + row * d + hh * (H / 2));
+                const Vec* pb = reinterpret_cast<const Vec*>(x + row * d + H + hh * (H / 2));
+#pragma unroll
+                for (int q = 0; q < (H / 2) / V; q++) {
+                    const Vec va = pa[q], vb = pb[q];
+#pragma unroll
+                    for (int e = 0; e < V; e++) {
+                        ra[tt][q * V + e] = va.e[e];
+                        rb[tt][q * V + e] = vb.e[e];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < H / 2; i++) {
+                    const int jp = hh * (H / 2) + i;
+                    if (jp < dh) {
+                        ra[tt][i] = x[row * d + jp];
+                        rb[tt][i] = x[row * d + dh + jp];
+                    }
                 }
             }
         }
+    };
+    if (PREFETCH) load_raw((int64_t)blockIdx.x * FLOW_WAVES + wave);
+    for (int64_t it = 0; it < rounds; it++) {
+        const int64_t tile = (it * gridDim.x + blockIdx.x) * FLOW_WAVES + wave;
+        if (!PREFETCH) load_raw(tile);
+        float xa[TPW][H / 2], xb[TPW][H / 2];
+#pragma unroll
+        for (int tt = 0; tt < TPW; tt++) {
+#pragma unroll
+            for (int i = 0; i < H / 2; i++) {
+                const int jp = hh * (H / 2) + i;  // padded dims: loc = 0, scale = 1 are not stored, keep them at zero
+                const bool real = jp < dh;
+                xa[tt][i] = real ? ((float)ra[tt][i] - loc[jp]) / scale[jp] : 0.0f;
+                xb[tt][i] = real ? ((float)rb[tt][i] - loc[dh + jp]) / scale[dh + jp] : 0.0f;
+            }
+        }
+        if (PREFETCH && it + 1 < rounds) load_raw(((it + 1) * gridDim.x + blockIdx.x) * FLOW_WAVES + wave);
         float ladj[TPW];
 #pragma unroll
         for (int tt = 0; tt < TPW; tt++) ladj[tt] = 0.0f;
@@ -320,11 +410,12 @@ static int launch_flow(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_couplin
 template <typename XT>
 static int dispatch_flow(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_coupling* f, double* out, hipStream_t st) {
     const int H = flow_half_pad(f->dims);
-    // two tiles per wave where the accumulators fit the 256-VGPR budget of 2 waves/SIMD
+    // one tile per wave with next-tile prefetch by default; ASMC_FLOW_TPW=2 selects two tiles per wave (shared A
+    // operands, no prefetch) where the accumulators fit the 256-VGPR budget of 2 waves/SIMD
     static const int tpw_env = getenv("ASMC_FLOW_TPW") ? atoi(getenv("ASMC_FLOW_TPW")) : 0;
 #define ASMC_FLOW_CASE(HH, WW)                                                                          \
     if (H == HH && f->hidden == WW) {                                                                   \
-        if (HH == 16 && WW <= 64 && tpw_env != 1) return launch_flow<HH, WW, XT, 512, (HH == 16 && WW <= 64) ? 2 : 1>(ctx, n, x, f, out, st); \
+        if (HH == 16 && WW <= 64 && tpw_env == 2) return launch_flow<HH, WW, XT, 512, (HH == 16 && WW <= 64) ? 2 : 1>(ctx, n, x, f, out, st); \
         return launch_flow<HH, WW, XT, 512, 1>(ctx, n, x, f, out, st);                                  \
     }
     ASMC_FLOW_CASE(16, 32)
