@@ -122,6 +122,8 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     dmalloc((void**)&c->d_tiles, sizeof(double) * (size_t)(c->n_tiles_max * 4 + 64));
     dmalloc((void**)&c->d_tiles_i, sizeof(long long) * (size_t)(c->n_tiles_max * 8 + 64));
     dmalloc((void**)&c->d_gram, sizeof(double) * (size_t)c->gram_blocks * d_max * d_max);
+    c->d_mmtab = nullptr;
+    if (d_max >= 64) dmalloc((void**)&c->d_mmtab, sizeof(double) * 2 * 144 * 64);
     dmalloc((void**)&c->d_guide, sizeof(unsigned int) * ((size_t)n_max / 4 + 8));
     dmalloc((void**)&c->d_flags, (size_t)n_max + 64);
     dmalloc((void**)&c->d_counts, sizeof(long long) * (size_t)(ASMC_MAX_PCN_STEPS + ASMC_MAX_BLOCKS + n_max / 64 + 8));
@@ -147,6 +149,7 @@ int asmc_ctx_destroy(asmc_ctx* c) {
     (void)hipFree(c->d_tiles);
     (void)hipFree(c->d_tiles_i);
     (void)hipFree(c->d_gram);
+    if (c->d_mmtab) (void)hipFree(c->d_mmtab);
     (void)hipFree(c->d_guide);
     (void)hipFree(c->d_flags);
     (void)hipFree(c->d_counts);

@@ -19,101 +19,11 @@
 
 #include "asmc_common.h"
 #include "asmc_tile.h"
-
-// =============================================================================================
-// Philox4x32-10 (Salmon et al. SC'11; Random123 constants) and Box-Muller
-// =============================================================================================
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0;
-        const uint32_t n2 = hi0 ^ c3 ^ k1;
-        c0 = n0;
-        c1 = lo1;
-        c2 = n2;
-        c3 = lo0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c0;
-    out[1] = c1;
-    out[2] = c2;
-    out[3] = c3;
-}
-
-__device__ __forceinline__ double u01_from_words(uint32_t hi, uint32_t lo) {
-    unsigned long long v = ((unsigned long long)hi << 21) ^ ((unsigned long long)lo >> 11);
-    v &= ((1ULL << 53) - 1ULL);
-    return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
-}
-
-// counter = {gid_lo, gid_hi, step, slot}; key = {seed_lo, seed_hi}
-__device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned long long gid,
-                                            uint32_t step, uint32_t slot, double& z0, double& z1) {
-    uint32_t w[4];
-    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, slot, (uint32_t)seed,
-                  (uint32_t)(seed >> 32), w);
-    const double u1 = u01_from_words(w[0], w[1]);
-    const double u2 = u01_from_words(w[2], w[3]);
-    const double r = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincospi(2.0 * u2, &s, &c);
-    z0 = r * c;
-    z1 = r * s;
-}
-
-// Fast noise (NOISE_F32): one Philox block -> FOUR standard normals through fp32 Box-Muller on the
-// hardware transcendental units (v_log_f32 / v_sin_f32 / v_cos_f32 / v_sqrt_f32):
-//   u = w*2^-32 + 2^-33 (float), t = w'*2^-32 revolutions, r = sqrt(-2 ln u), z = r (cos 2 pi t, sin 2 pi t).
-// ~1e-7 relative accuracy, tails to 6.7 sigma; 8x fewer VALU cycles than the fp64 path.
-__device__ __forceinline__ void normal_quad_f32(unsigned long long seed, unsigned long long gid, uint32_t step,
-                                                uint32_t slot, double& z0, double& z1, double& z2, double& z3) {
-    uint32_t w[4];
-    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, slot | 0x40000000u, (uint32_t)seed,
-                  (uint32_t)(seed >> 32), w);
-    const float k = 2.3283064365386963e-10f;  // 2^-32
-    const float u0 = fmaf((float)w[0], k, 1.1641532182693481e-10f);
-    const float u1 = fmaf((float)w[2], k, 1.1641532182693481e-10f);
-    const float t0 = (float)w[1] * k, t1 = (float)w[3] * k;
-    // ln u = log2(u) * ln 2
-    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
-    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
-    z0 = (double)(r0 * __builtin_amdgcn_cosf(t0));
-    z1 = (double)(r0 * __builtin_amdgcn_sinf(t0));
-    z2 = (double)(r1 * __builtin_amdgcn_cosf(t1));
-    z3 = (double)(r1 * __builtin_amdgcn_sinf(t1));
-}
-
-__device__ __forceinline__ double accept_uniform(unsigned long long seed, unsigned long long gid,
-                                                 uint32_t step) {
-    uint32_t w[4];
-    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, 0xFFFFFFFFu, (uint32_t)seed,
-                  (uint32_t)(seed >> 32), w);
-    return u01_from_words(w[0], w[1]);
-}
+#include "asmc_pcn_dev.h"
 
 // =============================================================================================
 // LDS row tiles
 // =============================================================================================
-struct MixDev {
-    int C;
-    const double* logw;
-    const double* mu;
-    const double* prec;
-};
-
-static inline MixDev to_dev(const asmc_mixture& m) {
-    MixDev r;
-    r.C = m.n_components;
-    r.logw = m.logw_dev;
-    r.mu = m.mu_dev;
-    r.prec = m.prec_dev;
-    return r;
-}
-
 // diagonal-mixture log-density of the row stored (as T) at `row`
 template <typename T>
 __device__ __forceinline__ double mixture_eval(const MixDev& m, int d, const char* row) {
@@ -139,25 +49,9 @@ __device__ __forceinline__ double mixture_eval(const MixDev& m, int d, const cha
     return best + log(s);
 }
 
-__device__ __forceinline__ double log_p_t(double ll, double lp, double lq, double beta) {
-    double r = (1.0 - beta) * lq + beta * (ll + lp);
-    return (r != r) ? -INFINITY : r;
-}
-
 // =============================================================================================
 // fused pCN step, generic in d: per-lane work vector v[k] lives in LDS (SoA: v[k*64 + lane])
 // =============================================================================================
-struct PcnDev {
-    int d;
-    double beta;
-    const double* mu;
-    const double* L;
-    const double* Linv;
-    MixDev ll, lp, lq;
-    unsigned long long seed, gid0;
-    int noise;
-    int mode;  // PCN_X_STEP / PCN_Y_STEP / PCN_WHITEN / PCN_UNWHITEN (register-resident kernels)
-};
 
 // PHASE 0: fused (propose + built-in targets + accept, in place)
 // PHASE 1: propose only (writes x_prop tile, qform_old, qform_new)
@@ -1423,6 +1317,34 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     const double t_b = now();
     ctx->h_pinned[0] = *rho_inout_host;
     ASMC_HIP(hipMemcpyAsync(d_rho, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, st));
+    if (asmc_pcn_mm_supported(pd.d, x) && !getenv("ASMC_PCN_GENERIC")) {
+        // d = 64 / 128: triangular mat-vecs on the fp64 matrix cores, always on the whitened state
+        rc = asmc_pcn_mm_pack(ctx, pd, st);
+        if (rc) return rc;
+        int grid = 0;
+        rc = asmc_pcn_mm_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, MM_WHITEN, d_rho, 0, d_block, &grid, st);
+        if (rc) return rc;
+        for (int t = 0; t < n_steps; t++) {
+            rc = asmc_pcn_mm_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, MM_STEP, d_rho, step0 + (uint32_t)t, d_block, &grid, st);
+            if (rc) return rc;
+            ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, grid, (const long long*)d_block, n, t, d_counts,
+                        d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+            ASMC_LAUNCH_CHECK();
+        }
+        rc = asmc_pcn_mm_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, MM_UNWHITEN, d_rho, 0, d_block, &grid, st);
+        if (rc) return rc;
+        long long* h_counts = reinterpret_cast<long long*>(ctx->h_pinned);
+        double* h_rho_hist = ctx->h_pinned + ASMC_MAX_PCN_STEPS + 8;
+        ASMC_HIP(hipMemcpyAsync(h_counts, d_counts, sizeof(long long) * n_steps, hipMemcpyDeviceToHost, st));
+        ASMC_HIP(hipMemcpyAsync(h_rho_hist, d_rho_hist, sizeof(double) * n_steps, hipMemcpyDeviceToHost, st));
+        ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8000, d_rho, sizeof(double), hipMemcpyDeviceToHost, st));
+        ASMC_HIP(hipStreamSynchronize(st));
+        for (int t = 0; t < n_steps; t++) n_accept_host[t] = (int64_t)h_counts[t];
+        if (rho_hist_host)
+            for (int t = 0; t < n_steps; t++) rho_hist_host[t] = h_rho_hist[t];
+        *rho_inout_host = ctx->h_pinned[8000];
+        return ASMC_OK;
+    }
     const bool reg_ok = pcn_reg_supported(pd.d, prm->x_dtype == ASMC_F64 ? 8 : 4, x);
     // whitened-state stepping: plain (single-component) targets, enough steps to amortise the two conversions
     const bool y_state = reg_ok && pd.ll.C == 1 && pd.lp.C == 1 && pd.lq.C == 1 && n_steps >= 4 && !getenv("ASMC_PCN_XSTATE");

@@ -937,3 +937,40 @@ def test_device_bisection_stress_equals_host_driven_exact_search(eng):
             mismatches.append((trial, n, kind, b0, tol, target, b_dev, b_host))
     assert not mismatches, mismatches
     assert cases == 40
+
+
+# ---- d = 64 / 128 pCN on the fp64 matrix cores (BASELINE config 5) ---------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,C,dtype,noise", [(128, 2, torch.float64, "f64"), (64, 1, torch.float64, "f64"),
+                                             (128, 2, torch.float64, "f32"), (128, 1, torch.float32, "f64")])
+def test_pcn_mfma_d64_d128_vs_oracle(eng, oracle, d, C, dtype, noise):
+    """asmc_pcn_mutate at d = 64 / 128 runs on v_mfma_f64_16x16x4_f64 (whitened state) — against the oracle's x-space
+    restatement over 3 steps: same accept decisions up to razor-edge cases, positions to 1e-9 (fp64 storage) /
+    2e-5 (fp32), carried log-probabilities equal to the densities at the stored positions."""
+    n = 1999  # ragged last group of 16
+    x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 41 + d, C=C)
+    om = [oracle.Mixture(*m) for m in mixes]
+    dm = [eng.make_mixture(*m) for m in mixes]
+    xd = torch.as_tensor(x).to(dtype).to(eng.device)
+    xr = xd.double().cpu().numpy().copy()
+    ll, lp, lq = (m.logpdf(xr) for m in om)
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    rho, beta, seed = 0.15, 0.6, 4321
+    eng.profile(True)
+    n_acc, rho_hist, _ = eng.pcn_mutate(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), dm[0],
+                                        dm[1], dm[2], seed, 50, rho, 3, 10, 0.234, False, noise)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert rep["k_pcn_mm_step"][0] == 3 and "k_pcn_step_generic" not in rep
+    llr, lpr, lqr = ll.copy(), lp.copy(), lq.copy()
+    acc_ref = [oracle.pcn_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, om[0], om[1], om[2], seed, 50, 10 + t, noise)
+               for t in range(3)]
+    got = xd.double().cpu().numpy()
+    tol = 1e-9 if (dtype == torch.float64 and noise == "f64") else 3e-5
+    close = np.all(np.abs(got - xr) <= tol * (1 + np.abs(xr)), axis=1)
+    edge = 3 if (dtype == torch.float64 and noise == "f64") else 40
+    assert (~close).sum() <= edge, (~close).sum()
+    assert np.all(np.abs(np.array(n_acc) - np.array(acc_ref)) <= edge)
+    assert 0.02 < np.mean(n_acc) / n < 0.98
+    np.testing.assert_allclose(lld.cpu().numpy(), om[0].logpdf(got), rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(lqd.cpu().numpy(), om[2].logpdf(got), rtol=1e-10, atol=1e-9)
