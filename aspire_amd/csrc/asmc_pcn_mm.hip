@@ -10,11 +10,14 @@
 // It runs on v_mfma_f64_16x16x4_f64 with the coefficient matrix as the A operand (one f64 per lane per
 // instruction, read from an LDS image packed in (row block, k-step, lane) order, zero blocks above the diagonal
 // skipped) and the particles' coordinates as the B operand.  Lane l = (p = l & 15, h = l >> 4) supplies
-// B[k = h][j = p], so it keeps the coordinates 4 s + h (s = 0..d/4-1) of particle p; the result block has column
-// p on the lane and rows h + 4 r — the SAME coordinates — so noise, mu, the densities' quadratic forms and the
-// write-back are all lane-local, and only the per-particle scalars are summed over the four lanes p + 16 h.
-// A wave steps 16 particles at a time; a block keeps the 72 KB (d = 128) operand image in LDS and loops over
-// particle groups, two blocks per CU.
+// B[k = h][j = p] and receives result rows h + 4 r of column p.  The contraction order inside a k-step and the row
+// order inside a block are free (they are folded into the operand image), so both are chosen such that lane (p, h)
+// owns the SAME coordinates of particle p on the input and on the output side, in adjacent pairs:
+//     coordinate(s, h) = 8 (s / 2) + 2 h + s % 2,   s = 0 .. d/4 - 1
+// Noise (one Philox pair = one owned pair of coordinates, no redundant draws), mu, the densities' quadratic forms
+// and the write-back are then lane-local with 16-byte accesses, and only per-particle scalars are summed over the
+// four lanes p + 16 h.  A wave steps 16 particles at a time; a block of 8 waves keeps the 72 KB (d = 128) operand
+// image and the densities' tables in LDS and loops over particle groups, one block per CU.
 #include <stdlib.h>
 
 #include "asmc_common.h"
@@ -23,6 +26,8 @@
 typedef double doublex4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int mm_ksum(int nb) { return 2 * nb * (nb + 1); }  // sum over row blocks of (4 ib + 4)
+
+__host__ __device__ constexpr int mm_coord(int s, int h) { return 8 * (s / 2) + 2 * h + (s % 2); }
 
 // pack a row-major [d x d] lower-triangular matrix into MFMA A-operand order
 __global__ __launch_bounds__(256) void k_mm_pack(int d, const double* __restrict__ M, double* __restrict__ pack) {
@@ -33,12 +38,14 @@ __global__ __launch_bounds__(256) void k_mm_pack(int d, const double* __restrict
         int ib = 0;
         while (mm_ksum(ib + 1) <= ks) ib++;
         const int s = ks - mm_ksum(ib);
-        const int i = 16 * ib + (lane & 15), k = 4 * s + (lane >> 4);
+        // A-operand lane: in-block result row rho = lane & 15 (result lane h = rho % 4, register r = rho / 4), k = lane >> 4
+        const int rho = lane & 15, kk = lane >> 4;
+        const int i = mm_coord(4 * ib + rho / 4, rho % 4), k = mm_coord(s, kk);
         pack[e] = (k <= i) ? M[(size_t)i * d + k] : 0.0;
     }
 }
 
-// out = M v for this lane's coordinates (out[4 ib + r] = coordinate 16 ib + 4 r + h).  Row blocks are taken in pairs
+// out = M v for this lane's coordinates (out[4 ib + r] = coordinate mm_coord(4 ib + r, h)).  Row blocks are taken in pairs
 // (ib, NB-1-ib): equal work per pair, and consecutive MFMAs alternate between two accumulators.
 template <int D>
 __device__ __forceinline__ void mm_trimatvec(const double* __restrict__ sA, const double (&v)[D / 4], double (&out)[D / 4],
@@ -71,20 +78,35 @@ __device__ __forceinline__ double quad_sum(double q) {  // over the four lanes p
     return q;
 }
 
-// diagonal-mixture log-density of the particle whose coordinates 4 s + h this lane holds (same formula as
-// mixture_eval in asmc_pcn.hip: log-sum-exp over the components' logw - q / 2)
+// Density tables in LDS, lane order: tab[c][s / 2][h] = {mu(s), mu(s+1), prec(s), prec(s+1)} for even s (32 bytes),
+// so a lane fetches the constants of an owned coordinate pair with two 16-byte reads.
 template <int D>
-__device__ __forceinline__ double mm_mixture(const MixDev& m, const double (&xv)[D / 4], int h) {
+__device__ __forceinline__ void mm_stage_tables(double* tab, const MixDev& m, int tid, int nthreads) {
+    const int per_c = D * 2;  // doubles per component
+    for (int e = tid; e < m.C * per_c; e += nthreads) {
+        const int c = e / per_c, w = e - c * per_c;
+        const int q = w & 3, hh = (w >> 2) & 3, sp = w >> 4;  // w = (sp * 4 + hh) * 4 + q
+        const int coord = mm_coord(2 * sp + (q & 1), hh);
+        tab[e] = (q < 2) ? m.mu[(size_t)c * D + coord] : m.prec[(size_t)c * D + coord];
+    }
+}
+
+// diagonal-mixture log-density of the particle whose coordinates this lane holds (same formula as mixture_eval in
+// asmc_pcn.hip: log-sum-exp over the components' logw - q / 2)
+template <int D>
+__device__ __forceinline__ double mm_mixture(const MixDev& m, const double* __restrict__ tab, const double (&xv)[D / 4], int h) {
     double terms[ASMC_MAX_COMPONENTS];
     double best = -INFINITY;
     for (int c = 0; c < m.C; c++) {
-        const double* mu = m.mu + (size_t)c * D + h;
-        const double* pr = m.prec + (size_t)c * D + h;
+        const double* tc = tab + (size_t)c * D * 2 + h * 4;
         double q = 0.0;
 #pragma unroll
-        for (int s = 0; s < D / 4; s++) {
-            const double t = xv[s] - mu[4 * s];
-            q = fma(t * t, pr[4 * s], q);
+        for (int sp = 0; sp < D / 8; sp++) {
+            const double2 mu2 = *reinterpret_cast<const double2*>(tc + sp * 16);
+            const double2 pr2 = *reinterpret_cast<const double2*>(tc + sp * 16 + 2);
+            const double t0 = xv[2 * sp] - mu2.x, t1 = xv[2 * sp + 1] - mu2.y;
+            q = fma(t0 * t0, pr2.x, q);
+            q = fma(t1 * t1, pr2.y, q);
         }
         q = quad_sum(q);
         terms[c] = m.logw[c] - 0.5 * q;
@@ -97,17 +119,34 @@ __device__ __forceinline__ double mm_mixture(const MixDev& m, const double (&xv)
     return best + log(sum);
 }
 
+#define MM_THREADS 512
+#define MM_WAVES (MM_THREADS / 64)
+
 template <typename T, int D, int NOISE, int MODE>
-__global__ __launch_bounds__(256, 2) void k_pcn_mm(int64_t n, T* __restrict__ x, double* __restrict__ ll,
-                                                  double* __restrict__ lp, double* __restrict__ lq,
-                                                  const double* __restrict__ pack, PcnDev p,
-                                                  const double* __restrict__ rho_ptr, uint32_t step,
-                                                  long long* __restrict__ block_counts) {
-    extern __shared__ __align__(16) double sA[];
+__global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict__ x, double* __restrict__ ll,
+                                                      double* __restrict__ lp, double* __restrict__ lq,
+                                                      const double* __restrict__ pack, PcnDev p,
+                                                      const double* __restrict__ rho_ptr, uint32_t step,
+                                                      long long* __restrict__ block_counts) {
+    extern __shared__ __align__(16) double smem[];
     constexpr int KS = D / 4;
     constexpr int TOTAL = mm_ksum(D / 16) * 64;
-    for (int e = threadIdx.x * 2; e < TOTAL; e += 256 * 2)
+    double* sA = smem;
+    double* s_mu = sA + TOTAL;                 // [D / 8][4 h][2]  reference mean in lane order
+    double* t_ll = s_mu + D;                   // density tables (MM_WHITEN does not need them)
+    double* t_lp = t_ll + (size_t)p.ll.C * D * 2;
+    double* t_lq = t_lp + (size_t)p.lp.C * D * 2;
+    for (int e = threadIdx.x * 2; e < TOTAL; e += MM_THREADS * 2)
         *reinterpret_cast<double2*>(sA + e) = *reinterpret_cast<const double2*>(pack + e);
+    for (int e = threadIdx.x; e < D; e += MM_THREADS) {
+        const int q = e & 1, hh = (e >> 1) & 3, sp = e >> 3;
+        s_mu[e] = p.mu[mm_coord(2 * sp + q, hh)];
+    }
+    if (MODE != MM_WHITEN) {
+        mm_stage_tables<D>(t_ll, p.ll, threadIdx.x, MM_THREADS);
+        mm_stage_tables<D>(t_lp, p.lp, threadIdx.x, MM_THREADS);
+        mm_stage_tables<D>(t_lq, p.lq, threadIdx.x, MM_THREADS);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pp = lane & 15, h = lane >> 4;
@@ -115,29 +154,52 @@ __global__ __launch_bounds__(256, 2) void k_pcn_mm(int64_t n, T* __restrict__ x,
     const double a = sqrt(1.0 - rho * rho);
     const int64_t n_groups = (n + 15) / 16;
     long long n_acc = 0;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < n_groups; g += (int64_t)gridDim.x * 4) {
+    struct alignas(2 * sizeof(T)) Pair {
+        T a, b;
+    };
+    for (int64_t g = (int64_t)blockIdx.x * MM_WAVES + wave; g < n_groups; g += (int64_t)gridDim.x * MM_WAVES) {
         const int64_t row = g * 16 + pp;
         const bool valid = row < n;
-        T* xr = x + row * D + h;
+        Pair* xr = reinterpret_cast<Pair*>(x + row * D + 2 * h);  // owned pairs sit 8 elements apart
         double v[KS], o[KS];
 #pragma unroll
-        for (int s = 0; s < KS; s++) v[s] = valid ? (double)xr[4 * s] : 0.0;
+        for (int sp = 0; sp < KS / 2; sp++) {
+            Pair t = {(T)0, (T)0};
+            if (valid) t = xr[sp * 4];
+            v[2 * sp] = (double)t.a;
+            v[2 * sp + 1] = (double)t.b;
+        }
+        const double* my_mu = s_mu + h * 2;  // {mu(2 sp), mu(2 sp + 1)} at my_mu[8 sp]
+        auto store_row = [&](const double (&w)[KS]) {
+#pragma unroll
+            for (int sp = 0; sp < KS / 2; sp++) {
+                Pair t;
+                t.a = (T)w[2 * sp];
+                t.b = (T)w[2 * sp + 1];
+                xr[sp * 4] = t;
+            }
+        };
         if (MODE == MM_WHITEN) {
 #pragma unroll
-            for (int s = 0; s < KS; s++) v[s] -= p.mu[4 * s + h];
-            mm_trimatvec<D>(sA, v, o, lane);
-            if (valid) {
-#pragma unroll
-                for (int s = 0; s < KS; s++) xr[4 * s] = (T)o[s];
+            for (int sp = 0; sp < KS / 2; sp++) {
+                const double2 m2 = *reinterpret_cast<const double2*>(my_mu + sp * 8);
+                v[2 * sp] -= m2.x;
+                v[2 * sp + 1] -= m2.y;
             }
+            mm_trimatvec<D>(sA, v, o, lane);
+            if (valid) store_row(o);
         } else if (MODE == MM_UNWHITEN) {
             mm_trimatvec<D>(sA, v, o, lane);
 #pragma unroll
-            for (int s = 0; s < KS; s++) o[s] = (double)(T)(p.mu[4 * s + h] + o[s]);
-            const double nll = mm_mixture<D>(p.ll, o, h), nlp = mm_mixture<D>(p.lp, o, h), nlq = mm_mixture<D>(p.lq, o, h);
+            for (int sp = 0; sp < KS / 2; sp++) {
+                const double2 m2 = *reinterpret_cast<const double2*>(my_mu + sp * 8);
+                o[2 * sp] = (double)(T)(m2.x + o[2 * sp]);
+                o[2 * sp + 1] = (double)(T)(m2.y + o[2 * sp + 1]);
+            }
+            const double nll = mm_mixture<D>(p.ll, t_ll, o, h), nlp = mm_mixture<D>(p.lp, t_lp, o, h),
+                         nlq = mm_mixture<D>(p.lq, t_lq, o, h);
             if (valid) {
-#pragma unroll
-                for (int s = 0; s < KS; s++) xr[4 * s] = (T)o[s];
+                store_row(o);
                 if (h == 0) ll[row] = nll, lp[row] = nlp, lq[row] = nlq;
             }
         } else {
@@ -147,33 +209,38 @@ __global__ __launch_bounds__(256, 2) void k_pcn_mm(int64_t n, T* __restrict__ x,
             for (int s = 0; s < KS; s++) q0 = fma(v[s], v[s], q0);
             q0 = quad_sum(q0);
 #pragma unroll
-            for (int s = 0; s < KS; s++) {
-                double z;
-                if (NOISE == ASMC_NOISE_F32) {  // coordinates 4 s .. 4 s + 3 come from Philox block s
-                    double z0, z1, z2, z3;
-                    normal_quad_f32(p.seed, gid, step, (uint32_t)s, z0, z1, z2, z3);
-                    z = h == 0 ? z0 : (h == 1 ? z1 : (h == 2 ? z2 : z3));
-                } else {  // coordinates 2 pr, 2 pr + 1 from pair pr
-                    double z0, z1;
-                    normal_pair(p.seed, gid, step, (uint32_t)(2 * s + (h >> 1)), z0, z1);
-                    z = (h & 1) ? z1 : z0;
+            for (int sp = 0; sp < KS / 2; sp++) {
+                double z0, z1;
+                if (NOISE == ASMC_NOISE_F32) {  // coordinates 4 q .. 4 q + 3 come from Philox block q: this lane owns two
+                    double w0, w1, w2, w3;
+                    normal_quad_f32(p.seed, gid, step, (uint32_t)(2 * sp + (h >> 1)), w0, w1, w2, w3);
+                    z0 = (h & 1) ? w2 : w0;
+                    z1 = (h & 1) ? w3 : w1;
+                } else {  // coordinates 2 pr, 2 pr + 1 from pair pr: exactly the owned pair
+                    normal_pair(p.seed, gid, step, (uint32_t)(4 * sp + h), z0, z1);
                 }
-                v[s] = (double)(T)fma(rho, z, a * v[s]);
-                q1 = fma(v[s], v[s], q1);
+                v[2 * sp] = (double)(T)fma(rho, z0, a * v[2 * sp]);
+                v[2 * sp + 1] = (double)(T)fma(rho, z1, a * v[2 * sp + 1]);
+                q1 = fma(v[2 * sp], v[2 * sp], q1);
+                q1 = fma(v[2 * sp + 1], v[2 * sp + 1], q1);
             }
             q1 = quad_sum(q1);
             mm_trimatvec<D>(sA, v, o, lane);
 #pragma unroll
-            for (int s = 0; s < KS; s++) o[s] = (double)(T)(p.mu[4 * s + h] + o[s]);
-            const double nll = mm_mixture<D>(p.ll, o, h), nlp = mm_mixture<D>(p.lp, o, h), nlq = mm_mixture<D>(p.lq, o, h);
+            for (int sp = 0; sp < KS / 2; sp++) {
+                const double2 m2 = *reinterpret_cast<const double2*>(my_mu + sp * 8);
+                o[2 * sp] = (double)(T)(m2.x + o[2 * sp]);
+                o[2 * sp + 1] = (double)(T)(m2.y + o[2 * sp + 1]);
+            }
+            const double nll = mm_mixture<D>(p.ll, t_ll, o, h), nlp = mm_mixture<D>(p.lp, t_lp, o, h),
+                         nlq = mm_mixture<D>(p.lq, t_lq, o, h);
             if (valid) {
                 const double lpn = log_p_t(nll, nlp, nlq, p.beta);
                 const double lpo = log_p_t(ll[row], lp[row], lq[row], p.beta);
                 const double log_a = (lpn + 0.5 * q1) - (lpo + 0.5 * q0);
                 const double u = accept_uniform(p.seed, gid, step);
                 if (log(u) < log_a) {
-#pragma unroll
-                    for (int s = 0; s < KS; s++) xr[4 * s] = (T)v[s];
+                    store_row(v);
                     if (h == 0) {
                         ll[row] = nll, lp[row] = nlp, lq[row] = nlq;
                         n_acc++;
@@ -183,11 +250,15 @@ __global__ __launch_bounds__(256, 2) void k_pcn_mm(int64_t n, T* __restrict__ x,
         }
     }
     if (MODE == MM_STEP) {
-        __shared__ long long s_cnt[4];
+        __shared__ long long s_cnt[MM_WAVES];
         n_acc = wave_sum_ll(n_acc);
         if (lane == 0) s_cnt[wave] = n_acc;
         __syncthreads();
-        if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (threadIdx.x == 0) {
+            long long t = 0;
+            for (int w = 0; w < MM_WAVES; w++) t += s_cnt[w];
+            block_counts[blockIdx.x] = t;
+        }
     }
 }
 
@@ -195,21 +266,22 @@ __global__ __launch_bounds__(256, 2) void k_pcn_mm(int64_t n, T* __restrict__ x,
 template <typename T, int D, int NOISE, int MODE>
 static int launch_mm(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const double* pack, const PcnDev& pd,
                      const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out, hipStream_t st) {
-    const size_t lds = (size_t)mm_ksum(D / 16) * 64 * sizeof(double);
+    const size_t lds = ((size_t)mm_ksum(D / 16) * 64 + D + (size_t)(pd.ll.C + pd.lp.C + pd.lq.C) * D * 2) * sizeof(double);
+    ASMC_REQUIRE(lds <= 160 * 1024 - 256, "operand image and density tables exceed the LDS");
     auto kern = k_pcn_mm<T, D, NOISE, MODE>;
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
+    static size_t attr_lds = 0;
+    if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_lds = lds;
     }
-    const int per_cu = lds > 80 * 1024 ? 1 : (lds > 40 * 1024 ? 2 : 4);
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
     const int64_t n_groups = (n + 15) / 16;
-    const int64_t want = (n_groups + 3) / 4;
+    const int64_t want = (n_groups + MM_WAVES - 1) / MM_WAVES;
     int grid = (int)(want < (int64_t)ctx->num_cu * per_cu ? want : (int64_t)ctx->num_cu * per_cu);
     if (grid > ASMC_MAX_BLOCKS) grid = ASMC_MAX_BLOCKS;
     *grid_out = grid;
     ASMC_LAUNCH(ctx, st, MODE == MM_STEP ? "k_pcn_mm_step" : MODE == MM_WHITEN ? "k_pcn_mm_whiten" : "k_pcn_mm_unwhiten", kern,
-                dim3(grid), dim3(256), lds, st, n, x, ll, lp, lq, pack, pd, rho_ptr, step, block_counts);
+                dim3(grid), dim3(MM_THREADS), lds, st, n, x, ll, lp, lq, pack, pd, rho_ptr, step, block_counts);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
