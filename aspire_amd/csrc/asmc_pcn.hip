@@ -1220,6 +1220,14 @@ int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
     const size_t elem = x_dtype == ASMC_F64 ? 8 : 4;
     const int rowbytes = (int)(d * elem);
     double* d_out = ctx->d_partials;
+    if (asmc_gram_mm_supported(d, x) && ctx->d_max >= d && !getenv("ASMC_GRAM_GENERIC")) {  // fp64 MFMA (asmc_pcn_mm.hip)
+        int grid = 0;
+        int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &grid, st);
+        if (rc) return rc;
+        ASMC_HIP(hipMemcpyAsync(gram_host, d_out, sizeof(double) * d * d, hipMemcpyDeviceToHost, st));
+        ASMC_HIP(hipStreamSynchronize(st));
+        return ASMC_OK;
+    }
     if (rowbytes % 16 == 0 && ((uintptr_t)x % 16) == 0 && d <= 128) {
         // register-blocked kernel: BLK = 4 (quadrant 32) for d <= 32, else BLK = 8 (quadrant 64)
         const int blk = d <= 32 ? 4 : 8;

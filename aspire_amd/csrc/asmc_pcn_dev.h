@@ -124,3 +124,6 @@ int asmc_pcn_mm_pack(asmc_ctx* ctx, const PcnDev& pd, hipStream_t st);
 int asmc_pcn_mm_launch(asmc_ctx* ctx, int64_t n, int x_dtype, void* x, double* ll, double* lp, double* lq, const PcnDev& pd,
                        int mode, const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
                        hipStream_t st);
+bool asmc_gram_mm_supported(int d, const void* x);
+int asmc_gram_mm_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* d_center, int* grid_out,
+                        hipStream_t st);

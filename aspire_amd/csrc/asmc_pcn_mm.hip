@@ -263,6 +263,124 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Centred Gram matrix  G = sum_i (x_i - c)(x_i - c)^T  for d = 64 / 128 on the fp64 matrix cores: the particle index is
+// the contraction index (4 particles per MFMA), both operands come from one LDS tile of 32 centred rows, and only
+// the block lower triangle is computed (wave w owns the row strips w and NB-1-w: NB + 1 blocks each, balanced).
+// Row stride D + 16 doubles: the two rows a 32-lane group reads land on disjoint banks.
+#define GRAM_TP 32
+
+template <typename T, int D>
+__global__ __launch_bounds__(64 * (D / 32)) void k_gram_mm(int64_t n, const T* __restrict__ x,
+                                                          const double* __restrict__ center,
+                                                          double* __restrict__ partials) {
+    extern __shared__ __align__(16) double tile[];
+    constexpr int NB = D / 16, NT = 64 * (D / 32), STRIDE = D + 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ia = wave, ib = NB - 1 - wave;
+    doublex4 accA[NB], accB[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) accA[j] = accB[j] = doublex4{0.0, 0.0, 0.0, 0.0};
+    // the next tile's rows are fetched into registers while the current tile is in the matrix pipe
+    constexpr int PER = GRAM_TP * D / NT;  // elements per thread and tile
+    T nxt[PER];
+    auto fetch = [&](int64_t t0) {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int e = q * NT + threadIdx.x;
+            const int r = e / D, c = e - r * D;
+            nxt[q] = (t0 + r < n) ? x[(t0 + r) * D + c] : (T)0;
+        }
+    };
+    const int64_t tstride = (int64_t)gridDim.x * GRAM_TP;
+    fetch((int64_t)blockIdx.x * GRAM_TP);
+    for (int64_t t0 = (int64_t)blockIdx.x * GRAM_TP; t0 < n; t0 += tstride) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int e = q * NT + threadIdx.x;
+            const int r = e / D, c = e - r * D;
+            tile[r * STRIDE + c] = (t0 + r < n) ? (double)nxt[q] - center[c] : 0.0;
+        }
+        __syncthreads();
+        if (t0 + tstride < n) fetch(t0 + tstride);
+#pragma unroll
+        for (int t = 0; t < GRAM_TP / 4; t++) {
+            const double* base = tile + (4 * t + (lane >> 4)) * STRIDE + (lane & 15);
+            const double aA = base[16 * ia], aB = base[16 * ib];
+#pragma unroll
+            for (int jb = 0; jb < NB; jb++) {
+                if (jb <= ib) {  // wave-uniform
+                    const double b = base[16 * jb];
+                    accB[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aB, b, accB[jb], 0, 0, 0);
+                    if (jb <= ia) accA[jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA, b, accA[jb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // block (i, j): lane holds G[16 i + (lane >> 4) + 4 r][16 j + (lane & 15)]; mirrored into the upper triangle
+    double* out = partials + (size_t)blockIdx.x * D * D;
+#pragma unroll
+    for (int jb = 0; jb < NB; jb++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int col = 16 * jb + (lane & 15);
+            if (jb <= ib) {
+                const int row = 16 * ib + (lane >> 4) + 4 * r;
+                out[(size_t)row * D + col] = accB[jb][r];
+                if (jb != ib) out[(size_t)col * D + row] = accB[jb][r];
+            }
+            if (jb <= ia && ia != ib) {
+                const int row = 16 * ia + (lane >> 4) + 4 * r;
+                out[(size_t)row * D + col] = accA[jb][r];
+                if (jb != ia) out[(size_t)col * D + row] = accA[jb][r];
+            }
+        }
+    }
+}
+
+// fixed-order sum of the per-block partial matrices, one thread per matrix entry (coalesced across entries)
+__global__ __launch_bounds__(256) void k_gram_mm_reduce(int nblocks, int ncols, const double* __restrict__ partials,
+                                                        double* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols) return;
+    double v = 0.0;
+    for (int b0 = 0; b0 < nblocks; b0 += 8) {
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) t[q] = (b0 + q < nblocks) ? partials[(size_t)(b0 + q) * ncols + col] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) v += t[q];
+    }
+    out[col] = v;
+}
+
+bool asmc_gram_mm_supported(int d, const void* x) { return (d == 64 || d == 128) && ((uintptr_t)x % 16 == 0); }
+
+// enqueues the Gram kernel and the reduction of its per-block partial matrices; the d x d result lands in ctx->d_partials
+int asmc_gram_mm_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* d_center, int* grid_out,
+                        hipStream_t st) {
+    int grid = (int)((n + GRAM_TP - 1) / GRAM_TP);
+    if (grid > ctx->gram_blocks) grid = ctx->gram_blocks;
+    *grid_out = grid;
+    const size_t lds = (size_t)GRAM_TP * (d + 16) * sizeof(double);
+#define GRAM_CASE(TT, DD) \
+    ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_mm<TT, DD>), dim3(grid), dim3(64 * (DD / 32)), lds, st, n, (const TT*)x, d_center, ctx->d_gram)
+    if (x_dtype == ASMC_F64) {
+        if (d == 128) GRAM_CASE(double, 128);
+        else GRAM_CASE(double, 64);
+    } else {
+        if (d == 128) GRAM_CASE(float, 128);
+        else GRAM_CASE(float, 64);
+    }
+#undef GRAM_CASE
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_gram_mm_reduce", k_gram_mm_reduce, dim3((d * d + 255) / 256), dim3(256), 0, st, grid, d * d,
+                (const double*)ctx->d_gram, ctx->d_partials);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 template <typename T, int D, int NOISE, int MODE>
 static int launch_mm(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const double* pack, const PcnDev& pd,
                      const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out, hipStream_t st) {
