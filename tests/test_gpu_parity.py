@@ -620,7 +620,7 @@ def test_fused_sampler_1m_d32_evidence(eng):
     assert sp.history.beta[-1] == 1.0
 
 
-def test_config5_shape_mixture_d128_generic_kernel(eng):
+def test_config5_shape_mixture_d128_mfma_kernels(eng):
     """BASELINE config 5 shape at reduced N: d=128 two-component Gaussian-mixture likelihood (the
     examples/smc_example.py construction), N(0,I) prior, q = N(0, 3^2 I); runs on the generic pCN kernel
     (d > 32) with the blocked Gram kernel; log Z is analytic (prior x normalised mixture => log Z = log of the
@@ -634,7 +634,11 @@ def test_config5_shape_mixture_d128_generic_kernel(eng):
     prior = DiagGaussianMixture.isotropic(d, 0.0, 1.0)
     sp = HipSMC(log_likelihood=lik, log_prior=prior, dims=d, prior_flow=GaussianFlow(d, sigma=3.0, engine=eng, seed=4),
                 xp=np, engine=eng, rng=np.random.default_rng(1))
+    eng.profile(True)
     out = sp.sample(n, sampler_kwargs=dict(n_steps=6), store_sample_history=False, max_n_steps=40)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert rep["k_pcn_mm_step"][0] >= 6 and rep["k_gram_mm"][0] >= 1 and "k_pcn_step_generic" not in rep
     # Z = 0.5 * N(2; 0, (1 + 0.5) I) + 0.5 * N(-2; 0, (1 + 1) I)   (Gaussian convolution), per-dim product
     def lg(mu, var):
         return -0.5 * d * np.log(2 * np.pi * var) - 0.5 * d * mu * mu / var
