@@ -302,7 +302,26 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_launch(int64_t n, 
                                                                     const double* __restrict__ approx_total,
                                                                     int64_t n_tiles, long long* __restrict__ tile_info,
                                                                     long long* __restrict__ tile_split,
-                                                                    double* __restrict__ tile_s2) {
+                                                                    double* __restrict__ tile_s2, double* __restrict__ cdf,
+                                                                    double carry_in, double* __restrict__ tile_s) {
+    if (blockIdx.x == 0) {
+        // Tile 0 enters with an EXACTLY known running sum (the carry), and it is the one tile that leaves several
+        // binades in a row (the sum grows from nothing): it is scanned element-wise right here, in parallel with the
+        // other tiles' transducers, instead of in the sequential chain.  tile_s[0] = carry, tile_s2[0] = exact sum
+        // behind the tile; flag 3 tells the chain to start behind it and the write pass to leave it alone.
+        __shared__ TD sh_td0[XT_THREADS / 64 + 1];
+        __shared__ double sh_s0;
+        __shared__ long long sh_pos0, sh_cross0;
+        const int64_t hi = ASMC_SCAN_TILE < n ? ASMC_SCAN_TILE : n;
+        const double s_out = exact_tile(w, cdf, 0, hi, carry_in, sh_td0, &sh_s0, &sh_pos0, &sh_cross0);
+        if (threadIdx.x == 0) {
+            tile_info[0] = 0, tile_info[1] = 0, tile_info[2] = 0, tile_info[3] = 3;
+            tile_split[0] = tile_split[1] = tile_split[2] = tile_split[3] = 0;
+            tile_s[0] = carry_in;
+            tile_s2[0] = s_out;
+        }
+        return;
+    }
     k_exact_tile_td_body(n, w, approx_prefix, *approx_total, n_tiles, tile_info, tile_split, tile_s2);
 }
 
@@ -329,8 +348,8 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const dou
     __shared__ long long sh_split[CHAIN_CHUNK * 4];
     __shared__ double sh_wc[CHAIN_CHUNK];  // weight of the predicted crossing element (pass C leaves it in tile_s2)
     int64_t chunk0 = -CHAIN_CHUNK;
-    int64_t t = 0;
-    double s = carry_in;
+    int64_t t = 1;            // tile 0 has been scanned exactly by pass C
+    double s = tile_s2[0];    // exact running sum behind tile 0
     while (t < n_tiles) {
         if (t + 64 > chunk0 + CHAIN_CHUNK || t < chunk0) {  // uniform: (re)stage so that tiles [t, t+64) are resident
             __syncthreads();
@@ -971,7 +990,7 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_exact_tile_td_launch", k_exact_tile_td_launch, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w,
                            (const double*)ctx->d_tiles, (const double*)d_approx_total, n_tiles, ctx->d_tiles_i, d_split,
-                           d_tile_s2);
+                           d_tile_s2, cdf, carry_in, d_tile_s);
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_exact_chain", k_exact_chain, dim3(1), dim3(XT_THREADS), 0, st, n, w, cdf, carry_in, n_tiles,
                            ctx->d_tiles_i, (const long long*)d_split, d_tile_s, d_tile_s2, d_total);
