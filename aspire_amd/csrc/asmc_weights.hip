@@ -338,86 +338,108 @@ __device__ __forceinline__ double ess_over_n(double m, double S1, double S2, dou
     return exp(l1 * 2.0 - l2) / N;
 }
 
+struct BisInit {
+    double beta0, target, tol, logN, N;
+};
+
 // Closes a bisection round: fixed-order reduction of the block partials, ESS of every candidate (one lane
-// each), the walk down the 4-level decision tree, and the candidates of the next round.  Runs in the LAST block
-// of the round's reduction kernel (k_bis_sums) or, for round 0, as its own launch.
-//   phase 0: the single candidate beta = 1 (smc/base.py:170-175), exact maximum from the max kernel (keys[0])
-//   phase 1: the 15 heap-ordered midpoints.  Their stabilising maxima are not searched for: at beta >= beta0
-//   every log-weight is (beta - beta0) * Delta_i up to rounding, so max_i lw_i(beta) = m(1) (beta - beta0)/(1 - beta0)
-//   to rounding as well, and the log-sum-exp only needs a shift near the maximum, not the maximum itself.
+// each), the walk down the 4-level decision tree, and the candidates of the next round.  Runs in the LAST block of
+// the round's reduction kernel (k_bis_sums).
+//   first round: the 15 heap-ordered midpoints of [beta0, 1] AND beta = 1 itself (16th column; smc/base.py:170-175:
+//   eff(1) >= target ends the search at beta* = 1); this round also creates the state record.
+//   Stabilising maxima are not searched for: at beta >= beta0 every log-weight is (beta - beta0) * Delta_i up to
+//   rounding, so max_i lw_i(beta) = m(1) (beta - beta0)/(1 - beta0) to rounding as well (m(1): exact, from the max
+//   kernel), and a log-sum-exp only needs a shift near the maximum, not the maximum itself.
 // State st[]: [0] beta_min [1] beta_max [2] done [3] target_eff [4] tol [5] log N [6] rounds [7] beta0 [8] N
 //   [9] ESS(1)/N [10] m(1) [11..13] (m, S1, S2) at beta_min [14] 1 when [11..13] are valid [16..30] midpoints
 //   [32] S1(1) [33] S2(1)  [34..38] next round's grid: c1, c2, m of the LOWEST candidate, spacing h, Delta_max
 __device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
-                                              const double* __restrict__ partials, int nblocks, int phase,
-                                              const unsigned long long* __restrict__ keys, double (*s_red)[33],
+                                              const double* __restrict__ partials, int nblocks, bool first,
+                                              double m_one_in, const BisInit& init, double (*s_red)[33],
                                               double* s_S, double* s_eff) {
     // the state record and the candidates' shifts are staged in LDS: thread 0's decision chain below must not pay a
     // global-memory latency per dependent access
     __shared__ double s_st[40];
     __shared__ double s_bp[4][16];  // c1, c2, m, shift of the candidates (in: m of this round; out: next round)
-    const int ncols = phase == 0 ? 2 : 32;
     const int col = threadIdx.x & 31, part = threadIdx.x >> 5, nparts = blockDim.x >> 5;
-    if (threadIdx.x < 40) s_st[threadIdx.x] = st[threadIdx.x];
-    if (threadIdx.x >= 64 && threadIdx.x < 80) s_bp[2][threadIdx.x - 64] = phase == 0 ? 0.0 : bp->m[threadIdx.x - 64];
-    if (phase == 0) {
-        // two columns only: spread the records over every thread (lane parity = column), reduce inside the wave with
-        // parity-preserving butterflies, then across the waves — a 16-thread sequential sum here cost 20 us
-        const int c2 = threadIdx.x & 1;
-        double v = 0.0;
-        for (int b = threadIdx.x >> 1; b < nblocks; b += blockDim.x >> 1) v += partials[(size_t)b * 2 + c2];
-#pragma unroll
-        for (int o = 32; o >= 2; o >>= 1) v += __shfl_xor(v, o, 64);
-        if ((threadIdx.x & 63) < 2) s_red[threadIdx.x >> 6][c2] = v;
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            double t = 0.0;
-            if (threadIdx.x < 2)
-                for (int q = 0; q < (int)(blockDim.x >> 6); q++) t += s_red[q][threadIdx.x];
-            s_S[threadIdx.x] = t;
-        }
-    } else {
-        double v = 0.0;
-        for (int b0 = part; b0 < nblocks; b0 += 8 * nparts) {  // eight records in flight per thread, fixed order
-            double t8[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int b = b0 + q * nparts;
-                t8[q] = b < nblocks ? partials[(size_t)b * ncols + col] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; q++) v += t8[q];
-        }
-        s_red[part][col] = v;
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            double t = 0.0;
-            for (int q = 0; q < nparts; q++) t += s_red[q][threadIdx.x];
-            s_S[threadIdx.x] = t;
-        }
+    if (threadIdx.x < 40) {
+        const int i = threadIdx.x;
+        s_st[i] = !first ? st[i]
+                         : (i == 0 ? init.beta0 : i == 1 ? 1.0 : i == 3 ? init.target : i == 4 ? init.tol : i == 5 ? init.logN
+                            : i == 7 ? init.beta0 : i == 8 ? init.N : i == 10 ? m_one_in : 0.0);
     }
+    if (!first && threadIdx.x >= 64 && threadIdx.x < 80) s_bp[2][threadIdx.x - 64] = bp->m[threadIdx.x - 64];
+    double v = 0.0;
+    for (int b0 = part; b0 < nblocks; b0 += 8 * nparts) {  // eight records in flight per thread, fixed order
+        double t8[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int b = b0 + q * nparts;
+            t8[q] = b < nblocks ? partials[(size_t)b * 32 + col] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) v += t8[q];
+    }
+    s_red[part][col] = v;
     __syncthreads();
-    const double logN = s_st[5], N = s_st[8], target = s_st[3], tol = s_st[4], beta0 = s_st[7];
-    const double m_one = phase == 0 ? key_to_f64(keys[0]) : s_st[10];
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+        for (int q = 0; q < nparts; q++) t += s_red[q][threadIdx.x];
+        s_S[threadIdx.x] = t;
+    }
+    const double logN = s_st[5], N = s_st[8], target = s_st[3], tol = s_st[4], beta0 = s_st[7], m_one = s_st[10];
+    const double inv = 1.0 / (1.0 - beta0);
+    // heap-ordered midpoints of the next four levels from (lo, hi), exactly the values the sequential loop visits
+    auto build = [&](double lo0, double hi0) {
+        double los[BIS_NODES], his[BIS_NODES];
+        los[0] = lo0;
+        his[0] = hi0;
+        for (int i = 0; i < BIS_NODES; i++) {
+            const double mid = 0.5 * (his[i] + los[i]);  // the reference's expression (smc/base.py:178)
+            s_st[16 + i] = mid;
+            const int l = 2 * i + 1, r = 2 * i + 2;
+            if (r < BIS_NODES) {
+                los[l] = los[i];
+                his[l] = mid;
+                los[r] = mid;
+                his[r] = his[i];
+            }
+            s_bp[0][i] = beta0 - mid;
+            s_bp[1][i] = mid - beta0;
+            s_bp[2][i] = m_one * ((mid - beta0) * inv);
+            s_bp[3][i] = 0.0;
+        }
+        s_bp[0][15] = beta0 - hi0;  // 16th column: the upper end of the bracket (beta = 1 in the first round)
+        s_bp[1][15] = hi0 - beta0;
+        s_bp[2][15] = m_one * ((hi0 - beta0) * inv);
+        s_bp[3][15] = 0.0;
+        s_st[34] = s_bp[0][7];  // heap node 7 = leftmost leaf = lowest candidate
+        s_st[35] = s_bp[1][7];
+        s_st[36] = s_bp[2][7];
+        s_st[37] = (hi0 - lo0) / 16.0;
+        s_st[38] = m_one * inv;
+    };
+    if (first && threadIdx.x == 0) build(beta0, 1.0);  // what this round's reduction kernel evaluated
+    __syncthreads();
     if (threadIdx.x < 16) {
         const int k = threadIdx.x;
-        const double m = phase == 0 ? m_one : s_bp[2][k];
-        s_eff[k] = (phase == 0 && k > 0) ? 0.0 : ess_over_n(m, s_S[2 * k], s_S[2 * k + 1], logN, N);
+        s_eff[k] = ess_over_n(s_bp[2][k], s_S[2 * k], s_S[2 * k + 1], logN, N);
     }
     __syncthreads();
-    bool write_bp = false;
     if (threadIdx.x == 0) {
         s_st[6] += 1.0;
         double bmin = s_st[0], bmax = s_st[1];
-        if (phase == 0) {
-            s_st[9] = s_eff[0];
-            s_st[10] = m_one;
-            s_st[32] = s_S[0], s_st[33] = s_S[1];
-            if (s_eff[0] >= target) {  // smc/base.py:174-175
+        bool at_one = false;
+        if (first) {
+            s_st[9] = s_eff[15];
+            s_st[32] = s_S[30], s_st[33] = s_S[31];
+            if (s_eff[15] >= target) {  // smc/base.py:174-175
                 bmin = 1.0;
-                s_st[11] = m_one, s_st[12] = s_S[0], s_st[13] = s_S[1], s_st[14] = 1.0;
+                at_one = true;
+                s_st[11] = m_one, s_st[12] = s_S[30], s_st[13] = s_S[31], s_st[14] = 1.0;
             }
-        } else {
+        }
+        if (!at_one) {
             int i = 0;
             for (int lev = 0; lev < BIS_LEVELS; lev++) {
                 if (!(bmax - bmin > tol)) break;
@@ -437,37 +459,12 @@ __device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<
         if (!(bmax - bmin > tol)) {  // converged (or eff(1.0) >= target made beta_min = 1)
             s_st[2] = 1.0;
         } else {
-            // next round: heap-ordered midpoints of the next four levels, exactly the values the sequential loop visits
-            double los[BIS_NODES], his[BIS_NODES];
-            los[0] = bmin;
-            his[0] = bmax;
-            const double inv = 1.0 / (1.0 - beta0);
-            for (int i = 0; i < BIS_NODES; i++) {
-                const double mid = 0.5 * (his[i] + los[i]);  // the reference's expression (smc/base.py:178)
-                s_st[16 + i] = mid;
-                const int l = 2 * i + 1, r = 2 * i + 2;
-                if (r < BIS_NODES) {
-                    los[l] = los[i];
-                    his[l] = mid;
-                    los[r] = mid;
-                    his[r] = his[i];
-                }
-                s_bp[0][i] = beta0 - mid;
-                s_bp[1][i] = mid - beta0;
-                s_bp[2][i] = m_one * ((mid - beta0) * inv);
-                s_bp[3][i] = 0.0;
-            }
-            for (int f = 0; f < 4; f++) s_bp[f][15] = s_bp[f][14];
-            s_st[34] = s_bp[0][7];  // heap node 7 = leftmost leaf = lowest candidate
-            s_st[35] = s_bp[1][7];
-            s_st[36] = s_bp[2][7];
-            s_st[37] = (bmax - bmin) / 16.0;
-            s_st[38] = m_one * inv;
+            build(bmin, bmax);
             s_st[39] = 1.0;  // marks that the candidate pack below is to be written
         }
     }
     __syncthreads();
-    write_bp = s_st[39] != 0.0;
+    const bool write_bp = s_st[39] != 0.0;
     if (threadIdx.x < 39) st[threadIdx.x] = s_st[threadIdx.x];
     if (write_bp && threadIdx.x >= 64 && threadIdx.x < 128) {
         const int f = (threadIdx.x - 64) >> 4, k = (threadIdx.x - 64) & 15;
@@ -476,54 +473,44 @@ __device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<
     }
 }
 
-struct BisInit {
-    double beta0, target, tol, logN, N;
-};
-
-__global__ __launch_bounds__(ASMC_BLOCK) void k_bis_tail(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
-                                                        const double* __restrict__ partials, int nblocks, int phase,
-                                                        const unsigned long long* __restrict__ keys, BisInit init) {
-    __shared__ double s_red[ASMC_BLOCK / 32][33];
-    __shared__ double s_S[32];
-    __shared__ double s_eff[16];
-    if (phase == 0) {  // round 0 also creates the state record (no host-to-device copy, no host sync before the search)
-        if (threadIdx.x < 40) {
-            const int i = threadIdx.x;
-            st[i] = i == 0 ? init.beta0 : i == 1 ? 1.0 : i == 3 ? init.target : i == 4 ? init.tol : i == 5 ? init.logN
-                    : i == 7 ? init.beta0 : i == 8 ? init.N : 0.0;
-        }
-        __syncthreads();
-    }
-    if (st[2] != 0.0) return;  // converged in an earlier round (uniform)
-    bis_tail_body(st, bp, partials, nblocks, phase, keys, s_red, s_S, s_eff);
-}
-
-// One bisection round in ONE launch.  The 15 candidates are equally spaced, beta_j = beta_1 + (j-1) h, and every
-// log-sum-exp is shifted by m_j = (beta_j - beta0) Delta_max, so for particle i
+// One bisection round in ONE launch.  The 15 candidates and the bracket's upper end are equally spaced,
+// beta_j = beta_1 + (j-1) h (j = 1..16), and every log-sum-exp is shifted by m_j = (beta_j - beta0) Delta_max, so for
+// particle i
 //     exp(lw_i(beta_j) - m_j) = exp(lw_i(beta_1) - m_1) * r_i^(j-1),   r_i = exp(h (Delta_i - Delta_max)) <= 1:
-// two exponentials per particle instead of fifteen.  The first factor uses the reference's own expression for the
+// two exponentials per particle instead of sixteen.  The first factor uses the reference's own expression for the
 // log-weight (samples.py:1222-1224); the progression is non-increasing in j, so it can neither overflow nor lose
-// a term that matters.  Relative deviation from fifteen direct exponentials: ~1e-14 (it decides `eff >= target`
+// a term that matters.  Relative deviation from direct exponentials: ~1e-14 (it decides `eff >= target`
 // comparisons only; the values reported at the chosen beta carry the same 1e-14).
 // The block that arrives last (ticket counter behind an agent-scope release) reduces the partials and runs the
-// tail, so a round costs one launch.
+// tail, so a round costs one launch; the first round derives its grid from m(1) (max kernel) itself.
 #define BIS_THREADS 512  // one block per CU: few, large partial records keep the last block's reduction short
 
 __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const double* __restrict__ ll,
                                                         const double* __restrict__ lp, const double* __restrict__ lq,
                                                         double* __restrict__ st, BetaPack<16>* __restrict__ bp,
-                                                        double* partials, unsigned int* ticket, int round) {
+                                                        double* partials, unsigned int* ticket, int round, BisInit init,
+                                                        const unsigned long long* __restrict__ keys) {
     __shared__ double s_red[BIS_THREADS / 32][33];
     __shared__ double s_S[32];
     __shared__ double s_eff[16];
     __shared__ int s_last;
-    if (st[2] != 0.0) return;  // converged in an earlier round (uniform across the grid)
-    const double c1 = st[34], c2 = st[35], m1 = st[36], h = st[37], dmax = st[38];
-    double s1[15], s2[15];
+    double c1, c2, m1, h, dmax, m_one = 0.0;
+    if (round == 0) {
+        m_one = key_to_f64(keys[0]);
+        const double lo = init.beta0;
+        double b1 = 1.0;
+        for (int lev = 0; lev < BIS_LEVELS; lev++) b1 = 0.5 * (b1 + lo);  // leftmost leaf of the first tree
+        const double inv = 1.0 / (1.0 - lo);
+        c1 = lo - b1, c2 = b1 - lo, m1 = m_one * ((b1 - lo) * inv), h = (1.0 - lo) / 16.0, dmax = m_one * inv;
+    } else {
+        if (st[2] != 0.0) return;  // converged in an earlier round (uniform across the grid)
+        c1 = st[34], c2 = st[35], m1 = st[36], h = st[37], dmax = st[38];
+    }
+    double s1[16], s2[16];
 #pragma unroll
-    for (int j = 0; j < 15; j++) s1[j] = 0.0, s2[j] = 0.0;
+    for (int j = 0; j < 16; j++) s1[j] = 0.0, s2[j] = 0.0;
     const int64_t stride = (int64_t)gridDim.x * BIS_THREADS;
-    // two particles per trip: six loads in flight before the first exponential (the loop is latency bound otherwise)
+    // two particles per trip: six loads in flight before the first exponential
     for (int64_t i = (int64_t)blockIdx.x * BIS_THREADS + threadIdx.x; i < n; i += 2 * stride) {
         const int64_t i2 = i + stride;
         const bool has2 = i2 < n;
@@ -534,7 +521,7 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const doubl
         double e2 = has2 ? exp(lw_of(a2, b2, q2, c1, c2) - m1) : 0.0;
         const double r2 = has2 ? exp(h * (((a2 + b2) - q2) - dmax)) : 0.0;
 #pragma unroll
-        for (int j = 0; j < 15; j++) {
+        for (int j = 0; j < 16; j++) {
             s1[j] += e;
             s2[j] += e * e;
             e *= r;
@@ -545,17 +532,16 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const doubl
     }
     __shared__ double s_p[BIS_THREADS / 64][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // wave-level reduction of the 30 accumulators as a butterfly reduce-scatter: at distance o a lane keeps one
+    // wave-level reduction of the 32 accumulators as a butterfly reduce-scatter: at distance o a lane keeps one
     // half of its values and trades the other half with its partner, so 16+8+4+2+1+1 = 32 values cross lanes
-    // instead of 30 x 6 (the cross-lane permutes run on the LDS pipe, which 8 waves per CU share; the plain
+    // instead of 32 x 6 (the cross-lane permutes run on the LDS pipe, which 8 waves per CU share; the plain
     // per-value butterflies cost more than the two exponentials per particle).  vals[c] = column c of the
-    // partial record (2 * heap index + {0: S1, 1: S2}); lane l ends up with the wave total of column l >> 1.
-    constexpr int HEAP_OF_SORTED[15] = {7, 3, 8, 1, 9, 4, 10, 0, 11, 5, 12, 2, 13, 6, 14};  // in-order -> heap index
+    // partial record (2 * heap index + {0: S1, 1: S2}; heap index 15 = the bracket's upper end); lane l ends up with
+    // the wave total of column l >> 1.
+    constexpr int HEAP_OF_SORTED[16] = {7, 3, 8, 1, 9, 4, 10, 0, 11, 5, 12, 2, 13, 6, 14, 15};  // in-order -> heap index
     double vals[32];
 #pragma unroll
-    for (int c = 0; c < 32; c++) vals[c] = 0.0;
-#pragma unroll
-    for (int j = 0; j < 15; j++) {
+    for (int j = 0; j < 16; j++) {
         vals[2 * HEAP_OF_SORTED[j]] = s1[j];
         vals[2 * HEAP_OF_SORTED[j] + 1] = s2[j];
     }
@@ -577,7 +563,6 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const doubl
         for (int w = 1; w < BIS_THREADS / 64; w++) v += s_p[w][threadIdx.x];
         partials[(size_t)blockIdx.x * 32 + threadIdx.x] = v;
     }
-    if (!ticket) return;  // the tail runs as its own launch
     // In-launch hand-off to the last-arriving block (cdna_hip_programming.md Guideline 16, counter form): the storing
     // wave drains its stores, the block meets, ONE lane releases at agent scope and draws a ticket.  The counter is
     // zeroed once per search by a memset on the stream and only ever grows: round r ends at ticket (r+1) * grid - 1.
@@ -595,7 +580,7 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const doubl
     }
     __syncthreads();
     if (!s_last) return;
-    bis_tail_body(st, bp, partials, (int)gridDim.x, 1, nullptr, s_red, s_S, s_eff);
+    bis_tail_body(st, bp, partials, (int)gridDim.x, round == 0, m_one, init, s_red, s_S, s_eff);
 }
 
 extern "C" {
@@ -673,38 +658,31 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
     BetaPack<16>* d_bp = reinterpret_cast<BetaPack<16>*>(ctx->d_small + 2560 + 64);
     double* h = ctx->h_pinned + 4096 + 512;
     const BisInit init = {beta0, target_eff, tol, log((double)n), (double)n};
-    // round 0: beta = 1 with its exact maximum (also the NaN census: for beta > beta0 the NaN pattern of the
-    // log-weights does not depend on beta)
+    // exact maximum at beta = 1 (also the NaN census: for beta > beta0 the NaN pattern of the log-weights does not
+    // depend on beta); every round, the first one included (it evaluates beta = 1 as its 16th candidate), is then ONE launch
     const double one = 1.0;
     rc = launch_max(ctx, n, ll, lp, lq, beta0, &one, 1, st);
     if (rc) return rc;
-    int grid1 = 0;
-    rc = launch_sums(ctx, n, ll, lp, lq, beta0, &one, nullptr, nullptr, 1, true, &grid1, st);
-    if (rc) return rc;
-    ASMC_LAUNCH(ctx, st, "k_bis_tail", k_bis_tail, dim3(1), dim3(ASMC_BLOCK), 0, st, d_st, d_bp, (const double*)ctx->d_partials, grid1, 0,
-                (const unsigned long long*)ctx->d_keys, init);
-    ASMC_LAUNCH_CHECK();
-    static const int bis_mult = getenv("ASMC_BIS_MULT") ? atoi(getenv("ASMC_BIS_MULT")) : 1;
-    const int grid = grid_for(n, BIS_THREADS, ctx->num_cu * bis_mult);
+    const int grid = grid_for(n, BIS_THREADS, ctx->num_cu);
     unsigned int* d_ticket = reinterpret_cast<unsigned int*>(ctx->d_keys + ASMC_MAX_BETAS + 4);  // zeroed by launch_max
-    // every round narrows the bracket 16x: ceil(log16((1 - beta0) / tol)) rounds reach the tolerance; one spare
-    // round (it exits at once when the flag is already set) covers rounding in that estimate
-    const int rounds = (int)ceil(log2((1.0 - beta0) / tol) / BIS_LEVELS - 1e-9) + 1;
-    for (int round = 0; round < rounds; round++) {
-        static const bool split = getenv("ASMC_BIS_SPLIT") != nullptr;
-        ASMC_LAUNCH(ctx, st, "k_bis_sums", k_bis_sums, dim3(grid), dim3(BIS_THREADS), 0, st, n, ll, lp, lq, d_st, d_bp, ctx->d_partials,
-                    split ? (unsigned int*)nullptr : d_ticket, round);
-        ASMC_LAUNCH_CHECK();
-        if (split) {
-            ASMC_LAUNCH(ctx, st, "k_bis_tail", k_bis_tail, dim3(1), dim3(ASMC_BLOCK), 0, st, d_st, d_bp, (const double*)ctx->d_partials, grid, 1,
-                        (const unsigned long long*)ctx->d_keys, init);
+    // every round narrows the bracket 16x: ceil(log16((1 - beta0) / tol)) rounds reach the tolerance.  Should
+    // rounding in that estimate leave the bracket a hair too wide, further rounds are launched one at a time.
+    int rounds = (int)ceil(log2((1.0 - beta0) / tol) / BIS_LEVELS - 1e-9);
+    if (rounds < 1) rounds = 1;
+    unsigned long long* hk = reinterpret_cast<unsigned long long*>(h + 40);
+    int launched = 0;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        for (; launched < rounds; launched++) {
+            ASMC_LAUNCH(ctx, st, "k_bis_sums", k_bis_sums, dim3(grid), dim3(BIS_THREADS), 0, st, n, ll, lp, lq, d_st, d_bp, ctx->d_partials,
+                        d_ticket, launched, init, (const unsigned long long*)ctx->d_keys);
             ASMC_LAUNCH_CHECK();
         }
+        ASMC_HIP(hipMemcpyAsync(h, d_st, sizeof(double) * 40, hipMemcpyDeviceToHost, st));
+        ASMC_HIP(hipMemcpyAsync(hk, ctx->d_keys + ASMC_MAX_BETAS, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        ASMC_HIP(hipStreamSynchronize(st));
+        if (h[2] != 0.0) break;  // converged
+        rounds++;
     }
-    ASMC_HIP(hipMemcpyAsync(h, d_st, sizeof(double) * 40, hipMemcpyDeviceToHost, st));
-    unsigned long long* hk = reinterpret_cast<unsigned long long*>(h + 40);
-    ASMC_HIP(hipMemcpyAsync(hk, ctx->d_keys + ASMC_MAX_BETAS, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    ASMC_HIP(hipStreamSynchronize(st));
     out_host[0] = h[0];               // beta_min = beta*
     out_host[1] = h[1];               // beta_max
     out_host[2] = h[2];               // converged flag
