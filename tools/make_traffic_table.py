@@ -28,7 +28,7 @@ def parse(path):
 n, d = 1_000_000, 32
 alg = {"k_bis_sums": 24 * n, "k_weights_max<1>": 24 * n, "k_weights_sums<1>": 24 * n, "k_weights_m2_lse": 24 * n,
        "k_weights_map<1>": 32 * n, "k_tile_sum": 8 * n, "k_exact_tile_td_launch": 8 * n, "k_exact_tile_write": 16 * n,
-       "k_divide_dev": 16 * n, "k_pcg64_uniforms": 8 * n, "k_search": 24 * n, "k_gather16": (2 * (d * 8 + 24) + 8) * n,
+       "k_divide_dev": 16 * n, "k_pcg64_uniforms": 8 * n, "k_search": 24 * n, "k_gather16": (2 * (d * 8 + 24) + 8) * n, "k_search_guided": 24 * n, "k_guide_build": 8 * n,
        "k_pcn_reg<double, 32, 1, 1>": (2 * d * 8 + 16) * n, "k_pcn_reg_flow<double, 32, 1, 0>": (2 * d * 8 + 16) * n,
        "k_pcn_reg_flow<double, 32, 1, 1>": (2 * d * 8 + 48) * n, "k_coupling_logprob<16, 64, double, 512, 2>": (d * 8 + 8) * n}
 rows = []
@@ -59,6 +59,7 @@ for kind, name, fb, wb, ab in rows:
     if kind != "bench":
         continue
     base = name.split("(")[0]
+    base = re.sub(r"_pow2<\d+>$", "", base)  # bench.py labels every gather variant k_gather16
     base = re.sub(r"<\d+>$", "<KT>", base) if base.startswith("k_weights_max") or base.startswith("k_weights_sums") else base
     # random row gather / binary search: the raw counter already matches the bytes those kernels can physically
     # touch (x2 would exceed them), so they are taken raw; streaming kernels are doubled
