@@ -120,7 +120,9 @@ class Aspire:
 
     def get_sampler_class(self, sampler_type: str) -> Callable:
         """aspire.py:272-305."""
-        if sampler_type in ["smc", "minipcn_smc"]:
+        if sampler_type == "importance":
+            from .samplers.importance import ImportanceSampler as SamplerClass
+        elif sampler_type in ["smc", "minipcn_smc"]:
             from .samplers.smc import HipSMC as SamplerClass
         else:
             from importlib.metadata import entry_points

@@ -978,3 +978,22 @@ def test_pcn_mfma_d64_d128_vs_oracle(eng, oracle, d, C, dtype, noise):
     assert 0.02 < np.mean(n_acc) / n < 0.98
     np.testing.assert_allclose(lld.cpu().numpy(), om[0].logpdf(got), rtol=1e-10, atol=1e-9)
     np.testing.assert_allclose(lqd.cpu().numpy(), om[2].logpdf(got), rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_importance_sampler_default_path_gpu(eng):
+    """`sample_posterior()` with the reference's default sampler ("importance") on the device: evidence of the
+    Gaussian product within its own error bar, weights consistent with the returned log-probabilities."""
+    from aspire_amd import Aspire
+    from aspire_amd.flows import GaussianFlow
+    from aspire_amd.targets import DiagGaussianMixture
+
+    d, n = 8, 200000
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    asp = Aspire(log_likelihood=lik, log_prior=lik, dims=d, xp=np, flow=GaussianFlow(d, sigma=1.2, engine=eng, seed=9))
+    out = asp.sample_posterior(n, engine=eng)  # sampler defaults to "importance" (aspire.py:383-395)
+    true = 0.5 * d * math.log(math.pi)
+    assert abs(float(out.log_evidence) - true) < 5 * float(out.log_evidence_error) + 1e-3
+    lw = np.asarray(out.log_likelihood) + np.asarray(out.log_prior) - np.asarray(out.log_q)
+    np.testing.assert_allclose(np.asarray(out.log_w), lw, rtol=1e-13, atol=1e-12)
+    assert 0 < float(out.effective_sample_size) <= n
