@@ -133,6 +133,57 @@ class BaseSamples:
             out["samples"] = samples
         return out
 
+    @classmethod
+    def from_dict(cls, dictionary):
+        """samples.py:181-207: flat ({parameter: column, ...}) or nested ({"samples": {...}}) dictionaries."""
+        dictionary = dict(dictionary)
+        if "samples" in dictionary:
+            samples = dictionary.pop("samples")
+            parameters = dictionary.pop("parameters")
+            if parameters is None:
+                parameters = sorted(samples.keys())
+            x = np.stack([np.asarray(samples[p]) for p in parameters], axis=-1)
+        else:
+            parameters = dictionary.pop("parameters")
+            if parameters is None:
+                raise ValueError("Parameters must be provided if samples are not nested in a 'samples' key")
+            x = np.stack([np.asarray(dictionary[p]) for p in parameters], axis=-1)
+            for p in parameters:
+                dictionary.pop(p, None)
+        known = {f.name for f in fields(cls) if f.init}
+        return cls(x=x, parameters=parameters, **{k: v for k, v in dictionary.items() if k in known})
+
+    def to_dataframe(self, include: list | None = None):
+        """samples.py:209-243: parameters as columns plus log_likelihood / log_prior / log_q (NaN when missing)."""
+        import pandas as pd
+
+        data = dict(zip(self.parameters, to_numpy(self.x).T))
+        for key in (["log_likelihood", "log_prior", "log_q"] if include is None else include):
+            v = getattr(self, key)
+            data[key] = to_numpy(v) if v is not None else np.full(len(self.x), np.nan)
+        return pd.DataFrame(data)
+
+    def __getstate__(self):
+        """Pickle as host arrays; device handles (engine, communicator, memoised reductions) are dropped."""
+        state = dict(self.__dict__)
+        for k in ("engine", "comm", "_wstats", "_ws1p"):
+            state.pop(k, None)
+        for k, v in list(state.items()):
+            if is_torch(v):
+                state[k] = to_numpy(v) if not is_torch_namespace(self.xp) else v.detach().cpu()
+        if state.get("xp") is not None:
+            state["xp"] = state["xp"].__name__  # modules do not pickle: the namespace travels by name
+        return state
+
+    def __setstate__(self, state):
+        import importlib
+
+        if isinstance(state.get("xp"), str):
+            state["xp"] = importlib.import_module(state["xp"])
+        self.__dict__.update(state)
+        self.__dict__.setdefault("engine", None)
+        self.__dict__.setdefault("comm", None)
+
     def __str__(self):
         return f"No. samples: {len(self.x)}\nNo. parameters: {self.x.shape[-1]}\n"
 
@@ -233,6 +284,17 @@ class Samples(BaseSamples):
     def scaled_weights(self):
         xp = torch if is_torch_namespace(self.xp) else np
         return xp.exp(self.log_w - self.log_w.max())
+
+    def rejection_sample(self, rng=None):
+        """samples.py:481-494: keep sample i with probability w_i / max w (returns x, log_likelihood, log_prior)."""
+        if rng is None:
+            rng = np.random.default_rng()
+        log_u = np.log(rng.uniform(size=len(self.x)))
+        log_w = to_numpy(self.log_w)
+        accept = (log_w - log_w.max()) > log_u
+        idx = accept if not is_torch(self.x) else torch.as_tensor(accept, device=self.x.device)
+        return self.__class__(x=self.x[idx], log_likelihood=self.log_likelihood[idx], log_prior=self.log_prior[idx],
+                              dtype=self.dtype, parameters=self.parameters, xp=self.xp)
 
     def __str__(self):
         out = super().__str__()
