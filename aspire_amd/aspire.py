@@ -89,17 +89,29 @@ class Aspire:
         "zuko" is accepted when zuko is importable and otherwise maps to "coupling" with a warning
         (zuko is not part of this image)."""
         backend = self.flow_backend.lower()
+        # aspire.py:182-191: the flow works behind a FlowTransform.  The built-in flows standardise internally (CouplingFlow
+        # loc/scale, GaussianFlow moments), so the transform is only materialised when it does more than an affine map:
+        # finite prior bounds with bounded_to_unbounded.  Without it the fused device paths (log q inside the pCN kernels)
+        # stay available.
+        data_transform = None
         if self.prior_bounds is not None and self.bounded_to_unbounded:
-            raise NotImplementedError("bounded-to-unbounded flow transforms are a 'next' row (SURVEY.md §8f)")
+            from .transforms import FlowTransform
+
+            params = self.parameters if self.parameters is not None else [f"x_{i}" for i in range(self.dims)]
+            data_transform = FlowTransform(parameters=params, prior_bounds=self.prior_bounds,
+                                           bounded_to_unbounded=True, bounded_transform=self.bounded_transform,
+                                           device=self.device, xp=self.xp, eps=self.eps, dtype=self.dtype)
+            if data_transform.is_identity or not data_transform._kind.any():
+                data_transform = None  # all bounds infinite: nothing beyond the internal standardisation
         if backend == "zuko":
             logger.warning("flow_backend='zuko' is not available here; using the built-in coupling flow")
             backend = "coupling"
         if backend == "coupling":
             kw = dict(self.flow_kwargs)
-            self._flow = CouplingFlow(dims=self.dims, device=self.device or "cpu",
+            self._flow = CouplingFlow(dims=self.dims, device=self.device or "cpu", data_transform=data_transform,
                                       dtype=kw.pop("flow_dtype", torch.float32), **kw)
         elif backend == "gaussian":
-            self._flow = GaussianFlow(dims=self.dims, **self.flow_kwargs)
+            self._flow = GaussianFlow(dims=self.dims, data_transform=data_transform, **self.flow_kwargs)
         else:
             raise ValueError(f"Unknown flow backend: {self.flow_backend}")
 

@@ -29,7 +29,23 @@ class Flow:
     def __init__(self, dims: int, device=None, data_transform=None):
         self.dims = dims
         self.device = device
-        self.data_transform = data_transform
+        self.data_transform = data_transform  # None = identity (flows/base.py:36-40)
+
+    # flows/base.py:54-61 — the flow lives in the data transform's space
+    def _has_transform(self) -> bool:
+        t = self.data_transform
+        return t is not None and not getattr(t, "is_identity", False)
+
+    def fit_data_transform(self, x):
+        return self.data_transform.fit(x) if self._has_transform() else x
+
+    def rescale(self, x):
+        """x -> (x', log|det dx'/dx|)."""
+        return self.data_transform.forward(x) if self._has_transform() else (x, None)
+
+    def inverse_rescale(self, x_prime):
+        """x' -> (x, log|det dx/dx'|)."""
+        return self.data_transform.inverse(x_prime) if self._has_transform() else (x_prime, None)
 
     def log_prob(self, x):
         raise NotImplementedError
@@ -80,6 +96,8 @@ class GaussianFlow(Flow):
         return self._dev
 
     def device_mixture(self, engine=None):
+        if self._has_transform():
+            raise ValueError("the proposal is Gaussian in the data transform's space, not in x")
         if engine is not None:
             self.engine = engine
         return self._device_params()[3]
@@ -87,6 +105,10 @@ class GaussianFlow(Flow):
     def fit(self, samples, **kwargs) -> FlowHistory:
         """Moment-match the diagonal Gaussian to the training samples (closed form)."""
         x = np.asarray(samples.detach().cpu() if isinstance(samples, torch.Tensor) else samples, dtype=np.float64)
+        if self._has_transform():
+            if getattr(self.data_transform, "engine", None) is None and hasattr(self.data_transform, "engine"):
+                self.data_transform.engine = self._eng()
+            x = np.asarray(self.fit_data_transform(x), dtype=np.float64)
         self.mu = x.mean(axis=0)
         self.sigma = x.std(axis=0, ddof=1)
         self._dev = None
@@ -97,11 +119,19 @@ class GaussianFlow(Flow):
         x, _ = e.gaussian_draw(n_samples, self.dims, self.dtype, mu, sigma, self.seed, self.gid0, self._draws,
                                want_lq=False)
         self._draws += 1
-        return x, e.mixture_logpdf(x, mix)
+        lq = e.mixture_logpdf(x, mix)
+        if self._has_transform():  # flows/torch/flows.py:327-346: (x, log p(x') - log|det dx/dx'|)
+            x, logj = self.inverse_rescale(x)
+            lq = lq - e.asarray(logj)
+            x = e.asarray(x, dtype=self.dtype)
+        return x, lq
 
     def log_prob(self, x):
         e, _, _, mix = self._device_params()
         xt = e.asarray(x, dtype=x.dtype if isinstance(x, torch.Tensor) and x.dtype in (torch.float32, torch.float64) else torch.float64)
+        if self._has_transform():  # flows/torch/flows.py:368-387: log p(x') + log|det dx'/dx|
+            xp_, logj = self.rescale(xt)
+            return e.mixture_logpdf(e.asarray(xp_, dtype=xt.dtype), mix) + e.asarray(logj)
         return e.mixture_logpdf(xt, mix)
 
 
@@ -184,6 +214,8 @@ class CouplingFlow(Flow):
         knowingly."""
         if self.dtype != torch.float32:
             raise ValueError("device_coupling needs a float32 flow")
+        if self._has_transform():
+            raise ValueError("the flow lives in the data transform's space; the kernel evaluates log q in x")
         key = (id(engine), self._version)
         if self._packed is None or self._packed[0] != key:
             ws, bs = self.export_layers()
@@ -225,8 +257,10 @@ class CouplingFlow(Flow):
     def fit(self, samples, n_epochs: int = 100, lr_annealing: bool = False, patience: int = 20, batch_size: int = 500,
             validation_fraction: float = 0.2, lr: float = 1e-3, clip_grad: float | None = None, **kwargs) -> FlowHistory:
         """Maximum-likelihood training, same knobs as ZukoFlow.fit (flows/torch/flows.py:170-325)."""
-        x = torch.as_tensor(np.asarray(samples.detach().cpu() if isinstance(samples, torch.Tensor) else samples),
-                            dtype=self.dtype, device=self.device)
+        xs = np.asarray(samples.detach().cpu() if isinstance(samples, torch.Tensor) else samples)
+        if self._has_transform():
+            xs = np.asarray(self.fit_data_transform(np.asarray(xs, dtype=np.float64)))
+        x = torch.as_tensor(xs, dtype=self.dtype, device=self.device)
         self.loc, self.scale = x.mean(0), x.std(0).clamp_min(1e-6)
         n = x.shape[0]
         perm = torch.randperm(n, generator=torch.Generator().manual_seed(0)).to(self.device)
@@ -272,10 +306,19 @@ class CouplingFlow(Flow):
     def sample_and_log_prob(self, n_samples: int, xp=None):
         z = torch.randn((n_samples, self.dims), device=self.device, dtype=self.dtype, generator=self._gen)
         x, ladj = self._from_latent(z)
-        return x, self._base_logp(z) - ladj
+        lq = self._base_logp(z) - ladj
+        if self._has_transform():  # flows/torch/flows.py:327-346
+            x, logj = self.inverse_rescale(x.double())
+            x = torch.as_tensor(x, device=self.device)
+            lq = lq.double() - torch.as_tensor(logj, device=self.device)
+        return x, lq
 
     @torch.no_grad()
     def log_prob(self, x, xp=None):
+        if self._has_transform():  # flows/torch/flows.py:368-387
+            xp_, logj = self.rescale(torch.as_tensor(x, device=self.device).double())
+            z, ladj = self._to_latent(torch.as_tensor(xp_, dtype=self.dtype, device=self.device))
+            return (self._base_logp(z) + ladj).double() + torch.as_tensor(logj, device=self.device)
         x = torch.as_tensor(x, dtype=self.dtype, device=self.device)
         z, ladj = self._to_latent(x)
         return self._base_logp(z) + ladj

@@ -180,3 +180,26 @@ class CompositeTransform:
                 "prior_bounds": self.prior_bounds, "bounded_to_unbounded": self.bounded_to_unbounded,
                 "bounded_transform": self.bounded_transform, "affine_transform": self.affine_transform,
                 "eps": self.eps, "device": self.device}
+
+
+class FlowTransform(CompositeTransform):
+    """The data transform the reference puts in front of its flows (transforms.py:345-395): a CompositeTransform
+    without periodic parameters, affine stage on by default."""
+
+    def __init__(self, parameters: list, prior_bounds: dict | None = None, bounded_to_unbounded: bool = True,
+                 bounded_transform: str = "probit", affine_transform: bool = True, device=None, xp=None,
+                 eps: float = 1e-6, dtype: Any = None, engine=None):
+        super().__init__(parameters=parameters, periodic_parameters=[], prior_bounds=prior_bounds,
+                         bounded_to_unbounded=bounded_to_unbounded, bounded_transform=bounded_transform,
+                         affine_transform=affine_transform, device=device, xp=xp, eps=eps, dtype=dtype, engine=engine)
+
+    def new_instance(self, xp=None, dtype: Any = None):
+        return self.__class__(parameters=self.parameters, prior_bounds=self.prior_bounds,
+                              bounded_to_unbounded=self.bounded_to_unbounded, bounded_transform=self.bounded_transform,
+                              affine_transform=self.affine_transform, device=self.device, xp=xp or self.xp, eps=self.eps,
+                              dtype=dtype or self.dtype, engine=self.engine)
+
+    def config_dict(self):
+        cfg = super().config_dict()
+        cfg.pop("periodic_parameters", None)
+        return cfg
