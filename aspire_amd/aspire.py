@@ -17,7 +17,7 @@ from typing import Any, Callable
 import numpy as np
 import torch
 
-from ._xp import is_torch_namespace
+from ._xp import is_torch_namespace, to_numpy
 from .flows import CouplingFlow, Flow, GaussianFlow
 from .history import FlowHistory, History
 from .samples import Samples
@@ -208,3 +208,41 @@ class Aspire:
         if return_history:
             return samples, self._sampler.history
         return samples
+
+    # ---- configuration / convenience (aspire.py:762-909) ---------------------------------------
+    def config_dict(self, include_sampler_config: bool = False, **kwargs) -> dict:
+        def fid(f):
+            return f"{getattr(f, '__module__', None)}.{getattr(f, '__qualname__', getattr(f, '__name__', repr(f)))}"
+
+        config = {
+            "log_likelihood": fid(self.log_likelihood), "log_prior": fid(self.log_prior), "dims": self.dims,
+            "parameters": self.parameters, "periodic_parameters": self.periodic_parameters,
+            "prior_bounds": self.prior_bounds, "bounded_to_unbounded": self.bounded_to_unbounded,
+            "bounded_transform": self.bounded_transform, "flow_matching": self.flow_matching, "device": self.device,
+            "xp": self.xp.__name__ if self.xp else None, "flow_backend": self.flow_backend,
+            "flow_kwargs": self.flow_kwargs, "eps": self.eps,
+        }
+        if include_sampler_config:
+            if hasattr(self, "_last_sampler_type"):
+                config["sampler_type"] = self._last_sampler_type
+            if self.sampler is None:
+                raise ValueError("Sampler has not been initialized.")
+            config["sampler_config"] = self.sampler.config_dict(**kwargs)
+        return config
+
+    def save_config_to_json(self, filename: str) -> None:
+        import json
+
+        with open(filename, "w") as f:
+            json.dump(self.config_dict(), f, indent=4, default=str)
+
+    def sample_flow(self, n_samples: int = 1, xp=None) -> Samples:
+        """aspire.py:891-909: draws from the flow (data transform included), no prior / likelihood evaluation."""
+        if self.flow is None:
+            self.init_flow()
+        x, log_q = self.flow.sample_and_log_prob(n_samples)
+        out_xp = xp if xp is not None else (self.xp if self.xp is not None else np)
+        if is_torch_namespace(out_xp):
+            return Samples(x=x, log_q=log_q, xp=out_xp, parameters=self.parameters, dtype=self.dtype)
+        return Samples(x=to_numpy(x), log_q=to_numpy(log_q), xp=np, parameters=self.parameters, dtype=self.dtype)
+
