@@ -442,6 +442,7 @@ class HipSMC(SMCSampler):
         return (isinstance(self._log_likelihood, DiagGaussianMixture)
                 and isinstance(self._log_prior, DiagGaussianMixture)
                 and hasattr(self.prior_flow, "device_mixture")
+                and not getattr(self.prior_flow, "_has_transform", lambda: False)()  # log q is Gaussian in x itself
                 and isinstance(self.preconditioning_transform, IdentityTransform))
 
     def mutate(self, particles: SMCSamples, beta: float, n_steps: int | None = None) -> SMCSamples:
