@@ -21,7 +21,9 @@ ASMC_NOISE_F64, ASMC_NOISE_F32 = 0, 1
 ASMC_MAX_BETAS = 32
 ASMC_MAX_COMPONENTS = 8
 ASMC_MAX_DIMS = 256
-ASMC_ABI_VERSION = 2
+ASMC_BIS_REC = 40
+ASMC_SELECT_THREADS = 65536
+ASMC_ABI_VERSION = 3
 
 
 class AsmcMixture(ctypes.Structure):
@@ -99,6 +101,14 @@ SIGNATURES = {
     "asmc_weights_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _pd, _i, _pd, _vp]),
     "asmc_weights_m2_lse": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _d, _d, _pd, _vp]),
     "asmc_find_beta": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _pd, _vp]),
+    "asmc_find_beta_shard_reduce": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _i, _vp, _vp]),
+    "asmc_find_beta_shard_decide": (_i, [_vp, _vp, _i, _i64, _d, _d, _d, _i, _vp]),
+    "asmc_find_beta_shard_result": (_i, [_vp, _pd, _vp]),
+    "asmc_weights_m2_lse_dev": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _d, _d, _vp, _vp]),
+    "asmc_cdf_total_dev": (_i, [_vp, _vp, _vp]),
+    "asmc_pcg64_select_stage_len": (_i64, [_i64]),
+    "asmc_pcg64_select": (_i, [_vp, POINTER(c_uint64), _i64, _d, _d, _vp, POINTER(c_int64), _vp]),
+    "asmc_pcg64_select_compact": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "asmc_weights_m2": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _pd, _vp]),
     "asmc_log_weights": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _vp, _vp]),
     "asmc_normalized_weights": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _vp, _vp]),

@@ -684,6 +684,74 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcg64_uniforms(const unsigned lo
     }
 }
 
+// Sharded owner-layout resampling: all n_total draws of the stream are generated on every rank; a wave keeps those
+// inside this rank's cdf slice [lo, hi) in its own segment of `stage` (no atomics: the order of the kept draws is
+// (wave, iteration, lane), a fixed function of the draw index), mapped to the local cdf's coordinate.
+#define SEL_WAVES (ASMC_SELECT_THREADS / 64)
+__global__ __launch_bounds__(ASMC_BLOCK) void k_pcg64_select(const unsigned long long* __restrict__ tab, U128 state0,
+                                                            int64_t n, double lo, double hi, int64_t iters,
+                                                            double* __restrict__ stage,
+                                                            long long* __restrict__ counts) {
+    const unsigned long long j = (unsigned long long)blockIdx.x * ASMC_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)(j >> 6);
+    unsigned long long delta = j + 1ULL;
+    U128 st = state0;
+    for (int b = 0; b < 64 && delta; b++, delta >>= 1) {
+        if (delta & 1ULL) {
+            U128 A = {tab[4 * b], tab[4 * b + 1]}, C = {tab[4 * b + 2], tab[4 * b + 3]};
+            st = u128_add(u128_mul(st, A), C);
+        }
+    }
+    const U128 AT = {tab[4 * PCG_THREADS_LOG2], tab[4 * PCG_THREADS_LOG2 + 1]};
+    const U128 CT = {tab[4 * PCG_THREADS_LOG2 + 2], tab[4 * PCG_THREADS_LOG2 + 3]};
+    const double inv_w = 1.0 / (hi - lo);
+    double* seg = stage + wave * 64 * iters;
+    long long pos = 0;
+    for (int64_t k = 0; k < iters; k++) {
+        const int64_t i = k * ASMC_SELECT_THREADS + (int64_t)j;
+        const unsigned long long x = st.hi ^ st.lo;
+        const unsigned rot = (unsigned)(st.hi >> 58);
+        const unsigned long long out = (x >> rot) | (x << ((64u - rot) & 63u));
+        const double u = (double)(out >> 11) * (1.0 / 9007199254740992.0);
+        const bool keep = i < n && u >= lo && u < hi;
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            double q = (u - lo) * inv_w;
+            if (q >= 1.0) q = 0x1.fffffffffffffp-1;
+            seg[pos + __popcll(mask & ((1ULL << lane) - 1ULL))] = q;
+        }
+        pos += __popcll(mask);
+        st = u128_add(u128_mul(st, AT), CT);
+    }
+    if (lane == 0) counts[wave] = pos;
+}
+
+// exclusive scan of the SEL_WAVES wave counts; offsets behind the counts, the total behind the offsets
+__global__ __launch_bounds__(SEL_WAVES) void k_select_scan(long long* __restrict__ counts) {
+    __shared__ long long s[SEL_WAVES];
+    const int t = threadIdx.x;
+    s[t] = counts[t];
+    __syncthreads();
+    for (int o = 1; o < SEL_WAVES; o <<= 1) {
+        const long long v = t >= o ? s[t - o] : 0;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    counts[SEL_WAVES + t] = s[t] - counts[t];
+    if (t == SEL_WAVES - 1) counts[2 * SEL_WAVES] = s[t];
+}
+
+__global__ __launch_bounds__(ASMC_BLOCK) void k_select_compact(int64_t iters, const double* __restrict__ stage,
+                                                              const long long* __restrict__ counts,
+                                                              double* __restrict__ q) {
+    const int64_t wave = blockIdx.x;
+    const long long cnt = counts[wave], off = counts[SEL_WAVES + wave];
+    const double* seg = stage + wave * 64 * iters;
+    for (long long t = threadIdx.x; t < cnt; t += ASMC_BLOCK) q[off + t] = seg[t];
+}
+
 __global__ __launch_bounds__(ASMC_BLOCK) void k_systematic(int64_t n_out, int64_t j0, int64_t n_total,
                                                           double u0, const double* __restrict__ v,
                                                           double* __restrict__ u) {
@@ -1039,13 +1107,75 @@ int asmc_cdf_normalize_last(asmc_ctx* ctx, int64_t n, double* cdf, asmc_stream s
     return ASMC_OK;
 }
 
+static int pcg_prepare_impl(asmc_ctx* ctx, const uint64_t state_host[4], hipStream_t st);
+static inline int pcg_prepare(asmc_ctx* ctx, const uint64_t state_host[4], hipStream_t st) {
+    return pcg_prepare_impl(ctx, state_host, st);
+}
+
 int asmc_pcg64_uniforms(asmc_ctx* ctx, const uint64_t state_host[4], uint64_t offset, int64_t n,
                         double* u, asmc_stream stream) {
     ASMC_REQUIRE(ctx && state_host && u, "null pointer");
     ASMC_REQUIRE(n > 0, "n must be positive");
     hipStream_t st = as_stream(stream);
-    // jump table for this stream's increment: A_0 = MULT, C_0 = inc; A_{i+1} = A_i^2, C_{i+1} = (A_i+1) C_i
-    // (rebuilt only when the increment changes, i.e. when a different Generator is passed)
+    int rc = pcg_prepare(ctx, state_host, st);
+    if (rc) return rc;
+    U128 s0 = {state_host[1], state_host[0]};
+    const int64_t threads = n < PCG_THREADS ? n : PCG_THREADS;
+    const int grid = (int)((threads + ASMC_BLOCK - 1) / ASMC_BLOCK);
+    ASMC_LAUNCH(ctx, st, "k_pcg64_uniforms", k_pcg64_uniforms, dim3(grid), dim3(ASMC_BLOCK), 0, st,
+                       (const unsigned long long*)ctx->d_pcgtab, s0, (unsigned long long)offset, n, u);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int64_t asmc_pcg64_select_stage_len(int64_t n_total) {
+    if (n_total <= 0) return 0;
+    return ((n_total + ASMC_SELECT_THREADS - 1) / ASMC_SELECT_THREADS) * ASMC_SELECT_THREADS;
+}
+
+int asmc_pcg64_select(asmc_ctx* ctx, const uint64_t state_host[4], int64_t n_total, double lo, double hi,
+                      double* stage, int64_t* count_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && state_host && stage && count_host, "null pointer");
+    ASMC_REQUIRE(n_total > 0, "n_total must be positive");
+    ASMC_REQUIRE(lo >= 0.0 && hi > lo && hi <= 1.0, "need 0 <= lo < hi <= 1");
+    static_assert(PCG_THREADS == ASMC_SELECT_THREADS, "the per-thread jump of the select kernel is 2^PCG_THREADS_LOG2");
+    hipStream_t st = as_stream(stream);
+    int rc = pcg_prepare(ctx, state_host, st);
+    if (rc) return rc;
+    U128 s0 = {state_host[1], state_host[0]};
+    const int64_t iters = (n_total + ASMC_SELECT_THREADS - 1) / ASMC_SELECT_THREADS;
+    ASMC_LAUNCH(ctx, st, "k_pcg64_select", k_pcg64_select, dim3(ASMC_SELECT_THREADS / ASMC_BLOCK), dim3(ASMC_BLOCK), 0, st,
+                (const unsigned long long*)ctx->d_pcgtab, s0, n_total, lo, hi, iters, stage, ctx->d_select);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_select_scan", k_select_scan, dim3(1), dim3(SEL_WAVES), 0, st, ctx->d_select);
+    ASMC_LAUNCH_CHECK();
+    long long* h = reinterpret_cast<long long*>(ctx->h_pinned);
+    ASMC_HIP(hipMemcpyAsync(h, ctx->d_select + 2 * SEL_WAVES, sizeof(long long), hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    *count_host = (int64_t)h[0];
+    return ASMC_OK;
+}
+
+int asmc_pcg64_select_compact(asmc_ctx* ctx, int64_t n_total, const double* stage, double* q, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && stage && q, "null pointer");
+    ASMC_REQUIRE(n_total > 0, "n_total must be positive");
+    hipStream_t st = as_stream(stream);
+    const int64_t iters = (n_total + ASMC_SELECT_THREADS - 1) / ASMC_SELECT_THREADS;
+    ASMC_LAUNCH(ctx, st, "k_select_compact", k_select_compact, dim3(SEL_WAVES), dim3(ASMC_BLOCK), 0, st, iters, stage,
+                (const long long*)ctx->d_select, q);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_cdf_total_dev(asmc_ctx* ctx, double* out_dev, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && out_dev, "null pointer");
+    ASMC_HIP(hipMemcpyAsync(out_dev, ctx->d_small + 1024, sizeof(double), hipMemcpyDeviceToDevice, as_stream(stream)));
+    return ASMC_OK;
+}
+
+// jump table for this stream's increment: A_0 = MULT, C_0 = inc; A_{i+1} = A_i^2, C_{i+1} = (A_i+1) C_i
+// (rebuilt only when the increment changes, i.e. when a different Generator is passed)
+static int pcg_prepare_impl(asmc_ctx* ctx, const uint64_t state_host[4], hipStream_t st) {
     if (!ctx->pcg_tab_valid || ctx->pcg_inc[0] != state_host[2] || ctx->pcg_inc[1] != state_host[3]) {
         unsigned long long* tab = reinterpret_cast<unsigned long long*>(ctx->h_pinned) + 4096;
         ASMC_HIP(hipStreamSynchronize(st));  // pinned staging may still be in use by a previous call
@@ -1066,12 +1196,6 @@ int asmc_pcg64_uniforms(asmc_ctx* ctx, const uint64_t state_host[4], uint64_t of
         ctx->pcg_inc[1] = state_host[3];
         ctx->pcg_tab_valid = 1;
     }
-    U128 s0 = {state_host[1], state_host[0]};
-    const int64_t threads = n < PCG_THREADS ? n : PCG_THREADS;
-    const int grid = (int)((threads + ASMC_BLOCK - 1) / ASMC_BLOCK);
-    ASMC_LAUNCH(ctx, st, "k_pcg64_uniforms", k_pcg64_uniforms, dim3(grid), dim3(ASMC_BLOCK), 0, st,
-                       (const unsigned long long*)ctx->d_pcgtab, s0, (unsigned long long)offset, n, u);
-    ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
 

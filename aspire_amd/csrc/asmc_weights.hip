@@ -351,24 +351,13 @@ struct BisInit {
 //   rounding, so max_i lw_i(beta) = m(1) (beta - beta0)/(1 - beta0) to rounding as well (m(1): exact, from the max
 //   kernel), and a log-sum-exp only needs a shift near the maximum, not the maximum itself.
 // State st[]: [0] beta_min [1] beta_max [2] done [3] target_eff [4] tol [5] log N [6] rounds [7] beta0 [8] N
-//   [9] ESS(1)/N [10] m(1) [11..13] (m, S1, S2) at beta_min [14] 1 when [11..13] are valid [16..30] midpoints
+//   [9] ESS(1)/N [10] m(1) [11..13] (m, S1, S2) at beta_min [14] 1 when [11..13] are valid [15] NaN log-weights
+//   (sharded search only) [16..30] midpoints
 //   [32] S1(1) [33] S2(1)  [34..38] next round's grid: c1, c2, m of the LOWEST candidate, spacing h, Delta_max
-__device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
-                                              const double* __restrict__ partials, int nblocks, bool first,
-                                              double m_one_in, const BisInit& init, double (*s_red)[33],
-                                              double* s_S, double* s_eff) {
-    // the state record and the candidates' shifts are staged in LDS: thread 0's decision chain below must not pay a
-    // global-memory latency per dependent access
-    __shared__ double s_st[40];
-    __shared__ double s_bp[4][16];  // c1, c2, m, shift of the candidates (in: m of this round; out: next round)
+// Fixed-order reduction of the block partial records (32 columns) into s_S; valid after the next __syncthreads().
+__device__ __forceinline__ void bis_reduce_partials(const double* __restrict__ partials, int nblocks,
+                                                    double (*s_red)[33], double* s_S) {
     const int col = threadIdx.x & 31, part = threadIdx.x >> 5, nparts = blockDim.x >> 5;
-    if (threadIdx.x < 40) {
-        const int i = threadIdx.x;
-        s_st[i] = !first ? st[i]
-                         : (i == 0 ? init.beta0 : i == 1 ? 1.0 : i == 3 ? init.target : i == 4 ? init.tol : i == 5 ? init.logN
-                            : i == 7 ? init.beta0 : i == 8 ? init.N : i == 10 ? m_one_in : 0.0);
-    }
-    if (!first && threadIdx.x >= 64 && threadIdx.x < 80) s_bp[2][threadIdx.x - 64] = bp->m[threadIdx.x - 64];
     double v = 0.0;
     for (int b0 = part; b0 < nblocks; b0 += 8 * nparts) {  // eight records in flight per thread, fixed order
         double t8[8];
@@ -387,6 +376,25 @@ __device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<
         for (int q = 0; q < nparts; q++) t += s_red[q][threadIdx.x];
         s_S[threadIdx.x] = t;
     }
+}
+
+// `partials` == nullptr: s_S already holds the column sums (sharded search: the rank records merged by k_bis_decide).
+__device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
+                                              const double* __restrict__ partials, int nblocks, bool first,
+                                              double m_one_in, const BisInit& init, double (*s_red)[33],
+                                              double* s_S, double* s_eff, double nan_total = 0.0) {
+    // the state record and the candidates' shifts are staged in LDS: thread 0's decision chain below must not pay a
+    // global-memory latency per dependent access
+    __shared__ double s_st[40];
+    __shared__ double s_bp[4][16];  // c1, c2, m, shift of the candidates (in: m of this round; out: next round)
+    if (threadIdx.x < 40) {
+        const int i = threadIdx.x;
+        s_st[i] = !first ? st[i]
+                         : (i == 0 ? init.beta0 : i == 1 ? 1.0 : i == 3 ? init.target : i == 4 ? init.tol : i == 5 ? init.logN
+                            : i == 7 ? init.beta0 : i == 8 ? init.N : i == 10 ? m_one_in : i == 15 ? nan_total : 0.0);
+    }
+    if (!first && threadIdx.x >= 64 && threadIdx.x < 80) s_bp[2][threadIdx.x - 64] = bp->m[threadIdx.x - 64];
+    if (partials) bis_reduce_partials(partials, nblocks, s_red, s_S);
     const double logN = s_st[5], N = s_st[8], target = s_st[3], tol = s_st[4], beta0 = s_st[7], m_one = s_st[10];
     const double inv = 1.0 / (1.0 - beta0);
     // heap-ordered midpoints of the next four levels from (lo, hi), exactly the values the sequential loop visits
@@ -489,7 +497,8 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const doubl
                                                         const double* __restrict__ lp, const double* __restrict__ lq,
                                                         double* __restrict__ st, BetaPack<16>* __restrict__ bp,
                                                         double* partials, unsigned int* ticket, int round, BisInit init,
-                                                        const unsigned long long* __restrict__ keys) {
+                                                        const unsigned long long* __restrict__ keys,
+                                                        double* __restrict__ rec_out) {
     __shared__ double s_red[BIS_THREADS / 32][33];
     __shared__ double s_S[32];
     __shared__ double s_eff[16];
@@ -580,7 +589,68 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const doubl
     }
     __syncthreads();
     if (!s_last) return;
+    if (rec_out) {
+        // sharded search: this rank's column sums, the shift base they are relative to (local m(1) in the first
+        // round, the merged one afterwards) and the local NaN census leave as one record; k_bis_decide closes the round
+        // on every rank after the all-gather
+        bis_reduce_partials(partials, (int)gridDim.x, s_red, s_S);
+        __syncthreads();
+        if (threadIdx.x < 32) rec_out[threadIdx.x] = s_S[threadIdx.x];
+        if (threadIdx.x == 32) rec_out[32] = round == 0 ? m_one : st[10];
+        if (threadIdx.x == 33) rec_out[33] = round == 0 ? (double)keys[ASMC_MAX_BETAS] : 0.0;
+        return;
+    }
     bis_tail_body(st, bp, partials, (int)gridDim.x, round == 0, m_one, init, s_red, s_S, s_eff);
+}
+
+// heap node k of the bisection tree rooted at (lo, hi): the midpoint the sequential loop would try there
+__device__ __forceinline__ double bis_heap_mid(int k, double lo, double hi) {
+    const int kp = k + 1;
+    const int depth = 31 - __clz(kp);
+    double mid = 0.5 * (hi + lo);
+    for (int lev = depth - 1; lev >= 0; lev--) {
+        if ((kp >> lev) & 1)
+            lo = mid;  // right child: eff >= target there
+        else
+            hi = mid;
+        mid = 0.5 * (hi + lo);
+    }
+    return mid;
+}
+
+// Sharded search, second half of a round (every rank runs it on the same all-gathered records, so every rank takes
+// the same decisions): merges the G rank records in rank order and runs the tail of the single-rank kernel.  First
+// round: the ranks reduced against their LOCAL m(1); the sums are rescaled to the merged maximum M = max_r m_r(1),
+// exp(lw - m_r t) = exp(lw - M t) exp((M - m_r) t) with t = (beta - beta0)/(1 - beta0).  Later rounds use M on every rank.
+__global__ __launch_bounds__(BIS_THREADS) void k_bis_decide(const double* __restrict__ recs, int world,
+                                                          double* __restrict__ st, BetaPack<16>* __restrict__ bp,
+                                                          int round, BisInit init) {
+    __shared__ double s_red[BIS_THREADS / 32][33];
+    __shared__ double s_S[32];
+    __shared__ double s_eff[16];
+    if (round > 0 && st[2] != 0.0) return;  // converged earlier
+    double m_all = recs[32], nan_total = 0.0;
+    for (int r = 1; r < world; r++) m_all = fmax(m_all, recs[(size_t)r * ASMC_BIS_REC + 32]);
+    if (round == 0)
+        for (int r = 0; r < world; r++) nan_total += recs[(size_t)r * ASMC_BIS_REC + 33];
+    if (threadIdx.x < 32) {
+        const int c = threadIdx.x, k = c >> 1;
+        double acc = 0.0;
+        if (round == 0) {
+            const double beta = k < BIS_NODES ? bis_heap_mid(k, init.beta0, 1.0) : 1.0;
+            const double t = (beta - init.beta0) * (1.0 / (1.0 - init.beta0));
+            const double pw = (c & 1) ? 2.0 : 1.0;
+            for (int r = 0; r < world; r++) {
+                const double mr = recs[(size_t)r * ASMC_BIS_REC + 32];
+                acc += recs[(size_t)r * ASMC_BIS_REC + c] * exp(pw * (mr * t - m_all * t));
+            }
+        } else {
+            for (int r = 0; r < world; r++) acc += recs[(size_t)r * ASMC_BIS_REC + c];
+        }
+        s_S[c] = acc;
+    }
+    __syncthreads();
+    bis_tail_body(st, bp, nullptr, 0, round == 0, m_all, init, s_red, s_S, s_eff, nan_total);
 }
 
 extern "C" {
@@ -674,7 +744,7 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
     for (int attempt = 0; attempt < 4; attempt++) {
         for (; launched < rounds; launched++) {
             ASMC_LAUNCH(ctx, st, "k_bis_sums", k_bis_sums, dim3(grid), dim3(BIS_THREADS), 0, st, n, ll, lp, lq, d_st, d_bp, ctx->d_partials,
-                        d_ticket, launched, init, (const unsigned long long*)ctx->d_keys);
+                        d_ticket, launched, init, (const unsigned long long*)ctx->d_keys, (double*)nullptr);
             ASMC_LAUNCH_CHECK();
         }
         ASMC_HIP(hipMemcpyAsync(h, d_st, sizeof(double) * 40, hipMemcpyDeviceToHost, st));
@@ -696,6 +766,65 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
     out_host[10] = h[10];             // (m, S1, S2) at beta = 1
     out_host[11] = h[32];
     out_host[12] = h[33];
+    return ASMC_OK;
+}
+
+static inline void bis_state(asmc_ctx* ctx, double** d_st, BetaPack<16>** d_bp, unsigned int** d_ticket) {
+    *d_st = ctx->d_small + 2560;
+    *d_bp = reinterpret_cast<BetaPack<16>*>(ctx->d_small + 2560 + 64);
+    *d_ticket = reinterpret_cast<unsigned int*>(ctx->d_keys + ASMC_MAX_BETAS + 4);  // zeroed by launch_max
+}
+
+int asmc_find_beta_shard_reduce(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq,
+                                double beta0, int round, double* rec_dev, asmc_stream stream) {
+    int rc = check_common(ctx, n, ll, lp, lq);
+    if (rc) return rc;
+    ASMC_REQUIRE(rec_dev != nullptr && round >= 0, "null record / negative round");
+    ASMC_REQUIRE(beta0 >= 0.0 && beta0 < 1.0, "bad beta0");
+    hipStream_t st = as_stream(stream);
+    double* d_st;
+    BetaPack<16>* d_bp;
+    unsigned int* d_ticket;
+    bis_state(ctx, &d_st, &d_bp, &d_ticket);
+    if (round == 0) {
+        const double one = 1.0;
+        rc = launch_max(ctx, n, ll, lp, lq, beta0, &one, 1, st);  // local m(1), local NaN census, ticket := 0
+        if (rc) return rc;
+    }
+    const BisInit init = {beta0, 0.0, 0.0, 0.0, 0.0};  // the reduction half only needs beta0
+    const int grid = grid_for(n, BIS_THREADS, ctx->num_cu);
+    ASMC_LAUNCH(ctx, st, "k_bis_sums", k_bis_sums, dim3(grid), dim3(BIS_THREADS), 0, st, n, ll, lp, lq, d_st, d_bp, ctx->d_partials,
+                d_ticket, round, init, (const unsigned long long*)ctx->d_keys, rec_dev);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_find_beta_shard_decide(asmc_ctx* ctx, const double* recs_dev, int world, int64_t n_global, double beta0,
+                                double target_eff, double tol, int round, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && recs_dev, "null pointer");
+    ASMC_REQUIRE(world >= 1 && n_global > 0 && round >= 0, "bad world / n_global / round");
+    ASMC_REQUIRE(tol > 0.0 && beta0 >= 0.0 && beta0 < 1.0, "bad beta0 / tolerance");
+    hipStream_t st = as_stream(stream);
+    double* d_st;
+    BetaPack<16>* d_bp;
+    unsigned int* d_ticket;
+    bis_state(ctx, &d_st, &d_bp, &d_ticket);
+    const BisInit init = {beta0, target_eff, tol, log((double)n_global), (double)n_global};
+    ASMC_LAUNCH(ctx, st, "k_bis_decide", k_bis_decide, dim3(1), dim3(BIS_THREADS), 0, st, recs_dev, world, d_st, d_bp, round, init);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_find_beta_shard_result(asmc_ctx* ctx, double* out_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && out_host, "null pointer");
+    hipStream_t st = as_stream(stream);
+    double* h = ctx->h_pinned + 4096 + 512;
+    ASMC_HIP(hipMemcpyAsync(h, ctx->d_small + 2560, sizeof(double) * 40, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    out_host[0] = h[0], out_host[1] = h[1], out_host[2] = h[2], out_host[3] = h[6], out_host[4] = h[9];
+    out_host[5] = h[15];
+    out_host[6] = h[11], out_host[7] = h[12], out_host[8] = h[13], out_host[9] = h[14];
+    out_host[10] = h[10], out_host[11] = h[32], out_host[12] = h[33];
     return ASMC_OK;
 }
 
@@ -738,6 +867,23 @@ int asmc_weights_m2_lse(asmc_ctx* ctx, int64_t n, const double* ll, const double
     ASMC_HIP(hipStreamSynchronize(st));
     out_host[0] = ctx->h_pinned[0];
     out_host[1] = ctx->h_pinned[1];
+    return ASMC_OK;
+}
+
+int asmc_weights_m2_lse_dev(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq,
+                            double beta0, double beta, double m, double mean_u, double shift, double mp,
+                            double* out_dev, asmc_stream stream) {
+    int rc = check_common(ctx, n, ll, lp, lq);
+    if (rc) return rc;
+    ASMC_REQUIRE(out_dev != nullptr, "null device pointer");
+    hipStream_t st = as_stream(stream);
+    const int grid = reduce_grid(ctx, n, 1);
+    ASMC_LAUNCH(ctx, st, "k_weights_m2_lse", k_weights_m2_lse, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, beta0 - beta,
+                beta - beta0, m, mean_u, shift, mp, ctx->d_partials);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_finalize_columns", k_finalize_columns, dim3(2), dim3(64), 0, st, grid, 2, ctx->d_partials,
+                out_dev, 1, 0, (const unsigned long long*)nullptr, (const unsigned long long*)nullptr);
+    ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
 

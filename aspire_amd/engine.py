@@ -239,6 +239,53 @@ class HipEngine:
         trip = (float(out[6]), float(out[7]), float(out[8])) if out[9] != 0.0 else None
         return float(out[0]), float(out[4]), bool(out[2]), int(out[3]), int(out[5]), trip, tuple(map(float, out[10:13]))
 
+    # sharded search (smc_math.find_beta_sharded drives the rounds; the all-gather between the halves is the caller's)
+    def find_beta_shard_reduce(self, ll, lp, lq, beta0: float, rnd: int, rec: torch.Tensor):
+        self._chk3(ll, lp, lq)
+        assert rec.dtype == torch.float64 and rec.numel() >= _lib.ASMC_BIS_REC and rec.is_contiguous()
+        check(self.lib.asmc_find_beta_shard_reduce(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0, rnd,
+                                                   _dptr(rec), self._stream), "asmc_find_beta_shard_reduce")
+
+    def find_beta_shard_decide(self, recs: torch.Tensor, world: int, n_global: int, beta0: float, target_eff: float,
+                               tol: float, rnd: int):
+        assert recs.dtype == torch.float64 and recs.numel() == world * _lib.ASMC_BIS_REC and recs.is_contiguous()
+        check(self.lib.asmc_find_beta_shard_decide(self._ctx, _dptr(recs), world, n_global, beta0, target_eff, tol, rnd,
+                                                   self._stream), "asmc_find_beta_shard_decide")
+
+    def find_beta_shard_result(self):
+        out = np.zeros(13)
+        check(self.lib.asmc_find_beta_shard_result(self._ctx, _f64p(out), self._stream), "asmc_find_beta_shard_result")
+        trip = (float(out[6]), float(out[7]), float(out[8])) if out[9] != 0.0 else None
+        return float(out[0]), float(out[4]), bool(out[2]), int(out[3]), int(out[5]), trip, tuple(map(float, out[10:13]))
+
+    def weights_m2_lse_dev(self, ll, lp, lq, beta0: float, beta: float, m: float, mean_u: float, shift: float, mp: float,
+                           out: torch.Tensor):
+        """weights_m2_lse with the two sums written to out[0:2] on the device (no host synchronisation)."""
+        self._chk3(ll, lp, lq)
+        assert out.dtype == torch.float64 and out.numel() >= 2
+        check(self.lib.asmc_weights_m2_lse_dev(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0, beta, m,
+                                               mean_u, shift, mp, _dptr(out), self._stream), "asmc_weights_m2_lse_dev")
+
+    def cdf_total_dev(self, out: torch.Tensor):
+        """Total of the last `cdf` call -> out[0] (device to device)."""
+        check(self.lib.asmc_cdf_total_dev(self._ctx, _dptr(out), self._stream), "asmc_cdf_total_dev")
+
+    def pcg64_select(self, state4: np.ndarray, n_total: int, lo: float, hi: float) -> torch.Tensor:
+        """The draws u of the next n_total PCG64 doubles with lo <= u < hi, as q = (u - lo)/(hi - lo), in the fixed
+        (wave, iteration, lane) order of include/asmc.h."""
+        st = np.ascontiguousarray(state4, dtype=np.uint64)
+        ns = self.lib.asmc_pcg64_select_stage_len(n_total)
+        if getattr(self, "_select_stage", None) is None or self._select_stage.numel() < ns:
+            self._select_stage = self.empty(ns)
+        cnt = ctypes.c_int64(0)
+        check(self.lib.asmc_pcg64_select(self._ctx, st.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n_total, lo, hi,
+                                         _dptr(self._select_stage), ctypes.byref(cnt), self._stream), "asmc_pcg64_select")
+        q = self.empty(int(cnt.value))
+        if cnt.value > 0:
+            check(self.lib.asmc_pcg64_select_compact(self._ctx, n_total, _dptr(self._select_stage), _dptr(q), self._stream),
+                  "asmc_pcg64_select_compact")
+        return q
+
     def weights_m2(self, ll, lp, lq, beta0: float, beta: float, m: float, mean_u: float) -> float:
         self._chk3(ll, lp, lq)
         out = ctypes.c_double(0.0)

@@ -42,6 +42,7 @@ class SMCSampler(MCMCSampler):
         self.device_bisection = True  # single-rank: whole adaptive-beta search on device (asmc_find_beta)
         self.resample_mode = "exact"
         self.resample_method = "multinomial"
+        self.shard_layout = "owner"  # sharded runs: offspring stay on the ancestor's rank ("slots": single-rank order)
 
     # ---- target efficiency (smc/base.py:80-121) -------------------------------------------
     @property
@@ -59,7 +60,15 @@ class SMCSampler(MCMCSampler):
 
     # ---- helpers --------------------------------------------------------------------------
     def _n_global(self, samples) -> int:
-        return len(samples.x) * self.comm.world
+        return samples._n_global()
+
+    def _gid0(self, samples) -> int:
+        """First global particle id of this rank's shard (keys the per-particle noise streams).  Equal shards: the
+        global particle index, so a sharded run in slot layout draws the same noise as a single-rank run.  Ragged
+        shards (owner layout): disjoint id ranges per rank."""
+        if samples.__dict__.get("ragged"):
+            return self.comm.rank << 40
+        return self.comm.rank * len(samples.x)
 
     def _stats(self, samples: SMCSamples, betas) -> list[smc_math.Stats]:
         return samples.weight_stats(betas)
@@ -79,10 +88,17 @@ class SMCSampler(MCMCSampler):
             return [smc_math.ess(s) / n for s in self._stats(samples, betas)]
 
         search_fn = None
-        if self.comm.world == 1 and hasattr(self.engine, "find_beta") and self.device_bisection and beta < 1.0:
+        sharded = self.comm.world > 1 and hasattr(self.engine, "find_beta_shard_reduce")
+        if ((self.comm.world == 1 and hasattr(self.engine, "find_beta")) or sharded) and self.device_bisection and beta < 1.0:
             def search_fn(beta_prev, target_eff, tol):
-                b, _, converged, passes, n_nan, trip, trip_one = self.engine.find_beta(
-                    samples.log_likelihood, samples.log_prior, samples.log_q, float(beta_prev), float(target_eff), float(tol))
+                if sharded:
+                    b, _, converged, passes, n_nan, trip, trip_one = smc_math.find_beta_sharded(
+                        self.engine, self.comm, samples.log_likelihood, samples.log_prior, samples.log_q, float(beta_prev),
+                        float(target_eff), float(tol), n)
+                else:
+                    b, _, converged, passes, n_nan, trip, trip_one = self.engine.find_beta(
+                        samples.log_likelihood, samples.log_prior, samples.log_q, float(beta_prev), float(target_eff),
+                        float(tol))
                 if n_nan > 0:
                     raise ValueError(f"Log weights contain NaN values for beta={b}")
                 if not converged:
@@ -101,9 +117,13 @@ class SMCSampler(MCMCSampler):
             rate=self.target_efficiency_rate, logger=logger, search_fn=search_fn)
         return beta, min_beta_step
 
-    def _wrap(self, x, ll, lp, lq, beta) -> SMCSamples:
+    def _wrap(self, x, ll, lp, lq, beta, like: SMCSamples | None = None) -> SMCSamples:
         s = SMCSamples(x=x, xp=torch, beta=beta, parameters=self.parameters, engine=self.engine, comm=self.comm)
         s.log_likelihood, s.log_prior, s.log_q = ll, lp, lq
+        if like is not None:  # shard bookkeeping of the population these particles came from
+            for k in ("n_global", "ragged"):
+                if k in like.__dict__:
+                    setattr(s, k, like.__dict__[k])
         return s
 
     # ---- the loop (smc/base.py:215-488) -----------------------------------------------------
@@ -221,17 +241,14 @@ class SMCSampler(MCMCSampler):
                 self.history.ess_target.append(float(smc_math.ess(st_one)))
 
                 log_evidence_ratio = smc_math.log_evidence_ratio(st_beta)
-                log_evidence_ratio_var, s1p = smc_math.evidence_variance_and_lse(
-                    e, comm, samples.log_likelihood, samples.log_prior, samples.log_q, float(samples.beta),
-                    float(beta), st_beta)
-                samples.remember_stats(beta, None, s1p)
+                # the evidence-variance pass (samples.py:1230-1242) shares its reduction with the resampling step
+                samples, log_evidence_ratio_var = samples.resample(
+                    beta, rng=self.rng, resample_mode=self.resample_mode, resample_method=self.resample_method,
+                    shard_layout=self.shard_layout, want_variance=True)
                 self.history.log_norm_ratio.append(float(log_evidence_ratio))
                 self.history.log_norm_ratio_var.append(float(log_evidence_ratio_var))
                 logger.info(f"it {iterations} - Log evidence ratio: {log_evidence_ratio:.2f} +/- "
                             f"{np.sqrt(log_evidence_ratio_var):.2f}")
-
-                samples = samples.resample(beta, rng=self.rng, resample_mode=self.resample_mode,
-                                           resample_method=self.resample_method)
                 samples = self.mutate(samples, beta)
                 if store_sample_history:
                     self.history.sample_history.append(samples.to_numpy())
@@ -247,7 +264,7 @@ class SMCSampler(MCMCSampler):
                     logger.warning(f"Final samples contain non-finite {name} values")
             final_samples = samples.resample(1.0, n_samples=n_final_samples, rng=self.rng,
                                              resample_mode=self.resample_mode,
-                                             resample_method=self.resample_method)
+                                             resample_method=self.resample_method, shard_layout=self.shard_layout)
             samples = self.mutate(final_samples, 1.0, n_steps=n_final_steps)
 
         samples.log_evidence = float(np.sum(np.asarray(self.history.log_norm_ratio, dtype=np.float64)))
@@ -345,10 +362,10 @@ class HipSMC(SMCSampler):
             resample_method=resample_method)
 
     # ---- reference Gaussian of the pCN proposal ----------------------------------------------
-    def _fit_reference_gaussian(self, x: torch.Tensor):
+    def _fit_reference_gaussian(self, x: torch.Tensor, n_global: int | None = None):
         """Population mean and covariance (ddof=1) over ALL ranks -> (mu, L, Linv) on device."""
         e, comm = self.engine, self.comm
-        n = x.shape[0] * comm.world
+        n = n_global or x.shape[0] * comm.world
         parts = comm.all_gather_f64(e.colsum(x))
         s = parts[0].copy()
         for r in range(1, comm.world):
@@ -389,15 +406,15 @@ class HipSMC(SMCSampler):
             T.engine = e
         ll, lp, lq = particles.log_likelihood, particles.log_prior, particles.log_q
         n_local = x.shape[0]
-        n_global = n_local * comm.world
-        gid0 = comm.rank * n_local
+        n_global = self._n_global(particles)
+        gid0 = self._gid0(particles)
         try:
             z = T.fit(x, comm=comm)
         except TypeError:  # a user-supplied transform with the reference's fit(x) signature
             z = T.fit(x)
         z = e.asarray(z, dtype=x.dtype)
         logj = e.asarray(T.inverse(z)[1])
-        mu, L, Linv = self._fit_reference_gaussian(z)
+        mu, L, Linv = self._fit_reference_gaussian(z, n_global)
         st = self._pcn_state
         if st["rho"] is None:
             st["rho"] = min(2.38 / math.sqrt(self.dims), 0.99)
@@ -421,7 +438,7 @@ class HipSMC(SMCSampler):
         x_new = e.asarray(T.inverse(z)[0], dtype=x.dtype)
         if e.count_nonfinite(lq)[0]:
             raise ValueError("Log proposal contains NaN values")
-        return self._wrap(x_new, ll, lp, lq, beta)
+        return self._wrap(x_new, ll, lp, lq, beta, like=particles)
 
     def _device_flow(self):
         """The proposal flow packed for the MFMA kernel, or None (not a float32 coupling flow of a supported shape)."""
@@ -460,9 +477,9 @@ class HipSMC(SMCSampler):
         self.fit_preconditioning_transform(particles.x)
         ll, lp, lq = particles.log_likelihood, particles.log_prior, particles.log_q
         n_local = x.shape[0]
-        n_global = n_local * comm.world
-        gid0 = comm.rank * n_local
-        mu, L, Linv = self._fit_reference_gaussian(x)
+        n_global = self._n_global(particles)
+        gid0 = self._gid0(particles)
+        mu, L, Linv = self._fit_reference_gaussian(x, n_global)
         st = self._pcn_state
         if st["rho"] is None:
             st["rho"] = min(2.38 / math.sqrt(self.dims), 0.99)
@@ -527,7 +544,7 @@ class HipSMC(SMCSampler):
         self.history.mcmc_step_size.append(float(st["rho"]))
         if e.count_nonfinite(lq)[0]:
             raise ValueError("Log proposal contains NaN values")
-        return self._wrap(x, ll, lp, lq, beta)
+        return self._wrap(x, ll, lp, lq, beta, like=particles)
 
 
 def _single_threaded_blas():

@@ -351,7 +351,8 @@ class SMCSamples(BaseSamples):
         return tuple(e.asarray(v) for v in (self.log_likelihood, self.log_prior, self.log_q))
 
     def _n_global(self) -> int:
-        return len(self.x) * self._comm().world
+        # sharded runs in owner layout have ragged shards: the population size travels with the object then
+        return self.__dict__.get("n_global") or len(self.x) * self._comm().world
 
     def _from_device(self, t):
         if is_torch_namespace(self.xp):
@@ -415,10 +416,15 @@ class SMCSamples(BaseSamples):
         return smc_math.ess(self._stats(beta))
 
     def resample(self, beta, n_samples: int | None = None, rng: np.random.Generator = None, *,
-                 resample_mode: str = "exact", resample_method: str = "multinomial") -> "SMCSamples":
+                 resample_mode: str = "exact", resample_method: str = "multinomial", shard_layout: str = "owner",
+                 want_variance: bool = False):
         """samples.py:1251-1287.  `resample_mode`: "exact" (sequential-order cdf == numpy cumsum,
         bit-exact indices) or "fast"; `resample_method`: "multinomial" (reference) or the opt-in
-        "systematic" / "stratified"."""
+        "systematic" / "stratified".  Sharded populations (`comm.world > 1`): `shard_layout="owner"` keeps every
+        offspring on its ancestor's rank (no row exchange; ragged shards), `"slots"` gives output slot j to rank
+        j // n_local and reproduces the single-rank particle order (smc_math.resample_owner / resample_indices).
+        `want_variance=True` also returns log_evidence_ratio_variance(beta), which the owner layout computes in the
+        same exchange."""
         if rng is None:
             rng = np.random.default_rng()
         comm = self._comm()
@@ -429,20 +435,42 @@ class SMCSamples(BaseSamples):
         if beta == self.beta:
             if n_samples is None or n_samples == n_global:
                 logger.warning("Resampling with the same beta value, returning identical samples")
-                return self
+                return (self, 0.0) if want_variance else self
             uniform = True
         e = self._eng()
         ll, lp, lq = self._dev3()
         x = e.asarray(self.x, dtype=self.x.dtype if is_torch(self.x) else torch.float64)
         st = None if uniform else self._stats(beta)
+        var = None
+
+        def wrap(xo, llo, lpo, lqo):
+            out = self.__class__(x=self._from_device(xo), log_likelihood=self._from_device(llo),
+                                 log_prior=self._from_device(lpo), log_q=self._from_device(lqo), beta=beta,
+                                 dtype=self.dtype, parameters=self.parameters, xp=self.xp, engine=self.engine,
+                                 comm=self.comm)
+            if comm.world > 1:
+                out.n_global = int(n_samples)
+            return (out, var) if want_variance else out
+
+        ragged = bool(self.__dict__.get("ragged"))  # set on every rank alike (owner layout produced this population)
+
+        if shard_layout == "owner" and smc_math.owner_layout_ok(e, comm, rng, resample_method, uniform):
+            idx, var, s1p = smc_math.resample_owner(e, comm, ll, lp, lq, float(self.beta), float(beta), int(n_samples), rng,
+                                                    mode=resample_mode, st=st)
+            if idx is not None:
+                res = wrap(*e.gather(idx, x, ll, lp, lq))
+                (res[0] if want_variance else res).ragged = True
+                return res
+            self.remember_stats(beta, None, s1p)  # shares too uneven: fall through to the slot layout, which rebalances
+        if want_variance and var is None and not uniform:
+            var, s1p = smc_math.evidence_variance_and_lse(e, comm, ll, lp, lq, float(self.beta), float(beta), st)
+            self.remember_stats(beta, None, s1p)
+        if ragged:  # the slot layout addresses particles as rank * n_local + i: equalise the shards first
+            x, ll, lp, lq = rebalance_shards(e, comm, x, ll, lp, lq)
         idx, _ = smc_math.resample_indices(e, comm, ll, lp, lq, float(self.beta), float(beta), int(n_samples), rng,
                                            mode=resample_mode, method=resample_method, uniform_weights=uniform,
                                            st=st, s1p=self.__dict__.get("_ws1p", {}).get(float(beta)))
-        xo, llo, lpo, lqo = gather_global(e, comm, idx, x, ll, lp, lq)
-        return self.__class__(x=self._from_device(xo), log_likelihood=self._from_device(llo),
-                              log_prior=self._from_device(lpo), log_q=self._from_device(lqo), beta=beta,
-                              dtype=self.dtype, parameters=self.parameters, xp=self.xp, engine=self.engine,
-                              comm=self.comm)
+        return wrap(*gather_global(e, comm, idx, x, ll, lp, lq))
 
     def __str__(self):
         out = super().__str__()
@@ -470,6 +498,28 @@ class SMCSamples(BaseSamples):
         sliced.log_evidence_error = self.log_evidence_error
         sliced.engine, sliced.comm = self.engine, self.comm
         return sliced
+
+
+def rebalance_shards(engine, comm, x, ll, lp, lq):
+    """Equal shards again (N / world rows per rank) without changing the global (rank-major) particle order: every
+    rank ships the row ranges that fall into another rank's slice with one variable all-to-all."""
+    world, rank, n_loc = comm.world, comm.rank, x.shape[0]
+    counts = comm.all_gather_f64(np.array([float(n_loc)])).reshape(-1).astype(np.int64)
+    total = int(counts.sum())
+    if total % world:
+        raise ValueError(f"cannot split {total} particles evenly over {world} ranks")
+    per = total // world
+    starts = np.concatenate([[0], np.cumsum(counts)])
+
+    def overlap(a0, a1, b0, b1):
+        return int(max(0, min(a1, b1) - max(a0, b0)))
+
+    send = [overlap(starts[rank], starts[rank + 1], r * per, (r + 1) * per) for r in range(world)]
+    recv = [overlap(starts[s], starts[s + 1], rank * per, (rank + 1) * per) for s in range(world)]
+    packed = torch.stack([ll, lp, lq], dim=1).contiguous()
+    x2 = comm.all_to_all_rows(x.contiguous(), send, recv)
+    s2 = comm.all_to_all_rows(packed, send, recv)
+    return x2, s2[:, 0].contiguous(), s2[:, 1].contiguous(), s2[:, 2].contiguous()
 
 
 def gather_global(engine, comm, idx, x, ll, lp, lq):

@@ -318,3 +318,88 @@ def resample_indices(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out:
     u = draw_uniforms(engine, rng, n_out, j0, j1 - j0, method)
     idx = engine.search(cdf, u)
     return idx, j0
+
+
+# ---- sharded runs: device-side search and owner-layout resampling ------------------------------------------------
+SHARD_IMBALANCE = 0.25  # owner layout is used while every rank's weight share stays within +-25 % of 1/world
+
+
+def find_beta_sharded(engine, comm, ll, lp, lq, beta0: float, target_eff: float, tol: float, n_global: int):
+    """`engine.find_beta` over a sharded population: every k-ary round is reduce (local kernel) -> all-gather of the
+    40-double rank records -> decide (same kernel on every rank), all enqueued on the stream; the host only reads the
+    result after the estimated number of rounds (include/asmc.h asmc_find_beta_shard_*).  Same return tuple."""
+    import torch
+
+    rounds = max(1, int(math.ceil(math.log2((1.0 - beta0) / tol) / BISECT_LEVELS - 1e-9)))
+    rec = engine.empty(40)
+    launched = 0
+    out = None
+    for _ in range(4):
+        while launched < rounds:
+            engine.find_beta_shard_reduce(ll, lp, lq, beta0, launched, rec)
+            recs = comm.all_gather_tensor(rec)
+            engine.find_beta_shard_decide(recs, comm.world, n_global, beta0, target_eff, tol, launched)
+            launched += 1
+        out = engine.find_beta_shard_result()
+        if out[2]:
+            break
+        rounds += 1
+    assert isinstance(rec, torch.Tensor)
+    return out
+
+
+def resample_owner(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out: int, rng, *, mode: str = "exact",
+                   st: Stats):
+    """Sharded multinomial resampling that keeps every offspring on its ancestor's rank.
+
+    The reference draws n_out ancestors i.i.d. from the normalised weights (samples.py:1276-1278).  Here the global cdf
+    is two-level: rank totals t_r in rank order, then each rank's own exact cumulative sum.  Every rank walks the same
+    n_out PCG64 draws, keeps those inside its slice [C_r, C_{r+1}) / T and looks them up in its local cdf, so no
+    particle row ever crosses a link; shard sizes become ragged (n_out * t_r / T in expectation, +-0.1 % at 1M).
+    One all-gather carries the rank totals together with the evidence-variance partials (samples.py:1230-1242).
+    Returns (idx_local or None, variance, s1p): idx_local is None when a rank's weight share is outside
+    1/world (1 +- SHARD_IMBALANCE) - the caller then uses the slot layout (`resample_indices` + row exchange), which
+    rebalances the shards; every rank takes that decision from the same gathered numbers."""
+    world, n_local = comm.world, ll.numel()
+    mean_u = st.S1 / st.n
+    shift = float((st.m + np.log(st.S1)) - math.log(st.n))
+    mp = st.m + shift
+    # the second log-sum-exp of samples.py:1277 sums to S1 up to rounding and the cdf is divided by its own total
+    # anyway, so the global constant does not need its own collective
+    lse = float(mp + np.log(st.S1))
+    if hasattr(engine, "weights_m2_lse_dev"):
+        rec = engine.empty(4)
+        engine.weights_m2_lse_dev(ll, lp, lq, beta0, beta, st.m, mean_u, shift, mp, rec)
+        w = engine.normalized_weights(ll, lp, lq, beta0, beta, shift, lse)
+        cdf, _ = engine.cdf(w, mode, 0.0, want_total=False, normalize=True)
+        engine.cdf_total_dev(rec[2:])
+        recs = engine.to_numpy(comm.all_gather_tensor(rec)).reshape(world, 4)[:, :3]
+    else:
+        m2, s1p = engine.weights_m2_lse(ll, lp, lq, beta0, beta, st.m, mean_u, shift, mp)
+        w = engine.normalized_weights(ll, lp, lq, beta0, beta, shift, lse)
+        cdf, total = engine.cdf(w, mode, 0.0)
+        engine.cdf_normalize(cdf, total)
+        recs = comm.all_gather_f64(np.array([m2, s1p, total]))
+    m2, s1p = float(recs[0, 0]), float(recs[0, 1])
+    for r in range(1, world):
+        m2, s1p = m2 + float(recs[r, 0]), s1p + float(recs[r, 1])
+    var_u = m2 / st.n
+    var = float(var_u / (st.n * (mean_u**2))) if mean_u != 0 else float("nan")
+    edges = np.concatenate([[0.0], np.cumsum(recs[:, 2])])  # C_r: rank totals accumulated in rank order
+    share = recs[:, 2] / edges[-1]
+    if not (np.all(share * world <= 1.0 + SHARD_IMBALANCE) and np.all(share * world >= 1.0 - SHARD_IMBALANCE)):
+        return None, var, s1p
+    lo = 0.0 if comm.rank == 0 else float(edges[comm.rank] / edges[-1])
+    hi = 1.0 if comm.rank == world - 1 else float(edges[comm.rank + 1] / edges[-1])
+    state = pcg64_state(rng)
+    q = engine.pcg64_select(state, int(n_out), lo, hi)
+    rng.bit_generator.advance(int(n_out))
+    if q.numel() == 0:
+        raise RuntimeError("owner-layout resampling left this rank without offspring")
+    return engine.search(cdf, q), var, s1p
+
+
+def owner_layout_ok(engine, comm, rng, method: str, uniform_weights: bool = False) -> bool:
+    """Owner layout needs the multinomial method on a PCG64 generator (the draws are regenerated on every rank)."""
+    return (comm.world > 1 and method == "multinomial" and not uniform_weights and hasattr(engine, "pcg64_select")
+            and pcg64_state(rng) is not None)

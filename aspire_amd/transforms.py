@@ -130,14 +130,14 @@ class CompositeTransform:
         z0 = xt.clone() if self.is_identity else e.transform_forward(xt, t0, want_logj=False)[0]
         if self.affine_transform:
             comm = comm or Comm()
-            n = z0.shape[0]
+            n_glob = z0.shape[0]
             sums = np.asarray(e.colsum(z0), dtype=np.float64)
-            if comm.world > 1:
-                parts = comm.all_gather_f64(sums)
-                sums = parts[0].copy()
+            if comm.world > 1:  # shards may be ragged (owner-layout resampling): the row count travels with the sums
+                parts = comm.all_gather_f64(np.concatenate([sums, [float(n_glob)]]))
+                tot = parts[0].copy()
                 for r in range(1, comm.world):
-                    sums = sums + parts[r]
-            n_glob = n * comm.world
+                    tot = tot + parts[r]
+                sums, n_glob = tot[:-1], int(tot[-1])
             mean = sums / n_glob
             m2 = np.diag(np.asarray(e.centered_gram(z0, mean), dtype=np.float64)).copy()
             if comm.world > 1:

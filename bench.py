@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-flow-leg", action="store_true", help="skip the coupling-flow (configs[2]) extra leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-layout", choices=["owner", "slots"], default="owner",
+                    help="N > 1: offspring stay on the ancestor's rank (default) or single-rank slot order with row exchange")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,14 +115,18 @@ def main():
                     m_one["m"] = sts[0].m
             return [smc_math.ess(s) / n_global for s in sts]
 
-        search_fn = None
         found = {}
-        if world == 1:  # single rank: whole bisection on device (asmc_find_beta); sharded: host-driven k-ary rounds
-            def search_fn(b0, target, tol):
+
+        # whole bisection on device: asmc_find_beta, or its sharded form (reduce -> all-gather -> decide per round)
+        def search_fn(b0, target, tol):
+            if world == 1:
                 b, _, conv, passes, n_nan, trip, trip_one = eng.find_beta(ll, lp, lq, b0, target, tol)
-                assert conv and n_nan == 0
-                found.update(beta=b, trip=trip, one=trip_one)
-                return b, passes
+            else:
+                b, _, conv, passes, n_nan, trip, trip_one = smc_math.find_beta_sharded(eng, comm, ll, lp, lq, b0, target,
+                                                                                      tol, n_global)
+            assert conv and n_nan == 0
+            found.update(beta=b, trip=trip, one=trip_one)
+            return b, passes
 
         beta, _, n_pass = smc_math.determine_beta(eff_fn, 0.0, adaptive=True, beta_step=float("nan"), min_beta_step=0.0,
                                                   max_beta_step=1.0, beta_tolerance=1e-6, adaptive_min_beta_step=False,
@@ -131,9 +137,18 @@ def main():
             st_b, st_1 = smc_math.Stats(*found["trip"], n_global), smc_math.Stats(*found["one"], n_global)
         else:
             st_b, st_1 = smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, [beta, 1.0], n_global)
-        var, s1p = smc_math.evidence_variance_and_lse(eng, comm, ll, lp, lq, 0.0, beta, st_b)
+        if world > 1 and args.shard_layout == "owner":
+            # offspring stay on the ancestor's rank: one all-gather (rank totals + variance partials), no row exchange
+            idx, var, s1p = smc_math.resample_owner(eng, comm, ll, lp, lq, 0.0, beta, n_global, rng,
+                                                    mode=args.resample_mode, st=st_b)
+            if idx is not None:
+                scal.update(beta=beta, ess=smc_math.ess(st_b), ess1=smc_math.ess(st_1),
+                            ratio=smc_math.log_evidence_ratio(st_b), var=var, passes=n_pass, layout="owner")
+                return eng.gather(idx, x, ll, lp, lq)
+        else:
+            var, s1p = smc_math.evidence_variance_and_lse(eng, comm, ll, lp, lq, 0.0, beta, st_b)
         scal.update(beta=beta, ess=smc_math.ess(st_b), ess1=smc_math.ess(st_1), ratio=smc_math.log_evidence_ratio(st_b),
-                    var=var, passes=n_pass)
+                    var=var, passes=n_pass, layout="slots")
         idx, _ = smc_math.resample_indices(eng, comm, ll, lp, lq, 0.0, beta, n_global, rng, mode=args.resample_mode,
                                            st=st_b, s1p=s1p)
         return gather_global(eng, comm, idx, x, ll, lp, lq)
@@ -177,7 +192,7 @@ def main():
         "k_bis_sums": 24 * n_local, "k_weights_m2_lse": 24 * n_local,
         "k_weights_map": 32 * n_local, "k_tile_sum": 8 * n_local, "k_exact_tile_td_launch": 8 * n_local,
         "k_exact_tile_write": 16 * n_local, "k_tile_scan": 16 * n_local, "k_divide": 16 * n_local,
-        "k_pcg64_uniforms": 8 * n_local, "k_search": 24 * n_local, "k_gather16": (2 * (row_b + 24) + 8) * n_local,
+        "k_pcg64_uniforms": 8 * n_local, "k_pcg64_select": 8 * n_local, "k_search": 24 * n_local, "k_gather16": (2 * (row_b + 24) + 8) * n_local,
         # serial dependency chain over tile records (+ the ~log2 N tiles that straddle a binade): latency bound
         "k_exact_chain": 40 * ((n_local + 2047) // 2048) + 16 * 2048 * 12,
     }
@@ -217,9 +232,9 @@ def main():
                    "n_steps_meaning": "temperature iterations (no mutation)", "particles_per_gpu": n_local,
                    "global_particles": n_global, "dims": d, "x_dtype": args.x_dtype, "resample_mode": args.resample_mode,
                    "resample_method": "multinomial", "beta_tolerance": 1e-6, "target_efficiency": 0.5,
-                   "parallelism": f"particle-shard x{world}"},
+                   "parallelism": f"particle-shard x{world}" + (f" ({scal.get('layout')} layout)" if world > 1 else "")},
         "roofline": roofline,
-        "scalars": {k: (float(v) if not isinstance(v, int) else v) for k, v in scal.items()},
+        "scalars": {k: (v if isinstance(v, (int, str)) else float(v)) for k, v in scal.items()},
     }
 
     # ---- extra: mutation path -------------------------------------------------------------------

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 2
+#define ASMC_ABI_VERSION 3
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -45,6 +45,8 @@ extern "C" {
 #define ASMC_F32 1
 
 #define ASMC_MAX_BETAS 32      /* candidate betas evaluated per pass */
+#define ASMC_BIS_REC 40        /* doubles per rank record of the sharded beta search (asmc_find_beta_shard_*) */
+#define ASMC_SELECT_THREADS 65536 /* generator threads of asmc_pcg64_select (fixes the order of the kept draws) */
 #define ASMC_MAX_COMPONENTS 8  /* mixture components of a built-in density */
 #define ASMC_MAX_DIMS 256
 
@@ -133,12 +135,28 @@ int asmc_weights_stats(asmc_ctx* ctx, int64_t n, const double* ll_dev, const dou
  * on the stream, two launches per round; decisions use the same scalar formulas on device.  The round-0
  * pass (beta = 1) finds the exact maximum; later rounds shift their log-sum-exps by
  * m(1) (beta - beta0) / (1 - beta0), which equals the maximum up to rounding (lw is linear in beta).
- * Single-rank only (sharded runs drive the rounds from the host because every pass needs a collective).
+ * Single rank; asmc_find_beta_shard_* below is the sharded form.
  * out_host[13] = {beta_star (= beta_min), beta_max, converged, device rounds, ESS(1.0)/N, n_nan,
  *                m, S1, S2 of the log-sum-exp at beta_star, 1 if that triple is valid, m, S1, S2 at beta = 1}. */
 int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
                    const double* lq_dev, double beta0, double target_eff, double tol,
                    double* out_host, asmc_stream stream);
+/* The same search with the particles sharded over `world` ranks (one process per GPU; the reference has no
+ * distributed mode).  A round is split at the rank boundary and never synchronises with the host:
+ *   asmc_find_beta_shard_reduce  this rank's sums of the round's 16 candidates -> rec_dev[ASMC_BIS_REC]
+ *                                ([0..31] column sums, [32] the shift base they are relative to, [33] NaN log-weights);
+ *   (caller)                     all-gather of the records in rank order (RCCL all_gather_into_tensor on the stream);
+ *   asmc_find_beta_shard_decide  every rank merges recs_dev[world][ASMC_BIS_REC] in rank order, takes the round's four
+ *                                bisection decisions and writes the next candidates (identical on every rank).
+ * Rounds 0, 1, 2, ... until asmc_find_beta_shard_result (the only synchronising call; same out_host[13] as
+ * asmc_find_beta, N = n_global) reports convergence; rounds after convergence are no-ops.  In round 0 the ranks
+ * shift by their local maximum at beta = 1 and the decide step rescales to the global one, so no separate
+ * all-reduce(max) is needed. */
+int asmc_find_beta_shard_reduce(asmc_ctx* ctx, int64_t n_local, const double* ll_dev, const double* lp_dev,
+                                const double* lq_dev, double beta0, int round, double* rec_dev, asmc_stream stream);
+int asmc_find_beta_shard_decide(asmc_ctx* ctx, const double* recs_dev, int world, int64_t n_global, double beta0,
+                                double target_eff, double tol, int round, asmc_stream stream);
+int asmc_find_beta_shard_result(asmc_ctx* ctx, double* out_host, asmc_stream stream);
 int asmc_weights_m2(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
                     const double* lq_dev, double beta0, double beta, double m, double mean_u,
                     double* m2_host, asmc_stream stream);
@@ -148,6 +166,11 @@ int asmc_weights_m2(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double
 int asmc_weights_m2_lse(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
                         const double* lq_dev, double beta0, double beta, double m, double mean_u,
                         double shift, double mp, double* out_host, asmc_stream stream);
+/* ... with the two sums left in device memory (out_dev[2]) and no host synchronisation: sharded runs all-gather them
+ * together with the local cdf total (asmc_cdf_total_dev). */
+int asmc_weights_m2_lse_dev(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
+                            const double* lq_dev, double beta0, double beta, double m, double mean_u,
+                            double shift, double mp, double* out_dev, asmc_stream stream);
 
 /* SMCSamples.log_weights(beta) as an array (samples.py:1244-1249): lw_out = lw(beta) + shift,
  * shift = logsumexp(lw) - log N formed on the host from asmc_weights_stats. */
@@ -181,8 +204,22 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w_dev, double* cdf_dev, int
              double carry_in, double* total_host, asmc_stream stream);
 int asmc_cdf_normalize(asmc_ctx* ctx, int64_t n, double* cdf_dev, double last, asmc_stream stream);
 int asmc_cdf_normalize_last(asmc_ctx* ctx, int64_t n, double* cdf_dev, asmc_stream stream);
+int asmc_cdf_total_dev(asmc_ctx* ctx, double* out_dev, asmc_stream stream); /* total of the last asmc_cdf, device to device */
 int asmc_pcg64_uniforms(asmc_ctx* ctx, const uint64_t state_host[4], uint64_t offset, int64_t n,
                         double* u_dev, asmc_stream stream);
+/* Sharded multinomial resampling with the offspring kept on the ancestor's rank: every rank walks
+ * the SAME n_total draws of the PCG64 stream and keeps those inside its own slice [lo, hi) of the global cdf, mapped
+ * to its local cdf's coordinate q = (u - lo) / (hi - lo) in [0, 1).
+ *   asmc_pcg64_select          generate + filter into stage_dev[asmc_pcg64_select_stage_len(n_total)]; count_host
+ *                              receives the number kept (synchronises);
+ *   asmc_pcg64_select_compact  the kept q's, dense, into q_dev[count].
+ * Order of the kept draws (part of the specification; tests/oracle restate it): draw i is generated by thread
+ * j = i % ASMC_SELECT_THREADS in iteration k = i / ASMC_SELECT_THREADS; kept draws are ordered by (j / 64, k, j % 64). */
+int64_t asmc_pcg64_select_stage_len(int64_t n_total);
+int asmc_pcg64_select(asmc_ctx* ctx, const uint64_t state_host[4], int64_t n_total, double lo, double hi,
+                      double* stage_dev, int64_t* count_host, asmc_stream stream);
+int asmc_pcg64_select_compact(asmc_ctx* ctx, int64_t n_total, const double* stage_dev, double* q_dev,
+                              asmc_stream stream);
 int asmc_systematic_uniforms(asmc_ctx* ctx, int64_t n_out, int64_t j0, int64_t n_total, double u0,
                              const double* v_dev /* NULL: systematic; else stratified */,
                              double* u_dev, asmc_stream stream);

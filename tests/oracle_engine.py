@@ -76,6 +76,80 @@ class OracleEngine:
         s = self.weights_sums(ll, lp, lq, beta0, betas, m)
         return np.column_stack([m, s[:, 0], s[:, 1], np.full(len(m), float(nn))])
 
+    # sharded beta search: numpy restatement of asmc_find_beta_shard_{reduce,decide,result} (include/asmc.h)
+    def find_beta_shard_reduce(self, ll, lp, lq, beta0, rnd, rec):
+        from aspire_amd.smc_math import _bisection_tree
+
+        st = self.__dict__.setdefault("_bis", {})
+        a = (_np(ll) + _np(lp)) - _np(lq)  # Delta_i: lw_i(beta) = (beta - beta0) Delta_i up to rounding
+        if rnd == 0:
+            lw1 = O.unnormalized_log_weights(_np(ll), _np(lp), _np(lq), beta0, 1.0)
+            base, n_nan = float(np.nanmax(lw1)), float(np.isnan(lw1).sum())
+            lo, hi = beta0, 1.0
+        else:
+            if st["done"]:
+                return
+            base, n_nan, lo, hi = st["m_one"], 0.0, st["lo"], st["hi"]
+        betas = _bisection_tree(lo, hi, 4) + [hi]
+        out = np.zeros(40)
+        for k, b in enumerate(betas):
+            lw = O.unnormalized_log_weights(_np(ll), _np(lp), _np(lq), beta0, float(b))
+            with np.errstate(all="ignore"):
+                e = np.exp(lw - base * ((b - beta0) / (1.0 - beta0)))
+            out[2 * k], out[2 * k + 1] = np.sum(e), np.sum(e * e)
+        out[32], out[33] = base, n_nan
+        rec[:] = torch.from_numpy(out)
+        del a
+
+    def find_beta_shard_decide(self, recs, world, n_global, beta0, target_eff, tol, rnd):
+        from aspire_amd.smc_math import Stats, _bisection_tree, ess
+
+        st = self.__dict__.setdefault("_bis", {})
+        if rnd > 0 and st["done"]:
+            return
+        r = _np(recs).reshape(world, 40)
+        m_all = float(r[:, 32].max())
+        if rnd == 0:
+            st.update(lo=beta0, hi=1.0, done=False, rounds=0, m_one=m_all, n_nan=float(r[:, 33].sum()), trip=None)
+        lo, hi = st["lo"], st["hi"]
+        betas = _bisection_tree(lo, hi, 4) + [hi]
+        S = np.zeros(32)
+        for k, b in enumerate(betas):
+            t = (b - beta0) / (1.0 - beta0)
+            for q in range(world):
+                f = np.exp(r[q, 32] * t - m_all * t) if rnd == 0 else 1.0
+                S[2 * k] += r[q, 2 * k] * f
+                S[2 * k + 1] += r[q, 2 * k + 1] * f * f
+        shift = [m_all * ((b - beta0) / (1.0 - beta0)) for b in betas]
+        eff = [ess(Stats(shift[k], S[2 * k], S[2 * k + 1], n_global)) / n_global for k in range(16)]
+        st["rounds"] += 1
+        at_one = False
+        if rnd == 0:
+            st["eff_one"], st["one"] = eff[15], (m_all, S[30], S[31])
+            if eff[15] >= target_eff:
+                lo, at_one, st["trip"] = 1.0, True, (m_all, S[30], S[31])
+        if not at_one:
+            i = 0
+            for _ in range(4):
+                if not (hi - lo > tol):
+                    break
+                if eff[i] >= target_eff:
+                    lo, st["trip"] = betas[i], (shift[i], S[2 * i], S[2 * i + 1])
+                    i = 2 * i + 2
+                else:
+                    hi = betas[i]
+                    i = 2 * i + 1
+        st["lo"], st["hi"] = lo, hi
+        st["done"] = not (hi - lo > tol)
+
+    def find_beta_shard_result(self):
+        st = self._bis
+        return (float(st["lo"]), float(st["eff_one"]), bool(st["done"]), int(st["rounds"]), int(st["n_nan"]), st["trip"],
+                tuple(map(float, st["one"])))
+
+    def pcg64_select(self, state4, n_total, lo, hi):
+        return torch.from_numpy(O.pcg64_select(np.array(state4, dtype=np.uint64), n_total, lo, hi))
+
     def weights_m2(self, ll, lp, lq, beta0, beta, m, mean_u):
         lw = O.unnormalized_log_weights(_np(ll), _np(lp), _np(lq), beta0, beta)
         return float(np.sum((np.exp(lw - m) - mean_u) ** 2))

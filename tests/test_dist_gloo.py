@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, engine_kind="oracle"):
     for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -37,8 +37,14 @@ def _worker(rank, world, port, out_dir):
     from aspire_amd.samples import gather_global
     from aspire_amd.targets import DiagGaussianMixture
 
-    eng = OracleEngine()
-    comm = TorchDistComm(torch.device("cpu"))
+    if engine_kind == "hip":  # tests/test_gpu_dist.py: both ranks share cuda:0, collectives staged through gloo
+        from aspire_amd.engine import HipEngine
+
+        eng = HipEngine(0, n_max=8192, d_max=32)
+        comm = TorchDistComm(eng.device)
+    else:
+        eng = OracleEngine()
+        comm = TorchDistComm(torch.device("cpu"))
     n, d = 4096, 4
     x, ll, lp, lq = synth(n, d, 3)
     lo, hi = rank * n // world, (rank + 1) * n // world
@@ -51,21 +57,52 @@ def _worker(rank, world, port, out_dir):
     # C2/C3: resample, exact and fast
     for mode in ("exact", "fast"):
         idx, j0 = smc_math.resample_indices(eng, comm, loc[1], loc[2], loc[3], 0.0, 0.1, n, np.random.default_rng(5), mode=mode)
-        res["idx_" + mode] = idx.numpy()
+        res["idx_" + mode] = eng.to_numpy(idx)
         res["j0_" + mode] = j0
         if mode == "exact":
             out = gather_global(eng, comm, idx, *loc)
-            res["x_out"] = out[0].numpy()
-            res["ll_out"] = out[1].numpy()
+            res["x_out"] = eng.to_numpy(out[0])
+            res["ll_out"] = eng.to_numpy(out[1])
     # whole sampler, sharded (fused pCN with host-side global adaptation)
     lik = DiagGaussianMixture.isotropic(d, normalized=False)
     sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=2.0, engine=eng, seed=3), xp=np,
                 engine=eng, comm=comm, rng=np.random.default_rng(4))
+    sp.shard_layout = "slots"  # reproduces the single-rank particle order
     post = sp.sample(1024, sampler_kwargs=dict(n_steps=3), store_sample_history=False)
     res["beta"] = np.array(sp.history.beta)
     res["logz"] = float(post.log_evidence)
     res["acc"] = np.array(sp.history.mcmc_acceptance)
-    res["x_post"] = np.asarray(post.x)
+    res["x_post"] = post.x.detach().cpu().numpy() if torch.is_tensor(post.x) else np.asarray(post.x)
+    # ---- owner layout: device-style sharded search, offspring stay on the ancestor's rank ----
+    res["fb"] = np.array(smc_math.find_beta_sharded(eng, comm, loc[1], loc[2], loc[3], 0.0, 0.5, 1e-6, n)[:2])
+    st01 = smc_math.global_stats(eng, comm, loc[1], loc[2], loc[3], 0.0, [0.1], n)[0]
+    idx, var, _ = smc_math.resample_owner(eng, comm, loc[1], loc[2], loc[3], 0.0, 0.1, n, np.random.default_rng(5), st=st01)
+    res["own_idx"] = eng.to_numpy(idx) + lo  # global ancestor ids
+    res["own_var"] = var
+    from aspire_amd.samples import SMCSamples, rebalance_shards
+
+    pop = SMCSamples(x=loc[0], log_likelihood=loc[1], log_prior=loc[2], log_q=loc[3], beta=0.0, xp=torch, engine=eng, comm=comm)
+    new, var2 = pop.resample(0.1, rng=np.random.default_rng(5), want_variance=True)
+    res["own_x"] = eng.to_numpy(new.x)
+    res["own_flags"] = np.array([new.n_global, int(new.ragged), var2 == var])
+    # ragged shards back to equal ones, global order kept
+    xb, llb, _, _ = rebalance_shards(eng, comm, new.x, new.log_likelihood, new.log_prior, new.log_q)
+    res["reb_x"], res["reb_ll"], res["own_ll"] = eng.to_numpy(xb), eng.to_numpy(llb), eng.to_numpy(new.log_likelihood)
+    # a second resampling from the ragged population through the slot layout (systematic has no owner form)
+    again = new.resample(0.3, rng=np.random.default_rng(6), resample_method="systematic")
+    res["again_n"] = np.array([len(again.x), int(bool(again.__dict__.get("ragged")))])
+    # uneven weight shares: rank 1 holds almost all the weight -> every rank falls back to the slot layout
+    ll_skew = loc[1] + (40.0 if rank == 1 else 0.0)
+    pop2 = SMCSamples(x=loc[0], log_likelihood=ll_skew, log_prior=loc[2], log_q=loc[3], beta=0.0, xp=torch, engine=eng, comm=comm)
+    sk = pop2.resample(0.5, rng=np.random.default_rng(7))
+    res["skew"] = np.array([len(sk.x), int(bool(sk.__dict__.get("ragged")))])
+    sp2 = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=2.0, engine=eng, seed=3), xp=np,
+                 engine=eng, comm=comm, rng=np.random.default_rng(4))
+    post2 = sp2.sample(1024, sampler_kwargs=dict(n_steps=3), store_sample_history=False)
+    res["own_beta"] = np.array(sp2.history.beta)
+    res["own_logz"] = float(post2.log_evidence)
+    res["own_logz_err"] = float(post2.log_evidence_error)
+    res["own_n"] = len(post2.x)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -131,3 +168,75 @@ def test_sharded_sampler_matches_single_rank(two_rank_results):
     np.testing.assert_allclose(r0["acc"], sp.history.mcmc_acceptance, atol=1e-12)
     xs = np.concatenate([r0["x_post"], r1["x_post"]])
     np.testing.assert_allclose(xs, np.asarray(post.x), rtol=1e-9, atol=1e-9)
+
+
+def test_sharded_beta_search_matches_host_bisection(two_rank_results):
+    from conftest import synth
+    from oracle_engine import OracleEngine
+
+    from aspire_amd import smc_math
+    from aspire_amd.comm import Comm
+
+    eng = OracleEngine()
+    x, ll, lp, lq = synth(4096, 4, 3)
+    t = [eng.asarray(a) for a in (ll, lp, lq)]
+
+    def eff_fn(betas, closed_form=False):
+        return [smc_math.ess(s) / 4096 for s in smc_math.global_stats(eng, Comm(), *t, 0.0, betas, 4096)]
+
+    beta, _, _ = smc_math.determine_beta(eff_fn, 0.0, adaptive=True, beta_step=float("nan"), min_beta_step=0.0,
+                                         max_beta_step=1.0, beta_tolerance=1e-6, adaptive_min_beta_step=False, target=0.5,
+                                         rate=1.0)
+    r0, r1 = two_rank_results
+    assert np.array_equal(r0["fb"], r1["fb"])
+    assert float(r0["fb"][0]) == beta  # same bisection decisions -> the same float
+
+
+def test_owner_layout_resampling(two_rank_results, oracle):
+    from conftest import synth
+
+    n = 4096
+    x, ll, lp, lq = synth(n, 4, 3)
+    r0, r1 = two_rank_results
+    got = np.sort(np.concatenate([r0["own_idx"], r1["own_idx"]]))
+    assert got.size == n  # the rank slices partition [0, 1): every draw is kept by exactly one rank
+    assert r0["own_idx"].max() < n // 2 <= r1["own_idx"].min()  # offspring stay on the ancestor's rank
+    # the two-level cdf differs from numpy's sequential one only by rounding: the same ancestors up to rare ties
+    ref = np.sort(oracle.resample_indices(ll, lp, lq, 0.0, 0.1, np.random.default_rng(5).random(n)))
+    assert (got != ref).sum() <= 2
+    # independent restatement of the specification (rank totals -> slices -> local cdf), draw order included
+    lw = oracle.unnormalized_log_weights(ll, lp, lq, 0.0, 0.1)
+    m = lw.max()
+    S1 = sum(np.sum(np.exp(lw[a:b] - m)) for a, b in ((0, n // 2), (n // 2, n)))
+    shift = (m + np.log(S1)) - np.log(n)
+    lse = (m + shift) + np.log(S1)
+    cdfs = [np.cumsum(np.exp((lw[a:b] + shift) - lse)) for a, b in ((0, n // 2), (n // 2, n))]
+    edges = np.concatenate([[0.0], np.cumsum([c[-1] for c in cdfs])])
+    cut = float(edges[1] / edges[2])
+    state = oracle.pcg64_state_from_numpy(np.random.default_rng(5))
+    for r, (res, lo_u, hi_u) in enumerate(((r0, 0.0, cut), (r1, cut, 1.0))):
+        q = oracle.pcg64_select(state, n, lo_u, hi_u)
+        want = oracle.searchsorted_right(cdfs[r] / cdfs[r][-1], q) + r * (n // 2)
+        assert np.array_equal(res["own_idx"], want)
+        assert np.array_equal(res["own_x"], x[want])
+    assert float(r0["own_var"]) == pytest.approx(oracle.log_evidence_ratio_variance(ll, lp, lq, 0.0, 0.1), rel=1e-10)
+    for res in (r0, r1):
+        assert res["own_flags"].tolist() == [n, 1, 1]
+        assert res["again_n"].tolist() == [n // 2, 0]  # slot layout hands back equal shards
+        assert res["skew"].tolist() == [n // 2, 0]  # imbalance -> slot layout
+    # rebalancing keeps the global order and yields equal shards
+    allx = np.concatenate([r0["own_x"], r1["own_x"]])
+    assert r0["reb_x"].shape[0] == r1["reb_x"].shape[0] == n // 2
+    assert np.array_equal(np.concatenate([r0["reb_x"], r1["reb_x"]]), allx)
+    assert np.array_equal(np.concatenate([r0["reb_ll"], r1["reb_ll"]]), np.concatenate([r0["own_ll"], r1["own_ll"]]))
+
+
+def test_owner_layout_sampler(two_rank_results):
+    r0, r1 = two_rank_results
+    assert np.array_equal(r0["own_beta"], r1["own_beta"]) and r0["own_beta"][-1] == 1.0
+    assert float(r0["own_logz"]) == float(r1["own_logz"])
+    assert int(r0["own_n"]) + int(r1["own_n"]) == 1024
+    # first temperature: nothing has been permuted yet, the search sees the same population as the slot-layout run
+    assert r0["own_beta"][0] == pytest.approx(r0["beta"][0], rel=1e-12)
+    analytic = 2.0 * np.log(np.pi)  # (d/2) log pi, d = 4
+    assert abs(float(r0["own_logz"]) - analytic) < 5 * float(r0["own_logz_err"]) + 0.05

@@ -1023,3 +1023,81 @@ def test_aspire_prior_bounds_default_flow_transform_gpu(eng, backend):
                                 store_sample_history=False)
     assert np.all(np.abs(np.asarray(post.x)) <= 4.0)
     assert abs(float(post.log_evidence) - true_logz) < 5 * float(post.log_evidence_error) + 0.05, (float(post.log_evidence), true_logz)
+
+
+# ---- sharded building blocks on one GPU: rank records, select kernel ----------------------
+@pytest.mark.parametrize("n,seed,beta0,target", [(4096, 3, 0.0, 0.5), (300001, 21, 0.0, 0.5), (1 << 20, 22, 0.2, 0.7),
+                                                 (50000, 23, 0.0, 0.01)])
+@pytest.mark.parametrize("split", [1, 2, 3])
+def test_find_beta_shard_rounds_match_single_rank_search(eng, n, seed, beta0, target, split):
+    """`split` emulated ranks (separate contexts on the one device, records concatenated by hand in rank order): the
+    merged search takes the single-rank kernel's decisions."""
+    from aspire_amd.engine import HipEngine
+
+    x, ll, lp, lq = synth(n, 4, seed)
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    want = eng.find_beta(lld, lpd, lqd, beta0, target, 1e-6)
+    engines = [eng] + [HipEngine(0, n_max=n, d_max=32) for _ in range(split - 1)]
+    cuts = [r * n // split for r in range(split + 1)]
+    parts = [tuple(t[cuts[r]:cuts[r + 1]].contiguous() for t in (lld, lpd, lqd)) for r in range(split)]
+    recs = [e.empty(40) for e in engines]
+    rounds = max(1, math.ceil(math.log2((1.0 - beta0) / 1e-6) / 4 - 1e-9))
+    for rnd in range(rounds + 1):  # one more than needed: rounds after convergence are no-ops
+        for e, p, rec in zip(engines, parts, recs):
+            e.find_beta_shard_reduce(*p, beta0, rnd, rec)
+        allrec = torch.cat(recs).contiguous()
+        for e in engines:
+            e.find_beta_shard_decide(allrec, split, n, beta0, target, 1e-6, rnd)
+    outs = [e.find_beta_shard_result() for e in engines]
+    for got in outs:
+        assert got[0] == want[0] and got[2] and got[3] == want[3]  # beta*, converged, rounds
+        assert got[1] == pytest.approx(want[1], rel=1e-11)
+        assert (got[5] is None) == (want[5] is None)
+        if got[5] is not None:
+            # local-maximum shifts rescaled to the merged one: same triple up to rounding of the shift
+            assert got[5][0] == pytest.approx(want[5][0], rel=1e-13, abs=1e-13)
+            assert got[5][1] == pytest.approx(want[5][1], rel=1e-11) and got[5][2] == pytest.approx(want[5][2], rel=1e-11)
+        assert got[6][1] == pytest.approx(want[6][1], rel=1e-11)
+    assert all(o == outs[0] for o in outs)  # identical on every rank
+    bad = eng.asarray(np.array([0.0, np.nan, 1.0, 2.0]))
+    z = eng.asarray(np.zeros(4))
+    rec = eng.empty(40)
+    eng.find_beta_shard_reduce(bad, z, z, 0.0, 0, rec)
+    eng.find_beta_shard_decide(rec, 1, 4, 0.0, 0.5, 1e-6, 0)
+    assert eng.find_beta_shard_result()[4] == 1  # NaN census travels in the record
+
+
+@pytest.mark.parametrize("n_total", [1, 63, 1000, 65536, 65537, 300001, 1 << 21])
+def test_pcg64_select_matches_specification(eng, oracle, n_total):
+    from aspire_amd.smc_math import pcg64_state
+
+    for seed, lo, hi in ((0, 0.0, 1.0), (5, 0.0, 0.37), (7, 0.37, 0.9000001), (9, 0.75, 1.0), (11, 0.5, 0.5 + 1e-9)):
+        st = pcg64_state(np.random.default_rng(seed))
+        q = eng.pcg64_select(st, n_total, lo, hi).cpu().numpy()
+        want = oracle.pcg64_select(st, n_total, lo, hi)
+        assert np.array_equal(q, want)
+        assert q.size == 0 or (q.min() >= 0.0 and q.max() < 1.0)
+    # the slices of a partition of [0, 1) keep every draw exactly once
+    st = pcg64_state(np.random.default_rng(3))
+    cuts = [0.0, 0.124, 0.5, 0.500001, 1.0]
+    assert sum(eng.pcg64_select(st, n_total, a, b).numel() for a, b in zip(cuts[:-1], cuts[1:])) == n_total
+
+
+def test_device_resident_partials_match_host_variants(eng):
+    n = 200003
+    x, ll, lp, lq = synth(n, 4, 31)
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    from aspire_amd import smc_math
+    from aspire_amd.comm import Comm
+
+    st = smc_math.global_stats(eng, Comm(), lld, lpd, lqd, 0.0, [0.2], n)[0]
+    shift = float((st.m + np.log(st.S1)) - math.log(n))
+    mp_ = st.m + shift
+    host = eng.weights_m2_lse(lld, lpd, lqd, 0.0, 0.2, st.m, st.S1 / n, shift, mp_)
+    rec = eng.empty(4)
+    eng.weights_m2_lse_dev(lld, lpd, lqd, 0.0, 0.2, st.m, st.S1 / n, shift, mp_, rec)
+    w = eng.normalized_weights(lld, lpd, lqd, 0.0, 0.2, shift, mp_ + math.log(st.S1))
+    _, total = eng.cdf(w, "exact", 0.0)
+    eng.cdf_total_dev(rec[2:])
+    got = rec.cpu().numpy()
+    assert got[0] == host[0] and got[1] == host[1] and got[2] == total
