@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-flow-leg", action="store_true", help="skip the coupling-flow (configs[2]) extra leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded-extras", action="store_true", help="N > 1: also run the full-sampler extra legs")
     ap.add_argument("--shard-layout", choices=["owner", "slots"], default="owner",
                     help="N > 1: offspring stay on the ancestor's rank (default) or single-rank slot order with row exchange")
     args = ap.parse_args()
@@ -259,6 +260,10 @@ def main():
                                "alg_bytes_per_step": b_step, "achieved_GBs": round(b_step / (ms * 1e-3) / 1e9, 1),
                                "frac_of_hbm_peak": round(b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "mean_accept": float(n_acc.mean() / n_local), "rho_final": rho, "noise": args.noise}
+        result["extra"] = extra
+    # The full-sampler legs issue many more collectives than the headline step; at N > 1 they only run on request, so
+    # that the scaling line cannot be lost to them (tools/rig2.sh exercises them with two ranks on one GPU).
+    if not args.no_extra and (world == 1 or args.sharded_extras):
         # one full sampler run (configs[2] shape with the analytic proposal): log-evidence check
         sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=sigma_q, seed=1, engine=eng, dtype=xdt),
                     xp=np, engine=eng, comm=comm, rng=np.random.default_rng(2), dtype=args.x_dtype.replace("f", "float"))

@@ -1,3 +1,3 @@
 cd /root/repo
 export ASMC_BENCH_BACKEND=gloo ASMC_BENCH_DEVICE=0
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 2 --no-flow-leg --no-cpu-baseline 2>&1 | grep -v 'hostname of the client\|amdgpu.ids' | head -80
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 2 --no-cpu-baseline --sharded-extras ${RIG_ARGS:-} 2>&1 | grep -v 'hostname of the client\|amdgpu.ids' | head -80
