@@ -21,6 +21,7 @@ ASMC_NOISE_F64, ASMC_NOISE_F32 = 0, 1
 ASMC_MAX_BETAS = 32
 ASMC_MAX_COMPONENTS = 8
 ASMC_MAX_DIMS = 256
+COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 65536
 ASMC_ABI_VERSION = 3
@@ -101,6 +102,7 @@ SIGNATURES = {
     "asmc_weights_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _pd, _i, _pd, _vp]),
     "asmc_weights_m2_lse": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _d, _d, _pd, _vp]),
     "asmc_find_beta": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _pd, _vp]),
+    "asmc_pcn_set_count_hook": (_i, [_vp, _vp, _vp, _vp, _i64]),
     "asmc_find_beta_shard_reduce": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _i, _vp, _vp]),
     "asmc_find_beta_shard_decide": (_i, [_vp, _vp, _i, _i64, _d, _d, _d, _i, _vp]),
     "asmc_find_beta_shard_result": (_i, [_vp, _pd, _vp]),

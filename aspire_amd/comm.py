@@ -38,6 +38,9 @@ class Comm:
     def all_to_all_rows(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int]) -> torch.Tensor:
         return send
 
+    def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
     def barrier(self):
         pass
 
@@ -99,6 +102,16 @@ class TorchDistComm(Comm):
         self.dist.all_to_all_single(out, send, output_split_sizes=list(map(int, recv_counts)),
                                     input_split_sizes=list(map(int, send_counts)), group=self.group)
         return out
+
+    def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place sum over ranks, enqueued on the current stream (no host synchronisation with RCCL)."""
+        if self._stage and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return t
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
 
     def barrier(self):
         self.dist.barrier(group=self.group)

@@ -76,6 +76,11 @@ struct asmc_ctx {
     long long* d_select;           // [2 * ASMC_SELECT_THREADS/64 + 8] wave counts, offsets, total of asmc_pcg64_select
     double* d_ptab;                // [2*32*32 + 32 + 3*8*(1+2*32)] packed pCN parameter block (d <= 32)
     double* d_mmtab;               // [2 * 144 * 64] MFMA operand images of L and Linv (d = 64 / 128; NULL when d_max < 64)
+    // sharded mutation: accept-count exchange between a step and its adaptation (asmc_pcn_set_count_hook)
+    int (*count_hook)(void*, asmc_stream);
+    void* count_hook_user;
+    long long* count_cell;
+    int64_t count_n_global;
     int64_t n_tiles_max;
     int gram_blocks;
     unsigned long long pcg_inc[2];  // increment the device jump table was built for

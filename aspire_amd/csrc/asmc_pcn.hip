@@ -657,6 +657,42 @@ __global__ __launch_bounds__(1024) void k_pcn_adapt(int nblocks, const long long
     }
 }
 
+__global__ __launch_bounds__(1024) void k_count_sum(int nblocks, const long long* __restrict__ block_counts,
+                                                   long long* __restrict__ cell) {
+    __shared__ long long s_c[16];
+    long long c = 0;
+    for (int b = threadIdx.x; b < nblocks; b += 1024) c += block_counts[b];
+    c = wave_sum_ll(c);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c = 0;
+        for (int w = 0; w < 16; w++) c += s_c[w];
+        cell[0] = c;
+    }
+}
+
+// closes step t: accept count (summed across ranks through the exchange hook when one is installed), history, adaptation
+static int pcn_close_step(asmc_ctx* ctx, hipStream_t st, int grid, const long long* d_block, int64_t n, int t,
+                          long long* d_counts, double* d_rho, double* d_rho_hist, double target, int adapt) {
+    if (ctx->count_hook) {
+        ASMC_LAUNCH(ctx, st, "k_count_sum", k_count_sum, dim3(1), dim3(1024), 0, st, grid, d_block, ctx->count_cell);
+        ASMC_LAUNCH_CHECK();
+        const int hrc = ctx->count_hook(ctx->count_hook_user, reinterpret_cast<asmc_stream>(st));
+        if (hrc != 0) {
+            asmc_set_error("accept-count exchange hook failed (%d)", hrc);
+            return ASMC_ERR_ARG;
+        }
+        ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, 1, (const long long*)ctx->count_cell,
+                    ctx->count_n_global, t, d_counts, d_rho, d_rho_hist, target, adapt);
+    } else {
+        ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, grid, d_block, n, t, d_counts, d_rho,
+                    d_rho_hist, target, adapt);
+    }
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
 // split-path accept: per particle decision + scalar update, then a flat conditional row copy
 __global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_accept_flags(
     int64_t n, double* __restrict__ ll, double* __restrict__ lp, double* __restrict__ lq,
@@ -1284,6 +1320,16 @@ int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
     return ASMC_OK;
 }
 
+int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int64_t* cell_dev, int64_t n_global) {
+    ASMC_REQUIRE(ctx != nullptr, "null ctx");
+    ASMC_REQUIRE(hook == nullptr || (cell_dev != nullptr && n_global > 0), "hook needs a device cell and n_global > 0");
+    ctx->count_hook = hook;
+    ctx->count_hook_user = user;
+    ctx->count_cell = reinterpret_cast<long long*>(cell_dev);
+    ctx->count_n_global = n_global;
+    return ASMC_OK;
+}
+
 int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq,
                     const asmc_pcn_params* prm, int n_steps, uint32_t step0, double* rho_inout_host,
                     int64_t* n_accept_host, double* rho_hist_host, asmc_stream stream) {
@@ -1335,9 +1381,8 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
         for (int t = 0; t < n_steps; t++) {
             rc = asmc_pcn_mm_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, MM_STEP, d_rho, step0 + (uint32_t)t, d_block, &grid, st);
             if (rc) return rc;
-            ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, grid, (const long long*)d_block, n, t, d_counts,
-                        d_rho, d_rho_hist, prm->target_accept, prm->adapt);
-            ASMC_LAUNCH_CHECK();
+            rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+            if (rc) return rc;
         }
         rc = asmc_pcn_mm_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, MM_UNWHITEN, d_rho, 0, d_block, &grid, st);
         if (rc) return rc;
@@ -1380,9 +1425,8 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     for (int t = 0; t < n_steps; t++) {
         rc = launch_mode(y_state ? PCN_Y_STEP : PCN_X_STEP, step0 + (uint32_t)t, &grid);
         if (rc) return rc;
-        ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, grid, (const long long*)d_block, n, t, d_counts,
-                    d_rho, d_rho_hist, prm->target_accept, prm->adapt);
-        ASMC_LAUNCH_CHECK();
+        rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+        if (rc) return rc;
     }
     if (y_state) {
         rc = launch_mode(PCN_UNWHITEN, 0, &grid);
@@ -1556,9 +1600,8 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
                 rc = dispatch_pcn_reg_flow<float, PCN_FLOW_ACCEPT>(ctx, n, (float*)x, (float*)x_prop, ll, lp, lq, ll_new, lp_new,
                                                                    lq_new, pd, d_rho, step, d_block, &grid, st);
             if (rc) return rc;
-            ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, grid, (const long long*)d_block, n, t, d_counts,
-                        d_rho, d_rho_hist, prm->target_accept, prm->adapt);
-            ASMC_LAUNCH_CHECK();
+            rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+            if (rc) return rc;
         }
         rc = convert(PCN_UNWHITEN_X);
         if (rc) return rc;
@@ -1594,9 +1637,8 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
             ASMC_LAUNCH(ctx, st, "k_copy_flagged_rows<float>", k_copy_flagged_rows<float>, dim3(g2), dim3(ASMC_BLOCK), 0, st,
                         n, d, (float*)x, (const float*)x_prop, (const unsigned char*)flags);
         ASMC_LAUNCH_CHECK();
-        ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, 1, (const long long*)d_cnt, n, t, d_counts,
-                    d_rho, d_rho_hist, prm->target_accept, prm->adapt);
-        ASMC_LAUNCH_CHECK();
+        rc = pcn_close_step(ctx, st, 1, (const long long*)d_cnt, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+        if (rc) return rc;
     }
     long long* h_counts = reinterpret_cast<long long*>(ctx->h_pinned);
     double* h_rho_hist = ctx->h_pinned + ASMC_MAX_PCN_STEPS + 8;

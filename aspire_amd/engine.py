@@ -464,6 +464,30 @@ class HipEngine:
               "asmc_centered_gram")
         return out
 
+    def set_count_hook(self, comm, n_global: int | None):
+        """Sharded mutation: let `pcn_mutate` / `pcn_mutate_flow` adapt the step size from the GLOBAL acceptance rate
+        with the whole step loop enqueued on the stream - after each step the library leaves this rank's accept
+        count in a device cell and calls back; the callback all-reduces the cell over `comm` (RCCL, on the stream).
+        `n_global=None` (or a single-rank comm) removes the hook.  Accept counts returned afterwards are global."""
+        if n_global is None or comm is None or comm.world == 1:
+            check(self.lib.asmc_pcn_set_count_hook(self._ctx, None, None, None, 0), "asmc_pcn_set_count_hook")
+            self._hook = None
+            return
+        cell = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+        def cb(_user, _stream):
+            try:
+                comm.all_reduce_sum_(cell)
+                return 0
+            except Exception as exc:  # exceptions must not unwind through the C frames
+                self._hook_error = exc
+                return 1
+
+        fn = _lib.COUNT_HOOK(cb)
+        self._hook = (fn, cell, cb)  # keep the trampoline and the cell alive while installed
+        check(self.lib.asmc_pcn_set_count_hook(self._ctx, ctypes.cast(fn, ctypes.c_void_p), None, _dptr(cell), int(n_global)),
+              "asmc_pcn_set_count_hook")
+
     def pcn_mutate(self, x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed, gid0, rho, n_steps, step0=0,
                    target_accept=0.234, adapt=True, noise="f64"):
         """n_steps fused pCN steps in place.  Returns (n_accept[n_steps], rho_hist[n_steps], rho_out)."""

@@ -487,11 +487,26 @@ class HipSMC(SMCSampler):
         step0 = st["step"]
         acc_rates = []
         dev_flow = self._device_flow()
+        # whole step loop on the device: always for one rank; sharded when the engine can exchange the accept counts
+        # between a step and its adaptation on the stream (asmc_pcn_set_count_hook), else one host round trip per step
+        on_device = comm.world == 1 or hasattr(e, "set_count_hook")
+        if comm.world > 1 and on_device:
+            e.set_count_hook(comm, n_global)
+        try:
+            return self._mutate_steps(particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0,
+                                      acc_rates, dev_flow, on_device, n_local, n_global, gid0)
+        finally:
+            if comm.world > 1 and on_device:
+                e.set_count_hook(None, None)
+
+    def _mutate_steps(self, particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0, acc_rates,
+                      dev_flow, on_device, n_local, n_global, gid0):
+        e, comm = self.engine, self.comm
         if self._flow_fused_ok(dev_flow):
             # flow proposal density evaluated on the MFMA inside the device-side step loop (BASELINE config 3)
             t_ll = self._log_likelihood.device_mixture(e)
             t_lp = self._log_prior.device_mixture(e)
-            if comm.world == 1:
+            if on_device:
                 done = 0
                 while done < n_steps:
                     chunk = min(n_steps - done, 2048)
@@ -512,7 +527,7 @@ class HipSMC(SMCSampler):
             t_ll = self._log_likelihood.device_mixture(e)
             t_lp = self._log_prior.device_mixture(e)
             t_lq = self.prior_flow.device_mixture(e)
-            if comm.world == 1:
+            if on_device:
                 done = 0
                 while done < n_steps:
                     chunk = min(n_steps - done, 2048)

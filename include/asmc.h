@@ -253,13 +253,20 @@ int asmc_compact_valid(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
  * asmc_pcn_mutate: n_steps fused pCN steps (propose + built-in target + accept) in place.
  *   rho_inout_host: step size in/out; n_accept_host[n_steps] accepted counts per step
  *   (LOCAL particles); rho_hist_host[n_steps] step size used at each step (may be NULL).
- *   With params->adapt the step size is adapted on device from the LOCAL acceptance rate
- *   (single-GPU); sharded runs call with n_steps=1 and adapt on the host after an all-reduce.
+ *   With params->adapt the step size is adapted on device after every step, from the LOCAL acceptance rate
+ *   or - sharded runs - from the GLOBAL one once asmc_pcn_set_count_hook has installed an exchange hook.
+ * asmc_pcn_set_count_hook: sharded mutation without host round trips.  After each step's kernel the library sums
+ *   this rank's accept count into cell_dev[0] (int64) and calls hook(user, stream); the hook must enqueue an in-place
+ *   SUM of cell_dev over all ranks on `stream` (RCCL all-reduce) and return 0.  The adaptation kernel then divides by
+ *   n_global, and n_accept_host reports GLOBAL counts.  hook == NULL removes it.  Applies to asmc_pcn_mutate and
+ *   asmc_pcn_mutate_flow.
  * asmc_pcn_propose / asmc_pcn_accept: the split form for arbitrary Python callables / torch flows
  *   (the host evaluates log_q, log_prior, log_likelihood on x_prop between the two calls,
  *   reference smc/base.py:507-519).  logj_old_dev / logj_new_dev (both or neither): log|det J| of the
  *   preconditioning transform at the current / proposed state, added to the tempered log-target
  *   (smc/base.py:515-517); logj_old_dev is updated in place for accepted particles. */
+typedef int (*asmc_count_hook)(void* user, asmc_stream stream);
+int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int64_t* cell_dev, int64_t n_global);
 int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, double* sum_host,
                 asmc_stream stream);
 int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
