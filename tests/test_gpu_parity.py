@@ -1101,3 +1101,24 @@ def test_device_resident_partials_match_host_variants(eng):
     eng.cdf_total_dev(rec[2:])
     got = rec.cpu().numpy()
     assert got[0] == host[0] and got[1] == host[1] and got[2] == total
+
+
+def test_pcg64_select_at_eight_rank_scale(eng, oracle):
+    """BASELINE config 4: 8 ranks x 1M particles -> every rank walks 8M draws and keeps its eighth."""
+    from aspire_amd.smc_math import pcg64_state
+
+    n_total = 8_000_000
+    st = pcg64_state(np.random.default_rng(17))
+    g = np.random.default_rng(1)
+    t = 1.0 + 1e-3 * g.normal(size=8)  # rank totals: equal shares +- 0.1 %
+    edges = np.concatenate([[0.0], np.cumsum(t)])
+    cuts = edges / edges[-1]
+    cuts[0], cuts[-1] = 0.0, 1.0
+    sizes = []
+    for r in range(8):
+        q = eng.pcg64_select(st, n_total, float(cuts[r]), float(cuts[r + 1]))
+        sizes.append(q.numel())
+        if r in (0, 5):
+            assert np.array_equal(q.cpu().numpy(), oracle.pcg64_select(st, n_total, float(cuts[r]), float(cuts[r + 1])))
+    assert sum(sizes) == n_total
+    assert max(abs(s - n_total / 8) for s in sizes) < 0.01 * n_total / 8
