@@ -24,7 +24,7 @@ ASMC_MAX_DIMS = 256
 COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 65536
-ASMC_ABI_VERSION = 3
+ASMC_ABI_VERSION = 4
 
 
 class AsmcMixture(ctypes.Structure):
@@ -53,6 +53,7 @@ class AsmcPcnParams(ctypes.Structure):
         ("target_accept", c_double),
         ("adapt", c_int32),
         ("noise", c_int32),
+        ("nu", c_double),
     ]
 
 
@@ -131,7 +132,7 @@ SIGNATURES = {
         _i,
         [_vp, _i64, _vp, _vp, _vp, _vp, POINTER(AsmcPcnParams), _i, _u32, _pd, _pi64, _pd, _vp],
     ),
-    "asmc_pcn_propose": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _u64, _u64, _u32, _vp]),
+    "asmc_pcn_propose": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _u64, _u64, _u32, _vp]),
     "asmc_pcn_accept": (
         _i,
         [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _u64, _u64, _u32, _pi64, _vp],

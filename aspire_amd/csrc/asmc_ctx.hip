@@ -126,6 +126,7 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     if (d_max >= 64) dmalloc((void**)&c->d_mmtab, sizeof(double) * 2 * 144 * 64);
     dmalloc((void**)&c->d_guide, sizeof(unsigned int) * ((size_t)n_max / 4 + 8));
     dmalloc((void**)&c->d_flags, (size_t)n_max + 64);
+    dmalloc((void**)&c->d_gamma, sizeof(double) * (size_t)n_max);
     dmalloc((void**)&c->d_counts, sizeof(long long) * (size_t)(ASMC_MAX_PCN_STEPS + ASMC_MAX_BLOCKS + n_max / 64 + 8));
     dmalloc((void**)&c->d_rho, sizeof(double) * (ASMC_MAX_PCN_STEPS + 8));
     dmalloc((void**)&c->d_pcgtab, sizeof(unsigned long long) * (64 * 4 + 8));
@@ -153,6 +154,7 @@ int asmc_ctx_destroy(asmc_ctx* c) {
     if (c->d_mmtab) (void)hipFree(c->d_mmtab);
     (void)hipFree(c->d_guide);
     (void)hipFree(c->d_flags);
+    (void)hipFree(c->d_gamma);
     (void)hipFree(c->d_counts);
     (void)hipFree(c->d_rho);
     (void)hipFree(c->d_pcgtab);

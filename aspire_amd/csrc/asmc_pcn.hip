@@ -97,16 +97,17 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_step(
                 v[j * 64] = s;
                 q0 = fma(s, s, q0);
             }
-            // y' = a y + rho xi, q1 = |y'|^2
+            // y' = a y + rho sqrt(s) xi (s = 1 for the Gaussian reference), q1 = |y'|^2
             double q1 = 0.0;
+            const double rs = tpcn_scale(rho, p.nu, q0, p.gam, i);
             for (int pr = 0; 2 * pr < d; pr++) {
                 double z0, z1;
                 normal_pair(p.seed, gid, step, (uint32_t)pr, z0, z1);
-                double y0 = fma(rho, z0, a * v[(2 * pr) * 64]);
+                double y0 = fma(rs, z0, a * v[(2 * pr) * 64]);
                 v[(2 * pr) * 64] = y0;
                 q1 = fma(y0, y0, q1);
                 if (2 * pr + 1 < d) {
-                    double y1 = fma(rho, z1, a * v[(2 * pr + 1) * 64]);
+                    double y1 = fma(rs, z1, a * v[(2 * pr + 1) * 64]);
                     v[(2 * pr + 1) * 64] = y1;
                     q1 = fma(y1, y1, q1);
                 }
@@ -119,8 +120,9 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_step(
                 v[j * 64] = (double)(T)(p.mu[j] + s);
             }
             if (PHASE == 1) {
-                qf_old[i] = q0;
-                qf_new[i] = q1;
+                // the accept kernel adds half of these to the tempered log-targets: twice the reference's correction
+                qf_old[i] = 2.0 * ref_corr(q0, p.nu, d);
+                qf_new[i] = 2.0 * ref_corr(q1, p.nu, d);
                 for (int j = 0; j < d; j++) row_set<T>(myrow, j, v[j * 64]);
             } else {
                 // the old row is still in `myrow`; stage x' into it only on acceptance, so evaluate
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_step(
                 }
                 const double lpn = log_p_t(nll, nlp, nlq, p.beta);
                 const double lpo = log_p_t(oll, olp, olq, p.beta);
-                const double log_a = (lpn + 0.5 * q1) - (lpo + 0.5 * q0);
+                const double log_a = (lpn + ref_corr(q1, p.nu, d)) - (lpo + ref_corr(q0, p.nu, d));
                 const double u = accept_uniform(p.seed, gid, step);
                 acc = log(u) < log_a;
                 if (acc) {
@@ -272,6 +274,8 @@ __device__ __forceinline__ double mixture_eval_regs(const MixDev& m, const doubl
 #define PTAB_SIZE(D) (2 * PTAB_TRI(D) + (D) + 3 * PTAB_MIX(D))
 struct PcnScalars {
     double beta;
+    double nu;  // Student-t degrees of freedom of the reference (tpCN) or <= 0 (Gaussian pCN)
+    const double* gam;  // per-particle Gamma((d + nu)/2, 1) variates of this step (k_gamma_draw), nullptr for pCN
     unsigned long long seed, gid0;
     int c_ll, c_lp, c_lq;
 };
@@ -315,6 +319,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 #define PCN_WHITEN 2
 #define PCN_UNWHITEN 3
 #define PCN_UNWHITEN_X 4  // y -> x in place, carried ll/lp/lq untouched (flow-proposal path)
+#define PCN_X_STEP_T 5    // PCN_X_STEP / PCN_Y_STEP with the Student-t reference (tpCN), selected at compile time
+#define PCN_Y_STEP_T 6
 
 template <typename T, int D, int NOISE, int MODE>
 __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restrict__ x, double* __restrict__ ll,
@@ -323,6 +329,8 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
                                                           const double* __restrict__ rho_ptr, uint32_t step,
                                                           long long* __restrict__ block_counts) {
     extern __shared__ __align__(16) char smem[];
+    constexpr bool TP = MODE == PCN_X_STEP_T || MODE == PCN_Y_STEP_T;
+    constexpr int M = TP ? MODE - PCN_X_STEP_T : MODE;
     constexpr int ROWB = D * (int)sizeof(T);
     constexpr int LDSROW = ROWB + 16;
     const int WPB = (int)(blockDim.x >> 6);  // waves per block: chosen by the launcher from the LDS budget
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
         char* gbase = reinterpret_cast<char*>(x) + row0 * ROWB;
         if (active) tile_load<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane);
         double oll = 0.0, olp = 0.0, olq = 0.0;
-        if (valid && (MODE == PCN_X_STEP || MODE == PCN_Y_STEP)) {
+        if (valid && (M == PCN_X_STEP || M == PCN_Y_STEP)) {
             oll = ll[i];
             olp = lp[i];
             olq = lq[i];
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
             const unsigned long long gid = p.gid0 + (unsigned long long)i;
             double v[D];
             row_to_regs<T, D>(myrow, v);
-            if (MODE == PCN_WHITEN) {
+            if (M == PCN_WHITEN) {
 #pragma unroll
                 for (int j = 0; j < D; j++) v[j] -= mup[j];
                 tri_matvec_inplace<D>(Lip, v);
@@ -375,11 +383,11 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
                 for (int j = 0; j < D; j++) v[j] = (double)(T)v[j];
                 regs_to_row<T, D>(myrow, v);
                 acc = true;
-            } else if (MODE == PCN_UNWHITEN || MODE == PCN_UNWHITEN_X) {
+            } else if (M == PCN_UNWHITEN || M == PCN_UNWHITEN_X) {
                 tri_matvec_inplace<D>(Lp, v);
 #pragma unroll
                 for (int j = 0; j < D; j++) v[j] = (double)(T)(mup[j] + v[j]);
-                if (MODE == PCN_UNWHITEN) {
+                if (M == PCN_UNWHITEN) {
                     ll[i] = mixture_eval_regs<D>(mll, v);
                     lp[i] = mixture_eval_regs<D>(mlp, v);
                     lq[i] = mixture_eval_regs<D>(mlq, v);
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
                 acc = true;
             } else {
                 double q0 = 0.0;
-                if (MODE == PCN_X_STEP) {
+                if (M == PCN_X_STEP) {
 #pragma unroll
                     for (int j = 0; j < D; j++) v[j] -= mup[j];
                     // y = Linv (x - mu), in place, 4 interleaved FMA chains per row group
@@ -398,16 +406,17 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
                 }
 #pragma unroll
                 for (int j = 0; j < D; j++) q0 = fma(v[j], v[j], q0);
-                // y' = a y + rho xi (rounded to the storage type when y is what gets stored); q1 = |y'|^2
+                // y' = a y + rho sqrt(s) xi (rounded to the storage type when y is what gets stored); q1 = |y'|^2
                 double q1 = 0.0;
+                const double rs = tpcn_scale_ct<TP>(rho, p.nu, q0, p.gam, i);
                 if (NOISE == ASMC_NOISE_F64) {
 #pragma unroll
                     for (int pr = 0; pr < D / 2; pr++) {
                         double z0, z1;
                         normal_pair(p.seed, gid, step, (uint32_t)pr, z0, z1);
-                        v[2 * pr] = fma(rho, z0, a * v[2 * pr]);
-                        v[2 * pr + 1] = fma(rho, z1, a * v[2 * pr + 1]);
-                        if (MODE == PCN_Y_STEP) {
+                        v[2 * pr] = fma(rs, z0, a * v[2 * pr]);
+                        v[2 * pr + 1] = fma(rs, z1, a * v[2 * pr + 1]);
+                        if (M == PCN_Y_STEP) {
                             v[2 * pr] = (double)(T)v[2 * pr];
                             v[2 * pr + 1] = (double)(T)v[2 * pr + 1];
                         }
@@ -426,15 +435,15 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
 #endif
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
-                            v[4 * qd + e] = fma(rho, z[e], a * v[4 * qd + e]);
-                            if (MODE == PCN_Y_STEP) v[4 * qd + e] = (double)(T)v[4 * qd + e];
+                            v[4 * qd + e] = fma(rs, z[e], a * v[4 * qd + e]);
+                            if (M == PCN_Y_STEP) v[4 * qd + e] = (double)(T)v[4 * qd + e];
                             q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
                         }
                         if (qd & 1) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 double nll, nlp, nlq;
-                if (MODE == PCN_X_STEP) {
+                if (M == PCN_X_STEP) {
                     // x' = mu + L y', rounded to the storage type
 #ifndef ASMC_ABLATE_MATVEC
                     tri_matvec_inplace<D>(Lp, v);
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
                 }
                 const double lpn = log_p_t(nll, nlp, nlq, p.beta);
                 const double lpo = log_p_t(oll, olp, olq, p.beta);
-                const double log_a = (lpn + 0.5 * q1) - (lpo + 0.5 * q0);
+                const double log_a = (lpn + ref_corr_ct<TP>(q1, p.nu, D)) - (lpo + ref_corr_ct<TP>(q0, p.nu, D));
                 const double u = accept_uniform(p.seed, gid, step);
                 acc = log(u) < log_a;
                 if (acc) {
@@ -497,7 +506,7 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
         }
         wave_lds_sync();
     }
-    if (MODE == PCN_X_STEP || MODE == PCN_Y_STEP) {
+    if (M == PCN_X_STEP || M == PCN_Y_STEP) {
         __shared__ long long s_cnt[ASMC_BLOCK / 64];
         n_acc = wave_sum_ll(n_acc);
         if (lane == 0) s_cnt[wave] = n_acc;
@@ -561,13 +570,14 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
             double q0 = 0.0, q1 = 0.0;
 #pragma unroll
             for (int j = 0; j < D; j++) q0 = fma(v[j], v[j], q0);
+            const double rs = tpcn_scale(rho, p.nu, q0, p.gam, i);  // the same variate in both modes
             if (NOISE == ASMC_NOISE_F64) {
 #pragma unroll
                 for (int pr = 0; pr < D / 2; pr++) {
                     double z0, z1;
                     normal_pair(p.seed, gid, step, (uint32_t)pr, z0, z1);
-                    v[2 * pr] = (double)(T)fma(rho, z0, a * v[2 * pr]);
-                    v[2 * pr + 1] = (double)(T)fma(rho, z1, a * v[2 * pr + 1]);
+                    v[2 * pr] = (double)(T)fma(rs, z0, a * v[2 * pr]);
+                    v[2 * pr + 1] = (double)(T)fma(rs, z1, a * v[2 * pr + 1]);
                     q1 = fma(v[2 * pr], v[2 * pr], q1);
                     q1 = fma(v[2 * pr + 1], v[2 * pr + 1], q1);
                     __builtin_amdgcn_sched_barrier(0);
@@ -579,7 +589,7 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
                     normal_quad_f32(p.seed, gid, step, (uint32_t)qd, z[0], z[1], z[2], z[3]);
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        v[4 * qd + e] = (double)(T)fma(rho, z[e], a * v[4 * qd + e]);
+                        v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
                         q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
                     }
                     if (qd & 1) __builtin_amdgcn_sched_barrier(0);
@@ -596,7 +606,7 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
             } else {
                 const double lpn = log_p_t(nll, nlp, nlq, p.beta);
                 const double lpo = log_p_t(oll, olp, olq, p.beta);
-                const double log_a = (lpn + 0.5 * q1) - (lpo + 0.5 * q0);
+                const double log_a = (lpn + ref_corr(q1, p.nu, D)) - (lpo + ref_corr(q0, p.nu, D));
                 const double u = accept_uniform(p.seed, gid, step);
                 acc = log(u) < log_a;
                 if (acc) {
@@ -627,6 +637,29 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
             block_counts[blockIdx.x] = tsum;
         }
     }
+}
+
+// tpCN: unit-scale Gamma(shape) variate of every particle for Markov step `step` (Marsaglia-Tsang, counter based)
+__global__ __launch_bounds__(ASMC_BLOCK) void k_gamma_draw(int64_t n, double shape, unsigned long long seed,
+                                                          unsigned long long gid0, uint32_t step,
+                                                          double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride)
+        out[i] = gamma_unit(shape, seed, gid0 + (unsigned long long)i, step);
+}
+
+// before a step kernel: draws the step's scale variates into ctx->d_gamma and points pd.gam at them (tpCN only)
+static int pcn_prepare_gamma(asmc_ctx* ctx, int64_t n, PcnDev& pd, uint32_t step, hipStream_t st) {
+    if (!(pd.nu > 0.0)) {
+        pd.gam = nullptr;
+        return ASMC_OK;
+    }
+    const int grid = grid_for(n, ASMC_BLOCK, ASMC_MAX_BLOCKS * 4);
+    ASMC_LAUNCH(ctx, st, "k_gamma_draw", k_gamma_draw, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, 0.5 * ((double)pd.d + pd.nu),
+                (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma);
+    ASMC_LAUNCH_CHECK();
+    pd.gam = ctx->d_gamma;
+    return ASMC_OK;
 }
 
 // sums the per-block accept counts of step `t`, records them, adapts the step size
@@ -1029,12 +1062,14 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     }
     PcnScalars ps;
     ps.beta = pd.beta;
+    ps.nu = pd.nu;
+    ps.gam = pd.gam;
     ps.seed = pd.seed;
     ps.gid0 = pd.gid0;
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
-    ASMC_LAUNCH(ctx, st, MODE == PCN_X_STEP ? "k_pcn_reg" : MODE == PCN_Y_STEP ? "k_pcn_reg_y" : MODE == PCN_WHITEN ? "k_pcn_whiten" : "k_pcn_unwhiten", kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
+    ASMC_LAUNCH(ctx, st, MODE == PCN_X_STEP ? "k_pcn_reg" : MODE == PCN_Y_STEP ? "k_pcn_reg_y" : MODE == PCN_X_STEP_T ? "k_tpcn_reg" : MODE == PCN_Y_STEP_T ? "k_tpcn_reg_y" : MODE == PCN_WHITEN ? "k_pcn_whiten" : "k_pcn_unwhiten", kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
                        rho_ptr, step, block_counts);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -1063,6 +1098,8 @@ static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double
     }
     PcnScalars ps;
     ps.beta = pd.beta;
+    ps.nu = pd.nu;
+    ps.gam = pd.gam;
     ps.seed = pd.seed;
     ps.gid0 = pd.gid0;
     ps.c_ll = pd.ll.C;
@@ -1112,6 +1149,10 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
     PCN_CASE2(DD, ASMC_NOISE_F32, PCN_X_STEP)   \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_Y_STEP)   \
     PCN_CASE2(DD, ASMC_NOISE_F32, PCN_Y_STEP)   \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_X_STEP_T) \
+    PCN_CASE2(DD, ASMC_NOISE_F32, PCN_X_STEP_T) \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_Y_STEP_T) \
+    PCN_CASE2(DD, ASMC_NOISE_F32, PCN_Y_STEP_T) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_WHITEN)   \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN_X)
@@ -1340,6 +1381,7 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     ASMC_REQUIRE(prm->x_dtype == ASMC_F64 || prm->x_dtype == ASMC_F32, "bad x_dtype");
     ASMC_REQUIRE(prm->mu_dev && prm->L_dev && prm->Linv_dev, "null reference-Gaussian pointer");
     ASMC_REQUIRE(*rho_inout_host > 0.0 && *rho_inout_host <= 1.0, "rho must be in (0, 1]");
+    ASMC_REQUIRE(!(prm->nu > 0.0) || prm->nu >= 1.0, "nu must be >= 1 (or <= 0 for the Gaussian reference)");
     int rc = check_mixture(prm->log_likelihood);
     if (!rc) rc = check_mixture(prm->log_prior);
     if (!rc) rc = check_mixture(prm->log_q);
@@ -1357,6 +1399,7 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     pd.seed = prm->seed;
     pd.gid0 = prm->gid0;
     pd.noise = prm->noise;
+    pd.nu = prm->nu;
     pd.mode = PCN_X_STEP;
     ASMC_REQUIRE(pd.noise == ASMC_NOISE_F64 || pd.noise == ASMC_NOISE_F32, "bad noise mode");
     // device step-size cell + history
@@ -1379,7 +1422,10 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
         rc = asmc_pcn_mm_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, MM_WHITEN, d_rho, 0, d_block, &grid, st);
         if (rc) return rc;
         for (int t = 0; t < n_steps; t++) {
-            rc = asmc_pcn_mm_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, MM_STEP, d_rho, step0 + (uint32_t)t, d_block, &grid, st);
+            rc = pcn_prepare_gamma(ctx, n, pd, step0 + (uint32_t)t, st);
+            if (rc) return rc;
+            rc = asmc_pcn_mm_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, pd.nu > 0.0 ? MM_STEP_T : MM_STEP, d_rho,
+                                    step0 + (uint32_t)t, d_block, &grid, st);
             if (rc) return rc;
             rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
             if (rc) return rc;
@@ -1423,7 +1469,10 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
         if (rc) return rc;
     }
     for (int t = 0; t < n_steps; t++) {
-        rc = launch_mode(y_state ? PCN_Y_STEP : PCN_X_STEP, step0 + (uint32_t)t, &grid);
+        const bool tp = pd.nu > 0.0 && reg_ok;  // the generic kernel branches on the variates' pointer at run time
+        rc = pcn_prepare_gamma(ctx, n, pd, step0 + (uint32_t)t, st);
+        if (rc) return rc;
+        rc = launch_mode(y_state ? (tp ? PCN_Y_STEP_T : PCN_Y_STEP) : (tp ? PCN_X_STEP_T : PCN_X_STEP), step0 + (uint32_t)t, &grid);
         if (rc) return rc;
         rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
         if (rc) return rc;
@@ -1449,9 +1498,10 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
 }
 
 int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, void* x_prop, double* qf_old,
-                     double* qf_new, const double* mu, const double* L, const double* Linv, double rho,
+                     double* qf_new, const double* mu, const double* L, const double* Linv, double rho, double nu,
                      uint64_t seed, uint64_t gid0, uint32_t step, asmc_stream stream) {
     ASMC_REQUIRE(ctx && x && x_prop && qf_old && qf_new && mu && L && Linv, "null pointer");
+    ASMC_REQUIRE(!(nu > 0.0) || nu >= 1.0, "nu must be >= 1 (or <= 0 for the Gaussian reference)");
     ASMC_REQUIRE(n > 0 && n <= ctx->n_max && d > 0 && d <= ASMC_MAX_DIMS, "bad sizes");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
     ASMC_REQUIRE(rho > 0.0 && rho <= 1.0, "rho must be in (0, 1]");
@@ -1464,10 +1514,13 @@ int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x
     pd.Linv = Linv;
     pd.seed = seed;
     pd.gid0 = gid0;
+    pd.nu = nu;
     ASMC_HIP(hipStreamSynchronize(st));
     ctx->h_pinned[0] = rho;
     ASMC_HIP(hipMemcpyAsync(ctx->d_rho, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, st));
     int grid = 0;
+    int rc = pcn_prepare_gamma(ctx, n, pd, step, st);
+    if (rc) return rc;
     if (x_dtype == ASMC_F64)
         return launch_pcn_step<double, 1>(ctx, n, (double*)const_cast<void*>(x), nullptr, nullptr, nullptr, pd, ctx->d_rho,
                                           step, nullptr, &grid, (double*)x_prop, qf_old, qf_new, st);
@@ -1528,6 +1581,7 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
     ASMC_REQUIRE(prm->mu_dev && prm->L_dev && prm->Linv_dev, "null reference-Gaussian pointer");
     ASMC_REQUIRE(*rho_inout_host > 0.0 && *rho_inout_host <= 1.0, "rho must be in (0, 1]");
     ASMC_REQUIRE(work_bytes >= asmc_pcn_flow_work_bytes(n, prm->d, prm->x_dtype), "work buffer too small");
+    ASMC_REQUIRE(!(prm->nu > 0.0) || prm->nu >= 1.0, "nu must be >= 1 (or <= 0 for the Gaussian reference)");
     int rc = check_mixture(prm->log_likelihood);
     if (!rc) rc = check_mixture(prm->log_prior);
     if (rc) return rc;
@@ -1550,6 +1604,7 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
     pd.Linv = prm->Linv_dev;
     pd.seed = prm->seed;
     pd.gid0 = prm->gid0;
+    pd.nu = prm->nu;
     double* d_rho = ctx->d_rho;
     double* d_rho_hist = ctx->d_rho + 8;
     long long* d_counts = ctx->d_counts;
@@ -1584,6 +1639,8 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
         if (rc) return rc;
         for (int t = 0; t < n_steps; t++) {
             const uint32_t step = step0 + (uint32_t)t;
+            rc = pcn_prepare_gamma(ctx, n, pd, step, st);
+            if (rc) return rc;
             if (prm->x_dtype == ASMC_F64)
                 rc = dispatch_pcn_reg_flow<double, PCN_FLOW_PROPOSE>(ctx, n, (double*)x, (double*)x_prop, ll, lp, lq, ll_new, lp_new,
                                                                      lq_new, pd, d_rho, step, d_block, &grid, st);
@@ -1609,6 +1666,8 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
     for (int t = 0; t < (reg_ok ? 0 : n_steps); t++) {
         const uint32_t step = step0 + (uint32_t)t;
         int grid = 0;
+        rc = pcn_prepare_gamma(ctx, n, pd, step, st);
+        if (rc) return rc;
         if (prm->x_dtype == ASMC_F64)
             rc = launch_pcn_step<double, 1>(ctx, n, (double*)x, nullptr, nullptr, nullptr, pd, d_rho, step, nullptr, &grid,
                                             (double*)x_prop, q0, q1, st);

@@ -79,6 +79,56 @@ __device__ __forceinline__ double accept_uniform(unsigned long long seed, unsign
     return u01_from_words(w[0], w[1]);
 }
 
+// ---- t-preconditioned Crank-Nicolson (step_fn "tpcn"; specification: DESIGN.md §3.6) ---------------------------
+// unit-scale Gamma(shape >= 1) variate, Marsaglia & Tsang (2000), counter slots 0x80000000 | {2a, 2a + 1} of attempt a < 8
+__device__ __forceinline__ double gamma_unit(double shape, unsigned long long seed, unsigned long long gid,
+                                             uint32_t step) {
+    const double dd = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
+    // fully unrolled (nested early exits, no loop): a loop here makes LLVM hoist and spill the callers' ~1300
+    // invariant scalar loads.  P(all 8 attempts fail) < 0.05^8 = 4e-11.
+#pragma unroll
+    for (uint32_t a = 0; a < 8; a++) {
+        double z0, z1;
+        normal_pair(seed, gid, step, 0x80000000u | (2u * a), z0, z1);
+        double v = 1.0 + c * z0;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        uint32_t w[4];
+        philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, 0x80000000u | (2u * a + 1u), (uint32_t)seed,
+                      (uint32_t)(seed >> 32), w);
+        const double u = u01_from_words(w[0], w[1]);
+        if (log(u) < 0.5 * z0 * z0 + dd - dd * v + dd * log(v)) return dd * v;
+    }
+    return dd;
+}
+// proposal scale rho sqrt(s), s = 1/G, G = g * 2/(nu + q0) with the unit-scale variate g = gam[i] drawn by k_gamma_draw
+// just before the step kernel.  (The rejection sampler lives in its own small kernel: any retry control flow inside the
+// register-resident / matrix-core step kernels makes LLVM hoist and spill their ~1300 invariant scalar loads; those
+// kernels also select the Student-t form at compile time, TP.)  gam == nullptr: Gaussian reference (rho).
+template <bool TP = true>
+__device__ __forceinline__ double tpcn_scale(double rho, double nu, double q0, const double* __restrict__ gam, int64_t i) {
+    if (!TP || gam == nullptr) return rho;
+    return rho * sqrt((nu + q0) / (2.0 * gam[i]));
+}
+// minus the log-density of the reference at |y|^2 = q, up to a constant: q/2 (Gaussian) or ((d + nu)/2) log(1 + q/nu)
+// compile-time forms for the register-resident / matrix-core kernels: straight-line code, no test of gam or nu
+template <bool TP>
+__device__ __forceinline__ double tpcn_scale_ct(double rho, double nu, double q0, const double* __restrict__ gam, int64_t i) {
+    if (!TP) return rho;
+    return rho * sqrt((nu + q0) / (2.0 * gam[i]));
+}
+template <bool TP>
+__device__ __forceinline__ double ref_corr_ct(double q, double nu, int d) {
+    if (!TP) return 0.5 * q;
+    return 0.5 * ((double)d + nu) * log1p(q / nu);
+}
+
+template <bool TP = true>
+__device__ __forceinline__ double ref_corr(double q, double nu, int d) {
+    if (!TP) return 0.5 * q;
+    return nu > 0.0 ? 0.5 * ((double)d + nu) * log1p(q / nu) : 0.5 * q;
+}
+
 struct MixDev {
     int C;
     const double* logw;
@@ -111,6 +161,8 @@ struct PcnDev {
     MixDev ll, lp, lq;
     unsigned long long seed, gid0;
     int noise;
+    double nu;  // > 0: Student-t reference with nu degrees of freedom (tpCN); <= 0: Gaussian reference (pCN)
+    const double* gam;  // [n] unit-scale Gamma((d + nu)/2) variates of the current step (tpCN), else nullptr
     int mode;  // PCN_X_STEP / PCN_Y_STEP / PCN_WHITEN / PCN_UNWHITEN (register-resident kernels)
 };
 
@@ -119,6 +171,7 @@ struct PcnDev {
 #define MM_WHITEN 0
 #define MM_STEP 1
 #define MM_UNWHITEN 2
+#define MM_STEP_T 3  // MM_STEP with the Student-t reference (tpCN)
 bool asmc_pcn_mm_supported(int d, const void* x);
 int asmc_pcn_mm_pack(asmc_ctx* ctx, const PcnDev& pd, hipStream_t st);
 int asmc_pcn_mm_launch(asmc_ctx* ctx, int64_t n, int x_dtype, void* x, double* ll, double* lp, double* lq, const PcnDev& pd,

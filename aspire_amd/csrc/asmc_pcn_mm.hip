@@ -129,6 +129,8 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
                                                       const double* __restrict__ rho_ptr, uint32_t step,
                                                       long long* __restrict__ block_counts) {
     extern __shared__ __align__(16) double smem[];
+    constexpr bool TP = MODE == MM_STEP_T;
+    constexpr int M = TP ? MM_STEP : MODE;
     constexpr int KS = D / 4;
     constexpr int TOTAL = mm_ksum(D / 16) * 64;
     double* sA = smem;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
         const int q = e & 1, hh = (e >> 1) & 3, sp = e >> 3;
         s_mu[e] = p.mu[mm_coord(2 * sp + q, hh)];
     }
-    if (MODE != MM_WHITEN) {
+    if (M != MM_WHITEN) {
         mm_stage_tables<D>(t_ll, p.ll, threadIdx.x, MM_THREADS);
         mm_stage_tables<D>(t_lp, p.lp, threadIdx.x, MM_THREADS);
         mm_stage_tables<D>(t_lq, p.lq, threadIdx.x, MM_THREADS);
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pp = lane & 15, h = lane >> 4;
-    const double rho = (MODE == MM_STEP) ? *rho_ptr : 0.0;
+    const double rho = (M == MM_STEP) ? *rho_ptr : 0.0;
     const double a = sqrt(1.0 - rho * rho);
     const int64_t n_groups = (n + 15) / 16;
     long long n_acc = 0;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
                 xr[sp * 4] = t;
             }
         };
-        if (MODE == MM_WHITEN) {
+        if (M == MM_WHITEN) {
 #pragma unroll
             for (int sp = 0; sp < KS / 2; sp++) {
                 const double2 m2 = *reinterpret_cast<const double2*>(my_mu + sp * 8);
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
             }
             mm_trimatvec<D>(sA, v, o, lane);
             if (valid) store_row(o);
-        } else if (MODE == MM_UNWHITEN) {
+        } else if (M == MM_UNWHITEN) {
             mm_trimatvec<D>(sA, v, o, lane);
 #pragma unroll
             for (int sp = 0; sp < KS / 2; sp++) {
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
 #pragma unroll
             for (int s = 0; s < KS; s++) q0 = fma(v[s], v[s], q0);
             q0 = quad_sum(q0);
+            const double rs = tpcn_scale_ct<TP>(rho, p.nu, q0, p.gam, valid ? row : 0);  // one variate per particle
 #pragma unroll
             for (int sp = 0; sp < KS / 2; sp++) {
                 double z0, z1;
@@ -219,8 +222,8 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
                 } else {  // coordinates 2 pr, 2 pr + 1 from pair pr: exactly the owned pair
                     normal_pair(p.seed, gid, step, (uint32_t)(4 * sp + h), z0, z1);
                 }
-                v[2 * sp] = (double)(T)fma(rho, z0, a * v[2 * sp]);
-                v[2 * sp + 1] = (double)(T)fma(rho, z1, a * v[2 * sp + 1]);
+                v[2 * sp] = (double)(T)fma(rs, z0, a * v[2 * sp]);
+                v[2 * sp + 1] = (double)(T)fma(rs, z1, a * v[2 * sp + 1]);
                 q1 = fma(v[2 * sp], v[2 * sp], q1);
                 q1 = fma(v[2 * sp + 1], v[2 * sp + 1], q1);
             }
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
             if (valid) {
                 const double lpn = log_p_t(nll, nlp, nlq, p.beta);
                 const double lpo = log_p_t(ll[row], lp[row], lq[row], p.beta);
-                const double log_a = (lpn + 0.5 * q1) - (lpo + 0.5 * q0);
+                const double log_a = (lpn + ref_corr_ct<TP>(q1, p.nu, D)) - (lpo + ref_corr_ct<TP>(q0, p.nu, D));
                 const double u = accept_uniform(p.seed, gid, step);
                 if (log(u) < log_a) {
                     store_row(v);
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
             }
         }
     }
-    if (MODE == MM_STEP) {
+    if (M == MM_STEP) {
         __shared__ long long s_cnt[MM_WAVES];
         n_acc = wave_sum_ll(n_acc);
         if (lane == 0) s_cnt[wave] = n_acc;
@@ -398,7 +401,7 @@ static int launch_mm(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, dou
     int grid = (int)(want < (int64_t)ctx->num_cu * per_cu ? want : (int64_t)ctx->num_cu * per_cu);
     if (grid > ASMC_MAX_BLOCKS) grid = ASMC_MAX_BLOCKS;
     *grid_out = grid;
-    ASMC_LAUNCH(ctx, st, MODE == MM_STEP ? "k_pcn_mm_step" : MODE == MM_WHITEN ? "k_pcn_mm_whiten" : "k_pcn_mm_unwhiten", kern,
+    ASMC_LAUNCH(ctx, st, MODE == MM_STEP ? "k_pcn_mm_step" : MODE == MM_STEP_T ? "k_tpcn_mm_step" : MODE == MM_WHITEN ? "k_pcn_mm_whiten" : "k_pcn_mm_unwhiten", kern,
                 dim3(grid), dim3(MM_THREADS), lds, st, n, x, ll, lp, lq, pack, pd, rho_ptr, step, block_counts);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -427,6 +430,10 @@ int asmc_pcn_mm_launch(asmc_ctx* ctx, int64_t n, int x_dtype, void* x, double* l
 #define MM_MODES(TT, DD)                                                         \
     if (mode == MM_WHITEN) { MM_CASE(TT, DD, ASMC_NOISE_F64, MM_WHITEN) }        \
     if (mode == MM_UNWHITEN) { MM_CASE(TT, DD, ASMC_NOISE_F64, MM_UNWHITEN) }    \
+    if (mode == MM_STEP_T) {                                                     \
+        if (pd.noise == ASMC_NOISE_F32) { MM_CASE(TT, DD, ASMC_NOISE_F32, MM_STEP_T) } \
+        MM_CASE(TT, DD, ASMC_NOISE_F64, MM_STEP_T)                               \
+    }                                                                            \
     if (pd.noise == ASMC_NOISE_F32) { MM_CASE(TT, DD, ASMC_NOISE_F32, MM_STEP) } \
     MM_CASE(TT, DD, ASMC_NOISE_F64, MM_STEP)
     if (x_dtype == ASMC_F64) {

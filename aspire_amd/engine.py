@@ -489,13 +489,14 @@ class HipEngine:
               "asmc_pcn_set_count_hook")
 
     def pcn_mutate(self, x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed, gid0, rho, n_steps, step0=0,
-                   target_accept=0.234, adapt=True, noise="f64"):
-        """n_steps fused pCN steps in place.  Returns (n_accept[n_steps], rho_hist[n_steps], rho_out)."""
+                   target_accept=0.234, adapt=True, noise="f64", nu=0.0):
+        """n_steps fused pCN steps in place (nu > 0: t-preconditioned steps with a Student-t reference).
+        Returns (n_accept[n_steps], rho_hist[n_steps], rho_out)."""
         self._chk3(ll, lp, lq)
         n, d = x.shape
         prm = AsmcPcnParams(d, self._xdt(x), beta, mu.data_ptr(), L.data_ptr(), Linv.data_ptr(), t_ll.c_struct(),
                             t_lp.c_struct(), t_lq.c_struct(), seed, gid0, target_accept, int(adapt),
-                            {"f64": 0, "f32": 1}[noise])
+                            {"f64": 0, "f32": 1}[noise], float(nu))
         n_acc = np.zeros(n_steps, dtype=np.int64)
         rho_hist = np.zeros(n_steps)
         rho_io = ctypes.c_double(rho)
@@ -506,13 +507,13 @@ class HipEngine:
         return n_acc, rho_hist, rho_io.value
 
     def pcn_mutate_flow(self, x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, flow: DeviceCoupling, seed, gid0, rho,
-                        n_steps, step0=0, target_accept=0.234, adapt=True, noise="f64"):
+                        n_steps, step0=0, target_accept=0.234, adapt=True, noise="f64", nu=0.0):
         """pcn_mutate with a coupling-flow proposal density (log_q evaluated on the MFMA each step)."""
         self._chk3(ll, lp, lq)
         n, d = x.shape
         prm = AsmcPcnParams(d, self._xdt(x), beta, mu.data_ptr(), L.data_ptr(), Linv.data_ptr(), t_ll.c_struct(),
                             t_lp.c_struct(), t_lp.c_struct(), seed, gid0, target_accept, int(adapt),
-                            {"f64": 0, "f32": 1}[noise])
+                            {"f64": 0, "f32": 1}[noise], float(nu))
         nbytes = self.lib.asmc_pcn_flow_work_bytes(n, d, self._xdt(x))
         if self._flow_work is None or self._flow_work.numel() < nbytes:
             self._flow_work = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -526,12 +527,12 @@ class HipEngine:
                                             _f64p(rho_hist), self._stream), "asmc_pcn_mutate_flow")
         return n_acc, rho_hist, rho_io.value
 
-    def pcn_propose(self, x, mu, L, Linv, rho, seed, gid0, step):
+    def pcn_propose(self, x, mu, L, Linv, rho, seed, gid0, step, nu=0.0):
         n, d = x.shape
         xp = torch.empty_like(x)
         q0, q1 = self.empty(n), self.empty(n)
         check(self.lib.asmc_pcn_propose(self._ctx, n, d, self._xdt(x), _dptr(x), _dptr(xp), _dptr(q0), _dptr(q1),
-                                        _dptr(mu), _dptr(L), _dptr(Linv), rho, seed, gid0, step, self._stream),
+                                        _dptr(mu), _dptr(L), _dptr(Linv), rho, float(nu), seed, gid0, step, self._stream),
               "asmc_pcn_propose")
         return xp, q0, q1
 

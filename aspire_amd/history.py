@@ -32,3 +32,4 @@ class SMCHistory(History):
     sample_history: list = field(default_factory=list)
     # additions of this implementation (not in the reference)
     mcmc_step_size: list[float] = field(default_factory=list)
+    mcmc_nu: list[float] = field(default_factory=list)  # degrees of freedom of the tpCN reference (inf: Gaussian)

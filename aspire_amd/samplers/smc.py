@@ -339,19 +339,19 @@ class HipSMC(SMCSampler):
         self.sampler_kwargs = dict(sampler_kwargs or {})
         self.sampler_kwargs.setdefault("n_steps", 5 * self.dims)  # minipcn.py:46
         self.sampler_kwargs.setdefault("target_acceptance_rate", 0.234)  # minipcn.py:47
-        # reference default is "tpcn" (minipcn.py:48); this build implements the Gaussian-reference
-        # pCN kernel and says so rather than silently substituting it
-        self.sampler_kwargs.setdefault("step_fn", "pcn")
+        # "tpcn" (t-preconditioned Crank-Nicolson, Student-t reference fitted per temperature) is the reference's
+        # default (minipcn.py:48); "pcn" is the Gaussian-reference special case
+        self.sampler_kwargs.setdefault("step_fn", "tpcn")
         self.sampler_kwargs.setdefault("verbose", False)
         # proposal-noise generator of the fused kernel: "f64" (fp64 Box-Muller, matches the oracle to 1e-12)
         # or "f32" (hardware fp32 Box-Muller, 4 normals per Philox block; the fast production mode)
         self.sampler_kwargs.setdefault("noise", "f64")
-        if self.sampler_kwargs["step_fn"] != "pcn":
+        if self.sampler_kwargs["step_fn"] not in ("pcn", "tpcn"):
             raise NotImplementedError(
-                f"step_fn={self.sampler_kwargs['step_fn']!r} is not implemented by the HIP mutation kernel; "
-                "use step_fn='pcn'")
+                f"step_fn={self.sampler_kwargs['step_fn']!r} is not implemented by the HIP mutation kernels; "
+                "use step_fn='tpcn' or 'pcn'")
         self.rng = rng or self.rng or np.random.default_rng()
-        self._pcn_state = {"rho": None, "step": 0}
+        self._pcn_state = {"rho": None, "step": 0, "nu": None}
         return super().sample(
             n_samples, n_steps=n_steps, adaptive=adaptive, target_efficiency=target_efficiency,
             target_efficiency_rate=target_efficiency_rate, n_final_samples=n_final_samples,
@@ -396,6 +396,32 @@ class HipSMC(SMCSampler):
             Linv = np.linalg.inv(L)
         return e.asarray(mean), e.asarray(np.tril(L)), e.asarray(np.tril(Linv))
 
+    def _fit_reference(self, x: torch.Tensor, n_global: int, step_fn: str):
+        """(mu, L, Linv, nu) of the mutation's reference distribution: Gaussian moments of the whole population
+        (`pcn`, nu = 0) or a Student-t fitted by EM to a strided subsample of `tpcn_fit_subsample` particles, the
+        same on every rank (`tpcn`; student_t.py).  A fit with nu above NU_GAUSSIAN runs the Gaussian kernels."""
+        if step_fn != "tpcn":
+            return (*self._fit_reference_gaussian(x, n_global), 0.0)
+        from ..student_t import NU_GAUSSIAN, _chol, fit_student_t
+
+        e, comm = self.engine, self.comm
+        m = int(self.sampler_kwargs.get("tpcn_fit_subsample", 2048))
+        k = max(1, min(m, n_global) // comm.world)
+        n_local = x.shape[0]
+        rows = torch.as_tensor((np.arange(k, dtype=np.int64) * n_local) // k, device=x.device)
+        sub = np.ascontiguousarray(e.to_numpy(x[rows]), dtype=np.float64)
+        if comm.world > 1:
+            sub = comm.all_gather_f64(sub).reshape(-1, x.shape[1])
+        st = self._pcn_state
+        with _single_threaded_blas():
+            mean, cov, nu = fit_student_t(sub, max_iter=int(self.sampler_kwargs.get("tpcn_fit_iters", 12)),
+                                          nu0=st.get("nu") or 20.0)
+            L = _chol(cov)
+            Linv = np.linalg.inv(L)
+        st["nu"] = nu
+        self.history.mcmc_nu.append(float(nu) if nu <= NU_GAUSSIAN else float("inf"))
+        return e.asarray(mean), e.asarray(np.tril(L)), e.asarray(np.tril(Linv)), (nu if nu <= NU_GAUSSIAN else 0.0)
+
     def _mutate_preconditioned(self, particles: SMCSamples, x: torch.Tensor, beta: float, n_steps: int, target: float):
         """smc/minipcn.py:105-132 with a non-trivial preconditioning transform: the chain runs in z = T(x) (refit at
         every temperature), the tempered log-target there is log p_t(T^-1(z)) + log|det dT^-1/dz| (smc/base.py:507-519).
@@ -414,7 +440,7 @@ class HipSMC(SMCSampler):
             z = T.fit(x)
         z = e.asarray(z, dtype=x.dtype)
         logj = e.asarray(T.inverse(z)[1])
-        mu, L, Linv = self._fit_reference_gaussian(z, n_global)
+        mu, L, Linv, nu = self._fit_reference(z, n_global, self.sampler_kwargs.get("step_fn", "tpcn"))
         st = self._pcn_state
         if st["rho"] is None:
             st["rho"] = min(2.38 / math.sqrt(self.dims), 0.99)
@@ -422,7 +448,7 @@ class HipSMC(SMCSampler):
         step0 = st["step"]
         acc_rates = []
         for t in range(n_steps):
-            z_prop, q0, q1 = e.pcn_propose(z, mu, L, Linv, st["rho"], seed, gid0, step0 + t)
+            z_prop, q0, q1 = e.pcn_propose(z, mu, L, Linv, st["rho"], seed, gid0, step0 + t, nu=nu)
             x_prop, logj_new = T.inverse(z_prop)
             x_prop, logj_new = e.asarray(x_prop, dtype=x.dtype), e.asarray(logj_new)
             lq_new = self._flow_log_prob(x_prop)
@@ -479,7 +505,7 @@ class HipSMC(SMCSampler):
         n_local = x.shape[0]
         n_global = self._n_global(particles)
         gid0 = self._gid0(particles)
-        mu, L, Linv = self._fit_reference_gaussian(x, n_global)
+        mu, L, Linv, nu = self._fit_reference(x, n_global, kwargs.get("step_fn", "tpcn"))
         st = self._pcn_state
         if st["rho"] is None:
             st["rho"] = min(2.38 / math.sqrt(self.dims), 0.99)
@@ -494,13 +520,13 @@ class HipSMC(SMCSampler):
             e.set_count_hook(comm, n_global)
         try:
             return self._mutate_steps(particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0,
-                                      acc_rates, dev_flow, on_device, n_local, n_global, gid0)
+                                      acc_rates, dev_flow, on_device, n_local, n_global, gid0, nu)
         finally:
             if comm.world > 1 and on_device:
                 e.set_count_hook(None, None)
 
     def _mutate_steps(self, particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0, acc_rates,
-                      dev_flow, on_device, n_local, n_global, gid0):
+                      dev_flow, on_device, n_local, n_global, gid0, nu=0.0):
         e, comm = self.engine, self.comm
         if self._flow_fused_ok(dev_flow):
             # flow proposal density evaluated on the MFMA inside the device-side step loop (BASELINE config 3)
@@ -511,14 +537,14 @@ class HipSMC(SMCSampler):
                 while done < n_steps:
                     chunk = min(n_steps - done, 2048)
                     n_acc, rho_hist, rho = e.pcn_mutate_flow(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed,
-                                                             gid0, st["rho"], chunk, step0 + done, target, True, noise)
+                                                             gid0, st["rho"], chunk, step0 + done, target, True, noise, nu)
                     st["rho"] = rho
                     acc_rates.extend((n_acc / n_global).tolist())
                     done += chunk
             else:
                 for t in range(n_steps):
                     n_acc, _, _ = e.pcn_mutate_flow(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed, gid0,
-                                                    st["rho"], 1, step0 + t, target, False, noise)
+                                                    st["rho"], 1, step0 + t, target, False, noise, nu)
                     tot = float(comm.all_gather_f64(np.array([float(n_acc[0])])).sum())
                     acc_rates.append(tot / n_global)
                     st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)
@@ -532,21 +558,21 @@ class HipSMC(SMCSampler):
                 while done < n_steps:
                     chunk = min(n_steps - done, 2048)
                     n_acc, rho_hist, rho = e.pcn_mutate(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed,
-                                                        gid0, st["rho"], chunk, step0 + done, target, True, noise)
+                                                        gid0, st["rho"], chunk, step0 + done, target, True, noise, nu)
                     st["rho"] = rho
                     acc_rates.extend((n_acc / n_global).tolist())
                     done += chunk
             else:
                 for t in range(n_steps):
                     n_acc, _, _ = e.pcn_mutate(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed, gid0,
-                                               st["rho"], 1, step0 + t, target, False, noise)
+                                               st["rho"], 1, step0 + t, target, False, noise, nu)
                     tot = float(comm.all_gather_f64(np.array([float(n_acc[0])])).sum())
                     acc_rates.append(tot / n_global)
                     st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)
             self.n_likelihood_evaluations += n_steps * n_local
         else:
             for t in range(n_steps):
-                x_prop, q0, q1 = e.pcn_propose(x, mu, L, Linv, st["rho"], seed, gid0, step0 + t)
+                x_prop, q0, q1 = e.pcn_propose(x, mu, L, Linv, st["rho"], seed, gid0, step0 + t, nu=nu)
                 lq_new = self._flow_log_prob(x_prop)
                 lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
                 n_acc = e.pcn_accept(x, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0,

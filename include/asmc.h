@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 3
+#define ASMC_ABI_VERSION 4
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -91,6 +91,11 @@ typedef struct {
     int32_t noise;            /* ASMC_NOISE_F64: fp64 Box-Muller, 2 normals / Philox block (1e-15 parity with
                                  the oracle); ASMC_NOISE_F32: fp32 hardware Box-Muller, 4 normals / block
                                  (fast; honoured by the register-resident kernels, d in {4,8,16,32}) */
+    double nu;                /* > 0 (>= 1): t-preconditioned Crank-Nicolson, the reference's default step_fn="tpcn"
+                                 (smc/minipcn.py:46-49): the reference distribution is Student-t(mu, L L^T, nu); the
+                                 proposal noise is scaled by sqrt(s), s ~ InvGamma((d + nu)/2, (nu + |y|^2)/2), and the
+                                 acceptance ratio carries ((d + nu)/2) log(1 + |y|^2/nu) instead of |y|^2/2.
+                                 <= 0: Gaussian reference (plain pCN) */
 } asmc_pcn_params;
 
 /* ---- library / context ---------------------------------------------------------------- */
@@ -278,6 +283,7 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, doubl
 int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
                      void* x_prop_dev, double* qform_old_dev, double* qform_new_dev,
                      const double* mu_dev, const double* L_dev, const double* Linv_dev, double rho,
+                     double nu /* as asmc_pcn_params.nu; the qform outputs are then (d + nu) log(1 + |y|^2/nu) */,
                      uint64_t seed, uint64_t gid0, uint32_t step, asmc_stream stream);
 int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x_dev,
                     const void* x_prop_dev, double* ll_dev, double* lp_dev, double* lq_dev,

@@ -77,6 +77,12 @@ def lib():
                 [i64, ci, vp, vp, vp, vp, d, vp, vp, vp, d, vp, vp, vp, u64, u64, u32, ci],
             ),
             "orc_pcn_noise_f32": (None, [u64, u64, u32, ci, vp, vp]),
+            "orc_gamma_unit": (d, [d, u64, u64, u32]),
+            "orc_tpcn_corr": (d, [d, ci, d]),
+            "orc_tpcn_step": (
+                i64,
+                [i64, ci, vp, vp, vp, vp, d, vp, vp, vp, d, d, vp, vp, vp, u64, u64, u32, ci],
+            ),
             "orc_pcn_adapt": (d, [d, d, d, ci]),
             "orc_moments": (None, [i64, ci, vp, vp, vp]),
             "orc_is_iteration": (ci, [i64, ci, vp, vp, vp, vp, d, d, d, vp, vp, vp, vp, vp, vp]),
@@ -352,6 +358,27 @@ def pcn_step(x, ll, lp, lq, beta, mu, L, Linv, rho, t_ll, t_lp, t_lq, seed, gid0
     a, b, c = t_ll.c_struct(), t_lp.c_struct(), t_lq.c_struct()
     return lib().orc_pcn_step(
         n, d, _p(x), _p(ll), _p(lp), _p(lq), beta, _p(mu), _p(L), _p(Linv), rho,
+        ctypes.addressof(a), ctypes.addressof(b), ctypes.addressof(c), seed, gid0, step, int(noise == "f32"),
+    )
+
+
+def gamma_unit(shape, seed, gid, step):
+    """Unit-scale Gamma(shape) variate of particle `gid` at Markov step `step` (tpCN scale mixture)."""
+    return lib().orc_gamma_unit(float(shape), seed, gid, step)
+
+
+def tpcn_corr(q, d, nu):
+    return np.array([lib().orc_tpcn_corr(float(v), int(d), float(nu)) for v in np.atleast_1d(q)])
+
+
+def tpcn_step(x, ll, lp, lq, beta, mu, L, Linv, rho, nu, t_ll, t_lp, t_lq, seed, gid0, step, noise="f64"):
+    """In-place t-preconditioned Crank-Nicolson step (Student-t reference with `nu` degrees of freedom)."""
+    assert x.dtype == np.float64 and x.flags.c_contiguous
+    n, d = x.shape
+    mu, L, Linv = _f64(mu), _f64(L), _f64(Linv)
+    a, b, c = t_ll.c_struct(), t_lp.c_struct(), t_lq.c_struct()
+    return lib().orc_tpcn_step(
+        n, d, _p(x), _p(ll), _p(lp), _p(lq), beta, _p(mu), _p(L), _p(Linv), rho, float(nu),
         ctypes.addressof(a), ctypes.addressof(b), ctypes.addressof(c), seed, gid0, step, int(noise == "f32"),
     )
 

@@ -252,26 +252,40 @@ class OracleEngine:
         return c.T @ c
 
     def pcn_mutate(self, x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed, gid0, rho, n_steps, step0=0,
-                   target_accept=0.234, adapt=True, noise="f64"):
+                   target_accept=0.234, adapt=True, noise="f64", nu=0.0):
         assert x.dtype == torch.float64
         n = x.shape[0]
         n_acc, hist = np.zeros(n_steps, dtype=np.int64), np.zeros(n_steps)
         for t in range(n_steps):
             hist[t] = rho
+            if nu > 0.0:
+                n_acc[t] = O.tpcn_step(_np(x), _np(ll), _np(lp), _np(lq), beta, _np(mu), _np(L), _np(Linv), rho, nu,
+                                       t_ll.mix, t_lp.mix, t_lq.mix, seed, gid0, step0 + t, noise)
+                if adapt:
+                    rho = O.pcn_adapt(rho, n_acc[t] / n, target_accept, t)
+                continue
             n_acc[t] = O.pcn_step(_np(x), _np(ll), _np(lp), _np(lq), beta, _np(mu), _np(L), _np(Linv), rho,
                                   t_ll.mix, t_lp.mix, t_lq.mix, seed, gid0, step0 + t, noise)
             if adapt:
                 rho = O.pcn_adapt(rho, n_acc[t] / n, target_accept, t)
         return n_acc, hist, rho
 
-    def pcn_propose(self, x, mu, L, Linv, rho, seed, gid0, step):
+    def pcn_propose(self, x, mu, L, Linv, rho, seed, gid0, step, nu=0.0):
         xn, mun, Ln, Li = _np(x).astype(np.float64), _np(mu), _np(L), _np(Linv)
         n, d = xn.shape
         y = (xn - mun) @ Li.T
         xi = np.stack([O.pcn_noise(seed, gid0 + i, step, d)[0] for i in range(n)])
-        yp = np.sqrt(1 - rho * rho) * y + rho * xi
+        q0 = (y * y).sum(1)
+        rs = np.full(n, rho)
+        if nu > 0.0:
+            g = np.array([O.gamma_unit(0.5 * (d + nu), seed, gid0 + i, step) for i in range(n)])
+            rs = rho * np.sqrt((nu + q0) / (2.0 * g))
+        yp = np.sqrt(1 - rho * rho) * y + rs[:, None] * xi
+        q1 = (yp * yp).sum(1)
         xp = (mun + yp @ Ln.T).astype(xn.dtype if x.dtype == torch.float64 else np.float32)
-        return (torch.from_numpy(xp).to(x.dtype), torch.from_numpy((y * y).sum(1)), torch.from_numpy((yp * yp).sum(1)))
+        if nu > 0.0:  # the accept step adds half of these: twice the Student-t correction
+            q0, q1 = 2.0 * O.tpcn_corr(q0, d, nu), 2.0 * O.tpcn_corr(q1, d, nu)
+        return torch.from_numpy(xp).to(x.dtype), torch.from_numpy(q0), torch.from_numpy(q1)
 
     def pcn_accept(self, x, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0, step,
                    logj_old=None, logj_new=None):

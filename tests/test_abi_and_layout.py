@@ -38,7 +38,7 @@ def test_struct_layouts_match_header():
 
     assert ctypes.sizeof(AsmcMixture) == 32
     assert AsmcPcnParams.log_likelihood.offset == 40 and AsmcPcnParams.seed.offset == 40 + 3 * 32
-    assert ctypes.sizeof(AsmcPcnParams) == 40 + 96 + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(AsmcPcnParams) == 40 + 96 + 8 + 8 + 8 + 8 + 8 and AsmcPcnParams.nu.offset == 168
 
 
 def test_error_reporting_without_gpu():

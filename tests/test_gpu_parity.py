@@ -1122,3 +1122,116 @@ def test_pcg64_select_at_eight_rank_scale(eng, oracle):
             assert np.array_equal(q.cpu().numpy(), oracle.pcg64_select(st, n_total, float(cuts[r]), float(cuts[r + 1])))
     assert sum(sizes) == n_total
     assert max(abs(s - n_total / 8) for s in sizes) < 0.01 * n_total / 8
+
+
+# ---- t-preconditioned Crank-Nicolson (step_fn "tpcn": Student-t reference; own specification, oracle orc_tpcn_step) ----
+@pytest.mark.parametrize("d,C,n_steps,noise,nu", [(32, 1, 1, "f64", 7.5), (32, 1, 4, "f64", 3.0), (4, 2, 1, "f64", 1.0),
+                                                  (7, 1, 1, "f64", 12.0), (8, 1, 4, "f32", 5.0), (64, 2, 3, "f64", 6.0),
+                                                  (128, 1, 3, "f32", 9.0)])
+def test_tpcn_step_vs_oracle(eng, oracle, d, C, n_steps, noise, nu):
+    """Every kernel family (register-resident x / whitened state, generic LDS, fp64 matrix cores) against the oracle's
+    restatement of the tpCN step: same gamma scale variates, proposals to 1e-9, accept decisions up to razor edges."""
+    n = 2999
+    x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 91 + d, C=C)
+    om = [oracle.Mixture(*m) for m in mixes]
+    dm = [eng.make_mixture(*m) for m in mixes]
+    ll, lp, lq = (m.logpdf(x) for m in om)
+    xd, lld, lpd, lqd = dev(eng, x, ll, lp, lq)
+    rho, beta, seed, gid0, step0 = (0.4 if d <= 32 else 0.15), 0.45, 9001, 77, 3
+    eng.profile(True)
+    n_acc, _, _ = eng.pcn_mutate(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), dm[0], dm[1],
+                                 dm[2], seed, gid0, rho, n_steps, step0, 0.234, False, noise, nu)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert rep["k_gamma_draw"][0] == n_steps
+    if d in (64, 128):
+        assert rep["k_tpcn_mm_step"][0] == n_steps
+    elif d in (4, 8, 16, 32):
+        assert rep["k_tpcn_reg_y" if (n_steps >= 4 and C == 1) else "k_tpcn_reg"][0] == n_steps
+    xr, llr, lpr, lqr = x.copy(), ll.copy(), lp.copy(), lq.copy()
+    acc_ref = [oracle.tpcn_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, nu, om[0], om[1], om[2], seed, gid0, step0 + t, noise)
+               for t in range(n_steps)]
+    got = xd.cpu().numpy()
+    tol = 1e-9 if noise == "f64" else 3e-5
+    close = np.all(np.abs(got - xr) <= tol * (1 + np.abs(xr)), axis=1)
+    edge = 3 if noise == "f64" else 40
+    assert (~close).sum() <= edge, (~close).sum()
+    assert np.all(np.abs(np.array(n_acc) - np.array(acc_ref)) <= edge)
+    assert 0.02 < np.mean(n_acc) / n < 0.98
+    np.testing.assert_allclose(lld.cpu().numpy(), om[0].logpdf(got), rtol=1e-10, atol=1e-9)
+    # the Student-t scale really is in play: a Gaussian-reference step from the same state proposes elsewhere
+    xg = eng.asarray(x)
+    eng.pcn_mutate(xg, *dev(eng, ll, lp, lq), beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), dm[0], dm[1], dm[2],
+                   seed, gid0, rho, n_steps, step0, 0.234, False, noise, 0.0)
+    assert not torch.equal(xg, xd)
+
+
+def test_tpcn_split_path_equals_fused(eng, oracle):
+    n, d, nu = 2000, 8, 4.5
+    x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 78)
+    om = [oracle.Mixture(*m) for m in mixes]
+    dm = [eng.make_mixture(*m) for m in mixes]
+    ll, lp, lq = (m.logpdf(x) for m in om)
+    a = dev(eng, x, ll, lp, lq)
+    b = dev(eng, x, ll, lp, lq)
+    mud, Ld, Lid = dev(eng, mu, L, Linv)
+    n_acc, _, _ = eng.pcn_mutate(*a, 0.6, mud, Ld, Lid, dm[0], dm[1], dm[2], 5, 0, 0.3, 1, 9, 0.234, False, "f64", nu)
+    xp, q0, q1 = eng.pcn_propose(b[0], mud, Ld, Lid, 0.3, 5, 0, 9, nu=nu)
+    lln, lpn, lqn = (eng.mixture_logpdf(xp, m) for m in dm)
+    nacc = eng.pcn_accept(b[0], xp, b[1], b[2], b[3], lln, lpn, lqn, q0, q1, 0.6, 5, 0, 9)
+    # the generic propose kernel accumulates |y|^2 in the opposite order to the register kernel: the scale sqrt(s)
+    # differs in the last bit, so positions agree to rounding instead of bitwise (they are bitwise equal for pCN)
+    assert abs(nacc - int(n_acc[0])) <= 1
+    far = (torch.abs(a[0] - b[0]) > 1e-12 * (1 + torch.abs(b[0]))).any(dim=1)
+    assert far.sum().item() <= 2
+    y = (x - mu) @ Linv.T
+    np.testing.assert_allclose(q0.cpu().numpy(), 2.0 * oracle.tpcn_corr((y * y).sum(1), d, nu), rtol=1e-12)
+
+
+def test_tpcn_scale_variates_are_inverse_gamma(eng):
+    """Proposal law through the split path (no accept step): from y = 0 with rho = 1 and the identity reference,
+    x' = sqrt(s) xi, s = nu / (2 g), g ~ Gamma((d + nu)/2)  =>  |x'|^2 (d + nu) / (nu d) ~ F(d, d + nu)."""
+    from scipy import stats
+
+    n, d, nu = 200000, 4, 6.0
+    eye = eng.asarray(np.eye(d))
+    xp, q0, q1 = eng.pcn_propose(eng.asarray(np.zeros((n, d))), eng.asarray(np.zeros(d)), eye, eye, 1.0, 5, 0, 0, nu=nu)
+    r2 = (xp.cpu().numpy() ** 2).sum(1)
+    assert stats.kstest(r2 * (d + nu) / (nu * d), stats.f(d, d + nu).cdf).pvalue > 1e-3
+    assert float(q0.abs().max()) == 0.0  # (d + nu) log(1 + 0 / nu)
+    np.testing.assert_allclose(q1.cpu().numpy(), (d + nu) * np.log1p(r2 / nu), rtol=1e-12)
+
+
+def test_tpcn_leaves_gaussian_target_invariant(eng):
+    n, d, nu = 200000, 4, 4.0
+    g = np.random.default_rng(1)
+    x = g.normal(size=(n, d)) * np.sqrt(0.5)
+    tgt = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    q = eng.make_mixture([-d * np.log(1.5) - 0.5 * d * np.log(2 * np.pi)], np.zeros((1, d)), np.full((1, d), 1 / 2.25))
+    xd = eng.asarray(x)
+    ll = eng.mixture_logpdf(xd, tgt)
+    lp = ll.clone()
+    lq = eng.mixture_logpdf(xd, q)
+    L = np.diag(np.full(d, 0.9))
+    n_acc, rho_hist, rho = eng.pcn_mutate(xd, ll, lp, lq, 1.0, eng.asarray(np.full(d, 0.2)), eng.asarray(L),
+                                          eng.asarray(np.linalg.inv(L)), tgt, tgt, q, 11, 0, 0.5, 40, 0, 0.234, True, "f64", nu)
+    xs = xd.cpu().numpy()
+    assert np.all(np.abs(xs.mean(0)) < 0.01) and np.all(np.abs(xs.var(0) - 0.5) < 0.01)
+    from scipy import stats
+
+    assert stats.kstest(xs[:, 0] / np.sqrt(0.5), "norm").pvalue > 1e-4  # still Gaussian, not t
+    np.testing.assert_allclose(ll.cpu().numpy(), -0.5 * (xs**2).sum(1), rtol=1e-12)
+
+
+def test_tpcn_default_sampler_run_gpu(eng):
+    from aspire_amd.flows import GaussianFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    d, n = 32, 200000
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=1.5, engine=eng, seed=3), xp=np,
+                engine=eng, rng=np.random.default_rng(4))
+    out = sp.sample(n, sampler_kwargs=dict(n_steps=16, noise="f32"), store_sample_history=False)
+    assert sp.sampler_kwargs["step_fn"] == "tpcn" and len(sp.history.mcmc_nu) == len(sp.history.beta)
+    assert abs(float(out.log_evidence) - 0.5 * d * math.log(math.pi)) < 5 * float(out.log_evidence_error) + 0.02
