@@ -256,6 +256,18 @@ def main():
         sync_all()
         ms = ev0.elapsed_time(ev1) / n_mc
         b_step = (2 * d * s_bytes + 16) * n_local
+        # the same loop with the Student-t reference (tpCN, nu = 8): + one gamma-variate kernel per step
+        eng.pcn_mutate(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, tgt, tgt, qm, 7, rank * n_local, 0.3, 4, 0, 0.234, True,
+                       args.noise, 8.0)
+        sync_all()
+        ev0.record()
+        eng.pcn_mutate(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, tgt, tgt, qm, 7, rank * n_local, 0.3, n_mc, 4, 0.234, True,
+                       args.noise, 8.0)
+        ev1.record()
+        sync_all()
+        ms_t = ev0.elapsed_time(ev1) / n_mc
+        extra["tpcn_kernel"] = {"ms_per_step": round(ms_t, 4), "particle_steps_per_s_per_gpu": n_local / (ms_t * 1e-3), "nu": 8.0,
+                                "noise": args.noise}
         extra["pcn_kernel"] = {"ms_per_step": round(ms, 4), "particle_steps_per_s_per_gpu": n_local / (ms * 1e-3),
                                "alg_bytes_per_step": b_step, "achieved_GBs": round(b_step / (ms * 1e-3) / 1e9, 1),
                                "frac_of_hbm_peak": round(b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -269,7 +281,7 @@ def main():
                     xp=np, engine=eng, comm=comm, rng=np.random.default_rng(2), dtype=args.x_dtype.replace("f", "float"))
         sync_all()
         t0 = time.perf_counter()
-        post = sp.sample(n_global, sampler_kwargs=dict(n_steps=n_mc, noise=args.noise), store_sample_history=False,
+        post = sp.sample(n_global, sampler_kwargs=dict(n_steps=n_mc, noise=args.noise, step_fn="pcn"), store_sample_history=False,
                          resample_mode=args.resample_mode)
         sync_all()
         t_s = time.perf_counter() - t0
@@ -281,6 +293,23 @@ def main():
                                 "analytic_log_evidence": true_logz,
                                 "abs_err_in_sigma": abs(float(post.log_evidence) - true_logz) / max(float(post.log_evidence_error), 1e-300),
                                 "mean_accept": float(np.mean(sp.history.mcmc_acceptance))}
+        # the reference's default mutation kernel (step_fn="tpcn": Student-t reference refitted per temperature)
+        spt = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=sigma_q, seed=1, engine=eng, dtype=xdt),
+                     xp=np, engine=eng, comm=comm, rng=np.random.default_rng(2), dtype=args.x_dtype.replace("f", "float"))
+        spt.sample(min(n_global, 65536 * world), sampler_kwargs=dict(n_steps=2, noise=args.noise), store_sample_history=False,
+                   resample_mode=args.resample_mode)  # warm (first-launch costs, scipy import)
+        sync_all()
+        t0 = time.perf_counter()
+        postt = spt.sample(n_global, sampler_kwargs=dict(n_steps=n_mc, noise=args.noise), store_sample_history=False,
+                           resample_mode=args.resample_mode)
+        sync_all()
+        t_t = time.perf_counter() - t0
+        extra["smc_tpcn_run"] = {"wall_s": round(t_t, 4), "temperatures": len(spt.history.beta), "mcmc_steps_per_temperature": n_mc,
+                                 "particle_steps_per_s": n_global * len(spt.history.beta) * n_mc / t_t,
+                                 "log_evidence": float(postt.log_evidence), "log_evidence_error": float(postt.log_evidence_error),
+                                 "abs_err_in_sigma": abs(float(postt.log_evidence) - true_logz) / max(float(postt.log_evidence_error), 1e-300),
+                                 "nu_per_temperature": [round(v, 2) for v in spt.history.mcmc_nu],
+                                 "mean_accept": float(np.mean(spt.history.mcmc_acceptance))}
         # configs[2] proper: coupling-flow proposal (4 coupling layers, MLP 16->64->64->32, float32) — flow
         # log-density on the fp32 MFMA inside the device-side pCN loop; roofline of that kernel against the
         # dense fp32 MFMA peak
@@ -292,12 +321,12 @@ def main():
             cflow.fit(sigma_q * 0.9 * gtrain.normal(size=(8000, d)), n_epochs=8)
             sp3 = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=cflow, xp=np, engine=eng, comm=comm,
                          rng=np.random.default_rng(2), dtype=args.x_dtype.replace("f", "float"))
-            sp3.sample(min(n_global, 65536 * world), sampler_kwargs=dict(n_steps=2, noise=args.noise), store_sample_history=False,
+            sp3.sample(min(n_global, 65536 * world), sampler_kwargs=dict(n_steps=2, noise=args.noise, step_fn="pcn"), store_sample_history=False,
                        resample_mode=args.resample_mode)  # warm (first-launch costs)
             sync_all()
             eng.profile(True)
             t0 = time.perf_counter()
-            post3 = sp3.sample(n_global, sampler_kwargs=dict(n_steps=n_mc, noise=args.noise), store_sample_history=False,
+            post3 = sp3.sample(n_global, sampler_kwargs=dict(n_steps=n_mc, noise=args.noise, step_fn="pcn"), store_sample_history=False,
                                resample_mode=args.resample_mode)
             sync_all()
             t3 = time.perf_counter() - t0
