@@ -414,8 +414,10 @@ class HipSMC(SMCSampler):
             sub = comm.all_gather_f64(sub).reshape(-1, x.shape[1])
         st = self._pcn_state
         with _single_threaded_blas():
-            mean, cov, nu = fit_student_t(sub, max_iter=int(self.sampler_kwargs.get("tpcn_fit_iters", 12)),
-                                          nu0=st.get("nu") or 20.0)
+            # EM sweeps: a cold start needs ~a dozen; later temperatures restart (mu, Sigma) from the subsample's
+            # moments and nu from the previous fit, and a few sweeps track the slowly changing population
+            iters = int(self.sampler_kwargs.get("tpcn_fit_iters", 12 if st.get("nu") is None else 4))
+            mean, cov, nu = fit_student_t(sub, max_iter=iters, nu0=st.get("nu") or 20.0)
             L = _chol(cov)
             Linv = np.linalg.inv(L)
         st["nu"] = nu

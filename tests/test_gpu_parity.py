@@ -620,7 +620,8 @@ def test_fused_sampler_1m_d32_evidence(eng):
     assert sp.history.beta[-1] == 1.0
 
 
-def test_config5_shape_mixture_d128_mfma_kernels(eng):
+@pytest.mark.parametrize("step_fn", ["tpcn", "pcn"])
+def test_config5_shape_mixture_d128_mfma_kernels(eng, step_fn):
     """BASELINE config 5 shape at reduced N: d=128 two-component Gaussian-mixture likelihood (the
     examples/smc_example.py construction), N(0,I) prior, q = N(0, 3^2 I); runs on the generic pCN kernel
     (d > 32) with the blocked Gram kernel; log Z is analytic (prior x normalised mixture => log Z = log of the
@@ -635,10 +636,14 @@ def test_config5_shape_mixture_d128_mfma_kernels(eng):
     sp = HipSMC(log_likelihood=lik, log_prior=prior, dims=d, prior_flow=GaussianFlow(d, sigma=3.0, engine=eng, seed=4),
                 xp=np, engine=eng, rng=np.random.default_rng(1))
     eng.profile(True)
-    out = sp.sample(n, sampler_kwargs=dict(n_steps=6), store_sample_history=False, max_n_steps=40)
+    out = sp.sample(n, sampler_kwargs=dict(n_steps=6, step_fn=step_fn), store_sample_history=False, max_n_steps=40)
     rep = eng.profile_report()
     eng.profile(False)
-    assert rep["k_pcn_mm_step"][0] >= 6 and rep["k_gram_mm"][0] >= 1 and "k_pcn_step_generic" not in rep
+    assert rep["k_tpcn_mm_step" if step_fn == "tpcn" else "k_pcn_mm_step"][0] >= 6 and "k_pcn_step_generic" not in rep
+    if step_fn == "pcn":  # Gaussian reference: population moments through the matrix-core Gram kernel
+        assert rep["k_gram_mm"][0] >= 1
+    else:  # Student-t reference: fitted on a host subsample, scale variates from their own kernel
+        assert rep["k_gamma_draw"][0] == rep["k_tpcn_mm_step"][0] and len(sp.history.mcmc_nu) == len(sp.history.beta)
     # Z = 0.5 * N(2; 0, (1 + 0.5) I) + 0.5 * N(-2; 0, (1 + 1) I)   (Gaussian convolution), per-dim product
     def lg(mu, var):
         return -0.5 * d * np.log(2 * np.pi * var) - 0.5 * d * mu * mu / var
@@ -714,8 +719,9 @@ def test_coupling_logprob_vs_torch_modules(eng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("xdt,d", [("f64", 32), ("f32", 32), ("f64", 8), ("f64", 20)])
-def test_pcn_mutate_flow_vs_split_calls(eng, xdt, d):
+@pytest.mark.parametrize("xdt,d,nu", [("f64", 32, 0.0), ("f32", 32, 0.0), ("f64", 8, 0.0), ("f64", 20, 0.0),
+                                        ("f64", 32, 5.0), ("f64", 20, 5.0)])
+def test_pcn_mutate_flow_vs_split_calls(eng, xdt, d, nu):
     """asmc_pcn_mutate_flow (whitened-state register kernels around the MFMA flow kernel, all steps enqueued on
     the device; d = 20 takes the generic composition) against the same steps issued one ABI call at a time in x
     space (propose / coupling_logprob / mixture_logpdf / accept), each of which is checked against the oracle
@@ -744,11 +750,11 @@ def test_pcn_mutate_flow_vs_split_calls(eng, xdt, d):
 
     xa, lla, lpa, lqa = init()
     n_acc, rho_hist, rho_out = eng.pcn_mutate_flow(xa, lla, lpa, lqa, beta, mu, L, Linv, t_ll, t_lp, dev, 77, 1000, rho,
-                                                   n_steps, 5, 0.234, False)
+                                                   n_steps, 5, 0.234, False, "f64", nu)
     xb, llb, lpb, lqb = init()
     acc_b = []
     for t in range(n_steps):
-        xp, q0, q1 = eng.pcn_propose(xb, mu, L, Linv, rho, 77, 1000, 5 + t)
+        xp, q0, q1 = eng.pcn_propose(xb, mu, L, Linv, rho, 77, 1000, 5 + t, nu=nu)
         lqn = eng.coupling_logprob(xp, dev)
         acc_b.append(eng.pcn_accept(xb, xp, llb, lpb, lqb, eng.mixture_logpdf(xp, t_ll), eng.mixture_logpdf(xp, t_lp), lqn,
                                     q0, q1, beta, 77, 1000, 5 + t))
@@ -772,7 +778,7 @@ def test_pcn_mutate_flow_vs_split_calls(eng, xdt, d):
     # adaptation on: rho_hist[t+1] = pcn_adapt(rho_hist[t], acc_t)
     xa, lla, lpa, lqa = init()
     n_acc, rho_hist, rho_out = eng.pcn_mutate_flow(xa, lla, lpa, lqa, beta, mu, L, Linv, t_ll, t_lp, dev, 77, 1000, rho,
-                                                   n_steps, 5, 0.234, True)
+                                                   n_steps, 5, 0.234, True, "f64", nu)
     r = rho
     for t in range(n_steps):
         assert rho_hist[t] == pytest.approx(r, rel=1e-12)
