@@ -71,6 +71,8 @@ struct asmc_ctx {
     unsigned int* d_guide;         // [n_max / 4 + 8] guide table of the resampling search
     unsigned char* d_flags;        // [n_max + 64] accept flags of the split-path pCN step
     double* d_gamma;               // [n_max] tpCN scale variates of the current step
+    void* d_ysoa;                  // coordinate-major whitened state of a mutation (grown on demand)
+    size_t ysoa_bytes;
     long long* d_counts;           // [ASMC_MAX_PCN_STEPS + max(ASMC_MAX_BLOCKS, n_max/64+1)] accept counts / partials
     double* d_rho;                 // [ASMC_MAX_PCN_STEPS + 8] step-size history on device
     unsigned long long* d_pcgtab;  // [64*4 + 8] PCG64 jump table

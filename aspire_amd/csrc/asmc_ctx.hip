@@ -155,6 +155,7 @@ int asmc_ctx_destroy(asmc_ctx* c) {
     (void)hipFree(c->d_guide);
     (void)hipFree(c->d_flags);
     (void)hipFree(c->d_gamma);
+    if (c->d_ysoa) (void)hipFree(c->d_ysoa);
     (void)hipFree(c->d_counts);
     (void)hipFree(c->d_rho);
     (void)hipFree(c->d_pcgtab);

@@ -276,6 +276,8 @@ struct PcnScalars {
     double beta;
     double nu;  // Student-t degrees of freedom of the reference (tpCN) or <= 0 (Gaussian pCN)
     const double* gam;  // per-particle Gamma((d + nu)/2, 1) variates of this step (k_gamma_draw), nullptr for pCN
+    void* ys;           // coordinate-major whitened state (PCN_*_S modes)
+    long long n_pad;    // its row length (n rounded up to 64)
     unsigned long long seed, gid0;
     int c_ll, c_lp, c_lq;
 };
@@ -321,16 +323,29 @@ __device__ __forceinline__ void wave_lds_sync() {
 #define PCN_UNWHITEN_X 4  // y -> x in place, carried ll/lp/lq untouched (flow-proposal path)
 #define PCN_X_STEP_T 5    // PCN_X_STEP / PCN_Y_STEP with the Student-t reference (tpCN), selected at compile time
 #define PCN_Y_STEP_T 6
+// whitened state kept COORDINATE-MAJOR in a scratch buffer (ys[j * n_pad + i]) for the length of a mutation: the step
+// kernel then needs no LDS staging at all (lane i reads 8 B of 64 consecutive particles per coordinate: 512-B coalesced
+// loads straight into registers), so its occupancy is set by registers (3 waves/SIMD) instead of the 17 KB LDS tile
+// (2 waves/SIMD), and rejected proposals cost no store.  x itself is only read by the first and written by the last.
+#define PCN_WHITEN_S 7      // x (row-major) -> ys
+#define PCN_Y_STEP_S 8      // step on ys
+#define PCN_Y_STEP_TS 9     // ... Student-t reference
+#define PCN_UNWHITEN_S 10   // ys -> x (row-major), ll / lp / lq re-evaluated at the stored x
 
 template <typename T, int D, int NOISE, int MODE>
-__global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restrict__ x, double* __restrict__ ll,
-                                                          double* __restrict__ lp, double* __restrict__ lq,
-                                                          const double* __restrict__ ptab, PcnScalars p,
-                                                          const double* __restrict__ rho_ptr, uint32_t step,
-                                                          long long* __restrict__ block_counts) {
+__device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, double* __restrict__ ll,
+                                             double* __restrict__ lp, double* __restrict__ lq,
+                                             const double* __restrict__ ptab, const PcnScalars& p,
+                                             const double* __restrict__ rho_ptr, uint32_t step,
+                                             long long* __restrict__ block_counts) {
     extern __shared__ __align__(16) char smem[];
-    constexpr bool TP = MODE == PCN_X_STEP_T || MODE == PCN_Y_STEP_T;
-    constexpr int M = TP ? MODE - PCN_X_STEP_T : MODE;
+    constexpr bool TP = MODE == PCN_X_STEP_T || MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS;
+    constexpr bool SOA = MODE >= PCN_WHITEN_S;
+    constexpr int M = MODE == PCN_WHITEN_S ? PCN_WHITEN : (MODE == PCN_Y_STEP_S || MODE == PCN_Y_STEP_TS) ? PCN_Y_STEP
+                      : MODE == PCN_UNWHITEN_S ? PCN_UNWHITEN : TP ? MODE - PCN_X_STEP_T : MODE;
+    constexpr bool ROW_IN = !SOA || M == PCN_WHITEN;     // the state arrives as row-major x through the LDS tile
+    constexpr bool ROW_OUT = !SOA || M == PCN_UNWHITEN;  // ... leaves that way
+    T* __restrict__ ys = reinterpret_cast<T*>(p.ys);
     constexpr int ROWB = D * (int)sizeof(T);
     constexpr int LDSROW = ROWB + 16;
     const int WPB = (int)(blockDim.x >> 6);  // waves per block: chosen by the launcher from the LDS budget
@@ -348,10 +363,12 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
         const bool active = true;
         const int64_t row0 = t * 64;
         const int64_t i = row0 + lane;
+        // coordinate-major state: wave-uniform tile base (scalar registers) + the lane as a 32-bit offset
+        T* __restrict__ ysw = ys + (int64_t)__builtin_amdgcn_readfirstlane((int)t) * 64;
         const bool valid = active && i < n;
         const int64_t valid_bytes = active ? (((n - row0) < 64 ? (n - row0) : 64) * (int64_t)ROWB) : 0;
         char* gbase = reinterpret_cast<char*>(x) + row0 * ROWB;
-        if (active) tile_load<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane);
+        if (active && ROW_IN) tile_load<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane);
         double oll = 0.0, olp = 0.0, olq = 0.0;
         if (valid && (M == PCN_X_STEP || M == PCN_Y_STEP)) {
             oll = ll[i];
@@ -374,15 +391,25 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
         if (valid) {
             const unsigned long long gid = p.gid0 + (unsigned long long)i;
             double v[D];
-            row_to_regs<T, D>(myrow, v);
+            if (ROW_IN) {
+                row_to_regs<T, D>(myrow, v);
+            } else {
+#pragma unroll
+                for (int j = 0; j < D; j++) v[j] = (double)ysw[(size_t)j * p.n_pad + (unsigned)lane];
+            }
             if (M == PCN_WHITEN) {
 #pragma unroll
                 for (int j = 0; j < D; j++) v[j] -= mup[j];
                 tri_matvec_inplace<D>(Lip, v);
+                if (SOA) {
 #pragma unroll
-                for (int j = 0; j < D; j++) v[j] = (double)(T)v[j];
-                regs_to_row<T, D>(myrow, v);
-                acc = true;
+                    for (int j = 0; j < D; j++) ysw[(size_t)j * p.n_pad + (unsigned)lane] = (T)v[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < D; j++) v[j] = (double)(T)v[j];
+                    regs_to_row<T, D>(myrow, v);
+                    acc = true;
+                }
             } else if (M == PCN_UNWHITEN || M == PCN_UNWHITEN_X) {
                 tri_matvec_inplace<D>(Lp, v);
 #pragma unroll
@@ -491,7 +518,12 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
                 const double u = accept_uniform(p.seed, gid, step);
                 acc = log(u) < log_a;
                 if (acc) {
-                    regs_to_row<T, D>(myrow, v);
+                    if (ROW_OUT) {
+                        regs_to_row<T, D>(myrow, v);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < D; j++) ysw[(size_t)j * p.n_pad + (unsigned)lane] = (T)v[j];
+                    }
                     ll[i] = nll;
                     lp[i] = nlp;
                     lq[i] = nlq;
@@ -501,7 +533,7 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
         }
         wave_lds_sync();
         {
-            const unsigned long long accmask = __ballot(acc);
+            const unsigned long long accmask = ROW_OUT ? __ballot(acc) : 0ULL;
             if (accmask != 0ULL) tile_store_rows<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane, accmask);
         }
         wave_lds_sync();
@@ -518,6 +550,16 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
         }
     }
 }
+
+template <typename T, int D, int NOISE, int MODE>
+__global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restrict__ x, double* __restrict__ ll,
+                                                          double* __restrict__ lp, double* __restrict__ lq,
+                                                          const double* __restrict__ ptab, PcnScalars p,
+                                                          const double* __restrict__ rho_ptr, uint32_t step,
+                                                          long long* __restrict__ block_counts) {
+    pcn_reg_body<T, D, NOISE, MODE>(n, x, ll, lp, lq, ptab, p, rho_ptr, step, block_counts);
+}
+// (a three-waves-per-SIMD build of the LDS-free step modes spills 200-300 B/lane to scratch and is slower: 0.19 vs 0.136 ms)
 
 // Flow-proposal pCN on the whitened state, split around the flow's log-density kernel (asmc_flow.hip):
 //   PCN_FLOW_PROPOSE  y' = a y + rho xi;  x' = mu + L y'  -> x_prop tile, ll'(x'), lp'(x') (built-in targets)
@@ -1044,8 +1086,9 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     // when the tile is large (d = 32 fp64: 17 KB tiles -> 2 blocks of 4 = 8 waves, but 9 single-wave blocks)
     constexpr size_t tile_bytes = (size_t)64 * LDSROW;
     static int wpb_env = getenv("ASMC_PCN_WPB") ? atoi(getenv("ASMC_PCN_WPB")) : 0;
-    const int wpb = wpb_env > 0 ? wpb_env : ((160 * 1024) / tile_bytes % 4 == 0 || tile_bytes * 12 <= 160 * 1024 ? 4 : 1);
-    const size_t lds_bytes = (size_t)wpb * tile_bytes;
+    constexpr bool NO_LDS = MODE == PCN_Y_STEP_S || MODE == PCN_Y_STEP_TS;  // coordinate-major state: registers only
+    const int wpb = wpb_env > 0 ? wpb_env : (NO_LDS || (160 * 1024) / tile_bytes % 4 == 0 || tile_bytes * 12 <= 160 * 1024 ? 4 : 1);
+    const size_t lds_bytes = NO_LDS ? 0 : (size_t)wpb * tile_bytes;
     const int64_t n_tiles = (n + 63) / 64;
     const int64_t grid64 = (n_tiles + wpb - 1) / wpb;
     if (grid64 > ASMC_PCN_MAX_GRID) {
@@ -1064,12 +1107,14 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     ps.beta = pd.beta;
     ps.nu = pd.nu;
     ps.gam = pd.gam;
+    ps.ys = pd.ys;
+    ps.n_pad = pd.n_pad;
     ps.seed = pd.seed;
     ps.gid0 = pd.gid0;
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
-    ASMC_LAUNCH(ctx, st, MODE == PCN_X_STEP ? "k_pcn_reg" : MODE == PCN_Y_STEP ? "k_pcn_reg_y" : MODE == PCN_X_STEP_T ? "k_tpcn_reg" : MODE == PCN_Y_STEP_T ? "k_tpcn_reg_y" : MODE == PCN_WHITEN ? "k_pcn_whiten" : "k_pcn_unwhiten", kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
+    ASMC_LAUNCH(ctx, st, MODE == PCN_X_STEP ? "k_pcn_reg" : (MODE == PCN_Y_STEP || MODE == PCN_Y_STEP_S) ? "k_pcn_reg_y" : MODE == PCN_X_STEP_T ? "k_tpcn_reg" : (MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS) ? "k_tpcn_reg_y" : (MODE == PCN_WHITEN || MODE == PCN_WHITEN_S) ? "k_pcn_whiten" : "k_pcn_unwhiten", kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
                        rho_ptr, step, block_counts);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -1100,6 +1145,8 @@ static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double
     ps.beta = pd.beta;
     ps.nu = pd.nu;
     ps.gam = pd.gam;
+    ps.ys = nullptr;
+    ps.n_pad = 0;
     ps.seed = pd.seed;
     ps.gid0 = pd.gid0;
     ps.c_ll = pd.ll.C;
@@ -1140,9 +1187,9 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
                            T* x_prop, double* qf_old, double* qf_new, hipStream_t st) {
     const int rowbytes = pd.d * (int)sizeof(T);
     if (PHASE == 0 && pcn_reg_supported(pd.d, sizeof(T), x)) {
-        switch (pd.d * 16 + (pd.noise == ASMC_NOISE_F32 ? 8 : 0) + pd.mode) {  // register-resident specialisations
+        switch (pd.d * 64 + (pd.noise == ASMC_NOISE_F32 ? 32 : 0) + pd.mode) {  // register-resident specialisations
 #define PCN_CASE2(DD, NZ, MD) \
-    case DD * 16 + (NZ == ASMC_NOISE_F32 ? 8 : 0) + MD: \
+    case DD * 64 + (NZ == ASMC_NOISE_F32 ? 32 : 0) + MD: \
         return launch_pcn_reg<T, DD, NZ, MD>(ctx, n, x, ll, lp, lq, pd, rho_ptr, step, block_counts, grid_out, st);
 #define PCN_CASE(DD)                            \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_X_STEP)   \
@@ -1153,6 +1200,12 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
     PCN_CASE2(DD, ASMC_NOISE_F32, PCN_X_STEP_T) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_Y_STEP_T) \
     PCN_CASE2(DD, ASMC_NOISE_F32, PCN_Y_STEP_T) \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_Y_STEP_S)  \
+    PCN_CASE2(DD, ASMC_NOISE_F32, PCN_Y_STEP_S)  \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_Y_STEP_TS) \
+    PCN_CASE2(DD, ASMC_NOISE_F32, PCN_Y_STEP_TS) \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_WHITEN_S)  \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN_S) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_WHITEN)   \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN_X)
@@ -1388,6 +1441,7 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
     PcnDev pd;
+    memset(&pd, 0, sizeof(pd));
     pd.d = prm->d;
     pd.beta = prm->beta;
     pd.mu = prm->mu_dev;
@@ -1447,10 +1501,31 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     const bool reg_ok = pcn_reg_supported(pd.d, prm->x_dtype == ASMC_F64 ? 8 : 4, x);
     // whitened-state stepping: plain (single-component) targets, enough steps to amortise the two conversions
     const bool y_state = reg_ok && pd.ll.C == 1 && pd.lp.C == 1 && pd.lq.C == 1 && n_steps >= 4 && !getenv("ASMC_PCN_XSTATE");
+    // whitened state in a coordinate-major scratch buffer (grown on demand, kept for the life of the ctx)
+    bool soa = y_state && !getenv("ASMC_PCN_AOS");
+    if (soa) {
+        const int64_t n_pad = ((n + 63) / 64) * 64;
+        const size_t need = (size_t)n_pad * pd.d * (prm->x_dtype == ASMC_F64 ? 8 : 4);
+        if (need > ctx->ysoa_bytes) {
+            ASMC_HIP(hipStreamSynchronize(st));
+            if (ctx->d_ysoa) (void)hipFree(ctx->d_ysoa);
+            ctx->d_ysoa = nullptr;
+            ctx->ysoa_bytes = 0;
+            if (hipMalloc(&ctx->d_ysoa, need) == hipSuccess)
+                ctx->ysoa_bytes = need;
+            else
+                soa = false;  // no room for the scratch: stay on the in-place row-major path
+        }
+        pd.ys = soa ? ctx->d_ysoa : nullptr;
+        pd.n_pad = n_pad;
+    }
     auto launch_mode = [&](int mode, uint32_t stp, int* grid) -> int {
+        if (soa) mode = mode == PCN_WHITEN ? PCN_WHITEN_S : mode == PCN_UNWHITEN ? PCN_UNWHITEN_S : mode == PCN_Y_STEP ? PCN_Y_STEP_S
+                        : mode == PCN_Y_STEP_T ? PCN_Y_STEP_TS : mode;
         pd.mode = mode;
         const int nz = pd.noise;
-        if (mode == PCN_WHITEN || mode == PCN_UNWHITEN || mode == PCN_UNWHITEN_X) pd.noise = ASMC_NOISE_F64;
+        if (mode == PCN_WHITEN || mode == PCN_UNWHITEN || mode == PCN_UNWHITEN_X || mode == PCN_WHITEN_S || mode == PCN_UNWHITEN_S)
+            pd.noise = ASMC_NOISE_F64;
         int r;
         if (prm->x_dtype == ASMC_F64)
             r = launch_pcn_step<double, 0>(ctx, n, (double*)x, ll, lp, lq, pd, d_rho, stp, d_block, grid, nullptr, nullptr, nullptr, st);

@@ -163,6 +163,8 @@ struct PcnDev {
     int noise;
     double nu;  // > 0: Student-t reference with nu degrees of freedom (tpCN); <= 0: Gaussian reference (pCN)
     const double* gam;  // [n] unit-scale Gamma((d + nu)/2) variates of the current step (tpCN), else nullptr
+    void* ys;           // coordinate-major whitened state of the register-resident kernels (or nullptr)
+    long long n_pad;
     int mode;  // PCN_X_STEP / PCN_Y_STEP / PCN_WHITEN / PCN_UNWHITEN (register-resident kernels)
 };
 
