@@ -331,6 +331,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 #define PCN_Y_STEP_S 8      // step on ys
 #define PCN_Y_STEP_TS 9     // ... Student-t reference
 #define PCN_UNWHITEN_S 10   // ys -> x (row-major), ll / lp / lq re-evaluated at the stored x
+#define PCN_UNWHITEN_XS 11  // ys -> x (row-major), carried ll / lp / lq untouched (flow-proposal path)
 
 template <typename T, int D, int NOISE, int MODE>
 __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, double* __restrict__ ll,
@@ -342,9 +343,10 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
     constexpr bool TP = MODE == PCN_X_STEP_T || MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS;
     constexpr bool SOA = MODE >= PCN_WHITEN_S;
     constexpr int M = MODE == PCN_WHITEN_S ? PCN_WHITEN : (MODE == PCN_Y_STEP_S || MODE == PCN_Y_STEP_TS) ? PCN_Y_STEP
-                      : MODE == PCN_UNWHITEN_S ? PCN_UNWHITEN : TP ? MODE - PCN_X_STEP_T : MODE;
+                      : MODE == PCN_UNWHITEN_S ? PCN_UNWHITEN : MODE == PCN_UNWHITEN_XS ? PCN_UNWHITEN_X
+                      : TP ? MODE - PCN_X_STEP_T : MODE;
     constexpr bool ROW_IN = !SOA || M == PCN_WHITEN;     // the state arrives as row-major x through the LDS tile
-    constexpr bool ROW_OUT = !SOA || M == PCN_UNWHITEN;  // ... leaves that way
+    constexpr bool ROW_OUT = !SOA || M == PCN_UNWHITEN || M == PCN_UNWHITEN_X;  // ... leaves that way
     T* __restrict__ ys = reinterpret_cast<T*>(p.ys);
     constexpr int ROWB = D * (int)sizeof(T);
     constexpr int LDSROW = ROWB + 16;
@@ -567,6 +569,8 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
 //                     ll', lp', lq' and accepts: y <- y' (accepted rows only), carried log-probs updated
 #define PCN_FLOW_PROPOSE 0
 #define PCN_FLOW_ACCEPT 1
+#define PCN_FLOW_PROPOSE_S 2  // the same with y coordinate-major in p.ys (see PCN_*_S above): propose stages only x'
+#define PCN_FLOW_ACCEPT_S 3   // through LDS, accept touches no LDS at all
 
 template <typename T, int D, int NOISE, int MODE>
 __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
@@ -575,6 +579,8 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
     const double* __restrict__ ptab, PcnScalars p, const double* __restrict__ rho_ptr, uint32_t step,
     long long* __restrict__ block_counts) {
     extern __shared__ __align__(16) char smem[];
+    constexpr bool SOA = MODE >= PCN_FLOW_PROPOSE_S;
+    constexpr int M = SOA ? MODE - PCN_FLOW_PROPOSE_S : MODE;
     constexpr int ROWB = D * (int)sizeof(T);
     constexpr int LDSROW = ROWB + 16;
     const int WPB = (int)(blockDim.x >> 6);
@@ -591,9 +597,10 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
         const int64_t i = row0 + lane;
         const bool valid = i < n;
         const int64_t valid_bytes = ((n - row0) < 64 ? (n - row0) : 64) * (int64_t)ROWB;
-        tile_load<16>(reinterpret_cast<const char*>(y) + row0 * ROWB, valid_bytes, ROWB, LDSROW, tile, lane);
+        if (!SOA) tile_load<16>(reinterpret_cast<const char*>(y) + row0 * ROWB, valid_bytes, ROWB, LDSROW, tile, lane);
+        T* __restrict__ ysw = reinterpret_cast<T*>(p.ys) + (int64_t)__builtin_amdgcn_readfirstlane((int)t) * 64;
         double oll = 0.0, olp = 0.0, olq = 0.0, nll = 0.0, nlp = 0.0, nlq = 0.0;
-        if (valid && MODE == PCN_FLOW_ACCEPT) {
+        if (valid && M == PCN_FLOW_ACCEPT) {
             oll = ll[i], olp = lp[i], olq = lq[i];
             nll = ll_new[i], nlp = lp_new[i], nlq = lq_new[i];
         }
@@ -608,7 +615,12 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
         if (valid) {
             const unsigned long long gid = p.gid0 + (unsigned long long)i;
             double v[D];
-            row_to_regs<T, D>(myrow, v);
+            if (SOA) {
+#pragma unroll
+                for (int j = 0; j < D; j++) v[j] = (double)ysw[(size_t)j * p.n_pad + (unsigned)lane];
+            } else {
+                row_to_regs<T, D>(myrow, v);
+            }
             double q0 = 0.0, q1 = 0.0;
 #pragma unroll
             for (int j = 0; j < D; j++) q0 = fma(v[j], v[j], q0);
@@ -637,7 +649,7 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
                     if (qd & 1) __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (MODE == PCN_FLOW_PROPOSE) {
+            if (M == PCN_FLOW_PROPOSE) {
                 tri_matvec_inplace<D>(Lp, v);
 #pragma unroll
                 for (int j = 0; j < D; j++) v[j] = (double)(T)(mup[j] + v[j]);
@@ -652,7 +664,12 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
                 const double u = accept_uniform(p.seed, gid, step);
                 acc = log(u) < log_a;
                 if (acc) {
-                    regs_to_row<T, D>(myrow, v);
+                    if (SOA) {
+#pragma unroll
+                        for (int j = 0; j < D; j++) ysw[(size_t)j * p.n_pad + (unsigned)lane] = (T)v[j];
+                    } else {
+                        regs_to_row<T, D>(myrow, v);
+                    }
                     ll[i] = nll;
                     lp[i] = nlp;
                     lq[i] = nlq;
@@ -662,13 +679,13 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
         }
         wave_lds_sync();
         {
-            const unsigned long long accmask = __ballot(acc);
-            char* obase = reinterpret_cast<char*>(MODE == PCN_FLOW_PROPOSE ? x_prop : y) + row0 * ROWB;
+            const unsigned long long accmask = (SOA && M == PCN_FLOW_ACCEPT) ? 0ULL : __ballot(acc);
+            char* obase = reinterpret_cast<char*>(M == PCN_FLOW_PROPOSE ? x_prop : y) + row0 * ROWB;
             if (accmask != 0ULL) tile_store_rows<16>(obase, valid_bytes, ROWB, LDSROW, tile, lane, accmask);
         }
         wave_lds_sync();
     }
-    if (MODE == PCN_FLOW_ACCEPT) {
+    if (M == PCN_FLOW_ACCEPT) {
         __shared__ long long s_cnt[ASMC_BLOCK / 64];
         n_acc = wave_sum_ll(n_acc);
         if (lane == 0) s_cnt[wave] = n_acc;
@@ -1127,8 +1144,9 @@ static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double
                                hipStream_t st) {
     constexpr int LDSROW = D * (int)sizeof(T) + 16;
     constexpr size_t tile_bytes = (size_t)64 * LDSROW;
-    const int wpb = ((160 * 1024) / tile_bytes % 4 == 0 || tile_bytes * 12 <= 160 * 1024) ? 4 : 1;
-    const size_t lds_bytes = (size_t)wpb * tile_bytes;
+    constexpr bool NO_LDS = MODE == PCN_FLOW_ACCEPT_S;
+    const int wpb = (NO_LDS || (160 * 1024) / tile_bytes % 4 == 0 || tile_bytes * 12 <= 160 * 1024) ? 4 : 1;
+    const size_t lds_bytes = NO_LDS ? 0 : (size_t)wpb * tile_bytes;
     const int64_t grid64 = ((n + 63) / 64 + wpb - 1) / wpb;
     if (grid64 > ASMC_PCN_MAX_GRID) {
         asmc_set_error("pcn: n=%lld exceeds the per-call block budget", (long long)n);
@@ -1145,14 +1163,14 @@ static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double
     ps.beta = pd.beta;
     ps.nu = pd.nu;
     ps.gam = pd.gam;
-    ps.ys = nullptr;
-    ps.n_pad = 0;
+    ps.ys = pd.ys;
+    ps.n_pad = pd.n_pad;
     ps.seed = pd.seed;
     ps.gid0 = pd.gid0;
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
-    ASMC_LAUNCH(ctx, st, MODE == PCN_FLOW_PROPOSE ? "k_pcn_flow_propose" : "k_pcn_flow_accept", kern, dim3((int)grid64),
+    ASMC_LAUNCH(ctx, st, (MODE == PCN_FLOW_PROPOSE || MODE == PCN_FLOW_PROPOSE_S) ? "k_pcn_flow_propose" : "k_pcn_flow_accept", kern, dim3((int)grid64),
                 dim3(wpb * 64), lds_bytes, st, n, y, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, (const double*)ctx->d_ptab, ps,
                 rho_ptr, step, block_counts);
     ASMC_LAUNCH_CHECK();
@@ -1206,6 +1224,7 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
     PCN_CASE2(DD, ASMC_NOISE_F32, PCN_Y_STEP_TS) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_WHITEN_S)  \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN_S) \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN_XS) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_WHITEN)   \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN_X)
@@ -1414,6 +1433,28 @@ int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
     return ASMC_OK;
 }
 
+// coordinate-major scratch for the whitened state of one mutation (grown on demand, kept for the life of the ctx);
+// false when the device has no room for it (callers then stay on the in-place row-major path)
+static bool pcn_ensure_ysoa(asmc_ctx* ctx, int64_t n, int d, int x_dtype, PcnDev& pd, hipStream_t st) {
+    if (getenv("ASMC_PCN_AOS")) return false;
+    const int64_t n_pad = ((n + 63) / 64) * 64;
+    const size_t need = (size_t)n_pad * d * (x_dtype == ASMC_F64 ? 8 : 4);
+    if (need > ctx->ysoa_bytes) {
+        if (hipStreamSynchronize(st) != hipSuccess) return false;
+        if (ctx->d_ysoa) (void)hipFree(ctx->d_ysoa);
+        ctx->d_ysoa = nullptr;
+        ctx->ysoa_bytes = 0;
+        if (hipMalloc(&ctx->d_ysoa, need) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        ctx->ysoa_bytes = need;
+    }
+    pd.ys = ctx->d_ysoa;
+    pd.n_pad = n_pad;
+    return true;
+}
+
 int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int64_t* cell_dev, int64_t n_global) {
     ASMC_REQUIRE(ctx != nullptr, "null ctx");
     ASMC_REQUIRE(hook == nullptr || (cell_dev != nullptr && n_global > 0), "hook needs a device cell and n_global > 0");
@@ -1502,23 +1543,7 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     // whitened-state stepping: plain (single-component) targets, enough steps to amortise the two conversions
     const bool y_state = reg_ok && pd.ll.C == 1 && pd.lp.C == 1 && pd.lq.C == 1 && n_steps >= 4 && !getenv("ASMC_PCN_XSTATE");
     // whitened state in a coordinate-major scratch buffer (grown on demand, kept for the life of the ctx)
-    bool soa = y_state && !getenv("ASMC_PCN_AOS");
-    if (soa) {
-        const int64_t n_pad = ((n + 63) / 64) * 64;
-        const size_t need = (size_t)n_pad * pd.d * (prm->x_dtype == ASMC_F64 ? 8 : 4);
-        if (need > ctx->ysoa_bytes) {
-            ASMC_HIP(hipStreamSynchronize(st));
-            if (ctx->d_ysoa) (void)hipFree(ctx->d_ysoa);
-            ctx->d_ysoa = nullptr;
-            ctx->ysoa_bytes = 0;
-            if (hipMalloc(&ctx->d_ysoa, need) == hipSuccess)
-                ctx->ysoa_bytes = need;
-            else
-                soa = false;  // no room for the scratch: stay on the in-place row-major path
-        }
-        pd.ys = soa ? ctx->d_ysoa : nullptr;
-        pd.n_pad = n_pad;
-    }
+    const bool soa = y_state && pcn_ensure_ysoa(ctx, n, pd.d, prm->x_dtype, pd, st);
     auto launch_mode = [&](int mode, uint32_t stp, int* grid) -> int {
         if (soa) mode = mode == PCN_WHITEN ? PCN_WHITEN_S : mode == PCN_UNWHITEN ? PCN_UNWHITEN_S : mode == PCN_Y_STEP ? PCN_Y_STEP_S
                         : mode == PCN_Y_STEP_T ? PCN_Y_STEP_TS : mode;
@@ -1702,9 +1727,10 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
         if (rc) return rc;
         long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
         int grid = 0;
+        const bool soa = pcn_ensure_ysoa(ctx, n, d, prm->x_dtype, pd, st);
         auto convert = [&](int mode) -> int {
             PcnDev pc = pd;
-            pc.mode = mode;
+            pc.mode = !soa ? mode : mode == PCN_WHITEN ? PCN_WHITEN_S : PCN_UNWHITEN_XS;
             pc.noise = ASMC_NOISE_F64;
             if (prm->x_dtype == ASMC_F64)
                 return launch_pcn_step<double, 0>(ctx, n, (double*)x, ll, lp, lq, pc, d_rho, 0, d_block, &grid, nullptr, nullptr, nullptr, st);
@@ -1716,21 +1742,21 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
             const uint32_t step = step0 + (uint32_t)t;
             rc = pcn_prepare_gamma(ctx, n, pd, step, st);
             if (rc) return rc;
+#define FLOW_STEP(TT, MD)                                                                                               \
+    dispatch_pcn_reg_flow<TT, MD>(ctx, n, (TT*)x, (TT*)x_prop, ll, lp, lq, ll_new, lp_new, lq_new, pd, d_rho, step, d_block, \
+                                  &grid, st)
             if (prm->x_dtype == ASMC_F64)
-                rc = dispatch_pcn_reg_flow<double, PCN_FLOW_PROPOSE>(ctx, n, (double*)x, (double*)x_prop, ll, lp, lq, ll_new, lp_new,
-                                                                     lq_new, pd, d_rho, step, d_block, &grid, st);
+                rc = soa ? FLOW_STEP(double, PCN_FLOW_PROPOSE_S) : FLOW_STEP(double, PCN_FLOW_PROPOSE);
             else
-                rc = dispatch_pcn_reg_flow<float, PCN_FLOW_PROPOSE>(ctx, n, (float*)x, (float*)x_prop, ll, lp, lq, ll_new, lp_new,
-                                                                    lq_new, pd, d_rho, step, d_block, &grid, st);
+                rc = soa ? FLOW_STEP(float, PCN_FLOW_PROPOSE_S) : FLOW_STEP(float, PCN_FLOW_PROPOSE);
             if (rc) return rc;
             rc = asmc_coupling_logprob(ctx, n, prm->x_dtype, x_prop, flow, lq_new, stream);
             if (rc) return rc;
             if (prm->x_dtype == ASMC_F64)
-                rc = dispatch_pcn_reg_flow<double, PCN_FLOW_ACCEPT>(ctx, n, (double*)x, (double*)x_prop, ll, lp, lq, ll_new, lp_new,
-                                                                    lq_new, pd, d_rho, step, d_block, &grid, st);
+                rc = soa ? FLOW_STEP(double, PCN_FLOW_ACCEPT_S) : FLOW_STEP(double, PCN_FLOW_ACCEPT);
             else
-                rc = dispatch_pcn_reg_flow<float, PCN_FLOW_ACCEPT>(ctx, n, (float*)x, (float*)x_prop, ll, lp, lq, ll_new, lp_new,
-                                                                   lq_new, pd, d_rho, step, d_block, &grid, st);
+                rc = soa ? FLOW_STEP(float, PCN_FLOW_ACCEPT_S) : FLOW_STEP(float, PCN_FLOW_ACCEPT);
+#undef FLOW_STEP
             if (rc) return rc;
             rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
             if (rc) return rc;
