@@ -332,6 +332,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 #define PCN_Y_STEP_TS 9     // ... Student-t reference
 #define PCN_UNWHITEN_S 10   // ys -> x (row-major), ll / lp / lq re-evaluated at the stored x
 #define PCN_UNWHITEN_XS 11  // ys -> x (row-major), carried ll / lp / lq untouched (flow-proposal path)
+// proposal half of the split path (arbitrary Python callables evaluate the densities between propose and accept):
+// x' -> the row-major buffer in p.ys, twice the reference's correction at y and y' -> the ll / lp arguments
+#define PCN_X_PROPOSE 12
+#define PCN_X_PROPOSE_T 13
 
 template <typename T, int D, int NOISE, int MODE>
 __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, double* __restrict__ ll,
@@ -340,9 +344,10 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
                                              const double* __restrict__ rho_ptr, uint32_t step,
                                              long long* __restrict__ block_counts) {
     extern __shared__ __align__(16) char smem[];
-    constexpr bool TP = MODE == PCN_X_STEP_T || MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS;
-    constexpr bool SOA = MODE >= PCN_WHITEN_S;
-    constexpr int M = MODE == PCN_WHITEN_S ? PCN_WHITEN : (MODE == PCN_Y_STEP_S || MODE == PCN_Y_STEP_TS) ? PCN_Y_STEP
+    constexpr bool TP = MODE == PCN_X_STEP_T || MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS || MODE == PCN_X_PROPOSE_T;
+    constexpr bool SOA = MODE >= PCN_WHITEN_S && MODE <= PCN_UNWHITEN_XS;
+    constexpr bool PROPOSE = MODE == PCN_X_PROPOSE || MODE == PCN_X_PROPOSE_T;
+    constexpr int M = PROPOSE ? PCN_X_STEP : MODE == PCN_WHITEN_S ? PCN_WHITEN : (MODE == PCN_Y_STEP_S || MODE == PCN_Y_STEP_TS) ? PCN_Y_STEP
                       : MODE == PCN_UNWHITEN_S ? PCN_UNWHITEN : MODE == PCN_UNWHITEN_XS ? PCN_UNWHITEN_X
                       : TP ? MODE - PCN_X_STEP_T : MODE;
     constexpr bool ROW_IN = !SOA || M == PCN_WHITEN;     // the state arrives as row-major x through the LDS tile
@@ -372,7 +377,7 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
         char* gbase = reinterpret_cast<char*>(x) + row0 * ROWB;
         if (active && ROW_IN) tile_load<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane);
         double oll = 0.0, olp = 0.0, olq = 0.0;
-        if (valid && (M == PCN_X_STEP || M == PCN_Y_STEP)) {
+        if (valid && !PROPOSE && (M == PCN_X_STEP || M == PCN_Y_STEP)) {
             oll = ll[i];
             olp = lp[i];
             olq = lq[i];
@@ -479,10 +484,20 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
 #endif
 #pragma unroll
                     for (int j = 0; j < D; j++) v[j] = (double)(T)(mup[j] + v[j]);
+                    if (PROPOSE) {
+                        ll[i] = 2.0 * ref_corr_ct<TP>(q0, p.nu, D);
+                        lp[i] = 2.0 * ref_corr_ct<TP>(q1, p.nu, D);
+                        regs_to_row<T, D>(myrow, v);
+                        acc = true;
+                    }
 #ifndef ASMC_ABLATE_TARGET
-                    nll = mixture_eval_regs<D>(mll, v);
-                    nlp = mixture_eval_regs<D>(mlp, v);
-                    nlq = mixture_eval_regs<D>(mlq, v);
+                    if (!PROPOSE) {
+                        nll = mixture_eval_regs<D>(mll, v);
+                        nlp = mixture_eval_regs<D>(mlp, v);
+                        nlq = mixture_eval_regs<D>(mlq, v);
+                    } else {
+                        nll = nlp = nlq = 0.0;
+                    }
 #else
                     nll = v[0], nlp = v[1], nlq = v[2];
 #endif
@@ -518,8 +533,8 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
                 const double lpo = log_p_t(oll, olp, olq, p.beta);
                 const double log_a = (lpn + ref_corr_ct<TP>(q1, p.nu, D)) - (lpo + ref_corr_ct<TP>(q0, p.nu, D));
                 const double u = accept_uniform(p.seed, gid, step);
-                acc = log(u) < log_a;
-                if (acc) {
+                if (!PROPOSE) acc = log(u) < log_a;
+                if (acc && !PROPOSE) {
                     if (ROW_OUT) {
                         regs_to_row<T, D>(myrow, v);
                     } else {
@@ -536,11 +551,12 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
         wave_lds_sync();
         {
             const unsigned long long accmask = ROW_OUT ? __ballot(acc) : 0ULL;
-            if (accmask != 0ULL) tile_store_rows<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane, accmask);
+            char* obase = PROPOSE ? reinterpret_cast<char*>(p.ys) + row0 * ROWB : gbase;
+            if (accmask != 0ULL) tile_store_rows<16>(obase, valid_bytes, ROWB, LDSROW, tile, lane, accmask);
         }
         wave_lds_sync();
     }
-    if (M == PCN_X_STEP || M == PCN_Y_STEP) {
+    if (!PROPOSE && (M == PCN_X_STEP || M == PCN_Y_STEP)) {
         __shared__ long long s_cnt[ASMC_BLOCK / 64];
         n_acc = wave_sum_ll(n_acc);
         if (lane == 0) s_cnt[wave] = n_acc;
@@ -1131,7 +1147,7 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
-    ASMC_LAUNCH(ctx, st, MODE == PCN_X_STEP ? "k_pcn_reg" : (MODE == PCN_Y_STEP || MODE == PCN_Y_STEP_S) ? "k_pcn_reg_y" : MODE == PCN_X_STEP_T ? "k_tpcn_reg" : (MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS) ? "k_tpcn_reg_y" : (MODE == PCN_WHITEN || MODE == PCN_WHITEN_S) ? "k_pcn_whiten" : "k_pcn_unwhiten", kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
+    ASMC_LAUNCH(ctx, st, MODE == PCN_X_STEP ? "k_pcn_reg" : (MODE == PCN_Y_STEP || MODE == PCN_Y_STEP_S) ? "k_pcn_reg_y" : MODE == PCN_X_STEP_T ? "k_tpcn_reg" : (MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS) ? "k_tpcn_reg_y" : (MODE == PCN_WHITEN || MODE == PCN_WHITEN_S) ? "k_pcn_whiten" : (MODE == PCN_X_PROPOSE || MODE == PCN_X_PROPOSE_T) ? "k_pcn_propose_reg" : "k_pcn_unwhiten", kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
                        rho_ptr, step, block_counts);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -1225,6 +1241,8 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_WHITEN_S)  \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN_S) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN_XS) \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_X_PROPOSE) \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_X_PROPOSE_T) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_WHITEN)   \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN_X)
@@ -1621,6 +1639,19 @@ int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x
     int grid = 0;
     int rc = pcn_prepare_gamma(ctx, n, pd, step, st);
     if (rc) return rc;
+    if (pcn_reg_supported(d, x_dtype == ASMC_F64 ? 8 : 4, x) && ((uintptr_t)x_prop % 16) == 0) {
+        // d in {4, 8, 16, 32}: the register-resident kernel's proposal half (same arithmetic as the fused step)
+        pd.mode = pd.nu > 0.0 ? PCN_X_PROPOSE_T : PCN_X_PROPOSE;
+        pd.noise = ASMC_NOISE_F64;
+        pd.ys = x_prop;
+        rc = pack_pcn_tables(ctx, pd, st);
+        if (rc) return rc;
+        if (x_dtype == ASMC_F64)
+            return launch_pcn_step<double, 0>(ctx, n, (double*)const_cast<void*>(x), qf_old, qf_new, nullptr, pd, ctx->d_rho,
+                                              step, nullptr, &grid, nullptr, nullptr, nullptr, st);
+        return launch_pcn_step<float, 0>(ctx, n, (float*)const_cast<void*>(x), qf_old, qf_new, nullptr, pd, ctx->d_rho, step,
+                                         nullptr, &grid, nullptr, nullptr, nullptr, st);
+    }
     if (x_dtype == ASMC_F64)
         return launch_pcn_step<double, 1>(ctx, n, (double*)const_cast<void*>(x), nullptr, nullptr, nullptr, pd, ctx->d_rho,
                                           step, nullptr, &grid, (double*)x_prop, qf_old, qf_new, st);

@@ -1,0 +1,28 @@
+"""Split propose/accept path with torch callables as densities (what a user with custom likelihoods runs), 1M x 32."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aspire_amd.engine import HipEngine
+
+n, d = int(os.environ.get("N", 1_000_000)), 32
+eng = HipEngine(0, n_max=n, d_max=32)
+g = torch.Generator("cuda").manual_seed(0)
+x = torch.randn((n, d), device="cuda", dtype=torch.float64, generator=g)
+mu, eye = eng.asarray(np.zeros(d)), eng.asarray(np.eye(d))
+f = lambda t: -0.5 * (t * t).sum(1)  # noqa: E731
+ll, lp, lq = f(x), f(x), f(x / 1.5)
+for nu in (0.0, 6.0):
+    for _ in range(3):
+        xp, q0, q1 = eng.pcn_propose(x, mu, eye, eye, 0.3, 5, 0, 1, nu=nu)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(20):
+        xp, q0, q1 = eng.pcn_propose(x, mu, eye, eye, 0.3, 5, 0, t, nu=nu)
+    torch.cuda.synchronize()
+    tp = (time.perf_counter() - t0) / 20
+    t0 = time.perf_counter()
+    for t in range(20):
+        xp, q0, q1 = eng.pcn_propose(x, mu, eye, eye, 0.3, 5, 0, t, nu=nu)
+        eng.pcn_accept(x, xp, ll, lp, lq, f(xp), f(xp), f(xp / 1.5), q0, q1, 0.5, 5, 0, t)
+    torch.cuda.synchronize()
+    print(f"nu={nu}: propose {tp*1e3:.3f} ms, full split step {(time.perf_counter()-t0)/20*1e3:.3f} ms")
