@@ -278,6 +278,7 @@ struct PcnScalars {
     const double* gam;  // per-particle Gamma((d + nu)/2, 1) variates of this step (k_gamma_draw), nullptr for pCN
     void* ys;           // coordinate-major whitened state (PCN_*_S modes)
     long long n_pad;    // its row length (n rounded up to 64)
+    int d_real;         // PCN_X_PROPOSE_PAD*: the problem's dimension (< D)
     unsigned long long seed, gid0;
     int c_ll, c_lp, c_lq;
 };
@@ -336,6 +337,40 @@ __device__ __forceinline__ void wave_lds_sync() {
 // x' -> the row-major buffer in p.ys, twice the reference's correction at y and y' -> the ll / lp arguments
 #define PCN_X_PROPOSE 12
 #define PCN_X_PROPOSE_T 13
+// the same for 16 < d < 32 on the D = 32 kernel: rows of d elements, coordinates d..31 held at zero, tables padded with
+// the identity (the generic LDS kernel needs 0.5-1.1 ms per proposal there, this one 0.3 ms)
+#define PCN_X_PROPOSE_PAD 14
+#define PCN_X_PROPOSE_PAD_T 15
+
+// 64-row tile copies for rows of `dr` < D elements (PCN_X_PROPOSE_PAD): fully unrolled, element-wise coalesced
+// accesses, row index by multiplication with magic = floor(2^32 / dr) + 1 (exact for e < 2^16) - no run-time loop, no
+// division (a loop here brings back the scalar-load hoisting described above)
+template <typename T, int D>
+__device__ __forceinline__ void pad_tile_load(const T* __restrict__ g, int64_t valid_elems, int dr, unsigned magic, int ldsrow,
+                                              char* lds, int lane) {
+#pragma unroll
+    for (int it = 0; it < D; it++) {
+        const int e = it * 64 + lane;
+        if (e < 64 * dr) {
+            const int r = (int)__umulhi((unsigned)e, magic), c = e - r * dr;
+            T v = (T)0;
+            if (e < valid_elems) v = g[e];
+            reinterpret_cast<T*>(lds + r * ldsrow)[c] = v;
+        }
+    }
+}
+template <typename T, int D>
+__device__ __forceinline__ void pad_tile_store_rows(T* __restrict__ g, int64_t valid_elems, int dr, unsigned magic, int ldsrow,
+                                                    const char* lds, int lane, unsigned long long rowmask) {
+#pragma unroll
+    for (int it = 0; it < D; it++) {
+        const int e = it * 64 + lane;
+        if (e < 64 * dr && e < valid_elems) {
+            const int r = (int)__umulhi((unsigned)e, magic), c = e - r * dr;
+            if ((rowmask >> r) & 1ULL) g[e] = reinterpret_cast<const T*>(lds + r * ldsrow)[c];
+        }
+    }
+}
 
 template <typename T, int D, int NOISE, int MODE>
 __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, double* __restrict__ ll,
@@ -344,9 +379,11 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
                                              const double* __restrict__ rho_ptr, uint32_t step,
                                              long long* __restrict__ block_counts) {
     extern __shared__ __align__(16) char smem[];
-    constexpr bool TP = MODE == PCN_X_STEP_T || MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS || MODE == PCN_X_PROPOSE_T;
+    constexpr bool TP = MODE == PCN_X_STEP_T || MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS || MODE == PCN_X_PROPOSE_T ||
+                        MODE == PCN_X_PROPOSE_PAD_T;
     constexpr bool SOA = MODE >= PCN_WHITEN_S && MODE <= PCN_UNWHITEN_XS;
-    constexpr bool PROPOSE = MODE == PCN_X_PROPOSE || MODE == PCN_X_PROPOSE_T;
+    constexpr bool PAD = MODE == PCN_X_PROPOSE_PAD || MODE == PCN_X_PROPOSE_PAD_T;
+    constexpr bool PROPOSE = MODE == PCN_X_PROPOSE || MODE == PCN_X_PROPOSE_T || PAD;
     constexpr int M = PROPOSE ? PCN_X_STEP : MODE == PCN_WHITEN_S ? PCN_WHITEN : (MODE == PCN_Y_STEP_S || MODE == PCN_Y_STEP_TS) ? PCN_Y_STEP
                       : MODE == PCN_UNWHITEN_S ? PCN_UNWHITEN : MODE == PCN_UNWHITEN_XS ? PCN_UNWHITEN_X
                       : TP ? MODE - PCN_X_STEP_T : MODE;
@@ -357,8 +394,11 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
     constexpr int LDSROW = ROWB + 16;
     const int WPB = (int)(blockDim.x >> 6);  // waves per block: chosen by the launcher from the LDS budget
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dr = PAD ? p.d_real : D;                                       // elements per stored row
+    const int rowb = PAD ? dr * (int)sizeof(T) : ROWB;
+    const int ldsrow = PAD ? lds_row_stride(rowb) : LDSROW;
     char* tile = smem + (size_t)wave * 64 * LDSROW;
-    char* myrow = tile + lane * LDSROW;
+    char* myrow = tile + lane * ldsrow;
     const double rho = *rho_ptr;
     const double a = sqrt(1.0 - rho * rho);
     long long n_acc = 0;
@@ -373,9 +413,13 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
         // coordinate-major state: wave-uniform tile base (scalar registers) + the lane as a 32-bit offset
         T* __restrict__ ysw = ys + (int64_t)__builtin_amdgcn_readfirstlane((int)t) * 64;
         const bool valid = active && i < n;
-        const int64_t valid_bytes = active ? (((n - row0) < 64 ? (n - row0) : 64) * (int64_t)ROWB) : 0;
-        char* gbase = reinterpret_cast<char*>(x) + row0 * ROWB;
-        if (active && ROW_IN) tile_load<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane);
+        const int64_t valid_bytes = active ? (((n - row0) < 64 ? (n - row0) : 64) * (int64_t)rowb) : 0;
+        char* gbase = reinterpret_cast<char*>(x) + row0 * rowb;
+        const unsigned magic = PAD ? 0xFFFFFFFFu / (unsigned)dr + 1u : 0u;
+        if (PAD)
+            pad_tile_load<T, D>(reinterpret_cast<const T*>(gbase), valid_bytes / (int64_t)sizeof(T), dr, magic, ldsrow, tile, lane);
+        else if (active && ROW_IN)
+            tile_load<16>(gbase, valid_bytes, ROWB, LDSROW, tile, lane);
         double oll = 0.0, olp = 0.0, olq = 0.0;
         if (valid && !PROPOSE && (M == PCN_X_STEP || M == PCN_Y_STEP)) {
             oll = ll[i];
@@ -398,7 +442,10 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
         if (valid) {
             const unsigned long long gid = p.gid0 + (unsigned long long)i;
             double v[D];
-            if (ROW_IN) {
+            if (PAD) {
+#pragma unroll
+                for (int j = 0; j < D; j++) v[j] = j < dr ? row_get<T>(myrow, j) : 0.0;  // padded mu is zero too
+            } else if (ROW_IN) {
                 row_to_regs<T, D>(myrow, v);
             } else {
 #pragma unroll
@@ -476,6 +523,14 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
                         if (qd & 1) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                if (PAD) {  // the padded coordinates carry no noise: y' = 0 there, and they stay out of |y'|^2
+                    q1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < D; j++) {
+                        v[j] = j < dr ? v[j] : 0.0;
+                        q1 = fma(v[j], v[j], q1);
+                    }
+                }
                 double nll, nlp, nlq;
                 if (M == PCN_X_STEP) {
                     // x' = mu + L y', rounded to the storage type
@@ -485,9 +540,15 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
 #pragma unroll
                     for (int j = 0; j < D; j++) v[j] = (double)(T)(mup[j] + v[j]);
                     if (PROPOSE) {
-                        ll[i] = 2.0 * ref_corr_ct<TP>(q0, p.nu, D);
-                        lp[i] = 2.0 * ref_corr_ct<TP>(q1, p.nu, D);
-                        regs_to_row<T, D>(myrow, v);
+                        ll[i] = 2.0 * ref_corr_ct<TP>(q0, p.nu, dr);
+                        lp[i] = 2.0 * ref_corr_ct<TP>(q1, p.nu, dr);
+                        if (PAD) {
+#pragma unroll
+                            for (int j = 0; j < D; j++)
+                                if (j < dr) row_set<T>(myrow, j, v[j]);
+                        } else {
+                            regs_to_row<T, D>(myrow, v);
+                        }
                         acc = true;
                     }
 #ifndef ASMC_ABLATE_TARGET
@@ -551,8 +612,14 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
         wave_lds_sync();
         {
             const unsigned long long accmask = ROW_OUT ? __ballot(acc) : 0ULL;
-            char* obase = PROPOSE ? reinterpret_cast<char*>(p.ys) + row0 * ROWB : gbase;
-            if (accmask != 0ULL) tile_store_rows<16>(obase, valid_bytes, ROWB, LDSROW, tile, lane, accmask);
+            char* obase = PROPOSE ? reinterpret_cast<char*>(p.ys) + row0 * rowb : gbase;
+            if (PAD) {
+                if (accmask != 0ULL)
+                    pad_tile_store_rows<T, D>(reinterpret_cast<T*>(obase), valid_bytes / (int64_t)sizeof(T), dr, magic, ldsrow, tile,
+                                              lane, accmask);
+            } else if (accmask != 0ULL) {
+                tile_store_rows<16>(obase, valid_bytes, ROWB, LDSROW, tile, lane, accmask);
+            }
         }
         wave_lds_sync();
     }
@@ -1077,16 +1144,17 @@ static int waves_for_lds(size_t per_wave_bytes, size_t* lds_bytes_out) {
 
 // gather the caller's tables into the ctx parameter block (one tiny kernel, stream ordered)
 __global__ __launch_bounds__(256) void k_pcn_pack(PcnDev pd, double* __restrict__ t) {
-    const int D = pd.d;
+    const int D = pd.dpad > pd.d ? pd.dpad : pd.d, dr = pd.d;  // tables of the D-dimensional kernel, identity beyond dr
     const int tri = D * (D + 1) / 2;
     for (int e = threadIdx.x; e < D * D; e += 256) {
         const int j = e / D, k = e - j * D;
         if (k <= j) {
-            t[j * (j + 1) / 2 + k] = pd.L[e];
-            t[tri + j * (j + 1) / 2 + k] = pd.Linv[e];
+            const bool in = j < dr;  // (k <= j < dr)
+            t[j * (j + 1) / 2 + k] = in ? pd.L[j * dr + k] : (k == j ? 1.0 : 0.0);
+            t[tri + j * (j + 1) / 2 + k] = in ? pd.Linv[j * dr + k] : (k == j ? 1.0 : 0.0);
         }
     }
-    for (int e = threadIdx.x; e < D; e += 256) t[2 * tri + e] = pd.mu[e];
+    for (int e = threadIdx.x; e < D; e += 256) t[2 * tri + e] = e < dr ? pd.mu[e] : 0.0;
     double* m0 = t + 2 * tri + D;
     const MixDev* mixes[3] = {&pd.ll, &pd.lp, &pd.lq};
     for (int i = 0; i < 3; i++) {
@@ -1142,12 +1210,13 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     ps.gam = pd.gam;
     ps.ys = pd.ys;
     ps.n_pad = pd.n_pad;
+    ps.d_real = pd.d;
     ps.seed = pd.seed;
     ps.gid0 = pd.gid0;
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
-    ASMC_LAUNCH(ctx, st, MODE == PCN_X_STEP ? "k_pcn_reg" : (MODE == PCN_Y_STEP || MODE == PCN_Y_STEP_S) ? "k_pcn_reg_y" : MODE == PCN_X_STEP_T ? "k_tpcn_reg" : (MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS) ? "k_tpcn_reg_y" : (MODE == PCN_WHITEN || MODE == PCN_WHITEN_S) ? "k_pcn_whiten" : (MODE == PCN_X_PROPOSE || MODE == PCN_X_PROPOSE_T) ? "k_pcn_propose_reg" : "k_pcn_unwhiten", kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
+    ASMC_LAUNCH(ctx, st, MODE == PCN_X_STEP ? "k_pcn_reg" : (MODE == PCN_Y_STEP || MODE == PCN_Y_STEP_S) ? "k_pcn_reg_y" : MODE == PCN_X_STEP_T ? "k_tpcn_reg" : (MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS) ? "k_tpcn_reg_y" : (MODE == PCN_WHITEN || MODE == PCN_WHITEN_S) ? "k_pcn_whiten" : (MODE >= PCN_X_PROPOSE && MODE <= PCN_X_PROPOSE_PAD_T) ? "k_pcn_propose_reg" : "k_pcn_unwhiten", kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
                        rho_ptr, step, block_counts);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -1181,6 +1250,7 @@ static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double
     ps.gam = pd.gam;
     ps.ys = pd.ys;
     ps.n_pad = pd.n_pad;
+    ps.d_real = pd.d;
     ps.seed = pd.seed;
     ps.gid0 = pd.gid0;
     ps.c_ll = pd.ll.C;
@@ -1220,8 +1290,9 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
                            const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
                            T* x_prop, double* qf_old, double* qf_new, hipStream_t st) {
     const int rowbytes = pd.d * (int)sizeof(T);
-    if (PHASE == 0 && pcn_reg_supported(pd.d, sizeof(T), x)) {
-        switch (pd.d * 64 + (pd.noise == ASMC_NOISE_F32 ? 32 : 0) + pd.mode) {  // register-resident specialisations
+    if (PHASE == 0 && (pd.dpad > pd.d || pcn_reg_supported(pd.d, sizeof(T), x))) {
+        const int dk = pd.dpad > pd.d ? pd.dpad : pd.d;
+        switch (dk * 64 + (pd.noise == ASMC_NOISE_F32 ? 32 : 0) + pd.mode) {  // register-resident specialisations
 #define PCN_CASE2(DD, NZ, MD) \
     case DD * 64 + (NZ == ASMC_NOISE_F32 ? 32 : 0) + MD: \
         return launch_pcn_reg<T, DD, NZ, MD>(ctx, n, x, ll, lp, lq, pd, rho_ptr, step, block_counts, grid_out, st);
@@ -1250,6 +1321,8 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
             PCN_CASE(8)
             PCN_CASE(16)
             PCN_CASE(32)
+            PCN_CASE2(32, ASMC_NOISE_F64, PCN_X_PROPOSE_PAD)
+            PCN_CASE2(32, ASMC_NOISE_F64, PCN_X_PROPOSE_PAD_T)
 #undef PCN_CASE
 #undef PCN_CASE2
             default: break;
@@ -1615,6 +1688,36 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     return ASMC_OK;
 }
 
+// proposal half of the split path for the step `step` (gamma variates drawn first when pd.nu > 0): register-resident
+// kernel for d in {4, 8, 16, 32}, the same kernel on identity-padded tables for 16 < d < 32, generic LDS kernel otherwise
+static int pcn_propose_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, void* x_prop, double* qf_old,
+                              double* qf_new, PcnDev pd, const double* rho_ptr, uint32_t step, hipStream_t st) {
+    int grid = 0;
+    int rc = pcn_prepare_gamma(ctx, n, pd, step, st);
+    if (rc) return rc;
+    const bool pad = d > 16 && d < 32 && !getenv("ASMC_PCN_GENERIC");
+    if (pad || (pcn_reg_supported(d, x_dtype == ASMC_F64 ? 8 : 4, x) && ((uintptr_t)x_prop % 16) == 0)) {
+        // d in {4, 8, 16, 32}: the register-resident kernel's proposal half (same arithmetic as the fused step);
+        // 16 < d < 32: the same kernel compiled for 32 dimensions with identity-padded tables
+        pd.dpad = pad ? 32 : 0;
+        pd.mode = pad ? (pd.nu > 0.0 ? PCN_X_PROPOSE_PAD_T : PCN_X_PROPOSE_PAD) : (pd.nu > 0.0 ? PCN_X_PROPOSE_T : PCN_X_PROPOSE);
+        pd.noise = ASMC_NOISE_F64;
+        pd.ys = x_prop;
+        rc = pack_pcn_tables(ctx, pd, st);
+        if (rc) return rc;
+        if (x_dtype == ASMC_F64)
+            return launch_pcn_step<double, 0>(ctx, n, (double*)const_cast<void*>(x), qf_old, qf_new, nullptr, pd, rho_ptr,
+                                              step, nullptr, &grid, nullptr, nullptr, nullptr, st);
+        return launch_pcn_step<float, 0>(ctx, n, (float*)const_cast<void*>(x), qf_old, qf_new, nullptr, pd, rho_ptr, step,
+                                         nullptr, &grid, nullptr, nullptr, nullptr, st);
+    }
+    if (x_dtype == ASMC_F64)
+        return launch_pcn_step<double, 1>(ctx, n, (double*)const_cast<void*>(x), nullptr, nullptr, nullptr, pd, rho_ptr,
+                                          step, nullptr, &grid, (double*)x_prop, qf_old, qf_new, st);
+    return launch_pcn_step<float, 1>(ctx, n, (float*)const_cast<void*>(x), nullptr, nullptr, nullptr, pd, rho_ptr, step,
+                                     nullptr, &grid, (float*)x_prop, qf_old, qf_new, st);
+}
+
 int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, void* x_prop, double* qf_old,
                      double* qf_new, const double* mu, const double* L, const double* Linv, double rho, double nu,
                      uint64_t seed, uint64_t gid0, uint32_t step, asmc_stream stream) {
@@ -1636,27 +1739,7 @@ int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x
     ASMC_HIP(hipStreamSynchronize(st));
     ctx->h_pinned[0] = rho;
     ASMC_HIP(hipMemcpyAsync(ctx->d_rho, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, st));
-    int grid = 0;
-    int rc = pcn_prepare_gamma(ctx, n, pd, step, st);
-    if (rc) return rc;
-    if (pcn_reg_supported(d, x_dtype == ASMC_F64 ? 8 : 4, x) && ((uintptr_t)x_prop % 16) == 0) {
-        // d in {4, 8, 16, 32}: the register-resident kernel's proposal half (same arithmetic as the fused step)
-        pd.mode = pd.nu > 0.0 ? PCN_X_PROPOSE_T : PCN_X_PROPOSE;
-        pd.noise = ASMC_NOISE_F64;
-        pd.ys = x_prop;
-        rc = pack_pcn_tables(ctx, pd, st);
-        if (rc) return rc;
-        if (x_dtype == ASMC_F64)
-            return launch_pcn_step<double, 0>(ctx, n, (double*)const_cast<void*>(x), qf_old, qf_new, nullptr, pd, ctx->d_rho,
-                                              step, nullptr, &grid, nullptr, nullptr, nullptr, st);
-        return launch_pcn_step<float, 0>(ctx, n, (float*)const_cast<void*>(x), qf_old, qf_new, nullptr, pd, ctx->d_rho, step,
-                                         nullptr, &grid, nullptr, nullptr, nullptr, st);
-    }
-    if (x_dtype == ASMC_F64)
-        return launch_pcn_step<double, 1>(ctx, n, (double*)const_cast<void*>(x), nullptr, nullptr, nullptr, pd, ctx->d_rho,
-                                          step, nullptr, &grid, (double*)x_prop, qf_old, qf_new, st);
-    return launch_pcn_step<float, 1>(ctx, n, (float*)const_cast<void*>(x), nullptr, nullptr, nullptr, pd, ctx->d_rho, step,
-                                     nullptr, &grid, (float*)x_prop, qf_old, qf_new, st);
+    return pcn_propose_launch(ctx, n, d, x_dtype, x, x_prop, qf_old, qf_new, pd, ctx->d_rho, step, st);
 }
 
 int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x, const void* x_prop, double* ll, double* lp,
@@ -1797,15 +1880,7 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
     }
     for (int t = 0; t < (reg_ok ? 0 : n_steps); t++) {
         const uint32_t step = step0 + (uint32_t)t;
-        int grid = 0;
-        rc = pcn_prepare_gamma(ctx, n, pd, step, st);
-        if (rc) return rc;
-        if (prm->x_dtype == ASMC_F64)
-            rc = launch_pcn_step<double, 1>(ctx, n, (double*)x, nullptr, nullptr, nullptr, pd, d_rho, step, nullptr, &grid,
-                                            (double*)x_prop, q0, q1, st);
-        else
-            rc = launch_pcn_step<float, 1>(ctx, n, (float*)x, nullptr, nullptr, nullptr, pd, d_rho, step, nullptr, &grid,
-                                           (float*)x_prop, q0, q1, st);
+        rc = pcn_propose_launch(ctx, n, d, prm->x_dtype, x, x_prop, q0, q1, pd, d_rho, step, st);
         if (rc) return rc;
         rc = asmc_coupling_logprob(ctx, n, prm->x_dtype, x_prop, flow, lq_new, stream);
         if (rc) return rc;

@@ -165,6 +165,7 @@ struct PcnDev {
     const double* gam;  // [n] unit-scale Gamma((d + nu)/2) variates of the current step (tpCN), else nullptr
     void* ys;           // coordinate-major whitened state of the register-resident kernels (or nullptr)
     long long n_pad;
+    int dpad;           // > d: run the d-dimensional problem on the kernels compiled for dpad (identity-padded tables)
     int mode;  // PCN_X_STEP / PCN_Y_STEP / PCN_WHITEN / PCN_UNWHITEN (register-resident kernels)
 };
 

@@ -1241,3 +1241,28 @@ def test_tpcn_default_sampler_run_gpu(eng):
     out = sp.sample(n, sampler_kwargs=dict(n_steps=16, noise="f32"), store_sample_history=False)
     assert sp.sampler_kwargs["step_fn"] == "tpcn" and len(sp.history.mcmc_nu) == len(sp.history.beta)
     assert abs(float(out.log_evidence) - 0.5 * d * math.log(math.pi)) < 5 * float(out.log_evidence_error) + 0.02
+
+
+@pytest.mark.parametrize("d,nu,dtype", [(20, 0.0, torch.float64), (31, 0.0, torch.float64), (17, 5.0, torch.float64),
+                                        (24, 0.0, torch.float32)])
+def test_pcn_propose_padded_dims_vs_oracle_engine(eng, oracle, d, nu, dtype):
+    """16 < d < 32: asmc_pcn_propose runs the 32-dimensional register kernel on identity-padded tables; proposals and
+    correction terms agree with the test double's restatement (same noise, same scale variates)."""
+    from oracle_engine import OracleEngine
+
+    n = 3001
+    x, mu, L, Linv, _ = _pcn_setup(eng, n, d, 300 + d)
+    xd = torch.as_tensor(x).to(dtype).to(eng.device)
+    eng.profile(True)
+    xp, q0, q1 = eng.pcn_propose(xd, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), 0.35, 99, 1000, 7, nu=nu)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert "k_pcn_propose_reg" in rep
+    ref = OracleEngine()
+    xr, r0, r1 = ref.pcn_propose(xd.double().cpu(), torch.as_tensor(mu), torch.as_tensor(L), torch.as_tensor(Linv), 0.35, 99,
+                                 1000, 7, nu=nu)
+    tol = 1e-11 if dtype == torch.float64 else 2e-6
+    np.testing.assert_allclose(xp.double().cpu().numpy(), xr.numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(q0.cpu().numpy(), r0.numpy(), rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(q1.cpu().numpy(), r1.numpy(), rtol=1e-9 if dtype == torch.float64 else 1e-4, atol=1e-9)
+    assert torch.equal(xd, torch.as_tensor(x).to(dtype).to(eng.device))  # the input is not touched
