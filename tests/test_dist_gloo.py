@@ -85,6 +85,9 @@ def _worker(rank, world, port, out_dir, engine_kind="oracle"):
     new, var2 = pop.resample(0.1, rng=np.random.default_rng(5), want_variance=True)
     res["own_x"] = eng.to_numpy(new.x)
     res["own_flags"] = np.array([new.n_global, int(new.ragged), var2 == var])
+    # a different output size (the sampler's n_final_samples): owner layout hands every draw to exactly one rank
+    odd = pop.resample(0.1, n_samples=1001, rng=np.random.default_rng(8))
+    res["odd_n"] = np.array([len(odd.x), odd.n_global])
     # ragged shards back to equal ones, global order kept
     xb, llb, _, _ = rebalance_shards(eng, comm, new.x, new.log_likelihood, new.log_prior, new.log_q)
     res["reb_x"], res["reb_ll"], res["own_ll"] = eng.to_numpy(xb), eng.to_numpy(llb), eng.to_numpy(new.log_likelihood)
@@ -220,6 +223,8 @@ def test_owner_layout_resampling(two_rank_results, oracle):
         assert np.array_equal(res["own_idx"], want)
         assert np.array_equal(res["own_x"], x[want])
     assert float(r0["own_var"]) == pytest.approx(oracle.log_evidence_ratio_variance(ll, lp, lq, 0.0, 0.1), rel=1e-10)
+    assert int(r0["odd_n"][0]) + int(r1["odd_n"][0]) == 1001 and int(r0["odd_n"][1]) == int(r1["odd_n"][1]) == 1001
+    assert abs(int(r0["odd_n"][0]) - 500) < 80  # shares ~ 1/2 each
     for res in (r0, r1):
         assert res["own_flags"].tolist() == [n, 1, 1]
         assert res["again_n"].tolist() == [n // 2, 0]  # slot layout hands back equal shards

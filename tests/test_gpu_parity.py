@@ -1266,3 +1266,24 @@ def test_pcn_propose_padded_dims_vs_oracle_engine(eng, oracle, d, nu, dtype):
     np.testing.assert_allclose(q0.cpu().numpy(), r0.numpy(), rtol=1e-11, atol=1e-11)
     np.testing.assert_allclose(q1.cpu().numpy(), r1.numpy(), rtol=1e-9 if dtype == torch.float64 else 1e-4, atol=1e-9)
     assert torch.equal(xd, torch.as_tensor(x).to(dtype).to(eng.device))  # the input is not touched
+
+
+def test_shard_entry_points_reject_bad_arguments(eng):
+    """Error convention of the sharded entry points: negative return code -> AsmcError with asmc_last_error()'s text."""
+    from aspire_amd._lib import AsmcError
+    from aspire_amd.smc_math import pcg64_state
+
+    st = pcg64_state(np.random.default_rng(0))
+    for lo, hi in ((0.5, 0.5), (0.6, 0.4), (-0.1, 0.5), (0.2, 1.5)):
+        with pytest.raises(AsmcError, match="lo < hi"):
+            eng.pcg64_select(st, 1000, lo, hi)
+    z = eng.asarray(np.zeros(8))
+    rec = eng.empty(40)
+    with pytest.raises(AsmcError, match="beta0"):
+        eng.find_beta_shard_reduce(z, z, z, 1.0, 0, rec)
+    with pytest.raises(AsmcError, match="tolerance"):
+        eng.find_beta_shard_decide(rec, 1, 8, 0.0, 0.5, 0.0, 0)
+    with pytest.raises(AsmcError, match="nu must be"):
+        x = eng.asarray(np.zeros((8, 4)))
+        eye = eng.asarray(np.eye(4))
+        eng.pcn_propose(x, eng.asarray(np.zeros(4)), eye, eye, 0.3, 1, 0, 0, nu=0.5)
