@@ -23,7 +23,7 @@ ASMC_MAX_COMPONENTS = 8
 ASMC_MAX_DIMS = 256
 COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
-ASMC_SELECT_THREADS = 65536
+ASMC_SELECT_THREADS = 262144
 ASMC_ABI_VERSION = 4
 
 

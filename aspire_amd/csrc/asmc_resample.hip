@@ -687,6 +687,7 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcg64_uniforms(const unsigned lo
 // Sharded owner-layout resampling: all n_total draws of the stream are generated on every rank; a wave keeps those
 // inside this rank's cdf slice [lo, hi) in its own segment of `stage` (no atomics: the order of the kept draws is
 // (wave, iteration, lane), a fixed function of the draw index), mapped to the local cdf's coordinate.
+#define SEL_LOG2 18  // log2(ASMC_SELECT_THREADS): 4096 waves keep every SIMD busy (65536 threads: 17 us per 2M draws)
 #define SEL_WAVES (ASMC_SELECT_THREADS / 64)
 __global__ __launch_bounds__(ASMC_BLOCK) void k_pcg64_select(const unsigned long long* __restrict__ tab, U128 state0,
                                                             int64_t n, double lo, double hi, int64_t iters,
@@ -703,8 +704,8 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcg64_select(const unsigned long
             st = u128_add(u128_mul(st, A), C);
         }
     }
-    const U128 AT = {tab[4 * PCG_THREADS_LOG2], tab[4 * PCG_THREADS_LOG2 + 1]};
-    const U128 CT = {tab[4 * PCG_THREADS_LOG2 + 2], tab[4 * PCG_THREADS_LOG2 + 3]};
+    const U128 AT = {tab[4 * SEL_LOG2], tab[4 * SEL_LOG2 + 1]};
+    const U128 CT = {tab[4 * SEL_LOG2 + 2], tab[4 * SEL_LOG2 + 3]};
     const double inv_w = 1.0 / (hi - lo);
     double* seg = stage + wave * 64 * iters;
     long long pos = 0;
@@ -728,28 +729,40 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcg64_select(const unsigned long
 }
 
 // exclusive scan of the SEL_WAVES wave counts; offsets behind the counts, the total behind the offsets
-__global__ __launch_bounds__(SEL_WAVES) void k_select_scan(long long* __restrict__ counts) {
-    __shared__ long long s[SEL_WAVES];
+__global__ __launch_bounds__(1024) void k_select_scan(long long* __restrict__ counts) {
+    constexpr int PER = SEL_WAVES / 1024;  // consecutive counts per thread
+    __shared__ long long s[1024];
     const int t = threadIdx.x;
-    s[t] = counts[t];
+    long long loc[PER], tot = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        loc[q] = counts[t * PER + q];
+        tot += loc[q];
+    }
+    s[t] = tot;
     __syncthreads();
-    for (int o = 1; o < SEL_WAVES; o <<= 1) {
+    for (int o = 1; o < 1024; o <<= 1) {
         const long long v = t >= o ? s[t - o] : 0;
         __syncthreads();
         s[t] += v;
         __syncthreads();
     }
-    counts[SEL_WAVES + t] = s[t] - counts[t];
-    if (t == SEL_WAVES - 1) counts[2 * SEL_WAVES] = s[t];
+    long long run = s[t] - tot;  // exclusive prefix of this thread's first count
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        counts[SEL_WAVES + t * PER + q] = run;
+        run += loc[q];
+    }
+    if (t == 1023) counts[2 * SEL_WAVES] = s[t];
 }
 
-__global__ __launch_bounds__(ASMC_BLOCK) void k_select_compact(int64_t iters, const double* __restrict__ stage,
-                                                              const long long* __restrict__ counts,
-                                                              double* __restrict__ q) {
+__global__ __launch_bounds__(64) void k_select_compact(int64_t iters, const double* __restrict__ stage,
+                                                       const long long* __restrict__ counts,
+                                                       double* __restrict__ q) {
     const int64_t wave = blockIdx.x;
     const long long cnt = counts[wave], off = counts[SEL_WAVES + wave];
     const double* seg = stage + wave * 64 * iters;
-    for (long long t = threadIdx.x; t < cnt; t += ASMC_BLOCK) q[off + t] = seg[t];
+    for (long long t = threadIdx.x; t < cnt; t += 64) q[off + t] = seg[t];
 }
 
 __global__ __launch_bounds__(ASMC_BLOCK) void k_systematic(int64_t n_out, int64_t j0, int64_t n_total,
@@ -1138,7 +1151,7 @@ int asmc_pcg64_select(asmc_ctx* ctx, const uint64_t state_host[4], int64_t n_tot
     ASMC_REQUIRE(ctx && state_host && stage && count_host, "null pointer");
     ASMC_REQUIRE(n_total > 0, "n_total must be positive");
     ASMC_REQUIRE(lo >= 0.0 && hi > lo && hi <= 1.0, "need 0 <= lo < hi <= 1");
-    static_assert(PCG_THREADS == ASMC_SELECT_THREADS, "the per-thread jump of the select kernel is 2^PCG_THREADS_LOG2");
+    static_assert((1 << SEL_LOG2) == ASMC_SELECT_THREADS && SEL_WAVES % 1024 == 0, "select kernel geometry");
     hipStream_t st = as_stream(stream);
     int rc = pcg_prepare(ctx, state_host, st);
     if (rc) return rc;
@@ -1147,7 +1160,7 @@ int asmc_pcg64_select(asmc_ctx* ctx, const uint64_t state_host[4], int64_t n_tot
     ASMC_LAUNCH(ctx, st, "k_pcg64_select", k_pcg64_select, dim3(ASMC_SELECT_THREADS / ASMC_BLOCK), dim3(ASMC_BLOCK), 0, st,
                 (const unsigned long long*)ctx->d_pcgtab, s0, n_total, lo, hi, iters, stage, ctx->d_select);
     ASMC_LAUNCH_CHECK();
-    ASMC_LAUNCH(ctx, st, "k_select_scan", k_select_scan, dim3(1), dim3(SEL_WAVES), 0, st, ctx->d_select);
+    ASMC_LAUNCH(ctx, st, "k_select_scan", k_select_scan, dim3(1), dim3(1024), 0, st, ctx->d_select);
     ASMC_LAUNCH_CHECK();
     long long* h = reinterpret_cast<long long*>(ctx->h_pinned);
     ASMC_HIP(hipMemcpyAsync(h, ctx->d_select + 2 * SEL_WAVES, sizeof(long long), hipMemcpyDeviceToHost, st));
@@ -1161,7 +1174,7 @@ int asmc_pcg64_select_compact(asmc_ctx* ctx, int64_t n_total, const double* stag
     ASMC_REQUIRE(n_total > 0, "n_total must be positive");
     hipStream_t st = as_stream(stream);
     const int64_t iters = (n_total + ASMC_SELECT_THREADS - 1) / ASMC_SELECT_THREADS;
-    ASMC_LAUNCH(ctx, st, "k_select_compact", k_select_compact, dim3(SEL_WAVES), dim3(ASMC_BLOCK), 0, st, iters, stage,
+    ASMC_LAUNCH(ctx, st, "k_select_compact", k_select_compact, dim3(SEL_WAVES), dim3(64), 0, st, iters, stage,
                 (const long long*)ctx->d_select, q);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;

@@ -46,7 +46,7 @@ extern "C" {
 
 #define ASMC_MAX_BETAS 32      /* candidate betas evaluated per pass */
 #define ASMC_BIS_REC 40        /* doubles per rank record of the sharded beta search (asmc_find_beta_shard_*) */
-#define ASMC_SELECT_THREADS 65536 /* generator threads of asmc_pcg64_select (fixes the order of the kept draws) */
+#define ASMC_SELECT_THREADS 262144 /* generator threads of asmc_pcg64_select (fixes the order of the kept draws) */
 #define ASMC_MAX_COMPONENTS 8  /* mixture components of a built-in density */
 #define ASMC_MAX_DIMS 256
 

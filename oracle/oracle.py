@@ -221,13 +221,13 @@ def pcg64_advance(state: np.ndarray, delta: int) -> None:
     lib().orc_pcg64_advance(_p(state), (delta >> 64) & m, delta & m)
 
 
-SELECT_THREADS = 65536  # include/asmc.h ASMC_SELECT_THREADS
+SELECT_THREADS = 262144  # include/asmc.h ASMC_SELECT_THREADS
 
 
 def pcg64_select(state: np.ndarray, n_total: int, lo: float, hi: float) -> np.ndarray:
     """Specification of asmc_pcg64_select (this repository's sharded owner-layout resampling; no reference
     counterpart): of the next n_total doubles of the stream keep lo <= u < hi, map to q = (u - lo) * (1 / (hi - lo))
-    clamped below 1, ordered by (thread // 64, iteration, thread % 64) with thread = i % 65536, iteration = i // 65536."""
+    clamped below 1, ordered by (thread // 64, iteration, thread % 64) with thread = i % 262144, iteration = i // 262144."""
     st = np.array(state, dtype=np.uint64)
     u = pcg64_random(st, int(n_total))
     i = np.arange(int(n_total), dtype=np.int64)
