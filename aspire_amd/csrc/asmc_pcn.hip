@@ -342,6 +342,29 @@ __device__ __forceinline__ void wave_lds_sync() {
 #define PCN_X_PROPOSE_PAD 14
 #define PCN_X_PROPOSE_PAD_T 15
 
+// coordinate-major state through buffer instructions: one 128-bit descriptor in SGPRs, the lane as a 32-bit VGPR
+// offset and the coordinate's row (j * n_pad + tile) as the scalar offset - instead of one 64-bit VGPR address pair per
+// coordinate (32 pairs = 64 VGPRs held from the loads to the conditional stores with plain global accesses)
+template <typename T>
+__device__ __forceinline__ double soa_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (sizeof(T) == 8) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+        return __builtin_bit_cast(double, v);
+    } else {
+        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+        return (double)__uint_as_float(v);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void soa_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x) {
+    if constexpr (sizeof(T) == 8) {
+        using u2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), r, (int)voff, (int)soff, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)x), r, (int)voff, (int)soff, 0);
+    }
+}
+
 // 64-row tile copies for rows of `dr` < D elements (PCN_X_PROPOSE_PAD): fully unrolled, element-wise coalesced
 // accesses, row index by multiplication with magic = floor(2^32 / dr) + 1 (exact for e < 2^16) - no run-time loop, no
 // division (a loop here brings back the scalar-load hoisting described above)
@@ -411,7 +434,16 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
         const int64_t row0 = t * 64;
         const int64_t i = row0 + lane;
         // coordinate-major state: wave-uniform tile base (scalar registers) + the lane as a 32-bit offset
-        T* __restrict__ ysw = ys + (int64_t)__builtin_amdgcn_readfirstlane((int)t) * 64;
+        // descriptor over the whole scratch buffer, built from wave-uniform values only (< 4 GB: checked by the host)
+        const unsigned long long ysa = (unsigned long long)(uintptr_t)ys;
+        T* ysu = reinterpret_cast<T*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ysa >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ysa));
+        const __amdgpu_buffer_rsrc_t ysr = __builtin_amdgcn_make_buffer_rsrc(
+            ysu, 0, SOA ? (int)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p.n_pad * D * sizeof(T))) : 0,
+            0x00020000);
+        const unsigned ys_tile = (unsigned)__builtin_amdgcn_readfirstlane((int)t) * 64u * (unsigned)sizeof(T);
+        const unsigned ys_row = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p.n_pad) * (unsigned)sizeof(T);
+        const unsigned ys_lane = (unsigned)lane * (unsigned)sizeof(T);
         const bool valid = active && i < n;
         const int64_t valid_bytes = active ? (((n - row0) < 64 ? (n - row0) : 64) * (int64_t)rowb) : 0;
         char* gbase = reinterpret_cast<char*>(x) + row0 * rowb;
@@ -449,7 +481,7 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
                 row_to_regs<T, D>(myrow, v);
             } else {
 #pragma unroll
-                for (int j = 0; j < D; j++) v[j] = (double)ysw[(size_t)j * p.n_pad + (unsigned)lane];
+                for (int j = 0; j < D; j++) v[j] = soa_load<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row);
             }
             if (M == PCN_WHITEN) {
 #pragma unroll
@@ -457,7 +489,7 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
                 tri_matvec_inplace<D>(Lip, v);
                 if (SOA) {
 #pragma unroll
-                    for (int j = 0; j < D; j++) ysw[(size_t)j * p.n_pad + (unsigned)lane] = (T)v[j];
+                    for (int j = 0; j < D; j++) soa_store<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row, v[j]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < D; j++) v[j] = (double)(T)v[j];
@@ -600,7 +632,7 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
                         regs_to_row<T, D>(myrow, v);
                     } else {
 #pragma unroll
-                        for (int j = 0; j < D; j++) ysw[(size_t)j * p.n_pad + (unsigned)lane] = (T)v[j];
+                        for (int j = 0; j < D; j++) soa_store<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row, v[j]);
                     }
                     ll[i] = nll;
                     lp[i] = nlp;
@@ -681,7 +713,16 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
         const bool valid = i < n;
         const int64_t valid_bytes = ((n - row0) < 64 ? (n - row0) : 64) * (int64_t)ROWB;
         if (!SOA) tile_load<16>(reinterpret_cast<const char*>(y) + row0 * ROWB, valid_bytes, ROWB, LDSROW, tile, lane);
-        T* __restrict__ ysw = reinterpret_cast<T*>(p.ys) + (int64_t)__builtin_amdgcn_readfirstlane((int)t) * 64;
+        // coordinate-major state through one buffer descriptor (see soa_load / soa_store)
+        const unsigned long long ysa = (unsigned long long)(uintptr_t)p.ys;
+        T* ysu = reinterpret_cast<T*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ysa >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ysa));
+        const __amdgpu_buffer_rsrc_t ysr = __builtin_amdgcn_make_buffer_rsrc(
+            ysu, 0, SOA ? (int)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p.n_pad * D * sizeof(T))) : 0,
+            0x00020000);
+        const unsigned ys_tile = (unsigned)__builtin_amdgcn_readfirstlane((int)t) * 64u * (unsigned)sizeof(T);
+        const unsigned ys_row = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p.n_pad) * (unsigned)sizeof(T);
+        const unsigned ys_lane = (unsigned)lane * (unsigned)sizeof(T);
         double oll = 0.0, olp = 0.0, olq = 0.0, nll = 0.0, nlp = 0.0, nlq = 0.0;
         if (valid && M == PCN_FLOW_ACCEPT) {
             oll = ll[i], olp = lp[i], olq = lq[i];
@@ -700,7 +741,7 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
             double v[D];
             if (SOA) {
 #pragma unroll
-                for (int j = 0; j < D; j++) v[j] = (double)ysw[(size_t)j * p.n_pad + (unsigned)lane];
+                for (int j = 0; j < D; j++) v[j] = soa_load<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row);
             } else {
                 row_to_regs<T, D>(myrow, v);
             }
@@ -749,7 +790,7 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
                 if (acc) {
                     if (SOA) {
 #pragma unroll
-                        for (int j = 0; j < D; j++) ysw[(size_t)j * p.n_pad + (unsigned)lane] = (T)v[j];
+                        for (int j = 0; j < D; j++) soa_store<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row, v[j]);
                     } else {
                         regs_to_row<T, D>(myrow, v);
                     }
@@ -1530,6 +1571,7 @@ static bool pcn_ensure_ysoa(asmc_ctx* ctx, int64_t n, int d, int x_dtype, PcnDev
     if (getenv("ASMC_PCN_AOS")) return false;
     const int64_t n_pad = ((n + 63) / 64) * 64;
     const size_t need = (size_t)n_pad * d * (x_dtype == ASMC_F64 ? 8 : 4);
+    if (need >= (1ULL << 32)) return false;  // the kernels address the buffer through one 32-bit-offset descriptor
     if (need > ctx->ysoa_bytes) {
         if (hipStreamSynchronize(st) != hipSuccess) return false;
         if (ctx->d_ysoa) (void)hipFree(ctx->d_ysoa);
