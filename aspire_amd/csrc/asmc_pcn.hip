@@ -823,12 +823,13 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
 }
 
 // tpCN: unit-scale Gamma(shape) variate of every particle for Markov step `step` (Marsaglia-Tsang, counter based)
+template <bool F32>
 __global__ __launch_bounds__(ASMC_BLOCK) void k_gamma_draw(int64_t n, double shape, unsigned long long seed,
                                                           unsigned long long gid0, uint32_t step,
                                                           double* __restrict__ out) {
     const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride)
-        out[i] = gamma_unit(shape, seed, gid0 + (unsigned long long)i, step);
+        out[i] = gamma_unit<F32>(shape, seed, gid0 + (unsigned long long)i, step);
 }
 
 // before a step kernel: draws the step's scale variates into ctx->d_gamma and points pd.gam at them (tpCN only)
@@ -838,8 +839,12 @@ static int pcn_prepare_gamma(asmc_ctx* ctx, int64_t n, PcnDev& pd, uint32_t step
         return ASMC_OK;
     }
     const int grid = grid_for(n, ASMC_BLOCK, ASMC_MAX_BLOCKS * 4);
-    ASMC_LAUNCH(ctx, st, "k_gamma_draw", k_gamma_draw, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, 0.5 * ((double)pd.d + pd.nu),
-                (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma);
+    if (pd.noise == ASMC_NOISE_F32)
+        ASMC_LAUNCH(ctx, st, "k_gamma_draw", k_gamma_draw<true>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n,
+                    0.5 * ((double)pd.d + pd.nu), (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma);
+    else
+        ASMC_LAUNCH(ctx, st, "k_gamma_draw", k_gamma_draw<false>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n,
+                    0.5 * ((double)pd.d + pd.nu), (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma);
     ASMC_LAUNCH_CHECK();
     pd.gam = ctx->d_gamma;
     return ASMC_OK;

@@ -80,23 +80,38 @@ __device__ __forceinline__ double accept_uniform(unsigned long long seed, unsign
 }
 
 // ---- t-preconditioned Crank-Nicolson (step_fn "tpcn"; specification: DESIGN.md §3.6) ---------------------------
-// unit-scale Gamma(shape >= 1) variate, Marsaglia & Tsang (2000), counter slots 0x80000000 | {2a, 2a + 1} of attempt a < 8
+// unit-scale Gamma(shape >= 1) variate, Marsaglia & Tsang (2000), counter slots 0x80000000 | {2a, 2a + 1} of attempt a < 8.
+// F32 (the fast-noise mode): ONE Philox block per attempt, slot 0xC0000000 | a - the normal from words 0, 1 through the
+// hardware fp32 Box-Muller of normal_quad_f32, the uniform from words 2, 3.
+template <bool F32 = false>
 __device__ __forceinline__ double gamma_unit(double shape, unsigned long long seed, unsigned long long gid,
                                              uint32_t step) {
     const double dd = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
-    // fully unrolled (nested early exits, no loop): a loop here makes LLVM hoist and spill the callers' ~1300
-    // invariant scalar loads.  P(all 8 attempts fail) < 0.05^8 = 4e-11.
+    // fully unrolled (nested early exits, no loop).  P(all 8 attempts fail) < 0.05^8 = 4e-11.
 #pragma unroll
     for (uint32_t a = 0; a < 8; a++) {
-        double z0, z1;
-        normal_pair(seed, gid, step, 0x80000000u | (2u * a), z0, z1);
+        double z0, u;
+        if (F32) {
+            uint32_t w[4];
+            philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, 0xC0000000u | a, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+            const float k = 2.3283064365386963e-10f;  // 2^-32
+            const float u0 = fmaf((float)w[0], k, 1.1641532182693481e-10f);
+            const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
+            z0 = (double)(r0 * __builtin_amdgcn_cosf((float)w[1] * k));
+            u = u01_from_words(w[2], w[3]);
+        } else {
+            double z1;
+            normal_pair(seed, gid, step, 0x80000000u | (2u * a), z0, z1);
+        }
         double v = 1.0 + c * z0;
         if (v <= 0.0) continue;
         v = v * v * v;
-        uint32_t w[4];
-        philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, 0x80000000u | (2u * a + 1u), (uint32_t)seed,
-                      (uint32_t)(seed >> 32), w);
-        const double u = u01_from_words(w[0], w[1]);
+        if (!F32) {
+            uint32_t w[4];
+            philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, 0x80000000u | (2u * a + 1u), (uint32_t)seed,
+                          (uint32_t)(seed >> 32), w);
+            u = u01_from_words(w[0], w[1]);
+        }
         if (log(u) < 0.5 * z0 * z0 + dd - dd * v + dd * log(v)) return dd * v;
     }
     return dd;
