@@ -946,8 +946,16 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_accept_flags(
             c++;
         }
     }
+    // one atomic per block (thousands of same-address atomics serialise at the L2: 8192 per-wave adds cost ~80 us)
+    __shared__ long long s_c[ASMC_BLOCK / 64];
     c = wave_sum_ll(c);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < ASMC_BLOCK / 64; w++) t += s_c[w];
+        if (t) atomicAdd(count, (unsigned long long)t);
+    }
 }
 
 template <typename T>
@@ -960,6 +968,47 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_copy_flagged_rows(int64_t n, int
         const int64_t r = e / d;
         if (flags[r]) x[e] = x_prop[e];
     }
+}
+
+// the same in 16-byte pieces, `cpr` pieces per row (row bytes a multiple of 16, n * cpr < 2^32): the row index comes from
+// a multiplication with magic = floor(2^32 / cpr) + 1 instead of a 64-bit division per element
+__global__ __launch_bounds__(ASMC_BLOCK) void k_copy_flagged_rows16(unsigned total, int shift, unsigned magic,
+                                                                   uint4* __restrict__ x, const uint4* __restrict__ x_prop,
+                                                                   const unsigned char* __restrict__ flags) {
+    const unsigned stride = gridDim.x * ASMC_BLOCK;
+    for (unsigned e = blockIdx.x * ASMC_BLOCK + threadIdx.x; e < total; e += stride) {
+        const unsigned r = shift >= 0 ? e >> shift : (unsigned)(((unsigned long long)e * magic) >> 32);
+        if (flags[r]) x[e] = x_prop[e];
+    }
+}
+
+static int launch_copy_flagged(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x, const void* x_prop,
+                               const unsigned char* flags, hipStream_t st) {
+    const int64_t rowb = (int64_t)d * (x_dtype == ASMC_F64 ? 8 : 4);
+    const int64_t cpr = rowb / 16;
+    // power-of-two piece counts shift; otherwise e * (floor(2^32 / cpr) + 1) >> 32 == e / cpr, exact while e * cpr < 2^32
+    const bool pow2 = cpr > 0 && (cpr & (cpr - 1)) == 0;
+    int shift = -1;
+    if (pow2)
+        for (shift = 0; (1LL << shift) < cpr; shift++) {
+        }
+    if (rowb % 16 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)x_prop % 16) == 0 && n * cpr < (1LL << 32) &&
+        (pow2 || n * cpr * cpr < (1LL << 32))) {
+        const unsigned total = (unsigned)(n * cpr);
+        const int grid = grid_for(total, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 4);
+        ASMC_LAUNCH(ctx, st, "k_copy_flagged_rows", k_copy_flagged_rows16, dim3(grid), dim3(ASMC_BLOCK), 0, st, total, shift,
+                    (unsigned)(0xFFFFFFFFu / (unsigned)cpr + 1u), (uint4*)x, (const uint4*)x_prop, flags);
+    } else {
+        const int grid2 = grid_for(n * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
+        if (x_dtype == ASMC_F64)
+            ASMC_LAUNCH(ctx, st, "k_copy_flagged_rows<double>", k_copy_flagged_rows<double>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d,
+                        (double*)x, (const double*)x_prop, flags);
+        else
+            ASMC_LAUNCH(ctx, st, "k_copy_flagged_rows<float>", k_copy_flagged_rows<float>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d,
+                        (float*)x, (const float*)x_prop, flags);
+    }
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
 }
 
 // =============================================================================================
@@ -1805,14 +1854,10 @@ int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x, const
                        lj_old, lj_new, qf_old, qf_new, beta, (unsigned long long)seed, (unsigned long long)gid0, step,
                        flags, ctx->d_keys);
     ASMC_LAUNCH_CHECK();
-    const int grid2 = grid_for(n * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
-    if (x_dtype == ASMC_F64)
-        ASMC_LAUNCH(ctx, st, "k_copy_flagged_rows<double>", k_copy_flagged_rows<double>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, (double*)x,
-                           (const double*)x_prop, (const unsigned char*)flags);
-    else
-        ASMC_LAUNCH(ctx, st, "k_copy_flagged_rows<float>", k_copy_flagged_rows<float>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, (float*)x,
-                           (const float*)x_prop, (const unsigned char*)flags);
-    ASMC_LAUNCH_CHECK();
+    {
+        const int rc2 = launch_copy_flagged(ctx, n, d, x_dtype, x, x_prop, flags, st);
+        if (rc2) return rc2;
+    }
     if (n_accept_host) {
         unsigned long long* h = reinterpret_cast<unsigned long long*>(ctx->h_pinned);
         ASMC_HIP(hipMemcpyAsync(h, ctx->d_keys, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1942,14 +1987,8 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
                     (const double*)nullptr, (const double*)q0, (const double*)q1, prm->beta, (unsigned long long)prm->seed,
                     (unsigned long long)prm->gid0, step, flags, d_cnt);
         ASMC_LAUNCH_CHECK();
-        const int g2 = grid_for(n * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
-        if (prm->x_dtype == ASMC_F64)
-            ASMC_LAUNCH(ctx, st, "k_copy_flagged_rows<double>", k_copy_flagged_rows<double>, dim3(g2), dim3(ASMC_BLOCK), 0, st,
-                        n, d, (double*)x, (const double*)x_prop, (const unsigned char*)flags);
-        else
-            ASMC_LAUNCH(ctx, st, "k_copy_flagged_rows<float>", k_copy_flagged_rows<float>, dim3(g2), dim3(ASMC_BLOCK), 0, st,
-                        n, d, (float*)x, (const float*)x_prop, (const unsigned char*)flags);
-        ASMC_LAUNCH_CHECK();
+        rc = launch_copy_flagged(ctx, n, d, prm->x_dtype, x, x_prop, flags, st);
+        if (rc) return rc;
         rc = pcn_close_step(ctx, st, 1, (const long long*)d_cnt, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
         if (rc) return rc;
     }

@@ -26,3 +26,9 @@ for nu in (0.0, 6.0):
         eng.pcn_accept(x, xp, ll, lp, lq, f(xp), f(xp), f(xp / 1.5), q0, q1, 0.5, 5, 0, t)
     torch.cuda.synchronize()
     print(f"nu={nu}: propose {tp*1e3:.3f} ms, full split step {(time.perf_counter()-t0)/20*1e3:.3f} ms")
+eng.profile(True)
+for t in range(10):
+    xp, q0, q1 = eng.pcn_propose(x, mu, eye, eye, 0.3, 5, 0, 100 + t, nu=0.0)
+    eng.pcn_accept(x, xp, ll, lp, lq, f(xp), f(xp), f(xp / 1.5), q0, q1, 0.5, 5, 0, 100 + t)
+rep = eng.profile_report(); eng.profile(False)
+print({k: (v[0], round(v[1] * 1e3, 1)) for k, v in rep.items()})
