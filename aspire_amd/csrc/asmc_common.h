@@ -72,6 +72,8 @@ struct asmc_ctx {
     unsigned char* d_flags;        // [n_max + 64] accept flags of the split-path pCN step
     double* d_gamma;               // [n_max] tpCN scale variates of the current step
     void* d_ysoa;                  // coordinate-major whitened state of a mutation (grown on demand)
+    double* d_student;             // [d_max (d_max + 1) + (ASMC_STUDENT_MAX_ROWS / 64) (d_max + 2)] tpCN fit: tables, partials
+    double* h_student;             // pinned staging of the same size
     size_t ysoa_bytes;
     long long* d_counts;           // [ASMC_MAX_PCN_STEPS + max(ASMC_MAX_BLOCKS, n_max/64+1)] accept counts / partials
     double* d_rho;                 // [ASMC_MAX_PCN_STEPS + 8] step-size history on device

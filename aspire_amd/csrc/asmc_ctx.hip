@@ -127,6 +127,9 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     dmalloc((void**)&c->d_guide, sizeof(unsigned int) * ((size_t)n_max / 4 + 8));
     dmalloc((void**)&c->d_flags, (size_t)n_max + 64);
     dmalloc((void**)&c->d_gamma, sizeof(double) * (size_t)n_max);
+    const size_t student = (size_t)d_max * (d_max + 1) + (size_t)(ASMC_STUDENT_MAX_ROWS / 64) * (d_max + 2);
+    dmalloc((void**)&c->d_student, sizeof(double) * student);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_student, sizeof(double) * student, hipHostMallocDefault);
     dmalloc((void**)&c->d_counts, sizeof(long long) * (size_t)(ASMC_MAX_PCN_STEPS + ASMC_MAX_BLOCKS + n_max / 64 + 8));
     dmalloc((void**)&c->d_rho, sizeof(double) * (ASMC_MAX_PCN_STEPS + 8));
     dmalloc((void**)&c->d_pcgtab, sizeof(unsigned long long) * (64 * 4 + 8));
@@ -155,6 +158,8 @@ int asmc_ctx_destroy(asmc_ctx* c) {
     (void)hipFree(c->d_guide);
     (void)hipFree(c->d_flags);
     (void)hipFree(c->d_gamma);
+    (void)hipFree(c->d_student);
+    if (c->h_student) (void)hipHostFree(c->h_student);
     if (c->d_ysoa) (void)hipFree(c->d_ysoa);
     (void)hipFree(c->d_counts);
     (void)hipFree(c->d_rho);

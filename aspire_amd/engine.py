@@ -464,6 +464,28 @@ class HipEngine:
               "asmc_centered_gram")
         return out
 
+    # ---- Student-t reference fit (tpCN): per-particle half of the EM on a device-resident subsample ----------------
+    def student_estep(self, xs: torch.Tensor, mu: np.ndarray, linv: np.ndarray, nu: float):
+        """(z [m] on device, sum z, sum (log z - z), sum z x [d]) for the subsample xs [m, d] fp64."""
+        assert xs.dtype == torch.float64 and xs.is_contiguous() and xs.dim() == 2
+        m, d = xs.shape
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        linv = np.ascontiguousarray(linv, dtype=np.float64)
+        z = self.empty(m)
+        sums = np.empty(d + 2)
+        check(self.lib.asmc_student_estep(self._ctx, m, d, _dptr(xs), _f64p(mu), _f64p(linv), float(nu), _dptr(z), _f64p(sums),
+                                          self._stream), "asmc_student_estep")
+        return z, float(sums[0]), float(sums[1]), sums[2:].copy()
+
+    def student_scale(self, xs: torch.Tensor, z: torch.Tensor, mu: np.ndarray) -> torch.Tensor:
+        """r = sqrt(z) (x - mu); centered_gram(r, 0) is the weighted scatter matrix of the M-step."""
+        m, d = xs.shape
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        r = torch.empty_like(xs)
+        check(self.lib.asmc_student_scale(self._ctx, m, d, _dptr(xs), _dptr(z), _f64p(mu), _dptr(r), self._stream),
+              "asmc_student_scale")
+        return r
+
     def set_count_hook(self, comm, n_global: int | None):
         """Sharded mutation: let `pcn_mutate` / `pcn_mutate_flow` adapt the step size from the GLOBAL acceptance rate
         with the whole step loop enqueued on the stream - after each step the library leaves this rank's accept

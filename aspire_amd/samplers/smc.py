@@ -402,22 +402,22 @@ class HipSMC(SMCSampler):
         same on every rank (`tpcn`; student_t.py).  A fit with nu above NU_GAUSSIAN runs the Gaussian kernels."""
         if step_fn != "tpcn":
             return (*self._fit_reference_gaussian(x, n_global), 0.0)
-        from ..student_t import NU_GAUSSIAN, _chol, fit_student_t
+        from ..student_t import NU_GAUSSIAN, _chol, fit_student_t_device
 
         e, comm = self.engine, self.comm
-        m = int(self.sampler_kwargs.get("tpcn_fit_subsample", 2048))
+        m = min(int(self.sampler_kwargs.get("tpcn_fit_subsample", 2048)), 16384)
         k = max(1, min(m, n_global) // comm.world)
         n_local = x.shape[0]
         rows = torch.as_tensor((np.arange(k, dtype=np.int64) * n_local) // k, device=x.device)
-        sub = np.ascontiguousarray(e.to_numpy(x[rows]), dtype=np.float64)
+        sub = x[rows].to(torch.float64).contiguous()  # strided subsample, stays on the device
         if comm.world > 1:
-            sub = comm.all_gather_f64(sub).reshape(-1, x.shape[1])
+            sub = comm.all_gather_tensor(sub)  # the same rows on every rank: identical fits
         st = self._pcn_state
         with _single_threaded_blas():
             # EM sweeps: a cold start needs ~a dozen; later temperatures restart (mu, Sigma) from the subsample's
             # moments and nu from the previous fit, and a few sweeps track the slowly changing population
             iters = int(self.sampler_kwargs.get("tpcn_fit_iters", 12 if st.get("nu") is None else 4))
-            mean, cov, nu = fit_student_t(sub, max_iter=iters, nu0=st.get("nu") or 20.0)
+            mean, cov, nu = fit_student_t_device(e, sub, max_iter=iters, nu0=st.get("nu") or 20.0)
             L = _chol(cov)
             Linv = np.linalg.inv(L)
         st["nu"] = nu

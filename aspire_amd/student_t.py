@@ -4,9 +4,13 @@ default: smc/minipcn.py:46-49; the fit itself lives in third-party minipcn, abse
 `fit_student_t` is the standard EM for a multivariate t with unknown location, scale matrix and degrees of freedom
 (Liu & Rubin 1995): E-step weights z_i = (nu + d)/(nu + delta_i), delta_i the Mahalanobis distance; M-step weighted
 mean and scale matrix; nu solves  -psi(nu/2) + log(nu/2) + 1 + mean(log z_i - z_i) + psi((nu+d)/2) - log((nu+d)/2) = 0.
-It runs on the host over a SUBSAMPLE of the particles (d x d control-plane work; the per-particle arithmetic of the
-mutation is in the HIP kernels).  The reference distribution only shapes the proposal - the Metropolis correction keeps
-the tempered target invariant for any (mu, Sigma, nu) - so a few thousand particles are plenty.
+It runs over a SUBSAMPLE of the particles: the reference distribution only shapes the proposal - the Metropolis
+correction keeps the tempered target invariant for any (mu, Sigma, nu) - so a few thousand particles are plenty.
+`fit_student_t_device` is what the sampler uses: everything that touches a particle (Mahalanobis distances, weights,
+weighted sums, the weighted scatter matrix) runs in HIP kernels on the device-resident subsample
+(asmc_student_estep / asmc_student_scale / asmc_centered_gram); the host keeps the d-vector, d x d and scalar algebra
+(weighted mean, Cholesky factor, the root in nu), as it does for the Gaussian reference.  `fit_student_t` is the same
+EM in numpy (test reference; also the restatement the device version is checked against).
 """
 from __future__ import annotations
 
@@ -55,6 +59,38 @@ def fit_student_t(data: np.ndarray, max_iter: int = 50, rtol: float = 1e-3, nu0:
             return -digamma(0.5 * v) + np.log(0.5 * v) + c
 
         # f decreases from +inf (v -> 0) to c (v -> inf): a root exists iff c < 0; otherwise the data are Gaussian
+        if not (c < 0.0) or f(NU_MAX) >= 0.0:
+            nu_new = NU_MAX
+        elif f(NU_MIN) <= 0.0:
+            nu_new = NU_MIN
+        else:
+            nu_new = float(brentq(f, NU_MIN, NU_MAX, xtol=1e-8, rtol=1e-10))
+        done = abs(nu_new - nu) <= rtol * nu
+        nu = nu_new
+        if done:
+            break
+    return mu, cov, float(min(max(nu, NU_MIN), NU_MAX))
+
+
+def fit_student_t_device(engine, xs, max_iter: int = 50, rtol: float = 1e-3, nu0: float = 20.0):
+    """`fit_student_t` with the per-particle arithmetic on the device.  xs: [m, d] fp64 device tensor."""
+    m, d = int(xs.shape[0]), int(xs.shape[1])
+    mu = np.asarray(engine.colsum(xs), dtype=np.float64) / m
+    cov = np.asarray(engine.centered_gram(xs, mu), dtype=np.float64) / max(m - 1, 1)
+    cov = 0.5 * (cov + cov.T)
+    nu = float(nu0)
+    zero = np.zeros(d)
+    for _ in range(max_iter):
+        Linv = np.linalg.inv(_chol(cov))
+        z, sum_z, sum_lz, sum_zx = engine.student_estep(xs, mu, np.tril(Linv), nu)
+        mu = sum_zx / sum_z
+        cov = np.asarray(engine.centered_gram(engine.student_scale(xs, z, mu), zero), dtype=np.float64) / m
+        cov = 0.5 * (cov + cov.T)
+        c = 1.0 + sum_lz / m + float(digamma(0.5 * (nu + d))) - np.log(0.5 * (nu + d))
+
+        def f(v):
+            return -digamma(0.5 * v) + np.log(0.5 * v) + c
+
         if not (c < 0.0) or f(NU_MAX) >= 0.0:
             nu_new = NU_MAX
         elif f(NU_MIN) <= 0.0:

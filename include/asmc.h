@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 4
+#define ASMC_ABI_VERSION 5
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -46,6 +46,7 @@ extern "C" {
 
 #define ASMC_MAX_BETAS 32      /* candidate betas evaluated per pass */
 #define ASMC_BIS_REC 40        /* doubles per rank record of the sharded beta search (asmc_find_beta_shard_*) */
+#define ASMC_STUDENT_MAX_ROWS 16384 /* largest subsample of the tpCN reference fit (asmc_student_*) */
 #define ASMC_SELECT_THREADS 262144 /* generator threads of asmc_pcg64_select (fixes the order of the kept draws) */
 #define ASMC_MAX_COMPONENTS 8  /* mixture components of a built-in density */
 #define ASMC_MAX_DIMS 256
@@ -270,6 +271,16 @@ int asmc_compact_valid(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
  *   reference smc/base.py:507-519).  logj_old_dev / logj_new_dev (both or neither): log|det J| of the
  *   preconditioning transform at the current / proposed state, added to the tempered log-target
  *   (smc/base.py:515-517); logj_old_dev is updated in place for accepted particles. */
+/* Student-t reference of the tpCN step (params->nu > 0): the EM fit of (mu, Sigma, nu) runs on a subsample of m particles
+ * (xs_dev [m, d] fp64, gathered by the caller); these calls are its per-particle half, the host keeps the d x d algebra.
+ * asmc_student_estep: y = Linv (x - mu), z = (nu + d)/(nu + |y|^2) -> z_dev[m];
+ *   sums_host[d + 2] = { sum z, sum (log z - z), sum z x[0..d) } (block partials added in block order).
+ * asmc_student_scale: r = sqrt(z) (x - mu) -> r_dev[m, d]; asmc_centered_gram(r, center 0) is then the weighted scatter. */
+int asmc_student_estep(asmc_ctx* ctx, int64_t m, int d, const double* xs_dev, const double* mu_host,
+                       const double* linv_host /* [d, d] row-major, lower triangle */, double nu, double* z_dev,
+                       double* sums_host, asmc_stream stream);
+int asmc_student_scale(asmc_ctx* ctx, int64_t m, int d, const double* xs_dev, const double* z_dev, const double* mu_host,
+                       double* r_dev, asmc_stream stream);
 typedef int (*asmc_count_hook)(void* user, asmc_stream stream);
 int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int64_t* cell_dev, int64_t n_global);
 int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, double* sum_host,

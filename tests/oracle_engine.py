@@ -147,6 +147,17 @@ class OracleEngine:
         return (float(st["lo"]), float(st["eff_one"]), bool(st["done"]), int(st["rounds"]), int(st["n_nan"]), st["trip"],
                 tuple(map(float, st["one"])))
 
+    # Student-t reference fit: numpy restatement of asmc_student_estep / asmc_student_scale
+    def student_estep(self, xs, mu, linv, nu):
+        x = _np(xs).astype(np.float64)
+        d = x.shape[1]
+        y = (x - np.asarray(mu)) @ np.tril(np.asarray(linv)).T
+        z = (nu + d) / (nu + (y * y).sum(1))
+        return torch.from_numpy(z), float(z.sum()), float((np.log(z) - z).sum()), (z[:, None] * x).sum(0)
+
+    def student_scale(self, xs, z, mu):
+        return torch.from_numpy(np.sqrt(_np(z))[:, None] * (_np(xs).astype(np.float64) - np.asarray(mu)))
+
     def pcg64_select(self, state4, n_total, lo, hi):
         return torch.from_numpy(O.pcg64_select(np.array(state4, dtype=np.uint64), n_total, lo, hi))
 

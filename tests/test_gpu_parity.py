@@ -1287,3 +1287,32 @@ def test_shard_entry_points_reject_bad_arguments(eng):
         x = eng.asarray(np.zeros((8, 4)))
         eye = eng.asarray(np.eye(4))
         eng.pcn_propose(x, eng.asarray(np.zeros(4)), eye, eye, 0.3, 1, 0, 0, nu=0.5)
+
+
+@pytest.mark.parametrize("m,d", [(2048, 32), (1999, 7), (4096, 128), (64, 2)])
+def test_student_fit_kernels_vs_numpy(eng, m, d):
+    """asmc_student_estep / asmc_student_scale against their numpy restatement, then the whole device-driven EM against the
+    all-numpy EM on heavy-tailed data."""
+    from oracle_engine import OracleEngine
+    from aspire_amd.student_t import fit_student_t, fit_student_t_device
+
+    g = np.random.default_rng(m + d)
+    A = g.normal(size=(d, d)) / np.sqrt(d)
+    L = np.linalg.cholesky(A @ A.T + 0.5 * np.eye(d))
+    x = 0.3 + (g.normal(size=(m, d)) @ L.T) / np.sqrt(g.chisquare(6.0, size=m) / 6.0)[:, None]
+    mu = x.mean(0) + 0.01
+    Linv = np.linalg.inv(L)
+    xd = eng.asarray(x)
+    z, sz, sl, szx = eng.student_estep(xd, mu, np.tril(Linv), 7.5)
+    zr, szr, slr, szxr = OracleEngine().student_estep(torch.as_tensor(x), mu, np.tril(Linv), 7.5)
+    np.testing.assert_allclose(z.cpu().numpy(), zr.numpy(), rtol=1e-12)
+    assert sz == pytest.approx(szr, rel=1e-12) and sl == pytest.approx(slr, rel=1e-11)
+    np.testing.assert_allclose(szx, szxr, rtol=1e-11, atol=1e-11)
+    r = eng.student_scale(xd, z, mu)
+    np.testing.assert_allclose(r.cpu().numpy(), np.sqrt(zr.numpy())[:, None] * (x - mu), rtol=1e-13, atol=1e-14)
+    if m > d + 10:
+        a = fit_student_t(x, max_iter=8)
+        b = fit_student_t_device(eng, xd, max_iter=8)
+        np.testing.assert_allclose(b[0], a[0], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(b[1], a[1], rtol=1e-7, atol=1e-9)
+        assert b[2] == pytest.approx(a[2], rel=1e-6)
