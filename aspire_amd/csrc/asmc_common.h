@@ -88,6 +88,7 @@ struct asmc_ctx {
     int64_t count_n_global;
     int64_t n_tiles_max;
     int gram_blocks;
+    size_t gram_cap;  // doubles in d_gram (>= gram_blocks * d_max^2; the d = 32 matrix-core Gram kernel uses up to 2048 partials)
     unsigned long long pcg_inc[2];  // increment the device jump table was built for
     int pcg_tab_valid;
     // optional per-kernel HIP-event timing (asmc_profile_enable / asmc_profile_report)

@@ -121,7 +121,9 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     dmalloc((void**)&c->d_keys, sizeof(unsigned long long) * (ASMC_MAX_BETAS + 8));
     dmalloc((void**)&c->d_tiles, sizeof(double) * (size_t)(c->n_tiles_max * 4 + 64));
     dmalloc((void**)&c->d_tiles_i, sizeof(long long) * (size_t)(c->n_tiles_max * 8 + 64));
-    dmalloc((void**)&c->d_gram, sizeof(double) * (size_t)c->gram_blocks * d_max * d_max);
+    c->gram_cap = (size_t)c->gram_blocks * d_max * d_max;
+    if (c->gram_cap < (size_t)2048 * 1024) c->gram_cap = (size_t)2048 * 1024;
+    dmalloc((void**)&c->d_gram, sizeof(double) * c->gram_cap);
     c->d_mmtab = nullptr;
     if (d_max >= 64) dmalloc((void**)&c->d_mmtab, sizeof(double) * 2 * 144 * 64);
     dmalloc((void**)&c->d_guide, sizeof(unsigned int) * ((size_t)n_max / 4 + 8));

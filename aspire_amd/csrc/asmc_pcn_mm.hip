@@ -342,42 +342,59 @@ __global__ __launch_bounds__(64 * (D / 32)) void k_gram_mm(int64_t n, const T* _
 }
 
 // fixed-order sum of the per-block partial matrices, one thread per matrix entry (coalesced across entries)
-__global__ __launch_bounds__(256) void k_gram_mm_reduce(int nblocks, int ncols, const double* __restrict__ partials,
-                                                        double* __restrict__ out) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= ncols) return;
-    double v = 0.0;
-    for (int b0 = 0; b0 < nblocks; b0 += 8) {
-        double t[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) t[q] = (b0 + q < nblocks) ? partials[(size_t)(b0 + q) * ncols + col] : 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; q++) v += t[q];
+// sums the per-block partial matrices in a fixed order: 16 columns per block, 64 groups of partials per column in flight
+__global__ __launch_bounds__(1024) void k_gram_mm_reduce(int nblocks, int ncols, const double* __restrict__ partials,
+                                                         double* __restrict__ out) {
+    __shared__ double s[64][17];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + c;
+    double v0 = 0.0, v1 = 0.0;
+    if (col < ncols) {
+        int b = g;
+        for (; b + 64 < nblocks; b += 128) {
+            v0 += partials[(size_t)b * ncols + col];
+            v1 += partials[(size_t)(b + 64) * ncols + col];
+        }
+        if (b < nblocks) v0 += partials[(size_t)b * ncols + col];
     }
-    out[col] = v;
+    s[g][c] = v0 + v1;
+    __syncthreads();
+    if (g == 0 && col < ncols) {
+        double t = 0.0;
+        for (int q = 0; q < 64; q++) t += s[q][c];
+        out[col] = t;
+    }
 }
 
-bool asmc_gram_mm_supported(int d, const void* x) { return (d == 64 || d == 128) && ((uintptr_t)x % 16 == 0); }
+bool asmc_gram_mm_supported(int d, const void* x) {
+    static const bool no32 = getenv("ASMC_GRAM_RB32") != nullptr;
+    return (d == 64 || d == 128 || (d == 32 && !no32)) && ((uintptr_t)x % 16 == 0);
+}
 
 // enqueues the Gram kernel and the reduction of its per-block partial matrices; the d x d result lands in ctx->d_partials
 int asmc_gram_mm_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* d_center, int* grid_out,
                         hipStream_t st) {
     int grid = (int)((n + GRAM_TP - 1) / GRAM_TP);
-    if (grid > ctx->gram_blocks) grid = ctx->gram_blocks;
+    // d = 32: one wave per block, so eight blocks per CU are needed to keep enough loads in flight
+    int cap = d == 32 ? 8 * ctx->num_cu : ctx->gram_blocks;
+    if ((size_t)cap * d * d > ctx->gram_cap) cap = (int)(ctx->gram_cap / ((size_t)d * d));
+    if (grid > cap) grid = cap;
     *grid_out = grid;
     const size_t lds = (size_t)GRAM_TP * (d + 16) * sizeof(double);
 #define GRAM_CASE(TT, DD) \
     ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_mm<TT, DD>), dim3(grid), dim3(64 * (DD / 32)), lds, st, n, (const TT*)x, d_center, ctx->d_gram)
     if (x_dtype == ASMC_F64) {
         if (d == 128) GRAM_CASE(double, 128);
-        else GRAM_CASE(double, 64);
+        else if (d == 64) GRAM_CASE(double, 64);
+        else GRAM_CASE(double, 32);
     } else {
         if (d == 128) GRAM_CASE(float, 128);
-        else GRAM_CASE(float, 64);
+        else if (d == 64) GRAM_CASE(float, 64);
+        else GRAM_CASE(float, 32);
     }
 #undef GRAM_CASE
     ASMC_LAUNCH_CHECK();
-    ASMC_LAUNCH(ctx, st, "k_gram_mm_reduce", k_gram_mm_reduce, dim3((d * d + 255) / 256), dim3(256), 0, st, grid, d * d,
+    ASMC_LAUNCH(ctx, st, "k_gram_mm_reduce", k_gram_mm_reduce, dim3((d * d + 15) / 16), dim3(1024), 0, st, grid, d * d,
                 (const double*)ctx->d_gram, ctx->d_partials);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
