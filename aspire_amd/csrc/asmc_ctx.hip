@@ -110,7 +110,7 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     c->d_max = d_max;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->n_tiles_max = (n_max + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE + 1;
-    c->gram_blocks = 2 * c->num_cu;
+    c->gram_blocks = (d_max <= 128 ? 4 : 2) * c->num_cu;  // partial matrices of the moment kernels (d_max^2 doubles each)
     if (c->gram_blocks > ASMC_MAX_BLOCKS) c->gram_blocks = ASMC_MAX_BLOCKS;
     hipError_t e = hipSuccess;
     auto dmalloc = [&](void** p, size_t bytes) {

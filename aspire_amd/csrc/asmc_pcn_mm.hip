@@ -376,7 +376,7 @@ int asmc_gram_mm_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void
                         hipStream_t st) {
     int grid = (int)((n + GRAM_TP - 1) / GRAM_TP);
     // d = 32: one wave per block, so eight blocks per CU are needed to keep enough loads in flight
-    int cap = d == 32 ? 8 * ctx->num_cu : ctx->gram_blocks;
+    int cap = d == 32 ? 8 * ctx->num_cu : 2 * ctx->num_cu;  // (more blocks change nothing at d = 64 / 128: measured)
     if ((size_t)cap * d * d > ctx->gram_cap) cap = (int)(ctx->gram_cap / ((size_t)d * d));
     if (grid > cap) grid = cap;
     *grid_out = grid;
