@@ -341,6 +341,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 // the identity (the generic LDS kernel needs 0.5-1.1 ms per proposal there, this one 0.3 ms)
 #define PCN_X_PROPOSE_PAD 14
 #define PCN_X_PROPOSE_PAD_T 15
+// coordinate-major whitened-state step for densities with several mixture components: x' = mu + L y' is materialised in
+// a second register array and handed to the general mixture evaluation (PCN_Y_STEP_S folds it into three quadratic
+// forms on the fly, which only works for single Gaussians); still one mat-vec per step and no LDS
+#define PCN_Y_STEP_SG 16
+#define PCN_Y_STEP_TSG 17
 
 // coordinate-major state through buffer instructions: one 128-bit descriptor in SGPRs, the lane as a 32-bit VGPR
 // offset and the coordinate's row (j * n_pad + tile) as the scalar offset - instead of one 64-bit VGPR address pair per
@@ -403,11 +408,12 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
                                              long long* __restrict__ block_counts) {
     extern __shared__ __align__(16) char smem[];
     constexpr bool TP = MODE == PCN_X_STEP_T || MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS || MODE == PCN_X_PROPOSE_T ||
-                        MODE == PCN_X_PROPOSE_PAD_T;
-    constexpr bool SOA = MODE >= PCN_WHITEN_S && MODE <= PCN_UNWHITEN_XS;
+                        MODE == PCN_X_PROPOSE_PAD_T || MODE == PCN_Y_STEP_TSG;
+    constexpr bool GEN = MODE == PCN_Y_STEP_SG || MODE == PCN_Y_STEP_TSG;  // general mixtures on the whitened state
+    constexpr bool SOA = (MODE >= PCN_WHITEN_S && MODE <= PCN_UNWHITEN_XS) || GEN;
     constexpr bool PAD = MODE == PCN_X_PROPOSE_PAD || MODE == PCN_X_PROPOSE_PAD_T;
     constexpr bool PROPOSE = MODE == PCN_X_PROPOSE || MODE == PCN_X_PROPOSE_T || PAD;
-    constexpr int M = PROPOSE ? PCN_X_STEP : MODE == PCN_WHITEN_S ? PCN_WHITEN : (MODE == PCN_Y_STEP_S || MODE == PCN_Y_STEP_TS) ? PCN_Y_STEP
+    constexpr int M = PROPOSE ? PCN_X_STEP : GEN ? PCN_Y_STEP : MODE == PCN_WHITEN_S ? PCN_WHITEN : (MODE == PCN_Y_STEP_S || MODE == PCN_Y_STEP_TS) ? PCN_Y_STEP
                       : MODE == PCN_UNWHITEN_S ? PCN_UNWHITEN : MODE == PCN_UNWHITEN_XS ? PCN_UNWHITEN_X
                       : TP ? MODE - PCN_X_STEP_T : MODE;
     constexpr bool ROW_IN = !SOA || M == PCN_WHITEN;     // the state arrives as row-major x through the LDS tile
@@ -594,6 +600,25 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
 #else
                     nll = v[0], nlp = v[1], nlq = v[2];
 #endif
+                } else if (GEN) {
+                    // v keeps y'; x' goes to a second register array for the general mixture evaluation
+                    double xq[D];
+#pragma unroll
+                    for (int g = 0; g < D / 4; g++) {
+                        const int j0 = 4 * g;
+                        double sr[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int k = 0; k < j0 + 4; k++) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++)
+                                if (k <= j0 + r) sr[r] = fma(Lp[(j0 + r) * (j0 + r + 1) / 2 + k], v[k], sr[r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; r++) xq[j0 + r] = (double)(T)(mup[j0 + r] + sr[r]);
+                    }
+                    nll = mixture_eval_regs<D>(mll, xq);
+                    nlp = mixture_eval_regs<D>(mlp, xq);
+                    nlq = mixture_eval_regs<D>(mlq, xq);
                 } else {
                     // v keeps y' (it is what gets stored); x'_j = mu_j + sum_k L[j,k] y'_k is produced four rows
                     // at a time and folded straight into the three quadratic forms (component 0 of each target)
@@ -1282,7 +1307,8 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     // when the tile is large (d = 32 fp64: 17 KB tiles -> 2 blocks of 4 = 8 waves, but 9 single-wave blocks)
     constexpr size_t tile_bytes = (size_t)64 * LDSROW;
     static int wpb_env = getenv("ASMC_PCN_WPB") ? atoi(getenv("ASMC_PCN_WPB")) : 0;
-    constexpr bool NO_LDS = MODE == PCN_Y_STEP_S || MODE == PCN_Y_STEP_TS;  // coordinate-major state: registers only
+    constexpr bool NO_LDS = MODE == PCN_Y_STEP_S || MODE == PCN_Y_STEP_TS || MODE == PCN_Y_STEP_SG ||
+                            MODE == PCN_Y_STEP_TSG;  // coordinate-major state: registers only
     const int wpb = wpb_env > 0 ? wpb_env : (NO_LDS || (160 * 1024) / tile_bytes % 4 == 0 || tile_bytes * 12 <= 160 * 1024 ? 4 : 1);
     const size_t lds_bytes = NO_LDS ? 0 : (size_t)wpb * tile_bytes;
     const int64_t n_tiles = (n + 63) / 64;
@@ -1311,7 +1337,7 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
-    ASMC_LAUNCH(ctx, st, MODE == PCN_X_STEP ? "k_pcn_reg" : (MODE == PCN_Y_STEP || MODE == PCN_Y_STEP_S) ? "k_pcn_reg_y" : MODE == PCN_X_STEP_T ? "k_tpcn_reg" : (MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS) ? "k_tpcn_reg_y" : (MODE == PCN_WHITEN || MODE == PCN_WHITEN_S) ? "k_pcn_whiten" : (MODE >= PCN_X_PROPOSE && MODE <= PCN_X_PROPOSE_PAD_T) ? "k_pcn_propose_reg" : "k_pcn_unwhiten", kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
+    ASMC_LAUNCH(ctx, st, MODE == PCN_X_STEP ? "k_pcn_reg" : (MODE == PCN_Y_STEP || MODE == PCN_Y_STEP_S || MODE == PCN_Y_STEP_SG) ? "k_pcn_reg_y" : MODE == PCN_X_STEP_T ? "k_tpcn_reg" : (MODE == PCN_Y_STEP_T || MODE == PCN_Y_STEP_TS || MODE == PCN_Y_STEP_TSG) ? "k_tpcn_reg_y" : (MODE == PCN_WHITEN || MODE == PCN_WHITEN_S) ? "k_pcn_whiten" : (MODE >= PCN_X_PROPOSE && MODE <= PCN_X_PROPOSE_PAD_T) ? "k_pcn_propose_reg" : "k_pcn_unwhiten", kern, dim3(grid), dim3(wpb * 64), lds_bytes, st, n, x, ll, lp, lq, (const double*)ctx->d_ptab, ps,
                        rho_ptr, step, block_counts);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -1404,6 +1430,10 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
     PCN_CASE2(DD, ASMC_NOISE_F32, PCN_Y_STEP_S)  \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_Y_STEP_TS) \
     PCN_CASE2(DD, ASMC_NOISE_F32, PCN_Y_STEP_TS) \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_Y_STEP_SG)  \
+    PCN_CASE2(DD, ASMC_NOISE_F32, PCN_Y_STEP_SG)  \
+    PCN_CASE2(DD, ASMC_NOISE_F64, PCN_Y_STEP_TSG) \
+    PCN_CASE2(DD, ASMC_NOISE_F32, PCN_Y_STEP_TSG) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_WHITEN_S)  \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN_S) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN_XS) \
@@ -1728,12 +1758,15 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     }
     const bool reg_ok = pcn_reg_supported(pd.d, prm->x_dtype == ASMC_F64 ? 8 : 4, x);
     // whitened-state stepping: plain (single-component) targets, enough steps to amortise the two conversions
-    const bool y_state = reg_ok && pd.ll.C == 1 && pd.lp.C == 1 && pd.lq.C == 1 && n_steps >= 4 && !getenv("ASMC_PCN_XSTATE");
+    const bool single = pd.ll.C == 1 && pd.lp.C == 1 && pd.lq.C == 1;
+    bool y_state = reg_ok && n_steps >= 4 && !getenv("ASMC_PCN_XSTATE");  // several components: only coordinate-major (below)
     // whitened state in a coordinate-major scratch buffer (grown on demand, kept for the life of the ctx)
     const bool soa = y_state && pcn_ensure_ysoa(ctx, n, pd.d, prm->x_dtype, pd, st);
+    if (!single && !soa) y_state = false;  // the row-major whitened-state kernel folds single Gaussians only
     auto launch_mode = [&](int mode, uint32_t stp, int* grid) -> int {
-        if (soa) mode = mode == PCN_WHITEN ? PCN_WHITEN_S : mode == PCN_UNWHITEN ? PCN_UNWHITEN_S : mode == PCN_Y_STEP ? PCN_Y_STEP_S
-                        : mode == PCN_Y_STEP_T ? PCN_Y_STEP_TS : mode;
+        if (soa) mode = mode == PCN_WHITEN ? PCN_WHITEN_S : mode == PCN_UNWHITEN ? PCN_UNWHITEN_S
+                        : mode == PCN_Y_STEP ? (single ? PCN_Y_STEP_S : PCN_Y_STEP_SG)
+                        : mode == PCN_Y_STEP_T ? (single ? PCN_Y_STEP_TS : PCN_Y_STEP_TSG) : mode;
         pd.mode = mode;
         const int nz = pd.noise;
         if (mode == PCN_WHITEN || mode == PCN_UNWHITEN || mode == PCN_UNWHITEN_X || mode == PCN_WHITEN_S || mode == PCN_UNWHITEN_S)

@@ -1316,3 +1316,42 @@ def test_student_fit_kernels_vs_numpy(eng, m, d):
         np.testing.assert_allclose(b[0], a[0], rtol=1e-8, atol=1e-9)
         np.testing.assert_allclose(b[1], a[1], rtol=1e-7, atol=1e-9)
         assert b[2] == pytest.approx(a[2], rel=1e-6)
+
+
+@pytest.mark.parametrize("d,C,nu,noise,dtype", [(32, 2, 0.0, "f64", torch.float64), (8, 3, 0.0, "f64", torch.float64),
+                                                (32, 2, 6.0, "f64", torch.float64), (16, 2, 0.0, "f32", torch.float32)])
+def test_pcn_whitened_state_with_mixture_targets_vs_oracle(eng, oracle, d, C, nu, noise, dtype):
+    """Several mixture components on the coordinate-major whitened state (PCN_Y_STEP_SG / _TSG: x' materialised in a second
+    register array): 4 steps against the oracle's x-space restatement."""
+    n = 3000
+    x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 500 + d, C=C)
+    om = [oracle.Mixture(*m) for m in mixes]
+    dm = [eng.make_mixture(*m) for m in mixes]
+    xd = torch.as_tensor(x).to(dtype).to(eng.device)
+    xr = xd.double().cpu().numpy().copy()
+    ll, lp, lq = (m.logpdf(xr) for m in om)
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    rho, beta, seed = 0.35, 0.6, 1777
+    eng.profile(True)
+    n_acc, _, _ = eng.pcn_mutate(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), dm[0], dm[1], dm[2],
+                                 seed, 50, rho, 4, 10, 0.234, False, noise, nu)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert rep["k_tpcn_reg_y" if nu > 0 else "k_pcn_reg_y"][0] == 4 and "k_pcn_reg" not in rep
+    llr, lpr, lqr = ll.copy(), lp.copy(), lq.copy()
+    def step(t):
+        if nu > 0:
+            return oracle.tpcn_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, nu, om[0], om[1], om[2], seed, 50, 10 + t, noise)
+        return oracle.pcn_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, om[0], om[1], om[2], seed, 50, 10 + t, noise)
+
+    acc_ref = [step(t) for t in range(4)]
+    got = xd.double().cpu().numpy()
+    exact = dtype == torch.float64 and noise == "f64"
+    tol = 1e-9 if exact else 3e-5
+    close = np.all(np.abs(got - xr) <= tol * (1 + np.abs(xr)), axis=1)
+    edge = 3 if exact else 60
+    assert (~close).sum() <= edge, (~close).sum()
+    assert np.all(np.abs(np.array(n_acc) - np.array(acc_ref)) <= edge)
+    assert 0.02 < np.mean(n_acc) / n < 0.98
+    np.testing.assert_allclose(lld.cpu().numpy(), om[0].logpdf(got), rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(lqd.cpu().numpy(), om[2].logpdf(got), rtol=1e-10, atol=1e-9)
