@@ -4,6 +4,7 @@ Bars: bit-exact for integer/index work (resample indices, PCG64 doubles, gather,
 relative 1e-12 (far inside the north-star's 1e-6) for log-weights and reductions.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1337,7 +1338,8 @@ def test_pcn_whitened_state_with_mixture_targets_vs_oracle(eng, oracle, d, C, nu
                                  seed, 50, rho, 4, 10, 0.234, False, noise, nu)
     rep = eng.profile_report()
     eng.profile(False)
-    assert rep["k_tpcn_reg_y" if nu > 0 else "k_pcn_reg_y"][0] == 4 and "k_pcn_reg" not in rep
+    if not os.environ.get("ASMC_PCN_AOS"):  # (the row-major fallback runs mixtures on the x-state kernel)
+        assert rep["k_tpcn_reg_y" if nu > 0 else "k_pcn_reg_y"][0] == 4 and "k_pcn_reg" not in rep
     llr, lpr, lqr = ll.copy(), lp.copy(), lq.copy()
     def step(t):
         if nu > 0:
