@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--no-flow-leg", action="store_true", help="skip the coupling-flow (configs[2]) extra leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded-extras", action="store_true", help="N > 1: also run the full-sampler extra legs")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="test rig: run the sharded code path (process group, collectives, owner layout) with the ranks at hand, "
+                         "also when that is a single rank - one GPU then shows the cost of the sharded machinery itself over RCCL")
     ap.add_argument("--shard-layout", choices=["owner", "slots"], default="owner",
                     help="N > 1: offspring stay on the ancestor's rank (default) or single-rank slot order with row exchange")
     args = ap.parse_args()
@@ -67,9 +70,14 @@ def main():
     if "ASMC_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["ASMC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
 
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -89,6 +97,10 @@ def main():
     s_bytes = 8 if args.x_dtype == "f64" else 4
     eng = HipEngine(local_rank, n_max=n_global, d_max=max(d, 32))  # the replicated exact cdf scan covers all N
     comm = default_comm(eng.device)
+    if sharded and world == 1:  # --force-sharded on one rank: the real communicator over a one-rank group
+        from aspire_amd.comm import TorchDistComm
+
+        comm = TorchDistComm(eng.device if backend == "nccl" else torch.device("cpu"))
 
     # ---- synthetic batch, resident in HBM ---------------------------------------------------
     sigma_q = 1.5
@@ -120,7 +132,7 @@ def main():
 
         # whole bisection on device: asmc_find_beta, or its sharded form (reduce -> all-gather -> decide per round)
         def search_fn(b0, target, tol):
-            if world == 1:
+            if not sharded:
                 b, _, conv, passes, n_nan, trip, trip_one = eng.find_beta(ll, lp, lq, b0, target, tol)
             else:
                 b, _, conv, passes, n_nan, trip, trip_one = smc_math.find_beta_sharded(eng, comm, ll, lp, lq, b0, target,
@@ -138,7 +150,7 @@ def main():
             st_b, st_1 = smc_math.Stats(*found["trip"], n_global), smc_math.Stats(*found["one"], n_global)
         else:
             st_b, st_1 = smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, [beta, 1.0], n_global)
-        if world > 1 and args.shard_layout == "owner":
+        if sharded and args.shard_layout == "owner":
             # offspring stay on the ancestor's rank: one all-gather (rank totals + variance partials), no row exchange
             idx, var, s1p = smc_math.resample_owner(eng, comm, ll, lp, lq, 0.0, beta, n_global, rng,
                                                     mode=args.resample_mode, st=st_b)
@@ -155,7 +167,7 @@ def main():
         return gather_global(eng, comm, idx, x, ll, lp, lq)
 
     def sync_all():
-        if world > 1:
+        if sharded:
             comm.barrier()
         torch.cuda.synchronize()
 
@@ -233,7 +245,7 @@ def main():
                    "n_steps_meaning": "temperature iterations (no mutation)", "particles_per_gpu": n_local,
                    "global_particles": n_global, "dims": d, "x_dtype": args.x_dtype, "resample_mode": args.resample_mode,
                    "resample_method": "multinomial", "beta_tolerance": 1e-6, "target_efficiency": 0.5,
-                   "parallelism": f"particle-shard x{world}" + (f" ({scal.get('layout')} layout)" if world > 1 else "")},
+                   "parallelism": f"particle-shard x{world}" + (f" ({scal.get('layout')} layout)" if sharded else "")},
         "roofline": roofline,
         "scalars": {k: (v if isinstance(v, (int, str)) else float(v)) for k, v in scal.items()},
     }
@@ -376,7 +388,7 @@ def main():
         result["cpu_baseline"]["beta_matches_gpu"] = bool(sc[0] == scal["beta"])
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
 
         dist.destroy_process_group()

@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""The collectives of the sharded path over the REAL RCCL backend with a one-rank world (a single GPU cannot host two
+RCCL ranks): device-tensor all-gathers inside the beta search, the rank-total exchange of owner-layout resampling and
+the stream-ordered accept-count all-reduce hook, each checked against the collective-free single-rank path."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from conftest import synth
+
+    from aspire_amd import smc_math
+    from aspire_amd.comm import Comm, TorchDistComm
+    from aspire_amd.engine import HipEngine
+
+    n, d = 1_000_000, 32
+    eng = HipEngine(0, n_max=n, d_max=d)
+    comm = TorchDistComm(eng.device)
+    assert not comm._stage and comm.world == 1
+    x, ll, lp, lq = synth(n, d, 3)
+    xd, lld, lpd, lqd = (eng.asarray(a) for a in (x, ll, lp, lq))
+    # 1. beta search: reduce -> all_gather_into_tensor (RCCL) -> decide, all on the stream
+    one = eng.find_beta(lld, lpd, lqd, 0.0, 0.5, 1e-6)
+    shd = smc_math.find_beta_sharded(eng, comm, lld, lpd, lqd, 0.0, 0.5, 1e-6, n)
+    assert shd[0] == one[0] and shd[2] and shd[3] == one[3], (one, shd)
+    np.testing.assert_allclose(shd[5], one[5], rtol=1e-11)
+    # 2. owner-layout resampling: one all-gather of (variance partial, rank total); same ancestors as the slot path
+    beta = one[0]
+    st = smc_math.Stats(*one[5], n)
+    idx_o, var_o, _ = smc_math.resample_owner(eng, comm, lld, lpd, lqd, 0.0, beta, n, np.random.default_rng(5), st=st)
+    var_s, s1p = smc_math.evidence_variance_and_lse(eng, Comm(), lld, lpd, lqd, 0.0, beta, st)
+    idx_s, _ = smc_math.resample_indices(eng, Comm(), lld, lpd, lqd, 0.0, beta, n, np.random.default_rng(5), st=st, s1p=s1p)
+    a, b = np.sort(idx_o.cpu().numpy()), np.sort(idx_s.cpu().numpy())
+    assert a.size == b.size == n and (a != b).sum() <= 4, (a != b).sum()
+    assert var_o == var_s
+    # 3. accept-count hook: in-place RCCL all-reduce of the device cell between a step and its adaptation
+    tgt = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    q = eng.make_mixture([-d * np.log(1.5) - 0.5 * d * np.log(2 * np.pi)], np.zeros((1, d)), np.full((1, d), 1 / 2.25))
+    mu, eye = eng.asarray(np.zeros(d)), eng.asarray(np.eye(d))
+
+    def run(hook):
+        xx = xd.clone()
+        a_, b_, c_ = eng.mixture_logpdf(xx, tgt), eng.mixture_logpdf(xx, tgt), eng.mixture_logpdf(xx, q)
+        if hook:
+            hc = TorchDistComm(eng.device)
+            hc.world = 2  # only all_reduce_sum_ is used by the hook; the sum over the one real rank is the local count
+            eng.set_count_hook(hc, n)
+        try:
+            return eng.pcn_mutate(xx, a_, b_, c_, 0.5, mu, eye, eye, tgt, tgt, q, 7, 0, 0.3, 12, 0, 0.234, True, "f32"), xx
+        finally:
+            eng.set_count_hook(None, None)
+
+    (acc0, hist0, rho0), x0 = run(False)
+    (acc1, hist1, rho1), x1 = run(True)
+    assert np.array_equal(acc0, acc1) and np.array_equal(hist0, hist1) and rho0 == rho1 and torch.equal(x0, x1)
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    print("nccl world-1 checks ok: beta*", one[0], "accept", acc1[:3].tolist())
+
+
+if __name__ == "__main__":
+    main()
