@@ -38,6 +38,11 @@ class Comm:
     def all_to_all_rows(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int]) -> torch.Tensor:
         return send
 
+    def all_gather_into(self, out: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """all_gather_tensor into a caller-owned buffer (hot loops: no allocation per call)."""
+        out.copy_(t)
+        return out
+
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
         return t
 
@@ -90,6 +95,13 @@ class TorchDistComm(Comm):
         if self._stage and t.is_cuda:
             return self.all_gather_tensor(t.cpu()).to(t.device)
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t, group=self.group)
+        return out
+
+    def all_gather_into(self, out: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        if self._stage and t.is_cuda:
+            out.copy_(self.all_gather_tensor(t.cpu()))
+            return out
         self.dist.all_gather_into_tensor(out, t, group=self.group)
         return out
 

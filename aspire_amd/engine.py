@@ -252,6 +252,20 @@ class HipEngine:
         check(self.lib.asmc_find_beta_shard_decide(self._ctx, _dptr(recs), world, n_global, beta0, target_eff, tol, rnd,
                                                    self._stream), "asmc_find_beta_shard_decide")
 
+    def find_beta_shard_rounds(self, comm, ll, lp, lq, beta0: float, target_eff: float, tol: float, n_global: int,
+                               rec: torch.Tensor, recs: torch.Tensor, first: int, last: int):
+        """Rounds first..last-1 (reduce -> all-gather -> decide) with the argument marshalling done once: the sharded
+        search is bound by the host's enqueue rate, not by the GPU."""
+        self._chk3(ll, lp, lq)
+        lib, ctx, st = self.lib, self._ctx, self._stream
+        a, b, c, r, rs = _dptr(ll), _dptr(lp), _dptr(lq), _dptr(rec), _dptr(recs)
+        n, world, gather = ll.numel(), comm.world, comm.all_gather_into
+        for rnd in range(first, last):
+            check(lib.asmc_find_beta_shard_reduce(ctx, n, a, b, c, beta0, rnd, r, st), "asmc_find_beta_shard_reduce")
+            gather(recs, rec)
+            check(lib.asmc_find_beta_shard_decide(ctx, rs, world, n_global, beta0, target_eff, tol, rnd, st),
+                  "asmc_find_beta_shard_decide")
+
     def find_beta_shard_result(self):
         out = np.zeros(13)
         check(self.lib.asmc_find_beta_shard_result(self._ctx, _f64p(out), self._stream), "asmc_find_beta_shard_result")

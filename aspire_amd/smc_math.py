@@ -331,13 +331,20 @@ def find_beta_sharded(engine, comm, ll, lp, lq, beta0: float, target_eff: float,
     import torch
 
     rounds = max(1, int(math.ceil(math.log2((1.0 - beta0) / tol) / BISECT_LEVELS - 1e-9)))
-    rec = engine.empty(40)
+    # record buffers live on the engine: the rounds are host-bound (three enqueues each), so no allocation per round
+    bufs = engine.__dict__.setdefault("_bis_bufs", {})
+    if bufs.get("world") != comm.world:
+        bufs.update(world=comm.world, rec=engine.empty(40), recs=engine.empty(40 * comm.world))
+    rec, recs = bufs["rec"], bufs["recs"]
     launched = 0
     out = None
     for _ in range(4):
+        if hasattr(engine, "find_beta_shard_rounds"):
+            engine.find_beta_shard_rounds(comm, ll, lp, lq, beta0, target_eff, tol, n_global, rec, recs, launched, rounds)
+            launched = max(launched, rounds)
         while launched < rounds:
             engine.find_beta_shard_reduce(ll, lp, lq, beta0, launched, rec)
-            recs = comm.all_gather_tensor(rec)
+            comm.all_gather_into(recs, rec)
             engine.find_beta_shard_decide(recs, comm.world, n_global, beta0, target_eff, tol, launched)
             launched += 1
         out = engine.find_beta_shard_result()
