@@ -176,11 +176,22 @@ def main():
     for _ in range(150 + args.warmup):
         is_step()
     sync_all()
+    prof = None
+    if os.environ.get("ASMC_BENCH_CPROFILE") and rank == 0:  # host-side hot spots of the step (stderr)
+        import cProfile
+
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = is_step()
     sync_all()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(18)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
         import torch.distributed as dist
