@@ -25,7 +25,7 @@ COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
-ASMC_ABI_VERSION = 5
+ASMC_ABI_VERSION = 6
 
 
 class AsmcMixture(ctypes.Structure):
@@ -105,6 +105,9 @@ SIGNATURES = {
     "asmc_weights_m2_lse": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _d, _d, _pd, _vp]),
     "asmc_find_beta": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _pd, _vp]),
     "asmc_pcn_set_count_hook": (_i, [_vp, _vp, _vp, _vp, _i64]),
+    "asmc_pcn_split_begin": (_i, [_vp, _d, _vp]),
+    "asmc_pcn_split_adapt": (_i, [_vp, _i64, _d, _i, _i, _vp]),
+    "asmc_pcn_split_end": (_i, [_vp, _i, POINTER(c_int64), _pd, _pd, _vp]),
     "asmc_student_estep": (_i, [_vp, _i64, _i, _vp, _pd, _pd, _d, _vp, _pd, _vp]),
     "asmc_student_scale": (_i, [_vp, _i64, _i, _vp, _vp, _pd, _vp, _vp]),
     "asmc_find_beta_shard_reduce": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _i, _vp, _vp]),

@@ -903,6 +903,8 @@ __global__ __launch_bounds__(1024) void k_pcn_adapt(int nblocks, const long long
     }
 }
 
+__global__ void k_set_scalar(double* __restrict__ cell, double v) { *cell = v; }
+
 __global__ __launch_bounds__(1024) void k_count_sum(int nblocks, const long long* __restrict__ block_counts,
                                                    long long* __restrict__ cell) {
     __shared__ long long s_c[16];
@@ -1854,7 +1856,7 @@ int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x
     ASMC_REQUIRE(!(nu > 0.0) || nu >= 1.0, "nu must be >= 1 (or <= 0 for the Gaussian reference)");
     ASMC_REQUIRE(n > 0 && n <= ctx->n_max && d > 0 && d <= ASMC_MAX_DIMS, "bad sizes");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
-    ASMC_REQUIRE(rho > 0.0 && rho <= 1.0, "rho must be in (0, 1]");
+    ASMC_REQUIRE(rho >= 0.0 && rho <= 1.0, "rho must be in (0, 1], or 0 for the device-resident step size");
     hipStream_t st = as_stream(stream);
     PcnDev pd;
     memset(&pd, 0, sizeof(pd));
@@ -1865,10 +1867,50 @@ int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x
     pd.seed = seed;
     pd.gid0 = gid0;
     pd.nu = nu;
-    ASMC_HIP(hipStreamSynchronize(st));
-    ctx->h_pinned[0] = rho;
-    ASMC_HIP(hipMemcpyAsync(ctx->d_rho, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, st));
+    if (rho > 0.0) {  // by kernel argument: no pinned staging, no synchronisation
+        ASMC_LAUNCH(ctx, st, "k_set_scalar", k_set_scalar, dim3(1), dim3(1), 0, st, ctx->d_rho, rho);
+        ASMC_LAUNCH_CHECK();
+    }
     return pcn_propose_launch(ctx, n, d, x_dtype, x, x_prop, qf_old, qf_new, pd, ctx->d_rho, step, st);
+}
+
+// Split path without a host round trip per step (asmc.h): the step size lives in the ctx, asmc_pcn_accept leaves its
+// count on the device, asmc_pcn_split_adapt closes the step like the fused loops do (exchange hook included).
+int asmc_pcn_split_begin(asmc_ctx* ctx, double rho0, asmc_stream stream) {
+    ASMC_REQUIRE(ctx != nullptr, "null ctx");
+    ASMC_REQUIRE(rho0 > 0.0 && rho0 <= 1.0, "rho must be in (0, 1]");
+    hipStream_t st = as_stream(stream);
+    ASMC_LAUNCH(ctx, st, "k_set_scalar", k_set_scalar, dim3(1), dim3(1), 0, st, ctx->d_rho, rho0);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_pcn_split_adapt(asmc_ctx* ctx, int64_t n_global, double target_accept, int t, int adapt, asmc_stream stream) {
+    ASMC_REQUIRE(ctx != nullptr, "null ctx");
+    ASMC_REQUIRE(n_global > 0 && t >= 0 && t < ASMC_MAX_PCN_STEPS, "bad n_global / step index");
+    hipStream_t st = as_stream(stream);
+    // the accept kernel's count cell (d_keys[0]) plays the part of a one-block partial
+    return pcn_close_step(ctx, st, 1, reinterpret_cast<const long long*>(ctx->d_keys), n_global, t, ctx->d_counts, ctx->d_rho,
+                          ctx->d_rho + 8, target_accept, adapt);
+}
+
+int asmc_pcn_split_end(asmc_ctx* ctx, int n_steps, int64_t* n_accept_host, double* rho_hist_host, double* rho_host,
+                       asmc_stream stream) {
+    ASMC_REQUIRE(ctx && n_accept_host && rho_host, "null pointer");
+    ASMC_REQUIRE(n_steps >= 1 && n_steps <= ASMC_MAX_PCN_STEPS, "n_steps out of range");
+    hipStream_t st = as_stream(stream);
+    long long* h_counts = reinterpret_cast<long long*>(ctx->h_pinned);
+    double* h_rho_hist = ctx->h_pinned + ASMC_MAX_PCN_STEPS + 8;
+    ASMC_HIP(hipStreamSynchronize(st));  // pinned staging may still be in flight
+    ASMC_HIP(hipMemcpyAsync(h_counts, ctx->d_counts, sizeof(long long) * n_steps, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipMemcpyAsync(h_rho_hist, ctx->d_rho + 8, sizeof(double) * n_steps, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8000, ctx->d_rho, sizeof(double), hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    for (int t = 0; t < n_steps; t++) n_accept_host[t] = (int64_t)h_counts[t];
+    if (rho_hist_host)
+        for (int t = 0; t < n_steps; t++) rho_hist_host[t] = h_rho_hist[t];
+    *rho_host = ctx->h_pinned[8000];
+    return ASMC_OK;
 }
 
 int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x, const void* x_prop, double* ll, double* lp,

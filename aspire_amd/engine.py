@@ -573,11 +573,29 @@ class HipEngine:
         return xp, q0, q1
 
     def pcn_accept(self, x, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0, step,
-                   logj_old=None, logj_new=None) -> int:
+                   logj_old=None, logj_new=None, want_count: bool = True):
+        """want_count=False leaves the accept count on the device (pcn_split_adapt consumes it): no synchronisation."""
         n, d = x.shape
         nacc = ctypes.c_int64(0)
         check(self.lib.asmc_pcn_accept(self._ctx, n, d, self._xdt(x), _dptr(x), _dptr(x_prop), _dptr(ll), _dptr(lp),
                                        _dptr(lq), _dptr(ll_new), _dptr(lp_new), _dptr(lq_new), _dptr(logj_old),
                                        _dptr(logj_new), _dptr(q0), _dptr(q1), beta, seed, gid0, step,
-                                       ctypes.byref(nacc), self._stream), "asmc_pcn_accept")
-        return int(nacc.value)
+                                       ctypes.byref(nacc) if want_count else None, self._stream), "asmc_pcn_accept")
+        return int(nacc.value) if want_count else None
+
+    # split path with the step size and the accept counts resident on the device (no host round trip per step)
+    def pcn_split_begin(self, rho: float):
+        check(self.lib.asmc_pcn_split_begin(self._ctx, float(rho), self._stream), "asmc_pcn_split_begin")
+
+    def pcn_split_adapt(self, n_global: int, target_accept: float, t: int, adapt: bool = True):
+        check(self.lib.asmc_pcn_split_adapt(self._ctx, int(n_global), float(target_accept), int(t), int(adapt), self._stream),
+              "asmc_pcn_split_adapt")
+
+    def pcn_split_end(self, n_steps: int):
+        """(n_accept[n_steps] (global when an exchange hook is installed), rho_hist[n_steps], rho) - synchronises."""
+        n_acc = np.zeros(n_steps, dtype=np.int64)
+        hist = np.zeros(n_steps)
+        rho = ctypes.c_double(0.0)
+        check(self.lib.asmc_pcn_split_end(self._ctx, n_steps, n_acc.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _f64p(hist),
+                                          ctypes.byref(rho), self._stream), "asmc_pcn_split_end")
+        return n_acc, hist, rho.value

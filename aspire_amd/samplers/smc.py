@@ -449,17 +449,43 @@ class HipSMC(SMCSampler):
         seed = int(self.rng.integers(0, 2**63 - 1, dtype=np.int64))
         step0 = st["step"]
         acc_rates = []
-        for t in range(n_steps):
-            z_prop, q0, q1 = e.pcn_propose(z, mu, L, Linv, st["rho"], seed, gid0, step0 + t, nu=nu)
+
+        def step(t, rho):
+            z_prop, q0, q1 = e.pcn_propose(z, mu, L, Linv, rho, seed, gid0, step0 + t, nu=nu)
             x_prop, logj_new = T.inverse(z_prop)
             x_prop, logj_new = e.asarray(x_prop, dtype=x.dtype), e.asarray(logj_new)
             lq_new = self._flow_log_prob(x_prop)
             lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
-            n_acc = e.pcn_accept(z, z_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0, step0 + t,
-                                 logj_old=logj, logj_new=logj_new)
-            tot = float(comm.all_gather_f64(np.array([float(n_acc)])).sum())
-            acc_rates.append(tot / n_global)
-            st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)
+            return z_prop, q0, q1, ll_new, lp_new, lq_new, logj_new
+
+        if hasattr(e, "pcn_split_begin"):
+            # step size and accept counts stay on the device: the host enqueues step t + 1 while step t runs
+            if comm.world > 1:
+                e.set_count_hook(comm, n_global)
+            try:
+                done = 0
+                while done < n_steps:
+                    chunk = min(n_steps - done, 2048)
+                    e.pcn_split_begin(st["rho"])
+                    for t in range(done, done + chunk):
+                        z_prop, q0, q1, ll_new, lp_new, lq_new, logj_new = step(t, 0.0)
+                        e.pcn_accept(z, z_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0, step0 + t,
+                                     logj_old=logj, logj_new=logj_new, want_count=False)
+                        e.pcn_split_adapt(n_global, target, t - done, True)
+                    n_acc, _, st["rho"] = e.pcn_split_end(chunk)
+                    acc_rates.extend((n_acc / n_global).tolist())
+                    done += chunk
+            finally:
+                if comm.world > 1:
+                    e.set_count_hook(None, None)
+        else:
+            for t in range(n_steps):
+                z_prop, q0, q1, ll_new, lp_new, lq_new, logj_new = step(t, st["rho"])
+                n_acc = e.pcn_accept(z, z_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0, step0 + t,
+                                     logj_old=logj, logj_new=logj_new)
+                tot = float(comm.all_gather_f64(np.array([float(n_acc)])).sum())
+                acc_rates.append(tot / n_global)
+                st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)
         st["step"] = step0 + n_steps
         self.history.mcmc_acceptance.append(float(np.mean(acc_rates)))
         self.history.mcmc_step_size.append(float(st["rho"]))
@@ -572,6 +598,23 @@ class HipSMC(SMCSampler):
                     acc_rates.append(tot / n_global)
                     st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)
             self.n_likelihood_evaluations += n_steps * n_local
+        elif hasattr(e, "pcn_split_begin") and on_device:
+            # arbitrary callables between propose and accept; step size and accept counts stay on the device (the exchange
+            # hook of sharded runs is already installed by the caller), so the host enqueues step t + 1 while step t runs
+            done = 0
+            while done < n_steps:
+                chunk = min(n_steps - done, 2048)
+                e.pcn_split_begin(st["rho"])
+                for t in range(done, done + chunk):
+                    x_prop, q0, q1 = e.pcn_propose(x, mu, L, Linv, 0.0, seed, gid0, step0 + t, nu=nu)
+                    lq_new = self._flow_log_prob(x_prop)
+                    lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
+                    e.pcn_accept(x, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0, step0 + t,
+                                 want_count=False)
+                    e.pcn_split_adapt(n_global, target, t - done, True)
+                n_acc, _, st["rho"] = e.pcn_split_end(chunk)
+                acc_rates.extend((n_acc / n_global).tolist())
+                done += chunk
         else:
             for t in range(n_steps):
                 x_prop, q0, q1 = e.pcn_propose(x, mu, L, Linv, st["rho"], seed, gid0, step0 + t, nu=nu)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 5
+#define ASMC_ABI_VERSION 6
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -296,6 +296,17 @@ int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x
                      const double* mu_dev, const double* L_dev, const double* Linv_dev, double rho,
                      double nu /* as asmc_pcn_params.nu; the qform outputs are then (d + nu) log(1 + |y|^2/nu) */,
                      uint64_t seed, uint64_t gid0, uint32_t step, asmc_stream stream);
+/* The split form without a host round trip per step (the host may enqueue step t + 1 while step t runs):
+ *   asmc_pcn_split_begin(rho0)                 step size into the ctx;
+ *   asmc_pcn_propose(..., rho = 0, ...)        uses the device-resident step size;
+ *   asmc_pcn_accept(..., n_accept_host = NULL) leaves the accept count on the device;
+ *   asmc_pcn_split_adapt(n_global, target, t, adapt)   closes step t: count (summed over ranks through the exchange hook
+ *                                              when one is installed) -> history, step-size adaptation, all on the stream;
+ *   asmc_pcn_split_end(n_steps, ...)           counts, step-size history and final step size to the host (synchronises). */
+int asmc_pcn_split_begin(asmc_ctx* ctx, double rho0, asmc_stream stream);
+int asmc_pcn_split_adapt(asmc_ctx* ctx, int64_t n_global, double target_accept, int t, int adapt, asmc_stream stream);
+int asmc_pcn_split_end(asmc_ctx* ctx, int n_steps, int64_t* n_accept_host, double* rho_hist_host, double* rho_host,
+                       asmc_stream stream);
 int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x_dev,
                     const void* x_prop_dev, double* ll_dev, double* lp_dev, double* lq_dev,
                     const double* ll_new_dev, const double* lp_new_dev, const double* lq_new_dev,

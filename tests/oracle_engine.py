@@ -267,21 +267,50 @@ class OracleEngine:
         assert x.dtype == torch.float64
         n = x.shape[0]
         n_acc, hist = np.zeros(n_steps, dtype=np.int64), np.zeros(n_steps)
+        hook = getattr(self, "_count_hook", None)  # sharded: counts are global and the rate is over the whole population
         for t in range(n_steps):
             hist[t] = rho
             if nu > 0.0:
-                n_acc[t] = O.tpcn_step(_np(x), _np(ll), _np(lp), _np(lq), beta, _np(mu), _np(L), _np(Linv), rho, nu,
-                                       t_ll.mix, t_lp.mix, t_lq.mix, seed, gid0, step0 + t, noise)
-                if adapt:
-                    rho = O.pcn_adapt(rho, n_acc[t] / n, target_accept, t)
-                continue
-            n_acc[t] = O.pcn_step(_np(x), _np(ll), _np(lp), _np(lq), beta, _np(mu), _np(L), _np(Linv), rho,
-                                  t_ll.mix, t_lp.mix, t_lq.mix, seed, gid0, step0 + t, noise)
+                c = O.tpcn_step(_np(x), _np(ll), _np(lp), _np(lq), beta, _np(mu), _np(L), _np(Linv), rho, nu,
+                                t_ll.mix, t_lp.mix, t_lq.mix, seed, gid0, step0 + t, noise)
+            else:
+                c = O.pcn_step(_np(x), _np(ll), _np(lp), _np(lq), beta, _np(mu), _np(L), _np(Linv), rho,
+                               t_ll.mix, t_lp.mix, t_lq.mix, seed, gid0, step0 + t, noise)
+            n_tot = n
+            if hook is not None:
+                c, n_tot = int(hook[0].all_gather_f64(np.array([float(c)])).sum()), hook[1]
+            n_acc[t] = c
             if adapt:
-                rho = O.pcn_adapt(rho, n_acc[t] / n, target_accept, t)
+                rho = O.pcn_adapt(rho, c / n_tot, target_accept, t)
         return n_acc, hist, rho
 
+    # split path with device-resident step size / counts: host-side restatement of asmc_pcn_split_{begin,adapt,end}
+    def pcn_split_begin(self, rho):
+        self._split = {"rho": float(rho), "counts": [], "hist": [], "last": 0}
+
+    def pcn_split_adapt(self, n_global, target_accept, t, adapt=True):
+        sp = self._split
+        c = sp["last"]
+        hook = getattr(self, "_count_hook", None)
+        if hook is not None:  # sharded: the global count (the product all-reduces a device cell through the exchange hook)
+            c = int(hook[0].all_gather_f64(np.array([float(c)])).sum())
+            n_global = hook[1]
+        sp["counts"].append(c)
+        sp["hist"].append(sp["rho"])
+        if adapt:
+            sp["rho"] = O.pcn_adapt(sp["rho"], c / n_global, target_accept, t)
+
+    def pcn_split_end(self, n_steps):
+        sp = self._split
+        assert len(sp["counts"]) == n_steps
+        return np.array(sp["counts"], dtype=np.int64), np.array(sp["hist"]), sp["rho"]
+
+    def set_count_hook(self, comm, n_global):
+        self._count_hook = None if (comm is None or n_global is None or comm.world == 1) else (comm, int(n_global))
+
     def pcn_propose(self, x, mu, L, Linv, rho, seed, gid0, step, nu=0.0):
+        if rho == 0.0:  # device-resident step size of the split session
+            rho = self._split["rho"]
         xn, mun, Ln, Li = _np(x).astype(np.float64), _np(mu), _np(L), _np(Linv)
         n, d = xn.shape
         y = (xn - mun) @ Li.T
@@ -299,7 +328,7 @@ class OracleEngine:
         return torch.from_numpy(xp).to(x.dtype), torch.from_numpy(q0), torch.from_numpy(q1)
 
     def pcn_accept(self, x, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0, step,
-                   logj_old=None, logj_new=None):
+                   logj_old=None, logj_new=None, want_count=True):
         n, d = x.shape
         u = np.array([O.pcn_noise(seed, gid0 + i, step, d)[1] for i in range(n)])
 
@@ -320,4 +349,7 @@ class OracleEngine:
         ll[acc_t], lp[acc_t], lq[acc_t] = ll_new[acc_t], lp_new[acc_t], lq_new[acc_t]
         if logj_old is not None and logj_new is not None:
             logj_old[acc_t] = logj_new[acc_t]
+        if not want_count:
+            self._split["last"] = int(acc.sum())
+            return None
         return int(acc.sum())
