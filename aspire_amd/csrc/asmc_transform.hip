@@ -42,11 +42,13 @@ __device__ __forceinline__ double floored_mod(double a, double b) {
 
 __device__ __forceinline__ double clip(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
-template <typename T, int VEC, int DIR>
+// DT > 0: the dimension as a compile-time constant (16-byte rows, VEC = 16): the tile copies then divide by constants and
+// the per-coordinate loop unrolls; DT = 0: any d at run time
+template <typename T, int VEC, int DIR, int DT = 0>
 __global__ __launch_bounds__(ASMC_BLOCK) void k_transform(int64_t n, const T* __restrict__ in, T* __restrict__ out,
                                                          double* __restrict__ logj, TransDev p, int waves_per_block) {
     extern __shared__ __align__(16) char smem[];
-    const int d = p.d;
+    const int d = DT > 0 ? DT : p.d;
     const int rowbytes = d * (int)sizeof(T);
     const int ldsrow = lds_row_stride(rowbytes);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_transform(int64_t n, const T* __
         if (row0 + lane < n) {
             double lj_b = 0.0;  // element terms of the bounded block
             bool any_bounded = false;
+#pragma unroll 4
             for (int j = 0; j < d; j++) {
                 double v = row_get<T>(myrow, j);
                 const int kind = p.kind[j];
@@ -136,7 +139,18 @@ static int launch_transform(asmc_ctx* ctx, int64_t n, const T* in, T* out, doubl
     const uintptr_t a = (uintptr_t)in | (uintptr_t)out;
     const int vec = (rowbytes % 16 == 0 && a % 16 == 0) ? 16 : (rowbytes % 8 == 0 && a % 8 == 0) ? 8 : 4;
     const char* label = DIR == 0 ? "k_transform_forward" : "k_transform_inverse";
-    if (vec == 16)
+    if (vec == 16 && (p.d == 8 || p.d == 16 || p.d == 32 || p.d == 64 || p.d == 128) && !getenv("ASMC_TRANSFORM_GENERIC")) {
+        switch (p.d) {
+#define TR_CASE(DD) \
+    case DD: ASMC_LAUNCH(ctx, st, label, (k_transform<T, 16, DIR, DD>), dim3(grid), dim3(wpb * 64), lds, st, n, in, out, logj, p, wpb); break;
+            TR_CASE(8)
+            TR_CASE(16)
+            TR_CASE(32)
+            TR_CASE(64)
+            TR_CASE(128)
+#undef TR_CASE
+        }
+    } else if (vec == 16)
         ASMC_LAUNCH(ctx, st, label, (k_transform<T, 16, DIR>), dim3(grid), dim3(wpb * 64), lds, st, n, in, out, logj, p, wpb);
     else if (vec == 8)
         ASMC_LAUNCH(ctx, st, label, (k_transform<T, 8, DIR>), dim3(grid), dim3(wpb * 64), lds, st, n, in, out, logj, p, wpb);

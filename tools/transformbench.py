@@ -7,8 +7,9 @@ from aspire_amd.transforms import CompositeTransform
 n, d = 1_000_000, 32
 eng = HipEngine(0, n_max=n, d_max=32)
 names = [f"x{i}" for i in range(d)]
-for kind in ("probit", "logit"):
-    T = CompositeTransform(names, prior_bounds={k: [-10.0, 10.0] for k in names}, bounded_transform=kind, engine=eng)
+for kind in ("probit", "logit", "affine-only"):
+    T = CompositeTransform(names, prior_bounds={k: [-10.0, 10.0] for k in names}, bounded_transform=kind if kind != "affine-only" else "probit",
+                           bounded_to_unbounded=kind != "affine-only", engine=eng)
     x = torch.rand((n, d), device="cuda", dtype=torch.float64) * 16 - 8
     z = T.fit(x)
     for name, fn, arg in (("forward", T.forward, x), ("inverse", T.inverse, z)):
