@@ -74,7 +74,7 @@ class AsmcCoupling(ctypes.Structure):
 class AsmcTransform(ctypes.Structure):
     _fields_ = [
         ("d", c_int32),
-        ("reserved", c_int32),
+        ("hints", c_int32),
         ("kind_dev", c_void_p),
         ("periodic_dev", c_void_p),
         ("lower_dev", c_void_p),

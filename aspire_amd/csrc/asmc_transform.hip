@@ -26,6 +26,7 @@ struct TransDev {
     double eps;
     double unit_logj;    // -sum_{bounded} log(upper - lower)      (forward sign)
     double affine_logj;  // -sum log|std|                          (forward sign)
+    int hints;           // ASMC_TR_NO_* bits
 };
 
 // numpy's floored modulo for floats (npy_divmod): the result takes the sign of the divisor
@@ -125,6 +126,122 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_transform(int64_t n, const T* __
     }
 }
 
+// One coordinate of the transform chain (shared by both kernels): returns the transformed value, adds the bounded block's
+// element term to lj_b and reports whether the coordinate belongs to that block.
+struct CoordPar {  // the table row of one coordinate, held in registers by the flat kernel
+    int kind, periodic;
+    double lo, up, mean, std;
+    double inv_w, inv_std;  // 1 / (up - lo), 1 / std (true divisions, once per thread)
+};
+// a / b from the stored reciprocal y = RN(1 / b): q0 = RN(a y), r = a - b q0 (exact in an FMA), q = RN(q0 + r y) - the
+// correctly rounded quotient (Markstein) for three FMAs instead of the ~30-instruction IEEE division sequence, whose
+// v_rcp_f64 made the forward transforms ALU-bound
+__device__ __forceinline__ double div_by(double a, double b, double y) {
+    const double q0 = a * y;
+    const double r = fma(-b, q0, a);
+    return fma(r, y, q0);
+}
+// HINTS: ASMC_TR_NO_* bits known at compile time - the branches they rule out are not even compiled (the forward kernel
+// with fmod, log, log1p and erfinv all inlined twice needed 256 VGPRs: one wave per SIMD)
+template <int DIR, int HINTS>
+__device__ __forceinline__ double transform_coord(double v, const CoordPar& c, bool affine, double eps, double& lj_b) {
+    const double half_log_2pi = 0.9189385332046727;
+    const int kind = c.kind;
+    const double lo = c.lo, up = c.up;
+    struct {
+        double eps;
+        bool mean;
+    } p = {eps, affine};
+    const struct {
+        double v;
+    } pm = {c.mean}, ps = {c.std};
+    if (DIR == 0) {
+        if (!(HINTS & ASMC_TR_NO_PERIODIC) && c.periodic) v = lo + floored_mod(v - lo, up - lo);
+        if ((HINTS & (ASMC_TR_NO_LOGIT | ASMC_TR_NO_PROBIT)) != (ASMC_TR_NO_LOGIT | ASMC_TR_NO_PROBIT) && kind != 0) {
+            double u = div_by(v - lo, up - lo, c.inv_w);
+            u = clip(u, p.eps, 1.0 - p.eps);
+            if (!(HINTS & ASMC_TR_NO_LOGIT) && ((HINTS & ASMC_TR_NO_PROBIT) || kind == 1)) {
+                const double a = log(u), b = log1p(-u);
+                v = a - b;
+                lj_b += -a - b;
+            } else {
+                v = erfinv(2.0 * u - 1.0) * 1.4142135623730951;
+                lj_b += 0.5 * (2.0 * half_log_2pi + v * v);
+            }
+        }
+        if (p.mean) v = div_by(v - pm.v, ps.v, c.inv_std);
+    } else {
+        if (p.mean) v = v * ps.v + pm.v;
+        if ((HINTS & (ASMC_TR_NO_LOGIT | ASMC_TR_NO_PROBIT)) != (ASMC_TR_NO_LOGIT | ASMC_TR_NO_PROBIT) && kind != 0) {
+            double u;
+            if (!(HINTS & ASMC_TR_NO_LOGIT) && ((HINTS & ASMC_TR_NO_PROBIT) || kind == 1)) {
+                u = 1.0 / (1.0 + exp(-v));
+                u = clip(u, p.eps, 1.0 - p.eps);
+                lj_b += log(u) + log1p(-u);
+            } else {
+                lj_b += -(0.5 * (2.0 * half_log_2pi + v * v));
+                u = 0.5 * (1.0 + erf(v / 1.4142135623730951));
+            }
+            v = (up - lo) * u + lo;
+        }
+        if (!(HINTS & ASMC_TR_NO_PERIODIC) && c.periodic) v = lo + floored_mod(v - lo, up - lo);
+    }
+    return v;
+}
+
+// Flat form for rows of TPR 16-byte pieces (TPR a power of two <= 64): one piece per thread, fully coalesced 16-byte loads
+// and stores with no LDS staging, the per-particle log-Jacobian by a butterfly over the TPR lanes of the row.  The
+// element terms are summed in butterfly order instead of coordinate order (differences ~1e-16 relative).
+template <typename T, int DIR, int HINTS>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_transform_flat(int64_t n, int tpr_log2, const uint4* __restrict__ in,
+                                                              uint4* __restrict__ out, double* __restrict__ logj, TransDev p) {
+    constexpr int EPT = 16 / (int)sizeof(T);  // elements per thread
+    const int tpr = 1 << tpr_log2;
+    const int64_t total = n << tpr_log2;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;  // a multiple of tpr: a thread keeps its coordinates
+    const int c = (int)(((int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x) & (tpr - 1));
+    CoordPar par[EPT];
+    bool any_b = false;
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const int j = c * EPT + k;
+        const double lo = p.lower[j], up = p.upper[j], sd = p.mean ? p.std[j] : 1.0;
+        par[k] = CoordPar{p.kind[j], p.periodic[j], lo, up, p.mean ? p.mean[j] : 0.0, sd, 1.0 / (up - lo), 1.0 / sd};
+        any_b |= par[k].kind != 0;
+    }
+    const bool affine = p.mean != nullptr;
+    for (int64_t e0 = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; e0 - (threadIdx.x & 63) < total; e0 += stride) {
+        const bool valid = e0 < total;  // whole waves stay in the loop for the shuffles
+        const int64_t row = e0 >> tpr_log2;
+        double lj_b = 0.0;
+        if (valid) {
+            uint4 q = in[e0];
+            T* vals = reinterpret_cast<T*>(&q);
+#pragma unroll
+            for (int k = 0; k < EPT; k++) vals[k] = (T)transform_coord<DIR, HINTS>((double)vals[k], par[k], affine, p.eps, lj_b);
+            out[e0] = q;
+        }
+        if (logj) {
+            int ab = any_b ? 1 : 0;
+            for (int o = tpr >> 1; o >= 1; o >>= 1) {
+                lj_b += __shfl_xor(lj_b, o, 64);
+                ab |= __shfl_xor(ab, o, 64);
+            }
+            if (valid && c == 0) {
+                double lj = 0.0;
+                if (DIR == 0) {
+                    if (ab) lj += lj_b + p.unit_logj;
+                    if (p.mean) lj += p.affine_logj;
+                } else {
+                    if (p.mean) lj += -p.affine_logj;
+                    if (ab) lj += lj_b + (-p.unit_logj);
+                }
+                logj[row] = lj;
+            }
+        }
+    }
+}
+
 template <typename T, int DIR>
 static int launch_transform(asmc_ctx* ctx, int64_t n, const T* in, T* out, double* logj, const TransDev& p,
                             hipStream_t st) {
@@ -139,6 +256,32 @@ static int launch_transform(asmc_ctx* ctx, int64_t n, const T* in, T* out, doubl
     const uintptr_t a = (uintptr_t)in | (uintptr_t)out;
     const int vec = (rowbytes % 16 == 0 && a % 16 == 0) ? 16 : (rowbytes % 8 == 0 && a % 8 == 0) ? 8 : 4;
     const char* label = DIR == 0 ? "k_transform_forward" : "k_transform_inverse";
+    {
+        // rows of a power-of-two number (<= 64) of 16-byte pieces: flat kernel, no LDS
+        const int pieces = rowbytes / 16;
+        if (rowbytes % 16 == 0 && a % 16 == 0 && pieces >= 1 && pieces <= 64 && (pieces & (pieces - 1)) == 0 &&
+            !getenv("ASMC_TRANSFORM_TILED")) {
+            int lg = 0;
+            while ((1 << lg) < pieces) lg++;
+            const int g = grid_for(n * pieces, ASMC_BLOCK, ctx->num_cu * 32);
+            switch (p.hints & 7) {
+#define FLAT_CASE(HH) \
+    case HH: ASMC_LAUNCH(ctx, st, label, (k_transform_flat<T, DIR, HH>), dim3(g), dim3(ASMC_BLOCK), 0, st, n, lg, (const uint4*)in, \
+                         (uint4*)out, logj, p); break;
+                FLAT_CASE(0)
+                FLAT_CASE(1)
+                FLAT_CASE(2)
+                FLAT_CASE(3)
+                FLAT_CASE(4)
+                FLAT_CASE(5)
+                FLAT_CASE(6)
+                FLAT_CASE(7)
+#undef FLAT_CASE
+            }
+            ASMC_LAUNCH_CHECK();
+            return ASMC_OK;
+        }
+    }
     if (vec == 16 && (p.d == 8 || p.d == 16 || p.d == 32 || p.d == 64 || p.d == 128) && !getenv("ASMC_TRANSFORM_GENERIC")) {
         switch (p.d) {
 #define TR_CASE(DD) \
@@ -179,6 +322,7 @@ static int run_transform(asmc_ctx* ctx, int64_t n, int x_dtype, const void* in, 
     p.eps = t->eps;
     p.unit_logj = t->unit_logj;
     p.affine_logj = t->affine_logj;
+    p.hints = t->hints;
     hipStream_t st = as_stream(stream);
     if (x_dtype == ASMC_F64)
         return dir == 0 ? launch_transform<double, 0>(ctx, n, (const double*)in, (double*)out, logj, p, st)

@@ -84,9 +84,10 @@ class DeviceTransform:
     eps: float
     unit_logj: float
     affine_logj: float
+    hints: int = 0  # ASMC_TR_NO_* bits (include/asmc.h)
 
     def c_struct(self) -> AsmcTransform:
-        return AsmcTransform(self.d, 0, self.kind.data_ptr(), self.periodic.data_ptr(), self.lower.data_ptr(),
+        return AsmcTransform(self.d, self.hints, self.kind.data_ptr(), self.periodic.data_ptr(), self.lower.data_ptr(),
                              self.upper.data_ptr(), None if self.mean is None else self.mean.data_ptr(),
                              None if self.std is None else self.std.data_ptr(), self.eps, self.unit_logj, self.affine_logj)
 
@@ -429,11 +430,13 @@ class HipEngine:
     def make_transform(self, kind, periodic, lower, upper, mean=None, std=None, eps=1e-6, unit_logj=0.0,
                        affine_logj=0.0) -> DeviceTransform:
         i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=self.device)  # noqa: E731
+        k, per = np.asarray(kind), np.asarray(periodic)
+        hints = (1 if not per.any() else 0) | (2 if not (k == 1).any() else 0) | (4 if not (k == 2).any() else 0)
         return DeviceTransform(len(kind), i32(kind), i32(periodic), self.asarray(np.asarray(lower, dtype=np.float64)),
                                self.asarray(np.asarray(upper, dtype=np.float64)),
                                None if mean is None else self.asarray(np.asarray(mean, dtype=np.float64)),
                                None if std is None else self.asarray(np.asarray(std, dtype=np.float64)), float(eps),
-                               float(unit_logj), float(affine_logj))
+                               float(unit_logj), float(affine_logj), int(hints))
 
     def _transform(self, fn, name, x: torch.Tensor, t: DeviceTransform, want_logj: bool):
         assert x.is_contiguous() and x.dim() == 2 and x.shape[1] == t.d

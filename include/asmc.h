@@ -369,9 +369,12 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, 
  * reference's scalars in FORWARD sign: unit_logj = -sum_{kind != 0} log(upper - lower),
  * affine_logj = -sum log|std| (computed by the host so that they round as the reference's do).
  * In-place operation (z_dev == x_dev) is allowed. */
+#define ASMC_TR_NO_PERIODIC 1 /* hints: what the tables do NOT contain (0 = unknown); they let the kernels compile */
+#define ASMC_TR_NO_LOGIT 2    /* the unused branches out (fmod, log / log1p / exp, erf / erfinv) */
+#define ASMC_TR_NO_PROBIT 4
 typedef struct asmc_transform {
     int32_t d;
-    int32_t reserved;
+    int32_t hints; /* ASMC_TR_NO_* bits, 0 when unknown */
     const int32_t* kind_dev;
     const int32_t* periodic_dev;
     const double* lower_dev;

@@ -17,3 +17,7 @@ for kind in ("probit", "logit", "affine-only"):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): fn(arg)
         torch.cuda.synchronize(); print(kind, name, round((time.perf_counter() - t0) / 10 * 1e3, 3), "ms")
+eng.profile(True)
+for _ in range(5):
+    T.forward(x); T.inverse(z)
+print({k: (v[0], round(v[1] * 1e3, 1)) for k, v in eng.profile_report().items()})
