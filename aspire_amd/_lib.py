@@ -25,7 +25,7 @@ COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
-ASMC_ABI_VERSION = 6
+ASMC_ABI_VERSION = 7
 
 
 class AsmcMixture(ctypes.Structure):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 6
+#define ASMC_ABI_VERSION 7
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
