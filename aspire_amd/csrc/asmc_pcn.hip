@@ -1100,6 +1100,70 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_mixture_logpdf(int64_t n, int d,
     }
 }
 
+// Flat form for rows of a power-of-two number (<= 64) of 16-byte pieces: one piece per thread, coalesced 16-byte loads with
+// no LDS, the piece's coordinates' (mu, prec) of every component in registers for the whole grid-stride loop, quadratic forms
+// completed by a butterfly over the row's lanes, log-sum-exp over the components by the row's first lane (same formula as
+// mixture_eval; the quadratic form is summed in butterfly order instead of coordinate order: ~1e-16 relative).
+template <typename T, int CMAX>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_mixture_flat(int64_t n, int d, int tpr_log2, const uint4* __restrict__ x, MixDev m,
+                                                            double* __restrict__ out) {
+    constexpr int EPT = 16 / (int)sizeof(T);
+    const int tpr = 1 << tpr_log2, C = m.C;
+    const int64_t total = n << tpr_log2;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;  // a multiple of tpr: a thread keeps its coordinates
+    const int c0 = (int)(((int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x) & (tpr - 1));
+    double mu[CMAX][EPT], pr[CMAX][EPT];
+#pragma unroll
+    for (int c = 0; c < CMAX; c++)
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            mu[c][k] = c < C ? m.mu[(size_t)c * d + c0 * EPT + k] : 0.0;
+            pr[c][k] = c < C ? m.prec[(size_t)c * d + c0 * EPT + k] : 0.0;
+        }
+    for (int64_t e0 = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; e0 - (threadIdx.x & 63) < total; e0 += stride) {
+        const bool valid = e0 < total;
+        double q[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; c++) q[c] = 0.0;
+        if (valid) {
+            const uint4 raw = x[e0];
+            const T* vals = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+            for (int c = 0; c < CMAX; c++)
+#pragma unroll
+                for (int k = 0; k < EPT; k++) {
+                    const double t = (double)vals[k] - mu[c][k];
+                    q[c] = fma(t * t, pr[c][k], q[c]);
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < CMAX; c++)
+            for (int o = tpr >> 1; o >= 1; o >>= 1) q[c] += __shfl_xor(q[c], o, 64);
+        if (valid && c0 == 0) {
+            double best = -INFINITY, terms[CMAX];
+#pragma unroll
+            for (int c = 0; c < CMAX; c++) {
+                terms[c] = c < C ? m.logw[c] - 0.5 * q[c] : -INFINITY;
+                best = fmax(best, terms[c]);
+            }
+            double r = terms[0];
+            if (C > 1) {
+                if (best == -INFINITY) {
+                    r = -INFINITY;
+                } else {
+                    double ssum = 0.0;
+#pragma unroll
+                    for (int c = 0; c < CMAX; c++)
+                        if (c < C) ssum += exp(terms[c] - best);
+                    r = best + log(ssum);
+                }
+            }
+            out[e0 >> tpr_log2] = r;
+        }
+    }
+}
+
+
 // =============================================================================================
 // population moments
 // =============================================================================================
@@ -1536,6 +1600,32 @@ int asmc_mixture_logpdf(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void
     const int grid = grid_for(n_tiles, wpb, cap);
     const int vec = pick_vec(rowbytes, x, x);
     const MixDev m = to_dev(*density);
+    {
+        const int pieces = rowbytes / 16;
+        if (rowbytes % 16 == 0 && ((uintptr_t)x % 16) == 0 && pieces >= 1 && pieces <= 64 && (pieces & (pieces - 1)) == 0 &&
+            m.C <= 4 && !getenv("ASMC_MIXTURE_TILED")) {
+            int lg = 0;
+            while ((1 << lg) < pieces) lg++;
+            const int g = grid_for(n * pieces, ASMC_BLOCK, ctx->num_cu * 32);
+            if (x_dtype == ASMC_F64) {
+                if (m.C == 1)
+                    ASMC_LAUNCH(ctx, st, "k_mixture_logpdf", (k_mixture_flat<double, 1>), dim3(g), dim3(ASMC_BLOCK), 0, st, n, d, lg,
+                                (const uint4*)x, m, out);
+                else
+                    ASMC_LAUNCH(ctx, st, "k_mixture_logpdf", (k_mixture_flat<double, 4>), dim3(g), dim3(ASMC_BLOCK), 0, st, n, d, lg,
+                                (const uint4*)x, m, out);
+            } else {
+                if (m.C == 1)
+                    ASMC_LAUNCH(ctx, st, "k_mixture_logpdf", (k_mixture_flat<float, 1>), dim3(g), dim3(ASMC_BLOCK), 0, st, n, d, lg,
+                                (const uint4*)x, m, out);
+                else
+                    ASMC_LAUNCH(ctx, st, "k_mixture_logpdf", (k_mixture_flat<float, 4>), dim3(g), dim3(ASMC_BLOCK), 0, st, n, d, lg,
+                                (const uint4*)x, m, out);
+            }
+            ASMC_LAUNCH_CHECK();
+            return ASMC_OK;
+        }
+    }
     auto launch = [&](auto kern, auto xp) {
         if (lds_bytes > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
