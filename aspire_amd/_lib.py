@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ASMC_LIB_PATH") or os.path.join(_HERE, "libasmc_hip.so")
 
 ASMC_OK = 0
+ASMC_ERR_UNSUPPORTED = -4
 ASMC_F64, ASMC_F32 = 0, 1
 ASMC_CDF_EXACT, ASMC_CDF_FAST = 0, 1
 ASMC_CDF_NORMALIZE = 0x100
@@ -25,7 +26,7 @@ COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
-ASMC_ABI_VERSION = 7
+ASMC_ABI_VERSION = 8
 
 
 class AsmcMixture(ctypes.Structure):
@@ -105,6 +106,10 @@ SIGNATURES = {
     "asmc_weights_m2_lse": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _d, _d, _pd, _vp]),
     "asmc_find_beta": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _pd, _vp]),
     "asmc_pcn_set_count_hook": (_i, [_vp, _vp, _vp, _vp, _i64]),
+    "asmc_pcn_ysplit_begin": (_i, [_vp, _i64, _vp, POINTER(AsmcPcnParams), _d, _vp]),
+    "asmc_pcn_ysplit_propose": (_i, [_vp, _i64, POINTER(AsmcPcnParams), _u32, _vp, _vp]),
+    "asmc_pcn_ysplit_accept": (_i, [_vp, _i64, POINTER(AsmcPcnParams), _u32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "asmc_pcn_ysplit_end": (_i, [_vp, _i64, _vp, POINTER(AsmcPcnParams), _vp]),
     "asmc_pcn_split_begin": (_i, [_vp, _d, _vp]),
     "asmc_pcn_split_adapt": (_i, [_vp, _i64, _d, _i, _i, _vp]),
     "asmc_pcn_split_end": (_i, [_vp, _i, POINTER(c_int64), _pd, _pd, _vp]),

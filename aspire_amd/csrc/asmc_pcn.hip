@@ -711,6 +711,8 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
 #define PCN_FLOW_ACCEPT 1
 #define PCN_FLOW_PROPOSE_S 2  // the same with y coordinate-major in p.ys (see PCN_*_S above): propose stages only x'
 #define PCN_FLOW_ACCEPT_S 3   // through LDS, accept touches no LDS at all
+#define PCN_FLOW_PROPOSE_SX 4 // PCN_FLOW_PROPOSE_S without the built-in densities: the proposal half of the whitened-state
+                              // split session, whose densities come from the caller (arbitrary Python callables)
 
 template <typename T, int D, int NOISE, int MODE>
 __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
@@ -720,7 +722,8 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
     long long* __restrict__ block_counts) {
     extern __shared__ __align__(16) char smem[];
     constexpr bool SOA = MODE >= PCN_FLOW_PROPOSE_S;
-    constexpr int M = SOA ? MODE - PCN_FLOW_PROPOSE_S : MODE;
+    constexpr bool NO_DENS = MODE == PCN_FLOW_PROPOSE_SX;
+    constexpr int M = NO_DENS ? PCN_FLOW_PROPOSE : SOA ? MODE - PCN_FLOW_PROPOSE_S : MODE;
     constexpr int ROWB = D * (int)sizeof(T);
     constexpr int LDSROW = ROWB + 16;
     const int WPB = (int)(blockDim.x >> 6);
@@ -802,8 +805,10 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
                 tri_matvec_inplace<D>(Lp, v);
 #pragma unroll
                 for (int j = 0; j < D; j++) v[j] = (double)(T)(mup[j] + v[j]);
-                ll_new[i] = mixture_eval_regs<D>(mll, v);
-                lp_new[i] = mixture_eval_regs<D>(mlp, v);
+                if (!NO_DENS) {
+                    ll_new[i] = mixture_eval_regs<D>(mll, v);
+                    lp_new[i] = mixture_eval_regs<D>(mlp, v);
+                }
                 regs_to_row<T, D>(myrow, v);
                 acc = true;
             } else {
@@ -1443,7 +1448,7 @@ static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
-    ASMC_LAUNCH(ctx, st, (MODE == PCN_FLOW_PROPOSE || MODE == PCN_FLOW_PROPOSE_S) ? "k_pcn_flow_propose" : "k_pcn_flow_accept", kern, dim3((int)grid64),
+    ASMC_LAUNCH(ctx, st, (MODE == PCN_FLOW_PROPOSE || MODE == PCN_FLOW_PROPOSE_S || MODE == PCN_FLOW_PROPOSE_SX) ? "k_pcn_flow_propose" : "k_pcn_flow_accept", kern, dim3((int)grid64),
                 dim3(wpb * 64), lds_bytes, st, n, y, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, (const double*)ctx->d_ptab, ps,
                 rho_ptr, step, block_counts);
     ASMC_LAUNCH_CHECK();
@@ -2001,6 +2006,123 @@ int asmc_pcn_split_end(asmc_ctx* ctx, int n_steps, int64_t* n_accept_host, doubl
         for (int t = 0; t < n_steps; t++) rho_hist_host[t] = h_rho_hist[t];
     *rho_host = ctx->h_pinned[8000];
     return ASMC_OK;
+}
+
+// ---- whitened-state session of the split path (asmc.h) -----------------------------------------------------------------
+static int ysplit_pd(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm, PcnDev& pd) {
+    ASMC_REQUIRE(ctx && prm, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+    ASMC_REQUIRE(prm->x_dtype == ASMC_F64 || prm->x_dtype == ASMC_F32, "bad x_dtype");
+    ASMC_REQUIRE(prm->mu_dev && prm->L_dev && prm->Linv_dev, "null reference pointer");
+    ASMC_REQUIRE(!(prm->nu > 0.0) || prm->nu >= 1.0, "nu must be >= 1 (or <= 0 for the Gaussian reference)");
+    memset(&pd, 0, sizeof(pd));
+    pd.d = prm->d;
+    pd.beta = prm->beta;
+    pd.mu = prm->mu_dev;
+    pd.L = prm->L_dev;
+    pd.Linv = prm->Linv_dev;
+    pd.seed = prm->seed;
+    pd.gid0 = prm->gid0;
+    pd.nu = prm->nu;
+    pd.noise = ASMC_NOISE_F64;  // the split path's noise is the parity mode's (as asmc_pcn_propose)
+    return ASMC_OK;
+}
+
+int asmc_pcn_ysplit_begin(asmc_ctx* ctx, int64_t n, const void* x, const asmc_pcn_params* prm, double rho0,
+                          asmc_stream stream) {
+    PcnDev pd;
+    int rc = ysplit_pd(ctx, n, prm, pd);
+    if (rc) return rc;
+    ASMC_REQUIRE(x != nullptr, "null pointer");
+    ASMC_REQUIRE(rho0 > 0.0 && rho0 <= 1.0, "rho must be in (0, 1]");
+    hipStream_t st = as_stream(stream);
+    if (!pcn_reg_supported(pd.d, prm->x_dtype == ASMC_F64 ? 8 : 4, x) || !pcn_ensure_ysoa(ctx, n, pd.d, prm->x_dtype, pd, st)) {
+        asmc_set_error("whitened-state split session: d=%d is not a register-kernel dimension or no scratch", pd.d);
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    ASMC_LAUNCH(ctx, st, "k_set_scalar", k_set_scalar, dim3(1), dim3(1), 0, st, ctx->d_rho, rho0);
+    ASMC_LAUNCH_CHECK();
+    rc = pack_pcn_tables(ctx, pd, st);
+    if (rc) return rc;
+    pd.mode = PCN_WHITEN_S;
+    int grid = 0;
+    long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
+    if (prm->x_dtype == ASMC_F64)
+        return launch_pcn_step<double, 0>(ctx, n, (double*)const_cast<void*>(x), nullptr, nullptr, nullptr, pd, ctx->d_rho, 0, d_block,
+                                          &grid, nullptr, nullptr, nullptr, st);
+    return launch_pcn_step<float, 0>(ctx, n, (float*)const_cast<void*>(x), nullptr, nullptr, nullptr, pd, ctx->d_rho, 0, d_block, &grid,
+                                     nullptr, nullptr, nullptr, st);
+}
+
+int asmc_pcn_ysplit_propose(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm, uint32_t step, void* x_prop,
+                            asmc_stream stream) {
+    PcnDev pd;
+    int rc = ysplit_pd(ctx, n, prm, pd);
+    if (rc) return rc;
+    ASMC_REQUIRE(x_prop != nullptr && ((uintptr_t)x_prop % 16) == 0, "x_prop must be a 16-byte aligned device buffer");
+    ASMC_REQUIRE(ctx->d_ysoa != nullptr, "no session (asmc_pcn_ysplit_begin)");
+    hipStream_t st = as_stream(stream);
+    pd.ys = ctx->d_ysoa;
+    pd.n_pad = ((n + 63) / 64) * 64;
+    rc = pack_pcn_tables(ctx, pd, st);  // (the caller's densities run between the calls of a session: do not rely on the
+    if (rc) return rc;                  // packed tables surviving them)
+    rc = pcn_prepare_gamma(ctx, n, pd, step, st);
+    if (rc) return rc;
+    int grid = 0;
+    long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
+    if (prm->x_dtype == ASMC_F64)
+        return dispatch_pcn_reg_flow<double, PCN_FLOW_PROPOSE_SX>(ctx, n, nullptr, (double*)x_prop, nullptr, nullptr, nullptr, nullptr,
+                                                                  nullptr, nullptr, pd, ctx->d_rho, step, d_block, &grid, st);
+    return dispatch_pcn_reg_flow<float, PCN_FLOW_PROPOSE_SX>(ctx, n, nullptr, (float*)x_prop, nullptr, nullptr, nullptr, nullptr,
+                                                             nullptr, nullptr, pd, ctx->d_rho, step, d_block, &grid, st);
+}
+
+int asmc_pcn_ysplit_accept(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm, uint32_t step, double* ll, double* lp,
+                           double* lq, const double* ll_new, const double* lp_new, const double* lq_new, int64_t n_global,
+                           int t, asmc_stream stream) {
+    PcnDev pd;
+    int rc = ysplit_pd(ctx, n, prm, pd);
+    if (rc) return rc;
+    ASMC_REQUIRE(ll && lp && lq && ll_new && lp_new && lq_new, "null pointer");
+    ASMC_REQUIRE(ctx->d_ysoa != nullptr, "no session (asmc_pcn_ysplit_begin)");
+    ASMC_REQUIRE(n_global > 0 && t >= 0 && t < ASMC_MAX_PCN_STEPS, "bad n_global / step index");
+    hipStream_t st = as_stream(stream);
+    pd.ys = ctx->d_ysoa;
+    pd.n_pad = ((n + 63) / 64) * 64;
+    pd.gam = pd.nu > 0.0 ? ctx->d_gamma : nullptr;  // the variates asmc_pcn_ysplit_propose drew for this step
+    int grid = 0;
+    long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
+    if (prm->x_dtype == ASMC_F64)
+        rc = dispatch_pcn_reg_flow<double, PCN_FLOW_ACCEPT_S>(ctx, n, nullptr, nullptr, ll, lp, lq, const_cast<double*>(ll_new),
+                                                              const_cast<double*>(lp_new), lq_new, pd, ctx->d_rho, step, d_block,
+                                                              &grid, st);
+    else
+        rc = dispatch_pcn_reg_flow<float, PCN_FLOW_ACCEPT_S>(ctx, n, nullptr, nullptr, ll, lp, lq, const_cast<double*>(ll_new),
+                                                             const_cast<double*>(lp_new), lq_new, pd, ctx->d_rho, step, d_block,
+                                                             &grid, st);
+    if (rc) return rc;
+    return pcn_close_step(ctx, st, grid, d_block, n_global, t, ctx->d_counts, ctx->d_rho, ctx->d_rho + 8, prm->target_accept,
+                          prm->adapt);
+}
+
+int asmc_pcn_ysplit_end(asmc_ctx* ctx, int64_t n, void* x, const asmc_pcn_params* prm, asmc_stream stream) {
+    PcnDev pd;
+    int rc = ysplit_pd(ctx, n, prm, pd);
+    if (rc) return rc;
+    ASMC_REQUIRE(x != nullptr && ctx->d_ysoa != nullptr, "null pointer / no session");
+    hipStream_t st = as_stream(stream);
+    pd.ys = ctx->d_ysoa;
+    pd.n_pad = ((n + 63) / 64) * 64;
+    pd.mode = PCN_UNWHITEN_XS;
+    rc = pack_pcn_tables(ctx, pd, st);
+    if (rc) return rc;
+    int grid = 0;
+    long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
+    if (prm->x_dtype == ASMC_F64)
+        return launch_pcn_step<double, 0>(ctx, n, (double*)x, nullptr, nullptr, nullptr, pd, ctx->d_rho, 0, d_block, &grid, nullptr,
+                                          nullptr, nullptr, st);
+    return launch_pcn_step<float, 0>(ctx, n, (float*)x, nullptr, nullptr, nullptr, pd, ctx->d_rho, 0, d_block, &grid, nullptr, nullptr,
+                                     nullptr, st);
 }
 
 int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x, const void* x_prop, double* ll, double* lp,

@@ -586,6 +586,40 @@ class HipEngine:
                                        ctypes.byref(nacc) if want_count else None, self._stream), "asmc_pcn_accept")
         return int(nacc.value) if want_count else None
 
+    # whitened-state session of the split path: y = L^-1 (x - mu) stays coordinate-major in the context between the calls
+    def pcn_ysplit_begin(self, x, beta, mu, L, Linv, seed, gid0, rho, target_accept=0.234, adapt=True, nu=0.0):
+        """Opens a session on x (left untouched until pcn_ysplit_end) and returns its handle, or None when the dimension has
+        no whitened-state kernels (the caller then uses pcn_propose / pcn_accept)."""
+        n, d = x.shape
+        prm = AsmcPcnParams(d, self._xdt(x), beta, mu.data_ptr(), L.data_ptr(), Linv.data_ptr(), AsmcMixture(), AsmcMixture(),
+                            AsmcMixture(), seed, gid0, target_accept, int(adapt), 0, float(nu))
+        rc = self.lib.asmc_pcn_ysplit_begin(self._ctx, n, _dptr(x), ctypes.byref(prm), float(rho), self._stream)
+        if rc == _lib.ASMC_ERR_UNSUPPORTED:
+            return None
+        check(rc, "asmc_pcn_ysplit_begin")
+        return {"prm": prm, "x": x, "keep": (mu, L, Linv)}
+
+    def pcn_ysplit_propose(self, sess, step: int):
+        x = sess["x"]
+        xp = torch.empty_like(x)
+        check(self.lib.asmc_pcn_ysplit_propose(self._ctx, x.shape[0], ctypes.byref(sess["prm"]), step, _dptr(xp), self._stream),
+              "asmc_pcn_ysplit_propose")
+        return xp
+
+    def pcn_ysplit_accept(self, sess, step: int, ll, lp, lq, ll_new, lp_new, lq_new, n_global: int, t: int):
+        self._chk3(ll, lp, lq)
+        ll_new, lp_new, lq_new = (v.to(torch.float64).contiguous() for v in (ll_new, lp_new, lq_new))
+        check(self.lib.asmc_pcn_ysplit_accept(self._ctx, sess["x"].shape[0], ctypes.byref(sess["prm"]), step, _dptr(ll), _dptr(lp),
+                                              _dptr(lq), _dptr(ll_new), _dptr(lp_new), _dptr(lq_new), int(n_global), int(t),
+                                              self._stream), "asmc_pcn_ysplit_accept")
+
+    def pcn_ysplit_end(self, sess, n_steps: int):
+        """Writes the chain state back into the session's x; returns what pcn_split_end returns."""
+        x = sess["x"]
+        check(self.lib.asmc_pcn_ysplit_end(self._ctx, x.shape[0], _dptr(x), ctypes.byref(sess["prm"]), self._stream),
+              "asmc_pcn_ysplit_end")
+        return self.pcn_split_end(n_steps)
+
     # split path with the step size and the accept counts resident on the device (no host round trip per step)
     def pcn_split_begin(self, rho: float):
         check(self.lib.asmc_pcn_split_begin(self._ctx, float(rho), self._stream), "asmc_pcn_split_begin")

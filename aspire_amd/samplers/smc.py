@@ -602,6 +602,21 @@ class HipSMC(SMCSampler):
             # arbitrary callables between propose and accept; step size and accept counts stay on the device (the exchange
             # hook of sharded runs is already installed by the caller), so the host enqueues step t + 1 while step t runs
             done = 0
+            while done < n_steps and hasattr(e, "pcn_ysplit_begin"):
+                # whitened-state session (d = 4, 8, 16, 32): the chain state stays coordinate-major on the device, a step is
+                # one mat-vec in the propose kernel and an LDS-free accept kernel
+                chunk = min(n_steps - done, 2048)
+                sess = e.pcn_ysplit_begin(x, beta, mu, L, Linv, seed, gid0, st["rho"], target, True, nu)
+                if sess is None:
+                    break
+                for t in range(done, done + chunk):
+                    x_prop = e.pcn_ysplit_propose(sess, step0 + t)
+                    lq_new = self._flow_log_prob(x_prop)
+                    lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
+                    e.pcn_ysplit_accept(sess, step0 + t, ll, lp, lq, ll_new, lp_new, lq_new, n_global, t - done)
+                n_acc, _, st["rho"] = e.pcn_ysplit_end(sess, chunk)
+                acc_rates.extend((n_acc / n_global).tolist())
+                done += chunk
             while done < n_steps:
                 chunk = min(n_steps - done, 2048)
                 e.pcn_split_begin(st["rho"])

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 7
+#define ASMC_ABI_VERSION 8
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -307,6 +307,25 @@ int asmc_pcn_split_begin(asmc_ctx* ctx, double rho0, asmc_stream stream);
 int asmc_pcn_split_adapt(asmc_ctx* ctx, int64_t n_global, double target_accept, int t, int adapt, asmc_stream stream);
 int asmc_pcn_split_end(asmc_ctx* ctx, int n_steps, int64_t* n_accept_host, double* rho_hist_host, double* rho_host,
                        asmc_stream stream);
+/* Whitened-state session of the split form (d in {4, 8, 16, 32}; otherwise ASMC_ERR_UNSUPPORTED and the caller uses
+ * asmc_pcn_propose / asmc_pcn_accept): the chain state is kept as y = L^-1 (x - mu), coordinate-major, in the context for
+ * the length of the mutation, so a step needs one mat-vec and no LDS staging of the state.
+ *   asmc_pcn_ysplit_begin    x -> y (x_dev is not modified), step size rho0 into the ctx;
+ *   asmc_pcn_ysplit_propose  y' = sqrt(1 - rho^2) y + rho sqrt(s) xi (not stored), x' = mu + L y' -> x_prop_dev [n, d];
+ *   (caller)                 log_q, log_prior, log_likelihood at x_prop (Python callables, flows, ...);
+ *   asmc_pcn_ysplit_accept   regenerates y' from the same counters, accepts (y <- y', carried log-probabilities updated) and
+ *                            closes step t like asmc_pcn_split_adapt (count exchange hook, history, adaptation);
+ *   asmc_pcn_ysplit_end      y -> x_dev;  asmc_pcn_split_end then returns counts, step-size history and final step size.
+ * params: d, x_dtype, beta, mu / L / Linv, seed, gid0, target_accept, adapt, nu are used; the mixtures are ignored; the
+ * noise is the parity mode's (fp64 Box-Muller), as in asmc_pcn_propose. */
+int asmc_pcn_ysplit_begin(asmc_ctx* ctx, int64_t n, const void* x_dev, const asmc_pcn_params* params, double rho0,
+                          asmc_stream stream);
+int asmc_pcn_ysplit_propose(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* params, uint32_t step, void* x_prop_dev,
+                            asmc_stream stream);
+int asmc_pcn_ysplit_accept(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* params, uint32_t step, double* ll_dev,
+                           double* lp_dev, double* lq_dev, const double* ll_new_dev, const double* lp_new_dev,
+                           const double* lq_new_dev, int64_t n_global, int t, asmc_stream stream);
+int asmc_pcn_ysplit_end(asmc_ctx* ctx, int64_t n, void* x_dev, const asmc_pcn_params* params, asmc_stream stream);
 int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x_dev,
                     const void* x_prop_dev, double* ll_dev, double* lp_dev, double* lq_dev,
                     const double* ll_new_dev, const double* lp_new_dev, const double* lq_new_dev,

@@ -327,6 +327,58 @@ class OracleEngine:
             q0, q1 = 2.0 * O.tpcn_corr(q0, d, nu), 2.0 * O.tpcn_corr(q1, d, nu)
         return torch.from_numpy(xp).to(x.dtype), torch.from_numpy(q0), torch.from_numpy(q1)
 
+    # whitened-state session of the split path: host-side restatement of asmc_pcn_ysplit_{begin,propose,accept,end}
+    def pcn_ysplit_begin(self, x, beta, mu, L, Linv, seed, gid0, rho, target_accept=0.234, adapt=True, nu=0.0):
+        n, d = x.shape
+        if d not in (4, 8, 16, 32):
+            return None
+        self.pcn_split_begin(rho)
+        npdt = np.float64 if x.dtype == torch.float64 else np.float32
+        y = ((_np(x).astype(np.float64) - _np(mu)) @ _np(Linv).T).astype(npdt).astype(np.float64)
+        return {"x": x, "y": y, "beta": beta, "mu": _np(mu), "L": _np(L), "seed": seed, "gid0": gid0, "target": target_accept,
+                "adapt": adapt, "nu": nu, "npdt": npdt, "prop": None}
+
+    def pcn_ysplit_propose(self, sess, step):
+        y, nu, seed, gid0 = sess["y"], sess["nu"], sess["seed"], sess["gid0"]
+        rho = self._split["rho"]
+        n, d = y.shape
+        xi = np.stack([O.pcn_noise(seed, gid0 + i, step, d)[0] for i in range(n)])
+        q0 = (y * y).sum(1)
+        rs = np.full(n, rho)
+        if nu > 0.0:
+            g = np.array([O.gamma_unit(0.5 * (d + nu), seed, gid0 + i, step) for i in range(n)])
+            rs = rho * np.sqrt((nu + q0) / (2.0 * g))
+        yp = (np.sqrt(1 - rho * rho) * y + rs[:, None] * xi).astype(sess["npdt"]).astype(np.float64)
+        sess["prop"] = (step, yp, q0, (yp * yp).sum(1))
+        xp = (sess["mu"] + yp @ sess["L"].T).astype(sess["npdt"])
+        return torch.from_numpy(xp)
+
+    def pcn_ysplit_accept(self, sess, step, ll, lp, lq, ll_new, lp_new, lq_new, n_global, t):
+        pstep, yp, q0, q1 = sess["prop"]
+        assert pstep == step
+        beta, nu, d = sess["beta"], sess["nu"], yp.shape[1]
+        n = yp.shape[0]
+        u = np.array([O.pcn_noise(sess["seed"], sess["gid0"] + i, step, d)[1] for i in range(n)])
+
+        def lpt(a, b, c):
+            with np.errstate(all="ignore"):
+                r = (1 - beta) * _np(c) + beta * (_np(a) + _np(b))
+            return np.where(np.isnan(r), -np.inf, r)
+
+        c0, c1 = (O.tpcn_corr(q0, d, nu), O.tpcn_corr(q1, d, nu)) if nu > 0.0 else (0.5 * q0, 0.5 * q1)
+        with np.errstate(all="ignore"):
+            acc = np.log(u) < (lpt(ll_new, lp_new, lq_new) + c1) - (lpt(ll, lp, lq) + c0)
+        sess["y"][acc] = yp[acc]
+        acc_t = torch.from_numpy(acc)
+        ll[acc_t], lp[acc_t], lq[acc_t] = ll_new[acc_t], lp_new[acc_t], lq_new[acc_t]
+        self._split["last"] = int(acc.sum())
+        self.pcn_split_adapt(n_global, sess["target"], t, sess["adapt"])
+
+    def pcn_ysplit_end(self, sess, n_steps):
+        xs = (sess["mu"] + sess["y"] @ sess["L"].T).astype(sess["npdt"])
+        sess["x"].copy_(torch.from_numpy(xs))
+        return self.pcn_split_end(n_steps)
+
     def pcn_accept(self, x, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0, step,
                    logj_old=None, logj_new=None, want_count=True):
         n, d = x.shape

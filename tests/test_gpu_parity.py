@@ -511,6 +511,82 @@ def test_pcn_split_path_equals_fused(eng, oracle):
         torch.testing.assert_close(u[same], v[same], rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("d,nu,dtype", [(8, 0.0, torch.float64), (32, 0.0, torch.float64), (4, 5.0, torch.float64),
+                                        (16, 7.5, torch.float64), (32, 0.0, torch.float32)])
+def test_pcn_ysplit_session_equals_fused(eng, oracle, d, nu, dtype):
+    """Whitened-state split session (propose -> caller's densities -> accept, state coordinate-major in the ctx) == the fused
+    whitened-state step loop on the same counters: same proposals bit for bit, decisions identical off a razor edge."""
+    n, steps = 3000, 3
+    x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 300 + d)
+    om = [oracle.Mixture(*m) for m in mixes]
+    dm = [eng.make_mixture(*m) for m in mixes]
+    ll, lp, lq = (m.logpdf(x) for m in om)
+    a = [eng.asarray(x).to(dtype)] + list(dev(eng, ll, lp, lq))
+    b = [eng.asarray(x).to(dtype)] + list(dev(eng, ll, lp, lq))
+    mud, Ld, Lid = dev(eng, mu, L, Linv)
+    n_acc, _, _ = eng.pcn_mutate(*a, 0.6, mud, Ld, Lid, dm[0], dm[1], dm[2], 5, 17, 0.3, steps, 4, 0.234, False, "f64", nu)
+    sess = eng.pcn_ysplit_begin(b[0], 0.6, mud, Ld, Lid, 5, 17, 0.3, 0.234, False, nu)
+    assert sess is not None
+    x_before = b[0].clone()
+    for t in range(steps):
+        xp = eng.pcn_ysplit_propose(sess, 4 + t)
+        lln, lpn, lqn = (eng.mixture_logpdf(xp, m) for m in dm)
+        eng.pcn_ysplit_accept(sess, 4 + t, b[1], b[2], b[3], lln, lpn, lqn, n, t)
+    assert torch.equal(b[0], x_before)  # the session owns the state until it ends
+    nb, hist, rho = eng.pcn_ysplit_end(sess, steps)
+    assert rho == 0.3 and np.all(hist == 0.3)
+    assert np.all(np.abs(nb - n_acc) <= 2)
+    tol = 1e-12 if dtype == torch.float64 else 2e-6
+    close = ((a[0] - b[0]).abs() <= tol * (1 + a[0].abs())).all(dim=1)
+    assert int((~close).sum()) <= 3
+    # (fp32 storage: the split form evaluates the densities at the stored, fp32-rounded x'; the fused loop at the fp64 registers)
+    lt = 1e-11 if dtype == torch.float64 else 1e-5
+    for u, v in zip(a[1:], b[1:]):
+        torch.testing.assert_close(u[close], v[close], rtol=lt, atol=lt)
+
+
+@pytest.mark.parametrize("d,nu", [(4, 0.0), (8, 6.0)])
+def test_pcn_ysplit_session_vs_test_double(eng, oracle, d, nu):
+    """... and == the host restatement the CPU suite runs the sampler on (adaptation included)."""
+    from oracle_engine import OracleEngine
+
+    n, steps = 400, 4
+    x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 350 + d)
+    om = [oracle.Mixture(*m) for m in mixes]
+    ll, lp, lq = (m.logpdf(x) for m in om)
+    ref = OracleEngine()
+    out = []
+    for e in (eng, ref):
+        st = [e.asarray(np.array(v)) for v in (x, ll, lp, lq)]
+        sess = e.pcn_ysplit_begin(st[0], 0.7, e.asarray(mu), e.asarray(L), e.asarray(Linv), 9, 1 << 40, 0.4, 0.234, True, nu)
+        for t in range(steps):
+            xp = e.pcn_ysplit_propose(sess, t)
+            new = [e.asarray(m.logpdf(xp.cpu().numpy().astype(np.float64))) for m in om]
+            e.pcn_ysplit_accept(sess, t, st[1], st[2], st[3], *new, n, t)
+        n_acc, hist, rho = e.pcn_ysplit_end(sess, steps)
+        out.append(([v.cpu().numpy() for v in st], n_acc, hist, rho))
+    (sa, na, ha, ra), (sb, nb, hb, rb) = out
+    np.testing.assert_array_equal(na, nb)
+    np.testing.assert_allclose(ha, hb, rtol=1e-14)
+    assert abs(ra - rb) < 1e-14
+    for u, v in zip(sa, sb):
+        np.testing.assert_allclose(u, v, rtol=1e-10, atol=1e-10)
+
+
+def test_pcn_ysplit_unsupported_dimension_and_errors(eng):
+    from aspire_amd._lib import AsmcError
+
+    x, mu, L, Linv, _ = _pcn_setup(eng, 100, 6, 3)
+    xd, mud, Ld, Lid = dev(eng, x, mu, L, Linv)
+    assert eng.pcn_ysplit_begin(xd, 0.5, mud, Ld, Lid, 1, 0, 0.3) is None
+    x, mu, L, Linv, _ = _pcn_setup(eng, 100, 8, 3)
+    xd, mud, Ld, Lid = dev(eng, x, mu, L, Linv)
+    with pytest.raises(AsmcError):
+        eng.pcn_ysplit_begin(xd, 0.5, mud, Ld, Lid, 1, 0, 1.5)
+    with pytest.raises(AsmcError):
+        eng.pcn_ysplit_begin(xd, 0.5, mud, Ld, Lid, 1, 0, 0.3, nu=0.5)
+
+
 def test_pcn_leaves_gaussian_target_invariant(eng):
     """Stationarity: particles ~ N(0, 1/2 I) stay N(0, 1/2 I) under many pCN steps at beta=1
     (ll = lp = -|x|^2/2), with the reference Gaussian deliberately mis-specified."""
