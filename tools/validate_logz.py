@@ -25,10 +25,15 @@ def closed_form_config5(d):
     return np.logaddexp(a, b) + np.log(0.5)
 
 
-def case(name, d, lik, prior, flow_fn, true, **kw):
+only = [c for c in os.environ.get("CASES", "").split(",") if c]
+
+
+def case(name, d, lik, prior, flow_fn, true, xp=np, **kw):
+    if only and not any(c in name for c in only):
+        return
     z, walls = [], []
     for s in range(seeds):
-        sp = HipSMC(log_likelihood=lik, log_prior=prior, dims=d, prior_flow=flow_fn(s), xp=np, engine=eng,
+        sp = HipSMC(log_likelihood=lik, log_prior=prior, dims=d, prior_flow=flow_fn(s), xp=xp, engine=eng,
                     rng=np.random.default_rng(100 + s))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -47,6 +52,11 @@ true32 = 0.5 * d * np.log(np.pi)
 gauss = lambda s: GaussianFlow(d, sigma=1.5, seed=s, engine=eng)  # noqa: E731
 case("config 2/3 shape, pcn", d, lik, lik, gauss, true32, step_fn="pcn")
 case("config 2/3 shape, tpcn", d, lik, lik, gauss, true32)
+
+# arbitrary callables (torch namespace): the split path, whitened-state session for d = 32
+tlik = lambda smp: -0.5 * (smp.x * smp.x).sum(1)  # noqa: E731
+case("callables, pcn", d, tlik, tlik, gauss, true32, xp=torch, step_fn="pcn")
+case("callables, tpcn", d, tlik, tlik, gauss, true32, xp=torch)
 
 
 def trained_flow(s):
