@@ -195,6 +195,8 @@ class CouplingFlow(Flow):
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(seed)
         self._packed, self._version = None, 0  # device pack cache; bumped whenever the parameters change
+        self._init_args = dict(dims=int(dims), n_layers=int(n_layers), hidden_features=[int(h) for h in hidden_features],
+                               seed=int(seed), dtype=str(dtype).replace("torch.", ""))
 
     def export_layers(self):
         """(weights, biases): fp32 numpy arrays, three dense layers per coupling layer, torch Linear layout."""
@@ -326,6 +328,43 @@ class CouplingFlow(Flow):
     @torch.no_grad()
     def forward(self, x, xp=None):
         return self._to_latent(torch.as_tensor(x, dtype=self.dtype, device=self.device))
+
+    # flows/torch/flows.py:63-110: <path>/config (one dataset per flattened key, utils.py:841-887) and <path>/weights (one
+    # dataset per state-dict entry).  `h5_file` is an open h5py File / Group or anything with the same group protocol
+    # (create_group, create_dataset, [] / items / in); this package does not import h5py itself.
+    def save(self, h5_file, path="flow"):
+        if self._has_transform():
+            raise NotImplementedError("saving a flow with a data transform is not supported; save the transform separately")
+        grp = h5_file.create_group(path)
+        cfg = grp.create_group("config")
+        for key, value in self._init_args.items():
+            cfg.create_dataset(key, data=np.asarray(value) if not isinstance(value, str) else value)
+        w = grp.create_group("weights")
+        for name, tensor in self.layers.state_dict().items():
+            w.create_dataset(name, data=tensor.detach().cpu().numpy())
+        w.create_dataset("_loc", data=self.loc.detach().cpu().numpy())
+        w.create_dataset("_scale", data=self.scale.detach().cpu().numpy())
+
+    @classmethod
+    def load(cls, h5_file, path="flow", device=None):
+        grp = h5_file[path]
+
+        def plain(v):
+            v = v[()] if hasattr(v, "shape") or hasattr(v, "dtype") else v
+            if isinstance(v, bytes):
+                v = v.decode()
+            return v.tolist() if isinstance(v, np.ndarray) else (v.item() if isinstance(v, np.generic) else v)
+
+        cfg = {k: plain(v) for k, v in grp["config"].items()}
+        cfg["dtype"] = getattr(torch, str(cfg["dtype"]))
+        obj = cls(device=device, **cfg)
+        weights = {name: torch.as_tensor(np.asarray(d[()])) for name, d in grp["weights"].items()}
+        obj.loc = weights.pop("_loc").to(device=obj.device, dtype=obj.dtype)
+        obj.scale = weights.pop("_scale").to(device=obj.device, dtype=obj.dtype)
+        obj.layers.load_state_dict(weights)
+        obj.layers.eval()
+        obj._version += 1
+        return obj
 
     @torch.no_grad()
     def inverse(self, z, xp=None):
