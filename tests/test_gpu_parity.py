@@ -545,12 +545,12 @@ def test_pcn_ysplit_session_equals_fused(eng, oracle, d, nu, dtype):
         torch.testing.assert_close(u[close], v[close], rtol=lt, atol=lt)
 
 
-@pytest.mark.parametrize("d,nu", [(4, 0.0), (8, 6.0)])
-def test_pcn_ysplit_session_vs_test_double(eng, oracle, d, nu):
-    """... and == the host restatement the CPU suite runs the sampler on (adaptation included)."""
+@pytest.mark.parametrize("d,nu,n", [(4, 0.0, 400), (8, 6.0, 400), (16, 0.0, 1), (32, 4.0, 65)])
+def test_pcn_ysplit_session_vs_test_double(eng, oracle, d, nu, n):
+    """... and == the host restatement the CPU suite runs the sampler on (adaptation included; ragged last tile, n = 1)."""
     from oracle_engine import OracleEngine
 
-    n, steps = 400, 4
+    steps = 4
     x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 350 + d)
     om = [oracle.Mixture(*m) for m in mixes]
     ll, lp, lq = (m.logpdf(x) for m in om)
