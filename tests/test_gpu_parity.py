@@ -1327,6 +1327,26 @@ def test_tpcn_default_sampler_run_gpu(eng):
     assert abs(float(out.log_evidence) - 0.5 * d * math.log(math.pi)) < 5 * float(out.log_evidence_error) + 0.02
 
 
+@pytest.mark.parametrize("d,step_fn", [(8, "pcn"), (32, "tpcn"), (6, "pcn")])
+def test_callable_density_sampler_run_gpu(eng, d, step_fn):
+    """Arbitrary torch callables as likelihood / prior: whitened-state split session where the dimension has kernels
+    (d = 8, 32), propose / accept otherwise (d = 6); evidence against the closed form either way."""
+    from aspire_amd.flows import GaussianFlow
+    from aspire_amd.samplers.smc import HipSMC
+
+    n = 100000
+    f = lambda smp: -0.5 * (smp.x * smp.x).sum(1)  # noqa: E731
+    eng.profile(True)
+    sp = HipSMC(log_likelihood=f, log_prior=f, dims=d, prior_flow=GaussianFlow(d, sigma=1.5, engine=eng, seed=3), xp=torch,
+                engine=eng, rng=np.random.default_rng(4))
+    out = sp.sample(n, sampler_kwargs=dict(n_steps=12, step_fn=step_fn), store_sample_history=False)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert ("k_pcn_flow_accept" in rep) == (d in (8, 32)) and ("k_pcn_accept_flags" in rep) == (d == 6)
+    assert abs(float(out.log_evidence) - 0.5 * d * math.log(math.pi)) < 5 * float(out.log_evidence_error) + 0.02
+    assert 0.05 < np.mean(sp.history.mcmc_acceptance) < 0.99
+
+
 @pytest.mark.parametrize("d,nu,dtype", [(20, 0.0, torch.float64), (31, 0.0, torch.float64), (17, 5.0, torch.float64),
                                         (24, 0.0, torch.float32)])
 def test_pcn_propose_padded_dims_vs_oracle_engine(eng, oracle, d, nu, dtype):
