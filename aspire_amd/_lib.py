@@ -108,7 +108,8 @@ SIGNATURES = {
     "asmc_pcn_set_count_hook": (_i, [_vp, _vp, _vp, _vp, _i64]),
     "asmc_pcn_ysplit_begin": (_i, [_vp, _i64, _vp, POINTER(AsmcPcnParams), _d, _vp]),
     "asmc_pcn_ysplit_propose": (_i, [_vp, _i64, POINTER(AsmcPcnParams), _u32, _vp, _vp]),
-    "asmc_pcn_ysplit_accept": (_i, [_vp, _i64, POINTER(AsmcPcnParams), _u32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "asmc_pcn_ysplit_accept": (_i, [_vp, _i64, POINTER(AsmcPcnParams), _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i,
+                                    _vp]),
     "asmc_pcn_ysplit_end": (_i, [_vp, _i64, _vp, POINTER(AsmcPcnParams), _vp]),
     "asmc_pcn_split_begin": (_i, [_vp, _d, _vp]),
     "asmc_pcn_split_adapt": (_i, [_vp, _i64, _d, _i, _i, _vp]),

@@ -713,6 +713,8 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
 #define PCN_FLOW_ACCEPT_S 3   // through LDS, accept touches no LDS at all
 #define PCN_FLOW_PROPOSE_SX 4 // PCN_FLOW_PROPOSE_S without the built-in densities: the proposal half of the whitened-state
                               // split session, whose densities come from the caller (arbitrary Python callables)
+#define PCN_FLOW_ACCEPT_SJ 5  // PCN_FLOW_ACCEPT_S with a carried log-Jacobian (chain in a preconditioned space): the two
+                              // arrays arrive through the y / x_prop parameters, which coordinate-major accept does not use
 
 template <typename T, int D, int NOISE, int MODE>
 __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
@@ -723,7 +725,8 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
     extern __shared__ __align__(16) char smem[];
     constexpr bool SOA = MODE >= PCN_FLOW_PROPOSE_S;
     constexpr bool NO_DENS = MODE == PCN_FLOW_PROPOSE_SX;
-    constexpr int M = NO_DENS ? PCN_FLOW_PROPOSE : SOA ? MODE - PCN_FLOW_PROPOSE_S : MODE;
+    constexpr bool HAS_LJ = MODE == PCN_FLOW_ACCEPT_SJ;
+    constexpr int M = NO_DENS ? PCN_FLOW_PROPOSE : HAS_LJ ? PCN_FLOW_ACCEPT : SOA ? MODE - PCN_FLOW_PROPOSE_S : MODE;
     constexpr int ROWB = D * (int)sizeof(T);
     constexpr int LDSROW = ROWB + 16;
     const int WPB = (int)(blockDim.x >> 6);
@@ -752,9 +755,12 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
         const unsigned ys_row = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p.n_pad) * (unsigned)sizeof(T);
         const unsigned ys_lane = (unsigned)lane * (unsigned)sizeof(T);
         double oll = 0.0, olp = 0.0, olq = 0.0, nll = 0.0, nlp = 0.0, nlq = 0.0;
+        double olj = 0.0, nlj = 0.0;
+        double* const lj = HAS_LJ ? static_cast<double*>(static_cast<void*>(y)) : nullptr;
         if (valid && M == PCN_FLOW_ACCEPT) {
             oll = ll[i], olp = lp[i], olq = lq[i];
             nll = ll_new[i], nlp = lp_new[i], nlq = lq_new[i];
+            if (HAS_LJ) olj = lj[i], nlj = static_cast<const double*>(static_cast<const void*>(x_prop))[i];
         }
         wave_lds_sync();
         bool acc = false;
@@ -812,12 +818,18 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
                 regs_to_row<T, D>(myrow, v);
                 acc = true;
             } else {
-                const double lpn = log_p_t(nll, nlp, nlq, p.beta);
-                const double lpo = log_p_t(oll, olp, olq, p.beta);
+                double lpn = log_p_t(nll, nlp, nlq, p.beta);
+                double lpo = log_p_t(oll, olp, olq, p.beta);
+                if (HAS_LJ) {  // as k_pcn_accept_flags: the log-Jacobian joins the tempered log-target, NaN -> -inf
+                    lpn += nlj, lpo += olj;
+                    lpn = (lpn != lpn) ? -INFINITY : lpn;
+                    lpo = (lpo != lpo) ? -INFINITY : lpo;
+                }
                 const double log_a = (lpn + ref_corr(q1, p.nu, D)) - (lpo + ref_corr(q0, p.nu, D));
                 const double u = accept_uniform(p.seed, gid, step);
                 acc = log(u) < log_a;
                 if (acc) {
+                    if (HAS_LJ) lj[i] = nlj;
                     if (SOA) {
 #pragma unroll
                         for (int j = 0; j < D; j++) soa_store<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row, v[j]);
@@ -1421,7 +1433,7 @@ static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double
                                hipStream_t st) {
     constexpr int LDSROW = D * (int)sizeof(T) + 16;
     constexpr size_t tile_bytes = (size_t)64 * LDSROW;
-    constexpr bool NO_LDS = MODE == PCN_FLOW_ACCEPT_S;
+    constexpr bool NO_LDS = MODE == PCN_FLOW_ACCEPT_S || MODE == PCN_FLOW_ACCEPT_SJ;
     const int wpb = (NO_LDS || (160 * 1024) / tile_bytes % 4 == 0 || tile_bytes * 12 <= 160 * 1024) ? 4 : 1;
     const size_t lds_bytes = NO_LDS ? 0 : (size_t)wpb * tile_bytes;
     const int64_t grid64 = ((n + 63) / 64 + wpb - 1) / wpb;
@@ -2078,12 +2090,13 @@ int asmc_pcn_ysplit_propose(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm
 }
 
 int asmc_pcn_ysplit_accept(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm, uint32_t step, double* ll, double* lp,
-                           double* lq, const double* ll_new, const double* lp_new, const double* lq_new, int64_t n_global,
-                           int t, asmc_stream stream) {
+                           double* lq, const double* ll_new, const double* lp_new, const double* lq_new, double* lj,
+                           const double* lj_new, int64_t n_global, int t, asmc_stream stream) {
     PcnDev pd;
     int rc = ysplit_pd(ctx, n, prm, pd);
     if (rc) return rc;
     ASMC_REQUIRE(ll && lp && lq && ll_new && lp_new && lq_new, "null pointer");
+    ASMC_REQUIRE((lj == nullptr) == (lj_new == nullptr), "log-Jacobian arrays: both or neither");
     ASMC_REQUIRE(ctx->d_ysoa != nullptr, "no session (asmc_pcn_ysplit_begin)");
     ASMC_REQUIRE(n_global > 0 && t >= 0 && t < ASMC_MAX_PCN_STEPS, "bad n_global / step index");
     hipStream_t st = as_stream(stream);
@@ -2092,7 +2105,15 @@ int asmc_pcn_ysplit_accept(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm,
     pd.gam = pd.nu > 0.0 ? ctx->d_gamma : nullptr;  // the variates asmc_pcn_ysplit_propose drew for this step
     int grid = 0;
     long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
-    if (prm->x_dtype == ASMC_F64)
+    if (lj && prm->x_dtype == ASMC_F64)
+        rc = dispatch_pcn_reg_flow<double, PCN_FLOW_ACCEPT_SJ>(ctx, n, lj, const_cast<double*>(lj_new), ll, lp, lq,
+                                                               const_cast<double*>(ll_new), const_cast<double*>(lp_new), lq_new,
+                                                               pd, ctx->d_rho, step, d_block, &grid, st);
+    else if (lj)
+        rc = dispatch_pcn_reg_flow<float, PCN_FLOW_ACCEPT_SJ>(
+            ctx, n, static_cast<float*>(static_cast<void*>(lj)), static_cast<float*>(static_cast<void*>(const_cast<double*>(lj_new))), ll,
+            lp, lq, const_cast<double*>(ll_new), const_cast<double*>(lp_new), lq_new, pd, ctx->d_rho, step, d_block, &grid, st);
+    else if (prm->x_dtype == ASMC_F64)
         rc = dispatch_pcn_reg_flow<double, PCN_FLOW_ACCEPT_S>(ctx, n, nullptr, nullptr, ll, lp, lq, const_cast<double*>(ll_new),
                                                               const_cast<double*>(lp_new), lq_new, pd, ctx->d_rho, step, d_block,
                                                               &grid, st);

@@ -606,12 +606,17 @@ class HipEngine:
               "asmc_pcn_ysplit_propose")
         return xp
 
-    def pcn_ysplit_accept(self, sess, step: int, ll, lp, lq, ll_new, lp_new, lq_new, n_global: int, t: int):
+    def pcn_ysplit_accept(self, sess, step: int, ll, lp, lq, ll_new, lp_new, lq_new, n_global: int, t: int,
+                          logj=None, logj_new=None):
+        """logj / logj_new: carried / proposed log-Jacobian of a chain in a preconditioned space (both or neither)."""
         self._chk3(ll, lp, lq)
         ll_new, lp_new, lq_new = (v.to(torch.float64).contiguous() for v in (ll_new, lp_new, lq_new))
+        if logj is not None:
+            assert logj.dtype == torch.float64 and logj.is_contiguous()
+            logj_new = logj_new.to(torch.float64).contiguous()
         check(self.lib.asmc_pcn_ysplit_accept(self._ctx, sess["x"].shape[0], ctypes.byref(sess["prm"]), step, _dptr(ll), _dptr(lp),
-                                              _dptr(lq), _dptr(ll_new), _dptr(lp_new), _dptr(lq_new), int(n_global), int(t),
-                                              self._stream), "asmc_pcn_ysplit_accept")
+                                              _dptr(lq), _dptr(ll_new), _dptr(lp_new), _dptr(lq_new), _dptr(logj),
+                                              _dptr(logj_new), int(n_global), int(t), self._stream), "asmc_pcn_ysplit_accept")
 
     def pcn_ysplit_end(self, sess, n_steps: int):
         """Writes the chain state back into the session's x; returns what pcn_split_end returns."""

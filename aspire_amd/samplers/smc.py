@@ -464,6 +464,24 @@ class HipSMC(SMCSampler):
                 e.set_count_hook(comm, n_global)
             try:
                 done = 0
+                while done < n_steps and hasattr(e, "pcn_ysplit_begin"):
+                    # whitened-state session on z (d = 4, 8, 16, 32): one mat-vec per step, LDS-free accept; the carried
+                    # log-Jacobian follows the accepted state inside the accept kernel
+                    chunk = min(n_steps - done, 2048)
+                    sess = e.pcn_ysplit_begin(z, beta, mu, L, Linv, seed, gid0, st["rho"], target, True, nu)
+                    if sess is None:
+                        break
+                    for t in range(done, done + chunk):
+                        z_prop = e.pcn_ysplit_propose(sess, step0 + t)
+                        x_prop, logj_new = T.inverse(z_prop)
+                        x_prop, logj_new = e.asarray(x_prop, dtype=x.dtype), e.asarray(logj_new)
+                        lq_new = self._flow_log_prob(x_prop)
+                        lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
+                        e.pcn_ysplit_accept(sess, step0 + t, ll, lp, lq, ll_new, lp_new, lq_new, n_global, t - done,
+                                            logj=logj, logj_new=logj_new)
+                    n_acc, _, st["rho"] = e.pcn_ysplit_end(sess, chunk)
+                    acc_rates.extend((n_acc / n_global).tolist())
+                    done += chunk
                 while done < n_steps:
                     chunk = min(n_steps - done, 2048)
                     e.pcn_split_begin(st["rho"])

@@ -315,6 +315,9 @@ int asmc_pcn_split_end(asmc_ctx* ctx, int n_steps, int64_t* n_accept_host, doubl
  *   (caller)                 log_q, log_prior, log_likelihood at x_prop (Python callables, flows, ...);
  *   asmc_pcn_ysplit_accept   regenerates y' from the same counters, accepts (y <- y', carried log-probabilities updated) and
  *                            closes step t like asmc_pcn_split_adapt (count exchange hook, history, adaptation);
+ *                            logj_dev / logj_new_dev (both or NULL): carried / proposed log|det J| of a chain that runs in a
+ *                            preconditioned space z = T(x) - they join the tempered log-target and follow the accepted
+ *                            state, as in asmc_pcn_accept (smc/base.py:507-519);
  *   asmc_pcn_ysplit_end      y -> x_dev;  asmc_pcn_split_end then returns counts, step-size history and final step size.
  * params: d, x_dtype, beta, mu / L / Linv, seed, gid0, target_accept, adapt, nu are used; the mixtures are ignored; the
  * noise is the parity mode's (fp64 Box-Muller), as in asmc_pcn_propose. */
@@ -324,7 +327,8 @@ int asmc_pcn_ysplit_propose(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* par
                             asmc_stream stream);
 int asmc_pcn_ysplit_accept(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* params, uint32_t step, double* ll_dev,
                            double* lp_dev, double* lq_dev, const double* ll_new_dev, const double* lp_new_dev,
-                           const double* lq_new_dev, int64_t n_global, int t, asmc_stream stream);
+                           const double* lq_new_dev, double* logj_dev, const double* logj_new_dev, int64_t n_global, int t,
+                           asmc_stream stream);
 int asmc_pcn_ysplit_end(asmc_ctx* ctx, int64_t n, void* x_dev, const asmc_pcn_params* params, asmc_stream stream);
 int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x_dev,
                     const void* x_prop_dev, double* ll_dev, double* lp_dev, double* lq_dev,

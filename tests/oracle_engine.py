@@ -353,7 +353,7 @@ class OracleEngine:
         xp = (sess["mu"] + yp @ sess["L"].T).astype(sess["npdt"])
         return torch.from_numpy(xp)
 
-    def pcn_ysplit_accept(self, sess, step, ll, lp, lq, ll_new, lp_new, lq_new, n_global, t):
+    def pcn_ysplit_accept(self, sess, step, ll, lp, lq, ll_new, lp_new, lq_new, n_global, t, logj=None, logj_new=None):
         pstep, yp, q0, q1 = sess["prop"]
         assert pstep == step
         beta, nu, d = sess["beta"], sess["nu"], yp.shape[1]
@@ -366,11 +366,18 @@ class OracleEngine:
             return np.where(np.isnan(r), -np.inf, r)
 
         c0, c1 = (O.tpcn_corr(q0, d, nu), O.tpcn_corr(q1, d, nu)) if nu > 0.0 else (0.5 * q0, 0.5 * q1)
+        new, old = lpt(ll_new, lp_new, lq_new), lpt(ll, lp, lq)
+        if logj is not None:
+            with np.errstate(all="ignore"):
+                new, old = new + _np(logj_new), old + _np(logj)
+            new, old = np.where(np.isnan(new), -np.inf, new), np.where(np.isnan(old), -np.inf, old)
         with np.errstate(all="ignore"):
-            acc = np.log(u) < (lpt(ll_new, lp_new, lq_new) + c1) - (lpt(ll, lp, lq) + c0)
+            acc = np.log(u) < (new + c1) - (old + c0)
         sess["y"][acc] = yp[acc]
         acc_t = torch.from_numpy(acc)
         ll[acc_t], lp[acc_t], lq[acc_t] = ll_new[acc_t], lp_new[acc_t], lq_new[acc_t]
+        if logj is not None:
+            logj[acc_t] = logj_new[acc_t]
         self._split["last"] = int(acc.sum())
         self.pcn_split_adapt(n_global, sess["target"], t, sess["adapt"])
 

@@ -573,6 +573,54 @@ def test_pcn_ysplit_session_vs_test_double(eng, oracle, d, nu, n):
         np.testing.assert_allclose(u, v, rtol=1e-10, atol=1e-10)
 
 
+@pytest.mark.parametrize("d,nu", [(8, 0.0), (32, 5.0)])
+def test_pcn_ysplit_accept_with_log_jacobian(eng, oracle, d, nu):
+    """Chain in a preconditioned space: carried / proposed log-Jacobians join the tempered log-target and follow the accepted
+    state - first step == the x-state propose / accept pair with the same arrays; several steps == the test double."""
+    from oracle_engine import OracleEngine
+
+    n = 3000
+    x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 400 + d)
+    om = [oracle.Mixture(*m) for m in mixes]
+    ll, lp, lq = (m.logpdf(x) for m in om)
+    g = np.random.default_rng(5)
+    lj0 = g.normal(size=n)
+    jac = lambda xp: 0.3 * np.sin(xp).sum(1)  # noqa: E731  (any smooth function of the proposal stands in for log|J|)
+    mud, Ld, Lid = dev(eng, mu, L, Linv)
+    a = list(dev(eng, x, ll, lp, lq, lj0))
+    b = list(dev(eng, x, ll, lp, lq, lj0))
+    zp, q0, q1 = eng.pcn_propose(a[0], mud, Ld, Lid, 0.35, 11, 3, 0, nu=nu)
+    new = [eng.asarray(m.logpdf(zp.cpu().numpy())) for m in om]
+    na = eng.pcn_accept(a[0], zp, a[1], a[2], a[3], *new, q0, q1, 0.6, 11, 3, 0, logj_old=a[4],
+                        logj_new=eng.asarray(jac(zp.cpu().numpy())))
+    sess = eng.pcn_ysplit_begin(b[0], 0.6, mud, Ld, Lid, 11, 3, 0.35, 0.234, False, nu)
+    zq = eng.pcn_ysplit_propose(sess, 0)
+    torch.testing.assert_close(zq, zp, rtol=1e-13, atol=1e-13)
+    new = [eng.asarray(m.logpdf(zq.cpu().numpy())) for m in om]
+    eng.pcn_ysplit_accept(sess, 0, b[1], b[2], b[3], *new, n, 0, logj=b[4], logj_new=eng.asarray(jac(zq.cpu().numpy())))
+    nb, _, _ = eng.pcn_ysplit_end(sess, 1)
+    assert abs(int(nb[0]) - na) <= 1 and 0 < na < n
+    same = (a[4] == b[4])
+    assert int((~same).sum()) <= 1 and int((a[4] != eng.asarray(lj0)).sum()) >= na - 1  # the Jacobian moved with the state
+    for u, v in zip(a, b):
+        torch.testing.assert_close(u[same], v[same], rtol=1e-11, atol=1e-11)
+    # several adapted steps against the host restatement
+    out = []
+    for e in (eng, OracleEngine()):
+        st = [e.asarray(np.array(v)) for v in (x[:300], ll[:300], lp[:300], lq[:300], lj0[:300])]
+        sess = e.pcn_ysplit_begin(st[0], 0.7, e.asarray(mu), e.asarray(L), e.asarray(Linv), 9, 5, 0.4, 0.234, True, nu)
+        for t in range(3):
+            xp = e.pcn_ysplit_propose(sess, t).cpu().numpy().astype(np.float64)
+            e.pcn_ysplit_accept(sess, t, st[1], st[2], st[3], *[e.asarray(m.logpdf(xp)) for m in om], 300, t, logj=st[4],
+                                logj_new=e.asarray(jac(xp)))
+        n_acc, hist, rho = e.pcn_ysplit_end(sess, 3)
+        out.append(([v.cpu().numpy() for v in st], n_acc, rho))
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    assert abs(out[0][2] - out[1][2]) < 1e-14
+    for u, v in zip(out[0][0], out[1][0]):
+        np.testing.assert_allclose(u, v, rtol=1e-10, atol=1e-10)
+
+
 def test_pcn_ysplit_unsupported_dimension_and_errors(eng):
     from aspire_amd._lib import AsmcError
 
