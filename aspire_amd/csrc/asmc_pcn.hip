@@ -1536,6 +1536,10 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
             default: break;
         }
     }
+    if (pd.mode >= PCN_WHITEN_S) {  // coordinate-major / propose modes exist as register kernels only
+        asmc_set_error("pcn: no kernel for mode %d at d=%d, noise=%d", pd.mode, pd.d, pd.noise);
+        return ASMC_ERR_UNSUPPORTED;
+    }
     const size_t per_wave = (size_t)64 * lds_row_stride(rowbytes) + (size_t)64 * 8 * pd.d;
     size_t lds_bytes = 0;
     const int wpb = waves_for_lds(per_wave, &lds_bytes);
@@ -2036,7 +2040,8 @@ static int ysplit_pd(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm, PcnDe
     pd.seed = prm->seed;
     pd.gid0 = prm->gid0;
     pd.nu = prm->nu;
-    pd.noise = ASMC_NOISE_F64;  // the split path's noise is the parity mode's (as asmc_pcn_propose)
+    ASMC_REQUIRE(prm->noise == ASMC_NOISE_F64 || prm->noise == ASMC_NOISE_F32, "bad noise mode");
+    pd.noise = prm->noise;  // same in every call of a session: accept regenerates what propose drew
     return ASMC_OK;
 }
 
@@ -2057,6 +2062,7 @@ int asmc_pcn_ysplit_begin(asmc_ctx* ctx, int64_t n, const void* x, const asmc_pc
     rc = pack_pcn_tables(ctx, pd, st);
     if (rc) return rc;
     pd.mode = PCN_WHITEN_S;
+    pd.noise = ASMC_NOISE_F64;  // (the whitening kernels draw nothing: they are instantiated under this key only)
     int grid = 0;
     long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
     if (prm->x_dtype == ASMC_F64)
@@ -2135,6 +2141,7 @@ int asmc_pcn_ysplit_end(asmc_ctx* ctx, int64_t n, void* x, const asmc_pcn_params
     pd.ys = ctx->d_ysoa;
     pd.n_pad = ((n + 63) / 64) * 64;
     pd.mode = PCN_UNWHITEN_XS;
+    pd.noise = ASMC_NOISE_F64;
     rc = pack_pcn_tables(ctx, pd, st);
     if (rc) return rc;
     int grid = 0;

@@ -587,12 +587,13 @@ class HipEngine:
         return int(nacc.value) if want_count else None
 
     # whitened-state session of the split path: y = L^-1 (x - mu) stays coordinate-major in the context between the calls
-    def pcn_ysplit_begin(self, x, beta, mu, L, Linv, seed, gid0, rho, target_accept=0.234, adapt=True, nu=0.0):
+    def pcn_ysplit_begin(self, x, beta, mu, L, Linv, seed, gid0, rho, target_accept=0.234, adapt=True, nu=0.0,
+                         noise="f64"):
         """Opens a session on x (left untouched until pcn_ysplit_end) and returns its handle, or None when the dimension has
         no whitened-state kernels (the caller then uses pcn_propose / pcn_accept)."""
         n, d = x.shape
         prm = AsmcPcnParams(d, self._xdt(x), beta, mu.data_ptr(), L.data_ptr(), Linv.data_ptr(), AsmcMixture(), AsmcMixture(),
-                            AsmcMixture(), seed, gid0, target_accept, int(adapt), 0, float(nu))
+                            AsmcMixture(), seed, gid0, target_accept, int(adapt), {"f64": 0, "f32": 1}[noise], float(nu))
         rc = self.lib.asmc_pcn_ysplit_begin(self._ctx, n, _dptr(x), ctypes.byref(prm), float(rho), self._stream)
         if rc == _lib.ASMC_ERR_UNSUPPORTED:
             return None

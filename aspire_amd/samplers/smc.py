@@ -468,7 +468,8 @@ class HipSMC(SMCSampler):
                     # whitened-state session on z (d = 4, 8, 16, 32): one mat-vec per step, LDS-free accept; the carried
                     # log-Jacobian follows the accepted state inside the accept kernel
                     chunk = min(n_steps - done, 2048)
-                    sess = e.pcn_ysplit_begin(z, beta, mu, L, Linv, seed, gid0, st["rho"], target, True, nu)
+                    sess = e.pcn_ysplit_begin(z, beta, mu, L, Linv, seed, gid0, st["rho"], target, True, nu,
+                                              self.sampler_kwargs.get("noise", "f64"))
                     if sess is None:
                         break
                     for t in range(done, done + chunk):
@@ -624,7 +625,7 @@ class HipSMC(SMCSampler):
                 # whitened-state session (d = 4, 8, 16, 32): the chain state stays coordinate-major on the device, a step is
                 # one mat-vec in the propose kernel and an LDS-free accept kernel
                 chunk = min(n_steps - done, 2048)
-                sess = e.pcn_ysplit_begin(x, beta, mu, L, Linv, seed, gid0, st["rho"], target, True, nu)
+                sess = e.pcn_ysplit_begin(x, beta, mu, L, Linv, seed, gid0, st["rho"], target, True, nu, noise)
                 if sess is None:
                     break
                 for t in range(done, done + chunk):

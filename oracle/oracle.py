@@ -78,6 +78,7 @@ def lib():
             ),
             "orc_pcn_noise_f32": (None, [u64, u64, u32, ci, vp, vp]),
             "orc_gamma_unit": (d, [d, u64, u64, u32]),
+            "orc_gamma_unit_mode": (d, [d, u64, u64, u32, ctypes.c_int]),
             "orc_tpcn_corr": (d, [d, ci, d]),
             "orc_tpcn_step": (
                 i64,
@@ -362,9 +363,9 @@ def pcn_step(x, ll, lp, lq, beta, mu, L, Linv, rho, t_ll, t_lp, t_lq, seed, gid0
     )
 
 
-def gamma_unit(shape, seed, gid, step):
+def gamma_unit(shape, seed, gid, step, noise="f64"):
     """Unit-scale Gamma(shape) variate of particle `gid` at Markov step `step` (tpCN scale mixture)."""
-    return lib().orc_gamma_unit(float(shape), seed, gid, step)
+    return lib().orc_gamma_unit_mode(float(shape), seed, gid, step, int(noise == "f32"))
 
 
 def tpcn_corr(q, d, nu):

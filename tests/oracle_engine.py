@@ -328,7 +328,7 @@ class OracleEngine:
         return torch.from_numpy(xp).to(x.dtype), torch.from_numpy(q0), torch.from_numpy(q1)
 
     # whitened-state session of the split path: host-side restatement of asmc_pcn_ysplit_{begin,propose,accept,end}
-    def pcn_ysplit_begin(self, x, beta, mu, L, Linv, seed, gid0, rho, target_accept=0.234, adapt=True, nu=0.0):
+    def pcn_ysplit_begin(self, x, beta, mu, L, Linv, seed, gid0, rho, target_accept=0.234, adapt=True, nu=0.0, noise="f64"):
         n, d = x.shape
         if d not in (4, 8, 16, 32):
             return None
@@ -336,17 +336,17 @@ class OracleEngine:
         npdt = np.float64 if x.dtype == torch.float64 else np.float32
         y = ((_np(x).astype(np.float64) - _np(mu)) @ _np(Linv).T).astype(npdt).astype(np.float64)
         return {"x": x, "y": y, "beta": beta, "mu": _np(mu), "L": _np(L), "seed": seed, "gid0": gid0, "target": target_accept,
-                "adapt": adapt, "nu": nu, "npdt": npdt, "prop": None}
+                "adapt": adapt, "nu": nu, "npdt": npdt, "prop": None, "noise": noise}
 
     def pcn_ysplit_propose(self, sess, step):
         y, nu, seed, gid0 = sess["y"], sess["nu"], sess["seed"], sess["gid0"]
         rho = self._split["rho"]
         n, d = y.shape
-        xi = np.stack([O.pcn_noise(seed, gid0 + i, step, d)[0] for i in range(n)])
+        xi = np.stack([O.pcn_noise(seed, gid0 + i, step, d, sess["noise"])[0] for i in range(n)])
         q0 = (y * y).sum(1)
         rs = np.full(n, rho)
         if nu > 0.0:
-            g = np.array([O.gamma_unit(0.5 * (d + nu), seed, gid0 + i, step) for i in range(n)])
+            g = np.array([O.gamma_unit(0.5 * (d + nu), seed, gid0 + i, step, sess["noise"]) for i in range(n)])
             rs = rho * np.sqrt((nu + q0) / (2.0 * g))
         yp = (np.sqrt(1 - rho * rho) * y + rs[:, None] * xi).astype(sess["npdt"]).astype(np.float64)
         sess["prop"] = (step, yp, q0, (yp * yp).sum(1))
@@ -358,7 +358,7 @@ class OracleEngine:
         assert pstep == step
         beta, nu, d = sess["beta"], sess["nu"], yp.shape[1]
         n = yp.shape[0]
-        u = np.array([O.pcn_noise(sess["seed"], sess["gid0"] + i, step, d)[1] for i in range(n)])
+        u = np.array([O.pcn_noise(sess["seed"], sess["gid0"] + i, step, d, sess["noise"])[1] for i in range(n)])
 
         def lpt(a, b, c):
             with np.errstate(all="ignore"):

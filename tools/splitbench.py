@@ -48,7 +48,7 @@ for nu in (0.0, 6.0):
                     eng.pcn_split_adapt(n, 0.234, t, True)
                 na, _, rho = eng.pcn_split_end(20)
             else:
-                sess = eng.pcn_ysplit_begin(xs, 0.5, mu, eye, eye, 5, 0, 0.3, 0.234, True, nu)
+                sess = eng.pcn_ysplit_begin(xs, 0.5, mu, eye, eye, 5, 0, 0.3, 0.234, True, nu, os.environ.get("NOISE", "f64"))
                 for t in range(20):
                     xp = eng.pcn_ysplit_propose(sess, t)
                     eng.pcn_ysplit_accept(sess, t, *l3, f(xp), f(xp), f(xp / 1.5), n, t)
@@ -57,7 +57,7 @@ for nu in (0.0, 6.0):
             dt = (time.perf_counter() - t0) / 20
         print(f"nu={nu} {kind}-state session: {dt*1e3:.3f} ms/step, mean accept {na.mean()/n:.3f}, rho {rho:.4f}")
 eng.profile(True)
-sess = eng.pcn_ysplit_begin(x, 0.5, mu, eye, eye, 5, 0, 0.3, 0.234, True, 0.0)
+sess = eng.pcn_ysplit_begin(x, 0.5, mu, eye, eye, 5, 0, 0.3, 0.234, True, 0.0, os.environ.get("NOISE", "f64"))
 for t in range(10):
     xp = eng.pcn_ysplit_propose(sess, t)
     eng.pcn_ysplit_accept(sess, t, ll, lp, lq, f(xp), f(xp), f(xp / 1.5), n, t)
