@@ -79,6 +79,7 @@ struct asmc_ctx {
     double* d_rho;                 // [ASMC_MAX_PCN_STEPS + 8] step-size history on device
     unsigned long long* d_pcgtab;  // [64*4 + 8] PCG64 jump table
     long long* d_select;           // [2 * ASMC_SELECT_THREADS/64 + 8] wave counts, offsets, total of asmc_pcg64_select
+    unsigned long long ptab_tag, ysplit_seq;  // who packed d_ptab last (0 = anyone; else the split session's number)
     double* d_ptab;                // [2*32*32 + 32 + 3*8*(1+2*32)] packed pCN parameter block (d <= 32)
     double* d_mmtab;               // [2 * 144 * 64] MFMA operand images of L and Linv (d = 64 / 128; NULL when d_max < 64)
     // sharded mutation: accept-count exchange between a step and its adaptation (asmc_pcn_set_count_hook)

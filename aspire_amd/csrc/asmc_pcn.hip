@@ -1372,6 +1372,7 @@ __global__ __launch_bounds__(256) void k_pcn_pack(PcnDev pd, double* __restrict_
 }
 
 static int pack_pcn_tables(asmc_ctx* ctx, const PcnDev& pd, hipStream_t st) {
+    ctx->ptab_tag = 0;
     ASMC_LAUNCH(ctx, st, "k_pcn_pack", k_pcn_pack, dim3(1), dim3(256), 0, st, pd, ctx->d_ptab);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -2061,6 +2062,7 @@ int asmc_pcn_ysplit_begin(asmc_ctx* ctx, int64_t n, const void* x, const asmc_pc
     ASMC_LAUNCH_CHECK();
     rc = pack_pcn_tables(ctx, pd, st);
     if (rc) return rc;
+    ctx->ptab_tag = ++ctx->ysplit_seq;
     pd.mode = PCN_WHITEN_S;
     pd.noise = ASMC_NOISE_F64;  // (the whitening kernels draw nothing: they are instantiated under this key only)
     int grid = 0;
@@ -2082,8 +2084,13 @@ int asmc_pcn_ysplit_propose(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm
     hipStream_t st = as_stream(stream);
     pd.ys = ctx->d_ysoa;
     pd.n_pad = ((n + 63) / 64) * 64;
-    rc = pack_pcn_tables(ctx, pd, st);  // (the caller's densities run between the calls of a session: do not rely on the
-    if (rc) return rc;                  // packed tables surviving them)
+    if (ctx->ptab_tag == 0 || ctx->ptab_tag != ctx->ysplit_seq) {
+        // someone else packed parameter tables on this context since asmc_pcn_ysplit_begin (cheap insurance; a context
+        // carries ONE mutation at a time - step size, counts and scale variates are per context - see include/asmc.h)
+        rc = pack_pcn_tables(ctx, pd, st);
+        if (rc) return rc;
+        ctx->ptab_tag = ctx->ysplit_seq;
+    }
     rc = pcn_prepare_gamma(ctx, n, pd, step, st);
     if (rc) return rc;
     int grid = 0;

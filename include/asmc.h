@@ -320,7 +320,10 @@ int asmc_pcn_split_end(asmc_ctx* ctx, int n_steps, int64_t* n_accept_host, doubl
  *                            state, as in asmc_pcn_accept (smc/base.py:507-519);
  *   asmc_pcn_ysplit_end      y -> x_dev;  asmc_pcn_split_end then returns counts, step-size history and final step size.
  * params: d, x_dtype, beta, mu / L / Linv, seed, gid0, target_accept, adapt, nu, noise are used (the same values in every
- * call of a session); the mixtures are ignored. */
+ * call of a session); the mixtures are ignored.  A context carries one mutation at a time (step size, accept counts,
+ * scale variates and the whitened state live in it): the caller's densities may use every other entry point on the same
+ * context between the calls (mixture / coupling log-densities, transforms, reductions) but not another asmc_pcn_* call;
+ * all calls of a session go to the same stream. */
 int asmc_pcn_ysplit_begin(asmc_ctx* ctx, int64_t n, const void* x_dev, const asmc_pcn_params* params, double rho0,
                           asmc_stream stream);
 int asmc_pcn_ysplit_propose(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* params, uint32_t step, void* x_prop_dev,
