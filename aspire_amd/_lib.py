@@ -26,7 +26,8 @@ COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
-ASMC_ABI_VERSION = 8
+ASMC_ABI_VERSION = 9
+ASMC_CDF_REC = 9
 
 
 class AsmcMixture(ctypes.Structure):
@@ -132,6 +133,10 @@ SIGNATURES = {
     "asmc_cdf_normalize": (_i, [_vp, _i64, _vp, _d, _vp]),
     "asmc_cdf_normalize_last": (_i, [_vp, _i64, _vp, _vp]),
     "asmc_pcg64_uniforms": (_i, [_vp, POINTER(c_uint64), _u64, _i64, _vp, _vp]),
+    "asmc_cdf_shard_tiles": (_i64, [_i64]),
+    "asmc_cdf_shard_records": (_i, [_vp, _i64, _vp, _vp, _d, _i, _vp, _vp]),
+    "asmc_cdf_shard_finish": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "asmc_select_range": (_i, [_vp, _i64, _vp, _vp, _vp, _pi64, _vp]),
     "asmc_systematic_uniforms": (_i, [_vp, _i64, _i64, _i64, _d, _vp, _vp, _vp]),
     "asmc_search": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "asmc_gather": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

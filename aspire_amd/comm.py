@@ -43,6 +43,14 @@ class Comm:
         out.copy_(t)
         return out
 
+    def all_gather_ragged(self, t: torch.Tensor, counts) -> torch.Tensor:
+        """Concatenate shards of DIFFERENT lengths along dim 0 in rank order; counts[r] = rows of rank r's shard, the
+        same list on every rank."""
+        return t
+
+    def all_gather_i64(self, arr) -> np.ndarray:
+        return np.asarray(arr, dtype=np.int64)[None, ...]
+
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
         return t
 
@@ -76,6 +84,10 @@ class TorchDistComm(Comm):
         # rigs; the production backend is "nccl" = RCCL, which exchanges device memory over xGMI directly)
         self._stage = dist.get_backend(group) == "gloo"
 
+    def _global(self, r: int) -> int:
+        """Group-relative rank -> global rank (send / recv / broadcast address peers by their global rank)."""
+        return r if self.group is None else self.dist.get_global_rank(self.group, r)
+
     def all_gather_f64(self, arr) -> np.ndarray:
         a = np.ascontiguousarray(arr, dtype=np.float64)
         t = torch.as_tensor(a.reshape(-1), device=self.device)
@@ -105,6 +117,27 @@ class TorchDistComm(Comm):
         self.dist.all_gather_into_tensor(out, t, group=self.group)
         return out
 
+    def all_gather_ragged(self, t: torch.Tensor, counts) -> torch.Tensor:
+        counts = [int(c) for c in counts]
+        assert len(counts) == self.world and t.shape[0] == counts[self.rank], (counts, self.rank, tuple(t.shape))
+        cap = max(counts)
+        if all(c == cap for c in counts):
+            return self.all_gather_tensor(t)
+        pad = torch.empty((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        if t.shape[0] < cap:
+            pad[t.shape[0]:] = 0
+        g = self.all_gather_tensor(pad)
+        return torch.cat([g[r * cap: r * cap + counts[r]] for r in range(self.world)], dim=0)
+
+    def all_gather_i64(self, arr) -> np.ndarray:
+        """Exact integers (counts, generator state words) - all_gather_f64 would round above 2^53."""
+        a = np.ascontiguousarray(arr, dtype=np.int64)
+        t = torch.as_tensor(a.reshape(-1), device=self.device)
+        out = torch.empty(self.world * t.numel(), dtype=torch.int64, device=self.device)
+        self.dist.all_gather_into_tensor(out, t, group=self.group)
+        return out.cpu().numpy().reshape((self.world,) + a.shape)
+
     def all_to_all_rows(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int]) -> torch.Tensor:
         """Variable all-to-all along dim 0 (rows grouped by destination rank in `send`)."""
         send = send.contiguous()
@@ -133,17 +166,17 @@ class TorchDistComm(Comm):
         if self.rank == 0:
             return None
         t = torch.empty(1, dtype=torch.float64, device=self.device)
-        self.dist.recv(t, src=self.rank - 1, group=self.group)
+        self.dist.recv(t, src=self._global(self.rank - 1), group=self.group)
         return float(t.item())
 
     def chain_send(self, value: float) -> None:
         if self.rank + 1 < self.world:
             t = torch.tensor([value], dtype=torch.float64, device=self.device)
-            self.dist.send(t, dst=self.rank + 1, group=self.group)
+            self.dist.send(t, dst=self._global(self.rank + 1), group=self.group)
 
     def broadcast_f64(self, value: float, src: int) -> float:
         t = torch.tensor([value], dtype=torch.float64, device=self.device)
-        self.dist.broadcast(t, src=src, group=self.group)
+        self.dist.broadcast(t, src=self._global(src), group=self.group)
         return float(t.item())
 
 

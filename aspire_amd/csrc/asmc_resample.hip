@@ -210,7 +210,8 @@ __device__ __forceinline__ void k_exact_tile_td_body(int64_t n, const double* __
                                                              double approx_total, int64_t n_tiles,
                                                              long long* __restrict__ tile_info,
                                                              long long* __restrict__ tile_split,
-                                                             double* __restrict__ tile_s2) {
+                                                             double* __restrict__ tile_s2,
+                                                             long long* __restrict__ rec_pk = nullptr) {
     __shared__ TD sh_td[XT_THREADS / 64 + 1];
     __shared__ double sh_ws[XT_THREADS / 64];
     __shared__ int sh_c;
@@ -277,6 +278,23 @@ __device__ __forceinline__ void k_exact_tile_td_body(int64_t n, const double* __
     TD excl, totalA, totalB = {0, 0};
     td_block_scan(mineA, excl, totalA, sh_td);
     if (flag == 2) td_block_scan(mineB, excl, totalB, sh_td);  // uniform per block
+    if (rec_pk) {  // sharded form: one packed record per tile {a0, a1, e, flag, b0, b1, c, nf_c, bits(w_c)}
+        long long* r = rec_pk + ASMC_CDF_REC * t;
+        if (tid == 0) {
+            r[0] = totalA.a0, r[1] = totalA.a1, r[2] = e, r[3] = flag;
+            r[4] = totalB.a0, r[5] = totalB.a1, r[6] = c;
+            if (flag != 2) r[7] = 0, r[8] = 0;
+        }
+        if (flag == 2 && tid == c / XT_E) {
+            double wc = 0.0;
+#pragma unroll
+            for (int j = 0; j < XT_E; j++)
+                if (j == c % XT_E) wc = wv[j];
+            r[7] = nf_c;
+            r[8] = __double_as_longlong(wc);
+        }
+        return;
+    }
     if (tid == 0) {
         tile_info[4 * t + 0] = totalA.a0;
         tile_info[4 * t + 1] = totalA.a1;
@@ -303,8 +321,9 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_launch(int64_t n, 
                                                                     int64_t n_tiles, long long* __restrict__ tile_info,
                                                                     long long* __restrict__ tile_split,
                                                                     double* __restrict__ tile_s2, double* __restrict__ cdf,
-                                                                    double carry_in, double* __restrict__ tile_s) {
-    if (blockIdx.x == 0) {
+                                                                    double carry_in, double* __restrict__ tile_s,
+                                                                    int first_exact, long long* __restrict__ rec_pk) {
+    if (blockIdx.x == 0 && first_exact) {
         // Tile 0 enters with an EXACTLY known running sum (the carry), and it is the one tile that leaves several
         // binades in a row (the sum grows from nothing): it is scanned element-wise right here, in parallel with the
         // other tiles' transducers, instead of in the sequential chain.  tile_s[0] = carry, tile_s2[0] = exact sum
@@ -315,14 +334,20 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_launch(int64_t n, 
         const int64_t hi = ASMC_SCAN_TILE < n ? ASMC_SCAN_TILE : n;
         const double s_out = exact_tile(w, cdf, 0, hi, carry_in, sh_td0, &sh_s0, &sh_pos0, &sh_cross0);
         if (threadIdx.x == 0) {
-            tile_info[0] = 0, tile_info[1] = 0, tile_info[2] = 0, tile_info[3] = 3;
-            tile_split[0] = tile_split[1] = tile_split[2] = tile_split[3] = 0;
-            tile_s[0] = carry_in;
-            tile_s2[0] = s_out;
+            if (rec_pk) {
+                rec_pk[0] = rec_pk[1] = rec_pk[2] = 0, rec_pk[3] = 3;
+                rec_pk[4] = rec_pk[5] = rec_pk[6] = rec_pk[7] = 0;
+                rec_pk[8] = __double_as_longlong(s_out);
+            } else {
+                tile_info[0] = 0, tile_info[1] = 0, tile_info[2] = 0, tile_info[3] = 3;
+                tile_split[0] = tile_split[1] = tile_split[2] = tile_split[3] = 0;
+                tile_s[0] = carry_in;
+                tile_s2[0] = s_out;
+            }
         }
         return;
     }
-    k_exact_tile_td_body(n, w, approx_prefix, *approx_total, n_tiles, tile_info, tile_split, tile_s2);
+    k_exact_tile_td_body(n, w, approx_prefix, *approx_total, n_tiles, tile_info, tile_split, tile_s2, rec_pk);
 }
 
 // Pass D: one block chains the EXACT running sum through the tiles.  Flag-1 tiles cost O(1) (verify the binade
@@ -465,6 +490,160 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const dou
     if (threadIdx.x == 0) *total_out = s;
 }
 
+
+// ---- sharded exact cdf (one process per GPU; the reference has no distributed mode) -------------------------------
+// numpy's cumsum over the GLOBAL weight vector is one sequential chain through every rank's shard.  Passes A-C above
+// need only an APPROXIMATE incoming sum, so every rank runs them on its own shard at once and emits one packed record
+// per tile; the records of all ranks are all-gathered (72 B per 2048 particles) and every rank then walks the SAME
+// chain over all of them - the exact sum entering each of its own tiles and the global total come out bit-identical
+// on every rank without a rank-to-rank dependency.  A tile whose prediction fails verification would need its
+// elements, which live on another rank: the chain then raises `fail` and the caller falls back to a replicated scan
+// over the all-gathered weights (same result, more traffic; rare: a running sum within rounding of a power of two at
+// a predicted crossing, leading zero weights, or two binade crossings inside one tile).
+__global__ __launch_bounds__(XT_THREADS) void k_exact_chain_pk(int64_t n_tiles, const long long* __restrict__ pk,
+                                                              double* __restrict__ tile_s, double* __restrict__ tile_s2,
+                                                              double* __restrict__ total_out, double* __restrict__ fail_out) {
+    __shared__ double sh_walk_s;
+    __shared__ long long sh_walk_t;
+    __shared__ int sh_split_ok;
+    constexpr int CHAIN_CHUNK = 512;
+    __shared__ long long sh_rec[CHAIN_CHUNK * ASMC_CDF_REC];
+    int64_t chunk0 = -CHAIN_CHUNK;
+    int64_t t = 0;
+    double s = 0.0;
+    bool failed = false;
+    if (pk[3] == 3) {  // the first rank's first tile was scanned element-wise from an exactly known sum (0)
+        s = __longlong_as_double(pk[8]);
+        if (threadIdx.x == 0) tile_s[0] = 0.0, tile_s2[0] = s;
+        t = 1;
+    }
+    while (t < n_tiles) {
+        if (t + 64 > chunk0 + CHAIN_CHUNK || t < chunk0) {
+            __syncthreads();
+            chunk0 = t;
+            const int64_t cnt = (n_tiles - chunk0 < CHAIN_CHUNK ? n_tiles - chunk0 : CHAIN_CHUNK) * ASMC_CDF_REC;
+            for (int64_t i = threadIdx.x; i < cnt; i += XT_THREADS) sh_rec[i] = pk[ASMC_CDF_REC * chunk0 + i];
+            __syncthreads();
+        }
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            const int64_t my_t = t + lane;
+            long long a0 = 0, a1 = 0, ee = 0, sf = 0;
+            if (my_t < n_tiles) {
+                const long long* rec = sh_rec + ASMC_CDF_REC * (my_t - chunk0);
+                a0 = rec[0], a1 = rec[1], ee = rec[2], sf = rec[3];
+            }
+            const int e_cur = binade_of(s);
+            const long long S = (s > 0.0) ? (long long)ldexp(s, 52 - e_cur) : -1;
+            const bool ok = (sf == 1) && (S >= 0) && ((int)ee == e_cur);
+            const unsigned long long bad_mask = ~__ballot(ok);
+            int stop = bad_mask ? (int)__builtin_ctzll(bad_mask) : 64;
+            TD inc = {ok ? a0 : 0, ok ? a1 : 0};
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                TD t2;
+                t2.a0 = __shfl_up(inc.a0, o, 64);
+                t2.a1 = __shfl_up(inc.a1, o, 64);
+                if (lane >= o) inc = td_compose(t2, inc);
+            }
+            const long long S_out = S + ((S & 1) ? inc.a1 : inc.a0);
+            long long ex0 = __shfl_up(inc.a0, 1, 64), ex1 = __shfl_up(inc.a1, 1, 64);
+            if (lane == 0) ex0 = ex1 = 0;
+            const long long my_S = S + ((S & 1) ? ex1 : ex0);
+            const unsigned long long ovf_mask = __ballot(S_out >= TWO53_LL);
+            const int first_ovf = ovf_mask ? (int)__builtin_ctzll(ovf_mask) : 64;
+            stop = stop < first_ovf ? stop : first_ovf;
+            const double my_s = ldexp((double)my_S, e_cur - 52);
+            const long long S_end = stop > 0 ? __shfl(S_out, stop - 1, 64) : S;
+            const double ss = (stop > 0) ? ldexp((double)S_end, e_cur - 52) : s;
+            if (lane < stop) tile_s[my_t] = my_s;
+            if (lane == 0) {
+                sh_walk_t = t + stop;
+                sh_walk_s = ss;
+            }
+        }
+        __syncthreads();
+        const bool advanced_full = (sh_walk_t == t + 64);
+        t = sh_walk_t;
+        s = sh_walk_s;
+        __syncthreads();
+        if (advanced_full) continue;
+        if (t >= n_tiles) break;
+        const long long* rec = sh_rec + ASMC_CDF_REC * (t - chunk0);
+        if (threadIdx.x == 0) {
+            int ok = 0;
+            if (rec[3] == 2) {  // predicted single crossing: O(1) with verification (as in k_exact_chain)
+                const int e = (int)rec[2];
+                const long long b0 = rec[4], b1 = rec[5], nf_c = rec[7];
+                if (s > 0.0 && binade_of(s) == e) {
+                    const long long S = (long long)ldexp(s, 52 - e);
+                    const long long S_A = S + ((S & 1) ? rec[1] : rec[0]);
+                    if (S_A < TWO53_LL && S_A + nf_c >= TWO53_LL) {
+                        const double s_new = ldexp((double)S_A, e - 52) + __longlong_as_double(rec[8]);
+                        if (binade_of(s_new) == e + 1) {
+                            const long long S2 = (long long)ldexp(s_new, 52 - (e + 1));
+                            const long long S_B = S2 + ((S2 & 1) ? b1 : b0);
+                            if (S_B < TWO53_LL) {
+                                tile_s[t] = s;
+                                tile_s2[t] = s_new;
+                                sh_walk_s = ldexp((double)S_B, e + 1 - 52);
+                                ok = 1;
+                            }
+                        }
+                    }
+                }
+            }
+            sh_split_ok = ok;
+        }
+        __syncthreads();
+        const bool done = sh_split_ok != 0;
+        if (done) s = sh_walk_s;
+        __syncthreads();
+        if (!done) {  // needs the tile's elements: not available here
+            failed = true;
+            break;
+        }
+        t++;
+    }
+    if (threadIdx.x == 0) {
+        *total_out = s;
+        *fail_out = failed ? 1.0 : 0.0;
+    }
+}
+
+// out[4] = {fail, global total, (exact sum entering this shard) / total, cdf of this shard's last element}: the last two
+// are the shard's slice [lo, hi) of the normalised global cdf, formed with the same division the write pass applies
+__global__ void k_shard_edges(const double* __restrict__ total, const double* __restrict__ fail,
+                              const double* __restrict__ s_in, const double* __restrict__ cdf_last,
+                              double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = *fail;
+        out[1] = *total;
+        out[2] = *s_in / *total;
+        out[3] = *cdf_last;
+    }
+}
+
+// ---- ordered range selection: out = u[(lo <= u) & (u < hi)] in index order (count / scan / scatter) ------------------
+__global__ __launch_bounds__(ASMC_BLOCK) void k_range_count(int64_t n, const double* __restrict__ u,
+                                                           const double* __restrict__ lohi,
+                                                           long long* __restrict__ tiles) {
+    const double lo = lohi[0], hi = lohi[1];
+    const int64_t base = (int64_t)blockIdx.x * ASMC_SCAN_TILE + (int64_t)threadIdx.x * (ASMC_SCAN_TILE / ASMC_BLOCK);
+    long long c = 0;
+#pragma unroll
+    for (int j = 0; j < ASMC_SCAN_TILE / ASMC_BLOCK; j++)
+        if (base + j < n) {
+            const double v = u[base + j];
+            c += (v >= lo && v < hi) ? 1 : 0;
+        }
+    __shared__ long long s_p[ASMC_BLOCK / 64];
+    c = wave_sum_ll(c);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tiles[blockIdx.x] = s_p[0] + s_p[1] + s_p[2] + s_p[3];
+}
+
 // Pass E: write the flag-1 / flag-2 tiles from their exact incoming sums (integer scans on the tile's grids).
 __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, const double* __restrict__ w,
                                                                 double* __restrict__ cdf,
@@ -472,10 +651,11 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, cons
                                                                 const long long* __restrict__ tile_split,
                                                                 const double* __restrict__ tile_s,
                                                                 const double* __restrict__ tile_s2,
-                                                                const double* __restrict__ norm_ptr) {
+                                                                const double* __restrict__ norm_ptr,
+                                                                const long long* __restrict__ rec_pk) {
     __shared__ TD sh_td[XT_THREADS / 64 + 1];
     const int64_t t = blockIdx.x;
-    const long long flag = tile_info[4 * t + 3];
+    const long long flag = rec_pk ? rec_pk[ASMC_CDF_REC * t + 3] : tile_info[4 * t + 3];
     // norm_ptr != NULL: the caller wants cdf / cdf[-1] (numpy's `cdf /= cdf[-1]`); the total is known by now, so
     // the division rides on this pass (tiles the chain wrote element-wise are divided in place)
     const double norm = norm_ptr ? *norm_ptr : 1.0;
@@ -488,8 +668,8 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, cons
         }
         return;
     }
-    const int e = (int)tile_info[4 * t + 2];
-    const int c = flag == 2 ? (int)tile_split[4 * t + 2] : ASMC_SCAN_TILE;
+    const int e = (int)(rec_pk ? rec_pk[ASMC_CDF_REC * t + 2] : tile_info[4 * t + 2]);
+    const int c = flag == 2 ? (int)(rec_pk ? rec_pk[ASMC_CDF_REC * t + 6] : tile_split[4 * t + 2]) : ASMC_SCAN_TILE;
     const int64_t base = t * ASMC_SCAN_TILE + (int64_t)threadIdx.x * XT_E;
     double wv[XT_E];
 #pragma unroll
@@ -1045,6 +1225,39 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_compact_scatter(
     }
 }
 
+
+__global__ __launch_bounds__(ASMC_BLOCK) void k_range_scatter(int64_t n, const double* __restrict__ u,
+                                                             const double* __restrict__ lohi,
+                                                             const long long* __restrict__ tiles,
+                                                             double* __restrict__ out) {
+    const double lo = lohi[0], hi = lohi[1];
+    const int64_t base = (int64_t)blockIdx.x * ASMC_SCAN_TILE + (int64_t)threadIdx.x * SC_E;
+    double v[SC_E];
+    bool ok[SC_E];
+    long long c = 0;
+#pragma unroll
+    for (int j = 0; j < SC_E; j++) {
+        v[j] = (base + j < n) ? u[base + j] : -1.0;
+        ok[j] = (base + j < n) && v[j] >= lo && v[j] < hi;
+        c += ok[j] ? 1 : 0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        long long t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __shared__ long long s_wave[ASMC_BLOCK / 64];
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    long long dst = tiles[blockIdx.x] + (inc - c);
+    for (int k = 0; k < wave; k++) dst += s_wave[k];
+#pragma unroll
+    for (int j = 0; j < SC_E; j++)
+        if (ok[j]) out[dst++] = v[j];
+}
+
 // =============================================================================================
 // host entry points
 // =============================================================================================
@@ -1071,14 +1284,14 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_exact_tile_td_launch", k_exact_tile_td_launch, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w,
                            (const double*)ctx->d_tiles, (const double*)d_approx_total, n_tiles, ctx->d_tiles_i, d_split,
-                           d_tile_s2, cdf, carry_in, d_tile_s);
+                           d_tile_s2, cdf, carry_in, d_tile_s, 1, (long long*)nullptr);
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_exact_chain", k_exact_chain, dim3(1), dim3(XT_THREADS), 0, st, n, w, cdf, carry_in, n_tiles,
                            ctx->d_tiles_i, (const long long*)d_split, d_tile_s, d_tile_s2, d_total);
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_exact_tile_write", k_exact_tile_write, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w, cdf,
                            (const long long*)ctx->d_tiles_i, (const long long*)d_split, (const double*)d_tile_s,
-                           (const double*)d_tile_s2, d_norm);
+                           (const double*)d_tile_s2, d_norm, (const long long*)nullptr);
         ASMC_LAUNCH_CHECK();
     } else if (mode == ASMC_CDF_FAST) {
         const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
@@ -1098,6 +1311,75 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
         ASMC_HIP(hipStreamSynchronize(st));
         *total_host = ctx->h_pinned[0];
     }
+    return ASMC_OK;
+}
+
+int64_t asmc_cdf_shard_tiles(int64_t n) { return n <= 0 ? 0 : (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE; }
+
+int asmc_cdf_shard_records(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, double approx_carry, int first_rank,
+                           int64_t* rec_dev, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && w && cdf && rec_dev, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+    ASMC_REQUIRE(approx_carry >= 0.0, "approx_carry must be non-negative");
+    hipStream_t st = as_stream(stream);
+    const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+    double* d_approx_total = ctx->d_small + 1025;
+    ASMC_LAUNCH(ctx, st, "k_tile_sum", k_tile_sum, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w, ctx->d_tiles);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles,
+                first_rank ? 0.0 : approx_carry, d_approx_total);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_exact_tile_td_launch", k_exact_tile_td_launch, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w,
+                (const double*)ctx->d_tiles, (const double*)d_approx_total, n_tiles, (long long*)nullptr, (long long*)nullptr,
+                (double*)nullptr, cdf, 0.0, (double*)nullptr, first_rank ? 1 : 0, (long long*)rec_dev);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_cdf_shard_finish(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, const int64_t* recs_all_dev,
+                          int64_t n_tiles_total, int64_t tile0, double* work_dev, double* out_dev, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && w && cdf && recs_all_dev && work_dev && out_dev, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+    const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+    ASMC_REQUIRE(tile0 >= 0 && tile0 + n_tiles <= n_tiles_total, "this shard's tiles do not fit the global tile list");
+    hipStream_t st = as_stream(stream);
+    double* tile_s = work_dev;
+    double* tile_s2 = work_dev + n_tiles_total;
+    double* d_total = ctx->d_small + 1024;
+    double* d_fail = ctx->d_small + 1026;
+    ASMC_LAUNCH(ctx, st, "k_exact_chain_pk", k_exact_chain_pk, dim3(1), dim3(XT_THREADS), 0, st, n_tiles_total,
+                (const long long*)recs_all_dev, tile_s, tile_s2, d_total, d_fail);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_exact_tile_write", k_exact_tile_write, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w, cdf,
+                (const long long*)nullptr, (const long long*)nullptr, (const double*)(tile_s + tile0),
+                (const double*)(tile_s2 + tile0), (const double*)d_total,
+                (const long long*)recs_all_dev + ASMC_CDF_REC * tile0);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_shard_edges", k_shard_edges, dim3(1), dim3(64), 0, st, (const double*)d_total, (const double*)d_fail,
+                (const double*)(tile_s + tile0), (const double*)(cdf + n - 1), out_dev);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_select_range(asmc_ctx* ctx, int64_t n, const double* u_dev, const double* lohi_dev, double* out_dev,
+                      int64_t* count_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && u_dev && lohi_dev && out_dev && count_host, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+    hipStream_t st = as_stream(stream);
+    const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+    long long* d_total = ctx->d_tiles_i + ctx->n_tiles_max * 8;
+    ASMC_LAUNCH(ctx, st, "k_range_count", k_range_count, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, u_dev, lohi_dev,
+                ctx->d_tiles_i);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_scan_tiles_ll", k_scan_tiles_ll, dim3(1), dim3(64), 0, st, n_tiles, ctx->d_tiles_i, d_total);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_range_scatter", k_range_scatter, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, u_dev, lohi_dev,
+                (const long long*)ctx->d_tiles_i, out_dev);
+    ASMC_LAUNCH_CHECK();
+    long long* h = reinterpret_cast<long long*>(ctx->h_pinned);
+    ASMC_HIP(hipMemcpyAsync(h, d_total, sizeof(long long), hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    *count_host = (int64_t)h[0];
     return ASMC_OK;
 }
 

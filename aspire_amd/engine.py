@@ -351,6 +351,38 @@ class HipEngine:
                                 carry_in, ctypes.byref(total) if want_total else None, self._stream), "asmc_cdf")
         return out, (total.value if want_total else None)
 
+    # ---- sharded exact cdf: this rank's slice of the GLOBAL sequential cumsum (include/asmc.h asmc_cdf_shard_*) ------
+    def cdf_shard_records(self, w: torch.Tensor, approx_carry: float, first_rank: bool):
+        """(cdf buffer, tile records [n_tiles, ASMC_CDF_REC] int64): the passes that need only an approximate
+        incoming sum.  No synchronisation."""
+        assert w.dtype == torch.float64 and w.is_contiguous()
+        n_tiles = int(self.lib.asmc_cdf_shard_tiles(w.numel()))
+        cdf = torch.empty_like(w)
+        rec = torch.empty((n_tiles, _lib.ASMC_CDF_REC), dtype=torch.int64, device=self.device)
+        check(self.lib.asmc_cdf_shard_records(self._ctx, w.numel(), _dptr(w), _dptr(cdf), float(approx_carry), int(first_rank),
+                                              _dptr(rec), self._stream), "asmc_cdf_shard_records")
+        return cdf, rec
+
+    def cdf_shard_finish(self, w: torch.Tensor, cdf: torch.Tensor, recs_all: torch.Tensor, tile0: int) -> torch.Tensor:
+        """Chain over ALL ranks' tile records + write of this rank's slice (divided by the global total) into `cdf`.
+        Returns the device vector {fail, total, lo, hi}.  No synchronisation."""
+        assert recs_all.dtype == torch.int64 and recs_all.is_contiguous() and recs_all.shape[1] == _lib.ASMC_CDF_REC
+        n_total = int(recs_all.shape[0])
+        work = self.empty(2 * n_total)
+        out = self.empty(4)
+        check(self.lib.asmc_cdf_shard_finish(self._ctx, w.numel(), _dptr(w), _dptr(cdf), _dptr(recs_all), n_total, int(tile0),
+                                             _dptr(work), _dptr(out), self._stream), "asmc_cdf_shard_finish")
+        return out
+
+    def select_range(self, u: torch.Tensor, lohi: torch.Tensor) -> torch.Tensor:
+        """u[(lo <= u) & (u < hi)] in index order; lohi = device tensor {lo, hi}.  Synchronises (the count)."""
+        assert u.dtype == torch.float64 and u.is_contiguous() and lohi.dtype == torch.float64 and lohi.numel() >= 2
+        out = torch.empty_like(u)
+        cnt = ctypes.c_int64(0)
+        check(self.lib.asmc_select_range(self._ctx, u.numel(), _dptr(u), _dptr(lohi), _dptr(out), ctypes.byref(cnt),
+                                         self._stream), "asmc_select_range")
+        return out[: int(cnt.value)]
+
     def cdf_normalize_last(self, cdf: torch.Tensor) -> torch.Tensor:
         check(self.lib.asmc_cdf_normalize_last(self._ctx, cdf.numel(), _dptr(cdf), self._stream), "asmc_cdf_normalize_last")
         return cdf

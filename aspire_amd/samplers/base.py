@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import logging
 import pickle
+from pathlib import Path
 from typing import Any, Callable
 
 import numpy as np
@@ -159,42 +160,107 @@ class Sampler:
         return config
 
     def _checkpoint_extra_state(self) -> dict:
+        """samplers/base.py:150-152."""
         return {}
 
-    def build_checkpoint_state(self, samples, iteration: int = 0, meta: dict | None = None) -> dict:
-        """samplers/base.py:158-178: same keys."""
+    def _restore_extra_state(self, state: dict) -> None:
+        """samplers/base.py:154-156."""
+        _ = state
+
+    def build_checkpoint_state(self, samples, iteration: int | None = None, meta: dict | None = None,
+                               include_sample_calls: str | bool = "last") -> dict:
+        """samplers/base.py:158-178: same keys, same order."""
         state = {"sampler": self.__class__.__name__, "iteration": iteration, "samples": samples,
-                 "config": self.config_dict(include_sample_calls=False),
+                 "config": self.config_dict(include_sample_calls=include_sample_calls),
                  "parameters": self.parameters, "meta": meta or {}}
         state.update(self._checkpoint_extra_state())
-        self._last_checkpoint_state = state
         return state
+
+    def serialize_checkpoint(self, state: dict, protocol: int | None = None) -> bytes:
+        """samplers/base.py:180-187."""
+        return pickle.dumps(state, protocol=pickle.HIGHEST_PROTOCOL if protocol is None else int(protocol))
+
+    def default_checkpoint_callback(self, state: dict) -> None:
+        """samplers/base.py:189-192: keep the latest checkpoint (state + pickled bytes) on the sampler."""
+        self._last_checkpoint_state = state
+        self._last_checkpoint_bytes = self.serialize_checkpoint(state)
+
+    def _rank_path(self, file_path) -> Path:
+        """Sharded runs: every rank checkpoints its own shard into its own file (`name.rank<r>.ext`)."""
+        file_path = Path(file_path)
+        if self.comm.world == 1:
+            return file_path
+        return file_path.with_name(f"{file_path.stem}.rank{self.comm.rank}{file_path.suffix}")
+
+    def default_file_checkpoint_callback(self, file_path: str | Path | None):
+        """samplers/base.py:194-216: overwrite `/checkpoint/state` of an HDF5 file (needs h5py); additionally a `.pkl`
+        path writes the same pickled bytes to a plain file (h5py is not part of every image)."""
+        if file_path is None:
+            return self.default_checkpoint_callback
+        file_path = self._rank_path(file_path)
+        lower = file_path.name.lower()
+        if not lower.endswith((".h5", ".hdf5", ".pkl", ".pickle")):
+            raise ValueError("Checkpoint file must be an HDF5 file (.h5 or .hdf5) or a pickle file (.pkl).")
+
+        def _callback(state: dict) -> None:
+            if lower.endswith((".h5", ".hdf5")):
+                from ..io import open_h5
+
+                with open_h5(file_path, "a") as h5_file:
+                    self.save_checkpoint_to_hdf(state, h5_file, path="checkpoint", dsetname="state")
+                self.default_checkpoint_callback(state)
+            else:
+                self.default_checkpoint_callback(state)
+                with open(file_path, "wb") as fp:
+                    fp.write(self._last_checkpoint_bytes)
+
+        return _callback
+
+    def save_checkpoint_to_hdf(self, state: dict, h5_file, path: str = "sampler_checkpoints", dsetname: str | None = None,
+                               protocol: int | None = None) -> None:
+        """samplers/base.py:218-236: the state as ONE pickled `S1` byte dataset `<path>/<dsetname>`; `h5_file` is an open
+        h5py.File or anything with its group protocol."""
+        from ..io import dump_state
+
+        if dsetname is None:
+            dsetname = f"iter_{state.get('iteration', 'unknown')}"
+        dump_state(state, h5_file, path=path, dsetname=dsetname, protocol=protocol or pickle.HIGHEST_PROTOCOL)
+
+    def load_checkpoint_from_file(self, file_path: str | Path, h5_path: str = "checkpoint", dsetname: str = "state") -> dict:
+        """samplers/base.py:238-253."""
+        file_path = Path(file_path)
+        if file_path.name.lower().endswith((".h5", ".hdf5")):
+            from ..io import load_state, open_h5
+
+            with open_h5(file_path, "r") as h5_file:
+                return load_state(h5_file, h5_path, dsetname)
+        with open(file_path, "rb") as f:
+            return pickle.loads(f.read())
+
+    def restore_from_checkpoint(self, source):
+        """samplers/base.py:255-276."""
+        if isinstance(source, (str, Path)):
+            p = Path(source)
+            state = self.load_checkpoint_from_file(p if p.exists() else self._rank_path(p))
+        elif isinstance(source, (bytes, bytearray)):
+            state = pickle.loads(source)
+        elif isinstance(source, dict):
+            state = source
+        else:
+            raise TypeError("Unsupported checkpoint source type.")
+        samples_saved = state.get("samples")
+        if samples_saved is None:
+            raise ValueError("Checkpoint missing samples.")
+        self._restore_extra_state(state)
+        return samples_saved, state
 
     @property
     def last_checkpoint_state(self):
         return self._last_checkpoint_state
 
-    def default_file_checkpoint_callback(self, file_path: str | None):
-        """Pickle-file stand-in for the reference's HDF5 `/checkpoint/state` blob
-        (samplers/base.py:194-252); h5py is not available in this image."""
-        if file_path is None:
-            return None
-
-        def _cb(state: dict):
-            with open(file_path, "wb") as fp:
-                pickle.dump(state, fp)
-
-        return _cb
-
-    def restore_from_checkpoint(self, source):
-        if isinstance(source, dict):
-            state = source
-        elif isinstance(source, (bytes, bytearray)):
-            state = pickle.loads(source)
-        else:
-            with open(source, "rb") as fp:
-                state = pickle.load(fp)
-        return state["samples"], state
+    @property
+    def last_checkpoint_bytes(self):
+        return self._last_checkpoint_bytes
 
 
 class MCMCSampler(Sampler):

@@ -63,15 +63,22 @@ class SMCSampler(MCMCSampler):
         return samples._n_global()
 
     def _gid0(self, samples) -> int:
-        """First global particle id of this rank's shard (keys the per-particle noise streams).  Equal shards: the
-        global particle index, so a sharded run in slot layout draws the same noise as a single-rank run.  Ragged
-        shards (owner layout): disjoint id ranges per rank."""
-        if samples.__dict__.get("ragged"):
-            return self.comm.rank << 40
+        """Global index of this rank's first particle (keys the per-particle noise streams): a sharded run in slot
+        layout draws the same noise as a single-rank run; ragged shards (owner layout) count the rows of the lower
+        ranks, so the id ranges stay disjoint and contiguous."""
+        if hasattr(samples, "gid0"):
+            return samples.gid0()
         return self.comm.rank * len(samples.x)
 
     def _stats(self, samples: SMCSamples, betas) -> list[smc_math.Stats]:
         return samples.weight_stats(betas)
+
+    def _global_counts(self, local_counts) -> list[int]:
+        """Element-wise sum of small integer censuses over the ranks (NaN guards must agree on every rank)."""
+        a = np.asarray(local_counts, dtype=np.int64)
+        if self.comm.world == 1:
+            return [int(v) for v in a]
+        return [int(v) for v in self.comm.all_gather_i64(a).sum(axis=0)]
 
     def determine_beta(self, samples: SMCSamples, beta: float, beta_step: float, min_beta_step: float,
                        max_beta_step: float = 1.0, beta_tolerance: float = DEFAULT_BETA_TOLERANCE):
@@ -121,7 +128,7 @@ class SMCSampler(MCMCSampler):
         s = SMCSamples(x=x, xp=torch, beta=beta, parameters=self.parameters, engine=self.engine, comm=self.comm)
         s.log_likelihood, s.log_prior, s.log_q = ll, lp, lq
         if like is not None:  # shard bookkeeping of the population these particles came from
-            for k in ("n_global", "ragged"):
+            for k in ("n_global", "ragged", "shard_counts"):
                 if k in like.__dict__:
                     setattr(s, k, like.__dict__[k])
         return s
@@ -148,6 +155,13 @@ class SMCSampler(MCMCSampler):
             self.engine.ensure_capacity(max(n_samples if comm.world > 1 else n_local, nf), self.dims)
         if hasattr(self.prior_flow, "gid0"):
             self.prior_flow.gid0 = comm.rank * n_local
+        # sharded runs: every rank walks the same resampling draws and draws the same mutation seeds, so the ranks'
+        # generators must be in the same state - rank 0's is handed to everyone (a no-op for one rank)
+        self.rng = smc_math.sync_rng(comm, self.rng)
+        if getattr(self.prior_flow, "seed_from_rng", False) and resume_from is None:
+            # the proposal's own draw stream follows the run's generator (in the reference flow sampling is stochastic per
+            # run); drawn after the synchronisation, so every rank gets the same seed and particle ids keep shards apart
+            self.prior_flow.seed = int(self.rng.integers(0, 2**63 - 1, dtype=np.int64))
         resumed = resume_from is not None
         if resumed:
             samples, beta, iterations = self.restore_from_checkpoint(resume_from)
@@ -164,9 +178,11 @@ class SMCSampler(MCMCSampler):
             self.history.sample_history.append(samples.to_numpy())
 
         e = self.engine
-        for name, arr in (("Log proposal", samples.log_q), ("Log prior", samples.log_prior),
-                          ("Log likelihood", samples.log_likelihood)):
-            if e.count_nonfinite(arr)[0]:
+        # one exchange for the three censuses: every rank raises (or none does), nobody is left waiting in a collective
+        nans = self._global_counts([e.count_nonfinite(arr)[0] for arr in (samples.log_q, samples.log_prior,
+                                                                           samples.log_likelihood)])
+        for name, n_nan in zip(("Log proposal", "Log prior", "Log likelihood"), nans):
+            if n_nan:
                 raise ValueError(f"{name} contains NaN values")
 
         self.sampler_kwargs = getattr(self, "sampler_kwargs", None) or {}
@@ -258,9 +274,10 @@ class SMCSampler(MCMCSampler):
 
         if n_final_samples is not None and self._n_global(samples) != n_final_samples:
             logger.info(f"Generating {n_final_samples} final samples")
-            for name, arr in (("log likelihood", samples.log_likelihood), ("log prior", samples.log_prior),
-                              ("log proposal", samples.log_q)):
-                if sum(e.count_nonfinite(arr)):
+            bad = self._global_counts([sum(e.count_nonfinite(arr)) for arr in (samples.log_likelihood, samples.log_prior,
+                                                                                  samples.log_q)])
+            for name, n_bad in zip(("log likelihood", "log prior", "log proposal"), bad):
+                if n_bad:
                     logger.warning(f"Final samples contain non-finite {name} values")
             final_samples = samples.resample(1.0, n_samples=n_final_samples, rng=self.rng,
                                              resample_mode=self.resample_mode,
@@ -296,15 +313,23 @@ class SMCSampler(MCMCSampler):
 
     # ---- checkpoint glue (smc/base.py:521-562) -----------------------------------------------
     def build_checkpoint_state(self, samples: SMCSamples, iteration: int, beta: float) -> dict:
-        return super().build_checkpoint_state(samples.to_numpy(), iteration, meta={"beta": beta})
+        """smc/base.py:521-530.  Sharded runs: every rank checkpoints ITS shard; the shard bookkeeping (rows per rank,
+        population size, rank, world) travels in `meta` next to the reference's `beta`."""
+        meta = {"beta": beta}
+        if self.comm.world > 1:
+            meta.update(rank=self.comm.rank, world=self.comm.world, n_global=samples._n_global(),
+                        shard_counts=samples.shard_counts_list())
+        return super().build_checkpoint_state(samples.to_numpy(), iteration, meta=meta)
 
     def _checkpoint_extra_state(self) -> dict:
+        """smc/base.py:532-544 (+ `pcn_state`: step size / step counter / nu of this repository's mutation kernel)."""
         rng_state = self.rng.bit_generator.state if hasattr(self.rng, "bit_generator") else None
         return {"history": copy.deepcopy(self.history), "rng_state": rng_state,
-                "sampler_kwargs": copy.deepcopy(getattr(self, "sampler_kwargs", None)),
+                "sampler_kwargs": getattr(self, "sampler_kwargs", None),
                 "pcn_state": copy.deepcopy(getattr(self, "_pcn_state", None))}
 
     def restore_from_checkpoint(self, source):
+        """smc/base.py:546-562."""
         samples, state = super().restore_from_checkpoint(source)
         meta = state.get("meta", {}) if isinstance(state, dict) else {}
         beta = meta.get("beta", None) if isinstance(meta, dict) else None
@@ -317,9 +342,16 @@ class SMCSampler(MCMCSampler):
             self.rng.bit_generator.state = rng_state
         if state.get("pcn_state") is not None:
             self._pcn_state = state["pcn_state"]
+        world = int(meta.get("world", 1)) if isinstance(meta, dict) else 1
+        if world != self.comm.world or (world > 1 and int(meta.get("rank", 0)) != self.comm.rank):
+            raise ValueError(f"checkpoint was written by rank {meta.get('rank', 0)} of {world}, this is rank "
+                             f"{self.comm.rank} of {self.comm.world}: a sharded run resumes with the same layout")
         e = self.engine
         s = self._wrap(e.asarray(samples.x, dtype=self.x_torch_dtype), e.asarray(samples.log_likelihood),
                        e.asarray(samples.log_prior), e.asarray(samples.log_q), beta)
+        if world > 1:
+            s.n_global, s.shard_counts = int(meta["n_global"]), [int(c) for c in meta["shard_counts"]]
+            s.ragged = len(set(s.shard_counts)) > 1
         return s, beta, iteration
 
 
@@ -509,7 +541,7 @@ class HipSMC(SMCSampler):
         self.history.mcmc_acceptance.append(float(np.mean(acc_rates)))
         self.history.mcmc_step_size.append(float(st["rho"]))
         x_new = e.asarray(T.inverse(z)[0], dtype=x.dtype)
-        if e.count_nonfinite(lq)[0]:
+        if self._global_counts([e.count_nonfinite(lq)[0]])[0]:
             raise ValueError("Log proposal contains NaN values")
         return self._wrap(x_new, ll, lp, lq, beta, like=particles)
 
@@ -662,7 +694,7 @@ class HipSMC(SMCSampler):
         st["step"] = step0 + n_steps
         self.history.mcmc_acceptance.append(float(np.mean(acc_rates)))
         self.history.mcmc_step_size.append(float(st["rho"]))
-        if e.count_nonfinite(lq)[0]:
+        if self._global_counts([e.count_nonfinite(lq)[0]])[0]:
             raise ValueError("Log proposal contains NaN values")
         return self._wrap(x, ll, lp, lq, beta, like=particles)
 

@@ -153,6 +153,30 @@ class BaseSamples:
         known = {f.name for f in fields(cls) if f.init}
         return cls(x=x, parameters=parameters, **{k: v for k, v in dictionary.items() if k in known})
 
+    def _encode_for_hdf5(self, flat: bool = True) -> dict:
+        """samples.py:282-287."""
+        d = self.to_numpy().to_dict(flat=flat)
+        d.pop("device", None)
+        d["dtype"] = str(np.dtype(to_numpy(self.x).dtype))
+        d["xp"] = "numpy"
+        return d
+
+    def save(self, h5_file, path: str = "samples", flat: bool = False):
+        """samples.py:289-305: converted to numpy, flattened into datasets under the group `path`."""
+        from .io import recursively_save_to_h5_file
+
+        recursively_save_to_h5_file(h5_file, path, self._encode_for_hdf5(flat=flat))
+
+    @classmethod
+    def load(cls, h5_file, path: str = "samples"):
+        """samples.py:307-322."""
+        from .io import load_from_h5_file
+
+        d = load_from_h5_file(h5_file, path)
+        d["xp"] = np
+        d["dtype"] = np.dtype(d["dtype"]) if isinstance(d.get("dtype"), str) else None
+        return cls.from_dict(d)
+
     def to_dataframe(self, include: list | None = None):
         """samples.py:209-243: parameters as columns plus log_likelihood / log_prior / log_q (NaN when missing)."""
         import pandas as pd
@@ -352,7 +376,7 @@ class SMCSamples(BaseSamples):
 
     def _n_global(self) -> int:
         # sharded runs in owner layout have ragged shards: the population size travels with the object then
-        return self.__dict__.get("n_global") or len(self.x) * self._comm().world
+        return self.__dict__.get("n_global") or int(sum(self.shard_counts_list()))
 
     def _from_device(self, t):
         if is_torch_namespace(self.xp):
@@ -443,24 +467,26 @@ class SMCSamples(BaseSamples):
         st = None if uniform else self._stats(beta)
         var = None
 
-        def wrap(xo, llo, lpo, lqo):
+        def wrap(xo, llo, lpo, lqo, counts=None):
             out = self.__class__(x=self._from_device(xo), log_likelihood=self._from_device(llo),
                                  log_prior=self._from_device(lpo), log_q=self._from_device(lqo), beta=beta,
                                  dtype=self.dtype, parameters=self.parameters, xp=self.xp, engine=self.engine,
                                  comm=self.comm)
             if comm.world > 1:
                 out.n_global = int(n_samples)
+                out.shard_counts = [int(c) for c in counts]
+                out.ragged = len(set(out.shard_counts)) > 1
             return (out, var) if want_variance else out
 
-        ragged = bool(self.__dict__.get("ragged"))  # set on every rank alike (owner layout produced this population)
+        counts = self.shard_counts_list()
+        ragged = len(set(counts)) > 1
 
         if shard_layout == "owner" and smc_math.owner_layout_ok(e, comm, rng, resample_method, uniform):
-            idx, var, s1p = smc_math.resample_owner(e, comm, ll, lp, lq, float(self.beta), float(beta), int(n_samples), rng,
-                                                    mode=resample_mode, st=st)
+            idx, var, s1p, new_counts = smc_math.resample_owner(
+                e, comm, ll, lp, lq, float(self.beta), float(beta), int(n_samples), rng, mode=resample_mode, st=st,
+                counts=counts, method=resample_method, uniform_weights=uniform)
             if idx is not None:
-                res = wrap(*e.gather(idx, x, ll, lp, lq))
-                (res[0] if want_variance else res).ragged = True
-                return res
+                return wrap(*e.gather(idx, x, ll, lp, lq), counts=new_counts)
             self.remember_stats(beta, None, s1p)  # shares too uneven: fall through to the slot layout, which rebalances
         if want_variance and var is None and not uniform:
             var, s1p = smc_math.evidence_variance_and_lse(e, comm, ll, lp, lq, float(self.beta), float(beta), st)
@@ -470,7 +496,22 @@ class SMCSamples(BaseSamples):
         idx, _ = smc_math.resample_indices(e, comm, ll, lp, lq, float(self.beta), float(beta), int(n_samples), rng,
                                            mode=resample_mode, method=resample_method, uniform_weights=uniform,
                                            st=st, s1p=self.__dict__.get("_ws1p", {}).get(float(beta)))
-        return wrap(*gather_global(e, comm, idx, x, ll, lp, lq))
+        per = -(-int(n_samples) // comm.world)  # output slots per rank (smc_math.resample_indices)
+        slot_counts = [max(0, min(per, int(n_samples) - r * per)) for r in range(comm.world)]
+        return wrap(*gather_global(e, comm, idx, x, ll, lp, lq), counts=slot_counts)
+
+    def shard_counts_list(self) -> list:
+        """Rows per rank of this (possibly sharded) population, in rank order."""
+        comm = self._comm()
+        c = self.__dict__.get("shard_counts")
+        if c is not None and len(c) == comm.world:
+            return [int(v) for v in c]
+        return [len(self.x)] * comm.world
+
+    def gid0(self) -> int:
+        """Global index of this rank's first particle (keys the per-particle noise streams)."""
+        comm = self._comm()
+        return int(sum(self.shard_counts_list()[:comm.rank]))
 
     def __str__(self):
         out = super().__str__()

@@ -355,58 +355,134 @@ def find_beta_sharded(engine, comm, ll, lp, lq, beta0: float, target_eff: float,
     return out
 
 
-def resample_owner(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out: int, rng, *, mode: str = "exact",
-                   st: Stats):
-    """Sharded multinomial resampling that keeps every offspring on its ancestor's rank.
+def _normalized_cdf(engine, w, mode: str):
+    """cumsum(w) / cumsum(w)[-1] of one array (numpy's cdf inside Generator.choice)."""
+    if hasattr(engine, "cdf_normalize_last"):  # divisor stays on the device, the division rides on the scan
+        return engine.cdf(w, mode, 0.0, want_total=False, normalize=True)[0]
+    cdf, last = engine.cdf(w, mode, 0.0)
+    engine.cdf_normalize(cdf, last)
+    return cdf
 
-    The reference draws n_out ancestors i.i.d. from the normalised weights (samples.py:1276-1278).  Here the global cdf
-    is two-level: rank totals t_r in rank order, then each rank's own exact cumulative sum.  Every rank walks the same
-    n_out PCG64 draws, keeps those inside its slice [C_r, C_{r+1}) / T and looks them up in its local cdf, so no
-    particle row ever crosses a link; shard sizes become ragged (n_out * t_r / T in expectation, +-0.1 % at 1M).
-    One all-gather carries the rank totals together with the evidence-variance partials (samples.py:1230-1242).
-    Returns (idx_local or None, variance, s1p): idx_local is None when a rank's weight share is outside
+
+def global_cdf_slice_replicated(engine, comm, w, counts, mode: str = "exact"):
+    """This rank's slice of the normalised GLOBAL cdf by brute force: all-gather of the weights (8 B/particle), the same
+    scan over all N on every rank, slice.  Returns (cdf_slice, edges) with edges = device tensor {fail = 0, 0, lo, hi}.
+    Used by `fast` mode, by engines without tile records (the CPU test double) and as the fallback of
+    `global_cdf_slice` when a tile record fails verification."""
+    import torch
+
+    w_all = comm.all_gather_ragged(w, counts)
+    if hasattr(engine, "ensure_capacity"):
+        engine.ensure_capacity(w_all.numel(), 1)
+    cdf_all = _normalized_cdf(engine, w_all, mode)
+    a = int(sum(counts[:comm.rank]))
+    b = a + int(counts[comm.rank])
+    zero = torch.zeros(1, dtype=cdf_all.dtype, device=cdf_all.device)
+    edges = torch.cat([zero, zero, cdf_all[a - 1:a] if a > 0 else zero, cdf_all[b - 1:b]])
+    return cdf_all[a:b], edges
+
+
+def global_cdf_slice(engine, comm, w, counts, approx_carry: float, mode: str = "exact", force_replicated: bool = False):
+    """This rank's slice of numpy's sequential cumsum over the GLOBAL weight vector, divided by the global total
+    (samples.py:1277-1278 -> Generator.choice), bit for bit, plus the slice's edges {fail, total, lo, hi} on the device.
+    Exact mode: every rank turns its shard into per-tile records from an approximate incoming sum, the records are
+    all-gathered (72 B per 2048 particles) and every rank walks the same verifying chain over all of them
+    (include/asmc.h asmc_cdf_shard_*): no rank waits for another rank's scan."""
+    if force_replicated or mode != "exact" or not hasattr(engine, "cdf_shard_records"):
+        return global_cdf_slice_replicated(engine, comm, w, counts, mode)
+    cdf, rec = engine.cdf_shard_records(w, approx_carry, comm.rank == 0)
+    tiles = [-(-int(c) // 2048) for c in counts]
+    recs_all = comm.all_gather_ragged(rec, tiles).contiguous()
+    edges = engine.cdf_shard_finish(w, cdf, recs_all, int(sum(tiles[:comm.rank])))
+    return cdf, edges
+
+
+def resample_owner(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out: int, rng, *, mode: str = "exact",
+                   st: Stats | None, counts=None, method: str = "multinomial", uniform_weights: bool = False,
+                   force_replicated: bool = False):
+    """Sharded resampling that keeps every offspring on its ancestor's rank and still selects EXACTLY the reference's
+    ancestors (samples.py:1276-1278: `rng.choice(N, n_out, p=w)` = searchsorted(cumsum(w) / cumsum(w)[-1], random(n_out))).
+
+    Every rank holds its slice of the global sequential cdf (`global_cdf_slice`), walks the same n_out draws of the
+    generator (the ranks' generators must be in the same state: `sync_rng`), keeps the draws u with
+    C_r <= u < C_{r+1} - exactly those whose ancestor it owns - in DRAW ORDER, and searches its slice: rank r ends up with
+    the sub-sequence of Generator.choice's index vector that points into its shard.  No particle row crosses a link;
+    shards become ragged (`counts`, the rows per rank, travel with the population).  Collectives: one all-gather of two
+    doubles (second log-sum-exp + evidence-variance partials, samples.py:1230-1242), one of the tile records, one of the
+    kept counts.
+    Returns (idx_local or None, variance, s1p, new_counts): idx_local is None when a rank's weight share is outside
     1/world (1 +- SHARD_IMBALANCE) - the caller then uses the slot layout (`resample_indices` + row exchange), which
     rebalances the shards; every rank takes that decision from the same gathered numbers."""
-    world, n_local = comm.world, ll.numel()
-    mean_u = st.S1 / st.n
-    shift = float((st.m + np.log(st.S1)) - math.log(st.n))
-    mp = st.m + shift
-    # the second log-sum-exp of samples.py:1277 sums to S1 up to rounding and the cdf is divided by its own total
-    # anyway, so the global constant does not need its own collective
-    lse = float(mp + np.log(st.S1))
-    if hasattr(engine, "weights_m2_lse_dev"):
-        rec = engine.empty(4)
-        engine.weights_m2_lse_dev(ll, lp, lq, beta0, beta, st.m, mean_u, shift, mp, rec)
-        w = engine.normalized_weights(ll, lp, lq, beta0, beta, shift, lse)
-        cdf, _ = engine.cdf(w, mode, 0.0, want_total=False, normalize=True)
-        engine.cdf_total_dev(rec[2:])
-        recs = engine.to_numpy(comm.all_gather_tensor(rec)).reshape(world, 4)[:, :3]
+    world, rank, n_local = comm.world, comm.rank, ll.numel()
+    counts = [n_local] * world if counts is None else [int(c) for c in counts]
+    assert counts[rank] == n_local, (counts, rank, n_local)
+    var, s1p = None, None
+    if uniform_weights:
+        # samples.py:1273-1274: log_w = zeros -> w = exp(0 - logsumexp(zeros)) = exp(0 - log N)
+        n_global = int(sum(counts))
+        lse = float(0.0 + np.log(np.float64(n_global)))
+        w = engine.full(n_local, float(np.exp(0.0 - lse)))
+        approx_carry = float(sum(counts[:rank])) / n_global
     else:
-        m2, s1p = engine.weights_m2_lse(ll, lp, lq, beta0, beta, st.m, mean_u, shift, mp)
+        mean_u = st.S1 / st.n
+        shift = float((st.m + np.log(st.S1)) - math.log(st.n))
+        mp = st.m + shift
+        if hasattr(engine, "weights_m2_lse_dev"):
+            rec = engine.empty(2)
+            engine.weights_m2_lse_dev(ll, lp, lq, beta0, beta, st.m, mean_u, shift, mp, rec)
+            parts = engine.to_numpy(comm.all_gather_tensor(rec)).reshape(world, 2)
+        else:
+            parts = comm.all_gather_f64(np.array(engine.weights_m2_lse(ll, lp, lq, beta0, beta, st.m, mean_u, shift, mp)))
+        m2, s1p = float(parts[0, 0]), float(parts[0, 1])
+        for r in range(1, world):  # rank order: the same floats on every rank
+            m2, s1p = m2 + float(parts[r, 0]), s1p + float(parts[r, 1])
+        var_u = m2 / st.n
+        var = float(var_u / (st.n * (mean_u**2))) if mean_u != 0 else float("nan")
+        share = parts[:, 1] / s1p
+        if not (np.all(share * world <= 1.0 + SHARD_IMBALANCE) and np.all(share * world >= 1.0 - SHARD_IMBALANCE)):
+            return None, var, s1p, None
+        lse = float(mp + np.log(s1p))  # second log-sum-exp, over the shifted log-weights (samples.py:1277)
         w = engine.normalized_weights(ll, lp, lq, beta0, beta, shift, lse)
-        cdf, total = engine.cdf(w, mode, 0.0)
-        engine.cdf_normalize(cdf, total)
-        recs = comm.all_gather_f64(np.array([m2, s1p, total]))
-    m2, s1p = float(recs[0, 0]), float(recs[0, 1])
-    for r in range(1, world):
-        m2, s1p = m2 + float(recs[r, 0]), s1p + float(recs[r, 1])
-    var_u = m2 / st.n
-    var = float(var_u / (st.n * (mean_u**2))) if mean_u != 0 else float("nan")
-    edges = np.concatenate([[0.0], np.cumsum(recs[:, 2])])  # C_r: rank totals accumulated in rank order
-    share = recs[:, 2] / edges[-1]
-    if not (np.all(share * world <= 1.0 + SHARD_IMBALANCE) and np.all(share * world >= 1.0 - SHARD_IMBALANCE)):
-        return None, var, s1p
-    lo = 0.0 if comm.rank == 0 else float(edges[comm.rank] / edges[-1])
-    hi = 1.0 if comm.rank == world - 1 else float(edges[comm.rank + 1] / edges[-1])
-    state = pcg64_state(rng)
-    q = engine.pcg64_select(state, int(n_out), lo, hi)
-    rng.bit_generator.advance(int(n_out))
-    if q.numel() == 0:
+        approx_carry = float(np.sum(parts[:rank, 1]) / s1p) if rank > 0 else 0.0
+    # every rank draws ALL n_out uniforms (PCG64: regenerated on the device by jump-ahead, 8 B per draw)
+    u_all = draw_uniforms(engine, rng, int(n_out), 0, int(n_out), method)
+    for attempt in range(2):
+        cdf, edges = global_cdf_slice(engine, comm, w, counts, approx_carry, mode, force_replicated or attempt == 1)
+        u_kept = engine.select_range(u_all, edges[2:4])  # synchronises: everything above is enqueued by now
+        info = comm.all_gather_i64(np.array([u_kept.numel(), int(round(float(edges[0].item())))], dtype=np.int64))
+        if not info[:, 1].any():
+            break
+        if attempt == 1:
+            raise RuntimeError("sharded cdf: the replicated scan reported a failure")
+    new_counts = [int(c) for c in info[:, 0]]
+    if sum(new_counts) != int(n_out):
+        raise RuntimeError(f"owner-layout resampling kept {sum(new_counts)} of {n_out} draws: the ranks' generators are not "
+                           "in the same state (pass the same seeded rng to every rank; HipSMC.sample synchronises it)")
+    if u_kept.numel() == 0:
         raise RuntimeError("owner-layout resampling left this rank without offspring")
-    return engine.search(cdf, q), var, s1p
+    return engine.search(cdf, u_kept), var, s1p, new_counts
+
+
+def sync_rng(comm, rng):
+    """Put every rank's generator into rank 0's state (sharded resampling walks the same draws on every rank; mutation
+    seeds are drawn from it).  PCG64 generators get the exact state words; anything else is re-seeded from an integer
+    that rank 0 draws.  Returns the generator to use."""
+    if comm.world == 1:
+        return rng
+    st = pcg64_state(rng)
+    has = comm.all_gather_i64(np.array([0 if st is None else 1], dtype=np.int64))[:, 0]
+    if has.all():
+        words = comm.all_gather_i64(st.view(np.int64))[0].view(np.uint64)
+        state = rng.bit_generator.state
+        state["state"]["state"] = (int(words[0]) << 64) | int(words[1])
+        state["state"]["inc"] = (int(words[2]) << 64) | int(words[3])
+        state["has_uint32"], state["uinteger"] = 0, 0
+        rng.bit_generator.state = state
+        return rng
+    seed = int(comm.all_gather_i64(np.array([int(rng.integers(0, 2**62))], dtype=np.int64))[0, 0])
+    return np.random.default_rng(seed)
 
 
 def owner_layout_ok(engine, comm, rng, method: str, uniform_weights: bool = False) -> bool:
-    """Owner layout needs the multinomial method on a PCG64 generator (the draws are regenerated on every rank)."""
-    return (comm.world > 1 and method == "multinomial" and not uniform_weights and hasattr(engine, "pcg64_select")
-            and pcg64_state(rng) is not None)
+    """Owner layout: any resampling method, any generator - every rank walks the same draws (`sync_rng`)."""
+    return comm.world > 1 and hasattr(engine, "select_range")

@@ -197,6 +197,11 @@ class OracleEngine:
         cdf /= last
         return cdf
 
+    def select_range(self, u, lohi):
+        """u[(lo <= u) & (u < hi)] in index order (asmc_select_range)."""
+        a, lo, hi = _np(u), float(lohi[0]), float(lohi[1])
+        return torch.from_numpy(a[(a >= lo) & (a < hi)].copy())
+
     def uniforms_pcg64(self, state4, offset, n):
         st = np.array(state4, dtype=np.uint64)
         O.pcg64_advance(st, int(offset))

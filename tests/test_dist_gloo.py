@@ -76,31 +76,48 @@ def _worker(rank, world, port, out_dir, engine_kind="oracle"):
     # ---- owner layout: device-style sharded search, offspring stay on the ancestor's rank ----
     res["fb"] = np.array(smc_math.find_beta_sharded(eng, comm, loc[1], loc[2], loc[3], 0.0, 0.5, 1e-6, n)[:2])
     st01 = smc_math.global_stats(eng, comm, loc[1], loc[2], loc[3], 0.0, [0.1], n)[0]
-    idx, var, _ = smc_math.resample_owner(eng, comm, loc[1], loc[2], loc[3], 0.0, 0.1, n, np.random.default_rng(5), st=st01)
+    idx, var, _, cnt = smc_math.resample_owner(eng, comm, loc[1], loc[2], loc[3], 0.0, 0.1, n, np.random.default_rng(5), st=st01)
     res["own_idx"] = eng.to_numpy(idx) + lo  # global ancestor ids
     res["own_var"] = var
+    res["own_counts"] = np.array(cnt)
+    # the same through the brute-force path (all-gathered weights, replicated scan): must select the same ancestors
+    idx_r, _, _, _ = smc_math.resample_owner(eng, comm, loc[1], loc[2], loc[3], 0.0, 0.1, n, np.random.default_rng(5), st=st01,
+                                             force_replicated=True)
+    res["own_idx_repl"] = eng.to_numpy(idx_r) + lo
+    # opt-in systematic resampling keeps its offspring at home too
+    idx_s, _, _, _ = smc_math.resample_owner(eng, comm, loc[1], loc[2], loc[3], 0.0, 0.1, n, np.random.default_rng(5), st=st01,
+                                             method="systematic")
+    res["own_idx_sys"] = eng.to_numpy(idx_s) + lo
     from aspire_amd.samples import SMCSamples, rebalance_shards
 
     pop = SMCSamples(x=loc[0], log_likelihood=loc[1], log_prior=loc[2], log_q=loc[3], beta=0.0, xp=torch, engine=eng, comm=comm)
     new, var2 = pop.resample(0.1, rng=np.random.default_rng(5), want_variance=True)
     res["own_x"] = eng.to_numpy(new.x)
     res["own_flags"] = np.array([new.n_global, int(new.ragged), var2 == var])
+    res["own_shard_counts"] = np.array(new.shard_counts)
+    res["own_gid0"] = np.array([new.gid0()])
     # a different output size (the sampler's n_final_samples): owner layout hands every draw to exactly one rank
     odd = pop.resample(0.1, n_samples=1001, rng=np.random.default_rng(8))
     res["odd_n"] = np.array([len(odd.x), odd.n_global])
     # ragged shards back to equal ones, global order kept
     xb, llb, _, _ = rebalance_shards(eng, comm, new.x, new.log_likelihood, new.log_prior, new.log_q)
     res["reb_x"], res["reb_ll"], res["own_ll"] = eng.to_numpy(xb), eng.to_numpy(llb), eng.to_numpy(new.log_likelihood)
-    # a second resampling from the ragged population through the slot layout (systematic has no owner form)
-    again = new.resample(0.3, rng=np.random.default_rng(6), resample_method="systematic")
-    res["again_n"] = np.array([len(again.x), int(bool(again.__dict__.get("ragged")))])
+    # a second resampling from the ragged population: owner layout again (ragged in, ragged out) ...
+    again = new.resample(0.3, rng=np.random.default_rng(6))
+    res["again_x"] = eng.to_numpy(again.x)
+    res["again_counts"] = np.array(again.shard_counts)
+    # ... and through the slot layout, which hands back equal shards
+    slots = new.resample(0.3, rng=np.random.default_rng(6), shard_layout="slots")
+    res["again_n"] = np.array([len(slots.x), int(bool(slots.__dict__.get("ragged")))])
+    res["slots_x"] = eng.to_numpy(slots.x)
     # uneven weight shares: rank 1 holds almost all the weight -> every rank falls back to the slot layout
     ll_skew = loc[1] + (40.0 if rank == 1 else 0.0)
     pop2 = SMCSamples(x=loc[0], log_likelihood=ll_skew, log_prior=loc[2], log_q=loc[3], beta=0.0, xp=torch, engine=eng, comm=comm)
     sk = pop2.resample(0.5, rng=np.random.default_rng(7))
     res["skew"] = np.array([len(sk.x), int(bool(sk.__dict__.get("ragged")))])
+    # every rank arrives with a DIFFERENT generator: sample() hands rank 0's state to everyone
     sp2 = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=2.0, engine=eng, seed=3), xp=np,
-                 engine=eng, comm=comm, rng=np.random.default_rng(4))
+                 engine=eng, comm=comm, rng=np.random.default_rng(4 + 100 * rank))
     post2 = sp2.sample(1024, sampler_kwargs=dict(n_steps=3), store_sample_history=False)
     res["own_beta"] = np.array(sp2.history.beta)
     res["own_logz"] = float(post2.log_evidence)
@@ -196,44 +213,53 @@ def test_sharded_beta_search_matches_host_bisection(two_rank_results):
 
 
 def test_owner_layout_resampling(two_rank_results, oracle):
+    """Default sharded layout: every rank holds EXACTLY the sub-sequence of numpy's Generator.choice index vector that
+    points into its shard - same ancestors, same multiplicities, in draw order (samples.py:1277-1278)."""
     from conftest import synth
 
     n = 4096
     x, ll, lp, lq = synth(n, 4, 3)
     r0, r1 = two_rank_results
-    got = np.sort(np.concatenate([r0["own_idx"], r1["own_idx"]]))
-    assert got.size == n  # the rank slices partition [0, 1): every draw is kept by exactly one rank
-    assert r0["own_idx"].max() < n // 2 <= r1["own_idx"].min()  # offspring stay on the ancestor's rank
-    # the two-level cdf differs from numpy's sequential one only by rounding: the same ancestors up to rare ties
-    ref = np.sort(oracle.resample_indices(ll, lp, lq, 0.0, 0.1, np.random.default_rng(5).random(n)))
-    assert (got != ref).sum() <= 2
-    # independent restatement of the specification (rank totals -> slices -> local cdf), draw order included
-    lw = oracle.unnormalized_log_weights(ll, lp, lq, 0.0, 0.1)
-    m = lw.max()
-    S1 = sum(np.sum(np.exp(lw[a:b] - m)) for a, b in ((0, n // 2), (n // 2, n)))
-    shift = (m + np.log(S1)) - np.log(n)
-    lse = (m + shift) + np.log(S1)
-    cdfs = [np.cumsum(np.exp((lw[a:b] + shift) - lse)) for a, b in ((0, n // 2), (n // 2, n))]
-    edges = np.concatenate([[0.0], np.cumsum([c[-1] for c in cdfs])])
-    cut = float(edges[1] / edges[2])
-    state = oracle.pcg64_state_from_numpy(np.random.default_rng(5))
-    for r, (res, lo_u, hi_u) in enumerate(((r0, 0.0, cut), (r1, cut, 1.0))):
-        q = oracle.pcg64_select(state, n, lo_u, hi_u)
-        want = oracle.searchsorted_right(cdfs[r] / cdfs[r][-1], q) + r * (n // 2)
-        assert np.array_equal(res["own_idx"], want)
-        assert np.array_equal(res["own_x"], x[want])
+    # the reference itself: Generator.choice on the normalised weights of the whole population
+    w = oracle.normalized_weights(ll, lp, lq, 0.0, 0.1)
+    ref = np.random.default_rng(5).choice(n, size=n, replace=True, p=w)
+    assert np.array_equal(ref, oracle.resample_indices(ll, lp, lq, 0.0, 0.1, np.random.default_rng(5).random(n)))
+    for r, res in enumerate((r0, r1)):
+        mine = ref[(ref >= r * n // 2) & (ref < (r + 1) * n // 2)]  # choice's draws that land in this rank's shard
+        assert np.array_equal(res["own_idx"], mine)  # no sort, no tolerance
+        assert np.array_equal(res["own_idx_repl"], mine)  # brute-force path (replicated scan): the same selection
+        assert np.array_equal(res["own_x"], x[mine])
+        assert res["own_counts"].tolist() == [int((ref < n // 2).sum()), int((ref >= n // 2).sum())]
+        assert res["own_shard_counts"].tolist() == res["own_counts"].tolist()
+    assert int(r0["own_gid0"][0]) == 0 and int(r1["own_gid0"][0]) == int((ref < n // 2).sum())
+    # systematic draws through the same owner machinery: the oracle's systematic ancestors, split by owner
+    u_sys = oracle.systematic_uniforms(n, float(np.random.default_rng(5).random()))
+    ref_sys = oracle.resample_indices(ll, lp, lq, 0.0, 0.1, u_sys)
+    assert np.array_equal(np.concatenate([r0["own_idx_sys"], r1["own_idx_sys"]]), ref_sys)  # sorted draws: rank-major order
     assert float(r0["own_var"]) == pytest.approx(oracle.log_evidence_ratio_variance(ll, lp, lq, 0.0, 0.1), rel=1e-10)
     assert int(r0["odd_n"][0]) + int(r1["odd_n"][0]) == 1001 and int(r0["odd_n"][1]) == int(r1["odd_n"][1]) == 1001
-    assert abs(int(r0["odd_n"][0]) - 500) < 80  # shares ~ 1/2 each
+    ref_odd = np.random.default_rng(8).choice(n, size=1001, replace=True, p=w)
+    assert int(r0["odd_n"][0]) == int((ref_odd < n // 2).sum())
     for res in (r0, r1):
         assert res["own_flags"].tolist() == [n, 1, 1]
         assert res["again_n"].tolist() == [n // 2, 0]  # slot layout hands back equal shards
         assert res["skew"].tolist() == [n // 2, 0]  # imbalance -> slot layout
     # rebalancing keeps the global order and yields equal shards
     allx = np.concatenate([r0["own_x"], r1["own_x"]])
+    allll = np.concatenate([r0["own_ll"], r1["own_ll"]])
     assert r0["reb_x"].shape[0] == r1["reb_x"].shape[0] == n // 2
     assert np.array_equal(np.concatenate([r0["reb_x"], r1["reb_x"]]), allx)
-    assert np.array_equal(np.concatenate([r0["reb_ll"], r1["reb_ll"]]), np.concatenate([r0["own_ll"], r1["own_ll"]]))
+    assert np.array_equal(np.concatenate([r0["reb_ll"], r1["reb_ll"]]), allll)
+    # second resampling FROM the ragged population: numpy's choice on the concatenated (rank-major) population
+    lp2 = -0.5 * np.sum(allx**2, axis=1)
+    lq2 = -0.5 * np.sum((allx / 1.5) ** 2, axis=1) - 4 * np.log(1.5) - 0.5 * 4 * np.log(2 * np.pi)
+    w2 = oracle.normalized_weights(allll, lp2, lq2, 0.1, 0.3)
+    ref2 = np.random.default_rng(6).choice(n, size=n, replace=True, p=w2)
+    c0 = int(r0["own_counts"][0])
+    assert np.array_equal(r0["again_x"], allx[ref2[ref2 < c0]]) and np.array_equal(r1["again_x"], allx[ref2[ref2 >= c0]])
+    assert r0["again_counts"].tolist() == [int((ref2 < c0).sum()), int((ref2 >= c0).sum())]
+    # ... and the slot layout selects the same ancestors, laid out in draw order over equal shards
+    assert np.array_equal(np.concatenate([r0["slots_x"], r1["slots_x"]]), allx[ref2])
 
 
 def test_owner_layout_sampler(two_rank_results):

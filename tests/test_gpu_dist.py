@@ -28,8 +28,13 @@ def test_sharded_search_and_owner_resampling_match_oracle(runs):
         h, o = runs["hip"][r], runs["oracle"][r]
         assert float(h["fb"][0]) == float(o["fb"][0])  # same bisection decisions on the merged rank records
         assert float(h["fb"][1]) == pytest.approx(float(o["fb"][1]), rel=1e-11)
-        assert np.array_equal(h["own_idx"], o["own_idx"])  # select order, slices and local search: index work, exact
+        assert np.array_equal(h["own_idx"], o["own_idx"])  # tile records -> replicated chain -> slice; ordered select; search
+        assert np.array_equal(h["own_idx_repl"], o["own_idx"])  # forced fallback (replicated scan): the same ancestors
+        assert np.array_equal(h["own_idx_sys"], o["own_idx_sys"])
         assert np.array_equal(h["own_x"], o["own_x"])
+        assert h["own_counts"].tolist() == o["own_counts"].tolist() and h["own_gid0"].tolist() == o["own_gid0"].tolist()
+        assert np.array_equal(h["again_x"], o["again_x"]) and h["again_counts"].tolist() == o["again_counts"].tolist()
+        assert np.array_equal(h["slots_x"], o["slots_x"])
         assert float(h["own_var"]) == pytest.approx(float(o["own_var"]), rel=1e-10)
         assert h["own_flags"].tolist() == o["own_flags"].tolist()
         assert np.array_equal(h["reb_x"], o["reb_x"])
