@@ -28,6 +28,7 @@ ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
 ASMC_ABI_VERSION = 9
 ASMC_CDF_REC = 9
+ASMC_CDF_STATE = 36
 
 
 class AsmcMixture(ctypes.Structure):
@@ -135,7 +136,8 @@ SIGNATURES = {
     "asmc_pcg64_uniforms": (_i, [_vp, POINTER(c_uint64), _u64, _i64, _vp, _vp]),
     "asmc_cdf_shard_tiles": (_i64, [_i64]),
     "asmc_cdf_shard_records": (_i, [_vp, _i64, _vp, _vp, _d, _i, _vp, _vp]),
-    "asmc_cdf_shard_finish": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "asmc_cdf_shard_chain": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _vp, _vp]),
+    "asmc_cdf_shard_finish": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "asmc_select_range": (_i, [_vp, _i64, _vp, _vp, _vp, _pi64, _vp]),
     "asmc_systematic_uniforms": (_i, [_vp, _i64, _i64, _i64, _d, _vp, _vp, _vp]),
     "asmc_search": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),

@@ -496,23 +496,43 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const dou
 // need only an APPROXIMATE incoming sum, so every rank runs them on its own shard at once and emits one packed record
 // per tile; the records of all ranks are all-gathered (72 B per 2048 particles) and every rank then walks the SAME
 // chain over all of them - the exact sum entering each of its own tiles and the global total come out bit-identical
-// on every rank without a rank-to-rank dependency.  A tile whose prediction fails verification would need its
-// elements, which live on another rank: the chain then raises `fail` and the caller falls back to a replicated scan
-// over the all-gathered weights (same result, more traffic; rare: a running sum within rounding of a power of two at
-// a predicted crossing, leading zero weights, or two binade crossings inside one tile).
+// on every rank without a rank waiting for another rank's scan.
+// A tile whose record fails verification needs its elements.  That is the rule, not the exception, at the very end of
+// the population: normalised weights sum to 1 up to the accumulated rounding of the sequential sum, so whether the last
+// adds cross 2^0 cannot be predicted from an approximate prefix.  The rank that OWNS such a tile scans it element-wise
+// right here (exact_tile) and PUBLISHES {tile, exact sum behind it}; a rank that meets a failing tile it does not own
+// stops.  The callers all-gather the ranks' states (ASMC_CDF_STATE doubles each) and run the kernel once more: it resumes
+// where it stopped and passes foreign failing tiles through the published sums.  Two rounds settle every case in which
+// the owners of failing tiles were not themselves blocked in front of them (in particular the tail case); anything else
+// leaves `complete` at 0 and the caller falls back to a replicated scan over the all-gathered weights.
+#define CDF_PUB_MAX 16
+// state row (ASMC_CDF_STATE doubles): [0] next tile, [1] exact sum entering it, [2] complete, [3] entries, [4 + 2k] tile,
+// [5 + 2k] exact sum behind that tile
 __global__ __launch_bounds__(XT_THREADS) void k_exact_chain_pk(int64_t n_tiles, const long long* __restrict__ pk,
                                                               double* __restrict__ tile_s, double* __restrict__ tile_s2,
-                                                              double* __restrict__ total_out, double* __restrict__ fail_out) {
-    __shared__ double sh_walk_s;
-    __shared__ long long sh_walk_t;
+                                                              double* __restrict__ done_here,
+                                                              const double* __restrict__ w, double* __restrict__ cdf,
+                                                              int64_t n_local, int64_t tile0, int64_t n_tiles_local,
+                                                              const double* __restrict__ states_all, int world, int rank,
+                                                              double* __restrict__ state_out) {
+    __shared__ TD sh_td[XT_THREADS / 64 + 1];
+    __shared__ double sh_s, sh_walk_s;
+    __shared__ long long sh_pos, sh_cross, sh_walk_t;
     __shared__ int sh_split_ok;
     constexpr int CHAIN_CHUNK = 512;
     __shared__ long long sh_rec[CHAIN_CHUNK * ASMC_CDF_REC];
     int64_t chunk0 = -CHAIN_CHUNK;
     int64_t t = 0;
     double s = 0.0;
-    bool failed = false;
-    if (pk[3] == 3) {  // the first rank's first tile was scanned element-wise from an exactly known sum (0)
+    int n_pub = 0;
+    bool blocked = false;
+    if (states_all) {  // second round: resume from this rank's own stop point
+        const double* mine = states_all + (int64_t)rank * ASMC_CDF_STATE;
+        t = (int64_t)mine[0];
+        s = mine[1];
+        n_pub = (int)mine[3];
+        if (threadIdx.x < 2 * CDF_PUB_MAX) state_out[4 + threadIdx.x] = mine[4 + threadIdx.x];  // keep what was published
+    } else if (pk[3] == 3) {  // the first rank's first tile was scanned element-wise from an exactly known sum (0)
         s = __longlong_as_double(pk[8]);
         if (threadIdx.x == 0) tile_s[0] = 0.0, tile_s2[0] = s;
         t = 1;
@@ -593,33 +613,65 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_chain_pk(int64_t n_tiles, 
                     }
                 }
             }
+            if (!ok && states_all) {  // a sum some rank published for this tile in the first round?
+                for (int q = 0; q < world && !ok; q++) {
+                    const double* row = states_all + (int64_t)q * ASMC_CDF_STATE;
+                    const int cnt = (int)row[3];
+                    for (int k = 0; k < cnt; k++)
+                        if ((int64_t)row[4 + 2 * k] == t) {
+                            if (q != rank) tile_s[t] = s;  // (own tiles were written when they were scanned)
+                            sh_walk_s = row[5 + 2 * k];
+                            ok = 2;
+                            break;
+                        }
+                }
+            }
             sh_split_ok = ok;
         }
         __syncthreads();
-        const bool done = sh_split_ok != 0;
-        if (done) s = sh_walk_s;
+        const int how = sh_split_ok;
+        if (how) s = sh_walk_s;
         __syncthreads();
-        if (!done) {  // needs the tile's elements: not available here
-            failed = true;
+        if (how) {
+            t++;
+            continue;
+        }
+        if (t < tile0 || t >= tile0 + n_tiles_local) {  // needs the tile's elements, and they are on another rank
+            blocked = true;
             break;
         }
+        // own tile: element-wise, exact; the write pass leaves it alone (done_here) and only divides it by the total
+        const int64_t lo = (t - tile0) * ASMC_SCAN_TILE;
+        const int64_t hi = (lo + ASMC_SCAN_TILE < n_local) ? lo + ASMC_SCAN_TILE : n_local;
+        if (threadIdx.x == 0) {
+            tile_s[t] = s;
+            done_here[t] = 1.0;
+        }
+        s = exact_tile(w, cdf, lo, hi, s, sh_td, &sh_s, &sh_pos, &sh_cross);
+        __syncthreads();
+        if (threadIdx.x == 0 && n_pub < CDF_PUB_MAX) {
+            state_out[4 + 2 * n_pub] = (double)t;
+            state_out[5 + 2 * n_pub] = s;
+        }
+        if (n_pub < CDF_PUB_MAX) n_pub++;
         t++;
     }
     if (threadIdx.x == 0) {
-        *total_out = s;
-        *fail_out = failed ? 1.0 : 0.0;
+        state_out[0] = (double)t;
+        state_out[1] = s;
+        state_out[2] = (!blocked && t >= n_tiles) ? 1.0 : 0.0;
+        state_out[3] = (double)n_pub;
     }
 }
 
 // out[4] = {fail, global total, (exact sum entering this shard) / total, cdf of this shard's last element}: the last two
 // are the shard's slice [lo, hi) of the normalised global cdf, formed with the same division the write pass applies
-__global__ void k_shard_edges(const double* __restrict__ total, const double* __restrict__ fail,
-                              const double* __restrict__ s_in, const double* __restrict__ cdf_last,
-                              double* __restrict__ out) {
+__global__ void k_shard_edges(const double* __restrict__ state, const double* __restrict__ s_in,
+                              const double* __restrict__ cdf_last, double* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        out[0] = *fail;
-        out[1] = *total;
-        out[2] = *s_in / *total;
+        out[0] = state[2] != 0.0 ? 0.0 : 1.0;
+        out[1] = state[1];
+        out[2] = *s_in / state[1];
         out[3] = *cdf_last;
     }
 }
@@ -652,10 +704,12 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, cons
                                                                 const double* __restrict__ tile_s,
                                                                 const double* __restrict__ tile_s2,
                                                                 const double* __restrict__ norm_ptr,
-                                                                const long long* __restrict__ rec_pk) {
+                                                                const long long* __restrict__ rec_pk,
+                                                                const double* __restrict__ done_here) {
     __shared__ TD sh_td[XT_THREADS / 64 + 1];
     const int64_t t = blockIdx.x;
-    const long long flag = rec_pk ? rec_pk[ASMC_CDF_REC * t + 3] : tile_info[4 * t + 3];
+    const long long flag = (done_here && done_here[t] != 0.0) ? 0
+                           : (rec_pk ? rec_pk[ASMC_CDF_REC * t + 3] : tile_info[4 * t + 3]);
     // norm_ptr != NULL: the caller wants cdf / cdf[-1] (numpy's `cdf /= cdf[-1]`); the total is known by now, so
     // the division rides on this pass (tiles the chain wrote element-wise are divided in place)
     const double norm = norm_ptr ? *norm_ptr : 1.0;
@@ -1291,7 +1345,7 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_exact_tile_write", k_exact_tile_write, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w, cdf,
                            (const long long*)ctx->d_tiles_i, (const long long*)d_split, (const double*)d_tile_s,
-                           (const double*)d_tile_s2, d_norm, (const long long*)nullptr);
+                           (const double*)d_tile_s2, d_norm, (const long long*)nullptr, (const double*)nullptr);
         ASMC_LAUNCH_CHECK();
     } else if (mode == ASMC_CDF_FAST) {
         const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
@@ -1336,27 +1390,42 @@ int asmc_cdf_shard_records(asmc_ctx* ctx, int64_t n, const double* w, double* cd
     return ASMC_OK;
 }
 
+int asmc_cdf_shard_chain(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, const int64_t* recs_all_dev,
+                         int64_t n_tiles_total, int64_t tile0, double* work_dev, const double* states_all_dev, int world,
+                         int rank, double* state_out_dev, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && w && cdf && recs_all_dev && work_dev && state_out_dev, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+    const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+    ASMC_REQUIRE(tile0 >= 0 && tile0 + n_tiles <= n_tiles_total, "this shard's tiles do not fit the global tile list");
+    ASMC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank / world");
+    hipStream_t st = as_stream(stream);
+    if (!states_all_dev)  // first round: nothing has been scanned element-wise yet
+        ASMC_HIP(hipMemsetAsync(work_dev + 2 * n_tiles_total, 0, sizeof(double) * (size_t)n_tiles_total, st));
+    ASMC_LAUNCH(ctx, st, "k_exact_chain_pk", k_exact_chain_pk, dim3(1), dim3(XT_THREADS), 0, st, n_tiles_total,
+                (const long long*)recs_all_dev, work_dev, work_dev + n_tiles_total, work_dev + 2 * n_tiles_total, w, cdf, n,
+                tile0, n_tiles, states_all_dev, world, rank, state_out_dev);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
 int asmc_cdf_shard_finish(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, const int64_t* recs_all_dev,
-                          int64_t n_tiles_total, int64_t tile0, double* work_dev, double* out_dev, asmc_stream stream) {
-    ASMC_REQUIRE(ctx && w && cdf && recs_all_dev && work_dev && out_dev, "null pointer");
+                          int64_t n_tiles_total, int64_t tile0, double* work_dev, const double* state_dev, double* out_dev,
+                          asmc_stream stream) {
+    ASMC_REQUIRE(ctx && w && cdf && recs_all_dev && work_dev && state_dev && out_dev, "null pointer");
     ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
     const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
     ASMC_REQUIRE(tile0 >= 0 && tile0 + n_tiles <= n_tiles_total, "this shard's tiles do not fit the global tile list");
     hipStream_t st = as_stream(stream);
     double* tile_s = work_dev;
     double* tile_s2 = work_dev + n_tiles_total;
-    double* d_total = ctx->d_small + 1024;
-    double* d_fail = ctx->d_small + 1026;
-    ASMC_LAUNCH(ctx, st, "k_exact_chain_pk", k_exact_chain_pk, dim3(1), dim3(XT_THREADS), 0, st, n_tiles_total,
-                (const long long*)recs_all_dev, tile_s, tile_s2, d_total, d_fail);
-    ASMC_LAUNCH_CHECK();
+    const double* done_here = work_dev + 2 * n_tiles_total;
     ASMC_LAUNCH(ctx, st, "k_exact_tile_write", k_exact_tile_write, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w, cdf,
                 (const long long*)nullptr, (const long long*)nullptr, (const double*)(tile_s + tile0),
-                (const double*)(tile_s2 + tile0), (const double*)d_total,
-                (const long long*)recs_all_dev + ASMC_CDF_REC * tile0);
+                (const double*)(tile_s2 + tile0), state_dev + 1, (const long long*)recs_all_dev + ASMC_CDF_REC * tile0,
+                done_here + tile0);
     ASMC_LAUNCH_CHECK();
-    ASMC_LAUNCH(ctx, st, "k_shard_edges", k_shard_edges, dim3(1), dim3(64), 0, st, (const double*)d_total, (const double*)d_fail,
-                (const double*)(tile_s + tile0), (const double*)(cdf + n - 1), out_dev);
+    ASMC_LAUNCH(ctx, st, "k_shard_edges", k_shard_edges, dim3(1), dim3(64), 0, st, state_dev, (const double*)(tile_s + tile0),
+                (const double*)(cdf + n - 1), out_dev);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }

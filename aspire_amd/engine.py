@@ -363,15 +363,31 @@ class HipEngine:
                                               _dptr(rec), self._stream), "asmc_cdf_shard_records")
         return cdf, rec
 
-    def cdf_shard_finish(self, w: torch.Tensor, cdf: torch.Tensor, recs_all: torch.Tensor, tile0: int) -> torch.Tensor:
-        """Chain over ALL ranks' tile records + write of this rank's slice (divided by the global total) into `cdf`.
-        Returns the device vector {fail, total, lo, hi}.  No synchronisation."""
+    def cdf_shard_chain(self, w: torch.Tensor, cdf: torch.Tensor, recs_all: torch.Tensor, tile0: int, work: torch.Tensor | None,
+                        states_all: torch.Tensor | None, world: int, rank: int):
+        """One round of the verifying chain over ALL ranks' tile records; returns (work, state[ASMC_CDF_STATE]).
+        Round 1: work = states_all = None.  Round 2: the work buffer of round 1 and the all-gathered states.
+        No synchronisation."""
         assert recs_all.dtype == torch.int64 and recs_all.is_contiguous() and recs_all.shape[1] == _lib.ASMC_CDF_REC
         n_total = int(recs_all.shape[0])
-        work = self.empty(2 * n_total)
+        if work is None:
+            work = self.empty(3 * n_total)
+        state = torch.zeros(_lib.ASMC_CDF_STATE, dtype=torch.float64, device=self.device)
+        if states_all is not None:
+            assert states_all.dtype == torch.float64 and states_all.is_contiguous() and states_all.numel() == world * _lib.ASMC_CDF_STATE
+        check(self.lib.asmc_cdf_shard_chain(self._ctx, w.numel(), _dptr(w), _dptr(cdf), _dptr(recs_all), n_total, int(tile0),
+                                            _dptr(work), _dptr(states_all), int(world), int(rank), _dptr(state), self._stream),
+              "asmc_cdf_shard_chain")
+        return work, state
+
+    def cdf_shard_finish(self, w: torch.Tensor, cdf: torch.Tensor, recs_all: torch.Tensor, tile0: int, work: torch.Tensor,
+                         state: torch.Tensor) -> torch.Tensor:
+        """Write this rank's slice (divided by the global total of its final chain state) into `cdf`; returns the device
+        vector {fail, total, lo, hi}.  No synchronisation."""
         out = self.empty(4)
-        check(self.lib.asmc_cdf_shard_finish(self._ctx, w.numel(), _dptr(w), _dptr(cdf), _dptr(recs_all), n_total, int(tile0),
-                                             _dptr(work), _dptr(out), self._stream), "asmc_cdf_shard_finish")
+        check(self.lib.asmc_cdf_shard_finish(self._ctx, w.numel(), _dptr(w), _dptr(cdf), _dptr(recs_all), int(recs_all.shape[0]),
+                                             int(tile0), _dptr(work), _dptr(state), _dptr(out), self._stream),
+              "asmc_cdf_shard_finish")
         return out
 
     def select_range(self, u: torch.Tensor, lohi: torch.Tensor) -> torch.Tensor:

@@ -386,14 +386,22 @@ def global_cdf_slice(engine, comm, w, counts, approx_carry: float, mode: str = "
     """This rank's slice of numpy's sequential cumsum over the GLOBAL weight vector, divided by the global total
     (samples.py:1277-1278 -> Generator.choice), bit for bit, plus the slice's edges {fail, total, lo, hi} on the device.
     Exact mode: every rank turns its shard into per-tile records from an approximate incoming sum, the records are
-    all-gathered (72 B per 2048 particles) and every rank walks the same verifying chain over all of them
-    (include/asmc.h asmc_cdf_shard_*): no rank waits for another rank's scan."""
+    all-gathered (72 B per 2048 particles) and every rank walks the same verifying chain over all of them, in two
+    rounds with one all-gather of the ranks' chain states in between (include/asmc.h asmc_cdf_shard_*): no rank waits
+    for another rank's scan.  edges[0] != 0: the chain could not be closed - the caller repeats with the replicated scan."""
     if force_replicated or mode != "exact" or not hasattr(engine, "cdf_shard_records"):
         return global_cdf_slice_replicated(engine, comm, w, counts, mode)
     cdf, rec = engine.cdf_shard_records(w, approx_carry, comm.rank == 0)
     tiles = [-(-int(c) // 2048) for c in counts]
     recs_all = comm.all_gather_ragged(rec, tiles).contiguous()
-    edges = engine.cdf_shard_finish(w, cdf, recs_all, int(sum(tiles[:comm.rank])))
+    tile0 = int(sum(tiles[:comm.rank]))
+    # round 1: every rank walks the chain; the owner of a tile that fails verification (the tail of normalised weights,
+    # typically) scans it element-wise and publishes the exact sum behind it, the others stop in front of it
+    work, state = engine.cdf_shard_chain(w, cdf, recs_all, tile0, None, None, comm.world, comm.rank)
+    states = comm.all_gather_tensor(state).contiguous()
+    # round 2: resume through the published sums
+    work, state = engine.cdf_shard_chain(w, cdf, recs_all, tile0, work, states, comm.world, comm.rank)
+    edges = engine.cdf_shard_finish(w, cdf, recs_all, tile0, work, state)
     return cdf, edges
 
 

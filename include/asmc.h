@@ -48,6 +48,7 @@ extern "C" {
 #define ASMC_BIS_REC 40        /* doubles per rank record of the sharded beta search (asmc_find_beta_shard_*) */
 #define ASMC_STUDENT_MAX_ROWS 16384 /* largest subsample of the tpCN reference fit (asmc_student_*) */
 #define ASMC_CDF_REC 9         /* int64 words per tile record of the sharded exact cdf (asmc_cdf_shard_*) */
+#define ASMC_CDF_STATE 36      /* doubles per rank state of its chain (asmc_cdf_shard_chain) */
 #define ASMC_SELECT_THREADS 262144 /* generator threads of asmc_pcg64_select (fixes the order of the kept draws) */
 #define ASMC_MAX_COMPONENTS 8  /* mixture components of a built-in density */
 #define ASMC_MAX_DIMS 256
@@ -216,28 +217,39 @@ int asmc_pcg64_uniforms(asmc_ctx* ctx, const uint64_t state_host[4], uint64_t of
                         double* u_dev, asmc_stream stream);
 /* Sharded exact cdf (one process per GPU; the reference has no distributed mode): this rank's slice of
  * numpy's SEQUENTIAL cumsum over the GLOBAL weight vector (ranks in order), divided by the global total - the values
- * Generator.choice searches (samples.py:1277-1278) - without a rank-to-rank dependency chain:
+ * Generator.choice searches (samples.py:1277-1278) - without a rank waiting for another rank's scan:
  *   asmc_cdf_shard_records  passes that need only an APPROXIMATE incoming sum (approx_carry = sum of the lower ranks'
  *                           weights to a few ulps; ignored on the first rank, whose first tile is scanned exactly from 0
  *                           into cdf_dev): one ASMC_CDF_REC-word record per 2048-particle tile -> rec_dev
  *                           [asmc_cdf_shard_tiles(n) * ASMC_CDF_REC];
- *   (caller)                all-gather of the records, concatenated in rank order;
- *   asmc_cdf_shard_finish   every rank walks the same chain over ALL tiles (verifying each record against the exact
- *                           running sum) and writes its own slice; tile0 = global index of this rank's first tile;
- *                           work_dev: 2 * n_tiles_total doubles of scratch;
- *                           out_dev[4] = {fail, global total, lo, hi}: [lo, hi) is this shard's slice of the normalised cdf
- *                           (lo = cdf of the last particle of the rank below, 0 on the first rank; hi = cdf_dev[n - 1]).
- * fail != 0: a record failed verification and its tile's elements are on another rank - cdf_dev is then undefined and
- * the caller recomputes with a replicated asmc_cdf over the all-gathered weights (same on every rank: the chain is
- * deterministic).  Neither call synchronises.
+ *   (caller)                all-gather of the records, concatenated in rank order -> recs_all_dev;
+ *   asmc_cdf_shard_chain    every rank walks the same chain over ALL tiles, verifying each record against the exact
+ *                           running sum; tile0 = global index of this rank's first tile; work_dev = 3 * n_tiles_total
+ *                           doubles of scratch kept between the calls.  A tile whose record fails verification (always
+ *                           possible where the sum approaches a power of two, i.e. at the very end of normalised weights)
+ *                           is scanned element-wise by the rank that owns it, which publishes the exact sum behind it in
+ *                           state_out_dev[ASMC_CDF_STATE]; other ranks stop there.  Round 1: states_all_dev = NULL.
+ *   (caller)                all-gather of the states -> states_all_dev [world * ASMC_CDF_STATE];
+ *   asmc_cdf_shard_chain    round 2 (states_all_dev given): resumes and passes foreign tiles through the published sums;
+ *   asmc_cdf_shard_finish   writes this rank's slice divided by the global total from its final state (state_dev =
+ *                           round 2's state_out_dev); out_dev[4] = {fail, global total, lo, hi}: [lo, hi) is this
+ *                           shard's slice of the normalised cdf (lo = cdf of the last particle of the rank below, 0 on the
+ *                           first rank; hi = cdf_dev[n - 1]).
+ * fail != 0: the chain could not be completed in two rounds (failing tiles on several ranks blocking each other): cdf_dev
+ * is undefined and the caller recomputes with a replicated asmc_cdf over the all-gathered weights.  None of the calls
+ * synchronises.
  * asmc_select_range: out = u[(lo <= u) & (u < hi)] in index order, lohi_dev = {lo, hi} on the device (out_dev + 2 of the
  *   call above); out_dev must hold n doubles; count_host receives the number kept (synchronises).  With u = the draws of
  *   asmc_pcg64_uniforms this is the sub-sequence of Generator.choice's draws whose ancestors live on this rank. */
 int64_t asmc_cdf_shard_tiles(int64_t n);
 int asmc_cdf_shard_records(asmc_ctx* ctx, int64_t n, const double* w_dev, double* cdf_dev, double approx_carry,
                            int first_rank, int64_t* rec_dev, asmc_stream stream);
+int asmc_cdf_shard_chain(asmc_ctx* ctx, int64_t n, const double* w_dev, double* cdf_dev, const int64_t* recs_all_dev,
+                         int64_t n_tiles_total, int64_t tile0, double* work_dev, const double* states_all_dev, int world,
+                         int rank, double* state_out_dev, asmc_stream stream);
 int asmc_cdf_shard_finish(asmc_ctx* ctx, int64_t n, const double* w_dev, double* cdf_dev, const int64_t* recs_all_dev,
-                          int64_t n_tiles_total, int64_t tile0, double* work_dev, double* out_dev, asmc_stream stream);
+                          int64_t n_tiles_total, int64_t tile0, double* work_dev, const double* state_dev, double* out_dev,
+                          asmc_stream stream);
 int asmc_select_range(asmc_ctx* ctx, int64_t n, const double* u_dev, const double* lohi_dev, double* out_dev,
                       int64_t* count_host, asmc_stream stream);
 

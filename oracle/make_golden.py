@@ -12,6 +12,11 @@ Files
   ref_initial.npz    G5  MCMCSampler.draw_initial_samples with invalid rows   (mcmc.py:49-110)
   ref_anchors.npz        the tiny known-answer cases of reference tests/test_samples.py:637-731
   ref_transforms.npz G6  CompositeTransform fit / forward / inverse + log|det J|     (transforms.py:142-316,411-646)
+  ref_checkpoint.npz G7  checkpoint state dicts of the G4 loop (keys, types, beta, iteration, generator state, particles),
+                         the HDF5 layout the reference writes for them and for SMCHistory.save
+                         (samplers/base.py:158-252, smc/base.py:521-562, history.py:83-112, utils.py:733-872)
+
+`python oracle/make_golden.py ref_checkpoint` regenerates only the named files.
 """
 from __future__ import annotations
 
@@ -26,6 +31,13 @@ sys.path.insert(0, HERE)
 import ref_shim  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+ONLY = {a.replace(".npz", "") for a in sys.argv[1:]}
+
+
+def save(name, arrays):
+    if ONLY and name.replace(".npz", "") not in ONLY:
+        return
+    np.savez_compressed(os.path.join(OUT, name), **arrays)
 
 
 def synth(n, d, seed, sigma_q=1.5):
@@ -65,7 +77,7 @@ def main():
                     g1[key + "_lw_stride"] = np.asarray(lw)[::257]
                     g1[key + "_lw_sum"] = float(np.sum(lw))
     g1["cases"] = np.array(cases, dtype=np.float64)
-    np.savez_compressed(os.path.join(OUT, "ref_weights.npz"), **g1)
+    save("ref_weights.npz", g1)
 
     # ---------------- G2 determine_beta ------------------------------------------------------
     class _Flow:
@@ -102,7 +114,7 @@ def main():
         b, ms = sp.determine_beta(s, 0.0, np.nan, 1 / 5, max_beta_step=0.25, beta_tolerance=1e-6)
         g2[f"n{n}_minstep"] = np.array([float(b), float(ms)])
     g2["cases"] = np.array(cases, dtype=np.float64)
-    np.savez_compressed(os.path.join(OUT, "ref_beta.npz"), **g2)
+    save("ref_beta.npz", g2)
 
     # ---------------- G3 resample indices ----------------------------------------------------
     g3 = {}
@@ -131,7 +143,7 @@ def main():
     order = np.argsort(lq, kind="stable")
     g3["samebeta_idx"] = order[np.searchsorted(lq[order], out.log_q)].astype(np.int64)
     g3["cases"] = np.array(cases, dtype=np.float64)
-    np.savez_compressed(os.path.join(OUT, "ref_resample.npz"), **g3)
+    save("ref_resample.npz", g3)
 
     # ---------------- G4 whole loop with stub mutate -----------------------------------------
     class GaussFlow:
@@ -201,7 +213,66 @@ def main():
         g4[name + "_log_evidence_error"] = float(out.log_evidence_error)
         g4[name + "_x_final"] = np.asarray(out.x)
         g4[name + "_nlike"] = sp.n_likelihood_evaluations
-    np.savez_compressed(os.path.join(OUT, "ref_loop.npz"), **g4)
+    save("ref_loop.npz", g4)
+
+
+    # ---------------- G7 checkpoint state of the G4 loop + HDF5 layout --------------------------
+    import json
+    import pickle
+
+    from fake_h5 import FakeGroup
+
+    sp = StubSMC(log_likelihood=log_like, log_prior=log_like, dims=4, prior_flow=GaussFlow(4, 2.0, 5), xp=np,
+                 rng=np.random.default_rng(9))
+    sp.kind = "rw"
+    sp.sampler_kwargs = {}
+    states = []
+    out = sp.sample(2000, store_sample_history=False, adaptive=True, target_efficiency=0.5, beta_tolerance=1e-6,
+                    checkpoint_callback=lambda st: states.append(dict(st)), checkpoint_every=1)
+    g7 = {"n_states": len(states), "final_beta": np.array(sp.history.beta), "final_x": np.asarray(out.x),
+          "final_log_evidence": float(out.log_evidence)}
+    for i, st in enumerate(states):
+        g7[f"s{i}_keys"] = np.array(list(st.keys()))  # insertion order is part of what the reference writes
+        g7[f"s{i}_types"] = np.array([type(v).__name__ for v in st.values()])
+        g7[f"s{i}_iteration"] = int(st["iteration"])
+        g7[f"s{i}_beta"] = float(st["meta"]["beta"])
+        g7[f"s{i}_meta_keys"] = np.array(list(st["meta"].keys()))
+        g7[f"s{i}_config"] = json.dumps(st["config"], sort_keys=True, default=str)
+        g7[f"s{i}_sampler"] = st["sampler"]
+        g7[f"s{i}_sampler_kwargs"] = json.dumps(st["sampler_kwargs"], sort_keys=True, default=str)
+        rs_ = st["rng_state"]
+        g7[f"s{i}_rng"] = json.dumps({"bit_generator": rs_["bit_generator"], "state": str(rs_["state"]["state"]),
+                                      "inc": str(rs_["state"]["inc"]), "has_uint32": int(rs_["has_uint32"]),
+                                      "uinteger": int(rs_["uinteger"])})
+        h = st["history"]
+        g7[f"s{i}_hist_beta"] = np.array(h.beta)
+        g7[f"s{i}_hist_log_norm_ratio"] = np.array(h.log_norm_ratio)
+        g7[f"s{i}_hist_log_norm_ratio_var"] = np.array(h.log_norm_ratio_var)
+        g7[f"s{i}_hist_ess"] = np.array(h.ess)
+        smp = st["samples"]
+        g7[f"s{i}_samples_type"] = type(smp).__name__
+        g7[f"s{i}_samples_dtypes"] = np.array([str(np.asarray(v).dtype) for v in (smp.x, smp.log_likelihood, smp.log_prior, smp.log_q)])
+        g7[f"s{i}_samples_beta"] = float(smp.beta)
+        if i in (1, len(states) - 1):  # full particle state at one mid-run checkpoint (resume test) and at the forced last one
+            g7[f"s{i}_x"], g7[f"s{i}_ll"] = np.asarray(smp.x), np.asarray(smp.log_likelihood)
+            g7[f"s{i}_lp"], g7[f"s{i}_lq"] = np.asarray(smp.log_prior), np.asarray(smp.log_q)
+    # what the reference's own writers put into an HDF5 file (through the in-memory group protocol)
+    f = FakeGroup()
+    sp.save_checkpoint_to_hdf(states[1], f, path="checkpoint", dsetname="state")
+    blob = f["checkpoint"]["state"]
+    g7["h5_state_dtype"], g7["h5_state_ndim"] = str(blob.dtype), len(blob.shape)
+    g7["h5_state_maxshape_none"] = int(blob.maxshape == (None,))
+    assert pickle.loads(blob[...].tobytes())["iteration"] == states[1]["iteration"]
+    sp.save_checkpoint_to_hdf(states[2], f, path="checkpoint", dsetname="state")  # overwrite in place (resize)
+    assert pickle.loads(f["checkpoint"]["state"][...].tobytes())["iteration"] == states[2]["iteration"]
+    f2 = FakeGroup()
+    sp.history.save(f2, path="smc_history")
+    lay = f2.layout()
+    g7["h5_history_paths"] = np.array(sorted(lay))
+    g7["h5_history_kinds"] = np.array([lay[k][0] for k in sorted(lay)])
+    g7["h5_history_shapes"] = np.array([json.dumps(lay[k][1]) for k in sorted(lay)])
+    g7["h5_history_beta"] = np.asarray(f2["smc_history"]["beta"][...])
+    save("ref_checkpoint.npz", g7)
 
     # ---------------- G5 draw_initial_samples -------------------------------------------------
     class HoleFlow(GaussFlow):
@@ -223,7 +294,7 @@ def main():
     init = sp.draw_initial_samples(500)
     g5 = dict(x=np.asarray(init.x), ll=np.asarray(init.log_likelihood), lp=np.asarray(init.log_prior),
               lq=np.asarray(init.log_q), nlike=sp.n_likelihood_evaluations)
-    np.savez_compressed(os.path.join(OUT, "ref_initial.npz"), **g5)
+    save("ref_initial.npz", g5)
 
     # ---------------- anchors from the reference's own tests ---------------------------------
     a = {}
@@ -234,7 +305,7 @@ def main():
     a["t10_ess"] = float(ut.effective_sample_size(s.log_weights(0.8)))
     a["t10_var"] = float(s.log_evidence_ratio_variance(0.8))
     a["t10_rows"] = s.resample(0.8, n_samples=7, rng=np.random.default_rng(42)).x[:, 0] / 2
-    np.savez_compressed(os.path.join(OUT, "ref_anchors.npz"), **a)
+    save("ref_anchors.npz", a)
 
     # ---------------- G6 preconditioning transforms -------------------------------------------
     import importlib
@@ -285,7 +356,7 @@ def main():
         if affine:
             g6[name + "_mean"], g6[name + "_std"] = np.asarray(T._affine_transform._mean), np.asarray(T._affine_transform._std)
     g6["names"] = np.array(list(tcases))
-    np.savez_compressed(os.path.join(OUT, "ref_transforms.npz"), **g6)
+    save("ref_transforms.npz", g6)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
