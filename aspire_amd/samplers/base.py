@@ -21,6 +21,23 @@ from ..targets import DiagGaussianMixture
 logger = logging.getLogger(__name__)
 
 
+def track_calls(func):
+    """utils.py:1003-1029: remember the positional and keyword arguments of every call of a sampler's `sample` method
+    (`config_dict` reports them; the checkpoint state carries that config).  The log lives on the instance, keyed by the
+    method's qualified name, so a subclass's `sample` and the base `sample` it calls keep separate logs as in the
+    reference."""
+    import functools
+
+    @functools.wraps(func)
+    def wrapper(self, *args, **kwargs):
+        log = self.__dict__.setdefault("_call_log", {}).setdefault(func.__qualname__, {"args": [], "kwargs": []})
+        log["args"].append(args)
+        log["kwargs"].append(kwargs)
+        return func(self, *args, **kwargs)
+
+    return wrapper
+
+
 class IdentityTransform:
     """transforms.py:125-139 — the default "smc" preconditioning for unbounded problems
     (aspire.py:337-341: affine_transform=False, bounded_to_unbounded=False)."""
@@ -65,7 +82,6 @@ class Sampler:
         self.preconditioning_transform = preconditioning_transform or IdentityTransform(xp=self.xp)
         self._engine = engine
         self._comm = comm
-        self._calls: list[dict] = []
 
     # ---- engine / communicator ----------------------------------------------------------
     @property
@@ -149,12 +165,23 @@ class Sampler:
 
     # ---- config / checkpoint plumbing (samplers/base.py:93-276, minimal) -------------------
     def config_dict(self, include_sample_calls: str | bool = "last") -> dict:
+        """samplers/base.py:93-141."""
         config = {"sampler_class": self.__class__.__name__}
-        if include_sample_calls is not False and self._calls:
-            if include_sample_calls in (True, "all"):
-                config["sample_calls"] = {str(i): c for i, c in enumerate(self._calls)}
-            elif str(include_sample_calls).lower() == "last":
-                config["sample_calls"] = self._calls[-1]
+        if include_sample_calls is not False:
+            if include_sample_calls is True:
+                include_sample_calls = "all"
+            if not isinstance(include_sample_calls, str):
+                raise ValueError("include_sample_calls must be a string ('last' or 'all') or False."
+                                 f"Received: {include_sample_calls} of type {type(include_sample_calls)}")
+            calls = self.__dict__.get("_call_log", {}).get(getattr(type(self).sample, "__qualname__", ""))
+            if calls is None:
+                return config
+            if include_sample_calls.lower() == "last":
+                config["sample_calls"] = {"args": calls["args"][-1] if calls["args"] else None,
+                                          "kwargs": calls["kwargs"][-1] if calls["kwargs"] else None}
+            elif include_sample_calls.lower() == "all":
+                config["sample_calls"] = {"args": {str(i): v for i, v in enumerate(calls["args"])},
+                                          "kwargs": {str(i): v for i, v in enumerate(calls["kwargs"])}}
             else:
                 raise ValueError("Invalid value for include_sample_calls. Must be 'last', 'all', or False.")
         return config

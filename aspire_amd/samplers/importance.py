@@ -13,10 +13,11 @@ import numpy as np
 
 from .. import smc_math
 from ..samples import Samples
-from .base import Sampler
+from .base import Sampler, track_calls
 
 
 class ImportanceSampler(Sampler):
+    @track_calls
     def sample(self, n_samples: int) -> Samples:
         e, comm = self.engine, self.comm
         x, log_q = self.prior_flow.sample_and_log_prob(n_samples)
@@ -38,7 +39,6 @@ class ImportanceSampler(Sampler):
         samples.evidence_error = math.exp(st.m) * math.sqrt(m2 / (n * (n - 1))) if n > 1 else float("nan")
         samples.log_evidence_error = abs(samples.evidence_error / samples.evidence) if samples.evidence else float("nan")
         samples.effective_sample_size = math.exp(2.0 * math.log(st.S1) - math.log(st.S2))
-        self._calls.append({"args": (n_samples,), "kwargs": {}})
         return samples
 
 

@@ -22,7 +22,7 @@ from ..history import SMCHistory
 from ..samples import SMCSamples, Samples, gather_global
 from ..smc_math import BetaScheduleError
 from ..targets import DiagGaussianMixture
-from .base import IdentityTransform, MCMCSampler
+from .base import IdentityTransform, MCMCSampler, track_calls
 
 logger = logging.getLogger(__name__)
 
@@ -134,6 +134,7 @@ class SMCSampler(MCMCSampler):
         return s
 
     # ---- the loop (smc/base.py:215-488) -----------------------------------------------------
+    @track_calls
     def sample(self, n_samples: int, n_steps: int | None = None, adaptive: bool = True,
                min_beta_step: float | None = None, max_beta_step: float | None = None,
                max_n_steps: int | None = None, target_efficiency: float = 0.5,
@@ -291,7 +292,6 @@ class SMCSampler(MCMCSampler):
 
         final_samples = samples.to_standard_samples()
         logger.info(f"Log evidence: {final_samples.log_evidence:.2f} +/- {final_samples.log_evidence_error:.2f}")
-        self._calls.append({"args": (n_samples,), "kwargs": {"n_steps": n_steps, "adaptive": adaptive}})
         return final_samples
 
     def mutate(self, particles, beta, n_steps=None):
@@ -360,6 +360,7 @@ class HipSMC(SMCSampler):
 
     rng = None
 
+    @track_calls
     def sample(self, n_samples: int, n_steps: int = None, min_beta_step: float | None = None,
                max_beta_step: float | None = None, max_n_steps: int | None = None, adaptive: bool = True,
                target_efficiency: float = 0.5, target_efficiency_rate: float = 1.0,

@@ -34,6 +34,17 @@ OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 ONLY = {a.replace(".npz", "") for a in sys.argv[1:]}
 
 
+class StateCollector:
+    """Checkpoint callback (module level: the reference records the sample() kwargs in the state's config, and the
+    state must stay picklable)."""
+
+    def __init__(self):
+        self.states = []
+
+    def __call__(self, state):
+        self.states.append(dict(state))
+
+
 def save(name, arrays):
     if ONLY and name.replace(".npz", "") not in ONLY:
         return
@@ -226,9 +237,10 @@ def main():
                  rng=np.random.default_rng(9))
     sp.kind = "rw"
     sp.sampler_kwargs = {}
-    states = []
+    collector = StateCollector()
     out = sp.sample(2000, store_sample_history=False, adaptive=True, target_efficiency=0.5, beta_tolerance=1e-6,
-                    checkpoint_callback=lambda st: states.append(dict(st)), checkpoint_every=1)
+                    checkpoint_callback=collector, checkpoint_every=1)
+    states = collector.states
     g7 = {"n_states": len(states), "final_beta": np.array(sp.history.beta), "final_x": np.asarray(out.x),
           "final_log_evidence": float(out.log_evidence)}
     for i, st in enumerate(states):

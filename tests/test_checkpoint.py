@@ -1,0 +1,195 @@
+"""Checkpoint state and HDF5 layout pinned to the REAL reference.
+
+Golden `tests/golden/ref_checkpoint.npz` (oracle/make_golden.py G7) holds what the reference's
+`SMCSampler.build_checkpoint_state` + `_checkpoint_extra_state` (samplers/base.py:158-178, smc/base.py:521-544) produced
+at every iteration of the G4 random-walk loop - keys in order, value types, iteration, beta, generator state, history,
+one full particle state - and the dataset layout its HDF5 writers produce (`dump_state`, `SMCHistory.save`).
+The same checks run on the CPU test double here and on the HIP engine in tests/test_gpu_fullsize.py.
+"""
+import json
+import pickle
+
+import numpy as np
+import pytest
+
+from fake_h5 import FakeGroup
+from test_host_logic import NumpyGaussFlow, StubSMC, _log_like
+
+from aspire_amd.history import SMCHistory
+from aspire_amd.samples import SMCSamples
+
+
+class Collector:  # module level: the state's config records the sample() kwargs and must stay picklable
+    def __init__(self):
+        self.states = []
+
+    def __call__(self, state):
+        self.states.append(dict(state))
+
+
+def run_with_checkpoints(eng, resume=None):
+    sp = StubSMC(log_likelihood=_log_like, log_prior=_log_like, dims=4, prior_flow=NumpyGaussFlow(4, 2.0, 5), xp=np,
+                 rng=np.random.default_rng(9), engine=eng)
+    sp.kind = "rw"
+    sp.sampler_kwargs = {}
+    if getattr(eng, "name", "") == "hip":  # the host random-walk stub works on host copies of the device tensors
+        import torch
+
+        orig = sp.mutate
+
+        def mutate(particles, beta, n_steps=None, _orig=orig):
+            cpu = particles.to_numpy()
+            cpu.x = torch.from_numpy(cpu.x)
+            out = _orig(cpu, beta)
+            return sp._wrap(eng.asarray(out.x), eng.asarray(out.log_likelihood), eng.asarray(out.log_prior),
+                            eng.asarray(out.log_q), beta)
+
+        sp.mutate = mutate
+    col = Collector()
+    extra = {} if resume is None else {"resume_from": resume}
+    out = sp.sample(2000, store_sample_history=False, adaptive=True, target_efficiency=0.5, beta_tolerance=1e-6,
+                    checkpoint_callback=col, checkpoint_every=1, **extra)
+    return sp, out, col.states
+
+
+def check_states_match_reference(states, g):
+    assert len(states) == int(g["n_states"])
+    for i, st in enumerate(states):
+        ref_keys = [str(k) for k in g[f"s{i}_keys"]]
+        assert list(st.keys())[:len(ref_keys)] == ref_keys  # the reference's keys, in its order (ours may append extras)
+        assert set(st) - set(ref_keys) <= {"pcn_state"}
+        for k, tname in zip(ref_keys, g[f"s{i}_types"]):
+            assert type(st[k]).__name__ == str(tname), (k, type(st[k]).__name__, str(tname))
+        assert st["sampler"] == str(g[f"s{i}_sampler"]) and st["iteration"] == int(g[f"s{i}_iteration"])
+        assert list(st["meta"]) == [str(k) for k in g[f"s{i}_meta_keys"]]
+        assert st["meta"]["beta"] == float(g[f"s{i}_beta"])
+        cfg, ref_cfg = st["config"], json.loads(str(g[f"s{i}_config"]))
+        assert cfg["sampler_class"] == ref_cfg["sampler_class"]
+        assert list(cfg["sample_calls"]["args"]) == ref_cfg["sample_calls"]["args"]
+        assert set(cfg["sample_calls"]["kwargs"]) == set(ref_cfg["sample_calls"]["kwargs"])
+        assert st["sampler_kwargs"] == json.loads(str(g[f"s{i}_sampler_kwargs"]))
+        rs, ref_rs = st["rng_state"], json.loads(str(g[f"s{i}_rng"]))
+        assert rs["bit_generator"] == ref_rs["bit_generator"]
+        assert (str(rs["state"]["state"]), str(rs["state"]["inc"])) == (ref_rs["state"], ref_rs["inc"])  # 128-bit words
+        assert (int(rs["has_uint32"]), int(rs["uinteger"])) == (ref_rs["has_uint32"], ref_rs["uinteger"])
+        h = st["history"]
+        assert np.array_equal(np.array(h.beta), g[f"s{i}_hist_beta"])
+        np.testing.assert_allclose(h.log_norm_ratio, g[f"s{i}_hist_log_norm_ratio"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(h.log_norm_ratio_var, g[f"s{i}_hist_log_norm_ratio_var"], rtol=1e-9)
+        np.testing.assert_allclose(h.ess, g[f"s{i}_hist_ess"], rtol=1e-11)
+        smp = st["samples"]
+        assert type(smp).__name__ == str(g[f"s{i}_samples_type"]) and smp.beta == float(g[f"s{i}_samples_beta"])
+        assert [str(np.asarray(v).dtype) for v in (smp.x, smp.log_likelihood, smp.log_prior, smp.log_q)] == \
+            [str(v) for v in g[f"s{i}_samples_dtypes"]]
+        assert isinstance(smp.x, np.ndarray)  # samples.to_numpy(): host arrays, whatever the engine
+        if f"s{i}_x" in g:
+            assert np.array_equal(smp.x, g[f"s{i}_x"]) and np.array_equal(smp.log_likelihood, g[f"s{i}_ll"])
+            assert np.array_equal(smp.log_prior, g[f"s{i}_lp"])
+            np.testing.assert_allclose(smp.log_q, g[f"s{i}_lq"], rtol=1e-15)
+        pickle.loads(pickle.dumps(st))  # serialisable as the reference's is (samplers/base.py:180-187)
+
+
+def reference_state_as_resume_source(g, i=1):
+    """The reference's checkpoint at iteration i+1, rebuilt from golden DATA into this package's containers."""
+    rs = json.loads(str(g[f"s{i}_rng"]))
+    hist = SMCHistory(beta=g[f"s{i}_hist_beta"].tolist(), log_norm_ratio=g[f"s{i}_hist_log_norm_ratio"].tolist(),
+                      log_norm_ratio_var=g[f"s{i}_hist_log_norm_ratio_var"].tolist(), ess=g[f"s{i}_hist_ess"].tolist())
+    smp = SMCSamples(x=g[f"s{i}_x"], log_likelihood=g[f"s{i}_ll"], log_prior=g[f"s{i}_lp"], log_q=g[f"s{i}_lq"],
+                     beta=float(g[f"s{i}_samples_beta"]))
+    return {"sampler": "StubSMC", "iteration": int(g[f"s{i}_iteration"]), "samples": smp, "config": {}, "parameters": None,
+            "meta": {"beta": float(g[f"s{i}_beta"])}, "history": hist,
+            "rng_state": {"bit_generator": rs["bit_generator"], "state": {"state": int(rs["state"]), "inc": int(rs["inc"])},
+                          "has_uint32": rs["has_uint32"], "uinteger": rs["uinteger"]}, "sampler_kwargs": {}}
+
+
+def check_resume_continues_reference_schedule(eng, g):
+    sp, out, states = run_with_checkpoints(eng, resume=reference_state_as_resume_source(g, 1))
+    assert np.array_equal(np.array(sp.history.beta), g["final_beta"])  # the reference's own continuation
+    x = out.x.cpu().numpy() if hasattr(out.x, "cpu") else np.asarray(out.x)
+    assert np.array_equal(x, g["final_x"])
+    assert float(out.log_evidence) == pytest.approx(float(g["final_log_evidence"]), rel=1e-12)
+    assert [st["iteration"] for st in states] == [int(g[f"s{i}_iteration"]) for i in range(2, int(g["n_states"]))]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from oracle_engine import OracleEngine
+
+    return OracleEngine()
+
+
+def test_checkpoint_states_match_reference_golden(eng, golden):
+    sp, out, states = run_with_checkpoints(eng)
+    check_states_match_reference(states, golden["ref_checkpoint"])
+    assert sp.last_checkpoint_state is None  # a user callback replaces the default one (smc/base.py:384-388)
+
+
+def test_resume_from_reference_state_continues_its_schedule(eng, golden):
+    check_resume_continues_reference_schedule(eng, golden["ref_checkpoint"])
+
+
+def test_default_callback_keeps_state_and_bytes(eng):
+    sp = StubSMC(log_likelihood=_log_like, log_prior=_log_like, dims=4, prior_flow=NumpyGaussFlow(4, 2.0, 5), xp=np,
+                 rng=np.random.default_rng(9), engine=eng)
+    sp.sampler_kwargs = {}
+    sp.sample(300, store_sample_history=False, checkpoint_every=1, beta_tolerance=1e-6)
+    st = sp.last_checkpoint_state
+    assert st is not None and pickle.loads(sp.last_checkpoint_bytes)["iteration"] == st["iteration"]
+    sp2 = StubSMC(log_likelihood=_log_like, log_prior=_log_like, dims=4, prior_flow=NumpyGaussFlow(4, 2.0, 5), xp=np,
+                  rng=np.random.default_rng(1), engine=eng)
+    sp2.sampler_kwargs = {}
+    out = sp2.sample(300, store_sample_history=False, resume_from=sp.last_checkpoint_bytes)  # finished run: nothing left to do
+    assert sp2.history.beta == sp.history.beta and len(out.x) == 300
+
+
+def test_hdf5_layout_matches_reference_writers(eng, golden, tmp_path):
+    """`/checkpoint/state` as the reference's dump_state writes it (S1 bytes, resizable, overwritten in place) and
+    SMCHistory.save's flattened datasets - through the h5py group protocol."""
+    g = golden["ref_checkpoint"]
+    sp, out, states = run_with_checkpoints(eng)
+    f = FakeGroup()
+    sp.save_checkpoint_to_hdf(states[1], f, path="checkpoint", dsetname="state")
+    blob = f["checkpoint"]["state"]
+    assert str(blob.dtype) == str(g["h5_state_dtype"]) and len(blob.shape) == int(g["h5_state_ndim"])
+    assert int(blob.maxshape == (None,)) == int(g["h5_state_maxshape_none"])
+    assert pickle.loads(blob[...].tobytes())["iteration"] == states[1]["iteration"]
+    sp.save_checkpoint_to_hdf(states[3], f, path="checkpoint", dsetname="state")  # a different size: resized in place
+    from aspire_amd.io import load_state
+
+    assert load_state(f, "checkpoint", "state")["iteration"] == states[3]["iteration"]
+    sp.save_checkpoint_to_hdf(states[2], f)  # default naming (samplers/base.py:226-228)
+    assert f"iter_{states[2]['iteration']}" in f["sampler_checkpoints"]
+    # history: same dataset paths, kinds and shapes as the reference's SMCHistory.save, same numbers
+    f2 = FakeGroup()
+    sp.history.save(f2, path="smc_history")
+    lay = f2.layout()
+    ref_paths = [str(p) for p in g["h5_history_paths"]]
+    assert set(ref_paths) <= set(lay)
+    assert set(lay) - set(ref_paths) <= {"smc_history/mcmc_step_size", "smc_history/mcmc_nu"}  # this package's extra fields
+    for p, kind, shape in zip(ref_paths, g["h5_history_kinds"], g["h5_history_shapes"]):
+        assert lay[p][0] == str(kind) and list(lay[p][1]) == json.loads(str(shape)), p
+    assert np.array_equal(f2["smc_history"]["beta"][...], g["h5_history_beta"])
+    back = SMCHistory.load(f2, path="smc_history")
+    assert back.beta == sp.history.beta and back.ess == sp.history.ess and back.sample_history == []
+    # file callbacks: pickle files work everywhere; .h5 needs h5py and says so
+    cb = sp.default_file_checkpoint_callback(str(tmp_path / "ck.pkl"))
+    cb(states[1])
+    assert sp.load_checkpoint_from_file(str(tmp_path / "ck.pkl"))["iteration"] == states[1]["iteration"]
+    with pytest.raises(ValueError, match="HDF5 file"):
+        sp.default_file_checkpoint_callback(str(tmp_path / "ck.txt"))
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="h5py"):
+            sp.default_file_checkpoint_callback(str(tmp_path / "ck.h5"))(states[1])
+
+
+def test_samples_save_load_roundtrip_through_group_protocol():
+    x = np.arange(12.0).reshape(6, 2)
+    s = SMCSamples(x=x, log_likelihood=np.linspace(0, 1, 6), log_prior=np.zeros(6), log_q=np.ones(6), beta=0.3,
+                   parameters=["a", "b"])
+    f = FakeGroup()
+    s.save(f, path="samples")
+    back = SMCSamples.load(f, path="samples")
+    assert np.array_equal(back.x, x) and back.parameters == ["a", "b"] and back.beta == 0.3
+    assert np.array_equal(back.log_likelihood, s.log_likelihood)

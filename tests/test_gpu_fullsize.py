@@ -319,3 +319,21 @@ def test_sampler_run_with_systematic_resampling_gets_the_evidence(big, method):
     assert sp.history.beta[-1] == 1.0
     assert abs(float(out.log_evidence) - true) < 3 * err + 2e-3, (float(out.log_evidence), true, err)
     assert float(out.x.double().var(dim=0).mean()) == pytest.approx(0.5, rel=0.03)
+
+
+# ---- checkpoint state pinned to the reference, with the HIP engine underneath ----------------------
+def test_checkpoint_states_match_reference_golden_hip(hip_engine, golden):
+    """The reference's own checkpoint dictionaries (golden ref_checkpoint.npz: keys, types, beta, iteration, generator
+    state, history, particles) reproduced by the loop running on the HIP kernels; samples arrive as host arrays."""
+    from test_checkpoint import check_states_match_reference, run_with_checkpoints
+
+    sp, out, states = run_with_checkpoints(hip_engine)
+    check_states_match_reference(states, golden["ref_checkpoint"])
+
+
+def test_resume_from_reference_state_on_hip_engine(hip_engine, golden):
+    """Resume from the REFERENCE's mid-run state (golden data): the GPU loop continues the reference's beta schedule and
+    ends on the reference's particles."""
+    from test_checkpoint import check_resume_continues_reference_schedule
+
+    check_resume_continues_reference_schedule(hip_engine, golden["ref_checkpoint"])
