@@ -68,12 +68,16 @@ class GaussianFlow(Flow):
 
     xp = torch
 
-    def __init__(self, dims: int, mu=0.0, sigma=1.0, seed: int = 1234, device=None, dtype=torch.float64,
+    def __init__(self, dims: int, mu=0.0, sigma=1.0, seed: int | None = None, device=None, dtype=torch.float64,
                  engine=None, data_transform=None):
         super().__init__(dims, device=device, data_transform=data_transform)
         self.mu = np.broadcast_to(np.asarray(mu, dtype=np.float64), (dims,)).copy()
         self.sigma = np.broadcast_to(np.asarray(sigma, dtype=np.float64), (dims,)).copy()
-        self.seed = int(seed)
+        # seed=None: the sampler derives the Philox key of the draw stream from ITS generator at the start of every run
+        # (in the reference flow sampling is stochastic per run, flows/torch/flows.py:327-346), so runs with different
+        # rng seeds start from different populations; an explicit seed pins the stream
+        self.seed_from_rng = seed is None
+        self.seed = 1234 if seed is None else int(seed)
         self.dtype = dtype if isinstance(dtype, torch.dtype) else {"float32": torch.float32, "float64": torch.float64}[np.dtype(dtype).name]
         self.engine = engine
         self.gid0 = 0  # global index of this rank's first particle (sharded runs)
@@ -227,6 +231,26 @@ class CouplingFlow(Flow):
             self._packed = (key, engine.make_coupling(self.dims, hidden, ws, bs, self.loc.detach().cpu().numpy(),
                                                      self.scale.detach().cpu().numpy()))
         return self._packed[1]
+
+    def sync_shards(self, comm):
+        """Sharded runs (one process per GPU): every rank must evaluate the SAME flow - training is not bit-reproducible
+        across processes - and draw its shard from its own stream.  Rank 0's parameters go to everyone (one all-gather of
+        the flattened parameters) and the latent generator is re-seeded per rank."""
+        if comm.world == 1:
+            return
+        params = [p for p in self.layers.parameters()]
+        flat = torch.cat([p.detach().reshape(-1).to(torch.float64) for p in params]
+                         + [self.loc.detach().double().reshape(-1), self.scale.detach().double().reshape(-1)]).contiguous()
+        root = comm.all_gather_tensor(flat)[: flat.numel()]
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                p.copy_(root[off: off + p.numel()].reshape(p.shape).to(p.dtype))
+                off += p.numel()
+            self.loc = root[off: off + self.dims].to(self.dtype)
+            self.scale = root[off + self.dims: off + 2 * self.dims].to(self.dtype)
+        self._gen.manual_seed(int(self._gen.initial_seed()) + 1_000_003 * int(comm.rank))
+        self._version += 1
 
     def to(self, device):
         self.device = torch.device(device)

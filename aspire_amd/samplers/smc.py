@@ -159,6 +159,8 @@ class SMCSampler(MCMCSampler):
         # sharded runs: every rank walks the same resampling draws and draws the same mutation seeds, so the ranks'
         # generators must be in the same state - rank 0's is handed to everyone (a no-op for one rank)
         self.rng = smc_math.sync_rng(comm, self.rng)
+        if comm.world > 1 and hasattr(self.prior_flow, "sync_shards"):
+            self.prior_flow.sync_shards(comm)  # the same trained flow on every rank, a separate draw stream per rank
         if getattr(self.prior_flow, "seed_from_rng", False) and resume_from is None:
             # the proposal's own draw stream follows the run's generator (in the reference flow sampling is stochastic per
             # run); drawn after the synchronisation, so every rank gets the same seed and particle ids keep shards apart

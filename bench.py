@@ -4,18 +4,19 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
 torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
 
-Workload (default, BASELINE.json configs[1]): 1M particles per GPU, d=32, Gaussian target
-(ll = lp = -|x|^2/2), analytic proposal q = N(0, 1.5^2 I) ("flow off"), IS-only: one *step* is one
-temperature iteration of the reference loop (smc/base.py:401-445) without mutation:
-  adaptive beta bisection (target efficiency 0.5, tol 1e-6) -> ESS(beta), ESS(1) -> evidence ratio +
-  variance -> resample (normalised weights, cdf, PCG64 uniforms, search, row gather).
-Inputs are resident in HBM before the timed region; every step processes the same pristine batch.
-`value` = particles x steps / time ("particle-steps/s"; here a step is a temperature iteration —
-SURVEY.md §8d calls this unit particle-iterations/s).
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 1M particles per GPU,
+d = 32, Gaussian target (ll = lp = -|x|^2/2), RealNVP coupling-flow proposal (4 coupling layers, MLP 16->64->64->32,
+float32, trained once before the timed region) whose log-density runs on the fp32 MFMA inside the mutation loop,
+adaptive tempering (target efficiency 0.5, tolerance 1e-6), exact multinomial resampling, pCN mutation with 32 steps
+per temperature and the sampler's DEFAULT fp64 proposal noise.
+One bench *step* = one complete `HipSMC.sample()` run (proposal draw, ~6 temperatures x [beta search, ESS, evidence,
+resample, reference fit, 32 mutation steps]).  `value` = particles x mutation steps executed / wall time of the K
+runs = particle-steps/s as SURVEY.md §8d defines it (N x number of mutation steps / wall of sample()).
+Particles are sharded over the ranks (weak scaling: 1M per GPU); all inputs are generated on the device.
 
-Extra (same JSON line, `extra`): the mutation path — fused pCN kernel throughput and one full
-`HipSMC.sample()` run with its log-evidence error for the analytic proposal, and configs[2] proper
-(coupling-flow proposal evaluated on the fp32 MFMA inside the device-side pCN loop).
+Same JSON line: `roofline` (the flow kernel against the fp32 MFMA peak; the pCN kernels against the HBM peak; the
+whole mutation step against both), `cpu_baseline` (the C oracle's restatement of the same mutation step on the host's
+cores, OpenMP), `extra` (IS-only temperature iteration of configs[1], the analytic-proposal runs, f32-noise variants).
 """
 from __future__ import annotations
 
@@ -33,26 +34,34 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+MFMA_F32_PEAK_TF = 157.3  # dense fp32-input MFMA peak (MI355X_MICROARCH.md, matrix cores)
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10, help="timed HipSMC.sample() runs")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--particles-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--dims", type=int, default=32)
     ap.add_argument("--x-dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--resample-mode", choices=["exact", "fast"], default="exact")
-    ap.add_argument("--mcmc-steps", type=int, default=32, help="pCN steps per temperature in the extra leg")
-    ap.add_argument("--noise", choices=["f64", "f32"], default="f32", help="proposal-noise generator of the pCN kernel")
+    ap.add_argument("--mcmc-steps", type=int, default=32, help="pCN steps per temperature")
+    ap.add_argument("--noise", choices=["f64", "f32"], default="f64", help="proposal-noise generator (sampler default: f64)")
+    ap.add_argument("--step-fn", choices=["pcn", "tpcn"], default="pcn")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--no-flow-leg", action="store_true", help="skip the coupling-flow (configs[2]) extra leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sharded-extras", action="store_true", help="N > 1: also run the full-sampler extra legs")
-    ap.add_argument("--force-sharded", action="store_true",
-                    help="test rig: run the sharded code path (process group, collectives, owner layout) with the ranks at hand, "
-                         "also when that is a single rank - one GPU then shows the cost of the sharded machinery itself over RCCL")
+    ap.add_argument("--sharded-extras", action="store_true", help="N > 1: also run the extra legs")
     ap.add_argument("--shard-layout", choices=["owner", "slots"], default="owner",
                     help="N > 1: offspring stay on the ancestor's rank (default) or single-rank slot order with row exchange")
     args = ap.parse_args()
@@ -70,14 +79,12 @@ def main():
     if "ASMC_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["ASMC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    sharded = world > 1 or args.force_sharded
+    sharded = world > 1
     if sharded:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -86,317 +93,294 @@ def main():
     from aspire_amd import smc_math
     from aspire_amd.comm import default_comm
     from aspire_amd.engine import HipEngine
-    from aspire_amd.flows import GaussianFlow
+    from aspire_amd.flows import CouplingFlow, GaussianFlow
     from aspire_amd.samplers.smc import HipSMC
-    from aspire_amd.samples import gather_global
     from aspire_amd.targets import DiagGaussianMixture
 
     n_local, d = args.particles_per_gpu, args.dims
     n_global = n_local * world
     xdt = torch.float64 if args.x_dtype == "f64" else torch.float32
+    xname = args.x_dtype.replace("f", "float")
     s_bytes = 8 if args.x_dtype == "f64" else 4
-    eng = HipEngine(local_rank, n_max=n_global, d_max=max(d, 32))  # the replicated exact cdf scan covers all N
+    n_mc = args.mcmc_steps
+    eng = HipEngine(local_rank, n_max=n_global, d_max=max(d, 32))  # sharded: the draws of all ranks are walked on every rank
     comm = default_comm(eng.device)
-    if sharded and world == 1:  # --force-sharded on one rank: the real communicator over a one-rank group
-        from aspire_amd.comm import TorchDistComm
 
-        comm = TorchDistComm(eng.device if backend == "nccl" else torch.device("cpu"))
-
-    # ---- synthetic batch, resident in HBM ---------------------------------------------------
+    # ---- the workload: targets, trained proposal flow -------------------------------------------------------------
     sigma_q = 1.5
-    flow = GaussianFlow(d, sigma=sigma_q, seed=0, engine=eng, dtype=xdt)
-    flow.gid0 = rank * n_local
     lik = DiagGaussianMixture.isotropic(d, normalized=False)
-    x, lq = flow.sample_and_log_prob(n_local)
-    ll = eng.mixture_logpdf(x, lik.device_mixture(eng))
-    lp = ll.clone()
-    torch.cuda.synchronize()
-
-    rng = np.random.default_rng(12345)
-    scal = {}
-
-    def is_step():
-        m_one = {}
-
-        def eff_fn(betas, closed_form=False):  # same as SMCSampler.determine_beta's (samplers/smc.py)
-            if closed_form and "m" in m_one:
-                shifts = [m_one["m"] * b for b in betas]
-                sts = smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, betas, n_global, shifts=shifts)
-            else:
-                sts = smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, betas, n_global)
-                if len(betas) == 1 and betas[0] == 1.0:
-                    m_one["m"] = sts[0].m
-            return [smc_math.ess(s) / n_global for s in sts]
-
-        found = {}
-
-        # whole bisection on device: asmc_find_beta, or its sharded form (reduce -> all-gather -> decide per round)
-        def search_fn(b0, target, tol):
-            if not sharded:
-                b, _, conv, passes, n_nan, trip, trip_one = eng.find_beta(ll, lp, lq, b0, target, tol)
-            else:
-                b, _, conv, passes, n_nan, trip, trip_one = smc_math.find_beta_sharded(eng, comm, ll, lp, lq, b0, target,
-                                                                                      tol, n_global)
-            assert conv and n_nan == 0
-            found.update(beta=b, trip=trip, one=trip_one)
-            return b, passes
-
-        beta, _, n_pass = smc_math.determine_beta(eff_fn, 0.0, adaptive=True, beta_step=float("nan"), min_beta_step=0.0,
-                                                  max_beta_step=1.0, beta_tolerance=1e-6, adaptive_min_beta_step=False,
-                                                  target=0.5, rate=1.0, search_fn=search_fn)
-        # same order as the sampler loop (smc/base.py:401-445): ESS(beta), ESS(1), evidence ratio + variance, resample;
-        # the device-side search has already reduced the batch at beta* and at 1.0
-        if found.get("beta") == beta and found.get("trip") is not None:
-            st_b, st_1 = smc_math.Stats(*found["trip"], n_global), smc_math.Stats(*found["one"], n_global)
-        else:
-            st_b, st_1 = smc_math.global_stats(eng, comm, ll, lp, lq, 0.0, [beta, 1.0], n_global)
-        if sharded and args.shard_layout == "owner":
-            # offspring stay on the ancestor's rank: one all-gather (rank totals + variance partials), no row exchange
-            idx, var, s1p = smc_math.resample_owner(eng, comm, ll, lp, lq, 0.0, beta, n_global, rng,
-                                                    mode=args.resample_mode, st=st_b)
-            if idx is not None:
-                scal.update(beta=beta, ess=smc_math.ess(st_b), ess1=smc_math.ess(st_1),
-                            ratio=smc_math.log_evidence_ratio(st_b), var=var, passes=n_pass, layout="owner")
-                return eng.gather(idx, x, ll, lp, lq)
-        else:
-            var, s1p = smc_math.evidence_variance_and_lse(eng, comm, ll, lp, lq, 0.0, beta, st_b)
-        scal.update(beta=beta, ess=smc_math.ess(st_b), ess1=smc_math.ess(st_1), ratio=smc_math.log_evidence_ratio(st_b),
-                    var=var, passes=n_pass, layout="slots")
-        idx, _ = smc_math.resample_indices(eng, comm, ll, lp, lq, 0.0, beta, n_global, rng, mode=args.resample_mode,
-                                           st=st_b, s1p=s1p)
-        return gather_global(eng, comm, idx, x, ll, lp, lq)
+    true_logz = 0.5 * d * math.log(math.pi)
+    cflow = CouplingFlow(d, n_layers=4, hidden_features=(64, 64), device=eng.device, dtype=torch.float32, seed=1234)
+    cflow.fit(sigma_q * 0.9 * np.random.default_rng(3).normal(size=(8000, d)), n_epochs=8)  # untimed
 
     def sync_all():
         if sharded:
             comm.barrier()
         torch.cuda.synchronize()
 
-    # untimed pre-warm (allocator pools, lazy code-object loads, one-off runtime stalls observed around the
-    # 15th-50th iteration of a fresh process: a single ~50 ms hiccup of the runtime), then the W warm-up steps
-    for _ in range(150 + args.warmup):
-        is_step()
-    sync_all()
-    prof = None
-    if os.environ.get("ASMC_BENCH_CPROFILE") and rank == 0:  # host-side hot spots of the step (stderr)
-        import cProfile
+    def run(seed: int, n=n_global, flow=cflow, step_fn=args.step_fn, noise=args.noise, steps=n_mc):
+        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=eng, comm=comm,
+                    rng=np.random.default_rng(seed), dtype=xname)
+        sp.shard_layout = args.shard_layout
+        post = sp.sample(n, sampler_kwargs=dict(n_steps=steps, noise=noise, step_fn=step_fn), store_sample_history=False,
+                         resample_mode=args.resample_mode)
+        return sp, post
 
-        prof = cProfile.Profile()
-        prof.enable()
+    run(1, n=min(n_global, 65536 * world), steps=2)  # first-launch costs (code objects, allocator pools, scipy import)
+    for w in range(args.warmup):
+        run(100 + w)
+    sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = is_step()
+    steps_done, zs, temps, accs = 0, [], [], []
+    for k in range(args.steps):
+        sp, post = run(1000 + k)
+        nt = len(sp.history.beta)
+        steps_done += nt * n_mc
+        temps.append(nt)
+        zs.append((float(post.log_evidence) - true_logz) / max(float(post.log_evidence_error), 1e-300))
+        accs.append(float(np.mean(sp.history.mcmc_acceptance)))
     sync_all()
     dt = time.perf_counter() - t0
-    if prof is not None:
-        import pstats
-
-        prof.disable()
-        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(18)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
         import torch.distributed as dist
 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    value = n_global * args.steps / dt
+    value = n_global * steps_done / dt
 
-    # ---- roofline of the dominant kernel -----------------------------------------------------------
-    # The same steps once more with the library's per-kernel HIP events switched on (events recorded on the
-    # launch stream around every kernel; kept out of the timed region because two event records per launch
-    # perturb a launch-bound loop).  achieved = algorithmic bytes per launch / average kernel duration.
+    # ---- roofline: one more run with the library's per-kernel HIP events switched on ---------------------------------
+    # (events are recorded on the launch stream around every kernel of the library; kept out of the timed region
+    # because two event records per launch perturb a launch-bound loop)
     eng.profile(True)
-    n_prof = min(args.steps, 10)
-    for _ in range(n_prof):
-        is_step()
+    sp_p, _ = run(2000)
     kern = eng.profile_report()
     eng.profile(False)
+    nt_p = len(sp_p.history.beta)
+    n_mut = nt_p * n_mc
     row_b = d * s_bytes
-    alg_bytes = {  # per launch, from SURVEY.md §8d's per-particle figures
-        "k_weights_max": 24 * n_local, "k_weights_sums": 24 * n_local, "k_weights_m2": 24 * n_local,
-        "k_bis_sums": 24 * n_local, "k_weights_m2_lse": 24 * n_local,
-        "k_weights_map": 32 * n_local, "k_tile_sum": 8 * n_local, "k_exact_tile_td_launch": 8 * n_local,
-        "k_exact_tile_write": 16 * n_local, "k_tile_scan": 16 * n_local, "k_divide": 16 * n_local,
-        "k_pcg64_uniforms": 8 * n_local, "k_pcg64_select": 8 * n_local, "k_search": 24 * n_local, "k_gather16": (2 * (row_b + 24) + 8) * n_local,
-        # serial dependency chain over tile records (+ the ~log2 N tiles that straddle a binade): latency bound
-        "k_exact_chain": 40 * ((n_local + 2047) // 2048) + 16 * 2048 * 12,
-    }
-
-    def alg_of(name):
-        base = name.split("<")[0]
-        return alg_bytes.get(base)
-
-    tot = {k: c * ms for k, (c, ms) in kern.items() if alg_of(k)}
-    dom = max(tot, key=tot.get)
-    dom_ms = kern[dom][1]
-    achieved = alg_of(dom) / (dom_ms * 1e-3) / 1e9
+    flow_flops = n_local * 4 * 2 * ((d // 2) * 64 + 64 * 64 + 64 * d)  # 4 coupling layers, MLP d/2 -> 64 -> 64 -> d
+    step_kernels = [k for k in kern if k.split("<")[0] in ("k_pcn_flow_propose", "k_coupling_logprob", "k_pcn_flow_accept",
+                                                              "k_pcn_adapt", "k_pcn_flow_fused", "k_gamma_draw")]
+    step_ms = sum(kern[k][0] * kern[k][1] for k in step_kernels) / max(n_mut, 1)
+    flow_k = next((k for k in kern if k.startswith("k_coupling_logprob") or k.startswith("k_pcn_flow_fused")), None)
+    flow_ms = kern[flow_k][1] if flow_k else None
+    pcn_ks = [k for k in kern if k.split("<")[0] in ("k_pcn_flow_propose", "k_pcn_flow_accept")]
+    pcn_ms = sum(kern[k][1] for k in pcn_ks)
+    # algorithmic bytes per particle per step: 2 d s + 16 for the pCN state update, + d s + 16 when the
+    # proposal density is a flow evaluated by its own pass over the proposed rows (x' written, re-read; log q written, re-read)
+    b_pcn = (2 * row_b + 16) * n_local
+    b_step = (3 * row_b + 32) * n_local
     traffic = None
-    try:  # HBM bytes per launch from the committed PMC run of this configuration (profiles/, separate passes)
+    try:  # HBM bytes per launch from the committed PMC run of this configuration (profiles/, separate --pmc passes)
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_per_launch.json")))
-        key = f"{dom.split('(')[0]}|n={n_local}|d={d}|{args.x_dtype}"
-        traffic = tr.get(key)
+        traffic = tr.get(f"{(flow_k or '').split('<')[0]}|n={n_local}|d={d}|{args.x_dtype}")
     except Exception:
         traffic = None
     per_kernel = {}
-    for k, (c, ms) in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
-        ab = alg_of(k)
-        per_kernel[k] = {"launches_per_step": round(c / n_prof, 2), "avg_us": round(ms * 1e3, 2),
-                         "alg_GBs": None if not ab else round(ab / (ms * 1e-3) / 1e9, 1)}
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_ms": round(dom_ms, 5),
-                "alg_bytes_per_launch": alg_of(dom), "gpu_busy_ms_per_step": round(sum(tot.values()) / n_prof, 4),
-                "per_kernel": per_kernel}
+    for k, (c, ms) in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:24]:
+        per_kernel[k] = {"launches_per_run": c, "avg_us": round(ms * 1e3, 2), "share_of_gpu_time": 0.0}
+    tot_ms = sum(c * ms for c, ms in kern.values())
+    for k in per_kernel:
+        per_kernel[k]["share_of_gpu_time"] = round(kern[k][0] * kern[k][1] / tot_ms, 4)
+    mfma_floor = flow_flops / (MFMA_F32_PEAK_TF * 1e12) * 1e3
+    hbm_floor = b_step / (HBM_PEAK_GBS * 1e9) * 1e3
+    roofline = {
+        "bound": "mfma", "kernel": flow_k, "dtype": "f32",
+        "achieved": round(flow_flops / (flow_ms * 1e-3) / 1e12, 2) if flow_ms else None, "peak": MFMA_F32_PEAK_TF,
+        "unit": "TFLOP/s", "frac": round(flow_flops / (flow_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4) if flow_ms else None,
+        "traffic": traffic, "avg_ms": round(flow_ms, 5) if flow_ms else None, "flops_per_launch": flow_flops,
+        "pcn_kernels": {"bound": "hbm", "kernels": pcn_ks, "avg_ms_per_step": round(pcn_ms, 5), "alg_bytes_per_step": b_pcn,
+                        "achieved": round(b_pcn / (pcn_ms * 1e-3) / 1e9, 1) if pcn_ms else None, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(b_pcn / (pcn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pcn_ms else None,
+                        "noise": args.noise},
+        "whole_step": {"device_ms_per_mutation_step": round(step_ms, 5), "flops_per_step": flow_flops,
+                       "alg_bytes_per_step": b_step, "mfma_floor_ms": round(mfma_floor, 5), "hbm_floor_ms": round(hbm_floor, 5),
+                       # both pipes perfectly overlapped (one fused kernel) / not overlapped at all
+                       "frac_overlapped": round(max(mfma_floor, hbm_floor) / step_ms, 4) if step_ms else None,
+                       "frac_serial": round((mfma_floor + hbm_floor) / step_ms, 4) if step_ms else None},
+        "gpu_busy_ms_per_run": round(tot_ms, 3), "wall_ms_per_run": round(dt / args.steps * 1e3, 3),
+        "mutation_share_of_gpu_time": round(step_ms * n_mut / tot_ms, 4) if tot_ms else None,
+        "per_kernel": per_kernel,
+    }
 
     result = {
         "metric": "particle-steps/sec (N x n_steps), 1M particles d=32; log-evidence err vs ref",
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "configs[1]: IS-only temperature iteration (bisection+ESS+evidence+resample), "
-                               f"{n_local} particles/GPU, d={d}, Gaussian target, analytic proposal N(0,1.5^2 I)",
-                   "n_steps_meaning": "temperature iterations (no mutation)", "particles_per_gpu": n_local,
-                   "global_particles": n_global, "dims": d, "x_dtype": args.x_dtype, "resample_mode": args.resample_mode,
-                   "resample_method": "multinomial", "beta_tolerance": 1e-6, "target_efficiency": 0.5,
-                   "parallelism": f"particle-shard x{world}" + (f" ({scal.get('layout')} layout)" if sharded else "")},
+        "config": {"workload": f"configs[2]: HipSMC.sample(), {n_local} particles/GPU, d={d}, Gaussian target, RealNVP "
+                               f"coupling-flow proposal (4 layers, MLP {d // 2}->64->64->{d}, f32 on the MFMA), adaptive "
+                               f"tempering, {n_mc} {args.step_fn} steps per temperature, {args.noise} proposal noise",
+                   "step_meaning": "one bench step = one full sample() run; value counts its mutation steps "
+                                   "(N x temperatures x mcmc steps / wall)",
+                   "particles_per_gpu": n_local, "global_particles": n_global, "dims": d, "x_dtype": args.x_dtype,
+                   "flow_dtype": "f32", "mcmc_steps_per_temperature": n_mc, "step_fn": args.step_fn, "noise": args.noise,
+                   "resample_mode": args.resample_mode, "resample_method": "multinomial", "beta_tolerance": 1e-6,
+                   "target_efficiency": 0.5,
+                   "parallelism": f"particle-shard x{world}" + (f" ({args.shard_layout} layout)" if sharded else "")},
+        "mutation_steps_per_run": steps_done / args.steps, "temperatures_per_run": float(np.mean(temps)),
+        "ms_per_mutation_step": dt / max(steps_done, 1) * 1e3,
+        "log_evidence": {"analytic": true_logz, "z_scores": [round(z, 3) for z in zs],
+                         "rms_z": float(np.sqrt(np.mean(np.square(zs)))), "max_abs_z": float(np.max(np.abs(zs))),
+                         "within_1_sigma_fraction": float(np.mean(np.abs(zs) <= 1.0))},
+        "mean_accept": float(np.mean(accs)),
         "roofline": roofline,
-        "scalars": {k: (v if isinstance(v, (int, str)) else float(v)) for k, v in scal.items()},
     }
 
-    # ---- extra: mutation path -------------------------------------------------------------------
-    if not args.no_extra:
-        extra = {}
-        mu0 = eng.asarray(np.zeros(d))
-        eye = eng.asarray(np.eye(d))
-        xm, llm, lpm, lqm = out[0].clone(), out[1].clone(), out[2].clone(), out[3].clone()
-        tgt, qm = lik.device_mixture(eng), flow.device_mixture(eng)
-        n_mc = args.mcmc_steps
-        eng.pcn_mutate(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, tgt, tgt, qm, 7, rank * n_local, 0.3, 4, 0, 0.234, True, args.noise)
-        sync_all()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        n_acc, rho_hist, rho = eng.pcn_mutate(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, tgt, tgt, qm, 7,
-                                              rank * n_local, 0.3, n_mc, 4, 0.234, True, args.noise)
-        ev1.record()
-        sync_all()
-        ms = ev0.elapsed_time(ev1) / n_mc
-        b_step = (2 * d * s_bytes + 16) * n_local
-        # the same loop with the Student-t reference (tpCN, nu = 8): + one gamma-variate kernel per step
-        eng.pcn_mutate(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, tgt, tgt, qm, 7, rank * n_local, 0.3, 4, 0, 0.234, True,
-                       args.noise, 8.0)
-        sync_all()
-        ev0.record()
-        eng.pcn_mutate(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, tgt, tgt, qm, 7, rank * n_local, 0.3, n_mc, 4, 0.234, True,
-                       args.noise, 8.0)
-        ev1.record()
-        sync_all()
-        ms_t = ev0.elapsed_time(ev1) / n_mc
-        extra["tpcn_kernel"] = {"ms_per_step": round(ms_t, 4), "particle_steps_per_s_per_gpu": n_local / (ms_t * 1e-3), "nu": 8.0,
-                                "noise": args.noise}
-        extra["pcn_kernel"] = {"ms_per_step": round(ms, 4), "particle_steps_per_s_per_gpu": n_local / (ms * 1e-3),
-                               "alg_bytes_per_step": b_step, "achieved_GBs": round(b_step / (ms * 1e-3) / 1e9, 1),
-                               "frac_of_hbm_peak": round(b_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                               "mean_accept": float(n_acc.mean() / n_local), "rho_final": rho, "noise": args.noise}
-        result["extra"] = extra
-    # The full-sampler legs issue many more collectives than the headline step; at N > 1 they only run on request, so
-    # that the scaling line cannot be lost to them (tools/rig2.sh exercises them with two ranks on one GPU).
+    # ---- extra legs ---------------------------------------------------------------------------------------------
     if not args.no_extra and (world == 1 or args.sharded_extras):
-        # one full sampler run (configs[2] shape with the analytic proposal): log-evidence check
-        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=sigma_q, seed=1, engine=eng, dtype=xdt),
-                    xp=np, engine=eng, comm=comm, rng=np.random.default_rng(2), dtype=args.x_dtype.replace("f", "float"))
-        sync_all()
-        t0 = time.perf_counter()
-        post = sp.sample(n_global, sampler_kwargs=dict(n_steps=n_mc, noise=args.noise, step_fn="pcn"), store_sample_history=False,
-                         resample_mode=args.resample_mode)
-        sync_all()
-        t_s = time.perf_counter() - t0
-        n_temps = len(sp.history.beta)
-        true_logz = 0.5 * d * math.log(math.pi)
-        extra["smc_pcn_run"] = {"wall_s": round(t_s, 4), "temperatures": n_temps, "mcmc_steps_per_temperature": n_mc,
-                                "particle_steps_per_s": n_global * n_temps * n_mc / t_s,
-                                "log_evidence": float(post.log_evidence), "log_evidence_error": float(post.log_evidence_error),
-                                "analytic_log_evidence": true_logz,
-                                "abs_err_in_sigma": abs(float(post.log_evidence) - true_logz) / max(float(post.log_evidence_error), 1e-300),
-                                "mean_accept": float(np.mean(sp.history.mcmc_acceptance))}
-        # the reference's default mutation kernel (step_fn="tpcn": Student-t reference refitted per temperature)
-        spt = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=sigma_q, seed=1, engine=eng, dtype=xdt),
-                     xp=np, engine=eng, comm=comm, rng=np.random.default_rng(2), dtype=args.x_dtype.replace("f", "float"))
-        spt.sample(min(n_global, 65536 * world), sampler_kwargs=dict(n_steps=2, noise=args.noise), store_sample_history=False,
-                   resample_mode=args.resample_mode)  # warm (first-launch costs, scipy import)
-        sync_all()
-        t0 = time.perf_counter()
-        postt = spt.sample(n_global, sampler_kwargs=dict(n_steps=n_mc, noise=args.noise), store_sample_history=False,
-                           resample_mode=args.resample_mode)
-        sync_all()
-        t_t = time.perf_counter() - t0
-        extra["smc_tpcn_run"] = {"wall_s": round(t_t, 4), "temperatures": len(spt.history.beta), "mcmc_steps_per_temperature": n_mc,
-                                 "particle_steps_per_s": n_global * len(spt.history.beta) * n_mc / t_t,
-                                 "log_evidence": float(postt.log_evidence), "log_evidence_error": float(postt.log_evidence_error),
-                                 "abs_err_in_sigma": abs(float(postt.log_evidence) - true_logz) / max(float(postt.log_evidence_error), 1e-300),
-                                 "nu_per_temperature": [round(v, 2) for v in spt.history.mcmc_nu],
-                                 "mean_accept": float(np.mean(spt.history.mcmc_acceptance))}
-        # configs[2] proper: coupling-flow proposal (4 coupling layers, MLP 16->64->64->32, float32) — flow
-        # log-density on the fp32 MFMA inside the device-side pCN loop; roofline of that kernel against the
-        # dense fp32 MFMA peak
-        if not args.no_flow_leg:
-            from aspire_amd.flows import CouplingFlow
+        extra = {}
+        # (a) configs[1]: the IS-only temperature iteration (bisection + ESS + evidence + exact resample + gather) on the
+        #     pristine analytic-proposal batch, as round 1 timed it
+        gflow = GaussianFlow(d, sigma=sigma_q, seed=0, engine=eng, dtype=xdt)
+        gflow.gid0 = rank * n_local
+        x, lq = gflow.sample_and_log_prob(n_local)
+        ll = eng.mixture_logpdf(x, lik.device_mixture(eng))
+        lp = ll.clone()
+        rng_is = np.random.default_rng(12345)
+        scal = {}
 
-            cflow = CouplingFlow(d, n_layers=4, hidden_features=(64, 64), device=eng.device, dtype=torch.float32, seed=1234)
-            gtrain = np.random.default_rng(3)
-            cflow.fit(sigma_q * 0.9 * gtrain.normal(size=(8000, d)), n_epochs=8)
-            sp3 = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=cflow, xp=np, engine=eng, comm=comm,
-                         rng=np.random.default_rng(2), dtype=args.x_dtype.replace("f", "float"))
-            sp3.sample(min(n_global, 65536 * world), sampler_kwargs=dict(n_steps=2, noise=args.noise, step_fn="pcn"), store_sample_history=False,
-                       resample_mode=args.resample_mode)  # warm (first-launch costs)
+        def is_step():
+            if sharded:
+                b, _, conv, _, n_nan, trip, trip_one = smc_math.find_beta_sharded(eng, comm, ll, lp, lq, 0.0, 0.5, 1e-6, n_global)
+            else:
+                b, _, conv, _, n_nan, trip, trip_one = eng.find_beta(ll, lp, lq, 0.0, 0.5, 1e-6)
+            assert conv and n_nan == 0
+            st_b, st_1 = smc_math.Stats(*trip, n_global), smc_math.Stats(*trip_one, n_global)
+            if sharded:
+                idx, var, _, _ = smc_math.resample_owner(eng, comm, ll, lp, lq, 0.0, b, n_global, rng_is,
+                                                         mode=args.resample_mode, st=st_b)
+            else:
+                var, s1p = smc_math.evidence_variance_and_lse(eng, comm, ll, lp, lq, 0.0, b, st_b)
+                idx, _ = smc_math.resample_indices(eng, comm, ll, lp, lq, 0.0, b, n_global, rng_is, mode=args.resample_mode,
+                                                   st=st_b, s1p=s1p)
+            scal.update(beta=b, ess=smc_math.ess(st_b), ess1=smc_math.ess(st_1), ratio=smc_math.log_evidence_ratio(st_b), var=var)
+            return eng.gather(idx, x, ll, lp, lq)
+
+        for _ in range(60):
+            is_step()
+        sync_all()
+        t0 = time.perf_counter()
+        n_is = 40
+        for _ in range(n_is):
+            out = is_step()
+        sync_all()
+        t_is = (time.perf_counter() - t0) / n_is
+        eng.profile(True)
+        for _ in range(10):
+            is_step()
+        kis = eng.profile_report()
+        eng.profile(False)
+        gk = next((k for k in kis if k.startswith("k_gather")), None)
+        g_bytes = (2 * (row_b + 24) + 8) * n_local
+        extra["is_only_step"] = {
+            "workload": "configs[1]: one temperature iteration without mutation on the pristine 1M x 32 batch",
+            "ms_per_step": round(t_is * 1e3, 4), "particle_iterations_per_s": n_global / t_is,
+            "alg_bytes_per_step": (64 + 2 * (row_b + 24)) * n_local,
+            "whole_step_frac_of_hbm_peak": round((64 + 2 * (row_b + 24)) * n_local / t_is / 1e9 / HBM_PEAK_GBS, 4),
+            "launches_per_step": round(sum(c for c, _ in kis.values()) / 10, 1),
+            "gpu_busy_ms_per_step": round(sum(c * ms for c, ms in kis.values()) / 10, 4),
+            "gather": None if gk is None else {"kernel": gk, "avg_us": round(kis[gk][1] * 1e3, 2),
+                                               "achieved_GBs": round(g_bytes / (kis[gk][1] * 1e-3) / 1e9, 1),
+                                               "frac_of_hbm_peak": round(g_bytes / (kis[gk][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "per_kernel_us": {k: [round(c / 10, 1), round(ms * 1e3, 2)] for k, (c, ms) in
+                              sorted(kis.items(), key=lambda kv: -kv[1][0] * kv[1][1])},
+            "scalars": {k: float(v) for k, v in scal.items()},
+        }
+        # (b) the fused pCN kernel on the resampled population: default f64 noise, and the fast f32 generator
+        mu0, eye = eng.asarray(np.zeros(d)), eng.asarray(np.eye(d))
+        tgt, qm = lik.device_mixture(eng), gflow.device_mixture(eng)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b_step_g = (2 * row_b + 16) * n_local
+        for noise in ("f64", "f32"):
+            for nu, label in ((0.0, "pcn"), (8.0, "tpcn")):
+                xm, llm, lpm, lqm = (t.clone() for t in out)
+                eng.pcn_mutate(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, tgt, tgt, qm, 7, rank * n_local, 0.3, 4, 0, 0.234, True, noise, nu)
+                sync_all()
+                ev0.record()
+                n_acc, _, rho = eng.pcn_mutate(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, tgt, tgt, qm, 7, rank * n_local,
+                                               0.3, n_mc, 4, 0.234, True, noise, nu)
+                ev1.record()
+                sync_all()
+                ms = ev0.elapsed_time(ev1) / n_mc
+                extra[f"{label}_kernel_{noise}_noise"] = {
+                    "ms_per_step": round(ms, 4), "particle_steps_per_s_per_gpu": n_local / (ms * 1e-3),
+                    "alg_bytes_per_step": b_step_g, "achieved_GBs": round(b_step_g / (ms * 1e-3) / 1e9, 1),
+                    "frac_of_hbm_peak": round(b_step_g / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "mean_accept": float(n_acc.mean() / n_local)}
+        # (c) full runs with the analytic proposal (no flow): pCN and the reference's default tpCN, default noise
+        for label, step_fn in (("smc_pcn_run", "pcn"), ("smc_tpcn_run", "tpcn")):
+            run(1, n=min(n_global, 65536 * world), flow=GaussianFlow(d, sigma=sigma_q, seed=1, engine=eng, dtype=xdt),
+                step_fn=step_fn, steps=2)
             sync_all()
-            eng.profile(True)
             t0 = time.perf_counter()
-            post3 = sp3.sample(n_global, sampler_kwargs=dict(n_steps=n_mc, noise=args.noise, step_fn="pcn"), store_sample_history=False,
-                               resample_mode=args.resample_mode)
+            spx, postx = run(2, flow=GaussianFlow(d, sigma=sigma_q, seed=1, engine=eng, dtype=xdt), step_fn=step_fn)
             sync_all()
-            t3 = time.perf_counter() - t0
-            rep3 = eng.profile_report()
-            eng.profile(False)
-            nt3 = len(sp3.history.beta)
-            flow_ms = rep3.get("k_coupling_logprob", (0, 0.0))[1]
-            flow_flops = n_local * 4 * 2 * ((d // 2) * 64 + 64 * 64 + 64 * d)
-            step_ms = sum(rep3.get(k, (0, 0.0))[1] for k in ("k_pcn_flow_propose", "k_coupling_logprob", "k_pcn_flow_accept", "k_pcn_adapt"))
-            extra["smc_pcn_flow_run"] = {
-                "wall_s": round(t3, 4), "temperatures": nt3, "mcmc_steps_per_temperature": n_mc,
-                "particle_steps_per_s": n_global * nt3 * n_mc / t3,
-                "log_evidence": float(post3.log_evidence), "log_evidence_error": float(post3.log_evidence_error),
-                "analytic_log_evidence": true_logz,
-                "abs_err_in_sigma": abs(float(post3.log_evidence) - true_logz) / max(float(post3.log_evidence_error), 1e-300),
-                "mean_accept": float(np.mean(sp3.history.mcmc_acceptance)),
-                "device_ms_per_mcmc_step": round(step_ms, 4),
-                "flow_kernel": {"bound": "mfma", "dtype": "f32", "avg_ms": round(flow_ms, 4), "flops_per_launch": flow_flops,
-                                "achieved_TFLOPs": round(flow_flops / (flow_ms * 1e-3) / 1e12, 1) if flow_ms else None,
-                                "peak_TFLOPs": 157.3,
-                                "frac": round(flow_flops / (flow_ms * 1e-3) / 1e12 / 157.3, 4) if flow_ms else None},
-            }
+            tx = time.perf_counter() - t0
+            ntx = len(spx.history.beta)
+            extra[label] = {"wall_s": round(tx, 4), "temperatures": ntx, "particle_steps_per_s": n_global * ntx * n_mc / tx,
+                            "log_evidence": float(postx.log_evidence), "log_evidence_error": float(postx.log_evidence_error),
+                            "abs_err_in_sigma": abs(float(postx.log_evidence) - true_logz) / max(float(postx.log_evidence_error), 1e-300),
+                            "mean_accept": float(np.mean(spx.history.mcmc_acceptance)), "noise": args.noise}
+        # (d) the headline run with the fast f32 noise generator
+        if args.noise == "f64":
+            run(3, noise="f32", n=min(n_global, 65536 * world), steps=2)
+            sync_all()
+            t0 = time.perf_counter()
+            spf, postf = run(4, noise="f32")
+            sync_all()
+            tf_ = time.perf_counter() - t0
+            extra["flow_run_f32_noise"] = {"wall_s": round(tf_, 4), "temperatures": len(spf.history.beta),
+                                           "particle_steps_per_s": n_global * len(spf.history.beta) * n_mc / tf_,
+                                           "abs_err_in_sigma": abs(float(postf.log_evidence) - true_logz) / max(float(postf.log_evidence_error), 1e-300)}
         result["extra"] = extra
 
-    # ---- CPU baseline: the oracle (kind "port") on a bounded sample, rank 0, N=1 only ---------------
+    # ---- CPU baseline: the oracle's restatement of the SAME mutation step (kind "port") on the host's cores -------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as O
 
+        ws, bs = cflow.export_layers()
+        loc, scale = cflow.loc.detach().cpu().numpy(), cflow.scale.detach().cpu().numpy()
+        g = np.random.default_rng(5)
         n_cpu = min(n_local, 1_000_000)
-        xc = x[:n_cpu].double().cpu().numpy()
-        llc, lpc, lqc = (t[:n_cpu].cpu().numpy() for t in (ll, lp, lq))
-        st = O.pcg64_state_from_numpy(np.random.default_rng(12345))
-        O.is_iteration(xc[:1000], llc[:1000], lpc[:1000], lqc[:1000], 0.0, 0.5, 1e-6, st.copy())  # warm the library
-        t0 = time.perf_counter()
-        n_it = 0
-        while True:
-            (_, _, _, _), sc = O.is_iteration(xc, llc, lpc, lqc, 0.0, 0.5, 1e-6, st)
-            n_it += 1
-            el = time.perf_counter() - t0
-            if el > 12.0 or n_it >= 20:
-                break
-        result["cpu_baseline"] = {"value": n_cpu * n_it / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
-                                  "sample": f"{n_it} IS-only temperature iterations of the same {n_cpu} x {d} fp64 batch "
-                                            f"(oracle/asmc_oracle.c orc_is_iteration, single thread)",
-                                  "host_cpus": os.cpu_count(), "beta": float(sc[0])}
-        result["cpu_baseline"]["beta_matches_gpu"] = bool(sc[0] == scal["beta"])
+        xc = np.sqrt(0.6) * g.normal(size=(n_cpu, d))  # a mid-schedule population
+        tg = O.Mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+        llc = -0.5 * np.sum(xc * xc, axis=1)
+        lpc = llc.copy()
+        lqc = np.zeros(n_cpu)
+        mu_c, L_c = np.zeros(d), np.sqrt(0.6) * np.eye(d)
+        Li_c = np.eye(d) / np.sqrt(0.6)
+        n_thr = O.max_threads()
+
+        def cpu_steps(n_part, threads, budget_s, max_steps):
+            xs, a, b, c = xc[:n_part].copy(), llc[:n_part].copy(), lpc[:n_part].copy(), lqc[:n_part].copy()
+            O.pcn_flow_step(xs[:256].copy(), a[:256].copy(), b[:256].copy(), c[:256].copy(), 0.5, mu_c, L_c, Li_c, 0.5, tg, tg, ws, bs,
+                            loc, scale, 9, 0, 0, "f64", threads)
+            t0, k = time.perf_counter(), 0
+            while True:
+                O.pcn_flow_step(xs, a, b, c, 0.5, mu_c, L_c, Li_c, 0.5, tg, tg, ws, bs, loc, scale, 9, 0, k, "f64", threads)
+                k += 1
+                el = time.perf_counter() - t0
+                if el > budget_s or k >= max_steps:
+                    return n_part * k / el, k, el
+
+        v1, k1, e1 = cpu_steps(min(n_cpu, 32768), 1, 6.0, 8)
+        vN, kN, eN = cpu_steps(n_cpu, 0, 12.0, 64)
+        result["cpu_baseline"] = {
+            "value": vN, "unit": "particle-steps/s", "cores": n_thr, "kind": "port",
+            "sample": f"{kN} mutation steps (pCN propose + coupling-flow log q in fp32 + targets + accept, the same flow and "
+                      f"noise streams; oracle/asmc_oracle.c orc_pcn_flow_step, OpenMP over particles) on {n_cpu} x {d} fp64 "
+                      f"particles, {eN:.1f} s",
+            "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
+            "single_thread": {"value": v1, "cores": 1, "sample": f"{k1} steps on {min(n_cpu, 32768)} particles, {e1:.1f} s"},
+            "gpu_over_cpu_all_cores": value / vN, "gpu_over_cpu_single_thread": value / v1,
+        }
+        try:  # restatement-to-reference ratio, measured in the build container (tools/ref_ratio.py)
+            result["cpu_baseline"]["port_vs_reference"] = json.load(open(os.path.join(ROOT, "profiles", "r02_ref_ratio.json")))
+        except Exception:
+            pass
     if rank == 0:
         print(json.dumps(result))
     if sharded:

@@ -89,6 +89,11 @@ def lib():
             "orc_is_iteration": (ci, [i64, ci, vp, vp, vp, vp, d, d, d, vp, vp, vp, vp, vp, vp]),
             "orc_coupling_logprob": (ci, [i64, ci, vp, ci, ci, vp, vp, vp, vp, vp]),
             "orc_transform": (ci, [i64, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, d, ci]),
+            "orc_pcn_flow_step": (
+                i64,
+                [i64, ci, vp, vp, vp, vp, d, vp, vp, vp, d, vp, vp, ci, ci, vp, vp, vp, vp, u64, u64, u32, ci, ci],
+            ),
+            "orc_max_threads": (ci, []),
         }
         for name, (res, args) in sig.items():
             fn = getattr(_lib, name)
@@ -426,6 +431,29 @@ def coupling_logprob(x, weights, biases, loc, scale):
     if st != 0:
         raise ValueError(f"orc_coupling_logprob failed ({st})")
     return out
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+def pcn_flow_step(x, ll, lp, lq, beta, mu, L, Linv, rho, t_ll, t_lp, weights, biases, loc, scale, seed, gid0, step,
+                  noise="f64", n_threads=1):
+    """In-place pCN step whose proposal density is a coupling flow (configs[2]); `n_threads` OpenMP threads
+    (0 = every core of the host).  Returns #accepted."""
+    assert x.dtype == np.float64 and x.flags.c_contiguous
+    n, d = x.shape
+    mu, L, Linv = _f64(mu), _f64(L), _f64(Linv)
+    ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+    bs = [np.ascontiguousarray(b, dtype=np.float32) for b in biases]
+    loc = np.ascontiguousarray(loc, dtype=np.float32)
+    scale = np.ascontiguousarray(scale, dtype=np.float32)
+    wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+    bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
+    a, b = t_ll.c_struct(), t_lp.c_struct()
+    return lib().orc_pcn_flow_step(n, d, _p(x), _p(ll), _p(lp), _p(lq), beta, _p(mu), _p(L), _p(Linv), rho,
+                                   ctypes.addressof(a), ctypes.addressof(b), len(ws) // 3, ws[0].shape[0], wp, bp,
+                                   loc.ctypes.data, scale.ctypes.data, seed, gid0, step, int(noise == "f32"), int(n_threads))
 
 
 def transform(x, kind, periodic, lower, upper, mean=None, std=None, eps=1e-6, inverse=False):

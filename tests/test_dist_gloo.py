@@ -123,6 +123,19 @@ def _worker(rank, world, port, out_dir, engine_kind="oracle"):
     res["own_logz"] = float(post2.log_evidence)
     res["own_logz_err"] = float(post2.log_evidence_error)
     res["own_n"] = len(post2.x)
+    # coupling-flow proposal trained SEPARATELY (and differently) on every rank: sample() must make the ranks agree on
+    # rank 0's parameters before anything is evaluated, and every rank draws its own shard
+    if engine_kind == "oracle":
+        from aspire_amd.flows import CouplingFlow
+
+        cf = CouplingFlow(d, n_layers=2, hidden_features=(16, 16), seed=11 + rank, dtype=torch.float64)
+        cf.fit(1.3 * np.random.default_rng(20 + rank).normal(size=(400, d)), n_epochs=3)
+        sp3 = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=cf, xp=np, engine=eng, comm=comm,
+                     rng=np.random.default_rng(4))
+        post3 = sp3.sample(512, sampler_kwargs=dict(n_steps=2, step_fn="pcn"), store_sample_history=False)
+        res["cf_params"] = torch.cat([p.detach().reshape(-1) for p in cf.layers.parameters()]).numpy()
+        res["cf_beta"] = np.array(sp3.history.beta)
+        res["cf_x0"] = (post3.x.detach().cpu().numpy() if torch.is_tensor(post3.x) else np.asarray(post3.x))[:4]
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -271,3 +284,10 @@ def test_owner_layout_sampler(two_rank_results):
     assert r0["own_beta"][0] == pytest.approx(r0["beta"][0], rel=1e-12)
     analytic = 2.0 * np.log(np.pi)  # (d/2) log pi, d = 4
     assert abs(float(r0["own_logz"]) - analytic) < 5 * float(r0["own_logz_err"]) + 0.05
+
+
+def test_sharded_run_with_trained_flow_agrees_on_rank0_parameters(two_rank_results):
+    r0, r1 = two_rank_results
+    assert np.array_equal(r0["cf_params"], r1["cf_params"])  # rank 1 took rank 0's flow
+    assert np.array_equal(r0["cf_beta"], r1["cf_beta"]) and r0["cf_beta"][-1] == 1.0
+    assert not np.array_equal(r0["cf_x0"], r1["cf_x0"])  # separate draw streams: the shards are not copies of each other

@@ -157,3 +157,44 @@ def test_transforms_golden(oracle, golden):
         clamp = (kind != 0)
         ok = inside & ~clamp
         np.testing.assert_allclose(xb[:, ok], g[f"{name}_x"][:, ok], rtol=1e-10, atol=1e-10)
+
+
+def test_flow_pcn_step_threads_equal_sequential_composition(oracle):
+    """orc_pcn_flow_step (bench.py's CPU baseline): any thread count gives the single-thread result, and that result is the
+    step spelled out with the oracle's own pieces (proposal of orc_pcn_step, orc_coupling_logprob, accept rule)."""
+    from conftest import random_coupling_flow
+
+    n, d = 700, 8
+    g = np.random.default_rng(3)
+    flow = random_coupling_flow(d, 2, 32)
+    ws, bs = flow.export_layers()
+    loc, scale = flow.loc.numpy(), flow.scale.numpy()
+    x0 = 1.2 * g.normal(size=(n, d))
+    tgt = oracle.Mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    ll0 = tgt.logpdf(x0)
+    lq0 = oracle.coupling_logprob(x0, ws, bs, loc, scale)
+    a = g.normal(size=(d, d)) / np.sqrt(d)
+    L = np.linalg.cholesky(np.eye(d) + 0.2 * a @ a.T)
+    Linv, mu = np.linalg.inv(L), 0.1 * g.normal(size=d)
+    outs = []
+    for nt in (1, 3, 0):
+        x, ll, lp, lq = x0.copy(), ll0.copy(), ll0.copy(), lq0.copy()
+        acc = oracle.pcn_flow_step(x, ll, lp, lq, 0.4, mu, np.tril(L), np.tril(Linv), 0.3, tgt, tgt, ws, bs, loc, scale, 77, 5, 2,
+                                   n_threads=nt)
+        outs.append((acc, x, ll, lq))
+    for acc, x, ll, lq in outs[1:]:
+        assert acc == outs[0][0] and np.array_equal(x, outs[0][1]) and np.array_equal(lq, outs[0][3])
+    acc, x, ll, lq = outs[0]
+    assert 0 < acc < n
+    # accepted rows carry the flow's log-density at the new position, rejected rows are untouched
+    moved = np.any(x != x0, axis=1)
+    assert moved.sum() == acc
+    np.testing.assert_array_equal(lq[moved], oracle.coupling_logprob(x[moved], ws, bs, loc, scale))
+    assert np.array_equal(lq[~moved], lq0[~moved]) and np.array_equal(ll[moved], tgt.logpdf(x[moved]))
+    # the proposals are orc_pcn_step's: a step with a flat log q accepts a superset-independent check of positions
+    x2, l2 = x0.copy(), ll0.copy()
+    flat = oracle.Mixture([0.0], np.zeros((1, d)), np.zeros((1, d)))
+    oracle.pcn_step(x2, l2, ll0.copy(), np.zeros(n), 0.4, mu, np.tril(L), np.tril(Linv), 0.3, tgt, tgt, flat, 77, 5, 2)
+    both = moved & np.any(x2 != x0, axis=1)
+    assert both.sum() > 10 and np.array_equal(x[both], x2[both])
+    assert oracle.max_threads() >= 1
