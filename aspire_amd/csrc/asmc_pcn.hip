@@ -269,20 +269,6 @@ __device__ __forceinline__ double mixture_eval_regs(const MixDev& m, const doubl
 // L and Linv are stored as PACKED lower triangles (row j at j(j+1)/2): 2 x 4.2 KB at d = 32, so that everything a
 // step touches (~10 KB) stays inside the 16 KB scalar data cache (dense 2 x 8 KB tables thrashed it).
 // layout (doubles): Ltri[D(D+1)/2] | Linvtri[D(D+1)/2] | mu[D] | 3 x { logw[8] | mu[8*D] | prec[8*D] }  (ll, lp, lq)
-#define PTAB_TRI(D) ((D) * ((D) + 1) / 2)
-#define PTAB_MIX(D) (ASMC_MAX_COMPONENTS * (1 + 2 * (D)))
-#define PTAB_SIZE(D) (2 * PTAB_TRI(D) + (D) + 3 * PTAB_MIX(D))
-struct PcnScalars {
-    double beta;
-    double nu;  // Student-t degrees of freedom of the reference (tpCN) or <= 0 (Gaussian pCN)
-    const double* gam;  // per-particle Gamma((d + nu)/2, 1) variates of this step (k_gamma_draw), nullptr for pCN
-    void* ys;           // coordinate-major whitened state (PCN_*_S modes)
-    long long n_pad;    // its row length (n rounded up to 64)
-    int d_real;         // PCN_X_PROPOSE_PAD*: the problem's dimension (< D)
-    unsigned long long seed, gid0;
-    int c_ll, c_lp, c_lq;
-};
-
 // v <- A v for a lower-triangular A stored packed by rows (wave-uniform, read through scalar loads), in place.
 // Descending row groups of RG: rows j0-RG+1..j0 only read v[0..j0], which later (lower) groups never need
 // overwritten entries of, so the update is legal in place.
@@ -346,29 +332,6 @@ __device__ __forceinline__ void wave_lds_sync() {
 // forms on the fly, which only works for single Gaussians); still one mat-vec per step and no LDS
 #define PCN_Y_STEP_SG 16
 #define PCN_Y_STEP_TSG 17
-
-// coordinate-major state through buffer instructions: one 128-bit descriptor in SGPRs, the lane as a 32-bit VGPR
-// offset and the coordinate's row (j * n_pad + tile) as the scalar offset - instead of one 64-bit VGPR address pair per
-// coordinate (32 pairs = 64 VGPRs held from the loads to the conditional stores with plain global accesses)
-template <typename T>
-__device__ __forceinline__ double soa_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    if constexpr (sizeof(T) == 8) {
-        const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
-        return __builtin_bit_cast(double, v);
-    } else {
-        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
-        return (double)__uint_as_float(v);
-    }
-}
-template <typename T>
-__device__ __forceinline__ void soa_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x) {
-    if constexpr (sizeof(T) == 8) {
-        using u2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), r, (int)voff, (int)soff, 0);
-    } else {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)x), r, (int)voff, (int)soff, 0);
-    }
-}
 
 // 64-row tile copies for rows of `dr` < D elements (PCN_X_PROPOSE_PAD): fully unrolled, element-wise coalesced
 // accesses, row index by multiplication with magic = floor(2^32 / dr) + 1 (exact for e < 2^16) - no run-time loop, no
@@ -1765,11 +1728,12 @@ int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
 
 // coordinate-major scratch for the whitened state of one mutation (grown on demand, kept for the life of the ctx);
 // false when the device has no room for it (callers then stay on the in-place row-major path)
-static bool pcn_ensure_ysoa(asmc_ctx* ctx, int64_t n, int d, int x_dtype, PcnDev& pd, hipStream_t st) {
+static bool pcn_ensure_ysoa(asmc_ctx* ctx, int64_t n, int d, int x_dtype, PcnDev& pd, hipStream_t st, bool with_scratch = false) {
     if (getenv("ASMC_PCN_AOS")) return false;
     const int64_t n_pad = ((n + 63) / 64) * 64;
-    const size_t need = (size_t)n_pad * d * (x_dtype == ASMC_F64 ? 8 : 4);
-    if (need >= (1ULL << 32)) return false;  // the kernels address the buffer through one 32-bit-offset descriptor
+    const size_t one = (size_t)n_pad * d * (x_dtype == ASMC_F64 ? 8 : 4);
+    if (one >= (1ULL << 32)) return false;  // the kernels address the buffer through one 32-bit-offset descriptor
+    const size_t need = with_scratch ? 2 * one : one;  // fused flow step: y' scratch of the same layout behind the state
     if (need > ctx->ysoa_bytes) {
         if (hipStreamSynchronize(st) != hipSuccess) return false;
         if (ctx->d_ysoa) (void)hipFree(ctx->d_ysoa);
@@ -2255,7 +2219,7 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
         if (rc) return rc;
         long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
         int grid = 0;
-        const bool soa = pcn_ensure_ysoa(ctx, n, d, prm->x_dtype, pd, st);
+        const bool soa = pcn_ensure_ysoa(ctx, n, d, prm->x_dtype, pd, st, asmc_pcn_flow_fused_ok(prm, flow));
         auto convert = [&](int mode) -> int {
             PcnDev pc = pd;
             pc.mode = !soa ? mode : mode == PCN_WHITEN ? PCN_WHITEN_S : PCN_UNWHITEN_XS;
@@ -2266,7 +2230,22 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
         };
         rc = convert(PCN_WHITEN);
         if (rc) return rc;
-        for (int t = 0; t < n_steps; t++) {
+        // one kernel per step (propose -> flow on the MFMA -> targets -> accept) where the shape allows it
+        const bool fused = soa && asmc_pcn_flow_fused_ok(prm, flow);
+        if (fused) ASMC_HIP(hipMemsetAsync(ctx->d_tilectr, 0, sizeof(unsigned int) * (size_t)n_steps, st));
+        for (int t = 0; t < (fused ? n_steps : 0); t++) {
+            const uint32_t step = step0 + (uint32_t)t;
+            rc = pcn_prepare_gamma(ctx, n, pd, step, st);
+            if (rc) return rc;
+            if (prm->x_dtype == ASMC_F64)
+                rc = asmc_pcn_flow_fused_launch(ctx, n, ASMC_F64, ll, lp, lq, pd, flow, d_rho, step, ctx->d_tilectr + t, d_block, &grid, st);
+            else
+                rc = asmc_pcn_flow_fused_launch(ctx, n, ASMC_F32, ll, lp, lq, pd, flow, d_rho, step, ctx->d_tilectr + t, d_block, &grid, st);
+            if (rc) return rc;
+            rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+            if (rc) return rc;
+        }
+        for (int t = 0; t < (fused ? 0 : n_steps); t++) {
             const uint32_t step = step0 + (uint32_t)t;
             rc = pcn_prepare_gamma(ctx, n, pd, step, st);
             if (rc) return rc;

@@ -185,6 +185,53 @@ struct PcnDev {
 };
 
 
+// ---- packed parameter block and coordinate-major state access of the register-resident kernels (d <= 32) ---------
+// layout (doubles): Ltri[D(D+1)/2] | Linvtri[D(D+1)/2] | mu[D] | 3 x { logw[8] | mu[8*D] | prec[8*D] }  (ll, lp, lq)
+#define PTAB_TRI(D) ((D) * ((D) + 1) / 2)
+#define PTAB_MIX(D) (ASMC_MAX_COMPONENTS * (1 + 2 * (D)))
+#define PTAB_SIZE(D) (2 * PTAB_TRI(D) + (D) + 3 * PTAB_MIX(D))
+struct PcnScalars {
+    double beta;
+    double nu;  // Student-t degrees of freedom of the reference (tpCN) or <= 0 (Gaussian pCN)
+    const double* gam;  // per-particle Gamma((d + nu)/2, 1) variates of this step (k_gamma_draw), nullptr for pCN
+    void* ys;           // coordinate-major whitened state (PCN_*_S modes)
+    long long n_pad;    // its row length (n rounded up to 64)
+    int d_real;         // PCN_X_PROPOSE_PAD*: the problem's dimension (< D)
+    unsigned long long seed, gid0;
+    int c_ll, c_lp, c_lq;
+};
+
+
+// coordinate-major state through buffer instructions: one 128-bit descriptor in SGPRs, the lane as a 32-bit VGPR
+// offset and the coordinate's row (j * n_pad + tile) as the scalar offset - instead of one 64-bit VGPR address pair per
+// coordinate (32 pairs = 64 VGPRs held from the loads to the conditional stores with plain global accesses)
+template <typename T>
+__device__ __forceinline__ double soa_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (sizeof(T) == 8) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+        return __builtin_bit_cast(double, v);
+    } else {
+        const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+        return (double)__uint_as_float(v);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void soa_store(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x) {
+    if constexpr (sizeof(T) == 8) {
+        using u2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), r, (int)voff, (int)soff, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)x), r, (int)voff, (int)soff, 0);
+    }
+}
+
+
+// fused flow-proposal step (asmc_pcn_fused.hip)
+bool asmc_pcn_flow_fused_ok(const asmc_pcn_params* prm, const asmc_coupling* f);
+int asmc_pcn_flow_fused_launch(asmc_ctx* ctx, int64_t n, int x_dtype, double* ll, double* lp, double* lq, const PcnDev& pd,
+                               const asmc_coupling* f, const double* rho_ptr, uint32_t step, unsigned int* tile_counter,
+                               long long* block_counts, int* grid_out, hipStream_t st);
+
 // d = 64 / 128 pCN on the fp64 matrix cores (asmc_pcn_mm.hip)
 #define MM_WHITEN 0
 #define MM_STEP 1

@@ -1,0 +1,320 @@
+// asmc_pcn_fused.hip — the flow-proposal pCN step as ONE kernel.
+#include <stdlib.h>
+
+#include "asmc_common.h"
+#include "asmc_pcn_dev.h"
+#include "asmc_flow_dev.h"
+
+// =============================================================================================================
+// Fused flow-proposal pCN step (reference smc/minipcn.py:97-114 around smc/base.py:507-519 with
+// flows/torch/flows.py:368-387 as log q): propose -> coupling flow on the fp32 MFMA -> built-in targets -> accept in ONE
+// kernel.  x' never touches HBM, y' is not regenerated, the step is one launch instead of three.
+//
+// A wave takes 64 particles at a time from a device-side tile counter (no ragged last round).  Phase 1 is the
+// register-resident proposal of k_pcn_reg_flow: one lane per particle, y read coordinate-major, y' = a y + rho xi,
+// x' = mu + L y' four rows at a time with wave-uniform coefficients (scalar loads), folded into the two quadratic forms
+// of the targets and converted to the flow's standardised fp32 input on the fly.  The flow kernel wants 32 particles
+// per tile with the two lane halves splitting each particle's coordinates: ONE v_permlane32_swap per register pair
+// (coordinate j of the lower coordinate block, coordinate j + 8 of the upper one) turns the 64 lane-private rows into
+// the operands of TWO flow tiles at once - its first result is tile A (particles 0-31: own value in the lower half, the
+// partner block from lane l - 32 in the upper half), its second tile B (particles 32-63).  After the four coupling
+// layers both halves of a tile hold log q, so lane l < 32 reads tile A's and lane l >= 32 tile B's: no shuffle back.
+// Phase 3 is the accept step on the lane's own particle: y <- y' for accepted lanes only.  y' does not wait in registers
+// for that (64 VGPRs next to the flow's accumulators would not fit two waves per SIMD): phase 1 parks it in a scratch
+// buffer of the state's layout (fire-and-forget stores), accepted lanes fetch it back (cache-hot) and store it into the state.
+// The flow's weights stay resident in LDS (115 KB at d = 32, W = 64: one block of 8 waves per CU, two waves per SIMD, so
+// one wave's vector work - noise, mat-vec, accept - runs in the shadow of its partner's MFMA chains).
+template <typename T, int W, int NOISE>
+__global__ __launch_bounds__(512) void k_pcn_flow_fused(
+    int64_t n, double* __restrict__ ll, double* __restrict__ lp, double* __restrict__ lq, const double* __restrict__ ptab,
+    PcnScalars p, const double* __restrict__ rho_ptr, uint32_t step, const float* __restrict__ packed, int n_layers,
+    const float* __restrict__ loc, const float* __restrict__ scale, float ladj0, float base_const,
+    unsigned int* __restrict__ tile_counter, long long* __restrict__ block_counts) {
+    constexpr int D = 32, H = 16, THREADS = 512;
+    using FD = FlowDims<H, W>;
+    extern __shared__ __align__(16) float sp[];
+    {   // flow weights -> LDS; all of a thread's loads are issued before its first LDS store
+        const int total4 = n_layers * FD::LAYER / 4;
+        for (int base = 0; base < total4; base += THREADS * 8) {
+            float4 tmp[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i4 = base + q * THREADS + threadIdx.x;
+                tmp[q] = i4 < total4 ? reinterpret_cast<const float4*>(packed)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i4 = base + q * THREADS + threadIdx.x;
+                if (i4 < total4) reinterpret_cast<float4*>(sp)[i4] = tmp[q];
+            }
+        }
+    }
+    // pCN tables behind the weights, read by every lane at the same address (LDS broadcast): the dense lower triangle of
+    // L (row stride D, so that two consecutive coefficients are one aligned 16-byte read), mu, the two targets' mean /
+    // precision rows and constants, the flow's loc / scale.  (Scalar loads would be the natural home of wave-uniform
+    // coefficients, but inside this kernel's tile loop LLVM issues all ~1400 of them up front and spills the SGPRs.)
+    double* tl = reinterpret_cast<double*>(sp + (size_t)n_layers * FD::LAYER);
+    constexpr int T_MU = D * D, T_LLMU = T_MU + D, T_LLPR = T_LLMU + D, T_LPMU = T_LLPR + D, T_LPPR = T_LPMU + D,
+                  T_LOGW = T_LPPR + D, T_LOC = T_LOGW + 2;  // then loc / scale: 2 x D floats = D doubles
+    {
+        const double* m0g = ptab + 2 * PTAB_TRI(D) + D;
+        for (int e = threadIdx.x; e < D * D; e += THREADS) {
+            const int j = e / D, k = e - j * D;
+            tl[e] = k <= j ? ptab[j * (j + 1) / 2 + k] : 0.0;
+        }
+        for (int e = threadIdx.x; e < D; e += THREADS) {
+            tl[T_MU + e] = ptab[2 * PTAB_TRI(D) + e];
+            tl[T_LLMU + e] = m0g[ASMC_MAX_COMPONENTS + e];
+            tl[T_LLPR + e] = m0g[ASMC_MAX_COMPONENTS * (1 + D) + e];
+            tl[T_LPMU + e] = m0g[PTAB_MIX(D) + ASMC_MAX_COMPONENTS + e];
+            tl[T_LPPR + e] = m0g[PTAB_MIX(D) + ASMC_MAX_COMPONENTS * (1 + D) + e];
+            reinterpret_cast<float*>(tl + T_LOC)[e] = loc[e];
+            reinterpret_cast<float*>(tl + T_LOC)[D + e] = scale[e];
+        }
+        if (threadIdx.x == 0) tl[T_LOGW] = m0g[0], tl[T_LOGW + 1] = m0g[PTAB_MIX(D)];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5;
+    const double rho = *rho_ptr;
+    const double a = sqrt(1.0 - rho * rho);
+    const int64_t n_tiles = (n + 63) / 64;
+    long long n_acc = 0;
+    // coordinate-major state through one buffer descriptor (see soa_load / soa_store)
+    const unsigned long long ysa = (unsigned long long)(uintptr_t)p.ys;
+    T* ysu = reinterpret_cast<T*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ysa >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ysa));
+    const __amdgpu_buffer_rsrc_t ysr = __builtin_amdgcn_make_buffer_rsrc(
+        ysu, 0, (int)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p.n_pad * D * sizeof(T))), 0x00020000);
+    const unsigned ys_row = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p.n_pad) * (unsigned)sizeof(T);
+    const unsigned ys_lane = (unsigned)lane * (unsigned)sizeof(T);
+    // y' scratch: the second half of the state allocation, same layout
+    const __amdgpu_buffer_rsrc_t ypr = __builtin_amdgcn_make_buffer_rsrc(
+        ysu + (size_t)__builtin_amdgcn_readfirstlane((int)(unsigned)p.n_pad) * D, 0,
+        (int)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p.n_pad * D * sizeof(T))), 0x00020000);
+    for (;;) {
+        unsigned t_l = 0;
+        if (lane == 0) t_l = atomicAdd(tile_counter, 1u);
+        const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)t_l);
+        if ((int64_t)t >= n_tiles) break;
+#ifdef FUSED_NOLOOP
+        if (t_l != 0xFFFFFFFFu) n_acc += 0;
+#endif
+        // the tables are loop invariant: an offset LLVM cannot see through keeps their reads inside the tile loop (hoisted,
+        // they would need a thousand registers)
+        int zoff;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
+        const double* __restrict__ Lt = tl + zoff;
+        const float* __restrict__ locs = reinterpret_cast<const float*>(tl + T_LOC) + zoff;
+        const int64_t i = (int64_t)t * 64 + lane;
+        const bool valid = i < n;
+        const unsigned ys_tile = t * 64u * (unsigned)sizeof(T);
+        const unsigned long long gid = p.gid0 + (unsigned long long)i;
+        // ---- phase 1: proposal, one lane per particle -------------------------------------------------------------
+        double v[D];
+#pragma unroll
+        for (int j = 0; j < D; j++) v[j] = valid ? soa_load<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row) : 0.0;
+        double oll = 0.0, olp = 0.0, olq = 0.0;
+        if (valid) oll = ll[i], olp = lp[i], olq = lq[i];
+        double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; j++) q0 = fma(v[j], v[j], q0);
+        const double rs = tpcn_scale(rho, p.nu, q0, p.gam, valid ? i : 0);
+        if (NOISE == ASMC_NOISE_F64) {
+#pragma unroll
+            for (int pr = 0; pr < D / 2; pr++) {
+                double z0, z1;
+                normal_pair(p.seed, gid, step, (uint32_t)pr, z0, z1);
+                v[2 * pr] = (double)(T)fma(rs, z0, a * v[2 * pr]);
+                v[2 * pr + 1] = (double)(T)fma(rs, z1, a * v[2 * pr + 1]);
+                q1 = fma(v[2 * pr], v[2 * pr], q1);
+                q1 = fma(v[2 * pr + 1], v[2 * pr + 1], q1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int qd = 0; qd < D / 4; qd++) {
+                double z[4];
+                normal_quad_f32(p.seed, gid, step, (uint32_t)qd, z[0], z[1], z[2], z[3]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
+                    q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
+                }
+                if (qd & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // x'_j = mu_j + sum_k L[j,k] y'_k, four rows at a time: straight into the targets' quadratic forms and into the
+        // flow's standardised fp32 input (the same (float) x' and division the stand-alone flow kernel applies)
+        float xf[D];
+        double qa = 0.0, qb = 0.0;
+#pragma unroll
+        for (int g = 0; g < D / 4; g++) {
+            const int j0 = 4 * g;
+            double sr[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < j0 + 4; k++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (k <= j0 + r) sr[r] = fma(Lt[(j0 + r) * D + k], v[k], sr[r]);
+                // ordering point every eight columns: the four running sums pass through an opaque statement that also
+                // counts as a memory write, so this chunk's FMAs stay in front of it and the next chunk's coefficient
+                // reads behind it.  (Left alone, instruction selection emits all ~560 LDS reads of the tile first and
+                // the FMAs after them, and the reads' results spill.)
+                if ((k & 7) == 7 || k == j0 + 3) asm volatile("" : "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3])::"memory");
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int j = j0 + r;
+                const double xj = (double)(T)(Lt[T_MU + j] + sr[r]);
+                const double ta = xj - Lt[T_LLMU + j], tb = xj - Lt[T_LPMU + j];
+                qa = fma(ta * ta, Lt[T_LLPR + j], qa);
+                qb = fma(tb * tb, Lt[T_LPPR + j], qb);
+                xf[j] = ((float)xj - locs[j]) / locs[D + j];
+            }
+        }
+        const double nll = Lt[T_LOGW] - 0.5 * qa;
+        const double nlp = Lt[T_LOGW + 1] - 0.5 * qb;
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < D; j++) soa_store<T>(ypr, ys_lane, ys_tile + (unsigned)j * ys_row, v[j]);
+        }
+#ifndef FUSED_NOSB
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        // ---- phase 2: two flow tiles (particles 0-31 and 32-63 of this wave) on the MFMA -----------------------------
+        float xaA[1][H / 2], xbA[1][H / 2], xaB[1][H / 2], xbB[1][H / 2];
+#pragma unroll
+        for (int r = 0; r < H / 2; r++) {
+            const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf[r]), __float_as_uint(xf[H / 2 + r]), false, false);
+            xaA[0][r] = __uint_as_float(s1[0]);
+            xaB[0][r] = __uint_as_float(s1[1]);
+            const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf[H + r]), __float_as_uint(xf[H + H / 2 + r]), false, false);
+            xbA[0][r] = __uint_as_float(s2[0]);
+            xbB[0][r] = __uint_as_float(s2[1]);
+        }
+        // (two explicit calls: as a loop over the tiles the flow's A-operand reads become loop invariant and LLVM hoists
+        // all 448 of them in front of it)
+        auto flow_tile = [&](float(&xa)[1][H / 2], float(&xb)[1][H / 2]) __attribute__((always_inline)) -> float {
+            float ladj[1] = {0.0f};
+#ifndef FUSED_NOFLOW
+            for (int c = 0; c < n_layers; c++) {
+                const float* lpk = sp + (size_t)c * FD::LAYER;
+                if ((c & 1) == 0)
+                    coupling_layer<H, W, 1>(xa, xb, lpk, lane, hh, ladj);
+                else
+                    coupling_layer<H, W, 1>(xb, xa, lpk, lane, hh, ladj);
+            }
+#endif
+            float q = 0.0f;
+#pragma unroll
+            for (int r = 0; r < H / 2; r++) q += xa[0][r] * xa[0][r] + xb[0][r] * xb[0][r];
+            q += __shfl_xor(q, 32);
+            const float lj = ladj[0] + __shfl_xor(ladj[0], 32);
+            return (-0.5f * q + base_const) + (ladj0 + lj);
+        };
+        float lqt[2];
+        lqt[0] = flow_tile(xaA, xbA);
+        __builtin_amdgcn_sched_barrier(0);  // one tile's accumulator chains at a time
+        lqt[1] = flow_tile(xaB, xbB);
+        __builtin_amdgcn_sched_barrier(0);
+        const double nlq = (double)(hh == 0 ? lqt[0] : lqt[1]);
+        // ---- phase 3: accept, on the lane's own particle ---------------------------------------------------------------
+        const double lpn = log_p_t(nll, nlp, nlq, p.beta);
+        const double lpo = log_p_t(oll, olp, olq, p.beta);
+        const double log_a = (lpn + ref_corr(q1, p.nu, D)) - (lpo + ref_corr(q0, p.nu, D));
+        const double u = accept_uniform(p.seed, gid, step);
+        if (valid && log(u) < log_a) {
+            double w[D];
+#pragma unroll
+            for (int j = 0; j < D; j++) w[j] = soa_load<T>(ypr, ys_lane, ys_tile + (unsigned)j * ys_row);
+#pragma unroll
+            for (int j = 0; j < D; j++) soa_store<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row, w[j]);
+            ll[i] = nll;
+            lp[i] = nlp;
+            lq[i] = nlq;
+            n_acc++;
+        }
+#ifndef FUSED_NOSB
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef FUSED_NOLOOP
+        break;
+#endif
+    }
+    __shared__ long long s_cnt[THREADS / 64];
+    n_acc = wave_sum_ll(n_acc);
+    if (lane == 0) s_cnt[wave] = n_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long tsum = 0;
+        for (int w = 0; w < THREADS / 64; w++) tsum += s_cnt[w];
+        block_counts[blockIdx.x] = tsum;
+    }
+}
+
+template <typename T>
+static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* lp, double* lq, const PcnDev& pd,
+                                 const asmc_coupling* f, const double* rho_ptr, uint32_t step, unsigned int* tile_counter,
+                                 long long* block_counts, int* grid_out, hipStream_t st) {
+    PcnScalars ps;
+    ps.beta = pd.beta;
+    ps.nu = pd.nu;
+    ps.gam = pd.gam;
+    ps.ys = pd.ys;
+    ps.n_pad = pd.n_pad;
+    ps.d_real = pd.d;
+    ps.seed = pd.seed;
+    ps.gid0 = pd.gid0;
+    ps.c_ll = pd.ll.C;
+    ps.c_lp = pd.lp.C;
+    ps.c_lq = 0;
+    const float ladj0 = (float)(-f->log_scale_sum);
+    const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
+    const int64_t n_tiles = (n + 63) / 64;
+    const int grid = (int)(n_tiles < (int64_t)ctx->num_cu * 8 ? (n_tiles + 7) / 8 : ctx->num_cu);  // one 8-wave block per CU
+    *grid_out = grid;
+#define ASMC_FUSED_CASE(WW, NZ)                                                                                          \
+    if (f->hidden == WW && pd.noise == NZ) {                                                                             \
+        auto kern = k_pcn_flow_fused<T, WW, NZ>;                                                                         \
+        const size_t lds = (size_t)f->n_layers * FlowDims<16, WW>::LAYER * sizeof(float) + (32 * 32 + 7 * 32 + 2) * sizeof(double); \
+        static size_t attr_lds = 0;                                                                                      \
+        if (lds > 64 * 1024 && lds > attr_lds) {                                                                         \
+            ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_lds = lds;                                                                                              \
+        }                                                                                                                \
+        ASMC_LAUNCH(ctx, st, "k_pcn_flow_fused", kern, dim3(grid), dim3(512), lds, st, n, ll, lp, lq,                     \
+                    (const double*)ctx->d_ptab, ps, rho_ptr, step, f->packed_dev, (int)f->n_layers, f->loc_dev, f->scale_dev, \
+                    ladj0, base_const, tile_counter, block_counts);                                                     \
+        ASMC_LAUNCH_CHECK();                                                                                             \
+        return ASMC_OK;                                                                                                  \
+    }
+    ASMC_FUSED_CASE(64, ASMC_NOISE_F64)
+    ASMC_FUSED_CASE(64, ASMC_NOISE_F32)
+    ASMC_FUSED_CASE(32, ASMC_NOISE_F64)
+    ASMC_FUSED_CASE(32, ASMC_NOISE_F32)
+    ASMC_FUSED_CASE(128, ASMC_NOISE_F64)
+    ASMC_FUSED_CASE(128, ASMC_NOISE_F32)
+#undef ASMC_FUSED_CASE
+    asmc_set_error("fused flow step: unsupported hidden width %d", (int)f->hidden);
+    return ASMC_ERR_UNSUPPORTED;
+}
+
+// whether the fused step covers this mutation: d = 32 on the coordinate-major whitened state, single-Gaussian targets,
+// every coupling layer resident in LDS next to nothing else
+bool asmc_pcn_flow_fused_ok(const asmc_pcn_params* prm, const asmc_coupling* f) {
+    if (getenv("ASMC_FLOW_SPLIT")) return false;
+    if (prm->d != 32 || f->dims != 32) return false;
+    if (prm->log_likelihood.n_components != 1 || prm->log_prior.n_components != 1) return false;
+    if (!(f->hidden == 32 || f->hidden == 64 || f->hidden == 128)) return false;
+    const size_t per_layer = (size_t)((2 * (f->hidden / 32) + 1) * 32 + f->hidden * 16 + f->hidden * f->hidden + 2 * 16 * f->hidden) * sizeof(float);
+    return per_layer * (size_t)f->n_layers <= 150 * 1024;
+}
+
+
+int asmc_pcn_flow_fused_launch(asmc_ctx* ctx, int64_t n, int x_dtype, double* ll, double* lp, double* lq, const PcnDev& pd,
+                               const asmc_coupling* f, const double* rho_ptr, uint32_t step, unsigned int* tile_counter,
+                               long long* block_counts, int* grid_out, hipStream_t st) {
+    if (x_dtype == ASMC_F64)
+        return launch_pcn_flow_fused<double>(ctx, n, ll, lp, lq, pd, f, rho_ptr, step, tile_counter, block_counts, grid_out, st);
+    return launch_pcn_flow_fused<float>(ctx, n, ll, lp, lq, pd, f, rho_ptr, step, tile_counter, block_counts, grid_out, st);
+}
