@@ -75,10 +75,26 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5;
+    const bool first_on_simd = __builtin_amdgcn_readfirstlane(wave) < 4;
     const double rho = *rho_ptr;
     const double a = sqrt(1.0 - rho * rho);
     const int64_t n_tiles = (n + 63) / 64;
     long long n_acc = 0;
+#ifdef FUSED_STAMP
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    int ntile = 0;
+#define STAMP(k)                                                  \
+    do {                                                          \
+        __builtin_amdgcn_sched_barrier(0);                        \
+        unsigned long long tn_;                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_)::"memory"); \
+        tsum[k] += tn_ - tprev;                                   \
+        tprev = tn_;                                              \
+        __builtin_amdgcn_sched_barrier(0);                        \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
     // coordinate-major state through one buffer descriptor (see soa_load / soa_store)
     const unsigned long long ysa = (unsigned long long)(uintptr_t)p.ys;
     T* ysu = reinterpret_cast<T*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ysa >> 32)) << 32) |
@@ -91,11 +107,15 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
     const __amdgpu_buffer_rsrc_t ypr = __builtin_amdgcn_make_buffer_rsrc(
         ysu + (size_t)__builtin_amdgcn_readfirstlane((int)(unsigned)p.n_pad) * D, 0,
         (int)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p.n_pad * D * sizeof(T))), 0x00020000);
+#ifdef FUSED_STAMP
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
     for (;;) {
         unsigned t_l = 0;
         if (lane == 0) t_l = atomicAdd(tile_counter, 1u);
         const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)t_l);
         if ((int64_t)t >= n_tiles) break;
+        STAMP(0);
 #ifdef FUSED_NOLOOP
         if (t_l != 0xFFFFFFFFu) n_acc += 0;
 #endif
@@ -118,6 +138,7 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
         double q0 = 0.0, q1 = 0.0;
 #pragma unroll
         for (int j = 0; j < D; j++) q0 = fma(v[j], v[j], q0);
+        STAMP(1);
         const double rs = tpcn_scale(rho, p.nu, q0, p.gam, valid ? i : 0);
         if (NOISE == ASMC_NOISE_F64) {
 #pragma unroll
@@ -143,6 +164,7 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
                 if (qd & 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        STAMP(2);
         // x'_j = mu_j + sum_k L[j,k] y'_k, four rows at a time: straight into the targets' quadratic forms and into the
         // flow's standardised fp32 input (the same (float) x' and division the stand-alone flow kernel applies)
         float xf[D];
@@ -171,13 +193,25 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
                 qb = fma(tb * tb, Lt[T_LPPR + j], qb);
                 xf[j] = ((float)xj - locs[j]) / locs[D + j];
             }
+            // ... and one behind the group's epilogue, so that its 28 table reads are not issued a row group early
+            asm volatile("" : "+v"(qa), "+v"(qb), "+v"(xf[j0]), "+v"(xf[j0 + 1]), "+v"(xf[j0 + 2]), "+v"(xf[j0 + 3])::"memory");
         }
         const double nll = Lt[T_LOGW] - 0.5 * qa;
         const double nlp = Lt[T_LOGW + 1] - 0.5 * qb;
+        STAMP(3);
         if (valid) {
 #pragma unroll
             for (int j = 0; j < D; j++) soa_store<T>(ypr, ys_lane, ys_tile + (unsigned)j * ys_row, v[j]);
         }
+        // everything of the acceptance test that does not need log q(x') is finished HERE, and pinned: left to the
+        // scheduler these computations sink below the flow, y' (64 VGPRs) stays alive across it for |y'|^2, and the
+        // accumulators spill.  log_p_t(ll', lp', lq') = (1 - beta) lq' + beta (ll' + lp'): the second product is formed now.
+        double t2 = p.beta * (nll + nlp);
+        double c1 = ref_corr(q1, p.nu, D);
+        double rhs = log_p_t(oll, olp, olq, p.beta) + ref_corr(q0, p.nu, D);
+        double logu = log(accept_uniform(p.seed, gid, step));
+        double kll = nll, klp = nlp;
+        asm volatile("" : "+v"(t2), "+v"(c1), "+v"(rhs), "+v"(logu), "+v"(kll), "+v"(klp));
 #ifndef FUSED_NOSB
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -212,28 +246,43 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
             const float lj = ladj[0] + __shfl_xor(ladj[0], 32);
             return (-0.5f * q + base_const) + (ladj0 + lj);
         };
+        // The two waves of a SIMD (waves w and w + 4 of the block) run the same program; left alone they fall into
+        // lockstep - both in the vector phases, then both fighting for the matrix pipe - and the MFMA sits idle half the
+        // time.  Static priorities break the tie: a wave in its matrix phase outranks a wave in a vector phase, and the
+        // first wave of a SIMD outranks the second when both are in the matrix phase, which pushes them into anti-phase.
+        if (first_on_simd)
+            __builtin_amdgcn_s_setprio(2);
+        else
+            __builtin_amdgcn_s_setprio(1);
+        STAMP(4);
         float lqt[2];
         lqt[0] = flow_tile(xaA, xbA);
         __builtin_amdgcn_sched_barrier(0);  // one tile's accumulator chains at a time
+        STAMP(5);
         lqt[1] = flow_tile(xaB, xbB);
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+        STAMP(6);
         const double nlq = (double)(hh == 0 ? lqt[0] : lqt[1]);
         // ---- phase 3: accept, on the lane's own particle ---------------------------------------------------------------
-        const double lpn = log_p_t(nll, nlp, nlq, p.beta);
-        const double lpo = log_p_t(oll, olp, olq, p.beta);
-        const double log_a = (lpn + ref_corr(q1, p.nu, D)) - (lpo + ref_corr(q0, p.nu, D));
-        const double u = accept_uniform(p.seed, gid, step);
-        if (valid && log(u) < log_a) {
+        double lpn = (1.0 - p.beta) * nlq + t2;
+        lpn = (lpn != lpn) ? -INFINITY : lpn;
+        const double log_a = (lpn + c1) - rhs;
+        if (valid && logu < log_a) {
             double w[D];
 #pragma unroll
             for (int j = 0; j < D; j++) w[j] = soa_load<T>(ypr, ys_lane, ys_tile + (unsigned)j * ys_row);
 #pragma unroll
             for (int j = 0; j < D; j++) soa_store<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row, w[j]);
-            ll[i] = nll;
-            lp[i] = nlp;
+            ll[i] = kll;
+            lp[i] = klp;
             lq[i] = nlq;
             n_acc++;
         }
+        STAMP(7);
+#ifdef FUSED_STAMP
+        ntile++;
+#endif
 #ifndef FUSED_NOSB
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -241,6 +290,11 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
         break;
 #endif
     }
+#ifdef FUSED_STAMP
+    if (lane == 0 && blockIdx.x == 7 && (wave == 0 || wave == 4) && ntile > 0)
+        printf("wave %d tiles %d | fetch %llu yload %llu noise %llu matvec %llu park+swap %llu flowA %llu flowB %llu accept %llu (cycles per tile)\n", wave, ntile,
+               tsum[0] / ntile, tsum[1] / ntile, tsum[2] / ntile, tsum[3] / ntile, tsum[4] / ntile, tsum[5] / ntile, tsum[6] / ntile, tsum[7] / ntile);
+#endif
     __shared__ long long s_cnt[THREADS / 64];
     n_acc = wave_sum_ll(n_acc);
     if (lane == 0) s_cnt[wave] = n_acc;
