@@ -942,9 +942,9 @@ def test_config3_flow_proposal_runs_on_the_mfma_path(eng):
     out = sp.sample(n, sampler_kwargs=dict(n_steps=8), store_sample_history=False)
     rep = eng.profile_report()
     eng.profile(False)
-    assert rep["k_coupling_logprob"][0] >= 8 * (len(sp.history.beta) - 1)
-    assert rep["k_pcn_flow_propose"][0] == rep["k_pcn_flow_accept"][0] >= 8
-    assert "k_pcn_propose" not in rep  # not the generic split path
+    # d = 32, single-Gaussian targets, resident flow: the whole step is ONE kernel (propose -> flow on the MFMA -> accept)
+    assert rep["k_pcn_flow_fused"][0] == 8 * len(sp.history.beta)
+    assert "k_pcn_propose" not in rep and "k_pcn_flow_propose" not in rep  # neither split path
     true = 0.5 * d * math.log(math.pi)
     assert sp.history.beta[-1] == 1.0
     assert abs(float(out.log_evidence) - true) < 5 * float(out.log_evidence_error) + 0.05, (float(out.log_evidence), true)
@@ -1513,3 +1513,102 @@ def test_pcn_whitened_state_with_mixture_targets_vs_oracle(eng, oracle, d, C, nu
     assert 0.02 < np.mean(n_acc) / n < 0.98
     np.testing.assert_allclose(lld.cpu().numpy(), om[0].logpdf(got), rtol=1e-10, atol=1e-9)
     np.testing.assert_allclose(lqd.cpu().numpy(), om[2].logpdf(got), rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("xdt,nu,noise,hidden,n", [("f64", 0.0, "f64", 64, 5000), ("f32", 0.0, "f64", 64, 4097), ("f64", 5.0, "f64", 64, 5000),
+                                                   ("f64", 0.0, "f32", 64, 70001), ("f64", 0.0, "f64", 32, 3000), ("f64", 0.0, "f64", 128, 640),
+                                                   ("f64", 0.0, "f64", 64, 1)])
+def test_pcn_flow_fused_step_vs_split_calls(eng, xdt, nu, noise, hidden, n):
+    """The fused flow-proposal step (k_pcn_flow_fused: propose -> coupling flow on the MFMA -> built-in targets -> accept in
+    one kernel; d = 32, single-Gaussian targets) against the same steps issued one ABI call at a time in x space, each of
+    which is checked against the oracle above: same proposals (same Philox counters), same flow arithmetic (the
+    stand-alone kernel's tile code), so positions agree to the rounding of the whitened state and accept decisions differ
+    only at razor edges; carried log-probabilities equal the densities at the returned positions; ragged last tile."""
+    from conftest import random_coupling_flow
+
+    d, n_steps, beta, rho = 32, 5, 0.35, 0.4
+    dt = torch.float64 if xdt == "f64" else torch.float32
+    flow = random_coupling_flow(d, 4, hidden)
+    dev = flow.device_coupling(eng)
+    g = torch.Generator(eng.device).manual_seed(3)
+    x0 = torch.randn((n, d), device=eng.device, dtype=torch.float64, generator=g).to(dt)
+    t_ll = eng.make_mixture([0.3], np.full((1, d), 0.25), np.ones((1, d)) * 1.5)
+    t_lp = eng.make_mixture([-0.5 * d * np.log(2 * np.pi)], np.zeros((1, d)), np.ones((1, d)))
+    mu = eng.asarray(0.1 * np.arange(d) / d)
+    A = np.eye(d) + 0.05 * np.tril(np.random.default_rng(2).normal(size=(d, d)), -1)
+    L, Linv = eng.asarray(A), eng.asarray(np.linalg.inv(A))
+
+    def init():
+        x = x0.clone()
+        return x, eng.mixture_logpdf(x, t_ll), eng.mixture_logpdf(x, t_lp), eng.coupling_logprob(x, dev)
+
+    xa, lla, lpa, lqa = init()
+    eng.profile(True)
+    n_acc, rho_hist, rho_out = eng.pcn_mutate_flow(xa, lla, lpa, lqa, beta, mu, L, Linv, t_ll, t_lp, dev, 77, 1000, rho,
+                                                   n_steps, 5, 0.234, False, noise, nu)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert rep["k_pcn_flow_fused"][0] == n_steps and "k_coupling_logprob" not in rep
+    xb, llb, lpb, lqb = init()
+    acc_b = []
+    if noise == "f64":  # the split ABI calls draw fp64 noise
+        for t in range(n_steps):
+            xp, q0, q1 = eng.pcn_propose(xb, mu, L, Linv, rho, 77, 1000, 5 + t, nu=nu)
+            lqn = eng.coupling_logprob(xp, dev)
+            acc_b.append(eng.pcn_accept(xb, xp, llb, lpb, lqb, eng.mixture_logpdf(xp, t_ll), eng.mixture_logpdf(xp, t_lp), lqn,
+                                        q0, q1, beta, 77, 1000, 5 + t))
+    else:  # fast noise: the three-kernel device loop is the comparison (ASMC_FLOW_SPLIT is read per call)
+        os.environ["ASMC_FLOW_SPLIT"] = "1"
+        try:
+            acc_b, _, _ = eng.pcn_mutate_flow(xb, llb, lpb, lqb, beta, mu, L, Linv, t_ll, t_lp, dev, 77, 1000, rho, n_steps, 5, 0.234,
+                                              False, noise, nu)
+        finally:
+            del os.environ["ASMC_FLOW_SPLIT"]
+        acc_b = acc_b.tolist()
+    assert n == 1 or 0 < sum(acc_b) < n * n_steps
+    tol = 1e-9 if xdt == "f64" else 2e-5
+    close = ((xa.double() - xb.double()).abs() <= tol * (1 + xb.double().abs())).all(dim=1)
+    edge = 5 if xdt == "f64" else 60
+    assert int((~close).sum()) <= edge, int((~close).sum())
+    assert np.all(np.abs(n_acc - np.array(acc_b)) <= edge)
+    torch.testing.assert_close(lla, eng.mixture_logpdf(xa, t_ll), rtol=1e-9 if xdt == "f64" else 1e-4, atol=1e-9 if xdt == "f64" else 2e-3)
+    torch.testing.assert_close(lpa, eng.mixture_logpdf(xa, t_lp), rtol=1e-9 if xdt == "f64" else 1e-4, atol=1e-9 if xdt == "f64" else 2e-3)
+    torch.testing.assert_close(lqa, eng.coupling_logprob(xa, dev), rtol=1e-5, atol=2e-3)
+    still = (xb == x0).all(dim=1) & close
+    assert bool(((xa[still].double() - x0[still].double()).abs() <= (1e-13 if xdt == "f64" else 1e-5) * (1 + x0[still].double().abs())).all())
+
+
+@pytest.mark.gpu
+def test_pcn_flow_fused_step_vs_oracle(eng, oracle):
+    """The same fused step against the CPU oracle's restatement of the whole step (orc_pcn_flow_step: proposal, fp32
+    coupling-flow log q, targets, accept): positions to 1e-9, accept decisions equal up to razor edges (the flow is fp32 on
+    both sides with different summation orders: |delta log q| ~ 1e-5 moves a handful of decisions per 10^4)."""
+    from conftest import random_coupling_flow
+
+    n, d, n_steps, beta, rho = 6000, 32, 3, 0.4, 0.35
+    flow = random_coupling_flow(d, 4, 64)
+    dev = flow.device_coupling(eng)
+    ws, bs = flow.export_layers()
+    g = np.random.default_rng(8)
+    x0 = 0.9 * g.normal(size=(n, d))
+    tgt_o = oracle.Mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    t_ll = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    a = g.normal(size=(d, d)) / np.sqrt(d)
+    L = np.linalg.cholesky(0.8 * (np.eye(d) + 0.2 * a @ a.T))
+    Linv, mu = np.linalg.inv(L), 0.05 * g.normal(size=d)
+    xr, llr = x0.copy(), tgt_o.logpdf(x0)
+    lpr, lqr = llr.copy(), oracle.coupling_logprob(x0, ws, bs, flow.loc.numpy(), flow.scale.numpy())
+    xd = eng.asarray(x0)
+    lld, lpd, lqd = eng.asarray(llr), eng.asarray(lpr), eng.coupling_logprob(xd, dev)
+    np.testing.assert_allclose(lqd.cpu().numpy(), lqr, rtol=1e-5, atol=3e-4)
+    n_acc, _, _ = eng.pcn_mutate_flow(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(np.tril(L)), eng.asarray(np.tril(Linv)),
+                                      t_ll, t_ll, dev, 4242, 17, rho, n_steps, 9, 0.234, False, "f64", 0.0)
+    acc_ref = [oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, np.tril(L), np.tril(Linv), rho, tgt_o, tgt_o, ws, bs,
+                                    flow.loc.numpy(), flow.scale.numpy(), 4242, 17, 9 + t, "f64", 0) for t in range(n_steps)]
+    got = xd.cpu().numpy()
+    close = np.all(np.abs(got - xr) <= 1e-9 * (1 + np.abs(xr)), axis=1)
+    assert (~close).sum() <= 12, (~close).sum()
+    assert np.all(np.abs(np.array(n_acc) - np.array(acc_ref)) <= 12) and 0.05 < np.mean(n_acc) / n < 0.95
+    np.testing.assert_allclose(lld.cpu().numpy()[close], llr[close], rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(lqd.cpu().numpy()[close], lqr[close], rtol=1e-5, atol=3e-4)
