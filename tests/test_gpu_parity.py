@@ -1529,7 +1529,7 @@ def test_pcn_flow_fused_step_vs_split_calls(eng, xdt, nu, noise, hidden, n):
 
     d, n_steps, beta, rho = 32, 5, 0.35, 0.4
     dt = torch.float64 if xdt == "f64" else torch.float32
-    flow = random_coupling_flow(d, 4, hidden)
+    flow = random_coupling_flow(d, 4 if hidden < 128 else 1, hidden)  # every layer must be resident in LDS (W = 128: one fits)
     dev = flow.device_coupling(eng)
     g = torch.Generator(eng.device).manual_seed(3)
     x0 = torch.randn((n, d), device=eng.device, dtype=torch.float64, generator=g).to(dt)
