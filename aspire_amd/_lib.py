@@ -26,7 +26,7 @@ COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
-ASMC_ABI_VERSION = 9
+ASMC_ABI_VERSION = 10
 ASMC_CDF_REC = 9
 ASMC_CDF_STATE = 36
 
@@ -107,6 +107,8 @@ SIGNATURES = {
     "asmc_weights_stats": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _pd, _i, _pd, _vp]),
     "asmc_weights_m2_lse": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _d, _d, _d, _pd, _vp]),
     "asmc_find_beta": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _pd, _vp]),
+    "asmc_importance_step": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "asmc_importance_result": (_i, [_vp, _pd, _vp]),
     "asmc_pcn_set_count_hook": (_i, [_vp, _vp, _vp, _vp, _i64]),
     "asmc_pcn_ysplit_begin": (_i, [_vp, _i64, _vp, POINTER(AsmcPcnParams), _d, _vp]),
     "asmc_pcn_ysplit_propose": (_i, [_vp, _i64, POINTER(AsmcPcnParams), _u32, _vp, _vp]),

@@ -78,6 +78,8 @@ struct asmc_ctx {
     long long* d_counts;           // [ASMC_MAX_PCN_STEPS + max(ASMC_MAX_BLOCKS, n_max/64+1)] accept counts / partials
     double* d_rho;                 // [ASMC_MAX_PCN_STEPS + 8] step-size history on device
     unsigned int* d_tilectr;       // [ASMC_MAX_PCN_STEPS] tile hand-out counters of the fused flow-proposal step (one per step)
+    unsigned int* d_bar;           // [4] arrival counter of the persistent importance-weight kernel's grid barriers (only grows)
+    unsigned int bar_base;         // its value when the next launch starts
     unsigned long long* d_pcgtab;  // [64*4 + 8] PCG64 jump table
     long long* d_select;           // [2 * ASMC_SELECT_THREADS/64 + 8] wave counts, offsets, total of asmc_pcg64_select
     unsigned long long ptab_tag, ysplit_seq;  // who packed d_ptab last (0 = anyone; else the split session's number)
@@ -101,6 +103,10 @@ struct asmc_ctx {
     // pinned host staging for scalar read-back / small uploads
     double* h_pinned;  // [8192] doubles
 };
+
+// asmc_weights.hip: the persistent weight kernel of asmc_importance_step (results in ctx->d_small + 2560 .. + 48)
+int asmc_is_weights_launch(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double beta0,
+                           double target_eff, double tol, double* w, double* tiles, hipStream_t st);
 
 static inline hipStream_t as_stream(asmc_stream s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -206,8 +206,7 @@ __device__ double exact_tile(const double* __restrict__ w, double* __restrict__ 
 // Predictions are only hints: pass D verifies every one of them against the exact running sum.
 // tile_info (long long, 4 per tile): {a0, a1, e, flag};  tile_split (4 per tile): {b0, b1, c - tile start, nf_c}
 __device__ __forceinline__ void k_exact_tile_td_body(int64_t n, const double* __restrict__ w,
-                                                             const double* __restrict__ approx_prefix,
-                                                             double approx_total, int64_t n_tiles,
+                                                             const double lo, int64_t n_tiles,
                                                              long long* __restrict__ tile_info,
                                                              long long* __restrict__ tile_split,
                                                              double* __restrict__ tile_s2,
@@ -217,7 +216,6 @@ __device__ __forceinline__ void k_exact_tile_td_body(int64_t n, const double* __
     __shared__ int sh_c;
     const int64_t t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double lo = approx_prefix[t];
     const int e = binade_of(lo);
     const double b1 = ldexp(1.0, e + 1);
     const int64_t base = t * ASMC_SCAN_TILE + (int64_t)tid * XT_E;
@@ -347,7 +345,7 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_launch(int64_t n, 
         }
         return;
     }
-    k_exact_tile_td_body(n, w, approx_prefix, *approx_total, n_tiles, tile_info, tile_split, tile_s2, rec_pk);
+    k_exact_tile_td_body(n, w, approx_prefix[blockIdx.x], n_tiles, tile_info, tile_split, tile_s2, rec_pk);
 }
 
 // Pass D: one block chains the EXACT running sum through the tiles.  Flag-1 tiles cost O(1) (verify the binade
@@ -696,7 +694,75 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_range_count(int64_t n, const dou
     if (threadIdx.x == 0) tiles[blockIdx.x] = s_p[0] + s_p[1] + s_p[2] + s_p[3];
 }
 
+// Guide table of the resampling search, filled by the pass that writes the normalised cdf (asmc_importance_step):
+// G[b] = #{k : cdf[k] <= b / NB}, b = 0..NB (k_guide_build's definition, the same table).  Element k owns the buckets
+// b with cdf[k-1] <= b / NB < cdf[k], i.e. [B(cdf[k-1]), B(cdf[k])) where B(v) = the smallest b with b / NB >= v
+// (B of the value in front of element 0 is 0); the last element also owns [B(cdf[n-1]), NB] -> n.
+__device__ __forceinline__ long long guide_first_bucket(double v, double fnb, long long nb) {
+    long long b = (long long)(v * fnb);
+    b = b < 0 ? 0 : (b > nb ? nb : b);
+    // settle on the very expression the search evaluates
+    while (b > 0 && (double)(b - 1) / fnb >= v) b--;
+    while (b <= nb && (double)b / fnb < v) b++;
+    return b;
+}
+
+#define GUIDE_QUEUE 512
+#define GUIDE_LONG 32  // runs of more buckets than this are filled by the whole block
+// c[j]: this thread's XT_E consecutive normalised cdf values (elements base + j < n), prev0: the value in front of the
+// tile's first element
+__device__ __forceinline__ void guide_fill_tile(int64_t n, int64_t base, const double (&c)[XT_E], double prev0,
+                                                int64_t nb, unsigned int* __restrict__ guide) {
+    __shared__ double sh_last[XT_THREADS];
+    __shared__ long long sh_q[GUIDE_QUEUE][2];
+    __shared__ unsigned int sh_qk[GUIDE_QUEUE];
+    __shared__ int sh_nq;
+    const int tid = threadIdx.x;
+    const double fnb = (double)nb;
+    double last = prev0;
+#pragma unroll
+    for (int j = 0; j < XT_E; j++)
+        if (base + j < n) last = c[j];
+    sh_last[tid] = last;  // a thread without elements passes the value in front of it on
+    if (tid == 0) sh_nq = 0;
+    __syncthreads();
+    if (base >= n) {
+        // no elements: nothing to own (threads behind the end of the population)
+    } else {
+        double prev = prev0;
+        if (tid > 0) prev = sh_last[tid - 1];
+        auto emit = [&](long long b_lo, long long b_hi, unsigned int k) {
+            if (b_hi - b_lo > GUIDE_LONG) {
+                const int slot = atomicAdd(&sh_nq, 1);
+                if (slot < GUIDE_QUEUE) {
+                    sh_q[slot][0] = b_lo, sh_q[slot][1] = b_hi, sh_qk[slot] = k;
+                    return;
+                }
+            }
+            for (long long b = b_lo; b < b_hi; b++) guide[b] = k;
+        };
+        long long b_lo = (base == 0) ? 0 : guide_first_bucket(prev, fnb, nb);
+#pragma unroll
+        for (int j = 0; j < XT_E; j++) {
+            if (base + j >= n) break;
+            const long long b_hi = guide_first_bucket(c[j], fnb, nb);
+            emit(b_lo, b_hi, (unsigned int)(base + j));
+            // the buckets at and behind cdf[n-1] count all n elements
+            if (base + j == n - 1) emit(b_hi, nb + 1, (unsigned int)n);
+            b_lo = b_hi;
+        }
+    }
+    __syncthreads();
+    const int nq = sh_nq < GUIDE_QUEUE ? sh_nq : GUIDE_QUEUE;
+    for (int e = 0; e < nq; e++) {
+        const long long b_lo = sh_q[e][0], b_hi = sh_q[e][1];
+        const unsigned int k = sh_qk[e];
+        for (long long b = b_lo + tid; b < b_hi; b += XT_THREADS) guide[b] = k;
+    }
+}
+
 // Pass E: write the flag-1 / flag-2 tiles from their exact incoming sums (integer scans on the tile's grids).
+// guide != NULL (with norm_ptr): also fill the search's guide table for this tile's stretch of [0, 1].
 __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, const double* __restrict__ w,
                                                                 double* __restrict__ cdf,
                                                                 const long long* __restrict__ tile_info,
@@ -705,7 +771,8 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, cons
                                                                 const double* __restrict__ tile_s2,
                                                                 const double* __restrict__ norm_ptr,
                                                                 const long long* __restrict__ rec_pk,
-                                                                const double* __restrict__ done_here) {
+                                                                const double* __restrict__ done_here,
+                                                                unsigned int* __restrict__ guide, int64_t nb) {
     __shared__ TD sh_td[XT_THREADS / 64 + 1];
     const int64_t t = blockIdx.x;
     const long long flag = (done_here && done_here[t] != 0.0) ? 0
@@ -713,21 +780,24 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, cons
     // norm_ptr != NULL: the caller wants cdf / cdf[-1] (numpy's `cdf /= cdf[-1]`); the total is known by now, so
     // the division rides on this pass (tiles the chain wrote element-wise are divided in place)
     const double norm = norm_ptr ? *norm_ptr : 1.0;
+    const int64_t base = t * ASMC_SCAN_TILE + (int64_t)threadIdx.x * XT_E;
+    double cv[XT_E];  // the values this thread leaves in cdf[base ..]
     if (flag != 1 && flag != 2) {  // uniform per block
         if (norm_ptr) {
-            const int64_t b0 = t * ASMC_SCAN_TILE + (int64_t)threadIdx.x * XT_E;
 #pragma unroll
-            for (int j = 0; j < XT_E; j++)
-                if (b0 + j < n) cdf[b0 + j] = cdf[b0 + j] / norm;
+            for (int j = 0; j < XT_E; j++) {
+                cv[j] = 0.0;
+                if (base + j < n) cdf[base + j] = cv[j] = cdf[base + j] / norm;
+            }
+            if (guide) guide_fill_tile(n, base, cv, tile_s[t] / norm, nb, guide);
         }
         return;
     }
     const int e = (int)(rec_pk ? rec_pk[ASMC_CDF_REC * t + 2] : tile_info[4 * t + 2]);
     const int c = flag == 2 ? (int)(rec_pk ? rec_pk[ASMC_CDF_REC * t + 6] : tile_split[4 * t + 2]) : ASMC_SCAN_TILE;
-    const int64_t base = t * ASMC_SCAN_TILE + (int64_t)threadIdx.x * XT_E;
     double wv[XT_E];
 #pragma unroll
-    for (int j = 0; j < XT_E; j++) wv[j] = (base + j < n) ? w[base + j] : 0.0;
+    for (int j = 0; j < XT_E; j++) wv[j] = (base + j < n) ? w[base + j] : 0.0, cv[j] = 0.0;
     {   // elements before c (all of them for flag 1) on the grid of e
         const long long S0 = (long long)ldexp(tile_s[t], 52 - e);
         long long ta0[XT_E], ta1[XT_E];
@@ -744,7 +814,7 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, cons
 #pragma unroll
         for (int j = 0; j < XT_E; j++) {
             S += (S & 1) ? ta1[j] : ta0[j];
-            if (base + j < n && threadIdx.x * XT_E + j < c) cdf[base + j] = ldexp((double)S, e - 52) / norm;
+            if (base + j < n && threadIdx.x * XT_E + j < c) cdf[base + j] = cv[j] = ldexp((double)S, e - 52) / norm;
         }
     }
     if (flag == 2) {  // element c, then the elements behind it on the grid of e + 1
@@ -765,10 +835,43 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, cons
         for (int j = 0; j < XT_E; j++) {
             const int k = threadIdx.x * XT_E + j;
             S += (S & 1) ? ta1[j] : ta0[j];
-            if (base + j < n && k > c) cdf[base + j] = ldexp((double)S, e + 1 - 52) / norm;
-            if (k == c) cdf[base + j] = s_new / norm;
+            if (base + j < n && k > c) cdf[base + j] = cv[j] = ldexp((double)S, e + 1 - 52) / norm;
+            if (k == c) cdf[base + j] = cv[j] = s_new / norm;
         }
     }
+    if (guide && norm_ptr) guide_fill_tile(n, base, cv, tile_s[t] / norm, nb, guide);
+}
+
+
+// k_scan_tiles folded into the transducer pass: a block adds up the tile sums in front of its tile itself (they are a
+// hint for the binade guess only, any summation order will do)
+__global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_scan(int64_t n, const double* __restrict__ w,
+                                                                  const double* __restrict__ tile_sums, int64_t n_tiles,
+                                                                  long long* __restrict__ tile_info,
+                                                                  long long* __restrict__ tile_split,
+                                                                  double* __restrict__ tile_s2, double* __restrict__ cdf,
+                                                                  double* __restrict__ tile_s) {
+    if (blockIdx.x == 0) {
+        __shared__ TD sh_td0[XT_THREADS / 64 + 1];
+        __shared__ double sh_s0;
+        __shared__ long long sh_pos0, sh_cross0;
+        const int64_t hi = ASMC_SCAN_TILE < n ? ASMC_SCAN_TILE : n;
+        const double s_out = exact_tile(w, cdf, 0, hi, 0.0, sh_td0, &sh_s0, &sh_pos0, &sh_cross0);
+        if (threadIdx.x == 0) {
+            tile_info[0] = 0, tile_info[1] = 0, tile_info[2] = 0, tile_info[3] = 3;
+            tile_split[0] = tile_split[1] = tile_split[2] = tile_split[3] = 0;
+            tile_s[0] = 0.0;
+            tile_s2[0] = s_out;
+        }
+        return;
+    }
+    __shared__ double s_pre[XT_THREADS / 64];
+    double acc = 0.0;
+    for (int64_t u = threadIdx.x; u < (int64_t)blockIdx.x; u += XT_THREADS) acc += tile_sums[u];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_pre[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    k_exact_tile_td_body(n, w, ((s_pre[0] + s_pre[1]) + s_pre[2]) + s_pre[3], n_tiles, tile_info, tile_split, tile_s2);
 }
 
 // =============================================================================================
@@ -1079,6 +1182,73 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_search_guided(int64_t n, const d
     }
 }
 
+// k_pcg64_uniforms + k_search_guided in one pass (asmc_importance_step): 2^SP_LOG2 threads, thread j takes the draws
+// j, j + T, j + 2T, ... of the stream (one jump-ahead per thread, then strides of T), four at a time so that four
+// independent lookups are in flight per lane; the uniforms never touch memory.
+#define SP_LOG2 18
+__global__ __launch_bounds__(ASMC_BLOCK) void k_search_pcg(const unsigned long long* __restrict__ tab, U128 state0,
+                                                          int tlog2, int64_t n, const double* __restrict__ cdf,
+                                                          int64_t nb, const unsigned int* __restrict__ guide,
+                                                          int64_t n_out, int64_t* __restrict__ idx) {
+    const int64_t T = (int64_t)1 << tlog2;
+    const unsigned long long j = (unsigned long long)blockIdx.x * ASMC_BLOCK + threadIdx.x;
+    if ((int64_t)j >= T || (int64_t)j >= n_out) return;
+    unsigned long long delta = j + 1ULL;  // post-step state of draw j: advance(state0, j + 1)
+    U128 st = state0;
+    for (int b = 0; b < 64 && delta; b++, delta >>= 1) {
+        if (delta & 1ULL) {
+            U128 A = {tab[4 * b], tab[4 * b + 1]}, C = {tab[4 * b + 2], tab[4 * b + 3]};
+            st = u128_add(u128_mul(st, A), C);
+        }
+    }
+    const U128 AT = {tab[4 * tlog2], tab[4 * tlog2 + 1]};
+    const U128 CT = {tab[4 * tlog2 + 2], tab[4 * tlog2 + 3]};
+    const double fnb = (double)nb;
+    for (int64_t i0 = (int64_t)j; i0 < n_out; i0 += 4 * T) {
+        double key[4];
+        int64_t lo[4], hi[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            lo[q] = 0, hi[q] = 0, key[q] = 0.0;
+            if (i0 + q * T < n_out) {
+                const unsigned long long x = st.hi ^ st.lo;
+                const unsigned rot = (unsigned)(st.hi >> 58);
+                const unsigned long long out = (x >> rot) | (x << ((64u - rot) & 63u));
+                key[q] = (double)(out >> 11) * (1.0 / 9007199254740992.0);
+                st = u128_add(u128_mul(st, AT), CT);
+                hi[q] = n;
+                if (guide) {
+                    int64_t b = (int64_t)(key[q] * fnb);
+                    b = b > nb - 1 ? nb - 1 : b;
+                    // make b / NB <= key < (b + 1) / NB hold for the very expressions the table was built with
+                    while (b > 0 && (double)b / fnb > key[q]) b--;
+                    while (b < nb - 1 && (double)(b + 1) / fnb <= key[q]) b++;
+                    lo[q] = guide[b];
+                    hi[q] = guide[b + 1];
+                }
+            }
+        }
+        bool any = true;
+        while (any) {
+            any = false;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (lo[q] < hi[q]) {
+                    const int64_t mid = lo[q] + ((hi[q] - lo[q]) >> 1);
+                    if (cdf[mid] <= key[q])
+                        lo[q] = mid + 1;
+                    else
+                        hi[q] = mid;
+                }
+                any |= lo[q] < hi[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (i0 + q * T < n_out) idx[i0 + q * T] = lo[q];
+    }
+}
+
 // =============================================================================================
 // gather rows
 // =============================================================================================
@@ -1345,7 +1515,8 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_exact_tile_write", k_exact_tile_write, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w, cdf,
                            (const long long*)ctx->d_tiles_i, (const long long*)d_split, (const double*)d_tile_s,
-                           (const double*)d_tile_s2, d_norm, (const long long*)nullptr, (const double*)nullptr);
+                           (const double*)d_tile_s2, d_norm, (const long long*)nullptr, (const double*)nullptr,
+                           (unsigned int*)nullptr, (int64_t)0);
         ASMC_LAUNCH_CHECK();
     } else if (mode == ASMC_CDF_FAST) {
         const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
@@ -1422,7 +1593,7 @@ int asmc_cdf_shard_finish(asmc_ctx* ctx, int64_t n, const double* w, double* cdf
     ASMC_LAUNCH(ctx, st, "k_exact_tile_write", k_exact_tile_write, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w, cdf,
                 (const long long*)nullptr, (const long long*)nullptr, (const double*)(tile_s + tile0),
                 (const double*)(tile_s2 + tile0), state_dev + 1, (const long long*)recs_all_dev + ASMC_CDF_REC * tile0,
-                done_here + tile0);
+                done_here + tile0, (unsigned int*)nullptr, (int64_t)0);
     ASMC_LAUNCH_CHECK();
     ASMC_LAUNCH(ctx, st, "k_shard_edges", k_shard_edges, dim3(1), dim3(64), 0, st, state_dev, (const double*)(tile_s + tile0),
                 (const double*)(cdf + n - 1), out_dev);
@@ -1593,6 +1764,61 @@ int asmc_search(asmc_ctx* ctx, int64_t n, const double* cdf, int64_t n_out, cons
     } else {
         ASMC_LAUNCH(ctx, st, "k_search", k_search, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, cdf, n_out, u, idx);
     }
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_importance_step(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double beta0,
+                         double target_eff, double tol, const uint64_t rng_state[4], int64_t n_out, double* w_scratch,
+                         double* cdf_scratch, int64_t* idx_out, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && ll && lp && lq && rng_state && w_scratch && cdf_scratch && idx_out, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max && n < (1LL << 32) && n_out > 0, "bad sizes");
+    ASMC_REQUIRE(tol > 0.0 && beta0 >= 0.0 && beta0 < 1.0, "bad beta0 / tolerance");
+    hipStream_t st = as_stream(stream);
+    // jump table of the generator's increment (host work + one upload, only when the increment changes)
+    int rc = pcg_prepare(ctx, rng_state, st);
+    if (rc) return rc;
+    // 1: beta search, evidence moments, normalised weights, tile sums (one persistent launch)
+    rc = asmc_is_weights_launch(ctx, n, ll, lp, lq, beta0, target_eff, tol, w_scratch, ctx->d_tiles, st);
+    if (rc) return rc;
+    // 2-4: numpy's sequential cumsum / cdf[-1] (passes C, D, E of asmc_cdf; the tile prefixes ride on pass C while
+    // there are few tiles), pass E also filling the search's guide table
+    const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+    double* d_total = ctx->d_small + 1024;
+    double* d_tile_s = ctx->d_tiles + ctx->n_tiles_max * 2;
+    double* d_tile_s2 = ctx->d_tiles + ctx->n_tiles_max * 3;
+    long long* d_split = ctx->d_tiles_i + ctx->n_tiles_max * 4;
+    if (n_tiles <= 1024) {
+        ASMC_LAUNCH(ctx, st, "k_exact_tile_td_scan", k_exact_tile_td_scan, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n,
+                    (const double*)w_scratch, (const double*)ctx->d_tiles, n_tiles, ctx->d_tiles_i, d_split, d_tile_s2,
+                    cdf_scratch, d_tile_s);
+    } else {
+        ASMC_LAUNCH(ctx, st, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, 0.0, ctx->d_small + 1025);
+        ASMC_LAUNCH_CHECK();
+        ASMC_LAUNCH(ctx, st, "k_exact_tile_td_launch", k_exact_tile_td_launch, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n,
+                    (const double*)w_scratch, (const double*)ctx->d_tiles, (const double*)(ctx->d_small + 1025), n_tiles,
+                    ctx->d_tiles_i, d_split, d_tile_s2, cdf_scratch, 0.0, d_tile_s, 1, (long long*)nullptr);
+    }
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_exact_chain", k_exact_chain, dim3(1), dim3(XT_THREADS), 0, st, n, (const double*)w_scratch, cdf_scratch,
+                0.0, n_tiles, ctx->d_tiles_i, (const long long*)d_split, d_tile_s, d_tile_s2, d_total);
+    ASMC_LAUNCH_CHECK();
+    static const bool no_guide = getenv("ASMC_SEARCH_PLAIN") != nullptr;
+    const int64_t nb = n / 4;
+    const bool guided = !no_guide && n >= (1 << 17) && n_out >= n / 8;
+    ASMC_LAUNCH(ctx, st, "k_exact_tile_write", k_exact_tile_write, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n,
+                (const double*)w_scratch, cdf_scratch, (const long long*)ctx->d_tiles_i, (const long long*)d_split,
+                (const double*)d_tile_s, (const double*)d_tile_s2, (const double*)d_total, (const long long*)nullptr,
+                (const double*)nullptr, guided ? ctx->d_guide : (unsigned int*)nullptr, nb);
+    ASMC_LAUNCH_CHECK();
+    // 5: rng.random(n_out) and searchsorted(cdf, u, side="right") in one pass
+    int tlog2 = SP_LOG2;
+    while (tlog2 > 6 && ((int64_t)1 << (tlog2 - 1)) >= n_out) tlog2--;
+    const int64_t threads = (int64_t)1 << tlog2;
+    U128 s0 = {rng_state[1], rng_state[0]};
+    ASMC_LAUNCH(ctx, st, "k_search_pcg", k_search_pcg, dim3((unsigned)((threads + ASMC_BLOCK - 1) / ASMC_BLOCK)), dim3(ASMC_BLOCK), 0, st,
+                (const unsigned long long*)ctx->d_pcgtab, s0, tlog2, n, (const double*)cdf_scratch, nb,
+                guided ? (const unsigned int*)ctx->d_guide : (const unsigned int*)nullptr, n_out, idx_out);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }

@@ -378,23 +378,26 @@ __device__ __forceinline__ void bis_reduce_partials(const double* __restrict__ p
     }
 }
 
-// `partials` == nullptr: s_S already holds the column sums (sharded search: the rank records merged by k_bis_decide).
-__device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
-                                              const double* __restrict__ partials, int nblocks, bool first,
-                                              double m_one_in, const BisInit& init, double (*s_red)[33],
-                                              double* s_S, double* s_eff, double nan_total = 0.0) {
-    // the state record and the candidates' shifts are staged in LDS: thread 0's decision chain below must not pay a
-    // global-memory latency per dependent access
-    __shared__ double s_st[40];
-    __shared__ double s_bp[4][16];  // c1, c2, m, shift of the candidates (in: m of this round; out: next round)
+// Block-local copy of the search state: the record st[0..39] (layout above) and the candidates' c1, c2, m, shift
+// (in: m of this round's candidates; out: those of the next round)
+struct BisLds {
+    double st[40];
+    double bp[4][16];
+};
+
+__device__ __forceinline__ void bis_lds_init(BisLds& L, const BisInit& init, double m_one, double nan_total) {
     if (threadIdx.x < 40) {
         const int i = threadIdx.x;
-        s_st[i] = !first ? st[i]
-                         : (i == 0 ? init.beta0 : i == 1 ? 1.0 : i == 3 ? init.target : i == 4 ? init.tol : i == 5 ? init.logN
-                            : i == 7 ? init.beta0 : i == 8 ? init.N : i == 10 ? m_one_in : i == 15 ? nan_total : 0.0);
+        L.st[i] = i == 0 ? init.beta0 : i == 1 ? 1.0 : i == 3 ? init.target : i == 4 ? init.tol : i == 5 ? init.logN
+                  : i == 7 ? init.beta0 : i == 8 ? init.N : i == 10 ? m_one : i == 15 ? nan_total : 0.0;
     }
-    if (!first && threadIdx.x >= 64 && threadIdx.x < 80) s_bp[2][threadIdx.x - 64] = bp->m[threadIdx.x - 64];
-    if (partials) bis_reduce_partials(partials, nblocks, s_red, s_S);
+}
+
+// Closes a round on the block-local state.  Precondition: L and s_S are filled and a __syncthreads() lies behind
+// that; returns behind a __syncthreads() with L.st[2] (done), L.st[39] (a new candidate pack was built) up to date.
+__device__ __forceinline__ void bis_tail_core(BisLds& L, bool first, const double* s_S, double* s_eff) {
+    double(&s_st)[40] = L.st;
+    double(&s_bp)[4][16] = L.bp;
     const double logN = s_st[5], N = s_st[8], target = s_st[3], tol = s_st[4], beta0 = s_st[7], m_one = s_st[10];
     const double inv = 1.0 / (1.0 - beta0);
     // heap-ordered midpoints of the next four levels from (lo, hi), exactly the values the sequential loop visits
@@ -436,6 +439,7 @@ __device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<
     __syncthreads();
     if (threadIdx.x == 0) {
         s_st[6] += 1.0;
+        s_st[39] = 0.0;
         double bmin = s_st[0], bmax = s_st[1];
         bool at_one = false;
         if (first) {
@@ -468,16 +472,35 @@ __device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<
             s_st[2] = 1.0;
         } else {
             build(bmin, bmax);
-            s_st[39] = 1.0;  // marks that the candidate pack below is to be written
+            s_st[39] = 1.0;  // marks that the candidate pack is new
         }
     }
     __syncthreads();
-    const bool write_bp = s_st[39] != 0.0;
-    if (threadIdx.x < 39) st[threadIdx.x] = s_st[threadIdx.x];
+}
+
+// Round tail on the state record in global memory (one launch per round: k_bis_sums' last block, k_bis_decide).
+// `partials` == nullptr: s_S already holds the column sums (sharded search: the rank records merged by k_bis_decide).
+__device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
+                                              const double* __restrict__ partials, int nblocks, bool first,
+                                              double m_one_in, const BisInit& init, double (*s_red)[33],
+                                              double* s_S, double* s_eff, double nan_total = 0.0) {
+    // the state record and the candidates' shifts are staged in LDS: thread 0's decision chain must not pay a
+    // global-memory latency per dependent access
+    __shared__ BisLds L;
+    if (first)
+        bis_lds_init(L, init, m_one_in, nan_total);
+    else if (threadIdx.x < 40)
+        L.st[threadIdx.x] = st[threadIdx.x];
+    if (!first && threadIdx.x >= 64 && threadIdx.x < 80) L.bp[2][threadIdx.x - 64] = bp->m[threadIdx.x - 64];
+    if (partials) bis_reduce_partials(partials, nblocks, s_red, s_S);
+    __syncthreads();
+    bis_tail_core(L, first, s_S, s_eff);
+    const bool write_bp = L.st[39] != 0.0;
+    if (threadIdx.x < 39) st[threadIdx.x] = L.st[threadIdx.x];
     if (write_bp && threadIdx.x >= 64 && threadIdx.x < 128) {
         const int f = (threadIdx.x - 64) >> 4, k = (threadIdx.x - 64) & 15;
         double* dst = f == 0 ? bp->c1 : f == 1 ? bp->c2 : f == 2 ? bp->m : bp->shift;
-        dst[k] = s_bp[f][k];
+        dst[k] = L.bp[f][k];
     }
 }
 
@@ -601,6 +624,328 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const doubl
         return;
     }
     bis_tail_body(st, bp, partials, (int)gridDim.x, round == 0, m_one, init, s_red, s_S, s_eff);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The importance step's weight half in ONE persistent launch (asmc_importance_weights; smc/base.py:167-186 followed by
+// samples.py:1230-1249 and :1276-1277): exact maximum at beta = 1 and the NaN census, the k-ary search rounds of
+// k_bis_sums, the evidence-variance / second log-sum-exp pass of k_weights_m2_lse and the normalised weights with the
+// scan's tile sums.  One block per CU, every block resident (the launch asks for no more blocks than CUs), the phases
+// separated by grid barriers on a counter that only grows (no memset node; the launch's budget of ISW_BARRIERS
+// arrivals per block is topped up at the end so that the next launch's base is where the counter stands).  A block
+// owns a contiguous range of whole 4096-particle chunks (two scan tiles); REG: one chunk per block, the particles'
+// (ll + lp, lq) stay in registers across all phases, so HBM/L2 is read once instead of once per round.
+// Every block closes a round redundantly from the same partial records (fixed order => the same bits everywhere):
+// no block waits for another one's decision, and the state record never leaves LDS between rounds.
+// Results: st_out[0..39] = the search record (layout above), [40] sum (exp(lw - m) - mean_u)^2, [41] S1', [42] lse',
+// [43] shift, [44] mp, [45] 1 when beta* was found and w / tile sums are those of beta* (otherwise w = 1/N).
+#define ISW_THREADS 512
+#define ISW_PER 8
+#define ISW_CHUNK (ISW_THREADS * ISW_PER)
+#define ISW_MAX_ROUNDS 20
+#define ISW_BARRIERS 32
+
+__device__ __forceinline__ void isw_barrier(unsigned int* ctr, unsigned int target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+template <bool REG>
+__global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const double* __restrict__ ll,
+                                                           const double* __restrict__ lp, const double* __restrict__ lq,
+                                                           double* __restrict__ st_out, double* partials,
+                                                           unsigned int* bar, unsigned int bar_base, BisInit init,
+                                                           int64_t chunk, double* __restrict__ w,
+                                                           double* __restrict__ tiles) {
+    __shared__ BisLds L;
+    __shared__ double s_red[ISW_THREADS / 32][33];
+    __shared__ double s_S[32];
+    __shared__ double s_eff[16];
+    __shared__ double s_p[ISW_THREADS / 64][32];
+    __shared__ double s_sc[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = (int)gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    const int nsub = (int)(chunk / ISW_CHUNK);
+    unsigned int nbar = 0;
+#ifdef ISW_STAMP
+    const unsigned long long t_start = wall_clock64();
+    int n_stamp = 0;
+    double stamps[16];
+#define ISW_MARK()                                                                         \
+    do {                                                                                   \
+        if (n_stamp < 16) stamps[n_stamp++] = (double)(wall_clock64() - t_start) * 0.01; \
+    } while (0)
+#else
+#define ISW_MARK() \
+    do {           \
+    } while (0)
+#endif
+    auto barrier = [&]() {
+        nbar++;
+        isw_barrier(bar, bar_base + nbar * (unsigned int)G);
+    };
+    auto pbuf = [&](unsigned int k) { return partials + (size_t)(k & 1u) * (size_t)G * 32; };
+
+    // REG: the block's particles as (ll + lp, lq) in LDS, staged once (64 KB of dynamic LDS)
+    extern __shared__ double s_part[];
+    double* s_ab = s_part;
+    double* s_q = s_part + ISW_CHUNK;
+    if (REG) {
+#pragma unroll
+        for (int k = 0; k < ISW_PER; k++) {
+            const int64_t i = lo + k * ISW_THREADS + tid;
+            const bool ok = i < hi;
+            const double a = ok ? ll[i] : 0.0, b = ok ? lp[i] : 0.0;
+            s_ab[k * ISW_THREADS + tid] = a + b;
+            s_q[k * ISW_THREADS + tid] = ok ? lq[i] : 0.0;
+        }
+        // every thread only ever reads back its own entries: no barrier needed
+    }
+    // particle k of sub-chunk `sub` of this thread: (ll + lp, lq); false behind the end of the block's range
+    auto get = [&](int sub, int k, double& abv, double& qv) {
+        const int64_t i = lo + (int64_t)sub * ISW_CHUNK + k * ISW_THREADS + tid;
+        const bool ok = i < hi;
+        if (REG) {
+            abv = s_ab[k * ISW_THREADS + tid];
+            qv = s_q[k * ISW_THREADS + tid];
+        } else {
+            const double a = ok ? ll[i] : 0.0, b = ok ? lp[i] : 0.0;
+            abv = a + b;
+            qv = ok ? lq[i] : 0.0;
+        }
+        return ok;
+    };
+    // the reference's log-weight (samples.py:1222-1224) from ll + lp and lq
+    auto lw_at = [&](double abv, double qv, double c1, double c2) {
+        const double t1 = c1 * qv;
+        const double t2 = c2 * abv;
+        return t1 + t2;
+    };
+
+    // ---- phase 0: exact maximum of the log-weights at beta = 1 and the NaN census ---------------------------------
+    {
+        const double c1 = init.beta0 - 1.0, c2 = 1.0 - init.beta0;
+        double mx = -INFINITY;
+        long long nn = 0;
+        for (int sub = 0; sub < nsub; sub++) {
+#pragma unroll 4
+            for (int k = 0; k < ISW_PER; k++) {
+                double abv, qv;
+                if (get(sub, k, abv, qv)) {
+                    const double lw = lw_at(abv, qv, c1, c2);
+                    if (lw != lw)
+                        nn++;
+                    else
+                        mx = fmax(mx, lw);
+                }
+            }
+        }
+        mx = wave_max(mx);
+        nn = wave_sum_ll(nn);
+        if (lane == 0) s_p[wave][0] = mx, s_p[wave][1] = (double)nn;
+        __syncthreads();
+        if (tid == 0) {
+            double v = s_p[0][0], c = s_p[0][1];
+            for (int x = 1; x < ISW_THREADS / 64; x++) v = fmax(v, s_p[x][0]), c += s_p[x][1];
+            double* rec = pbuf(1) + (size_t)blockIdx.x * 32;
+            rec[0] = v;
+            rec[1] = c;
+        }
+        ISW_MARK();
+        barrier();
+        ISW_MARK();
+        if (tid < 64) {
+            double v = -INFINITY, c = 0.0;
+            for (int b = tid; b < G; b += 64) {
+                const double* rec = pbuf(1) + (size_t)b * 32;
+                v = fmax(v, rec[0]);
+                c += rec[1];
+            }
+            v = wave_max(v);
+            c = wave_sum(c);  // integer-valued: any order gives the same sum
+            if (tid == 0) s_sc[0] = v, s_sc[1] = c;
+        }
+        __syncthreads();
+    }
+    const double m_one = s_sc[0], nan_total = s_sc[1];
+    bis_lds_init(L, init, m_one, nan_total);
+    __syncthreads();
+
+    // ---- phase 1: the search rounds (k_bis_sums on the resident particles) ------------------------------------------
+    for (int round = 0; round < ISW_MAX_ROUNDS; round++) {
+        double c1, c2, m1, h, dmax;
+        if (round == 0) {
+            const double lo0 = init.beta0;
+            double b1 = 1.0;
+            for (int lev = 0; lev < BIS_LEVELS; lev++) b1 = 0.5 * (b1 + lo0);  // leftmost leaf of the first tree
+            const double inv = 1.0 / (1.0 - lo0);
+            c1 = lo0 - b1, c2 = b1 - lo0, m1 = m_one * ((b1 - lo0) * inv), h = (1.0 - lo0) / 16.0, dmax = m_one * inv;
+        } else {
+            c1 = L.st[34], c2 = L.st[35], m1 = L.st[36], h = L.st[37], dmax = L.st[38];
+        }
+        double s1[16], s2[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) s1[j] = 0.0, s2[j] = 0.0;
+        for (int sub = 0; sub < nsub; sub++) {
+#pragma unroll 1
+            for (int k = 0; k < ISW_PER; k += 2) {  // two particles per trip (k_bis_sums)
+                double ab0, q0, ab1, q1;
+                const bool v0 = get(sub, k, ab0, q0), v1 = get(sub, k + 1, ab1, q1);
+                double e = v0 ? exp(lw_at(ab0, q0, c1, c2) - m1) : 0.0;
+                const double r = v0 ? exp(h * ((ab0 - q0) - dmax)) : 0.0;
+                double e2 = v1 ? exp(lw_at(ab1, q1, c1, c2) - m1) : 0.0;
+                const double r2 = v1 ? exp(h * ((ab1 - q1) - dmax)) : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    s1[j] += e;
+                    s2[j] += e * e;
+                    e *= r;
+                    s1[j] += e2;
+                    s2[j] += e2 * e2;
+                    e2 *= r2;
+                }
+            }
+        }
+        // wave-level butterfly reduce-scatter of the 32 accumulators (see k_bis_sums)
+        constexpr int HEAP_OF_SORTED[16] = {7, 3, 8, 1, 9, 4, 10, 0, 11, 5, 12, 2, 13, 6, 14, 15};
+        double vals[32];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            vals[2 * HEAP_OF_SORTED[j]] = s1[j];
+            vals[2 * HEAP_OF_SORTED[j] + 1] = s2[j];
+        }
+#pragma unroll
+        for (int o = 32, cnt = 32; o >= 2; o >>= 1, cnt >>= 1) {
+            const bool up = (lane & o) != 0;
+#pragma unroll
+            for (int k = 0; k < cnt / 2; k++) {
+                const double keep = up ? vals[k + cnt / 2] : vals[k];
+                const double send = up ? vals[k] : vals[k + cnt / 2];
+                vals[k] = keep + __shfl_xor(send, o, 64);
+            }
+        }
+        vals[0] += __shfl_xor(vals[0], 1, 64);
+        if ((lane & 1) == 0) s_p[wave][lane >> 1] = vals[0];
+        __syncthreads();
+        double* buf = pbuf(nbar + 1);
+        if (tid < 32) {
+            double v = s_p[0][tid];
+            for (int x = 1; x < ISW_THREADS / 64; x++) v += s_p[x][tid];
+            buf[(size_t)blockIdx.x * 32 + tid] = v;
+        }
+        ISW_MARK();
+        barrier();
+        ISW_MARK();
+        bis_reduce_partials(buf, G, s_red, s_S);
+        __syncthreads();
+        bis_tail_core(L, round == 0, s_S, s_eff);
+        ISW_MARK();
+        if (L.st[2] != 0.0) break;  // uniform: every block took the same decisions
+    }
+
+    // ---- phase 2: evidence variance + second log-sum-exp at beta*, then the normalised weights -----------------------
+    const double beta0 = init.beta0, beta = L.st[0], N = init.N;
+    const bool found = L.st[2] != 0.0 && L.st[14] != 0.0 && nan_total == 0.0 && beta > beta0;
+    const double c1 = beta0 - beta, c2 = beta - beta0;
+    const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+    double shift = 0.0, mp = 0.0, lse = 0.0;
+    if (found) {
+        // smc_math.evidence_variance_and_lse's scalars, same operation order
+        const double m = L.st[11], S1 = L.st[12];
+        const double mean_u = S1 / N;
+        shift = (m + log(S1)) - init.logN;
+        mp = m + shift;
+        double acc = 0.0, s1p = 0.0;
+        for (int sub = 0; sub < nsub; sub++) {
+#pragma unroll 2
+            for (int k = 0; k < ISW_PER; k++) {
+                double abv, qv;
+                if (get(sub, k, abv, qv)) {
+                    const double lw = lw_at(abv, qv, c1, c2);
+                    const double dlt = exp(lw - m) - mean_u;
+                    acc += dlt * dlt;
+                    s1p += exp((lw + shift) - mp);
+                }
+            }
+        }
+        acc = wave_sum(acc);
+        s1p = wave_sum(s1p);
+        __syncthreads();
+        if (lane == 0) s_p[wave][0] = acc, s_p[wave][1] = s1p;
+        __syncthreads();
+        double* buf = pbuf(nbar + 1);
+        if (tid < 2) {
+            double v = s_p[0][tid];
+            for (int x = 1; x < ISW_THREADS / 64; x++) v += s_p[x][tid];
+            buf[(size_t)blockIdx.x * 32 + tid] = v;
+        }
+        barrier();
+        if (tid < 64) {  // k_finalize_columns' order: 64 strided chains, then the wave butterfly
+            double v0 = 0.0, v1 = 0.0;
+            for (int b = tid; b < G; b += 64) {
+                v0 += buf[(size_t)b * 32];
+                v1 += buf[(size_t)b * 32 + 1];
+            }
+            v0 = wave_sum(v0);
+            v1 = wave_sum(v1);
+            if (tid == 0) s_sc[2] = v0, s_sc[3] = v1, s_sc[4] = mp + log(v1);  // lse' = mp + log S1'
+        }
+        __syncthreads();
+        lse = s_sc[4];
+    }
+    const double w_uniform = 1.0 / N;
+    for (int sub = 0; sub < nsub; sub++) {
+        double ts0 = 0.0, ts1 = 0.0;
+#pragma unroll 2
+        for (int k = 0; k < ISW_PER; k++) {
+            double abv, qv;
+            if (get(sub, k, abv, qv)) {
+                const double wv = found ? exp((lw_at(abv, qv, c1, c2) + shift) - lse) : w_uniform;
+                w[lo + (int64_t)sub * ISW_CHUNK + k * ISW_THREADS + tid] = wv;
+                if (k < ISW_PER / 2)
+                    ts0 += wv;
+                else
+                    ts1 += wv;
+            }
+        }
+        ts0 = wave_sum(ts0);
+        ts1 = wave_sum(ts1);
+        __syncthreads();
+        if (lane == 0) s_p[wave][0] = ts0, s_p[wave][1] = ts1;
+        __syncthreads();
+        if (tid < 2) {
+            double v = s_p[0][tid];
+            for (int x = 1; x < ISW_THREADS / 64; x++) v += s_p[x][tid];
+            const int64_t t = (lo + (int64_t)sub * ISW_CHUNK) / ASMC_SCAN_TILE + tid;
+            if (t < n_tiles) tiles[t] = v;
+        }
+    }
+    if (blockIdx.x == 0) {
+        if (tid < 40) st_out[tid] = L.st[tid];
+        if (tid == 40) st_out[40] = found ? s_sc[2] : 0.0;
+        if (tid == 41) st_out[41] = found ? s_sc[3] : 0.0;
+        if (tid == 42) st_out[42] = lse;
+        if (tid == 43) st_out[43] = shift;
+        if (tid == 44) st_out[44] = mp;
+        if (tid == 45) st_out[45] = found ? 1.0 : 0.0;
+#ifdef ISW_STAMP
+        ISW_MARK();
+        if (tid == 0)
+            for (int k = 0; k < 16; k++) st_out[48 + k] = k < n_stamp ? stamps[k] : -1.0;
+#endif
+        // top the counter up to this launch's budget: the next launch's base
+        if (tid == 0)
+            __hip_atomic_fetch_add(bar, (unsigned int)(ISW_BARRIERS - nbar) * (unsigned int)G, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // heap node k of the bisection tree rooted at (lo, hi): the midpoint the sequential loop would try there
@@ -766,6 +1111,60 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
     out_host[10] = h[10];             // (m, S1, S2) at beta = 1
     out_host[11] = h[32];
     out_host[12] = h[33];
+    return ASMC_OK;
+}
+
+}  // extern "C"
+
+int asmc_is_weights_launch(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double beta0,
+                           double target_eff, double tol, double* w, double* tiles, hipStream_t st) {
+    const BisInit init = {beta0, target_eff, tol, log((double)n), (double)n};
+    int64_t chunk = ISW_CHUNK;
+    int64_t grid = (n + chunk - 1) / chunk;
+    const bool reg = grid <= ctx->num_cu;
+    if (!reg) {
+        chunk = (n + ctx->num_cu - 1) / ctx->num_cu;
+        chunk = (chunk + ISW_CHUNK - 1) / ISW_CHUNK * ISW_CHUNK;
+        grid = (n + chunk - 1) / chunk;
+    }
+    double* d_st = ctx->d_small + 2560;
+    const unsigned int base = ctx->bar_base;
+    ctx->bar_base += (unsigned int)ISW_BARRIERS * (unsigned int)grid;
+    if (reg) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_is_weights<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ISW_CHUNK * (int)sizeof(double)));
+            attr_set = true;
+        }
+        ASMC_LAUNCH(ctx, st, "k_is_weights", k_is_weights<true>, dim3((unsigned)grid), dim3(ISW_THREADS),
+                    2 * ISW_CHUNK * sizeof(double), st, n, ll, lp, lq, d_st,
+                    ctx->d_partials, ctx->d_bar, base, init, chunk, w, tiles);
+    } else
+        ASMC_LAUNCH(ctx, st, "k_is_weights", k_is_weights<false>, dim3((unsigned)grid), dim3(ISW_THREADS), 0, st, n, ll, lp, lq, d_st,
+                    ctx->d_partials, ctx->d_bar, base, init, chunk, w, tiles);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+extern "C" {
+
+int asmc_importance_result(asmc_ctx* ctx, double* out_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && out_host, "null pointer");
+    hipStream_t st = as_stream(stream);
+    double* h = ctx->h_pinned + 4096 + 512;
+    ASMC_HIP(hipMemcpyAsync(h, ctx->d_small + 2560, sizeof(double) * 64, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    out_host[0] = h[0], out_host[1] = h[1], out_host[2] = h[2], out_host[3] = h[6], out_host[4] = h[9];
+    out_host[5] = h[15];
+    out_host[6] = h[11], out_host[7] = h[12], out_host[8] = h[13], out_host[9] = h[14];
+    out_host[10] = h[10], out_host[11] = h[32], out_host[12] = h[33];
+    out_host[13] = h[40], out_host[14] = h[41], out_host[15] = h[45];
+#ifdef ISW_STAMP
+    fprintf(stderr, "k_is_weights stamps (us, block 0):");
+    for (int k = 48; k < 64; k++) fprintf(stderr, " %.2f", h[k]);
+    fprintf(stderr, "\n");
+#endif
     return ASMC_OK;
 }
 

@@ -240,6 +240,31 @@ class HipEngine:
         trip = (float(out[6]), float(out[7]), float(out[8])) if out[9] != 0.0 else None
         return float(out[0]), float(out[4]), bool(out[2]), int(out[3]), int(out[5]), trip, tuple(map(float, out[10:13]))
 
+    def importance_step(self, ll, lp, lq, beta0: float, target_eff: float, tol: float, state4: np.ndarray, n_out: int):
+        """Enqueue one iteration's adaptive-beta search, evidence moments and resampling indices for the next `n_out`
+        PCG64 doubles behind `state4` (include/asmc.h asmc_importance_step; no host synchronisation).  Returns the device
+        index tensor; `importance_result()` then reads the scalars."""
+        self._chk3(ll, lp, lq)
+        n = ll.numel()
+        st = np.ascontiguousarray(state4, dtype=np.uint64)
+        bufs = self.__dict__.setdefault("_is_bufs", {})
+        if bufs.get("n") != n:
+            bufs.update(n=n, w=self.empty(n), cdf=self.empty(n))
+        idx = torch.empty(n_out, dtype=torch.int64, device=self.device)
+        check(self.lib.asmc_importance_step(self._ctx, n, _dptr(ll), _dptr(lp), _dptr(lq), beta0, target_eff, tol,
+                                            st.ctypes.data_as(ctypes.c_void_p), n_out, _dptr(bufs["w"]), _dptr(bufs["cdf"]),
+                                            _dptr(idx), self._stream), "asmc_importance_step")
+        return idx
+
+    def importance_result(self):
+        """(beta_star, eff_at_one, converged, rounds, n_nan, (m, S1, S2) at beta_star or None, (m, S1, S2) at 1,
+        m2, S1', found) of the last `importance_step` (synchronises)."""
+        out = np.zeros(16)
+        check(self.lib.asmc_importance_result(self._ctx, _f64p(out), self._stream), "asmc_importance_result")
+        trip = (float(out[6]), float(out[7]), float(out[8])) if out[9] != 0.0 else None
+        return (float(out[0]), float(out[4]), bool(out[2]), int(out[3]), int(out[5]), trip, tuple(map(float, out[10:13])),
+                float(out[13]), float(out[14]), bool(out[15]))
+
     # sharded search (smc_math.find_beta_sharded drives the rounds; the all-gather between the halves is the caller's)
     def find_beta_shard_reduce(self, ll, lp, lq, beta0: float, rnd: int, rec: torch.Tensor):
         self._chk3(ll, lp, lq)

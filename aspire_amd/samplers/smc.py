@@ -40,6 +40,7 @@ class SMCSampler(MCMCSampler):
                          preconditioning_transform=preconditioning_transform, rng=rng, engine=engine, comm=comm)
         self._adaptive_target_efficiency = False
         self.device_bisection = True  # single-rank: whole adaptive-beta search on device (asmc_find_beta)
+        self.fused_importance_step = True  # single-rank: search + moments + resampling enqueued as one chain
         self.resample_mode = "exact"
         self.resample_method = "multinomial"
         self.shard_layout = "owner"  # sharded runs: offspring stay on the ancestor's rank ("slots": single-rank order)
@@ -98,7 +99,11 @@ class SMCSampler(MCMCSampler):
         sharded = self.comm.world > 1 and hasattr(self.engine, "find_beta_shard_reduce")
         if ((self.comm.world == 1 and hasattr(self.engine, "find_beta")) or sharded) and self.device_bisection and beta < 1.0:
             def search_fn(beta_prev, target_eff, tol):
-                if sharded:
+                spec = samples.__dict__.get("_spec")
+                if (spec is not None and spec["key"] == (float(target_eff), float(tol)) and spec["search"][2]
+                        and float(beta_prev) == float(samples.beta)):
+                    b, _, converged, passes, n_nan, trip, trip_one = spec["search"]  # the fused step already searched
+                elif sharded:
                     b, _, converged, passes, n_nan, trip, trip_one = smc_math.find_beta_sharded(
                         self.engine, self.comm, samples.log_likelihood, samples.log_prior, samples.log_q, float(beta_prev),
                         float(target_eff), float(tol), n)
@@ -242,6 +247,13 @@ class SMCSampler(MCMCSampler):
         if run_smc_loop:
             while True:
                 iterations += 1
+                if self.fused_importance_step and self.adaptive and self.device_bisection and beta < 1.0:
+                    # search + evidence moments + resampling at beta* in one chain of launches, one synchronisation;
+                    # determine_beta and resample below pick the parked results up (or redo the step when the
+                    # schedule rules choose another beta)
+                    samples.speculate_importance_step(self.current_target_efficiency(beta), beta_tolerance, self.rng,
+                                                      resample_mode=self.resample_mode,
+                                                      resample_method=self.resample_method)
                 beta, min_beta_step = self.determine_beta(samples, beta, beta_step, min_beta_step,
                                                           max_beta_step=self.max_beta_step,
                                                           beta_tolerance=beta_tolerance)

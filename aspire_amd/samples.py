@@ -413,6 +413,43 @@ class SMCSamples(BaseSamples):
         if s1p is not None:
             self.__dict__.setdefault("_ws1p", {})[float(beta)] = float(s1p)
 
+    def speculate_importance_step(self, target_eff: float, tol: float, rng, *, resample_mode: str = "exact",
+                                  resample_method: str = "multinomial") -> bool:
+        """Enqueue the whole importance step of one iteration - adaptive-beta search (smc/base.py:167-186), evidence
+        moments (samples.py:1226-1242) and the multinomial resampling of all N particles at beta* (samples.py:1251-1287)
+        - as one chain of launches with a single host synchronisation (include/asmc.h asmc_importance_step), and park
+        the results on this object: the sampler's `determine_beta` then finds the search result, and `resample(beta*)`
+        the resampled rows.  Speculative: the host's schedule rules (min / max beta step) may pick another beta than
+        beta*, in which case `resample` ignores the parked rows and the generator has not been touched.
+        Returns False when the step does not apply (sharded run, non-PCG64 generator, other resampling schemes)."""
+        self.__dict__.pop("_spec", None)
+        e, comm = self._eng(), self._comm()
+        st4 = smc_math.pcg64_state(rng)
+        if (comm.world != 1 or not hasattr(e, "importance_step") or st4 is None or resample_mode != "exact"
+                or resample_method != "multinomial" or not float(self.beta) < 1.0):
+            return False
+        ll, lp, lq = self._dev3()
+        x = e.asarray(self.x, dtype=self.x.dtype if is_torch(self.x) else torch.float64)
+        n = ll.numel()
+        idx = e.importance_step(ll, lp, lq, float(self.beta), float(target_eff), float(tol), st4, n)
+        rows = e.gather(idx, x, ll, lp, lq)
+        b, eff1, conv, passes, n_nan, trip, trip_one, m2, _, found = e.importance_result()
+        self._spec = dict(key=(float(target_eff), float(tol)), search=(b, eff1, conv, passes, n_nan, trip, trip_one),
+                          found=bool(found and conv), beta=float(b), rows=rows, m2=m2, rng=rng,
+                          state=[int(v) for v in st4], n=n)
+        return True
+
+    def _take_speculated(self, beta: float, n_samples: int, rng, resample_mode: str, resample_method: str):
+        """The rows `speculate_importance_step` parked, if they are the answer to this `resample` call; else None."""
+        spec = self.__dict__.pop("_spec", None)
+        if (spec is None or not spec["found"] or spec["beta"] != float(beta) or spec["n"] != n_samples
+                or spec["rng"] is not rng or resample_mode != "exact" or resample_method != "multinomial"):
+            return None
+        st4 = smc_math.pcg64_state(rng)
+        if st4 is None or [int(v) for v in st4] != spec["state"]:
+            return None
+        return spec
+
     def unnormalized_log_weights(self, beta: float):
         """samples.py:1221-1224."""
         ll, lp, lq = self._dev3()
@@ -480,6 +517,15 @@ class SMCSamples(BaseSamples):
 
         counts = self.shard_counts_list()
         ragged = len(set(counts)) > 1
+
+        spec = None if uniform else self._take_speculated(beta, int(n_samples), rng, resample_mode, resample_method)
+        if spec is not None:
+            # samples.py:1230-1242 from the sum the fused step left (smc_math.evidence_variance_and_lse's formula)
+            mean_u = st.S1 / st.n
+            var_u = spec["m2"] / st.n
+            var = float(var_u / (st.n * (mean_u**2))) if mean_u != 0 else float("nan")
+            rng.bit_generator.advance(int(n_samples))  # the n draws Generator.choice takes
+            return wrap(*spec["rows"], counts=counts)
 
         if shard_layout == "owner" and smc_math.owner_layout_ok(e, comm, rng, resample_method, uniform):
             idx, var, s1p, new_counts = smc_math.resample_owner(

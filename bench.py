@@ -242,6 +242,18 @@ def main():
         scal = {}
 
         def is_step():
+            if not sharded and args.resample_mode == "exact" and hasattr(eng, "importance_step"):
+                # the sampler loop's path (SMCSamples.speculate_importance_step): one chain of launches, one sync
+                idx = eng.importance_step(ll, lp, lq, 0.0, 0.5, 1e-6, smc_math.pcg64_state(rng_is), n_global)
+                rows = eng.gather(idx, x, ll, lp, lq)
+                b, _, conv, _, n_nan, trip, trip_one, m2, _, found = eng.importance_result()
+                assert conv and found and n_nan == 0
+                rng_is.bit_generator.advance(n_global)
+                st_b, st_1 = smc_math.Stats(*trip, n_global), smc_math.Stats(*trip_one, n_global)
+                mean_u = st_b.S1 / n_global
+                scal.update(beta=b, ess=smc_math.ess(st_b), ess1=smc_math.ess(st_1), ratio=smc_math.log_evidence_ratio(st_b),
+                            var=(m2 / n_global) / (n_global * mean_u**2))
+                return rows
             if sharded:
                 b, _, conv, _, n_nan, trip, trip_one = smc_math.find_beta_sharded(eng, comm, ll, lp, lq, 0.0, 0.5, 1e-6, n_global)
             else:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 9
+#define ASMC_ABI_VERSION 10
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -149,6 +149,24 @@ int asmc_weights_stats(asmc_ctx* ctx, int64_t n, const double* ll_dev, const dou
 int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
                    const double* lq_dev, double beta0, double target_eff, double tol,
                    double* out_host, asmc_stream stream);
+
+/* One iteration's importance step for a single-rank population, enqueued without a host round trip
+ * (smc/base.py:167-186 determine_beta, samples.py:1226-1249 evidence ratio / variance, samples.py:1276-1278
+ * resampling indices): asmc_find_beta + asmc_weights_m2_lse + asmc_normalized_weights + asmc_cdf(EXACT | NORMALIZE) +
+ * asmc_pcg64_uniforms + asmc_search as five launches (persistent weight kernel; transducer, chain and write passes of
+ * the exact scan, the write pass filling the search's guide table; search with the uniforms generated in registers).
+ * idx_out[j] (device, n_out entries) = searchsorted(cumsum(w) / cumsum(w)[-1], u_j, side="right") for the next n_out
+ * doubles u of the PCG64 stream `rng_state` = {state_hi, state_lo, inc_hi, inc_lo}; the caller advances its generator by
+ * n_out once it accepts the step.  w_scratch, cdf_scratch: n doubles each (device).
+ * SPECULATIVE: beta* is only known on the device.  When the search finds no valid beta* (NaN log-weights, no candidate
+ * above beta0, not converged) the weights are uniform (idx_out is then a valid but meaningless draw) and
+ * asmc_importance_result reports found = 0; the caller redoes the step through the step-by-step entry points.
+ * asmc_importance_result (synchronises): out_host[16] = asmc_find_beta's 13 values, then
+ * [13] sum (exp(lw - m) - mean_u)^2, [14] S1' of the second log-sum-exp (both at beta*), [15] found. */
+int asmc_importance_step(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev, const double* lq_dev,
+                         double beta0, double target_eff, double tol, const uint64_t rng_state[4], int64_t n_out,
+                         double* w_scratch_dev, double* cdf_scratch_dev, int64_t* idx_out_dev, asmc_stream stream);
+int asmc_importance_result(asmc_ctx* ctx, double* out_host, asmc_stream stream);
 /* The same search with the particles sharded over `world` ranks (one process per GPU; the reference has no
  * distributed mode).  A round is split at the rank boundary and never synchronises with the host:
  *   asmc_find_beta_shard_reduce  this rank's sums of the round's 16 candidates -> rec_dev[ASMC_BIS_REC]

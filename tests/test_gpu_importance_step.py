@@ -1,0 +1,181 @@
+"""asmc_importance_step (search + evidence moments + resampling as one chain of launches, one synchronisation) against
+the step-by-step entry points it fuses, against the oracle, and inside the sampler loop.
+
+Bars: beta* and the resampling indices bit-exact; the reduced sums within 1e-12 (they are summed in another order)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import synth
+
+from aspire_amd import smc_math
+from aspire_amd.comm import Comm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(hip_engine):
+    return hip_engine
+
+
+def dev(eng, *arrs):
+    return tuple(eng.asarray(a) for a in arrs)
+
+
+def _step_by_step(eng, lld, lpd, lqd, beta0, target, tol, n, seed):
+    b, eff1, conv, passes, n_nan, trip, trip_one = eng.find_beta(lld, lpd, lqd, beta0, target, tol)
+    assert conv and n_nan == 0 and trip is not None
+    st = smc_math.Stats(*trip, n)
+    var, s1p = smc_math.evidence_variance_and_lse(eng, Comm(), lld, lpd, lqd, beta0, b, st)
+    rng = np.random.default_rng(seed)
+    idx, _ = smc_math.resample_indices(eng, Comm(), lld, lpd, lqd, beta0, b, n, rng, mode="exact", st=st, s1p=s1p)
+    return b, eff1, passes, trip, trip_one, var, s1p, idx.cpu().numpy(), rng
+
+
+@pytest.mark.parametrize("n,d,seed,beta0,target", [
+    (1000, 2, 3, 0.0, 0.5), (4097, 3, 4, 0.0, 0.5), (300001, 4, 5, 0.1, 0.6), (1 << 20, 4, 6, 0.0, 0.5),
+    (1 << 20, 2, 7, 0.25, 0.9), (1_500_003, 2, 8, 0.0, 0.5), (2_000_000, 2, 9, 0.3, 0.3)])
+def test_importance_step_equals_the_step_by_step_path(eng, n, d, seed, beta0, target):
+    """n <= 1M: the persistent kernel keeps the particles in LDS; above it streams them once per phase."""
+    x, ll, lp, lq = synth(n, d, seed)
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    tol = 1e-6
+    b, eff1, passes, trip, trip_one, var, s1p, idx_ref, rng_ref = _step_by_step(eng, lld, lpd, lqd, beta0, target, tol, n, 21)
+    rng = np.random.default_rng(21)
+    idx = eng.importance_step(lld, lpd, lqd, beta0, target, tol, smc_math.pcg64_state(rng), n)
+    fb, feff1, fconv, fpasses, fnan, ftrip, ftrip_one, m2, fs1p, found = eng.importance_result()
+    assert found and fconv and fnan == 0
+    assert fb == b and fpasses == passes  # same candidates, same decisions
+    assert feff1 == pytest.approx(eff1, rel=1e-12)
+    assert ftrip[0] == trip[0] and ftrip_one[0] == trip_one[0]  # shifts / maxima: exact
+    np.testing.assert_allclose(ftrip[1:], trip[1:], rtol=1e-12)
+    np.testing.assert_allclose(ftrip_one[1:], trip_one[1:], rtol=1e-12)
+    st = smc_math.Stats(*ftrip, n)
+    mean_u = st.S1 / n
+    assert (m2 / n) / (n * mean_u**2) == pytest.approx(var, rel=1e-10)
+    assert fs1p == pytest.approx(s1p, rel=1e-12)
+    got = idx.cpu().numpy()
+    assert np.array_equal(got, idx_ref), (int((got != idx_ref).sum()), n)
+
+
+def test_importance_step_indices_vs_oracle_1m(eng, oracle):
+    """Against numpy's algorithm itself (oracle: sequential cumsum + searchsorted on the host uniforms)."""
+    n = 1 << 20
+    x, ll, lp, lq = synth(n, 2, 99)
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    rng = np.random.default_rng(5)
+    idx = eng.importance_step(lld, lpd, lqd, 0.0, 0.5, 1e-6, smc_math.pcg64_state(rng), n)
+    b, _, conv, _, _, trip, _, _, _, found = eng.importance_result()
+    assert found and conv
+    ref = oracle.resample_indices(ll, lp, lq, 0.0, b, np.random.default_rng(5).random(n))
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    # the oracle's own search lands on the same beta*
+    target = 0.5
+    assert oracle.ess_at_beta(ll, lp, lq, 0.0, b) / n >= target
+    assert oracle.ess_at_beta(ll, lp, lq, 0.0, min(1.0, b + 2e-6)) / n < target
+
+
+@pytest.mark.parametrize("n_out", [1, 63, 1000, 262144, 262145, 1_048_577])
+def test_importance_step_draw_counts(eng, n_out):
+    """n_out != N: the search's thread count and strides adapt; still the stream's first n_out doubles."""
+    n = 200_003
+    x, ll, lp, lq = synth(n, 2, 31)
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    rng = np.random.default_rng(8)
+    idx = eng.importance_step(lld, lpd, lqd, 0.0, 0.5, 1e-6, smc_math.pcg64_state(rng), n_out)
+    b, _, conv, _, _, trip, _, _, s1p, found = eng.importance_result()
+    assert found
+    ref, _ = smc_math.resample_indices(eng, Comm(), lld, lpd, lqd, 0.0, b, n_out, np.random.default_rng(8), mode="exact",
+                                       st=smc_math.Stats(*trip, n))
+    assert np.array_equal(idx.cpu().numpy(), ref.cpu().numpy())
+
+
+def test_importance_step_heavy_weights_guide_table(eng):
+    """A few particles own most of the mass: long runs of guide buckets per element (the block-wide fill)."""
+    n = 1 << 19
+    g = np.random.default_rng(17)
+    ll = g.normal(size=n)
+    ll[[5, 70000, n - 3]] += 14.0  # three particles carry ~all of the weight at beta = 1
+    lp, lq = g.normal(size=n) * 0.01, g.normal(size=n) * 0.01
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    for target in (0.5, 1e-6):  # 1e-6: eff(1) >= target -> beta* = 1 with three dominant weights
+        b, eff1, passes, trip, trip_one, var, s1p, idx_ref, _ = _step_by_step(eng, lld, lpd, lqd, 0.0, target, 1e-6, n, 4)
+        rng = np.random.default_rng(4)
+        idx = eng.importance_step(lld, lpd, lqd, 0.0, target, 1e-6, smc_math.pcg64_state(rng), n)
+        res = eng.importance_result()
+        assert res[-1] and res[0] == b
+        assert np.array_equal(idx.cpu().numpy(), idx_ref)
+    assert b == 1.0
+
+
+def test_importance_step_reports_failures(eng):
+    """NaN log-weights and a search that cannot leave beta0 are reported, and the parked draw stays in bounds."""
+    n = 100_000
+    x, ll, lp, lq = synth(n, 2, 41)
+    ll_nan = ll.copy()
+    ll_nan[123] = np.nan
+    rng = np.random.default_rng(1)
+    idx = eng.importance_step(*dev(eng, ll_nan, lp, lq), 0.0, 0.5, 1e-6, smc_math.pcg64_state(rng), n)
+    res = eng.importance_result()
+    assert res[4] == 1 and not res[-1]
+    got = idx.cpu().numpy()
+    assert got.min() >= 0 and got.max() <= n
+    # target efficiency above 1: no beta > beta0 qualifies
+    idx = eng.importance_step(*dev(eng, ll, lp, lq), 0.2, 1.5, 1e-6, smc_math.pcg64_state(rng), n)
+    res = eng.importance_result()
+    assert not res[-1] and res[5] is None
+    # back-to-back launches share the barrier counter: a normal step afterwards still works
+    idx = eng.importance_step(*dev(eng, ll, lp, lq), 0.0, 0.5, 1e-6, smc_math.pcg64_state(rng), n)
+    assert eng.importance_result()[-1]
+
+
+def _np(t):
+    return t.cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def _run(eng, fused, n, d, seed, **kw):
+    from aspire_amd.flows import GaussianFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=1.5, engine=eng, seed=1),
+                xp=np, engine=eng, rng=np.random.default_rng(seed))
+    sp.fused_importance_step = fused
+    out = sp.sample(n, sampler_kwargs=dict(n_steps=4), store_sample_history=False, **kw)
+    return sp, out
+
+
+@pytest.mark.parametrize("n,d", [(20000, 8), (300000, 32)])
+def test_sampler_with_and_without_the_fused_step(eng, n, d):
+    """Same beta schedule, same particles, same generator state; evidence terms to rounding."""
+    sp_a, out_a = _run(eng, True, n, d, 3)
+    sp_b, out_b = _run(eng, False, n, d, 3)
+    assert sp_a.history.beta == sp_b.history.beta
+    np.testing.assert_allclose(sp_a.history.log_norm_ratio, sp_b.history.log_norm_ratio, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(sp_a.history.log_norm_ratio_var, sp_b.history.log_norm_ratio_var, rtol=1e-9)
+    np.testing.assert_allclose(sp_a.history.ess, sp_b.history.ess, rtol=1e-11)
+    assert np.array_equal(_np(out_a.x), _np(out_b.x))
+    assert sp_a.rng.bit_generator.state == sp_b.rng.bit_generator.state
+    d_ = d
+    assert abs(float(out_a.log_evidence) - 0.5 * d_ * math.log(math.pi)) < max(5 * float(out_a.log_evidence_error), 0.05)
+
+
+def test_sampler_fused_step_is_used_and_schedule_clamps_fall_back(eng):
+    """The fused chain is what runs (k_is_weights / k_search_pcg launches, no k_bis_sums); with a max beta step that
+    caps beta below beta* the parked rows are dropped and the result equals the step-by-step run."""
+    eng.profile(True)
+    sp, out = _run(eng, True, 50000, 8, 5)
+    rep = eng.profile_report()
+    eng.profile(False)
+    temps = len(sp.history.beta)
+    assert rep["k_is_weights"][0] == temps
+    assert "k_bis_sums" not in rep and "k_search_pcg" in rep
+    sp_a, out_a = _run(eng, True, 50000, 8, 6, max_beta_step=0.05)
+    sp_b, out_b = _run(eng, False, 50000, 8, 6, max_beta_step=0.05)
+    assert sp_a.history.beta == sp_b.history.beta and max(np.diff([0.0] + sp_a.history.beta)) <= 0.05 + 1e-12
+    assert np.array_equal(_np(out_a.x), _np(out_b.x))
+    assert sp_a.rng.bit_generator.state == sp_b.rng.bit_generator.state
