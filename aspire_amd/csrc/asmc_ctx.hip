@@ -135,8 +135,8 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     dmalloc((void**)&c->d_counts, sizeof(long long) * (size_t)(ASMC_MAX_PCN_STEPS + ASMC_MAX_BLOCKS + n_max / 64 + 8));
     dmalloc((void**)&c->d_rho, sizeof(double) * (ASMC_MAX_PCN_STEPS + 8));
     dmalloc((void**)&c->d_tilectr, sizeof(unsigned int) * ASMC_MAX_PCN_STEPS);
-    dmalloc((void**)&c->d_bar, sizeof(unsigned int) * 4);
-    if (e == hipSuccess) e = hipMemset(c->d_bar, 0, sizeof(unsigned int) * 4);
+    dmalloc((void**)&c->d_bar, sizeof(unsigned int) * 1024 * 17);
+    if (e == hipSuccess) e = hipMemset(c->d_bar, 0, sizeof(unsigned int) * 1024 * 17);
     dmalloc((void**)&c->d_pcgtab, sizeof(unsigned long long) * (64 * 4 + 8));
     dmalloc((void**)&c->d_select, sizeof(long long) * (2 * (ASMC_SELECT_THREADS / 64) + 8));
     dmalloc((void**)&c->d_ptab, sizeof(double) * (2 * 32 * 32 + 32 + 3 * ASMC_MAX_COMPONENTS * (1 + 2 * 32) + 64));

@@ -359,15 +359,15 @@ __device__ __forceinline__ void bis_reduce_partials(const double* __restrict__ p
                                                     double (*s_red)[33], double* s_S) {
     const int col = threadIdx.x & 31, part = threadIdx.x >> 5, nparts = blockDim.x >> 5;
     double v = 0.0;
-    for (int b0 = part; b0 < nblocks; b0 += 8 * nparts) {  // eight records in flight per thread, fixed order
-        double t8[8];
+    for (int b0 = part; b0 < nblocks; b0 += 16 * nparts) {  // sixteen records in flight per thread, fixed order
+        double t16[16];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < 16; q++) {
             const int b = b0 + q * nparts;
-            t8[q] = b < nblocks ? partials[(size_t)b * 32 + col] : 0.0;
+            t16[q] = b < nblocks ? partials[(size_t)b * 32 + col] : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 8; q++) v += t8[q];
+        for (int q = 0; q < 16; q++) v += t16[q];
     }
     s_red[part][col] = v;
     __syncthreads();
@@ -645,13 +645,28 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const doubl
 #define ISW_MAX_ROUNDS 20
 #define ISW_BARRIERS 32
 
-__device__ __forceinline__ void isw_barrier(unsigned int* ctr, unsigned int target) {
+// Two-level arrival: block b counts in on the counter of its group b % ISW_GROUPS (the counters sit in different
+// memory channels, so the same-address atomics of one arrival wave serialise 8-fold less); the last block of a group
+// counts the group in on the top counter, which everybody polls with plain device-scope loads.
+// bar: [0] top counter, [ISW_BAR_STRIDE * (1 + g)] group g; bases: their values when this launch started.
+#define ISW_GROUPS 8
+#define ISW_BAR_STRIDE 1024  // counters 4 KB apart
+struct IswBases {
+    unsigned int top, group[ISW_GROUPS];
+};
+__device__ __forceinline__ void isw_barrier(unsigned int* bar, const IswBases& bases, unsigned int k, int G) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+        const int g = blockIdx.x % ISW_GROUPS;
+        const unsigned int ngroups = G < ISW_GROUPS ? G : ISW_GROUPS;
+        const unsigned int gsize = (unsigned int)(G - g + ISW_GROUPS - 1) / ISW_GROUPS;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0)
+        const unsigned int old = __hip_atomic_fetch_add(bar + ISW_BAR_STRIDE * (1 + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old - bases.group[g] == k * gsize - 1u)  // this block completes its group's k-th arrival
+            __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int target = bases.top + k * ngroups;
+        while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0)
             __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -662,7 +677,7 @@ template <bool REG>
 __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const double* __restrict__ ll,
                                                            const double* __restrict__ lp, const double* __restrict__ lq,
                                                            double* __restrict__ st_out, double* partials,
-                                                           unsigned int* bar, unsigned int bar_base, BisInit init,
+                                                           unsigned int* bar, IswBases bar_bases, BisInit init,
                                                            int64_t chunk, double* __restrict__ w,
                                                            double* __restrict__ tiles) {
     __shared__ BisLds L;
@@ -690,7 +705,7 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
 #endif
     auto barrier = [&]() {
         nbar++;
-        isw_barrier(bar, bar_base + nbar * (unsigned int)G);
+        isw_barrier(bar, bar_bases, nbar, G);
     };
     auto pbuf = [&](unsigned int k) { return partials + (size_t)(k & 1u) * (size_t)G * 32; };
 
@@ -941,10 +956,15 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
         if (tid == 0)
             for (int k = 0; k < 16; k++) st_out[48 + k] = k < n_stamp ? stamps[k] : -1.0;
 #endif
-        // top the counter up to this launch's budget: the next launch's base
-        if (tid == 0)
-            __hip_atomic_fetch_add(bar, (unsigned int)(ISW_BARRIERS - nbar) * (unsigned int)G, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+        // top the counters up to this launch's budget: the next launch's bases
+        const unsigned int left = (unsigned int)(ISW_BARRIERS - nbar);
+        if (tid == 0) __hip_atomic_fetch_add(bar, left * (unsigned int)(G < ISW_GROUPS ? G : ISW_GROUPS), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+        if (tid >= 1 && tid <= ISW_GROUPS && tid - 1 < G) {
+            const int g = tid - 1;
+            __hip_atomic_fetch_add(bar + ISW_BAR_STRIDE * (1 + g), left * ((unsigned int)(G - g + ISW_GROUPS - 1) / ISW_GROUPS),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1128,8 +1148,13 @@ int asmc_is_weights_launch(asmc_ctx* ctx, int64_t n, const double* ll, const dou
         grid = (n + chunk - 1) / chunk;
     }
     double* d_st = ctx->d_small + 2560;
-    const unsigned int base = ctx->bar_base;
-    ctx->bar_base += (unsigned int)ISW_BARRIERS * (unsigned int)grid;
+    IswBases bases;
+    bases.top = ctx->bar_base[0];
+    ctx->bar_base[0] += (unsigned int)ISW_BARRIERS * (unsigned int)(grid < ISW_GROUPS ? grid : ISW_GROUPS);
+    for (int g = 0; g < ISW_GROUPS; g++) {
+        bases.group[g] = ctx->bar_base[1 + g];
+        if (g < grid) ctx->bar_base[1 + g] += (unsigned int)ISW_BARRIERS * (unsigned int)((grid - g + ISW_GROUPS - 1) / ISW_GROUPS);
+    }
     if (reg) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -1139,10 +1164,10 @@ int asmc_is_weights_launch(asmc_ctx* ctx, int64_t n, const double* ll, const dou
         }
         ASMC_LAUNCH(ctx, st, "k_is_weights", k_is_weights<true>, dim3((unsigned)grid), dim3(ISW_THREADS),
                     2 * ISW_CHUNK * sizeof(double), st, n, ll, lp, lq, d_st,
-                    ctx->d_partials, ctx->d_bar, base, init, chunk, w, tiles);
+                    ctx->d_partials, ctx->d_bar, bases, init, chunk, w, tiles);
     } else
         ASMC_LAUNCH(ctx, st, "k_is_weights", k_is_weights<false>, dim3((unsigned)grid), dim3(ISW_THREADS), 0, st, n, ll, lp, lq, d_st,
-                    ctx->d_partials, ctx->d_bar, base, init, chunk, w, tiles);
+                    ctx->d_partials, ctx->d_bar, bases, init, chunk, w, tiles);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
