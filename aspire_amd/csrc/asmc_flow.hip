@@ -31,7 +31,7 @@
 
 #include "asmc_flow_dev.h"
 
-template <int H, int W, typename XT, int FLOW_THREADS, int TPW>
+template <int H, int W, typename XT, int FLOW_THREADS, int TPW, bool HS>
 __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, int d, const XT* __restrict__ x,
                                                                   const float* __restrict__ packed, int n_layers,
                                                                   int resident, const float* __restrict__ loc,
@@ -44,7 +44,10 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, in
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, hh = lane >> 5;
     const int dh = d / 2;
-    if (resident) {
+    if (resident && HS) {
+        flow_stage_hs<H, W, FLOW_THREADS>(sp, packed, n_layers);  // split-fp16 operand images (asmc_flow_dev.h)
+        __syncthreads();
+    } else if (resident) {
         // all of a thread's loads are issued before the first LDS store: 14 dependent round trips to L2 would
         // otherwise cost ~5 % of the kernel at 1M particles
         const int total4 = n_layers * FD::LAYER / 4;
@@ -129,12 +132,21 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, in
             const float* lp = sp + (resident ? (size_t)c * FD::LAYER : 0);
             if (!resident) {
                 __syncthreads();  // every wave is done with the previous layer's block
-                for (int i = threadIdx.x * 4; i < FD::LAYER; i += FLOW_THREADS * 4)
-                    *reinterpret_cast<float4*>(sp + i) =
-                        *reinterpret_cast<const float4*>(packed + (size_t)c * FD::LAYER + i);
+                if (HS)
+                    flow_stage_hs<H, W, FLOW_THREADS>(sp, packed + (size_t)c * FD::LAYER, 1);
+                else
+                    for (int i = threadIdx.x * 4; i < FD::LAYER; i += FLOW_THREADS * 4)
+                        *reinterpret_cast<float4*>(sp + i) =
+                            *reinterpret_cast<const float4*>(packed + (size_t)c * FD::LAYER + i);
                 __syncthreads();
             }
-            if ((c & 1) == 0)
+            if constexpr (HS) {
+                static_assert(TPW == 1, "the split-fp16 layers take one tile per wave");
+                if ((c & 1) == 0)
+                    coupling_layer_hs<H, W>(xa[0], xb[0], lp, lane, hh, ladj[0]);
+                else
+                    coupling_layer_hs<H, W>(xb[0], xa[0], lp, lane, hh, ladj[0]);
+            } else if ((c & 1) == 0)
                 coupling_layer<H, W, TPW>(xa, xb, lp, lane, hh, ladj);
             else
                 coupling_layer<H, W, TPW>(xb, xa, lp, lane, hh, ladj);
@@ -154,6 +166,13 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, in
 
 // ---------------------------------------------------------------------------------------------
 // host side
+// flow arithmetic: split-fp16 MFMA (fp32-equivalent operands, asmc_flow_dev.h) unless ASMC_FLOW_MATH=f32 asks for the
+// fp32 MFMA chain (read at every launch: a process can compare the two)
+bool asmc_flow_math_split() {
+    const char* e = getenv("ASMC_FLOW_MATH");
+    return !(e && strcmp(e, "f32") == 0);
+}
+
 static int flow_half_pad(int dims) { return ((dims / 2 + 15) / 16) * 16; }
 
 static bool flow_supported(int dims, int hidden) {
@@ -236,7 +255,7 @@ extern "C" int asmc_coupling_pack(int dims, int n_layers, int hidden, const floa
     return ASMC_OK;
 }
 
-template <int H, int W, typename XT, int FLOW_THREADS, int TPW>
+template <int H, int W, typename XT, int FLOW_THREADS, int TPW, bool HS>
 static int launch_flow(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_coupling* f, double* out, hipStream_t st) {
     using FD = FlowDims<H, W>;
     const size_t all = (size_t)f->n_layers * FD::LAYER * sizeof(float);
@@ -244,7 +263,7 @@ static int launch_flow(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_couplin
     const size_t lds = resident ? all : (size_t)FD::LAYER * sizeof(float);
     ASMC_REQUIRE(lds <= 160 * 1024, "one coupling layer does not fit in LDS");
     constexpr int FLOW_WAVES = FLOW_THREADS / 64;
-    auto kern = k_coupling_logprob<H, W, XT, FLOW_THREADS, TPW>;
+    auto kern = k_coupling_logprob<H, W, XT, FLOW_THREADS, TPW, HS>;
     static size_t attr_lds = 0;  // per instantiation
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -268,10 +287,12 @@ static int dispatch_flow(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_coupl
     // one tile per wave with next-tile prefetch by default; ASMC_FLOW_TPW=2 selects two tiles per wave (shared A
     // operands, no prefetch) where the accumulators fit the 256-VGPR budget of 2 waves/SIMD
     static const int tpw_env = getenv("ASMC_FLOW_TPW") ? atoi(getenv("ASMC_FLOW_TPW")) : 0;
+    const bool hs = asmc_flow_math_split();
 #define ASMC_FLOW_CASE(HH, WW)                                                                          \
     if (H == HH && f->hidden == WW) {                                                                   \
-        if (HH == 16 && WW <= 64 && tpw_env == 2) return launch_flow<HH, WW, XT, 512, (HH == 16 && WW <= 64) ? 2 : 1>(ctx, n, x, f, out, st); \
-        return launch_flow<HH, WW, XT, 512, 1>(ctx, n, x, f, out, st);                                  \
+        if (HH == 16 && WW <= 64 && tpw_env == 2) return launch_flow<HH, WW, XT, 512, (HH == 16 && WW <= 64) ? 2 : 1, false>(ctx, n, x, f, out, st); \
+        if (hs) return launch_flow<HH, WW, XT, 512, 1, true>(ctx, n, x, f, out, st);                    \
+        return launch_flow<HH, WW, XT, 512, 1, false>(ctx, n, x, f, out, st);                           \
     }
     ASMC_FLOW_CASE(16, 32)
     ASMC_FLOW_CASE(16, 64)

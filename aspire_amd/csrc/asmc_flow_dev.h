@@ -151,3 +151,141 @@ __device__ __forceinline__ void coupling_layer(const float (&cond)[TPW][H / 2], 
         }
 }
 
+
+
+// ---- split-fp16 form of the same layers (v_mfma_f32_32x32x16_f16) ----------------------------------------------------
+// An fp32 value x is carried as the fp16 pair (hi, lo) = (rn16(x), rn16(x - hi)): x = hi + lo up to 2^-24 |x| (2^-25
+// absolute below 2^-2; gfx950's matrix core honours fp16 subnormals on input - tools/ubench/mfma_f16_denorm.hip - so the
+// residual keeps its bits there).  A layer's product is accumulated in fp32 as  Wh xh + Wh xl + Wl xh  (the dropped
+// Wl xl is below 2^-24 of the term): three fp16 MFMAs of K = 16 do the work of eight fp32 MFMAs of K = 2 in 3/16 of the
+// matrix-pipe time, at the accuracy of fp32 operands.  Range: |x| < 65504 for activations and weights (beyond that the
+// pair is inf/NaN and the proposal is rejected like any other NaN density).
+// The operand images are a regrouping of the fp32 pack: K16 step S of an output block takes the k-steps 8S .. 8S+7 of
+// the fp32 layout, i.e. the float4 slots 2G' and 2G'+1 (G' = block * steps + S) of the (group, lane) order become the
+// lane's eight hi halves and eight lo halves in those same two 16-byte slots (flow_stage_hs converts while staging the
+// weights into LDS).  The B operand of step S is registers 8 (S % 2) .. + 7 of accumulator block S / 2 of the previous
+// layer, converted lane-locally.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+template <bool RELU>
+__device__ __forceinline__ void split8_f16(const float (&x)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float v = RELU ? fmaxf(x[j], 0.0f) : x[j];
+        const _Float16 h = (_Float16)v;
+        hi[j] = h;
+        lo[j] = (_Float16)(v - (float)h);
+    }
+}
+
+// out[NBO] += Wt * act(in), `in` = NBI accumulator blocks of the previous layer (pre-activation), A = the matrix's image
+template <int NBO, int NBI, bool RELU>
+__device__ __forceinline__ void dense_from_acc_hs(floatx16 (&out)[NBO], const floatx16 (&in)[NBI], const float* __restrict__ A,
+                                                  int lane) {
+    constexpr int ST = NBI * 2;  // K16 steps
+    const half8* Ap = reinterpret_cast<const half8*>(A) + lane;
+#pragma unroll
+    for (int S = 0; S < ST; S++) {
+        float xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) xv[j] = in[S / 2][8 * (S % 2) + j];
+        half8 bh, bl;
+        split8_f16<RELU>(xv, bh, bl);
+        half8 ah[NBO], al[NBO];
+#pragma unroll
+        for (int nbo = 0; nbo < NBO; nbo++) {
+            ah[nbo] = Ap[(size_t)(2 * (nbo * ST + S)) * 64];
+            al[nbo] = Ap[(size_t)(2 * (nbo * ST + S) + 1) * 64];
+        }
+#pragma unroll
+        for (int nbo = 0; nbo < NBO; nbo++) out[nbo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[nbo], bh, out[nbo], 0, 0, 0);
+#pragma unroll
+        for (int nbo = 0; nbo < NBO; nbo++) out[nbo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[nbo], bl, out[nbo], 0, 0, 0);
+#pragma unroll
+        for (int nbo = 0; nbo < NBO; nbo++) out[nbo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[nbo], bh, out[nbo], 0, 0, 0);
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void acc_bias1(floatx16 (&acc)[NB], const float* __restrict__ b, int hh) {
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[nb][r] = b[(nb * 16 + r) * 2 + hh];
+}
+
+// one coupling layer of one 32-particle tile: cond / trans are the lane half's H / 2 coordinates
+template <int H, int W>
+__device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], float (&trans)[H / 2], const float* __restrict__ lp,
+                                                  int lane, int hh, float& ladj) {
+    using FD = FlowDims<H, W>;
+    const float* b1 = lp;
+    const float* b2 = b1 + FD::NB1 * 32;
+    const float* b3 = b2 + FD::NB1 * 32;
+    const float* A1 = b3 + FD::NB3 * 32;
+    const float* A2 = A1 + W * H;
+    const float* A3 = A2 + W * W;
+    floatx16 h1[FD::NB1];
+    acc_bias1<FD::NB1>(h1, b1, hh);
+    {
+        constexpr int ST = H / 16;  // K16 steps over the conditioner inputs
+        const half8* Ap = reinterpret_cast<const half8*>(A1) + lane;
+#pragma unroll
+        for (int S = 0; S < ST; S++) {
+            float xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) xv[j] = cond[8 * S + j];
+            half8 bh, bl;
+            split8_f16<false>(xv, bh, bl);
+            half8 ah[FD::NB1], al[FD::NB1];
+#pragma unroll
+            for (int nb = 0; nb < FD::NB1; nb++) {
+                ah[nb] = Ap[(size_t)(2 * (nb * ST + S)) * 64];
+                al[nb] = Ap[(size_t)(2 * (nb * ST + S) + 1) * 64];
+            }
+#pragma unroll
+            for (int nb = 0; nb < FD::NB1; nb++) h1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[nb], bh, h1[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < FD::NB1; nb++) h1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[nb], bl, h1[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < FD::NB1; nb++) h1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[nb], bh, h1[nb], 0, 0, 0);
+        }
+    }
+    floatx16 h2[FD::NB1];
+    acc_bias1<FD::NB1>(h2, b2, hh);
+    dense_from_acc_hs<FD::NB1, FD::NB1, true>(h2, h1, A2, lane);
+    floatx16 o[FD::NB3];
+    acc_bias1<FD::NB3>(o, b3, hh);
+    dense_from_acc_hs<FD::NB3, FD::NB1, true>(o, h2, A3, lane);
+#pragma unroll
+    for (int q = 0; q < H / 2; q++) {
+        const float sraw = o[q / 16][q % 16];
+        const float t = o[(H / 2 + q) / 16][(H / 2 + q) % 16];
+        const float s = 2.0f - 4.0f * __frcp_rn(__expf(sraw) + 1.0f);  // 2 tanh(sraw / 2), see coupling_layer
+        trans[q] = (trans[q] - t) * __expf(-s);
+        ladj -= s;
+    }
+}
+
+// Stage `n_layers` coupling layers from the fp32 pack in HBM into LDS as split-fp16 operand images (biases copied).
+template <int H, int W, int THREADS>
+__device__ __forceinline__ void flow_stage_hs(float* __restrict__ sp, const float* __restrict__ packed, int n_layers) {
+    using FD = FlowDims<H, W>;
+    constexpr int L4 = FD::LAYER / 4, B4 = FD::BIAS / 4;
+    const int total4 = n_layers * L4;
+    for (int i4 = threadIdx.x; i4 < total4; i4 += THREADS) {
+        const int in_layer = i4 % L4;
+        if (in_layer < B4) {
+            reinterpret_cast<float4*>(sp)[i4] = reinterpret_cast<const float4*>(packed)[i4];
+            continue;
+        }
+        const int local = in_layer - B4;
+        if ((local / 64) & 1) continue;  // the even slot group's thread converts the pair
+        const float4 f0 = reinterpret_cast<const float4*>(packed)[i4], f1 = reinterpret_cast<const float4*>(packed)[i4 + 64];
+        const float xv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        half8 hi, lo;
+        split8_f16<false>(xv, hi, lo);
+        reinterpret_cast<half8*>(sp)[i4] = hi;
+        reinterpret_cast<half8*>(sp)[i4 + 64] = lo;
+    }
+}

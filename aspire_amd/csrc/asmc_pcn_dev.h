@@ -4,6 +4,8 @@
 #pragma once
 #include "asmc_common.h"
 
+bool asmc_flow_math_split();  // asmc_flow.hip
+
 // =============================================================================================
 // Philox4x32-10 (Salmon et al. SC'11; Random123 constants) and Box-Muller
 // =============================================================================================

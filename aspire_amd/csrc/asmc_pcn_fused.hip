@@ -24,7 +24,7 @@
 // buffer of the state's layout (fire-and-forget stores), accepted lanes fetch it back (cache-hot) and store it into the state.
 // The flow's weights stay resident in LDS (115 KB at d = 32, W = 64: one block of 8 waves per CU, two waves per SIMD, so
 // one wave's vector work - noise, mat-vec, accept - runs in the shadow of its partner's MFMA chains).
-template <typename T, int W, int NOISE>
+template <typename T, int W, int NOISE, bool HS>
 __global__ __launch_bounds__(512) void k_pcn_flow_fused(
     int64_t n, double* __restrict__ ll, double* __restrict__ lp, double* __restrict__ lq, const double* __restrict__ ptab,
     PcnScalars p, const double* __restrict__ rho_ptr, uint32_t step, const float* __restrict__ packed, int n_layers,
@@ -33,7 +33,9 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
     constexpr int D = 32, H = 16, THREADS = 512;
     using FD = FlowDims<H, W>;
     extern __shared__ __align__(16) float sp[];
-    {   // flow weights -> LDS; all of a thread's loads are issued before its first LDS store
+    if (HS) {
+        flow_stage_hs<H, W, THREADS>(sp, packed, n_layers);  // split-fp16 operand images (asmc_flow_dev.h)
+    } else {  // flow weights -> LDS; all of a thread's loads are issued before its first LDS store
         const int total4 = n_layers * FD::LAYER / 4;
         for (int base = 0; base < total4; base += THREADS * 8) {
             float4 tmp[8];
@@ -110,7 +112,12 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
 #ifdef FUSED_STAMP
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 #endif
-    for (;;) {
+#ifdef FUSED_HALF
+    const bool idle_wave = wave >= 4;  // diagnostic: one wave per SIMD, so the stamps show a wave's own time per phase
+#else
+    const bool idle_wave = false;
+#endif
+    for (; !idle_wave;) {
         unsigned t_l = 0;
         if (lane == 0) t_l = atomicAdd(tile_counter, 1u);
         const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)t_l);
@@ -233,7 +240,12 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
 #ifndef FUSED_NOFLOW
             for (int c = 0; c < n_layers; c++) {
                 const float* lpk = sp + (size_t)c * FD::LAYER;
-                if ((c & 1) == 0)
+                if (HS) {
+                    if ((c & 1) == 0)
+                        coupling_layer_hs<H, W>(xa[0], xb[0], lpk, lane, hh, ladj[0]);
+                    else
+                        coupling_layer_hs<H, W>(xb[0], xa[0], lpk, lane, hh, ladj[0]);
+                } else if ((c & 1) == 0)
                     coupling_layer<H, W, 1>(xa, xb, lpk, lane, hh, ladj);
                 else
                     coupling_layer<H, W, 1>(xb, xa, lpk, lane, hh, ladj);
@@ -327,9 +339,12 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
     const int64_t n_tiles = (n + 63) / 64;
     const int grid = (int)(n_tiles < (int64_t)ctx->num_cu * 8 ? (n_tiles + 7) / 8 : ctx->num_cu);  // one 8-wave block per CU
     *grid_out = grid;
-#define ASMC_FUSED_CASE(WW, NZ)                                                                                          \
-    if (f->hidden == WW && pd.noise == NZ) {                                                                             \
-        auto kern = k_pcn_flow_fused<T, WW, NZ>;                                                                         \
+    // flow arithmetic: split-fp16 MFMA (fp32-equivalent operands, asmc_flow_dev.h) unless ASMC_FLOW_MATH=f32 asks for the
+    // fp32 MFMA chain
+    const bool hs = asmc_flow_math_split();
+#define ASMC_FUSED_CASE(WW, NZ, HSV)                                                                                     \
+    if (f->hidden == WW && pd.noise == NZ && hs == HSV) {                                                                \
+        auto kern = k_pcn_flow_fused<T, WW, NZ, HSV>;                                                                         \
         const size_t lds = (size_t)f->n_layers * FlowDims<16, WW>::LAYER * sizeof(float) + (32 * 32 + 7 * 32 + 2) * sizeof(double); \
         static size_t attr_lds = 0;                                                                                      \
         if (lds > 64 * 1024 && lds > attr_lds) {                                                                         \
@@ -342,12 +357,18 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
         ASMC_LAUNCH_CHECK();                                                                                             \
         return ASMC_OK;                                                                                                  \
     }
-    ASMC_FUSED_CASE(64, ASMC_NOISE_F64)
-    ASMC_FUSED_CASE(64, ASMC_NOISE_F32)
-    ASMC_FUSED_CASE(32, ASMC_NOISE_F64)
-    ASMC_FUSED_CASE(32, ASMC_NOISE_F32)
-    ASMC_FUSED_CASE(128, ASMC_NOISE_F64)
-    ASMC_FUSED_CASE(128, ASMC_NOISE_F32)
+    ASMC_FUSED_CASE(64, ASMC_NOISE_F64, true)
+    ASMC_FUSED_CASE(64, ASMC_NOISE_F64, false)
+    ASMC_FUSED_CASE(64, ASMC_NOISE_F32, true)
+    ASMC_FUSED_CASE(64, ASMC_NOISE_F32, false)
+    ASMC_FUSED_CASE(32, ASMC_NOISE_F64, true)
+    ASMC_FUSED_CASE(32, ASMC_NOISE_F64, false)
+    ASMC_FUSED_CASE(32, ASMC_NOISE_F32, true)
+    ASMC_FUSED_CASE(32, ASMC_NOISE_F32, false)
+    ASMC_FUSED_CASE(128, ASMC_NOISE_F64, true)
+    ASMC_FUSED_CASE(128, ASMC_NOISE_F64, false)
+    ASMC_FUSED_CASE(128, ASMC_NOISE_F32, true)
+    ASMC_FUSED_CASE(128, ASMC_NOISE_F32, false)
 #undef ASMC_FUSED_CASE
     asmc_set_error("fused flow step: unsupported hidden width %d", (int)f->hidden);
     return ASMC_ERR_UNSUPPORTED;

@@ -35,6 +35,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3  # dense fp32-input MFMA peak (MI355X_MICROARCH.md, matrix cores)
+MFMA_F16_PEAK_TF = 2516.6  # dense fp16 MFMA peak (same table)
 
 
 def cpu_model() -> str:
@@ -118,6 +119,8 @@ def main():
             comm.barrier()
         torch.cuda.synchronize()
 
+    flow_math = "f32-mfma" if os.environ.get("ASMC_FLOW_MATH") == "f32" else "f16x2-split"
+
     def run(seed: int, n=n_global, flow=cflow, step_fn=args.step_fn, noise=args.noise, steps=n_mc):
         sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=eng, comm=comm,
                     rng=np.random.default_rng(seed), dtype=xname)
@@ -187,6 +190,15 @@ def main():
     hbm_floor = b_step / (HBM_PEAK_GBS * 1e9) * 1e3
     roofline = {
         "bound": "mfma", "kernel": flow_k, "dtype": "f32",
+        # how the fp32 layers are executed: split-fp16 = each fp32 operand as an fp16 (hi, lo) pair, three
+        # v_mfma_f32_32x32x16_f16 products per K = 16 with fp32 accumulation (operand accuracy 2^-24, csrc/asmc_flow_dev.h);
+        # `achieved` / `frac` price the ALGORITHMIC fp32 flops against the fp32-input MFMA peak, `executed_*` the fp16
+        # products actually issued against the dense fp16 peak
+        "flow_math": flow_math,
+        "executed_flops_per_launch": 3 * flow_flops if flow_math == "f16x2-split" else flow_flops,
+        "executed_frac_of_its_mfma_peak": (round(3 * flow_flops / (flow_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4)
+                                           if flow_math == "f16x2-split" else
+                                           round(flow_flops / (flow_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)) if flow_ms else None,
         "achieved": round(flow_flops / (flow_ms * 1e-3) / 1e12, 2) if flow_ms else None, "peak": MFMA_F32_PEAK_TF,
         "unit": "TFLOP/s", "frac": round(flow_flops / (flow_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4) if flow_ms else None,
         "traffic": traffic, "avg_ms": round(flow_ms, 5) if flow_ms else None, "flops_per_launch": flow_flops,
@@ -215,7 +227,7 @@ def main():
                    "step_meaning": "one bench step = one full sample() run; value counts its mutation steps "
                                    "(N x temperatures x mcmc steps / wall)",
                    "particles_per_gpu": n_local, "global_particles": n_global, "dims": d, "x_dtype": args.x_dtype,
-                   "flow_dtype": "f32", "mcmc_steps_per_temperature": n_mc, "step_fn": args.step_fn, "noise": args.noise,
+                   "flow_dtype": "f32", "flow_math": flow_math, "mcmc_steps_per_temperature": n_mc, "step_fn": args.step_fn, "noise": args.noise,
                    "resample_mode": args.resample_mode, "resample_method": "multinomial", "beta_tolerance": 1e-6,
                    "target_efficiency": 0.5,
                    "parallelism": f"particle-shard x{world}" + (f" ({args.shard_layout} layout)" if sharded else "")},
@@ -346,6 +358,23 @@ def main():
             extra["flow_run_f32_noise"] = {"wall_s": round(tf_, 4), "temperatures": len(spf.history.beta),
                                            "particle_steps_per_s": n_global * len(spf.history.beta) * n_mc / tf_,
                                            "abs_err_in_sigma": abs(float(postf.log_evidence) - true_logz) / max(float(postf.log_evidence_error), 1e-300)}
+        # (e) the headline run with the flow on the fp32 MFMA chain (v_mfma_f32_32x32x2_f32) instead of the default split-fp16
+        #     products: same operands to fp32 accuracy, 16/3 of the matrix-pipe time
+        if flow_math == "f16x2-split":
+            os.environ["ASMC_FLOW_MATH"] = "f32"
+            try:
+                run(3, n=min(n_global, 65536 * world), steps=2)
+                sync_all()
+                t0 = time.perf_counter()
+                spm, postm = run(4)
+                sync_all()
+                tm_ = time.perf_counter() - t0
+                extra["flow_run_f32_mfma"] = {"wall_s": round(tm_, 4), "temperatures": len(spm.history.beta),
+                                              "particle_steps_per_s": n_global * len(spm.history.beta) * n_mc / tm_,
+                                              "log_evidence": float(postm.log_evidence),
+                                              "abs_err_in_sigma": abs(float(postm.log_evidence) - true_logz) / max(float(postm.log_evidence_error), 1e-300)}
+            finally:
+                os.environ.pop("ASMC_FLOW_MATH", None)
         result["extra"] = extra
 
     # ---- CPU baseline: the oracle's restatement of the SAME mutation step (kind "port") on the host's cores -------
