@@ -203,6 +203,10 @@ __device__ __forceinline__ void dense_from_acc_hs(floatx16 (&out)[NBO], const fl
         for (int nbo = 0; nbo < NBO; nbo++) out[nbo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[nbo], bl, out[nbo], 0, 0, 0);
 #pragma unroll
         for (int nbo = 0; nbo < NBO; nbo++) out[nbo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[nbo], bh, out[nbo], 0, 0, 0);
+#ifdef FLOW_HS4
+#pragma unroll
+        for (int nbo = 0; nbo < NBO; nbo++) out[nbo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[nbo], bl, out[nbo], 0, 0, 0);
+#endif
     }
 }
 
@@ -249,6 +253,10 @@ __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], fl
             for (int nb = 0; nb < FD::NB1; nb++) h1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[nb], bl, h1[nb], 0, 0, 0);
 #pragma unroll
             for (int nb = 0; nb < FD::NB1; nb++) h1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[nb], bh, h1[nb], 0, 0, 0);
+#ifdef FLOW_HS4
+#pragma unroll
+            for (int nb = 0; nb < FD::NB1; nb++) h1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[nb], bl, h1[nb], 0, 0, 0);
+#endif
         }
     }
     floatx16 h2[FD::NB1];

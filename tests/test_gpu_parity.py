@@ -1612,3 +1612,41 @@ def test_pcn_flow_fused_step_vs_oracle(eng, oracle):
     assert np.all(np.abs(np.array(n_acc) - np.array(acc_ref)) <= 12) and 0.05 < np.mean(n_acc) / n < 0.95
     np.testing.assert_allclose(lld.cpu().numpy()[close], llr[close], rtol=1e-10, atol=1e-9)
     np.testing.assert_allclose(lqd.cpu().numpy()[close], lqr[close], rtol=1e-5, atol=3e-4)
+
+
+# ---- split-fp16 MFMA flow arithmetic: accuracy of the operands, not of a reduced-precision flow --------------------
+@pytest.mark.parametrize("hidden,scale_x", [(64, 1.0), (32, 3.0), (128, 0.2)])
+def test_split_fp16_flow_is_as_accurate_as_the_fp32_mfma_chain(eng, hidden, scale_x, monkeypatch):
+    """The flow's fp32 layers run as three fp16 MFMA products per K = 16 on (hi, lo) operand pairs.  Against the same
+    flow evaluated in fp64 (torch, CPU) its error must be that of fp32 arithmetic: the fp32 MFMA chain's own rms error on
+    in-distribution rows, within 4x of its worst case on far-out rows, and inside the north-star's 1e-6 relative bar on
+    log q wherever the fp32 chain is (tools/flow_accuracy.py prints the table, torch's fp32 evaluation included)."""
+    from conftest import random_coupling_flow
+
+    d, n = 32, 1 << 16
+    n_layers = 4 if hidden < 128 else 1
+    flow = random_coupling_flow(d, n_layers, hidden, seed=11)
+    f64 = random_coupling_flow(d, n_layers, hidden, seed=11, dtype=torch.float64)
+    f64.layers.load_state_dict(flow.layers.state_dict())  # the fp32 parameters, widened
+    f64.loc, f64.scale = flow.loc.double(), flow.scale.double()
+    g = np.random.default_rng(2)
+    x = scale_x * g.normal(size=(n, d))
+    x[:64] *= 4.0  # a few far-out rows: large activations
+    with torch.no_grad():
+        ref = f64.log_prob(torch.as_tensor(x)).numpy()
+    dev = flow.device_coupling(eng)
+    xd = eng.asarray(x)
+    monkeypatch.setenv("ASMC_FLOW_MATH", "f32")
+    lq32 = eng.coupling_logprob(xd, dev).cpu().numpy()
+    monkeypatch.delenv("ASMC_FLOW_MATH")
+    lqhs = eng.coupling_logprob(xd, dev).cpu().numpy()
+    assert not np.array_equal(lq32, lqhs)  # two different instruction streams
+    e32, ehs = np.abs(lq32 - ref), np.abs(lqhs - ref)
+    assert np.all(np.isfinite(lqhs))
+    rms = lambda e: float(np.sqrt(np.mean(e**2)))  # noqa: E731
+    # in-distribution rows: the same error as the fp32 chain (both are dominated by fp32 accumulation rounding)
+    assert rms(ehs[64:]) <= 1.25 * rms(e32[64:]) + 1e-7, (rms(ehs[64:]), rms(e32[64:]))
+    # rows four times outside: the (hi, lo) pairs carry 2^-24 relative operand error where fp32 operands carry none
+    assert ehs.max() <= 4.0 * e32.max() + 4e-6, (ehs.max(), e32.max())
+    rel32, relhs = np.max(e32 / np.maximum(np.abs(ref), 1.0)), np.max(ehs / np.maximum(np.abs(ref), 1.0))
+    assert relhs < max(1e-6, 2.0 * rel32), (relhs, rel32)
