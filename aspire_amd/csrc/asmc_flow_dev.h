@@ -142,10 +142,10 @@ __device__ __forceinline__ void coupling_layer(const float (&cond)[TPW][H / 2], 
         for (int q = 0; q < H / 2; q++) {
             const float sraw = o[tt][q / 16][q % 16];
             const float t = o[tt][(H / 2 + q) / 16][(H / 2 + q) % 16];
-            // s = 2 tanh(sraw / 2) = 2 - 4 / (exp(sraw) + 1) on the hardware exp2 / rcp units: absolute error
+            // s = 2 tanh(sraw / 2) = 2 - 4 / (exp(sraw) + 1) on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32): absolute error
             // ~1e-7, which is all that matters (s is added to the log-determinant and exponentiated); libm's
             // tanhf + expf would cost as many issue cycles per layer as a third of its MFMAs
-            const float s = 2.0f - 4.0f * __frcp_rn(__expf(sraw) + 1.0f);
+            const float s = 2.0f - 4.0f * __builtin_amdgcn_rcpf(__expf(sraw) + 1.0f);
             trans[tt][q] = (trans[tt][q] - t) * __expf(-s);
             ladj[tt] -= s;
         }
@@ -171,7 +171,9 @@ template <bool RELU>
 __device__ __forceinline__ void split8_f16(const float (&x)[8], half8& hi, half8& lo) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const float v = RELU ? fmaxf(x[j], 0.0f) : x[j];
+        // ReLU on the bit pattern: one v_max_i32 (negative floats are negative integers; fmaxf would canonicalise the
+        // MFMA result first, two instructions)
+        const float v = RELU ? __int_as_float(max(__float_as_int(x[j]), 0)) : x[j];
         const _Float16 h = (_Float16)v;
         hi[j] = h;
         lo[j] = (_Float16)(v - (float)h);
@@ -269,7 +271,7 @@ __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], fl
     for (int q = 0; q < H / 2; q++) {
         const float sraw = o[q / 16][q % 16];
         const float t = o[(H / 2 + q) / 16][(H / 2 + q) % 16];
-        const float s = 2.0f - 4.0f * __frcp_rn(__expf(sraw) + 1.0f);  // 2 tanh(sraw / 2), see coupling_layer
+        const float s = 2.0f - 4.0f * __builtin_amdgcn_rcpf(__expf(sraw) + 1.0f);  // 2 tanh(sraw / 2), see coupling_layer
         trans[q] = (trans[q] - t) * __expf(-s);
         ladj -= s;
     }

@@ -1,12 +1,13 @@
-// Do fp32-input MFMAs (v_mfma_f32_32x32x2_f32) and vector-ALU work of ANOTHER wave on the same SIMD overlap?
+// Do MFMAs (fp32-input v_mfma_f32_32x32x2_f32; fp16 v_mfma_f32_32x32x16_f16) and vector-ALU work of ANOTHER wave on the same SIMD overlap?
 // 512-thread blocks, one per CU: waves 0-3 (one per SIMD) issue MFMAs, waves 4-7 (their SIMD partners) issue VALU FMAs.
 // Prints the time of {MFMA only, VALU only, both}: "both" ~ max means separate pipes, ~ sum means a shared datapath.
 // build: hipcc -O3 --offload-arch=gfx950 tools/ubench/mfma_valu_overlap.hip -o tools/ubench/mfma_valu_overlap
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-template <int VKIND>  // 0: v_fma_f64, 1: v_fma_f32, 2: integer mul/xor (Philox-like), 3: bf16 MFMA in the partner instead
+template <int VKIND, int MKIND>  // VKIND 0: v_fma_f64, 1: v_fma_f32, 2: integer mul/xor (Philox-like); MKIND 0: fp32-input MFMA, 1: fp16 MFMA
 __global__ __launch_bounds__(512) void k(int mode, int iters, float* out) {
     const int wave = threadIdx.x >> 6;
     const bool mfma_wave = wave < 4;
@@ -14,11 +15,22 @@ __global__ __launch_bounds__(512) void k(int mode, int iters, float* out) {
         if (!(mode & 1)) return;
         floatx16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
         float x = threadIdx.x * 1e-3f, y = 1.0f + threadIdx.x * 1e-4f;
-        for (int i = 0; i < iters; i++) {
-            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
-            a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+        if (MKIND == 0) {
+            for (int i = 0; i < iters; i++) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+                a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+            }
+        } else {
+            half8 hx, hy;
+            for (int j = 0; j < 8; j++) hx[j] = (_Float16)(x + j), hy[j] = (_Float16)(y - j);
+            for (int i = 0; i < 2 * iters; i++) {  // 32 cycles each: the same matrix-pipe time as the fp32 form's loop
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hx, hy, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hy, hx, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hx, hx, a2, 0, 0, 0);
+                a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hy, hy, a3, 0, 0, 0);
+            }
         }
         out[blockIdx.x * 512 + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
     } else {
@@ -45,7 +57,7 @@ __global__ __launch_bounds__(512) void k(int mode, int iters, float* out) {
     }
 }
 
-template <int VKIND>
+template <int VKIND, int MKIND>
 void run(const char* name) {
     float* out;
     hipMalloc(&out, 256 * 512 * sizeof(float));
@@ -54,10 +66,10 @@ void run(const char* name) {
     const int iters = 20000;
     float ms[4] = {0, 0, 0, 0};
     for (int mode = 1; mode <= 3; mode++) {
-        hipLaunchKernelGGL(k<VKIND>, dim3(256), dim3(512), 0, 0, mode, 100, out);
+        hipLaunchKernelGGL((k<VKIND, MKIND>), dim3(256), dim3(512), 0, 0, mode, 100, out);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k<VKIND>, dim3(256), dim3(512), 0, 0, mode, iters, out);
+        hipLaunchKernelGGL((k<VKIND, MKIND>), dim3(256), dim3(512), 0, 0, mode, iters, out);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms[mode], e0, e1);
@@ -68,8 +80,13 @@ void run(const char* name) {
 }
 
 int main() {
-    run<0>("fma_f64");
-    run<1>("fma_f32");
-    run<2>("int mul");
+    printf("fp32-input MFMA (v_mfma_f32_32x32x2_f32) in waves 0-3:\n");
+    run<0, 0>("fma_f64");
+    run<1, 0>("fma_f32");
+    run<2, 0>("int mul");
+    printf("fp16 MFMA (v_mfma_f32_32x32x16_f16) in waves 0-3:\n");
+    run<0, 1>("fma_f64");
+    run<1, 1>("fma_f32");
+    run<2, 1>("int mul");
     return 0;
 }
