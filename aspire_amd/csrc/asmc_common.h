@@ -71,6 +71,7 @@ struct asmc_ctx {
     unsigned int* d_guide;         // [n_max / 4 + 8] guide table of the resampling search
     unsigned char* d_flags;        // [n_max + 64] accept flags of the split-path pCN step
     double* d_gamma;               // [n_max] tpCN scale variates of the current step
+    double* d_rec;                 // [4 * n_max] (ll, lp, lq, 0) records of asmc_gather's source population
     void* d_ysoa;                  // coordinate-major whitened state of a mutation (grown on demand)
     double* d_student;             // [d_max (d_max + 1) + (ASMC_STUDENT_MAX_ROWS / 64) (d_max + 2)] tpCN fit: tables, partials
     double* h_student;             // pinned staging of the same size

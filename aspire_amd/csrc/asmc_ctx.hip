@@ -129,6 +129,7 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     dmalloc((void**)&c->d_guide, sizeof(unsigned int) * ((size_t)n_max / 4 + 8));
     dmalloc((void**)&c->d_flags, (size_t)n_max + 64);
     dmalloc((void**)&c->d_gamma, sizeof(double) * (size_t)n_max);
+    dmalloc((void**)&c->d_rec, sizeof(double) * 4 * (size_t)n_max);
     const size_t student = (size_t)d_max * (d_max + 1) + (size_t)(ASMC_STUDENT_MAX_ROWS / 64) * (d_max + 2);
     dmalloc((void**)&c->d_student, sizeof(double) * student);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_student, sizeof(double) * student, hipHostMallocDefault);
@@ -169,6 +170,7 @@ int asmc_ctx_destroy(asmc_ctx* c) {
     (void)hipFree(c->d_counts);
     (void)hipFree(c->d_rho);
     (void)hipFree(c->d_tilectr);
+    (void)hipFree(c->d_rec);
     (void)hipFree(c->d_bar);
     (void)hipFree(c->d_pcgtab);
     (void)hipFree(c->d_select);

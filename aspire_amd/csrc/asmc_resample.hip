@@ -1256,15 +1256,51 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_search_pcg(const unsigned long l
 // every random row is fetched as full 64-B+ bursts and the output is written fully coalesced.
 // power-of-two rows (cpr = 2^SH 16-byte chunks): shifts instead of 64-bit divisions, four chunks in flight per lane,
 // non-temporal stores (the output is not re-read by this kernel and should not displace the cdf / input rows in L2)
+// The three log-probabilities of the gathered rows: one output per lane, coalesced stores.  A random 8-byte read costs
+// a whole sector request, and at 1M x 32 fp64 the three of them per draw cost 40 % of the gather; with `rec` (the
+// source's (ll, lp, lq, 0) records, k_pack_records) a draw reads one 32-byte sector instead.
+struct alignas(32) LogRec {
+    double ll, lp, lq, pad;
+};
+__global__ __launch_bounds__(ASMC_BLOCK) void k_pack_records(int64_t n, const double* __restrict__ ll, const double* __restrict__ lp,
+                                                            const double* __restrict__ lq, LogRec* __restrict__ rec) {
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) rec[i] = LogRec{ll[i], lp[i], lq[i], 0.0};
+}
+__device__ __forceinline__ void gather_scalars(int64_t n_out, const int64_t* __restrict__ idx, const LogRec* __restrict__ rec,
+                                               const double* __restrict__ ll_in, const double* __restrict__ lp_in,
+                                               const double* __restrict__ lq_in, double* __restrict__ ll_out,
+                                               double* __restrict__ lp_out, double* __restrict__ lq_out) {
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t j = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; j < n_out; j += stride) {
+        const int64_t s = idx[j];
+        double a, b, c;
+        if (rec) {
+            const LogRec r = rec[s];
+            a = r.ll, b = r.lp, c = r.lq;
+        } else {
+            a = ll_in[s], b = lp_in[s], c = lq_in[s];
+        }
+        __builtin_nontemporal_store(a, &ll_out[j]);
+        __builtin_nontemporal_store(b, &lp_out[j]);
+        __builtin_nontemporal_store(c, &lq_out[j]);
+    }
+}
+
 template <int SH>
 __global__ __launch_bounds__(ASMC_BLOCK) void k_gather16_pow2(int64_t n_out, const int64_t* __restrict__ idx,
+                                                             const LogRec* __restrict__ rec,
                                                              const uint4* __restrict__ x_in, uint4* __restrict__ x_out,
                                                              const double* __restrict__ ll_in,
                                                              const double* __restrict__ lp_in,
                                                              const double* __restrict__ lq_in,
                                                              double* __restrict__ ll_out, double* __restrict__ lp_out,
                                                              double* __restrict__ lq_out) {
+#ifdef GATHER_U
+    constexpr int U = GATHER_U;
+#else
     constexpr int U = 4;
+#endif
     const int64_t total = n_out << SH;
     const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
     for (int64_t c0 = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; c0 < total; c0 += U * stride) {
@@ -1278,7 +1314,15 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_gather16_pow2(int64_t n_out, con
 #pragma unroll
         for (int q = 0; q < U; q++) {
             const int64_t c = c0 + q * stride;
-            if (c < total) v[q] = x_in[(src[q] << SH) + (c & ((1 << SH) - 1))];
+            if (c < total) {
+#ifdef GATHER_NTLOAD
+                const uint4* sp4 = &x_in[(src[q] << SH) + (c & ((1 << SH) - 1))];
+                v[q].x = __builtin_nontemporal_load(&sp4->x), v[q].y = __builtin_nontemporal_load(&sp4->y);
+                v[q].z = __builtin_nontemporal_load(&sp4->z), v[q].w = __builtin_nontemporal_load(&sp4->w);
+#else
+                v[q] = x_in[(src[q] << SH) + (c & ((1 << SH) - 1))];
+#endif
+            }
         }
 #pragma unroll
         for (int q = 0; q < U; q++) {
@@ -1288,19 +1332,15 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_gather16_pow2(int64_t n_out, con
                 __builtin_nontemporal_store(v[q].y, &x_out[c].y);
                 __builtin_nontemporal_store(v[q].z, &x_out[c].z);
                 __builtin_nontemporal_store(v[q].w, &x_out[c].w);
-                const int k = (int)(c & ((1 << SH) - 1));
-                if (k < 3) {  // lanes 0..2 of a row move its three log-probabilities: one load + one store instruction
-                    const double* sp = k == 0 ? ll_in : (k == 1 ? lp_in : lq_in);
-                    double* dp = k == 0 ? ll_out : (k == 1 ? lp_out : lq_out);
-                    dp[c >> SH] = sp[src[q]];
-                }
             }
         }
     }
+    gather_scalars(n_out, idx, rec, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
 }
 
 __global__ __launch_bounds__(ASMC_BLOCK) void k_gather16(int64_t n_out, const int64_t* __restrict__ idx,
-                                                        int cpr, const uint4* __restrict__ x_in,
+                                                        const LogRec* __restrict__ rec, int cpr,
+                                                        const uint4* __restrict__ x_in,
                                                         uint4* __restrict__ x_out,
                                                         const double* __restrict__ ll_in,
                                                         const double* __restrict__ lp_in,
@@ -1321,34 +1361,21 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_gather16(int64_t n_out, const in
         const uint4 v1 = x_in[s1 * cpr + k1];
         x_out[c] = v0;
         x_out[c1] = v1;
-        if (k0 == 0) {
-            ll_out[r0] = ll_in[s0];
-            lp_out[r0] = lp_in[s0];
-            lq_out[r0] = lq_in[s0];
-        }
-        if (k1 == 0) {
-            ll_out[r1] = ll_in[s1];
-            lp_out[r1] = lp_in[s1];
-            lq_out[r1] = lq_in[s1];
-        }
     }
     for (; c < total; c += stride) {
         const int64_t r0 = c / cpr;
         const int k0 = (int)(c - r0 * cpr);
         const int64_t s0 = idx[r0];
         x_out[c] = x_in[s0 * cpr + k0];
-        if (k0 == 0) {
-            ll_out[r0] = ll_in[s0];
-            lp_out[r0] = lp_in[s0];
-            lq_out[r0] = lq_in[s0];
-        }
     }
+    gather_scalars(n_out, idx, rec, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
 }
 
 // generic element-wise fallback (row bytes not a multiple of 16)
 template <typename T>
 __global__ __launch_bounds__(ASMC_BLOCK) void k_gather_elem(int64_t n_out, const int64_t* __restrict__ idx,
-                                                           int d, const T* __restrict__ x_in,
+                                                           const LogRec* __restrict__ rec, int d,
+                                                           const T* __restrict__ x_in,
                                                            T* __restrict__ x_out,
                                                            const double* __restrict__ ll_in,
                                                            const double* __restrict__ lp_in,
@@ -1363,12 +1390,8 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_gather_elem(int64_t n_out, const
         const int k = (int)(c - r * d);
         const int64_t s = idx[r];
         x_out[c] = x_in[s * d + k];
-        if (k == 0) {
-            ll_out[r] = ll_in[s];
-            lp_out[r] = lp_in[s];
-            lq_out[r] = lq_in[s];
-        }
     }
+    gather_scalars(n_out, idx, rec, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
 }
 
 // =============================================================================================
@@ -1823,14 +1846,22 @@ int asmc_importance_step(asmc_ctx* ctx, int64_t n, const double* ll, const doubl
     return ASMC_OK;
 }
 
-int asmc_gather(asmc_ctx* ctx, int64_t n_out, const int64_t* idx, int d, int x_dtype, const void* x_in,
+int asmc_gather(asmc_ctx* ctx, int64_t n_in, int64_t n_out, const int64_t* idx, int d, int x_dtype, const void* x_in,
                 void* x_out, const double* ll_in, const double* lp_in, const double* lq_in,
                 double* ll_out, double* lp_out, double* lq_out, asmc_stream stream) {
     ASMC_REQUIRE(ctx && idx && x_in && x_out && ll_in && lp_in && lq_in && ll_out && lp_out && lq_out,
                  "null pointer");
-    ASMC_REQUIRE(n_out > 0 && d > 0, "bad sizes");
+    ASMC_REQUIRE(n_in > 0 && n_out > 0 && d > 0, "bad sizes");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
     hipStream_t st = as_stream(stream);
+    const LogRec* rec = nullptr;
+    if (n_in <= ctx->n_max && n_out >= n_in / 4 && n_in >= (1 << 16)) {  // enough draws to pay for the packing pass
+        LogRec* r = reinterpret_cast<LogRec*>(ctx->d_rec);
+        ASMC_LAUNCH(ctx, st, "k_pack_records", k_pack_records, dim3(grid_for(n_in, ASMC_BLOCK * 2, ASMC_MAX_BLOCKS * 2)), dim3(ASMC_BLOCK), 0, st,
+                    n_in, ll_in, lp_in, lq_in, r);
+        ASMC_LAUNCH_CHECK();
+        rec = r;
+    }
     const size_t elem = x_dtype == ASMC_F64 ? 8 : 4;
     const size_t rowbytes = elem * (size_t)d;
     const bool vec_ok = (rowbytes % 16 == 0) && (((uintptr_t)x_in | (uintptr_t)x_out) % 16 == 0);
@@ -1841,23 +1872,23 @@ int asmc_gather(asmc_ctx* ctx, int64_t n_out, const int64_t* idx, int d, int x_d
 #define ASMC_GATHER_POW2(SHV)                                                                                       \
     if (!plain_gather && cpr == (1 << SHV)) {                                                                      \
         ASMC_LAUNCH(ctx, st, "k_gather16", k_gather16_pow2<SHV>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx,   \
-                    (const uint4*)x_in, (uint4*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);               \
+                    rec, (const uint4*)x_in, (uint4*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);               \
     } else
         ASMC_GATHER_POW2(4)
         ASMC_GATHER_POW2(3)
         ASMC_GATHER_POW2(5)
         {
-    ASMC_LAUNCH(ctx, st, "k_gather16", k_gather16, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, cpr,
+    ASMC_LAUNCH(ctx, st, "k_gather16", k_gather16, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, rec, cpr,
                            (const uint4*)x_in, (uint4*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
         }
 #undef ASMC_GATHER_POW2
     } else if (x_dtype == ASMC_F64) {
         const int grid = grid_for(n_out * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
-        ASMC_LAUNCH(ctx, st, "k_gather_elem<double>", k_gather_elem<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, d,
+        ASMC_LAUNCH(ctx, st, "k_gather_elem<double>", k_gather_elem<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, rec, d,
                            (const double*)x_in, (double*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
     } else {
         const int grid = grid_for(n_out * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
-        ASMC_LAUNCH(ctx, st, "k_gather_elem<float>", k_gather_elem<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, d,
+        ASMC_LAUNCH(ctx, st, "k_gather_elem<float>", k_gather_elem<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, rec, d,
                            (const float*)x_in, (float*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
     }
     ASMC_LAUNCH_CHECK();

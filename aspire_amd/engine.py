@@ -458,7 +458,7 @@ class HipEngine:
         n_out, d = idx.numel(), x.shape[1]
         xo = torch.empty((n_out, d), dtype=x.dtype, device=self.device)
         llo, lpo, lqo = (torch.empty(n_out, dtype=torch.float64, device=self.device) for _ in range(3))
-        check(self.lib.asmc_gather(self._ctx, n_out, _dptr(idx), d, self._xdt(x), _dptr(x), _dptr(xo), _dptr(ll),
+        check(self.lib.asmc_gather(self._ctx, x.shape[0], n_out, _dptr(idx), d, self._xdt(x), _dptr(x), _dptr(xo), _dptr(ll),
                                    _dptr(lp), _dptr(lq), _dptr(llo), _dptr(lpo), _dptr(lqo), self._stream), "asmc_gather")
         return xo, llo, lpo, lqo
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 10
+#define ASMC_ABI_VERSION 11
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -289,7 +289,11 @@ int asmc_systematic_uniforms(asmc_ctx* ctx, int64_t n_out, int64_t j0, int64_t n
                              double* u_dev, asmc_stream stream);
 int asmc_search(asmc_ctx* ctx, int64_t n, const double* cdf_dev, int64_t n_out, const double* u_dev,
                 int64_t* idx_dev, asmc_stream stream);
-int asmc_gather(asmc_ctx* ctx, int64_t n_out, const int64_t* idx_dev, int d, int x_dtype,
+/* x_out[j] = x_in[idx[j]] and the same for the three log-probability vectors (samples.py:1278-1287, `self[idx]`).
+ * n_in = rows of the source population (idx values are < n_in): when the population fits the ctx and most of it is
+ * drawn, (ll, lp, lq) are first packed into one 32-byte record per particle, so that a draw costs ONE random sector
+ * read for its three scalars instead of three. */
+int asmc_gather(asmc_ctx* ctx, int64_t n_in, int64_t n_out, const int64_t* idx_dev, int d, int x_dtype,
                 const void* x_in_dev, void* x_out_dev, const double* ll_in_dev,
                 const double* lp_in_dev, const double* lq_in_dev, double* ll_out_dev,
                 double* lp_out_dev, double* lq_out_dev, asmc_stream stream);
