@@ -78,7 +78,7 @@ struct asmc_ctx {
     size_t ysoa_bytes;
     long long* d_counts;           // [ASMC_MAX_PCN_STEPS + max(ASMC_MAX_BLOCKS, n_max/64+1)] accept counts / partials
     double* d_rho;                 // [ASMC_MAX_PCN_STEPS + 8] step-size history on device
-    unsigned int* d_tilectr;       // [ASMC_MAX_PCN_STEPS] tile hand-out counters of the fused flow-proposal step (one per step)
+    unsigned int* d_tilectr;       // [2 * ASMC_MAX_PCN_STEPS] fused flow-proposal step: tile hand-out counters, then blocks-done counters (one each per step)
     unsigned int* d_bar;           // [1024 * 17] arrival counters of the persistent importance-weight kernel's grid barriers (4 KB apart; they only grow)
     unsigned int bar_base[17];     // their values when the next launch starts (top, 16 groups)
     unsigned long long* d_pcgtab;  // [64*4 + 8] PCG64 jump table

@@ -2232,18 +2232,22 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
         if (rc) return rc;
         // one kernel per step (propose -> flow on the MFMA -> targets -> accept) where the shape allows it
         const bool fused = soa && asmc_pcn_flow_fused_ok(prm, flow);
-        if (fused) ASMC_HIP(hipMemsetAsync(ctx->d_tilectr, 0, sizeof(unsigned int) * (size_t)n_steps, st));
+        // counters of the fused steps: [t] tile hand-out, [ASMC_MAX_PCN_STEPS + t] blocks done
+        if (fused) ASMC_HIP(hipMemsetAsync(ctx->d_tilectr, 0, sizeof(unsigned int) * 2 * ASMC_MAX_PCN_STEPS, st));
         for (int t = 0; t < (fused ? n_steps : 0); t++) {
             const uint32_t step = step0 + (uint32_t)t;
             rc = pcn_prepare_gamma(ctx, n, pd, step, st);
             if (rc) return rc;
-            if (prm->x_dtype == ASMC_F64)
-                rc = asmc_pcn_flow_fused_launch(ctx, n, ASMC_F64, ll, lp, lq, pd, flow, d_rho, step, ctx->d_tilectr + t, d_block, &grid, st);
-            else
-                rc = asmc_pcn_flow_fused_launch(ctx, n, ASMC_F32, ll, lp, lq, pd, flow, d_rho, step, ctx->d_tilectr + t, d_block, &grid, st);
+            // single rank: the step's last block adapts the step size itself; sharded: the ranks' counts are exchanged first
+            PcnAdaptArgs ad = {nullptr, d_counts, d_rho, d_rho_hist, prm->target_accept, n, t, prm->adapt};
+            if (!ctx->count_hook) ad.done = ctx->d_tilectr + ASMC_MAX_PCN_STEPS + t;
+            rc = asmc_pcn_flow_fused_launch(ctx, n, prm->x_dtype == ASMC_F64 ? ASMC_F64 : ASMC_F32, ll, lp, lq, pd, flow, d_rho, step,
+                                            ctx->d_tilectr + t, d_block, &grid, ad, st);
             if (rc) return rc;
-            rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
-            if (rc) return rc;
+            if (ctx->count_hook) {
+                rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+                if (rc) return rc;
+            }
         }
         for (int t = 0; t < (fused ? 0 : n_steps); t++) {
             const uint32_t step = step0 + (uint32_t)t;

@@ -6,6 +6,18 @@
 
 bool asmc_flow_math_split();  // asmc_flow.hip
 
+// step-size adaptation closed by the last block of a step's kernel (k_pcn_adapt's arithmetic); done == NULL: left to a
+// k_pcn_adapt launch (sharded runs exchange the accept counts between ranks first)
+struct PcnAdaptArgs {
+    unsigned int* done;     // zeroed arrival counter of this step
+    long long* counts_out;  // [t] <- accepted particles of the step
+    double* rho;            // step size: read by this step, adapted for the next
+    double* rho_hist;       // [t] <- the step size this step used
+    double target;
+    int64_t n;
+    int t, adapt;
+};
+
 // =============================================================================================
 // Philox4x32-10 (Salmon et al. SC'11; Random123 constants) and Box-Muller
 // =============================================================================================
@@ -232,7 +244,7 @@ __device__ __forceinline__ void soa_store(__amdgpu_buffer_rsrc_t r, unsigned vof
 bool asmc_pcn_flow_fused_ok(const asmc_pcn_params* prm, const asmc_coupling* f);
 int asmc_pcn_flow_fused_launch(asmc_ctx* ctx, int64_t n, int x_dtype, double* ll, double* lp, double* lq, const PcnDev& pd,
                                const asmc_coupling* f, const double* rho_ptr, uint32_t step, unsigned int* tile_counter,
-                               long long* block_counts, int* grid_out, hipStream_t st);
+                               long long* block_counts, int* grid_out, const PcnAdaptArgs& adapt, hipStream_t st);
 
 // d = 64 / 128 pCN on the fp64 matrix cores (asmc_pcn_mm.hip)
 #define MM_WHITEN 0

@@ -27,9 +27,9 @@
 template <typename T, int W, int NOISE, bool HS>
 __global__ __launch_bounds__(512) void k_pcn_flow_fused(
     int64_t n, double* __restrict__ ll, double* __restrict__ lp, double* __restrict__ lq, const double* __restrict__ ptab,
-    PcnScalars p, const double* __restrict__ rho_ptr, uint32_t step, const float* __restrict__ packed, int n_layers,
+    PcnScalars p, const double* rho_ptr, uint32_t step, const float* __restrict__ packed, int n_layers,
     const float* __restrict__ loc, const float* __restrict__ scale, float ladj0, float base_const,
-    unsigned int* __restrict__ tile_counter, long long* __restrict__ block_counts) {
+    unsigned int* __restrict__ tile_counter, long long* __restrict__ block_counts, PcnAdaptArgs ad) {
     constexpr int D = 32, H = 16, THREADS = 512;
     using FD = FlowDims<H, W>;
     extern __shared__ __align__(16) float sp[];
@@ -316,12 +316,43 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
         for (int w = 0; w < THREADS / 64; w++) tsum += s_cnt[w];
         block_counts[blockIdx.x] = tsum;
     }
+    if (ad.done == nullptr) return;
+    // the block that finishes last closes the step: total accept count, step-size adaptation (k_pcn_adapt's arithmetic)
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned int tk = __hip_atomic_fetch_add(ad.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (tk == gridDim.x - 1u);
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last) return;
+    long long c = 0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += THREADS)
+        c += __hip_atomic_load(&block_counts[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c = wave_sum_ll(c);
+    __syncthreads();
+    if (lane == 0) s_cnt[wave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c = 0;
+        for (int w = 0; w < THREADS / 64; w++) c += s_cnt[w];
+        ad.counts_out[ad.t] = c;
+        ad.rho_hist[ad.t] = rho;
+        if (ad.adapt) {
+            const double acc = (double)c / (double)ad.n;
+            double r = exp(log(rho) + (acc - ad.target) / pow((double)(ad.t + 1), 0.75));
+            r = r < 1e-4 ? 1e-4 : r;
+            r = r > 0.99 ? 0.99 : r;
+            *ad.rho = r;
+        }
+    }
 }
 
 template <typename T>
 static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* lp, double* lq, const PcnDev& pd,
                                  const asmc_coupling* f, const double* rho_ptr, uint32_t step, unsigned int* tile_counter,
-                                 long long* block_counts, int* grid_out, hipStream_t st) {
+                                 long long* block_counts, int* grid_out, const PcnAdaptArgs& adapt, hipStream_t st) {
     PcnScalars ps;
     ps.beta = pd.beta;
     ps.nu = pd.nu;
@@ -353,7 +384,7 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
         }                                                                                                                \
         ASMC_LAUNCH(ctx, st, "k_pcn_flow_fused", kern, dim3(grid), dim3(512), lds, st, n, ll, lp, lq,                     \
                     (const double*)ctx->d_ptab, ps, rho_ptr, step, f->packed_dev, (int)f->n_layers, f->loc_dev, f->scale_dev, \
-                    ladj0, base_const, tile_counter, block_counts);                                                     \
+                    ladj0, base_const, tile_counter, block_counts, adapt);                                                     \
         ASMC_LAUNCH_CHECK();                                                                                             \
         return ASMC_OK;                                                                                                  \
     }
@@ -388,8 +419,8 @@ bool asmc_pcn_flow_fused_ok(const asmc_pcn_params* prm, const asmc_coupling* f) 
 
 int asmc_pcn_flow_fused_launch(asmc_ctx* ctx, int64_t n, int x_dtype, double* ll, double* lp, double* lq, const PcnDev& pd,
                                const asmc_coupling* f, const double* rho_ptr, uint32_t step, unsigned int* tile_counter,
-                               long long* block_counts, int* grid_out, hipStream_t st) {
+                               long long* block_counts, int* grid_out, const PcnAdaptArgs& adapt, hipStream_t st) {
     if (x_dtype == ASMC_F64)
-        return launch_pcn_flow_fused<double>(ctx, n, ll, lp, lq, pd, f, rho_ptr, step, tile_counter, block_counts, grid_out, st);
-    return launch_pcn_flow_fused<float>(ctx, n, ll, lp, lq, pd, f, rho_ptr, step, tile_counter, block_counts, grid_out, st);
+        return launch_pcn_flow_fused<double>(ctx, n, ll, lp, lq, pd, f, rho_ptr, step, tile_counter, block_counts, grid_out, adapt, st);
+    return launch_pcn_flow_fused<float>(ctx, n, ll, lp, lq, pd, f, rho_ptr, step, tile_counter, block_counts, grid_out, adapt, st);
 }
