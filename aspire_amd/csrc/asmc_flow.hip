@@ -120,8 +120,8 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, in
             for (int i = 0; i < H / 2; i++) {
                 const int jp = hh * (H / 2) + i;  // padded dims: loc = 0, scale = 1 are not stored, keep them at zero
                 const bool real = jp < dh;
-                xa[tt][i] = real ? ((float)ra[tt][i] - loc[jp]) / scale[jp] : 0.0f;
-                xb[tt][i] = real ? ((float)rb[tt][i] - loc[dh + jp]) / scale[dh + jp] : 0.0f;
+                xa[tt][i] = real ? flow_standardise((float)ra[tt][i], loc[jp], scale[jp], 1.0f / scale[jp]) : 0.0f;
+                xb[tt][i] = real ? flow_standardise((float)rb[tt][i], loc[dh + jp], scale[dh + jp], 1.0f / scale[dh + jp]) : 0.0f;
             }
         }
         if (PREFETCH && it + 1 < rounds) load_raw(((it + 1) * gridDim.x + blockIdx.x) * FLOW_WAVES + wave);

@@ -7,6 +7,15 @@
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 
+// the flow's standardisation (x - loc) / scale through the reciprocal y = rn(1 / scale): q0 = a y, r = a - scale q0 (exact in
+// the FMA), q = q0 + r y - the correctly rounded quotient in three instructions instead of the ten of an IEEE division
+__device__ __forceinline__ float flow_standardise(float x, float loc, float scale, float rcp) {
+    const float a = x - loc;
+    const float q0 = a * rcp;
+    const float r = fmaf(-scale, q0, a);
+    return fmaf(r, rcp, q0);
+}
+
 template <int H, int W>
 struct FlowDims {
     static constexpr int NB1 = W / 32;  // accumulator blocks of a hidden layer

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
     // coefficients, but inside this kernel's tile loop LLVM issues all ~1400 of them up front and spills the SGPRs.)
     double* tl = reinterpret_cast<double*>(sp + (size_t)n_layers * FD::LAYER);
     constexpr int T_MU = D * D, T_LLMU = T_MU + D, T_LLPR = T_LLMU + D, T_LPMU = T_LLPR + D, T_LPPR = T_LPMU + D,
-                  T_LOGW = T_LPPR + D, T_LOC = T_LOGW + 2;  // then loc / scale: 2 x D floats = D doubles
+                  T_LOGW = T_LPPR + D, T_LOC = T_LOGW + 2;  // then loc / scale / 1/scale: 3 x D floats = 1.5 D doubles
     {
         const double* m0g = ptab + 2 * PTAB_TRI(D) + D;
         for (int e = threadIdx.x; e < D * D; e += THREADS) {
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
             tl[T_LPPR + e] = m0g[PTAB_MIX(D) + ASMC_MAX_COMPONENTS * (1 + D) + e];
             reinterpret_cast<float*>(tl + T_LOC)[e] = loc[e];
             reinterpret_cast<float*>(tl + T_LOC)[D + e] = scale[e];
+            reinterpret_cast<float*>(tl + T_LOC)[2 * D + e] = 1.0f / scale[e];
         }
         if (threadIdx.x == 0) tl[T_LOGW] = m0g[0], tl[T_LOGW + 1] = m0g[PTAB_MIX(D)];
     }
@@ -128,8 +129,10 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
 #endif
         // the tables are loop invariant: an offset LLVM cannot see through keeps their reads inside the tile loop (hoisted,
         // they would need a thousand registers)
+        // (a VECTOR register: one base address + 16-bit immediate offsets reach every table entry; with a scalar offset the
+        // addresses are formed on the scalar side and each far read pays a v_mov - 350 of them per tile)
         int zoff;
-        asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zoff));
         const double* __restrict__ Lt = tl + zoff;
         const float* __restrict__ locs = reinterpret_cast<const float*>(tl + T_LOC) + zoff;
         const int64_t i = (int64_t)t * 64 + lane;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(512) void k_pcn_flow_fused(
                 const double ta = xj - Lt[T_LLMU + j], tb = xj - Lt[T_LPMU + j];
                 qa = fma(ta * ta, Lt[T_LLPR + j], qa);
                 qb = fma(tb * tb, Lt[T_LPPR + j], qb);
-                xf[j] = ((float)xj - locs[j]) / locs[D + j];
+                xf[j] = flow_standardise((float)xj, locs[j], locs[D + j], locs[2 * D + j]);
             }
             // ... and one behind the group's epilogue, so that its 28 table reads are not issued a row group early
             asm volatile("" : "+v"(qa), "+v"(qb), "+v"(xf[j0]), "+v"(xf[j0 + 1]), "+v"(xf[j0 + 2]), "+v"(xf[j0 + 3])::"memory");
