@@ -48,6 +48,71 @@ __device__ __forceinline__ double u01_from_words(uint32_t hi, uint32_t lo) {
     return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
 }
 
+// ---- fp64 elementary functions of the Box-Muller transform on their restricted domains -----------------------------
+// The noise is most of the vector-ALU work of every pCN kernel; the general-purpose library versions
+// carry range checks, special cases and argument reductions these arguments never need.  Algorithms and coefficients:
+// FreeBSD msun e_log.c / k_sin.c / k_cos.c (each < 1 ulp); -ffp-contract=off, so every fma below is written out.
+
+// log(u), u in [2^-54, 1]
+__device__ __forceinline__ double bm_log_unit(double u) {
+    double m = __builtin_amdgcn_frexp_mant(u);  // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(u);
+    const bool lowhalf = m < 0.70710678118654752440;
+    m = lowhalf ? m + m : m;  // sqrt(1/2) <= m < sqrt(2)
+    k = lowhalf ? k - 1 : k;
+    const double f = m - 1.0;
+    const double d = 2.0 + f;
+    // s = f / d: v_rcp_f64 refined twice is far below the 1e-18 this term needs
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double s = f * r;
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    // k ln2_hi - ((hfsq - (s (hfsq + R) + k ln2_lo)) - f)
+    return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
+}
+
+// sqrt(a), 1e-17 < a < 1e3: v_rsq_f64 + one coupled Goldschmidt step + the final residual correction
+__device__ __forceinline__ double bm_sqrt(double a) {
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double dres = fma(-g, g, a);
+    return a > 0.0 ? fma(dres, h, g) : 0.0;
+}
+
+// (sin, cos)(2 pi u), u in (0, 1]: quarter-turn reduction (exact), kernels on |x| <= pi/4
+__device__ __forceinline__ void bm_sincos_turns(double u, double& sn, double& cs) {
+    const double q = __builtin_rint(4.0 * u);  // 0 .. 4
+    const double f = fma(q, -0.25, u);         // exact, |f| <= 1/8
+    const double x = f * 6.28318530717958647692;
+    const double z = x * x;
+    const double v = z * x;
+    const double rs = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                 -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    const double sx = fma(v, fma(z, rs, -1.66666666666666324348e-01), x);
+    const double rc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                 -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double wv = 1.0 - hz;
+    const double cx = wv + fma(z, rc, (1.0 - wv) - hz);
+    const int qi = (int)q;
+    // angle = x + q pi/2: q = 0 (s, c); 1 (c, -s); 2 (-s, -c); 3 (-c, s); 4 = 0
+    const bool swap = qi & 1;
+    const double s0 = swap ? cx : sx, c0 = swap ? sx : cx;
+    sn = (qi & 2) ? -s0 : s0;
+    cs = ((qi + 1) & 2) ? -c0 : c0;
+}
+
 // counter = {gid_lo, gid_hi, step, slot}; key = {seed_lo, seed_hi}
 __device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned long long gid,
                                             uint32_t step, uint32_t slot, double& z0, double& z1) {
@@ -56,9 +121,15 @@ __device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned lo
                   (uint32_t)(seed >> 32), w);
     const double u1 = u01_from_words(w[0], w[1]);
     const double u2 = u01_from_words(w[2], w[3]);
+#ifdef ASMC_NOISE_LIBM  // the device library's log / sqrt / sincospi instead (diagnostic: same values to an ulp or two)
     const double r = sqrt(-2.0 * log(u1));
     double s, c;
     sincospi(2.0 * u2, &s, &c);
+#else
+    const double r = bm_sqrt(-2.0 * bm_log_unit(u1));
+    double s, c;
+    bm_sincos_turns(u2, s, c);
+#endif
     z0 = r * c;
     z1 = r * s;
 }

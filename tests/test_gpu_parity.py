@@ -348,6 +348,23 @@ def test_philox_normals_match_oracle_and_are_normal(eng, oracle):
     assert stats.kstest(big.cpu().numpy().ravel(), "norm").pvalue > 1e-3
 
 
+def test_box_muller_functions_agree_with_libm_to_ulps(eng, oracle):
+    """The kernels' own fp64 log / sqrt / sin / cos of the Box-Muller transform (restricted domains, asmc_pcn_dev.h)
+    against the oracle's libm on the same Philox words: 65 536 normals, tails included."""
+    d, n = 32, 2048
+    x, _ = eng.gaussian_draw(n, d, torch.float64, eng.asarray(np.zeros(d)), eng.asarray(np.ones(d)), 99, 5, 1, want_lq=False)
+    xn = x.cpu().numpy()
+    ref = np.stack([oracle.pcn_noise(99, 5 + i, 1, d)[0] for i in range(n)])
+    err = np.abs(xn - ref)
+    # the oracle rounds the angle 2 pi u before taking cos / sin (half an ulp of up to 2 pi = 4.4e-16 rad, times the pair's
+    # radius); the kernels reduce u by quarter turns exactly.  Beyond that: a few ulp of the value itself.  (Against an
+    # 80-bit evaluation the kernels are the closer of the two: tools/bm_check.py, profiles/r02_box_muller_accuracy.txt.)
+    radius = np.sqrt(ref[:, 0::2] ** 2 + ref[:, 1::2] ** 2).repeat(2, axis=1)
+    tol = 8e-16 * radius + 4 * np.spacing(np.abs(ref)) + 2e-16
+    assert np.all(err <= tol), float((err / tol).max())
+    assert np.abs(ref).max() > 3.5  # the sample reaches into the tails
+
+
 @pytest.mark.parametrize("d,C,dtype", [(32, 1, torch.float64), (4, 2, torch.float64), (7, 3, torch.float32), (128, 2, torch.float64)])
 def test_mixture_logpdf_vs_oracle(eng, oracle, d, C, dtype):
     g = np.random.default_rng(9)
