@@ -714,12 +714,17 @@ class HipSMC(SMCSampler):
         return self._wrap(x, ll, lp, lq, beta, like=particles)
 
 
+_BLAS_CONTROLLER = []  # the process's ThreadpoolController, discovered once (the discovery walks every loaded library: ~1 ms)
+
+
 def _single_threaded_blas():
     try:
-        from threadpoolctl import threadpool_limits
+        if not _BLAS_CONTROLLER:
+            from threadpoolctl import ThreadpoolController
 
-        return threadpool_limits(limits=1)
-    except Exception:  # threadpoolctl missing: fall through (only a performance matter)
+            _BLAS_CONTROLLER.append(ThreadpoolController())
+        return _BLAS_CONTROLLER[0].limit(limits=1)
+    except Exception:  # threadpoolctl missing or too old: fall through (only a performance matter)
         import contextlib
 
         return contextlib.nullcontext()
