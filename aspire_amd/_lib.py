@@ -109,6 +109,7 @@ SIGNATURES = {
     "asmc_find_beta": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _pd, _vp]),
     "asmc_importance_step": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _vp, _i64, _vp, _vp, _vp, _vp]),
     "asmc_importance_result": (_i, [_vp, _pd, _vp]),
+    "asmc_importance_available": (_i, [_vp]),
     "asmc_pcn_set_count_hook": (_i, [_vp, _vp, _vp, _vp, _i64]),
     "asmc_pcn_ysplit_begin": (_i, [_vp, _i64, _vp, POINTER(AsmcPcnParams), _d, _vp]),
     "asmc_pcn_ysplit_propose": (_i, [_vp, _i64, POINTER(AsmcPcnParams), _u32, _vp, _vp]),

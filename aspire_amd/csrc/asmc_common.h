@@ -79,8 +79,9 @@ struct asmc_ctx {
     long long* d_counts;           // [ASMC_MAX_PCN_STEPS + max(ASMC_MAX_BLOCKS, n_max/64+1)] accept counts / partials
     double* d_rho;                 // [ASMC_MAX_PCN_STEPS + 8] step-size history on device
     unsigned int* d_tilectr;       // [2 * ASMC_MAX_PCN_STEPS] fused flow-proposal step: tile hand-out counters, then blocks-done counters (one each per step)
-    unsigned int* d_bar;           // [1024 * 17] arrival counters of the persistent importance-weight kernel's grid barriers (4 KB apart; they only grow)
-    unsigned int bar_base[17];     // their values when the next launch starts (top, 16 groups)
+    unsigned int* d_bar;           // [1024 * 17] arrival counters + the poison cell of the persistent importance-weight kernel's grid barriers (4 KB apart; they only grow)
+    unsigned int bar_base[17];     // their values when the next launch starts (top, groups)
+    int isw_disabled;              // a launch was not fully resident once (barrier time-out): the step-by-step path from now on
     unsigned long long* d_pcgtab;  // [64*4 + 8] PCG64 jump table
     long long* d_select;           // [2 * ASMC_SELECT_THREADS/64 + 8] wave counts, offsets, total of asmc_pcg64_select
     unsigned long long ptab_tag, ysplit_seq;  // who packed d_ptab last (0 = anyone; else the split session's number)

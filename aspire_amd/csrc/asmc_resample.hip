@@ -1245,7 +1245,7 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_search_pcg(const unsigned long l
         }
 #pragma unroll
         for (int q = 0; q < 4; q++)
-            if (i0 + q * T < n_out) idx[i0 + q * T] = lo[q];
+            if (i0 + q * T < n_out) idx[i0 + q * T] = lo[q] < n ? lo[q] : n - 1;  // (== lo: u < 1 = cdf[n-1]; a garbage cdf must not index past the rows)
     }
 }
 

@@ -654,7 +654,13 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const doubl
 struct IswBases {
     unsigned int top, group[ISW_GROUPS];
 };
-__device__ __forceinline__ void isw_barrier(unsigned int* bar, const IswBases& bases, unsigned int k, int G) {
+// Returns false when the other blocks did not arrive within ~0.5 s: the launch was not fully resident (two such kernels
+// of different processes sharing the GPU can each hold half of the CUs).  The caller then abandons the search - uniform
+// weights, found = 0 - and raises the poison cell; the host resets the counters and stops using this kernel.
+#define ISW_POISON_CELL (ISW_BAR_STRIDE * (ISW_GROUPS + 2))
+#define ISW_SPIN_LIMIT (1 << 18)
+__device__ __forceinline__ bool isw_barrier(unsigned int* bar, const IswBases& bases, unsigned int k, int G) {
+    __shared__ int s_ok;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -666,11 +672,17 @@ __device__ __forceinline__ void isw_barrier(unsigned int* bar, const IswBases& b
         if (old - bases.group[g] == k * gsize - 1u)  // this block completes its group's k-th arrival
             __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned int target = bases.top + k * ngroups;
-        while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0)
+        int spins = 0;
+        while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0 && spins < ISW_SPIN_LIMIT) {
             __builtin_amdgcn_s_sleep(1);
+            spins++;
+        }
+        s_ok = spins < ISW_SPIN_LIMIT;
+        if (!s_ok) __hip_atomic_store(bar + ISW_POISON_CELL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+    return s_ok != 0;
 }
 
 template <bool REG>
@@ -703,9 +715,11 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
     do {           \
     } while (0)
 #endif
+    bool poisoned = false;  // a barrier timed out: finish with uniform weights (see isw_barrier)
     auto barrier = [&]() {
+        if (poisoned) return;
         nbar++;
-        isw_barrier(bar, bar_bases, nbar, G);
+        poisoned = !isw_barrier(bar, bar_bases, nbar, G);
     };
     auto pbuf = [&](unsigned int k) { return partials + (size_t)(k & 1u) * (size_t)G * 32; };
 
@@ -858,6 +872,7 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
         }
         ISW_MARK();
         barrier();
+        if (poisoned) break;
         ISW_MARK();
         bis_reduce_partials(buf, G, s_red, s_S);
         __syncthreads();
@@ -868,7 +883,7 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
 
     // ---- phase 2: evidence variance + second log-sum-exp at beta*, then the normalised weights -----------------------
     const double beta0 = init.beta0, beta = L.st[0], N = init.N;
-    const bool found = L.st[2] != 0.0 && L.st[14] != 0.0 && nan_total == 0.0 && beta > beta0;
+    bool found = !poisoned && L.st[2] != 0.0 && L.st[14] != 0.0 && nan_total == 0.0 && beta > beta0;
     const double c1 = beta0 - beta, c2 = beta - beta0;
     const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
     double shift = 0.0, mp = 0.0, lse = 0.0;
@@ -915,6 +930,7 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
         }
         __syncthreads();
         lse = s_sc[4];
+        if (poisoned) found = false;
     }
     const double w_uniform = 1.0 / N;
     for (int sub = 0; sub < nsub; sub++) {
@@ -957,7 +973,7 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
             for (int k = 0; k < 16; k++) st_out[48 + k] = k < n_stamp ? stamps[k] : -1.0;
 #endif
         // top the counters up to this launch's budget: the next launch's bases
-        const unsigned int left = (unsigned int)(ISW_BARRIERS - nbar);
+        const unsigned int left = poisoned ? 0u : (unsigned int)(ISW_BARRIERS - nbar);  // (poisoned: the host resets them)
         if (tid == 0) __hip_atomic_fetch_add(bar, left * (unsigned int)(G < ISW_GROUPS ? G : ISW_GROUPS), __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT);
         if (tid >= 1 && tid <= ISW_GROUPS && tid - 1 < G) {
@@ -1138,6 +1154,10 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
 
 int asmc_is_weights_launch(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double beta0,
                            double target_eff, double tol, double* w, double* tiles, hipStream_t st) {
+    if (ctx->isw_disabled) {
+        asmc_set_error("asmc_importance_step: disabled on this context (an earlier launch was not fully resident)");
+        return ASMC_ERR_UNSUPPORTED;
+    }
     const BisInit init = {beta0, target_eff, tol, log((double)n), (double)n};
     int64_t chunk = ISW_CHUNK;
     int64_t grid = (n + chunk - 1) / chunk;
@@ -1150,6 +1170,7 @@ int asmc_is_weights_launch(asmc_ctx* ctx, int64_t n, const double* ll, const dou
     double* d_st = ctx->d_small + 2560;
     IswBases bases;
     bases.top = ctx->bar_base[0];
+    if (getenv("ASMC_ISW_TEST_TIMEOUT")) bases.top += 1000000u;  // test hook: the barriers of this launch can never complete
     ctx->bar_base[0] += (unsigned int)ISW_BARRIERS * (unsigned int)(grid < ISW_GROUPS ? grid : ISW_GROUPS);
     for (int g = 0; g < ISW_GROUPS; g++) {
         bases.group[g] = ctx->bar_base[1 + g];
@@ -1178,13 +1199,23 @@ int asmc_importance_result(asmc_ctx* ctx, double* out_host, asmc_stream stream) 
     ASMC_REQUIRE(ctx && out_host, "null pointer");
     hipStream_t st = as_stream(stream);
     double* h = ctx->h_pinned + 4096 + 512;
+    unsigned int* hp = reinterpret_cast<unsigned int*>(h + 64);
     ASMC_HIP(hipMemcpyAsync(h, ctx->d_small + 2560, sizeof(double) * 64, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipMemcpyAsync(hp, ctx->d_bar + ISW_POISON_CELL, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipStreamSynchronize(st));
     out_host[0] = h[0], out_host[1] = h[1], out_host[2] = h[2], out_host[3] = h[6], out_host[4] = h[9];
     out_host[5] = h[15];
     out_host[6] = h[11], out_host[7] = h[12], out_host[8] = h[13], out_host[9] = h[14];
     out_host[10] = h[10], out_host[11] = h[32], out_host[12] = h[33];
     out_host[13] = h[40], out_host[14] = h[41], out_host[15] = h[45];
+    if (hp[0] != 0) {
+        // a grid barrier timed out (isw_barrier): nothing of this step is valid; reset the counters and leave the
+        // persistent kernel alone from now on - the caller redoes the step through the step-by-step entry points
+        ASMC_HIP(hipMemsetAsync(ctx->d_bar, 0, sizeof(unsigned int) * ISW_BAR_STRIDE * (ISW_GROUPS + 3), st));
+        memset(ctx->bar_base, 0, sizeof(ctx->bar_base));
+        ctx->isw_disabled = 1;
+        out_host[2] = 0.0, out_host[9] = 0.0, out_host[15] = 0.0;
+    }
 #ifdef ISW_STAMP
     fprintf(stderr, "k_is_weights stamps (us, block 0):");
     for (int k = 48; k < 64; k++) fprintf(stderr, " %.2f", h[k]);
@@ -1192,6 +1223,8 @@ int asmc_importance_result(asmc_ctx* ctx, double* out_host, asmc_stream stream) 
 #endif
     return ASMC_OK;
 }
+
+int asmc_importance_available(asmc_ctx* ctx) { return ctx && !ctx->isw_disabled ? 1 : 0; }
 
 static inline void bis_state(asmc_ctx* ctx, double** d_st, BetaPack<16>** d_bp, unsigned int** d_ticket) {
     *d_st = ctx->d_small + 2560;

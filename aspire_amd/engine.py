@@ -262,6 +262,8 @@ class HipEngine:
         out = np.zeros(16)
         check(self.lib.asmc_importance_result(self._ctx, _f64p(out), self._stream), "asmc_importance_result")
         trip = (float(out[6]), float(out[7]), float(out[8])) if out[9] != 0.0 else None
+        if not out[2] and not out[15] and self.lib.asmc_importance_available(self._ctx) == 0:
+            self.importance_step_disabled = True  # the persistent kernel was not fully resident once: step-by-step from now on
         return (float(out[0]), float(out[4]), bool(out[2]), int(out[3]), int(out[5]), trip, tuple(map(float, out[10:13])),
                 float(out[13]), float(out[14]), bool(out[15]))
 

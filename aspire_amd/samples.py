@@ -431,6 +431,8 @@ class SMCSamples(BaseSamples):
         ll, lp, lq = self._dev3()
         x = e.asarray(self.x, dtype=self.x.dtype if is_torch(self.x) else torch.float64)
         n = ll.numel()
+        if getattr(e, "importance_step_disabled", False):
+            return False
         idx = e.importance_step(ll, lp, lq, float(self.beta), float(target_eff), float(tol), st4, n)
         rows = e.gather(idx, x, ll, lp, lq)
         b, eff1, conv, passes, n_nan, trip, trip_one, m2, _, found = e.importance_result()

@@ -167,6 +167,10 @@ int asmc_importance_step(asmc_ctx* ctx, int64_t n, const double* ll_dev, const d
                          double beta0, double target_eff, double tol, const uint64_t rng_state[4], int64_t n_out,
                          double* w_scratch_dev, double* cdf_scratch_dev, int64_t* idx_out_dev, asmc_stream stream);
 int asmc_importance_result(asmc_ctx* ctx, double* out_host, asmc_stream stream);
+/* 1 while asmc_importance_step can be used on this ctx; 0 once a launch of its persistent kernel timed out at a grid barrier
+ * (not fully resident, e.g. another process's kernel of the same kind on the GPU): that step reported found = 0, the counters
+ * were reset, and the caller stays on the step-by-step entry points. */
+int asmc_importance_available(asmc_ctx* ctx);
 /* The same search with the particles sharded over `world` ranks (one process per GPU; the reference has no
  * distributed mode).  A round is split at the rank boundary and never synchronises with the host:
  *   asmc_find_beta_shard_reduce  this rank's sums of the round's 16 candidates -> rec_dev[ASMC_BIS_REC]

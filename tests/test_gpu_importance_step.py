@@ -179,3 +179,27 @@ def test_sampler_fused_step_is_used_and_schedule_clamps_fall_back(eng):
     assert sp_a.history.beta == sp_b.history.beta and max(np.diff([0.0] + sp_a.history.beta)) <= 0.05 + 1e-12
     assert np.array_equal(_np(out_a.x), _np(out_b.x))
     assert sp_a.rng.bit_generator.state == sp_b.rng.bit_generator.state
+
+
+def test_barrier_timeout_abandons_the_step_and_the_sampler_falls_back(monkeypatch):
+    """A launch of the persistent kernel that is not fully resident (two such kernels of different processes sharing the
+    GPU) must not hang: its barriers time out, the step reports found = 0 with in-bounds indices, the context stops
+    using the kernel, and the sampler carries on through the step-by-step entry points with the same results."""
+    from aspire_amd.engine import HipEngine
+
+    e2 = HipEngine(0, n_max=1 << 17, d_max=8)  # its own context: the fallback is sticky
+    n = 100_000
+    x, ll, lp, lq = synth(n, 2, 41)
+    rng = np.random.default_rng(1)
+    monkeypatch.setenv("ASMC_ISW_TEST_TIMEOUT", "1")
+    idx = e2.importance_step(*(e2.asarray(a) for a in (ll, lp, lq)), 0.0, 0.5, 1e-6, smc_math.pcg64_state(rng), n)
+    res = e2.importance_result()
+    monkeypatch.delenv("ASMC_ISW_TEST_TIMEOUT")
+    assert not res[-1] and not res[2] and e2.importance_step_disabled
+    got = idx.cpu().numpy()
+    assert got.min() >= 0 and got.max() < n
+    with pytest.raises(Exception):
+        e2.importance_step(*(e2.asarray(a) for a in (ll, lp, lq)), 0.0, 0.5, 1e-6, smc_math.pcg64_state(rng), n)
+    sp_a, out_a = _run(e2, True, 20000, 8, 3)   # speculation is skipped on this engine now
+    sp_b, out_b = _run(e2, False, 20000, 8, 3)
+    assert sp_a.history.beta == sp_b.history.beta and np.array_equal(_np(out_a.x), _np(out_b.x))
