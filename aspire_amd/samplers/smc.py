@@ -97,7 +97,10 @@ class SMCSampler(MCMCSampler):
 
         search_fn = None
         sharded = self.comm.world > 1 and hasattr(self.engine, "find_beta_shard_reduce")
-        if ((self.comm.world == 1 and hasattr(self.engine, "find_beta")) or sharded) and self.device_bisection and beta < 1.0:
+        spec0 = samples.__dict__.get("_spec")
+        have_spec = spec0 is not None and spec0["search"][2] and float(beta) == float(samples.beta)
+        if (((self.comm.world == 1 and hasattr(self.engine, "find_beta")) or sharded or have_spec) and self.device_bisection
+                and beta < 1.0):
             def search_fn(beta_prev, target_eff, tol):
                 spec = samples.__dict__.get("_spec")
                 if (spec is not None and spec["key"] == (float(target_eff), float(tol)) and spec["search"][2]

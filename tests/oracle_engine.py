@@ -181,6 +181,40 @@ class OracleEngine:
         a = _np(v)
         return int(np.isnan(a).sum()), int(np.isinf(a).sum())
 
+    # ---- the importance step as one call (HipEngine.importance_step / importance_result; host-logic double) ----------
+    def importance_step(self, ll, lp, lq, beta0, target_eff, tol, state4, n_out):
+        """Search (the sharded rounds over a one-rank world), evidence moments, exact resampling indices for the next
+        n_out doubles of the PCG64 stream: what asmc_importance_step enqueues, computed eagerly."""
+        from aspire_amd import _lib
+        from aspire_amd.smc_math import Stats
+
+        n = ll.numel()
+        rec = torch.zeros(_lib.ASMC_BIS_REC, dtype=torch.float64)
+        for rnd in range(64):
+            self.find_beta_shard_reduce(ll, lp, lq, beta0, rnd, rec)
+            self.find_beta_shard_decide(rec, 1, n, beta0, target_eff, tol, rnd)
+            if self._bis["done"]:
+                break
+        b, eff1, conv, rounds, n_nan, trip, one = self.find_beta_shard_result()
+        found = bool(conv and trip is not None and n_nan == 0 and b > beta0)
+        m2 = s1p = 0.0
+        if found:
+            st = Stats(*trip, n)
+            shift = float((st.m + np.log(st.S1)) - np.log(float(n)))
+            mp = st.m + shift
+            m2, s1p = self.weights_m2_lse(ll, lp, lq, beta0, b, st.m, st.S1 / n, shift, mp)
+            w = self.normalized_weights(ll, lp, lq, beta0, b, shift, float(mp + np.log(s1p)))
+        else:
+            w = torch.full((n,), 1.0 / n, dtype=torch.float64)
+        cdf, last = self.cdf(w, "exact", 0.0)
+        cdf = self.cdf_normalize(cdf, last)
+        idx = self.search(cdf, self.uniforms_pcg64(state4, 0, n_out))
+        self._is_result = (b, eff1, conv, rounds, n_nan, trip, one, m2, s1p, found)
+        return idx
+
+    def importance_result(self):
+        return self._is_result
+
     # ---- resampling -------------------------------------------------------------------------
     def cdf(self, w, mode="exact", carry_in=0.0):
         a = _np(w).copy()
