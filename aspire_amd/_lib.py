@@ -26,7 +26,7 @@ COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
-ASMC_ABI_VERSION = 11
+ASMC_ABI_VERSION = 12
 ASMC_CDF_REC = 9
 ASMC_CDF_STATE = 36
 
@@ -147,6 +147,7 @@ SIGNATURES = {
     "asmc_gather": (_i, [_vp, _i64, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "asmc_gaussian_draw": (_i, [_vp, _i64, _i, _i, _vp, _vp, _u64, _u64, _u32, _vp, _vp, _vp]),
     "asmc_mixture_logpdf": (_i, [_vp, _i64, _i, _i, _vp, POINTER(AsmcMixture), _vp, _vp]),
+    "asmc_mixture_logpdf_premap": (_i, [_vp, _i64, _i, _i, _vp, _vp, POINTER(AsmcMixture), _vp, _vp]),
     "asmc_compact_valid": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pi64, _vp]),
     "asmc_colsum": (_i, [_vp, _i64, _i, _i, _vp, _pd, _vp]),
     "asmc_centered_gram": (_i, [_vp, _i64, _i, _i, _vp, _pd, _pd, _vp]),

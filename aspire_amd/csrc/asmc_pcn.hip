@@ -1086,7 +1086,9 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_mixture_logpdf(int64_t n, int d,
 // mixture_eval; the quadratic form is summed in butterfly order instead of coordinate order: ~1e-16 relative).
 template <typename T, int CMAX>
 __global__ __launch_bounds__(ASMC_BLOCK) void k_mixture_flat(int64_t n, int d, int tpr_log2, const uint4* __restrict__ x, MixDev m,
-                                                            double* __restrict__ out) {
+                                                            double* __restrict__ out, const double* __restrict__ premap) {
+    // premap != NULL (asmc_mixture_logpdf_premap): the density is evaluated at t_j = clip(a_j x_j + b_j, lo_j, hi_j) and
+    // sum_j h_j t_j^2 is added; rows a, b, lo, hi, h of d doubles each
     constexpr int EPT = 16 / (int)sizeof(T);
     const int tpr = 1 << tpr_log2, C = m.C;
     const int64_t total = n << tpr_log2;
@@ -1100,25 +1102,46 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_mixture_flat(int64_t n, int d, i
             mu[c][k] = c < C ? m.mu[(size_t)c * d + c0 * EPT + k] : 0.0;
             pr[c][k] = c < C ? m.prec[(size_t)c * d + c0 * EPT + k] : 0.0;
         }
+    double pa[EPT], pb[EPT], plo[EPT], phi[EPT], ph[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const int j = c0 * EPT + k;
+        pa[k] = premap ? premap[j] : 1.0;
+        pb[k] = premap ? premap[d + j] : 0.0;
+        plo[k] = premap ? premap[2 * d + j] : -INFINITY;
+        phi[k] = premap ? premap[3 * d + j] : INFINITY;
+        ph[k] = premap ? premap[4 * d + j] : 0.0;
+    }
     for (int64_t e0 = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; e0 - (threadIdx.x & 63) < total; e0 += stride) {
         const bool valid = e0 < total;
-        double q[CMAX];
+        double q[CMAX], extra = 0.0;
 #pragma unroll
         for (int c = 0; c < CMAX; c++) q[c] = 0.0;
         if (valid) {
             const uint4 raw = x[e0];
             const T* vals = reinterpret_cast<const T*>(&raw);
+            double xv[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; k++) {
+                xv[k] = (double)vals[k];
+                if (premap) {
+                    xv[k] = fmin(fmax(xv[k] * pa[k] + pb[k], plo[k]), phi[k]);
+                    extra = fma(ph[k] * xv[k], xv[k], extra);
+                }
+            }
 #pragma unroll
             for (int c = 0; c < CMAX; c++)
 #pragma unroll
                 for (int k = 0; k < EPT; k++) {
-                    const double t = (double)vals[k] - mu[c][k];
+                    const double t = xv[k] - mu[c][k];
                     q[c] = fma(t * t, pr[c][k], q[c]);
                 }
         }
 #pragma unroll
         for (int c = 0; c < CMAX; c++)
             for (int o = tpr >> 1; o >= 1; o >>= 1) q[c] += __shfl_xor(q[c], o, 64);
+        if (premap)
+            for (int o = tpr >> 1; o >= 1; o >>= 1) extra += __shfl_xor(extra, o, 64);
         if (valid && c0 == 0) {
             double best = -INFINITY, terms[CMAX];
 #pragma unroll
@@ -1138,7 +1161,7 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_mixture_flat(int64_t n, int d, i
                     r = best + log(ssum);
                 }
             }
-            out[e0 >> tpr_log2] = r;
+            out[e0 >> tpr_log2] = r + extra;
         }
     }
 }
@@ -1567,8 +1590,8 @@ int asmc_gaussian_draw(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const doubl
     return ASMC_OK;
 }
 
-int asmc_mixture_logpdf(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const asmc_mixture* density,
-                        double* out, asmc_stream stream) {
+static int mixture_logpdf_impl(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const asmc_mixture* density,
+                               double* out, const double* premap, asmc_stream stream) {
     ASMC_REQUIRE(ctx && x && density && out, "null pointer");
     ASMC_REQUIRE(n > 0 && d > 0 && d <= ASMC_MAX_DIMS, "bad sizes");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
@@ -1595,21 +1618,25 @@ int asmc_mixture_logpdf(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void
             if (x_dtype == ASMC_F64) {
                 if (m.C == 1)
                     ASMC_LAUNCH(ctx, st, "k_mixture_logpdf", (k_mixture_flat<double, 1>), dim3(g), dim3(ASMC_BLOCK), 0, st, n, d, lg,
-                                (const uint4*)x, m, out);
+                                (const uint4*)x, m, out, premap);
                 else
                     ASMC_LAUNCH(ctx, st, "k_mixture_logpdf", (k_mixture_flat<double, 4>), dim3(g), dim3(ASMC_BLOCK), 0, st, n, d, lg,
-                                (const uint4*)x, m, out);
+                                (const uint4*)x, m, out, premap);
             } else {
                 if (m.C == 1)
                     ASMC_LAUNCH(ctx, st, "k_mixture_logpdf", (k_mixture_flat<float, 1>), dim3(g), dim3(ASMC_BLOCK), 0, st, n, d, lg,
-                                (const uint4*)x, m, out);
+                                (const uint4*)x, m, out, premap);
                 else
                     ASMC_LAUNCH(ctx, st, "k_mixture_logpdf", (k_mixture_flat<float, 4>), dim3(g), dim3(ASMC_BLOCK), 0, st, n, d, lg,
-                                (const uint4*)x, m, out);
+                                (const uint4*)x, m, out, premap);
             }
             ASMC_LAUNCH_CHECK();
             return ASMC_OK;
         }
+    }
+    if (premap) {
+        asmc_set_error("asmc_mixture_logpdf_premap: rows must be a power-of-two number (<= 64) of 16-byte pieces, <= 4 components");
+        return ASMC_ERR_UNSUPPORTED;
     }
     auto launch = [&](auto kern, auto xp) {
         if (lds_bytes > 64 * 1024)
@@ -1628,6 +1655,17 @@ int asmc_mixture_logpdf(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void
     }
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
+}
+
+int asmc_mixture_logpdf(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const asmc_mixture* density,
+                        double* out, asmc_stream stream) {
+    return mixture_logpdf_impl(ctx, n, d, x_dtype, x, density, out, nullptr, stream);
+}
+
+int asmc_mixture_logpdf_premap(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* premap_dev,
+                               const asmc_mixture* density, double* out, asmc_stream stream) {
+    ASMC_REQUIRE(premap_dev != nullptr, "null premap");
+    return mixture_logpdf_impl(ctx, n, d, x_dtype, x, density, out, premap_dev, stream);
 }
 
 int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, double* sum_host, asmc_stream stream) {

@@ -53,7 +53,7 @@ __device__ __forceinline__ double u01_from_words(uint32_t hi, uint32_t lo) {
 // carry range checks, special cases and argument reductions these arguments never need.  Algorithms and coefficients:
 // FreeBSD msun e_log.c / k_sin.c / k_cos.c (each < 1 ulp); -ffp-contract=off, so every fma below is written out.
 
-// log(u), u in [2^-54, 1]
+// log(u) for a positive normal u (the Box-Muller radius feeds it [2^-54, 1], the logit transform (1, 2])
 __device__ __forceinline__ double bm_log_unit(double u) {
     double m = __builtin_amdgcn_frexp_mant(u);  // [0.5, 1)
     int k = __builtin_amdgcn_frexp_exp(u);

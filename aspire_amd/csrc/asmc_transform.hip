@@ -14,6 +14,7 @@
 // Traffic: 2 d s + 8 bytes per particle — HBM bound.
 #include "asmc_common.h"
 #include "asmc_tile.h"
+#include "asmc_pcn_dev.h"  // bm_log_unit
 
 struct TransDev {
     int d;
@@ -175,9 +176,20 @@ __device__ __forceinline__ double transform_coord(double v, const CoordPar& c, b
         if ((HINTS & (ASMC_TR_NO_LOGIT | ASMC_TR_NO_PROBIT)) != (ASMC_TR_NO_LOGIT | ASMC_TR_NO_PROBIT) && kind != 0) {
             double u;
             if (!(HINTS & ASMC_TR_NO_LOGIT) && ((HINTS & ASMC_TR_NO_PROBIT) || kind == 1)) {
-                u = 1.0 / (1.0 + exp(-v));
+                // sigmoid and log u + log(1 - u) from ONE exponential: with e = exp(-|v|), r = 1 / (1 + e):
+                // u = r (v >= 0) or e r, and log u + log(1 - u) = -|v| - 2 log(1 + e); on the clamped ends the clamp's own
+                // constant.  (The reference's expressions - utils.py:196-245 - cost an exp, a division and two logs; the
+                // values agree to a few ulp.)
+                const double av = fabs(v);
+                const double ex = exp(-av);
+                const double x1 = 1.0 + ex;  // (1, 2]
+                double r = __builtin_amdgcn_rcp(x1);
+                r = fma(fma(-x1, r, 1.0), r, r);
+                r = fma(fma(-x1, r, 1.0), r, r);
+                u = v >= 0.0 ? r : ex * r;
+                const bool clamped = u < p.eps || u > 1.0 - p.eps;
                 u = clip(u, p.eps, 1.0 - p.eps);
-                lj_b += log(u) + log1p(-u);
+                lj_b += clamped ? log(p.eps) + log1p(-p.eps) : -av - 2.0 * bm_log_unit(x1);
             } else {
                 lj_b += -(0.5 * (2.0 * half_log_2pi + v * v));
                 u = 0.5 * (1.0 + erf(v / 1.4142135623730951));

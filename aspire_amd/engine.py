@@ -487,6 +487,16 @@ class HipEngine:
                                            _dptr(out), self._stream), "asmc_mixture_logpdf")
         return out
 
+    def mixture_logpdf_premap(self, x: torch.Tensor, premap: torch.Tensor, mix: DeviceMixture) -> torch.Tensor:
+        """log mixture(t) + sum_j h_j t_j^2 at t = clip(a x + b, lo, hi); premap = rows (a, b, lo, hi, h) of d doubles
+        (include/asmc.h asmc_mixture_logpdf_premap)."""
+        assert x.is_contiguous() and x.dim() == 2 and premap.dtype == torch.float64 and premap.numel() == 5 * x.shape[1]
+        out = self.empty(x.shape[0])
+        cs = mix.c_struct()
+        check(self.lib.asmc_mixture_logpdf_premap(self._ctx, x.shape[0], x.shape[1], self._xdt(x), _dptr(x), _dptr(premap),
+                                                  ctypes.byref(cs), _dptr(out), self._stream), "asmc_mixture_logpdf_premap")
+        return out
+
     def make_coupling(self, dims: int, hidden: int, weights, biases, loc, scale) -> DeviceCoupling:
         packed = pack_coupling(self.lib, dims, hidden, weights, biases)
         scale = np.asarray(scale, dtype=np.float32)

@@ -130,6 +130,67 @@ class GaussianFlow(Flow):
             x = e.asarray(x, dtype=self.dtype)
         return x, lq
 
+    def log_prob_from_preconditioned(self, T):
+        """`(z, logj) -> log q(T^-1(z))` for the preconditioning transform `T` of the chain (`logj` = log|det dT^-1/dz| at z,
+        which the chain has anyway), WITHOUT the round trip z -> x -> this flow's latent through the bounded stage's
+        special functions; None when the shortcut does not apply.
+
+        It applies when `T` and this flow's data transform share their bounded -> unbounded stage (same logit or probit
+        coordinates, bounds and eps, nothing periodic - what `Aspire(prior_bounds=...)` builds for both).  Then
+        x = P^-1(y) with y = z s_T + m_T, and the flow's latent is w = (t - m_f) / s_f with t = P(x) = clip(y): the clip is
+        the forward transform's eps clamp of the unit interval.  log q(x) = log N(w; mu, sigma^2) - sum log s_f + log|dP/dx|
+        (flows/torch/flows.py:368-387 behind transforms.py:270-316) is a Gaussian in t - one premapped pass over z,
+        asmc_mixture_logpdf_premap - plus the bounded stage's log-Jacobian:
+          logit  (utils.py:196-245): the inverse clamps the unit interval exactly like the forward, so
+                 log|dP/dx| at x = -(log|dP^-1/dy| at y) = -(logj + aff_T), aff_T = T's affine log-Jacobian (0 without one);
+          probit (transforms.py:540-571): the inverse does not clamp, so the term is written out,
+                 sum_bounded (0.5 log 2 pi + 0.5 t^2 - log(up - lo)), and rides on the same pass.
+        The reference's own round trip loses digits of y in the tails (u next to 0 or 1); this form does not."""
+        from scipy.special import erfinv
+
+        Tf = self.data_transform
+        if not self._has_transform() or self.mu is None:
+            return None
+        need = ("_kind", "_periodic", "_lower", "_upper", "_mean", "_std", "eps", "affine_transform")
+        if any(not hasattr(t, k) for t in (T, Tf) for k in need):
+            return None
+        kind = np.asarray(Tf._kind)
+        b = kind != 0
+        kinds = set(kind[b].tolist())
+        if (not np.array_equal(kind, np.asarray(T._kind)) or len(kinds) > 1 or np.any(Tf._periodic) or np.any(T._periodic)
+                or Tf.eps != T.eps or not np.array_equal(Tf._lower[b], T._lower[b])
+                or not np.array_equal(Tf._upper[b], T._upper[b])):
+            return None
+        if (T.affine_transform and T._mean is None) or (Tf.affine_transform and Tf._mean is None):
+            return None
+        e = self._eng()
+        if not hasattr(e, "mixture_logpdf_premap"):
+            return None
+        d = self.dims
+        one, zero = np.ones(d), np.zeros(d)
+        s_t, m_t = (np.asarray(T._std), np.asarray(T._mean)) if T.affine_transform else (one, zero)
+        s_f, m_f = (np.asarray(Tf._std), np.asarray(Tf._mean)) if Tf.affine_transform else (one, zero)
+        probit = kinds == {2}
+        eps = float(Tf.eps)
+        if probit:
+            t_lo, t_hi = (float(np.sqrt(2.0) * erfinv(2.0 * u - 1.0)) for u in (eps, 1.0 - eps))
+        else:  # logit of the clamped unit interval, as the forward transform forms it: log(u) - log1p(-u)
+            t_lo, t_hi = (float(np.log(u) - np.log1p(-u)) for u in (eps, 1.0 - eps))
+        premap = np.stack([s_t, m_t, np.where(b, t_lo, -np.inf), np.where(b, t_hi, np.inf),
+                           np.where(b, 0.5, 0.0) if probit else zero])
+        sig = np.asarray(self.sigma, dtype=np.float64) * s_f
+        mean = np.asarray(self.mu, dtype=np.float64) * s_f + m_f
+        const = -np.log(sig).sum() - 0.5 * d * np.log(2.0 * np.pi)
+        if probit:
+            const += b.sum() * 0.5 * np.log(2.0 * np.pi) - np.log(Tf._upper[b] - Tf._lower[b]).sum()
+        elif T.affine_transform:
+            const += np.log(s_t).sum()  # - aff_T
+        mix = e.make_mixture([const], mean[None], (1.0 / sig**2)[None])
+        pm = e.asarray(np.ascontiguousarray(premap, dtype=np.float64))
+        if probit or not b.any():
+            return lambda z, logj: e.mixture_logpdf_premap(z, pm, mix)
+        return lambda z, logj: e.mixture_logpdf_premap(z, pm, mix) - logj
+
     def log_prob(self, x):
         e, _, _, mix = self._device_params()
         xt = e.asarray(x, dtype=x.dtype if isinstance(x, torch.Tensor) and x.dtype in (torch.float32, torch.float64) else torch.float64)

@@ -500,11 +500,26 @@ class HipSMC(SMCSampler):
         step0 = st["step"]
         acc_rates = []
 
+        # log q(x') straight from z' when the flow's data transform and T share their bounded stage (no erfinv round trip)
+        logq_z = None
+        if self.sampler_kwargs.get("flow_from_preconditioned", True) and hasattr(self.prior_flow, "log_prob_from_preconditioned"):
+            logq_z = self.prior_flow.log_prob_from_preconditioned(T)
+
+        def flow_lq(z_prop, x_prop, logj_new):
+            nonlocal logq_z
+            if logq_z is not None and z_prop.dtype in (torch.float64, torch.float32) and z_prop.is_contiguous():
+                try:
+                    return logq_z(z_prop, logj_new)
+                except Exception as exc:  # a row shape the premapped kernel does not take: the round trip from here on
+                    logger.info("log q from the preconditioned coordinate is not available: %s", exc)
+                    logq_z = None
+            return self._flow_log_prob(x_prop)
+
         def step(t, rho):
             z_prop, q0, q1 = e.pcn_propose(z, mu, L, Linv, rho, seed, gid0, step0 + t, nu=nu)
             x_prop, logj_new = T.inverse(z_prop)
             x_prop, logj_new = e.asarray(x_prop, dtype=x.dtype), e.asarray(logj_new)
-            lq_new = self._flow_log_prob(x_prop)
+            lq_new = flow_lq(z_prop, x_prop, logj_new)
             lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
             return z_prop, q0, q1, ll_new, lp_new, lq_new, logj_new
 
@@ -526,7 +541,7 @@ class HipSMC(SMCSampler):
                         z_prop = e.pcn_ysplit_propose(sess, step0 + t)
                         x_prop, logj_new = T.inverse(z_prop)
                         x_prop, logj_new = e.asarray(x_prop, dtype=x.dtype), e.asarray(logj_new)
-                        lq_new = self._flow_log_prob(x_prop)
+                        lq_new = flow_lq(z_prop, x_prop, logj_new)
                         lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
                         e.pcn_ysplit_accept(sess, step0 + t, ll, lp, lq, ll_new, lp_new, lq_new, n_global, t - done,
                                             logj=logj, logj_new=logj_new)

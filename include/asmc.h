@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 11
+#define ASMC_ABI_VERSION 12
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -314,6 +314,15 @@ int asmc_gaussian_draw(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const doubl
                        void* x_out_dev, double* lq_out_dev, asmc_stream stream);
 int asmc_mixture_logpdf(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
                         const asmc_mixture* density, double* out_dev, asmc_stream stream);
+/* The same density evaluated behind a per-coordinate affine map and clamp, plus a quadratic term:
+ *   out_i = log sum_c w_c N(t_i; mu_c, diag prec_c^-1) + sum_j h_j t_ij^2,   t_ij = clip(a_j x_ij + b_j, lo_j, hi_j),
+ * premap_dev = rows a, b, lo, hi, h of d doubles.  It is the proposal flow's log q(x') written as a function of the
+ * preconditioned coordinate z' when the flow's data transform and the preconditioning transform share their bounded ->
+ * unbounded stage (reference flows/torch/flows.py:368-387 behind transforms.py:270-316): the probit / erfinv round trip
+ * z' -> x' -> flow latent collapses to an affine map, the clamp reproducing the forward transform's eps clip.
+ * Rows must be a power-of-two number (<= 64) of 16-byte pieces, <= 4 components. */
+int asmc_mixture_logpdf_premap(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, const double* premap_dev,
+                               const asmc_mixture* density, double* out_dev, asmc_stream stream);
 int asmc_compact_valid(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
                        const double* ll_dev, const double* lp_dev, const double* lq_dev,
                        void* x_out_dev, double* ll_out_dev, double* lp_out_dev, double* lq_out_dev,

@@ -994,7 +994,9 @@ def test_transform_kernels_match_reference_golden(eng, golden):
         np.testing.assert_allclose(eng.to_numpy(lj), g[f"{name}_lj"], rtol=1e-12, atol=1e-11)
         x2, lj2 = T.inverse(eng.asarray(g[f"{name}_z2"]))
         np.testing.assert_allclose(eng.to_numpy(x2), g[f"{name}_x2"], rtol=1e-12, atol=1e-12)
-        np.testing.assert_allclose(eng.to_numpy(lj2), g[f"{name}_lj2"], rtol=1e-12, atol=1e-11)
+        # inverse log-Jacobian: the reference's logit form, log(u) + log1p(-u) on the ROUNDED u = 1 / (1 + exp(-v)), loses up
+        # to ~1e-10 to cancellation where u is next to 1; the kernel's -|v| - 2 log(1 + exp(-|v|)) does not
+        np.testing.assert_allclose(eng.to_numpy(lj2), g[f"{name}_lj2"], rtol=1e-12, atol=2e-10)
 
 
 @pytest.mark.gpu
@@ -1667,3 +1669,43 @@ def test_split_fp16_flow_is_as_accurate_as_the_fp32_mfma_chain(eng, hidden, scal
     assert rms(ehs[:64]) <= 4.0 * rms(e32[:64]) + 1e-5, (rms(ehs[:64]), rms(e32[:64]))
     rel32, relhs = np.max(e32 / np.maximum(np.abs(ref), 1.0)), np.max(ehs / np.maximum(np.abs(ref), 1.0))
     assert relhs < max(1e-6, 2.0 * rel32), (relhs, rel32)
+
+
+# ---- bounded priors: log q(x') from the preconditioned coordinate, without the probit / erfinv round trip --------------
+@pytest.mark.parametrize("d,dtype,unbounded,kind,affine", [
+    (32, torch.float64, (), "probit", True), (8, torch.float64, (1, 5), "probit", True), (16, torch.float32, (), "probit", True),
+    (32, torch.float64, (), "logit", False), (8, torch.float64, (0, 3), "logit", True), (16, torch.float32, (), "logit", False)])
+def test_flow_log_prob_from_preconditioned_equals_the_round_trip(eng, d, dtype, unbounded, kind, affine):
+    """GaussianFlow behind a FlowTransform and a CompositeTransform preconditioning built from the same prior bounds
+    (what Aspire(prior_bounds=...) does): log q(T^-1(z)) evaluated as one premapped Gaussian pass over z equals
+    flow.log_prob(T.inverse(z)) - including rows pushed beyond the eps clip of the unit interval."""
+    from aspire_amd.flows import GaussianFlow
+    from aspire_amd.transforms import CompositeTransform, FlowTransform
+
+    g = np.random.default_rng(12)
+    names = [f"p{i}" for i in range(d)]
+    bounds = {p: ([-np.inf, np.inf] if i in unbounded else [float(-3 - i % 3), float(4 + i % 5)]) for i, p in enumerate(names)}
+    centre = np.array([0.0 if i in unbounded else 0.5 * (bounds[p][0] + bounds[p][1]) for i, p in enumerate(names)])
+    Tf = FlowTransform(names, prior_bounds=bounds, bounded_transform=kind, engine=eng)
+    flow = GaussianFlow(d, engine=eng, data_transform=Tf, dtype=dtype)
+    flow.fit(centre + 1.2 * g.normal(size=(4000, d)).clip(-2.4, 2.4))
+    T = CompositeTransform(names, prior_bounds=bounds, bounded_to_unbounded=True, bounded_transform=kind, affine_transform=affine,
+                           engine=eng)
+    T.fit(centre + 0.9 * g.normal(size=(3000, d)).clip(-3.0, 3.0))
+    f = flow.log_prob_from_preconditioned(T)
+    assert f is not None
+    n = 20000
+    z = eng.asarray((1.4 if affine else 3.0) * g.normal(size=(n, d)), dtype=dtype)
+    z[:50] *= 4.0  # far rows: y beyond the clip of the forward transform
+    x, logj = T.inverse(z)
+    ref = flow.log_prob(eng.asarray(x, dtype=dtype)).cpu().numpy()
+    got = f(z, eng.asarray(logj)).cpu().numpy()
+    assert np.all(np.isfinite(got))
+    tol = 1e-8 if dtype == torch.float64 else 2e-3  # fp32 rows: x' itself is rounded to fp32 on the round trip
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * 10)
+    # not applicable: another eps, or another bounded stage
+    assert flow.log_prob_from_preconditioned(CompositeTransform(names, prior_bounds=bounds, bounded_transform=kind, eps=1e-5,
+                                                                engine=eng)) is None
+    other = CompositeTransform(names, prior_bounds=bounds, bounded_transform="logit" if kind == "probit" else "probit", engine=eng)
+    other.fit(centre + 0.5 * g.normal(size=(500, d)).clip(-2, 2))
+    assert flow.log_prob_from_preconditioned(other) is None
