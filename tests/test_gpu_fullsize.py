@@ -83,6 +83,12 @@ def test_config4_population_8m_is_step_bit_exact(big, oracle):
     xo, llo, lpo, lqo = big.gather(idx, x, ll, lp, lq)
     ref_t = torch.as_tensor(ref, device=big.device)
     assert torch.equal(xo, x[ref_t]) and torch.equal(llo, ll[ref_t]) and torch.equal(lqo, lq[ref_t])
+    # the same iteration as ONE chain of launches (asmc_importance_step; 8M: the persistent kernel streams the particles,
+    # the tile prefixes come from the separate scan): same beta*, same ancestors
+    idx2 = big.importance_step(ll, lp, lq, 0.0, 0.5, 1e-6, smc_math.pcg64_state(np.random.default_rng(8)), n)
+    res = big.importance_result()
+    assert res[-1] and res[0] == b and res[3] == 5
+    assert np.array_equal(idx2.cpu().numpy(), ref)
     del xo, x
     torch.cuda.empty_cache()
 
