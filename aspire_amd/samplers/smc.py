@@ -455,7 +455,11 @@ class HipSMC(SMCSampler):
         from ..student_t import NU_GAUSSIAN, _chol, fit_student_t_device
 
         e, comm = self.engine, self.comm
-        m = min(int(self.sampler_kwargs.get("tpcn_fit_subsample", 2048)), 16384)
+        # The fit adapts the kernel to the particles it then moves, which biases log Z by O(parameters / fitted rows): with
+        # 2048 rows the d = 128 runs of BASELINE config 5 came out +0.9 sigma high on average over 30 seeds (rms 1.26), with
+        # d^2 rows -0.15 sigma (rms 0.78) for 4 % more wall time; d = 32 shows nothing at 2048 (tools/validate_logz.py,
+        # profiles/r02_tpcn_subsample_bias.txt).
+        m = min(int(self.sampler_kwargs.get("tpcn_fit_subsample", max(2048, self.dims * self.dims))), 16384)
         k = max(1, min(m, n_global) // comm.world)
         n_local = x.shape[0]
         rows = torch.as_tensor((np.arange(k, dtype=np.int64) * n_local) // k, device=x.device)

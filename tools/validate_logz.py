@@ -70,5 +70,6 @@ d5 = 128
 lik5 = DiagGaussianMixture(np.stack([2 * np.ones(d5), -2 * np.ones(d5)]), np.stack([0.5 * np.ones(d5), np.ones(d5)]))
 prior5 = DiagGaussianMixture.isotropic(d5, 0.0, 1.0)
 g5 = lambda s: GaussianFlow(d5, sigma=3.0, engine=eng, seed=4 + s)  # noqa: E731
-case("config 5 (1 GPU), tpcn", d5, lik5, prior5, g5, closed_form_config5(d5))
+sub = {"tpcn_fit_subsample": int(os.environ["TPCN_SUB"])} if "TPCN_SUB" in os.environ else {}
+case("config 5 (1 GPU), tpcn", d5, lik5, prior5, g5, closed_form_config5(d5), **sub)
 case("config 5 (1 GPU), pcn", d5, lik5, prior5, g5, closed_form_config5(d5), step_fn="pcn")
