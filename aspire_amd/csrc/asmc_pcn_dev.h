@@ -113,14 +113,8 @@ __device__ __forceinline__ void bm_sincos_turns(double u, double& sn, double& cs
     cs = ((qi + 1) & 2) ? -c0 : c0;
 }
 
-// counter = {gid_lo, gid_hi, step, slot}; key = {seed_lo, seed_hi}
-__device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned long long gid,
-                                            uint32_t step, uint32_t slot, double& z0, double& z1) {
-    uint32_t w[4];
-    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, slot, (uint32_t)seed,
-                  (uint32_t)(seed >> 32), w);
-    const double u1 = u01_from_words(w[0], w[1]);
-    const double u2 = u01_from_words(w[2], w[3]);
+// two uniforms in (0, 1] -> two standard normals
+__device__ __forceinline__ void box_muller(double u1, double u2, double& z0, double& z1) {
 #ifdef ASMC_NOISE_LIBM  // the device library's log / sqrt / sincospi instead (diagnostic: same values to an ulp or two)
     const double r = sqrt(-2.0 * log(u1));
     double s, c;
@@ -132,6 +126,15 @@ __device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned lo
 #endif
     z0 = r * c;
     z1 = r * s;
+}
+
+// counter = {gid_lo, gid_hi, step, slot}; key = {seed_lo, seed_hi}
+__device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned long long gid,
+                                            uint32_t step, uint32_t slot, double& z0, double& z1) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, slot, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), w);
+    box_muller(u01_from_words(w[0], w[1]), u01_from_words(w[2], w[3]), z0, z1);
 }
 
 // Fast noise (NOISE_F32): one Philox block -> FOUR standard normals through fp32 Box-Muller on the
