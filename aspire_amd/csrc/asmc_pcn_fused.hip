@@ -5,6 +5,10 @@
 #include "asmc_pcn_dev.h"
 #include "asmc_flow_dev.h"
 
+#ifndef FUSED_THREADS
+#define FUSED_THREADS 512  // 8 waves per CU: two per SIMD (the weights in LDS allow one block per CU)
+#endif
+
 // =============================================================================================================
 // Fused flow-proposal pCN step (reference smc/minipcn.py:97-114 around smc/base.py:507-519 with
 // flows/torch/flows.py:368-387 as log q): propose -> coupling flow on the fp32 MFMA -> built-in targets -> accept in ONE
@@ -25,12 +29,12 @@
 // The flow's weights stay resident in LDS (115 KB at d = 32, W = 64: one block of 8 waves per CU, two waves per SIMD, so
 // one wave's vector work - noise, mat-vec, accept - runs in the shadow of its partner's MFMA chains).
 template <typename T, int W, int NOISE, bool HS>
-__global__ __launch_bounds__(512) void k_pcn_flow_fused(
+__global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     int64_t n, double* __restrict__ ll, double* __restrict__ lp, double* __restrict__ lq, const double* __restrict__ ptab,
     PcnScalars p, const double* rho_ptr, uint32_t step, const float* __restrict__ packed, int n_layers,
     const float* __restrict__ loc, const float* __restrict__ scale, float ladj0, float base_const,
     unsigned int* __restrict__ tile_counter, long long* __restrict__ block_counts, PcnAdaptArgs ad) {
-    constexpr int D = 32, H = 16, THREADS = 512;
+    constexpr int D = 32, H = 16, THREADS = FUSED_THREADS;
     using FD = FlowDims<H, W>;
     extern __shared__ __align__(16) float sp[];
     if (HS) {
@@ -371,7 +375,7 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
     const float ladj0 = (float)(-f->log_scale_sum);
     const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
     const int64_t n_tiles = (n + 63) / 64;
-    const int grid = (int)(n_tiles < (int64_t)ctx->num_cu * 8 ? (n_tiles + 7) / 8 : ctx->num_cu);  // one 8-wave block per CU
+    const int grid = (int)(n_tiles < (int64_t)ctx->num_cu * (FUSED_THREADS / 64) ? (n_tiles + FUSED_THREADS / 64 - 1) / (FUSED_THREADS / 64) : ctx->num_cu);  // one 8-wave block per CU
     *grid_out = grid;
     // flow arithmetic: split-fp16 MFMA (fp32-equivalent operands, asmc_flow_dev.h) unless ASMC_FLOW_MATH=f32 asks for the
     // fp32 MFMA chain
@@ -385,7 +389,7 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
             ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             attr_lds = lds;                                                                                              \
         }                                                                                                                \
-        ASMC_LAUNCH(ctx, st, "k_pcn_flow_fused", kern, dim3(grid), dim3(512), lds, st, n, ll, lp, lq,                     \
+        ASMC_LAUNCH(ctx, st, "k_pcn_flow_fused", kern, dim3(grid), dim3(FUSED_THREADS), lds, st, n, ll, lp, lq,                     \
                     (const double*)ctx->d_ptab, ps, rho_ptr, step, f->packed_dev, (int)f->n_layers, f->loc_dev, f->scale_dev, \
                     ladj0, base_const, tile_counter, block_counts, adapt);                                                     \
         ASMC_LAUNCH_CHECK();                                                                                             \
