@@ -269,10 +269,16 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         // lockstep - both in the vector phases, then both fighting for the matrix pipe - and the MFMA sits idle half the
         // time.  Static priorities break the tie: a wave in its matrix phase outranks a wave in a vector phase, and the
         // first wave of a SIMD outranks the second when both are in the matrix phase, which pushes them into anti-phase.
+#ifndef FUSED_PRIO_A
+#define FUSED_PRIO_A 2
+#define FUSED_PRIO_B 1
+#endif
+#ifndef FUSED_NOPRIO
         if (first_on_simd)
-            __builtin_amdgcn_s_setprio(2);
+            __builtin_amdgcn_s_setprio(FUSED_PRIO_A);
         else
-            __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(FUSED_PRIO_B);
+#endif
         STAMP(4);
         float lqt[2];
         lqt[0] = flow_tile(xaA, xbA);
