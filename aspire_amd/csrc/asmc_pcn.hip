@@ -20,6 +20,7 @@
 #include "asmc_common.h"
 #include "asmc_tile.h"
 #include "asmc_pcn_dev.h"
+#include "asmc_transform_dev.h"
 
 // =============================================================================================
 // LDS row tiles
@@ -678,6 +679,18 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
                               // split session, whose densities come from the caller (arbitrary Python callables)
 #define PCN_FLOW_ACCEPT_SJ 5  // PCN_FLOW_ACCEPT_S with a carried log-Jacobian (chain in a preconditioned space): the two
                               // arrays arrive through the y / x_prop parameters, which coordinate-major accept does not use
+// PCN_FLOW_PROPOSE_SX whose proposal lives in a preconditioned space z = T(x) (reference
+// transforms.py:294-316 inside smc/minipcn.py:105-119): the inverse transform x' = T^-1(z') and its log-Jacobian are
+// applied to the register-resident proposal, and - when the proposal flow's data transform shares T's bounded stage -
+// log q(x') is evaluated from z' in the same pass (asmc_mixture_logpdf_premap's arithmetic).  x' goes to x_prop, log|J| to
+// ll_new, log q to lp_new; lq_new carries the packed table (TRTAB_* below).  One variant per bounded stage.
+#define PCN_FLOW_PROPOSE_SXT_LOGIT 6
+#define PCN_FLOW_PROPOSE_SXT_PROBIT 7
+// packed table of the transform epilogue: TRTAB_ROWS rows of D doubles, then TRTAB_SCALARS scalars
+//   rows: kind, lower, upper, mean, std, 1/(upper-lower), 1/std, premap a, b, lo, hi, h, q mean, q precision
+//   scalars: eps, unit_logj, affine_logj, has_affine, q log-weight, has_q, minus_logj
+#define TRTAB_ROWS 14
+#define TRTAB_SCALARS 8
 
 template <typename T, int D, int NOISE, int MODE>
 __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
@@ -687,7 +700,8 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
     long long* __restrict__ block_counts) {
     extern __shared__ __align__(16) char smem[];
     constexpr bool SOA = MODE >= PCN_FLOW_PROPOSE_S;
-    constexpr bool NO_DENS = MODE == PCN_FLOW_PROPOSE_SX;
+    constexpr bool TR = MODE == PCN_FLOW_PROPOSE_SXT_LOGIT || MODE == PCN_FLOW_PROPOSE_SXT_PROBIT;
+    constexpr bool NO_DENS = MODE == PCN_FLOW_PROPOSE_SX || TR;
     constexpr bool HAS_LJ = MODE == PCN_FLOW_ACCEPT_SJ;
     constexpr int M = NO_DENS ? PCN_FLOW_PROPOSE : HAS_LJ ? PCN_FLOW_ACCEPT : SOA ? MODE - PCN_FLOW_PROPOSE_S : MODE;
     constexpr int ROWB = D * (int)sizeof(T);
@@ -777,6 +791,38 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
                 if (!NO_DENS) {
                     ll_new[i] = mixture_eval_regs<D>(mll, v);
                     lp_new[i] = mixture_eval_regs<D>(mlp, v);
+                }
+                if (TR) {
+                    constexpr int HINTS = ASMC_TR_NO_PERIODIC |
+                                          (MODE == PCN_FLOW_PROPOSE_SXT_LOGIT ? ASMC_TR_NO_PROBIT : ASMC_TR_NO_LOGIT);
+                    const double* __restrict__ tt = lq_new;
+                    const double* __restrict__ sc = tt + TRTAB_ROWS * D;
+                    const double eps = sc[0];
+                    const bool has_affine = sc[3] != 0.0, has_q = sc[5] != 0.0;
+                    double lj_b = 0.0, quad = 0.0, qq = 0.0;
+                    bool any_b = false;
+#pragma unroll
+                    for (int j = 0; j < D; j++) {
+                        if (has_q) {  // log q(x') from z' (asmc_mixture_logpdf_premap)
+                            const double tq = clip(v[j] * tt[7 * D + j] + tt[8 * D + j], tt[9 * D + j], tt[10 * D + j]);
+                            quad = fma(tt[11 * D + j] * tq, tq, quad);
+                            const double dq = tq - tt[12 * D + j];
+                            qq = fma(dq * dq, tt[13 * D + j], qq);
+                        }
+                        CoordPar c;
+                        c.kind = (int)tt[j], c.periodic = 0;
+                        c.lo = tt[D + j], c.up = tt[2 * D + j], c.mean = tt[3 * D + j], c.std = tt[4 * D + j];
+                        c.inv_w = tt[5 * D + j], c.inv_std = tt[6 * D + j];
+                        any_b |= c.kind != 0;
+                        v[j] = (double)(T)transform_coord<1, HINTS>(v[j], c, has_affine, eps, lj_b);
+                        // keep the table reads of later coordinates behind this one's arithmetic (hoisted, they cost 100 VGPRs)
+                        if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    double lj = 0.0;  // k_transform's grouping: affine constant, then the bounded block
+                    if (has_affine) lj += -sc[2];
+                    if (any_b) lj += lj_b + (-sc[1]);
+                    ll_new[i] = lj;
+                    if (has_q) lp_new[i] = ((sc[4] - 0.5 * qq) + quad) - (sc[6] != 0.0 ? lj : 0.0);
                 }
                 regs_to_row<T, D>(myrow, v);
                 acc = true;
@@ -1447,7 +1493,7 @@ static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
-    ASMC_LAUNCH(ctx, st, (MODE == PCN_FLOW_PROPOSE || MODE == PCN_FLOW_PROPOSE_S || MODE == PCN_FLOW_PROPOSE_SX) ? "k_pcn_flow_propose" : "k_pcn_flow_accept", kern, dim3((int)grid64),
+    ASMC_LAUNCH(ctx, st, (MODE == PCN_FLOW_PROPOSE || MODE == PCN_FLOW_PROPOSE_S || MODE == PCN_FLOW_PROPOSE_SX || MODE >= PCN_FLOW_PROPOSE_SXT_LOGIT) ? "k_pcn_flow_propose" : "k_pcn_flow_accept", kern, dim3((int)grid64),
                 dim3(wpb * 64), lds_bytes, st, n, y, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, (const double*)ctx->d_ptab, ps,
                 rho_ptr, step, block_counts);
     ASMC_LAUNCH_CHECK();
@@ -2102,6 +2148,76 @@ int asmc_pcn_ysplit_propose(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm
                                                                   nullptr, nullptr, pd, ctx->d_rho, step, d_block, &grid, st);
     return dispatch_pcn_reg_flow<float, PCN_FLOW_PROPOSE_SX>(ctx, n, nullptr, (float*)x_prop, nullptr, nullptr, nullptr, nullptr,
                                                              nullptr, nullptr, pd, ctx->d_rho, step, d_block, &grid, st);
+}
+
+// packs the transform epilogue's table (TRTAB_*) from the device-resident transform / premap / mixture tables
+__global__ void k_trtab_pack(int d, const int* __restrict__ kind, const double* __restrict__ lower, const double* __restrict__ upper,
+                             const double* __restrict__ mean, const double* __restrict__ sd, const double* __restrict__ premap,
+                             const double* __restrict__ q_logw, const double* __restrict__ q_mu, const double* __restrict__ q_prec,
+                             double eps, double unit_logj, double affine_logj, int minus_logj, double* __restrict__ out) {
+    const int j = threadIdx.x;
+    if (j < d) {
+        out[j] = (double)kind[j];
+        out[d + j] = lower[j];
+        out[2 * d + j] = upper[j];
+        out[3 * d + j] = mean ? mean[j] : 0.0;
+        out[4 * d + j] = sd ? sd[j] : 1.0;
+        out[5 * d + j] = 1.0 / (upper[j] - lower[j]);
+        out[6 * d + j] = sd ? 1.0 / sd[j] : 1.0;
+        for (int r = 0; r < 5; r++) out[(7 + r) * d + j] = premap ? premap[r * d + j] : 0.0;
+        out[12 * d + j] = q_mu ? q_mu[j] : 0.0;
+        out[13 * d + j] = q_prec ? q_prec[j] : 0.0;
+    }
+    if (j == 0) {
+        double* sc = out + TRTAB_ROWS * d;
+        sc[0] = eps, sc[1] = unit_logj, sc[2] = affine_logj, sc[3] = mean ? 1.0 : 0.0;
+        sc[4] = q_logw ? q_logw[0] : 0.0, sc[5] = premap ? 1.0 : 0.0, sc[6] = minus_logj ? 1.0 : 0.0, sc[7] = 0.0;
+    }
+}
+
+int asmc_pcn_ysplit_propose_tr(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm, uint32_t step, const asmc_transform* t,
+                               const double* premap_dev, const asmc_mixture* qmix, int minus_logj, void* x_prop,
+                               double* logj_out, double* lq_out, asmc_stream stream) {
+    PcnDev pd;
+    int rc = ysplit_pd(ctx, n, prm, pd);
+    if (rc) return rc;
+    ASMC_REQUIRE(t && x_prop && logj_out && ((uintptr_t)x_prop % 16) == 0, "null / misaligned pointer");
+    ASMC_REQUIRE(ctx->d_ysoa != nullptr, "no session (asmc_pcn_ysplit_begin)");
+    ASMC_REQUIRE(t->d == pd.d && t->kind_dev && t->lower_dev && t->upper_dev, "transform tables missing or of another dimension");
+    ASMC_REQUIRE((t->mean_dev == nullptr) == (t->std_dev == nullptr), "affine stage needs both mean and std");
+    ASMC_REQUIRE((premap_dev == nullptr) == (qmix == nullptr) && (premap_dev == nullptr) == (lq_out == nullptr),
+                 "premap, mixture and lq_out come together");
+    ASMC_REQUIRE(!qmix || qmix->n_components == 1, "the proposal density must be a single Gaussian");
+    const int logit = (t->hints & 7) == (ASMC_TR_NO_PERIODIC | ASMC_TR_NO_PROBIT);
+    const int probit = (t->hints & 7) == (ASMC_TR_NO_PERIODIC | ASMC_TR_NO_LOGIT);
+    if (!logit && !probit) {
+        asmc_set_error("asmc_pcn_ysplit_propose_tr: the transform must be non-periodic with ONE bounded stage (hints %d)", t->hints);
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = as_stream(stream);
+    pd.ys = ctx->d_ysoa;
+    pd.n_pad = ((n + 63) / 64) * 64;
+    if (ctx->ptab_tag == 0 || ctx->ptab_tag != ctx->ysplit_seq) {
+        rc = pack_pcn_tables(ctx, pd, st);
+        if (rc) return rc;
+        ctx->ptab_tag = ctx->ysplit_seq;
+    }
+    rc = pcn_prepare_gamma(ctx, n, pd, step, st);
+    if (rc) return rc;
+    double* d_tab = ctx->d_small + 3072;  // TRTAB_ROWS * 32 + TRTAB_SCALARS doubles
+    ASMC_LAUNCH(ctx, st, "k_trtab_pack", k_trtab_pack, dim3(1), dim3(64), 0, st, pd.d, t->kind_dev, t->lower_dev, t->upper_dev,
+                t->mean_dev, t->std_dev, premap_dev, qmix ? qmix->logw_dev : (const double*)nullptr,
+                qmix ? qmix->mu_dev : (const double*)nullptr, qmix ? qmix->prec_dev : (const double*)nullptr, t->eps, t->unit_logj,
+                t->affine_logj, minus_logj, d_tab);
+    ASMC_LAUNCH_CHECK();
+    int grid = 0;
+    long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
+#define PROPOSE_TR(TT, MD) \
+    dispatch_pcn_reg_flow<TT, MD>(ctx, n, nullptr, (TT*)x_prop, nullptr, nullptr, nullptr, logj_out, lq_out, (const double*)d_tab, pd, \
+                                  ctx->d_rho, step, d_block, &grid, st)
+    if (prm->x_dtype == ASMC_F64) return logit ? PROPOSE_TR(double, PCN_FLOW_PROPOSE_SXT_LOGIT) : PROPOSE_TR(double, PCN_FLOW_PROPOSE_SXT_PROBIT);
+    return logit ? PROPOSE_TR(float, PCN_FLOW_PROPOSE_SXT_LOGIT) : PROPOSE_TR(float, PCN_FLOW_PROPOSE_SXT_PROBIT);
+#undef PROPOSE_TR
 }
 
 int asmc_pcn_ysplit_accept(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm, uint32_t step, double* ll, double* lp,

@@ -692,6 +692,27 @@ class HipEngine:
               "asmc_pcn_ysplit_propose")
         return xp
 
+    def pcn_ysplit_propose_tr(self, sess, step: int, t: DeviceTransform, logq=None):
+        """`pcn_ysplit_propose` for a chain in the preconditioned space of `t`: returns (x', log|det dT^-1/dz| at z', log q(x')
+        or None).  `logq` = (premap tensor [5 d], DeviceMixture with one component, minus_logj) evaluates the proposal
+        flow's density from z' in the same pass (include/asmc.h asmc_pcn_ysplit_propose_tr)."""
+        x = sess["x"]
+        xp = torch.empty_like(x)
+        logj = self.empty(x.shape[0])
+        lq = self.empty(x.shape[0]) if logq is not None else None
+        ts = t.c_struct()
+        if logq is not None:
+            premap, mix, minus = logq
+            ms = mix.c_struct()
+            check(self.lib.asmc_pcn_ysplit_propose_tr(self._ctx, x.shape[0], ctypes.byref(sess["prm"]), step, ctypes.byref(ts),
+                                                      _dptr(premap), ctypes.byref(ms), int(bool(minus)), _dptr(xp), _dptr(logj),
+                                                      _dptr(lq), self._stream), "asmc_pcn_ysplit_propose_tr")
+        else:
+            check(self.lib.asmc_pcn_ysplit_propose_tr(self._ctx, x.shape[0], ctypes.byref(sess["prm"]), step, ctypes.byref(ts),
+                                                      None, None, 0, _dptr(xp), _dptr(logj), None, self._stream),
+                  "asmc_pcn_ysplit_propose_tr")
+        return xp, logj, lq
+
     def pcn_ysplit_accept(self, sess, step: int, ll, lp, lq, ll_new, lp_new, lq_new, n_global: int, t: int,
                           logj=None, logj_new=None):
         """logj / logj_new: carried / proposed log-Jacobian of a chain in a preconditioned space (both or neither)."""

@@ -187,9 +187,14 @@ class GaussianFlow(Flow):
             const += np.log(s_t).sum()  # - aff_T
         mix = e.make_mixture([const], mean[None], (1.0 / sig**2)[None])
         pm = e.asarray(np.ascontiguousarray(premap, dtype=np.float64))
-        if probit or not b.any():
-            return lambda z, logj: e.mixture_logpdf_premap(z, pm, mix)
-        return lambda z, logj: e.mixture_logpdf_premap(z, pm, mix) - logj
+        minus = not (probit or not b.any())
+
+        def logq(z, logj):
+            out = e.mixture_logpdf_premap(z, pm, mix)
+            return out - logj if minus else out
+
+        logq.fused_args = (pm, mix, minus)  # for asmc_pcn_ysplit_propose_tr, which evaluates this inside the propose kernel
+        return logq
 
     def log_prob(self, x):
         e, _, _, mix = self._device_params()

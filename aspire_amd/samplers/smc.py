@@ -541,11 +541,25 @@ class HipSMC(SMCSampler):
                                               self.sampler_kwargs.get("noise", "f64"))
                     if sess is None:
                         break
+                    # inverse transform (and log q, when it is available from z') inside the propose kernel where the
+                    # transform has one bounded stage and nothing periodic
+                    t_dev = None
+                    if (self.sampler_kwargs.get("fuse_transform", True) and hasattr(e, "pcn_ysplit_propose_tr")
+                            and hasattr(T, "_tables") and not np.any(getattr(T, "_periodic", [1]))):
+                        td = T._tables()[1]
+                        if td.hints & 7 in (5, 3):  # ASMC_TR_NO_PERIODIC | NO_PROBIT (logit) / NO_LOGIT (probit)
+                            t_dev = td
                     for t in range(done, done + chunk):
-                        z_prop = e.pcn_ysplit_propose(sess, step0 + t)
-                        x_prop, logj_new = T.inverse(z_prop)
-                        x_prop, logj_new = e.asarray(x_prop, dtype=x.dtype), e.asarray(logj_new)
-                        lq_new = flow_lq(z_prop, x_prop, logj_new)
+                        if t_dev is not None:
+                            x_prop, logj_new, lq_new = e.pcn_ysplit_propose_tr(sess, step0 + t, t_dev,
+                                                                               getattr(logq_z, "fused_args", None))
+                            if lq_new is None:
+                                lq_new = self._flow_log_prob(x_prop)
+                        else:
+                            z_prop = e.pcn_ysplit_propose(sess, step0 + t)
+                            x_prop, logj_new = T.inverse(z_prop)
+                            x_prop, logj_new = e.asarray(x_prop, dtype=x.dtype), e.asarray(logj_new)
+                            lq_new = flow_lq(z_prop, x_prop, logj_new)
                         lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
                         e.pcn_ysplit_accept(sess, step0 + t, ll, lp, lq, ll_new, lp_new, lq_new, n_global, t - done,
                                             logj=logj, logj_new=logj_new)

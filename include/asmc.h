@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 12
+#define ASMC_ABI_VERSION 13
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -490,6 +490,18 @@ int asmc_transform_forward(asmc_ctx* ctx, int64_t n, int x_dtype, const void* x_
                            double* logj_dev, const asmc_transform* t, asmc_stream stream);
 int asmc_transform_inverse(asmc_ctx* ctx, int64_t n, int x_dtype, const void* z_dev, void* x_dev,
                            double* logj_dev, const asmc_transform* t, asmc_stream stream);
+
+/* asmc_pcn_ysplit_propose for a chain that lives in a preconditioned space z = T(x) (reference
+ * transforms.py:294-316 inside smc/minipcn.py:105-119): the inverse transform and its log-Jacobian are applied to the
+ * register-resident proposal, so the kernel emits x' = T^-1(z') (x_prop_dev) and log|det dT^-1/dz| at z' (logj_out_dev)
+ * directly - no z' round trip through HBM, no separate asmc_transform_inverse pass.  `t`: a non-periodic transform with ONE
+ * bounded stage (logit or probit; hints say which) and an optional affine stage.
+ * premap_dev / qmix / lq_out_dev (all three or none): the proposal flow's log q(x') as a function of z' when the flow's data
+ * transform shares T's bounded stage - asmc_mixture_logpdf_premap's arithmetic on a single Gaussian, minus log|J| when
+ * minus_logj != 0 (the logit form; see GaussianFlow.log_prob_from_preconditioned) - evaluated in the same pass. */
+int asmc_pcn_ysplit_propose_tr(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm, uint32_t step, const asmc_transform* t,
+                               const double* premap_dev, const asmc_mixture* qmix, int minus_logj, void* x_prop_dev,
+                               double* logj_out_dev, double* lq_out_dev, asmc_stream stream);
 
 #ifdef __cplusplus
 }

@@ -1709,3 +1709,44 @@ def test_flow_log_prob_from_preconditioned_equals_the_round_trip(eng, d, dtype, 
     other = CompositeTransform(names, prior_bounds=bounds, bounded_transform="logit" if kind == "probit" else "probit", engine=eng)
     other.fit(centre + 0.5 * g.normal(size=(500, d)).clip(-2, 2))
     assert flow.log_prob_from_preconditioned(other) is None
+
+
+@pytest.mark.parametrize("d,dtype,kind,affine,noise,nu", [
+    (32, torch.float64, "logit", False, "f64", 0.0), (32, torch.float64, "probit", True, "f64", 5.0),
+    (8, torch.float32, "logit", True, "f32", 0.0), (16, torch.float64, "probit", False, "f32", 0.0)])
+def test_ysplit_propose_with_the_transform_inside_equals_the_separate_passes(eng, d, dtype, kind, affine, noise, nu):
+    """asmc_pcn_ysplit_propose_tr (inverse transform, log|J| and - through the premap - log q(x') applied to the
+    register-resident proposal) against asmc_pcn_ysplit_propose + asmc_transform_inverse + asmc_mixture_logpdf_premap on
+    the same session: the same x', log|J| (other summation order) and log q."""
+    from aspire_amd.flows import GaussianFlow
+    from aspire_amd.transforms import CompositeTransform, FlowTransform
+
+    g = np.random.default_rng(21)
+    n = 5000
+    names = [f"p{i}" for i in range(d)]
+    bounds = {p: [float(-2 - i % 3), float(3 + i % 4)] for i, p in enumerate(names)}
+    centre = np.array([0.5 * (bounds[p][0] + bounds[p][1]) for p in names])
+    Tf = FlowTransform(names, prior_bounds=bounds, bounded_transform=kind, engine=eng)
+    flow = GaussianFlow(d, engine=eng, data_transform=Tf, dtype=dtype)
+    flow.fit(centre + 1.1 * g.normal(size=(3000, d)).clip(-2.0, 2.0))
+    T = CompositeTransform(names, prior_bounds=bounds, bounded_to_unbounded=True, bounded_transform=kind, affine_transform=affine,
+                           engine=eng)
+    x0 = eng.asarray(centre + 0.8 * g.normal(size=(n, d)).clip(-2.5, 2.5), dtype=dtype)
+    z = eng.asarray(T.fit(x0), dtype=dtype)
+    logq = flow.log_prob_from_preconditioned(T)
+    assert logq is not None
+    mu = eng.asarray(0.05 * g.normal(size=d))
+    A = np.eye(d) * (1.0 if affine else 2.0) + 0.05 * np.tril(g.normal(size=(d, d)), -1)
+    L, Linv = eng.asarray(A), eng.asarray(np.linalg.inv(A))
+    sess = eng.pcn_ysplit_begin(z, 0.4, mu, L, Linv, 77, 1000, 0.5, 0.234, True, nu, noise)
+    assert sess is not None
+    t_dev = T._tables()[1]
+    zp = eng.pcn_ysplit_propose(sess, 9)
+    x_ref, lj_ref = T.inverse(zp)
+    lq_ref = logq(zp, eng.asarray(lj_ref))
+    x_f, lj_f, lq_f = eng.pcn_ysplit_propose_tr(sess, 9, t_dev, logq.fused_args)
+    assert torch.equal(x_f, eng.asarray(x_ref, dtype=dtype))
+    np.testing.assert_allclose(lj_f.cpu().numpy(), eng.asarray(lj_ref).cpu().numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(lq_f.cpu().numpy(), lq_ref.cpu().numpy(), rtol=1e-12, atol=1e-11)
+    x_g, lj_g, none = eng.pcn_ysplit_propose_tr(sess, 9, t_dev, None)  # without the density
+    assert none is None and torch.equal(x_g, x_f) and torch.equal(lj_g, lj_f)
