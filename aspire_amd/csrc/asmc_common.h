@@ -78,9 +78,10 @@ struct asmc_ctx {
     size_t ysoa_bytes;
     long long* d_counts;           // [ASMC_MAX_PCN_STEPS + max(ASMC_MAX_BLOCKS, n_max/64+1)] accept counts / partials
     double* d_rho;                 // [ASMC_MAX_PCN_STEPS + 8] step-size history on device
-    unsigned int* d_tilectr;       // [2 * ASMC_MAX_PCN_STEPS] fused flow-proposal step: tile hand-out counters, then blocks-done counters (one each per step)
+    unsigned int* d_tilectr;       // [2 * ASMC_MAX_PCN_STEPS + 2] fused flow-proposal step: tile hand-out counters, blocks-done counters (one each per step), non-finite density count (64-bit)
     unsigned int* d_bar;           // [1024 * 17] arrival counters + the poison cell of the persistent importance-weight kernel's grid barriers (4 KB apart; they only grow)
     unsigned int bar_base[17];     // their values when the next launch starts (top, groups)
+    unsigned long long flow_nonfinite;  // non-finite flow densities among the proposals of the last asmc_pcn_mutate_flow
     int isw_disabled;              // a launch was not fully resident once (barrier time-out): the step-by-step path from now on
     unsigned long long* d_pcgtab;  // [64*4 + 8] PCG64 jump table
     long long* d_select;           // [2 * ASMC_SELECT_THREADS/64 + 8] wave counts, offsets, total of asmc_pcg64_select

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, in
         }
         if (PREFETCH && it + 1 < rounds) load_raw(((it + 1) * gridDim.x + blockIdx.x) * FLOW_WAVES + wave);
         float ladj[TPW];
+        float amax = 0.0f;  // largest operand the split-fp16 layers converted (this lane's particle; TPW = 1 there)
 #pragma unroll
         for (int tt = 0; tt < TPW; tt++) ladj[tt] = 0.0f;
         for (int c = 0; c < n_layers; c++) {
@@ -143,9 +144,9 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, in
             if constexpr (HS) {
                 static_assert(TPW == 1, "the split-fp16 layers take one tile per wave");
                 if ((c & 1) == 0)
-                    coupling_layer_hs<H, W>(xa[0], xb[0], lp, lane, hh, ladj[0]);
+                    coupling_layer_hs<H, W>(xa[0], xb[0], lp, lane, hh, ladj[0], amax);
                 else
-                    coupling_layer_hs<H, W>(xb[0], xa[0], lp, lane, hh, ladj[0]);
+                    coupling_layer_hs<H, W>(xb[0], xa[0], lp, lane, hh, ladj[0], amax);
             } else if ((c & 1) == 0)
                 coupling_layer<H, W, TPW>(xa, xb, lp, lane, hh, ladj);
             else
@@ -159,7 +160,10 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, in
             for (int i = 0; i < H / 2; i++) q += xa[tt][i] * xa[tt][i] + xb[tt][i] * xb[tt][i];
             q += __shfl_xor(q, 32);
             const float lj = ladj[tt] + __shfl_xor(ladj[tt], 32);
-            if (tile < n_tiles && row < n && hh == 0) out[row] = (double)((-0.5f * q + base_const) + (ladj0 + lj));
+            const float am = fmaxf(amax, __shfl_xor(amax, 32));
+            // an operand past the fp16 range makes the split products garbage: report NaN, not a finite wrong number
+            const float val = (HS && !(am < FLOW_HS_MAX)) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
+            if (tile < n_tiles && row < n && hh == 0) out[row] = (double)val;
         }
     }
 }
@@ -199,6 +203,16 @@ extern "C" int asmc_coupling_pack(int dims, int n_layers, int hidden, const floa
     }
     const int H = flow_half_pad(dims), Wd = hidden, dh = dims / 2;
     const int NB1 = Wd / 32, NB3 = H / 16;
+    if (asmc_flow_math_split()) {  // the split-fp16 layers carry every weight as an fp16 pair
+        const int64_t sizes[3] = {(int64_t)Wd * dh, (int64_t)Wd * Wd, (int64_t)dims * Wd};
+        for (int c = 0; c < 3 * n_layers; c++)
+            for (int64_t k = 0; k < sizes[c % 3]; k++)
+                if (!(fabsf(weights_host[c][k]) < 65504.0f)) {
+                    asmc_set_error("asmc_coupling_pack: weight %g of matrix %d is outside the fp16 operand range of the split-fp16 "
+                                   "flow kernels (|w| < 65504); ASMC_FLOW_MATH=f32 selects the fp32 MFMA chain", (double)weights_host[c][k], c);
+                    return ASMC_ERR_UNSUPPORTED;
+                }
+    }
     const int64_t layer = flow_layer_floats(H, Wd);
     auto unit = [](int s, int hh) { return 32 * (s / 16) + acc_row(s % 16, hh); };  // s-th hidden unit held by half hh
     // packed output row (block nb, row i) -> row of the torch output layer ([s_0..s_dh-1, t_0..t_dh-1]) or -1

@@ -176,8 +176,17 @@ __device__ __forceinline__ void coupling_layer(const float (&cond)[TPW][H / 2], 
 // layer, converted lane-locally.
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+// `amax` collects the largest operand magnitude a lane has converted: past FLOW_HS_MAX the fp16 pair is inf / NaN and -
+// ReLU squashing NaNs - the density would come out FINITE AND WRONG, so the callers turn it into NaN (rejected and counted)
+#define FLOW_HS_MAX 65504.0f
 template <bool RELU>
-__device__ __forceinline__ void split8_f16(const float (&x)[8], half8& hi, half8& lo) {
+__device__ __forceinline__ void split8_f16(const float (&x)[8], half8& hi, half8& lo, float& amax) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const float v0 = RELU ? __int_as_float(max(__float_as_int(x[j]), 0)) : x[j];
+        const float v1 = RELU ? __int_as_float(max(__float_as_int(x[j + 1]), 0)) : x[j + 1];
+        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v0)), __builtin_fabsf(v1));  // one v_max3_f32
+    }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         // ReLU on the bit pattern: one v_max_i32 (negative floats are negative integers; fmaxf would canonicalise the
@@ -192,7 +201,7 @@ __device__ __forceinline__ void split8_f16(const float (&x)[8], half8& hi, half8
 // out[NBO] += Wt * act(in), `in` = NBI accumulator blocks of the previous layer (pre-activation), A = the matrix's image
 template <int NBO, int NBI, bool RELU>
 __device__ __forceinline__ void dense_from_acc_hs(floatx16 (&out)[NBO], const floatx16 (&in)[NBI], const float* __restrict__ A,
-                                                  int lane) {
+                                                  int lane, float& amax) {
     constexpr int ST = NBI * 2;  // K16 steps
     const half8* Ap = reinterpret_cast<const half8*>(A) + lane;
 #pragma unroll
@@ -201,7 +210,7 @@ __device__ __forceinline__ void dense_from_acc_hs(floatx16 (&out)[NBO], const fl
 #pragma unroll
         for (int j = 0; j < 8; j++) xv[j] = in[S / 2][8 * (S % 2) + j];
         half8 bh, bl;
-        split8_f16<RELU>(xv, bh, bl);
+        split8_f16<RELU>(xv, bh, bl, amax);
         half8 ah[NBO], al[NBO];
 #pragma unroll
         for (int nbo = 0; nbo < NBO; nbo++) {
@@ -232,7 +241,7 @@ __device__ __forceinline__ void acc_bias1(floatx16 (&acc)[NB], const float* __re
 // one coupling layer of one 32-particle tile: cond / trans are the lane half's H / 2 coordinates
 template <int H, int W>
 __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], float (&trans)[H / 2], const float* __restrict__ lp,
-                                                  int lane, int hh, float& ladj) {
+                                                  int lane, int hh, float& ladj, float& amax) {
     using FD = FlowDims<H, W>;
     const float* b1 = lp;
     const float* b2 = b1 + FD::NB1 * 32;
@@ -251,7 +260,7 @@ __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], fl
 #pragma unroll
             for (int j = 0; j < 8; j++) xv[j] = cond[8 * S + j];
             half8 bh, bl;
-            split8_f16<false>(xv, bh, bl);
+            split8_f16<false>(xv, bh, bl, amax);
             half8 ah[FD::NB1], al[FD::NB1];
 #pragma unroll
             for (int nb = 0; nb < FD::NB1; nb++) {
@@ -272,10 +281,10 @@ __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], fl
     }
     floatx16 h2[FD::NB1];
     acc_bias1<FD::NB1>(h2, b2, hh);
-    dense_from_acc_hs<FD::NB1, FD::NB1, true>(h2, h1, A2, lane);
+    dense_from_acc_hs<FD::NB1, FD::NB1, true>(h2, h1, A2, lane, amax);
     floatx16 o[FD::NB3];
     acc_bias1<FD::NB3>(o, b3, hh);
-    dense_from_acc_hs<FD::NB3, FD::NB1, true>(o, h2, A3, lane);
+    dense_from_acc_hs<FD::NB3, FD::NB1, true>(o, h2, A3, lane, amax);
 #pragma unroll
     for (int q = 0; q < H / 2; q++) {
         const float sraw = o[q / 16][q % 16];
@@ -303,7 +312,8 @@ __device__ __forceinline__ void flow_stage_hs(float* __restrict__ sp, const floa
         const float4 f0 = reinterpret_cast<const float4*>(packed)[i4], f1 = reinterpret_cast<const float4*>(packed)[i4 + 64];
         const float xv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
         half8 hi, lo;
-        split8_f16<false>(xv, hi, lo);
+        float wmax = 0.0f;  // (weights beyond the fp16 range are refused when the flow is packed: asmc_coupling_pack)
+        split8_f16<false>(xv, hi, lo, wmax);
         reinterpret_cast<half8*>(sp)[i4] = hi;
         reinterpret_cast<half8*>(sp)[i4 + 64] = lo;
     }

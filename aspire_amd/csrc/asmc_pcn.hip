@@ -2387,13 +2387,14 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
         // one kernel per step (propose -> flow on the MFMA -> targets -> accept) where the shape allows it
         const bool fused = soa && asmc_pcn_flow_fused_ok(prm, flow);
         // counters of the fused steps: [t] tile hand-out, [ASMC_MAX_PCN_STEPS + t] blocks done
-        if (fused) ASMC_HIP(hipMemsetAsync(ctx->d_tilectr, 0, sizeof(unsigned int) * 2 * ASMC_MAX_PCN_STEPS, st));
+        if (fused) ASMC_HIP(hipMemsetAsync(ctx->d_tilectr, 0, sizeof(unsigned int) * (2 * ASMC_MAX_PCN_STEPS + 2), st));
         for (int t = 0; t < (fused ? n_steps : 0); t++) {
             const uint32_t step = step0 + (uint32_t)t;
             rc = pcn_prepare_gamma(ctx, n, pd, step, st);
             if (rc) return rc;
             // single rank: the step's last block adapts the step size itself; sharded: the ranks' counts are exchanged first
-            PcnAdaptArgs ad = {nullptr, d_counts, d_rho, d_rho_hist, prm->target_accept, n, t, prm->adapt};
+            PcnAdaptArgs ad = {nullptr, reinterpret_cast<unsigned long long*>(ctx->d_tilectr + 2 * ASMC_MAX_PCN_STEPS), d_counts, d_rho,
+                               d_rho_hist, prm->target_accept, n, t, prm->adapt};
             if (!ctx->count_hook) ad.done = ctx->d_tilectr + ASMC_MAX_PCN_STEPS + t;
             rc = asmc_pcn_flow_fused_launch(ctx, n, prm->x_dtype == ASMC_F64 ? ASMC_F64 : ASMC_F32, ll, lp, lq, pd, flow, d_rho, step,
                                             ctx->d_tilectr + t, d_block, &grid, ad, st);
@@ -2456,12 +2457,17 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
     ASMC_HIP(hipMemcpyAsync(h_counts, d_counts, sizeof(long long) * n_steps, hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipMemcpyAsync(h_rho_hist, d_rho_hist, sizeof(double) * n_steps, hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8000, d_rho, sizeof(double), hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8001, ctx->d_tilectr + 2 * ASMC_MAX_PCN_STEPS, sizeof(unsigned long long),
+                            hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipStreamSynchronize(st));
     for (int t = 0; t < n_steps; t++) n_accept_host[t] = (int64_t)h_counts[t];
     if (rho_hist_host)
         for (int t = 0; t < n_steps; t++) rho_hist_host[t] = h_rho_hist[t];
     *rho_inout_host = ctx->h_pinned[8000];
+    memcpy(&ctx->flow_nonfinite, ctx->h_pinned + 8001, sizeof(unsigned long long));  // fused steps only (else stale zero)
     return ASMC_OK;
 }
+
+int64_t asmc_pcn_flow_nonfinite(asmc_ctx* ctx) { return ctx ? (int64_t)ctx->flow_nonfinite : -1; }
 
 }  // extern "C"

@@ -10,6 +10,7 @@ bool asmc_flow_math_split();  // asmc_flow.hip
 // k_pcn_adapt launch (sharded runs exchange the accept counts between ranks first)
 struct PcnAdaptArgs {
     unsigned int* done;     // zeroed arrival counter of this step
+    unsigned long long* nonfinite;  // += proposals whose flow density came out non-finite (rejected); may be NULL
     long long* counts_out;  // [t] <- accepted particles of the step
     double* rho;            // step size: read by this step, adapted for the next
     double* rho_hist;       // [t] <- the step size this step used

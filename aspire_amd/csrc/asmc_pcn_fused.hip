@@ -86,7 +86,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     const double rho = *rho_ptr;
     const double a = sqrt(1.0 - rho * rho);
     const int64_t n_tiles = (n + 63) / 64;
-    long long n_acc = 0;
+    long long n_acc = 0, n_bad = 0;
 #ifdef FUSED_STAMP
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     int ntile = 0;
@@ -244,14 +244,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         // all 448 of them in front of it)
         auto flow_tile = [&](float(&xa)[1][H / 2], float(&xb)[1][H / 2]) __attribute__((always_inline)) -> float {
             float ladj[1] = {0.0f};
+            float amax = 0.0f;  // largest operand the split-fp16 layers converted for this lane's particle
 #ifndef FUSED_NOFLOW
             for (int c = 0; c < n_layers; c++) {
                 const float* lpk = sp + (size_t)c * FD::LAYER;
                 if (HS) {
                     if ((c & 1) == 0)
-                        coupling_layer_hs<H, W>(xa[0], xb[0], lpk, lane, hh, ladj[0]);
+                        coupling_layer_hs<H, W>(xa[0], xb[0], lpk, lane, hh, ladj[0], amax);
                     else
-                        coupling_layer_hs<H, W>(xb[0], xa[0], lpk, lane, hh, ladj[0]);
+                        coupling_layer_hs<H, W>(xb[0], xa[0], lpk, lane, hh, ladj[0], amax);
                 } else if ((c & 1) == 0)
                     coupling_layer<H, W, 1>(xa, xb, lpk, lane, hh, ladj);
                 else
@@ -263,7 +264,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             for (int r = 0; r < H / 2; r++) q += xa[0][r] * xa[0][r] + xb[0][r] * xb[0][r];
             q += __shfl_xor(q, 32);
             const float lj = ladj[0] + __shfl_xor(ladj[0], 32);
-            return (-0.5f * q + base_const) + (ladj0 + lj);
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            // an operand past the fp16 range: the pair was inf / NaN and the density is garbage - make it NaN
+            return !(amax < FLOW_HS_MAX) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
         };
         // The two waves of a SIMD (waves w and w + 4 of the block) run the same program; left alone they fall into
         // lockstep - both in the vector phases, then both fighting for the matrix pipe - and the MFMA sits idle half the
@@ -290,6 +293,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         STAMP(6);
         const double nlq = (double)(hh == 0 ? lqt[0] : lqt[1]);
         // ---- phase 3: accept, on the lane's own particle ---------------------------------------------------------------
+        // a non-finite log q(x') (NaN, or +-inf: fp16 operand overflow at |activation| >= 65504 in the split products,
+        // asmc_flow_dev.h) rejects the proposal; counted, so that the host can tell the user
+        if (valid && !(fabs(nlq) < INFINITY)) n_bad++;
         double lpn = (1.0 - p.beta) * nlq + t2;
         lpn = (lpn != lpn) ? -INFINITY : lpn;
         const double log_a = (lpn + c1) - rhs;
@@ -322,6 +328,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
 #endif
     __shared__ long long s_cnt[THREADS / 64];
     n_acc = wave_sum_ll(n_acc);
+    n_bad = wave_sum_ll(n_bad);
+    if (lane == 0 && n_bad != 0 && ad.nonfinite) atomicAdd(ad.nonfinite, (unsigned long long)n_bad);
     if (lane == 0) s_cnt[wave] = n_acc;
     __syncthreads();
     if (threadIdx.x == 0) {

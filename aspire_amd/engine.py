@@ -651,6 +651,10 @@ class HipEngine:
                                             _f64p(rho_hist), self._stream), "asmc_pcn_mutate_flow")
         return n_acc, rho_hist, rho_io.value
 
+    def pcn_flow_nonfinite(self) -> int:
+        """Proposals of the last `pcn_mutate_flow` whose flow density was not finite (rejected)."""
+        return int(self.lib.asmc_pcn_flow_nonfinite(self._ctx))
+
     def pcn_propose(self, x, mu, L, Linv, rho, seed, gid0, step, nu=0.0):
         n, d = x.shape
         xp = torch.empty_like(x)

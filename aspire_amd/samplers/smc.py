@@ -671,6 +671,10 @@ class HipSMC(SMCSampler):
                     st["rho"] = rho
                     acc_rates.extend((n_acc / n_global).tolist())
                     done += chunk
+                    n_bad = e.pcn_flow_nonfinite() if hasattr(e, "pcn_flow_nonfinite") else 0
+                    if n_bad > 0:
+                        logger.warning(f"{n_bad} proposals had a non-finite flow density and were rejected (a badly scaled flow "
+                                       "overflows the fp16 operand pairs of the flow kernel; ASMC_FLOW_MATH=f32 uses fp32 MFMAs)")
             else:
                 for t in range(n_steps):
                     n_acc, _, _ = e.pcn_mutate_flow(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed, gid0,

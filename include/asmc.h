@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 13
+#define ASMC_ABI_VERSION 14
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -459,6 +459,10 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, 
                          void* work_dev, int64_t work_bytes, int n_steps, uint32_t step0,
                          double* rho_inout_host, int64_t* n_accept_host, double* rho_hist_host,
                          asmc_stream stream);
+/* Proposals of the last asmc_pcn_mutate_flow whose flow density was not finite (they were rejected).  The flow's fp32 layers
+ * run as split-fp16 MFMA products (operands |.| < 65504): a badly scaled flow shows up here; ASMC_FLOW_MATH=f32 selects the
+ * fp32 MFMA chain.  Counted by the one-kernel step only. */
+int64_t asmc_pcn_flow_nonfinite(asmc_ctx* ctx);
 
 /* ---- preconditioning transforms ------------------------------------------
  * Element-wise CompositeTransform of the reference (transforms.py:142-316): periodic wrap (:411-436),

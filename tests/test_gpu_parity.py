@@ -1750,3 +1750,46 @@ def test_ysplit_propose_with_the_transform_inside_equals_the_separate_passes(eng
     np.testing.assert_allclose(lq_f.cpu().numpy(), lq_ref.cpu().numpy(), rtol=1e-12, atol=1e-11)
     x_g, lj_g, none = eng.pcn_ysplit_propose_tr(sess, 9, t_dev, None)  # without the density
     assert none is None and torch.equal(x_g, x_f) and torch.equal(lj_g, lj_f)
+
+
+def test_fused_flow_step_reports_non_finite_flow_densities(eng, monkeypatch):
+    """A flow whose activations leave the fp16 operand range (|.| >= 65504) turns into NaN densities in the split-fp16
+    layers: those proposals are rejected AND counted (asmc_pcn_flow_nonfinite), so the host can say so; the fp32 MFMA
+    chain evaluates the same flow without loss."""
+    from conftest import random_coupling_flow
+
+    d, n = 32, 20000
+    flow = random_coupling_flow(d, 4, 64)
+    with torch.no_grad():
+        lin = [m for m in flow.layers[0].net if isinstance(m, torch.nn.Linear)]
+        lin[0].weight.mul_(1e5)  # weights stay inside the fp16 range, hidden activations of the first layer reach ~1e5
+        lin[1].weight.mul_(1e-5)  # ... brought back to O(1) by the next layer: finite in fp32 arithmetic
+    flow._version += 1
+    dev = flow.device_coupling(eng)
+    g = torch.Generator(eng.device).manual_seed(5)
+    x0 = torch.randn((n, d), device=eng.device, dtype=torch.float64, generator=g)
+    tgt = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    mu, eye = eng.asarray(np.zeros(d)), eng.asarray(np.eye(d))
+
+    def run():
+        x = x0.clone()
+        ll = eng.mixture_logpdf(x, tgt)
+        n_acc, _, _ = eng.pcn_mutate_flow(x, ll, ll.clone(), eng.coupling_logprob(x, dev), 0.5, mu, eye, eye, tgt, tgt, dev, 3, 0, 0.3,
+                                          2, 0, 0.234, False, "f64")
+        return int(n_acc.sum()), eng.pcn_flow_nonfinite()
+
+    acc_hs, bad_hs = run()
+    assert bad_hs > 0.3 * 2 * n and acc_hs < 0.7 * 2 * n  # many proposals overflow the operand pairs: rejected and counted
+    lq = eng.coupling_logprob(x0, dev).cpu().numpy()  # the stand-alone kernel reports them as NaN, never as a wrong number
+    assert np.isnan(lq).sum() > 0.3 * n
+    monkeypatch.setenv("ASMC_FLOW_MATH", "f32")
+    acc_32, bad_32 = run()
+    assert bad_32 == 0 and acc_32 > 0
+    assert np.all(np.isfinite(eng.coupling_logprob(x0, dev).cpu().numpy()))
+    # weights beyond the range are refused when the flow is packed for the split-fp16 kernels
+    monkeypatch.delenv("ASMC_FLOW_MATH")
+    with torch.no_grad():
+        lin[0].weight.mul_(10.0)
+    flow._version += 1
+    with pytest.raises(Exception):
+        flow.device_coupling(eng)
