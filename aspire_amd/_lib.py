@@ -26,7 +26,7 @@ COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
-ASMC_ABI_VERSION = 14
+ASMC_ABI_VERSION = 15
 ASMC_CDF_REC = 9
 ASMC_CDF_STATE = 36
 
@@ -166,6 +166,7 @@ SIGNATURES = {
     "asmc_coupling_pack_floats": (_i64, [_i, _i, _i]),
     "asmc_coupling_pack": (_i, [_i, _i, _i, POINTER(c_void_p), POINTER(c_void_p), _vp]),
     "asmc_coupling_logprob": (_i, [_vp, _i64, _i, _vp, POINTER(AsmcCoupling), _vp, _vp]),
+    "asmc_coupling_sample": (_i, [_vp, _i64, _i, POINTER(AsmcCoupling), _u64, _u64, _u32, _vp, _vp, _vp]),
     "asmc_transform_forward": (_i, [_vp, _i64, _i, _vp, _vp, _vp, POINTER(AsmcTransform), _vp]),
     "asmc_transform_inverse": (_i, [_vp, _i64, _i, _vp, _vp, _vp, POINTER(AsmcTransform), _vp]),
     "asmc_pcn_flow_work_bytes": (_i64, [_i64, _i, _i]),

@@ -30,6 +30,7 @@
 #include "asmc_common.h"
 
 #include "asmc_flow_dev.h"
+#include "asmc_pcn_dev.h"  // normal_quad_f32 (the sampling kernel draws its latent from the counter-based generator)
 
 template <int H, int W, typename XT, int FLOW_THREADS, int TPW, bool HS>
 __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, int d, const XT* __restrict__ x,
@@ -164,6 +165,82 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_logprob(int64_t n, in
             // an operand past the fp16 range makes the split products garbage: report NaN, not a finite wrong number
             const float val = (HS && !(am < FLOW_HS_MAX)) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
             if (tile < n_tiles && row < n && hh == 0) out[row] = (double)val;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sampling direction (reference flows/torch/flows.py:327-346, Flow.sample_and_log_prob): z ~ N(0, I) from the counter-based
+// generator (fp32 Box-Muller quads of asmc_pcn_dev.h, keyed by the global particle index: the draw does not depend on how
+// the population is sharded), the coupling layers inverted in reverse order on the same split-fp16 conditioner code,
+// x = z' scale + loc, and log q(x) = N(z) - sum s - sum log scale from the same pass.  Same tile layout as the density kernel.
+template <int H, int W, typename XT, int FLOW_THREADS>
+__global__ __launch_bounds__(FLOW_THREADS) void k_coupling_sample(int64_t n, int d, const float* __restrict__ packed, int n_layers,
+                                                                 const float* __restrict__ loc, const float* __restrict__ scale,
+                                                                 float ladj0, float base_const, unsigned long long seed,
+                                                                 unsigned long long gid0, uint32_t draw_id, XT* __restrict__ x,
+                                                                 double* __restrict__ out) {
+    extern __shared__ __align__(16) float sp[];
+    using FD = FlowDims<H, W>;
+    constexpr int FLOW_WAVES = FLOW_THREADS / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 31, hh = lane >> 5;
+    const int dh = d / 2;
+    flow_stage_hs<H, W, FLOW_THREADS>(sp, packed, n_layers);
+    __syncthreads();
+    const int64_t n_tiles = (n + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * FLOW_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * FLOW_WAVES) {
+        const int64_t row = tile * 32 + p;
+        const unsigned long long gid = gid0 + (unsigned long long)(row < n ? row : n - 1);
+        float xa[H / 2], xb[H / 2];
+        float q = 0.0f;
+        {   // coordinate c is element c % 4 of quad c / 4 of this particle's draw
+            int have = -1;
+            double zq[4] = {0.0, 0.0, 0.0, 0.0};
+            auto normal_at = [&](int c) {
+                if ((c >> 2) != have) {
+                    have = c >> 2;
+                    normal_quad_f32(seed, gid, draw_id, (uint32_t)have, zq[0], zq[1], zq[2], zq[3]);
+                }
+                return (float)zq[c & 3];
+            };
+#pragma unroll
+            for (int i = 0; i < H / 2; i++) {
+                const int jp = hh * (H / 2) + i;
+                xa[i] = jp < dh ? normal_at(jp) : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < H / 2; i++) {
+                const int jp = hh * (H / 2) + i;
+                xb[i] = jp < dh ? normal_at(dh + jp) : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < H / 2; i++) q += xa[i] * xa[i] + xb[i] * xb[i];
+        }
+        float ladj = 0.0f, amax = 0.0f;
+        for (int c = n_layers - 1; c >= 0; c--) {
+            const float* lp = sp + (size_t)c * FD::LAYER;
+            if ((c & 1) == 0)
+                coupling_layer_hs<H, W, true>(xa, xb, lp, lane, hh, ladj, amax);
+            else
+                coupling_layer_hs<H, W, true>(xb, xa, lp, lane, hh, ladj, amax);
+        }
+        q += __shfl_xor(q, 32);
+        const float lj = ladj + __shfl_xor(ladj, 32);
+        const float am = fmaxf(amax, __shfl_xor(amax, 32));
+        const float val = !(am < FLOW_HS_MAX) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
+        if (row < n) {
+#pragma unroll
+            for (int i = 0; i < H / 2; i++) {
+                const int jp = hh * (H / 2) + i;
+                if (jp < dh) {
+                    const float va = xa[i] * scale[jp];
+                    const float vb = xb[i] * scale[dh + jp];
+                    x[row * d + jp] = (XT)(va + loc[jp]);
+                    x[row * d + dh + jp] = (XT)(vb + loc[dh + jp]);
+                }
+            }
+            if (hh == 0) out[row] = (double)val;
         }
     }
 }
@@ -334,4 +411,60 @@ extern "C" int asmc_coupling_logprob(asmc_ctx* ctx, int64_t n, int x_dtype, cons
     if (x_dtype == ASMC_F32) return dispatch_flow<float>(ctx, n, (const float*)x_dev, flow, out_dev, st);
     asmc_set_error("asmc_coupling_logprob: bad x_dtype");
     return ASMC_ERR_ARG;
+}
+
+template <int H, int W, typename XT>
+static int launch_flow_sample(asmc_ctx* ctx, int64_t n, const asmc_coupling* f, unsigned long long seed, unsigned long long gid0,
+                              uint32_t draw_id, XT* x, double* out, hipStream_t st) {
+    using FD = FlowDims<H, W>;
+    const size_t lds = (size_t)f->n_layers * FD::LAYER * sizeof(float);
+    if (lds > 150 * 1024) {
+        asmc_set_error("asmc_coupling_sample: the flow's layers must be resident in LDS together");
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    auto kern = k_coupling_sample<H, W, XT, 512>;
+    static size_t attr_lds = 0;  // per instantiation
+    if (lds > 64 * 1024 && lds > attr_lds) {
+        ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t want = (n_tiles + 7) / 8;
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    const int grid = (int)(want < (int64_t)ctx->num_cu * per_cu ? want : (int64_t)ctx->num_cu * per_cu);
+    const float ladj0 = (float)(-f->log_scale_sum);
+    const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
+    ASMC_LAUNCH(ctx, st, "k_coupling_sample", kern, dim3(grid), dim3(512), lds, st, n, (int)f->dims, f->packed_dev, (int)f->n_layers,
+                f->loc_dev, f->scale_dev, ladj0, base_const, seed, gid0, draw_id, x, out);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+extern "C" int asmc_coupling_sample(asmc_ctx* ctx, int64_t n, int x_dtype, const asmc_coupling* flow, uint64_t seed, uint64_t gid0,
+                                    uint32_t draw_id, void* x_out_dev, double* lq_out_dev, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && flow && x_out_dev && lq_out_dev, "null pointer");
+    ASMC_REQUIRE(n > 0, "n must be positive");
+    ASMC_REQUIRE(flow->packed_dev && flow->loc_dev && flow->scale_dev, "flow parameters missing");
+    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    if (!flow_supported(flow->dims, flow->hidden) || flow->n_layers < 1 || !asmc_flow_math_split()) {
+        asmc_set_error("asmc_coupling_sample: unsupported flow shape, or the fp32 MFMA chain was asked for (split-fp16 layers only)");
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int H = flow_half_pad(flow->dims);
+#define ASMC_SAMPLE_CASE(HH, WW)                                                                                          \
+    if (H == HH && flow->hidden == WW) {                                                                                  \
+        if (x_dtype == ASMC_F64)                                                                                          \
+            return launch_flow_sample<HH, WW, double>(ctx, n, flow, seed, gid0, draw_id, (double*)x_out_dev, lq_out_dev, st); \
+        return launch_flow_sample<HH, WW, float>(ctx, n, flow, seed, gid0, draw_id, (float*)x_out_dev, lq_out_dev, st);   \
+    }
+    ASMC_SAMPLE_CASE(16, 32)
+    ASMC_SAMPLE_CASE(16, 64)
+    ASMC_SAMPLE_CASE(16, 128)
+    ASMC_SAMPLE_CASE(32, 32)
+    ASMC_SAMPLE_CASE(32, 64)
+    ASMC_SAMPLE_CASE(32, 128)
+#undef ASMC_SAMPLE_CASE
+    asmc_set_error("asmc_coupling_sample: unsupported flow shape");
+    return ASMC_ERR_UNSUPPORTED;
 }

@@ -239,7 +239,9 @@ __device__ __forceinline__ void acc_bias1(floatx16 (&acc)[NB], const float* __re
 }
 
 // one coupling layer of one 32-particle tile: cond / trans are the lane half's H / 2 coordinates
-template <int H, int W>
+// INVERSE: the sampling direction, x_b = z_b exp(s) + t (flows.py _Coupling.inverse); ladj collects -s in both directions, so
+// that base(z) + ladj is log q of the sample as well
+template <int H, int W, bool INVERSE = false>
 __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], float (&trans)[H / 2], const float* __restrict__ lp,
                                                   int lane, int hh, float& ladj, float& amax) {
     using FD = FlowDims<H, W>;
@@ -290,7 +292,12 @@ __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], fl
         const float sraw = o[q / 16][q % 16];
         const float t = o[(H / 2 + q) / 16][(H / 2 + q) % 16];
         const float s = 2.0f - 4.0f * __builtin_amdgcn_rcpf(__expf(sraw) + 1.0f);  // 2 tanh(sraw / 2), see coupling_layer
-        trans[q] = (trans[q] - t) * __expf(-s);
+        if (INVERSE) {
+            const float m = trans[q] * __expf(s);
+            trans[q] = m + t;
+        } else {
+            trans[q] = (trans[q] - t) * __expf(-s);
+        }
         ladj -= s;
     }
 }

@@ -512,6 +512,15 @@ class HipEngine:
                                              self._stream), "asmc_coupling_logprob")
         return out
 
+    def coupling_sample(self, n: int, dtype, flow: DeviceCoupling, seed: int, gid0: int, draw_id: int):
+        """(x [n, dims] in `dtype`, log q(x)): n draws from the coupling flow (include/asmc.h asmc_coupling_sample)."""
+        x = torch.empty((n, flow.dims), dtype=dtype, device=self.device)
+        lq = self.empty(n)
+        cs = flow.c_struct()
+        check(self.lib.asmc_coupling_sample(self._ctx, n, self._xdt(x), ctypes.byref(cs), int(seed) & (2**64 - 1), int(gid0),
+                                            int(draw_id) & 0xFFFFFFFF, _dptr(x), _dptr(lq), self._stream), "asmc_coupling_sample")
+        return x, lq
+
     def make_transform(self, kind, periodic, lower, upper, mean=None, std=None, eps=1e-6, unit_logj=0.0,
                        affine_logj=0.0) -> DeviceTransform:
         i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=self.device)  # noqa: E731

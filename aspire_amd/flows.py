@@ -395,7 +395,32 @@ class CouplingFlow(Flow):
         return hist
 
     @torch.no_grad()
+    def attach_engine(self, engine, sample_dtype=None, gid0: int = 0):
+        """Let `sample_and_log_prob` draw on `engine` (asmc_coupling_sample: latent draws from the counter-based generator,
+        inverted coupling layers on the matrix cores, x emitted in `sample_dtype`); `gid0` = global index of this rank's
+        first particle.  Without an engine, or for shapes the kernel does not take, the torch modules sample."""
+        self.engine, self.sample_dtype, self.gid0 = engine, sample_dtype, int(gid0)
+
+    def _sample_on_engine(self, n_samples: int):
+        e = getattr(self, "engine", None)
+        if (e is None or not hasattr(e, "coupling_sample") or self.dtype != torch.float32 or self._has_transform()
+                or getattr(self, "_engine_sampling_off", False)):
+            return None
+        try:
+            dev = self.device_coupling(e)
+            self._hip_draws = getattr(self, "_hip_draws", 0) + 1
+            return e.coupling_sample(n_samples, getattr(self, "sample_dtype", None) or self.dtype, dev,
+                                     int(self._gen.initial_seed()), getattr(self, "gid0", 0), self._hip_draws)
+        except Exception as exc:  # unsupported shape / fp32-MFMA mode: the torch modules from here on
+            logger.info("flow samples with its torch modules: %s", exc)
+            self._engine_sampling_off = True
+            return None
+
+    @torch.no_grad()
     def sample_and_log_prob(self, n_samples: int, xp=None):
+        out = self._sample_on_engine(n_samples)
+        if out is not None:
+            return out
         z = torch.randn((n_samples, self.dims), device=self.device, dtype=self.dtype, generator=self._gen)
         x, ladj = self._from_latent(z)
         lq = self._base_logp(z) - ladj

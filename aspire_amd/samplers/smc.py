@@ -164,6 +164,9 @@ class SMCSampler(MCMCSampler):
             self.engine.ensure_capacity(max(n_samples if comm.world > 1 else n_local, nf), self.dims)
         if hasattr(self.prior_flow, "gid0"):
             self.prior_flow.gid0 = comm.rank * n_local
+        if hasattr(self.prior_flow, "attach_engine") and (getattr(self, "sampler_kwargs", None) or {}).get("flow_sample_on_engine", True):
+            # the proposal draw itself on the engine (asmc_coupling_sample), emitted in the particles' dtype
+            self.prior_flow.attach_engine(self.engine, getattr(self, "x_torch_dtype", None), comm.rank * n_local)
         # sharded runs: every rank walks the same resampling draws and draws the same mutation seeds, so the ranks'
         # generators must be in the same state - rank 0's is handed to everyone (a no-op for one rank)
         self.rng = smc_math.sync_rng(comm, self.rng)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 14
+#define ASMC_ABI_VERSION 15
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -447,6 +447,13 @@ int asmc_coupling_pack(int dims, int n_layers, int hidden, const float* const* w
                        const float* const* biases_host, float* packed_host);
 int asmc_coupling_logprob(asmc_ctx* ctx, int64_t n, int x_dtype, const void* x_dev,
                           const asmc_coupling* flow, double* out_dev, asmc_stream stream);
+/* The sampling direction of the same flow (reference flows/torch/flows.py:327-346, Flow.sample_and_log_prob; the proposal draw
+ * of mcmc.py:49-110): n latent draws z ~ N(0, I) from the counter-based generator (fp32 Box-Muller; key `seed`, counter = global
+ * particle index gid0 + i and draw_id, so a draw does not depend on how the population is sharded), pushed through the inverted
+ * coupling layers on the matrix cores; x_out_dev [n, dims] in x_dtype and log q(x) of every sample from the same pass.
+ * Split-fp16 layers with every layer resident in LDS; ASMC_ERR_UNSUPPORTED otherwise (the caller samples with its own modules). */
+int asmc_coupling_sample(asmc_ctx* ctx, int64_t n, int x_dtype, const asmc_coupling* flow, uint64_t seed, uint64_t gid0,
+                         uint32_t draw_id, void* x_out_dev, double* lq_out_dev, asmc_stream stream);
 
 /* asmc_pcn_mutate_flow: asmc_pcn_mutate with the proposal density q given by a coupling flow instead
  * of a built-in mixture (params->log_q is ignored): per step propose -> log q(x') on the MFMA ->

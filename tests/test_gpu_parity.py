@@ -1794,3 +1794,53 @@ def test_fused_flow_step_reports_non_finite_flow_densities(eng, monkeypatch):
     flow._version += 1
     with pytest.raises(Exception):
         flow.device_coupling(eng)
+
+
+# ---- proposal draw from the coupling flow on the engine (asmc_coupling_sample) -----------------------------------------
+@pytest.mark.parametrize("d,hidden,n_layers,dtype", [(32, 64, 4, torch.float64), (32, 32, 3, torch.float32), (16, 64, 4, torch.float64),
+                                                      (6, 32, 2, torch.float64), (64, 32, 2, torch.float64)])
+def test_coupling_sample_is_a_draw_from_the_flow(eng, d, hidden, n_layers, dtype):
+    """The sampling kernel against the flow it samples: the reported log q equals the density kernel's (and torch's) at the
+    emitted x, the latent recovered by the torch modules is standard normal, and the draw is keyed by the global particle
+    index (a shard of the same draw is the same rows)."""
+    from scipy import stats
+
+    from conftest import random_coupling_flow
+
+    flow = random_coupling_flow(d, n_layers, hidden, seed=7)
+    dev = flow.device_coupling(eng)
+    n = 40000
+    x, lq = eng.coupling_sample(n, dtype, dev, 99, 1000, 3)
+    assert x.dtype == dtype and tuple(x.shape) == (n, d)
+    lq_k = eng.coupling_logprob(x, dev)
+    np.testing.assert_allclose(lq.cpu().numpy(), lq_k.cpu().numpy(), rtol=2e-5, atol=2e-4)
+    with torch.no_grad():
+        z, _ = flow.forward(x.float().cpu())
+        lq_t = flow.log_prob(x.float().cpu()).double().numpy()
+    np.testing.assert_allclose(lq.cpu().numpy(), lq_t, rtol=1e-4, atol=2e-3)
+    z = z.double().numpy()
+    assert np.all(np.abs(z.mean(0)) < 0.03) and np.all(np.abs(z.var(0) - 1.0) < 0.05)
+    assert stats.kstest(z[:, 0], "norm").pvalue > 1e-4 and stats.kstest(z[:, d - 1], "norm").pvalue > 1e-4
+    assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.03
+    xs, lqs = eng.coupling_sample(100, dtype, dev, 99, 1000 + 777, 3)  # rows 777.. of the same draw
+    assert torch.equal(xs, x[777:877]) and torch.equal(lqs, lq[777:877])
+    x2, _ = eng.coupling_sample(100, dtype, dev, 99, 1000, 4)  # another draw id: other rows
+    assert not torch.equal(x2, x[:100])
+
+
+def test_coupling_flow_samples_on_the_engine_inside_the_sampler(eng):
+    from aspire_amd.flows import CouplingFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    d, n = 32, 100000
+    flow = CouplingFlow(d, n_layers=4, hidden_features=(64, 64), device=eng.device, dtype=torch.float32, seed=12)
+    flow.fit(1.3 * np.random.default_rng(3).normal(size=(4000, d)), n_epochs=4)
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=eng, rng=np.random.default_rng(2))
+    eng.profile(True)
+    out = sp.sample(n, sampler_kwargs=dict(n_steps=8, step_fn="pcn"), store_sample_history=False)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert rep["k_coupling_sample"][0] >= 1
+    assert abs(float(out.log_evidence) - 0.5 * d * math.log(math.pi)) < max(5 * float(out.log_evidence_error), 0.05)
