@@ -1909,6 +1909,11 @@ int asmc_compact_valid(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
     ASMC_LAUNCH_CHECK();
     ASMC_LAUNCH(ctx, st, "k_scan_tiles_ll", k_scan_tiles_ll, dim3(1), dim3(64), 0, st, n_tiles, ctx->d_tiles_i, d_total);
     ASMC_LAUNCH_CHECK();
+    long long* h = reinterpret_cast<long long*>(ctx->h_pinned);
+    ASMC_HIP(hipMemcpyAsync(h, d_total, sizeof(long long), hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    *n_valid_host = (int64_t)h[0];
+    if (h[0] == (long long)n) return ASMC_OK;  // already compact (the usual case): nothing is copied, the caller keeps its inputs
     if (x_dtype == ASMC_F64)
         ASMC_LAUNCH(ctx, st, "k_compact_scatter<double>", k_compact_scatter<double>, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, d,
                            (const double*)x, ll, lp, lq, (const long long*)ctx->d_tiles_i, (double*)x_out,
@@ -1918,10 +1923,6 @@ int asmc_compact_valid(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
                            (const float*)x, ll, lp, lq, (const long long*)ctx->d_tiles_i, (float*)x_out,
                            ll_out, lp_out, lq_out);
     ASMC_LAUNCH_CHECK();
-    long long* h = reinterpret_cast<long long*>(ctx->h_pinned);
-    ASMC_HIP(hipMemcpyAsync(h, d_total, sizeof(long long), hipMemcpyDeviceToHost, st));
-    ASMC_HIP(hipStreamSynchronize(st));
-    *n_valid_host = (int64_t)h[0];
     return ASMC_OK;
 }
 

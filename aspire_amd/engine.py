@@ -558,6 +558,8 @@ class HipEngine:
                                           _dptr(xo), _dptr(llo), _dptr(lpo), _dptr(lqo), ctypes.byref(nv), self._stream),
               "asmc_compact_valid")
         k = int(nv.value)
+        if k == n:  # every row valid: the library copied nothing (include/asmc.h)
+            return x, ll, lp, lq
         return xo[:k], llo[:k], lpo[:k], lqo[:k]
 
     # ---- moments / pCN ---------------------------------------------------------------------

@@ -316,6 +316,14 @@ def test_gather_rows_exact(eng, d, dtype):
     assert np.array_equal(b.cpu().numpy(), lp[idx]) and np.array_equal(c.cpu().numpy(), lq[idx])
 
 
+def test_compact_valid_copies_nothing_when_every_row_is_valid(eng):
+    g = np.random.default_rng(8)
+    n, d = 5000, 5
+    x, ll, lp, lq = dev(eng, g.normal(size=(n, d)), g.normal(size=n), g.normal(size=n), g.normal(size=n))
+    got = eng.compact_valid(x, ll, lp, lq)
+    assert all(a is b for a, b in zip(got, (x, ll, lp, lq)))
+
+
 def test_compact_valid_matches_oracle(eng, oracle):
     g = np.random.default_rng(8)
     n, d = 10007, 5
