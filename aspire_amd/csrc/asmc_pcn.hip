@@ -2393,15 +2393,22 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
             rc = pcn_prepare_gamma(ctx, n, pd, step, st);
             if (rc) return rc;
             // single rank: the step's last block adapts the step size itself; sharded: the ranks' counts are exchanged first
-            PcnAdaptArgs ad = {nullptr, reinterpret_cast<unsigned long long*>(ctx->d_tilectr + 2 * ASMC_MAX_PCN_STEPS), d_counts, d_rho,
-                               d_rho_hist, prm->target_accept, n, t, prm->adapt};
-            if (!ctx->count_hook) ad.done = ctx->d_tilectr + ASMC_MAX_PCN_STEPS + t;
+            PcnAdaptArgs ad = {ctx->d_tilectr + ASMC_MAX_PCN_STEPS + t,
+                               reinterpret_cast<unsigned long long*>(ctx->d_tilectr + 2 * ASMC_MAX_PCN_STEPS),
+                               ctx->count_hook ? ctx->count_cell : nullptr, d_counts, d_rho, d_rho_hist, prm->target_accept, n, t,
+                               prm->adapt};
             rc = asmc_pcn_flow_fused_launch(ctx, n, prm->x_dtype == ASMC_F64 ? ASMC_F64 : ASMC_F32, ll, lp, lq, pd, flow, d_rho, step,
                                             ctx->d_tilectr + t, d_block, &grid, ad, st);
             if (rc) return rc;
-            if (ctx->count_hook) {
-                rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
-                if (rc) return rc;
+            if (ctx->count_hook) {  // the kernel's last block left this rank's count in the cell: exchange, then adapt
+                const int hrc = ctx->count_hook(ctx->count_hook_user, reinterpret_cast<asmc_stream>(st));
+                if (hrc != 0) {
+                    asmc_set_error("accept-count exchange hook failed (%d)", hrc);
+                    return ASMC_ERR_ARG;
+                }
+                ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, 1, (const long long*)ctx->count_cell,
+                            ctx->count_n_global, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+                ASMC_LAUNCH_CHECK();
             }
         }
         for (int t = 0; t < (fused ? 0 : n_steps); t++) {

@@ -11,6 +11,8 @@ bool asmc_flow_math_split();  // asmc_flow.hip
 struct PcnAdaptArgs {
     unsigned int* done;     // zeroed arrival counter of this step
     unsigned long long* nonfinite;  // += proposals whose flow density came out non-finite (rejected); may be NULL
+    long long* cell;        // sharded runs: the rank's count goes HERE (the exchange hook sums it over the ranks, k_pcn_adapt
+                            // closes the step); NULL: this kernel closes the step itself
     long long* counts_out;  // [t] <- accepted particles of the step
     double* rho;            // step size: read by this step, adapted for the next
     double* rho_hist;       // [t] <- the step size this step used

@@ -358,6 +358,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     if (threadIdx.x == 0) {
         c = 0;
         for (int w = 0; w < THREADS / 64; w++) c += s_cnt[w];
+        if (ad.cell) {  // sharded: hand the rank's count to the exchange hook
+            ad.cell[0] = c;
+            return;
+        }
         ad.counts_out[ad.t] = c;
         ad.rho_hist[ad.t] = rho;
         if (ad.adapt) {
