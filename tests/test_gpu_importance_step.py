@@ -36,7 +36,7 @@ def _step_by_step(eng, lld, lpd, lqd, beta0, target, tol, n, seed):
 
 
 @pytest.mark.parametrize("n,d,seed,beta0,target", [
-    (1000, 2, 3, 0.0, 0.5), (4097, 3, 4, 0.0, 0.5), (300001, 4, 5, 0.1, 0.6), (1 << 20, 4, 6, 0.0, 0.5),
+    (3, 2, 1, 0.0, 0.5), (64, 2, 2, 0.0, 0.7), (257, 2, 2, 0.2, 0.5), (1000, 2, 3, 0.0, 0.5), (4097, 3, 4, 0.0, 0.5), (300001, 4, 5, 0.1, 0.6), (1 << 20, 4, 6, 0.0, 0.5),
     (1 << 20, 2, 7, 0.25, 0.9), (1_500_003, 2, 8, 0.0, 0.5), (2_000_000, 2, 9, 0.3, 0.3)])
 def test_importance_step_equals_the_step_by_step_path(eng, n, d, seed, beta0, target):
     """n <= 1M: the persistent kernel keeps the particles in LDS; above it streams them once per phase."""
