@@ -195,6 +195,10 @@ def main():
         # `achieved` / `frac` price the ALGORITHMIC fp32 flops against the fp32-input MFMA peak, `executed_*` the fp16
         # products actually issued against the dense fp16 peak
         "flow_math": flow_math,
+        # what actually limits the kernel in its split-fp16 form (rocprofv3 --pmc, profiles/r02_pmc_fused_step_end.txt): the
+        # vector ALU (fp64 Box-Muller noise, the triangular mat-vec, the flow's bias / ReLU / hi-lo conversion / tanh), not the
+        # matrix pipe - vector ALU active 62 % and matrix pipe 20.5 % of SIMD time, 2.5 TB/s of HBM traffic
+        "limiter": "vector-ALU issue" if flow_math == "f16x2-split" else "matrix pipe (fp32-input MFMA) + vector ALU, not overlapped",
         "executed_flops_per_launch": 3 * flow_flops if flow_math == "f16x2-split" else flow_flops,
         "executed_frac_of_its_mfma_peak": (round(3 * flow_flops / (flow_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4)
                                            if flow_math == "f16x2-split" else
