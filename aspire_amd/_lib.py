@@ -26,7 +26,7 @@ COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
-ASMC_ABI_VERSION = 15
+ASMC_ABI_VERSION = 16
 ASMC_CDF_REC = 9
 ASMC_CDF_STATE = 36
 
@@ -112,6 +112,7 @@ SIGNATURES = {
     "asmc_importance_available": (_i, [_vp]),
     "asmc_pcn_flow_nonfinite": (_i64, [_vp]),
     "asmc_pcn_set_count_hook": (_i, [_vp, _vp, _vp, _vp, _i64]),
+    "asmc_pcn_set_count_rccl": (_i, [_vp, _vp, _vp, _vp, _i64]),
     "asmc_pcn_ysplit_begin": (_i, [_vp, _i64, _vp, POINTER(AsmcPcnParams), _d, _vp]),
     "asmc_pcn_ysplit_propose": (_i, [_vp, _i64, POINTER(AsmcPcnParams), _u32, _vp, _vp]),
     "asmc_pcn_ysplit_propose_tr": (_i, [_vp, _i64, POINTER(AsmcPcnParams), _u32, POINTER(AsmcTransform), _vp, POINTER(AsmcMixture), _i,

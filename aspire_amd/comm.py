@@ -16,6 +16,8 @@ is latency bound, so every scalar exchange is ONE all-gather followed by a local
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -25,6 +27,12 @@ class Comm:
 
     rank = 0
     world = 1
+    force_sharded = False  # test rig: take the sharded code path with a one-rank group (tools/rig1.sh)
+
+    @property
+    def sharded(self) -> bool:
+        """True when the population is split over ranks, i.e. when the collective forms of the hot path run."""
+        return self.world > 1 or self.force_sharded
 
     def all_gather_f64(self, arr) -> np.ndarray:
         return np.asarray(arr, dtype=np.float64)[None, ...]
@@ -83,6 +91,48 @@ class TorchDistComm(Comm):
         # gloo moves host memory only: device tensors are staged through the host (debugging / CPU-only test
         # rigs; the production backend is "nccl" = RCCL, which exchanges device memory over xGMI directly)
         self._stage = dist.get_backend(group) == "gloo"
+
+    def rccl_direct(self):
+        """(address of ncclAllReduce, ncclComm_t) of a communicator of this group's ranks that belongs to the HIP library's
+        own launches (include/asmc.h asmc_pcn_set_count_rccl): the per-step accept-count exchange is then an RCCL kernel on
+        the step kernels' stream - torch.distributed runs its collectives on a stream of its own, and every call costs
+        two stream hand-overs (about 13 us of idle GPU per step boundary, profiles/r02_rig1_*).  The communicator is made
+        the textbook way - rank 0 draws an ncclUniqueId, the group broadcasts it, every rank calls ncclCommInitRank - on
+        the RCCL that torch has loaded.  None when the backend is not RCCL (gloo rigs) or ASMC_RCCL_DIRECT=0."""
+        if hasattr(self, "_rccl"):
+            return self._rccl
+        self._rccl = None
+        if self._stage or self.device.type != "cuda" or os.environ.get("ASMC_RCCL_DIRECT", "1") == "0":
+            return None
+        import ctypes
+
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if not os.path.exists(path):
+            return None
+        lib = ctypes.CDLL(path)  # the instance torch has loaded
+
+        class UniqueId(ctypes.Structure):
+            _fields_ = [("internal", ctypes.c_byte * 128)]  # rccl.h NCCL_UNIQUE_ID_BYTES
+
+        lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+        lib.ncclGetErrorString.restype = ctypes.c_char_p
+        uid = UniqueId()
+        if self.rank == 0:
+            rc = lib.ncclGetUniqueId(ctypes.byref(uid))
+            if rc != 0:
+                raise RuntimeError(f"ncclGetUniqueId: {lib.ncclGetErrorString(rc).decode()}")
+        t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=self.device)
+        self.dist.broadcast(t, src=self._global(0), group=self.group)
+        ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = lib.ncclCommInitRank(ctypes.byref(handle), self.world, uid, self.rank)
+        if rc != 0:
+            raise RuntimeError(f"ncclCommInitRank: {lib.ncclGetErrorString(rc).decode()}")
+        self._rccl_lib = lib
+        self._rccl = (ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value, handle.value)
+        return self._rccl
 
     def _global(self, r: int) -> int:
         """Group-relative rank -> global rank (send / recv / broadcast address peers by their global rank)."""

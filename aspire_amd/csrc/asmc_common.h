@@ -93,6 +93,8 @@ struct asmc_ctx {
     void* count_hook_user;
     long long* count_cell;
     int64_t count_n_global;
+    void* rccl_allreduce;  // asmc_pcn_set_count_rccl: the process's ncclAllReduce and a communicator
+    void* rccl_comm;
     int64_t n_tiles_max;
     int gram_blocks;
     size_t gram_cap;  // doubles in d_gram (>= gram_blocks * d_max^2; the d = 32 matrix-core Gram kernel uses up to 2048 partials)

@@ -906,7 +906,9 @@ static int pcn_prepare_gamma(asmc_ctx* ctx, int64_t n, PcnDev& pd, uint32_t step
 __global__ __launch_bounds__(1024) void k_pcn_adapt(int nblocks, const long long* __restrict__ block_counts,
                                                    int64_t n, int t, long long* __restrict__ counts_out,
                                                    double* __restrict__ rho_ptr, double* __restrict__ rho_hist,
-                                                   double target, int adapt) {
+                                                   double target, int adapt, const double* __restrict__ rho_src) {
+    // rho_src: where the step size step t used is kept when it is not *rho_ptr (fused flow steps of sharded runs, which
+    // adapt in the next step's prologue: *rho_ptr is only brought up to date here, at the end of a call)
     __shared__ long long s_c[16];
     long long c = 0;
     for (int b = threadIdx.x; b < nblocks; b += 1024) c += block_counts[b];
@@ -917,15 +919,9 @@ __global__ __launch_bounds__(1024) void k_pcn_adapt(int nblocks, const long long
         c = 0;
         for (int w = 0; w < 16; w++) c += s_c[w];
         counts_out[t] = c;
-        const double rho = *rho_ptr;
+        const double rho = rho_src ? *rho_src : *rho_ptr;
         rho_hist[t] = rho;
-        if (adapt) {
-            const double acc = (double)c / (double)n;
-            double r = exp(log(rho) + (acc - target) / pow((double)(t + 1), 0.75));
-            r = r < 1e-4 ? 1e-4 : r;
-            r = r > 0.99 ? 0.99 : r;
-            *rho_ptr = r;
-        }
+        *rho_ptr = adapt ? pcn_adapt_rho(rho, c, n, target, t) : rho;
     }
 }
 
@@ -958,10 +954,10 @@ static int pcn_close_step(asmc_ctx* ctx, hipStream_t st, int grid, const long lo
             return ASMC_ERR_ARG;
         }
         ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, 1, (const long long*)ctx->count_cell,
-                    ctx->count_n_global, t, d_counts, d_rho, d_rho_hist, target, adapt);
+                    ctx->count_n_global, t, d_counts, d_rho, d_rho_hist, target, adapt, (const double*)nullptr);
     } else {
         ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, grid, d_block, n, t, d_counts, d_rho,
-                    d_rho_hist, target, adapt);
+                    d_rho_hist, target, adapt, (const double*)nullptr);
     }
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -1844,6 +1840,24 @@ int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int
     return ASMC_OK;
 }
 
+// the exchange issued by the library: RCCL's all-reduce on the step kernels' own stream (include/asmc.h)
+typedef int (*rccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+static int rccl_count_hook(void* user, asmc_stream stream) {
+    asmc_ctx* ctx = static_cast<asmc_ctx*>(user);
+    const int nccl_int64 = 4, nccl_sum = 0;  // rccl.h: ncclInt64, ncclSum
+    return reinterpret_cast<rccl_allreduce_fn>(ctx->rccl_allreduce)(ctx->count_cell, ctx->count_cell, 1, nccl_int64, nccl_sum,
+                                                                    ctx->rccl_comm, reinterpret_cast<hipStream_t>(stream));
+}
+
+int asmc_pcn_set_count_rccl(asmc_ctx* ctx, void* allreduce_fn, void* nccl_comm, int64_t* cell_dev, int64_t n_global) {
+    ASMC_REQUIRE(ctx != nullptr, "null ctx");
+    if (allreduce_fn == nullptr) return asmc_pcn_set_count_hook(ctx, nullptr, nullptr, nullptr, 0);
+    ASMC_REQUIRE(nccl_comm != nullptr, "null communicator");
+    ctx->rccl_allreduce = allreduce_fn;
+    ctx->rccl_comm = nccl_comm;
+    return asmc_pcn_set_count_hook(ctx, rccl_count_hook, ctx, cell_dev, n_global);
+}
+
 int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq,
                     const asmc_pcn_params* prm, int n_steps, uint32_t step0, double* rho_inout_host,
                     int64_t* n_accept_host, double* rho_hist_host, asmc_stream stream) {
@@ -2392,23 +2406,28 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
             const uint32_t step = step0 + (uint32_t)t;
             rc = pcn_prepare_gamma(ctx, n, pd, step, st);
             if (rc) return rc;
-            // single rank: the step's last block adapts the step size itself; sharded: the ranks' counts are exchanged first
+            // single rank: the step's last block adapts the step size itself; sharded: the ranks' counts are exchanged
+            // between the steps and the next step's prologue adapts (PcnAdaptArgs)
             PcnAdaptArgs ad = {ctx->d_tilectr + ASMC_MAX_PCN_STEPS + t,
                                reinterpret_cast<unsigned long long*>(ctx->d_tilectr + 2 * ASMC_MAX_PCN_STEPS),
-                               ctx->count_hook ? ctx->count_cell : nullptr, d_counts, d_rho, d_rho_hist, prm->target_accept, n, t,
-                               prm->adapt};
+                               ctx->count_hook ? ctx->count_cell : nullptr,
+                               ctx->count_hook && t > 0 ? ctx->count_cell : nullptr, d_counts, d_rho, d_rho_hist,
+                               prm->target_accept, ctx->count_hook ? ctx->count_n_global : n, t, prm->adapt};
             rc = asmc_pcn_flow_fused_launch(ctx, n, prm->x_dtype == ASMC_F64 ? ASMC_F64 : ASMC_F32, ll, lp, lq, pd, flow, d_rho, step,
                                             ctx->d_tilectr + t, d_block, &grid, ad, st);
             if (rc) return rc;
-            if (ctx->count_hook) {  // the kernel's last block left this rank's count in the cell: exchange, then adapt
+            if (ctx->count_hook) {  // the kernel's last block left this rank's count in the cell: exchange it
                 const int hrc = ctx->count_hook(ctx->count_hook_user, reinterpret_cast<asmc_stream>(st));
                 if (hrc != 0) {
                     asmc_set_error("accept-count exchange hook failed (%d)", hrc);
                     return ASMC_ERR_ARG;
                 }
-                ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, 1, (const long long*)ctx->count_cell,
-                            ctx->count_n_global, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
-                ASMC_LAUNCH_CHECK();
+                if (t == n_steps - 1) {  // nobody's prologue follows the last step
+                    ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, 1,
+                                (const long long*)ctx->count_cell, ctx->count_n_global, t, d_counts, d_rho, d_rho_hist,
+                                prm->target_accept, prm->adapt, (const double*)(d_rho_hist + t));
+                    ASMC_LAUNCH_CHECK();
+                }
             }
         }
         for (int t = 0; t < (fused ? 0 : n_steps); t++) {

@@ -7,19 +7,33 @@
 bool asmc_flow_math_split();  // asmc_flow.hip
 
 // step-size adaptation closed by the last block of a step's kernel (k_pcn_adapt's arithmetic); done == NULL: left to a
-// k_pcn_adapt launch (sharded runs exchange the accept counts between ranks first)
+// k_pcn_adapt launch.  Sharded runs exchange the accept counts between ranks first: the last block leaves the rank's
+// count in `cell`, the exchange hook sums it over the ranks on the stream, and the NEXT step's kernel adapts the step
+// size in its prologue (`prev_cell`: every block derives the same rho from rho_hist[t-1] and the global count, block 0
+// records them), so a step boundary is the exchange alone; a k_pcn_adapt launch closes the last step of a call.
 struct PcnAdaptArgs {
     unsigned int* done;     // zeroed arrival counter of this step
     unsigned long long* nonfinite;  // += proposals whose flow density came out non-finite (rejected); may be NULL
-    long long* cell;        // sharded runs: the rank's count goes HERE (the exchange hook sums it over the ranks, k_pcn_adapt
-                            // closes the step); NULL: this kernel closes the step itself
+    long long* cell;        // sharded runs: the rank's count goes HERE; NULL: this kernel closes the step itself
+    const long long* prev_cell;  // sharded runs, t > 0: the GLOBAL count of step t-1 (every block reads it BEFORE it
+                                 // arrives at `done`, the last block overwrites `cell` after all have arrived)
     long long* counts_out;  // [t] <- accepted particles of the step
     double* rho;            // step size: read by this step, adapted for the next
     double* rho_hist;       // [t] <- the step size this step used
     double target;
-    int64_t n;
+    int64_t n;              // population the acceptance rate refers to (sharded: the global one)
     int t, adapt;
 };
+
+// log rho += (acc - target)/(t+1)^0.75, rho clipped to [1e-4, 0.99]; one definition for every kernel that
+// adapts, so that the ranks of a sharded run and the single-rank kernels agree to the bit
+__device__ __forceinline__ double pcn_adapt_rho(double rho, long long c, int64_t n, double target, int t) {
+    const double acc = (double)c / (double)n;
+    double r = exp(log(rho) + (acc - target) / pow((double)(t + 1), 0.75));
+    r = r < 1e-4 ? 1e-4 : r;
+    r = r > 0.99 ? 0.99 : r;
+    return r;
+}
 
 // =============================================================================================
 // Philox4x32-10 (Salmon et al. SC'11; Random123 constants) and Box-Muller

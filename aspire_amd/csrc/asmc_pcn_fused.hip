@@ -83,7 +83,16 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5;
     const bool first_on_simd = __builtin_amdgcn_readfirstlane(wave) < 4;
-    const double rho = *rho_ptr;
+    double rho;
+    if (ad.prev_cell) {  // sharded, t > 0: close step t-1 here (see PcnAdaptArgs)
+        const long long cp = *ad.prev_cell;
+        const double rp = ad.rho_hist[ad.t - 1];
+        rho = ad.adapt ? pcn_adapt_rho(rp, cp, ad.n, ad.target, ad.t - 1) : rp;
+        if (blockIdx.x == 0 && threadIdx.x == 0) ad.counts_out[ad.t - 1] = cp;
+    } else {
+        rho = *rho_ptr;
+    }
+    if (ad.cell && blockIdx.x == 0 && threadIdx.x == 0) ad.rho_hist[ad.t] = rho;
     const double a = sqrt(1.0 - rho * rho);
     const int64_t n_tiles = (n + 63) / 64;
     long long n_acc = 0, n_bad = 0;
@@ -364,13 +373,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         }
         ad.counts_out[ad.t] = c;
         ad.rho_hist[ad.t] = rho;
-        if (ad.adapt) {
-            const double acc = (double)c / (double)ad.n;
-            double r = exp(log(rho) + (acc - ad.target) / pow((double)(ad.t + 1), 0.75));
-            r = r < 1e-4 ? 1e-4 : r;
-            r = r > 0.99 ? 0.99 : r;
-            *ad.rho = r;
-        }
+        if (ad.adapt) *ad.rho = pcn_adapt_rho(rho, c, ad.n, ad.target, ad.t);
     }
 }
 

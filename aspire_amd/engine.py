@@ -604,11 +604,17 @@ class HipEngine:
         with the whole step loop enqueued on the stream - after each step the library leaves this rank's accept
         count in a device cell and calls back; the callback all-reduces the cell over `comm` (RCCL, on the stream).
         `n_global=None` (or a single-rank comm) removes the hook.  Accept counts returned afterwards are global."""
-        if n_global is None or comm is None or comm.world == 1:
+        if n_global is None or comm is None or not comm.sharded:
             check(self.lib.asmc_pcn_set_count_hook(self._ctx, None, None, None, 0), "asmc_pcn_set_count_hook")
             self._hook = None
             return
         cell = torch.zeros(1, dtype=torch.int64, device=self.device)
+        direct = comm.rccl_direct() if hasattr(comm, "rccl_direct") else None
+        if direct is not None:  # the library issues the all-reduce itself, on its own stream
+            self._hook = (None, cell, None)
+            check(self.lib.asmc_pcn_set_count_rccl(self._ctx, ctypes.c_void_p(direct[0]), ctypes.c_void_p(direct[1]), _dptr(cell),
+                                                   int(n_global)), "asmc_pcn_set_count_rccl")
+            return
 
         def cb(_user, _stream):
             try:

@@ -302,7 +302,7 @@ class CouplingFlow(Flow):
         """Sharded runs (one process per GPU): every rank must evaluate the SAME flow - training is not bit-reproducible
         across processes - and draw its shard from its own stream.  Rank 0's parameters go to everyone (one all-gather of
         the flattened parameters) and the latent generator is re-seeded per rank."""
-        if comm.world == 1:
+        if not comm.sharded:
             return
         params = [p for p in self.layers.parameters()]
         flat = torch.cat([p.detach().reshape(-1).to(torch.float64) for p in params]

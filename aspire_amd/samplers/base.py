@@ -215,7 +215,7 @@ class Sampler:
     def _rank_path(self, file_path) -> Path:
         """Sharded runs: every rank checkpoints its own shard into its own file (`name.rank<r>.ext`)."""
         file_path = Path(file_path)
-        if self.comm.world == 1:
+        if not self.comm.sharded:
             return file_path
         return file_path.with_name(f"{file_path.stem}.rank{self.comm.rank}{file_path.suffix}")
 

@@ -34,7 +34,7 @@ class ImportanceSampler(Sampler):
         samples.evidence = math.exp(samples.log_evidence)
         # sum (w - Z)^2 = e^{2m} sum (e^{lw - m} - Z e^{-m})^2  with Z e^{-m} = S1 / N
         m2 = e.weights_m2(ll, lp, lq, 0.0, 1.0, st.m, st.S1 / n)
-        if comm.world > 1:
+        if comm.sharded:
             m2 = float(np.sum(comm.all_gather_f64(np.array([m2]))))
         samples.evidence_error = math.exp(st.m) * math.sqrt(m2 / (n * (n - 1))) if n > 1 else float("nan")
         samples.log_evidence_error = abs(samples.evidence_error / samples.evidence) if samples.evidence else float("nan")

@@ -77,7 +77,7 @@ class SMCSampler(MCMCSampler):
     def _global_counts(self, local_counts) -> list[int]:
         """Element-wise sum of small integer censuses over the ranks (NaN guards must agree on every rank)."""
         a = np.asarray(local_counts, dtype=np.int64)
-        if self.comm.world == 1:
+        if not self.comm.sharded:
             return [int(v) for v in a]
         return [int(v) for v in self.comm.all_gather_i64(a).sum(axis=0)]
 
@@ -96,10 +96,10 @@ class SMCSampler(MCMCSampler):
             return [smc_math.ess(s) / n for s in self._stats(samples, betas)]
 
         search_fn = None
-        sharded = self.comm.world > 1 and hasattr(self.engine, "find_beta_shard_reduce")
+        sharded = self.comm.sharded and hasattr(self.engine, "find_beta_shard_reduce")
         spec0 = samples.__dict__.get("_spec")
         have_spec = spec0 is not None and spec0["search"][2] and float(beta) == float(samples.beta)
-        if (((self.comm.world == 1 and hasattr(self.engine, "find_beta")) or sharded or have_spec) and self.device_bisection
+        if (((not self.comm.sharded and hasattr(self.engine, "find_beta")) or sharded or have_spec) and self.device_bisection
                 and beta < 1.0):
             def search_fn(beta_prev, target_eff, tol):
                 spec = samples.__dict__.get("_spec")
@@ -161,7 +161,7 @@ class SMCSampler(MCMCSampler):
         n_local = n_samples // comm.world
         if hasattr(self.engine, "ensure_capacity"):
             nf = n_final_samples or 0
-            self.engine.ensure_capacity(max(n_samples if comm.world > 1 else n_local, nf), self.dims)
+            self.engine.ensure_capacity(max(n_samples if comm.sharded else n_local, nf), self.dims)
         if hasattr(self.prior_flow, "gid0"):
             self.prior_flow.gid0 = comm.rank * n_local
         if hasattr(self.prior_flow, "attach_engine") and (getattr(self, "sampler_kwargs", None) or {}).get("flow_sample_on_engine", True):
@@ -170,7 +170,7 @@ class SMCSampler(MCMCSampler):
         # sharded runs: every rank walks the same resampling draws and draws the same mutation seeds, so the ranks'
         # generators must be in the same state - rank 0's is handed to everyone (a no-op for one rank)
         self.rng = smc_math.sync_rng(comm, self.rng)
-        if comm.world > 1 and hasattr(self.prior_flow, "sync_shards"):
+        if comm.sharded and hasattr(self.prior_flow, "sync_shards"):
             self.prior_flow.sync_shards(comm)  # the same trained flow on every rank, a separate draw stream per rank
         if getattr(self.prior_flow, "seed_from_rng", False) and resume_from is None:
             # the proposal's own draw stream follows the run's generator (in the reference flow sampling is stochastic per
@@ -336,7 +336,7 @@ class SMCSampler(MCMCSampler):
         """smc/base.py:521-530.  Sharded runs: every rank checkpoints ITS shard; the shard bookkeeping (rows per rank,
         population size, rank, world) travels in `meta` next to the reference's `beta`."""
         meta = {"beta": beta}
-        if self.comm.world > 1:
+        if self.comm.sharded:
             meta.update(rank=self.comm.rank, world=self.comm.world, n_global=samples._n_global(),
                         shard_counts=samples.shard_counts_list())
         return super().build_checkpoint_state(samples.to_numpy(), iteration, meta=meta)
@@ -467,7 +467,7 @@ class HipSMC(SMCSampler):
         n_local = x.shape[0]
         rows = torch.as_tensor((np.arange(k, dtype=np.int64) * n_local) // k, device=x.device)
         sub = x[rows].to(torch.float64).contiguous()  # strided subsample, stays on the device
-        if comm.world > 1:
+        if comm.sharded:
             sub = comm.all_gather_tensor(sub)  # the same rows on every rank: identical fits
         st = self._pcn_state
         with _single_threaded_blas():
@@ -532,7 +532,7 @@ class HipSMC(SMCSampler):
 
         if hasattr(e, "pcn_split_begin"):
             # step size and accept counts stay on the device: the host enqueues step t + 1 while step t runs
-            if comm.world > 1:
+            if comm.sharded:
                 e.set_count_hook(comm, n_global)
             try:
                 done = 0
@@ -581,7 +581,7 @@ class HipSMC(SMCSampler):
                     acc_rates.extend((n_acc / n_global).tolist())
                     done += chunk
             finally:
-                if comm.world > 1:
+                if comm.sharded:
                     e.set_count_hook(None, None)
         else:
             for t in range(n_steps):
@@ -648,14 +648,14 @@ class HipSMC(SMCSampler):
         dev_flow = self._device_flow()
         # whole step loop on the device: always for one rank; sharded when the engine can exchange the accept counts
         # between a step and its adaptation on the stream (asmc_pcn_set_count_hook), else one host round trip per step
-        on_device = comm.world == 1 or hasattr(e, "set_count_hook")
-        if comm.world > 1 and on_device:
+        on_device = not comm.sharded or hasattr(e, "set_count_hook")
+        if comm.sharded and on_device:
             e.set_count_hook(comm, n_global)
         try:
             return self._mutate_steps(particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0,
                                       acc_rates, dev_flow, on_device, n_local, n_global, gid0, nu)
         finally:
-            if comm.world > 1 and on_device:
+            if comm.sharded and on_device:
                 e.set_count_hook(None, None)
 
     def _mutate_steps(self, particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0, acc_rates,

@@ -425,7 +425,7 @@ class SMCSamples(BaseSamples):
         self.__dict__.pop("_spec", None)
         e, comm = self._eng(), self._comm()
         st4 = smc_math.pcg64_state(rng)
-        if (comm.world != 1 or not hasattr(e, "importance_step") or st4 is None or resample_mode != "exact"
+        if (comm.sharded or not hasattr(e, "importance_step") or st4 is None or resample_mode != "exact"
                 or resample_method != "multinomial" or not float(self.beta) < 1.0):
             return False
         ll, lp, lq = self._dev3()
@@ -483,7 +483,7 @@ class SMCSamples(BaseSamples):
                  want_variance: bool = False):
         """samples.py:1251-1287.  `resample_mode`: "exact" (sequential-order cdf == numpy cumsum,
         bit-exact indices) or "fast"; `resample_method`: "multinomial" (reference) or the opt-in
-        "systematic" / "stratified".  Sharded populations (`comm.world > 1`): `shard_layout="owner"` keeps every
+        "systematic" / "stratified".  Sharded populations (`comm.sharded`): `shard_layout="owner"` keeps every
         offspring on its ancestor's rank (no row exchange; ragged shards), `"slots"` gives output slot j to rank
         j // n_local and reproduces the single-rank particle order (smc_math.resample_owner / resample_indices).
         `want_variance=True` also returns log_evidence_ratio_variance(beta), which the owner layout computes in the
@@ -511,7 +511,7 @@ class SMCSamples(BaseSamples):
                                  log_prior=self._from_device(lpo), log_q=self._from_device(lqo), beta=beta,
                                  dtype=self.dtype, parameters=self.parameters, xp=self.xp, engine=self.engine,
                                  comm=self.comm)
-            if comm.world > 1:
+            if comm.sharded:
                 out.n_global = int(n_samples)
                 out.shard_counts = [int(c) for c in counts]
                 out.ragged = len(set(out.shard_counts)) > 1
@@ -617,7 +617,7 @@ def gather_global(engine, comm, idx, x, ll, lp, lq):
     World 1: one row-gather kernel (samples.py:1279-1287).  Sharded: requests are bucketed by owner
     rank, exchanged with one all-to-all of the index lists, served by the owner's gather kernel and
     returned with one all-to-all of rows; a final local gather restores the output order."""
-    if comm.world == 1:
+    if not comm.sharded:
         return engine.gather(idx, x, ll, lp, lq)
     n_local = x.shape[0]
     d = x.shape[1]

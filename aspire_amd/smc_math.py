@@ -43,13 +43,13 @@ def global_stats(engine, comm, ll, lp, lq, beta0: float, betas, n_global: int, s
     if shifts is not None:
         m = np.asarray(shifts, dtype=np.float64)
         sums = engine.weights_sums(ll, lp, lq, beta0, betas, m)
-        if comm.world > 1:
+        if comm.sharded:
             allsums = comm.all_gather_f64(sums)
             sums = allsums[0].copy()
             for r in range(1, comm.world):
                 sums = sums + allsums[r]
         return [Stats(float(m[k]), float(sums[k, 0]), float(sums[k, 1]), n_global) for k in range(betas.size)]
-    if comm.world == 1:
+    if not comm.sharded:
         st = engine.weights_stats(ll, lp, lq, beta0, betas)
         n_nan = int(st[:, 3].max())
         m, S1, S2 = st[:, 0], st[:, 1], st[:, 2]
@@ -91,7 +91,7 @@ def evidence_variance(engine, comm, ll, lp, lq, beta0: float, beta: float, st: S
     """samples.py:1230-1242: u = exp(lw - max); var(u) / (N mean(u)^2), population variance."""
     mean_u = st.S1 / st.n
     m2 = engine.weights_m2(ll, lp, lq, beta0, beta, st.m, mean_u)
-    if comm.world > 1:
+    if comm.sharded:
         parts = comm.all_gather_f64(np.array([m2]))
         m2 = float(parts[0, 0])
         for r in range(1, comm.world):
@@ -110,7 +110,7 @@ def evidence_variance_and_lse(engine, comm, ll, lp, lq, beta0: float, beta: floa
     shift = float((st.m + np.log(st.S1)) - math.log(st.n))
     mp = st.m + shift
     m2, s1p = engine.weights_m2_lse(ll, lp, lq, beta0, beta, st.m, mean_u, shift, mp)
-    if comm.world > 1:
+    if comm.sharded:
         parts = comm.all_gather_f64(np.array([m2, s1p]))
         m2, s1p = float(parts[0, 0]), float(parts[0, 1])
         for r in range(1, comm.world):
@@ -290,7 +290,7 @@ def resample_indices(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out:
         # second log-sum-exp, over the shifted log-weights (samples.py:1277)
         if s1p is not None:
             pass
-        elif comm.world == 1:
+        elif not comm.sharded:
             s1p = engine.weights_sums(ll, lp, lq, beta0, [beta], [mp], [shift])[0, 0]
         else:
             parts = comm.all_gather_f64(engine.weights_sums(ll, lp, lq, beta0, [beta], [mp], [shift]))
@@ -302,7 +302,7 @@ def resample_indices(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out:
     # cumulative sum in GLOBAL particle order.  Sharded: every rank needs the whole normalised cdf for its
     # searches anyway, so the weights (8 B/particle) are all-gathered and each rank runs the same exact
     # (sequential-order) scan over all N — no rank-to-rank dependency chain, and bitwise identical everywhere.
-    if comm.world > 1:
+    if comm.sharded:
         w = comm.all_gather_tensor(w)
         if hasattr(engine, "ensure_capacity"):
             engine.ensure_capacity(w.numel(), 1)
@@ -475,7 +475,7 @@ def sync_rng(comm, rng):
     """Put every rank's generator into rank 0's state (sharded resampling walks the same draws on every rank; mutation
     seeds are drawn from it).  PCG64 generators get the exact state words; anything else is re-seeded from an integer
     that rank 0 draws.  Returns the generator to use."""
-    if comm.world == 1:
+    if not comm.sharded:
         return rng
     st = pcg64_state(rng)
     has = comm.all_gather_i64(np.array([0 if st is None else 1], dtype=np.int64))[:, 0]
@@ -493,4 +493,4 @@ def sync_rng(comm, rng):
 
 def owner_layout_ok(engine, comm, rng, method: str, uniform_weights: bool = False) -> bool:
     """Owner layout: any resampling method, any generator - every rank walks the same draws (`sync_rng`)."""
-    return comm.world > 1 and hasattr(engine, "select_range")
+    return comm.sharded and hasattr(engine, "select_range")

@@ -132,7 +132,7 @@ class CompositeTransform:
             comm = comm or Comm()
             n_glob = z0.shape[0]
             sums = np.asarray(e.colsum(z0), dtype=np.float64)
-            if comm.world > 1:  # shards may be ragged (owner-layout resampling): the row count travels with the sums
+            if comm.sharded:  # shards may be ragged (owner-layout resampling): the row count travels with the sums
                 parts = comm.all_gather_f64(np.concatenate([sums, [float(n_glob)]]))
                 tot = parts[0].copy()
                 for r in range(1, comm.world):
@@ -140,7 +140,7 @@ class CompositeTransform:
                 sums, n_glob = tot[:-1], int(tot[-1])
             mean = sums / n_glob
             m2 = np.diag(np.asarray(e.centered_gram(z0, mean), dtype=np.float64)).copy()
-            if comm.world > 1:
+            if comm.sharded:
                 parts = comm.all_gather_f64(m2)
                 m2 = parts[0].copy()
                 for r in range(1, comm.world):

@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded-extras", action="store_true", help="N > 1: also run the extra legs")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="test rig: run the sharded code path (process group, RCCL collectives, owner layout) with a ONE-rank "
+                         "group - one GPU then shows the cost of the sharded machinery itself")
     ap.add_argument("--shard-layout", choices=["owner", "slots"], default="owner",
                     help="N > 1: offspring stay on the ancestor's rank (default) or single-rank slot order with row exchange")
     args = ap.parse_args()
@@ -80,12 +83,14 @@ def main():
     if "ASMC_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["ASMC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    sharded = world > 1
+    sharded = world > 1 or args.force_sharded
     if sharded:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -106,6 +111,11 @@ def main():
     n_mc = args.mcmc_steps
     eng = HipEngine(local_rank, n_max=n_global, d_max=max(d, 32))  # sharded: the draws of all ranks are walked on every rank
     comm = default_comm(eng.device)
+    if sharded and world == 1:  # --force-sharded: the real communicator over a one-rank group
+        from aspire_amd.comm import TorchDistComm
+
+        comm = TorchDistComm(eng.device if backend == "nccl" else torch.device("cpu"))
+        comm.force_sharded = True
 
     # ---- the workload: targets, trained proposal flow -------------------------------------------------------------
     sigma_q = 1.5
@@ -234,7 +244,8 @@ def main():
                    "flow_dtype": "f32", "flow_math": flow_math, "mcmc_steps_per_temperature": n_mc, "step_fn": args.step_fn, "noise": args.noise,
                    "resample_mode": args.resample_mode, "resample_method": "multinomial", "beta_tolerance": 1e-6,
                    "target_efficiency": 0.5,
-                   "parallelism": f"particle-shard x{world}" + (f" ({args.shard_layout} layout)" if sharded else "")},
+                   "parallelism": f"particle-shard x{world}" + (f" ({args.shard_layout} layout)" if sharded else "")
+                   + (" [--force-sharded rig: sharded code path over a one-rank RCCL group]" if sharded and world == 1 else "")},
         "mutation_steps_per_run": steps_done / args.steps, "temperatures_per_run": float(np.mean(temps)),
         "ms_per_mutation_step": dt / max(steps_done, 1) * 1e3,
         "log_evidence": {"analytic": true_logz, "z_scores": [round(z, 3) for z in zs],
@@ -426,8 +437,26 @@ def main():
             result["cpu_baseline"]["port_vs_reference"] = json.load(open(os.path.join(ROOT, "profiles", "r02_ref_ratio.json")))
         except Exception:
             pass
+    # The JSON line must be the LAST thing on the job's stdout.  RCCL writes a version banner through C stdio, which is
+    # flushed when a process exits - after Python's own prints: every rank flushes it now, ranks other than 0 close
+    # their stdout before the barrier, and rank 0 closes its own right after the line.
+    def hush():
+        import ctypes
+
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+
+    if sharded:
+        if rank != 0:
+            hush()
+        comm.barrier()
     if rank == 0:
-        print(json.dumps(result))
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(result), flush=True)
+        hush()
     if sharded:
         import torch.distributed as dist
 

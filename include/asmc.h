@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 15
+#define ASMC_ABI_VERSION 16
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -343,6 +343,10 @@ int asmc_compact_valid(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
  *   SUM of cell_dev over all ranks on `stream` (RCCL all-reduce) and return 0.  The adaptation kernel then divides by
  *   n_global, and n_accept_host reports GLOBAL counts.  hook == NULL removes it.  Applies to asmc_pcn_mutate and
  *   asmc_pcn_mutate_flow.
+ * asmc_pcn_set_count_rccl: the same exchange issued by the library itself - ncclAllReduce(cell, cell, 1, ncclInt64,
+ *   ncclSum, nccl_comm, stream) on the stream the step kernels run on, so a step boundary is one small RCCL kernel with
+ *   no stream hop and no host callback.  The library does not link RCCL: the caller passes the address of the
+ *   process's own ncclAllReduce and an ncclComm_t it has created (one rank per GPU).  allreduce_fn == NULL removes it.
  * asmc_pcn_propose / asmc_pcn_accept: the split form for arbitrary Python callables / torch flows
  *   (the host evaluates log_q, log_prior, log_likelihood on x_prop between the two calls,
  *   reference smc/base.py:507-519).  logj_old_dev / logj_new_dev (both or neither): log|det J| of the
@@ -360,6 +364,7 @@ int asmc_student_scale(asmc_ctx* ctx, int64_t m, int d, const double* xs_dev, co
                        double* r_dev, asmc_stream stream);
 typedef int (*asmc_count_hook)(void* user, asmc_stream stream);
 int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int64_t* cell_dev, int64_t n_global);
+int asmc_pcn_set_count_rccl(asmc_ctx* ctx, void* allreduce_fn, void* nccl_comm, int64_t* cell_dev, int64_t n_global);
 int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, double* sum_host,
                 asmc_stream stream);
 int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,

@@ -57,7 +57,8 @@ def main():
         a_, b_, c_ = eng.mixture_logpdf(xx, tgt), eng.mixture_logpdf(xx, tgt), eng.mixture_logpdf(xx, q)
         if hook:
             hc = TorchDistComm(eng.device)
-            hc.world = 2  # only all_reduce_sum_ is used by the hook; the sum over the one real rank is the local count
+            hc.force_sharded = True  # one real rank: the global sum is the local count
+            hc._rccl = None  # this leg: the Python callback form of the hook (torch.distributed's all-reduce)
             eng.set_count_hook(hc, n)
         try:
             return eng.pcn_mutate(xx, a_, b_, c_, 0.5, mu, eye, eye, tgt, tgt, q, 7, 0, 0.3, 12, 0, 0.234, True, "f32"), xx
@@ -67,9 +68,51 @@ def main():
     (acc0, hist0, rho0), x0 = run(False)
     (acc1, hist1, rho1), x1 = run(True)
     assert np.array_equal(acc0, acc1) and np.array_equal(hist0, hist1) and rho0 == rho1 and torch.equal(x0, x1)
+    # 4. fused flow steps (k_pcn_flow_fused): the sharded form leaves the rank's count in the cell, the exchange runs between
+    #    the steps and the NEXT step's prologue adapts - with the exchange as the Python callback and as the library's own
+    #    ncclAllReduce on a communicator made by comm.rccl_direct(); both must reproduce the single-rank run to the bit
+    from conftest import random_coupling_flow
+
+    flow = random_coupling_flow(d, 4, 64)
+    dev = flow.device_coupling(eng)
+    A = np.eye(d) + 0.05 * np.tril(np.random.default_rng(2).normal(size=(d, d)), -1)
+    Lf, Lfi = eng.asarray(A), eng.asarray(np.linalg.inv(A))
+
+    def run_flow(kind, adapt=True, steps=9):
+        xx = xd.clone()
+        a_, b_, c_ = eng.mixture_logpdf(xx, tgt), eng.mixture_logpdf(xx, tgt), eng.coupling_logprob(xx, dev)
+        if kind:
+            hc = TorchDistComm(eng.device)
+            hc.force_sharded = True
+            if kind == "python":
+                hc._rccl = None
+            else:
+                assert hc.rccl_direct() is not None
+            eng.set_count_hook(hc, n)
+        eng.profile(True)
+        try:
+            out = eng.pcn_mutate_flow(xx, a_, b_, c_, 0.5, mu, Lf, Lfi, tgt, tgt, dev, 11, 0, 0.3, steps, 3, 0.234, adapt, "f64", 0.0)
+        finally:
+            eng.set_count_hook(None, None)
+            rep = eng.profile_report()
+            eng.profile(False)
+        assert rep["k_pcn_flow_fused"][0] == steps
+        assert rep.get("k_pcn_adapt", (0, 0))[0] == (1 if kind else 0), rep.get("k_pcn_adapt")  # only the call's last step
+        return out, xx, a_, c_
+
+    for adapt in (True, False):
+        (a0, h0, r0), x0, l0, q0 = run_flow(None, adapt)
+        assert (len(set(h0.tolist())) > 1) == adapt
+        for kind in ("python", "rccl"):
+            (a1, h1, r1), x1, l1, q1 = run_flow(kind, adapt)
+            assert np.array_equal(a0, a1) and np.array_equal(h0, h1) and r0 == r1, (kind, a0, a1, h0, h1, r0, r1)
+            assert torch.equal(x0, x1) and torch.equal(l0, l1) and torch.equal(q0, q1), kind
+    (a0, h0, r0), x0, _, _ = run_flow(None, True, steps=1)  # a one-step call: no prologue ever adapts
+    (a1, h1, r1), x1, _, _ = run_flow("rccl", True, steps=1)
+    assert np.array_equal(a0, a1) and np.array_equal(h0, h1) and r0 == r1 and torch.equal(x0, x1)
     torch.cuda.synchronize()
     dist.destroy_process_group()
-    print("nccl world-1 checks ok: beta*", one[0], "accept", acc1[:3].tolist())
+    print("nccl world-1 checks ok: beta*", one[0], "accept", acc1[:3].tolist(), "flow accept", a1.tolist())
 
 
 if __name__ == "__main__":

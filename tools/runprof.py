@@ -13,6 +13,17 @@ from aspire_amd.targets import DiagGaussianMixture
 
 n, d = int(os.environ.get("N", 1 << 20)), 32
 eng = HipEngine(0, n_max=n, d_max=32)
+comm = None
+if os.environ.get("SHARDED"):  # the sharded code path over a one-rank RCCL group (tools/rig1.sh)
+    import torch.distributed as dist
+    from aspire_amd.comm import TorchDistComm
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    comm = TorchDistComm(eng.device)
+    comm.force_sharded = True
 lik = DiagGaussianMixture.isotropic(d, normalized=False)
 flow = CouplingFlow(d, n_layers=4, hidden_features=(64, 64), device=eng.device, dtype=torch.float32, seed=1234)
 flow.fit(1.5 * 0.9 * np.random.default_rng(3).normal(size=(8000, d)), n_epochs=8)
@@ -20,7 +31,7 @@ flow.fit(1.5 * 0.9 * np.random.default_rng(3).normal(size=(8000, d)), n_epochs=8
 
 def run(seed):
     sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=eng, rng=np.random.default_rng(seed),
-                dtype="float64")
+                dtype="float64", **({"comm": comm} if comm is not None else {}))
     out = sp.sample(n, sampler_kwargs=dict(n_steps=32, noise="f64", step_fn="pcn"), store_sample_history=False)
     return sp, out
 
@@ -43,5 +54,8 @@ run(10)
 torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30)
-print(s.getvalue()[:6000])
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45)
+print(s.getvalue()[:9000])
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("cumtime").print_stats("aspire_amd", 40)
+print(s.getvalue()[:9000])
