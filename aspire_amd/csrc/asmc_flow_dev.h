@@ -187,15 +187,49 @@ __device__ __forceinline__ void split8_f16(const float (&x)[8], half8& hi, half8
         const float v1 = RELU ? __int_as_float(max(__float_as_int(x[j + 1]), 0)) : x[j + 1];
         amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v0)), __builtin_fabsf(v1));  // one v_max3_f32
     }
+    // ReLU on the bit pattern: one v_max_i32 (negative floats are negative integers; fmaxf would canonicalise the MFMA
+    // result first, two instructions)
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = RELU ? __int_as_float(max(__float_as_int(x[j]), 0)) : x[j];
+#ifdef FLOW_SPLIT_CVT
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        // ReLU on the bit pattern: one v_max_i32 (negative floats are negative integers; fmaxf would canonicalise the
-        // MFMA result first, two instructions)
-        const float v = RELU ? __int_as_float(max(__float_as_int(x[j]), 0)) : x[j];
-        const _Float16 h = (_Float16)v;
+        const _Float16 h = (_Float16)v[j];
         hi[j] = h;
-        lo[j] = (_Float16)(v - (float)h);
+        lo[j] = (_Float16)(v[j] - (float)h);
     }
+#else
+    // lo = rn16(v - hi) as ONE mixed-precision FMA per element (fp16 hi taken from its half of the packed register, times
+    // -1, plus the fp32 v; v - hi is exact in fp32, so the single rounding is the conversion's), written straight into
+    // its half of the packed lo register: 3 instructions per pair instead of cvt_pk + 2 cvt + pk_add + cvt_pk.  hipcc
+    // folds fma(h, -1, v) back into a subtraction, hence the asm; its inputs are vector-ALU results (v_max_i32 /
+    // v_cvt_pk_f16_f32 / register moves, never an MFMA's D), and the trailing s_nop 1 covers the packed registers' use as
+    // an MFMA operand (cdna_hip_programming.md 5.7 item 2).
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    half2v hp[4], lp[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) hp[j] = half2v{(_Float16)v[2 * j], (_Float16)v[2 * j + 1]};
+    asm("v_fma_mixlo_f16 %0, %4, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %5, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %6, -1.0, %12 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %7, -1.0, %14 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %4, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %5, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %6, -1.0, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %7, -1.0, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(lp[0]), "=&v"(lp[1]), "=&v"(lp[2]), "=&v"(lp[3])
+        : "v"(hp[0]), "v"(hp[1]), "v"(hp[2]), "v"(hp[3]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]),
+          "v"(v[6]), "v"(v[7]));
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        hi[2 * j] = hp[j][0];
+        hi[2 * j + 1] = hp[j][1];
+        lo[2 * j] = lp[j][0];
+        lo[2 * j + 1] = lp[j][1];
+    }
+#endif
 }
 
 // out[NBO] += Wt * act(in), `in` = NBI accumulator blocks of the previous layer (pre-activation), A = the matrix's image
