@@ -2,6 +2,7 @@
 #include <stdlib.h>
 
 #include "asmc_common.h"
+#include <type_traits>
 #include "asmc_pcn_dev.h"
 #include "asmc_flow_dev.h"
 
@@ -28,6 +29,26 @@
 // buffer of the state's layout (fire-and-forget stores), accepted lanes fetch it back (cache-hot) and store it into the state.
 // The flow's weights stay resident in LDS (115 KB at d = 32, W = 64: one block of 8 waves per CU, two waves per SIMD, so
 // one wave's vector work - noise, mat-vec, accept - runs in the shadow of its partner's MFMA chains).
+#ifndef MV_DEPTH
+#define MV_DEPTH 4  // batches of mat-vec coefficients in flight (16 VGPRs each)
+#endif
+typedef double double2v __attribute__((ext_vector_type(2)));
+// row group of batch bi: the groups' batches are laid end to end, group g has 2 g + 2 of them (g (g + 1) in front of it)
+__host__ __device__ constexpr int mv_group(int bi) {
+    int g = 0;
+    while ((g + 1) * (g + 2) <= bi) g++;
+    return g;
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void mv_for_each(F& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        mv_for_each<I + 1, N>(f);
+    }
+}
+#ifndef MV_CHUNK
+#define MV_CHUNK 8  // columns of L between two ordering points of the mat-vec
+#endif
 template <typename T, int W, int NOISE, bool HS>
 __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     int64_t n, double* __restrict__ ll, double* __restrict__ lp, double* __restrict__ lq, const double* __restrict__ ptab,
@@ -192,6 +213,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         // flow's standardised fp32 input (the same (float) x' and division the stand-alone flow kernel applies)
         float xf[D];
         double qa = 0.0, qb = 0.0;
+#ifdef MV_COMPILER
 #pragma unroll
         for (int g = 0; g < D / 4; g++) {
             const int j0 = 4 * g;
@@ -205,7 +227,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
                 // counts as a memory write, so this chunk's FMAs stay in front of it and the next chunk's coefficient
                 // reads behind it.  (Left alone, instruction selection emits all ~560 LDS reads of the tile first and
                 // the FMAs after them, and the reads' results spill.)
-                if ((k & 7) == 7 || k == j0 + 3) asm volatile("" : "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3])::"memory");
+                if ((k & (MV_CHUNK - 1)) == MV_CHUNK - 1 || k == j0 + 3) asm volatile("" : "+v"(sr[0]), "+v"(sr[1]), "+v"(sr[2]), "+v"(sr[3])::"memory");
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -219,6 +241,69 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             // ... and one behind the group's epilogue, so that its 28 table reads are not issued a row group early
             asm volatile("" : "+v"(qa), "+v"(qb), "+v"(xf[j0]), "+v"(xf[j0 + 1]), "+v"(xf[j0 + 2]), "+v"(xf[j0 + 3])::"memory");
         }
+#else
+        // The coefficient reads are issued by hand, three batches ahead of their FMAs.  A batch = the two coefficients
+        // L[j0+r][2b], L[j0+r][2b+1] of the four rows of a row group (four 16-byte broadcast reads, one base register +
+        // immediate offsets); the 72 batches of the lower triangle form ONE stream across the row groups, so the queue
+        // never drains.  Left to hipcc the reads come two batches at a time with a full wait in front of every eight FMAs
+        // (66 LDS latencies per tile: 16 k of the wave's 71 k cycles per tile when it runs alone).  The waits count only
+        // this stream's own reads: LDS returns in order, so "at most 4 (P - 1) younger operations outstanding" implies the
+        // batch is there whatever hipcc has put into the queue in between.  Same FMA order per row as before.
+        {
+            constexpr int NB = (D / 4) * (D / 4 + 1), P = MV_DEPTH;  // sum over g of (2 g + 2) column pairs
+            const unsigned lbase = (unsigned)(size_t)tl + (unsigned)zoff;
+            double2v ring[P][4];
+            double sr[4] = {0.0, 0.0, 0.0, 0.0};
+            auto issue = [&](auto bc) {
+                constexpr int bi = decltype(bc)::value, g = mv_group(bi), b = bi - g * (g + 1), slot = bi % P;
+                constexpr int o0 = ((4 * g + 0) * D + 2 * b) * 8, o1 = o0 + D * 8, o2 = o1 + D * 8, o3 = o2 + D * 8;
+                auto& rg = ring[slot];  // (asm operands do not capture: name the captured objects first)
+                const unsigned lb = lbase;
+                asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"
+                             "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                             : "=&v"(rg[0]), "=&v"(rg[1]), "=&v"(rg[2]), "=&v"(rg[3])
+                             : "v"(lb), "n"(o0), "n"(o1), "n"(o2), "n"(o3));
+            };
+            auto consume = [&](auto bc) {
+                constexpr int bi = decltype(bc)::value, g = mv_group(bi), b = bi - g * (g + 1), slot = bi % P, j0 = 4 * g;
+                constexpr int ahead = (NB - 1 - bi) < (P - 1) ? (NB - 1 - bi) : (P - 1);
+                if constexpr (bi + P - 1 < NB) issue(std::integral_constant<int, (bi + P - 1 < NB ? bi + P - 1 : 0)>{});
+                auto& rg = ring[slot];
+                static_assert(ahead <= 3, "lgkmcnt holds 15");
+                if constexpr (ahead == 0)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rg[0]), "+v"(rg[1]), "+v"(rg[2]), "+v"(rg[3]));
+                else if constexpr (ahead == 1)
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(rg[0]), "+v"(rg[1]), "+v"(rg[2]), "+v"(rg[3]));
+                else if constexpr (ahead == 2)
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(rg[0]), "+v"(rg[1]), "+v"(rg[2]), "+v"(rg[3]));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(rg[0]), "+v"(rg[1]), "+v"(rg[2]), "+v"(rg[3]));
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (2 * b + e <= j0 + r) sr[r] = fma(rg[r][e], v[2 * b + e], sr[r]);
+                if constexpr (b == 2 * g + 1) {  // the row group is complete
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int j = j0 + r;
+                        const double xj = (double)(T)(Lt[T_MU + j] + sr[r]);
+                        const double ta = xj - Lt[T_LLMU + j], tb = xj - Lt[T_LPMU + j];
+                        qa = fma(ta * ta, Lt[T_LLPR + j], qa);
+                        qb = fma(tb * tb, Lt[T_LPPR + j], qb);
+                        xf[j] = flow_standardise((float)xj, locs[j], locs[D + j], locs[2 * D + j]);
+                        sr[r] = 0.0;
+                    }
+                    // pinned behind the group's epilogue, so that its 28 table reads are not issued a row group early
+                    auto &a0 = qa, &a1 = qb;
+                    auto &f0 = xf[j0], &f1 = xf[j0 + 1], &f2 = xf[j0 + 2], &f3 = xf[j0 + 3];
+                    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3)::"memory");
+                }
+            };
+            mv_for_each<0, (P - 1 < NB ? P - 1 : NB)>(issue);
+            mv_for_each<0, NB>(consume);
+        }
+#endif
         const double nll = Lt[T_LOGW] - 0.5 * qa;
         const double nlp = Lt[T_LOGW + 1] - 0.5 * qb;
         STAMP(3);
