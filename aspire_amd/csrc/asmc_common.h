@@ -16,6 +16,8 @@
 
 void asmc_set_error(const char* fmt, ...);
 struct asmc_ctx;
+int asmc_count_nonfinite_enqueue(asmc_ctx* ctx, int64_t n, const double* v, hipStream_t st);
+struct asmc_ctx;
 void asmc_prof_begin(asmc_ctx* ctx, const char* label, hipStream_t st);
 void asmc_prof_end(asmc_ctx* ctx, hipStream_t st);
 #define ASMC_PROF_MAX 8192
@@ -93,6 +95,7 @@ struct asmc_ctx {
     void* count_hook_user;
     long long* count_cell;
     int64_t count_n_global;
+    unsigned long long lq_nan;  // NaNs in the carried log q after the last mutation call (asmc_pcn_lq_nan)
     void* rccl_allreduce;  // asmc_pcn_set_count_rccl: the process's ncclAllReduce and a communicator
     void* rccl_comm;
     int64_t n_tiles_max;

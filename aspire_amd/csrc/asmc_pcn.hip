@@ -1840,6 +1840,16 @@ int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int
     return ASMC_OK;
 }
 
+// The reference checks the carried log q for NaN after every mutation (smc/minipcn.py: "Log proposal contains NaN values").
+// The count rides on the mutation call's own read-back instead of a call and a synchronisation of its own: NaN / inf counts
+// of lq -> h_pinned[8002 .. 8003], read by asmc_pcn_lq_nan after the call's synchronisation.
+static int pcn_enqueue_lq_check(asmc_ctx* ctx, int64_t n, const double* lq, hipStream_t st) {
+    const int rc = asmc_count_nonfinite_enqueue(ctx, n, lq, st);
+    if (rc) return rc;
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8002, ctx->d_keys, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, st));
+    return ASMC_OK;
+}
+
 // the exchange issued by the library: RCCL's all-reduce on the step kernels' own stream (include/asmc.h)
 typedef int (*rccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 static int rccl_count_hook(void* user, asmc_stream stream) {
@@ -1925,11 +1935,14 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
         ASMC_HIP(hipMemcpyAsync(h_counts, d_counts, sizeof(long long) * n_steps, hipMemcpyDeviceToHost, st));
         ASMC_HIP(hipMemcpyAsync(h_rho_hist, d_rho_hist, sizeof(double) * n_steps, hipMemcpyDeviceToHost, st));
         ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8000, d_rho, sizeof(double), hipMemcpyDeviceToHost, st));
+        rc = pcn_enqueue_lq_check(ctx, n, lq, st);
+        if (rc) return rc;
         ASMC_HIP(hipStreamSynchronize(st));
         for (int t = 0; t < n_steps; t++) n_accept_host[t] = (int64_t)h_counts[t];
         if (rho_hist_host)
             for (int t = 0; t < n_steps; t++) rho_hist_host[t] = h_rho_hist[t];
         *rho_inout_host = ctx->h_pinned[8000];
+        memcpy(&ctx->lq_nan, ctx->h_pinned + 8002, sizeof(unsigned long long));
         return ASMC_OK;
     }
     const bool reg_ok = pcn_reg_supported(pd.d, prm->x_dtype == ASMC_F64 ? 8 : 4, x);
@@ -1984,7 +1997,10 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     ASMC_HIP(hipMemcpyAsync(h_counts, d_counts, sizeof(long long) * n_steps, hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipMemcpyAsync(h_rho_hist, d_rho_hist, sizeof(double) * n_steps, hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8000, d_rho, sizeof(double), hipMemcpyDeviceToHost, st));
+    rc = pcn_enqueue_lq_check(ctx, n, lq, st);
+    if (rc) return rc;
     ASMC_HIP(hipStreamSynchronize(st));
+    memcpy(&ctx->lq_nan, ctx->h_pinned + 8002, sizeof(unsigned long long));
     if (dbg) fprintf(stderr, "[asmc_pcn_mutate] sync0 %.3f ms, enqueue %.3f ms, drain %.3f ms (n_steps=%d)\n", t_b - t_a, t_c - t_b, now() - t_c, n_steps);
     for (int t = 0; t < n_steps; t++) n_accept_host[t] = (int64_t)h_counts[t];
     if (rho_hist_host)
@@ -2485,7 +2501,10 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
     ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8000, d_rho, sizeof(double), hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8001, ctx->d_tilectr + 2 * ASMC_MAX_PCN_STEPS, sizeof(unsigned long long),
                             hipMemcpyDeviceToHost, st));
+    rc = pcn_enqueue_lq_check(ctx, n, lq, st);
+    if (rc) return rc;
     ASMC_HIP(hipStreamSynchronize(st));
+    memcpy(&ctx->lq_nan, ctx->h_pinned + 8002, sizeof(unsigned long long));
     for (int t = 0; t < n_steps; t++) n_accept_host[t] = (int64_t)h_counts[t];
     if (rho_hist_host)
         for (int t = 0; t < n_steps; t++) rho_hist_host[t] = h_rho_hist[t];
@@ -2495,5 +2514,7 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
 }
 
 int64_t asmc_pcn_flow_nonfinite(asmc_ctx* ctx) { return ctx ? (int64_t)ctx->flow_nonfinite : -1; }
+
+int64_t asmc_pcn_lq_nan(asmc_ctx* ctx) { return ctx ? (int64_t)ctx->lq_nan : -1; }
 
 }  // extern "C"

@@ -1369,15 +1369,25 @@ int asmc_normalized_weights(asmc_ctx* ctx, int64_t n, const double* ll, const do
     return ASMC_OK;
 }
 
+}  // extern "C"
+
+// NaN / inf counts of v[0..n) into ctx->d_keys[0..1], enqueued only (the mutation calls read them back with their own results)
+int asmc_count_nonfinite_enqueue(asmc_ctx* ctx, int64_t n, const double* v, hipStream_t st) {
+    ASMC_HIP(hipMemsetAsync(ctx->d_keys, 0, sizeof(unsigned long long) * 2, st));
+    const int grid = grid_for(n, ASMC_BLOCK * 8, ASMC_MAX_BLOCKS);
+    ASMC_LAUNCH(ctx, st, "k_count_nonfinite", k_count_nonfinite, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, v, ctx->d_keys);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+extern "C" {
 int asmc_count_nonfinite(asmc_ctx* ctx, int64_t n, const double* v, int64_t* n_nan_host,
                          int64_t* n_inf_host, asmc_stream stream) {
     ASMC_REQUIRE(ctx && v, "null pointer");
     ASMC_REQUIRE(n > 0, "n must be positive");
     hipStream_t st = as_stream(stream);
-    ASMC_HIP(hipMemsetAsync(ctx->d_keys, 0, sizeof(unsigned long long) * 2, st));
-    const int grid = grid_for(n, ASMC_BLOCK * 8, ASMC_MAX_BLOCKS);
-    ASMC_LAUNCH(ctx, st, "k_count_nonfinite", k_count_nonfinite, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, v, ctx->d_keys);
-    ASMC_LAUNCH_CHECK();
+    const int rc = asmc_count_nonfinite_enqueue(ctx, n, v, st);
+    if (rc) return rc;
     unsigned long long* h = reinterpret_cast<unsigned long long*>(ctx->h_pinned);
     ASMC_HIP(hipMemcpyAsync(h, ctx->d_keys, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipStreamSynchronize(st));

@@ -668,6 +668,10 @@ class HipEngine:
                                             _f64p(rho_hist), self._stream), "asmc_pcn_mutate_flow")
         return n_acc, rho_hist, rho_io.value
 
+    def pcn_lq_nan(self) -> int:
+        """NaNs in the carried log q after the last pcn_mutate / pcn_mutate_flow call (counted by the call itself)."""
+        return int(self.lib.asmc_pcn_lq_nan(self._ctx))
+
     def pcn_flow_nonfinite(self) -> int:
         """Proposals of the last `pcn_mutate_flow` whose flow density was not finite (rejected)."""
         return int(self.lib.asmc_pcn_flow_nonfinite(self._ctx))

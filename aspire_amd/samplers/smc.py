@@ -447,7 +447,19 @@ class HipSMC(SMCSampler):
             else:
                 raise RuntimeError("could not factor the particle covariance")
             Linv = np.linalg.inv(L)
-        return e.asarray(mean), e.asarray(np.tril(L)), e.asarray(np.tril(Linv))
+        return self._upload_reference(mean, L, Linv)
+
+    def _upload_reference(self, mean, L, Linv):
+        """(mu, tril L, tril Linv) on the device through ONE upload: each pageable host-to-device copy costs ~30 us of
+        idle GPU at a temperature boundary."""
+        d = self.dims
+        seg = -(-d // 32) * 32  # segment starts stay 256-byte aligned
+        host = np.zeros(seg + 2 * seg * d)
+        host[:d] = mean
+        host[seg:seg + d * d] = np.tril(L).reshape(-1)
+        host[seg + seg * d:seg + seg * d + d * d] = np.tril(Linv).reshape(-1)
+        dev = self.engine.asarray(host)
+        return dev[:d], dev[seg:seg + d * d].view(d, d), dev[seg + seg * d:seg + seg * d + d * d].view(d, d)
 
     def _fit_reference(self, x: torch.Tensor, n_global: int, step_fn: str):
         """(mu, L, Linv, nu) of the mutation's reference distribution: Gaussian moments of the whole population
@@ -479,7 +491,7 @@ class HipSMC(SMCSampler):
             Linv = np.linalg.inv(L)
         st["nu"] = nu
         self.history.mcmc_nu.append(float(nu) if nu <= NU_GAUSSIAN else float("inf"))
-        return e.asarray(mean), e.asarray(np.tril(L)), e.asarray(np.tril(Linv)), (nu if nu <= NU_GAUSSIAN else 0.0)
+        return (*self._upload_reference(mean, L, Linv), (nu if nu <= NU_GAUSSIAN else 0.0))
 
     def _mutate_preconditioned(self, particles: SMCSamples, x: torch.Tensor, beta: float, n_steps: int, target: float):
         """smc/minipcn.py:105-132 with a non-trivial preconditioning transform: the chain runs in z = T(x) (refit at
@@ -672,6 +684,7 @@ class HipSMC(SMCSampler):
                     n_acc, rho_hist, rho = e.pcn_mutate_flow(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed,
                                                              gid0, st["rho"], chunk, step0 + done, target, True, noise, nu)
                     st["rho"] = rho
+                    st["lq_checked"] = hasattr(e, "pcn_lq_nan")
                     acc_rates.extend((n_acc / n_global).tolist())
                     done += chunk
                     n_bad = e.pcn_flow_nonfinite() if hasattr(e, "pcn_flow_nonfinite") else 0
@@ -697,6 +710,7 @@ class HipSMC(SMCSampler):
                     n_acc, rho_hist, rho = e.pcn_mutate(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed,
                                                         gid0, st["rho"], chunk, step0 + done, target, True, noise, nu)
                     st["rho"] = rho
+                    st["lq_checked"] = hasattr(e, "pcn_lq_nan")
                     acc_rates.extend((n_acc / n_global).tolist())
                     done += chunk
             else:
@@ -752,7 +766,9 @@ class HipSMC(SMCSampler):
         st["step"] = step0 + n_steps
         self.history.mcmc_acceptance.append(float(np.mean(acc_rates)))
         self.history.mcmc_step_size.append(float(st["rho"]))
-        if self._global_counts([e.count_nonfinite(lq)[0]])[0]:
+        # the device-side loops count the NaNs of the carried log q themselves and return the count with their results
+        n_nan = e.pcn_lq_nan() if st.pop("lq_checked", False) else e.count_nonfinite(lq)[0]
+        if self._global_counts([n_nan])[0]:
             raise ValueError("Log proposal contains NaN values")
         return self._wrap(x, ll, lp, lq, beta, like=particles)
 

@@ -364,6 +364,9 @@ int asmc_student_scale(asmc_ctx* ctx, int64_t m, int d, const double* xs_dev, co
                        double* r_dev, asmc_stream stream);
 typedef int (*asmc_count_hook)(void* user, asmc_stream stream);
 int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int64_t* cell_dev, int64_t n_global);
+/* NaNs in the carried log q after the last asmc_pcn_mutate / asmc_pcn_mutate_flow call (the reference's check after every
+ * mutation, smc/minipcn.py; counted on the device and read back with the call's own results: no extra synchronisation) */
+int64_t asmc_pcn_lq_nan(asmc_ctx* ctx);
 int asmc_pcn_set_count_rccl(asmc_ctx* ctx, void* allreduce_fn, void* nccl_comm, int64_t* cell_dev, int64_t n_global);
 int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, double* sum_host,
                 asmc_stream stream);

@@ -1804,6 +1804,37 @@ def test_fused_flow_step_reports_non_finite_flow_densities(eng, monkeypatch):
         flow.device_coupling(eng)
 
 
+def test_mutation_calls_count_the_nans_of_the_carried_log_q(eng):
+    """The reference checks log q for NaN after every mutation (smc/minipcn.py).  asmc_pcn_mutate / asmc_pcn_mutate_flow count
+    them on the device and hand the count back with their own results (asmc_pcn_lq_nan): equal to asmc_count_nonfinite of the
+    array afterwards, for a clean batch and for one with poisoned rows.  (A NaN log q alone does not survive a step: the
+    tempered log-probability of such a state counts as -inf, as in smc/base.py, and the first finite proposal replaces it;
+    rows whose POSITION is NaN propose NaN and keep it.)"""
+    from conftest import random_coupling_flow
+
+    d, n = 32, 30000
+    flow = random_coupling_flow(d, 4, 64)
+    dev = flow.device_coupling(eng)
+    g = torch.Generator(eng.device).manual_seed(11)
+    x0 = torch.randn((n, d), device=eng.device, dtype=torch.float64, generator=g)
+    tgt = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    q = eng.make_mixture([-d * np.log(1.5) - 0.5 * d * np.log(2 * np.pi)], np.zeros((1, d)), np.full((1, d), 1 / 2.25))
+    mu, eye = eng.asarray(np.zeros(d)), eng.asarray(np.eye(d))
+    for poisoned in (0, 37):
+        for kind in ("flow", "mixture"):
+            x = x0.clone()
+            ll = eng.mixture_logpdf(x, tgt)
+            lq = eng.coupling_logprob(x, dev) if kind == "flow" else eng.mixture_logpdf(x, q)
+            lq[:poisoned] = float("nan")
+            x[:poisoned] = float("nan")
+            if kind == "flow":
+                eng.pcn_mutate_flow(x, ll, ll.clone(), lq, 0.5, mu, eye, eye, tgt, tgt, dev, 3, 0, 0.3, 3, 0, 0.234, True, "f64")
+            else:
+                eng.pcn_mutate(x, ll, ll.clone(), lq, 0.5, mu, eye, eye, tgt, tgt, q, 3, 0, 0.3, 3, 0, 0.234, True, "f64")
+            assert eng.pcn_lq_nan() == eng.count_nonfinite(lq)[0]
+            assert (eng.pcn_lq_nan() > 0) == (poisoned > 0)
+
+
 # ---- proposal draw from the coupling flow on the engine (asmc_coupling_sample) -----------------------------------------
 @pytest.mark.parametrize("d,hidden,n_layers,dtype", [(32, 64, 4, torch.float64), (32, 32, 3, torch.float32), (16, 64, 4, torch.float64),
                                                       (6, 32, 2, torch.float64), (64, 32, 2, torch.float64)])
