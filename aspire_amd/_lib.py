@@ -156,6 +156,7 @@ SIGNATURES = {
     "asmc_compact_valid": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pi64, _vp]),
     "asmc_colsum": (_i, [_vp, _i64, _i, _i, _vp, _pd, _vp]),
     "asmc_centered_gram": (_i, [_vp, _i64, _i, _i, _vp, _pd, _pd, _vp]),
+    "asmc_mean_gram": (_i, [_vp, _i64, _i, _i, _vp, _i64, _pd, _pd, _vp]),
     "asmc_pcn_mutate": (
         _i,
         [_vp, _i64, _vp, _vp, _vp, _vp, POINTER(AsmcPcnParams), _i, _u32, _pd, _pi64, _pd, _vp],

@@ -1729,6 +1729,48 @@ int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, dou
     return ASMC_OK;
 }
 
+__global__ void k_center_from_sum(int d, const double* __restrict__ sum, double n, double* __restrict__ center) {
+    const int j = threadIdx.x;
+    if (j < d) center[j] = sum[j] / n;
+}
+
+// Column sums and the Gram matrix centred on sum / n_mean in ONE enqueue and one synchronisation (the reference fit of a
+// single-rank temperature boundary: the centre never visits the host; same division, same kernels, same bits as
+// asmc_colsum -> host division -> asmc_centered_gram).  Shapes without the fp64-MFMA Gram kernel take the two calls.
+int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, int64_t n_mean, double* sum_host,
+                   double* gram_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && sum_host && gram_host, "null pointer");
+    ASMC_REQUIRE(n > 0 && n_mean > 0 && d > 0 && d <= ctx->d_max && d <= 128, "bad sizes (gram supports d <= 128)");
+    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    if (!(asmc_gram_mm_supported(d, x) && d <= ASMC_BLOCK) || getenv("ASMC_GRAM_GENERIC")) {
+        int rc = asmc_colsum(ctx, n, d, x_dtype, x, sum_host, stream);
+        if (rc) return rc;
+        double center[128];
+        for (int j = 0; j < d; j++) center[j] = sum_host[j] / (double)n_mean;
+        return asmc_centered_gram(ctx, n, d, x_dtype, x, center, gram_host, stream);
+    }
+    hipStream_t st = as_stream(stream);
+    int grid = grid_for(n, (ASMC_BLOCK / d) * 16, ctx->gram_blocks);
+    if (x_dtype == ASMC_F64)
+        ASMC_LAUNCH(ctx, st, "k_colsum<double>", k_colsum<double>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const double*)x, ctx->d_gram);
+    else
+        ASMC_LAUNCH(ctx, st, "k_colsum<float>", k_colsum<float>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const float*)x, ctx->d_gram);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(d), dim3(64), 0, st, grid, d, (const double*)ctx->d_gram, ctx->d_small);
+    ASMC_LAUNCH_CHECK();
+    double* d_center = ctx->d_small + 2048;
+    ASMC_LAUNCH(ctx, st, "k_center_from_sum", k_center_from_sum, dim3(1), dim3(128), 0, st, d, (const double*)ctx->d_small, (double)n_mean, d_center);
+    ASMC_LAUNCH_CHECK();
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, sizeof(double) * d, hipMemcpyDeviceToHost, st));
+    int ggrid = 0;
+    int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &ggrid, st);
+    if (rc) return rc;
+    ASMC_HIP(hipMemcpyAsync(gram_host, ctx->d_partials, sizeof(double) * d * d, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    memcpy(sum_host, ctx->h_pinned, sizeof(double) * d);
+    return ASMC_OK;
+}
+
 int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* center_host,
                        double* gram_host, asmc_stream stream) {
     ASMC_REQUIRE(ctx && x && center_host && gram_host, "null pointer");

@@ -577,6 +577,15 @@ class HipEngine:
               "asmc_centered_gram")
         return out
 
+    def mean_gram(self, x: torch.Tensor, n_mean: int) -> tuple[np.ndarray, np.ndarray]:
+        """(column sums, Gram matrix centred on sums / n_mean) in one enqueue with one synchronisation; equal to
+        colsum -> division -> centered_gram bit for bit."""
+        n, d = x.shape
+        s, g = np.empty(d), np.empty((d, d))
+        check(self.lib.asmc_mean_gram(self._ctx, n, d, self._xdt(x), _dptr(x), int(n_mean), _f64p(s), _f64p(g), self._stream),
+              "asmc_mean_gram")
+        return s, g
+
     # ---- Student-t reference fit (tpCN): per-particle half of the EM on a device-resident subsample ----------------
     def student_estep(self, xs: torch.Tensor, mu: np.ndarray, linv: np.ndarray, nu: float):
         """(z [m] on device, sum z, sum (log z - z), sum z x [d]) for the subsample xs [m, d] fp64."""

@@ -419,15 +419,19 @@ class HipSMC(SMCSampler):
         """Population mean and covariance (ddof=1) over ALL ranks -> (mu, L, Linv) on device."""
         e, comm = self.engine, self.comm
         n = n_global or x.shape[0] * comm.world
-        parts = comm.all_gather_f64(e.colsum(x))
-        s = parts[0].copy()
-        for r in range(1, comm.world):
-            s = s + parts[r]
-        mean = s / n
-        parts = comm.all_gather_f64(e.centered_gram(x, mean))
-        g = parts[0].copy()
-        for r in range(1, comm.world):
-            g = g + parts[r]
+        if not comm.sharded and hasattr(e, "mean_gram"):
+            s, g = e.mean_gram(x, n)  # both passes enqueued together: the centre never visits the host
+            mean = s / n
+        else:
+            parts = comm.all_gather_f64(e.colsum(x))
+            s = parts[0].copy()
+            for r in range(1, comm.world):
+                s = s + parts[r]
+            mean = s / n
+            parts = comm.all_gather_f64(e.centered_gram(x, mean))
+            g = parts[0].copy()
+            for r in range(1, comm.world):
+                g = g + parts[r]
         cov = g / max(n - 1, 1)
         cov = 0.5 * (cov + cov.T)
         scale = float(np.mean(np.diag(cov)))

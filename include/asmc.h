@@ -370,6 +370,11 @@ int64_t asmc_pcn_lq_nan(asmc_ctx* ctx);
 int asmc_pcn_set_count_rccl(asmc_ctx* ctx, void* allreduce_fn, void* nccl_comm, int64_t* cell_dev, int64_t n_global);
 int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, double* sum_host,
                 asmc_stream stream);
+/* asmc_colsum followed by asmc_centered_gram around sum / n_mean, as one enqueue with one synchronisation (the centre stays
+ * on the device; the results equal the two calls' bit for bit).  Reference: the population moments behind the pCN reference
+ * Gaussian, smc/minipcn.py:75-84. */
+int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, int64_t n_mean, double* sum_host,
+                   double* gram_host /* [d, d] */, asmc_stream stream);
 int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
                        const double* center_host, double* gram_host, asmc_stream stream);
 int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, double* lp_dev,

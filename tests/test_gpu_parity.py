@@ -1804,6 +1804,20 @@ def test_fused_flow_step_reports_non_finite_flow_densities(eng, monkeypatch):
         flow.device_coupling(eng)
 
 
+@pytest.mark.parametrize("n,d,dt", [(100_003, 32, torch.float64), (65_536, 128, torch.float64), (40_000, 32, torch.float32),
+                                    (5_001, 12, torch.float64), (70_000, 64, torch.float64)])
+def test_mean_gram_equals_the_two_calls(eng, n, d, dt):
+    """asmc_mean_gram (column sums -> centre on the device -> centred Gram matrix, one synchronisation) against asmc_colsum,
+    the host's division and asmc_centered_gram: the same bits, for the fp64-MFMA shapes and for the ones that fall back."""
+    g = torch.Generator(eng.device).manual_seed(n)
+    x = (0.3 + torch.randn((n, d), device=eng.device, dtype=torch.float64, generator=g)).to(dt)
+    n_mean = n + 7  # the divisor is the caller's (the global population of a sharded run)
+    s0 = eng.colsum(x)
+    g0 = eng.centered_gram(x, s0 / n_mean)
+    s1, g1 = eng.mean_gram(x, n_mean)
+    assert np.array_equal(s0, s1) and np.array_equal(g0, g1)
+
+
 def test_mutation_calls_count_the_nans_of_the_carried_log_q(eng):
     """The reference checks log q for NaN after every mutation (smc/minipcn.py).  asmc_pcn_mutate / asmc_pcn_mutate_flow count
     them on the device and hand the count back with their own results (asmc_pcn_lq_nan): equal to asmc_count_nonfinite of the
