@@ -113,7 +113,8 @@ SIGNATURES = {
     "asmc_pcn_flow_nonfinite": (_i64, [_vp]),
     "asmc_pcn_lq_nan": (_i64, [_vp]),
     "asmc_pcn_set_count_hook": (_i, [_vp, _vp, _vp, _vp, _i64]),
-    "asmc_pcn_set_count_rccl": (_i, [_vp, _vp, _vp, _vp, _i64]),
+    "asmc_set_rccl": (_i, [_vp, _vp, _vp]),
+    "asmc_pcn_set_count_rccl": (_i, [_vp, _vp, _i64]),
     "asmc_pcn_ysplit_begin": (_i, [_vp, _i64, _vp, POINTER(AsmcPcnParams), _d, _vp]),
     "asmc_pcn_ysplit_propose": (_i, [_vp, _i64, POINTER(AsmcPcnParams), _u32, _vp, _vp]),
     "asmc_pcn_ysplit_propose_tr": (_i, [_vp, _i64, POINTER(AsmcPcnParams), _u32, POINTER(AsmcTransform), _vp, POINTER(AsmcMixture), _i,
@@ -147,6 +148,7 @@ SIGNATURES = {
     "asmc_cdf_shard_chain": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _vp, _vp]),
     "asmc_cdf_shard_finish": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "asmc_select_range": (_i, [_vp, _i64, _vp, _vp, _vp, _pi64, _vp]),
+    "asmc_select_range_dev": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "asmc_systematic_uniforms": (_i, [_vp, _i64, _i64, _i64, _d, _vp, _vp, _vp]),
     "asmc_search": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "asmc_gather": (_i, [_vp, _i64, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -156,7 +158,7 @@ SIGNATURES = {
     "asmc_compact_valid": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _pi64, _vp]),
     "asmc_colsum": (_i, [_vp, _i64, _i, _i, _vp, _pd, _vp]),
     "asmc_centered_gram": (_i, [_vp, _i64, _i, _i, _vp, _pd, _pd, _vp]),
-    "asmc_mean_gram": (_i, [_vp, _i64, _i, _i, _vp, _i64, _pd, _pd, _vp]),
+    "asmc_mean_gram": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _pd, _pd, _vp]),
     "asmc_pcn_mutate": (
         _i,
         [_vp, _i64, _vp, _vp, _vp, _vp, POINTER(AsmcPcnParams), _i, _u32, _pd, _pi64, _pd, _vp],

@@ -1737,9 +1737,15 @@ __global__ void k_center_from_sum(int d, const double* __restrict__ sum, double 
 // Column sums and the Gram matrix centred on sum / n_mean in ONE enqueue and one synchronisation (the reference fit of a
 // single-rank temperature boundary: the centre never visits the host; same division, same kernels, same bits as
 // asmc_colsum -> host division -> asmc_centered_gram).  Shapes without the fp64-MFMA Gram kernel take the two calls.
-int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, int64_t n_mean, double* sum_host,
-                   double* gram_host, asmc_stream stream) {
+int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, int64_t n_mean, int across_ranks,
+                   double* sum_host, double* gram_host, asmc_stream stream) {
     ASMC_REQUIRE(ctx && x && sum_host && gram_host, "null pointer");
+    typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    const allreduce_fn allreduce = reinterpret_cast<allreduce_fn>(ctx->rccl_allreduce);
+    const int nccl_f64 = 8, nccl_sum = 0;  // rccl.h: ncclFloat64, ncclSum
+    ASMC_REQUIRE(!across_ranks || (allreduce && ctx->rccl_comm), "across_ranks needs asmc_set_rccl");
+    ASMC_REQUIRE(!across_ranks || (asmc_gram_mm_supported(d, x) && d <= ASMC_BLOCK && !getenv("ASMC_GRAM_GENERIC")),
+                 "across_ranks: shape without the device-side path (use asmc_colsum / asmc_centered_gram and merge on the host)");
     ASMC_REQUIRE(n > 0 && n_mean > 0 && d > 0 && d <= ctx->d_max && d <= 128, "bad sizes (gram supports d <= 128)");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
     if (!(asmc_gram_mm_supported(d, x) && d <= ASMC_BLOCK) || getenv("ASMC_GRAM_GENERIC")) {
@@ -1758,6 +1764,10 @@ int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, 
     ASMC_LAUNCH_CHECK();
     ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(d), dim3(64), 0, st, grid, d, (const double*)ctx->d_gram, ctx->d_small);
     ASMC_LAUNCH_CHECK();
+    if (across_ranks && allreduce(ctx->d_small, ctx->d_small, (size_t)d, nccl_f64, nccl_sum, ctx->rccl_comm, st) != 0) {
+        asmc_set_error("asmc_mean_gram: ncclAllReduce failed");
+        return ASMC_ERR_ARG;
+    }
     double* d_center = ctx->d_small + 2048;
     ASMC_LAUNCH(ctx, st, "k_center_from_sum", k_center_from_sum, dim3(1), dim3(128), 0, st, d, (const double*)ctx->d_small, (double)n_mean, d_center);
     ASMC_LAUNCH_CHECK();
@@ -1765,6 +1775,10 @@ int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, 
     int ggrid = 0;
     int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &ggrid, st);
     if (rc) return rc;
+    if (across_ranks && allreduce(ctx->d_partials, ctx->d_partials, (size_t)d * d, nccl_f64, nccl_sum, ctx->rccl_comm, st) != 0) {
+        asmc_set_error("asmc_mean_gram: ncclAllReduce failed");
+        return ASMC_ERR_ARG;
+    }
     ASMC_HIP(hipMemcpyAsync(gram_host, ctx->d_partials, sizeof(double) * d * d, hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipStreamSynchronize(st));
     memcpy(sum_host, ctx->h_pinned, sizeof(double) * d);
@@ -1901,12 +1915,18 @@ static int rccl_count_hook(void* user, asmc_stream stream) {
                                                                     ctx->rccl_comm, reinterpret_cast<hipStream_t>(stream));
 }
 
-int asmc_pcn_set_count_rccl(asmc_ctx* ctx, void* allreduce_fn, void* nccl_comm, int64_t* cell_dev, int64_t n_global) {
+int asmc_set_rccl(asmc_ctx* ctx, void* allreduce_fn, void* nccl_comm) {
     ASMC_REQUIRE(ctx != nullptr, "null ctx");
-    if (allreduce_fn == nullptr) return asmc_pcn_set_count_hook(ctx, nullptr, nullptr, nullptr, 0);
-    ASMC_REQUIRE(nccl_comm != nullptr, "null communicator");
+    ASMC_REQUIRE((allreduce_fn == nullptr) == (nccl_comm == nullptr), "function and communicator come together");
     ctx->rccl_allreduce = allreduce_fn;
     ctx->rccl_comm = nccl_comm;
+    return ASMC_OK;
+}
+
+int asmc_pcn_set_count_rccl(asmc_ctx* ctx, int64_t* cell_dev, int64_t n_global) {
+    ASMC_REQUIRE(ctx != nullptr, "null ctx");
+    if (cell_dev == nullptr) return asmc_pcn_set_count_hook(ctx, nullptr, nullptr, nullptr, 0);
+    ASMC_REQUIRE(ctx->rccl_allreduce && ctx->rccl_comm, "asmc_set_rccl first");
     return asmc_pcn_set_count_hook(ctx, rccl_count_hook, ctx, cell_dev, n_global);
 }
 

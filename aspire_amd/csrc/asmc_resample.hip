@@ -1646,6 +1646,35 @@ int asmc_select_range(asmc_ctx* ctx, int64_t n, const double* u_dev, const doubl
     return ASMC_OK;
 }
 
+__global__ void k_range_info(const long long* __restrict__ total, const double* __restrict__ edges, long long* __restrict__ info) {
+    info[0] = total[0];
+    info[1] = (long long)llrint(edges[0]);
+}
+
+// asmc_select_range without the synchronisation: the count and the slice's failure flag (edges_dev[0], asmc_cdf_shard_finish)
+// go to info_dev[0..1] (int64) - owner-layout resampling all-gathers them over the ranks and reads everything back at once
+int asmc_select_range_dev(asmc_ctx* ctx, int64_t n, const double* u_dev, const double* edges_dev, double* out_dev,
+                          int64_t* info_dev, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && u_dev && edges_dev && out_dev && info_dev, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+    hipStream_t st = as_stream(stream);
+    const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+    long long* d_total = ctx->d_tiles_i + ctx->n_tiles_max * 8;
+    const double* lohi_dev = edges_dev + 2;
+    ASMC_LAUNCH(ctx, st, "k_range_count", k_range_count, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, u_dev, lohi_dev,
+                ctx->d_tiles_i);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_scan_tiles_ll", k_scan_tiles_ll, dim3(1), dim3(64), 0, st, n_tiles, ctx->d_tiles_i, d_total);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_range_scatter", k_range_scatter, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, u_dev, lohi_dev,
+                (const long long*)ctx->d_tiles_i, out_dev);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_range_info", k_range_info, dim3(1), dim3(1), 0, st, (const long long*)d_total, edges_dev,
+                reinterpret_cast<long long*>(info_dev));
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
 int asmc_cdf_normalize(asmc_ctx* ctx, int64_t n, double* cdf, double last, asmc_stream stream) {
     ASMC_REQUIRE(ctx && cdf, "null pointer");
     ASMC_REQUIRE(n > 0, "n must be positive");

@@ -10,6 +10,7 @@ so that the host logic (`smc_math.py`, the sampler loop) can be exercised withou
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -426,6 +427,16 @@ class HipEngine:
                                          self._stream), "asmc_select_range")
         return out[: int(cnt.value)]
 
+    def select_range_dev(self, u: torch.Tensor, edges: torch.Tensor):
+        """`select_range(u, edges[2:4])` enqueued only: (out buffer of u's length, int64 device tensor {kept, edges[0] as the
+        failure flag}); the caller slices the buffer once it has read the count."""
+        assert u.dtype == torch.float64 and u.is_contiguous() and edges.dtype == torch.float64 and edges.numel() >= 4
+        out = torch.empty_like(u)
+        info = torch.empty(2, dtype=torch.int64, device=self.device)
+        check(self.lib.asmc_select_range_dev(self._ctx, u.numel(), _dptr(u), _dptr(edges), _dptr(out), _dptr(info),
+                                             self._stream), "asmc_select_range_dev")
+        return out, info
+
     def cdf_normalize_last(self, cdf: torch.Tensor) -> torch.Tensor:
         check(self.lib.asmc_cdf_normalize_last(self._ctx, cdf.numel(), _dptr(cdf), self._stream), "asmc_cdf_normalize_last")
         return cdf
@@ -577,14 +588,21 @@ class HipEngine:
               "asmc_centered_gram")
         return out
 
-    def mean_gram(self, x: torch.Tensor, n_mean: int) -> tuple[np.ndarray, np.ndarray]:
+    def mean_gram(self, x: torch.Tensor, n_mean: int, comm=None) -> tuple[np.ndarray, np.ndarray]:
         """(column sums, Gram matrix centred on sums / n_mean) in one enqueue with one synchronisation; equal to
-        colsum -> division -> centered_gram bit for bit."""
+        colsum -> division -> centered_gram bit for bit.  With a sharded `comm` that has an RCCL communicator for the
+        library (`use_rccl`), both are summed over the ranks on the stream (n_mean: the global population)."""
         n, d = x.shape
         s, g = np.empty(d), np.empty((d, d))
-        check(self.lib.asmc_mean_gram(self._ctx, n, d, self._xdt(x), _dptr(x), int(n_mean), _f64p(s), _f64p(g), self._stream),
-              "asmc_mean_gram")
+        across = int(comm is not None and comm.sharded)
+        check(self.lib.asmc_mean_gram(self._ctx, n, d, self._xdt(x), _dptr(x), int(n_mean), across, _f64p(s), _f64p(g),
+                                      self._stream), "asmc_mean_gram")
         return s, g
+
+    def mean_gram_across_ranks_ok(self, x: torch.Tensor, comm) -> bool:
+        """The shapes asmc_mean_gram sums over the ranks itself (the fp64-MFMA Gram kernel's), given a communicator."""
+        return (x.shape[1] in (32, 64, 128) and x.data_ptr() % 16 == 0 and not os.environ.get("ASMC_GRAM_GENERIC")
+                and self.use_rccl(comm))
 
     # ---- Student-t reference fit (tpCN): per-particle half of the EM on a device-resident subsample ----------------
     def student_estep(self, xs: torch.Tensor, mu: np.ndarray, linv: np.ndarray, nu: float):
@@ -608,6 +626,17 @@ class HipEngine:
               "asmc_student_scale")
         return r
 
+    def use_rccl(self, comm) -> bool:
+        """Hand the library the communicator `comm.rccl_direct()` makes for the collectives it issues itself (include/asmc.h
+        asmc_set_rccl); False when the communicator has none (single rank, gloo rigs, ASMC_RCCL_DIRECT=0)."""
+        direct = comm.rccl_direct() if comm is not None and hasattr(comm, "rccl_direct") else None
+        if direct is None:
+            return False
+        if getattr(self, "_rccl_set", None) != direct:
+            check(self.lib.asmc_set_rccl(self._ctx, ctypes.c_void_p(direct[0]), ctypes.c_void_p(direct[1])), "asmc_set_rccl")
+            self._rccl_set = direct
+        return True
+
     def set_count_hook(self, comm, n_global: int | None):
         """Sharded mutation: let `pcn_mutate` / `pcn_mutate_flow` adapt the step size from the GLOBAL acceptance rate
         with the whole step loop enqueued on the stream - after each step the library leaves this rank's accept
@@ -618,11 +647,9 @@ class HipEngine:
             self._hook = None
             return
         cell = torch.zeros(1, dtype=torch.int64, device=self.device)
-        direct = comm.rccl_direct() if hasattr(comm, "rccl_direct") else None
-        if direct is not None:  # the library issues the all-reduce itself, on its own stream
+        if self.use_rccl(comm):  # the library issues the all-reduce itself, on its own stream
             self._hook = (None, cell, None)
-            check(self.lib.asmc_pcn_set_count_rccl(self._ctx, ctypes.c_void_p(direct[0]), ctypes.c_void_p(direct[1]), _dptr(cell),
-                                                   int(n_global)), "asmc_pcn_set_count_rccl")
+            check(self.lib.asmc_pcn_set_count_rccl(self._ctx, _dptr(cell), int(n_global)), "asmc_pcn_set_count_rccl")
             return
 
         def cb(_user, _stream):

@@ -422,6 +422,9 @@ class HipSMC(SMCSampler):
         if not comm.sharded and hasattr(e, "mean_gram"):
             s, g = e.mean_gram(x, n)  # both passes enqueued together: the centre never visits the host
             mean = s / n
+        elif hasattr(e, "mean_gram_across_ranks_ok") and e.mean_gram_across_ranks_ok(x, comm):
+            s, g = e.mean_gram(x, n, comm)  # ... and both sums cross the ranks on the stream (RCCL all-reduce)
+            mean = s / n
         else:
             parts = comm.all_gather_f64(e.colsum(x))
             s = parts[0].copy()

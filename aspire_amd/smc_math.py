@@ -456,8 +456,14 @@ def resample_owner(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out: i
     u_all = draw_uniforms(engine, rng, int(n_out), 0, int(n_out), method)
     for attempt in range(2):
         cdf, edges = global_cdf_slice(engine, comm, w, counts, approx_carry, mode, force_replicated or attempt == 1)
-        u_kept = engine.select_range(u_all, edges[2:4])  # synchronises: everything above is enqueued by now
-        info = comm.all_gather_i64(np.array([u_kept.numel(), int(round(float(edges[0].item())))], dtype=np.int64))
+        if hasattr(engine, "select_range_dev") and edges.is_contiguous() and edges.numel() == 4:
+            # count and failure flag stay on the device until the ranks' pairs have been gathered: one synchronisation
+            buf, info_dev = engine.select_range_dev(u_all, edges)
+            info = engine.to_numpy(comm.all_gather_tensor(info_dev)).reshape(world, 2)
+            u_kept = buf[: int(info[rank, 0])]
+        else:
+            u_kept = engine.select_range(u_all, edges[2:4])  # synchronises: everything above is enqueued by now
+            info = comm.all_gather_i64(np.array([u_kept.numel(), int(round(float(edges[0].item())))], dtype=np.int64))
         if not info[:, 1].any():
             break
         if attempt == 1:

@@ -274,6 +274,11 @@ int asmc_cdf_shard_finish(asmc_ctx* ctx, int64_t n, const double* w_dev, double*
                           asmc_stream stream);
 int asmc_select_range(asmc_ctx* ctx, int64_t n, const double* u_dev, const double* lohi_dev, double* out_dev,
                       int64_t* count_host, asmc_stream stream);
+/* the same selection, enqueued only: info_dev[0] = kept count, info_dev[1] = the failure flag edges_dev[0] of the slice
+ * (edges_dev = {fail, total, lo, hi} as asmc_cdf_shard_finish leaves them) - the caller all-gathers info_dev over the ranks
+ * and reads all of it back with one synchronisation */
+int asmc_select_range_dev(asmc_ctx* ctx, int64_t n, const double* u_dev, const double* edges_dev, double* out_dev,
+                          int64_t* info_dev, asmc_stream stream);
 
 /* Sharded multinomial resampling with the offspring kept on the ancestor's rank: every rank walks
  * the SAME n_total draws of the PCG64 stream and keeps those inside its own slice [lo, hi) of the global cdf, mapped
@@ -343,10 +348,11 @@ int asmc_compact_valid(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
  *   SUM of cell_dev over all ranks on `stream` (RCCL all-reduce) and return 0.  The adaptation kernel then divides by
  *   n_global, and n_accept_host reports GLOBAL counts.  hook == NULL removes it.  Applies to asmc_pcn_mutate and
  *   asmc_pcn_mutate_flow.
- * asmc_pcn_set_count_rccl: the same exchange issued by the library itself - ncclAllReduce(cell, cell, 1, ncclInt64,
- *   ncclSum, nccl_comm, stream) on the stream the step kernels run on, so a step boundary is one small RCCL kernel with
- *   no stream hop and no host callback.  The library does not link RCCL: the caller passes the address of the
- *   process's own ncclAllReduce and an ncclComm_t it has created (one rank per GPU).  allreduce_fn == NULL removes it.
+ * asmc_set_rccl: hands the library a communicator of its own for the collectives it issues ITSELF, on the stream its
+ *   kernels run on (no stream hop, no host callback).  The library does not link RCCL: the caller passes the address of
+ *   the process's own ncclAllReduce and an ncclComm_t it has created (one rank per GPU); NULL, NULL removes them.
+ * asmc_pcn_set_count_rccl: the accept-count exchange as ncclAllReduce(cell, cell, 1, ncclInt64, ncclSum) on that
+ *   communicator: a step boundary is one small RCCL kernel.  cell_dev == NULL removes it.
  * asmc_pcn_propose / asmc_pcn_accept: the split form for arbitrary Python callables / torch flows
  *   (the host evaluates log_q, log_prior, log_likelihood on x_prop between the two calls,
  *   reference smc/base.py:507-519).  logj_old_dev / logj_new_dev (both or neither): log|det J| of the
@@ -367,14 +373,18 @@ int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int
 /* NaNs in the carried log q after the last asmc_pcn_mutate / asmc_pcn_mutate_flow call (the reference's check after every
  * mutation, smc/minipcn.py; counted on the device and read back with the call's own results: no extra synchronisation) */
 int64_t asmc_pcn_lq_nan(asmc_ctx* ctx);
-int asmc_pcn_set_count_rccl(asmc_ctx* ctx, void* allreduce_fn, void* nccl_comm, int64_t* cell_dev, int64_t n_global);
+int asmc_set_rccl(asmc_ctx* ctx, void* allreduce_fn, void* nccl_comm);
+int asmc_pcn_set_count_rccl(asmc_ctx* ctx, int64_t* cell_dev, int64_t n_global);
 int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, double* sum_host,
                 asmc_stream stream);
 /* asmc_colsum followed by asmc_centered_gram around sum / n_mean, as one enqueue with one synchronisation (the centre stays
- * on the device; the results equal the two calls' bit for bit).  Reference: the population moments behind the pCN reference
+ * on the device; the results equal the two calls' bit for bit).  across_ranks != 0 (sharded populations, after asmc_set_rccl):
+ * both results are summed over the ranks by ncclAllReduce on the stream - every rank receives the same bits - and n_mean is
+ * the global population; fp64-MFMA shapes only (d in {32, 64, 128} rows 16-byte aligned), other shapes return an error and
+ * the caller merges the two calls' partials on the host.  Reference: the population moments behind the pCN reference
  * Gaussian, smc/minipcn.py:75-84. */
-int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, int64_t n_mean, double* sum_host,
-                   double* gram_host /* [d, d] */, asmc_stream stream);
+int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, int64_t n_mean, int across_ranks,
+                   double* sum_host, double* gram_host /* [d, d] */, asmc_stream stream);
 int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
                        const double* center_host, double* gram_host, asmc_stream stream);
 int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, double* lp_dev,

@@ -110,6 +110,13 @@ def main():
     (a0, h0, r0), x0, _, _ = run_flow(None, True, steps=1)  # a one-step call: no prologue ever adapts
     (a1, h1, r1), x1, _, _ = run_flow("rccl", True, steps=1)
     assert np.array_equal(a0, a1) and np.array_equal(h0, h1) and r0 == r1 and torch.equal(x0, x1)
+    # 5. reference fit: column sums and centred Gram matrix summed over the ranks by the library's own all-reduces
+    hc = TorchDistComm(eng.device)
+    hc.force_sharded = True
+    assert eng.mean_gram_across_ranks_ok(xd, hc)
+    s0, g0 = eng.mean_gram(xd, n)
+    s1, g1 = eng.mean_gram(xd, n, hc)
+    assert np.array_equal(s0, s1) and np.array_equal(g0, g1)
     torch.cuda.synchronize()
     dist.destroy_process_group()
     print("nccl world-1 checks ok: beta*", one[0], "accept", acc1[:3].tolist(), "flow accept", a1.tolist())
