@@ -159,6 +159,8 @@ SIGNATURES = {
     "asmc_colsum": (_i, [_vp, _i64, _i, _i, _vp, _pd, _vp]),
     "asmc_centered_gram": (_i, [_vp, _i64, _i, _i, _vp, _pd, _pd, _vp]),
     "asmc_mean_gram": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _pd, _pd, _vp]),
+    "asmc_mean_gram_enqueue": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _vp]),
+    "asmc_mean_gram_fetch": (_i, [_vp, _i, _pd, _pd, _vp]),
     "asmc_pcn_mutate": (
         _i,
         [_vp, _i64, _vp, _vp, _vp, _vp, POINTER(AsmcPcnParams), _i, _u32, _pd, _pi64, _pd, _vp],

@@ -110,6 +110,8 @@ struct asmc_ctx {
     const char** prof_label;    // [ASMC_PROF_MAX]
     // pinned host staging for scalar read-back / small uploads
     double* h_pinned;  // [8192] doubles
+    double* h_gram;    // [128 + 128 * 128] doubles: asmc_mean_gram's results (sum | Gram) until asmc_mean_gram_fetch
+    int gram_pending_d;  // d of an enqueued, not yet fetched asmc_mean_gram (0: none)
 };
 
 // asmc_weights.hip: the persistent weight kernel of asmc_importance_step (results in ctx->d_small + 2560 .. + 48)

@@ -143,6 +143,7 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     dmalloc((void**)&c->d_select, sizeof(long long) * (2 * (ASMC_SELECT_THREADS / 64) + 8));
     dmalloc((void**)&c->d_ptab, sizeof(double) * (2 * 32 * 32 + 32 + 3 * ASMC_MAX_COMPONENTS * (1 + 2 * 32) + 64));
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_pinned, sizeof(double) * 8192, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_gram, sizeof(double) * (128 + 128 * 128), hipHostMallocDefault);
     if (e != hipSuccess) {
         asmc_set_error("asmc_ctx_create: allocation failed: %s", hipGetErrorString(e));
         asmc_ctx_destroy(c);
@@ -182,6 +183,7 @@ int asmc_ctx_destroy(asmc_ctx* c) {
         delete[] c->prof_label;
     }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_gram) (void)hipHostFree(c->h_gram);
     delete c;
     return ASMC_OK;
 }

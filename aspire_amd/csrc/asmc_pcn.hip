@@ -1735,26 +1735,20 @@ __global__ void k_center_from_sum(int d, const double* __restrict__ sum, double 
 }
 
 // Column sums and the Gram matrix centred on sum / n_mean in ONE enqueue and one synchronisation (the reference fit of a
-// single-rank temperature boundary: the centre never visits the host; same division, same kernels, same bits as
-// asmc_colsum -> host division -> asmc_centered_gram).  Shapes without the fp64-MFMA Gram kernel take the two calls.
-int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, int64_t n_mean, int across_ranks,
-                   double* sum_host, double* gram_host, asmc_stream stream) {
-    ASMC_REQUIRE(ctx && x && sum_host && gram_host, "null pointer");
+// temperature boundary: the centre never visits the host; same division, same kernels, same bits as asmc_colsum -> host
+// division -> asmc_centered_gram).  _enqueue leaves both results on their way to pinned memory, _fetch waits for the stream
+// and hands them out: a caller with other work on the stream (the importance step's chain) pays one synchronisation for all.
+int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, int64_t n_mean, int across_ranks,
+                           asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x, "null pointer");
+    ASMC_REQUIRE(n > 0 && n_mean > 0 && d > 0 && d <= ctx->d_max && d <= 128, "bad sizes (gram supports d <= 128)");
+    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    ASMC_REQUIRE(asmc_gram_mm_supported(d, x) && d <= ASMC_BLOCK && !getenv("ASMC_GRAM_GENERIC"),
+                 "shape without the device-side path (asmc_mean_gram falls back to the two calls; across_ranks: merge on the host)");
     typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
     const allreduce_fn allreduce = reinterpret_cast<allreduce_fn>(ctx->rccl_allreduce);
     const int nccl_f64 = 8, nccl_sum = 0;  // rccl.h: ncclFloat64, ncclSum
     ASMC_REQUIRE(!across_ranks || (allreduce && ctx->rccl_comm), "across_ranks needs asmc_set_rccl");
-    ASMC_REQUIRE(!across_ranks || (asmc_gram_mm_supported(d, x) && d <= ASMC_BLOCK && !getenv("ASMC_GRAM_GENERIC")),
-                 "across_ranks: shape without the device-side path (use asmc_colsum / asmc_centered_gram and merge on the host)");
-    ASMC_REQUIRE(n > 0 && n_mean > 0 && d > 0 && d <= ctx->d_max && d <= 128, "bad sizes (gram supports d <= 128)");
-    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
-    if (!(asmc_gram_mm_supported(d, x) && d <= ASMC_BLOCK) || getenv("ASMC_GRAM_GENERIC")) {
-        int rc = asmc_colsum(ctx, n, d, x_dtype, x, sum_host, stream);
-        if (rc) return rc;
-        double center[128];
-        for (int j = 0; j < d; j++) center[j] = sum_host[j] / (double)n_mean;
-        return asmc_centered_gram(ctx, n, d, x_dtype, x, center, gram_host, stream);
-    }
     hipStream_t st = as_stream(stream);
     int grid = grid_for(n, (ASMC_BLOCK / d) * 16, ctx->gram_blocks);
     if (x_dtype == ASMC_F64)
@@ -1771,7 +1765,7 @@ int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, 
     double* d_center = ctx->d_small + 2048;
     ASMC_LAUNCH(ctx, st, "k_center_from_sum", k_center_from_sum, dim3(1), dim3(128), 0, st, d, (const double*)ctx->d_small, (double)n_mean, d_center);
     ASMC_LAUNCH_CHECK();
-    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned, ctx->d_small, sizeof(double) * d, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipMemcpyAsync(ctx->h_gram, ctx->d_small, sizeof(double) * d, hipMemcpyDeviceToHost, st));
     int ggrid = 0;
     int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &ggrid, st);
     if (rc) return rc;
@@ -1779,10 +1773,35 @@ int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, 
         asmc_set_error("asmc_mean_gram: ncclAllReduce failed");
         return ASMC_ERR_ARG;
     }
-    ASMC_HIP(hipMemcpyAsync(gram_host, ctx->d_partials, sizeof(double) * d * d, hipMemcpyDeviceToHost, st));
-    ASMC_HIP(hipStreamSynchronize(st));
-    memcpy(sum_host, ctx->h_pinned, sizeof(double) * d);
+    ASMC_HIP(hipMemcpyAsync(ctx->h_gram + 128, ctx->d_partials, sizeof(double) * d * d, hipMemcpyDeviceToHost, st));
+    ctx->gram_pending_d = d;
     return ASMC_OK;
+}
+
+int asmc_mean_gram_fetch(asmc_ctx* ctx, int d, double* sum_host, double* gram_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && sum_host && gram_host, "null pointer");
+    ASMC_REQUIRE(ctx->gram_pending_d == d && d > 0, "no asmc_mean_gram_enqueue of this d is pending");
+    ASMC_HIP(hipStreamSynchronize(as_stream(stream)));
+    memcpy(sum_host, ctx->h_gram, sizeof(double) * d);
+    memcpy(gram_host, ctx->h_gram + 128, sizeof(double) * d * d);
+    ctx->gram_pending_d = 0;
+    return ASMC_OK;
+}
+
+int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, int64_t n_mean, int across_ranks,
+                   double* sum_host, double* gram_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && sum_host && gram_host, "null pointer");
+    ASMC_REQUIRE(n > 0 && n_mean > 0 && d > 0 && d <= ctx->d_max && d <= 128, "bad sizes (gram supports d <= 128)");
+    if (!across_ranks && (!(asmc_gram_mm_supported(d, x) && d <= ASMC_BLOCK) || getenv("ASMC_GRAM_GENERIC"))) {
+        int rc = asmc_colsum(ctx, n, d, x_dtype, x, sum_host, stream);  // shapes without the fp64-MFMA Gram kernel
+        if (rc) return rc;
+        double center[128];
+        for (int j = 0; j < d; j++) center[j] = sum_host[j] / (double)n_mean;
+        return asmc_centered_gram(ctx, n, d, x_dtype, x, center, gram_host, stream);
+    }
+    const int rc = asmc_mean_gram_enqueue(ctx, n, d, x_dtype, x, n_mean, across_ranks, stream);
+    if (rc) return rc;
+    return asmc_mean_gram_fetch(ctx, d, sum_host, gram_host, stream);
 }
 
 int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* center_host,

@@ -599,6 +599,20 @@ class HipEngine:
                                       self._stream), "asmc_mean_gram")
         return s, g
 
+    def mean_gram_enqueue(self, x: torch.Tensor, n_mean: int) -> bool:
+        """Start `mean_gram` on the stream without waiting (single rank); False for shapes without the device-side path."""
+        n, d = x.shape
+        if not (d in (32, 64, 128) and x.data_ptr() % 16 == 0 and not os.environ.get("ASMC_GRAM_GENERIC")):
+            return False
+        check(self.lib.asmc_mean_gram_enqueue(self._ctx, n, d, self._xdt(x), _dptr(x), int(n_mean), 0, self._stream),
+              "asmc_mean_gram_enqueue")
+        return True
+
+    def mean_gram_fetch(self, d: int) -> tuple[np.ndarray, np.ndarray]:
+        s, g = np.empty(d), np.empty((d, d))
+        check(self.lib.asmc_mean_gram_fetch(self._ctx, d, _f64p(s), _f64p(g), self._stream), "asmc_mean_gram_fetch")
+        return s, g
+
     def mean_gram_across_ranks_ok(self, x: torch.Tensor, comm) -> bool:
         """The shapes asmc_mean_gram sums over the ranks itself (the fp64-MFMA Gram kernel's), given a communicator."""
         return (x.shape[1] in (32, 64, 128) and x.data_ptr() % 16 == 0 and not os.environ.get("ASMC_GRAM_GENERIC")

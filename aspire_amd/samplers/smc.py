@@ -81,6 +81,11 @@ class SMCSampler(MCMCSampler):
             return [int(v) for v in a]
         return [int(v) for v in self.comm.all_gather_i64(a).sum(axis=0)]
 
+    def _speculated_moments_n(self, samples) -> int | None:
+        """Population size for the moments the fused importance step may compute behind its gather (see HipSMC); None:
+        this sampler's mutation does not use them."""
+        return None
+
     def determine_beta(self, samples: SMCSamples, beta: float, beta_step: float, min_beta_step: float,
                        max_beta_step: float = 1.0, beta_tolerance: float = DEFAULT_BETA_TOLERANCE):
         """smc/base.py:123-213; the ESS evaluations of one k-ary bisection round share a device pass."""
@@ -259,7 +264,8 @@ class SMCSampler(MCMCSampler):
                     # schedule rules choose another beta)
                     samples.speculate_importance_step(self.current_target_efficiency(beta), beta_tolerance, self.rng,
                                                       resample_mode=self.resample_mode,
-                                                      resample_method=self.resample_method)
+                                                      resample_method=self.resample_method,
+                                                      moments_n=self._speculated_moments_n(samples))
                 beta, min_beta_step = self.determine_beta(samples, beta, beta_step, min_beta_step,
                                                           max_beta_step=self.max_beta_step,
                                                           beta_tolerance=beta_tolerance)
@@ -415,11 +421,26 @@ class HipSMC(SMCSampler):
             resample_method=resample_method)
 
     # ---- reference Gaussian of the pCN proposal ----------------------------------------------
-    def _fit_reference_gaussian(self, x: torch.Tensor, n_global: int | None = None):
-        """Population mean and covariance (ddof=1) over ALL ranks -> (mu, L, Linv) on device."""
+    def _speculated_moments_n(self, samples) -> int | None:
+        """The population size when the coming mutation fits its reference Gaussian to the moments of the whole resampled
+        population in x space (`pcn` steps, identity preconditioning, one rank): the fused importance step then computes
+        them right behind its gather.  None otherwise."""
+        T = self.preconditioning_transform
+        if (self.comm.sharded or self.sampler_kwargs.get("step_fn", "tpcn") != "pcn"
+                or not (isinstance(T, IdentityTransform) or getattr(T, "is_identity", False))):
+            return None
+        return int(self._n_global(samples))
+
+    def _fit_reference_gaussian(self, x: torch.Tensor, n_global: int | None = None, moments=None):
+        """Population mean and covariance (ddof=1) over ALL ranks -> (mu, L, Linv) on device.  `moments`: what the fused
+        importance step parked for exactly these rows (`SMCSamples.speculate_importance_step`)."""
         e, comm = self.engine, self.comm
         n = n_global or x.shape[0] * comm.world
-        if not comm.sharded and hasattr(e, "mean_gram"):
+        if (moments is not None and not comm.sharded and moments[0] == x.data_ptr() and moments[1] == tuple(x.shape)
+                and moments[2] == n):
+            s, g = moments[3], moments[4]
+            mean = s / n
+        elif not comm.sharded and hasattr(e, "mean_gram"):
             s, g = e.mean_gram(x, n)  # both passes enqueued together: the centre never visits the host
             mean = s / n
         elif hasattr(e, "mean_gram_across_ranks_ok") and e.mean_gram_across_ranks_ok(x, comm):
@@ -468,12 +489,12 @@ class HipSMC(SMCSampler):
         dev = self.engine.asarray(host)
         return dev[:d], dev[seg:seg + d * d].view(d, d), dev[seg + seg * d:seg + seg * d + d * d].view(d, d)
 
-    def _fit_reference(self, x: torch.Tensor, n_global: int, step_fn: str):
+    def _fit_reference(self, x: torch.Tensor, n_global: int, step_fn: str, moments=None):
         """(mu, L, Linv, nu) of the mutation's reference distribution: Gaussian moments of the whole population
         (`pcn`, nu = 0) or a Student-t fitted by EM to a strided subsample of `tpcn_fit_subsample` particles, the
         same on every rank (`tpcn`; student_t.py).  A fit with nu above NU_GAUSSIAN runs the Gaussian kernels."""
         if step_fn != "tpcn":
-            return (*self._fit_reference_gaussian(x, n_global), 0.0)
+            return (*self._fit_reference_gaussian(x, n_global, moments), 0.0)
         from ..student_t import NU_GAUSSIAN, _chol, fit_student_t_device
 
         e, comm = self.engine, self.comm
@@ -657,7 +678,7 @@ class HipSMC(SMCSampler):
         n_local = x.shape[0]
         n_global = self._n_global(particles)
         gid0 = self._gid0(particles)
-        mu, L, Linv, nu = self._fit_reference(x, n_global, kwargs.get("step_fn", "tpcn"))
+        mu, L, Linv, nu = self._fit_reference(x, n_global, kwargs.get("step_fn", "tpcn"), particles.__dict__.get("_moments"))
         st = self._pcn_state
         if st["rho"] is None:
             st["rho"] = min(2.38 / math.sqrt(self.dims), 0.99)

@@ -414,13 +414,16 @@ class SMCSamples(BaseSamples):
             self.__dict__.setdefault("_ws1p", {})[float(beta)] = float(s1p)
 
     def speculate_importance_step(self, target_eff: float, tol: float, rng, *, resample_mode: str = "exact",
-                                  resample_method: str = "multinomial") -> bool:
+                                  resample_method: str = "multinomial", moments_n: int | None = None) -> bool:
         """Enqueue the whole importance step of one iteration - adaptive-beta search (smc/base.py:167-186), evidence
         moments (samples.py:1226-1242) and the multinomial resampling of all N particles at beta* (samples.py:1251-1287)
         - as one chain of launches with a single host synchronisation (include/asmc.h asmc_importance_step), and park
         the results on this object: the sampler's `determine_beta` then finds the search result, and `resample(beta*)`
         the resampled rows.  Speculative: the host's schedule rules (min / max beta step) may pick another beta than
         beta*, in which case `resample` ignores the parked rows and the generator has not been touched.
+        `moments_n`: also enqueue the column sums and the centred Gram matrix of the resampled rows (centre = sums /
+        moments_n; `engine.mean_gram`) behind the gather, so that the mutation's reference fit costs no pass and no
+        synchronisation of its own; they travel with the resampled population (`_moments`).
         Returns False when the step does not apply (sharded run, non-PCG64 generator, other resampling schemes)."""
         self.__dict__.pop("_spec", None)
         e, comm = self._eng(), self._comm()
@@ -435,10 +438,14 @@ class SMCSamples(BaseSamples):
             return False
         idx = e.importance_step(ll, lp, lq, float(self.beta), float(target_eff), float(tol), st4, n)
         rows = e.gather(idx, x, ll, lp, lq)
+        with_moments = bool(moments_n) and hasattr(e, "mean_gram_enqueue") and e.mean_gram_enqueue(rows[0], int(moments_n))
         b, eff1, conv, passes, n_nan, trip, trip_one, m2, _, found = e.importance_result()
+        moments = None
+        if with_moments:
+            moments = (rows[0].data_ptr(), tuple(rows[0].shape), int(moments_n), *e.mean_gram_fetch(rows[0].shape[1]))
         self._spec = dict(key=(float(target_eff), float(tol)), search=(b, eff1, conv, passes, n_nan, trip, trip_one),
                           found=bool(found and conv), beta=float(b), rows=rows, m2=m2, rng=rng,
-                          state=[int(v) for v in st4], n=n)
+                          state=[int(v) for v in st4], n=n, moments=moments)
         return True
 
     def _take_speculated(self, beta: float, n_samples: int, rng, resample_mode: str, resample_method: str):
@@ -527,7 +534,10 @@ class SMCSamples(BaseSamples):
             var_u = spec["m2"] / st.n
             var = float(var_u / (st.n * (mean_u**2))) if mean_u != 0 else float("nan")
             rng.bit_generator.advance(int(n_samples))  # the n draws Generator.choice takes
-            return wrap(*spec["rows"], counts=counts)
+            res = wrap(*spec["rows"], counts=counts)
+            if spec.get("moments") is not None:
+                (res[0] if want_variance else res).__dict__["_moments"] = spec["moments"]
+            return res
 
         if shard_layout == "owner" and smc_math.owner_layout_ok(e, comm, rng, resample_method, uniform):
             idx, var, s1p, new_counts = smc_math.resample_owner(

@@ -385,6 +385,12 @@ int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
  * Gaussian, smc/minipcn.py:75-84. */
 int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, int64_t n_mean, int across_ranks,
                    double* sum_host, double* gram_host /* [d, d] */, asmc_stream stream);
+/* The two halves of asmc_mean_gram for a caller that has more on the stream: _enqueue starts both passes and their copies to
+ * pinned memory (fp64-MFMA shapes only, error otherwise), _fetch synchronises the stream and hands the results out.  One
+ * pending request per context. */
+int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, int64_t n_mean, int across_ranks,
+                           asmc_stream stream);
+int asmc_mean_gram_fetch(asmc_ctx* ctx, int d, double* sum_host, double* gram_host /* [d, d] */, asmc_stream stream);
 int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
                        const double* center_host, double* gram_host, asmc_stream stream);
 int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, double* lp_dev,

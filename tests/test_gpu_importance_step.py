@@ -181,6 +181,37 @@ def test_sampler_fused_step_is_used_and_schedule_clamps_fall_back(eng):
     assert sp_a.rng.bit_generator.state == sp_b.rng.bit_generator.state
 
 
+def test_reference_fit_moments_ride_on_the_fused_step(eng, monkeypatch):
+    """`pcn` steps fit their reference Gaussian to the moments of the resampled population: the fused importance step
+    enqueues them behind its gather (asmc_mean_gram_enqueue / _fetch) and the mutation finds them parked - one moments
+    pass per temperature, no pass of its own - with results identical to the run that computes them in the mutation."""
+    from aspire_amd.samplers.smc import HipSMC
+
+    kw = dict(n_steps=3, step_fn="pcn")
+
+    def run(seed):
+        from aspire_amd.flows import GaussianFlow
+        from aspire_amd.targets import DiagGaussianMixture
+
+        lik = DiagGaussianMixture.isotropic(32, normalized=False)
+        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=32, prior_flow=GaussianFlow(32, sigma=1.5, engine=eng, seed=1),
+                    xp=np, engine=eng, rng=np.random.default_rng(seed))
+        eng.profile(True)
+        out = sp.sample(100_000, sampler_kwargs=dict(kw), store_sample_history=False)
+        rep = eng.profile_report()
+        eng.profile(False)
+        return sp, out, rep
+
+    sp_a, out_a, rep_a = run(4)
+    temps = len(sp_a.history.beta)
+    assert rep_a["k_is_weights"][0] == temps and rep_a["k_colsum<double>"][0] == temps and rep_a["k_gram_mm"][0] == temps
+    monkeypatch.setattr(HipSMC, "_speculated_moments_n", lambda self, samples: None)
+    sp_b, out_b, rep_b = run(4)
+    assert rep_b["k_colsum<double>"][0] == temps
+    assert sp_a.history.beta == sp_b.history.beta and sp_a.history.mcmc_acceptance == sp_b.history.mcmc_acceptance
+    assert np.array_equal(_np(out_a.x), _np(out_b.x)) and float(out_a.log_evidence) == float(out_b.log_evidence)
+
+
 def test_barrier_timeout_abandons_the_step_and_the_sampler_falls_back(monkeypatch):
     """A launch of the persistent kernel that is not fully resident (two such kernels of different processes sharing the
     GPU) must not hang: its barriers time out, the step reports found = 0 with in-bounds indices, the context stops
