@@ -131,7 +131,32 @@ class TorchDistComm(Comm):
         if rc != 0:
             raise RuntimeError(f"ncclCommInitRank: {lib.ncclGetErrorString(rc).decode()}")
         self._rccl_lib = lib
-        self._rccl = (ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value, handle.value)
+        fn = ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value
+        # Self-test before the library relies on it: the two reductions it issues (int64 and float64 sums, the enum values
+        # it passes) on known inputs, on the current stream.  A wrong answer on ANY rank (agreed through the group) leaves
+        # the hot path on torch.distributed's collectives.
+        lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p]
+        with torch.cuda.device(self.device):
+            ti = torch.tensor([self.rank + 1, 7], dtype=torch.int64, device=self.device)
+            tf = torch.tensor([0.5 * (self.rank + 1), -1.25], dtype=torch.float64, device=self.device)
+            st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            rc_i = lib.ncclAllReduce(ctypes.c_void_p(ti.data_ptr()), ctypes.c_void_p(ti.data_ptr()), 2, 4, 0, handle, st)
+            rc_f = lib.ncclAllReduce(ctypes.c_void_p(tf.data_ptr()), ctypes.c_void_p(tf.data_ptr()), 2, 8, 0, handle, st)
+            tri = self.world * (self.world + 1) // 2
+            good = (rc_i == 0 and rc_f == 0 and ti.tolist() == [tri, 7 * self.world]
+                    and tf.tolist() == [0.5 * tri, -1.25 * self.world])
+        flag = torch.tensor([0 if good else 1], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.SUM, group=self.group)
+        if int(flag.item()) != 0:
+            import logging
+
+            logging.getLogger(__name__).warning("the library's own RCCL communicator failed its self-test on %d rank(s): "
+                                                "collectives stay on torch.distributed", int(flag.item()))
+            lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            lib.ncclCommDestroy(handle)
+            return None
+        self._rccl = (fn, handle.value)
         return self._rccl
 
     def _global(self, r: int) -> int:

@@ -796,7 +796,11 @@ class HipSMC(SMCSampler):
         self.history.mcmc_step_size.append(float(st["rho"]))
         # the device-side loops count the NaNs of the carried log q themselves and return the count with their results
         n_nan = e.pcn_lq_nan() if st.pop("lq_checked", False) else e.count_nonfinite(lq)[0]
-        if self._global_counts([n_nan])[0]:
+        # Sharded runs: every rank must take the same decision, which costs a collective and a synchronisation per
+        # temperature.  While another importance step follows, its beta search counts the NaN weights of ALL ranks in the
+        # records it exchanges anyway and raises there ("Log weights contain NaN values"); only the last mutation asks the ranks.
+        deferred = comm.sharded and beta < 1.0 and self.adaptive and self.device_bisection
+        if not deferred and self._global_counts([n_nan])[0]:
             raise ValueError("Log proposal contains NaN values")
         return self._wrap(x, ll, lp, lq, beta, like=particles)
 
