@@ -207,7 +207,7 @@ def main():
         "flow_math": flow_math,
         # what actually limits the kernel in its split-fp16 form (rocprofv3 --pmc, profiles/r02_pmc_fused_step_end.txt): the
         # vector ALU (fp64 Box-Muller noise, the triangular mat-vec, the flow's bias / ReLU / hi-lo conversion / tanh), not the
-        # matrix pipe - vector ALU active 62 % and matrix pipe 20.5 % of SIMD time, 2.5 TB/s of HBM traffic
+        # matrix pipe - vector ALU active 66 % and matrix pipe 22 % of SIMD time (profiles/r02x_pmc_fused_step.txt), 2.5 TB/s of HBM traffic
         "limiter": "vector-ALU issue" if flow_math == "f16x2-split" else "matrix pipe (fp32-input MFMA) + vector ALU, not overlapped",
         "executed_flops_per_launch": 3 * flow_flops if flow_math == "f16x2-split" else flow_flops,
         "executed_frac_of_its_mfma_peak": (round(3 * flow_flops / (flow_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4)
