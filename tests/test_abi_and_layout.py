@@ -106,3 +106,19 @@ def test_oracle_vs_reference_live_if_present(oracle):
     out = s.resample(0.45, rng=np.random.default_rng(5))
     idx = oracle.resample_indices(ll, lp, lq, 0.1, 0.45, np.random.default_rng(5).random(777))
     assert np.array_equal(np.asarray(out.x), x[idx])
+
+
+def test_hand_issued_lds_reads_are_not_touched_before_their_waits():
+    """k_pcn_flow_fused issues the mat-vec's coefficient reads from inline asm, several batches ahead of the waits that cover
+    them; hipcc must not copy, spill or reuse a destination register in between (it believes the data is there when the asm
+    statement ends).  tools/audit_asm_loads.py compiles the kernel to assembly (no GPU needed) and walks every instantiation."""
+    import shutil
+    import subprocess
+    import sys
+
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "audit_asm_loads.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "24 instantiations, 1728 read batches, 0 violations" in r.stdout, r.stdout
