@@ -105,59 +105,62 @@ class TorchDistComm(Comm):
         if self._stage or self.device.type != "cuda" or os.environ.get("ASMC_RCCL_DIRECT", "1") == "0":
             return None
         import ctypes
+        import logging
 
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        if not os.path.exists(path):
-            return None
-        lib = ctypes.CDLL(path)  # the instance torch has loaded
+        log = logging.getLogger(__name__)
+
+        def all_agree(ok: bool) -> bool:
+            """Every step below is taken by all ranks or by none: the ranks agree on each outcome through the group."""
+            flag = torch.tensor([0 if ok else 1], dtype=torch.int64, device=self.device)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.SUM, group=self.group)
+            return int(flag.item()) == 0
 
         class UniqueId(ctypes.Structure):
             _fields_ = [("internal", ctypes.c_byte * 128)]  # rccl.h NCCL_UNIQUE_ID_BYTES
 
-        lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
-        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
-        lib.ncclGetErrorString.restype = ctypes.c_char_p
-        uid = UniqueId()
-        if self.rank == 0:
-            rc = lib.ncclGetUniqueId(ctypes.byref(uid))
-            if rc != 0:
-                raise RuntimeError(f"ncclGetUniqueId: {lib.ncclGetErrorString(rc).decode()}")
+        lib, uid, ok = None, UniqueId(), True
+        try:
+            lib = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))  # the instance torch has loaded
+            lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+            lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+            lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+            lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            if self.rank == 0 and lib.ncclGetUniqueId(ctypes.byref(uid)) != 0:
+                ok = False
+        except (OSError, AttributeError) as exc:
+            log.warning("no RCCL entry points for the library's own communicator (%s)", exc)
+            ok = False
         t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=self.device)
         self.dist.broadcast(t, src=self._global(0), group=self.group)
+        if not all_agree(ok):
+            log.warning("the library's own RCCL communicator could not be set up: collectives stay on torch.distributed")
+            return None
         ctypes.memmove(ctypes.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            rc = lib.ncclCommInitRank(ctypes.byref(handle), self.world, uid, self.rank)
-        if rc != 0:
-            raise RuntimeError(f"ncclCommInitRank: {lib.ncclGetErrorString(rc).decode()}")
-        self._rccl_lib = lib
-        fn = ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value
+            ok = lib.ncclCommInitRank(ctypes.byref(handle), self.world, uid, self.rank) == 0
         # Self-test before the library relies on it: the two reductions it issues (int64 and float64 sums, the enum values
-        # it passes) on known inputs, on the current stream.  A wrong answer on ANY rank (agreed through the group) leaves
-        # the hot path on torch.distributed's collectives.
-        lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
-                                      ctypes.c_void_p, ctypes.c_void_p]
-        with torch.cuda.device(self.device):
-            ti = torch.tensor([self.rank + 1, 7], dtype=torch.int64, device=self.device)
-            tf = torch.tensor([0.5 * (self.rank + 1), -1.25], dtype=torch.float64, device=self.device)
-            st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            rc_i = lib.ncclAllReduce(ctypes.c_void_p(ti.data_ptr()), ctypes.c_void_p(ti.data_ptr()), 2, 4, 0, handle, st)
-            rc_f = lib.ncclAllReduce(ctypes.c_void_p(tf.data_ptr()), ctypes.c_void_p(tf.data_ptr()), 2, 8, 0, handle, st)
-            tri = self.world * (self.world + 1) // 2
-            good = (rc_i == 0 and rc_f == 0 and ti.tolist() == [tri, 7 * self.world]
-                    and tf.tolist() == [0.5 * tri, -1.25 * self.world])
-        flag = torch.tensor([0 if good else 1], dtype=torch.int64, device=self.device)
-        self.dist.all_reduce(flag, op=self.dist.ReduceOp.SUM, group=self.group)
-        if int(flag.item()) != 0:
-            import logging
-
-            logging.getLogger(__name__).warning("the library's own RCCL communicator failed its self-test on %d rank(s): "
-                                                "collectives stay on torch.distributed", int(flag.item()))
-            lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        # it passes) on known inputs, on the current stream.  A failure or a wrong answer on ANY rank leaves the hot path on
+        # torch.distributed's collectives.
+        if all_agree(ok):
+            with torch.cuda.device(self.device):
+                ti = torch.tensor([self.rank + 1, 7], dtype=torch.int64, device=self.device)
+                tf = torch.tensor([0.5 * (self.rank + 1), -1.25], dtype=torch.float64, device=self.device)
+                st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+                rc_i = lib.ncclAllReduce(ctypes.c_void_p(ti.data_ptr()), ctypes.c_void_p(ti.data_ptr()), 2, 4, 0, handle, st)
+                rc_f = lib.ncclAllReduce(ctypes.c_void_p(tf.data_ptr()), ctypes.c_void_p(tf.data_ptr()), 2, 8, 0, handle, st)
+                tri = self.world * (self.world + 1) // 2
+                ok = (rc_i == 0 and rc_f == 0 and ti.tolist() == [tri, 7 * self.world]
+                      and tf.tolist() == [0.5 * tri, -1.25 * self.world])
+            if all_agree(ok):
+                self._rccl_lib = lib
+                self._rccl = (ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value, handle.value)
+                return self._rccl
+        log.warning("the library's own RCCL communicator failed its set-up or self-test: collectives stay on torch.distributed")
+        if handle.value:
             lib.ncclCommDestroy(handle)
-            return None
-        self._rccl = (fn, handle.value)
-        return self._rccl
+        return None
 
     def _global(self, r: int) -> int:
         """Group-relative rank -> global rank (send / recv / broadcast address peers by their global rank)."""
