@@ -1,6 +1,9 @@
 """The sharded path's collectives over the REAL RCCL backend ("nccl") with a one-rank world - a single GPU cannot host
 two RCCL ranks, but one rank exercises what gloo cannot: device-tensor all-gathers between kernels enqueued through the
-C ABI (stream ordering), and the accept-count all-reduce hook.  Runs tools/nccl_world1.py in a process of its own."""
+C ABI (stream ordering), the accept-count exchange in both its forms (Python callback; the library's own ncclAllReduce on a
+communicator made by TorchDistComm.rccl_direct, with the step size adapted in the next step's prologue), the reference fit's
+moments summed by the library, and the WHOLE sampler through the sharded code path (Comm.force_sharded) against the
+single-rank run: same schedule, same log Z, same particles.  Runs tools/nccl_world1.py in a process of its own."""
 import os
 import socket
 import subprocess

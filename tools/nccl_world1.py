@@ -117,6 +117,37 @@ def main():
     s0, g0 = eng.mean_gram(xd, n)
     s1, g1 = eng.mean_gram(xd, n, hc)
     assert np.array_equal(s0, s1) and np.array_equal(g0, g1)
+    # 6. the whole sampler through the sharded code path (every `comm.sharded` branch: sharded search, owner-layout
+    #    resampling, summed moments, exchanged accept counts with the prologue adaptation) against the single-rank run:
+    #    one rank owns everything, so log Z, the schedule and the final particles must be identical
+    from aspire_amd.flows import CouplingFlow, GaussianFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    cflow = CouplingFlow(d, n_layers=4, hidden_features=(64, 64), device=eng.device, dtype=torch.float32, seed=5)
+    cflow.fit(1.35 * np.random.default_rng(3).normal(size=(4000, d)), n_epochs=3)
+
+    def run_sampler(sharded, flow, step_fn):
+        flow._draws = flow._hip_draws = 0  # the proposal draws are keyed by a per-flow call counter: same draws in both runs
+        kw = {}
+        if sharded:
+            c = TorchDistComm(eng.device)
+            c.force_sharded = True
+            kw["comm"] = c
+        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=eng, rng=np.random.default_rng(21),
+                    dtype="float64", **kw)
+        out = sp.sample(200_000, sampler_kwargs=dict(n_steps=4, step_fn=step_fn), store_sample_history=False)
+        return sp, out
+
+    for flow, step_fn in ((cflow, "pcn"), (GaussianFlow(d, sigma=1.5, seed=2, engine=eng), "tpcn")):
+        sp0, out0 = run_sampler(False, flow, step_fn)
+        sp1, out1 = run_sampler(True, flow, step_fn)
+        assert sp0.history.beta == sp1.history.beta, (sp0.history.beta, sp1.history.beta)
+        assert sp0.history.mcmc_acceptance == sp1.history.mcmc_acceptance
+        assert float(out0.log_evidence) == float(out1.log_evidence), (float(out0.log_evidence), float(out1.log_evidence))
+        x0_, x1_ = (o.x.cpu().numpy() if isinstance(o.x, torch.Tensor) else np.asarray(o.x) for o in (out0, out1))
+        assert np.array_equal(x0_, x1_)
     torch.cuda.synchronize()
     dist.destroy_process_group()
     print("nccl world-1 checks ok: beta*", one[0], "accept", acc1[:3].tolist(), "flow accept", a1.tolist())
