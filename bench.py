@@ -433,7 +433,7 @@ def main():
             "single_thread": {"value": v1, "cores": 1, "sample": f"{k1} steps on {min(n_cpu, 32768)} particles, {e1:.1f} s"},
             "gpu_over_cpu_all_cores": value / vN, "gpu_over_cpu_single_thread": value / v1,
         }
-        try:  # restatement-to-reference ratio, measured in the build container (tools/ref_ratio.py)
+        try:  # restatement-to-reference ratio, measured in the build container (tests/tools/ref_ratio.py)
             result["cpu_baseline"]["port_vs_reference"] = json.load(open(os.path.join(ROOT, "profiles", "r02_ref_ratio.json")))
         except Exception:
             pass

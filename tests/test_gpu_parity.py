@@ -366,7 +366,7 @@ def test_box_muller_functions_agree_with_libm_to_ulps(eng, oracle):
     err = np.abs(xn - ref)
     # the oracle rounds the angle 2 pi u before taking cos / sin (half an ulp of up to 2 pi = 4.4e-16 rad, times the pair's
     # radius); the kernels reduce u by quarter turns exactly.  Beyond that: a few ulp of the value itself.  (Against an
-    # 80-bit evaluation the kernels are the closer of the two: tools/bm_check.py, profiles/r02_box_muller_accuracy.txt.)
+    # 80-bit evaluation the kernels are the closer of the two: tests/tools/bm_check.py, profiles/r02_box_muller_accuracy.txt.)
     radius = np.sqrt(ref[:, 0::2] ** 2 + ref[:, 1::2] ** 2).repeat(2, axis=1)
     tol = 8e-16 * radius + 4 * np.spacing(np.abs(ref)) + 2e-16
     assert np.all(err <= tol), float((err / tol).max())

@@ -2,7 +2,7 @@
 the same Philox words (who is closer to the exact value, and by how many ulp)."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import oracle as O
 from aspire_amd.engine import HipEngine
