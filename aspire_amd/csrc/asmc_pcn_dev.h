@@ -158,8 +158,9 @@ __device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned lo
 // hardware transcendental units (v_log_f32 / v_sin_f32 / v_cos_f32 / v_sqrt_f32):
 //   u = w*2^-32 + 2^-33 (float), t = w'*2^-32 revolutions, r = sqrt(-2 ln u), z = r (cos 2 pi t, sin 2 pi t).
 // ~1e-7 relative accuracy, tails to 6.7 sigma; 8x fewer VALU cycles than the fp64 path.
-__device__ __forceinline__ void normal_quad_f32(unsigned long long seed, unsigned long long gid, uint32_t step,
-                                                uint32_t slot, double& z0, double& z1, double& z2, double& z3) {
+// the four fp32 normals of Philox block `slot` (fast-noise mode); normal_quad_f32 widens them
+__device__ __forceinline__ void normal_quad_f32_raw(unsigned long long seed, unsigned long long gid, uint32_t step,
+                                                    uint32_t slot, float& f0, float& f1, float& f2, float& f3) {
     uint32_t w[4];
     philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, slot | 0x40000000u, (uint32_t)seed,
                   (uint32_t)(seed >> 32), w);
@@ -170,10 +171,20 @@ __device__ __forceinline__ void normal_quad_f32(unsigned long long seed, unsigne
     // ln u = log2(u) * ln 2
     const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
     const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
-    z0 = (double)(r0 * __builtin_amdgcn_cosf(t0));
-    z1 = (double)(r0 * __builtin_amdgcn_sinf(t0));
-    z2 = (double)(r1 * __builtin_amdgcn_cosf(t1));
-    z3 = (double)(r1 * __builtin_amdgcn_sinf(t1));
+    f0 = r0 * __builtin_amdgcn_cosf(t0);
+    f1 = r0 * __builtin_amdgcn_sinf(t0);
+    f2 = r1 * __builtin_amdgcn_cosf(t1);
+    f3 = r1 * __builtin_amdgcn_sinf(t1);
+}
+
+__device__ __forceinline__ void normal_quad_f32(unsigned long long seed, unsigned long long gid, uint32_t step,
+                                                uint32_t slot, double& z0, double& z1, double& z2, double& z3) {
+    float f0, f1, f2, f3;
+    normal_quad_f32_raw(seed, gid, step, slot, f0, f1, f2, f3);
+    z0 = (double)f0;
+    z1 = (double)f1;
+    z2 = (double)f2;
+    z3 = (double)f3;
 }
 
 __device__ __forceinline__ double accept_uniform(unsigned long long seed, unsigned long long gid,

@@ -211,14 +211,31 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
             for (int s = 0; s < KS; s++) q0 = fma(v[s], v[s], q0);
             q0 = quad_sum(q0);
             const double rs = tpcn_scale_ct<TP>(rho, p.nu, q0, p.gam, valid ? row : 0);  // one variate per particle
+            // fast-noise mode: coordinates 4 q .. 4 q + 3 come from Philox block q = 2 sp + (h >> 1); this lane owns the first
+            // two of them (h even) or the last two (h odd), its partner lane 16 away the others.  One block per lane PAIR:
+            // the even lane draws the block of sp = 2 m, the odd lane the block of sp = 2 m + 1, and two v_permlane16_swap
+            // (odd rows of the first operand <-> even rows of the second) hand each lane its halves of both blocks.
+            float zf[NOISE == ASMC_NOISE_F32 ? KS : 1];
+            if (NOISE == ASMC_NOISE_F32) {
+#pragma unroll
+                for (int m = 0; m < KS / 4; m++) {
+                    const uint32_t slot = (uint32_t)(2 * (2 * m + (h & 1)) + (h >> 1));
+                    float f0, f1, f2, f3;
+                    normal_quad_f32_raw(p.seed, gid, step, slot, f0, f1, f2, f3);
+                    const auto s02 = __builtin_amdgcn_permlane16_swap(__float_as_uint(f0), __float_as_uint(f2), false, false);
+                    const auto s13 = __builtin_amdgcn_permlane16_swap(__float_as_uint(f1), __float_as_uint(f3), false, false);
+                    zf[4 * m] = __uint_as_float(s02[0]);      // sp = 2 m:     first / second owned coordinate
+                    zf[4 * m + 1] = __uint_as_float(s13[0]);
+                    zf[4 * m + 2] = __uint_as_float(s02[1]);  // sp = 2 m + 1
+                    zf[4 * m + 3] = __uint_as_float(s13[1]);
+                }
+            }
 #pragma unroll
             for (int sp = 0; sp < KS / 2; sp++) {
                 double z0, z1;
-                if (NOISE == ASMC_NOISE_F32) {  // coordinates 4 q .. 4 q + 3 come from Philox block q: this lane owns two
-                    double w0, w1, w2, w3;
-                    normal_quad_f32(p.seed, gid, step, (uint32_t)(2 * sp + (h >> 1)), w0, w1, w2, w3);
-                    z0 = (h & 1) ? w2 : w0;
-                    z1 = (h & 1) ? w3 : w1;
+                if (NOISE == ASMC_NOISE_F32) {
+                    z0 = (double)zf[(2 * sp) % KS];
+                    z1 = (double)zf[(2 * sp + 1) % KS];
                 } else {  // coordinates 2 pr, 2 pr + 1 from pair pr: exactly the owned pair
                     normal_pair(p.seed, gid, step, (uint32_t)(4 * sp + h), z0, z1);
                 }
