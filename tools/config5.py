@@ -27,7 +27,7 @@ def run(nn, profile):
     eng.profile(profile)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = sp.sample(nn, sampler_kwargs=dict(n_steps=steps, noise="f32"), store_sample_history=False)
+    out = sp.sample(nn, sampler_kwargs=dict(n_steps=steps, noise=os.environ.get("NOISE", "f32")), store_sample_history=False)
     torch.cuda.synchronize()
     return sp, out, time.perf_counter() - t0
 
