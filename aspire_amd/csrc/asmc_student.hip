@@ -12,19 +12,58 @@
 __global__ __launch_bounds__(ST_ROWS) void k_student_estep(int64_t m, int d, const double* __restrict__ xs,
                                                           const double* __restrict__ tab, double nu,
                                                           double* __restrict__ z_out, double* __restrict__ partials) {
-    extern __shared__ double s_dx[];  // [d][64]: centred row of every lane, coordinate-major (conflict-free)
+    extern __shared__ double s_dx[];  // [d][64]: centred row of every lane, coordinate-major (conflict-free) | packed lower triangle
     const int lane = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * ST_ROWS + lane;
     const bool valid = i < m;
     const double* mu = tab;
-    const double* Linv = tab + d;
+    // The triangle's coefficients are wave-uniform.  Read from global memory they were one scalar load and one wait per
+    // FMA of a single dependent chain - 8 256 exposed latencies per row at d = 128, 434 us for 16 384 rows with one wave
+    // per CU.  Staged into LDS (66 KB at d = 128, next to the 64 KB of centred rows) the inner loop is two LDS reads and an
+    // FMA, and hipcc pipelines the reads across iterations.  Same order of operations: same bits.
+    double* s_L = s_dx + (size_t)d * ST_ROWS;
+    const int tri = d * (d + 1) / 2;
+    const double* Lp = tab + d;  // packed by the host: row j at j (j + 1) / 2
+#pragma unroll 8
+    for (int e = lane; e < tri; e += ST_ROWS) s_L[e] = Lp[e];
     for (int k = 0; k < d; k++) s_dx[k * ST_ROWS + lane] = valid ? xs[(size_t)i * d + k] - mu[k] : 0.0;
+    __syncthreads();
+    // four rows at a time: four independent FMA chains share every read of the centred coordinate; each row's own chain
+    // still runs k = 0 .. j in order, and delta collects the rows in order
     double delta = 0.0;
-    for (int j = 0; j < d; j++) {
-        const double* row = Linv + (size_t)j * d;
-        double y = 0.0;
-        for (int k = 0; k <= j; k++) y = fma(row[k], s_dx[k * ST_ROWS + lane], y);
-        delta = fma(y, y, delta);
+    for (int j0 = 0; j0 < d; j0 += 4) {
+        const double* r0 = s_L + (size_t)j0 * (j0 + 1) / 2;
+        const double* r1 = r0 + j0 + 1;
+        const double* r2 = r1 + j0 + 2;
+        const double* r3 = r2 + j0 + 3;
+        double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
+#pragma unroll 4
+        for (int k = 0; k <= j0; k++) {
+            const double xk = s_dx[k * ST_ROWS + lane];
+            y0 = fma(r0[k], xk, y0);
+            y1 = fma(r1[k], xk, y1);
+            y2 = fma(r2[k], xk, y2);
+            y3 = fma(r3[k], xk, y3);
+        }
+        const int rem = d - j0;  // rows j0 .. j0 + min(4, rem) - 1 exist
+        if (rem > 1) {
+            const double x1 = s_dx[(j0 + 1) * ST_ROWS + lane];
+            y1 = fma(r1[j0 + 1], x1, y1);
+            if (rem > 2) {
+                y2 = fma(r2[j0 + 1], x1, y2);
+                const double x2 = s_dx[(j0 + 2) * ST_ROWS + lane];
+                y2 = fma(r2[j0 + 2], x2, y2);
+                if (rem > 3) {
+                    y3 = fma(r3[j0 + 1], x1, y3);
+                    y3 = fma(r3[j0 + 2], x2, y3);
+                    y3 = fma(r3[j0 + 3], s_dx[(j0 + 3) * ST_ROWS + lane], y3);
+                }
+            }
+        }
+        delta = fma(y0, y0, delta);
+        if (rem > 1) delta = fma(y1, y1, delta);
+        if (rem > 2) delta = fma(y2, y2, delta);
+        if (rem > 3) delta = fma(y3, y3, delta);
     }
     const double z = valid ? (nu + (double)d) / (nu + delta) : 0.0;
     if (valid) z_out[i] = z;
@@ -64,9 +103,11 @@ int asmc_student_estep(asmc_ctx* ctx, int64_t m, int d, const double* xs, const 
     double* h = ctx->h_student;
     ASMC_HIP(hipStreamSynchronize(st));  // pinned staging may still be in flight from the previous call
     memcpy(h, mu_host, sizeof(double) * d);
-    memcpy(h + d, linv_host, sizeof(double) * (size_t)d * d);
-    ASMC_HIP(hipMemcpyAsync(d_tab, h, sizeof(double) * ((size_t)d * d + d), hipMemcpyHostToDevice, st));
-    const size_t lds = sizeof(double) * (size_t)d * ST_ROWS;
+    for (int j = 0; j < d; j++)  // lower triangle, packed: the kernel stages it into LDS with one contiguous copy
+        memcpy(h + d + (size_t)j * (j + 1) / 2, linv_host + (size_t)j * d, sizeof(double) * (j + 1));
+    ASMC_HIP(hipMemcpyAsync(d_tab, h, sizeof(double) * ((size_t)d * (d + 1) / 2 + d), hipMemcpyHostToDevice, st));
+    const size_t dpad = ((size_t)d + 3) & ~(size_t)3;  // the kernel walks four rows at a time (rows >= d are read, never used)
+    const size_t lds = sizeof(double) * ((size_t)d * ST_ROWS + dpad * (dpad + 1) / 2);
     static size_t attr_lds = 0;
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_student_estep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -1474,7 +1474,7 @@ def test_shard_entry_points_reject_bad_arguments(eng):
         eng.pcn_propose(x, eng.asarray(np.zeros(4)), eye, eye, 0.3, 1, 0, 0, nu=0.5)
 
 
-@pytest.mark.parametrize("m,d", [(2048, 32), (1999, 7), (4096, 128), (64, 2)])
+@pytest.mark.parametrize("m,d", [(2048, 32), (1999, 7), (4096, 128), (64, 2), (1000, 5), (16384, 128), (700, 13)])
 def test_student_fit_kernels_vs_numpy(eng, m, d):
     """asmc_student_estep / asmc_student_scale against their numpy restatement, then the whole device-driven EM against the
     all-numpy EM on heavy-tailed data."""
