@@ -181,6 +181,11 @@ SIGNATURES = {
         _i,
         [_vp, _i64, _vp, _vp, _vp, _vp, POINTER(AsmcPcnParams), POINTER(AsmcCoupling), _vp, _i64, _i, _u32, _pd, _pi64, _pd, _vp],
     ),
+    "asmc_pcn_mutate_flow_enqueue": (
+        _i,
+        [_vp, _i64, _vp, _vp, _vp, _vp, POINTER(AsmcPcnParams), POINTER(AsmcCoupling), _vp, _i64, _i, _u32, _d, _vp],
+    ),
+    "asmc_pcn_mutate_flow_result": (_i, [_vp, _i, _pd, _pi64, _pd, _vp]),
 }
 
 _lib = None

@@ -184,6 +184,7 @@ int asmc_ctx_destroy(asmc_ctx* c) {
     }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_gram) (void)hipHostFree(c->h_gram);
+    if (c->ev_mutate) (void)hipEventDestroy(c->ev_mutate);
     delete c;
     return ASMC_OK;
 }

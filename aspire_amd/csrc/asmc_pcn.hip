@@ -2426,6 +2426,24 @@ int64_t asmc_pcn_flow_work_bytes(int64_t n, int d, int x_dtype) {
     return xb + 5 * (((n * 8 + 255) / 256) * 256);
 }
 
+// waits for a flow-mutation call's read-back (counts | step sizes | rho | non-finite count | NaNs of log q) and hands it out
+static int mutate_flow_collect(asmc_ctx* ctx, int n_steps, double* rho_out_host, int64_t* n_accept_host, double* rho_hist_host,
+                               hipStream_t st, hipEvent_t ev = nullptr) {
+    const long long* h_counts = reinterpret_cast<const long long*>(ctx->h_pinned);
+    const double* h_rho_hist = ctx->h_pinned + ASMC_MAX_PCN_STEPS + 8;
+    if (ev)
+        ASMC_HIP(hipEventSynchronize(ev));
+    else
+        ASMC_HIP(hipStreamSynchronize(st));
+    memcpy(&ctx->lq_nan, ctx->h_pinned + 8002, sizeof(unsigned long long));
+    for (int t = 0; t < n_steps; t++) n_accept_host[t] = (int64_t)h_counts[t];
+    if (rho_hist_host)
+        for (int t = 0; t < n_steps; t++) rho_hist_host[t] = h_rho_hist[t];
+    *rho_out_host = ctx->h_pinned[8000];
+    memcpy(&ctx->flow_nonfinite, ctx->h_pinned + 8001, sizeof(unsigned long long));  // fused steps only (else stale zero)
+    return ASMC_OK;
+}
+
 int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq,
                          const asmc_pcn_params* prm, const asmc_coupling* flow, void* work_dev, int64_t work_bytes,
                          int n_steps, uint32_t step0, double* rho_inout_host, int64_t* n_accept_host,
@@ -2584,14 +2602,34 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
                             hipMemcpyDeviceToHost, st));
     rc = pcn_enqueue_lq_check(ctx, n, lq, st);
     if (rc) return rc;
-    ASMC_HIP(hipStreamSynchronize(st));
-    memcpy(&ctx->lq_nan, ctx->h_pinned + 8002, sizeof(unsigned long long));
-    for (int t = 0; t < n_steps; t++) n_accept_host[t] = (int64_t)h_counts[t];
-    if (rho_hist_host)
-        for (int t = 0; t < n_steps; t++) rho_hist_host[t] = h_rho_hist[t];
-    *rho_inout_host = ctx->h_pinned[8000];
-    memcpy(&ctx->flow_nonfinite, ctx->h_pinned + 8001, sizeof(unsigned long long));  // fused steps only (else stale zero)
-    return ASMC_OK;
+    if (ctx->mutate_defer) {  // asmc_pcn_mutate_flow_enqueue: the results wait in pinned memory for asmc_pcn_mutate_flow_result
+        if (!ctx->ev_mutate) ASMC_HIP(hipEventCreateWithFlags(&ctx->ev_mutate, hipEventDisableTiming));
+        ASMC_HIP(hipEventRecord(ctx->ev_mutate, st));  // _result waits for THIS point, not for what the caller enqueues behind it
+        ctx->mutate_pending_steps = n_steps;
+        return ASMC_OK;
+    }
+    return mutate_flow_collect(ctx, n_steps, rho_inout_host, n_accept_host, rho_hist_host, st);
+}
+
+int asmc_pcn_mutate_flow_enqueue(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq,
+                                 const asmc_pcn_params* prm, const asmc_coupling* flow, void* work_dev, int64_t work_bytes,
+                                 int n_steps, uint32_t step0, double rho, asmc_stream stream) {
+    ASMC_REQUIRE(ctx != nullptr, "null ctx");
+    ASMC_REQUIRE(ctx->mutate_pending_steps == 0, "a deferred mutation is still pending (asmc_pcn_mutate_flow_result)");
+    int64_t dummy_acc = 0;
+    ctx->mutate_defer = 1;
+    const int rc = asmc_pcn_mutate_flow(ctx, n, x, ll, lp, lq, prm, flow, work_dev, work_bytes, n_steps, step0, &rho, &dummy_acc,
+                                        nullptr, stream);
+    ctx->mutate_defer = 0;
+    return rc;
+}
+
+int asmc_pcn_mutate_flow_result(asmc_ctx* ctx, int n_steps, double* rho_out_host, int64_t* n_accept_host, double* rho_hist_host,
+                                asmc_stream stream) {
+    ASMC_REQUIRE(ctx && rho_out_host && n_accept_host, "null pointer");
+    ASMC_REQUIRE(ctx->mutate_pending_steps == n_steps && n_steps > 0, "no deferred mutation of this length is pending");
+    ctx->mutate_pending_steps = 0;
+    return mutate_flow_collect(ctx, n_steps, rho_out_host, n_accept_host, rho_hist_host, as_stream(stream), ctx->ev_mutate);
 }
 
 int64_t asmc_pcn_flow_nonfinite(asmc_ctx* ctx) { return ctx ? (int64_t)ctx->flow_nonfinite : -1; }

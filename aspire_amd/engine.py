@@ -718,6 +718,34 @@ class HipEngine:
                                             _f64p(rho_hist), self._stream), "asmc_pcn_mutate_flow")
         return n_acc, rho_hist, rho_io.value
 
+    def pcn_mutate_flow_enqueue(self, x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, flow: DeviceCoupling, seed, gid0, rho,
+                                n_steps, step0=0, target_accept=0.234, adapt=True, noise="f64", nu=0.0):
+        """`pcn_mutate_flow` without the wait: everything is on the stream when this returns, `pcn_mutate_flow_result(handle)`
+        synchronises and returns what `pcn_mutate_flow` returns.  The caller may enqueue more behind it in between."""
+        self._chk3(ll, lp, lq)
+        n, d = x.shape
+        prm = AsmcPcnParams(d, self._xdt(x), beta, mu.data_ptr(), L.data_ptr(), Linv.data_ptr(), t_ll.c_struct(),
+                            t_lp.c_struct(), t_lp.c_struct(), seed, gid0, target_accept, int(adapt),
+                            {"f64": 0, "f32": 1}[noise], float(nu))
+        nbytes = self.lib.asmc_pcn_flow_work_bytes(n, d, self._xdt(x))
+        if self._flow_work is None or self._flow_work.numel() < nbytes:
+            self._flow_work = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        cs = flow.c_struct()
+        check(self.lib.asmc_pcn_mutate_flow_enqueue(self._ctx, n, _dptr(x), _dptr(ll), _dptr(lp), _dptr(lq), ctypes.byref(prm),
+                                                    ctypes.byref(cs), _dptr(self._flow_work), nbytes, n_steps, step0,
+                                                    float(rho), self._stream), "asmc_pcn_mutate_flow_enqueue")
+        return (int(n_steps), (mu, L, Linv, t_ll, t_lp, flow, prm, cs))  # keeps the kernels' tables alive until the result
+
+    def pcn_mutate_flow_result(self, handle):
+        n_steps = handle[0]
+        n_acc = np.zeros(n_steps, dtype=np.int64)
+        rho_hist = np.zeros(n_steps)
+        rho_out = ctypes.c_double(0.0)
+        check(self.lib.asmc_pcn_mutate_flow_result(self._ctx, n_steps, ctypes.byref(rho_out),
+                                                   n_acc.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _f64p(rho_hist),
+                                                   self._stream), "asmc_pcn_mutate_flow_result")
+        return n_acc, rho_hist, rho_out.value
+
     def pcn_lq_nan(self) -> int:
         """NaNs in the carried log q after the last pcn_mutate / pcn_mutate_flow call (counted by the call itself)."""
         return int(self.lib.asmc_pcn_lq_nan(self._ctx))

@@ -11,6 +11,7 @@ from __future__ import annotations
 import copy
 import logging
 import math
+import os
 from typing import Any, Callable
 
 import numpy as np
@@ -80,6 +81,16 @@ class SMCSampler(MCMCSampler):
         if not self.comm.sharded:
             return [int(v) for v in a]
         return [int(v) for v in self.comm.all_gather_i64(a).sum(axis=0)]
+
+    def _importance_step_follows(self, beta: float) -> bool:
+        """Another temperature follows this mutation and its importance step runs as the fused chain of launches (single
+        rank): the mutation may then enqueue that chain behind itself."""
+        if os.environ.get("ASMC_IS_AHEAD", "1") == "0":  # escape hatch / A-B switch
+            return False
+        return (self.fused_importance_step and getattr(self, "adaptive", False) and self.device_bisection and beta < 1.0
+                and not self.comm.sharded and hasattr(self.engine, "pcn_mutate_flow_enqueue")
+                and hasattr(self.engine, "importance_step") and not getattr(self.engine, "importance_step_disabled", False)
+                and getattr(self, "_beta_tolerance", None) is not None)
 
     def _speculated_moments_n(self, samples) -> int | None:
         """Population size for the moments the fused importance step may compute behind its gather (see HipSMC); None:
@@ -258,7 +269,11 @@ class SMCSampler(MCMCSampler):
         if run_smc_loop:
             while True:
                 iterations += 1
-                if self.fused_importance_step and self.adaptive and self.device_bisection and beta < 1.0:
+                self._beta_tolerance = beta_tolerance
+                if hasattr(samples, "finish_speculation"):
+                    samples.finish_speculation()  # an importance step the mutation enqueued behind itself
+                if (self.fused_importance_step and self.adaptive and self.device_bisection and beta < 1.0
+                        and "_spec" not in samples.__dict__):  # (a mutation may already have run the step behind itself)
                     # search + evidence moments + resampling at beta* in one chain of launches, one synchronisation;
                     # determine_beta and resample below pick the parked results up (or redo the step when the
                     # schedule rules choose another beta)
@@ -709,8 +724,23 @@ class HipSMC(SMCSampler):
                 done = 0
                 while done < n_steps:
                     chunk = min(n_steps - done, 2048)
-                    n_acc, rho_hist, rho = e.pcn_mutate_flow(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed,
-                                                             gid0, st["rho"], chunk, step0 + done, target, True, noise, nu)
+                    ahead = chunk == n_steps and n_steps <= 1024 and self._importance_step_follows(beta)
+                    if ahead:
+                        # the next temperature's importance step (search, resampling, gather, moments) goes onto the stream
+                        # right behind the mutation, BEFORE the host waits for either: the GPU does not idle while Python
+                        # does the bookkeeping of the finished mutation
+                        handle = e.pcn_mutate_flow_enqueue(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed, gid0,
+                                                           st["rho"], chunk, step0, target, True, noise, nu)
+                        out = self._wrap(x, ll, lp, lq, beta, like=particles)
+                        ok = out.speculate_importance_step(self.current_target_efficiency(beta), self._beta_tolerance, self.rng,
+                                                           resample_mode=self.resample_mode, resample_method=self.resample_method,
+                                                           moments_n=self._speculated_moments_n(out), defer=True)
+                        n_acc, rho_hist, rho = e.pcn_mutate_flow_result(handle)  # waits for the mutation only
+                        if ok:
+                            st["prewrapped"] = out  # the step's results are collected when the next iteration asks for them
+                    else:
+                        n_acc, rho_hist, rho = e.pcn_mutate_flow(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed,
+                                                                 gid0, st["rho"], chunk, step0 + done, target, True, noise, nu)
                     st["rho"] = rho
                     st["lq_checked"] = hasattr(e, "pcn_lq_nan")
                     acc_rates.extend((n_acc / n_global).tolist())
@@ -800,9 +830,10 @@ class HipSMC(SMCSampler):
         # temperature.  While another importance step follows, its beta search counts the NaN weights of ALL ranks in the
         # records it exchanges anyway and raises there ("Log weights contain NaN values"); only the last mutation asks the ranks.
         deferred = comm.sharded and beta < 1.0 and self.adaptive and self.device_bisection
+        pre = st.pop("prewrapped", None)
         if not deferred and self._global_counts([n_nan])[0]:
             raise ValueError("Log proposal contains NaN values")
-        return self._wrap(x, ll, lp, lq, beta, like=particles)
+        return pre if pre is not None else self._wrap(x, ll, lp, lq, beta, like=particles)
 
 
 _BLAS_CONTROLLER = []  # the process's ThreadpoolController, discovered once (the discovery walks every loaded library: ~1 ms)

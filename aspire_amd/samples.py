@@ -190,7 +190,7 @@ class BaseSamples:
     def __getstate__(self):
         """Pickle as host arrays; device handles (engine, communicator, memoised reductions) are dropped."""
         state = dict(self.__dict__)
-        for k in ("engine", "comm", "_wstats", "_ws1p"):
+        for k in ("engine", "comm", "_wstats", "_ws1p", "_spec", "_spec_pending", "_moments"):
             state.pop(k, None)
         for k, v in list(state.items()):
             if is_torch(v):
@@ -414,7 +414,8 @@ class SMCSamples(BaseSamples):
             self.__dict__.setdefault("_ws1p", {})[float(beta)] = float(s1p)
 
     def speculate_importance_step(self, target_eff: float, tol: float, rng, *, resample_mode: str = "exact",
-                                  resample_method: str = "multinomial", moments_n: int | None = None) -> bool:
+                                  resample_method: str = "multinomial", moments_n: int | None = None,
+                                  defer: bool = False) -> bool:
         """Enqueue the whole importance step of one iteration - adaptive-beta search (smc/base.py:167-186), evidence
         moments (samples.py:1226-1242) and the multinomial resampling of all N particles at beta* (samples.py:1251-1287)
         - as one chain of launches with a single host synchronisation (include/asmc.h asmc_importance_step), and park
@@ -424,8 +425,10 @@ class SMCSamples(BaseSamples):
         `moments_n`: also enqueue the column sums and the centred Gram matrix of the resampled rows (centre = sums /
         moments_n; `engine.mean_gram`) behind the gather, so that the mutation's reference fit costs no pass and no
         synchronisation of its own; they travel with the resampled population (`_moments`).
+        `defer`: enqueue only; the caller has more to wait for on the stream and calls `finish_speculation()` itself.
         Returns False when the step does not apply (sharded run, non-PCG64 generator, other resampling schemes)."""
         self.__dict__.pop("_spec", None)
+        self.__dict__.pop("_spec_pending", None)
         e, comm = self._eng(), self._comm()
         st4 = smc_math.pcg64_state(rng)
         if (comm.sharded or not hasattr(e, "importance_step") or st4 is None or resample_mode != "exact"
@@ -439,14 +442,25 @@ class SMCSamples(BaseSamples):
         idx = e.importance_step(ll, lp, lq, float(self.beta), float(target_eff), float(tol), st4, n)
         rows = e.gather(idx, x, ll, lp, lq)
         with_moments = bool(moments_n) and hasattr(e, "mean_gram_enqueue") and e.mean_gram_enqueue(rows[0], int(moments_n))
-        b, eff1, conv, passes, n_nan, trip, trip_one, m2, _, found = e.importance_result()
-        moments = None
-        if with_moments:
-            moments = (rows[0].data_ptr(), tuple(rows[0].shape), int(moments_n), *e.mean_gram_fetch(rows[0].shape[1]))
-        self._spec = dict(key=(float(target_eff), float(tol)), search=(b, eff1, conv, passes, n_nan, trip, trip_one),
-                          found=bool(found and conv), beta=float(b), rows=rows, m2=m2, rng=rng,
-                          state=[int(v) for v in st4], n=n, moments=moments)
+        self._spec_pending = dict(key=(float(target_eff), float(tol)), rows=rows, rng=rng, state=[int(v) for v in st4], n=n,
+                                  moments_n=int(moments_n) if with_moments else None)
+        if not defer:
+            self.finish_speculation()
         return True
+
+    def finish_speculation(self):
+        """Wait for an enqueued importance step and park its results (`speculate_importance_step`)."""
+        p = self.__dict__.pop("_spec_pending", None)
+        if p is None:
+            return
+        e = self._eng()
+        b, eff1, conv, passes, n_nan, trip, trip_one, m2, _, found = e.importance_result()
+        moments, rows = None, p["rows"]
+        if p["moments_n"] is not None:
+            moments = (rows[0].data_ptr(), tuple(rows[0].shape), p["moments_n"], *e.mean_gram_fetch(rows[0].shape[1]))
+        self._spec = dict(key=p["key"], search=(b, eff1, conv, passes, n_nan, trip, trip_one),
+                          found=bool(found and conv), beta=float(b), rows=rows, m2=m2, rng=p["rng"],
+                          state=p["state"], n=p["n"], moments=moments)
 
     def _take_speculated(self, beta: float, n_samples: int, rng, resample_mode: str, resample_method: str):
         """The rows `speculate_importance_step` parked, if they are the answer to this `resample` call; else None."""

@@ -497,6 +497,16 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, 
                          void* work_dev, int64_t work_bytes, int n_steps, uint32_t step0,
                          double* rho_inout_host, int64_t* n_accept_host, double* rho_hist_host,
                          asmc_stream stream);
+/* The same call in two halves, for a caller that has more to put on the stream behind the mutation (the next temperature's
+ * importance step, asmc_importance_step): _enqueue starts everything including the read-back into pinned memory and returns,
+ * _result waits for the mutation's own read-back (an event recorded behind it - not for what the caller has enqueued since) and
+ * hands the results out.  One pending mutation per context; the tables the kernels read
+ * (params, flow) must stay alive until _result. */
+int asmc_pcn_mutate_flow_enqueue(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, double* lp_dev, double* lq_dev,
+                                 const asmc_pcn_params* params, const asmc_coupling* flow, void* work_dev,
+                                 int64_t work_bytes, int n_steps, uint32_t step0, double rho, asmc_stream stream);
+int asmc_pcn_mutate_flow_result(asmc_ctx* ctx, int n_steps, double* rho_out_host, int64_t* n_accept_host,
+                                double* rho_hist_host, asmc_stream stream);
 /* Proposals of the last asmc_pcn_mutate_flow whose flow density was not finite (they were rejected).  The flow's fp32 layers
  * run as split-fp16 MFMA products (operands |.| < 65504): a badly scaled flow shows up here; ASMC_FLOW_MATH=f32 selects the
  * fp32 MFMA chain.  Counted by the one-kernel step only. */

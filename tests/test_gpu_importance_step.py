@@ -212,6 +212,42 @@ def test_reference_fit_moments_ride_on_the_fused_step(eng, monkeypatch):
     assert np.array_equal(_np(out_a.x), _np(out_b.x)) and float(out_a.log_evidence) == float(out_b.log_evidence)
 
 
+def test_importance_step_enqueued_behind_the_mutation(eng, monkeypatch):
+    """Flow-proposal runs put the next temperature's importance step onto the stream behind the mutation, before the host
+    waits for either (asmc_pcn_mutate_flow_enqueue / _result: the result waits for an event behind the mutation's own
+    read-back, the step's results are collected at the top of the next iteration).  Same schedule, same log Z, same particles
+    as the run that starts the step after the mutation has returned (ASMC_IS_AHEAD=0), and the path is the one taken."""
+    from conftest import random_coupling_flow
+
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    d = 32
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    flow = random_coupling_flow(d, 4, 64)
+    taken = []
+    orig = eng.pcn_mutate_flow_enqueue
+
+    def run():
+        flow._draws = flow._hip_draws = 0
+        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=eng, rng=np.random.default_rng(9),
+                    dtype="float64")
+        out = sp.sample(60_000, sampler_kwargs=dict(n_steps=3, step_fn="pcn"), store_sample_history=False)
+        return sp, out
+
+    monkeypatch.setattr(eng, "pcn_mutate_flow_enqueue", lambda *a, **k: (taken.append(1), orig(*a, **k))[1])
+    sp_a, out_a = run()
+    assert len(taken) == len(sp_a.history.beta) - 1  # every mutation but the last one has a step behind it
+    monkeypatch.setenv("ASMC_IS_AHEAD", "0")
+    n_before = len(taken)
+    sp_b, out_b = run()
+    assert len(taken) == n_before
+    assert sp_a.history.beta == sp_b.history.beta and sp_a.history.mcmc_acceptance == sp_b.history.mcmc_acceptance
+    assert sp_a.history.log_norm_ratio == sp_b.history.log_norm_ratio
+    assert float(out_a.log_evidence) == float(out_b.log_evidence) and np.array_equal(_np(out_a.x), _np(out_b.x))
+    assert sp_a.rng.bit_generator.state == sp_b.rng.bit_generator.state
+
+
 def test_barrier_timeout_abandons_the_step_and_the_sampler_falls_back(monkeypatch):
     """A launch of the persistent kernel that is not fully resident (two such kernels of different processes sharing the
     GPU) must not hang: its barriers time out, the step reports found = 0 with in-bounds indices, the context stops
