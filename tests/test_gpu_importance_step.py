@@ -248,6 +248,47 @@ def test_importance_step_enqueued_behind_the_mutation(eng, monkeypatch):
     assert sp_a.rng.bit_generator.state == sp_b.rng.bit_generator.state
 
 
+_CKPT = []
+
+
+def _ckpt_cb(state):  # module level: the checkpoint state carries its callback, and local functions do not pickle
+    import pickle
+
+    _CKPT.append(pickle.dumps(state))
+
+
+def test_pending_importance_step_survives_history_and_checkpoints(eng, monkeypatch):
+    """Between the mutation that enqueued the next importance step and the iteration that collects it, the sampler stores the
+    sample history and calls the checkpoint callback: the pending step must not leak into either (pickled states drop it),
+    and the run equals the one without the look-ahead."""
+    from conftest import random_coupling_flow
+
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    d = 32
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    flow = random_coupling_flow(d, 4, 64)
+
+    def run(ahead):
+        monkeypatch.setenv("ASMC_IS_AHEAD", ahead)
+        flow._draws = flow._hip_draws = 0
+        _CKPT.clear()
+        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=eng, rng=np.random.default_rng(9),
+                    dtype="float64")
+        out = sp.sample(50_000, sampler_kwargs=dict(n_steps=3, step_fn="pcn"), store_sample_history=True,
+                        checkpoint_callback=_ckpt_cb, checkpoint_every=1)
+        return sp, out, list(_CKPT)
+
+    sp_a, out_a, st_a = run("1")
+    sp_b, out_b, st_b = run("0")
+    assert sp_a.history.beta == sp_b.history.beta and float(out_a.log_evidence) == float(out_b.log_evidence)
+    assert len(sp_a.history.sample_history) == len(sp_a.history.beta) + 1 and len(st_a) == len(st_b) > 0
+    assert all(np.array_equal(np.asarray(a.x), np.asarray(b.x))
+               for a, b in zip(sp_a.history.sample_history, sp_b.history.sample_history))
+    assert [len(a) for a in st_a] == [len(b) for b in st_b]  # no device rows, no pending step inside the pickles
+
+
 def test_barrier_timeout_abandons_the_step_and_the_sampler_falls_back(monkeypatch):
     """A launch of the persistent kernel that is not fully resident (two such kernels of different processes sharing the
     GPU) must not hang: its barriers time out, the step reports found = 0 with in-bounds indices, the context stops
