@@ -110,6 +110,7 @@ SIGNATURES = {
     "asmc_importance_step": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _vp, _i64, _vp, _vp, _vp, _vp]),
     "asmc_importance_result": (_i, [_vp, _pd, _vp]),
     "asmc_importance_available": (_i, [_vp]),
+    "asmc_importance_result_enqueue": (_i, [_vp, _vp]),
     "asmc_pcn_flow_nonfinite": (_i64, [_vp]),
     "asmc_pcn_lq_nan": (_i64, [_vp]),
     "asmc_pcn_set_count_hook": (_i, [_vp, _vp, _vp, _vp, _i64]),

@@ -97,6 +97,8 @@ struct asmc_ctx {
     int64_t count_n_global;
     int mutate_defer, mutate_pending_steps;  // asmc_pcn_mutate_flow_enqueue / _result
     hipEvent_t ev_mutate;                    // recorded behind a deferred mutation's read-back
+    hipEvent_t ev_is;                        // ... behind asmc_importance_result_enqueue's copies
+    int is_result_pending;
     unsigned long long lq_nan;  // NaNs in the carried log q after the last mutation call (asmc_pcn_lq_nan)
     void* rccl_allreduce;  // asmc_pcn_set_count_rccl: the process's ncclAllReduce and a communicator
     void* rccl_comm;

@@ -185,6 +185,7 @@ int asmc_ctx_destroy(asmc_ctx* c) {
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_gram) (void)hipHostFree(c->h_gram);
     if (c->ev_mutate) (void)hipEventDestroy(c->ev_mutate);
+    if (c->ev_is) (void)hipEventDestroy(c->ev_is);
     delete c;
     return ASMC_OK;
 }

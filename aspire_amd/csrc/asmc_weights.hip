@@ -1195,14 +1195,35 @@ int asmc_is_weights_launch(asmc_ctx* ctx, int64_t n, const double* ll, const dou
 
 extern "C" {
 
-int asmc_importance_result(asmc_ctx* ctx, double* out_host, asmc_stream stream) {
-    ASMC_REQUIRE(ctx && out_host, "null pointer");
+// The read-back of asmc_importance_result put on the stream NOW, with an event behind it: a caller that enqueues more work
+// behind the step (the gather's consumers: asmc_mean_gram_enqueue) can then collect the step's scalars as soon as the step
+// itself is done, while that work is still running.
+int asmc_importance_result_enqueue(asmc_ctx* ctx, asmc_stream stream) {
+    ASMC_REQUIRE(ctx != nullptr, "null ctx");
     hipStream_t st = as_stream(stream);
     double* h = ctx->h_pinned + 4096 + 512;
     unsigned int* hp = reinterpret_cast<unsigned int*>(h + 64);
     ASMC_HIP(hipMemcpyAsync(h, ctx->d_small + 2560, sizeof(double) * 64, hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipMemcpyAsync(hp, ctx->d_bar + ISW_POISON_CELL, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-    ASMC_HIP(hipStreamSynchronize(st));
+    if (!ctx->ev_is) ASMC_HIP(hipEventCreateWithFlags(&ctx->ev_is, hipEventDisableTiming));
+    ASMC_HIP(hipEventRecord(ctx->ev_is, st));
+    ctx->is_result_pending = 1;
+    return ASMC_OK;
+}
+
+int asmc_importance_result(asmc_ctx* ctx, double* out_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && out_host, "null pointer");
+    hipStream_t st = as_stream(stream);
+    double* h = ctx->h_pinned + 4096 + 512;
+    unsigned int* hp = reinterpret_cast<unsigned int*>(h + 64);
+    if (ctx->is_result_pending) {  // asmc_importance_result_enqueue has put the copies on the stream already
+        ctx->is_result_pending = 0;
+        ASMC_HIP(hipEventSynchronize(ctx->ev_is));
+    } else {
+        ASMC_HIP(hipMemcpyAsync(h, ctx->d_small + 2560, sizeof(double) * 64, hipMemcpyDeviceToHost, st));
+        ASMC_HIP(hipMemcpyAsync(hp, ctx->d_bar + ISW_POISON_CELL, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        ASMC_HIP(hipStreamSynchronize(st));
+    }
     out_host[0] = h[0], out_host[1] = h[1], out_host[2] = h[2], out_host[3] = h[6], out_host[4] = h[9];
     out_host[5] = h[15];
     out_host[6] = h[11], out_host[7] = h[12], out_host[8] = h[13], out_host[9] = h[14];

@@ -257,6 +257,10 @@ class HipEngine:
                                             _dptr(idx), self._stream), "asmc_importance_step")
         return idx
 
+    def importance_result_enqueue(self):
+        """Start `importance_result`'s read-back now (event behind it): work enqueued after this call does not delay it."""
+        check(self.lib.asmc_importance_result_enqueue(self._ctx, self._stream), "asmc_importance_result_enqueue")
+
     def importance_result(self):
         """(beta_star, eff_at_one, converged, rounds, n_nan, (m, S1, S2) at beta_star or None, (m, S1, S2) at 1,
         m2, S1', found) of the last `importance_step` (synchronises)."""
@@ -606,6 +610,7 @@ class HipEngine:
             return False
         check(self.lib.asmc_mean_gram_enqueue(self._ctx, n, d, self._xdt(x), _dptr(x), int(n_mean), 0, self._stream),
               "asmc_mean_gram_enqueue")
+        self._gram_gen = getattr(self, "_gram_gen", 0) + 1  # names the request: a fetch is for the LATEST one only
         return True
 
     def mean_gram_fetch(self, d: int) -> tuple[np.ndarray, np.ndarray]:

@@ -452,8 +452,8 @@ class HipSMC(SMCSampler):
         e, comm = self.engine, self.comm
         n = n_global or x.shape[0] * comm.world
         if (moments is not None and not comm.sharded and moments[0] == x.data_ptr() and moments[1] == tuple(x.shape)
-                and moments[2] == n):
-            s, g = moments[3], moments[4]
+                and moments[2] == n and moments[3] == getattr(e, "_gram_gen", None)):
+            s, g = e.mean_gram_fetch(x.shape[1])  # enqueued behind the importance step's gather; waits for the stream
             mean = s / n
         elif not comm.sharded and hasattr(e, "mean_gram"):
             s, g = e.mean_gram(x, n)  # both passes enqueued together: the centre never visits the host

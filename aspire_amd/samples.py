@@ -441,9 +441,11 @@ class SMCSamples(BaseSamples):
             return False
         idx = e.importance_step(ll, lp, lq, float(self.beta), float(target_eff), float(tol), st4, n)
         rows = e.gather(idx, x, ll, lp, lq)
+        if hasattr(e, "importance_result_enqueue"):
+            e.importance_result_enqueue()  # the step's scalars come back as soon as the step is done, not behind the moments
         with_moments = bool(moments_n) and hasattr(e, "mean_gram_enqueue") and e.mean_gram_enqueue(rows[0], int(moments_n))
         self._spec_pending = dict(key=(float(target_eff), float(tol)), rows=rows, rng=rng, state=[int(v) for v in st4], n=n,
-                                  moments_n=int(moments_n) if with_moments else None)
+                                  moments_n=int(moments_n) if with_moments else None, gram_gen=getattr(e, "_gram_gen", None))
         if not defer:
             self.finish_speculation()
         return True
@@ -456,8 +458,8 @@ class SMCSamples(BaseSamples):
         e = self._eng()
         b, eff1, conv, passes, n_nan, trip, trip_one, m2, _, found = e.importance_result()
         moments, rows = None, p["rows"]
-        if p["moments_n"] is not None:
-            moments = (rows[0].data_ptr(), tuple(rows[0].shape), p["moments_n"], *e.mean_gram_fetch(rows[0].shape[1]))
+        if p["moments_n"] is not None:  # still on the stream: fetched by the reference fit (HipSMC._fit_reference_gaussian)
+            moments = (rows[0].data_ptr(), tuple(rows[0].shape), p["moments_n"], p["gram_gen"])
         self._spec = dict(key=p["key"], search=(b, eff1, conv, passes, n_nan, trip, trip_one),
                           found=bool(found and conv), beta=float(b), rows=rows, m2=m2, rng=p["rng"],
                           state=p["state"], n=p["n"], moments=moments)

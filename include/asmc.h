@@ -167,6 +167,10 @@ int asmc_importance_step(asmc_ctx* ctx, int64_t n, const double* ll_dev, const d
                          double beta0, double target_eff, double tol, const uint64_t rng_state[4], int64_t n_out,
                          double* w_scratch_dev, double* cdf_scratch_dev, int64_t* idx_out_dev, asmc_stream stream);
 int asmc_importance_result(asmc_ctx* ctx, double* out_host, asmc_stream stream);
+/* Puts asmc_importance_result's read-back on the stream now, with an event behind it: the next asmc_importance_result waits
+ * for that event only - not for what the caller has enqueued behind the step since (asmc_mean_gram_enqueue on the gathered
+ * rows) - so the host can go on with the schedule while those passes run. */
+int asmc_importance_result_enqueue(asmc_ctx* ctx, asmc_stream stream);
 /* 1 while asmc_importance_step can be used on this ctx; 0 once a launch of its persistent kernel timed out at a grid barrier
  * (not fully resident, e.g. another process's kernel of the same kind on the GPU): that step reported found = 0, the counters
  * were reset, and the caller stays on the step-by-step entry points. */
