@@ -603,12 +603,16 @@ class HipEngine:
                                       self._stream), "asmc_mean_gram")
         return s, g
 
-    def mean_gram_enqueue(self, x: torch.Tensor, n_mean: int) -> bool:
-        """Start `mean_gram` on the stream without waiting (single rank); False for shapes without the device-side path."""
+    def mean_gram_enqueue(self, x: torch.Tensor, n_mean: int, comm=None) -> bool:
+        """Start `mean_gram` on the stream without waiting; False for shapes without the device-side path (and, for a sharded
+        `comm`, without a communicator for the library's own all-reduces: `use_rccl`)."""
         n, d = x.shape
         if not (d in (32, 64, 128) and x.data_ptr() % 16 == 0 and not os.environ.get("ASMC_GRAM_GENERIC")):
             return False
-        check(self.lib.asmc_mean_gram_enqueue(self._ctx, n, d, self._xdt(x), _dptr(x), int(n_mean), 0, self._stream),
+        across = int(comm is not None and comm.sharded)
+        if across and not self.use_rccl(comm):
+            return False
+        check(self.lib.asmc_mean_gram_enqueue(self._ctx, n, d, self._xdt(x), _dptr(x), int(n_mean), across, self._stream),
               "asmc_mean_gram_enqueue")
         self._gram_gen = getattr(self, "_gram_gen", 0) + 1  # names the request: a fetch is for the LATEST one only
         return True

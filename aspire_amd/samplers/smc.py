@@ -82,6 +82,11 @@ class SMCSampler(MCMCSampler):
             return [int(v) for v in a]
         return [int(v) for v in self.comm.all_gather_i64(a).sum(axis=0)]
 
+    def _resample_moments_n(self, samples) -> int | None:
+        """Population size when the mutation behind this resampling fits its reference Gaussian to the moments of the whole
+        resampled population (see HipSMC): the resampling call then starts them behind its gather.  None otherwise."""
+        return None
+
     def _importance_step_follows(self, beta: float) -> bool:
         """Another temperature follows this mutation and its importance step runs as the fused chain of launches (single
         rank): the mutation may then enqueue that chain behind itself."""
@@ -302,7 +307,7 @@ class SMCSampler(MCMCSampler):
                 # the evidence-variance pass (samples.py:1230-1242) shares its reduction with the resampling step
                 samples, log_evidence_ratio_var = samples.resample(
                     beta, rng=self.rng, resample_mode=self.resample_mode, resample_method=self.resample_method,
-                    shard_layout=self.shard_layout, want_variance=True)
+                    shard_layout=self.shard_layout, want_variance=True, moments_n=self._resample_moments_n(samples))
                 self.history.log_norm_ratio.append(float(log_evidence_ratio))
                 self.history.log_norm_ratio_var.append(float(log_evidence_ratio_var))
                 logger.info(f"it {iterations} - Log evidence ratio: {log_evidence_ratio:.2f} +/- "
@@ -446,12 +451,19 @@ class HipSMC(SMCSampler):
             return None
         return int(self._n_global(samples))
 
+    def _resample_moments_n(self, samples) -> int | None:
+        T = self.preconditioning_transform
+        if (self.sampler_kwargs.get("step_fn", "tpcn") != "pcn"
+                or not (isinstance(T, IdentityTransform) or getattr(T, "is_identity", False))):
+            return None
+        return int(self._n_global(samples))
+
     def _fit_reference_gaussian(self, x: torch.Tensor, n_global: int | None = None, moments=None):
         """Population mean and covariance (ddof=1) over ALL ranks -> (mu, L, Linv) on device.  `moments`: what the fused
         importance step parked for exactly these rows (`SMCSamples.speculate_importance_step`)."""
         e, comm = self.engine, self.comm
         n = n_global or x.shape[0] * comm.world
-        if (moments is not None and not comm.sharded and moments[0] == x.data_ptr() and moments[1] == tuple(x.shape)
+        if (moments is not None and moments[0] == x.data_ptr() and moments[1] == tuple(x.shape)
                 and moments[2] == n and moments[3] == getattr(e, "_gram_gen", None)):
             s, g = e.mean_gram_fetch(x.shape[1])  # enqueued behind the importance step's gather; waits for the stream
             mean = s / n

@@ -503,7 +503,7 @@ class SMCSamples(BaseSamples):
 
     def resample(self, beta, n_samples: int | None = None, rng: np.random.Generator = None, *,
                  resample_mode: str = "exact", resample_method: str = "multinomial", shard_layout: str = "owner",
-                 want_variance: bool = False):
+                 want_variance: bool = False, moments_n: int | None = None):
         """samples.py:1251-1287.  `resample_mode`: "exact" (sequential-order cdf == numpy cumsum,
         bit-exact indices) or "fast"; `resample_method`: "multinomial" (reference) or the opt-in
         "systematic" / "stratified".  Sharded populations (`comm.sharded`): `shard_layout="owner"` keeps every
@@ -534,6 +534,11 @@ class SMCSamples(BaseSamples):
                                  log_prior=self._from_device(lpo), log_q=self._from_device(lqo), beta=beta,
                                  dtype=self.dtype, parameters=self.parameters, xp=self.xp, engine=self.engine,
                                  comm=self.comm)
+            # `moments_n`: the caller's mutation fits its reference Gaussian to the moments of these rows - start them now
+            # (engine.mean_gram_enqueue; summed over the ranks of a sharded run), they are fetched when the fit needs them
+            if (moments_n and spec is None and is_torch(xo) and hasattr(e, "mean_gram_enqueue")
+                    and e.mean_gram_enqueue(xo, int(moments_n), comm)):
+                out.__dict__["_moments"] = (xo.data_ptr(), tuple(xo.shape), int(moments_n), e._gram_gen)
             if comm.sharded:
                 out.n_global = int(n_samples)
                 out.shard_counts = [int(c) for c in counts]
