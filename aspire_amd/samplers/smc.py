@@ -509,11 +509,26 @@ class HipSMC(SMCSampler):
         idle GPU at a temperature boundary."""
         d = self.dims
         seg = -(-d // 32) * 32  # segment starts stay 256-byte aligned
-        host = np.zeros(seg + 2 * seg * d)
+        size = seg + 2 * seg * d
+        device = getattr(self.engine, "device", None)
+        if isinstance(device, torch.device) and device.type == "cuda":
+            # pinned staging + one asynchronous copy on the stream (a pageable upload is a blocking ~40 us); both buffers are
+            # reused: the previous temperature's kernels have finished with them when its mutation's results were collected
+            bufs = self.__dict__.get("_ref_bufs")
+            if bufs is None or bufs[0].numel() != size:
+                bufs = self._ref_bufs = (torch.zeros(size, dtype=torch.float64).pin_memory(),
+                                         torch.empty(size, dtype=torch.float64, device=device))
+            host_t, dev = bufs
+            host = host_t.numpy()
+        else:
+            host_t, dev, host = None, None, np.zeros(size)
         host[:d] = mean
         host[seg:seg + d * d] = np.tril(L).reshape(-1)
         host[seg + seg * d:seg + seg * d + d * d] = np.tril(Linv).reshape(-1)
-        dev = self.engine.asarray(host)
+        if dev is None:
+            dev = self.engine.asarray(host)
+        else:
+            dev.copy_(host_t, non_blocking=True)
         return dev[:d], dev[seg:seg + d * d].view(d, d), dev[seg + seg * d:seg + seg * d + d * d].view(d, d)
 
     def _fit_reference(self, x: torch.Tensor, n_global: int, step_fn: str, moments=None):
