@@ -151,11 +151,18 @@ class TorchDistComm(Comm):
                 rc_i = lib.ncclAllReduce(ctypes.c_void_p(ti.data_ptr()), ctypes.c_void_p(ti.data_ptr()), 2, 4, 0, handle, st)
                 rc_f = lib.ncclAllReduce(ctypes.c_void_p(tf.data_ptr()), ctypes.c_void_p(tf.data_ptr()), 2, 8, 0, handle, st)
                 tri = self.world * (self.world + 1) // 2
-                ok = (rc_i == 0 and rc_f == 0 and ti.tolist() == [tri, 7 * self.world]
-                      and tf.tolist() == [0.5 * tri, -1.25 * self.world])
+                lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                              ctypes.c_void_p]
+                tg = torch.tensor([1.5 + self.rank, -2.0 * self.rank], dtype=torch.float64, device=self.device)
+                tgo = torch.zeros(2 * self.world, dtype=torch.float64, device=self.device)
+                rc_g = lib.ncclAllGather(ctypes.c_void_p(tg.data_ptr()), ctypes.c_void_p(tgo.data_ptr()), 2, 8, handle, st)
+                want = [v for r in range(self.world) for v in (1.5 + r, -2.0 * r)]
+                ok = (rc_i == 0 and rc_f == 0 and rc_g == 0 and ti.tolist() == [tri, 7 * self.world]
+                      and tf.tolist() == [0.5 * tri, -1.25 * self.world] and tgo.tolist() == want)
             if all_agree(ok):
                 self._rccl_lib = lib
-                self._rccl = (ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value, handle.value)
+                self._rccl = (ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value, handle.value,
+                              ctypes.cast(lib.ncclAllGather, ctypes.c_void_p).value)
                 return self._rccl
         log.warning("the library's own RCCL communicator failed its set-up or self-test: collectives stay on torch.distributed")
         if handle.value:

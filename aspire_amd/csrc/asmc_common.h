@@ -102,6 +102,7 @@ struct asmc_ctx {
     unsigned long long lq_nan;  // NaNs in the carried log q after the last mutation call (asmc_pcn_lq_nan)
     void* rccl_allreduce;  // asmc_pcn_set_count_rccl: the process's ncclAllReduce and a communicator
     void* rccl_comm;
+    void* rccl_allgather;  // the process's ncclAllGather (asmc_set_rccl_allgather)
     int64_t n_tiles_max;
     int gram_blocks;
     size_t gram_cap;  // doubles in d_gram (>= gram_blocks * d_max^2; the d = 32 matrix-core Gram kernel uses up to 2048 partials)

@@ -1942,6 +1942,12 @@ int asmc_set_rccl(asmc_ctx* ctx, void* allreduce_fn, void* nccl_comm) {
     return ASMC_OK;
 }
 
+int asmc_set_rccl_allgather(asmc_ctx* ctx, void* allgather_fn) {
+    ASMC_REQUIRE(ctx != nullptr, "null ctx");
+    ctx->rccl_allgather = allgather_fn;
+    return ASMC_OK;
+}
+
 int asmc_pcn_set_count_rccl(asmc_ctx* ctx, int64_t* cell_dev, int64_t n_global) {
     ASMC_REQUIRE(ctx != nullptr, "null ctx");
     if (cell_dev == nullptr) return asmc_pcn_set_count_hook(ctx, nullptr, nullptr, nullptr, 0);

@@ -1293,6 +1293,30 @@ int asmc_find_beta_shard_decide(asmc_ctx* ctx, const double* recs_dev, int world
     return ASMC_OK;
 }
 
+// Rounds first .. last-1 of the sharded search as ONE call: reduce -> ncclAllGather of the ranks' records on the library's
+// own communicator (asmc_set_rccl + asmc_set_rccl_allgather; same stream, no stream hop, no host callback) -> decide.
+int asmc_find_beta_shard_rounds(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double beta0,
+                                double target_eff, double tol, int world, int64_t n_global, double* rec_dev, double* recs_dev,
+                                int first, int last, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && rec_dev && recs_dev, "null pointer");
+    ASMC_REQUIRE(ctx->rccl_allgather && ctx->rccl_comm, "asmc_set_rccl / asmc_set_rccl_allgather first");
+    ASMC_REQUIRE(first >= 0 && last >= first, "bad round range");
+    typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+    const allgather_fn allgather = reinterpret_cast<allgather_fn>(ctx->rccl_allgather);
+    const int nccl_f64 = 8;  // rccl.h: ncclFloat64
+    for (int r = first; r < last; r++) {
+        int rc = asmc_find_beta_shard_reduce(ctx, n, ll, lp, lq, beta0, r, rec_dev, stream);
+        if (rc) return rc;
+        if (allgather(rec_dev, recs_dev, (size_t)ASMC_BIS_REC, nccl_f64, ctx->rccl_comm, as_stream(stream)) != 0) {
+            asmc_set_error("asmc_find_beta_shard_rounds: ncclAllGather failed");
+            return ASMC_ERR_ARG;
+        }
+        rc = asmc_find_beta_shard_decide(ctx, recs_dev, world, n_global, beta0, target_eff, tol, r, stream);
+        if (rc) return rc;
+    }
+    return ASMC_OK;
+}
+
 int asmc_find_beta_shard_result(asmc_ctx* ctx, double* out_host, asmc_stream stream) {
     ASMC_REQUIRE(ctx && out_host, "null pointer");
     hipStream_t st = as_stream(stream);

@@ -293,6 +293,10 @@ class HipEngine:
         lib, ctx, st = self.lib, self._ctx, self._stream
         a, b, c, r, rs = _dptr(ll), _dptr(lp), _dptr(lq), _dptr(rec), _dptr(recs)
         n, world, gather = ll.numel(), comm.world, comm.all_gather_into
+        if last > first and self.use_rccl(comm):  # the library gathers the records itself: one call for all the rounds
+            check(lib.asmc_find_beta_shard_rounds(ctx, n, a, b, c, beta0, target_eff, tol, world, n_global, r, rs, first, last, st),
+                  "asmc_find_beta_shard_rounds")
+            return
         for rnd in range(first, last):
             check(lib.asmc_find_beta_shard_reduce(ctx, n, a, b, c, beta0, rnd, r, st), "asmc_find_beta_shard_reduce")
             gather(recs, rec)
@@ -657,6 +661,7 @@ class HipEngine:
             return False
         if getattr(self, "_rccl_set", None) != direct:
             check(self.lib.asmc_set_rccl(self._ctx, ctypes.c_void_p(direct[0]), ctypes.c_void_p(direct[1])), "asmc_set_rccl")
+            check(self.lib.asmc_set_rccl_allgather(self._ctx, ctypes.c_void_p(direct[2])), "asmc_set_rccl_allgather")
             self._rccl_set = direct
         return True
 

@@ -190,6 +190,11 @@ int asmc_find_beta_shard_reduce(asmc_ctx* ctx, int64_t n_local, const double* ll
                                 const double* lq_dev, double beta0, int round, double* rec_dev, asmc_stream stream);
 int asmc_find_beta_shard_decide(asmc_ctx* ctx, const double* recs_dev, int world, int64_t n_global, double beta0,
                                 double target_eff, double tol, int round, asmc_stream stream);
+/* rounds first .. last-1 in one call: reduce -> ncclAllGather of the records on the library's own communicator (same
+ * stream) -> decide; rec_dev[ASMC_BIS_REC], recs_dev[world * ASMC_BIS_REC] are the caller's */
+int asmc_find_beta_shard_rounds(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev, const double* lq_dev,
+                                double beta0, double target_eff, double tol, int world, int64_t n_global, double* rec_dev,
+                                double* recs_dev, int first, int last, asmc_stream stream);
 int asmc_find_beta_shard_result(asmc_ctx* ctx, double* out_host, asmc_stream stream);
 int asmc_weights_m2(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
                     const double* lq_dev, double beta0, double beta, double m, double mean_u,
@@ -378,6 +383,7 @@ int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int
  * mutation, smc/minipcn.py; counted on the device and read back with the call's own results: no extra synchronisation) */
 int64_t asmc_pcn_lq_nan(asmc_ctx* ctx);
 int asmc_set_rccl(asmc_ctx* ctx, void* allreduce_fn, void* nccl_comm);
+int asmc_set_rccl_allgather(asmc_ctx* ctx, void* allgather_fn); /* the process's ncclAllGather, for asmc_find_beta_shard_rounds */
 int asmc_pcn_set_count_rccl(asmc_ctx* ctx, int64_t* cell_dev, int64_t n_global);
 int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, double* sum_host,
                 asmc_stream stream);
