@@ -116,6 +116,7 @@ SIGNATURES = {
     "asmc_pcn_set_count_hook": (_i, [_vp, _vp, _vp, _vp, _i64]),
     "asmc_set_rccl": (_i, [_vp, _vp, _vp]),
     "asmc_set_rccl_allgather": (_i, [_vp, _vp]),
+    "asmc_rccl_all_gather": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "asmc_find_beta_shard_rounds": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _i, _i64, _vp, _vp, _i, _i, _vp]),
     "asmc_pcn_set_count_rccl": (_i, [_vp, _vp, _i64]),
     "asmc_pcn_ysplit_begin": (_i, [_vp, _i64, _vp, POINTER(AsmcPcnParams), _d, _vp]),

@@ -1948,6 +1948,21 @@ int asmc_set_rccl_allgather(asmc_ctx* ctx, void* allgather_fn) {
     return ASMC_OK;
 }
 
+// equal-sized all-gather of 8-byte elements on the library's communicator and stream (the small exchanges of owner-layout
+// resampling: evidence partials, chain states, kept counts)
+int asmc_rccl_all_gather(asmc_ctx* ctx, const void* send_dev, void* recv_dev, int64_t count, int is_int64, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && send_dev && recv_dev && count > 0, "bad arguments");
+    ASMC_REQUIRE(ctx->rccl_allgather && ctx->rccl_comm, "asmc_set_rccl / asmc_set_rccl_allgather first");
+    typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+    const int dt = is_int64 ? 4 : 8;  // rccl.h: ncclInt64, ncclFloat64
+    if (reinterpret_cast<allgather_fn>(ctx->rccl_allgather)(send_dev, recv_dev, (size_t)count, dt, ctx->rccl_comm,
+                                                            reinterpret_cast<hipStream_t>(stream)) != 0) {
+        asmc_set_error("asmc_rccl_all_gather: ncclAllGather failed");
+        return ASMC_ERR_ARG;
+    }
+    return ASMC_OK;
+}
+
 int asmc_pcn_set_count_rccl(asmc_ctx* ctx, int64_t* cell_dev, int64_t n_global) {
     ASMC_REQUIRE(ctx != nullptr, "null ctx");
     if (cell_dev == nullptr) return asmc_pcn_set_count_hook(ctx, nullptr, nullptr, nullptr, 0);

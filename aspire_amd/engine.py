@@ -665,6 +665,16 @@ class HipEngine:
             self._rccl_set = direct
         return True
 
+    def all_gather(self, comm, t: torch.Tensor) -> torch.Tensor:
+        """`comm.all_gather_tensor(t)` for the small fp64 / int64 exchanges of the sharded hot path: through the library's own
+        communicator on its own stream when there is one (`use_rccl`), else through torch.distributed."""
+        if t.dtype in (torch.float64, torch.int64) and t.is_contiguous() and t.is_cuda and self.use_rccl(comm):
+            out = torch.empty((comm.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            check(self.lib.asmc_rccl_all_gather(self._ctx, _dptr(t), _dptr(out), t.numel(), int(t.dtype == torch.int64),
+                                                self._stream), "asmc_rccl_all_gather")
+            return out
+        return comm.all_gather_tensor(t)
+
     def set_count_hook(self, comm, n_global: int | None):
         """Sharded mutation: let `pcn_mutate` / `pcn_mutate_flow` adapt the step size from the GLOBAL acceptance rate
         with the whole step loop enqueued on the stream - after each step the library leaves this rank's accept

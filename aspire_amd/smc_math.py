@@ -398,7 +398,7 @@ def global_cdf_slice(engine, comm, w, counts, approx_carry: float, mode: str = "
     # round 1: every rank walks the chain; the owner of a tile that fails verification (the tail of normalised weights,
     # typically) scans it element-wise and publishes the exact sum behind it, the others stop in front of it
     work, state = engine.cdf_shard_chain(w, cdf, recs_all, tile0, None, None, comm.world, comm.rank)
-    states = comm.all_gather_tensor(state).contiguous()
+    states = (engine.all_gather(comm, state) if hasattr(engine, "all_gather") else comm.all_gather_tensor(state)).contiguous()
     # round 2: resume through the published sums
     work, state = engine.cdf_shard_chain(w, cdf, recs_all, tile0, work, states, comm.world, comm.rank)
     edges = engine.cdf_shard_finish(w, cdf, recs_all, tile0, work, state)
@@ -438,7 +438,8 @@ def resample_owner(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out: i
         if hasattr(engine, "weights_m2_lse_dev"):
             rec = engine.empty(2)
             engine.weights_m2_lse_dev(ll, lp, lq, beta0, beta, st.m, mean_u, shift, mp, rec)
-            parts = engine.to_numpy(comm.all_gather_tensor(rec)).reshape(world, 2)
+            parts = engine.to_numpy(engine.all_gather(comm, rec) if hasattr(engine, "all_gather")
+                                    else comm.all_gather_tensor(rec)).reshape(world, 2)
         else:
             parts = comm.all_gather_f64(np.array(engine.weights_m2_lse(ll, lp, lq, beta0, beta, st.m, mean_u, shift, mp)))
         m2, s1p = float(parts[0, 0]), float(parts[0, 1])
@@ -459,7 +460,8 @@ def resample_owner(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out: i
         if hasattr(engine, "select_range_dev") and edges.is_contiguous() and edges.numel() == 4:
             # count and failure flag stay on the device until the ranks' pairs have been gathered: one synchronisation
             buf, info_dev = engine.select_range_dev(u_all, edges)
-            info = engine.to_numpy(comm.all_gather_tensor(info_dev)).reshape(world, 2)
+            info = engine.to_numpy(engine.all_gather(comm, info_dev) if hasattr(engine, "all_gather")
+                                   else comm.all_gather_tensor(info_dev)).reshape(world, 2)
             u_kept = buf[: int(info[rank, 0])]
         else:
             u_kept = engine.select_range(u_all, edges[2:4])  # synchronises: everything above is enqueued by now

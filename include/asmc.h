@@ -384,6 +384,8 @@ int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int
 int64_t asmc_pcn_lq_nan(asmc_ctx* ctx);
 int asmc_set_rccl(asmc_ctx* ctx, void* allreduce_fn, void* nccl_comm);
 int asmc_set_rccl_allgather(asmc_ctx* ctx, void* allgather_fn); /* the process's ncclAllGather, for asmc_find_beta_shard_rounds */
+/* equal-sized all-gather of `count` 8-byte elements per rank (fp64, or int64 with is_int64) on that communicator and stream */
+int asmc_rccl_all_gather(asmc_ctx* ctx, const void* send_dev, void* recv_dev, int64_t count, int is_int64, asmc_stream stream);
 int asmc_pcn_set_count_rccl(asmc_ctx* ctx, int64_t* cell_dev, int64_t n_global);
 int asmc_colsum(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, double* sum_host,
                 asmc_stream stream);
