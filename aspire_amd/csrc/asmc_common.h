@@ -13,8 +13,13 @@
 #define ASMC_SCAN_TILE 2048     // elements per scan tile (256 threads x 8)
 #define ASMC_PCN_MAX_GRID (1 << 20)  // blocks per pCN launch (>= 64 particles each): up to 67M particles per rank
 #define ASMC_MAX_PCN_STEPS 2048 // per asmc_pcn_mutate call (bounded by the pinned staging buffer)
+// Box-Muller tables of the default noise (asmc_pcn_dev.h bm_pair32): entries of two doubles
+#define BM_SC_N 256                   // [0, 256): (sin, cos)(2 pi (k + 1/2) / 256)
+#define BM_LG_N 128                   // [256, 384): (rc_i, 2 ln rc_i)
+#define BM_TAB_N (BM_SC_N + BM_LG_N)
 
 void asmc_set_error(const char* fmt, ...);
+void asmc_bm_table_host(double* tab);  // asmc_ctx.hip: the 2 * BM_TAB_N doubles (long double libm)
 struct asmc_ctx;
 int asmc_count_nonfinite_enqueue(asmc_ctx* ctx, int64_t n, const double* v, hipStream_t st);
 struct asmc_ctx;
@@ -89,6 +94,7 @@ struct asmc_ctx {
     long long* d_select;           // [2 * ASMC_SELECT_THREADS/64 + 8] wave counts, offsets, total of asmc_pcg64_select
     unsigned long long ptab_tag, ysplit_seq;  // who packed d_ptab last (0 = anyone; else the split session's number)
     double* d_ptab;                // [2*32*32 + 32 + 3*8*(1+2*32)] packed pCN parameter block (d <= 32)
+    double* d_bmtab;               // [2 * 384] Box-Muller tables of the default noise (asmc_pcn_dev.h bm_pair32)
     double* d_mmtab;               // [2 * 144 * 64] MFMA operand images of L and Linv (d = 64 / 128; NULL when d_max < 64)
     // sharded mutation: accept-count exchange between a step and its adaptation (asmc_pcn_set_count_hook)
     int (*count_hook)(void*, asmc_stream);

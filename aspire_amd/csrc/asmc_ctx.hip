@@ -1,6 +1,8 @@
 // asmc_ctx.hip — library context, scratch allocation, error reporting.
 #include <stdarg.h>
 
+#include <math.h>
+
 #include "asmc_common.h"
 
 static thread_local char g_err[512] = "";
@@ -22,6 +24,23 @@ void asmc_prof_end(asmc_ctx* ctx, hipStream_t st) {
     if (!ctx || !ctx->prof_on || ctx->prof_n >= ASMC_PROF_MAX) return;
     (void)hipEventRecord(ctx->prof_ev[2 * ctx->prof_n + 1], st);
     ctx->prof_n++;
+}
+
+// The tables of the default noise's Box-Muller transform (asmc_pcn_dev.h bm_pair32), in long double libm:
+// [0, 256): (sin, cos)(2 pi (k + 1/2) / 256); [256, 384): (rc_i, 2 ln rc_i), rc_i = fl(1 / c_i), c_i = 1/2 + (i + 1/2) / 256.
+void asmc_bm_table_host(double* tab) {
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int k = 0; k < BM_SC_N; k++) {
+        const long double ang = two_pi * ((long double)k + 0.5L) / (long double)BM_SC_N;
+        tab[2 * k] = (double)sinl(ang);
+        tab[2 * k + 1] = (double)cosl(ang);
+    }
+    for (int i = 0; i < BM_LG_N; i++) {
+        const long double c = 0.5L + ((long double)i + 0.5L) / (2.0L * BM_LG_N);
+        const double rc = (double)(1.0L / c);
+        tab[2 * (BM_SC_N + i)] = rc;
+        tab[2 * (BM_SC_N + i) + 1] = (double)(2.0L * logl((long double)rc));
+    }
 }
 
 extern "C" {
@@ -142,6 +161,12 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     dmalloc((void**)&c->d_pcgtab, sizeof(unsigned long long) * (64 * 4 + 8));
     dmalloc((void**)&c->d_select, sizeof(long long) * (2 * (ASMC_SELECT_THREADS / 64) + 8));
     dmalloc((void**)&c->d_ptab, sizeof(double) * (2 * 32 * 32 + 32 + 3 * ASMC_MAX_COMPONENTS * (1 + 2 * 32) + 64));
+    dmalloc((void**)&c->d_bmtab, sizeof(double) * 2 * BM_TAB_N);
+    if (e == hipSuccess) {
+        double tab[2 * BM_TAB_N];
+        asmc_bm_table_host(tab);
+        e = hipMemcpy(c->d_bmtab, tab, sizeof(tab), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_pinned, sizeof(double) * 8192, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_gram, sizeof(double) * (128 + 128 * 128), hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -177,6 +202,7 @@ int asmc_ctx_destroy(asmc_ctx* c) {
     (void)hipFree(c->d_pcgtab);
     (void)hipFree(c->d_select);
     (void)hipFree(c->d_ptab);
+    (void)hipFree(c->d_bmtab);
     if (c->prof_ev) {
         for (int i = 0; i < 2 * ASMC_PROF_MAX; i++) (void)hipEventDestroy(c->prof_ev[i]);
         delete[] c->prof_ev;

@@ -74,6 +74,8 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_step(
     const double a = sqrt(1.0 - rho * rho);
     long long n_acc = 0;
     const int64_t n_tiles = (n + 63) / 64;
+    bm_d2* bmt = bm_lds();  // the Box-Muller tables (the first tile's __syncthreads publishes them)
+    bm_tab_stage_rt(bmt, p.bmtab);
     for (int64_t tile0 = (int64_t)blockIdx.x * waves_per_block; tile0 < n_tiles;
          tile0 += (int64_t)gridDim.x * waves_per_block) {
         const int64_t t = tile0 + wave;
@@ -101,16 +103,13 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_step(
             // y' = a y + rho sqrt(s) xi (s = 1 for the Gaussian reference), q1 = |y'|^2
             double q1 = 0.0;
             const double rs = tpcn_scale(rho, p.nu, q0, p.gam, i);
-            for (int pr = 0; 2 * pr < d; pr++) {
-                double z0, z1;
-                normal_pair(p.seed, gid, step, (uint32_t)pr, z0, z1);
-                double y0 = fma(rs, z0, a * v[(2 * pr) * 64]);
-                v[(2 * pr) * 64] = y0;
-                q1 = fma(y0, y0, q1);
-                if (2 * pr + 1 < d) {
-                    double y1 = fma(rs, z1, a * v[(2 * pr + 1) * 64]);
-                    v[(2 * pr + 1) * 64] = y1;
-                    q1 = fma(y1, y1, q1);
+            for (int qd = 0; 4 * qd < d; qd++) {
+                double z[4];
+                normal_quad(p.seed, gid, step, (uint32_t)qd, bmt, z[0], z[1], z[2], z[3]);
+                for (int e = 0; e < 4 && 4 * qd + e < d; e++) {
+                    const double ye = fma(rs, z[e], a * v[(4 * qd + e) * 64]);
+                    v[(4 * qd + e) * 64] = ye;
+                    q1 = fma(ye, ye, q1);
                 }
             }
             // x' = mu + L y' (in place, descending rows); rounded to the storage type
@@ -396,6 +395,13 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
     const double a = sqrt(1.0 - rho * rho);
     long long n_acc = 0;
     const int64_t n_tiles = (n + 63) / 64;
+    // the Box-Muller tables of the default noise, staged by the whole block (the only block-wide barrier of the kernel)
+    bm_d2* bmt = nullptr;
+    if constexpr (NOISE == ASMC_NOISE_F64 && (M == PCN_X_STEP || M == PCN_Y_STEP)) {
+        bmt = bm_lds();
+        bm_tab_stage_rt(bmt, p.bmtab);
+        __syncthreads();
+    }
     // one 64-particle tile per wave and NO tile loop: with a loop LLVM hoists the ~1300 loop-invariant
     // table loads and the fp64 polynomial constants out of it and then spills them
     const int64_t t = (int64_t)blockIdx.x * WPB + wave;
@@ -494,18 +500,18 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
                 const double rs = tpcn_scale_ct<TP>(rho, p.nu, q0, p.gam, i);
                 if (NOISE == ASMC_NOISE_F64) {
 #pragma unroll
-                    for (int pr = 0; pr < D / 2; pr++) {
-                        double z0, z1;
-                        normal_pair(p.seed, gid, step, (uint32_t)pr, z0, z1);
-                        v[2 * pr] = fma(rs, z0, a * v[2 * pr]);
-                        v[2 * pr + 1] = fma(rs, z1, a * v[2 * pr + 1]);
-                        if (M == PCN_Y_STEP) {
-                            v[2 * pr] = (double)(T)v[2 * pr];
-                            v[2 * pr + 1] = (double)(T)v[2 * pr + 1];
+                    for (int qd = 0; qd < (D + 3) / 4; qd++) {
+                        double z[4];
+                        normal_quad(p.seed, gid, step, (uint32_t)qd, bmt, z[0], z[1], z[2], z[3]);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if (4 * qd + e < D) {
+                                v[4 * qd + e] = fma(rs, z[e], a * v[4 * qd + e]);
+                                if (M == PCN_Y_STEP) v[4 * qd + e] = (double)(T)v[4 * qd + e];
+                                q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
+                            }
                         }
-                        q1 = fma(v[2 * pr], v[2 * pr], q1);
-                        q1 = fma(v[2 * pr + 1], v[2 * pr + 1], q1);
-                        __builtin_amdgcn_sched_barrier(0);  // one pair at a time (register pressure)
+                        __builtin_amdgcn_sched_barrier(0);  // one block at a time (register pressure)
                     }
                 } else {
 #pragma unroll
@@ -714,6 +720,12 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
     const double a = sqrt(1.0 - rho * rho);
     long long n_acc = 0;
     const int64_t n_tiles = (n + 63) / 64;
+    bm_d2* bmt = nullptr;  // Box-Muller tables of the default noise (see pcn_reg_body)
+    if constexpr (NOISE == ASMC_NOISE_F64) {
+        bmt = bm_lds();
+        bm_tab_stage_rt(bmt, p.bmtab);
+        __syncthreads();
+    }
     const int64_t t = (int64_t)blockIdx.x * WPB + wave;  // one tile per wave, no loop (see k_pcn_reg)
     if (t < n_tiles) {
         const int64_t row0 = t * 64;
@@ -762,13 +774,16 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
             const double rs = tpcn_scale(rho, p.nu, q0, p.gam, i);  // the same variate in both modes
             if (NOISE == ASMC_NOISE_F64) {
 #pragma unroll
-                for (int pr = 0; pr < D / 2; pr++) {
-                    double z0, z1;
-                    normal_pair(p.seed, gid, step, (uint32_t)pr, z0, z1);
-                    v[2 * pr] = (double)(T)fma(rs, z0, a * v[2 * pr]);
-                    v[2 * pr + 1] = (double)(T)fma(rs, z1, a * v[2 * pr + 1]);
-                    q1 = fma(v[2 * pr], v[2 * pr], q1);
-                    q1 = fma(v[2 * pr + 1], v[2 * pr + 1], q1);
+                for (int qd = 0; qd < (D + 3) / 4; qd++) {
+                    double z[4];
+                    normal_quad(p.seed, gid, step, (uint32_t)qd, bmt, z[0], z[1], z[2], z[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (4 * qd + e < D) {
+                            v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
+                            q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -877,10 +892,16 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
 template <bool F32>
 __global__ __launch_bounds__(ASMC_BLOCK) void k_gamma_draw(int64_t n, double shape, unsigned long long seed,
                                                           unsigned long long gid0, uint32_t step,
-                                                          double* __restrict__ out) {
+                                                          double* __restrict__ out, const double* __restrict__ bmtab) {
+    bm_d2* bmt = nullptr;
+    if constexpr (!F32) {
+        bmt = bm_lds();
+        bm_tab_stage<ASMC_BLOCK>(bmt, bmtab);
+        __syncthreads();
+    }
     const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride)
-        out[i] = gamma_unit<F32>(shape, seed, gid0 + (unsigned long long)i, step);
+        out[i] = gamma_unit<F32>(shape, seed, gid0 + (unsigned long long)i, step, bmt);
 }
 
 // before a step kernel: draws the step's scale variates into ctx->d_gamma and points pd.gam at them (tpCN only)
@@ -892,10 +913,12 @@ static int pcn_prepare_gamma(asmc_ctx* ctx, int64_t n, PcnDev& pd, uint32_t step
     const int grid = grid_for(n, ASMC_BLOCK, ASMC_MAX_BLOCKS * 4);
     if (pd.noise == ASMC_NOISE_F32)
         ASMC_LAUNCH(ctx, st, "k_gamma_draw", k_gamma_draw<true>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n,
-                    0.5 * ((double)pd.d + pd.nu), (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma);
+                    0.5 * ((double)pd.d + pd.nu), (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma,
+                    (const double*)ctx->d_bmtab);
     else
         ASMC_LAUNCH(ctx, st, "k_gamma_draw", k_gamma_draw<false>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n,
-                    0.5 * ((double)pd.d + pd.nu), (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma);
+                    0.5 * ((double)pd.d + pd.nu), (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma,
+                    (const double*)ctx->d_bmtab);
     ASMC_LAUNCH_CHECK();
     pd.gam = ctx->d_gamma;
     return ASMC_OK;
@@ -1067,18 +1090,24 @@ template <typename T>
 __global__ __launch_bounds__(ASMC_BLOCK) void k_gaussian_draw(int64_t n, int d, const double* __restrict__ mu,
                                                              const double* __restrict__ sigma,
                                                              unsigned long long seed, unsigned long long gid0,
-                                                             uint32_t draw_id, T* __restrict__ x) {
-    const int pairs = (d + 1) / 2;
-    const int64_t total = n * pairs;
+                                                             uint32_t draw_id, T* __restrict__ x,
+                                                             const double* __restrict__ bmtab) {
+    bm_d2* bmt = bm_lds();
+    bm_tab_stage<ASMC_BLOCK>(bmt, bmtab);
+    __syncthreads();
+    const int quads = (d + 3) / 4;  // one Philox block = four coordinates (asmc_pcn_dev.h normal_quad)
+    const int64_t total = n * quads;
     const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
     for (int64_t e = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; e < total; e += stride) {
-        const int64_t i = e / pairs;
-        const int pr = (int)(e - i * pairs);
-        double z0, z1;
-        normal_pair(seed, gid0 + (unsigned long long)i, draw_id, (uint32_t)pr, z0, z1);
-        const int j = 2 * pr;
-        x[i * d + j] = (T)fma(sigma[j], z0, mu[j]);
-        if (j + 1 < d) x[i * d + j + 1] = (T)fma(sigma[j + 1], z1, mu[j + 1]);
+        const int64_t i = e / quads;
+        const int qd = (int)(e - i * quads);
+        double z[4];
+        normal_quad(seed, gid0 + (unsigned long long)i, draw_id, (uint32_t)qd, bmt, z[0], z[1], z[2], z[3]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int j = 4 * qd + c;
+            if (j < d) x[i * d + j] = (T)fma(sigma[j], z[c], mu[j]);
+        }
     }
 }
 
@@ -1366,7 +1395,7 @@ static int pick_vec(int rowbytes, const void* p0, const void* p1) {
 }
 
 static int waves_for_lds(size_t per_wave_bytes, size_t* lds_bytes_out) {
-    const size_t budget = 160 * 1024 - 1024;
+    const size_t budget = 160 * 1024 - 1024 - BM_TAB_N * 16;  // (the block's Box-Muller tables sit next to the tiles)
     int w = ASMC_BLOCK / 64;
     while (w > 1 && per_wave_bytes * (size_t)w > budget) w >>= 1;
     *lds_bytes_out = per_wave_bytes * (size_t)w;
@@ -1421,7 +1450,10 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     static int wpb_env = getenv("ASMC_PCN_WPB") ? atoi(getenv("ASMC_PCN_WPB")) : 0;
     constexpr bool NO_LDS = MODE == PCN_Y_STEP_S || MODE == PCN_Y_STEP_TS || MODE == PCN_Y_STEP_SG ||
                             MODE == PCN_Y_STEP_TSG;  // coordinate-major state: registers only
-    const int wpb = wpb_env > 0 ? wpb_env : (NO_LDS || (160 * 1024) / tile_bytes % 4 == 0 || tile_bytes * 12 <= 160 * 1024 ? 4 : 1);
+    // kernels that draw the default noise keep its 6 KB of tables per BLOCK next to the tiles: four waves share them
+    constexpr bool BM = NOISE == ASMC_NOISE_F64 && !(MODE == PCN_WHITEN || MODE == PCN_WHITEN_S || MODE == PCN_UNWHITEN ||
+                                                     MODE == PCN_UNWHITEN_S || MODE == PCN_UNWHITEN_X || MODE == PCN_UNWHITEN_XS);
+    const int wpb = wpb_env > 0 ? wpb_env : (BM || NO_LDS || (160 * 1024) / tile_bytes % 4 == 0 || tile_bytes * 12 <= 160 * 1024 ? 4 : 1);
     const size_t lds_bytes = NO_LDS ? 0 : (size_t)wpb * tile_bytes;
     const int64_t n_tiles = (n + 63) / 64;
     const int64_t grid64 = (n_tiles + wpb - 1) / wpb;
@@ -1446,6 +1478,7 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     ps.d_real = pd.d;
     ps.seed = pd.seed;
     ps.gid0 = pd.gid0;
+    ps.bmtab = pd.bmtab;
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
@@ -1463,7 +1496,7 @@ static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double
     constexpr int LDSROW = D * (int)sizeof(T) + 16;
     constexpr size_t tile_bytes = (size_t)64 * LDSROW;
     constexpr bool NO_LDS = MODE == PCN_FLOW_ACCEPT_S || MODE == PCN_FLOW_ACCEPT_SJ;
-    const int wpb = (NO_LDS || (160 * 1024) / tile_bytes % 4 == 0 || tile_bytes * 12 <= 160 * 1024) ? 4 : 1;
+    const int wpb = (NOISE == ASMC_NOISE_F64 || NO_LDS || (160 * 1024) / tile_bytes % 4 == 0 || tile_bytes * 12 <= 160 * 1024) ? 4 : 1;  // (f64 noise: 6 KB of tables per block)
     const size_t lds_bytes = NO_LDS ? 0 : (size_t)wpb * tile_bytes;
     const int64_t grid64 = ((n + 63) / 64 + wpb - 1) / wpb;
     if (grid64 > ASMC_PCN_MAX_GRID) {
@@ -1486,6 +1519,7 @@ static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double
     ps.d_real = pd.d;
     ps.seed = pd.seed;
     ps.gid0 = pd.gid0;
+    ps.bmtab = pd.bmtab;
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
@@ -1572,12 +1606,12 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
     const size_t per_wave = (size_t)64 * lds_row_stride(rowbytes) + (size_t)64 * 8 * pd.d;
     size_t lds_bytes = 0;
     const int wpb = waves_for_lds(per_wave, &lds_bytes);
-    if (per_wave > 160 * 1024 - 1024) {
+    if (per_wave > 160 * 1024 - 1024 - BM_TAB_N * 16) {
         asmc_set_error("pcn: d=%d needs %zu B of LDS per wave (unsupported)", pd.d, per_wave);
         return ASMC_ERR_UNSUPPORTED;
     }
     const int64_t n_tiles = (n + 63) / 64;
-    int blocks_per_cu = (int)((160 * 1024) / lds_bytes);
+    int blocks_per_cu = (int)((160 * 1024) / (lds_bytes + BM_TAB_N * 16));
     blocks_per_cu = blocks_per_cu < 1 ? 1 : (blocks_per_cu > 8 ? 8 : blocks_per_cu);
     int cap = ctx->num_cu * blocks_per_cu * 2;  // two rounds of resident blocks, grid-stride over tiles
     if (cap > ASMC_MAX_BLOCKS) cap = ASMC_MAX_BLOCKS;
@@ -1615,16 +1649,16 @@ int asmc_gaussian_draw(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const doubl
     ASMC_REQUIRE(n > 0 && d > 0 && d <= ASMC_MAX_DIMS, "bad sizes");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(n * ((d + 1) / 2), ASMC_BLOCK * 2, ASMC_MAX_BLOCKS * 2);
+    const int grid = grid_for(n * ((d + 3) / 4), ASMC_BLOCK * 2, ASMC_MAX_BLOCKS * 2);
     const int grid2 = grid_for(n, ASMC_BLOCK, ASMC_MAX_BLOCKS * 2);
     if (x_dtype == ASMC_F64) {
         ASMC_LAUNCH(ctx, st, "k_gaussian_draw<double>", k_gaussian_draw<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma,
-                           (unsigned long long)seed, (unsigned long long)gid0, draw_id, (double*)x_out);
+                           (unsigned long long)seed, (unsigned long long)gid0, draw_id, (double*)x_out, (const double*)ctx->d_bmtab);
         ASMC_LAUNCH_CHECK();
         if (lq_out) ASMC_LAUNCH(ctx, st, "k_gaussian_logq<double>", k_gaussian_logq<double>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma, (const double*)x_out, lq_out);
     } else {
         ASMC_LAUNCH(ctx, st, "k_gaussian_draw<float>", k_gaussian_draw<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma,
-                           (unsigned long long)seed, (unsigned long long)gid0, draw_id, (float*)x_out);
+                           (unsigned long long)seed, (unsigned long long)gid0, draw_id, (float*)x_out, (const double*)ctx->d_bmtab);
         ASMC_LAUNCH_CHECK();
         if (lq_out) ASMC_LAUNCH(ctx, st, "k_gaussian_logq<float>", k_gaussian_logq<float>, dim3(grid2), dim3(ASMC_BLOCK), 0, st, n, d, mu, sigma, (const float*)x_out, lq_out);
     }
@@ -1988,6 +2022,7 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     hipStream_t st = as_stream(stream);
     PcnDev pd;
     memset(&pd, 0, sizeof(pd));
+    pd.bmtab = ctx->d_bmtab;
     pd.d = prm->d;
     pd.beta = prm->beta;
     pd.mu = prm->mu_dev;
@@ -2152,6 +2187,7 @@ int asmc_pcn_propose(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x
     hipStream_t st = as_stream(stream);
     PcnDev pd;
     memset(&pd, 0, sizeof(pd));
+    pd.bmtab = ctx->d_bmtab;
     pd.d = d;
     pd.mu = mu;
     pd.L = L;
@@ -2213,6 +2249,7 @@ static int ysplit_pd(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm, PcnDe
     ASMC_REQUIRE(prm->mu_dev && prm->L_dev && prm->Linv_dev, "null reference pointer");
     ASMC_REQUIRE(!(prm->nu > 0.0) || prm->nu >= 1.0, "nu must be >= 1 (or <= 0 for the Gaussian reference)");
     memset(&pd, 0, sizeof(pd));
+    pd.bmtab = ctx->d_bmtab;
     pd.d = prm->d;
     pd.beta = prm->beta;
     pd.mu = prm->mu_dev;
@@ -2494,6 +2531,7 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
     double* lq_new = reinterpret_cast<double*>(w + xb + 4 * vb);
     PcnDev pd;
     memset(&pd, 0, sizeof(pd));
+    pd.bmtab = ctx->d_bmtab;
     pd.d = d;
     pd.mu = prm->mu_dev;
     pd.L = prm->L_dev;

@@ -145,13 +145,83 @@ __device__ __forceinline__ void box_muller(double u1, double u2, double& z0, dou
     z1 = r * s;
 }
 
-// counter = {gid_lo, gid_hi, step, slot}; key = {seed_lo, seed_hi}
-__device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned long long gid,
-                                            uint32_t step, uint32_t slot, double& z0, double& z1) {
+// ---- the default ("f64") noise: table-driven fp64 Box-Muller on 32-bit uniforms (round 3) ---------------------------
+// One Philox block = FOUR standard normals (two Box-Muller pairs).  Words (w0, w1) make pair A, (w2, w3) pair B:
+//     u = (w_r + 1/2) 2^-32  in (0, 1),   t = (w_a + 1/2) 2^-32 turns,   r = sqrt(-2 ln u),   (z_even, z_odd) = r (cos, sin)(2 pi t)
+// all in fp64.  32-bit uniforms: |z| <= 6.76, P(|z| > 6.66) = 2.7e-11 is the mass a 53-bit radius would add; the angle has
+// 2^32 directions.  (Rounds 1-2 spent one block per PAIR on two 53-bit uniforms and evaluated log / sincos with msun's
+// general kernels: 179 vector instructions per pair, 45 % of the fused flow step's vector work.)  The two elementary
+// functions are table driven (bm_tab: 6 KB, staged into LDS by every kernel that draws):
+//   * ln: X = w_r + 1/2 = 2^e m, m in [1/2, 1); interval i = top 7 mantissa bits of m, c_i its centre, rc_i = fl(1 / c_i);
+//     r = fma(m, rc_i, -1) (|r| <= 2^-8, one rounding) and -2 ln u = (32 - e) 2 ln 2 + 2 ln(rc_i) - 2 log1p(r) with the
+//     degree-6 series of log1p (truncation 2^-56 / 3.5); the table holds (rc_i, 2 ln rc_i).
+//   * sincos: the top 8 bits of w_a pick (S, C) = (sin, cos)(2 pi (k + 1/2) / 256) from the table, the other 24 bits are
+//     x = 2 pi ((w_a mod 2^24) + 1/2 - 2^23) 2^-32, |x| <= 2 pi / 512, whose sine and cosine - 1 are 4- and 3-term series
+//     (truncation 1.7e-23, 1.3e-20); angle addition S + (S (cos x - 1) + C sin x), C + (C (cos x - 1) - S sin x).
+// Against libm on the same (u, t) (the CPU restatement used by the tests): a few 1e-16 absolute.
+// (BM_SC_N, BM_LG_N, BM_TAB_N: asmc_common.h)
+typedef double bm_d2 __attribute__((ext_vector_type(2)));
+void asmc_bm_table_host(double* tab);  // asmc_ctx.hip
+
+template <int THREADS>
+__device__ __forceinline__ void bm_tab_stage(bm_d2* __restrict__ s, const double* __restrict__ g) {
+    for (int e = threadIdx.x; e < BM_TAB_N; e += THREADS) s[e] = reinterpret_cast<const bm_d2*>(g)[e];
+}
+__device__ __forceinline__ void bm_tab_stage_rt(bm_d2* __restrict__ s, const double* __restrict__ g) {
+    for (int e = threadIdx.x; e < BM_TAB_N; e += (int)blockDim.x) s[e] = reinterpret_cast<const bm_d2*>(g)[e];
+}
+// the calling kernel's own 6 KB of LDS for the tables (one allocation per kernel that calls it; the caller stages
+// and synchronises)
+__device__ __forceinline__ bm_d2* bm_lds() {
+    __shared__ bm_d2 s_bm[BM_TAB_N];
+    return s_bm;
+}
+
+// one Box-Muller pair from a radius word and an angle word
+__device__ __forceinline__ void bm_pair32(uint32_t wr, uint32_t wa, const bm_d2* __restrict__ tab, double& z0, double& z1) {
+    const bm_d2 sc = tab[wa >> 24];
+    const double X = (double)wr + 0.5;
+    const double m = __builtin_amdgcn_frexp_mant(X);  // [1/2, 1)
+    const int e = __builtin_amdgcn_frexp_exp(X);      // 0 .. 32
+    const uint32_t mh = (uint32_t)((unsigned long long)__double_as_longlong(m) >> 32);
+    const bm_d2 lg = tab[BM_SC_N + ((mh >> 13) & (BM_LG_N - 1))];
+    // angle residual: sin x, cos x - 1
+    const double x = fma((double)((int)(wa & 0xFFFFFFu) - (1 << 23)), 1.4629180792671596e-09, 7.314590396335798e-10);  // 2 pi 2^-32, pi 2^-32
+    const double z = x * x;
+    const double ps = fma(z, fma(z, -1.9841269841269841e-04, 8.3333333333333332e-03), -1.6666666666666666e-01);
+    const double sx = fma(x * z, ps, x);
+    const double cm1 = z * fma(z, fma(z, -1.3888888888888889e-03, 4.1666666666666664e-02), -0.5);
+    const double sn = sc.x + fma(sc.y, sx, sc.x * cm1);
+    const double cs = sc.y + fma(-sc.x, sx, sc.y * cm1);
+    // radius
+    const double r = fma(m, lg.x, -1.0);
+    double p = fma(r, 3.3333333333333331e-01, -4.0000000000000002e-01);
+    p = fma(r, p, 0.5);
+    p = fma(r, p, -6.6666666666666663e-01);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, -2.0);
+    const double a = fma((double)(32 - e), 1.3862943611198906, lg.y) + r * p;
+    const double rad = bm_sqrt(a);
+    z0 = rad * cs;
+    z1 = rad * sn;
+}
+
+// counter = {gid_lo, gid_hi, step, slot}; key = {seed_lo, seed_hi}.  Coordinates 4 q .. 4 q + 3 come from the block with
+// slot = q | 0x20000000.
+__device__ __forceinline__ void normal_quad(unsigned long long seed, unsigned long long gid, uint32_t step, uint32_t q,
+                                            const bm_d2* __restrict__ tab, double& z0, double& z1, double& z2, double& z3) {
     uint32_t w[4];
-    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, slot, (uint32_t)seed,
-                  (uint32_t)(seed >> 32), w);
-    box_muller(u01_from_words(w[0], w[1]), u01_from_words(w[2], w[3]), z0, z1);
+    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, q | 0x20000000u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    bm_pair32(w[0], w[1], tab, z0, z1);
+    bm_pair32(w[2], w[3], tab, z2, z3);
+}
+// coordinates 2 pr, 2 pr + 1 alone (a whole block for one pair: callers that own single pairs)
+__device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned long long gid, uint32_t step, uint32_t pr,
+                                            const bm_d2* __restrict__ tab, double& z0, double& z1) {
+    uint32_t w[4];
+    philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, (pr >> 1) | 0x20000000u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+    const bool second = pr & 1u;
+    bm_pair32(second ? w[2] : w[0], second ? w[3] : w[1], tab, z0, z1);
 }
 
 // Fast noise (NOISE_F32): one Philox block -> FOUR standard normals through fp32 Box-Muller on the
@@ -196,38 +266,32 @@ __device__ __forceinline__ double accept_uniform(unsigned long long seed, unsign
 }
 
 // ---- t-preconditioned Crank-Nicolson (step_fn "tpcn"; specification: DESIGN.md §3.6) ---------------------------
-// unit-scale Gamma(shape >= 1) variate, Marsaglia & Tsang (2000), counter slots 0x80000000 | {2a, 2a + 1} of attempt a < 8.
-// F32 (the fast-noise mode): ONE Philox block per attempt, slot 0xC0000000 | a - the normal from words 0, 1 through the
-// hardware fp32 Box-Muller of normal_quad_f32, the uniform from words 2, 3.
+// unit-scale Gamma(shape >= 1) variate, Marsaglia & Tsang (2000): ONE Philox block per attempt a < 8 - the normal from words
+// 0, 1 (the first variate of bm_pair32 in the default mode, slot 0x80000000 | a; the hardware fp32 Box-Muller of
+// normal_quad_f32 in the fast-noise mode F32, slot 0xC0000000 | a), the 53-bit uniform from words 2, 3.
 template <bool F32 = false>
 __device__ __forceinline__ double gamma_unit(double shape, unsigned long long seed, unsigned long long gid,
-                                             uint32_t step) {
+                                             uint32_t step, const bm_d2* __restrict__ tab) {
     const double dd = shape - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * dd);
     // fully unrolled (nested early exits, no loop).  P(all 8 attempts fail) < 0.05^8 = 4e-11.
 #pragma unroll
     for (uint32_t a = 0; a < 8; a++) {
-        double z0, u;
+        double z0;
+        uint32_t w[4];
+        philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, (F32 ? 0xC0000000u : 0x80000000u) | a, (uint32_t)seed, (uint32_t)(seed >> 32), w);
         if (F32) {
-            uint32_t w[4];
-            philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, 0xC0000000u | a, (uint32_t)seed, (uint32_t)(seed >> 32), w);
             const float k = 2.3283064365386963e-10f;  // 2^-32
             const float u0 = fmaf((float)w[0], k, 1.1641532182693481e-10f);
             const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
             z0 = (double)(r0 * __builtin_amdgcn_cosf((float)w[1] * k));
-            u = u01_from_words(w[2], w[3]);
         } else {
             double z1;
-            normal_pair(seed, gid, step, 0x80000000u | (2u * a), z0, z1);
+            bm_pair32(w[0], w[1], tab, z0, z1);
         }
+        const double u = u01_from_words(w[2], w[3]);
         double v = 1.0 + c * z0;
         if (v <= 0.0) continue;
         v = v * v * v;
-        if (!F32) {
-            uint32_t w[4];
-            philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, 0x80000000u | (2u * a + 1u), (uint32_t)seed,
-                          (uint32_t)(seed >> 32), w);
-            u = u01_from_words(w[0], w[1]);
-        }
         if (log(u) < 0.5 * z0 * z0 + dd - dd * v + dd * log(v)) return dd * v;
     }
     return dd;
@@ -296,6 +360,7 @@ struct PcnDev {
     const double* gam;  // [n] unit-scale Gamma((d + nu)/2) variates of the current step (tpCN), else nullptr
     void* ys;           // coordinate-major whitened state of the register-resident kernels (or nullptr)
     long long n_pad;
+    const double* bmtab;  // the Box-Muller tables in HBM (ctx->d_bmtab)
     int dpad;           // > d: run the d-dimensional problem on the kernels compiled for dpad (identity-padded tables)
     int mode;  // PCN_X_STEP / PCN_Y_STEP / PCN_WHITEN / PCN_UNWHITEN (register-resident kernels)
 };
@@ -315,6 +380,7 @@ struct PcnScalars {
     int d_real;         // PCN_X_PROPOSE_PAD*: the problem's dimension (< D)
     unsigned long long seed, gid0;
     int c_ll, c_lp, c_lq;
+    const double* bmtab;  // the Box-Muller tables in HBM (ctx->d_bmtab)
 };
 
 

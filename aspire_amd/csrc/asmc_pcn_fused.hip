@@ -29,6 +29,7 @@
 // buffer of the state's layout (fire-and-forget stores), accepted lanes fetch it back (cache-hot) and store it into the state.
 // The flow's weights stay resident in LDS (115 KB at d = 32, W = 64: one block of 8 waves per CU, two waves per SIMD, so
 // one wave's vector work - noise, mat-vec, accept - runs in the shadow of its partner's MFMA chains).
+#define FUSED_TL_DOUBLES (32 * 32 + 7 * 32 + 2)  // doubles of the pCN tables in LDS (d = 32), 16-byte aligned end
 #ifndef MV_DEPTH
 #define MV_DEPTH 4  // batches of mat-vec coefficients in flight (16 VGPRs each)
 #endif
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     double* tl = reinterpret_cast<double*>(sp + (size_t)n_layers * FD::LAYER);
     constexpr int T_MU = D * D, T_LLMU = T_MU + D, T_LLPR = T_LLMU + D, T_LPMU = T_LLPR + D, T_LPPR = T_LPMU + D,
                   T_LOGW = T_LPPR + D, T_LOC = T_LOGW + 2;  // then loc / scale / 1/scale: 3 x D floats = 1.5 D doubles
+    static_assert(T_LOC + 3 * D / 2 <= FUSED_TL_DOUBLES, "pCN tables");
     {
         const double* m0g = ptab + 2 * PTAB_TRI(D) + D;
         for (int e = threadIdx.x; e < D * D; e += THREADS) {
@@ -101,6 +103,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         }
         if (threadIdx.x == 0) tl[T_LOGW] = m0g[0], tl[T_LOGW + 1] = m0g[PTAB_MIX(D)];
     }
+    // ... and the Box-Muller tables of the default noise behind them (6 KB)
+    bm_d2* bmt = reinterpret_cast<bm_d2*>(tl + FUSED_TL_DOUBLES);
+    if (NOISE == ASMC_NOISE_F64) bm_tab_stage<THREADS>(bmt, p.bmtab);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5;
     const bool first_on_simd = __builtin_amdgcn_readfirstlane(wave) < 4;
@@ -186,13 +191,14 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         const double rs = tpcn_scale(rho, p.nu, q0, p.gam, valid ? i : 0);
         if (NOISE == ASMC_NOISE_F64) {
 #pragma unroll
-            for (int pr = 0; pr < D / 2; pr++) {
-                double z0, z1;
-                normal_pair(p.seed, gid, step, (uint32_t)pr, z0, z1);
-                v[2 * pr] = (double)(T)fma(rs, z0, a * v[2 * pr]);
-                v[2 * pr + 1] = (double)(T)fma(rs, z1, a * v[2 * pr + 1]);
-                q1 = fma(v[2 * pr], v[2 * pr], q1);
-                q1 = fma(v[2 * pr + 1], v[2 * pr + 1], q1);
+            for (int qd = 0; qd < D / 4; qd++) {
+                double z[4];
+                normal_quad(p.seed, gid, step, (uint32_t)qd, bmt, z[0], z[1], z[2], z[3]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
+                    q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -478,6 +484,7 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = 0;
+    ps.bmtab = pd.bmtab;
     const float ladj0 = (float)(-f->log_scale_sum);
     const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
     const int64_t n_tiles = (n + 63) / 64;
@@ -489,7 +496,7 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
 #define ASMC_FUSED_CASE(WW, NZ, HSV)                                                                                     \
     if (f->hidden == WW && pd.noise == NZ && hs == HSV) {                                                                \
         auto kern = k_pcn_flow_fused<T, WW, NZ, HSV>;                                                                         \
-        const size_t lds = (size_t)f->n_layers * FlowDims<16, WW>::LAYER * sizeof(float) + (32 * 32 + 7 * 32 + 2) * sizeof(double); \
+        const size_t lds = (size_t)f->n_layers * FlowDims<16, WW>::LAYER * sizeof(float) + FUSED_TL_DOUBLES * sizeof(double) + BM_TAB_N * sizeof(bm_d2); \
         static size_t attr_lds = 0;                                                                                      \
         if (lds > 64 * 1024 && lds > attr_lds) {                                                                         \
             ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -526,7 +533,7 @@ bool asmc_pcn_flow_fused_ok(const asmc_pcn_params* prm, const asmc_coupling* f) 
     if (prm->log_likelihood.n_components != 1 || prm->log_prior.n_components != 1) return false;
     if (!(f->hidden == 32 || f->hidden == 64 || f->hidden == 128)) return false;
     const size_t per_layer = (size_t)((2 * (f->hidden / 32) + 1) * 32 + f->hidden * 16 + f->hidden * f->hidden + 2 * 16 * f->hidden) * sizeof(float);
-    return per_layer * (size_t)f->n_layers <= 150 * 1024;
+    return per_layer * (size_t)f->n_layers + FUSED_TL_DOUBLES * sizeof(double) + BM_TAB_N * sizeof(bm_d2) <= 160 * 1024;
 }
 
 

@@ -149,6 +149,11 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
         mm_stage_tables<D>(t_lp, p.lp, threadIdx.x, MM_THREADS);
         mm_stage_tables<D>(t_lq, p.lq, threadIdx.x, MM_THREADS);
     }
+    bm_d2* bmt = nullptr;  // Box-Muller tables of the default noise
+    if constexpr (M == MM_STEP && NOISE == ASMC_NOISE_F64) {
+        bmt = bm_lds();
+        bm_tab_stage<MM_THREADS>(bmt, p.bmtab);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pp = lane & 15, h = lane >> 4;
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
                     z0 = (double)zf[(2 * sp) % KS];
                     z1 = (double)zf[(2 * sp + 1) % KS];
                 } else {  // coordinates 2 pr, 2 pr + 1 from pair pr: exactly the owned pair
-                    normal_pair(p.seed, gid, step, (uint32_t)(4 * sp + h), z0, z1);
+                    normal_pair(p.seed, gid, step, (uint32_t)(4 * sp + h), bmt, z0, z1);
                 }
                 v[2 * sp] = (double)(T)fma(rs, z0, a * v[2 * sp]);
                 v[2 * sp + 1] = (double)(T)fma(rs, z1, a * v[2 * sp + 1]);
@@ -422,7 +427,7 @@ template <typename T, int D, int NOISE, int MODE>
 static int launch_mm(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const double* pack, const PcnDev& pd,
                      const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out, hipStream_t st) {
     const size_t lds = ((size_t)mm_ksum(D / 16) * 64 + D + (size_t)(pd.ll.C + pd.lp.C + pd.lq.C) * D * 2) * sizeof(double);
-    ASMC_REQUIRE(lds <= 160 * 1024 - 256, "operand image and density tables exceed the LDS");
+    ASMC_REQUIRE(lds <= 160 * 1024 - 256 - BM_TAB_N * sizeof(bm_d2), "operand image and density tables exceed the LDS");
     auto kern = k_pcn_mm<T, D, NOISE, MODE>;
     static size_t attr_lds = 0;
     if (lds > 64 * 1024 && lds > attr_lds) {

@@ -119,7 +119,7 @@ def main():
     assert np.array_equal(s0, s1) and np.array_equal(g0, g1)
     # 6. the whole sampler through the sharded code path (every `comm.sharded` branch: sharded search, owner-layout
     #    resampling, summed moments, exchanged accept counts with the prologue adaptation) against the single-rank run:
-    #    one rank owns everything, so log Z, the schedule and the final particles must be identical
+    #    one rank owns everything, so the schedule and the final particles must be identical (log Z to rounding)
     from aspire_amd.flows import CouplingFlow, GaussianFlow
     from aspire_amd.samplers.smc import HipSMC
     from aspire_amd.targets import DiagGaussianMixture
@@ -145,7 +145,10 @@ def main():
         sp1, out1 = run_sampler(True, flow, step_fn)
         assert sp0.history.beta == sp1.history.beta, (sp0.history.beta, sp1.history.beta)
         assert sp0.history.mcmc_acceptance == sp1.history.mcmc_acceptance
-        assert float(out0.log_evidence) == float(out1.log_evidence), (float(out0.log_evidence), float(out1.log_evidence))
+        # (the evidence terms come from different reduction orders - the persistent single-rank kernel against the per-round
+        # records of the sharded search - so log Z agrees to rounding, not to the bit; schedule and particles are exact)
+        assert abs(float(out0.log_evidence) - float(out1.log_evidence)) <= 1e-13 * abs(float(out0.log_evidence)), (
+            float(out0.log_evidence), float(out1.log_evidence))
         x0_, x1_ = (o.x.cpu().numpy() if isinstance(o.x, torch.Tensor) else np.asarray(o.x) for o in (out0, out1))
         assert np.array_equal(x0_, x1_)
     torch.cuda.synchronize()
