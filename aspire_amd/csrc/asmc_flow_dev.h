@@ -336,6 +336,139 @@ __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], fl
     }
 }
 
+// ---- two tiles through one coupling layer, matrix and vector work interleaved by hand (round 3) ---------------------------
+// coupling_layer_hs leaves the order of a tile's instructions to the compiler, which emits a K-step's conversions (16-24
+// vector instructions) and then its MFMAs back to back (3-6 of them, 32 cycles each): while a burst runs the wave has no
+// vector instruction to issue, and while it converts the matrix pipe idles - in the fused flow step (two waves per SIMD)
+// the two pipes ran one after the other: vector ALU active 58 %, matrix pipe 24 %, sum 83 % of the kernel.  Here the wave's TWO
+// flow tiles (A, B) go through the layer together, one K-step group at a time, and every MFMA of one tile is followed by a
+// quarter of the OTHER tile's next operand conversion (two elements: ReLU, range check, hi pair, lo pair - about one MFMA's
+// worth of issue cycles), fenced by scheduling barriers so that the order survives:
+//     cvt A(0);  for g:  { MFMAs A(g) | cvt B(g) }  { MFMAs B(g) | cvt A(g + 1) }  ...  { MFMAs B(last) | epilogue A };  epilogue B
+// The A operands of a group are read once for both tiles.  Same operations in the same order per accumulator as
+// coupling_layer_hs: bit-identical results.
+typedef unsigned flow_u4 __attribute__((ext_vector_type(4)));
+
+// elements (x0, x1) -> their packed hi halves and lo halves (see split8_f16)
+template <bool RELU>
+__device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& hp, unsigned& lp, float& amax) {
+    const float v0 = RELU ? __int_as_float(max(__float_as_int(x0), 0)) : x0;
+    const float v1 = RELU ? __int_as_float(max(__float_as_int(x1), 0)) : x1;
+    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v0)), __builtin_fabsf(v1));  // one v_max3_f32
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const half2v h = half2v{(_Float16)v0, (_Float16)v1};
+    half2v l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(l)
+        : "v"(h), "v"(v0), "v"(v1));
+    hp = __builtin_bit_cast(unsigned, h);
+    lp = __builtin_bit_cast(unsigned, l);
+}
+
+template <int H, int W>
+__device__ __forceinline__ void coupling_layer_hs2(const float (&condA)[H / 2], float (&transA)[H / 2], const float (&condB)[H / 2],
+                                                   float (&transB)[H / 2], const float* __restrict__ lp, int lane, int hh,
+                                                   float& ladjA, float& ladjB, float& amaxA, float& amaxB) {
+    using FD = FlowDims<H, W>;
+    static_assert(H == 16, "one K16 step over the conditioner inputs");
+    constexpr int NB1 = FD::NB1, NB3 = FD::NB3, ST1 = H / 16, ST2 = 2 * NB1, G = ST1 + 2 * ST2;
+    const float* b1 = lp;
+    const float* b2 = b1 + NB1 * 32;
+    const float* b3 = b2 + NB1 * 32;
+    const float* a1f = b3 + NB3 * 32;
+    const half8* A1 = reinterpret_cast<const half8*>(a1f) + lane;
+    const half8* A2 = reinterpret_cast<const half8*>(a1f + W * H) + lane;
+    const half8* A3 = reinterpret_cast<const half8*>(a1f + W * H + W * W) + lane;
+    floatx16 h1A[NB1], h1B[NB1], h2A[NB1], h2B[NB1], oA[NB3], oB[NB3];
+    acc_bias1<NB1>(h1A, b1, hh);  // (each tile reads its own copy of the bias: LDS reads cost no vector instruction, moves would)
+    acc_bias1<NB1>(h1B, b1, hh);
+    // source element j of group g's operand: the conditioner input (g < ST1), then h1 (pre-activation), then h2
+    auto src = [&](const float (&cond)[H / 2], const floatx16 (&h1)[NB1], const floatx16 (&h2)[NB1], int g, int j) -> float {
+        if (g < ST1) return cond[8 * g + j];
+        const int S = (g - ST1) % ST2;
+        return g < ST1 + ST2 ? h1[S / 2][8 * (S % 2) + j] : h2[S / 2][8 * (S % 2) + j];
+    };
+    unsigned hpA[4], lpA[4], hpB[4], lpB[4];
+    auto cvtA = [&](int g, int c) {
+        if (g < ST1) split2_f16<false>(src(condA, h1A, h2A, g, 2 * c), src(condA, h1A, h2A, g, 2 * c + 1), hpA[c], lpA[c], amaxA);
+        else split2_f16<true>(src(condA, h1A, h2A, g, 2 * c), src(condA, h1A, h2A, g, 2 * c + 1), hpA[c], lpA[c], amaxA);
+    };
+    auto cvtB = [&](int g, int c) {
+        if (g < ST1) split2_f16<false>(src(condB, h1B, h2B, g, 2 * c), src(condB, h1B, h2B, g, 2 * c + 1), hpB[c], lpB[c], amaxB);
+        else split2_f16<true>(src(condB, h1B, h2B, g, 2 * c), src(condB, h1B, h2B, g, 2 * c + 1), hpB[c], lpB[c], amaxB);
+    };
+    auto pack = [](const unsigned (&q)[4]) -> half8 { return __builtin_bit_cast(half8, flow_u4{q[0], q[1], q[2], q[3]}); };
+    // the epilogue of one tile in four parts (two of its H / 2 coordinates each)
+    auto epi = [&](const floatx16 (&o)[NB3], float (&trans)[H / 2], float& ladj, int c) {
+#pragma unroll
+        for (int q = 2 * c; q < 2 * c + 2; q++) {
+            const float sraw = o[q / 16][q % 16];
+            const float t = o[(H / 2 + q) / 16][(H / 2 + q) % 16];
+            const float sv = 2.0f - 4.0f * __builtin_amdgcn_rcpf(__expf(sraw) + 1.0f);  // 2 tanh(sraw / 2), see coupling_layer
+            trans[q] = (trans[q] - t) * __expf(-sv);
+            ladj -= sv;
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; c++) cvtA(0, c);
+    half8 bhA = pack(hpA), blA = pack(lpA), bhB, blB;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        // group g: layer, K-step, output blocks, operand image
+        const int layer = g < ST1 ? 0 : g < ST1 + ST2 ? 1 : 2;
+        const int S = layer == 0 ? g : (g - ST1) % ST2, ST = layer == 0 ? ST1 : ST2;
+        const int NBO = layer == 2 ? NB3 : NB1;
+        const half8* Ap = layer == 0 ? A1 : layer == 1 ? A2 : A3;
+        half8 ah[NB1 > NB3 ? NB1 : NB3], al[NB1 > NB3 ? NB1 : NB3];
+#pragma unroll
+        for (int nb = 0; nb < NBO; nb++) {
+            ah[nb] = Ap[(size_t)(2 * (nb * ST + S)) * 64];
+            al[nb] = Ap[(size_t)(2 * (nb * ST + S) + 1) * 64];
+        }
+        if (layer == 1 && S == 0) {  // the accumulators of the layer that starts here: bias
+            acc_bias1<NB1>(h2A, b2, hh);
+            acc_bias1<NB1>(h2B, b2, hh);
+        }
+        if (layer == 2 && S == 0) {
+            acc_bias1<NB3>(oA, b3, hh);
+            acc_bias1<NB3>(oB, b3, hh);
+        }
+        const int NM = 3 * NBO;
+        // { MFMAs A(g) | cvt B(g) }
+#pragma unroll
+        for (int m = 0; m < NM; m++) {
+            const int k = m / NBO, nb = m % NBO;
+            floatx16& acc = layer == 0 ? h1A[nb] : layer == 1 ? h2A[nb] : oA[nb];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < 2 ? ah[nb] : al[nb], k == 1 ? blA : bhA, acc, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (c * NM / 4 == m) cvtB(g, c);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bhB = pack(hpB), blB = pack(lpB);
+        // { MFMAs B(g) | cvt A(g + 1) }, the last group: { MFMAs B | epilogue A } - whose o is complete since the slot before
+#pragma unroll
+        for (int m = 0; m < NM; m++) {
+            const int k = m / NBO, nb = m % NBO;
+            floatx16& acc = layer == 0 ? h1B[nb] : layer == 1 ? h2B[nb] : oB[nb];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < 2 ? ah[nb] : al[nb], k == 1 ? blB : bhB, acc, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (c * NM / 4 == m) {
+                    if (g + 1 < G) cvtA(g + 1, c);
+                    else epi(oA, transA, ladjA, c);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g + 1 < G) bhA = pack(hpA), blA = pack(lpA);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) epi(oB, transB, ladjB, c);
+}
+
 // Stage `n_layers` coupling layers from the fp32 pack in HBM into LDS as split-fp16 operand images (biases copied).
 template <int H, int W, int THREADS>
 __device__ __forceinline__ void flow_stage_hs(float* __restrict__ sp, const float* __restrict__ packed, int n_layers) {

@@ -414,6 +414,9 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
         const unsigned long long ysa = (unsigned long long)(uintptr_t)ys;
         T* ysu = reinterpret_cast<T*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ysa >> 32)) << 32) |
                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ysa));
+        // after fused flow steps a tile's state lives in the half of the allocation its parity byte names (asmc_pcn_fused.hip)
+        if (M == PCN_UNWHITEN_X && SOA && p.tile_par != nullptr && __builtin_amdgcn_readfirstlane((int)p.tile_par[t]) != 0)
+            ysu += (size_t)__builtin_amdgcn_readfirstlane((int)(unsigned)p.n_pad) * D;
         const __amdgpu_buffer_rsrc_t ysr = __builtin_amdgcn_make_buffer_rsrc(
             ysu, 0, SOA ? (int)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p.n_pad * D * sizeof(T))) : 0,
             0x00020000);
@@ -1479,6 +1482,7 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     ps.seed = pd.seed;
     ps.gid0 = pd.gid0;
     ps.bmtab = pd.bmtab;
+    ps.tile_par = pd.tile_par;
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
@@ -1520,6 +1524,7 @@ static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double
     ps.seed = pd.seed;
     ps.gid0 = pd.gid0;
     ps.bmtab = pd.bmtab;
+    ps.tile_par = pd.tile_par;
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
@@ -2576,6 +2581,10 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
         const bool fused = soa && asmc_pcn_flow_fused_ok(prm, flow);
         // counters of the fused steps: [t] tile hand-out, [ASMC_MAX_PCN_STEPS + t] blocks done
         if (fused) ASMC_HIP(hipMemsetAsync(ctx->d_tilectr, 0, sizeof(unsigned int) * (2 * ASMC_MAX_PCN_STEPS + 2), st));
+        if (fused) {  // every tile starts in half 0 of the state allocation (tile parities: the split path's flag bytes are free here)
+            ASMC_HIP(hipMemsetAsync(ctx->d_flags, 0, (size_t)((n + 63) / 64), st));
+            pd.tile_par = ctx->d_flags;
+        }
         for (int t = 0; t < (fused ? n_steps : 0); t++) {
             const uint32_t step = step0 + (uint32_t)t;
             rc = pcn_prepare_gamma(ctx, n, pd, step, st);

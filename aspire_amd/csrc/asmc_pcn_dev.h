@@ -177,33 +177,50 @@ __device__ __forceinline__ bm_d2* bm_lds() {
     return s_bm;
 }
 
-// one Box-Muller pair from a radius word and an angle word
-__device__ __forceinline__ void bm_pair32(uint32_t wr, uint32_t wa, const bm_d2* __restrict__ tab, double& z0, double& z1) {
-    const bm_d2 sc = tab[wa >> 24];
+// one Box-Muller pair from a radius word and an angle word, in three stages so that callers with several pairs in flight
+// can issue every table read before the first use (LDS latency): indices -> table-free series -> combination
+struct BmPair {
+    double m, sx, cm1;  // mantissa of w_r + 1/2; sin x and cos x - 1 of the angle residual
+    int e;              // its exponent
+};
+__device__ __forceinline__ void bm_pair_idx(uint32_t wr, uint32_t wa, BmPair& t, uint32_t& i_sc, uint32_t& i_lg) {
+    i_sc = wa >> 24;
     const double X = (double)wr + 0.5;
-    const double m = __builtin_amdgcn_frexp_mant(X);  // [1/2, 1)
-    const int e = __builtin_amdgcn_frexp_exp(X);      // 0 .. 32
-    const uint32_t mh = (uint32_t)((unsigned long long)__double_as_longlong(m) >> 32);
-    const bm_d2 lg = tab[BM_SC_N + ((mh >> 13) & (BM_LG_N - 1))];
-    // angle residual: sin x, cos x - 1
+    t.m = __builtin_amdgcn_frexp_mant(X);  // [1/2, 1)
+    t.e = __builtin_amdgcn_frexp_exp(X);   // 0 .. 32
+    const uint32_t mh = (uint32_t)((unsigned long long)__double_as_longlong(t.m) >> 32);
+    i_lg = BM_SC_N + ((mh >> 13) & (BM_LG_N - 1));
     const double x = fma((double)((int)(wa & 0xFFFFFFu) - (1 << 23)), 1.4629180792671596e-09, 7.314590396335798e-10);  // 2 pi 2^-32, pi 2^-32
     const double z = x * x;
     const double ps = fma(z, fma(z, -1.9841269841269841e-04, 8.3333333333333332e-03), -1.6666666666666666e-01);
-    const double sx = fma(x * z, ps, x);
-    const double cm1 = z * fma(z, fma(z, -1.3888888888888889e-03, 4.1666666666666664e-02), -0.5);
-    const double sn = sc.x + fma(sc.y, sx, sc.x * cm1);
-    const double cs = sc.y + fma(-sc.x, sx, sc.y * cm1);
-    // radius
-    const double r = fma(m, lg.x, -1.0);
+    t.sx = fma(x * z, ps, x);
+    t.cm1 = z * fma(z, fma(z, -1.3888888888888889e-03, 4.1666666666666664e-02), -0.5);
+}
+__device__ __forceinline__ void bm_pair_fin(const BmPair& t, const bm_d2 sc, const bm_d2 lg, double& z0, double& z1) {
+    const double sn = sc.x + fma(sc.y, t.sx, sc.x * t.cm1);
+    const double cs = sc.y + fma(-sc.x, t.sx, sc.y * t.cm1);
+    const double r = fma(t.m, lg.x, -1.0);
     double p = fma(r, 3.3333333333333331e-01, -4.0000000000000002e-01);
     p = fma(r, p, 0.5);
     p = fma(r, p, -6.6666666666666663e-01);
     p = fma(r, p, 1.0);
     p = fma(r, p, -2.0);
-    const double a = fma((double)(32 - e), 1.3862943611198906, lg.y) + r * p;
-    const double rad = bm_sqrt(a);
+    const double a = fma((double)(32 - t.e), 1.3862943611198906, lg.y) + r * p;  // -2 ln u >= 2.3e-10
+    // sqrt(a): v_rsq_f64 + one coupled Goldschmidt step + the residual correction (bm_sqrt without its a <= 0 guard)
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = 0.5 * y;
+    const double rr = fma(-h, g, 0.5);
+    g = fma(g, rr, g);
+    h = fma(h, rr, h);
+    const double rad = fma(fma(-g, g, a), h, g);
     z0 = rad * cs;
     z1 = rad * sn;
+}
+__device__ __forceinline__ void bm_pair32(uint32_t wr, uint32_t wa, const bm_d2* __restrict__ tab, double& z0, double& z1) {
+    BmPair t;
+    uint32_t i_sc, i_lg;
+    bm_pair_idx(wr, wa, t, i_sc, i_lg);
+    bm_pair_fin(t, tab[i_sc], tab[i_lg], z0, z1);
 }
 
 // counter = {gid_lo, gid_hi, step, slot}; key = {seed_lo, seed_hi}.  Coordinates 4 q .. 4 q + 3 come from the block with
@@ -212,8 +229,13 @@ __device__ __forceinline__ void normal_quad(unsigned long long seed, unsigned lo
                                             const bm_d2* __restrict__ tab, double& z0, double& z1, double& z2, double& z3) {
     uint32_t w[4];
     philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), step, q | 0x20000000u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
-    bm_pair32(w[0], w[1], tab, z0, z1);
-    bm_pair32(w[2], w[3], tab, z2, z3);
+    BmPair ta, tb;
+    uint32_t ia_sc, ia_lg, ib_sc, ib_lg;
+    bm_pair_idx(w[0], w[1], ta, ia_sc, ia_lg);
+    bm_pair_idx(w[2], w[3], tb, ib_sc, ib_lg);
+    const bm_d2 sca = tab[ia_sc], lga = tab[ia_lg], scb = tab[ib_sc], lgb = tab[ib_lg];
+    bm_pair_fin(ta, sca, lga, z0, z1);
+    bm_pair_fin(tb, scb, lgb, z2, z3);
 }
 // coordinates 2 pr, 2 pr + 1 alone (a whole block for one pair: callers that own single pairs)
 __device__ __forceinline__ void normal_pair(unsigned long long seed, unsigned long long gid, uint32_t step, uint32_t pr,
@@ -361,6 +383,7 @@ struct PcnDev {
     void* ys;           // coordinate-major whitened state of the register-resident kernels (or nullptr)
     long long n_pad;
     const double* bmtab;  // the Box-Muller tables in HBM (ctx->d_bmtab)
+    unsigned char* tile_par;  // fused flow step: which half of the state allocation holds each 64-particle tile (else nullptr)
     int dpad;           // > d: run the d-dimensional problem on the kernels compiled for dpad (identity-padded tables)
     int mode;  // PCN_X_STEP / PCN_Y_STEP / PCN_WHITEN / PCN_UNWHITEN (register-resident kernels)
 };
@@ -381,6 +404,7 @@ struct PcnScalars {
     unsigned long long seed, gid0;
     int c_ll, c_lp, c_lq;
     const double* bmtab;  // the Box-Muller tables in HBM (ctx->d_bmtab)
+    unsigned char* tile_par;  // see PcnDev
 };
 
 

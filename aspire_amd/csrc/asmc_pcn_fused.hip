@@ -55,7 +55,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     int64_t n, double* __restrict__ ll, double* __restrict__ lp, double* __restrict__ lq, const double* __restrict__ ptab,
     PcnScalars p, const double* rho_ptr, uint32_t step, const float* __restrict__ packed, int n_layers,
     const float* __restrict__ loc, const float* __restrict__ scale, float ladj0, float base_const,
-    unsigned int* __restrict__ tile_counter, long long* __restrict__ block_counts, PcnAdaptArgs ad) {
+    unsigned int* __restrict__ tile_counter, long long* __restrict__ block_counts, PcnAdaptArgs ad, int par_words) {
     constexpr int D = 32, H = 16, THREADS = FUSED_THREADS;
     using FD = FlowDims<H, W>;
     extern __shared__ __align__(16) float sp[];
@@ -106,6 +106,20 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     // ... and the Box-Muller tables of the default noise behind them (6 KB)
     bm_d2* bmt = reinterpret_cast<bm_d2*>(tl + FUSED_TL_DOUBLES);
     if (NOISE == ASMC_NOISE_F64) bm_tab_stage<THREADS>(bmt, p.bmtab);
+    // ... and the tiles' parity bits (below), one bit per tile, when they fit (par_words > 0): a snapshot is all a launch
+    // needs - a tile is read once per launch, before its own wave may flip it
+    unsigned* const par_bits = reinterpret_cast<unsigned*>(bmt + BM_TAB_N);
+    for (int wd = threadIdx.x; wd < par_words; wd += THREADS) {
+        const uint4 b0 = reinterpret_cast<const uint4*>(p.tile_par)[2 * wd], b1 = reinterpret_cast<const uint4*>(p.tile_par)[2 * wd + 1];
+        const unsigned q[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        unsigned bits = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {  // bytes (0 / 1) of a dword -> 4 bits: the product lines bit 0 of byte m up at bit 24 + m
+            const unsigned nib = (((q[k] & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+            bits |= nib << (4 * k);
+        }
+        par_bits[wd] = bits;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5;
     const bool first_on_simd = __builtin_amdgcn_readfirstlane(wave) < 4;
@@ -141,14 +155,17 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     const unsigned long long ysa = (unsigned long long)(uintptr_t)p.ys;
     T* ysu = reinterpret_cast<T*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ysa >> 32)) << 32) |
                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ysa));
-    const __amdgpu_buffer_rsrc_t ysr = __builtin_amdgcn_make_buffer_rsrc(
-        ysu, 0, (int)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p.n_pad * D * sizeof(T))), 0x00020000);
+    // The allocation holds TWO copies of the state's layout.  Where a tile's current state lives is the tile's parity byte
+    // (p.tile_par, zeroed when the state is whitened into half 0): a step reads y from its half A = half[par], parks y' in
+    // the other half B before the flow, and after the accept test either copies the REJECTED lanes' y from A to B and
+    // flips the parity, or the ACCEPTED lanes' y' from B to A and leaves it - whichever moves fewer lanes (none at all
+    // when every lane accepted).  One store of the state per step instead of park + re-read + store: HBM traffic per launch
+    // 1.04 -> 0.55 GB at 98 % acceptance (round 2 parked in half 1 and always copied the accepted lanes back).
+    const int half_records = (int)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p.n_pad * D * sizeof(T)));
+    T* const ysu1 = ysu + (size_t)__builtin_amdgcn_readfirstlane((int)(unsigned)p.n_pad) * D;
     const unsigned ys_row = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p.n_pad) * (unsigned)sizeof(T);
     const unsigned ys_lane = (unsigned)lane * (unsigned)sizeof(T);
-    // y' scratch: the second half of the state allocation, same layout
-    const __amdgpu_buffer_rsrc_t ypr = __builtin_amdgcn_make_buffer_rsrc(
-        ysu + (size_t)__builtin_amdgcn_readfirstlane((int)(unsigned)p.n_pad) * D, 0,
-        (int)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p.n_pad * D * sizeof(T))), 0x00020000);
+    unsigned char* __restrict__ const tile_par = p.tile_par;
 #ifdef FUSED_STAMP
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 #endif
@@ -157,15 +174,40 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
 #else
     const bool idle_wave = false;
 #endif
-    for (; !idle_wave;) {
+    // Software pipeline over the tiles a wave takes from the device-side counter: the NEXT tile's index is requested when
+    // the flow phase starts (no memory instruction in that phase waits behind it), and its state loads are issued right
+    // after the flow, in front of this tile's accept step - so a tile's counter round trip, parity lookup and 32 state
+    // loads no longer sit one after the other in front of its first instruction.
+    auto tile_fetch = [&]() -> unsigned {
         unsigned t_l = 0;
         if (lane == 0) t_l = atomicAdd(tile_counter, 1u);
-        const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)t_l);
-        if ((int64_t)t >= n_tiles) break;
+        return t_l;
+    };
+    auto tile_parity = [&](unsigned t) -> unsigned {
+        if (par_words > 0) return (unsigned)__builtin_amdgcn_readfirstlane((int)((par_bits[t >> 5] >> (t & 31u)) & 1u));
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)tile_par[t]);
+    };
+    auto tile_load = [&](unsigned t, unsigned par, double(&v)[D], double& oll, double& olp, double& olq) __attribute__((always_inline)) {
+        const int64_t i = (int64_t)t * 64 + lane;
+        const bool valid = i < n;
+        const unsigned ys_tile = t * 64u * (unsigned)sizeof(T);
+        const __amdgpu_buffer_rsrc_t ysr = __builtin_amdgcn_make_buffer_rsrc(par ? ysu1 : ysu, 0, half_records, 0x00020000);  // A
+#pragma unroll
+        for (int j = 0; j < D; j++) v[j] = valid ? soa_load<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row) : 0.0;
+        oll = olp = olq = 0.0;
+        if (valid) oll = ll[i], olp = lp[i], olq = lq[i];
+    };
+    double v[D];
+    double oll = 0.0, olp = 0.0, olq = 0.0;
+    unsigned t = idle_wave ? 0xFFFFFFFFu : (unsigned)__builtin_amdgcn_readfirstlane((int)tile_fetch());
+    unsigned par = 0;
+    bool have = (int64_t)t < n_tiles;
+    if (have) {
+        par = tile_parity(t);
+        tile_load(t, par, v, oll, olp, olq);
+    }
+    while (have) {
         STAMP(0);
-#ifdef FUSED_NOLOOP
-        if (t_l != 0xFFFFFFFFu) n_acc += 0;
-#endif
         // the tables are loop invariant: an offset LLVM cannot see through keeps their reads inside the tile loop (hoisted,
         // they would need a thousand registers)
         // (a VECTOR register: one base address + 16-bit immediate offsets reach every table entry; with a scalar offset the
@@ -177,13 +219,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         const int64_t i = (int64_t)t * 64 + lane;
         const bool valid = i < n;
         const unsigned ys_tile = t * 64u * (unsigned)sizeof(T);
+        const __amdgpu_buffer_rsrc_t ypr = __builtin_amdgcn_make_buffer_rsrc(par ? ysu : ysu1, 0, half_records, 0x00020000);  // B
         const unsigned long long gid = p.gid0 + (unsigned long long)i;
-        // ---- phase 1: proposal, one lane per particle -------------------------------------------------------------
-        double v[D];
-#pragma unroll
-        for (int j = 0; j < D; j++) v[j] = valid ? soa_load<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row) : 0.0;
-        double oll = 0.0, olp = 0.0, olq = 0.0;
-        if (valid) oll = ll[i], olp = lp[i], olq = lq[i];
+        // ---- phase 1: proposal, one lane per particle (y, ll, lp, lq: loaded behind the previous tile's flow) ---------
         double q0 = 0.0, q1 = 0.0;
 #pragma unroll
         for (int j = 0; j < D; j++) q0 = fma(v[j], v[j], q0);
@@ -199,7 +237,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
                     v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
                     q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+#ifndef FUSED_NOISE_SB
+#define FUSED_NOISE_SB 1  // quads between two scheduling barriers of the noise phase
+#endif
+                if (qd % FUSED_NOISE_SB == FUSED_NOISE_SB - 1) __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll
@@ -383,11 +424,38 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             __builtin_amdgcn_s_setprio(FUSED_PRIO_B);
 #endif
         STAMP(4);
+        const unsigned tn_l = tile_fetch();  // the next tile's index: back long before the flow is through
         float lqt[2];
-        lqt[0] = flow_tile(xaA, xbA);
-        __builtin_amdgcn_sched_barrier(0);  // one tile's accumulator chains at a time
-        STAMP(5);
-        lqt[1] = flow_tile(xaB, xbB);
+#ifndef FUSED_FLOW2
+#define FUSED_FLOW2 1  // both tiles through each coupling layer together, MFMAs and conversions interleaved by hand (asmc_flow_dev.h)
+#endif
+        if (HS && FUSED_FLOW2) {
+            float ladjA = 0.0f, ladjB = 0.0f, amaxA = 0.0f, amaxB = 0.0f;
+            for (int c = 0; c < n_layers; c++) {
+                const float* lpk = sp + (size_t)c * FD::LAYER;
+                if ((c & 1) == 0)
+                    coupling_layer_hs2<H, W>(xaA[0], xbA[0], xaB[0], xbB[0], lpk, lane, hh, ladjA, ladjB, amaxA, amaxB);
+                else
+                    coupling_layer_hs2<H, W>(xbA[0], xaA[0], xbB[0], xaB[0], lpk, lane, hh, ladjA, ladjB, amaxA, amaxB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            auto finish = [&](const float(&xa)[1][H / 2], const float(&xb)[1][H / 2], float ladj, float amax) -> float {
+                float q = 0.0f;
+#pragma unroll
+                for (int r = 0; r < H / 2; r++) q += xa[0][r] * xa[0][r] + xb[0][r] * xb[0][r];
+                q += __shfl_xor(q, 32);
+                const float lj = ladj + __shfl_xor(ladj, 32);
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                return !(amax < FLOW_HS_MAX) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
+            };
+            lqt[0] = finish(xaA, xbA, ladjA, amaxA);
+            lqt[1] = finish(xaB, xbB, ladjB, amaxB);
+        } else {
+            lqt[0] = flow_tile(xaA, xbA);
+            __builtin_amdgcn_sched_barrier(0);  // one tile's accumulator chains at a time
+            STAMP(5);
+            lqt[1] = flow_tile(xaB, xbB);
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
         STAMP(6);
@@ -399,16 +467,40 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         double lpn = (1.0 - p.beta) * nlq + t2;
         lpn = (lpn != lpn) ? -INFINITY : lpn;
         const double log_a = (lpn + c1) - rhs;
-        if (valid && logu < log_a) {
-            double w[D];
+        const bool accepted = valid && logu < log_a;
+        // the next tile's state goes into flight in front of this tile's stores and copies
+        const unsigned tn = (unsigned)__builtin_amdgcn_readfirstlane((int)tn_l);
+        const bool have_n = (int64_t)tn < n_tiles;
+        unsigned par_n = 0;
+        double vn[D];
 #pragma unroll
-            for (int j = 0; j < D; j++) w[j] = soa_load<T>(ypr, ys_lane, ys_tile + (unsigned)j * ys_row);
-#pragma unroll
-            for (int j = 0; j < D; j++) soa_store<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row, w[j]);
+        for (int j = 0; j < D; j++) vn[j] = 0.0;  // (left undefined for the last tile, LLVM carries the OLD y through the whole body instead: 64 VGPRs, spills)
+        double olln = 0.0, olpn = 0.0, olqn = 0.0;
+        if (have_n) {
+            par_n = tile_parity(tn);
+            tile_load(tn, par_n, vn, olln, olpn, olqn);
+        }
+        if (accepted) {
             ll[i] = kll;
             lp[i] = klp;
             lq[i] = nlq;
             n_acc++;
+        }
+        {
+            const int n_a = __builtin_popcountll(__ballot(accepted)), n_r = __builtin_popcountll(__ballot(valid && !accepted));
+            const bool flip = n_a > 0 && n_r <= n_a;  // wave uniform: the state moves to half B
+            if (flip ? n_r > 0 : n_a > 0) {           // somebody has to be copied (src -> dst)
+                const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(flip == (par != 0) ? ysu1 : ysu, 0, half_records, 0x00020000);
+                const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(flip == (par != 0) ? ysu : ysu1, 0, half_records, 0x00020000);
+                if (valid && accepted != flip) {
+                    double w[D];
+#pragma unroll
+                    for (int j = 0; j < D; j++) w[j] = soa_load<T>(src, ys_lane, ys_tile + (unsigned)j * ys_row);
+#pragma unroll
+                    for (int j = 0; j < D; j++) soa_store<T>(dst, ys_lane, ys_tile + (unsigned)j * ys_row, w[j]);
+                }
+            }
+            if (flip && lane == 0) tile_par[t] = (unsigned char)(par ^ 1u);
         }
         STAMP(7);
 #ifdef FUSED_STAMP
@@ -417,9 +509,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
 #ifndef FUSED_NOSB
         __builtin_amdgcn_sched_barrier(0);
 #endif
-#ifdef FUSED_NOLOOP
-        break;
-#endif
+        t = tn, par = par_n, have = have_n;
+        oll = olln, olp = olpn, olq = olqn;
+#pragma unroll
+        for (int j = 0; j < D; j++) v[j] = vn[j];
     }
 #ifdef FUSED_STAMP
     if (lane == 0 && blockIdx.x == 7 && (wave == 0 || wave == 4) && ntile > 0)
@@ -485,6 +578,7 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
     ps.c_lp = pd.lp.C;
     ps.c_lq = 0;
     ps.bmtab = pd.bmtab;
+    ps.tile_par = pd.tile_par;
     const float ladj0 = (float)(-f->log_scale_sum);
     const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
     const int64_t n_tiles = (n + 63) / 64;
@@ -496,7 +590,10 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
 #define ASMC_FUSED_CASE(WW, NZ, HSV)                                                                                     \
     if (f->hidden == WW && pd.noise == NZ && hs == HSV) {                                                                \
         auto kern = k_pcn_flow_fused<T, WW, NZ, HSV>;                                                                         \
-        const size_t lds = (size_t)f->n_layers * FlowDims<16, WW>::LAYER * sizeof(float) + FUSED_TL_DOUBLES * sizeof(double) + BM_TAB_N * sizeof(bm_d2); \
+        const size_t lds0 = (size_t)f->n_layers * FlowDims<16, WW>::LAYER * sizeof(float) + FUSED_TL_DOUBLES * sizeof(double) + BM_TAB_N * sizeof(bm_d2); \
+        const size_t par_bytes = (size_t)((n_tiles + 31) / 32) * 4;   /* the tiles' parity bits ride in LDS when they fit */ \
+        const int par_words = lds0 + par_bytes <= 160 * 1024 ? (int)(par_bytes / 4) : 0;                                     \
+        const size_t lds = lds0 + (size_t)par_words * 4;                                                                     \
         static size_t attr_lds = 0;                                                                                      \
         if (lds > 64 * 1024 && lds > attr_lds) {                                                                         \
             ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -504,11 +601,12 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
         }                                                                                                                \
         ASMC_LAUNCH(ctx, st, "k_pcn_flow_fused", kern, dim3(grid), dim3(FUSED_THREADS), lds, st, n, ll, lp, lq,                     \
                     (const double*)ctx->d_ptab, ps, rho_ptr, step, f->packed_dev, (int)f->n_layers, f->loc_dev, f->scale_dev, \
-                    ladj0, base_const, tile_counter, block_counts, adapt);                                                     \
+                    ladj0, base_const, tile_counter, block_counts, adapt, par_words);                                          \
         ASMC_LAUNCH_CHECK();                                                                                             \
         return ASMC_OK;                                                                                                  \
     }
     ASMC_FUSED_CASE(64, ASMC_NOISE_F64, true)
+#ifndef FUSED_ONLY_HEADLINE  // (diagnostic builds compile the headline instantiation alone: seconds instead of minutes)
     ASMC_FUSED_CASE(64, ASMC_NOISE_F64, false)
     ASMC_FUSED_CASE(64, ASMC_NOISE_F32, true)
     ASMC_FUSED_CASE(64, ASMC_NOISE_F32, false)
@@ -520,6 +618,7 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
     ASMC_FUSED_CASE(128, ASMC_NOISE_F64, false)
     ASMC_FUSED_CASE(128, ASMC_NOISE_F32, true)
     ASMC_FUSED_CASE(128, ASMC_NOISE_F32, false)
+#endif
 #undef ASMC_FUSED_CASE
     asmc_set_error("fused flow step: unsupported hidden width %d", (int)f->hidden);
     return ASMC_ERR_UNSUPPORTED;
