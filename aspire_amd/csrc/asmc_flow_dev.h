@@ -349,12 +349,12 @@ __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], fl
 // coupling_layer_hs: bit-identical results.
 typedef unsigned flow_u4 __attribute__((ext_vector_type(4)));
 
-// elements (x0, x1) -> their packed hi halves and lo halves (see split8_f16)
+// elements (x0, x1) -> their packed hi halves and lo halves (see split8_f16).  The range check rides on the hi halves
+// (split4_range below): an element past the fp16 range converts to inf, and 65504 itself is flagged like before.
 template <bool RELU>
-__device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& hp, unsigned& lp, float& amax) {
+__device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& hp, unsigned& lp) {
     const float v0 = RELU ? __int_as_float(max(__float_as_int(x0), 0)) : x0;
     const float v1 = RELU ? __int_as_float(max(__float_as_int(x1), 0)) : x1;
-    amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v0)), __builtin_fabsf(v1));  // one v_max3_f32
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     const half2v h = half2v{(_Float16)v0, (_Float16)v1};
     half2v l;
@@ -366,11 +366,26 @@ __device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& hp, uns
     hp = __builtin_bit_cast(unsigned, h);
     lp = __builtin_bit_cast(unsigned, l);
 }
+// largest magnitude among the hi halves of FOUR elements (two packed registers) folded into the packed running maximum:
+// one v_pk_maximum3_f16 (gfx950; IEEE maximum, so a NaN sticks) - after a ReLU the halves are non-negative; signed inputs
+// take a second instruction on the negated pairs.  amax_pk starts at 0.
+template <bool SIGNED>
+__device__ __forceinline__ void split4_range(unsigned h0, unsigned h1, unsigned& amax_pk) {
+    asm("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(amax_pk) : "v"(h0), "v"(h1));
+    if (SIGNED) asm("v_pk_maximum3_f16 %0, %0, %1, %2 neg_lo:[0,1,1] neg_hi:[0,1,1]" : "+v"(amax_pk) : "v"(h0), "v"(h1));
+}
+// the two halves of the packed running maximum -> the fp32 maximum the callers compare with FLOW_HS_MAX
+__device__ __forceinline__ float range_pk_max(unsigned amax_pk) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const half2v a = __builtin_bit_cast(half2v, amax_pk);
+    const float a0 = (float)a[0], a1 = (float)a[1];
+    return (a0 != a0 || a1 != a1) ? __builtin_nanf("") : __builtin_fmaxf(a0, a1);
+}
 
 template <int H, int W>
 __device__ __forceinline__ void coupling_layer_hs2(const float (&condA)[H / 2], float (&transA)[H / 2], const float (&condB)[H / 2],
                                                    float (&transB)[H / 2], const float* __restrict__ lp, int lane, int hh,
-                                                   float& ladjA, float& ladjB, float& amaxA, float& amaxB) {
+                                                   float& ladjA, float& ladjB, unsigned& amaxA, unsigned& amaxB) {
     using FD = FlowDims<H, W>;
     static_assert(H == 16, "one K16 step over the conditioner inputs");
     constexpr int NB1 = FD::NB1, NB3 = FD::NB3, ST1 = H / 16, ST2 = 2 * NB1, G = ST1 + 2 * ST2;
@@ -391,13 +406,21 @@ __device__ __forceinline__ void coupling_layer_hs2(const float (&condA)[H / 2], 
         return g < ST1 + ST2 ? h1[S / 2][8 * (S % 2) + j] : h2[S / 2][8 * (S % 2) + j];
     };
     unsigned hpA[4], lpA[4], hpB[4], lpB[4];
-    auto cvtA = [&](int g, int c) {
-        if (g < ST1) split2_f16<false>(src(condA, h1A, h2A, g, 2 * c), src(condA, h1A, h2A, g, 2 * c + 1), hpA[c], lpA[c], amaxA);
-        else split2_f16<true>(src(condA, h1A, h2A, g, 2 * c), src(condA, h1A, h2A, g, 2 * c + 1), hpA[c], lpA[c], amaxA);
+    auto cvtA = [&](int g, int c) {  // quarter c of group g's operand; the odd quarters also range-check their pair of quarters
+        if (g < ST1) split2_f16<false>(src(condA, h1A, h2A, g, 2 * c), src(condA, h1A, h2A, g, 2 * c + 1), hpA[c], lpA[c]);
+        else split2_f16<true>(src(condA, h1A, h2A, g, 2 * c), src(condA, h1A, h2A, g, 2 * c + 1), hpA[c], lpA[c]);
+        if (c & 1) {
+            if (g < ST1) split4_range<true>(hpA[c - 1], hpA[c], amaxA);
+            else split4_range<false>(hpA[c - 1], hpA[c], amaxA);
+        }
     };
     auto cvtB = [&](int g, int c) {
-        if (g < ST1) split2_f16<false>(src(condB, h1B, h2B, g, 2 * c), src(condB, h1B, h2B, g, 2 * c + 1), hpB[c], lpB[c], amaxB);
-        else split2_f16<true>(src(condB, h1B, h2B, g, 2 * c), src(condB, h1B, h2B, g, 2 * c + 1), hpB[c], lpB[c], amaxB);
+        if (g < ST1) split2_f16<false>(src(condB, h1B, h2B, g, 2 * c), src(condB, h1B, h2B, g, 2 * c + 1), hpB[c], lpB[c]);
+        else split2_f16<true>(src(condB, h1B, h2B, g, 2 * c), src(condB, h1B, h2B, g, 2 * c + 1), hpB[c], lpB[c]);
+        if (c & 1) {
+            if (g < ST1) split4_range<true>(hpB[c - 1], hpB[c], amaxB);
+            else split4_range<false>(hpB[c - 1], hpB[c], amaxB);
+        }
     };
     auto pack = [](const unsigned (&q)[4]) -> half8 { return __builtin_bit_cast(half8, flow_u4{q[0], q[1], q[2], q[3]}); };
     // the epilogue of one tile in four parts (two of its H / 2 coordinates each)

@@ -430,7 +430,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
 #define FUSED_FLOW2 1  // both tiles through each coupling layer together, MFMAs and conversions interleaved by hand (asmc_flow_dev.h)
 #endif
         if (HS && FUSED_FLOW2) {
-            float ladjA = 0.0f, ladjB = 0.0f, amaxA = 0.0f, amaxB = 0.0f;
+            float ladjA = 0.0f, ladjB = 0.0f;
+            unsigned amaxA = 0u, amaxB = 0u;  // packed fp16 running maxima of the operands' hi halves
             for (int c = 0; c < n_layers; c++) {
                 const float* lpk = sp + (size_t)c * FD::LAYER;
                 if ((c & 1) == 0)
@@ -439,7 +440,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
                     coupling_layer_hs2<H, W>(xbA[0], xaA[0], xbB[0], xaB[0], lpk, lane, hh, ladjA, ladjB, amaxA, amaxB);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            auto finish = [&](const float(&xa)[1][H / 2], const float(&xb)[1][H / 2], float ladj, float amax) -> float {
+            auto finish = [&](const float(&xa)[1][H / 2], const float(&xb)[1][H / 2], float ladj, unsigned amax_pk) -> float {
+                float amax = range_pk_max(amax_pk);
                 float q = 0.0f;
 #pragma unroll
                 for (int r = 0; r < H / 2; r++) q += xa[0][r] * xa[0][r] + xb[0][r] * xb[0][r];
