@@ -37,6 +37,19 @@ def open_h5(path, mode: str = "r"):
     return f
 
 
+def _string_array(values) -> np.ndarray:
+    """A list of str as an array h5py can store.  A bare `dtype=object` array carries no vlen-string metadata and real h5py
+    refuses it ("Object dtype dtype('O') has no native HDF5 equivalent"): with h5py importable this is the reference's
+    `h5py.string_dtype("utf-8")` array (utils.py:665-668); without it, fixed-width UTF-8 bytes (`dtype="S"`), which
+    `decode_from_hdf5` reads back to the same list."""
+    try:
+        import h5py
+
+        return np.array(list(values), dtype=h5py.string_dtype(encoding="utf-8"))
+    except ImportError:
+        return np.array([v.encode("utf-8") for v in values], dtype="S")
+
+
 def encode_for_hdf5(value: Any) -> Any:
     """utils.py:652-688 (the cases the SMC path produces: arrays, scalars, strings, lists, dicts, None)."""
     try:
@@ -54,7 +67,7 @@ def encode_for_hdf5(value: Any) -> Any:
         return value
     if isinstance(value, (list, tuple)):
         if all(isinstance(v, str) for v in value):
-            return np.array(value, dtype=object)  # h5py.string_dtype(encoding="utf-8") is `object` underneath
+            return _string_array(value)
         return [encode_for_hdf5(v) for v in value]
     if isinstance(value, dict):
         if not value:
@@ -106,7 +119,7 @@ def recursively_save_to_h5_file(h5_file, path: str, dictionary: dict) -> None:
                 try:
                     group.create_dataset(full_key, data=encode_for_hdf5(value))
                 except (TypeError, ValueError):
-                    group.create_dataset(full_key, data=np.array(str(value), dtype=object))
+                    group.create_dataset(full_key, data=_string_array([str(value)])[0])
 
     _save("", dictionary)
 

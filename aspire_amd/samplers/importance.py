@@ -4,6 +4,10 @@ proposal flow, evaluate prior and likelihood, attach importance weights (src/asp
 The reductions behind `Samples.compute_weights` run in the same HIP kernels as the SMC path (one tempering step from
 beta 0 to 1): log_w = ll + lp - log_q, log Z = logsumexp(log_w) - log N, the evidence error
 sqrt(sum (w - Z)^2 / (N (N - 1))) from the centred second moment, ESS = exp(2 LSE - LSE(2 .)).
+
+Status: OUTSIDE the accelerated hot path (SURVEY.md §2 lists the reference's importance sampler as out of scope).  It is
+kept because the facade's default is `sampler="importance"` and the bounded-prior tests draw through it; it is not
+benchmarked and carries no parity claim beyond those tests.
 """
 from __future__ import annotations
 

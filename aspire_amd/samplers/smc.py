@@ -42,6 +42,7 @@ class SMCSampler(MCMCSampler):
         self._adaptive_target_efficiency = False
         self.device_bisection = True  # single-rank: whole adaptive-beta search on device (asmc_find_beta)
         self.fused_importance_step = True  # single-rank: search + moments + resampling enqueued as one chain
+        self.last_mutation_path = None  # which of the mutation code paths the last `mutate` call took (a description; `engine.profile` names the kernels)
         self.resample_mode = "exact"
         self.resample_method = "multinomial"
         self.shard_layout = "owner"  # sharded runs: offspring stay on the ancestor's rank ("slots": single-rank order)
@@ -220,36 +221,15 @@ class SMCSampler(MCMCSampler):
             if n_nan:
                 raise ValueError(f"{name} contains NaN values")
 
-        self.sampler_kwargs = getattr(self, "sampler_kwargs", None) or {}
-        n_final_steps = self.sampler_kwargs.pop("n_final_steps", None)
-
-        self.target_efficiency = target_efficiency
-        self.target_efficiency_rate = target_efficiency_rate
-
-        if n_steps is not None:
-            beta_step = 1 / n_steps
-        elif not adaptive:
-            raise ValueError("Either n_steps or adaptive=True must be set")
-        else:
-            beta_step = np.nan
-        self.adaptive = adaptive
-
-        if min_beta_step is None:
-            if max_n_steps is None:
-                min_beta_step = 0.0
-                self.adaptive_min_beta_step = False
-            else:
-                min_beta_step = 1 / max_n_steps
-                self.adaptive_min_beta_step = True
-        else:
-            self.adaptive_min_beta_step = False
-
-        if max_beta_step is not None:
-            if max_beta_step <= 0 or max_beta_step >= 1:
-                raise ValueError("max_beta_step must be in (0, 1)")
-            self.max_beta_step = max_beta_step
-        else:
-            self.max_beta_step = 1.0
+        self.sampler_kwargs = dict(getattr(self, "sampler_kwargs", None) or {})
+        n_final_steps = self.sampler_kwargs.pop("n_final_steps", None)  # (a loop option, not a mutation-kernel option)
+        self.target_efficiency, self.target_efficiency_rate = target_efficiency, target_efficiency_rate
+        # the temperature schedule's rules (smc/base.py:344-367, error texts included): a fixed ladder of 1/n_steps, or the
+        # ESS search between a floor (1/max_n_steps when only that is given: that floor follows the remaining distance) and a
+        # ceiling
+        rules = smc_math.schedule_rules(n_steps, adaptive, min_beta_step, max_beta_step, max_n_steps)
+        beta_step, min_beta_step = rules.beta_step, rules.min_beta_step
+        self.adaptive, self.adaptive_min_beta_step, self.max_beta_step = adaptive, rules.adaptive_floor, rules.max_beta_step
         iterations = iterations or 0
         if checkpoint_callback is None and checkpoint_every is not None:
             checkpoint_callback = self.default_file_checkpoint_callback(checkpoint_file_path)
@@ -714,6 +694,7 @@ class HipSMC(SMCSampler):
         T = self.preconditioning_transform
         transformed = not (isinstance(T, IdentityTransform) or getattr(T, "is_identity", False))
         if transformed:
+            self.last_mutation_path = "preconditioned chain (z = T(x)): split propose / accept around the transform"
             return self._mutate_preconditioned(particles, x, beta, n_steps, target)
         self.fit_preconditioning_transform(particles.x)
         ll, lp, lq = particles.log_likelihood, particles.log_prior, particles.log_q
@@ -745,6 +726,7 @@ class HipSMC(SMCSampler):
         e, comm = self.engine, self.comm
         if self._flow_fused_ok(dev_flow):
             # flow proposal density evaluated on the MFMA inside the device-side step loop (BASELINE config 3)
+            self.last_mutation_path = "flow: device-side step loop (asmc_pcn_mutate_flow; one fused kernel per step where its shape is covered)"
             t_ll = self._log_likelihood.device_mixture(e)
             t_lp = self._log_prior.device_mixture(e)
             if on_device:
@@ -785,6 +767,7 @@ class HipSMC(SMCSampler):
                     st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)
             self.n_likelihood_evaluations += n_steps * n_local
         elif self._fused_ok():
+            self.last_mutation_path = "built-in densities: device-side step loop (asmc_pcn_mutate)"
             t_ll = self._log_likelihood.device_mixture(e)
             t_lp = self._log_prior.device_mixture(e)
             t_lq = self.prior_flow.device_mixture(e)
@@ -810,6 +793,7 @@ class HipSMC(SMCSampler):
             # arbitrary callables between propose and accept; step size and accept counts stay on the device (the exchange
             # hook of sharded runs is already installed by the caller), so the host enqueues step t + 1 while step t runs
             done = 0
+            self.last_mutation_path = "callables: split propose / accept with the step closed on the stream (asmc_pcn_split_*)"
             while done < n_steps and hasattr(e, "pcn_ysplit_begin"):
                 # whitened-state session (d = 4, 8, 16, 32): the chain state stays coordinate-major on the device, a step is
                 # one mat-vec in the propose kernel and an LDS-free accept kernel
@@ -817,6 +801,7 @@ class HipSMC(SMCSampler):
                 sess = e.pcn_ysplit_begin(x, beta, mu, L, Linv, seed, gid0, st["rho"], target, True, nu, noise)
                 if sess is None:
                     break
+                self.last_mutation_path = "callables: whitened-state session (asmc_pcn_ysplit_*)"
                 for t in range(done, done + chunk):
                     x_prop = e.pcn_ysplit_propose(sess, step0 + t)
                     lq_new = self._flow_log_prob(x_prop)
@@ -839,6 +824,7 @@ class HipSMC(SMCSampler):
                 acc_rates.extend((n_acc / n_global).tolist())
                 done += chunk
         else:
+            self.last_mutation_path = "callables: split propose / accept, one host round trip per step"
             for t in range(n_steps):
                 x_prop, q0, q1 = e.pcn_propose(x, mu, L, Linv, st["rho"], seed, gid0, step0 + t, nu=nu)
                 lq_new = self._flow_log_prob(x_prop)

@@ -10,6 +10,8 @@ from __future__ import annotations
 import math
 from dataclasses import dataclass
 
+from typing import NamedTuple
+
 import numpy as np
 
 BISECT_LEVELS = 4  # candidate betas per pass = 2**4 - 1 = 15 (one k-ary bisection round)
@@ -158,6 +160,27 @@ def _bisection_tree(lo: float, hi: float, levels: int):
             los[l], his[l] = los[i], mids[i]
             los[r], his[r] = mids[i], his[i]
     return mids
+
+
+class ScheduleRules(NamedTuple):
+    beta_step: float        # fixed ladder: the increment (NaN when the schedule is adaptive)
+    min_beta_step: float    # floor of an adaptive step
+    max_beta_step: float    # its ceiling
+    adaptive_floor: bool    # the floor is rescaled by the remaining distance to beta = 1 after every step
+
+
+def schedule_rules(n_steps, adaptive, min_beta_step, max_beta_step, max_n_steps) -> ScheduleRules:
+    """The rules `determine_beta` applies, from `sample()`'s keywords - the reference's set-up (smc/base.py:344-367) with
+    its error behaviour: a fixed number of steps wins over `adaptive`; neither is an error; without an explicit floor,
+    `max_n_steps` implies the floor 1/max_n_steps, and that one adapts (smc/base.py:198-201); the ceiling must lie in (0, 1)."""
+    if n_steps is None and not adaptive:
+        raise ValueError("Either n_steps or adaptive=True must be set")
+    ladder = float("nan") if n_steps is None else 1 / n_steps
+    floor_follows = min_beta_step is None and max_n_steps is not None
+    floor = (1 / max_n_steps if floor_follows else 0.0) if min_beta_step is None else min_beta_step
+    if max_beta_step is not None and not 0 < max_beta_step < 1:
+        raise ValueError("max_beta_step must be in (0, 1)")
+    return ScheduleRules(ladder, floor, 1.0 if max_beta_step is None else max_beta_step, floor_follows)
 
 
 def determine_beta(eff_fn, beta: float, *, adaptive: bool, beta_step: float, min_beta_step: float,

@@ -197,35 +197,47 @@ def main():
     for k in per_kernel:
         per_kernel[k]["share_of_gpu_time"] = round(kern[k][0] * kern[k][1] / tot_ms, 4)
     mfma_floor = flow_flops / (MFMA_F32_PEAK_TF * 1e12) * 1e3
-    hbm_floor = b_step / (HBM_PEAK_GBS * 1e9) * 1e3
+    hbm_floor = b_pcn / (HBM_PEAK_GBS * 1e9) * 1e3
+    split = flow_math == "f16x2-split"
+    exec_flops = 3 * flow_flops if split else flow_flops          # MFMA flops actually issued per launch
+    exec_peak = MFMA_F16_PEAK_TF if split else MFMA_F32_PEAK_TF   # dense peak of the instruction that issues them
+    sq = None
+    try:  # SQ counters of the dominant kernel from the committed rocprofv3 --pmc run (profiles/sq_counters.json)
+        sqj = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))
+        sq = sqj.get(f"{(flow_k or '').split('<')[0]}|n={n_local}|d={d}|{args.x_dtype}|{args.noise}")
+    except Exception:
+        sq = None
     roofline = {
-        "bound": "mfma", "kernel": flow_k, "dtype": "f32",
-        # how the fp32 layers are executed: split-fp16 = each fp32 operand as an fp16 (hi, lo) pair, three
-        # v_mfma_f32_32x32x16_f16 products per K = 16 with fp32 accumulation (operand accuracy 2^-24, csrc/asmc_flow_dev.h);
-        # `achieved` / `frac` price the ALGORITHMIC fp32 flops against the fp32-input MFMA peak, `executed_*` the fp16
-        # products actually issued against the dense fp16 peak
+        # the dominant kernel, priced against the pipe it USES ("achieved / peak at the dtype used"): the fp32
+        # layers run as split-fp16 products (each fp32 operand an fp16 (hi, lo) pair, three v_mfma_f32_32x32x16_f16 per K = 16
+        # with fp32 accumulation, csrc/asmc_flow_dev.h), so `achieved` counts the fp16 MFMA flops issued and `peak` is the
+        # dense fp16 matrix peak; ASMC_FLOW_MATH=f32 prices the fp32-input MFMA chain against its own peak
+        "bound": "mfma", "kernel": flow_k, "dtype": "f16 (split products of f32 operands)" if split else "f32",
         "flow_math": flow_math,
-        # what actually limits the kernel in its split-fp16 form (rocprofv3 --pmc, profiles/r02_pmc_fused_step_end.txt): the
-        # vector ALU (fp64 Box-Muller noise, the triangular mat-vec, the flow's bias / ReLU / hi-lo conversion / tanh), not the
-        # matrix pipe - vector ALU active 66 % and matrix pipe 22 % of SIMD time (profiles/r02x_pmc_fused_step.txt), 2.5 TB/s of HBM traffic
-        "limiter": "vector-ALU issue" if flow_math == "f16x2-split" else "matrix pipe (fp32-input MFMA) + vector ALU, not overlapped",
-        "executed_flops_per_launch": 3 * flow_flops if flow_math == "f16x2-split" else flow_flops,
-        "executed_frac_of_its_mfma_peak": (round(3 * flow_flops / (flow_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4)
-                                           if flow_math == "f16x2-split" else
-                                           round(flow_flops / (flow_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)) if flow_ms else None,
-        "achieved": round(flow_flops / (flow_ms * 1e-3) / 1e12, 2) if flow_ms else None, "peak": MFMA_F32_PEAK_TF,
-        "unit": "TFLOP/s", "frac": round(flow_flops / (flow_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4) if flow_ms else None,
-        "traffic": traffic, "avg_ms": round(flow_ms, 5) if flow_ms else None, "flops_per_launch": flow_flops,
+        "achieved": round(exec_flops / (flow_ms * 1e-3) / 1e12, 2) if flow_ms else None, "peak": exec_peak, "unit": "TFLOP/s",
+        "frac": round(exec_flops / (flow_ms * 1e-3) / 1e12 / exec_peak, 4) if flow_ms else None,
+        "flops_per_launch": exec_flops, "algorithmic_f32_flops_per_launch": flow_flops,
+        # the same launch against the HBM roofline: SURVEY §8d's fused bytes 2 d s + 16 per particle per step
+        "hbm_frac": round(b_pcn / (flow_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if flow_ms else None,
+        "algorithmic_bytes_per_launch": b_pcn,
+        "traffic": traffic,
+        "traffic_over_algorithmic": round(traffic / b_pcn, 3) if traffic else None,
+        # what limits it (rocprofv3 --pmc SQ counters of the committed profile, fractions of SIMD time): the vector ALU
+        "limiter": "vector-ALU issue (fp64 noise + mat-vec, the flow's ReLU / hi-lo conversions); matrix pipe and vector ALU add up",
+        "valu_active": sq.get("valu_active") if sq else None, "mfma_busy": sq.get("mfma_busy") if sq else None,
+        "valu_insts_per_64_particle_tile": sq.get("valu_insts_per_tile") if sq else None,
+        "sq_counters_source": sq.get("source") if sq else None,
+        # round 2's headline definition, kept for continuity only: algorithmic fp32 flops / fp32-input MFMA peak
+        "fp32_equivalent_frac": round(flow_flops / (flow_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4) if flow_ms else None,
+        "avg_ms": round(flow_ms, 5) if flow_ms else None,
         "pcn_kernels": {"bound": "hbm", "kernels": pcn_ks, "avg_ms_per_step": round(pcn_ms, 5), "alg_bytes_per_step": b_pcn,
                         "achieved": round(b_pcn / (pcn_ms * 1e-3) / 1e9, 1) if pcn_ms else None, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(b_pcn / (pcn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pcn_ms else None,
                         "noise": args.noise},
-        "whole_step": {"device_ms_per_mutation_step": round(step_ms, 5), "flops_per_step": flow_flops,
-                       "alg_bytes_per_step": b_step, "mfma_floor_ms": round(mfma_floor, 5), "hbm_floor_ms": round(hbm_floor, 5),
-                       # both pipes perfectly overlapped (one fused kernel) / not overlapped at all
-                       "frac_overlapped": round(max(mfma_floor, hbm_floor) / step_ms, 4) if step_ms else None,
-                       "frac_serial": round((mfma_floor + hbm_floor) / step_ms, 4) if step_ms else None},
+        "whole_step": {"device_ms_per_mutation_step": round(step_ms, 5), "executed_mfma_floor_ms": round(exec_flops / (exec_peak * 1e12) * 1e3, 5),
+                       "f32_mfma_floor_ms": round(mfma_floor, 5), "hbm_floor_ms": round(hbm_floor, 5)},
         "gpu_busy_ms_per_run": round(tot_ms, 3), "wall_ms_per_run": round(dt / args.steps * 1e3, 3),
+        "gpu_busy_over_wall": round(tot_ms / (dt / args.steps * 1e3), 4),
         "mutation_share_of_gpu_time": round(step_ms * n_mut / tot_ms, 4) if tot_ms else None,
         "per_kernel": per_kernel,
     }
@@ -390,6 +402,8 @@ def main():
                                               "abs_err_in_sigma": abs(float(postm.log_evidence) - true_logz) / max(float(postm.log_evidence_error), 1e-300)}
             finally:
                 os.environ.pop("ASMC_FLOW_MATH", None)
+            # top level next to `value`: the same workload with every flow product on the fp32-input matrix instruction
+            result["value_strict_fp32"] = extra["flow_run_f32_mfma"]["particle_steps_per_s"]
         result["extra"] = extra
 
     # ---- CPU baseline: the oracle's restatement of the SAME mutation step (kind "port") on the host's cores -------
@@ -422,15 +436,38 @@ def main():
                 if el > budget_s or k >= max_steps:
                     return n_part * k / el, k, el
 
-        v1, k1, e1 = cpu_steps(min(n_cpu, 32768), 1, 6.0, 8)
-        vN, kN, eN = cpu_steps(n_cpu, 0, 12.0, 64)
+        v1, k1, e1 = cpu_steps(min(n_cpu, 32768), 1, 5.0, 8)
+        # thread sweep on bounded samples (a container may own fewer cores than os.cpu_count() shows: the cgroup quota is
+        # reported, and the best point of the sweep is the baseline), then the longer run at the best thread count
+        def cgroup_cpus():
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                return None if q == "max" else float(q) / float(per)
+            except Exception:
+                return None
+
+        def affinity_cpus():
+            try:
+                return len(os.sched_getaffinity(0))
+            except Exception:
+                return None
+
+        sweep = {}
+        for thr in sorted({t for t in (8, 32, n_thr // 2, n_thr) if 1 < t <= n_thr}):
+            vs_, ks_, es_ = cpu_steps(min(n_cpu, 4096 * thr), thr, 2.5, 6)
+            sweep[thr] = vs_
+        best_thr = max(sweep, key=sweep.get) if sweep else 1
+        vN, kN, eN = cpu_steps(n_cpu, best_thr, 10.0, 64)
         result["cpu_baseline"] = {
-            "value": vN, "unit": "particle-steps/s", "cores": n_thr, "kind": "port",
+            "value": vN, "unit": "particle-steps/s", "cores": best_thr, "kind": "port",
             "sample": f"{kN} mutation steps (pCN propose + coupling-flow log q in fp32 + targets + accept, the same flow and "
-                      f"noise streams; oracle/asmc_oracle.c orc_pcn_flow_step, OpenMP over particles) on {n_cpu} x {d} fp64 "
-                      f"particles, {eN:.1f} s",
-            "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
+                      f"noise streams; oracle/asmc_oracle.c orc_pcn_flow_step, OpenMP over particles, {best_thr} threads = the best "
+                      f"point of the thread sweep) on {n_cpu} x {d} fp64 particles, {eN:.1f} s",
+            "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "omp_max_threads": n_thr,
+            "cgroup_cpu_quota": cgroup_cpus(), "affinity_cpus": affinity_cpus(),
             "single_thread": {"value": v1, "cores": 1, "sample": f"{k1} steps on {min(n_cpu, 32768)} particles, {e1:.1f} s"},
+            "thread_sweep": {str(t): round(v) for t, v in sweep.items()},
+            "speedup_over_single_thread": round(vN / v1, 1), "parallel_efficiency": round(vN / v1 / best_thr, 3),
             "gpu_over_cpu_all_cores": value / vN, "gpu_over_cpu_single_thread": value / v1,
         }
         try:  # restatement-to-reference ratio, measured in the build container (tests/tools/ref_ratio.py)

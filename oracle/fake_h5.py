@@ -20,8 +20,12 @@ class FakeDataset:
                 self._a = np.array(data, dtype=object)
             else:
                 self._a = np.array(data)
-                if self._a.dtype == object and not all(isinstance(v, (str, bytes)) for v in self._a.ravel()):
-                    raise TypeError("Object dtype has no native HDF5 equivalent")
+                # real h5py stores an object array only when its dtype carries the vlen-string tag that
+                # h5py.string_dtype() attaches (np.dtype("O", metadata={"vlen": str})); a bare dtype=object array raises
+                meta = self._a.dtype.metadata or {}
+                if self._a.dtype == object and (meta.get("vlen") not in (str, bytes)
+                                                or not all(isinstance(v, (str, bytes)) for v in self._a.ravel())):
+                    raise TypeError("Object dtype dtype('O') has no native HDF5 equivalent")
         else:
             self._a = np.zeros(shape, dtype=dtype)
         self.maxshape = maxshape

@@ -100,7 +100,7 @@ def install() -> None:
             raise RuntimeError("h5py stub: HDF5 is not available in this image")
 
     h5py.File = File
-    h5py.string_dtype = lambda **k: object
+    h5py.string_dtype = lambda **k: __import__("numpy").dtype("O", metadata={"vlen": str})  # what the real one returns
     sys.modules["h5py"] = h5py
 
     orng = types.ModuleType("orng")
