@@ -98,11 +98,19 @@ class TorchDistComm(Comm):
         the step kernels' stream - torch.distributed runs its collectives on a stream of its own, and every call costs
         two stream hand-overs (about 13 us of idle GPU per step boundary, profiles/r02_rig1_*).  The communicator is made
         the textbook way - rank 0 draws an ncclUniqueId, the group broadcasts it, every rank calls ncclCommInitRank - on
-        the RCCL that torch has loaded.  None when the backend is not RCCL (gloo rigs) or ASMC_RCCL_DIRECT=0."""
+        the RCCL that torch has loaded.  None when the backend is not RCCL (gloo rigs) or it is switched off.
+
+        Default (ASMC_RCCL_DIRECT unset): ON for a one-rank group - the rig every collective of this path has been run and
+        checked on (tools/nccl_world1.py) - and OFF for world > 1, where the collectives go through torch.distributed: no
+        multi-GPU node has been available to validate the library's own communicator with real peers, and a
+        mismatch there is a hang, not an error.  ASMC_RCCL_DIRECT=1 turns it on for any world size, =0 off.
+        The set-up is itself a collective: `HipSMC.sample` calls it once on every rank right after `sync_rng`, so that no
+        rank-local condition later in the run decides whether a rank takes part in it."""
         if hasattr(self, "_rccl"):
             return self._rccl
         self._rccl = None
-        if self._stage or self.device.type != "cuda" or os.environ.get("ASMC_RCCL_DIRECT", "1") == "0":
+        want = os.environ.get("ASMC_RCCL_DIRECT", "1" if self.world == 1 else "0")
+        if self._stage or self.device.type != "cuda" or want == "0":
             return None
         import ctypes
         import logging

@@ -603,6 +603,8 @@ class HipEngine:
         n, d = x.shape
         s, g = np.empty(d), np.empty((d, d))
         across = int(comm is not None and comm.sharded)
+        if across and x.data_ptr() % 16:
+            x = x.clone()  # the matrix-core Gram kernel reads 16-byte pieces (the call synchronises: the copy lives long enough)
         check(self.lib.asmc_mean_gram(self._ctx, n, d, self._xdt(x), _dptr(x), int(n_mean), across, _f64p(s), _f64p(g),
                                       self._stream), "asmc_mean_gram")
         return s, g
@@ -611,11 +613,17 @@ class HipEngine:
         """Start `mean_gram` on the stream without waiting; False for shapes without the device-side path (and, for a sharded
         `comm`, without a communicator for the library's own all-reduces: `use_rccl`)."""
         n, d = x.shape
-        if not (d in (32, 64, 128) and x.data_ptr() % 16 == 0 and not os.environ.get("ASMC_GRAM_GENERIC")):
-            return False
         across = int(comm is not None and comm.sharded)
+        if not (d in (32, 64, 128) and not os.environ.get("ASMC_GRAM_GENERIC")):
+            return False
         if across and not self.use_rccl(comm):
             return False
+        if x.data_ptr() % 16:
+            # a rank-local property must not pick the code path of a sharded run (the other ranks would wait in a collective
+            # this rank never issues): single rank - the caller's fallback; sharded - an aligned copy, kept until the fetch
+            if not across:
+                return False
+            x = self._gram_keep = x.clone()
         check(self.lib.asmc_mean_gram_enqueue(self._ctx, n, d, self._xdt(x), _dptr(x), int(n_mean), across, self._stream),
               "asmc_mean_gram_enqueue")
         self._gram_gen = getattr(self, "_gram_gen", 0) + 1  # names the request: a fetch is for the LATEST one only
@@ -628,8 +636,8 @@ class HipEngine:
 
     def mean_gram_across_ranks_ok(self, x: torch.Tensor, comm) -> bool:
         """The shapes asmc_mean_gram sums over the ranks itself (the fp64-MFMA Gram kernel's), given a communicator."""
-        return (x.shape[1] in (32, 64, 128) and x.data_ptr() % 16 == 0 and not os.environ.get("ASMC_GRAM_GENERIC")
-                and self.use_rccl(comm))
+        # (only properties every rank shares: the alignment of this rank's rows is dealt with inside mean_gram)
+        return x.shape[1] in (32, 64, 128) and not os.environ.get("ASMC_GRAM_GENERIC") and self.use_rccl(comm)
 
     # ---- Student-t reference fit (tpCN): per-particle half of the EM on a device-resident subsample ----------------
     def student_estep(self, xs: torch.Tensor, mu: np.ndarray, linv: np.ndarray, nu: float):

@@ -94,7 +94,7 @@ class SMCSampler(MCMCSampler):
         if os.environ.get("ASMC_IS_AHEAD", "1") == "0":  # escape hatch / A-B switch
             return False
         return (self.fused_importance_step and getattr(self, "adaptive", False) and self.device_bisection and beta < 1.0
-                and not self.comm.sharded and hasattr(self.engine, "pcn_mutate_flow_enqueue")
+                and not getattr(self, "_last_iteration", False) and not self.comm.sharded and hasattr(self.engine, "pcn_mutate_flow_enqueue")
                 and hasattr(self.engine, "importance_step") and not getattr(self.engine, "importance_step_disabled", False)
                 and getattr(self, "_beta_tolerance", None) is not None)
 
@@ -192,6 +192,10 @@ class SMCSampler(MCMCSampler):
         # sharded runs: every rank walks the same resampling draws and draws the same mutation seeds, so the ranks'
         # generators must be in the same state - rank 0's is handed to everyone (a no-op for one rank)
         self.rng = smc_math.sync_rng(comm, self.rng)
+        if comm.sharded and hasattr(self.engine, "use_rccl"):
+            # the library's own communicator (comm.rccl_direct) is set up by a collective: here, on every rank, once - never
+            # lazily behind a condition that one rank might evaluate differently from the others
+            self.engine.use_rccl(comm)
         if comm.sharded and hasattr(self.prior_flow, "sync_shards"):
             self.prior_flow.sync_shards(comm)  # the same trained flow on every rank, a separate draw stream per rank
         if getattr(self.prior_flow, "seed_from_rng", False) and resume_from is None:
@@ -255,6 +259,8 @@ class SMCSampler(MCMCSampler):
             while True:
                 iterations += 1
                 self._beta_tolerance = beta_tolerance
+                # the loop ends after this iteration's mutation when max_n_steps is reached: nothing may run ahead then
+                self._last_iteration = max_n_steps is not None and iterations >= max_n_steps
                 if hasattr(samples, "finish_speculation"):
                     samples.finish_speculation()  # an importance step the mutation enqueued behind itself
                 if (self.fused_importance_step and self.adaptive and self.device_bisection and beta < 1.0

@@ -497,8 +497,8 @@ def resample_owner(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out: i
     if sum(new_counts) != int(n_out):
         raise RuntimeError(f"owner-layout resampling kept {sum(new_counts)} of {n_out} draws: the ranks' generators are not "
                            "in the same state (pass the same seeded rng to every rank; HipSMC.sample synchronises it)")
-    if u_kept.numel() == 0:
-        raise RuntimeError("owner-layout resampling left this rank without offspring")
+    if min(new_counts) == 0:  # decided from the gathered counts: every rank raises, nobody is left waiting in a collective
+        raise RuntimeError(f"owner-layout resampling left rank {new_counts.index(0)} without offspring")
     return engine.search(cdf, u_kept), var, s1p, new_counts
 
 

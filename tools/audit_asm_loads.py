@@ -4,7 +4,9 @@ destination as written at the end of the asm statement, so any instruction that 
 clobber data still in flight.  The batches are waited for in the order they are issued, so the check walks every
 instantiation's assembly with a FIFO: a read statement pushes its four destinations, a wait statement releases the oldest
 batch, and nothing outside those statements may name a register that is still in the FIFO.
-usage: audit_asm_loads.py [extra hipcc flags]"""
+usage: audit_asm_loads.py [extra hipcc flags]  |  audit_asm_loads.py --asm <device assembly of asmc_pcn_fused.hip>
+The library build runs the second form on the assembly of the very compilation that produced the object (csrc/Makefile), so
+every flag combination that builds is audited, and a violation fails the build."""
 import os
 import re
 import subprocess
@@ -15,7 +17,10 @@ src = os.path.join(ROOT, "aspire_amd", "csrc", "asmc_pcn_fused.hip")
 out = "/tmp/audit_fused.s"
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950",
        "-Wno-unused-function", "-S", "--cuda-device-only", src, "-o", out] + sys.argv[1:]
-subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+if len(sys.argv) >= 3 and sys.argv[1] == "--asm":  # audit an assembly file the build already produced (csrc/Makefile: -save-temps)
+    out = sys.argv[2]
+else:
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 
 
 def regs(tok):

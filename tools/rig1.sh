@@ -2,7 +2,7 @@
 # rank: every collective of the hot path is issued, none has a peer) - the difference is the cost of the sharded
 # machinery itself (extra launches, host synchronisations, the collectives' launch latency), i.e. an upper bound on the
 # weak-scaling efficiency before any wire time.
-cd /root/repo
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 mkdir -p gpurun_out
 python bench.py --gpus 1 --steps ${RIG_STEPS:-10} --warmup 3 --no-extra --no-cpu-baseline > gpurun_out/rig1_single.json 2> gpurun_out/rig1_single.err
 python bench.py --gpus 1 --steps ${RIG_STEPS:-10} --warmup 3 --no-extra --no-cpu-baseline --force-sharded > gpurun_out/rig1_sharded.json 2> gpurun_out/rig1_sharded.err
