@@ -123,3 +123,30 @@ class FakeGroup:
             else:
                 out[p] = (v.dtype.kind, tuple(v.shape))
         return out
+
+
+class FakeFile(FakeGroup):
+    """`h5py.File(path, mode)` over the in-memory groups above; contents persist per path for the life of the process, so a
+    file re-opened in append mode shows what an earlier `with` block wrote (the reference's `AspireFile` subclasses this
+    through the shim's h5py stub and opens its checkpoint file several times per `sample_posterior` call)."""
+
+    _store: dict = {}
+
+    def __init__(self, name, mode="r", *args, **kwargs):
+        super().__init__()
+        name = str(name)
+        if mode in ("w", "w-"):
+            FakeFile._store.pop(name, None)
+        if name not in FakeFile._store:
+            if mode in ("r", "r+"):
+                raise FileNotFoundError(name)
+            FakeFile._store[name] = ({}, {})
+        self._items, self.attrs = FakeFile._store[name]
+        self.mode, self.filename = ("r+" if mode == "a" else mode), name
+
+    def __delitem__(self, path):
+        node, leaf = self._walk(path, False)
+        del node._items[leaf]
+
+    def close(self):
+        pass

@@ -9,7 +9,7 @@ five packages missing from this image.  Substitutions:
   array_api_compat  <- sklearn.externals.array_api_compat (vendored v1.12)
   array_api_extra   <- sklearn.externals.array_api_extra (+ a `default_dtype` helper)
   wrapt             <- a minimal `wrapt.decorator`
-  h5py              <- import-time stub (HDF5 checkpointing is out of scope)
+  h5py              <- stub whose File is oracle/fake_h5.FakeFile (in-memory groups / datasets with h5py's protocol)
   orng              <- ArrayRNG delegating to numpy.random.default_rng
 """
 from __future__ import annotations
@@ -94,12 +94,10 @@ def install() -> None:
     sys.modules["wrapt"] = wrapt
 
     h5py = types.ModuleType("h5py")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fake_h5 import FakeFile  # in-memory stand-in: the reference's AspireFile subclasses h5py.File (utils.py:910)
 
-    class File:
-        def __init__(self, *a, **k):
-            raise RuntimeError("h5py stub: HDF5 is not available in this image")
-
-    h5py.File = File
+    h5py.File = FakeFile
     h5py.string_dtype = lambda **k: __import__("numpy").dtype("O", metadata={"vlen": str})  # what the real one returns
     sys.modules["h5py"] = h5py
 
