@@ -94,6 +94,7 @@ def lib():
                 [i64, ci, vp, vp, vp, vp, d, vp, vp, vp, d, vp, vp, ci, ci, vp, vp, vp, vp, u64, u64, u32, ci, ci],
             ),
             "orc_max_threads": (ci, []),
+            "orc_set_margin_sink": (None, [vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(_lib, name)
@@ -431,6 +432,22 @@ def coupling_logprob(x, weights, biases, loc, scale):
     if st != 0:
         raise ValueError(f"orc_coupling_logprob failed ({st})")
     return out
+
+
+class accept_margins:
+    """`with accept_margins(n) as m:` - the pCN / tpCN / flow step functions called inside record particle i's accept margin
+    log_a - log u in m[i] (the decision is m[i] > 0); used to show that mismatching decisions are razor edges."""
+
+    def __init__(self, n):
+        self.m = np.full(int(n), np.nan)
+
+    def __enter__(self):
+        lib().orc_set_margin_sink(_p(self.m))
+        return self.m
+
+    def __exit__(self, *exc):
+        lib().orc_set_margin_sink(None)
+        return False
 
 
 def max_threads() -> int:

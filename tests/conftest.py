@@ -71,3 +71,18 @@ def random_coupling_flow(d, n_layers=4, hidden=64, seed=3, dtype=None, device="c
         flow.scale = (0.5 + torch.rand(d, generator=g)).to(flow.scale)
     flow._version += 1
     return flow
+
+
+def flow_log_prob_f64(flow, x):
+    """log q(x) of a CouplingFlow evaluated in fp64 by the torch modules on the CPU: the SAME fp32 parameters, widened
+    (the judge of the flow kernels' arithmetic: the north star's bar is 1e-6 relative on log-weights)."""
+    import torch
+
+    from aspire_amd.flows import CouplingFlow
+
+    hidden = [m.out_features for m in flow.layers[0].net if isinstance(m, torch.nn.Linear)][:-1]
+    f64 = CouplingFlow(flow.dims, n_layers=len(flow.layers), hidden_features=tuple(hidden), device="cpu", dtype=torch.float64)
+    f64.layers.load_state_dict({k: v.detach().cpu().double() for k, v in flow.layers.state_dict().items()})
+    f64.loc, f64.scale = flow.loc.detach().cpu().double(), flow.scale.detach().cpu().double()
+    with torch.no_grad():
+        return f64.log_prob(torch.as_tensor(np.asarray(x, dtype=np.float64))).numpy()

@@ -291,3 +291,111 @@ def test_sharded_run_with_trained_flow_agrees_on_rank0_parameters(two_rank_resul
     assert np.array_equal(r0["cf_params"], r1["cf_params"])  # rank 1 took rank 0's flow
     assert np.array_equal(r0["cf_beta"], r1["cf_beta"]) and r0["cf_beta"][-1] == 1.0
     assert not np.array_equal(r0["cf_x0"], r1["cf_x0"])  # separate draw streams: the shards are not copies of each other
+
+
+# ---- world 8 (the node's rank count) on the CPU test double --------------------------------------------------------------
+def _worker8(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import synth
+    from oracle_engine import OracleEngine
+
+    from aspire_amd import smc_math
+    from aspire_amd.comm import TorchDistComm
+    from aspire_amd.flows import GaussianFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.samples import SMCSamples
+    from aspire_amd.targets import DiagGaussianMixture
+
+    eng, comm = OracleEngine(), TorchDistComm(torch.device("cpu"))
+    n, d = world * 4096, 4
+    x, ll, lp, lq = synth(n, d, 13)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    loc = [eng.asarray(a[lo:hi]) for a in (x, ll, lp, lq)]
+    res = {}
+    res["fb"] = np.array(smc_math.find_beta_sharded(eng, comm, loc[1], loc[2], loc[3], 0.0, 0.5, 1e-6, n)[:2])
+    pop = SMCSamples(x=loc[0], log_likelihood=loc[1], log_prior=loc[2], log_q=loc[3], beta=0.0, xp=torch, engine=eng, comm=comm)
+    # owner layout, eight ragged shards
+    new, var = pop.resample(0.08, rng=np.random.default_rng(5), want_variance=True)
+    res["own_x"], res["own_counts"], res["own_var"] = eng.to_numpy(new.x), np.array(new.shard_counts), var
+    res["own_flags"] = np.array([new.n_global, int(new.ragged), new.gid0()])
+    # a second resampling FROM the ragged population, to a size the ranks cannot share equally
+    odd = new.resample(0.2, n_samples=n - 3, rng=np.random.default_rng(6))
+    res["odd_x"], res["odd_counts"] = eng.to_numpy(odd.x), np.array(odd.shard_counts)
+    # skew: ranks 2 and 5 hold almost all the weight -> the +-25 % rule sends every rank to the slot layout, which rebalances
+    ll_skew = loc[1] + (30.0 if rank in (2, 5) else 0.0)
+    pop2 = SMCSamples(x=loc[0], log_likelihood=ll_skew, log_prior=loc[2], log_q=loc[3], beta=0.0, xp=torch, engine=eng, comm=comm)
+    sk = pop2.resample(0.5, rng=np.random.default_rng(7))
+    res["skew_x"], res["skew_flags"] = eng.to_numpy(sk.x), np.array([len(sk.x), int(bool(sk.__dict__.get("ragged")))])
+    # the whole sampler over eight ranks, with a final population the ranks cannot share equally; every rank arrives with
+    # its own generator
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=2.0, engine=eng, seed=3), xp=np,
+                engine=eng, comm=comm, rng=np.random.default_rng(40 + rank))
+    post = sp.sample(world * 256, n_final_samples=world * 256 - 5, sampler_kwargs=dict(n_steps=2, n_final_steps=1),
+                     store_sample_history=False)
+    res["beta"], res["logz"], res["logz_err"] = np.array(sp.history.beta), float(post.log_evidence), float(post.log_evidence_error)
+    res["n_post"] = len(post.x)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def eight_rank_results(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("gloo8"))
+    mp.spawn(_worker8, args=(8, _free_port(), out), nprocs=8, join=True)
+    return [np.load(os.path.join(out, f"rank{r}.npz")) for r in range(8)]
+
+
+def test_world8_owner_layout_is_generator_choice(eight_rank_results, oracle):
+    """Eight ranks: every rank holds exactly the sub-sequence of numpy's Generator.choice index vector that points into
+    its shard - first from equal shards, then from the ragged population to a size that 8 does not divide."""
+    from conftest import synth
+
+    world, n = 8, 8 * 4096
+    x, ll, lp, lq = synth(n, 4, 13)
+    rs = eight_rank_results
+    w = oracle.normalized_weights(ll, lp, lq, 0.0, 0.08)
+    ref = np.random.default_rng(5).choice(n, size=n, replace=True, p=w)
+    counts = [int(((ref >= r * 4096) & (ref < (r + 1) * 4096)).sum()) for r in range(world)]
+    for r, res in enumerate(rs):
+        assert np.array_equal(res["own_x"], x[ref[(ref >= r * 4096) & (ref < (r + 1) * 4096)]])
+        assert res["own_counts"].tolist() == counts
+        assert res["own_flags"].tolist() == [n, 1, int(sum(counts[:r]))]
+        assert float(res["own_var"]) == pytest.approx(oracle.log_evidence_ratio_variance(ll, lp, lq, 0.0, 0.08), rel=1e-10)
+        assert np.array_equal(res["fb"], rs[0]["fb"])
+    # second step: Generator.choice on the concatenated (rank-major) ragged population, n - 3 draws
+    allx = np.concatenate([res["own_x"] for res in rs])
+    ll2 = -0.5 * np.sum(allx**2, axis=1)
+    lq2 = -0.5 * np.sum((allx / 1.5) ** 2, axis=1) - 4 * np.log(1.5) - 0.5 * 4 * np.log(2 * np.pi)
+    w2 = oracle.normalized_weights(ll2, ll2, lq2, 0.08, 0.2)
+    ref2 = np.random.default_rng(6).choice(n, size=n - 3, replace=True, p=w2)
+    edges = np.concatenate([[0], np.cumsum(counts)])
+    for r, res in enumerate(rs):
+        mine = ref2[(ref2 >= edges[r]) & (ref2 < edges[r + 1])]
+        assert np.array_equal(res["odd_x"], allx[mine])
+    assert int(sum(len(res["odd_x"]) for res in rs)) == n - 3 and rs[0]["odd_counts"].tolist() == [len(res["odd_x"]) for res in rs]
+
+
+def test_world8_skew_falls_back_to_slots_and_sampler_runs(eight_rank_results, oracle):
+    from conftest import synth
+
+    world, n = 8, 8 * 4096
+    x, ll, lp, lq = synth(n, 4, 13)
+    rs = eight_rank_results
+    ll_skew = ll.copy()
+    for r in (2, 5):
+        ll_skew[r * 4096:(r + 1) * 4096] += 30.0
+    w = oracle.normalized_weights(ll_skew, lp, lq, 0.0, 0.5)
+    ref = np.random.default_rng(7).choice(n, size=n, replace=True, p=w)
+    assert all(res["skew_flags"].tolist() == [n // world, 0] for res in rs)  # equal shards again: the slot layout ran
+    assert np.array_equal(np.concatenate([res["skew_x"] for res in rs]), x[ref])  # ... with the reference's ancestors in draw order
+    # sampler: the same schedule and evidence on every rank, the odd final population shared out completely
+    assert all(np.array_equal(res["beta"], rs[0]["beta"]) and float(res["logz"]) == float(rs[0]["logz"]) for res in rs)
+    assert rs[0]["beta"][-1] == 1.0 and sum(int(res["n_post"]) for res in rs) == world * 256 - 5
+    assert abs(float(rs[0]["logz"]) - 2.0 * np.log(np.pi)) < 5 * float(rs[0]["logz_err"]) + 0.1

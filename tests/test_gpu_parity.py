@@ -1629,14 +1629,26 @@ def test_pcn_flow_fused_step_vs_oracle(eng, oracle):
     lpr, lqr = llr.copy(), oracle.coupling_logprob(x0, ws, bs, flow.loc.numpy(), flow.scale.numpy())
     xd = eng.asarray(x0)
     lld, lpd, lqd = eng.asarray(llr), eng.asarray(lpr), eng.coupling_logprob(xd, dev)
-    np.testing.assert_allclose(lqd.cpu().numpy(), lqr, rtol=1e-5, atol=3e-4)
+    np.testing.assert_allclose(lqd.cpu().numpy(), lqr, rtol=1e-5, atol=3e-4)  # two fp32 evaluations, different summation order
+    from conftest import flow_log_prob_f64
+
+    ref64 = flow_log_prob_f64(flow, x0)  # the bar itself: 1e-6 relative against the same flow in fp64
+    assert np.max(np.abs(lqd.cpu().numpy() - ref64) / np.maximum(np.abs(ref64), 1.0)) <= 1e-6
     n_acc, _, _ = eng.pcn_mutate_flow(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(np.tril(L)), eng.asarray(np.tril(Linv)),
                                       t_ll, t_ll, dev, 4242, 17, rho, n_steps, 9, 0.234, False, "f64", 0.0)
-    acc_ref = [oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, np.tril(L), np.tril(Linv), rho, tgt_o, tgt_o, ws, bs,
-                                    flow.loc.numpy(), flow.scale.numpy(), 4242, 17, 9 + t, "f64", 0) for t in range(n_steps)]
+    acc_ref, margins = [], []
+    for t in range(n_steps):
+        with oracle.accept_margins(n) as m:
+            acc_ref.append(oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, np.tril(L), np.tril(Linv), rho, tgt_o, tgt_o, ws, bs,
+                                                flow.loc.numpy(), flow.scale.numpy(), 4242, 17, 9 + t, "f64", 0))
+        margins.append(m.copy())
     got = xd.cpu().numpy()
     close = np.all(np.abs(got - xr) <= 1e-9 * (1 + np.abs(xr)), axis=1)
     assert (~close).sum() <= 12, (~close).sum()
+    # ... and they ARE razor edges: a row that ends elsewhere took a different decision at some step, and at its first such
+    # step both sides held the same state - the restatement's accept margin log_a - log u there is within fp32 flow rounding
+    razor = np.min(np.abs(np.array(margins)), axis=0)
+    assert np.all(razor[~close] <= 1e-4), razor[~close]
     assert np.all(np.abs(np.array(n_acc) - np.array(acc_ref)) <= 12) and 0.05 < np.mean(n_acc) / n < 0.95
     np.testing.assert_allclose(lld.cpu().numpy()[close], llr[close], rtol=1e-10, atol=1e-9)
     np.testing.assert_allclose(lqd.cpu().numpy()[close], lqr[close], rtol=1e-5, atol=3e-4)
