@@ -80,6 +80,9 @@ struct asmc_ctx {
     double* d_gamma;               // [n_max] tpCN scale variates of the current step
     double* d_rec;                 // [4 * n_max] (ll, lp, lq, 0) records of asmc_gather's source population
     void* d_ysoa;                  // coordinate-major whitened state of a mutation (grown on demand)
+    void* d_xpad;                  // zero-padded tables + rows of a mutation whose d has no kernels of its own (grown on demand)
+    size_t xpad_bytes;
+    int d_max_pad;                 // widest padded problem the scratch of this ctx carries (next supported width >= d_max)
     double* d_student;             // [d_max (d_max + 1) + (ASMC_STUDENT_MAX_ROWS / 64) (d_max + 2)] tpCN fit: tables, partials
     double* h_student;             // pinned staging of the same size
     size_t ysoa_bytes;

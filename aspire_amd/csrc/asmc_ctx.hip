@@ -144,7 +144,8 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     if (c->gram_cap < (size_t)2048 * 1024) c->gram_cap = (size_t)2048 * 1024;
     dmalloc((void**)&c->d_gram, sizeof(double) * c->gram_cap);
     c->d_mmtab = nullptr;
-    if (d_max >= 64) dmalloc((void**)&c->d_mmtab, sizeof(double) * 2 * 144 * 64);
+    c->d_max_pad = d_max <= 4 ? 4 : d_max <= 8 ? 8 : d_max <= 16 ? 16 : d_max <= 32 ? 32 : d_max <= 64 ? 64 : d_max <= 128 ? 128 : 0;
+    if (d_max > 32) dmalloc((void**)&c->d_mmtab, sizeof(double) * 2 * 144 * 64);  // (d in 33 .. 63 runs zero-padded on the d = 64 kernels)
     dmalloc((void**)&c->d_guide, sizeof(unsigned int) * ((size_t)n_max / 4 + 8));
     dmalloc((void**)&c->d_flags, (size_t)n_max + 64);
     dmalloc((void**)&c->d_gamma, sizeof(double) * (size_t)n_max);
@@ -194,6 +195,7 @@ int asmc_ctx_destroy(asmc_ctx* c) {
     (void)hipFree(c->d_student);
     if (c->h_student) (void)hipHostFree(c->h_student);
     if (c->d_ysoa) (void)hipFree(c->d_ysoa);
+    if (c->d_xpad) (void)hipFree(c->d_xpad);
     (void)hipFree(c->d_counts);
     (void)hipFree(c->d_rho);
     (void)hipFree(c->d_tilectr);

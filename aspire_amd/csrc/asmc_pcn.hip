@@ -387,6 +387,7 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
     const int WPB = (int)(blockDim.x >> 6);  // waves per block: chosen by the launcher from the LDS budget
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dr = PAD ? p.d_real : D;                                       // elements per stored row
+    const int dn = (p.d_noise > 0 && p.d_noise < D) ? p.d_noise : D;         // real dimension of a zero-padded problem (asmc_pcn_mutate)
     const int rowb = PAD ? dr * (int)sizeof(T) : ROWB;
     const int ldsrow = PAD ? lds_row_stride(rowb) : LDSROW;
     char* tile = smem + (size_t)wave * 64 * LDSROW;
@@ -534,11 +535,12 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
                         if (qd & 1) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                if (PAD) {  // the padded coordinates carry no noise: y' = 0 there, and they stay out of |y'|^2
+                if (PAD || dn < D) {  // the padded coordinates carry no noise: y' = 0 there, and they stay out of |y'|^2
+                    const int dm = PAD ? dr : dn;  // (dn < D: a wave-uniform branch that only zero-padded problems take)
                     q1 = 0.0;
 #pragma unroll
                     for (int j = 0; j < D; j++) {
-                        v[j] = j < dr ? v[j] : 0.0;
+                        v[j] = j < dm ? v[j] : 0.0;
                         q1 = fma(v[j], v[j], q1);
                     }
                 }
@@ -622,7 +624,7 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
                 }
                 const double lpn = log_p_t(nll, nlp, nlq, p.beta);
                 const double lpo = log_p_t(oll, olp, olq, p.beta);
-                const double log_a = (lpn + ref_corr_ct<TP>(q1, p.nu, D)) - (lpo + ref_corr_ct<TP>(q0, p.nu, D));
+                const double log_a = (lpn + ref_corr_ct<TP>(q1, p.nu, dn)) - (lpo + ref_corr_ct<TP>(q0, p.nu, dn));
                 const double u = accept_uniform(p.seed, gid, step);
                 if (!PROPOSE) acc = log(u) < log_a;
                 if (acc && !PROPOSE) {
@@ -916,11 +918,11 @@ static int pcn_prepare_gamma(asmc_ctx* ctx, int64_t n, PcnDev& pd, uint32_t step
     const int grid = grid_for(n, ASMC_BLOCK, ASMC_MAX_BLOCKS * 4);
     if (pd.noise == ASMC_NOISE_F32)
         ASMC_LAUNCH(ctx, st, "k_gamma_draw", k_gamma_draw<true>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n,
-                    0.5 * ((double)pd.d + pd.nu), (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma,
+                    0.5 * ((double)(pd.d_noise > 0 ? pd.d_noise : pd.d) + pd.nu), (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma,
                     (const double*)ctx->d_bmtab);
     else
         ASMC_LAUNCH(ctx, st, "k_gamma_draw", k_gamma_draw<false>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n,
-                    0.5 * ((double)pd.d + pd.nu), (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma,
+                    0.5 * ((double)(pd.d_noise > 0 ? pd.d_noise : pd.d) + pd.nu), (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma,
                     (const double*)ctx->d_bmtab);
     ASMC_LAUNCH_CHECK();
     pd.gam = ctx->d_gamma;
@@ -1483,6 +1485,7 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     ps.gid0 = pd.gid0;
     ps.bmtab = pd.bmtab;
     ps.tile_par = pd.tile_par;
+    ps.d_noise = pd.d_noise;
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
@@ -1525,6 +1528,7 @@ static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double
     ps.gid0 = pd.gid0;
     ps.bmtab = pd.bmtab;
     ps.tile_par = pd.tile_par;
+    ps.d_noise = pd.d_noise;
     ps.c_ll = pd.ll.C;
     ps.c_lp = pd.lp.C;
     ps.c_lq = pd.lq.C;
@@ -2009,9 +2013,148 @@ int asmc_pcn_set_count_rccl(asmc_ctx* ctx, int64_t* cell_dev, int64_t n_global) 
     return asmc_pcn_set_count_hook(ctx, rccl_count_hook, ctx, cell_dev, n_global);
 }
 
+}  // extern "C" (templates below)
+
+// ---- any d <= 128 on the fast kernels: zero-padding to the next supported width ------------------------------------------
+// The register-resident kernels exist for d in {4, 8, 16, 32}, the matrix-core kernels for d in {64, 128}; every other d used
+// to fall to the generic LDS kernel (6-9x slower).  A d-dimensional problem is the same as the D-dimensional one with
+// x = (x, 0), mu = (mu, 0), L = diag(L, I), zero precisions on the padded coordinates of every density component, and NO
+// noise on the padded coordinates (PcnDev.d_noise: y' = 0 there, |y|^2 and the Student-t dimension stay d's) - the real
+// coordinates see exactly the arithmetic of the unpadded specification (same noise words: they are keyed by coordinate).
+// Cost: two copy passes over the rows per call (pad, un-pad) and N x D x s bytes of scratch, grown on demand.
+static int pcn_pad_dim(int d) {
+    const int widths[] = {4, 8, 16, 32, 64, 128};
+    for (int D : widths)
+        if (d <= D) return D;
+    return 0;
+}
+template <typename T>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_pad_rows(int64_t n, int d, int D, const T* __restrict__ x, T* __restrict__ xp) {
+    const int64_t total = n * D, stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t e = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; e < total; e += stride) {
+        const int64_t i = e / D;
+        const int j = (int)(e - i * D);
+        xp[e] = j < d ? x[i * d + j] : (T)0;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_unpad_rows(int64_t n, int d, int D, const T* __restrict__ xp, T* __restrict__ x) {
+    const int64_t total = n * d, stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t e = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; e < total; e += stride) {
+        const int64_t i = e / d;
+        const int j = (int)(e - i * d);
+        x[e] = xp[i * D + j];
+    }
+}
+// padded tables: mu[D] | L[D, D] | Linv[D, D] | 3 x (mu[C_max, D] | prec[C_max, D]) for ll, lp, lq
+__global__ __launch_bounds__(256) void k_pad_tables(int d, int D, PcnDev p, double* __restrict__ out) {
+    double* mu = out;
+    double* L = mu + D;
+    double* Li = L + (size_t)D * D;
+    for (int e = threadIdx.x; e < D; e += 256) mu[e] = e < d ? p.mu[e] : 0.0;
+    for (int e = threadIdx.x; e < D * D; e += 256) {
+        const int i = e / D, j = e - i * D;
+        const bool in = i < d && j < d;
+        L[e] = in ? p.L[i * d + j] : (i == j ? 1.0 : 0.0);
+        Li[e] = in ? p.Linv[i * d + j] : (i == j ? 1.0 : 0.0);
+    }
+    const MixDev* mix[3] = {&p.ll, &p.lp, &p.lq};
+    for (int k = 0; k < 3; k++) {
+        double* m = Li + (size_t)D * D + (size_t)k * 2 * ASMC_MAX_COMPONENTS * D;
+        double* pr = m + (size_t)ASMC_MAX_COMPONENTS * D;
+        for (int e = threadIdx.x; e < mix[k]->C * D; e += 256) {
+            const int c = e / D, j = e - c * D;
+            m[e] = j < d ? mix[k]->mu[c * d + j] : 0.0;
+            pr[e] = j < d ? mix[k]->prec[c * d + j] : 0.0;
+        }
+    }
+}
+
+static int pcn_mutate_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq, const asmc_pcn_params* prm,
+                           int n_steps, uint32_t step0, double* rho_inout_host, int64_t* n_accept_host, double* rho_hist_host,
+                           asmc_stream stream, int d_noise);
+
+static int pcn_mutate_padded(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq, const asmc_pcn_params* prm,
+                             int D, int n_steps, uint32_t step0, double* rho_inout_host, int64_t* n_accept_host,
+                             double* rho_hist_host, asmc_stream stream) {
+    hipStream_t st = as_stream(stream);
+    const int d = prm->d;
+    const size_t es = prm->x_dtype == ASMC_F64 ? 8 : 4;
+    const size_t tab_doubles = (size_t)D + 2 * (size_t)D * D + 3 * 2 * (size_t)ASMC_MAX_COMPONENTS * D;
+    const size_t tab_bytes = ((tab_doubles * 8 + 255) / 256) * 256;
+    const size_t need = tab_bytes + (size_t)n * D * es;
+    if (need > ctx->xpad_bytes) {
+        ASMC_HIP(hipStreamSynchronize(st));
+        if (ctx->d_xpad) (void)hipFree(ctx->d_xpad);
+        ctx->d_xpad = nullptr;
+        ctx->xpad_bytes = 0;
+        if (hipMalloc(&ctx->d_xpad, need) != hipSuccess) {
+            (void)hipGetLastError();
+            asmc_set_error("pcn: no device memory for the zero-padded copy of the state (%zu bytes)", need);
+            return ASMC_ERR_NOMEM;
+        }
+        ctx->xpad_bytes = need;
+    }
+    double* tab = reinterpret_cast<double*>(ctx->d_xpad);
+    void* xp = reinterpret_cast<char*>(ctx->d_xpad) + tab_bytes;
+    PcnDev src;
+    memset(&src, 0, sizeof(src));
+    src.mu = prm->mu_dev, src.L = prm->L_dev, src.Linv = prm->Linv_dev;
+    src.ll = to_dev(prm->log_likelihood), src.lp = to_dev(prm->log_prior), src.lq = to_dev(prm->log_q);
+    ASMC_LAUNCH(ctx, st, "k_pad_tables", k_pad_tables, dim3(1), dim3(256), 0, st, d, D, src, tab);
+    ASMC_LAUNCH_CHECK();
+    const int grid = grid_for(n * D, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
+    if (es == 8)
+        ASMC_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const double*)x, (double*)xp);
+    else
+        ASMC_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const float*)x, (float*)xp);
+    ASMC_LAUNCH_CHECK();
+    asmc_pcn_params p2 = *prm;
+    p2.d = D;
+    p2.mu_dev = tab;
+    p2.L_dev = tab + D;
+    p2.Linv_dev = p2.L_dev + (size_t)D * D;
+    asmc_mixture* mix[3] = {&p2.log_likelihood, &p2.log_prior, &p2.log_q};
+    for (int k = 0; k < 3; k++) {
+        mix[k]->mu_dev = p2.Linv_dev + (size_t)D * D + (size_t)k * 2 * ASMC_MAX_COMPONENTS * D;
+        mix[k]->prec_dev = mix[k]->mu_dev + (size_t)ASMC_MAX_COMPONENTS * D;
+    }
+    int rc = pcn_mutate_impl(ctx, n, xp, ll, lp, lq, &p2, n_steps, step0, rho_inout_host, n_accept_host, rho_hist_host, stream, d);
+    if (rc) return rc;
+    if (es == 8)
+        ASMC_LAUNCH(ctx, st, "k_unpad_rows", k_unpad_rows<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const double*)xp, (double*)x);
+    else
+        ASMC_LAUNCH(ctx, st, "k_unpad_rows", k_unpad_rows<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const float*)xp, (float*)x);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+extern "C" {
+
 int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq,
                     const asmc_pcn_params* prm, int n_steps, uint32_t step0, double* rho_inout_host,
                     int64_t* n_accept_host, double* rho_hist_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && prm, "null pointer");
+    ASMC_REQUIRE(prm->d > 0 && prm->d <= ASMC_MAX_DIMS, "bad d");
+    const int D = pcn_pad_dim(prm->d);
+    const bool fast_as_is = prm->d == D;
+    if (!fast_as_is && D > 0 && D <= ctx->d_max_pad && !getenv("ASMC_PCN_GENERIC") && !getenv("ASMC_PCN_NOPAD")) {
+        ASMC_REQUIRE(ll && lp && lq && rho_inout_host && n_accept_host, "null pointer");
+        ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+        ASMC_REQUIRE(prm->x_dtype == ASMC_F64 || prm->x_dtype == ASMC_F32, "bad x_dtype");
+        ASMC_REQUIRE(prm->mu_dev && prm->L_dev && prm->Linv_dev, "null reference-Gaussian pointer");
+        int rc = check_mixture(prm->log_likelihood);
+        if (!rc) rc = check_mixture(prm->log_prior);
+        if (!rc) rc = check_mixture(prm->log_q);
+        if (rc) return rc;
+        return pcn_mutate_padded(ctx, n, x, ll, lp, lq, prm, D, n_steps, step0, rho_inout_host, n_accept_host, rho_hist_host, stream);
+    }
+    return pcn_mutate_impl(ctx, n, x, ll, lp, lq, prm, n_steps, step0, rho_inout_host, n_accept_host, rho_hist_host, stream, 0);
+}
+
+static int pcn_mutate_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq, const asmc_pcn_params* prm,
+                           int n_steps, uint32_t step0, double* rho_inout_host, int64_t* n_accept_host, double* rho_hist_host,
+                           asmc_stream stream, int d_noise) {
     ASMC_REQUIRE(ctx && x && ll && lp && lq && prm && rho_inout_host && n_accept_host, "null pointer");
     ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
     ASMC_REQUIRE(n_steps >= 1 && n_steps <= ASMC_MAX_PCN_STEPS, "n_steps out of range (<= 2048 per call)");
@@ -2029,6 +2172,7 @@ int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, d
     memset(&pd, 0, sizeof(pd));
     pd.bmtab = ctx->d_bmtab;
     pd.d = prm->d;
+    pd.d_noise = d_noise;
     pd.beta = prm->beta;
     pd.mu = prm->mu_dev;
     pd.L = prm->L_dev;

@@ -384,6 +384,7 @@ struct PcnDev {
     long long n_pad;
     const double* bmtab;  // the Box-Muller tables in HBM (ctx->d_bmtab)
     unsigned char* tile_par;  // fused flow step: which half of the state allocation holds each 64-particle tile (else nullptr)
+    int d_noise;        // > 0: a d_noise-dimensional problem zero-padded to d (asmc_pcn_mutate): coordinates >= d_noise get no noise
     int dpad;           // > d: run the d-dimensional problem on the kernels compiled for dpad (identity-padded tables)
     int mode;  // PCN_X_STEP / PCN_Y_STEP / PCN_WHITEN / PCN_UNWHITEN (register-resident kernels)
 };
@@ -405,6 +406,7 @@ struct PcnScalars {
     int c_ll, c_lp, c_lq;
     const double* bmtab;  // the Box-Muller tables in HBM (ctx->d_bmtab)
     unsigned char* tile_par;  // see PcnDev
+    int d_noise;              // see PcnDev (0: no padding)
 };
 
 

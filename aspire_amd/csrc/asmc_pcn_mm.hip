@@ -157,6 +157,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pp = lane & 15, h = lane >> 4;
+    const int dn = (p.d_noise > 0 && p.d_noise < D) ? p.d_noise : D;  // real dimension of a zero-padded problem
     const double rho = (M == MM_STEP) ? *rho_ptr : 0.0;
     const double a = sqrt(1.0 - rho * rho);
     const int64_t n_groups = (n + 15) / 16;
@@ -249,6 +250,14 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
                 q1 = fma(v[2 * sp], v[2 * sp], q1);
                 q1 = fma(v[2 * sp + 1], v[2 * sp + 1], q1);
             }
+            if (dn < D) {  // a zero-padded problem (asmc_pcn_mutate): the padded coordinates carry no noise, y' = 0 there
+                q1 = 0.0;
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    v[s] = mm_coord(s, h) < dn ? v[s] : 0.0;
+                    q1 = fma(v[s], v[s], q1);
+                }
+            }
             q1 = quad_sum(q1);
             mm_trimatvec<D>(sA, v, o, lane);
 #pragma unroll
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
             if (valid) {
                 const double lpn = log_p_t(nll, nlp, nlq, p.beta);
                 const double lpo = log_p_t(ll[row], lp[row], lq[row], p.beta);
-                const double log_a = (lpn + ref_corr_ct<TP>(q1, p.nu, D)) - (lpo + ref_corr_ct<TP>(q0, p.nu, D));
+                const double log_a = (lpn + ref_corr_ct<TP>(q1, p.nu, dn)) - (lpo + ref_corr_ct<TP>(q0, p.nu, dn));
                 const double u = accept_uniform(p.seed, gid, step);
                 if (log(u) < log_a) {
                     store_row(v);

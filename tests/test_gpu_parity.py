@@ -416,10 +416,12 @@ def _pcn_setup(eng, n, d, seed, dtype=torch.float64, C=1):
     return x, mu, np.tril(L), np.tril(Linv), mixes
 
 
-@pytest.mark.parametrize("d,C", [(32, 1), (4, 2), (7, 1), (2, 1)])
+@pytest.mark.parametrize("d,C", [(32, 1), (4, 2), (7, 1), (2, 1), (20, 1), (20, 3), (48, 1), (100, 2), (3, 1), (127, 1)])
 def test_pcn_step_vs_oracle(eng, oracle, d, C):
     """One fused pCN step == the oracle's restatement of the same specification: proposals to 1e-12,
-    accept decisions identical except where log u is within 1e-9 of log alpha."""
+    accept decisions identical except where log u is within 1e-9 of log alpha.  Every d <= 128 runs on the
+    register-resident / matrix-core kernels - a d without kernels of its own zero-padded to the next width
+    (asmc_pcn_mutate) - never on the generic LDS kernel."""
     n = 3000
     x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 21 + d, C=C)
     om = [oracle.Mixture(*m) for m in mixes]
@@ -427,12 +429,18 @@ def test_pcn_step_vs_oracle(eng, oracle, d, C):
     dm = [eng.make_mixture(*m) for m in mixes]
     xd, lld, lpd, lqd = dev(eng, x, ll, lp, lq)
     rho, beta, seed, gid0, step = 0.4, 0.37, 4242, 1000, 5
+    eng.profile(True)
     n_acc, rho_hist, rho_out = eng.pcn_mutate(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv),
                                               dm[0], dm[1], dm[2], seed, gid0, rho, 1, step, 0.234, False)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert not any(k.startswith(("k_pcn_step_generic", "k_pcn_propose")) for k in rep), sorted(rep)
+    assert ("k_pad_rows" in rep) == (d not in (4, 8, 16, 32, 64, 128))
     xr, llr, lpr, lqr = x.copy(), ll.copy(), lp.copy(), lq.copy()
     acc_ref = oracle.pcn_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, om[0], om[1], om[2], seed, gid0, step)
     got = xd.cpu().numpy()
-    moved_g = np.any(got != x, axis=1)
+    # (the matrix-core kernels always step on the whitened state: a rejected row comes back through y -> x with rounding)
+    moved_g = np.any(np.abs(got - x) > 1e-9 * (1 + np.abs(x)), axis=1)
     moved_r = np.any(xr != x, axis=1)
     disagree = moved_g != moved_r
     assert disagree.sum() <= 2, disagree.sum()  # only razor-edge accept decisions may differ
@@ -442,6 +450,43 @@ def test_pcn_step_vs_oracle(eng, oracle, d, C):
     np.testing.assert_allclose(lqd.cpu().numpy()[same], lqr[same], rtol=1e-11, atol=1e-11)
     assert abs(int(n_acc[0]) - acc_ref) <= 2 and rho_out == rho and rho_hist[0] == rho
     assert 0.02 < n_acc[0] / n < 0.98
+
+
+@pytest.mark.parametrize("d,step_fn,dtype", [(20, "pcn", torch.float64), (7, "tpcn", torch.float64), (48, "pcn", torch.float64),
+                                             (100, "tpcn", torch.float64), (20, "pcn", torch.float32)])
+def test_padded_dimensions_multi_step_vs_oracle(eng, oracle, d, step_fn, dtype):
+    """Four steps of a problem whose d has no kernels of its own (zero-padded to 8 / 32 / 64 / 128 inside asmc_pcn_mutate):
+    pCN and tpCN (the Student-t correction and the Gamma shape keep the REAL dimension) against the oracle at the real d."""
+    n, nu = 3000, 6.5
+    x, mu, L, Linv, mixes = _pcn_setup(eng, n, d, 77 + d)
+    om = [oracle.Mixture(*m) for m in mixes]
+    dm = [eng.make_mixture(*m) for m in mixes]
+    xd = torch.as_tensor(x).to(dtype).to(eng.device)
+    xr = xd.double().cpu().numpy().copy()
+    ll, lp, lq = (m.logpdf(xr) for m in om)
+    lld, lpd, lqd = dev(eng, ll, lp, lq)
+    rho, beta, seed = 0.3, 0.55, 991
+    eng.profile(True)
+    n_acc, _, _ = eng.pcn_mutate(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), dm[0], dm[1], dm[2],
+                                 seed, 70, rho, 4, 20, 0.234, False, "f64", nu if step_fn == "tpcn" else 0.0)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert "k_pad_rows" in rep and "k_unpad_rows" in rep and not any(k.startswith("k_pcn_step_generic") for k in rep), sorted(rep)
+    llr, lpr, lqr = ll.copy(), lp.copy(), lq.copy()
+    acc_ref = []
+    for t in range(4):
+        if step_fn == "tpcn":
+            acc_ref.append(oracle.tpcn_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, nu, om[0], om[1], om[2], seed, 70, 20 + t))
+        else:
+            acc_ref.append(oracle.pcn_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, om[0], om[1], om[2], seed, 70, 20 + t))
+    got = xd.double().cpu().numpy()
+    tol = 1e-9 if dtype == torch.float64 else 2e-5
+    edge = 3 if dtype == torch.float64 else 40
+    close = np.all(np.abs(got - xr) <= tol * (1 + np.abs(xr)), axis=1)
+    assert (~close).sum() <= edge, (~close).sum()
+    assert np.all(np.abs(np.array(n_acc) - np.array(acc_ref)) <= edge) and 0.02 < np.mean(n_acc) / n < 0.98
+    if dtype == torch.float64:
+        np.testing.assert_allclose(lld.cpu().numpy()[close], llr[close], rtol=1e-9, atol=1e-9)
 
 
 @pytest.mark.parametrize("d,dtype", [(32, torch.float64), (8, torch.float64), (32, torch.float32)])
