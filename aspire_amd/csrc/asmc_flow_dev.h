@@ -351,18 +351,26 @@ typedef unsigned flow_u4 __attribute__((ext_vector_type(4)));
 
 // elements (x0, x1) -> their packed hi halves and lo halves (see split8_f16).  The range check rides on the hi halves
 // (split4_range below): an element past the fp16 range converts to inf, and 65504 itself is flagged like before.
-template <bool RELU>
+// NOP: end the statement with the two wait states a just-written VGPR needs before an MFMA reads it as an operand
+// (cdna_hip_programming.md 5.7 item 2) - only the LAST quarter of an operand can be followed directly by its consumer.
+template <bool RELU, bool NOP = true>
 __device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& hp, unsigned& lp) {
     const float v0 = RELU ? __int_as_float(max(__float_as_int(x0), 0)) : x0;
     const float v1 = RELU ? __int_as_float(max(__float_as_int(x1), 0)) : x1;
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     const half2v h = half2v{(_Float16)v0, (_Float16)v1};
     half2v l;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "s_nop 1"
-        : "=&v"(l)
-        : "v"(h), "v"(v0), "v"(v1));
+    if (NOP)
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "s_nop 1"
+            : "=&v"(l)
+            : "v"(h), "v"(v0), "v"(v1));
+    else
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(l)
+            : "v"(h), "v"(v0), "v"(v1));
     hp = __builtin_bit_cast(unsigned, h);
     lp = __builtin_bit_cast(unsigned, l);
 }
@@ -407,16 +415,28 @@ __device__ __forceinline__ void coupling_layer_hs2(const float (&condA)[H / 2], 
     };
     unsigned hpA[4], lpA[4], hpB[4], lpB[4];
     auto cvtA = [&](int g, int c) {  // quarter c of group g's operand; the odd quarters also range-check their pair of quarters
-        if (g < ST1) split2_f16<false>(src(condA, h1A, h2A, g, 2 * c), src(condA, h1A, h2A, g, 2 * c + 1), hpA[c], lpA[c]);
-        else split2_f16<true>(src(condA, h1A, h2A, g, 2 * c), src(condA, h1A, h2A, g, 2 * c + 1), hpA[c], lpA[c]);
+        const float e0 = src(condA, h1A, h2A, g, 2 * c), e1 = src(condA, h1A, h2A, g, 2 * c + 1);
+        if (c == 3) {  // the quarter that may be followed directly by the MFMAs that read the operand: wait states inside
+            if (g < ST1) split2_f16<false, true>(e0, e1, hpA[c], lpA[c]);
+            else split2_f16<true, true>(e0, e1, hpA[c], lpA[c]);
+        } else {
+            if (g < ST1) split2_f16<false, false>(e0, e1, hpA[c], lpA[c]);
+            else split2_f16<true, false>(e0, e1, hpA[c], lpA[c]);
+        }
         if (c & 1) {
             if (g < ST1) split4_range<true>(hpA[c - 1], hpA[c], amaxA);
             else split4_range<false>(hpA[c - 1], hpA[c], amaxA);
         }
     };
     auto cvtB = [&](int g, int c) {
-        if (g < ST1) split2_f16<false>(src(condB, h1B, h2B, g, 2 * c), src(condB, h1B, h2B, g, 2 * c + 1), hpB[c], lpB[c]);
-        else split2_f16<true>(src(condB, h1B, h2B, g, 2 * c), src(condB, h1B, h2B, g, 2 * c + 1), hpB[c], lpB[c]);
+        const float e0 = src(condB, h1B, h2B, g, 2 * c), e1 = src(condB, h1B, h2B, g, 2 * c + 1);
+        if (c == 3) {  // the quarter that may be followed directly by the MFMAs that read the operand: wait states inside
+            if (g < ST1) split2_f16<false, true>(e0, e1, hpB[c], lpB[c]);
+            else split2_f16<true, true>(e0, e1, hpB[c], lpB[c]);
+        } else {
+            if (g < ST1) split2_f16<false, false>(e0, e1, hpB[c], lpB[c]);
+            else split2_f16<true, false>(e0, e1, hpB[c], lpB[c]);
+        }
         if (c & 1) {
             if (g < ST1) split4_range<true>(hpB[c - 1], hpB[c], amaxB);
             else split4_range<false>(hpB[c - 1], hpB[c], amaxB);
