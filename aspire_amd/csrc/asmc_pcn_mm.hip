@@ -236,19 +236,36 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
                     zf[4 * m + 3] = __uint_as_float(s13[1]);
                 }
             }
+            // default noise: the same sharing - a lane's pair 4 sp + h is one HALF of Philox block 2 sp + (h >> 1), whose other half
+            // belongs to the partner lane 16 away.  The even lane draws the block of sp = 2 m, the odd lane that of sp = 2 m + 1
+            // (all four normals each), and four v_permlane16_swap (the two words of two doubles) trade the halves: afterwards
+            // every lane holds its pair of sp = 2 m in (za0, za1) and of sp = 2 m + 1 in (zb0, zb1).  Same normals as one block
+            // per lane and pair (round 2), half the Philox blocks.
+            auto swap64 = [](double& x, double& y) {  // odd rows of x <-> even rows of y
+                const unsigned long long xb = (unsigned long long)__double_as_longlong(x), yb = (unsigned long long)__double_as_longlong(y);
+                const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)xb, (unsigned)yb, false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(xb >> 32), (unsigned)(yb >> 32), false, false);
+                x = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));
+                y = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+            };
 #pragma unroll
-            for (int sp = 0; sp < KS / 2; sp++) {
-                double z0, z1;
+            for (int m = 0; m < KS / 4; m++) {
+                double zz[4];
                 if (NOISE == ASMC_NOISE_F32) {
-                    z0 = (double)zf[(2 * sp) % KS];
-                    z1 = (double)zf[(2 * sp + 1) % KS];
-                } else {  // coordinates 2 pr, 2 pr + 1 from pair pr: exactly the owned pair
-                    normal_pair(p.seed, gid, step, (uint32_t)(4 * sp + h), bmt, z0, z1);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) zz[e] = (double)zf[4 * m + e];
+                } else {
+                    const uint32_t blk = (uint32_t)(2 * (2 * m + (h & 1)) + (h >> 1));
+                    normal_quad(p.seed, gid, step, blk, bmt, zz[0], zz[1], zz[2], zz[3]);
+                    swap64(zz[0], zz[2]);
+                    swap64(zz[1], zz[3]);
                 }
-                v[2 * sp] = (double)(T)fma(rs, z0, a * v[2 * sp]);
-                v[2 * sp + 1] = (double)(T)fma(rs, z1, a * v[2 * sp + 1]);
-                q1 = fma(v[2 * sp], v[2 * sp], q1);
-                q1 = fma(v[2 * sp + 1], v[2 * sp + 1], q1);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int s = 4 * m + e;
+                    v[s] = (double)(T)fma(rs, zz[e], a * v[s]);
+                    q1 = fma(v[s], v[s], q1);
+                }
             }
             if (dn < D) {  // a zero-padded problem (asmc_pcn_mutate): the padded coordinates carry no noise, y' = 0 there
                 q1 = 0.0;
