@@ -37,7 +37,7 @@ def case(name, d, lik, prior, flow_fn, true, xp=np, **kw):
                     rng=np.random.default_rng(100 + s))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = sp.sample(n, sampler_kwargs=dict(n_steps=32, noise="f32", **kw), store_sample_history=False)
+        out = sp.sample(n, sampler_kwargs=dict(n_steps=32, noise=os.environ.get("NOISE", "f64"), **kw), store_sample_history=False)
         torch.cuda.synchronize()
         walls.append(time.perf_counter() - t0)
         z.append((float(out.log_evidence) - true) / float(out.log_evidence_error))
