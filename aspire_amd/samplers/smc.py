@@ -729,117 +729,157 @@ class HipSMC(SMCSampler):
 
     def _mutate_steps(self, particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0, acc_rates,
                       dev_flow, on_device, n_local, n_global, gid0, nu=0.0):
-        e, comm = self.engine, self.comm
+        """The mutation's step loop.  Four code paths, chosen from what the densities are (`last_mutation_path` names the one
+        taken): the flow-proposal loop on the device, the built-in-density loop on the device, arbitrary callables between
+        device-side propose / accept halves, and the same with one host round trip per step."""
+        e = self.engine
+        m = (particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0, acc_rates, dev_flow, on_device,
+             n_local, n_global, gid0, nu)
         if self._flow_fused_ok(dev_flow):
-            # flow proposal density evaluated on the MFMA inside the device-side step loop (BASELINE config 3)
-            self.last_mutation_path = "flow: device-side step loop (asmc_pcn_mutate_flow; one fused kernel per step where its shape is covered)"
-            t_ll = self._log_likelihood.device_mixture(e)
-            t_lp = self._log_prior.device_mixture(e)
-            if on_device:
-                done = 0
-                while done < n_steps:
-                    chunk = min(n_steps - done, 2048)
-                    ahead = chunk == n_steps and n_steps <= 1024 and self._importance_step_follows(beta)
-                    if ahead:
-                        # the next temperature's importance step (search, resampling, gather, moments) goes onto the stream
-                        # right behind the mutation, BEFORE the host waits for either: the GPU does not idle while Python
-                        # does the bookkeeping of the finished mutation
-                        handle = e.pcn_mutate_flow_enqueue(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed, gid0,
-                                                           st["rho"], chunk, step0, target, True, noise, nu)
-                        out = self._wrap(x, ll, lp, lq, beta, like=particles)
-                        ok = out.speculate_importance_step(self.current_target_efficiency(beta), self._beta_tolerance, self.rng,
-                                                           resample_mode=self.resample_mode, resample_method=self.resample_method,
-                                                           moments_n=self._speculated_moments_n(out), defer=True)
-                        n_acc, rho_hist, rho = e.pcn_mutate_flow_result(handle)  # waits for the mutation only
-                        if ok:
-                            st["prewrapped"] = out  # the step's results are collected when the next iteration asks for them
-                    else:
-                        n_acc, rho_hist, rho = e.pcn_mutate_flow(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed,
-                                                                 gid0, st["rho"], chunk, step0 + done, target, True, noise, nu)
-                    st["rho"] = rho
-                    st["lq_checked"] = hasattr(e, "pcn_lq_nan")
-                    acc_rates.extend((n_acc / n_global).tolist())
-                    done += chunk
-                    n_bad = e.pcn_flow_nonfinite() if hasattr(e, "pcn_flow_nonfinite") else 0
-                    if n_bad > 0:
-                        logger.warning(f"{n_bad} proposals had a non-finite flow density and were rejected (a badly scaled flow "
-                                       "overflows the fp16 operand pairs of the flow kernel; ASMC_FLOW_MATH=f32 uses fp32 MFMAs)")
-            else:
-                for t in range(n_steps):
-                    n_acc, _, _ = e.pcn_mutate_flow(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed, gid0,
-                                                    st["rho"], 1, step0 + t, target, False, noise, nu)
-                    tot = float(comm.all_gather_f64(np.array([float(n_acc[0])])).sum())
-                    acc_rates.append(tot / n_global)
-                    st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)
-            self.n_likelihood_evaluations += n_steps * n_local
+            self._steps_flow_on_device(m)
         elif self._fused_ok():
-            self.last_mutation_path = "built-in densities: device-side step loop (asmc_pcn_mutate)"
-            t_ll = self._log_likelihood.device_mixture(e)
-            t_lp = self._log_prior.device_mixture(e)
-            t_lq = self.prior_flow.device_mixture(e)
-            if on_device:
-                done = 0
-                while done < n_steps:
-                    chunk = min(n_steps - done, 2048)
-                    n_acc, rho_hist, rho = e.pcn_mutate(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed,
-                                                        gid0, st["rho"], chunk, step0 + done, target, True, noise, nu)
-                    st["rho"] = rho
-                    st["lq_checked"] = hasattr(e, "pcn_lq_nan")
-                    acc_rates.extend((n_acc / n_global).tolist())
-                    done += chunk
-            else:
-                for t in range(n_steps):
-                    n_acc, _, _ = e.pcn_mutate(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed, gid0,
-                                               st["rho"], 1, step0 + t, target, False, noise, nu)
-                    tot = float(comm.all_gather_f64(np.array([float(n_acc[0])])).sum())
-                    acc_rates.append(tot / n_global)
-                    st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)
-            self.n_likelihood_evaluations += n_steps * n_local
+            self._steps_builtin_on_device(m)
         elif hasattr(e, "pcn_split_begin") and on_device:
-            # arbitrary callables between propose and accept; step size and accept counts stay on the device (the exchange
-            # hook of sharded runs is already installed by the caller), so the host enqueues step t + 1 while step t runs
+            self._steps_callables_split(m)
+        else:
+            self._steps_callables_round_trip(m)
+        return self._finish_mutation(m)
+
+    def _steps_flow_on_device(self, m):
+        """Coupling-flow proposal density evaluated on the matrix cores inside the device-side step loop (BASELINE config 3)."""
+        e, comm = self.engine, self.comm
+        (particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0, acc_rates, dev_flow, on_device,
+         n_local, n_global, gid0, nu) = m
+        # flow proposal density evaluated on the MFMA inside the device-side step loop (BASELINE config 3)
+        self.last_mutation_path = "flow: device-side step loop (asmc_pcn_mutate_flow; one fused kernel per step where its shape is covered)"
+        t_ll = self._log_likelihood.device_mixture(e)
+        t_lp = self._log_prior.device_mixture(e)
+        if on_device:
             done = 0
-            self.last_mutation_path = "callables: split propose / accept with the step closed on the stream (asmc_pcn_split_*)"
-            while done < n_steps and hasattr(e, "pcn_ysplit_begin"):
-                # whitened-state session (d = 4, 8, 16, 32): the chain state stays coordinate-major on the device, a step is
-                # one mat-vec in the propose kernel and an LDS-free accept kernel
-                chunk = min(n_steps - done, 2048)
-                sess = e.pcn_ysplit_begin(x, beta, mu, L, Linv, seed, gid0, st["rho"], target, True, nu, noise)
-                if sess is None:
-                    break
-                self.last_mutation_path = "callables: whitened-state session (asmc_pcn_ysplit_*)"
-                for t in range(done, done + chunk):
-                    x_prop = e.pcn_ysplit_propose(sess, step0 + t)
-                    lq_new = self._flow_log_prob(x_prop)
-                    lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
-                    e.pcn_ysplit_accept(sess, step0 + t, ll, lp, lq, ll_new, lp_new, lq_new, n_global, t - done)
-                n_acc, _, st["rho"] = e.pcn_ysplit_end(sess, chunk)
-                acc_rates.extend((n_acc / n_global).tolist())
-                done += chunk
             while done < n_steps:
                 chunk = min(n_steps - done, 2048)
-                e.pcn_split_begin(st["rho"])
-                for t in range(done, done + chunk):
-                    x_prop, q0, q1 = e.pcn_propose(x, mu, L, Linv, 0.0, seed, gid0, step0 + t, nu=nu)
-                    lq_new = self._flow_log_prob(x_prop)
-                    lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
-                    e.pcn_accept(x, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0, step0 + t,
-                                 want_count=False)
-                    e.pcn_split_adapt(n_global, target, t - done, True)
-                n_acc, _, st["rho"] = e.pcn_split_end(chunk)
+                ahead = chunk == n_steps and n_steps <= 1024 and self._importance_step_follows(beta)
+                if ahead:
+                    # the next temperature's importance step (search, resampling, gather, moments) goes onto the stream
+                    # right behind the mutation, BEFORE the host waits for either: the GPU does not idle while Python
+                    # does the bookkeeping of the finished mutation
+                    handle = e.pcn_mutate_flow_enqueue(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed, gid0,
+                                                       st["rho"], chunk, step0, target, True, noise, nu)
+                    out = self._wrap(x, ll, lp, lq, beta, like=particles)
+                    ok = out.speculate_importance_step(self.current_target_efficiency(beta), self._beta_tolerance, self.rng,
+                                                       resample_mode=self.resample_mode, resample_method=self.resample_method,
+                                                       moments_n=self._speculated_moments_n(out), defer=True)
+                    n_acc, rho_hist, rho = e.pcn_mutate_flow_result(handle)  # waits for the mutation only
+                    if ok:
+                        st["prewrapped"] = out  # the step's results are collected when the next iteration asks for them
+                else:
+                    n_acc, rho_hist, rho = e.pcn_mutate_flow(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed,
+                                                             gid0, st["rho"], chunk, step0 + done, target, True, noise, nu)
+                st["rho"] = rho
+                st["lq_checked"] = hasattr(e, "pcn_lq_nan")
+                acc_rates.extend((n_acc / n_global).tolist())
+                done += chunk
+                n_bad = e.pcn_flow_nonfinite() if hasattr(e, "pcn_flow_nonfinite") else 0
+                if n_bad > 0:
+                    logger.warning(f"{n_bad} proposals had a non-finite flow density and were rejected (a badly scaled flow "
+                                   "overflows the fp16 operand pairs of the flow kernel; ASMC_FLOW_MATH=f32 uses fp32 MFMAs)")
+        else:
+            for t in range(n_steps):
+                n_acc, _, _ = e.pcn_mutate_flow(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed, gid0,
+                                                st["rho"], 1, step0 + t, target, False, noise, nu)
+                tot = float(comm.all_gather_f64(np.array([float(n_acc[0])])).sum())
+                acc_rates.append(tot / n_global)
+                st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)
+        self.n_likelihood_evaluations += n_steps * n_local
+
+    def _steps_builtin_on_device(self, m):
+        """Built-in densities (DiagGaussianMixture targets, analytic proposal): the whole loop in asmc_pcn_mutate."""
+        e, comm = self.engine, self.comm
+        (particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0, acc_rates, dev_flow, on_device,
+         n_local, n_global, gid0, nu) = m
+        self.last_mutation_path = "built-in densities: device-side step loop (asmc_pcn_mutate)"
+        t_ll = self._log_likelihood.device_mixture(e)
+        t_lp = self._log_prior.device_mixture(e)
+        t_lq = self.prior_flow.device_mixture(e)
+        if on_device:
+            done = 0
+            while done < n_steps:
+                chunk = min(n_steps - done, 2048)
+                n_acc, rho_hist, rho = e.pcn_mutate(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed,
+                                                    gid0, st["rho"], chunk, step0 + done, target, True, noise, nu)
+                st["rho"] = rho
+                st["lq_checked"] = hasattr(e, "pcn_lq_nan")
                 acc_rates.extend((n_acc / n_global).tolist())
                 done += chunk
         else:
-            self.last_mutation_path = "callables: split propose / accept, one host round trip per step"
             for t in range(n_steps):
-                x_prop, q0, q1 = e.pcn_propose(x, mu, L, Linv, st["rho"], seed, gid0, step0 + t, nu=nu)
-                lq_new = self._flow_log_prob(x_prop)
-                lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
-                n_acc = e.pcn_accept(x, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0,
-                                     step0 + t)
-                tot = float(comm.all_gather_f64(np.array([float(n_acc)])).sum())
+                n_acc, _, _ = e.pcn_mutate(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed, gid0,
+                                           st["rho"], 1, step0 + t, target, False, noise, nu)
+                tot = float(comm.all_gather_f64(np.array([float(n_acc[0])])).sum())
                 acc_rates.append(tot / n_global)
                 st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)
+        self.n_likelihood_evaluations += n_steps * n_local
+
+    def _steps_callables_split(self, m):
+        """Arbitrary callables between the propose and accept halves; step size and accept counts stay on the device."""
+        e, comm = self.engine, self.comm
+        (particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0, acc_rates, dev_flow, on_device,
+         n_local, n_global, gid0, nu) = m
+        # arbitrary callables between propose and accept; step size and accept counts stay on the device (the exchange
+        # hook of sharded runs is already installed by the caller), so the host enqueues step t + 1 while step t runs
+        done = 0
+        self.last_mutation_path = "callables: split propose / accept with the step closed on the stream (asmc_pcn_split_*)"
+        while done < n_steps and hasattr(e, "pcn_ysplit_begin"):
+            # whitened-state session (d = 4, 8, 16, 32): the chain state stays coordinate-major on the device, a step is
+            # one mat-vec in the propose kernel and an LDS-free accept kernel
+            chunk = min(n_steps - done, 2048)
+            sess = e.pcn_ysplit_begin(x, beta, mu, L, Linv, seed, gid0, st["rho"], target, True, nu, noise)
+            if sess is None:
+                break
+            self.last_mutation_path = "callables: whitened-state session (asmc_pcn_ysplit_*)"
+            for t in range(done, done + chunk):
+                x_prop = e.pcn_ysplit_propose(sess, step0 + t)
+                lq_new = self._flow_log_prob(x_prop)
+                lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
+                e.pcn_ysplit_accept(sess, step0 + t, ll, lp, lq, ll_new, lp_new, lq_new, n_global, t - done)
+            n_acc, _, st["rho"] = e.pcn_ysplit_end(sess, chunk)
+            acc_rates.extend((n_acc / n_global).tolist())
+            done += chunk
+        while done < n_steps:
+            chunk = min(n_steps - done, 2048)
+            e.pcn_split_begin(st["rho"])
+            for t in range(done, done + chunk):
+                x_prop, q0, q1 = e.pcn_propose(x, mu, L, Linv, 0.0, seed, gid0, step0 + t, nu=nu)
+                lq_new = self._flow_log_prob(x_prop)
+                lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
+                e.pcn_accept(x, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0, step0 + t,
+                             want_count=False)
+                e.pcn_split_adapt(n_global, target, t - done, True)
+            n_acc, _, st["rho"] = e.pcn_split_end(chunk)
+            acc_rates.extend((n_acc / n_global).tolist())
+            done += chunk
+
+    def _steps_callables_round_trip(self, m):
+        """Arbitrary callables, one host round trip per step (engines without the split entry points; sharded without a count hook)."""
+        e, comm = self.engine, self.comm
+        (particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0, acc_rates, dev_flow, on_device,
+         n_local, n_global, gid0, nu) = m
+        self.last_mutation_path = "callables: split propose / accept, one host round trip per step"
+        for t in range(n_steps):
+            x_prop, q0, q1 = e.pcn_propose(x, mu, L, Linv, st["rho"], seed, gid0, step0 + t, nu=nu)
+            lq_new = self._flow_log_prob(x_prop)
+            lp_new, ll_new = self._eval_prior_likelihood(x_prop, lq_new)
+            n_acc = e.pcn_accept(x, x_prop, ll, lp, lq, ll_new, lp_new, lq_new, q0, q1, beta, seed, gid0,
+                                 step0 + t)
+            tot = float(comm.all_gather_f64(np.array([float(n_acc)])).sum())
+            acc_rates.append(tot / n_global)
+            st["rho"] = pcn_adapt(st["rho"], acc_rates[-1], target, t)
+
+    def _finish_mutation(self, m):
+        """Bookkeeping behind every path: step counter, history, the NaN check of the carried log q, the wrapped population."""
+        e, comm = self.engine, self.comm
+        (particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0, acc_rates, dev_flow, on_device,
+         n_local, n_global, gid0, nu) = m
         st["step"] = step0 + n_steps
         self.history.mcmc_acceptance.append(float(np.mean(acc_rates)))
         self.history.mcmc_step_size.append(float(st["rho"]))
