@@ -553,8 +553,8 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
 #pragma unroll
                     for (int j = 0; j < D; j++) v[j] = (double)(T)(mup[j] + v[j]);
                     if (PROPOSE) {
-                        ll[i] = 2.0 * ref_corr_ct<TP>(q0, p.nu, dr);
-                        lp[i] = 2.0 * ref_corr_ct<TP>(q1, p.nu, dr);
+                        ll[i] = 2.0 * ref_corr_ct<TP>(q0, p.nu, PAD ? dr : dn);
+                        lp[i] = 2.0 * ref_corr_ct<TP>(q1, p.nu, PAD ? dr : dn);
                         if (PAD) {
 #pragma unroll
                             for (int j = 0; j < D; j++)
@@ -1649,6 +1649,61 @@ static int check_mixture(const asmc_mixture& m) {
     return ASMC_OK;
 }
 
+// ---- any d <= 128 on the fast kernels: zero-padding to the next supported width ------------------------------------------
+// The register-resident kernels exist for d in {4, 8, 16, 32}, the matrix-core kernels for d in {64, 128}; every other d used
+// to fall to the generic LDS kernel (6-9x slower).  A d-dimensional problem is the same as the D-dimensional one with
+// x = (x, 0), mu = (mu, 0), L = diag(L, I), zero precisions on the padded coordinates of every density component, and NO
+// noise on the padded coordinates (PcnDev.d_noise: y' = 0 there, |y|^2 and the Student-t dimension stay d's) - the real
+// coordinates see exactly the arithmetic of the unpadded specification (same noise words: they are keyed by coordinate).
+// Cost: two copy passes over the rows per call (pad, un-pad) and N x D x s bytes of scratch, grown on demand.
+static int pcn_pad_dim(int d) {
+    const int widths[] = {4, 8, 16, 32, 64, 128};
+    for (int D : widths)
+        if (d <= D) return D;
+    return 0;
+}
+template <typename T>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_pad_rows(int64_t n, int d, int D, const T* __restrict__ x, T* __restrict__ xp) {
+    const int64_t total = n * D, stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t e = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; e < total; e += stride) {
+        const int64_t i = e / D;
+        const int j = (int)(e - i * D);
+        xp[e] = j < d ? x[i * d + j] : (T)0;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(ASMC_BLOCK) void k_unpad_rows(int64_t n, int d, int D, const T* __restrict__ xp, T* __restrict__ x) {
+    const int64_t total = n * d, stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    for (int64_t e = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; e < total; e += stride) {
+        const int64_t i = e / d;
+        const int j = (int)(e - i * d);
+        x[e] = xp[i * D + j];
+    }
+}
+// padded tables: mu[D] | L[D, D] | Linv[D, D] | 3 x (mu[C_max, D] | prec[C_max, D]) for ll, lp, lq
+__global__ __launch_bounds__(256) void k_pad_tables(int d, int D, PcnDev p, double* __restrict__ out) {
+    double* mu = out;
+    double* L = mu + D;
+    double* Li = L + (size_t)D * D;
+    for (int e = threadIdx.x; e < D; e += 256) mu[e] = e < d ? p.mu[e] : 0.0;
+    for (int e = threadIdx.x; e < D * D; e += 256) {
+        const int i = e / D, j = e - i * D;
+        const bool in = i < d && j < d;
+        L[e] = in ? p.L[i * d + j] : (i == j ? 1.0 : 0.0);
+        Li[e] = in ? p.Linv[i * d + j] : (i == j ? 1.0 : 0.0);
+    }
+    const MixDev* mix[3] = {&p.ll, &p.lp, &p.lq};
+    for (int k = 0; k < 3; k++) {
+        double* m = Li + (size_t)D * D + (size_t)k * 2 * ASMC_MAX_COMPONENTS * D;
+        double* pr = m + (size_t)ASMC_MAX_COMPONENTS * D;
+        for (int e = threadIdx.x; e < mix[k]->C * D; e += 256) {
+            const int c = e / D, j = e - c * D;
+            m[e] = j < d ? mix[k]->mu[c * d + j] : 0.0;
+            pr[e] = j < d ? mix[k]->prec[c * d + j] : 0.0;
+        }
+    }
+}
+
 extern "C" {
 
 int asmc_gaussian_draw(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const double* mu, const double* sigma,
@@ -1868,6 +1923,41 @@ int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
         ASMC_HIP(hipStreamSynchronize(st));
         return ASMC_OK;
     }
+    {
+        // any other d <= 128: a zero-padded copy of the rows (centre padded with zeros) through the matrix-core kernel of the next
+        // width >= 32; the d x d corner of its result is the answer (k_gram_rb took 1 ms at d = 48 and 8.5 ms at d = 100 per call)
+        const int D = pcn_pad_dim(d) < 32 ? 32 : pcn_pad_dim(d);
+        if (D > 0 && D != d && D <= (ctx->d_max_pad < 32 ? 32 : ctx->d_max_pad) && !getenv("ASMC_GRAM_GENERIC") && !getenv("ASMC_PCN_NOPAD")) {
+            const size_t need = (size_t)n * D * elem;
+            if (need > ctx->xpad_bytes) {
+                ASMC_HIP(hipStreamSynchronize(st));
+                if (ctx->d_xpad) (void)hipFree(ctx->d_xpad);
+                ctx->d_xpad = nullptr;
+                ctx->xpad_bytes = 0;
+                if (hipMalloc(&ctx->d_xpad, need) != hipSuccess) {
+                    (void)hipGetLastError();
+                    asmc_set_error("centered_gram: no device memory for the zero-padded copy of the rows (%zu bytes)", need);
+                    return ASMC_ERR_NOMEM;
+                }
+                ctx->xpad_bytes = need;
+            }
+            for (int j = d; j < D; j++) ctx->h_pinned[2048 + j] = 0.0;
+            ASMC_HIP(hipMemcpyAsync(d_center, ctx->h_pinned + 2048, sizeof(double) * D, hipMemcpyHostToDevice, st));
+            const int pg = grid_for(n * D, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
+            if (elem == 8)
+                ASMC_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows<double>, dim3(pg), dim3(ASMC_BLOCK), 0, st, n, d, D, (const double*)x, (double*)ctx->d_xpad);
+            else
+                ASMC_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows<float>, dim3(pg), dim3(ASMC_BLOCK), 0, st, n, d, D, (const float*)x, (float*)ctx->d_xpad);
+            ASMC_LAUNCH_CHECK();
+            int grid = 0;
+            int rc = asmc_gram_mm_launch(ctx, n, D, x_dtype, ctx->d_xpad, d_center, &grid, st);
+            if (rc) return rc;
+            ASMC_HIP(hipMemcpy2DAsync(gram_host, sizeof(double) * d, d_out, sizeof(double) * D, sizeof(double) * d, d,
+                                      hipMemcpyDeviceToHost, st));
+            ASMC_HIP(hipStreamSynchronize(st));
+            return ASMC_OK;
+        }
+    }
     if (rowbytes % 16 == 0 && ((uintptr_t)x % 16) == 0 && d <= 128) {
         // register-blocked kernel: BLK = 4 (quadrant 32) for d <= 32, else BLK = 8 (quadrant 64)
         const int blk = d <= 32 ? 4 : 8;
@@ -2014,61 +2104,6 @@ int asmc_pcn_set_count_rccl(asmc_ctx* ctx, int64_t* cell_dev, int64_t n_global) 
 }
 
 }  // extern "C" (templates below)
-
-// ---- any d <= 128 on the fast kernels: zero-padding to the next supported width ------------------------------------------
-// The register-resident kernels exist for d in {4, 8, 16, 32}, the matrix-core kernels for d in {64, 128}; every other d used
-// to fall to the generic LDS kernel (6-9x slower).  A d-dimensional problem is the same as the D-dimensional one with
-// x = (x, 0), mu = (mu, 0), L = diag(L, I), zero precisions on the padded coordinates of every density component, and NO
-// noise on the padded coordinates (PcnDev.d_noise: y' = 0 there, |y|^2 and the Student-t dimension stay d's) - the real
-// coordinates see exactly the arithmetic of the unpadded specification (same noise words: they are keyed by coordinate).
-// Cost: two copy passes over the rows per call (pad, un-pad) and N x D x s bytes of scratch, grown on demand.
-static int pcn_pad_dim(int d) {
-    const int widths[] = {4, 8, 16, 32, 64, 128};
-    for (int D : widths)
-        if (d <= D) return D;
-    return 0;
-}
-template <typename T>
-__global__ __launch_bounds__(ASMC_BLOCK) void k_pad_rows(int64_t n, int d, int D, const T* __restrict__ x, T* __restrict__ xp) {
-    const int64_t total = n * D, stride = (int64_t)gridDim.x * ASMC_BLOCK;
-    for (int64_t e = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; e < total; e += stride) {
-        const int64_t i = e / D;
-        const int j = (int)(e - i * D);
-        xp[e] = j < d ? x[i * d + j] : (T)0;
-    }
-}
-template <typename T>
-__global__ __launch_bounds__(ASMC_BLOCK) void k_unpad_rows(int64_t n, int d, int D, const T* __restrict__ xp, T* __restrict__ x) {
-    const int64_t total = n * d, stride = (int64_t)gridDim.x * ASMC_BLOCK;
-    for (int64_t e = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; e < total; e += stride) {
-        const int64_t i = e / d;
-        const int j = (int)(e - i * d);
-        x[e] = xp[i * D + j];
-    }
-}
-// padded tables: mu[D] | L[D, D] | Linv[D, D] | 3 x (mu[C_max, D] | prec[C_max, D]) for ll, lp, lq
-__global__ __launch_bounds__(256) void k_pad_tables(int d, int D, PcnDev p, double* __restrict__ out) {
-    double* mu = out;
-    double* L = mu + D;
-    double* Li = L + (size_t)D * D;
-    for (int e = threadIdx.x; e < D; e += 256) mu[e] = e < d ? p.mu[e] : 0.0;
-    for (int e = threadIdx.x; e < D * D; e += 256) {
-        const int i = e / D, j = e - i * D;
-        const bool in = i < d && j < d;
-        L[e] = in ? p.L[i * d + j] : (i == j ? 1.0 : 0.0);
-        Li[e] = in ? p.Linv[i * d + j] : (i == j ? 1.0 : 0.0);
-    }
-    const MixDev* mix[3] = {&p.ll, &p.lp, &p.lq};
-    for (int k = 0; k < 3; k++) {
-        double* m = Li + (size_t)D * D + (size_t)k * 2 * ASMC_MAX_COMPONENTS * D;
-        double* pr = m + (size_t)ASMC_MAX_COMPONENTS * D;
-        for (int e = threadIdx.x; e < mix[k]->C * D; e += 256) {
-            const int c = e / D, j = e - c * D;
-            m[e] = j < d ? mix[k]->mu[c * d + j] : 0.0;
-            pr[e] = j < d ? mix[k]->prec[c * d + j] : 0.0;
-        }
-    }
-}
 
 static int pcn_mutate_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq, const asmc_pcn_params* prm,
                            int n_steps, uint32_t step0, double* rho_inout_host, int64_t* n_accept_host, double* rho_hist_host,
@@ -2317,6 +2352,64 @@ static int pcn_propose_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, cons
                                               step, nullptr, &grid, nullptr, nullptr, nullptr, st);
         return launch_pcn_step<float, 0>(ctx, n, (float*)const_cast<void*>(x), qf_old, qf_new, nullptr, pd, rho_ptr, step,
                                          nullptr, &grid, nullptr, nullptr, nullptr, st);
+    }
+    if (asmc_pcn_mm_supported(d, x) && ((uintptr_t)x_prop % 16) == 0 && ctx->d_mmtab && !getenv("ASMC_PCN_GENERIC")) {
+        // d = 64 / 128: both mat-vecs of the proposal on the fp64 matrix cores (the generic LDS kernel took 10 / 76 ms per
+        // step at 1M particles - the path every user with Python densities and d > 32 was on)
+        pd.noise = ASMC_NOISE_F64;
+        rc = asmc_pcn_mm_pack(ctx, pd, st);
+        if (rc) return rc;
+        return asmc_pcn_mm_launch(ctx, n, x_dtype, const_cast<void*>(x), qf_old, qf_new, reinterpret_cast<double*>(x_prop), pd,
+                                  pd.nu > 0.0 ? MM_XPROPOSE_T : MM_XPROPOSE, rho_ptr, step, nullptr, &grid, st);
+    }
+    const int D = pcn_pad_dim(d);
+    if (D != d && D > 0 && D <= ctx->d_max_pad && !(D == 32 && d > 16) && !getenv("ASMC_PCN_GENERIC") && !getenv("ASMC_PCN_NOPAD")) {
+        // any other d <= 128 (17 .. 31 have the in-kernel padding above): zero-padded copies of the rows and of the reference's
+        // tables, the D-dimensional proposal kernel with the noise masked beyond d, x' copied back without the padding
+        const size_t es = x_dtype == ASMC_F64 ? 8 : 4;
+        const size_t tab_doubles = (size_t)D + 2 * (size_t)D * D;
+        const size_t tab_bytes = ((tab_doubles * 8 + 255) / 256) * 256;
+        const size_t row_bytes = (((size_t)n * D * es + 255) / 256) * 256;
+        const size_t need = tab_bytes + 2 * row_bytes;
+        if (need > ctx->xpad_bytes) {
+            ASMC_HIP(hipStreamSynchronize(st));
+            if (ctx->d_xpad) (void)hipFree(ctx->d_xpad);
+            ctx->d_xpad = nullptr;
+            ctx->xpad_bytes = 0;
+            if (hipMalloc(&ctx->d_xpad, need) != hipSuccess) {
+                (void)hipGetLastError();
+                asmc_set_error("pcn: no device memory for the zero-padded copies of a proposal (%zu bytes)", need);
+                return ASMC_ERR_NOMEM;
+            }
+            ctx->xpad_bytes = need;
+        }
+        double* tab = reinterpret_cast<double*>(ctx->d_xpad);
+        void* xp = reinterpret_cast<char*>(ctx->d_xpad) + tab_bytes;
+        void* xq = reinterpret_cast<char*>(xp) + row_bytes;
+        PcnDev src = pd;
+        src.ll.C = src.lp.C = src.lq.C = 0;
+        ASMC_LAUNCH(ctx, st, "k_pad_tables", k_pad_tables, dim3(1), dim3(256), 0, st, d, D, src, tab);
+        ASMC_LAUNCH_CHECK();
+        const int pg = grid_for(n * D, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
+        if (es == 8)
+            ASMC_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows<double>, dim3(pg), dim3(ASMC_BLOCK), 0, st, n, d, D, (const double*)x, (double*)xp);
+        else
+            ASMC_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows<float>, dim3(pg), dim3(ASMC_BLOCK), 0, st, n, d, D, (const float*)x, (float*)xp);
+        ASMC_LAUNCH_CHECK();
+        PcnDev p2 = pd;
+        p2.d = D;
+        p2.d_noise = d;
+        p2.mu = tab;
+        p2.L = tab + D;
+        p2.Linv = p2.L + (size_t)D * D;
+        rc = pcn_propose_launch(ctx, n, D, x_dtype, xp, xq, qf_old, qf_new, p2, rho_ptr, step, st);
+        if (rc) return rc;
+        if (es == 8)
+            ASMC_LAUNCH(ctx, st, "k_unpad_rows", k_unpad_rows<double>, dim3(pg), dim3(ASMC_BLOCK), 0, st, n, d, D, (const double*)xq, (double*)x_prop);
+        else
+            ASMC_LAUNCH(ctx, st, "k_unpad_rows", k_unpad_rows<float>, dim3(pg), dim3(ASMC_BLOCK), 0, st, n, d, D, (const float*)xq, (float*)x_prop);
+        ASMC_LAUNCH_CHECK();
+        return ASMC_OK;
     }
     if (x_dtype == ASMC_F64)
         return launch_pcn_step<double, 1>(ctx, n, (double*)const_cast<void*>(x), nullptr, nullptr, nullptr, pd, rho_ptr,

@@ -445,6 +445,8 @@ int asmc_pcn_flow_fused_launch(asmc_ctx* ctx, int64_t n, int x_dtype, double* ll
 #define MM_STEP 1
 #define MM_UNWHITEN 2
 #define MM_STEP_T 3  // MM_STEP with the Student-t reference (tpCN)
+#define MM_XPROPOSE 4    // proposal half of the split path on the x-state: y = Linv (x - mu), y' = a y + rho xi, x' = mu + L y' -> x_prop, quadratic forms
+#define MM_XPROPOSE_T 5  // ... with the Student-t reference
 bool asmc_pcn_mm_supported(int d, const void* x);
 int asmc_pcn_mm_pack(asmc_ctx* ctx, const PcnDev& pd, hipStream_t st);
 int asmc_pcn_mm_launch(asmc_ctx* ctx, int64_t n, int x_dtype, void* x, double* ll, double* lp, double* lq, const PcnDev& pd,

@@ -129,28 +129,31 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
                                                       const double* __restrict__ rho_ptr, uint32_t step,
                                                       long long* __restrict__ block_counts) {
     extern __shared__ __align__(16) double smem[];
-    constexpr bool TP = MODE == MM_STEP_T;
-    constexpr int M = TP ? MM_STEP : MODE;
+    constexpr bool TP = MODE == MM_STEP_T || MODE == MM_XPROPOSE_T;
+    constexpr int M = MODE == MM_STEP_T ? MM_STEP : MODE == MM_XPROPOSE_T ? MM_XPROPOSE : MODE;
+    // MM_XPROPOSE (the split path's proposal half, arbitrary callables as densities): both operand images are resident -
+    // `pack` = L's image, followed by Linv's; ll / lp receive the two quadratic forms, lq is the x' buffer (rows of T)
     constexpr int KS = D / 4;
     constexpr int TOTAL = mm_ksum(D / 16) * 64;
     double* sA = smem;
-    double* s_mu = sA + TOTAL;                 // [D / 8][4 h][2]  reference mean in lane order
+    double* sB = sA + TOTAL;                   // MM_XPROPOSE: the image of Linv behind L's
+    double* s_mu = sA + (M == MM_XPROPOSE ? 2 : 1) * TOTAL;  // [D / 8][4 h][2]  reference mean in lane order
     double* t_ll = s_mu + D;                   // density tables (MM_WHITEN does not need them)
     double* t_lp = t_ll + (size_t)p.ll.C * D * 2;
     double* t_lq = t_lp + (size_t)p.lp.C * D * 2;
-    for (int e = threadIdx.x * 2; e < TOTAL; e += MM_THREADS * 2)
+    for (int e = threadIdx.x * 2; e < (M == MM_XPROPOSE ? 2 : 1) * TOTAL; e += MM_THREADS * 2)
         *reinterpret_cast<double2*>(sA + e) = *reinterpret_cast<const double2*>(pack + e);
     for (int e = threadIdx.x; e < D; e += MM_THREADS) {
         const int q = e & 1, hh = (e >> 1) & 3, sp = e >> 3;
         s_mu[e] = p.mu[mm_coord(2 * sp + q, hh)];
     }
-    if (M != MM_WHITEN) {
+    if (M != MM_WHITEN && M != MM_XPROPOSE) {
         mm_stage_tables<D>(t_ll, p.ll, threadIdx.x, MM_THREADS);
         mm_stage_tables<D>(t_lp, p.lp, threadIdx.x, MM_THREADS);
         mm_stage_tables<D>(t_lq, p.lq, threadIdx.x, MM_THREADS);
     }
     bm_d2* bmt = nullptr;  // Box-Muller tables of the default noise
-    if constexpr (M == MM_STEP && NOISE == ASMC_NOISE_F64) {
+    if constexpr ((M == MM_STEP || M == MM_XPROPOSE) && NOISE == ASMC_NOISE_F64) {
         bmt = bm_lds();
         bm_tab_stage<MM_THREADS>(bmt, p.bmtab);
     }
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pp = lane & 15, h = lane >> 4;
     const int dn = (p.d_noise > 0 && p.d_noise < D) ? p.d_noise : D;  // real dimension of a zero-padded problem
-    const double rho = (M == MM_STEP) ? *rho_ptr : 0.0;
+    const double rho = (M == MM_STEP || M == MM_XPROPOSE) ? *rho_ptr : 0.0;
     const double a = sqrt(1.0 - rho * rho);
     const int64_t n_groups = (n + 15) / 16;
     long long n_acc = 0;
@@ -212,6 +215,17 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
             }
         } else {
             const unsigned long long gid = p.gid0 + (unsigned long long)row;
+            if (M == MM_XPROPOSE) {  // x -> y = Linv (x - mu)
+#pragma unroll
+                for (int sp = 0; sp < KS / 2; sp++) {
+                    const double2 m2 = *reinterpret_cast<const double2*>(my_mu + sp * 8);
+                    v[2 * sp] -= m2.x;
+                    v[2 * sp + 1] -= m2.y;
+                }
+                mm_trimatvec<D>(sB, v, o, lane);
+#pragma unroll
+                for (int s = 0; s < KS; s++) v[s] = o[s];
+            }
             double q0 = 0.0, q1 = 0.0;
 #pragma unroll
             for (int s = 0; s < KS; s++) q0 = fma(v[s], v[s], q0);
@@ -282,6 +296,23 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
                 const double2 m2 = *reinterpret_cast<const double2*>(my_mu + sp * 8);
                 o[2 * sp] = (double)(T)(m2.x + o[2 * sp]);
                 o[2 * sp + 1] = (double)(T)(m2.y + o[2 * sp + 1]);
+            }
+            if (M == MM_XPROPOSE) {  // x' and the two forms the accept kernel adds half of (asmc_pcn_accept)
+                if (valid) {
+                    Pair* xo = reinterpret_cast<Pair*>(reinterpret_cast<T*>(lq) + row * D + 2 * h);
+#pragma unroll
+                    for (int sp = 0; sp < KS / 2; sp++) {
+                        Pair t;
+                        t.a = (T)o[2 * sp];
+                        t.b = (T)o[2 * sp + 1];
+                        xo[sp * 4] = t;
+                    }
+                    if (h == 0) {
+                        ll[row] = 2.0 * ref_corr_ct<TP>(q0, p.nu, dn);
+                        lp[row] = 2.0 * ref_corr_ct<TP>(q1, p.nu, dn);
+                    }
+                }
+                continue;
             }
             const double nll = mm_mixture<D>(p.ll, t_ll, o, h), nlp = mm_mixture<D>(p.lp, t_lp, o, h),
                          nlq = mm_mixture<D>(p.lq, t_lq, o, h);
@@ -452,7 +483,9 @@ int asmc_gram_mm_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void
 template <typename T, int D, int NOISE, int MODE>
 static int launch_mm(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const double* pack, const PcnDev& pd,
                      const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out, hipStream_t st) {
-    const size_t lds = ((size_t)mm_ksum(D / 16) * 64 + D + (size_t)(pd.ll.C + pd.lp.C + pd.lq.C) * D * 2) * sizeof(double);
+    constexpr bool XP = MODE == MM_XPROPOSE || MODE == MM_XPROPOSE_T;
+    const size_t lds = XP ? ((size_t)2 * mm_ksum(D / 16) * 64 + D) * sizeof(double)
+                          : ((size_t)mm_ksum(D / 16) * 64 + D + (size_t)(pd.ll.C + pd.lp.C + pd.lq.C) * D * 2) * sizeof(double);
     ASMC_REQUIRE(lds <= 160 * 1024 - 256 - BM_TAB_N * sizeof(bm_d2), "operand image and density tables exceed the LDS");
     auto kern = k_pcn_mm<T, D, NOISE, MODE>;
     static size_t attr_lds = 0;
@@ -466,7 +499,7 @@ static int launch_mm(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, dou
     int grid = (int)(want < (int64_t)ctx->num_cu * per_cu ? want : (int64_t)ctx->num_cu * per_cu);
     if (grid > ASMC_MAX_BLOCKS) grid = ASMC_MAX_BLOCKS;
     *grid_out = grid;
-    ASMC_LAUNCH(ctx, st, MODE == MM_STEP ? "k_pcn_mm_step" : MODE == MM_STEP_T ? "k_tpcn_mm_step" : MODE == MM_WHITEN ? "k_pcn_mm_whiten" : "k_pcn_mm_unwhiten", kern,
+    ASMC_LAUNCH(ctx, st, XP ? "k_pcn_mm_propose" : MODE == MM_STEP ? "k_pcn_mm_step" : MODE == MM_STEP_T ? "k_tpcn_mm_step" : MODE == MM_WHITEN ? "k_pcn_mm_whiten" : "k_pcn_mm_unwhiten", kern,
                 dim3(grid), dim3(MM_THREADS), lds, st, n, x, ll, lp, lq, pack, pd, rho_ptr, step, block_counts);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -494,6 +527,8 @@ int asmc_pcn_mm_launch(asmc_ctx* ctx, int64_t n, int x_dtype, void* x, double* l
     return launch_mm<TT, DD, NZ, MD>(ctx, n, (TT*)x, ll, lp, lq, pack, pd, rho_ptr, step, block_counts, grid_out, st);
 #define MM_MODES(TT, DD)                                                         \
     if (mode == MM_WHITEN) { MM_CASE(TT, DD, ASMC_NOISE_F64, MM_WHITEN) }        \
+    if (mode == MM_XPROPOSE) { MM_CASE(TT, DD, ASMC_NOISE_F64, MM_XPROPOSE) }    \
+    if (mode == MM_XPROPOSE_T) { MM_CASE(TT, DD, ASMC_NOISE_F64, MM_XPROPOSE_T) } \
     if (mode == MM_UNWHITEN) { MM_CASE(TT, DD, ASMC_NOISE_F64, MM_UNWHITEN) }    \
     if (mode == MM_STEP_T) {                                                     \
         if (pd.noise == ASMC_NOISE_F32) { MM_CASE(TT, DD, ASMC_NOISE_F32, MM_STEP_T) } \

@@ -385,7 +385,7 @@ def test_mixture_logpdf_vs_oracle(eng, oracle, d, C, dtype):
     np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("d", [2, 3, 4, 32, 64, 128])
+@pytest.mark.parametrize("d", [2, 3, 4, 12, 32, 48, 64, 100, 128])
 def test_moments_vs_oracle(eng, oracle, d):
     g = np.random.default_rng(10)
     n = 30011
@@ -1474,10 +1474,15 @@ def test_callable_density_sampler_run_gpu(eng, d, step_fn):
 
 
 @pytest.mark.parametrize("d,nu,dtype", [(20, 0.0, torch.float64), (31, 0.0, torch.float64), (17, 5.0, torch.float64),
-                                        (24, 0.0, torch.float32)])
+                                        (24, 0.0, torch.float32), (6, 0.0, torch.float64), (12, 5.0, torch.float64),
+                                        (48, 0.0, torch.float64), (64, 0.0, torch.float64), (64, 5.0, torch.float32),
+                                        (100, 5.0, torch.float64), (100, 0.0, torch.float32), (128, 0.0, torch.float64),
+                                        (128, 4.0, torch.float64)])
 def test_pcn_propose_padded_dims_vs_oracle_engine(eng, oracle, d, nu, dtype):
-    """16 < d < 32: asmc_pcn_propose runs the 32-dimensional register kernel on identity-padded tables; proposals and
-    correction terms agree with the test double's restatement (same noise, same scale variates)."""
+    """Every d <= 128 proposes on a fast kernel: 16 < d < 32 on the 32-dimensional register kernel with identity-padded tables
+    inside the kernel, d = 64 / 128 on the fp64 matrix cores (k_pcn_mm_propose), every other d on zero-padded copies of the
+    rows through the kernel of the next width; proposals and correction terms agree with the test double's restatement (same
+    noise, same scale variates) and the generic LDS kernel is never launched."""
     from oracle_engine import OracleEngine
 
     n = 3001
@@ -1487,7 +1492,8 @@ def test_pcn_propose_padded_dims_vs_oracle_engine(eng, oracle, d, nu, dtype):
     xp, q0, q1 = eng.pcn_propose(xd, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), 0.35, 99, 1000, 7, nu=nu)
     rep = eng.profile_report()
     eng.profile(False)
-    assert "k_pcn_propose_reg" in rep
+    assert ("k_pcn_mm_propose" if d > 32 else "k_pcn_propose_reg") in rep and "k_pcn_propose" not in rep
+    assert ("k_pad_rows" in rep) == (d not in (64, 128) and not 16 < d < 32)
     ref = OracleEngine()
     xr, r0, r1 = ref.pcn_propose(xd.double().cpu(), torch.as_tensor(mu), torch.as_tensor(L), torch.as_tensor(Linv), 0.35, 99,
                                  1000, 7, nu=nu)
