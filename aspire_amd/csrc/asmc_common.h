@@ -30,6 +30,7 @@ void asmc_prof_end(asmc_ctx* ctx, hipStream_t st);
 // the stream the kernel is launched on
 #define ASMC_LAUNCH(ctx, st, label, ...)   \
     do {                                   \
+        (ctx)->rec_n = 0; /* any launch may rewrite the arrays ctx->d_rec was packed from */ \
         asmc_prof_begin((ctx), (label), (st)); \
         hipLaunchKernelGGL(__VA_ARGS__);   \
         asmc_prof_end((ctx), (st));        \
@@ -79,6 +80,8 @@ struct asmc_ctx {
     unsigned char* d_flags;        // [n_max + 64] accept flags of the split-path pCN step
     double* d_gamma;               // [n_max] tpCN scale variates of the current step
     double* d_rec;                 // [4 * n_max] (ll, lp, lq, 0) records of asmc_gather's source population
+    const void* rec_src[3];        // the arrays asmc_importance_step packed into d_rec (k_is_weights writes the records on
+    int64_t rec_n;                 //   its way); rec_n != 0: still valid - the next asmc_gather of exactly these skips its packing pass
     void* d_ysoa;                  // coordinate-major whitened state of a mutation (grown on demand)
     void* d_xpad;                  // zero-padded tables + rows of a mutation whose d has no kernels of its own (grown on demand)
     size_t xpad_bytes;
@@ -130,7 +133,7 @@ struct asmc_ctx {
 
 // asmc_weights.hip: the persistent weight kernel of asmc_importance_step (results in ctx->d_small + 2560 .. + 48)
 int asmc_is_weights_launch(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double beta0,
-                           double target_eff, double tol, double* w, double* tiles, hipStream_t st);
+                           double target_eff, double tol, double* w, double* tiles, double* rec, hipStream_t st);
 
 static inline hipStream_t as_stream(asmc_stream s) { return reinterpret_cast<hipStream_t>(s); }
 

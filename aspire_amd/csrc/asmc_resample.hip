@@ -1831,7 +1831,9 @@ int asmc_importance_step(asmc_ctx* ctx, int64_t n, const double* ll, const doubl
     int rc = pcg_prepare(ctx, rng_state, st);
     if (rc) return rc;
     // 1: beta search, evidence moments, normalised weights, tile sums (one persistent launch)
-    rc = asmc_is_weights_launch(ctx, n, ll, lp, lq, beta0, target_eff, tol, w_scratch, ctx->d_tiles, st);
+    // (the kernel also leaves the (ll, lp, lq, 0) records of asmc_gather in ctx->d_rec: tagged at the end of this call)
+    static const bool no_rec = getenv("ASMC_IS_NO_RECORDS") != nullptr;
+    rc = asmc_is_weights_launch(ctx, n, ll, lp, lq, beta0, target_eff, tol, w_scratch, ctx->d_tiles, no_rec ? nullptr : ctx->d_rec, st);
     if (rc) return rc;
     // 2-4: numpy's sequential cumsum / cdf[-1] (passes C, D, E of asmc_cdf; the tile prefixes ride on pass C while
     // there are few tiles), pass E also filling the search's guide table
@@ -1872,6 +1874,7 @@ int asmc_importance_step(asmc_ctx* ctx, int64_t n, const double* ll, const doubl
                 (const unsigned long long*)ctx->d_pcgtab, s0, tlog2, n, (const double*)cdf_scratch, nb,
                 guided ? (const unsigned int*)ctx->d_guide : (const unsigned int*)nullptr, n_out, idx_out);
     ASMC_LAUNCH_CHECK();
+    if (!no_rec) ctx->rec_src[0] = ll, ctx->rec_src[1] = lp, ctx->rec_src[2] = lq, ctx->rec_n = n;  // (any later launch clears it)
     return ASMC_OK;
 }
 
@@ -1884,7 +1887,9 @@ int asmc_gather(asmc_ctx* ctx, int64_t n_in, int64_t n_out, const int64_t* idx, 
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
     hipStream_t st = as_stream(stream);
     const LogRec* rec = nullptr;
-    if (n_in <= ctx->n_max && n_out >= n_in / 4 && n_in >= (1 << 16)) {  // enough draws to pay for the packing pass
+    if (ctx->rec_n == n_in && ctx->rec_src[0] == ll_in && ctx->rec_src[1] == lp_in && ctx->rec_src[2] == lq_in) {
+        rec = reinterpret_cast<const LogRec*>(ctx->d_rec);  // packed by the importance step that selected these draws
+    } else if (n_in <= ctx->n_max && n_out >= n_in / 4 && n_in >= (1 << 16)) {  // enough draws to pay for the packing pass
         LogRec* r = reinterpret_cast<LogRec*>(ctx->d_rec);
         ASMC_LAUNCH(ctx, st, "k_pack_records", k_pack_records, dim3(grid_for(n_in, ASMC_BLOCK * 2, ASMC_MAX_BLOCKS * 2)), dim3(ASMC_BLOCK), 0, st,
                     n_in, ll_in, lp_in, lq_in, r);

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "asmc_common.h"
+#include "asmc_bisect.h"
 
 template <int KT>
 struct BetaPack {
@@ -325,7 +326,7 @@ static int check_common(asmc_ctx* ctx, int64_t n, const void* a, const void* b, 
 // Device-side k-ary bisection (smc/base.py:167-186): the whole adaptive-beta search runs as a chain of
 // launches without host round trips.  State (doubles) in ctx->d_small + 2048:
 //   [0] beta_min  [1] beta_max  [2] done  [3] target_eff  [4] tol  [5] log N  [6] n_pass  [7] beta0
-//   [8] N  [9] first_pass_done  [16..31] heap-ordered midpoints of the current round
+//   [8] N  [9] ESS(1)/N  [16..27] bracket and next grid as dyadic node indices (asmc_bisect.h)
 #define BIS_LEVELS 4
 #define BIS_NODES 15
 
@@ -340,11 +341,16 @@ __device__ __forceinline__ double ess_over_n(double m, double S1, double S2, dou
 
 struct BisInit {
     double beta0, target, tol, logN, N;
+    double plain;  // 1: no prediction windows (ASMC_SEARCH_PLAIN: the 16-ary search of rounds 1-2, for comparison)
 };
+static double bis_plain_mode() {
+    static const double v = getenv("ASMC_SEARCH_PLAIN") ? 1.0 : 0.0;
+    return v;
+}
 
-// Closes a bisection round: fixed-order reduction of the block partials, ESS of every candidate (one lane
-// each), the walk down the 4-level decision tree, and the candidates of the next round.  Runs in the LAST block of
-// the round's reduction kernel (k_bis_sums).
+// Closes a search round: fixed-order reduction of the block partials, ESS of every candidate (one lane each), the
+// decisions and the sixteen nodes of the next round (asmc_bisect.h: plain 16-ary step or a window around the predicted
+// root).  Runs in the LAST block of the round's reduction kernel (k_bis_sums).
 //   first round: the 15 heap-ordered midpoints of [beta0, 1] AND beta = 1 itself (16th column; smc/base.py:170-175:
 //   eff(1) >= target ends the search at beta* = 1); this round also creates the state record.
 //   Stabilising maxima are not searched for: at beta >= beta0 every log-weight is (beta - beta0) * Delta_i up to
@@ -352,7 +358,7 @@ struct BisInit {
 //   kernel), and a log-sum-exp only needs a shift near the maximum, not the maximum itself.
 // State st[]: [0] beta_min [1] beta_max [2] done [3] target_eff [4] tol [5] log N [6] rounds [7] beta0 [8] N
 //   [9] ESS(1)/N [10] m(1) [11..13] (m, S1, S2) at beta_min [14] 1 when [11..13] are valid [15] NaN log-weights
-//   (sharded search only) [16..30] midpoints
+//   (sharded search only) [16..27] the planner's bracket / grid in node indices (asmc_bisect.h)
 //   [32] S1(1) [33] S2(1)  [34..38] next round's grid: c1, c2, m of the LOWEST candidate, spacing h, Delta_max
 // Fixed-order reduction of the block partial records (32 columns) into s_S; valid after the next __syncthreads().
 __device__ __forceinline__ void bis_reduce_partials(const double* __restrict__ partials, int nblocks,
@@ -378,6 +384,63 @@ __device__ __forceinline__ void bis_reduce_partials(const double* __restrict__ p
     }
 }
 
+// The same reduction for records whose sums were shifted by each block's OWN maximum (first round of k_is_weights: no
+// grid-wide maximum pass in front of it).  The first round's candidates are beta0 + ks (1 - beta0) / 16, ks = 1 .. 16, so
+// record b, candidate ks, power pw in {1, 2} is rescaled to the merged maximum M by
+//     exp(lw - m_b t) = exp(lw - M t) exp((m_b - M) / 16)^(pw ks),   t = ks / 16
+// (what k_bis_decide does with the ranks' records of a sharded search): ONE exponential per record and an integer power.
+// `mrec`: (m_b, NaN count) per block; a block without a finite log-weight (its sums are zero) counts as m_b = M.
+// Also returns the merged maximum and the NaN census in s_mn[0], s_mn[1].  nblocks <= 512.
+__device__ __forceinline__ void bis_reduce_partials_scaled(const double* __restrict__ partials, const double* __restrict__ mrec,
+                                                           int nblocks, double (*s_red)[33], double* s_S, double* s_base,
+                                                           double* s_mn) {
+    const int col = threadIdx.x & 31, part = threadIdx.x >> 5, nparts = blockDim.x >> 5;
+    // sorted position (1 .. 16) of heap column k: the inverse of bis_col_of_sorted
+    const int k = col >> 1;
+    int ks = 16;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (bis_col_of_sorted(j) == k) ks = j + 1;
+    double t16[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int b = part + q * nparts;
+        t16[q] = b < nblocks ? partials[(size_t)b * 32 + col] : 0.0;
+    }
+    const int b_own = threadIdx.x;  // blockDim.x = 512 >= nblocks
+    const double m_own = b_own < nblocks ? mrec[2 * b_own] : -INFINITY, n_own = b_own < nblocks ? mrec[2 * b_own + 1] : 0.0;
+    {
+        double v = wave_max(m_own == m_own ? m_own : -INFINITY), c = wave_sum(n_own);  // (integer-valued counts: any order)
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][0] = v, s_red[threadIdx.x >> 6][1] = c;
+    }
+    __syncthreads();
+    double m_all = -INFINITY, nan_total = 0.0;
+    for (int x = 0; x < (int)(blockDim.x >> 6); x++) m_all = fmax(m_all, s_red[x][0]), nan_total += s_red[x][1];
+    if (threadIdx.x == 0) s_mn[0] = m_all, s_mn[1] = nan_total;
+    s_base[b_own] = (m_own > -INFINITY && m_all > -INFINITY) ? exp((m_own - m_all) * (1.0 / 16.0)) : 1.0;
+    __syncthreads();
+    const int e0 = ((col & 1) ? 2 : 1) * ks;  // 1 .. 32
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int b = part + q * nparts;
+        double f = 1.0, pw = b < nblocks ? s_base[b] : 1.0;
+#pragma unroll
+        for (int bit = 0; bit < 6; bit++) {
+            if ((e0 >> bit) & 1) f *= pw;
+            pw *= pw;
+        }
+        v += t16[q] * f;
+    }
+    s_red[part][col] = v;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double tt = 0.0;
+        for (int q = 0; q < nparts; q++) tt += s_red[q][threadIdx.x];
+        s_S[threadIdx.x] = tt;
+    }
+}
+
 // Block-local copy of the search state: the record st[0..39] (layout above) and the candidates' c1, c2, m, shift
 // (in: m of this round's candidates; out: those of the next round)
 struct BisLds {
@@ -389,119 +452,57 @@ __device__ __forceinline__ void bis_lds_init(BisLds& L, const BisInit& init, dou
     if (threadIdx.x < 40) {
         const int i = threadIdx.x;
         L.st[i] = i == 0 ? init.beta0 : i == 1 ? 1.0 : i == 3 ? init.target : i == 4 ? init.tol : i == 5 ? init.logN
-                  : i == 7 ? init.beta0 : i == 8 ? init.N : i == 10 ? m_one : i == 15 ? nan_total : 0.0;
+                  : i == 7 ? init.beta0 : i == 8 ? init.N : i == 10 ? m_one : i == 15 ? nan_total : i == BIS_MODE ? init.plain : 0.0;
     }
 }
 
 // Closes a round on the block-local state.  Precondition: L and s_S are filled and a __syncthreads() lies behind
-// that; returns behind a __syncthreads() with L.st[2] (done), L.st[39] (a new candidate pack was built) up to date.
+// that; returns behind a __syncthreads() with L.st[2] (done), L.st[39] (a new candidate grid was chosen) up to date.
+// Lanes 0-15: the floats of this round's sixteen nodes (asmc_bisect.h: bis_node_beta - exactly the values the sequential
+// loop would hold), their shifts and ESS/N; lane 0: the decisions and the next grid (bis_plan).
 __device__ __forceinline__ void bis_tail_core(BisLds& L, bool first, const double* s_S, double* s_eff) {
     double(&s_st)[40] = L.st;
-    double(&s_bp)[4][16] = L.bp;
-    const double logN = s_st[5], N = s_st[8], target = s_st[3], tol = s_st[4], beta0 = s_st[7], m_one = s_st[10];
-    const double inv = 1.0 / (1.0 - beta0);
-    // heap-ordered midpoints of the next four levels from (lo, hi), exactly the values the sequential loop visits
-    auto build = [&](double lo0, double hi0) {
-        double los[BIS_NODES], his[BIS_NODES];
-        los[0] = lo0;
-        his[0] = hi0;
-        for (int i = 0; i < BIS_NODES; i++) {
-            const double mid = 0.5 * (his[i] + los[i]);  // the reference's expression (smc/base.py:178)
-            s_st[16 + i] = mid;
-            const int l = 2 * i + 1, r = 2 * i + 2;
-            if (r < BIS_NODES) {
-                los[l] = los[i];
-                his[l] = mid;
-                los[r] = mid;
-                his[r] = his[i];
-            }
-            s_bp[0][i] = beta0 - mid;
-            s_bp[1][i] = mid - beta0;
-            s_bp[2][i] = m_one * ((mid - beta0) * inv);
-            s_bp[3][i] = 0.0;
-        }
-        s_bp[0][15] = beta0 - hi0;  // 16th column: the upper end of the bracket (beta = 1 in the first round)
-        s_bp[1][15] = hi0 - beta0;
-        s_bp[2][15] = m_one * ((hi0 - beta0) * inv);
-        s_bp[3][15] = 0.0;
-        s_st[34] = s_bp[0][7];  // heap node 7 = leftmost leaf = lowest candidate
-        s_st[35] = s_bp[1][7];
-        s_st[36] = s_bp[2][7];
-        s_st[37] = (hi0 - lo0) / 16.0;
-        s_st[38] = m_one * inv;
-    };
-    if (first && threadIdx.x == 0) build(beta0, 1.0);  // what this round's reduction kernel evaluated
-    __syncthreads();
     if (threadIdx.x < 16) {
-        const int k = threadIdx.x;
-        s_eff[k] = ess_over_n(s_bp[2][k], s_S[2 * k], s_S[2 * k + 1], logN, N);
+        const int j = threadIdx.x;
+        const double beta0 = s_st[BIS_BETA0], m_one = s_st[BIS_M_ONE];
+        const int LU = first ? 4 : (int)s_st[BIS_LU];
+        const long long K = first ? (long long)(j + 1) : (long long)s_st[BIS_KFIRST] + j * (long long)s_st[BIS_STRIDE];
+        const double b = bis_node_beta(K, LU, beta0);
+        const double mj = m_one * ((b - beta0) * (1.0 / (1.0 - beta0)));
+        const int c = bis_col_of_sorted(j);
+        const double e = ess_over_n(mj, s_S[2 * c], s_S[2 * c + 1], s_st[BIS_LOGN], s_st[BIS_N]);
+        L.bp[0][j] = b;
+        L.bp[1][j] = log(e) - log(s_st[BIS_TARGET]);
+        L.bp[2][j] = mj;
+        s_eff[j] = e;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        s_st[6] += 1.0;
-        s_st[39] = 0.0;
-        double bmin = s_st[0], bmax = s_st[1];
-        bool at_one = false;
-        if (first) {
-            s_st[9] = s_eff[15];
-            s_st[32] = s_S[30], s_st[33] = s_S[31];
-            if (s_eff[15] >= target) {  // smc/base.py:174-175
-                bmin = 1.0;
-                at_one = true;
-                s_st[11] = m_one, s_st[12] = s_S[30], s_st[13] = s_S[31], s_st[14] = 1.0;
-            }
-        }
-        if (!at_one) {
-            int i = 0;
-            for (int lev = 0; lev < BIS_LEVELS; lev++) {
-                if (!(bmax - bmin > tol)) break;
-                const double mid = s_st[16 + i];
-                if (s_eff[i] >= target) {
-                    bmin = mid;
-                    s_st[11] = s_bp[2][i], s_st[12] = s_S[2 * i], s_st[13] = s_S[2 * i + 1], s_st[14] = 1.0;
-                    i = 2 * i + 2;
-                } else {
-                    bmax = mid;
-                    i = 2 * i + 1;
-                }
-            }
-        }
-        s_st[0] = bmin;
-        s_st[1] = bmax;
-        if (!(bmax - bmin > tol)) {  // converged (or eff(1.0) >= target made beta_min = 1)
-            s_st[2] = 1.0;
-        } else {
-            build(bmin, bmax);
-            s_st[39] = 1.0;  // marks that the candidate pack is new
-        }
+        double r[40];  // the record in registers: the decision chain pays no LDS round trip per access
+#pragma unroll
+        for (int i = 0; i < 40; i++) r[i] = s_st[i];
+        bis_plan(r, first, L.bp[0], L.bp[2], s_eff, L.bp[1], s_S);
+#pragma unroll
+        for (int i = 0; i < 40; i++) s_st[i] = r[i];
     }
     __syncthreads();
 }
 
 // Round tail on the state record in global memory (one launch per round: k_bis_sums' last block, k_bis_decide).
 // `partials` == nullptr: s_S already holds the column sums (sharded search: the rank records merged by k_bis_decide).
-__device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<16>* __restrict__ bp,
-                                              const double* __restrict__ partials, int nblocks, bool first,
-                                              double m_one_in, const BisInit& init, double (*s_red)[33],
+__device__ __forceinline__ void bis_tail_body(double* __restrict__ st, const double* __restrict__ partials, int nblocks,
+                                              bool first, double m_one_in, const BisInit& init, double (*s_red)[33],
                                               double* s_S, double* s_eff, double nan_total = 0.0) {
-    // the state record and the candidates' shifts are staged in LDS: thread 0's decision chain must not pay a
-    // global-memory latency per dependent access
+    // the state record is staged in LDS: lane 0's decision chain must not pay a global-memory latency per dependent access
     __shared__ BisLds L;
     if (first)
         bis_lds_init(L, init, m_one_in, nan_total);
     else if (threadIdx.x < 40)
         L.st[threadIdx.x] = st[threadIdx.x];
-    if (!first && threadIdx.x >= 64 && threadIdx.x < 80) L.bp[2][threadIdx.x - 64] = bp->m[threadIdx.x - 64];
     if (partials) bis_reduce_partials(partials, nblocks, s_red, s_S);
     __syncthreads();
     bis_tail_core(L, first, s_S, s_eff);
-    const bool write_bp = L.st[39] != 0.0;
-    if (threadIdx.x < 39) st[threadIdx.x] = L.st[threadIdx.x];
-    if (write_bp && threadIdx.x >= 64 && threadIdx.x < 128) {
-        const int f = (threadIdx.x - 64) >> 4, k = (threadIdx.x - 64) & 15;
-        double* dst = f == 0 ? bp->c1 : f == 1 ? bp->c2 : f == 2 ? bp->m : bp->shift;
-        dst[k] = L.bp[f][k];
-    }
+    if (threadIdx.x < 40) st[threadIdx.x] = L.st[threadIdx.x];
 }
 
 // One bisection round in ONE launch.  The 15 candidates and the bracket's upper end are equally spaced,
@@ -518,7 +519,7 @@ __device__ __forceinline__ void bis_tail_body(double* __restrict__ st, BetaPack<
 
 __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const double* __restrict__ ll,
                                                         const double* __restrict__ lp, const double* __restrict__ lq,
-                                                        double* __restrict__ st, BetaPack<16>* __restrict__ bp,
+                                                        double* __restrict__ st,
                                                         double* partials, unsigned int* ticket, int round, BisInit init,
                                                         const unsigned long long* __restrict__ keys,
                                                         double* __restrict__ rec_out) {
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const doubl
         if (threadIdx.x == 33) rec_out[33] = round == 0 ? (double)keys[ASMC_MAX_BETAS] : 0.0;
         return;
     }
-    bis_tail_body(st, bp, partials, (int)gridDim.x, round == 0, m_one, init, s_red, s_S, s_eff);
+    bis_tail_body(st, partials, (int)gridDim.x, round == 0, m_one, init, s_red, s_S, s_eff);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -661,7 +662,9 @@ struct IswBases {
 #define ISW_SPIN_LIMIT (1 << 18)
 __device__ __forceinline__ bool isw_barrier(unsigned int* bar, const IswBases& bases, unsigned int k, int G) {
     __shared__ int s_ok;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // only wave 0 writes what the other blocks read behind the barrier (partial records, block maxima): the other waves'
+    // stores (the gather's records, the weights) need not have landed
+    if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const int g = blockIdx.x % ISW_GROUPS;
@@ -691,13 +694,14 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
                                                            double* __restrict__ st_out, double* partials,
                                                            unsigned int* bar, IswBases bar_bases, BisInit init,
                                                            int64_t chunk, double* __restrict__ w,
-                                                           double* __restrict__ tiles) {
+                                                           double* __restrict__ tiles, double* __restrict__ rec) {
     __shared__ BisLds L;
     __shared__ double s_red[ISW_THREADS / 32][33];
     __shared__ double s_S[32];
     __shared__ double s_eff[16];
     __shared__ double s_p[ISW_THREADS / 64][32];
     __shared__ double s_sc[8];
+    __shared__ double s_base[ISW_THREADS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = (int)gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
     const int nsub = (int)(chunk / ISW_CHUNK);
@@ -722,6 +726,7 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
         poisoned = !isw_barrier(bar, bar_bases, nbar, G);
     };
     auto pbuf = [&](unsigned int k) { return partials + (size_t)(k & 1u) * (size_t)G * 32; };
+    double* mrec = partials + (size_t)2 * G * 32;  // (maximum, NaN count) of every block
 
     // REG: the block's particles as (ll + lp, lq) in LDS, staged once (64 KB of dynamic LDS)
     extern __shared__ double s_part[];
@@ -732,9 +737,11 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
         for (int k = 0; k < ISW_PER; k++) {
             const int64_t i = lo + k * ISW_THREADS + tid;
             const bool ok = i < hi;
-            const double a = ok ? ll[i] : 0.0, b = ok ? lp[i] : 0.0;
+            const double a = ok ? ll[i] : 0.0, b = ok ? lp[i] : 0.0, q = ok ? lq[i] : 0.0;
             s_ab[k * ISW_THREADS + tid] = a + b;
-            s_q[k * ISW_THREADS + tid] = ok ? lq[i] : 0.0;
+            s_q[k * ISW_THREADS + tid] = q;
+            // the (ll, lp, lq, 0) record asmc_gather reads per draw (k_pack_records' job, done on the way)
+            if (rec && ok) *reinterpret_cast<double4*>(rec + 4 * i) = make_double4(a, b, q, 0.0);
         }
         // every thread only ever reads back its own entries: no barrier needed
     }
@@ -759,7 +766,8 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
         return t1 + t2;
     };
 
-    // ---- phase 0: exact maximum of the log-weights at beta = 1 and the NaN census ---------------------------------
+    // ---- phase 0: THIS BLOCK's maximum of the log-weights at beta = 1 and its NaN census (no grid barrier: the first
+    // search round shifts by the block's own maximum and the round's reduction rescales to the merged one) -------------
     {
         const double c1 = init.beta0 - 1.0, c2 = 1.0 - init.beta0;
         double mx = -INFINITY;
@@ -768,7 +776,17 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
 #pragma unroll 4
             for (int k = 0; k < ISW_PER; k++) {
                 double abv, qv;
-                if (get(sub, k, abv, qv)) {
+                bool ok;
+                if (REG) {
+                    ok = get(sub, k, abv, qv);
+                } else {  // streaming: the records are packed from this first read
+                    const int64_t i = lo + (int64_t)sub * ISW_CHUNK + k * ISW_THREADS + tid;
+                    ok = i < hi;
+                    const double a = ok ? ll[i] : 0.0, b = ok ? lp[i] : 0.0;
+                    abv = a + b, qv = ok ? lq[i] : 0.0;
+                    if (rec && ok) *reinterpret_cast<double4*>(rec + 4 * i) = make_double4(a, b, qv, 0.0);
+                }
+                if (ok) {
                     const double lw = lw_at(abv, qv, c1, c2);
                     if (lw != lw)
                         nn++;
@@ -784,29 +802,15 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
         if (tid == 0) {
             double v = s_p[0][0], c = s_p[0][1];
             for (int x = 1; x < ISW_THREADS / 64; x++) v = fmax(v, s_p[x][0]), c += s_p[x][1];
-            double* rec = pbuf(1) + (size_t)blockIdx.x * 32;
-            rec[0] = v;
-            rec[1] = c;
-        }
-        ISW_MARK();
-        barrier();
-        ISW_MARK();
-        if (tid < 64) {
-            double v = -INFINITY, c = 0.0;
-            for (int b = tid; b < G; b += 64) {
-                const double* rec = pbuf(1) + (size_t)b * 32;
-                v = fmax(v, rec[0]);
-                c += rec[1];
-            }
-            v = wave_max(v);
-            c = wave_sum(c);  // integer-valued: any order gives the same sum
-            if (tid == 0) s_sc[0] = v, s_sc[1] = c;
+            s_sc[0] = v, s_sc[1] = c;
+            mrec[2 * blockIdx.x] = v, mrec[2 * blockIdx.x + 1] = c;
         }
         __syncthreads();
+        ISW_MARK();
     }
-    const double m_one = s_sc[0], nan_total = s_sc[1];
-    bis_lds_init(L, init, m_one, nan_total);
-    __syncthreads();
+    const double m_block = s_sc[0] > -INFINITY ? s_sc[0] : 0.0;  // (no finite log-weight in the block: its sums are zero)
+    double m_one = 0.0, nan_total = 0.0;
+    bis_lds_init(L, init, 0.0, 0.0);  // (a poisoned first barrier leaves the loop before the record is created)
 
     // ---- phase 1: the search rounds (k_bis_sums on the resident particles) ------------------------------------------
     for (int round = 0; round < ISW_MAX_ROUNDS; round++) {
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
             double b1 = 1.0;
             for (int lev = 0; lev < BIS_LEVELS; lev++) b1 = 0.5 * (b1 + lo0);  // leftmost leaf of the first tree
             const double inv = 1.0 / (1.0 - lo0);
-            c1 = lo0 - b1, c2 = b1 - lo0, m1 = m_one * ((b1 - lo0) * inv), h = (1.0 - lo0) / 16.0, dmax = m_one * inv;
+            c1 = lo0 - b1, c2 = b1 - lo0, m1 = m_block * ((b1 - lo0) * inv), h = (1.0 - lo0) / 16.0, dmax = m_block * inv;
         } else {
             c1 = L.st[34], c2 = L.st[35], m1 = L.st[36], h = L.st[37], dmax = L.st[38];
         }
@@ -874,7 +878,15 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
         barrier();
         if (poisoned) break;
         ISW_MARK();
-        bis_reduce_partials(buf, G, s_red, s_S);
+        if (round == 0) {
+            // merged maximum and NaN census of the blocks and the records rescaled to it; this creates the state record
+            bis_reduce_partials_scaled(buf, mrec, G, s_red, s_S, s_base, s_sc);
+            __syncthreads();
+            m_one = s_sc[0], nan_total = s_sc[1];
+            bis_lds_init(L, init, m_one, nan_total);
+        } else {
+            bis_reduce_partials(buf, G, s_red, s_S);
+        }
         __syncthreads();
         bis_tail_core(L, round == 0, s_S, s_eff);
         ISW_MARK();
@@ -1004,8 +1016,7 @@ __device__ __forceinline__ double bis_heap_mid(int k, double lo, double hi) {
 // round: the ranks reduced against their LOCAL m(1); the sums are rescaled to the merged maximum M = max_r m_r(1),
 // exp(lw - m_r t) = exp(lw - M t) exp((M - m_r) t) with t = (beta - beta0)/(1 - beta0).  Later rounds use M on every rank.
 __global__ __launch_bounds__(BIS_THREADS) void k_bis_decide(const double* __restrict__ recs, int world,
-                                                          double* __restrict__ st, BetaPack<16>* __restrict__ bp,
-                                                          int round, BisInit init) {
+                                                          double* __restrict__ st, int round, BisInit init) {
     __shared__ double s_red[BIS_THREADS / 32][33];
     __shared__ double s_S[32];
     __shared__ double s_eff[16];
@@ -1031,7 +1042,7 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_decide(const double* __rest
         s_S[c] = acc;
     }
     __syncthreads();
-    bis_tail_body(st, bp, nullptr, 0, round == 0, m_all, init, s_red, s_S, s_eff, nan_total);
+    bis_tail_body(st, nullptr, 0, round == 0, m_all, init, s_red, s_S, s_eff, nan_total);
 }
 
 extern "C" {
@@ -1106,9 +1117,8 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
     ASMC_REQUIRE(tol > 0.0 && beta0 >= 0.0 && beta0 < 1.0, "bad beta0 / tolerance");
     hipStream_t st = as_stream(stream);
     double* d_st = ctx->d_small + 2560;
-    BetaPack<16>* d_bp = reinterpret_cast<BetaPack<16>*>(ctx->d_small + 2560 + 64);
     double* h = ctx->h_pinned + 4096 + 512;
-    const BisInit init = {beta0, target_eff, tol, log((double)n), (double)n};
+    const BisInit init = {beta0, target_eff, tol, log((double)n), (double)n, bis_plain_mode()};
     // exact maximum at beta = 1 (also the NaN census: for beta > beta0 the NaN pattern of the log-weights does not
     // depend on beta); every round, the first one included (it evaluates beta = 1 as its 16th candidate), is then ONE launch
     const double one = 1.0;
@@ -1116,15 +1126,17 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
     if (rc) return rc;
     const int grid = grid_for(n, BIS_THREADS, ctx->num_cu);
     unsigned int* d_ticket = reinterpret_cast<unsigned int*>(ctx->d_keys + ASMC_MAX_BETAS + 4);  // zeroed by launch_max
-    // every round narrows the bracket 16x: ceil(log16((1 - beta0) / tol)) rounds reach the tolerance.  Should
-    // rounding in that estimate leave the bracket a hair too wide, further rounds are launched one at a time.
+    // a plain round narrows the bracket 16x, a prediction window that holds the root by much more (asmc_bisect.h): smooth
+    // populations need 3 rounds whatever the tolerance.  Three are enqueued (fewer when plain rounds reach the tolerance
+    // sooner); a search that is not done after them gets further rounds one at a time.
     int rounds = (int)ceil(log2((1.0 - beta0) / tol) / BIS_LEVELS - 1e-9);
     if (rounds < 1) rounds = 1;
+    if (rounds > 3) rounds = 3;
     unsigned long long* hk = reinterpret_cast<unsigned long long*>(h + 40);
     int launched = 0;
-    for (int attempt = 0; attempt < 4; attempt++) {
+    for (int attempt = 0; attempt < 32; attempt++) {
         for (; launched < rounds; launched++) {
-            ASMC_LAUNCH(ctx, st, "k_bis_sums", k_bis_sums, dim3(grid), dim3(BIS_THREADS), 0, st, n, ll, lp, lq, d_st, d_bp, ctx->d_partials,
+            ASMC_LAUNCH(ctx, st, "k_bis_sums", k_bis_sums, dim3(grid), dim3(BIS_THREADS), 0, st, n, ll, lp, lq, d_st, ctx->d_partials,
                         d_ticket, launched, init, (const unsigned long long*)ctx->d_keys, (double*)nullptr);
             ASMC_LAUNCH_CHECK();
         }
@@ -1153,14 +1165,15 @@ int asmc_find_beta(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp,
 }  // extern "C"
 
 int asmc_is_weights_launch(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double beta0,
-                           double target_eff, double tol, double* w, double* tiles, hipStream_t st) {
+                           double target_eff, double tol, double* w, double* tiles, double* rec, hipStream_t st) {
     if (ctx->isw_disabled) {
         asmc_set_error("asmc_importance_step: disabled on this context (an earlier launch was not fully resident)");
         return ASMC_ERR_UNSUPPORTED;
     }
-    const BisInit init = {beta0, target_eff, tol, log((double)n), (double)n};
+    const BisInit init = {beta0, target_eff, tol, log((double)n), (double)n, bis_plain_mode()};
     int64_t chunk = ISW_CHUNK;
     int64_t grid = (n + chunk - 1) / chunk;
+    ASMC_REQUIRE(ctx->num_cu <= ISW_THREADS, "more compute units than the first round's reduction has threads");
     const bool reg = grid <= ctx->num_cu;
     if (!reg) {
         chunk = (n + ctx->num_cu - 1) / ctx->num_cu;
@@ -1185,10 +1198,10 @@ int asmc_is_weights_launch(asmc_ctx* ctx, int64_t n, const double* ll, const dou
         }
         ASMC_LAUNCH(ctx, st, "k_is_weights", k_is_weights<true>, dim3((unsigned)grid), dim3(ISW_THREADS),
                     2 * ISW_CHUNK * sizeof(double), st, n, ll, lp, lq, d_st,
-                    ctx->d_partials, ctx->d_bar, bases, init, chunk, w, tiles);
+                    ctx->d_partials, ctx->d_bar, bases, init, chunk, w, tiles, rec);
     } else
         ASMC_LAUNCH(ctx, st, "k_is_weights", k_is_weights<false>, dim3((unsigned)grid), dim3(ISW_THREADS), 0, st, n, ll, lp, lq, d_st,
-                    ctx->d_partials, ctx->d_bar, bases, init, chunk, w, tiles);
+                    ctx->d_partials, ctx->d_bar, bases, init, chunk, w, tiles, rec);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
@@ -1247,9 +1260,8 @@ int asmc_importance_result(asmc_ctx* ctx, double* out_host, asmc_stream stream) 
 
 int asmc_importance_available(asmc_ctx* ctx) { return ctx && !ctx->isw_disabled ? 1 : 0; }
 
-static inline void bis_state(asmc_ctx* ctx, double** d_st, BetaPack<16>** d_bp, unsigned int** d_ticket) {
+static inline void bis_state(asmc_ctx* ctx, double** d_st, unsigned int** d_ticket) {
     *d_st = ctx->d_small + 2560;
-    *d_bp = reinterpret_cast<BetaPack<16>*>(ctx->d_small + 2560 + 64);
     *d_ticket = reinterpret_cast<unsigned int*>(ctx->d_keys + ASMC_MAX_BETAS + 4);  // zeroed by launch_max
 }
 
@@ -1261,17 +1273,16 @@ int asmc_find_beta_shard_reduce(asmc_ctx* ctx, int64_t n, const double* ll, cons
     ASMC_REQUIRE(beta0 >= 0.0 && beta0 < 1.0, "bad beta0");
     hipStream_t st = as_stream(stream);
     double* d_st;
-    BetaPack<16>* d_bp;
     unsigned int* d_ticket;
-    bis_state(ctx, &d_st, &d_bp, &d_ticket);
+    bis_state(ctx, &d_st, &d_ticket);
     if (round == 0) {
         const double one = 1.0;
         rc = launch_max(ctx, n, ll, lp, lq, beta0, &one, 1, st);  // local m(1), local NaN census, ticket := 0
         if (rc) return rc;
     }
-    const BisInit init = {beta0, 0.0, 0.0, 0.0, 0.0};  // the reduction half only needs beta0
+    const BisInit init = {beta0, 0.0, 0.0, 0.0, 0.0, 0.0};  // the reduction half only needs beta0
     const int grid = grid_for(n, BIS_THREADS, ctx->num_cu);
-    ASMC_LAUNCH(ctx, st, "k_bis_sums", k_bis_sums, dim3(grid), dim3(BIS_THREADS), 0, st, n, ll, lp, lq, d_st, d_bp, ctx->d_partials,
+    ASMC_LAUNCH(ctx, st, "k_bis_sums", k_bis_sums, dim3(grid), dim3(BIS_THREADS), 0, st, n, ll, lp, lq, d_st, ctx->d_partials,
                 d_ticket, round, init, (const unsigned long long*)ctx->d_keys, rec_dev);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -1284,11 +1295,10 @@ int asmc_find_beta_shard_decide(asmc_ctx* ctx, const double* recs_dev, int world
     ASMC_REQUIRE(tol > 0.0 && beta0 >= 0.0 && beta0 < 1.0, "bad beta0 / tolerance");
     hipStream_t st = as_stream(stream);
     double* d_st;
-    BetaPack<16>* d_bp;
     unsigned int* d_ticket;
-    bis_state(ctx, &d_st, &d_bp, &d_ticket);
-    const BisInit init = {beta0, target_eff, tol, log((double)n_global), (double)n_global};
-    ASMC_LAUNCH(ctx, st, "k_bis_decide", k_bis_decide, dim3(1), dim3(BIS_THREADS), 0, st, recs_dev, world, d_st, d_bp, round, init);
+    bis_state(ctx, &d_st, &d_ticket);
+    const BisInit init = {beta0, target_eff, tol, log((double)n_global), (double)n_global, bis_plain_mode()};
+    ASMC_LAUNCH(ctx, st, "k_bis_decide", k_bis_decide, dim3(1), dim3(BIS_THREADS), 0, st, recs_dev, world, d_st, round, init);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }

@@ -353,7 +353,9 @@ def find_beta_sharded(engine, comm, ll, lp, lq, beta0: float, target_eff: float,
     result after the estimated number of rounds (include/asmc.h asmc_find_beta_shard_*).  Same return tuple."""
     import torch
 
-    rounds = max(1, int(math.ceil(math.log2((1.0 - beta0) / tol) / BISECT_LEVELS - 1e-9)))
+    # plain rounds narrow the bracket 16x, a prediction window that holds the root by much more (csrc/asmc_bisect.h): three
+    # rounds are enqueued (fewer when plain rounds reach the tolerance sooner), further ones one at a time
+    rounds = min(3, max(1, int(math.ceil(math.log2((1.0 - beta0) / tol) / BISECT_LEVELS - 1e-9))))
     # record buffers live on the engine: the rounds are host-bound (three enqueues each), so no allocation per round
     bufs = engine.__dict__.setdefault("_bis_bufs", {})
     if bufs.get("world") != comm.world:
@@ -361,7 +363,7 @@ def find_beta_sharded(engine, comm, ll, lp, lq, beta0: float, target_eff: float,
     rec, recs = bufs["rec"], bufs["recs"]
     launched = 0
     out = None
-    for _ in range(4):
+    for _ in range(32):
         if hasattr(engine, "find_beta_shard_rounds"):
             engine.find_beta_shard_rounds(comm, ll, lp, lq, beta0, target_eff, tol, n_global, rec, recs, launched, rounds)
             launched = max(launched, rounds)

@@ -310,7 +310,9 @@ int asmc_search(asmc_ctx* ctx, int64_t n, const double* cdf_dev, int64_t n_out, 
 /* x_out[j] = x_in[idx[j]] and the same for the three log-probability vectors (samples.py:1278-1287, `self[idx]`).
  * n_in = rows of the source population (idx values are < n_in): when the population fits the ctx and most of it is
  * drawn, (ll, lp, lq) are first packed into one 32-byte record per particle, so that a draw costs ONE random sector
- * read for its three scalars instead of three. */
+ * read for its three scalars instead of three.  asmc_importance_step packs those records on its way: an asmc_gather of
+ * the SAME three arrays and n_in that follows it with no other call on this ctx in between skips the packing pass - the
+ * caller must not have rewritten the arrays between the two calls (any library launch in between drops the records). */
 int asmc_gather(asmc_ctx* ctx, int64_t n_in, int64_t n_out, const int64_t* idx_dev, int d, int x_dtype,
                 const void* x_in_dev, void* x_out_dev, const double* ll_in_dev,
                 const double* lp_in_dev, const double* lq_in_dev, double* ll_out_dev,

@@ -311,3 +311,30 @@ def test_barrier_timeout_abandons_the_step_and_the_sampler_falls_back(monkeypatc
     sp_a, out_a = _run(e2, True, 20000, 8, 3)   # speculation is skipped on this engine now
     sp_b, out_b = _run(e2, False, 20000, 8, 3)
     assert sp_a.history.beta == sp_b.history.beta and np.array_equal(_np(out_a.x), _np(out_b.x))
+
+
+@pytest.mark.parametrize("n", [200_000, 1_300_000])
+def test_gather_reuses_the_records_the_step_packed_and_only_those(eng, n):
+    """k_is_weights writes the (ll, lp, lq, 0) records of asmc_gather on its way (resident and streaming variants): a gather
+    of the same arrays right behind the step launches no packing pass; any library launch in between, or other arrays, and
+    the gather packs again.  Rows and scalars equal torch indexing every time."""
+    x, ll, lp, lq = synth(n, 4, 31)
+    xd, lld, lpd, lqd = dev(eng, x, ll, lp, lq)
+    rng = np.random.default_rng(5)
+
+    def gathered(call_between, ll_arg):
+        idx = eng.importance_step(lld, lpd, lqd, 0.0, 0.5, 1e-6, smc_math.pcg64_state(rng), n)
+        if call_between:
+            eng.count_nonfinite(lld)
+        eng.profile(True)
+        rows = eng.gather(idx, xd, ll_arg, lpd, lqd)
+        rep = eng.profile_report()
+        eng.profile(False)
+        eng.importance_result()
+        assert torch.equal(rows[0], xd[idx]) and torch.equal(rows[1], ll_arg[idx])
+        assert torch.equal(rows[2], lpd[idx]) and torch.equal(rows[3], lqd[idx])
+        return "k_pack_records" in rep
+
+    assert not gathered(False, lld)
+    assert gathered(True, lld)
+    assert gathered(False, lld.clone())
