@@ -26,7 +26,7 @@ COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
-ASMC_ABI_VERSION = 16
+ASMC_ABI_VERSION = 17
 ASMC_CDF_REC = 9
 ASMC_CDF_STATE = 36
 
@@ -165,6 +165,8 @@ SIGNATURES = {
     "asmc_mean_gram": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _pd, _pd, _vp]),
     "asmc_mean_gram_enqueue": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _vp]),
     "asmc_mean_gram_fetch": (_i, [_vp, _i, _pd, _pd, _vp]),
+    "asmc_reference_factor": (_i, [_vp, _i, _i64, _i64, _pd, _pd, _vp, _vp]),
+    "asmc_reference_factor_status": (_i, [_vp, POINTER(ctypes.c_int)]),
     "asmc_pcn_mutate": (
         _i,
         [_vp, _i64, _vp, _vp, _vp, _vp, POINTER(AsmcPcnParams), _i, _u32, _pd, _pi64, _pd, _vp],

@@ -24,6 +24,7 @@ struct asmc_ctx;
 int asmc_count_nonfinite_enqueue(asmc_ctx* ctx, int64_t n, const double* v, hipStream_t st);
 struct asmc_ctx;
 void asmc_prof_begin(asmc_ctx* ctx, const char* label, hipStream_t st);
+void asmc_poison_lds(asmc_ctx* ctx, hipStream_t st);  // diagnostic (ASMC_POISON_LDS): every CU's LDS filled with 0xFF bytes
 void asmc_prof_end(asmc_ctx* ctx, hipStream_t st);
 #define ASMC_PROF_MAX 8192
 // every kernel goes through this macro so that bench.py can time individual kernels with HIP events recorded on
@@ -31,6 +32,7 @@ void asmc_prof_end(asmc_ctx* ctx, hipStream_t st);
 #define ASMC_LAUNCH(ctx, st, label, ...)   \
     do {                                   \
         (ctx)->rec_n = 0; /* any launch may rewrite the arrays ctx->d_rec was packed from */ \
+        if ((ctx)->poison_lds) asmc_poison_lds((ctx), (st)); \
         asmc_prof_begin((ctx), (label), (st)); \
         hipLaunchKernelGGL(__VA_ARGS__);   \
         asmc_prof_end((ctx), (st));        \
@@ -95,6 +97,8 @@ struct asmc_ctx {
     unsigned int* d_bar;           // [1024 * 17] arrival counters + the poison cell of the persistent importance-weight kernel's grid barriers (4 KB apart; they only grow)
     unsigned int bar_base[17];     // their values when the next launch starts (top, groups)
     unsigned long long flow_nonfinite;  // non-finite flow densities among the proposals of the last asmc_pcn_mutate_flow
+    int poison_lds;                // ASMC_POISON_LDS: a kernel that fills the LDS of every CU with NaN patterns runs in front of EVERY launch
+                                   //   (a read of LDS that the kernel itself has not written then shows in the results, run after run)
     int isw_disabled;              // a launch was not fully resident once (barrier time-out): the step-by-step path from now on
     unsigned long long* d_pcgtab;  // [64*4 + 8] PCG64 jump table
     long long* d_select;           // [2 * ASMC_SELECT_THREADS/64 + 8] wave counts, offsets, total of asmc_pcg64_select
@@ -128,6 +132,7 @@ struct asmc_ctx {
     // pinned host staging for scalar read-back / small uploads
     double* h_pinned;  // [8192] doubles
     double* h_gram;    // [128 + 128 * 128] doubles: asmc_mean_gram's results (sum | Gram) until asmc_mean_gram_fetch
+    double* d_ref;     // the same on the device (d_small / d_partials are every other call's scratch): asmc_reference_factor
     int gram_pending_d;  // d of an enqueued, not yet fetched asmc_mean_gram (0: none)
 };
 

@@ -14,6 +14,26 @@ void asmc_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// Diagnostic (ASMC_POISON_LDS=1): one block per CU that owns the whole LDS and fills it with 0xFF bytes - NaN as fp64 / fp32 /
+// fp16, -1 as an integer.  In front of every launch it turns a read of uninitialised LDS into a repeatable wrong answer (the
+// GPU address sanitizer is not available on this pool); the persistent kernels' residency rules are not affected (it ends
+// before the next kernel starts).
+__global__ __launch_bounds__(256) void k_poison_lds(int words) {
+    extern __shared__ unsigned int s_poison[];
+    for (int i = threadIdx.x; i < words; i += 256) s_poison[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (s_poison[(threadIdx.x * 977) % words] != 0xFFFFFFFFu) __builtin_trap();  // (keeps the stores alive)
+}
+void asmc_poison_lds(asmc_ctx* ctx, hipStream_t st) {
+    const int bytes = 160 * 1024 - 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_poison_lds, dim3(4 * ctx->num_cu), dim3(256), bytes, st, bytes / 4);
+}
+
 void asmc_prof_begin(asmc_ctx* ctx, const char* label, hipStream_t st) {
     if (!ctx || !ctx->prof_on || ctx->prof_n >= ASMC_PROF_MAX) return;
     ctx->prof_label[ctx->prof_n] = label;
@@ -144,6 +164,7 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     if (c->gram_cap < (size_t)2048 * 1024) c->gram_cap = (size_t)2048 * 1024;
     dmalloc((void**)&c->d_gram, sizeof(double) * c->gram_cap);
     c->d_mmtab = nullptr;
+    c->poison_lds = getenv("ASMC_POISON_LDS") != nullptr;
     c->d_max_pad = d_max <= 4 ? 4 : d_max <= 8 ? 8 : d_max <= 16 ? 16 : d_max <= 32 ? 32 : d_max <= 64 ? 64 : d_max <= 128 ? 128 : 0;
     if (d_max > 32) dmalloc((void**)&c->d_mmtab, sizeof(double) * 2 * 144 * 64);  // (d in 33 .. 63 runs zero-padded on the d = 64 kernels)
     dmalloc((void**)&c->d_guide, sizeof(unsigned int) * ((size_t)n_max / 4 + 8));
@@ -163,6 +184,7 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     dmalloc((void**)&c->d_select, sizeof(long long) * (2 * (ASMC_SELECT_THREADS / 64) + 8));
     dmalloc((void**)&c->d_ptab, sizeof(double) * (2 * 32 * 32 + 32 + 3 * ASMC_MAX_COMPONENTS * (1 + 2 * 32) + 64));
     dmalloc((void**)&c->d_bmtab, sizeof(double) * 2 * BM_TAB_N);
+    dmalloc((void**)&c->d_ref, sizeof(double) * (128 + 128 * 128));
     if (e == hipSuccess) {
         double tab[2 * BM_TAB_N];
         asmc_bm_table_host(tab);
@@ -205,6 +227,7 @@ int asmc_ctx_destroy(asmc_ctx* c) {
     (void)hipFree(c->d_select);
     (void)hipFree(c->d_ptab);
     (void)hipFree(c->d_bmtab);
+    (void)hipFree(c->d_ref);
     if (c->prof_ev) {
         for (int i = 0; i < 2 * ASMC_PROF_MAX; i++) (void)hipEventDestroy(c->prof_ev[i]);
         delete[] c->prof_ev;

@@ -1832,6 +1832,107 @@ __global__ void k_center_from_sum(int d, const double* __restrict__ sum, double 
     if (j < d) center[j] = sum[j] / n;
 }
 
+// The reference Gaussian of a mutation from the population moments, on the device (smc/minipcn.py:75-84: mean and
+// covariance of the particles; this repository's pCN specification whitens with the Cholesky factor): what the host did with
+// numpy between two temperatures - cov = G / (n - 1), symmetrised; L = chol(cov + jitter * mean(diag) * I) with the jitter
+// ladder 0, 1e-12, 1e-10, ... of twelve tries; Linv = L^-1 - in ONE block behind the Gram kernel, so the mutation's kernels
+// follow without a host round trip (fetch, LAPACK, upload: ~0.2 ms of idle GPU per temperature).
+// out = [mu (seg) | L (d x d, zeros above the diagonal) | pad to seg x d | Linv (d x d)], seg = 32 ceil(d / 32) doubles;
+// status[0] = jitter tries used (0: none), -1: not factorable / not finite.
+#define REF_THREADS 256
+__global__ __launch_bounds__(REF_THREADS) void k_ref_factor(int d, const double* __restrict__ sum, const double* __restrict__ gram,
+                                                           double n_mean, double n_cov, double* __restrict__ out,
+                                                           double* __restrict__ status) {
+    extern __shared__ __align__(16) double s_a[];  // [d][d + 1]
+    __shared__ double s_diag[128];
+    __shared__ double s_scale;
+    const int tid = threadIdx.x, ld = d + 1, seg = (d + 31) / 32 * 32;
+    double* o_mu = out;
+    double* o_L = out + seg;
+    double* o_Li = out + seg + (size_t)seg * d;
+    const double denom = n_cov - 1.0 > 1.0 ? n_cov - 1.0 : 1.0;
+    for (int j = tid; j < d; j += REF_THREADS) o_mu[j] = sum[j] / n_mean;
+    int tries = -1;
+    double jitter = 0.0;
+    for (int attempt = 0; attempt < 12; attempt++) {
+        __syncthreads();
+        for (int e = tid; e < d * d; e += REF_THREADS) {
+            const int i = e / d, j = e - i * d;
+            s_a[i * ld + j] = 0.5 * (gram[(size_t)i * d + j] / denom + gram[(size_t)j * d + i] / denom);
+        }
+        __syncthreads();
+        if (attempt == 0) {
+            if (tid == 0) {
+                double t = 0.0;
+                for (int j = 0; j < d; j++) t += s_a[j * ld + j];
+                t /= (double)d;
+                s_scale = (t > 0.0 && t < INFINITY) ? t : 1.0;
+            }
+        } else {
+            for (int j = tid; j < d; j += REF_THREADS) s_a[j * ld + j] += jitter * s_scale;
+        }
+        // right-looking Cholesky with ONE barrier per column: the trailing block takes A[i][k] -= A[i][j] A[k][j] / A[j][j]
+        // (kept symmetric: both halves are updated); column j itself is left unscaled - it is not read again - and becomes
+        // L[i][j] = A[i][j] / sqrt(A[j][j]) in the pass behind the loop
+        bool ok = true;
+        for (int j = 0; j < d; j++) {
+            __syncthreads();
+            const double p = s_a[j * ld + j];  // the same value in every thread: the test below is uniform
+            if (!(p > 0.0 && p < INFINITY)) {
+                ok = false;
+                break;
+            }
+            const double rp = 1.0 / p;
+            const int m = d - j - 1;
+            for (int e = tid; e < m * m; e += REF_THREADS) {
+                const int i = j + 1 + e / m, k = j + 1 + e % m;
+                s_a[i * ld + k] = fma(-(s_a[i * ld + j] * rp), s_a[k * ld + j], s_a[i * ld + k]);
+            }
+        }
+        if (ok) {
+            tries = attempt;
+            break;
+        }
+        jitter = jitter == 0.0 ? 1e-12 : jitter * 100.0;
+    }
+    __syncthreads();
+    if (tid == 0) status[0] = (double)tries;
+    if (tries < 0) return;
+    for (int j = tid; j < d; j += REF_THREADS) s_diag[j] = sqrt(s_a[j * ld + j]);
+    __syncthreads();
+    for (int e = tid; e < d * d; e += REF_THREADS) {
+        const int i = e / d, j = e - i * d;
+        double v = 0.0;
+        if (j < i) v = s_a[i * ld + j] / s_diag[j];
+        if (j == i) v = s_diag[j];
+        o_L[e] = v;
+        if (j < i) s_a[i * ld + j] = v;  // (the strict lower triangle: no other thread touches it in this pass)
+    }
+    __syncthreads();
+    // Linv by forward substitution, every column at once and without a barrier: thread c solves L x = e_c and keeps x_i
+    // (i > c) in the FREE upper triangle, at A[c][i] - its own row; L is only read (the same address in every thread)
+    for (int c = tid; c < d; c += REF_THREADS) {
+        const double xc = 1.0 / s_diag[c];
+        for (int i = c + 1; i < d; i++) {
+            double acc = s_a[i * ld + c] * xc;
+            for (int k = c + 1; k < i; k++) acc = fma(s_a[i * ld + k], s_a[c * ld + k], acc);
+            s_a[c * ld + i] = -acc / s_diag[i];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < d * d; e += REF_THREADS) {
+        const int i = e / d, j = e - i * d;
+        o_Li[e] = j < i ? s_a[j * ld + i] : j == i ? 1.0 / s_diag[i] : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_keep_moments(int d, const double* __restrict__ sum, const double* __restrict__ gram,
+                                                     double* __restrict__ keep) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < d) keep[e] = sum[e];
+    else if (e < d + d * d) keep[128 + e - d] = gram[e - d];
+}
+
 // Column sums and the Gram matrix centred on sum / n_mean in ONE enqueue and one synchronisation (the reference fit of a
 // temperature boundary: the centre never visits the host; same division, same kernels, same bits as asmc_colsum -> host
 // division -> asmc_centered_gram).  _enqueue leaves both results on their way to pinned memory, _fetch waits for the stream
@@ -1872,6 +1973,10 @@ int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const v
         return ASMC_ERR_ARG;
     }
     ASMC_HIP(hipMemcpyAsync(ctx->h_gram + 128, ctx->d_partials, sizeof(double) * d * d, hipMemcpyDeviceToHost, st));
+    // ... and a copy that stays on the device for asmc_reference_factor (d_small / d_partials are every call's scratch)
+    ASMC_LAUNCH(ctx, st, "k_keep_moments", k_keep_moments, dim3((d * d + d + 255) / 256), dim3(256), 0, st, d, (const double*)ctx->d_small,
+                (const double*)ctx->d_partials, ctx->d_ref);
+    ASMC_LAUNCH_CHECK();
     ctx->gram_pending_d = d;
     return ASMC_OK;
 }
@@ -1883,6 +1988,47 @@ int asmc_mean_gram_fetch(asmc_ctx* ctx, int d, double* sum_host, double* gram_ho
     memcpy(sum_host, ctx->h_gram, sizeof(double) * d);
     memcpy(gram_host, ctx->h_gram + 128, sizeof(double) * d * d);
     ctx->gram_pending_d = 0;
+    return ASMC_OK;
+}
+
+// (mu, L, Linv) of the reference Gaussian from the moments of the pending asmc_mean_gram_enqueue (consumed: no fetch
+// follows) or, with sum_host / gram_host, from moments the caller merged on the host (uploaded first): k_ref_factor on the
+// stream.  The status lands in pinned memory behind it; asmc_reference_factor_status reads it after the caller's next
+// synchronisation of the stream.
+int asmc_reference_factor(asmc_ctx* ctx, int d, int64_t n_mean, int64_t n_cov, const double* sum_host, const double* gram_host,
+                          double* out_dev, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && out_dev, "null pointer");
+    ASMC_REQUIRE(d > 0 && d <= 128 && n_mean > 0 && n_cov > 0, "bad sizes (d <= 128)");
+    ASMC_REQUIRE((sum_host == nullptr) == (gram_host == nullptr), "sum_host and gram_host come together");
+    hipStream_t st = as_stream(stream);
+    if (gram_host) {
+        ASMC_REQUIRE(ctx->gram_pending_d == 0, "an asmc_mean_gram_enqueue is pending: its results would be overwritten");
+        ASMC_HIP(hipStreamSynchronize(st));  // (the pinned staging may still feed an earlier copy)
+        memcpy(ctx->h_gram, sum_host, sizeof(double) * d);
+        memcpy(ctx->h_gram + 128, gram_host, sizeof(double) * d * d);
+        ASMC_HIP(hipMemcpyAsync(ctx->d_ref, ctx->h_gram, sizeof(double) * (128 + (size_t)d * d), hipMemcpyHostToDevice, st));
+    } else {
+        ASMC_REQUIRE(ctx->gram_pending_d == d, "no asmc_mean_gram_enqueue of this d is pending");
+        ctx->gram_pending_d = 0;
+    }
+    const size_t lds = sizeof(double) * (size_t)d * (d + 1);
+    static size_t attr_lds = 0;
+    if (lds > 64 * 1024 && lds > attr_lds) {
+        ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ref_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    double* d_status = ctx->d_small + 2300;
+    ASMC_LAUNCH(ctx, st, "k_ref_factor", k_ref_factor, dim3(1), dim3(REF_THREADS), lds, st, d, (const double*)ctx->d_ref,
+                (const double*)(ctx->d_ref + 128), (double)n_mean, (double)n_cov, out_dev, d_status);
+    ASMC_LAUNCH_CHECK();
+    ctx->h_pinned[8010] = -2.0;  // (not yet known)
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8010, d_status, sizeof(double), hipMemcpyDeviceToHost, st));
+    return ASMC_OK;
+}
+
+int asmc_reference_factor_status(asmc_ctx* ctx, int* status_host) {
+    ASMC_REQUIRE(ctx && status_host, "null pointer");
+    *status_host = (int)ctx->h_pinned[8010];  // -2: the stream has not been synchronised since asmc_reference_factor
     return ASMC_OK;
 }
 

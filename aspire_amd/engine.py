@@ -634,6 +634,37 @@ class HipEngine:
         check(self.lib.asmc_mean_gram_fetch(self._ctx, d, _f64p(s), _f64p(g), self._stream), "asmc_mean_gram_fetch")
         return s, g
 
+    def reference_factor(self, d: int, n_mean: int, n_cov: int, moments=None):
+        """(mu, L, Linv) of the mutation's reference Gaussian as device tensors, factored ON the device behind the moments of
+        the pending `mean_gram_enqueue` (moments=None: consumed, no fetch follows) or of `moments` = (sums, Gram) merged on the
+        host (include/asmc.h asmc_reference_factor).  Nothing is synchronised: `reference_factor_status()` after the next
+        synchronisation says whether the covariance could be factored."""
+        seg = -(-d // 32) * 32
+        size = seg + 2 * seg * d
+        bufs = self.__dict__.setdefault("_ref_out", {})
+        # two buffers in turn: the previous mutation's kernels may still read theirs when the next fit is enqueued
+        slot = bufs["slot"] = 1 - bufs.get("slot", 1)
+        if bufs.get(("buf", slot)) is None or bufs[("buf", slot)].numel() != size:
+            bufs[("buf", slot)] = torch.zeros(size, dtype=torch.float64, device=self.device)
+        out = bufs[("buf", slot)]
+        if moments is None:
+            sp, gp = None, None
+        else:
+            s = np.ascontiguousarray(moments[0], dtype=np.float64)
+            g = np.ascontiguousarray(moments[1], dtype=np.float64)
+            assert s.shape == (d,) and g.shape == (d, d)
+            sp, gp = _f64p(s), _f64p(g)
+        check(self.lib.asmc_reference_factor(self._ctx, d, int(n_mean), int(n_cov), sp, gp, _dptr(out), self._stream),
+              "asmc_reference_factor")
+        return out[:d], out[seg:seg + d * d].view(d, d), out[seg + seg * d:seg + seg * d + d * d].view(d, d)
+
+    def reference_factor_status(self) -> int:
+        """Jitter tries the last `reference_factor` needed (0: none); -1: the covariance was not factorable; -2: the stream has
+        not been synchronised since."""
+        st = ctypes.c_int(0)
+        check(self.lib.asmc_reference_factor_status(self._ctx, ctypes.byref(st)), "asmc_reference_factor_status")
+        return int(st.value)
+
     def mean_gram_across_ranks_ok(self, x: torch.Tensor, comm) -> bool:
         """The shapes asmc_mean_gram sums over the ranks itself (the fp64-MFMA Gram kernel's), given a communicator."""
         # (only properties every rank shares: the alignment of this rank's rows is dealt with inside mean_gram)

@@ -449,14 +449,24 @@ class HipSMC(SMCSampler):
         importance step parked for exactly these rows (`SMCSamples.speculate_importance_step`)."""
         e, comm = self.engine, self.comm
         n = n_global or x.shape[0] * comm.world
+        device_fit = hasattr(e, "reference_factor") and x.shape[1] <= 128 and not os.environ.get("ASMC_HOST_REFERENCE_FIT")
         if (moments is not None and moments[0] == x.data_ptr() and moments[1] == tuple(x.shape)
                 and moments[2] == n and moments[3] == getattr(e, "_gram_gen", None)):
+            if device_fit:  # mean, covariance, Cholesky factor and its inverse never visit the host (asmc_reference_factor)
+                self._ref_fit_pending = True
+                return e.reference_factor(x.shape[1], n, n)
             s, g = e.mean_gram_fetch(x.shape[1])  # enqueued behind the importance step's gather; waits for the stream
             mean = s / n
         elif not comm.sharded and hasattr(e, "mean_gram"):
+            if device_fit and e.mean_gram_enqueue(x, n):
+                self._ref_fit_pending = True
+                return e.reference_factor(x.shape[1], n, n)
             s, g = e.mean_gram(x, n)  # both passes enqueued together: the centre never visits the host
             mean = s / n
         elif hasattr(e, "mean_gram_across_ranks_ok") and e.mean_gram_across_ranks_ok(x, comm):
+            if device_fit and e.mean_gram_enqueue(x, n, comm):
+                self._ref_fit_pending = True
+                return e.reference_factor(x.shape[1], n, n)
             s, g = e.mean_gram(x, n, comm)  # ... and both sums cross the ranks on the stream (RCCL all-reduce)
             mean = s / n
         else:
@@ -469,6 +479,9 @@ class HipSMC(SMCSampler):
             g = parts[0].copy()
             for r in range(1, comm.world):
                 g = g + parts[r]
+        if device_fit:  # the same factorisation kernel on every path of a device engine: the same bits single-rank and sharded
+            self._ref_fit_pending = True
+            return e.reference_factor(x.shape[1], n, n, moments=(s, g))
         cov = g / max(n - 1, 1)
         cov = 0.5 * (cov + cov.T)
         scale = float(np.mean(np.diag(cov)))
@@ -701,7 +714,9 @@ class HipSMC(SMCSampler):
         transformed = not (isinstance(T, IdentityTransform) or getattr(T, "is_identity", False))
         if transformed:
             self.last_mutation_path = "preconditioned chain (z = T(x)): split propose / accept around the transform"
-            return self._mutate_preconditioned(particles, x, beta, n_steps, target)
+            out = self._mutate_preconditioned(particles, x, beta, n_steps, target)
+            self._check_reference_fit()
+            return out
         self.fit_preconditioning_transform(particles.x)
         ll, lp, lq = particles.log_likelihood, particles.log_prior, particles.log_q
         n_local = x.shape[0]
@@ -721,11 +736,27 @@ class HipSMC(SMCSampler):
         if comm.sharded and on_device:
             e.set_count_hook(comm, n_global)
         try:
-            return self._mutate_steps(particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0,
-                                      acc_rates, dev_flow, on_device, n_local, n_global, gid0, nu)
+            out = self._mutate_steps(particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0,
+                                     acc_rates, dev_flow, on_device, n_local, n_global, gid0, nu)
         finally:
             if comm.sharded and on_device:
                 e.set_count_hook(None, None)
+        self._check_reference_fit()
+        return out
+
+    def _check_reference_fit(self):
+        """The device-side factorisation of the reference covariance (`engine.reference_factor`) reports behind the mutation
+        it served: the steps' results have been collected, so its status is on the host."""
+        if not self.__dict__.pop("_ref_fit_pending", False):
+            return
+        status = self.engine.reference_factor_status()
+        if status == -2:  # nothing has synchronised the stream since (a mutation of zero steps)
+            torch.cuda.synchronize(self.engine.device)
+            status = self.engine.reference_factor_status()
+        if status < 0:
+            raise RuntimeError("could not factor the particle covariance")
+        if status > 0:
+            logger.info("reference covariance factored with jitter (try %d)", status)
 
     def _mutate_steps(self, particles, x, ll, lp, lq, beta, n_steps, target, noise, mu, L, Linv, st, seed, step0, acc_rates,
                       dev_flow, on_device, n_local, n_global, gid0, nu=0.0):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 16
+#define ASMC_ABI_VERSION 17
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -405,6 +405,16 @@ int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_d
 int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, int64_t n_mean, int across_ranks,
                            asmc_stream stream);
 int asmc_mean_gram_fetch(asmc_ctx* ctx, int d, double* sum_host, double* gram_host /* [d, d] */, asmc_stream stream);
+/* The reference Gaussian of the coming mutation from those moments WITHOUT a host round trip (smc/minipcn.py:75-84; what the
+ * host did with numpy: cov = G / (n_cov - 1), symmetrised, L = chol(cov + jitter mean(diag) I) with the jitter ladder 0, 1e-12,
+ * 1e-10, ... of twelve tries, Linv = L^-1): one block on the stream behind the Gram kernel.  sum_host = gram_host = NULL: the
+ * moments of the pending asmc_mean_gram_enqueue (consumed - no _fetch follows); otherwise moments the caller merged on the
+ * host, uploaded first.  out_dev: [mu | pad to seg | L (d x d row-major, zeros above the diagonal) | pad to seg x d | Linv],
+ * seg = 32 ceil(d / 32) doubles.  d <= 128.  asmc_reference_factor_status (after the caller's next synchronisation of the
+ * stream): jitter tries used (0: none), -1: not factorable / not finite, -2: not synchronised yet. */
+int asmc_reference_factor(asmc_ctx* ctx, int d, int64_t n_mean, int64_t n_cov, const double* sum_host, const double* gram_host,
+                          double* out_dev, asmc_stream stream);
+int asmc_reference_factor_status(asmc_ctx* ctx, int* status_host);
 int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
                        const double* center_host, double* gram_host, asmc_stream stream);
 int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, double* lp_dev,

@@ -1597,6 +1597,7 @@ def test_pcn_whitened_state_with_mixture_targets_vs_oracle(eng, oracle, d, C, nu
 @pytest.mark.gpu
 @pytest.mark.parametrize("xdt,nu,noise,hidden,n", [("f64", 0.0, "f64", 64, 5000), ("f32", 0.0, "f64", 64, 4097), ("f64", 5.0, "f64", 64, 5000),
                                                    ("f64", 0.0, "f32", 64, 70001), ("f64", 0.0, "f64", 32, 3000), ("f64", 0.0, "f64", 128, 640),
+                                                   ("f64", 0.0, "f64", 128, 100_000), ("f64", 0.0, "f64", 32, 100_000),
                                                    ("f64", 0.0, "f64", 64, 1)])
 def test_pcn_flow_fused_step_vs_split_calls(eng, xdt, nu, noise, hidden, n):
     """The fused flow-proposal step (k_pcn_flow_fused: propose -> coupling flow on the MFMA -> built-in targets -> accept in
@@ -1960,3 +1961,87 @@ def test_coupling_flow_samples_on_the_engine_inside_the_sampler(eng):
     eng.profile(False)
     assert rep["k_coupling_sample"][0] >= 1
     assert abs(float(out.log_evidence) - 0.5 * d * math.log(math.pi)) < max(5 * float(out.log_evidence_error), 0.05)
+
+
+@pytest.mark.parametrize("d", [4, 20, 32, 64, 100, 128])
+def test_reference_factor_on_the_device_vs_numpy(eng, d):
+    """asmc_reference_factor (mean, covariance, Cholesky factor and its inverse of the mutation's reference Gaussian in one
+    block on the stream) against numpy on the same moments: from the host's (sums, Gram) for every d <= 128, from the pending
+    asmc_mean_gram_enqueue for the matrix-core shapes; the jitter ladder on a singular covariance; -1 for a NaN."""
+    n = 5000 + d
+    g = torch.Generator(eng.device).manual_seed(d)
+    A = torch.randn((d, d), device=eng.device, dtype=torch.float64, generator=g) / math.sqrt(d) + 0.7 * torch.eye(d, device=eng.device, dtype=torch.float64)
+    x = (0.3 + torch.randn((n, d), device=eng.device, dtype=torch.float64, generator=g) @ A).contiguous()
+    s, gram = eng.mean_gram(x, n)
+    cov = gram / (n - 1)
+    cov = 0.5 * (cov + cov.T)
+    Lr = np.linalg.cholesky(cov)
+
+    def check(mu, L, Linv):
+        torch.cuda.synchronize()
+        assert eng.reference_factor_status() == 0
+        np.testing.assert_allclose(mu.cpu().numpy(), s / n, rtol=1e-15)
+        Lh, Lih = L.cpu().numpy(), Linv.cpu().numpy()
+        assert np.all(np.triu(Lh, 1) == 0) and np.all(np.triu(Lih, 1) == 0)
+        np.testing.assert_allclose(Lh, Lr, rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(Lih @ Lh, np.eye(d), atol=1e-11)
+
+    check(*eng.reference_factor(d, n, n, moments=(s, gram)))
+    if d in (32, 64, 128):
+        assert eng.mean_gram_enqueue(x, n)
+        eng.count_nonfinite(x[:, 0].contiguous())  # other launches use the same scratch: the moments have their own copy
+        check(*eng.reference_factor(d, n, n))
+        with pytest.raises(Exception, match="pending"):
+            eng.mean_gram_fetch(d)  # consumed by the factorisation
+    # a rank-deficient covariance needs the jitter; a NaN cannot be factored
+    v = np.ones((d, 1))
+    mu, L, Linv = eng.reference_factor(d, n, n, moments=(np.zeros(d), (n - 1) * (v @ v.T)))
+    torch.cuda.synchronize()
+    if d > 1:
+        assert eng.reference_factor_status() >= 1
+        Lh = L.cpu().numpy()
+        np.testing.assert_allclose(Lh @ Lh.T, v @ v.T, atol=1e-6)
+    bad = gram.copy()
+    bad[0, 0] = np.nan
+    eng.reference_factor(d, n, n, moments=(s, bad))
+    torch.cuda.synchronize()
+    assert eng.reference_factor_status() == -1
+
+
+@pytest.mark.parametrize("hidden,n", [(64, 640), (64, 100_000), (128, 6400), (128, 100_000), (32, 100_000)])
+def test_fused_flow_step_is_repeatable_and_carries_the_densities_of_its_positions(eng, hidden, n):
+    """Twelve calls of the fused flow-proposal step on fresh copies of one batch, other kernels in between (tools/stress_fused.py
+    in small): every call returns the bits of the first, and the carried log q / log-likelihood are the densities at the returned
+    positions.  (The split-fp16 instantiation for hidden width 128 failed exactly this - it spilled 300 registers around the
+    hand-scheduled flow code and returned different log q from run to run; that width now runs the fp32 MFMA chain.)"""
+    from conftest import random_coupling_flow
+
+    d, n_steps = 32, 5
+    flow = random_coupling_flow(d, 4 if hidden < 128 else 1, hidden)
+    dev = flow.device_coupling(eng)
+    g = torch.Generator(eng.device).manual_seed(3)
+    x0 = torch.randn((n, d), device=eng.device, dtype=torch.float64, generator=g)
+    t_ll = eng.make_mixture([0.3], np.full((1, d), 0.25), np.ones((1, d)) * 1.5)
+    t_lp = eng.make_mixture([-0.5 * d * np.log(2 * np.pi)], np.zeros((1, d)), np.ones((1, d)))
+    mu = eng.asarray(0.1 * np.arange(d) / d)
+    A = np.eye(d) + 0.05 * np.tril(np.random.default_rng(2).normal(size=(d, d)), -1)
+    L, Linv = eng.asarray(A), eng.asarray(np.linalg.inv(A))
+    big = torch.randn((20000, 128), device=eng.device, dtype=torch.float64, generator=g)
+    ll0, lp0, lq0 = eng.mixture_logpdf(x0, t_ll), eng.mixture_logpdf(x0, t_lp), eng.coupling_logprob(x0, dev)
+    first = None
+    for it in range(12):
+        x, ll, lp, lq = x0.clone(), ll0.clone(), lp0.clone(), lq0.clone()
+        if it % 3 == 1:
+            eng.reference_factor(128, 20000, 20000, moments=eng.mean_gram(big, 20000))
+        eng.profile(it == 0)
+        n_acc, _, _ = eng.pcn_mutate_flow(x, ll, lp, lq, 0.35, mu, L, Linv, t_ll, t_lp, dev, 77, 1000, 0.4, n_steps, 5, 0.234,
+                                          False, "f64", 0.0)
+        if it == 0:
+            assert eng.profile_report()["k_pcn_flow_fused"][0] == n_steps
+            eng.profile(False)
+        torch.testing.assert_close(lq, eng.coupling_logprob(x, dev), rtol=1e-5, atol=2e-3)
+        torch.testing.assert_close(ll, eng.mixture_logpdf(x, t_ll), rtol=1e-9, atol=1e-9)
+        if first is None:
+            first = (x, lq, n_acc)
+        else:
+            assert torch.equal(x, first[0]) and torch.equal(lq, first[1]) and np.array_equal(n_acc, first[2]), it
