@@ -1835,23 +1835,32 @@ __global__ void k_center_from_sum(int d, const double* __restrict__ sum, double 
 // The reference Gaussian of a mutation from the population moments, on the device (smc/minipcn.py:75-84: mean and
 // covariance of the particles; this repository's pCN specification whitens with the Cholesky factor): what the host did with
 // numpy between two temperatures - cov = G / (n - 1), symmetrised; L = chol(cov + jitter * mean(diag) * I) with the jitter
-// ladder 0, 1e-12, 1e-10, ... of twelve tries; Linv = L^-1 - in ONE block behind the Gram kernel, so the mutation's kernels
+// ladder 0, 1e-12, 1e-10, ... of twelve tries (denom = n - 1); Linv = L^-1 - in ONE block behind the Gram kernel, so the mutation's kernels
 // follow without a host round trip (fetch, LAPACK, upload: ~0.2 ms of idle GPU per temperature).
 // out = [mu (seg) | L (d x d, zeros above the diagonal) | pad to seg x d | Linv (d x d)], seg = 32 ceil(d / 32) doubles;
 // status[0] = jitter tries used (0: none), -1: not factorable / not finite.
 #define REF_THREADS 256
+// Also the factorisation inside the device-side EM of the Student-t reference (asmc_student_fit): `sum` == NULL leaves the mean
+// alone, `tab` (mu | Linv's lower triangle packed by rows) is what k_student_estep stages, `em` / `it`: the EM's state record -
+// iterations behind the one that converged are skipped, a failed factorisation is recorded there.
 __global__ __launch_bounds__(REF_THREADS) void k_ref_factor(int d, const double* __restrict__ sum, const double* __restrict__ gram,
-                                                           double n_mean, double n_cov, double* __restrict__ out,
-                                                           double* __restrict__ status) {
+                                                           double n_mean, double denom, double* __restrict__ out,
+                                                           double* __restrict__ status, double* __restrict__ tab,
+                                                           double* __restrict__ em, int it) {
     extern __shared__ __align__(16) double s_a[];  // [d][d + 1]
     __shared__ double s_diag[128];
     __shared__ double s_scale;
+    if (em && (double)it > em[2]) return;  // (uniform: every thread reads the same cell)
     const int tid = threadIdx.x, ld = d + 1, seg = (d + 31) / 32 * 32;
     double* o_mu = out;
     double* o_L = out + seg;
     double* o_Li = out + seg + (size_t)seg * d;
-    const double denom = n_cov - 1.0 > 1.0 ? n_cov - 1.0 : 1.0;
-    for (int j = tid; j < d; j += REF_THREADS) o_mu[j] = sum[j] / n_mean;
+    if (sum)
+        for (int j = tid; j < d; j += REF_THREADS) {
+            const double mj = sum[j] / n_mean;
+            if (out) o_mu[j] = mj;
+            if (tab) tab[j] = mj;
+        }
     int tries = -1;
     double jitter = 0.0;
     for (int attempt = 0; attempt < 12; attempt++) {
@@ -1896,7 +1905,10 @@ __global__ __launch_bounds__(REF_THREADS) void k_ref_factor(int d, const double*
         jitter = jitter == 0.0 ? 1e-12 : jitter * 100.0;
     }
     __syncthreads();
-    if (tid == 0) status[0] = (double)tries;
+    if (tid == 0) {
+        if (status) status[0] = (double)tries;
+        if (em && tries < 0) em[3] = -1.0;
+    }
     if (tries < 0) return;
     for (int j = tid; j < d; j += REF_THREADS) s_diag[j] = sqrt(s_a[j * ld + j]);
     __syncthreads();
@@ -1905,7 +1917,7 @@ __global__ __launch_bounds__(REF_THREADS) void k_ref_factor(int d, const double*
         double v = 0.0;
         if (j < i) v = s_a[i * ld + j] / s_diag[j];
         if (j == i) v = s_diag[j];
-        o_L[e] = v;
+        if (out) o_L[e] = v;
         if (j < i) s_a[i * ld + j] = v;  // (the strict lower triangle: no other thread touches it in this pass)
     }
     __syncthreads();
@@ -1922,7 +1934,9 @@ __global__ __launch_bounds__(REF_THREADS) void k_ref_factor(int d, const double*
     __syncthreads();
     for (int e = tid; e < d * d; e += REF_THREADS) {
         const int i = e / d, j = e - i * d;
-        o_Li[e] = j < i ? s_a[j * ld + i] : j == i ? 1.0 / s_diag[i] : 0.0;
+        const double v = j < i ? s_a[j * ld + i] : j == i ? 1.0 / s_diag[i] : 0.0;
+        if (out) o_Li[e] = v;
+        if (tab && j <= i) tab[d + i * (i + 1) / 2 + j] = v;
     }
 }
 
@@ -1991,6 +2005,22 @@ int asmc_mean_gram_fetch(asmc_ctx* ctx, int d, double* sum_host, double* gram_ho
     return ASMC_OK;
 }
 
+}  // extern "C"
+int asmc_ref_factor_launch(asmc_ctx* ctx, int d, const double* sum, const double* gram, double n_mean, double denom, double* out,
+                           double* status, double* tab, double* em, int it, hipStream_t st) {
+    const size_t lds = sizeof(double) * (size_t)d * (d + 1);
+    static size_t attr_lds = 0;
+    if (lds > 64 * 1024 && lds > attr_lds) {
+        ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ref_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    ASMC_LAUNCH(ctx, st, "k_ref_factor", k_ref_factor, dim3(1), dim3(REF_THREADS), lds, st, d, sum, gram, n_mean, denom, out, status, tab,
+                em, it);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+extern "C" {
+
 // (mu, L, Linv) of the reference Gaussian from the moments of the pending asmc_mean_gram_enqueue (consumed: no fetch
 // follows) or, with sum_host / gram_host, from moments the caller merged on the host (uploaded first): k_ref_factor on the
 // stream.  The status lands in pinned memory behind it; asmc_reference_factor_status reads it after the caller's next
@@ -2011,16 +2041,10 @@ int asmc_reference_factor(asmc_ctx* ctx, int d, int64_t n_mean, int64_t n_cov, c
         ASMC_REQUIRE(ctx->gram_pending_d == d, "no asmc_mean_gram_enqueue of this d is pending");
         ctx->gram_pending_d = 0;
     }
-    const size_t lds = sizeof(double) * (size_t)d * (d + 1);
-    static size_t attr_lds = 0;
-    if (lds > 64 * 1024 && lds > attr_lds) {
-        ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ref_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
-    }
     double* d_status = ctx->d_small + 2300;
-    ASMC_LAUNCH(ctx, st, "k_ref_factor", k_ref_factor, dim3(1), dim3(REF_THREADS), lds, st, d, (const double*)ctx->d_ref,
-                (const double*)(ctx->d_ref + 128), (double)n_mean, (double)n_cov, out_dev, d_status);
-    ASMC_LAUNCH_CHECK();
+    const int rc = asmc_ref_factor_launch(ctx, d, ctx->d_ref, ctx->d_ref + 128, (double)n_mean, (double)(n_cov - 1 > 1 ? n_cov - 1 : 1),
+                                          out_dev, d_status, nullptr, nullptr, 0, st);
+    if (rc) return rc;
     ctx->h_pinned[8010] = -2.0;  // (not yet known)
     ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8010, d_status, sizeof(double), hipMemcpyDeviceToHost, st));
     return ASMC_OK;

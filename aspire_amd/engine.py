@@ -692,6 +692,29 @@ class HipEngine:
               "asmc_student_scale")
         return r
 
+    def student_fit(self, xs: torch.Tensor, max_iter: int, rtol: float, nu0: float):
+        """The whole Student-t EM on the device (include/asmc.h asmc_student_fit): ((mu, L, Linv) device views, nu, iterations,
+        status, mu_host, Sigma_host); None for shapes the device-side EM does not take (the host-driven EM serves them)."""
+        assert xs.dtype == torch.float64 and xs.is_contiguous() and xs.dim() == 2
+        m, d = xs.shape
+        if d not in (32, 64, 128) or xs.data_ptr() % 16 or os.environ.get("ASMC_GRAM_GENERIC"):
+            return None
+        seg = -(-d // 32) * 32
+        size = seg + 2 * seg * d
+        bufs = self.__dict__.setdefault("_ref_out", {})
+        slot = bufs["slot"] = 1 - bufs.get("slot", 1)
+        if bufs.get(("buf", slot)) is None or bufs[("buf", slot)].numel() != size:
+            bufs[("buf", slot)] = torch.zeros(size, dtype=torch.float64, device=self.device)
+        out = bufs[("buf", slot)]
+        scr = self.__dict__.setdefault("_student_scratch", {})
+        if scr.get("shape") != (m, d):
+            scr.update(shape=(m, d), r=torch.empty((m, d), dtype=torch.float64, device=self.device), z=self.empty(m))
+        res = np.empty(4 + d + d * d)
+        check(self.lib.asmc_student_fit(self._ctx, m, d, _dptr(xs), int(max_iter), float(rtol), float(nu0), _dptr(scr["r"]),
+                                        _dptr(scr["z"]), _dptr(out), _f64p(res), self._stream), "asmc_student_fit")
+        views = (out[:d], out[seg:seg + d * d].view(d, d), out[seg + seg * d:seg + seg * d + d * d].view(d, d))
+        return views, float(res[0]), int(res[1]), int(res[2]), res[4:4 + d].copy(), res[4 + d:].reshape(d, d).copy()
+
     def use_rccl(self, comm) -> bool:
         """Hand the library the communicator `comm.rccl_direct()` makes for the collectives it issues itself (include/asmc.h
         asmc_set_rccl); False when the communicator has none (single rank, gloo rigs, ASMC_RCCL_DIRECT=0)."""

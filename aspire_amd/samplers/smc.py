@@ -551,10 +551,20 @@ class HipSMC(SMCSampler):
         if comm.sharded:
             sub = comm.all_gather_tensor(sub)  # the same rows on every rank: identical fits
         st = self._pcn_state
+        # EM sweeps: a cold start needs ~a dozen; later temperatures restart (mu, Sigma) from the subsample's
+        # moments and nu from the previous fit, and a few sweeps track the slowly changing population
+        iters = int(self.sampler_kwargs.get("tpcn_fit_iters", 12 if st.get("nu") is None else 4))
+        fit = None
+        if hasattr(e, "student_fit") and not os.environ.get("ASMC_HOST_REFERENCE_FIT"):
+            fit = e.student_fit(sub, iters, 1e-3, st.get("nu") or 20.0)  # every sweep on the stream, one synchronisation
+        if fit is not None:
+            (mu_d, L_d, Linv_d), nu, _, status, _, _ = fit
+            if status < 0:
+                raise RuntimeError("could not factor the scale matrix of the Student-t fit")
+            st["nu"] = nu
+            self.history.mcmc_nu.append(float(nu) if nu <= NU_GAUSSIAN else float("inf"))
+            return mu_d, L_d, Linv_d, (nu if nu <= NU_GAUSSIAN else 0.0)
         with _single_threaded_blas():
-            # EM sweeps: a cold start needs ~a dozen; later temperatures restart (mu, Sigma) from the subsample's
-            # moments and nu from the previous fit, and a few sweeps track the slowly changing population
-            iters = int(self.sampler_kwargs.get("tpcn_fit_iters", 12 if st.get("nu") is None else 4))
             mean, cov, nu = fit_student_t_device(e, sub, max_iter=iters, nu0=st.get("nu") or 20.0)
             L = _chol(cov)
             Linv = np.linalg.inv(L)

@@ -379,6 +379,14 @@ int asmc_student_estep(asmc_ctx* ctx, int64_t m, int d, const double* xs_dev, co
                        double* sums_host, asmc_stream stream);
 int asmc_student_scale(asmc_ctx* ctx, int64_t m, int d, const double* xs_dev, const double* z_dev, const double* mu_host,
                        double* r_dev, asmc_stream stream);
+/* The whole EM of the Student-t reference on the stream (student_t.py fit_student_t_device: initial moments, then per iteration
+ * the factorisation of the scale matrix, E-step, weighted mean, degrees of freedom, scatter matrix), one synchronisation at the
+ * end instead of three per iteration; iterations behind the one that meets |nu' - nu| <= rtol nu return at once.  d in {32, 64,
+ * 128}, rows 16-byte aligned, m <= ASMC_STUDENT_MAX_ROWS.  r_scratch_dev [m, d], z_scratch_dev [m]: scratch.  out_dev: (mu | L |
+ * Linv) of the final fit in asmc_reference_factor's layout.  result_host [4 + d + d * d]: nu (clamped to [1, 1e6]), iterations,
+ * factorisation status (0 / -1), converged, mu, Sigma. */
+int asmc_student_fit(asmc_ctx* ctx, int64_t m, int d, const double* xs_dev, int max_iter, double rtol, double nu0,
+                     double* r_scratch_dev, double* z_scratch_dev, double* out_dev, double* result_host, asmc_stream stream);
 typedef int (*asmc_count_hook)(void* user, asmc_stream stream);
 int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int64_t* cell_dev, int64_t n_global);
 /* NaNs in the carried log q after the last asmc_pcn_mutate / asmc_pcn_mutate_flow call (the reference's check after every

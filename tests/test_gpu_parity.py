@@ -2045,3 +2045,30 @@ def test_fused_flow_step_is_repeatable_and_carries_the_densities_of_its_position
             first = (x, lq, n_acc)
         else:
             assert torch.equal(x, first[0]) and torch.equal(lq, first[1]) and np.array_equal(n_acc, first[2]), it
+
+
+@pytest.mark.parametrize("m,d,iters", [(2048, 32, 12), (4096, 64, 6), (16384, 128, 8), (2048, 32, 1), (1999, 32, 50)])
+def test_student_fit_on_the_device_vs_numpy_em(eng, m, d, iters):
+    """asmc_student_fit (every EM sweep on the stream: factorisation, E-step, weighted mean, the root in nu by a section search,
+    scatter matrix; one synchronisation) against the all-numpy EM of student_t.fit_student_t on heavy-tailed data: same
+    iteration count, location / scale matrix / degrees of freedom to the rounding of two different factorisations and root
+    finders; the factor it leaves for the mutation is the Cholesky factor of the returned scale matrix."""
+    from aspire_amd.student_t import fit_student_t
+
+    g = np.random.default_rng(m + d)
+    A = g.normal(size=(d, d)) / np.sqrt(d)
+    L0 = np.linalg.cholesky(A @ A.T + 0.5 * np.eye(d))
+    x = 0.3 + (g.normal(size=(m, d)) @ L0.T) / np.sqrt(g.chisquare(6.0, size=m) / 6.0)[:, None]
+    xd = eng.asarray(x)
+    (mu_d, L_d, Linv_d), nu, n_it, status, mu_h, cov_h = eng.student_fit(xd, iters, 1e-3, 20.0)
+    assert status == 0 and 1 <= n_it <= iters
+    # the numpy EM stopped by the same rule
+    ref_mu, ref_cov, ref_nu = fit_student_t(x, max_iter=iters)
+    np.testing.assert_allclose(mu_h, ref_mu, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(cov_h, ref_cov, rtol=1e-7, atol=1e-9)
+    assert nu == pytest.approx(ref_nu, rel=1e-6)
+    assert 2.0 < nu < 30.0 or iters == 1
+    np.testing.assert_allclose(mu_d.cpu().numpy(), mu_h, rtol=0, atol=0)
+    Lh = L_d.cpu().numpy()
+    np.testing.assert_allclose(Lh @ Lh.T, cov_h, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(Linv_d.cpu().numpy() @ Lh, np.eye(d), atol=1e-10)
