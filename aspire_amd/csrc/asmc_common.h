@@ -12,6 +12,7 @@
 #define ASMC_MAX_BLOCKS 2048    // cap for grid-stride reduction kernels (256 CUs x 8)
 #define ASMC_SCAN_TILE 2048     // elements per scan tile (256 threads x 8)
 #define ASMC_PCN_MAX_GRID (1 << 20)  // blocks per pCN launch (>= 64 particles each): up to 67M particles per rank
+#define ASMC_GAMMA_BATCH 8       // Markov steps whose tpCN scale variates one k_gamma_draw launch draws (ctx->d_gamma holds that many)
 #define ASMC_MAX_PCN_STEPS 2048 // per asmc_pcn_mutate call (bounded by the pinned staging buffer)
 // Box-Muller tables of the default noise (asmc_pcn_dev.h bm_pair32): entries of two doubles
 #define BM_SC_N 256                   // [0, 256): (sin, cos)(2 pi (k + 1/2) / 256)
@@ -80,7 +81,13 @@ struct asmc_ctx {
     double* d_gram;                // [gram_blocks * d_max * d_max] gram partials
     unsigned int* d_guide;         // [n_max / 4 + 8] guide table of the resampling search
     unsigned char* d_flags;        // [n_max + 64] accept flags of the split-path pCN step
-    double* d_gamma;               // [n_max] tpCN scale variates of the current step
+    double* d_gamma;               // [ASMC_GAMMA_BATCH][n_max] tpCN scale variates of the current steps
+    // which steps' variates ctx->d_gamma holds (pcn_prepare_gamma)
+    int64_t gam_n;
+    unsigned long long gam_seed, gam_gid0;
+    double gam_shape;
+    int gam_noise, gam_count;
+    uint32_t gam_step0;
     double* d_rec;                 // [4 * n_max] (ll, lp, lq, 0) records of asmc_gather's source population
     const void* rec_src[3];        // the arrays asmc_importance_step packed into d_rec (k_is_weights writes the records on
     int64_t rec_n;                 //   its way); rec_n != 0: still valid - the next asmc_gather of exactly these skips its packing pass

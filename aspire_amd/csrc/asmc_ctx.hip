@@ -169,7 +169,7 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     if (d_max > 32) dmalloc((void**)&c->d_mmtab, sizeof(double) * 2 * 144 * 64);  // (d in 33 .. 63 runs zero-padded on the d = 64 kernels)
     dmalloc((void**)&c->d_guide, sizeof(unsigned int) * ((size_t)n_max / 4 + 8));
     dmalloc((void**)&c->d_flags, (size_t)n_max + 64);
-    dmalloc((void**)&c->d_gamma, sizeof(double) * (size_t)n_max);
+    dmalloc((void**)&c->d_gamma, sizeof(double) * ((size_t)ASMC_GAMMA_BATCH * (size_t)n_max + 64 * ASMC_GAMMA_BATCH));
     dmalloc((void**)&c->d_rec, sizeof(double) * 4 * (size_t)n_max);
     const size_t student = (size_t)d_max * (d_max + 1) + (size_t)(ASMC_STUDENT_MAX_ROWS / 64) * (d_max + 2);
     dmalloc((void**)&c->d_student, sizeof(double) * student);

@@ -893,10 +893,11 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
     }
 }
 
-// tpCN: unit-scale Gamma(shape) variate of every particle for Markov step `step` (Marsaglia-Tsang, counter based)
+// tpCN: unit-scale Gamma(shape) variates of every particle for the Markov steps step .. step + nsteps - 1 (Marsaglia-Tsang,
+// counter based: a step's variates do not depend on the chain, so several steps are drawn by one launch)
 template <bool F32>
 __global__ __launch_bounds__(ASMC_BLOCK) void k_gamma_draw(int64_t n, double shape, unsigned long long seed,
-                                                          unsigned long long gid0, uint32_t step,
+                                                          unsigned long long gid0, uint32_t step, int nsteps, int64_t stride_n,
                                                           double* __restrict__ out, const double* __restrict__ bmtab) {
     bm_d2* bmt = nullptr;
     if constexpr (!F32) {
@@ -906,26 +907,43 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_gamma_draw(int64_t n, double sha
     }
     const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride)
-        out[i] = gamma_unit<F32>(shape, seed, gid0 + (unsigned long long)i, step, bmt);
+        for (int s = 0; s < nsteps; s++)
+            out[(size_t)s * stride_n + i] = gamma_unit<F32>(shape, seed, gid0 + (unsigned long long)i, step + (uint32_t)s, bmt);
 }
 
-// before a step kernel: draws the step's scale variates into ctx->d_gamma and points pd.gam at them (tpCN only)
+// before a step kernel: points pd.gam at the step's scale variates in ctx->d_gamma (tpCN only), drawing the next
+// ASMC_GAMMA_BATCH steps' worth when the step is not among those already there (one launch per eight steps instead of one
+// per step: 15 us of every 150 us step)
 static int pcn_prepare_gamma(asmc_ctx* ctx, int64_t n, PcnDev& pd, uint32_t step, hipStream_t st) {
     if (!(pd.nu > 0.0)) {
         pd.gam = nullptr;
         return ASMC_OK;
     }
-    const int grid = grid_for(n, ASMC_BLOCK, ASMC_MAX_BLOCKS * 4);
-    if (pd.noise == ASMC_NOISE_F32)
-        ASMC_LAUNCH(ctx, st, "k_gamma_draw", k_gamma_draw<true>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n,
-                    0.5 * ((double)(pd.d_noise > 0 ? pd.d_noise : pd.d) + pd.nu), (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma,
-                    (const double*)ctx->d_bmtab);
-    else
-        ASMC_LAUNCH(ctx, st, "k_gamma_draw", k_gamma_draw<false>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n,
-                    0.5 * ((double)(pd.d_noise > 0 ? pd.d_noise : pd.d) + pd.nu), (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, ctx->d_gamma,
-                    (const double*)ctx->d_bmtab);
-    ASMC_LAUNCH_CHECK();
-    pd.gam = ctx->d_gamma;
+    const double shape = 0.5 * ((double)(pd.d_noise > 0 ? pd.d_noise : pd.d) + pd.nu);
+    const int64_t stride_n = (n + 63) / 64 * 64;
+    const bool hit = ctx->gam_count > 0 && ctx->gam_n == n && ctx->gam_seed == (unsigned long long)pd.seed &&
+                     ctx->gam_gid0 == (unsigned long long)pd.gid0 && ctx->gam_shape == shape && ctx->gam_noise == pd.noise &&
+                     step >= ctx->gam_step0 && step - ctx->gam_step0 < (uint32_t)ctx->gam_count;
+    if (!hit) {
+        int batch = (int)((int64_t)ASMC_GAMMA_BATCH * ctx->n_max / stride_n);  // what the buffer holds
+        if (batch > ASMC_GAMMA_BATCH) batch = ASMC_GAMMA_BATCH;
+        if (batch < 1) batch = 1;
+        static const bool single = getenv("ASMC_GAMMA_PER_STEP") != nullptr;
+        if (single) batch = 1;
+        const int grid = grid_for(n, ASMC_BLOCK, ASMC_MAX_BLOCKS * 4);
+        if (pd.noise == ASMC_NOISE_F32)
+            ASMC_LAUNCH(ctx, st, "k_gamma_draw", k_gamma_draw<true>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, shape,
+                        (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, batch, stride_n, ctx->d_gamma,
+                        (const double*)ctx->d_bmtab);
+        else
+            ASMC_LAUNCH(ctx, st, "k_gamma_draw", k_gamma_draw<false>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, shape,
+                        (unsigned long long)pd.seed, (unsigned long long)pd.gid0, step, batch, stride_n, ctx->d_gamma,
+                        (const double*)ctx->d_bmtab);
+        ASMC_LAUNCH_CHECK();
+        ctx->gam_n = n, ctx->gam_seed = (unsigned long long)pd.seed, ctx->gam_gid0 = (unsigned long long)pd.gid0;
+        ctx->gam_shape = shape, ctx->gam_noise = pd.noise, ctx->gam_step0 = step, ctx->gam_count = batch;
+    }
+    pd.gam = ctx->d_gamma + (size_t)(step - ctx->gam_step0) * stride_n;
     return ASMC_OK;
 }
 
@@ -2814,7 +2832,8 @@ int asmc_pcn_ysplit_accept(asmc_ctx* ctx, int64_t n, const asmc_pcn_params* prm,
     hipStream_t st = as_stream(stream);
     pd.ys = ctx->d_ysoa;
     pd.n_pad = ((n + 63) / 64) * 64;
-    pd.gam = pd.nu > 0.0 ? ctx->d_gamma : nullptr;  // the variates asmc_pcn_ysplit_propose drew for this step
+    rc = pcn_prepare_gamma(ctx, n, pd, step, st);  // the variates asmc_pcn_ysplit_propose drew for this step (still there; else redrawn: counter based)
+    if (rc) return rc;
     int grid = 0;
     long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
     if (lj && prm->x_dtype == ASMC_F64)

@@ -849,8 +849,9 @@ def test_config5_shape_mixture_d128_mfma_kernels(eng, step_fn):
     assert rep["k_tpcn_mm_step" if step_fn == "tpcn" else "k_pcn_mm_step"][0] >= 6 and "k_pcn_step_generic" not in rep
     if step_fn == "pcn":  # Gaussian reference: population moments through the matrix-core Gram kernel
         assert rep["k_gram_mm"][0] >= 1
-    else:  # Student-t reference: fitted on a host subsample, scale variates from their own kernel
-        assert rep["k_gamma_draw"][0] == rep["k_tpcn_mm_step"][0] and len(sp.history.mcmc_nu) == len(sp.history.beta)
+    else:  # Student-t reference: fitted to a subsample on the device, scale variates from their own kernel (several steps per launch)
+        assert 1 <= rep["k_gamma_draw"][0] <= rep["k_tpcn_mm_step"][0] and len(sp.history.mcmc_nu) == len(sp.history.beta)
+        assert "k_student_mstep" in rep
     # Z = 0.5 * N(2; 0, (1 + 0.5) I) + 0.5 * N(-2; 0, (1 + 1) I)   (Gaussian convolution), per-dim product
     def lg(mu, var):
         return -0.5 * d * np.log(2 * np.pi * var) - 0.5 * d * mu * mu / var
@@ -1359,7 +1360,7 @@ def test_tpcn_step_vs_oracle(eng, oracle, d, C, n_steps, noise, nu):
                                  dm[2], seed, gid0, rho, n_steps, step0, 0.234, False, noise, nu)
     rep = eng.profile_report()
     eng.profile(False)
-    assert rep["k_gamma_draw"][0] == n_steps
+    assert rep["k_gamma_draw"][0] == -(-n_steps // 8)  # one launch draws the variates of eight steps
     if d in (64, 128):
         assert rep["k_tpcn_mm_step"][0] == n_steps
     elif d in (4, 8, 16, 32):
