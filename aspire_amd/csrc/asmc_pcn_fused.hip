@@ -429,7 +429,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
 #ifndef FUSED_FLOW2
 #define FUSED_FLOW2 1  // both tiles through each coupling layer together, MFMAs and conversions interleaved by hand (asmc_flow_dev.h)
 #endif
-        if (HS && FUSED_FLOW2) {
+        if (HS && FUSED_FLOW2 && W < 128) {  // (W = 128: the two interleaved tiles need 288 accumulator registers - one tile at a time there)
             float ladjA = 0.0f, ladjB = 0.0f;
             unsigned amaxA = 0u, amaxB = 0u;  // packed fp16 running maxima of the operands' hi halves
             for (int c = 0; c < n_layers; c++) {
@@ -588,11 +588,10 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
     *grid_out = grid;
     // flow arithmetic: split-fp16 MFMA (fp32-equivalent operands, asmc_flow_dev.h) unless ASMC_FLOW_MATH=f32 asks for the
     // fp32 MFMA chain
-    // Hidden width 128 stays on the fp32 MFMA chain: its split-fp16 instantiation needs 288 accumulator registers for the two
-    // interleaved tiles, the compiler spills ~300 of them around the hand-scheduled conversion / MFMA sequence, and the step
-    // then returns run-to-run different log q (tools/stress_fused.py: every run at 100k particles; the fp32 chain: none in
-    // thousands).  Until that instantiation is restructured (one tile at a time) the slower, exact chain serves W = 128.
-    const bool hs = asmc_flow_math_split() && f->hidden != 128;
+    // (Hidden width 128 goes through its coupling layers ONE flow tile at a time: the two interleaved tiles of coupling_layer_hs2
+    // need 288 accumulator registers there, the compiler spilled ~300 around the hand-scheduled conversion / MFMA sequence and
+    // the step returned run-to-run different log q - tools/stress_fused.py.)
+    const bool hs = asmc_flow_math_split();
 #define ASMC_FUSED_CASE(WW, NZ, HSV)                                                                                     \
     if (f->hidden == WW && pd.noise == NZ && hs == HSV) {                                                                \
         auto kern = k_pcn_flow_fused<T, WW, NZ, HSV>;                                                                         \
@@ -620,7 +619,9 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
     ASMC_FUSED_CASE(32, ASMC_NOISE_F64, false)
     ASMC_FUSED_CASE(32, ASMC_NOISE_F32, true)
     ASMC_FUSED_CASE(32, ASMC_NOISE_F32, false)
+    ASMC_FUSED_CASE(128, ASMC_NOISE_F64, true)
     ASMC_FUSED_CASE(128, ASMC_NOISE_F64, false)
+    ASMC_FUSED_CASE(128, ASMC_NOISE_F32, true)
     ASMC_FUSED_CASE(128, ASMC_NOISE_F32, false)
 #endif
 #undef ASMC_FUSED_CASE
