@@ -2975,9 +2975,10 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
     long long* d_counts = ctx->d_counts;
     unsigned long long* d_cnt = ctx->d_keys;  // accept counter of the current step
     unsigned char* flags = ctx->d_flags;
-    ASMC_HIP(hipStreamSynchronize(st));
-    ctx->h_pinned[0] = *rho_inout_host;
-    ASMC_HIP(hipMemcpyAsync(d_rho, ctx->h_pinned, sizeof(double), hipMemcpyHostToDevice, st));
+    // the step size goes to the device as a kernel argument: no pinned staging, so no synchronisation in front of this call's
+    // launches - the host enqueues the whole mutation while the reference fit's passes are still running
+    ASMC_LAUNCH(ctx, st, "k_set_scalar", k_set_scalar, dim3(1), dim3(1), 0, st, d_rho, *rho_inout_host);
+    ASMC_LAUNCH_CHECK();
     // register-resident whitened-state path (d in {4, 8, 16, 32}): x -> y once, then per step
     // propose / flow / accept / adapt, y -> x at the end; four launches per step, no host round trip
     const bool reg_ok = pcn_reg_supported(d, prm->x_dtype == ASMC_F64 ? 8 : 4, x) && !getenv("ASMC_PCN_XSTATE");
