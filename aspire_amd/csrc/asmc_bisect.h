@@ -138,7 +138,7 @@ BIS_HD void bis_plan(double* st, bool first, const double* beta, const double* m
         K_lo = 0, K_hi = 1LL << LU;
         K_first = stride = 1LL << (LU - 4);
         y_lo = -log(target), y_hi = y[15], bmin = beta0, bmax = 1.0, window = 0, trip_ok = false;
-        mode = st[BIS_MODE] != 0.0;  // a caller may start in plain mode (ablation: ASMC_SEARCH_PLAIN)
+        mode = st[BIS_MODE] != 0.0;  // a caller may start in plain mode (ablation: ASMC_BISECT_PLAIN)
         st[BIS_WINDOWS] = st[BIS_MISSES] = 0.0;
         st[BIS_EFF_ONE] = eff[15];
         st[BIS_S1_ONE] = S[30], st[BIS_S2_ONE] = S[31];

@@ -341,10 +341,10 @@ __device__ __forceinline__ double ess_over_n(double m, double S1, double S2, dou
 
 struct BisInit {
     double beta0, target, tol, logN, N;
-    double plain;  // 1: no prediction windows (ASMC_SEARCH_PLAIN: the 16-ary search of rounds 1-2, for comparison)
+    double plain;  // 1: no prediction windows (ASMC_BISECT_PLAIN: the 16-ary search of rounds 1-2, for comparison)
 };
 static double bis_plain_mode() {
-    static const double v = getenv("ASMC_SEARCH_PLAIN") ? 1.0 : 0.0;
+    static const double v = getenv("ASMC_BISECT_PLAIN") ? 1.0 : 0.0;
     return v;
 }
 
