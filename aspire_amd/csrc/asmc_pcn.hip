@@ -2068,6 +2068,65 @@ int asmc_reference_factor(asmc_ctx* ctx, int d, int64_t n_mean, int64_t n_cov, c
     return ASMC_OK;
 }
 
+// The sharded form of the same fit without a host round trip: column sums and the centred Gram matrix into the CALLER's device
+// buffers (the caller sums each over the ranks with its own stream-ordered all-reduce), then the factorisation from them.
+__global__ __launch_bounds__(256) void k_copy_doubles(int n, const double* __restrict__ src, double* __restrict__ dst) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n) dst[e] = src[e];
+}
+
+int asmc_colsum_dev(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, double* sum_dev, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && sum_dev, "null pointer");
+    ASMC_REQUIRE(n > 0 && d > 0 && d <= ctx->d_max && d <= ASMC_BLOCK, "bad sizes");
+    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    hipStream_t st = as_stream(stream);
+    const int grid = grid_for(n, (ASMC_BLOCK / d) * 16, ctx->gram_blocks);
+    if (x_dtype == ASMC_F64)
+        ASMC_LAUNCH(ctx, st, "k_colsum<double>", k_colsum<double>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const double*)x, ctx->d_gram);
+    else
+        ASMC_LAUNCH(ctx, st, "k_colsum<float>", k_colsum<float>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const float*)x, ctx->d_gram);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(d), dim3(64), 0, st, grid, d, (const double*)ctx->d_gram, sum_dev);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_centered_gram_dev(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* sum_dev, int64_t n_mean,
+                           double* gram_dev, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && sum_dev && gram_dev, "null pointer");
+    ASMC_REQUIRE(n > 0 && n_mean > 0 && d > 0 && d <= ctx->d_max && d <= 128, "bad sizes (gram supports d <= 128)");
+    ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    if (!asmc_gram_mm_supported(d, x) || getenv("ASMC_GRAM_GENERIC")) {
+        asmc_set_error("asmc_centered_gram_dev: shape without the matrix-core Gram kernel (d in {32, 64, 128}, 16-byte aligned rows)");
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = as_stream(stream);
+    double* d_center = ctx->d_small + 2048;
+    ASMC_LAUNCH(ctx, st, "k_center_from_sum", k_center_from_sum, dim3(1), dim3(128), 0, st, d, sum_dev, (double)n_mean, d_center);
+    ASMC_LAUNCH_CHECK();
+    int ggrid = 0;
+    const int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &ggrid, st);
+    if (rc) return rc;
+    ASMC_LAUNCH(ctx, st, "k_copy_doubles", k_copy_doubles, dim3((d * d + 255) / 256), dim3(256), 0, st, d * d, (const double*)ctx->d_partials,
+                gram_dev);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_reference_factor_dev(asmc_ctx* ctx, int d, int64_t n_mean, int64_t n_cov, const double* sum_dev, const double* gram_dev,
+                              double* out_dev, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && sum_dev && gram_dev && out_dev, "null pointer");
+    ASMC_REQUIRE(d > 0 && d <= 128 && n_mean > 0 && n_cov > 0, "bad sizes (d <= 128)");
+    hipStream_t st = as_stream(stream);
+    double* d_status = ctx->d_small + 2300;
+    const int rc = asmc_ref_factor_launch(ctx, d, sum_dev, gram_dev, (double)n_mean, (double)(n_cov - 1 > 1 ? n_cov - 1 : 1), out_dev,
+                                          d_status, nullptr, nullptr, 0, st);
+    if (rc) return rc;
+    ctx->h_pinned[8010] = -2.0;
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8010, d_status, sizeof(double), hipMemcpyDeviceToHost, st));
+    return ASMC_OK;
+}
+
 int asmc_reference_factor_status(asmc_ctx* ctx, int* status_host) {
     ASMC_REQUIRE(ctx && status_host, "null pointer");
     *status_host = (int)ctx->h_pinned[8010];  // -2: the stream has not been synchronised since asmc_reference_factor

@@ -634,7 +634,22 @@ class HipEngine:
         check(self.lib.asmc_mean_gram_fetch(self._ctx, d, _f64p(s), _f64p(g), self._stream), "asmc_mean_gram_fetch")
         return s, g
 
-    def reference_factor(self, d: int, n_mean: int, n_cov: int, moments=None):
+    def colsum_dev(self, x: torch.Tensor) -> torch.Tensor:
+        """Column sums of this rank's rows as a device tensor (no synchronisation): the caller all-reduces them on the stream."""
+        n, d = x.shape
+        s = self.empty(d)
+        check(self.lib.asmc_colsum_dev(self._ctx, n, d, self._xdt(x), _dptr(x), _dptr(s), self._stream), "asmc_colsum_dev")
+        return s
+
+    def centered_gram_dev(self, x: torch.Tensor, sums: torch.Tensor, n_mean: int) -> torch.Tensor:
+        """Gram matrix of this rank's rows around sums / n_mean (device tensors in and out, no synchronisation); d in {32, 64, 128}."""
+        n, d = x.shape
+        g = self.empty((d, d))
+        check(self.lib.asmc_centered_gram_dev(self._ctx, n, d, self._xdt(x), _dptr(x), _dptr(sums), int(n_mean), _dptr(g),
+                                              self._stream), "asmc_centered_gram_dev")
+        return g
+
+    def reference_factor(self, d: int, n_mean: int, n_cov: int, moments=None, moments_dev=None):
         """(mu, L, Linv) of the mutation's reference Gaussian as device tensors, factored ON the device behind the moments of
         the pending `mean_gram_enqueue` (moments=None: consumed, no fetch follows) or of `moments` = (sums, Gram) merged on the
         host (include/asmc.h asmc_reference_factor).  Nothing is synchronised: `reference_factor_status()` after the next
@@ -647,6 +662,13 @@ class HipEngine:
         if bufs.get(("buf", slot)) is None or bufs[("buf", slot)].numel() != size:
             bufs[("buf", slot)] = torch.zeros(size, dtype=torch.float64, device=self.device)
         out = bufs[("buf", slot)]
+        if moments_dev is not None:  # (sums, Gram) already on the device (summed over the ranks by the caller)
+            s_d, g_d = moments_dev
+            assert s_d.dtype == torch.float64 and g_d.dtype == torch.float64 and s_d.numel() == d and g_d.numel() == d * d
+            self._ref_keep = (s_d, g_d)  # the kernel reads them when the stream gets there
+            check(self.lib.asmc_reference_factor_dev(self._ctx, d, int(n_mean), int(n_cov), _dptr(s_d), _dptr(g_d), _dptr(out),
+                                                     self._stream), "asmc_reference_factor_dev")
+            return out[:d], out[seg:seg + d * d].view(d, d), out[seg + seg * d:seg + seg * d + d * d].view(d, d)
         if moments is None:
             sp, gp = None, None
         else:

@@ -469,6 +469,15 @@ class HipSMC(SMCSampler):
                 return e.reference_factor(x.shape[1], n, n)
             s, g = e.mean_gram(x, n, comm)  # ... and both sums cross the ranks on the stream (RCCL all-reduce)
             mean = s / n
+        elif (device_fit and comm.sharded and hasattr(e, "colsum_dev") and hasattr(comm, "all_reduce_sum_")
+              and x.shape[1] in (32, 64, 128) and not os.environ.get("ASMC_GRAM_GENERIC")):
+            # sharded, no communicator of the library's own: the rank's sums and Gram matrix stay on the device, torch.distributed
+            # sums them over the ranks on the stream (RCCL), the factorisation follows - no host round trip
+            xs = x if x.data_ptr() % 16 == 0 else x.clone()  # (a rank-local property must not pick the code path of a sharded run)
+            s_d = comm.all_reduce_sum_(e.colsum_dev(xs))
+            g_d = comm.all_reduce_sum_(e.centered_gram_dev(xs, s_d, n))
+            self._ref_fit_pending = True
+            return e.reference_factor(x.shape[1], n, n, moments_dev=(s_d, g_d))
         else:
             parts = comm.all_gather_f64(e.colsum(x))
             s = parts[0].copy()

@@ -423,6 +423,15 @@ int asmc_mean_gram_fetch(asmc_ctx* ctx, int d, double* sum_host, double* gram_ho
 int asmc_reference_factor(asmc_ctx* ctx, int d, int64_t n_mean, int64_t n_cov, const double* sum_host, const double* gram_host,
                           double* out_dev, asmc_stream stream);
 int asmc_reference_factor_status(asmc_ctx* ctx, int* status_host);
+/* The same fit for a sharded population without a host round trip: the rank's column sums / centred Gram matrix (centre =
+ * sum_dev / n_mean, i.e. the GLOBAL sums and population once the caller has all-reduced sum_dev) land in the caller's device
+ * buffers, the caller sums them over the ranks on the stream (torch.distributed all_reduce = RCCL), and asmc_reference_factor_dev
+ * factors the result.  asmc_centered_gram_dev: d in {32, 64, 128}, 16-byte aligned rows (ASMC_ERR_UNSUPPORTED otherwise). */
+int asmc_colsum_dev(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, double* sum_dev /* [d] */, asmc_stream stream);
+int asmc_centered_gram_dev(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, const double* sum_dev, int64_t n_mean,
+                           double* gram_dev /* [d, d] */, asmc_stream stream);
+int asmc_reference_factor_dev(asmc_ctx* ctx, int d, int64_t n_mean, int64_t n_cov, const double* sum_dev, const double* gram_dev,
+                              double* out_dev, asmc_stream stream);
 int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev,
                        const double* center_host, double* gram_host, asmc_stream stream);
 int asmc_pcn_mutate(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, double* lp_dev,

@@ -1994,6 +1994,14 @@ def test_reference_factor_on_the_device_vs_numpy(eng, d):
         check(*eng.reference_factor(d, n, n))
         with pytest.raises(Exception, match="pending"):
             eng.mean_gram_fetch(d)  # consumed by the factorisation
+        # the sharded form: sums and Gram matrix in the caller's device buffers (all-reduced there by the caller), same bits
+        s_d = eng.colsum_dev(x)
+        g_d = eng.centered_gram_dev(x, s_d, n)
+        assert np.array_equal(s_d.cpu().numpy(), s) and np.array_equal(g_d.cpu().numpy(), gram)
+        mu2, L2, Li2 = eng.reference_factor(d, n, n, moments_dev=(s_d, g_d))
+        mu1, L1, Li1 = eng.reference_factor(d, n, n, moments=(s, gram))
+        torch.cuda.synchronize()
+        assert torch.equal(mu1, mu2) and torch.equal(L1, L2) and torch.equal(Li1, Li2)
     # a rank-deficient covariance needs the jitter; a NaN cannot be factored
     v = np.ones((d, 1))
     mu, L, Linv = eng.reference_factor(d, n, n, moments=(np.zeros(d), (n - 1) * (v @ v.T)))
