@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from ._xp import is_torch_namespace, to_numpy
-from .flows import CouplingFlow, Flow, GaussianFlow
+from .flows import CouplingFlow, Flow, GaussianFlow, MAFFlow
 from .history import FlowHistory, History
 from .samples import Samples
 from .samplers.base import IdentityTransform, Sampler
@@ -85,7 +85,8 @@ class Aspire:
         return samples
 
     def init_flow(self):
-        """aspire.py:177-206.  Backends: "coupling" (PyTorch RealNVP) and "gaussian" (analytic, HIP).
+        """aspire.py:177-206.  Backends: "coupling" (PyTorch RealNVP, HIP kernels in the hot path), "maf" (masked autoregressive
+        flow, the reference's default flow class; PyTorch passes only) and "gaussian" (analytic, HIP).
         "zuko" is accepted when zuko is importable and otherwise maps to "coupling" with a warning
         (zuko is not part of this image)."""
         backend = self.flow_backend.lower()
@@ -106,7 +107,14 @@ class Aspire:
         if backend == "zuko":
             logger.warning("flow_backend='zuko' is not available here; using the built-in coupling flow")
             backend = "coupling"
-        if backend == "coupling":
+        if backend == "maf" or str(self.flow_kwargs.get("flow_class", "")).upper() == "MAF":
+            # the reference's default flow class (ZukoFlow(flow_class="MAF"), flows/torch/flows.py:140-164): PyTorch passes only
+            kw = {k: v for k, v in self.flow_kwargs.items() if k != "flow_class"}
+            if "transforms" in kw:  # zuko's name for the number of autoregressive transforms
+                kw["n_transforms"] = int(kw.pop("transforms"))
+            self._flow = MAFFlow(dims=self.dims, device=self.device or "cpu", data_transform=data_transform,
+                                 dtype=kw.pop("flow_dtype", torch.float32), **kw)
+        elif backend == "coupling":
             kw = dict(self.flow_kwargs)
             self._flow = CouplingFlow(dims=self.dims, device=self.device or "cpu", data_transform=data_transform,
                                       dtype=kw.pop("flow_dtype", torch.float32), **kw)

@@ -484,3 +484,94 @@ class CouplingFlow(Flow):
     @torch.no_grad()
     def inverse(self, z, xp=None):
         return self._from_latent(torch.as_tensor(z, dtype=self.dtype, device=self.device))
+
+
+class _MaskedLinear(torch.nn.Linear):
+    """Linear layer whose weight is multiplied by a fixed 0/1 mask (MADE, Germain et al. 2015)."""
+
+    def __init__(self, n_in, n_out, mask):
+        super().__init__(n_in, n_out)
+        self.register_buffer("mask", mask)
+
+    def forward(self, x):
+        return torch.nn.functional.linear(x, self.weight * self.mask, self.bias)
+
+
+class _Autoregressive(torch.nn.Module):
+    """One masked autoregressive affine transform: z_i = (x_i - t_i(x_<i)) exp(-s_i(x_<i)) in the layer's variable order
+    (`order[k]` = position of variable k; reversed on every other layer).  data -> latent is one pass of the masked MLP,
+    latent -> data one pass per variable."""
+
+    def __init__(self, dims, hidden, reverse):
+        super().__init__()
+        deg_in = torch.arange(1, dims + 1)
+        if reverse:
+            deg_in = deg_in.flip(0)
+        self.register_buffer("order", deg_in)
+        layers, deg_prev = [], deg_in
+        for h in hidden:
+            deg_h = (torch.arange(h) % max(dims - 1, 1)) + 1
+            layers += [_MaskedLinear(len(deg_prev), h, (deg_h[:, None] >= deg_prev[None, :]).to(torch.get_default_dtype())),
+                       torch.nn.ReLU()]
+            deg_prev = deg_h
+        deg_out = torch.cat([deg_in, deg_in])  # (log-scale, shift) of variable k see variables of strictly lower degree
+        layers.append(_MaskedLinear(len(deg_prev), 2 * dims, (deg_out[:, None] > deg_prev[None, :]).to(torch.get_default_dtype())))
+        self.net = torch.nn.Sequential(*layers)
+        torch.nn.init.zeros_(self.net[-1].weight)
+        torch.nn.init.zeros_(self.net[-1].bias)
+        self.dims = dims
+
+    def _st(self, x):
+        h = self.net(x)
+        return 2.0 * torch.tanh(h[:, : self.dims] / 2.0), h[:, self.dims:]  # bounded log-scale, as the coupling layers
+
+    def forward(self, x):  # data -> latent
+        s, t = self._st(x)
+        return (x - t) * torch.exp(-s), -s.sum(-1)
+
+    def inverse(self, z):  # latent -> data: variable of degree 1 first
+        x = torch.zeros_like(z)
+        for k in torch.argsort(self.order).tolist():
+            s, t = self._st(x)
+            x[:, k] = z[:, k] * torch.exp(s[:, k]) + t[:, k]
+        s, _ = self._st(x)
+        return x, s.sum(-1)
+
+
+class MAFFlow(CouplingFlow):
+    """Masked autoregressive flow (Papamakarios et al. 2017) - the flow class the reference asks zuko for by default
+    (`ZukoFlow(flow_class="MAF")`, flows/torch/flows.py:140-164; zuko is absent from this image, so this is the repository's
+    own statement of the architecture: `n_transforms` MADE transforms with alternating variable order, affine with a bounded
+    log-scale).  Training, sampling, `log_prob`, `forward` / `inverse`, save / load are CouplingFlow's; the passes themselves
+    run in PyTorch (north star: PyTorch-ROCm for the flow forward / inverse pass) - there is no HIP kernel for this flow, so a
+    mutation with it evaluates log q between the device-side propose and accept halves (`HipSMC.last_mutation_path`)."""
+
+    def __init__(self, dims: int, n_transforms: int = 3, hidden_features=(64, 64), seed: int = 1234, device=None,
+                 dtype=torch.float32, data_transform=None):
+        Flow.__init__(self, dims, device=torch.device(device or "cpu"), data_transform=data_transform)
+        self.dtype = dtype
+        torch.manual_seed(seed)
+        hidden = tuple(map(int, hidden_features))
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            self.layers = torch.nn.ModuleList([_Autoregressive(dims, hidden, reverse=bool(i % 2)) for i in range(n_transforms)])
+        finally:
+            torch.set_default_dtype(prev)
+        self.layers.to(device=self.device, dtype=dtype)
+        self.loc = torch.zeros(dims, device=self.device, dtype=dtype)
+        self.scale = torch.ones(dims, device=self.device, dtype=dtype)
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(seed)
+        self._packed, self._version = None, 0
+        self._init_args = dict(dims=int(dims), n_transforms=int(n_transforms), hidden_features=[int(h) for h in hidden],
+                               seed=int(seed), dtype=str(dtype).replace("torch.", ""))
+
+    def export_layers(self):
+        raise ValueError("a masked autoregressive flow has no HIP kernel: its passes run in PyTorch")
+
+    def device_coupling(self, engine):
+        raise ValueError("a masked autoregressive flow has no HIP kernel: its passes run in PyTorch")
+
+    def _sample_on_engine(self, n_samples: int):
+        return None

@@ -2082,3 +2082,21 @@ def test_student_fit_on_the_device_vs_numpy_em(eng, m, d, iters):
     Lh = L_d.cpu().numpy()
     np.testing.assert_allclose(Lh @ Lh.T, cov_h, rtol=1e-11, atol=1e-12)
     np.testing.assert_allclose(Linv_d.cpu().numpy() @ Lh, np.eye(d), atol=1e-10)
+
+
+def test_sampler_with_a_maf_proposal_gpu(eng):
+    """The reference's default flow class as the proposal (MAFFlow: PyTorch passes, no HIP kernel): the mutation evaluates log q
+    between the device-side propose and accept halves; evidence of the Gaussian product within its error bar."""
+    from aspire_amd.flows import MAFFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    d, n = 8, 50000
+    flow = MAFFlow(d, n_transforms=2, hidden_features=(32, 32), seed=3, device=eng.device)
+    flow.fit(1.3 * np.random.default_rng(0).normal(size=(4000, d)), n_epochs=6)
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=torch, engine=eng, rng=np.random.default_rng(4))
+    out = sp.sample(n, sampler_kwargs=dict(n_steps=8, step_fn="pcn"), store_sample_history=False)
+    assert "callables" in sp.last_mutation_path
+    assert abs(float(out.log_evidence) - 0.5 * d * math.log(math.pi)) < 5 * float(out.log_evidence_error) + 0.02
+    assert 0.05 < np.mean(sp.history.mcmc_acceptance) < 0.99
