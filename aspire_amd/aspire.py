@@ -179,8 +179,17 @@ class Aspire:
                                                device=self.device, dtype=self.dtype, **pk)
             else:  # the reference builds a CompositeTransform with every stage off: the identity
                 transform = IdentityTransform(xp=self.xp)
-        elif preconditioning == "flow":
-            raise NotImplementedError("flow preconditioning is out of scope (SURVEY.md §2)")
+        elif preconditioning == "flow":  # aspire.py:351-366: a flow refitted to the particles at every temperature
+            from .transforms import FlowPreconditioningTransform
+
+            pk = dict(preconditioning_kwargs or {})
+            pk.setdefault("affine_transform", False)
+            params = self.parameters if self.parameters is not None else [f"x_{i}" for i in range(self.dims)]
+            transform = FlowPreconditioningTransform(parameters=params, flow_backend=self.flow_backend,
+                                                     flow_kwargs=self.flow_kwargs, flow_matching=self.flow_matching,
+                                                     periodic_parameters=self.periodic_parameters,
+                                                     bounded_to_unbounded=self.bounded_to_unbounded, prior_bounds=self.prior_bounds,
+                                                     xp=self.xp, dtype=self.dtype, device=self.device, **pk)
         else:
             raise ValueError(f"Unknown preconditioning: {preconditioning}")
         return SamplerClass(log_likelihood=self.log_likelihood, log_prior=self.log_prior, dims=self.dims,

@@ -203,3 +203,103 @@ class FlowTransform(CompositeTransform):
         cfg = super().config_dict()
         cfg.pop("periodic_parameters", None)
         return cfg
+
+
+class FlowPreconditioningTransform:
+    """`preconditioning="flow"` (reference transforms.py:649-748): at every temperature a normalising flow is trained on the
+    current particles and the Markov chain runs in its latent space, z = flow(T(x)) with T the composite data transform
+    (periodic / bounded / affine stages) the reference puts in front of the flow.  The flow is one of this package's
+    (`flow_backend` "coupling" or "maf"; zuko is absent); its passes and its training run in PyTorch, the composite stages on
+    the engine.  `HipSMC._mutate_preconditioned` drives it through the split propose / accept kernels like any user transform."""
+
+    def __init__(self, parameters: list, flow_backend: str = "coupling", prior_bounds: dict | None = None,
+                 bounded_to_unbounded: bool = True, bounded_transform: str = "probit", affine_transform: bool = True,
+                 periodic_parameters: list | None = None, device=None, xp=None, eps: float = 1e-6, dtype: Any = None,
+                 flow_matching: bool = False, flow_kwargs: dict | None = None, fit_kwargs: dict | None = None, engine=None):
+        if flow_matching:
+            raise NotImplementedError("flow matching is out of scope (SURVEY.md §2)")
+        self.parameters, self.periodic_parameters = parameters, periodic_parameters or []
+        self.prior_bounds, self.bounded_to_unbounded, self.bounded_transform = prior_bounds, bounded_to_unbounded, bounded_transform
+        self.affine_transform, self.eps, self.device, self.xp, self.dtype = affine_transform, eps, device, xp, dtype
+        fc, fb = str((flow_kwargs or {}).get("flow_class", "")).upper(), str(flow_backend).lower()
+        self.flow_backend = "maf" if (fc == "MAF" or fb == "maf") else "coupling" if fb in ("coupling", "zuko") else fb
+        if self.flow_backend not in ("maf", "coupling"):
+            raise ValueError(f"flow preconditioning needs a trainable flow (backend 'coupling' or 'maf'), not {flow_backend!r}")
+        self.flow_matching = flow_matching
+        self.flow_kwargs = {k: v for k, v in dict(flow_kwargs or {}).items() if k != "flow_class"}
+        self.fit_kwargs = dict(fit_kwargs or {})
+        self.engine = engine
+        self._data_transform = CompositeTransform(parameters=parameters, periodic_parameters=periodic_parameters,
+                                                  prior_bounds=prior_bounds, bounded_to_unbounded=bounded_to_unbounded,
+                                                  bounded_transform=bounded_transform, affine_transform=affine_transform,
+                                                  device=device, xp=xp, eps=eps, dtype=dtype, engine=engine)
+        self.flow = None
+
+    is_identity = False
+
+    def _flow_device(self, like):
+        import torch
+
+        return like.device if isinstance(like, torch.Tensor) else torch.device(self.device or "cpu")
+
+    def fit(self, x, comm: Comm | None = None):
+        import torch
+
+        from .flows import CouplingFlow, MAFFlow
+
+        if self._data_transform.engine is None:
+            self._data_transform.engine = self.engine
+        u = self._data_transform.fit(x, comm=comm)
+        ut = torch.as_tensor(u) if not isinstance(u, torch.Tensor) else u
+        kw = dict(self.flow_kwargs)
+        if "transforms" in kw:
+            kw["n_transforms"] = int(kw.pop("transforms"))
+        cls = MAFFlow if self.flow_backend == "maf" else CouplingFlow
+        self.flow = cls(dims=len(self.parameters), device=self._flow_device(ut), dtype=kw.pop("flow_dtype", torch.float32), **kw)
+        self.flow.fit(ut, **self.fit_kwargs)
+        if comm is not None and comm.sharded:
+            self.flow.sync_shards(comm)  # every rank's chain must run in the SAME latent space
+        return self._cast(self.flow.forward(ut)[0], u)
+
+    def _cast(self, z, like):
+        import torch
+
+        if isinstance(like, torch.Tensor):
+            return z.to(like.dtype)
+        return z.double().cpu().numpy()
+
+    def forward(self, x):
+        import torch
+
+        u, lj1 = self._data_transform.forward(x)
+        ut = torch.as_tensor(u)
+        z, lj2 = self.flow.forward(ut)
+        if isinstance(u, torch.Tensor):
+            return z.to(u.dtype), torch.as_tensor(lj1, device=z.device).double() + lj2.double()
+        return z.double().cpu().numpy(), np.asarray(lj1) + lj2.double().cpu().numpy()
+
+    def inverse(self, z):
+        import torch
+
+        zt = torch.as_tensor(z)
+        u, lj2 = self.flow.inverse(zt)
+        if isinstance(z, torch.Tensor):
+            x, lj1 = self._data_transform.inverse(u.to(z.dtype))
+            return x, torch.as_tensor(lj1, device=u.device).double() + lj2.double()
+        x, lj1 = self._data_transform.inverse(u.double().cpu().numpy())
+        return x, np.asarray(lj1) + lj2.double().cpu().numpy()
+
+    def new_instance(self, xp=None, dtype: Any = None):
+        return self.__class__(parameters=self.parameters, periodic_parameters=self.periodic_parameters,
+                              prior_bounds=self.prior_bounds, bounded_to_unbounded=self.bounded_to_unbounded,
+                              bounded_transform=self.bounded_transform, affine_transform=self.affine_transform,
+                              device=self.device, xp=xp or self.xp, eps=self.eps, dtype=dtype or self.dtype,
+                              flow_backend=self.flow_backend, flow_matching=self.flow_matching, flow_kwargs=self.flow_kwargs,
+                              fit_kwargs=self.fit_kwargs, engine=self.engine)
+
+    def save(self, h5_file, path="data_transform"):
+        raise NotImplementedError("FlowPreconditioningTransform does not support save method yet.")  # transforms.py:745-748
+
+    def config_dict(self):
+        return {**self._data_transform.config_dict(), "flow_backend": self.flow_backend, "flow_kwargs": self.flow_kwargs,
+                "fit_kwargs": self.fit_kwargs}
