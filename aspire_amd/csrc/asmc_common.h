@@ -33,6 +33,7 @@ void asmc_prof_end(asmc_ctx* ctx, hipStream_t st);
 #define ASMC_LAUNCH(ctx, st, label, ...)   \
     do {                                   \
         (ctx)->rec_n = 0; /* any launch may rewrite the arrays ctx->d_rec was packed from */ \
+        (ctx)->cs_n = 0;  /* ... or the scratch that holds a gather's column-sum partials */ \
         if ((ctx)->poison_lds) asmc_poison_lds((ctx), (st)); \
         asmc_prof_begin((ctx), (label), (st)); \
         hipLaunchKernelGGL(__VA_ARGS__);   \
@@ -91,6 +92,9 @@ struct asmc_ctx {
     double* d_rec;                 // [4 * n_max] (ll, lp, lq, 0) records of asmc_gather's source population
     const void* rec_src[3];        // the arrays asmc_importance_step packed into d_rec (k_is_weights writes the records on
     int64_t rec_n;                 //   its way); rec_n != 0: still valid - the next asmc_gather of exactly these skips its packing pass
+    const void* cs_x;              // the fp64 rows asmc_gather wrote last, whose column-sum partials sit in d_gram [cs_grid][cs_d]
+    int64_t cs_n;                  //   (cs_n != 0: still there - an asmc_mean_gram_enqueue of exactly these rows skips its k_colsum pass)
+    int cs_d, cs_grid;
     void* d_ysoa;                  // coordinate-major whitened state of a mutation (grown on demand)
     void* d_xpad;                  // zero-padded tables + rows of a mutation whose d has no kernels of its own (grown on demand)
     size_t xpad_bytes;

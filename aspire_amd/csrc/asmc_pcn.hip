@@ -1982,7 +1982,11 @@ int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const v
     ASMC_REQUIRE(!across_ranks || (allreduce && ctx->rccl_comm), "across_ranks needs asmc_set_rccl");
     hipStream_t st = as_stream(stream);
     int grid = grid_for(n, (ASMC_BLOCK / d) * 16, ctx->gram_blocks);
-    if (x_dtype == ASMC_F64)
+    // rows that asmc_gather has just written: their column-sum partials came with the gather (no pass over the rows)
+    const bool from_gather = ctx->cs_n == n && ctx->cs_x == x && ctx->cs_d == d && x_dtype == ASMC_F64;
+    if (from_gather)
+        grid = ctx->cs_grid;
+    else if (x_dtype == ASMC_F64)
         ASMC_LAUNCH(ctx, st, "k_colsum<double>", k_colsum<double>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const double*)x, ctx->d_gram);
     else
         ASMC_LAUNCH(ctx, st, "k_colsum<float>", k_colsum<float>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const float*)x, ctx->d_gram);
@@ -2080,8 +2084,11 @@ int asmc_colsum_dev(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x,
     ASMC_REQUIRE(n > 0 && d > 0 && d <= ctx->d_max && d <= ASMC_BLOCK, "bad sizes");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
     hipStream_t st = as_stream(stream);
-    const int grid = grid_for(n, (ASMC_BLOCK / d) * 16, ctx->gram_blocks);
-    if (x_dtype == ASMC_F64)
+    int grid = grid_for(n, (ASMC_BLOCK / d) * 16, ctx->gram_blocks);
+    const bool from_gather = ctx->cs_n == n && ctx->cs_x == x && ctx->cs_d == d && x_dtype == ASMC_F64;  // (see asmc_mean_gram_enqueue)
+    if (from_gather)
+        grid = ctx->cs_grid;
+    else if (x_dtype == ASMC_F64)
         ASMC_LAUNCH(ctx, st, "k_colsum<double>", k_colsum<double>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const double*)x, ctx->d_gram);
     else
         ASMC_LAUNCH(ctx, st, "k_colsum<float>", k_colsum<float>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const float*)x, ctx->d_gram);

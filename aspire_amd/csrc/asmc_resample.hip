@@ -1287,7 +1287,10 @@ __device__ __forceinline__ void gather_scalars(int64_t n_out, const int64_t* __r
     }
 }
 
-template <int SH>
+// CS: the rows are fp64 - the column sums of the gathered rows ride along (a lane always handles the same 16-byte piece of a
+// row: the grid stride is a multiple of the pieces per row), one partial row of d sums per block in cs_partials; the
+// reference fit behind the gather (asmc_mean_gram_enqueue) then needs no column-sum pass over the rows (70 us at 1M x 32).
+template <int SH, bool CS>
 __global__ __launch_bounds__(ASMC_BLOCK) void k_gather16_pow2(int64_t n_out, const int64_t* __restrict__ idx,
                                                              const LogRec* __restrict__ rec,
                                                              const uint4* __restrict__ x_in, uint4* __restrict__ x_out,
@@ -1295,7 +1298,8 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_gather16_pow2(int64_t n_out, con
                                                              const double* __restrict__ lp_in,
                                                              const double* __restrict__ lq_in,
                                                              double* __restrict__ ll_out, double* __restrict__ lp_out,
-                                                             double* __restrict__ lq_out) {
+                                                             double* __restrict__ lq_out, double* __restrict__ cs_partials) {
+    double cs0 = 0.0, cs1 = 0.0;
 #ifdef GATHER_U
     constexpr int U = GATHER_U;
 #else
@@ -1332,7 +1336,28 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_gather16_pow2(int64_t n_out, con
                 __builtin_nontemporal_store(v[q].y, &x_out[c].y);
                 __builtin_nontemporal_store(v[q].z, &x_out[c].z);
                 __builtin_nontemporal_store(v[q].w, &x_out[c].w);
+                if (CS) {
+                    cs0 += __longlong_as_double((long long)(((unsigned long long)v[q].y << 32) | v[q].x));
+                    cs1 += __longlong_as_double((long long)(((unsigned long long)v[q].w << 32) | v[q].z));
+                }
             }
+        }
+    }
+    if (CS) {
+        constexpr int CPR = 1 << SH;
+        __shared__ double s_cs[ASMC_BLOCK / 64][2 * CPR];
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) {
+            cs0 += __shfl_xor(cs0, o, 64);
+            cs1 += __shfl_xor(cs1, o, 64);
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane < CPR) s_cs[wave][2 * lane] = cs0, s_cs[wave][2 * lane + 1] = cs1;
+        __syncthreads();
+        if (threadIdx.x < 2 * CPR) {
+            double t = 0.0;
+            for (int w = 0; w < ASMC_BLOCK / 64; w++) t += s_cs[w][threadIdx.x];
+            cs_partials[(size_t)blockIdx.x * (2 * CPR) + threadIdx.x] = t;
         }
     }
     gather_scalars(n_out, idx, rec, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
@@ -1903,10 +1928,19 @@ int asmc_gather(asmc_ctx* ctx, int64_t n_in, int64_t n_out, const int64_t* idx, 
         const int cpr = (int)(rowbytes / 16);
         const int grid = grid_for(n_out * cpr, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
         static const bool plain_gather = getenv("ASMC_GATHER_PLAIN") != nullptr;
+        bool cs_done = false;
+        // fp64 rows of a width the moment kernels take: the column sums of the gathered rows ride along (tagged below)
+        const bool cs = x_dtype == ASMC_F64 && (d == 32 || d == 64 || d == 16) && (size_t)grid * d <= ctx->gram_cap &&
+                        !getenv("ASMC_GATHER_NO_COLSUM");
 #define ASMC_GATHER_POW2(SHV)                                                                                       \
     if (!plain_gather && cpr == (1 << SHV)) {                                                                      \
-        ASMC_LAUNCH(ctx, st, "k_gather16", k_gather16_pow2<SHV>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx,   \
-                    rec, (const uint4*)x_in, (uint4*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);               \
+        if (cs)                                                                                                    \
+            ASMC_LAUNCH(ctx, st, "k_gather16", (k_gather16_pow2<SHV, true>), dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, \
+                        rec, (const uint4*)x_in, (uint4*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out, ctx->d_gram);  \
+        else                                                                                                       \
+            ASMC_LAUNCH(ctx, st, "k_gather16", (k_gather16_pow2<SHV, false>), dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, \
+                        rec, (const uint4*)x_in, (uint4*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out, (double*)nullptr); \
+        cs_done = cs;                                                                                              \
     } else
         ASMC_GATHER_POW2(4)
         ASMC_GATHER_POW2(3)
@@ -1916,6 +1950,8 @@ int asmc_gather(asmc_ctx* ctx, int64_t n_in, int64_t n_out, const int64_t* idx, 
                            (const uint4*)x_in, (uint4*)x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out);
         }
 #undef ASMC_GATHER_POW2
+        // (any later launch drops the tag: the partials live in the moment kernels' scratch)
+        if (cs_done) ctx->cs_x = x_out, ctx->cs_n = n_out, ctx->cs_d = d, ctx->cs_grid = grid;
     } else if (x_dtype == ASMC_F64) {
         const int grid = grid_for(n_out * d, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
         ASMC_LAUNCH(ctx, st, "k_gather_elem<double>", k_gather_elem<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n_out, idx, rec, d,

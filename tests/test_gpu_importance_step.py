@@ -204,10 +204,11 @@ def test_reference_fit_moments_ride_on_the_fused_step(eng, monkeypatch):
 
     sp_a, out_a, rep_a = run(4)
     temps = len(sp_a.history.beta)
-    assert rep_a["k_is_weights"][0] == temps and rep_a["k_colsum<double>"][0] == temps and rep_a["k_gram_mm"][0] == temps
+    # (the column sums ride along the gather: no k_colsum pass over the rows it has just written)
+    assert rep_a["k_is_weights"][0] == temps and "k_colsum<double>" not in rep_a and rep_a["k_gram_mm"][0] == temps
     monkeypatch.setattr(HipSMC, "_speculated_moments_n", lambda self, samples: None)
     sp_b, out_b, rep_b = run(4)
-    assert rep_b["k_colsum<double>"][0] == temps
+    assert rep_b["k_gram_mm"][0] == temps and rep_b["k_reduce_columns"][0] == temps
     assert sp_a.history.beta == sp_b.history.beta and sp_a.history.mcmc_acceptance == sp_b.history.mcmc_acceptance
     assert np.array_equal(_np(out_a.x), _np(out_b.x)) and float(out_a.log_evidence) == float(out_b.log_evidence)
 
@@ -338,3 +339,42 @@ def test_gather_reuses_the_records_the_step_packed_and_only_those(eng, n):
     assert not gathered(False, lld)
     assert gathered(True, lld)
     assert gathered(False, lld.clone())
+
+
+@pytest.mark.parametrize("d", [32, 64, 16])
+def test_column_sums_ride_along_the_gather_and_only_for_its_rows(eng, d):
+    """asmc_gather of fp64 rows leaves the column-sum partials of the rows it wrote; asmc_mean_gram_enqueue / asmc_colsum_dev of
+    exactly those rows, with no other launch in between, start from them (no k_colsum pass) and agree with the column sums of a
+    separate pass to rounding; any launch in between, or other rows, and the pass runs."""
+    n = 150_000
+    g = torch.Generator(eng.device).manual_seed(d)
+    x = (0.2 + torch.randn((n, d), device=eng.device, dtype=torch.float64, generator=g)).contiguous()
+    ll = torch.randn(n, device=eng.device, dtype=torch.float64, generator=g)
+    idx = torch.randint(0, n, (n,), device=eng.device, generator=g)
+
+    def sums(call_between, other_rows):
+        rows = eng.gather(idx, x, ll, ll, ll)
+        if call_between:
+            eng.count_nonfinite(ll)
+        target = rows[0].clone() if other_rows else rows[0]
+        eng.profile(True)
+        s_d = eng.colsum_dev(target)
+        rep = eng.profile_report()
+        eng.profile(False)
+        ref = eng.colsum(target)
+        np.testing.assert_allclose(s_d.cpu().numpy(), ref, rtol=1e-12, atol=1e-9)
+        assert torch.equal(rows[0], x[idx])
+        return "k_colsum<double>" in rep
+
+    assert not sums(False, False)
+    assert sums(True, False) and sums(False, True)
+    if d in (32, 64):  # the enqueue form behind the importance step's gather
+        rows = eng.gather(idx, x, ll, ll, ll)
+        eng.profile(True)
+        assert eng.mean_gram_enqueue(rows[0], n)
+        rep = eng.profile_report()
+        eng.profile(False)
+        s, gr = eng.mean_gram_fetch(d)
+        assert "k_colsum<double>" not in rep and "k_gram_mm" in rep
+        np.testing.assert_allclose(s, eng.colsum(rows[0]), rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(gr, eng.centered_gram(rows[0], s / n), rtol=1e-9, atol=1e-6)
