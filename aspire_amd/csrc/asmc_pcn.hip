@@ -1861,12 +1861,12 @@ __global__ void k_center_from_sum(int d, const double* __restrict__ sum, double 
 // Also the factorisation inside the device-side EM of the Student-t reference (asmc_student_fit): `sum` == NULL leaves the mean
 // alone, `tab` (mu | Linv's lower triangle packed by rows) is what k_student_estep stages, `em` / `it`: the EM's state record -
 // iterations behind the one that converged are skipped, a failed factorisation is recorded there.
-__global__ __launch_bounds__(REF_THREADS) void k_ref_factor(int d, const double* __restrict__ sum, const double* __restrict__ gram,
+__global__ __launch_bounds__(1024) void k_ref_factor(int d, const double* __restrict__ sum, const double* __restrict__ gram,
                                                            double n_mean, double denom, double* __restrict__ out,
                                                            double* __restrict__ status, double* __restrict__ tab,
                                                            double* __restrict__ em, int it) {
     extern __shared__ __align__(16) double s_a[];  // [d][d + 1]
-    __shared__ double s_diag[128];
+    __shared__ double s_diag[128], s_rdiag[128];
     __shared__ double s_scale;
     if (em && (double)it > em[2]) return;  // (uniform: every thread reads the same cell)
     const int tid = threadIdx.x, ld = d + 1, seg = (d + 31) / 32 * 32;
@@ -1880,13 +1880,14 @@ __global__ __launch_bounds__(REF_THREADS) void k_ref_factor(int d, const double*
             if (out) o_mu[j] = mj;
             if (tab) tab[j] = mj;
         }
+    const double inv_denom = 1.0 / denom;
     int tries = -1;
     double jitter = 0.0;
     for (int attempt = 0; attempt < 12; attempt++) {
         __syncthreads();
         for (int e = tid; e < d * d; e += NT) {
             const int i = e / d, j = e - i * d;
-            s_a[i * ld + j] = 0.5 * (gram[(size_t)i * d + j] / denom + gram[(size_t)j * d + i] / denom);
+            s_a[i * ld + j] = 0.5 * (gram[(size_t)i * d + j] * inv_denom + gram[(size_t)j * d + i] * inv_denom);
         }
         __syncthreads();
         if (attempt == 0) {
@@ -1910,11 +1911,13 @@ __global__ __launch_bounds__(REF_THREADS) void k_ref_factor(int d, const double*
                 ok = false;
                 break;
             }
-            const double rp = 1.0 / p;
-            const int m = d - j - 1;
-            for (int e = tid; e < m * m; e += NT) {
-                const int i = j + 1 + e / m, k = j + 1 + e % m;
-                s_a[i * ld + k] = fma(-(s_a[i * ld + j] * rp), s_a[k * ld + j], s_a[i * ld + k]);
+            double rp = __builtin_amdgcn_rcp(p);  // hardware reciprocal + two Newton steps: the division's chain is half of a column's latency
+            rp = fma(fma(-p, rp, 1.0), rp, rp);
+            rp = fma(fma(-p, rp, 1.0), rp, rp);
+            // threads as a (NT / 32) x 32 patch walking the trailing block: no integer division per element
+            for (int i = j + 1 + (tid >> 5); i < d; i += NT >> 5) {
+                const double li = s_a[i * ld + j] * rp;
+                for (int k = j + 1 + (tid & 31); k < d; k += 32) s_a[i * ld + k] = fma(-li, s_a[k * ld + j], s_a[i * ld + k]);
             }
         }
         if (ok) {
@@ -1929,31 +1932,52 @@ __global__ __launch_bounds__(REF_THREADS) void k_ref_factor(int d, const double*
         if (em && tries < 0) em[3] = -1.0;
     }
     if (tries < 0) return;
-    for (int j = tid; j < d; j += NT) s_diag[j] = sqrt(s_a[j * ld + j]);
+    for (int j = tid; j < d; j += NT) {
+        const double sd = sqrt(s_a[j * ld + j]);
+        s_diag[j] = sd, s_rdiag[j] = 1.0 / sd;
+    }
     __syncthreads();
     for (int e = tid; e < d * d; e += NT) {
         const int i = e / d, j = e - i * d;
         double v = 0.0;
-        if (j < i) v = s_a[i * ld + j] / s_diag[j];
+        if (j < i) v = s_a[i * ld + j] * s_rdiag[j];
         if (j == i) v = s_diag[j];
         if (out) o_L[e] = v;
         if (j < i) s_a[i * ld + j] = v;  // (the strict lower triangle: no other thread touches it in this pass)
     }
     __syncthreads();
-    // Linv by forward substitution, every column at once and without a barrier: thread c solves L x = e_c and keeps x_i
-    // (i > c) in the FREE upper triangle, at A[c][i] - its own row; L is only read (the same address in every thread)
-    for (int c = tid; c < d; c += NT) {
-        const double xc = 1.0 / s_diag[c];
-        for (int i = c + 1; i < d; i++) {
-            double acc = s_a[i * ld + c] * xc;
-            for (int k = c + 1; k < i; k++) acc = fma(s_a[i * ld + k], s_a[c * ld + k], acc);
-            s_a[c * ld + i] = -acc / s_diag[i];
+    // Linv by forward substitution, every column at once and without a block barrier: a group of G lanes of one wave solves
+    // L x = e_c for column c - the lanes split the dot product of a row (a single lane's chain of d^2 / 2 dependent LDS reads
+    // was 30 of the kernel's 40 us at d = 32 and 520 us at d = 128) - and keeps x_i (i > c) in the FREE upper triangle, at
+    // A[c][i], its own row; L is only read.  LDS operations of a wave complete in order: the lanes of a group see x_i
+    // as soon as the instruction that wrote it has issued.
+    {
+        const int per = NT / d;
+        const int G = per >= 8 ? 8 : per >= 4 ? 4 : per >= 2 ? 2 : 1;
+        const int c = tid / G, q = tid % G;
+        if (c < d) {
+            const double xc = s_rdiag[c];
+            for (int i = c + 1; i < d; i++) {
+                double acc = q == 0 ? s_a[i * ld + c] * xc : 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+                int k = c + 1 + q;
+                for (; k + 3 * G < i; k += 4 * G) {  // four independent chains: the LDS reads of a row pipeline
+                    acc = fma(s_a[i * ld + k], s_a[c * ld + k], acc);
+                    acc1 = fma(s_a[i * ld + k + G], s_a[c * ld + k + G], acc1);
+                    acc2 = fma(s_a[i * ld + k + 2 * G], s_a[c * ld + k + 2 * G], acc2);
+                    acc3 = fma(s_a[i * ld + k + 3 * G], s_a[c * ld + k + 3 * G], acc3);
+                }
+                for (; k < i; k += G) acc = fma(s_a[i * ld + k], s_a[c * ld + k], acc);
+                acc = (acc + acc1) + (acc2 + acc3);
+                for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                if (q == 0) s_a[c * ld + i] = -acc * s_rdiag[i];
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
     __syncthreads();
     for (int e = tid; e < d * d; e += NT) {
         const int i = e / d, j = e - i * d;
-        const double v = j < i ? s_a[j * ld + i] : j == i ? 1.0 / s_diag[i] : 0.0;
+        const double v = j < i ? s_a[j * ld + i] : j == i ? s_rdiag[i] : 0.0;
         if (out) o_Li[e] = v;
         if (tab && j <= i) tab[d + i * (i + 1) / 2 + j] = v;
     }
@@ -2037,7 +2061,11 @@ int asmc_ref_factor_launch(asmc_ctx* ctx, int d, const double* sum, const double
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ref_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    ASMC_LAUNCH(ctx, st, "k_ref_factor", k_ref_factor, dim3(1), dim3(REF_THREADS), lds, st, d, sum, gram, n_mean, denom, out,
+    // d <= 32 is bound by the per-column latency whatever the block (38-41 us from 256 to 1024 threads); d = 128 by the trailing
+    // updates: 683 us with 256 threads, 516 with 1024
+    static const int ref_env = getenv("ASMC_REF_THREADS") ? atoi(getenv("ASMC_REF_THREADS")) : 0;
+    const int ref_threads = ref_env > 0 ? ref_env : (d <= 32 ? REF_THREADS : 1024);
+    ASMC_LAUNCH(ctx, st, "k_ref_factor", k_ref_factor, dim3(1), dim3(ref_threads), lds, st, d, sum, gram, n_mean, denom, out,
                 status, tab, em, it);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;

@@ -564,9 +564,10 @@ class HipSMC(SMCSampler):
         # moments and nu from the previous fit, and a few sweeps track the slowly changing population
         iters = int(self.sampler_kwargs.get("tpcn_fit_iters", 12 if st.get("nu") is None else 4))
         fit = None
-        # every sweep on the stream, one synchronisation (d <= 64: at d = 128 the one-block factorisation of every sweep costs more
-        # than the host's LAPACK and its round trips - 0.92 against 0.88 s per config-5 run)
-        if hasattr(e, "student_fit") and self.dims <= 64 and not os.environ.get("ASMC_HOST_REFERENCE_FIT"):
+        # every sweep on the stream, one synchronisation (config 5, d = 128: 0.87 s per run against 0.88-0.97 s with the host's
+        # LAPACK and its round trips, which depend on the box's host)
+        if (hasattr(e, "student_fit") and self.dims <= int(os.environ.get("ASMC_DEVICE_EM_MAX_D", 128))
+                and not os.environ.get("ASMC_HOST_REFERENCE_FIT")):
             fit = e.student_fit(sub, iters, 1e-3, st.get("nu") or 20.0)
         if fit is not None:
             (mu_d, L_d, Linv_d), nu, _, status, _, _ = fit

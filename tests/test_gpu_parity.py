@@ -851,7 +851,7 @@ def test_config5_shape_mixture_d128_mfma_kernels(eng, step_fn):
         assert rep["k_gram_mm"][0] >= 1
     else:  # Student-t reference: fitted to a subsample on the device, scale variates from their own kernel (several steps per launch)
         assert 1 <= rep["k_gamma_draw"][0] <= rep["k_tpcn_mm_step"][0] and len(sp.history.mcmc_nu) == len(sp.history.beta)
-        assert "k_student_estep" in rep  # (d = 128: the host drives the EM's sweeps; d <= 64: asmc_student_fit)
+        assert "k_student_mstep" in rep  # the whole EM on the device (asmc_student_fit)
     # Z = 0.5 * N(2; 0, (1 + 0.5) I) + 0.5 * N(-2; 0, (1 + 1) I)   (Gaussian convolution), per-dim product
     def lg(mu, var):
         return -0.5 * d * np.log(2 * np.pi * var) - 0.5 * d * mu * mu / var
