@@ -166,7 +166,7 @@ SIGNATURES = {
     "asmc_mean_gram_enqueue": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _vp]),
     "asmc_mean_gram_fetch": (_i, [_vp, _i, _pd, _pd, _vp]),
     "asmc_reference_factor": (_i, [_vp, _i, _i64, _i64, _pd, _pd, _vp, _vp]),
-    "asmc_colsum_dev": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
+    "asmc_colsum_dev": (_i, [_vp, _i64, _i, _i, _vp, _i, _vp, _vp]),
     "asmc_centered_gram_dev": (_i, [_vp, _i64, _i, _i, _vp, _vp, _i64, _vp, _vp]),
     "asmc_reference_factor_dev": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "asmc_student_fit": (_i, [_vp, _i64, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _pd, _vp]),

@@ -1994,8 +1994,9 @@ __global__ __launch_bounds__(256) void k_keep_moments(int d, const double* __res
 // temperature boundary: the centre never visits the host; same division, same kernels, same bits as asmc_colsum -> host
 // division -> asmc_centered_gram).  _enqueue leaves both results on their way to pinned memory, _fetch waits for the stream
 // and hands them out: a caller with other work on the stream (the importance step's chain) pays one synchronisation for all.
-int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, int64_t n_mean, int across_ranks,
+int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, int64_t n_mean, int across_flags,
                            asmc_stream stream) {
+    const int across_ranks = across_flags & ASMC_GRAM_ACROSS_RANKS;
     ASMC_REQUIRE(ctx && x, "null pointer");
     ASMC_REQUIRE(n > 0 && n_mean > 0 && d > 0 && d <= ctx->d_max && d <= 128, "bad sizes (gram supports d <= 128)");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
@@ -2007,8 +2008,10 @@ int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const v
     ASMC_REQUIRE(!across_ranks || (allreduce && ctx->rccl_comm), "across_ranks needs asmc_set_rccl");
     hipStream_t st = as_stream(stream);
     int grid = grid_for(n, (ASMC_BLOCK / d) * 16, ctx->gram_blocks);
-    // rows that asmc_gather has just written: their column-sum partials came with the gather (no pass over the rows)
-    const bool from_gather = ctx->cs_n == n && ctx->cs_x == x && ctx->cs_d == d && x_dtype == ASMC_F64;
+    // rows that asmc_gather has just written AND that the caller vouches for (ASMC_GRAM_FROM_GATHER: nothing has rewritten them
+    // since - the library cannot see a caller's own kernels): their column-sum partials came with the gather, no pass over the rows
+    const bool from_gather = (across_flags & ASMC_GRAM_FROM_GATHER) && ctx->cs_n == n && ctx->cs_x == x && ctx->cs_d == d &&
+                             x_dtype == ASMC_F64;
     if (from_gather)
         grid = ctx->cs_grid;
     else if (x_dtype == ASMC_F64)
@@ -2108,13 +2111,14 @@ __global__ __launch_bounds__(256) void k_copy_doubles(int n, const double* __res
     if (e < n) dst[e] = src[e];
 }
 
-int asmc_colsum_dev(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, double* sum_dev, asmc_stream stream) {
+int asmc_colsum_dev(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, int from_gather_flag, double* sum_dev,
+                    asmc_stream stream) {
     ASMC_REQUIRE(ctx && x && sum_dev, "null pointer");
     ASMC_REQUIRE(n > 0 && d > 0 && d <= ctx->d_max && d <= ASMC_BLOCK, "bad sizes");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
     hipStream_t st = as_stream(stream);
     int grid = grid_for(n, (ASMC_BLOCK / d) * 16, ctx->gram_blocks);
-    const bool from_gather = ctx->cs_n == n && ctx->cs_x == x && ctx->cs_d == d && x_dtype == ASMC_F64;  // (see asmc_mean_gram_enqueue)
+    const bool from_gather = from_gather_flag && ctx->cs_n == n && ctx->cs_x == x && ctx->cs_d == d && x_dtype == ASMC_F64;  // (see asmc_mean_gram_enqueue)
     if (from_gather)
         grid = ctx->cs_grid;
     else if (x_dtype == ASMC_F64)

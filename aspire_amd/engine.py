@@ -609,7 +609,7 @@ class HipEngine:
                                       self._stream), "asmc_mean_gram")
         return s, g
 
-    def mean_gram_enqueue(self, x: torch.Tensor, n_mean: int, comm=None) -> bool:
+    def mean_gram_enqueue(self, x: torch.Tensor, n_mean: int, comm=None, gathered: bool = False) -> bool:
         """Start `mean_gram` on the stream without waiting; False for shapes without the device-side path (and, for a sharded
         `comm`, without a communicator for the library's own all-reduces: `use_rccl`)."""
         n, d = x.shape
@@ -624,8 +624,9 @@ class HipEngine:
             if not across:
                 return False
             x = self._gram_keep = x.clone()
-        check(self.lib.asmc_mean_gram_enqueue(self._ctx, n, d, self._xdt(x), _dptr(x), int(n_mean), across, self._stream),
-              "asmc_mean_gram_enqueue")
+        # gathered: x is what the last `gather` returned and nothing has rewritten it since - its column sums rode along the gather
+        check(self.lib.asmc_mean_gram_enqueue(self._ctx, n, d, self._xdt(x), _dptr(x), int(n_mean), across | (2 if gathered else 0),
+                                              self._stream), "asmc_mean_gram_enqueue")
         self._gram_gen = getattr(self, "_gram_gen", 0) + 1  # names the request: a fetch is for the LATEST one only
         return True
 
@@ -634,11 +635,12 @@ class HipEngine:
         check(self.lib.asmc_mean_gram_fetch(self._ctx, d, _f64p(s), _f64p(g), self._stream), "asmc_mean_gram_fetch")
         return s, g
 
-    def colsum_dev(self, x: torch.Tensor) -> torch.Tensor:
+    def colsum_dev(self, x: torch.Tensor, gathered: bool = False) -> torch.Tensor:
         """Column sums of this rank's rows as a device tensor (no synchronisation): the caller all-reduces them on the stream."""
         n, d = x.shape
         s = self.empty(d)
-        check(self.lib.asmc_colsum_dev(self._ctx, n, d, self._xdt(x), _dptr(x), _dptr(s), self._stream), "asmc_colsum_dev")
+        check(self.lib.asmc_colsum_dev(self._ctx, n, d, self._xdt(x), _dptr(x), int(bool(gathered)), _dptr(s), self._stream),
+              "asmc_colsum_dev")
         return s
 
     def centered_gram_dev(self, x: torch.Tensor, sums: torch.Tensor, n_mean: int) -> torch.Tensor:

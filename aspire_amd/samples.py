@@ -443,7 +443,8 @@ class SMCSamples(BaseSamples):
         rows = e.gather(idx, x, ll, lp, lq)
         if hasattr(e, "importance_result_enqueue"):
             e.importance_result_enqueue()  # the step's scalars come back as soon as the step is done, not behind the moments
-        with_moments = bool(moments_n) and hasattr(e, "mean_gram_enqueue") and e.mean_gram_enqueue(rows[0], int(moments_n))
+        with_moments = (bool(moments_n) and hasattr(e, "mean_gram_enqueue")
+                        and e.mean_gram_enqueue(rows[0], int(moments_n), gathered=True))  # (the rows come straight from the gather)
         self._spec_pending = dict(key=(float(target_eff), float(tol)), rows=rows, rng=rng, state=[int(v) for v in st4], n=n,
                                   moments_n=int(moments_n) if with_moments else None, gram_gen=getattr(e, "_gram_gen", None))
         if not defer:
@@ -537,7 +538,7 @@ class SMCSamples(BaseSamples):
             # `moments_n`: the caller's mutation fits its reference Gaussian to the moments of these rows - start them now
             # (engine.mean_gram_enqueue; summed over the ranks of a sharded run), they are fetched when the fit needs them
             if (moments_n and spec is None and is_torch(xo) and hasattr(e, "mean_gram_enqueue")
-                    and e.mean_gram_enqueue(xo, int(moments_n), comm)):
+                    and e.mean_gram_enqueue(xo, int(moments_n), comm, gathered=True)):  # (xo comes straight from a gather)
                 out.__dict__["_moments"] = (xo.data_ptr(), tuple(xo.shape), int(moments_n), e._gram_gen)
             if comm.sharded:
                 out.n_global = int(n_samples)

@@ -410,6 +410,11 @@ int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_d
 /* The two halves of asmc_mean_gram for a caller that has more on the stream: _enqueue starts both passes and their copies to
  * pinned memory (fp64-MFMA shapes only, error otherwise), _fetch synchronises the stream and hands the results out.  One
  * pending request per context. */
+/* across_ranks is a set of flags: ASMC_GRAM_ACROSS_RANKS (1) as above; ASMC_GRAM_FROM_GATHER (2): x_dev are the rows the last
+ * asmc_gather on this ctx wrote and NOTHING has rewritten them since (the caller vouches for its own kernels; any library launch
+ * in between is noticed) - the column sums that rode along the gather are used and the pass over the rows is skipped. */
+#define ASMC_GRAM_ACROSS_RANKS 1
+#define ASMC_GRAM_FROM_GATHER 2
 int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, int64_t n_mean, int across_ranks,
                            asmc_stream stream);
 int asmc_mean_gram_fetch(asmc_ctx* ctx, int d, double* sum_host, double* gram_host /* [d, d] */, asmc_stream stream);
@@ -427,7 +432,8 @@ int asmc_reference_factor_status(asmc_ctx* ctx, int* status_host);
  * sum_dev / n_mean, i.e. the GLOBAL sums and population once the caller has all-reduced sum_dev) land in the caller's device
  * buffers, the caller sums them over the ranks on the stream (torch.distributed all_reduce = RCCL), and asmc_reference_factor_dev
  * factors the result.  asmc_centered_gram_dev: d in {32, 64, 128}, 16-byte aligned rows (ASMC_ERR_UNSUPPORTED otherwise). */
-int asmc_colsum_dev(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, double* sum_dev /* [d] */, asmc_stream stream);
+int asmc_colsum_dev(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, int from_gather /* see ASMC_GRAM_FROM_GATHER */,
+                    double* sum_dev /* [d] */, asmc_stream stream);
 int asmc_centered_gram_dev(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x_dev, const double* sum_dev, int64_t n_mean,
                            double* gram_dev /* [d, d] */, asmc_stream stream);
 int asmc_reference_factor_dev(asmc_ctx* ctx, int d, int64_t n_mean, int64_t n_cov, const double* sum_dev, const double* gram_dev,

@@ -209,8 +209,14 @@ def test_reference_fit_moments_ride_on_the_fused_step(eng, monkeypatch):
     monkeypatch.setattr(HipSMC, "_speculated_moments_n", lambda self, samples: None)
     sp_b, out_b, rep_b = run(4)
     assert rep_b["k_gram_mm"][0] == temps and rep_b["k_reduce_columns"][0] == temps
-    assert sp_a.history.beta == sp_b.history.beta and sp_a.history.mcmc_acceptance == sp_b.history.mcmc_acceptance
-    assert np.array_equal(_np(out_a.x), _np(out_b.x)) and float(out_a.log_evidence) == float(out_b.log_evidence)
+    # (a fit behind the gather starts from the column sums that rode along it, a fit at mutation time from its own pass over the
+    # rows: the two reference Gaussians agree to rounding, so the runs agree up to accept decisions at a razor's edge)
+    assert len(sp_a.history.beta) == len(sp_b.history.beta) and sp_a.history.beta[0] == sp_b.history.beta[0]
+    np.testing.assert_allclose(sp_a.history.beta, sp_b.history.beta, rtol=1e-4)
+    np.testing.assert_allclose(sp_a.history.mcmc_acceptance, sp_b.history.mcmc_acceptance, atol=2e-3)
+    same = np.all(np.abs(_np(out_a.x) - _np(out_b.x)) <= 1e-9 * (1 + np.abs(_np(out_b.x))), axis=1)
+    assert same.mean() > 0.5
+    assert abs(float(out_a.log_evidence) - float(out_b.log_evidence)) < 3 * float(out_a.log_evidence_error)
 
 
 def test_importance_step_enqueued_behind_the_mutation(eng, monkeypatch):
@@ -358,7 +364,7 @@ def test_column_sums_ride_along_the_gather_and_only_for_its_rows(eng, d):
             eng.count_nonfinite(ll)
         target = rows[0].clone() if other_rows else rows[0]
         eng.profile(True)
-        s_d = eng.colsum_dev(target)
+        s_d = eng.colsum_dev(target, gathered=True)
         rep = eng.profile_report()
         eng.profile(False)
         ref = eng.colsum(target)
@@ -368,10 +374,15 @@ def test_column_sums_ride_along_the_gather_and_only_for_its_rows(eng, d):
 
     assert not sums(False, False)
     assert sums(True, False) and sums(False, True)
+    rows = eng.gather(idx, x, ll, ll, ll)  # without the caller's word the pass runs (the library cannot see a caller's own kernels)
+    eng.profile(True)
+    eng.colsum_dev(rows[0])
+    assert "k_colsum<double>" in eng.profile_report()
+    eng.profile(False)
     if d in (32, 64):  # the enqueue form behind the importance step's gather
         rows = eng.gather(idx, x, ll, ll, ll)
         eng.profile(True)
-        assert eng.mean_gram_enqueue(rows[0], n)
+        assert eng.mean_gram_enqueue(rows[0], n, gathered=True)
         rep = eng.profile_report()
         eng.profile(False)
         s, gr = eng.mean_gram_fetch(d)
