@@ -420,57 +420,75 @@ __global__ __launch_bounds__(64 * (D / 32)) void k_gram_mm(int64_t n, const T* _
     }
 }
 
-// d = 32 without the LDS tile: a lane loads its matrix-core operand element straight from the row-major rows - lane (k, i) of a
-// group of four particles reads x[p + k][i] (sixteen lanes = 128 contiguous bytes, four such runs per load) for the coordinate
-// blocks 0-15 and 16-31, and since the A operand of block row I and the B operand of block column J have the same lane layout the
-// same registers feed all three lower blocks (0,0), (1,0), (1,1).  Every byte is loaded once and nothing is staged: 103 -> 5x us
-// at 1M x 32 (the LDS version moved 2.4 TB/s).  Same particle-to-block assignment and the same accumulation order per accumulator
-// as k_gram_mm<T, 32>: the same bits.
-template <typename T>
-__global__ __launch_bounds__(64) void k_gram32_stream(int64_t n, const T* __restrict__ x, const double* __restrict__ center,
-                                                     double* __restrict__ partials) {
-    constexpr int D = 32, U = 8;  // U groups of four particles per trip = one 32-row tile of k_gram_mm
+// d = 32 / 64 without the LDS tile: a lane loads its matrix-core operand element straight from the row-major rows - lane (k, i) of a
+// group of four particles reads x[p + k][16 b + i] (sixteen lanes = 128 contiguous bytes, four such runs per load) for every
+// coordinate block b, and since the A operand of block row I and the B operand of block column J have the same lane layout the
+// same registers feed all lower blocks (I, J).  Every byte is loaded once and nothing is staged: 103 -> 60 us at 1M x 32 (the LDS
+// version moved 2.4 TB/s), 516 -> 1xx us at 1M x 64.  Same particle-to-block assignment (32-row tiles) and the same accumulation
+// order per accumulator as k_gram_mm<T, D>: the same bits.
+template <typename T, int D>
+__global__ __launch_bounds__(64) void k_gram_stream(int64_t n, const T* __restrict__ x, const double* __restrict__ center,
+                                                   double* __restrict__ partials) {
+    constexpr int NB = D / 16, U = D == 32 ? 8 : 4, TRIPS = 8 / U;  // U groups of four particles per fetch; 32 rows per tile
+    constexpr int NACC = NB * (NB + 1) / 2;
     const int lane = threadIdx.x, kq = lane >> 4, ci = lane & 15;
-    const double c0 = center[ci], c1 = center[16 + ci];
-    doublex4 a00 = {0.0, 0.0, 0.0, 0.0}, a10 = a00, a11 = a00;
-    const int64_t stride = (int64_t)gridDim.x * 4 * U;
-    T v0[U], v1[U];
+    double cen[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) cen[b] = center[16 * b + ci];
+    doublex4 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) acc[a] = doublex4{0.0, 0.0, 0.0, 0.0};
+    const int64_t stride = (int64_t)gridDim.x * 32;
+    T v[NB][U];
     auto fetch = [&](int64_t p0) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int64_t p = p0 + 4 * u + kq;
             const bool ok = p < n;
-            v0[u] = ok ? x[p * D + ci] : (T)0;
-            v1[u] = ok ? x[p * D + 16 + ci] : (T)0;
+#pragma unroll
+            for (int b = 0; b < NB; b++) v[b][u] = ok ? x[p * D + 16 * b + ci] : (T)0;
         }
     };
-    fetch((int64_t)blockIdx.x * 4 * U);
-    for (int64_t p0 = (int64_t)blockIdx.x * 4 * U; p0 < n; p0 += stride) {
-        double d0[U], d1[U];
+    fetch((int64_t)blockIdx.x * 32);
+    for (int64_t t0 = (int64_t)blockIdx.x * 32; t0 < n; t0 += stride) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const bool ok = p0 + 4 * u + kq < n;
-            d0[u] = ok ? (double)v0[u] - c0 : 0.0;
-            d1[u] = ok ? (double)v1[u] - c1 : 0.0;
-        }
-        if (p0 + stride < n) fetch(p0 + stride);  // the next trip's rows are in flight while this one is in the matrix pipe
+        for (int h = 0; h < TRIPS; h++) {
+            const int64_t p0 = t0 + 4 * U * h;
+            double dv[NB][U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(d1[u], d0[u], a10, 0, 0, 0);
-            a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(d1[u], d1[u], a11, 0, 0, 0);
-            a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(d0[u], d0[u], a00, 0, 0, 0);
+            for (int u = 0; u < U; u++) {
+                const bool ok = p0 + 4 * u + kq < n;
+#pragma unroll
+                for (int b = 0; b < NB; b++) dv[b][u] = ok ? (double)v[b][u] - cen[b] : 0.0;
+            }
+            // the next fetch is in flight while this one is in the matrix pipe
+            const int64_t pn = h + 1 < TRIPS ? p0 + 4 * U : t0 + stride;
+            if (pn < n) fetch(pn);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                // k_gram_mm's order within a group of four particles: for jb: accB[jb] (row strip NB - 1 - w) then accA[jb] - per
+                // accumulator only the order over the groups matters, which is u ascending here as there
+#pragma unroll
+                for (int ib = 0; ib < NB; ib++)
+#pragma unroll
+                    for (int jb = 0; jb <= ib; jb++)
+                        acc[ib * (ib + 1) / 2 + jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[ib][u], dv[jb][u], acc[ib * (ib + 1) / 2 + jb], 0, 0, 0);
+            }
         }
     }
-    // block (i, j): lane holds G[16 i + (lane >> 4) + 4 r][16 j + (lane & 15)]; (1, 0) mirrored into the upper triangle
+    // block (i, j): lane holds G[16 i + (lane >> 4) + 4 r][16 j + (lane & 15)]; mirrored into the upper triangle
     double* out = partials + (size_t)blockIdx.x * D * D;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int rr = kq + 4 * r;
-        out[(size_t)rr * D + ci] = a00[r];
-        out[(size_t)(16 + rr) * D + 16 + ci] = a11[r];
-        out[(size_t)(16 + rr) * D + ci] = a10[r];
-        out[(size_t)ci * D + 16 + rr] = a10[r];
-    }
+    for (int ib = 0; ib < NB; ib++)
+#pragma unroll
+        for (int jb = 0; jb <= ib; jb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * ib + kq + 4 * r, col = 16 * jb + ci;
+                const double val = acc[ib * (ib + 1) / 2 + jb][r];
+                out[(size_t)row * D + col] = val;
+                if (jb != ib) out[(size_t)col * D + row] = val;
+            }
 }
 
 // fixed-order sum of the per-block partial matrices, one thread per matrix entry (coalesced across entries)
@@ -509,19 +527,23 @@ int asmc_gram_mm_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void
     int grid = (int)((n + GRAM_TP - 1) / GRAM_TP);
     // d = 32: one wave per block, so eight blocks per CU are needed to keep enough loads in flight
     static const int per_cu32 = getenv("ASMC_GRAM32_PER_CU") ? atoi(getenv("ASMC_GRAM32_PER_CU")) : 8;
-    int cap = d == 32 ? per_cu32 * ctx->num_cu : 2 * ctx->num_cu;  // (more blocks change nothing at d = 64 / 128: measured)
+    int cap = (d == 32 || (d == 64 && !getenv("ASMC_GRAM_LDS32"))) ? per_cu32 * ctx->num_cu : 2 * ctx->num_cu;  // (one wave per block: eight blocks per CU)  // (more blocks change nothing at d = 64 / 128: measured)
     if ((size_t)cap * d * d > ctx->gram_cap) cap = (int)(ctx->gram_cap / ((size_t)d * d));
     if (grid > cap) grid = cap;
     *grid_out = grid;
     const size_t lds = (size_t)GRAM_TP * (d + 16) * sizeof(double);
 #define GRAM_CASE(TT, DD) \
     ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_mm<TT, DD>), dim3(grid), dim3(64 * (DD / 32)), lds, st, n, (const TT*)x, d_center, ctx->d_gram)
-    static const bool lds32 = getenv("ASMC_GRAM_LDS32") != nullptr;  // (the LDS-tile kernel at d = 32, for comparison)
-    if (d == 32 && !lds32) {
-        if (x_dtype == ASMC_F64)
-            ASMC_LAUNCH(ctx, st, "k_gram_mm", k_gram32_stream<double>, dim3(grid), dim3(64), 0, st, n, (const double*)x, d_center, ctx->d_gram);
+    static const bool lds_tile = getenv("ASMC_GRAM_LDS32") != nullptr;  // (the LDS-tile kernel at d = 32 / 64, for comparison)
+    if ((d == 32 || d == 64) && !lds_tile) {
+        if (x_dtype == ASMC_F64 && d == 32)
+            ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_stream<double, 32>), dim3(grid), dim3(64), 0, st, n, (const double*)x, d_center, ctx->d_gram);
+        else if (x_dtype == ASMC_F64)
+            ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_stream<double, 64>), dim3(grid), dim3(64), 0, st, n, (const double*)x, d_center, ctx->d_gram);
+        else if (d == 32)
+            ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_stream<float, 32>), dim3(grid), dim3(64), 0, st, n, (const float*)x, d_center, ctx->d_gram);
         else
-            ASMC_LAUNCH(ctx, st, "k_gram_mm", k_gram32_stream<float>, dim3(grid), dim3(64), 0, st, n, (const float*)x, d_center, ctx->d_gram);
+            ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_stream<float, 64>), dim3(grid), dim3(64), 0, st, n, (const float*)x, d_center, ctx->d_gram);
     } else if (x_dtype == ASMC_F64) {
         if (d == 128) GRAM_CASE(double, 128);
         else if (d == 64) GRAM_CASE(double, 64);
