@@ -1397,13 +1397,24 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_gram_rb(int64_t n, int d, const 
     }
 }
 
-__global__ __launch_bounds__(64) void k_reduce_columns(int nblocks, int ncols, const double* __restrict__ partials,
-                                                      double* __restrict__ out) {
+// one block per column; 64 threads (one wave: the order every caller has always had) or 256 (the gather's column-sum partials:
+// 4 096 rows - 24 us with one wave): strided partial sums, the wave's butterfly, then the waves in order
+__global__ __launch_bounds__(256) void k_reduce_columns(int nblocks, int ncols, const double* __restrict__ partials,
+                                                       double* __restrict__ out) {
+    __shared__ double s_w[4];
+    const int nt = (int)blockDim.x;
     for (int col = blockIdx.x; col < ncols; col += gridDim.x) {
         double v = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += 64) v += partials[(size_t)b * ncols + col];
+        for (int b = threadIdx.x; b < nblocks; b += nt) v += partials[(size_t)b * ncols + col];
         v = wave_sum(v);
-        if (threadIdx.x == 0) out[col] = v;
+        if (nt == 64) {
+            if (threadIdx.x == 0) out[col] = v;
+        } else {
+            if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) out[col] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+            __syncthreads();
+        }
     }
 }
 
@@ -2019,7 +2030,7 @@ int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const v
     else
         ASMC_LAUNCH(ctx, st, "k_colsum<float>", k_colsum<float>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const float*)x, ctx->d_gram);
     ASMC_LAUNCH_CHECK();
-    ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(d), dim3(64), 0, st, grid, d, (const double*)ctx->d_gram, ctx->d_small);
+    ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(d), dim3(from_gather ? 256 : 64), 0, st, grid, d, (const double*)ctx->d_gram, ctx->d_small);
     ASMC_LAUNCH_CHECK();
     if (across_ranks && allreduce(ctx->d_small, ctx->d_small, (size_t)d, nccl_f64, nccl_sum, ctx->rccl_comm, st) != 0) {
         asmc_set_error("asmc_mean_gram: ncclAllReduce failed");
@@ -2126,7 +2137,7 @@ int asmc_colsum_dev(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x,
     else
         ASMC_LAUNCH(ctx, st, "k_colsum<float>", k_colsum<float>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const float*)x, ctx->d_gram);
     ASMC_LAUNCH_CHECK();
-    ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(d), dim3(64), 0, st, grid, d, (const double*)ctx->d_gram, sum_dev);
+    ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(d), dim3(from_gather ? 256 : 64), 0, st, grid, d, (const double*)ctx->d_gram, sum_dev);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
