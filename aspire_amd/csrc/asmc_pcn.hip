@@ -2039,7 +2039,6 @@ int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const v
     double* d_center = ctx->d_small + 2048;
     ASMC_LAUNCH(ctx, st, "k_center_from_sum", k_center_from_sum, dim3(1), dim3(128), 0, st, d, (const double*)ctx->d_small, (double)n_mean, d_center);
     ASMC_LAUNCH_CHECK();
-    ASMC_HIP(hipMemcpyAsync(ctx->h_gram, ctx->d_small, sizeof(double) * d, hipMemcpyDeviceToHost, st));
     int ggrid = 0;
     int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &ggrid, st);
     if (rc) return rc;
@@ -2047,8 +2046,8 @@ int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const v
         asmc_set_error("asmc_mean_gram: ncclAllReduce failed");
         return ASMC_ERR_ARG;
     }
-    ASMC_HIP(hipMemcpyAsync(ctx->h_gram + 128, ctx->d_partials, sizeof(double) * d * d, hipMemcpyDeviceToHost, st));
-    // ... and a copy that stays on the device for asmc_reference_factor (d_small / d_partials are every call's scratch)
+    // the results stay on the device (d_small / d_partials are every call's scratch): asmc_reference_factor reads them there,
+    // asmc_mean_gram_fetch copies them out when a caller wants them on the host
     ASMC_LAUNCH(ctx, st, "k_keep_moments", k_keep_moments, dim3((d * d + d + 255) / 256), dim3(256), 0, st, d, (const double*)ctx->d_small,
                 (const double*)ctx->d_partials, ctx->d_ref);
     ASMC_LAUNCH_CHECK();
@@ -2059,6 +2058,7 @@ int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const v
 int asmc_mean_gram_fetch(asmc_ctx* ctx, int d, double* sum_host, double* gram_host, asmc_stream stream) {
     ASMC_REQUIRE(ctx && sum_host && gram_host, "null pointer");
     ASMC_REQUIRE(ctx->gram_pending_d == d && d > 0, "no asmc_mean_gram_enqueue of this d is pending");
+    ASMC_HIP(hipMemcpyAsync(ctx->h_gram, ctx->d_ref, sizeof(double) * (128 + (size_t)d * d), hipMemcpyDeviceToHost, as_stream(stream)));
     ASMC_HIP(hipStreamSynchronize(as_stream(stream)));
     memcpy(sum_host, ctx->h_gram, sizeof(double) * d);
     memcpy(gram_host, ctx->h_gram + 128, sizeof(double) * d * d);
