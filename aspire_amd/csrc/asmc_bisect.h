@@ -208,7 +208,7 @@ BIS_HD void bis_plan(double* st, bool first, const double* beta, const double* m
     for (int guard = 0; guard < 64 && K_hi - K_lo == F; guard++) {
         const double width = bmax - bmin;
         if (width > tol) {  // one level deeper than estimated
-            if (LU >= 58) break;
+            if (LU >= 52) break;  // (node indices are kept in doubles: exact below 2^53; such a tolerance is below the floats' spacing)
             if (F > 1)
                 F >>= 1;
             else
