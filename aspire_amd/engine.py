@@ -241,7 +241,8 @@ class HipEngine:
         trip = (float(out[6]), float(out[7]), float(out[8])) if out[9] != 0.0 else None
         return float(out[0]), float(out[4]), bool(out[2]), int(out[3]), int(out[5]), trip, tuple(map(float, out[10:13]))
 
-    def importance_step(self, ll, lp, lq, beta0: float, target_eff: float, tol: float, state4: np.ndarray, n_out: int):
+    def importance_step(self, ll, lp, lq, beta0: float, target_eff: float, tol: float, state4: np.ndarray, n_out: int,
+                        idx_out: torch.Tensor | None = None):
         """Enqueue one iteration's adaptive-beta search, evidence moments and resampling indices for the next `n_out`
         PCG64 doubles behind `state4` (include/asmc.h asmc_importance_step; no host synchronisation).  Returns the device
         index tensor; `importance_result()` then reads the scalars."""
@@ -251,7 +252,8 @@ class HipEngine:
         bufs = self.__dict__.setdefault("_is_bufs", {})
         if bufs.get("n") != n:
             bufs.update(n=n, w=self.empty(n), cdf=self.empty(n))
-        idx = torch.empty(n_out, dtype=torch.int64, device=self.device)
+        idx = idx_out if idx_out is not None else torch.empty(n_out, dtype=torch.int64, device=self.device)
+        assert idx.dtype == torch.int64 and idx.numel() == n_out and idx.is_contiguous()
         check(self.lib.asmc_importance_step(self._ctx, n, _dptr(ll), _dptr(lp), _dptr(lq), beta0, target_eff, tol,
                                             st.ctypes.data_as(ctypes.c_void_p), n_out, _dptr(bufs["w"]), _dptr(bufs["cdf"]),
                                             _dptr(idx), self._stream), "asmc_importance_step")
@@ -473,12 +475,19 @@ class HipEngine:
               "asmc_search")
         return idx
 
-    def gather(self, idx, x, ll, lp, lq):
+    def gather(self, idx, x, ll, lp, lq, out=None):
+        """Rows `idx` of (x, ll, lp, lq); `out` = caller-owned (x, ll, lp, lq) destination buffers (no allocation)."""
         assert idx.dtype == torch.int64 and idx.is_contiguous() and x.is_contiguous()
         self._chk3(ll, lp, lq)
         n_out, d = idx.numel(), x.shape[1]
-        xo = torch.empty((n_out, d), dtype=x.dtype, device=self.device)
-        llo, lpo, lqo = (torch.empty(n_out, dtype=torch.float64, device=self.device) for _ in range(3))
+        if out is not None:
+            xo, llo, lpo, lqo = out
+            assert xo.shape == (n_out, d) and xo.dtype == x.dtype and xo.is_contiguous()
+            self._chk3(llo, lpo, lqo)
+            assert llo.numel() == n_out and lpo.numel() == n_out and lqo.numel() == n_out
+        else:
+            xo = torch.empty((n_out, d), dtype=x.dtype, device=self.device)
+            llo, lpo, lqo = (torch.empty(n_out, dtype=torch.float64, device=self.device) for _ in range(3))
         check(self.lib.asmc_gather(self._ctx, x.shape[0], n_out, _dptr(idx), d, self._xdt(x), _dptr(x), _dptr(xo), _dptr(ll),
                                    _dptr(lp), _dptr(lq), _dptr(llo), _dptr(lpo), _dptr(lqo), self._stream), "asmc_gather")
         return xo, llo, lpo, lqo

@@ -21,6 +21,7 @@ cores, OpenMP), `extra` (IS-only temperature iteration of configs[1], the analyt
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import math
 import os
@@ -73,6 +74,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Host-side pauses of the interpreter's cycle collector are recorded (generation, ms) so that a stall inside a timed leg
+    # can be attributed: round 3's driver run of the IS-only leg lost ~80 ms of its 91 ms to ONE such event.
+    gc_log, gc_t0 = [], [0.0]
+
+    def _gc_cb(phase, info):
+        if phase == "start":
+            gc_t0[0] = time.perf_counter()
+        else:
+            gc_log.append((info["generation"], (time.perf_counter() - gc_t0[0]) * 1e3))
+
+    gc.callbacks.append(_gc_cb)
+
+    def gc_summary(since: int):
+        ev = gc_log[since:]
+        full = [ms for g, ms in ev if g == 2]
+        return {"collections": len(ev), "full_collections": len(full), "total_ms": round(sum(ms for _, ms in ev), 3),
+                "max_pause_ms": round(max((ms for _, ms in ev), default=0.0), 3)}
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -142,7 +160,14 @@ def main():
     run(1, n=min(n_global, 65536 * world), steps=2)  # first-launch costs (code objects, allocator pools, scipy import)
     for w in range(args.warmup):
         run(100 + w)
+    # the interpreter's long-lived objects (torch, numpy, scipy, the trained flow: ~1e6 of them) go to the permanent
+    # generation: a full collection inside a timed leg then walks only what the legs themselves created (it cost 60-80 ms
+    # before; ASMC_BENCH_NO_GC_FREEZE=1 restores that)
+    if not os.environ.get("ASMC_BENCH_NO_GC_FREEZE"):
+        gc.collect()
+        gc.freeze()
     sync_all()
+    gc_mark = len(gc_log)
     t0 = time.perf_counter()
     steps_done, zs, temps, accs = 0, [], [], []
     for k in range(args.steps):
@@ -154,6 +179,7 @@ def main():
         accs.append(float(np.mean(sp.history.mcmc_acceptance)))
     sync_all()
     dt = time.perf_counter() - t0
+    gc_headline = gc_summary(gc_mark)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
         import torch.distributed as dist
@@ -264,6 +290,7 @@ def main():
                          "rms_z": float(np.sqrt(np.mean(np.square(zs)))), "max_abs_z": float(np.max(np.abs(zs))),
                          "within_1_sigma_fraction": float(np.mean(np.abs(zs) <= 1.0))},
         "mean_accept": float(np.mean(accs)),
+        "host_gc_in_timed_region": gc_headline,
         "roofline": roofline,
     }
 
@@ -280,18 +307,36 @@ def main():
         rng_is = np.random.default_rng(12345)
         scal = {}
 
+        # every device buffer of the leg is allocated ONCE (index vector, two sets of gather destinations used in turn): the
+        # timed loop performs no allocation, so allocator state left behind by the headline runs cannot enter the figure
+        idx_buf = torch.empty(n_global, dtype=torch.int64, device=eng.device)
+        out_bufs = [(torch.empty_like(x), torch.empty_like(ll), torch.empty_like(lp), torch.empty_like(lq)) for _ in range(2)]
+        host_t = {"enqueue_search_resample": 0.0, "enqueue_gather": 0.0, "wait_result": 0.0, "python_scalars": 0.0}
+        is_calls = [0]
+
         def is_step():
+            k = is_calls[0] = is_calls[0] + 1
+            dst = out_bufs[k & 1]
             if not sharded and args.resample_mode == "exact" and hasattr(eng, "importance_step"):
                 # the sampler loop's path (SMCSamples.speculate_importance_step): one chain of launches, one sync
-                idx = eng.importance_step(ll, lp, lq, 0.0, 0.5, 1e-6, smc_math.pcg64_state(rng_is), n_global)
-                rows = eng.gather(idx, x, ll, lp, lq)
+                h0 = time.perf_counter()
+                idx = eng.importance_step(ll, lp, lq, 0.0, 0.5, 1e-6, smc_math.pcg64_state(rng_is), n_global, idx_out=idx_buf)
+                h1 = time.perf_counter()
+                rows = eng.gather(idx, x, ll, lp, lq, out=dst)
+                h2 = time.perf_counter()
                 b, _, conv, _, n_nan, trip, trip_one, m2, _, found = eng.importance_result()
+                h3 = time.perf_counter()
                 assert conv and found and n_nan == 0
                 rng_is.bit_generator.advance(n_global)
                 st_b, st_1 = smc_math.Stats(*trip, n_global), smc_math.Stats(*trip_one, n_global)
                 mean_u = st_b.S1 / n_global
                 scal.update(beta=b, ess=smc_math.ess(st_b), ess1=smc_math.ess(st_1), ratio=smc_math.log_evidence_ratio(st_b),
                             var=(m2 / n_global) / (n_global * mean_u**2))
+                h4 = time.perf_counter()
+                host_t["enqueue_search_resample"] += h1 - h0
+                host_t["enqueue_gather"] += h2 - h1
+                host_t["wait_result"] += h3 - h2
+                host_t["python_scalars"] += h4 - h3
                 return rows
             if sharded:
                 b, _, conv, _, n_nan, trip, trip_one = smc_math.find_beta_sharded(eng, comm, ll, lp, lq, 0.0, 0.5, 1e-6, n_global)
@@ -307,17 +352,27 @@ def main():
                 idx, _ = smc_math.resample_indices(eng, comm, ll, lp, lq, 0.0, b, n_global, rng_is, mode=args.resample_mode,
                                                    st=st_b, s1p=s1p)
             scal.update(beta=b, ess=smc_math.ess(st_b), ess1=smc_math.ess(st_1), ratio=smc_math.log_evidence_ratio(st_b), var=var)
-            return eng.gather(idx, x, ll, lp, lq)
+            return eng.gather(idx, x, ll, lp, lq, out=dst if idx.numel() == n_local else None)
 
         for _ in range(60):
             is_step()
         sync_all()
-        t0 = time.perf_counter()
-        n_is = 40
-        for _ in range(n_is):
-            out = is_step()
-        sync_all()
-        t_is = (time.perf_counter() - t0) / n_is
+        # timed in batches: the figure is the MEDIAN batch (min / max beside it), each batch bracketed by a device sync
+        n_batches, n_is = 7, 20
+        batch_ms = []
+        for key in host_t:
+            host_t[key] = 0.0
+        gc_mark_is = len(gc_log)
+        for _ in range(n_batches):
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(n_is):
+                out = is_step()
+            sync_all()
+            batch_ms.append((time.perf_counter() - t0) / n_is * 1e3)
+        host_ms = {k: round(v / (n_batches * n_is) * 1e3, 4) for k, v in host_t.items()}
+        gc_is = gc_summary(gc_mark_is)
+        t_is = float(np.median(batch_ms)) * 1e-3
         eng.profile(True)
         for _ in range(10):
             is_step()
@@ -325,13 +380,24 @@ def main():
         eng.profile(False)
         gk = next((k for k in kis if k.startswith("k_gather")), None)
         g_bytes = (2 * (row_b + 24) + 8) * n_local
+        busy_is = sum(c * ms for c, ms in kis.values()) / 10
+        diag = None
+        if t_is * 1e3 > 1.3 * busy_is:
+            worst = max(host_ms, key=host_ms.get)
+            diag = (f"median wall {t_is * 1e3:.3f} ms > 1.3 x GPU-busy {busy_is:.3f} ms: host side dominates, largest host "
+                    f"segment '{worst}' = {host_ms[worst]:.3f} ms per step (wait_result includes the GPU time of the step)")
         extra["is_only_step"] = {
             "workload": "configs[1]: one temperature iteration without mutation on the pristine 1M x 32 batch",
             "ms_per_step": round(t_is * 1e3, 4), "particle_iterations_per_s": n_global / t_is,
+            "ms_per_step_batches": {"min": round(min(batch_ms), 4), "median": round(t_is * 1e3, 4), "max": round(max(batch_ms), 4),
+                                    "n_batches": n_batches, "steps_per_batch": n_is},
+            "host_ms_per_step": host_ms, "host_gc": gc_is,
+            "wall_over_gpu_busy": round(t_is * 1e3 / busy_is, 3) if busy_is else None,
+            "diagnosis": diag,
             "alg_bytes_per_step": (64 + 2 * (row_b + 24)) * n_local,
             "whole_step_frac_of_hbm_peak": round((64 + 2 * (row_b + 24)) * n_local / t_is / 1e9 / HBM_PEAK_GBS, 4),
             "launches_per_step": round(sum(c for c, _ in kis.values()) / 10, 1),
-            "gpu_busy_ms_per_step": round(sum(c * ms for c, ms in kis.values()) / 10, 4),
+            "gpu_busy_ms_per_step": round(busy_is, 4),
             "gather": None if gk is None else {"kernel": gk, "avg_us": round(kis[gk][1] * 1e3, 2),
                                                "achieved_GBs": round(g_bytes / (kis[gk][1] * 1e-3) / 1e9, 1),
                                                "frac_of_hbm_peak": round(g_bytes / (kis[gk][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
