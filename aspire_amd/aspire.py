@@ -112,6 +112,11 @@ class Aspire:
             kw = {k: v for k, v in self.flow_kwargs.items() if k != "flow_class"}
             if "transforms" in kw:  # zuko's name for the number of autoregressive transforms
                 kw["n_transforms"] = int(kw.pop("transforms"))
+            known = {"n_transforms", "hidden_features", "seed", "flow_dtype"}
+            unknown = sorted(k for k in kw if k not in known)
+            if unknown:  # zuko-only options (passes, randperm, activation, ...): this flow has no counterpart - say so, go on
+                logger.warning("MAFFlow ignores flow_kwargs %s (zuko options without a counterpart here)", unknown)
+                kw = {k: v for k, v in kw.items() if k in known}
             self._flow = MAFFlow(dims=self.dims, device=self.device or "cpu", data_transform=data_transform,
                                  dtype=kw.pop("flow_dtype", torch.float32), **kw)
         elif backend == "coupling":

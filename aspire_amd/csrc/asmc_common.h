@@ -142,6 +142,7 @@ struct asmc_ctx {
     const char** prof_label;    // [ASMC_PROF_MAX]
     // pinned host staging for scalar read-back / small uploads
     double* h_pinned;  // [8192] doubles
+    unsigned ref_status_gen;  // asmc_reference_factor: generation of the pinned status cell in use (asmc_pcn.hip)
     double* h_gram;    // [128 + 128 * 128] doubles: asmc_mean_gram's results (sum | Gram) until asmc_mean_gram_fetch
     double* d_ref;     // the same on the device (d_small / d_partials are every other call's scratch): asmc_reference_factor
     int gram_pending_d;  // d of an enqueued, not yet fetched asmc_mean_gram (0: none)

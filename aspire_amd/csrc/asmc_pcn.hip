@@ -1942,7 +1942,15 @@ __global__ __launch_bounds__(1024) void k_ref_factor(int d, const double* __rest
         if (status) status[0] = (double)tries;
         if (em && tries < 0) em[3] = -1.0;
     }
-    if (tries < 0) return;
+    if (tries < 0) {
+        // no factor: poison (L, Linv) so that a mutation that runs before the host has looked at the status cannot use the
+        // factors an earlier fit left in this slot - NaN proposals are rejected and counted, never silently accepted
+        if (out)
+            for (int e = tid; e < d * d; e += NT) o_L[e] = __builtin_nan(""), o_Li[e] = __builtin_nan("");
+        if (tab)
+            for (int e = tid; e < d * (d + 1) / 2; e += NT) tab[d + e] = __builtin_nan("");
+        return;
+    }
     for (int j = tid; j < d; j += NT) {
         const double sd = sqrt(s_a[j * ld + j]);
         s_diag[j] = sd, s_rdiag[j] = 1.0 / sd;
@@ -2067,6 +2075,20 @@ int asmc_mean_gram_fetch(asmc_ctx* ctx, int d, double* sum_host, double* gram_ho
 }
 
 }  // extern "C"
+// Every factorisation request reads its status back into a pinned cell OF ITS OWN (a ring indexed by a generation counter): the
+// host writes the "not yet known" sentinel into a cell that no copy still in flight targets - an earlier request's late copy
+// lands in its own cell and cannot be mistaken for this request's status.  (The ring is deeper than the requests a caller can
+// have in flight between two synchronisations: one per temperature.)
+#define REF_STATUS_CELL0 8010
+#define REF_STATUS_CELLS 16
+static int ref_status_request(asmc_ctx* ctx, const double* d_status, hipStream_t st) {
+    ctx->ref_status_gen++;
+    double* cell = ctx->h_pinned + REF_STATUS_CELL0 + ctx->ref_status_gen % REF_STATUS_CELLS;
+    *cell = -2.0;
+    ASMC_HIP(hipMemcpyAsync(cell, d_status, sizeof(double), hipMemcpyDeviceToHost, st));
+    return ASMC_OK;
+}
+
 int asmc_ref_factor_launch(asmc_ctx* ctx, int d, const double* sum, const double* gram, double n_mean, double denom, double* out,
                            double* status, double* tab, double* em, int it, hipStream_t st) {
     const size_t lds = sizeof(double) * (size_t)d * (d + 1);
@@ -2110,9 +2132,7 @@ int asmc_reference_factor(asmc_ctx* ctx, int d, int64_t n_mean, int64_t n_cov, c
     const int rc = asmc_ref_factor_launch(ctx, d, ctx->d_ref, ctx->d_ref + 128, (double)n_mean, (double)(n_cov - 1 > 1 ? n_cov - 1 : 1),
                                           out_dev, d_status, nullptr, nullptr, 0, st);
     if (rc) return rc;
-    ctx->h_pinned[8010] = -2.0;  // (not yet known)
-    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8010, d_status, sizeof(double), hipMemcpyDeviceToHost, st));
-    return ASMC_OK;
+    return ref_status_request(ctx, d_status, st);
 }
 
 // The sharded form of the same fit without a host round trip: column sums and the centred Gram matrix into the CALLER's device
@@ -2173,14 +2193,12 @@ int asmc_reference_factor_dev(asmc_ctx* ctx, int d, int64_t n_mean, int64_t n_co
     const int rc = asmc_ref_factor_launch(ctx, d, sum_dev, gram_dev, (double)n_mean, (double)(n_cov - 1 > 1 ? n_cov - 1 : 1), out_dev,
                                           d_status, nullptr, nullptr, 0, st);
     if (rc) return rc;
-    ctx->h_pinned[8010] = -2.0;
-    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8010, d_status, sizeof(double), hipMemcpyDeviceToHost, st));
-    return ASMC_OK;
+    return ref_status_request(ctx, d_status, st);
 }
 
 int asmc_reference_factor_status(asmc_ctx* ctx, int* status_host) {
     ASMC_REQUIRE(ctx && status_host, "null pointer");
-    *status_host = (int)ctx->h_pinned[8010];  // -2: the stream has not been synchronised since asmc_reference_factor
+    *status_host = (int)ctx->h_pinned[REF_STATUS_CELL0 + ctx->ref_status_gen % REF_STATUS_CELLS];  // -2: the stream has not been synchronised since asmc_reference_factor
     return ASMC_OK;
 }
 

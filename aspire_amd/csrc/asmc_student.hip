@@ -122,6 +122,9 @@ __global__ __launch_bounds__(256) void k_student_mstep(int64_t m, int d, int blo
     __shared__ double s_lab[2];
     if ((double)it > em[2]) return;
     const int tid = threadIdx.x;
+    // every thread takes its copy of the state BEFORE the first barrier: thread 0 rewrites em[0] at the end of the kernel, and a
+    // wave that read it late would see the new nu, form another `c` and could take the branch with the barriers alone
+    const double nu = em[0], rtol = em[4];
     if (tid < d + 2) {
         double t = 0.0;
         for (int b = 0; b < blocks; b++) t += partials[(size_t)b * (d + 2) + tid];  // block order: the host's sum
@@ -130,7 +133,6 @@ __global__ __launch_bounds__(256) void k_student_mstep(int64_t m, int d, int blo
     __syncthreads();
     const double sum_z = s_sum[0], sum_lz = s_sum[1];
     if (tid < d) tab[tid] = s_sum[2 + tid] / sum_z;
-    const double nu = em[0], rtol = em[4];
     const double c = 1.0 + sum_lz / (double)m - log_minus_digamma(0.5 * (nu + (double)d));
     // f(v) = log(v/2) - psi(v/2) + c, decreasing from +inf to c
     double nu_new;

@@ -730,8 +730,10 @@ class HipEngine:
         status, mu_host, Sigma_host); None for shapes the device-side EM does not take (the host-driven EM serves them)."""
         assert xs.dtype == torch.float64 and xs.is_contiguous() and xs.dim() == 2
         m, d = xs.shape
-        if d not in (32, 64, 128) or xs.data_ptr() % 16 or os.environ.get("ASMC_GRAM_GENERIC"):
+        if d not in (32, 64, 128) or os.environ.get("ASMC_GRAM_GENERIC"):
             return None
+        if xs.data_ptr() % 16:  # alignment is a rank-local accident: never let it choose the code path (ranks must agree bit for bit)
+            xs = xs.clone()
         seg = -(-d // 32) * 32
         size = seg + 2 * seg * d
         bufs = self.__dict__.setdefault("_ref_out", {})

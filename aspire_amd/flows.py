@@ -10,6 +10,7 @@
 """
 from __future__ import annotations
 
+import contextlib
 import logging
 import math
 
@@ -253,12 +254,13 @@ class CouplingFlow(Flow):
                  dtype=torch.float32, data_transform=None):
         super().__init__(dims, device=torch.device(device or "cpu"), data_transform=data_transform)
         self.dtype = dtype
-        torch.manual_seed(seed)
         half = torch.arange(dims) < (dims + 1) // 2
         masks = [half if i % 2 == 0 else ~half for i in range(n_layers)]
         if dims == 1:
             raise ValueError("CouplingFlow needs dims >= 2")
-        self.layers = torch.nn.ModuleList([_Coupling(dims, m, tuple(map(int, hidden_features))) for m in masks])
+        self._seed, self._rng_snapshot = int(seed), None
+        with self._private_rng():  # initialisation draws from the flow's own stream: the process-wide torch RNG is left alone
+            self.layers = torch.nn.ModuleList([_Coupling(dims, m, tuple(map(int, hidden_features))) for m in masks])
         self.layers.to(device=self.device, dtype=dtype)
         self.loc = torch.zeros(dims, device=self.device, dtype=dtype)
         self.scale = torch.ones(dims, device=self.device, dtype=dtype)
@@ -267,6 +269,26 @@ class CouplingFlow(Flow):
         self._packed, self._version = None, 0  # device pack cache; bumped whenever the parameters change
         self._init_args = dict(dims=int(dims), n_layers=int(n_layers), hidden_features=[int(h) for h in hidden_features],
                                seed=int(seed), dtype=str(dtype).replace("torch.", ""))
+
+    @contextlib.contextmanager
+    def _private_rng(self):
+        """The flow's own torch RNG stream (weight initialisation, the shuffles of `fit`): seeded with the flow's seed on first
+        use, carried from one use to the next, and run inside `torch.random.fork_rng`, so that building or training a flow
+        never re-seeds or advances the process-wide generators (a user density drawing from torch's RNG saw repeated streams
+        when every refit called `torch.manual_seed`).  The stream is the one `torch.manual_seed(seed)` used to start: trained
+        parameters are unchanged."""
+        cuda = [self.device] if self.device.type == "cuda" else []
+        with torch.random.fork_rng(devices=cuda):
+            if self._rng_snapshot is None:
+                torch.manual_seed(self._seed)
+            else:
+                torch.set_rng_state(self._rng_snapshot[0])
+                if cuda and self._rng_snapshot[1] is not None:
+                    torch.cuda.set_rng_state(self._rng_snapshot[1], self.device)
+            try:
+                yield
+            finally:
+                self._rng_snapshot = (torch.get_rng_state(), torch.cuda.get_rng_state(self.device) if cuda else None)
 
     def export_layers(self):
         """(weights, biases): fp32 numpy arrays, three dense layers per coupling layer, torch Linear layout."""
@@ -361,6 +383,16 @@ class CouplingFlow(Flow):
         opt = torch.optim.Adam(self.layers.parameters(), lr=lr)
         hist = FlowHistory()
         best, best_state, bad = float("inf"), None, 0
+        with self._private_rng():
+            best, best_state = self._train(opt, hist, xt, xv, n_val, n_epochs, batch_size, patience, clip_grad)
+        if best_state is not None:
+            self.layers.load_state_dict(best_state)
+        self.layers.eval()
+        self._version += 1
+        return hist
+
+    def _train(self, opt, hist, xt, xv, n_val, n_epochs, batch_size, patience, clip_grad):
+        best, best_state, bad = float("inf"), None, 0
         for _ in range(n_epochs):
             self.layers.train()
             order = torch.randperm(xt.shape[0], device=self.device)
@@ -388,11 +420,7 @@ class CouplingFlow(Flow):
                     bad += 1
                     if bad >= patience:
                         break
-        if best_state is not None:
-            self.layers.load_state_dict(best_state)
-        self.layers.eval()
-        self._version += 1
-        return hist
+        return best, best_state
 
     @torch.no_grad()
     def attach_engine(self, engine, sample_dtype=None, gid0: int = 0):
@@ -443,6 +471,21 @@ class CouplingFlow(Flow):
     @torch.no_grad()
     def forward(self, x, xp=None):
         return self._to_latent(torch.as_tensor(x, dtype=self.dtype, device=self.device))
+
+    @torch.no_grad()
+    def log_prob_f64(self, x):
+        """log q(x) with the SAME parameters widened to fp64 and fp64 arithmetic throughout (on the flow's device): the
+        yardstick the accuracy of the fp32 / split-fp16 kernels is quoted against (bench.py `flow_max_rel_vs_fp64`)."""
+        import copy
+
+        x = torch.as_tensor(x, device=self.device).to(torch.float64)
+        layers = copy.deepcopy(self.layers).to(torch.float64)
+        z = (x - self.loc.double()) / self.scale.double()
+        ladj = -torch.log(self.scale.double()).sum().expand(x.shape[0]).clone()
+        for layer in layers:
+            z, l = layer(z)
+            ladj = ladj + l
+        return self._base_logp(z) + ladj
 
     # flows/torch/flows.py:63-110: <path>/config (one dataset per flattened key, utils.py:841-887) and <path>/weights (one
     # dataset per state-dict entry).  `h5_file` is an open h5py File / Group or anything with the same group protocol
@@ -550,12 +593,13 @@ class MAFFlow(CouplingFlow):
                  dtype=torch.float32, data_transform=None):
         Flow.__init__(self, dims, device=torch.device(device or "cpu"), data_transform=data_transform)
         self.dtype = dtype
-        torch.manual_seed(seed)
+        self._seed, self._rng_snapshot = int(seed), None
         hidden = tuple(map(int, hidden_features))
         prev = torch.get_default_dtype()
         torch.set_default_dtype(dtype)
         try:
-            self.layers = torch.nn.ModuleList([_Autoregressive(dims, hidden, reverse=bool(i % 2)) for i in range(n_transforms)])
+            with self._private_rng():
+                self.layers = torch.nn.ModuleList([_Autoregressive(dims, hidden, reverse=bool(i % 2)) for i in range(n_transforms)])
         finally:
             torch.set_default_dtype(prev)
         self.layers.to(device=self.device, dtype=dtype)

@@ -256,9 +256,19 @@ class FlowPreconditioningTransform:
             kw["n_transforms"] = int(kw.pop("transforms"))
         cls = MAFFlow if self.flow_backend == "maf" else CouplingFlow
         self.flow = cls(dims=len(self.parameters), device=self._flow_device(ut), dtype=kw.pop("flow_dtype", torch.float32), **kw)
-        self.flow.fit(ut, **self.fit_kwargs)
         if comm is not None and comm.sharded:
-            self.flow.sync_shards(comm)  # every rank's chain must run in the SAME latent space
+            # the latent space is fitted to the WHOLE population, once: every rank contributes an equal strided share of at most
+            # `fit_subsample` rows (all-gather, as the Student-t reference fit does), rank 0 trains on them, and its parameters
+            # go to everyone - training is not bit-reproducible across processes, and every chain must run in the SAME space
+            m = int(self.fit_kwargs.get("fit_subsample", 16384))
+            k = max(1, min(m // comm.world, ut.shape[0]))
+            rows = torch.as_tensor((np.arange(k, dtype=np.int64) * ut.shape[0]) // k, device=ut.device)
+            pooled = comm.all_gather_ragged(ut[rows].contiguous(), [int(c) for c in comm.all_gather_i64(np.array([k]))[:, 0]])
+            if comm.rank == 0:
+                self.flow.fit(pooled, **{a: b for a, b in self.fit_kwargs.items() if a != "fit_subsample"})
+            self.flow.sync_shards(comm)
+        else:
+            self.flow.fit(ut, **{a: b for a, b in self.fit_kwargs.items() if a != "fit_subsample"})
         return self._cast(self.flow.forward(ut)[0], u)
 
     def _cast(self, z, like):

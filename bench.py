@@ -39,6 +39,18 @@ MFMA_F32_PEAK_TF = 157.3  # dense fp32-input MFMA peak (MI355X_MICROARCH.md, mat
 MFMA_F16_PEAK_TF = 2516.6  # dense fp16 MFMA peak (same table)
 
 
+def kernel_source_hash() -> str:
+    """sha256 (16 hex digits) over the sources of the dominant kernel: the fused flow-proposal step, the flow layers and the
+    proposal noise.  profiles/traffic_per_launch.json and profiles/sq_counters.json are stamped with it."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("asmc_pcn_fused.hip", "asmc_flow_dev.h", "asmc_pcn_dev.h"):
+        with open(os.path.join(ROOT, "aspire_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -204,16 +216,22 @@ def main():
     step_ms = sum(kern[k][0] * kern[k][1] for k in step_kernels) / max(n_mut, 1)
     flow_k = next((k for k in kern if k.startswith("k_coupling_logprob") or k.startswith("k_pcn_flow_fused")), None)
     flow_ms = kern[flow_k][1] if flow_k else None
-    pcn_ks = [k for k in kern if k.split("<")[0] in ("k_pcn_flow_propose", "k_pcn_flow_accept")]
-    pcn_ms = sum(kern[k][1] for k in pcn_ks)
     # algorithmic bytes per particle per step: 2 d s + 16 for the pCN state update, + d s + 16 when the
     # proposal density is a flow evaluated by its own pass over the proposed rows (x' written, re-read; log q written, re-read)
     b_pcn = (2 * row_b + 16) * n_local
     b_step = (3 * row_b + 32) * n_local
-    traffic = None
+    # Counters that bench.py cannot collect itself (rocprofv3 --pmc needs its own passes) come from the committed profile
+    # files.  They describe ONE build of the kernel: both files carry the hash of the kernel's sources at collection time
+    # (tools/stamp_profiles.py) and the fields are null when the tree's sources have moved on.
+    src_hash = kernel_source_hash()
+    traffic, traffic_src = None, None
     try:  # HBM bytes per launch from the committed PMC run of this configuration (profiles/, separate --pmc passes)
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_per_launch.json")))
-        traffic = tr.get(f"{(flow_k or '').split('<')[0]}|n={n_local}|d={d}|{args.x_dtype}")
+        if tr.get("_kernel_source_hash") == src_hash:
+            traffic = tr.get(f"{(flow_k or '').split('<')[0]}|n={n_local}|d={d}|{args.x_dtype}")
+            traffic_src = tr.get("_comment")
+        else:
+            traffic_src = "stale: profiles/traffic_per_launch.json was collected on other kernel sources"
     except Exception:
         traffic = None
     per_kernel = {}
@@ -227,39 +245,58 @@ def main():
     split = flow_math == "f16x2-split"
     exec_flops = 3 * flow_flops if split else flow_flops          # MFMA flops actually issued per launch
     exec_peak = MFMA_F16_PEAK_TF if split else MFMA_F32_PEAK_TF   # dense peak of the instruction that issues them
-    sq = None
+    sq, sq_src = None, None
     try:  # SQ counters of the dominant kernel from the committed rocprofv3 --pmc run (profiles/sq_counters.json)
         sqj = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))
-        sq = sqj.get(f"{(flow_k or '').split('<')[0]}|n={n_local}|d={d}|{args.x_dtype}|{args.noise}")
+        if sqj.get("_kernel_source_hash") == src_hash:
+            sq = sqj.get(f"{(flow_k or '').split('<')[0]}|n={n_local}|d={d}|{args.x_dtype}|{args.noise}")
+            sq_src = sq.get("source") if sq else None
+        else:
+            sq_src = "stale: profiles/sq_counters.json was collected on other kernel sources"
     except Exception:
         sq = None
+    # accuracy of the flow arithmetic of THIS run (north star: log-weights within 1e-6 relative): the device kernel's log q on a
+    # 64k subsample of the run's own final population against the same parameters evaluated in fp64
+    flow_rel = None
+    try:
+        xs_acc = torch.as_tensor(post.x, device=eng.device)
+        rows = torch.arange(0, xs_acc.shape[0], max(1, xs_acc.shape[0] // 65536), device=eng.device)[:65536]
+        xa = xs_acc[rows].to(torch.float64).contiguous()
+        got = eng.coupling_logprob(xa, cflow.device_coupling(eng))
+        ref64 = cflow.log_prob_f64(xa)
+        rel = (got - ref64).abs() / ref64.abs().clamp_min(1.0)
+        flow_rel = {"max_rel": float(rel.max()), "rows": int(rows.numel()), "nonfinite": int((~torch.isfinite(got)).sum()),
+                    "what": "asmc_coupling_logprob (the fused step's layer arithmetic) on a strided subsample of the last timed run's "
+                            "posterior, against CouplingFlow.log_prob_f64 (same fp32 parameters widened, fp64 arithmetic); "
+                            "denominator max(|log q|, 1)"}
+    except Exception as exc:  # never lose the line over the side measurement
+        flow_rel = {"error": repr(exc)}
     roofline = {
         # the dominant kernel, priced against the pipe it USES ("achieved / peak at the dtype used"): the fp32
         # layers run as split-fp16 products (each fp32 operand an fp16 (hi, lo) pair, three v_mfma_f32_32x32x16_f16 per K = 16
-        # with fp32 accumulation, csrc/asmc_flow_dev.h), so `achieved` counts the fp16 MFMA flops issued and `peak` is the
-        # dense fp16 matrix peak; ASMC_FLOW_MATH=f32 prices the fp32-input MFMA chain against its own peak
+        # with fp32 accumulation, csrc/asmc_flow_dev.h).  THREE fractions, because they answer different questions:
+        #   frac_algorithmic  SURVEY §8d's own definition: the flow's 57 kflop per particle / time / dense fp16 peak
+        #   frac (executed)   the fp16 MFMA flops actually issued (3 x algorithmic) / time / the same peak
+        #   hbm_frac          SURVEY §8d's fused bytes 2 d s + 16 per particle / time / HBM peak
         "bound": "mfma", "kernel": flow_k, "dtype": "f16 (split products of f32 operands)" if split else "f32",
         "flow_math": flow_math,
         "achieved": round(exec_flops / (flow_ms * 1e-3) / 1e12, 2) if flow_ms else None, "peak": exec_peak, "unit": "TFLOP/s",
         "frac": round(exec_flops / (flow_ms * 1e-3) / 1e12 / exec_peak, 4) if flow_ms else None,
+        "frac_algorithmic": round(flow_flops / (flow_ms * 1e-3) / 1e12 / exec_peak, 4) if flow_ms else None,
+        "achieved_algorithmic": round(flow_flops / (flow_ms * 1e-3) / 1e12, 2) if flow_ms else None,
         "flops_per_launch": exec_flops, "algorithmic_f32_flops_per_launch": flow_flops,
-        # the same launch against the HBM roofline: SURVEY §8d's fused bytes 2 d s + 16 per particle per step
         "hbm_frac": round(b_pcn / (flow_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if flow_ms else None,
+        "hbm_achieved_GBs": round(b_pcn / (flow_ms * 1e-3) / 1e9, 1) if flow_ms else None,
         "algorithmic_bytes_per_launch": b_pcn,
-        "traffic": traffic,
+        "traffic": traffic, "traffic_source": traffic_src,
         "traffic_over_algorithmic": round(traffic / b_pcn, 3) if traffic else None,
         # what limits it (rocprofv3 --pmc SQ counters of the committed profile, fractions of SIMD time): the vector ALU
         "limiter": "vector-ALU issue (fp64 noise + mat-vec, the flow's ReLU / hi-lo conversions); matrix pipe and vector ALU add up",
         "valu_active": sq.get("valu_active") if sq else None, "mfma_busy": sq.get("mfma_busy") if sq else None,
         "valu_insts_per_64_particle_tile": sq.get("valu_insts_per_tile") if sq else None,
-        "sq_counters_source": sq.get("source") if sq else None,
-        # round 2's headline definition, kept for continuity only: algorithmic fp32 flops / fp32-input MFMA peak
-        "fp32_equivalent_frac": round(flow_flops / (flow_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4) if flow_ms else None,
+        "sq_counters_source": sq_src, "kernel_source_hash": src_hash,
+        "flow_max_rel_vs_fp64": flow_rel,
         "avg_ms": round(flow_ms, 5) if flow_ms else None,
-        "pcn_kernels": {"bound": "hbm", "kernels": pcn_ks, "avg_ms_per_step": round(pcn_ms, 5), "alg_bytes_per_step": b_pcn,
-                        "achieved": round(b_pcn / (pcn_ms * 1e-3) / 1e9, 1) if pcn_ms else None, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(b_pcn / (pcn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pcn_ms else None,
-                        "noise": args.noise},
         "whole_step": {"device_ms_per_mutation_step": round(step_ms, 5), "executed_mfma_floor_ms": round(exec_flops / (exec_peak * 1e12) * 1e3, 5),
                        "f32_mfma_floor_ms": round(mfma_floor, 5), "hbm_floor_ms": round(hbm_floor, 5)},
         "gpu_busy_ms_per_run": round(tot_ms, 3), "wall_ms_per_run": round(dt / args.steps * 1e3, 3),
@@ -541,7 +578,7 @@ def main():
             "gpu_over_cpu_all_cores": value / vN, "gpu_over_cpu_single_thread": value / v1,
         }
         try:  # restatement-to-reference ratio, measured in the build container (tests/tools/ref_ratio.py)
-            result["cpu_baseline"]["port_vs_reference"] = json.load(open(os.path.join(ROOT, "profiles", "r02_ref_ratio.json")))
+            result["cpu_baseline"]["port_vs_reference"] = json.load(open(os.path.join(ROOT, "profiles", "ref_ratio.json")))
         except Exception:
             pass
     # The JSON line must be the LAST thing on the job's stdout.  RCCL writes a version banner through C stdio, which is

@@ -217,6 +217,19 @@ def test_reference_fit_moments_ride_on_the_fused_step(eng, monkeypatch):
     same = np.all(np.abs(_np(out_a.x) - _np(out_b.x)) <= 1e-9 * (1 + np.abs(_np(out_b.x))), axis=1)
     assert same.mean() > 0.5
     assert abs(float(out_a.log_evidence) - float(out_b.log_evidence)) < 3 * float(out_a.log_evidence_error)
+    # EXACT leg (round-3 advice): with the ride-along column sums switched off (ASMC_GATHER_NO_COLSUM=1) both arms start their
+    # reference fit from the same k_colsum pass, so a fit enqueued behind the gather and a fit at mutation time must agree bit
+    # for bit - stale moments or wrong rows in the ahead path cannot hide behind the loose comparison above
+    monkeypatch.undo()
+    monkeypatch.setenv("ASMC_GATHER_NO_COLSUM", "1")
+    sp_c, out_c, rep_c = run(4)
+    assert rep_c["k_is_weights"][0] == temps and rep_c["k_gram_mm"][0] == temps
+    monkeypatch.setattr(HipSMC, "_speculated_moments_n", lambda self, samples: None)
+    sp_d, out_d, rep_d = run(4)
+    assert sp_c.history.beta == sp_d.history.beta and sp_c.history.mcmc_acceptance == sp_d.history.mcmc_acceptance
+    assert sp_c.history.log_norm_ratio == sp_d.history.log_norm_ratio
+    assert float(out_c.log_evidence) == float(out_d.log_evidence) and np.array_equal(_np(out_c.x), _np(out_d.x))
+    assert sp_c.rng.bit_generator.state == sp_d.rng.bit_generator.state
 
 
 def test_importance_step_enqueued_behind_the_mutation(eng, monkeypatch):

@@ -4,7 +4,7 @@ Times the REAL reference (mj-will/aspire, imported through oracle/ref_shim.py) a
 (oracle/asmc_oracle.c, the CPU baseline `kind: "port"` that travels to the GPU box) on the same IS-only temperature
 iteration of BASELINE configs[1] (1M x 32 fp64; smc/base.py:401-445 without mutate: determine_beta, ESS, evidence ratio
 + variance, resample).  The mutation step cannot be timed on the reference: its arithmetic lives in the absent
-third-party `minipcn`.  Writes profiles/r02_ref_ratio.json, which bench.py quotes next to its CPU baseline.
+third-party `minipcn`.  Writes profiles/ref_ratio.json, which bench.py quotes next to its CPU baseline.
 """
 import json
 import os
@@ -62,10 +62,11 @@ def main():
         "reference_s_per_iteration": min(tr), "port_s_per_iteration": min(tp),
         "reference_particle_iterations_per_s": n / min(tr), "port_particle_iterations_per_s": n / min(tp),
         "port_over_reference_speed": min(tr) / min(tp),
+        "measured": "round 4 build container, re-run of tests/tools/ref_ratio.py on the round's oracle",
         "note": "identical beta* and resampled rows on both sides; the mutation step has no reference timing (minipcn absent)",
     }
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    with open(os.path.join(ROOT, "profiles", "r02_ref_ratio.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "ref_ratio.json"), "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1))
 
