@@ -26,7 +26,8 @@ COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
-ASMC_ABI_VERSION = 17
+ASMC_ABI_VERSION = 18
+ASMC_FLOW_COUPLING, ASMC_FLOW_MAF = 0, 1  # asmc_coupling.kind
 ASMC_CDF_REC = 9
 ASMC_CDF_STATE = 36
 
@@ -66,7 +67,7 @@ class AsmcCoupling(ctypes.Structure):
         ("dims", c_int32),
         ("n_layers", c_int32),
         ("hidden", c_int32),
-        ("reserved", c_int32),
+        ("kind", c_int32),  # ASMC_FLOW_COUPLING / ASMC_FLOW_MAF
         ("packed_dev", c_void_p),
         ("loc_dev", c_void_p),
         ("scale_dev", c_void_p),
@@ -182,6 +183,8 @@ SIGNATURES = {
     ),
     "asmc_coupling_pack_floats": (_i64, [_i, _i, _i]),
     "asmc_coupling_pack": (_i, [_i, _i, _i, POINTER(c_void_p), POINTER(c_void_p), _vp]),
+    "asmc_maf_pack_floats": (_i64, [_i, _i, _i]),
+    "asmc_maf_pack": (_i, [_i, _i, _i, POINTER(c_void_p), POINTER(c_void_p), _vp]),
     "asmc_coupling_logprob": (_i, [_vp, _i64, _i, _vp, POINTER(AsmcCoupling), _vp, _vp]),
     "asmc_coupling_sample": (_i, [_vp, _i64, _i, POINTER(AsmcCoupling), _u64, _u64, _u32, _vp, _vp, _vp]),
     "asmc_transform_forward": (_i, [_vp, _i64, _i, _vp, _vp, _vp, POINTER(AsmcTransform), _vp]),

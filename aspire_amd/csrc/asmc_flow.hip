@@ -246,6 +246,135 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_sample(int64_t n, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// Masked autoregressive flow (include/asmc.h, ASMC_FLOW_MAF; reference flows/torch/flows.py:140-168 asks zuko for it by
+// default).  A transform is a coupling layer whose conditioner input and transformed block are BOTH the whole x (the MADE masks
+// sit in the weights as zeros), so the tile layout and the layer code are the coupling kernels' with H / 2 = the coordinates a
+// lane half holds: half hh of a particle's lane pair owns coordinates [hh H/2, (hh + 1) H/2).  Density: one pass per transform.
+template <int H, int W, typename XT, int FLOW_THREADS, bool HS>
+__global__ __launch_bounds__(FLOW_THREADS) void k_maf_logprob(int64_t n, int d, const XT* __restrict__ x,
+                                                             const float* __restrict__ packed, int n_layers,
+                                                             const float* __restrict__ loc, const float* __restrict__ scale,
+                                                             float ladj0, float base_const, double* __restrict__ out) {
+    extern __shared__ __align__(16) float sp[];
+    using FD = FlowDims<H, W>;
+    constexpr int FLOW_WAVES = FLOW_THREADS / 64, DL = H / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 31, hh = lane >> 5;
+    if (HS) {
+        flow_stage_hs<H, W, FLOW_THREADS>(sp, packed, n_layers);
+    } else {
+        const int total4 = n_layers * FD::LAYER / 4;
+        for (int i4 = threadIdx.x; i4 < total4; i4 += FLOW_THREADS) reinterpret_cast<float4*>(sp)[i4] = reinterpret_cast<const float4*>(packed)[i4];
+    }
+    __syncthreads();
+    const int64_t n_tiles = (n + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * FLOW_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * FLOW_WAVES) {
+        const int64_t row = tile * 32 + p;
+        const bool valid = row < n;
+        float xv[1][DL];
+#pragma unroll
+        for (int i = 0; i < DL; i++) {
+            const int jp = hh * DL + i;  // padded coordinates stay at zero: their weights are zero, their (s, t) come out zero
+            xv[0][i] = (valid && jp < d) ? flow_standardise((float)x[row * d + jp], loc[jp], scale[jp], 1.0f / scale[jp]) : 0.0f;
+        }
+        float ladj[1] = {0.0f};
+        float amax = 0.0f;
+        for (int c = 0; c < n_layers; c++) {
+            const float* lp = sp + (size_t)c * FD::LAYER;
+            float cond[1][DL];
+#pragma unroll
+            for (int i = 0; i < DL; i++) cond[0][i] = xv[0][i];
+            if constexpr (HS)
+                coupling_layer_hs<H, W>(cond[0], xv[0], lp, lane, hh, ladj[0], amax);
+            else
+                coupling_layer<H, W, 1>(cond, xv, lp, lane, hh, ladj);
+        }
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DL; i++) q += xv[0][i] * xv[0][i];
+        q += __shfl_xor(q, 32);
+        const float lj = ladj[0] + __shfl_xor(ladj[0], 32);
+        const float am = fmaxf(amax, __shfl_xor(amax, 32));
+        const float val = (HS && !(am < FLOW_HS_MAX)) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
+        if (valid && hh == 0) out[row] = (double)val;
+    }
+}
+
+// Sampling (flows/torch/flows.py:327-346): z ~ N(0, I) from the counter-based generator, the transforms inverted in reverse
+// order.  Inverting ONE transform: x_i = z_i exp(s_i(x_<i)) + t_i(x_<i) in the transform's variable order.  The order lives in
+// the masks, which the kernel does not see - it iterates x <- z exp(s(x)) + t(x) on ALL coordinates `d` times from x = 0: after
+// pass k every coordinate whose inputs have degree < k is final (its inputs were final a pass earlier), so d passes fix them
+// all, and the last pass's s is the log-determinant.  Values of not-yet-final coordinates are clamped into the fp16 operand
+// range: they reach other coordinates only through masked (zero) weights, and 0 x finite = 0.
+template <int H, int W, typename XT, int FLOW_THREADS>
+__global__ __launch_bounds__(FLOW_THREADS) void k_maf_sample(int64_t n, int d, const float* __restrict__ packed, int n_layers,
+                                                            const float* __restrict__ loc, const float* __restrict__ scale,
+                                                            float ladj0, float base_const, unsigned long long seed,
+                                                            unsigned long long gid0, uint32_t draw_id, XT* __restrict__ x,
+                                                            double* __restrict__ out) {
+    extern __shared__ __align__(16) float sp[];
+    using FD = FlowDims<H, W>;
+    constexpr int FLOW_WAVES = FLOW_THREADS / 64, DL = H / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 31, hh = lane >> 5;
+    flow_stage_hs<H, W, FLOW_THREADS>(sp, packed, n_layers);
+    __syncthreads();
+    const int64_t n_tiles = (n + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * FLOW_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * FLOW_WAVES) {
+        const int64_t row = tile * 32 + p;
+        const unsigned long long gid = gid0 + (unsigned long long)(row < n ? row : n - 1);
+        float zv[DL], xv[DL];
+        float q = 0.0f;
+        {   // coordinate c is element c % 4 of quad c / 4 of this particle's draw
+            int have = -1;
+            double zq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < DL; i++) {
+                const int jp = hh * DL + i;
+                if (jp < d && (jp >> 2) != have) {
+                    have = jp >> 2;
+                    normal_quad_f32(seed, gid, draw_id, (uint32_t)have, zq[0], zq[1], zq[2], zq[3]);
+                }
+                zv[i] = jp < d ? (float)zq[jp & 3] : 0.0f;
+                q += zv[i] * zv[i];
+            }
+        }
+        float ladj = 0.0f, amax = 0.0f;
+        for (int c = n_layers - 1; c >= 0; c--) {
+            const float* lp = sp + (size_t)c * FD::LAYER;
+#pragma unroll
+            for (int i = 0; i < DL; i++) xv[i] = 0.0f;
+            float ladj_pass = 0.0f, amax_pass = 0.0f;
+            for (int pass = 0; pass < d; pass++) {
+                float cond[DL], tr[DL];
+#pragma unroll
+                for (int i = 0; i < DL; i++) cond[i] = xv[i], tr[i] = zv[i];
+                ladj_pass = 0.0f, amax_pass = 0.0f;
+                coupling_layer_hs<H, W, true>(cond, tr, lp, lane, hh, ladj_pass, amax_pass);
+#pragma unroll
+                for (int i = 0; i < DL; i++) xv[i] = pass + 1 < d ? fminf(fmaxf(tr[i], -60000.0f), 60000.0f) : tr[i];
+            }
+            ladj += ladj_pass;  // (the final pass: every s is evaluated at final inputs)
+            amax = fmaxf(amax, amax_pass);
+#pragma unroll
+            for (int i = 0; i < DL; i++) zv[i] = xv[i];
+        }
+        q += __shfl_xor(q, 32);
+        const float lj = ladj + __shfl_xor(ladj, 32);
+        const float am = fmaxf(amax, __shfl_xor(amax, 32));
+        const float val = !(am < FLOW_HS_MAX) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
+        if (row < n) {
+#pragma unroll
+            for (int i = 0; i < DL; i++) {
+                const int jp = hh * DL + i;
+                if (jp < d) x[row * d + jp] = (XT)(zv[i] * scale[jp] + loc[jp]);
+            }
+            if (hh == 0) out[row] = (double)val;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // flow arithmetic: split-fp16 MFMA (fp32-equivalent operands, asmc_flow_dev.h) unless ASMC_FLOW_MATH=f32 asks for the
 // fp32 MFMA chain (read at every launch: a process can compare the two)
@@ -271,22 +400,19 @@ extern "C" int64_t asmc_coupling_pack_floats(int dims, int n_layers, int hidden)
     return (int64_t)n_layers * flow_layer_floats(flow_half_pad(dims), hidden);
 }
 
-extern "C" int asmc_coupling_pack(int dims, int n_layers, int hidden, const float* const* weights_host,
-                                  const float* const* biases_host, float* packed_host) {
-    ASMC_REQUIRE(weights_host && biases_host && packed_host, "null pointer");
-    if (!flow_supported(dims, hidden) || n_layers < 1) {
-        asmc_set_error("asmc_coupling_pack: unsupported flow (dims even and <= 64, hidden in {32,64,128})");
-        return ASMC_ERR_UNSUPPORTED;
-    }
-    const int H = flow_half_pad(dims), Wd = hidden, dh = dims / 2;
+// The packing of `n_layers` conditioner MLPs  dh -> Wd -> Wd -> 2 dh  into MFMA operand order, for lane halves that hold H / 2
+// (>= dh / 2 ... padded) inputs each.  A coupling flow of d dims calls it with dh = d / 2 (inputs = the conditioner half,
+// outputs = (s_raw, t) of the transformed half); a masked autoregressive flow with dh = d (inputs = outputs = the whole x).
+static int flow_pack_layers(const char* who, int H, int dh, int n_layers, int Wd, const float* const* weights_host,
+                            const float* const* biases_host, float* packed_host) {
     const int NB1 = Wd / 32, NB3 = H / 16;
     if (asmc_flow_math_split()) {  // the split-fp16 layers carry every weight as an fp16 pair
-        const int64_t sizes[3] = {(int64_t)Wd * dh, (int64_t)Wd * Wd, (int64_t)dims * Wd};
+        const int64_t sizes[3] = {(int64_t)Wd * dh, (int64_t)Wd * Wd, (int64_t)2 * dh * Wd};
         for (int c = 0; c < 3 * n_layers; c++)
             for (int64_t k = 0; k < sizes[c % 3]; k++)
                 if (!(fabsf(weights_host[c][k]) < 65504.0f)) {
-                    asmc_set_error("asmc_coupling_pack: weight %g of matrix %d is outside the fp16 operand range of the split-fp16 "
-                                   "flow kernels (|w| < 65504); ASMC_FLOW_MATH=f32 selects the fp32 MFMA chain", (double)weights_host[c][k], c);
+                    asmc_set_error("%s: weight %g of matrix %d is outside the fp16 operand range of the split-fp16 "
+                                   "flow kernels (|w| < 65504); ASMC_FLOW_MATH=f32 selects the fp32 MFMA chain", who, (double)weights_host[c][k], c);
                     return ASMC_ERR_UNSUPPORTED;
                 }
     }
@@ -346,6 +472,41 @@ extern "C" int asmc_coupling_pack(int dims, int n_layers, int hidden, const floa
     return ASMC_OK;
 }
 
+
+extern "C" int asmc_coupling_pack(int dims, int n_layers, int hidden, const float* const* weights_host,
+                                  const float* const* biases_host, float* packed_host) {
+    ASMC_REQUIRE(weights_host && biases_host && packed_host, "null pointer");
+    if (!flow_supported(dims, hidden) || n_layers < 1) {
+        asmc_set_error("asmc_coupling_pack: unsupported flow (dims even and <= 64, hidden in {32,64,128})");
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    return flow_pack_layers("asmc_coupling_pack", flow_half_pad(dims), dims / 2, n_layers, hidden, weights_host, biases_host, packed_host);
+}
+
+// ---- masked autoregressive flow: a transform = a coupling layer whose conditioner input and transformed block are both x -----
+static int maf_half_pad(int dims) { return ((dims + 15) / 16) * 16; }  // H of the layer templates: lane halves hold H / 2 coordinates
+static bool maf_supported(int dims, int hidden) {
+    return dims >= 1 && dims <= 32 && (hidden == 32 || hidden == 64 || hidden == 128);
+}
+
+extern "C" int64_t asmc_maf_pack_floats(int dims, int n_transforms, int hidden) {
+    if (!maf_supported(dims, hidden) || n_transforms < 1) {
+        asmc_set_error("asmc_maf_pack_floats: unsupported flow (dims <= 32, hidden in {32,64,128})");
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    return (int64_t)n_transforms * flow_layer_floats(maf_half_pad(dims), hidden);
+}
+
+extern "C" int asmc_maf_pack(int dims, int n_transforms, int hidden, const float* const* weights_host,
+                             const float* const* biases_host, float* packed_host) {
+    ASMC_REQUIRE(weights_host && biases_host && packed_host, "null pointer");
+    if (!maf_supported(dims, hidden) || n_transforms < 1) {
+        asmc_set_error("asmc_maf_pack: unsupported flow (dims <= 32, hidden in {32,64,128})");
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    return flow_pack_layers("asmc_maf_pack", maf_half_pad(dims), dims, n_transforms, hidden, weights_host, biases_host, packed_host);
+}
+
 template <int H, int W, typename XT, int FLOW_THREADS, int TPW, bool HS>
 static int launch_flow(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_coupling* f, double* out, hipStream_t st) {
     using FD = FlowDims<H, W>;
@@ -396,17 +557,99 @@ static int dispatch_flow(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_coupl
     return ASMC_ERR_UNSUPPORTED;
 }
 
+template <int H, int W, typename XT, bool HS>
+static int launch_maf(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_coupling* f, double* out, hipStream_t st) {
+    using FD = FlowDims<H, W>;
+    const size_t lds = (size_t)f->n_layers * FD::LAYER * sizeof(float);
+    if (lds > 160 * 1024) {
+        asmc_set_error("masked autoregressive flow: %d transforms of width %d do not fit in LDS together (%zu bytes)", (int)f->n_layers, W, lds);
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    auto kern = k_maf_logprob<H, W, XT, 512, HS>;
+    static size_t attr_lds = 0;  // per instantiation
+    if (lds > 64 * 1024 && lds > attr_lds) {
+        ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const int64_t want = ((n + 31) / 32 + 7) / 8;
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    const int grid = (int)(want < (int64_t)ctx->num_cu * per_cu ? want : (int64_t)ctx->num_cu * per_cu);
+    const float ladj0 = (float)(-f->log_scale_sum);
+    const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
+    ASMC_LAUNCH(ctx, st, "k_maf_logprob", kern, dim3(grid), dim3(512), lds, st, n, (int)f->dims, x, f->packed_dev, (int)f->n_layers,
+                f->loc_dev, f->scale_dev, ladj0, base_const, out);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+template <typename XT>
+static int dispatch_maf(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_coupling* f, double* out, hipStream_t st) {
+    if (!maf_supported(f->dims, f->hidden) || f->n_layers < 1) {
+        asmc_set_error("masked autoregressive flow: unsupported shape (dims <= 32, hidden in {32,64,128})");
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    const int H = maf_half_pad(f->dims);
+    const bool hs = asmc_flow_math_split();
+#define ASMC_MAF_CASE(HH, WW)                                                              \
+    if (H == HH && f->hidden == WW) {                                                      \
+        if (hs) return launch_maf<HH, WW, XT, true>(ctx, n, x, f, out, st);                \
+        return launch_maf<HH, WW, XT, false>(ctx, n, x, f, out, st);                       \
+    }
+    ASMC_MAF_CASE(16, 32)
+    ASMC_MAF_CASE(16, 64)
+    ASMC_MAF_CASE(16, 128)
+    ASMC_MAF_CASE(32, 32)
+    ASMC_MAF_CASE(32, 64)
+    ASMC_MAF_CASE(32, 128)
+#undef ASMC_MAF_CASE
+    asmc_set_error("masked autoregressive flow: unsupported shape");
+    return ASMC_ERR_UNSUPPORTED;
+}
+
+template <int H, int W, typename XT>
+static int launch_maf_sample(asmc_ctx* ctx, int64_t n, const asmc_coupling* f, unsigned long long seed, unsigned long long gid0,
+                             uint32_t draw_id, XT* x, double* out, hipStream_t st) {
+    using FD = FlowDims<H, W>;
+    const size_t lds = (size_t)f->n_layers * FD::LAYER * sizeof(float);
+    if (lds > 160 * 1024) {
+        asmc_set_error("asmc_coupling_sample: the flow's transforms must be resident in LDS together");
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    auto kern = k_maf_sample<H, W, XT, 512>;
+    static size_t attr_lds = 0;  // per instantiation
+    if (lds > 64 * 1024 && lds > attr_lds) {
+        ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const int64_t want = ((n + 31) / 32 + 7) / 8;
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    const int grid = (int)(want < (int64_t)ctx->num_cu * per_cu ? want : (int64_t)ctx->num_cu * per_cu);
+    const float ladj0 = (float)(-f->log_scale_sum);
+    const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
+    ASMC_LAUNCH(ctx, st, "k_maf_sample", kern, dim3(grid), dim3(512), lds, st, n, (int)f->dims, f->packed_dev, (int)f->n_layers,
+                f->loc_dev, f->scale_dev, ladj0, base_const, seed, gid0, draw_id, x, out);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
 extern "C" int asmc_coupling_logprob(asmc_ctx* ctx, int64_t n, int x_dtype, const void* x_dev,
                                      const asmc_coupling* flow, double* out_dev, asmc_stream stream) {
     ASMC_REQUIRE(ctx != nullptr, "null ctx");
     ASMC_REQUIRE(flow && x_dev && out_dev, "null pointer");
     ASMC_REQUIRE(n > 0, "n must be positive");
     ASMC_REQUIRE(flow->packed_dev && flow->loc_dev && flow->scale_dev, "flow parameters missing");
+    ASMC_REQUIRE(flow->kind == ASMC_FLOW_COUPLING || flow->kind == ASMC_FLOW_MAF, "bad flow kind");
+    hipStream_t st = (hipStream_t)stream;
+    if (flow->kind == ASMC_FLOW_MAF) {
+        if (x_dtype == ASMC_F64) return dispatch_maf<double>(ctx, n, (const double*)x_dev, flow, out_dev, st);
+        if (x_dtype == ASMC_F32) return dispatch_maf<float>(ctx, n, (const float*)x_dev, flow, out_dev, st);
+        asmc_set_error("asmc_coupling_logprob: bad x_dtype");
+        return ASMC_ERR_ARG;
+    }
     if (!flow_supported(flow->dims, flow->hidden) || flow->n_layers < 1) {
         asmc_set_error("asmc_coupling_logprob: unsupported flow (dims even and <= 64, hidden in {32,64,128})");
         return ASMC_ERR_UNSUPPORTED;
     }
-    hipStream_t st = (hipStream_t)stream;
     if (x_dtype == ASMC_F64) return dispatch_flow<double>(ctx, n, (const double*)x_dev, flow, out_dev, st);
     if (x_dtype == ASMC_F32) return dispatch_flow<float>(ctx, n, (const float*)x_dev, flow, out_dev, st);
     asmc_set_error("asmc_coupling_logprob: bad x_dtype");
@@ -446,6 +689,30 @@ extern "C" int asmc_coupling_sample(asmc_ctx* ctx, int64_t n, int x_dtype, const
     ASMC_REQUIRE(n > 0, "n must be positive");
     ASMC_REQUIRE(flow->packed_dev && flow->loc_dev && flow->scale_dev, "flow parameters missing");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+    ASMC_REQUIRE(flow->kind == ASMC_FLOW_COUPLING || flow->kind == ASMC_FLOW_MAF, "bad flow kind");
+    if (flow->kind == ASMC_FLOW_MAF) {
+        if (!maf_supported(flow->dims, flow->hidden) || flow->n_layers < 1 || !asmc_flow_math_split()) {
+            asmc_set_error("asmc_coupling_sample: unsupported autoregressive flow shape, or the fp32 MFMA chain was asked for (split-fp16 layers only)");
+            return ASMC_ERR_UNSUPPORTED;
+        }
+        hipStream_t stm = (hipStream_t)stream;
+        const int Hm = maf_half_pad(flow->dims);
+#define ASMC_MAF_SAMPLE_CASE(HH, WW)                                                                                      \
+    if (Hm == HH && flow->hidden == WW) {                                                                                 \
+        if (x_dtype == ASMC_F64)                                                                                          \
+            return launch_maf_sample<HH, WW, double>(ctx, n, flow, seed, gid0, draw_id, (double*)x_out_dev, lq_out_dev, stm); \
+        return launch_maf_sample<HH, WW, float>(ctx, n, flow, seed, gid0, draw_id, (float*)x_out_dev, lq_out_dev, stm);   \
+    }
+        ASMC_MAF_SAMPLE_CASE(16, 32)
+        ASMC_MAF_SAMPLE_CASE(16, 64)
+        ASMC_MAF_SAMPLE_CASE(16, 128)
+        ASMC_MAF_SAMPLE_CASE(32, 32)
+        ASMC_MAF_SAMPLE_CASE(32, 64)
+        ASMC_MAF_SAMPLE_CASE(32, 128)
+#undef ASMC_MAF_SAMPLE_CASE
+        asmc_set_error("asmc_coupling_sample: unsupported autoregressive flow shape");
+        return ASMC_ERR_UNSUPPORTED;
+    }
     if (!flow_supported(flow->dims, flow->hidden) || flow->n_layers < 1 || !asmc_flow_math_split()) {
         asmc_set_error("asmc_coupling_sample: unsupported flow shape, or the fp32 MFMA chain was asked for (split-fp16 layers only)");
         return ASMC_ERR_UNSUPPORTED;

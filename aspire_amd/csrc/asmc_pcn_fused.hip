@@ -47,20 +47,30 @@ __device__ __forceinline__ void mv_for_each(F& f) {
         mv_for_each<I + 1, N>(f);
     }
 }
+#ifndef FUSED_PRIO_A
+#define FUSED_PRIO_A 2
+#define FUSED_PRIO_B 1
+#endif
 #ifndef MV_CHUNK
 #define MV_CHUNK 8  // columns of L between two ordering points of the mat-vec
 #endif
-template <typename T, int W, int NOISE, bool HS>
+// KIND: ASMC_FLOW_COUPLING - the coupling layers described above; ASMC_FLOW_MAF - masked autoregressive transforms
+// (flows/torch/flows.py:140-168, the reference's default flow class): a transform is a coupling layer whose conditioner input and
+// transformed block are both the whole x (asmc_flow.hip), so a flow tile holds 16 coordinates per lane instead of 8 + 8 and the
+// swap pairs coordinate i with coordinate 16 + i.
+template <typename T, int W, int NOISE, bool HS, int KIND = ASMC_FLOW_COUPLING>
 __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     int64_t n, double* __restrict__ ll, double* __restrict__ lp, double* __restrict__ lq, const double* __restrict__ ptab,
     PcnScalars p, const double* rho_ptr, uint32_t step, const float* __restrict__ packed, int n_layers,
     const float* __restrict__ loc, const float* __restrict__ scale, float ladj0, float base_const,
     unsigned int* __restrict__ tile_counter, long long* __restrict__ block_counts, PcnAdaptArgs ad, int par_words) {
     constexpr int D = 32, H = 16, THREADS = FUSED_THREADS;
-    using FD = FlowDims<H, W>;
+    constexpr int HF = KIND == ASMC_FLOW_MAF ? 32 : H;  // H of the flow's layer templates (lane halves hold HF / 2 inputs)
+    static_assert(KIND == ASMC_FLOW_COUPLING || HS, "the autoregressive variant runs the split-fp16 layers only");
+    using FD = FlowDims<HF, W>;
     extern __shared__ __align__(16) float sp[];
     if (HS) {
-        flow_stage_hs<H, W, THREADS>(sp, packed, n_layers);  // split-fp16 operand images (asmc_flow_dev.h)
+        flow_stage_hs<HF, W, THREADS>(sp, packed, n_layers);  // split-fp16 operand images (asmc_flow_dev.h)
     } else {  // flow weights -> LDS; all of a thread's loads are issued before its first LDS store
         const int total4 = n_layers * FD::LAYER / 4;
         for (int base = 0; base < total4; base += THREADS * 8) {
@@ -371,6 +381,45 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         __builtin_amdgcn_sched_barrier(0);
 #endif
         // ---- phase 2: two flow tiles (particles 0-31 and 32-63 of this wave) on the MFMA -----------------------------
+        float lqt[2];
+        unsigned tn_l = 0;
+        if constexpr (KIND == ASMC_FLOW_MAF) {
+            float xA[16], xB[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {  // tile A: (own coordinate r | lane l - 32's coordinate 16 + r); tile B the other two
+                const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf[r]), __float_as_uint(xf[16 + r]), false, false);
+                xA[r] = __uint_as_float(s1[0]);
+                xB[r] = __uint_as_float(s1[1]);
+            }
+#ifndef FUSED_NOPRIO
+            if (first_on_simd)
+                __builtin_amdgcn_s_setprio(FUSED_PRIO_A);
+            else
+                __builtin_amdgcn_s_setprio(FUSED_PRIO_B);
+#endif
+            STAMP(4);
+            tn_l = tile_fetch();  // the next tile's index: back long before the flow is through
+            auto maf_tile = [&](float(&xv)[16]) __attribute__((always_inline)) -> float {
+                float ladj = 0.0f, amax = 0.0f;
+                for (int c = 0; c < n_layers; c++) {
+                    float cond[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) cond[r] = xv[r];
+                    coupling_layer_hs<HF, W>(cond, xv, sp + (size_t)c * FD::LAYER, lane, hh, ladj, amax);
+                }
+                float q = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) q += xv[r] * xv[r];
+                q += __shfl_xor(q, 32);
+                const float lj = ladj + __shfl_xor(ladj, 32);
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                return !(amax < FLOW_HS_MAX) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
+            };
+            lqt[0] = maf_tile(xA);
+            __builtin_amdgcn_sched_barrier(0);  // one tile's accumulator chains at a time
+            STAMP(5);
+            lqt[1] = maf_tile(xB);
+        } else {
         float xaA[1][H / 2], xbA[1][H / 2], xaB[1][H / 2], xbB[1][H / 2];
 #pragma unroll
         for (int r = 0; r < H / 2; r++) {
@@ -413,10 +462,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         // lockstep - both in the vector phases, then both fighting for the matrix pipe - and the MFMA sits idle half the
         // time.  Static priorities break the tie: a wave in its matrix phase outranks a wave in a vector phase, and the
         // first wave of a SIMD outranks the second when both are in the matrix phase, which pushes them into anti-phase.
-#ifndef FUSED_PRIO_A
-#define FUSED_PRIO_A 2
-#define FUSED_PRIO_B 1
-#endif
 #ifndef FUSED_NOPRIO
         if (first_on_simd)
             __builtin_amdgcn_s_setprio(FUSED_PRIO_A);
@@ -424,8 +469,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             __builtin_amdgcn_s_setprio(FUSED_PRIO_B);
 #endif
         STAMP(4);
-        const unsigned tn_l = tile_fetch();  // the next tile's index: back long before the flow is through
-        float lqt[2];
+        tn_l = tile_fetch();  // the next tile's index: back long before the flow is through
 #ifndef FUSED_FLOW2
 #define FUSED_FLOW2 1  // both tiles through each coupling layer together, MFMAs and conversions interleaved by hand (asmc_flow_dev.h)
 #endif
@@ -458,6 +502,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             STAMP(5);
             lqt[1] = flow_tile(xaB, xbB);
         }
+        }  // KIND
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
         STAMP(6);
@@ -592,10 +637,10 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
     // need 288 accumulator registers there, the compiler spilled ~300 around the hand-scheduled conversion / MFMA sequence and
     // the step returned run-to-run different log q - tools/stress_fused.py.)
     const bool hs = asmc_flow_math_split();
-#define ASMC_FUSED_CASE(WW, NZ, HSV)                                                                                     \
-    if (f->hidden == WW && pd.noise == NZ && hs == HSV) {                                                                \
-        auto kern = k_pcn_flow_fused<T, WW, NZ, HSV>;                                                                         \
-        const size_t lds0 = (size_t)f->n_layers * FlowDims<16, WW>::LAYER * sizeof(float) + FUSED_TL_DOUBLES * sizeof(double) + BM_TAB_N * sizeof(bm_d2); \
+#define ASMC_FUSED_CASE_K(WW, NZ, HSV, KD)                                                                                \
+    if (f->hidden == WW && pd.noise == NZ && hs == HSV && f->kind == KD) {                                                \
+        auto kern = k_pcn_flow_fused<T, WW, NZ, HSV, KD>;                                                                     \
+        const size_t lds0 = (size_t)f->n_layers * FlowDims<(KD == ASMC_FLOW_MAF ? 32 : 16), WW>::LAYER * sizeof(float) + FUSED_TL_DOUBLES * sizeof(double) + BM_TAB_N * sizeof(bm_d2); \
         const size_t par_bytes = (size_t)((n_tiles + 31) / 32) * 4;   /* the tiles' parity bits ride in LDS when they fit */ \
         const int par_words = lds0 + par_bytes <= 160 * 1024 ? (int)(par_bytes / 4) : 0;                                     \
         const size_t lds = lds0 + (size_t)par_words * 4;                                                                     \
@@ -610,6 +655,7 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
         ASMC_LAUNCH_CHECK();                                                                                             \
         return ASMC_OK;                                                                                                  \
     }
+#define ASMC_FUSED_CASE(WW, NZ, HSV) ASMC_FUSED_CASE_K(WW, NZ, HSV, ASMC_FLOW_COUPLING)
     ASMC_FUSED_CASE(64, ASMC_NOISE_F64, true)
 #ifndef FUSED_ONLY_HEADLINE  // (diagnostic builds compile the headline instantiation alone: seconds instead of minutes)
     ASMC_FUSED_CASE(64, ASMC_NOISE_F64, false)
@@ -623,9 +669,15 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
     ASMC_FUSED_CASE(128, ASMC_NOISE_F64, false)
     ASMC_FUSED_CASE(128, ASMC_NOISE_F32, true)
     ASMC_FUSED_CASE(128, ASMC_NOISE_F32, false)
+    // masked autoregressive transforms (split-fp16 layers; the fp32 MFMA chain takes the split propose / flow / accept kernels)
+    ASMC_FUSED_CASE_K(64, ASMC_NOISE_F64, true, ASMC_FLOW_MAF)
+    ASMC_FUSED_CASE_K(64, ASMC_NOISE_F32, true, ASMC_FLOW_MAF)
+    ASMC_FUSED_CASE_K(32, ASMC_NOISE_F64, true, ASMC_FLOW_MAF)
+    ASMC_FUSED_CASE_K(32, ASMC_NOISE_F32, true, ASMC_FLOW_MAF)
 #endif
 #undef ASMC_FUSED_CASE
-    asmc_set_error("fused flow step: unsupported hidden width %d", (int)f->hidden);
+#undef ASMC_FUSED_CASE_K
+    asmc_set_error("fused flow step: unsupported flow (kind %d, hidden width %d)", (int)f->kind, (int)f->hidden);
     return ASMC_ERR_UNSUPPORTED;
 }
 
@@ -636,6 +688,11 @@ bool asmc_pcn_flow_fused_ok(const asmc_pcn_params* prm, const asmc_coupling* f) 
     if (prm->d != 32 || f->dims != 32) return false;
     if (prm->log_likelihood.n_components != 1 || prm->log_prior.n_components != 1) return false;
     if (!(f->hidden == 32 || f->hidden == 64 || f->hidden == 128)) return false;
+    if (f->kind == ASMC_FLOW_MAF) {  // split-fp16 layers only, widths whose accumulators fit one tile at a time
+        if (!asmc_flow_math_split() || f->hidden == 128) return false;
+        const size_t per_tr = (size_t)((2 * (f->hidden / 32) + 2) * 32 + f->hidden * 32 + f->hidden * f->hidden + 2 * 32 * f->hidden) * sizeof(float);
+        return per_tr * (size_t)f->n_layers + FUSED_TL_DOUBLES * sizeof(double) + BM_TAB_N * sizeof(bm_d2) <= 160 * 1024;
+    }
     const size_t per_layer = (size_t)((2 * (f->hidden / 32) + 1) * 32 + f->hidden * 16 + f->hidden * f->hidden + 2 * 16 * f->hidden) * sizeof(float);
     return per_layer * (size_t)f->n_layers + FUSED_TL_DOUBLES * sizeof(double) + BM_TAB_N * sizeof(bm_d2) <= 160 * 1024;
 }

@@ -61,13 +61,14 @@ class DeviceCoupling:
     dims: int
     n_layers: int
     hidden: int
-    packed: torch.Tensor  # fp32 [asmc_coupling_pack_floats]
+    packed: torch.Tensor  # fp32 [asmc_coupling_pack_floats / asmc_maf_pack_floats]
     loc: torch.Tensor  # fp32 [dims]
     scale: torch.Tensor  # fp32 [dims]
     log_scale_sum: float
+    kind: int = 0  # ASMC_FLOW_COUPLING (0) / ASMC_FLOW_MAF (1)
 
     def c_struct(self) -> AsmcCoupling:
-        return AsmcCoupling(self.dims, self.n_layers, self.hidden, 0, self.packed.data_ptr(), self.loc.data_ptr(),
+        return AsmcCoupling(self.dims, self.n_layers, self.hidden, self.kind, self.packed.data_ptr(), self.loc.data_ptr(),
                             self.scale.data_ptr(), self.log_scale_sum)
 
 
@@ -111,6 +112,27 @@ def pack_coupling(lib, dims: int, hidden: int, weights, biases) -> np.ndarray:
     wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
     bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
     check(lib.asmc_coupling_pack(dims, n_layers, hidden, wp, bp, out.ctypes.data_as(ctypes.c_void_p)), "asmc_coupling_pack")
+    return out
+
+
+def pack_maf(lib, dims: int, hidden: int, weights, biases) -> np.ndarray:
+    """Host-side packing of a masked autoregressive flow (asmc_maf_pack): the MASKED dense layers, three per transform, in
+    torch.nn.Linear layout ([hidden, dims], [hidden, hidden], [2 dims, hidden])."""
+    n_tr = len(weights) // 3
+    assert len(weights) == len(biases) == 3 * n_tr and n_tr >= 1
+    ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+    bs = [np.ascontiguousarray(b, dtype=np.float32) for b in biases]
+    for c in range(n_tr):
+        assert ws[3 * c].shape == (hidden, dims) and ws[3 * c + 1].shape == (hidden, hidden)
+        assert ws[3 * c + 2].shape == (2 * dims, hidden)
+        assert bs[3 * c].shape == (hidden,) and bs[3 * c + 1].shape == (hidden,) and bs[3 * c + 2].shape == (2 * dims,)
+    nfl = lib.asmc_maf_pack_floats(dims, n_tr, hidden)
+    if nfl < 0:
+        raise _lib.AsmcError(f"autoregressive flow shape not supported by the HIP kernel: {lib.asmc_last_error().decode()}")
+    out = np.empty(nfl, dtype=np.float32)
+    wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+    bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
+    check(lib.asmc_maf_pack(dims, n_tr, hidden, wp, bp, out.ctypes.data_as(ctypes.c_void_p)), "asmc_maf_pack")
     return out
 
 
@@ -531,6 +553,15 @@ class HipEngine:
         return DeviceCoupling(dims, len(weights) // 3, hidden, self.asarray(packed, dtype=torch.float32),
                               self.asarray(np.asarray(loc, dtype=np.float32), dtype=torch.float32),
                               self.asarray(scale, dtype=torch.float32), float(np.log(scale.astype(np.float64)).sum()))
+
+    def make_maf(self, dims: int, hidden: int, weights, biases, loc, scale) -> DeviceCoupling:
+        """A masked autoregressive flow on the device (include/asmc.h ASMC_FLOW_MAF): `weights` are the MASKED matrices."""
+        packed = pack_maf(self.lib, dims, hidden, weights, biases)
+        scale = np.asarray(scale, dtype=np.float32)
+        return DeviceCoupling(dims, len(weights) // 3, hidden, self.asarray(packed, dtype=torch.float32),
+                              self.asarray(np.asarray(loc, dtype=np.float32), dtype=torch.float32),
+                              self.asarray(scale, dtype=torch.float32), float(np.log(scale.astype(np.float64)).sum()),
+                              kind=_lib.ASMC_FLOW_MAF)
 
     def coupling_logprob(self, x: torch.Tensor, flow: DeviceCoupling) -> torch.Tensor:
         assert x.is_contiguous() and x.dim() == 2 and x.shape[1] == flow.dims

@@ -585,9 +585,10 @@ class MAFFlow(CouplingFlow):
     """Masked autoregressive flow (Papamakarios et al. 2017) - the flow class the reference asks zuko for by default
     (`ZukoFlow(flow_class="MAF")`, flows/torch/flows.py:140-164; zuko is absent from this image, so this is the repository's
     own statement of the architecture: `n_transforms` MADE transforms with alternating variable order, affine with a bounded
-    log-scale).  Training, sampling, `log_prob`, `forward` / `inverse`, save / load are CouplingFlow's; the passes themselves
-    run in PyTorch (north star: PyTorch-ROCm for the flow forward / inverse pass) - there is no HIP kernel for this flow, so a
-    mutation with it evaluates log q between the device-side propose and accept halves (`HipSMC.last_mutation_path`)."""
+    log-scale).  Training, `log_prob`, `forward` / `inverse`, save / load are CouplingFlow's PyTorch code.  In the hot path the
+    flow runs on the HIP kernels (`device_coupling` -> include/asmc.h ASMC_FLOW_MAF): the mutation's log q inside
+    `asmc_pcn_mutate_flow` (one fused kernel per step at dims = 32) and the proposal draw in `asmc_coupling_sample` - no torch op
+    inside the mutation loop."""
 
     def __init__(self, dims: int, n_transforms: int = 3, hidden_features=(64, 64), seed: int = 1234, device=None,
                  dtype=torch.float32, data_transform=None):
@@ -612,10 +613,33 @@ class MAFFlow(CouplingFlow):
                                seed=int(seed), dtype=str(dtype).replace("torch.", ""))
 
     def export_layers(self):
-        raise ValueError("a masked autoregressive flow has no HIP kernel: its passes run in PyTorch")
+        """(weights, biases): the MASKED fp32 matrices (weight * mask) of the three dense layers of every transform, torch
+        Linear layout - what `asmc_maf_pack` takes (the masks, and with them each transform's variable order, travel inside
+        the weights as zeros)."""
+        ws, bs = [], []
+        for layer in self.layers:
+            lin = [m for m in layer.net if isinstance(m, _MaskedLinear)]
+            if len(lin) != 3:
+                raise ValueError("the HIP autoregressive kernel needs exactly two hidden layers")
+            for m in lin:
+                ws.append((m.weight * m.mask).detach().to("cpu", torch.float32).numpy())
+                bs.append(m.bias.detach().to("cpu", torch.float32).numpy())
+        return ws, bs
 
     def device_coupling(self, engine):
-        raise ValueError("a masked autoregressive flow has no HIP kernel: its passes run in PyTorch")
-
-    def _sample_on_engine(self, n_samples: int):
-        return None
+        """Pack the flow for the HIP kernels (asmc_coupling_logprob / _sample / asmc_pcn_mutate_flow with kind = ASMC_FLOW_MAF).
+        float32 flows of dims <= 32 with two equal hidden widths in {32, 64, 128}; raises otherwise so that callers fall back
+        to the torch modules knowingly."""
+        if self.dtype != torch.float32:
+            raise ValueError("device_coupling needs a float32 flow")
+        if self._has_transform():
+            raise ValueError("the flow lives in the data transform's space; the kernel evaluates log q in x")
+        key = (id(engine), self._version)
+        if self._packed is None or self._packed[0] != key:
+            ws, bs = self.export_layers()
+            hidden = ws[0].shape[0]
+            if ws[1].shape != (hidden, hidden):
+                raise ValueError("the HIP autoregressive kernel needs equal hidden widths")
+            self._packed = (key, engine.make_maf(self.dims, hidden, ws, bs, self.loc.detach().cpu().numpy(),
+                                                 self.scale.detach().cpu().numpy()))
+        return self._packed[1]

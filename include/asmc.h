@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 17
+#define ASMC_ABI_VERSION 18
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -510,11 +510,13 @@ int asmc_pcn_accept(asmc_ctx* ctx, int64_t n, int d, int x_dtype, void* x_dev,
  *     [hidden, d/2], [hidden, hidden], [d, hidden] with output rows s_raw_0.. then t_0..);
  *     writes them in MFMA operand order into packed_host.
  *   asmc_coupling_logprob: out_dev[i] = log q(x_i). */
+#define ASMC_FLOW_COUPLING 0 /* affine coupling layers with alternating half masks (above) */
+#define ASMC_FLOW_MAF 1      /* masked autoregressive transforms (below) */
 typedef struct asmc_coupling {
     int32_t dims;
-    int32_t n_layers;
+    int32_t n_layers; /* coupling layers, or autoregressive transforms */
     int32_t hidden;
-    int32_t reserved;
+    int32_t kind;     /* ASMC_FLOW_COUPLING / ASMC_FLOW_MAF: every entry point that takes a flow dispatches on it */
     const float* packed_dev; /* asmc_coupling_pack output copied to the device */
     const float* loc_dev;    /* [dims] */
     const float* scale_dev;  /* [dims] */
@@ -532,6 +534,27 @@ int asmc_coupling_logprob(asmc_ctx* ctx, int64_t n, int x_dtype, const void* x_d
  * Split-fp16 layers with every layer resident in LDS; ASMC_ERR_UNSUPPORTED otherwise (the caller samples with its own modules). */
 int asmc_coupling_sample(asmc_ctx* ctx, int64_t n, int x_dtype, const asmc_coupling* flow, uint64_t seed, uint64_t gid0,
                          uint32_t draw_id, void* x_out_dev, double* lq_out_dev, asmc_stream stream);
+
+/* ---- masked autoregressive flow (MAF), the reference's DEFAULT flow class ---------------------------------------------
+ * ZukoFlow(flow_class="MAF") (flows/torch/flows.py:140-168) evaluated by log_prob (:368-387) in every MCMC step and by
+ * sample_and_log_prob (:327-346) in the proposal draw.  zuko is absent: the architecture is this repository's statement of
+ * Papamakarios et al. 2017 (aspire_amd/flows.py MAFFlow) - x' = (x - loc) / scale, then n_layers autoregressive transforms
+ * z_i = (x_i - t_i(x_<i)) exp(-s_i(x_<i)), s = 2 tanh(s_raw / 2), with (s_raw, t) = MLP dims -> hidden -> hidden -> 2 dims
+ * (ReLU) whose weights carry the MADE masks (the masks, and with them each transform's variable order, are folded into the
+ * weights the caller hands over: the kernels see dense layers);  log q(x) = N(z; 0, I) - sum s - sum log scale.
+ * A transform is evaluated exactly like a coupling layer whose conditioner input AND transformed block are the whole x: the
+ * same split-fp16 MFMA layers, the same packing with the roles "dims / 2 -> dims".  dims <= 32 (odd dims allowed), hidden in
+ * {32, 64, 128}; the density is ONE pass per transform, sampling inverts a transform by `dims` passes (each pass fixes the
+ * coordinates whose inputs are already final; intermediate values are clamped to the fp16 operand range so that a
+ * not-yet-final coordinate cannot poison the others through a masked - zero - weight), used once per run.
+ *   asmc_maf_pack_floats / asmc_maf_pack (host only): weights_host[3t+0..2] / biases_host[3t+0..2] = the three MASKED dense
+ *     layers of transform t in torch.nn.Linear layout ([hidden, dims], [hidden, hidden], [2 dims, hidden] with output rows
+ *     s_raw_0 .. s_raw_{dims-1}, t_0 .. t_{dims-1}).
+ * The packed block goes into an asmc_coupling with kind = ASMC_FLOW_MAF; asmc_coupling_logprob, asmc_coupling_sample,
+ * asmc_pcn_mutate_flow(_enqueue) take it as they take a coupling flow (the fused one-kernel step at dims = 32). */
+int64_t asmc_maf_pack_floats(int dims, int n_transforms, int hidden);
+int asmc_maf_pack(int dims, int n_transforms, int hidden, const float* const* weights_host, const float* const* biases_host,
+                  float* packed_host);
 
 /* asmc_pcn_mutate_flow: asmc_pcn_mutate with the proposal density q given by a coupling flow instead
  * of a built-in mixture (params->log_q is ignored): per step propose -> log q(x') on the MFMA ->

@@ -88,10 +88,15 @@ def lib():
             "orc_moments": (None, [i64, ci, vp, vp, vp]),
             "orc_is_iteration": (ci, [i64, ci, vp, vp, vp, vp, d, d, d, vp, vp, vp, vp, vp, vp]),
             "orc_coupling_logprob": (ci, [i64, ci, vp, ci, ci, vp, vp, vp, vp, vp]),
+            "orc_maf_logprob": (ci, [i64, ci, vp, ci, ci, vp, vp, vp, vp, vp]),
             "orc_transform": (ci, [i64, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, d, ci]),
             "orc_pcn_flow_step": (
                 i64,
                 [i64, ci, vp, vp, vp, vp, d, vp, vp, vp, d, vp, vp, ci, ci, vp, vp, vp, vp, u64, u64, u32, ci, ci],
+            ),
+            "orc_pcn_flow_step_kind": (
+                i64,
+                [i64, ci, vp, vp, vp, vp, d, vp, vp, vp, d, vp, vp, ci, ci, vp, vp, vp, vp, u64, u64, u32, ci, ci, ci],
             ),
             "orc_max_threads": (ci, []),
             "orc_set_margin_sink": (None, [vp]),
@@ -434,6 +439,24 @@ def coupling_logprob(x, weights, biases, loc, scale):
     return out
 
 
+def maf_logprob(x, weights, biases, loc, scale):
+    """fp32 log-density of the masked autoregressive flow; weights: the MASKED matrices, 3 per transform, torch Linear layout."""
+    x = _f64(np.atleast_2d(x))
+    n, d = x.shape
+    ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+    bs = [np.ascontiguousarray(b, dtype=np.float32) for b in biases]
+    hidden = ws[0].shape[0]
+    loc = np.ascontiguousarray(loc, dtype=np.float32)
+    scale = np.ascontiguousarray(scale, dtype=np.float32)
+    wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+    bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
+    out = np.empty(n)
+    st = lib().orc_maf_logprob(n, d, _p(x), len(ws) // 3, hidden, wp, bp, loc.ctypes.data, scale.ctypes.data, _p(out))
+    if st != 0:
+        raise ValueError(f"orc_maf_logprob failed ({st})")
+    return out
+
+
 class accept_margins:
     """`with accept_margins(n) as m:` - the pCN / tpCN / flow step functions called inside record particle i's accept margin
     log_a - log u in m[i] (the decision is m[i] > 0); used to show that mismatching decisions are razor edges."""
@@ -455,7 +478,7 @@ def max_threads() -> int:
 
 
 def pcn_flow_step(x, ll, lp, lq, beta, mu, L, Linv, rho, t_ll, t_lp, weights, biases, loc, scale, seed, gid0, step,
-                  noise="f64", n_threads=1):
+                  noise="f64", n_threads=1, flow_kind="coupling"):
     """In-place pCN step whose proposal density is a coupling flow (configs[2]); `n_threads` OpenMP threads
     (0 = every core of the host).  Returns #accepted."""
     assert x.dtype == np.float64 and x.flags.c_contiguous
@@ -468,9 +491,10 @@ def pcn_flow_step(x, ll, lp, lq, beta, mu, L, Linv, rho, t_ll, t_lp, weights, bi
     wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
     bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
     a, b = t_ll.c_struct(), t_lp.c_struct()
-    return lib().orc_pcn_flow_step(n, d, _p(x), _p(ll), _p(lp), _p(lq), beta, _p(mu), _p(L), _p(Linv), rho,
-                                   ctypes.addressof(a), ctypes.addressof(b), len(ws) // 3, ws[0].shape[0], wp, bp,
-                                   loc.ctypes.data, scale.ctypes.data, seed, gid0, step, int(noise == "f32"), int(n_threads))
+    return lib().orc_pcn_flow_step_kind(n, d, _p(x), _p(ll), _p(lp), _p(lq), beta, _p(mu), _p(L), _p(Linv), rho,
+                                        ctypes.addressof(a), ctypes.addressof(b), len(ws) // 3, ws[0].shape[0], wp, bp,
+                                        loc.ctypes.data, scale.ctypes.data, seed, gid0, step, int(noise == "f32"), int(n_threads),
+                                        int(flow_kind == "maf"))
 
 
 def transform(x, kind, periodic, lower, upper, mean=None, std=None, eps=1e-6, inverse=False):
