@@ -512,6 +512,115 @@ __device__ __forceinline__ void coupling_layer_hs2(const float (&condA)[H / 2], 
     for (int c = 0; c < 4; c++) epi(oB, transB, ladjB, c);
 }
 
+// ---- ONE tile through a coupling layer, its own conversions in the shadow of its own MFMAs (round 4) --------------------------
+// coupling_layer_hs2 hides a tile's operand conversions behind the OTHER tile's MFMAs, which keeps two tiles' accumulators alive
+// (128 registers at W = 64) and leaves no room for anything else across the flow.  Here ONE tile runs with its conversions
+// software-pipelined against its own MFMAs: while the MFMAs of K-step group g issue, the operand of group g + 1 is converted a
+// quarter at a time - possible whenever group g + 1 reads the PREVIOUS layer's accumulators (complete since that layer ended).
+// Only the first group of a layer cannot start early (its source is what group g is still accumulating): three short bubbles per
+// coupling layer, which the SIMD's other wave fills.  Peak accumulators: 64 registers - the fused pCN step keeps the proposal y'
+// (64 registers) in the register file across the flow instead of parking it in HBM.  PREFETCH: the A operands of group g + 1 are
+// read from LDS while group g's MFMAs issue (16 more registers at W = 64).
+// Same operations in the same order per accumulator as coupling_layer_hs / _hs2: bit-identical results.
+template <int H, int W, bool PREFETCH = true>
+__device__ __forceinline__ void coupling_layer_hs1p(const float (&cond)[H / 2], float (&trans)[H / 2], const float* __restrict__ lp,
+                                                    int lane, int hh, float& ladj, unsigned& amax) {
+    using FD = FlowDims<H, W>;
+    constexpr int NB1 = FD::NB1, NB3 = FD::NB3, ST1 = H / 16, ST2 = 2 * NB1, G = ST1 + 2 * ST2;
+    constexpr int NBM = NB1 > NB3 ? NB1 : NB3;
+    const float* b1 = lp;
+    const float* b2 = b1 + NB1 * 32;
+    const float* b3 = b2 + NB1 * 32;
+    const float* a1f = b3 + NB3 * 32;
+    const half8* A1 = reinterpret_cast<const half8*>(a1f) + lane;
+    const half8* A2 = reinterpret_cast<const half8*>(a1f + W * H) + lane;
+    const half8* A3 = reinterpret_cast<const half8*>(a1f + W * H + W * W) + lane;
+    floatx16 h1[NB1], h2[NB1], o[NB3];
+    acc_bias1<NB1>(h1, b1, hh);
+    auto src = [&](int g, int j) -> float {
+        if (g < ST1) return cond[8 * g + j];
+        const int S = (g - ST1) % ST2;
+        return g < ST1 + ST2 ? h1[S / 2][8 * (S % 2) + j] : h2[S / 2][8 * (S % 2) + j];
+    };
+    auto first_of_layer = [](int g) { return g == 0 || g == ST1 || g == ST1 + ST2; };
+    unsigned hp[4], lq[4];
+    auto cvt = [&](int g, int c, bool last) {  // quarter c of group g's operand; `last`: the MFMAs that read it may follow directly
+        const float e0 = src(g, 2 * c), e1 = src(g, 2 * c + 1);
+        if (last) {
+            if (g < ST1) split2_f16<false, true>(e0, e1, hp[c], lq[c]);
+            else split2_f16<true, true>(e0, e1, hp[c], lq[c]);
+        } else {
+            if (g < ST1) split2_f16<false, false>(e0, e1, hp[c], lq[c]);
+            else split2_f16<true, false>(e0, e1, hp[c], lq[c]);
+        }
+        if (c & 1) {
+            if (g < ST1) split4_range<true>(hp[c - 1], hp[c], amax);
+            else split4_range<false>(hp[c - 1], hp[c], amax);
+        }
+    };
+    auto pack = [](const unsigned (&q)[4]) -> half8 { return __builtin_bit_cast(half8, flow_u4{q[0], q[1], q[2], q[3]}); };
+    auto a_ptr = [&](int g) -> const half8* { return g < ST1 ? A1 : g < ST1 + ST2 ? A2 : A3; };
+    auto a_load = [&](int g, half8 (&ah)[NBM], half8 (&al)[NBM]) {
+        const int layer = g < ST1 ? 0 : g < ST1 + ST2 ? 1 : 2;
+        const int S = layer == 0 ? g : (g - ST1) % ST2, ST = layer == 0 ? ST1 : ST2, NBO = layer == 2 ? NB3 : NB1;
+        const half8* Ap = a_ptr(g);
+#pragma unroll
+        for (int nb = 0; nb < NBO; nb++) {
+            ah[nb] = Ap[(size_t)(2 * (nb * ST + S)) * 64];
+            al[nb] = Ap[(size_t)(2 * (nb * ST + S) + 1) * 64];
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; c++) cvt(0, c, c == 3);
+    half8 bh = pack(hp), bl = pack(lq);
+    half8 ah[NBM], al[NBM], ahn[NBM], aln[NBM];
+    a_load(0, ah, al);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int layer = g < ST1 ? 0 : g < ST1 + ST2 ? 1 : 2;
+        const int NBO = layer == 2 ? NB3 : NB1, NM = 3 * NBO;
+        const bool more = g + 1 < G, overlap = more && !first_of_layer(g + 1);
+        if (g == ST1) acc_bias1<NB1>(h2, b2, hh);
+        if (g == ST1 + ST2) acc_bias1<NB3>(o, b3, hh);
+        if (PREFETCH && more) a_load(g + 1, ahn, aln);  // lands while this group's MFMAs issue
+#pragma unroll
+        for (int m = 0; m < NM; m++) {
+            const int k = m / NBO, nb = m % NBO;
+            floatx16& acc = layer == 0 ? h1[nb] : layer == 1 ? h2[nb] : o[nb];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(k < 2 ? ah[nb] : al[nb], k == 1 ? bl : bh, acc, 0, 0, 0);
+            if (overlap) {
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (c * NM / 4 == m) cvt(g + 1, c, c == 3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {
+            if (!overlap) {  // the next layer's first operand: its source is complete only now
+#pragma unroll
+                for (int c = 0; c < 4; c++) cvt(g + 1, c, c == 3);
+            }
+            bh = pack(hp), bl = pack(lq);
+            if (PREFETCH) {
+#pragma unroll
+                for (int nb = 0; nb < NBM; nb++) ah[nb] = ahn[nb], al[nb] = aln[nb];
+            } else {
+                a_load(g + 1, ah, al);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < H / 2; q++) {
+        const float sraw = o[q / 16][q % 16];
+        const float t = o[(H / 2 + q) / 16][(H / 2 + q) % 16];
+        const float sv = 2.0f - 4.0f * __builtin_amdgcn_rcpf(__expf(sraw) + 1.0f);  // 2 tanh(sraw / 2), see coupling_layer
+        trans[q] = (trans[q] - t) * __expf(-sv);
+        ladj -= sv;
+    }
+}
+
 // Stage `n_layers` coupling layers from the fp32 pack in HBM into LDS as split-fp16 operand images (biases copied).
 template <int H, int W, int THREADS>
 __device__ __forceinline__ void flow_stage_hs(float* __restrict__ sp, const float* __restrict__ packed, int n_layers) {

@@ -47,6 +47,17 @@ __device__ __forceinline__ void mv_for_each(F& f) {
         mv_for_each<I + 1, N>(f);
     }
 }
+// FUSED_INPLACE (round 4): the proposal y' stays in the register file across the flow and ACCEPTED lanes store it into the state
+// in place - one state array, no park, no copy of the minority, HBM traffic = the algorithmic 2 d s + 16 bytes per particle at
+// any acceptance rate.  The flow then runs one 32-particle tile at a time (coupling_layer_hs1p: 64 accumulator registers instead
+// of the 128 of the two interleaved tiles, which is where y' lives).  FUSED_INPLACE=0: round 3's two-halves state with a parity
+// byte per tile and the two tiles interleaved (coupling_layer_hs2).
+#ifndef FUSED_INPLACE
+#define FUSED_INPLACE 1
+#endif
+#ifndef HS1P_PREFETCH
+#define HS1P_PREFETCH (W < 128)  // A operands of the next K-step group read while the current group's MFMAs issue
+#endif
 #ifndef FUSED_PRIO_A
 #define FUSED_PRIO_A 2
 #define FUSED_PRIO_B 1
@@ -194,6 +205,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         return t_l;
     };
     auto tile_parity = [&](unsigned t) -> unsigned {
+        if (FUSED_INPLACE) return 0u;  // one state array
         if (par_words > 0) return (unsigned)__builtin_amdgcn_readfirstlane((int)((par_bits[t >> 5] >> (t & 31u)) & 1u));
         return (unsigned)__builtin_amdgcn_readfirstlane((int)tile_par[t]);
     };
@@ -229,7 +241,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         const int64_t i = (int64_t)t * 64 + lane;
         const bool valid = i < n;
         const unsigned ys_tile = t * 64u * (unsigned)sizeof(T);
+#if !FUSED_INPLACE
         const __amdgpu_buffer_rsrc_t ypr = __builtin_amdgcn_make_buffer_rsrc(par ? ysu : ysu1, 0, half_records, 0x00020000);  // B
+#endif
         const unsigned long long gid = p.gid0 + (unsigned long long)i;
         // ---- phase 1: proposal, one lane per particle (y, ll, lp, lq: loaded behind the previous tile's flow) ---------
         double q0 = 0.0, q1 = 0.0;
@@ -364,10 +378,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         const double nll = Lt[T_LOGW] - 0.5 * qa;
         const double nlp = Lt[T_LOGW + 1] - 0.5 * qb;
         STAMP(3);
+#if !FUSED_INPLACE
         if (valid) {
 #pragma unroll
             for (int j = 0; j < D; j++) soa_store<T>(ypr, ys_lane, ys_tile + (unsigned)j * ys_row, v[j]);
         }
+#endif
         // everything of the acceptance test that does not need log q(x') is finished HERE, and pinned: left to the
         // scheduler these computations sink below the flow, y' (64 VGPRs) stays alive across it for |y'|^2, and the
         // accumulators spill.  log_p_t(ll', lp', lq') = (1 - beta) lq' + beta (ll' + lp'): the second product is formed now.
@@ -473,7 +489,32 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
 #ifndef FUSED_FLOW2
 #define FUSED_FLOW2 1  // both tiles through each coupling layer together, MFMAs and conversions interleaved by hand (asmc_flow_dev.h)
 #endif
-        if (HS && FUSED_FLOW2 && W < 128) {  // (W = 128: the two interleaved tiles need 288 accumulator registers - one tile at a time there)
+        if (HS && FUSED_INPLACE) {  // one tile at a time, conversions in the shadow of the tile's own MFMAs; y' stays in registers
+            auto one_tile = [&](float(&xa)[1][H / 2], float(&xb)[1][H / 2]) __attribute__((always_inline)) -> float {
+                float ladj = 0.0f;
+                unsigned amax_pk = 0u;
+                for (int c = 0; c < n_layers; c++) {
+                    const float* lpk = sp + (size_t)c * FD::LAYER;
+                    if ((c & 1) == 0)
+                        coupling_layer_hs1p<H, W, HS1P_PREFETCH>(xa[0], xb[0], lpk, lane, hh, ladj, amax_pk);
+                    else
+                        coupling_layer_hs1p<H, W, HS1P_PREFETCH>(xb[0], xa[0], lpk, lane, hh, ladj, amax_pk);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                float amax = range_pk_max(amax_pk);
+                float q = 0.0f;
+#pragma unroll
+                for (int r = 0; r < H / 2; r++) q += xa[0][r] * xa[0][r] + xb[0][r] * xb[0][r];
+                q += __shfl_xor(q, 32);
+                const float lj = ladj + __shfl_xor(ladj, 32);
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                return !(amax < FLOW_HS_MAX) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
+            };
+            lqt[0] = one_tile(xaA, xbA);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(5);
+            lqt[1] = one_tile(xaB, xbB);
+        } else if (HS && FUSED_FLOW2 && W < 128) {  // (W = 128: the two interleaved tiles need 288 accumulator registers - one tile at a time there)
             float ladjA = 0.0f, ladjB = 0.0f;
             unsigned amaxA = 0u, amaxB = 0u;  // packed fp16 running maxima of the operands' hi halves
             for (int c = 0; c < n_layers; c++) {
@@ -533,6 +574,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             lq[i] = nlq;
             n_acc++;
         }
+#if FUSED_INPLACE
+        if (accepted) {  // y' is still in registers: the accepted lanes' rows change in place, nothing else moves
+            const __amdgpu_buffer_rsrc_t ysw = __builtin_amdgcn_make_buffer_rsrc(ysu, 0, half_records, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < D; j++) soa_store<T>(ysw, ys_lane, ys_tile + (unsigned)j * ys_row, v[j]);
+        }
+#else
         {
             const int n_a = __builtin_popcountll(__ballot(accepted)), n_r = __builtin_popcountll(__ballot(valid && !accepted));
             const bool flip = n_a > 0 && n_r <= n_a;  // wave uniform: the state moves to half B
@@ -549,6 +597,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             }
             if (flip && lane == 0) tile_par[t] = (unsigned char)(par ^ 1u);
         }
+#endif
         STAMP(7);
 #ifdef FUSED_STAMP
         ntile++;
@@ -642,7 +691,7 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
         auto kern = k_pcn_flow_fused<T, WW, NZ, HSV, KD>;                                                                     \
         const size_t lds0 = (size_t)f->n_layers * FlowDims<(KD == ASMC_FLOW_MAF ? 32 : 16), WW>::LAYER * sizeof(float) + FUSED_TL_DOUBLES * sizeof(double) + BM_TAB_N * sizeof(bm_d2); \
         const size_t par_bytes = (size_t)((n_tiles + 31) / 32) * 4;   /* the tiles' parity bits ride in LDS when they fit */ \
-        const int par_words = lds0 + par_bytes <= 160 * 1024 ? (int)(par_bytes / 4) : 0;                                     \
+        const int par_words = (!FUSED_INPLACE && lds0 + par_bytes <= 160 * 1024) ? (int)(par_bytes / 4) : 0;                     \
         const size_t lds = lds0 + (size_t)par_words * 4;                                                                     \
         static size_t attr_lds = 0;                                                                                      \
         if (lds > 64 * 1024 && lds > attr_lds) {                                                                         \

@@ -2085,8 +2085,9 @@ def test_student_fit_on_the_device_vs_numpy_em(eng, m, d, iters):
 
 
 def test_sampler_with_a_maf_proposal_gpu(eng):
-    """The reference's default flow class as the proposal (MAFFlow: PyTorch passes, no HIP kernel): the mutation evaluates log q
-    between the device-side propose and accept halves; evidence of the Gaussian product within its error bar."""
+    """The reference's default flow class as the proposal at a dimension without the one-kernel step (d = 8): the device-side
+    step loop with k_maf_logprob between the propose and accept kernels - no torch pass, no host round trip per step (round 3
+    ran MAFFlow's PyTorch modules here); evidence of the Gaussian product within its error bar."""
     from aspire_amd.flows import MAFFlow
     from aspire_amd.samplers.smc import HipSMC
     from aspire_amd.targets import DiagGaussianMixture
@@ -2096,8 +2097,12 @@ def test_sampler_with_a_maf_proposal_gpu(eng):
     flow.fit(1.3 * np.random.default_rng(0).normal(size=(4000, d)), n_epochs=6)
     lik = DiagGaussianMixture.isotropic(d, normalized=False)
     sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=torch, engine=eng, rng=np.random.default_rng(4))
+    eng.profile(True)
     out = sp.sample(n, sampler_kwargs=dict(n_steps=8, step_fn="pcn"), store_sample_history=False)
-    assert "callables" in sp.last_mutation_path
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert "flow: device-side step loop" in sp.last_mutation_path
+    assert rep["k_maf_logprob"][0] >= 8 * len(sp.history.beta) and rep["k_maf_sample"][0] >= 1
     assert abs(float(out.log_evidence) - 0.5 * d * math.log(math.pi)) < 5 * float(out.log_evidence_error) + 0.02
     assert 0.05 < np.mean(sp.history.mcmc_acceptance) < 0.99
 
