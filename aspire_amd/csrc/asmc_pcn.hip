@@ -2348,6 +2348,8 @@ static bool pcn_ensure_ysoa(asmc_ctx* ctx, int64_t n, int d, int x_dtype, PcnDev
             return false;
         }
         ctx->ysoa_bytes = need;
+        // the fused flow step reads whole 64-particle tiles: the slots behind a ragged last tile must hold finite numbers
+        if (hipMemsetAsync(ctx->d_ysoa, 0, need, st) != hipSuccess) return false;
     }
     pd.ys = ctx->d_ysoa;
     pd.n_pad = n_pad;

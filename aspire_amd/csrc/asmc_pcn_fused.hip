@@ -55,6 +55,43 @@ __device__ __forceinline__ void mv_for_each(F& f) {
 #ifndef FUSED_INPLACE
 #define FUSED_INPLACE 1
 #endif
+// FUSED_MVMFMA (round 4): x' = mu + L y' on the fp64 matrix cores (v_mfma_f64_16x16x4_f64) instead of 528 vector FMAs per
+// particle fed by 288 LDS broadcast reads per tile (the mat-vec was LDS-latency bound: 11 k of a lone wave's 61 k cycles per tile
+// for 2 k cycles of arithmetic).  The 64 lane-private rows of y' are turned into MFMA operands IN PLACE by a 4 x 4 transpose of
+// (register within a K-step, 16-lane group) - two swap stages, v_permlane32_swap then v_permlane16_swap - after which register
+// 4 s + r holds, in lane (g, n), coordinate 4 s + g of particle 16 r + n: the B operand of K-step s for particle block r.  The
+// coefficient image (A operand: one double per lane per (row block, K-step), zero above the diagonal) costs 12 LDS reads per
+// tile.  A lane receives rows 16 mb + 4 g + r of its four particle blocks; the quadratic forms are summed over a particle's four
+// lanes by the same transpose (+ 3 adds), the flow's standardised input is formed in place and ONE v_permlane16_swap per
+// register pair lands it in the flow tiles' layout (lane half hh: coordinates 8 hh .. 8 hh + 7 of either half - the layout the
+// permlane32 swaps produced).  The accepted lanes' y' is stored from the transposed registers (each still a run of 16
+// consecutive particles of one coordinate: 128-byte segments).  Coupling flows only; FUSED_INPLACE only.
+#ifndef FUSED_MVMFMA
+#define FUSED_MVMFMA FUSED_INPLACE
+#endif
+typedef double fused_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fused_swap32(double& x, double& y) {  // x.lanes[32..63] <-> y.lanes[0..31]
+    const unsigned long long xb = __builtin_bit_cast(unsigned long long, x), yb = __builtin_bit_cast(unsigned long long, y);
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)xb, (unsigned)yb, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(xb >> 32), (unsigned)(yb >> 32), false, false);
+    x = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
+    y = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+}
+__device__ __forceinline__ void fused_swap16(double& x, double& y) {  // the odd 16-lane rows of x <-> the even rows of y
+    const unsigned long long xb = __builtin_bit_cast(unsigned long long, x), yb = __builtin_bit_cast(unsigned long long, y);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)xb, (unsigned)yb, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(xb >> 32), (unsigned)(yb >> 32), false, false);
+    x = __builtin_bit_cast(double, ((unsigned long long)hi[0] << 32) | lo[0]);
+    y = __builtin_bit_cast(double, ((unsigned long long)hi[1] << 32) | lo[1]);
+}
+// (q0, q1, q2, q3)[lane (g, n)] -> (q_g of lane (0, n), q_g of lane (1, n), q_g of lane (2, n), q_g of lane (3, n)): the 4 x 4
+// transpose of (register, 16-lane group)
+__device__ __forceinline__ void fused_transpose4(double& q0, double& q1, double& q2, double& q3) {
+    fused_swap32(q0, q2);
+    fused_swap32(q1, q3);
+    fused_swap16(q0, q1);
+    fused_swap16(q2, q3);
+}
 #ifndef HS1P_PREFETCH
 #define HS1P_PREFETCH (W < 128)  // A operands of the next K-step group read while the current group's MFMAs issue
 #endif
@@ -106,21 +143,45 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     constexpr int T_MU = D * D, T_LLMU = T_MU + D, T_LLPR = T_LLMU + D, T_LPMU = T_LLPR + D, T_LPPR = T_LPMU + D,
                   T_LOGW = T_LPPR + D, T_LOC = T_LOGW + 2;  // then loc / scale / 1/scale: 3 x D floats = 1.5 D doubles
     static_assert(T_LOC + 3 * D / 2 <= FUSED_TL_DOUBLES, "pCN tables");
+    constexpr bool MVM = FUSED_MVMFMA && FUSED_INPLACE && KIND == ASMC_FLOW_COUPLING;  // the mat-vec on the fp64 matrix cores
     {
         const double* m0g = ptab + 2 * PTAB_TRI(D) + D;
-        for (int e = threadIdx.x; e < D * D; e += THREADS) {
-            const int j = e / D, k = e - j * D;
-            tl[e] = k <= j ? ptab[j * (j + 1) / 2 + k] : 0.0;
-        }
-        for (int e = threadIdx.x; e < D; e += THREADS) {
-            tl[T_MU + e] = ptab[2 * PTAB_TRI(D) + e];
-            tl[T_LLMU + e] = m0g[ASMC_MAX_COMPONENTS + e];
-            tl[T_LLPR + e] = m0g[ASMC_MAX_COMPONENTS * (1 + D) + e];
-            tl[T_LPMU + e] = m0g[PTAB_MIX(D) + ASMC_MAX_COMPONENTS + e];
-            tl[T_LPPR + e] = m0g[PTAB_MIX(D) + ASMC_MAX_COMPONENTS * (1 + D) + e];
-            reinterpret_cast<float*>(tl + T_LOC)[e] = loc[e];
-            reinterpret_cast<float*>(tl + T_LOC)[D + e] = scale[e];
-            reinterpret_cast<float*>(tl + T_LOC)[2 * D + e] = 1.0f / scale[e];
+        if (MVM) {
+            // A-operand image of L: slot (mb, s) = mb == 0 ? s : 4 + s (row block mb, K-step s; s < 4 mb + 4), 64 doubles each:
+            // lane l supplies A[i = l & 15][k = l >> 4]; accumulator row i = h + 4 r lands in lane group h, register r, and is made
+            // to BE row 16 mb + 4 h + r of x' by storing that row of L at image row i = (row % 4) * 4 ... i.e. i % 4 = h, i / 4 = r
+            for (int e = threadIdx.x; e < 12 * 64; e += THREADS) {
+                const int slot = e >> 6, l = e & 63, mb = slot < 4 ? 0 : 1, sidx = slot < 4 ? slot : slot - 4;
+                const int i = l & 15, j = 16 * mb + 4 * (i & 3) + (i >> 2), k = 4 * sidx + (l >> 4);
+                tl[e] = k <= j ? ptab[j * (j + 1) / 2 + k] : 0.0;
+            }
+            // per-row tables in the order a lane reads them: entry h * 8 + mb * 4 + r <-> row 16 mb + 4 h + r
+            for (int e = threadIdx.x; e < D; e += THREADS) {
+                const int j = 16 * ((e >> 2) & 1) + 4 * (e >> 3) + (e & 3);
+                tl[T_MU + e] = ptab[2 * PTAB_TRI(D) + j];
+                tl[T_LLMU + e] = m0g[ASMC_MAX_COMPONENTS + j];
+                tl[T_LLPR + e] = m0g[ASMC_MAX_COMPONENTS * (1 + D) + j];
+                tl[T_LPMU + e] = m0g[PTAB_MIX(D) + ASMC_MAX_COMPONENTS + j];
+                tl[T_LPPR + e] = m0g[PTAB_MIX(D) + ASMC_MAX_COMPONENTS * (1 + D) + j];
+                reinterpret_cast<float*>(tl + T_LOC)[e] = loc[j];
+                reinterpret_cast<float*>(tl + T_LOC)[D + e] = scale[j];
+                reinterpret_cast<float*>(tl + T_LOC)[2 * D + e] = 1.0f / scale[j];
+            }
+        } else {
+            for (int e = threadIdx.x; e < D * D; e += THREADS) {
+                const int j = e / D, k = e - j * D;
+                tl[e] = k <= j ? ptab[j * (j + 1) / 2 + k] : 0.0;
+            }
+            for (int e = threadIdx.x; e < D; e += THREADS) {
+                tl[T_MU + e] = ptab[2 * PTAB_TRI(D) + e];
+                tl[T_LLMU + e] = m0g[ASMC_MAX_COMPONENTS + e];
+                tl[T_LLPR + e] = m0g[ASMC_MAX_COMPONENTS * (1 + D) + e];
+                tl[T_LPMU + e] = m0g[PTAB_MIX(D) + ASMC_MAX_COMPONENTS + e];
+                tl[T_LPPR + e] = m0g[PTAB_MIX(D) + ASMC_MAX_COMPONENTS * (1 + D) + e];
+                reinterpret_cast<float*>(tl + T_LOC)[e] = loc[e];
+                reinterpret_cast<float*>(tl + T_LOC)[D + e] = scale[e];
+                reinterpret_cast<float*>(tl + T_LOC)[2 * D + e] = 1.0f / scale[e];
+            }
         }
         if (threadIdx.x == 0) tl[T_LOGW] = m0g[0], tl[T_LOGW + 1] = m0g[PTAB_MIX(D)];
     }
@@ -214,8 +275,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         const bool valid = i < n;
         const unsigned ys_tile = t * 64u * (unsigned)sizeof(T);
         const __amdgpu_buffer_rsrc_t ysr = __builtin_amdgcn_make_buffer_rsrc(par ? ysu1 : ysu, 0, half_records, 0x00020000);  // A
+        // (unconditional: a tile's 64 slots exist - the state is padded to whole tiles and zeroed when allocated; a ragged last
+        // tile's spare lanes carry finite leftovers that no other lane ever sees and `valid` keeps out of every result)
+        (void)valid;
 #pragma unroll
-        for (int j = 0; j < D; j++) v[j] = valid ? soa_load<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row) : 0.0;
+        for (int j = 0; j < D; j++) v[j] = soa_load<T>(ysr, ys_lane, ys_tile + (unsigned)j * ys_row);
         oll = olp = olq = 0.0;
         if (valid) oll = ll[i], olp = lp[i], olq = lq[i];
     };
@@ -246,11 +310,16 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
 #endif
         const unsigned long long gid = p.gid0 + (unsigned long long)i;
         // ---- phase 1: proposal, one lane per particle (y, ll, lp, lq: loaded behind the previous tile's flow) ---------
-        double q0 = 0.0, q1 = 0.0;
+        // |y|^2 is accumulated coordinate by coordinate as the noise loop consumes y (same chain, same bits): summed up front it
+        // made the tile's first instruction wait for ALL 32 state loads - they now land behind the first noise quads.  Only the
+        // Student-t reference needs the sum before the first proposal coordinate (its scale depends on it).
+        double q0 = 0.0, q1 = 0.0, q0t = 0.0;
+        if (p.gam != nullptr) {  // (tpcn_scale's own test)
 #pragma unroll
-        for (int j = 0; j < D; j++) q0 = fma(v[j], v[j], q0);
+            for (int j = 0; j < D; j++) q0t = fma(v[j], v[j], q0t);
+        }
         STAMP(1);
-        const double rs = tpcn_scale(rho, p.nu, q0, p.gam, valid ? i : 0);
+        const double rs = tpcn_scale(rho, p.nu, q0t, p.gam, valid ? i : 0);
         if (NOISE == ASMC_NOISE_F64) {
 #pragma unroll
             for (int qd = 0; qd < D / 4; qd++) {
@@ -258,6 +327,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
                 normal_quad(p.seed, gid, step, (uint32_t)qd, bmt, z[0], z[1], z[2], z[3]);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
+                    q0 = fma(v[4 * qd + e], v[4 * qd + e], q0);
                     v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
                     q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
                 }
@@ -273,6 +343,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
                 normal_quad_f32(p.seed, gid, step, (uint32_t)qd, z[0], z[1], z[2], z[3]);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
+                    q0 = fma(v[4 * qd + e], v[4 * qd + e], q0);
                     v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
                     q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
                 }
@@ -284,6 +355,54 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         // flow's standardised fp32 input (the same (float) x' and division the stand-alone flow kernel applies)
         float xf[D];
         double qa = 0.0, qb = 0.0;
+        if constexpr (MVM) {
+            // y' -> MFMA operands, in place: register 4 s + r <- (coordinate 4 s + g, particle 16 r + n) in lane (g, n)
+#pragma unroll
+            for (int sI = 0; sI < D / 4; sI++) fused_transpose4(v[4 * sI], v[4 * sI + 1], v[4 * sI + 2], v[4 * sI + 3]);
+            const double* __restrict__ rowt = Lt + (lane >> 4) * 8;  // this lane group's rows: entry mb * 4 + r <-> row 16 mb + 4 g + r
+            const double* __restrict__ Aimg = Lt + lane;
+            fused_d4 acc[2][4];
+#pragma unroll
+            for (int mb = 0; mb < 2; mb++) {
+                const fused_d4 m = {rowt[T_MU + 4 * mb], rowt[T_MU + 4 * mb + 1], rowt[T_MU + 4 * mb + 2], rowt[T_MU + 4 * mb + 3]};
+#pragma unroll
+                for (int nb = 0; nb < 4; nb++) acc[mb][nb] = m;
+            }
+#pragma unroll
+            for (int sI = 0; sI < D / 4; sI++) {
+                const double a1 = Aimg[(4 + sI) * 64];
+                const double a0 = sI < 4 ? Aimg[sI * 64] : 0.0;
+#pragma unroll
+                for (int nb = 0; nb < 4; nb++) {
+                    if (sI < 4) acc[0][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, v[4 * sI + nb], acc[0][nb], 0, 0, 0);
+                    acc[1][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, v[4 * sI + nb], acc[1][nb], 0, 0, 0);
+                }
+                if (sI & 1) __builtin_amdgcn_sched_barrier(0);  // (operand reads stay next to their K-steps)
+            }
+            double qpa[4] = {0.0, 0.0, 0.0, 0.0}, qpb[4] = {0.0, 0.0, 0.0, 0.0};
+            const float* __restrict__ locr = locs + (lane >> 4) * 8;
+#pragma unroll
+            for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int e = 4 * mb + r;
+                    const double ma = rowt[T_LLMU + e], pa = rowt[T_LLPR + e], mbb = rowt[T_LPMU + e], pb = rowt[T_LPPR + e];
+                    const float lc = locr[e], sc = locr[D + e], rc = locr[2 * D + e];
+#pragma unroll
+                    for (int nb = 0; nb < 4; nb++) {
+                        const double xj = (double)(T)acc[mb][nb][r];
+                        const double ta = xj - ma, tb = xj - mbb;
+                        qpa[nb] = fma(ta * ta, pa, qpa[nb]);
+                        qpb[nb] = fma(tb * tb, pb, qpb[nb]);
+                        xf[(4 * mb + nb) * 4 + r] = flow_standardise((float)xj, lc, sc, rc);
+                    }
+                }
+            // a particle's four lanes hold its partial sums: the same transpose brings them into the particle's own lane
+            fused_transpose4(qpa[0], qpa[1], qpa[2], qpa[3]);
+            fused_transpose4(qpb[0], qpb[1], qpb[2], qpb[3]);
+            qa = (qpa[0] + qpa[1]) + (qpa[2] + qpa[3]);
+            qb = (qpb[0] + qpb[1]) + (qpb[2] + qpb[3]);
+        } else {
 #ifdef MV_COMPILER
 #pragma unroll
         for (int g = 0; g < D / 4; g++) {
@@ -375,6 +494,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             mv_for_each<0, NB>(consume);
         }
 #endif
+        }  // !MVM
         const double nll = Lt[T_LOGW] - 0.5 * qa;
         const double nlp = Lt[T_LOGW + 1] - 0.5 * qb;
         STAMP(3);
@@ -390,7 +510,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         double t2 = p.beta * (nll + nlp);
         double c1 = ref_corr(q1, p.nu, D);
         double rhs = log_p_t(oll, olp, olq, p.beta) + ref_corr(q0, p.nu, D);
-        double logu = log(accept_uniform(p.seed, gid, step));
+        // (bm_log_unit: the noise generator's < 1 ulp log for positive normal arguments - the uniform is (k + 1/2) 2^-53 -
+        // without libm's special-case and range code: a third of the instructions)
+        double logu = bm_log_unit(accept_uniform(p.seed, gid, step));
         double kll = nll, klp = nlp;
         asm volatile("" : "+v"(t2), "+v"(c1), "+v"(rhs), "+v"(logu), "+v"(kll), "+v"(klp));
 #ifndef FUSED_NOSB
@@ -437,6 +559,26 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             lqt[1] = maf_tile(xB);
         } else {
         float xaA[1][H / 2], xbA[1][H / 2], xaB[1][H / 2], xbB[1][H / 2];
+        if constexpr (MVM) {
+            // lane (g, n) holds rows 4 g + r (mb = 0) and 16 + 4 g + r (mb = 1) of particles 16 nb + n.  Flow tile A = particles 0-31
+            // (nb = 0 in the even lane groups, nb = 1 in the odd ones), lane half hh = g >> 1: swapping the odd rows of the nb = 0
+            // register with the even rows of the nb = 1 register hands every lane the four rows its neighbour group computed for
+            // ITS particle - (first result: rows 8 hh + r, second: rows 8 hh + 4 + r).  Tile B likewise from nb = 2, 3.
+#pragma unroll
+            for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const auto sA = __builtin_amdgcn_permlane16_swap(__float_as_uint(xf[(4 * mb + 0) * 4 + r]), __float_as_uint(xf[(4 * mb + 1) * 4 + r]), false, false);
+                    const auto sB = __builtin_amdgcn_permlane16_swap(__float_as_uint(xf[(4 * mb + 2) * 4 + r]), __float_as_uint(xf[(4 * mb + 3) * 4 + r]), false, false);
+                    if (mb == 0) {
+                        xaA[0][r] = __uint_as_float(sA[0]), xaA[0][4 + r] = __uint_as_float(sA[1]);
+                        xaB[0][r] = __uint_as_float(sB[0]), xaB[0][4 + r] = __uint_as_float(sB[1]);
+                    } else {
+                        xbA[0][r] = __uint_as_float(sA[0]), xbA[0][4 + r] = __uint_as_float(sA[1]);
+                        xbB[0][r] = __uint_as_float(sB[0]), xbB[0][4 + r] = __uint_as_float(sB[1]);
+                    }
+                }
+        } else {
 #pragma unroll
         for (int r = 0; r < H / 2; r++) {
             const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf[r]), __float_as_uint(xf[H / 2 + r]), false, false);
@@ -445,6 +587,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf[H + r]), __float_as_uint(xf[H + H / 2 + r]), false, false);
             xbA[0][r] = __uint_as_float(s2[0]);
             xbB[0][r] = __uint_as_float(s2[1]);
+        }
         }
         // (two explicit calls: as a loop over the tiles the flow's A-operand reads become loop invariant and LLVM hoists
         // all 448 of them in front of it)
@@ -556,6 +699,48 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         lpn = (lpn != lpn) ? -INFINITY : lpn;
         const double log_a = (lpn + c1) - rhs;
         const bool accepted = valid && logu < log_a;
+#if FUSED_INPLACE
+        // y' is stored FIRST: its registers are free once the stores have issued, so the next tile's state loads into them - with
+        // the loads in front (round 3's order, when y' was parked and dead by now) both tiles' rows are alive at once and the loop
+        // ends with 64 register copies behind a full wait for the loads (2-10 k cycles per tile on the stamps)
+        if (accepted) {
+            ll[i] = kll;
+            lp[i] = klp;
+            lq[i] = nlq;
+            n_acc++;
+        }
+        if constexpr (MVM) {
+            // y' sits transposed: register 4 s + r = (coordinate 4 s + g, particle 16 r + n) in lane (g, n) - still runs of 16
+            // consecutive particles of one coordinate.  Register r's lanes are live where particle 16 r + n accepted.
+            const unsigned long long accmask = __ballot(accepted);
+            const unsigned ys_lane_t = (unsigned)(lane >> 4) * ys_row + (unsigned)(lane & 15) * (unsigned)sizeof(T);
+            const __amdgpu_buffer_rsrc_t ysw = __builtin_amdgcn_make_buffer_rsrc(ysu, 0, half_records, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if ((accmask >> (16 * r + (lane & 15))) & 1ull) {
+#pragma unroll
+                    for (int sI = 0; sI < D / 4; sI++)
+                        soa_store<T>(ysw, ys_lane_t, ys_tile + (unsigned)(4 * sI) * ys_row + (unsigned)(16 * r) * (unsigned)sizeof(T), v[4 * sI + r]);
+                }
+            }
+        } else if (accepted) {  // y' is still in registers: the accepted lanes' rows change in place, nothing else moves
+            const __amdgpu_buffer_rsrc_t ysw = __builtin_amdgcn_make_buffer_rsrc(ysu, 0, half_records, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < D; j++) soa_store<T>(ysw, ys_lane, ys_tile + (unsigned)j * ys_row, v[j]);
+        }
+        // ... and the next tile's state goes into flight behind them
+        const unsigned tn = (unsigned)__builtin_amdgcn_readfirstlane((int)tn_l);
+        const bool have_n = (int64_t)tn < n_tiles;
+        unsigned par_n = 0;
+        double vn[D];
+#pragma unroll
+        for (int j = 0; j < D; j++) vn[j] = 0.0;  // (left undefined for the last tile, LLVM carries the OLD y through the whole body instead: 64 VGPRs, spills)
+        double olln = 0.0, olpn = 0.0, olqn = 0.0;
+        if (have_n) {
+            par_n = tile_parity(tn);
+            tile_load(tn, par_n, vn, olln, olpn, olqn);
+        }
+#else
         // the next tile's state goes into flight in front of this tile's stores and copies
         const unsigned tn = (unsigned)__builtin_amdgcn_readfirstlane((int)tn_l);
         const bool have_n = (int64_t)tn < n_tiles;
@@ -574,13 +759,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             lq[i] = nlq;
             n_acc++;
         }
-#if FUSED_INPLACE
-        if (accepted) {  // y' is still in registers: the accepted lanes' rows change in place, nothing else moves
-            const __amdgpu_buffer_rsrc_t ysw = __builtin_amdgcn_make_buffer_rsrc(ysu, 0, half_records, 0x00020000);
-#pragma unroll
-            for (int j = 0; j < D; j++) soa_store<T>(ysw, ys_lane, ys_tile + (unsigned)j * ys_row, v[j]);
-        }
-#else
         {
             const int n_a = __builtin_popcountll(__ballot(accepted)), n_r = __builtin_popcountll(__ballot(valid && !accepted));
             const bool flip = n_a > 0 && n_r <= n_a;  // wave uniform: the state moves to half B
