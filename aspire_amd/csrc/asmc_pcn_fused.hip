@@ -29,7 +29,8 @@
 // buffer of the state's layout (fire-and-forget stores), accepted lanes fetch it back (cache-hot) and store it into the state.
 // The flow's weights stay resident in LDS (115 KB at d = 32, W = 64: one block of 8 waves per CU, two waves per SIMD, so
 // one wave's vector work - noise, mat-vec, accept - runs in the shadow of its partner's MFMA chains).
-#define FUSED_TL_DOUBLES (32 * 32 + 7 * 32 + 2)  // doubles of the pCN tables in LDS (d = 32), 16-byte aligned end
+#define FUSED_TL_DOUBLES 1368  // doubles of the pCN tables in LDS (d = 32), 16-byte aligned end: the larger of the two layouts below
+#define FUSED_MAX_COMPONENTS 4  // mixture components per built-in target in the matrix-core variant
 #ifndef MV_DEPTH
 #define MV_DEPTH 4  // batches of mat-vec coefficients in flight (16 VGPRs each)
 #endif
@@ -143,6 +144,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     constexpr int T_MU = D * D, T_LLMU = T_MU + D, T_LLPR = T_LLMU + D, T_LPMU = T_LLPR + D, T_LPPR = T_LPMU + D,
                   T_LOGW = T_LPPR + D, T_LOC = T_LOGW + 2;  // then loc / scale / 1/scale: 3 x D floats = 1.5 D doubles
     static_assert(T_LOC + 3 * D / 2 <= FUSED_TL_DOUBLES, "pCN tables");
+    // matrix-core variant: operand image of L | mu | per target t (0 = likelihood, 1 = prior) and component c: mean, precision |
+    // log-weights [t * 4 + c] | loc / scale / 1/scale (floats); per-row tables in the lanes' reading order (below)
+    constexpr int M_MU = 12 * 64, M_MIX = M_MU + D, M_LOGW = M_MIX + 2 * FUSED_MAX_COMPONENTS * 2 * D, M_LOC = M_LOGW + 2 * FUSED_MAX_COMPONENTS;
+    static_assert(M_LOC + 3 * D / 2 <= FUSED_TL_DOUBLES, "pCN tables (matrix-core variant)");
     constexpr bool MVM = FUSED_MVMFMA && FUSED_INPLACE && KIND == ASMC_FLOW_COUPLING;  // the mat-vec on the fp64 matrix cores
     {
         const double* m0g = ptab + 2 * PTAB_TRI(D) + D;
@@ -158,14 +163,22 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             // per-row tables in the order a lane reads them: entry h * 8 + mb * 4 + r <-> row 16 mb + 4 h + r
             for (int e = threadIdx.x; e < D; e += THREADS) {
                 const int j = 16 * ((e >> 2) & 1) + 4 * (e >> 3) + (e & 3);
-                tl[T_MU + e] = ptab[2 * PTAB_TRI(D) + j];
-                tl[T_LLMU + e] = m0g[ASMC_MAX_COMPONENTS + j];
-                tl[T_LLPR + e] = m0g[ASMC_MAX_COMPONENTS * (1 + D) + j];
-                tl[T_LPMU + e] = m0g[PTAB_MIX(D) + ASMC_MAX_COMPONENTS + j];
-                tl[T_LPPR + e] = m0g[PTAB_MIX(D) + ASMC_MAX_COMPONENTS * (1 + D) + j];
-                reinterpret_cast<float*>(tl + T_LOC)[e] = loc[j];
-                reinterpret_cast<float*>(tl + T_LOC)[D + e] = scale[j];
-                reinterpret_cast<float*>(tl + T_LOC)[2 * D + e] = 1.0f / scale[j];
+                tl[M_MU + e] = ptab[2 * PTAB_TRI(D) + j];
+                reinterpret_cast<float*>(tl + M_LOC)[e] = loc[j];
+                reinterpret_cast<float*>(tl + M_LOC)[D + e] = scale[j];
+                reinterpret_cast<float*>(tl + M_LOC)[2 * D + e] = 1.0f / scale[j];
+            }
+            for (int e = threadIdx.x; e < 2 * FUSED_MAX_COMPONENTS * D; e += THREADS) {
+                const int tc = e / D, er = e % D, tt = tc / FUSED_MAX_COMPONENTS, c = tc % FUSED_MAX_COMPONENTS;
+                const int j = 16 * ((er >> 2) & 1) + 4 * (er >> 3) + (er & 3);
+                const bool live = c < (tt == 0 ? p.c_ll : p.c_lp);
+                const double* mg = m0g + (size_t)tt * PTAB_MIX(D);
+                tl[M_MIX + tc * 2 * D + er] = live ? mg[ASMC_MAX_COMPONENTS + c * D + j] : 0.0;
+                tl[M_MIX + tc * 2 * D + D + er] = live ? mg[ASMC_MAX_COMPONENTS * (1 + D) + c * D + j] : 0.0;
+            }
+            if (threadIdx.x < 2 * FUSED_MAX_COMPONENTS) {
+                const int tt = threadIdx.x / FUSED_MAX_COMPONENTS, c = threadIdx.x % FUSED_MAX_COMPONENTS;
+                tl[M_LOGW + threadIdx.x] = c < (tt == 0 ? p.c_ll : p.c_lp) ? m0g[(size_t)tt * PTAB_MIX(D) + c] : -INFINITY;
             }
         } else {
             for (int e = threadIdx.x; e < D * D; e += THREADS) {
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
                 reinterpret_cast<float*>(tl + T_LOC)[2 * D + e] = 1.0f / scale[e];
             }
         }
-        if (threadIdx.x == 0) tl[T_LOGW] = m0g[0], tl[T_LOGW + 1] = m0g[PTAB_MIX(D)];
+        if (!MVM && threadIdx.x == 0) tl[T_LOGW] = m0g[0], tl[T_LOGW + 1] = m0g[PTAB_MIX(D)];
     }
     // ... and the Box-Muller tables of the default noise behind them (6 KB)
     bm_d2* bmt = reinterpret_cast<bm_d2*>(tl + FUSED_TL_DOUBLES);
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         int zoff;
         asm volatile("v_mov_b32 %0, 0" : "=v"(zoff));
         const double* __restrict__ Lt = tl + zoff;
-        const float* __restrict__ locs = reinterpret_cast<const float*>(tl + T_LOC) + zoff;
+        const float* __restrict__ locs = reinterpret_cast<const float*>(tl + (MVM ? M_LOC : T_LOC)) + zoff;
         const int64_t i = (int64_t)t * 64 + lane;
         const bool valid = i < n;
         const unsigned ys_tile = t * 64u * (unsigned)sizeof(T);
@@ -354,7 +367,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         // x'_j = mu_j + sum_k L[j,k] y'_k, four rows at a time: straight into the targets' quadratic forms and into the
         // flow's standardised fp32 input (the same (float) x' and division the stand-alone flow kernel applies)
         float xf[D];
-        double qa = 0.0, qb = 0.0;
+        double qa = 0.0, qb = 0.0, mix_ll = 0.0, mix_lp = 0.0;
         if constexpr (MVM) {
             // y' -> MFMA operands, in place: register 4 s + r <- (coordinate 4 s + g, particle 16 r + n) in lane (g, n)
 #pragma unroll
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             fused_d4 acc[2][4];
 #pragma unroll
             for (int mb = 0; mb < 2; mb++) {
-                const fused_d4 m = {rowt[T_MU + 4 * mb], rowt[T_MU + 4 * mb + 1], rowt[T_MU + 4 * mb + 2], rowt[T_MU + 4 * mb + 3]};
+                const fused_d4 m = {rowt[M_MU + 4 * mb], rowt[M_MU + 4 * mb + 1], rowt[M_MU + 4 * mb + 2], rowt[M_MU + 4 * mb + 3]};
 #pragma unroll
                 for (int nb = 0; nb < 4; nb++) acc[mb][nb] = m;
             }
@@ -386,7 +399,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int e = 4 * mb + r;
-                    const double ma = rowt[T_LLMU + e], pa = rowt[T_LLPR + e], mbb = rowt[T_LPMU + e], pb = rowt[T_LPPR + e];
+                    const double ma = rowt[M_MIX + e], pa = rowt[M_MIX + D + e];  // component 0 of the likelihood ...
+                    const double mbb = rowt[M_MIX + FUSED_MAX_COMPONENTS * 2 * D + e], pb = rowt[M_MIX + FUSED_MAX_COMPONENTS * 2 * D + D + e];  // ... and of the prior
                     const float lc = locr[e], sc = locr[D + e], rc = locr[2 * D + e];
 #pragma unroll
                     for (int nb = 0; nb < 4; nb++) {
@@ -402,6 +416,41 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             fused_transpose4(qpb[0], qpb[1], qpb[2], qpb[3]);
             qa = (qpa[0] + qpa[1]) + (qpa[2] + qpa[3]);
             qb = (qpb[0] + qpb[1]) + (qpb[2] + qpb[3]);
+            // mixture targets (<= FUSED_MAX_COMPONENTS components each): the further components' quadratic forms from the same
+            // accumulators, folded into a running (max, sum) log-sum-exp in mixture_eval_regs' order (asmc_pcn.hip); a plain
+            // Gaussian target (the headline) never enters the loops
+            auto more_components = [&](int tt, int C, double q0c) -> double {
+                double best = Lt[M_LOGW + tt * FUSED_MAX_COMPONENTS] - 0.5 * q0c;
+                if (C == 1) return best;
+                double ssum = 1.0;
+#pragma unroll 1
+                for (int c = 1; c < C; c++) {
+                    const double* __restrict__ tb = rowt + M_MIX + (tt * FUSED_MAX_COMPONENTS + c) * 2 * D;
+                    double qp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const double mc = tb[4 * mb + r], pc = tb[D + 4 * mb + r];
+#pragma unroll
+                            for (int nb = 0; nb < 4; nb++) {
+                                const double tv = (double)(T)acc[mb][nb][r] - mc;
+                                qp[nb] = fma(tv * tv, pc, qp[nb]);
+                            }
+                        }
+                    fused_transpose4(qp[0], qp[1], qp[2], qp[3]);
+                    const double tc = Lt[M_LOGW + tt * FUSED_MAX_COMPONENTS + c] - 0.5 * ((qp[0] + qp[1]) + (qp[2] + qp[3]));
+                    if (tc > best) {
+                        ssum = fma(ssum, exp(best - tc), 1.0);
+                        best = tc;
+                    } else if (tc > -INFINITY) {
+                        ssum += exp(tc - best);
+                    }
+                }
+                return best == -INFINITY ? -INFINITY : best + log(ssum);
+            };
+            mix_ll = more_components(0, p.c_ll, qa);
+            mix_lp = more_components(1, p.c_lp, qb);
         } else {
 #ifdef MV_COMPILER
 #pragma unroll
@@ -495,8 +544,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         }
 #endif
         }  // !MVM
-        const double nll = Lt[T_LOGW] - 0.5 * qa;
-        const double nlp = Lt[T_LOGW + 1] - 0.5 * qb;
+        const double nll = MVM ? mix_ll : Lt[T_LOGW] - 0.5 * qa;
+        const double nlp = MVM ? mix_lp : Lt[T_LOGW + 1] - 0.5 * qb;
         STAMP(3);
 #if !FUSED_INPLACE
         if (valid) {
@@ -913,7 +962,11 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
 bool asmc_pcn_flow_fused_ok(const asmc_pcn_params* prm, const asmc_coupling* f) {
     if (getenv("ASMC_FLOW_SPLIT")) return false;
     if (prm->d != 32 || f->dims != 32) return false;
-    if (prm->log_likelihood.n_components != 1 || prm->log_prior.n_components != 1) return false;
+    // mixture targets: the matrix-core variant (coupling layers) takes up to FUSED_MAX_COMPONENTS components each
+    const bool mvm = FUSED_MVMFMA && FUSED_INPLACE && f->kind == ASMC_FLOW_COUPLING;
+    const int cmax = mvm ? FUSED_MAX_COMPONENTS : 1;
+    if (prm->log_likelihood.n_components < 1 || prm->log_likelihood.n_components > cmax) return false;
+    if (prm->log_prior.n_components < 1 || prm->log_prior.n_components > cmax) return false;
     if (!(f->hidden == 32 || f->hidden == 64 || f->hidden == 128)) return false;
     if (f->kind == ASMC_FLOW_MAF) {  // split-fp16 layers only, widths whose accumulators fit one tile at a time
         if (!asmc_flow_math_split() || f->hidden == 128) return false;

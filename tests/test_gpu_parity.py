@@ -1707,6 +1707,64 @@ def test_pcn_flow_fused_step_vs_oracle(eng, oracle):
     np.testing.assert_allclose(lqd.cpu().numpy()[close], lqr[close], rtol=1e-5, atol=3e-4)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("c_ll,c_lp,xdt", [(2, 1, "f64"), (3, 4, "f64"), (4, 2, "f32"), (1, 3, "f64")])
+def test_pcn_flow_fused_step_with_mixture_targets_vs_oracle(eng, oracle, c_ll, c_lp, xdt):
+    """Built-in MIXTURE targets (up to four components each: BASELINE config 5's two-component likelihood shape at d = 32) stay
+    on the one-kernel flow-proposal step: the further components' quadratic forms come from the same matrix-core accumulators
+    and are folded into a running log-sum-exp.  Against the oracle's restatement of the whole step (orc_pcn_flow_step with
+    orc_diag_mixture_logpdf targets); round 3 sent any mixture target to the split propose / flow / accept kernels."""
+    from conftest import random_coupling_flow
+
+    n, d, n_steps, beta, rho = 5000, 32, 3, 0.45, 0.3
+    dt = torch.float64 if xdt == "f64" else torch.float32
+    flow = random_coupling_flow(d, 4, 64, seed=5)
+    dev = flow.device_coupling(eng)
+    ws, bs = flow.export_layers()
+    g = np.random.default_rng(21)
+
+    def mix(C, spread):
+        logw = np.log(g.dirichlet(np.ones(C) * 3.0))
+        return logw, spread * g.normal(size=(C, d)), 0.5 + g.random(size=(C, d))
+
+    m_ll, m_lp = mix(c_ll, 0.8), mix(c_lp, 0.3)
+    o_ll, o_lp = oracle.Mixture(*m_ll), oracle.Mixture(*m_lp)
+    t_ll, t_lp = eng.make_mixture(*m_ll), eng.make_mixture(*m_lp)
+    x0 = torch.as_tensor(0.9 * g.normal(size=(n, d))).to(dt)
+    xr = x0.double().numpy().copy()
+    a = g.normal(size=(d, d)) / np.sqrt(d)
+    L = np.tril(np.linalg.cholesky(0.8 * (np.eye(d) + 0.2 * a @ a.T)))
+    Linv, mu = np.tril(np.linalg.inv(L)), 0.05 * g.normal(size=d)
+    llr, lpr = o_ll.logpdf(xr), o_lp.logpdf(xr)
+    lqr = oracle.coupling_logprob(xr, ws, bs, flow.loc.numpy(), flow.scale.numpy())
+    xd = x0.to(eng.device).contiguous()
+    lld, lpd, lqd = eng.asarray(llr), eng.asarray(lpr), eng.coupling_logprob(xd, dev)
+    eng.profile(True)
+    n_acc, _, _ = eng.pcn_mutate_flow(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), t_ll, t_lp, dev,
+                                      99, 40, rho, n_steps, 2, 0.234, False, "f64", 0.0)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert rep["k_pcn_flow_fused"][0] == n_steps and "k_coupling_logprob" not in rep and "k_pcn_flow_propose" not in rep
+    acc_ref, margins = [], []
+    for t in range(n_steps):
+        with oracle.accept_margins(n) as m:
+            acc_ref.append(oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, o_ll, o_lp, ws, bs, flow.loc.numpy(),
+                                                flow.scale.numpy(), 99, 40, 2 + t, "f64", 0))
+        margins.append(m.copy())
+    got = xd.double().cpu().numpy()
+    tol = 1e-9 if xdt == "f64" else 3e-5
+    close = np.all(np.abs(got - xr) <= tol * (1 + np.abs(xr)), axis=1)
+    edge = 12 if xdt == "f64" else 80
+    assert (~close).sum() <= edge, (~close).sum()
+    if xdt == "f64":
+        razor = np.min(np.abs(np.array(margins)), axis=0)
+        assert np.all(razor[~close] <= 1e-4), razor[~close]
+    assert np.all(np.abs(np.array(n_acc) - np.array(acc_ref)) <= edge) and 0.03 < np.mean(n_acc) / n < 0.97
+    # carried densities = the mixtures at the returned positions
+    np.testing.assert_allclose(lld.cpu().numpy(), o_ll.logpdf(got), rtol=1e-10 if xdt == "f64" else 1e-4, atol=1e-9 if xdt == "f64" else 2e-3)
+    np.testing.assert_allclose(lpd.cpu().numpy(), o_lp.logpdf(got), rtol=1e-10 if xdt == "f64" else 1e-4, atol=1e-9 if xdt == "f64" else 2e-3)
+
+
 # ---- split-fp16 MFMA flow arithmetic: accuracy of the operands, not of a reduced-precision flow --------------------
 @pytest.mark.parametrize("hidden,scale_x", [(64, 1.0), (32, 3.0), (128, 0.2)])
 def test_split_fp16_flow_is_as_accurate_as_the_fp32_mfma_chain(eng, hidden, scale_x, monkeypatch):
