@@ -246,10 +246,18 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_coupling_sample(int64_t n, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// coordinate held in slot i of lane half hh of an autoregressive tile (DL = H / 2 slots per lane): the first DL / 2 slots are
+// coordinates hh DL/2 .. of the lower DL coordinates, the other DL / 2 the same range of the upper DL - the order in which the
+// coupling tiles hold their two halves, so that the fused pCN step stages both kinds of flow with the same swaps
+template <int DL>
+__device__ __forceinline__ constexpr int maf_coord(int hh, int i) {
+    return (i / (DL / 2)) * DL + hh * (DL / 2) + i % (DL / 2);
+}
+
 // Masked autoregressive flow (include/asmc.h, ASMC_FLOW_MAF; reference flows/torch/flows.py:140-168 asks zuko for it by
 // default).  A transform is a coupling layer whose conditioner input and transformed block are BOTH the whole x (the MADE masks
 // sit in the weights as zeros), so the tile layout and the layer code are the coupling kernels' with H / 2 = the coordinates a
-// lane half holds: half hh of a particle's lane pair owns coordinates [hh H/2, (hh + 1) H/2).  Density: one pass per transform.
+// lane half holds (maf_coord above).  Density: one pass per transform.
 template <int H, int W, typename XT, int FLOW_THREADS, bool HS>
 __global__ __launch_bounds__(FLOW_THREADS) void k_maf_logprob(int64_t n, int d, const XT* __restrict__ x,
                                                              const float* __restrict__ packed, int n_layers,
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_maf_logprob(int64_t n, int d, 
         float xv[1][DL];
 #pragma unroll
         for (int i = 0; i < DL; i++) {
-            const int jp = hh * DL + i;  // padded coordinates stay at zero: their weights are zero, their (s, t) come out zero
+            const int jp = maf_coord<DL>(hh, i);  // padded coordinates stay at zero: their weights are zero, their (s, t) come out zero
             xv[0][i] = (valid && jp < d) ? flow_standardise((float)x[row * d + jp], loc[jp], scale[jp], 1.0f / scale[jp]) : 0.0f;
         }
         float ladj[1] = {0.0f};
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_maf_sample(int64_t n, int d, c
             double zq[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int i = 0; i < DL; i++) {
-                const int jp = hh * DL + i;
+                const int jp = maf_coord<DL>(hh, i);
                 if (jp < d && (jp >> 2) != have) {
                     have = jp >> 2;
                     normal_quad_f32(seed, gid, draw_id, (uint32_t)have, zq[0], zq[1], zq[2], zq[3]);
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_maf_sample(int64_t n, int d, c
         if (row < n) {
 #pragma unroll
             for (int i = 0; i < DL; i++) {
-                const int jp = hh * DL + i;
+                const int jp = maf_coord<DL>(hh, i);
                 if (jp < d) x[row * d + jp] = (XT)(zv[i] * scale[jp] + loc[jp]);
             }
             if (hh == 0) out[row] = (double)val;
@@ -403,8 +411,11 @@ extern "C" int64_t asmc_coupling_pack_floats(int dims, int n_layers, int hidden)
 // The packing of `n_layers` conditioner MLPs  dh -> Wd -> Wd -> 2 dh  into MFMA operand order, for lane halves that hold H / 2
 // (>= dh / 2 ... padded) inputs each.  A coupling flow of d dims calls it with dh = d / 2 (inputs = the conditioner half,
 // outputs = (s_raw, t) of the transformed half); a masked autoregressive flow with dh = d (inputs = outputs = the whole x).
+// `maf`: the lane halves' slots hold the coordinates in the autoregressive kernels' order (maf_coord below) instead of hh H/2 + i.
 static int flow_pack_layers(const char* who, int H, int dh, int n_layers, int Wd, const float* const* weights_host,
-                            const float* const* biases_host, float* packed_host) {
+                            const float* const* biases_host, float* packed_host, bool maf = false) {
+    // slot i of lane half hh -> coordinate (coupling flows: index inside the conditioner / transformed half)
+    auto coord = [&](int hh, int i) { return maf ? (i / (H / 4)) * (H / 2) + hh * (H / 4) + i % (H / 4) : hh * (H / 2) + i; };
     const int NB1 = Wd / 32, NB3 = H / 16;
     if (asmc_flow_math_split()) {  // the split-fp16 layers carry every weight as an fp16 pair
         const int64_t sizes[3] = {(int64_t)Wd * dh, (int64_t)Wd * Wd, (int64_t)2 * dh * Wd};
@@ -421,7 +432,7 @@ static int flow_pack_layers(const char* who, int H, int dh, int n_layers, int Wd
     // packed output row (block nb, row i) -> row of the torch output layer ([s_0..s_dh-1, t_0..t_dh-1]) or -1
     auto out_row = [&](int nb, int i) {
         const int hh = (i / 4) % 2, r = 4 * (i / 8) + i % 4, q = 16 * nb + r;
-        const int jp = hh * (H / 2) + (q < H / 2 ? q : q - H / 2);
+        const int jp = coord(hh, q < H / 2 ? q : q - H / 2);
         if (jp >= dh) return -1;
         return q < H / 2 ? jp : dh + jp;
     };
@@ -450,7 +461,7 @@ static int flow_pack_layers(const char* who, int H, int dh, int n_layers, int Wd
             for (int g = 0; g < H / 8; g++)
                 for (int l = 0; l < 64; l++)
                     for (int e = 0; e < 4; e++) {
-                        const int in = (l / 32) * (H / 2) + 4 * g + e;
+                        const int in = coord(l / 32, 4 * g + e);
                         A1[((int64_t)(nb * (H / 8) + g) * 64 + l) * 4 + e] =
                             in < dh ? W1[(int64_t)(32 * nb + l % 32) * dh + in] : 0.0f;
                     }
@@ -504,7 +515,7 @@ extern "C" int asmc_maf_pack(int dims, int n_transforms, int hidden, const float
         asmc_set_error("asmc_maf_pack: unsupported flow (dims <= 32, hidden in {32,64,128})");
         return ASMC_ERR_UNSUPPORTED;
     }
-    return flow_pack_layers("asmc_maf_pack", maf_half_pad(dims), dims, n_transforms, hidden, weights_host, biases_host, packed_host);
+    return flow_pack_layers("asmc_maf_pack", maf_half_pad(dims), dims, n_transforms, hidden, weights_host, biases_host, packed_host, true);
 }
 
 template <int H, int W, typename XT, int FLOW_THREADS, int TPW, bool HS>

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     // log-weights [t * 4 + c] | loc / scale / 1/scale (floats); per-row tables in the lanes' reading order (below)
     constexpr int M_MU = 12 * 64, M_MIX = M_MU + D, M_LOGW = M_MIX + 2 * FUSED_MAX_COMPONENTS * 2 * D, M_LOC = M_LOGW + 2 * FUSED_MAX_COMPONENTS;
     static_assert(M_LOC + 3 * D / 2 <= FUSED_TL_DOUBLES, "pCN tables (matrix-core variant)");
-    constexpr bool MVM = FUSED_MVMFMA && FUSED_INPLACE && KIND == ASMC_FLOW_COUPLING;  // the mat-vec on the fp64 matrix cores
+    constexpr bool MVM = FUSED_MVMFMA && FUSED_INPLACE;  // the mat-vec on the fp64 matrix cores
     {
         const double* m0g = ptab + 2 * PTAB_TRI(D) + D;
         if (MVM) {
@@ -570,43 +570,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         // ---- phase 2: two flow tiles (particles 0-31 and 32-63 of this wave) on the MFMA -----------------------------
         float lqt[2];
         unsigned tn_l = 0;
-        if constexpr (KIND == ASMC_FLOW_MAF) {
-            float xA[16], xB[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {  // tile A: (own coordinate r | lane l - 32's coordinate 16 + r); tile B the other two
-                const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(xf[r]), __float_as_uint(xf[16 + r]), false, false);
-                xA[r] = __uint_as_float(s1[0]);
-                xB[r] = __uint_as_float(s1[1]);
-            }
-#ifndef FUSED_NOPRIO
-            if (first_on_simd)
-                __builtin_amdgcn_s_setprio(FUSED_PRIO_A);
-            else
-                __builtin_amdgcn_s_setprio(FUSED_PRIO_B);
-#endif
-            STAMP(4);
-            tn_l = tile_fetch();  // the next tile's index: back long before the flow is through
-            auto maf_tile = [&](float(&xv)[16]) __attribute__((always_inline)) -> float {
-                float ladj = 0.0f, amax = 0.0f;
-                for (int c = 0; c < n_layers; c++) {
-                    float cond[16];
-#pragma unroll
-                    for (int r = 0; r < 16; r++) cond[r] = xv[r];
-                    coupling_layer_hs<HF, W>(cond, xv, sp + (size_t)c * FD::LAYER, lane, hh, ladj, amax);
-                }
-                float q = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; r++) q += xv[r] * xv[r];
-                q += __shfl_xor(q, 32);
-                const float lj = ladj + __shfl_xor(ladj, 32);
-                amax = fmaxf(amax, __shfl_xor(amax, 32));
-                return !(amax < FLOW_HS_MAX) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
-            };
-            lqt[0] = maf_tile(xA);
-            __builtin_amdgcn_sched_barrier(0);  // one tile's accumulator chains at a time
-            STAMP(5);
-            lqt[1] = maf_tile(xB);
-        } else {
         float xaA[1][H / 2], xbA[1][H / 2], xaB[1][H / 2], xbB[1][H / 2];
         if constexpr (MVM) {
             // lane (g, n) holds rows 4 g + r (mb = 0) and 16 + 4 g + r (mb = 1) of particles 16 nb + n.  Flow tile A = particles 0-31
@@ -638,6 +601,40 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             xbB[0][r] = __uint_as_float(s2[1]);
         }
         }
+        if constexpr (KIND == ASMC_FLOW_MAF) {
+            // an autoregressive tile holds 16 coordinates per lane: the two coupling-style halves back to back (maf_coord, asmc_flow.hip)
+            float xA[16], xB[16];
+#pragma unroll
+            for (int r = 0; r < 8; r++) xA[r] = xaA[0][r], xA[8 + r] = xbA[0][r], xB[r] = xaB[0][r], xB[8 + r] = xbB[0][r];
+#ifndef FUSED_NOPRIO
+            if (first_on_simd)
+                __builtin_amdgcn_s_setprio(FUSED_PRIO_A);
+            else
+                __builtin_amdgcn_s_setprio(FUSED_PRIO_B);
+#endif
+            STAMP(4);
+            tn_l = tile_fetch();  // the next tile's index: back long before the flow is through
+            auto maf_tile = [&](float(&xv)[16]) __attribute__((always_inline)) -> float {
+                float ladj = 0.0f, amax = 0.0f;
+                for (int c = 0; c < n_layers; c++) {
+                    float cond[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) cond[r] = xv[r];
+                    coupling_layer_hs<HF, W>(cond, xv, sp + (size_t)c * FD::LAYER, lane, hh, ladj, amax);
+                }
+                float q = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) q += xv[r] * xv[r];
+                q += __shfl_xor(q, 32);
+                const float lj = ladj + __shfl_xor(ladj, 32);
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                return !(amax < FLOW_HS_MAX) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
+            };
+            lqt[0] = maf_tile(xA);
+            __builtin_amdgcn_sched_barrier(0);  // one tile's accumulator chains at a time
+            STAMP(5);
+            lqt[1] = maf_tile(xB);
+        } else {
         // (two explicit calls: as a loop over the tiles the flow's A-operand reads become loop invariant and LLVM hoists
         // all 448 of them in front of it)
         auto flow_tile = [&](float(&xa)[1][H / 2], float(&xb)[1][H / 2]) __attribute__((always_inline)) -> float {
@@ -962,8 +959,8 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
 bool asmc_pcn_flow_fused_ok(const asmc_pcn_params* prm, const asmc_coupling* f) {
     if (getenv("ASMC_FLOW_SPLIT")) return false;
     if (prm->d != 32 || f->dims != 32) return false;
-    // mixture targets: the matrix-core variant (coupling layers) takes up to FUSED_MAX_COMPONENTS components each
-    const bool mvm = FUSED_MVMFMA && FUSED_INPLACE && f->kind == ASMC_FLOW_COUPLING;
+    // mixture targets: the matrix-core variant takes up to FUSED_MAX_COMPONENTS components each
+    const bool mvm = FUSED_MVMFMA && FUSED_INPLACE;
     const int cmax = mvm ? FUSED_MAX_COMPONENTS : 1;
     if (prm->log_likelihood.n_components < 1 || prm->log_likelihood.n_components > cmax) return false;
     if (prm->log_prior.n_components < 1 || prm->log_prior.n_components > cmax) return false;
