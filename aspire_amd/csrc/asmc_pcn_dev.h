@@ -42,8 +42,15 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
+#ifdef ASMC_PHILOX_MULHI  // (round 1-3 form: two multiply instructions per product)
         const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+#else  // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32): half the integer multiplies of a block
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * (unsigned long long)c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * (unsigned long long)c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#endif
         const uint32_t n0 = hi1 ^ c1 ^ k0;
         const uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0;

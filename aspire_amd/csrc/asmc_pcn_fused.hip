@@ -94,7 +94,7 @@ __device__ __forceinline__ void fused_transpose4(double& q0, double& q1, double&
     fused_swap16(q2, q3);
 }
 #ifndef HS1P_PREFETCH
-#define HS1P_PREFETCH (W < 128)  // A operands of the next K-step group read while the current group's MFMAs issue
+#define HS1P_PREFETCH false  // (true: the A operands of the next K-step group are read while the current group's MFMAs issue - 16 more registers, measured: no gain)
 #endif
 #ifndef FUSED_PRIO_A
 #define FUSED_PRIO_A 2
@@ -107,7 +107,10 @@ __device__ __forceinline__ void fused_transpose4(double& q0, double& q1, double&
 // (flows/torch/flows.py:140-168, the reference's default flow class): a transform is a coupling layer whose conditioner input and
 // transformed block are both the whole x (asmc_flow.hip), so a flow tile holds 16 coordinates per lane instead of 8 + 8 and the
 // swap pairs coordinate i with coordinate 16 + i.
-template <typename T, int W, int NOISE, bool HS, int KIND = ASMC_FLOW_COUPLING>
+// MIX: built-in MIXTURE targets (2 .. FUSED_MAX_COMPONENTS components) - their own instantiations: the component loop keeps the
+// mat-vec accumulators alive past the first quadratic forms, and compiled into the single-Gaussian kernel it cost the headline
+// 90 spilled registers (0.294 -> 0.320 ms per step).
+template <typename T, int W, int NOISE, bool HS, int KIND = ASMC_FLOW_COUPLING, bool MIX = false>
 __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     int64_t n, double* __restrict__ ll, double* __restrict__ lp, double* __restrict__ lq, const double* __restrict__ ptab,
     PcnScalars p, const double* rho_ptr, uint32_t step, const float* __restrict__ packed, int n_layers,
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             // Gaussian target (the headline) never enters the loops
             auto more_components = [&](int tt, int C, double q0c) -> double {
                 double best = Lt[M_LOGW + tt * FUSED_MAX_COMPONENTS] - 0.5 * q0c;
-                if (C == 1) return best;
+                if (!MIX || C == 1) return best;
                 double ssum = 1.0;
 #pragma unroll 1
                 for (int c = 1; c < C; c++) {
@@ -563,7 +566,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         // without libm's special-case and range code: a third of the instructions)
         double logu = bm_log_unit(accept_uniform(p.seed, gid, step));
         double kll = nll, klp = nlp;
-        asm volatile("" : "+v"(t2), "+v"(c1), "+v"(rhs), "+v"(logu), "+v"(kll), "+v"(klp));
+        // ... folded into ONE number: accept  <=>  log u < ((1 - beta) lq' + t2 + c1) - rhs  <=>  (1 - beta) lq' + kacc > 0.  Four
+        // doubles fewer alive across the flow (the kernel sits at the 256-register edge: they were spills); the re-association moves
+        // a decision only where its margin is within an ulp or two of the sum (the razor edges the parity tests allow for)
+        double kacc = ((t2 + c1) - rhs) - logu;
+        asm volatile("" : "+v"(kacc), "+v"(kll), "+v"(klp));
 #ifndef FUSED_NOSB
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -741,10 +748,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         // a non-finite log q(x') (NaN, or +-inf: fp16 operand overflow at |activation| >= 65504 in the split products,
         // asmc_flow_dev.h) rejects the proposal; counted, so that the host can tell the user
         if (valid && !(fabs(nlq) < INFINITY)) n_bad++;
-        double lpn = (1.0 - p.beta) * nlq + t2;
-        lpn = (lpn != lpn) ? -INFINITY : lpn;
-        const double log_a = (lpn + c1) - rhs;
-        const bool accepted = valid && logu < log_a;
+        const bool accepted = valid && fma(1.0 - p.beta, nlq, kacc) > 0.0;  // (a NaN density compares false: rejected)
 #if FUSED_INPLACE
         // y' is stored FIRST: its registers are free once the stores have issued, so the next tile's state loads into them - with
         // the loads in front (round 3's order, when y' was parked and dead by now) both tiles' rows are alive at once and the loop
@@ -910,9 +914,11 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
     // need 288 accumulator registers there, the compiler spilled ~300 around the hand-scheduled conversion / MFMA sequence and
     // the step returned run-to-run different log q - tools/stress_fused.py.)
     const bool hs = asmc_flow_math_split();
-#define ASMC_FUSED_CASE_K(WW, NZ, HSV, KD)                                                                                \
-    if (f->hidden == WW && pd.noise == NZ && hs == HSV && f->kind == KD) {                                                \
-        auto kern = k_pcn_flow_fused<T, WW, NZ, HSV, KD>;                                                                     \
+    const bool mix = pd.ll.C > 1 || pd.lp.C > 1;
+#define ASMC_FUSED_CASE_K(WW, NZ, HSV, KD) ASMC_FUSED_CASE_KM(WW, NZ, HSV, KD, false)
+#define ASMC_FUSED_CASE_KM(WW, NZ, HSV, KD, MX)                                                                           \
+    if (f->hidden == WW && pd.noise == NZ && hs == HSV && f->kind == KD && mix == MX) {                                   \
+        auto kern = k_pcn_flow_fused<T, WW, NZ, HSV, KD, MX>;                                                                 \
         const size_t lds0 = (size_t)f->n_layers * FlowDims<(KD == ASMC_FLOW_MAF ? 32 : 16), WW>::LAYER * sizeof(float) + FUSED_TL_DOUBLES * sizeof(double) + BM_TAB_N * sizeof(bm_d2); \
         const size_t par_bytes = (size_t)((n_tiles + 31) / 32) * 4;   /* the tiles' parity bits ride in LDS when they fit */ \
         const int par_words = (!FUSED_INPLACE && lds0 + par_bytes <= 160 * 1024) ? (int)(par_bytes / 4) : 0;                     \
@@ -930,7 +936,9 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
     }
 #define ASMC_FUSED_CASE(WW, NZ, HSV) ASMC_FUSED_CASE_K(WW, NZ, HSV, ASMC_FLOW_COUPLING)
     ASMC_FUSED_CASE(64, ASMC_NOISE_F64, true)
-#ifndef FUSED_ONLY_HEADLINE  // (diagnostic builds compile the headline instantiation alone: seconds instead of minutes)
+#ifndef FUSED_ONLY_HEADLINE
+    ASMC_FUSED_CASE_KM(64, ASMC_NOISE_F64, true, ASMC_FLOW_COUPLING, true)  // mixture targets
+    ASMC_FUSED_CASE_KM(64, ASMC_NOISE_F32, true, ASMC_FLOW_COUPLING, true)  // (diagnostic builds compile the headline instantiation alone: seconds instead of minutes)
     ASMC_FUSED_CASE(64, ASMC_NOISE_F64, false)
     ASMC_FUSED_CASE(64, ASMC_NOISE_F32, true)
     ASMC_FUSED_CASE(64, ASMC_NOISE_F32, false)
@@ -950,6 +958,7 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
 #endif
 #undef ASMC_FUSED_CASE
 #undef ASMC_FUSED_CASE_K
+#undef ASMC_FUSED_CASE_KM
     asmc_set_error("fused flow step: unsupported flow (kind %d, hidden width %d)", (int)f->kind, (int)f->hidden);
     return ASMC_ERR_UNSUPPORTED;
 }
@@ -960,7 +969,7 @@ bool asmc_pcn_flow_fused_ok(const asmc_pcn_params* prm, const asmc_coupling* f) 
     if (getenv("ASMC_FLOW_SPLIT")) return false;
     if (prm->d != 32 || f->dims != 32) return false;
     // mixture targets: the matrix-core variant takes up to FUSED_MAX_COMPONENTS components each
-    const bool mvm = FUSED_MVMFMA && FUSED_INPLACE;
+    const bool mvm = FUSED_MVMFMA && FUSED_INPLACE && f->kind == ASMC_FLOW_COUPLING && f->hidden == 64 && asmc_flow_math_split();  // (the mixture instantiations)
     const int cmax = mvm ? FUSED_MAX_COMPONENTS : 1;
     if (prm->log_likelihood.n_components < 1 || prm->log_likelihood.n_components > cmax) return false;
     if (prm->log_prior.n_components < 1 || prm->log_prior.n_components > cmax) return false;
