@@ -1,8 +1,9 @@
 """Container-only shim that makes the *real* reference importable for golden generation.
 
 TEST INFRASTRUCTURE — never imported by the product (`aspire_amd/`), never run on the GPU box
-(`/root/reference` does not exist there).  Used only by `oracle/make_golden.py` and by
-`tests/test_oracle_vs_reference.py` (which skips when `/root/reference` is absent).
+(`/root/reference` does not exist there).  Used only by `oracle/make_golden.py`, `tests/tools/ref_ratio.py`,
+`tests/test_reference_seam.py` and `tests/test_abi_and_layout.py::test_oracle_vs_reference_live_if_present` (which skip when
+`/root/reference` is absent).
 
 The reference (mj-will/aspire, `/root/reference/src/aspire`) declares python>=3.11 and depends on
 five packages missing from this image.  Substitutions:

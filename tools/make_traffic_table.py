@@ -29,7 +29,7 @@ n, d = 1_000_000, 32
 alg = {"k_bis_sums": 24 * n, "k_weights_max<1>": 24 * n, "k_weights_sums<1>": 24 * n, "k_weights_m2_lse": 24 * n,
        "k_weights_map<1>": 32 * n, "k_tile_sum": 8 * n, "k_exact_tile_td_launch": 8 * n, "k_exact_tile_write": 16 * n,
        "k_divide_dev": 16 * n, "k_pcg64_uniforms": 8 * n, "k_search": 24 * n, "k_gather16": (2 * (d * 8 + 24) + 8) * n, "k_search_guided": 24 * n, "k_guide_build": 8 * n,
-       "k_is_weights": 32 * n, "k_exact_tile_td_scan": 8 * n, "k_search_pcg": 16 * n, "k_pcn_flow_fused": (2 * d * 8 + 48) * n,
+       "k_is_weights": 32 * n, "k_exact_tile_td_scan": 8 * n, "k_search_pcg": 16 * n, "k_pcn_flow_fused": (2 * d * 8 + 48) * n,  # 2 d s + three log-density arrays read and (accepted rows) written
        "k_pcn_reg<double, 32, 1, 1>": (2 * d * 8 + 16) * n, "k_pcn_reg_flow<double, 32, 1, 0>": (2 * d * 8 + 16) * n,
        "k_pcn_reg_flow<double, 32, 1, 1>": (2 * d * 8 + 48) * n, "k_coupling_logprob<16, 64, double, 512, 2>": (d * 8 + 8) * n}
 rows = []
@@ -67,6 +67,6 @@ for kind, name, fb, wb, ab in rows:
     mult = 1 if base.startswith(("k_gather16", "k_search")) else 2
     tr[f"{base}|n={n}|d={d}|f64"] = round(mult * fb + wb, -5)
     if base.startswith(("k_pcn_flow_fused<", "k_is_weights<")):  # bench.py looks these up without the template arguments
-        tr[f"{base.split('<')[0]}|n={n}|d={d}|f64"] = round(mult * fb + wb, -5)
+        tr.setdefault(f"{base.split('<')[0]}|n={n}|d={d}|f64", round(mult * fb + wb, -5))  # (the first row: the headline instantiation)
 json.dump(tr, open(os.path.join(ROOT, "profiles", "traffic_per_launch.json"), "w"), indent=1)
 print(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.md")).read())
