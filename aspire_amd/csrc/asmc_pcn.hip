@@ -3063,18 +3063,22 @@ static int mutate_flow_collect(asmc_ctx* ctx, int n_steps, double* rho_out_host,
     return ASMC_OK;
 }
 
-int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq,
-                         const asmc_pcn_params* prm, const asmc_coupling* flow, void* work_dev, int64_t work_bytes,
-                         int n_steps, uint32_t step0, double* rho_inout_host, int64_t* n_accept_host,
-                         double* rho_hist_host, asmc_stream stream) {
+}  // extern "C"
+
+// d_noise > 0: a d_noise-dimensional problem zero-padded to prm->d = 32 by asmc_pcn_mutate_flow below (the flow keeps its own
+// dims = d_noise); only the one-kernel step takes it
+static int pcn_mutate_flow_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq,
+                                const asmc_pcn_params* prm, const asmc_coupling* flow, void* work_dev, int64_t work_bytes,
+                                int n_steps, uint32_t step0, double* rho_inout_host, int64_t* n_accept_host,
+                                double* rho_hist_host, asmc_stream stream, int d_noise) {
     ASMC_REQUIRE(ctx && x && ll && lp && lq && prm && flow && work_dev && rho_inout_host && n_accept_host, "null pointer");
     ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
     ASMC_REQUIRE(n_steps >= 1 && n_steps <= ASMC_MAX_PCN_STEPS, "n_steps out of range (<= 2048 per call)");
-    ASMC_REQUIRE(prm->d > 0 && prm->d <= ASMC_MAX_DIMS && prm->d == flow->dims, "bad d");
+    ASMC_REQUIRE(prm->d > 0 && prm->d <= ASMC_MAX_DIMS && (d_noise > 0 ? d_noise : prm->d) == flow->dims, "bad d");
     ASMC_REQUIRE(prm->x_dtype == ASMC_F64 || prm->x_dtype == ASMC_F32, "bad x_dtype");
     ASMC_REQUIRE(prm->mu_dev && prm->L_dev && prm->Linv_dev, "null reference-Gaussian pointer");
     ASMC_REQUIRE(*rho_inout_host > 0.0 && *rho_inout_host <= 1.0, "rho must be in (0, 1]");
-    ASMC_REQUIRE(work_bytes >= asmc_pcn_flow_work_bytes(n, prm->d, prm->x_dtype), "work buffer too small");
+    ASMC_REQUIRE(d_noise > 0 || work_bytes >= asmc_pcn_flow_work_bytes(n, prm->d, prm->x_dtype), "work buffer too small");
     ASMC_REQUIRE(!(prm->nu > 0.0) || prm->nu >= 1.0, "nu must be >= 1 (or <= 0 for the Gaussian reference)");
     int rc = check_mixture(prm->log_likelihood);
     if (!rc) rc = check_mixture(prm->log_prior);
@@ -3100,6 +3104,7 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
     pd.seed = prm->seed;
     pd.gid0 = prm->gid0;
     pd.nu = prm->nu;
+    pd.d_noise = d_noise;
     double* d_rho = ctx->d_rho;
     double* d_rho_hist = ctx->d_rho + 8;
     long long* d_counts = ctx->d_counts;
@@ -3136,6 +3141,10 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
         if (rc) return rc;
         // one kernel per step (propose -> flow on the MFMA -> targets -> accept) where the shape allows it
         const bool fused = soa && asmc_pcn_flow_fused_ok(prm, flow);
+        if (d_noise > 0 && !fused) {
+            asmc_set_error("asmc_pcn_mutate_flow: the zero-padded form needs the one-kernel step");
+            return ASMC_ERR_UNSUPPORTED;
+        }
         // counters of the fused steps: [t] tile hand-out, [ASMC_MAX_PCN_STEPS + t] blocks done
         if (fused) ASMC_HIP(hipMemsetAsync(ctx->d_tilectr, 0, sizeof(unsigned int) * (2 * ASMC_MAX_PCN_STEPS + 2), st));
         if (fused) {  // every tile starts in half 0 of the state allocation (tile parities: the split path's flag bytes are free here)
@@ -3196,6 +3205,10 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
         rc = convert(PCN_UNWHITEN_X);
         if (rc) return rc;
     }
+    if (d_noise > 0 && !reg_ok) {
+        asmc_set_error("asmc_pcn_mutate_flow: the zero-padded form needs the one-kernel step");
+        return ASMC_ERR_UNSUPPORTED;
+    }
     for (int t = 0; t < (reg_ok ? 0 : n_steps); t++) {
         const uint32_t step = step0 + (uint32_t)t;
         rc = pcn_propose_launch(ctx, n, d, prm->x_dtype, x, x_prop, q0, q1, pd, d_rho, step, st);
@@ -3234,6 +3247,84 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
         return ASMC_OK;
     }
     return mutate_flow_collect(ctx, n_steps, rho_inout_host, n_accept_host, rho_hist_host, st);
+}
+
+extern "C" {
+
+int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq,
+                         const asmc_pcn_params* prm, const asmc_coupling* flow, void* work_dev, int64_t work_bytes,
+                         int n_steps, uint32_t step0, double* rho_inout_host, int64_t* n_accept_host,
+                         double* rho_hist_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && x && prm && flow, "null pointer");
+    // Fewer than 32 dimensions: the one-kernel step on a zero-padded copy (pcn_mutate_padded's scheme: padded rows and tables,
+    // the identity beyond d, no noise there) wherever the flow's shape is one the kernel takes - any even d for a coupling flow,
+    // 17 .. 31 for an autoregressive one.  Round 3 ran propose / flow / accept kernels at d = 8 / 16 (0.35 / 0.42 ms per step
+    // at 1M particles) and the x-state split path at the other d (0.8 ms at d = 20).
+    asmc_pcn_params p2 = *prm;
+    p2.d = 32;
+    if (prm->d >= 2 && prm->d < 32 && prm->d == flow->dims && 32 <= ctx->d_max_pad && !getenv("ASMC_PCN_GENERIC") &&
+        !getenv("ASMC_PCN_NOPAD") && asmc_pcn_flow_fused_ok(&p2, flow) && !getenv("ASMC_PCN_AOS") && !getenv("ASMC_PCN_XSTATE")) {
+        ASMC_REQUIRE(ll && lp && lq && rho_inout_host && n_accept_host && work_dev, "null pointer");
+        ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+        ASMC_REQUIRE(prm->x_dtype == ASMC_F64 || prm->x_dtype == ASMC_F32, "bad x_dtype");
+        ASMC_REQUIRE(prm->mu_dev && prm->L_dev && prm->Linv_dev, "null reference-Gaussian pointer");
+        int rc = check_mixture(prm->log_likelihood);
+        if (!rc) rc = check_mixture(prm->log_prior);
+        if (rc) return rc;
+        hipStream_t st = as_stream(stream);
+        const int d = prm->d, D = 32;
+        const size_t es = prm->x_dtype == ASMC_F64 ? 8 : 4;
+        const size_t tab_doubles = (size_t)D + 2 * (size_t)D * D + 3 * 2 * (size_t)ASMC_MAX_COMPONENTS * D;
+        const size_t tab_bytes = ((tab_doubles * 8 + 255) / 256) * 256;
+        const size_t need = tab_bytes + (size_t)n * D * es;
+        if (need > ctx->xpad_bytes) {
+            ASMC_HIP(hipStreamSynchronize(st));
+            if (ctx->d_xpad) (void)hipFree(ctx->d_xpad);
+            ctx->d_xpad = nullptr;
+            ctx->xpad_bytes = 0;
+            if (hipMalloc(&ctx->d_xpad, need) != hipSuccess) {
+                (void)hipGetLastError();
+                asmc_set_error("pcn: no device memory for the zero-padded copy of the state (%zu bytes)", need);
+                return ASMC_ERR_NOMEM;
+            }
+            ctx->xpad_bytes = need;
+        }
+        double* tab = reinterpret_cast<double*>(ctx->d_xpad);
+        void* xp = reinterpret_cast<char*>(ctx->d_xpad) + tab_bytes;
+        PcnDev src;
+        memset(&src, 0, sizeof(src));
+        src.mu = prm->mu_dev, src.L = prm->L_dev, src.Linv = prm->Linv_dev;
+        src.ll = to_dev(prm->log_likelihood), src.lp = to_dev(prm->log_prior);
+        src.lq = src.lp;  // (placeholder: the proposal density is the flow)
+        ASMC_LAUNCH(ctx, st, "k_pad_tables", k_pad_tables, dim3(1), dim3(256), 0, st, d, D, src, tab);
+        ASMC_LAUNCH_CHECK();
+        const int grid = grid_for(n * D, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
+        if (es == 8)
+            ASMC_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const double*)x, (double*)xp);
+        else
+            ASMC_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const float*)x, (float*)xp);
+        ASMC_LAUNCH_CHECK();
+        p2.mu_dev = tab;
+        p2.L_dev = tab + D;
+        p2.Linv_dev = p2.L_dev + (size_t)D * D;
+        asmc_mixture* mix[2] = {&p2.log_likelihood, &p2.log_prior};
+        for (int k = 0; k < 2; k++) {
+            mix[k]->mu_dev = p2.Linv_dev + (size_t)D * D + (size_t)k * 2 * ASMC_MAX_COMPONENTS * D;
+            mix[k]->prec_dev = mix[k]->mu_dev + (size_t)ASMC_MAX_COMPONENTS * D;
+        }
+        // the unpadding copy must sit behind the mutation on the stream whether or not the caller defers the read-back
+        rc = pcn_mutate_flow_impl(ctx, n, xp, ll, lp, lq, &p2, flow, work_dev, work_bytes, n_steps, step0, rho_inout_host, n_accept_host,
+                                  rho_hist_host, stream, d);
+        if (rc) return rc;
+        if (es == 8)
+            ASMC_LAUNCH(ctx, st, "k_unpad_rows", k_unpad_rows<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const double*)xp, (double*)x);
+        else
+            ASMC_LAUNCH(ctx, st, "k_unpad_rows", k_unpad_rows<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const float*)xp, (float*)x);
+        ASMC_LAUNCH_CHECK();
+        return ASMC_OK;
+    }
+    return pcn_mutate_flow_impl(ctx, n, x, ll, lp, lq, prm, flow, work_dev, work_bytes, n_steps, step0, rho_inout_host, n_accept_host,
+                                rho_hist_host, stream, 0);
 }
 
 int asmc_pcn_mutate_flow_enqueue(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq,

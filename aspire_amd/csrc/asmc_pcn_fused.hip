@@ -154,27 +154,39 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     constexpr bool MVM = FUSED_MVMFMA && FUSED_INPLACE;  // the mat-vec on the fp64 matrix cores
     {
         const double* m0g = ptab + 2 * PTAB_TRI(D) + D;
+        // A problem of fewer than 32 dimensions arrives zero-padded to 32 (asmc_pcn_mutate_flow: tables with the identity beyond
+        // dr = p.d_noise, state rows padded, no noise on the padding).  y keeps its natural order; the ROWS of x' are placed where
+        // the flow's tiles want them: a coupling flow of dr dims splits x at dr / 2 and holds each half in 16 slots, so row r < 16
+        // is coordinate r of the first half (r < dr / 2) and row 16 + r coordinate dr / 2 + r of the second - both still below the
+        // diagonal of L's natural order, so the triangular K-step pattern holds; an autoregressive flow keeps the natural order.
+        // Padding rows have no coefficients, no mean, no weight in the targets and loc = 0, scale = 1.
+        const int dr = (p.d_noise > 0 && p.d_noise < D) ? p.d_noise : D;
+        const int dhalf = KIND == ASMC_FLOW_MAF ? 16 : dr / 2;
+        auto nat = [&](int r) -> int {  // row of the 32-row layout -> natural coordinate, or -1 for padding
+            const int c = r < 16 ? (r < dhalf ? r : -1) : (r - 16 + dhalf);
+            return (c >= 0 && c < dr) ? c : -1;
+        };
         if (MVM) {
             // A-operand image of L: slot (mb, s) = mb == 0 ? s : 4 + s (row block mb, K-step s; s < 4 mb + 4), 64 doubles each:
             // lane l supplies A[i = l & 15][k = l >> 4]; accumulator row i = h + 4 r lands in lane group h, register r, and is made
             // to BE row 16 mb + 4 h + r of x' by storing that row of L at image row i = (row % 4) * 4 ... i.e. i % 4 = h, i / 4 = r
             for (int e = threadIdx.x; e < 12 * 64; e += THREADS) {
                 const int slot = e >> 6, l = e & 63, mb = slot < 4 ? 0 : 1, sidx = slot < 4 ? slot : slot - 4;
-                const int i = l & 15, j = 16 * mb + 4 * (i & 3) + (i >> 2), k = 4 * sidx + (l >> 4);
-                tl[e] = k <= j ? ptab[j * (j + 1) / 2 + k] : 0.0;
+                const int i = l & 15, j = nat(16 * mb + 4 * (i & 3) + (i >> 2)), k = 4 * sidx + (l >> 4);
+                tl[e] = (j >= 0 && k <= j) ? ptab[j * (j + 1) / 2 + k] : 0.0;
             }
             // per-row tables in the order a lane reads them: entry h * 8 + mb * 4 + r <-> row 16 mb + 4 h + r
             for (int e = threadIdx.x; e < D; e += THREADS) {
-                const int j = 16 * ((e >> 2) & 1) + 4 * (e >> 3) + (e & 3);
-                tl[M_MU + e] = ptab[2 * PTAB_TRI(D) + j];
-                reinterpret_cast<float*>(tl + M_LOC)[e] = loc[j];
-                reinterpret_cast<float*>(tl + M_LOC)[D + e] = scale[j];
-                reinterpret_cast<float*>(tl + M_LOC)[2 * D + e] = 1.0f / scale[j];
+                const int j = nat(16 * ((e >> 2) & 1) + 4 * (e >> 3) + (e & 3));
+                tl[M_MU + e] = j >= 0 ? ptab[2 * PTAB_TRI(D) + j] : 0.0;
+                reinterpret_cast<float*>(tl + M_LOC)[e] = j >= 0 ? loc[j] : 0.0f;
+                reinterpret_cast<float*>(tl + M_LOC)[D + e] = j >= 0 ? scale[j] : 1.0f;
+                reinterpret_cast<float*>(tl + M_LOC)[2 * D + e] = j >= 0 ? 1.0f / scale[j] : 1.0f;
             }
             for (int e = threadIdx.x; e < 2 * FUSED_MAX_COMPONENTS * D; e += THREADS) {
                 const int tc = e / D, er = e % D, tt = tc / FUSED_MAX_COMPONENTS, c = tc % FUSED_MAX_COMPONENTS;
-                const int j = 16 * ((er >> 2) & 1) + 4 * (er >> 3) + (er & 3);
-                const bool live = c < (tt == 0 ? p.c_ll : p.c_lp);
+                const int j = nat(16 * ((er >> 2) & 1) + 4 * (er >> 3) + (er & 3));
+                const bool live = j >= 0 && c < (tt == 0 ? p.c_ll : p.c_lp);
                 const double* mg = m0g + (size_t)tt * PTAB_MIX(D);
                 tl[M_MIX + tc * 2 * D + er] = live ? mg[ASMC_MAX_COMPONENTS + c * D + j] : 0.0;
                 tl[M_MIX + tc * 2 * D + D + er] = live ? mg[ASMC_MAX_COMPONENTS * (1 + D) + c * D + j] : 0.0;
@@ -232,6 +244,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     }
     if (ad.cell && blockIdx.x == 0 && threadIdx.x == 0) ad.rho_hist[ad.t] = rho;
     const double a = sqrt(1.0 - rho * rho);
+    const int dn = __builtin_amdgcn_readfirstlane((p.d_noise > 0 && p.d_noise < 32) ? p.d_noise : 32);  // real dimension of a zero-padded problem
     const int64_t n_tiles = (n + 63) / 64;
     long long n_acc = 0, n_bad = 0;
 #ifdef FUSED_STAMP
@@ -339,10 +352,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         if (NOISE == ASMC_NOISE_F64) {
 #pragma unroll
             for (int qd = 0; qd < D / 4; qd++) {
+                if (4 * qd >= dn) continue;  // (wave uniform) a zero-padded problem: no noise beyond its dimension - y stays 0 there
                 double z[4];
                 normal_quad(p.seed, gid, step, (uint32_t)qd, bmt, z[0], z[1], z[2], z[3]);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
+                    if (4 * qd + e >= dn) continue;  // (the quad that straddles the dimension)
                     q0 = fma(v[4 * qd + e], v[4 * qd + e], q0);
                     v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
                     q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
@@ -355,10 +370,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         } else {
 #pragma unroll
             for (int qd = 0; qd < D / 4; qd++) {
+                if (4 * qd >= dn) continue;
                 double z[4];
                 normal_quad_f32(p.seed, gid, step, (uint32_t)qd, z[0], z[1], z[2], z[3]);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
+                    if (4 * qd + e >= dn) continue;
                     q0 = fma(v[4 * qd + e], v[4 * qd + e], q0);
                     v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
                     q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
@@ -560,8 +577,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         // scheduler these computations sink below the flow, y' (64 VGPRs) stays alive across it for |y'|^2, and the
         // accumulators spill.  log_p_t(ll', lp', lq') = (1 - beta) lq' + beta (ll' + lp'): the second product is formed now.
         double t2 = p.beta * (nll + nlp);
-        double c1 = ref_corr(q1, p.nu, D);
-        double rhs = log_p_t(oll, olp, olq, p.beta) + ref_corr(q0, p.nu, D);
+        double c1 = ref_corr(q1, p.nu, dn);
+        double rhs = log_p_t(oll, olp, olq, p.beta) + ref_corr(q0, p.nu, dn);
         // (bm_log_unit: the noise generator's < 1 ulp log for positive normal arguments - the uniform is (k + 1/2) 2^-53 -
         // without libm's special-case and range code: a third of the instructions)
         double logu = bm_log_unit(accept_uniform(p.seed, gid, step));
@@ -896,6 +913,7 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
     ps.ys = pd.ys;
     ps.n_pad = pd.n_pad;
     ps.d_real = pd.d;
+    ps.d_noise = pd.d_noise;
     ps.seed = pd.seed;
     ps.gid0 = pd.gid0;
     ps.c_ll = pd.ll.C;
@@ -967,7 +985,11 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
 // every coupling layer resident in LDS next to nothing else
 bool asmc_pcn_flow_fused_ok(const asmc_pcn_params* prm, const asmc_coupling* f) {
     if (getenv("ASMC_FLOW_SPLIT")) return false;
-    if (prm->d != 32 || f->dims != 32) return false;
+    // d = 32 as it is; fewer dimensions zero-padded to 32 by asmc_pcn_mutate_flow (prm->d is 32 by then, the flow keeps its own)
+    if (prm->d != 32 || f->dims > 32 || f->dims < 2) return false;
+    if (f->dims != 32 && !(FUSED_MVMFMA && FUSED_INPLACE)) return false;  // (the padded layout lives in the matrix-core variant's tables)
+    if (f->kind == ASMC_FLOW_COUPLING && (f->dims % 2)) return false;
+    if (f->kind == ASMC_FLOW_MAF && f->dims <= 16) return false;  // (its tiles are packed 8 coordinates per lane half there)
     // mixture targets: the matrix-core variant takes up to FUSED_MAX_COMPONENTS components each
     const bool mvm = FUSED_MVMFMA && FUSED_INPLACE && f->kind == ASMC_FLOW_COUPLING && f->hidden == 64 && asmc_flow_math_split();  // (the mixture instantiations)
     const int cmax = mvm ? FUSED_MAX_COMPONENTS : 1;

@@ -932,7 +932,7 @@ def test_coupling_logprob_vs_torch_modules(eng):
                                         ("f64", 32, 5.0), ("f64", 20, 5.0)])
 def test_pcn_mutate_flow_vs_split_calls(eng, xdt, d, nu):
     """asmc_pcn_mutate_flow (whitened-state register kernels around the MFMA flow kernel, all steps enqueued on
-    the device; d = 20 takes the generic composition) against the same steps issued one ABI call at a time in x
+    the device; d = 20 is zero-padded into the one-kernel step, d = 8 likewise) against the same steps issued one ABI call at a time in x
     space (propose / coupling_logprob / mixture_logpdf / accept), each of which is checked against the oracle
     above.  The whitened state rounds differently (1e-13 relative in fp64, 1e-6 in fp32 storage), so accept
     decisions may differ for razor-edge cases; everything else must agree, and the carried log-probabilities
@@ -974,9 +974,17 @@ def test_pcn_mutate_flow_vs_split_calls(eng, xdt, d, nu):
     edge = 5 if xdt == "f64" else 60
     assert int((~close).sum()) <= edge, int((~close).sum())
     assert np.all(np.abs(n_acc - np.array(acc_b)) <= edge)
-    if d == 20:  # generic composition: the very same kernels, bit-identical
-        assert bool(close.all()) and n_acc.tolist() == acc_b
-        for a, b in ((xa, xb), (lla, llb), (lpa, lpb), (lqa, lqb)):
+    if d == 20:  # round 4: zero-padded into the one-kernel step (above: agreement to the whitened state's rounding); the generic
+        # composition it replaced is still there (ASMC_PCN_NOPAD=1) and is the very same kernels as the split calls: bit-identical
+        xc, llc, lpc, lqc = init()
+        os.environ["ASMC_PCN_NOPAD"] = "1"
+        try:
+            n_acc_c, _, _ = eng.pcn_mutate_flow(xc, llc, lpc, lqc, beta, mu, L, Linv, t_ll, t_lp, dev, 77, 1000, rho, n_steps, 5, 0.234,
+                                                False, "f64", nu)
+        finally:
+            del os.environ["ASMC_PCN_NOPAD"]
+        assert n_acc_c.tolist() == acc_b
+        for a, b in ((xc, xb), (llc, llb), (lpc, lpb), (lqc, lqb)):
             assert torch.equal(a, b)
     # carried log-probabilities are the densities at the returned positions
     torch.testing.assert_close(lla, eng.mixture_logpdf(xa, t_ll), rtol=1e-9 if xdt == "f64" else 1e-4, atol=1e-9 if xdt == "f64" else 2e-3)
@@ -1763,6 +1771,79 @@ def test_pcn_flow_fused_step_with_mixture_targets_vs_oracle(eng, oracle, c_ll, c
     # carried densities = the mixtures at the returned positions
     np.testing.assert_allclose(lld.cpu().numpy(), o_ll.logpdf(got), rtol=1e-10 if xdt == "f64" else 1e-4, atol=1e-9 if xdt == "f64" else 2e-3)
     np.testing.assert_allclose(lpd.cpu().numpy(), o_lp.logpdf(got), rtol=1e-10 if xdt == "f64" else 1e-4, atol=1e-9 if xdt == "f64" else 2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,nu,xdt", [(8, 0.0, "f64"), (12, 0.0, "f64"), (16, 0.0, "f64"), (20, 0.0, "f64"), (30, 0.0, "f64"), (2, 0.0, "f64"),
+                                      (16, 5.0, "f64"), (20, 0.0, "f32"), (10, 4.0, "f64")])
+def test_pcn_flow_fused_step_below_32_dimensions_vs_oracle(eng, oracle, d, nu, xdt):
+    """A flow-proposal mutation in fewer than 32 dimensions takes the ONE-kernel step too (round 4): the library pads rows and
+    tables to 32 (identity beyond d, no noise there), the kernel places the rows of x' where the coupling tiles want their two
+    halves.  Against the oracle's d-dimensional restatement of the whole step (pCN and, with nu, tpCN); the trace shows one
+    k_pcn_flow_fused per step and neither the propose / accept halves of d = 8 / 16 nor the x-state split path of the other d
+    (round 3: 0.35 / 0.42 ms and 0.8 ms per step at 1M particles)."""
+    from conftest import random_coupling_flow
+
+    n, n_steps, beta, rho = 3000, 3, 0.45, 0.35
+    dt = torch.float64 if xdt == "f64" else torch.float32
+    flow = random_coupling_flow(d, 4, 64, seed=7)
+    dev = flow.device_coupling(eng)
+    ws, bs = flow.export_layers()
+    g = np.random.default_rng(31 + d)
+    tgt = ([0.1], 0.2 * g.normal(size=(1, d)), 0.7 + g.random(size=(1, d)))
+    o_t, t_t = oracle.Mixture(*tgt), eng.make_mixture(*tgt)
+    x0 = torch.as_tensor(0.9 * g.normal(size=(n, d))).to(dt)
+    xr = x0.double().numpy().copy()
+    a = g.normal(size=(d, d)) / np.sqrt(d)
+    L = np.tril(np.linalg.cholesky(0.8 * (np.eye(d) + 0.2 * a @ a.T)))
+    Linv, mu = np.tril(np.linalg.inv(L)), 0.05 * g.normal(size=d)
+    llr = o_t.logpdf(xr)
+    lpr = llr.copy()
+    lqr = oracle.coupling_logprob(xr, ws, bs, flow.loc.numpy(), flow.scale.numpy())
+    xd = x0.to(eng.device).contiguous()
+    lld, lpd, lqd = eng.asarray(llr), eng.asarray(lpr), eng.coupling_logprob(xd, dev)
+    eng.profile(True)
+    n_acc, _, _ = eng.pcn_mutate_flow(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), t_t, t_t, dev,
+                                      123, 40, rho, n_steps, 2, 0.234, False, "f64", nu)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert rep["k_pcn_flow_fused"][0] == n_steps, sorted(rep)
+    assert not any(k.startswith(("k_coupling_logprob", "k_pcn_flow_propose", "k_pcn_flow_accept", "k_pcn_propose", "k_pcn_mm", "k_copy_flagged")) for k in rep), sorted(rep)
+    acc_ref, margins = [], []
+    for t in range(n_steps):
+        with oracle.accept_margins(n) as m:
+            if nu > 0:
+                acc_ref.append(oracle.tpcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, nu, o_t, o_t, ws, bs, flow.loc.numpy(),
+                                                     flow.scale.numpy(), 123, 40, 2 + t, "f64") if hasattr(oracle, "tpcn_flow_step") else None)
+            else:
+                acc_ref.append(oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, o_t, o_t, ws, bs, flow.loc.numpy(),
+                                                    flow.scale.numpy(), 123, 40, 2 + t, "f64", 0))
+        margins.append(m.copy())
+    got = xd.double().cpu().numpy()
+    # carried densities = the targets / the flow at the returned positions, whatever the reference measure
+    np.testing.assert_allclose(lld.cpu().numpy(), o_t.logpdf(got), rtol=1e-10 if xdt == "f64" else 1e-4, atol=1e-9 if xdt == "f64" else 2e-3)
+    torch.testing.assert_close(lqd, eng.coupling_logprob(xd, dev), rtol=1e-5, atol=2e-3)
+    assert 0.03 < np.mean(n_acc) / n < 0.97
+    if nu > 0:  # no oracle restatement of the flow step with the Student-t reference: the split kernels are the comparison
+        xb = x0.to(eng.device).contiguous()
+        llb, lpb, lqb = eng.asarray(llr), eng.asarray(lpr), eng.coupling_logprob(xb, dev)
+        os.environ["ASMC_PCN_NOPAD"] = "1"
+        try:
+            acc_b, _, _ = eng.pcn_mutate_flow(xb, llb, lpb, lqb, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), t_t, t_t, dev,
+                                              123, 40, rho, n_steps, 2, 0.234, False, "f64", nu)
+        finally:
+            del os.environ["ASMC_PCN_NOPAD"]
+        close = ((xd.double() - xb.double()).abs() <= 1e-9 * (1 + xb.double().abs())).all(dim=1)
+        assert int((~close).sum()) <= 8 and np.all(np.abs(np.asarray(n_acc) - np.asarray(acc_b)) <= 8)
+        return
+    tol = 1e-9 if xdt == "f64" else 3e-5
+    close = np.all(np.abs(got - xr) <= tol * (1 + np.abs(xr)), axis=1)
+    edge = 12 if xdt == "f64" else 80
+    assert (~close).sum() <= edge, (~close).sum()
+    if xdt == "f64":
+        razor = np.min(np.abs(np.array(margins)), axis=0)
+        assert np.all(razor[~close] <= 1e-4), razor[~close]
+    assert np.all(np.abs(np.array(n_acc) - np.array(acc_ref)) <= edge)
 
 
 # ---- split-fp16 MFMA flow arithmetic: accuracy of the operands, not of a reduced-precision flow --------------------
