@@ -639,13 +639,16 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             STAMP(4);
             tn_l = tile_fetch();  // the next tile's index: back long before the flow is through
             auto maf_tile = [&](float(&xv)[16]) __attribute__((always_inline)) -> float {
-                float ladj = 0.0f, amax = 0.0f;
+                float ladj = 0.0f;
+                unsigned amax_pk = 0u;
                 for (int c = 0; c < n_layers; c++) {
                     float cond[16];
 #pragma unroll
                     for (int r = 0; r < 16; r++) cond[r] = xv[r];
-                    coupling_layer_hs<HF, W>(cond, xv, sp + (size_t)c * FD::LAYER, lane, hh, ladj, amax);
+                    coupling_layer_hs1p<HF, W, false>(cond, xv, sp + (size_t)c * FD::LAYER, lane, hh, ladj, amax_pk);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                float amax = range_pk_max(amax_pk);
                 float q = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; r++) q += xv[r] * xv[r];
