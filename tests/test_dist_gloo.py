@@ -136,6 +136,21 @@ def _worker(rank, world, port, out_dir, engine_kind="oracle"):
         res["cf_params"] = torch.cat([p.detach().reshape(-1) for p in cf.layers.parameters()]).numpy()
         res["cf_beta"] = np.array(sp3.history.beta)
         res["cf_x0"] = (post3.x.detach().cpu().numpy() if torch.is_tensor(post3.x) else np.asarray(post3.x))[:4]
+        # preconditioning="flow" on a sharded population (round-3 advice): ONE fit on a pooled subsample (rank 0 trains, everyone
+        # takes its parameters) instead of one per rank thrown away; and building / training a flow leaves the process-wide torch
+        # RNG alone (every refit used to call torch.manual_seed: a user density drawing from torch saw repeated streams)
+        from aspire_amd.transforms import FlowPreconditioningTransform
+
+        torch.manual_seed(900 + rank)
+        probe_before = torch.get_rng_state().clone()
+        fpt = FlowPreconditioningTransform(parameters=[f"p{i}" for i in range(d)], flow_backend="coupling", xp=np,
+                                           flow_kwargs=dict(n_layers=2, hidden_features=(8, 8)),
+                                           fit_kwargs=dict(n_epochs=2, fit_subsample=512), engine=eng)
+        z = fpt.fit(np.asarray(x[lo:hi]) + 0.25 * rank, comm=comm)  # the shards differ: a per-rank fit would differ too
+        res["fpt_params"] = torch.cat([p.detach().reshape(-1).double() for p in fpt.flow.layers.parameters()]
+                                      + [fpt.flow.loc.double().reshape(-1), fpt.flow.scale.double().reshape(-1)]).numpy()
+        res["fpt_rng_untouched"] = np.array(int(torch.equal(torch.get_rng_state(), probe_before)))
+        res["fpt_z_shape"] = np.array(np.asarray(z).shape)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -291,6 +306,13 @@ def test_sharded_run_with_trained_flow_agrees_on_rank0_parameters(two_rank_resul
     assert np.array_equal(r0["cf_params"], r1["cf_params"])  # rank 1 took rank 0's flow
     assert np.array_equal(r0["cf_beta"], r1["cf_beta"]) and r0["cf_beta"][-1] == 1.0
     assert not np.array_equal(r0["cf_x0"], r1["cf_x0"])  # separate draw streams: the shards are not copies of each other
+
+
+def test_sharded_flow_preconditioning_fits_once_on_a_pooled_subsample(two_rank_results):
+    r0, r1 = two_rank_results
+    assert np.array_equal(r0["fpt_params"], r1["fpt_params"])  # one latent space for every rank's chain
+    assert np.all(np.isfinite(r0["fpt_params"])) and int(r0["fpt_rng_untouched"]) == 1 and int(r1["fpt_rng_untouched"]) == 1
+    assert tuple(r0["fpt_z_shape"]) == (2048, 4)
 
 
 # ---- world 8 (the node's rank count) on the CPU test double --------------------------------------------------------------
