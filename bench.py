@@ -291,7 +291,7 @@ def main():
         "traffic": traffic, "traffic_source": traffic_src,
         "traffic_over_algorithmic": round(traffic / b_pcn, 3) if traffic else None,
         # what limits it (rocprofv3 --pmc SQ counters of the committed profile, fractions of SIMD time): the vector ALU
-        "limiter": "vector-ALU issue (fp64 noise + mat-vec, the flow's ReLU / hi-lo conversions); matrix pipe and vector ALU add up",
+        "limiter": "vector-ALU issue (fp64 noise, the flow's ReLU / hi-lo conversions and epilogues); matrix pipe (fp16 flow layers + the fp64 mat-vec) and vector ALU add up",
         "valu_active": sq.get("valu_active") if sq else None, "mfma_busy": sq.get("mfma_busy") if sq else None,
         "valu_insts_per_64_particle_tile": sq.get("valu_insts_per_tile") if sq else None,
         "sq_counters_source": sq_src, "kernel_source_hash": src_hash,
@@ -488,6 +488,36 @@ def main():
             extra["flow_run_f32_noise"] = {"wall_s": round(tf_, 4), "temperatures": len(spf.history.beta),
                                            "particle_steps_per_s": n_global * len(spf.history.beta) * n_mc / tf_,
                                            "abs_err_in_sigma": abs(float(postf.log_evidence) - true_logz) / max(float(postf.log_evidence_error), 1e-300)}
+        # (d2) the same workload with the reference's DEFAULT flow class as the proposal (ZukoFlow(flow_class="MAF"),
+        #      flows/torch/flows.py:140-168; here MAFFlow: 3 masked autoregressive transforms, MLP 32 -> 64 -> 64 -> 64): proposal draw
+        #      in k_maf_sample, every mutation step in the MAF instantiation of k_pcn_flow_fused
+        try:
+            from aspire_amd.flows import MAFFlow
+
+            mflow = MAFFlow(d, n_transforms=3, hidden_features=(64, 64), device=eng.device, dtype=torch.float32, seed=1234)
+            mflow.fit(sigma_q * 0.9 * np.random.default_rng(3).normal(size=(8000, d)), n_epochs=8)  # untimed
+            if sharded:
+                mflow.sync_shards(comm)
+            run(3, flow=mflow, n=min(n_global, 65536 * world), steps=2)
+            sync_all()
+            eng.profile(True)
+            t0 = time.perf_counter()
+            spq, postq = run(4, flow=mflow)
+            sync_all()
+            tq = time.perf_counter() - t0
+            kq = eng.profile_report()
+            eng.profile(False)
+            fk = next((k for k in kq if k.startswith("k_pcn_flow_fused")), None)
+            extra["flow_run_maf"] = {"wall_s": round(tq, 4), "temperatures": len(spq.history.beta),
+                                     "particle_steps_per_s": n_global * len(spq.history.beta) * n_mc / tq,
+                                     "log_evidence": float(postq.log_evidence),
+                                     "abs_err_in_sigma": abs(float(postq.log_evidence) - true_logz) / max(float(postq.log_evidence_error), 1e-300),
+                                     "mean_accept": float(np.mean(spq.history.mcmc_acceptance)),
+                                     "fused_step_us": round(kq[fk][1] * 1e3, 2) if fk else None,
+                                     "draw_us": round(kq["k_maf_sample"][1] * 1e3, 1) if "k_maf_sample" in kq else None,
+                                     "torch_ops_in_mutation_loop": 0 if fk and not any(k.startswith("k_pcn_flow_propose") for k in kq) else None}
+        except Exception as exc:  # an extra leg never costs the line
+            extra["flow_run_maf"] = {"error": repr(exc)}
         # (e) the headline run with the flow on the fp32 MFMA chain (v_mfma_f32_32x32x2_f32) instead of the default split-fp16
         #     products: same operands to fp32 accuracy, 16/3 of the matrix-pipe time
         if flow_math == "f16x2-split":
