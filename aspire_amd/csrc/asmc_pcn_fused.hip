@@ -289,11 +289,33 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     // the flow phase starts (no memory instruction in that phase waits behind it), and its state loads are issued right
     // after the flow, in front of this tile's accept step - so a tile's counter round trip, parity lookup and 32 state
     // loads no longer sit one after the other in front of its first instruction.
+#ifdef FUSED_STATIC_TILES  // diagnostic: tiles dealt round-robin, no counter (what the hand-out itself costs)
+    unsigned static_next = blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
     auto tile_fetch = [&]() -> unsigned {
-        unsigned t_l = 0;
-        if (lane == 0) t_l = atomicAdd(tile_counter, 1u);
+        const unsigned t_l = static_next;
+        static_next += gridDim.x * (THREADS / 64);
         return t_l;
     };
+#else
+    // Tiles are DEALT round-robin for as many whole rounds as there are (wave w of the grid takes tiles w, w + W, w + 2 W, ...);
+    // only the remainder - fewer tiles than waves - goes through the device-side counter, to whichever waves get there first.
+    // Round 3 drew every tile from the counter: 15 625 returning atomics on one word per launch run the memory-side atomic unit
+    // at 60 % of what it can serve (MI355X_MICROARCH.md, dequeue), and the waits behind it cost the step 4 % (0.314 -> 0.302 ms
+    // with no counter at all; grouped requests had cost 3-4 % in tail imbalance).
+    const unsigned deal_stride = gridDim.x * (unsigned)(THREADS / 64);
+    const unsigned n_dealt = (unsigned)(((n + 63) / 64) / deal_stride) * deal_stride;
+    unsigned deal_next = blockIdx.x * (unsigned)(THREADS / 64) + (threadIdx.x >> 6);
+    auto tile_fetch = [&]() -> unsigned {
+        if (deal_next < n_dealt) {  // (wave uniform)
+            const unsigned t_d = deal_next;
+            deal_next += deal_stride;
+            return t_d;
+        }
+        unsigned t_l = 0;
+        if (lane == 0) t_l = n_dealt + atomicAdd(tile_counter, 1u);
+        return t_l;
+    };
+#endif
     auto tile_parity = [&](unsigned t) -> unsigned {
         if (FUSED_INPLACE) return 0u;  // one state array
         if (par_words > 0) return (unsigned)__builtin_amdgcn_readfirstlane((int)((par_bits[t >> 5] >> (t & 31u)) & 1u));
