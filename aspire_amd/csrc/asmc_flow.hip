@@ -448,14 +448,14 @@ static int flow_pack_layers(const char* who, int H, int dh, int n_layers, int Wd
         for (int nb = 0; nb < NB1; nb++)
             for (int r = 0; r < 16; r++)
                 for (int hh = 0; hh < 2; hh++) {
-                    b1[(nb * 16 + r) * 2 + hh] = B1[32 * nb + acc_row(r, hh)];
-                    b2[(nb * 16 + r) * 2 + hh] = B2[32 * nb + acc_row(r, hh)];
+                    b1[hh * NB1 * 16 + nb * 16 + r] = B1[32 * nb + acc_row(r, hh)];  // [lane half][block][register]: a lane reads its 16 values of a block as four 16-byte reads
+                    b2[hh * NB1 * 16 + nb * 16 + r] = B2[32 * nb + acc_row(r, hh)];
                 }
         for (int nb = 0; nb < NB3; nb++)
             for (int r = 0; r < 16; r++)
                 for (int hh = 0; hh < 2; hh++) {
                     const int o = out_row(nb, acc_row(r, hh));
-                    b3[(nb * 16 + r) * 2 + hh] = o >= 0 ? B3[o] : 0.0f;
+                    b3[hh * NB3 * 16 + nb * 16 + r] = o >= 0 ? B3[o] : 0.0f;
                 }
         for (int nb = 0; nb < NB1; nb++)
             for (int g = 0; g < H / 8; g++)

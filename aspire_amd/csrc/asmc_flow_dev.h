@@ -35,7 +35,7 @@ __device__ __forceinline__ void acc_bias(floatx16 (&acc)[TPW][NB], const float* 
     for (int nb = 0; nb < NB; nb++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float v = b[(nb * 16 + r) * 2 + hh];
+            const float v = b[hh * NB * 16 + nb * 16 + r];
 #pragma unroll
             for (int tt = 0; tt < TPW; tt++) acc[tt][nb][r] = v;
         }
@@ -269,7 +269,7 @@ __device__ __forceinline__ void acc_bias1(floatx16 (&acc)[NB], const float* __re
 #pragma unroll
     for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[nb][r] = b[(nb * 16 + r) * 2 + hh];
+        for (int r = 0; r < 16; r++) acc[nb][r] = b[hh * NB * 16 + nb * 16 + r];  // contiguous per lane half: 16-byte LDS reads
 }
 
 // one coupling layer of one 32-particle tile: cond / trans are the lane half's H / 2 coordinates
