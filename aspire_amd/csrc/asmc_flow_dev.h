@@ -535,8 +535,12 @@ __device__ __forceinline__ void coupling_layer_hs1p(const float (&cond)[H / 2], 
     const half8* A1 = reinterpret_cast<const half8*>(a1f) + lane;
     const half8* A2 = reinterpret_cast<const half8*>(a1f + W * H) + lane;
     const half8* A3 = reinterpret_cast<const half8*>(a1f + W * H + W * W) + lane;
+#ifndef HS1P_EARLY_BIAS
+#define HS1P_EARLY_BIAS 0  // 1: the second layer's accumulators take their bias before the first layer's MFMAs; 2: ... and the output layer's at the start of the second
+#endif
     floatx16 h1[NB1], h2[NB1], o[NB3];
     acc_bias1<NB1>(h1, b1, hh);
+    if (HS1P_EARLY_BIAS >= 1) acc_bias1<NB1>(h2, b2, hh);
     auto src = [&](int g, int j) -> float {
         if (g < ST1) return cond[8 * g + j];
         const int S = (g - ST1) % ST2;
@@ -581,8 +585,8 @@ __device__ __forceinline__ void coupling_layer_hs1p(const float (&cond)[H / 2], 
         const int layer = g < ST1 ? 0 : g < ST1 + ST2 ? 1 : 2;
         const int NBO = layer == 2 ? NB3 : NB1, NM = 3 * NBO;
         const bool more = g + 1 < G, overlap = more && !first_of_layer(g + 1);
-        if (g == ST1) acc_bias1<NB1>(h2, b2, hh);
-        if (g == ST1 + ST2) acc_bias1<NB3>(o, b3, hh);
+        if (g == ST1 && HS1P_EARLY_BIAS < 1) acc_bias1<NB1>(h2, b2, hh);
+        if (g == (HS1P_EARLY_BIAS >= 2 ? ST1 : ST1 + ST2)) acc_bias1<NB3>(o, b3, hh);
         if (PREFETCH && more) a_load(g + 1, ahn, aln);  // lands while this group's MFMAs issue
 #pragma unroll
         for (int m = 0; m < NM; m++) {

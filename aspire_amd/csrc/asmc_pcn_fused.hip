@@ -377,12 +377,21 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
                 if (4 * qd >= dn) continue;  // (wave uniform) a zero-padded problem: no noise beyond its dimension - y stays 0 there
                 double z[4];
                 normal_quad(p.seed, gid, step, (uint32_t)qd, bmt, z[0], z[1], z[2], z[3]);
+                if (4 * qd + 4 <= dn) {  // (wave uniform; the common case: no per-element test, no selects)
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    if (4 * qd + e >= dn) continue;  // (the quad that straddles the dimension)
-                    q0 = fma(v[4 * qd + e], v[4 * qd + e], q0);
-                    v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
-                    q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
+                    for (int e = 0; e < 4; e++) {
+                        q0 = fma(v[4 * qd + e], v[4 * qd + e], q0);
+                        v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
+                        q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
+                    }
+                } else {  // the quad that straddles the dimension of a zero-padded problem
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (4 * qd + e >= dn) continue;
+                        q0 = fma(v[4 * qd + e], v[4 * qd + e], q0);
+                        v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
+                        q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
+                    }
                 }
 #ifndef FUSED_NOISE_SB
 #define FUSED_NOISE_SB 1  // quads between two scheduling barriers of the noise phase
@@ -395,12 +404,21 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
                 if (4 * qd >= dn) continue;
                 double z[4];
                 normal_quad_f32(p.seed, gid, step, (uint32_t)qd, z[0], z[1], z[2], z[3]);
+                if (4 * qd + 4 <= dn) {  // (wave uniform; the common case: no per-element test, no selects)
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    if (4 * qd + e >= dn) continue;
-                    q0 = fma(v[4 * qd + e], v[4 * qd + e], q0);
-                    v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
-                    q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
+                    for (int e = 0; e < 4; e++) {
+                        q0 = fma(v[4 * qd + e], v[4 * qd + e], q0);
+                        v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
+                        q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
+                    }
+                } else {  // the quad that straddles the dimension of a zero-padded problem
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (4 * qd + e >= dn) continue;
+                        q0 = fma(v[4 * qd + e], v[4 * qd + e], q0);
+                        v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
+                        q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
+                    }
                 }
                 if (qd & 1) __builtin_amdgcn_sched_barrier(0);
             }
