@@ -463,6 +463,31 @@ def main():
                     "alg_bytes_per_step": b_step_g, "achieved_GBs": round(b_step_g / (ms * 1e-3) / 1e9, 1),
                     "frac_of_hbm_peak": round(b_step_g / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "mean_accept": float(n_acc.mean() / n_local)}
+        # (b2) the one-kernel flow-proposal step AWAY from the headline's 98 % acceptance and single-Gaussian targets (round 3's
+        #      kernel parked / copied state and slowed down by 28 % at ordinary acceptance rates, and sent mixture targets to
+        #      three kernels per step): kernel time from the library's HIP events, 16 steps each on the resampled 1M x 32 batch
+        try:
+            devc = cflow.device_coupling(eng)
+            rob = {}
+            mix2 = DiagGaussianMixture(np.stack([0.4 * np.ones(d), -0.4 * np.ones(d)]), np.stack([np.ones(d), 0.7 * np.ones(d)])).device_mixture(eng)
+            for label, rho_r, adapt_r, t_lik in (("accept_98pct", 0.02, False, tgt), ("accept_adapted_to_23pct_target", 0.3, True, tgt),
+                                                  ("two_component_mixture_likelihood", 0.3, True, mix2)):
+                xm, llm, lpm, lqm = (t.clone() for t in out)
+                llm = eng.mixture_logpdf(xm, t_lik)
+                lqm = eng.coupling_logprob(xm, devc)
+                eng.pcn_mutate_flow(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, t_lik, tgt, devc, 7, rank * n_local, rho_r, 4, 0, 0.234, adapt_r, "f64", 0.0)
+                eng.profile(True)
+                n_acc_r, _, _ = eng.pcn_mutate_flow(xm, llm, lpm, lqm, scal["beta"], mu0, eye, eye, t_lik, tgt, devc, 7, rank * n_local, rho_r, 16, 4,
+                                                    0.234, adapt_r, "f64", 0.0)
+                kr = eng.profile_report()
+                eng.profile(False)
+                fk = next((k for k in kr if k.startswith("k_pcn_flow_fused")), None)
+                rob[label] = {"kernel": fk, "launches": kr[fk][0] if fk else None, "avg_us": round(kr[fk][1] * 1e3, 2) if fk else None,
+                              "mean_accept": float(np.mean(n_acc_r) / n_local),
+                              "other_step_kernels": sorted(k for k in kr if k.startswith(("k_coupling_logprob", "k_pcn_flow_propose", "k_pcn_flow_accept")))}
+            extra["fused_step_by_regime"] = rob
+        except Exception as exc:
+            extra["fused_step_by_regime"] = {"error": repr(exc)}
         # (c) full runs with the analytic proposal (no flow): pCN and the reference's default tpCN, default noise
         for label, step_fn in (("smc_pcn_run", "pcn"), ("smc_tpcn_run", "tpcn")):
             run(1, n=min(n_global, 65536 * world), flow=GaussianFlow(d, sigma=sigma_q, seed=1, engine=eng, dtype=xdt),
