@@ -66,6 +66,17 @@ def trained_flow(s):
 
 
 case("config 3, coupling flow + pcn", d, lik, lik, trained_flow, true32, step_fn="pcn")
+
+
+def trained_maf(s):  # the reference's default flow class
+    from aspire_amd.flows import MAFFlow
+
+    f = MAFFlow(d, n_transforms=3, hidden_features=(64, 64), device=eng.device, dtype=torch.float32, seed=1234 + s)
+    f.fit(1.5 * 0.9 * np.random.default_rng(3 + s).normal(size=(8000, d)), n_epochs=8)
+    return f
+
+
+case("config 3, MAF flow + pcn", d, lik, lik, trained_maf, true32, step_fn="pcn")
 d5 = 128
 lik5 = DiagGaussianMixture(np.stack([2 * np.ones(d5), -2 * np.ones(d5)]), np.stack([0.5 * np.ones(d5), np.ones(d5)]))
 prior5 = DiagGaussianMixture.isotropic(d5, 0.0, 1.0)
