@@ -33,7 +33,7 @@ class Aspire:
                  parameters: list[str] | None = None, periodic_parameters: list[str] | None = None,
                  prior_bounds: dict[str, tuple[float, float]] | None = None, bounded_to_unbounded: bool = True,
                  bounded_transform: str = "logit", device: str | None = None, xp: Callable | None = None,
-                 flow: Flow | None = None, flow_backend: str = "coupling", flow_matching: bool = False,
+                 flow: Flow | None = None, flow_backend: str = "zuko", flow_matching: bool = False,
                  eps: float = 1e-6, dtype: Any | str | None = None, **kwargs) -> None:
         self.log_likelihood = log_likelihood
         self.log_prior = log_prior
@@ -105,8 +105,14 @@ class Aspire:
             if data_transform.is_identity or not data_transform._kind.any():
                 data_transform = None  # all bounds infinite: nothing beyond the internal standardisation
         if backend == "zuko":
-            logger.warning("flow_backend='zuko' is not available here; using the built-in coupling flow")
-            backend = "coupling"
+            # the reference's default backend (aspire.py:79-98) with its default flow class, a masked autoregressive flow
+            # (flows/torch/flows.py:140-164).  zuko itself is absent: `MAFFlow` restates the architecture and runs on the HIP kernels.
+            # Other zuko classes (NSF, ...) have no counterpart: the coupling flow stands in, with a warning.
+            fc = str(self.flow_kwargs.get("flow_class", "MAF")).upper()
+            if fc != "MAF":
+                logger.warning("zuko flow class %r is not available here; using the built-in coupling flow", fc)
+                self.flow_kwargs = {k: v for k, v in self.flow_kwargs.items() if k != "flow_class"}
+            backend = "maf" if fc == "MAF" else "coupling"
         if backend == "maf" or str(self.flow_kwargs.get("flow_class", "")).upper() == "MAF":
             # the reference's default flow class (ZukoFlow(flow_class="MAF"), flows/torch/flows.py:140-164): PyTorch passes only
             kw = {k: v for k, v in self.flow_kwargs.items() if k != "flow_class"}
