@@ -495,7 +495,10 @@ extern "C" int asmc_coupling_pack(int dims, int n_layers, int hidden, const floa
 }
 
 // ---- masked autoregressive flow: a transform = a coupling layer whose conditioner input and transformed block are both x -----
-static int maf_half_pad(int dims) { return ((dims + 15) / 16) * 16; }  // H of the layer templates: lane halves hold H / 2 coordinates
+// H of the layer templates (lane halves hold H / 2 coordinates): 32 for every dims <= 32 - a narrower tile (H = 16 at dims <= 16) would
+// halve the first and last layers' work in the stand-alone kernels, but the one-kernel pCN step (asmc_pcn_fused.hip) is built on
+// the 32-wide tile, and that step is where the flow is evaluated 32 times per temperature
+static int maf_half_pad(int dims) { return dims <= 32 ? 32 : ((dims + 15) / 16) * 16; }
 static bool maf_supported(int dims, int hidden) {
     return dims >= 1 && dims <= 32 && (hidden == 32 || hidden == 64 || hidden == 128);
 }
@@ -606,9 +609,6 @@ static int dispatch_maf(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_coupli
         if (hs) return launch_maf<HH, WW, XT, true>(ctx, n, x, f, out, st);                \
         return launch_maf<HH, WW, XT, false>(ctx, n, x, f, out, st);                       \
     }
-    ASMC_MAF_CASE(16, 32)
-    ASMC_MAF_CASE(16, 64)
-    ASMC_MAF_CASE(16, 128)
     ASMC_MAF_CASE(32, 32)
     ASMC_MAF_CASE(32, 64)
     ASMC_MAF_CASE(32, 128)
@@ -714,9 +714,6 @@ extern "C" int asmc_coupling_sample(asmc_ctx* ctx, int64_t n, int x_dtype, const
             return launch_maf_sample<HH, WW, double>(ctx, n, flow, seed, gid0, draw_id, (double*)x_out_dev, lq_out_dev, stm); \
         return launch_maf_sample<HH, WW, float>(ctx, n, flow, seed, gid0, draw_id, (float*)x_out_dev, lq_out_dev, stm);   \
     }
-        ASMC_MAF_SAMPLE_CASE(16, 32)
-        ASMC_MAF_SAMPLE_CASE(16, 64)
-        ASMC_MAF_SAMPLE_CASE(16, 128)
         ASMC_MAF_SAMPLE_CASE(32, 32)
         ASMC_MAF_SAMPLE_CASE(32, 64)
         ASMC_MAF_SAMPLE_CASE(32, 128)

@@ -3258,7 +3258,7 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
     ASMC_REQUIRE(ctx && x && prm && flow, "null pointer");
     // Fewer than 32 dimensions: the one-kernel step on a zero-padded copy (pcn_mutate_padded's scheme: padded rows and tables,
     // the identity beyond d, no noise there) wherever the flow's shape is one the kernel takes - any even d for a coupling flow,
-    // 17 .. 31 for an autoregressive one.  Round 3 ran propose / flow / accept kernels at d = 8 / 16 (0.35 / 0.42 ms per step
+    // any d for an autoregressive one.  Round 3 ran propose / flow / accept kernels at d = 8 / 16 (0.35 / 0.42 ms per step
     // at 1M particles) and the x-state split path at the other d (0.8 ms at d = 20).
     asmc_pcn_params p2 = *prm;
     p2.d = 32;

@@ -1032,7 +1032,6 @@ bool asmc_pcn_flow_fused_ok(const asmc_pcn_params* prm, const asmc_coupling* f) 
     if (prm->d != 32 || f->dims > 32 || f->dims < 2) return false;
     if (f->dims != 32 && !(FUSED_MVMFMA && FUSED_INPLACE)) return false;  // (the padded layout lives in the matrix-core variant's tables)
     if (f->kind == ASMC_FLOW_COUPLING && (f->dims % 2)) return false;
-    if (f->kind == ASMC_FLOW_MAF && f->dims <= 16) return false;  // (its tiles are packed 8 coordinates per lane half there)
     // mixture targets: the matrix-core variant takes up to FUSED_MAX_COMPONENTS components each
     const bool mvm = FUSED_MVMFMA && FUSED_INPLACE && f->kind == ASMC_FLOW_COUPLING && f->hidden == 64 && asmc_flow_math_split();  // (the mixture instantiations)
     const int cmax = mvm ? FUSED_MAX_COMPONENTS : 1;

@@ -551,7 +551,7 @@ int asmc_coupling_sample(asmc_ctx* ctx, int64_t n, int x_dtype, const asmc_coupl
  *     layers of transform t in torch.nn.Linear layout ([hidden, dims], [hidden, hidden], [2 dims, hidden] with output rows
  *     s_raw_0 .. s_raw_{dims-1}, t_0 .. t_{dims-1}).
  * The packed block goes into an asmc_coupling with kind = ASMC_FLOW_MAF; asmc_coupling_logprob, asmc_coupling_sample,
- * asmc_pcn_mutate_flow(_enqueue) take it as they take a coupling flow (the fused one-kernel step at dims = 32). */
+ * asmc_pcn_mutate_flow(_enqueue) take it as they take a coupling flow (the fused one-kernel step at every dims <= 32). */
 int64_t asmc_maf_pack_floats(int dims, int n_transforms, int hidden);
 int asmc_maf_pack(int dims, int n_transforms, int hidden, const float* const* weights_host, const float* const* biases_host,
                   float* packed_host);

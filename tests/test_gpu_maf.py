@@ -131,15 +131,15 @@ def _mutation_setup(eng, n, d, seed):
     return x0, 0.05 * g.normal(size=d), np.tril(L), np.tril(np.linalg.inv(L))
 
 
-@pytest.mark.parametrize("d,hidden,n,fused", [(32, 64, 6000, True), (32, 32, 2500, True), (16, 64, 3000, False), (7, 32, 2000, False),
-                                              (20, 64, 2500, True), (31, 32, 2000, True)])
+@pytest.mark.parametrize("d,hidden,n,fused", [(32, 64, 6000, True), (32, 32, 2500, True), (16, 64, 3000, True), (7, 32, 2000, True),
+                                              (20, 64, 2500, True), (31, 32, 2000, True), (3, 64, 1500, True), (16, 128, 1500, False)])
 def test_maf_mutation_vs_oracle(eng, oracle, d, hidden, n, fused):
     """asmc_pcn_mutate_flow with an autoregressive proposal density against the oracle's restatement of the whole step
-    (orc_pcn_flow_step_kind, flow_kind = maf): 17 <= d <= 32 takes the ONE-kernel step (k_pcn_flow_fused, the MAF instantiation;
-    d < 32 zero-padded inside the library), smaller dims the device-side propose / k_maf_logprob / accept loop - no torch op, no
-    host round trip inside the loop either way."""
+    (orc_pcn_flow_step_kind, flow_kind = maf): every d <= 32 (odd ones too) takes the ONE-kernel step (k_pcn_flow_fused, the MAF
+    instantiation; d < 32 zero-padded inside the library); hidden width 128 has no one-kernel instantiation and runs the
+    device-side propose / k_maf_logprob / accept loop - no torch op, no host round trip inside the loop either way."""
     n_steps, beta, rho = 3, 0.4, 0.35
-    flow = random_maf(d, 3, hidden, seed=6)
+    flow = random_maf(d, 3 if hidden < 128 else 1, hidden, seed=6)
     dev = flow.device_coupling(eng)
     ws, bs = flow.export_layers()
     x0, mu, L, Linv = _mutation_setup(eng, n, d, 8)

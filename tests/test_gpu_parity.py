@@ -2224,9 +2224,9 @@ def test_student_fit_on_the_device_vs_numpy_em(eng, m, d, iters):
 
 
 def test_sampler_with_a_maf_proposal_gpu(eng):
-    """The reference's default flow class as the proposal at a dimension without the one-kernel step (d = 8): the device-side
-    step loop with k_maf_logprob between the propose and accept kernels - no torch pass, no host round trip per step (round 3
-    ran MAFFlow's PyTorch modules here); evidence of the Gaussian product within its error bar."""
+    """The reference's default flow class as the proposal at d = 8: the proposal draw in k_maf_sample and every mutation step in the
+    one-kernel step (zero-padded to 32 dimensions inside the library) - no torch pass, no host round trip per step (round 3 ran
+    MAFFlow's PyTorch modules here); evidence of the Gaussian product within its error bar."""
     from aspire_amd.flows import MAFFlow
     from aspire_amd.samplers.smc import HipSMC
     from aspire_amd.targets import DiagGaussianMixture
@@ -2241,7 +2241,7 @@ def test_sampler_with_a_maf_proposal_gpu(eng):
     rep = eng.profile_report()
     eng.profile(False)
     assert "flow: device-side step loop" in sp.last_mutation_path
-    assert rep["k_maf_logprob"][0] >= 8 * len(sp.history.beta) and rep["k_maf_sample"][0] >= 1
+    assert rep["k_pcn_flow_fused"][0] == 8 * len(sp.history.beta) and rep["k_maf_sample"][0] >= 1 and "k_maf_logprob" not in rep
     assert abs(float(out.log_evidence) - 0.5 * d * math.log(math.pi)) < 5 * float(out.log_evidence_error) + 0.02
     assert 0.05 < np.mean(sp.history.mcmc_acceptance) < 0.99
 
