@@ -4,6 +4,7 @@ import ast
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -127,3 +128,44 @@ def test_hand_issued_lds_reads_are_not_touched_before_their_waits():
 
     m = re.search(r"(\d+) instantiations, (\d+) read batches, 0 violations", r.stdout)
     assert m and int(m.group(1)) >= 24, r.stdout
+
+
+def test_flow_packing_places_every_weight_once():
+    """asmc_coupling_pack / asmc_maf_pack are host-only (no GPU): the MFMA operand image is a permutation of the layers' weights and
+    biases padded with zeros - coupling flow at a padded dimension, autoregressive flow at an odd one (its MADE masks leave zeros in
+    the matrices) - and a weight outside the fp16 operand range of the split-fp16 kernels is refused, not silently clipped."""
+    from aspire_amd import _lib
+    from aspire_amd.engine import pack_coupling, pack_maf
+
+    lib = _lib.load()
+    g = np.random.default_rng(0)
+
+    def layers(n, w_in, hidden, w_out, mask_p=0.0):
+        ws, bs = [], []
+        for _ in range(n):
+            for shape in ((hidden, w_in), (hidden, hidden), (w_out, hidden)):
+                w = g.normal(size=shape).astype(np.float32)
+                if mask_p:
+                    w[g.random(size=shape) < mask_p] = 0.0
+                ws.append(w)
+                bs.append(g.normal(size=shape[0]).astype(np.float32))
+        return ws, bs
+
+    d, hidden, n = 20, 32, 2
+    ws, bs = layers(n, d // 2, hidden, d)
+    packed = pack_coupling(lib, d, hidden, ws, bs)
+    assert packed.size == lib.asmc_coupling_pack_floats(d, n, hidden)
+    want = np.sort(np.concatenate([a.ravel() for a in ws + bs]))
+    assert np.array_equal(np.sort(packed[packed != 0.0]), want)
+
+    d, hidden, n = 7, 64, 3
+    ws, bs = layers(n, d, hidden, 2 * d, mask_p=0.4)
+    packed = pack_maf(lib, d, hidden, ws, bs)
+    assert packed.size == lib.asmc_maf_pack_floats(d, n, hidden)
+    want = np.sort(np.concatenate([a.ravel() for a in ws + bs]))
+    assert np.array_equal(np.sort(packed[packed != 0.0]), want[want != 0.0])
+
+    ws[1][3, 5] = 1e5  # beyond fp16: the split products would see inf
+    with pytest.raises(_lib.AsmcError, match="fp16 operand range"):
+        pack_maf(lib, d, hidden, ws, bs)
+    assert lib.asmc_maf_pack_floats(33, 3, 64) < 0 and lib.asmc_coupling_pack_floats(21, 2, 64) < 0  # shapes without kernels
