@@ -26,7 +26,7 @@ COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
-ASMC_ABI_VERSION = 18
+ASMC_ABI_VERSION = 19
 ASMC_FLOW_COUPLING, ASMC_FLOW_MAF = 0, 1  # asmc_coupling.kind
 ASMC_CDF_REC = 9
 ASMC_CDF_STATE = 36
@@ -150,6 +150,11 @@ SIGNATURES = {
     "asmc_pcg64_uniforms": (_i, [_vp, POINTER(c_uint64), _u64, _i64, _vp, _vp]),
     "asmc_cdf_shard_tiles": (_i64, [_i64]),
     "asmc_cdf_shard_records": (_i, [_vp, _i64, _vp, _vp, _d, _i, _vp, _vp]),
+    "asmc_cdf_shard_records_dev": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "asmc_cdf_shard_finish_select": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "asmc_weights_m2_lse_shard": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "asmc_normalized_weights_shard": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
+    "asmc_shard_step_result": (_i, [_vp, _vp, _i, _pd, _vp]),
     "asmc_cdf_shard_chain": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _vp, _vp]),
     "asmc_cdf_shard_finish": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "asmc_select_range": (_i, [_vp, _i64, _vp, _vp, _vp, _pi64, _vp]),

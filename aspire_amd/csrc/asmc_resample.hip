@@ -348,6 +348,38 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_launch(int64_t n, 
     k_exact_tile_td_body(n, w, approx_prefix[blockIdx.x], n_tiles, tile_info, tile_split, tile_s2, rec_pk);
 }
 
+// The sharded step's form: the tiles' sums arrive with the weights (k_weights_map_shard) and the incoming sum is a device-side
+// result; a block adds up what lies in front of its tile itself (hints for the binade guess only: any order will do) -
+// k_tile_sum and k_scan_tiles are not launched
+__global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_shard(int64_t n, const double* __restrict__ w,
+                                                                   const double* __restrict__ tile_sums,
+                                                                   const double* __restrict__ carry_dev, int64_t n_tiles,
+                                                                   double* __restrict__ cdf, int first_exact,
+                                                                   long long* __restrict__ rec_pk) {
+    if (blockIdx.x == 0 && first_exact) {
+        __shared__ TD sh_td0[XT_THREADS / 64 + 1];
+        __shared__ double sh_s0;
+        __shared__ long long sh_pos0, sh_cross0;
+        const int64_t hi = ASMC_SCAN_TILE < n ? ASMC_SCAN_TILE : n;
+        const double s_out = exact_tile(w, cdf, 0, hi, 0.0, sh_td0, &sh_s0, &sh_pos0, &sh_cross0);
+        if (threadIdx.x == 0) {
+            rec_pk[0] = rec_pk[1] = rec_pk[2] = 0, rec_pk[3] = 3;
+            rec_pk[4] = rec_pk[5] = rec_pk[6] = rec_pk[7] = 0;
+            rec_pk[8] = __double_as_longlong(s_out);
+        }
+        return;
+    }
+    __shared__ double s_pre[XT_THREADS / 64];
+    double acc = 0.0;
+    for (int64_t u = threadIdx.x; u < (int64_t)blockIdx.x; u += XT_THREADS) acc += tile_sums[u];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_pre[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    double pre = first_exact ? 0.0 : *carry_dev;
+    for (int k = 0; k < XT_THREADS / 64; k++) pre += s_pre[k];
+    k_exact_tile_td_body(n, w, pre, n_tiles, (long long*)nullptr, (long long*)nullptr, (double*)nullptr, rec_pk);
+}
+
 // Pass D: one block chains the EXACT running sum through the tiles.  Flag-1 tiles cost O(1) (verify the binade
 // guess against the exact incoming sum, apply the tile transducer; 64 of them per wave-level scan); flag-2
 // tiles cost O(1) as well (apply A, verify that the add of element c is the one that leaves the binade, do that
@@ -524,6 +556,11 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_chain_pk(int64_t n_tiles, 
     double s = 0.0;
     int n_pub = 0;
     bool blocked = false;
+    if (!states_all) {  // first round: nothing has been scanned element-wise, nothing published (one block: no memset launches)
+        for (int64_t i = threadIdx.x; i < n_tiles; i += XT_THREADS) done_here[i] = 0.0;
+        if (threadIdx.x < 2 * CDF_PUB_MAX) state_out[4 + threadIdx.x] = 0.0;
+        __syncthreads();
+    }
     if (states_all) {  // second round: resume from this rank's own stop point
         const double* mine = states_all + (int64_t)rank * ASMC_CDF_STATE;
         t = (int64_t)mine[0];
@@ -896,11 +933,12 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_tile_sum(int64_t n, const double
 // exclusive scan of tile sums by one block, sequential over chunks of 1024; tiles[] overwritten
 // with the exclusive prefix (+carry); total written to total_out.
 __global__ __launch_bounds__(1024) void k_scan_tiles(int64_t n_tiles, double* __restrict__ tiles,
-                                                    double carry_in, double* __restrict__ total_out) {
+                                                    double carry_in, double* __restrict__ total_out,
+                                                    const double* __restrict__ carry_dev) {
     __shared__ double s_wave[16];
     __shared__ double s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_carry = carry_in;
+    if (tid == 0) s_carry = carry_dev ? *carry_dev : carry_in;  // (sharded step: the incoming sum is a device-side result)
     __syncthreads();
     for (int64_t start = 0; start < n_tiles; start += 1024) {
         const int64_t i = start + tid;
@@ -1498,11 +1536,64 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_compact_scatter(
 }
 
 
+// k_shard_edges + k_range_count in one launch (the sharded step's chain of launches): every block forms the slice's edges
+// itself, with k_shard_edges' own division, and block 0 leaves them in edges_out[4]
+__global__ __launch_bounds__(ASMC_BLOCK) void k_range_count_shard(int64_t n, const double* __restrict__ u,
+                                                                 const double* __restrict__ state,
+                                                                 const double* __restrict__ s_in,
+                                                                 const double* __restrict__ cdf_last,
+                                                                 long long* __restrict__ tiles,
+                                                                 double* __restrict__ edges_out) {
+    const double lo = *s_in / state[1], hi = *cdf_last;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        edges_out[0] = state[2] != 0.0 ? 0.0 : 1.0;
+        edges_out[1] = state[1];
+        edges_out[2] = lo;
+        edges_out[3] = hi;
+    }
+    const int64_t base = (int64_t)blockIdx.x * ASMC_SCAN_TILE + (int64_t)threadIdx.x * (ASMC_SCAN_TILE / ASMC_BLOCK);
+    long long c = 0;
+#pragma unroll
+    for (int j = 0; j < ASMC_SCAN_TILE / ASMC_BLOCK; j++)
+        if (base + j < n) {
+            const double v = u[base + j];
+            c += (v >= lo && v < hi) ? 1 : 0;
+        }
+    __shared__ long long s_p[ASMC_BLOCK / 64];
+    c = wave_sum_ll(c);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tiles[blockIdx.x] = s_p[0] + s_p[1] + s_p[2] + s_p[3];
+}
+
+// SELF_SCAN: `tiles` holds the tiles' COUNTS (k_range_count's output as it is) and a block adds up the counts in front of its
+// tile itself (integers: any order); the last block leaves info_out = {kept, failure flag of the slice (edges[0])} - the
+// k_scan_tiles_ll and k_range_info launches of the step-by-step form
+template <bool SELF_SCAN>
 __global__ __launch_bounds__(ASMC_BLOCK) void k_range_scatter(int64_t n, const double* __restrict__ u,
                                                              const double* __restrict__ lohi,
                                                              const long long* __restrict__ tiles,
-                                                             double* __restrict__ out) {
+                                                             double* __restrict__ out, long long* __restrict__ info_out) {
     const double lo = lohi[0], hi = lohi[1];
+    __shared__ long long s_front;
+    if (SELF_SCAN) {
+        long long f = 0;
+        for (int64_t k = threadIdx.x; k < (int64_t)blockIdx.x; k += ASMC_BLOCK) f += tiles[k];
+        f = wave_sum_ll(f);
+        __shared__ long long s_f[ASMC_BLOCK / 64];
+        if ((threadIdx.x & 63) == 0) s_f[threadIdx.x >> 6] = f;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long tot = 0;
+            for (int k = 0; k < ASMC_BLOCK / 64; k++) tot += s_f[k];
+            s_front = tot;
+            if (blockIdx.x == gridDim.x - 1) {
+                info_out[0] = tot + tiles[blockIdx.x];
+                info_out[1] = (long long)llrint(lohi[-2]);  // edges[0]
+            }
+        }
+        __syncthreads();
+    }
     const int64_t base = (int64_t)blockIdx.x * ASMC_SCAN_TILE + (int64_t)threadIdx.x * SC_E;
     double v[SC_E];
     bool ok[SC_E];
@@ -1523,7 +1614,7 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_range_scatter(int64_t n, const d
     __shared__ long long s_wave[ASMC_BLOCK / 64];
     if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
-    long long dst = tiles[blockIdx.x] + (inc - c);
+    long long dst = (SELF_SCAN ? s_front : tiles[blockIdx.x]) + (inc - c);
     for (int k = 0; k < wave; k++) dst += s_wave[k];
 #pragma unroll
     for (int j = 0; j < SC_E; j++)
@@ -1552,7 +1643,7 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
         double* d_approx_total = ctx->d_small + 1025;
         ASMC_LAUNCH(ctx, st, "k_tile_sum", k_tile_sum, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w, ctx->d_tiles);
         ASMC_LAUNCH_CHECK();
-        ASMC_LAUNCH(ctx, st, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, carry_in, d_approx_total);
+        ASMC_LAUNCH(ctx, st, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, carry_in, d_approx_total, (const double*)nullptr);
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_exact_tile_td_launch", k_exact_tile_td_launch, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w,
                            (const double*)ctx->d_tiles, (const double*)d_approx_total, n_tiles, ctx->d_tiles_i, d_split,
@@ -1570,7 +1661,7 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
         const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
         ASMC_LAUNCH(ctx, st, "k_tile_sum", k_tile_sum, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w, ctx->d_tiles);
         ASMC_LAUNCH_CHECK();
-        ASMC_LAUNCH(ctx, st, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, carry_in, d_total);
+        ASMC_LAUNCH(ctx, st, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, carry_in, d_total, (const double*)nullptr);
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_tile_scan", k_tile_scan, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w,
                            (const double*)ctx->d_tiles, cdf, d_norm);
@@ -1589,8 +1680,8 @@ int asmc_cdf(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, int mode, d
 
 int64_t asmc_cdf_shard_tiles(int64_t n) { return n <= 0 ? 0 : (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE; }
 
-int asmc_cdf_shard_records(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, double approx_carry, int first_rank,
-                           int64_t* rec_dev, asmc_stream stream) {
+static int cdf_shard_records_impl(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, double approx_carry,
+                                  const double* approx_carry_dev, int first_rank, int64_t* rec_dev, asmc_stream stream) {
     ASMC_REQUIRE(ctx && w && cdf && rec_dev, "null pointer");
     ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
     ASMC_REQUIRE(approx_carry >= 0.0, "approx_carry must be non-negative");
@@ -1600,11 +1691,30 @@ int asmc_cdf_shard_records(asmc_ctx* ctx, int64_t n, const double* w, double* cd
     ASMC_LAUNCH(ctx, st, "k_tile_sum", k_tile_sum, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, w, ctx->d_tiles);
     ASMC_LAUNCH_CHECK();
     ASMC_LAUNCH(ctx, st, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles,
-                first_rank ? 0.0 : approx_carry, d_approx_total);
+                first_rank ? 0.0 : approx_carry, d_approx_total, first_rank ? (const double*)nullptr : approx_carry_dev);
     ASMC_LAUNCH_CHECK();
     ASMC_LAUNCH(ctx, st, "k_exact_tile_td_launch", k_exact_tile_td_launch, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w,
                 (const double*)ctx->d_tiles, (const double*)d_approx_total, n_tiles, (long long*)nullptr, (long long*)nullptr,
                 (double*)nullptr, cdf, 0.0, (double*)nullptr, first_rank ? 1 : 0, (long long*)rec_dev);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_cdf_shard_records(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, double approx_carry, int first_rank,
+                           int64_t* rec_dev, asmc_stream stream) {
+    return cdf_shard_records_impl(ctx, n, w, cdf, approx_carry, nullptr, first_rank, rec_dev, stream);
+}
+
+int asmc_cdf_shard_records_dev(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, const double* approx_carry_dev,
+                               const double* tile_sums_dev, int first_rank, int64_t* rec_dev, asmc_stream stream) {
+    ASMC_REQUIRE(approx_carry_dev != nullptr, "null pointer");
+    if (!tile_sums_dev) return cdf_shard_records_impl(ctx, n, w, cdf, 0.0, approx_carry_dev, first_rank, rec_dev, stream);
+    ASMC_REQUIRE(ctx && w && cdf && rec_dev, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+    hipStream_t st = as_stream(stream);
+    const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+    ASMC_LAUNCH(ctx, st, "k_exact_tile_td_shard", k_exact_tile_td_shard, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w,
+                tile_sums_dev, approx_carry_dev, n_tiles, cdf, first_rank ? 1 : 0, (long long*)rec_dev);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
@@ -1618,8 +1728,6 @@ int asmc_cdf_shard_chain(asmc_ctx* ctx, int64_t n, const double* w, double* cdf,
     ASMC_REQUIRE(tile0 >= 0 && tile0 + n_tiles <= n_tiles_total, "this shard's tiles do not fit the global tile list");
     ASMC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank / world");
     hipStream_t st = as_stream(stream);
-    if (!states_all_dev)  // first round: nothing has been scanned element-wise yet
-        ASMC_HIP(hipMemsetAsync(work_dev + 2 * n_tiles_total, 0, sizeof(double) * (size_t)n_tiles_total, st));
     ASMC_LAUNCH(ctx, st, "k_exact_chain_pk", k_exact_chain_pk, dim3(1), dim3(XT_THREADS), 0, st, n_tiles_total,
                 (const long long*)recs_all_dev, work_dev, work_dev + n_tiles_total, work_dev + 2 * n_tiles_total, w, cdf, n,
                 tile0, n_tiles, states_all_dev, world, rank, state_out_dev);
@@ -1649,6 +1757,37 @@ int asmc_cdf_shard_finish(asmc_ctx* ctx, int64_t n, const double* w, double* cdf
     return ASMC_OK;
 }
 
+// asmc_cdf_shard_finish + asmc_select_range_dev in three launches instead of six (write pass; edges + count; scan + scatter +
+// info): the form the one-chain sharded step uses.  Same results, bit for bit.
+int asmc_cdf_shard_finish_select(asmc_ctx* ctx, int64_t n, const double* w, double* cdf, const int64_t* recs_all_dev,
+                                 int64_t n_tiles_total, int64_t tile0, double* work_dev, const double* state_dev,
+                                 int64_t n_u, const double* u_dev, double* edges_out_dev, double* out_dev, int64_t* info_dev,
+                                 asmc_stream stream) {
+    ASMC_REQUIRE(ctx && w && cdf && recs_all_dev && work_dev && state_dev && u_dev && edges_out_dev && out_dev && info_dev,
+                 "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max && n_u > 0 && n_u <= ctx->n_max, "n out of range for this ctx");
+    const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+    ASMC_REQUIRE(tile0 >= 0 && tile0 + n_tiles <= n_tiles_total, "this shard's tiles do not fit the global tile list");
+    hipStream_t st = as_stream(stream);
+    double* tile_s = work_dev;
+    double* tile_s2 = work_dev + n_tiles_total;
+    const double* done_here = work_dev + 2 * n_tiles_total;
+    ASMC_LAUNCH(ctx, st, "k_exact_tile_write", k_exact_tile_write, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n, w, cdf,
+                (const long long*)nullptr, (const long long*)nullptr, (const double*)(tile_s + tile0),
+                (const double*)(tile_s2 + tile0), state_dev + 1, (const long long*)recs_all_dev + ASMC_CDF_REC * tile0,
+                done_here + tile0, (unsigned int*)nullptr, (int64_t)0);
+    ASMC_LAUNCH_CHECK();
+    const int64_t u_tiles = (n_u + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+    ASMC_LAUNCH(ctx, st, "k_range_count_shard", k_range_count_shard, dim3((unsigned)u_tiles), dim3(ASMC_BLOCK), 0, st, n_u, u_dev,
+                state_dev, (const double*)(tile_s + tile0), (const double*)(cdf + n - 1), ctx->d_tiles_i, edges_out_dev);
+    ASMC_LAUNCH_CHECK();
+    ASMC_LAUNCH(ctx, st, "k_range_scatter<scan>", k_range_scatter<true>, dim3((unsigned)u_tiles), dim3(ASMC_BLOCK), 0, st, n_u,
+                u_dev, (const double*)(edges_out_dev + 2), (const long long*)ctx->d_tiles_i, out_dev,
+                reinterpret_cast<long long*>(info_dev));
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
 int asmc_select_range(asmc_ctx* ctx, int64_t n, const double* u_dev, const double* lohi_dev, double* out_dev,
                       int64_t* count_host, asmc_stream stream) {
     ASMC_REQUIRE(ctx && u_dev && lohi_dev && out_dev && count_host, "null pointer");
@@ -1661,8 +1800,8 @@ int asmc_select_range(asmc_ctx* ctx, int64_t n, const double* u_dev, const doubl
     ASMC_LAUNCH_CHECK();
     ASMC_LAUNCH(ctx, st, "k_scan_tiles_ll", k_scan_tiles_ll, dim3(1), dim3(64), 0, st, n_tiles, ctx->d_tiles_i, d_total);
     ASMC_LAUNCH_CHECK();
-    ASMC_LAUNCH(ctx, st, "k_range_scatter", k_range_scatter, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, u_dev, lohi_dev,
-                (const long long*)ctx->d_tiles_i, out_dev);
+    ASMC_LAUNCH(ctx, st, "k_range_scatter", k_range_scatter<false>, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, u_dev, lohi_dev,
+                (const long long*)ctx->d_tiles_i, out_dev, (long long*)nullptr);
     ASMC_LAUNCH_CHECK();
     long long* h = reinterpret_cast<long long*>(ctx->h_pinned);
     ASMC_HIP(hipMemcpyAsync(h, d_total, sizeof(long long), hipMemcpyDeviceToHost, st));
@@ -1691,8 +1830,8 @@ int asmc_select_range_dev(asmc_ctx* ctx, int64_t n, const double* u_dev, const d
     ASMC_LAUNCH_CHECK();
     ASMC_LAUNCH(ctx, st, "k_scan_tiles_ll", k_scan_tiles_ll, dim3(1), dim3(64), 0, st, n_tiles, ctx->d_tiles_i, d_total);
     ASMC_LAUNCH_CHECK();
-    ASMC_LAUNCH(ctx, st, "k_range_scatter", k_range_scatter, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, u_dev, lohi_dev,
-                (const long long*)ctx->d_tiles_i, out_dev);
+    ASMC_LAUNCH(ctx, st, "k_range_scatter", k_range_scatter<false>, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, u_dev, lohi_dev,
+                (const long long*)ctx->d_tiles_i, out_dev, (long long*)nullptr);
     ASMC_LAUNCH_CHECK();
     ASMC_LAUNCH(ctx, st, "k_range_info", k_range_info, dim3(1), dim3(1), 0, st, (const long long*)d_total, edges_dev,
                 reinterpret_cast<long long*>(info_dev));
@@ -1872,7 +2011,7 @@ int asmc_importance_step(asmc_ctx* ctx, int64_t n, const double* ll, const doubl
                     (const double*)w_scratch, (const double*)ctx->d_tiles, n_tiles, ctx->d_tiles_i, d_split, d_tile_s2,
                     cdf_scratch, d_tile_s);
     } else {
-        ASMC_LAUNCH(ctx, st, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, 0.0, ctx->d_small + 1025);
+        ASMC_LAUNCH(ctx, st, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(1024), 0, st, n_tiles, ctx->d_tiles, 0.0, ctx->d_small + 1025, (const double*)nullptr);
         ASMC_LAUNCH_CHECK();
         ASMC_LAUNCH(ctx, st, "k_exact_tile_td_launch", k_exact_tile_td_launch, dim3((unsigned)n_tiles), dim3(XT_THREADS), 0, st, n,
                     (const double*)w_scratch, (const double*)ctx->d_tiles, (const double*)(ctx->d_small + 1025), n_tiles,

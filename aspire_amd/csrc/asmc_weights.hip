@@ -228,6 +228,133 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_weights_map(int64_t n, const dou
     }
 }
 
+// Sharded importance step: the two passes above with their scalars taken from the search state the last k_bis_decide left
+// on the device (st[BIS_*], identical on every rank) - no host decision sits between the search, the evidence moments and
+// the weights.  The scalars are formed in smc_math.resample_owner's operation order (= k_is_weights' phase 2).
+#define SHARD_TICKET_CELL (1024 * 12)  // in ctx->d_bar (zeroed at creation), behind the persistent kernel's barrier counters
+struct ShardScalars {
+    double c1, c2, m, mean_u, shift, mp;
+    bool found;
+};
+__device__ __forceinline__ ShardScalars shard_scalars(const double* __restrict__ st) {
+    ShardScalars s;
+    const double beta0 = st[BIS_BETA0], beta = st[BIS_BMIN], N = st[BIS_N];
+    s.found = st[BIS_DONE] != 0.0 && st[BIS_TRIP_OK] != 0.0 && st[BIS_NAN] == 0.0 && beta > beta0;
+    s.c1 = beta0 - beta, s.c2 = beta - beta0;
+    s.m = st[BIS_TRIP_M];
+    const double S1 = st[BIS_TRIP_S1];
+    s.mean_u = S1 / N;
+    s.shift = (s.m + log(S1)) - st[BIS_LOGN];
+    s.mp = s.m + s.shift;
+    return s;
+}
+
+__global__ __launch_bounds__(ASMC_BLOCK) void k_weights_m2_lse_shard(int64_t n, const double* __restrict__ ll,
+                                                                    const double* __restrict__ lp,
+                                                                    const double* __restrict__ lq,
+                                                                    const double* __restrict__ st,
+                                                                    double* partials, unsigned int* ticket,
+                                                                    double* __restrict__ out) {
+    const ShardScalars s = shard_scalars(st);
+    double acc = 0.0, s1p = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    if (s.found)
+        for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) {
+            const double lw = lw_of(ll[i], lp[i], lq[i], s.c1, s.c2);
+            const double dlt = exp(lw - s.m) - s.mean_u;
+            acc += dlt * dlt;
+            s1p += exp((lw + s.shift) - s.mp);
+        }
+    __shared__ double s_p[ASMC_BLOCK / 64][2];
+    acc = wave_sum(acc);
+    s1p = wave_sum(s1p);
+    if ((threadIdx.x & 63) == 0) {
+        s_p[threadIdx.x >> 6][0] = acc;
+        s_p[threadIdx.x >> 6][1] = s1p;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double v = s_p[0][threadIdx.x];
+        for (int w = 1; w < ASMC_BLOCK / 64; w++) v += s_p[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * 2 + threadIdx.x] = v;
+    }
+    // k_finalize_columns by the block that arrives last (k_bis_sums' hand-off; the counter resets itself for the next call)
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1u);
+        if (s_last) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 128) return;
+    {
+        const int col = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        double v = 0.0;
+        for (int b = lane; b < (int)gridDim.x; b += 64) v += __builtin_nontemporal_load(partials + (size_t)b * 2 + col);
+        v = wave_sum(v);
+        if (lane == 0) out[col] = v;
+    }
+}
+
+// w = exp((lw + shift) - lse) with lse = mp + log(S1'), S1' = the ranks' second sums added in rank order (parts[world][2], the
+// all-gathered outputs of the pass above); carry_out[0] = this rank's approximate incoming cdf sum (the lower ranks' share).
+// A search that has not converged (or NaN weights, or an empty sum) leaves uniform weights and the uniform carry: everything
+// enqueued behind stays well defined, the host discards it when it reads the state.
+__global__ __launch_bounds__(ASMC_BLOCK) void k_weights_map_shard(int64_t n, const double* __restrict__ ll,
+                                                                 const double* __restrict__ lp,
+                                                                 const double* __restrict__ lq,
+                                                                 const double* __restrict__ st,
+                                                                 const double* __restrict__ parts, int world, int rank,
+                                                                 double carry_uniform, double* __restrict__ out,
+                                                                 double* __restrict__ carry_out,
+                                                                 double* __restrict__ tile_sums,
+                                                                 double* __restrict__ st_copy) {
+    const ShardScalars s = shard_scalars(st);
+    double s1p = parts[1], below = 0.0;
+    for (int r = 1; r < world; r++) {
+        if (r == rank) below = s1p;
+        s1p += parts[2 * r + 1];
+    }
+    const bool found = s.found && s1p > 0.0 && s1p < INFINITY;
+    const double lse = s.mp + log(s1p);
+    const double w_uniform = 1.0 / st[BIS_N];
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) carry_out[0] = found ? below / s1p : carry_uniform;
+        if (st_copy && threadIdx.x < 40) st_copy[threadIdx.x] = st[threadIdx.x];  // the search state, next to parts / info
+    }
+    // one block per scan tile (ASMC_SCAN_TILE particles): the tile's weight sum - the cdf's approximate prefix hints, any
+    // order will do - leaves with the weights
+    const int64_t base = (int64_t)blockIdx.x * ASMC_SCAN_TILE;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < ASMC_SCAN_TILE / ASMC_BLOCK; k++) {
+        const int64_t i = base + k * ASMC_BLOCK + threadIdx.x;
+        if (i < n) {
+            const double lw = lw_of(ll[i], lp[i], lq[i], s.c1, s.c2) + s.shift;
+            const double wv = found ? exp(lw - lse) : w_uniform;
+            out[i] = wv;
+            acc += wv;
+        }
+    }
+    __shared__ double s_t[ASMC_BLOCK / 64];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_t[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v = s_t[0];
+        for (int w = 1; w < ASMC_BLOCK / 64; w++) v += s_t[w];
+        tile_sums[blockIdx.x] = v;
+    }
+}
+
 __global__ __launch_bounds__(ASMC_BLOCK) void k_count_nonfinite(int64_t n, const double* __restrict__ v,
                                                                unsigned long long* __restrict__ counters) {
     long long n_nan = 0, n_inf = 0;
@@ -1396,6 +1523,63 @@ int asmc_weights_m2_lse_dev(asmc_ctx* ctx, int64_t n, const double* ll, const do
     ASMC_LAUNCH(ctx, st, "k_finalize_columns", k_finalize_columns, dim3(2), dim3(64), 0, st, grid, 2, ctx->d_partials,
                 out_dev, 1, 0, (const unsigned long long*)nullptr, (const unsigned long long*)nullptr);
     ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+// Sharded importance step with device-resident scalars (include/asmc.h): the search state of asmc_find_beta_shard_decide
+// stays where it is, these passes read it there.
+int asmc_weights_m2_lse_shard(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double* out_dev,
+                              asmc_stream stream) {
+    int rc = check_common(ctx, n, ll, lp, lq);
+    if (rc) return rc;
+    ASMC_REQUIRE(out_dev != nullptr, "null device pointer");
+    hipStream_t st = as_stream(stream);
+    double* d_st;
+    unsigned int* d_ticket;
+    bis_state(ctx, &d_st, &d_ticket);
+    const int grid = reduce_grid(ctx, n, 1);
+    ASMC_LAUNCH(ctx, st, "k_weights_m2_lse_shard", k_weights_m2_lse_shard, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq,
+                (const double*)d_st, ctx->d_partials, ctx->d_bar + SHARD_TICKET_CELL, out_dev);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+int asmc_normalized_weights_shard(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq,
+                                  const double* parts_dev, int world, int rank, double carry_uniform, double* w_out,
+                                  double* carry_out_dev, double* tile_sums_dev, double* state_copy_dev, asmc_stream stream) {
+    int rc = check_common(ctx, n, ll, lp, lq);
+    if (rc) return rc;
+    ASMC_REQUIRE(parts_dev && w_out && carry_out_dev && tile_sums_dev, "null pointer");
+    ASMC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank / world");
+    ASMC_REQUIRE(carry_uniform >= 0.0 && carry_uniform < 1.0, "bad uniform carry");
+    hipStream_t st = as_stream(stream);
+    double* d_st;
+    unsigned int* d_ticket;
+    bis_state(ctx, &d_st, &d_ticket);
+    const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
+    ASMC_LAUNCH(ctx, st, "k_weights_map_shard", k_weights_map_shard, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq,
+                (const double*)d_st, parts_dev, world, rank, carry_uniform, w_out, carry_out_dev, tile_sums_dev, state_copy_dev);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+// The one synchronisation of the sharded importance step: res_dev = {search state [40] (asmc_normalized_weights_shard's
+// state_copy_dev), the ranks' (m2, S1') pairs [2 world], their (kept, fail) int64 pairs [2 world]}, one contiguous buffer ->
+// out_host[13 + 4 world] (asmc_find_beta_shard_result's 13 values, the pairs, the int64 pairs as doubles).
+int asmc_shard_step_result(asmc_ctx* ctx, const double* res_dev, int world, double* out_host, asmc_stream stream) {
+    ASMC_REQUIRE(ctx && res_dev && out_host, "null pointer");
+    ASMC_REQUIRE(world >= 1 && world <= 64, "world out of range");
+    hipStream_t st = as_stream(stream);
+    double* h = ctx->h_pinned + 4096 + 512;
+    ASMC_HIP(hipMemcpyAsync(h, res_dev, sizeof(double) * (40 + 4 * world), hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipStreamSynchronize(st));
+    out_host[0] = h[0], out_host[1] = h[1], out_host[2] = h[2], out_host[3] = h[6], out_host[4] = h[9];
+    out_host[5] = h[15];
+    out_host[6] = h[11], out_host[7] = h[12], out_host[8] = h[13], out_host[9] = h[14];
+    out_host[10] = h[10], out_host[11] = h[32], out_host[12] = h[33];
+    for (int i = 0; i < 2 * world; i++) out_host[13 + i] = h[40 + i];
+    const int64_t* hi = reinterpret_cast<const int64_t*>(h + 40 + 2 * world);
+    for (int i = 0; i < 2 * world; i++) out_host[13 + 2 * world + i] = (double)hi[i];
     return ASMC_OK;
 }
 

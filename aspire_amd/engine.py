@@ -341,6 +341,51 @@ class HipEngine:
         check(self.lib.asmc_weights_m2_lse_dev(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0, beta, m,
                                                mean_u, shift, mp, _dptr(out), self._stream), "asmc_weights_m2_lse_dev")
 
+    # sharded importance step with the scalars left on the device (include/asmc.h asmc_weights_m2_lse_shard ...)
+    def weights_m2_lse_shard(self, ll, lp, lq, out: torch.Tensor):
+        """`weights_m2_lse_dev` at the beta the sharded search has just left on the device (no host value involved)."""
+        self._chk3(ll, lp, lq)
+        assert out.dtype == torch.float64 and out.numel() >= 2
+        check(self.lib.asmc_weights_m2_lse_shard(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), _dptr(out), self._stream),
+              "asmc_weights_m2_lse_shard")
+
+    def normalized_weights_shard(self, ll, lp, lq, parts: torch.Tensor, world: int, rank: int, carry_uniform: float,
+                                 state_copy: torch.Tensor | None = None):
+        """(w, carry, tile_sums): the normalised weights from the all-gathered (m2, S1') pairs, this rank's approximate
+        incoming cdf sum (a one-element device tensor) and the weights' sums per scan tile, both for `cdf_shard_records`.
+        `state_copy` (40 doubles): receives the search state, for `shard_step_result`'s single read-back."""
+        self._chk3(ll, lp, lq)
+        assert parts.dtype == torch.float64 and parts.numel() == 2 * world and parts.is_contiguous()
+        assert state_copy is None or (state_copy.dtype == torch.float64 and state_copy.numel() >= 40 and state_copy.is_contiguous())
+        w, carry = torch.empty_like(ll), self.empty(1)
+        tile_sums = self.empty(int(self.lib.asmc_cdf_shard_tiles(ll.numel())))
+        check(self.lib.asmc_normalized_weights_shard(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), _dptr(parts), world,
+                                                     rank, float(carry_uniform), _dptr(w), _dptr(carry), _dptr(tile_sums),
+                                                     _dptr(state_copy), self._stream), "asmc_normalized_weights_shard")
+        return w, carry, tile_sums
+
+    def shard_step_result(self, res: torch.Tensor, world: int):
+        """The sharded step's one synchronisation; res = {state copy [40], parts [2 world], info [2 world] int64 bits} in one
+        device buffer.  Returns (`find_beta_shard_result` tuple, parts[world, 2], info[world, 2] int64)."""
+        assert res.dtype == torch.float64 and res.numel() == 40 + 4 * world and res.is_contiguous()
+        out = np.zeros(13 + 4 * world)
+        check(self.lib.asmc_shard_step_result(self._ctx, _dptr(res), world, _f64p(out), self._stream), "asmc_shard_step_result")
+        trip = (float(out[6]), float(out[7]), float(out[8])) if out[9] != 0.0 else None
+        search = (float(out[0]), float(out[4]), bool(out[2]), int(out[3]), int(out[5]), trip, tuple(map(float, out[10:13])))
+        return search, out[13:13 + 2 * world].reshape(world, 2).copy(), out[13 + 2 * world:].reshape(world, 2).astype(np.int64)
+
+    def cdf_shard_finish_select(self, w, cdf, recs_all, tile0: int, work, state, u: torch.Tensor):
+        """`cdf_shard_finish` + `select_range_dev` in three launches: (edges {fail, total, lo, hi}, buffer with the kept draws
+        in front, int64 device tensor {kept, fail}).  No synchronisation."""
+        assert u.dtype == torch.float64 and u.is_contiguous()
+        edges, out = self.empty(4), torch.empty_like(u)
+        info = torch.empty(2, dtype=torch.int64, device=self.device)
+        check(self.lib.asmc_cdf_shard_finish_select(self._ctx, w.numel(), _dptr(w), _dptr(cdf), _dptr(recs_all),
+                                                    int(recs_all.shape[0]), int(tile0), _dptr(work), _dptr(state), u.numel(),
+                                                    _dptr(u), _dptr(edges), _dptr(out), _dptr(info), self._stream),
+              "asmc_cdf_shard_finish_select")
+        return edges, out, info
+
     def cdf_total_dev(self, out: torch.Tensor):
         """Total of the last `cdf` call -> out[0] (device to device)."""
         check(self.lib.asmc_cdf_total_dev(self._ctx, _dptr(out), self._stream), "asmc_cdf_total_dev")
@@ -412,13 +457,21 @@ class HipEngine:
         return out, (total.value if want_total else None)
 
     # ---- sharded exact cdf: this rank's slice of the GLOBAL sequential cumsum (include/asmc.h asmc_cdf_shard_*) ------
-    def cdf_shard_records(self, w: torch.Tensor, approx_carry: float, first_rank: bool):
+    def cdf_shard_records(self, w: torch.Tensor, approx_carry, first_rank: bool, tile_sums: torch.Tensor | None = None):
         """(cdf buffer, tile records [n_tiles, ASMC_CDF_REC] int64): the passes that need only an approximate
-        incoming sum.  No synchronisation."""
+        incoming sum - a float, or a one-element device tensor when it is itself a result still on the stream
+        (`normalized_weights_shard`).  No synchronisation."""
         assert w.dtype == torch.float64 and w.is_contiguous()
         n_tiles = int(self.lib.asmc_cdf_shard_tiles(w.numel()))
         cdf = torch.empty_like(w)
         rec = torch.empty((n_tiles, _lib.ASMC_CDF_REC), dtype=torch.int64, device=self.device)
+        if isinstance(approx_carry, torch.Tensor):
+            assert approx_carry.dtype == torch.float64 and approx_carry.numel() >= 1 and approx_carry.is_cuda
+            assert tile_sums is None or (tile_sums.dtype == torch.float64 and tile_sums.numel() == n_tiles)
+            check(self.lib.asmc_cdf_shard_records_dev(self._ctx, w.numel(), _dptr(w), _dptr(cdf), _dptr(approx_carry),
+                                                      _dptr(tile_sums), int(first_rank), _dptr(rec), self._stream),
+                  "asmc_cdf_shard_records_dev")
+            return cdf, rec
         check(self.lib.asmc_cdf_shard_records(self._ctx, w.numel(), _dptr(w), _dptr(cdf), float(approx_carry), int(first_rank),
                                               _dptr(rec), self._stream), "asmc_cdf_shard_records")
         return cdf, rec
@@ -432,7 +485,7 @@ class HipEngine:
         n_total = int(recs_all.shape[0])
         if work is None:
             work = self.empty(3 * n_total)
-        state = torch.zeros(_lib.ASMC_CDF_STATE, dtype=torch.float64, device=self.device)
+        state = torch.empty(_lib.ASMC_CDF_STATE, dtype=torch.float64, device=self.device)  # (round 1 zeroes it itself)
         if states_all is not None:
             assert states_all.dtype == torch.float64 and states_all.is_contiguous() and states_all.numel() == world * _lib.ASMC_CDF_STATE
         check(self.lib.asmc_cdf_shard_chain(self._ctx, w.numel(), _dptr(w), _dptr(cdf), _dptr(recs_all), n_total, int(tile0),
@@ -793,14 +846,19 @@ class HipEngine:
             self._rccl_set = direct
         return True
 
-    def all_gather(self, comm, t: torch.Tensor) -> torch.Tensor:
+    def all_gather(self, comm, t: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         """`comm.all_gather_tensor(t)` for the small fp64 / int64 exchanges of the sharded hot path: through the library's own
-        communicator on its own stream when there is one (`use_rccl`), else through torch.distributed."""
+        communicator on its own stream when there is one (`use_rccl`), else through torch.distributed.  `out`: a contiguous
+        buffer of world * t.numel() elements of t's dtype to gather into (a slice of a larger result buffer)."""
+        assert out is None or (out.dtype == t.dtype and out.numel() == comm.world * t.numel() and out.is_contiguous())
         if t.dtype in (torch.float64, torch.int64) and t.is_contiguous() and t.is_cuda and self.use_rccl(comm):
-            out = torch.empty((comm.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            if out is None:
+                out = torch.empty((comm.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             check(self.lib.asmc_rccl_all_gather(self._ctx, _dptr(t), _dptr(out), t.numel(), int(t.dtype == torch.int64),
                                                 self._stream), "asmc_rccl_all_gather")
             return out
+        if out is not None:
+            return comm.all_gather_into(out, t.contiguous())
         return comm.all_gather_tensor(t)
 
     def set_count_hook(self, comm, n_global: int | None):

@@ -94,8 +94,9 @@ class SMCSampler(MCMCSampler):
         if os.environ.get("ASMC_IS_AHEAD", "1") == "0":  # escape hatch / A-B switch
             return False
         return (self.fused_importance_step and getattr(self, "adaptive", False) and self.device_bisection and beta < 1.0
-                and not getattr(self, "_last_iteration", False) and not self.comm.sharded and hasattr(self.engine, "pcn_mutate_flow_enqueue")
-                and hasattr(self.engine, "importance_step") and not getattr(self.engine, "importance_step_disabled", False)
+                and not getattr(self, "_last_iteration", False) and hasattr(self.engine, "pcn_mutate_flow_enqueue")
+                and ((self.shard_layout == "owner" and smc_math.shard_step_available(self.engine, self.comm)) if self.comm.sharded
+                     else (hasattr(self.engine, "importance_step") and not getattr(self.engine, "importance_step_disabled", False)))
                 and getattr(self, "_beta_tolerance", None) is not None)
 
     def _speculated_moments_n(self, samples) -> int | None:
@@ -271,7 +272,8 @@ class SMCSampler(MCMCSampler):
                     samples.speculate_importance_step(self.current_target_efficiency(beta), beta_tolerance, self.rng,
                                                       resample_mode=self.resample_mode,
                                                       resample_method=self.resample_method,
-                                                      moments_n=self._speculated_moments_n(samples))
+                                                      moments_n=self._speculated_moments_n(samples),
+                                                      shard_layout=self.shard_layout)
                 beta, min_beta_step = self.determine_beta(samples, beta, beta_step, min_beta_step,
                                                           max_beta_step=self.max_beta_step,
                                                           beta_tolerance=beta_tolerance)
@@ -429,10 +431,11 @@ class HipSMC(SMCSampler):
     # ---- reference Gaussian of the pCN proposal ----------------------------------------------
     def _speculated_moments_n(self, samples) -> int | None:
         """The population size when the coming mutation fits its reference Gaussian to the moments of the whole resampled
-        population in x space (`pcn` steps, identity preconditioning, one rank): the fused importance step then computes
-        them right behind its gather.  None otherwise."""
+        population in x space (`pcn` steps, identity preconditioning): the fused importance step (one rank) or the sharded
+        step's finish then computes them right behind its gather.  None otherwise."""
         T = self.preconditioning_transform
-        if (self.comm.sharded or self.sampler_kwargs.get("step_fn", "tpcn") != "pcn"
+        if ((self.comm.sharded and not (self.shard_layout == "owner" and smc_math.shard_step_available(self.engine, self.comm)))
+                or self.sampler_kwargs.get("step_fn", "tpcn") != "pcn"
                 or not (isinstance(T, IdentityTransform) or getattr(T, "is_identity", False))):
             return None
         return int(self._n_global(samples))
@@ -821,7 +824,8 @@ class HipSMC(SMCSampler):
                     out = self._wrap(x, ll, lp, lq, beta, like=particles)
                     ok = out.speculate_importance_step(self.current_target_efficiency(beta), self._beta_tolerance, self.rng,
                                                        resample_mode=self.resample_mode, resample_method=self.resample_method,
-                                                       moments_n=self._speculated_moments_n(out), defer=True)
+                                                       moments_n=self._speculated_moments_n(out), defer=True,
+                                                       shard_layout=self.shard_layout)
                     n_acc, rho_hist, rho = e.pcn_mutate_flow_result(handle)  # waits for the mutation only
                     if ok:
                         st["prewrapped"] = out  # the step's results are collected when the next iteration asks for them

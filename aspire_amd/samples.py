@@ -415,7 +415,7 @@ class SMCSamples(BaseSamples):
 
     def speculate_importance_step(self, target_eff: float, tol: float, rng, *, resample_mode: str = "exact",
                                   resample_method: str = "multinomial", moments_n: int | None = None,
-                                  defer: bool = False) -> bool:
+                                  defer: bool = False, shard_layout: str = "owner") -> bool:
         """Enqueue the whole importance step of one iteration - adaptive-beta search (smc/base.py:167-186), evidence
         moments (samples.py:1226-1242) and the multinomial resampling of all N particles at beta* (samples.py:1251-1287)
         - as one chain of launches with a single host synchronisation (include/asmc.h asmc_importance_step), and park
@@ -426,13 +426,31 @@ class SMCSamples(BaseSamples):
         moments_n; `engine.mean_gram`) behind the gather, so that the mutation's reference fit costs no pass and no
         synchronisation of its own; they travel with the resampled population (`_moments`).
         `defer`: enqueue only; the caller has more to wait for on the stream and calls `finish_speculation()` itself.
-        Returns False when the step does not apply (sharded run, non-PCG64 generator, other resampling schemes)."""
+        Sharded populations (owner layout): the chain runs up to the ranks' offspring counts (`smc_math.shard_step_enqueue`:
+        search, moments, weights, global cdf slice, draw selection, with the collectives on the stream between them);
+        `finish_speculation` synchronises once and puts the search and the gather behind it.
+        Returns False when the step does not apply (non-PCG64 generator, other resampling schemes, slot layout, engines
+        without these entry points)."""
         self.__dict__.pop("_spec", None)
         self.__dict__.pop("_spec_pending", None)
         e, comm = self._eng(), self._comm()
         st4 = smc_math.pcg64_state(rng)
-        if (comm.sharded or not hasattr(e, "importance_step") or st4 is None or resample_mode != "exact"
-                or resample_method != "multinomial" or not float(self.beta) < 1.0):
+        if st4 is None or resample_mode != "exact" or resample_method != "multinomial" or not float(self.beta) < 1.0:
+            return False
+        if comm.sharded:
+            if shard_layout != "owner" or not smc_math.shard_step_available(e, comm):
+                return False
+            ll, lp, lq = self._dev3()
+            x = e.asarray(self.x, dtype=self.x.dtype if is_torch(self.x) else torch.float64)
+            n = self._n_global()
+            h = smc_math.shard_step_enqueue(e, comm, ll, lp, lq, float(self.beta), float(target_eff), float(tol), n,
+                                            self.shard_counts_list(), st4, n)
+            self._spec_pending = dict(key=(float(target_eff), float(tol)), shard=h, src=(x, ll, lp, lq), rng=rng,
+                                      state=[int(v) for v in st4], n=n, moments_n=int(moments_n) if moments_n else None)
+            if not defer:
+                self.finish_speculation()
+            return True
+        if not hasattr(e, "importance_step"):
             return False
         ll, lp, lq = self._dev3()
         x = e.asarray(self.x, dtype=self.x.dtype if is_torch(self.x) else torch.float64)
@@ -457,6 +475,18 @@ class SMCSamples(BaseSamples):
         if p is None:
             return
         e = self._eng()
+        if "shard" in p:
+            comm = self._comm()
+            search, ok, m2, _, new_counts, u_kept = smc_math.shard_step_finish(e, comm, p["shard"])
+            rows, moments = None, None
+            if ok:  # this rank's sub-sequence of Generator.choice's index vector, then its rows (samples.py:1278-1287)
+                rows = e.gather(e.search(p["shard"]["cdf"], u_kept), *p["src"])
+                if (p["moments_n"] is not None and hasattr(e, "mean_gram_enqueue")
+                        and e.mean_gram_enqueue(rows[0], p["moments_n"], comm, gathered=True)):
+                    moments = (rows[0].data_ptr(), tuple(rows[0].shape), p["moments_n"], e._gram_gen)
+            self._spec = dict(key=p["key"], search=search, found=bool(ok), beta=float(search[0]), rows=rows, m2=m2, rng=p["rng"],
+                              state=p["state"], n=p["n"], moments=moments, counts=new_counts)
+            return
         b, eff1, conv, passes, n_nan, trip, trip_one, m2, _, found = e.importance_result()
         moments, rows = None, p["rows"]
         if p["moments_n"] is not None:  # still on the stream: fetched by the reference fit (HipSMC._fit_reference_gaussian)
@@ -556,7 +586,7 @@ class SMCSamples(BaseSamples):
             var_u = spec["m2"] / st.n
             var = float(var_u / (st.n * (mean_u**2))) if mean_u != 0 else float("nan")
             rng.bit_generator.advance(int(n_samples))  # the n draws Generator.choice takes
-            res = wrap(*spec["rows"], counts=counts)
+            res = wrap(*spec["rows"], counts=spec.get("counts") or counts)
             if spec.get("moments") is not None:
                 (res[0] if want_variance else res).__dict__["_moments"] = spec["moments"]
             return res

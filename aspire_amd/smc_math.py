@@ -8,6 +8,7 @@ beta schedule and evidence match it.  File:line citations are relative to the re
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 from typing import NamedTuple
@@ -407,16 +408,13 @@ def global_cdf_slice_replicated(engine, comm, w, counts, mode: str = "exact"):
     return cdf_all[a:b], edges
 
 
-def global_cdf_slice(engine, comm, w, counts, approx_carry: float, mode: str = "exact", force_replicated: bool = False):
-    """This rank's slice of numpy's sequential cumsum over the GLOBAL weight vector, divided by the global total
-    (samples.py:1277-1278 -> Generator.choice), bit for bit, plus the slice's edges {fail, total, lo, hi} on the device.
-    Exact mode: every rank turns its shard into per-tile records from an approximate incoming sum, the records are
-    all-gathered (72 B per 2048 particles) and every rank walks the same verifying chain over all of them, in two
-    rounds with one all-gather of the ranks' chain states in between (include/asmc.h asmc_cdf_shard_*): no rank waits
-    for another rank's scan.  edges[0] != 0: the chain could not be closed - the caller repeats with the replicated scan."""
-    if force_replicated or mode != "exact" or not hasattr(engine, "cdf_shard_records"):
-        return global_cdf_slice_replicated(engine, comm, w, counts, mode)
-    cdf, rec = engine.cdf_shard_records(w, approx_carry, comm.rank == 0)
+def _global_cdf_chain(engine, comm, w, counts, approx_carry, tile_sums=None):
+    """The enqueue-only part of `global_cdf_slice` up to the second chain round: (cdf buffer, all ranks' tile records, this
+    rank's first global tile, chain scratch, final chain state)."""
+    if tile_sums is not None:
+        cdf, rec = engine.cdf_shard_records(w, approx_carry, comm.rank == 0, tile_sums)
+    else:
+        cdf, rec = engine.cdf_shard_records(w, approx_carry, comm.rank == 0)
     tiles = [-(-int(c) // 2048) for c in counts]
     recs_all = comm.all_gather_ragged(rec, tiles).contiguous()
     tile0 = int(sum(tiles[:comm.rank]))
@@ -426,6 +424,19 @@ def global_cdf_slice(engine, comm, w, counts, approx_carry: float, mode: str = "
     states = (engine.all_gather(comm, state) if hasattr(engine, "all_gather") else comm.all_gather_tensor(state)).contiguous()
     # round 2: resume through the published sums
     work, state = engine.cdf_shard_chain(w, cdf, recs_all, tile0, work, states, comm.world, comm.rank)
+    return cdf, recs_all, tile0, work, state
+
+
+def global_cdf_slice(engine, comm, w, counts, approx_carry: float, mode: str = "exact", force_replicated: bool = False):
+    """This rank's slice of numpy's sequential cumsum over the GLOBAL weight vector, divided by the global total
+    (samples.py:1277-1278 -> Generator.choice), bit for bit, plus the slice's edges {fail, total, lo, hi} on the device.
+    Exact mode: every rank turns its shard into per-tile records from an approximate incoming sum, the records are
+    all-gathered (72 B per 2048 particles) and every rank walks the same verifying chain over all of them, in two
+    rounds with one all-gather of the ranks' chain states in between (include/asmc.h asmc_cdf_shard_*): no rank waits
+    for another rank's scan.  edges[0] != 0: the chain could not be closed - the caller repeats with the replicated scan."""
+    if force_replicated or mode != "exact" or not hasattr(engine, "cdf_shard_records"):
+        return global_cdf_slice_replicated(engine, comm, w, counts, mode)
+    cdf, recs_all, tile0, work, state = _global_cdf_chain(engine, comm, w, counts, approx_carry)
     edges = engine.cdf_shard_finish(w, cdf, recs_all, tile0, work, state)
     return cdf, edges
 
@@ -502,6 +513,74 @@ def resample_owner(engine, comm, ll, lp, lq, beta0: float, beta: float, n_out: i
     if min(new_counts) == 0:  # decided from the gathered counts: every rank raises, nobody is left waiting in a collective
         raise RuntimeError(f"owner-layout resampling left rank {new_counts.index(0)} without offspring")
     return engine.search(cdf, u_kept), var, s1p, new_counts
+
+
+def shard_step_available(engine, comm) -> bool:
+    """The sharded importance step can run as one chain of launches (`shard_step_enqueue`): the engine has the passes that
+    take their scalars from the device, and ASMC_SHARD_STEP=0 has not switched it off (A-B switch / escape hatch)."""
+    return (comm.sharded and all(hasattr(engine, k) for k in ("weights_m2_lse_shard", "normalized_weights_shard", "all_gather",
+                                                              "shard_step_result", "find_beta_shard_rounds",
+                                                              "cdf_shard_finish_select"))
+            and os.environ.get("ASMC_SHARD_STEP", "1") != "0")
+
+
+def shard_step_enqueue(engine, comm, ll, lp, lq, beta0: float, target_eff: float, tol: float, n_global: int, counts,
+                       state4, n_out: int):
+    """The importance step of a SHARDED population up to the ranks' offspring counts - adaptive-beta search
+    (smc/base.py:167-186), evidence-variance and second log-sum-exp partials (samples.py:1230-1242, :1277), normalised weights,
+    this rank's slice of the global sequential cdf, the draws of Generator.choice that fall into it (samples.py:1278) - as ONE
+    chain of launches and collectives with no host decision in between: what `find_beta_sharded` and `resample_owner` read
+    back between their phases (beta*, the weight sums, the shares) stays on the device and parameterises the next launch
+    (include/asmc.h asmc_weights_m2_lse_shard).  Nothing here synchronises; `shard_step_finish` does, once.
+    `state4`: the PCG64 state words of the generator every rank holds in the same state (`sync_rng`).  Returns the handle for
+    `shard_step_finish`."""
+    world, rank, n_local = comm.world, comm.rank, ll.numel()
+    counts = [int(c) for c in counts]
+    assert counts[rank] == n_local and sum(counts) == int(n_global), (counts, rank, n_local, n_global)
+    import torch
+
+    # search: the rounds `find_beta_sharded` enqueues before it looks (plain rounds narrow the bracket 16x each)
+    rounds = min(3, max(1, int(math.ceil(math.log2((1.0 - beta0) / tol) / BISECT_LEVELS - 1e-9))))
+    bufs = engine.__dict__.setdefault("_bis_bufs", {})
+    if bufs.get("world") != world:
+        bufs.update(world=world, rec=engine.empty(40), recs=engine.empty(40 * world))
+    engine.find_beta_shard_rounds(comm, ll, lp, lq, beta0, target_eff, tol, n_global, bufs["rec"], bufs["recs"], 0, rounds)
+    # evidence moments + second log-sum-exp at the beta the last decide step left on the device; the gathered pairs, the
+    # search state and (below) the ranks' offspring counts share ONE buffer: the step's single read-back
+    res = engine.empty(40 + 4 * world)
+    part = engine.empty(2)
+    engine.weights_m2_lse_shard(ll, lp, lq, part)
+    parts = engine.all_gather(comm, part, out=res[40:40 + 2 * world])
+    w, carry, tile_sums = engine.normalized_weights_shard(ll, lp, lq, parts, world, rank, float(sum(counts[:rank])) / float(n_global),
+                                                          state_copy=res[:40])
+    u_all = engine.uniforms_pcg64(state4, 0, int(n_out))  # every rank walks ALL n_out draws
+    cdf, recs_all, tile0, work, state = _global_cdf_chain(engine, comm, w, counts, carry, tile_sums)
+    edges, buf, info_dev = engine.cdf_shard_finish_select(w, cdf, recs_all, tile0, work, state, u_all)
+    engine.all_gather(comm, info_dev, out=res[40 + 2 * world:].view(torch.int64))
+    return dict(res=res, cdf=cdf, buf=buf, rounds=rounds, world=world, rank=rank, n_out=int(n_out), n_global=int(n_global),
+                keep=(w, u_all, edges, recs_all, work, state, tile_sums, carry, part, info_dev))
+
+
+def shard_step_finish(engine, comm, h):
+    """Wait for `shard_step_enqueue`'s chain and take the decisions `find_beta_sharded` / `resample_owner` take, from the same
+    numbers in the same order (every rank reads the same gathered values, so every rank decides alike).  Returns
+    (search tuple, ok, m2, s1p, new_counts, u_kept): `ok` False - search not converged in the rounds enqueued, NaN weights,
+    a weight share outside 1/world (1 +- SHARD_IMBALANCE), a cdf chain that needs the replicated scan, a rank left without
+    offspring - means the caller runs the step phase by phase (which handles or reports each of these); the generator has not
+    been touched."""
+    world, rank = h["world"], h["rank"]
+    search, parts, info = engine.shard_step_result(h["res"], world)
+    _, _, converged, _, n_nan, trip, _ = search
+    if not converged or n_nan > 0 or trip is None:
+        return search, False, None, None, None, None
+    m2, s1p = float(parts[0, 0]), float(parts[0, 1])
+    for r in range(1, world):  # rank order: the same floats on every rank
+        m2, s1p = m2 + float(parts[r, 0]), s1p + float(parts[r, 1])
+    share = parts[:, 1] / s1p if s1p > 0 else np.full(world, np.nan)
+    ok = bool(np.all(share * world <= 1.0 + SHARD_IMBALANCE) and np.all(share * world >= 1.0 - SHARD_IMBALANCE))
+    new_counts = [int(c) for c in info[:, 0]]
+    ok = ok and not info[:, 1].any() and sum(new_counts) == h["n_out"] and min(new_counts) > 0
+    return search, ok, m2, s1p, new_counts, (h["buf"][: new_counts[rank]] if ok else None)
 
 
 def sync_rng(comm, rng):

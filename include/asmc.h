@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 18
+#define ASMC_ABI_VERSION 19
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -211,6 +211,41 @@ int asmc_weights_m2_lse_dev(asmc_ctx* ctx, int64_t n, const double* ll_dev, cons
                             const double* lq_dev, double beta0, double beta, double m, double mean_u,
                             double shift, double mp, double* out_dev, asmc_stream stream);
 
+/* The sharded importance step without a host decision between its collectives (one process per GPU; the reference has no
+ * distributed mode, SURVEY.md §8e - the contract is samples.py:1221-1287 on the GLOBAL population).  The search state that
+ * asmc_find_beta_shard_decide leaves on the device (beta*, the (m, S1, S2) triple at beta*, N, log N; identical on every
+ * rank) parameterises the passes behind it:
+ *   asmc_weights_m2_lse_shard      asmc_weights_m2_lse_dev with beta, m, mean_u = S1/N, shift = (m + log S1) - log N and
+ *                                  mp = m + shift formed on the device in that order -> out_dev[2] (one launch: the block
+ *                                  that arrives last adds up the blocks' partials in the two-launch form's order);
+ *   (caller)                       all-gather of the pairs in rank order -> parts_dev[world][2];
+ *   asmc_normalized_weights_shard  S1' = sum of parts[r][1] in rank order, lse = mp + log S1', w = exp((lw + shift) - lse)
+ *                                  -> w_out_dev; carry_out_dev[0] = (sum of the lower ranks' parts[r][1]) / S1', the
+ *                                  approximate incoming sum of asmc_cdf_shard_records_dev; tile_sums_dev
+ *                                  [asmc_cdf_shard_tiles(n)] = the weights' sums per 2048-particle scan tile (the records
+ *                                  pass's prefix hints); state_copy_dev[40] (optional) = the search state, so that it can sit
+ *                                  in one buffer with the gathered pairs for asmc_shard_step_result;
+ *   asmc_cdf_shard_records_dev     asmc_cdf_shard_records with approx_carry read from the device and, when tile_sums_dev is
+ *                                  given, without its own tile-sum and scan launches;
+ *   asmc_cdf_shard_chain x 2       as before (the first round zeroes its own scratch and state);
+ *   asmc_cdf_shard_finish_select   asmc_cdf_shard_finish + asmc_select_range_dev in three launches: the slice's edges
+ *                                  {fail, total, lo, hi} -> edges_out_dev[4], the draws u with lo <= u < hi in index order ->
+ *                                  out_dev, {kept, fail} -> info_dev[2];
+ *   (caller)                       all-gather of the info pairs;
+ *   asmc_shard_step_result         THE synchronisation: res_dev = {state copy [40], parts [2 world], info pairs [2 world]
+ *                                  (int64)} in ONE buffer -> out_host[13 + 4 world] = asmc_find_beta_shard_result's 13
+ *                                  values, parts, then the (kept, fail) pairs as doubles.
+ * Everything in front of asmc_shard_step_result is enqueue-only, so the whole chain can sit behind a mutation's step loop.
+ * A search that did not converge within the rounds enqueued (or met NaN weights) leaves uniform weights 1/N and
+ * carry_uniform behind - every later launch stays well defined - and the host, seeing converged = 0, discards the chain and
+ * continues the search round by round. */
+int asmc_weights_m2_lse_shard(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev, const double* lq_dev,
+                              double* out_dev, asmc_stream stream);
+int asmc_normalized_weights_shard(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev, const double* lq_dev,
+                                  const double* parts_dev, int world, int rank, double carry_uniform, double* w_out_dev,
+                                  double* carry_out_dev, double* tile_sums_dev, double* state_copy_dev, asmc_stream stream);
+int asmc_shard_step_result(asmc_ctx* ctx, const double* res_dev, int world, double* out_host, asmc_stream stream);
+
 /* SMCSamples.log_weights(beta) as an array (samples.py:1244-1249): lw_out = lw(beta) + shift,
  * shift = logsumexp(lw) - log N formed on the host from asmc_weights_stats. */
 int asmc_log_weights(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev,
@@ -275,12 +310,19 @@ int asmc_pcg64_uniforms(asmc_ctx* ctx, const uint64_t state_host[4], uint64_t of
 int64_t asmc_cdf_shard_tiles(int64_t n);
 int asmc_cdf_shard_records(asmc_ctx* ctx, int64_t n, const double* w_dev, double* cdf_dev, double approx_carry,
                            int first_rank, int64_t* rec_dev, asmc_stream stream);
+int asmc_cdf_shard_records_dev(asmc_ctx* ctx, int64_t n, const double* w_dev, double* cdf_dev,
+                               const double* approx_carry_dev, const double* tile_sums_dev, int first_rank, int64_t* rec_dev,
+                               asmc_stream stream);
 int asmc_cdf_shard_chain(asmc_ctx* ctx, int64_t n, const double* w_dev, double* cdf_dev, const int64_t* recs_all_dev,
                          int64_t n_tiles_total, int64_t tile0, double* work_dev, const double* states_all_dev, int world,
                          int rank, double* state_out_dev, asmc_stream stream);
 int asmc_cdf_shard_finish(asmc_ctx* ctx, int64_t n, const double* w_dev, double* cdf_dev, const int64_t* recs_all_dev,
                           int64_t n_tiles_total, int64_t tile0, double* work_dev, const double* state_dev, double* out_dev,
                           asmc_stream stream);
+int asmc_cdf_shard_finish_select(asmc_ctx* ctx, int64_t n, const double* w_dev, double* cdf_dev, const int64_t* recs_all_dev,
+                                 int64_t n_tiles_total, int64_t tile0, double* work_dev, const double* state_dev, int64_t n_u,
+                                 const double* u_dev, double* edges_out_dev, double* out_dev, int64_t* info_dev,
+                                 asmc_stream stream);
 int asmc_select_range(asmc_ctx* ctx, int64_t n, const double* u_dev, const double* lohi_dev, double* out_dev,
                       int64_t* count_host, asmc_stream stream);
 /* the same selection, enqueued only: info_dev[0] = kept count, info_dev[1] = the failure flag edges_dev[0] of the slice

@@ -151,6 +151,31 @@ def _worker(rank, world, port, out_dir, engine_kind="oracle"):
                                       + [fpt.flow.loc.double().reshape(-1), fpt.flow.scale.double().reshape(-1)]).numpy()
         res["fpt_rng_untouched"] = np.array(int(torch.equal(torch.get_rng_state(), probe_before)))
         res["fpt_z_shape"] = np.array(np.asarray(z).shape)
+    if engine_kind == "hip":
+        # the sharded importance step as ONE chain of launches (smc_math.shard_step_enqueue: the scalars between the phases
+        # stay on the device) against the phase-by-phase path above: same beta*, same ancestors, same variance, same generator
+        rng_a, rng_b = np.random.default_rng(5), np.random.default_rng(5)
+        pop_a = SMCSamples(x=loc[0], log_likelihood=loc[1], log_prior=loc[2], log_q=loc[3], beta=0.0, xp=torch, engine=eng, comm=comm)
+        took = pop_a.speculate_importance_step(0.5, 1e-6, rng_a)
+        spec = pop_a.__dict__.get("_spec") or {}
+        res["chain_flags"] = np.array([int(bool(took)), int(bool(spec.get("found"))), int(spec.get("rows") is not None)])
+        b_chain = float(spec.get("beta", -1.0))
+        pop_a.remember_stats(b_chain, smc_math.Stats(*spec["search"][5], n))
+        new_a, var_a = pop_a.resample(b_chain, rng=rng_a, want_variance=True)
+        os.environ["ASMC_SHARD_STEP"] = "0"
+        pop_b = SMCSamples(x=loc[0], log_likelihood=loc[1], log_prior=loc[2], log_q=loc[3], beta=0.0, xp=torch, engine=eng, comm=comm)
+        assert not pop_b.speculate_importance_step(0.5, 1e-6, rng_b)
+        fb = smc_math.find_beta_sharded(eng, comm, loc[1], loc[2], loc[3], 0.0, 0.5, 1e-6, n)
+        b_steps = fb[0]
+        pop_b.remember_stats(b_steps, smc_math.Stats(*fb[5], n))  # (what the sampler's determine_beta keeps of the search)
+        new_b, var_b = pop_b.resample(b_steps, rng=rng_b, want_variance=True)
+        del os.environ["ASMC_SHARD_STEP"]
+        res["chain_beta"] = np.array([b_chain, b_steps])
+        res["chain_var"] = np.array([var_a, var_b])
+        res["chain_x"], res["steps_x"] = eng.to_numpy(new_a.x), eng.to_numpy(new_b.x)
+        res["chain_ll"], res["steps_ll"] = eng.to_numpy(new_a.log_likelihood), eng.to_numpy(new_b.log_likelihood)
+        res["chain_counts"], res["steps_counts"] = np.array(new_a.shard_counts), np.array(new_b.shard_counts)
+        res["chain_rng"] = np.array([rng_a.integers(0, 2**62), rng_b.integers(0, 2**62)])
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()

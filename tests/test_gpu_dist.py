@@ -50,3 +50,18 @@ def test_sharded_sampler_matches_oracle(runs):
         assert float(h["logz"]) == pytest.approx(float(o["logz"]), abs=1e-7)
         assert float(h["own_logz"]) == pytest.approx(float(o["own_logz"]), abs=1e-7)
         assert int(h["own_n"]) == int(o["own_n"])
+
+
+def test_sharded_step_as_one_chain_equals_the_phase_by_phase_path(runs):
+    """smc_math.shard_step_enqueue / shard_step_finish (search -> moments -> weights -> cdf slice -> draw selection with the
+    scalars left on the device, one synchronisation) against find_beta_sharded + resample_owner (a host decision after every
+    phase): bit-identical beta*, evidence variance, ancestors and generator state on both ranks.  Contract:
+    /root/reference/src/aspire/samples.py:1221-1287 on the global population."""
+    for r in range(2):
+        h = runs["hip"][r]
+        assert h["chain_flags"].tolist() == [1, 1, 1]
+        assert h["chain_beta"][0] == h["chain_beta"][1] == float(h["fb"][0])
+        assert h["chain_var"][0] == h["chain_var"][1]
+        assert np.array_equal(h["chain_x"], h["steps_x"]) and np.array_equal(h["chain_ll"], h["steps_ll"])
+        assert h["chain_counts"].tolist() == h["steps_counts"].tolist()
+        assert h["chain_rng"][0] == h["chain_rng"][1]

@@ -47,6 +47,26 @@ def main():
     # single-rank index vector itself, in draw order
     assert np.array_equal(idx_o.cpu().numpy(), idx_s.cpu().numpy())
     assert var_o == var_s
+    # 2b. the same step as ONE chain of launches and RCCL collectives (smc_math.shard_step_enqueue: beta*, the weight sums and
+    #     the shares stay on the device between the phases; one synchronisation): same beta*, same rows, same variance
+    from aspire_amd.samples import SMCSamples
+
+    hc = TorchDistComm(eng.device)
+    hc.force_sharded = True
+    pop = SMCSamples(x=xd, log_likelihood=lld, log_prior=lpd, log_q=lqd, beta=0.0, xp=torch, engine=eng, comm=hc)
+    rng = np.random.default_rng(5)
+    eng.profile(True)
+    assert pop.speculate_importance_step(0.5, 1e-6, rng)
+    rep = eng.profile_report()
+    eng.profile(False)
+    spec = pop._spec
+    assert spec["found"] and spec["beta"] == beta and spec["counts"] == [n], (spec["found"], spec["beta"], beta, spec["counts"])
+    assert "k_weights_m2_lse_shard" in rep and "k_weights_map_shard" in rep, sorted(rep)
+    rows_s = eng.gather(idx_s, xd, lld, lpd, lqd)
+    assert all(torch.equal(a, b) for a, b in zip(spec["rows"], rows_s))
+    mean_u = st.S1 / st.n
+    assert float(spec["m2"] / st.n / (st.n * mean_u**2)) == var_s
+    assert smc_math.pcg64_state(rng).tolist() == smc_math.pcg64_state(np.random.default_rng(5)).tolist()  # untouched until resample()
     # 3. accept-count hook: in-place RCCL all-reduce of the device cell between a step and its adaptation
     tgt = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
     q = eng.make_mixture([-d * np.log(1.5) - 0.5 * d * np.log(2 * np.pi)], np.zeros((1, d)), np.full((1, d), 1 / 2.25))
