@@ -152,7 +152,8 @@ SIGNATURES = {
     "asmc_cdf_shard_records": (_i, [_vp, _i64, _vp, _vp, _d, _i, _vp, _vp]),
     "asmc_cdf_shard_records_dev": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "asmc_cdf_shard_finish_select": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "asmc_weights_m2_lse_shard": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "asmc_weights_m2_lse_shard": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i64, _d, _d, _d, _i, _vp]),
+    "asmc_find_beta_shard_round": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _i, _i64, _i, _vp, _vp, _vp]),
     "asmc_normalized_weights_shard": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "asmc_shard_step_result": (_i, [_vp, _vp, _i, _pd, _vp]),
     "asmc_cdf_shard_chain": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _vp, _vp]),

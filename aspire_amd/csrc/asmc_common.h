@@ -130,6 +130,7 @@ struct asmc_ctx {
     void* rccl_allreduce;  // asmc_pcn_set_count_rccl: the process's ncclAllReduce and a communicator
     void* rccl_comm;
     void* rccl_allgather;  // the process's ncclAllGather (asmc_set_rccl_allgather)
+    double* shard_st;              // the search state the one-chain sharded step's passes read (asmc_weights_m2_lse_shard sets it)
     int64_t n_tiles_max;
     int gram_blocks;
     size_t gram_cap;  // doubles in d_gram (>= gram_blocks * d_max^2; the d = 32 matrix-core Gram kernel uses up to 2048 partials)
@@ -153,7 +154,7 @@ struct asmc_ctx {
 int asmc_ref_factor_launch(asmc_ctx* ctx, int d, const double* sum, const double* gram, double n_mean, double denom, double* out,
                            double* status, double* tab, double* em, int it, hipStream_t st);
 int asmc_gram_mm_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* d_center, int* grid_out,
-                        hipStream_t st);
+                        hipStream_t st, double* out2);
 bool asmc_gram_mm_supported(int d, const void* x);
 int asmc_is_weights_launch(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double beta0,
                            double target_eff, double tol, double* w, double* tiles, double* rec, hipStream_t st);

@@ -176,8 +176,8 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_student, sizeof(double) * student, hipHostMallocDefault);
     dmalloc((void**)&c->d_counts, sizeof(long long) * (size_t)(ASMC_MAX_PCN_STEPS + ASMC_MAX_BLOCKS + n_max / 64 + 8));
     dmalloc((void**)&c->d_rho, sizeof(double) * (ASMC_MAX_PCN_STEPS + 8));
-    dmalloc((void**)&c->d_tilectr, sizeof(unsigned int) * (2 * ASMC_MAX_PCN_STEPS + 2));
-    if (e == hipSuccess) e = hipMemset(c->d_tilectr, 0, sizeof(unsigned int) * (2 * ASMC_MAX_PCN_STEPS + 2));
+    dmalloc((void**)&c->d_tilectr, sizeof(unsigned int) * (2 * ASMC_MAX_PCN_STEPS + 4));
+    if (e == hipSuccess) e = hipMemset(c->d_tilectr, 0, sizeof(unsigned int) * (2 * ASMC_MAX_PCN_STEPS + 4));
     dmalloc((void**)&c->d_bar, sizeof(unsigned int) * 1024 * 17);
     if (e == hipSuccess) e = hipMemset(c->d_bar, 0, sizeof(unsigned int) * 1024 * 17);
     dmalloc((void**)&c->d_pcgtab, sizeof(unsigned long long) * (64 * 4 + 8));

@@ -1399,21 +1399,27 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_gram_rb(int64_t n, int d, const 
 
 // one block per column; 64 threads (one wave: the order every caller has always had) or 256 (the gather's column-sum partials:
 // 4 096 rows - 24 us with one wave): strided partial sums, the wave's butterfly, then the waves in order
+// keep / center (optional): the sum also goes to keep[col] (k_keep_moments' copy) and center[col] = sum / n_mean
+// (k_center_from_sum's division) - the reference fit of one rank then needs neither of those launches
 __global__ __launch_bounds__(256) void k_reduce_columns(int nblocks, int ncols, const double* __restrict__ partials,
-                                                       double* __restrict__ out) {
+                                                       double* __restrict__ out, double* __restrict__ keep = nullptr,
+                                                       double* __restrict__ center = nullptr, double n_mean = 1.0) {
     __shared__ double s_w[4];
     const int nt = (int)blockDim.x;
     for (int col = blockIdx.x; col < ncols; col += gridDim.x) {
         double v = 0.0;
         for (int b = threadIdx.x; b < nblocks; b += nt) v += partials[(size_t)b * ncols + col];
         v = wave_sum(v);
-        if (nt == 64) {
-            if (threadIdx.x == 0) out[col] = v;
-        } else {
+        if (nt != 64) {
             if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
             __syncthreads();
-            if (threadIdx.x == 0) out[col] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+            v = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
             __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            out[col] = v;
+            if (keep) keep[col] = v;
+            if (center) center[col] = v / n_mean;
         }
     }
 }
@@ -1437,7 +1443,8 @@ static int waves_for_lds(size_t per_wave_bytes, size_t* lds_bytes_out) {
 }
 
 // gather the caller's tables into the ctx parameter block (one tiny kernel, stream ordered)
-__global__ __launch_bounds__(256) void k_pcn_pack(PcnDev pd, double* __restrict__ t) {
+__global__ __launch_bounds__(256) void k_pcn_pack(PcnDev pd, double* __restrict__ t, double* __restrict__ rho_cell, double rho) {
+    if (rho_cell && threadIdx.x == 0) *rho_cell = rho;  // (the call's starting step size rides along: no k_set_scalar launch)
     const int D = pd.dpad > pd.d ? pd.dpad : pd.d, dr = pd.d;  // tables of the D-dimensional kernel, identity beyond dr
     const int tri = D * (D + 1) / 2;
     for (int e = threadIdx.x; e < D * D; e += 256) {
@@ -1462,9 +1469,9 @@ __global__ __launch_bounds__(256) void k_pcn_pack(PcnDev pd, double* __restrict_
     }
 }
 
-static int pack_pcn_tables(asmc_ctx* ctx, const PcnDev& pd, hipStream_t st) {
+static int pack_pcn_tables(asmc_ctx* ctx, const PcnDev& pd, hipStream_t st, double* rho_cell = nullptr, double rho = 0.0) {
     ctx->ptab_tag = 0;
-    ASMC_LAUNCH(ctx, st, "k_pcn_pack", k_pcn_pack, dim3(1), dim3(256), 0, st, pd, ctx->d_ptab);
+    ASMC_LAUNCH(ctx, st, "k_pcn_pack", k_pcn_pack, dim3(1), dim3(256), 0, st, pd, ctx->d_ptab, rho_cell, rho);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
@@ -2038,27 +2045,34 @@ int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const v
     else
         ASMC_LAUNCH(ctx, st, "k_colsum<float>", k_colsum<float>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const float*)x, ctx->d_gram);
     ASMC_LAUNCH_CHECK();
-    ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(d), dim3(from_gather ? 256 : 64), 0, st, grid, d, (const double*)ctx->d_gram, ctx->d_small);
-    ASMC_LAUNCH_CHECK();
-    if (across_ranks && allreduce(ctx->d_small, ctx->d_small, (size_t)d, nccl_f64, nccl_sum, ctx->rccl_comm, st) != 0) {
-        asmc_set_error("asmc_mean_gram: ncclAllReduce failed");
-        return ASMC_ERR_ARG;
-    }
     double* d_center = ctx->d_small + 2048;
-    ASMC_LAUNCH(ctx, st, "k_center_from_sum", k_center_from_sum, dim3(1), dim3(128), 0, st, d, (const double*)ctx->d_small, (double)n_mean, d_center);
+    // the results stay on the device (d_small / d_partials are every call's scratch; ctx->d_ref = {sums [128], Gram}):
+    // asmc_reference_factor reads them there, asmc_mean_gram_fetch copies them out when a caller wants them on the host.
+    // One rank: the reductions write the kept copies and the centre themselves; across ranks the all-reduces sit in between.
+    ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(d), dim3(from_gather ? 256 : 64), 0, st, grid, d,
+                (const double*)ctx->d_gram, ctx->d_small, across_ranks ? (double*)nullptr : ctx->d_ref,
+                across_ranks ? (double*)nullptr : d_center, (double)n_mean);
     ASMC_LAUNCH_CHECK();
-    int ggrid = 0;
-    int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &ggrid, st);
-    if (rc) return rc;
-    if (across_ranks && allreduce(ctx->d_partials, ctx->d_partials, (size_t)d * d, nccl_f64, nccl_sum, ctx->rccl_comm, st) != 0) {
-        asmc_set_error("asmc_mean_gram: ncclAllReduce failed");
-        return ASMC_ERR_ARG;
+    if (across_ranks) {
+        if (allreduce(ctx->d_small, ctx->d_small, (size_t)d, nccl_f64, nccl_sum, ctx->rccl_comm, st) != 0) {
+            asmc_set_error("asmc_mean_gram: ncclAllReduce failed");
+            return ASMC_ERR_ARG;
+        }
+        ASMC_LAUNCH(ctx, st, "k_center_from_sum", k_center_from_sum, dim3(1), dim3(128), 0, st, d, (const double*)ctx->d_small, (double)n_mean, d_center);
+        ASMC_LAUNCH_CHECK();
     }
-    // the results stay on the device (d_small / d_partials are every call's scratch): asmc_reference_factor reads them there,
-    // asmc_mean_gram_fetch copies them out when a caller wants them on the host
-    ASMC_LAUNCH(ctx, st, "k_keep_moments", k_keep_moments, dim3((d * d + d + 255) / 256), dim3(256), 0, st, d, (const double*)ctx->d_small,
-                (const double*)ctx->d_partials, ctx->d_ref);
-    ASMC_LAUNCH_CHECK();
+    int ggrid = 0;
+    int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &ggrid, st, across_ranks ? (double*)nullptr : ctx->d_ref + 128);
+    if (rc) return rc;
+    if (across_ranks) {
+        if (allreduce(ctx->d_partials, ctx->d_partials, (size_t)d * d, nccl_f64, nccl_sum, ctx->rccl_comm, st) != 0) {
+            asmc_set_error("asmc_mean_gram: ncclAllReduce failed");
+            return ASMC_ERR_ARG;
+        }
+        ASMC_LAUNCH(ctx, st, "k_keep_moments", k_keep_moments, dim3((d * d + d + 255) / 256), dim3(256), 0, st, d, (const double*)ctx->d_small,
+                    (const double*)ctx->d_partials, ctx->d_ref);
+        ASMC_LAUNCH_CHECK();
+    }
     ctx->gram_pending_d = d;
     return ASMC_OK;
 }
@@ -2176,7 +2190,7 @@ int asmc_centered_gram_dev(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const v
     ASMC_LAUNCH(ctx, st, "k_center_from_sum", k_center_from_sum, dim3(1), dim3(128), 0, st, d, sum_dev, (double)n_mean, d_center);
     ASMC_LAUNCH_CHECK();
     int ggrid = 0;
-    const int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &ggrid, st);
+    const int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &ggrid, st, nullptr);
     if (rc) return rc;
     ASMC_LAUNCH(ctx, st, "k_copy_doubles", k_copy_doubles, dim3((d * d + 255) / 256), dim3(256), 0, st, d * d, (const double*)ctx->d_partials,
                 gram_dev);
@@ -2233,7 +2247,7 @@ int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
     double* d_out = ctx->d_partials;
     if (asmc_gram_mm_supported(d, x) && ctx->d_max >= d && !getenv("ASMC_GRAM_GENERIC")) {  // fp64 MFMA (asmc_pcn_mm.hip)
         int grid = 0;
-        int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &grid, st);
+        int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &grid, st, nullptr);
         if (rc) return rc;
         ASMC_HIP(hipMemcpyAsync(gram_host, d_out, sizeof(double) * d * d, hipMemcpyDeviceToHost, st));
         ASMC_HIP(hipStreamSynchronize(st));
@@ -2266,7 +2280,7 @@ int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
                 ASMC_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows<float>, dim3(pg), dim3(ASMC_BLOCK), 0, st, n, d, D, (const float*)x, (float*)ctx->d_xpad);
             ASMC_LAUNCH_CHECK();
             int grid = 0;
-            int rc = asmc_gram_mm_launch(ctx, n, D, x_dtype, ctx->d_xpad, d_center, &grid, st);
+            int rc = asmc_gram_mm_launch(ctx, n, D, x_dtype, ctx->d_xpad, d_center, &grid, st, nullptr);
             if (rc) return rc;
             ASMC_HIP(hipMemcpy2DAsync(gram_host, sizeof(double) * d, d_out, sizeof(double) * D, sizeof(double) * d, d,
                                       hipMemcpyDeviceToHost, st));
@@ -3058,7 +3072,7 @@ static int mutate_flow_collect(asmc_ctx* ctx, int n_steps, double* rho_out_host,
     for (int t = 0; t < n_steps; t++) n_accept_host[t] = (int64_t)h_counts[t];
     if (rho_hist_host)
         for (int t = 0; t < n_steps; t++) rho_hist_host[t] = h_rho_hist[t];
-    *rho_out_host = ctx->h_pinned[8000];
+    *rho_out_host = h_rho_hist[-8];
     memcpy(&ctx->flow_nonfinite, ctx->h_pinned + 8001, sizeof(unsigned long long));  // fused steps only (else stale zero)
     return ASMC_OK;
 }
@@ -3112,11 +3126,13 @@ static int pcn_mutate_flow_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, d
     unsigned char* flags = ctx->d_flags;
     // the step size goes to the device as a kernel argument: no pinned staging, so no synchronisation in front of this call's
     // launches - the host enqueues the whole mutation while the reference fit's passes are still running
-    ASMC_LAUNCH(ctx, st, "k_set_scalar", k_set_scalar, dim3(1), dim3(1), 0, st, d_rho, *rho_inout_host);
-    ASMC_LAUNCH_CHECK();
     // register-resident whitened-state path (d in {4, 8, 16, 32}): x -> y once, then per step
     // propose / flow / accept / adapt, y -> x at the end; four launches per step, no host round trip
     const bool reg_ok = pcn_reg_supported(d, prm->x_dtype == ASMC_F64 ? 8 : 4, x) && !getenv("ASMC_PCN_XSTATE");
+    if (!reg_ok) {  // (the register path's table pack carries the step size)
+        ASMC_LAUNCH(ctx, st, "k_set_scalar", k_set_scalar, dim3(1), dim3(1), 0, st, d_rho, *rho_inout_host);
+        ASMC_LAUNCH_CHECK();
+    }
     if (reg_ok) {
         pd.beta = prm->beta;
         pd.ll = to_dev(prm->log_likelihood);
@@ -3124,7 +3140,7 @@ static int pcn_mutate_flow_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, d
         pd.lq = pd.lp;  // placeholder: the proposal density is the flow
         pd.noise = prm->noise;
         ASMC_REQUIRE(pd.noise == ASMC_NOISE_F64 || pd.noise == ASMC_NOISE_F32, "bad noise mode");
-        rc = pack_pcn_tables(ctx, pd, st);
+        rc = pack_pcn_tables(ctx, pd, st, d_rho, *rho_inout_host);
         if (rc) return rc;
         long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
         int grid = 0;
@@ -3146,9 +3162,10 @@ static int pcn_mutate_flow_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, d
             return ASMC_ERR_UNSUPPORTED;
         }
         // counters of the fused steps: [t] tile hand-out, [ASMC_MAX_PCN_STEPS + t] blocks done
-        if (fused) ASMC_HIP(hipMemsetAsync(ctx->d_tilectr, 0, sizeof(unsigned int) * (2 * ASMC_MAX_PCN_STEPS + 2), st));
+        // (sizes in multiples of 16 bytes: a ragged memset is two fill kernels)
+        if (fused) ASMC_HIP(hipMemsetAsync(ctx->d_tilectr, 0, sizeof(unsigned int) * (2 * ASMC_MAX_PCN_STEPS + 4), st));
         if (fused) {  // every tile starts in half 0 of the state allocation (tile parities: the split path's flag bytes are free here)
-            ASMC_HIP(hipMemsetAsync(ctx->d_flags, 0, (size_t)((n + 63) / 64), st));
+            ASMC_HIP(hipMemsetAsync(ctx->d_flags, 0, ((size_t)((n + 63) / 64) + 15) / 16 * 16, st));
             pd.tile_par = ctx->d_flags;
         }
         for (int t = 0; t < (fused ? n_steps : 0); t++) {
@@ -3234,8 +3251,8 @@ static int pcn_mutate_flow_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, d
     long long* h_counts = reinterpret_cast<long long*>(ctx->h_pinned);
     double* h_rho_hist = ctx->h_pinned + ASMC_MAX_PCN_STEPS + 8;
     ASMC_HIP(hipMemcpyAsync(h_counts, d_counts, sizeof(long long) * n_steps, hipMemcpyDeviceToHost, st));
-    ASMC_HIP(hipMemcpyAsync(h_rho_hist, d_rho_hist, sizeof(double) * n_steps, hipMemcpyDeviceToHost, st));
-    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8000, d_rho, sizeof(double), hipMemcpyDeviceToHost, st));
+    // the step size and its history in one copy (d_rho_hist = d_rho + 8): rho lands at h_rho_hist[-8]
+    ASMC_HIP(hipMemcpyAsync(h_rho_hist - 8, d_rho, sizeof(double) * (8 + n_steps), hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8001, ctx->d_tilectr + 2 * ASMC_MAX_PCN_STEPS, sizeof(unsigned long long),
                             hipMemcpyDeviceToHost, st));
     rc = pcn_enqueue_lq_check(ctx, n, lq, st);

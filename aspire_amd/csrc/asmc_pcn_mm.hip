@@ -494,7 +494,7 @@ __global__ __launch_bounds__(64) void k_gram_stream(int64_t n, const T* __restri
 // fixed-order sum of the per-block partial matrices, one thread per matrix entry (coalesced across entries)
 // sums the per-block partial matrices in a fixed order: 16 columns per block, 64 groups of partials per column in flight
 __global__ __launch_bounds__(1024) void k_gram_mm_reduce(int nblocks, int ncols, const double* __restrict__ partials,
-                                                         double* __restrict__ out) {
+                                                         double* __restrict__ out, double* __restrict__ out2) {
     __shared__ double s[64][17];
     const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + c;
@@ -513,6 +513,7 @@ __global__ __launch_bounds__(1024) void k_gram_mm_reduce(int nblocks, int ncols,
         double t = 0.0;
         for (int q = 0; q < 64; q++) t += s[q][c];
         out[col] = t;
+        if (out2) out2[col] = t;  // (the copy asmc_reference_factor reads: no k_keep_moments launch on one rank)
     }
 }
 
@@ -523,7 +524,7 @@ bool asmc_gram_mm_supported(int d, const void* x) {
 
 // enqueues the Gram kernel and the reduction of its per-block partial matrices; the d x d result lands in ctx->d_partials
 int asmc_gram_mm_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* d_center, int* grid_out,
-                        hipStream_t st) {
+                        hipStream_t st, double* out2) {
     int grid = (int)((n + GRAM_TP - 1) / GRAM_TP);
     // d = 32: one wave per block, so eight blocks per CU are needed to keep enough loads in flight
     static const int per_cu32 = getenv("ASMC_GRAM32_PER_CU") ? atoi(getenv("ASMC_GRAM32_PER_CU")) : 8;
@@ -556,7 +557,7 @@ int asmc_gram_mm_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void
 #undef GRAM_CASE
     ASMC_LAUNCH_CHECK();
     ASMC_LAUNCH(ctx, st, "k_gram_mm_reduce", k_gram_mm_reduce, dim3((d * d + 15) / 16), dim3(1024), 0, st, grid, d * d,
-                (const double*)ctx->d_gram, ctx->d_partials);
+                (const double*)ctx->d_gram, ctx->d_partials, out2);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }

@@ -228,133 +228,6 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_weights_map(int64_t n, const dou
     }
 }
 
-// Sharded importance step: the two passes above with their scalars taken from the search state the last k_bis_decide left
-// on the device (st[BIS_*], identical on every rank) - no host decision sits between the search, the evidence moments and
-// the weights.  The scalars are formed in smc_math.resample_owner's operation order (= k_is_weights' phase 2).
-#define SHARD_TICKET_CELL (1024 * 12)  // in ctx->d_bar (zeroed at creation), behind the persistent kernel's barrier counters
-struct ShardScalars {
-    double c1, c2, m, mean_u, shift, mp;
-    bool found;
-};
-__device__ __forceinline__ ShardScalars shard_scalars(const double* __restrict__ st) {
-    ShardScalars s;
-    const double beta0 = st[BIS_BETA0], beta = st[BIS_BMIN], N = st[BIS_N];
-    s.found = st[BIS_DONE] != 0.0 && st[BIS_TRIP_OK] != 0.0 && st[BIS_NAN] == 0.0 && beta > beta0;
-    s.c1 = beta0 - beta, s.c2 = beta - beta0;
-    s.m = st[BIS_TRIP_M];
-    const double S1 = st[BIS_TRIP_S1];
-    s.mean_u = S1 / N;
-    s.shift = (s.m + log(S1)) - st[BIS_LOGN];
-    s.mp = s.m + s.shift;
-    return s;
-}
-
-__global__ __launch_bounds__(ASMC_BLOCK) void k_weights_m2_lse_shard(int64_t n, const double* __restrict__ ll,
-                                                                    const double* __restrict__ lp,
-                                                                    const double* __restrict__ lq,
-                                                                    const double* __restrict__ st,
-                                                                    double* partials, unsigned int* ticket,
-                                                                    double* __restrict__ out) {
-    const ShardScalars s = shard_scalars(st);
-    double acc = 0.0, s1p = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
-    if (s.found)
-        for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) {
-            const double lw = lw_of(ll[i], lp[i], lq[i], s.c1, s.c2);
-            const double dlt = exp(lw - s.m) - s.mean_u;
-            acc += dlt * dlt;
-            s1p += exp((lw + s.shift) - s.mp);
-        }
-    __shared__ double s_p[ASMC_BLOCK / 64][2];
-    acc = wave_sum(acc);
-    s1p = wave_sum(s1p);
-    if ((threadIdx.x & 63) == 0) {
-        s_p[threadIdx.x >> 6][0] = acc;
-        s_p[threadIdx.x >> 6][1] = s1p;
-    }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        double v = s_p[0][threadIdx.x];
-        for (int w = 1; w < ASMC_BLOCK / 64; w++) v += s_p[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * 2 + threadIdx.x] = v;
-    }
-    // k_finalize_columns by the block that arrives last (k_bis_sums' hand-off; the counter resets itself for the next call)
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1u);
-        if (s_last) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
-    __syncthreads();
-    if (!s_last || threadIdx.x >= 128) return;
-    {
-        const int col = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        double v = 0.0;
-        for (int b = lane; b < (int)gridDim.x; b += 64) v += __builtin_nontemporal_load(partials + (size_t)b * 2 + col);
-        v = wave_sum(v);
-        if (lane == 0) out[col] = v;
-    }
-}
-
-// w = exp((lw + shift) - lse) with lse = mp + log(S1'), S1' = the ranks' second sums added in rank order (parts[world][2], the
-// all-gathered outputs of the pass above); carry_out[0] = this rank's approximate incoming cdf sum (the lower ranks' share).
-// A search that has not converged (or NaN weights, or an empty sum) leaves uniform weights and the uniform carry: everything
-// enqueued behind stays well defined, the host discards it when it reads the state.
-__global__ __launch_bounds__(ASMC_BLOCK) void k_weights_map_shard(int64_t n, const double* __restrict__ ll,
-                                                                 const double* __restrict__ lp,
-                                                                 const double* __restrict__ lq,
-                                                                 const double* __restrict__ st,
-                                                                 const double* __restrict__ parts, int world, int rank,
-                                                                 double carry_uniform, double* __restrict__ out,
-                                                                 double* __restrict__ carry_out,
-                                                                 double* __restrict__ tile_sums,
-                                                                 double* __restrict__ st_copy) {
-    const ShardScalars s = shard_scalars(st);
-    double s1p = parts[1], below = 0.0;
-    for (int r = 1; r < world; r++) {
-        if (r == rank) below = s1p;
-        s1p += parts[2 * r + 1];
-    }
-    const bool found = s.found && s1p > 0.0 && s1p < INFINITY;
-    const double lse = s.mp + log(s1p);
-    const double w_uniform = 1.0 / st[BIS_N];
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) carry_out[0] = found ? below / s1p : carry_uniform;
-        if (st_copy && threadIdx.x < 40) st_copy[threadIdx.x] = st[threadIdx.x];  // the search state, next to parts / info
-    }
-    // one block per scan tile (ASMC_SCAN_TILE particles): the tile's weight sum - the cdf's approximate prefix hints, any
-    // order will do - leaves with the weights
-    const int64_t base = (int64_t)blockIdx.x * ASMC_SCAN_TILE;
-    double acc = 0.0;
-#pragma unroll 4
-    for (int k = 0; k < ASMC_SCAN_TILE / ASMC_BLOCK; k++) {
-        const int64_t i = base + k * ASMC_BLOCK + threadIdx.x;
-        if (i < n) {
-            const double lw = lw_of(ll[i], lp[i], lq[i], s.c1, s.c2) + s.shift;
-            const double wv = found ? exp(lw - lse) : w_uniform;
-            out[i] = wv;
-            acc += wv;
-        }
-    }
-    __shared__ double s_t[ASMC_BLOCK / 64];
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) s_t[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double v = s_t[0];
-        for (int w = 1; w < ASMC_BLOCK / 64; w++) v += s_t[w];
-        tile_sums[blockIdx.x] = v;
-    }
-}
-
 __global__ __launch_bounds__(ASMC_BLOCK) void k_count_nonfinite(int64_t n, const double* __restrict__ v,
                                                                unsigned long long* __restrict__ counters) {
     long long n_nan = 0, n_inf = 0;
@@ -632,6 +505,59 @@ __device__ __forceinline__ void bis_tail_body(double* __restrict__ st, const dou
     if (threadIdx.x < 40) st[threadIdx.x] = L.st[threadIdx.x];
 }
 
+// heap node k of the bisection tree rooted at (lo, hi): the midpoint the sequential loop would try there
+__device__ __forceinline__ double bis_heap_mid(int k, double lo, double hi) {
+    const int kp = k + 1;
+    const int depth = 31 - __clz(kp);
+    double mid = 0.5 * (hi + lo);
+    for (int lev = depth - 1; lev >= 0; lev--) {
+        if ((kp >> lev) & 1)
+            lo = mid;  // right child: eff >= target there
+        else
+            hi = mid;
+        mid = 0.5 * (hi + lo);
+    }
+    return mid;
+}
+
+// Sharded search, the decide half of round `round` on a BLOCK-LOCAL state (what k_bis_decide does on the record in global
+// memory): merges the ranks' records in rank order and closes the round.  Every block of the NEXT kernel of the chain runs
+// it redundantly from the same gathered records (fixed order: the same bits everywhere), so the round costs no launch of its
+// own.  `st_prev`: the state record after the previous round (unused in round 0, which creates it).  Returns behind a
+// __syncthreads(); a search that had converged earlier passes through unchanged.
+__device__ __forceinline__ void bis_shard_decide(BisLds& L, const double* __restrict__ recs, int world, int round,
+                                                 const BisInit& init, const double* __restrict__ st_prev, double* s_S,
+                                                 double* s_eff) {
+    if (round > 0) {
+        if (threadIdx.x < 40) L.st[threadIdx.x] = st_prev[threadIdx.x];
+        __syncthreads();
+        if (L.st[2] != 0.0) return;  // converged earlier (uniform: every thread reads the same value)
+    }
+    double m_all = recs[32], nan_total = 0.0;
+    for (int r = 1; r < world; r++) m_all = fmax(m_all, recs[(size_t)r * ASMC_BIS_REC + 32]);
+    if (round == 0)
+        for (int r = 0; r < world; r++) nan_total += recs[(size_t)r * ASMC_BIS_REC + 33];
+    if (threadIdx.x < 32) {
+        const int c = threadIdx.x, k = c >> 1;
+        double acc = 0.0;
+        if (round == 0) {
+            const double beta = k < BIS_NODES ? bis_heap_mid(k, init.beta0, 1.0) : 1.0;
+            const double t = (beta - init.beta0) * (1.0 / (1.0 - init.beta0));
+            const double pw = (c & 1) ? 2.0 : 1.0;
+            for (int r = 0; r < world; r++) {
+                const double mr = recs[(size_t)r * ASMC_BIS_REC + 32];
+                acc += recs[(size_t)r * ASMC_BIS_REC + c] * exp(pw * (mr * t - m_all * t));
+            }
+        } else {
+            for (int r = 0; r < world; r++) acc += recs[(size_t)r * ASMC_BIS_REC + c];
+        }
+        s_S[c] = acc;
+    }
+    if (round == 0) bis_lds_init(L, init, m_all, nan_total);
+    __syncthreads();
+    bis_tail_core(L, round == 0, s_S, s_eff);
+}
+
 // One bisection round in ONE launch.  The 15 candidates and the bracket's upper end are equally spaced,
 // beta_j = beta_1 + (j-1) h (j = 1..16), and every log-sum-exp is shifted by m_j = (beta_j - beta0) Delta_max, so for
 // particle i
@@ -649,13 +575,24 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const doubl
                                                         double* __restrict__ st,
                                                         double* partials, unsigned int* ticket, int round, BisInit init,
                                                         const unsigned long long* __restrict__ keys,
-                                                        double* __restrict__ rec_out) {
+                                                        double* __restrict__ rec_out,
+                                                        const double* __restrict__ recs_prev = nullptr, int world = 0,
+                                                        const double* __restrict__ st_prev = nullptr) {
     __shared__ double s_red[BIS_THREADS / 32][33];
     __shared__ double s_S[32];
     __shared__ double s_eff[16];
     __shared__ int s_last;
-    double c1, c2, m1, h, dmax, m_one = 0.0;
-    if (round == 0) {
+    __shared__ BisLds Lf;  // folded sharded rounds (recs_prev given): the state after the previous round's decide half
+    double c1, c2, m1, h, dmax, m_one = 0.0, m_base = 0.0;
+    if (recs_prev) {
+        // round >= 1 of the one-chain sharded step: the previous round is closed HERE, by every block, from the gathered
+        // records; block 0 leaves the state in `st` (the other of the two state buffers: nobody reads what is being written)
+        bis_shard_decide(Lf, recs_prev, world, round - 1, init, st_prev, s_S, s_eff);
+        if (blockIdx.x == 0 && threadIdx.x < 40) st[threadIdx.x] = Lf.st[threadIdx.x];
+        if (Lf.st[2] != 0.0) return;
+        c1 = Lf.st[34], c2 = Lf.st[35], m1 = Lf.st[36], h = Lf.st[37], dmax = Lf.st[38], m_base = Lf.st[10];
+        __syncthreads();  // (s_S, s_eff are reused by the last block below)
+    } else if (round == 0) {
         m_one = key_to_f64(keys[0]);
         const double lo = init.beta0;
         double b1 = 1.0;
@@ -747,7 +684,7 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_sums(int64_t n, const doubl
         bis_reduce_partials(partials, (int)gridDim.x, s_red, s_S);
         __syncthreads();
         if (threadIdx.x < 32) rec_out[threadIdx.x] = s_S[threadIdx.x];
-        if (threadIdx.x == 32) rec_out[32] = round == 0 ? m_one : st[10];
+        if (threadIdx.x == 32) rec_out[32] = round == 0 ? m_one : recs_prev ? m_base : st[10];
         if (threadIdx.x == 33) rec_out[33] = round == 0 ? (double)keys[ASMC_MAX_BETAS] : 0.0;
         return;
     }
@@ -1123,21 +1060,6 @@ __global__ __launch_bounds__(ISW_THREADS) void k_is_weights(int64_t n, const dou
     }
 }
 
-// heap node k of the bisection tree rooted at (lo, hi): the midpoint the sequential loop would try there
-__device__ __forceinline__ double bis_heap_mid(int k, double lo, double hi) {
-    const int kp = k + 1;
-    const int depth = 31 - __clz(kp);
-    double mid = 0.5 * (hi + lo);
-    for (int lev = depth - 1; lev >= 0; lev--) {
-        if ((kp >> lev) & 1)
-            lo = mid;  // right child: eff >= target there
-        else
-            hi = mid;
-        mid = 0.5 * (hi + lo);
-    }
-    return mid;
-}
-
 // Sharded search, second half of a round (every rank runs it on the same all-gathered records, so every rank takes
 // the same decisions): merges the G rank records in rank order and runs the tail of the single-rank kernel.  First
 // round: the ranks reduced against their LOCAL m(1); the sums are rescaled to the merged maximum M = max_r m_r(1),
@@ -1170,6 +1092,142 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_decide(const double* __rest
     }
     __syncthreads();
     bis_tail_body(st, nullptr, 0, round == 0, m_all, init, s_red, s_S, s_eff, nan_total);
+}
+
+// Sharded importance step: k_weights_m2_lse and k_weights_map<1> with their scalars taken from the search state the last k_bis_decide left
+// on the device (st[BIS_*], identical on every rank) - no host decision sits between the search, the evidence moments and
+// the weights.  The scalars are formed in smc_math.resample_owner's operation order (= k_is_weights' phase 2).
+#define SHARD_TICKET_CELL (1024 * 12)  // in ctx->d_bar (zeroed at creation), behind the persistent kernel's barrier counters
+struct ShardScalars {
+    double c1, c2, m, mean_u, shift, mp;
+    bool found;
+};
+__device__ __forceinline__ ShardScalars shard_scalars(const double* __restrict__ st) {
+    ShardScalars s;
+    const double beta0 = st[BIS_BETA0], beta = st[BIS_BMIN], N = st[BIS_N];
+    s.found = st[BIS_DONE] != 0.0 && st[BIS_TRIP_OK] != 0.0 && st[BIS_NAN] == 0.0 && beta > beta0;
+    s.c1 = beta0 - beta, s.c2 = beta - beta0;
+    s.m = st[BIS_TRIP_M];
+    const double S1 = st[BIS_TRIP_S1];
+    s.mean_u = S1 / N;
+    s.shift = (s.m + log(S1)) - st[BIS_LOGN];
+    s.mp = s.m + s.shift;
+    return s;
+}
+
+__global__ __launch_bounds__(ASMC_BLOCK) void k_weights_m2_lse_shard(int64_t n, const double* __restrict__ ll,
+                                                                    const double* __restrict__ lp,
+                                                                    const double* __restrict__ lq,
+                                                                    const double* __restrict__ st,
+                                                                    double* partials, unsigned int* ticket,
+                                                                    double* __restrict__ out,
+                                                                    const double* __restrict__ recs_last, int world,
+                                                                    int last_round, BisInit init, double* __restrict__ st_out) {
+    __shared__ BisLds Lf;
+    __shared__ double s_S[32];
+    __shared__ double s_eff[16];
+    if (recs_last) {  // the search's last round is closed here (bis_shard_decide); block 0 leaves the final state in st_out
+        bis_shard_decide(Lf, recs_last, world, last_round, init, st, s_S, s_eff);
+        if (blockIdx.x == 0 && threadIdx.x < 40) st_out[threadIdx.x] = Lf.st[threadIdx.x];
+    }
+    const ShardScalars s = shard_scalars(recs_last ? Lf.st : st);
+    double acc = 0.0, s1p = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
+    if (s.found)
+        for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) {
+            const double lw = lw_of(ll[i], lp[i], lq[i], s.c1, s.c2);
+            const double dlt = exp(lw - s.m) - s.mean_u;
+            acc += dlt * dlt;
+            s1p += exp((lw + s.shift) - s.mp);
+        }
+    __shared__ double s_p[ASMC_BLOCK / 64][2];
+    acc = wave_sum(acc);
+    s1p = wave_sum(s1p);
+    if ((threadIdx.x & 63) == 0) {
+        s_p[threadIdx.x >> 6][0] = acc;
+        s_p[threadIdx.x >> 6][1] = s1p;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double v = s_p[0][threadIdx.x];
+        for (int w = 1; w < ASMC_BLOCK / 64; w++) v += s_p[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * 2 + threadIdx.x] = v;
+    }
+    // k_finalize_columns by the block that arrives last (k_bis_sums' hand-off; the counter resets itself for the next call)
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1u);
+        if (s_last) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 128) return;
+    {
+        const int col = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        double v = 0.0;
+        for (int b = lane; b < (int)gridDim.x; b += 64) v += __builtin_nontemporal_load(partials + (size_t)b * 2 + col);
+        v = wave_sum(v);
+        if (lane == 0) out[col] = v;
+    }
+}
+
+// w = exp((lw + shift) - lse) with lse = mp + log(S1'), S1' = the ranks' second sums added in rank order (parts[world][2], the
+// all-gathered outputs of the pass above); carry_out[0] = this rank's approximate incoming cdf sum (the lower ranks' share).
+// A search that has not converged (or NaN weights, or an empty sum) leaves uniform weights and the uniform carry: everything
+// enqueued behind stays well defined, the host discards it when it reads the state.
+__global__ __launch_bounds__(ASMC_BLOCK) void k_weights_map_shard(int64_t n, const double* __restrict__ ll,
+                                                                 const double* __restrict__ lp,
+                                                                 const double* __restrict__ lq,
+                                                                 const double* __restrict__ st,
+                                                                 const double* __restrict__ parts, int world, int rank,
+                                                                 double carry_uniform, double* __restrict__ out,
+                                                                 double* __restrict__ carry_out,
+                                                                 double* __restrict__ tile_sums,
+                                                                 double* __restrict__ st_copy) {
+    const ShardScalars s = shard_scalars(st);
+    double s1p = parts[1], below = 0.0;
+    for (int r = 1; r < world; r++) {
+        if (r == rank) below = s1p;
+        s1p += parts[2 * r + 1];
+    }
+    const bool found = s.found && s1p > 0.0 && s1p < INFINITY;
+    const double lse = s.mp + log(s1p);
+    const double w_uniform = 1.0 / st[BIS_N];
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) carry_out[0] = found ? below / s1p : carry_uniform;
+        if (st_copy && threadIdx.x < 40) st_copy[threadIdx.x] = st[threadIdx.x];  // the search state, next to parts / info
+    }
+    // one block per scan tile (ASMC_SCAN_TILE particles): the tile's weight sum - the cdf's approximate prefix hints, any
+    // order will do - leaves with the weights
+    const int64_t base = (int64_t)blockIdx.x * ASMC_SCAN_TILE;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < ASMC_SCAN_TILE / ASMC_BLOCK; k++) {
+        const int64_t i = base + k * ASMC_BLOCK + threadIdx.x;
+        if (i < n) {
+            const double lw = lw_of(ll[i], lp[i], lq[i], s.c1, s.c2) + s.shift;
+            const double wv = found ? exp(lw - lse) : w_uniform;
+            out[i] = wv;
+            acc += wv;
+        }
+    }
+    __shared__ double s_t[ASMC_BLOCK / 64];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_t[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v = s_t[0];
+        for (int w = 1; w < ASMC_BLOCK / 64; w++) v += s_t[w];
+        tile_sums[blockIdx.x] = v;
+    }
 }
 
 extern "C" {
@@ -1528,18 +1586,58 @@ int asmc_weights_m2_lse_dev(asmc_ctx* ctx, int64_t n, const double* ll, const do
 
 // Sharded importance step with device-resident scalars (include/asmc.h): the search state of asmc_find_beta_shard_decide
 // stays where it is, these passes read it there.
+// state record S_r (after r closed rounds) of the folded sharded search: two buffers, S_r in buffer r & 1 - the kernel that
+// closes round r - 1 reads S_{r-1} while its block 0 writes S_r
+static inline double* shard_state_buf(asmc_ctx* ctx, int r) { return ctx->d_small + 2560 + ((r & 1) ? 64 : 0); }
+
+int asmc_find_beta_shard_round(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double beta0,
+                               double target_eff, double tol, int world, int64_t n_global, int round, const double* recs_prev_dev,
+                               double* rec_dev, asmc_stream stream) {
+    int rc = check_common(ctx, n, ll, lp, lq);
+    if (rc) return rc;
+    ASMC_REQUIRE(rec_dev != nullptr && round >= 0 && (round == 0 || recs_prev_dev), "null record / negative round");
+    ASMC_REQUIRE(world >= 1 && n_global > 0 && tol > 0.0 && beta0 >= 0.0 && beta0 < 1.0, "bad world / n_global / beta0 / tolerance");
+    if (round == 0) return asmc_find_beta_shard_reduce(ctx, n, ll, lp, lq, beta0, 0, rec_dev, stream);
+    hipStream_t st = as_stream(stream);
+    double* d_st;
+    unsigned int* d_ticket;
+    bis_state(ctx, &d_st, &d_ticket);
+    const BisInit init = {beta0, target_eff, tol, log((double)n_global), (double)n_global, bis_plain_mode()};
+    const int grid = grid_for(n, BIS_THREADS, ctx->num_cu);
+    ASMC_LAUNCH(ctx, st, "k_bis_sums", k_bis_sums, dim3(grid), dim3(BIS_THREADS), 0, st, n, ll, lp, lq, shard_state_buf(ctx, round),
+                ctx->d_partials, d_ticket, round, init, (const unsigned long long*)ctx->d_keys, rec_dev, recs_prev_dev, world,
+                (const double*)shard_state_buf(ctx, round - 1));
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
+// Sharded importance step with device-resident scalars (include/asmc.h): the search state stays on the device, these passes
+// read it there.  recs_last_dev given: the search ran as asmc_find_beta_shard_round x n_rounds and its last round is closed
+// inside this pass; NULL: the state asmc_find_beta_shard_decide left.
 int asmc_weights_m2_lse_shard(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double* out_dev,
-                              asmc_stream stream) {
+                              const double* recs_last_dev, int world, int64_t n_global, double beta0, double target_eff,
+                              double tol, int n_rounds, asmc_stream stream) {
     int rc = check_common(ctx, n, ll, lp, lq);
     if (rc) return rc;
     ASMC_REQUIRE(out_dev != nullptr, "null device pointer");
+    ASMC_REQUIRE(!recs_last_dev || (world >= 1 && n_global > 0 && n_rounds >= 1 && tol > 0.0 && beta0 >= 0.0 && beta0 < 1.0),
+                 "bad world / n_global / rounds / beta0 / tolerance");
     hipStream_t st = as_stream(stream);
     double* d_st;
     unsigned int* d_ticket;
     bis_state(ctx, &d_st, &d_ticket);
     const int grid = reduce_grid(ctx, n, 1);
-    ASMC_LAUNCH(ctx, st, "k_weights_m2_lse_shard", k_weights_m2_lse_shard, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq,
-                (const double*)d_st, ctx->d_partials, ctx->d_bar + SHARD_TICKET_CELL, out_dev);
+    BisInit init = {beta0, target_eff, tol, 0.0, 0.0, bis_plain_mode()};
+    const double* st_in = d_st;
+    double* st_out = nullptr;
+    if (recs_last_dev) {
+        init.logN = log((double)n_global), init.N = (double)n_global;
+        st_in = shard_state_buf(ctx, n_rounds - 1);
+        st_out = shard_state_buf(ctx, n_rounds);
+    }
+    ctx->shard_st = recs_last_dev ? st_out : d_st;
+    ASMC_LAUNCH(ctx, st, "k_weights_m2_lse_shard", k_weights_m2_lse_shard, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq, st_in,
+                ctx->d_partials, ctx->d_bar + SHARD_TICKET_CELL, out_dev, recs_last_dev, world, n_rounds - 1, init, st_out);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
@@ -1552,13 +1650,11 @@ int asmc_normalized_weights_shard(asmc_ctx* ctx, int64_t n, const double* ll, co
     ASMC_REQUIRE(parts_dev && w_out && carry_out_dev && tile_sums_dev, "null pointer");
     ASMC_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank / world");
     ASMC_REQUIRE(carry_uniform >= 0.0 && carry_uniform < 1.0, "bad uniform carry");
+    ASMC_REQUIRE(ctx->shard_st != nullptr, "asmc_weights_m2_lse_shard first");
     hipStream_t st = as_stream(stream);
-    double* d_st;
-    unsigned int* d_ticket;
-    bis_state(ctx, &d_st, &d_ticket);
     const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
     ASMC_LAUNCH(ctx, st, "k_weights_map_shard", k_weights_map_shard, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq,
-                (const double*)d_st, parts_dev, world, rank, carry_uniform, w_out, carry_out_dev, tile_sums_dev, state_copy_dev);
+                (const double*)ctx->shard_st, parts_dev, world, rank, carry_uniform, w_out, carry_out_dev, tile_sums_dev, state_copy_dev);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }

@@ -342,11 +342,25 @@ class HipEngine:
                                                mean_u, shift, mp, _dptr(out), self._stream), "asmc_weights_m2_lse_dev")
 
     # sharded importance step with the scalars left on the device (include/asmc.h asmc_weights_m2_lse_shard ...)
-    def weights_m2_lse_shard(self, ll, lp, lq, out: torch.Tensor):
-        """`weights_m2_lse_dev` at the beta the sharded search has just left on the device (no host value involved)."""
+    def find_beta_shard_round(self, ll, lp, lq, beta0: float, target_eff: float, tol: float, world: int, n_global: int, rnd: int,
+                              recs_prev: torch.Tensor | None, rec: torch.Tensor):
+        """Round `rnd` of the sharded search with the previous round's decide half folded in (recs_prev = the all-gathered
+        records of round rnd - 1; None in round 0): one launch per round; the caller all-gathers `rec` afterwards."""
+        self._chk3(ll, lp, lq)
+        assert rec.dtype == torch.float64 and rec.numel() >= _lib.ASMC_BIS_REC and rec.is_contiguous()
+        assert rnd == 0 or (recs_prev is not None and recs_prev.numel() == world * _lib.ASMC_BIS_REC and recs_prev.is_contiguous())
+        check(self.lib.asmc_find_beta_shard_round(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), beta0, target_eff, tol,
+                                                  world, n_global, rnd, _dptr(recs_prev) if rnd else None, _dptr(rec),
+                                                  self._stream), "asmc_find_beta_shard_round")
+
+    def weights_m2_lse_shard(self, ll, lp, lq, out: torch.Tensor, recs_last: torch.Tensor | None = None, world: int = 1,
+                             n_global: int = 0, beta0: float = 0.0, target_eff: float = 0.5, tol: float = 1e-6, n_rounds: int = 0):
+        """`weights_m2_lse_dev` at the beta the sharded search has left on the device (no host value involved).  `recs_last`: the
+        all-gathered records of the search's last round (`find_beta_shard_round` x n_rounds), closed inside this pass."""
         self._chk3(ll, lp, lq)
         assert out.dtype == torch.float64 and out.numel() >= 2
-        check(self.lib.asmc_weights_m2_lse_shard(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), _dptr(out), self._stream),
+        check(self.lib.asmc_weights_m2_lse_shard(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), _dptr(out),
+                                                 _dptr(recs_last), world, n_global, beta0, target_eff, tol, n_rounds, self._stream),
               "asmc_weights_m2_lse_shard")
 
     def normalized_weights_shard(self, ll, lp, lq, parts: torch.Tensor, world: int, rank: int, carry_uniform: float,
@@ -870,7 +884,9 @@ class HipEngine:
             check(self.lib.asmc_pcn_set_count_hook(self._ctx, None, None, None, 0), "asmc_pcn_set_count_hook")
             self._hook = None
             return
-        cell = torch.zeros(1, dtype=torch.int64, device=self.device)
+        cell = self.__dict__.get("_count_cell")  # (the library writes it before every exchange: one allocation, no fill per call)
+        if cell is None:
+            cell = self._count_cell = torch.zeros(1, dtype=torch.int64, device=self.device)
         if self.use_rccl(comm):  # the library issues the all-reduce itself, on its own stream
             self._hook = (None, cell, None)
             check(self.lib.asmc_pcn_set_count_rccl(self._ctx, _dptr(cell), int(n_global)), "asmc_pcn_set_count_rccl")

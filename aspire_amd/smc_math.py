@@ -519,7 +519,7 @@ def shard_step_available(engine, comm) -> bool:
     """The sharded importance step can run as one chain of launches (`shard_step_enqueue`): the engine has the passes that
     take their scalars from the device, and ASMC_SHARD_STEP=0 has not switched it off (A-B switch / escape hatch)."""
     return (comm.sharded and all(hasattr(engine, k) for k in ("weights_m2_lse_shard", "normalized_weights_shard", "all_gather",
-                                                              "shard_step_result", "find_beta_shard_rounds",
+                                                              "shard_step_result", "find_beta_shard_round",
                                                               "cdf_shard_finish_select"))
             and os.environ.get("ASMC_SHARD_STEP", "1") != "0")
 
@@ -544,12 +544,15 @@ def shard_step_enqueue(engine, comm, ll, lp, lq, beta0: float, target_eff: float
     bufs = engine.__dict__.setdefault("_bis_bufs", {})
     if bufs.get("world") != world:
         bufs.update(world=world, rec=engine.empty(40), recs=engine.empty(40 * world))
-    engine.find_beta_shard_rounds(comm, ll, lp, lq, beta0, target_eff, tol, n_global, bufs["rec"], bufs["recs"], 0, rounds)
+    rec, recs = bufs["rec"], bufs["recs"]
+    for r in range(rounds):  # one launch + one all-gather per round: round r closes round r - 1 itself (no decide launch)
+        engine.find_beta_shard_round(ll, lp, lq, beta0, target_eff, tol, world, n_global, r, recs if r else None, rec)
+        engine.all_gather(comm, rec, out=recs)
     # evidence moments + second log-sum-exp at the beta the last decide step left on the device; the gathered pairs, the
     # search state and (below) the ranks' offspring counts share ONE buffer: the step's single read-back
     res = engine.empty(40 + 4 * world)
     part = engine.empty(2)
-    engine.weights_m2_lse_shard(ll, lp, lq, part)
+    engine.weights_m2_lse_shard(ll, lp, lq, part, recs, world, n_global, beta0, target_eff, tol, rounds)  # (closes the last round)
     parts = engine.all_gather(comm, part, out=res[40:40 + 2 * world])
     w, carry, tile_sums = engine.normalized_weights_shard(ll, lp, lq, parts, world, rank, float(sum(counts[:rank])) / float(n_global),
                                                           state_copy=res[:40])

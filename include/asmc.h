@@ -215,7 +215,15 @@ int asmc_weights_m2_lse_dev(asmc_ctx* ctx, int64_t n, const double* ll_dev, cons
  * distributed mode, SURVEY.md §8e - the contract is samples.py:1221-1287 on the GLOBAL population).  The search state that
  * asmc_find_beta_shard_decide leaves on the device (beta*, the (m, S1, S2) triple at beta*, N, log N; identical on every
  * rank) parameterises the passes behind it:
- *   asmc_weights_m2_lse_shard      asmc_weights_m2_lse_dev with beta, m, mean_u = S1/N, shift = (m + log S1) - log N and
+ *   asmc_find_beta_shard_round     a search round WITHOUT a decide launch: round r >= 1 closes round r - 1 itself - every
+ *                                  block merges recs_prev_dev[world][ASMC_BIS_REC] (the all-gathered records of round r - 1)
+ *                                  in rank order and takes asmc_find_beta_shard_decide's decisions on a block-local copy of
+ *                                  the state (fixed order: the same bits in every block and on every rank) - then reduces
+ *                                  this rank's sums of round r -> rec_dev.  Round 0 = asmc_find_beta_shard_reduce(round 0).
+ *                                  (caller) all-gather of rec_dev after every round;
+ *   asmc_weights_m2_lse_shard      closes the LAST round (n_rounds - 1) the same way when recs_last_dev is given (NULL: the
+ *                                  state asmc_find_beta_shard_decide left), then asmc_weights_m2_lse_dev with beta, m,
+ *                                  mean_u = S1/N, shift = (m + log S1) - log N and
  *                                  mp = m + shift formed on the device in that order -> out_dev[2] (one launch: the block
  *                                  that arrives last adds up the blocks' partials in the two-launch form's order);
  *   (caller)                       all-gather of the pairs in rank order -> parts_dev[world][2];
@@ -239,8 +247,12 @@ int asmc_weights_m2_lse_dev(asmc_ctx* ctx, int64_t n, const double* ll_dev, cons
  * A search that did not converge within the rounds enqueued (or met NaN weights) leaves uniform weights 1/N and
  * carry_uniform behind - every later launch stays well defined - and the host, seeing converged = 0, discards the chain and
  * continues the search round by round. */
+int asmc_find_beta_shard_round(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev, const double* lq_dev,
+                               double beta0, double target_eff, double tol, int world, int64_t n_global, int round,
+                               const double* recs_prev_dev, double* rec_dev, asmc_stream stream);
 int asmc_weights_m2_lse_shard(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev, const double* lq_dev,
-                              double* out_dev, asmc_stream stream);
+                              double* out_dev, const double* recs_last_dev, int world, int64_t n_global, double beta0,
+                              double target_eff, double tol, int n_rounds, asmc_stream stream);
 int asmc_normalized_weights_shard(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev, const double* lq_dev,
                                   const double* parts_dev, int world, int rank, double carry_uniform, double* w_out_dev,
                                   double* carry_out_dev, double* tile_sums_dev, double* state_copy_dev, asmc_stream stream);
