@@ -178,6 +178,8 @@ SIGNATURES = {
     "asmc_reference_factor_dev": (_i, [_vp, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "asmc_student_fit": (_i, [_vp, _i64, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _pd, _vp]),
     "asmc_reference_factor_status": (_i, [_vp, POINTER(ctypes.c_int)]),
+    "asmc_reference_factor_generation": (_i64, [_vp]),
+    "asmc_reference_factor_status_of": (_i, [_vp, _i64, POINTER(ctypes.c_int)]),
     "asmc_pcn_mutate": (
         _i,
         [_vp, _i64, _vp, _vp, _vp, _vp, POINTER(AsmcPcnParams), _i, _u32, _pd, _pi64, _pd, _vp],

@@ -2216,6 +2216,19 @@ int asmc_reference_factor_status(asmc_ctx* ctx, int* status_host) {
     return ASMC_OK;
 }
 
+// the request a caller has just made, and the status of one particular request: a mutation asks about the factorisation
+// that served IT - the next temperature's may already be on the stream behind it (asmc_reference_factor_status reads the latest
+// request's cell: -2 until that one has run)
+int64_t asmc_reference_factor_generation(asmc_ctx* ctx) { return ctx ? (int64_t)ctx->ref_status_gen : -1; }
+int asmc_reference_factor_status_of(asmc_ctx* ctx, int64_t generation, int* status_host) {
+    ASMC_REQUIRE(ctx && status_host, "null pointer");
+    ASMC_REQUIRE(generation > 0 && (uint64_t)generation <= ctx->ref_status_gen &&
+                     ctx->ref_status_gen - (uint64_t)generation < REF_STATUS_CELLS,
+                 "no such factorisation request (or more than 15 requests ago)");
+    *status_host = (int)ctx->h_pinned[REF_STATUS_CELL0 + (unsigned)generation % REF_STATUS_CELLS];
+    return ASMC_OK;
+}
+
 int asmc_mean_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, int64_t n_mean, int across_ranks,
                    double* sum_host, double* gram_host, asmc_stream stream) {
     ASMC_REQUIRE(ctx && x && sum_host && gram_host, "null pointer");

@@ -777,6 +777,7 @@ class HipEngine:
             self._ref_keep = (s_d, g_d)  # the kernel reads them when the stream gets there
             check(self.lib.asmc_reference_factor_dev(self._ctx, d, int(n_mean), int(n_cov), _dptr(s_d), _dptr(g_d), _dptr(out),
                                                      self._stream), "asmc_reference_factor_dev")
+            self.ref_generation = int(self.lib.asmc_reference_factor_generation(self._ctx))
             return out[:d], out[seg:seg + d * d].view(d, d), out[seg + seg * d:seg + seg * d + d * d].view(d, d)
         if moments is None:
             sp, gp = None, None
@@ -787,12 +788,18 @@ class HipEngine:
             sp, gp = _f64p(s), _f64p(g)
         check(self.lib.asmc_reference_factor(self._ctx, d, int(n_mean), int(n_cov), sp, gp, _dptr(out), self._stream),
               "asmc_reference_factor")
+        self.ref_generation = int(self.lib.asmc_reference_factor_generation(self._ctx))  # (reference_factor_status(generation))
         return out[:d], out[seg:seg + d * d].view(d, d), out[seg + seg * d:seg + seg * d + d * d].view(d, d)
 
-    def reference_factor_status(self) -> int:
+    def reference_factor_status(self, generation: int | None = None) -> int:
         """Jitter tries the last `reference_factor` needed (0: none); -1: the covariance was not factorable; -2: the stream has
-        not been synchronised since."""
+        not been synchronised since.  `generation`: of that particular request (`ref_generation` right after the call) - the
+        latest one may be the NEXT temperature's, still waiting on the stream."""
         st = ctypes.c_int(0)
+        if generation is not None:
+            check(self.lib.asmc_reference_factor_status_of(self._ctx, int(generation), ctypes.byref(st)),
+                  "asmc_reference_factor_status_of")
+            return int(st.value)
         check(self.lib.asmc_reference_factor_status(self._ctx, ctypes.byref(st)), "asmc_reference_factor_status")
         return int(st.value)
 

@@ -104,6 +104,10 @@ class SMCSampler(MCMCSampler):
         this sampler's mutation does not use them."""
         return None
 
+    def _factor_ahead(self) -> bool:
+        """Whether the speculated importance step may also enqueue the factorisation of the reference Gaussian (see HipSMC)."""
+        return False
+
     def determine_beta(self, samples: SMCSamples, beta: float, beta_step: float, min_beta_step: float,
                        max_beta_step: float = 1.0, beta_tolerance: float = DEFAULT_BETA_TOLERANCE):
         """smc/base.py:123-213; the ESS evaluations of one k-ary bisection round share a device pass."""
@@ -273,7 +277,7 @@ class SMCSampler(MCMCSampler):
                                                       resample_mode=self.resample_mode,
                                                       resample_method=self.resample_method,
                                                       moments_n=self._speculated_moments_n(samples),
-                                                      shard_layout=self.shard_layout)
+                                                      shard_layout=self.shard_layout, factor_ahead=self._factor_ahead())
                 beta, min_beta_step = self.determine_beta(samples, beta, beta_step, min_beta_step,
                                                           max_beta_step=self.max_beta_step,
                                                           beta_tolerance=beta_tolerance)
@@ -440,6 +444,12 @@ class HipSMC(SMCSampler):
             return None
         return int(self._n_global(samples))
 
+    def _factor_ahead(self) -> bool:
+        """The reference Gaussian is factored on the device (`_fit_reference_gaussian`'s device fit): the speculated importance
+        step may enqueue the factorisation right behind the moments (ASMC_FACTOR_AHEAD=0: A-B switch)."""
+        return (hasattr(self.engine, "reference_factor") and self.dims <= 128 and not os.environ.get("ASMC_HOST_REFERENCE_FIT")
+                and os.environ.get("ASMC_FACTOR_AHEAD", "1") != "0")
+
     def _resample_moments_n(self, samples) -> int | None:
         T = self.preconditioning_transform
         if (self.sampler_kwargs.get("step_fn", "tpcn") != "pcn"
@@ -457,6 +467,10 @@ class HipSMC(SMCSampler):
                 and moments[2] == n and moments[3] == getattr(e, "_gram_gen", None)):
             if device_fit:  # mean, covariance, Cholesky factor and its inverse never visit the host (asmc_reference_factor)
                 self._ref_fit_pending = True
+                if len(moments) > 4 and moments[4] is not None:
+                    # factored already, right behind the moments (speculate_importance_step's factor_ahead)
+                    self._ref_fit_generation = moments[4][3]
+                    return moments[4][:3]
                 return e.reference_factor(x.shape[1], n, n)
             s, g = e.mean_gram_fetch(x.shape[1])  # enqueued behind the importance step's gather; waits for the stream
             mean = s / n
@@ -547,7 +561,11 @@ class HipSMC(SMCSampler):
         (`pcn`, nu = 0) or a Student-t fitted by EM to a strided subsample of `tpcn_fit_subsample` particles, the
         same on every rank (`tpcn`; student_t.py).  A fit with nu above NU_GAUSSIAN runs the Gaussian kernels."""
         if step_fn != "tpcn":
-            return (*self._fit_reference_gaussian(x, n_global, moments), 0.0)
+            out = self._fit_reference_gaussian(x, n_global, moments)
+            if self.__dict__.get("_ref_fit_pending") and self.__dict__.get("_ref_fit_generation") is None:
+                # the request just made (later ones - the next temperature's, enqueued behind this mutation - get their own cell)
+                self._ref_fit_generation = getattr(self.engine, "ref_generation", None)
+            return (*out, 0.0)
         from ..student_t import NU_GAUSSIAN, _chol, fit_student_t_device
 
         e, comm = self.engine, self.comm
@@ -774,10 +792,12 @@ class HipSMC(SMCSampler):
         it served: the steps' results have been collected, so its status is on the host."""
         if not self.__dict__.pop("_ref_fit_pending", False):
             return
-        status = self.engine.reference_factor_status()
+        # the request that served THIS mutation: the next temperature's factorisation may already sit on the stream behind it
+        gen = self.__dict__.pop("_ref_fit_generation", None)
+        status = self.engine.reference_factor_status(gen) if gen else self.engine.reference_factor_status()
         if status == -2:  # nothing has synchronised the stream since (a mutation of zero steps)
             torch.cuda.synchronize(self.engine.device)
-            status = self.engine.reference_factor_status()
+            status = self.engine.reference_factor_status(gen) if gen else self.engine.reference_factor_status()
         if status < 0:
             raise RuntimeError("could not factor the particle covariance")
         if status > 0:
@@ -825,7 +845,7 @@ class HipSMC(SMCSampler):
                     ok = out.speculate_importance_step(self.current_target_efficiency(beta), self._beta_tolerance, self.rng,
                                                        resample_mode=self.resample_mode, resample_method=self.resample_method,
                                                        moments_n=self._speculated_moments_n(out), defer=True,
-                                                       shard_layout=self.shard_layout)
+                                                       shard_layout=self.shard_layout, factor_ahead=self._factor_ahead())
                     n_acc, rho_hist, rho = e.pcn_mutate_flow_result(handle)  # waits for the mutation only
                     if ok:
                         st["prewrapped"] = out  # the step's results are collected when the next iteration asks for them

@@ -415,7 +415,7 @@ class SMCSamples(BaseSamples):
 
     def speculate_importance_step(self, target_eff: float, tol: float, rng, *, resample_mode: str = "exact",
                                   resample_method: str = "multinomial", moments_n: int | None = None,
-                                  defer: bool = False, shard_layout: str = "owner") -> bool:
+                                  defer: bool = False, shard_layout: str = "owner", factor_ahead: bool = False) -> bool:
         """Enqueue the whole importance step of one iteration - adaptive-beta search (smc/base.py:167-186), evidence
         moments (samples.py:1226-1242) and the multinomial resampling of all N particles at beta* (samples.py:1251-1287)
         - as one chain of launches with a single host synchronisation (include/asmc.h asmc_importance_step), and park
@@ -425,6 +425,9 @@ class SMCSamples(BaseSamples):
         `moments_n`: also enqueue the column sums and the centred Gram matrix of the resampled rows (centre = sums /
         moments_n; `engine.mean_gram`) behind the gather, so that the mutation's reference fit costs no pass and no
         synchronisation of its own; they travel with the resampled population (`_moments`).
+        `factor_ahead` (with `moments_n`): the reference Gaussian's factorisation (`engine.reference_factor`: covariance ->
+        Cholesky factor -> inverse, one block) goes behind the moments as well - it depends on the resampled rows only, not on
+        what the host decides from the step's scalars, so it runs while the host is still reading them.
         `defer`: enqueue only; the caller has more to wait for on the stream and calls `finish_speculation()` itself.
         Sharded populations (owner layout): the chain runs up to the ranks' offspring counts (`smc_math.shard_step_enqueue`:
         search, moments, weights, global cdf slice, draw selection, with the collectives on the stream between them);
@@ -446,7 +449,8 @@ class SMCSamples(BaseSamples):
             h = smc_math.shard_step_enqueue(e, comm, ll, lp, lq, float(self.beta), float(target_eff), float(tol), n,
                                             self.shard_counts_list(), st4, n)
             self._spec_pending = dict(key=(float(target_eff), float(tol)), shard=h, src=(x, ll, lp, lq), rng=rng,
-                                      state=[int(v) for v in st4], n=n, moments_n=int(moments_n) if moments_n else None)
+                                      state=[int(v) for v in st4], n=n, moments_n=int(moments_n) if moments_n else None,
+                                      factor_ahead=bool(factor_ahead))
             if not defer:
                 self.finish_speculation()
             return True
@@ -463,8 +467,13 @@ class SMCSamples(BaseSamples):
             e.importance_result_enqueue()  # the step's scalars come back as soon as the step is done, not behind the moments
         with_moments = (bool(moments_n) and hasattr(e, "mean_gram_enqueue")
                         and e.mean_gram_enqueue(rows[0], int(moments_n), gathered=True))  # (the rows come straight from the gather)
+        factor = None
+        if with_moments and factor_ahead and hasattr(e, "reference_factor"):
+            factor = e.reference_factor(int(rows[0].shape[1]), int(moments_n), int(moments_n))
+            factor = (*factor, getattr(e, "ref_generation", None))  # (mu, L, Linv, the request's generation: its status cell)
         self._spec_pending = dict(key=(float(target_eff), float(tol)), rows=rows, rng=rng, state=[int(v) for v in st4], n=n,
-                                  moments_n=int(moments_n) if with_moments else None, gram_gen=getattr(e, "_gram_gen", None))
+                                  moments_n=int(moments_n) if with_moments else None, gram_gen=getattr(e, "_gram_gen", None),
+                                  factor=factor)
         if not defer:
             self.finish_speculation()
         return True
@@ -477,20 +486,30 @@ class SMCSamples(BaseSamples):
         e = self._eng()
         if "shard" in p:
             comm = self._comm()
-            search, ok, m2, _, new_counts, u_kept = smc_math.shard_step_finish(e, comm, p["shard"])
+            search, parts, info, u_kept = smc_math.shard_step_wait(e, comm, p["shard"])
             rows, moments = None, None
-            if ok:  # this rank's sub-sequence of Generator.choice's index vector, then its rows (samples.py:1278-1287)
+            if u_kept is not None:
+                # this rank's sub-sequence of Generator.choice's index vector, then its rows (samples.py:1278-1287): enqueued
+                # BEFORE the host has examined the gathered numbers - a step it then rejects (rare) just drops the rows
                 rows = e.gather(e.search(p["shard"]["cdf"], u_kept), *p["src"])
                 if (p["moments_n"] is not None and hasattr(e, "mean_gram_enqueue")
                         and e.mean_gram_enqueue(rows[0], p["moments_n"], comm, gathered=True)):
-                    moments = (rows[0].data_ptr(), tuple(rows[0].shape), p["moments_n"], e._gram_gen)
+                    factor = None
+                    if p.get("factor_ahead") and hasattr(e, "reference_factor"):
+                        factor = e.reference_factor(int(rows[0].shape[1]), p["moments_n"], p["moments_n"])
+                        factor = (*factor, getattr(e, "ref_generation", None))
+                    moments = (rows[0].data_ptr(), tuple(rows[0].shape), p["moments_n"], e._gram_gen, factor)
+            ok, m2, _, new_counts = smc_math.shard_step_check(p["shard"], search, parts, info)
+            ok = ok and rows is not None
+            if not ok:
+                rows, moments = None, None
             self._spec = dict(key=p["key"], search=search, found=bool(ok), beta=float(search[0]), rows=rows, m2=m2, rng=p["rng"],
                               state=p["state"], n=p["n"], moments=moments, counts=new_counts)
             return
         b, eff1, conv, passes, n_nan, trip, trip_one, m2, _, found = e.importance_result()
         moments, rows = None, p["rows"]
         if p["moments_n"] is not None:  # still on the stream: fetched by the reference fit (HipSMC._fit_reference_gaussian)
-            moments = (rows[0].data_ptr(), tuple(rows[0].shape), p["moments_n"], p["gram_gen"])
+            moments = (rows[0].data_ptr(), tuple(rows[0].shape), p["moments_n"], p["gram_gen"], p.get("factor"))
         self._spec = dict(key=p["key"], search=(b, eff1, conv, passes, n_nan, trip, trip_one),
                           found=bool(found and conv), beta=float(b), rows=rows, m2=m2, rng=p["rng"],
                           state=p["state"], n=p["n"], moments=moments)

@@ -531,9 +531,9 @@ def shard_step_enqueue(engine, comm, ll, lp, lq, beta0: float, target_eff: float
     this rank's slice of the global sequential cdf, the draws of Generator.choice that fall into it (samples.py:1278) - as ONE
     chain of launches and collectives with no host decision in between: what `find_beta_sharded` and `resample_owner` read
     back between their phases (beta*, the weight sums, the shares) stays on the device and parameterises the next launch
-    (include/asmc.h asmc_weights_m2_lse_shard).  Nothing here synchronises; `shard_step_finish` does, once.
+    (include/asmc.h asmc_weights_m2_lse_shard).  Nothing here synchronises; `shard_step_wait` does, once.
     `state4`: the PCG64 state words of the generator every rank holds in the same state (`sync_rng`).  Returns the handle for
-    `shard_step_finish`."""
+    `shard_step_wait` / `shard_step_check`."""
     world, rank, n_local = comm.world, comm.rank, ll.numel()
     counts = [int(c) for c in counts]
     assert counts[rank] == n_local and sum(counts) == int(n_global), (counts, rank, n_local, n_global)
@@ -564,18 +564,28 @@ def shard_step_enqueue(engine, comm, ll, lp, lq, beta0: float, target_eff: float
                 keep=(w, u_all, edges, recs_all, work, state, tile_sums, carry, part, info_dev))
 
 
-def shard_step_finish(engine, comm, h):
-    """Wait for `shard_step_enqueue`'s chain and take the decisions `find_beta_sharded` / `resample_owner` take, from the same
-    numbers in the same order (every rank reads the same gathered values, so every rank decides alike).  Returns
-    (search tuple, ok, m2, s1p, new_counts, u_kept): `ok` False - search not converged in the rounds enqueued, NaN weights,
-    a weight share outside 1/world (1 +- SHARD_IMBALANCE), a cdf chain that needs the replicated scan, a rank left without
-    offspring - means the caller runs the step phase by phase (which handles or reports each of these); the generator has not
-    been touched."""
-    world, rank = h["world"], h["rank"]
-    search, parts, info = engine.shard_step_result(h["res"], world)
+def shard_step_wait(engine, comm, h):
+    """Wait for `shard_step_enqueue`'s chain (its ONE synchronisation).  Returns (search tuple, parts[world, 2], info[world, 2],
+    kept): `kept` = this rank's draws (a view of the selection buffer) when the numbers read back are those of a finished step
+    - the caller may enqueue the search and the gather behind them right away, before `shard_step_check` has looked at the rest
+    (the GPU then does not idle while the host decides) - else None."""
+    search, parts, info = engine.shard_step_result(h["res"], h["world"])
+    _, _, converged, _, n_nan, trip, _ = search
+    cnt = int(info[h["rank"], 0])
+    usable = converged and n_nan == 0 and trip is not None and not info[:, 1].any() and 0 < cnt <= h["buf"].numel()
+    return search, parts, info, (h["buf"][:cnt] if usable else None)
+
+
+def shard_step_check(h, search, parts, info):
+    """The decisions `find_beta_sharded` / `resample_owner` take, from the same numbers in the same order (every rank reads the
+    same gathered values, so every rank decides alike).  Returns (ok, m2, s1p, new_counts): `ok` False - search not converged in
+    the rounds enqueued, NaN weights, a weight share outside 1/world (1 +- SHARD_IMBALANCE), a cdf chain that needs the
+    replicated scan, a rank left without offspring - means the caller runs the step phase by phase (which handles or reports
+    each of these); the generator has not been touched."""
+    world = h["world"]
     _, _, converged, _, n_nan, trip, _ = search
     if not converged or n_nan > 0 or trip is None:
-        return search, False, None, None, None, None
+        return False, None, None, None
     m2, s1p = float(parts[0, 0]), float(parts[0, 1])
     for r in range(1, world):  # rank order: the same floats on every rank
         m2, s1p = m2 + float(parts[r, 0]), s1p + float(parts[r, 1])
@@ -583,7 +593,7 @@ def shard_step_finish(engine, comm, h):
     ok = bool(np.all(share * world <= 1.0 + SHARD_IMBALANCE) and np.all(share * world >= 1.0 - SHARD_IMBALANCE))
     new_counts = [int(c) for c in info[:, 0]]
     ok = ok and not info[:, 1].any() and sum(new_counts) == h["n_out"] and min(new_counts) > 0
-    return search, ok, m2, s1p, new_counts, (h["buf"][: new_counts[rank]] if ok else None)
+    return ok, m2, s1p, new_counts
 
 
 def sync_rng(comm, rng):

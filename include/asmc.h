@@ -482,6 +482,11 @@ int asmc_mean_gram_fetch(asmc_ctx* ctx, int d, double* sum_host, double* gram_ho
 int asmc_reference_factor(asmc_ctx* ctx, int d, int64_t n_mean, int64_t n_cov, const double* sum_host, const double* gram_host,
                           double* out_dev, asmc_stream stream);
 int asmc_reference_factor_status(asmc_ctx* ctx, int* status_host);
+/* the generation number of the request just made (1, 2, ...) and the status of that particular request: a caller that keeps
+ * the next temperature's factorisation on the stream behind a mutation asks about the one that served the mutation (valid for
+ * the last 15 requests) */
+int64_t asmc_reference_factor_generation(asmc_ctx* ctx);
+int asmc_reference_factor_status_of(asmc_ctx* ctx, int64_t generation, int* status_host);
 /* The same fit for a sharded population without a host round trip: the rank's column sums / centred Gram matrix (centre =
  * sum_dev / n_mean, i.e. the GLOBAL sums and population once the caller has all-reduced sum_dev) land in the caller's device
  * buffers, the caller sums them over the ranks on the stream (torch.distributed all_reduce = RCCL), and asmc_reference_factor_dev

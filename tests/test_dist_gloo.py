@@ -176,6 +176,27 @@ def _worker(rank, world, port, out_dir, engine_kind="oracle"):
         res["chain_ll"], res["steps_ll"] = eng.to_numpy(new_a.log_likelihood), eng.to_numpy(new_b.log_likelihood)
         res["chain_counts"], res["steps_counts"] = np.array(new_a.shard_counts), np.array(new_b.shard_counts)
         res["chain_rng"] = np.array([rng_a.integers(0, 2**62), rng_b.integers(0, 2**62)])
+        # a step the chain must hand back: rank 1 holds almost all the weight, so the shares leave 1/world (1 +- 25 %) - the
+        # chain runs to its end on the device all the same (nothing hangs, the generator is untouched), reports found = False
+        # and resample() takes the phase-by-phase path to the slot layout
+        rng_c, rng_d = np.random.default_rng(7), np.random.default_rng(7)
+        ll_skew = loc[1] + (400.0 if rank == 1 else 0.0)  # (uneven at ANY beta the search can pick)
+        pop_c = SMCSamples(x=loc[0], log_likelihood=ll_skew, log_prior=loc[2], log_q=loc[3], beta=0.0, xp=torch, engine=eng, comm=comm)
+        took_c = pop_c.speculate_importance_step(0.5, 1e-6, rng_c)
+        spec_c = pop_c.__dict__.get("_spec") or {}
+        res["chain_skew_flags"] = np.array([int(bool(took_c)), int(bool(spec_c.get("found")))])
+        fb_c = smc_math.find_beta_sharded(eng, comm, ll_skew, loc[2], loc[3], 0.0, 0.5, 1e-6, n)  # (what determine_beta does next)
+        pop_c.remember_stats(fb_c[0], smc_math.Stats(*fb_c[5], n))
+        sk_c = pop_c.resample(fb_c[0], rng=rng_c)
+        os.environ["ASMC_SHARD_STEP"] = "0"
+        pop_d = SMCSamples(x=loc[0], log_likelihood=ll_skew, log_prior=loc[2], log_q=loc[3], beta=0.0, xp=torch, engine=eng, comm=comm)
+        fb_d = smc_math.find_beta_sharded(eng, comm, ll_skew, loc[2], loc[3], 0.0, 0.5, 1e-6, n)
+        pop_d.remember_stats(fb_d[0], smc_math.Stats(*fb_d[5], n))
+        sk_d = pop_d.resample(fb_d[0], rng=rng_d)
+        del os.environ["ASMC_SHARD_STEP"]
+        res["chain_skew_beta"] = np.array([fb_c[0], fb_d[0]])
+        res["chain_skew_x"], res["steps_skew_x"] = eng.to_numpy(sk_c.x), eng.to_numpy(sk_d.x)
+        res["chain_skew_rng"] = np.array([rng_c.integers(0, 2**62), rng_d.integers(0, 2**62)])
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()

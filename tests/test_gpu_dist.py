@@ -53,7 +53,7 @@ def test_sharded_sampler_matches_oracle(runs):
 
 
 def test_sharded_step_as_one_chain_equals_the_phase_by_phase_path(runs):
-    """smc_math.shard_step_enqueue / shard_step_finish (search -> moments -> weights -> cdf slice -> draw selection with the
+    """smc_math.shard_step_enqueue / shard_step_wait / shard_step_check (search -> moments -> weights -> cdf slice -> draw selection with the
     scalars left on the device, one synchronisation) against find_beta_sharded + resample_owner (a host decision after every
     phase): bit-identical beta*, evidence variance, ancestors and generator state on both ranks.  Contract:
     /root/reference/src/aspire/samples.py:1221-1287 on the global population."""
@@ -65,3 +65,16 @@ def test_sharded_step_as_one_chain_equals_the_phase_by_phase_path(runs):
         assert np.array_equal(h["chain_x"], h["steps_x"]) and np.array_equal(h["chain_ll"], h["steps_ll"])
         assert h["chain_counts"].tolist() == h["steps_counts"].tolist()
         assert h["chain_rng"][0] == h["chain_rng"][1]
+
+
+def test_sharded_chain_hands_a_step_it_cannot_take_back_to_the_phase_by_phase_path(runs):
+    """Rank 1 holds all the weight (log-likelihood + 400): the search needs more rounds than the chain enqueues and the shares
+    leave 1/world (1 +- 25 %).  The chain still runs to its end on the device (uniform weights behind an unfinished search: every
+    later launch stays well defined, nothing hangs), reports the step as not taken and leaves the generator alone; the search and
+    resample() then go phase by phase exactly as without the chain."""
+    for r in range(2):
+        h = runs["hip"][r]
+        assert h["chain_skew_flags"].tolist() == [1, 0], h["chain_skew_flags"]
+        assert h["chain_skew_beta"][0] == h["chain_skew_beta"][1]
+        assert np.array_equal(h["chain_skew_x"], h["steps_skew_x"])
+        assert h["chain_skew_rng"][0] == h["chain_skew_rng"][1]
