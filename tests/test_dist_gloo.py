@@ -197,6 +197,29 @@ def _worker(rank, world, port, out_dir, engine_kind="oracle"):
         res["chain_skew_beta"] = np.array([fb_c[0], fb_d[0]])
         res["chain_skew_x"], res["steps_skew_x"] = eng.to_numpy(sk_c.x), eng.to_numpy(sk_d.x)
         res["chain_skew_rng"] = np.array([rng_c.integers(0, 2**62), rng_d.integers(0, 2**62)])
+        # the WHOLE sharded sampler with a coupling-flow proposal (the one-kernel flow step, accept counts exchanged through the
+        # Python callback hook): the chain form - enqueued behind the mutation's step loop, factorisation behind its moments -
+        # against the phase-by-phase form (ASMC_SHARD_STEP=0: nothing runs ahead): same schedule, same log Z, same particles
+        from aspire_amd.flows import CouplingFlow
+
+        def flow_run():
+            cf = CouplingFlow(d, n_layers=2, hidden_features=(64, 64), seed=11, dtype=torch.float32, device=eng.device)
+            cf.fit(1.3 * np.random.default_rng(20).normal(size=(400, d)), n_epochs=2)
+            spf = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=cf, xp=torch, engine=eng, comm=comm,
+                         rng=np.random.default_rng(4))
+            post = spf.sample(2048, target_efficiency=0.9, sampler_kwargs=dict(n_steps=4, step_fn="pcn"), store_sample_history=False)
+            return (np.array(spf.history.beta), float(post.log_evidence), np.array(spf.history.mcmc_acceptance),
+                    post.x.detach().cpu().numpy(), spf.last_mutation_path)
+
+        a = flow_run()
+        os.environ["ASMC_SHARD_STEP"] = "0"
+        b = flow_run()
+        del os.environ["ASMC_SHARD_STEP"]
+        res["flow_chain_beta"], res["flow_steps_beta"] = a[0], b[0]
+        res["flow_chain_logz"] = np.array([a[1], b[1]])
+        res["flow_chain_acc"], res["flow_steps_acc"] = a[2], b[2]
+        res["flow_chain_x"], res["flow_steps_x"] = a[3], b[3]
+        res["flow_chain_path"] = np.array([int("device-side step loop" in a[4]), int("device-side step loop" in b[4])])
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()

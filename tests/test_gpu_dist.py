@@ -78,3 +78,16 @@ def test_sharded_chain_hands_a_step_it_cannot_take_back_to_the_phase_by_phase_pa
         assert h["chain_skew_beta"][0] == h["chain_skew_beta"][1]
         assert np.array_equal(h["chain_skew_x"], h["steps_skew_x"])
         assert h["chain_skew_rng"][0] == h["chain_skew_rng"][1]
+
+
+def test_sharded_flow_sampler_chain_form_equals_phase_by_phase_form(runs):
+    """Two ranks, coupling-flow proposal, the one-kernel flow step with the accept counts exchanged through the callback hook:
+    the sampler with the importance step as one chain behind the mutation (and the reference factorisation behind its moments)
+    against ASMC_SHARD_STEP=0, where nothing runs ahead - bit-identical schedule, acceptance history, log Z and particles."""
+    for r in range(2):
+        h = runs["hip"][r]
+        assert h["flow_chain_path"].tolist() == [1, 1]
+        assert np.array_equal(h["flow_chain_beta"], h["flow_steps_beta"]) and len(h["flow_chain_beta"]) >= 3
+        assert np.array_equal(h["flow_chain_acc"], h["flow_steps_acc"])
+        assert h["flow_chain_logz"][0] == h["flow_chain_logz"][1]
+        assert np.array_equal(h["flow_chain_x"], h["flow_steps_x"])
