@@ -154,7 +154,7 @@ struct asmc_ctx {
 int asmc_ref_factor_launch(asmc_ctx* ctx, int d, const double* sum, const double* gram, double n_mean, double denom, double* out,
                            double* status, double* tab, double* em, int it, hipStream_t st);
 int asmc_gram_mm_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* d_center, int* grid_out,
-                        hipStream_t st, double* out2);
+                        hipStream_t st, double* out2, double n_div);
 bool asmc_gram_mm_supported(int d, const void* x);
 int asmc_is_weights_launch(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double beta0,
                            double target_eff, double tol, double* w, double* tiles, double* rec, hipStream_t st);

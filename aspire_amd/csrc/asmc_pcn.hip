@@ -1399,8 +1399,8 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_gram_rb(int64_t n, int d, const 
 
 // one block per column; 64 threads (one wave: the order every caller has always had) or 256 (the gather's column-sum partials:
 // 4 096 rows - 24 us with one wave): strided partial sums, the wave's butterfly, then the waves in order
-// keep / center (optional): the sum also goes to keep[col] (k_keep_moments' copy) and center[col] = sum / n_mean
-// (k_center_from_sum's division) - the reference fit of one rank then needs neither of those launches
+// keep / center (optional): the sum also goes to keep[col] (the copy asmc_reference_factor reads in ctx->d_ref) and
+// center[col] = sum / n_mean (k_center_from_sum's division)
 __global__ __launch_bounds__(256) void k_reduce_columns(int nblocks, int ncols, const double* __restrict__ partials,
                                                        double* __restrict__ out, double* __restrict__ keep = nullptr,
                                                        double* __restrict__ center = nullptr, double n_mean = 1.0) {
@@ -2009,13 +2009,6 @@ __global__ __launch_bounds__(1024) void k_ref_factor(int d, const double* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void k_keep_moments(int d, const double* __restrict__ sum, const double* __restrict__ gram,
-                                                     double* __restrict__ keep) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < d) keep[e] = sum[e];
-    else if (e < d + d * d) keep[128 + e - d] = gram[e - d];
-}
-
 // Column sums and the Gram matrix centred on sum / n_mean in ONE enqueue and one synchronisation (the reference fit of a
 // temperature boundary: the centre never visits the host; same division, same kernels, same bits as asmc_colsum -> host
 // division -> asmc_centered_gram).  _enqueue leaves both results on their way to pinned memory, _fetch waits for the stream
@@ -2045,33 +2038,23 @@ int asmc_mean_gram_enqueue(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const v
     else
         ASMC_LAUNCH(ctx, st, "k_colsum<float>", k_colsum<float>, dim3(grid), dim3(ASMC_BLOCK), ASMC_BLOCK * sizeof(double), st, n, d, (const float*)x, ctx->d_gram);
     ASMC_LAUNCH_CHECK();
-    double* d_center = ctx->d_small + 2048;
-    // the results stay on the device (d_small / d_partials are every call's scratch; ctx->d_ref = {sums [128], Gram}):
-    // asmc_reference_factor reads them there, asmc_mean_gram_fetch copies them out when a caller wants them on the host.
-    // One rank: the reductions write the kept copies and the centre themselves; across ranks the all-reduces sit in between.
+    // the results stay on the device in ctx->d_ref = {sums [128], Gram} (d_small / d_partials are every call's scratch):
+    // asmc_reference_factor reads them there, asmc_mean_gram_fetch copies them out when a caller wants them on the host.  The
+    // reductions write them there themselves, the all-reduces of a sharded run work on them in place, and the Gram kernel forms
+    // the centre sum / n_mean itself: no launch sits between the passes and the collectives.
     ASMC_LAUNCH(ctx, st, "k_reduce_columns", k_reduce_columns, dim3(d), dim3(from_gather ? 256 : 64), 0, st, grid, d,
-                (const double*)ctx->d_gram, ctx->d_small, across_ranks ? (double*)nullptr : ctx->d_ref,
-                across_ranks ? (double*)nullptr : d_center, (double)n_mean);
+                (const double*)ctx->d_gram, ctx->d_small, ctx->d_ref, (double*)nullptr, (double)n_mean);
     ASMC_LAUNCH_CHECK();
-    if (across_ranks) {
-        if (allreduce(ctx->d_small, ctx->d_small, (size_t)d, nccl_f64, nccl_sum, ctx->rccl_comm, st) != 0) {
-            asmc_set_error("asmc_mean_gram: ncclAllReduce failed");
-            return ASMC_ERR_ARG;
-        }
-        ASMC_LAUNCH(ctx, st, "k_center_from_sum", k_center_from_sum, dim3(1), dim3(128), 0, st, d, (const double*)ctx->d_small, (double)n_mean, d_center);
-        ASMC_LAUNCH_CHECK();
+    if (across_ranks && allreduce(ctx->d_ref, ctx->d_ref, (size_t)d, nccl_f64, nccl_sum, ctx->rccl_comm, st) != 0) {
+        asmc_set_error("asmc_mean_gram: ncclAllReduce failed");
+        return ASMC_ERR_ARG;
     }
     int ggrid = 0;
-    int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &ggrid, st, across_ranks ? (double*)nullptr : ctx->d_ref + 128);
+    int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, ctx->d_ref, &ggrid, st, ctx->d_ref + 128, (double)n_mean);
     if (rc) return rc;
-    if (across_ranks) {
-        if (allreduce(ctx->d_partials, ctx->d_partials, (size_t)d * d, nccl_f64, nccl_sum, ctx->rccl_comm, st) != 0) {
-            asmc_set_error("asmc_mean_gram: ncclAllReduce failed");
-            return ASMC_ERR_ARG;
-        }
-        ASMC_LAUNCH(ctx, st, "k_keep_moments", k_keep_moments, dim3((d * d + d + 255) / 256), dim3(256), 0, st, d, (const double*)ctx->d_small,
-                    (const double*)ctx->d_partials, ctx->d_ref);
-        ASMC_LAUNCH_CHECK();
+    if (across_ranks && allreduce(ctx->d_ref + 128, ctx->d_ref + 128, (size_t)d * d, nccl_f64, nccl_sum, ctx->rccl_comm, st) != 0) {
+        asmc_set_error("asmc_mean_gram: ncclAllReduce failed");
+        return ASMC_ERR_ARG;
     }
     ctx->gram_pending_d = d;
     return ASMC_OK;
@@ -2190,7 +2173,7 @@ int asmc_centered_gram_dev(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const v
     ASMC_LAUNCH(ctx, st, "k_center_from_sum", k_center_from_sum, dim3(1), dim3(128), 0, st, d, sum_dev, (double)n_mean, d_center);
     ASMC_LAUNCH_CHECK();
     int ggrid = 0;
-    const int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &ggrid, st, nullptr);
+    const int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &ggrid, st, nullptr, 0.0);
     if (rc) return rc;
     ASMC_LAUNCH(ctx, st, "k_copy_doubles", k_copy_doubles, dim3((d * d + 255) / 256), dim3(256), 0, st, d * d, (const double*)ctx->d_partials,
                 gram_dev);
@@ -2260,7 +2243,7 @@ int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
     double* d_out = ctx->d_partials;
     if (asmc_gram_mm_supported(d, x) && ctx->d_max >= d && !getenv("ASMC_GRAM_GENERIC")) {  // fp64 MFMA (asmc_pcn_mm.hip)
         int grid = 0;
-        int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &grid, st, nullptr);
+        int rc = asmc_gram_mm_launch(ctx, n, d, x_dtype, x, d_center, &grid, st, nullptr, 0.0);
         if (rc) return rc;
         ASMC_HIP(hipMemcpyAsync(gram_host, d_out, sizeof(double) * d * d, hipMemcpyDeviceToHost, st));
         ASMC_HIP(hipStreamSynchronize(st));
@@ -2293,7 +2276,7 @@ int asmc_centered_gram(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
                 ASMC_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows<float>, dim3(pg), dim3(ASMC_BLOCK), 0, st, n, d, D, (const float*)x, (float*)ctx->d_xpad);
             ASMC_LAUNCH_CHECK();
             int grid = 0;
-            int rc = asmc_gram_mm_launch(ctx, n, D, x_dtype, ctx->d_xpad, d_center, &grid, st, nullptr);
+            int rc = asmc_gram_mm_launch(ctx, n, D, x_dtype, ctx->d_xpad, d_center, &grid, st, nullptr, 0.0);
             if (rc) return rc;
             ASMC_HIP(hipMemcpy2DAsync(gram_host, sizeof(double) * d, d_out, sizeof(double) * D, sizeof(double) * d, d,
                                       hipMemcpyDeviceToHost, st));

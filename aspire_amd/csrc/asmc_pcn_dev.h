@@ -461,4 +461,4 @@ int asmc_pcn_mm_launch(asmc_ctx* ctx, int64_t n, int x_dtype, void* x, double* l
                        hipStream_t st);
 bool asmc_gram_mm_supported(int d, const void* x);
 int asmc_gram_mm_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* d_center, int* grid_out,
-                        hipStream_t st, double* out2);
+                        hipStream_t st, double* out2, double n_div);

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
 
 template <typename T, int D>
 __global__ __launch_bounds__(64 * (D / 32)) void k_gram_mm(int64_t n, const T* __restrict__ x,
-                                                          const double* __restrict__ center,
+                                                          const double* __restrict__ center, double n_div,
                                                           double* __restrict__ partials) {
     extern __shared__ __align__(16) double tile[];
     constexpr int NB = D / 16, NT = 64 * (D / 32), STRIDE = D + 16;
@@ -373,6 +373,15 @@ __global__ __launch_bounds__(64 * (D / 32)) void k_gram_mm(int64_t n, const T* _
             nxt[q] = (t0 + r < n) ? x[(t0 + r) * D + c] : (T)0;
         }
     };
+    // n_div > 0: `center` holds column SUMS and the centre is sum / n_div (k_center_from_sum's division, done here: the
+    // reference fit needs no launch between the sums' all-reduce and this kernel)
+    double cen[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int e = q * NT + threadIdx.x;
+        const double cv = center[e % D];
+        cen[q] = n_div > 0.0 ? cv / n_div : cv;
+    }
     const int64_t tstride = (int64_t)gridDim.x * GRAM_TP;
     fetch((int64_t)blockIdx.x * GRAM_TP);
     for (int64_t t0 = (int64_t)blockIdx.x * GRAM_TP; t0 < n; t0 += tstride) {
@@ -381,7 +390,7 @@ __global__ __launch_bounds__(64 * (D / 32)) void k_gram_mm(int64_t n, const T* _
         for (int q = 0; q < PER; q++) {
             const int e = q * NT + threadIdx.x;
             const int r = e / D, c = e - r * D;
-            tile[r * STRIDE + c] = (t0 + r < n) ? (double)nxt[q] - center[c] : 0.0;
+            tile[r * STRIDE + c] = (t0 + r < n) ? (double)nxt[q] - cen[q] : 0.0;
         }
         __syncthreads();
         if (t0 + tstride < n) fetch(t0 + tstride);
@@ -428,13 +437,13 @@ __global__ __launch_bounds__(64 * (D / 32)) void k_gram_mm(int64_t n, const T* _
 // order per accumulator as k_gram_mm<T, D>: the same bits.
 template <typename T, int D>
 __global__ __launch_bounds__(64) void k_gram_stream(int64_t n, const T* __restrict__ x, const double* __restrict__ center,
-                                                   double* __restrict__ partials) {
+                                                   double n_div, double* __restrict__ partials) {
     constexpr int NB = D / 16, U = D == 32 ? 8 : 4, TRIPS = 8 / U;  // U groups of four particles per fetch; 32 rows per tile
     constexpr int NACC = NB * (NB + 1) / 2;
     const int lane = threadIdx.x, kq = lane >> 4, ci = lane & 15;
     double cen[NB];
 #pragma unroll
-    for (int b = 0; b < NB; b++) cen[b] = center[16 * b + ci];
+    for (int b = 0; b < NB; b++) cen[b] = n_div > 0.0 ? center[16 * b + ci] / n_div : center[16 * b + ci];  // (see k_gram_mm)
     doublex4 acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = doublex4{0.0, 0.0, 0.0, 0.0};
@@ -513,7 +522,7 @@ __global__ __launch_bounds__(1024) void k_gram_mm_reduce(int nblocks, int ncols,
         double t = 0.0;
         for (int q = 0; q < 64; q++) t += s[q][c];
         out[col] = t;
-        if (out2) out2[col] = t;  // (the copy asmc_reference_factor reads: no k_keep_moments launch on one rank)
+        if (out2) out2[col] = t;  // (the copy asmc_reference_factor reads, ctx->d_ref + 128)
     }
 }
 
@@ -524,7 +533,7 @@ bool asmc_gram_mm_supported(int d, const void* x) {
 
 // enqueues the Gram kernel and the reduction of its per-block partial matrices; the d x d result lands in ctx->d_partials
 int asmc_gram_mm_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void* x, const double* d_center, int* grid_out,
-                        hipStream_t st, double* out2) {
+                        hipStream_t st, double* out2, double n_div) {
     int grid = (int)((n + GRAM_TP - 1) / GRAM_TP);
     // d = 32: one wave per block, so eight blocks per CU are needed to keep enough loads in flight
     static const int per_cu32 = getenv("ASMC_GRAM32_PER_CU") ? atoi(getenv("ASMC_GRAM32_PER_CU")) : 8;
@@ -534,17 +543,17 @@ int asmc_gram_mm_launch(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void
     *grid_out = grid;
     const size_t lds = (size_t)GRAM_TP * (d + 16) * sizeof(double);
 #define GRAM_CASE(TT, DD) \
-    ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_mm<TT, DD>), dim3(grid), dim3(64 * (DD / 32)), lds, st, n, (const TT*)x, d_center, ctx->d_gram)
+    ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_mm<TT, DD>), dim3(grid), dim3(64 * (DD / 32)), lds, st, n, (const TT*)x, d_center, n_div, ctx->d_gram)
     static const bool lds_tile = getenv("ASMC_GRAM_LDS32") != nullptr;  // (the LDS-tile kernel at d = 32 / 64, for comparison)
     if ((d == 32 || d == 64) && !lds_tile) {
         if (x_dtype == ASMC_F64 && d == 32)
-            ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_stream<double, 32>), dim3(grid), dim3(64), 0, st, n, (const double*)x, d_center, ctx->d_gram);
+            ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_stream<double, 32>), dim3(grid), dim3(64), 0, st, n, (const double*)x, d_center, n_div, ctx->d_gram);
         else if (x_dtype == ASMC_F64)
-            ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_stream<double, 64>), dim3(grid), dim3(64), 0, st, n, (const double*)x, d_center, ctx->d_gram);
+            ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_stream<double, 64>), dim3(grid), dim3(64), 0, st, n, (const double*)x, d_center, n_div, ctx->d_gram);
         else if (d == 32)
-            ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_stream<float, 32>), dim3(grid), dim3(64), 0, st, n, (const float*)x, d_center, ctx->d_gram);
+            ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_stream<float, 32>), dim3(grid), dim3(64), 0, st, n, (const float*)x, d_center, n_div, ctx->d_gram);
         else
-            ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_stream<float, 64>), dim3(grid), dim3(64), 0, st, n, (const float*)x, d_center, ctx->d_gram);
+            ASMC_LAUNCH(ctx, st, "k_gram_mm", (k_gram_stream<float, 64>), dim3(grid), dim3(64), 0, st, n, (const float*)x, d_center, n_div, ctx->d_gram);
     } else if (x_dtype == ASMC_F64) {
         if (d == 128) GRAM_CASE(double, 128);
         else if (d == 64) GRAM_CASE(double, 64);

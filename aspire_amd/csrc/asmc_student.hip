@@ -279,7 +279,7 @@ int asmc_student_fit(asmc_ctx* ctx, int64_t m, int d, const double* xs, int max_
                     (const double*)d_tab, r_scratch, (const double*)d_em, it);
         ASMC_LAUNCH_CHECK();
         int ggrid = 0;
-        rc = asmc_gram_mm_launch(ctx, m, d, ASMC_F64, r_scratch, d_zero, &ggrid, st, nullptr);
+        rc = asmc_gram_mm_launch(ctx, m, d, ASMC_F64, r_scratch, d_zero, &ggrid, st, nullptr, 0.0);
         if (rc) return rc;
         ASMC_LAUNCH(ctx, st, "k_student_keep", k_student_keep, dim3((d * d + 255) / 256), dim3(256), 0, st, d, (const double*)ctx->d_partials,
                     ctx->d_ref + 128, (const double*)d_em, it);
