@@ -38,10 +38,13 @@ __device__ __forceinline__ double pcn_adapt_rho(double rho, long long c, int64_t
 // =============================================================================================
 // Philox4x32-10 (Salmon et al. SC'11; Random123 constants) and Box-Muller
 // =============================================================================================
+#ifndef ASMC_PHILOX_ROUNDS
+#define ASMC_PHILOX_ROUNDS 10  // (the specification; other values exist for timing experiments only: tools/build_variant.sh)
+#endif
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < ASMC_PHILOX_ROUNDS; r++) {
 #ifdef ASMC_PHILOX_MULHI  // (round 1-3 form: two multiply instructions per product)
         const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;

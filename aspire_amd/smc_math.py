@@ -572,7 +572,9 @@ def shard_step_wait(engine, comm, h):
     search, parts, info = engine.shard_step_result(h["res"], h["world"])
     _, _, converged, _, n_nan, trip, _ = search
     cnt = int(info[h["rank"], 0])
-    usable = converged and n_nan == 0 and trip is not None and not info[:, 1].any() and 0 < cnt <= h["buf"].numel()
+    # (a rank-UNIFORM condition - every rank reads the same gathered numbers: what follows contains collectives)
+    usable = (converged and n_nan == 0 and trip is not None and not info[:, 1].any()
+              and int(info[:, 0].min()) > 0 and int(info[:, 0].max()) <= h["buf"].numel())
     return search, parts, info, (h["buf"][:cnt] if usable else None)
 
 
