@@ -605,9 +605,11 @@ def sync_rng(comm, rng):
     if not comm.sharded:
         return rng
     st = pcg64_state(rng)
-    has = comm.all_gather_i64(np.array([0 if st is None else 1], dtype=np.int64))[:, 0]
-    if has.all():
-        words = comm.all_gather_i64(st.view(np.int64))[0].view(np.uint64)
+    # one exchange: {is PCG64, the four state words} of every rank
+    mine = np.concatenate([[0 if st is None else 1], (st.view(np.int64) if st is not None else np.zeros(4, dtype=np.int64))]).astype(np.int64)
+    allst = comm.all_gather_i64(mine)
+    if allst[:, 0].all():
+        words = np.ascontiguousarray(allst[0, 1:]).view(np.uint64)
         state = rng.bit_generator.state
         state["state"]["state"] = (int(words[0]) << 64) | int(words[1])
         state["state"]["inc"] = (int(words[2]) << 64) | int(words[3])

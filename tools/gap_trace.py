@@ -43,11 +43,14 @@ if bound:
           f"{sum(b[0] for b in bound) / m / 1e3:.0f} us, busy {sum(b[1] for b in bound) / m / 1e3:.0f} us")
 
 import os
+if os.environ.get("ALL") and bound:  # the distribution: wall us / busy us / launches of every boundary, sorted by wall
+    print("all boundaries (wall/busy/launches):", " ".join(f"{b[0] / 1e3:.0f}/{b[1] / 1e3:.0f}/{b[2]}" for b in bound))
 if os.environ.get("TIMELINE") and timelines:
     timelines = [t for t in timelines if t[0] < 20e6]
     timelines.sort(key=lambda t: t[0])
-    wall, t0, ks = timelines[len(timelines) // 2]
-    print(f"-- the median boundary ({wall / 1e3:.0f} us): start offset, duration, idle before, kernel")
+    which = len(timelines) * 9 // 10 if os.environ.get("TIMELINE") == "p90" else len(timelines) // 2
+    wall, t0, ks = timelines[which]
+    print(f"-- the {'90th-percentile' if which != len(timelines) // 2 else 'median'} boundary ({wall / 1e3:.0f} us): start offset, duration, idle before, kernel")
     prev = t0
     for s_, e_, n_ in ks:
         print(f"{(s_ - t0) / 1e3:8.1f} {(e_ - s_) / 1e3:7.1f} {(s_ - prev) / 1e3:7.1f}  {n_.split('(')[0][:70]}")

@@ -10,6 +10,7 @@ for k in single sharded; do
   rocprofv3 --kernel-trace --stats -d /tmp/trace_$k -o bench --output-format csv -- python3 $R/bench.py --no-extra --no-cpu-baseline --steps 5 --warmup 2 $F > $O/$k.log 2>&1
   cp /tmp/trace_$k/bench_kernel_stats.csv $O/${k}_kernel_stats.csv
   TIMELINE=1 python3 $R/tools/gap_trace.py /tmp/trace_$k/bench_kernel_trace.csv > $O/${k}_gaps.txt 2>&1
+  ALL=1 TIMELINE=p90 python3 $R/tools/gap_trace.py /tmp/trace_$k/bench_kernel_trace.csv > $O/${k}_gaps_p90.txt 2>&1
 done
 [ -z "$NO_RIG" ] && bash $R/tools/rig1.sh
 cat $O/*_gaps.txt
