@@ -173,6 +173,26 @@ def _worker_eight(rank, world, port, out_dir):
     pop2 = SMCSamples(x=x, log_likelihood=ll, log_prior=zero.clone(), log_q=zero.clone(), beta=0.0, xp=torch, engine=eng, comm=comm)
     new2, _ = pop2.resample(0.25, rng=np.random.default_rng(4), want_variance=True)
     res["ht_ll"], res["ht_x"], res["ht_ragged"] = eng.to_numpy(ll), eng.to_numpy(new2.x), np.array([int(bool(new2.__dict__.get("ragged")))])
+    # (iii) the importance step as ONE chain (smc_math.shard_step_enqueue) over eight shards, twice: from equal shards, then from
+    # the ragged population the first step leaves (gid offsets, ragged tile lists, the incoming cdf sums of seven lower ranks)
+    ll3 = -4.0 * (x * x).sum(1)  # (sharp enough for two temperatures below beta = 1)
+    pop3 = SMCSamples(x=x, log_likelihood=ll3, log_prior=zero.clone(), log_q=zero.clone(), beta=0.0, xp=torch, engine=eng, comm=comm)
+    rng3 = np.random.default_rng(5)
+    took = pop3.speculate_importance_step(0.5, 1e-6, rng3)
+    spec = pop3.__dict__.get("_spec") or {}
+    b3 = float(spec.get("beta", -1.0))
+    pop3.remember_stats(b3, smc_math.Stats(*spec["search"][5], n))
+    new3, var3 = pop3.resample(b3, rng=rng3, want_variance=True)
+    res["ch_flags"] = np.array([int(bool(took)), int(bool(spec.get("found"))), int(bool(new3.__dict__.get("ragged")))])
+    res["ch_beta"], res["ch_ll"], res["ch_x"], res["ch_var"] = np.array([b3]), eng.to_numpy(ll3), eng.to_numpy(new3.x), np.array([var3])
+    res["ch_counts"] = np.array(new3.shard_counts)
+    took2 = new3.speculate_importance_step(0.5, 1e-6, rng3)
+    spec2 = new3.__dict__.get("_spec") or {}
+    b4 = float(spec2.get("beta", -1.0))
+    new3.remember_stats(b4, smc_math.Stats(*spec2["search"][5], n))
+    new4 = new3.resample(b4, rng=rng3)
+    res["ch2_flags"] = np.array([int(bool(took2)), int(bool(spec2.get("found")))])
+    res["ch2_beta"], res["ch2_ll_in"], res["ch2_x"] = np.array([b4]), eng.to_numpy(new3.log_likelihood), eng.to_numpy(new4.x)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -199,3 +219,25 @@ def test_eight_ranks_on_one_gpu_owner_layout_equals_generator_choice(oracle, tmp
             assert np.array_equal(res["ht_x"], x[ref2[(ref2 >= edges[r]) & (ref2 < edges[r + 1])]])
     else:  # weight shares outside +-25 %: the slot layout, draw order over equal shards
         assert np.array_equal(np.concatenate([res["ht_x"] for res in rs]), x[ref2])
+    # (iii) the one-chain step: beta* identical on every rank, the ancestors Generator.choice picks at that beta, by owner, in
+    # draw order; then the same from the ragged population (concatenated rank-major), continuing the same generator
+    for res in rs:
+        assert res["ch_flags"].tolist() == [1, 1, 1] and res["ch2_flags"].tolist() == [1, 1]
+        assert res["ch_beta"][0] == rs[0]["ch_beta"][0] and res["ch2_beta"][0] == rs[0]["ch2_beta"][0]
+        assert res["ch_var"][0] == rs[0]["ch_var"][0]
+    b3 = float(rs[0]["ch_beta"][0])
+    ll3 = np.concatenate([r["ch_ll"] for r in rs])
+    g5 = np.random.default_rng(5)
+    ref3 = g5.choice(n, size=n, replace=True, p=oracle.normalized_weights(ll3, zero, zero, 0.0, b3))
+    for r, res in enumerate(rs):
+        assert np.array_equal(res["ch_x"], x[ref3[(ref3 >= edges[r]) & (ref3 < edges[r + 1])]])
+        assert res["ch_counts"].tolist() == [int(((ref3 >= edges[q]) & (ref3 < edges[q + 1])).sum()) for q in range(world)]
+    assert float(rs[0]["ch_var"][0]) == pytest.approx(oracle.log_evidence_ratio_variance(ll3, zero, zero, 0.0, b3), rel=1e-10)
+    x2 = np.concatenate([r["ch_x"] for r in rs])
+    ll_in = np.concatenate([r["ch2_ll_in"] for r in rs])
+    np.testing.assert_allclose(ll_in, -4.0 * (x2 * x2).sum(1), rtol=1e-13)  # (the gathered values travel with their rows)
+    b4 = float(rs[0]["ch2_beta"][0])
+    ref4 = g5.choice(n, size=n, replace=True, p=oracle.normalized_weights(ll_in, zero, zero, b3, b4))
+    edges2 = np.concatenate([[0], np.cumsum(rs[0]["ch_counts"])])
+    for r, res in enumerate(rs):
+        assert np.array_equal(res["ch2_x"], x2[ref4[(ref4 >= edges2[r]) & (ref4 < edges2[r + 1])]])
