@@ -461,6 +461,7 @@ class HipSMC(SMCSampler):
         """Population mean and covariance (ddof=1) over ALL ranks -> (mu, L, Linv) on device.  `moments`: what the fused
         importance step parked for exactly these rows (`SMCSamples.speculate_importance_step`)."""
         e, comm = self.engine, self.comm
+        self.__dict__.pop("_ref_fit_generation", None)  # (set below / by _fit_reference for the request THIS fit makes or takes over)
         n = n_global or x.shape[0] * comm.world
         device_fit = hasattr(e, "reference_factor") and x.shape[1] <= 128 and not os.environ.get("ASMC_HOST_REFERENCE_FIT")
         if (moments is not None and moments[0] == x.data_ptr() and moments[1] == tuple(x.shape)
