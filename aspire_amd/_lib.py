@@ -26,7 +26,7 @@ COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
-ASMC_ABI_VERSION = 19
+ASMC_ABI_VERSION = 20
 ASMC_FLOW_COUPLING, ASMC_FLOW_MAF = 0, 1  # asmc_coupling.kind
 ASMC_CDF_REC = 9
 ASMC_CDF_STATE = 36
@@ -154,7 +154,9 @@ SIGNATURES = {
     "asmc_cdf_shard_finish_select": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "asmc_weights_m2_lse_shard": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i64, _d, _d, _d, _i, _vp]),
     "asmc_find_beta_shard_round": (_i, [_vp, _i64, _vp, _vp, _vp, _d, _d, _d, _i, _i64, _i, _vp, _vp, _vp]),
-    "asmc_normalized_weights_shard": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
+    "asmc_normalized_weights_shard": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _i, _vp]),
+    "asmc_rec_token": (_i64, [_vp]),
+    "asmc_rec_claim": (_i, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "asmc_shard_step_result": (_i, [_vp, _vp, _i, _pd, _vp]),
     "asmc_cdf_shard_chain": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _vp, _vp]),
     "asmc_cdf_shard_finish": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),

@@ -68,6 +68,8 @@ void asmc_prof_end(asmc_ctx* ctx, hipStream_t st);
         }                                                                                   \
     } while (0)
 
+// fused flow step's counters (2 * ASMC_MAX_PCN_STEPS + 4 words), rounded to 256 bytes: ctx->d_flags starts right behind them
+#define ASMC_TILECTR_BYTES ((sizeof(unsigned int) * (2 * ASMC_MAX_PCN_STEPS + 4) + 255) / 256 * 256)
 struct asmc_ctx {
     int device;
     int64_t n_max;
@@ -81,7 +83,7 @@ struct asmc_ctx {
     long long* d_tiles_i;          // [n_tiles_max * 8 + 64] integer tile records (exact cdf: info + split; compaction)
     double* d_gram;                // [gram_blocks * d_max * d_max] gram partials
     unsigned int* d_guide;         // [n_max / 4 + 8] guide table of the resampling search
-    unsigned char* d_flags;        // [n_max + 64] accept flags of the split-path pCN step
+    unsigned char* d_flags;        // [n_max + 64] accept flags of the split-path pCN step (inside d_tilectr's allocation, behind the counters)
     double* d_gamma;               // [ASMC_GAMMA_BATCH][n_max] tpCN scale variates of the current steps
     // which steps' variates ctx->d_gamma holds (pcn_prepare_gamma)
     int64_t gam_n;
@@ -92,6 +94,10 @@ struct asmc_ctx {
     double* d_rec;                 // [4 * n_max] (ll, lp, lq, 0) records of asmc_gather's source population
     const void* rec_src[3];        // the arrays asmc_importance_step packed into d_rec (k_is_weights writes the records on
     int64_t rec_n;                 //   its way); rec_n != 0: still valid - the next asmc_gather of exactly these skips its packing pass
+    uint64_t rec_token;            // generation of d_rec's contents (every pass that writes d_rec bumps it) ...
+    const void* rec_hold_src[3];   // ... and the arrays / count / generation of a pack that asmc_normalized_weights_shard did on its
+    int64_t rec_hold_n;            //   way: asmc_rec_claim(token) re-validates it for the next asmc_gather when nothing has
+    uint64_t rec_hold_token;       //   rewritten d_rec since (the launches in between - the chain's, the search's - do not touch it)
     const void* cs_x;              // the fp64 rows asmc_gather wrote last, whose column-sum partials sit in d_gram [cs_grid][cs_d]
     int64_t cs_n;                  //   (cs_n != 0: still there - an asmc_mean_gram_enqueue of exactly these rows skips its k_colsum pass)
     int cs_d, cs_grid;

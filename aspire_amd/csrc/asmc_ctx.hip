@@ -168,7 +168,9 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     c->d_max_pad = d_max <= 4 ? 4 : d_max <= 8 ? 8 : d_max <= 16 ? 16 : d_max <= 32 ? 32 : d_max <= 64 ? 64 : d_max <= 128 ? 128 : 0;
     if (d_max > 32) dmalloc((void**)&c->d_mmtab, sizeof(double) * 2 * 144 * 64);  // (d in 33 .. 63 runs zero-padded on the d = 64 kernels)
     dmalloc((void**)&c->d_guide, sizeof(unsigned int) * ((size_t)n_max / 4 + 8));
-    dmalloc((void**)&c->d_flags, (size_t)n_max + 64);
+    // the fused flow step's counters sit directly in FRONT of the flag bytes: one memset clears both (asmc_pcn_mutate_flow)
+    dmalloc((void**)&c->d_tilectr, ASMC_TILECTR_BYTES + (size_t)n_max + 64);
+    c->d_flags = c->d_tilectr ? reinterpret_cast<unsigned char*>(c->d_tilectr) + ASMC_TILECTR_BYTES : nullptr;
     dmalloc((void**)&c->d_gamma, sizeof(double) * ((size_t)ASMC_GAMMA_BATCH * (size_t)n_max + 64 * ASMC_GAMMA_BATCH));
     dmalloc((void**)&c->d_rec, sizeof(double) * 4 * (size_t)n_max);
     const size_t student = (size_t)d_max * (d_max + 1) + (size_t)(ASMC_STUDENT_MAX_ROWS / 64) * (d_max + 2);
@@ -176,8 +178,7 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_student, sizeof(double) * student, hipHostMallocDefault);
     dmalloc((void**)&c->d_counts, sizeof(long long) * (size_t)(ASMC_MAX_PCN_STEPS + ASMC_MAX_BLOCKS + n_max / 64 + 8));
     dmalloc((void**)&c->d_rho, sizeof(double) * (ASMC_MAX_PCN_STEPS + 8));
-    dmalloc((void**)&c->d_tilectr, sizeof(unsigned int) * (2 * ASMC_MAX_PCN_STEPS + 4));
-    if (e == hipSuccess) e = hipMemset(c->d_tilectr, 0, sizeof(unsigned int) * (2 * ASMC_MAX_PCN_STEPS + 4));
+    if (e == hipSuccess) e = hipMemset(c->d_tilectr, 0, ASMC_TILECTR_BYTES);
     dmalloc((void**)&c->d_bar, sizeof(unsigned int) * 1024 * 17);
     if (e == hipSuccess) e = hipMemset(c->d_bar, 0, sizeof(unsigned int) * 1024 * 17);
     dmalloc((void**)&c->d_pcgtab, sizeof(unsigned long long) * (64 * 4 + 8));
@@ -212,7 +213,6 @@ int asmc_ctx_destroy(asmc_ctx* c) {
     (void)hipFree(c->d_gram);
     if (c->d_mmtab) (void)hipFree(c->d_mmtab);
     (void)hipFree(c->d_guide);
-    (void)hipFree(c->d_flags);
     (void)hipFree(c->d_gamma);
     (void)hipFree(c->d_student);
     if (c->h_student) (void)hipHostFree(c->h_student);

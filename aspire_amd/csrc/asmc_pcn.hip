@@ -3159,9 +3159,9 @@ static int pcn_mutate_flow_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, d
         }
         // counters of the fused steps: [t] tile hand-out, [ASMC_MAX_PCN_STEPS + t] blocks done
         // (sizes in multiples of 16 bytes: a ragged memset is two fill kernels)
-        if (fused) ASMC_HIP(hipMemsetAsync(ctx->d_tilectr, 0, sizeof(unsigned int) * (2 * ASMC_MAX_PCN_STEPS + 4), st));
-        if (fused) {  // every tile starts in half 0 of the state allocation (tile parities: the split path's flag bytes are free here)
-            ASMC_HIP(hipMemsetAsync(ctx->d_flags, 0, ((size_t)((n + 63) / 64) + 15) / 16 * 16, st));
+        if (fused) {  // ... and every tile starts in half 0 of the state allocation (tile parities: the split path's flag bytes,
+            // free here, which sit right behind the counters: ONE fill)
+            ASMC_HIP(hipMemsetAsync(ctx->d_tilectr, 0, ASMC_TILECTR_BYTES + ((size_t)((n + 63) / 64) + 15) / 16 * 16, st));
             pd.tile_par = ctx->d_flags;
         }
         for (int t = 0; t < (fused ? n_steps : 0); t++) {

@@ -1999,6 +1999,7 @@ int asmc_importance_step(asmc_ctx* ctx, int64_t n, const double* ll, const doubl
     static const bool no_rec = getenv("ASMC_IS_NO_RECORDS") != nullptr;
     rc = asmc_is_weights_launch(ctx, n, ll, lp, lq, beta0, target_eff, tol, w_scratch, ctx->d_tiles, no_rec ? nullptr : ctx->d_rec, st);
     if (rc) return rc;
+    if (!no_rec) ctx->rec_token++;  // (d_rec rewritten)
     // 2-4: numpy's sequential cumsum / cdf[-1] (passes C, D, E of asmc_cdf; the tile prefixes ride on pass C while
     // there are few tiles), pass E also filling the search's guide table
     const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
@@ -2042,6 +2043,19 @@ int asmc_importance_step(asmc_ctx* ctx, int64_t n, const double* ll, const doubl
     return ASMC_OK;
 }
 
+// The (ll, lp, lq, 0) records that asmc_normalized_weights_shard packed on its way (pack_records = 1) become the next asmc_gather's
+// records if `token` (asmc_rec_token right after that call) is still d_rec's generation, i.e. no other pass has rewritten d_rec
+// since, and the arrays are the ones packed.  Returns 1 when claimed, 0 otherwise (the gather then packs for itself).  Call it
+// directly in front of asmc_gather: any launch in between drops the claim again.
+int64_t asmc_rec_token(asmc_ctx* ctx) { return ctx ? (int64_t)ctx->rec_token : -1; }
+int asmc_rec_claim(asmc_ctx* ctx, int64_t token, int64_t n, const double* ll, const double* lp, const double* lq) {
+    if (!ctx || token <= 0 || (uint64_t)token != ctx->rec_token || ctx->rec_hold_token != (uint64_t)token || ctx->rec_hold_n != n ||
+        ctx->rec_hold_src[0] != ll || ctx->rec_hold_src[1] != lp || ctx->rec_hold_src[2] != lq)
+        return 0;
+    ctx->rec_src[0] = ll, ctx->rec_src[1] = lp, ctx->rec_src[2] = lq, ctx->rec_n = n;
+    return 1;
+}
+
 int asmc_gather(asmc_ctx* ctx, int64_t n_in, int64_t n_out, const int64_t* idx, int d, int x_dtype, const void* x_in,
                 void* x_out, const double* ll_in, const double* lp_in, const double* lq_in,
                 double* ll_out, double* lp_out, double* lq_out, asmc_stream stream) {
@@ -2058,6 +2072,7 @@ int asmc_gather(asmc_ctx* ctx, int64_t n_in, int64_t n_out, const int64_t* idx, 
         ASMC_LAUNCH(ctx, st, "k_pack_records", k_pack_records, dim3(grid_for(n_in, ASMC_BLOCK * 2, ASMC_MAX_BLOCKS * 2)), dim3(ASMC_BLOCK), 0, st,
                     n_in, ll_in, lp_in, lq_in, r);
         ASMC_LAUNCH_CHECK();
+        ctx->rec_token++;  // (d_rec rewritten)
         rec = r;
     }
     const size_t elem = x_dtype == ASMC_F64 ? 8 : 4;

@@ -25,6 +25,10 @@ struct BetaPack {
     double shift[KT];  // additive shift applied before subtracting m
 };
 
+// self-resetting arrival counters in ctx->d_bar (zeroed at creation), behind the persistent kernel's barrier counters
+#define SHARD_TICKET_CELL (1024 * 12)
+#define COUNT_TICKET_CELL (1024 * 12 + 64)
+
 __device__ __forceinline__ double lw_of(double ll, double lp, double lq, double c1, double c2) {
     // (self.beta - beta) * log_q + (beta - self.beta) * (log_likelihood + log_prior)
     double t1 = c1 * lq;
@@ -228,8 +232,11 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_weights_map(int64_t n, const dou
     }
 }
 
+// NaN / inf census of v.  The blocks leave their counts in `partials` and the block that arrives last adds them up and WRITES
+// counters[0..1] (k_bis_sums' hand-off on a counter that resets itself): no memset in front of the kernel, no atomics on the result.
 __global__ __launch_bounds__(ASMC_BLOCK) void k_count_nonfinite(int64_t n, const double* __restrict__ v,
-                                                               unsigned long long* __restrict__ counters) {
+                                                               unsigned long long* __restrict__ counters,
+                                                               unsigned long long* partials, unsigned int* ticket) {
     long long n_nan = 0, n_inf = 0;
     const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) {
@@ -239,12 +246,37 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_count_nonfinite(int64_t n, const
         else if (isinf(x))
             n_inf++;
     }
+    __shared__ long long s_c[ASMC_BLOCK / 64][2];
+    __shared__ int s_last;
     n_nan = wave_sum_ll(n_nan);
     n_inf = wave_sum_ll(n_inf);
-    if ((threadIdx.x & 63) == 0) {
-        if (n_nan) atomicAdd(&counters[0], (unsigned long long)n_nan);
-        if (n_inf) atomicAdd(&counters[1], (unsigned long long)n_inf);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6][0] = n_nan, s_c[threadIdx.x >> 6][1] = n_inf;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long a = 0, b = 0;
+        for (int w = 0; w < ASMC_BLOCK / 64; w++) a += s_c[w][0], b += s_c[w][1];
+        partials[2 * blockIdx.x] = (unsigned long long)a;
+        partials[2 * blockIdx.x + 1] = (unsigned long long)b;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1u);
+        if (s_last) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    long long a = 0, b = 0;
+    for (int k = threadIdx.x; k < (int)gridDim.x; k += 64) {
+        a += (long long)__hip_atomic_load(&partials[2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b += (long long)__hip_atomic_load(&partials[2 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    a = wave_sum_ll(a);
+    b = wave_sum_ll(b);
+    if (threadIdx.x == 0) counters[0] = (unsigned long long)a, counters[1] = (unsigned long long)b;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1097,7 +1129,6 @@ __global__ __launch_bounds__(BIS_THREADS) void k_bis_decide(const double* __rest
 // Sharded importance step: k_weights_m2_lse and k_weights_map<1> with their scalars taken from the search state the last k_bis_decide left
 // on the device (st[BIS_*], identical on every rank) - no host decision sits between the search, the evidence moments and
 // the weights.  The scalars are formed in smc_math.resample_owner's operation order (= k_is_weights' phase 2).
-#define SHARD_TICKET_CELL (1024 * 12)  // in ctx->d_bar (zeroed at creation), behind the persistent kernel's barrier counters
 struct ShardScalars {
     double c1, c2, m, mean_u, shift, mp;
     bool found;
@@ -1191,7 +1222,7 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_weights_map_shard(int64_t n, con
                                                                  double carry_uniform, double* __restrict__ out,
                                                                  double* __restrict__ carry_out,
                                                                  double* __restrict__ tile_sums,
-                                                                 double* __restrict__ st_copy) {
+                                                                 double* __restrict__ st_copy, double* __restrict__ rec) {
     const ShardScalars s = shard_scalars(st);
     double s1p = parts[1], below = 0.0;
     for (int r = 1; r < world; r++) {
@@ -1213,7 +1244,10 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_weights_map_shard(int64_t n, con
     for (int k = 0; k < ASMC_SCAN_TILE / ASMC_BLOCK; k++) {
         const int64_t i = base + k * ASMC_BLOCK + threadIdx.x;
         if (i < n) {
-            const double lw = lw_of(ll[i], lp[i], lq[i], s.c1, s.c2) + s.shift;
+            const double a = ll[i], b = lp[i], q = lq[i];
+            // the (ll, lp, lq, 0) record asmc_gather reads per draw (k_pack_records' job, done on the way: asmc_rec_claim)
+            if (rec) *reinterpret_cast<double4*>(rec + 4 * i) = make_double4(a, b, q, 0.0);
+            const double lw = lw_of(a, b, q, s.c1, s.c2) + s.shift;
             const double wv = found ? exp(lw - lse) : w_uniform;
             out[i] = wv;
             acc += wv;
@@ -1644,7 +1678,8 @@ int asmc_weights_m2_lse_shard(asmc_ctx* ctx, int64_t n, const double* ll, const 
 
 int asmc_normalized_weights_shard(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq,
                                   const double* parts_dev, int world, int rank, double carry_uniform, double* w_out,
-                                  double* carry_out_dev, double* tile_sums_dev, double* state_copy_dev, asmc_stream stream) {
+                                  double* carry_out_dev, double* tile_sums_dev, double* state_copy_dev, int pack_records,
+                                  asmc_stream stream) {
     int rc = check_common(ctx, n, ll, lp, lq);
     if (rc) return rc;
     ASMC_REQUIRE(parts_dev && w_out && carry_out_dev && tile_sums_dev, "null pointer");
@@ -1654,8 +1689,14 @@ int asmc_normalized_weights_shard(asmc_ctx* ctx, int64_t n, const double* ll, co
     hipStream_t st = as_stream(stream);
     const int64_t n_tiles = (n + ASMC_SCAN_TILE - 1) / ASMC_SCAN_TILE;
     ASMC_LAUNCH(ctx, st, "k_weights_map_shard", k_weights_map_shard, dim3((unsigned)n_tiles), dim3(ASMC_BLOCK), 0, st, n, ll, lp, lq,
-                (const double*)ctx->shard_st, parts_dev, world, rank, carry_uniform, w_out, carry_out_dev, tile_sums_dev, state_copy_dev);
+                (const double*)ctx->shard_st, parts_dev, world, rank, carry_uniform, w_out, carry_out_dev, tile_sums_dev, state_copy_dev,
+                pack_records ? ctx->d_rec : (double*)nullptr);
     ASMC_LAUNCH_CHECK();
+    if (pack_records) {  // d_rec rewritten: a new generation, held for asmc_rec_claim
+        ctx->rec_token++;
+        ctx->rec_hold_src[0] = ll, ctx->rec_hold_src[1] = lp, ctx->rec_hold_src[2] = lq;
+        ctx->rec_hold_n = n, ctx->rec_hold_token = ctx->rec_token;
+    }
     return ASMC_OK;
 }
 
@@ -1708,9 +1749,9 @@ int asmc_normalized_weights(asmc_ctx* ctx, int64_t n, const double* ll, const do
 
 // NaN / inf counts of v[0..n) into ctx->d_keys[0..1], enqueued only (the mutation calls read them back with their own results)
 int asmc_count_nonfinite_enqueue(asmc_ctx* ctx, int64_t n, const double* v, hipStream_t st) {
-    ASMC_HIP(hipMemsetAsync(ctx->d_keys, 0, sizeof(unsigned long long) * 2, st));
     const int grid = grid_for(n, ASMC_BLOCK * 8, ASMC_MAX_BLOCKS);
-    ASMC_LAUNCH(ctx, st, "k_count_nonfinite", k_count_nonfinite, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, v, ctx->d_keys);
+    ASMC_LAUNCH(ctx, st, "k_count_nonfinite", k_count_nonfinite, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, v, ctx->d_keys,
+                reinterpret_cast<unsigned long long*>(ctx->d_partials), ctx->d_bar + COUNT_TICKET_CELL);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }

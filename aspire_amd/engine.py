@@ -373,10 +373,20 @@ class HipEngine:
         assert state_copy is None or (state_copy.dtype == torch.float64 and state_copy.numel() >= 40 and state_copy.is_contiguous())
         w, carry = torch.empty_like(ll), self.empty(1)
         tile_sums = self.empty(int(self.lib.asmc_cdf_shard_tiles(ll.numel())))
+        # the gather's (ll, lp, lq, 0) records ride along where the gather would pack them itself (asmc_gather's threshold)
+        pack = ll.numel() >= (1 << 16)
         check(self.lib.asmc_normalized_weights_shard(self._ctx, ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq), _dptr(parts), world,
                                                      rank, float(carry_uniform), _dptr(w), _dptr(carry), _dptr(tile_sums),
-                                                     _dptr(state_copy), self._stream), "asmc_normalized_weights_shard")
+                                                     _dptr(state_copy), int(pack), self._stream), "asmc_normalized_weights_shard")
+        self.rec_token = int(self.lib.asmc_rec_token(self._ctx)) if pack else 0
         return w, carry, tile_sums
+
+    def rec_claim(self, token: int, ll, lp, lq) -> bool:
+        """Directly in front of `gather(idx, x, ll, lp, lq)`: use the records `normalized_weights_shard` packed (its `rec_token`)
+        if nothing has rewritten them since; False: the gather packs for itself."""
+        if not token:
+            return False
+        return bool(self.lib.asmc_rec_claim(self._ctx, int(token), ll.numel(), _dptr(ll), _dptr(lp), _dptr(lq)))
 
     def shard_step_result(self, res: torch.Tensor, world: int):
         """The sharded step's one synchronisation; res = {state copy [40], parts [2 world], info [2 world] int64 bits} in one

@@ -491,7 +491,10 @@ class SMCSamples(BaseSamples):
             if u_kept is not None:
                 # this rank's sub-sequence of Generator.choice's index vector, then its rows (samples.py:1278-1287): enqueued
                 # BEFORE the host has examined the gathered numbers - a step it then rejects (rare) just drops the rows
-                rows = e.gather(e.search(p["shard"]["cdf"], u_kept), *p["src"])
+                idx = e.search(p["shard"]["cdf"], u_kept)
+                if hasattr(e, "rec_claim"):  # (the (ll, lp, lq) records were packed by the weights pass: no packing launch)
+                    e.rec_claim(p["shard"].get("rec_token", 0), *p["src"][1:])
+                rows = e.gather(idx, *p["src"])
                 if (p["moments_n"] is not None and hasattr(e, "mean_gram_enqueue")
                         and e.mean_gram_enqueue(rows[0], p["moments_n"], comm, gathered=True)):
                     factor = None

@@ -556,11 +556,13 @@ def shard_step_enqueue(engine, comm, ll, lp, lq, beta0: float, target_eff: float
     parts = engine.all_gather(comm, part, out=res[40:40 + 2 * world])
     w, carry, tile_sums = engine.normalized_weights_shard(ll, lp, lq, parts, world, rank, float(sum(counts[:rank])) / float(n_global),
                                                           state_copy=res[:40])
+    rec_token = getattr(engine, "rec_token", 0)  # (the gather's records were packed on the way: engine.rec_claim)
     u_all = engine.uniforms_pcg64(state4, 0, int(n_out))  # every rank walks ALL n_out draws
     cdf, recs_all, tile0, work, state = _global_cdf_chain(engine, comm, w, counts, carry, tile_sums)
     edges, buf, info_dev = engine.cdf_shard_finish_select(w, cdf, recs_all, tile0, work, state, u_all)
     engine.all_gather(comm, info_dev, out=res[40 + 2 * world:].view(torch.int64))
     return dict(res=res, cdf=cdf, buf=buf, rounds=rounds, world=world, rank=rank, n_out=int(n_out), n_global=int(n_global),
+                rec_token=rec_token,
                 keep=(w, u_all, edges, recs_all, work, state, tile_sums, carry, part, info_dev))
 
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 19
+#define ASMC_ABI_VERSION 20
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -255,7 +255,14 @@ int asmc_weights_m2_lse_shard(asmc_ctx* ctx, int64_t n, const double* ll_dev, co
                               double target_eff, double tol, int n_rounds, asmc_stream stream);
 int asmc_normalized_weights_shard(asmc_ctx* ctx, int64_t n, const double* ll_dev, const double* lp_dev, const double* lq_dev,
                                   const double* parts_dev, int world, int rank, double carry_uniform, double* w_out_dev,
-                                  double* carry_out_dev, double* tile_sums_dev, double* state_copy_dev, asmc_stream stream);
+                                  double* carry_out_dev, double* tile_sums_dev, double* state_copy_dev, int pack_records,
+                                  asmc_stream stream);
+/* pack_records = 1: the pass also leaves the (ll, lp, lq, 0) records asmc_gather reads per draw in the context (what asmc_gather's
+ * own packing pass would write).  asmc_rec_token right after the call names that generation of the records; asmc_rec_claim(token,
+ * n, ll, lp, lq) directly in front of the asmc_gather of exactly these arrays makes the gather use them - if no other pass has
+ * rewritten the records since (returns 1; 0: the gather packs for itself). */
+int64_t asmc_rec_token(asmc_ctx* ctx);
+int asmc_rec_claim(asmc_ctx* ctx, int64_t token, int64_t n, const double* ll_dev, const double* lp_dev, const double* lq_dev);
 int asmc_shard_step_result(asmc_ctx* ctx, const double* res_dev, int world, double* out_host, asmc_stream stream);
 
 /* SMCSamples.log_weights(beta) as an array (samples.py:1244-1249): lw_out = lw(beta) + shift,

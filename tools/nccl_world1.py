@@ -61,7 +61,7 @@ def main():
     eng.profile(False)
     spec = pop._spec
     assert spec["found"] and spec["beta"] == beta and spec["counts"] == [n], (spec["found"], spec["beta"], beta, spec["counts"])
-    assert "k_weights_m2_lse_shard" in rep and "k_weights_map_shard" in rep and "k_bis_decide" not in rep, sorted(rep)
+    assert "k_weights_m2_lse_shard" in rep and "k_weights_map_shard" in rep and "k_bis_decide" not in rep and "k_pack_records" not in rep, sorted(rep)
     rows_s = eng.gather(idx_s, xd, lld, lpd, lqd)
     assert all(torch.equal(a, b) for a, b in zip(spec["rows"], rows_s))
     mean_u = st.S1 / st.n
