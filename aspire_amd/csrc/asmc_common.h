@@ -23,6 +23,7 @@ void asmc_set_error(const char* fmt, ...);
 void asmc_bm_table_host(double* tab);  // asmc_ctx.hip: the 2 * BM_TAB_N doubles (long double libm)
 struct asmc_ctx;
 int asmc_count_nonfinite_enqueue(asmc_ctx* ctx, int64_t n, const double* v, hipStream_t st);
+unsigned long long* asmc_count_slot(asmc_ctx* ctx);  // where the last asmc_count_nonfinite_enqueue leaves {NaN, inf} counts
 struct asmc_ctx;
 void asmc_prof_begin(asmc_ctx* ctx, const char* label, hipStream_t st);
 void asmc_poison_lds(asmc_ctx* ctx, hipStream_t st);  // diagnostic (ASMC_POISON_LDS): every CU's LDS filled with 0xFF bytes
@@ -94,6 +95,7 @@ struct asmc_ctx {
     double* d_rec;                 // [4 * n_max] (ll, lp, lq, 0) records of asmc_gather's source population
     const void* rec_src[3];        // the arrays asmc_importance_step packed into d_rec (k_is_weights writes the records on
     int64_t rec_n;                 //   its way); rec_n != 0: still valid - the next asmc_gather of exactly these skips its packing pass
+    unsigned count_gen;            // k_count_nonfinite's count slots are used in turn (asmc_weights.hip)
     uint64_t rec_token;            // generation of d_rec's contents (every pass that writes d_rec bumps it) ...
     const void* rec_hold_src[3];   // ... and the arrays / count / generation of a pack that asmc_normalized_weights_shard did on its
     int64_t rec_hold_n;            //   way: asmc_rec_claim(token) re-validates it for the next asmc_gather when nothing has

@@ -2382,7 +2382,7 @@ int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int
 static int pcn_enqueue_lq_check(asmc_ctx* ctx, int64_t n, const double* lq, hipStream_t st) {
     const int rc = asmc_count_nonfinite_enqueue(ctx, n, lq, st);
     if (rc) return rc;
-    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8002, ctx->d_keys, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8002, asmc_count_slot(ctx), sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, st));
     return ASMC_OK;
 }
 

@@ -27,7 +27,7 @@ struct BetaPack {
 
 // self-resetting arrival counters in ctx->d_bar (zeroed at creation), behind the persistent kernel's barrier counters
 #define SHARD_TICKET_CELL (1024 * 12)
-#define COUNT_TICKET_CELL (1024 * 12 + 64)
+#define COUNT_CELLS (1024 * 12 + 64)  // two (NaN, inf) count slots of k_count_nonfinite, 8-byte aligned
 
 __device__ __forceinline__ double lw_of(double ll, double lp, double lq, double c1, double c2) {
     // (self.beta - beta) * log_q + (beta - self.beta) * (log_likelihood + log_prior)
@@ -232,11 +232,13 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_weights_map(int64_t n, const dou
     }
 }
 
-// NaN / inf census of v.  The blocks leave their counts in `partials` and the block that arrives last adds them up and WRITES
-// counters[0..1] (k_bis_sums' hand-off on a counter that resets itself): no memset in front of the kernel, no atomics on the result.
+// NaN / inf census of v into counters[0..1].  No memset in front of it: the counters are TWO slots used in turn - a launch adds
+// into the slot the previous launch zeroed (the first one: zeroed at creation) and zeroes the other one for the next launch
+// (`next_slot`: nobody else touches it during this launch).  Atomics only where something was found.
 __global__ __launch_bounds__(ASMC_BLOCK) void k_count_nonfinite(int64_t n, const double* __restrict__ v,
                                                                unsigned long long* __restrict__ counters,
-                                                               unsigned long long* partials, unsigned int* ticket) {
+                                                               unsigned long long* __restrict__ next_slot) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) next_slot[threadIdx.x] = 0ull;
     long long n_nan = 0, n_inf = 0;
     const int64_t stride = (int64_t)gridDim.x * ASMC_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * ASMC_BLOCK + threadIdx.x; i < n; i += stride) {
@@ -246,37 +248,12 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_count_nonfinite(int64_t n, const
         else if (isinf(x))
             n_inf++;
     }
-    __shared__ long long s_c[ASMC_BLOCK / 64][2];
-    __shared__ int s_last;
     n_nan = wave_sum_ll(n_nan);
     n_inf = wave_sum_ll(n_inf);
-    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6][0] = n_nan, s_c[threadIdx.x >> 6][1] = n_inf;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long a = 0, b = 0;
-        for (int w = 0; w < ASMC_BLOCK / 64; w++) a += s_c[w][0], b += s_c[w][1];
-        partials[2 * blockIdx.x] = (unsigned long long)a;
-        partials[2 * blockIdx.x + 1] = (unsigned long long)b;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1u);
-        if (s_last) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_nan) atomicAdd(&counters[0], (unsigned long long)n_nan);
+        if (n_inf) atomicAdd(&counters[1], (unsigned long long)n_inf);
     }
-    __syncthreads();
-    if (!s_last || threadIdx.x >= 64) return;
-    long long a = 0, b = 0;
-    for (int k = threadIdx.x; k < (int)gridDim.x; k += 64) {
-        a += (long long)__hip_atomic_load(&partials[2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b += (long long)__hip_atomic_load(&partials[2 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    a = wave_sum_ll(a);
-    b = wave_sum_ll(b);
-    if (threadIdx.x == 0) counters[0] = (unsigned long long)a, counters[1] = (unsigned long long)b;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1747,11 +1724,17 @@ int asmc_normalized_weights(asmc_ctx* ctx, int64_t n, const double* ll, const do
 
 }  // extern "C"
 
-// NaN / inf counts of v[0..n) into ctx->d_keys[0..1], enqueued only (the mutation calls read them back with their own results)
+// NaN / inf counts of v[0..n), enqueued only (the mutation calls read them back with their own results); the counts land in
+// asmc_count_slot(ctx) - the slot of the LAST enqueue
+static inline unsigned long long* count_slot(asmc_ctx* ctx, unsigned gen) {
+    return reinterpret_cast<unsigned long long*>(ctx->d_bar + COUNT_CELLS) + 2 * (gen & 1u);
+}
+unsigned long long* asmc_count_slot(asmc_ctx* ctx) { return count_slot(ctx, ctx->count_gen); }
 int asmc_count_nonfinite_enqueue(asmc_ctx* ctx, int64_t n, const double* v, hipStream_t st) {
+    ctx->count_gen++;
     const int grid = grid_for(n, ASMC_BLOCK * 8, ASMC_MAX_BLOCKS);
-    ASMC_LAUNCH(ctx, st, "k_count_nonfinite", k_count_nonfinite, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, v, ctx->d_keys,
-                reinterpret_cast<unsigned long long*>(ctx->d_partials), ctx->d_bar + COUNT_TICKET_CELL);
+    ASMC_LAUNCH(ctx, st, "k_count_nonfinite", k_count_nonfinite, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, v,
+                count_slot(ctx, ctx->count_gen), count_slot(ctx, ctx->count_gen + 1));
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
@@ -1765,7 +1748,7 @@ int asmc_count_nonfinite(asmc_ctx* ctx, int64_t n, const double* v, int64_t* n_n
     const int rc = asmc_count_nonfinite_enqueue(ctx, n, v, st);
     if (rc) return rc;
     unsigned long long* h = reinterpret_cast<unsigned long long*>(ctx->h_pinned);
-    ASMC_HIP(hipMemcpyAsync(h, ctx->d_keys, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipMemcpyAsync(h, asmc_count_slot(ctx), sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, st));
     ASMC_HIP(hipStreamSynchronize(st));
     if (n_nan_host) *n_nan_host = (int64_t)h[0];
     if (n_inf_host) *n_inf_host = (int64_t)h[1];
