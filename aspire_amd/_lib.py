@@ -26,7 +26,7 @@ COUNT_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ASMC_BIS_REC = 40
 ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
-ASMC_ABI_VERSION = 20
+ASMC_ABI_VERSION = 21
 ASMC_FLOW_COUPLING, ASMC_FLOW_MAF = 0, 1  # asmc_coupling.kind
 ASMC_CDF_REC = 9
 ASMC_CDF_STATE = 36
@@ -158,6 +158,8 @@ SIGNATURES = {
     "asmc_rec_token": (_i64, [_vp]),
     "asmc_rec_claim": (_i, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "asmc_shard_step_result": (_i, [_vp, _vp, _i, _pd, _vp]),
+    "asmc_shard_step_finish": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                   _pd, POINTER(ctypes.c_int), _vp]),
     "asmc_cdf_shard_chain": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i, _i, _vp, _vp]),
     "asmc_cdf_shard_finish": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "asmc_select_range": (_i, [_vp, _i64, _vp, _vp, _vp, _pi64, _vp]),

@@ -1984,6 +1984,39 @@ int asmc_search(asmc_ctx* ctx, int64_t n, const double* cdf, int64_t n_out, cons
     return ASMC_OK;
 }
 
+// The sharded step's one synchronisation AND what follows it, without the host interpreter in between: waits for the chain
+// (asmc_shard_step_result), and when the numbers read back are those of a finished step - search converged, no NaN weights,
+// no slice that needs the replicated scan, every rank's offspring count in (0, cap]: conditions every rank evaluates on the same
+// gathered values - puts this rank's search (asmc_search over its kept draws) and gather (asmc_gather into the caller's
+// cap-row buffers; the records packed on the way are claimed by rec_token) onto the stream right away.  *launched = 1 then, and
+// out_host[13 + 2 world + 2 rank] is the number of rows written.  The caller still takes resample_owner's decisions (shares,
+// totals) from out_host and drops the rows if they say so.
+int asmc_shard_step_finish(asmc_ctx* ctx, const double* res_dev, int world, int rank, int64_t n_local, const double* cdf_dev,
+                           const double* kept_dev, int64_t cap, int64_t* idx_dev, int d, int x_dtype, const void* x_in,
+                           void* x_out, const double* ll_in, const double* lp_in, const double* lq_in, double* ll_out,
+                           double* lp_out, double* lq_out, int64_t rec_token, double* out_host, int* launched,
+                           asmc_stream stream) {
+    ASMC_REQUIRE(ctx && res_dev && cdf_dev && kept_dev && idx_dev && x_in && x_out && ll_in && lp_in && lq_in && ll_out && lp_out &&
+                     lq_out && out_host && launched,
+                 "null pointer");
+    ASMC_REQUIRE(world >= 1 && rank >= 0 && rank < world && n_local > 0 && cap > 0 && d > 0, "bad sizes");
+    *launched = 0;
+    int rc = asmc_shard_step_result(ctx, res_dev, world, out_host, stream);
+    if (rc) return rc;
+    const double* info = out_host + 13 + 2 * world;  // (kept, fail) per rank, as doubles
+    bool usable = out_host[2] != 0.0 && out_host[5] == 0.0 && out_host[9] != 0.0;
+    for (int r = 0; r < world && usable; r++) usable = info[2 * r + 1] == 0.0 && info[2 * r] > 0.0 && info[2 * r] <= (double)cap;
+    if (!usable) return ASMC_OK;
+    const int64_t cnt = (int64_t)info[2 * rank];
+    rc = asmc_search(ctx, n_local, cdf_dev, cnt, kept_dev, idx_dev, stream);
+    if (rc) return rc;
+    (void)asmc_rec_claim(ctx, rec_token, n_local, ll_in, lp_in, lq_in);
+    rc = asmc_gather(ctx, n_local, cnt, idx_dev, d, x_dtype, x_in, x_out, ll_in, lp_in, lq_in, ll_out, lp_out, lq_out, stream);
+    if (rc) return rc;
+    *launched = 1;
+    return ASMC_OK;
+}
+
 int asmc_importance_step(asmc_ctx* ctx, int64_t n, const double* ll, const double* lp, const double* lq, double beta0,
                          double target_eff, double tol, const uint64_t rng_state[4], int64_t n_out, double* w_scratch,
                          double* cdf_scratch, int64_t* idx_out, asmc_stream stream) {

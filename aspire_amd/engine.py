@@ -398,6 +398,35 @@ class HipEngine:
         search = (float(out[0]), float(out[4]), bool(out[2]), int(out[3]), int(out[5]), trip, tuple(map(float, out[10:13])))
         return search, out[13:13 + 2 * world].reshape(world, 2).copy(), out[13 + 2 * world:].reshape(world, 2).astype(np.int64)
 
+    def shard_step_finish(self, res: torch.Tensor, world: int, rank: int, cdf: torch.Tensor, kept: torch.Tensor, cap: int, x, ll, lp,
+                          lq, rec_token: int = 0):
+        """`shard_step_result` and - when the step read back is a finished one - this rank's search and gather enqueued from C
+        right behind the synchronisation (include/asmc.h asmc_shard_step_finish), into buffers of `cap` rows allocated before
+        the wait.  Returns (search tuple, parts[world, 2], info[world, 2], rows or None); rows = (x, ll, lp, lq) of this rank's
+        offspring (views of the cap-row buffers)."""
+        assert res.dtype == torch.float64 and res.numel() == 40 + 4 * world and res.is_contiguous()
+        assert x.is_contiguous() and cdf.is_contiguous() and kept.is_contiguous() and kept.numel() >= cap
+        self._chk3(ll, lp, lq)
+        d = x.shape[1]
+        idx = torch.empty(cap, dtype=torch.int64, device=self.device)
+        xo = torch.empty((cap, d), dtype=x.dtype, device=self.device)
+        llo, lpo, lqo = (torch.empty(cap, dtype=torch.float64, device=self.device) for _ in range(3))
+        out = np.zeros(13 + 4 * world)
+        launched = ctypes.c_int(0)
+        check(self.lib.asmc_shard_step_finish(self._ctx, _dptr(res), world, rank, ll.numel(), _dptr(cdf), _dptr(kept), int(cap), _dptr(idx),
+                                              d, self._xdt(x), _dptr(x), _dptr(xo), _dptr(ll), _dptr(lp), _dptr(lq), _dptr(llo), _dptr(lpo),
+                                              _dptr(lqo), int(rec_token), _f64p(out), ctypes.byref(launched), self._stream),
+              "asmc_shard_step_finish")
+        trip = (float(out[6]), float(out[7]), float(out[8])) if out[9] != 0.0 else None
+        search = (float(out[0]), float(out[4]), bool(out[2]), int(out[3]), int(out[5]), trip, tuple(map(float, out[10:13])))
+        parts = out[13:13 + 2 * world].reshape(world, 2).copy()
+        info = out[13 + 2 * world:].reshape(world, 2).astype(np.int64)
+        rows = None
+        if launched.value:
+            cnt = int(info[rank, 0])
+            rows = (xo[:cnt], llo[:cnt], lpo[:cnt], lqo[:cnt])
+        return search, parts, info, rows
+
     def cdf_shard_finish_select(self, w, cdf, recs_all, tile0: int, work, state, u: torch.Tensor):
         """`cdf_shard_finish` + `select_range_dev` in three launches: (edges {fail, total, lo, hi}, buffer with the kept draws
         in front, int64 device tensor {kept, fail}).  No synchronisation."""

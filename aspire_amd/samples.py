@@ -486,15 +486,24 @@ class SMCSamples(BaseSamples):
         e = self._eng()
         if "shard" in p:
             comm = self._comm()
-            search, parts, info, u_kept = smc_math.shard_step_wait(e, comm, p["shard"])
+            h = p["shard"]
             rows, moments = None, None
-            if u_kept is not None:
-                # this rank's sub-sequence of Generator.choice's index vector, then its rows (samples.py:1278-1287): enqueued
-                # BEFORE the host has examined the gathered numbers - a step it then rejects (rare) just drops the rows
-                idx = e.search(p["shard"]["cdf"], u_kept)
-                if hasattr(e, "rec_claim"):  # (the (ll, lp, lq) records were packed by the weights pass: no packing launch)
-                    e.rec_claim(p["shard"].get("rec_token", 0), *p["src"][1:])
-                rows = e.gather(idx, *p["src"])
+            if hasattr(e, "shard_step_finish"):
+                # the wait, and right behind it - from C, no interpreter in between - this rank's search and gather (samples.py:
+                # 1278-1287: its sub-sequence of Generator.choice's index vector, then its rows) into buffers sized before the
+                # wait: shares stay within 1/world (1 +- SHARD_IMBALANCE) or the step is redone phase by phase anyway
+                cap = min(h["n_out"], int((1.0 + 2.0 * smc_math.SHARD_IMBALANCE) * h["n_out"] / h["world"]) + 2048)
+                search, parts, info, rows = e.shard_step_finish(h["res"], h["world"], h["rank"], h["cdf"], h["buf"], cap, *p["src"],
+                                                                rec_token=h.get("rec_token", 0))
+            else:
+                search, parts, info, u_kept = smc_math.shard_step_wait(e, comm, h)
+                if u_kept is not None:
+                    idx = e.search(h["cdf"], u_kept)
+                    if hasattr(e, "rec_claim"):
+                        e.rec_claim(h.get("rec_token", 0), *p["src"][1:])
+                    rows = e.gather(idx, *p["src"])
+            if rows is not None:
+                # (enqueued BEFORE the host has examined the gathered numbers - a step it then rejects (rare) just drops the rows)
                 if (p["moments_n"] is not None and hasattr(e, "mean_gram_enqueue")
                         and e.mean_gram_enqueue(rows[0], p["moments_n"], comm, gathered=True)):
                     factor = None

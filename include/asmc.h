@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 20
+#define ASMC_ABI_VERSION 21
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -264,6 +264,16 @@ int asmc_normalized_weights_shard(asmc_ctx* ctx, int64_t n, const double* ll_dev
 int64_t asmc_rec_token(asmc_ctx* ctx);
 int asmc_rec_claim(asmc_ctx* ctx, int64_t token, int64_t n, const double* ll_dev, const double* lp_dev, const double* lq_dev);
 int asmc_shard_step_result(asmc_ctx* ctx, const double* res_dev, int world, double* out_host, asmc_stream stream);
+/* asmc_shard_step_result and, when the step it reads back is a finished one (converged, no NaN weights, no slice that needs the
+ * replicated scan, every rank's offspring count in (0, cap] - rank-uniform conditions), this rank's asmc_search over its kept
+ * draws (kept_dev, as asmc_cdf_shard_finish_select left them) and asmc_gather of its offspring into the caller's cap-row
+ * buffers, enqueued from C right behind the synchronisation; *launched = 1 then, the rows written = this rank's count in
+ * out_host.  rec_token: asmc_rec_token after asmc_normalized_weights_shard (0: none). */
+int asmc_shard_step_finish(asmc_ctx* ctx, const double* res_dev, int world, int rank, int64_t n_local, const double* cdf_dev,
+                           const double* kept_dev, int64_t cap, int64_t* idx_dev, int d, int x_dtype, const void* x_in_dev,
+                           void* x_out_dev, const double* ll_in_dev, const double* lp_in_dev, const double* lq_in_dev,
+                           double* ll_out_dev, double* lp_out_dev, double* lq_out_dev, int64_t rec_token, double* out_host,
+                           int* launched, asmc_stream stream);
 
 /* SMCSamples.log_weights(beta) as an array (samples.py:1244-1249): lw_out = lw(beta) + shift,
  * shift = logsumexp(lw) - log N formed on the host from asmc_weights_stats. */
