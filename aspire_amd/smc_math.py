@@ -519,8 +519,7 @@ def shard_step_available(engine, comm) -> bool:
     """The sharded importance step can run as one chain of launches (`shard_step_enqueue`): the engine has the passes that
     take their scalars from the device, and ASMC_SHARD_STEP=0 has not switched it off (A-B switch / escape hatch)."""
     return (comm.sharded and all(hasattr(engine, k) for k in ("weights_m2_lse_shard", "normalized_weights_shard", "all_gather",
-                                                              "shard_step_result", "find_beta_shard_round",
-                                                              "cdf_shard_finish_select"))
+                                                              "shard_step_result", "find_beta_shard_round", "select_range_dev"))
             and os.environ.get("ASMC_SHARD_STEP", "1") != "0")
 
 
@@ -540,7 +539,9 @@ def shard_step_enqueue(engine, comm, ll, lp, lq, beta0: float, target_eff: float
     import torch
 
     # search: the rounds `find_beta_sharded` enqueues before it looks (plain rounds narrow the bracket 16x each)
-    rounds = min(3, max(1, int(math.ceil(math.log2((1.0 - beta0) / tol) / BISECT_LEVELS - 1e-9))))
+    # (an engine whose rounds are all plain - no prediction windows: the CPU test double - says how many it may need)
+    rounds = min(getattr(engine, "search_rounds_cap", 3),
+                 max(1, int(math.ceil(math.log2((1.0 - beta0) / tol) / BISECT_LEVELS - 1e-9))))
     bufs = engine.__dict__.setdefault("_bis_bufs", {})
     if bufs.get("world") != world:
         bufs.update(world=world, rec=engine.empty(40), recs=engine.empty(40 * world))
@@ -558,12 +559,17 @@ def shard_step_enqueue(engine, comm, ll, lp, lq, beta0: float, target_eff: float
                                                           state_copy=res[:40])
     rec_token = getattr(engine, "rec_token", 0)  # (the gather's records were packed on the way: engine.rec_claim)
     u_all = engine.uniforms_pcg64(state4, 0, int(n_out))  # every rank walks ALL n_out draws
-    cdf, recs_all, tile0, work, state = _global_cdf_chain(engine, comm, w, counts, carry, tile_sums)
-    edges, buf, info_dev = engine.cdf_shard_finish_select(w, cdf, recs_all, tile0, work, state, u_all)
+    if hasattr(engine, "cdf_shard_finish_select"):  # write pass + edges / count + scan / scatter / info: three launches
+        cdf, recs_all, tile0, work, state = _global_cdf_chain(engine, comm, w, counts, carry, tile_sums)
+        edges, buf, info_dev = engine.cdf_shard_finish_select(w, cdf, recs_all, tile0, work, state, u_all)
+        keep = (w, u_all, edges, recs_all, work, state, tile_sums, carry, part, info_dev)
+    else:  # engines without the tile-record machinery (the CPU test double): the same slice through the replicated scan
+        cdf, edges = global_cdf_slice(engine, comm, w, counts, float(carry[0]), "exact")
+        buf, info_dev = engine.select_range_dev(u_all, edges)
+        keep = (w, u_all, edges, carry, part, info_dev)
     engine.all_gather(comm, info_dev, out=res[40 + 2 * world:].view(torch.int64))
     return dict(res=res, cdf=cdf, buf=buf, rounds=rounds, world=world, rank=rank, n_out=int(n_out), n_global=int(n_global),
-                rec_token=rec_token,
-                keep=(w, u_all, edges, recs_all, work, state, tile_sums, carry, part, info_dev))
+                rec_token=rec_token, keep=keep)
 
 
 def shard_step_wait(engine, comm, h):

@@ -30,6 +30,7 @@ def _np(t):
 class OracleEngine:
     name = "oracle"
     device = torch.device("cpu")
+    search_rounds_cap = 16  # plain 16-ary rounds only (no prediction windows): the chain enqueues as many as the tolerance needs
 
     # ---- plumbing ---------------------------------------------------------------------------
     def ensure_capacity(self, n, d):
@@ -146,6 +147,72 @@ class OracleEngine:
         st = self._bis
         return (float(st["lo"]), float(st["eff_one"]), bool(st["done"]), int(st["rounds"]), int(st["n_nan"]), st["trip"],
                 tuple(map(float, st["one"])))
+
+    # ---- the sharded importance step as one chain (HipEngine's shard-step entry points; host-logic double) -----------------
+    # The double computes eagerly, so "the scalars stay on the device" means: they stay in self._bis / the tensors handed on,
+    # and the host logic (smc_math.shard_step_enqueue / _wait / _check, SMCSamples.speculate_importance_step) reads them only
+    # through shard_step_result - the same call order, the same collectives, the same decisions as on the GPU.
+    def all_gather(self, comm, t, out=None):
+        g = comm.all_gather_tensor(t.contiguous())
+        if out is None:
+            return g
+        out.copy_(g.reshape(out.shape))
+        return out
+
+    def find_beta_shard_round(self, ll, lp, lq, beta0, target_eff, tol, world, n_global, rnd, recs_prev, rec):
+        if rnd > 0:  # a round closes the previous one itself (asmc_find_beta_shard_round)
+            self.find_beta_shard_decide(recs_prev, world, n_global, beta0, target_eff, tol, rnd - 1)
+        self.find_beta_shard_reduce(ll, lp, lq, beta0, rnd, rec)
+
+    def _shard_scalars(self, n_global):
+        b, _, conv, _, n_nan, trip, _ = self.find_beta_shard_result()
+        found = bool(conv and trip is not None and n_nan == 0 and b > self._bis_beta0)
+        if not found:
+            return None
+        m, S1 = float(trip[0]), float(trip[1])
+        shift = float((m + np.log(S1)) - np.log(float(n_global)))
+        return b, m, S1 / n_global, shift, m + shift
+
+    def weights_m2_lse_shard(self, ll, lp, lq, out, recs_last=None, world=1, n_global=0, beta0=0.0, target_eff=0.5, tol=1e-6,
+                             n_rounds=0):
+        if recs_last is not None:  # closes the search's last round (asmc_weights_m2_lse_shard)
+            self.find_beta_shard_decide(recs_last, world, n_global, beta0, target_eff, tol, n_rounds - 1)
+        self._bis_beta0, self._bis_n = float(beta0), int(n_global)
+        sc = self._shard_scalars(n_global)
+        m2 = s1p = 0.0
+        if sc is not None:
+            b, m, mean_u, shift, mp = sc
+            m2, s1p = self.weights_m2_lse(ll, lp, lq, beta0, b, m, mean_u, shift, mp)
+        out[0], out[1] = m2, s1p
+
+    def normalized_weights_shard(self, ll, lp, lq, parts, world, rank, carry_uniform, state_copy=None):
+        pr = _np(parts).reshape(world, 2)
+        sc = self._shard_scalars(self._bis_n)
+        s1p = float(pr[0, 1])
+        below = 0.0
+        for r in range(1, world):  # rank order (k_weights_map_shard)
+            if r == rank:
+                below = s1p
+            s1p += float(pr[r, 1])
+        found = sc is not None and s1p > 0.0 and np.isfinite(s1p)
+        if found:
+            b, _, _, shift, mp = sc
+            w = self.normalized_weights(ll, lp, lq, self._bis_beta0, b, shift, float(mp + np.log(s1p)))
+        else:
+            w = torch.full((ll.numel(),), 1.0 / self._bis_n, dtype=torch.float64)
+        self.rec_token = 0
+        return w, torch.tensor([below / s1p if found else carry_uniform], dtype=torch.float64), None
+
+    def select_range_dev(self, u, edges):
+        kept = self.select_range(u, edges[2:4])
+        buf = torch.empty_like(u)
+        buf[: kept.numel()] = kept
+        return buf, torch.tensor([kept.numel(), int(round(float(edges[0])))], dtype=torch.int64)
+
+    def shard_step_result(self, res, world):
+        r = _np(res)
+        info = r[40 + 2 * world:].view(np.int64).reshape(world, 2).copy()
+        return self.find_beta_shard_result(), r[40:40 + 2 * world].reshape(world, 2).copy(), info
 
     # Student-t reference fit: numpy restatement of asmc_student_estep / asmc_student_scale
     def student_estep(self, xs, mu, linv, nu):

@@ -151,7 +151,7 @@ def _worker(rank, world, port, out_dir, engine_kind="oracle"):
                                       + [fpt.flow.loc.double().reshape(-1), fpt.flow.scale.double().reshape(-1)]).numpy()
         res["fpt_rng_untouched"] = np.array(int(torch.equal(torch.get_rng_state(), probe_before)))
         res["fpt_z_shape"] = np.array(np.asarray(z).shape)
-    if engine_kind == "hip":
+    if True:  # (both engines: the HIP kernels on the GPU, the host logic of the same chain on the CPU test double)
         # the sharded importance step as ONE chain of launches (smc_math.shard_step_enqueue: the scalars between the phases
         # stay on the device) against the phase-by-phase path above: same beta*, same ancestors, same variance, same generator
         rng_a, rng_b = np.random.default_rng(5), np.random.default_rng(5)
@@ -197,6 +197,7 @@ def _worker(rank, world, port, out_dir, engine_kind="oracle"):
         res["chain_skew_beta"] = np.array([fb_c[0], fb_d[0]])
         res["chain_skew_x"], res["steps_skew_x"] = eng.to_numpy(sk_c.x), eng.to_numpy(sk_d.x)
         res["chain_skew_rng"] = np.array([rng_c.integers(0, 2**62), rng_d.integers(0, 2**62)])
+    if engine_kind == "hip":
         # the WHOLE sharded sampler with a coupling-flow proposal (the one-kernel flow step, accept counts exchanged through the
         # Python callback hook): the chain form - enqueued behind the mutation's step loop, factorisation behind its moments -
         # against the phase-by-phase form (ASMC_SHARD_STEP=0: nothing runs ahead): same schedule, same log Z, same particles
@@ -230,6 +231,25 @@ def two_rank_results(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("gloo"))
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     return [np.load(os.path.join(out, f"rank{r}.npz")) for r in range(2)]
+
+
+def test_sharded_step_as_one_chain_equals_the_phase_by_phase_path_on_cpu(two_rank_results):
+    """The host logic of the one-chain sharded importance step (smc_math.shard_step_enqueue / _wait / _check,
+    SMCSamples.speculate_importance_step / finish_speculation / resample's parked-rows branch) on the CPU test double, two gloo
+    ranks: same beta*, evidence variance, ancestors and generator state as find_beta_sharded + resample_owner; a step the chain
+    cannot take (all the weight on one rank) is reported as such and redone phase by phase.  The GPU form of the same test runs
+    in tests/test_gpu_dist.py.  Contract: /root/reference/src/aspire/samples.py:1221-1287 on the global population."""
+    for h in two_rank_results:
+        assert h["chain_flags"].tolist() == [1, 1, 1]
+        assert h["chain_beta"][0] == h["chain_beta"][1] == float(h["fb"][0])
+        assert h["chain_var"][0] == h["chain_var"][1]
+        assert np.array_equal(h["chain_x"], h["steps_x"]) and np.array_equal(h["chain_ll"], h["steps_ll"])
+        assert h["chain_counts"].tolist() == h["steps_counts"].tolist()
+        assert h["chain_rng"][0] == h["chain_rng"][1]
+        assert h["chain_skew_flags"].tolist() == [1, 0], h["chain_skew_flags"]
+        assert h["chain_skew_beta"][0] == h["chain_skew_beta"][1]
+        assert np.array_equal(h["chain_skew_x"], h["steps_skew_x"])
+        assert h["chain_skew_rng"][0] == h["chain_skew_rng"][1]
 
 
 def test_sharded_reductions_match_single_rank(two_rank_results, oracle):
