@@ -125,6 +125,31 @@ def test_config3_flow_logprob_1m_vs_oracle_subsample(big, oracle, trained_flow):
     assert rel.max() <= 1e-6, rel.max()
 
 
+def test_config3_maf_logprob_1m_vs_fp64_subsample(big):
+    """The reference's default flow class (masked autoregressive, flows/torch/flows.py:140-168) at full size: asmc_coupling_logprob
+    with kind = ASMC_FLOW_MAF over 1M x 32 rows of a TRAINED flow; a strided 64k subsample against the SAME parameters evaluated
+    in fp64 (MAFFlow.log_prob_f64) - the north star's bar: max relative error <= 1e-6 - and every value finite."""
+    from aspire_amd.flows import MAFFlow
+
+    n, d = 1_000_000, 32
+    flow = MAFFlow(d, n_transforms=3, hidden_features=(64, 64), device=big.device, dtype=torch.float32, seed=1234)
+    flow.fit(1.5 * 0.9 * np.random.default_rng(3).normal(size=(8000, d)), n_epochs=8)
+    g = torch.Generator(big.device).manual_seed(18)
+    x = 1.4 * torch.randn((n, d), device=big.device, dtype=torch.float64, generator=g)
+    big.profile(True)
+    got = big.coupling_logprob(x, flow.device_coupling(big))
+    rep = big.profile_report()
+    big.profile(False)
+    assert any(k.startswith("k_maf_logprob") for k in rep), sorted(rep)
+    assert bool(torch.isfinite(got).all())
+    rows = torch.arange(0, n, n // 65536, device=big.device)[:65536]
+    with torch.no_grad():
+        ref64 = flow.log_prob_f64(x[rows]).cpu().numpy()
+    sub = got[rows].cpu().numpy()
+    rel = np.abs(sub - ref64) / np.maximum(np.abs(ref64), 1.0)
+    assert rel.max() <= 1e-6, rel.max()
+
+
 def test_config3_full_run_1m_d32_flow_pcn_32_steps(big, trained_flow):
     """configs[2] as stated: HipSMC.sample(1M) with the trained coupling-flow proposal, 32 pCN steps per temperature,
     default fp64 noise; the whole mutation loop runs in asmc_pcn_mutate_flow; log Z within 3 sigma of (d/2) log pi."""
