@@ -161,8 +161,8 @@ def main():
 
     flow_math = "f32-mfma" if os.environ.get("ASMC_FLOW_MATH") == "f32" else "f16x2-split"
 
-    def run(seed: int, n=n_global, flow=cflow, step_fn=args.step_fn, noise=args.noise, steps=n_mc):
-        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=eng, comm=comm,
+    def run(seed: int, n=n_global, flow=cflow, step_fn=args.step_fn, noise=args.noise, steps=n_mc, comm_=None):
+        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=eng, comm=comm_ or comm,
                     rng=np.random.default_rng(seed), dtype=xname)
         sp.shard_layout = args.shard_layout
         post = sp.sample(n, sampler_kwargs=dict(n_steps=steps, noise=noise, step_fn=step_fn), store_sample_history=False,
@@ -562,6 +562,54 @@ def main():
                 os.environ.pop("ASMC_FLOW_MATH", None)
             # top level next to `value`: the same workload with every flow product on the fp32-input matrix instruction
             result["value_strict_fp32"] = extra["flow_run_f32_mfma"]["particle_steps_per_s"]
+        # (f) what the SHARDED code path costs before any wire time: the headline run through the sharded
+        #     machinery over a ONE-rank RCCL group made in this process - every collective of the hot path is issued (the beta
+        #     search's records, the evidence partials, tile records and chain states of the exact cdf, offspring counts, the
+        #     per-step accept counts, the reference fit's moments), none has a peer - against the single-rank runs, interleaved
+        if not sharded and not os.environ.get("ASMC_BENCH_NO_SHARDED_LEG"):
+            try:
+                import torch.distributed as dist
+
+                from aspire_amd.comm import TorchDistComm
+
+                made_group = False
+                if not dist.is_initialized():
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+                    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+                    made_group = True
+                scomm = TorchDistComm(eng.device)
+                scomm.force_sharded = True
+                run(5, n=65536, steps=2, comm_=scomm)
+                run(6, comm_=scomm)
+                sync_all()
+                t_single, t_shard = [], []
+                for k in range(4):
+                    for which, acc in ((None, t_single), (scomm, t_shard)):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        sps, posts = run(2000 + k, comm_=which)
+                        torch.cuda.synchronize()
+                        acc.append((time.perf_counter() - t0) * 1e3)
+                eng.profile(True)
+                sps, posts = run(2100, comm_=scomm)
+                torch.cuda.synchronize()
+                ks = eng.profile_report()
+                eng.profile(False)
+                ms1, ms2 = float(np.median(t_single)), float(np.median(t_shard))
+                extra["sharded_path_one_rank_group"] = {
+                    "what": "sample() through the sharded code path over a one-rank RCCL group (all collectives issued, no peer) "
+                            "against the single-rank path, 4 runs each, interleaved, same workload as the headline",
+                    "ms_per_run_single": round(ms1, 3), "ms_per_run_sharded": round(ms2, 3), "overhead": round(ms2 / ms1 - 1.0, 4),
+                    "importance_step_as_one_chain": bool(smc_math.shard_step_available(eng, scomm)
+                                                         and "k_weights_m2_lse_shard" in ks and "k_bis_decide" not in ks),
+                    "host_synchronisations_per_temperature_in_the_step": 1,
+                    "abs_err_in_sigma": abs(float(posts.log_evidence) - true_logz) / max(float(posts.log_evidence_error), 1e-300),
+                    "library_issues_its_own_collectives": bool(scomm.rccl_direct() is not None)}
+                if made_group:
+                    dist.destroy_process_group()
+            except Exception as exc:  # an extra leg never costs the line
+                extra["sharded_path_one_rank_group"] = {"error": repr(exc)}
         result["extra"] = extra
 
     # ---- CPU baseline: the oracle's restatement of the SAME mutation step (kind "port") on the host's cores -------
