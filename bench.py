@@ -62,6 +62,11 @@ def cpu_model() -> str:
 
 
 def main():
+    # stdout carries ONE line - the JSON record.  Libraries write banners there (RCCL prints its version block when a communicator
+    # is made): from here on file descriptor 1 is stderr, and the record goes to the descriptor stdout had.
+    sys.stdout.flush()
+    record_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10, help="timed HipSMC.sample() runs")
@@ -702,7 +707,7 @@ def main():
         import ctypes
 
         ctypes.CDLL(None).fflush(None)
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=record_out, flush=True)
         hush()
     if sharded:
         import torch.distributed as dist

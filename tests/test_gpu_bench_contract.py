@@ -1,0 +1,37 @@
+"""The driver's contract with bench.py, checked on a small workload: ONE JSON line on stdout carrying the metric BASELINE.json
+names, whole-job throughput, the roofline of the dominant kernel measured in the run, the CPU baseline timed beside it, and the
+extra legs - none of which may fail silently (a leg that raised reports {"error": ...})."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_roofline_cpu_baseline_and_extra_legs():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--particles-per-gpu", "262144"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:3]
+    j = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert j["metric"].split(";")[0].replace(" x ", "×").replace("N×n_steps", "N×n_steps")[:14] == base["metric"][:14]
+    assert j["unit"] == "particle-steps/s" and j["value"] > 0 and j["higher_is_better"] is True and j["scaling"] == "weak"
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["ms_per_step"] > 0 and j["vs_baseline"] is None
+    assert j["dtype"] == "f64" and j["data"] == "synthetic" and "workload" in j["config"] and "model" not in j["config"]
+    rf = j["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] > 0
+    assert rf["achieved"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    assert rf["kernel"] == "k_pcn_flow_fused" and 0 < rf["frac_algorithmic"] < rf["frac"] < 1 and rf["avg_ms"] > 0
+    cb = j["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"] and cb["unit"] == j["unit"]
+    legs = j["extra"]
+    for name in ("is_only_step", "fused_step_by_regime", "flow_run_maf", "flow_run_f32_mfma", "sharded_path_one_rank_group"):
+        assert name in legs and "error" not in legs[name], (name, legs.get(name))
+    assert legs["sharded_path_one_rank_group"]["importance_step_as_one_chain"] is True
+    assert legs["flow_run_maf"]["torch_ops_in_mutation_loop"] == 0
