@@ -2156,6 +2156,52 @@ def test_reference_factor_on_the_device_vs_numpy(eng, d):
     assert eng.reference_factor_status() == -1
 
 
+@pytest.mark.parametrize("d,nu", [(64, 0.0), (48, 0.0), (64, 6.0), (34, 0.0)])
+def test_pcn_mutate_flow_above_32_dimensions_equals_split_calls(eng, d, nu):
+    """A neural proposal density at 32 < d <= 64 - the widths the flow kernels take (wider flows stay on their torch modules
+    and run through the callables path) - (smc/base.py:507-519 is called for any `dims`): asmc_pcn_mutate_flow composes
+    each step from the matrix-core propose kernel, the flow kernel, the targets and the accept / copy kernels on the x state - a
+    one-kernel step does not fit (four 64-dimensional coupling layers are 160 KB of split-fp16 operands).  Those are
+    the kernels behind the one-call-at-a-time ABI (propose / coupling_logprob / mixture_logpdf / accept), each checked against
+    the oracle elsewhere: the device-side loop must return their bits - positions, carried log-probabilities, accept counts."""
+    from conftest import random_coupling_flow
+
+    n, n_steps, beta, rho = 3000, 4, 0.35, 0.3
+    flow = random_coupling_flow(d, 2, 64)
+    dev = flow.device_coupling(eng)
+    g = torch.Generator(eng.device).manual_seed(5)
+    x0 = torch.randn((n, d), device=eng.device, dtype=torch.float64, generator=g)
+    t_ll = eng.make_mixture([0.0, -0.3], np.stack([np.full(d, 0.4), np.full(d, -0.4)]), np.ones((2, d)) * 1.5)
+    t_lp = eng.make_mixture([-0.5 * d * np.log(2 * np.pi)], np.zeros((1, d)), np.ones((1, d)))
+    mu = eng.asarray(0.1 * np.arange(d) / d)
+    A = np.eye(d) + 0.03 * np.tril(np.random.default_rng(2).normal(size=(d, d)), -1)
+    L, Linv = eng.asarray(A), eng.asarray(np.linalg.inv(A))
+
+    def init():
+        x = x0.clone()
+        return x, eng.mixture_logpdf(x, t_ll), eng.mixture_logpdf(x, t_lp), eng.coupling_logprob(x, dev)
+
+    xa, lla, lpa, lqa = init()
+    eng.profile(True)
+    n_acc, rho_hist, rho_out = eng.pcn_mutate_flow(xa, lla, lpa, lqa, beta, mu, L, Linv, t_ll, t_lp, dev, 77, 1000, rho, n_steps, 5,
+                                                   0.234, False, "f64", nu)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert "k_pcn_flow_fused" not in rep and any(k.startswith("k_coupling_logprob") for k in rep), sorted(rep)
+    xb, llb, lpb, lqb = init()
+    acc_b = []
+    for t in range(n_steps):
+        xp, q0, q1 = eng.pcn_propose(xb, mu, L, Linv, rho, 77, 1000, 5 + t, nu=nu)
+        lqn = eng.coupling_logprob(xp, dev)
+        acc_b.append(eng.pcn_accept(xb, xp, llb, lpb, lqb, eng.mixture_logpdf(xp, t_ll), eng.mixture_logpdf(xp, t_lp), lqn, q0, q1,
+                                    beta, 77, 1000, 5 + t))
+    assert 0 < sum(acc_b) < n * n_steps and n_acc.tolist() == acc_b and rho_out == rho
+    for a, b in ((xa, xb), (lla, llb), (lpa, lpb), (lqa, lqb)):
+        assert torch.equal(a, b)
+    torch.testing.assert_close(lla, eng.mixture_logpdf(xa, t_ll), rtol=1e-9, atol=1e-9)
+    torch.testing.assert_close(lqa, eng.coupling_logprob(xa, dev), rtol=1e-5, atol=2e-3)
+
+
 @pytest.mark.parametrize("hidden,n", [(64, 640), (64, 100_000), (128, 6400), (128, 100_000), (32, 100_000)])
 def test_fused_flow_step_is_repeatable_and_carries_the_densities_of_its_positions(eng, hidden, n):
     """Twelve calls of the fused flow-proposal step on fresh copies of one batch, other kernels in between (tools/stress_fused.py
