@@ -98,6 +98,10 @@ def lib():
                 i64,
                 [i64, ci, vp, vp, vp, vp, d, vp, vp, vp, d, vp, vp, ci, ci, vp, vp, vp, vp, u64, u64, u32, ci, ci, ci],
             ),
+            "orc_tpcn_flow_step_kind": (
+                i64,
+                [i64, ci, vp, vp, vp, vp, d, vp, vp, vp, d, d, vp, vp, ci, ci, vp, vp, vp, vp, u64, u64, u32, ci, ci, ci],
+            ),
             "orc_max_threads": (ci, []),
             "orc_set_margin_sink": (None, [vp]),
         }
@@ -495,6 +499,30 @@ def pcn_flow_step(x, ll, lp, lq, beta, mu, L, Linv, rho, t_ll, t_lp, weights, bi
                                         ctypes.addressof(a), ctypes.addressof(b), len(ws) // 3, ws[0].shape[0], wp, bp,
                                         loc.ctypes.data, scale.ctypes.data, seed, gid0, step, int(noise == "f32"), int(n_threads),
                                         int(flow_kind == "maf"))
+
+
+def tpcn_flow_step(x, ll, lp, lq, beta, mu, L, Linv, rho, nu, t_ll, t_lp, weights, biases, loc, scale, seed, gid0, step,
+                   noise="f64", n_threads=1, flow_kind="coupling"):
+    """In-place t-preconditioned Crank-Nicolson step (Student-t reference, `nu` > 0 degrees of freedom) whose proposal
+    density is a neural flow: the reference's default pairing (smc/minipcn.py:46-49 `step_fn="tpcn"` around
+    smc/base.py:507-519 with flows/torch/flows.py:140 `flow_class="MAF"`).  Returns #accepted."""
+    assert x.dtype == np.float64 and x.flags.c_contiguous
+    n, d = x.shape
+    mu, L, Linv = _f64(mu), _f64(L), _f64(Linv)
+    ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+    bs = [np.ascontiguousarray(b, dtype=np.float32) for b in biases]
+    loc = np.ascontiguousarray(loc, dtype=np.float32)
+    scale = np.ascontiguousarray(scale, dtype=np.float32)
+    wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+    bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
+    a, b = t_ll.c_struct(), t_lp.c_struct()
+    r = lib().orc_tpcn_flow_step_kind(n, d, _p(x), _p(ll), _p(lp), _p(lq), beta, _p(mu), _p(L), _p(Linv), rho, float(nu),
+                                      ctypes.addressof(a), ctypes.addressof(b), len(ws) // 3, ws[0].shape[0], wp, bp,
+                                      loc.ctypes.data, scale.ctypes.data, seed, gid0, step, int(noise == "f32"), int(n_threads),
+                                      int(flow_kind == "maf"))
+    if r < 0:
+        raise ValueError(f"orc_tpcn_flow_step_kind failed ({r})")
+    return r
 
 
 def transform(x, kind, periodic, lower, upper, mean=None, std=None, eps=1e-6, inverse=False):

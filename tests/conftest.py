@@ -73,6 +73,27 @@ def random_coupling_flow(d, n_layers=4, hidden=64, seed=3, dtype=None, device="c
     return flow
 
 
+def random_maf_flow(d, n_transforms=3, hidden=64, seed=3):
+    """MAFFlow with every (masked) dense layer randomised and a non-trivial standardisation."""
+    import torch
+
+    from aspire_amd.flows import MAFFlow, _MaskedLinear
+
+    flow = MAFFlow(d, n_transforms=n_transforms, hidden_features=(hidden, hidden), seed=seed, device="cpu", dtype=torch.float32)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for layer in flow.layers:
+            for m in layer.net:
+                if isinstance(m, _MaskedLinear):
+                    fan = max(1.0, float(m.mask.sum(1).mean()))
+                    m.weight.copy_((0.7 * torch.randn(m.weight.shape, generator=g) / fan**0.5).to(m.weight))
+                    m.bias.copy_((0.1 * torch.randn(m.bias.shape, generator=g)).to(m.bias))
+        flow.loc = (0.3 * torch.randn(d, generator=g)).to(flow.loc)
+        flow.scale = (0.5 + torch.rand(d, generator=g)).to(flow.scale)
+    flow._version += 1
+    return flow
+
+
 def flow_log_prob_f64(flow, x):
     """log q(x) of a CouplingFlow evaluated in fp64 by the torch modules on the CPU: the SAME fp32 parameters, widened
     (the judge of the flow kernels' arithmetic: the north star's bar is 1e-6 relative on log-weights)."""

