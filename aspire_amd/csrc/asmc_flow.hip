@@ -314,12 +314,20 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_maf_logprob(int64_t n, int d, 
 // pass k every coordinate whose inputs have degree < k is final (its inputs were final a pass earlier), so d passes fix them
 // all, and the last pass's s is the log-determinant.  Values of not-yet-final coordinates are clamped into the fp16 operand
 // range: they reach other coordinates only through masked (zero) weights, and 0 x finite = 0.
+// Early exit (round 5): a pass that returns its input bit for bit - every coordinate of every particle of the tile - has found
+// the fixed point; every further pass would return the same bits and the same s, so the loop stops there and the result is
+// the d-pass result exactly.  A trained flow close to its initialisation (weak couplings) gets there in a few passes; a
+// transform with a full-length dependency chain still takes d of them.
+// Range: a not-yet-final coordinate (up to +-60000) times a first-layer weight can leave the fp16 range in a HIDDEN
+// unit; the inf then meets masked (zero) weights, 0 x inf = NaN lands in coordinates that were already final and the clamp
+// would turn it into -60000 without a trace.  So the operand maximum is kept over ALL passes of all transforms and a NaN in
+// any pass's output is a failure of its own: either makes the row's log q NaN (rejected and counted like any NaN density).
 template <int H, int W, typename XT, int FLOW_THREADS>
 __global__ __launch_bounds__(FLOW_THREADS) void k_maf_sample(int64_t n, int d, const float* __restrict__ packed, int n_layers,
                                                             const float* __restrict__ loc, const float* __restrict__ scale,
                                                             float ladj0, float base_const, unsigned long long seed,
                                                             unsigned long long gid0, uint32_t draw_id, XT* __restrict__ x,
-                                                            double* __restrict__ out) {
+                                                            double* __restrict__ out, int all_passes) {
     extern __shared__ __align__(16) float sp[];
     using FD = FlowDims<H, W>;
     constexpr int FLOW_WAVES = FLOW_THREADS / 64, DL = H / 2;
@@ -352,18 +360,26 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_maf_sample(int64_t n, int d, c
             const float* lp = sp + (size_t)c * FD::LAYER;
 #pragma unroll
             for (int i = 0; i < DL; i++) xv[i] = 0.0f;
-            float ladj_pass = 0.0f, amax_pass = 0.0f;
+            float ladj_pass = 0.0f;
             for (int pass = 0; pass < d; pass++) {
                 float cond[DL], tr[DL];
 #pragma unroll
                 for (int i = 0; i < DL; i++) cond[i] = xv[i], tr[i] = zv[i];
-                ladj_pass = 0.0f, amax_pass = 0.0f;
+                ladj_pass = 0.0f;
+                float amax_pass = 0.0f;
                 coupling_layer_hs<H, W, true>(cond, tr, lp, lane, hh, ladj_pass, amax_pass);
+                bool same = true, nan = false;
+#pragma unroll
+                for (int i = 0; i < DL; i++) {
+                    same = same && (__float_as_uint(tr[i]) == __float_as_uint(xv[i]));  // (xv is the clamped input: equal bits also mean that no clamp was active)
+                    nan = nan || (tr[i] != tr[i]);
+                }
+                amax = fmaxf(amax, nan ? __builtin_inff() : amax_pass);  // every pass counts, not just the last
 #pragma unroll
                 for (int i = 0; i < DL; i++) xv[i] = pass + 1 < d ? fminf(fmaxf(tr[i], -60000.0f), 60000.0f) : tr[i];
+                if (!all_passes && __all(same)) break;  // (wave uniform) the fixed point: this pass's s was evaluated at final inputs
             }
             ladj += ladj_pass;  // (the final pass: every s is evaluated at final inputs)
-            amax = fmaxf(amax, amax_pass);
 #pragma unroll
             for (int i = 0; i < DL; i++) zv[i] = xv[i];
         }
@@ -638,7 +654,8 @@ static int launch_maf_sample(asmc_ctx* ctx, int64_t n, const asmc_coupling* f, u
     const float ladj0 = (float)(-f->log_scale_sum);
     const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
     ASMC_LAUNCH(ctx, st, "k_maf_sample", kern, dim3(grid), dim3(512), lds, st, n, (int)f->dims, f->packed_dev, (int)f->n_layers,
-                f->loc_dev, f->scale_dev, ladj0, base_const, seed, gid0, draw_id, x, out);
+                f->loc_dev, f->scale_dev, ladj0, base_const, seed, gid0, draw_id, x, out,
+                getenv("ASMC_MAF_SAMPLE_ALL_PASSES") ? 1 : 0);  // (diagnostic: the d-pass loop without the fixed-point exit)
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }

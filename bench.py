@@ -546,8 +546,34 @@ def main():
                                      "fused_step_us": round(kq[fk][1] * 1e3, 2) if fk else None,
                                      "draw_us": round(kq["k_maf_sample"][1] * 1e3, 1) if "k_maf_sample" in kq else None,
                                      "torch_ops_in_mutation_loop": 0 if fk and not any(k.startswith("k_pcn_flow_propose") for k in kq) else None}
+            # (d3) the reference's DEFAULTS end to end: step_fn="tpcn" and n_steps = 5 d mutation steps per temperature
+            #      (smc/minipcn.py:46-49, :89-91) with its default flow class as the proposal (flows/torch/flows.py:140) - the
+            #      pairing k_pcn_flow_fused<.., MAF> with the Student-t reference is checked against orc_tpcn_flow_step_kind
+            n_ref = 5 * d
+            run(3, flow=mflow, n=min(n_global, 65536 * world), steps=2, step_fn="tpcn")
+            sync_all()
+            eng.profile(True)
+            t0 = time.perf_counter()
+            spr, postr = run(5, flow=mflow, step_fn="tpcn", steps=n_ref)
+            sync_all()
+            tr_ = time.perf_counter() - t0
+            kr = eng.profile_report()
+            eng.profile(False)
+            fkr = next((k for k in kr if k.startswith("k_pcn_flow_fused")), None)
+            extra["reference_defaults_run"] = {
+                "what": f"sample() with the reference's defaults: step_fn='tpcn', n_steps = 5 d = {n_ref} per temperature "
+                        "(smc/minipcn.py:46-49), MAF proposal (flows/torch/flows.py:140)",
+                "wall_s": round(tr_, 4), "temperatures": len(spr.history.beta), "mcmc_steps_per_temperature": n_ref,
+                "particle_steps_per_s": n_global * len(spr.history.beta) * n_ref / tr_,
+                "log_evidence": float(postr.log_evidence),
+                "abs_err_in_sigma": abs(float(postr.log_evidence) - true_logz) / max(float(postr.log_evidence_error), 1e-300),
+                "mean_accept": float(np.mean(spr.history.mcmc_acceptance)),
+                "fused_step_us": round(kr[fkr][1] * 1e3, 2) if fkr else None,
+                "fused_launches": int(kr[fkr][0]) if fkr else 0,
+                "mutation_path": getattr(spr, "last_mutation_path", None)}
         except Exception as exc:  # an extra leg never costs the line
-            extra["flow_run_maf"] = {"error": repr(exc)}
+            extra.setdefault("flow_run_maf", {"error": repr(exc)})
+            extra.setdefault("reference_defaults_run", {"error": repr(exc)})
         # (e) the headline run with the flow on the fp32 MFMA chain (v_mfma_f32_32x32x2_f32) instead of the default split-fp16
         #     products: same operands to fp32 accuracy, 16/3 of the matrix-pipe time
         if flow_math == "f16x2-split":

@@ -110,6 +110,54 @@ def test_maf_sample_inverts_the_density_pass(eng, d, n_tr, hidden, n, dtype):
     assert not torch.equal(x3, x)
 
 
+@pytest.mark.parametrize("d,n_tr,hidden,n,weak", [(32, 3, 64, 30000, False), (32, 3, 64, 30000, True), (7, 2, 32, 3000, True)])
+def test_maf_sample_fixed_point_exit_returns_the_d_pass_bits(eng, monkeypatch, d, n_tr, hidden, n, weak):
+    """k_maf_sample stops inverting a transform once a pass returns its input bit for bit (round 5): the rows and log q are the
+    bits of the full d-pass loop (ASMC_MAF_SAMPLE_ALL_PASSES=1), for a flow with strong couplings (where a transform needs its d
+    passes anyway) and for a weakly coupled one (the shape of a trained, near-identity flow), which finishes in a few passes."""
+    flow = random_maf(d, n_tr, hidden, seed=14)
+    if weak:
+        from aspire_amd.flows import _MaskedLinear
+
+        with torch.no_grad():
+            for layer in flow.layers:
+                last = [m for m in layer.net if isinstance(m, _MaskedLinear)][-1]
+                last.weight.mul_(0.02)
+        flow._version += 1
+    dev = flow.device_coupling(eng)
+    x, lq = eng.coupling_sample(n, torch.float64, dev, 77, 0, 3)
+    monkeypatch.setenv("ASMC_MAF_SAMPLE_ALL_PASSES", "1")
+    x2, lq2 = eng.coupling_sample(n, torch.float64, dev, 77, 0, 3)
+    assert torch.equal(x, x2) and torch.equal(lq, lq2)
+    assert torch.isfinite(lq).all()
+
+
+def test_maf_sample_flags_a_transient_overflow(eng):
+    """an intermediate pass whose hidden activations leave the fp16 operand range (a not-yet-final coordinate times a
+    large first-layer weight) poisons coordinates that were already final through 0 x inf; the range check now covers EVERY pass,
+    so such a row comes back with log q = NaN instead of a silently clamped position."""
+    from aspire_amd.flows import _MaskedLinear
+
+    d = 8
+    flow = random_maf(d, 1, 32, seed=5)
+    with torch.no_grad():
+        first = [m for m in flow.layers[0].net if isinstance(m, _MaskedLinear)][0]
+        last = [m for m in flow.layers[0].net if isinstance(m, _MaskedLinear)][-1]
+        first.weight.mul_(400.0)   # hidden pre-activations of garbage inputs leave the fp16 range ...
+        last.weight.mul_(30.0)     # ... and the shifts t are large enough to produce such inputs
+    flow._version += 1
+    dev = flow.device_coupling(eng)
+    x, lq = eng.coupling_sample(4096, torch.float64, dev, 5, 0, 1)
+    ok = torch.isfinite(lq)
+    # rows that came back finite are exact: density of the returned rows in fp64
+    if ok.any():
+        ref = flow.log_prob_f64(x[ok]).to(lq.device)
+        good = torch.isfinite(ref)
+        rel = ((lq[ok][good] - ref[good]).abs() / ref[good].abs().clamp_min(1.0))
+        assert float(rel.max()) <= 1e-4, float(rel.max())
+    assert torch.isfinite(x).all()
+
+
 def _mutation_setup(eng, n, d, seed):
     g = np.random.default_rng(seed)
     x0 = 0.9 * g.normal(size=(n, d))
