@@ -126,7 +126,14 @@ class Aspire:
             self._flow = MAFFlow(dims=self.dims, device=self.device or "cpu", data_transform=data_transform,
                                  dtype=kw.pop("flow_dtype", torch.float32), **kw)
         elif backend == "coupling":
-            kw = dict(self.flow_kwargs)
+            kw = {k: v for k, v in self.flow_kwargs.items() if k != "flow_class"}
+            if "transforms" in kw:  # zuko's name for the number of transforms
+                kw["n_layers"] = int(kw.pop("transforms"))
+            known = {"n_layers", "hidden_features", "seed", "flow_dtype"}
+            unknown = sorted(k for k in kw if k not in known)
+            if unknown:  # zuko-only options (bins, passes, randperm, ...) of the class this flow stands in for
+                logger.warning("CouplingFlow ignores flow_kwargs %s (zuko options without a counterpart here)", unknown)
+                kw = {k: v for k, v in kw.items() if k in known}
             self._flow = CouplingFlow(dims=self.dims, device=self.device or "cpu", data_transform=data_transform,
                                       dtype=kw.pop("flow_dtype", torch.float32), **kw)
         elif backend == "gaussian":
@@ -137,8 +144,6 @@ class Aspire:
     def fit(self, samples: Samples, checkpoint_path: str | None = None, checkpoint_save_config: bool = True,
             overwrite: bool = False, **kwargs) -> History:
         """aspire.py:208-270 (flow training runs in PyTorch, upstream of the hot path)."""
-        if checkpoint_path is not None:
-            raise NotImplementedError("HDF5 checkpoint files are out of scope (h5py unavailable)")
         if self.xp is None:
             self.xp = samples.xp
         if self.parameters is None and samples.parameters is not None:
@@ -147,7 +152,110 @@ class Aspire:
             self.init_flow()
         self.training_samples = samples
         logger.info(f"Training with {len(samples.x)} samples")
-        return self.flow.fit(samples.x, **kwargs) or FlowHistory()
+        history = self.flow.fit(samples.x, **kwargs) or FlowHistory()
+        if checkpoint_path is not None:  # aspire.py:251-269: config group (once) and the flow (if missing, or overwrite)
+            store = self._open_checkpoint_store(checkpoint_path)
+            if store is None:
+                self._write_config_sidecar(checkpoint_path, sampler=False, save_config=checkpoint_save_config)
+            else:
+                with store as h5_file:
+                    if checkpoint_save_config:
+                        if "aspire_config" in h5_file:
+                            del h5_file["aspire_config"]
+                        self.save_config(h5_file, include_sampler_config=False)
+                    if "flow" in h5_file:
+                        if overwrite:
+                            del h5_file["flow"]
+                            self._try_save_flow(h5_file)
+                    else:
+                        self._try_save_flow(h5_file)
+        return history
+
+    # ---- checkpoint files (aspire.py:501-557, 799-870) ----------------------------------------------------------------
+    @staticmethod
+    def _is_hdf5_path(path) -> bool:
+        return str(path).lower().endswith((".h5", ".hdf5"))
+
+    def _open_checkpoint_store(self, path):
+        """The file behind `checkpoint_path`, opened for appending: an h5py File (through `io.open_h5`, the reference's
+        `AspireFile`) when the path names an HDF5 file and h5py imports, else None - the caller then takes the pickle route
+        (`.pkl` sampler checkpoints + a JSON sidecar with the two config dictionaries)."""
+        if not self._is_hdf5_path(path):
+            return None
+        from . import io
+
+        try:
+            return io.open_h5(path, "a")
+        except RuntimeError as exc:  # h5py is not installed
+            logger.warning("%s; writing pickle checkpoints next to %s instead", exc, path)
+            return None
+
+    @staticmethod
+    def _pickle_checkpoint_path(path) -> str:
+        from pathlib import Path
+
+        p = Path(path)
+        return str(p if p.name.lower().endswith((".pkl", ".pickle")) else p.with_suffix(".pkl"))
+
+    def _write_config_sidecar(self, path, sampler: bool, save_config: bool = True) -> None:
+        """Pickle route: `<checkpoint>.config.json` holds what the HDF5 route stores as the `aspire_config` and
+        `sampler_config` groups."""
+        if not save_config:
+            return
+        import json
+        from pathlib import Path
+
+        side = Path(self._pickle_checkpoint_path(path)).with_suffix(".config.json")
+        doc = {"aspire_config": self.config_dict(include_sampler_config=False)}
+        if sampler and self.sampler is not None:
+            cfg = self.sampler.config_dict(include_sample_calls="last")
+            if hasattr(self, "_last_sampler_type"):
+                cfg["sampler_type"] = self._last_sampler_type
+            doc["sampler_config"] = cfg
+        with open(side, "w") as f:
+            json.dump(doc, f, indent=2, default=str)
+
+    def _try_save_flow(self, h5_file, path: str = "flow") -> bool:
+        """`save_flow` for flows that can be stored (a flow with a data transform, or a user-supplied proposal without `save`,
+        is skipped with a warning: the checkpoint stays usable, the flow has to be rebuilt by the caller)."""
+        try:
+            self.save_flow(h5_file, path=path)
+            return True
+        except (NotImplementedError, AttributeError) as exc:
+            logger.warning("flow not saved to the checkpoint file: %s", exc)
+            if path in h5_file:
+                del h5_file[path]
+            return False
+
+    def save_config(self, h5_file, path: str = "aspire_config", **kwargs) -> None:
+        """aspire.py:799-819: the configuration as one group of dotted datasets."""
+        from .io import recursively_save_to_h5_file
+
+        recursively_save_to_h5_file(h5_file, path, self.config_dict(**kwargs))
+
+    def save_sampler_config(self, h5_file, path: str = "sampler_config", **kwargs) -> None:
+        """aspire.py:821-851: the configuration of the last sampler (+ `sampler_type`)."""
+        from .io import recursively_save_to_h5_file
+
+        config = self.sampler.config_dict(**kwargs) if self.sampler else {}
+        if hasattr(self, "_last_sampler_type"):
+            config["sampler_type"] = self._last_sampler_type
+        recursively_save_to_h5_file(h5_file, path, config)
+
+    def save_flow(self, h5_file, path: str = "flow") -> None:
+        """aspire.py:853-866."""
+        if self.flow is None:
+            raise ValueError("Flow has not been initialized.")
+        self.flow.save(h5_file, path=path)
+
+    def load_flow(self, h5_file, path: str = "flow") -> None:
+        """aspire.py:868-883: the flow class follows `flow_backend` / `flow_kwargs["flow_class"]` as in `init_flow`."""
+        backend = str(self.flow_backend).lower()
+        fc = str(self.flow_kwargs.get("flow_class", "MAF")).upper()
+        if backend == "gaussian":
+            raise ValueError("the analytic Gaussian proposal has no parameters to load")
+        cls = MAFFlow if (backend == "maf" or (backend == "zuko" and fc == "MAF") or fc == "MAF" and backend != "coupling") else CouplingFlow
+        self._flow = cls.load(h5_file, path=path, device=self.device or "cpu")
 
     def get_sampler_class(self, sampler_type: str) -> Callable:
         """aspire.py:272-305."""
@@ -212,8 +320,6 @@ class Aspire:
                          preconditioning_kwargs: dict | None = None, checkpoint_path: str | None = None,
                          checkpoint_every: int = 1, checkpoint_save_config: bool = True, **kwargs) -> Samples:
         """aspire.py:383-570."""
-        if checkpoint_path is not None:
-            raise NotImplementedError("HDF5 checkpoint files are out of scope; pass checkpoint_callback instead")
         SamplerClass = self.get_sampler_class(sampler)
         init_params = signature(SamplerClass.__init__).parameters
         sampler_kwargs = {k: v for k, v in kwargs.items() if k in init_params and k != "self"}
@@ -221,12 +327,40 @@ class Aspire:
         self._sampler = self.init_sampler(sampler, preconditioning=preconditioning,
                                           preconditioning_kwargs=preconditioning_kwargs, **sampler_kwargs)
         self._last_sampler_type = sampler
+        saved_flow, hdf5_route = False, False
+        if checkpoint_path is not None:  # aspire.py:501-529
+            supports = {"checkpoint_file_path", "checkpoint_every"}.issubset(signature(self._sampler.sample).parameters)
+            store = self._open_checkpoint_store(checkpoint_path)
+            hdf5_route = store is not None
+            if not supports:
+                logger.warning(f"Sampler {sampler} does not support checkpointing. Checkpoint will not be saved.")
+            else:
+                kwargs.setdefault("checkpoint_file_path", checkpoint_path if hdf5_route else self._pickle_checkpoint_path(checkpoint_path))
+                kwargs.setdefault("checkpoint_every", checkpoint_every)
+            if hdf5_route:
+                with store as h5_file:
+                    if self.flow is not None and "flow" not in h5_file:
+                        saved_flow = self._try_save_flow(h5_file)
         samples = self._sampler.sample(n_samples, **kwargs)
+        if checkpoint_path is not None:  # aspire.py:539-557: the two config groups behind the sampler's own /checkpoint/state
+            if hdf5_route:
+                with self._open_checkpoint_store(checkpoint_path) as h5_file:
+                    if checkpoint_save_config:
+                        for grp in ("aspire_config", "sampler_config"):
+                            if grp in h5_file:
+                                del h5_file[grp]
+                        self.save_config(h5_file, include_sampler_config=False)
+                        self.save_sampler_config(h5_file, include_sample_calls="last")
+                    if self.flow is not None and not saved_flow and "flow" not in h5_file:
+                        self._try_save_flow(h5_file)
+            else:
+                self._write_config_sidecar(checkpoint_path, sampler=True, save_config=checkpoint_save_config)
         self._last_sample_posterior_kwargs = {
             "n_samples": n_samples, "sampler": sampler, "xp": xp, "return_history": return_history,
             "preconditioning": preconditioning, "preconditioning_kwargs": preconditioning_kwargs,
             "sampler_init_kwargs": sampler_kwargs,
             "sample_kwargs": {k: v for k, v in kwargs.items() if k not in ("rng", "checkpoint_callback")},
+            "checkpoint_path": None if checkpoint_path is None else str(checkpoint_path),
         }
         out_xp = xp if xp is not None else (self.xp if self.xp is not None else np)
         samples = samples.to_namespace(out_xp) if is_torch_namespace(out_xp) else samples.to_numpy()
