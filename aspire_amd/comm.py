@@ -65,6 +65,12 @@ class Comm:
     def barrier(self):
         pass
 
+    def signal(self, tag: str) -> None:
+        """One rank tells the others that a long host-side job (flow training) is done - see TorchDistComm.signal."""
+
+    def await_signal(self, tag: str, timeout_s: float = 86400.0) -> None:
+        """Wait for `signal(tag)` of the producing rank without sitting in a collective."""
+
     def chain_recv(self) -> float | None:
         return None
 
@@ -253,6 +259,36 @@ class TorchDistComm(Comm):
 
     def barrier(self):
         self.dist.barrier(group=self.group)
+
+    # A wait of UNBOUNDED length (one rank trains a flow, the others wait for its parameters) must not sit inside a collective:
+    # the NCCL / gloo watchdog ends a collective that has waited its timeout (10-30 min by default).  The producer sets a key in
+    # the process group's key-value store when it is done; the consumers block on that key with a day-long timeout and only then
+    # enter the broadcast.  (Private accessor of torch.distributed; without it the wait degrades to the collective itself.)
+    def _store(self):
+        try:
+            from torch.distributed import distributed_c10d as c10d
+
+            return c10d._get_default_store()
+        except Exception:
+            return None
+
+    def signal(self, tag: str) -> None:
+        st = self._store()
+        if st is not None:
+            st.set(f"asmc/{tag}/{self._signal_epoch(tag, bump=True)}", b"1")
+
+    def await_signal(self, tag: str, timeout_s: float = 86400.0) -> None:
+        st = self._store()
+        if st is not None:
+            from datetime import timedelta
+
+            st.wait([f"asmc/{tag}/{self._signal_epoch(tag, bump=True)}"], timedelta(seconds=float(timeout_s)))
+
+    def _signal_epoch(self, tag: str, bump: bool) -> int:
+        ep = self.__dict__.setdefault("_signal_epochs", {})
+        if bump:
+            ep[tag] = ep.get(tag, 0) + 1
+        return ep.get(tag, 0)
 
     # exact-cdf carry: rank r waits for the exact running sum of ranks < r, then forwards its own
     def chain_recv(self) -> float | None:

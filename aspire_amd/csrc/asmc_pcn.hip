@@ -3281,6 +3281,7 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
         ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
         ASMC_REQUIRE(prm->x_dtype == ASMC_F64 || prm->x_dtype == ASMC_F32, "bad x_dtype");
         ASMC_REQUIRE(prm->mu_dev && prm->L_dev && prm->Linv_dev, "null reference-Gaussian pointer");
+        ASMC_REQUIRE(work_bytes >= asmc_pcn_flow_work_bytes(n, prm->d, prm->x_dtype), "work buffer too small");  // (as documented, whichever path serves the call)
         int rc = check_mixture(prm->log_likelihood);
         if (!rc) rc = check_mixture(prm->log_prior);
         if (rc) return rc;
@@ -3325,16 +3326,32 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
             mix[k]->mu_dev = p2.Linv_dev + (size_t)D * D + (size_t)k * 2 * ASMC_MAX_COMPONENTS * D;
             mix[k]->prec_dev = mix[k]->mu_dev + (size_t)ASMC_MAX_COMPONENTS * D;
         }
-        // the unpadding copy must sit behind the mutation on the stream whether or not the caller defers the read-back
+        // The unpadding copy must sit behind the mutation on the stream AND in front of the read-back's synchronisation: the
+        // blocking form returns with x final (it used to synchronise inside the impl and enqueue the copy after
+        // that, so a C caller reading x on another stream saw the padded run's input).  So the impl always runs deferred
+        // here, the copy follows, and the blocking form collects afterwards.
+        const int caller_defers = ctx->mutate_defer;
+        ctx->mutate_defer = 1;
         rc = pcn_mutate_flow_impl(ctx, n, xp, ll, lp, lq, &p2, flow, work_dev, work_bytes, n_steps, step0, rho_inout_host, n_accept_host,
                                   rho_hist_host, stream, d);
+        ctx->mutate_defer = caller_defers;
+        if (rc == ASMC_ERR_UNSUPPORTED) {
+            // the one-kernel step declined after the pre-check (no register path for this pointer, no coordinate-major state): nothing
+            // of the caller's has been touched yet (only the padded copy was whitened) - the unpadded path serves the shape, as before
+            ctx->mutate_pending_steps = 0;
+            return pcn_mutate_flow_impl(ctx, n, x, ll, lp, lq, prm, flow, work_dev, work_bytes, n_steps, step0, rho_inout_host,
+                                        n_accept_host, rho_hist_host, stream, 0);
+        }
         if (rc) return rc;
         if (es == 8)
             ASMC_LAUNCH(ctx, st, "k_unpad_rows", k_unpad_rows<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const double*)xp, (double*)x);
         else
             ASMC_LAUNCH(ctx, st, "k_unpad_rows", k_unpad_rows<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const float*)xp, (float*)x);
         ASMC_LAUNCH_CHECK();
-        return ASMC_OK;
+        if (caller_defers) return ASMC_OK;  // asmc_pcn_mutate_flow_result waits for the mutation's event; the copy is stream-ordered behind it
+        ctx->mutate_pending_steps = 0;
+        // (stream synchronisation, not the event recorded in front of the copy: x must be final when this call returns)
+        return mutate_flow_collect(ctx, n_steps, rho_inout_host, n_accept_host, rho_hist_host, st);
     }
     return pcn_mutate_flow_impl(ctx, n, x, ll, lp, lq, prm, flow, work_dev, work_bytes, n_steps, step0, rho_inout_host, n_accept_host,
                                 rho_hist_host, stream, 0);

@@ -68,6 +68,8 @@ def encode_for_hdf5(value: Any) -> Any:
         return str(value)
     if isinstance(value, dict):
         return {key: encode_for_hdf5(item) for key, item in value.items()} if value else EMPTY_DICT_TOKEN
+    if isinstance(value, set):  # (utils.py:679-680: element-wise; no HDF5 type takes a set, so the writer's str() fall-back stores it)
+        return {encode_for_hdf5(item) for item in value}
     if isinstance(value, (list, tuple)):
         if value and all(isinstance(item, str) for item in value):
             return _string_array(value)
@@ -101,6 +103,8 @@ def decode_from_hdf5(value: Any) -> Any:
         return {(key.decode("utf-8") if isinstance(key, bytes) else key): decode_from_hdf5(item) for key, item in value.items()}
     if isinstance(value, (list, tuple)):
         return type(value)(decode_from_hdf5(item) for item in value)
+    if isinstance(value, set):
+        return {decode_from_hdf5(item) for item in value}
     return value
 
 
@@ -160,8 +164,14 @@ def _write_byte_dataset(where, name: str, payload: bytes) -> None:
 
 
 def dump_pickle_to_hdf(memfp, fp, path: str | None = None, dsetname: str = "state") -> None:
-    """The bytes of an in-memory pickle stream (`memfp`, any object with `getvalue()`) -> `<path>/<dsetname>`."""
-    _write_byte_dataset(fp if path is None else fp.require_group(path), dsetname, memfp.getvalue())
+    """The bytes of a pickle stream -> `<path>/<dsetname>`.  `memfp`: a `BytesIO` (`getvalue()`), or - as the reference
+    accepts (`utils.py:733-757`: `seek(0)`, `read()`) - any seekable binary stream."""
+    if hasattr(memfp, "getvalue"):
+        payload = memfp.getvalue()
+    else:
+        memfp.seek(0)
+        payload = memfp.read()
+    _write_byte_dataset(fp if path is None else fp.require_group(path), dsetname, payload)
 
 
 def dump_state(state, fp, path: str | None = None, dsetname: str = "state", protocol: int = pickle.HIGHEST_PROTOCOL) -> None:

@@ -260,12 +260,20 @@ class FlowPreconditioningTransform:
             # the latent space is fitted to the WHOLE population, once: every rank contributes an equal strided share of at most
             # `fit_subsample` rows (all-gather, as the Student-t reference fit does), rank 0 trains on them, and its parameters
             # go to everyone - training is not bit-reproducible across processes, and every chain must run in the SAME space
-            m = int(self.fit_kwargs.get("fit_subsample", 16384))
-            k = max(1, min(m // comm.world, ut.shape[0]))
+            # `fit_subsample` (default 16384 pooled rows; None = every row of every rank) is a choice of THIS path: a single-rank
+            # run trains on all its rows, as the reference does (transforms.py:700-716), so the two fit slightly different
+            # problems unless fit_subsample=None.
+            m = self.fit_kwargs.get("fit_subsample", 16384)
+            k = ut.shape[0] if m is None else max(1, min(int(m) // comm.world, ut.shape[0]))
             rows = torch.as_tensor((np.arange(k, dtype=np.int64) * ut.shape[0]) // k, device=ut.device)
             pooled = comm.all_gather_ragged(ut[rows].contiguous(), [int(c) for c in comm.all_gather_i64(np.array([k]))[:, 0]])
+            # the training can take longer than a collective may wait (watchdog timeouts): the other ranks block on a store key,
+            # not inside sync_shards' first collective
             if comm.rank == 0:
                 self.flow.fit(pooled, **{a: b for a, b in self.fit_kwargs.items() if a != "fit_subsample"})
+                comm.signal("flow_precond_fit")
+            else:
+                comm.await_signal("flow_precond_fit")
             self.flow.sync_shards(comm)
         else:
             self.flow.fit(ut, **{a: b for a, b in self.fit_kwargs.items() if a != "fit_subsample"})

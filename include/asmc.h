@@ -647,7 +647,10 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, 
  * importance step, asmc_importance_step): _enqueue starts everything including the read-back into pinned memory and returns,
  * _result waits for the mutation's own read-back (an event recorded behind it - not for what the caller has enqueued since) and
  * hands the results out.  One pending mutation per context; the tables the kernels read
- * (params, flow) must stay alive until _result. */
+ * (params, flow) must stay alive until _result.
+ * Ordering of x_dev: the blocking form returns with x_dev, ll / lp / lq final (it synchronises the stream behind every kernel
+ * that writes them, the un-padding copy of a d < 32 problem included).  After _result the scalars are final and x_dev / ll /
+ * lp / lq are STREAM-ORDERED: work enqueued on `stream` sees them, another stream or the host must synchronise `stream`. */
 int asmc_pcn_mutate_flow_enqueue(asmc_ctx* ctx, int64_t n, void* x_dev, double* ll_dev, double* lp_dev, double* lq_dev,
                                  const asmc_pcn_params* params, const asmc_coupling* flow, void* work_dev,
                                  int64_t work_bytes, int n_steps, uint32_t step0, double rho, asmc_stream stream);

@@ -321,3 +321,27 @@ def test_facade_fit_checkpoint_saves_config_and_flow(monkeypatch, tmp_path):
     asp.fit(Samples(x=x, xp=np), checkpoint_path=path, overwrite=True, n_epochs=1)
     with FakeFile(path, "r") as f:
         assert any(not np.array_equal(np.array(v[()]), w0[k]) for k, v in f["flow/weights"].items())
+
+
+def test_io_accepts_any_seekable_stream_and_set_leaves(tmp_path):
+    """`dump_pickle_to_hdf` takes what the reference takes (utils.py:733-757: seek(0), read()) - a file object, not
+    only a BytesIO - and a set leaf goes through the reference's branch (element-wise encode, then the writer's str() fall-back)."""
+    import io as pyio
+
+    from aspire_amd.io import (decode_from_hdf5, dump_pickle_to_hdf, encode_for_hdf5, load_from_h5_file, load_state,
+                               recursively_save_to_h5_file)
+
+    state = {"iteration": 3, "payload": np.arange(5)}
+    f = FakeGroup()
+    dump_pickle_to_hdf(pyio.BytesIO(pickle.dumps(state)), f, path="checkpoint")
+    assert load_state(f)["iteration"] == 3
+    raw = tmp_path / "blob.bin"
+    raw.write_bytes(pickle.dumps(state))
+    with open(raw, "rb") as fp:  # BufferedReader: no getvalue()
+        fp.read(4)               # (the position does not matter: the reference rewinds)
+        dump_pickle_to_hdf(fp, f, path="checkpoint2")
+    assert np.array_equal(load_state(f, "checkpoint2")["payload"], np.arange(5))
+    assert encode_for_hdf5({"a", None}) == {"a", "__none__"} and decode_from_hdf5({b"__none__", "x"}) == {None, "x"}
+    g = FakeGroup()
+    recursively_save_to_h5_file(g, "cfg", {"tags": {"only"}})
+    assert load_from_h5_file(g, "cfg")["tags"] in ("{'only'}", ["{'only'}"])
