@@ -125,6 +125,8 @@ struct asmc_ctx {
     double* d_ptab;                // [2*32*32 + 32 + 3*8*(1+2*32)] packed pCN parameter block (d <= 32)
     double* d_bmtab;               // [2 * 384] Box-Muller tables of the default noise (asmc_pcn_dev.h bm_pair32)
     double* d_mmtab;               // [2 * 144 * 64] MFMA operand images of L and Linv (d = 64 / 128; NULL when d_max < 64)
+    double* d_f16tab;              // resident tables of the flow-proposal step at d = 64 / 128 (asmc_flow16.hip; allocated on first use)
+    size_t f16tab_bytes;
     // sharded mutation: accept-count exchange between a step and its adaptation (asmc_pcn_set_count_hook)
     int (*count_hook)(void*, asmc_stream);
     void* count_hook_user;
@@ -156,6 +158,17 @@ struct asmc_ctx {
     double* d_ref;     // the same on the device (d_small / d_partials are every other call's scratch): asmc_reference_factor
     int gram_pending_d;  // d of an enqueued, not yet fetched asmc_mean_gram (0: none)
 };
+
+// asmc_flow16.hip: flows of more than 32 dimensions (packed layout 1: 16-particle groups, streamed weights)
+extern "C" int asmc_flow_layout(int kind, int dims, int hidden);
+int64_t asmc_flow16_pack_floats(int kind, int dims, int n_layers, int hidden);
+int asmc_flow16_pack(int kind, int dims, int n_layers, int hidden, const float* const* weights_host, const float* const* biases_host,
+                     float* packed_host);
+int asmc_flow16_logprob(asmc_ctx* ctx, int64_t n, int x_dtype, const void* x, const asmc_coupling* f, double* out, hipStream_t st);
+int asmc_flow16_sample(asmc_ctx* ctx, int64_t n, int x_dtype, const asmc_coupling* f, unsigned long long seed, unsigned long long gid0,
+                       uint32_t draw_id, void* x_out, double* lq_out, hipStream_t st);
+bool asmc_pcn_flow16_ok(const asmc_pcn_params* prm, const asmc_coupling* f);
+bool asmc_flow_math_split();
 
 // asmc_weights.hip: the persistent weight kernel of asmc_importance_step (results in ctx->d_small + 2560 .. + 48)
 // k_ref_factor on the stream (asmc_pcn.hip; asmc_reference_factor and the Student-t EM of asmc_student.hip)

@@ -212,6 +212,7 @@ int asmc_ctx_destroy(asmc_ctx* c) {
     (void)hipFree(c->d_tiles_i);
     (void)hipFree(c->d_gram);
     if (c->d_mmtab) (void)hipFree(c->d_mmtab);
+    if (c->d_f16tab) (void)hipFree(c->d_f16tab);
     (void)hipFree(c->d_guide);
     (void)hipFree(c->d_gamma);
     (void)hipFree(c->d_student);

@@ -409,14 +409,16 @@ bool asmc_flow_math_split() {
 
 static int flow_half_pad(int dims) { return ((dims / 2 + 15) / 16) * 16; }
 
-static bool flow_supported(int dims, int hidden) {
+static bool flow_supported(int dims, int hidden) {  // (layout 0: 32-particle tiles; dims > 32 take layout 1, asmc_flow16.hip)
     const int H = flow_half_pad(dims);
-    return dims >= 2 && dims % 2 == 0 && (H == 16 || H == 32) && (hidden == 32 || hidden == 64 || hidden == 128);
+    return dims <= 32 && dims >= 2 && dims % 2 == 0 && (H == 16 || H == 32) && (hidden == 32 || hidden == 64 || hidden == 128);
 }
 
 static int64_t flow_layer_floats(int H, int Wd) { return (int64_t)(2 * (Wd / 32) + H / 16) * 32 + (int64_t)Wd * H + (int64_t)Wd * Wd + 2LL * H * Wd; }
 
 extern "C" int64_t asmc_coupling_pack_floats(int dims, int n_layers, int hidden) {
+    if (asmc_flow_layout(ASMC_FLOW_COUPLING, dims, hidden) == 1 && n_layers >= 1)  // 32 < dims <= 128: 16-particle groups (asmc_flow16.hip)
+        return asmc_flow16_pack_floats(ASMC_FLOW_COUPLING, dims, n_layers, hidden);
     if (!flow_supported(dims, hidden) || n_layers < 1) {
         asmc_set_error("asmc_coupling_pack_floats: unsupported flow (dims even and <= 64, hidden in {32,64,128})");
         return ASMC_ERR_UNSUPPORTED;
@@ -503,8 +505,10 @@ static int flow_pack_layers(const char* who, int H, int dh, int n_layers, int Wd
 extern "C" int asmc_coupling_pack(int dims, int n_layers, int hidden, const float* const* weights_host,
                                   const float* const* biases_host, float* packed_host) {
     ASMC_REQUIRE(weights_host && biases_host && packed_host, "null pointer");
+    if (asmc_flow_layout(ASMC_FLOW_COUPLING, dims, hidden) == 1 && n_layers >= 1)
+        return asmc_flow16_pack(ASMC_FLOW_COUPLING, dims, n_layers, hidden, weights_host, biases_host, packed_host);
     if (!flow_supported(dims, hidden) || n_layers < 1) {
-        asmc_set_error("asmc_coupling_pack: unsupported flow (dims even and <= 64, hidden in {32,64,128})");
+        asmc_set_error("asmc_coupling_pack: unsupported flow (dims even and <= 128, hidden in {32,64,128})");
         return ASMC_ERR_UNSUPPORTED;
     }
     return flow_pack_layers("asmc_coupling_pack", flow_half_pad(dims), dims / 2, n_layers, hidden, weights_host, biases_host, packed_host);
@@ -520,6 +524,8 @@ static bool maf_supported(int dims, int hidden) {
 }
 
 extern "C" int64_t asmc_maf_pack_floats(int dims, int n_transforms, int hidden) {
+    if (asmc_flow_layout(ASMC_FLOW_MAF, dims, hidden) == 1 && n_transforms >= 1)
+        return asmc_flow16_pack_floats(ASMC_FLOW_MAF, dims, n_transforms, hidden);
     if (!maf_supported(dims, hidden) || n_transforms < 1) {
         asmc_set_error("asmc_maf_pack_floats: unsupported flow (dims <= 32, hidden in {32,64,128})");
         return ASMC_ERR_UNSUPPORTED;
@@ -530,6 +536,8 @@ extern "C" int64_t asmc_maf_pack_floats(int dims, int n_transforms, int hidden) 
 extern "C" int asmc_maf_pack(int dims, int n_transforms, int hidden, const float* const* weights_host,
                              const float* const* biases_host, float* packed_host) {
     ASMC_REQUIRE(weights_host && biases_host && packed_host, "null pointer");
+    if (asmc_flow_layout(ASMC_FLOW_MAF, dims, hidden) == 1 && n_transforms >= 1)
+        return asmc_flow16_pack(ASMC_FLOW_MAF, dims, n_transforms, hidden, weights_host, biases_host, packed_host);
     if (!maf_supported(dims, hidden) || n_transforms < 1) {
         asmc_set_error("asmc_maf_pack: unsupported flow (dims <= 32, hidden in {32,64,128})");
         return ASMC_ERR_UNSUPPORTED;
@@ -668,6 +676,11 @@ extern "C" int asmc_coupling_logprob(asmc_ctx* ctx, int64_t n, int x_dtype, cons
     ASMC_REQUIRE(flow->packed_dev && flow->loc_dev && flow->scale_dev, "flow parameters missing");
     ASMC_REQUIRE(flow->kind == ASMC_FLOW_COUPLING || flow->kind == ASMC_FLOW_MAF, "bad flow kind");
     hipStream_t st = (hipStream_t)stream;
+    if (asmc_flow_layout(flow->kind, flow->dims, flow->hidden) == 1) {
+        ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
+        ASMC_REQUIRE(flow->n_layers >= 1, "bad n_layers");
+        return asmc_flow16_logprob(ctx, n, x_dtype, x_dev, flow, out_dev, st);
+    }
     if (flow->kind == ASMC_FLOW_MAF) {
         if (x_dtype == ASMC_F64) return dispatch_maf<double>(ctx, n, (const double*)x_dev, flow, out_dev, st);
         if (x_dtype == ASMC_F32) return dispatch_maf<float>(ctx, n, (const float*)x_dev, flow, out_dev, st);
@@ -718,6 +731,8 @@ extern "C" int asmc_coupling_sample(asmc_ctx* ctx, int64_t n, int x_dtype, const
     ASMC_REQUIRE(flow->packed_dev && flow->loc_dev && flow->scale_dev, "flow parameters missing");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
     ASMC_REQUIRE(flow->kind == ASMC_FLOW_COUPLING || flow->kind == ASMC_FLOW_MAF, "bad flow kind");
+    if (asmc_flow_layout(flow->kind, flow->dims, flow->hidden) == 1)
+        return asmc_flow16_sample(ctx, n, x_dtype, flow, seed, gid0, draw_id, x_out_dev, lq_out_dev, (hipStream_t)stream);
     if (flow->kind == ASMC_FLOW_MAF) {
         if (!maf_supported(flow->dims, flow->hidden) || flow->n_layers < 1 || !asmc_flow_math_split()) {
             asmc_set_error("asmc_coupling_sample: unsupported autoregressive flow shape, or the fp32 MFMA chain was asked for (split-fp16 layers only)");

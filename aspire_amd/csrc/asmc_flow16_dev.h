@@ -1,0 +1,282 @@
+// asmc_flow16_dev.h — neural-flow densities for 32 < d <= 128 on 16-particle groups (round 5).
+//
+// The d <= 32 kernels (asmc_flow_dev.h) give a wave two 32-particle tiles with the lane halves splitting a particle's
+// coordinates, and keep every layer of the flow resident in LDS.  Neither survives d = 64 / 128: four coupling layers of a
+// 64-dimensional flow are 164 KB of split-fp16 operands, and a lane half would hold 32 - 64 coordinates next to 64
+// accumulator registers.  Here a wave owns SIXTEEN particles and a particle is spread over FOUR lanes - the layout of the
+// d = 64 / 128 pCN kernels (asmc_pcn_mm.hip): lane (p = l & 15, h = l >> 4) holds the D / 4 coordinates
+//     coordinate(s, h) = 8 (s / 2) + 2 h + s % 2,   s = 0 .. D / 4 - 1                               (mm_coord)
+// of particle p, so the proposal x' = mu + L y' (fp64 MFMA 16x16x4, N = 16 particles) hands its result to the flow without a
+// shuffle.  The dense layers run on v_mfma_f32_16x16x32_f16 (A = weights [16 units x 32 inputs], B = activations [32 inputs
+// x 16 particles], fp32 accumulation) as the same three split-fp16 products per K step as the d <= 32 kernels
+// (asmc_flow_dev.h: hi hi, hi lo, lo hi).  In the 16 x 16 accumulator lane (p, g) holds rows 4 g + r of column p: with the
+// contraction order of the next layer chosen as   k(S, g, j) = 16 (2 S + j / 4) + 4 g + j % 4   (K step S, lane group g, slot
+// j of the lane's eight) the accumulators of one layer ARE the B operand of the next - activations never leave the lane, and
+// the first layer takes its inputs straight from the lane's own coordinates (the permutations live in the packed weights).
+// Output rows are packed so that (s_raw, t) of a coordinate land in the lane that holds it, s_raw and t blocks alternating
+// (block 2 m: s_raw of the lane's slots 4 m .. 4 m + 3, block 2 m + 1: their t) - the epilogue runs per pair of blocks and
+// the output accumulators need eight registers however wide the flow is.
+//
+// Weights are STREAMED: the packed operand images (fp16 pairs, split on the host) are cut into chunks of whole output
+// blocks, at most FLOW16_CHUNK_WORDS words each; two LDS slots take them in turn (global_load_lds, no staging registers),
+// chunk q + 1 in flight while the block's waves compute on chunk q, one workgroup barrier per chunk.  Every wave of a block
+// therefore walks the flow in lockstep, one 16-particle group per wave and round.
+// Coupling flows (flows.py CouplingFlow; RealNVP) and masked autoregressive flows (MAFFlow; the reference's default class,
+// flows/torch/flows.py:140-168) share the code: a coupling layer conditions on the lane's first (or second) D / 8 slots and
+// transforms the others, an autoregressive transform conditions on and transforms all D / 4.
+#pragma once
+#include "asmc_common.h"
+#include "asmc_flow_dev.h"
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define FLOW16_CHUNK_WORDS 8192  // 32 KB per LDS slot
+
+__host__ __device__ constexpr int f16_coord(int s, int h) { return 8 * (s / 2) + 2 * h + (s % 2); }  // = mm_coord (asmc_pcn_mm.hip)
+
+template <int KIND, int D, int W>
+struct Flow16 {
+    static_assert(D == 64 || D == 128, "padded dimension");
+    static_assert(W == 32 || W == 64 || W == 128, "hidden width");
+    static constexpr bool MAF = KIND == ASMC_FLOW_MAF;
+    static constexpr int SL = D / 4;                  // coordinate slots per lane
+    static constexpr int CS = MAF ? SL : SL / 2;      // conditioner slots per lane = transformed slots per lane
+    static constexpr int KS1 = CS / 8;                // K = 32 steps of the first dense layer
+    static constexpr int KS2 = W / 32;                // ... of a layer that reads a hidden layer
+    static constexpr int NB1 = W / 16;                // 16-row output blocks of a hidden layer
+    static constexpr int NB3 = CS / 2;                // ... of the output layer: (s_raw, t) x CS slots x 4 lanes / 16
+    static constexpr int OUT = NB3 * 16;
+    static constexpr int BIAS = 2 * W + OUT;          // floats per layer (b1 | b2 | b3 in lane order)
+    static constexpr int BLK1 = KS1 * 512, BLK2 = KS2 * 512;  // 4-byte words per output block: (hi, lo) images of every K step
+    static constexpr int A1 = NB1 * BLK1, A2 = NB1 * BLK2, A3 = NB3 * BLK2;
+    static constexpr int LAYER_A = A1 + A2 + A3;      // words of operand images per layer
+    // blocks per chunk (whole blocks, <= FLOW16_CHUNK_WORDS words) and chunks per matrix
+    static constexpr int BC1 = FLOW16_CHUNK_WORDS / BLK1 < NB1 ? FLOW16_CHUNK_WORDS / BLK1 : NB1;
+    static constexpr int BC2 = FLOW16_CHUNK_WORDS / BLK2 < NB1 ? FLOW16_CHUNK_WORDS / BLK2 : NB1;
+    static constexpr int BC3r = FLOW16_CHUNK_WORDS / BLK2 < NB3 ? FLOW16_CHUNK_WORDS / BLK2 : NB3;
+    static constexpr int BC3 = BC3r < NB3 ? (BC3r / 2) * 2 : BC3r;  // (s_raw, t) block pairs stay in one chunk
+    static_assert(BC1 >= 1 && BC2 >= 1 && BC3 >= 2, "an output block pair must fit a chunk");
+    static_assert(NB1 % BC1 == 0 && NB1 % BC2 == 0 && NB3 % BC3 == 0, "chunks of equal size");
+    static constexpr int P1 = NB1 / BC1, P2 = NB1 / BC2, P3 = NB3 / BC3;
+    static constexpr int NPARTS = P1 + P2 + P3;       // chunks per layer
+    // word offset and length of chunk i of a layer (relative to the layer's operand images)
+    static constexpr __host__ __device__ int part_off(int i) {
+        return i < P1 ? i * BC1 * BLK1 : i < P1 + P2 ? A1 + (i - P1) * BC2 * BLK2 : A1 + A2 + (i - P1 - P2) * BC3 * BLK2;
+    }
+    static constexpr __host__ __device__ int part_words(int i) { return i < P1 ? BC1 * BLK1 : i < P1 + P2 ? BC2 * BLK2 : BC3 * BLK2; }
+};
+
+// words of the packed block: [biases of every layer][operand images of every layer]
+template <int KIND, int D, int W>
+__host__ __device__ constexpr int64_t flow16_words(int n_layers) {
+    return (int64_t)n_layers * (Flow16<KIND, D, W>::BIAS + Flow16<KIND, D, W>::LAYER_A);
+}
+
+// eight fp32 values -> their (hi, lo) fp16 operand halves; the range check rides on the hi halves (asmc_flow_dev.h)
+template <bool RELU>
+__device__ __forceinline__ void f16_split8(const float (&x)[8], half8& hi, half8& lo, unsigned& amax_pk) {
+    unsigned hp[4], lp[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (c == 3)
+            split2_f16<RELU, true>(x[2 * c], x[2 * c + 1], hp[c], lp[c]);
+        else
+            split2_f16<RELU, false>(x[2 * c], x[2 * c + 1], hp[c], lp[c]);
+    }
+    split4_range<!RELU>(hp[0], hp[1], amax_pk);
+    split4_range<!RELU>(hp[2], hp[3], amax_pk);
+    hi = __builtin_bit_cast(half8, flow_u4{hp[0], hp[1], hp[2], hp[3]});
+    lo = __builtin_bit_cast(half8, flow_u4{lp[0], lp[1], lp[2], lp[3]});
+}
+
+// The stream of weight chunks through two LDS slots.  `slots`: 2 x FLOW16_CHUNK_WORDS words of LDS; `gA`: the flow's
+// operand images in HBM (word 0 = chunk 0 of layer 0).  next() closes the previous chunk (every wave of the block is
+// through with it), makes the current one visible and puts the one after it into flight; it returns the current chunk.
+// The sequence wraps: after the last chunk of the last layer comes chunk 0 of layer 0 (the next round's).
+template <class FD, int THREADS>
+struct Flow16Stream {
+    const float* __restrict__ gA;
+    float* slots;
+    int n_layers;
+    int layer, part;  // the chunk that is IN FLIGHT (issued, not yet waited for)
+    unsigned parity;  // slot it goes to
+
+    __device__ __forceinline__ void issue(int l, int p, unsigned slot) {
+        const int off = l * FD::LAYER_A + FD::part_off(p);
+        const int words = FD::part_words(p);
+        // wave w, instruction q: 1 KiB at words (q * WAVES + w) * 256 .. + 255 of the chunk (the LDS side is wave-uniform base +
+        // lane * 16 bytes: contiguous in exactly this order)
+        constexpr int WAVES = THREADS / 64;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int q = wave; q * 256 < words; q += WAVES) {
+            const float* src = gA + off + q * 256 + lane * 4;
+            float* dst = slots + slot * FLOW16_CHUNK_WORDS + q * 256;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    }
+    // called once, before the first round: chunk 0 into slot 0
+    __device__ __forceinline__ void start(const float* g, float* s, int nl) {
+        gA = g, slots = s, n_layers = nl;
+        layer = 0, part = 0, parity = 0;
+        issue(0, 0, 0);
+    }
+    __device__ __forceinline__ const float* next() {
+        // the chunk in flight has landed (this wave's share: vmcnt; everybody's: the barrier), and every wave is past its reads
+        // of the chunk before it - whose slot the chunk after this one may now overwrite
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* cur = slots + parity * FLOW16_CHUNK_WORDS;
+        int l = layer, p = part + 1;
+        if (p == FD::NPARTS) p = 0, l = (l + 1 == n_layers) ? 0 : l + 1;
+        layer = l, part = p, parity ^= 1u;
+        issue(l, p, parity);
+        return cur;
+    }
+};
+
+// acc[b] (b = 0 .. NBC - 1: the chunk's output blocks) = bias + A_b * B over KS K = 32 steps, three fp16 products per step.
+// A: LDS image of the chunk ([block][K step][hi | lo][lane] x 16 bytes); bias: the layer's bias row in lane order (float4 per
+// (block, lane group)), already offset to the chunk's first block.
+template <int NBC, int KS>
+__device__ __forceinline__ void f16_dense(floatx4 (&acc)[NBC], const half8 (&bh)[KS], const half8 (&bl)[KS], const float* __restrict__ A,
+                                          const float* __restrict__ bias, int lane) {
+    const half8* Ap = reinterpret_cast<const half8*>(A) + lane;
+    const int g = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < NBC; b++) acc[b] = *reinterpret_cast<const floatx4*>(bias + (b * 4 + g) * 4);
+#pragma unroll
+    for (int b0 = 0; b0 < NBC; b0 += 2) {
+        constexpr int PB = 2;
+#pragma unroll
+        for (int S = 0; S < KS; S++) {
+            half8 ah[PB], al[PB];
+#pragma unroll
+            for (int e = 0; e < PB; e++) {
+                if (b0 + e < NBC) {
+                    ah[e] = Ap[(size_t)(((b0 + e) * KS + S) * 2) * 64];
+                    al[e] = Ap[(size_t)(((b0 + e) * KS + S) * 2 + 1) * 64];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < PB; e++)
+                if (b0 + e < NBC) acc[b0 + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[e], bh[S], acc[b0 + e], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < PB; e++)
+                if (b0 + e < NBC) acc[b0 + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[e], bl[S], acc[b0 + e], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < PB; e++)
+                if (b0 + e < NBC) acc[b0 + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[e], bh[S], acc[b0 + e], 0, 0, 0);
+        }
+    }
+}
+
+// One layer (coupling layer or autoregressive transform) of one 16-particle group.  xf: the lane's SL standardised
+// coordinates (updated in place); `first` (compile time: the slots must stay registers): the coupling layer conditions on
+// slots [0, CS) and transforms [CS, 2 CS), else the other way round (ignored by autoregressive transforms).  INVERSE: the sampling direction x_b = z_b exp(s) + t.
+template <class FD, int W, int THREADS, bool first, bool INVERSE = false>
+__device__ __forceinline__ void f16_layer(float (&xf)[FD::SL], const float* __restrict__ bias, Flow16Stream<FD, THREADS>& stream,
+                                          int lane, float& ladj, unsigned& amax_pk) {
+    constexpr int CS = FD::CS, KS1 = FD::KS1, KS2 = FD::KS2, NB1 = FD::NB1;
+    // ---- first dense layer: conditioner slots -> hidden 1
+    half8 bh1[KS1], bl1[KS1];
+#pragma unroll
+    for (int S = 0; S < KS1; S++) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = FD::MAF ? xf[8 * S + j] : (first ? xf[8 * S + j] : xf[CS + 8 * S + j]);
+        f16_split8<false>(v, bh1[S], bl1[S], amax_pk);
+    }
+    floatx4 h1[NB1];
+#pragma unroll
+    for (int p = 0; p < FD::P1; p++) {
+        const float* A = stream.next();
+        floatx4 part[FD::BC1];
+        f16_dense<FD::BC1, KS1>(part, bh1, bl1, A, bias + p * FD::BC1 * 16, lane);
+#pragma unroll
+        for (int b = 0; b < FD::BC1; b++) h1[p * FD::BC1 + b] = part[b];
+    }
+    // ---- second: relu(hidden 1) -> hidden 2.  K step S takes the lane's registers of blocks 2 S, 2 S + 1
+    half8 bh2[KS2], bl2[KS2];
+#pragma unroll
+    for (int S = 0; S < KS2; S++) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = h1[2 * S + j / 4][j % 4];
+        f16_split8<true>(v, bh2[S], bl2[S], amax_pk);
+    }
+    floatx4 h2[NB1];
+#pragma unroll
+    for (int p = 0; p < FD::P2; p++) {
+        const float* A = stream.next();
+        floatx4 part[FD::BC2];
+        f16_dense<FD::BC2, KS2>(part, bh2, bl2, A, bias + W + p * FD::BC2 * 16, lane);
+#pragma unroll
+        for (int b = 0; b < FD::BC2; b++) h2[p * FD::BC2 + b] = part[b];
+    }
+    // ---- output layer, a pair of blocks at a time: (s_raw, t) of four of the lane's transformed slots
+#pragma unroll
+    for (int S = 0; S < KS2; S++) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = h2[2 * S + j / 4][j % 4];
+        f16_split8<true>(v, bh2[S], bl2[S], amax_pk);
+    }
+#pragma unroll
+    for (int p = 0; p < FD::P3; p++) {
+        const float* A = stream.next();
+#pragma unroll
+        for (int pr = 0; pr < FD::BC3 / 2; pr++) {
+            floatx4 o[2];
+            f16_dense<2, KS2>(o, bh2, bl2, A + (size_t)pr * 2 * FD::BLK2, bias + 2 * W + (p * FD::BC3 + 2 * pr) * 16, lane);
+            const int m = p * (FD::BC3 / 2) + pr;  // the lane's transformed slots 4 m .. 4 m + 3
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float sraw = o[0][r], tt = o[1][r];
+                const float sv = 2.0f - 4.0f * __builtin_amdgcn_rcpf(__expf(sraw) + 1.0f);  // 2 tanh(sraw / 2)
+                float& xt = FD::MAF ? xf[4 * m + r] : (first ? xf[CS + 4 * m + r] : xf[4 * m + r]);
+                if (INVERSE)
+                    xt = xt * __expf(sv) + tt;
+                else
+                    xt = (xt - tt) * __expf(-sv);
+                ladj -= sv;
+            }
+        }
+    }
+}
+
+// sum over the four lanes p, p + 16, p + 32, p + 48 of a particle
+__device__ __forceinline__ float f16_quad_sum(float q) {
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    return q;
+}
+__device__ __forceinline__ float f16_quad_max(float q) {
+    q = fmaxf(q, __shfl_xor(q, 16, 64));
+    q = fmaxf(q, __shfl_xor(q, 32, 64));
+    return q;
+}
+
+// log q of the group's particles from the lane's standardised coordinates (every lane of a particle returns it)
+template <class FD, int W, int THREADS>
+__device__ __forceinline__ float f16_logprob(float (&xf)[FD::SL], int n_layers, const float* __restrict__ biases,
+                                             Flow16Stream<FD, THREADS>& stream, int lane, float ladj0, float base_const) {
+    float ladj = 0.0f;
+    unsigned amax_pk = 0u;
+    for (int c = 0; c < n_layers; c += 2) {  // (n_layers is uniform over the block: every wave meets the same barriers)
+        f16_layer<FD, W, THREADS, true>(xf, biases + c * FD::BIAS, stream, lane, ladj, amax_pk);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < n_layers) {
+            f16_layer<FD, W, THREADS, false>(xf, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float q = 0.0f;
+#pragma unroll
+    for (int s = 0; s < FD::SL; s++) q = fmaf(xf[s], xf[s], q);
+    q = f16_quad_sum(q);
+    const float lj = f16_quad_sum(ladj);
+    float am = range_pk_max(amax_pk);
+    am = (am != am) ? __builtin_inff() : am;
+    am = f16_quad_max(am);
+    return !(am < FLOW_HS_MAX) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
+}

@@ -3262,6 +3262,80 @@ static int pcn_mutate_flow_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, d
     return mutate_flow_collect(ctx, n_steps, rho_inout_host, n_accept_host, rho_hist_host, st);
 }
 
+// 32 < d <= 128 (x: the state with D = 64 / 128 columns - the problem itself or its zero-padded copy, d_noise = its real
+// dimension then): whiten, n_steps launches of the one-kernel step on 16-particle groups (asmc_flow16.hip), un-whiten.  The
+// carried ll / lp / lq are the step kernel's own (MM_UNWHITEN_X re-evaluates nothing).
+static int pcn_mutate_flow16_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq, const asmc_pcn_params* prm,
+                                  const asmc_coupling* flow, int n_steps, uint32_t step0, double* rho_inout_host,
+                                  int64_t* n_accept_host, double* rho_hist_host, asmc_stream stream, int d_noise) {
+    ASMC_REQUIRE(ctx && x && ll && lp && lq && prm && flow && rho_inout_host && n_accept_host, "null pointer");
+    ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+    ASMC_REQUIRE(n_steps >= 1 && n_steps <= ASMC_MAX_PCN_STEPS, "n_steps out of range (<= 2048 per call)");
+    ASMC_REQUIRE(prm->x_dtype == ASMC_F64 || prm->x_dtype == ASMC_F32, "bad x_dtype");
+    ASMC_REQUIRE(prm->mu_dev && prm->L_dev && prm->Linv_dev, "null reference-Gaussian pointer");
+    ASMC_REQUIRE(*rho_inout_host > 0.0 && *rho_inout_host <= 1.0, "rho must be in (0, 1]");
+    ASMC_REQUIRE(!(prm->nu > 0.0) || prm->nu >= 1.0, "nu must be >= 1 (or <= 0 for the Gaussian reference)");
+    ASMC_REQUIRE(prm->noise == ASMC_NOISE_F64 || prm->noise == ASMC_NOISE_F32, "bad noise mode");
+    ASMC_REQUIRE(ctx->d_mmtab != nullptr && ((uintptr_t)x % 16) == 0, "flow16: ctx was created with d_max <= 32, or a misaligned state");
+    hipStream_t st = as_stream(stream);
+    PcnDev pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.bmtab = ctx->d_bmtab;
+    pd.d = prm->d;
+    pd.d_noise = d_noise;
+    pd.beta = prm->beta;
+    pd.mu = prm->mu_dev;
+    pd.L = prm->L_dev;
+    pd.Linv = prm->Linv_dev;
+    pd.ll = to_dev(prm->log_likelihood);
+    pd.lp = to_dev(prm->log_prior);
+    pd.lq = pd.lp;  // placeholder: the proposal density is the flow
+    pd.seed = prm->seed;
+    pd.gid0 = prm->gid0;
+    pd.noise = prm->noise;
+    pd.nu = prm->nu;
+    double* d_rho = ctx->d_rho;
+    double* d_rho_hist = ctx->d_rho + 8;
+    long long* d_counts = ctx->d_counts;
+    long long* d_block = ctx->d_counts + ASMC_MAX_PCN_STEPS;
+    unsigned long long* d_bad = reinterpret_cast<unsigned long long*>(ctx->d_tilectr + 2 * ASMC_MAX_PCN_STEPS);
+    ASMC_LAUNCH(ctx, st, "k_set_scalar", k_set_scalar, dim3(1), dim3(1), 0, st, d_rho, *rho_inout_host);
+    ASMC_LAUNCH_CHECK();
+    ASMC_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), st));
+    int rc = asmc_pcn_mm_pack(ctx, pd, st);
+    if (rc) return rc;
+    rc = asmc_pcn_flow16_tables(ctx, pd, flow, st);
+    if (rc) return rc;
+    int grid = 0;
+    rc = asmc_pcn_mm_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, MM_WHITEN, d_rho, 0, d_block, &grid, st);
+    if (rc) return rc;
+    for (int t = 0; t < n_steps; t++) {
+        const uint32_t step = step0 + (uint32_t)t;
+        rc = pcn_prepare_gamma(ctx, n, pd, step, st);
+        if (rc) return rc;
+        rc = asmc_pcn_flow16_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, flow, d_rho, step, d_block, &grid, d_bad, st);
+        if (rc) return rc;
+        rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+        if (rc) return rc;
+    }
+    rc = asmc_pcn_mm_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, MM_UNWHITEN_X, d_rho, 0, d_block, &grid, st);
+    if (rc) return rc;
+    long long* h_counts = reinterpret_cast<long long*>(ctx->h_pinned);
+    double* h_rho_hist = ctx->h_pinned + ASMC_MAX_PCN_STEPS + 8;
+    ASMC_HIP(hipMemcpyAsync(h_counts, d_counts, sizeof(long long) * n_steps, hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipMemcpyAsync(h_rho_hist - 8, d_rho, sizeof(double) * (8 + n_steps), hipMemcpyDeviceToHost, st));
+    ASMC_HIP(hipMemcpyAsync(ctx->h_pinned + 8001, d_bad, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    rc = pcn_enqueue_lq_check(ctx, n, lq, st);
+    if (rc) return rc;
+    if (ctx->mutate_defer) {
+        if (!ctx->ev_mutate) ASMC_HIP(hipEventCreateWithFlags(&ctx->ev_mutate, hipEventDisableTiming));
+        ASMC_HIP(hipEventRecord(ctx->ev_mutate, st));
+        ctx->mutate_pending_steps = n_steps;
+        return ASMC_OK;
+    }
+    return mutate_flow_collect(ctx, n_steps, rho_inout_host, n_accept_host, rho_hist_host, st);
+}
+
 extern "C" {
 
 int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* lp, double* lq,
@@ -3273,6 +3347,81 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
     // the identity beyond d, no noise there) wherever the flow's shape is one the kernel takes - any even d for a coupling flow,
     // any d for an autoregressive one.  Round 3 ran propose / flow / accept kernels at d = 8 / 16 (0.35 / 0.42 ms per step
     // at 1M particles) and the x-state split path at the other d (0.8 ms at d = 20).
+    // More than 32 dimensions (round 5): the one-kernel step on 16-particle groups at D = 64 / 128 (asmc_flow16.hip), the
+    // problem zero-padded to D when it is narrower.  Round 4 ran propose / flow / targets / accept / copy kernels at 32 < d <= 64
+    // with a coupling flow (1.2 - 1.8 ms per step at 1M particles) and had no device path for an autoregressive flow there.
+    if (prm->d > 32 && prm->d <= 128 && prm->d == flow->dims && ctx->d_mmtab && !getenv("ASMC_PCN_GENERIC") && !getenv("ASMC_PCN_NOPAD") &&
+        !getenv("ASMC_PCN_XSTATE")) {
+        const int d = prm->d, D = d <= 64 ? 64 : 128;
+        asmc_pcn_params p16 = *prm;
+        p16.d = D;
+        if (D <= ctx->d_max_pad && asmc_pcn_flow16_ok(&p16, flow)) {
+            ASMC_REQUIRE(ll && lp && lq && rho_inout_host && n_accept_host, "null pointer");
+            ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
+            ASMC_REQUIRE(prm->x_dtype == ASMC_F64 || prm->x_dtype == ASMC_F32, "bad x_dtype");
+            ASMC_REQUIRE(prm->mu_dev && prm->L_dev && prm->Linv_dev, "null reference-Gaussian pointer");
+            int rc = check_mixture(prm->log_likelihood);
+            if (!rc) rc = check_mixture(prm->log_prior);
+            if (rc) return rc;
+            hipStream_t st = as_stream(stream);
+            if (d == D && ((uintptr_t)x % 16) == 0)
+                return pcn_mutate_flow16_impl(ctx, n, x, ll, lp, lq, prm, flow, n_steps, step0, rho_inout_host, n_accept_host, rho_hist_host,
+                                              stream, 0);
+            const size_t es = prm->x_dtype == ASMC_F64 ? 8 : 4;
+            const size_t tab_doubles = (size_t)D + 2 * (size_t)D * D + 3 * 2 * (size_t)ASMC_MAX_COMPONENTS * D;
+            const size_t tab_bytes = ((tab_doubles * 8 + 255) / 256) * 256;
+            const size_t need = tab_bytes + (size_t)n * D * es;
+            if (need > ctx->xpad_bytes) {
+                ASMC_HIP(hipStreamSynchronize(st));
+                if (ctx->d_xpad) (void)hipFree(ctx->d_xpad);
+                ctx->d_xpad = nullptr;
+                ctx->xpad_bytes = 0;
+                if (hipMalloc(&ctx->d_xpad, need) != hipSuccess) {
+                    (void)hipGetLastError();
+                    asmc_set_error("pcn: no device memory for the zero-padded copy of the state (%zu bytes)", need);
+                    return ASMC_ERR_NOMEM;
+                }
+                ctx->xpad_bytes = need;
+            }
+            double* tab = reinterpret_cast<double*>(ctx->d_xpad);
+            void* xp = reinterpret_cast<char*>(ctx->d_xpad) + tab_bytes;
+            PcnDev src;
+            memset(&src, 0, sizeof(src));
+            src.mu = prm->mu_dev, src.L = prm->L_dev, src.Linv = prm->Linv_dev;
+            src.ll = to_dev(prm->log_likelihood), src.lp = to_dev(prm->log_prior);
+            src.lq = src.lp;  // (placeholder: the proposal density is the flow)
+            ASMC_LAUNCH(ctx, st, "k_pad_tables", k_pad_tables, dim3(1), dim3(256), 0, st, d, D, src, tab);
+            ASMC_LAUNCH_CHECK();
+            const int grid = grid_for(n * D, ASMC_BLOCK * 4, ASMC_MAX_BLOCKS * 2);
+            if (es == 8)
+                ASMC_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const double*)x, (double*)xp);
+            else
+                ASMC_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const float*)x, (float*)xp);
+            ASMC_LAUNCH_CHECK();
+            p16.mu_dev = tab;
+            p16.L_dev = tab + D;
+            p16.Linv_dev = p16.L_dev + (size_t)D * D;
+            asmc_mixture* mix[2] = {&p16.log_likelihood, &p16.log_prior};
+            for (int k = 0; k < 2; k++) {
+                mix[k]->mu_dev = p16.Linv_dev + (size_t)D * D + (size_t)k * 2 * ASMC_MAX_COMPONENTS * D;
+                mix[k]->prec_dev = mix[k]->mu_dev + (size_t)ASMC_MAX_COMPONENTS * D;
+            }
+            const int caller_defers = ctx->mutate_defer;  // (the un-padding copy goes in front of the read-back's wait: see below)
+            ctx->mutate_defer = 1;
+            rc = pcn_mutate_flow16_impl(ctx, n, xp, ll, lp, lq, &p16, flow, n_steps, step0, rho_inout_host, n_accept_host, rho_hist_host,
+                                        stream, d);
+            ctx->mutate_defer = caller_defers;
+            if (rc) return rc;
+            if (es == 8)
+                ASMC_LAUNCH(ctx, st, "k_unpad_rows", k_unpad_rows<double>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const double*)xp, (double*)x);
+            else
+                ASMC_LAUNCH(ctx, st, "k_unpad_rows", k_unpad_rows<float>, dim3(grid), dim3(ASMC_BLOCK), 0, st, n, d, D, (const float*)xp, (float*)x);
+            ASMC_LAUNCH_CHECK();
+            if (caller_defers) return ASMC_OK;
+            ctx->mutate_pending_steps = 0;
+            return mutate_flow_collect(ctx, n_steps, rho_inout_host, n_accept_host, rho_hist_host, st);
+        }
+    }
     asmc_pcn_params p2 = *prm;
     p2.d = 32;
     if (prm->d >= 2 && prm->d < 32 && prm->d == flow->dims && 32 <= ctx->d_max_pad && !getenv("ASMC_PCN_GENERIC") &&

@@ -457,8 +457,14 @@ int asmc_pcn_flow_fused_launch(asmc_ctx* ctx, int64_t n, int x_dtype, double* ll
 #define MM_STEP_T 3  // MM_STEP with the Student-t reference (tpCN)
 #define MM_XPROPOSE 4    // proposal half of the split path on the x-state: y = Linv (x - mu), y' = a y + rho xi, x' = mu + L y' -> x_prop, quadratic forms
 #define MM_XPROPOSE_T 5  // ... with the Student-t reference
+#define MM_UNWHITEN_X 6  // x = mu + L y only: the carried ll / lp / lq stay (a flow-proposal mutation: log q is not a built-in density)
 bool asmc_pcn_mm_supported(int d, const void* x);
 int asmc_pcn_mm_pack(asmc_ctx* ctx, const PcnDev& pd, hipStream_t st);
+// asmc_flow16.hip: the one-kernel flow-proposal step at d = 64 / 128 (padded), tables built once per mutation
+int asmc_pcn_flow16_tables(asmc_ctx* ctx, const PcnDev& pd, const asmc_coupling* f, hipStream_t st);
+int asmc_pcn_flow16_launch(asmc_ctx* ctx, int64_t n, int x_dtype, void* x, double* ll, double* lp, double* lq, const PcnDev& pd,
+                           const asmc_coupling* f, const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
+                           unsigned long long* nonfinite, hipStream_t st);
 int asmc_pcn_mm_launch(asmc_ctx* ctx, int64_t n, int x_dtype, void* x, double* ll, double* lp, double* lq, const PcnDev& pd,
                        int mode, const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
                        hipStream_t st);

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
         const int q = e & 1, hh = (e >> 1) & 3, sp = e >> 3;
         s_mu[e] = p.mu[mm_coord(2 * sp + q, hh)];
     }
-    if (M != MM_WHITEN && M != MM_XPROPOSE) {
+    if (M != MM_WHITEN && M != MM_XPROPOSE && M != MM_UNWHITEN_X) {
         mm_stage_tables<D>(t_ll, p.ll, threadIdx.x, MM_THREADS);
         mm_stage_tables<D>(t_lp, p.lp, threadIdx.x, MM_THREADS);
         mm_stage_tables<D>(t_lq, p.lq, threadIdx.x, MM_THREADS);
@@ -198,6 +198,15 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
                 v[2 * sp + 1] -= m2.y;
             }
             mm_trimatvec<D>(sA, v, o, lane);
+            if (valid) store_row(o);
+        } else if (M == MM_UNWHITEN_X) {
+            mm_trimatvec<D>(sA, v, o, lane);
+#pragma unroll
+            for (int sp = 0; sp < KS / 2; sp++) {
+                const double2 m2 = *reinterpret_cast<const double2*>(my_mu + sp * 8);
+                o[2 * sp] = (double)(T)(m2.x + o[2 * sp]);
+                o[2 * sp + 1] = (double)(T)(m2.y + o[2 * sp + 1]);
+            }
             if (valid) store_row(o);
         } else if (M == MM_UNWHITEN) {
             mm_trimatvec<D>(sA, v, o, lane);
@@ -577,6 +586,7 @@ static int launch_mm(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, dou
                      const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out, hipStream_t st) {
     constexpr bool XP = MODE == MM_XPROPOSE || MODE == MM_XPROPOSE_T;
     const size_t lds = XP ? ((size_t)2 * mm_ksum(D / 16) * 64 + D) * sizeof(double)
+                     : MODE == MM_UNWHITEN_X ? ((size_t)mm_ksum(D / 16) * 64 + D) * sizeof(double)
                           : ((size_t)mm_ksum(D / 16) * 64 + D + (size_t)(pd.ll.C + pd.lp.C + pd.lq.C) * D * 2) * sizeof(double);
     ASMC_REQUIRE(lds <= 160 * 1024 - 256 - BM_TAB_N * sizeof(bm_d2), "operand image and density tables exceed the LDS");
     auto kern = k_pcn_mm<T, D, NOISE, MODE>;
@@ -622,6 +632,7 @@ int asmc_pcn_mm_launch(asmc_ctx* ctx, int64_t n, int x_dtype, void* x, double* l
     if (mode == MM_XPROPOSE) { MM_CASE(TT, DD, ASMC_NOISE_F64, MM_XPROPOSE) }    \
     if (mode == MM_XPROPOSE_T) { MM_CASE(TT, DD, ASMC_NOISE_F64, MM_XPROPOSE_T) } \
     if (mode == MM_UNWHITEN) { MM_CASE(TT, DD, ASMC_NOISE_F64, MM_UNWHITEN) }    \
+    if (mode == MM_UNWHITEN_X) { MM_CASE(TT, DD, ASMC_NOISE_F64, MM_UNWHITEN_X) } \
     if (mode == MM_STEP_T) {                                                     \
         if (pd.noise == ASMC_NOISE_F32) { MM_CASE(TT, DD, ASMC_NOISE_F32, MM_STEP_T) } \
         MM_CASE(TT, DD, ASMC_NOISE_F64, MM_STEP_T)                               \

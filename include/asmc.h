@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 21
+#define ASMC_ABI_VERSION 22
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -598,6 +598,10 @@ typedef struct asmc_coupling {
     const float* scale_dev;  /* [dims] */
     double log_scale_sum;    /* sum_j log(scale_j) */
 } asmc_coupling;
+/* Packed layout of a flow of this shape: 0 = 32-particle tiles with every layer resident in LDS (dims <= 32), 1 = 16-particle
+ * groups with the weights streamed through LDS (32 < dims <= 128: csrc/asmc_flow16.hip; coupling flows need even dims), < 0 =
+ * no kernel.  The pack functions below choose it from the shape; every entry point that takes an asmc_coupling follows. */
+int asmc_flow_layout(int kind, int dims, int hidden);
 int64_t asmc_coupling_pack_floats(int dims, int n_layers, int hidden);
 int asmc_coupling_pack(int dims, int n_layers, int hidden, const float* const* weights_host,
                        const float* const* biases_host, float* packed_host);

@@ -1,0 +1,176 @@
+"""Neural-flow proposals at 32 < d <= 128 on the HIP kernels (round 5; csrc/asmc_flow16.hip).
+
+The reference evaluates the proposal flow's density inside the tempered target of every MCMC step at ANY dims
+(`/root/reference/src/aspire/samplers/smc/base.py:507-519` around `flows/torch/flows.py:368-387`), its default flow class
+being a masked autoregressive flow (`flows/torch/flows.py:140`) and its default step `tpcn` (`smc/minipcn.py:46-49`).  Rounds 2-4
+kept that on one kernel only at d <= 32.  Here: the density kernel and the one-kernel mutation step on 16-particle groups with
+streamed weights, coupling and autoregressive flows, every d up to 128 (narrower problems zero-padded to 64 / 128), against
+(i) the same parameters evaluated in fp64 by the torch modules - north star: log-weights within 1e-6 relative - and (ii) the C
+oracle's restatements (`orc_coupling_logprob`, `orc_maf_logprob`, `orc_pcn_flow_step_kind`, `orc_tpcn_flow_step_kind`).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from aspire_amd.engine import HipEngine
+
+    return HipEngine(0, n_max=1 << 20, d_max=128)
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    import oracle as O
+
+    return O
+
+
+def _flow(kind, d, n_layers, hidden, seed=3):
+    from conftest import random_coupling_flow, random_maf_flow
+
+    return random_coupling_flow(d, n_layers, hidden, seed=seed) if kind == "coupling" else random_maf_flow(d, n_layers, hidden, seed=seed)
+
+
+def _f64(flow, x):
+    from conftest import flow_log_prob_f64
+
+    if hasattr(flow, "log_prob_f64") and type(flow).__name__ == "MAFFlow":
+        return flow.log_prob_f64(x).numpy()
+    return flow_log_prob_f64(flow, x)
+
+
+@pytest.mark.parametrize("kind,d,n_layers,hidden,n,dtype", [
+    ("coupling", 64, 4, 64, 20011, torch.float64), ("coupling", 48, 4, 64, 5000, torch.float64),
+    ("coupling", 128, 4, 64, 9001, torch.float64), ("coupling", 100, 3, 64, 3000, torch.float64),
+    ("coupling", 34, 2, 64, 1000, torch.float32), ("coupling", 64, 2, 32, 2000, torch.float64),
+    ("coupling", 64, 1, 128, 1500, torch.float64), ("coupling", 128, 1, 128, 1000, torch.float64),
+    ("maf", 64, 3, 64, 20011, torch.float64), ("maf", 33, 2, 64, 3000, torch.float64), ("maf", 128, 3, 64, 9001, torch.float64),
+    ("maf", 100, 2, 64, 3000, torch.float32), ("maf", 64, 2, 32, 2000, torch.float64), ("maf", 128, 1, 128, 700, torch.float64),
+    ("maf", 64, 3, 64, 1, torch.float64), ("coupling", 64, 4, 64, 17, torch.float64)])
+def test_flow16_logprob_vs_fp64_and_oracle(eng, oracle, kind, d, n_layers, hidden, n, dtype):
+    """asmc_coupling_logprob at more than 32 dimensions (packed layout 1): the same flow in fp64 to 1e-6 relative, the oracle's
+    fp32 restatement to fp32 rounding; padded dims, odd dims (autoregressive), ragged last group, float32 rows, hidden 32 / 128."""
+    flow = _flow(kind, d, n_layers, hidden)
+    dev = flow.device_coupling(eng)
+    assert eng.lib.asmc_flow_layout(dev.kind, d, hidden) == 1
+    g = np.random.default_rng(5)
+    x = (flow.loc.numpy() + 1.1 * flow.scale.numpy() * g.normal(size=(n, d))).astype(np.float64)
+    xd = torch.as_tensor(x, device=eng.device).to(dtype).contiguous()
+    got = eng.coupling_logprob(xd, dev).cpu().numpy()
+    xr = xd.double().cpu().numpy()
+    ws, bs = flow.export_layers()
+    want = (oracle.coupling_logprob if kind == "coupling" else oracle.maf_logprob)(xr, ws, bs, flow.loc.numpy(), flow.scale.numpy())
+    assert np.all(np.isfinite(got))
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=6e-4)
+    ref64 = _f64(flow, xr)
+    rel = np.abs(got - ref64) / np.maximum(np.abs(ref64), 1.0)
+    assert rel.max() <= 1e-6, rel.max()
+
+
+def test_flow16_out_of_range_operand_is_nan(eng):
+    flow = _flow("maf", 64, 3, 64)
+    dev = flow.device_coupling(eng)
+    x = np.random.default_rng(0).normal(size=(300, 64))
+    x[11] *= 1e6
+    got = eng.coupling_logprob(eng.asarray(x), dev).cpu().numpy()
+    assert np.isnan(got[11]) and np.all(np.isfinite(np.delete(got, 11)))
+
+
+def _setup(n, d, seed):
+    g = np.random.default_rng(seed)
+    x0 = 0.9 * g.normal(size=(n, d))
+    a = g.normal(size=(d, d)) / np.sqrt(d)
+    L = np.linalg.cholesky(0.8 * (np.eye(d) + 0.2 * a @ a.T))
+    return x0, 0.05 * g.normal(size=d), np.tril(L), np.tril(np.linalg.inv(L))
+
+
+@pytest.mark.parametrize("kind,d,n_layers,n,nu,xdt,mix", [
+    ("coupling", 64, 4, 4000, 0.0, "f64", False), ("coupling", 64, 4, 4000, 5.0, "f64", False),
+    ("coupling", 48, 4, 3000, 0.0, "f64", False), ("coupling", 48, 3, 3000, 4.0, "f64", True),
+    ("coupling", 128, 4, 3000, 0.0, "f64", False), ("coupling", 128, 2, 2000, 6.0, "f64", True),
+    ("coupling", 100, 2, 2000, 0.0, "f64", False),
+    ("maf", 64, 3, 4000, 0.0, "f64", False), ("maf", 64, 3, 4000, 5.0, "f64", False), ("maf", 48, 3, 3000, 3.0, "f64", False),
+    ("maf", 33, 2, 2000, 0.0, "f64", False), ("maf", 128, 3, 3000, 5.0, "f64", False), ("maf", 100, 2, 2000, 0.0, "f64", True),
+    ("coupling", 64, 4, 3000, 0.0, "f32", False), ("maf", 128, 2, 2000, 4.0, "f32", False)])
+def test_flow16_mutation_vs_oracle(eng, oracle, kind, d, n_layers, n, nu, xdt, mix):
+    """asmc_pcn_mutate_flow at 32 < d <= 128: ONE kernel per step (k_pcn_flow16 / k_tpcn_flow16: proposal, x' = mu + L y' on the
+    fp64 matrix cores, flow with streamed weights, built-in targets, accept), no k_coupling_logprob / k_pcn_mm_propose /
+    k_mixture_logpdf / k_copy_flagged_rows of round 4's five-kernel path; against the oracle's restatement of the whole step -
+    pCN, and the reference's default tpCN (step_fn, smc/minipcn.py:46-49) - with razor-edge margins for rows whose decision
+    differs; single-Gaussian and mixture targets (BASELINE configs[4]'s shape at d = 128)."""
+    n_steps, beta, rho = 3, 0.4, 0.3
+    dt = torch.float64 if xdt == "f64" else torch.float32
+    flow = _flow(kind, d, n_layers, 64, seed=6)
+    dev = flow.device_coupling(eng)
+    ws, bs = flow.export_layers()
+    x0, mu, L, Linv = _setup(n, d, 8)
+    g = np.random.default_rng(4)
+    if mix:
+        m_ll = (np.log([0.4, 0.6]), 0.5 * g.normal(size=(2, d)), 0.6 + g.random(size=(2, d)))
+    else:
+        m_ll = ([0.0], 0.1 * g.normal(size=(1, d)), 0.7 + 0.6 * g.random(size=(1, d)))
+    m_lp = ([0.0], np.zeros((1, d)), np.ones((1, d)))
+    o_ll, o_lp = oracle.Mixture(*m_ll), oracle.Mixture(*m_lp)
+    t_ll, t_lp = eng.make_mixture(*m_ll), eng.make_mixture(*m_lp)
+    x0t = torch.as_tensor(x0).to(dt)
+    xr = x0t.double().numpy().copy()
+    flp = oracle.coupling_logprob if kind == "coupling" else oracle.maf_logprob
+    llr, lpr, lqr = o_ll.logpdf(xr), o_lp.logpdf(xr), flp(xr, ws, bs, flow.loc.numpy(), flow.scale.numpy())
+    xd = x0t.to(eng.device).contiguous()
+    lld, lpd, lqd = eng.asarray(llr), eng.asarray(lpr), eng.coupling_logprob(xd, dev)
+    eng.profile(True)
+    n_acc, _, _ = eng.pcn_mutate_flow(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), t_ll, t_lp, dev,
+                                      4242, 17, rho, n_steps, 9, 0.234, False, "f64", nu)
+    rep = eng.profile_report()
+    eng.profile(False)
+    step_k = "k_tpcn_flow16" if nu > 0 else "k_pcn_flow16"
+    assert rep[step_k][0] == n_steps, sorted(rep)
+    assert not any(k.startswith(("k_coupling_logprob", "k_flow16_logprob", "k_maf_logprob", "k_pcn_mm_propose", "k_mixture_logpdf",
+                                 "k_copy_flagged", "k_pcn_accept")) for k in rep), sorted(rep)
+    acc_ref, margins = [], []
+    for t in range(n_steps):
+        with oracle.accept_margins(n) as m:
+            if nu > 0:
+                acc_ref.append(oracle.tpcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, nu, o_ll, o_lp, ws, bs, flow.loc.numpy(),
+                                                     flow.scale.numpy(), 4242, 17, 9 + t, "f64", 0, flow_kind=kind))
+            else:
+                acc_ref.append(oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, o_ll, o_lp, ws, bs, flow.loc.numpy(),
+                                                    flow.scale.numpy(), 4242, 17, 9 + t, "f64", 0, flow_kind=kind))
+        margins.append(m.copy())
+    got = xd.double().cpu().numpy()
+    tol = 1e-9 if xdt == "f64" else 3e-5
+    close = np.all(np.abs(got - xr) <= tol * (1 + np.abs(xr)), axis=1)
+    edge = 12 if xdt == "f64" else 80
+    assert (~close).sum() <= edge, (~close).sum()
+    if xdt == "f64":
+        razor = np.min(np.abs(np.array(margins)), axis=0)  # rows that ended elsewhere took their other decision at a razor's edge
+        assert np.all(razor[~close] <= 2e-4), razor[~close]
+    assert np.all(np.abs(np.array(n_acc) - np.array(acc_ref)) <= edge) and 0.03 < np.mean(n_acc) / n < 0.97
+    np.testing.assert_allclose(lld.cpu().numpy(), o_ll.logpdf(got), rtol=1e-10 if xdt == "f64" else 1e-4, atol=1e-9 if xdt == "f64" else 3e-3)
+    np.testing.assert_allclose(lpd.cpu().numpy(), o_lp.logpdf(got), rtol=1e-10 if xdt == "f64" else 1e-4, atol=1e-9 if xdt == "f64" else 3e-3)
+    torch.testing.assert_close(lqd, eng.coupling_logprob(xd, dev), rtol=1e-5, atol=3e-3)  # carried log q = the flow at the returned rows
+
+
+def test_flow16_step_is_repeatable_and_adapts(eng):
+    """Same inputs, same bits, call after call (other kernels in between); with adaptation on, the step size moves towards the
+    target acceptance and the history is what the library reports."""
+    n, d = 30000, 64
+    flow = _flow("maf", d, 3, 64, seed=21)
+    dev = flow.device_coupling(eng)
+    x0, mu, L, Linv = _setup(n, d, 5)
+    t = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    outs = []
+    for _ in range(4):
+        x = eng.asarray(x0)
+        ll, lp, lq = eng.mixture_logpdf(x, t), eng.mixture_logpdf(x, t), eng.coupling_logprob(x, dev)
+        acc, rho, hist = eng.pcn_mutate_flow(x, ll, lp, lq, 0.5, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), t, t, dev, 5, 0, 0.3, 6, 0,
+                                             0.234, True, "f64", 4.0)
+        outs.append((x.clone(), lq.clone(), np.asarray(acc), rho, np.asarray(hist)))
+        eng.coupling_logprob(eng.asarray(np.random.default_rng(1).normal(size=(3000, d))), dev)
+    for xo, lqo, acc, rho, hist in outs[1:]:
+        assert torch.equal(xo, outs[0][0]) and torch.equal(lqo, outs[0][1]) and np.array_equal(acc, outs[0][2]) and rho == outs[0][3]
+    assert outs[0][4][0] == 0.3 and len(set(outs[0][4])) > 1
