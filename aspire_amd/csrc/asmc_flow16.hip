@@ -167,7 +167,7 @@ __global__ __launch_bounds__(THREADS) void k_flow16_logprob(int64_t n, int d, co
     extern __shared__ __align__(16) float sm[];
     constexpr int WAVES = THREADS / 64, SL = FD::SL;
     float* slots = sm;                                  // 2 x FLOW16_CHUNK_WORDS
-    float* s_bias = slots + 2 * FLOW16_CHUNK_WORDS;     // n_layers x BIAS
+    float* s_bias = slots + 2 * FD::CW;                 // n_layers x BIAS
     float* s_loc = s_bias + n_layers * FD::BIAS;        // [slot s][lane group h] x {loc, scale, 1/scale}: 3 x D floats
     Flow16Stream<FD, THREADS> stream;
     stream.start(packed + (size_t)n_layers * FD::BIAS, slots, n_layers);
@@ -187,12 +187,12 @@ __global__ __launch_bounds__(THREADS) void k_flow16_logprob(int64_t n, int d, co
         const int64_t g = it * per_round + (int64_t)blockIdx.x * WAVES + wave;
         const int64_t row = g * 16 + p;
         const bool valid = row < n;
-        float xf[SL];
+        F16State<FD> xf;
 #pragma unroll
         for (int s = 0; s < SL; s++) {
             const int j = f16_nat(KIND, D, d, f16_coord(s, h));
             const float xv = (valid && j >= 0) ? (float)x[row * d + j] : 0.0f;
-            xf[s] = j >= 0 ? flow_standardise(xv, s_loc[s * 4 + h], s_loc[D + s * 4 + h], s_loc[2 * D + s * 4 + h]) : 0.0f;
+            xf.set(s, j >= 0 ? flow_standardise(xv, s_loc[s * 4 + h], s_loc[D + s * 4 + h], s_loc[2 * D + s * 4 + h]) : 0.0f);
         }
         const float val = f16_logprob<FD, W, THREADS>(xf, n_layers, s_bias, stream, lane, ladj0, base_const);
         if (valid && h == 0) out[row] = (double)val;
@@ -352,13 +352,13 @@ __device__ __forceinline__ double f16_mixture(const MixDev& m, const double* __r
     return best + log(sum);
 }
 
-template <typename T, int D, int W, int KIND, int NOISE, bool TP, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_pcn_flow16(int64_t n, T* __restrict__ x, double* __restrict__ ll, double* __restrict__ lp,
+template <typename T, int D, int W, int KIND, int NOISE, bool TP, int THREADS, int CW>
+__global__ __launch_bounds__(THREADS, 2) void k_pcn_flow16(int64_t n, T* __restrict__ x, double* __restrict__ ll, double* __restrict__ lp,
                                                        double* __restrict__ lq, const double* __restrict__ blob, int blob_doubles,
                                                        PcnDev p, const double* __restrict__ rho_ptr, uint32_t step,
                                                        const float* __restrict__ packed, int n_layers, float ladj0, float base_const,
                                                        long long* __restrict__ block_counts, unsigned long long* __restrict__ nonfinite) {
-    using FD = Flow16<KIND, D, W>;
+    using FD = Flow16<KIND, D, W, CW>;
     extern __shared__ __align__(16) double smem[];
     constexpr int KS = D / 4, WAVES = THREADS / 64;
     constexpr int TOTAL = f16_ksum(D / 16) * 64;
@@ -459,9 +459,9 @@ __global__ __launch_bounds__(THREADS) void k_pcn_flow16(int64_t n, T* __restrict
             o[2 * sp + 1] = (double)(T)(m2.y + o[2 * sp + 1]);
         }
         const double nll = f16_mixture<D>(p.ll, t_ll, o, h), nlp = f16_mixture<D>(p.lp, t_lp, o, h);
-        float xf[KS];
+        F16State<FD> xf;
 #pragma unroll
-        for (int s = 0; s < KS; s++) xf[s] = flow_standardise((float)o[s], s_loc[s * 4 + h], s_loc[D + s * 4 + h], s_loc[2 * D + s * 4 + h]);
+        for (int s = 0; s < KS; s++) xf.set(s, flow_standardise((float)o[s], s_loc[s * 4 + h], s_loc[D + s * 4 + h], s_loc[2 * D + s * 4 + h]));
         // everything of the accept test that does not need log q(x'), pinned in front of the flow
         const double c1 = ref_corr_ct<TP>(q1, p.nu, dn), c0 = ref_corr_ct<TP>(q0, p.nu, dn);
         const double logu = log(accept_uniform(p.seed, gid, step));
@@ -506,11 +506,11 @@ static size_t f16_blob_doubles(int D, int c_ll, int c_lp) {
     return (size_t)f16_ksum(D / 16) * 64 + D + (size_t)(c_ll + c_lp) * D * 2 + (3 * D) / 2;
 }
 
-template <int KIND, int D, int W>
+template <int KIND, int D, int W, int CW = FLOW16_CHUNK_WORDS>
 static size_t f16_step_lds(int n_layers, int c_ll, int c_lp, int noise) {
-    using FD = Flow16<KIND, D, W>;
+    using FD = Flow16<KIND, D, W, CW>;
     return f16_blob_doubles(D, c_ll, c_lp) * 8 + (size_t)n_layers * FD::BIAS * 4 + (noise == ASMC_NOISE_F64 ? BM_TAB_N * sizeof(bm_d2) : 0) +
-           2 * FLOW16_CHUNK_WORDS * 4 + 8 * 8 /* s_cnt */;
+           2 * (size_t)CW * 4 + 16 * 8 /* s_cnt */;
 }
 
 // shapes of the one-kernel step (every instantiation is x 2 state dtypes x 2 noise generators x pCN / tpCN)
@@ -530,13 +530,18 @@ bool asmc_pcn_flow16_ok(const asmc_pcn_params* prm, const asmc_coupling* f) {
     return lds > 0 && lds <= 160 * 1024;
 }
 
-template <typename T, int D, int W, int KIND, int NOISE, bool TP>
-static int launch_pcn_flow16(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const double* blob, const PcnDev& pd,
-                             const asmc_coupling* f, const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
-                             unsigned long long* nonfinite, hipStream_t st) {
-    constexpr int THREADS = 512;
-    const size_t lds = f16_step_lds<KIND, D, W>(f->n_layers, pd.ll.C, pd.lp.C, NOISE) - 64;
-    auto kern = k_pcn_flow16<T, D, W, KIND, NOISE, TP, THREADS>;
+// Launch geometry (ASMC_F16_GEOM picks one for experiments; default per shape below):
+//   0  one block of 8 waves per CU, 32 KB chunks (one barrier per dense matrix)
+//   1  TWO blocks of 4 waves per CU, 16 KB chunks: the blocks' phases drift apart, so one block's noise / accept work (vector
+//      ALU) runs beside the other's flow layers (matrix pipe) - within a block every wave is in the same phase (shared stream)
+//   2  one block of 8 waves per CU, one chunk per LAYER (D = 64: 40 - 64 KB slots)
+template <typename T, int D, int W, int KIND, int NOISE, bool TP, int THREADS, int CW, int PER_CU>
+static int launch_pcn_flow16_g(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const double* blob, const PcnDev& pd,
+                               const asmc_coupling* f, const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
+                               unsigned long long* nonfinite, hipStream_t st) {
+    const size_t lds = f16_step_lds<KIND, D, W, CW>(f->n_layers, pd.ll.C, pd.lp.C, NOISE) - 128;
+    if ((lds + 128) * PER_CU > 160 * 1024) return ASMC_ERR_UNSUPPORTED;  // (the caller tries the next geometry)
+    auto kern = k_pcn_flow16<T, D, W, KIND, NOISE, TP, THREADS, CW>;
     static size_t attr_lds = 0;
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -544,7 +549,7 @@ static int launch_pcn_flow16(asmc_ctx* ctx, int64_t n, T* x, double* ll, double*
     }
     const int64_t n_groups = (n + 15) / 16;
     const int64_t want = (n_groups + THREADS / 64 - 1) / (THREADS / 64);
-    const int grid = (int)(want < (int64_t)ctx->num_cu ? want : (int64_t)ctx->num_cu);  // one block per CU (LDS)
+    const int grid = (int)(want < (int64_t)ctx->num_cu * PER_CU ? want : (int64_t)ctx->num_cu * PER_CU);
     *grid_out = grid;
     const float ladj0 = (float)(-f->log_scale_sum);
     const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
@@ -553,6 +558,24 @@ static int launch_pcn_flow16(asmc_ctx* ctx, int64_t n, T* x, double* ll, double*
                 nonfinite);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
+}
+
+template <typename T, int D, int W, int KIND, int NOISE, bool TP>
+static int launch_pcn_flow16(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const double* blob, const PcnDev& pd,
+                             const asmc_coupling* f, const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
+                             unsigned long long* nonfinite, hipStream_t st) {
+    static const int geom_env = getenv("ASMC_F16_GEOM") ? atoi(getenv("ASMC_F16_GEOM")) : -1;
+    const int geom = geom_env >= 0 ? geom_env : (D == 64 ? 1 : 0);
+    int rc = ASMC_ERR_UNSUPPORTED;
+#define F16_ARGS ctx, n, x, ll, lp, lq, blob, pd, f, rho_ptr, step, block_counts, grid_out, nonfinite, st
+    if constexpr (D == 64) {
+        if (geom == 1) rc = launch_pcn_flow16_g<T, D, W, KIND, NOISE, TP, 256, 4096, 2>(F16_ARGS);
+        if (geom == 2) rc = launch_pcn_flow16_g<T, D, W, KIND, NOISE, TP, 512, Flow16<KIND, D, W>::LAYER_A, 1>(F16_ARGS);
+    }
+    if (rc == ASMC_ERR_UNSUPPORTED) rc = launch_pcn_flow16_g<T, D, W, KIND, NOISE, TP, 512, FLOW16_CHUNK_WORDS, 1>(F16_ARGS);
+#undef F16_ARGS
+    if (rc == ASMC_ERR_UNSUPPORTED) asmc_set_error("flow16 step: the step's tables exceed the LDS");
+    return rc;
 }
 
 // builds the resident tables of a mutation (once, before its steps) into ctx->d_f16tab
@@ -602,8 +625,155 @@ int asmc_pcn_flow16_launch(asmc_ctx* ctx, int64_t n, int x_dtype, void* x, doubl
     return ASMC_ERR_UNSUPPORTED;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Sampling (flows/torch/flows.py:327-346, Flow.sample_and_log_prob; the proposal draw of mcmc.py:49-110) at more than 32
+// dimensions: z ~ N(0, I) from the counter-based generator exactly as the d <= 32 kernels draw it (fp32 Box-Muller quads keyed
+// by the global particle index: coordinate j is element j % 4 of quad j / 4), the layers inverted in reverse order on the same
+// layer code, x = x' scale + loc and log q(x) = N(z) - sum s - sum log scale from the same pass.  A coupling layer inverts in
+// one evaluation; an autoregressive transform by fixed-point passes x <- z exp(s(x)) + t(x) from x = 0 (asmc_flow.hip,
+// k_maf_sample: at most d passes, stopping at the first pass that returns its input bit for bit - here for every particle of
+// the BLOCK, whose waves share the weight stream; the operand range is checked over all passes).
+template <int KIND, int D, int W, typename XT, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_flow16_sample(int64_t n, int d, const float* __restrict__ packed, int n_layers,
+                                                          const float* __restrict__ loc, const float* __restrict__ scale, float ladj0,
+                                                          float base_const, unsigned long long seed, unsigned long long gid0,
+                                                          uint32_t draw_id, XT* __restrict__ x, double* __restrict__ out, int all_passes) {
+    using FD = Flow16<KIND, D, W>;
+    extern __shared__ __align__(16) float sm[];
+    constexpr int WAVES = THREADS / 64, SL = FD::SL, CS = FD::CS;
+    float* slots = sm;
+    float* s_bias = slots + 2 * FD::CW;
+    Flow16Stream<FD, THREADS> stream;
+    stream.start(packed + (size_t)n_layers * FD::BIAS, slots, n_layers, FD::MAF ? F16_REPEAT : F16_BACKWARD);
+    for (int e = threadIdx.x; e < n_layers * FD::BIAS; e += THREADS) s_bias[e] = packed[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, h = lane >> 4;
+    const int64_t n_groups = (n + 15) / 16;
+    const int64_t per_round = (int64_t)gridDim.x * WAVES;
+    const int64_t rounds = (n_groups + per_round - 1) / per_round;
+    for (int64_t it = 0; it < rounds; it++) {
+        const int64_t g = it * per_round + (int64_t)blockIdx.x * WAVES + wave;
+        const int64_t row = g * 16 + p;
+        const bool valid = row < n;
+        const unsigned long long gid = gid0 + (unsigned long long)(valid ? row : (n - 1));
+        F16State<FD> z;
+        float q = 0.0f;
+#pragma unroll
+        for (int sp = 0; sp < SL / 2; sp++) {  // the lane's coordinate pairs: two elements of one quad (the pair starts at an even coordinate)
+            const int j0 = f16_nat(KIND, D, d, f16_coord(2 * sp, h)), j1 = f16_nat(KIND, D, d, f16_coord(2 * sp + 1, h));
+            double zq[4] = {0.0, 0.0, 0.0, 0.0};
+            if (j0 >= 0) normal_quad_f32(seed, gid, draw_id, (uint32_t)(j0 >> 2), zq[0], zq[1], zq[2], zq[3]);
+            float z0 = 0.0f, z1 = 0.0f;
+            if (j0 >= 0) z0 = (float)((j0 & 3) == 0 ? zq[0] : (j0 & 3) == 1 ? zq[1] : (j0 & 3) == 2 ? zq[2] : zq[3]);
+            if (j1 >= 0) {
+                if ((j1 >> 2) != (j0 >> 2)) normal_quad_f32(seed, gid, draw_id, (uint32_t)(j1 >> 2), zq[0], zq[1], zq[2], zq[3]);
+                z1 = (float)((j1 & 3) == 0 ? zq[0] : (j1 & 3) == 1 ? zq[1] : (j1 & 3) == 2 ? zq[2] : zq[3]);
+            }
+            z.set(2 * sp, z0);
+            z.set(2 * sp + 1, z1);
+            q = fmaf(z0, z0, fmaf(z1, z1, q));
+        }
+        float ladj = 0.0f, amax = 0.0f;
+        if constexpr (FD::MAF) {
+            for (int c = n_layers - 1; c >= 0; c--) {
+                float xv[CS];
+#pragma unroll
+                for (int i = 0; i < CS; i++) xv[i] = 0.0f;
+                float ladj_pass = 0.0f;
+                for (int pass = 0; pass < d; pass++) {
+                    float tr[CS];
+#pragma unroll
+                    for (int i = 0; i < CS; i++) tr[i] = z.a[i];
+                    ladj_pass = 0.0f;
+                    unsigned amax_pk = 0u;
+                    f16_layer<FD, W, THREADS, true>(xv, tr, s_bias + c * FD::BIAS, stream, lane, ladj_pass, amax_pk);
+                    bool same = true, nan = false;
+#pragma unroll
+                    for (int i = 0; i < CS; i++) {
+                        same = same && (__float_as_uint(tr[i]) == __float_as_uint(xv[i]));
+                        nan = nan || (tr[i] != tr[i]);
+                    }
+                    float am = range_pk_max(amax_pk);
+                    am = (am != am || nan) ? __builtin_inff() : am;
+                    amax = fmaxf(amax, am);  // every pass counts (asmc_flow.hip, k_maf_sample)
+#pragma unroll
+                    for (int i = 0; i < CS; i++) xv[i] = pass + 1 < d ? fminf(fmaxf(tr[i], -60000.0f), 60000.0f) : tr[i];
+                    // the fixed point, for every particle of the block (its waves share the stream: a block-uniform decision)
+                    if (!all_passes && __syncthreads_and(same ? 1 : 0)) break;
+                }
+                ladj += ladj_pass;
+#pragma unroll
+                for (int i = 0; i < CS; i++) z.a[i] = xv[i];
+                // the stream has put this transform's first chunk into flight again; the next one needed is the transform below
+                // (or, after the last, the top transform of the next round)
+                stream.redirect(c > 0 ? c - 1 : n_layers - 1);
+            }
+        } else {
+            unsigned amax_pk = 0u;
+            for (int c = n_layers - 1; c >= 0; c--) {
+                if ((c & 1) == 0)
+                    f16_layer<FD, W, THREADS, true>(z.a, z.b, s_bias + c * FD::BIAS, stream, lane, ladj, amax_pk);
+                else
+                    f16_layer<FD, W, THREADS, true>(z.b, z.a, s_bias + c * FD::BIAS, stream, lane, ladj, amax_pk);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            amax = range_pk_max(amax_pk);
+            amax = (amax != amax) ? __builtin_inff() : amax;
+        }
+        q = f16_quad_sum(q);
+        const float lj = f16_quad_sum(ladj);
+        const float am = f16_quad_max(amax);
+        const float val = !(am < FLOW_HS_MAX) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
+        if (valid) {
+#pragma unroll
+            for (int s = 0; s < SL; s++) {
+                const int j = f16_nat(KIND, D, d, f16_coord(s, h));
+                if (j >= 0) x[row * d + j] = (XT)(z.get(s) * scale[j] + loc[j]);
+            }
+            if (h == 0) out[row] = (double)val;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int KIND, int D, int W, typename XT>
+static int launch_flow16_sample(asmc_ctx* ctx, int64_t n, const asmc_coupling* f, unsigned long long seed, unsigned long long gid0,
+                                uint32_t draw_id, XT* x, double* out, hipStream_t st) {
+    using FD = Flow16<KIND, D, W>;
+    constexpr int THREADS = 512;
+    const size_t lds = (size_t)(2 * FLOW16_CHUNK_WORDS + f->n_layers * FD::BIAS) * sizeof(float);
+    ASMC_REQUIRE(lds <= 160 * 1024, "flow16: biases exceed the LDS");
+    auto kern = k_flow16_sample<KIND, D, W, XT, THREADS>;
+    static size_t attr_lds = 0;
+    if (lds > 64 * 1024 && lds > attr_lds) {
+        ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const int64_t n_groups = (n + 15) / 16;
+    const int64_t want = (n_groups + THREADS / 64 - 1) / (THREADS / 64);
+    const int grid = (int)(want < (int64_t)ctx->num_cu * 2 ? want : (int64_t)ctx->num_cu * 2);
+    const float ladj0 = (float)(-f->log_scale_sum);
+    const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
+    ASMC_LAUNCH(ctx, st, "k_flow16_sample", kern, dim3(grid), dim3(THREADS), lds, st, n, (int)f->dims, f->packed_dev, (int)f->n_layers,
+                f->loc_dev, f->scale_dev, ladj0, base_const, seed, gid0, draw_id, x, out, getenv("ASMC_MAF_SAMPLE_ALL_PASSES") ? 1 : 0);
+    ASMC_LAUNCH_CHECK();
+    return ASMC_OK;
+}
+
 int asmc_flow16_sample(asmc_ctx* ctx, int64_t n, int x_dtype, const asmc_coupling* f, unsigned long long seed, unsigned long long gid0,
                        uint32_t draw_id, void* x_out, double* lq_out, hipStream_t st) {
-    asmc_set_error("asmc_coupling_sample: flows of more than 32 dimensions are sampled by the caller's own modules");
+    if (!asmc_flow_math_split()) {
+        asmc_set_error("flows of more than 32 dimensions run the split-fp16 layers only (ASMC_FLOW_MATH=f32 is not available there)");
+        return ASMC_ERR_UNSUPPORTED;
+    }
+    const int D = f16_pad_dim(f->dims);
+#define X(K, DD, WW)                                                                                                                     \
+    if (f->kind == K && D == DD && f->hidden == WW) {                                                                                    \
+        if (x_dtype == ASMC_F64) return launch_flow16_sample<K, DD, WW, double>(ctx, n, f, seed, gid0, draw_id, (double*)x_out, lq_out, st); \
+        return launch_flow16_sample<K, DD, WW, float>(ctx, n, f, seed, gid0, draw_id, (float*)x_out, lq_out, st);                        \
+    }
+    F16_SHAPES(X)
+#undef X
+    asmc_set_error("flow16 sample: unsupported shape (kind %d, dims %d, hidden %d)", (int)f->kind, (int)f->dims, (int)f->hidden);
     return ASMC_ERR_UNSUPPORTED;
 }

@@ -30,12 +30,15 @@
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-#define FLOW16_CHUNK_WORDS 8192  // 32 KB per LDS slot
+#define FLOW16_CHUNK_WORDS 8192  // default: 32 KB per LDS slot
 
 __host__ __device__ constexpr int f16_coord(int s, int h) { return 8 * (s / 2) + 2 * h + (s % 2); }  // = mm_coord (asmc_pcn_mm.hip)
 
-template <int KIND, int D, int W>
+// CW: words per LDS slot of the weight stream.  A slot that takes a whole layer's operand images makes the layer ONE chunk
+// (WHOLE: one barrier per layer); otherwise a chunk is a run of whole output blocks of one matrix.
+template <int KIND, int D, int W, int CWV = FLOW16_CHUNK_WORDS>
 struct Flow16 {
+    static constexpr int CW = CWV;
     static_assert(D == 64 || D == 128, "padded dimension");
     static_assert(W == 32 || W == 64 || W == 128, "hidden width");
     static constexpr bool MAF = KIND == ASMC_FLOW_MAF;
@@ -50,20 +53,23 @@ struct Flow16 {
     static constexpr int BLK1 = KS1 * 512, BLK2 = KS2 * 512;  // 4-byte words per output block: (hi, lo) images of every K step
     static constexpr int A1 = NB1 * BLK1, A2 = NB1 * BLK2, A3 = NB3 * BLK2;
     static constexpr int LAYER_A = A1 + A2 + A3;      // words of operand images per layer
-    // blocks per chunk (whole blocks, <= FLOW16_CHUNK_WORDS words) and chunks per matrix
-    static constexpr int BC1 = FLOW16_CHUNK_WORDS / BLK1 < NB1 ? FLOW16_CHUNK_WORDS / BLK1 : NB1;
-    static constexpr int BC2 = FLOW16_CHUNK_WORDS / BLK2 < NB1 ? FLOW16_CHUNK_WORDS / BLK2 : NB1;
-    static constexpr int BC3r = FLOW16_CHUNK_WORDS / BLK2 < NB3 ? FLOW16_CHUNK_WORDS / BLK2 : NB3;
+    static constexpr bool WHOLE = CW >= LAYER_A;
+    // blocks per chunk (whole blocks, <= CW words) and chunks per matrix
+    static constexpr int BC1 = CW / BLK1 < NB1 ? CW / BLK1 : NB1;
+    static constexpr int BC2 = CW / BLK2 < NB1 ? CW / BLK2 : NB1;
+    static constexpr int BC3r = CW / BLK2 < NB3 ? CW / BLK2 : NB3;
     static constexpr int BC3 = BC3r < NB3 ? (BC3r / 2) * 2 : BC3r;  // (s_raw, t) block pairs stay in one chunk
     static_assert(BC1 >= 1 && BC2 >= 1 && BC3 >= 2, "an output block pair must fit a chunk");
     static_assert(NB1 % BC1 == 0 && NB1 % BC2 == 0 && NB3 % BC3 == 0, "chunks of equal size");
     static constexpr int P1 = NB1 / BC1, P2 = NB1 / BC2, P3 = NB3 / BC3;
-    static constexpr int NPARTS = P1 + P2 + P3;       // chunks per layer
+    static constexpr int NPARTS = WHOLE ? 1 : P1 + P2 + P3;  // chunks per layer
     // word offset and length of chunk i of a layer (relative to the layer's operand images)
     static constexpr __host__ __device__ int part_off(int i) {
-        return i < P1 ? i * BC1 * BLK1 : i < P1 + P2 ? A1 + (i - P1) * BC2 * BLK2 : A1 + A2 + (i - P1 - P2) * BC3 * BLK2;
+        return WHOLE ? 0 : i < P1 ? i * BC1 * BLK1 : i < P1 + P2 ? A1 + (i - P1) * BC2 * BLK2 : A1 + A2 + (i - P1 - P2) * BC3 * BLK2;
     }
-    static constexpr __host__ __device__ int part_words(int i) { return i < P1 ? BC1 * BLK1 : i < P1 + P2 ? BC2 * BLK2 : BC3 * BLK2; }
+    static constexpr __host__ __device__ int part_words(int i) {
+        return WHOLE ? LAYER_A : i < P1 ? BC1 * BLK1 : i < P1 + P2 ? BC2 * BLK2 : BC3 * BLK2;
+    }
 };
 
 // words of the packed block: [biases of every layer][operand images of every layer]
@@ -89,48 +95,64 @@ __device__ __forceinline__ void f16_split8(const float (&x)[8], half8& hi, half8
     lo = __builtin_bit_cast(half8, flow_u4{lp[0], lp[1], lp[2], lp[3]});
 }
 
-// The stream of weight chunks through two LDS slots.  `slots`: 2 x FLOW16_CHUNK_WORDS words of LDS; `gA`: the flow's
+// The stream of weight chunks through two LDS slots.  `slots`: 2 x FD::CW words of LDS; `gA`: the flow's
 // operand images in HBM (word 0 = chunk 0 of layer 0).  next() closes the previous chunk (every wave of the block is
 // through with it), makes the current one visible and puts the one after it into flight; it returns the current chunk.
-// The sequence wraps: after the last chunk of the last layer comes chunk 0 of layer 0 (the next round's).
+// Which layer follows a layer's last chunk is the stream's `mode`: F16_FORWARD (the density: 0, 1, .., n - 1, then 0 again for
+// the next round), F16_BACKWARD (sampling a coupling flow: n - 1, .., 0, then n - 1) or F16_REPEAT (the passes that invert one
+// autoregressive transform: the same layer again; redirect() replaces a chunk that was put into flight on that assumption).
+#define F16_FORWARD 0
+#define F16_BACKWARD 1
+#define F16_REPEAT 2
 template <class FD, int THREADS>
 struct Flow16Stream {
     const float* __restrict__ gA;
     float* slots;
-    int n_layers;
+    int n_layers, mode;
     int layer, part;  // the chunk that is IN FLIGHT (issued, not yet waited for)
     unsigned parity;  // slot it goes to
 
     __device__ __forceinline__ void issue(int l, int p, unsigned slot) {
         const int off = l * FD::LAYER_A + FD::part_off(p);
         const int words = FD::part_words(p);
-        // wave w, instruction q: 1 KiB at words (q * WAVES + w) * 256 .. + 255 of the chunk (the LDS side is wave-uniform base +
-        // lane * 16 bytes: contiguous in exactly this order)
+        // wave w takes the 1 KiB pieces w, w + WAVES, ... of the chunk (the LDS side of a piece is wave-uniform base + lane * 16
+        // bytes: contiguous in exactly the order of the source)
         constexpr int WAVES = THREADS / 64;
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         for (int q = wave; q * 256 < words; q += WAVES) {
             const float* src = gA + off + q * 256 + lane * 4;
-            float* dst = slots + slot * FLOW16_CHUNK_WORDS + q * 256;
+            float* dst = slots + slot * FD::CW + q * 256;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     }
-    // called once, before the first round: chunk 0 into slot 0
-    __device__ __forceinline__ void start(const float* g, float* s, int nl) {
-        gA = g, slots = s, n_layers = nl;
-        layer = 0, part = 0, parity = 0;
-        issue(0, 0, 0);
+    // called once, before the first round: the first chunk of layer `l0` into slot 0
+    __device__ __forceinline__ void start(const float* g, float* s, int nl, int md = F16_FORWARD) {
+        gA = g, slots = s, n_layers = nl, mode = md;
+        layer = md == F16_FORWARD ? 0 : nl - 1, part = 0, parity = 0;
+        issue(layer, 0, 0);
     }
     __device__ __forceinline__ const float* next() {
         // the chunk in flight has landed (this wave's share: vmcnt; everybody's: the barrier), and every wave is past its reads
         // of the chunk before it - whose slot the chunk after this one may now overwrite
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const float* cur = slots + parity * FLOW16_CHUNK_WORDS;
+        const float* cur = slots + parity * FD::CW;
         int l = layer, p = part + 1;
-        if (p == FD::NPARTS) p = 0, l = (l + 1 == n_layers) ? 0 : l + 1;
+        if (p == FD::NPARTS) {
+            p = 0;
+            if (mode == F16_FORWARD) l = (l + 1 == n_layers) ? 0 : l + 1;
+            if (mode == F16_BACKWARD) l = (l == 0) ? n_layers - 1 : l - 1;
+        }
         layer = l, part = p, parity ^= 1u;
         issue(l, p, parity);
         return cur;
+    }
+    // the chunk in flight is not the one the caller needs next (block-uniform decision): chunk 0 of layer l instead
+    __device__ __forceinline__ void redirect(int l) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        layer = l, part = 0;
+        issue(l, 0, parity);
     }
 };
 
@@ -170,26 +192,30 @@ __device__ __forceinline__ void f16_dense(floatx4 (&acc)[NBC], const half8 (&bh)
     }
 }
 
-// One layer (coupling layer or autoregressive transform) of one 16-particle group.  xf: the lane's SL standardised
-// coordinates (updated in place); `first` (compile time: the slots must stay registers): the coupling layer conditions on
-// slots [0, CS) and transforms [CS, 2 CS), else the other way round (ignored by autoregressive transforms).  INVERSE: the sampling direction x_b = z_b exp(s) + t.
-template <class FD, int W, int THREADS, bool first, bool INVERSE = false>
-__device__ __forceinline__ void f16_layer(float (&xf)[FD::SL], const float* __restrict__ bias, Flow16Stream<FD, THREADS>& stream,
-                                          int lane, float& ladj, unsigned& amax_pk) {
-    constexpr int CS = FD::CS, KS1 = FD::KS1, KS2 = FD::KS2, NB1 = FD::NB1;
+// One layer (coupling layer or autoregressive transform) of one 16-particle group.  cond: the lane's CS conditioner inputs,
+// trans: its CS transformed coordinates (updated in place).  A coupling layer passes its two halves (which is which alternates
+// with the layer); an autoregressive transform passes the same array twice for the density (every conditioner input is
+// converted before the first coordinate changes) and (current estimate, latent copy) for a pass of its inversion.
+// INVERSE: the sampling direction x_b = z_b exp(s) + t.
+template <class FD, int W, int THREADS, bool INVERSE = false>
+__device__ __forceinline__ void f16_layer(const float (&cond)[FD::CS], float (&trans)[FD::CS], const float* __restrict__ bias,
+                                          Flow16Stream<FD, THREADS>& stream, int lane, float& ladj, unsigned& amax_pk) {
+    constexpr int KS1 = FD::KS1, KS2 = FD::KS2, NB1 = FD::NB1;
     // ---- first dense layer: conditioner slots -> hidden 1
     half8 bh1[KS1], bl1[KS1];
 #pragma unroll
     for (int S = 0; S < KS1; S++) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = FD::MAF ? xf[8 * S + j] : (first ? xf[8 * S + j] : xf[CS + 8 * S + j]);
+        for (int j = 0; j < 8; j++) v[j] = cond[8 * S + j];
         f16_split8<false>(v, bh1[S], bl1[S], amax_pk);
     }
     floatx4 h1[NB1];
+    const float* Aw = nullptr;  // WHOLE: the layer's one chunk
+    if constexpr (FD::WHOLE) Aw = stream.next();
 #pragma unroll
     for (int p = 0; p < FD::P1; p++) {
-        const float* A = stream.next();
+        const float* A = FD::WHOLE ? Aw + (size_t)p * FD::BC1 * FD::BLK1 : stream.next();
         floatx4 part[FD::BC1];
         f16_dense<FD::BC1, KS1>(part, bh1, bl1, A, bias + p * FD::BC1 * 16, lane);
 #pragma unroll
@@ -207,7 +233,7 @@ __device__ __forceinline__ void f16_layer(float (&xf)[FD::SL], const float* __re
     floatx4 h2[NB1];
 #pragma unroll
     for (int p = 0; p < FD::P2; p++) {
-        const float* A = stream.next();
+        const float* A = FD::WHOLE ? Aw + FD::A1 + (size_t)p * FD::BC2 * FD::BLK2 : stream.next();
         floatx4 part[FD::BC2];
         f16_dense<FD::BC2, KS2>(part, bh2, bl2, A, bias + W + p * FD::BC2 * 16, lane);
 #pragma unroll
@@ -223,7 +249,7 @@ __device__ __forceinline__ void f16_layer(float (&xf)[FD::SL], const float* __re
     }
 #pragma unroll
     for (int p = 0; p < FD::P3; p++) {
-        const float* A = stream.next();
+        const float* A = FD::WHOLE ? Aw + FD::A1 + FD::A2 + (size_t)p * FD::BC3 * FD::BLK2 : stream.next();
 #pragma unroll
         for (int pr = 0; pr < FD::BC3 / 2; pr++) {
             floatx4 o[2];
@@ -233,16 +259,31 @@ __device__ __forceinline__ void f16_layer(float (&xf)[FD::SL], const float* __re
             for (int r = 0; r < 4; r++) {
                 const float sraw = o[0][r], tt = o[1][r];
                 const float sv = 2.0f - 4.0f * __builtin_amdgcn_rcpf(__expf(sraw) + 1.0f);  // 2 tanh(sraw / 2)
-                float& xt = FD::MAF ? xf[4 * m + r] : (first ? xf[CS + 4 * m + r] : xf[4 * m + r]);
-                if (INVERSE)
-                    xt = xt * __expf(sv) + tt;
-                else
+                float& xt = trans[4 * m + r];
+                if (INVERSE) {
+                    const float mm = xt * __expf(sv);
+                    xt = mm + tt;
+                } else {
                     xt = (xt - tt) * __expf(-sv);
+                }
                 ladj -= sv;
             }
         }
     }
 }
+
+// the lane's standardised coordinates: slot s of the lane is a[s] (autoregressive flows: every slot; coupling flows: the
+// first-half slots s < CS) or b[s - CS] (coupling flows: the second-half slots)
+template <class FD>
+struct F16State {
+    float a[FD::CS];
+    float b[FD::MAF ? 1 : FD::CS];
+    __device__ __forceinline__ void set(int s, float v) {  // (s: compile-time constant after unrolling)
+        if (FD::MAF || s < FD::CS) a[s] = v;
+        else b[FD::MAF ? 0 : s - FD::CS] = v;
+    }
+    __device__ __forceinline__ float get(int s) const { return (FD::MAF || s < FD::CS) ? a[s] : b[FD::MAF ? 0 : s - FD::CS]; }
+};
 
 // sum over the four lanes p, p + 16, p + 32, p + 48 of a particle
 __device__ __forceinline__ float f16_quad_sum(float q) {
@@ -258,21 +299,29 @@ __device__ __forceinline__ float f16_quad_max(float q) {
 
 // log q of the group's particles from the lane's standardised coordinates (every lane of a particle returns it)
 template <class FD, int W, int THREADS>
-__device__ __forceinline__ float f16_logprob(float (&xf)[FD::SL], int n_layers, const float* __restrict__ biases,
+__device__ __forceinline__ float f16_logprob(F16State<FD>& x, int n_layers, const float* __restrict__ biases,
                                              Flow16Stream<FD, THREADS>& stream, int lane, float ladj0, float base_const) {
     float ladj = 0.0f;
     unsigned amax_pk = 0u;
     for (int c = 0; c < n_layers; c += 2) {  // (n_layers is uniform over the block: every wave meets the same barriers)
-        f16_layer<FD, W, THREADS, true>(xf, biases + c * FD::BIAS, stream, lane, ladj, amax_pk);
+        if constexpr (FD::MAF) {
+            f16_layer<FD, W, THREADS>(x.a, x.a, biases + c * FD::BIAS, stream, lane, ladj, amax_pk);
+        } else {
+            f16_layer<FD, W, THREADS>(x.a, x.b, biases + c * FD::BIAS, stream, lane, ladj, amax_pk);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < n_layers) {
-            f16_layer<FD, W, THREADS, false>(xf, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk);
+            if constexpr (FD::MAF) {
+                f16_layer<FD, W, THREADS>(x.a, x.a, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk);
+            } else {
+                f16_layer<FD, W, THREADS>(x.b, x.a, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     float q = 0.0f;
 #pragma unroll
-    for (int s = 0; s < FD::SL; s++) q = fmaf(xf[s], xf[s], q);
+    for (int s = 0; s < FD::SL; s++) q = fmaf(x.get(s), x.get(s), q);
     q = f16_quad_sum(q);
     const float lj = f16_quad_sum(ladj);
     float am = range_pk_max(amax_pk);

@@ -167,10 +167,84 @@ def test_flow16_step_is_repeatable_and_adapts(eng):
     for _ in range(4):
         x = eng.asarray(x0)
         ll, lp, lq = eng.mixture_logpdf(x, t), eng.mixture_logpdf(x, t), eng.coupling_logprob(x, dev)
-        acc, rho, hist = eng.pcn_mutate_flow(x, ll, lp, lq, 0.5, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), t, t, dev, 5, 0, 0.3, 6, 0,
+        acc, hist, rho = eng.pcn_mutate_flow(x, ll, lp, lq, 0.5, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), t, t, dev, 5, 0, 0.3, 6, 0,
                                              0.234, True, "f64", 4.0)
         outs.append((x.clone(), lq.clone(), np.asarray(acc), rho, np.asarray(hist)))
         eng.coupling_logprob(eng.asarray(np.random.default_rng(1).normal(size=(3000, d))), dev)
     for xo, lqo, acc, rho, hist in outs[1:]:
         assert torch.equal(xo, outs[0][0]) and torch.equal(lqo, outs[0][1]) and np.array_equal(acc, outs[0][2]) and rho == outs[0][3]
     assert outs[0][4][0] == 0.3 and len(set(outs[0][4])) > 1
+
+
+@pytest.mark.parametrize("kind,d,n_layers,n,dtype", [("coupling", 64, 4, 30000, torch.float64), ("coupling", 48, 3, 4000, torch.float32),
+                                                     ("coupling", 128, 4, 6000, torch.float64), ("coupling", 100, 2, 3001, torch.float64),
+                                                     ("maf", 64, 3, 20000, torch.float64), ("maf", 33, 2, 3000, torch.float64),
+                                                     ("maf", 128, 2, 4000, torch.float64), ("maf", 100, 2, 2000, torch.float32)])
+def test_flow16_sample_inverts_the_density_pass(eng, kind, d, n_layers, n, dtype):
+    """asmc_coupling_sample at more than 32 dimensions (k_flow16_sample): the returned log q is the density of the returned x
+    (fp64 evaluation of the same flow), pushing x back through the flow recovers a standard normal latent, and a draw does not
+    depend on how the population is sharded (global particle index); autoregressive transforms are inverted by fixed-point
+    passes that stop, per block, at the first pass that changes nothing - the bits of the full d-pass loop."""
+    import math
+    import os
+
+    flow = _flow(kind, d, n_layers, 64, seed=4)
+    dev = flow.device_coupling(eng)
+    eng.profile(True)
+    x, lq = eng.coupling_sample(n, dtype, dev, 1234, 0, 1)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert rep["k_flow16_sample"][0] == 1
+    assert torch.isfinite(x).all() and torch.isfinite(lq).all()
+    ref = torch.as_tensor(_f64(flow, x.double().cpu().numpy()), device=lq.device)
+    tol = 2e-6 if dtype == torch.float64 else 3e-4  # (float32 rows: x itself is rounded after the density was formed)
+    rel = ((lq - ref).abs() / ref.abs().clamp_min(1.0)).max()
+    assert float(rel) <= tol, float(rel)
+    z, _ = flow.forward(x.float().cpu())
+    z = z.double().numpy()
+    assert abs(z.mean()) < 5.0 / math.sqrt(n * d) and abs(z.var() - 1.0) < 0.05
+    h = (n // 2) // 16 * 16 + 5  # a shard boundary inside a 16-particle group
+    x2, lq2 = eng.coupling_sample(n - h, dtype, dev, 1234, h, 1)
+    assert torch.equal(x2, x[h:]) and torch.equal(lq2, lq[h:])
+    x3, _ = eng.coupling_sample(n, dtype, dev, 1234, 0, 2)
+    assert not torch.equal(x3, x)
+    if kind == "maf":
+        os.environ["ASMC_MAF_SAMPLE_ALL_PASSES"] = "1"
+        try:
+            x4, lq4 = eng.coupling_sample(n, dtype, dev, 1234, 0, 1)
+        finally:
+            del os.environ["ASMC_MAF_SAMPLE_ALL_PASSES"]
+        assert torch.equal(x4, x) and torch.equal(lq4, lq)
+
+
+@pytest.mark.parametrize("kind,d", [("maf", 64), ("coupling", 48)])
+def test_smc_run_with_a_neural_proposal_above_32_dimensions_stays_on_the_device(eng, kind, d):
+    """A whole HipSMC.sample() at more than 32 dimensions with a trained neural proposal: the initial draw in k_flow16_sample,
+    every mutation step in k_(t)pcn_flow16 - no propose / accept halves with a density kernel or a torch log_prob between them -
+    and log Z within 3 sigma of the closed form.  (Round 4: an autoregressive proposal above 32 dimensions ran PyTorch passes
+    between two kernels per step, a coupling proposal five kernels per step.)"""
+    import math
+
+    from aspire_amd.flows import CouplingFlow, MAFFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    n = 100_000
+    if kind == "maf":
+        flow = MAFFlow(d, n_transforms=2, hidden_features=(64, 64), seed=7, device=eng.device, dtype=torch.float32)
+    else:
+        flow = CouplingFlow(d, n_layers=4, hidden_features=(64, 64), seed=7, device=eng.device, dtype=torch.float32)
+    flow.fit(1.3 * 0.9 * np.random.default_rng(3).normal(size=(8000, d)), n_epochs=6)
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=eng, rng=np.random.default_rng(11), dtype="float64")
+    eng.profile(True)
+    out = sp.sample(n, sampler_kwargs=dict(n_steps=12), store_sample_history=False)  # (step_fn: the reference's default, tpcn)
+    rep = eng.profile_report()
+    eng.profile(False)
+    temps = len(sp.history.beta)
+    assert rep["k_tpcn_flow16"][0] == 12 * temps and rep["k_flow16_sample"][0] >= 1, sorted(rep)
+    for name in rep:
+        assert not name.startswith(("k_pcn_propose", "k_pcn_accept", "k_pcn_mm_propose", "k_coupling_logprob", "k_maf_logprob",
+                                    "k_copy_flagged_rows")), name
+    z = (float(out.log_evidence) - 0.5 * d * math.log(math.pi)) / float(out.log_evidence_error)
+    assert abs(z) < 3.0, z
