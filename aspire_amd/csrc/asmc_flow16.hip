@@ -464,7 +464,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_pcn_flow16(int64_t n, T* __restr
         for (int s = 0; s < KS; s++) xf.set(s, flow_standardise((float)o[s], s_loc[s * 4 + h], s_loc[D + s * 4 + h], s_loc[2 * D + s * 4 + h]));
         // everything of the accept test that does not need log q(x'), pinned in front of the flow
         const double c1 = ref_corr_ct<TP>(q1, p.nu, dn), c0 = ref_corr_ct<TP>(q0, p.nu, dn);
-        const double logu = log(accept_uniform(p.seed, gid, step));
+        const double logu = bm_log_unit(accept_uniform(p.seed, gid, step));  // (< 1 ulp for the uniform's range: asmc_pcn_fused.hip)
         const double lpo = log_p_t(oll, olp, olq, p.beta);
         double k_new = c1, k_old = lpo + c0, k_ll = nll, k_lp = nlp, k_lu = logu;
         asm volatile("" : "+v"(k_new), "+v"(k_old), "+v"(k_ll), "+v"(k_lp), "+v"(k_lu));
@@ -530,11 +530,11 @@ bool asmc_pcn_flow16_ok(const asmc_pcn_params* prm, const asmc_coupling* f) {
     return lds > 0 && lds <= 160 * 1024;
 }
 
-// Launch geometry (ASMC_F16_GEOM picks one for experiments; default per shape below):
-//   0  one block of 8 waves per CU, 32 KB chunks (one barrier per dense matrix)
-//   1  TWO blocks of 4 waves per CU, 16 KB chunks: the blocks' phases drift apart, so one block's noise / accept work (vector
-//      ALU) runs beside the other's flow layers (matrix pipe) - within a block every wave is in the same phase (shared stream)
-//   2  one block of 8 waves per CU, one chunk per LAYER (D = 64: 40 - 64 KB slots)
+// Launch geometry: one block of 8 waves per CU (two per SIMD; the step sits at ~200 registers).  CW = the LDS slot of the
+// weight stream: 32 KB (one barrier per dense matrix), or - D = 64, where the L image is small - a whole layer (40 - 64 KB:
+// one barrier per layer; 638 -> 600 us per step at 1M x 64, profiles/r05_flow16_geometry.txt).  Two independent 4-wave blocks
+// per CU with 16 KB slots (their phases free to drift apart, vector work of one beside matrix work of the other) measured
+// SLOWER, 685 us: every wave of a block is in the same phase, and two half-size blocks pay the stream twice.
 template <typename T, int D, int W, int KIND, int NOISE, bool TP, int THREADS, int CW, int PER_CU>
 static int launch_pcn_flow16_g(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const double* blob, const PcnDev& pd,
                                const asmc_coupling* f, const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
@@ -564,13 +564,11 @@ template <typename T, int D, int W, int KIND, int NOISE, bool TP>
 static int launch_pcn_flow16(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const double* blob, const PcnDev& pd,
                              const asmc_coupling* f, const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
                              unsigned long long* nonfinite, hipStream_t st) {
-    static const int geom_env = getenv("ASMC_F16_GEOM") ? atoi(getenv("ASMC_F16_GEOM")) : -1;
-    const int geom = geom_env >= 0 ? geom_env : (D == 64 ? 1 : 0);
+    static const bool small_slots = getenv("ASMC_F16_SMALL_SLOTS") != nullptr;  // (A/B switch: 32 KB slots at D = 64 too)
     int rc = ASMC_ERR_UNSUPPORTED;
 #define F16_ARGS ctx, n, x, ll, lp, lq, blob, pd, f, rho_ptr, step, block_counts, grid_out, nonfinite, st
     if constexpr (D == 64) {
-        if (geom == 1) rc = launch_pcn_flow16_g<T, D, W, KIND, NOISE, TP, 256, 4096, 2>(F16_ARGS);
-        if (geom == 2) rc = launch_pcn_flow16_g<T, D, W, KIND, NOISE, TP, 512, Flow16<KIND, D, W>::LAYER_A, 1>(F16_ARGS);
+        if (!small_slots) rc = launch_pcn_flow16_g<T, D, W, KIND, NOISE, TP, 512, Flow16<KIND, D, W>::LAYER_A, 1>(F16_ARGS);
     }
     if (rc == ASMC_ERR_UNSUPPORTED) rc = launch_pcn_flow16_g<T, D, W, KIND, NOISE, TP, 512, FLOW16_CHUNK_WORDS, 1>(F16_ARGS);
 #undef F16_ARGS
