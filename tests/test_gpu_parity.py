@@ -2157,13 +2157,14 @@ def test_reference_factor_on_the_device_vs_numpy(eng, d):
 
 
 @pytest.mark.parametrize("d,nu", [(64, 0.0), (48, 0.0), (64, 6.0), (34, 0.0)])
-def test_pcn_mutate_flow_above_32_dimensions_equals_split_calls(eng, d, nu):
-    """A neural proposal density at 32 < d <= 64 - the widths the flow kernels take (wider flows stay on their torch modules
-    and run through the callables path) - (smc/base.py:507-519 is called for any `dims`): asmc_pcn_mutate_flow composes
-    each step from the matrix-core propose kernel, the flow kernel, the targets and the accept / copy kernels on the x state - a
-    one-kernel step does not fit (four 64-dimensional coupling layers are 160 KB of split-fp16 operands).  Those are
-    the kernels behind the one-call-at-a-time ABI (propose / coupling_logprob / mixture_logpdf / accept), each checked against
-    the oracle elsewhere: the device-side loop must return their bits - positions, carried log-probabilities, accept counts."""
+def test_pcn_mutate_flow_above_32_dimensions_equals_split_calls(eng, d, nu, monkeypatch):
+    """The FALLBACK of a neural proposal density above 32 dimensions (smc/base.py:507-519 is called for any `dims`): when the
+    one-kernel step of round 5 (k_pcn_flow16, tests/test_gpu_flow16.py) cannot take a mutation - its tables exceed the LDS, or
+    ASMC_FLOW16_OFF=1 as here - asmc_pcn_mutate_flow composes each step from the matrix-core propose kernel, the flow kernel,
+    the targets and the accept / copy kernels on the x state (round 4's only path).  Those are the kernels behind the
+    one-call-at-a-time ABI (propose / coupling_logprob / mixture_logpdf / accept), each checked against the oracle elsewhere: the
+    device-side loop must return their bits - positions, carried log-probabilities, accept counts."""
+    monkeypatch.setenv("ASMC_FLOW16_OFF", "1")
     from conftest import random_coupling_flow
 
     n, n_steps, beta, rho = 3000, 4, 0.35, 0.3
@@ -2187,7 +2188,8 @@ def test_pcn_mutate_flow_above_32_dimensions_equals_split_calls(eng, d, nu):
                                                    0.234, False, "f64", nu)
     rep = eng.profile_report()
     eng.profile(False)
-    assert "k_pcn_flow_fused" not in rep and any(k.startswith("k_coupling_logprob") for k in rep), sorted(rep)
+    assert "k_pcn_flow_fused" not in rep and "k_pcn_flow16" not in rep and "k_tpcn_flow16" not in rep, sorted(rep)
+    assert any(k.startswith(("k_coupling_logprob", "k_flow16_logprob")) for k in rep), sorted(rep)
     xb, llb, lpb, lqb = init()
     acc_b = []
     for t in range(n_steps):
