@@ -233,6 +233,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5;
     const bool first_on_simd = __builtin_amdgcn_readfirstlane(wave) < 4;
+#ifdef FUSED_STAGGER  // experiment (MI355X_MICROARCH.md, two waves per SIMD, item 9): the second wave of every SIMD starts late
+    if (!first_on_simd) {
+#pragma unroll 1
+        for (int i = 0; i < FUSED_STAGGER; i++) __builtin_amdgcn_s_sleep(127);  // 127 x 64 cycles each
+    }
+#endif
     double rho;
     if (ad.prev_cell) {  // sharded, t > 0: close step t-1 here (see PcnAdaptArgs)
         const long long cp = *ad.prev_cell;
