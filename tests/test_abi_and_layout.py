@@ -168,4 +168,32 @@ def test_flow_packing_places_every_weight_once():
     ws[1][3, 5] = 1e5  # beyond fp16: the split products would see inf
     with pytest.raises(_lib.AsmcError, match="fp16 operand range"):
         pack_maf(lib, d, hidden, ws, bs)
-    assert lib.asmc_maf_pack_floats(33, 3, 64) < 0 and lib.asmc_coupling_pack_floats(21, 2, 64) < 0  # shapes without kernels
+    assert lib.asmc_maf_pack_floats(129, 3, 64) < 0 and lib.asmc_coupling_pack_floats(21, 2, 64) < 0  # shapes without kernels
+    assert lib.asmc_coupling_pack_floats(130, 2, 64) < 0 and lib.asmc_maf_pack_floats(64, 3, 48) < 0
+
+    # more than 32 dimensions (round 5; packed layout 1, csrc/asmc_flow16.hip): biases in fp32, every weight ONCE as an fp16
+    # (hi, lo) pair - hi + lo is the weight to fp32 accuracy - whatever the padding (d = 48 -> 64, 100 -> 128) and the kind
+    assert lib.asmc_flow_layout(_lib.ASMC_FLOW_COUPLING, 32, 64) == 0 and lib.asmc_flow_layout(_lib.ASMC_FLOW_MAF, 33, 64) == 1
+    assert lib.asmc_flow_layout(_lib.ASMC_FLOW_COUPLING, 48, 64) == 1 and lib.asmc_flow_layout(_lib.ASMC_FLOW_COUPLING, 47, 64) < 0
+    for kind, d, hidden, n in (("coupling", 48, 64, 2), ("coupling", 128, 32, 1), ("maf", 33, 64, 2), ("maf", 100, 64, 1), ("maf", 64, 128, 1)):
+        if kind == "coupling":
+            ws, bs = layers(n, d // 2, hidden, d)
+            packed = pack_coupling(lib, d, hidden, ws, bs)
+            assert packed.size == lib.asmc_coupling_pack_floats(d, n, hidden)
+        else:
+            ws, bs = layers(n, d, hidden, 2 * d, mask_p=0.3)
+            packed = pack_maf(lib, d, hidden, ws, bs)
+            assert packed.size == lib.asmc_maf_pack_floats(d, n, hidden)
+        D = 64 if d <= 64 else 128
+        n_out = (D if kind == "coupling" else 2 * D)
+        n_bias = n * (2 * hidden + n_out)
+        bias = packed[:n_bias]
+        want_b = np.sort(np.concatenate([b.ravel() for b in bs]))
+        assert np.array_equal(np.sort(bias[bias != 0.0]), want_b[want_b != 0.0])
+        halves = packed[n_bias:].view(np.float16).reshape(-1, 2, 64, 8).astype(np.float32)  # [block x K step][hi | lo][lane][8]
+        vals = (halves[:, 0] + halves[:, 1]).ravel()
+        got = np.sort(vals[vals != 0.0])
+        want = np.sort(np.concatenate([a.ravel() for a in ws]))
+        want = want[want != 0.0]
+        assert got.size == want.size
+        np.testing.assert_allclose(got, want, rtol=3e-7, atol=4e-8)  # (the lo half of a small weight is an fp16 subnormal: 6e-8 apart)
