@@ -574,6 +574,78 @@ def main():
         except Exception as exc:  # an extra leg never costs the line
             extra.setdefault("flow_run_maf", {"error": repr(exc)})
             extra.setdefault("reference_defaults_run", {"error": repr(exc)})
+        # (d4) flow-proposal steps ABOVE 32 dimensions (round 5, csrc/asmc_flow16.hip): the one-kernel step on 16-particle groups
+        #      with streamed weights, coupling and autoregressive proposals at d = 64 / 128 (narrower problems run zero-padded on
+        #      these: d = 48 costs what d = 64 does), 8 steps at 1M particles; hbm_frac = (2 d s + 16) bytes per particle / time / peak
+        try:
+            from aspire_amd.flows import MAFFlow as _MAF
+
+            big = {}
+            if n_global * 128 * 8 * 3 < 40e9:  # (state + padded copies)
+                eng_big = eng if eng.d_max >= 128 else HipEngine(local_rank, n_max=n_local, d_max=128)
+                for kind, dd in (("coupling", 64), ("maf", 64), ("coupling", 128), ("maf", 128)):
+                    fl = (CouplingFlow(dd, n_layers=4, hidden_features=(64, 64), device=eng_big.device, dtype=torch.float32, seed=5) if kind == "coupling"
+                          else _MAF(dd, n_transforms=3, hidden_features=(64, 64), device=eng_big.device, dtype=torch.float32, seed=5))
+                    fl.fit(1.2 * np.random.default_rng(3).normal(size=(4000, dd)), n_epochs=2)  # untimed: non-trivial weights
+                    dev_f = fl.device_coupling(eng_big)
+                    gx = torch.Generator(eng_big.device).manual_seed(dd)
+                    xs_ = torch.randn((n_local, dd), device=eng_big.device, dtype=torch.float64, generator=gx)
+                    t_l = eng_big.make_mixture([0.0], np.zeros((1, dd)), np.ones((1, dd)))
+                    mu_ = eng_big.asarray(np.zeros(dd))
+                    L_ = eng_big.asarray(np.eye(dd))
+                    ll_, lp_, lq_ = eng_big.mixture_logpdf(xs_, t_l), eng_big.mixture_logpdf(xs_, t_l), eng_big.coupling_logprob(xs_, dev_f)
+                    for nu_, name in ((0.0, "pcn"), (5.0, "tpcn")):
+                        args_ = (xs_, ll_, lp_, lq_, 0.5, mu_, L_, L_, t_l, t_l, dev_f, 7, 0, 0.15, 8, 0, 0.234, False, "f64", nu_)
+                        eng_big.pcn_mutate_flow(*args_)
+                        eng_big.profile(True)
+                        eng_big.pcn_mutate_flow(*args_)
+                        kk = eng_big.profile_report()
+                        eng_big.profile(False)
+                        sk = next((k for k in kk if k.startswith(("k_pcn_flow16", "k_tpcn_flow16"))), None)
+                        ms_ = kk[sk][1] if sk else None
+                        big[f"{kind}_d{dd}_{name}"] = {
+                            "step_kernel": sk, "us_per_step": round(ms_ * 1e3, 1) if ms_ else None,
+                            "hbm_frac": round((2 * dd * 8 + 16) * n_local / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_ else None,
+                            "kernels_per_step": round(sum(c for k, (c, _) in kk.items() if k.startswith(("k_pcn", "k_tpcn", "k_flow", "k_coupling", "k_mixture", "k_copy", "k_gamma")) and "whiten" not in k and "adapt" not in k) / 8, 2)}
+                    del xs_, ll_, lp_, lq_
+                if eng_big is not eng:
+                    eng_big.close()
+            extra["flow_step_above_32_dims"] = big
+        except Exception as exc:
+            extra["flow_step_above_32_dims"] = {"error": repr(exc)}
+        # (d5) BASELINE configs[4]'s mutation step on ONE GPU: 1M x 128, two-component mixture likelihood, analytic proposal,
+        #      k_pcn_mm on the fp64 matrix cores (8 pCN steps, default noise); algorithmic bytes 2 d s + 16 = 2064 per particle
+        try:
+            d5 = 128
+            eng5 = eng if eng.d_max >= d5 else HipEngine(local_rank, n_max=n_local, d_max=d5)
+            lik5 = DiagGaussianMixture(np.stack([2 * np.ones(d5), -2 * np.ones(d5)]), np.stack([0.5 * np.ones(d5), np.ones(d5)]))
+            pri5 = DiagGaussianMixture.isotropic(d5, 0.0, 1.0)
+            q5 = GaussianFlow(d5, sigma=3.0, engine=eng5, seed=4, dtype=xdt)
+            x5, lq5 = q5.sample_and_log_prob(n_local)
+            ll5 = eng5.mixture_logpdf(x5, lik5.device_mixture(eng5))
+            lp5 = eng5.mixture_logpdf(x5, pri5.device_mixture(eng5))
+            mu5, L5 = eng5.asarray(np.zeros(d5)), eng5.asarray(3.0 * np.eye(d5))
+            Li5 = eng5.asarray(np.eye(d5) / 3.0)
+            c5 = {}
+            for nu_, name in ((0.0, "pcn"), (5.0, "tpcn")):
+                a5 = (x5, ll5, lp5, lq5, 0.3, mu5, L5, Li5, lik5.device_mixture(eng5), pri5.device_mixture(eng5), q5.device_mixture(eng5), 7, 0,
+                      0.1, 8, 0, 0.234, False)
+                eng5.pcn_mutate(*a5, noise=args.noise, nu=nu_)
+                eng5.profile(True)
+                eng5.pcn_mutate(*a5, noise=args.noise, nu=nu_)
+                k5 = eng5.profile_report()
+                eng5.profile(False)
+                sk = next((k for k in k5 if k.startswith(("k_pcn_mm_step", "k_tpcn_mm_step"))), None)
+                ms_ = k5[sk][1] if sk else None
+                c5[name] = {"step_kernel": sk, "us_per_step": round(ms_ * 1e3, 1) if ms_ else None,
+                            "algorithmic_bytes_per_particle": 2 * d5 * s_bytes + 16,
+                            "hbm_frac": round((2 * d5 * s_bytes + 16) * n_local / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_ else None,
+                            "fp64_matrix_flops_per_particle": 144 * 2048 // 16}
+            extra["config5_step"] = c5
+            if eng5 is not eng:
+                eng5.close()
+        except Exception as exc:
+            extra["config5_step"] = {"error": repr(exc)}
         # (e) the headline run with the flow on the fp32 MFMA chain (v_mfma_f32_32x32x2_f32) instead of the default split-fp16
         #     products: same operands to fp32 accuracy, 16/3 of the matrix-pipe time
         if flow_math == "f16x2-split":
