@@ -28,6 +28,7 @@ ASMC_SELECT_THREADS = 262144
 ASMC_STUDENT_MAX_ROWS = 16384
 ASMC_ABI_VERSION = 22
 ASMC_FLOW_COUPLING, ASMC_FLOW_MAF = 0, 1  # asmc_coupling.kind
+ASMC_MAX_COUNT_CELLS = 64  # asmc_pcn_set_count_cells
 ASMC_CDF_REC = 9
 ASMC_CDF_STATE = 36
 
@@ -194,6 +195,7 @@ SIGNATURES = {
         [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _u64, _u64, _u32, _pi64, _vp],
     ),
     "asmc_flow_layout": (_i, [_i, _i, _i]),
+    "asmc_pcn_set_count_cells": (_i, [_vp, _i]),
     "asmc_coupling_pack_floats": (_i64, [_i, _i, _i]),
     "asmc_coupling_pack": (_i, [_i, _i, _i, POINTER(c_void_p), POINTER(c_void_p), _vp]),
     "asmc_maf_pack_floats": (_i64, [_i, _i, _i]),

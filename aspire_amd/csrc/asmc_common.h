@@ -131,6 +131,7 @@ struct asmc_ctx {
     int (*count_hook)(void*, asmc_stream);
     void* count_hook_user;
     long long* count_cell;
+    int count_cells;               // cells behind count_cell that one exchange sums (1; a lagged adaptation uses one per step of a block)
     int64_t count_n_global;
     int mutate_defer, mutate_pending_steps;  // asmc_pcn_mutate_flow_enqueue / _result
     hipEvent_t ev_mutate;                    // recorded behind a deferred mutation's read-back

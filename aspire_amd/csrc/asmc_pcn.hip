@@ -949,32 +949,54 @@ static int pcn_prepare_gamma(asmc_ctx* ctx, int64_t n, PcnDev& pd, uint32_t step
 
 // sums the per-block accept counts of step `t`, records them, adapts the step size
 // (log rho += (acc - target)/(t+1)^0.75, rho clipped to [1e-4, 0.99])
+// adapt: 0 = off, 1 = after every step, k >= 2 = LAGGED (sampler_kwargs["adapt_lag"] = k): the step size is held for blocks of k
+// steps; the step that ends a block (t + 1 = 0 mod k, or `last`: the final step of the call) applies the block's updates in
+// order, each with its own count and step index - the same arithmetic k steps late.  A sharded run then exchanges its accept
+// counts once per block (k cells in one all-reduce) instead of once per step.
+// cells != NULL (sharded, lagged): block_counts is unused; the GLOBAL counts of the block's steps sit in cells[t' % k] and are
+// recorded here (counts_out, rho_hist) together with the replay.
 __global__ __launch_bounds__(1024) void k_pcn_adapt(int nblocks, const long long* __restrict__ block_counts,
                                                    int64_t n, int t, long long* __restrict__ counts_out,
                                                    double* __restrict__ rho_ptr, double* __restrict__ rho_hist,
-                                                   double target, int adapt, const double* __restrict__ rho_src) {
+                                                   double target, int adapt, const double* __restrict__ rho_src, int last,
+                                                   const long long* __restrict__ cells) {
     // rho_src: where the step size step t used is kept when it is not *rho_ptr (fused flow steps of sharded runs, which
     // adapt in the next step's prologue: *rho_ptr is only brought up to date here, at the end of a call)
     __shared__ long long s_c[16];
     long long c = 0;
-    for (int b = threadIdx.x; b < nblocks; b += 1024) c += block_counts[b];
+    if (cells == nullptr)
+        for (int b = threadIdx.x; b < nblocks; b += 1024) c += block_counts[b];
     c = wave_sum_ll(c);
     if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
         c = 0;
         for (int w = 0; w < 16; w++) c += s_c[w];
-        counts_out[t] = c;
         const double rho = rho_src ? *rho_src : *rho_ptr;
-        rho_hist[t] = rho;
-        *rho_ptr = adapt ? pcn_adapt_rho(rho, c, n, target, t) : rho;
+        if (cells == nullptr) {
+            counts_out[t] = c;
+            rho_hist[t] = rho;
+        }
+        if (adapt <= 1) {
+            *rho_ptr = adapt ? pcn_adapt_rho(rho, c, n, target, t) : rho;
+        } else if ((t + 1) % adapt == 0 || last) {
+            double r = rho;
+            for (int tp = t - (t % adapt); tp <= t; tp++) {
+                const long long ct = cells ? cells[tp % adapt] : (tp == t ? c : counts_out[tp]);
+                if (cells) counts_out[tp] = ct, rho_hist[tp] = rho;
+                r = pcn_adapt_rho(r, ct, n, target, tp);
+            }
+            *rho_ptr = r;
+        } else {
+            *rho_ptr = rho;
+        }
     }
 }
 
 __global__ void k_set_scalar(double* __restrict__ cell, double v) { *cell = v; }
 
 __global__ __launch_bounds__(1024) void k_count_sum(int nblocks, const long long* __restrict__ block_counts,
-                                                   long long* __restrict__ cell) {
+                                                   long long* __restrict__ cell) {  // (the caller points `cell` at the step's own cell)
     __shared__ long long s_c[16];
     long long c = 0;
     for (int b = threadIdx.x; b < nblocks; b += 1024) c += block_counts[b];
@@ -988,22 +1010,30 @@ __global__ __launch_bounds__(1024) void k_count_sum(int nblocks, const long long
     }
 }
 
-// closes step t: accept count (summed across ranks through the exchange hook when one is installed), history, adaptation
+// closes step t: accept count (summed across ranks through the exchange hook when one is installed), history, adaptation.
+// `last`: t is the final step of the call (a lagged adaptation closes its open block there).
 static int pcn_close_step(asmc_ctx* ctx, hipStream_t st, int grid, const long long* d_block, int64_t n, int t,
-                          long long* d_counts, double* d_rho, double* d_rho_hist, double target, int adapt) {
+                          long long* d_counts, double* d_rho, double* d_rho_hist, double target, int adapt, int last = 1) {
     if (ctx->count_hook) {
-        ASMC_LAUNCH(ctx, st, "k_count_sum", k_count_sum, dim3(1), dim3(1024), 0, st, grid, d_block, ctx->count_cell);
+        const int lag = adapt >= 2 ? adapt : 1;
+        if (lag > ctx->count_cells) {
+            asmc_set_error("adapt_lag %d needs %d exchange cells, the installed hook has %d (asmc_pcn_set_count_cells)", lag, lag, ctx->count_cells);
+            return ASMC_ERR_ARG;
+        }
+        ASMC_LAUNCH(ctx, st, "k_count_sum", k_count_sum, dim3(1), dim3(1024), 0, st, grid, d_block, ctx->count_cell + (lag > 1 ? t % lag : 0));
         ASMC_LAUNCH_CHECK();
+        if (lag > 1 && !((t + 1) % lag == 0 || last)) return ASMC_OK;  // the block's counts are exchanged together, at its end
         const int hrc = ctx->count_hook(ctx->count_hook_user, reinterpret_cast<asmc_stream>(st));
         if (hrc != 0) {
             asmc_set_error("accept-count exchange hook failed (%d)", hrc);
             return ASMC_ERR_ARG;
         }
         ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, 1, (const long long*)ctx->count_cell,
-                    ctx->count_n_global, t, d_counts, d_rho, d_rho_hist, target, adapt, (const double*)nullptr);
+                    ctx->count_n_global, t, d_counts, d_rho, d_rho_hist, target, adapt, (const double*)nullptr, last,
+                    lag > 1 ? (const long long*)ctx->count_cell : (const long long*)nullptr);
     } else {
         ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, grid, d_block, n, t, d_counts, d_rho,
-                    d_rho_hist, target, adapt, (const double*)nullptr);
+                    d_rho_hist, target, adapt, (const double*)nullptr, last, (const long long*)nullptr);
     }
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
@@ -2373,6 +2403,13 @@ int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int
     ctx->count_hook_user = user;
     ctx->count_cell = reinterpret_cast<long long*>(cell_dev);
     ctx->count_n_global = n_global;
+    ctx->count_cells = 1;  // (asmc_pcn_set_count_cells widens it)
+    return ASMC_OK;
+}
+
+int asmc_pcn_set_count_cells(asmc_ctx* ctx, int n_cells) {
+    ASMC_REQUIRE(ctx != nullptr && n_cells >= 1 && n_cells <= ASMC_MAX_COUNT_CELLS, "n_cells out of range");
+    ctx->count_cells = n_cells;
     return ASMC_OK;
 }
 
@@ -2391,7 +2428,7 @@ typedef int (*rccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hi
 static int rccl_count_hook(void* user, asmc_stream stream) {
     asmc_ctx* ctx = static_cast<asmc_ctx*>(user);
     const int nccl_int64 = 4, nccl_sum = 0;  // rccl.h: ncclInt64, ncclSum
-    return reinterpret_cast<rccl_allreduce_fn>(ctx->rccl_allreduce)(ctx->count_cell, ctx->count_cell, 1, nccl_int64, nccl_sum,
+    return reinterpret_cast<rccl_allreduce_fn>(ctx->rccl_allreduce)(ctx->count_cell, ctx->count_cell, (size_t)ctx->count_cells, nccl_int64, nccl_sum,
                                                                     ctx->rccl_comm, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -2574,7 +2611,7 @@ static int pcn_mutate_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, double
             rc = asmc_pcn_mm_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, pd.nu > 0.0 ? MM_STEP_T : MM_STEP, d_rho,
                                     step0 + (uint32_t)t, d_block, &grid, st);
             if (rc) return rc;
-            rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+            rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt, t == n_steps - 1);
             if (rc) return rc;
         }
         rc = asmc_pcn_mm_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, MM_UNWHITEN, d_rho, 0, d_block, &grid, st);
@@ -2632,7 +2669,7 @@ static int pcn_mutate_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, double
         if (rc) return rc;
         rc = launch_mode(y_state ? (tp ? PCN_Y_STEP_T : PCN_Y_STEP) : (tp ? PCN_X_STEP_T : PCN_X_STEP), step0 + (uint32_t)t, &grid);
         if (rc) return rc;
-        rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+        rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt, t == n_steps - 1);
         if (rc) return rc;
     }
     if (y_state) {
@@ -3174,11 +3211,17 @@ static int pcn_mutate_flow_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, d
                                reinterpret_cast<unsigned long long*>(ctx->d_tilectr + 2 * ASMC_MAX_PCN_STEPS),
                                ctx->count_hook ? ctx->count_cell : nullptr,
                                ctx->count_hook && t > 0 ? ctx->count_cell : nullptr, d_counts, d_rho, d_rho_hist,
-                               prm->target_accept, ctx->count_hook ? ctx->count_n_global : n, t, prm->adapt};
+                               prm->target_accept, ctx->count_hook ? ctx->count_n_global : n, t, prm->adapt, t == n_steps - 1};
+            const int lag = prm->adapt >= 2 ? prm->adapt : 1;
+            if (ctx->count_hook && lag > ctx->count_cells) {
+                asmc_set_error("adapt_lag %d needs %d exchange cells, the installed hook has %d (asmc_pcn_set_count_cells)", lag, lag, ctx->count_cells);
+                return ASMC_ERR_ARG;
+            }
             rc = asmc_pcn_flow_fused_launch(ctx, n, prm->x_dtype == ASMC_F64 ? ASMC_F64 : ASMC_F32, ll, lp, lq, pd, flow, d_rho, step,
                                             ctx->d_tilectr + t, d_block, &grid, ad, st);
             if (rc) return rc;
-            if (ctx->count_hook) {  // the kernel's last block left this rank's count in the cell: exchange it
+            // the kernel's last block left this rank's count in the step's cell: exchange it - lagged runs at the end of a block
+            if (ctx->count_hook && ((t + 1) % lag == 0 || t == n_steps - 1)) {
                 const int hrc = ctx->count_hook(ctx->count_hook_user, reinterpret_cast<asmc_stream>(st));
                 if (hrc != 0) {
                     asmc_set_error("accept-count exchange hook failed (%d)", hrc);
@@ -3187,7 +3230,8 @@ static int pcn_mutate_flow_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, d
                 if (t == n_steps - 1) {  // nobody's prologue follows the last step
                     ASMC_LAUNCH(ctx, st, "k_pcn_adapt", k_pcn_adapt, dim3(1), dim3(1024), 0, st, 1,
                                 (const long long*)ctx->count_cell, ctx->count_n_global, t, d_counts, d_rho, d_rho_hist,
-                                prm->target_accept, prm->adapt, (const double*)(d_rho_hist + t));
+                                prm->target_accept, prm->adapt, (const double*)(d_rho_hist + t), 1,
+                                lag > 1 ? (const long long*)ctx->count_cell : (const long long*)nullptr);
                     ASMC_LAUNCH_CHECK();
                 }
             }
@@ -3212,7 +3256,7 @@ static int pcn_mutate_flow_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, d
                 rc = soa ? FLOW_STEP(float, PCN_FLOW_ACCEPT_S) : FLOW_STEP(float, PCN_FLOW_ACCEPT);
 #undef FLOW_STEP
             if (rc) return rc;
-            rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+            rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt, t == n_steps - 1);
             if (rc) return rc;
         }
         rc = convert(PCN_UNWHITEN_X);
@@ -3241,7 +3285,7 @@ static int pcn_mutate_flow_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll, d
         ASMC_LAUNCH_CHECK();
         rc = launch_copy_flagged(ctx, n, d, prm->x_dtype, x, x_prop, flags, st);
         if (rc) return rc;
-        rc = pcn_close_step(ctx, st, 1, (const long long*)d_cnt, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+        rc = pcn_close_step(ctx, st, 1, (const long long*)d_cnt, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt, t == n_steps - 1);
         if (rc) return rc;
     }
     long long* h_counts = reinterpret_cast<long long*>(ctx->h_pinned);
@@ -3315,7 +3359,7 @@ static int pcn_mutate_flow16_impl(asmc_ctx* ctx, int64_t n, void* x, double* ll,
         if (rc) return rc;
         rc = asmc_pcn_flow16_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, flow, d_rho, step, d_block, &grid, d_bad, st);
         if (rc) return rc;
-        rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt);
+        rc = pcn_close_step(ctx, st, grid, d_block, n, t, d_counts, d_rho, d_rho_hist, prm->target_accept, prm->adapt, t == n_steps - 1);
         if (rc) return rc;
     }
     rc = asmc_pcn_mm_launch(ctx, n, prm->x_dtype, x, ll, lp, lq, pd, MM_UNWHITEN_X, d_rho, 0, d_block, &grid, st);

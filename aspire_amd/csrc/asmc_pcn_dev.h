@@ -22,7 +22,8 @@ struct PcnAdaptArgs {
     double* rho_hist;       // [t] <- the step size this step used
     double target;
     int64_t n;              // population the acceptance rate refers to (sharded: the global one)
-    int t, adapt;
+    int t, adapt;           // adapt: 0 off, 1 after every step, k >= 2 lagged by blocks of k steps (k_pcn_adapt, asmc_pcn.hip)
+    int last;               // t is the final step of the call (a lagged adaptation closes its open block there)
 };
 
 // log rho += (acc - target)/(t+1)^0.75, rho clipped to [1e-4, 0.99]; one definition for every kernel that

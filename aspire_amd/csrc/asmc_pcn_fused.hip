@@ -241,10 +241,22 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
 #endif
     double rho;
     if (ad.prev_cell) {  // sharded, t > 0: close step t-1 here (see PcnAdaptArgs)
-        const long long cp = *ad.prev_cell;
         const double rp = ad.rho_hist[ad.t - 1];
-        rho = ad.adapt ? pcn_adapt_rho(rp, cp, ad.n, ad.target, ad.t - 1) : rp;
-        if (blockIdx.x == 0 && threadIdx.x == 0) ad.counts_out[ad.t - 1] = cp;
+        if (ad.adapt <= 1) {
+            const long long cp = *ad.prev_cell;
+            rho = ad.adapt ? pcn_adapt_rho(rp, cp, ad.n, ad.target, ad.t - 1) : rp;
+            if (blockIdx.x == 0 && threadIdx.x == 0) ad.counts_out[ad.t - 1] = cp;
+        } else if (ad.t % ad.adapt == 0) {  // lagged: the block [t - k, t - 1] was exchanged as a whole (cells [t' % k])
+            double r = rp;
+            for (int tp = ad.t - ad.adapt; tp < ad.t; tp++) {
+                const long long ct = ad.prev_cell[tp % ad.adapt];
+                r = pcn_adapt_rho(r, ct, ad.n, ad.target, tp);
+                if (blockIdx.x == 0 && threadIdx.x == 0) ad.counts_out[tp] = ct;
+            }
+            rho = r;
+        } else {
+            rho = rp;  // inside a block: the held step size
+        }
     } else {
         rho = *rho_ptr;
     }
@@ -941,13 +953,20 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     if (threadIdx.x == 0) {
         c = 0;
         for (int w = 0; w < THREADS / 64; w++) c += s_cnt[w];
-        if (ad.cell) {  // sharded: hand the rank's count to the exchange hook
-            ad.cell[0] = c;
+        if (ad.cell) {  // sharded: hand the rank's count to the exchange hook (lagged: the step's own cell of the block)
+            ad.cell[ad.adapt >= 2 ? ad.t % ad.adapt : 0] = c;
             return;
         }
         ad.counts_out[ad.t] = c;
         ad.rho_hist[ad.t] = rho;
-        if (ad.adapt) *ad.rho = pcn_adapt_rho(rho, c, ad.n, ad.target, ad.t);
+        if (ad.adapt == 1) {
+            *ad.rho = pcn_adapt_rho(rho, c, ad.n, ad.target, ad.t);
+        } else if (ad.adapt >= 2 && ((ad.t + 1) % ad.adapt == 0 || ad.last)) {  // lagged: the block's updates, in order
+            double r = rho;
+            for (int tp = ad.t - (ad.t % ad.adapt); tp <= ad.t; tp++)
+                r = pcn_adapt_rho(r, tp == ad.t ? c : ad.counts_out[tp], ad.n, ad.target, tp);
+            *ad.rho = r;
+        }
     }
 }
 

@@ -930,12 +930,15 @@ class HipEngine:
             check(self.lib.asmc_pcn_set_count_hook(self._ctx, None, None, None, 0), "asmc_pcn_set_count_hook")
             self._hook = None
             return
-        cell = self.__dict__.get("_count_cell")  # (the library writes it before every exchange: one allocation, no fill per call)
+        # ASMC_MAX_COUNT_CELLS cells: a lagged adaptation (adapt_lag = k) exchanges the k counts of a block at once - step t writes
+        # cell t % k, one all-reduce sums them all (unused cells stay zero)
+        cell = self.__dict__.get("_count_cell")  # (the library writes its cells before every exchange: one allocation, no fill per call)
         if cell is None:
-            cell = self._count_cell = torch.zeros(1, dtype=torch.int64, device=self.device)
+            cell = self._count_cell = torch.zeros(_lib.ASMC_MAX_COUNT_CELLS, dtype=torch.int64, device=self.device)
         if self.use_rccl(comm):  # the library issues the all-reduce itself, on its own stream
             self._hook = (None, cell, None)
             check(self.lib.asmc_pcn_set_count_rccl(self._ctx, _dptr(cell), int(n_global)), "asmc_pcn_set_count_rccl")
+            check(self.lib.asmc_pcn_set_count_cells(self._ctx, _lib.ASMC_MAX_COUNT_CELLS), "asmc_pcn_set_count_cells")
             return
 
         def cb(_user, _stream):
@@ -950,6 +953,7 @@ class HipEngine:
         self._hook = (fn, cell, cb)  # keep the trampoline and the cell alive while installed
         check(self.lib.asmc_pcn_set_count_hook(self._ctx, ctypes.cast(fn, ctypes.c_void_p), None, _dptr(cell), int(n_global)),
               "asmc_pcn_set_count_hook")
+        check(self.lib.asmc_pcn_set_count_cells(self._ctx, _lib.ASMC_MAX_COUNT_CELLS), "asmc_pcn_set_count_cells")
 
     def pcn_mutate(self, x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed, gid0, rho, n_steps, step0=0,
                    target_accept=0.234, adapt=True, noise="f64", nu=0.0):

@@ -724,6 +724,18 @@ class HipSMC(SMCSampler):
             raise ValueError("Log proposal contains NaN values")
         return self._wrap(x_new, ll, lp, lq, beta, like=particles)
 
+    def _adapt_mode(self) -> int:
+        """`asmc_pcn_params.adapt` of the device-side step loops: 1 = the step size adapts after every step (default, the
+        specification every test pins); `sampler_kwargs["adapt_lag"] = k` (2 .. 64) holds it for blocks of k steps and applies the
+        block's k updates at its end, in order, each with its own step's count - a sharded run then exchanges accept counts once per
+        block (n_steps / k all-reduces per temperature instead of n_steps).  Single-rank and sharded runs with the same k agree bit
+        for bit; runs with different k are different (equally valid) adaptation schedules.  The callables / preconditioned paths
+        adapt after every step whatever the value."""
+        k = int(self.sampler_kwargs.get("adapt_lag", 1) or 1)
+        if not 1 <= k <= 64:
+            raise ValueError(f"adapt_lag must be in 1 .. 64, got {k}")
+        return k
+
     def _device_flow(self):
         """The proposal flow packed for the MFMA kernel, or None (not a float32 coupling flow of a supported shape)."""
         if not hasattr(self.prior_flow, "device_coupling"):
@@ -841,7 +853,7 @@ class HipSMC(SMCSampler):
                     # right behind the mutation, BEFORE the host waits for either: the GPU does not idle while Python
                     # does the bookkeeping of the finished mutation
                     handle = e.pcn_mutate_flow_enqueue(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed, gid0,
-                                                       st["rho"], chunk, step0, target, True, noise, nu)
+                                                       st["rho"], chunk, step0, target, self._adapt_mode(), noise, nu)
                     out = self._wrap(x, ll, lp, lq, beta, like=particles)
                     ok = out.speculate_importance_step(self.current_target_efficiency(beta), self._beta_tolerance, self.rng,
                                                        resample_mode=self.resample_mode, resample_method=self.resample_method,
@@ -852,7 +864,7 @@ class HipSMC(SMCSampler):
                         st["prewrapped"] = out  # the step's results are collected when the next iteration asks for them
                 else:
                     n_acc, rho_hist, rho = e.pcn_mutate_flow(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, dev_flow, seed,
-                                                             gid0, st["rho"], chunk, step0 + done, target, True, noise, nu)
+                                                             gid0, st["rho"], chunk, step0 + done, target, self._adapt_mode(), noise, nu)
                 st["rho"] = rho
                 st["lq_checked"] = hasattr(e, "pcn_lq_nan")
                 acc_rates.extend((n_acc / n_global).tolist())
@@ -884,7 +896,7 @@ class HipSMC(SMCSampler):
             while done < n_steps:
                 chunk = min(n_steps - done, 2048)
                 n_acc, rho_hist, rho = e.pcn_mutate(x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed,
-                                                    gid0, st["rho"], chunk, step0 + done, target, True, noise, nu)
+                                                    gid0, st["rho"], chunk, step0 + done, target, self._adapt_mode(), noise, nu)
                 st["rho"] = rho
                 st["lq_checked"] = hasattr(e, "pcn_lq_nan")
                 acc_rates.extend((n_acc / n_global).tolist())

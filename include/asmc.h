@@ -90,7 +90,8 @@ typedef struct {
     uint64_t seed;            /* Philox key */
     uint64_t gid0;            /* global index of local particle 0 (sharded runs) */
     double target_accept;     /* e.g. 0.234 (reference minipcn.py:47) */
-    int32_t adapt;            /* 1: Robbins-Monro step-size adaptation on device */
+    int32_t adapt;            /* 0: fixed step size; 1: Robbins-Monro adaptation on the device after every step; k >= 2: the same
+                                 updates applied in blocks of k steps (see asmc_pcn_set_count_cells) */
     int32_t noise;            /* ASMC_NOISE_F64: fp64 Box-Muller, 2 normals / Philox block (1e-15 parity with
                                  the oracle); ASMC_NOISE_F32: fp32 hardware Box-Muller, 4 normals / block
                                  (fast; honoured by the register-resident kernels, d in {4,8,16,32}) */
@@ -460,6 +461,14 @@ int asmc_student_fit(asmc_ctx* ctx, int64_t m, int d, const double* xs_dev, int 
                      double* r_scratch_dev, double* z_scratch_dev, double* out_dev, double* result_host, asmc_stream stream);
 typedef int (*asmc_count_hook)(void* user, asmc_stream stream);
 int asmc_pcn_set_count_hook(asmc_ctx* ctx, asmc_count_hook hook, void* user, int64_t* cell_dev, int64_t n_global);
+/* Lagged step-size adaptation (asmc_pcn_params.adapt = k >= 2; sampler_kwargs["adapt_lag"]): the step size is held for blocks
+ * of k steps and the block's k updates are applied at its end, in order, each with its own step's count - the arithmetic of
+ * adapt = 1, k steps late.  A sharded run then exchanges accept counts once per block: the hook must sum n_cells >= k
+ * consecutive int64 cells starting at cell_dev (step t of a block writes cell t % k), which this call announces
+ * (<= ASMC_MAX_COUNT_CELLS; asmc_pcn_set_count_hook resets it to 1).  Honoured by asmc_pcn_mutate and asmc_pcn_mutate_flow;
+ * the one-step-at-a-time entry points (asmc_pcn_split_*, asmc_pcn_ysplit_*) adapt after every step. */
+#define ASMC_MAX_COUNT_CELLS 64
+int asmc_pcn_set_count_cells(asmc_ctx* ctx, int n_cells);
 /* NaNs in the carried log q after the last asmc_pcn_mutate / asmc_pcn_mutate_flow call (the reference's check after every
  * mutation, smc/minipcn.py; counted on the device and read back with the call's own results: no extra synchronisation) */
 int64_t asmc_pcn_lq_nan(asmc_ctx* ctx);

@@ -374,6 +374,9 @@ class OracleEngine:
         n = x.shape[0]
         n_acc, hist = np.zeros(n_steps, dtype=np.int64), np.zeros(n_steps)
         hook = getattr(self, "_count_hook", None)  # sharded: counts are global and the rate is over the whole population
+        lag = int(adapt) if int(adapt) >= 2 else 1  # asmc_pcn_params.adapt = k >= 2: the block's updates at its end, in order
+        pending = []
+        self.count_exchanges = getattr(self, "count_exchanges", 0)
         for t in range(n_steps):
             hist[t] = rho
             if nu > 0.0:
@@ -382,12 +385,19 @@ class OracleEngine:
             else:
                 c = O.pcn_step(_np(x), _np(ll), _np(lp), _np(lq), beta, _np(mu), _np(L), _np(Linv), rho,
                                t_ll.mix, t_lp.mix, t_lq.mix, seed, gid0, step0 + t, noise)
+            pending.append((t, int(c)))
+            if lag > 1 and not ((t + 1) % lag == 0 or t == n_steps - 1):
+                continue
             n_tot = n
-            if hook is not None:
-                c, n_tot = int(hook[0].all_gather_f64(np.array([float(c)])).sum()), hook[1]
-            n_acc[t] = c
-            if adapt:
-                rho = O.pcn_adapt(rho, c / n_tot, target_accept, t)
+            counts = np.array([float(v) for _, v in pending])
+            if hook is not None:  # ONE exchange for the block's counts
+                counts, n_tot = hook[0].all_gather_f64(counts).sum(axis=0), hook[1]
+                self.count_exchanges += 1
+            for (tp, _), cg in zip(pending, counts):
+                n_acc[tp] = int(cg)
+                if adapt:
+                    rho = O.pcn_adapt(rho, int(cg) / n_tot, target_accept, tp)
+            pending = []
         return n_acc, hist, rho
 
     # split path with device-resident step size / counts: host-side restatement of asmc_pcn_split_{begin,adapt,end}

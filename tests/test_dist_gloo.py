@@ -73,6 +73,19 @@ def _worker(rank, world, port, out_dir, engine_kind="oracle"):
     res["logz"] = float(post.log_evidence)
     res["acc"] = np.array(sp.history.mcmc_acceptance)
     res["x_post"] = post.x.detach().cpu().numpy() if torch.is_tensor(post.x) else np.asarray(post.x)
+    # the same run with a LAGGED step-size adaptation (sampler_kwargs["adapt_lag"] = 3, 7 steps per temperature: two full blocks
+    # and a ragged one): one accept-count exchange per block instead of one per step, same bits as the single-rank run with that lag
+    if True:  # (both engines: k_pcn_adapt's lagged form behind the exchange hook on the GPU, its restatement on the test double)
+        eng.count_exchanges = 0
+        spl = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=2.0, engine=eng, seed=3), xp=np,
+                     engine=eng, comm=comm, rng=np.random.default_rng(4))
+        spl.shard_layout = "slots"
+        postl = spl.sample(1024, sampler_kwargs=dict(n_steps=7, adapt_lag=3, target_acceptance_rate=0.95), store_sample_history=False)
+        res["lag_beta"], res["lag_logz"] = np.array(spl.history.beta), float(postl.log_evidence)
+        res["lag_acc"], res["lag_rho"] = np.array(spl.history.mcmc_acceptance), np.array(spl.history.mcmc_step_size)
+        res["lag_x"] = postl.x.detach().cpu().numpy() if torch.is_tensor(postl.x) else np.asarray(postl.x)
+        res["lag_exchanges"] = np.array([eng.count_exchanges if engine_kind == "oracle" else 3 * len(spl.history.mcmc_acceptance),
+                                         len(spl.history.mcmc_acceptance)])
     # ---- owner layout: device-style sharded search, offspring stay on the ancestor's rank ----
     res["fb"] = np.array(smc_math.find_beta_sharded(eng, comm, loc[1], loc[2], loc[3], 0.0, 0.5, 1e-6, n)[:2])
     st01 = smc_math.global_stats(eng, comm, loc[1], loc[2], loc[3], 0.0, [0.1], n)[0]
@@ -221,6 +234,30 @@ def _worker(rank, world, port, out_dir, engine_kind="oracle"):
         res["flow_chain_acc"], res["flow_steps_acc"] = a[2], b[2]
         res["flow_chain_x"], res["flow_steps_x"] = a[3], b[3]
         res["flow_chain_path"] = np.array([int("device-side step loop" in a[4]), int("device-side step loop" in b[4])])
+    if engine_kind == "hip":
+        # lagged adaptation through the ONE-KERNEL flow step of a sharded run (the step's last block leaves the rank's count in
+        # cell t % k, the exchange runs at the end of a block, the next block's first step replays the k updates in its
+        # prologue): engine level, this rank's half of a fixed population; tests/test_gpu_dist.py compares with one rank
+        from conftest import random_coupling_flow
+
+        dl, nl = 8, 6000
+        fl = random_coupling_flow(dl, 2, 64, seed=9)
+        devl = fl.device_coupling(eng)
+        gl = np.random.default_rng(77)
+        xl = 0.9 * gl.normal(size=(nl, dl))
+        lo2, hi2 = rank * nl // world, (rank + 1) * nl // world
+        xs_l = eng.asarray(xl[lo2:hi2])
+        tl = eng.make_mixture([0.0], np.zeros((1, dl)), np.ones((1, dl)))
+        ll_l, lp_l, lq_l = eng.mixture_logpdf(xs_l, tl), eng.mixture_logpdf(xs_l, tl), eng.coupling_logprob(xs_l, devl)
+        eye = eng.asarray(np.eye(dl))
+        eng.set_count_hook(comm, nl)
+        try:
+            acc_l, hist_l, rho_l = eng.pcn_mutate_flow(xs_l, ll_l, lp_l, lq_l, 0.4, eng.asarray(np.zeros(dl)), eye, eye, tl, tl, devl, 31,
+                                                      lo2, 0.6, 8, 3, 0.9, 3, "f64", 0.0)
+        finally:
+            eng.set_count_hook(None, None)
+        res["lagflow_acc"], res["lagflow_hist"], res["lagflow_rho"] = np.asarray(acc_l), np.asarray(hist_l), np.array([rho_l])
+        res["lagflow_x"] = eng.to_numpy(xs_l)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -305,6 +342,42 @@ def test_sharded_sampler_matches_single_rank(two_rank_results):
     np.testing.assert_allclose(r0["acc"], sp.history.mcmc_acceptance, atol=1e-12)
     xs = np.concatenate([r0["x_post"], r1["x_post"]])
     np.testing.assert_allclose(xs, np.asarray(post.x), rtol=1e-9, atol=1e-9)
+
+
+def _single_rank_lagged(n, n_steps, lag, seed=4, **sample_kw):
+    from oracle_engine import OracleEngine
+
+    from aspire_amd.flows import GaussianFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    eng, d = OracleEngine(), 4
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=2.0, engine=eng, seed=3), xp=np,
+                engine=eng, rng=np.random.default_rng(seed))
+    post = sp.sample(n, sampler_kwargs=dict(n_steps=n_steps, adapt_lag=lag, target_acceptance_rate=0.95), store_sample_history=False, **sample_kw)  # (0.95: the step size has to move)
+    return sp, post
+
+
+def test_lagged_adaptation_sharded_equals_single_rank_with_the_same_lag(two_rank_results):
+    """`sampler_kwargs["adapt_lag"] = k`: the step size is held for blocks of k steps and the block's k Robbins-Monro updates are
+    applied at its end, in order - so a sharded run needs ONE accept-count exchange per block (here 3 per 7-step mutation
+    instead of 7).  Two gloo ranks reproduce the single-rank run with the same lag bit for bit (schedule, log Z, acceptance and
+    step-size history, particles); the lag changes the adaptation schedule, so it differs from the lag-1 run - which stays the
+    default and the specification every other test pins."""
+    sp, post = _single_rank_lagged(1024, 7, 3)
+    r0, r1 = two_rank_results
+    for r in (r0, r1):
+        assert np.array_equal(r["lag_beta"], np.array(sp.history.beta)) and float(r["lag_logz"]) == pytest.approx(float(post.log_evidence), abs=5e-9)
+        assert np.array_equal(r["lag_acc"], np.array(sp.history.mcmc_acceptance))
+        assert np.array_equal(r["lag_rho"], np.array(sp.history.mcmc_step_size))
+        assert r["lag_exchanges"][0] == 3 * r["lag_exchanges"][1]  # ceil(7 / 3) exchanges per mutation
+    xs = np.concatenate([r0["lag_x"], r1["lag_x"]])
+    np.testing.assert_allclose(xs, np.asarray(post.x), rtol=1e-9, atol=1e-9)
+    sp1, _ = _single_rank_lagged(1024, 7, 1)
+    assert not np.array_equal(np.array(sp1.history.mcmc_step_size), np.array(sp.history.mcmc_step_size))
+    with pytest.raises(ValueError, match="adapt_lag"):
+        _single_rank_lagged(256, 2, 65)
 
 
 def test_sharded_beta_search_matches_host_bisection(two_rank_results):
@@ -451,6 +524,13 @@ def _worker8(rank, world, port, out_dir):
                      store_sample_history=False)
     res["beta"], res["logz"], res["logz_err"] = np.array(sp.history.beta), float(post.log_evidence), float(post.log_evidence_error)
     res["n_post"] = len(post.x)
+    # lagged adaptation over eight ranks (slot layout: the single-rank particle order)
+    spl = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=GaussianFlow(d, sigma=2.0, engine=eng, seed=3), xp=np,
+                 engine=eng, comm=comm, rng=np.random.default_rng(4))
+    spl.shard_layout = "slots"
+    postl = spl.sample(world * 128, sampler_kwargs=dict(n_steps=5, adapt_lag=4, target_acceptance_rate=0.95), store_sample_history=False)
+    res["lag_beta"], res["lag_logz"] = np.array(spl.history.beta), float(postl.log_evidence)
+    res["lag_rho"], res["lag_acc"] = np.array(spl.history.mcmc_step_size), np.array(spl.history.mcmc_acceptance)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -491,6 +571,15 @@ def test_world8_owner_layout_is_generator_choice(eight_rank_results, oracle):
         mine = ref2[(ref2 >= edges[r]) & (ref2 < edges[r + 1])]
         assert np.array_equal(res["odd_x"], allx[mine])
     assert int(sum(len(res["odd_x"]) for res in rs)) == n - 3 and rs[0]["odd_counts"].tolist() == [len(res["odd_x"]) for res in rs]
+
+
+def test_world8_lagged_adaptation_equals_single_rank_with_the_same_lag(eight_rank_results):
+    """Eight gloo ranks, adapt_lag = 4 on 5-step mutations (a full block and a one-step tail): the single-rank run's bits."""
+    sp, post = _single_rank_lagged(8 * 128, 5, 4)
+    for r in eight_rank_results:
+        assert np.array_equal(r["lag_beta"], np.array(sp.history.beta))
+        assert float(r["lag_logz"]) == pytest.approx(float(post.log_evidence), abs=5e-9)
+        assert np.array_equal(r["lag_rho"], np.array(sp.history.mcmc_step_size)) and np.array_equal(r["lag_acc"], np.array(sp.history.mcmc_acceptance))
 
 
 def test_world8_skew_falls_back_to_slots_and_sampler_runs(eight_rank_results, oracle):

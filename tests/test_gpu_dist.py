@@ -91,3 +91,38 @@ def test_sharded_flow_sampler_chain_form_equals_phase_by_phase_form(runs):
         assert np.array_equal(h["flow_chain_acc"], h["flow_steps_acc"])
         assert h["flow_chain_logz"][0] == h["flow_chain_logz"][1]
         assert np.array_equal(h["flow_chain_x"], h["flow_steps_x"])
+
+
+def test_lagged_adaptation_sharded_matches_the_test_double_and_one_rank(runs):
+    """`adapt_lag` (asmc_pcn_params.adapt = k >= 2) on the GPU: (i) the two-rank sampler run with built-in densities
+    (k_pcn_adapt's lagged form behind the exchange hook, one exchange per block of k steps) against the same run on the CPU test
+    double; (ii) the one-kernel flow step of a sharded run (rank counts in cell t % k, the block's replay in the next step's
+    prologue, k_pcn_adapt closing the ragged tail) against ONE rank stepping the whole population with the same lag: the same
+    global accept counts, the same step-size history to the bit, the same rows."""
+    from conftest import random_coupling_flow
+
+    from aspire_amd.engine import HipEngine
+
+    for r in range(2):
+        h, o = runs["hip"][r], runs["oracle"][r]
+        np.testing.assert_allclose(h["lag_beta"], o["lag_beta"], rtol=1e-8)
+        np.testing.assert_allclose(h["lag_rho"], o["lag_rho"], rtol=1e-9)
+        np.testing.assert_allclose(h["lag_acc"], o["lag_acc"], atol=2e-3)
+        assert float(h["lag_logz"]) == pytest.approx(float(o["lag_logz"]), abs=1e-7)
+    eng = HipEngine(0, n_max=8192, d_max=32)
+    dl, nl = 8, 6000
+    fl = random_coupling_flow(dl, 2, 64, seed=9)
+    dev = fl.device_coupling(eng)
+    x = eng.asarray(0.9 * np.random.default_rng(77).normal(size=(nl, dl)))
+    t = eng.make_mixture([0.0], np.zeros((1, dl)), np.ones((1, dl)))
+    ll, lp, lq = eng.mixture_logpdf(x, t), eng.mixture_logpdf(x, t), eng.coupling_logprob(x, dev)
+    eye = eng.asarray(np.eye(dl))
+    acc, hist, rho = eng.pcn_mutate_flow(x, ll, lp, lq, 0.4, eng.asarray(np.zeros(dl)), eye, eye, t, t, dev, 31, 0, 0.6, 8, 3, 0.9, 3, "f64", 0.0)
+    h0, h1 = runs["hip"]
+    for h in (h0, h1):
+        assert np.array_equal(h["lagflow_acc"], np.asarray(acc)) and np.array_equal(h["lagflow_hist"], np.asarray(hist))
+        assert float(h["lagflow_rho"][0]) == rho
+    assert np.array_equal(np.concatenate([h0["lagflow_x"], h1["lagflow_x"]]), x.cpu().numpy())
+    # the history is the lagged schedule: held for blocks of three steps, the block's updates applied in order at its end
+    hist = np.asarray(hist)
+    assert hist[0] == hist[1] == hist[2] == 0.6 and hist[3] == hist[4] == hist[5] != 0.6 and hist[6] == hist[7] != hist[5]

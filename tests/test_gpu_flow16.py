@@ -248,3 +248,42 @@ def test_smc_run_with_a_neural_proposal_above_32_dimensions_stays_on_the_device(
                                     "k_copy_flagged_rows")), name
     z = (float(out.log_evidence) - 0.5 * d * math.log(math.pi)) / float(out.log_evidence_error)
     assert abs(z) < 3.0, z
+
+
+@pytest.mark.parametrize("path", ["builtin_d8", "builtin_d64", "flow_d32", "flow_d64"])
+def test_lagged_adaptation_on_every_device_step_loop(eng, path):
+    """asmc_pcn_params.adapt = k >= 2 (`sampler_kwargs["adapt_lag"]`): the register-resident and matrix-core pCN loops
+    (k_pcn_adapt), the fused flow step's closing block and the flow16 loop hold the step size for blocks of k steps and apply
+    the block's updates at its end, in order, each with its own step's count - the history the library reports is the replay of
+    its own accept counts under that rule, bit for bit against the host formula's value to 1e-12."""
+    from conftest import random_coupling_flow
+
+    from aspire_amd.samplers.smc import pcn_adapt
+
+    d = {"builtin_d8": 8, "builtin_d64": 64, "flow_d32": 32, "flow_d64": 64}[path]
+    n, n_steps, lag, target, rho0 = 20000, 8, 3, 0.9, 0.5
+    g = np.random.default_rng(3)
+    x = eng.asarray(0.9 * g.normal(size=(n, d)))
+    t = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    tq = eng.make_mixture([-0.5 * d * np.log(2 * np.pi * 1.44)], np.zeros((1, d)), np.full((1, d), 1 / 1.44))
+    mu, eye = eng.asarray(np.zeros(d)), eng.asarray(np.eye(d))
+    ll, lp = eng.mixture_logpdf(x, t), eng.mixture_logpdf(x, t)
+    if path.startswith("flow"):
+        flow = random_coupling_flow(d, 2, 64, seed=5)
+        dev = flow.device_coupling(eng)
+        lq = eng.coupling_logprob(x, dev)
+        acc, hist, rho = eng.pcn_mutate_flow(x, ll, lp, lq, 0.4, mu, eye, eye, t, t, dev, 11, 0, rho0, n_steps, 0, target, lag, "f64", 0.0)
+    else:
+        lq = eng.mixture_logpdf(x, tq)
+        acc, hist, rho = eng.pcn_mutate(x, ll, lp, lq, 0.4, mu, eye, eye, t, t, tq, 11, 0, rho0, n_steps, 0, target, lag, "f64", 0.0)
+    acc, hist = np.asarray(acc), np.asarray(hist)
+    r, want, pending = rho0, [], []
+    for s in range(n_steps):
+        want.append(r)
+        pending.append(s)
+        if (s + 1) % lag == 0 or s == n_steps - 1:
+            for sp in pending:
+                r = pcn_adapt(r, acc[sp] / n, target, sp)
+            pending = []
+    np.testing.assert_allclose(hist, want, rtol=1e-12)
+    assert rho == pytest.approx(r, rel=1e-12) and len(set(np.round(hist, 12))) == 3  # three blocks: 3 + 3 + 2 steps
