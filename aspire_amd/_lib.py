@@ -73,6 +73,8 @@ class AsmcCoupling(ctypes.Structure):
         ("loc_dev", c_void_p),
         ("scale_dev", c_void_p),
         ("log_scale_sum", c_double),
+        ("affine", c_int32),  # ASMC_AFFINE_TANH (0) / ASMC_AFFINE_SOFTCLIP (1)
+        ("reserved", c_int32),
     ]
 
 

@@ -262,7 +262,7 @@ template <int H, int W, typename XT, int FLOW_THREADS, bool HS>
 __global__ __launch_bounds__(FLOW_THREADS) void k_maf_logprob(int64_t n, int d, const XT* __restrict__ x,
                                                              const float* __restrict__ packed, int n_layers,
                                                              const float* __restrict__ loc, const float* __restrict__ scale,
-                                                             float ladj0, float base_const, double* __restrict__ out) {
+                                                             float ladj0, float base_const, double* __restrict__ out, int form) {
     extern __shared__ __align__(16) float sp[];
     using FD = FlowDims<H, W>;
     constexpr int FLOW_WAVES = FLOW_THREADS / 64, DL = H / 2;
@@ -293,9 +293,9 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_maf_logprob(int64_t n, int d, 
 #pragma unroll
             for (int i = 0; i < DL; i++) cond[0][i] = xv[0][i];
             if constexpr (HS)
-                coupling_layer_hs<H, W>(cond[0], xv[0], lp, lane, hh, ladj[0], amax);
+                coupling_layer_hs<H, W>(cond[0], xv[0], lp, lane, hh, ladj[0], amax, form);
             else
-                coupling_layer<H, W, 1>(cond, xv, lp, lane, hh, ladj);
+                coupling_layer<H, W, 1>(cond, xv, lp, lane, hh, ladj, form);
         }
         float q = 0.0f;
 #pragma unroll
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_maf_sample(int64_t n, int d, c
                                                             const float* __restrict__ loc, const float* __restrict__ scale,
                                                             float ladj0, float base_const, unsigned long long seed,
                                                             unsigned long long gid0, uint32_t draw_id, XT* __restrict__ x,
-                                                            double* __restrict__ out, int all_passes) {
+                                                            double* __restrict__ out, int all_passes, int form) {
     extern __shared__ __align__(16) float sp[];
     using FD = FlowDims<H, W>;
     constexpr int FLOW_WAVES = FLOW_THREADS / 64, DL = H / 2;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_maf_sample(int64_t n, int d, c
                 for (int i = 0; i < DL; i++) cond[i] = xv[i], tr[i] = zv[i];
                 ladj_pass = 0.0f;
                 float amax_pass = 0.0f;
-                coupling_layer_hs<H, W, true>(cond, tr, lp, lane, hh, ladj_pass, amax_pass);
+                coupling_layer_hs<H, W, true>(cond, tr, lp, lane, hh, ladj_pass, amax_pass, form);
                 bool same = true, nan = false;
 #pragma unroll
                 for (int i = 0; i < DL; i++) {
@@ -615,7 +615,7 @@ static int launch_maf(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_coupling
     const float ladj0 = (float)(-f->log_scale_sum);
     const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
     ASMC_LAUNCH(ctx, st, "k_maf_logprob", kern, dim3(grid), dim3(512), lds, st, n, (int)f->dims, x, f->packed_dev, (int)f->n_layers,
-                f->loc_dev, f->scale_dev, ladj0, base_const, out);
+                f->loc_dev, f->scale_dev, ladj0, base_const, out, (int)f->affine);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
@@ -663,7 +663,7 @@ static int launch_maf_sample(asmc_ctx* ctx, int64_t n, const asmc_coupling* f, u
     const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
     ASMC_LAUNCH(ctx, st, "k_maf_sample", kern, dim3(grid), dim3(512), lds, st, n, (int)f->dims, f->packed_dev, (int)f->n_layers,
                 f->loc_dev, f->scale_dev, ladj0, base_const, seed, gid0, draw_id, x, out,
-                getenv("ASMC_MAF_SAMPLE_ALL_PASSES") ? 1 : 0);  // (diagnostic: the d-pass loop without the fixed-point exit)
+                getenv("ASMC_MAF_SAMPLE_ALL_PASSES") ? 1 : 0, (int)f->affine);  // (all_passes: diagnostic, the d-pass loop without the fixed-point exit)
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
@@ -675,6 +675,7 @@ extern "C" int asmc_coupling_logprob(asmc_ctx* ctx, int64_t n, int x_dtype, cons
     ASMC_REQUIRE(n > 0, "n must be positive");
     ASMC_REQUIRE(flow->packed_dev && flow->loc_dev && flow->scale_dev, "flow parameters missing");
     ASMC_REQUIRE(flow->kind == ASMC_FLOW_COUPLING || flow->kind == ASMC_FLOW_MAF, "bad flow kind");
+    ASMC_REQUIRE(flow->affine == ASMC_AFFINE_TANH || (flow->affine == ASMC_AFFINE_SOFTCLIP && flow->kind == ASMC_FLOW_MAF), "bad affine form (the soft-clipped form is for autoregressive flows)");
     hipStream_t st = (hipStream_t)stream;
     if (asmc_flow_layout(flow->kind, flow->dims, flow->hidden) == 1) {
         ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
@@ -731,6 +732,7 @@ extern "C" int asmc_coupling_sample(asmc_ctx* ctx, int64_t n, int x_dtype, const
     ASMC_REQUIRE(flow->packed_dev && flow->loc_dev && flow->scale_dev, "flow parameters missing");
     ASMC_REQUIRE(x_dtype == ASMC_F64 || x_dtype == ASMC_F32, "bad x_dtype");
     ASMC_REQUIRE(flow->kind == ASMC_FLOW_COUPLING || flow->kind == ASMC_FLOW_MAF, "bad flow kind");
+    ASMC_REQUIRE(flow->affine == ASMC_AFFINE_TANH || (flow->affine == ASMC_AFFINE_SOFTCLIP && flow->kind == ASMC_FLOW_MAF), "bad affine form (the soft-clipped form is for autoregressive flows)");
     if (asmc_flow_layout(flow->kind, flow->dims, flow->hidden) == 1)
         return asmc_flow16_sample(ctx, n, x_dtype, flow, seed, gid0, draw_id, x_out_dev, lq_out_dev, (hipStream_t)stream);
     if (flow->kind == ASMC_FLOW_MAF) {

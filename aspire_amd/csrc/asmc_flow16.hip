@@ -162,7 +162,7 @@ int asmc_flow16_pack(int kind, int dims, int n_layers, int hidden, const float* 
 template <int KIND, int D, int W, typename XT, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_flow16_logprob(int64_t n, int d, const XT* __restrict__ x, const float* __restrict__ packed,
                                                            int n_layers, const float* __restrict__ loc, const float* __restrict__ scale,
-                                                           float ladj0, float base_const, double* __restrict__ out) {
+                                                           float ladj0, float base_const, double* __restrict__ out, int form) {
     using FD = Flow16<KIND, D, W>;
     extern __shared__ __align__(16) float sm[];
     constexpr int WAVES = THREADS / 64, SL = FD::SL;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(THREADS) void k_flow16_logprob(int64_t n, int d, co
             const float xv = (valid && j >= 0) ? (float)x[row * d + j] : 0.0f;
             xf.set(s, j >= 0 ? flow_standardise(xv, s_loc[s * 4 + h], s_loc[D + s * 4 + h], s_loc[2 * D + s * 4 + h]) : 0.0f);
         }
-        const float val = f16_logprob<FD, W, THREADS>(xf, n_layers, s_bias, stream, lane, ladj0, base_const);
+        const float val = f16_logprob<FD, W, THREADS>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, FD::MAF ? form : 0);
         if (valid && h == 0) out[row] = (double)val;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the chunk the last next() put into flight
@@ -219,7 +219,7 @@ static int launch_flow16_logprob(asmc_ctx* ctx, int64_t n, const XT* x, const as
     const float ladj0 = (float)(-f->log_scale_sum);
     const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
     ASMC_LAUNCH(ctx, st, "k_flow16_logprob", kern, dim3(grid), dim3(THREADS), lds, st, n, (int)f->dims, x, f->packed_dev, (int)f->n_layers,
-                f->loc_dev, f->scale_dev, ladj0, base_const, out);
+                f->loc_dev, f->scale_dev, ladj0, base_const, out, (int)f->affine);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_pcn_flow16(int64_t n, T* __restr
                                                        double* __restrict__ lq, const double* __restrict__ blob, int blob_doubles,
                                                        PcnDev p, const double* __restrict__ rho_ptr, uint32_t step,
                                                        const float* __restrict__ packed, int n_layers, float ladj0, float base_const,
-                                                       long long* __restrict__ block_counts, unsigned long long* __restrict__ nonfinite) {
+                                                       long long* __restrict__ block_counts, unsigned long long* __restrict__ nonfinite, int form) {
     using FD = Flow16<KIND, D, W, CW>;
     extern __shared__ __align__(16) double smem[];
     constexpr int KS = D / 4, WAVES = THREADS / 64;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(THREADS, 2) void k_pcn_flow16(int64_t n, T* __restr
         double k_new = c1, k_old = lpo + c0, k_ll = nll, k_lp = nlp, k_lu = logu;
         asm volatile("" : "+v"(k_new), "+v"(k_old), "+v"(k_ll), "+v"(k_lp), "+v"(k_lu));
         __builtin_amdgcn_sched_barrier(0);
-        const double nlq = (double)f16_logprob<FD, W, THREADS>(xf, n_layers, s_bias, stream, lane, ladj0, base_const);
+        const double nlq = (double)f16_logprob<FD, W, THREADS>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, FD::MAF ? form : 0);
         __builtin_amdgcn_sched_barrier(0);
         if (valid && h == 0 && !(fabs(nlq) < INFINITY)) n_bad++;
         const double lpn = log_p_t(k_ll, k_lp, nlq, p.beta);
@@ -555,7 +555,7 @@ static int launch_pcn_flow16_g(asmc_ctx* ctx, int64_t n, T* x, double* ll, doubl
     const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
     ASMC_LAUNCH(ctx, st, TP ? "k_tpcn_flow16" : "k_pcn_flow16", kern, dim3(grid), dim3(THREADS), lds, st, n, x, ll, lp, lq, blob,
                 (int)f16_blob_doubles(D, pd.ll.C, pd.lp.C), pd, rho_ptr, step, f->packed_dev, (int)f->n_layers, ladj0, base_const, block_counts,
-                nonfinite);
+                nonfinite, (int)f->affine);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }
@@ -635,7 +635,7 @@ template <int KIND, int D, int W, typename XT, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_flow16_sample(int64_t n, int d, const float* __restrict__ packed, int n_layers,
                                                           const float* __restrict__ loc, const float* __restrict__ scale, float ladj0,
                                                           float base_const, unsigned long long seed, unsigned long long gid0,
-                                                          uint32_t draw_id, XT* __restrict__ x, double* __restrict__ out, int all_passes) {
+                                                          uint32_t draw_id, XT* __restrict__ x, double* __restrict__ out, int all_passes, int form) {
     using FD = Flow16<KIND, D, W>;
     extern __shared__ __align__(16) float sm[];
     constexpr int WAVES = THREADS / 64, SL = FD::SL, CS = FD::CS;
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(THREADS) void k_flow16_sample(int64_t n, int d, con
                     for (int i = 0; i < CS; i++) tr[i] = z.a[i];
                     ladj_pass = 0.0f;
                     unsigned amax_pk = 0u;
-                    f16_layer<FD, W, THREADS, true>(xv, tr, s_bias + c * FD::BIAS, stream, lane, ladj_pass, amax_pk);
+                    f16_layer<FD, W, THREADS, true>(xv, tr, s_bias + c * FD::BIAS, stream, lane, ladj_pass, amax_pk, form);
                     bool same = true, nan = false;
 #pragma unroll
                     for (int i = 0; i < CS; i++) {
@@ -753,7 +753,7 @@ static int launch_flow16_sample(asmc_ctx* ctx, int64_t n, const asmc_coupling* f
     const float ladj0 = (float)(-f->log_scale_sum);
     const float base_const = (float)(-0.5 * f->dims * 1.8378770664093453);
     ASMC_LAUNCH(ctx, st, "k_flow16_sample", kern, dim3(grid), dim3(THREADS), lds, st, n, (int)f->dims, f->packed_dev, (int)f->n_layers,
-                f->loc_dev, f->scale_dev, ladj0, base_const, seed, gid0, draw_id, x, out, getenv("ASMC_MAF_SAMPLE_ALL_PASSES") ? 1 : 0);
+                f->loc_dev, f->scale_dev, ladj0, base_const, seed, gid0, draw_id, x, out, getenv("ASMC_MAF_SAMPLE_ALL_PASSES") ? 1 : 0, (int)f->affine);
     ASMC_LAUNCH_CHECK();
     return ASMC_OK;
 }

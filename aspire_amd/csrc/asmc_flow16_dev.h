@@ -199,7 +199,7 @@ __device__ __forceinline__ void f16_dense(floatx4 (&acc)[NBC], const half8 (&bh)
 // INVERSE: the sampling direction x_b = z_b exp(s) + t.
 template <class FD, int W, int THREADS, bool INVERSE = false>
 __device__ __forceinline__ void f16_layer(const float (&cond)[FD::CS], float (&trans)[FD::CS], const float* __restrict__ bias,
-                                          Flow16Stream<FD, THREADS>& stream, int lane, float& ladj, unsigned& amax_pk) {
+                                          Flow16Stream<FD, THREADS>& stream, int lane, float& ladj, unsigned& amax_pk, int form = 0) {
     constexpr int KS1 = FD::KS1, KS2 = FD::KS2, NB1 = FD::NB1;
     // ---- first dense layer: conditioner slots -> hidden 1
     half8 bh1[KS1], bl1[KS1];
@@ -258,15 +258,7 @@ __device__ __forceinline__ void f16_layer(const float (&cond)[FD::CS], float (&t
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const float sraw = o[0][r], tt = o[1][r];
-                const float sv = 2.0f - 4.0f * __builtin_amdgcn_rcpf(__expf(sraw) + 1.0f);  // 2 tanh(sraw / 2)
-                float& xt = trans[4 * m + r];
-                if (INVERSE) {
-                    const float mm = xt * __expf(sv);
-                    xt = mm + tt;
-                } else {
-                    xt = (xt - tt) * __expf(-sv);
-                }
-                ladj -= sv;
+                flow_affine<INVERSE>(trans[4 * m + r], sraw, tt, ladj, form);  // (asmc_flow_dev.h: form 0 = 2 tanh(sraw / 2); 1 = zuko's soft clip)
             }
         }
     }
@@ -300,19 +292,19 @@ __device__ __forceinline__ float f16_quad_max(float q) {
 // log q of the group's particles from the lane's standardised coordinates (every lane of a particle returns it)
 template <class FD, int W, int THREADS>
 __device__ __forceinline__ float f16_logprob(F16State<FD>& x, int n_layers, const float* __restrict__ biases,
-                                             Flow16Stream<FD, THREADS>& stream, int lane, float ladj0, float base_const) {
+                                             Flow16Stream<FD, THREADS>& stream, int lane, float ladj0, float base_const, int form = 0) {
     float ladj = 0.0f;
     unsigned amax_pk = 0u;
     for (int c = 0; c < n_layers; c += 2) {  // (n_layers is uniform over the block: every wave meets the same barriers)
         if constexpr (FD::MAF) {
-            f16_layer<FD, W, THREADS>(x.a, x.a, biases + c * FD::BIAS, stream, lane, ladj, amax_pk);
+            f16_layer<FD, W, THREADS>(x.a, x.a, biases + c * FD::BIAS, stream, lane, ladj, amax_pk, form);
         } else {
             f16_layer<FD, W, THREADS>(x.a, x.b, biases + c * FD::BIAS, stream, lane, ladj, amax_pk);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < n_layers) {
             if constexpr (FD::MAF) {
-                f16_layer<FD, W, THREADS>(x.a, x.a, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk);
+                f16_layer<FD, W, THREADS>(x.a, x.a, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk, form);
             } else {
                 f16_layer<FD, W, THREADS>(x.b, x.a, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk);
             }

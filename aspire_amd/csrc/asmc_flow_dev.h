@@ -16,6 +16,35 @@ __device__ __forceinline__ float flow_standardise(float x, float loc, float scal
     return fmaf(r, rcp, q0);
 }
 
+// (s_raw, t) of a transformed coordinate -> the coordinate and the log-determinant.
+// form 0 - this repository's flows: s = 2 tanh(s_raw / 2) (= 2 - 4 / (exp(s_raw) + 1)), z = (x - t) exp(-s), ladj -= s;
+// form 1 - ASMC_AFFINE_SOFTCLIP, zuko's MonotonicAffineTransform with slope 1e-3 (flows/torch/flows.py:156-168 builds zuko
+//   flows; zuko is absent from the build image, so this follows its documented arithmetic and is UNVERIFIED against it):
+//   ls = s_raw / (1 + |s_raw| / ln(1000)), z = x exp(ls) + t, ladj += ls.
+// INVERSE: the sampling direction.  ladj collects the log-determinant of x -> z in both directions.
+template <bool INVERSE>
+__device__ __forceinline__ void flow_affine(float& x, float sraw, float t, float& ladj, int form) {
+    if (form == 0) {
+        const float sv = 2.0f - 4.0f * __builtin_amdgcn_rcpf(__expf(sraw) + 1.0f);
+        if (INVERSE) {
+            const float m = x * __expf(sv);
+            x = m + t;
+        } else {
+            x = (x - t) * __expf(-sv);
+        }
+        ladj -= sv;
+    } else {
+        const float ls = sraw * __builtin_amdgcn_rcpf(1.0f + __builtin_fabsf(sraw) * 0.14476482730108395f);  // 1 / ln(1000)
+        if (INVERSE) {
+            x = (x - t) * __expf(-ls);
+        } else {
+            const float m = x * __expf(ls);
+            x = m + t;
+        }
+        ladj += ls;
+    }
+}
+
 template <int H, int W>
 struct FlowDims {
     static constexpr int NB1 = W / 32;  // accumulator blocks of a hidden layer
@@ -107,7 +136,7 @@ __device__ __forceinline__ void dense_from_acc(floatx16 (&out)[TPW][NBO], const 
 
 template <int H, int W, int TPW>
 __device__ __forceinline__ void coupling_layer(const float (&cond)[TPW][H / 2], float (&trans)[TPW][H / 2],
-                                               const float* __restrict__ lp, int lane, int hh, float (&ladj)[TPW]) {
+                                               const float* __restrict__ lp, int lane, int hh, float (&ladj)[TPW], int form = 0) {
     using FD = FlowDims<H, W>;
     const float* b1 = lp;
     const float* b2 = b1 + FD::NB1 * 32;
@@ -154,9 +183,7 @@ __device__ __forceinline__ void coupling_layer(const float (&cond)[TPW][H / 2], 
             // s = 2 tanh(sraw / 2) = 2 - 4 / (exp(sraw) + 1) on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32): absolute error
             // ~1e-7, which is all that matters (s is added to the log-determinant and exponentiated); libm's
             // tanhf + expf would cost as many issue cycles per layer as a third of its MFMAs
-            const float s = 2.0f - 4.0f * __builtin_amdgcn_rcpf(__expf(sraw) + 1.0f);
-            trans[tt][q] = (trans[tt][q] - t) * __expf(-s);
-            ladj[tt] -= s;
+            flow_affine<false>(trans[tt][q], sraw, t, ladj[tt], form);
         }
 }
 
@@ -277,7 +304,7 @@ __device__ __forceinline__ void acc_bias1(floatx16 (&acc)[NB], const float* __re
 // that base(z) + ladj is log q of the sample as well
 template <int H, int W, bool INVERSE = false>
 __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], float (&trans)[H / 2], const float* __restrict__ lp,
-                                                  int lane, int hh, float& ladj, float& amax) {
+                                                  int lane, int hh, float& ladj, float& amax, int form = 0) {
     using FD = FlowDims<H, W>;
     const float* b1 = lp;
     const float* b2 = b1 + FD::NB1 * 32;
@@ -325,14 +352,7 @@ __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], fl
     for (int q = 0; q < H / 2; q++) {
         const float sraw = o[q / 16][q % 16];
         const float t = o[(H / 2 + q) / 16][(H / 2 + q) % 16];
-        const float s = 2.0f - 4.0f * __builtin_amdgcn_rcpf(__expf(sraw) + 1.0f);  // 2 tanh(sraw / 2), see coupling_layer
-        if (INVERSE) {
-            const float m = trans[q] * __expf(s);
-            trans[q] = m + t;
-        } else {
-            trans[q] = (trans[q] - t) * __expf(-s);
-        }
-        ladj -= s;
+        flow_affine<INVERSE>(trans[q], sraw, t, ladj, form);  // (form 0: s = 2 tanh(sraw / 2), see coupling_layer)
     }
 }
 
@@ -524,7 +544,7 @@ __device__ __forceinline__ void coupling_layer_hs2(const float (&condA)[H / 2], 
 // Same operations in the same order per accumulator as coupling_layer_hs / _hs2: bit-identical results.
 template <int H, int W, bool PREFETCH = true>
 __device__ __forceinline__ void coupling_layer_hs1p(const float (&cond)[H / 2], float (&trans)[H / 2], const float* __restrict__ lp,
-                                                    int lane, int hh, float& ladj, unsigned& amax) {
+                                                    int lane, int hh, float& ladj, unsigned& amax, int form = 0) {
     using FD = FlowDims<H, W>;
     constexpr int NB1 = FD::NB1, NB3 = FD::NB3, ST1 = H / 16, ST2 = 2 * NB1, G = ST1 + 2 * ST2;
     constexpr int NBM = NB1 > NB3 ? NB1 : NB3;
@@ -619,9 +639,7 @@ __device__ __forceinline__ void coupling_layer_hs1p(const float (&cond)[H / 2], 
     for (int q = 0; q < H / 2; q++) {
         const float sraw = o[q / 16][q % 16];
         const float t = o[(H / 2 + q) / 16][(H / 2 + q) % 16];
-        const float sv = 2.0f - 4.0f * __builtin_amdgcn_rcpf(__expf(sraw) + 1.0f);  // 2 tanh(sraw / 2), see coupling_layer
-        trans[q] = (trans[q] - t) * __expf(-sv);
-        ladj -= sv;
+        flow_affine<false>(trans[q], sraw, t, ladj, form);  // (form 0: 2 tanh(sraw / 2), see coupling_layer)
     }
 }
 

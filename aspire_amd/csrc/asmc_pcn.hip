@@ -3387,6 +3387,8 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
                          int n_steps, uint32_t step0, double* rho_inout_host, int64_t* n_accept_host,
                          double* rho_hist_host, asmc_stream stream) {
     ASMC_REQUIRE(ctx && x && prm && flow, "null pointer");
+    ASMC_REQUIRE(flow->affine == ASMC_AFFINE_TANH || (flow->affine == ASMC_AFFINE_SOFTCLIP && flow->kind == ASMC_FLOW_MAF),
+                 "bad affine form (the soft-clipped form is for autoregressive flows)");
     // Fewer than 32 dimensions: the one-kernel step on a zero-padded copy (pcn_mutate_padded's scheme: padded rows and tables,
     // the identity beyond d, no noise there) wherever the flow's shape is one the kernel takes - any even d for a coupling flow,
     // any d for an autoregressive one.  Round 3 ran propose / flow / accept kernels at d = 8 / 16 (0.35 / 0.42 ms per step

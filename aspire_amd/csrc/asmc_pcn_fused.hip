@@ -115,7 +115,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
     int64_t n, double* __restrict__ ll, double* __restrict__ lp, double* __restrict__ lq, const double* __restrict__ ptab,
     PcnScalars p, const double* rho_ptr, uint32_t step, const float* __restrict__ packed, int n_layers,
     const float* __restrict__ loc, const float* __restrict__ scale, float ladj0, float base_const,
-    unsigned int* __restrict__ tile_counter, long long* __restrict__ block_counts, PcnAdaptArgs ad, int par_words) {
+    unsigned int* __restrict__ tile_counter, long long* __restrict__ block_counts, PcnAdaptArgs ad, int par_words, int affine) {
     constexpr int D = 32, H = 16, THREADS = FUSED_THREADS;
     constexpr int HF = KIND == ASMC_FLOW_MAF ? 32 : H;  // H of the flow's layer templates (lane halves hold HF / 2 inputs)
     static_assert(KIND == ASMC_FLOW_COUPLING || HS, "the autoregressive variant runs the split-fp16 layers only");
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
                     float cond[16];
 #pragma unroll
                     for (int r = 0; r < 16; r++) cond[r] = xv[r];
-                    coupling_layer_hs1p<HF, W, false>(cond, xv, sp + (size_t)c * FD::LAYER, lane, hh, ladj, amax_pk);
+                    coupling_layer_hs1p<HF, W, false>(cond, xv, sp + (size_t)c * FD::LAYER, lane, hh, ladj, amax_pk, affine);  // (affine: asmc_coupling.affine, autoregressive flows)
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 float amax = range_pk_max(amax_pk);
@@ -1016,7 +1016,7 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
         }                                                                                                                \
         ASMC_LAUNCH(ctx, st, "k_pcn_flow_fused", kern, dim3(grid), dim3(FUSED_THREADS), lds, st, n, ll, lp, lq,                     \
                     (const double*)ctx->d_ptab, ps, rho_ptr, step, f->packed_dev, (int)f->n_layers, f->loc_dev, f->scale_dev, \
-                    ladj0, base_const, tile_counter, block_counts, adapt, par_words);                                          \
+                    ladj0, base_const, tile_counter, block_counts, adapt, par_words, KD == ASMC_FLOW_MAF ? (int)f->affine : 0);  \
         ASMC_LAUNCH_CHECK();                                                                                             \
         return ASMC_OK;                                                                                                  \
     }

@@ -66,10 +66,11 @@ class DeviceCoupling:
     scale: torch.Tensor  # fp32 [dims]
     log_scale_sum: float
     kind: int = 0  # ASMC_FLOW_COUPLING (0) / ASMC_FLOW_MAF (1)
+    affine: int = 0  # ASMC_AFFINE_TANH (0) / ASMC_AFFINE_SOFTCLIP (1: zuko's monotonic affine form, autoregressive flows only)
 
     def c_struct(self) -> AsmcCoupling:
         return AsmcCoupling(self.dims, self.n_layers, self.hidden, self.kind, self.packed.data_ptr(), self.loc.data_ptr(),
-                            self.scale.data_ptr(), self.log_scale_sum)
+                            self.scale.data_ptr(), self.log_scale_sum, self.affine, 0)
 
 
 @dataclass
@@ -660,14 +661,14 @@ class HipEngine:
                               self.asarray(np.asarray(loc, dtype=np.float32), dtype=torch.float32),
                               self.asarray(scale, dtype=torch.float32), float(np.log(scale.astype(np.float64)).sum()))
 
-    def make_maf(self, dims: int, hidden: int, weights, biases, loc, scale) -> DeviceCoupling:
+    def make_maf(self, dims: int, hidden: int, weights, biases, loc, scale, affine: int = 0) -> DeviceCoupling:
         """A masked autoregressive flow on the device (include/asmc.h ASMC_FLOW_MAF): `weights` are the MASKED matrices."""
         packed = pack_maf(self.lib, dims, hidden, weights, biases)
         scale = np.asarray(scale, dtype=np.float32)
         return DeviceCoupling(dims, len(weights) // 3, hidden, self.asarray(packed, dtype=torch.float32),
                               self.asarray(np.asarray(loc, dtype=np.float32), dtype=torch.float32),
                               self.asarray(scale, dtype=torch.float32), float(np.log(scale.astype(np.float64)).sum()),
-                              kind=_lib.ASMC_FLOW_MAF)
+                              kind=_lib.ASMC_FLOW_MAF, affine=int(affine))
 
     def coupling_logprob(self, x: torch.Tensor, flow: DeviceCoupling) -> torch.Tensor:
         assert x.is_contiguous() and x.dim() == 2 and x.shape[1] == flow.dims

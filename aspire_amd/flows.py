@@ -538,6 +538,9 @@ class CouplingFlow(Flow):
         return self._from_latent(torch.as_tensor(z, dtype=self.dtype, device=self.device))
 
 
+_LN_1000 = 6.907755278982137  # -ln(slope) of zuko's MonotonicAffineTransform, slope = 1e-3
+
+
 class _MaskedLinear(torch.nn.Linear):
     """Linear layer whose weight is multiplied by a fixed 0/1 mask (MADE, Germain et al. 2015)."""
 
@@ -554,8 +557,9 @@ class _Autoregressive(torch.nn.Module):
     (`order[k]` = position of variable k; reversed on every other layer).  data -> latent is one pass of the masked MLP,
     latent -> data one pass per variable."""
 
-    def __init__(self, dims, hidden, reverse):
+    def __init__(self, dims, hidden, reverse, affine="tanh"):
         super().__init__()
+        self.affine = affine
         deg_in = torch.arange(1, dims + 1)
         if reverse:
             deg_in = deg_in.flip(0)
@@ -575,6 +579,12 @@ class _Autoregressive(torch.nn.Module):
 
     def _st(self, x):
         h = self.net(x)
+        if self.affine == "zuko":
+            # zuko's MonotonicAffineTransform (slope 1e-3): z = x exp(ls) + shift with the soft-clipped log-scale
+            # ls = raw / (1 + |raw| / ln 1000)  -  written in this module's convention z = (x - t) exp(-s): s = -ls, t = -shift exp(s)
+            raw, shift = h[:, : self.dims], h[:, self.dims:]
+            s = -raw / (1.0 + raw.abs() / _LN_1000)
+            return s, -shift * torch.exp(s)
         return 2.0 * torch.tanh(h[:, : self.dims] / 2.0), h[:, self.dims:]  # bounded log-scale, as the coupling layers
 
     def forward(self, x):  # data -> latent
@@ -600,16 +610,20 @@ class MAFFlow(CouplingFlow):
     inside the mutation loop."""
 
     def __init__(self, dims: int, n_transforms: int = 3, hidden_features=(64, 64), seed: int = 1234, device=None,
-                 dtype=torch.float32, data_transform=None):
+                 dtype=torch.float32, data_transform=None, affine: str = "tanh"):
         Flow.__init__(self, dims, device=torch.device(device or "cpu"), data_transform=data_transform)
         self.dtype = dtype
         self._seed, self._rng_snapshot = int(seed), None
+        if affine not in ("tanh", "zuko"):
+            raise ValueError(f"affine must be 'tanh' or 'zuko', got {affine!r}")
+        self.affine = affine
         hidden = tuple(map(int, hidden_features))
         prev = torch.get_default_dtype()
         torch.set_default_dtype(dtype)
         try:
             with self._private_rng():
-                self.layers = torch.nn.ModuleList([_Autoregressive(dims, hidden, reverse=bool(i % 2)) for i in range(n_transforms)])
+                self.layers = torch.nn.ModuleList([_Autoregressive(dims, hidden, reverse=bool(i % 2), affine=affine)
+                                                   for i in range(n_transforms)])
         finally:
             torch.set_default_dtype(prev)
         self.layers.to(device=self.device, dtype=dtype)
@@ -619,7 +633,69 @@ class MAFFlow(CouplingFlow):
         self._gen.manual_seed(seed)
         self._packed, self._version = None, 0
         self._init_args = dict(dims=int(dims), n_transforms=int(n_transforms), hidden_features=[int(h) for h in hidden],
-                               seed=int(seed), dtype=str(dtype).replace("torch.", ""))
+                               seed=int(seed), dtype=str(dtype).replace("torch.", ""), affine=str(affine))
+
+    @classmethod
+    def from_zuko_state_dict(cls, state_dict, device=None, dtype=torch.float32):
+        """A flow the REFERENCE trained - `zuko.flows.MAF(features, 0, transforms=T, hidden_features=(h1, h2))`, what
+        `ZukoFlow(flow_class="MAF")` builds (`/root/reference/src/aspire/flows/torch/flows.py:156-168`) and `BaseTorchFlow.save`
+        stores entry by entry (`flows.py:63-87`: `flow/weights/<state-dict key>`) - as an `MAFFlow` that runs on the HIP kernels.
+
+        **UNVERIFIED**: zuko is not installed in the build image and no file of it is in the reference tree, so this follows zuko's
+        documented module layout and arithmetic (v1.x) and could only be tested against a restatement of that documentation
+        (`tests/test_host_logic.py::test_zuko_state_dict_adapter_...`), never against the package:
+        * keys `transform.transforms.<i>.hyper.<2 k>.{weight, bias, mask}`, k = 0, 1, 2 (a `MaskedMLP`: `MaskedLinear`s at the
+          even positions of a Sequential, ReLU between them), `F.linear(x, mask * weight, bias)`; the buffer
+          `transform.transforms.<i>.order` and the base distribution's buffers are not needed (the variable order lives in the masks);
+        * the last layer emits, per feature i, `(shift_i, scale_i)` in rows `2 i`, `2 i + 1`
+          (`phi.unflatten(-1, (-1, 2))`); `MonotonicAffineTransform(shift, scale, slope=1e-3)` maps
+          `z = x * exp(scale / (1 + |scale / log(slope)|)) + shift` with that exponent as the log-determinant.
+        The rows are regrouped to this class's `[scale_0 .. scale_{d-1} | shift_0 .. shift_{d-1}]` and the transforms evaluate the
+        soft-clipped form (`affine="zuko"`; device side `asmc_coupling.affine = ASMC_AFFINE_SOFTCLIP`).  The reference's flows carry
+        no standardisation of their own (`loc = 0`, `scale = 1`); a data transform, if any, stays with the caller."""
+        import re
+
+        pat = re.compile(r"(?:^|\.)transforms\.(\d+)\.hyper\.(\d+)\.(weight|bias|mask)$")
+        found: dict = {}
+        for key, value in state_dict.items():
+            m = pat.search(key)
+            if m:
+                found.setdefault(int(m.group(1)), {}).setdefault(int(m.group(2)), {})[m.group(3)] = torch.as_tensor(np.asarray(value) if not isinstance(value, torch.Tensor) else value)
+        if not found:
+            raise ValueError("no `transforms.<i>.hyper.<k>.{weight,bias,mask}` entries: not a zuko MAF state dict")
+        n_tr = max(found) + 1
+        lin0 = [found[0][k] for k in sorted(found[0])]
+        if len(lin0) != 3:
+            raise ValueError(f"expected two hidden layers (three masked linear layers per transform), found {len(lin0)}")
+        dims = int(lin0[0]["weight"].shape[1])
+        hidden = (int(lin0[0]["weight"].shape[0]), int(lin0[1]["weight"].shape[0]))
+        if tuple(lin0[2]["weight"].shape) != (2 * dims, hidden[1]):
+            raise ValueError("the last layer must emit (shift, scale) per feature; flows with a context are not supported")
+        flow = cls(dims, n_transforms=n_tr, hidden_features=hidden, device=device, dtype=dtype, affine="zuko")
+        regroup = torch.cat([torch.arange(1, 2 * dims, 2), torch.arange(0, 2 * dims, 2)])  # [scale rows | shift rows]
+        with torch.no_grad():
+            for i in range(n_tr):
+                if i not in found or len(found[i]) != 3:
+                    raise ValueError(f"transform {i} is incomplete")
+                ours = [m for m in flow.layers[i].net if isinstance(m, _MaskedLinear)]
+                for j, (k, m) in enumerate(zip(sorted(found[i]), ours)):
+                    w, b, mask = found[i][k]["weight"], found[i][k]["bias"], found[i][k].get("mask")
+                    if mask is None:
+                        mask = torch.ones_like(w)
+                    if j == 2:
+                        w, b, mask = w[regroup], b[regroup], mask[regroup]
+                    if tuple(w.shape) != tuple(m.weight.shape):
+                        raise ValueError(f"transform {i}, layer {j}: shape {tuple(w.shape)}, expected {tuple(m.weight.shape)}")
+                    m.weight.copy_(w.to(m.weight))
+                    m.bias.copy_(b.to(m.bias))
+                    m.mask.copy_(mask.to(m.mask))
+                # the variable order of `inverse` (which coordinate is final after how many passes): degree of input k = 1 + the
+                # number of inputs its shift / scale may depend on (read off the composed masks)
+                dep = ((ours[2].mask[:dims] != 0).double() @ (ours[1].mask != 0).double() @ (ours[0].mask != 0).double()) > 0
+                flow.layers[i].order.copy_((dep.sum(1) + 1).to(flow.layers[i].order))
+        flow.layers.eval()
+        flow._version += 1
+        return flow
 
     def export_layers(self):
         """(weights, biases): the MASKED fp32 matrices (weight * mask) of the three dense layers of every transform, torch
@@ -637,7 +713,7 @@ class MAFFlow(CouplingFlow):
 
     def device_coupling(self, engine):
         """Pack the flow for the HIP kernels (asmc_coupling_logprob / _sample / asmc_pcn_mutate_flow with kind = ASMC_FLOW_MAF).
-        float32 flows of dims <= 32 with two equal hidden widths in {32, 64, 128}; raises otherwise so that callers fall back
+        float32 flows of dims <= 128 with two equal hidden widths in {32, 64, 128}; raises otherwise so that callers fall back
         to the torch modules knowingly."""
         if self.dtype != torch.float32:
             raise ValueError("device_coupling needs a float32 flow")
@@ -650,5 +726,5 @@ class MAFFlow(CouplingFlow):
             if ws[1].shape != (hidden, hidden):
                 raise ValueError("the HIP autoregressive kernel needs equal hidden widths")
             self._packed = (key, engine.make_maf(self.dims, hidden, ws, bs, self.loc.detach().cpu().numpy(),
-                                                 self.scale.detach().cpu().numpy()))
+                                                 self.scale.detach().cpu().numpy(), affine=1 if self.affine == "zuko" else 0))
         return self._packed[1]

@@ -606,7 +606,16 @@ typedef struct asmc_coupling {
     const float* loc_dev;    /* [dims] */
     const float* scale_dev;  /* [dims] */
     double log_scale_sum;    /* sum_j log(scale_j) */
+    int32_t affine;          /* how (s_raw, t) act on a coordinate: 0 = this repository's flows, s = 2 tanh(s_raw / 2),
+                                z = (x - t) exp(-s);  ASMC_AFFINE_SOFTCLIP = zuko's MonotonicAffineTransform (slope 1e-3):
+                                ls = s_raw / (1 + |s_raw| / ln 1000), z = x exp(ls) + t - for flows trained by the reference
+                                (flows/torch/flows.py:156-168; aspire_amd.flows.MAFFlow.from_zuko_state_dict).  zuko is absent
+                                from the build image: that form follows its documented arithmetic and is UNVERIFIED against it.
+                                Autoregressive flows only. */
+    int32_t reserved;
 } asmc_coupling;
+#define ASMC_AFFINE_TANH 0
+#define ASMC_AFFINE_SOFTCLIP 1
 /* Packed layout of a flow of this shape: 0 = 32-particle tiles with every layer resident in LDS (dims <= 32), 1 = 16-particle
  * groups with the weights streamed through LDS (32 < dims <= 128: csrc/asmc_flow16.hip; coupling flows need even dims), < 0 =
  * no kernel.  The pack functions below choose it from the shape; every entry point that takes an asmc_coupling follows. */

@@ -89,6 +89,7 @@ def lib():
             "orc_is_iteration": (ci, [i64, ci, vp, vp, vp, vp, d, d, d, vp, vp, vp, vp, vp, vp]),
             "orc_coupling_logprob": (ci, [i64, ci, vp, ci, ci, vp, vp, vp, vp, vp]),
             "orc_maf_logprob": (ci, [i64, ci, vp, ci, ci, vp, vp, vp, vp, vp]),
+            "orc_maf_logprob_form": (ci, [i64, ci, vp, ci, ci, vp, vp, vp, vp, ci, vp]),
             "orc_transform": (ci, [i64, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, d, ci]),
             "orc_pcn_flow_step": (
                 i64,
@@ -443,8 +444,9 @@ def coupling_logprob(x, weights, biases, loc, scale):
     return out
 
 
-def maf_logprob(x, weights, biases, loc, scale):
-    """fp32 log-density of the masked autoregressive flow; weights: the MASKED matrices, 3 per transform, torch Linear layout."""
+def maf_logprob(x, weights, biases, loc, scale, affine=0):
+    """fp32 log-density of the masked autoregressive flow; weights: the MASKED matrices, 3 per transform, torch Linear layout.
+    affine = 1: zuko's soft-clipped monotonic affine form (orc_maf_logprob_form)."""
     x = _f64(np.atleast_2d(x))
     n, d = x.shape
     ws = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
@@ -455,7 +457,7 @@ def maf_logprob(x, weights, biases, loc, scale):
     wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
     bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
     out = np.empty(n)
-    st = lib().orc_maf_logprob(n, d, _p(x), len(ws) // 3, hidden, wp, bp, loc.ctypes.data, scale.ctypes.data, _p(out))
+    st = lib().orc_maf_logprob_form(n, d, _p(x), len(ws) // 3, hidden, wp, bp, loc.ctypes.data, scale.ctypes.data, int(affine), _p(out))
     if st != 0:
         raise ValueError(f"orc_maf_logprob failed ({st})")
     return out
@@ -498,7 +500,7 @@ def pcn_flow_step(x, ll, lp, lq, beta, mu, L, Linv, rho, t_ll, t_lp, weights, bi
     return lib().orc_pcn_flow_step_kind(n, d, _p(x), _p(ll), _p(lp), _p(lq), beta, _p(mu), _p(L), _p(Linv), rho,
                                         ctypes.addressof(a), ctypes.addressof(b), len(ws) // 3, ws[0].shape[0], wp, bp,
                                         loc.ctypes.data, scale.ctypes.data, seed, gid0, step, int(noise == "f32"), int(n_threads),
-                                        int(flow_kind == "maf"))
+                                        {"coupling": 0, "maf": 1, "maf_softclip": 2}[flow_kind])
 
 
 def tpcn_flow_step(x, ll, lp, lq, beta, mu, L, Linv, rho, nu, t_ll, t_lp, weights, biases, loc, scale, seed, gid0, step,
@@ -519,7 +521,7 @@ def tpcn_flow_step(x, ll, lp, lq, beta, mu, L, Linv, rho, nu, t_ll, t_lp, weight
     r = lib().orc_tpcn_flow_step_kind(n, d, _p(x), _p(ll), _p(lp), _p(lq), beta, _p(mu), _p(L), _p(Linv), rho, float(nu),
                                       ctypes.addressof(a), ctypes.addressof(b), len(ws) // 3, ws[0].shape[0], wp, bp,
                                       loc.ctypes.data, scale.ctypes.data, seed, gid0, step, int(noise == "f32"), int(n_threads),
-                                      int(flow_kind == "maf"))
+                                      {"coupling": 0, "maf": 1, "maf_softclip": 2}[flow_kind])
     if r < 0:
         raise ValueError(f"orc_tpcn_flow_step_kind failed ({r})")
     return r

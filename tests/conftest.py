@@ -94,6 +94,57 @@ def random_maf_flow(d, n_transforms=3, hidden=64, seed=3):
     return flow
 
 
+def zuko_like_state_dict(d, hidden=(64, 64), n_transforms=3, seed=0, scale=0.7):
+    """A state dict with the key layout and semantics zuko DOCUMENTS for `zuko.flows.MAF(d, 0, transforms=T,
+    hidden_features=hidden)` (zuko itself is absent: see MAFFlow.from_zuko_state_dict): per transform a MaskedMLP
+    `hyper.{0,2,4}.{weight,bias,mask}` whose last layer emits (shift_i, scale_i) in rows 2 i, 2 i + 1; orders alternate between
+    ascending and descending.  Masks are valid MADE masks built from degrees; weights random."""
+    g = np.random.default_rng(seed)
+    sd = {}
+    for i in range(n_transforms):
+        order = np.arange(d) if i % 2 == 0 else np.arange(d)[::-1].copy()
+        deg = [order]
+        for h in hidden:
+            deg.append(g.integers(0, max(d - 1, 1), size=h))
+        mats = []
+        for k, h in enumerate(hidden):
+            mats.append((deg[k + 1][:, None] >= deg[k][None, :]).astype(np.float32))
+        out_order = np.repeat(order, 2)
+        mats.append((out_order[:, None] > deg[-1][None, :]).astype(np.float32))
+        for k, m in enumerate(mats):
+            fan = max(1.0, m.sum(1).mean())
+            sd[f"transform.transforms.{i}.hyper.{2 * k}.weight"] = (scale * g.normal(size=m.shape) / np.sqrt(fan)).astype(np.float32)
+            sd[f"transform.transforms.{i}.hyper.{2 * k}.bias"] = (0.1 * g.normal(size=m.shape[0])).astype(np.float32)
+            sd[f"transform.transforms.{i}.hyper.{2 * k}.mask"] = m
+        sd[f"transform.transforms.{i}.order"] = order.astype(np.int64)
+    sd["base._0"] = np.zeros(d, dtype=np.float32)
+    sd["base._1"] = np.ones(d, dtype=np.float32)
+    return sd
+
+
+def zuko_documented_log_prob(sd, x):
+    """log p(x) of the flow `zuko_like_state_dict` describes, from zuko's documented arithmetic, in numpy fp64: MaskedLinear =
+    F.linear(x, mask * weight, bias); ReLU between; phi.unflatten(-1, (-1, 2)) -> (shift, scale);
+    MonotonicAffineTransform(shift, scale, slope=1e-3): y = x exp(scale / (1 + |scale / log(slope)|)) + shift; DiagNormal(0, 1) base."""
+    x = np.asarray(x, dtype=np.float64)
+    n, d = x.shape
+    n_tr = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("transform.transforms.") and ".hyper." in k)
+    z, ladj = x.copy(), np.zeros(n)
+    for i in range(n_tr):
+        h = z
+        for k in (0, 2, 4):
+            w = sd[f"transform.transforms.{i}.hyper.{k}.weight"].astype(np.float64) * sd[f"transform.transforms.{i}.hyper.{k}.mask"]
+            h = h @ w.T + sd[f"transform.transforms.{i}.hyper.{k}.bias"].astype(np.float64)
+            if k < 4:
+                h = np.maximum(h, 0.0)
+        phi = h.reshape(n, d, 2)
+        shift, raw = phi[..., 0], phi[..., 1]
+        ls = raw / (1.0 + np.abs(raw / np.log(1e-3)))
+        z = z * np.exp(ls) + shift
+        ladj += ls.sum(1)
+    return -0.5 * (z**2).sum(1) - 0.5 * d * np.log(2 * np.pi) + ladj
+
+
 def flow_log_prob_f64(flow, x):
     """log q(x) of a CouplingFlow evaluated in fp64 by the torch modules on the CPU: the SAME fp32 parameters, widened
     (the judge of the flow kernels' arithmetic: the north star's bar is 1e-6 relative on log-weights)."""

@@ -287,3 +287,74 @@ def test_lagged_adaptation_on_every_device_step_loop(eng, path):
             pending = []
     np.testing.assert_allclose(hist, want, rtol=1e-12)
     assert rho == pytest.approx(r, rel=1e-12) and len(set(np.round(hist, 12))) == 3  # three blocks: 3 + 3 + 2 steps
+
+
+@pytest.mark.parametrize("d,hidden,n", [(8, 32, 3000), (32, 64, 20000), (48, 64, 4000), (64, 64, 9000), (128, 64, 3000)])
+def test_zuko_form_autoregressive_flow_on_the_kernels(eng, oracle, d, hidden, n):
+    """A flow in zuko's affine form (`asmc_coupling.affine = ASMC_AFFINE_SOFTCLIP`; `MAFFlow.from_zuko_state_dict`: what the
+    reference's `Aspire.fit` trains, flows/torch/flows.py:156-168 - zuko absent, its documented arithmetic, UNVERIFIED against the
+    package) through every kernel family that takes an autoregressive flow: density (d <= 32: k_maf_logprob; above:
+    k_flow16_logprob) against the same parameters in fp64 (<= 1e-6 relative) and against the oracle's fp32 restatement; the
+    draw (density of the returned rows; the early exit returns the d-pass bits); the one-kernel mutation step, pCN and tpCN,
+    against `orc_(t)pcn_flow_step_kind` with the soft-clipped form."""
+    from conftest import zuko_like_state_dict
+
+    from aspire_amd.flows import MAFFlow
+
+    flow = MAFFlow.from_zuko_state_dict(zuko_like_state_dict(d, (hidden, hidden), 3, seed=d + 1, scale=0.5))
+    dev = flow.device_coupling(eng)
+    assert dev.affine == 1 and dev.kind == 1
+    ws, bs = flow.export_layers()
+    g = np.random.default_rng(3)
+    x = 1.1 * g.normal(size=(n, d))
+    xd = eng.asarray(x)
+    got = eng.coupling_logprob(xd, dev).cpu().numpy()
+    want = oracle.maf_logprob(x, ws, bs, flow.loc.numpy(), flow.scale.numpy(), affine=1)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=6e-4)
+    ref64 = flow.log_prob_f64(x).numpy()
+    assert np.max(np.abs(got - ref64) / np.maximum(np.abs(ref64), 1.0)) <= 1e-6
+    # draw
+    xs, lqs = eng.coupling_sample(2000, torch.float64, dev, 99, 0, 1)
+    refs = flow.log_prob_f64(xs.double().cpu().numpy()).numpy()
+    assert np.max(np.abs(lqs.cpu().numpy() - refs) / np.maximum(np.abs(refs), 1.0)) <= 3e-6
+    # mutation, both step functions
+    n_steps, beta, rho = 3, 0.4, 0.3
+    x0, mu, L, Linv = _setup(n, d, 8)
+    o_t = oracle.Mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    t_t = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    for nu in (0.0, 5.0):
+        xr = x0.copy()
+        llr, lpr = o_t.logpdf(xr), o_t.logpdf(xr)
+        lqr = oracle.maf_logprob(xr, ws, bs, flow.loc.numpy(), flow.scale.numpy(), affine=1)
+        xm = eng.asarray(x0)
+        lld, lpd, lqd = eng.asarray(llr), eng.asarray(lpr), eng.coupling_logprob(xm, dev)
+        eng.profile(True)
+        n_acc, _, _ = eng.pcn_mutate_flow(xm, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), t_t, t_t, dev, 4242, 17, rho,
+                                          n_steps, 9, 0.234, False, "f64", nu)
+        rep = eng.profile_report()
+        eng.profile(False)
+        one = [k for k in rep if k.startswith(("k_pcn_flow_fused", "k_pcn_flow16", "k_tpcn_flow16"))]
+        assert one and rep[one[0]][0] == n_steps, sorted(rep)
+        acc_ref, margins = [], []
+        for t in range(n_steps):
+            with oracle.accept_margins(n) as m:
+                if nu > 0:
+                    acc_ref.append(oracle.tpcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, nu, o_t, o_t, ws, bs, flow.loc.numpy(),
+                                                         flow.scale.numpy(), 4242, 17, 9 + t, "f64", 0, flow_kind="maf_softclip"))
+                else:
+                    acc_ref.append(oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, o_t, o_t, ws, bs, flow.loc.numpy(),
+                                                        flow.scale.numpy(), 4242, 17, 9 + t, "f64", 0, flow_kind="maf_softclip"))
+            margins.append(m.copy())
+        gotx = xm.cpu().numpy()
+        close = np.all(np.abs(gotx - xr) <= 1e-9 * (1 + np.abs(xr)), axis=1)
+        assert (~close).sum() <= 12, (~close).sum()
+        razor = np.min(np.abs(np.array(margins)), axis=0)
+        assert np.all(razor[~close] <= 2e-4), razor[~close]
+        assert np.all(np.abs(np.array(n_acc) - np.array(acc_ref)) <= 12) and 0.03 < np.mean(n_acc) / n < 0.97
+    # a coupling flow cannot carry the form
+    from conftest import random_coupling_flow
+
+    cdev = random_coupling_flow(8, 2, 32).device_coupling(eng)
+    cdev.affine = 1
+    with pytest.raises(Exception, match="affine"):
+        eng.coupling_logprob(eng.asarray(np.zeros((4, 8))), cdev)
