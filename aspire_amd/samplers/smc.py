@@ -739,12 +739,50 @@ class HipSMC(SMCSampler):
     def _device_flow(self):
         """The proposal flow packed for the MFMA kernel, or None (not a float32 coupling flow of a supported shape)."""
         if not hasattr(self.prior_flow, "device_coupling"):
-            return None
+            return self._adapted_zuko_flow()
         try:
             return self.prior_flow.device_coupling(self.engine)
         except (ValueError, RuntimeError) as exc:
             logger.info("flow stays on its torch modules: %s", exc)
             return None
+
+    def _adapted_zuko_flow(self):
+        """OPT-IN (`sampler_kwargs["zuko_adapter"] = True`): a proposal that is the reference's own `ZukoFlow(flow_class="MAF")`
+        (what `Aspire.fit` trains and hands to the sampler through the plug-in seam, flows/torch/flows.py:156-168) has no
+        `device_coupling`; its zuko module's state dict is repacked for the HIP kernels by `MAFFlow.from_zuko_state_dict`, so
+        that the mutation runs the one-kernel flow step instead of the callables split path.  Off by default because zuko is
+        absent from the build image: the adapter follows zuko's documented layout and is UNVERIFIED against the package - the
+        first mutation cross-checks it against the flow's own `log_prob` on 256 particles and refuses on a mismatch."""
+        if not self.sampler_kwargs.get("zuko_adapter", False):
+            return None
+        pf = self.prior_flow
+        inner = getattr(pf, "_flow", None)
+        if inner is None or not hasattr(inner, "state_dict"):
+            return None
+        dt = getattr(pf, "data_transform", None)
+        if dt is not None and type(dt).__name__ != "IdentityTransform":
+            logger.info("zuko adapter: the flow lives behind a data transform; it stays on its own modules")
+            return None
+        cache = self.__dict__.get("_zuko_cache")
+        key = id(inner)
+        if cache is None or cache[0] != key:
+            from ..flows import MAFFlow
+
+            try:
+                adapted = MAFFlow.from_zuko_state_dict(inner.state_dict(), device=self.engine.device)
+                dev = adapted.device_coupling(self.engine)
+                probe = torch.randn((256, self.dims), device=self.engine.device, dtype=torch.float64)
+                mine = self.engine.coupling_logprob(probe, dev)
+                theirs = self._to_dev(pf.log_prob(probe.to(getattr(pf, "dtype", torch.float32))))
+                err = float(((mine - theirs).abs() / theirs.abs().clamp_min(1.0)).max())
+                if not err <= 1e-4:
+                    raise ValueError(f"adapted flow disagrees with the flow's own log_prob (max relative difference {err:.3g})")
+                logger.warning("zuko adapter in use (unverified against zuko itself; agrees with this flow's log_prob to %.1e)", err)
+            except Exception as exc:
+                logger.warning("zuko adapter declined: %s", exc)
+                dev = None
+            cache = self._zuko_cache = (key, dev)
+        return cache[1]
 
     def _flow_fused_ok(self, dev_flow) -> bool:
         return (dev_flow is not None and isinstance(self._log_likelihood, DiagGaussianMixture)

@@ -358,3 +358,51 @@ def test_zuko_form_autoregressive_flow_on_the_kernels(eng, oracle, d, hidden, n)
     cdev.affine = 1
     with pytest.raises(Exception, match="affine"):
         eng.coupling_logprob(eng.asarray(np.zeros((4, 8))), cdev)
+
+
+def test_opt_in_zuko_adapter_puts_a_reference_style_flow_on_the_one_kernel_step(eng):
+    """`sampler_kwargs["zuko_adapter"] = True`: a proposal WITHOUT `device_coupling` whose `_flow.state_dict()` has zuko's MAF
+    layout (the shape of the reference's `ZukoFlow`, flows/torch/flows.py:156-168; here a stand-in that evaluates zuko's
+    documented arithmetic in PyTorch - zuko itself is absent) is repacked for the kernels, cross-checked against the flow's own
+    `log_prob` on a probe batch, and the mutation runs the one-kernel flow step instead of propose / accept kernels around
+    PyTorch passes.  Without the opt-in the same proposal takes the callables path."""
+    import math
+
+    from conftest import zuko_like_state_dict
+
+    from aspire_amd.flows import MAFFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    d, n = 32, 50_000
+    sd = {k: torch.as_tensor(v) for k, v in zuko_like_state_dict(d, (64, 64), 3, seed=2, scale=0.15).items()}
+    inner = MAFFlow.from_zuko_state_dict(sd, device=eng.device)  # (used by the stand-in for its torch arithmetic only)
+
+    class Module:
+        def state_dict(self):
+            return sd
+
+    class ZukoLike:  # what the seam hands over: log_prob / sample_and_log_prob, a zuko module in `_flow`, no device_coupling
+        dims, dtype, xp, data_transform = d, torch.float32, torch, None
+        _flow = Module()
+
+        def log_prob(self, x, xp=None):
+            return inner.log_prob(torch.as_tensor(x, device=eng.device, dtype=torch.float32))
+
+        def sample_and_log_prob(self, n_samples, xp=None):
+            return inner.sample_and_log_prob(n_samples)
+
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    for opt_in in (True, False):
+        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=ZukoLike(), xp=np, engine=eng, rng=np.random.default_rng(11),
+                    dtype="float64")
+        eng.profile(True)
+        out = sp.sample(n if opt_in else 4096, sampler_kwargs=dict(n_steps=4, step_fn="pcn", zuko_adapter=opt_in), store_sample_history=False)
+        rep = eng.profile_report()
+        eng.profile(False)
+        if opt_in:
+            assert "flow: device-side step loop" in sp.last_mutation_path and rep["k_pcn_flow_fused"][0] == 4 * len(sp.history.beta)
+            z = (float(out.log_evidence) - 0.5 * d * math.log(math.pi)) / float(out.log_evidence_error)
+            assert abs(z) < 4.0, z
+        else:
+            assert "k_pcn_flow_fused" not in rep and "flow: device-side step loop" not in sp.last_mutation_path
