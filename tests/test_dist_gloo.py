@@ -258,6 +258,31 @@ def _worker(rank, world, port, out_dir, engine_kind="oracle"):
             eng.set_count_hook(None, None)
         res["lagflow_acc"], res["lagflow_hist"], res["lagflow_rho"] = np.asarray(acc_l), np.asarray(hist_l), np.array([rho_l])
         res["lagflow_x"] = eng.to_numpy(xs_l)
+        # the same through the one-kernel step above 32 dimensions (k_tpcn_flow16: k_count_sum -> exchange -> k_pcn_adapt per
+        # step, or per block of a lagged adaptation), d = 48 zero-padded to 64, autoregressive proposal
+        from conftest import random_maf_flow
+
+        from aspire_amd.engine import HipEngine as _HE
+
+        eng64 = _HE(0, n_max=8192, d_max=64)
+        d6, n6 = 48, 4000
+        f6 = random_maf_flow(d6, 2, 64, seed=13)
+        dev6 = f6.device_coupling(eng64)
+        x6 = 0.9 * np.random.default_rng(78).normal(size=(n6, d6))
+        lo6, hi6 = rank * n6 // world, (rank + 1) * n6 // world
+        t6 = eng64.make_mixture([0.0], np.zeros((1, d6)), np.ones((1, d6)))
+        eye6, mu6 = eng64.asarray(np.eye(d6)), eng64.asarray(np.zeros(d6))
+        for lag6 in (1, 3):
+            xs6 = eng64.asarray(x6[lo6:hi6])
+            l6, p6, q6 = eng64.mixture_logpdf(xs6, t6), eng64.mixture_logpdf(xs6, t6), eng64.coupling_logprob(xs6, dev6)
+            eng64.set_count_hook(comm, n6)
+            try:
+                a6, h6, r6 = eng64.pcn_mutate_flow(xs6, l6, p6, q6, 0.4, mu6, eye6, eye6, t6, t6, dev6, 41, lo6, 0.5, 7, 2, 0.9, lag6, "f64", 5.0)
+            finally:
+                eng64.set_count_hook(None, None)
+            res[f"f16_acc_{lag6}"], res[f"f16_hist_{lag6}"], res[f"f16_rho_{lag6}"] = np.asarray(a6), np.asarray(h6), np.array([r6])
+            res[f"f16_x_{lag6}"] = eng64.to_numpy(xs6)
+        eng64.close()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()

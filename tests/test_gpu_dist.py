@@ -126,3 +126,29 @@ def test_lagged_adaptation_sharded_matches_the_test_double_and_one_rank(runs):
     # the history is the lagged schedule: held for blocks of three steps, the block's updates applied in order at its end
     hist = np.asarray(hist)
     assert hist[0] == hist[1] == hist[2] == 0.6 and hist[3] == hist[4] == hist[5] != 0.6 and hist[6] == hist[7] != hist[5]
+
+
+def test_flow16_step_sharded_equals_one_rank(runs):
+    """The one-kernel flow step above 32 dimensions (k_tpcn_flow16; d = 48 padded to 64, autoregressive proposal) on two ranks with
+    the accept counts exchanged through the hook - per step, and per block of a lagged adaptation - against ONE rank stepping the
+    whole population: the same global counts, step-size history and rows, bit for bit."""
+    from conftest import random_maf_flow
+
+    from aspire_amd.engine import HipEngine
+
+    eng = HipEngine(0, n_max=8192, d_max=64)
+    d6, n6 = 48, 4000
+    f6 = random_maf_flow(d6, 2, 64, seed=13)
+    dev6 = f6.device_coupling(eng)
+    x6 = 0.9 * np.random.default_rng(78).normal(size=(n6, d6))
+    t6 = eng.make_mixture([0.0], np.zeros((1, d6)), np.ones((1, d6)))
+    eye6, mu6 = eng.asarray(np.eye(d6)), eng.asarray(np.zeros(d6))
+    h0, h1 = runs["hip"]
+    for lag in (1, 3):
+        x = eng.asarray(x6)
+        ll, lp, lq = eng.mixture_logpdf(x, t6), eng.mixture_logpdf(x, t6), eng.coupling_logprob(x, dev6)
+        acc, hist, rho = eng.pcn_mutate_flow(x, ll, lp, lq, 0.4, mu6, eye6, eye6, t6, t6, dev6, 41, 0, 0.5, 7, 2, 0.9, lag, "f64", 5.0)
+        for h in (h0, h1):
+            assert np.array_equal(h[f"f16_acc_{lag}"], np.asarray(acc)) and np.array_equal(h[f"f16_hist_{lag}"], np.asarray(hist))
+            assert float(h[f"f16_rho_{lag}"][0]) == rho
+        assert np.array_equal(np.concatenate([h0[f"f16_x_{lag}"], h1[f"f16_x_{lag}"]]), x.cpu().numpy())
