@@ -406,3 +406,34 @@ def test_opt_in_zuko_adapter_puts_a_reference_style_flow_on_the_one_kernel_step(
             assert abs(z) < 4.0, z
         else:
             assert "k_pcn_flow_fused" not in rep and "flow: device-side step loop" not in sp.last_mutation_path
+
+
+@pytest.mark.parametrize("kind,d,hidden,n", [("coupling", 64, 32, 2000), ("maf", 48, 128, 1500), ("maf", 64, 64, 7), ("coupling", 128, 64, 1)])
+def test_flow_mutation_above_32_dimensions_other_widths_and_tiny_populations(eng, oracle, kind, d, hidden, n):
+    """Hidden widths the one-kernel step is not built for (32 / 128 above 32 dimensions) take the composed path - propose on the
+    matrix cores, k_flow16_logprob, targets, accept - and a population smaller than one 16-particle group runs the one-kernel step
+    on a single ragged group: both against the oracle's restatement of the step."""
+    n_steps, beta, rho = 3, 0.4, 0.3
+    flow = _flow(kind, d, 2, hidden, seed=9)
+    dev = flow.device_coupling(eng)
+    ws, bs = flow.export_layers()
+    x0, mu, L, Linv = _setup(n, d, 18)
+    o_t = oracle.Mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    t_t = eng.make_mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
+    flp = oracle.coupling_logprob if kind == "coupling" else oracle.maf_logprob
+    xr = x0.copy()
+    llr, lpr, lqr = o_t.logpdf(xr), o_t.logpdf(xr), flp(xr, ws, bs, flow.loc.numpy(), flow.scale.numpy())
+    xd = eng.asarray(x0)
+    lld, lpd, lqd = eng.asarray(llr), eng.asarray(lpr), eng.coupling_logprob(xd, dev)
+    eng.profile(True)
+    n_acc, _, _ = eng.pcn_mutate_flow(xd, lld, lpd, lqd, beta, eng.asarray(mu), eng.asarray(L), eng.asarray(Linv), t_t, t_t, dev, 4242, 17, rho,
+                                      n_steps, 9, 0.234, False, "f64", 0.0)
+    rep = eng.profile_report()
+    eng.profile(False)
+    assert ("k_pcn_flow16" in rep) == (hidden == 64), sorted(rep)
+    acc_ref = [oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, o_t, o_t, ws, bs, flow.loc.numpy(), flow.scale.numpy(), 4242, 17,
+                                    9 + t, "f64", 0, flow_kind=kind) for t in range(n_steps)]
+    got = xd.cpu().numpy()
+    close = np.all(np.abs(got - xr) <= 1e-9 * (1 + np.abs(xr)), axis=1)
+    assert (~close).sum() <= 4 and np.all(np.abs(np.array(n_acc) - np.array(acc_ref)) <= 4)
+    np.testing.assert_allclose(lqd.cpu().numpy()[close], lqr[close], rtol=1e-5, atol=6e-4)

@@ -32,7 +32,8 @@ def run(nn, profile):
     return sp, out, time.perf_counter() - t0
 
 
-run(min(n, 65536), False)  # warm
+if not os.environ.get("NOWARM"):  # (NOWARM=1 under rocprofv3 --pmc: every launch of the trace is then a 1M-particle launch)
+    run(min(n, 65536), False)  # warm
 sp, out, dt = run(n, True)
 rep = eng.profile_report()
 eng.profile(False)

@@ -15,7 +15,7 @@ for set in "${sets[@]}" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
   D=64 KIND=coupling rocprofv3 --pmc $set -d /tmp/pf16_$tag -o k --output-format csv -- python3 $R/tools/flow16_bench.py > /dev/null 2>&1
   python3 $R/tools/pmc_summary.py /tmp/pf16_$tag k_pcn_flow16 >> $O/pmc_flow16_d64.txt 2>&1
-  STEPS=4 NOISE=f64 rocprofv3 --pmc $set -d /tmp/pc5_$tag -o k --output-format csv -- python3 $R/tools/config5.py > /dev/null 2>&1
+  NOWARM=1 STEPS=4 NOISE=f64 rocprofv3 --pmc $set -d /tmp/pc5_$tag -o k --output-format csv -- python3 $R/tools/config5.py > /dev/null 2>&1
   python3 $R/tools/pmc_summary.py /tmp/pc5_$tag k_pcn_mm >> $O/pmc_config5_step.txt 2>&1
 done
 DIMS=8,16,20,32,48,64,100,128 python3 $R/tools/flow_dims.py 2>&1 | grep -v amdgpu.ids > $O/flow_dims.txt
