@@ -939,12 +939,13 @@ class HipEngine:
         if self.use_rccl(comm):  # the library issues the all-reduce itself, on its own stream
             self._hook = (None, cell, None)
             check(self.lib.asmc_pcn_set_count_rccl(self._ctx, _dptr(cell), int(n_global)), "asmc_pcn_set_count_rccl")
-            check(self.lib.asmc_pcn_set_count_cells(self._ctx, _lib.ASMC_MAX_COUNT_CELLS), "asmc_pcn_set_count_cells")
+            self._count_active = 1
             return
 
         def cb(_user, _stream):
             try:
-                comm.all_reduce_sum_(cell)
+                k = self.__dict__.get("_count_active", 1)
+                comm.all_reduce_sum_(cell if k >= cell.numel() else cell[:k])  # (k = 1 unless the adaptation is lagged)
                 return 0
             except Exception as exc:  # exceptions must not unwind through the C frames
                 self._hook_error = exc
@@ -954,13 +955,26 @@ class HipEngine:
         self._hook = (fn, cell, cb)  # keep the trampoline and the cell alive while installed
         check(self.lib.asmc_pcn_set_count_hook(self._ctx, ctypes.cast(fn, ctypes.c_void_p), None, _dptr(cell), int(n_global)),
               "asmc_pcn_set_count_hook")
-        check(self.lib.asmc_pcn_set_count_cells(self._ctx, _lib.ASMC_MAX_COUNT_CELLS), "asmc_pcn_set_count_cells")
+        self._count_active = 1
+
+    def _count_cells_for(self, adapt) -> None:
+        """Before a device-side step loop of a sharded run: the exchange sums exactly the cells the loop writes - one, or k for a
+        lagged adaptation (`adapt` = k >= 2) - so that the default schedule's per-step all-reduce stays an 8-byte one."""
+        if self.__dict__.get("_hook") is None:
+            return
+        k = max(1, int(adapt))
+        if k != self.__dict__.get("_count_active"):
+            if k > _lib.ASMC_MAX_COUNT_CELLS:
+                raise ValueError(f"adapt_lag {k} exceeds {_lib.ASMC_MAX_COUNT_CELLS}")
+            check(self.lib.asmc_pcn_set_count_cells(self._ctx, k), "asmc_pcn_set_count_cells")
+            self._count_active = k
 
     def pcn_mutate(self, x, ll, lp, lq, beta, mu, L, Linv, t_ll, t_lp, t_lq, seed, gid0, rho, n_steps, step0=0,
                    target_accept=0.234, adapt=True, noise="f64", nu=0.0):
         """n_steps fused pCN steps in place (nu > 0: t-preconditioned steps with a Student-t reference).
         Returns (n_accept[n_steps], rho_hist[n_steps], rho_out)."""
         self._chk3(ll, lp, lq)
+        self._count_cells_for(adapt)
         n, d = x.shape
         prm = AsmcPcnParams(d, self._xdt(x), beta, mu.data_ptr(), L.data_ptr(), Linv.data_ptr(), t_ll.c_struct(),
                             t_lp.c_struct(), t_lq.c_struct(), seed, gid0, target_accept, int(adapt),
@@ -978,6 +992,7 @@ class HipEngine:
                         n_steps, step0=0, target_accept=0.234, adapt=True, noise="f64", nu=0.0):
         """pcn_mutate with a coupling-flow proposal density (log_q evaluated on the MFMA each step)."""
         self._chk3(ll, lp, lq)
+        self._count_cells_for(adapt)
         n, d = x.shape
         prm = AsmcPcnParams(d, self._xdt(x), beta, mu.data_ptr(), L.data_ptr(), Linv.data_ptr(), t_ll.c_struct(),
                             t_lp.c_struct(), t_lp.c_struct(), seed, gid0, target_accept, int(adapt),
@@ -1000,6 +1015,7 @@ class HipEngine:
         """`pcn_mutate_flow` without the wait: everything is on the stream when this returns, `pcn_mutate_flow_result(handle)`
         synchronises and returns what `pcn_mutate_flow` returns.  The caller may enqueue more behind it in between."""
         self._chk3(ll, lp, lq)
+        self._count_cells_for(adapt)
         n, d = x.shape
         prm = AsmcPcnParams(d, self._xdt(x), beta, mu.data_ptr(), L.data_ptr(), Linv.data_ptr(), t_ll.c_struct(),
                             t_lp.c_struct(), t_lp.c_struct(), seed, gid0, target_accept, int(adapt),

@@ -638,7 +638,7 @@ class MAFFlow(CouplingFlow):
     @classmethod
     def from_zuko_state_dict(cls, state_dict, device=None, dtype=torch.float32):
         """A flow the REFERENCE trained - `zuko.flows.MAF(features, 0, transforms=T, hidden_features=(h1, h2))`, what
-        `ZukoFlow(flow_class="MAF")` builds (`/root/reference/src/aspire/flows/torch/flows.py:156-168`) and `BaseTorchFlow.save`
+        `ZukoFlow(flow_class="MAF")` builds (`src/aspire/flows/torch/flows.py:156-168` of the reference) and `BaseTorchFlow.save`
         stores entry by entry (`flows.py:63-87`: `flow/weights/<state-dict key>`) - as an `MAFFlow` that runs on the HIP kernels.
 
         **UNVERIFIED**: zuko is not installed in the build image and no file of it is in the reference tree, so this follows zuko's
