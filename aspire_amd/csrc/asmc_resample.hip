@@ -54,21 +54,65 @@ __device__ __forceinline__ void td_of(double w, int e, long long& a0, long long&
 }
 
 // ---- block-level ordered scan of transducers --------------------------------------------------
+// 256 threads x 8 elements.  (512 x 4 was measured in round 5: nothing at 1M - the passes are chains of barriers and LDS round
+// trips, not instruction issue - and the transducer pass of 8M particles went from 45 to 75 us.)
 #define XT_THREADS ASMC_BLOCK
-#define XT_E (ASMC_SCAN_TILE / ASMC_BLOCK)  // 8 elements per thread, one 2048-element tile per block pass
+#define XT_E (ASMC_SCAN_TILE / XT_THREADS)  // 8 elements per thread, one 2048-element tile per block pass
+
+// ---- wave-level ordered scan of transducers on the DPP network (round 5) ---------------------------------------------
+// A lane's (a0, a1) moves as four 32-bit DPP moves; a lane without a source reads 0 = the identity transducer, so no step needs a
+// lane test.  row_shr 1 / 2 / 4 / 8 scan the rows of 16, row_bcast15 hands rows 1 and 3 the totals of rows 0 and 2, row_bcast31
+// hands rows 2 and 3 the total of the first two.  (Before: six rounds of four ds_bpermute, ~130 cycles of LDS latency each, in
+// kernels that run one wave per SIMD.  Composition is associative - exact integers - so the network does not change a bit.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_ll(long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)v & 0xFFFFFFFFull), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)v >> 32), CTRL, ROW_MASK, 0xF, false);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+#define DPP_WAVE_SHR1 0x138
+
+__device__ __forceinline__ TD td_wave_scan(TD inc) {  // inclusive, lane order
+#define TD_SCAN_STEP(CTRL, MASK)                                          \
+    {                                                                     \
+        const TD t_ = {dpp_ll<CTRL, MASK>(inc.a0), dpp_ll<CTRL, MASK>(inc.a1)}; \
+        inc = td_compose(t_, inc);                                        \
+    }
+    TD_SCAN_STEP(DPP_ROW_SHR(1), 0xF)
+    TD_SCAN_STEP(DPP_ROW_SHR(2), 0xF)
+    TD_SCAN_STEP(DPP_ROW_SHR(4), 0xF)
+    TD_SCAN_STEP(DPP_ROW_SHR(8), 0xF)
+    TD_SCAN_STEP(DPP_ROW_BCAST15, 0xA)
+    TD_SCAN_STEP(DPP_ROW_BCAST31, 0xC)
+#undef TD_SCAN_STEP
+    return inc;
+}
+__device__ __forceinline__ TD td_wave_shr1(TD inc) {  // the lane below's value, identity in lane 0
+    return TD{dpp_ll<DPP_WAVE_SHR1, 0xF>(inc.a0), dpp_ll<DPP_WAVE_SHR1, 0xF>(inc.a1)};
+}
+
+// running sum s > 0  <->  (binade e, integer S on the grid 2^(e-52)): the mantissa with its implicit bit - the same values as
+// binade_of(s) and (long long)ldexp(s, 52 - e), without the library sequences (the chain's walk is a lone wave: ~10 cycles an instruction)
+__device__ __forceinline__ void sum_split(double s, int& e, long long& S) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(s);
+    const int ex = (int)((b >> 52) & 0x7FF);
+    const long long m = (long long)(b & 0xFFFFFFFFFFFFFull);
+    e = ex ? ex - 1023 : -1022;
+    S = ex ? (m | (1LL << 52)) : m;
+}
+// ldexp((double)S, e - 52) for 2^52 <= S <= 2^53 (any S < 2^53 at e = -1022): S's bit 52 is the exponent field's last bit
+__device__ __forceinline__ double sum_join(long long S, int e) {
+    return __longlong_as_double(S + ((long long)(e + 1022) << 52));
+}
 
 // in: `mine` = composition of this thread's elements.  out: excl = composition of all lower threads,
 // total = composition of the whole block (valid in every thread).  sh: [XT_THREADS/64 + 1] TDs.
 __device__ __forceinline__ void td_block_scan(TD mine, TD& excl, TD& total, TD* sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    TD inc = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        TD t;
-        t.a0 = __shfl_up(inc.a0, o, 64);
-        t.a1 = __shfl_up(inc.a1, o, 64);
-        if (lane >= o) inc = td_compose(t, inc);
-    }
+    const TD inc = td_wave_scan(mine);
     if (lane == 63) sh[wave] = inc;
     __syncthreads();
     TD wave_prefix = {0, 0};
@@ -78,10 +122,7 @@ __device__ __forceinline__ void td_block_scan(TD mine, TD& excl, TD& total, TD* 
         if (v < wave) wave_prefix = td_compose(wave_prefix, sh[v]);
         tot = td_compose(tot, sh[v]);
     }
-    excl.a0 = __shfl_up(inc.a0, 1, 64);
-    excl.a1 = __shfl_up(inc.a1, 1, 64);
-    if (lane == 0) excl = TD{0, 0};
-    excl = td_compose(wave_prefix, excl);
+    excl = td_compose(wave_prefix, td_wave_shr1(inc));
     total = tot;
     __syncthreads();  // sh may be reused by the caller
 }
@@ -98,7 +139,7 @@ __device__ __forceinline__ int binade_of(double s) {
 }
 
 // Exact sequential-order cumulative sum of ONE tile w[lo, hi) (hi - lo <= 2048) starting from the exact
-// running sum s0, by the whole block.  Each thread owns 8 fixed elements (loaded once); every pass scans the
+// running sum s0, by the whole block.  Each thread owns XT_E fixed elements (loaded once); every pass scans the
 // still-open elements on the grid of the current binade and restarts behind the first element whose add
 // leaves the binade (that add is a genuine fp64 add).  Returns the exact running sum at `hi`.
 __device__ double exact_tile(const double* __restrict__ w, double* __restrict__ cdf, int64_t lo, int64_t hi,
@@ -381,11 +422,20 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_shard(int64_t n, c
 }
 
 // Pass D: one block chains the EXACT running sum through the tiles.  Flag-1 tiles cost O(1) (verify the binade
-// guess against the exact incoming sum, apply the tile transducer; 64 of them per wave-level scan); flag-2
-// tiles cost O(1) as well (apply A, verify that the add of element c is the one that leaves the binade, do that
-// add in fp64, apply B on the next grid); any tile that fails a check or is flagged 0 is processed element-wise
-// by exact_tile.  tile_s[t] = exact sum entering tile t, tile_s2[t] = exact sum right after element c;
-// tile_info[4t+3] stays 1 / 2 if pass E must still write the tile and becomes 0 if it has been written here.
+// guess against the exact incoming sum, apply the tile transducer); flag-2 tiles cost O(1) as well (apply A, verify
+// that the add of element c is the one that leaves the binade, do that add in fp64, apply B on the next grid); any
+// tile that fails a check or is flagged 0 is processed element-wise by exact_tile.  tile_s[t] = exact sum entering
+// tile t, tile_s2[t] = exact sum right after element c; tile_info[4t+3] stays 1 / 2 if pass E must still write the
+// tile and becomes 0 if it has been written here.
+//
+// Round 5: the scans left the sequential chain.  A run of flag-1 tiles of one predicted binade (a PIECE) acts on the
+// running sum through the composition of its transducers whatever the sum is, so the ordered scans INSIDE the pieces do
+// not depend on the chain: the four waves compute them for a whole chunk of 512 tiles at once (segmented DPP scans, 64
+// tiles each), and the chain itself - wave 0 alone, no workgroup barrier - only verifies a piece's binade against the
+// exact incoming sum, adds the prefixes (one ballot for the 2^53 check), and steps over the flag-2 tiles: ~30
+// instructions per piece instead of one 64-lane scan behind every crossing (1M particles: 15 batches x 1.12 us +
+// 8 x 0.6 us of a lone wave -> the figure in profiles/README.md).  Same integers in the same association-free algebra:
+// the same bits.
 __global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const double* __restrict__ w,
                                                            double* __restrict__ cdf, double carry_in,
                                                            int64_t n_tiles, long long* __restrict__ tile_info,
@@ -394,119 +444,193 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const dou
                                                            double* __restrict__ total_out) {
     __shared__ TD sh_td[XT_THREADS / 64 + 1];
     __shared__ double sh_s, sh_walk_s;
-    __shared__ int sh_split_ok;
     __shared__ long long sh_pos, sh_cross, sh_walk_t;
+    __shared__ int sh_need;
     // tile records of the current chunk of CHAIN_CHUNK tiles, staged once by the whole block: the walk below then
     // reads LDS instead of paying a global-load latency in every round of the sequential chain
     constexpr int CHAIN_CHUNK = 512;
-    __shared__ long long sh_info[CHAIN_CHUNK * 4];
-    __shared__ long long sh_split[CHAIN_CHUNK * 4];
+    constexpr int GROUPS = CHAIN_CHUNK / 64;
+    __shared__ __attribute__((aligned(16))) long long sh_info[CHAIN_CHUNK * 4];
+    __shared__ __attribute__((aligned(16))) long long sh_split[CHAIN_CHUNK * 4];
     __shared__ double sh_wc[CHAIN_CHUNK];  // weight of the predicted crossing element (pass C leaves it in tile_s2)
-    int64_t chunk0 = -CHAIN_CHUNK;
+    __shared__ long long sh_inc[CHAIN_CHUNK * 2];  // inclusive composition of the tile's piece up to and including the tile
+    __shared__ unsigned long long sh_headm[GROUPS], sh_okm[GROUPS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t t = 1;            // tile 0 has been scanned exactly by pass C
     double s = tile_s2[0];    // exact running sum behind tile 0
     while (t < n_tiles) {
-        if (t + 64 > chunk0 + CHAIN_CHUNK || t < chunk0) {  // uniform: (re)stage so that tiles [t, t+64) are resident
-            __syncthreads();
-            chunk0 = t;
-            const int64_t cnt = (n_tiles - chunk0 < CHAIN_CHUNK ? n_tiles - chunk0 : CHAIN_CHUNK) * 4;
-            for (int64_t i = threadIdx.x; i < cnt; i += XT_THREADS) {
-                sh_info[i] = tile_info[4 * chunk0 + i];
-                sh_split[i] = tile_split[4 * chunk0 + i];
-            }
-            for (int64_t i = threadIdx.x; i < cnt / 4; i += XT_THREADS) sh_wc[i] = tile_s2[chunk0 + i];
-            __syncthreads();
-        }
-        // wave 0 walks up to 64 tiles per round: lane l holds tile t+l's record, the chain itself is a scalar
-        // recurrence evaluated redundantly by all lanes on values broadcast with readlane (no memory latency
-        // inside the dependent chain)
-        if (threadIdx.x < 64) {
-            const int lane = threadIdx.x;
-            const int64_t my_t = t + lane;
-            long long a0 = 0, a1 = 0, ee = 0, sf = 0;
-            if (my_t < n_tiles) {
-                const long long* rec = sh_info + 4 * (my_t - chunk0);
-                a0 = rec[0];
-                a1 = rec[1];
-                ee = rec[2];
-                sf = rec[3];
-            }
-            // chain state as (integer S on the grid of binade e_cur): consecutive safe tiles of one binade are
-            // pure integer transducer applications, so a batch of 64 tiles is ONE wave-level ordered scan; the
-            // first tile that is flagged unsafe, sits in another binade or would push S past 2^53 stops the walk
-            // and goes through exact_tile
-            const int e_cur = binade_of(s);
-            const long long S = (s > 0.0) ? (long long)ldexp(s, 52 - e_cur) : -1;
-            const bool ok = (sf == 1) && (S >= 0) && ((int)ee == e_cur);
-            const unsigned long long bad_mask = ~__ballot(ok);
-            int stop = bad_mask ? (int)__builtin_ctzll(bad_mask) : 64;
-            TD inc = {ok ? a0 : 0, ok ? a1 : 0};
+        __syncthreads();
+        const int64_t chunk0 = t;  // (re)stage: the tiles from t on
+        const int64_t n_in = n_tiles - chunk0 < CHAIN_CHUNK ? n_tiles - chunk0 : CHAIN_CHUNK;
+        {   // every load of the chunk in flight at once (16-byte halves of the 32-byte records): one memory latency
+            static_assert(CHAIN_CHUNK % XT_THREADS == 0, "whole tiles per thread");
+            constexpr int PER = CHAIN_CHUNK / XT_THREADS;
+            typedef unsigned long long __attribute__((ext_vector_type(2))) rec_half;
+            const rec_half* gi = reinterpret_cast<const rec_half*>(tile_info + 4 * chunk0);
+            const rec_half* gs = reinterpret_cast<const rec_half*>(tile_split + 4 * chunk0);
+            rec_half vi[2 * PER], vs[2 * PER];
+            double wc[PER];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                TD t2;
-                t2.a0 = __shfl_up(inc.a0, o, 64);
-                t2.a1 = __shfl_up(inc.a1, o, 64);
-                if (lane >= o) inc = td_compose(t2, inc);
+            for (int q = 0; q < PER; q++) {
+                const int k = (int)threadIdx.x + q * XT_THREADS;
+                const bool in = k < n_in;
+                const rec_half z = {0ull, 0ull};
+                vi[2 * q] = in ? gi[2 * k] : z;
+                vi[2 * q + 1] = in ? gi[2 * k + 1] : z;
+                vs[2 * q] = in ? gs[2 * k] : z;
+                vs[2 * q + 1] = in ? gs[2 * k + 1] : z;
+                wc[q] = in ? tile_s2[chunk0 + k] : 0.0;
             }
-            const long long S_out = S + ((S & 1) ? inc.a1 : inc.a0);
-            long long ex0 = __shfl_up(inc.a0, 1, 64), ex1 = __shfl_up(inc.a1, 1, 64);
-            if (lane == 0) ex0 = ex1 = 0;
-            const long long my_S = S + ((S & 1) ? ex1 : ex0);
-            const unsigned long long ovf_mask = __ballot(S_out >= TWO53_LL);
-            const int first_ovf = ovf_mask ? (int)__builtin_ctzll(ovf_mask) : 64;
-            stop = stop < first_ovf ? stop : first_ovf;
-            const double my_s = ldexp((double)my_S, e_cur - 52);
-            const long long S_end = stop > 0 ? __shfl(S_out, stop - 1, 64) : S;
-            const double ss = (stop > 0) ? ldexp((double)S_end, e_cur - 52) : s;
-            if (lane < stop) tile_s[my_t] = my_s;
-            if (lane == 0) {
-                sh_walk_t = t + stop;
-                sh_walk_s = ss;
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const int k = (int)threadIdx.x + q * XT_THREADS;
+                reinterpret_cast<rec_half*>(sh_info)[2 * k] = vi[2 * q];
+                reinterpret_cast<rec_half*>(sh_info)[2 * k + 1] = vi[2 * q + 1];
+                reinterpret_cast<rec_half*>(sh_split)[2 * k] = vs[2 * q];
+                reinterpret_cast<rec_half*>(sh_split)[2 * k + 1] = vs[2 * q + 1];
+                sh_wc[k] = wc[q];
             }
         }
         __syncthreads();
-        const bool advanced_full = (sh_walk_t == t + 64);
-        t = sh_walk_t;
-        s = sh_walk_s;
+        // the pieces' scans, 64 tiles per wave and pass: a piece starts at a flag-1 tile whose predecessor (in the group) is not
+        // flag 1 or sits in another predicted binade; every other tile is a piece of its own (identity)
+        for (int g = wave; g < GROUPS; g += XT_THREADS / 64) {
+            const int k = g * 64 + lane;
+            long long a0 = 0, a1 = 0;
+            int ee = 0;
+            bool ok = false;
+            if (k < n_in) {
+                const long long* rec = sh_info + 4 * k;
+                ok = rec[3] == 1;
+                ee = (int)rec[2];
+                // (clamped to 2^54: still "past 2^53" for the chain's check, and 64 of them cannot overflow an int64, so the
+                // scan below composes without the saturation)
+                a0 = ok ? (rec[0] < TD_BIG ? rec[0] : TD_BIG) : 0;
+                a1 = ok ? (rec[1] < TD_BIG ? rec[1] : TD_BIG) : 0;
+            }
+            const int e_prev = __builtin_amdgcn_update_dpp(0, ee, DPP_WAVE_SHR1, 0xF, 0xF, false);
+            const int ok_prev = __builtin_amdgcn_update_dpp(0, (int)ok, DPP_WAVE_SHR1, 0xF, 0xF, false);
+            int f = (!ok || lane == 0 || !ok_prev || e_prev != ee) ? 1 : 0;  // piece start (or a tile outside the pieces)
+            const unsigned long long headm = __ballot(f != 0), okm = __ballot(ok);
+            TD inc = {a0, a1};
+            // segmented inclusive scan: a lane that has met its piece's start keeps its value
+#define SEG_STEP(CTRL, MASK)                                                    \
+    {                                                                           \
+        const TD l_ = {dpp_ll<CTRL, MASK>(inc.a0), dpp_ll<CTRL, MASK>(inc.a1)}; \
+        const int lf_ = __builtin_amdgcn_update_dpp(0, f, CTRL, MASK, 0xF, false); \
+        const TD c_ = {l_.a0 + ((l_.a0 & 1) ? inc.a1 : inc.a0), l_.a1 + ((l_.a1 & 1) ? inc.a0 : inc.a1)}; \
+        inc = f ? inc : c_;                                                     \
+        f |= lf_;                                                               \
+    }
+            SEG_STEP(DPP_ROW_SHR(1), 0xF)
+            SEG_STEP(DPP_ROW_SHR(2), 0xF)
+            SEG_STEP(DPP_ROW_SHR(4), 0xF)
+            SEG_STEP(DPP_ROW_SHR(8), 0xF)
+            SEG_STEP(DPP_ROW_BCAST15, 0xA)
+            SEG_STEP(DPP_ROW_BCAST31, 0xC)
+#undef SEG_STEP
+            sh_inc[2 * k] = inc.a0;
+            sh_inc[2 * k + 1] = inc.a1;
+            if (lane == 0) sh_headm[g] = headm, sh_okm[g] = okm;
+        }
         __syncthreads();
-        if (advanced_full) continue;
-        if (t >= n_tiles) break;
-        if (sh_info[4 * (t - chunk0) + 3] == 2) {  // predicted single crossing: O(1) with verification
-            if (threadIdx.x == 0) {
-                const long long* rec = sh_info + 4 * (t - chunk0);
-                const int e = (int)rec[2];
-                const long long* sp = sh_split + 4 * (t - chunk0);
-                const long long b0 = sp[0], b1 = sp[1], nf_c = sp[3];
-                int ok = 0;
-                if (s > 0.0 && binade_of(s) == e) {
-                    const long long S = (long long)ldexp(s, 52 - e);
-                    const long long S_A = S + ((S & 1) ? rec[1] : rec[0]);
-                    if (S_A < TWO53_LL && S_A + nf_c >= TWO53_LL) {  // no add before c leaves the binade, c's does
-                        const double s_new = ldexp((double)S_A, e - 52) + sh_wc[t - chunk0];
-                        if (binade_of(s_new) == e + 1) {
-                            const long long S2 = (long long)ldexp(s_new, 52 - (e + 1));
-                            const long long S_B = S2 + ((S2 & 1) ? b1 : b0);
-                            if (S_B < TWO53_LL) {  // and none after it does
-                                tile_s[t] = s;
-                                tile_s2[t] = s_new;
-                                sh_walk_s = ldexp((double)S_B, e + 1 - 52);
-                                ok = 1;
+        // the chain: wave 0 alone, every lane the same scalars (same-address LDS reads, readlane)
+        if (threadIdx.x < 64) {
+            int need = 0;
+            for (int g = 0; g < GROUPS && !need; g++) {
+                const int64_t base_t = chunk0 + (int64_t)g * 64;
+                if (base_t >= n_tiles) break;
+                const int k = g * 64 + lane;
+                const int64_t my_t = base_t + lane;
+                const long long inc0 = sh_inc[2 * k], inc1 = sh_inc[2 * k + 1];
+                const int ee = (int)sh_info[4 * k + 2];
+                const unsigned long long headm = (unsigned long long)readlane_ll((long long)sh_headm[g], 0),
+                                         okm = (unsigned long long)readlane_ll((long long)sh_okm[g], 0);  // scalars
+                const bool head = (headm >> lane) & 1;
+                TD ex = td_wave_shr1(TD{inc0, inc1});  // composition of the piece in front of this tile
+                if (head) ex = TD{0, 0};
+                int pos = 0;
+                t = base_t;
+                while (pos < 64 && base_t + pos < n_tiles) {
+                    t = base_t + pos;
+                    if (!((okm >> pos) & 1)) {  // a tile outside the pieces
+                        const int kk = g * 64 + pos;
+                        if (sh_info[4 * kk + 3] == 2) {  // predicted single crossing: O(1) with verification
+                            const long long* rec = sh_info + 4 * kk;
+                            const int e = (int)rec[2];
+                            const long long* sp = sh_split + 4 * kk;
+                            const long long b0 = sp[0], b1 = sp[1], nf_c = sp[3];
+                            bool done = false;
+                            int e_s;
+                            long long S1;
+                            sum_split(s, e_s, S1);
+                            if (s > 0.0 && e_s == e) {
+                                const long long S_A = S1 + ((S1 & 1) ? rec[1] : rec[0]);
+                                if (S_A < TWO53_LL && S_A + nf_c >= TWO53_LL) {  // no add before c leaves the binade, c's does
+                                    const double s_new = sum_join(S_A, e) + sh_wc[kk];  // (2^52 <= S_A < 2^53, or e = -1022)
+                                    int e2;
+                                    long long S2;
+                                    sum_split(s_new, e2, S2);
+                                    if (e2 == e + 1) {
+                                        const long long S_B = S2 + ((S2 & 1) ? b1 : b0);
+                                        if (S_B < TWO53_LL) {  // and none after it does
+                                            if (lane == 0) {
+                                                tile_s[t] = s;
+                                                tile_s2[t] = s_new;
+                                            }
+                                            s = sum_join(S_B, e + 1);
+                                            done = true;
+                                        }
+                                    }
+                                }
+                            }
+                            if (done) {
+                                pos++;
+                                t = base_t + pos;
+                                continue;
                             }
                         }
+                        need = 1;  // the whole block, element-wise
+                        break;
+                    }
+                    // the piece [pos, end)
+                    const unsigned long long rest = pos < 63 ? headm >> (pos + 1) : 0ull;
+                    int end = rest ? pos + 1 + (int)__builtin_ctzll(rest) : 64;
+                    const int e_p = __builtin_amdgcn_readlane(ee, pos);
+                    int e_cur;
+                    long long S;
+                    sum_split(s, e_cur, S);
+                    if (!(s > 0.0) || e_cur != e_p) {  // the binade guess fails at the piece's first tile
+                        need = 1;
+                        break;
+                    }
+                    const long long S_out = S + ((S & 1) ? inc1 : inc0);
+                    const long long my_S = S + ((S & 1) ? ex.a1 : ex.a0);
+                    const bool in_piece = lane >= pos && lane < end;
+                    const unsigned long long ovf = __ballot(in_piece && S_out >= TWO53_LL);
+                    if (ovf) end = (int)__builtin_ctzll(ovf);  // that tile would push S past 2^53
+                    if (lane >= pos && lane < end) tile_s[my_t] = sum_join(my_S, e_cur);
+                    if (end > pos) s = sum_join(readlane_ll(S_out, end - 1), e_cur);
+                    pos = end;
+                    t = base_t + pos;
+                    if (ovf) {
+                        need = 1;
+                        break;
                     }
                 }
-                sh_split_ok = ok;
             }
-            __syncthreads();
-            const bool done = sh_split_ok != 0;
-            if (done) s = sh_walk_s;
-            __syncthreads();
-            if (done) {
-                t++;
-                continue;
+            if (lane == 0) {
+                sh_walk_t = t;
+                sh_walk_s = s;
+                sh_need = need;
             }
         }
-        // tile t needs the element-wise treatment
+        __syncthreads();
+        t = sh_walk_t;
+        s = sh_walk_s;
+        const bool need = sh_need != 0;
+        __syncthreads();
+        if (!need) continue;  // the chunk is used up (or the chain is done)
         const int64_t lo = t * ASMC_SCAN_TILE;
         const int64_t hi = (lo + ASMC_SCAN_TILE < n) ? lo + ASMC_SCAN_TILE : n;
         if (threadIdx.x == 0) {
@@ -908,7 +1032,9 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_scan(int64_t n, co
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s_pre[threadIdx.x >> 6] = acc;
     __syncthreads();
-    k_exact_tile_td_body(n, w, ((s_pre[0] + s_pre[1]) + s_pre[2]) + s_pre[3], n_tiles, tile_info, tile_split, tile_s2);
+    double pre = 0.0;
+    for (int k = 0; k < XT_THREADS / 64; k++) pre += s_pre[k];
+    k_exact_tile_td_body(n, w, pre, n_tiles, tile_info, tile_split, tile_s2);
 }
 
 // =============================================================================================
