@@ -138,23 +138,236 @@ __device__ __forceinline__ int binade_of(double s) {
     return e < -1022 ? -1022 : e;
 }
 
+// ---- a tile with SEVERAL binade crossings in O(1) per crossing (round 5) ------------------------------------------
+// Tile 0 (the running sum grows from nothing: a crossing at elements ~1, 2, 4, ... 1024) and every tile pass C flags 0
+// used to take one block-wide pass PER CROSSING in exact_tile's loop (2.7 - 3 us each: 21.7 us for tile 0 at 1M, the
+// critical path of the transducer kernel).  Here the whole tile is handled the way passes C - E handle the population:
+//   predict   an approximate prefix P (parallel rounding) gives every element the binade of the sum it is added to
+//             (be = the binade AFTER its predecessor, handed on literally, so a run of elements between two predicted
+//             crossings sits on ONE grid by construction) and marks the elements whose add leaves it;
+//   scan      transducers of the non-crossing elements on their grids, ordered scan SEGMENTED at the crossing elements
+//             (per element: the composition since the last crossing);
+//   verify    one wave walks the crossings with the EXACT sum: the segment in front of crossing k maps S -> S_A < 2^53
+//             (nothing inside it leaves the binade), S_A + floor(w_c / q) >= 2^53 (the crossing element does), the
+//             genuine fp64 add lands in the predicted next binade.  ~35 instructions per crossing;
+//   write     element i of a verified segment: S_in + composition-up-to-i, on the segment's grid.
+// Whatever fails verification (or more than XF_KMAX predicted crossings) is left to the loop below, which resumes
+// behind the last verified crossing.  Predictions are hints; only verified integers reach the cdf: the same bits.
+#define XF_KMAX 64
+struct XFast {
+    int c_pos[XF_KMAX], c_e[XF_KMAX], c_ea[XF_KMAX];
+    double c_w[XF_KMAX], cross_s[XF_KMAX];
+    long long c_nf[XF_KMAX], c_T0[XF_KMAX], c_T1[XF_KMAX];
+    long long seg_S[XF_KMAX + 1];
+    int seg_e[XF_KMAX + 1];
+    long long T_last0, T_last1;
+    double wsum[XT_THREADS / 64];
+    int wcnt[XT_THREADS / 64], wf[XT_THREADS / 64];
+    TD wv[XT_THREADS / 64];
+    int last_ba[XT_THREADS];
+    int k_ok;
+};
+
+__device__ __forceinline__ int binade_bits(double p) {  // binade_of for p >= 0 (exponent field; 0 and subnormals: -1022)
+    const int ex = (int)(((unsigned long long)__double_as_longlong(p) >> 52) & 0x7FF);
+    return ex ? ex - 1023 : -1022;
+}
+
+// Leaves *sh_pos = first element not written, *sh_s = exact running sum in front of it (thread 0; the caller synchronises).
+__device__ void exact_tile_fast(double* __restrict__ cdf, int64_t lo, int64_t hi, double s0, const double (&wv)[XT_E],
+                                XFast& F, double* sh_s, long long* sh_pos) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = lo + (int64_t)tid * XT_E;
+    // approximate prefixes
+    double tsum = 0.0;
+#pragma unroll
+    for (int j = 0; j < XT_E; j++) tsum += wv[j];
+    double inc = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) F.wsum[wave] = inc;
+    __syncthreads();
+    double p = s0;
+    for (int v = 0; v < wave; v++) p += F.wsum[v];
+    p += inc - tsum;
+    int ba[XT_E];
+#pragma unroll
+    for (int j = 0; j < XT_E; j++) {
+        p += wv[j];
+        ba[j] = binade_bits(p);
+    }
+    F.last_ba[tid] = ba[XT_E - 1];
+    __syncthreads();
+    int be[XT_E];
+    bool cross[XT_E];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < XT_E; j++) {
+        be[j] = j ? ba[j - 1] : (tid ? F.last_ba[tid - 1] : binade_bits(s0));
+        cross[j] = ba[j] != be[j];
+        cnt += cross[j] ? 1 : 0;
+    }
+    int cinc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(cinc, o, 64);
+        if (lane >= o) cinc += v;
+    }
+    // transducers, the thread's aggregate since its last crossing
+    long long ta0[XT_E], ta1[XT_E], nfc[XT_E];
+    TD agg = {0, 0};
+    int f = 0;
+#pragma unroll
+    for (int j = 0; j < XT_E; j++) {
+        td_of(wv[j], be[j], ta0[j], ta1[j], nfc[j]);
+        if (cross[j]) {
+            agg = TD{0, 0};
+            f = 1;
+        } else {
+            agg = td_compose(agg, TD{ta0[j], ta1[j]});
+        }
+    }
+    // segmented inclusive scan over the wave (a lane that has met a crossing keeps its value)
+    TD iv = agg;
+    int fl = f;
+#define XF_SEG_STEP(CTRL, MASK)                                               \
+    {                                                                         \
+        const TD l_ = {dpp_ll<CTRL, MASK>(iv.a0), dpp_ll<CTRL, MASK>(iv.a1)}; \
+        const int lf_ = __builtin_amdgcn_update_dpp(0, fl, CTRL, MASK, 0xF, false); \
+        const TD c_ = td_compose(l_, iv);                                     \
+        iv = fl ? iv : c_;                                                    \
+        fl |= lf_;                                                            \
+    }
+    XF_SEG_STEP(DPP_ROW_SHR(1), 0xF)
+    XF_SEG_STEP(DPP_ROW_SHR(2), 0xF)
+    XF_SEG_STEP(DPP_ROW_SHR(4), 0xF)
+    XF_SEG_STEP(DPP_ROW_SHR(8), 0xF)
+    XF_SEG_STEP(DPP_ROW_BCAST15, 0xA)
+    XF_SEG_STEP(DPP_ROW_BCAST31, 0xC)
+#undef XF_SEG_STEP
+    const TD ev = td_wave_shr1(iv);  // what lies in front of this thread inside the wave (identity in lane 0)
+    const int ef = __builtin_amdgcn_update_dpp(0, fl, DPP_WAVE_SHR1, 0xF, 0xF, false);
+    if (lane == 63) F.wv[wave] = iv, F.wf[wave] = fl, F.wcnt[wave] = cinc;
+    __syncthreads();
+    TD pv = {0, 0};
+    int k = cinc - cnt, K = 0;
+#pragma unroll
+    for (int v = 0; v < XT_THREADS / 64; v++) {
+        if (v < wave) {
+            pv = F.wf[v] ? F.wv[v] : td_compose(pv, F.wv[v]);
+            k += F.wcnt[v];
+        }
+        K += F.wcnt[v];
+    }
+    if (K > XF_KMAX) {  // uniform: not this way
+        if (tid == 0) *sh_s = s0, *sh_pos = lo;
+        return;
+    }
+    TD run = ef ? ev : td_compose(pv, ev);
+    const int k0 = k;
+    long long in0[XT_E], in1[XT_E];
+    int seg[XT_E];
+#pragma unroll
+    for (int j = 0; j < XT_E; j++) {
+        if (cross[j]) {
+            F.c_pos[k] = tid * XT_E + j;
+            F.c_e[k] = be[j];
+            F.c_ea[k] = ba[j];
+            F.c_w[k] = wv[j];
+            F.c_nf[k] = nfc[j];
+            F.c_T0[k] = run.a0;
+            F.c_T1[k] = run.a1;
+            run = TD{0, 0};
+            seg[j] = k;  // (its own index among the crossings)
+            k++;
+        } else {
+            run = td_compose(run, TD{ta0[j], ta1[j]});
+            seg[j] = k;  // the segment behind crossing k - 1
+        }
+        in0[j] = run.a0;
+        in1[j] = run.a1;
+    }
+    if (tid == XT_THREADS - 1) F.T_last0 = run.a0, F.T_last1 = run.a1;
+    __syncthreads();
+    if (tid < 64) {  // the walk: every lane the same scalars
+        double s = s0, s_end = s0;
+        int kk = 0;
+        for (; kk < K; kk++) {
+            int e_cur;
+            long long S;
+            sum_split(s, e_cur, S);
+            if (e_cur != F.c_e[kk]) break;
+            const long long S_A = S + ((S & 1) ? F.c_T1[kk] : F.c_T0[kk]);
+            if (!(S_A < TWO53_LL && S_A + F.c_nf[kk] >= TWO53_LL)) break;  // nothing in front of c leaves the binade, c does
+            const double s_new = sum_join(S_A, e_cur) + F.c_w[kk];
+            if (binade_bits(s_new) != F.c_ea[kk]) break;  // ... into the binade the next segment was built on
+            if (lane == 0) F.seg_S[kk] = S, F.seg_e[kk] = e_cur, F.cross_s[kk] = s_new;
+            s = s_new;
+        }
+        if (kk == K) {  // the stretch behind the last crossing
+            int e_cur;
+            long long S;
+            sum_split(s, e_cur, S);
+            const long long S_end = S + ((S & 1) ? F.T_last1 : F.T_last0);
+            if (S_end < TWO53_LL) {
+                if (lane == 0) F.seg_S[K] = S, F.seg_e[K] = e_cur;
+                s_end = sum_join(S_end, e_cur);
+                kk = K + 1;
+            }
+        }
+        if (lane == 0) {
+            F.k_ok = kk;
+            *sh_s = kk == K + 1 ? s_end : s;
+            *sh_pos = kk == K + 1 ? hi : (kk == 0 ? lo : lo + F.c_pos[kk - 1] + 1);
+        }
+    }
+    __syncthreads();
+    const int k_ok = F.k_ok;
+#pragma unroll
+    for (int j = 0; j < XT_E; j++) {
+        if (base + j >= hi || seg[j] >= k_ok) continue;
+        if (cross[j]) {
+            cdf[base + j] = F.cross_s[seg[j]];
+        } else {
+            const long long S_in = F.seg_S[seg[j]];
+            cdf[base + j] = sum_join(S_in + ((S_in & 1) ? in1[j] : in0[j]), F.seg_e[seg[j]]);
+        }
+    }
+    (void)k0;
+}
+
 // Exact sequential-order cumulative sum of ONE tile w[lo, hi) (hi - lo <= 2048) starting from the exact
 // running sum s0, by the whole block.  Each thread owns XT_E fixed elements (loaded once); every pass scans the
 // still-open elements on the grid of the current binade and restarts behind the first element whose add
 // leaves the binade (that add is a genuine fp64 add).  Returns the exact running sum at `hi`.
+// try_fast: several crossings expected (tile 0, tiles flagged 0): exact_tile_fast first, the loop for what it leaves.
 __device__ double exact_tile(const double* __restrict__ w, double* __restrict__ cdf, int64_t lo, int64_t hi,
-                             double s0, TD* sh_td, double* sh_s, long long* sh_pos, long long* sh_cross) {
+                             double s0, TD* sh_td, double* sh_s, long long* sh_pos, long long* sh_cross,
+                             bool try_fast = false) {
     const int tid = threadIdx.x;
     const int64_t base = lo + (int64_t)tid * XT_E;
     double wv[XT_E];
 #pragma unroll
     for (int j = 0; j < XT_E; j++) wv[j] = (base + j < hi) ? w[base + j] : 0.0;
+    __shared__ XFast sh_fast;
+    if (try_fast) {  // uniform
+        exact_tile_fast(cdf, lo, hi, s0, wv, sh_fast, sh_s, sh_pos);
+    } else if (tid == 0) {
+        *sh_s = s0;
+        *sh_pos = lo;
+    }
+    __syncthreads();
     // the very first elements change binade at almost every add: plain sequential adds by one thread, on values
     // staged through LDS (a dependent chain of global loads would cost ~0.5 us per element)
     __shared__ double sh_head[64];
-    if (lo == 0 && tid < 64) sh_head[tid] = (tid < hi) ? w[tid] : 0.0;
+    const bool head = lo == 0 && *sh_pos == 0;  // (uniform; with try_fast only if nothing at all was verified)
     __syncthreads();
-    if (lo == 0 && tid < 64) {
+    if (head && tid < 64) sh_head[tid] = (tid < hi) ? w[tid] : 0.0;
+    __syncthreads();
+    if (head && tid < 64) {
         // every lane runs the same chain (LDS broadcast reads); lane j keeps the j-th partial sum and writes it
         const int64_t lim = hi < 64 ? hi : 64;
         double s = s0, mine_s = 0.0;
@@ -167,9 +380,6 @@ __device__ double exact_tile(const double* __restrict__ w, double* __restrict__ 
             *sh_s = s;
             *sh_pos = lim;
         }
-    } else if (lo != 0 && tid == 0) {
-        *sh_s = s0;
-        *sh_pos = lo;
     }
     __syncthreads();
     while (true) {
@@ -371,7 +581,7 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_launch(int64_t n, 
         __shared__ double sh_s0;
         __shared__ long long sh_pos0, sh_cross0;
         const int64_t hi = ASMC_SCAN_TILE < n ? ASMC_SCAN_TILE : n;
-        const double s_out = exact_tile(w, cdf, 0, hi, carry_in, sh_td0, &sh_s0, &sh_pos0, &sh_cross0);
+        const double s_out = exact_tile(w, cdf, 0, hi, carry_in, sh_td0, &sh_s0, &sh_pos0, &sh_cross0, true);
         if (threadIdx.x == 0) {
             if (rec_pk) {
                 rec_pk[0] = rec_pk[1] = rec_pk[2] = 0, rec_pk[3] = 3;
@@ -402,7 +612,7 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_shard(int64_t n, c
         __shared__ double sh_s0;
         __shared__ long long sh_pos0, sh_cross0;
         const int64_t hi = ASMC_SCAN_TILE < n ? ASMC_SCAN_TILE : n;
-        const double s_out = exact_tile(w, cdf, 0, hi, 0.0, sh_td0, &sh_s0, &sh_pos0, &sh_cross0);
+        const double s_out = exact_tile(w, cdf, 0, hi, 0.0, sh_td0, &sh_s0, &sh_pos0, &sh_cross0, true);
         if (threadIdx.x == 0) {
             rec_pk[0] = rec_pk[1] = rec_pk[2] = 0, rec_pk[3] = 3;
             rec_pk[4] = rec_pk[5] = rec_pk[6] = rec_pk[7] = 0;
@@ -436,12 +646,10 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_shard(int64_t n, c
 // instructions per piece instead of one 64-lane scan behind every crossing (1M particles: 15 batches x 1.12 us +
 // 8 x 0.6 us of a lone wave -> the figure in profiles/README.md).  Same integers in the same association-free algebra:
 // the same bits.
-__global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const double* __restrict__ w,
-                                                           double* __restrict__ cdf, double carry_in,
-                                                           int64_t n_tiles, long long* __restrict__ tile_info,
-                                                           const long long* __restrict__ tile_split,
-                                                           double* __restrict__ tile_s, double* __restrict__ tile_s2,
-                                                           double* __restrict__ total_out) {
+__device__ __forceinline__ void exact_chain_body(int64_t n, const double* __restrict__ w, double* __restrict__ cdf,
+                                                 int64_t n_tiles, long long* __restrict__ tile_info,
+                                                 const long long* __restrict__ tile_split, double* __restrict__ tile_s,
+                                                 double* __restrict__ tile_s2, double* __restrict__ total_out) {
     __shared__ TD sh_td[XT_THREADS / 64 + 1];
     __shared__ double sh_s, sh_walk_s;
     __shared__ long long sh_pos, sh_cross, sh_walk_t;
@@ -637,11 +845,21 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const dou
             tile_info[4 * t + 3] = 0;
             tile_s[t] = s;
         }
-        s = exact_tile(w, cdf, lo, hi, s, sh_td, &sh_s, &sh_pos, &sh_cross);
+        // (a tile pass C itself flagged 0 expects several crossings; one that failed a verification has one, somewhere else)
+        s = exact_tile(w, cdf, lo, hi, s, sh_td, &sh_s, &sh_pos, &sh_cross, sh_info[4 * (t - chunk0) + 3] == 0);
         __syncthreads();
         t++;
     }
     if (threadIdx.x == 0) *total_out = s;
+}
+
+__global__ __launch_bounds__(XT_THREADS) void k_exact_chain(int64_t n, const double* __restrict__ w,
+                                                           double* __restrict__ cdf, double carry_in,
+                                                           int64_t n_tiles, long long* __restrict__ tile_info,
+                                                           const long long* __restrict__ tile_split,
+                                                           double* __restrict__ tile_s, double* __restrict__ tile_s2,
+                                                           double* __restrict__ total_out) {
+    exact_chain_body(n, w, cdf, n_tiles, tile_info, tile_split, tile_s, tile_s2, total_out);
 }
 
 
@@ -1006,18 +1224,17 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_write(int64_t n, cons
 
 // k_scan_tiles folded into the transducer pass: a block adds up the tile sums in front of its tile itself (they are a
 // hint for the binade guess only, any summation order will do)
-__global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_scan(int64_t n, const double* __restrict__ w,
-                                                                  const double* __restrict__ tile_sums, int64_t n_tiles,
-                                                                  long long* __restrict__ tile_info,
-                                                                  long long* __restrict__ tile_split,
-                                                                  double* __restrict__ tile_s2, double* __restrict__ cdf,
-                                                                  double* __restrict__ tile_s) {
+__device__ __forceinline__ void exact_tile_td_scan_block(int64_t n, const double* __restrict__ w,
+                                                         const double* __restrict__ tile_sums, int64_t n_tiles,
+                                                         long long* __restrict__ tile_info, long long* __restrict__ tile_split,
+                                                         double* __restrict__ tile_s2, double* __restrict__ cdf,
+                                                         double* __restrict__ tile_s) {
     if (blockIdx.x == 0) {
         __shared__ TD sh_td0[XT_THREADS / 64 + 1];
         __shared__ double sh_s0;
         __shared__ long long sh_pos0, sh_cross0;
         const int64_t hi = ASMC_SCAN_TILE < n ? ASMC_SCAN_TILE : n;
-        const double s_out = exact_tile(w, cdf, 0, hi, 0.0, sh_td0, &sh_s0, &sh_pos0, &sh_cross0);
+        const double s_out = exact_tile(w, cdf, 0, hi, 0.0, sh_td0, &sh_s0, &sh_pos0, &sh_cross0, true);
         if (threadIdx.x == 0) {
             tile_info[0] = 0, tile_info[1] = 0, tile_info[2] = 0, tile_info[3] = 3;
             tile_split[0] = tile_split[1] = tile_split[2] = tile_split[3] = 0;
@@ -1036,6 +1253,19 @@ __global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_scan(int64_t n, co
     for (int k = 0; k < XT_THREADS / 64; k++) pre += s_pre[k];
     k_exact_tile_td_body(n, w, pre, n_tiles, tile_info, tile_split, tile_s2);
 }
+
+__global__ __launch_bounds__(XT_THREADS) void k_exact_tile_td_scan(int64_t n, const double* __restrict__ w,
+                                                                  const double* __restrict__ tile_sums, int64_t n_tiles,
+                                                                  long long* __restrict__ tile_info,
+                                                                  long long* __restrict__ tile_split,
+                                                                  double* __restrict__ tile_s2, double* __restrict__ cdf,
+                                                                  double* __restrict__ tile_s) {
+    exact_tile_td_scan_block(n, w, tile_sums, n_tiles, tile_info, tile_split, tile_s2, cdf, tile_s);
+}
+
+// (Passes C and D as ONE launch - the chain as an extra block behind pass C's, waiting on an arrival counter behind agent-scope
+// releases - was measured in round 5: 45.9 us against 17.7 + 24.1 us for the two launches.  489 release fences and the chain's
+// 50 KB of LDS in every block cost more than the launch boundary.  Not kept.)
 
 // =============================================================================================
 // fast cdf: reduce-then-scan (fixed order => deterministic)

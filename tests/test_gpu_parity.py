@@ -204,6 +204,39 @@ def test_exact_cdf_is_numpy_cumsum_bitwise(eng, n, kind):
     assert total == ref[-1]
 
 
+@pytest.mark.parametrize("kind", ["growth", "steps", "late_steps", "huge", "zeros_then_growth"])
+@pytest.mark.parametrize("n", [100, 2048, 6000, 300001])
+def test_exact_cdf_tiles_with_many_binade_crossings(eng, n, kind):
+    """Tiles in which the running sum leaves SEVERAL binades (exact_tile_fast: predicted crossings verified one by one; more than
+    64 of them, or a failed verification, fall back to one block-wide pass per crossing): still numpy's cumsum bit for bit."""
+    g = np.random.default_rng(n + len(kind))
+    if kind == "growth":  # every one of the first 200 adds at least doubles the sum (more crossings than the fast path takes)
+        w = np.exp(g.normal(size=n))
+        k = min(200, n)
+        w[:k] = np.ldexp(1.0 + g.random(k), 3 * np.arange(k) - 700)
+    elif kind == "steps":  # the scale jumps by 2^7 every 300 elements: several crossings inside most early tiles
+        w = np.exp(g.normal(size=n)) * np.ldexp(1.0, np.minimum(7 * (np.arange(n) // 300), 1100) - 200)
+    elif kind == "late_steps":  # smooth first, then three jumps inside one late tile
+        w = np.exp(g.normal(size=n))
+        for j, at in enumerate((n // 2, n // 2 + 37, n // 2 + 300)):
+            w[at:] *= 2.0 ** (11 + j)
+    elif kind == "huge":  # sums near the top of the range
+        w = np.exp(g.normal(size=n)) * 1e300 / n
+    else:  # zeros in front, then growth from subnormals
+        w = np.zeros(n)
+        k = n // 3
+        w[k:] = np.ldexp(1.0 + g.random(n - k), np.minimum(4 * np.arange(n - k) - 1074, 0))
+    cdf, total = eng.cdf(eng.asarray(w), "exact", 0.0)
+    ref = np.cumsum(w)
+    got = cdf.cpu().numpy()
+    assert np.array_equal(got, ref), np.flatnonzero(got != ref)[:5]
+    assert total == ref[-1]
+    # and behind an exact carry
+    cdf2, total2 = eng.cdf(eng.asarray(w), "exact", 0.37)
+    ref2 = np.cumsum(np.concatenate([[0.37], w]))[1:]
+    assert np.array_equal(cdf2.cpu().numpy(), ref2) and total2 == ref2[-1]
+
+
 @pytest.mark.parametrize("kind", ["smooth", "heavy", "equal"])
 @pytest.mark.parametrize("n", [1_100_003, 8_000_000])
 def test_exact_cdf_bitwise_beyond_one_chain_chunk(kind, n):
