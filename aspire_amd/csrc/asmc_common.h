@@ -83,7 +83,7 @@ struct asmc_ctx {
     double* d_tiles;               // [n_tiles_max * 4 + 64] scan tile aggregates
     long long* d_tiles_i;          // [n_tiles_max * 8 + 64] integer tile records (exact cdf: info + split; compaction)
     double* d_gram;                // [gram_blocks * d_max * d_max] gram partials
-    unsigned int* d_guide;         // [n_max / 4 + 8] guide table of the resampling search
+    unsigned int* d_guide;         // [n_max + 8] guide table of the resampling search (importance step: one bucket per cdf entry; asmc_search: one per four)
     unsigned char* d_flags;        // [n_max + 64] accept flags of the split-path pCN step (inside d_tilectr's allocation, behind the counters)
     double* d_gamma;               // [ASMC_GAMMA_BATCH][n_max] tpCN scale variates of the current steps
     // which steps' variates ctx->d_gamma holds (pcn_prepare_gamma)
