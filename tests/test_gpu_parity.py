@@ -237,6 +237,17 @@ def test_exact_cdf_tiles_with_many_binade_crossings(eng, n, kind):
     assert np.array_equal(cdf2.cpu().numpy(), ref2) and total2 == ref2[-1]
 
 
+def test_exact_cdf_fuzz_against_numpy():
+    """tools/fuzz_exact_cdf.py, a short run: random lengths and weight laws with binade crossings everywhere, with and without a
+    carry - numpy's cumsum bit for bit (20 000 rounds over four seeds ran clean on the round-5 tree)."""
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_exact_cdf.py")
+    out = subprocess.run([sys.executable, tool], env=dict(os.environ, ROUNDS="150", SEED="7"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("kind", ["smooth", "heavy", "equal"])
 @pytest.mark.parametrize("n", [1_100_003, 8_000_000])
 def test_exact_cdf_bitwise_beyond_one_chain_chunk(kind, n):
