@@ -296,7 +296,7 @@ def main():
         "traffic": traffic, "traffic_source": traffic_src,
         "traffic_over_algorithmic": round(traffic / b_pcn, 3) if traffic else None,
         # what limits it (rocprofv3 --pmc SQ counters of the committed profile, fractions of SIMD time): the vector ALU
-        "limiter": "vector-ALU issue (fp64 noise, the flow's ReLU / hi-lo conversions and epilogues); matrix pipe (fp16 flow layers + the fp64 mat-vec) and vector ALU add up",
+        "limiter": "instruction issue: vector ALU (fp64 noise, the flow's ReLU / hi-lo conversions and epilogues) + about half of the matrix-pipe time - an fp16 MFMA hides about half of a partner wave's vector work on this chip, an fp64 MFMA none (DESIGN 3.1 / 3.8): some instruction issues for 0.79 of SIMD time, the idle 0.21 is matrix time nobody can issue beside",
         "valu_active": sq.get("valu_active") if sq else None, "mfma_busy": sq.get("mfma_busy") if sq else None,
         "valu_insts_per_64_particle_tile": sq.get("valu_insts_per_tile") if sq else None,
         "sq_counters_source": sq_src, "kernel_source_hash": src_hash,
