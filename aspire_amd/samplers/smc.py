@@ -20,8 +20,7 @@ import torch
 from .. import smc_math
 from .._xp import is_torch, to_numpy
 from ..history import SMCHistory
-from ..samples import SMCSamples, Samples, gather_global
-from ..smc_math import BetaScheduleError
+from ..samples import SMCSamples, Samples
 from ..targets import DiagGaussianMixture
 from .base import IdentityTransform, MCMCSampler, track_calls
 
