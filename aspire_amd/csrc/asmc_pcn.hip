@@ -851,8 +851,8 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg_flow(
                 double lpo = log_p_t(oll, olp, olq, p.beta);
                 if (HAS_LJ) {  // as k_pcn_accept_flags: the log-Jacobian joins the tempered log-target, NaN -> -inf
                     lpn += nlj, lpo += olj;
-                    lpn = (lpn != lpn) ? -INFINITY : lpn;
-                    lpo = (lpo != lpo) ? -INFINITY : lpo;
+                    lpn = log_p_t_guard(lpn);
+                    lpo = log_p_t_guard(lpo);
                 }
                 const double log_a = (lpn + ref_corr(q1, p.nu, D)) - (lpo + ref_corr(q0, p.nu, D));
                 const double u = accept_uniform(p.seed, gid, step);
@@ -1053,11 +1053,11 @@ __global__ __launch_bounds__(ASMC_BLOCK) void k_pcn_accept_flags(
         double lpo = log_p_t(ll[i], lp[i], lq[i], beta);
         if (lj_new) {
             lpn += lj_new[i];
-            lpn = (lpn != lpn) ? -INFINITY : lpn;
+            lpn = log_p_t_guard(lpn);
         }
         if (lj_old) {
             lpo += lj_old[i];
-            lpo = (lpo != lpo) ? -INFINITY : lpo;
+            lpo = log_p_t_guard(lpo);
         }
         const double log_a = (lpn + 0.5 * qf_new[i]) - (lpo + 0.5 * qf_old[i]);
         const double u = accept_uniform(seed, gid0 + (unsigned long long)i, step);

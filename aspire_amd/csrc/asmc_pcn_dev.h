@@ -374,9 +374,15 @@ static inline MixDev to_dev(const asmc_mixture& m) {
 }
 
 
+// samples.py:1217-1219 + smc/base.py:507-519: the tempered log-target, NaN -> -inf as the reference maps it.  +inf -> -inf
+// as well (round 6): the reference's integration test with a +inf likelihood hole (tests/integration_tests/
+// test_integration.py:131-166) finishes, so the third-party step it calls cannot let a particle settle on a +inf
+// log-target (it would carry ll = +inf, the next log-sum-exp is NaN and the temperature search stalls).  This repository's
+// reading of that unverified behaviour: a proposal whose tempered log-target is +inf or NaN is rejected (and counted as a
+// rejection); a carried +inf (only a caller-supplied state can hold one) loses against any finite proposal.
+__device__ __forceinline__ double log_p_t_guard(double r) { return (r < INFINITY) ? r : -INFINITY; }
 __device__ __forceinline__ double log_p_t(double ll, double lp, double lq, double beta) {
-    double r = (1.0 - beta) * lq + beta * (ll + lp);
-    return (r != r) ? -INFINITY : r;
+    return log_p_t_guard((1.0 - beta) * lq + beta * (ll + lp));
 }
 
 

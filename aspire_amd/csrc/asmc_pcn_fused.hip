@@ -634,7 +634,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         // everything of the acceptance test that does not need log q(x') is finished HERE, and pinned: left to the
         // scheduler these computations sink below the flow, y' (64 VGPRs) stays alive across it for |y'|^2, and the
         // accumulators spill.  log_p_t(ll', lp', lq') = (1 - beta) lq' + beta (ll' + lp'): the second product is formed now.
+        // (a +inf or NaN target term turns the folded constant into NaN: rejected, see log_p_t)
         double t2 = p.beta * (nll + nlp);
+        t2 = (t2 < INFINITY) ? t2 : __builtin_nan("");
         double c1 = ref_corr(q1, p.nu, dn);
         double rhs = log_p_t(oll, olp, olq, p.beta) + ref_corr(q0, p.nu, dn);
         // (bm_log_unit: the noise generator's < 1 ulp log for positive normal arguments - the uniform is (k + 1/2) 2^-53 -
@@ -825,8 +827,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         // ---- phase 3: accept, on the lane's own particle ---------------------------------------------------------------
         // a non-finite log q(x') (NaN, or +-inf: fp16 operand overflow at |activation| >= 65504 in the split products,
         // asmc_flow_dev.h) rejects the proposal; counted, so that the host can tell the user
-        if (valid && !(fabs(nlq) < INFINITY)) n_bad++;
-        const bool accepted = valid && fma(1.0 - p.beta, nlq, kacc) > 0.0;  // (a NaN density compares false: rejected)
+        const bool lq_finite = fabs(nlq) < INFINITY;
+        if (valid && !lq_finite) n_bad++;
+        const bool accepted = valid && lq_finite && fma(1.0 - p.beta, nlq, kacc) > 0.0;  // (a NaN density compares false: rejected)
 #if FUSED_INPLACE
         // y' is stored FIRST: its registers are free once the stores have issued, so the next tile's state loads into them - with
         // the loads in front (round 3's order, when y' was parked and dead by now) both tiles' rows are alive at once and the loop

@@ -335,7 +335,7 @@ class SMCSampler(MCMCSampler):
         raise NotImplementedError
 
     def log_prob(self, z, beta=None):
-        """smc/base.py:507-519: tempered log-target in the preconditioned space, NaN -> -inf.
+        """smc/base.py:507-519: tempered log-target in the preconditioned space, NaN (and +inf) -> -inf.
         Accepts numpy or torch input and answers in the same namespace (used by custom `mutate`
         implementations; the built-in mutation fuses this into the pCN kernel)."""
         x, log_abs_det_jacobian = self.preconditioning_transform.inverse(z)
@@ -345,7 +345,8 @@ class SMCSampler(MCMCSampler):
         log_prob = (1 - beta) * log_q + beta * (ll + lp)
         if log_abs_det_jacobian is not None:
             log_prob = log_prob + self._to_dev(log_abs_det_jacobian)
-        log_prob = torch.where(torch.isnan(log_prob), torch.full_like(log_prob, -math.inf), log_prob)
+        # NaN -> -inf (smc/base.py:518); +inf -> -inf as well, as every accept kernel maps it (csrc/asmc_pcn_dev.h, log_p_t)
+        log_prob = torch.where(log_prob < math.inf, log_prob, torch.full_like(log_prob, -math.inf))
         return log_prob if is_torch(z) else to_numpy(log_prob)
 
     # ---- checkpoint glue (smc/base.py:521-562) -----------------------------------------------

@@ -479,14 +479,14 @@ class OracleEngine:
         def lpt(a, b, c):
             with np.errstate(all="ignore"):
                 r = (1 - beta) * _np(c) + beta * (_np(a) + _np(b))
-            return np.where(np.isnan(r), -np.inf, r)
+            return np.where(r < np.inf, r, -np.inf)  # NaN and +inf -> -inf (csrc/asmc_pcn_dev.h: log_p_t)
 
         c0, c1 = (O.tpcn_corr(q0, d, nu), O.tpcn_corr(q1, d, nu)) if nu > 0.0 else (0.5 * q0, 0.5 * q1)
         new, old = lpt(ll_new, lp_new, lq_new), lpt(ll, lp, lq)
         if logj is not None:
             with np.errstate(all="ignore"):
                 new, old = new + _np(logj_new), old + _np(logj)
-            new, old = np.where(np.isnan(new), -np.inf, new), np.where(np.isnan(old), -np.inf, old)
+            new, old = np.where(new < np.inf, new, -np.inf), np.where(old < np.inf, old, -np.inf)
         with np.errstate(all="ignore"):
             acc = np.log(u) < (new + c1) - (old + c0)
         sess["y"][acc] = yp[acc]
@@ -510,13 +510,16 @@ class OracleEngine:
         def lpt(a, b, c):
             with np.errstate(all="ignore"):
                 r = (1 - beta) * _np(c) + beta * (_np(a) + _np(b))
-            return np.where(np.isnan(r), -np.inf, r)
+            return np.where(r < np.inf, r, -np.inf)  # NaN and +inf -> -inf (csrc/asmc_pcn_dev.h: log_p_t)
 
         new, old = lpt(ll_new, lp_new, lq_new), lpt(ll, lp, lq)
-        if logj_new is not None:
-            new = new + _np(logj_new)
-        if logj_old is not None:
-            old = old + _np(logj_old)
+        with np.errstate(all="ignore"):  # k_pcn_accept_flags: the log-Jacobian joins the log-target, then the guard again
+            if logj_new is not None:
+                new = new + _np(logj_new)
+                new = np.where(new < np.inf, new, -np.inf)
+            if logj_old is not None:
+                old = old + _np(logj_old)
+                old = np.where(old < np.inf, old, -np.inf)
         with np.errstate(all="ignore"):
             acc = np.log(u) < (new + 0.5 * _np(q1)) - (old + 0.5 * _np(q0))
         acc_t = torch.from_numpy(acc)
