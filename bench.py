@@ -61,7 +61,70 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def launch_ranks(n_gpus: int) -> int:
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: this process becomes the launcher.  It starts N fresh
+    copies of itself, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as
+    `torch.distributed.run` would set them), relays rank 0's stdout - the ONE JSON line - and returns the worst exit status.
+    It never touches the GPU itself (no HIP call, no `torch.cuda.is_available()`: only `device_count()`, which does not
+    initialise the runtime on this image) and never re-execs.  When the ranks cannot be started (fewer visible GPUs than ranks)
+    it returns non-zero instead of measuring one GPU: a line with `n_gpus: 1` under `--gpus 8` would void a scaling run.
+    Test rig: ASMC_BENCH_DEVICE=<i> (with ASMC_BENCH_BACKEND=gloo) puts every rank on GPU i."""
+    import socket
+    import subprocess
+
+    if "ASMC_BENCH_DEVICE" not in os.environ:
+        have = torch.cuda.device_count()
+        if have < n_gpus:
+            print(f"bench.py: --gpus {n_gpus} but {have} HIP device(s) visible; refusing to measure fewer GPUs than asked for",
+                  file=sys.stderr)
+            return 2
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd(),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    import threading
+
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        failed = next((p for p in procs if p.poll() not in (None, 0)), None)
+        time.sleep(0.05)
+    if failed is not None:  # one rank died: its peers would wait in a collective until a watchdog fires - end exactly those processes
+        time.sleep(2.0)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out = got[0] if got else ""
+    worst = next((rc if rc > 0 else 1 for rc in rcs if rc != 0), 0)
+    lines = [ln for ln in (out or "").splitlines() if ln.strip()]
+    if worst == 0 and len(lines) != 1:
+        print(f"bench.py: rank 0 printed {len(lines)} lines, expected one", file=sys.stderr)
+        worst = 3
+    if worst == 0:
+        sys.stdout.write(lines[0] + "\n")
+        sys.stdout.flush()
+    else:
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+    return worst
+
+
 def main():
+    # `--gpus N` without a launcher around it: become the launcher, before anything touches the GPU
+    if "WORLD_SIZE" not in os.environ:
+        pre = argparse.ArgumentParser(add_help=False)
+        pre.add_argument("--gpus", type=int, default=1)
+        n_req = pre.parse_known_args()[0].gpus
+        if n_req > 1:
+            raise SystemExit(launch_ranks(n_req))
     # stdout carries ONE line - the JSON record.  Libraries write banners there (RCCL prints its version block when a communicator
     # is made): from here on file descriptor 1 is stderr, and the record goes to the descriptor stdout had.
     sys.stdout.flush()
@@ -108,7 +171,7 @@ def main():
         full = [ms for g, ms in ev if g == 2]
         return {"collections": len(ev), "full_collections": len(full), "total_ms": round(sum(ms for _, ms in ev), 3),
                 "max_pause_ms": round(max((ms for _, ms in ev), default=0.0), 3)}
-    if world != args.gpus and world > 1:
+    if world != args.gpus:  # (a launcher's WORLD_SIZE that disagrees with --gpus: never measure another job than the one asked for)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")

@@ -197,3 +197,25 @@ def test_flow_packing_places_every_weight_once():
         want = want[want != 0.0]
         assert got.size == want.size
         np.testing.assert_allclose(got, want, rtol=3e-7, atol=4e-8)  # (the lo half of a small weight is an fp16 subnormal: 6e-8 apart)
+
+
+def test_bench_launcher_refuses_without_devices_and_fails_with_its_ranks():
+    """bench.py --gpus N (N > 1) without a launcher becomes the launcher before any GPU call.  Here (no GPU):
+    it refuses when fewer devices are visible than ranks asked for, and when its ranks fail it fails with them - never a line
+    for another job than the one asked for."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU host: the refusal path needs fewer devices than ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ASMC_BENCH_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and r.stdout.strip() == "" and "refusing" in r.stderr
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=300, env=dict(env, ASMC_BENCH_DEVICE="0", ASMC_BENCH_BACKEND="gloo"))
+        assert r.returncode != 0 and r.stdout.strip() == "" and "rank exit codes" in r.stderr

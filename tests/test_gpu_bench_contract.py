@@ -35,3 +35,35 @@ def test_bench_prints_one_json_line_with_roofline_cpu_baseline_and_extra_legs():
         assert name in legs and "error" not in legs[name], (name, legs.get(name))
     assert legs["sharded_path_one_rank_group"]["importance_step_as_one_chain"] is True
     assert legs["flow_run_maf"]["torch_ops_in_mutation_loop"] == 0
+
+
+def test_bench_gpus_2_launches_its_own_ranks_and_reports_both():
+    """`python bench.py --gpus 2` as the driver runs `--gpus 1` - no launcher around it: the process starts its own two ranks
+    before any GPU call and relays rank 0's line.  One-GPU rig: both ranks on GPU 0, collectives staged
+    through gloo.  The line must describe the TWO-rank job: n_gpus 2, global population 2 x per-GPU (samples.py:1277-1278 acts on
+    the global population)."""
+    env = dict(os.environ, ASMC_BENCH_BACKEND="gloo", ASMC_BENCH_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--particles-per-gpu", "131072", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:3]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    cfg = j["config"]
+    assert cfg["particles_per_gpu"] == 131072 and cfg["global_particles"] == 2 * cfg["particles_per_gpu"]
+    assert cfg["parallelism"].startswith("particle-shard x2")
+
+
+def test_bench_refuses_more_gpus_than_are_visible():
+    """... and when the ranks cannot be started it exits non-zero instead of measuring one GPU."""
+    import torch
+
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ASMC_BENCH_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "refusing" in r.stderr
