@@ -153,23 +153,57 @@ class Aspire:
         self.training_samples = samples
         logger.info(f"Training with {len(samples.x)} samples")
         history = self.flow.fit(samples.x, **kwargs) or FlowHistory()
-        if checkpoint_path is not None:  # aspire.py:251-269: config group (once) and the flow (if missing, or overwrite)
-            store = self._open_checkpoint_store(checkpoint_path)
-            if store is None:
-                self._write_config_sidecar(checkpoint_path, sampler=False, save_config=checkpoint_save_config)
-            else:
-                with store as h5_file:
-                    if checkpoint_save_config:
-                        if "aspire_config" in h5_file:
-                            del h5_file["aspire_config"]
-                        self.save_config(h5_file, include_sampler_config=False)
-                    if "flow" in h5_file:
-                        if overwrite:
-                            del h5_file["flow"]
-                            self._try_save_flow(h5_file)
-                    else:
-                        self._try_save_flow(h5_file)
+        # aspire.py:251-269: config group (once) and the flow (if missing, or overwrite).  Sharded runs: the file's shared groups
+        # are written by rank 0 alone (HDF5 has one writer; the per-rank sampler state goes to `<stem>.rank<r>.<ext>`), the
+        # other ranks wait behind a barrier so that nobody opens the file while it is being written
+        comm = self._checkpoint_comm()
+        if checkpoint_path is not None and comm.rank != 0:
+            comm.barrier()
+        elif checkpoint_path is not None:
+            try:
+                self._fit_checkpoint(checkpoint_path, checkpoint_save_config, overwrite)
+            finally:
+                comm.barrier()
         return history
+
+    def _checkpoint_comm(self):
+        """The communicator whose rank 0 owns the shared groups of a checkpoint file: the sampler's, else the process group's."""
+        comm = getattr(self._sampler, "comm", None) if self._sampler is not None else None
+        if comm is None:
+            from .comm import default_comm
+
+            comm = default_comm(self.device or "cpu")
+        return comm
+
+    def _fit_checkpoint(self, checkpoint_path, checkpoint_save_config: bool, overwrite: bool) -> None:
+        """aspire.py:251-269 (rank 0 only in a sharded run)."""
+        store = self._open_checkpoint_store(checkpoint_path)
+        if store is None:
+            self._write_config_sidecar(checkpoint_path, sampler=False, save_config=checkpoint_save_config)
+            return
+        with store as h5_file:
+            if checkpoint_save_config:
+                if "aspire_config" in h5_file:
+                    del h5_file["aspire_config"]
+                self.save_config(h5_file, include_sampler_config=False)
+            if "flow" in h5_file:
+                if overwrite:
+                    del h5_file["flow"]
+                    self._try_save_flow(h5_file)
+            else:
+                self._try_save_flow(h5_file)
+
+    def _hdf5_route(self, path) -> bool:
+        """Whether `checkpoint_path` is served as an HDF5 file (its name says so and h5py imports) - decided WITHOUT opening it:
+        in a sharded run only rank 0 ever opens the shared file."""
+        if not self._is_hdf5_path(path):
+            return False
+        from . import io
+
+        if not io.h5py_available():
+            logger.warning("HDF5 files need h5py, which is not installed; writing pickle checkpoints next to %s instead", path)
+            return False
+        return True
 
     # ---- checkpoint files (aspire.py:501-557, 799-870) ----------------------------------------------------------------
     @staticmethod
@@ -315,6 +349,21 @@ class Aspire:
                             prior_flow=self.flow, xp=self.xp, dtype=self.dtype,
                             preconditioning_transform=transform, parameters=self.parameters, **kwargs)
 
+    def _sample_checkpoint_config(self, checkpoint_path, hdf5_route: bool, save_config: bool, saved_flow: bool) -> None:
+        """aspire.py:539-557 (rank 0 only in a sharded run)."""
+        if not hdf5_route:
+            self._write_config_sidecar(checkpoint_path, sampler=True, save_config=save_config)
+            return
+        with self._open_checkpoint_store(checkpoint_path) as h5_file:
+            if save_config:
+                for grp in ("aspire_config", "sampler_config"):
+                    if grp in h5_file:
+                        del h5_file[grp]
+                self.save_config(h5_file, include_sampler_config=False)
+                self.save_sampler_config(h5_file, include_sample_calls="last")
+            if self.flow is not None and not saved_flow and "flow" not in h5_file:
+                self._try_save_flow(h5_file)
+
     def sample_posterior(self, n_samples: int | None = None, sampler: str = "importance", xp: Any = None,
                          return_history: bool = False, preconditioning: str | None = None,
                          preconditioning_kwargs: dict | None = None, checkpoint_path: str | None = None,
@@ -328,33 +377,31 @@ class Aspire:
                                           preconditioning_kwargs=preconditioning_kwargs, **sampler_kwargs)
         self._last_sampler_type = sampler
         saved_flow, hdf5_route = False, False
+        comm = self._checkpoint_comm()
         if checkpoint_path is not None:  # aspire.py:501-529
             supports = {"checkpoint_file_path", "checkpoint_every"}.issubset(signature(self._sampler.sample).parameters)
-            store = self._open_checkpoint_store(checkpoint_path)
-            hdf5_route = store is not None
+            hdf5_route = self._hdf5_route(checkpoint_path)
             if not supports:
                 logger.warning(f"Sampler {sampler} does not support checkpointing. Checkpoint will not be saved.")
             else:
                 kwargs.setdefault("checkpoint_file_path", checkpoint_path if hdf5_route else self._pickle_checkpoint_path(checkpoint_path))
                 kwargs.setdefault("checkpoint_every", checkpoint_every)
-            if hdf5_route:
-                with store as h5_file:
-                    if self.flow is not None and "flow" not in h5_file:
-                        saved_flow = self._try_save_flow(h5_file)
+            # sharded runs: the file's shared groups (flow, aspire_config, sampler_config) and the JSON sidecar are written by rank 0
+            # alone, the others wait behind a barrier; the sampler's own state is per rank (`<stem>.rank<r>.<ext>`, samplers/base.py)
+            try:
+                if hdf5_route and comm.rank == 0:
+                    with self._open_checkpoint_store(checkpoint_path) as h5_file:
+                        if self.flow is not None and "flow" not in h5_file:
+                            saved_flow = self._try_save_flow(h5_file)
+            finally:
+                comm.barrier()
         samples = self._sampler.sample(n_samples, **kwargs)
         if checkpoint_path is not None:  # aspire.py:539-557: the two config groups behind the sampler's own /checkpoint/state
-            if hdf5_route:
-                with self._open_checkpoint_store(checkpoint_path) as h5_file:
-                    if checkpoint_save_config:
-                        for grp in ("aspire_config", "sampler_config"):
-                            if grp in h5_file:
-                                del h5_file[grp]
-                        self.save_config(h5_file, include_sampler_config=False)
-                        self.save_sampler_config(h5_file, include_sample_calls="last")
-                    if self.flow is not None and not saved_flow and "flow" not in h5_file:
-                        self._try_save_flow(h5_file)
-            else:
-                self._write_config_sidecar(checkpoint_path, sampler=True, save_config=checkpoint_save_config)
+            try:
+                if comm.rank == 0:
+                    self._sample_checkpoint_config(checkpoint_path, hdf5_route, checkpoint_save_config, saved_flow)
+            finally:
+                comm.barrier()
         self._last_sample_posterior_kwargs = {
             "n_samples": n_samples, "sampler": sampler, "xp": xp, "return_history": return_history,
             "preconditioning": preconditioning, "preconditioning_kwargs": preconditioning_kwargs,

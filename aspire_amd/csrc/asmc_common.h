@@ -160,6 +160,12 @@ struct asmc_ctx {
     int gram_pending_d;  // d of an enqueued, not yet fetched asmc_mean_gram (0: none)
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: the "already raised" guards of the launchers
+// are kept per device (a process with contexts on two devices must raise it on both)
+#define ASMC_MAX_DEVICES 64
+static inline int asmc_dev_slot(const asmc_ctx* ctx) { return ctx->device & (ASMC_MAX_DEVICES - 1); }
+
+
 // asmc_flow16.hip: flows of more than 32 dimensions (packed layout 1: 16-particle groups, streamed weights)
 extern "C" int asmc_flow_layout(int kind, int dims, int hidden);
 int64_t asmc_flow16_pack_floats(int kind, int dims, int n_layers, int hidden);

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_poison_lds(int words) {
 }
 void asmc_poison_lds(asmc_ctx* ctx, hipStream_t st) {
     const int bytes = 160 * 1024 - 1024;
-    static bool attr_set = false;
+    static bool attr_set_dev[ASMC_MAX_DEVICES] = {false}; bool& attr_set = attr_set_dev[asmc_dev_slot(ctx)];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_set = true;

@@ -554,7 +554,7 @@ static int launch_flow(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_couplin
     ASMC_REQUIRE(lds <= 160 * 1024, "one coupling layer does not fit in LDS");
     constexpr int FLOW_WAVES = FLOW_THREADS / 64;
     auto kern = k_coupling_logprob<H, W, XT, FLOW_THREADS, TPW, HS>;
-    static size_t attr_lds = 0;  // per instantiation
+    static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];  // per instantiation
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
@@ -604,7 +604,7 @@ static int launch_maf(asmc_ctx* ctx, int64_t n, const XT* x, const asmc_coupling
         return ASMC_ERR_UNSUPPORTED;
     }
     auto kern = k_maf_logprob<H, W, XT, 512, HS>;
-    static size_t attr_lds = 0;  // per instantiation
+    static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];  // per instantiation
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
@@ -651,7 +651,7 @@ static int launch_maf_sample(asmc_ctx* ctx, int64_t n, const asmc_coupling* f, u
         return ASMC_ERR_UNSUPPORTED;
     }
     auto kern = k_maf_sample<H, W, XT, 512>;
-    static size_t attr_lds = 0;  // per instantiation
+    static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];  // per instantiation
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
@@ -708,7 +708,7 @@ static int launch_flow_sample(asmc_ctx* ctx, int64_t n, const asmc_coupling* f, 
         return ASMC_ERR_UNSUPPORTED;
     }
     auto kern = k_coupling_sample<H, W, XT, 512>;
-    static size_t attr_lds = 0;  // per instantiation
+    static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];  // per instantiation
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;

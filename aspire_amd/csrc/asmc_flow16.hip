@@ -207,7 +207,7 @@ static int launch_flow16_logprob(asmc_ctx* ctx, int64_t n, const XT* x, const as
     const size_t lds = (size_t)(2 * FLOW16_CHUNK_WORDS + f->n_layers * FD::BIAS + 3 * D) * sizeof(float);
     ASMC_REQUIRE(lds <= 160 * 1024, "flow16: biases exceed the LDS");
     auto kern = k_flow16_logprob<KIND, D, W, XT, THREADS>;
-    static size_t attr_lds = 0;
+    static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
@@ -542,7 +542,7 @@ static int launch_pcn_flow16_g(asmc_ctx* ctx, int64_t n, T* x, double* ll, doubl
     const size_t lds = f16_step_lds<KIND, D, W, CW>(f->n_layers, pd.ll.C, pd.lp.C, NOISE) - 128;
     if ((lds + 128) * PER_CU > 160 * 1024) return ASMC_ERR_UNSUPPORTED;  // (the caller tries the next geometry)
     auto kern = k_pcn_flow16<T, D, W, KIND, NOISE, TP, THREADS, CW>;
-    static size_t attr_lds = 0;
+    static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
@@ -742,7 +742,7 @@ static int launch_flow16_sample(asmc_ctx* ctx, int64_t n, const asmc_coupling* f
     const size_t lds = (size_t)(2 * FLOW16_CHUNK_WORDS + f->n_layers * FD::BIAS) * sizeof(float);
     ASMC_REQUIRE(lds <= 160 * 1024, "flow16: biases exceed the LDS");
     auto kern = k_flow16_sample<KIND, D, W, XT, THREADS>;
-    static size_t attr_lds = 0;
+    static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;

@@ -1535,7 +1535,7 @@ static int launch_pcn_reg(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp
     const int grid = (int)grid64;
     *grid_out = grid;
     auto kern = k_pcn_reg<T, D, NOISE, MODE>;
-    static bool attr_set = false;  // per instantiation; the attribute call costs tens of microseconds
+    static bool attr_set_dev[ASMC_MAX_DEVICES] = {false}; bool& attr_set = attr_set_dev[asmc_dev_slot(ctx)];  // per instantiation; the attribute call costs tens of microseconds
     if (lds_bytes > 64 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
@@ -1578,7 +1578,7 @@ static int launch_pcn_reg_flow(asmc_ctx* ctx, int64_t n, T* y, T* x_prop, double
     }
     *grid_out = (int)grid64;
     auto kern = k_pcn_reg_flow<T, D, NOISE, MODE>;
-    static bool attr_set = false;
+    static bool attr_set_dev[ASMC_MAX_DEVICES] = {false}; bool& attr_set = attr_set_dev[asmc_dev_slot(ctx)];
     if (lds_bytes > 64 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
@@ -2119,7 +2119,7 @@ static int ref_status_request(asmc_ctx* ctx, const double* d_status, hipStream_t
 int asmc_ref_factor_launch(asmc_ctx* ctx, int d, const double* sum, const double* gram, double n_mean, double denom, double* out,
                            double* status, double* tab, double* em, int it, hipStream_t st) {
     const size_t lds = sizeof(double) * (size_t)d * (d + 1);
-    static size_t attr_lds = 0;
+    static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ref_factor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;

@@ -1012,7 +1012,7 @@ static int launch_pcn_flow_fused(asmc_ctx* ctx, int64_t n, double* ll, double* l
         const size_t par_bytes = (size_t)((n_tiles + 31) / 32) * 4;   /* the tiles' parity bits ride in LDS when they fit */ \
         const int par_words = (!FUSED_INPLACE && lds0 + par_bytes <= 160 * 1024) ? (int)(par_bytes / 4) : 0;                     \
         const size_t lds = lds0 + (size_t)par_words * 4;                                                                     \
-        static size_t attr_lds = 0;                                                                                      \
+        static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];                                                                                      \
         if (lds > 64 * 1024 && lds > attr_lds) {                                                                         \
             ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             attr_lds = lds;                                                                                              \

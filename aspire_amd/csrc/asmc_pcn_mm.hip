@@ -590,7 +590,7 @@ static int launch_mm(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, dou
                           : ((size_t)mm_ksum(D / 16) * 64 + D + (size_t)(pd.ll.C + pd.lp.C + pd.lq.C) * D * 2) * sizeof(double);
     ASMC_REQUIRE(lds <= 160 * 1024 - 256 - BM_TAB_N * sizeof(bm_d2), "operand image and density tables exceed the LDS");
     auto kern = k_pcn_mm<T, D, NOISE, MODE>;
-    static size_t attr_lds = 0;
+    static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;

@@ -195,7 +195,7 @@ int asmc_student_estep(asmc_ctx* ctx, int64_t m, int d, const double* xs, const 
     ASMC_HIP(hipMemcpyAsync(d_tab, h, sizeof(double) * ((size_t)d * (d + 1) / 2 + d), hipMemcpyHostToDevice, st));
     const size_t dpad = ((size_t)d + 3) & ~(size_t)3;  // the kernel walks four rows at a time (rows >= d are read, never used)
     const size_t lds = sizeof(double) * ((size_t)d * ST_ROWS + dpad * (dpad + 1) / 2);
-    static size_t attr_lds = 0;
+    static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_student_estep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
@@ -259,7 +259,7 @@ int asmc_student_fit(asmc_ctx* ctx, int64_t m, int d, const double* xs, int max_
     ASMC_HIP(hipMemsetAsync(d_zero, 0, sizeof(double) * d, st));
     const size_t dpad = ((size_t)d + 3) & ~(size_t)3;
     const size_t lds = sizeof(double) * ((size_t)d * ST_ROWS + dpad * (dpad + 1) / 2);
-    static size_t attr_lds = 0;
+    static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];
     if (lds > 64 * 1024 && lds > attr_lds) {
         ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_student_estep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;

@@ -1386,7 +1386,7 @@ int asmc_is_weights_launch(asmc_ctx* ctx, int64_t n, const double* ll, const dou
         if (g < grid) ctx->bar_base[1 + g] += (unsigned int)ISW_BARRIERS * (unsigned int)((grid - g + ISW_GROUPS - 1) / ISW_GROUPS);
     }
     if (reg) {
-        static bool attr_set = false;
+        static bool attr_set_dev[ASMC_MAX_DEVICES] = {false}; bool& attr_set = attr_set_dev[asmc_dev_slot(ctx)];
         if (!attr_set) {
             ASMC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_is_weights<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ISW_CHUNK * (int)sizeof(double)));

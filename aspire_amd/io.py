@@ -27,6 +27,14 @@ EMPTY_DICT_TOKEN = "__empty_dict__"
 _TOKENS = {NONE_TOKEN: lambda: None, EMPTY_DICT_TOKEN: dict}
 
 
+def h5py_available() -> bool:
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        return False
+    return True
+
+
 def open_h5(path, mode: str = "r"):
     """`h5py.File(path, mode)`, stamped with `aspire_version` when it is writable (the reference's `AspireFile`)."""
     try:

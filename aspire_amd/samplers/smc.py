@@ -764,7 +764,13 @@ class HipSMC(SMCSampler):
             logger.info("zuko adapter: the flow lives behind a data transform; it stays on its own modules")
             return None
         cache = self.__dict__.get("_zuko_cache")
-        key = id(inner)
+        # keyed on the parameters' in-place version counters and storage, not on the module's identity alone: a second fit()
+        # retrains the SAME module object in place, and id() values are reused after garbage collection
+        try:
+            key = (id(inner), tuple((p.data_ptr(), int(p._version)) for p in inner.parameters()),
+                   tuple((b.data_ptr(), int(b._version)) for b in inner.buffers()))
+        except Exception:
+            key = object()  # cannot tell whether the flow changed: rebuild (and cross-check) on every call
         if cache is None or cache[0] != key:
             from ..flows import MAFFlow
 

@@ -7,6 +7,7 @@ one full particle state - and the dataset layout its HDF5 writers produce (`dump
 The same checks run on the CPU test double here and on the HIP engine in tests/test_gpu_fullsize.py.
 """
 import json
+import os
 import pickle
 
 import numpy as np
@@ -233,6 +234,7 @@ def test_facade_sample_posterior_writes_the_reference_groups_through_the_h5py_pr
     from aspire_amd.io import load_from_h5_file, load_state
 
     monkeypatch.setattr(io, "open_h5", lambda path, mode="r": FakeFile(path, mode))
+    monkeypatch.setattr(io, "h5py_available", lambda: True)
     eng = OracleEngine()
     asp = _facade(eng)
     path = str(tmp_path / "facade_run.h5")
@@ -303,6 +305,7 @@ def test_facade_fit_checkpoint_saves_config_and_flow(monkeypatch, tmp_path):
     from aspire_amd.samples import Samples
 
     monkeypatch.setattr(io, "open_h5", lambda path, mode="r": FakeFile(path, mode))
+    monkeypatch.setattr(io, "h5py_available", lambda: True)
     d = 4
     asp = Aspire(log_likelihood=_log_like, log_prior=_log_like, dims=d, xp=np, flow_backend="coupling",
                  n_layers=2, hidden_features=(16, 16), seed=3)
@@ -349,3 +352,75 @@ def test_io_accepts_any_seekable_stream_and_set_leaves(tmp_path):
     g = FakeGroup()
     recursively_save_to_h5_file(g, "cfg", {"tags": {"only"}})
     assert load_from_h5_file(g, "cfg")["tags"] in ("{'only'}", ["{'only'}"])
+
+
+# ---- sharded runs: ONE writer for the shared groups of a checkpoint file ------------------------------------------
+def _ckpt_rank_worker(rank, world, port, out_dir):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fake_h5 import FakeFile
+    from oracle_engine import OracleEngine
+
+    from aspire_amd import Aspire, io
+    from aspire_amd.comm import TorchDistComm
+    from aspire_amd.samples import Samples
+
+    opened = []
+
+    def open_h5(path, mode="r"):
+        opened.append((str(path), mode))
+        return FakeFile(path, mode)
+
+    io.open_h5, io.h5py_available = open_h5, (lambda: True)
+    eng, comm, d = OracleEngine(), TorchDistComm(torch.device("cpu")), 3
+    asp = Aspire(log_likelihood=_log_like, log_prior=_log_like, dims=d, xp=np, flow_backend="coupling", n_layers=2,
+                 hidden_features=(16, 16), seed=3, parameters=[f"p{i}" for i in range(d)])
+    x = np.random.default_rng(0).normal(size=(256, d))
+    shared = os.path.join(out_dir, "run.h5")
+    asp.fit(Samples(x=x, xp=np), checkpoint_path=shared, n_epochs=1)
+    asp.sample_posterior(400, sampler="smc", checkpoint_path=shared, checkpoint_every=1, engine=eng, comm=comm,
+                         rng=np.random.default_rng(5), sampler_kwargs=dict(n_steps=2, step_fn="pcn"), store_sample_history=False)
+    # the pickle route (no h5py): per-rank state files, ONE sidecar
+    io.h5py_available = lambda: False
+    pk = os.path.join(out_dir, "other.h5")
+    asp.sample_posterior(400, sampler="smc", checkpoint_path=pk, engine=eng, comm=comm, rng=np.random.default_rng(5),
+                         sampler_kwargs=dict(n_steps=2, step_fn="pcn"), store_sample_history=False)
+    groups = sorted(FakeFile(shared, "r").keys()) if rank == 0 else []
+    with open(os.path.join(out_dir, f"opened{rank}.json"), "w") as f:
+        json.dump({"opened": opened, "groups": groups}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_checkpoint_files_have_one_writer_for_the_shared_groups(tmp_path):
+    """Two gloo ranks, `Aspire.fit` + `Aspire.sample_posterior(checkpoint_path=...)`: only rank 0 ever opens the shared file
+    (flow, aspire_config, sampler_config), every rank writes its sampler state to `<stem>.rank<r>.h5`; on the pickle route the
+    JSON sidecar has one writer and the states are per rank."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_ckpt_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    logs = [json.load(open(tmp_path / f"opened{r}.json")) for r in range(2)]
+    shared = str(tmp_path / "run.h5")
+    assert any(p == shared for p, _ in logs[0]["opened"]) and not any(p == shared for p, _ in logs[1]["opened"])
+    for r in range(2):
+        assert any(p == str(tmp_path / f"run.rank{r}.h5") for p, _ in logs[r]["opened"])
+        assert (tmp_path / f"other.rank{r}.pkl").exists()
+    assert {"aspire_config", "sampler_config", "flow"} <= set(logs[0]["groups"])
+    assert (tmp_path / "other.config.json").exists()
+    side = json.load(open(tmp_path / "other.config.json"))
+    assert side["sampler_config"]["sampler_type"] == "smc"
