@@ -279,6 +279,7 @@ def test_facade_checkpoint_path_without_h5py_takes_the_pickle_route(monkeypatch,
         raise RuntimeError("HDF5 files need h5py, which is not installed")
 
     monkeypatch.setattr(io, "open_h5", no_h5py)
+    monkeypatch.setattr(io, "h5py_available", lambda: False)
 
     eng = OracleEngine()
     for name in ("run.h5", "other.pkl"):
