@@ -117,6 +117,35 @@ def launch_ranks(n_gpus: int) -> int:
     return worst
 
 
+def derive_limiter(sq: dict | None, hbm_frac: float | None, mfma_frac_executed: float | None) -> dict:
+    """What bounds the dominant kernel, derived from the numbers the line carries: the SQ counters of the committed profile (fractions
+    of SIMD time / of wave cycles; None when the kernel sources have moved on since they were collected) and the two measured
+    rates of this run.  The largest share names the limiter; the shares and the rule travel with it."""
+    shares = {}
+    if sq:
+        for key, label in (("valu_active", "vector-ALU issue"), ("mfma_busy", "matrix pipe busy"),
+                           ("wait_any_of_wave_cycles", "waves parked at s_waitcnt / barriers"),
+                           ("wait_inst_any_of_wave_cycles", "issue stalls (dependencies, pipe busy)")):
+            if sq.get(key) is not None:
+                shares[label] = float(sq[key])
+    if hbm_frac is not None:
+        shares["HBM bandwidth (algorithmic bytes / peak)"] = float(hbm_frac)
+    if mfma_frac_executed is not None:
+        shares["matrix-pipe arithmetic (executed flops / dense peak)"] = float(mfma_frac_executed)
+    if not shares:
+        return {"name": None, "shares": {}, "rule": "no counters"}
+    name = max(shares, key=shares.get)
+    v, m = shares.get("vector-ALU issue"), shares.get("matrix pipe busy")
+    out = {"name": name, "shares": {k: round(x, 4) for k, x in sorted(shares.items(), key=lambda kv: -kv[1])},
+           "rule": "largest share; SQ shares are fractions of SIMD time (valu_active, mfma_busy) or of wave cycles (waits) from "
+                   "profiles/sq_counters.json, the two rates are measured in this run",
+           "counters_current": bool(sq)}
+    if v is not None and m is not None:
+        # the mix bound of DESIGN 3.1: an fp16 MFMA hides about half of a partner wave's vector work, so time >= V + other issue + M / 2
+        out["valu_plus_half_mfma"] = round(v + 0.5 * m, 4)
+    return out
+
+
 def main():
     # `--gpus N` without a launcher around it: become the launcher, before anything touches the GPU
     if "WORLD_SIZE" not in os.environ:
@@ -229,9 +258,11 @@ def main():
 
     flow_math = "f32-mfma" if os.environ.get("ASMC_FLOW_MATH") == "f32" else "f16x2-split"
 
-    def run(seed: int, n=n_global, flow=cflow, step_fn=args.step_fn, noise=args.noise, steps=n_mc, comm_=None):
-        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=eng, comm=comm_ or comm,
-                    rng=np.random.default_rng(seed), dtype=xname)
+    def run(seed: int, n=n_global, flow=cflow, step_fn=args.step_fn, noise=args.noise, steps=n_mc, comm_=None, x_dtype=xname,
+            targets=None, xp_=np):
+        t_ll, t_lp = targets or (lik, lik)
+        sp = HipSMC(log_likelihood=t_ll, log_prior=t_lp, dims=d, prior_flow=flow, xp=xp_, engine=eng, comm=comm_ or comm,
+                    rng=np.random.default_rng(seed), dtype=x_dtype)
         sp.shard_layout = args.shard_layout
         post = sp.sample(n, sampler_kwargs=dict(n_steps=steps, noise=noise, step_fn=step_fn), store_sample_history=False,
                          resample_mode=args.resample_mode)
@@ -359,7 +390,8 @@ def main():
         "traffic": traffic, "traffic_source": traffic_src,
         "traffic_over_algorithmic": round(traffic / b_pcn, 3) if traffic else None,
         # what limits it (rocprofv3 --pmc SQ counters of the committed profile, fractions of SIMD time): the vector ALU
-        "limiter": "instruction issue: vector ALU (fp64 noise, the flow's ReLU / hi-lo conversions and epilogues) + about half of the matrix-pipe time - an fp16 MFMA hides about half of a partner wave's vector work on this chip, an fp64 MFMA none (DESIGN 3.1 / 3.8): some instruction issues for 0.79 of SIMD time, the idle 0.21 is matrix time nobody can issue beside",
+        "limiter": derive_limiter(sq, b_pcn / (flow_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if flow_ms else None,
+                                  exec_flops / (flow_ms * 1e-3) / 1e12 / exec_peak if flow_ms else None),
         "valu_active": sq.get("valu_active") if sq else None, "mfma_busy": sq.get("mfma_busy") if sq else None,
         "valu_insts_per_64_particle_tile": sq.get("valu_insts_per_tile") if sq else None,
         "sq_counters_source": sq_src, "kernel_source_hash": src_hash,
@@ -709,6 +741,118 @@ def main():
                 eng5.close()
         except Exception as exc:
             extra["config5_step"] = {"error": repr(exc)}
+        # (d6) BASELINE configs[4] END TO END on one GPU: 1M x 128, equal-weight mixture of two Gaussians
+        #      (mu = +-2, cov 1/2 I and I: examples/smc_example.py:34-53 lifted to d = 128), prior N(0, I), q = N(0, 3^2 I), adaptive
+        #      tempering, the reference's default step (tpCN), n_mc steps per temperature, default noise; log Z against the closed form
+        try:
+            d5 = 128
+            eng5 = eng if eng.d_max >= d5 else HipEngine(local_rank, n_max=n_local, d_max=d5)
+            lik5 = DiagGaussianMixture(np.stack([2 * np.ones(d5), -2 * np.ones(d5)]), np.stack([0.5 * np.ones(d5), np.ones(d5)]))
+            pri5 = DiagGaussianMixture.isotropic(d5, 0.0, 1.0)
+
+            def lg5(mu_, var_):
+                return -0.5 * d5 * np.log(2 * np.pi * var_) - 0.5 * d5 * mu_ * mu_ / var_
+
+            true5 = float(np.logaddexp(np.log(0.5) + lg5(2.0, 1.5), np.log(0.5) + lg5(2.0, 2.0)))
+
+            def run5(nn, seed_):
+                sp5 = HipSMC(log_likelihood=lik5, log_prior=pri5, dims=d5, prior_flow=GaussianFlow(d5, sigma=3.0, engine=eng5, seed=4, dtype=xdt),
+                             xp=np, engine=eng5, rng=np.random.default_rng(seed_), dtype=xname)
+                return sp5, sp5.sample(nn, sampler_kwargs=dict(n_steps=n_mc, step_fn="tpcn", noise=args.noise), store_sample_history=False)
+
+            run5(65536, 1)
+            torch.cuda.synchronize()
+            eng5.profile(True)
+            t0 = time.perf_counter()
+            sp5, post5 = run5(n_local, 2)
+            torch.cuda.synchronize()
+            t5 = time.perf_counter() - t0
+            k5r = eng5.profile_report()
+            eng5.profile(False)
+            nt5 = len(sp5.history.beta)
+            sk5 = next((k for k in k5r if k.startswith(("k_tpcn_mm_step", "k_pcn_mm_step"))), None)
+            ms5 = k5r[sk5][1] if sk5 else None
+            busy5 = sum(c * ms for c, ms in k5r.values())
+            conv5 = {k: round(c * ms / nt5, 4) for k, (c, ms) in k5r.items() if "whiten" in k}
+            extra["config5_run"] = {
+                "workload": f"configs[4] on one GPU: {n_local} x {d5}, two-component mixture likelihood, N(0, I) prior, q = N(0, 9 I), adaptive "
+                            f"tempering, tpCN, {n_mc} steps per temperature, {args.noise} noise",
+                "wall_s": round(t5, 4), "temperatures": nt5, "particle_steps_per_s": n_local * nt5 * n_mc / t5,
+                "log_evidence": float(post5.log_evidence), "log_evidence_closed_form": true5,
+                "log_evidence_error": float(post5.log_evidence_error),
+                "abs_err_in_sigma": abs(float(post5.log_evidence) - true5) / max(float(post5.log_evidence_error), 1e-300),
+                "mean_accept": float(np.mean(sp5.history.mcmc_acceptance)),
+                "step_kernel": sk5, "step_us": round(ms5 * 1e3, 1) if ms5 else None,
+                "step_launches": int(k5r[sk5][0]) if sk5 else 0,
+                "algorithmic_bytes_per_particle_step": 2 * d5 * s_bytes + 16,
+                "hbm_frac": round((2 * d5 * s_bytes + 16) * n_local / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms5 else None,
+                "gpu_busy_over_wall": round(busy5 * 1e-3 / t5, 4),
+                "state_conversion_ms_per_temperature": conv5,
+                "mutation_path": getattr(sp5, "last_mutation_path", None)}
+            if eng5 is not eng:
+                eng5.close()
+        except Exception as exc:
+            extra["config5_run"] = {"error": repr(exc)}
+        # (d7) the headline workload with fp32 STATE ("x fp64 and fp32 variants"; log-probabilities stay fp64, H7):
+        #      algorithmic bytes per particle-step 2 d 4 + 16 = 272
+        try:
+            other = "float32" if xname == "float64" else "float64"
+            run(3, n=min(n_global, 65536 * world), steps=2, x_dtype=other)
+            sync_all()
+            eng.profile(True)
+            t0 = time.perf_counter()
+            sp32, post32 = run(4, x_dtype=other)
+            sync_all()
+            t32 = time.perf_counter() - t0
+            k32 = eng.profile_report()
+            eng.profile(False)
+            fk32 = next((k for k in k32 if k.startswith("k_pcn_flow_fused")), None)
+            b32 = (2 * d * (4 if other == "float32" else 8) + 16) * n_local
+            extra["headline_x_f32" if other == "float32" else "headline_x_f64"] = {
+                "x_dtype": other, "wall_s": round(t32, 4), "temperatures": len(sp32.history.beta),
+                "particle_steps_per_s": n_global * len(sp32.history.beta) * n_mc / t32,
+                "log_evidence": float(post32.log_evidence),
+                "abs_err_in_sigma": abs(float(post32.log_evidence) - true_logz) / max(float(post32.log_evidence_error), 1e-300),
+                "mean_accept": float(np.mean(sp32.history.mcmc_acceptance)),
+                "step_kernel": fk32, "step_us": round(k32[fk32][1] * 1e3, 2) if fk32 else None,
+                "algorithmic_bytes_per_launch": b32,
+                "hbm_frac": round(b32 / (k32[fk32][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if fk32 else None,
+                "returned_x_dtype": str(getattr(post32.x, "dtype", None))}
+        except Exception as exc:
+            extra["headline_x_f32"] = {"error": repr(exc)}
+        # (d8) the headline workload with Python CALLABLES as the densities (the path every user of the reference's seam takes:
+        #      smc/base.py:507-519 calls log_prior, then log_likelihood, on a Samples-like object each step): torch callables on the
+        #      device rows, the trained coupling flow as the proposal; the library's launches per step are counted from its own
+        #      events, the callables' torch ops ride between them
+        try:
+            def t_like(smp):
+                return -0.5 * (smp.x * smp.x).sum(1)
+
+            run(3, n=min(n_global, 65536 * world), steps=2, targets=(t_like, t_like), xp_=torch)
+            sync_all()
+            eng.profile(True)
+            t0 = time.perf_counter()
+            spc, postc = run(4, targets=(t_like, t_like), xp_=torch)
+            sync_all()
+            tc_ = time.perf_counter() - t0
+            kc = eng.profile_report()
+            eng.profile(False)
+            ntc = len(spc.history.beta)
+            lib_launches = sum(c for c, _ in kc.values())
+            lev = postc.log_evidence
+            extra["callables_run"] = {
+                "what": "configs[2] with torch-callable log_likelihood / log_prior (split path: propose kernel -> flow density -> callables -> accept kernel)",
+                "wall_s": round(tc_, 4), "temperatures": ntc, "particle_steps_per_s": n_global * ntc * n_mc / tc_,
+                "ms_per_step": round(tc_ / (ntc * n_mc) * 1e3, 4),
+                "library_launches_per_step": round(lib_launches / (ntc * n_mc), 2),
+                "library_gpu_ms_per_step": round(sum(c * ms for c, ms in kc.values()) / (ntc * n_mc), 4),
+                "log_evidence": float(lev), "abs_err_in_sigma": abs(float(lev) - true_logz) / max(float(postc.log_evidence_error), 1e-300),
+                "mean_accept": float(np.mean(spc.history.mcmc_acceptance)),
+                "likelihood_evaluations": int(spc.n_likelihood_evaluations),
+                "mutation_path": getattr(spc, "last_mutation_path", None),
+                "top_kernels_us": {k: [int(c), round(ms * 1e3, 1)] for k, (c, ms) in sorted(kc.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:6]}}
+        except Exception as exc:
+            extra["callables_run"] = {"error": repr(exc)}
         # (e) the headline run with the flow on the fp32 MFMA chain (v_mfma_f32_32x32x2_f32) instead of the default split-fp16
         #     products: same operands to fp32 accuracy, 16/3 of the matrix-pipe time
         if flow_math == "f16x2-split":

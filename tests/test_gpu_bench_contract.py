@@ -31,8 +31,18 @@ def test_bench_prints_one_json_line_with_roofline_cpu_baseline_and_extra_legs():
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"] and cb["unit"] == j["unit"]
     legs = j["extra"]
-    for name in ("is_only_step", "fused_step_by_regime", "flow_run_maf", "flow_run_f32_mfma", "sharded_path_one_rank_group"):
+    for name in ("is_only_step", "fused_step_by_regime", "flow_run_maf", "flow_run_f32_mfma", "sharded_path_one_rank_group",
+                 "config5_run", "headline_x_f32", "callables_run"):
         assert name in legs and "error" not in legs[name], (name, legs.get(name))
+    # round 6 legs: configs[4] end to end (tpCN, d = 128), the headline with fp32 state, the headline with callable densities
+    c5 = legs["config5_run"]
+    assert c5["step_kernel"].startswith("k_tpcn_mm_step") and c5["temperatures"] > 5 and c5["abs_err_in_sigma"] < 5 and 0 < c5["hbm_frac"] < 1
+    f32 = legs["headline_x_f32"]
+    assert f32["x_dtype"] == "float32" and f32["step_kernel"].startswith("k_pcn_flow_fused") and "float32" in f32["returned_x_dtype"] and f32["abs_err_in_sigma"] < 5
+    cal = legs["callables_run"]
+    assert cal["ms_per_step"] > 0 and cal["library_launches_per_step"] >= 2 and "callables" in cal["mutation_path"] and cal["abs_err_in_sigma"] < 5
+    lim = rf["limiter"]
+    assert isinstance(lim, dict) and lim["name"] in lim["shares"] and lim["shares"][lim["name"]] == max(lim["shares"].values())
     assert legs["sharded_path_one_rank_group"]["importance_step_as_one_chain"] is True
     assert legs["flow_run_maf"]["torch_ops_in_mutation_loop"] == 0
 

@@ -27,7 +27,7 @@ def run(nn, profile):
     eng.profile(profile)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = sp.sample(nn, sampler_kwargs=dict(n_steps=steps, noise=os.environ.get("NOISE", "f32")), store_sample_history=False)
+    out = sp.sample(nn, sampler_kwargs=dict(n_steps=steps, noise=os.environ.get("NOISE", "f32"), step_fn=os.environ.get("STEP_FN", "tpcn")), store_sample_history=False)
     torch.cuda.synchronize()
     return sp, out, time.perf_counter() - t0
 
@@ -48,5 +48,5 @@ nt = len(sp.history.beta)
 print(f"N={n} d={d}: wall {dt:.3f} s, {nt} temperatures x {steps} pCN steps = {n*nt*steps/dt/1e9:.3f} G particle-steps/s")
 print(f"log Z = {float(out.log_evidence):.4f} +- {float(out.log_evidence_error):.4f}   closed form {true:.4f}   "
       f"mean accept {np.mean(sp.history.mcmc_acceptance):.3f}")
-for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:10]:
+for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:int(os.environ.get("TOP", 10))]:
     print(f"  {k:24s} n={v[0]:5d} avg_us={v[1]*1e3:9.1f} total_ms={v[0]*v[1]:8.2f}")
