@@ -194,7 +194,9 @@ __global__ __launch_bounds__(THREADS) void k_flow16_logprob(int64_t n, int d, co
             const float xv = (valid && j >= 0) ? (float)x[row * d + j] : 0.0f;
             xf.set(s, j >= 0 ? flow_standardise(xv, s_loc[s * 4 + h], s_loc[D + s * 4 + h], s_loc[2 * D + s * 4 + h]) : 0.0f);
         }
-        const float val = f16_logprob<FD, W, THREADS>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, FD::MAF ? form : 0);
+        // (the affine form as a compile-time constant of each branch: asmc_flow16_dev.h f16_layer)
+        const float val = (!FD::MAF || form == 0) ? f16_logprob<FD, W, THREADS, 0>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, 0)
+                                                  : f16_logprob<FD, W, THREADS, 1>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, 1);
         if (valid && h == 0) out[row] = (double)val;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the chunk the last next() put into flight
@@ -420,7 +422,11 @@ __global__ __launch_bounds__(THREADS, 2) void k_pcn_flow16(int64_t n, T* __restr
 #pragma unroll
         for (int m = 0; m < KS / 4; m++) {
             double zz[4];
-            const uint32_t blk = (uint32_t)(2 * (2 * m + (h & 1)) + (h >> 1));
+            uint32_t blk = (uint32_t)(2 * (2 * m + (h & 1)) + (h >> 1));
+            // D = 128 sits at the register limit: left alone, the compiler hoists the parts of each block's first Philox round that do
+            // not change from round to round out of the loop over the rounds - eight blocks' worth of lane-dependent values, which it
+            // then spills and reloads with a full wait in front of every block.  An opaque block index keeps them inside the loop.
+            if constexpr (D == 128) asm volatile("" : "+v"(blk));
             if (NOISE == ASMC_NOISE_F32) {
                 float f0, f1, f2, f3;
                 normal_quad_f32_raw(p.seed, gid, step, blk, f0, f1, f2, f3);
@@ -469,7 +475,8 @@ __global__ __launch_bounds__(THREADS, 2) void k_pcn_flow16(int64_t n, T* __restr
         double k_new = c1, k_old = lpo + c0, k_ll = nll, k_lp = nlp, k_lu = logu;
         asm volatile("" : "+v"(k_new), "+v"(k_old), "+v"(k_ll), "+v"(k_lp), "+v"(k_lu));
         __builtin_amdgcn_sched_barrier(0);
-        const double nlq = (double)f16_logprob<FD, W, THREADS>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, FD::MAF ? form : 0);
+        const double nlq = (!FD::MAF || form == 0) ? (double)f16_logprob<FD, W, THREADS, 0>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, 0)
+                                                   : (double)f16_logprob<FD, W, THREADS, 1>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, 1);
         __builtin_amdgcn_sched_barrier(0);
         if (valid && h == 0 && !(fabs(nlq) < INFINITY)) n_bad++;
         const double lpn = log_p_t(k_ll, k_lp, nlq, p.beta);
@@ -514,7 +521,13 @@ static size_t f16_step_lds(int n_layers, int c_ll, int c_lp, int noise) {
 }
 
 // shapes of the one-kernel step (every instantiation is x 2 state dtypes x 2 noise generators x pCN / tpCN)
+#ifdef F16_DIAG_ONLY_D128  // diagnostic builds (register / spill experiments): the D = 128 steps alone, seconds instead of minutes
+#define F16_STEP_SHAPES(X) X(ASMC_FLOW_COUPLING, 128, 64) X(ASMC_FLOW_MAF, 128, 64)
+#elif defined(F16_DIAG_ONLY_D64)
+#define F16_STEP_SHAPES(X) X(ASMC_FLOW_COUPLING, 64, 64)
+#else
 #define F16_STEP_SHAPES(X) X(ASMC_FLOW_COUPLING, 64, 64) X(ASMC_FLOW_COUPLING, 128, 64) X(ASMC_FLOW_MAF, 64, 64) X(ASMC_FLOW_MAF, 128, 64)
+#endif
 
 // whether the one-kernel step takes this mutation (prm->d is the PADDED dimension 64 / 128; the flow keeps its own dims)
 bool asmc_pcn_flow16_ok(const asmc_pcn_params* prm, const asmc_coupling* f) {

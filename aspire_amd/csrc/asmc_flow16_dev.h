@@ -197,11 +197,18 @@ __device__ __forceinline__ void f16_dense(floatx4 (&acc)[NBC], const half8 (&bh)
 // with the layer); an autoregressive transform passes the same array twice for the density (every conditioner input is
 // converted before the first coordinate changes) and (current estimate, latent copy) for a pass of its inversion.
 // INVERSE: the sampling direction x_b = z_b exp(s) + t.
-template <class FD, int W, int THREADS, bool INVERSE = false>
+// FORM: the affine form (asmc_flow_dev.h flow_affine) as a compile-time constant, or -1: the run-time argument `form` (a uniform
+// branch per coordinate then sits between the output layer's matrix instructions and cuts the scheduler's blocks: the density
+// kernels pass the constant).
+template <class FD, int W, int THREADS, bool INVERSE = false, int FORM = -1>
 __device__ __forceinline__ void f16_layer(const float (&cond)[FD::CS], float (&trans)[FD::CS], const float* __restrict__ bias,
                                           Flow16Stream<FD, THREADS>& stream, int lane, float& ladj, unsigned& amax_pk, int form = 0) {
     constexpr int KS1 = FD::KS1, KS2 = FD::KS2, NB1 = FD::NB1;
     // ---- first dense layer: conditioner slots -> hidden 1
+    // (The operand is converted IN FRONT of the stream's barrier, never right in front of the products: the lo halves are written by
+    // inline assembly (split2_f16), which the compiler's hazard recogniser does not see - placed behind the barrier, the register
+    // allocator reused a first product's bias accumulator (SrcC, still being read by the matrix pipe) as their destination and the
+    // first layer came out wrong; round 6, found by tools/debug_flow16_step_lq.py.)
     half8 bh1[KS1], bl1[KS1];
 #pragma unroll
     for (int S = 0; S < KS1; S++) {
@@ -247,6 +254,17 @@ __device__ __forceinline__ void f16_layer(const float (&cond)[FD::CS], float (&t
         for (int j = 0; j < 8; j++) v[j] = h2[2 * S + j / 4][j % 4];
         f16_split8<true>(v, bh2[S], bl2[S], amax_pk);
     }
+    // The epilogue of a pair (exp / rcp chains: vector and transcendental work) is written BEHIND the matrix instructions of the next
+    // pair, which it does not depend on - one basic block, so the scheduler places it between them (round 6; round 5 ran every
+    // pair's epilogue between two bursts of matrix instructions: 12 MFMAs, ~90 vector instructions with their wait states, ...).
+    floatx4 po[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    auto epilogue = [&](const floatx4 (&o)[2], int m) {  // the lane's transformed slots 4 m .. 4 m + 3
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float sraw = o[0][r], tt = o[1][r];
+            flow_affine<INVERSE>(trans[4 * m + r], sraw, tt, ladj, FORM >= 0 ? FORM : form);  // (asmc_flow_dev.h: form 0 = 2 tanh(sraw / 2); 1 = zuko's soft clip)
+        }
+    };
 #pragma unroll
     for (int p = 0; p < FD::P3; p++) {
         const float* A = FD::WHOLE ? Aw + FD::A1 + FD::A2 + (size_t)p * FD::BC3 * FD::BLK2 : stream.next();
@@ -254,14 +272,12 @@ __device__ __forceinline__ void f16_layer(const float (&cond)[FD::CS], float (&t
         for (int pr = 0; pr < FD::BC3 / 2; pr++) {
             floatx4 o[2];
             f16_dense<2, KS2>(o, bh2, bl2, A + (size_t)pr * 2 * FD::BLK2, bias + 2 * W + (p * FD::BC3 + 2 * pr) * 16, lane);
-            const int m = p * (FD::BC3 / 2) + pr;  // the lane's transformed slots 4 m .. 4 m + 3
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float sraw = o[0][r], tt = o[1][r];
-                flow_affine<INVERSE>(trans[4 * m + r], sraw, tt, ladj, form);  // (asmc_flow_dev.h: form 0 = 2 tanh(sraw / 2); 1 = zuko's soft clip)
-            }
+            const int m = p * (FD::BC3 / 2) + pr;
+            if (m > 0) epilogue(po, m - 1);
+            po[0] = o[0], po[1] = o[1];
         }
     }
+    epilogue(po, FD::P3 * (FD::BC3 / 2) - 1);
 }
 
 // the lane's standardised coordinates: slot s of the lane is a[s] (autoregressive flows: every slot; coupling flows: the
@@ -290,23 +306,23 @@ __device__ __forceinline__ float f16_quad_max(float q) {
 }
 
 // log q of the group's particles from the lane's standardised coordinates (every lane of a particle returns it)
-template <class FD, int W, int THREADS>
+template <class FD, int W, int THREADS, int FORM = -1>
 __device__ __forceinline__ float f16_logprob(F16State<FD>& x, int n_layers, const float* __restrict__ biases,
                                              Flow16Stream<FD, THREADS>& stream, int lane, float ladj0, float base_const, int form = 0) {
     float ladj = 0.0f;
     unsigned amax_pk = 0u;
     for (int c = 0; c < n_layers; c += 2) {  // (n_layers is uniform over the block: every wave meets the same barriers)
         if constexpr (FD::MAF) {
-            f16_layer<FD, W, THREADS>(x.a, x.a, biases + c * FD::BIAS, stream, lane, ladj, amax_pk, form);
+            f16_layer<FD, W, THREADS, false, FORM>(x.a, x.a, biases + c * FD::BIAS, stream, lane, ladj, amax_pk, form);
         } else {
-            f16_layer<FD, W, THREADS>(x.a, x.b, biases + c * FD::BIAS, stream, lane, ladj, amax_pk);
+            f16_layer<FD, W, THREADS, false, 0>(x.a, x.b, biases + c * FD::BIAS, stream, lane, ladj, amax_pk);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < n_layers) {
             if constexpr (FD::MAF) {
-                f16_layer<FD, W, THREADS>(x.a, x.a, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk, form);
+                f16_layer<FD, W, THREADS, false, FORM>(x.a, x.a, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk, form);
             } else {
-                f16_layer<FD, W, THREADS>(x.b, x.a, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk);
+                f16_layer<FD, W, THREADS, false, 0>(x.b, x.a, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
