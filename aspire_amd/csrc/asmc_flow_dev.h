@@ -542,7 +542,9 @@ __device__ __forceinline__ void coupling_layer_hs2(const float (&condA)[H / 2], 
 // (64 registers) in the register file across the flow instead of parking it in HBM.  PREFETCH: the A operands of group g + 1 are
 // read from LDS while group g's MFMAs issue (16 more registers at W = 64).
 // Same operations in the same order per accumulator as coupling_layer_hs / _hs2: bit-identical results.
-template <int H, int W, bool PREFETCH = true>
+// FORM: the affine form (flow_affine) as a compile-time constant, or -1 for the run-time argument (then every coordinate of the epilogue
+// carries a uniform branch).
+template <int H, int W, bool PREFETCH = true, int FORM = -1>
 __device__ __forceinline__ void coupling_layer_hs1p(const float (&cond)[H / 2], float (&trans)[H / 2], const float* __restrict__ lp,
                                                     int lane, int hh, float& ladj, unsigned& amax, int form = 0) {
     using FD = FlowDims<H, W>;
@@ -639,7 +641,7 @@ __device__ __forceinline__ void coupling_layer_hs1p(const float (&cond)[H / 2], 
     for (int q = 0; q < H / 2; q++) {
         const float sraw = o[q / 16][q % 16];
         const float t = o[(H / 2 + q) / 16][(H / 2 + q) % 16];
-        flow_affine<false>(trans[q], sraw, t, ladj, form);  // (form 0: 2 tanh(sraw / 2), see coupling_layer)
+        flow_affine<false>(trans[q], sraw, t, ladj, FORM >= 0 ? FORM : form);  // (form 0: 2 tanh(sraw / 2), see coupling_layer)
     }
 }
 

@@ -698,14 +698,17 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
 #endif
             STAMP(4);
             tn_l = tile_fetch();  // the next tile's index: back long before the flow is through
-            auto maf_tile = [&](float(&xv)[16]) __attribute__((always_inline)) -> float {
+            // (the affine form - asmc_coupling.affine, autoregressive flows - reaches the layers as a compile-time constant: a run-time
+            // argument is a uniform branch per coordinate inside the epilogue; round 6)
+            auto maf_tile = [&](float(&xv)[16], auto form_c) __attribute__((always_inline)) -> float {
+                constexpr int FORM = decltype(form_c)::value;
                 float ladj = 0.0f;
                 unsigned amax_pk = 0u;
                 for (int c = 0; c < n_layers; c++) {
                     float cond[16];
 #pragma unroll
                     for (int r = 0; r < 16; r++) cond[r] = xv[r];
-                    coupling_layer_hs1p<HF, W, false>(cond, xv, sp + (size_t)c * FD::LAYER, lane, hh, ladj, amax_pk, affine);  // (affine: asmc_coupling.affine, autoregressive flows)
+                    coupling_layer_hs1p<HF, W, false, FORM>(cond, xv, sp + (size_t)c * FD::LAYER, lane, hh, ladj, amax_pk, FORM);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 float amax = range_pk_max(amax_pk);
@@ -717,10 +720,17 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
                 amax = fmaxf(amax, __shfl_xor(amax, 32));
                 return !(amax < FLOW_HS_MAX) ? __builtin_nanf("") : (-0.5f * q + base_const) + (ladj0 + lj);
             };
-            lqt[0] = maf_tile(xA);
-            __builtin_amdgcn_sched_barrier(0);  // one tile's accumulator chains at a time
-            STAMP(5);
-            lqt[1] = maf_tile(xB);
+            if (affine == 0) {  // (wave uniform)
+                lqt[0] = maf_tile(xA, std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);  // one tile's accumulator chains at a time
+                STAMP(5);
+                lqt[1] = maf_tile(xB, std::integral_constant<int, 0>{});
+            } else {
+                lqt[0] = maf_tile(xA, std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(5);
+                lqt[1] = maf_tile(xB, std::integral_constant<int, 1>{});
+            }
         } else {
         // (two explicit calls: as a loop over the tiles the flow's A-operand reads become loop invariant and LLVM hoists
         // all 448 of them in front of it)

@@ -1,5 +1,5 @@
 """Micro-driver of the flow-proposal mutation step (asmc_pcn_mutate_flow) at 1M x 32: timing per step and the per-kernel
-HIP-event table; used under rocprofv3 --pmc by tools/pmc_flowstep.sh.  NOISE=f64|f32, STEPS, N, RHO, ADAPT env."""
+HIP-event table; used under rocprofv3 --pmc by tools/pmc_flowstep.sh.  NOISE=f64|f32, STEPS, N, RHO, ADAPT, KIND=coupling|maf env."""
 import os
 import sys
 
@@ -9,7 +9,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from conftest import random_coupling_flow  # noqa: E402
+from conftest import random_coupling_flow, random_maf_flow  # noqa: E402
 
 from aspire_amd.engine import HipEngine  # noqa: E402
 from aspire_amd.flows import GaussianFlow  # noqa: E402
@@ -21,7 +21,7 @@ def main():
     steps, noise = int(os.environ.get("STEPS", 16)), os.environ.get("NOISE", "f64")
     rho0, adapt = float(os.environ.get("RHO", 0.3)), os.environ.get("ADAPT", "1") == "1"  # RHO=0.02 ADAPT=0: ~98 % acceptance
     eng = HipEngine(0, n_max=n, d_max=32)
-    flow = random_coupling_flow(d, 4, 64)
+    flow = random_maf_flow(d, 3, 64) if os.environ.get("KIND", "coupling") == "maf" else random_coupling_flow(d, 4, 64)
     dev = flow.device_coupling(eng)
     lik = DiagGaussianMixture.isotropic(d, normalized=False)
     g = GaussianFlow(d, sigma=0.8, seed=3, engine=eng)
