@@ -292,10 +292,12 @@ __global__ __launch_bounds__(FLOW_THREADS) void k_maf_logprob(int64_t n, int d, 
             float cond[1][DL];
 #pragma unroll
             for (int i = 0; i < DL; i++) cond[0][i] = xv[0][i];
-            if constexpr (HS)
-                coupling_layer_hs<H, W>(cond[0], xv[0], lp, lane, hh, ladj[0], amax, form);
-            else
+            if constexpr (HS) {  // (the affine form as a compile-time constant of each branch: no per-coordinate branch in the epilogue)
+                if (form == 0) coupling_layer_hs<H, W, false, 0>(cond[0], xv[0], lp, lane, hh, ladj[0], amax, 0);
+                else coupling_layer_hs<H, W, false, 1>(cond[0], xv[0], lp, lane, hh, ladj[0], amax, 1);
+            } else {
                 coupling_layer<H, W, 1>(cond, xv, lp, lane, hh, ladj, form);
+            }
         }
         float q = 0.0f;
 #pragma unroll

@@ -302,7 +302,7 @@ __device__ __forceinline__ void acc_bias1(floatx16 (&acc)[NB], const float* __re
 // one coupling layer of one 32-particle tile: cond / trans are the lane half's H / 2 coordinates
 // INVERSE: the sampling direction, x_b = z_b exp(s) + t (flows.py _Coupling.inverse); ladj collects -s in both directions, so
 // that base(z) + ladj is log q of the sample as well
-template <int H, int W, bool INVERSE = false>
+template <int H, int W, bool INVERSE = false, int FORM = -1>  // (FORM: see coupling_layer_hs1p)
 __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], float (&trans)[H / 2], const float* __restrict__ lp,
                                                   int lane, int hh, float& ladj, float& amax, int form = 0) {
     using FD = FlowDims<H, W>;
@@ -352,7 +352,7 @@ __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], fl
     for (int q = 0; q < H / 2; q++) {
         const float sraw = o[q / 16][q % 16];
         const float t = o[(H / 2 + q) / 16][(H / 2 + q) % 16];
-        flow_affine<INVERSE>(trans[q], sraw, t, ladj, form);  // (form 0: s = 2 tanh(sraw / 2), see coupling_layer)
+        flow_affine<INVERSE>(trans[q], sraw, t, ladj, FORM >= 0 ? FORM : form);  // (form 0: s = 2 tanh(sraw / 2), see coupling_layer)
     }
 }
 

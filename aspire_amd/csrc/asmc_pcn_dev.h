@@ -345,16 +345,25 @@ __device__ __forceinline__ double tpcn_scale_ct(double rho, double nu, double q0
     if (!TP) return rho;
     return rho * sqrt((nu + q0) / (2.0 * gam[i]));
 }
+// log(1 + x) for x >= 0 - the Student-t reference's correction, x = |y|^2 / nu, twice per particle and step of the reference's default
+// step (tpCN) - by the noise generator's table-free log on fl(1 + x) (round 6).  The rounding of 1 + x is an absolute 1.1e-16 in the
+// result, which enters the accept test through a difference of O(1) terms; the device library's log1p spends about 150 vector
+// instructions on ranges and signs this argument never has.  Non-finite arguments propagate as log1p propagates them.
+__device__ __forceinline__ double log1p_nonneg(double x) {
+    const double u = 1.0 + x;
+    const double r = bm_log_unit(u);
+    return u < INFINITY ? r : u;
+}
 template <bool TP>
 __device__ __forceinline__ double ref_corr_ct(double q, double nu, int d) {
     if (!TP) return 0.5 * q;
-    return 0.5 * ((double)d + nu) * log1p(q / nu);
+    return 0.5 * ((double)d + nu) * log1p_nonneg(q / nu);
 }
 
 template <bool TP = true>
 __device__ __forceinline__ double ref_corr(double q, double nu, int d) {
     if (!TP) return 0.5 * q;
-    return nu > 0.0 ? 0.5 * ((double)d + nu) * log1p(q / nu) : 0.5 * q;
+    return nu > 0.0 ? 0.5 * ((double)d + nu) * log1p_nonneg(q / nu) : 0.5 * q;
 }
 
 struct MixDev {
