@@ -526,7 +526,12 @@ static size_t f16_step_lds(int n_layers, int c_ll, int c_lp, int noise) {
 #elif defined(F16_DIAG_ONLY_D64)
 #define F16_STEP_SHAPES(X) X(ASMC_FLOW_COUPLING, 64, 64)
 #else
-#define F16_STEP_SHAPES(X) X(ASMC_FLOW_COUPLING, 64, 64) X(ASMC_FLOW_COUPLING, 128, 64) X(ASMC_FLOW_MAF, 64, 64) X(ASMC_FLOW_MAF, 128, 64)
+// (hidden widths 32 and 128 since round 6 - the reference forwards any `hidden_features`, flows/torch/flows.py:164; width 128 keeps
+// 64 more activation registers per lane than width 64 and spills at D = 128: one kernel, but not the speed of the default width)
+#define F16_STEP_SHAPES(X)                                                                                                          \
+    X(ASMC_FLOW_COUPLING, 64, 64) X(ASMC_FLOW_COUPLING, 128, 64) X(ASMC_FLOW_MAF, 64, 64) X(ASMC_FLOW_MAF, 128, 64)                  \
+    X(ASMC_FLOW_COUPLING, 64, 32) X(ASMC_FLOW_COUPLING, 128, 32) X(ASMC_FLOW_MAF, 64, 32) X(ASMC_FLOW_MAF, 128, 32)                  \
+    X(ASMC_FLOW_COUPLING, 64, 128) X(ASMC_FLOW_COUPLING, 128, 128) X(ASMC_FLOW_MAF, 64, 128) X(ASMC_FLOW_MAF, 128, 128)
 #endif
 
 // whether the one-kernel step takes this mutation (prm->d is the PADDED dimension 64 / 128; the flow keeps its own dims)

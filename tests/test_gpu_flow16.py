@@ -97,6 +97,20 @@ def _setup(n, d, seed):
     ("maf", 33, 2, 2000, 0.0, "f64", False), ("maf", 128, 3, 3000, 5.0, "f64", False), ("maf", 100, 2, 2000, 0.0, "f64", True),
     ("coupling", 64, 4, 3000, 0.0, "f32", False), ("maf", 128, 2, 2000, 4.0, "f32", False)])
 def test_flow16_mutation_vs_oracle(eng, oracle, kind, d, n_layers, n, nu, xdt, mix):
+    _flow16_mutation_vs_oracle(eng, oracle, kind, d, n_layers, n, nu, xdt, mix, 64)
+
+
+@pytest.mark.parametrize("kind,d,n_layers,n,nu,hidden", [
+    ("coupling", 64, 3, 3000, 0.0, 32), ("coupling", 64, 2, 3000, 5.0, 128), ("maf", 64, 2, 3000, 0.0, 128), ("maf", 48, 3, 2000, 4.0, 32),
+    ("coupling", 128, 2, 2000, 0.0, 128), ("maf", 128, 2, 2000, 5.0, 32), ("maf", 100, 1, 1500, 0.0, 128), ("coupling", 100, 2, 1500, 3.0, 32)])
+def test_flow16_mutation_at_hidden_widths_32_and_128_vs_oracle(eng, oracle, kind, d, n_layers, n, nu, hidden):
+    """The one-kernel step at the other hidden widths (round 6; the reference forwards any `hidden_features`,
+    flows/torch/flows.py:164): same checks as at the default width - `rep[k_(t)pcn_flow16] == n_steps` inside asserts that the
+    composed multi-kernel path did not run."""
+    _flow16_mutation_vs_oracle(eng, oracle, kind, d, n_layers, n, nu, "f64", False, hidden)
+
+
+def _flow16_mutation_vs_oracle(eng, oracle, kind, d, n_layers, n, nu, xdt, mix, hidden):
     """asmc_pcn_mutate_flow at 32 < d <= 128: ONE kernel per step (k_pcn_flow16 / k_tpcn_flow16: proposal, x' = mu + L y' on the
     fp64 matrix cores, flow with streamed weights, built-in targets, accept), no k_coupling_logprob / k_pcn_mm_propose /
     k_mixture_logpdf / k_copy_flagged_rows of round 4's five-kernel path; against the oracle's restatement of the whole step -
@@ -104,7 +118,7 @@ def test_flow16_mutation_vs_oracle(eng, oracle, kind, d, n_layers, n, nu, xdt, m
     differs; single-Gaussian and mixture targets (BASELINE configs[4]'s shape at d = 128)."""
     n_steps, beta, rho = 3, 0.4, 0.3
     dt = torch.float64 if xdt == "f64" else torch.float32
-    flow = _flow(kind, d, n_layers, 64, seed=6)
+    flow = _flow(kind, d, n_layers, hidden, seed=6)
     dev = flow.device_coupling(eng)
     ws, bs = flow.export_layers()
     x0, mu, L, Linv = _setup(n, d, 8)
@@ -410,9 +424,9 @@ def test_opt_in_zuko_adapter_puts_a_reference_style_flow_on_the_one_kernel_step(
 
 @pytest.mark.parametrize("kind,d,hidden,n", [("coupling", 64, 32, 2000), ("maf", 48, 128, 1500), ("maf", 64, 64, 7), ("coupling", 128, 64, 1)])
 def test_flow_mutation_above_32_dimensions_other_widths_and_tiny_populations(eng, oracle, kind, d, hidden, n):
-    """Hidden widths the one-kernel step is not built for (32 / 128 above 32 dimensions) take the composed path - propose on the
-    matrix cores, k_flow16_logprob, targets, accept - and a population smaller than one 16-particle group runs the one-kernel step
-    on a single ragged group: both against the oracle's restatement of the step."""
+    """Hidden widths 32 / 128 above 32 dimensions (round 5: the composed path - propose on the matrix cores, k_flow16_logprob,
+    targets, accept; round 6: the one-kernel step is built for them too) and a population smaller than one 16-particle group,
+    which runs the one-kernel step on a single ragged group: against the oracle's restatement of the step."""
     n_steps, beta, rho = 3, 0.4, 0.3
     flow = _flow(kind, d, 2, hidden, seed=9)
     dev = flow.device_coupling(eng)
@@ -430,7 +444,7 @@ def test_flow_mutation_above_32_dimensions_other_widths_and_tiny_populations(eng
                                       n_steps, 9, 0.234, False, "f64", 0.0)
     rep = eng.profile_report()
     eng.profile(False)
-    assert ("k_pcn_flow16" in rep) == (hidden == 64), sorted(rep)
+    assert rep["k_pcn_flow16"][0] == n_steps and not any(k.startswith(("k_flow16_logprob", "k_pcn_mm_propose", "k_pcn_accept")) for k in rep), sorted(rep)
     acc_ref = [oracle.pcn_flow_step(xr, llr, lpr, lqr, beta, mu, L, Linv, rho, o_t, o_t, ws, bs, flow.loc.numpy(), flow.scale.numpy(), 4242, 17,
                                     9 + t, "f64", 0, flow_kind=kind) for t in range(n_steps)]
     got = xd.cpu().numpy()

@@ -16,7 +16,8 @@ from aspire_amd.engine import HipEngine  # noqa: E402
 n, d = int(os.environ.get("N", 1_000_000)), int(os.environ.get("D", 64))
 kind, nu, steps = os.environ.get("KIND", "coupling"), float(os.environ.get("NU", 0.0)), int(os.environ.get("STEPS", 8))
 eng = HipEngine(0, n_max=n, d_max=128)
-flow = random_coupling_flow(d, 4, 64) if kind == "coupling" else random_maf_flow(d, 3, 64)
+w = int(os.environ.get("W", 64))
+flow = random_coupling_flow(d, 4, w) if kind == "coupling" else random_maf_flow(d, 3, w)
 dev = flow.device_coupling(eng)
 g = torch.Generator(eng.device).manual_seed(d)
 x = torch.randn((n, d), device=eng.device, dtype=torch.float64, generator=g)
@@ -30,4 +31,4 @@ eng.profile(True)
 acc, _, _ = eng.pcn_mutate_flow(*args)
 for k, (c, ms) in sorted(eng.profile_report().items(), key=lambda kv: -kv[1][0] * kv[1][1])[:6]:
     print(f"   {k:28s} {c:4d} x {ms * 1e3:9.2f} us")
-print(f"{kind} d={d} nu={nu}: accept {np.mean(acc) / n:.3f}")
+print(f"{kind} d={d} W={w} nu={nu}: accept {np.mean(acc) / n:.3f}")
