@@ -166,7 +166,9 @@ int asmc_ctx_create(asmc_ctx** ctx_out, int device, int64_t n_max, int d_max) {
     c->d_mmtab = nullptr;
     c->poison_lds = getenv("ASMC_POISON_LDS") != nullptr;
     c->d_max_pad = d_max <= 4 ? 4 : d_max <= 8 ? 8 : d_max <= 16 ? 16 : d_max <= 32 ? 32 : d_max <= 64 ? 64 : d_max <= 128 ? 128 : 0;
-    if (d_max > 32) dmalloc((void**)&c->d_mmtab, sizeof(double) * 2 * 144 * 64);  // (d in 33 .. 63 runs zero-padded on the d = 64 kernels)
+    // operand images of the d = 64 / 128 kernels (147 KB): every context has them - a d <= 32 problem whose proposal flow lives in the
+    // 16-particle-group layout (asmc_flow_layout = 1: an autoregressive flow of hidden width 128) runs zero-padded on the D = 64 step
+    dmalloc((void**)&c->d_mmtab, sizeof(double) * 2 * 144 * 64);
     dmalloc((void**)&c->d_guide, sizeof(unsigned int) * ((size_t)n_max + 8));
     // the fused flow step's counters sit directly in FRONT of the flag bytes: one memset clears both (asmc_pcn_mutate_flow)
     dmalloc((void**)&c->d_tilectr, ASMC_TILECTR_BYTES + (size_t)n_max + 64);

@@ -31,7 +31,11 @@ extern "C" int asmc_flow_layout(int kind, int dims, int hidden) {
     }
     if (kind == ASMC_FLOW_MAF) {
         if (dims < 1 || dims > 128) return -1;
-        return dims > 32 ? 1 : 0;
+        // hidden width 128 at d <= 32 (round 6): the d <= 32 kernels keep every transform resident in LDS - 113 KB each at this width, so
+        // two transforms already do not fit (round 5 refused them: "do not fit in LDS together") - and their one-kernel step has no
+        // autoregressive instantiation of this width.  The 16-particle-group kernels stream their weights: the flow runs on them,
+        // zero-padded to D = 64 (density, sampling and the one-kernel step).
+        return (dims > 32 || hidden == 128) ? 1 : 0;
     }
     return -1;
 }

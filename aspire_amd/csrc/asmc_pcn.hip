@@ -3396,12 +3396,14 @@ int asmc_pcn_mutate_flow(asmc_ctx* ctx, int64_t n, void* x, double* ll, double* 
     // More than 32 dimensions (round 5): the one-kernel step on 16-particle groups at D = 64 / 128 (asmc_flow16.hip), the
     // problem zero-padded to D when it is narrower.  Round 4 ran propose / flow / targets / accept / copy kernels at 32 < d <= 64
     // with a coupling flow (1.2 - 1.8 ms per step at 1M particles) and had no device path for an autoregressive flow there.
-    if (prm->d > 32 && prm->d <= 128 && prm->d == flow->dims && ctx->d_mmtab && !getenv("ASMC_PCN_GENERIC") && !getenv("ASMC_PCN_NOPAD") &&
+    // (... and at d <= 32 when the flow itself lives in that layout: asmc_flow_layout = 1, an autoregressive flow of hidden width 128)
+    const bool lay16 = asmc_flow_layout(flow->kind, flow->dims, flow->hidden) == 1;
+    if ((prm->d > 32 || lay16) && prm->d <= 128 && prm->d == flow->dims && ctx->d_mmtab && !getenv("ASMC_PCN_GENERIC") && !getenv("ASMC_PCN_NOPAD") &&
         !getenv("ASMC_PCN_XSTATE")) {
         const int d = prm->d, D = d <= 64 ? 64 : 128;
         asmc_pcn_params p16 = *prm;
         p16.d = D;
-        if (D <= ctx->d_max_pad && asmc_pcn_flow16_ok(&p16, flow)) {
+        if ((D <= ctx->d_max_pad || d <= 32) && asmc_pcn_flow16_ok(&p16, flow)) {
             ASMC_REQUIRE(ll && lp && lq && rho_inout_host && n_accept_host, "null pointer");
             ASMC_REQUIRE(n > 0 && n <= ctx->n_max, "n out of range for this ctx");
             ASMC_REQUIRE(prm->x_dtype == ASMC_F64 || prm->x_dtype == ASMC_F32, "bad x_dtype");

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ASMC_ABI_VERSION 22
+#define ASMC_ABI_VERSION 23
 
 #define ASMC_OK 0
 #define ASMC_ERR_ARG (-1)
@@ -440,7 +440,13 @@ int asmc_compact_valid(asmc_ctx* ctx, int64_t n, int d, int x_dtype, const void*
  *   (the host evaluates log_q, log_prior, log_likelihood on x_prop between the two calls,
  *   reference smc/base.py:507-519).  logj_old_dev / logj_new_dev (both or neither): log|det J| of the
  *   preconditioning transform at the current / proposed state, added to the tempered log-target
- *   (smc/base.py:515-517); logj_old_dev is updated in place for accepted particles. */
+ *   (smc/base.py:515-517); logj_old_dev is updated in place for accepted particles.
+ * Non-finite log-targets (every step entry point; ABI 23): the tempered log-target (1 - beta) log q + beta (ll + lp) [+ log|det J|]
+ *   is mapped to -inf when it is NaN - the reference's rule, smc/base.py:518 - AND when it is +inf: such a proposal is rejected and
+ *   counted as a rejection, and no particle settles on log_likelihood = +inf (the next log-sum-exp would be NaN and the temperature
+ *   search would stall).  That is this library's reading of what the third-party step the reference calls (minipcn, absent here) must
+ *   do for the reference's own +inf likelihood-hole test to finish (tests/integration_tests/test_integration.py:131-166);
+ *   unverified against the package.  A carried +inf (caller-supplied state) loses against any finite proposal. */
 /* Student-t reference of the tpCN step (params->nu > 0): the EM fit of (mu, Sigma, nu) runs on a subsample of m particles
  * (xs_dev [m, d] fp64, gathered by the caller); these calls are its per-particle half, the host keeps the d x d algebra.
  * asmc_student_estep: y = Linv (x - mu), z = (nu + d)/(nu + |y|^2) -> z_dev[m];
@@ -617,8 +623,11 @@ typedef struct asmc_coupling {
 #define ASMC_AFFINE_TANH 0
 #define ASMC_AFFINE_SOFTCLIP 1
 /* Packed layout of a flow of this shape: 0 = 32-particle tiles with every layer resident in LDS (dims <= 32), 1 = 16-particle
- * groups with the weights streamed through LDS (32 < dims <= 128: csrc/asmc_flow16.hip; coupling flows need even dims), < 0 =
- * no kernel.  The pack functions below choose it from the shape; every entry point that takes an asmc_coupling follows. */
+ * groups with the weights streamed through LDS (32 < dims <= 128: csrc/asmc_flow16.hip; coupling flows need even dims; and -
+ * ABI 23 - autoregressive flows of hidden width 128 at ANY dims <= 128: the resident layout holds one such transform at most),
+ * < 0 = no kernel.  The pack functions below choose it from the shape; every entry point that takes an asmc_coupling follows.
+ * The one-kernel mutation step (asmc_pcn_mutate_flow) exists for hidden widths 32 / 64 / 128 in layout 1 (ABI 23; width 64 only
+ * before) and for 32 / 64 - coupling flows: 128 too, while the layers fit the LDS - in layout 0. */
 int asmc_flow_layout(int kind, int dims, int hidden);
 int64_t asmc_coupling_pack_floats(int dims, int n_layers, int hidden);
 int asmc_coupling_pack(int dims, int n_layers, int hidden, const float* const* weights_host,

@@ -39,6 +39,7 @@ def oracle():
 @pytest.mark.parametrize("d,n_tr,hidden,n,dtype", [(32, 3, 64, 70001, torch.float64), (32, 3, 64, 4097, torch.float32),
                                                    (7, 2, 32, 3000, torch.float64), (16, 3, 64, 5000, torch.float64),
                                                    (20, 2, 64, 2500, torch.float64), (32, 1, 128, 1500, torch.float64),
+                                                   (32, 3, 128, 3000, torch.float64), (9, 3, 128, 1000, torch.float32),  # (round 5: "do not fit in LDS together")
                                                    (1, 2, 32, 100, torch.float64), (32, 3, 64, 1, torch.float64)])
 def test_maf_logprob_vs_fp64_and_oracle(eng, oracle, d, n_tr, hidden, n, dtype):
     """asmc_coupling_logprob with kind = ASMC_FLOW_MAF: the same flow in fp64 to 1e-6 relative (the north star's bar), the C
@@ -168,19 +169,21 @@ def _mutation_setup(eng, n, d, seed):
 
 @pytest.mark.parametrize("d,hidden,n,fused,nu", [(32, 64, 6000, True, 0.0), (32, 32, 2500, True, 0.0), (16, 64, 3000, True, 0.0),
                                                  (7, 32, 2000, True, 0.0), (20, 64, 2500, True, 0.0), (31, 32, 2000, True, 0.0),
-                                                 (3, 64, 1500, True, 0.0), (16, 128, 1500, False, 0.0),
+                                                 (3, 64, 1500, True, 0.0), (16, 128, 1500, False, 0.0), (32, 128, 2000, False, 0.0),
                                                  (32, 64, 6000, True, 5.0), (20, 64, 2500, True, 3.0), (7, 32, 2000, True, 8.0),
                                                  (16, 128, 1500, False, 5.0)])
 def test_maf_mutation_vs_oracle(eng, oracle, d, hidden, n, fused, nu):
     """asmc_pcn_mutate_flow with an autoregressive proposal density against the oracle's restatement of the whole step
     (orc_pcn_flow_step_kind, flow_kind = maf): every d <= 32 (odd ones too) takes the ONE-kernel step (k_pcn_flow_fused, the MAF
-    instantiation; d < 32 zero-padded inside the library); hidden width 128 has no one-kernel instantiation and runs the
-    device-side propose / k_maf_logprob / accept loop - no torch op, no host round trip inside the loop either way.
+    instantiation; d < 32 zero-padded inside the library); hidden width 128 (round 5: one transform at most, on a three-kernel
+    loop - more did not fit the LDS) lives in the streamed-weight layout since round 6 and takes the one-kernel step of the
+    16-particle-group kernels, zero-padded to D = 64 - no torch op, no host round trip inside the loop either way.
     nu > 0: the reference's DEFAULT pairing - step_fn="tpcn" (smc/minipcn.py:46-49) with flow_class="MAF"
     (flows/torch/flows.py:140) - against orc_tpcn_flow_step_kind."""
     n_steps, beta, rho = 3, 0.4, 0.35
-    flow = random_maf(d, 3 if hidden < 128 else 1, hidden, seed=6)
+    flow = random_maf(d, 3, hidden, seed=6)
     dev = flow.device_coupling(eng)
+    assert eng.lib.asmc_flow_layout(dev.kind, d, hidden) == (1 if hidden == 128 else 0)
     ws, bs = flow.export_layers()
     x0, mu, L, Linv = _mutation_setup(eng, n, d, 8)
     tgt_o = oracle.Mixture([0.0], np.zeros((1, d)), np.ones((1, d)))
@@ -197,7 +200,7 @@ def test_maf_mutation_vs_oracle(eng, oracle, d, hidden, n, fused, nu):
     if fused:
         assert rep["k_pcn_flow_fused"][0] == n_steps and "k_maf_logprob" not in rep
     else:
-        assert rep["k_maf_logprob"][0] == n_steps and "k_pcn_flow_fused" not in rep
+        assert rep["k_tpcn_flow16" if nu > 0 else "k_pcn_flow16"][0] == n_steps and "k_pcn_flow_fused" not in rep and "k_maf_logprob" not in rep, sorted(rep)
     acc_ref, margins = [], []
     for t in range(n_steps):
         with oracle.accept_margins(n) as m:

@@ -21,7 +21,8 @@ def main():
     steps, noise = int(os.environ.get("STEPS", 16)), os.environ.get("NOISE", "f64")
     rho0, adapt = float(os.environ.get("RHO", 0.3)), os.environ.get("ADAPT", "1") == "1"  # RHO=0.02 ADAPT=0: ~98 % acceptance
     eng = HipEngine(0, n_max=n, d_max=32)
-    flow = random_maf_flow(d, 3, 64) if os.environ.get("KIND", "coupling") == "maf" else random_coupling_flow(d, 4, 64)
+    w = int(os.environ.get("W", 64))
+    flow = random_maf_flow(d, 3, w) if os.environ.get("KIND", "coupling") == "maf" else random_coupling_flow(d, 4, w)
     dev = flow.device_coupling(eng)
     lik = DiagGaussianMixture.isotropic(d, normalized=False)
     g = GaussianFlow(d, sigma=0.8, seed=3, engine=eng)
