@@ -150,9 +150,17 @@ class Aspire:
             self.parameters = samples.parameters.copy()
         if self.flow is None:
             self.init_flow()
+        elif getattr(self, "_skip_flow_training", False) and not overwrite:  # aspire.py:239-243: a checkpointed flow was loaded
+            logger.info("Skipping flow training because a checkpointed flow was loaded.")
+            return FlowHistory()
         self.training_samples = samples
         logger.info(f"Training with {len(samples.x)} samples")
         history = self.flow.fit(samples.x, **kwargs) or FlowHistory()
+        defaults = getattr(self, "_checkpoint_defaults", None)  # aspire.py:248-254: inside `auto_checkpoint`
+        if checkpoint_path is None and defaults:  # (the config group is written once per context)
+            checkpoint_path = defaults["path"]
+            checkpoint_save_config = bool(defaults["save_config"]) and not defaults.get("saved_config", False)
+            defaults["saved_config"] = defaults.get("saved_config", False) or bool(defaults["save_config"])
         # aspire.py:251-269: config group (once) and the flow (if missing, or overwrite).  Sharded runs: the file's shared groups
         # are written by rank 0 alone (HDF5 has one writer; the per-rank sampler state goes to `<stem>.rank<r>.<ext>`), the
         # other ranks wait behind a barrier so that nobody opens the file while it is being written
@@ -369,6 +377,17 @@ class Aspire:
                          preconditioning_kwargs: dict | None = None, checkpoint_path: str | None = None,
                          checkpoint_every: int = 1, checkpoint_save_config: bool = True, **kwargs) -> Samples:
         """aspire.py:383-570."""
+        # aspire.py:453-467: after `resume_from_file` / inside `auto_checkpoint(resume=True)` the call continues the saved run
+        if sampler == "importance" and getattr(self, "_resume_sampler_type", None):
+            sampler = self._resume_sampler_type
+        if "resume_from" not in kwargs and hasattr(self, "_resume_from_default"):
+            kwargs["resume_from"] = self._resume_from_default
+            kwargs.update(getattr(self, "_resume_overrides", {}) or {})
+            if n_samples in (None, 1000) and getattr(self, "_resume_n_samples", None):
+                n_samples = self._resume_n_samples
+        defaults = getattr(self, "_checkpoint_defaults", None)  # aspire.py:490-494
+        if checkpoint_path is None and defaults:
+            checkpoint_path, checkpoint_every, checkpoint_save_config = defaults["path"], defaults["every"], defaults["save_config"]
         SamplerClass = self.get_sampler_class(sampler)
         init_params = signature(SamplerClass.__init__).parameters
         sampler_kwargs = {k: v for k, v in kwargs.items() if k in init_params and k != "self"}
@@ -417,6 +436,179 @@ class Aspire:
         if return_history:
             return samples, self._sampler.history
         return samples
+
+    # ---- resuming a saved run (aspire.py:573-760, 911-1200) -----------------------------------------------------------------
+    @staticmethod
+    def _plain(value):
+        """What an HDF5 / JSON config leaf becomes as a constructor argument."""
+        if isinstance(value, np.generic):
+            return value.item()
+        if isinstance(value, np.ndarray):
+            return value.tolist()
+        if isinstance(value, dict):
+            return {k: Aspire._plain(v) for k, v in value.items()}
+        if isinstance(value, (list, tuple)):
+            return [Aspire._plain(v) for v in value]
+        return value
+
+    @classmethod
+    def _load_resume_data(cls, file_path, checkpoint_path: str = "checkpoint", checkpoint_dset: str = "state",
+                          config_path: str = "aspire_config", sampler_config_path: str = "sampler_config") -> dict:
+        """aspire.py:911-999: what a checkpoint file says about the run it belongs to - the two config dictionaries, the sampler
+        type, the number of samples the run asked for and whether a sampler state is there.  HDF5 files through `io.open_h5`;
+        without h5py (or for a `.pkl` path) the pickle route's `<stem>.pkl` + `<stem>.config.json`."""
+        from pathlib import Path
+
+        from . import io
+
+        out = {"aspire_config": None, "sampler_config": None, "sampler_type": None, "n_samples": None, "state": None,
+               "state_path": None, "hdf5": False}
+        path = Path(file_path)
+        if cls._is_hdf5_path(path) and io.h5py_available() and path.is_file():
+            out["hdf5"] = True
+            with io.open_h5(path, "r") as h5_file:
+                if config_path in h5_file:
+                    out["aspire_config"] = cls._plain(io.load_from_h5_file(h5_file, config_path))
+                if sampler_config_path in h5_file:
+                    out["sampler_config"] = cls._plain(io.load_from_h5_file(h5_file, sampler_config_path))
+                try:
+                    out["state"] = io.load_state(h5_file, checkpoint_path, checkpoint_dset)
+                    out["state_path"] = str(path)
+                except Exception:
+                    logger.warning("Checkpoint not found at %s/%s in %s; will resume without a checkpoint.", checkpoint_path,
+                                   checkpoint_dset, path)
+        else:
+            import json
+            import pickle
+
+            pkl = Path(cls._pickle_checkpoint_path(path))
+            side = pkl.with_suffix(".config.json")
+            if side.is_file():
+                doc = json.load(open(side))
+                out["aspire_config"], out["sampler_config"] = doc.get("aspire_config"), doc.get("sampler_config")
+            rank_pkl = pkl if pkl.is_file() else None
+            if rank_pkl is not None:
+                try:
+                    out["state"] = pickle.loads(rank_pkl.read_bytes())
+                    out["state_path"] = str(pkl)
+                except Exception:
+                    logger.warning("Failed to decode checkpoint; proceeding without resume state.")
+            elif any(pkl.parent.glob(f"{pkl.stem}.rank*{pkl.suffix}")):
+                out["state_path"] = str(pkl)  # a sharded run: every rank restores its own `<stem>.rank<r>.pkl` (samplers/base.py)
+        sc = out["sampler_config"]
+        if isinstance(sc, dict):
+            out["sampler_type"] = sc.get("sampler_type")
+            out["n_samples"] = cls._resume_n_samples_from_sampler_config(sc)
+        if out["n_samples"] is None and isinstance(out["state"], dict) and out["state"].get("samples") is not None:
+            out["n_samples"] = len(out["state"]["samples"])
+        return out
+
+    @staticmethod
+    def _resume_n_samples_from_sampler_config(sampler_config) -> int | None:
+        """aspire.py:1030-1063: the `n_samples` of the saved `sample()` call."""
+        calls = sampler_config.get("sample_calls") if isinstance(sampler_config, dict) else None
+        if not isinstance(calls, dict):
+            return None
+        args = calls.get("args")
+        try:
+            if args is not None and not isinstance(args, (str, bytes, dict)) and len(args) > 0:
+                return int(args[0])
+            kw = calls.get("kwargs")
+            if isinstance(kw, dict) and "n_samples" in kw:
+                return int(kw["n_samples"])
+        except (TypeError, ValueError):
+            return None
+        return None
+
+    def _set_resume_defaults(self, data: dict, sampler: str | None = None, resume_kwargs: dict | None = None) -> None:
+        """aspire.py:1001-1028: the next `sample_posterior` call continues from the saved state (nothing to do without one)."""
+        if data.get("state_path") is None:
+            return
+        state = data.get("state") or {}
+        self._resume_from_default = data["state_path"]
+        self._resume_sampler_type = sampler or data.get("sampler_type") or (state.get("sampler") if isinstance(state, dict) else None)
+        if self._resume_sampler_type == "HipSMC":  # (a state records the class name, `sample_posterior` takes the registry name)
+            self._resume_sampler_type = "smc"
+        self._resume_n_samples = data.get("n_samples")
+        self._resume_overrides = dict(resume_kwargs or {})
+        self._resume_sampler_config = {k: v for k, v in (data.get("sampler_config") or {}).items() if k != "sampler_class"}
+
+    @classmethod
+    def resume_from_file(cls, file_path: str, *, log_likelihood: Callable, log_prior: Callable, sampler: str | None = None,
+                         checkpoint_path: str = "checkpoint", checkpoint_dset: str = "state", flow_path: str = "flow",
+                         config_path: str = "aspire_config", resume_kwargs: dict | None = None, **aspire_kwargs):
+        """aspire.py:573-646: rebuild the object from ONE file (config + flow + sampler state) and arm it so that the next
+        `sample_posterior()` continues the saved run.  The two densities are not stored and must be passed.  Extra keywords
+        (`engine=...`, `flow=...` for a proposal the file could not store) go to the constructor."""
+        from . import io
+
+        data = cls._load_resume_data(file_path, checkpoint_path, checkpoint_dset, config_path)
+        cfg = data["aspire_config"]
+        if cfg is None:
+            raise ValueError(f"Config path '{config_path}' not found in {file_path}")
+        cfg = {k: v for k, v in cfg.items() if k not in ("sampler_config", "sampler_type", "log_likelihood", "log_prior")}
+        xp_name = cfg.pop("xp", None)
+        flow_kwargs = cfg.pop("flow_kwargs", None) or {}
+        if isinstance(cfg.get("prior_bounds"), dict):
+            cfg["prior_bounds"] = {k: tuple(v) for k, v in cfg["prior_bounds"].items()}
+        xp = None
+        if isinstance(xp_name, str):
+            xp = np if "numpy" in xp_name else (torch if "torch" in xp_name else None)
+        given_flow = aspire_kwargs.pop("flow", None)
+        aspire = cls(log_likelihood=log_likelihood, log_prior=log_prior, xp=xp, flow=given_flow,
+                     **{**cfg, **(flow_kwargs if isinstance(flow_kwargs, dict) else {}), **aspire_kwargs})
+        if given_flow is None:
+            loaded = False
+            if data["hdf5"]:
+                with io.open_h5(file_path, "r") as h5_file:
+                    if flow_path in h5_file:
+                        aspire.load_flow(h5_file, path=flow_path)
+                        loaded = True
+            if not loaded:
+                raise ValueError(f"Flow path '{flow_path}' not found in {file_path} (pass flow=... for a proposal the file does not hold)")
+        aspire._set_resume_defaults(data, sampler=sampler, resume_kwargs=resume_kwargs)
+        aspire._skip_flow_training = True
+        aspire._checkpoint_defaults = {"path": file_path, "every": 1, "save_config": False, "save_flow": False,
+                                       "saved_config": False, "saved_flow": False}
+        return aspire
+
+    def auto_checkpoint(self, path: str, every: int = 1, save_config: bool = True, save_flow: bool = True, resume: bool = False):
+        """aspire.py:648-747: inside the context `fit` / `sample_posterior` write to `path` by default; with `resume=True` and an
+        existing file the saved flow is loaded (training is then skipped) and the next `sample_posterior()` continues the run."""
+        from contextlib import contextmanager
+
+        @contextmanager
+        def ctx():
+            attrs = ["_checkpoint_defaults", "_resume_from_default", "_resume_sampler_type", "_resume_n_samples", "_resume_overrides",
+                     "_resume_sampler_config", "_skip_flow_training"]
+            saved = {a: getattr(self, a) for a in attrs if hasattr(self, a)}
+            self._checkpoint_defaults = {"path": path, "every": every, "save_config": save_config, "save_flow": save_flow,
+                                         "saved_config": False, "saved_flow": False}
+            if resume:
+                from . import io
+
+                data = self._load_resume_data(path)
+                if data["state_path"] is not None or data["aspire_config"] is not None:
+                    logger.info(f"Resuming from checkpoint file at {path}")
+                    if data["hdf5"]:
+                        try:
+                            with io.open_h5(path, "r") as h5_file:
+                                if "flow" in h5_file:
+                                    self.load_flow(h5_file, path="flow")
+                        except (ValueError, KeyError) as exc:
+                            logger.warning("Flow not loaded from %s: %s", path, exc)
+                    self._set_resume_defaults(data)
+                    self._skip_flow_training = self.flow is not None
+            try:
+                yield self
+            finally:
+                for a in attrs:
+                    if a in saved:
+                        setattr(self, a, saved[a])
+                    elif hasattr(self, a):
+                        delattr(self, a)
+
+        return ctx()
 
     # ---- configuration / convenience (aspire.py:762-909) ---------------------------------------
     def config_dict(self, include_sampler_config: bool = False, **kwargs) -> dict:

@@ -65,8 +65,8 @@ class Comm:
     def barrier(self):
         pass
 
-    def signal(self, tag: str) -> None:
-        """One rank tells the others that a long host-side job (flow training) is done - see TorchDistComm.signal."""
+    def signal(self, tag: str, error: BaseException | str | None = None) -> None:
+        """One rank tells the others that a long host-side job (flow training) is done, or failed - see TorchDistComm.signal."""
 
     def await_signal(self, tag: str, timeout_s: float = 86400.0) -> None:
         """Wait for `signal(tag)` of the producing rank without sitting in a collective."""
@@ -272,17 +272,47 @@ class TorchDistComm(Comm):
         except Exception:
             return None
 
-    def signal(self, tag: str) -> None:
+    def _signal_key(self, tag: str) -> str:
+        """Key of the next signal on `tag`: namespaced by the ranks of THIS communicator's group (two sub-groups waiting on the same
+        tag must not see each other's keys) and by a per-(group, tag) epoch every member advances once per signal / await pair."""
+        try:
+            ranks = self.dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.dist.get_world_size()))
+        except Exception:
+            ranks = list(range(self.world))
+        ns = f"{min(ranks)}-{max(ranks)}-{len(ranks)}"
+        return f"asmc/{ns}/{tag}/{self._signal_epoch(tag, bump=True)}"
+
+    def signal(self, tag: str, error: BaseException | str | None = None) -> None:
+        """Tell the waiting ranks that the long job is done - or that it FAILED (`error`): they raise instead of waiting out the
+        day-long timeout.  Call it from a `finally` / `except` of the producing rank."""
         st = self._store()
-        if st is not None:
-            st.set(f"asmc/{tag}/{self._signal_epoch(tag, bump=True)}", b"1")
+        key = self._signal_key(tag)
+        if st is None:
+            self._warn_no_store()
+            return
+        st.set(key, b"ok" if error is None else ("error:" + str(error)[:400]).encode("utf-8", "replace"))
 
     def await_signal(self, tag: str, timeout_s: float = 86400.0) -> None:
         st = self._store()
-        if st is not None:
-            from datetime import timedelta
+        key = self._signal_key(tag)
+        if st is None:
+            self._warn_no_store()
+            return
+        from datetime import timedelta
 
-            st.wait([f"asmc/{tag}/{self._signal_epoch(tag, bump=True)}"], timedelta(seconds=float(timeout_s)))
+        st.wait([key], timedelta(seconds=float(timeout_s)))
+        val = bytes(st.get(key))
+        if val.startswith(b"error:"):
+            raise RuntimeError(f"rank 0 failed while the other ranks waited on '{tag}': {val[6:].decode('utf-8', 'replace')}")
+
+    def _warn_no_store(self) -> None:
+        if not self.__dict__.get("_warned_no_store"):
+            self.__dict__["_warned_no_store"] = True
+            import logging
+
+            logging.getLogger(__name__).warning(
+                "torch.distributed's default store is not reachable: waits of unbounded length fall back to the next collective "
+                "and its watchdog timeout")
 
     def _signal_epoch(self, tag: str, bump: bool) -> int:
         ep = self.__dict__.setdefault("_signal_epochs", {})

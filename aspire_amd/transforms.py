@@ -270,7 +270,11 @@ class FlowPreconditioningTransform:
             # the training can take longer than a collective may wait (watchdog timeouts): the other ranks block on a store key,
             # not inside sync_shards' first collective
             if comm.rank == 0:
-                self.flow.fit(pooled, **{a: b for a, b in self.fit_kwargs.items() if a != "fit_subsample"})
+                try:
+                    self.flow.fit(pooled, **{a: b for a, b in self.fit_kwargs.items() if a != "fit_subsample"})
+                except BaseException as exc:  # the waiting ranks raise too instead of sitting out the day-long timeout
+                    comm.signal("flow_precond_fit", error=exc)
+                    raise
                 comm.signal("flow_precond_fit")
             else:
                 comm.await_signal("flow_precond_fit")

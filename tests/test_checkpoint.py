@@ -425,3 +425,81 @@ def test_sharded_checkpoint_files_have_one_writer_for_the_shared_groups(tmp_path
     assert (tmp_path / "other.config.json").exists()
     side = json.load(open(tmp_path / "other.config.json"))
     assert side["sampler_config"]["sampler_type"] == "smc"
+
+
+# ---- resuming through the facade: auto_checkpoint / resume_from_file (aspire.py:573-760) ------------------------------------------
+def test_facade_auto_checkpoint_and_resume_from_file_continue_a_saved_run(monkeypatch, tmp_path):
+    """`with aspire.auto_checkpoint(path)`: `fit` and `sample_posterior` write config, flow and the sampler's state to ONE file
+    without being told to; `Aspire.resume_from_file(path, log_likelihood=..., log_prior=...)` rebuilds the object from that file
+    (constructor arguments, trained flow) and the next `sample_posterior()` continues from the saved state with the saved sampler
+    and sample count; `auto_checkpoint(path, resume=True)` does the same on an existing object and skips the flow training."""
+    import torch
+    from fake_h5 import FakeFile
+    from oracle_engine import OracleEngine
+
+    from aspire_amd import Aspire, io
+    from aspire_amd.samples import Samples
+
+    monkeypatch.setattr(io, "open_h5", lambda path, mode="r": FakeFile(path, mode))
+    monkeypatch.setattr(io, "h5py_available", lambda: True)
+    real_is_file = os.path.isfile
+    d, eng = 3, OracleEngine()
+    params = [f"p{i}" for i in range(d)]
+    path = str(tmp_path / "auto.h5")
+    open(path, "wb").close()  # (the in-memory stand-in has no file on disk: the resume code asks the file system whether one exists)
+
+    def sharp(samples):  # a target that takes several temperatures from this proposal
+        return 40.0 * _log_like(samples)
+
+    budget = {"left": 10 ** 9}
+
+    def crashing(samples):  # ... and a likelihood that dies part-way through the first run
+        budget["left"] -= 1
+        if budget["left"] < 0:
+            raise RuntimeError("node lost")
+        return sharp(samples)
+
+    def make(ll=sharp):
+        return Aspire(log_likelihood=ll, log_prior=_log_like, dims=d, xp=np, flow_backend="coupling", n_layers=2,
+                      hidden_features=(16, 16), seed=3, parameters=params)
+
+    asp = make(crashing)
+    x = np.random.default_rng(0).normal(size=(256, d))
+    with asp.auto_checkpoint(path, every=1):
+        asp.fit(Samples(x=x, xp=np, parameters=params), n_epochs=1)
+        budget["left"] = 7  # the initial draw and about two temperatures of two steps, then the "crash"
+        with pytest.raises(RuntimeError, match="node lost"):
+            asp.sample_posterior(300, sampler="smc", engine=eng, rng=np.random.default_rng(5),
+                                 sampler_kwargs=dict(n_steps=2, step_fn="pcn"), store_sample_history=False)
+    assert not hasattr(asp, "_checkpoint_defaults")
+    with FakeFile(path, "r") as f:
+        assert {"aspire_config", "flow", "checkpoint"} <= set(f.keys())
+        st = io.load_state(f)
+        n_iter, beta_saved = st["iteration"], st["meta"]["beta"]
+    assert n_iter >= 1 and beta_saved < 1.0
+    # a fresh object from the file alone continues the interrupted run
+    calls = {"n": 0}
+
+    def counting_like(s):
+        calls["n"] += 1
+        return sharp(s)
+
+    asp2 = Aspire.resume_from_file(path, log_likelihood=counting_like, log_prior=_log_like, sampler="smc")
+    assert asp2.dims == d and asp2.parameters == params and asp2.flow_backend == "coupling" and asp2.flow is not None
+    a = asp.flow.log_prob(torch.as_tensor(x[:16]))
+    b = asp2.flow.log_prob(torch.as_tensor(x[:16]))
+    np.testing.assert_allclose(np.asarray(a), np.asarray(b), rtol=1e-6, atol=1e-6)
+    assert asp2._resume_sampler_type == "smc" and asp2._resume_n_samples == 300
+    out2 = asp2.sample_posterior(engine=eng, rng=np.random.default_rng(6), sampler_kwargs=dict(n_steps=2, step_fn="pcn"),
+                                 store_sample_history=False)
+    h2 = asp2.sampler.history
+    assert len(out2) == 300 and len(h2.beta) > n_iter and h2.beta[n_iter - 1] == beta_saved and h2.beta[-1] == 1.0 and calls["n"] > 0
+    # the same on an existing object
+    asp3 = make()
+    with asp3.auto_checkpoint(path, resume=True):
+        assert asp3._skip_flow_training and asp3.flow is not None
+        hist = asp3.fit(Samples(x=x, xp=np, parameters=params), n_epochs=5)  # skipped: the checkpointed flow was loaded
+        out3 = asp3.sample_posterior(engine=eng, rng=np.random.default_rng(7), sampler_kwargs=dict(n_steps=2, step_fn="pcn"),
+                                     store_sample_history=False)
+    assert len(out3) == 300 and not hasattr(asp3, "_resume_from_default") and not hasattr(asp3, "_skip_flow_training")
+    assert real_is_file(path)

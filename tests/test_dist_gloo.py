@@ -624,3 +624,38 @@ def test_world8_skew_falls_back_to_slots_and_sampler_runs(eight_rank_results, or
     assert all(np.array_equal(res["beta"], rs[0]["beta"]) and float(res["logz"]) == float(rs[0]["logz"]) for res in rs)
     assert rs[0]["beta"][-1] == 1.0 and sum(int(res["n_post"]) for res in rs) == world * 256 - 5
     assert abs(float(rs[0]["logz"]) - 2.0 * np.log(np.pi)) < 5 * float(rs[0]["logz_err"]) + 0.1
+
+
+# ---- signal / await_signal: a producer's failure reaches the waiting ranks ------------------------------------------
+def _signal_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aspire_amd.comm import TorchDistComm
+
+    comm = TorchDistComm(torch.device("cpu"))
+    res = {}
+    # 1: the ordinary hand-off; 2: the producer fails - the waiter raises with its message instead of waiting a day
+    if rank == 0:
+        comm.signal("job")
+        comm.signal("job", error=ValueError("training diverged"))
+        res["ok"] = 1
+    else:
+        comm.await_signal("job", timeout_s=60)
+        try:
+            comm.await_signal("job", timeout_s=60)
+            res["raised"] = 0
+        except RuntimeError as exc:
+            res["raised"] = 1
+            res["msg"] = np.frombuffer(str(exc).encode(), dtype=np.uint8)
+    np.savez(os.path.join(out_dir, f"sig{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_signal_carries_a_producer_failure_to_the_waiting_ranks(tmp_path):
+    mp.spawn(_signal_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r1 = np.load(os.path.join(str(tmp_path), "sig1.npz"))
+    assert int(r1["raised"]) == 1 and b"training diverged" in bytes(r1["msg"])
