@@ -51,5 +51,9 @@ c = parse(os.path.join(ROOT, f"gpurun_out/{tag}/pmc_flow16_d64.txt"), "k_pcn_flo
 out[f"k_pcn_flow16|n={n}|d=64|f64|f64|coupling"] = entry(c, (n + 15) // 16, f"profiles/{tag}_pmc_flow16_d64.txt", "16_particle_group")
 c = parse(os.path.join(ROOT, f"gpurun_out/{tag}/pmc_config5_step.txt"), "k_pcn_mm<double, 128, 0, 3>")
 out[f"k_tpcn_mm_step|n={n}|d=128|f64|f64"] = entry(c, (n + 15) // 16, f"profiles/{tag}_pmc_config5_step.txt", "16_particle_group")
+p_maf = os.path.join(ROOT, f"gpurun_out/{tag}/pmc_flow16_maf_d128.txt")  # (round 6: the reference's default flow class at configs[4]'s dimension)
+if os.path.exists(p_maf):
+    c = parse(p_maf, "k_pcn_flow16<double, 128, 64, 1, 0, false")
+    out[f"k_pcn_flow16|n={n}|d=128|f64|f64|maf"] = entry(c, (n + 15) // 16, f"profiles/{tag}_pmc_flow16_maf_d128.txt", "16_particle_group")
 json.dump(out, open(os.path.join(ROOT, "profiles", "sq_counters.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
