@@ -87,7 +87,8 @@ def test_maf_out_of_range_operand_is_nan_not_a_wrong_number(eng):
 
 
 @pytest.mark.parametrize("d,n_tr,hidden,n,dtype", [(32, 3, 64, 50000, torch.float64), (7, 2, 32, 4000, torch.float32),
-                                                   (16, 3, 64, 4097, torch.float64)])
+                                                   (16, 3, 64, 4097, torch.float64),
+                                                   (32, 3, 128, 20000, torch.float64), (12, 2, 128, 3000, torch.float64)])  # (round 6: the streamed layout at d <= 32)
 def test_maf_sample_inverts_the_density_pass(eng, d, n_tr, hidden, n, dtype):
     """asmc_coupling_sample with kind = ASMC_FLOW_MAF (d passes per transform, whatever the variable order): the returned log q
     is the density of the returned x (fp64 evaluation of the same flow), pushing x back through the flow recovers a standard
@@ -308,3 +309,34 @@ def test_smc_run_with_the_default_flow_class_stays_on_the_device(eng):
                                     "k_pad_rows", "k_copy_flagged_rows")), name
     z = (float(out.log_evidence) - 0.5 * d * math.log(math.pi)) / float(out.log_evidence_error)
     assert abs(z) < 3.0, z
+
+
+def test_smc_run_with_an_autoregressive_flow_of_hidden_width_128_at_d_below_32(eng):
+    """`Aspire(flow_backend="zuko", hidden_features=(128, 128))`-style run at d = 16 (the reference forwards any width,
+    flows/torch/flows.py:164): round 5 refused more than one such transform on the device; since round 6 the flow lives in the
+    streamed-weight layout (asmc_flow_layout = 1) - the draw in k_flow16_sample, every mutation step ONE kernel (k_pcn_flow16 on the
+    problem zero-padded to D = 64), on a context created for d_max = 32 - and log Z comes out within 3 sigma of the closed form."""
+    from aspire_amd.engine import HipEngine
+    from aspire_amd.flows import MAFFlow
+    from aspire_amd.samplers.smc import HipSMC
+    from aspire_amd.targets import DiagGaussianMixture
+
+    d, n = 16, 100_000
+    small = HipEngine(0, n_max=n, d_max=32)
+    flow = MAFFlow(d, n_transforms=3, hidden_features=(128, 128), seed=7, device=small.device, dtype=torch.float32)
+    flow.fit(1.5 * 0.9 * np.random.default_rng(3).normal(size=(8000, d)), n_epochs=6)
+    assert small.lib.asmc_flow_layout(1, d, 128) == 1
+    lik = DiagGaussianMixture.isotropic(d, normalized=False)
+    sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow, xp=np, engine=small, rng=np.random.default_rng(11), dtype="float64")
+    small.profile(True)
+    out = sp.sample(n, sampler_kwargs=dict(n_steps=8, step_fn="pcn"), store_sample_history=False)
+    rep = small.profile_report()
+    small.profile(False)
+    temps = len(sp.history.beta)
+    assert "flow: device-side step loop" in sp.last_mutation_path, sp.last_mutation_path
+    assert rep["k_pcn_flow16"][0] == 8 * temps and rep["k_flow16_sample"][0] >= 1, sorted(rep)
+    for name in rep:
+        assert not name.startswith(("k_pcn_propose", "k_pcn_accept", "k_pcn_flow_propose", "k_pcn_flow_accept", "k_maf_logprob", "k_copy_flagged_rows")), name
+    z = (float(out.log_evidence) - 0.5 * d * math.log(math.pi)) / float(out.log_evidence_error)
+    assert abs(z) < 3.0, z
+    small.close()
