@@ -77,6 +77,21 @@ def trained_maf(s):  # the reference's default flow class
 
 
 case("config 3, MAF flow + pcn", d, lik, lik, trained_maf, true32, step_fn="pcn")
+case("reference defaults: MAF + tpcn", d, lik, lik, trained_maf, true32)  # (round 6: the autoregressive instantiation of the fused step changed)
+
+d6 = 64  # the flow16 step (changed in round 6) inside whole runs: autoregressive proposal at d = 64, tpCN
+
+
+def trained_maf64(s):
+    from aspire_amd.flows import MAFFlow
+
+    f = MAFFlow(d6, n_transforms=3, hidden_features=(64, 64), device=eng.device, dtype=torch.float32, seed=1234 + s)
+    f.fit(1.5 * 0.9 * np.random.default_rng(3 + s).normal(size=(8000, d6)), n_epochs=8)
+    return f
+
+
+lik6 = DiagGaussianMixture.isotropic(d6, normalized=False)
+case("d = 64, MAF flow + tpcn (flow16)", d6, lik6, lik6, trained_maf64, 0.5 * d6 * np.log(np.pi))
 d5 = 128
 lik5 = DiagGaussianMixture(np.stack([2 * np.ones(d5), -2 * np.ones(d5)]), np.stack([0.5 * np.ones(d5), np.ones(d5)]))
 prior5 = DiagGaussianMixture.isotropic(d5, 0.0, 1.0)
