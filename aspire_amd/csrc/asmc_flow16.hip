@@ -476,16 +476,21 @@ __global__ __launch_bounds__(THREADS, 2) void k_pcn_flow16(int64_t n, T* __restr
         const double c1 = ref_corr_ct<TP>(q1, p.nu, dn), c0 = ref_corr_ct<TP>(q0, p.nu, dn);
         const double logu = bm_log_unit(accept_uniform(p.seed, gid, step));  // (< 1 ulp for the uniform's range: asmc_pcn_fused.hip)
         const double lpo = log_p_t(oll, olp, olq, p.beta);
-        double k_new = c1, k_old = lpo + c0, k_ll = nll, k_lp = nlp, k_lu = logu;
-        asm volatile("" : "+v"(k_new), "+v"(k_old), "+v"(k_ll), "+v"(k_lp), "+v"(k_lu));
+        // ... folded into ONE number, as the d <= 32 step does (asmc_pcn_fused.hip): accept  <=>  log u < ((1 - beta) lq' + t2 + c1) - k_old
+        // <=>  (1 - beta) lq' + kacc > 0 - three doubles alive across the flow instead of five (D = 128 spills them); the
+        // re-association moves a decision only where its margin is within an ulp or two (the razor edges the parity tests allow for).
+        // A +inf or NaN target term turns kacc into NaN: rejected (log_p_t's rule).
+        double t2 = p.beta * (nll + nlp);
+        t2 = (t2 < INFINITY) ? t2 : __builtin_nan("");
+        double kacc = ((t2 + c1) - (lpo + c0)) - logu, k_ll = nll, k_lp = nlp;
+        asm volatile("" : "+v"(kacc), "+v"(k_ll), "+v"(k_lp));
         __builtin_amdgcn_sched_barrier(0);
         const double nlq = (!FD::MAF || form == 0) ? (double)f16_logprob<FD, W, THREADS, 0>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, 0)
                                                    : (double)f16_logprob<FD, W, THREADS, 1>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, 1);
         __builtin_amdgcn_sched_barrier(0);
         if (valid && h == 0 && !(fabs(nlq) < INFINITY)) n_bad++;
-        const double lpn = log_p_t(k_ll, k_lp, nlq, p.beta);
-        const double log_a = (lpn + k_new) - k_old;
-        if (valid && k_lu < log_a) {  // (a NaN density: log_p_t gives -inf, rejected)
+        const bool lq_finite = fabs(nlq) < INFINITY;
+        if (valid && lq_finite && fma(1.0 - p.beta, nlq, kacc) > 0.0) {  // (a NaN / infinite density: rejected)
 #pragma unroll
             for (int sp = 0; sp < KS / 2; sp++) {
                 Pair t;
