@@ -500,9 +500,11 @@ class CouplingFlow(Flow):
     # dataset per state-dict entry).  `h5_file` is an open h5py File / Group or anything with the same group protocol
     # (create_group, create_dataset, [] / items / in); this package does not import h5py itself.
     def save(self, h5_file, path="flow"):
-        if self._has_transform():
-            raise NotImplementedError("saving a flow with a data transform is not supported; save the transform separately")
         grp = h5_file.create_group(path)
+        if self._has_transform():  # flows/torch/flows.py:77-78: the data transform travels in `<path>/data_transform`
+            if not hasattr(self.data_transform, "save"):
+                raise NotImplementedError("the flow's data transform cannot be saved (no `save`)")
+            self.data_transform.save(grp, "data_transform")
         cfg = grp.create_group("config")
         for key, value in self._init_args.items():
             cfg.create_dataset(key, data=np.asarray(value) if not isinstance(value, str) else value)
@@ -524,6 +526,10 @@ class CouplingFlow(Flow):
 
         cfg = {k: plain(v) for k, v in grp["config"].items()}
         cfg["dtype"] = getattr(torch, str(cfg["dtype"]))
+        if "data_transform" in grp:  # flows/torch/flows.py:94-102
+            from .transforms import CompositeTransform
+
+            cfg["data_transform"] = CompositeTransform.load(grp, "data_transform", strict=False)
         obj = cls(device=device, **cfg)
         weights = {name: torch.as_tensor(np.asarray(d[()])) for name, d in grp["weights"].items()}
         obj.loc = weights.pop("_loc").to(device=obj.device, dtype=obj.dtype)

@@ -740,6 +740,8 @@ class HipSMC(SMCSampler):
         """The proposal flow packed for the MFMA kernel, or None (not a float32 coupling flow of a supported shape)."""
         if not hasattr(self.prior_flow, "device_coupling"):
             return self._adapted_zuko_flow()
+        if not hasattr(self.engine, "coupling_logprob"):  # (as `_flow_log_prob`: an engine without flow kernels - the tests' CPU double)
+            return None
         try:
             return self.prior_flow.device_coupling(self.engine)
         except (ValueError, RuntimeError) as exc:

@@ -181,6 +181,58 @@ class CompositeTransform:
                 "bounded_transform": self.bounded_transform, "affine_transform": self.affine_transform,
                 "eps": self.eps, "device": self.device}
 
+    # transforms.py:63-122, 338-346, 639-646: a group with the class name as an attribute, `config` (dotted leaves) and the fitted
+    # state of the affine stage (`affine_transform/mean`, `affine_transform/std`); `h5_file`: anything with h5py's group protocol
+    def save(self, h5_file, path: str = "data_transform") -> None:
+        from .io import recursively_save_to_h5_file
+
+        grp = h5_file.create_group(path)
+        grp.attrs["class"] = self.__class__.__name__
+        cfg = self.config_dict()
+        cfg["prior_bounds"] = None if cfg["prior_bounds"] is None else {k: [float(v[0]), float(v[1])] for k, v in cfg["prior_bounds"].items()}
+        recursively_save_to_h5_file(grp, "config", cfg)
+        if self.affine_transform and self._mean is not None:
+            aff = grp.create_group("affine_transform")
+            aff.create_dataset("mean", data=np.asarray(self._mean, dtype=np.float64))
+            aff.create_dataset("std", data=np.asarray(self._std, dtype=np.float64))
+
+    @classmethod
+    def load(cls, h5_file, path: str = "data_transform", strict: bool = False, engine=None):
+        from .io import load_from_h5_file
+
+        grp = h5_file[path]
+        name = grp.attrs["class"]
+        name = name.decode() if isinstance(name, bytes) else str(name)
+        known = {c.__name__: c for c in (CompositeTransform, FlowTransform)}
+        if name != cls.__name__:
+            if strict:
+                raise ValueError(f"Expected class {cls.__name__}, got {name}.")
+            if name not in known:
+                raise ValueError(f"Unknown transform class {name}")
+            cls = known[name]
+        cfg = load_from_h5_file(grp, "config")
+        xp_name = cfg.pop("xp", None)
+        cfg.pop("dtype", None)
+        if isinstance(cfg.get("prior_bounds"), dict):
+            cfg["prior_bounds"] = {k: (float(np.asarray(v)[0]), float(np.asarray(v)[1])) for k, v in cfg["prior_bounds"].items()}
+        for key in ("parameters", "periodic_parameters"):
+            if key in cfg and cfg[key] is not None:
+                cfg[key] = [str(v) for v in np.asarray(cfg[key]).tolist()] if not isinstance(cfg[key], list) else cfg[key]
+        if cls is FlowTransform:
+            cfg.pop("periodic_parameters", None)
+        for key in ("bounded_to_unbounded", "affine_transform"):
+            if key in cfg:
+                cfg[key] = bool(cfg[key])
+        if "eps" in cfg:
+            cfg["eps"] = float(cfg["eps"])
+        xp = None if xp_name is None else (torch if "torch" in str(xp_name) else np)
+        obj = cls(xp=xp, engine=engine, **cfg)
+        if obj.affine_transform and "affine_transform" in grp:
+            obj._mean = np.asarray(grp["affine_transform"]["mean"][()], dtype=np.float64)
+            obj._std = np.asarray(grp["affine_transform"]["std"][()], dtype=np.float64)
+            obj._affine_logj = float(-np.log(np.abs(obj._std)).sum())
+        return obj
+
 
 class FlowTransform(CompositeTransform):
     """The data transform the reference puts in front of its flows (transforms.py:345-395): a CompositeTransform

@@ -357,8 +357,9 @@ class OracleEngine:
         return self._transform(z, t, True, want_logj)
 
     def compact_valid(self, x, ll, lp, lq):
-        assert x.dtype == torch.float64
-        return tuple(torch.from_numpy(a) for a in O.compact_valid(_np(x), _np(ll), _np(lp), _np(lq)))
+        # (float32 rows, as the HIP engine takes them: the oracle's row compaction is dtype blind - through float64 and back, exact)
+        out = tuple(torch.from_numpy(a) for a in O.compact_valid(_np(x).astype(np.float64), _np(ll), _np(lp), _np(lq)))
+        return (out[0].to(x.dtype),) + out[1:]
 
     # ---- moments / pCN ----------------------------------------------------------------------
     def colsum(self, x):
