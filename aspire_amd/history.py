@@ -18,11 +18,28 @@ class History:
 
         recursively_save_to_h5_file(h5_file, path, copy.deepcopy(self.__dict__))
 
+    @classmethod
+    def load(cls, h5_file, path="history"):
+        """history.py:22-48: the dataclass's own fields through its constructor, anything else in the group as plain attributes."""
+        from .io import load_from_h5_file
+
+        dictionary = load_from_h5_file(h5_file, path)
+        names = set(cls.__dataclass_fields__)
+        inst = cls(**{k: v for k, v in dictionary.items() if k in names})
+        for k, v in dictionary.items():
+            if k not in names:
+                setattr(inst, k, v)
+        return inst
+
 
 @dataclass
 class FlowHistory(History):
     training_loss: list[float] = field(default_factory=list)
     validation_loss: list[float] = field(default_factory=list)
+
+    def save(self, h5_file, path="flow_history"):
+        """history.py:66-68."""
+        super().save(h5_file, path=path)
 
 
 @dataclass

@@ -157,8 +157,12 @@ class BaseSamples:
         """samples.py:282-287."""
         d = self.to_numpy().to_dict(flat=flat)
         d.pop("device", None)
-        d["dtype"] = str(np.dtype(to_numpy(self.x).dtype))
-        d["xp"] = "numpy"
+        # the namespace and the dtype travel as the reference writes them (utils.py:544-565): the module's name, and the dtype as
+        # {"__dtype__": True, "xp": <module name>, "dtype": <name>} - `load` then hands the samples back in THAT namespace
+        xp_name = getattr(self.xp, "__name__", "numpy")
+        dt = self.dtype if self.dtype is not None else getattr(self.x, "dtype", None)
+        d["dtype"] = None if dt is None else {"__dtype__": True, "xp": xp_name, "dtype": str(dt).split(".")[-1]}
+        d["xp"] = xp_name
         return d
 
     def save(self, h5_file, path: str = "samples", flat: bool = False):
@@ -173,8 +177,18 @@ class BaseSamples:
         from .io import load_from_h5_file
 
         d = load_from_h5_file(h5_file, path)
-        d["xp"] = np
-        d["dtype"] = np.dtype(d["dtype"]) if isinstance(d.get("dtype"), str) else None
+        xp_name = d.get("xp")
+        xp_name = xp_name if isinstance(xp_name, str) else "numpy"
+        try:  # (the module the file names - "numpy", "torch", or array_api_compat's wrappers where that package is installed)
+            import importlib
+
+            xp = importlib.import_module(xp_name)
+        except ImportError:
+            xp = torch if "torch" in xp_name else np
+        enc = d.get("dtype")
+        name = enc.get("dtype") if isinstance(enc, dict) else (enc if isinstance(enc, str) else None)
+        d["xp"] = xp
+        d["dtype"] = None if name is None else resolve_dtype(str(name).split(".")[-1], xp)
         return cls.from_dict(d)
 
     def to_dataframe(self, include: list | None = None):
@@ -340,6 +354,10 @@ class Samples(BaseSamples):
         return self.__class__(x=to_numpy(self.x), parameters=self.parameters, log_likelihood=conv(self.log_likelihood),
                               log_prior=conv(self.log_prior), log_q=conv(self.log_q),
                               log_evidence=self.log_evidence, log_evidence_error=self.log_evidence_error)
+
+    def to_dataframe(self, include: list | None = None):
+        """samples.py:559-578: the importance weights' logarithm next to the three log-probabilities by default."""
+        return super().to_dataframe(["log_likelihood", "log_prior", "log_q", "log_w"] if include is None else include)
 
     def __getitem__(self, idx):
         sliced = super().__getitem__(idx)

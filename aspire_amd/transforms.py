@@ -80,6 +80,28 @@ class CompositeTransform:
         self._affine_logj = 0.0
         self._dev = None  # (engine, DeviceTransform) cache
 
+    # The reference composes stage objects (`_periodic_transform`, `_bounded_transform`, `_affine_transform`: transforms.py:192-236); here the
+    # stages are the columns of ONE device table.  These read-only views answer what callers of the reference read off the stages (their
+    # presence, `dtype`, the bounds, the fitted affine moments); a stage that is switched off is None, as there.
+    def _stage_view(self, **kw):
+        from types import SimpleNamespace
+
+        return SimpleNamespace(dtype=self.dtype, xp=self.xp, **kw)
+
+    @property
+    def _periodic_transform(self):
+        w = self._periodic.astype(bool)
+        return self._stage_view(lower=self._lower[w], upper=self._upper[w]) if w.any() else None
+
+    @property
+    def _bounded_transform(self):
+        b = self._kind != 0
+        return self._stage_view(lower=self._lower[b], upper=self._upper[b], eps=self.eps, name=self.bounded_transform) if b.any() else None
+
+    @property
+    def _affine_transform(self):
+        return self._stage_view(_mean=self._mean, _std=self._std) if self.affine_transform else None
+
     # ---- plumbing ---------------------------------------------------------------------------
     @property
     def is_identity(self) -> bool:
@@ -190,6 +212,8 @@ class CompositeTransform:
         grp.attrs["class"] = self.__class__.__name__
         cfg = self.config_dict()
         cfg["prior_bounds"] = None if cfg["prior_bounds"] is None else {k: [float(v[0]), float(v[1])] for k, v in cfg["prior_bounds"].items()}
+        # the dtype as the reference encodes it (utils.py:544-565): {"__dtype__": True, "xp": <module name>, "dtype": <name>}
+        cfg["dtype"] = None if self.dtype is None else {"__dtype__": True, "xp": cfg["xp"], "dtype": str(self.dtype).split(".")[-1]}
         recursively_save_to_h5_file(grp, "config", cfg)
         if self.affine_transform and self._mean is not None:
             aff = grp.create_group("affine_transform")
@@ -212,7 +236,8 @@ class CompositeTransform:
             cls = known[name]
         cfg = load_from_h5_file(grp, "config")
         xp_name = cfg.pop("xp", None)
-        cfg.pop("dtype", None)
+        enc = cfg.pop("dtype", None)
+        dt_name = enc.get("dtype") if isinstance(enc, dict) else (enc if isinstance(enc, str) else None)
         if isinstance(cfg.get("prior_bounds"), dict):
             cfg["prior_bounds"] = {k: (float(np.asarray(v)[0]), float(np.asarray(v)[1])) for k, v in cfg["prior_bounds"].items()}
         for key in ("parameters", "periodic_parameters"):
@@ -225,8 +250,20 @@ class CompositeTransform:
                 cfg[key] = bool(cfg[key])
         if "eps" in cfg:
             cfg["eps"] = float(cfg["eps"])
-        xp = None if xp_name is None else (torch if "torch" in str(xp_name) else np)
-        obj = cls(xp=xp, engine=engine, **cfg)
+        xp = None
+        if xp_name is not None:
+            try:  # (the module the file names, or plain numpy / torch where that wrapper package is absent)
+                import importlib
+
+                xp = importlib.import_module(str(xp_name))
+            except ImportError:
+                xp = torch if "torch" in str(xp_name) else np
+        dtype = None
+        if dt_name is not None:
+            from ._xp import resolve_dtype
+
+            dtype = resolve_dtype(str(dt_name).split(".")[-1], xp if xp is not None else np)
+        obj = cls(xp=xp, engine=engine, dtype=dtype, **cfg)
         if obj.affine_transform and "affine_transform" in grp:
             obj._mean = np.asarray(grp["affine_transform"]["mean"][()], dtype=np.float64)
             obj._std = np.asarray(grp["affine_transform"]["std"][()], dtype=np.float64)

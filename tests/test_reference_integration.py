@@ -173,3 +173,65 @@ def test_auto_checkpoint_resume_skips_flow_training(h5, tmp_path, bounded_to_unb
         resumed.flow.fit = original_fit
         assert history.training_loss == []
         assert history.validation_loss == []
+
+
+# ---- /root/reference/tests/test_history.py:10-41 (the save / load tests; plotting is out of scope) ------------------------------
+def test_history_save_load(h5, tmp_path):
+    from aspire_amd.history import History
+
+    history = History()
+    history.stat = [1, 2, 3]
+    with h5.open_h5(tmp_path / "history.h5", "w") as f:
+        history.save(f, path="history")
+    with h5.open_h5(tmp_path / "history.h5", "r") as f:
+        loaded_history = History.load(f, path="history")
+    assert np.array_equal(loaded_history.stat, [1, 2, 3])
+
+
+def test_smc_history_save_load(h5, tmp_path):
+    from aspire_amd.history import SMCHistory
+    from aspire_amd.samples import SMCSamples
+
+    history = SMCHistory()
+    samples = SMCSamples(x=np.array([[1, 2], [3, 4]]), beta=0.5, parameters=["x1", "x2"])
+    history.sample_history.append(samples)
+    with h5.open_h5(tmp_path / "smc_history.h5", "w") as f:
+        history.save(f, path="smc_history")
+    with h5.open_h5(tmp_path / "smc_history.h5", "r") as f:
+        loaded_history = SMCHistory.load(f, path="smc_history")
+    assert isinstance(loaded_history.sample_history[0], SMCSamples)
+    assert len(loaded_history.sample_history) == 1
+    assert np.array_equal(loaded_history.sample_history[0].x, [[1, 2], [3, 4]])
+    assert loaded_history.sample_history[0].beta == 0.5
+    assert loaded_history.sample_history[0].parameters == ["x1", "x2"]
+
+
+# ---- /root/reference/tests/test_flows/test_torch_flows/test_zuko_flows.py (the flow class the reference builds by default) -------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_zuko_flow(h5, dtype):
+    from aspire_amd.flows import MAFFlow
+    from aspire_amd.transforms import FlowTransform
+
+    dims = 3
+    parameters = [f"x_{i}" for i in range(dims)]
+    data_transform = FlowTransform(parameters=parameters, xp=torch, dtype=dtype)
+    flow = MAFFlow(dims=dims, seed=42, device="cpu", data_transform=data_transform)
+    x = torch.randn(100, dims, device=flow.device)
+    flow.fit_data_transform(x)
+    assert flow.dims == dims
+    x = torch.tensor([0.1, 0.2, 0.3], device=flow.device)
+    log_prob = flow.log_prob(x)
+    assert log_prob.shape == (1,)
+
+
+def test_zuko_flow_save_and_load(h5, tmp_path):
+    from aspire_amd.flows import MAFFlow
+
+    flow = MAFFlow(dims=2, seed=42, device="cpu")
+    x = torch.randn(100, 2, device=flow.device)
+    with h5.open_h5(tmp_path / "result.h5", "w") as f:
+        flow.save(f, "flow")
+    with h5.open_h5(tmp_path / "result.h5", "r") as f:
+        loaded_flow = MAFFlow.load(f, "flow")
+    assert loaded_flow.dims == flow.dims
+    assert torch.allclose(torch.as_tensor(flow.log_prob(x)), torch.as_tensor(loaded_flow.log_prob(x)))
