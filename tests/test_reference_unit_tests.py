@@ -25,10 +25,15 @@ CASES = [
     ("test_samples.py", "not jax and (basesamples or test_samples_ or smc or str_contains)", 29),
     ("test_history.py", "not jax and not plot and not smc_history_samples", 2),
     ("test_transforms.py", "not jax and (composite or flow_transform)", 30),
+    # the end-to-end scenarios: fit -> sample_posterior with the importance and SMC samplers (both bounded settings, three dtypes, numpy and
+    # torch inputs), save_config / save_flow, the likelihood hole with -inf / nan / +inf, auto_checkpoint / resume_from_file.  Left
+    # out: the emcee / blackjax kernels and the stand-alone `minipcn` MCMC sampler, flowjax.
+    ("integration_tests/test_integration.py", "not jax and not flowjax and not emcee and not blackjax and not (minipcn and not smc)", 46),
+    ("integration_tests/test_checkpointing.py", "not jax", 20),
 ]
 
 
-@pytest.mark.parametrize("fname,select,at_least", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("fname,select,at_least", CASES, ids=[os.path.basename(c[0]) for c in CASES])
 def test_reference_unit_tests_pass_against_this_package(fname, select, at_least):
     with tempfile.TemporaryDirectory() as tmp:
         env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "tests", "tools"), PYTHONDONTWRITEBYTECODE="1")

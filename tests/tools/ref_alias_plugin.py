@@ -11,6 +11,10 @@ import os
 import sys
 import types
 
+# /root/reference is read-only for this repository: pytest's assertion rewriter would otherwise cache bytecode of the reference's
+# test modules in a __pycache__ next to them.  Set before any of them is imported (a `-p` plugin loads ahead of collection).
+sys.dont_write_bytecode = True
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
@@ -24,7 +28,15 @@ def _install():
     import sklearn.externals.array_api_compat.common as aaccommon
     import sklearn.externals.array_api_compat.numpy as aacnp
     import sklearn.externals.array_api_compat.torch as aact
-    from fake_h5 import FakeFile
+    from fake_h5 import FakeFile as _MemFile
+
+    class FakeFile(_MemFile):
+        """The in-memory file, plus an empty file on disk under its name: callers test `Path(...).is_file()` before resuming."""
+
+        def __init__(self, name, mode="r", *a, **k):
+            super().__init__(name, mode, *a, **k)
+            if mode not in ("r", "r+"):
+                open(str(name), "ab").close()
 
     sys.modules.update({"array_api_compat": aac, "array_api_compat.numpy": aacnp, "array_api_compat.torch": aact,
                         "array_api_compat.common": aaccommon})
