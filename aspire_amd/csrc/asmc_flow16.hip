@@ -358,8 +358,11 @@ __device__ __forceinline__ double f16_mixture(const MixDev& m, const double* __r
     return best + log(sum);
 }
 
+#ifdef F16_SKEW
+__device__ unsigned g_f16_ticket[4096];
+#endif
 template <typename T, int D, int W, int KIND, int NOISE, bool TP, int THREADS, int CW>
-__global__ __launch_bounds__(THREADS, 2) void k_pcn_flow16(int64_t n, T* __restrict__ x, double* __restrict__ ll, double* __restrict__ lp,
+__global__ __launch_bounds__(THREADS, THREADS > 512 ? 1 : 2) void k_pcn_flow16(int64_t n, T* __restrict__ x, double* __restrict__ ll, double* __restrict__ lp,
                                                        double* __restrict__ lq, const double* __restrict__ blob, int blob_doubles,
                                                        PcnDev p, const double* __restrict__ rho_ptr, uint32_t step,
                                                        const float* __restrict__ packed, int n_layers, float ladj0, float base_const,
@@ -382,6 +385,20 @@ __global__ __launch_bounds__(THREADS, 2) void k_pcn_flow16(int64_t n, T* __restr
     for (int e = threadIdx.x; e < n_layers * FD::BIAS; e += THREADS) s_bias[e] = packed[e];
     if (NOISE == ASMC_NOISE_F64) bm_tab_stage<THREADS>(bmt, p.bmtab);
     __syncthreads();
+#ifdef F16_SKEW  // diagnostic builds (two 4-wave blocks per CU): the SECOND block to arrive on a CU starts F16_SKEW x 8128 cycles late
+    {
+        __shared__ unsigned s_tick;
+        if (threadIdx.x == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            s_tick = atomicAdd(&g_f16_ticket[((xcc & 15u) << 8) | ((hw >> 8) & 0xFFu)], 1u);
+        }
+        __syncthreads();
+        if (s_tick & 1u)
+            for (int i = 0; i < F16_SKEW; i++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pp = lane & 15, h = lane >> 4;
     const int dn = (p.d_noise > 0 && p.d_noise < D) ? p.d_noise : D;  // real dimension of a zero-padded problem
@@ -594,6 +611,12 @@ static int launch_pcn_flow16(asmc_ctx* ctx, int64_t n, T* x, double* ll, double*
     static const bool small_slots = getenv("ASMC_F16_SMALL_SLOTS") != nullptr;  // (A/B switch: 32 KB slots at D = 64 too)
     int rc = ASMC_ERR_UNSUPPORTED;
 #define F16_ARGS ctx, n, x, ll, lp, lq, blob, pd, f, rho_ptr, step, block_counts, grid_out, nonfinite, st
+#ifdef F16_SKEW
+    if constexpr (D == 64) return launch_pcn_flow16_g<T, D, W, KIND, NOISE, TP, 256, 4096, 2>(F16_ARGS);
+#endif
+#ifdef F16_WAVES12  // diagnostic builds: three waves per SIMD (168 registers)
+    if constexpr (D == 64) return launch_pcn_flow16_g<T, D, W, KIND, NOISE, TP, 768, Flow16<KIND, D, W>::LAYER_A, 1>(F16_ARGS);
+#endif
     if constexpr (D == 64) {
         if (!small_slots) rc = launch_pcn_flow16_g<T, D, W, KIND, NOISE, TP, 512, Flow16<KIND, D, W>::LAYER_A, 1>(F16_ARGS);
     }

@@ -749,13 +749,14 @@ class HipSMC(SMCSampler):
             return None
 
     def _adapted_zuko_flow(self):
-        """OPT-IN (`sampler_kwargs["zuko_adapter"] = True`): a proposal that is the reference's own `ZukoFlow(flow_class="MAF")`
-        (what `Aspire.fit` trains and hands to the sampler through the plug-in seam, flows/torch/flows.py:156-168) has no
-        `device_coupling`; its zuko module's state dict is repacked for the HIP kernels by `MAFFlow.from_zuko_state_dict`, so
-        that the mutation runs the one-kernel flow step instead of the callables split path.  Off by default because zuko is
-        absent from the build image: the adapter follows zuko's documented layout and is UNVERIFIED against the package - the
-        first mutation cross-checks it against the flow's own `log_prob` on 256 particles and refuses on a mismatch."""
-        if not self.sampler_kwargs.get("zuko_adapter", False):
+        """A proposal that is the reference's own `ZukoFlow(flow_class="MAF")` (what `Aspire.fit` trains and hands to the sampler
+        through the plug-in seam, flows/torch/flows.py:156-168) has no `device_coupling`; its zuko module's state dict is repacked
+        for the HIP kernels by `MAFFlow.from_zuko_state_dict`, so that the mutation runs the one-kernel flow step instead of the
+        callables split path.  zuko is absent from the build image: the adapter follows zuko's documented layout and is UNVERIFIED
+        against the package, so every adapted flow is cross-checked against the flow's OWN `log_prob` before it is used - on 256
+        standard-normal points and 256 of the flow's own draws - and declined on a mismatch (the flow then stays on its modules).
+        On by default since round 6 (the check decides); `sampler_kwargs["zuko_adapter"] = False` switches it off."""
+        if not self.sampler_kwargs.get("zuko_adapter", True) or not hasattr(self.engine, "coupling_logprob"):
             return None
         pf = self.prior_flow
         inner = getattr(pf, "_flow", None)
@@ -780,12 +781,18 @@ class HipSMC(SMCSampler):
                 adapted = MAFFlow.from_zuko_state_dict(inner.state_dict(), device=self.engine.device)
                 dev = adapted.device_coupling(self.engine)
                 probe = torch.randn((256, self.dims), device=self.engine.device, dtype=torch.float64)
+                try:  # ... and where the flow itself puts its mass
+                    own = pf.sample_and_log_prob(256)[0]
+                    own = self._to_dev(own).reshape(256, self.dims).to(torch.float64)
+                    probe = torch.cat([probe, own[torch.isfinite(own).all(dim=1)]])
+                except Exception as exc:
+                    logger.info("zuko adapter: no draws from the flow for the cross-check (%s); standard-normal probes only", exc)
                 mine = self.engine.coupling_logprob(probe, dev)
                 theirs = self._to_dev(pf.log_prob(probe.to(getattr(pf, "dtype", torch.float32))))
                 err = float(((mine - theirs).abs() / theirs.abs().clamp_min(1.0)).max())
                 if not err <= 1e-4:
                     raise ValueError(f"adapted flow disagrees with the flow's own log_prob (max relative difference {err:.3g})")
-                logger.warning("zuko adapter in use (unverified against zuko itself; agrees with this flow's log_prob to %.1e)", err)
+                logger.info("zuko adapter in use (unverified against zuko itself; agrees with this flow's log_prob to %.1e on %d points)", err, len(probe))
             except Exception as exc:
                 logger.warning("zuko adapter declined: %s", exc)
                 dev = None

@@ -374,12 +374,13 @@ def test_zuko_form_autoregressive_flow_on_the_kernels(eng, oracle, d, hidden, n)
         eng.coupling_logprob(eng.asarray(np.zeros((4, 8))), cdev)
 
 
-def test_opt_in_zuko_adapter_puts_a_reference_style_flow_on_the_one_kernel_step(eng):
-    """`sampler_kwargs["zuko_adapter"] = True`: a proposal WITHOUT `device_coupling` whose `_flow.state_dict()` has zuko's MAF
+def test_zuko_adapter_puts_a_reference_style_flow_on_the_one_kernel_step(eng):
+    """A proposal WITHOUT `device_coupling` whose `_flow.state_dict()` has zuko's MAF
     layout (the shape of the reference's `ZukoFlow`, flows/torch/flows.py:156-168; here a stand-in that evaluates zuko's
     documented arithmetic in PyTorch - zuko itself is absent) is repacked for the kernels, cross-checked against the flow's own
     `log_prob` on a probe batch, and the mutation runs the one-kernel flow step instead of propose / accept kernels around
-    PyTorch passes.  Without the opt-in the same proposal takes the callables path."""
+    PyTorch passes - by default since round 6 (the cross-check decides) and with `zuko_adapter=True`; `zuko_adapter=False` keeps the
+    same proposal on the callables path, and a flow whose own `log_prob` disagrees with its state dict is declined."""
     import math
 
     from conftest import zuko_like_state_dict
@@ -407,11 +408,16 @@ def test_opt_in_zuko_adapter_puts_a_reference_style_flow_on_the_one_kernel_step(
             return inner.sample_and_log_prob(n_samples)
 
     lik = DiagGaussianMixture.isotropic(d, normalized=False)
-    for opt_in in (True, False):
-        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=ZukoLike(), xp=np, engine=eng, rng=np.random.default_rng(11),
+    class Disagrees(ZukoLike):  # (a module whose arithmetic is NOT what its state dict says under zuko's layout)
+        def log_prob(self, x, xp=None):
+            return 1.01 * inner.log_prob(torch.as_tensor(x, device=eng.device, dtype=torch.float32)) + 0.3
+
+    for extra, flow_cls in ((dict(zuko_adapter=True), ZukoLike), (dict(), ZukoLike), (dict(zuko_adapter=False), ZukoLike), (dict(), Disagrees)):
+        opt_in = extra.get("zuko_adapter", True) and flow_cls is ZukoLike
+        sp = HipSMC(log_likelihood=lik, log_prior=lik, dims=d, prior_flow=flow_cls(), xp=np, engine=eng, rng=np.random.default_rng(11),
                     dtype="float64")
         eng.profile(True)
-        out = sp.sample(n if opt_in else 4096, sampler_kwargs=dict(n_steps=4, step_fn="pcn", zuko_adapter=opt_in), store_sample_history=False)
+        out = sp.sample(n if opt_in else 4096, sampler_kwargs=dict(n_steps=4, step_fn="pcn", **extra), store_sample_history=False)
         rep = eng.profile_report()
         eng.profile(False)
         if opt_in:
