@@ -161,7 +161,8 @@ class BaseSamples:
         # {"__dtype__": True, "xp": <module name>, "dtype": <name>} - `load` then hands the samples back in THAT namespace
         xp_name = getattr(self.xp, "__name__", "numpy")
         dt = self.dtype if self.dtype is not None else getattr(self.x, "dtype", None)
-        d["dtype"] = None if dt is None else {"__dtype__": True, "xp": xp_name, "dtype": str(dt).split(".")[-1]}
+        dt_name = None if dt is None else (str(dt).split(".")[-1] if isinstance(dt, torch.dtype) else np.dtype(dt).name)
+        d["dtype"] = None if dt_name is None else {"__dtype__": True, "xp": xp_name, "dtype": dt_name}
         d["xp"] = xp_name
         return d
 

@@ -213,7 +213,8 @@ class CompositeTransform:
         cfg = self.config_dict()
         cfg["prior_bounds"] = None if cfg["prior_bounds"] is None else {k: [float(v[0]), float(v[1])] for k, v in cfg["prior_bounds"].items()}
         # the dtype as the reference encodes it (utils.py:544-565): {"__dtype__": True, "xp": <module name>, "dtype": <name>}
-        cfg["dtype"] = None if self.dtype is None else {"__dtype__": True, "xp": cfg["xp"], "dtype": str(self.dtype).split(".")[-1]}
+        dt_name = None if self.dtype is None else (str(self.dtype).split(".")[-1] if isinstance(self.dtype, torch.dtype) else np.dtype(self.dtype).name)
+        cfg["dtype"] = None if dt_name is None else {"__dtype__": True, "xp": cfg["xp"], "dtype": dt_name}
         recursively_save_to_h5_file(grp, "config", cfg)
         if self.affine_transform and self._mean is not None:
             aff = grp.create_group("affine_transform")
