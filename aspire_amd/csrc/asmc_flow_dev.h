@@ -293,10 +293,18 @@ __device__ __forceinline__ void dense_from_acc_hs(floatx16 (&out)[NBO], const fl
 
 template <int NB>
 __device__ __forceinline__ void acc_bias1(floatx16 (&acc)[NB], const float* __restrict__ b, int hh) {
+    // contiguous per lane half, read as 16-byte vectors.  (Written as sixteen scalar reads, the two layer-parity branches of the fused
+    // step shared their FIRST dword: the compiler hoisted that one read above the branch, fetched the other fifteen as misaligned
+    // ds_read2_b32 pairs and reassembled the accumulator with 22 moves per layer - round 6, from the generated code.)
+    typedef float bias_f4 __attribute__((ext_vector_type(4)));
+    const bias_f4* __restrict__ bp = reinterpret_cast<const bias_f4*>(b + hh * NB * 16);
 #pragma unroll
     for (int nb = 0; nb < NB; nb++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[nb][r] = b[hh * NB * 16 + nb * 16 + r];  // contiguous per lane half: 16-byte LDS reads
+        for (int q = 0; q < 4; q++) {
+            const bias_f4 t = bp[nb * 4 + q];
+            acc[nb][4 * q] = t.x, acc[nb][4 * q + 1] = t.y, acc[nb][4 * q + 2] = t.z, acc[nb][4 * q + 3] = t.w;
+        }
 }
 
 // one coupling layer of one 32-particle tile: cond / trans are the lane half's H / 2 coordinates

@@ -389,13 +389,19 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
         }
         STAMP(1);
         const double rs = tpcn_scale(rho, p.nu, q0t, p.gam, valid ? i : 0);
-        if (NOISE == ASMC_NOISE_F64) {
+        // The real dimension of a zero-padded problem (dn < D) is a RUN-TIME uniform: tested per quad it is two branches per quad and, where
+        // the paths meet, copies of the running sums and of the quad's coordinates (six 64-bit moves per quad in the generated code of
+        // round 5) - and every branch ends a scheduling region.  One branch per tile instead: the full-width loop carries no test at all
+        // (round 6; the same finding as the flows' affine form).
+        auto noise_phase = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
             for (int qd = 0; qd < D / 4; qd++) {
-                if (4 * qd >= dn) continue;  // (wave uniform) a zero-padded problem: no noise beyond its dimension - y stays 0 there
+                if (!FULL && 4 * qd >= dn) continue;  // (wave uniform) a zero-padded problem: no noise beyond its dimension - y stays 0 there
                 double z[4];
-                normal_quad(p.seed, gid, step, (uint32_t)qd, bmt, z[0], z[1], z[2], z[3]);
-                if (4 * qd + 4 <= dn) {  // (wave uniform; the common case: no per-element test, no selects)
+                if constexpr (NOISE == ASMC_NOISE_F64) normal_quad(p.seed, gid, step, (uint32_t)qd, bmt, z[0], z[1], z[2], z[3]);
+                else normal_quad_f32(p.seed, gid, step, (uint32_t)qd, z[0], z[1], z[2], z[3]);
+                if (FULL || 4 * qd + 4 <= dn) {  // (wave uniform; the common case: no per-element test, no selects)
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         q0 = fma(v[4 * qd + e], v[4 * qd + e], q0);
@@ -414,33 +420,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
 #ifndef FUSED_NOISE_SB
 #define FUSED_NOISE_SB 1  // quads between two scheduling barriers of the noise phase
 #endif
-                if (qd % FUSED_NOISE_SB == FUSED_NOISE_SB - 1) __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-#pragma unroll
-            for (int qd = 0; qd < D / 4; qd++) {
-                if (4 * qd >= dn) continue;
-                double z[4];
-                normal_quad_f32(p.seed, gid, step, (uint32_t)qd, z[0], z[1], z[2], z[3]);
-                if (4 * qd + 4 <= dn) {  // (wave uniform; the common case: no per-element test, no selects)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        q0 = fma(v[4 * qd + e], v[4 * qd + e], q0);
-                        v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
-                        q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
-                    }
-                } else {  // the quad that straddles the dimension of a zero-padded problem
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        if (4 * qd + e >= dn) continue;
-                        q0 = fma(v[4 * qd + e], v[4 * qd + e], q0);
-                        v[4 * qd + e] = (double)(T)fma(rs, z[e], a * v[4 * qd + e]);
-                        q1 = fma(v[4 * qd + e], v[4 * qd + e], q1);
-                    }
+                if constexpr (NOISE == ASMC_NOISE_F64) {
+                    if (qd % FUSED_NOISE_SB == FUSED_NOISE_SB - 1) __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    if (qd & 1) __builtin_amdgcn_sched_barrier(0);
                 }
-                if (qd & 1) __builtin_amdgcn_sched_barrier(0);
             }
-        }
+        };
+        if (dn == D) noise_phase(std::true_type{});
+        else noise_phase(std::false_type{});
         STAMP(2);
         // x'_j = mu_j + sum_k L[j,k] y'_k, four rows at a time: straight into the targets' quadratic forms and into the
         // flow's standardised fp32 input (the same (float) x' and division the stand-alone flow kernel applies)
@@ -453,9 +441,21 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
             const double* __restrict__ rowt = Lt + (lane >> 4) * 8;  // this lane group's rows: entry mb * 4 + r <-> row 16 mb + 4 g + r
             const double* __restrict__ Aimg = Lt + lane;
             fused_d4 acc[2][4];
+            // (the per-row tables are read as 16-byte vectors: `ds_read_b128` takes a 16-bit byte offset, the `ds_read2_b64` the compiler
+            // picks for scalar doubles only 8 bits of 8 bytes - every read beyond 2 KB of the lane's base cost one `v_add_u32`, 33 per tile)
+            typedef double row_d2 __attribute__((ext_vector_type(2)));
+            typedef float row_f2 __attribute__((ext_vector_type(2)));
+            static_assert(M_MU % 2 == 0 && M_MIX % 2 == 0 && D % 4 == 0, "16-byte aligned row tables");
+            const row_d2* __restrict__ row2 = reinterpret_cast<const row_d2*>(rowt);
+            auto row4 = [&](int off, int mb, double (&out)[4]) {
+                const row_d2 lo = row2[(off + 4 * mb) / 2], hi = row2[(off + 4 * mb) / 2 + 1];
+                out[0] = lo.x, out[1] = lo.y, out[2] = hi.x, out[3] = hi.y;
+            };
 #pragma unroll
             for (int mb = 0; mb < 2; mb++) {
-                const fused_d4 m = {rowt[M_MU + 4 * mb], rowt[M_MU + 4 * mb + 1], rowt[M_MU + 4 * mb + 2], rowt[M_MU + 4 * mb + 3]};
+                double mu4[4];
+                row4(M_MU, mb, mu4);
+                const fused_d4 m = {mu4[0], mu4[1], mu4[2], mu4[3]};
 #pragma unroll
                 for (int nb = 0; nb < 4; nb++) acc[mb][nb] = m;
             }
@@ -475,18 +475,25 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
 #pragma unroll
             for (int mb = 0; mb < 2; mb++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int e = 4 * mb + r;
-                    const double ma = rowt[M_MIX + e], pa = rowt[M_MIX + D + e];  // component 0 of the likelihood ...
-                    const double mbb = rowt[M_MIX + FUSED_MAX_COMPONENTS * 2 * D + e], pb = rowt[M_MIX + FUSED_MAX_COMPONENTS * 2 * D + D + e];  // ... and of the prior
-                    const float lc = locr[e], sc = locr[D + e], rc = locr[2 * D + e];
+                for (int rp = 0; rp < 2; rp++) {  // two rows at a time: four 16-byte table reads + three 8-byte ones in flight, not eight + six
+                    const int e2 = (4 * mb + 2 * rp) / 2;
+                    const row_d2 ma2 = row2[M_MIX / 2 + e2], pa2 = row2[(M_MIX + D) / 2 + e2];  // component 0 of the likelihood ...
+                    const row_d2 mb2 = row2[(M_MIX + FUSED_MAX_COMPONENTS * 2 * D) / 2 + e2], pb2 = row2[(M_MIX + FUSED_MAX_COMPONENTS * 2 * D + D) / 2 + e2];  // ... and of the prior
+                    const row_f2 lc2 = reinterpret_cast<const row_f2*>(locr)[e2], sc2 = reinterpret_cast<const row_f2*>(locr + D)[e2],
+                                 rc2 = reinterpret_cast<const row_f2*>(locr + 2 * D)[e2];
 #pragma unroll
-                    for (int nb = 0; nb < 4; nb++) {
-                        const double xj = (double)(T)acc[mb][nb][r];
-                        const double ta = xj - ma, tb = xj - mbb;
-                        qpa[nb] = fma(ta * ta, pa, qpa[nb]);
-                        qpb[nb] = fma(tb * tb, pb, qpb[nb]);
-                        xf[(4 * mb + nb) * 4 + r] = flow_standardise((float)xj, lc, sc, rc);
+                    for (int rr = 0; rr < 2; rr++) {
+                        const int r = 2 * rp + rr;
+                        const double ma = ma2[rr], pa = pa2[rr], mbb = mb2[rr], pb = pb2[rr];
+                        const float lc = lc2[rr], sc = sc2[rr], rc = rc2[rr];
+#pragma unroll
+                        for (int nb = 0; nb < 4; nb++) {
+                            const double xj = (double)(T)acc[mb][nb][r];
+                            const double ta = xj - ma, tb = xj - mbb;
+                            qpa[nb] = fma(ta * ta, pa, qpa[nb]);
+                            qpb[nb] = fma(tb * tb, pb, qpb[nb]);
+                            xf[(4 * mb + nb) * 4 + r] = flow_standardise((float)xj, lc, sc, rc);
+                        }
                     }
                 }
             // a particle's four lanes hold its partial sums: the same transpose brings them into the particle's own lane
