@@ -333,7 +333,8 @@ __device__ __forceinline__ double f16_quad_sum_d(double q) {
 
 // diagonal-mixture log-density from the lane's coordinates (asmc_pcn_mm.hip mm_mixture: same order of operations)
 template <int D>
-__device__ __forceinline__ double f16_mixture(const MixDev& m, const double* __restrict__ tab, const double (&xv)[D / 4], int h) {
+__device__ __forceinline__ double f16_mixture(const MixDev& m, const double* __restrict__ tab, const double* __restrict__ logw,
+                                              const double (&xv)[D / 4], int h) {  // logw: the log-weights, staged in LDS (see mm_mixture)
     double terms[ASMC_MAX_COMPONENTS];
     double best = -INFINITY;
     for (int c = 0; c < m.C; c++) {
@@ -348,7 +349,7 @@ __device__ __forceinline__ double f16_mixture(const MixDev& m, const double* __r
             q = fma(t1 * t1, pr2.y, q);
         }
         q = f16_quad_sum_d(q);
-        terms[c] = m.logw[c] - 0.5 * q;
+        terms[c] = logw[c] - 0.5 * q;
         best = fmax(best, terms[c]);
     }
     if (m.C == 1) return terms[0];
@@ -384,6 +385,12 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 1 : 2) void k_pcn_flow16(i
     for (int e = threadIdx.x * 2; e < blob_doubles; e += THREADS * 2) *reinterpret_cast<double2*>(smem + e) = *reinterpret_cast<const double2*>(blob + e);
     for (int e = threadIdx.x; e < n_layers * FD::BIAS; e += THREADS) s_bias[e] = packed[e];
     if (NOISE == ASMC_NOISE_F64) bm_tab_stage<THREADS>(bmt, p.bmtab);
+    __shared__ double s_logw[2 * ASMC_MAX_COMPONENTS];  // log-weights of (ll, lp): read per group, never through the global pointer
+    if (threadIdx.x < 2 * ASMC_MAX_COMPONENTS) {
+        const int c = threadIdx.x % ASMC_MAX_COMPONENTS;
+        const MixDev& mt = threadIdx.x < ASMC_MAX_COMPONENTS ? p.ll : p.lp;
+        s_logw[threadIdx.x] = c < mt.C ? mt.logw[c] : 0.0;
+    }
     __syncthreads();
 #ifdef F16_SKEW  // diagnostic builds (two 4-wave blocks per CU): the SECOND block to arrive on a CU starts F16_SKEW x 8128 cycles late
     {
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 1 : 2) void k_pcn_flow16(i
             o[2 * sp] = (double)(T)(m2.x + o[2 * sp]);
             o[2 * sp + 1] = (double)(T)(m2.y + o[2 * sp + 1]);
         }
-        const double nll = f16_mixture<D>(p.ll, t_ll, o, h), nlp = f16_mixture<D>(p.lp, t_lp, o, h);
+        const double nll = f16_mixture<D>(p.ll, t_ll, s_logw, o, h), nlp = f16_mixture<D>(p.lp, t_lp, s_logw + ASMC_MAX_COMPONENTS, o, h);
         F16State<FD> xf;
 #pragma unroll
         for (int s = 0; s < KS; s++) xf.set(s, flow_standardise((float)o[s], s_loc[s * 4 + h], s_loc[D + s * 4 + h], s_loc[2 * D + s * 4 + h]));
@@ -543,7 +550,7 @@ template <int KIND, int D, int W, int CW = FLOW16_CHUNK_WORDS>
 static size_t f16_step_lds(int n_layers, int c_ll, int c_lp, int noise) {
     using FD = Flow16<KIND, D, W, CW>;
     return f16_blob_doubles(D, c_ll, c_lp) * 8 + (size_t)n_layers * FD::BIAS * 4 + (noise == ASMC_NOISE_F64 ? BM_TAB_N * sizeof(bm_d2) : 0) +
-           2 * (size_t)CW * 4 + 16 * 8 /* s_cnt */;
+           2 * (size_t)CW * 4 + 16 * 8 /* s_cnt */ + 2 * ASMC_MAX_COMPONENTS * 8 /* s_logw */;
 }
 
 // shapes of the one-kernel step (every instantiation is x 2 state dtypes x 2 noise generators x pCN / tpCN)
@@ -583,8 +590,8 @@ template <typename T, int D, int W, int KIND, int NOISE, bool TP, int THREADS, i
 static int launch_pcn_flow16_g(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, double* lq, const double* blob, const PcnDev& pd,
                                const asmc_coupling* f, const double* rho_ptr, uint32_t step, long long* block_counts, int* grid_out,
                                unsigned long long* nonfinite, hipStream_t st) {
-    const size_t lds = f16_step_lds<KIND, D, W, CW>(f->n_layers, pd.ll.C, pd.lp.C, NOISE) - 128;
-    if ((lds + 128) * PER_CU > 160 * 1024) return ASMC_ERR_UNSUPPORTED;  // (the caller tries the next geometry)
+    const size_t lds = f16_step_lds<KIND, D, W, CW>(f->n_layers, pd.ll.C, pd.lp.C, NOISE) - 256;  // (the static part: s_cnt, s_logw)
+    if ((lds + 256) * PER_CU > 160 * 1024) return ASMC_ERR_UNSUPPORTED;  // (the caller tries the next geometry)
     auto kern = k_pcn_flow16<T, D, W, KIND, NOISE, TP, THREADS, CW>;
     static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];
     if (lds > 64 * 1024 && lds > attr_lds) {

@@ -94,7 +94,8 @@ __device__ __forceinline__ void mm_stage_tables(double* tab, const MixDev& m, in
 // diagonal-mixture log-density of the particle whose coordinates this lane holds (same formula as mixture_eval in
 // asmc_pcn.hip: log-sum-exp over the components' logw - q / 2)
 template <int D>
-__device__ __forceinline__ double mm_mixture(const MixDev& m, const double* __restrict__ tab, const double (&xv)[D / 4], int h) {
+__device__ __forceinline__ double mm_mixture(const MixDev& m, const double* __restrict__ tab, const double* __restrict__ logw,
+                                             const double (&xv)[D / 4], int h) {  // logw: the components' log-weights, STAGED IN LDS by the caller
     double terms[ASMC_MAX_COMPONENTS];
     double best = -INFINITY;
     for (int c = 0; c < m.C; c++) {
@@ -109,7 +110,9 @@ __device__ __forceinline__ double mm_mixture(const MixDev& m, const double* __re
             q = fma(t1 * t1, pr2.y, q);
         }
         q = quad_sum(q);
-        terms[c] = m.logw[c] - 0.5 * q;
+        // (read through the mixture's device pointer this was a global load with a full `s_waitcnt vmcnt(0)` per component and
+        // density, inside the loop over the groups: the wave drained its row loads and stores three times per group - round 6)
+        terms[c] = logw[c] - 0.5 * q;
         best = fmax(best, terms[c]);
     }
     if (m.C == 1) return terms[0];
@@ -147,7 +150,13 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
         const int q = e & 1, hh = (e >> 1) & 3, sp = e >> 3;
         s_mu[e] = p.mu[mm_coord(2 * sp + q, hh)];
     }
+    __shared__ double s_logw[3 * ASMC_MAX_COMPONENTS];  // log-weights of (ll, lp, lq)
     if (M != MM_WHITEN && M != MM_XPROPOSE && M != MM_UNWHITEN_X) {
+        if (threadIdx.x < 3 * ASMC_MAX_COMPONENTS) {
+            const int t = threadIdx.x / ASMC_MAX_COMPONENTS, c = threadIdx.x % ASMC_MAX_COMPONENTS;
+            const MixDev& mt = t == 0 ? p.ll : t == 1 ? p.lp : p.lq;
+            s_logw[threadIdx.x] = c < mt.C ? mt.logw[c] : 0.0;
+        }
         mm_stage_tables<D>(t_ll, p.ll, threadIdx.x, MM_THREADS);
         mm_stage_tables<D>(t_lp, p.lp, threadIdx.x, MM_THREADS);
         mm_stage_tables<D>(t_lq, p.lq, threadIdx.x, MM_THREADS);
@@ -216,8 +225,8 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
                 o[2 * sp] = (double)(T)(m2.x + o[2 * sp]);
                 o[2 * sp + 1] = (double)(T)(m2.y + o[2 * sp + 1]);
             }
-            const double nll = mm_mixture<D>(p.ll, t_ll, o, h), nlp = mm_mixture<D>(p.lp, t_lp, o, h),
-                         nlq = mm_mixture<D>(p.lq, t_lq, o, h);
+            const double nll = mm_mixture<D>(p.ll, t_ll, s_logw, o, h), nlp = mm_mixture<D>(p.lp, t_lp, s_logw + ASMC_MAX_COMPONENTS, o, h),
+                         nlq = mm_mixture<D>(p.lq, t_lq, s_logw + 2 * ASMC_MAX_COMPONENTS, o, h);
             if (valid) {
                 store_row(o);
                 if (h == 0) ll[row] = nll, lp[row] = nlp, lq[row] = nlq;
@@ -323,8 +332,8 @@ __global__ __launch_bounds__(MM_THREADS) void k_pcn_mm(int64_t n, T* __restrict_
                 }
                 continue;
             }
-            const double nll = mm_mixture<D>(p.ll, t_ll, o, h), nlp = mm_mixture<D>(p.lp, t_lp, o, h),
-                         nlq = mm_mixture<D>(p.lq, t_lq, o, h);
+            const double nll = mm_mixture<D>(p.ll, t_ll, s_logw, o, h), nlp = mm_mixture<D>(p.lp, t_lp, s_logw + ASMC_MAX_COMPONENTS, o, h),
+                         nlq = mm_mixture<D>(p.lq, t_lq, s_logw + 2 * ASMC_MAX_COMPONENTS, o, h);
             if (valid) {
                 const double lpn = log_p_t(nll, nlp, nlq, p.beta);
                 const double lpo = log_p_t(ll[row], lp[row], lq[row], p.beta);
@@ -588,7 +597,7 @@ static int launch_mm(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* lp, dou
     const size_t lds = XP ? ((size_t)2 * mm_ksum(D / 16) * 64 + D) * sizeof(double)
                      : MODE == MM_UNWHITEN_X ? ((size_t)mm_ksum(D / 16) * 64 + D) * sizeof(double)
                           : ((size_t)mm_ksum(D / 16) * 64 + D + (size_t)(pd.ll.C + pd.lp.C + pd.lq.C) * D * 2) * sizeof(double);
-    ASMC_REQUIRE(lds <= 160 * 1024 - 256 - BM_TAB_N * sizeof(bm_d2), "operand image and density tables exceed the LDS");
+    ASMC_REQUIRE(lds <= 160 * 1024 - 512 - BM_TAB_N * sizeof(bm_d2), "operand image and density tables exceed the LDS");  // (512: the static part - block counts, log-weights)
     auto kern = k_pcn_mm<T, D, NOISE, MODE>;
     static size_t attr_lds_dev[ASMC_MAX_DEVICES] = {0}; size_t& attr_lds = attr_lds_dev[asmc_dev_slot(ctx)];
     if (lds > 64 * 1024 && lds > attr_lds) {
