@@ -598,6 +598,11 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
                     // v keeps y' (it is what gets stored); x'_j = mu_j + sum_k L[j,k] y'_k is produced four rows
                     // at a time and folded straight into the three quadratic forms (component 0 of each target)
                     double qa = 0.0, qb = 0.0, qc = 0.0;
+                    // L comes from the BLOCKED copy of the table (PTAB_BLK): sixteen consecutive doubles per 4 x 4 block, in the order of
+                    // use.  Read from the row-packed triangle the scalar loads were merged into 64-byte pieces that straddle row groups -
+                    // data loaded long before its use, which the pCN instantiation then parked in vector-register lanes: 1 134
+                    // v_writelane / v_readlane per tile next to 1 092 fp64 FMAs (round 5's generated code).  Same products, same order.
+                    const double* __restrict__ Lb = tab + PTAB_SIZE(D);
 #pragma unroll
                     for (int g = 0; g < D / 4; g++) {
                         const int j0 = 4 * g;
@@ -606,7 +611,7 @@ __device__ __forceinline__ void pcn_reg_body(int64_t n, T* __restrict__ x, doubl
                         for (int k = 0; k < j0 + 4; k++) {
 #pragma unroll
                             for (int r = 0; r < 4; r++)
-                                if (k <= j0 + r) sr[r] = fma(Lp[(j0 + r) * (j0 + r + 1) / 2 + k], v[k], sr[r]);
+                                if (k <= j0 + r) sr[r] = fma(Lb[16 * (g * (g + 1) / 2 + k / 4) + 4 * (k % 4) + r], v[k], sr[r]);
                         }
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
@@ -676,7 +681,9 @@ __global__ __launch_bounds__(ASMC_BLOCK, 2) void k_pcn_reg(int64_t n, T* __restr
                                                           long long* __restrict__ block_counts) {
     pcn_reg_body<T, D, NOISE, MODE>(n, x, ll, lp, lq, ptab, p, rho_ptr, step, block_counts);
 }
-// (a three-waves-per-SIMD build of the LDS-free step modes spills 200-300 B/lane to scratch and is slower: 0.19 vs 0.136 ms)
+// (a three-waves-per-SIMD build of the LDS-free step modes spills 200-300 B/lane to scratch and is slower: 0.19 vs 0.136 ms; round 6,
+// with the blocked table: the pCN step at 168 registers spills 52 B and takes 165 us against 148 at two waves; the Student-t step
+// fits three waves by itself - profiles/r06_ab_pcn_blocked_L.txt)
 
 // Flow-proposal pCN on the whitened state, split around the flow's log-density kernel (asmc_flow.hip):
 //   PCN_FLOW_PROPOSE  y' = a y + rho xi;  x' = mu + L y'  -> x_prop tile, ll'(x'), lp'(x') (built-in targets)
@@ -1486,6 +1493,17 @@ __global__ __launch_bounds__(256) void k_pcn_pack(PcnDev pd, double* __restrict_
         }
     }
     for (int e = threadIdx.x; e < D; e += 256) t[2 * tri + e] = e < dr ? pd.mu[e] : 0.0;
+    if (D % 4 == 0) {  // the blocked copy of L (PTAB_BLK)
+        double* tb = t + 2 * tri + D + 3 * PTAB_MIX(D);
+        const int nblk = (D / 4) * (D / 4 + 1) / 2;
+        for (int e = threadIdx.x; e < nblk * 16; e += 256) {
+            const int b = e >> 4, kk = (e >> 2) & 3, r = e & 3;
+            int g = 0;
+            while ((g + 1) * (g + 2) / 2 <= b) g++;
+            const int c = b - g * (g + 1) / 2, j = 4 * g + r, k = 4 * c + kk;
+            tb[e] = k > j ? 0.0 : (j < dr ? pd.L[j * dr + k] : (k == j ? 1.0 : 0.0));
+        }
+    }
     double* m0 = t + 2 * tri + D;
     const MixDev* mixes[3] = {&pd.ll, &pd.lp, &pd.lq};
     for (int i = 0; i < 3; i++) {
@@ -1663,12 +1681,17 @@ static int launch_pcn_step(asmc_ctx* ctx, int64_t n, T* x, double* ll, double* l
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_WHITEN)   \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN) \
     PCN_CASE2(DD, ASMC_NOISE_F64, PCN_UNWHITEN_X)
+#ifdef PCN_DIAG_ONLY_D32S  // diagnostic builds (generated-code experiments): the coordinate-major d = 32 steps alone
+            PCN_CASE2(32, ASMC_NOISE_F64, PCN_Y_STEP_S)
+            PCN_CASE2(32, ASMC_NOISE_F64, PCN_Y_STEP_TS)
+#else
             PCN_CASE(4)
             PCN_CASE(8)
             PCN_CASE(16)
             PCN_CASE(32)
             PCN_CASE2(32, ASMC_NOISE_F64, PCN_X_PROPOSE_PAD)
             PCN_CASE2(32, ASMC_NOISE_F64, PCN_X_PROPOSE_PAD_T)
+#endif
 #undef PCN_CASE
 #undef PCN_CASE2
             default: break;

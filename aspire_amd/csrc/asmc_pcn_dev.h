@@ -421,6 +421,9 @@ struct PcnDev {
 #define PTAB_TRI(D) ((D) * ((D) + 1) / 2)
 #define PTAB_MIX(D) (ASMC_MAX_COMPONENTS * (1 + 2 * (D)))
 #define PTAB_SIZE(D) (2 * PTAB_TRI(D) + (D) + 3 * PTAB_MIX(D))
+// behind it (round 6): L once more, in the order the coordinate-major step consumes it - the 4 x 4 blocks of the lower block triangle,
+// row group by row group, block (g, c) at 16 (g (g + 1) / 2 + c), entry [k % 4][r] = L[4 g + r][4 c + k % 4] (zero above the diagonal)
+#define PTAB_BLK(D) (((D) / 4) * ((D) / 4 + 1) / 2 * 16)
 struct PcnScalars {
     double beta;
     double nu;  // Student-t degrees of freedom of the reference (tpCN) or <= 0 (Gaussian pCN)
