@@ -118,7 +118,9 @@ struct Flow16Stream {
         // wave w takes the 1 KiB pieces w, w + WAVES, ... of the chunk (the LDS side of a piece is wave-uniform base + lane * 16
         // bytes: contiguous in exactly the order of the source)
         constexpr int WAVES = THREADS / 64;
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        // (the wave index as a SCALAR: derived from threadIdx.x it counts as divergent, and the LDS base of global_load_lds - the M0
+        // register - then sits in a waterfall loop that the compiler wraps around each chunk's whole block of matrix instructions)
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
         for (int q = wave; q * 256 < words; q += WAVES) {
             const float* src = gA + off + q * 256 + lane * 4;
             float* dst = slots + slot * FD::CW + q * 256;
