@@ -5,7 +5,7 @@ OUT=$1; shift
 : > $OUT
 for rep in 1 2 3; do
   for v in "$@"; do
-    for kind in maf coupling; do
+    for kind in ${KINDS:-maf coupling}; do
       if [ "$v" = tree ]; then
         r=$(KIND=$kind RHO=0.02 ADAPT=0 STEPS=32 python tools/flowstep_bench.py 2>&1 | grep -E "ms/step|k_pcn_flow_fused" | tr -s ' ' | tr '\n' ' ')
       else
