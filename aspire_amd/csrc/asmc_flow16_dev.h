@@ -260,12 +260,11 @@ __device__ __forceinline__ void f16_layer(const float (&cond)[FD::CS], float (&t
     // pair, which it does not depend on - one basic block, so the scheduler places it between them (round 6; round 5 ran every
     // pair's epilogue between two bursts of matrix instructions: 12 MFMAs, ~90 vector instructions with their wait states, ...).
     floatx4 po[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
-    auto epilogue = [&](const floatx4 (&o)[2], int m) {  // the lane's transformed slots 4 m .. 4 m + 3
+    flow_f2 lacc = {0.0f, 0.0f};  // the layer's log-determinant per coordinate parity (flow_affine2), folded into ladj at the end
+    auto epilogue = [&](const floatx4 (&o)[2], int m) {  // the lane's transformed slots 4 m .. 4 m + 3, two at a time
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float sraw = o[0][r], tt = o[1][r];
-            flow_affine<INVERSE>(trans[4 * m + r], sraw, tt, ladj, FORM >= 0 ? FORM : form);  // (asmc_flow_dev.h: form 0 = 2 tanh(sraw / 2); 1 = zuko's soft clip)
-        }
+        for (int r = 0; r < 4; r += 2)  // (asmc_flow_dev.h: form 0 = 2 tanh(sraw / 2); 1 = zuko's soft clip)
+            flow_affine2<INVERSE>(trans[4 * m + r], trans[4 * m + r + 1], o[0][r], o[0][r + 1], o[1][r], o[1][r + 1], lacc, FORM >= 0 ? FORM : form);
     };
 #pragma unroll
     for (int p = 0; p < FD::P3; p++) {
@@ -280,6 +279,7 @@ __device__ __forceinline__ void f16_layer(const float (&cond)[FD::CS], float (&t
         }
     }
     epilogue(po, FD::P3 * (FD::BC3 / 2) - 1);
+    ladj += lacc.x + lacc.y;
 }
 
 // the lane's standardised coordinates: slot s of the lane is a[s] (autoregressive flows: every slot; coupling flows: the

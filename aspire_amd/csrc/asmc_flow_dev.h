@@ -45,6 +45,51 @@ __device__ __forceinline__ void flow_affine(float& x, float sraw, float t, float
     }
 }
 
+// TWO coordinates of an affine transform at once, on the packed fp32 instructions (v_pk_mul / v_pk_add / v_pk_fma_f32: two results per
+// lane and issue slot) - round 6: the scalar form cost 9.5 vector instructions per coordinate, this one 6.5 (three of them the
+// transcendentals).  Form 0 per coordinate: e = exp2(s_raw log2 e), r = 1 / (e + 1), s = fma(r, -4, 2) [= 2 tanh(s_raw / 2)],
+// z = (x - t) exp2(fma(r, 4 log2 e, -2 log2 e)) [= (x - t) exp(-s), the exponent formed from r by ONE fma instead of through s];
+// sampling direction: x = fma(z, exp2(fma(r, -4 log2 e, 2 log2 e)), t).  `lacc` collects the layer's log-determinant per PARITY of the
+// coordinate (the caller adds lacc.x + lacc.y to its running value at the end of the layer): every kernel family pairs and folds
+// the same way (coupling_layer, _hs, _hs2, _hs1p, f16_layer), so a carried log q and its re-evaluation still agree bit for bit.
+typedef float flow_f2 __attribute__((ext_vector_type(2)));
+template <bool INVERSE>
+__device__ __forceinline__ void flow_affine2(float& x0, float& x1, float s0, float s1, float t0, float t1, flow_f2& lacc, int form) {
+    constexpr float L2E = 1.4426950408889634f;
+    const flow_f2 sr = {s0, s1}, tt = {t0, t1};
+    flow_f2 xx = {x0, x1};
+    if (form == 0) {
+        const flow_f2 a = sr * L2E;
+        const flow_f2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+        const flow_f2 d = e + 1.0f;
+        const flow_f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        const flow_f2 sv = __builtin_elementwise_fma(r, (flow_f2)(-4.0f), (flow_f2)(2.0f));
+        if (INVERSE) {
+            const flow_f2 ea = __builtin_elementwise_fma(r, (flow_f2)(-4.0f * L2E), (flow_f2)(2.0f * L2E));
+            const flow_f2 w = {__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)};
+            xx = __builtin_elementwise_fma(xx, w, tt);
+        } else {
+            const flow_f2 ea = __builtin_elementwise_fma(r, (flow_f2)(4.0f * L2E), (flow_f2)(-2.0f * L2E));
+            const flow_f2 w = {__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)};
+            xx = (xx - tt) * w;
+        }
+        lacc -= sv;
+    } else {
+        const flow_f2 ab = {__builtin_fabsf(s0), __builtin_fabsf(s1)};
+        const flow_f2 dn = __builtin_elementwise_fma(ab, (flow_f2)(0.14476482730108395f), (flow_f2)(1.0f));  // 1 + |s_raw| / ln(1000)
+        const flow_f2 ls = sr * (flow_f2){__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y)};
+        if (INVERSE) {
+            const flow_f2 ea = ls * (-L2E);
+            xx = (xx - tt) * (flow_f2){__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)};
+        } else {
+            const flow_f2 ea = ls * L2E;
+            xx = __builtin_elementwise_fma(xx, (flow_f2){__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)}, tt);
+        }
+        lacc += ls;
+    }
+    x0 = xx.x, x1 = xx.y;
+}
+
 template <int H, int W>
 struct FlowDims {
     static constexpr int NB1 = W / 32;  // accumulator blocks of a hidden layer
@@ -175,16 +220,19 @@ __device__ __forceinline__ void coupling_layer(const float (&cond)[TPW][H / 2], 
     acc_bias<TPW, FD::NB3>(o, b3, hh);
     dense_from_acc<TPW, FD::NB3, FD::NB1>(o, h2, A3, lane);
 #pragma unroll
-    for (int tt = 0; tt < TPW; tt++)
+    for (int tt = 0; tt < TPW; tt++) {
+        static_assert((H / 2) % 2 == 0, "coordinates in pairs");
+        flow_f2 lacc = {0.0f, 0.0f};
 #pragma unroll
-        for (int q = 0; q < H / 2; q++) {
-            const float sraw = o[tt][q / 16][q % 16];
-            const float t = o[tt][(H / 2 + q) / 16][(H / 2 + q) % 16];
+        for (int q = 0; q < H / 2; q += 2) {
             // s = 2 tanh(sraw / 2) = 2 - 4 / (exp(sraw) + 1) on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32): absolute error
             // ~1e-7, which is all that matters (s is added to the log-determinant and exponentiated); libm's
             // tanhf + expf would cost as many issue cycles per layer as a third of its MFMAs
-            flow_affine<false>(trans[tt][q], sraw, t, ladj[tt], form);
+            flow_affine2<false>(trans[tt][q], trans[tt][q + 1], o[tt][q / 16][q % 16], o[tt][(q + 1) / 16][(q + 1) % 16],
+                                o[tt][(H / 2 + q) / 16][(H / 2 + q) % 16], o[tt][(H / 2 + q + 1) / 16][(H / 2 + q + 1) % 16], lacc, form);
         }
+        ladj[tt] += lacc.x + lacc.y;
+    }
 }
 
 
@@ -356,12 +404,12 @@ __device__ __forceinline__ void coupling_layer_hs(const float (&cond)[H / 2], fl
     floatx16 o[FD::NB3];
     acc_bias1<FD::NB3>(o, b3, hh);
     dense_from_acc_hs<FD::NB3, FD::NB1, true>(o, h2, A3, lane, amax);
+    flow_f2 lacc = {0.0f, 0.0f};
 #pragma unroll
-    for (int q = 0; q < H / 2; q++) {
-        const float sraw = o[q / 16][q % 16];
-        const float t = o[(H / 2 + q) / 16][(H / 2 + q) % 16];
-        flow_affine<INVERSE>(trans[q], sraw, t, ladj, FORM >= 0 ? FORM : form);  // (form 0: s = 2 tanh(sraw / 2), see coupling_layer)
-    }
+    for (int q = 0; q < H / 2; q += 2)  // (form 0: s = 2 tanh(sraw / 2), see coupling_layer; pairs: flow_affine2)
+        flow_affine2<INVERSE>(trans[q], trans[q + 1], o[q / 16][q % 16], o[(q + 1) / 16][(q + 1) % 16], o[(H / 2 + q) / 16][(H / 2 + q) % 16],
+                              o[(H / 2 + q + 1) / 16][(H / 2 + q + 1) % 16], lacc, FORM >= 0 ? FORM : form);
+    ladj += lacc.x + lacc.y;
 }
 
 // ---- two tiles through one coupling layer, matrix and vector work interleaved by hand (round 3) ---------------------------
@@ -472,15 +520,11 @@ __device__ __forceinline__ void coupling_layer_hs2(const float (&condA)[H / 2], 
     };
     auto pack = [](const unsigned (&q)[4]) -> half8 { return __builtin_bit_cast(half8, flow_u4{q[0], q[1], q[2], q[3]}); };
     // the epilogue of one tile in four parts (two of its H / 2 coordinates each)
-    auto epi = [&](const floatx16 (&o)[NB3], float (&trans)[H / 2], float& ladj, int c) {
-#pragma unroll
-        for (int q = 2 * c; q < 2 * c + 2; q++) {
-            const float sraw = o[q / 16][q % 16];
-            const float t = o[(H / 2 + q) / 16][(H / 2 + q) % 16];
-            const float sv = 2.0f - 4.0f * __builtin_amdgcn_rcpf(__expf(sraw) + 1.0f);  // 2 tanh(sraw / 2), see coupling_layer
-            trans[q] = (trans[q] - t) * __expf(-sv);
-            ladj -= sv;
-        }
+    flow_f2 laccA = {0.0f, 0.0f}, laccB = {0.0f, 0.0f};  // (folded into ladjA / ladjB behind the last part)
+    auto epi = [&](const floatx16 (&o)[NB3], float (&trans)[H / 2], flow_f2& lacc, int c) {
+        const int q = 2 * c;  // 2 tanh(sraw / 2), see coupling_layer; the pair (q, q + 1): flow_affine2
+        flow_affine2<false>(trans[q], trans[q + 1], o[q / 16][q % 16], o[(q + 1) / 16][(q + 1) % 16], o[(H / 2 + q) / 16][(H / 2 + q) % 16],
+                            o[(H / 2 + q + 1) / 16][(H / 2 + q + 1) % 16], lacc, 0);
     };
 #pragma unroll
     for (int c = 0; c < 4; c++) cvtA(0, c);
@@ -530,14 +574,16 @@ __device__ __forceinline__ void coupling_layer_hs2(const float (&condA)[H / 2], 
             for (int c = 0; c < 4; c++)
                 if (c * NM / 4 == m) {
                     if (g + 1 < G) cvtA(g + 1, c);
-                    else epi(oA, transA, ladjA, c);
+                    else epi(oA, transA, laccA, c);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (g + 1 < G) bhA = pack(hpA), blA = pack(lpA);
     }
 #pragma unroll
-    for (int c = 0; c < 4; c++) epi(oB, transB, ladjB, c);
+    for (int c = 0; c < 4; c++) epi(oB, transB, laccB, c);
+    ladjA += laccA.x + laccA.y;
+    ladjB += laccB.x + laccB.y;
 }
 
 // ---- ONE tile through a coupling layer, its own conversions in the shadow of its own MFMAs (round 4) --------------------------
@@ -645,12 +691,12 @@ __device__ __forceinline__ void coupling_layer_hs1p(const float (&cond)[H / 2], 
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    flow_f2 lacc = {0.0f, 0.0f};
 #pragma unroll
-    for (int q = 0; q < H / 2; q++) {
-        const float sraw = o[q / 16][q % 16];
-        const float t = o[(H / 2 + q) / 16][(H / 2 + q) % 16];
-        flow_affine<false>(trans[q], sraw, t, ladj, FORM >= 0 ? FORM : form);  // (form 0: 2 tanh(sraw / 2), see coupling_layer)
-    }
+    for (int q = 0; q < H / 2; q += 2)  // (form 0: 2 tanh(sraw / 2), see coupling_layer; pairs: flow_affine2)
+        flow_affine2<false>(trans[q], trans[q + 1], o[q / 16][q % 16], o[(q + 1) / 16][(q + 1) % 16], o[(H / 2 + q) / 16][(H / 2 + q) % 16],
+                            o[(H / 2 + q + 1) / 16][(H / 2 + q + 1) % 16], lacc, FORM >= 0 ? FORM : form);
+    ladj += lacc.x + lacc.y;
 }
 
 // Stage `n_layers` coupling layers from the fp32 pack in HBM into LDS as split-fp16 operand images (biases copied).

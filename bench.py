@@ -78,32 +78,41 @@ def launch_ranks(n_gpus: int) -> int:
             print(f"bench.py: --gpus {n_gpus} but {have} HIP device(s) visible; refusing to measure fewer GPUs than asked for",
                   file=sys.stderr)
             return 2
-    with socket.socket() as sk:  # a free rendezvous port
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n_gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd(),
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
     import threading
 
-    got = []
-    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
-    failed = None
-    while failed is None and any(p.poll() is None for p in procs):
-        failed = next((p for p in procs if p.poll() not in (None, 0)), None)
-        time.sleep(0.05)
-    if failed is not None:  # one rank died: its peers would wait in a collective until a watchdog fires - end exactly those processes
-        time.sleep(2.0)
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    rcs = [p.wait() for p in procs]
-    reader.join(timeout=10)
-    out = got[0] if got else ""
+    for attempt in range(3):
+        with socket.socket() as sk:  # a free rendezvous port
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for r in range(n_gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=os.getcwd(),
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=subprocess.PIPE if r == 0 else None,
+                                          text=True if r == 0 else None))
+        got, err0 = [], []
+        reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
+        ereader = threading.Thread(target=lambda: err0.append(procs[0].stderr.read()), daemon=True)  # rank 0 hosts the rendezvous
+        reader.start(), ereader.start()
+        failed = None
+        while failed is None and any(p.poll() is None for p in procs):
+            failed = next((p for p in procs if p.poll() not in (None, 0)), None)
+            time.sleep(0.05)
+        if failed is not None:  # one rank died: its peers would wait in a collective until a watchdog fires - end exactly those processes
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        rcs = [p.wait() for p in procs]
+        reader.join(timeout=10), ereader.join(timeout=10)
+        out, err = (got[0] if got else ""), (err0[0] if err0 else "")
+        # the port was free when it was picked, not necessarily when rank 0 listened on it: that one failure is repeated on a fresh port
+        if any(rcs) and "EADDRINUSE" in err and attempt < 2:
+            print("bench.py: rendezvous port taken before rank 0 could listen on it; starting the ranks again", file=sys.stderr)
+            continue
+        sys.stderr.write(err)
+        break
     worst = next((rc if rc > 0 else 1 for rc in rcs if rc != 0), 0)
     lines = [ln for ln in (out or "").splitlines() if ln.strip()]
     if worst == 0 and len(lines) != 1:

@@ -406,15 +406,9 @@ def test_sharded_checkpoint_files_have_one_writer_for_the_shared_groups(tmp_path
     """Two gloo ranks, `Aspire.fit` + `Aspire.sample_posterior(checkpoint_path=...)`: only rank 0 ever opens the shared file
     (flow, aspire_config, sampler_config), every rank writes its sampler state to `<stem>.rank<r>.h5`; on the pickle route the
     JSON sidecar has one writer and the states are per rank."""
-    import socket
+    from test_dist_gloo import spawn_ranks
 
-    import torch.multiprocessing as mp
-
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    mp.spawn(_ckpt_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    spawn_ranks(_ckpt_rank_worker, 2, lambda port: (2, port, str(tmp_path)))
     logs = [json.load(open(tmp_path / f"opened{r}.json")) for r in range(2)]
     shared = str(tmp_path / "run.h5")
     assert any(p == shared for p, _ in logs[0]["opened"]) and not any(p == shared for p, _ in logs[1]["opened"])

@@ -21,6 +21,21 @@ def _free_port():
     return p
 
 
+def spawn_ranks(fn, nprocs, make_args, attempts=4):
+    """`mp.spawn(fn, args=make_args(port), nprocs)` on a free rendezvous port.  The port is only KNOWN to be free at the moment it is
+    picked: another process of the box (or a socket of the previous test still in TIME_WAIT) can take it before rank 0 listens - seen
+    once on a GPU box as EADDRINUSE for every test of a module.  A rendezvous that fails that way is repeated on a fresh port."""
+    import torch.multiprocessing as mp
+
+    for attempt in range(attempts):
+        try:
+            return mp.spawn(fn, args=make_args(_free_port()), nprocs=nprocs, join=True)
+        except Exception as exc:  # (ProcessRaisedException carries the child's traceback as text)
+            if attempt + 1 < attempts and ("EADDRINUSE" in str(exc) or "address already in use" in str(exc).lower()):
+                continue
+            raise
+
+
 def _worker(rank, world, port, out_dir, engine_kind="oracle"):
     for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
@@ -291,7 +306,7 @@ def _worker(rank, world, port, out_dir, engine_kind="oracle"):
 @pytest.fixture(scope="module")
 def two_rank_results(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("gloo"))
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    spawn_ranks(_worker, 2, lambda port: (2, port, out))
     return [np.load(os.path.join(out, f"rank{r}.npz")) for r in range(2)]
 
 
@@ -564,7 +579,7 @@ def _worker8(rank, world, port, out_dir):
 @pytest.fixture(scope="module")
 def eight_rank_results(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("gloo8"))
-    mp.spawn(_worker8, args=(8, _free_port(), out), nprocs=8, join=True)
+    spawn_ranks(_worker8, 8, lambda port: (8, port, out))
     return [np.load(os.path.join(out, f"rank{r}.npz")) for r in range(8)]
 
 
@@ -656,6 +671,6 @@ def _signal_worker(rank, world, port, out_dir):
 
 
 def test_signal_carries_a_producer_failure_to_the_waiting_ranks(tmp_path):
-    mp.spawn(_signal_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    spawn_ranks(_signal_worker, 2, lambda port: (2, port, str(tmp_path)))
     r1 = np.load(os.path.join(str(tmp_path), "sig1.npz"))
     assert int(r1["raised"]) == 1 and b"training diverged" in bytes(r1["msg"])

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
-from test_dist_gloo import _free_port, _worker
+from test_dist_gloo import _worker, spawn_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +18,7 @@ def runs(tmp_path_factory):
     out = {}
     for kind in ("oracle", "hip"):
         d = str(tmp_path_factory.mktemp("dist_" + kind))
-        mp.spawn(_worker, args=(2, _free_port(), d, kind), nprocs=2, join=True)
+        spawn_ranks(_worker, 2, lambda port, d=d, kind=kind: (2, port, d, kind))
         out[kind] = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(2)]
     return out
 

@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from test_dist_gloo import _free_port
+from test_dist_gloo import spawn_ranks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
@@ -79,7 +79,7 @@ def _worker_config4(rank, world, port, out_dir):
 
 def test_config4_two_ranks_x_4m_sharded_is_step_bit_exact(oracle, tmp_path):
     out = str(tmp_path)
-    mp.spawn(_worker_config4, args=(2, _free_port(), out), nprocs=2, join=True)
+    spawn_ranks(_worker_config4, 2, lambda port: (2, port, out))
     rs = [np.load(os.path.join(out, f"rank{r}.npz")) for r in range(2)]
     full = np.load(os.path.join(out, "full.npz"))
     ll, lp, lq = full["ll"], full["lp"], full["lq"]
@@ -132,7 +132,7 @@ def test_config5_two_ranks_x_512k_d128_mixture_sampler(hip_engine, tmp_path):
 
     n, d = 1 << 20, 128
     out = str(tmp_path)
-    mp.spawn(_worker_config5, args=(2, _free_port(), out, n), nprocs=2, join=True)
+    spawn_ranks(_worker_config5, 2, lambda port: (2, port, out, n))
     rs = [np.load(os.path.join(out, f"rank{r}.npz")) for r in range(2)]
     hip_engine.ensure_capacity(n, d)
     lik, prior, true = _config5_targets(d)
@@ -201,7 +201,7 @@ def _worker_eight(rank, world, port, out_dir):
 def test_eight_ranks_on_one_gpu_owner_layout_equals_generator_choice(oracle, tmp_path):
     out = str(tmp_path)
     world = 8
-    mp.spawn(_worker_eight, args=(world, _free_port(), out), nprocs=world, join=True)
+    spawn_ranks(_worker_eight, world, lambda port: (world, port, out))
     rs = [np.load(os.path.join(out, f"rank{r}.npz")) for r in range(world)]
     x = np.concatenate([r["x"] for r in rs])
     n = x.shape[0]

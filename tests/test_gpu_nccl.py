@@ -16,12 +16,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_sharded_collectives_over_rccl_one_rank_world():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_world1.py")], env=env, capture_output=True, text=True,
-                       timeout=600)
+    for attempt in range(4):  # (a port picked as free can be taken before the rendezvous listens on it: repeat on a fresh one)
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_world1.py")], env=env, capture_output=True, text=True,
+                           timeout=600)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "nccl world-1 checks ok" in r.stdout
