@@ -45,6 +45,24 @@ def resolve_dtype(dtype, xp):
     return np.dtype(dtype)
 
 
+def resolve_xp(name, default=np):
+    """The array namespace a saved file NAMES (reference utils.py resolve_xp: a backend name -> its module).  Only array namespaces are
+    accepted - `numpy`, `torch`, and the `array_api_compat` wrappers of the two wherever that package lives (`array_api_compat.torch`,
+    `sklearn.externals.array_api_compat.numpy`, ...): a file is data and does not get to import arbitrary modules.  A wrapper package that
+    is not installed resolves to the plain module; anything else to `default`."""
+    import importlib
+
+    if not isinstance(name, str) or not name:
+        return default
+    last = name.rsplit(".", 1)[-1]
+    if last not in ("numpy", "torch") or not (name == last or name.endswith("array_api_compat." + last)):
+        return default
+    try:
+        return importlib.import_module(name)
+    except ImportError:
+        return torch if last == "torch" else np
+
+
 def default_dtype(xp):
     return torch.get_default_dtype() if is_torch_namespace(xp) else np.dtype(np.float64)
 

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import smc_math
-from ._xp import asarray, default_dtype, is_torch, is_torch_namespace, namespace_of, resolve_dtype, to_numpy
+from ._xp import asarray, default_dtype, is_torch, is_torch_namespace, namespace_of, resolve_dtype, resolve_xp, to_numpy
 from .comm import Comm
 
 logger = logging.getLogger(__name__)
@@ -180,12 +180,7 @@ class BaseSamples:
         d = load_from_h5_file(h5_file, path)
         xp_name = d.get("xp")
         xp_name = xp_name if isinstance(xp_name, str) else "numpy"
-        try:  # (the module the file names - "numpy", "torch", or array_api_compat's wrappers where that package is installed)
-            import importlib
-
-            xp = importlib.import_module(xp_name)
-        except ImportError:
-            xp = torch if "torch" in xp_name else np
+        xp = resolve_xp(xp_name)  # ("numpy", "torch", or array_api_compat's wrappers of the two where that package is installed)
         enc = d.get("dtype")
         name = enc.get("dtype") if isinstance(enc, dict) else (enc if isinstance(enc, str) else None)
         d["xp"] = xp
@@ -215,10 +210,8 @@ class BaseSamples:
         return state
 
     def __setstate__(self, state):
-        import importlib
-
         if isinstance(state.get("xp"), str):
-            state["xp"] = importlib.import_module(state["xp"])
+            state["xp"] = resolve_xp(state["xp"])
         self.__dict__.update(state)
         self.__dict__.setdefault("engine", None)
         self.__dict__.setdefault("comm", None)

@@ -252,13 +252,10 @@ class CompositeTransform:
         if "eps" in cfg:
             cfg["eps"] = float(cfg["eps"])
         xp = None
-        if xp_name is not None:
-            try:  # (the module the file names, or plain numpy / torch where that wrapper package is absent)
-                import importlib
+        if xp_name is not None:  # (the array namespace the file names, or plain numpy / torch where that wrapper package is absent)
+            from ._xp import resolve_xp
 
-                xp = importlib.import_module(str(xp_name))
-            except ImportError:
-                xp = torch if "torch" in str(xp_name) else np
+            xp = resolve_xp(str(xp_name))
         dtype = None
         if dt_name is not None:
             from ._xp import resolve_dtype

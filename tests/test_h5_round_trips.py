@@ -104,3 +104,21 @@ def test_composite_transform_round_trip(opener, tmp_path, xp, dtype):
     y1, j1 = back.forward(xp.asarray(x, dtype=dtype))
     np.testing.assert_array_equal(np.asarray(y0), np.asarray(y1))
     np.testing.assert_array_equal(np.asarray(j0), np.asarray(j1))
+
+
+def test_a_saved_namespace_name_only_resolves_to_an_array_namespace(tmp_path):
+    """A file names the array namespace of what it holds (reference utils.py resolve_xp).  Only `numpy`, `torch` and the array_api_compat
+    wrappers of the two resolve; any other module name in a file falls back to numpy instead of being imported."""
+    from aspire_amd._xp import resolve_xp
+
+    assert resolve_xp("numpy") is np and resolve_xp("torch") is torch
+    assert resolve_xp("array_api_compat.torch").__name__.endswith("torch")  # (the wrapper, or torch itself where it is not installed)
+    assert resolve_xp("sklearn.externals.array_api_compat.numpy").__name__.endswith("numpy")
+    for hostile in ("os", "subprocess", "antigravity", "evil.numpy", "numpy.evil", "torch.hub", "", None, 7):
+        assert resolve_xp(hostile) is np
+    with FakeFile(str(tmp_path / "n.h5"), "w") as f:
+        Samples(np.zeros((3, 2))).save(f, path="s")
+        del f["s/xp"]
+        f["s"].create_dataset("xp", data="subprocess")  # a tampered file
+    with FakeFile(str(tmp_path / "n.h5"), "r") as f:
+        assert Samples.load(f, path="s").xp is np
