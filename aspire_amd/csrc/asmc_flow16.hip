@@ -509,8 +509,8 @@ __global__ __launch_bounds__(THREADS, THREADS > 512 ? 1 : 2) void k_pcn_flow16(i
         double kacc = ((t2 + c1) - (lpo + c0)) - logu, k_ll = nll, k_lp = nlp;
         asm volatile("" : "+v"(kacc), "+v"(k_ll), "+v"(k_lp));
         __builtin_amdgcn_sched_barrier(0);
-        const double nlq = (!FD::MAF || form == 0) ? (double)f16_logprob<FD, W, THREADS, 0>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, 0)
-                                                   : (double)f16_logprob<FD, W, THREADS, 1>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, 1);
+        const double nlq = (!FD::MAF || form == 0) ? (double)f16_logprob<FD, W, THREADS, 0, true>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, 0)
+                                                   : (double)f16_logprob<FD, W, THREADS, 1, true>(xf, n_layers, s_bias, stream, lane, ladj0, base_const, 1);
         __builtin_amdgcn_sched_barrier(0);
         if (valid && h == 0 && !(fabs(nlq) < INFINITY)) n_bad++;
         const bool lq_finite = fabs(nlq) < INFINITY;

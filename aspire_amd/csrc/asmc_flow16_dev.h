@@ -79,18 +79,20 @@ __host__ __device__ constexpr int64_t flow16_words(int n_layers) {
 }
 
 // eight fp32 values -> their (hi, lo) fp16 operand halves; the range check rides on the hi halves (asmc_flow_dev.h)
-template <bool RELU>
+template <bool RELU, bool PROP = false>  // (PROP: asmc_flow_dev.h split2_f16 - NaN-propagating ReLU, no range check)
 __device__ __forceinline__ void f16_split8(const float (&x)[8], half8& hi, half8& lo, unsigned& amax_pk) {
     unsigned hp[4], lp[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         if (c == 3)
-            split2_f16<RELU, true>(x[2 * c], x[2 * c + 1], hp[c], lp[c]);
+            split2_f16<RELU, true, PROP>(x[2 * c], x[2 * c + 1], hp[c], lp[c]);
         else
-            split2_f16<RELU, false>(x[2 * c], x[2 * c + 1], hp[c], lp[c]);
+            split2_f16<RELU, false, PROP>(x[2 * c], x[2 * c + 1], hp[c], lp[c]);
     }
-    split4_range<!RELU>(hp[0], hp[1], amax_pk);
-    split4_range<!RELU>(hp[2], hp[3], amax_pk);
+    if (!PROP) {
+        split4_range<!RELU>(hp[0], hp[1], amax_pk);
+        split4_range<!RELU>(hp[2], hp[3], amax_pk);
+    }
     hi = __builtin_bit_cast(half8, flow_u4{hp[0], hp[1], hp[2], hp[3]});
     lo = __builtin_bit_cast(half8, flow_u4{lp[0], lp[1], lp[2], lp[3]});
 }
@@ -202,7 +204,7 @@ __device__ __forceinline__ void f16_dense(floatx4 (&acc)[NBC], const half8 (&bh)
 // FORM: the affine form (asmc_flow_dev.h flow_affine) as a compile-time constant, or -1: the run-time argument `form` (a uniform
 // branch per coordinate then sits between the output layer's matrix instructions and cuts the scheduler's blocks: the density
 // kernels pass the constant).
-template <class FD, int W, int THREADS, bool INVERSE = false, int FORM = -1>
+template <class FD, int W, int THREADS, bool INVERSE = false, int FORM = -1, bool PROP = false>
 __device__ __forceinline__ void f16_layer(const float (&cond)[FD::CS], float (&trans)[FD::CS], const float* __restrict__ bias,
                                           Flow16Stream<FD, THREADS>& stream, int lane, float& ladj, unsigned& amax_pk, int form = 0) {
     constexpr int KS1 = FD::KS1, KS2 = FD::KS2, NB1 = FD::NB1;
@@ -217,7 +219,7 @@ __device__ __forceinline__ void f16_layer(const float (&cond)[FD::CS], float (&t
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) v[j] = cond[8 * S + j];
-        f16_split8<false>(v, bh1[S], bl1[S], amax_pk);
+        f16_split8<false, PROP>(v, bh1[S], bl1[S], amax_pk);
     }
     floatx4 h1[NB1];
     const float* Aw = nullptr;  // WHOLE: the layer's one chunk
@@ -237,7 +239,7 @@ __device__ __forceinline__ void f16_layer(const float (&cond)[FD::CS], float (&t
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) v[j] = h1[2 * S + j / 4][j % 4];
-        f16_split8<true>(v, bh2[S], bl2[S], amax_pk);
+        f16_split8<true, PROP>(v, bh2[S], bl2[S], amax_pk);
     }
     floatx4 h2[NB1];
 #pragma unroll
@@ -254,7 +256,7 @@ __device__ __forceinline__ void f16_layer(const float (&cond)[FD::CS], float (&t
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) v[j] = h2[2 * S + j / 4][j % 4];
-        f16_split8<true>(v, bh2[S], bl2[S], amax_pk);
+        f16_split8<true, PROP>(v, bh2[S], bl2[S], amax_pk);
     }
     // The epilogue of a pair (exp / rcp chains: vector and transcendental work) is written BEHIND the matrix instructions of the next
     // pair, which it does not depend on - one basic block, so the scheduler places it between them (round 6; round 5 ran every
@@ -308,23 +310,23 @@ __device__ __forceinline__ float f16_quad_max(float q) {
 }
 
 // log q of the group's particles from the lane's standardised coordinates (every lane of a particle returns it)
-template <class FD, int W, int THREADS, int FORM = -1>
+template <class FD, int W, int THREADS, int FORM = -1, bool PROP = false>
 __device__ __forceinline__ float f16_logprob(F16State<FD>& x, int n_layers, const float* __restrict__ biases,
                                              Flow16Stream<FD, THREADS>& stream, int lane, float ladj0, float base_const, int form = 0) {
     float ladj = 0.0f;
     unsigned amax_pk = 0u;
     for (int c = 0; c < n_layers; c += 2) {  // (n_layers is uniform over the block: every wave meets the same barriers)
         if constexpr (FD::MAF) {
-            f16_layer<FD, W, THREADS, false, FORM>(x.a, x.a, biases + c * FD::BIAS, stream, lane, ladj, amax_pk, form);
+            f16_layer<FD, W, THREADS, false, FORM, PROP>(x.a, x.a, biases + c * FD::BIAS, stream, lane, ladj, amax_pk, form);
         } else {
-            f16_layer<FD, W, THREADS, false, 0>(x.a, x.b, biases + c * FD::BIAS, stream, lane, ladj, amax_pk);
+            f16_layer<FD, W, THREADS, false, 0, PROP>(x.a, x.b, biases + c * FD::BIAS, stream, lane, ladj, amax_pk);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < n_layers) {
             if constexpr (FD::MAF) {
-                f16_layer<FD, W, THREADS, false, FORM>(x.a, x.a, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk, form);
+                f16_layer<FD, W, THREADS, false, FORM, PROP>(x.a, x.a, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk, form);
             } else {
-                f16_layer<FD, W, THREADS, false, 0>(x.b, x.a, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk);
+                f16_layer<FD, W, THREADS, false, 0, PROP>(x.b, x.a, biases + (c + 1) * FD::BIAS, stream, lane, ladj, amax_pk);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

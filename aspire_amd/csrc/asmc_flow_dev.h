@@ -429,10 +429,15 @@ typedef unsigned flow_u4 __attribute__((ext_vector_type(4)));
 // (split4_range below): an element past the fp16 range converts to inf, and 65504 itself is flagged like before.
 // NOP: end the statement with the two wait states a just-written VGPR needs before an MFMA reads it as an operand
 // (cdna_hip_programming.md 5.7 item 2) - only the LAST quarter of an operand can be followed directly by its consumer.
-template <bool RELU, bool NOP = true>
+// PROP (round 6, the one-kernel step kernels): the ReLU is the IEEE-754-2019 maximum (v_maximum3_f32 x, 0, 0 - one instruction, like the
+// integer maximum), which PROPAGATES a NaN instead of squashing one of negative sign to zero.  An element past the fp16 range then needs
+// no range check at all: it converts to (hi, lo) = (+-inf, -+inf), the products with any weight - zero included - accumulate to NaN, and
+// the NaN reaches log q, where the step rejects and counts it exactly as the explicit check's NaN was.  The stand-alone density / sampling
+// kernels keep the explicit check (a sampling pass must return finite positions): same bits wherever nothing overflowed.
+template <bool RELU, bool NOP = true, bool PROP = false>
 __device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& hp, unsigned& lp) {
-    const float v0 = RELU ? __int_as_float(max(__float_as_int(x0), 0)) : x0;
-    const float v1 = RELU ? __int_as_float(max(__float_as_int(x1), 0)) : x1;
+    const float v0 = !RELU ? x0 : PROP ? __builtin_elementwise_maximum(x0, 0.0f) : __int_as_float(max(__float_as_int(x0), 0));
+    const float v1 = !RELU ? x1 : PROP ? __builtin_elementwise_maximum(x1, 0.0f) : __int_as_float(max(__float_as_int(x1), 0));
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     const half2v h = half2v{(_Float16)v0, (_Float16)v1};
     half2v l;
@@ -598,7 +603,7 @@ __device__ __forceinline__ void coupling_layer_hs2(const float (&condA)[H / 2], 
 // Same operations in the same order per accumulator as coupling_layer_hs / _hs2: bit-identical results.
 // FORM: the affine form (flow_affine) as a compile-time constant, or -1 for the run-time argument (then every coordinate of the epilogue
 // carries a uniform branch).
-template <int H, int W, bool PREFETCH = true, int FORM = -1>
+template <int H, int W, bool PREFETCH = true, int FORM = -1, bool PROP = false>  // (PROP: no range check, NaN-propagating ReLU - split2_f16)
 __device__ __forceinline__ void coupling_layer_hs1p(const float (&cond)[H / 2], float (&trans)[H / 2], const float* __restrict__ lp,
                                                     int lane, int hh, float& ladj, unsigned& amax, int form = 0) {
     using FD = FlowDims<H, W>;
@@ -627,13 +632,13 @@ __device__ __forceinline__ void coupling_layer_hs1p(const float (&cond)[H / 2], 
     auto cvt = [&](int g, int c, bool last) {  // quarter c of group g's operand; `last`: the MFMAs that read it may follow directly
         const float e0 = src(g, 2 * c), e1 = src(g, 2 * c + 1);
         if (last) {
-            if (g < ST1) split2_f16<false, true>(e0, e1, hp[c], lq[c]);
-            else split2_f16<true, true>(e0, e1, hp[c], lq[c]);
+            if (g < ST1) split2_f16<false, true, PROP>(e0, e1, hp[c], lq[c]);
+            else split2_f16<true, true, PROP>(e0, e1, hp[c], lq[c]);
         } else {
-            if (g < ST1) split2_f16<false, false>(e0, e1, hp[c], lq[c]);
-            else split2_f16<true, false>(e0, e1, hp[c], lq[c]);
+            if (g < ST1) split2_f16<false, false, PROP>(e0, e1, hp[c], lq[c]);
+            else split2_f16<true, false, PROP>(e0, e1, hp[c], lq[c]);
         }
-        if (c & 1) {
+        if (!PROP && (c & 1)) {
             if (g < ST1) split4_range<true>(hp[c - 1], hp[c], amax);
             else split4_range<false>(hp[c - 1], hp[c], amax);
         }

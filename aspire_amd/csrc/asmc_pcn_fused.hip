@@ -715,7 +715,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
                     float cond[16];
 #pragma unroll
                     for (int r = 0; r < 16; r++) cond[r] = xv[r];
-                    coupling_layer_hs1p<HF, W, false, FORM>(cond, xv, sp + (size_t)c * FD::LAYER, lane, hh, ladj, amax_pk, FORM);
+                    coupling_layer_hs1p<HF, W, false, FORM, true>(cond, xv, sp + (size_t)c * FD::LAYER, lane, hh, ladj, amax_pk, FORM);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 float amax = range_pk_max(amax_pk);
@@ -789,9 +789,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
                 for (int c = 0; c < n_layers; c++) {
                     const float* lpk = sp + (size_t)c * FD::LAYER;
                     if ((c & 1) == 0)
-                        coupling_layer_hs1p<H, W, HS1P_PREFETCH>(xa[0], xb[0], lpk, lane, hh, ladj, amax_pk);
+                        coupling_layer_hs1p<H, W, HS1P_PREFETCH, 0, true>(xa[0], xb[0], lpk, lane, hh, ladj, amax_pk);
                     else
-                        coupling_layer_hs1p<H, W, HS1P_PREFETCH>(xb[0], xa[0], lpk, lane, hh, ladj, amax_pk);
+                        coupling_layer_hs1p<H, W, HS1P_PREFETCH, 0, true>(xb[0], xa[0], lpk, lane, hh, ladj, amax_pk);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 float amax = range_pk_max(amax_pk);
