@@ -482,18 +482,20 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_pcn_flow_fused(
                     const row_f2 lc2 = reinterpret_cast<const row_f2*>(locr)[e2], sc2 = reinterpret_cast<const row_f2*>(locr + D)[e2],
                                  rc2 = reinterpret_cast<const row_f2*>(locr + 2 * D)[e2];
 #pragma unroll
-                    for (int rr = 0; rr < 2; rr++) {
-                        const int r = 2 * rp + rr;
-                        const double ma = ma2[rr], pa = pa2[rr], mbb = mb2[rr], pb = pb2[rr];
-                        const float lc = lc2[rr], sc = sc2[rr], rc = rc2[rr];
+                    for (int nb = 0; nb < 4; nb++) {
+                        double xj[2];
 #pragma unroll
-                        for (int nb = 0; nb < 4; nb++) {
-                            const double xj = (double)(T)acc[mb][nb][r];
-                            const double ta = xj - ma, tb = xj - mbb;
-                            qpa[nb] = fma(ta * ta, pa, qpa[nb]);
-                            qpb[nb] = fma(tb * tb, pb, qpb[nb]);
-                            xf[(4 * mb + nb) * 4 + r] = flow_standardise((float)xj, lc, sc, rc);
+                        for (int rr = 0; rr < 2; rr++) {  // (per accumulator: the same order of operations as before - rows ascending within nb)
+                            const int r = 2 * rp + rr;
+                            xj[rr] = (double)(T)acc[mb][nb][r];
+                            const double ta = xj[rr] - ma2[rr], tb = xj[rr] - mb2[rr];
+                            qpa[nb] = fma(ta * ta, pa2[rr], qpa[nb]);
+                            qpb[nb] = fma(tb * tb, pb2[rr], qpb[nb]);
                         }
+                        // the flow's input of the two rows on the packed fp32 instructions (flow_standardise2: same bits, 4 instructions per pair)
+                        const flow_std2 z2 = flow_standardise2(flow_std2{(float)xj[0], (float)xj[1]}, lc2, sc2, rc2);
+                        xf[(4 * mb + nb) * 4 + 2 * rp] = z2.x;
+                        xf[(4 * mb + nb) * 4 + 2 * rp + 1] = z2.y;
                     }
                 }
             // a particle's four lanes hold its partial sums: the same transpose brings them into the particle's own lane
